@@ -1,0 +1,343 @@
+"""ORACLE - test infrastructure, not product code.
+
+CPU (torch fp32) restatement of the reference's decoder hot path, written from the maths in
+SURVEY.md Appendix A, each function citing the reference file:line it follows (paths relative
+to the reference root, `projects/mmdet3d_plugin/models/utils/`).  Only tests/, the smoke check
+in __graft_entry__.py and bench.py's `cpu_baseline` leg may import this file; the product path
+(graph-detr4d_amd/) never does and fails loudly when its HIP library is missing.
+
+Parity pin: the reference ships no tests and no golden vectors, so this oracle
+is pinned against outputs of the reference itself run in the build container
+(tools/gen_golden.py imports the reference's files unmodified under an mmcv stub and writes
+tests/golden/*.npz; tests/test_oracle_golden.py checks every function here against them).
+Third-party arithmetic that is NOT in the reference tree (mmcv 1.x MultiScaleDeformableAttn,
+mmcv MultiheadAttention / FFN / BaseTransformerLayer, mmdet DetrTransformerDecoderLayer; no
+version pinned anywhere in the reference) is restated from its published semantics; at that
+boundary parity is pinned only by ATen's F.grid_sample / nn.MultiheadAttention in this
+container.
+
+All parameters are passed as a flat dict of tensors keyed by the reference's state-dict
+names (e.g. 'value_proj.weight'), so a reference checkpoint slice can be fed directly.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """deform3d_cross_attn.py:16-31 (detr3d_transformer.py:28-43 is the same on [0,1])."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps, max=1) / (1 - x).clamp(min=eps, max=1))
+
+
+def _linear(x, p, name):
+    return F.linear(x, p[name + '.weight'], p.get(name + '.bias'))
+
+
+def lidar2img_tensor(img_metas, like):
+    """deform3d_cross_attn.py:215-219: stack img_meta['lidar2img'] -> (B, N, 4, 4) fp32."""
+    mats = np.asarray([m['lidar2img'] for m in img_metas])
+    return like.new_tensor(mats)
+
+
+def denormalise(ref, pc_range):
+    """deform3d_cross_attn.py:222-224: ref*(hi-lo)+lo, (hi-lo) evaluated in Python floats."""
+    out = ref.clone()
+    for k in range(3):
+        out[..., k:k + 1] = ref[..., k:k + 1] * (pc_range[k + 3] - pc_range[k]) + pc_range[k]
+    return out
+
+
+def project(points, lidar2img, img_h, img_w, eps=1e-5):
+    """Projection block, deform3d_cross_attn.py:232-252 (same at detr3d_transformer.py:409-420).
+
+    points (B, M, 3) metres; lidar2img (B, N, 4, 4).  Returns uv (B, N, M, 2) normalised by
+    the image W/H and the bool mask (B, N, M) = z>eps & 0<u<1 & 0<v<1.  Arithmetic order is
+    the reference's: batched matmul, IEEE division by max(z, eps), then by W and H.
+    """
+    b, m, _ = points.shape
+    n = lidar2img.shape[1]
+    hom = torch.cat((points, torch.ones_like(points[..., :1])), -1)
+    hom = hom.view(b, 1, m, 4).repeat(1, n, 1, 1).unsqueeze(-1)
+    mats = lidar2img.view(b, n, 1, 4, 4).repeat(1, 1, m, 1, 1)
+    cam = torch.matmul(mats, hom).squeeze(-1)
+    z = cam[..., 2:3]
+    mask = z > eps
+    uv = cam[..., 0:2] / torch.max(z, torch.ones_like(z) * eps)
+    uv[..., 0] /= img_w
+    uv[..., 1] /= img_h
+    mask = (mask & (uv[..., 0:1] > 0.) & (uv[..., 0:1] < 1.0)
+            & (uv[..., 1:2] > 0.) & (uv[..., 1:2] < 1.0))
+    return uv, mask.squeeze(-1)
+
+
+def flatten_pyramid(value):
+    """deform3d_cross_attn.py:264-272: list of (B,N,C,H,W) -> (B*N, sum(HW), C) channels-last."""
+    flat, shapes = [], []
+    for v in value:
+        b, n, c, h, w = v.shape
+        shapes.append((h, w))
+        flat.append(v.reshape(b * n, c, h * w).transpose(1, 2))
+    return torch.cat(flat, 1), shapes
+
+
+def bilinear_zero_pad(value_l, x, y):
+    """Third-party MSDA sampling rule (mmcv ms_deform_attn kernel; == grid_sample bilinear,
+    zeros padding, align_corners=False).  value_l (H, W, D); x, y pixel coords (...,) with the
+    -0.5 shift already applied.  Returns (..., D).  Explicit-gather form, independent of ATen.
+    """
+    h, w, _ = value_l.shape
+    x0 = torch.floor(x)
+    y0 = torch.floor(y)
+    dx = x - x0
+    dy = y - y0
+    out = 0
+    for (yy, xx, wt) in ((y0, x0, (1 - dy) * (1 - dx)), (y0, x0 + 1, (1 - dy) * dx),
+                         (y0 + 1, x0, dy * (1 - dx)), (y0 + 1, x0 + 1, dy * dx)):
+        ok = (xx >= 0) & (xx <= w - 1) & (yy >= 0) & (yy <= h - 1)
+        xi = xx.clamp(0, w - 1).long()
+        yi = yy.clamp(0, h - 1).long()
+        out = out + value_l[yi, xi] * (wt * ok).unsqueeze(-1)
+    return out
+
+
+def msda(value, shapes, loc, weights):
+    """Third-party MSDA (mmcv multi_scale_deformable_attn), call site deform3d_cross_attn.py:302-309.
+
+    value (S, sum(HW), Hh, Dh); loc (S, Q, Hh, L, P, 2) in [0,1]; weights (S, Q, Hh, L*P).
+    Returns (S, Q, Hh*Dh).  Uses ATen grid_sample (the arbiter for this boundary).
+    """
+    s, _, hh, dh = value.shape
+    _, q, _, nl, npnt, _ = loc.shape
+    parts = value.split([h * w for h, w in shapes], dim=1)
+    acc = []
+    for lvl, (h, w) in enumerate(shapes):
+        v = parts[lvl].permute(0, 2, 3, 1).reshape(s * hh, dh, h, w)
+        g = (2 * loc[:, :, :, lvl] - 1).permute(0, 2, 1, 3, 4).reshape(s * hh, q, npnt, 2)
+        acc.append(F.grid_sample(v, g, mode='bilinear', padding_mode='zeros', align_corners=False))
+    samp = torch.stack(acc, dim=-2).flatten(-2)                       # (S*Hh, Dh, Q, L*P)
+    wt = weights.permute(0, 2, 1, 3).reshape(s * hh, 1, q, nl * npnt)
+    return (samp * wt).sum(-1).view(s, hh * dh, q).transpose(1, 2).contiguous()
+
+
+def scrambled_cam_weights(cam_logits, num_cams):
+    """deform3d_cross_attn.py:211-212: the (B,Q,N) Linear output is VIEWED as (B,N,Q,1)."""
+    b, q, n = cam_logits.shape
+    return cam_logits.reshape(b, num_cams, q, 1)
+
+
+def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
+                     img_h, img_w):
+    """The fused kernel's contract (a3+a5+a6+a7-reduction; deform3d_cross_attn.py:220-324).
+
+    value (B*N, sum(HW), Hh, Dh) already value_proj-ed; ref (B,Q,3) in [0,1];
+    offsets (B,Q,Hh,P,3) metres; attn_logits (B,Q,Hh,L*P); cam_logits (B,Q,N) un-scrambled
+    Linear output; lidar2img (B,N,4,4).
+    Returns out (B,Q,Hh*Dh) = sum_n sigmoid(cam[b,n,q]) * MSDA_n, uv (B,N,Q,Hh,P,2) and
+    mask (B,N,Q,Hh,P) bool.
+    """
+    b, q, hh, p, _ = offsets.shape
+    n = lidar2img.shape[1]
+    nl = len(shapes)
+    pts = denormalise(ref, pc_range).view(b, q, 1, 1, 3) + offsets          # :229
+    uv, mask = project(pts.reshape(b, q * hh * p, 3), lidar2img, img_h, img_w)
+    uv = uv.view(b, n, q, hh, p, 2)
+    mask = mask.view(b, n, q, hh, p)
+    loc = uv.view(b * n, q, hh, 1, p, 2).expand(-1, -1, -1, nl, -1, -1)     # :228 repeat over L
+    # :277,281-284  query.repeat(N,1,1) stacks rows as [b0,b1,..,b0,b1,..] while values/masks are
+    # ordered b*N+n, so value row i=b*N+n is paired with the logits of batch (i % B).  Identity
+    # for B=1 (every shipped config); reproduced for B>1 because it is what the reference computes.
+    rows = torch.arange(b * n) % b
+    w = attn_logits.softmax(-1)[rows].view(b, n, q, hh, nl, p)
+    w = (w * mask.view(b, n, q, hh, 1, p)).reshape(b * n, q, hh, nl * p)
+    per_cam = msda(value, shapes, loc, w).view(b, n, q, -1)                 # :302-304
+    cam = scrambled_cam_weights(cam_logits, n).sigmoid()                    # :320
+    return (per_cam * cam).sum(1), uv, mask                                  # :322-324
+
+
+def deform3d_cross_attn(p, query, value, query_pos, reference_points, img_metas, pc_range,
+                        num_heads=8, num_points=4, depth_encode=False, return_parts=False):
+    """Deform3DCrossAttn.forward in eval mode, deform3d_cross_attn.py:196-339 (Appendix A.1)."""
+    x = query if query_pos is None else query + query_pos                   # :203-204
+    x = x.permute(1, 0, 2)                                                  # :207
+    b, q, c = x.shape
+    nl = len(value)
+    n = value[0].shape[1]
+    l2i = lidar2img_tensor(img_metas, reference_points)
+    img_h, img_w = img_metas[0]['img_shape'][0][0], img_metas[0]['img_shape'][0][1]
+    cam_logits = _linear(x, p, 'cam_attention_weights')                     # :211
+    offsets = _linear(x, p, 'deform_sampling_offsets').view(b, q, num_heads, num_points, 3)
+    attn_logits = _linear(x, p, 'attention_weights').view(b, q, num_heads, nl * num_points)
+    flat, shapes = flatten_pyramid(value)
+    val = _linear(flat, p, 'value_proj').view(b * n, flat.shape[1], num_heads, c // num_heads)
+    agg, uv, mask = sample_aggregate(val, shapes, reference_points, offsets, attn_logits,
+                                     cam_logits, l2i, pc_range, img_h, img_w)
+    out = _linear(agg, p, 'output_proj').permute(1, 0, 2)                   # :326-327
+    ref3d = reference_points
+    if depth_encode:                                                        # :331-333
+        depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
+        ref3d = torch.cat([ref3d, depth], -1)
+    pos = position_encoder(p, inverse_sigmoid(ref3d)).permute(1, 0, 2)      # :334
+    res = out + query + pos                                                 # :336 (dropout = id)
+    if return_parts:
+        return res, dict(agg=agg, uv=uv, mask=mask, offsets=offsets, attn_logits=attn_logits,
+                         cam_logits=cam_logits, value=val, pos=pos)
+    return res
+
+
+def position_encoder(p, x, prefix='position_encoder'):
+    """deform3d_cross_attn.py:104-111: Linear, LN, ReLU, Linear, LN, ReLU."""
+    c = p[prefix + '.0.weight'].shape[0]
+    x = F.linear(x, p[prefix + '.0.weight'], p[prefix + '.0.bias'])
+    x = F.relu(F.layer_norm(x, (c,), p[prefix + '.1.weight'], p[prefix + '.1.bias']))
+    x = F.linear(x, p[prefix + '.3.weight'], p[prefix + '.3.bias'])
+    return F.relu(F.layer_norm(x, (c,), p[prefix + '.4.weight'], p[prefix + '.4.bias']))
+
+
+def feature_sampling(mlvl_feats, reference_points, pc_range, img_metas):
+    """feature_sampling, detr3d_transformer.py:397-438 (Appendix A.2).
+
+    Returns (ref_3d (B,Q,3), sampled (B,C,Q,N,1,L), mask (B,1,Q,N,1,1) bool).
+    """
+    l2i = lidar2img_tensor(img_metas, reference_points)
+    b, q, _ = reference_points.shape
+    n = l2i.shape[1]
+    img_h, img_w = img_metas[0]['img_shape'][0][0], img_metas[0]['img_shape'][0][1]
+    pts = denormalise(reference_points, pc_range)
+    hom = torch.cat((pts, torch.ones_like(pts[..., :1])), -1)
+    hom = hom.view(b, 1, q, 4).repeat(1, n, 1, 1).unsqueeze(-1)
+    cam = torch.matmul(l2i.view(b, n, 1, 4, 4).repeat(1, 1, q, 1, 1), hom).squeeze(-1)
+    eps = 1e-5
+    z = cam[..., 2:3]
+    mask = z > eps
+    uv = cam[..., 0:2] / torch.maximum(z, torch.ones_like(z) * eps)
+    uv[..., 0] /= img_w
+    uv[..., 1] /= img_h
+    uv = (uv - 0.5) * 2                                                     # :421
+    mask = (mask & (uv[..., 0:1] > -1.0) & (uv[..., 0:1] < 1.0)
+            & (uv[..., 1:2] > -1.0) & (uv[..., 1:2] < 1.0))
+    mask = mask.view(b, n, 1, q, 1, 1).permute(0, 2, 3, 1, 4, 5)
+    sampled = []
+    for feat in mlvl_feats:
+        _, _, c, h, w = feat.shape
+        s = F.grid_sample(feat.reshape(b * n, c, h, w), uv.view(b * n, q, 1, 2),
+                          mode='bilinear', padding_mode='zeros', align_corners=False)
+        sampled.append(s.view(b, n, c, q, 1).permute(0, 2, 3, 1, 4))
+    sampled = torch.stack(sampled, -1).view(b, -1, q, n, 1, len(mlvl_feats))
+    return reference_points.clone(), sampled, mask
+
+
+def detr3d_cross_atten(p, query, value, query_pos, reference_points, img_metas, pc_range,
+                       num_points=1):
+    """Detr3DCrossAtten.forward in eval mode, detr3d_transformer.py:358-390 (Appendix A.2)."""
+    x = query if query_pos is None else query + query_pos
+    x = x.permute(1, 0, 2)
+    b, q, _ = x.shape
+    n = value[0].shape[1]
+    nl = len(value)
+    logits = _linear(x, p, 'attention_weights').view(b, 1, q, n, num_points, nl)   # :373-374
+    ref3d, sampled, mask = feature_sampling(value, reference_points, pc_range, img_metas)
+    sampled = torch.nan_to_num(sampled)
+    w = logits.sigmoid() * mask                                             # :381
+    out = (sampled * w).sum(-1).sum(-1).sum(-1).permute(2, 0, 1)            # :382-384
+    out = _linear(out, p, 'output_proj')
+    pos = position_encoder(p, inverse_sigmoid(ref3d)).permute(1, 0, 2)
+    return out + query + pos                                                # :390
+
+
+def multihead_self_attn(p, query, query_pos, num_heads=8, attn_mask=None, prefix='attn.'):
+    """Decoder self-attention: third-party mmcv MultiheadAttention -> nn.MultiheadAttention
+    (config call site: projects/configs/detr4d/detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78).
+
+    q = k = query + query_pos, v = query; packed in_proj; softmax(q k^T / sqrt(d)) v; out_proj;
+    returns identity + out (dropout = identity in eval).  query (Q, B, C).
+    """
+    nq, b, c = query.shape
+    d = c // num_heads
+    qk = query if query_pos is None else query + query_pos
+    w, bias = p[prefix + 'in_proj_weight'], p[prefix + 'in_proj_bias']
+    qh = F.linear(qk, w[:c], bias[:c])
+    kh = F.linear(qk, w[c:2 * c], bias[c:2 * c])
+    vh = F.linear(query, w[2 * c:], bias[2 * c:])
+
+    def heads(t):
+        return t.reshape(nq, b * num_heads, d).transpose(0, 1)              # (B*h, Q, d)
+    qh, kh, vh = heads(qh), heads(kh), heads(vh)
+    scores = torch.bmm(qh * (1.0 / math.sqrt(d)), kh.transpose(1, 2))
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            scores = scores.masked_fill(attn_mask, float('-inf'))
+        else:
+            scores = scores + attn_mask
+    o = torch.bmm(scores.softmax(-1), vh).transpose(0, 1).reshape(nq, b, c)
+    o = F.linear(o, p[prefix + 'out_proj.weight'], p[prefix + 'out_proj.bias'])
+    return query + o
+
+
+def ffn(p, x, prefix='ffns.0.'):
+    """Third-party mmcv FFN (config :86-87): x + W2 relu(W1 x)."""
+    h = F.relu(F.linear(x, p[prefix + 'layers.0.0.weight'], p[prefix + 'layers.0.0.bias']))
+    return x + F.linear(h, p[prefix + 'layers.1.weight'], p[prefix + 'layers.1.bias'])
+
+
+def _sub(p, prefix):
+    return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+def decoder_layer(p, query, value, query_pos, reference_points, img_metas, pc_range,
+                  cross='Deform3DCrossAttn', num_heads=8, num_points=4, attn_mask=None,
+                  depth_encode=False):
+    """Post-norm DetrTransformerDecoderLayer (third-party mmdet/mmcv), order
+    self_attn, norm, cross_attn, norm, ffn, norm (config :88-89; Appendix A.4)."""
+    c = query.shape[-1]
+
+    def ln(x, i):
+        return F.layer_norm(x, (c,), p[f'norms.{i}.weight'], p[f'norms.{i}.bias'])
+    x = multihead_self_attn(p, query, query_pos, num_heads, attn_mask, prefix='attentions.0.attn.')
+    x = ln(x, 0)
+    cp = _sub(p, 'attentions.1.')
+    if cross == 'Deform3DCrossAttn':
+        x = deform3d_cross_attn(cp, x, value, query_pos, reference_points, img_metas, pc_range,
+                                num_heads, num_points, depth_encode)
+    else:
+        x = detr3d_cross_atten(cp, x, value, query_pos, reference_points, img_metas, pc_range,
+                               num_points)
+    x = ln(x, 1)
+    x = ffn(p, x)
+    return ln(x, 2)
+
+
+def decoder(layer_params, query, value, query_pos, reference_points, img_metas, pc_range,
+            reg_branches=None, **kw):
+    """Detr3DTransformerDecoder.forward with return_intermediate=True,
+    detr3d_transformer.py:166-225.  reg_branches: list of callables (Q-first output -> (B,Q,>=5))."""
+    out = query
+    inter, inter_ref = [], []
+    for lid, p in enumerate(layer_params):
+        out = decoder_layer(p, out, value, query_pos, reference_points, img_metas, pc_range, **kw)
+        if reg_branches is not None:
+            tmp = reg_branches[lid](out.permute(1, 0, 2))                   # :199-202
+            new = torch.zeros_like(reference_points)
+            new[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
+            new[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
+            reference_points = new.sigmoid().detach()                       # :212-214
+        inter.append(out)
+        inter_ref.append(reference_points)
+    return torch.stack(inter), torch.stack(inter_ref)
+
+
+def transformer(p, layer_params, mlvl_feats, query_embed, img_metas, pc_range,
+                reg_branches=None, **kw):
+    """Detr3DTransformer.forward, detr3d_transformer.py:86-150."""
+    b = mlvl_feats[0].shape[0]
+    c = query_embed.shape[1] // 2
+    query_pos, query = torch.split(query_embed, c, dim=1)                   # :130
+    query_pos = query_pos.unsqueeze(0).expand(b, -1, -1)
+    query = query.unsqueeze(0).expand(b, -1, -1)
+    ref = _linear(query_pos, p, 'reference_points').sigmoid()               # :133-134
+    states, refs = decoder(layer_params, query.permute(1, 0, 2), mlvl_feats,
+                           query_pos.permute(1, 0, 2), ref, img_metas, pc_range,
+                           reg_branches=reg_branches, **kw)
+    return states, ref, refs
