@@ -1,0 +1,59 @@
+"""ctypes binding of libgd4d.so (C ABI declared in include/gd4d.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C graph-detr4d_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgd4d.so')
+ABI_VERSION = 1
+
+F32, BF16 = 0, 1
+
+_c = ctypes
+_vp, _i, _f = _c.c_void_p, _c.c_int, _c.c_float
+
+# name -> (restype, argtypes); must list every symbol include/gd4d.h declares
+SIGNATURES = {
+    'gd4d_abi_version': (_i, []),
+    'gd4d_error_string': (_c.c_char_p, [_i]),
+    'gd4d_last_hip_error': (_c.c_char_p, []),
+    'gd4d_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
+                                 _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class Gd4dError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libgd4d.so once; raises Gd4dError if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Gd4dError(f'{LIB_PATH} not found: the HIP extension is not built '
+                        '(run __graft_entry__.build()); there is no CPU fallback')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gd4d_abi_version() != ABI_VERSION:
+        raise Gd4dError(f'libgd4d.so ABI {lib.gd4d_abi_version()} != expected {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        lib = load()
+        msg = lib.gd4d_error_string(code).decode()
+        hip = lib.gd4d_last_hip_error().decode()
+        raise Gd4dError(f'{what} failed: {msg} (code {code})' + (f'; HIP: {hip}' if hip else ''))

@@ -1,0 +1,38 @@
+// Shared helpers for libgd4d.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gd4d.h"
+
+#define GD4D_WAVE 64
+
+namespace gd4d {
+
+void set_last_hip_error(hipError_t e);
+
+// Record and translate a launch failure (never synchronises).
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_hip_error(e);
+    return GD4D_ELAUNCH;
+  }
+  return GD4D_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) {
+  return __uint_as_float(static_cast<uint32_t>(v) << 16);
+}
+
+// round-to-nearest-even f32 -> bf16 bits (NaN kept quiet)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+}  // namespace gd4d

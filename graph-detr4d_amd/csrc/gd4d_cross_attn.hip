@@ -1,0 +1,257 @@
+// gd4d_cross_attn_fwd: fused 3D->2D projection + visibility mask + masked softmax weights +
+// multi-camera / multi-level bilinear gather + sigmoid-camera-weighted reduction, for gfx950.
+//
+// Reference semantics: Deform3DCrossAttn.forward, deform3d_cross_attn.py:220-258 (projection,
+// mask), :281-284 (softmax * mask), :301-304 (third-party mmcv MSDA gather), :320-324 (camera
+// weights, sum over cameras).  Maths restated in SURVEY.md Appendix A.1.
+//
+// Work mapping (wave64): one wavefront = one (batch, query).  The 256 output channels of a query
+// are exactly 64 lanes x float4, so lane `c4` owns channels [4*c4, 4*c4+4) and belongs to head
+// h = 4*c4 / Dh.  With Hh = 8, Dh = 32 the 8 lanes of a head read one 128-byte line per bilinear
+// corner (a full L2 line, fully coalesced); no cross-lane reduction is ever needed and the wave
+// writes its 1 KiB output row once.  Cameras the query cannot see (about 82 % of (query, camera)
+// pairs on a surround rig) are skipped wave-uniformly.
+//
+// Phase A (projection) is spread over the 64 lanes: entry e = (camera, head, point) -> one lane
+// computes u, v and the visibility bit with the reference's exact fp32 operation order
+// (no FMA contraction, IEEE division) and parks (u, v) in LDS; phase B re-reads the four points of
+// the lane's head per camera (LDS broadcast within the head's lane group).
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+struct CrossAttnParams {
+  const void* value;
+  const float* ref;
+  const float* offsets;
+  const float* attn_logits;
+  const float* cam_logits;
+  const float* lidar2img;
+  float* out;
+  uint8_t* mask_out;
+  float* uv_out;
+  int B, N, Q, L, S;
+  int lvl_h[GD4D_MAX_LEVELS];
+  int lvl_w[GD4D_MAX_LEVELS];
+  int lvl_start[GD4D_MAX_LEVELS];
+  float rng_scale[3];  // float(double(hi) - double(lo))
+  float rng_lo[3];     // float(lo)
+  float img_h, img_w;
+};
+
+constexpr int kPoints = 4;   // sampling points per head (reference configs: num_points=4)
+constexpr int kChannels = 256;
+
+// ---- phase A: bit-exact projection of one (camera, head, point) entry ------------------------
+// Order of operations is the reference's torch-CPU arithmetic:
+//   p = ref*scale + lo (two roundings); X = p + off; c = ((m0*X + m1*Y) + m2*Z) + m3;
+//   u = (cx / max(cz, eps)) / W; v = (cy / max(cz, eps)) / H; all IEEE, no contraction.
+__device__ __forceinline__ bool project_entry(const CrossAttnParams& p, const float* __restrict__ m,
+                                              float X, float Y, float Z, float& u, float& v) {
+  // NOTE: this translation unit is built with -ffp-contract=off; HIP's __fmul_rn/__fadd_rn are
+  // plain operators that the compiler would otherwise contract into v_fma_f32 (seen in the ISA).
+  const float eps = 1e-5f;
+  const float cx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+  const float cy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+  const float cz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+  bool vis = cz > eps;
+  const float zc = fmaxf(cz, eps);
+  u = (cx / zc) / p.img_w;       // IEEE-correct division (v_div_scale/fmas/fixup)
+  v = (cy / zc) / p.img_h;
+  vis = vis && (u > 0.f) && (u < 1.f) && (v > 0.f) && (v < 1.f);
+  return vis;
+}
+
+template <typename VT> struct Quad;  // 4 consecutive channels of one pixel/head
+template <> struct Quad<float> {
+  static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+};
+template <> struct Quad<uint16_t> {
+  static __device__ __forceinline__ float4 load(const uint16_t* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  }
+};
+
+__device__ __forceinline__ void softmax_lp(const float* __restrict__ logits, int n, float* w) {
+  float mx = logits[0];
+  for (int i = 1; i < n; ++i) mx = fmaxf(mx, logits[i]);
+  float sum = 0.f;
+  for (int i = 0; i < n; ++i) { w[i] = expf(logits[i] - mx); sum += w[i]; }
+  float inv = 1.0f / sum;
+  for (int i = 0; i < n; ++i) w[i] *= inv;
+}
+
+// LT > 0: number of levels known at compile time (fully unrolled gather); LT == 0: runtime p.L.
+template <typename VT, int HH, int LT>
+__global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttnParams p) {
+  constexpr int DH = kChannels / HH;
+  constexpr int LANES_PER_HEAD = DH / 4;
+  constexpr int E = HH * kPoints;          // projection entries per camera
+  constexpr int LMAX = LT > 0 ? LT : GD4D_MAX_LEVELS;
+  extern __shared__ float2 s_uv[];         // [N][E]; x < 0 marks "not visible"
+
+  const int lane = threadIdx.x;
+  const int bq = blockIdx.x;
+  const int b = bq / p.Q;
+  const int q = bq - b * p.Q;
+  const int L = LT > 0 ? LT : p.L;
+
+  // ---------------- phase A ----------------
+  {
+    const float* rp = p.ref + (size_t)bq * 3;
+    const float px = rp[0] * p.rng_scale[0] + p.rng_lo[0];     // two roundings (contract off)
+    const float py = rp[1] * p.rng_scale[1] + p.rng_lo[1];
+    const float pz = rp[2] * p.rng_scale[2] + p.rng_lo[2];
+    const float* offs = p.offsets + (size_t)bq * E * 3;
+    const int total = p.N * E;
+    for (int e = lane; e < total; e += GD4D_WAVE) {
+      const int n = e / E;
+      const int hp = e - n * E;
+      const float X = px + offs[hp * 3 + 0];
+      const float Y = py + offs[hp * 3 + 1];
+      const float Z = pz + offs[hp * 3 + 2];
+      const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
+      float u, v;
+      const bool vis = project_entry(p, m, X, Y, Z, u, v);
+      s_uv[e] = vis ? make_float2(u, v) : make_float2(-1.f, -1.f);
+      const size_t o = (((size_t)b * p.N + n) * p.Q + q) * E + hp;
+      if (p.mask_out) p.mask_out[o] = vis ? 1 : 0;
+      if (p.uv_out) { p.uv_out[o * 2] = u; p.uv_out[o * 2 + 1] = v; }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase B ----------------
+  const int h = lane / LANES_PER_HEAD;
+  float aw[LMAX * kPoints];
+  if (p.B == 1) softmax_lp(p.attn_logits + ((size_t)bq * HH + h) * L * kPoints, L * kPoints, aw);
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const VT* vlane = static_cast<const VT*>(p.value) + lane * 4;
+  for (int n = 0; n < p.N; ++n) {
+    const float2* su = s_uv + n * E + h * kPoints;
+    float2 pu[kPoints];
+#pragma unroll
+    for (int k = 0; k < kPoints; ++k) pu[k] = su[k];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kPoints; ++k) any |= pu[k].x >= 0.f;
+    if (!__any(any)) continue;                               // wave-uniform skip
+
+    const int row = b * p.N + n;
+    if (p.B > 1) {   // reference quirk: logits of batch (row % B), deform3d_cross_attn.py:277
+      const int bb = row % p.B;
+      softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * kPoints, L * kPoints, aw);
+    }
+    const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];   // raw-view scramble
+    const float cw = 1.0f / (1.0f + expf(-cl));
+    const VT* vrow = vlane + (size_t)row * p.S * kChannels;
+
+#pragma unroll
+    for (int k = 0; k < kPoints; ++k) {
+      if (pu[k].x >= 0.f) {
+        const float u = pu[k].x, v = pu[k].y;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          if (LT == 0 && l >= L) break;
+          const int W = p.lvl_w[l], H = p.lvl_h[l];
+          const float x = fmaf(u, (float)W, -0.5f);
+          const float y = fmaf(v, (float)H, -0.5f);
+          const float xf = floorf(x), yf = floorf(y);
+          const float dx = x - xf, dy = y - yf;
+          const int x0 = (int)xf, y0 = (int)yf;
+          const float wl = aw[l * kPoints + k] * cw;
+          const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W;      // x0 <= W-1 and x0+1 >= 0 always hold for u in (0,1)
+          const bool y0ok = y0 >= 0, y1ok = y0 + 1 < H;
+          const float w00 = (x0ok && y0ok) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
+          const float w01 = (x1ok && y0ok) ? wl * dx * (1.f - dy) : 0.f;
+          const float w10 = (x0ok && y1ok) ? wl * (1.f - dx) * dy : 0.f;
+          const float w11 = (x1ok && y1ok) ? wl * dx * dy : 0.f;
+          // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
+          const int xa = x0ok ? x0 : 0, xb = x1ok ? x0 + 1 : W - 1;
+          const int ya = y0ok ? y0 : 0, yb = y1ok ? y0 + 1 : H - 1;
+          const VT* lvl = vrow + (size_t)p.lvl_start[l] * kChannels;
+          const float4 v00 = Quad<VT>::load(lvl + (ya * W + xa) * kChannels);
+          const float4 v01 = Quad<VT>::load(lvl + (ya * W + xb) * kChannels);
+          const float4 v10 = Quad<VT>::load(lvl + (yb * W + xa) * kChannels);
+          const float4 v11 = Quad<VT>::load(lvl + (yb * W + xb) * kChannels);
+          acc.x = fmaf(w00, v00.x, acc.x); acc.y = fmaf(w00, v00.y, acc.y);
+          acc.z = fmaf(w00, v00.z, acc.z); acc.w = fmaf(w00, v00.w, acc.w);
+          acc.x = fmaf(w01, v01.x, acc.x); acc.y = fmaf(w01, v01.y, acc.y);
+          acc.z = fmaf(w01, v01.z, acc.z); acc.w = fmaf(w01, v01.w, acc.w);
+          acc.x = fmaf(w10, v10.x, acc.x); acc.y = fmaf(w10, v10.y, acc.y);
+          acc.z = fmaf(w10, v10.z, acc.z); acc.w = fmaf(w10, v10.w, acc.w);
+          acc.x = fmaf(w11, v11.x, acc.x); acc.y = fmaf(w11, v11.y, acc.y);
+          acc.z = fmaf(w11, v11.z, acc.z); acc.w = fmaf(w11, v11.w, acc.w);
+        }
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(p.out + (size_t)bq * kChannels + lane * 4) = acc;
+}
+
+template <typename VT, int HH>
+static int launch_levels(const CrossAttnParams& p, hipStream_t s) {
+  const dim3 grid(p.B * p.Q), block(GD4D_WAVE);
+  const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
+  switch (p.L) {
+    case 1: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 1>), grid, block, lds, s, p); break;
+    case 2: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 2>), grid, block, lds, s, p); break;
+    case 3: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 3>), grid, block, lds, s, p); break;
+    case 4: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 4>), grid, block, lds, s, p); break;
+    default: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 0>), grid, block, lds, s, p); break;
+  }
+  return check_launch();
+}
+
+template <typename VT>
+static int launch_heads(const CrossAttnParams& p, int Hh, hipStream_t s) {
+  switch (Hh) {
+    case 4: return launch_levels<VT, 4>(p, s);
+    case 8: return launch_levels<VT, 8>(p, s);
+    case 16: return launch_levels<VT, 16>(p, s);
+    default: return GD4D_EUNSUPPORTED;
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float* ref,
+                                   const float* offsets, const float* attn_logits,
+                                   const float* cam_logits, const float* lidar2img,
+                                   const double* pc_range, float img_h, float img_w, float* out,
+                                   uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
+                                   int Dh, int L, int P, int value_dtype, void* stream) {
+  using namespace gd4d;
+  if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img ||
+      !pc_range || !out)
+    return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || Dh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f))
+    return GD4D_EINVAL;
+  if (Hh * Dh != kChannels || P != kPoints || L > GD4D_MAX_LEVELS || N > 64) return GD4D_EUNSUPPORTED;
+  if (value_dtype != GD4D_F32 && value_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
+  if (!aligned16(value) || !aligned16(out)) return GD4D_EALIGN;
+
+  CrossAttnParams p{};
+  p.value = value; p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits;
+  p.cam_logits = cam_logits; p.lidar2img = lidar2img; p.out = out; p.mask_out = mask_out;
+  p.uv_out = uv_out;
+  p.B = B; p.N = N; p.Q = Q; p.L = L;
+  int start = 0;
+  for (int l = 0; l < L; ++l) {
+    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+    if (h <= 0 || w <= 0) return GD4D_EINVAL;
+    p.lvl_h[l] = h; p.lvl_w[l] = w; p.lvl_start[l] = start;
+    start += h * w;
+  }
+  p.S = start;
+  for (int k = 0; k < 3; ++k) {
+    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
+    p.rng_lo[k] = static_cast<float>(pc_range[k]);
+  }
+  p.img_h = img_h; p.img_w = img_w;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return value_dtype == GD4D_F32 ? launch_heads<float>(p, Hh, s) : launch_heads<uint16_t>(p, Hh, s);
+}

@@ -1,0 +1,93 @@
+/*
+ * gd4d.h - C ABI of libgd4d.so: the MI355X (gfx950) decoder hot path of Graph-DETR4D.
+ *
+ * The reference has NO native code of its own: its hot path calls third-party
+ * kernels (mmcv MultiScaleDeformableAttnFunction, ATen grid_sampler / nn.MultiheadAttention /
+ * addmm) from Python.  Each entry point below therefore names the reference call site
+ * (file:line under projects/mmdet3d_plugin/models/utils/) whose tensor-level work it replaces;
+ * the Python-side binding a maintainer would add is in INTEGRATION.md and is what
+ * graph-detr4d_amd/_lib.py does with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in any signature
+ *     (`stream` is a hipStream_t passed as void*, NULL = the null stream);
+ *   - every pointer is DEVICE memory unless its comment says "host";
+ *   - the caller owns and allocates every buffer (incl. workspaces, sized by *_workspace_bytes);
+ *     the library never allocates device memory, never synchronises, and launches only on `stream`;
+ *   - tensors are dense, row-major, innermost dimension last, in the order written in the comment;
+ *   - return value: GD4D_OK (0) or a negative GD4D_E* code (see gd4d_error_string);
+ *   - dtype codes: GD4D_F32 / GD4D_BF16 describe the STORAGE type of feature/value tensors;
+ *     query-side tensors, weights, accumulation and outputs are always fp32.
+ */
+#ifndef GD4D_H_
+#define GD4D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD4D_ABI_VERSION 1
+
+enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
+
+enum {
+  GD4D_OK = 0,
+  GD4D_EINVAL = -1,       /* NULL pointer / non-positive size */
+  GD4D_EUNSUPPORTED = -2, /* shape outside what the kernels are built for (see each function) */
+  GD4D_EALIGN = -3,       /* pointer not 16-byte aligned where the kernel does 16-byte accesses */
+  GD4D_ELAUNCH = -4,      /* hipLaunch / hipGetLastError failed */
+  GD4D_EWORKSPACE = -5    /* workspace too small */
+};
+
+#define GD4D_MAX_LEVELS 8
+
+int gd4d_abi_version(void);
+const char* gd4d_error_string(int code);
+/* Text of the last HIP error seen by this thread inside the library ("" if none). */
+const char* gd4d_last_hip_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * gd4d_cross_attn_fwd - fused 3D->2D projection + visibility mask + masked softmax weights +
+ * multi-camera / multi-level bilinear gather + per-camera sigmoid-weighted reduction.
+ *
+ * Replaces, in Deform3DCrossAttn.forward (deform3d_cross_attn.py):
+ *   :220-258  de-normalise reference points, add metre offsets, lidar2img matmul, depth/border mask
+ *   :274,281-284  softmax over L*P, multiplied by the mask without renormalisation
+ *   :301-304  MultiScaleDeformableAttnFunction.apply (third-party mmcv CUDA kernel)
+ *   :320-324  sigmoid camera weights (raw-view "scramble" of :211-212 applied here) and sum over cameras
+ *
+ *   value        (B*N, S, Hh, Dh)  S = sum_l H_l*W_l; output of value_proj, channels-last head-major
+ *   level_hw     host, L x 2 int32 (H_l, W_l)       (reference: spatial_shapes, :271)
+ *   ref          (B, Q, 3) fp32 in [0,1]            (reference_points)
+ *   offsets      (B, Q, Hh, P, 3) fp32 metres       (deform_sampling_offsets(query), :227)
+ *   attn_logits  (B, Q, Hh, L, P) fp32              (attention_weights(query), :281)
+ *   cam_logits   (B, Q, N) fp32, the UN-scrambled Linear output (:211); weight of camera n for
+ *                query q is sigmoid(flat[b][n*Q + q])
+ *   lidar2img    (B, N, 4, 4) fp32, rows act on [x y z 1]^T
+ *   pc_range     host, 6 doubles [x0 y0 z0 x1 y1 z1] ((hi-lo) is formed in double like the
+ *                reference's Python floats, :222-224)
+ *   img_h, img_w img_metas[0]['img_shape'][0][:2]   (:242-243)
+ *   out          (B, Q, Hh*Dh) fp32 = sum_n sigmoid(cam) * MSDA_n   (input of output_proj, :326)
+ *   mask_out     optional (B, N, Q, Hh, P) uint8 visibility mask (bit-exact vs the reference's CPU
+ *                arithmetic at this boundary); NULL to skip
+ *   uv_out       optional (B, N, Q, Hh, P, 2) fp32 normalised image coordinates; NULL to skip
+ *
+ * Attention logits for value row i = b*N+n are taken from batch (i % B): this is what the
+ * reference's `query.repeat(num_cams,1,1)` (:277) pairs them with; identity for B = 1.
+ *
+ * Supported: Hh*Dh == 256 and Dh % 4 == 0 (fp32) / Dh % 8 == 0 (bf16), P == 4, 1 <= L <= 8,
+ * N <= 64.  `value` 16-byte aligned.
+ */
+int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float* ref,
+                        const float* offsets, const float* attn_logits, const float* cam_logits,
+                        const float* lidar2img, const double* pc_range, float img_h, float img_w,
+                        float* out, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
+                        int Dh, int L, int P, int value_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GD4D_H_ */

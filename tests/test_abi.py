@@ -1,0 +1,38 @@
+"""The C-ABI library loads and exports every symbol include/gd4d.h declares (no compute, no GPU)."""
+import os
+import re
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    from graph_detr4d_amd import _lib
+    hdr = open(os.path.join(repo_root, 'include', 'gd4d.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(gd4d_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'libgd4d.so does not export {name}'
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.gd4d_abi_version() == _lib.ABI_VERSION
+    assert b'not supported' in lib.gd4d_error_string(-2)
+
+
+def test_product_path_never_imports_oracle(repo_root):
+    """The package must not route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(repo_root, 'graph-detr4d_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'c_oracle' not in src and 'torch_oracle' not in src, f
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from graph_detr4d_amd import _lib, ops
+    z = torch.zeros
+    with pytest.raises(_lib.Gd4dError):
+        ops.cross_attn_fwd(z(6, 4, 8, 32), [(2, 2)], z(1, 3, 3), z(1, 3, 8, 4, 3), z(1, 3, 8, 1, 4),
+                           z(1, 3, 6), z(1, 6, 4, 4), [0, 0, 0, 1, 1, 1], 8, 8)

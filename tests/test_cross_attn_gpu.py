@@ -1,0 +1,120 @@
+"""Parity of the fused HIP kernel (through the C ABI) against golden vectors captured from the
+reference and against the CPU oracle on seeded inputs.  GPU only."""
+import pytest
+import torch
+
+from golden_io import Golden
+
+pytestmark = pytest.mark.gpu
+
+DEFORM_CASES = ['deform_n6', 'deform_n12_depth', 'deform_n24_b2', 'deform_edge']
+# fp32 tolerance of the path: north_star asks 1e-3; the kernel only reorders fp32 sums
+ATOL = RTOL = 1e-4
+
+
+def _inputs(g, dev, value_dtype=torch.float32):
+    from oracle import torch_oracle as O
+    m = g.meta
+    b, n, q = m['batch'], m['num_cams'], m['num_query']
+    sd = g.state()
+    flat, shapes = O.flatten_pyramid(g.feats())
+    val = torch.nn.functional.linear(flat, sd['value_proj.weight'], sd['value_proj.bias'])
+    val = val.view(b * n, -1, 8, 32).to(value_dtype)
+    l2i = torch.from_numpy(g.arrays['lidar2img']).unsqueeze(0).expand(b, -1, -1, -1).contiguous()
+    args = dict(value=val, level_hw=shapes, ref=g.t('reference_points'),
+                offsets=g.t('offsets').view(b, q, 8, 4, 3).contiguous(),
+                attn_logits=g.t('attn_logits').view(b, q, 8, 4, 4).contiguous(),
+                cam_logits=g.t('cam_logits'), lidar2img=l2i)
+    dev_args = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in args.items()}
+    return args, dev_args, m
+
+
+@pytest.mark.parametrize('name', DEFORM_CASES)
+def test_fused_kernel_matches_reference_golden(name):
+    from graph_detr4d_amd import ops
+    g = Golden(name)
+    args, d, m = _inputs(g, 'cuda')
+    out, mask, uv = ops.cross_attn_fwd(**d, pc_range=m['pc_range'], img_h=m['img_shape'][0],
+                                       img_w=m['img_shape'][1], want_mask=True, want_uv=True)
+    b, n, q = m['batch'], m['num_cams'], m['num_query']
+    gmask = g.t('mask').view(b, n, q, 8, 4, 4)[..., 0, :]          # (B,N,Q,Hh,P): equal for all levels
+    guv = g.t('uv').view(b, n, q, 8, 4, 4, 2)[..., 0, :, :]
+    assert torch.equal(mask.cpu(), gmask), 'visibility mask must be bit-exact'
+    assert torch.equal(uv.cpu(), guv), 'projected coordinates must be bit-exact'
+    torch.testing.assert_close(out.cpu(), g.t('agg'), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n24_b2'])
+def test_fused_kernel_bf16_values(name):
+    """bf16 storage of the value tensor, fp32 accumulate: compare with the oracle fed the SAME
+    bf16-rounded values (so only summation order differs)."""
+    from graph_detr4d_amd import ops
+    from oracle import torch_oracle as O
+    g = Golden(name)
+    args, d, m = _inputs(g, 'cuda', torch.bfloat16)
+    out = ops.cross_attn_fwd(**d, pc_range=m['pc_range'], img_h=m['img_shape'][0], img_w=m['img_shape'][1])
+    ref, _, _ = O.sample_aggregate(args['value'].float(), args['level_hw'], args['ref'], args['offsets'],
+                                   args['attn_logits'].flatten(-2), args['cam_logits'], args['lidar2img'],
+                                   m['pc_range'], m['img_shape'][0], m['img_shape'][1])
+    torch.testing.assert_close(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_fused_kernel_vs_oracle_seeded_midsize():
+    """Seeded synthetic rig, Q=300, N=12, real pyramid aspect (reduced), random offsets."""
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import torch_oracle as O
+    torch.manual_seed(5)
+    b, q, n = 1, 300, 12
+    levels = [(29, 50), (15, 25), (8, 13), (4, 7)]
+    l2i = torch.from_numpy(synthetic.camera_rig(2)).unsqueeze(0)
+    val = torch.randn(b * n, sum(h * w for h, w in levels), 8, 32)
+    ref = torch.rand(b, q, 3)
+    offsets = torch.randn(b, q, 8, 4, 3) * 2.0
+    attn = torch.randn(b, q, 8, 4, 4)
+    cam = torch.randn(b, q, n)
+    o_ref, uv_ref, m_ref = O.sample_aggregate(val, levels, ref, offsets, attn.flatten(-2), cam, l2i,
+                                              synthetic.PC_RANGE, 900, 1600)
+    out, mask = ops.cross_attn_fwd(val.cuda(), levels, ref.cuda(), offsets.cuda(), attn.cuda(), cam.cuda(),
+                                   l2i.cuda(), synthetic.PC_RANGE, 900, 1600, want_mask=True)
+    # torch's batched matmul on THIS host decides m_ref; the C-level arithmetic is pinned by the
+    # golden tests above, so here only require agreement away from the decision thresholds.
+    mism = (mask.cpu() != m_ref.to(torch.uint8))
+    assert mism.float().mean().item() < 1e-4
+    if not mism.any():
+        torch.testing.assert_close(out.cpu(), o_ref, rtol=RTOL, atol=ATOL)
+
+
+def test_linearity_and_invisible_cameras_full_size():
+    """Size-independent properties at the BASELINE size (900 queries, 24 cameras, 4 levels):
+    (i) linear in `value`; (ii) appending cameras that see nothing leaves the output unchanged
+    given the same per-camera logits (T-invariance); (iii) all-zero value -> zero output."""
+    from graph_detr4d_amd import ops, synthetic
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(11)
+    b, q, n = 1, 900, 24
+    levels = synthetic.R50_LEVELS
+    s = sum(h * w for h, w in levels)
+    l2i = torch.from_numpy(synthetic.camera_rig(4)).unsqueeze(0).to(dev)
+    v1 = torch.randn(n, s, 8, 32, generator=g).to(dev)
+    v2 = torch.randn(n, s, 8, 32, generator=g).to(dev)
+    ref = torch.rand(b, q, 3, generator=g).to(dev)
+    offsets = (torch.randn(b, q, 8, 4, 3, generator=g) * 2).to(dev)
+    attn = torch.randn(b, q, 8, 4, 4, generator=g).to(dev)
+    cam = torch.randn(b, q, n, generator=g).to(dev)
+
+    def run(v, l2i_=l2i, cam_=cam):
+        return ops.cross_attn_fwd(v, levels, ref, offsets, attn, cam_, l2i_, synthetic.PC_RANGE, 900, 1600)
+    o1, o2, o12 = run(v1), run(v2), run(v1 * 0.5 + v2 * 2.0)
+    torch.testing.assert_close(o12, o1 * 0.5 + o2 * 2.0, rtol=1e-4, atol=1e-4)
+    assert run(torch.zeros_like(v1)).abs().max().item() == 0.0
+    assert o1.abs().max().item() > 0.1
+    # (ii) cameras behind everything: z <= 0 for every point => masked
+    blind = l2i.clone()
+    blind[:, 12:] = 0.0
+    blind[:, 12:, 2, 3] = -1.0
+    o_blind = run(v1, blind)
+    o_half = ops.cross_attn_fwd(v1[:12].contiguous(), levels, ref, offsets, attn,
+                                # scrambled view: camera n of query q reads flat[n*Q+q]; keep those values
+                                cam.reshape(b, -1)[:, :12 * q].reshape(b, q, 12).contiguous(),
+                                l2i[:, :12].contiguous(), synthetic.PC_RANGE, 900, 1600)
+    torch.testing.assert_close(o_blind, o_half, rtol=1e-6, atol=1e-6)
