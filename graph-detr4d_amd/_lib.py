@@ -23,6 +23,8 @@ SIGNATURES = {
     'gd4d_last_hip_error': (_c.c_char_p, []),
     'gd4d_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_detr3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
+                             _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

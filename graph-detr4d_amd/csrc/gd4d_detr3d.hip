@@ -1,0 +1,139 @@
+// gd4d_detr3d_fwd: DETR3D-baseline cross-attention core for gfx950 - feature_sampling
+// (detr3d_transformer.py:397-438) fused with the sigmoid weighting and the sum over cameras and
+// levels of Detr3DCrossAtten.forward (detr3d_transformer.py:373-383).  SURVEY.md Appendix A.2.
+//
+// The feature maps stay in the layout the reference's caller provides: per level (B*N, C, H, W)
+// NCHW.  One workgroup = one (batch, query); thread c = channel c, so every global load of a wave
+// walks 64 channel planes at the same (y, x): strided by H*W floats, but only the few pixels a
+// query projects to are ever touched (about 1 camera x 4 levels x 4 corners per query), which is
+// far less traffic than re-laying-out the whole pyramid first.  The projection is spread over the
+// first N threads (bit-exact arithmetic, translation unit built with -ffp-contract=off).
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+struct Detr3dParams {
+  const float* feats[GD4D_MAX_LEVELS];
+  const float* ref;
+  const float* attn_logits;   // (B, Q, N, P=1, L)
+  const float* lidar2img;
+  float* out;                 // (B, Q, C) or null
+  uint8_t* mask_out;          // (B, N, Q) or null
+  float* sampled_out;         // (B, C, Q, N, 1, L) or null
+  int B, N, Q, C, L;
+  int lvl_h[GD4D_MAX_LEVELS];
+  int lvl_w[GD4D_MAX_LEVELS];
+  float rng_scale[3];
+  float rng_lo[3];
+  float img_h, img_w;
+};
+
+// ATen grid_sampler, bilinear / zeros / align_corners=False, on grid coordinate g in [-1, 1]:
+//   x = ((g + 1) * size - 1) / 2 ; corners floor(x), floor(x)+1 ; out-of-map corners contribute 0.
+__device__ __forceinline__ float unnormalize(float g, int size) {
+  return ((g + 1.f) * (float)size - 1.f) / 2.f;
+}
+
+__global__ __launch_bounds__(256) void detr3d_fwd_kernel(const Detr3dParams p) {
+  extern __shared__ float s_mem[];
+  float2* s_uv = reinterpret_cast<float2*>(s_mem);            // [N] grid coords in [-1,1]
+  float* s_w = s_mem + 2 * p.N;                               // [N*L] sigmoid(logit) * vis
+  int* s_vis = reinterpret_cast<int*>(s_w + p.N * p.L);       // [N]
+
+  const int bq = blockIdx.x;
+  const int b = bq / p.Q, q = bq - b * p.Q;
+  const int t = threadIdx.x;
+
+  if (t < p.N) {
+    const int n = t;
+    const float* rp = p.ref + (size_t)bq * 3;
+    const float X = rp[0] * p.rng_scale[0] + p.rng_lo[0];
+    const float Y = rp[1] * p.rng_scale[1] + p.rng_lo[1];
+    const float Z = rp[2] * p.rng_scale[2] + p.rng_lo[2];
+    const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
+    const float eps = 1e-5f;
+    const float cx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+    const float cy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+    const float cz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+    bool vis = cz > eps;
+    const float zc = fmaxf(cz, eps);
+    float u = (cx / zc) / p.img_w;
+    float v = (cy / zc) / p.img_h;
+    u = (u - 0.5f) * 2.f;                                     // detr3d_transformer.py:421
+    v = (v - 0.5f) * 2.f;
+    vis = vis && (u > -1.f) && (u < 1.f) && (v > -1.f) && (v < 1.f);
+    s_uv[n] = make_float2(u, v);
+    s_vis[n] = vis ? 1 : 0;
+    if (p.mask_out) p.mask_out[((size_t)b * p.N + n) * p.Q + q] = vis ? 1 : 0;
+  }
+  __syncthreads();
+  for (int e = t; e < p.N * p.L; e += blockDim.x) {
+    const int n = e / p.L;
+    const float lg = p.attn_logits[(size_t)bq * p.N * p.L + e];
+    s_w[e] = s_vis[n] ? 1.0f / (1.0f + expf(-lg)) : 0.f;
+  }
+  __syncthreads();
+
+  const bool want_all = p.sampled_out != nullptr;     // feature_sampling() returns every camera
+  for (int c = t; c < p.C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int n = 0; n < p.N; ++n) {
+      if (!want_all && !s_vis[n]) continue;                   // workgroup-uniform
+      const float2 g = s_uv[n];
+      for (int l = 0; l < p.L; ++l) {
+        const int H = p.lvl_h[l], W = p.lvl_w[l];
+        const float x = unnormalize(g.x, W), y = unnormalize(g.y, H);
+        const float xf = floorf(x), yf = floorf(y);
+        const float dx = x - xf, dy = y - yf;
+        // float compares first: far-away points can exceed the int range
+        const bool x0ok = xf >= 0.f && xf <= (float)(W - 1), x1ok = xf + 1.f >= 0.f && xf + 1.f <= (float)(W - 1);
+        const bool y0ok = yf >= 0.f && yf <= (float)(H - 1), y1ok = yf + 1.f >= 0.f && yf + 1.f <= (float)(H - 1);
+        float s = 0.f;
+        if ((x0ok || x1ok) && (y0ok || y1ok)) {
+          const int x0 = (int)xf, y0 = (int)yf;
+          const float* plane = p.feats[l] + ((size_t)(b * p.N + n) * p.C + c) * H * W;
+          if (x0ok && y0ok) s += (1.f - dx) * (1.f - dy) * plane[y0 * W + x0];
+          if (x1ok && y0ok) s += dx * (1.f - dy) * plane[y0 * W + x0 + 1];
+          if (x0ok && y1ok) s += (1.f - dx) * dy * plane[(y0 + 1) * W + x0];
+          if (x1ok && y1ok) s += dx * dy * plane[(y0 + 1) * W + x0 + 1];
+        }
+        if (want_all)
+          p.sampled_out[((((size_t)b * p.C + c) * p.Q + q) * p.N + n) * p.L + l] = s;
+        acc = fmaf(s_w[n * p.L + l], s, acc);
+      }
+    }
+    if (p.out) p.out[(size_t)bq * p.C + c] = acc;
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const float* ref,
+                               const float* attn_logits, const float* lidar2img,
+                               const double* pc_range, float img_h, float img_w, float* out,
+                               uint8_t* mask_out, float* sampled_out, int B, int N, int Q, int C,
+                               int L, int P, void* stream) {
+  using namespace gd4d;
+  if (!feats || !level_hw || !ref || !attn_logits || !lidar2img || !pc_range) return GD4D_EINVAL;
+  if (!out && !sampled_out && !mask_out) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || C <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
+  if (L > GD4D_MAX_LEVELS || P != 1 || N > 256) return GD4D_EUNSUPPORTED;
+  Detr3dParams p{};
+  for (int l = 0; l < L; ++l) {
+    if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
+    p.feats[l] = static_cast<const float*>(feats[l]);
+    p.lvl_h[l] = level_hw[2 * l];
+    p.lvl_w[l] = level_hw[2 * l + 1];
+  }
+  p.ref = ref; p.attn_logits = attn_logits; p.lidar2img = lidar2img;
+  p.out = out; p.mask_out = mask_out; p.sampled_out = sampled_out;
+  p.B = B; p.N = N; p.Q = Q; p.C = C; p.L = L;
+  for (int k = 0; k < 3; ++k) {
+    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
+    p.rng_lo[k] = static_cast<float>(pc_range[k]);
+  }
+  p.img_h = img_h; p.img_w = img_w;
+  const size_t lds = sizeof(float) * (size_t)(2 * N + N * L) + sizeof(int) * (size_t)N;
+  hipLaunchKernelGGL(detr3d_fwd_kernel, dim3(B * Q), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}

@@ -1,0 +1,161 @@
+"""DETR3D-side modules of the hot path: `Detr3DCrossAtten`, `feature_sampling`,
+`Detr3DTransformerDecoder`, `Detr3DTransformer`.
+
+Drop-ins for the reference classes of the same names in
+projects/mmdet3d_plugin/models/utils/detr3d_transformer.py (:46, :153, :229, :397): same registry
+type names, constructor keywords, state-dict keys and call signatures.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .deform3d_cross_attn import Deform3DCrossAttn
+from .registry import (ATTENTION, TRANSFORMER, TRANSFORMER_LAYER_SEQUENCE,
+                       build_transformer_layer_sequence)
+from .transformer_layers import TransformerLayerSequence
+
+inverse_sigmoid = Fn.inverse_sigmoid
+
+
+def feature_sampling(mlvl_feats, reference_points, pc_range, img_metas):
+    """Reference: detr3d_transformer.py:397-438.  Returns (reference_points_3d (B,Q,3),
+    sampled_feats (B,C,Q,N,1,L), mask (B,1,Q,N,1,1) bool) computed by gd4d_detr3d_fwd."""
+    Fn.require_gpu(reference_points, 'reference_points')
+    Fn.require_inference(reference_points, *mlvl_feats)
+    lidar2img = Fn.lidar2img_device(img_metas, reference_points)
+    img_h, img_w = Fn.img_hw(img_metas)
+    b, q = reference_points.shape[:2]
+    n, nl = mlvl_feats[0].shape[1], len(mlvl_feats)
+    dummy = reference_points.new_zeros(b, q, n, 1, nl)
+    r = ops.detr3d_fwd([f.contiguous() for f in mlvl_feats], reference_points.contiguous(), dummy,
+                       lidar2img, pc_range, img_h, img_w, want_out=False, want_mask=True,
+                       want_sampled=True)
+    mask = r['mask'].bool().permute(0, 2, 1).reshape(b, 1, q, n, 1, 1)
+    return reference_points.clone(), r['sampled'], mask
+
+
+@ATTENTION.register_module()
+class Detr3DCrossAtten(nn.Module):
+    """DETR3D baseline cross-attention (reference :229-390): one sampling point per query, no
+    heads, sigmoid weights over cameras x levels."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=5, num_cams=6,
+                 im2col_step=64, pc_range=None, dropout=0.1, norm_cfg=None, init_cfg=None,
+                 batch_first=False):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, '
+                             f'but got {embed_dims} and {num_heads}')
+        self.norm_cfg = norm_cfg
+        self.init_cfg = init_cfg
+        self.pc_range = pc_range
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.num_cams = num_cams
+        self.batch_first = batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.attention_weights = nn.Linear(embed_dims, num_cams * num_levels * num_points)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.position_encoder = nn.Sequential(
+            nn.Linear(3, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True),
+            nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True))
+        self.init_weight()
+
+    def init_weight(self):
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if residual is not None:
+            raise NameError('Detr3DCrossAtten: residual must be None (as in the reference)')
+        img_metas = kwargs['img_metas']
+        Fn.require_gpu(query, 'query')
+        Fn.require_inference(query, query_pos, reference_points, *value)
+        if self.num_points != 1:
+            raise NotImplementedError('Detr3DCrossAtten: the gfx950 kernel is built for '
+                                      'num_points=1 (every reference config)')
+        inp_residual = query
+        x = query if query_pos is None else query + query_pos
+        x = x.permute(1, 0, 2)
+        logits = Fn.linear(x, self.attention_weights.weight, self.attention_weights.bias)
+        lidar2img = Fn.lidar2img_device(img_metas, x)
+        img_h, img_w = Fn.img_hw(img_metas)
+        agg = ops.detr3d_fwd([f.contiguous() for f in value], reference_points.contiguous(),
+                             logits.contiguous(), lidar2img, self.pc_range, img_h, img_w)['out']
+        out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
+        pos_feat = self.position_encoder(inverse_sigmoid(reference_points)).permute(1, 0, 2)
+        return self.dropout(out) + inp_residual + pos_feat
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class Detr3DTransformerDecoder(TransformerLayerSequence):
+    """Reference :153-225: loop over layers, refine reference points with reg_branches."""
+
+    def __init__(self, *args, return_intermediate=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+
+    def forward(self, query, *args, reference_points=None, reg_branches=None, **kwargs):
+        output = query
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            output = layer(output, *args, reference_points=reference_points, **kwargs)
+            if reg_branches is not None:
+                tmp = reg_branches[lid](output.permute(1, 0, 2))
+                assert reference_points.shape[-1] == 3
+                new_ref = torch.zeros_like(reference_points)
+                new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
+                new_ref[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
+                reference_points = new_ref.sigmoid().detach()
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+@TRANSFORMER.register_module()
+class Detr3DTransformer(nn.Module):
+    """Reference :46-150: split query_embed, predict initial reference points, run the decoder."""
+
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300,
+                 decoder=None, init_cfg=None, **kwargs):
+        super().__init__()
+        self.decoder = build_transformer_layer_sequence(decoder)
+        self.embed_dims = self.decoder.embed_dims
+        self.num_feature_levels = num_feature_levels
+        self.num_cams = num_cams
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.reference_points = nn.Linear(self.embed_dims, 3)
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, (Detr3DCrossAtten, Deform3DCrossAttn)):
+                m.init_weight()
+        nn.init.xavier_uniform_(self.reference_points.weight)
+        nn.init.constant_(self.reference_points.bias, 0.)
+
+    def forward(self, mlvl_feats, query_embed, reg_branches=None, **kwargs):
+        assert query_embed is not None
+        bs = mlvl_feats[0].size(0)
+        query_pos, query = torch.split(query_embed, self.embed_dims, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        query = query.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+        inter_states, inter_references = self.decoder(
+            query=query.permute(1, 0, 2), key=None, value=mlvl_feats,
+            query_pos=query_pos.permute(1, 0, 2), reference_points=reference_points,
+            reg_branches=reg_branches, **kwargs)
+        return inter_states, init_reference_out, inter_references

@@ -68,3 +68,32 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
     if want_uv:
         res += (uv,)
     return res if len(res) > 1 else out
+
+
+def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_out=True,
+               want_mask=False, want_sampled=False):
+    """gd4d_detr3d_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) fp32 (NCHW per camera);
+    ref (B,Q,3); attn_logits (B,Q,N,1,L) (any shape with B*Q*N*L elements in that order).
+    Returns a dict with the requested 'out' (B,Q,C), 'mask' (B,N,Q) uint8,
+    'sampled' (B,C,Q,N,1,L)."""
+    lib = _lib.load()
+    b, n, c = feats[0].shape[:3]
+    q = ref.shape[1]
+    nl = len(feats)
+    if attn_logits.numel() != b * q * n * nl:
+        raise ValueError('attn_logits must have B*Q*N*L elements (num_points must be 1)')
+    f32 = torch.float32
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    dev = ref.device
+    out = torch.empty(b, q, c, device=dev, dtype=f32) if want_out else None
+    mask = torch.empty(b, n, q, device=dev, dtype=torch.uint8) if want_mask else None
+    sampled = torch.empty(b, c, q, n, 1, nl, device=dev, dtype=f32) if want_sampled else None
+    code = lib.gd4d_detr3d_fwd(
+        ptrs, lv, _dev(ref, 'ref', f32), _dev(attn_logits, 'attn_logits', f32),
+        _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w),
+        _dev(out, 'out') if want_out else None, _dev(mask, 'mask') if want_mask else None,
+        _dev(sampled, 'sampled') if want_sampled else None, b, n, q, c, nl, 1, _stream())
+    _lib.check(code, 'gd4d_detr3d_fwd')
+    return dict(out=out, mask=mask, sampled=sampled)

@@ -87,6 +87,30 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
                         float* out, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
                         int Dh, int L, int P, int value_dtype, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * gd4d_detr3d_fwd - DETR3D-baseline core: feature_sampling (detr3d_transformer.py:397-438) fused
+ * with sigmoid(logits) * mask and the sum over levels / points / cameras of
+ * Detr3DCrossAtten.forward (detr3d_transformer.py:373-383).  Replaces the per-level ATen
+ * F.grid_sample calls (:429-435) and the (B, C, Q, N, 1, L) intermediate.
+ *
+ *   feats        host array of L device pointers, level l = (B*N, C, H_l, W_l) fp32 NCHW
+ *                (exactly the `mlvl_feats` the reference's caller passes, viewed B*N)
+ *   level_hw     host, L x 2 int32 (H_l, W_l)
+ *   ref          (B, Q, 3) fp32 in [0,1]
+ *   attn_logits  (B, Q, N, P=1, L) fp32            (attention_weights(query), :373-374)
+ *   lidar2img    (B, N, 4, 4) fp32;  pc_range host 6 doubles;  img_h/img_w as above
+ *   out          optional (B, Q, C) fp32 = sum_{n,l} sigmoid(logit) * vis * bilinear  (input of
+ *                output_proj, :386)
+ *   mask_out     optional (B, N, Q) uint8 visibility (-1 < u',v' < 1 and z > eps), bit-exact
+ *   sampled_out  optional (B, C, Q, N, 1, L) fp32: feature_sampling()'s `sampled_feats`, computed
+ *                for EVERY camera like the reference (no visibility skipping)
+ * At least one of out / mask_out / sampled_out must be non-NULL.  Supported: P == 1, L <= 8.
+ */
+int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const float* ref,
+                    const float* attn_logits, const float* lidar2img, const double* pc_range,
+                    float img_h, float img_w, float* out, uint8_t* mask_out, float* sampled_out,
+                    int B, int N, int Q, int C, int L, int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,75 @@
+"""Host-side logic of the drop-in boundary that needs no GPU: registry, constructor contracts,
+state-dict key names, init conventions, loud failure on CPU tensors."""
+import pytest
+import torch
+
+import graph_detr4d_amd as G
+from golden_io import Golden, sub
+from graph_detr4d_amd import _lib
+
+PC = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+
+def _decoder_cfg(cross, n=6, layers=2):
+    return dict(type='Detr3DTransformerDecoder', num_layers=layers, return_intermediate=True,
+                transformerlayers=dict(
+                    type='DetrTransformerDecoderLayer',
+                    attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1), cross],
+                    feedforward_channels=512, ffn_dropout=0.1,
+                    operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+
+
+def test_registry_builds_reference_type_names():
+    for t in ('Deform3DCrossAttn', 'Detr3DCrossAtten', 'MultiheadAttention'):
+        assert t in G.ATTENTION
+    m = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=12, pc_range=PC, num_points=4,
+                               embed_dims=256), dict(batch_first=False))
+    assert isinstance(m, G.Deform3DCrossAttn) and m.num_cams == 12 and m.num_levels == 4
+    with pytest.raises(KeyError):
+        G.build_attention(dict(type='Detr3DCrossAttenMP'))     # dangling name in the reference too
+    with pytest.raises(ValueError):
+        G.Deform3DCrossAttn(embed_dims=250, num_heads=8)
+
+
+@pytest.mark.parametrize('name', ['decoder_deform', 'decoder_detr3d'])
+def test_state_dict_keys_match_reference(name):
+    """Key names AND shapes equal those of the reference model the golden was captured from."""
+    g = Golden(name)
+    m = g.meta
+    cross = (dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=PC, num_points=4, embed_dims=256)
+             if m['cross'] == 'Deform3DCrossAttn' else
+             dict(type='Detr3DCrossAtten', num_cams=m['num_cams'], pc_range=PC, num_points=1, embed_dims=256))
+    tr = G.Detr3DTransformer(num_feature_levels=4, num_cams=m['num_cams'],
+                             decoder=_decoder_cfg(cross, m['num_cams'], m['num_layers']))
+    ours = {k: tuple(v.shape) for k, v in tr.state_dict().items()}
+    ref = {k: tuple(v.shape) for k, v in g.state().items()}
+    assert ours == ref
+    tr.load_state_dict(g.state(), strict=True)
+
+
+def test_init_weight_matches_reference_convention():
+    """deform3d_cross_attn.py:129-150: zero logits, head directions x (i+1) metres in the bias."""
+    m = G.Deform3DCrossAttn(num_cams=6, pc_range=PC, num_points=4)
+    assert m.attention_weights.weight.abs().sum() == 0 and m.cam_attention_weights.weight.abs().sum() == 0
+    assert m.deform_sampling_offsets.weight.abs().sum() == 0
+    bias = m.deform_sampling_offsets.bias.view(8, 4, 3)
+    torch.testing.assert_close(bias[0], torch.tensor([[1., 0., 1.]]) * torch.arange(1, 5.)[:, None])
+    torch.testing.assert_close(bias[:, 1], bias[:, 0] * 2)
+    assert bias.abs().amax(-1).allclose(torch.arange(1, 5.).expand(8, 4))
+    g = Golden('deform_n6')          # a reference module's untouched-by-quantisation layout
+    assert set(k for k in g.state()) == set(m.state_dict().keys())
+
+
+def test_forward_fails_loudly_without_gpu_and_with_residual():
+    m = G.Deform3DCrossAttn(num_cams=6, pc_range=PC, num_points=4).eval()
+    q = torch.zeros(5, 1, 256)
+    feats = [torch.zeros(1, 6, 256, 4, 4)] * 4
+    metas = [dict(lidar2img=[torch.eye(4).numpy()] * 6, img_shape=[(32, 32, 3)] * 6)]
+    with torch.no_grad():
+        with pytest.raises(_lib.Gd4dError):
+            m(q, None, feats, None, query_pos=q, reference_points=torch.rand(1, 5, 3), img_metas=metas)
+        with pytest.raises(NameError):
+            m(q, None, feats, q, query_pos=q, reference_points=torch.rand(1, 5, 3), img_metas=metas)
+    with pytest.raises(KeyError):
+        with torch.no_grad():
+            m(q, None, feats, None, query_pos=q, reference_points=torch.rand(1, 5, 3))   # img_metas mandatory

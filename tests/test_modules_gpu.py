@@ -1,0 +1,102 @@
+"""Module-level parity on the GPU: our registry modules, loaded with the reference's state dict,
+against outputs captured from the reference's own forward (tests/golden).  Tolerance: fp32 path,
+north_star asks 1e-3; we hold 2e-4 (GEMM summation order differs between rocBLAS/MFMA and MKL)."""
+import pytest
+import torch
+
+import graph_detr4d_amd as G
+from golden_io import Golden, sub
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=2e-4, atol=2e-4)
+DEV = 'cuda'
+
+
+def _metas(g):
+    return g.img_metas()
+
+
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_n24_b2', 'deform_edge'])
+def test_deform3d_cross_attn_module(name):
+    g = Golden(name)
+    m = g.meta
+    mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=m['pc_range'],
+                                 num_points=4, embed_dims=256, depth_encode=m['depth_encode']),
+                            dict(batch_first=False))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    feats = [f.to(DEV) for f in g.feats()]
+    with torch.no_grad():
+        out = mod(g.t('query').to(DEV), None, feats, None, query_pos=g.t('query_pos').to(DEV),
+                  key_pos=None, attn_mask=None, key_padding_mask=None,
+                  reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+    assert out.shape == g.t('out').shape
+    torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
+
+
+@pytest.mark.parametrize('name', ['detr3d_n6', 'detr3d_n12_b2'])
+def test_detr3d_cross_atten_module_and_feature_sampling(name):
+    g = Golden(name)
+    m = g.meta
+    feats = [f.to(DEV) for f in g.feats()]
+    ref = g.t('reference_points').to(DEV)
+    with torch.no_grad():
+        ref3d, sampled, mask = G.feature_sampling(feats, ref, m['pc_range'], _metas(g))
+    assert torch.equal(mask.cpu().to(torch.uint8), g.t('fs_mask')), 'feature_sampling mask must be bit-exact'
+    torch.testing.assert_close(sampled.cpu(), g.t('fs_sampled'), rtol=1e-5, atol=1e-5)
+    assert torch.equal(ref3d.cpu(), g.t('fs_ref3d'))
+    mod = G.build_attention(dict(type='Detr3DCrossAtten', num_cams=m['num_cams'], pc_range=m['pc_range'],
+                                 num_points=1, embed_dims=256), dict(batch_first=False))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    with torch.no_grad():
+        out = mod(g.t('query').to(DEV), None, feats, None, query_pos=g.t('query_pos').to(DEV),
+                  reference_points=ref, img_metas=_metas(g))
+    torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
+
+
+@pytest.mark.parametrize('name', ['self_attn', 'self_attn_mask'])
+def test_self_attention_module(name):
+    g = Golden(name)
+    mod = G.build_attention(dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                            dict(batch_first=False))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    q, qp = g.t('query').to(DEV), g.t('query_pos').to(DEV)
+    mask = g.t('attn_mask').bool().to(DEV) if g.has('attn_mask') else None
+    with torch.no_grad():
+        out = mod(q, q, q, None, query_pos=qp, key_pos=qp, attn_mask=mask, key_padding_mask=None)
+    torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
+
+
+@pytest.mark.parametrize('name', ['decoder_deform', 'decoder_detr3d'])
+def test_transformer_decoder(name):
+    """Detr3DTransformer -> Detr3DTransformerDecoder -> 2 post-norm layers, with reg-branch
+    reference-point refinement, against the reference's (inter_states, init_ref, inter_refs)."""
+    g = Golden(name)
+    m = g.meta
+    n = m['num_cams']
+    cross = (dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4, embed_dims=256)
+             if m['cross'] == 'Deform3DCrossAttn' else
+             dict(type='Detr3DCrossAtten', num_cams=n, pc_range=m['pc_range'], num_points=1, embed_dims=256))
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1), cross],
+                         feedforward_channels=512, ffn_dropout=0.1,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    nn = torch.nn
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                        nn.Linear(256, 10)) for _ in range(m['num_layers'])])
+    regs.load_state_dict(g.state(prefix='reg.'), strict=True)
+    regs = regs.to(DEV).eval()
+    with torch.no_grad():
+        states, init_ref, refs = tr([f.to(DEV) for f in g.feats()], g.t('query_embed').to(DEV),
+                                    reg_branches=regs, img_metas=_metas(g))
+    torch.testing.assert_close(init_ref.cpu(), g.t('init_reference'), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(refs.cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(states.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
