@@ -1,0 +1,284 @@
+#!/usr/bin/env python
+"""Benchmark of the Graph-DETR4D decoder hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one sample (6 cameras x T frames, pre-computed FPN pyramid resident in HBM) pushed
+through the 6-layer decoder (self-attention + Deform3DCrossAttn + FFN + reference-point refinement),
+eval mode, batch 1 per GPU - BASELINE.json's metric "6-cam samples/sec through decoder at
+900q x T=4".  N > 1 runs one independent replica per GPU (the path shards by sample; inference has
+no data-path collective), so scaling is "weak".  Rank 0 prints ONE JSON line.
+
+The JSON line also carries
+  roofline      - the fused sample-aggregate kernel (gd4d_cross_attn_fwd): algorithmic bytes per
+                  launch (SURVEY.md §8d formula, V counted from the kernel's own visibility mask)
+                  / mean launch duration measured with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline  - the CPU oracle (oracle/torch_oracle.py, a port of the reference path) timed on this
+                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=4, help='T temporal frames (cameras = 6*T)')
+    ap.add_argument('--queries', type=int, default=900)
+    ap.add_argument('--layers', type=int, default=6)
+    ap.add_argument('--levels', default='r50', choices=['r50', 'vov'])
+    ap.add_argument('--value-dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help='storage of the projected value tensor (fp32 = the reference-parity mode)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-layers', type=int, default=None,
+                    help='decoder layers of the CPU-baseline sample (default: bounded automatically)')
+    return ap.parse_args()
+
+
+def build_decoder(G, num_cams, layers, value_dtype, seed):
+    from graph_detr4d_amd import synthetic
+    torch.manual_seed(seed)
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=num_cams,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=layers, return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                    dict(type='Deform3DCrossAttn', num_cams=num_cams,
+                                         pc_range=synthetic.PC_RANGE, num_points=4, embed_dims=256,
+                                         value_dtype=value_dtype)],
+                         feedforward_channels=512, ffn_dropout=0.1,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.init_weights()
+    for i, layer in enumerate(tr.decoder.layers):
+        synthetic.randomise_cross_attn_(layer.attentions[1], seed=seed + i)
+    nn = torch.nn
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                        nn.Linear(256, 10)) for _ in range(layers)])
+    for r in regs:                                   # small refinements, like a trained head's deltas
+        nn.init.normal_(r[-1].weight, std=0.02)
+        nn.init.zeros_(r[-1].bias)
+    return tr.eval(), regs.eval()
+
+
+def state_as_oracle_params(tr):
+    sd = {k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    n = len(tr.decoder.layers)
+    layers = [{k[len(f'decoder.layers.{i}.'):]: v for k, v in sd.items()
+               if k.startswith(f'decoder.layers.{i}.')} for i in range(n)]
+    return sd, layers
+
+
+def cpu_baseline(tr, regs, feats_cpu, query_embed, metas, pc_range, layers_to_time):
+    """Oracle (CPU port of the reference path) on this host's cores, bounded sample."""
+    from oracle import torch_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd, layer_params = state_as_oracle_params(tr)
+    regs_cpu = [r.cpu() for r in regs]
+    small = [f[:, :, :, :8, :8].contiguous() for f in feats_cpu]      # warm-up: page in code paths
+    with torch.no_grad():
+        O.transformer(sd, layer_params[:1], small, query_embed[:64], metas, pc_range,
+                      reg_branches=regs_cpu[:1], cross='Deform3DCrossAttn', num_points=4)
+        t0 = time.perf_counter()
+        O.transformer(sd, layer_params[:layers_to_time], feats_cpu, query_embed, metas, pc_range,
+                      reg_branches=regs_cpu[:layers_to_time], cross='Deform3DCrossAttn', num_points=4)
+        dt = time.perf_counter() - t0
+    per_layer = dt / layers_to_time
+    full = per_layer * len(layer_params)
+    return dict(value=1.0 / full, unit='samples/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{layers_to_time} of {len(layer_params)} decoder layers of one sample '
+                       f'(same inputs) in {dt:.2f} s, scaled to {len(layer_params)} layers',
+                ms_per_layer=per_layer * 1e3)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    if a.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import graph_detr4d_amd as G
+    from graph_detr4d_amd import _lib, ops, synthetic
+    _lib.load()                                       # fail loudly if the HIP library is missing
+
+    n_cams = 6 * a.frames
+    levels = synthetic.R50_LEVELS if a.levels == 'r50' else synthetic.VOV_LEVELS
+    seed = 1000 + 2 + rank                            # 1000 + config + rank
+    tr, regs = build_decoder(G, n_cams, a.layers, a.value_dtype, seed)
+    feats_cpu = synthetic.feature_pyramid(n_cams, levels, seed=seed)
+    g = torch.Generator().manual_seed(seed + 3)
+    query_embed_cpu = torch.randn(a.queries, 512, generator=g)
+    rig = synthetic.camera_rig(a.frames)
+    metas = synthetic.make_img_metas(rig, batch=1)
+
+    tr, regs = tr.to(dev), regs.to(dev)
+    feats = [f.to(dev) for f in feats_cpu]            # inputs resident in HBM before timing
+    query_embed = query_embed_cpu.to(dev)
+
+    def step():
+        return tr(feats, query_embed, reg_branches=regs, img_metas=metas)
+
+    launch = 'eager'
+    run = step
+    with torch.no_grad():
+        out = step()
+        torch.cuda.synchronize()
+        if not a.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                with torch.cuda.graph(graph):
+                    static_out = step()
+                run = graph.replay
+                launch = 'hipgraph'
+                graph.replay()
+                torch.cuda.synchronize()
+                torch.testing.assert_close(static_out[0], out[0], rtol=1e-5, atol=1e-5)
+            except Exception as e:                    # report, never hide
+                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly',
+                      file=sys.stderr)
+                run, launch = step, 'eager'
+
+        def sync():
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(a.warmup):
+            run()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        sync()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
+    roofline, kernels = None, {}
+    if rank == 0:
+        roofline, kernels = fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        n_layers = a.cpu_layers or (1 if n_cams > 6 else 2)
+        cpu = cpu_baseline(tr, regs, feats_cpu, query_embed_cpu, metas, synthetic.PC_RANGE,
+                           min(n_layers, a.layers))
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        line = {
+            'metric': f'decoder_samples_per_sec_{a.queries}q_T{a.frames}',
+            'value': a.gpus * a.steps / elapsed, 'unit': 'samples/s', 'n_gpus': a.gpus,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if a.value_dtype == 'fp32' else 'bf16-storage/f32-accumulate',
+            'data': 'synthetic',
+            'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
+                                   f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
+                                   f'{"x".join(str(h) + "*" + str(w) for h, w in levels)}, 256 ch, '
+                                   f'batch 1 per GPU, pyramid resident in HBM',
+                       'baseline_config': 'configs[2]', 'launch': launch,
+                       'parallelism': f'replicas x{a.gpus}' if a.gpus > 1 else 'single GPU'},
+            'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic):
+    """Re-run the decoder once, intercepting the fused kernel's inputs per layer; then time each
+    layer's launch with HIP events on the launch stream (torch's current stream IS the stream the
+    C ABI launches on) and count V from the kernel's own mask."""
+    from graph_detr4d_amd import functional as Fn
+    captured = []
+    orig = Fn.sample_aggregate
+
+    def spy(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w):
+        captured.append(dict(value=value, shapes=shapes, ref=ref.contiguous(), offsets=offsets.contiguous(),
+                             attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img,
+                             pc_range=pc_range, img_h=img_h, img_w=img_w))
+        return orig(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w)
+    Fn.sample_aggregate = spy
+    try:
+        with torch.no_grad():
+            tr(feats, query_embed, reg_branches=regs, img_metas=metas)
+    finally:
+        Fn.sample_aggregate = orig
+    torch.cuda.synchronize()
+    iters = 20
+    tot_bytes, tot_ms, launches = 0.0, 0.0, 0
+    per_layer = []
+    for c in captured:
+        call = lambda **kw: ops.cross_attn_fwd(c['value'], c['shapes'], c['ref'], c['offsets'], c['attn'],  # noqa: E731
+                                               c['cam'], c['l2i'], c['pc_range'], c['img_h'], c['img_w'], **kw)
+        out, mask = call(want_mask=True)
+        b, n, q, hh, p = mask.shape
+        nl = len(c['shapes'])
+        dh = c['value'].shape[-1]
+        es = c['value'].element_size()
+        v = int(mask.sum().item()) * nl                      # visible (cam, query, head, level, point) tuples
+        side = q * (3 + hh * p * 3 + hh * nl * p + n) * 4 + n * 64 + q * hh * dh * 4
+        alg = min(v * 4 * dh * es, c['value'].numel() * es) + side
+        for _ in range(3):
+            call(out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call(out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg,
+                              us=ms * 1e3, gbs=alg / ms / 1e6))
+        tot_bytes += alg
+        tot_ms += ms
+        launches += 1
+    achieved = tot_bytes / tot_ms / 1e6                      # GB/s, mean over the decoder's launches
+    roofline = dict(kernel='gd4d cross_attn_fwd_wave (fused project+sample+aggregate)', bound='hbm',
+                    achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                    traffic=None, alg_bytes_per_launch=tot_bytes / launches,
+                    us_per_launch=tot_ms / launches * 1e3, launches_per_step=launches)
+    return roofline, {'cross_attn_fwd_per_layer': per_layer}
+
+
+if __name__ == '__main__':
+    main()

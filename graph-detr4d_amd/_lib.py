@@ -25,6 +25,8 @@ SIGNATURES = {
                                  _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_detr3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                              _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_value_proj_workspace_bytes': (_c.c_size_t, []),
 }
 
 _lib = None

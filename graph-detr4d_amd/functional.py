@@ -61,17 +61,16 @@ def linear(x, weight, bias=None):
 
 
 def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
-    """value_proj over the flattened multi-camera pyramid (deform3d_cross_attn.py:264-280).
+    """value_proj over the flattened multi-camera pyramid (deform3d_cross_attn.py:264-280), one HIP
+    pass (ops.value_proj_fwd): NCHW in, channels-last head-major out, no transposed/concatenated copies.
 
     value: list of L tensors (B, N, C, H_l, W_l).  Returns ((B*N, S, Hh, Dh) tensor, [(H_l, W_l)]).
     """
     shapes = [tuple(v.shape[-2:]) for v in value]
     b, n, c = value[0].shape[:3]
-    flat = torch.cat([v.reshape(b * n, c, -1) for v in value], dim=2)      # (B*N, C, S)
-    out = torch.matmul(flat.transpose(1, 2), weight.t())                   # (B*N, S, C)
-    if bias is not None:
-        out = out + bias
-    return out.view(b * n, -1, num_heads, c // num_heads).to(out_dtype).contiguous(), shapes
+    out = ops.value_proj_fwd([v.contiguous() for v in value], weight.contiguous(),
+                             None if bias is None else bias.contiguous(), out_dtype)
+    return out.view(b * n, -1, num_heads, c // num_heads), shapes
 
 
 def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,

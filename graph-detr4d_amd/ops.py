@@ -97,3 +97,23 @@ def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_
         _dev(sampled, 'sampled') if want_sampled else None, b, n, q, c, nl, 1, _stream())
     _lib.check(code, 'gd4d_detr3d_fwd')
     return dict(out=out, mask=mask, sampled=sampled)
+
+
+def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None):
+    """gd4d_value_proj_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) or (R, C, H_l, W_l) fp32;
+    weight (C, C); bias (C) or None.  Returns (R, S, C) in `out_dtype`."""
+    lib = _lib.load()
+    f32 = torch.float32
+    c = weight.shape[0]
+    r = feats[0].numel() // (c * feats[0].shape[-1] * feats[0].shape[-2])
+    nl = len(feats)
+    s = sum(f.shape[-1] * f.shape[-2] for f in feats)
+    if out is None:
+        out = torch.empty(r, s, c, device=weight.device, dtype=out_dtype)
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    code = lib.gd4d_value_proj_fwd(ptrs, lv, _dev(weight, 'weight', f32),
+                                   _dev(bias, 'bias', f32) if bias is not None else None,
+                                   _dev(out, 'out'), r, c, nl, _lib.F32, _value_dtype(out), _stream())
+    _lib.check(code, 'gd4d_value_proj_fwd')
+    return out

@@ -111,6 +111,29 @@ int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const flo
                     float img_h, float img_w, float* out, uint8_t* mask_out, float* sampled_out,
                     int B, int N, int Q, int C, int L, int P, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * gd4d_value_proj_fwd - value_proj (Linear C -> C) over the flattened multi-camera pyramid.
+ *
+ * Replaces, in Deform3DCrossAttn.forward (deform3d_cross_attn.py):
+ *   :264-269  per-level .flatten(2).transpose(1,2) (a transposed copy) and torch.cat over levels
+ *   :278-280  self.value_proj(value_flatten) and the view to (B*N, S, Hh, Dh)
+ * by ONE pass that reads the NCHW maps as the caller holds them and writes the channels-last,
+ * head-major value tensor gd4d_cross_attn_fwd consumes.
+ *
+ *   feats     host array of L device pointers; level l = (R, C, H_l, W_l) fp32 NCHW, R = B*N
+ *   level_hw  host, L x 2 int32
+ *   weight    (C, C) fp32 row-major [out][in]   (value_proj.weight);  bias (C) fp32 or NULL
+ *   out       (R, S, C) `out_dtype` (GD4D_F32 | GD4D_BF16), S = sum_l H_l*W_l; C = Hh*Dh so the
+ *             buffer is also (R, S, Hh, Dh)
+ * Arithmetic: split-bf16 x3 MFMA with fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi):
+ * fp32-class accuracy (<= ~2^-17 relative per product), see DESIGN.md.
+ * Supported: C == 256, in_dtype == GD4D_F32, L <= 8.  No workspace.
+ */
+int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
+                        const float* bias, void* out, int R, int C, int L, int in_dtype,
+                        int out_dtype, void* stream);
+size_t gd4d_value_proj_workspace_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

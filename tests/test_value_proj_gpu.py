@@ -1,0 +1,65 @@
+"""gd4d_value_proj_fwd (split-bf16 x3 MFMA, NCHW -> channels-last) against an fp64 reference GEMM
+and against the fp32 torch Linear the reference runs.  GPU only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(feats, w, b):
+    flat = torch.cat([f.reshape(-1, f.shape[-3], f.shape[-2] * f.shape[-1]) for f in feats], 2)
+    return torch.matmul(flat.transpose(1, 2).double(), w.double().t()) + b.double()
+
+
+@pytest.mark.parametrize('levels', [[(16, 28), (8, 14), (4, 7), (2, 4)],     # ragged tails at every level
+                                    [(5, 13)], [(1, 1), (1, 3)], [(8, 8), (8, 8), (3, 3)]])
+@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
+def test_value_proj_matches_fp64(levels, out_dtype):
+    from graph_detr4d_amd import ops
+    torch.manual_seed(3)
+    r = 5
+    feats = [torch.randn(r, 256, h, w) for h, w in levels]
+    w = torch.randn(256, 256) * 0.06
+    w[3, 7] = 1.0                      # asymmetric landmarks: catches transposed operands / outputs
+    w[200, 1] = -2.0
+    b = torch.randn(256)
+    got = ops.value_proj_fwd([f.cuda() for f in feats], w.cuda(), b.cuda(), out_dtype).float().cpu()
+    ref = _ref(feats, w, b)
+    if out_dtype == torch.float32:
+        # fp32-class: split-bf16 x3 keeps ~2^-17 relative per product
+        assert (got.double() - ref).abs().max().item() < 5e-5
+        f32 = torch.nn.functional.linear(torch.cat([f.reshape(r, 256, -1) for f in feats], 2).transpose(1, 2), w, b)
+        assert (got - f32).abs().max().item() < 5e-5
+    else:
+        torch.testing.assert_close(got.double(), ref, rtol=1e-2, atol=1e-2)
+        assert (got.double() - ref.float().bfloat16().double()).abs().max().item() < 0.04
+
+
+def test_value_proj_identity_weight_is_a_transpose():
+    """W = I, bias = 0 -> out[r, pix, c] == in[r, c, pix] to split precision; layout check."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(4)
+    f = torch.randn(3, 256, 9, 11)
+    got = ops.value_proj_fwd([f.cuda()], torch.eye(256).cuda(), None).cpu()
+    want = f.reshape(3, 256, 99).transpose(1, 2)
+    # x = hi + lo keeps 16 significant bits: |err| <= 2^-16 |x|
+    assert ((got - want).abs() <= want.abs() * 2.0 ** -16 + 1e-7).all()
+    assert got.shape == (3, 99, 256)
+
+
+def test_value_proj_full_size_properties():
+    """BASELINE size (24 cameras, 116x200..15x25): linearity in the input and agreement with an
+    fp32 GEMM on a random subset of pixels."""
+    from graph_detr4d_amd import ops, synthetic
+    torch.manual_seed(6)
+    dev = 'cuda'
+    feats = [torch.randn(24, 256, h, w, device=dev) for h, w in synthetic.R50_LEVELS]
+    w = (torch.randn(256, 256, device=dev) * 0.06)
+    b = torch.randn(256, device=dev)
+    o1 = ops.value_proj_fwd(feats, w, b)
+    o2 = ops.value_proj_fwd([2.0 * f for f in feats], w, None)
+    torch.testing.assert_close(o2 + b, 2.0 * (o1 - b) + b, rtol=1e-4, atol=1e-4)
+    idx = torch.randint(0, o1.shape[1], (500,), device=dev)
+    flat = torch.cat([f.reshape(24, 256, -1) for f in feats], 2)[:, :, idx]      # (24, 256, 500)
+    ref = torch.matmul(flat.transpose(1, 2).double(), w.double().t()) + b.double()
+    assert (o1[:, idx].double() - ref).abs().max().item() < 5e-5
