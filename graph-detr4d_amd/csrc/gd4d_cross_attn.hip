@@ -16,6 +16,8 @@
 // computes u, v and the visibility bit with the reference's exact fp32 operation order
 // (no FMA contraction, IEEE division) and parks (u, v) in LDS; phase B re-reads the four points of
 // the lane's head per camera (LDS broadcast within the head's lane group).
+#include <stdlib.h>
+
 #include "gd4d_common.h"
 
 namespace gd4d {
@@ -192,16 +194,186 @@ __global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttn
   *reinterpret_cast<float4*>(p.out + (size_t)bq * kChannels + lane * 4) = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2: one WORKGROUP of WAVES wavefronts per (batch, query).  Same lane -> (head, channel quad)
+// mapping as above inside each wave; the query's VISIBLE cameras are compacted (ballot) and dealt
+// round-robin to the waves, so a query seen by many cameras no longer serialises its gathers in
+// one wave (the v1 kernel is latency-bound: ~17 dependent load batches per wave).  Inside a camera
+// the code is branch-free - an invisible point of a visible camera (~5 %) gets weight 0 and reads
+// the map centre - so all 4 points x L levels x 4 corners loads can be issued back to back.
+// Partial sums are combined through LDS in fixed wave order (deterministic).
+template <typename VT, int HH, int LT, int WAVES>
+__global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_fwd_block(const CrossAttnParams p) {
+  constexpr int DH = kChannels / HH;
+  constexpr int LANES_PER_HEAD = DH / 4;
+  constexpr int E = HH * kPoints;
+  constexpr int LMAX = LT > 0 ? LT : GD4D_MAX_LEVELS;
+  constexpr int THREADS = GD4D_WAVE * WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float4* s_red = reinterpret_cast<float4*>(smem_raw);                       // [WAVES-1][64]
+  float2* s_uv = reinterpret_cast<float2*>(smem_raw + (WAVES - 1) * GD4D_WAVE * sizeof(float4));  // [N][E]
+  int* s_camvis = reinterpret_cast<int*>(s_uv + p.N * E);                    // [N]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bq = blockIdx.x;
+  const int b = bq / p.Q;
+  const int q = bq - b * p.Q;
+  const int L = LT > 0 ? LT : p.L;
+
+  // ---------------- phase A: projection, spread over the whole workgroup ----------------
+  {
+    const float* rp = p.ref + (size_t)bq * 3;
+    const float px = rp[0] * p.rng_scale[0] + p.rng_lo[0];
+    const float py = rp[1] * p.rng_scale[1] + p.rng_lo[1];
+    const float pz = rp[2] * p.rng_scale[2] + p.rng_lo[2];
+    const float* offs = p.offsets + (size_t)bq * E * 3;
+    const int total = p.N * E;
+    for (int e0 = wave * GD4D_WAVE; e0 < total; e0 += THREADS) {
+      const int e = e0 + lane;
+      bool vis = false;
+      if (e < total) {
+        const int n = e / E;
+        const int hp = e - n * E;
+        const float X = px + offs[hp * 3 + 0];
+        const float Y = py + offs[hp * 3 + 1];
+        const float Z = pz + offs[hp * 3 + 2];
+        const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
+        float u, v;
+        vis = project_entry(p, m, X, Y, Z, u, v);
+        s_uv[e] = vis ? make_float2(u, v) : make_float2(-1.f, -1.f);
+        const size_t o = (((size_t)b * p.N + n) * p.Q + q) * E + hp;
+        if (p.mask_out) p.mask_out[o] = vis ? 1 : 0;
+        if (p.uv_out) { p.uv_out[o * 2] = u; p.uv_out[o * 2 + 1] = v; }
+      }
+      // per-camera "any point of any head visible": E consecutive entries belong to one camera
+      const unsigned long long bal = __ballot(vis);
+      static_assert(E <= GD4D_WAVE && GD4D_WAVE % E == 0, "E = 4*heads must divide 64");
+      constexpr int CPW = GD4D_WAVE / E;          // whole cameras covered by one wave iteration
+      if (lane < CPW) {
+        const int n = e0 / E + lane;
+        const unsigned long long ones = E == 64 ? ~0ull : ((1ull << (E & 63)) - 1ull);
+        if (n < p.N) s_camvis[n] = (bal & (ones << (lane * (E & 63)))) ? 1 : 0;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase B ----------------
+  const int h = lane / LANES_PER_HEAD;
+  float aw[LMAX * kPoints];
+  if (p.B == 1) softmax_lp(p.attn_logits + ((size_t)bq * HH + h) * L * kPoints, L * kPoints, aw);
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned long long cams = __ballot(lane < p.N && s_camvis[lane < p.N ? lane : 0] != 0);
+  int idx = 0;
+  while (cams) {
+    const int n = __builtin_ctzll(cams);
+    cams &= cams - 1;
+    if ((idx++ % WAVES) != wave) continue;                   // round-robin deal of visible cameras
+
+    const float2* su = s_uv + n * E + h * kPoints;
+    float2 pu[kPoints];
+#pragma unroll
+    for (int k = 0; k < kPoints; ++k) pu[k] = su[k];
+    const int row = b * p.N + n;
+    if (p.B > 1) {
+      const int bb = row % p.B;
+      softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * kPoints, L * kPoints, aw);
+    }
+    const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];
+    const float cw = 1.0f / (1.0f + expf(-cl));
+    const VT* vrow = static_cast<const VT*>(p.value) + (size_t)row * p.S * kChannels;   // wave-uniform
+    const unsigned lane_off = lane * 4;
+
+#pragma unroll
+    for (int k = 0; k < kPoints; ++k) {
+      const bool pv = pu[k].x >= 0.f;
+      const float u = pv ? pu[k].x : 0.5f, v = pv ? pu[k].y : 0.5f;
+      const float cwk = pv ? cw : 0.f;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        if (LT == 0 && l >= L) break;
+        const int W = p.lvl_w[l], H = p.lvl_h[l];
+        const float x = fmaf(u, (float)W, -0.5f);
+        const float y = fmaf(v, (float)H, -0.5f);
+        const float xf = floorf(x), yf = floorf(y);
+        const float dx = x - xf, dy = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float wl = aw[l * kPoints + k] * cwk;
+        const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W;
+        const bool y0ok = y0 >= 0, y1ok = y0 + 1 < H;
+        const float w00 = (x0ok && y0ok) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
+        const float w01 = (x1ok && y0ok) ? wl * dx * (1.f - dy) : 0.f;
+        const float w10 = (x0ok && y1ok) ? wl * (1.f - dx) * dy : 0.f;
+        const float w11 = (x1ok && y1ok) ? wl * dx * dy : 0.f;
+        const int xa = x0ok ? x0 : 0, xb = x1ok ? x0 + 1 : W - 1;
+        const int ya = y0ok ? y0 : 0, yb = y1ok ? y0 + 1 : H - 1;
+        const unsigned r0 = (unsigned)(p.lvl_start[l] + ya * W), r1 = (unsigned)(p.lvl_start[l] + yb * W);
+        const float4 v00 = Quad<VT>::load(vrow + ((r0 + xa) * (unsigned)kChannels + lane_off));
+        const float4 v01 = Quad<VT>::load(vrow + ((r0 + xb) * (unsigned)kChannels + lane_off));
+        const float4 v10 = Quad<VT>::load(vrow + ((r1 + xa) * (unsigned)kChannels + lane_off));
+        const float4 v11 = Quad<VT>::load(vrow + ((r1 + xb) * (unsigned)kChannels + lane_off));
+        acc.x = fmaf(w00, v00.x, acc.x); acc.y = fmaf(w00, v00.y, acc.y);
+        acc.z = fmaf(w00, v00.z, acc.z); acc.w = fmaf(w00, v00.w, acc.w);
+        acc.x = fmaf(w01, v01.x, acc.x); acc.y = fmaf(w01, v01.y, acc.y);
+        acc.z = fmaf(w01, v01.z, acc.z); acc.w = fmaf(w01, v01.w, acc.w);
+        acc.x = fmaf(w10, v10.x, acc.x); acc.y = fmaf(w10, v10.y, acc.y);
+        acc.z = fmaf(w10, v10.z, acc.z); acc.w = fmaf(w10, v10.w, acc.w);
+        acc.x = fmaf(w11, v11.x, acc.x); acc.y = fmaf(w11, v11.y, acc.y);
+        acc.z = fmaf(w11, v11.z, acc.z); acc.w = fmaf(w11, v11.w, acc.w);
+      }
+    }
+  }
+
+  // ---------------- deterministic cross-wave reduction ----------------
+  if (WAVES > 1) {
+    if (wave > 0) s_red[(wave - 1) * GD4D_WAVE + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) {
+        const float4 o = s_red[(w - 1) * GD4D_WAVE + lane];
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      }
+    }
+  }
+  if (wave == 0) *reinterpret_cast<float4*>(p.out + (size_t)bq * kChannels + lane * 4) = acc;
+}
+
+static int cross_attn_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GD4D_CROSS_ATTN_VARIANT");     // dev A/B switch: 1 = wave per query, 2 = workgroup per query
+    v = e ? atoi(e) : 2;
+    if (v != 1) v = 2;
+  }
+  return v;
+}
+
+template <typename VT, int HH, int LT>
+static void launch_one(const CrossAttnParams& p, hipStream_t s) {
+  const dim3 grid(p.B * p.Q);
+  if (cross_attn_variant() == 1) {
+    const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
+    hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, LT>), grid, dim3(GD4D_WAVE), lds, s, p);
+  } else {
+    constexpr int WAVES = 4;
+    const size_t lds = (WAVES - 1) * GD4D_WAVE * sizeof(float4) + (size_t)p.N * HH * kPoints * sizeof(float2) +
+                       (size_t)p.N * sizeof(int);
+    hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
+  }
+}
+
 template <typename VT, int HH>
 static int launch_levels(const CrossAttnParams& p, hipStream_t s) {
-  const dim3 grid(p.B * p.Q), block(GD4D_WAVE);
-  const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
   switch (p.L) {
-    case 1: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 1>), grid, block, lds, s, p); break;
-    case 2: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 2>), grid, block, lds, s, p); break;
-    case 3: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 3>), grid, block, lds, s, p); break;
-    case 4: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 4>), grid, block, lds, s, p); break;
-    default: hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, 0>), grid, block, lds, s, p); break;
+    case 1: launch_one<VT, HH, 1>(p, s); break;
+    case 2: launch_one<VT, HH, 2>(p, s); break;
+    case 3: launch_one<VT, HH, 3>(p, s); break;
+    case 4: launch_one<VT, HH, 4>(p, s); break;
+    default: launch_one<VT, HH, 0>(p, s); break;
   }
   return check_launch();
 }
