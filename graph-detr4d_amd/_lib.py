@@ -27,6 +27,7 @@ SIGNATURES = {
                              _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_workspace_bytes': (_c.c_size_t, []),
+    'gd4d_value_proj_multi_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -29,6 +29,8 @@
 //     (128 B per pixel row, one full L2 line) straight from the accumulators;
 //   * next tile's global loads are issued before the MFMA phase (register prefetch) and LDS is
 //     double buffered, so HBM reads overlap the matrix work.
+#include <stdlib.h>
+
 #include "gd4d_common.h"
 
 namespace gd4d {
@@ -47,10 +49,10 @@ struct ValueProjParams {
   int start[GD4D_MAX_LEVELS];        // pixel offset of level l inside a row of `out`
   int tiles[GD4D_MAX_LEVELS];        // tiles per camera-row at level l
   int tile_base[GD4D_MAX_LEVELS + 1];  // prefix over levels of R * tiles[l]
-  const float* weight;               // (C, C) row-major [co][ci]
-  const float* bias;                 // (C) or null
-  void* out;                         // (R, S, C)
-  int R, L, S;
+  const float* weight[GD4D_MAX_LAYERS];   // per decoder layer: (C, C) row-major [co][ci]
+  const float* bias[GD4D_MAX_LAYERS];     // (C) or null
+  void* out[GD4D_MAX_LAYERS];             // (R, S, C)
+  int R, L, S, NL;
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo_elem, float hi_elem) {
@@ -101,10 +103,19 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValuePr
   const int col = lane & 31;           // MFMA column (output channel within the wave's block) / A row
   const int kg = lane >> 5;            // which 8 of the 16 k of a step this lane holds
 
+  // Workgroup -> (layer, slot).  Consecutive workgroups serve different layers of the SAME tile
+  // sequence, so the NL layer groups sweep the pyramid in step and all but the first reader of a
+  // tile are served from L2 / Infinity Cache instead of HBM.
+  const int layer = blockIdx.x % p.NL;
+  const int slot = blockIdx.x / p.NL;
+  const int slots = gridDim.x / p.NL;
+  const float* __restrict__ weight = p.weight[layer];
+  void* __restrict__ outp = p.out[layer];
+
   // ---- W fragments for this wave: co = 32*wave + col, k = 16*s + 8*kg .. +8 ----
   bf16x8 whi[VP_KSTEPS], wlo[VP_KSTEPS];
   {
-    const float* wrow = p.weight + (size_t)(32 * wave + col) * VP_C + 8 * kg;
+    const float* wrow = weight + (size_t)(32 * wave + col) * VP_C + 8 * kg;
 #pragma unroll
     for (int s = 0; s < VP_KSTEPS; ++s) {
       const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * s);
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValuePr
       wlo[s] = as_bf16x8(l);
     }
   }
-  const float bias = p.bias ? p.bias[32 * wave + col] : 0.f;
+  const float bias = p.bias[layer] ? p.bias[layer][32 * wave + col] : 0.f;
 
   // staging role of this thread: pixel column `spix` of the tile, channels [sc0, sc0 + CPT)
   const int spix = tid % BM;
@@ -160,15 +171,15 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValuePr
     }
   };
 
-  int t = blockIdx.x;
+  int t = slot;
   if (t >= total) return;
   issue_loads(t);
   park(0);
   __syncthreads();
 
   int buf = 0;
-  for (; t < total; t += gridDim.x) {
-    const int tn = t + gridDim.x;
+  for (; t < total; t += slots) {
+    const int tn = t + slots;
     const bool has_next = tn < total;
     if (has_next) issue_loads(tn);            // register prefetch: in flight during the MFMA phase
 
@@ -199,17 +210,18 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValuePr
     // ---- epilogue: C/D layout col = lane&31 (co), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pix) ----
     {
       const int hw = p.hw[lvl];
-      const size_t obase = ((size_t)row * p.S + p.start[lvl]) * VP_C + 32 * wave + col;
+      const size_t obase = ((size_t)row * p.S + p.start[lvl] + pix0 + 4 * kg) * VP_C + 32 * wave + col;
+      const bool full = pix0 + BM <= hw;                     // workgroup-uniform
 #pragma unroll
       for (int m = 0; m < SUB; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int pix = pix0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kg;
-          if (pix < hw) {
+          const int dp = 32 * m + (r & 3) + 8 * (r >> 2);    // pixel offset inside the tile (minus 4*kg)
+          if (full || pix0 + dp + 4 * kg < hw) {
             if (OUT_BF16)
-              static_cast<uint16_t*>(p.out)[obase + (size_t)pix * VP_C] = f32_to_bf16(acc[m][r]);
+              static_cast<uint16_t*>(outp)[obase + (size_t)dp * VP_C] = f32_to_bf16(acc[m][r]);
             else
-              static_cast<float*>(p.out)[obase + (size_t)pix * VP_C] = acc[m][r];
+              static_cast<float*>(outp)[obase + (size_t)dp * VP_C] = acc[m][r];
           }
         }
       }
@@ -225,51 +237,90 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValuePr
 
 extern "C" size_t gd4d_value_proj_workspace_bytes(void) { return 0; }
 
-extern "C" int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
-                                   const float* bias, void* out, int R, int C, int L, int in_dtype,
-                                   int out_dtype, void* stream) {
-  using namespace gd4d;
-  if (!feats || !level_hw || !weight || !out) return GD4D_EINVAL;
-  if (R <= 0 || C <= 0 || L <= 0) return GD4D_EINVAL;
-  if (C != VP_C || L > GD4D_MAX_LEVELS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
-  if (out_dtype != GD4D_F32 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
-  if (!aligned16(weight)) return GD4D_EALIGN;
-  constexpr int BM = 64;
-  ValueProjParams p{};
+namespace gd4d {
+
+static int vp_tile_pixels() {
+  static int bm = 0;
+  if (!bm) {
+    const char* e = getenv("GD4D_VP_BM");            // dev A/B switch
+    bm = (e && atoi(e) == 64) ? 64 : 32;
+  }
+  return bm;
+}
+
+template <int BM>
+static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, int NL, int out_dtype,
+                     hipStream_t st) {
   int s = 0, base = 0;
   for (int l = 0; l < L; ++l) {
-    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
-    if (!feats[l] || h <= 0 || w <= 0) return GD4D_EINVAL;
-    p.in[l] = feats[l];
-    p.hw[l] = h * w;
+    const int hw = level_hw[2 * l] * level_hw[2 * l + 1];
+    p.hw[l] = hw;
     p.start[l] = s;
-    p.tiles[l] = (h * w + BM - 1) / BM;
+    p.tiles[l] = (hw + BM - 1) / BM;
     p.tile_base[l] = base;
-    s += h * w;
+    s += hw;
     base += R * p.tiles[l];
   }
-  p.tile_base[L] = base;
-  for (int l = L + 1; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
-  p.weight = weight; p.bias = bias; p.out = out;
-  p.R = R; p.L = L; p.S = s;
+  for (int l = L; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
+  p.S = s;
   int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus <= 0) cus = 256;
-  }
-  const int grid = base < cus ? base : cus;            // persistent: one workgroup per CU
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  int slots = cus / NL;                                // persistent: <= one workgroup per CU
+  if (slots < 1) slots = 1;
+  if (slots > base) slots = base;
+  const int grid = slots * NL;
   const size_t lds = 2 * 2 * (size_t)BM * VP_C * 2;    // 2 buffers x (hi, lo) x [BM][256] bf16
-  hipStream_t st = static_cast<hipStream_t>(stream);
   if (out_dtype == GD4D_BF16) {
-    static bool attr_b = false;
-    if (!attr_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_kernel<BM, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_b = true; }
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_kernel<BM, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL((value_proj_kernel<BM, true>), dim3(grid), dim3(VP_THREADS), lds, st, p);
   } else {
-    static bool attr_f = false;
-    if (!attr_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_kernel<BM, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_f = true; }
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_kernel<BM, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL((value_proj_kernel<BM, false>), dim3(grid), dim3(VP_THREADS), lds, st, p);
   }
   return check_launch();
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
+                                         const float* const* weights, const float* const* biases,
+                                         void* const* outs, int R, int C, int L, int NL, int in_dtype,
+                                         int out_dtype, void* stream) {
+  using namespace gd4d;
+  if (!feats || !level_hw || !weights || !outs) return GD4D_EINVAL;
+  if (R <= 0 || C <= 0 || L <= 0 || NL <= 0) return GD4D_EINVAL;
+  if (C != VP_C || L > GD4D_MAX_LEVELS || NL > GD4D_MAX_LAYERS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+  if (out_dtype != GD4D_F32 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
+  ValueProjParams p{};
+  for (int l = 0; l < L; ++l) {
+    if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
+    p.in[l] = feats[l];
+  }
+  for (int i = 0; i < NL; ++i) {
+    if (!weights[i] || !outs[i]) return GD4D_EINVAL;
+    if (!aligned16(weights[i])) return GD4D_EALIGN;
+    p.weight[i] = weights[i];
+    p.bias[i] = biases ? biases[i] : nullptr;
+    p.out[i] = outs[i];
+  }
+  p.R = R; p.L = L; p.NL = NL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return vp_tile_pixels() == 64 ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
+                                : vp_launch<32>(p, level_hw, R, L, NL, out_dtype, st);
+}
+
+extern "C" int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
+                                   const float* bias, void* out, int R, int C, int L, int in_dtype,
+                                   int out_dtype, void* stream) {
+  if (!weight || !out) return GD4D_EINVAL;
+  const float* ws[1] = {weight};
+  const float* bs[1] = {bias};
+  void* os[1] = {out};
+  return gd4d_value_proj_multi_fwd(feats, level_hw, ws, bs, os, R, C, L, 1, in_dtype, out_dtype, stream);
 }

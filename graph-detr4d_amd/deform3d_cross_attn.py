@@ -115,8 +115,12 @@ class Deform3DCrossAttn(nn.Module):
         offsets = qside[..., n:n + hh * npt * 3].reshape(b, q, hh, npt, 3)
         attn_logits = qside[..., n + hh * npt * 3:].reshape(b, q, hh, nl, npt)
 
-        val, shapes = Fn.value_projection(value, self.value_proj.weight, self.value_proj.bias, hh,
-                                          self.value_dtype)
+        cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
+        if cached is not None and cached[2] is value:
+            val, shapes = cached[0], cached[1]       # projected by the decoder for all layers at once
+        else:
+            val, shapes = Fn.value_projection(value, self.value_proj.weight, self.value_proj.bias,
+                                              hh, self.value_dtype)
         lidar2img = Fn.lidar2img_device(img_metas, x)
         img_h, img_w = Fn.img_hw(img_metas)
         agg = Fn.sample_aggregate(val, shapes, reference_points, offsets, attn_logits, cam_logits,

@@ -102,9 +102,24 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         super().__init__(*args, **kwargs)
         self.return_intermediate = return_intermediate
 
+    def _preproject_values(self, kwargs):
+        """All layers get the same `value` pyramid: run every Deform3DCrossAttn.value_proj over it in
+        ONE launch (pyramid read from HBM once, not once per layer) and hand each layer its tensor."""
+        value = kwargs.get('value')
+        if not isinstance(value, (list, tuple)) or len(value) == 0 or not value[0].is_cuda:
+            return kwargs
+        mods = [a for layer in self.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
+        if len(mods) < 2 or len(mods) > 8 or len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) != 1:
+            return kwargs
+        Fn.require_inference(*value)
+        kwargs = dict(kwargs)
+        kwargs[Fn.VALUE_CACHE_KEY] = Fn.project_values_for_layers(mods, value)
+        return kwargs
+
     def forward(self, query, *args, reference_points=None, reg_branches=None, **kwargs):
         output = query
         intermediate, intermediate_reference_points = [], []
+        kwargs = self._preproject_values(kwargs)
         for lid, layer in enumerate(self.layers):
             output = layer(output, *args, reference_points=reference_points, **kwargs)
             if reg_branches is not None:

@@ -73,6 +73,27 @@ def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
     return out.view(b * n, -1, num_heads, c // num_heads), shapes
 
 
+VALUE_CACHE_KEY = '_gd4d_value_cache'
+
+
+def project_values_for_layers(modules, value):
+    """Project the SAME pyramid with every layer's value_proj in one launch
+    (ops.value_proj_multi_fwd).  Every decoder layer receives the same `value` list
+    (detr3d_transformer.py:192-198), so the pyramid is read once instead of once per layer.
+
+    modules: the Deform3DCrossAttn instances (one per decoder layer).  Returns the dict handed to
+    them through kwargs[VALUE_CACHE_KEY]: {id(module): (value tensor, shapes, source list)}.
+    """
+    shapes = [tuple(v.shape[-2:]) for v in value]
+    b, n, c = value[0].shape[:3]
+    hh = modules[0].num_heads
+    outs = ops.value_proj_multi_fwd([v.contiguous() for v in value],
+                                    [m.value_proj.weight.contiguous() for m in modules],
+                                    [m.value_proj.bias.contiguous() for m in modules],
+                                    modules[0].value_dtype)
+    return {id(m): (o.view(b * n, -1, hh, c // hh), shapes, value) for m, o in zip(modules, outs)}
+
+
 def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
                      img_h, img_w):
     """The fused HIP kernel (ops.cross_attn_fwd): projection + mask + softmax + gather + camera sum."""

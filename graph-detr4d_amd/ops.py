@@ -117,3 +117,26 @@ def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None):
                                    _dev(out, 'out'), r, c, nl, _lib.F32, _value_dtype(out), _stream())
     _lib.check(code, 'gd4d_value_proj_fwd')
     return out
+
+
+def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32):
+    """gd4d_value_proj_multi_fwd: project the same pyramid with NL (weight, bias) pairs in one
+    launch.  Returns a list of NL tensors (R, S, C)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    nlayers = len(weights)
+    c = weights[0].shape[0]
+    r = feats[0].numel() // (c * feats[0].shape[-1] * feats[0].shape[-2])
+    nl = len(feats)
+    s = sum(f.shape[-1] * f.shape[-2] for f in feats)
+    outs = [torch.empty(r, s, c, device=weights[0].device, dtype=out_dtype) for _ in range(nlayers)]
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    wp = (ctypes.c_void_p * nlayers)(*[_dev(w, 'weight', f32).value for w in weights])
+    bp = (ctypes.c_void_p * nlayers)(*[(_dev(b, 'bias', f32).value if b is not None else None)
+                                       for b in biases])
+    op = (ctypes.c_void_p * nlayers)(*[_dev(o, 'out').value for o in outs])
+    code = lib.gd4d_value_proj_multi_fwd(ptrs, lv, wp, bp, op, r, c, nl, nlayers, _lib.F32,
+                                         _value_dtype(outs[0]), _stream())
+    _lib.check(code, 'gd4d_value_proj_multi_fwd')
+    return outs

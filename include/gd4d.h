@@ -43,6 +43,7 @@ enum {
 };
 
 #define GD4D_MAX_LEVELS 8
+#define GD4D_MAX_LAYERS 8
 
 int gd4d_abi_version(void);
 const char* gd4d_error_string(int code);
@@ -133,6 +134,17 @@ int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const
                         const float* bias, void* out, int R, int C, int L, int in_dtype,
                         int out_dtype, void* stream);
 size_t gd4d_value_proj_workspace_bytes(void);
+
+/* gd4d_value_proj_multi_fwd - the same projection for NL decoder layers in ONE launch.
+ * Every decoder layer receives the same `value` list (Detr3DTransformerDecoder.forward passes
+ * `*args` unchanged to each layer, detr3d_transformer.py:192-198), so the NL value_proj GEMMs share
+ * their input: the layer groups sweep the pyramid together and it is read from HBM once instead of
+ * NL times.  weights / biases / outs: host arrays of NL device pointers (biases or its entries may
+ * be NULL).  NL <= GD4D_MAX_LAYERS.  Results are bit-identical to NL gd4d_value_proj_fwd calls. */
+int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
+                              const float* const* weights, const float* const* biases,
+                              void* const* outs, int R, int C, int L, int NL, int in_dtype,
+                              int out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,3 +63,15 @@ def test_value_proj_full_size_properties():
     flat = torch.cat([f.reshape(24, 256, -1) for f in feats], 2)[:, :, idx]      # (24, 256, 500)
     ref = torch.matmul(flat.transpose(1, 2).double(), w.double().t()) + b.double()
     assert (o1[:, idx].double() - ref).abs().max().item() < 5e-5
+
+
+def test_multi_layer_projection_is_bit_identical_to_single_calls():
+    """gd4d_value_proj_multi_fwd (6 layers, one launch) == 6 x gd4d_value_proj_fwd, bit for bit."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(8)
+    feats = [torch.randn(7, 256, h, w).cuda() for h, w in [(20, 36), (10, 18), (5, 9), (3, 5)]]
+    ws = [(torch.randn(256, 256) * 0.06).cuda() for _ in range(6)]
+    bs = [torch.randn(256).cuda() if i % 2 == 0 else None for i in range(6)]
+    multi = ops.value_proj_multi_fwd(feats, ws, bs)
+    for w, b, m in zip(ws, bs, multi):
+        assert torch.equal(m, ops.value_proj_fwd(feats, w, b))
