@@ -1,0 +1,256 @@
+// gd4d_linear_fwd / gd4d_layernorm_fwd: the decoder's query-side dense layers on the fp32 MFMA.
+//
+// The reference runs these as nn.Linear / nn.LayerNorm (ATen addmm + elementwise kernels):
+//   deform3d_cross_attn.py:211,227,281  camera logits / metre offsets / attention logits of (query+pos)
+//   deform3d_cross_attn.py:326,334      output_proj, position_encoder (Linear-LN-ReLU-Linear-LN-ReLU)
+//   nn.MultiheadAttention in_proj / out_proj (config ...ceph.py:74-78), mmcv FFN (:86), LayerNorm x3
+// Sizes are tiny (M = 900 rows, K <= 512, N <= 768): what matters is launch count and fusing the
+// elementwise neighbours, not peak TFLOP/s.  One kernel computes
+//     y[m, n] = act( sum_k (x[m,k] + (n < n_split ? x2[m,k] : 0)) * W[n,k] + b[n] ) + r1[m,n] + r2[m,n]
+// with v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: exact fp32 products, the same numerics
+// class as the reference's fp32 GEMM).
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct LinearParams {
+  const float* x;      // (M, K), row stride ldx
+  const float* x2;     // optional addend on the input rows (query_pos), same layout as x
+  const float* w;      // (N, K) row-major
+  const float* bias;   // (N) or null
+  const float* r1;     // optional residual (M, N), row stride ldr1
+  const float* r2;     // optional second residual, row stride ldr2
+  float* y;            // (M, N), row stride ldy
+  int M, K, N, n_split, flags;      // flags: bit0 ReLU on the output, bit1 inverse_sigmoid on the input
+  int ldx, ldy, ldr1, ldr2;
+};
+
+// inverse_sigmoid of the reference (deform3d_cross_attn.py:16-31), eps = 1e-5
+__device__ __forceinline__ float inv_sigmoid(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float a = fminf(fmaxf(x, 1e-5f), 1.f), b = fminf(fmaxf(1.f - x, 1e-5f), 1.f);
+  return logf(a / b);
+}
+
+constexpr int LN_TM = 32, LN_TN = 32, LN_WAVES = 4, LN_KC = 64;   // k per wave-chunk
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// One workgroup = one 32 x 32 output tile; its 4 waves split K in 64-wide chunks (wave w takes
+// chunks w, w+4, ..) and the partial tiles are summed through LDS once.
+//
+// MFMA operands go straight from global memory into registers with v_mfma_f32_16x16x4_f32:
+// lane (i = l&15, g = l>>4) supplies A[i][k] / B[k][i] for ONE k per instruction, and WHICH k the
+// four lane groups pair up is free as long as A and B agree.  So group g owns k = 16j + 4g + e:
+// it loads one float4 (e = 0..3) per 16-k step j, and the four groups of a row read 64 contiguous
+// bytes - 16 cache lines per load instruction instead of 64 with a row-per-lane layout (the L1 tag
+// rate, not the MFMA, bounds these tiny GEMMs).
+__global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParams p) {
+  __shared__ float s_part[LN_WAVES - 1][16][64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * LN_TM, n0 = blockIdx.y * LN_TN;
+  const bool add2 = p.x2 != nullptr && n0 < p.n_split;     // block-uniform (n_split % 32 == 0)
+  const bool in_isig = (p.flags & 2) != 0;
+  const bool vec = (p.K % 4 == 0) && (p.ldx % 4 == 0);
+
+  // rows of the two 16-row A blocks and the two 16-row W blocks this lane feeds (clamped rows are never stored)
+  const float* xr[2];
+  const float* x2r[2];
+  const float* wr[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int gm = min(m0 + 16 * t + i16, p.M - 1);
+    const int gn = min(n0 + 16 * t + i16, p.N - 1);
+    xr[t] = p.x + (size_t)gm * p.ldx;
+    x2r[t] = add2 ? p.x2 + (size_t)gm * p.ldx : nullptr;
+    wr[t] = p.w + (size_t)gn * p.K;
+  }
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load4 = [&](const float* row, const float* row2, int k, bool is_x) {
+    float v[4];
+    if (vec && k + 4 <= p.K) {
+      const float4 t = *reinterpret_cast<const float4*>(row + k);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      if (row2) {
+        const float4 u = *reinterpret_cast<const float4*>(row2 + k);
+        v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? row[k + e] + (row2 ? row2[k + e] : 0.f) : 0.f;
+    }
+    if (is_x && in_isig) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? inv_sigmoid(v[e]) : 0.f;
+    }
+    return f32x4{v[0], v[1], v[2], v[3]};
+  };
+
+  for (int kc = wave * LN_KC; kc < p.K; kc += LN_KC * LN_WAVES) {
+    f32x4 av[4][2], bv[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // all 16 (+8) loads of the chunk in flight together
+      const int k = kc + 16 * j + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        av[j][t] = load4(xr[t], x2r[t], k, true);
+        bv[j][t] = load4(wr[t], nullptr, k, false);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][a][e], bv[j][c][e], acc[a][c], 0, 0, 0);
+  }
+
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_part[wave - 1][(a * 2 + c) * 4 + r][lane] = acc[a][c][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // C/D of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int n = n0 + 16 * c + i16;
+        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[a][c][r];
+#pragma unroll
+          for (int w = 0; w < LN_WAVES - 1; ++w) v += s_part[w][(a * 2 + c) * 4 + r][lane];
+          const int m = m0 + 16 * a + 4 * g + r;
+          if (m < p.M && n < p.N) {
+            v += bias;
+            if (p.flags & 1) v = fmaxf(v, 0.f);
+            if (p.r1) v += p.r1[(size_t)m * p.ldr1 + n];
+            if (p.r2) v += p.r2[(size_t)m * p.ldr2 + n];
+            p.y[(size_t)m * p.ldy + n] = v;
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension (C <= 1024, C % 4 == 0): one wave per row.
+//   y = LN(x + res) * gamma + beta, optional ReLU.  Statistics like ATen: biased variance, eps
+//   inside the sqrt, two-pass (mean, then centred sum of squares) in fp32.
+struct LayerNormParams {
+  const float* x;
+  const float* res;     // optional, added before normalisation
+  const float* gamma;
+  const float* beta;
+  float* y;
+  int M, C, relu;
+  float eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const float* x = p.x + (size_t)row * p.C;
+  const float* r = p.res ? p.res + (size_t)row * p.C : nullptr;
+  float4 v[4];                                   // up to 1024 channels: 4 float4 per lane
+  const int nv = p.C / 4;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      v[i] = reinterpret_cast<const float4*>(x)[c];
+      if (r) {
+        const float4 t = reinterpret_cast<const float4*>(r)[c];
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.C + p.eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float4 g = reinterpret_cast<const float4*>(p.gamma)[c];
+      const float4 b = reinterpret_cast<const float4*>(p.beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      reinterpret_cast<float4*>(p.y + (size_t)row * p.C)[c] = o;
+    }
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
+                               const float* r1, const float* r2, float* y, int M, int K, int N,
+                               int n_split, int flags, int ldx, int ldy, int ldr1, int ldr2,
+                               void* stream) {
+  using namespace gd4d;
+  if (!x || !w || !y) return GD4D_EINVAL;
+  if (M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return GD4D_EINVAL;
+  if (r1 && ldr1 < N) return GD4D_EINVAL;
+  if (r2 && ldr2 < N) return GD4D_EINVAL;
+  if (x2 && (n_split % LN_TN) != 0 && n_split < N) return GD4D_EUNSUPPORTED;   // split must align to tiles
+  if (!aligned16(x) || !aligned16(w) || (x2 && !aligned16(x2))) return GD4D_EALIGN;
+  LinearParams p{x, x2, w, bias, r1, r2, y, M, K, N, x2 ? n_split : 0, flags, ldx, ldy, ldr1, ldr2};
+  const dim3 grid((M + LN_TM - 1) / LN_TM, (N + LN_TN - 1) / LN_TN);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LN_WAVES), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                                  float* y, int M, int C, float eps, int relu, void* stream) {
+  using namespace gd4d;
+  if (!x || !gamma || !beta || !y || M <= 0 || C <= 0) return GD4D_EINVAL;
+  if (C % 4 != 0 || C > 1024) return GD4D_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || (res && !aligned16(res)))
+    return GD4D_EALIGN;
+  LayerNormParams p{x, res, gamma, beta, y, M, C, relu, eps};
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}

@@ -1,0 +1,182 @@
+// gd4d_mha_core_fwd: softmax(q k^T / sqrt(d) [+ mask]) v for the decoder self-attention, gfx950.
+//
+// Reference: third-party mmcv MultiheadAttention -> nn.MultiheadAttention (config call site
+// projects/configs/detr4d/detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78); H-DETR passes a
+// boolean self-attention mask (h_detr3d_transformer.py:149-157).  The packed in-projection and the
+// out-projection are gd4d_linear_fwd launches; this kernel is the part in between and never
+// materialises the (heads, Q, Q) score tensor the reference writes and re-reads.
+//
+// Everything is fp32 on v_mfma_f32_16x16x4_f32 (exact fp32 products).  One workgroup = 8 waves =
+// one (batch, head, 16-query tile); the waves split the keys 8 ways (flash-decoding style) and merge
+// their (max, sum, O) triples through LDS.
+//
+// Layout trick: the scores are computed TRANSPOSED, S^T = K Q^T (MFMA rows = keys, cols = queries),
+// with MFMA row rho of a 16-key tile holding key (rho>>2) + 4*(rho&3).  The C/D layout then leaves
+// lane (query i = lane&15, g = lane>>4), register r with key g + 4r - which is exactly the
+// B-operand layout (k = g + 4s at step s) of the second product O^T = V^T P^T.  The probabilities
+// never move between lanes; the softmax reductions are 4 in-lane values + two xor-shuffles.
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct MhaParams {
+  const float* q; const float* k; const float* v;   // row (l*B + b), row strides ldq/ldk/ldv, head h at +32*h
+  const void* mask;                                  // (Lq, Lk) uint8 (nonzero = masked) or float additive
+  float* out;                                        // (Lq*B, heads*32)
+  int Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind;   // 0 none, 1 bool, 2 float
+  float scale;
+};
+
+constexpr int MHA_D = 32;
+constexpr int MHA_WAVES = 8;
+
+__global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParams p) {
+  __shared__ float s_m[MHA_WAVES][16];
+  __shared__ float s_l[MHA_WAVES][16];
+  __shared__ float s_o[MHA_WAVES][MHA_D][17];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = lane & 15;            // query column of this lane
+  const int g = lane >> 4;             // lane group
+  const int q0 = blockIdx.x * 16;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const float NEG_INF = -__builtin_inff();
+
+  // Q^T as B operand: lane (col = query qi, g) holds q[qi][8g + s] at k-step s (any k<->dim map works
+  // as long as A uses the same one).  Rows beyond Lq are clamped (their outputs are never written).
+  float qf[8];
+  {
+    const int qrow = min(q0 + qi, p.Lq - 1);
+    const float* src = p.q + ((size_t)qrow * p.B + b) * p.ldq + h * MHA_D + 8 * g;
+    const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+    qf[0] = a.x * p.scale; qf[1] = a.y * p.scale; qf[2] = a.z * p.scale; qf[3] = a.w * p.scale;
+    qf[4] = c.x * p.scale; qf[5] = c.y * p.scale; qf[6] = c.z * p.scale; qf[7] = c.w * p.scale;
+  }
+  const int krho = (qi >> 2) + 4 * (qi & 3);     // key (within a tile) held by MFMA row rho = lane&15
+
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};    // O^T rows d = 4g + r, and 16 + 4g + r
+  float m = NEG_INF, l = 0.f;                                     // running max (per query), partial sum (per lane)
+
+  const int ntiles = (p.Lk + 15) / 16;
+  const size_t hoff = (size_t)h * MHA_D;
+  // register prefetch: the next tile's K row (2 x float4) and V columns (8 dwords) are requested
+  // before the current tile's MFMAs, so L2 latency overlaps the matrix work.
+  float4 ka, kc;
+  float vv[8];
+  auto fetch = [&](int kt, float4& a, float4& c, float* vdst) {
+    const int kbase = kt * 16;
+    const int krow = min(kbase + krho, p.Lk - 1);
+    const float* src = p.k + ((size_t)krow * p.B + b) * p.ldk + hoff + 8 * g;
+    a = *reinterpret_cast<const float4*>(src);
+    c = *reinterpret_cast<const float4*>(src + 4);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int vrow = min(kbase + g + 4 * st, p.Lk - 1);      // out-of-range keys get probability 0
+      const float* vs = p.v + ((size_t)vrow * p.B + b) * p.ldv + hoff + qi;
+      vdst[2 * st] = vs[0];
+      vdst[2 * st + 1] = vs[16];
+    }
+  };
+  if (wave < ntiles) fetch(wave, ka, kc, vv);
+  for (int kt = wave; kt < ntiles; kt += MHA_WAVES) {
+    const int kbase = kt * 16;
+    float4 na = ka, nc = kc;
+    float nv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) nv[i] = vv[i];
+    if (kt + MHA_WAVES < ntiles) fetch(kt + MHA_WAVES, na, nc, nv);
+    // ---- S^T = K Q^T ----
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qf[0], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qf[1], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qf[2], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qf[3], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.x, qf[4], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.y, qf[5], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.z, qf[6], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.w, qf[7], s, 0, 0, 0);
+    // lane (qi, g) reg r  <->  key kbase + g + 4r
+    float sc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kbase + g + 4 * r;
+      float val = s[r];
+      if (key >= p.Lk) {
+        val = NEG_INF;
+      } else if (p.mask_kind) {
+        const size_t mi = (size_t)min(q0 + qi, p.Lq - 1) * p.Lk + key;
+        if (p.mask_kind == 1) { if (static_cast<const uint8_t*>(p.mask)[mi]) val = NEG_INF; }
+        else val += static_cast<const float*>(p.mask)[mi];
+      }
+      sc[r] = val;
+    }
+    float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    // all keys so far masked: keep everything at zero weight without creating NaN here
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    const float corr = expf(m - m_use);           // m = -inf -> 0
+    float pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] = expf(sc[r] - m_use);
+    l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o0[r] *= corr; o1[r] *= corr; }
+    // ---- O^T += V^T P^T : A = V^T[d = lane&15 (+16)][key = kbase + g + 4s], B = P^T = pr[s] ----
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[2 * st], pr[st], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[2 * st + 1], pr[st], o1, 0, 0, 0);
+    }
+    ka = na; kc = nc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vv[i] = nv[i];
+  }
+
+  // ---- merge the key-slices ----
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (g == 0) { s_m[wave][qi] = m; s_l[wave][qi] = l; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    s_o[wave][4 * g + r][qi] = o0[r];
+    s_o[wave][16 + 4 * g + r][qi] = o1[r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 16 * MHA_D; e += 64 * MHA_WAVES) {
+    const int i = e / MHA_D, d = e % MHA_D;                    // consecutive threads -> consecutive d
+    if (q0 + i >= p.Lq) continue;
+    float mm = s_m[0][i];
+#pragma unroll
+    for (int w = 1; w < MHA_WAVES; ++w) mm = fmaxf(mm, s_m[w][i]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < MHA_WAVES; ++w) {
+      const float f = expf(s_m[w][i] - mm);                    // fully masked row: -inf - -inf = NaN, as ATen
+      num += s_o[w][d][i] * f;
+      den += s_l[w][i] * f;
+    }
+    p.out[((size_t)(q0 + i) * p.B + b) * p.ldo + h * MHA_D + d] = num / den;
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask,
+                                 float* out, int Lq, int Lk, int B, int H, int D, int ldq, int ldk,
+                                 int ldv, int ldo, int mask_kind, float scale, void* stream) {
+  using namespace gd4d;
+  if (!q || !k || !v || !out || Lq <= 0 || Lk <= 0 || B <= 0 || H <= 0) return GD4D_EINVAL;
+  if (D != MHA_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
+  if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return GD4D_EINVAL;
+  if (!aligned16(q) || !aligned16(k) || (ldq % 4) || (ldk % 4)) return GD4D_EALIGN;
+  MhaParams p{q, k, v, mask, out, Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind, scale};
+  hipLaunchKernelGGL(mha_core_kernel, dim3((Lq + 15) / 16, H, B), dim3(64 * MHA_WAVES), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}

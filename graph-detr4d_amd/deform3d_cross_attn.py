@@ -95,25 +95,29 @@ class Deform3DCrossAttn(nn.Module):
         Fn.require_inference(query, query_pos, reference_points, *value)
 
         inp_residual = query
-        x = query if query_pos is None else query + query_pos
-        x = x.permute(1, 0, 2)                                            # (B, Q, C)
-        b, q, c = x.shape
+        q_len, b, c = query.shape
+        q = q_len
         hh, npt, nl = self.num_heads, self.num_points, self.num_levels
+        n = self.num_cams
         if len(value) != nl:
             raise ValueError(f'expected {nl} feature levels, got {len(value)}')
-        if value[0].shape[1] != self.num_cams:
-            raise ValueError(f'expected {self.num_cams} cameras, got {value[0].shape[1]}')
+        if value[0].shape[1] != n:
+            raise ValueError(f'expected {n} cameras, got {value[0].shape[1]}')
 
-        # query-side projections: one GEMM for [camera logits | metre offsets | attention logits]
-        w_cat = torch.cat([self.cam_attention_weights.weight, self.deform_sampling_offsets.weight,
-                           self.attention_weights.weight], 0)
-        b_cat = torch.cat([self.cam_attention_weights.bias, self.deform_sampling_offsets.bias,
-                           self.attention_weights.bias], 0)
-        qside = Fn.linear(x, w_cat, b_cat)
-        n = self.num_cams
-        cam_logits = qside[..., :n].contiguous()                          # un-scrambled (B, Q, N)
-        offsets = qside[..., n:n + hh * npt * 3].reshape(b, q, hh, npt, 3)
-        attn_logits = qside[..., n + hh * npt * 3:].reshape(b, q, hh, nl, npt)
+        # query-side projections of (query + query_pos), the add fused into each GEMM's load (:204-228,281).
+        # Rows are (q, b)-ordered in memory; for B = 1 that IS the reference's (B, Q, C) permute (:207).
+        if b == 1:
+            xq, xp = query, query_pos
+        else:
+            xq = query.permute(1, 0, 2).contiguous()
+            xp = None if query_pos is None else query_pos.permute(1, 0, 2).contiguous()
+        kw = dict(x2=xp) if xp is not None else {}
+        cam_logits = Fn.linear(xq, self.cam_attention_weights.weight, self.cam_attention_weights.bias,
+                               **kw).view(b, q, n)                                   # un-scrambled
+        offsets = Fn.linear(xq, self.deform_sampling_offsets.weight, self.deform_sampling_offsets.bias,
+                            **kw).view(b, q, hh, npt, 3)
+        attn_logits = Fn.linear(xq, self.attention_weights.weight, self.attention_weights.bias,
+                                **kw).view(b, q, hh, nl, npt)
 
         cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
         if cached is not None and cached[2] is value:
@@ -121,15 +125,19 @@ class Deform3DCrossAttn(nn.Module):
         else:
             val, shapes = Fn.value_projection(value, self.value_proj.weight, self.value_proj.bias,
                                               hh, self.value_dtype)
-        lidar2img = Fn.lidar2img_device(img_metas, x)
+        lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
         agg = Fn.sample_aggregate(val, shapes, reference_points, offsets, attn_logits, cam_logits,
                                   lidar2img, self.pc_range, img_h, img_w)    # (B, Q, C)
 
-        out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
         ref3d = reference_points
         if self.depth_encode:                                             # :331-333
             depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
             ref3d = torch.cat([ref3d, depth], dim=-1)
-        pos_feat = self.position_encoder(Fn.inverse_sigmoid(ref3d)).permute(1, 0, 2)
-        return self.dropout(out) + inp_residual + pos_feat
+        pos_feat = Fn.position_encoder(self.position_encoder, ref3d)     # (B, Q, C)
+        if b == 1 and not self.training:
+            # output_proj with both residuals of :336 in its epilogue; (B=1,Q,C) and (Q,1,C) share memory
+            return Fn.linear(agg, self.output_proj.weight, self.output_proj.bias,
+                             r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
+        out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
+        return self.dropout(out) + inp_residual + pos_feat.permute(1, 0, 2)

@@ -82,16 +82,24 @@ class Detr3DCrossAtten(nn.Module):
             raise NotImplementedError('Detr3DCrossAtten: the gfx950 kernel is built for '
                                       'num_points=1 (every reference config)')
         inp_residual = query
-        x = query if query_pos is None else query + query_pos
-        x = x.permute(1, 0, 2)
-        logits = Fn.linear(x, self.attention_weights.weight, self.attention_weights.bias)
-        lidar2img = Fn.lidar2img_device(img_metas, x)
+        q, b, c = query.shape
+        if b == 1:
+            xq, xp = query, query_pos
+        else:
+            xq = query.permute(1, 0, 2).contiguous()
+            xp = None if query_pos is None else query_pos.permute(1, 0, 2).contiguous()
+        logits = Fn.linear(xq, self.attention_weights.weight, self.attention_weights.bias,
+                           **(dict(x2=xp) if xp is not None else {})).view(b, q, -1)
+        lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
         agg = ops.detr3d_fwd([f.contiguous() for f in value], reference_points.contiguous(),
                              logits.contiguous(), lidar2img, self.pc_range, img_h, img_w)['out']
+        pos_feat = Fn.position_encoder(self.position_encoder, reference_points)
+        if b == 1 and not self.training:
+            return Fn.linear(agg, self.output_proj.weight, self.output_proj.bias,
+                             r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
-        pos_feat = self.position_encoder(inverse_sigmoid(reference_points)).permute(1, 0, 2)
-        return self.dropout(out) + inp_residual + pos_feat
+        return self.dropout(out) + inp_residual + pos_feat.permute(1, 0, 2)
 
 
 @TRANSFORMER_LAYER_SEQUENCE.register_module()

@@ -55,9 +55,27 @@ def img_hw(img_metas):
     return float(shp[0]), float(shp[1])
 
 
-def linear(x, weight, bias=None):
-    """Query-side dense layers (900 x 256 x {24..768}).  Plain library GEMM for now."""
-    return F.linear(x, weight, bias)
+def linear(x, weight, bias=None, **kw):
+    """Dense layer on the last dim via gd4d_linear_fwd (fp32 MFMA).  Keywords: x2 / n_split (input
+    addend for the first output columns), relu, r1 / r2 (residuals), inv_sigmoid_in."""
+    return ops.linear_fwd(x.contiguous(), weight.contiguous(), None if bias is None else bias.contiguous(),
+                          **{k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in kw.items()})
+
+
+def layer_norm(x, norm, res=None, relu=False):
+    """nn.LayerNorm module `norm` applied through gd4d_layernorm_fwd (optionally LN(x + res), ReLU)."""
+    return ops.layernorm_fwd(x.contiguous(), norm.weight.contiguous(), norm.bias.contiguous(), norm.eps,
+                             res=None if res is None else res.contiguous(), relu=relu)
+
+
+def position_encoder(seq, ref):
+    """Reference position_encoder = Linear, LN, ReLU, Linear, LN, ReLU on inverse_sigmoid(ref)
+    (deform3d_cross_attn.py:104-111,334): 4 launches (inverse_sigmoid fused into the first Linear's load,
+    ReLU into the LayerNorms)."""
+    h = linear(ref, seq[0].weight, seq[0].bias, inv_sigmoid_in=True)
+    h = layer_norm(h, seq[1], relu=True)
+    h = linear(h, seq[3].weight, seq[3].bias)
+    return layer_norm(h, seq[4], relu=True)
 
 
 def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):

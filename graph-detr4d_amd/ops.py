@@ -140,3 +140,74 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32):
                                          _value_dtype(outs[0]), _stream())
     _lib.check(code, 'gd4d_value_proj_multi_fwd')
     return outs
+
+
+def _opt(t, name):
+    return _dev(t, name, torch.float32) if t is not None else None
+
+
+def linear_fwd(x, weight, bias=None, x2=None, n_split=None, relu=False, r1=None, r2=None, out=None,
+               inv_sigmoid_in=False):
+    """gd4d_linear_fwd on the last dimension: y = act((x [+ x2 for cols < n_split]) W^T + b) [+r1] [+r2].
+    x (..., K) contiguous; weight (N, K); residuals (..., N) contiguous.  Returns (..., N)."""
+    lib = _lib.load()
+    k = x.shape[-1]
+    n = weight.shape[0]
+    m = x.numel() // k
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    if x2 is not None and x2.shape != x.shape:
+        raise ValueError('x2 must have the shape of x')
+    code = lib.gd4d_linear_fwd(_dev(x, 'x', torch.float32), _opt(x2, 'x2'), _dev(weight, 'weight', torch.float32),
+                               _opt(bias, 'bias'), _opt(r1, 'r1'), _opt(r2, 'r2'), _dev(out, 'out'),
+                               m, k, n, n if n_split is None else int(n_split),
+                               int(bool(relu)) | (2 if inv_sigmoid_in else 0),
+                               k, n, n, n, _stream())
+    _lib.check(code, 'gd4d_linear_fwd')
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, res=None, relu=False):
+    """gd4d_layernorm_fwd over the last dimension of a contiguous tensor."""
+    lib = _lib.load()
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    code = lib.gd4d_layernorm_fwd(_dev(x, 'x', torch.float32), _opt(res, 'res'), _dev(gamma, 'gamma', torch.float32),
+                                  _dev(beta, 'beta', torch.float32), _dev(out, 'out'), x.numel() // c, c,
+                                  float(eps), int(bool(relu)), _stream())
+    _lib.check(code, 'gd4d_layernorm_fwd')
+    return out
+
+
+def mha_core_fwd(q, k, v, num_heads, attn_mask=None):
+    """gd4d_mha_core_fwd.  q (Lq, B, C), k / v (Lk, B, C): each contiguous or a last-dim slice of a packed
+    (L, B, 3C) in-projection buffer.  attn_mask: None, bool/uint8 (Lq, Lk) (nonzero = masked) or float
+    additive (Lq, Lk).  Returns (Lq, B, C)."""
+    lib = _lib.load()
+    lq, b, c = q.shape
+    lk = k.shape[0]
+    d = c // num_heads
+
+    def ld(t, name):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise _lib.Gd4dError(f'{name} must be a float32 GPU tensor')
+        if t.stride(2) != 1 or t.stride(0) != t.stride(1) * t.shape[1]:
+            raise ValueError(f'{name} must be row-strided (L, B, C)')
+        return t.stride(1)
+    out = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
+    kind, mptr = 0, None
+    if attn_mask is not None:
+        if attn_mask.dim() != 2:
+            raise NotImplementedError('only 2-D (Lq, Lk) attention masks are supported')
+        if attn_mask.dtype in (torch.bool, torch.uint8):
+            attn_mask, kind = attn_mask.to(torch.uint8), 1
+        else:
+            attn_mask, kind = attn_mask.float(), 2
+        attn_mask = attn_mask.contiguous()
+        mptr = _dev(attn_mask, 'attn_mask')
+    code = lib.gd4d_mha_core_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
+                                 ctypes.c_void_p(v.data_ptr()), mptr, _dev(out, 'out'), lq, lk, b,
+                                 num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, kind,
+                                 1.0 / (d ** 0.5), _stream())
+    _lib.check(code, 'gd4d_mha_core_fwd')
+    return out

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as Fn
+from . import ops
 from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, build_attention,
                        build_transformer_layer)
 
@@ -69,6 +70,10 @@ class MultiheadAttention(nn.Module):
         Fn.require_inference(query, key, value, query_pos)
         if key_padding_mask is not None:
             raise NotImplementedError('key_padding_mask is never set on the decoder self-attention path')
+        eval_mode = not self.training
+        if (eval_mode and not self.batch_first and key is query and value is query
+                and query_pos is not None and key_pos is query_pos and identity.shape == query.shape):
+            return self._packed_self_attention(query, query_pos, attn_mask, identity)
         q_in = query if query_pos is None else query + query_pos
         k_in = key if key_pos is None else key + key_pos
         if self.batch_first:
@@ -78,23 +83,24 @@ class MultiheadAttention(nn.Module):
             out = out.transpose(0, 1)
         return identity + self.dropout_layer(self.proj_drop(out))
 
+    def _packed_self_attention(self, query, query_pos, attn_mask, identity):
+        """The decoder's case (q = k = query + query_pos, v = query): one in-projection GEMM with the
+        positional add fused into its load, the attention core, and the out-projection with the
+        residual fused into its epilogue - 3 launches."""
+        c = self.embed_dims
+        qkv = Fn.linear(query, self.attn.in_proj_weight, self.attn.in_proj_bias, x2=query_pos, n_split=2 * c)
+        q, k, v = qkv.split(c, dim=-1)
+        o = ops.mha_core_fwd(q, k, v, self.num_heads, attn_mask)
+        return Fn.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, r1=identity)
+
     def _attention(self, q_in, k_in, v_in, attn_mask):
-        """(L, B, C) x3 -> (L, B, C): packed in-projection, softmax(q k^T / sqrt(d)) v, out_proj."""
-        c, h = self.embed_dims, self.num_heads
-        d = c // h
+        """General (L, B, C) x3 -> (L, B, C): three in-projections, attention core, out_proj."""
+        c = self.embed_dims
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
-        lq, b, _ = q_in.shape
-        lk = k_in.shape[0]
-        qh = Fn.linear(q_in, w[:c], bias[:c]).reshape(lq, b * h, d).transpose(0, 1)
-        kh = Fn.linear(k_in, w[c:2 * c], bias[c:2 * c]).reshape(lk, b * h, d).transpose(0, 1)
-        vh = Fn.linear(v_in, w[2 * c:], bias[2 * c:]).reshape(lk, b * h, d).transpose(0, 1)
-        scores = torch.bmm(qh * (1.0 / math.sqrt(d)), kh.transpose(1, 2))
-        if attn_mask is not None:
-            if attn_mask.dtype == torch.bool:
-                scores = scores.masked_fill(attn_mask, float('-inf'))
-            else:
-                scores = scores + attn_mask
-        o = torch.bmm(scores.softmax(-1), vh).transpose(0, 1).reshape(lq, b, c)
+        qh = Fn.linear(q_in, w[:c], bias[:c])
+        kh = Fn.linear(k_in, w[c:2 * c], bias[c:2 * c])
+        vh = Fn.linear(v_in, w[2 * c:], bias[2 * c:])
+        o = ops.mha_core_fwd(qh, kh, vh, self.num_heads, attn_mask)
         return Fn.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
 
@@ -122,6 +128,11 @@ class FFN(nn.Module):
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
+        if not self.training and len(self.layers) == 3 and x.is_cuda:
+            Fn.require_inference(x)
+            hdn = Fn.linear(x, self.layers[0][0].weight, self.layers[0][0].bias, relu=True)
+            res = (x if identity is None else identity) if self.add_identity else None
+            return Fn.linear(hdn, self.layers[1].weight, self.layers[1].bias, r1=res)
         out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
@@ -194,7 +205,7 @@ class BaseTransformerLayer(nn.Module):
                 attn_i += 1
                 identity = query
             elif op == 'norm':
-                query = self.norms[norm_i](query)
+                query = Fn.layer_norm(query, self.norms[norm_i]) if query.is_cuda else self.norms[norm_i](query)
                 norm_i += 1
             elif op == 'cross_attn':
                 query = self.attentions[attn_i](

@@ -146,6 +146,49 @@ int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                               void* const* outs, int R, int C, int L, int NL, int in_dtype,
                               int out_dtype, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * gd4d_linear_fwd - the decoder's small dense layers on the fp32 MFMA, with the elementwise
+ * neighbours fused:  y = act((x [+ x2 for output columns < n_split]) W^T + bias) [+ r1] [+ r2]
+ *
+ * Replaces nn.Linear call sites of the hot path: deform3d_cross_attn.py:211 (cam_attention_weights),
+ * :227 (deform_sampling_offsets), :281 (attention_weights) - all three on (query + query_pos), :204 -
+ * :326 (output_proj, with the residual adds of :336), :334 (position_encoder Linears);
+ * nn.MultiheadAttention in_proj (q,k from query+query_pos, v from query: n_split = 2C) / out_proj;
+ * mmcv FFN Linears; Detr3DCrossAtten :373, :386.
+ *   x, x2 (M, K) row stride ldx (x2 optional); w (N, K) row-major; bias (N) or NULL;
+ *   r1 / r2 optional residuals (M, N) with row strides ldr1 / ldr2; y (M, N) row stride ldy.
+ * n_split must be a multiple of 32 when x2 is given (or >= N).  fp32 in, fp32 accumulate.
+ * flags: GD4D_LIN_RELU = ReLU on the output (before the residuals); GD4D_LIN_INV_SIGMOID_IN = apply the
+ * reference's inverse_sigmoid (deform3d_cross_attn.py:16-31) to x while loading it (position_encoder
+ * input, :334).
+ */
+#define GD4D_LIN_RELU 1
+#define GD4D_LIN_INV_SIGMOID_IN 2
+int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
+                    const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
+                    int flags, int ldx, int ldy, int ldr1, int ldr2, void* stream);
+
+/* gd4d_layernorm_fwd - y = LayerNorm(x [+ res]) * gamma + beta [, ReLU] over the last dim
+ * (biased variance, eps inside the sqrt, like ATen).  Replaces the nn.LayerNorm of
+ * position_encoder (deform3d_cross_attn.py:104-111) and the decoder layer's three norms.
+ * C % 4 == 0, C <= 1024. */
+int gd4d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                       float* y, int M, int C, float eps, int relu, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * gd4d_mha_core_fwd - softmax(q k^T * scale [+ mask]) v per head, never materialising the score
+ * tensor.  The middle of nn.MultiheadAttention as used by the decoder self-attention (mmcv
+ * MultiheadAttention; config .../detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78;
+ * H-DETR mask: h_detr3d_transformer.py:149-157).
+ *   q (Lq*B rows), k, v (Lk*B rows): row index l*B + b, row strides ldq/ldk/ldv, head h at column
+ *   offset h*D (so q, k, v may alias the three thirds of one packed in-projection buffer);
+ *   mask: NULL, or (Lq, Lk) uint8 with nonzero = masked (mask_kind 1), or (Lq, Lk) fp32 additive
+ *   (mask_kind 2);  out (Lq*B, H*D) row stride ldo.  Supported: D == 32.  fp32 throughout.
+ */
+int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask, float* out,
+                      int Lq, int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo,
+                      int mask_kind, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

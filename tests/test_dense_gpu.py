@@ -1,0 +1,93 @@
+"""gd4d_linear_fwd / gd4d_layernorm_fwd / gd4d_mha_core_fwd against fp64 references.  GPU only."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('m,k,n', [(900, 256, 768), (900, 256, 248), (37, 3, 256), (900, 512, 256),
+                                   (65, 256, 10), (1, 4, 5), (130, 36, 70)])
+def test_linear_matches_fp64(m, k, n):
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + k + n)
+    x, w, b = torch.randn(m, k), torch.randn(n, k) * 0.1, torch.randn(n)
+    w[min(3, n - 1), min(2, k - 1)] = 2.5            # asymmetric landmark
+    got = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda()).cpu()
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert (got.double() - ref).abs().max().item() < 2e-5 * max(1.0, math.sqrt(k) / 4)
+
+
+def test_linear_fused_epilogue_and_input_addend():
+    """y = relu((x + x2 [cols < 512]) W^T + b) + r1 + r2  - the in-projection / FFN / output_proj forms."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(0)
+    m, k, n = 900, 256, 768
+    x, x2 = torch.randn(m, 1, k), torch.randn(m, 1, k)
+    w, b = torch.randn(n, k) * 0.06, torch.randn(n)
+    r1, r2 = torch.randn(m, 1, n), torch.randn(m, 1, n)
+    got = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), x2=x2.cuda(), n_split=512, relu=True,
+                         r1=r1.cuda(), r2=r2.cuda()).cpu()
+    xa = torch.cat([F.linear((x + x2).double(), w[:512].double(), b[:512].double()),
+                    F.linear(x.double(), w[512:].double(), b[512:].double())], -1)
+    ref = xa.relu() + r1.double() + r2.double()
+    assert got.shape == (m, 1, n)
+    assert (got.double() - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (False, True)])
+def test_layernorm_matches_aten(relu, res):
+    from graph_detr4d_amd import ops
+    torch.manual_seed(1)
+    x, r = torch.randn(900, 1, 256) * 3 + 0.5, torch.randn(900, 1, 256)
+    g, b = torch.randn(256), torch.randn(256)
+    got = ops.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), res=r.cuda() if res else None, relu=relu).cpu()
+    ref = F.layer_norm((x + r if res else x).double(), (256,), g.double(), b.double())
+    if relu:
+        ref = ref.relu()
+    assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('l,b,mask', [(900, 1, None), (50, 2, None), (48, 1, 'bool'), (2700, 1, 'bool'),
+                                      (77, 3, 'float'), (5, 1, None)])
+def test_mha_core_matches_fp64(l, b, mask):
+    from graph_detr4d_amd import ops
+    torch.manual_seed(l)
+    h, d = 8, 32
+    qkv = torch.randn(l, b, 3 * h * d)
+    am = None
+    if mask == 'bool':
+        kk = l // 3
+        am = torch.zeros(l, l, dtype=torch.bool)
+        am[kk:, :kk] = True
+        am[:kk, kk:] = True
+    elif mask == 'float':
+        am = torch.randn(l, l)
+    dq = qkv.cuda()
+    qv, kv, vv = dq.split(h * d, dim=-1)
+    got = ops.mha_core_fwd(qv, kv, vv, h, None if am is None else am.cuda()).cpu()
+    q, k, v = (t.reshape(l, b * h, d).transpose(0, 1).double() for t in qkv.split(h * d, dim=-1))
+    sc = torch.bmm(q / math.sqrt(d), k.transpose(1, 2))
+    if am is not None:
+        sc = sc.masked_fill(am, float('-inf')) if am.dtype == torch.bool else sc + am.double()
+    ref = torch.bmm(sc.softmax(-1), v).transpose(0, 1).reshape(l, b, h * d)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+def test_linear_inverse_sigmoid_input():
+    """position_encoder input transform: Linear(inverse_sigmoid(ref)), K = 3 and 4."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(2)
+    for k in (3, 4):
+        x = torch.rand(900, k)
+        x[0] = 0.0
+        x[1] = 1.0
+        x[2] = 1e-7
+        w, b = torch.randn(256, k), torch.randn(256)
+        got = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), inv_sigmoid_in=True).cpu()
+        xc = x.clamp(0, 1)
+        isg = torch.log(xc.clamp(min=1e-5, max=1) / (1 - xc).clamp(min=1e-5, max=1))
+        ref = F.linear(isg.double(), w.double(), b.double())
+        assert (got.double() - ref).abs().max().item() < 5e-5
