@@ -53,6 +53,8 @@ struct ValueProjParams {
   const float* bias[GD4D_MAX_LAYERS];     // (C) or null
   void* out[GD4D_MAX_LAYERS];             // (R, S, C)
   int R, L, S, NL;
+  int xcd_groups;                         // 1: layer groups co-located per XCD (grid % (8*NL) == 0)
+  int dbg;                                // dev ablation bits (GD4D_VP_DBG): 1 = skip stores, 2 = skip MFMAs
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo_elem, float hi_elem) {
@@ -239,6 +241,278 @@ extern "C" size_t gd4d_value_proj_workspace_bytes(void) { return 0; }
 
 namespace gd4d {
 
+// ---------------------------------------------------------------------------------------------
+// v2: software-pipelined variant (BM = 32).  Counters on the kernel above showed the MFMA pipe only
+// ~38 % busy and the waves parked ~44 % of the time: every tile ran load -> MFMA -> store -> convert
+// as workgroup-wide phases.  Here the phases of THREE consecutive tiles overlap inside one barrier
+// interval:
+//     tile t+2 : HBM -> LDS raw fp32 image by LDS-DMA (global_load_lds, no VGPR staging)
+//     tile t+1 : raw fp32 -> hi/lo bf16 [pix][ci] image, sliced into the 16 k-steps of ...
+//     tile t   : ... the MFMA loop, so VALU/LDS conversion work issues under the matrix pipe
+//     tile t-1 : accumulators are stored at the top of the interval (they drain during the MFMAs)
+// One __syncthreads per tile.  LDS: 2 raw images (2 x 32 KB) + 2 bf16 hi/lo images (2 x 32 KB).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+#define GD4D_SGPR(x) __builtin_amdgcn_readfirstlane(x)
+
+template <bool OUT_BF16, int DBG>   // DBG: compile-time ablation bits (dev only; production = 0)
+__global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const ValueProjParams p) {
+  constexpr int BM = 32;
+  constexpr int RAW = VP_C * BM * 4;               // bytes of one raw [256 ci][32 pix] fp32 image
+  constexpr int IMG = BM * VP_C * 2;               // bytes of one bf16 [32 pix][256 ci] image
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // raw[2] | {hi, lo}[2]
+  char* const raw_base = smem;
+  char* const img_base = smem + 2 * RAW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31;
+  const int kg = lane >> 5;
+
+  // Workgroup -> (layer, slot).  Observed dispatch places workgroup b on XCD b % 8 (speed only): the
+  // NL workgroups that serve the same slot are put on ONE XCD so they sweep the same tiles through
+  // the same L2 - the pyramid is then fetched once per slot instead of once per layer.
+  int layer, slot, slots;
+  {
+    const int per_xcd = gridDim.x / 8;             // host guarantees gridDim.x % 8 == 0 when p.xcd_groups
+    if (p.xcd_groups) {
+      const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+      layer = idx % p.NL;
+      slot = xcd * (per_xcd / p.NL) + idx / p.NL;
+      slots = 8 * (per_xcd / p.NL);
+    } else {
+      layer = blockIdx.x % p.NL;
+      slot = blockIdx.x / p.NL;
+      slots = gridDim.x / p.NL;
+    }
+  }
+  const float* __restrict__ weight = p.weight[layer];
+  void* __restrict__ outp = p.out[layer];
+
+  bf16x8 whi[VP_KSTEPS], wlo[VP_KSTEPS];
+  {
+    const float* wrow = weight + (size_t)(32 * wave + col) * VP_C + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < VP_KSTEPS; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * s);
+      const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      u32x4 h, l;
+      split8(v, h, l);
+      whi[s] = as_bf16x8(h);
+      wlo[s] = as_bf16x8(l);
+    }
+  }
+  const float bias = p.bias[layer] ? p.bias[layer][32 * wave + col] : 0.f;
+
+  const int total = p.tile_base[p.L];
+  const int ntile = slot < total ? (total - slot + slots - 1) / slots : 0;
+  if (ntile == 0) return;
+
+  // Level table in the tail of LDS (dynamic indexing of the by-value kernarg struct would make the
+  // compiler copy it to scratch).  Written with static indices; read only at level boundaries.
+  int* const tab = reinterpret_cast<int*>(smem + 2 * RAW + 4 * IMG);     // [L][6]: hw, tiles, start, base, in.lo, in.hi
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < GD4D_MAX_LEVELS; ++l) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(p.in[l]);
+      tab[6 * l + 0] = p.hw[l]; tab[6 * l + 1] = p.tiles[l]; tab[6 * l + 2] = p.start[l];
+      tab[6 * l + 3] = p.tile_base[l]; tab[6 * l + 4] = (int)(unsigned)(a & 0xffffffffu); tab[6 * l + 5] = (int)(unsigned)(a >> 32);
+    }
+  }
+  __syncthreads();
+
+  // Tile cursor (DMA side, runs two tiles ahead): plain workgroup-uniform scalars, advanced without
+  // divisions; level parameters change only at level boundaries.
+  int c_lvl, c_row, c_tin, c_hw, c_tiles, c_start;
+  const float* c_in;
+  auto set_level = [&](int lvl) {
+    c_lvl = lvl;
+    c_hw = GD4D_SGPR(tab[6 * lvl + 0]); c_tiles = GD4D_SGPR(tab[6 * lvl + 1]); c_start = GD4D_SGPR(tab[6 * lvl + 2]);
+    const unsigned lo = (unsigned)GD4D_SGPR(tab[6 * lvl + 4]), hi = (unsigned)GD4D_SGPR(tab[6 * lvl + 5]);
+    c_in = reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
+  };
+  {
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
+      if (l < p.L && slot >= p.tile_base[l]) lvl = l;
+    set_level(GD4D_SGPR(lvl));
+    const int rel = slot - GD4D_SGPR(tab[6 * c_lvl + 3]);
+    c_row = GD4D_SGPR(rel / c_tiles);                 // the only division, once per workgroup
+    c_tin = GD4D_SGPR(rel - c_row * c_tiles);
+  }
+  auto advance = [&]() {
+    c_tin += slots;
+    while (c_tin >= c_tiles && c_lvl < p.L) {
+      c_tin -= c_tiles;
+      if (++c_row == p.R) {
+        c_row = 0;
+        if (c_lvl + 1 < p.L) set_level(c_lvl + 1); else c_lvl = p.L;
+      }
+    }
+    c_tin = GD4D_SGPR(c_tin); c_row = GD4D_SGPR(c_row); c_lvl = GD4D_SGPR(c_lvl);
+  };
+
+  // LDS-DMA of the tile under the cursor into raw image `rb`.  Wave w fills ci rows [32w, 32w+32).
+  auto issue_dma = [&](int rb) {
+    if (DBG & 4) return;
+    const int hw = c_hw;
+    const int pix0 = c_tin * BM;
+    const float* src = c_in + (size_t)c_row * VP_C * hw;
+    char* dst = raw_base + rb * RAW + (32 * wave) * (BM * 4);
+    const bool wide = (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);   // wave-uniform
+    if (wide) {
+      // one instruction = 8 ci rows x 128 B; a quad that starts inside the row also ends inside it
+      int pq = pix0 + 4 * (lane & 7);
+      if (pq >= hw) pq = hw - 4;                    // tail lanes re-read the last quad (never stored)
+      const float* g = src + (size_t)(32 * wave + (lane >> 3)) * hw + pq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(8 * i) * hw),
+                                         (lds_void_t*)(dst + i * 8 * (BM * 4)), 16, 0, 0);
+    } else {
+      // one instruction = 2 ci rows x 128 B, one pixel per lane (clamped exactly at the row end)
+      const int px = min(pix0 + (lane & 31), hw - 1);
+      const float* g = src + (size_t)(32 * wave + (lane >> 5)) * hw + px;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(2 * i) * hw),
+                                         (lds_void_t*)(dst + i * 2 * (BM * 4)), 4, 0, 0);
+    }
+  };
+
+  // conversion role of this thread: pixel spix, channels [16*scg, 16*scg + 16)
+  const int spix = tid & 31;
+  const int scg = tid >> 5;
+
+  // FIFO of (first output pixel row, valid pixel rows) for tiles k, k+1, k+2 - filled at DMA time
+  int orow0 = 0, orem0 = 0, orow1 = 0, orem1 = 0, orow2 = 0, orem2 = 0;
+  auto tile_info = [&](int& orow, int& orem) {
+    orow = GD4D_SGPR(c_row * p.S + c_start + c_tin * BM);
+    orem = GD4D_SGPR(c_hw - c_tin * BM);
+  };
+
+  // ---- prologue: tiles 0 and 1 in flight, tile 0 converted ----
+  issue_dma(0);
+  tile_info(orow0, orem0);
+  advance();
+  if (ntile > 1) { issue_dma(1); tile_info(orow1, orem1); advance(); }
+  __syncthreads();                                 // (drains the DMAs)
+  {
+    const float* rawf = reinterpret_cast<const float*>(raw_base) + (16 * scg) * BM + spix;
+    float cv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cv[j] = rawf[j * BM];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 h, l;
+      split8(cv + 8 * c, h, l);
+      const int off = lds_off(spix, 2 * scg + c);
+      *reinterpret_cast<u32x4*>(img_base + off) = h;
+      *reinterpret_cast<u32x4*>(img_base + IMG + off) = l;
+    }
+  }
+  __syncthreads();
+
+  f32x16 prev;                                     // accumulators of the previous tile, stored one interval later
+  int prow = 0, prem = 0;                          // its first output pixel row / valid pixel rows
+  // store accumulator row r of the previous tile (one store instruction)
+  auto store_one = [&](int r, bool full) {
+    if (DBG & 1) { asm volatile("" ::"v"(prev[r])); return; }
+    const int dp = (r & 3) + 8 * (r >> 2);
+    const size_t o = ((size_t)prow + 4 * kg + dp) * VP_C + 32 * wave + col;
+    if (full || dp + 4 * kg < prem) {
+      if (OUT_BF16) static_cast<uint16_t*>(outp)[o] = f32_to_bf16(prev[r]);
+      else static_cast<float*>(outp)[o] = prev[r];
+    }
+  };
+
+  for (int k = 0; k < ntile; ++k) {
+    // VMEM program order of this interval: [DMA of tile k+2] then [<= 16 stores of tile k-1].
+    // The counted wait at the bottom lets the stores stay in flight across the barrier.
+    if (k + 2 < ntile) { issue_dma(k & 1); tile_info(orow2, orem2); advance(); }
+    // The 16 stores of tile k-1 are spread over the 16 k-steps below (one each), so every store has
+    // ~96 cycles of MFMA work to drain behind instead of backing up the wave's issue.
+    const bool has_prev = k > 0;
+    const bool full_prev = prem >= BM;              // workgroup-uniform; tail tiles take the guarded path
+    const int ib = k & 1;
+    const char* hi_img = img_base + ib * 2 * IMG;
+    const char* lo_img = hi_img + IMG;
+    char* nhi_img = img_base + (ib ^ 1) * 2 * IMG;  // tile k+1 is converted into the other image ...
+    char* nlo_img = nhi_img + IMG;
+    const float* rawf = reinterpret_cast<const float*>(raw_base + (ib ^ 1) * RAW) + (16 * scg) * BM + spix;  // ... from raw[(k+1)&1]
+
+    f32x16 acc0, acc1;                              // two independent MFMA chains
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = 0.f; }
+    float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // A fragments through a 3-deep register ring: the reads for k-step s+2 are issued before the
+    // MFMAs of step s, so LDS latency is covered by matrix work instead of alternating with it.
+    u32x4 fh[3], fl[3];
+    auto frag_load = [&](int s2, u32x4& h, u32x4& l) {
+      if (DBG & 8) { h = u32x4{0u, 0u, 0u, 0u}; l = h; return; }
+      const int off = lds_off(col, 2 * s2 + kg);
+      h = *reinterpret_cast<const u32x4*>(hi_img + off);
+      l = *reinterpret_cast<const u32x4*>(lo_img + off);
+    };
+    frag_load(0, fh[0], fl[0]);
+    frag_load(1, fh[1], fl[1]);
+#pragma unroll
+    for (int s = 0; s < VP_KSTEPS; ++s) {
+      if (s + 2 < VP_KSTEPS) frag_load(s + 2, fh[(s + 2) % 3], fl[(s + 2) % 3]);
+      // 1/16 of the next tile's conversion per k-step (harmless garbage after the last tile)
+      if (!(DBG & 16)) cv[s & 7] = rawf[s * BM];
+      if (has_prev) store_one(s, full_prev);
+      __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ABOVE this step's MFMAs
+      const bf16x8 ahi = as_bf16x8(fh[s % 3]);
+      const bf16x8 alo = as_bf16x8(fl[s % 3]);
+      if (!(DBG & 2)) {
+        if (DBG & 32) __builtin_amdgcn_s_setprio(1);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[s], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[s], acc1, 0, 0, 0);
+        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
+      } else {
+        asm volatile("" ::"v"(ahi), "v"(alo));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((s & 7) == 7 && !(DBG & 16)) {
+        u32x4 h, l;
+        split8(cv, h, l);
+        const int woff = lds_off(spix, 2 * scg + (s >> 3));
+        *reinterpret_cast<u32x4*>(nhi_img + woff) = h;
+        *reinterpret_cast<u32x4*>(nlo_img + woff) = l;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev[r] = acc0[r] + acc1[r];
+    prow = orow0; prem = orem0;
+    orow0 = orow1; orem0 = orem1; orow1 = orow2; orem1 = orem2;
+    // Raw barrier + explicit waits (a __syncthreads() here makes the compiler drain vmcnt(0), i.e. wait
+    // for every store of the previous tile).  Needed before the barrier: this wave's LDS writes done
+    // (lgkmcnt) and the DMA of tile k+2 landed - it was issued BEFORE the <= 16 stores, and VMEM ops
+    // retire in order, so "at most 16 outstanding" implies the DMA is complete.
+    if (!has_prev || full_prev) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) store_one(r, prem >= BM);
+}
+
+static int vp_variant() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("GD4D_VP_VARIANT");        // dev A/B switch: 1 = phase kernel, 2 = pipelined
+    v = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  return v;
+}
+
 static int vp_tile_pixels() {
   static int bm = 0;
   if (!bm) {
@@ -271,6 +545,32 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
   if (slots < 1) slots = 1;
   if (slots > base) slots = base;
   const int grid = slots * NL;
+  if (BM == 32 && vp_variant() == 2) {
+    // co-locate the NL workgroups of a slot on one XCD: grid = 8 XCDs x (cus/8 rounded down to a multiple of NL)
+    int g2 = grid;
+    p.xcd_groups = 0;
+    if (NL > 1 && cus % 8 == 0 && (cus / 8) >= NL) {
+      const int per_xcd = ((cus / 8) / NL) * NL;
+      if (8 * (per_xcd / NL) <= base) { g2 = 8 * per_xcd; p.xcd_groups = 1; }
+    }
+    const int grid = g2;
+    const size_t lds2 = 2 * (size_t)VP_C * 32 * 4 + 2 * 2 * (size_t)32 * VP_C * 2 + 256;   // raw[2] + {hi,lo}[2] = 128 KB, + level table
+    const bool ob = out_dtype == GD4D_BF16;
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(VP_THREADS), lds2, st, p);
+    };
+    switch (p.dbg) {                                 // ablation builds exist for fp32 output only
+      case 1: go(value_proj_pipe_kernel<false, 1>); break;
+      case 2: go(value_proj_pipe_kernel<false, 2>); break;
+      case 3: go(value_proj_pipe_kernel<false, 3>); break;
+      case 7: go(value_proj_pipe_kernel<false, 7>); break;
+      case 31: go(value_proj_pipe_kernel<false, 31>); break;
+      case 32: go(value_proj_pipe_kernel<false, 32>); break;
+      default: if (ob) go(value_proj_pipe_kernel<true, 0>); else go(value_proj_pipe_kernel<false, 0>); break;
+    }
+    return check_launch();
+  }
   const size_t lds = 2 * 2 * (size_t)BM * VP_C * 2;    // 2 buffers x (hi, lo) x [BM][256] bf16
   if (out_dtype == GD4D_BF16) {
     static bool attr = false;
@@ -310,6 +610,7 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
     p.out[i] = outs[i];
   }
   p.R = R; p.L = L; p.NL = NL;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GD4D_VP_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   return vp_tile_pixels() == 64 ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
                                 : vp_launch<32>(p, level_hw, R, L, NL, out_dtype, st);
