@@ -30,6 +30,7 @@ SIGNATURES = {
     'gd4d_linear_fwd': (_i, [_vp] * 7 + [_i] * 9 + [_vp]),
     'gd4d_layernorm_fwd': (_i, [_vp] * 5 + [_i, _i, _f, _i, _vp]),
     'gd4d_mha_core_fwd': (_i, [_vp] * 5 + [_i] * 10 + [_f, _vp]),
+    'gd4d_refine_reference_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_value_proj_multi_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
 

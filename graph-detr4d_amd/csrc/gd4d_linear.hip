@@ -224,6 +224,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Reference-point refinement of Detr3DTransformerDecoder.forward (detr3d_transformer.py:201-214):
+//   new_xy = sigmoid(tmp[..., 0:2] + inverse_sigmoid(ref_xy)); new_z = sigmoid(tmp[..., 4] + inverse_sigmoid(ref_z))
+// (about a dozen elementwise launches in the reference) as one kernel, one thread per query.
+__global__ __launch_bounds__(256) void refine_reference_kernel(const float* __restrict__ tmp,
+                                                               const float* __restrict__ ref,
+                                                               float* __restrict__ out, int M, int ldt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float* t = tmp + (size_t)i * ldt;
+  const float* r = ref + (size_t)i * 3;
+  const float a = t[0] + inv_sigmoid(r[0]);
+  const float b = t[1] + inv_sigmoid(r[1]);
+  const float c = t[4] + inv_sigmoid(r[2]);
+  out[(size_t)i * 3 + 0] = 1.0f / (1.0f + expf(-a));
+  out[(size_t)i * 3 + 1] = 1.0f / (1.0f + expf(-b));
+  out[(size_t)i * 3 + 2] = 1.0f / (1.0f + expf(-c));
+}
+
 }  // namespace gd4d
 
 extern "C" int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
@@ -252,5 +271,15 @@ extern "C" int gd4d_layernorm_fwd(const float* x, const float* res, const float*
     return GD4D_EALIGN;
   LayerNormParams p{x, res, gamma, beta, y, M, C, relu, eps};
   hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_refine_reference_fwd(const float* tmp, const float* ref, float* out, int M, int ldt,
+                                         void* stream) {
+  using namespace gd4d;
+  if (!tmp || !ref || !out || M <= 0) return GD4D_EINVAL;
+  if (ldt < 5) return GD4D_EUNSUPPORTED;
+  hipLaunchKernelGGL(refine_reference_kernel, dim3((M + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), tmp, ref, out, M, ldt);
   return check_launch();
 }

@@ -131,12 +131,15 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         for lid, layer in enumerate(self.layers):
             output = layer(output, *args, reference_points=reference_points, **kwargs)
             if reg_branches is not None:
-                tmp = reg_branches[lid](output.permute(1, 0, 2))
                 assert reference_points.shape[-1] == 3
-                new_ref = torch.zeros_like(reference_points)
-                new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
-                new_ref[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
-                reference_points = new_ref.sigmoid().detach()
+                tmp = Fn.run_branch(reg_branches[lid], output.permute(1, 0, 2).contiguous())
+                if tmp.is_cuda and tmp.dtype == torch.float32:
+                    reference_points = Fn.refine_reference(tmp, reference_points).detach()
+                else:
+                    new_ref = torch.zeros_like(reference_points)
+                    new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
+                    new_ref[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
+                    reference_points = new_ref.sigmoid().detach()
             if self.return_intermediate:
                 intermediate.append(output)
                 intermediate_reference_points.append(reference_points)

@@ -91,6 +91,30 @@ def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
     return out.view(b * n, -1, num_heads, c // num_heads), shapes
 
 
+def run_branch(branch, x):
+    """A head branch (reg_branches[lid]) applied to x.  nn.Sequential chains of Linear / ReLU - what
+    Detr3DHead builds (dense_heads/detr3d_head.py:58-75) - run on gd4d_linear_fwd with the ReLUs fused;
+    anything else is simply called."""
+    mods = list(branch) if isinstance(branch, torch.nn.Sequential) else None
+    if not mods or not x.is_cuda or not all(isinstance(m, (torch.nn.Linear, torch.nn.ReLU)) for m in mods) \
+            or not isinstance(mods[0], torch.nn.Linear):
+        return branch(x)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        if not isinstance(lin, torch.nn.Linear):
+            return branch(x) if i == 0 else torch.relu(x)
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
+        x = linear(x, lin.weight, lin.bias, relu=relu)
+        i += 2 if relu else 1
+    return x
+
+
+def refine_reference(tmp, reference_points):
+    """detr3d_transformer.py:201-214 as one launch (ops.refine_reference_fwd)."""
+    return ops.refine_reference_fwd(tmp.contiguous(), reference_points.contiguous())
+
+
 VALUE_CACHE_KEY = '_gd4d_value_cache'
 
 

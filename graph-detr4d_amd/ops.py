@@ -211,3 +211,13 @@ def mha_core_fwd(q, k, v, num_heads, attn_mask=None):
                                  1.0 / (d ** 0.5), _stream())
     _lib.check(code, 'gd4d_mha_core_fwd')
     return out
+
+
+def refine_reference_fwd(tmp, ref):
+    """gd4d_refine_reference_fwd: tmp (..., >=5) regression deltas, ref (..., 3) in [0,1] -> new ref."""
+    lib = _lib.load()
+    out = torch.empty_like(ref)
+    code = lib.gd4d_refine_reference_fwd(_dev(tmp, 'tmp', torch.float32), _dev(ref, 'ref', torch.float32),
+                                         _dev(out, 'out'), ref.numel() // 3, tmp.shape[-1], _stream())
+    _lib.check(code, 'gd4d_refine_reference_fwd')
+    return out

@@ -189,6 +189,13 @@ int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void
                       int Lq, int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo,
                       int mask_kind, float scale, void* stream);
 
+/* gd4d_refine_reference_fwd - reference-point refinement between decoder layers
+ * (Detr3DTransformerDecoder.forward, detr3d_transformer.py:201-214):
+ *   out[:, 0:2] = sigmoid(tmp[:, 0:2] + inverse_sigmoid(ref[:, 0:2]));
+ *   out[:, 2]   = sigmoid(tmp[:, 4]   + inverse_sigmoid(ref[:, 2]))
+ * tmp (M, ldt) = reg_branches[lid](output), ldt >= 5; ref, out (M, 3) fp32. */
+int gd4d_refine_reference_fwd(const float* tmp, const float* ref, float* out, int M, int ldt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

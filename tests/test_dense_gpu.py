@@ -91,3 +91,19 @@ def test_linear_inverse_sigmoid_input():
         isg = torch.log(xc.clamp(min=1e-5, max=1) / (1 - xc).clamp(min=1e-5, max=1))
         ref = F.linear(isg.double(), w.double(), b.double())
         assert (got.double() - ref).abs().max().item() < 5e-5
+
+
+def test_refine_reference_matches_reference_formula():
+    from graph_detr4d_amd import ops
+    torch.manual_seed(9)
+    tmp, ref = torch.randn(2, 900, 10), torch.rand(2, 900, 3)
+    ref[0, 0] = torch.tensor([0.0, 1.0, 1e-7])
+    got = ops.refine_reference_fwd(tmp.cuda(), ref.cuda()).cpu()
+
+    def isg(x, eps=1e-5):
+        x = x.clamp(0, 1)
+        return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+    want = torch.zeros_like(ref)
+    want[..., :2] = tmp[..., :2] + isg(ref[..., :2])
+    want[..., 2:3] = tmp[..., 4:5] + isg(ref[..., 2:3])
+    torch.testing.assert_close(got, want.sigmoid(), rtol=1e-5, atol=1e-6)
