@@ -45,6 +45,7 @@ def parse():
                     help='storage of the projected value tensor (fp32 = the reference-parity mode)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-threads', type=int, default=None, help='torch threads of the CPU baseline (default: min(cores, 16), the fastest measured)')
     ap.add_argument('--cpu-layers', type=int, default=None,
                     help='decoder layers of the CPU-baseline sample (default: bounded automatically)')
     return ap.parse_args()
@@ -84,34 +85,39 @@ def state_as_oracle_params(tr):
     return sd, layers
 
 
-def cpu_baseline(tr, regs, feats_cpu, query_embed, metas, pc_range, layers_to_time):
-    """Oracle (CPU port of the reference path) on this host's cores, bounded sample."""
+def cpu_baseline(tr, regs, feats_cpu, query_embed, metas, pc_range, layers_to_time, threads=None, repeats=3):
+    """Oracle (CPU port of the reference path) on this host's cores: the same sample through
+    `layers_to_time` decoder layers, median of `repeats` runs (about 10 s of CPU work)."""
     from oracle import torch_oracle as O
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # measured on the 2 x 64-core GPU box: 16 threads 0.60 s/layer, 32: 0.81, 64: 0.93, 256: 15.7
+    torch.set_num_threads(threads or min(cores, 16))
     sd, layer_params = state_as_oracle_params(tr)
     regs_cpu = [r.cpu() for r in regs]
     small = [f[:, :, :, :8, :8].contiguous() for f in feats_cpu]      # warm-up: page in code paths
+    times = []
     with torch.no_grad():
         O.transformer(sd, layer_params[:1], small, query_embed[:64], metas, pc_range,
                       reg_branches=regs_cpu[:1], cross='Deform3DCrossAttn', num_points=4)
-        t0 = time.perf_counter()
-        O.transformer(sd, layer_params[:layers_to_time], feats_cpu, query_embed, metas, pc_range,
-                      reg_branches=regs_cpu[:layers_to_time], cross='Deform3DCrossAttn', num_points=4)
-        dt = time.perf_counter() - t0
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            O.transformer(sd, layer_params[:layers_to_time], feats_cpu, query_embed, metas, pc_range,
+                          reg_branches=regs_cpu[:layers_to_time], cross='Deform3DCrossAttn', num_points=4)
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     per_layer = dt / layers_to_time
     full = per_layer * len(layer_params)
     return dict(value=1.0 / full, unit='samples/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{layers_to_time} of {len(layer_params)} decoder layers of one sample '
-                       f'(same inputs) in {dt:.2f} s, scaled to {len(layer_params)} layers',
+                sample=f'one sample (same inputs as the GPU run) through {layers_to_time} of '
+                       f'{len(layer_params)} decoder layers, median of {repeats} runs = {dt:.2f} s'
+                       + ('' if layers_to_time == len(layer_params) else ', scaled to all layers'),
                 ms_per_layer=per_layer * 1e3)
 
 
 def main():
     a = parse()
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    from graph_detr4d_amd import dist as D
+    rank, local_rank, world = D.env()
     if world != a.gpus and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if a.gpus > 1 and world == 1:
@@ -120,10 +126,7 @@ def main():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    D.init(backend='nccl', device=dev)               # RCCL; no-op for a single process
 
     import graph_detr4d_amd as G
     from graph_detr4d_amd import _lib, ops, synthetic
@@ -131,8 +134,8 @@ def main():
 
     n_cams = 6 * a.frames
     levels = synthetic.R50_LEVELS if a.levels == 'r50' else synthetic.VOV_LEVELS
-    seed = 1000 + 2 + rank                            # 1000 + config + rank
-    tr, regs = build_decoder(G, n_cams, a.layers, a.value_dtype, seed)
+    seed = D.sample_seed(1000 + 2, rank)              # 1000 + config + rank
+    tr, regs = build_decoder(G, n_cams, a.layers, a.value_dtype, 1000 + 2)   # same model on every rank
     feats_cpu = synthetic.feature_pyramid(n_cams, levels, seed=seed)
     g = torch.Generator().manual_seed(seed + 3)
     query_embed_cpu = torch.randn(a.queries, 512, generator=g)
@@ -171,24 +174,7 @@ def main():
                       file=sys.stderr)
                 run, launch = step, 'eager'
 
-        def sync():
-            torch.cuda.synchronize()
-            if world > 1:
-                torch.distributed.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(a.warmup):
-            run()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            run()
-        sync()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = D.timed_steps(run, a.steps, a.warmup, dev)   # barrier + synchronise both sides, MAX over ranks
 
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
@@ -197,15 +183,15 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        n_layers = a.cpu_layers or (1 if n_cams > 6 else 2)
+        n_layers = a.cpu_layers or a.layers
         cpu = cpu_baseline(tr, regs, feats_cpu, query_embed_cpu, metas, synthetic.PC_RANGE,
-                           min(n_layers, a.layers))
+                           min(n_layers, a.layers), a.cpu_threads)
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         line = {
             'metric': f'decoder_samples_per_sec_{a.queries}q_T{a.frames}',
-            'value': a.gpus * a.steps / elapsed, 'unit': 'samples/s', 'n_gpus': a.gpus,
+            'value': D.aggregate_throughput(1, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if a.value_dtype == 'fp32' else 'bf16-storage/f32-accumulate',
@@ -219,9 +205,7 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
         }
         print(json.dumps(line))
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    D.shutdown()
 
 
 def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic):

@@ -1,0 +1,87 @@
+"""Replica-parallel plumbing for N > 1 (one process per GPU, `torch.distributed`; backend "nccl" is
+RCCL on ROCm, "gloo" for the CPU tests).
+
+The decoder hot path shards by SAMPLE exactly like the reference (samples_per_gpu=1 under DDP,
+projects/mmdet3d_plugin/apis/mmdet_distill_train.py:62-82): inference has no exchange step inside
+the path, so the only collectives are a barrier and a MAX-reduce of the elapsed time.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def env():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+def init(backend=None, device=None):
+    """Initialise the default process group when WORLD_SIZE > 1.  Returns (rank, world)."""
+    rank, _, world = env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if backend is None:
+            backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
+        kw = {}
+        if backend == 'nccl' and device is not None:
+            kw['device_id'] = torch.device(device)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sample_indices(num_samples, rank, world):
+    """Samples of this rank: r, r+W, r+2W, ... (DistributedSampler order without shuffling)."""
+    return list(range(rank, num_samples, world))
+
+
+def sample_seed(base_seed, rank):
+    """Synthetic-input seed of the sample a rank processes (1000+config+rank)."""
+    return base_seed + rank
+
+
+def sync(device=None):
+    """barrier + device synchronise on both sides (the bench contract's bracket)."""
+    cuda = device is not None and torch.device(device).type == 'cuda'
+    if cuda:
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    dev = device if (device is not None and dist.get_backend() == 'nccl') else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(run, steps, warmup, device=None):
+    """`warmup` untimed calls of run(), then exactly `steps` timed calls bracketed by sync();
+    returns the MAX elapsed seconds over ranks."""
+    for _ in range(warmup):
+        run()
+    sync(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    sync(device)
+    return max_over_ranks(time.perf_counter() - t0, device)
+
+
+def aggregate_throughput(units_per_rank_step, steps, world, elapsed):
+    """Whole-job units/s: every rank processed units_per_rank_step * steps units in `elapsed` (max) s."""
+    return units_per_rank_step * steps * world / elapsed

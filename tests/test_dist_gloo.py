@@ -1,0 +1,69 @@
+"""N > 1 path of the bench (replicas sharded by sample, barrier, MAX-reduced timing) with two gloo
+processes on CPU."""
+import os
+import socket
+import time
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from graph_detr4d_amd import dist as D
+    r, w = D.init(backend='gloo')
+    assert (r, w) == (rank, world)
+    idx = D.sample_indices(7, r, w)
+    seed = D.sample_seed(1002, r)
+    calls = []
+
+    def run():                      # rank 1 is the slow rank
+        calls.append(1)
+        time.sleep(0.02 if r == 1 else 0.001)
+    elapsed = D.timed_steps(run, steps=5, warmup=2, device=None)
+    mx = D.max_over_ranks(float(r + 1))
+    thr = D.aggregate_throughput(1, 5, w, elapsed)
+    q.put((r, idx, seed, len(calls), elapsed, mx, thr))
+    D.shutdown()
+
+
+def test_two_rank_replicas_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, idx0, seed0, n0, e0, mx0, thr0), (r1, idx1, seed1, n1, e1, mx1, thr1) = res
+    assert sorted(idx0 + idx1) == list(range(7)) and not set(idx0) & set(idx1)      # disjoint, complete
+    assert (seed0, seed1) == (1002, 1003)
+    assert n0 == n1 == 7                                   # 2 warm-up + exactly 5 timed steps
+    assert abs(e0 - e1) < 1e-9 and e0 >= 5 * 0.02 * 0.9    # both ranks report the slow rank's time
+    assert mx0 == mx1 == 2.0
+    assert abs(thr0 - 2 * 5 / e0) < 1e-9                   # whole-job aggregate
+
+
+def test_single_process_helpers():
+    from graph_detr4d_amd import dist as D
+    assert D.sample_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert D.max_over_ranks(3.5) == 3.5
+    n = []
+    e = D.timed_steps(lambda: n.append(1), steps=3, warmup=1)
+    assert len(n) == 4 and e >= 0
