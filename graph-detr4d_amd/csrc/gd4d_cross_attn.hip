@@ -33,6 +33,7 @@ struct CrossAttnParams {
   uint8_t* mask_out;
   float* uv_out;
   int B, N, Q, L, S;
+  int head_major;      // value layout: 0 = (B*N, S, Hh, Dh) pixel-major, 1 = (B*N, Hh, S, Dh) head-major planes
   int lvl_h[GD4D_MAX_LEVELS];
   int lvl_w[GD4D_MAX_LEVELS];
   int lvl_start[GD4D_MAX_LEVELS];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttn
 // the map centre - so all 4 points x L levels x 4 corners loads can be issued back to back.
 // Partial sums are combined through LDS in fixed wave order (deterministic).
 template <typename VT, int HH, int LT, int WAVES>
-__global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_fwd_block(const CrossAttnParams p) {
+__global__ __launch_bounds__(GD4D_WAVE * WAVES, 3) void cross_attn_fwd_block(const CrossAttnParams p) {
   constexpr int DH = kChannels / HH;
   constexpr int LANES_PER_HEAD = DH / 4;
   constexpr int E = HH * kPoints;
@@ -285,13 +286,21 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_fwd_block(const 
     const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];
     const float cw = 1.0f / (1.0f + expf(-cl));
     const VT* vrow = static_cast<const VT*>(p.value) + (size_t)row * p.S * kChannels;   // wave-uniform
-    const unsigned lane_off = lane * 4;
+    // pixel stride / lane offset of the two layouts (elements)
+    const unsigned pix_stride = p.head_major ? (unsigned)DH : (unsigned)kChannels;
+    const unsigned lane_off = p.head_major ? (unsigned)(h * p.S * DH + (lane % LANES_PER_HEAD) * 4) : (unsigned)(lane * 4);
 
 #pragma unroll
     for (int k = 0; k < kPoints; ++k) {
       const bool pv = pu[k].x >= 0.f;
       const float u = pv ? pu[k].x : 0.5f, v = pv ? pu[k].y : 0.5f;
       const float cwk = pv ? cw : 0.f;
+      // Stage 1: addresses of all L x 4 corners of this point.  Stage 2: issue every load.  Stage 3
+      // (below a scheduling barrier): weights + FMAs.  Left to itself the compiler keeps only 2-4
+      // loads in flight per wave to save registers; a gather kernel lives on memory-level parallelism.
+      unsigned off[LMAX][4];
+      float fx[LMAX], fy[LMAX];
+      unsigned okm = 0;                              // 4 bits per level: x0ok, x1ok, y0ok, y1ok
 #pragma unroll
       for (int l = 0; l < LMAX; ++l) {
         if (LT == 0 && l >= L) break;
@@ -299,30 +308,44 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_fwd_block(const 
         const float x = fmaf(u, (float)W, -0.5f);
         const float y = fmaf(v, (float)H, -0.5f);
         const float xf = floorf(x), yf = floorf(y);
-        const float dx = x - xf, dy = y - yf;
+        fx[l] = x - xf; fy[l] = y - yf;
         const int x0 = (int)xf, y0 = (int)yf;
-        const float wl = aw[l * kPoints + k] * cwk;
         const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W;
         const bool y0ok = y0 >= 0, y1ok = y0 + 1 < H;
-        const float w00 = (x0ok && y0ok) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
-        const float w01 = (x1ok && y0ok) ? wl * dx * (1.f - dy) : 0.f;
-        const float w10 = (x0ok && y1ok) ? wl * (1.f - dx) * dy : 0.f;
-        const float w11 = (x1ok && y1ok) ? wl * dx * dy : 0.f;
+        okm |= ((x0ok ? 1u : 0u) | (x1ok ? 2u : 0u) | (y0ok ? 4u : 0u) | (y1ok ? 8u : 0u)) << (4 * l);
+        // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
         const int xa = x0ok ? x0 : 0, xb = x1ok ? x0 + 1 : W - 1;
         const int ya = y0ok ? y0 : 0, yb = y1ok ? y0 + 1 : H - 1;
         const unsigned r0 = (unsigned)(p.lvl_start[l] + ya * W), r1 = (unsigned)(p.lvl_start[l] + yb * W);
-        const float4 v00 = Quad<VT>::load(vrow + ((r0 + xa) * (unsigned)kChannels + lane_off));
-        const float4 v01 = Quad<VT>::load(vrow + ((r0 + xb) * (unsigned)kChannels + lane_off));
-        const float4 v10 = Quad<VT>::load(vrow + ((r1 + xa) * (unsigned)kChannels + lane_off));
-        const float4 v11 = Quad<VT>::load(vrow + ((r1 + xb) * (unsigned)kChannels + lane_off));
-        acc.x = fmaf(w00, v00.x, acc.x); acc.y = fmaf(w00, v00.y, acc.y);
-        acc.z = fmaf(w00, v00.z, acc.z); acc.w = fmaf(w00, v00.w, acc.w);
-        acc.x = fmaf(w01, v01.x, acc.x); acc.y = fmaf(w01, v01.y, acc.y);
-        acc.z = fmaf(w01, v01.z, acc.z); acc.w = fmaf(w01, v01.w, acc.w);
-        acc.x = fmaf(w10, v10.x, acc.x); acc.y = fmaf(w10, v10.y, acc.y);
-        acc.z = fmaf(w10, v10.z, acc.z); acc.w = fmaf(w10, v10.w, acc.w);
-        acc.x = fmaf(w11, v11.x, acc.x); acc.y = fmaf(w11, v11.y, acc.y);
-        acc.z = fmaf(w11, v11.z, acc.z); acc.w = fmaf(w11, v11.w, acc.w);
+        off[l][0] = (r0 + xa) * pix_stride + lane_off;
+        off[l][1] = (r0 + xb) * pix_stride + lane_off;
+        off[l][2] = (r1 + xa) * pix_stride + lane_off;
+        off[l][3] = (r1 + xb) * pix_stride + lane_off;
+      }
+      float4 val[LMAX][4];
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        if (LT == 0 && l >= L) break;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) val[l][c] = Quad<VT>::load(vrow + off[l][c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        if (LT == 0 && l >= L) break;
+        const float wl = aw[l * kPoints + k] * cwk;
+        const float dx = fx[l], dy = fy[l];
+        const unsigned ok = okm >> (4 * l);
+        const float w00 = ((ok & 5u) == 5u) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
+        const float w01 = ((ok & 6u) == 6u) ? wl * dx * (1.f - dy) : 0.f;
+        const float w10 = ((ok & 9u) == 9u) ? wl * (1.f - dx) * dy : 0.f;
+        const float w11 = ((ok & 10u) == 10u) ? wl * dx * dy : 0.f;
+        const float wc[4] = {w00, w01, w10, w11};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc.x = fmaf(wc[c], val[l][c].x, acc.x); acc.y = fmaf(wc[c], val[l][c].y, acc.y);
+          acc.z = fmaf(wc[c], val[l][c].z, acc.z); acc.w = fmaf(wc[c], val[l][c].w, acc.w);
+        }
       }
     }
   }
@@ -355,7 +378,7 @@ static int cross_attn_variant() {
 template <typename VT, int HH, int LT>
 static void launch_one(const CrossAttnParams& p, hipStream_t s) {
   const dim3 grid(p.B * p.Q);
-  if (cross_attn_variant() == 1) {
+  if (cross_attn_variant() == 1 && !p.head_major) {
     const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
     hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, LT>), grid, dim3(GD4D_WAVE), lds, s, p);
   } else {
@@ -395,7 +418,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
                                    const float* cam_logits, const float* lidar2img,
                                    const double* pc_range, float img_h, float img_w, float* out,
                                    uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
-                                   int Dh, int L, int P, int value_dtype, void* stream) {
+                                   int Dh, int L, int P, int value_dtype, int value_layout, void* stream) {
   using namespace gd4d;
   if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img ||
       !pc_range || !out)
@@ -404,6 +427,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
     return GD4D_EINVAL;
   if (Hh * Dh != kChannels || P != kPoints || L > GD4D_MAX_LEVELS || N > 64) return GD4D_EUNSUPPORTED;
   if (value_dtype != GD4D_F32 && value_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
+  if (value_layout != GD4D_LAYOUT_PIXEL_MAJOR && value_layout != GD4D_LAYOUT_HEAD_MAJOR) return GD4D_EUNSUPPORTED;
   if (!aligned16(value) || !aligned16(out)) return GD4D_EALIGN;
 
   CrossAttnParams p{};
@@ -411,6 +435,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
   p.cam_logits = cam_logits; p.lidar2img = lidar2img; p.out = out; p.mask_out = mask_out;
   p.uv_out = uv_out;
   p.B = B; p.N = N; p.Q = Q; p.L = L;
+  p.head_major = value_layout == GD4D_LAYOUT_HEAD_MAJOR;
   int start = 0;
   for (int l = 0; l < L; ++l) {
     const int h = level_hw[2 * l], w = level_hw[2 * l + 1];

@@ -53,6 +53,7 @@ struct ValueProjParams {
   const float* bias[GD4D_MAX_LAYERS];     // (C) or null
   void* out[GD4D_MAX_LAYERS];             // (R, S, C)
   int R, L, S, NL;
+  int head_major, Hh, Dh;                 // output layout: (R, S, C) or (R, Hh, S, Dh)
   int xcd_groups;                         // 1: layer groups co-located per XCD (grid % (8*NL) == 0)
   int dbg;                                // dev ablation bits (GD4D_VP_DBG): 1 = skip stores, 2 = skip MFMAs
 };
@@ -256,7 +257,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 #define GD4D_SGPR(x) __builtin_amdgcn_readfirstlane(x)
 
-template <bool OUT_BF16, int DBG>   // DBG: compile-time ablation bits (dev only; production = 0)
+template <bool OUT_BF16, int DBG, bool HEAD_MAJOR = false>   // DBG: compile-time ablation bits (dev only; production = 0)
 __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const ValueProjParams p) {
   constexpr int BM = 32;
   constexpr int RAW = VP_C * BM * 4;               // bytes of one raw [256 ci][32 pix] fp32 image
@@ -419,11 +420,20 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
 
   f32x16 prev;                                     // accumulators of the previous tile, stored one interval later
   int prow = 0, prem = 0;                          // its first output pixel row / valid pixel rows
+  // head-major: element offset of this lane's (head, channel) inside a camera row's planes
+  const size_t hm_base = (size_t)((32 * wave + col) / p.Dh) * p.S * p.Dh + (32 * wave + col) % p.Dh;
+  int pcam = 0, ppix = 0;                          // camera row / first pixel (in-row) of the previous tile
   // store accumulator row r of the previous tile (one store instruction)
   auto store_one = [&](int r, bool full) {
     if (DBG & 1) { asm volatile("" ::"v"(prev[r])); return; }
     const int dp = (r & 3) + 8 * (r >> 2);
-    const size_t o = ((size_t)prow + 4 * kg + dp) * VP_C + 32 * wave + col;
+    size_t o;
+    if (HEAD_MAJOR) {
+      // prow = cam_row * S + pixel-in-row; plane (cam_row, head) holds S x Dh elements
+      o = hm_base + (size_t)(pcam * p.Hh) * p.S * p.Dh + (size_t)(ppix + 4 * kg + dp) * p.Dh;
+    } else {
+      o = ((size_t)prow + 4 * kg + dp) * VP_C + 32 * wave + col;
+    }
     if (full || dp + 4 * kg < prem) {
       if (OUT_BF16) static_cast<uint16_t*>(outp)[o] = f32_to_bf16(prev[r]);
       else static_cast<float*>(outp)[o] = prev[r];
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
 #pragma unroll
     for (int r = 0; r < 16; ++r) prev[r] = acc0[r] + acc1[r];
     prow = orow0; prem = orem0;
+    if (HEAD_MAJOR) { pcam = GD4D_SGPR(prow / p.S); ppix = GD4D_SGPR(prow - pcam * p.S); }   // once per tile
     orow0 = orow1; orem0 = orem1; orow1 = orow2; orem1 = orem2;
     // Raw barrier + explicit waits (a __syncthreads() here makes the compiler drain vmcnt(0), i.e. wait
     // for every store of the previous tile).  Needed before the barrier: this wave's LDS writes done
@@ -545,7 +556,7 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
   if (slots < 1) slots = 1;
   if (slots > base) slots = base;
   const int grid = slots * NL;
-  if (BM == 32 && vp_variant() == 2) {
+  if (BM == 32 && (vp_variant() == 2 || p.head_major)) {
     // co-locate the NL workgroups of a slot on one XCD: grid = 8 XCDs x (cus/8 rounded down to a multiple of NL)
     int g2 = grid;
     p.xcd_groups = 0;
@@ -567,7 +578,10 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
       case 7: go(value_proj_pipe_kernel<false, 7>); break;
       case 31: go(value_proj_pipe_kernel<false, 31>); break;
       case 32: go(value_proj_pipe_kernel<false, 32>); break;
-      default: if (ob) go(value_proj_pipe_kernel<true, 0>); else go(value_proj_pipe_kernel<false, 0>); break;
+      default:
+        if (p.head_major) { if (ob) go(value_proj_pipe_kernel<true, 0, true>); else go(value_proj_pipe_kernel<false, 0, true>); }
+        else { if (ob) go(value_proj_pipe_kernel<true, 0>); else go(value_proj_pipe_kernel<false, 0>); }
+        break;
     }
     return check_launch();
   }
@@ -590,13 +604,15 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
 
 extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                                          const float* const* weights, const float* const* biases,
-                                         void* const* outs, int R, int C, int L, int NL, int in_dtype,
-                                         int out_dtype, void* stream) {
+                                         void* const* outs, int R, int C, int L, int NL, int Hh,
+                                         int in_dtype, int out_dtype, int out_layout, void* stream) {
   using namespace gd4d;
   if (!feats || !level_hw || !weights || !outs) return GD4D_EINVAL;
   if (R <= 0 || C <= 0 || L <= 0 || NL <= 0) return GD4D_EINVAL;
   if (C != VP_C || L > GD4D_MAX_LEVELS || NL > GD4D_MAX_LAYERS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
   if (out_dtype != GD4D_F32 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
+  if (out_layout != GD4D_LAYOUT_PIXEL_MAJOR && out_layout != GD4D_LAYOUT_HEAD_MAJOR) return GD4D_EUNSUPPORTED;
+  if (Hh <= 0 || C % Hh != 0) return GD4D_EINVAL;
   ValueProjParams p{};
   for (int l = 0; l < L; ++l) {
     if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
@@ -610,18 +626,19 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
     p.out[i] = outs[i];
   }
   p.R = R; p.L = L; p.NL = NL;
+  p.head_major = out_layout == GD4D_LAYOUT_HEAD_MAJOR; p.Hh = Hh; p.Dh = C / Hh;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GD4D_VP_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return vp_tile_pixels() == 64 ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
-                                : vp_launch<32>(p, level_hw, R, L, NL, out_dtype, st);
+  return (vp_tile_pixels() == 64 && !p.head_major) ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
+                                                   : vp_launch<32>(p, level_hw, R, L, NL, out_dtype, st);
 }
 
 extern "C" int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
-                                   const float* bias, void* out, int R, int C, int L, int in_dtype,
-                                   int out_dtype, void* stream) {
+                                   const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
+                                   int out_dtype, int out_layout, void* stream) {
   if (!weight || !out) return GD4D_EINVAL;
   const float* ws[1] = {weight};
   const float* bs[1] = {bias};
   void* os[1] = {out};
-  return gd4d_value_proj_multi_fwd(feats, level_hw, ws, bs, os, R, C, L, 1, in_dtype, out_dtype, stream);
+  return gd4d_value_proj_multi_fwd(feats, level_hw, ws, bs, os, R, C, L, 1, Hh, in_dtype, out_dtype, out_layout, stream);
 }

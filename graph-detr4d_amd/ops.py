@@ -33,17 +33,18 @@ def _value_dtype(t):
 
 
 def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                   img_h, img_w, want_mask=False, want_uv=False, out=None):
-    """gd4d_cross_attn_fwd.  value (B*N, S, Hh, Dh); ref (B,Q,3); offsets (B,Q,Hh,P,3);
+                   img_h, img_w, want_mask=False, want_uv=False, out=None, head_major=False):
+    """gd4d_cross_attn_fwd.  value (B*N, S, Hh, Dh), or (B*N, Hh, S, Dh) with head_major=True;
+    ref (B,Q,3); offsets (B,Q,Hh,P,3);
     attn_logits (B,Q,Hh,L,P) (or (B,Q,Hh,L*P)); cam_logits (B,Q,N); lidar2img (B,N,4,4).
     Returns out (B,Q,Hh*Dh) [, mask (B,N,Q,Hh,P) uint8] [, uv (B,N,Q,Hh,P,2)]."""
     lib = _lib.load()
     b, q = ref.shape[0], ref.shape[1]
     n = lidar2img.shape[1]
-    hh, dh = value.shape[2], value.shape[3]
+    hh, dh = (value.shape[1], value.shape[3]) if head_major else (value.shape[2], value.shape[3])
     p = offsets.shape[3]
     nl = len(level_hw)
-    if value.shape[0] != b * n or value.shape[1] != sum(h * w for h, w in level_hw):
+    if value.shape[0] != b * n or value.shape[2 if head_major else 1] != sum(h * w for h, w in level_hw):
         raise ValueError(f'value shape {tuple(value.shape)} inconsistent with B*N={b * n}, '
                          f'levels {level_hw}')
     if attn_logits.numel() != b * q * hh * nl * p or cam_logits.numel() != b * q * n:
@@ -60,7 +61,8 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
         _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32),
         _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(out, 'out', f32),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None,
-        b, n, q, hh, dh, nl, p, _value_dtype(value), _stream())
+        b, n, q, hh, dh, nl, p, _value_dtype(value), _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR,
+        _stream())
     _lib.check(code, 'gd4d_cross_attn_fwd')
     res = (out,)
     if want_mask:
@@ -99,9 +101,10 @@ def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_
     return dict(out=out, mask=mask, sampled=sampled)
 
 
-def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None):
+def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None, num_heads=8, head_major=False):
     """gd4d_value_proj_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) or (R, C, H_l, W_l) fp32;
-    weight (C, C); bias (C) or None.  Returns (R, S, C) in `out_dtype`."""
+    weight (C, C); bias (C) or None.  Returns (R, S, C) in `out_dtype`, or (R, Hh, S, C/Hh) with
+    head_major=True."""
     lib = _lib.load()
     f32 = torch.float32
     c = weight.shape[0]
@@ -109,19 +112,21 @@ def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None):
     nl = len(feats)
     s = sum(f.shape[-1] * f.shape[-2] for f in feats)
     if out is None:
-        out = torch.empty(r, s, c, device=weight.device, dtype=out_dtype)
+        shape = (r, num_heads, s, c // num_heads) if head_major else (r, s, c)
+        out = torch.empty(*shape, device=weight.device, dtype=out_dtype)
     ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
     code = lib.gd4d_value_proj_fwd(ptrs, lv, _dev(weight, 'weight', f32),
                                    _dev(bias, 'bias', f32) if bias is not None else None,
-                                   _dev(out, 'out'), r, c, nl, _lib.F32, _value_dtype(out), _stream())
+                                   _dev(out, 'out'), r, c, nl, num_heads, _lib.F32, _value_dtype(out),
+                                   _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR, _stream())
     _lib.check(code, 'gd4d_value_proj_fwd')
     return out
 
 
-def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32):
+def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_heads=8, head_major=False):
     """gd4d_value_proj_multi_fwd: project the same pyramid with NL (weight, bias) pairs in one
-    launch.  Returns a list of NL tensors (R, S, C)."""
+    launch.  Returns a list of NL tensors (R, S, C) (or (R, Hh, S, C/Hh) with head_major=True)."""
     lib = _lib.load()
     f32 = torch.float32
     nlayers = len(weights)
@@ -129,15 +134,17 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32):
     r = feats[0].numel() // (c * feats[0].shape[-1] * feats[0].shape[-2])
     nl = len(feats)
     s = sum(f.shape[-1] * f.shape[-2] for f in feats)
-    outs = [torch.empty(r, s, c, device=weights[0].device, dtype=out_dtype) for _ in range(nlayers)]
+    shape = (r, num_heads, s, c // num_heads) if head_major else (r, s, c)
+    outs = [torch.empty(*shape, device=weights[0].device, dtype=out_dtype) for _ in range(nlayers)]
     ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
     wp = (ctypes.c_void_p * nlayers)(*[_dev(w, 'weight', f32).value for w in weights])
     bp = (ctypes.c_void_p * nlayers)(*[(_dev(b, 'bias', f32).value if b is not None else None)
                                        for b in biases])
     op = (ctypes.c_void_p * nlayers)(*[_dev(o, 'out').value for o in outs])
-    code = lib.gd4d_value_proj_multi_fwd(ptrs, lv, wp, bp, op, r, c, nl, nlayers, _lib.F32,
-                                         _value_dtype(outs[0]), _stream())
+    code = lib.gd4d_value_proj_multi_fwd(ptrs, lv, wp, bp, op, r, c, nl, nlayers, num_heads, _lib.F32,
+                                         _value_dtype(outs[0]),
+                                         _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR, _stream())
     _lib.check(code, 'gd4d_value_proj_multi_fwd')
     return outs
 

@@ -29,9 +29,15 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 1
+#define GD4D_ABI_VERSION 2
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
+
+/* Layout of the projected value tensor (output of gd4d_value_proj_*, input of gd4d_cross_attn_fwd):
+ *   PIXEL_MAJOR (B*N, S, Hh, Dh) - what mmcv's MultiScaleDeformableAttnFunction takes (deform3d_cross_attn.py:280)
+ *   HEAD_MAJOR  (B*N, Hh, S, Dh) - one contiguous S x Dh plane per (camera, head): the two x-adjacent
+ *                bilinear corners of a head are one contiguous 2*Dh run (better DRAM locality). */
+enum { GD4D_LAYOUT_PIXEL_MAJOR = 0, GD4D_LAYOUT_HEAD_MAJOR = 1 };
 
 enum {
   GD4D_OK = 0,
@@ -60,7 +66,7 @@ const char* gd4d_last_hip_error(void);
  *   :301-304  MultiScaleDeformableAttnFunction.apply (third-party mmcv CUDA kernel)
  *   :320-324  sigmoid camera weights (raw-view "scramble" of :211-212 applied here) and sum over cameras
  *
- *   value        (B*N, S, Hh, Dh)  S = sum_l H_l*W_l; output of value_proj, channels-last head-major
+ *   value        (B*N, S, Hh, Dh) or (B*N, Hh, S, Dh) per `value_layout`; S = sum_l H_l*W_l; output of value_proj
  *   level_hw     host, L x 2 int32 (H_l, W_l)       (reference: spatial_shapes, :271)
  *   ref          (B, Q, 3) fp32 in [0,1]            (reference_points)
  *   offsets      (B, Q, Hh, P, 3) fp32 metres       (deform_sampling_offsets(query), :227)
@@ -86,7 +92,7 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
                         const float* offsets, const float* attn_logits, const float* cam_logits,
                         const float* lidar2img, const double* pc_range, float img_h, float img_w,
                         float* out, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
-                        int Dh, int L, int P, int value_dtype, void* stream);
+                        int Dh, int L, int P, int value_dtype, int value_layout, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_detr3d_fwd - DETR3D-baseline core: feature_sampling (detr3d_transformer.py:397-438) fused
@@ -124,15 +130,15 @@ int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const flo
  *   feats     host array of L device pointers; level l = (R, C, H_l, W_l) fp32 NCHW, R = B*N
  *   level_hw  host, L x 2 int32
  *   weight    (C, C) fp32 row-major [out][in]   (value_proj.weight);  bias (C) fp32 or NULL
- *   out       (R, S, C) `out_dtype` (GD4D_F32 | GD4D_BF16), S = sum_l H_l*W_l; C = Hh*Dh so the
- *             buffer is also (R, S, Hh, Dh)
+ *   out       `out_dtype` (GD4D_F32 | GD4D_BF16); (R, S, C) = (R, S, Hh, Dh) for GD4D_LAYOUT_PIXEL_MAJOR,
+ *             (R, Hh, S, C/Hh) for GD4D_LAYOUT_HEAD_MAJOR;  S = sum_l H_l*W_l
  * Arithmetic: split-bf16 x3 MFMA with fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi):
  * fp32-class accuracy (<= ~2^-17 relative per product), see DESIGN.md.
  * Supported: C == 256, in_dtype == GD4D_F32, L <= 8.  No workspace.
  */
 int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
-                        const float* bias, void* out, int R, int C, int L, int in_dtype,
-                        int out_dtype, void* stream);
+                        const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
+                        int out_dtype, int out_layout, void* stream);
 size_t gd4d_value_proj_workspace_bytes(void);
 
 /* gd4d_value_proj_multi_fwd - the same projection for NL decoder layers in ONE launch.
@@ -143,8 +149,8 @@ size_t gd4d_value_proj_workspace_bytes(void);
  * be NULL).  NL <= GD4D_MAX_LAYERS.  Results are bit-identical to NL gd4d_value_proj_fwd calls. */
 int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                               const float* const* weights, const float* const* biases,
-                              void* const* outs, int R, int C, int L, int NL, int in_dtype,
-                              int out_dtype, void* stream);
+                              void* const* outs, int R, int C, int L, int NL, int Hh, int in_dtype,
+                              int out_dtype, int out_layout, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_linear_fwd - the decoder's small dense layers on the fp32 MFMA, with the elementwise

@@ -29,13 +29,17 @@ def _inputs(g, dev, value_dtype=torch.float32):
     return args, dev_args, m
 
 
+@pytest.mark.parametrize('head_major', [False, True])
 @pytest.mark.parametrize('name', DEFORM_CASES)
-def test_fused_kernel_matches_reference_golden(name):
+def test_fused_kernel_matches_reference_golden(name, head_major):
     from graph_detr4d_amd import ops
     g = Golden(name)
     args, d, m = _inputs(g, 'cuda')
+    if head_major:                         # (B*N, S, Hh, Dh) -> (B*N, Hh, S, Dh) planes
+        d['value'] = d['value'].permute(0, 2, 1, 3).contiguous()
     out, mask, uv = ops.cross_attn_fwd(**d, pc_range=m['pc_range'], img_h=m['img_shape'][0],
-                                       img_w=m['img_shape'][1], want_mask=True, want_uv=True)
+                                       img_w=m['img_shape'][1], want_mask=True, want_uv=True,
+                                       head_major=head_major)
     b, n, q = m['batch'], m['num_cams'], m['num_query']
     gmask = g.t('mask').view(b, n, q, 8, 4, 4)[..., 0, :]          # (B,N,Q,Hh,P): equal for all levels
     guv = g.t('uv').view(b, n, q, 8, 4, 4, 2)[..., 0, :, :]

@@ -75,3 +75,18 @@ def test_multi_layer_projection_is_bit_identical_to_single_calls():
     multi = ops.value_proj_multi_fwd(feats, ws, bs)
     for w, b, m in zip(ws, bs, multi):
         assert torch.equal(m, ops.value_proj_fwd(feats, w, b))
+
+
+@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
+def test_head_major_layout_is_a_permutation_of_pixel_major(out_dtype):
+    """GD4D_LAYOUT_HEAD_MAJOR output (R, Hh, S, Dh) == pixel-major (R, S, Hh, Dh) permuted, bit for bit."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(10)
+    feats = [torch.randn(5, 256, h, w).cuda() for h, w in [(20, 36), (10, 18), (5, 9), (3, 5)]]
+    w, b = (torch.randn(256, 256) * 0.06).cuda(), torch.randn(256).cuda()
+    pm = ops.value_proj_fwd(feats, w, b, out_dtype)
+    hm = ops.value_proj_fwd(feats, w, b, out_dtype, head_major=True)
+    assert hm.shape == (5, 8, pm.shape[1], 32)
+    assert torch.equal(hm, pm.view(5, -1, 8, 32).permute(0, 2, 1, 3))
+    hm6 = ops.value_proj_multi_fwd(feats, [w] * 3, [b] * 3, out_dtype, head_major=True)
+    assert all(torch.equal(x, hm) for x in hm6)

@@ -15,8 +15,11 @@ def main():
     ap.add_argument('--frames', type=int, default=4)
     ap.add_argument('--queries', type=int, default=900)
     ap.add_argument('--dtype', default='f32')
-    ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--iters', type=int, default=60)
     ap.add_argument('--all-visible', action='store_true')
+    ap.add_argument('--head-major', action='store_true')
+    ap.add_argument('--rotate', type=int, default=6,
+                    help='distinct value tensors to rotate through (cache-cold like the real decoder; 1 = warm)')
     a = ap.parse_args()
     dev = 'cuda'
     n, q = 6 * a.frames, a.queries
@@ -25,6 +28,11 @@ def main():
     g = torch.Generator().manual_seed(0)
     dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
     val = torch.randn(n, s, 8, 32, generator=g).to(dev, dt)
+    vals = [val] + [torch.randn_like(val) for _ in range(a.rotate - 1)]
+    if a.head_major:
+        vals = [v.permute(0, 2, 1, 3).contiguous() for v in vals]
+        val = vals[0]
+    hm = dict(head_major=a.head_major)
     rig = synthetic.camera_rig(a.frames)
     if a.all_visible:
         rig[:] = rig[0]
@@ -39,22 +47,22 @@ def main():
     attn = torch.randn(1, q, 8, 4, 4, generator=g).to(dev)
     cam = torch.randn(1, q, n, generator=g).to(dev)
     out, mask = ops.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600,
-                                   want_mask=True)
+                                   want_mask=True, **hm)
     vis = int(mask.sum().item())
     es = val.element_size()
     alg = vis * 4 * 4 * 32 * es + q * (3 + 96 + 128 + n) * 4 + n * 64 + q * 256 * 4
     alg = min(alg, val.numel() * es + q * 256 * 4)
     for _ in range(5):
-        ops.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, out=out)
+        ops.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, out=out, **hm)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(a.iters):
-        ops.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, out=out)
+    for i in range(a.iters):
+        ops.cross_attn_fwd(vals[i % len(vals)], levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, out=out, **hm)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    print(f'N={n} Q={q} {a.dtype} visible(h,p) tuples={vis} ({vis / mask.numel():.3f}) '
+    print(f'head_major={int(a.head_major)} rotate={a.rotate} N={n} Q={q} {a.dtype} visible(h,p) tuples={vis} ({vis / mask.numel():.3f}) '
           f'alg_bytes={alg / 1e6:.1f} MB  {ms * 1e3:.1f} us  {alg / ms / 1e9:.2f} TB/s  '
           f'frac_of_8TB/s={alg / ms / 1e9 / 8:.3f}')
 

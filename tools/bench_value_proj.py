@@ -16,13 +16,14 @@ def main():
     ap.add_argument('--layers', type=int, default=1)
     ap.add_argument('--out', default='f32')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--head-major', action='store_true')
     a = ap.parse_args()
     dev = 'cuda'
     feats = [torch.randn(a.cams, 256, h, w, device=dev) for h, w in synthetic.R50_LEVELS]
     ws = [torch.randn(256, 256, device=dev) * 0.06 for _ in range(a.layers)]
     bs = [torch.randn(256, device=dev) for _ in range(a.layers)]
     odt = torch.float32 if a.out == 'f32' else torch.bfloat16
-    run = lambda: ops.value_proj_multi_fwd(feats, ws, bs, odt)  # noqa: E731
+    run = lambda: ops.value_proj_multi_fwd(feats, ws, bs, odt, head_major=a.head_major)  # noqa: E731
     outs = run()
     for _ in range(2):
         run()
@@ -37,7 +38,7 @@ def main():
     rd = sum(f.numel() * 4 for f in feats)
     wr = sum(o.numel() * o.element_size() for o in outs)
     fl = 2 * 256 * 256 * sum(f.shape[0] * f.shape[2] * f.shape[3] for f in feats) * a.layers
-    print(f'cams={a.cams} layers={a.layers} out={a.out} BM={os.environ.get("GD4D_VP_BM", "32")}: {ms * 1e3:.1f} us  '
+    print(f'head_major={int(a.head_major)} cams={a.cams} layers={a.layers} out={a.out} BM={os.environ.get("GD4D_VP_BM", "32")}: {ms * 1e3:.1f} us  '
           f'min-bytes {(rd + wr) / 1e6:.0f} MB -> {(rd + wr) / ms / 1e9:.2f} TB/s  '
           f'{fl / ms / 1e9:.0f} TFLOP/s (x3 MFMA work: {3 * fl / ms / 1e9:.0f})')
 
