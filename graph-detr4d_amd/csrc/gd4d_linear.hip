@@ -97,6 +97,38 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
     return f32x4{v[0], v[1], v[2], v[3]};
   };
 
+  // Epilogue operands (bias, residuals) are requested NOW by the wave that will need them, so their
+  // memory latency overlaps the K loop instead of following the reduction.
+  float pre_bias[2] = {0.f, 0.f};
+  float pre_res[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre_res[a][c][r] = 0.f;
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = n0 + 16 * c + i16;
+      if (n < p.N) {
+        if (p.bias) pre_bias[c] = p.bias[n];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * a + 4 * g + r;
+            if (m < p.M) {
+              float t = 0.f;
+              if (p.r1) t += p.r1[(size_t)m * p.ldr1 + n];
+              if (p.r2) t += p.r2[(size_t)m * p.ldr2 + n];
+              pre_res[a][c][r] = t;
+            }
+          }
+      }
+    }
+  }
+
   for (int kc = wave * LN_KC; kc < p.K; kc += LN_KC * LN_WAVES) {
     f32x4 av[4][2], bv[4][2];
 #pragma unroll
@@ -135,7 +167,6 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int n = n0 + 16 * c + i16;
-        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[a][c][r];
@@ -143,10 +174,9 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
           for (int w = 0; w < LN_WAVES - 1; ++w) v += s_part[w][(a * 2 + c) * 4 + r][lane];
           const int m = m0 + 16 * a + 4 * g + r;
           if (m < p.M && n < p.N) {
-            v += bias;
+            v += pre_bias[c];
             if (p.flags & 1) v = fmaxf(v, 0.f);
-            if (p.r1) v += p.r1[(size_t)m * p.ldr1 + n];
-            if (p.r2) v += p.r2[(size_t)m * p.ldr2 + n];
+            v += pre_res[a][c][r];
             p.y[(size_t)m * p.ldy + n] = v;
           }
         }
