@@ -24,6 +24,7 @@ SIGNATURES = {
     'gd4d_last_hip_error': (_c.c_char_p, []),
     'gd4d_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_cross_attn_bwd': (_i, [_vp] * 8 + [_f, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),
     'gd4d_detr3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                              _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

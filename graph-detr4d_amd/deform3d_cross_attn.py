@@ -92,7 +92,8 @@ class Deform3DCrossAttn(nn.Module):
             raise TypeError('value must be the list of multi-camera feature maps (B, N, C, H, W)')
         img_metas = kwargs['img_metas']
         Fn.require_gpu(query, 'query')
-        Fn.require_inference(query, query_pos, reference_points, *value)
+        if Fn.wants_grad(self, query, query_pos, reference_points, *value):
+            return self._forward_autograd(query, value, query_pos, reference_points, img_metas)
 
         inp_residual = query
         q_len, b, c = query.shape
@@ -141,3 +142,31 @@ class Deform3DCrossAttn(nn.Module):
                              r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
         return self.dropout(out) + inp_residual + pos_feat.permute(1, 0, 2)
+
+    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
+        """Training path: the same maths with autograd.  The gather runs gd4d_cross_attn_fwd/_bwd, value_proj
+        runs the HIP forward with a GEMM backward, the small dense layers are torch ops."""
+        import torch.nn.functional as F
+        from .autograd import CrossAttnFunction, ValueProjFunction
+        inp_residual = query
+        x = query if query_pos is None else query + query_pos
+        x = x.permute(1, 0, 2)                                            # (B, Q, C)
+        b, q, c = x.shape
+        hh, npt, nl = self.num_heads, self.num_points, self.num_levels
+        cam_logits = self.cam_attention_weights(x)                        # un-scrambled (B, Q, N)
+        offsets = self.deform_sampling_offsets(x).view(b, q, hh, npt, 3)
+        attn_logits = self.attention_weights(x).view(b, q, hh, nl, npt)
+        shapes = [tuple(v.shape[-2:]) for v in value]
+        val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)
+        val = val.view(val.shape[0], -1, hh, c // hh)
+        lidar2img = Fn.lidar2img_device(img_metas, query)
+        img_h, img_w = Fn.img_hw(img_metas)
+        agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
+                                      shapes, self.pc_range, img_h, img_w)
+        out = self.output_proj(agg).permute(1, 0, 2)
+        ref3d = reference_points
+        if self.depth_encode:
+            depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
+            ref3d = torch.cat([ref3d, depth], dim=-1)
+        pos_feat = self.position_encoder(Fn.inverse_sigmoid(ref3d)).permute(1, 0, 2)
+        return self.dropout(out) + inp_residual + pos_feat

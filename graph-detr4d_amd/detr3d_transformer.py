@@ -123,6 +123,8 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         if not isinstance(value, (list, tuple)) or len(value) == 0 or not value[0].is_cuda:
             return kwargs
         mods = [a for layer in self.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
+        if mods and Fn.wants_grad(mods[0], *value):
+            return kwargs
         if len(mods) < 2 or len(mods) > 8 or len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) != 1:
             return kwargs
         Fn.require_inference(*value)
@@ -138,8 +140,10 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points, **kwargs)
             if reg_branches is not None:
                 assert reference_points.shape[-1] == 3
-                tmp = Fn.run_branch(reg_branches[lid], output.permute(1, 0, 2).contiguous())
-                if tmp.is_cuda and tmp.dtype == torch.float32:
+                grad = Fn.wants_grad(reg_branches[lid], output)
+                tmp = reg_branches[lid](output.permute(1, 0, 2)) if grad else \
+                    Fn.run_branch(reg_branches[lid], output.permute(1, 0, 2).contiguous())
+                if tmp.is_cuda and tmp.dtype == torch.float32 and not grad:
                     reference_points = Fn.refine_reference(tmp, reference_points).detach()
                 else:
                     new_ref = torch.zeros_like(reference_points)

@@ -6,12 +6,20 @@ import torch.nn.functional as F
 from . import _lib, ops
 
 
+def wants_grad(module, *tensors):
+    """True when autograd must see this call: grad mode on and a parameter or input requires grad."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors):
+        return True
+    return module is not None and any(p.requires_grad for p in module.parameters())
+
+
 def require_inference(*tensors):
-    """The HIP path is forward-only for now: refuse silently-wrong autograd use."""
+    """Forward-only entry points: refuse silently-wrong autograd use."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            'graph-detr4d_amd: backward kernels are not built yet - call the decoder under '
-            'torch.no_grad() (inference / evaluation)')
+            'graph-detr4d_amd: this entry point has no backward - call it under torch.no_grad()')
 
 
 def require_gpu(t, name):

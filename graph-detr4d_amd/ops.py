@@ -228,3 +228,30 @@ def refine_reference_fwd(tmp, ref):
                                          _dev(out, 'out'), ref.numel() // 3, tmp.shape[-1], _stream())
     _lib.check(code, 'gd4d_refine_reference_fwd')
     return out
+
+
+def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
+                   grad_out):
+    """gd4d_cross_attn_bwd.  Returns (grad_value, grad_ref, grad_offsets, grad_attn_logits, grad_cam_logits)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    b, q = ref.shape[0], ref.shape[1]
+    n = lidar2img.shape[1]
+    hh, dh = value.shape[2], value.shape[3]
+    p = offsets.shape[3]
+    nl = len(level_hw)
+    gv = torch.zeros_like(value, dtype=f32)
+    gr = torch.empty_like(ref)
+    go = torch.empty(b, q, hh, p, 3, device=ref.device, dtype=f32)
+    ga = torch.empty(b, q, hh, nl, p, device=ref.device, dtype=f32)
+    gc = torch.empty(b, q, n, device=ref.device, dtype=f32)
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    code = lib.gd4d_cross_attn_bwd(
+        _dev(value, 'value', f32), lv, _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32),
+        _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32),
+        _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(grad_out, 'grad_out', f32),
+        _dev(gv, 'grad_value'), _dev(gr, 'grad_ref'), _dev(go, 'grad_offsets'), _dev(ga, 'grad_attn_logits'),
+        _dev(gc, 'grad_cam_logits'), b, n, q, hh, dh, nl, p, _lib.F32, _lib.PIXEL_MAJOR, _stream())
+    _lib.check(code, 'gd4d_cross_attn_bwd')
+    return gv, gr, go, ga, gc

@@ -67,10 +67,10 @@ class MultiheadAttention(nn.Module):
         if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
             key_pos = query_pos
         Fn.require_gpu(query, 'query')
-        Fn.require_inference(query, key, value, query_pos)
         if key_padding_mask is not None:
             raise NotImplementedError('key_padding_mask is never set on the decoder self-attention path')
-        eval_mode = not self.training
+        grad = Fn.wants_grad(self, query, key, value, query_pos)
+        eval_mode = not self.training and not grad
         if (eval_mode and not self.batch_first and key is query and value is query
                 and query_pos is not None and key_pos is query_pos and identity.shape == query.shape):
             return self._packed_self_attention(query, query_pos, attn_mask, identity)
@@ -78,7 +78,8 @@ class MultiheadAttention(nn.Module):
         k_in = key if key_pos is None else key + key_pos
         if self.batch_first:
             q_in, k_in, value = (t.transpose(0, 1) for t in (q_in, k_in, value))
-        out = self._attention(q_in, k_in, value, attn_mask)
+        out = self._attention_autograd(q_in, k_in, value, attn_mask) if grad else \
+            self._attention(q_in, k_in, value, attn_mask)
         if self.batch_first:
             out = out.transpose(0, 1)
         return identity + self.dropout_layer(self.proj_drop(out))
@@ -102,6 +103,25 @@ class MultiheadAttention(nn.Module):
         vh = Fn.linear(v_in, w[2 * c:], bias[2 * c:])
         o = ops.mha_core_fwd(qh, kh, vh, self.num_heads, attn_mask)
         return Fn.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
+
+
+    # training path (torch ops so autograd flows); attention-weight dropout as nn.MultiheadAttention applies it
+    def _attention_autograd(self, q_in, k_in, v_in, attn_mask):
+        c, h = self.embed_dims, self.num_heads
+        d = c // h
+        w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
+        lq, b, _ = q_in.shape
+        lk = k_in.shape[0]
+        qh = F.linear(q_in, w[:c], bias[:c]).reshape(lq, b * h, d).transpose(0, 1)
+        kh = F.linear(k_in, w[c:2 * c], bias[c:2 * c]).reshape(lk, b * h, d).transpose(0, 1)
+        vh = F.linear(v_in, w[2 * c:], bias[2 * c:]).reshape(lk, b * h, d).transpose(0, 1)
+        scores = torch.bmm(qh * (1.0 / math.sqrt(d)), kh.transpose(1, 2))
+        if attn_mask is not None:
+            scores = scores.masked_fill(attn_mask, float('-inf')) if attn_mask.dtype == torch.bool \
+                else scores + attn_mask
+        attn = F.dropout(scores.softmax(-1), p=self.attn_drop, training=self.training)
+        o = torch.bmm(attn, vh).transpose(0, 1).reshape(lq, b, c)
+        return F.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
 
 @FEEDFORWARD_NETWORK.register_module()
@@ -128,8 +148,7 @@ class FFN(nn.Module):
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
-        if not self.training and len(self.layers) == 3 and x.is_cuda:
-            Fn.require_inference(x)
+        if not self.training and len(self.layers) == 3 and x.is_cuda and not Fn.wants_grad(self, x, identity):
             hdn = Fn.linear(x, self.layers[0][0].weight, self.layers[0][0].bias, relu=True)
             res = (x if identity is None else identity) if self.add_identity else None
             return Fn.linear(hdn, self.layers[1].weight, self.layers[1].bias, r1=res)
@@ -205,7 +224,9 @@ class BaseTransformerLayer(nn.Module):
                 attn_i += 1
                 identity = query
             elif op == 'norm':
-                query = Fn.layer_norm(query, self.norms[norm_i]) if query.is_cuda else self.norms[norm_i](query)
+                norm = self.norms[norm_i]
+                query = Fn.layer_norm(query, norm) if (query.is_cuda and not Fn.wants_grad(norm, query)) \
+                    else norm(query)
                 norm_i += 1
             elif op == 'cross_attn':
                 query = self.attentions[attn_i](

@@ -202,6 +202,31 @@ int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void
  * tmp (M, ldt) = reg_branches[lid](output), ldt >= 5; ref, out (M, 3) fp32. */
 int gd4d_refine_reference_fwd(const float* tmp, const float* ref, float* out, int M, int ldt, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * gd4d_cross_attn_bwd - backward of gd4d_cross_attn_fwd.
+ *
+ * Replaces what autograd runs in the reference for deform3d_cross_attn.py:220-324: the third-party mmcv
+ * `ms_deformable_col2im` kernel (grad of value by atomic adds, grad of sampling locations and
+ * attention weights) plus the elementwise backward chain through softmax * mask, the sigmoid camera
+ * weights (with the raw-view scramble), the divisions and the lidar2img matmul.  The visibility
+ * mask carries no gradient (piecewise constant), as in the reference.
+ *
+ *   inputs as gd4d_cross_attn_fwd, plus grad_out (B, Q, Hh*Dh) = dL/d out
+ *   grad_value        same shape/layout as value, fp32, MUST be zero-filled by the caller (atomic adds)
+ *   grad_ref          (B, Q, 3)        dL/d reference_points (normalised units)
+ *   grad_offsets      (B, Q, Hh, P, 3) dL/d offsets (metres)
+ *   grad_attn_logits  (B, Q, Hh, L, P)
+ *   grad_cam_logits   (B, Q, N)        in the un-scrambled layout of cam_logits
+ * Supported: B == 1 (samples_per_gpu = 1, every training config), fp32 pixel-major value, L <= 4.
+ * Accumulation order of grad_value is not deterministic (fp32 atomics), like the mmcv kernel.
+ */
+int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, const float* ref, const float* offsets,
+                        const float* attn_logits, const float* cam_logits, const float* lidar2img,
+                        const double* pc_range, float img_h, float img_w, const float* grad_out,
+                        void* grad_value, float* grad_ref, float* grad_offsets, float* grad_attn_logits,
+                        float* grad_cam_logits, int B, int N, int Q, int Hh, int Dh, int L, int P,
+                        int value_dtype, int value_layout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
