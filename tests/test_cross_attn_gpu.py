@@ -122,3 +122,58 @@ def test_linearity_and_invisible_cameras_full_size():
                                 cam.reshape(b, -1)[:, :12 * q].reshape(b, q, 12).contiguous(),
                                 l2i[:, :12].contiguous(), synthetic.PC_RANGE, 900, 1600)
     torch.testing.assert_close(o_blind, o_half, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('heads,levels,n,q', [
+    (8, [(6, 9)], 1, 7),                                   # one camera, one level, odd query count
+    (8, [(12, 20), (6, 10)], 3, 33),
+    (8, [(12, 20), (6, 10), (3, 5)], 6, 40),
+    (8, [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 6, 21),   # 5 levels: runtime-L kernel path
+    (4, [(12, 20), (6, 10), (3, 5), (2, 3)], 6, 50),       # Dh = 64
+    (16, [(12, 20), (6, 10), (3, 5), (2, 3)], 6, 50),      # Dh = 16
+    (8, [(6, 10), (3, 5)], 64, 9),                         # the 64-camera maximum
+])
+def test_fused_kernel_shape_coverage_vs_c_oracle(heads, levels, n, q):
+    """Every compiled template path against the plain-C oracle (bit-exact mask / uv)."""
+    import numpy as np
+    from graph_detr4d_amd import ops
+    from oracle import c_oracle
+    rng = np.random.default_rng(heads * 1000 + n * 10 + len(levels))
+    dh = 256 // heads
+    s = sum(h * w for h, w in levels)
+    val = rng.standard_normal((n, s, heads, dh)).astype(np.float32)
+    ref = rng.random((1, q, 3)).astype(np.float32)
+    ref[..., 0] = 0.5 + 0.2 * ref[..., 0]                  # keep a good share of points in view
+    ref[..., 1] = 0.45 + 0.1 * ref[..., 1]
+    offsets = (rng.standard_normal((1, q, heads, 4, 3)) * 1.0).astype(np.float32)
+    attn = rng.standard_normal((1, q, heads, len(levels), 4)).astype(np.float32)
+    cam = rng.standard_normal((1, q, n)).astype(np.float32)
+    # n cameras fanned around the forward direction
+    from graph_detr4d_amd import synthetic
+    base = synthetic.camera_rig(max(1, (n + 5) // 6))[:n]
+    l2i = base[None].astype(np.float32)
+    pc = synthetic.PC_RANGE
+    o_ref, m_ref, uv_ref = c_oracle.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, pc, 900, 1600)
+    t = lambda a: torch.from_numpy(a).cuda()                # noqa: E731
+    out, mask, uv = ops.cross_attn_fwd(t(val), levels, t(ref), t(offsets), t(attn), t(cam), t(l2i), pc, 900, 1600,
+                                       want_mask=True, want_uv=True)
+    assert m_ref.sum() > 0
+    assert np.array_equal(mask.cpu().numpy(), m_ref)
+    assert np.array_equal(uv.cpu().numpy(), uv_ref)
+    np.testing.assert_allclose(out.cpu().numpy(), o_ref, rtol=1e-4, atol=1e-4)
+    # bf16 storage of the same values
+    vb = t(val).bfloat16()
+    o_b, _, _ = c_oracle.cross_attn_fwd(vb.float().cpu().numpy(), levels, ref, offsets, attn, cam, l2i, pc, 900, 1600)
+    out_b = ops.cross_attn_fwd(vb, levels, t(ref), t(offsets), t(attn), t(cam), t(l2i), pc, 900, 1600)
+    np.testing.assert_allclose(out_b.cpu().numpy(), o_b, rtol=1e-4, atol=1e-4)
+
+
+def test_unsupported_shapes_fail_loudly():
+    from graph_detr4d_amd import _lib, ops
+    z = lambda *s: torch.zeros(*s, device='cuda')           # noqa: E731
+    with pytest.raises(_lib.Gd4dError, match='not supported'):   # 5 points per head
+        ops.cross_attn_fwd(z(6, 4, 8, 32), [(2, 2)], z(1, 3, 3), z(1, 3, 8, 5, 3), z(1, 3, 8, 1, 5), z(1, 3, 6),
+                           z(1, 6, 4, 4), [0, 0, 0, 1, 1, 1], 8, 8)
+    with pytest.raises(_lib.Gd4dError, match='not supported'):   # embed_dims 128
+        ops.cross_attn_fwd(z(6, 4, 8, 16), [(2, 2)], z(1, 3, 3), z(1, 3, 8, 4, 3), z(1, 3, 8, 1, 4), z(1, 3, 6),
+                           z(1, 6, 4, 4), [0, 0, 0, 1, 1, 1], 8, 8)
