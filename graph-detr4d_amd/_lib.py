@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgd4d.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -27,13 +27,13 @@ SIGNATURES = {
     'gd4d_cross_attn_bwd': (_i, [_vp] * 8 + [_f, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),
     'gd4d_detr3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                              _i, _i, _i, _i, _i, _i, _vp]),
-    'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_workspace_bytes': (_c.c_size_t, []),
     'gd4d_linear_fwd': (_i, [_vp] * 7 + [_i] * 9 + [_vp]),
     'gd4d_layernorm_fwd': (_i, [_vp] * 5 + [_i, _i, _f, _i, _vp]),
     'gd4d_mha_core_fwd': (_i, [_vp] * 5 + [_i] * 10 + [_f, _vp]),
     'gd4d_refine_reference_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
-    'gd4d_value_proj_multi_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_value_proj_multi_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -55,6 +55,7 @@ struct ValueProjParams {
   int R, L, S, NL;
   int head_major, Hh, Dh;                 // output layout: (R, S, C) or (R, Hh, S, Dh)
   int xcd_groups;                         // 1: layer groups co-located per XCD (grid % (8*NL) == 0)
+  int single_product;                     // 1: bf16-class single product (GD4D_VP_PRECISION_BF16)
   int dbg;                                // dev ablation bits (GD4D_VP_DBG): 1 = skip stores, 2 = skip MFMAs
 };
 
@@ -257,7 +258,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 #define GD4D_SGPR(x) __builtin_amdgcn_readfirstlane(x)
 
-template <bool OUT_BF16, int DBG, bool HEAD_MAJOR = false>   // DBG: compile-time ablation bits (dev only; production = 0)
+// SINGLE: one bf16 product a_hi*w_hi (bf16-class accuracy, for bf16 value storage) instead of the
+// fp32-class three-product split: 1/3 of the MFMAs, no lo image (half the LDS traffic).
+template <bool OUT_BF16, int DBG, bool HEAD_MAJOR = false, bool SINGLE = false>   // DBG: compile-time ablation bits (dev only; production = 0)
 __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const ValueProjParams p) {
   constexpr int BM = 32;
   constexpr int RAW = VP_C * BM * 4;               // bytes of one raw [256 ci][32 pix] fp32 image
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
       split8(cv + 8 * c, h, l);
       const int off = lds_off(spix, 2 * scg + c);
       *reinterpret_cast<u32x4*>(img_base + off) = h;
-      *reinterpret_cast<u32x4*>(img_base + IMG + off) = l;
+      if (!SINGLE) *reinterpret_cast<u32x4*>(img_base + IMG + off) = l;
     }
   }
   __syncthreads();
@@ -482,8 +485,10 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
       if (!(DBG & 2)) {
         if (DBG & 32) __builtin_amdgcn_s_setprio(1);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[s], acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[s], acc1, 0, 0, 0);
+        if (!SINGLE) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[s], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[s], acc1, 0, 0, 0);
+        }
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
       } else {
         asm volatile("" ::"v"(ahi), "v"(alo));
@@ -494,11 +499,11 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
         split8(cv, h, l);
         const int woff = lds_off(spix, 2 * scg + (s >> 3));
         *reinterpret_cast<u32x4*>(nhi_img + woff) = h;
-        *reinterpret_cast<u32x4*>(nlo_img + woff) = l;
+        if (!SINGLE) *reinterpret_cast<u32x4*>(nlo_img + woff) = l;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) prev[r] = acc0[r] + acc1[r];
+    for (int r = 0; r < 16; ++r) prev[r] = SINGLE ? acc0[r] : acc0[r] + acc1[r];
     prow = orow0; prem = orem0;
     if (HEAD_MAJOR) { pcam = GD4D_SGPR(prow / p.S); ppix = GD4D_SGPR(prow - pcam * p.S); }   // once per tile
     orow0 = orow1; orem0 = orem1; orow1 = orow2; orem1 = orem2;
@@ -506,7 +511,8 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
     // for every store of the previous tile).  Needed before the barrier: this wave's LDS writes done
     // (lgkmcnt) and the DMA of tile k+2 landed - it was issued BEFORE the <= 16 stores, and VMEM ops
     // retire in order, so "at most 16 outstanding" implies the DMA is complete.
-    if (!has_prev || full_prev) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    // (k = 0 issues no stores, so nothing sits behind the DMA in the queue: full drain there too)
+    if (has_prev && full_prev) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -556,7 +562,7 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
   if (slots < 1) slots = 1;
   if (slots > base) slots = base;
   const int grid = slots * NL;
-  if (BM == 32 && (vp_variant() == 2 || p.head_major)) {
+  if (BM == 32 && (vp_variant() == 2 || p.head_major || p.single_product)) {
     // co-locate the NL workgroups of a slot on one XCD: grid = 8 XCDs x (cus/8 rounded down to a multiple of NL)
     int g2 = grid;
     p.xcd_groups = 0;
@@ -579,7 +585,9 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
       case 31: go(value_proj_pipe_kernel<false, 31>); break;
       case 32: go(value_proj_pipe_kernel<false, 32>); break;
       default:
-        if (p.head_major) { if (ob) go(value_proj_pipe_kernel<true, 0, true>); else go(value_proj_pipe_kernel<false, 0, true>); }
+        if (p.single_product) {                      // bf16 output only (validated by the caller)
+          if (p.head_major) go(value_proj_pipe_kernel<true, 0, true, true>); else go(value_proj_pipe_kernel<true, 0, false, true>);
+        } else if (p.head_major) { if (ob) go(value_proj_pipe_kernel<true, 0, true>); else go(value_proj_pipe_kernel<false, 0, true>); }
         else { if (ob) go(value_proj_pipe_kernel<true, 0>); else go(value_proj_pipe_kernel<false, 0>); }
         break;
     }
@@ -605,7 +613,8 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
 extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                                          const float* const* weights, const float* const* biases,
                                          void* const* outs, int R, int C, int L, int NL, int Hh,
-                                         int in_dtype, int out_dtype, int out_layout, void* stream) {
+                                         int in_dtype, int out_dtype, int out_layout, int precision,
+                                         void* stream) {
   using namespace gd4d;
   if (!feats || !level_hw || !weights || !outs) return GD4D_EINVAL;
   if (R <= 0 || C <= 0 || L <= 0 || NL <= 0) return GD4D_EINVAL;
@@ -613,6 +622,8 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
   if (out_dtype != GD4D_F32 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (out_layout != GD4D_LAYOUT_PIXEL_MAJOR && out_layout != GD4D_LAYOUT_HEAD_MAJOR) return GD4D_EUNSUPPORTED;
   if (Hh <= 0 || C % Hh != 0) return GD4D_EINVAL;
+  if (precision != GD4D_VP_PRECISION_F32 && precision != GD4D_VP_PRECISION_BF16) return GD4D_EUNSUPPORTED;
+  if (precision == GD4D_VP_PRECISION_BF16 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   ValueProjParams p{};
   for (int l = 0; l < L; ++l) {
     if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
@@ -627,18 +638,20 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
   }
   p.R = R; p.L = L; p.NL = NL;
   p.head_major = out_layout == GD4D_LAYOUT_HEAD_MAJOR; p.Hh = Hh; p.Dh = C / Hh;
+  p.single_product = precision == GD4D_VP_PRECISION_BF16;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GD4D_VP_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return (vp_tile_pixels() == 64 && !p.head_major) ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
+  return (vp_tile_pixels() == 64 && !p.head_major && !p.single_product) ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
                                                    : vp_launch<32>(p, level_hw, R, L, NL, out_dtype, st);
 }
 
 extern "C" int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
                                    const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
-                                   int out_dtype, int out_layout, void* stream) {
+                                   int out_dtype, int out_layout, int precision, void* stream) {
   if (!weight || !out) return GD4D_EINVAL;
   const float* ws[1] = {weight};
   const float* bs[1] = {bias};
   void* os[1] = {out};
-  return gd4d_value_proj_multi_fwd(feats, level_hw, ws, bs, os, R, C, L, 1, Hh, in_dtype, out_dtype, out_layout, stream);
+  return gd4d_value_proj_multi_fwd(feats, level_hw, ws, bs, os, R, C, L, 1, Hh, in_dtype, out_dtype, out_layout,
+                                   precision, stream);
 }

@@ -108,7 +108,7 @@ def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
     hm = use_head_major(out_dtype)
     out = ops.value_proj_fwd([v.contiguous() for v in value], weight.contiguous(),
                              None if bias is None else bias.contiguous(), out_dtype,
-                             num_heads=num_heads, head_major=hm)
+                             num_heads=num_heads, head_major=hm, bf16_math=out_dtype == torch.bfloat16)
     return (out if hm else out.view(b * n, -1, num_heads, c // num_heads)), shapes
 
 
@@ -154,7 +154,8 @@ def project_values_for_layers(modules, value):
     outs = ops.value_proj_multi_fwd([v.contiguous() for v in value],
                                     [m.value_proj.weight.contiguous() for m in modules],
                                     [m.value_proj.bias.contiguous() for m in modules],
-                                    modules[0].value_dtype, num_heads=hh, head_major=hm)
+                                    modules[0].value_dtype, num_heads=hh, head_major=hm,
+                                    bf16_math=modules[0].value_dtype == torch.bfloat16)
     return {id(m): ((o if hm else o.view(b * n, -1, hh, c // hh)), shapes, value) for m, o in zip(modules, outs)}
 
 

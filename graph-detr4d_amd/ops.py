@@ -101,7 +101,8 @@ def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_
     return dict(out=out, mask=mask, sampled=sampled)
 
 
-def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None, num_heads=8, head_major=False):
+def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None, num_heads=8, head_major=False,
+                   bf16_math=False):
     """gd4d_value_proj_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) or (R, C, H_l, W_l) fp32;
     weight (C, C); bias (C) or None.  Returns (R, S, C) in `out_dtype`, or (R, Hh, S, C/Hh) with
     head_major=True."""
@@ -119,12 +120,14 @@ def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None, num_h
     code = lib.gd4d_value_proj_fwd(ptrs, lv, _dev(weight, 'weight', f32),
                                    _dev(bias, 'bias', f32) if bias is not None else None,
                                    _dev(out, 'out'), r, c, nl, num_heads, _lib.F32, _value_dtype(out),
-                                   _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR, _stream())
+                                   _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR, int(bool(bf16_math)),
+                                   _stream())
     _lib.check(code, 'gd4d_value_proj_fwd')
     return out
 
 
-def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_heads=8, head_major=False):
+def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_heads=8, head_major=False,
+                         bf16_math=False):
     """gd4d_value_proj_multi_fwd: project the same pyramid with NL (weight, bias) pairs in one
     launch.  Returns a list of NL tensors (R, S, C) (or (R, Hh, S, C/Hh) with head_major=True)."""
     lib = _lib.load()
@@ -144,7 +147,8 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_he
     op = (ctypes.c_void_p * nlayers)(*[_dev(o, 'out').value for o in outs])
     code = lib.gd4d_value_proj_multi_fwd(ptrs, lv, wp, bp, op, r, c, nl, nlayers, num_heads, _lib.F32,
                                          _value_dtype(outs[0]),
-                                         _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR, _stream())
+                                         _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR,
+                                         int(bool(bf16_math)), _stream())
     _lib.check(code, 'gd4d_value_proj_multi_fwd')
     return outs
 

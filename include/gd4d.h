@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 2
+#define GD4D_ABI_VERSION 3
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -38,6 +38,10 @@ enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
  *   HEAD_MAJOR  (B*N, Hh, S, Dh) - one contiguous S x Dh plane per (camera, head): the two x-adjacent
  *                bilinear corners of a head are one contiguous 2*Dh run (better DRAM locality). */
 enum { GD4D_LAYOUT_PIXEL_MAJOR = 0, GD4D_LAYOUT_HEAD_MAJOR = 1 };
+
+/* Arithmetic of gd4d_value_proj_*: F32 = split-bf16 x3 MFMA, fp32-class results (<= ~2^-17 relative per
+ * product); BF16 = one bf16 product per MAC with fp32 accumulation (bf16-class, only with bf16 output). */
+enum { GD4D_VP_PRECISION_F32 = 0, GD4D_VP_PRECISION_BF16 = 1 };
 
 enum {
   GD4D_OK = 0,
@@ -138,7 +142,7 @@ int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const flo
  */
 int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
                         const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
-                        int out_dtype, int out_layout, void* stream);
+                        int out_dtype, int out_layout, int precision, void* stream);
 size_t gd4d_value_proj_workspace_bytes(void);
 
 /* gd4d_value_proj_multi_fwd - the same projection for NL decoder layers in ONE launch.
@@ -150,7 +154,7 @@ size_t gd4d_value_proj_workspace_bytes(void);
 int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                               const float* const* weights, const float* const* biases,
                               void* const* outs, int R, int C, int L, int NL, int Hh, int in_dtype,
-                              int out_dtype, int out_layout, void* stream);
+                              int out_dtype, int out_layout, int precision, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_linear_fwd - the decoder's small dense layers on the fp32 MFMA, with the elementwise

@@ -90,3 +90,37 @@ def test_head_major_layout_is_a_permutation_of_pixel_major(out_dtype):
     assert torch.equal(hm, pm.view(5, -1, 8, 32).permute(0, 2, 1, 3))
     hm6 = ops.value_proj_multi_fwd(feats, [w] * 3, [b] * 3, out_dtype, head_major=True)
     assert all(torch.equal(x, hm) for x in hm6)
+
+
+@pytest.mark.parametrize('head_major', [False, True])
+def test_bf16_math_mode(head_major):
+    """GD4D_VP_PRECISION_BF16: one bf16 product per MAC, fp32 accumulate, bf16 output - equals an fp64 GEMM
+    of the bf16-rounded operands up to accumulation order and the final bf16 rounding."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(12)
+    feats = [torch.randn(4, 256, h, w) for h, w in [(16, 28), (8, 14), (4, 7), (2, 4)]]
+    w, b = torch.randn(256, 256) * 0.06, torch.randn(256)
+    got = ops.value_proj_fwd([f.cuda() for f in feats], w.cuda(), b.cuda(), torch.bfloat16, head_major=head_major,
+                             bf16_math=True).float().cpu()
+    if head_major:
+        got = got.permute(0, 2, 1, 3).reshape(4, -1, 256)
+    flat = torch.cat([f.reshape(4, 256, -1) for f in feats], 2).bfloat16().double()
+    ref = torch.matmul(flat.transpose(1, 2), w.bfloat16().double().t()) + b.double()
+    assert (got.double() - ref).abs().max().item() < 0.03          # bf16 output rounding at |v| <= 4
+    assert (got.double() - ref).abs().mean().item() < 3e-3
+
+
+def test_value_proj_repeatable_under_load():
+    """Race screen for the pipelined kernel (LDS-DMA + counted vmcnt across a raw barrier): 12 launches of
+    the full-size problem with other traffic in between must be bit-identical."""
+    from graph_detr4d_amd import ops, synthetic
+    torch.manual_seed(13)
+    dev = 'cuda'
+    feats = [torch.randn(24, 256, h, w, device=dev) for h, w in synthetic.R50_LEVELS]
+    w, b = torch.randn(256, 256, device=dev) * 0.06, torch.randn(256, device=dev)
+    ref = ops.value_proj_fwd(feats, w, b).clone()
+    junk = torch.empty(64 << 20, device=dev)
+    for i in range(12):
+        junk.normal_()                                     # unrelated HBM traffic / cache pollution
+        got = ops.value_proj_fwd(feats, w, b)
+        assert torch.equal(got, ref), f'run {i} differs'

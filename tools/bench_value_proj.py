@@ -17,13 +17,14 @@ def main():
     ap.add_argument('--out', default='f32')
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--head-major', action='store_true')
+    ap.add_argument('--bf16-math', action='store_true')
     a = ap.parse_args()
     dev = 'cuda'
     feats = [torch.randn(a.cams, 256, h, w, device=dev) for h, w in synthetic.R50_LEVELS]
     ws = [torch.randn(256, 256, device=dev) * 0.06 for _ in range(a.layers)]
     bs = [torch.randn(256, device=dev) for _ in range(a.layers)]
     odt = torch.float32 if a.out == 'f32' else torch.bfloat16
-    run = lambda: ops.value_proj_multi_fwd(feats, ws, bs, odt, head_major=a.head_major)  # noqa: E731
+    run = lambda: ops.value_proj_multi_fwd(feats, ws, bs, odt, head_major=a.head_major, bf16_math=a.bf16_math)  # noqa: E731
     outs = run()
     for _ in range(2):
         run()
