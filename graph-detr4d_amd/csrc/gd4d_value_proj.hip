@@ -521,11 +521,261 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const Va
   for (int r = 0; r < 16; ++r) store_one(r, prem >= BM);
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: one wave per SIMD.  4 waves per workgroup (one workgroup per CU), wave w owns output channels
+// [64w, 64w+64) and keeps W_hi / W_lo fragments for both 32-channel blocks in registers (256 of the
+// 512 VGPR+AGPR entries a lone wave may use).  Compared with the 8-wave kernels: every A fragment
+// pair read from LDS feeds 6 MFMAs instead of 3 (half the LDS fragment traffic per tile), the matrix
+// pipe of a SIMD belongs to one wave (no two-wave arbitration), and the wave's other work (DMA issue,
+// conversion slices, stores of the previous tile) is interleaved into its own MFMA stream.
+template <bool OUT_BF16, bool HEAD_MAJOR>
+__global__ __launch_bounds__(256, 1) void value_proj_w4_kernel(const ValueProjParams p) {
+  constexpr int BM = 32;
+  constexpr int RAW = VP_C * BM * 4;
+  constexpr int IMG = BM * VP_C * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // raw[2] | {hi, lo}[2]
+  char* const raw_base = smem;
+  char* const img_base = smem + 2 * RAW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31;
+  const int kg = lane >> 5;
+
+  int layer, slot, slots;
+  {
+    const int per_xcd = gridDim.x / 8;
+    if (p.xcd_groups) {
+      const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+      layer = idx % p.NL;
+      slot = xcd * (per_xcd / p.NL) + idx / p.NL;
+      slots = 8 * (per_xcd / p.NL);
+    } else {
+      layer = blockIdx.x % p.NL;
+      slot = blockIdx.x / p.NL;
+      slots = gridDim.x / p.NL;
+    }
+  }
+  const float* __restrict__ weight = p.weight[layer];
+  void* __restrict__ outp = p.out[layer];
+
+  bf16x8 whi[2][VP_KSTEPS], wlo[2][VP_KSTEPS];
+  float bias[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int co = 64 * wave + 32 * cb + col;
+    const float* wrow = weight + (size_t)co * VP_C + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < VP_KSTEPS; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * s);
+      const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      u32x4 h, l;
+      split8(v, h, l);
+      whi[cb][s] = as_bf16x8(h);
+      wlo[cb][s] = as_bf16x8(l);
+    }
+    bias[cb] = p.bias[layer] ? p.bias[layer][co] : 0.f;
+  }
+
+  const int total = p.tile_base[p.L];
+  const int ntile = slot < total ? (total - slot + slots - 1) / slots : 0;
+  if (ntile == 0) return;
+
+  // level table in the tail of LDS (see value_proj_pipe_kernel)
+  int* const tab = reinterpret_cast<int*>(smem + 2 * RAW + 4 * IMG);
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < GD4D_MAX_LEVELS; ++l) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(p.in[l]);
+      tab[6 * l + 0] = p.hw[l]; tab[6 * l + 1] = p.tiles[l]; tab[6 * l + 2] = p.start[l];
+      tab[6 * l + 3] = p.tile_base[l]; tab[6 * l + 4] = (int)(unsigned)(a & 0xffffffffu); tab[6 * l + 5] = (int)(unsigned)(a >> 32);
+    }
+  }
+  __syncthreads();
+  int c_lvl, c_row, c_tin, c_hw, c_tiles, c_start;
+  const float* c_in;
+  auto set_level = [&](int lvl) {
+    c_lvl = lvl;
+    c_hw = GD4D_SGPR(tab[6 * lvl + 0]); c_tiles = GD4D_SGPR(tab[6 * lvl + 1]); c_start = GD4D_SGPR(tab[6 * lvl + 2]);
+    const unsigned lo = (unsigned)GD4D_SGPR(tab[6 * lvl + 4]), hi = (unsigned)GD4D_SGPR(tab[6 * lvl + 5]);
+    c_in = reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
+  };
+  {
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
+      if (l < p.L && slot >= p.tile_base[l]) lvl = l;
+    set_level(GD4D_SGPR(lvl));
+    const int rel = slot - GD4D_SGPR(tab[6 * c_lvl + 3]);
+    c_row = GD4D_SGPR(rel / c_tiles);
+    c_tin = GD4D_SGPR(rel - c_row * c_tiles);
+  }
+  auto advance = [&]() {
+    c_tin += slots;
+    while (c_tin >= c_tiles && c_lvl < p.L) {
+      c_tin -= c_tiles;
+      if (++c_row == p.R) {
+        c_row = 0;
+        if (c_lvl + 1 < p.L) set_level(c_lvl + 1); else c_lvl = p.L;
+      }
+    }
+    c_tin = GD4D_SGPR(c_tin); c_row = GD4D_SGPR(c_row); c_lvl = GD4D_SGPR(c_lvl);
+  };
+
+  // LDS-DMA: wave w fills ci rows [64w, 64w+64) of the raw image
+  auto issue_dma = [&](int rb) {
+    const int hw = c_hw;
+    const int pix0 = c_tin * BM;
+    const float* src = c_in + (size_t)c_row * VP_C * hw;
+    char* dst = raw_base + rb * RAW + (64 * wave) * (BM * 4);
+    const bool wide = (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    if (wide) {
+      int pq = pix0 + 4 * (lane & 7);
+      if (pq >= hw) pq = hw - 4;
+      const float* g = src + (size_t)(64 * wave + (lane >> 3)) * hw + pq;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(8 * i) * hw),
+                                         (lds_void_t*)(dst + i * 8 * (BM * 4)), 16, 0, 0);
+    } else {
+      const int px = min(pix0 + (lane & 31), hw - 1);
+      const float* g = src + (size_t)(64 * wave + (lane >> 5)) * hw + px;
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(2 * i) * hw),
+                                         (lds_void_t*)(dst + i * 2 * (BM * 4)), 4, 0, 0);
+    }
+  };
+
+  // conversion role: pixel spix, channels [32*scg, 32*scg + 32)
+  const int spix = tid & 31;
+  const int scg = tid >> 5;                         // 0..7
+
+  int orow0 = 0, orem0 = 0, orow1 = 0, orem1 = 0, orow2 = 0, orem2 = 0;
+  auto tile_info = [&](int& orow, int& orem) {
+    orow = GD4D_SGPR(c_row * p.S + c_start + c_tin * BM);
+    orem = GD4D_SGPR(c_hw - c_tin * BM);
+  };
+
+  issue_dma(0);
+  tile_info(orow0, orem0);
+  advance();
+  if (ntile > 1) { issue_dma(1); tile_info(orow1, orem1); advance(); }
+  __syncthreads();
+  {
+    const float* rawf = reinterpret_cast<const float*>(raw_base) + (32 * scg) * BM + spix;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float cv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cv[j] = rawf[(8 * c + j) * BM];
+      u32x4 h, l;
+      split8(cv, h, l);
+      const int off = lds_off(spix, 4 * scg + c);
+      *reinterpret_cast<u32x4*>(img_base + off) = h;
+      *reinterpret_cast<u32x4*>(img_base + IMG + off) = l;
+    }
+  }
+  __syncthreads();
+
+  f32x16 prev[2];
+  int prow = 0, prem = 0, pcam = 0, ppix = 0;
+  const size_t hm_base0 = (size_t)((64 * wave + col) / p.Dh) * p.S * p.Dh + (64 * wave + col) % p.Dh;
+  const size_t hm_base1 = (size_t)((64 * wave + 32 + col) / p.Dh) * p.S * p.Dh + (64 * wave + 32 + col) % p.Dh;
+  auto store_one = [&](int cb, int r, bool full) {
+    const int dp = (r & 3) + 8 * (r >> 2);
+    size_t o;
+    if (HEAD_MAJOR) o = (cb ? hm_base1 : hm_base0) + (size_t)(pcam * p.Hh) * p.S * p.Dh + (size_t)(ppix + 4 * kg + dp) * p.Dh;
+    else o = ((size_t)prow + 4 * kg + dp) * VP_C + 64 * wave + 32 * cb + col;
+    if (full || dp + 4 * kg < prem) {
+      if (OUT_BF16) static_cast<uint16_t*>(outp)[o] = f32_to_bf16(prev[cb][r]);
+      else static_cast<float*>(outp)[o] = prev[cb][r];
+    }
+  };
+
+  for (int k = 0; k < ntile; ++k) {
+    if (k + 2 < ntile) { issue_dma(k & 1); tile_info(orow2, orem2); advance(); }
+    const bool has_prev = k > 0;
+    const bool full_prev = prem >= BM;
+    const int ib = k & 1;
+    const char* hi_img = img_base + ib * 2 * IMG;
+    const char* lo_img = hi_img + IMG;
+    char* nhi_img = img_base + (ib ^ 1) * 2 * IMG;
+    char* nlo_img = nhi_img + IMG;
+    const float* rawf = reinterpret_cast<const float*>(raw_base + (ib ^ 1) * RAW) + (32 * scg) * BM + spix;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][r] = bias[cb];
+    float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 fh[2], fl[2];
+    {
+      const int off = lds_off(col, kg);
+      fh[0] = *reinterpret_cast<const u32x4*>(hi_img + off);
+      fl[0] = *reinterpret_cast<const u32x4*>(lo_img + off);
+    }
+#pragma unroll
+    for (int s = 0; s < VP_KSTEPS; ++s) {
+      if (s + 1 < VP_KSTEPS) {                       // prefetch the next step's A fragments
+        const int off = lds_off(col, 2 * (s + 1) + kg);
+        fh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(hi_img + off);
+        fl[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(lo_img + off);
+      }
+      // 2/32 of the next tile's conversion and 2/32 of the previous tile's stores per k-step
+      cv[(2 * s) & 7] = rawf[(2 * s) * BM];
+      cv[(2 * s + 1) & 7] = rawf[(2 * s + 1) * BM];
+      if (has_prev) { store_one(0, s, full_prev); store_one(1, s, full_prev); }
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 ahi = as_bf16x8(fh[s & 1]);
+      const bf16x8 alo = as_bf16x8(fl[s & 1]);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[cb][s], acc[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[cb][s], acc[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi[cb][s], acc[cb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((s & 3) == 3) {                            // 8 channels gathered: one chunk of the next image
+        u32x4 h, l;
+        split8(cv, h, l);
+        const int woff = lds_off(spix, 4 * scg + (s >> 2));
+        *reinterpret_cast<u32x4*>(nhi_img + woff) = h;
+        *reinterpret_cast<u32x4*>(nlo_img + woff) = l;
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[cb][r] = acc[cb][r];
+    prow = orow0; prem = orem0;
+    if (HEAD_MAJOR) { pcam = GD4D_SGPR(prow / p.S); ppix = GD4D_SGPR(prow - pcam * p.S); }
+    orow0 = orow1; orem0 = orem1; orow1 = orow2; orem1 = orem2;
+    // DMA of tile k+2 was issued before this interval's 32 stores (see value_proj_pipe_kernel)
+    if (has_prev && full_prev) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { store_one(0, r, prem >= BM); store_one(1, r, prem >= BM); }
+}
+
 static int vp_variant() {
   static int v = 0;
   if (!v) {
     const char* e = getenv("GD4D_VP_VARIANT");        // dev A/B switch: 1 = phase kernel, 2 = pipelined
-    v = (e && atoi(e) == 1) ? 1 : 2;
+    v = e ? atoi(e) : 2;
+    if (v < 1 || v > 3) v = 2;
   }
   return v;
 }
@@ -562,7 +812,7 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
   if (slots < 1) slots = 1;
   if (slots > base) slots = base;
   const int grid = slots * NL;
-  if (BM == 32 && (vp_variant() == 2 || p.head_major || p.single_product)) {
+  if (BM == 32 && (vp_variant() >= 2 || p.head_major || p.single_product)) {
     // co-locate the NL workgroups of a slot on one XCD: grid = 8 XCDs x (cus/8 rounded down to a multiple of NL)
     int g2 = grid;
     p.xcd_groups = 0;
@@ -573,6 +823,15 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
     const int grid = g2;
     const size_t lds2 = 2 * (size_t)VP_C * 32 * 4 + 2 * 2 * (size_t)32 * VP_C * 2 + 256;   // raw[2] + {hi,lo}[2] = 128 KB, + level table
     const bool ob = out_dtype == GD4D_BF16;
+    if (vp_variant() == 3 && !p.single_product && p.dbg == 0) {     // one wave per SIMD
+      auto go4 = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds2, st, p);
+      };
+      if (p.head_major) { if (ob) go4(value_proj_w4_kernel<true, true>); else go4(value_proj_w4_kernel<false, true>); }
+      else { if (ob) go4(value_proj_w4_kernel<true, false>); else go4(value_proj_w4_kernel<false, false>); }
+      return check_launch();
+    }
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(VP_THREADS), lds2, st, p);

@@ -18,11 +18,15 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--head-major', action='store_true')
     ap.add_argument('--bf16-math', action='store_true')
+    ap.add_argument('--zeros', action='store_true', help='zero-filled operands (DVFS / power probe)')
     a = ap.parse_args()
     dev = 'cuda'
     feats = [torch.randn(a.cams, 256, h, w, device=dev) for h, w in synthetic.R50_LEVELS]
     ws = [torch.randn(256, 256, device=dev) * 0.06 for _ in range(a.layers)]
     bs = [torch.randn(256, device=dev) for _ in range(a.layers)]
+    if a.zeros:
+        feats = [torch.zeros_like(f) for f in feats]
+        ws = [torch.zeros_like(w) for w in ws]
     odt = torch.float32 if a.out == 'f32' else torch.bfloat16
     run = lambda: ops.value_proj_multi_fwd(feats, ws, bs, odt, head_major=a.head_major, bf16_math=a.bf16_math)  # noqa: E731
     outs = run()
