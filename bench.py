@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--levels', default='r50', choices=['r50', 'vov'])
     ap.add_argument('--value-dtype', default='fp32', choices=['fp32', 'bf16'],
                     help='storage of the projected value tensor (fp32 = the reference-parity mode)')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="'train': forward + backward + one flat RCCL gradient all-reduce + SGD per step (secondary metric)")
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None, help='torch threads of the CPU baseline (default: min(cores, 16), the fastest measured)')
@@ -149,6 +151,10 @@ def main():
     def step():
         return tr(feats, query_embed, reg_branches=regs, img_metas=metas)
 
+    if a.mode == 'train':
+        train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels)
+        return
+
     launch = 'eager'
     run = step
     with torch.no_grad():
@@ -203,6 +209,43 @@ def main():
                        'baseline_config': 'configs[2]', 'launch': launch,
                        'parallelism': f'replicas x{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
+        }
+        print(json.dumps(line))
+    D.shutdown()
+
+
+def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels):
+    """Secondary mode: one training step of the decoder per sample - forward, a synthetic loss, backward
+    (gd4d_cross_attn_bwd + GEMM backward of value_proj), ONE flat gradient all-reduce over RCCL, SGD.
+    The feature pyramid requires grad (it comes from the backbone in the reference's training)."""
+    for f in feats:
+        f.requires_grad_(True)
+    params = list(tr.parameters()) + list(regs.parameters())
+    opt = torch.optim.SGD(params, lr=1e-4)
+    reducer = D.FlatGradAllReducer(params)
+    tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
+
+    def run():
+        opt.zero_grad(set_to_none=False)
+        for f in feats:
+            f.grad = None
+        states, _, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
+        loss = (states ** 2).mean()
+        loss.backward()
+        reducer.reduce()
+        opt.step()
+    elapsed = D.timed_steps(run, a.steps, a.warmup, dev)
+    if rank == 0:
+        line = {
+            'metric': f'decoder_train_samples_per_sec_{a.queries}q_T{a.frames}',
+            'value': D.aggregate_throughput(1, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'training step of the {a.layers}-layer decoder (forward + backward + flat gradient '
+                                   f'all-reduce of {reducer.bytes_per_step() / 1e6:.1f} MB + SGD), {a.queries} queries, '
+                                   f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
+                       'launch': 'eager', 'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
+            'roofline': None, 'cpu_baseline': None,
         }
         print(json.dumps(line))
     D.shutdown()

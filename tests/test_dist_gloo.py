@@ -67,3 +67,51 @@ def test_single_process_helpers():
     n = []
     e = D.timed_steps(lambda: n.append(1), steps=3, warmup=1)
     assert len(n) == 4 and e >= 0
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from graph_detr4d_amd import dist as D
+    D.init(backend='gloo')
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    net[2].bias.requires_grad_(False)                       # frozen parameter is skipped
+    x = torch.full((3, 8), float(rank + 1))
+    net(x).sum().backward()
+    net[0].bias.grad = None                                  # a parameter without grad on this rank
+    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    red = D.FlatGradAllReducer(net.parameters())
+    extras = red.reduce(extras=torch.tensor([float(rank + 1), 10.0]))
+    q.put((rank, [None if g is None else g.numpy() for g in local],
+           [None if p.grad is None else p.grad.numpy() for p in net.parameters()], extras.numpy(), red.bytes_per_step()))
+    D.shutdown()
+
+
+def test_flat_gradient_allreduce_two_ranks():
+    import numpy as np
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, loc0, avg0, ex0, nbytes), (_, loc1, avg1, ex1, _) = res
+    assert nbytes == (8 * 16 + 16 + 16 * 4) * 4             # frozen bias excluded
+    for a0, a1, l0, l1 in zip(avg0, avg1, loc0, loc1):
+        if a0 is None:                                        # the frozen parameter
+            assert a1 is None
+            continue
+        np.testing.assert_array_equal(a0, a1)                 # both ranks hold the same averaged gradient
+        z = np.zeros_like(a0)
+        np.testing.assert_allclose(a0, ((z if l0 is None else l0) + (z if l1 is None else l1)) / 2, rtol=1e-6)
+    np.testing.assert_allclose(ex0, [3.0, 20.0])              # extras are summed, not averaged
+    np.testing.assert_allclose(ex1, [3.0, 20.0])
