@@ -195,3 +195,16 @@ class Detr3DTransformer(nn.Module):
             query_pos=query_pos.permute(1, 0, 2), reference_points=reference_points,
             reg_branches=reg_branches, **kwargs)
         return inter_states, init_reference_out, inter_references
+
+
+@TRANSFORMER.register_module()
+class HDetr3DTransformer(Detr3DTransformer):
+    """H-DETR variant (reference: utils/h_detr3d_transformer.py:48-160): identical to Detr3DTransformer
+    except that `forward(mlvl_feats, query_embed, reg_branches=None, decoder_self_attn_mask=None)` hands a
+    per-attention list of masks - [one-to-one / one-to-many block mask, None]
+    (dense_heads/h_detr3d_head_pe.py:299-314) - to the decoder as `attn_masks`.  The boolean mask is
+    applied inside gd4d_mha_core_fwd (True = masked)."""
+
+    def forward(self, mlvl_feats, query_embed, reg_branches=None, decoder_self_attn_mask=None, **kwargs):
+        return super().forward(mlvl_feats, query_embed, reg_branches=reg_branches,
+                               attn_masks=decoder_self_attn_mask, **kwargs)

@@ -100,3 +100,41 @@ def test_transformer_decoder(name):
     torch.testing.assert_close(init_ref.cpu(), g.t('init_reference'), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(refs.cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(states.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+
+
+def test_hdetr_transformer_mask_path_equals_oracle():
+    """HDetr3DTransformer: 48 queries = 16 one-to-one + 32 one-to-many with the block self-attention mask
+    of h_detr3d_head_pe.py:299-303, against the CPU oracle driven with the same mask."""
+    from oracle import torch_oracle as O
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+    cross = dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4, embed_dims=256)
+    cfg = dict(type='HDetr3DTransformer', num_feature_levels=4, num_cams=n,
+               decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                            transformerlayers=dict(
+                                type='DetrTransformerDecoderLayer',
+                                attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1), cross],
+                                feedforward_channels=512, ffn_dropout=0.1,
+                                operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm'))))
+    tr = G.build_transformer(cfg)
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    torch.manual_seed(3)
+    nq, k = 48, 16
+    qe = torch.randn(nq, 512)
+    mask = torch.zeros(nq, nq, dtype=torch.bool)
+    mask[k:, :k] = True
+    mask[:k, k:] = True
+    with torch.no_grad():
+        states, init_ref, refs = tr([f.to(DEV) for f in g.feats()], qe.to(DEV), reg_branches=None,
+                                    decoder_self_attn_mask=[mask.to(DEV), None], img_metas=g.img_metas())
+    sd = g.state()
+    layers = [sub(sd, f'decoder.layers.{i}.') for i in range(m['num_layers'])]
+    s_ref, i_ref, r_ref = O.transformer(sd, layers, g.feats(), qe, g.img_metas(), m['pc_range'], reg_branches=None,
+                                        cross='Deform3DCrossAttn', num_points=4, attn_mask=mask)
+    torch.testing.assert_close(states.cpu(), s_ref, rtol=1e-3, atol=1e-3)
+    # the mask must matter: without it the result differs
+    with torch.no_grad():
+        s2, _, _ = tr([f.to(DEV) for f in g.feats()], qe.to(DEV), reg_branches=None, img_metas=g.img_metas())
+    assert (s2.cpu() - s_ref).abs().max().item() > 1e-3
