@@ -190,9 +190,11 @@ class Detr3DTransformer(nn.Module):
         query = query.unsqueeze(0).expand(bs, -1, -1)
         reference_points = self.reference_points(query_pos).sigmoid()
         init_reference_out = reference_points
+        # (Q, B, C) dense copies made ONCE: query_pos / query are strided slices of query_embed, and every
+        # fused kernel downstream wants dense rows (otherwise each layer re-copies them)
         inter_states, inter_references = self.decoder(
-            query=query.permute(1, 0, 2), key=None, value=mlvl_feats,
-            query_pos=query_pos.permute(1, 0, 2), reference_points=reference_points,
+            query=query.permute(1, 0, 2).contiguous(), key=None, value=mlvl_feats,
+            query_pos=query_pos.permute(1, 0, 2).contiguous(), reference_points=reference_points,
             reg_branches=reg_branches, **kwargs)
         return inter_states, init_reference_out, inter_references
 
