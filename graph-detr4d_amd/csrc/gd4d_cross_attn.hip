@@ -203,8 +203,13 @@ __global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttn
 // the code is branch-free - an invisible point of a visible camera (~5 %) gets weight 0 and reads
 // the map centre - so all 4 points x L levels x 4 corners loads can be issued back to back.
 // Partial sums are combined through LDS in fixed wave order (deterministic).
+#ifdef GD4D_GATHER_HALF
+#define GD4D_GATHER_OCC 4
+#else
+#define GD4D_GATHER_OCC 3
+#endif
 template <typename VT, int HH, int LT, int WAVES>
-__global__ __launch_bounds__(GD4D_WAVE * WAVES, 3) void cross_attn_fwd_block(const CrossAttnParams p) {
+__global__ __launch_bounds__(GD4D_WAVE * WAVES, GD4D_GATHER_OCC) void cross_attn_fwd_block(const CrossAttnParams p) {
   constexpr int DH = kChannels / HH;
   constexpr int LANES_PER_HEAD = DH / 4;
   constexpr int E = HH * kPoints;
@@ -322,29 +327,40 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES, 3) void cross_attn_fwd_block(con
         off[l][2] = (r1 + xa) * pix_stride + lane_off;
         off[l][3] = (r1 + xb) * pix_stride + lane_off;
       }
-      float4 val[LMAX][4];
+#ifdef GD4D_GATHER_HALF
+      constexpr int NB = 2;
+#else
+      constexpr int NB = 1;
+#endif
+      constexpr int LB = (LMAX + NB - 1) / NB;
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l) {
-        if (LT == 0 && l >= L) break;
+      for (int hb = 0; hb < NB; ++hb) {
+        float4 val[LB][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) val[l][c] = Quad<VT>::load(vrow + off[l][c]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int li = 0; li < LB; ++li) {
+          const int l = hb * LB + li;
+          if (l >= LMAX || (LT == 0 && l >= L)) break;
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l) {
-        if (LT == 0 && l >= L) break;
-        const float wl = aw[l * kPoints + k] * cwk;
-        const float dx = fx[l], dy = fy[l];
-        const unsigned ok = okm >> (4 * l);
-        const float w00 = ((ok & 5u) == 5u) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
-        const float w01 = ((ok & 6u) == 6u) ? wl * dx * (1.f - dy) : 0.f;
-        const float w10 = ((ok & 9u) == 9u) ? wl * (1.f - dx) * dy : 0.f;
-        const float w11 = ((ok & 10u) == 10u) ? wl * dx * dy : 0.f;
-        const float wc[4] = {w00, w01, w10, w11};
+          for (int c = 0; c < 4; ++c) val[li][c] = Quad<VT>::load(vrow + off[l][c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc.x = fmaf(wc[c], val[l][c].x, acc.x); acc.y = fmaf(wc[c], val[l][c].y, acc.y);
-          acc.z = fmaf(wc[c], val[l][c].z, acc.z); acc.w = fmaf(wc[c], val[l][c].w, acc.w);
+        for (int li = 0; li < LB; ++li) {
+          const int l = hb * LB + li;
+          if (l >= LMAX || (LT == 0 && l >= L)) break;
+          const float wl = aw[l * kPoints + k] * cwk;
+          const float dx = fx[l], dy = fy[l];
+          const unsigned ok = okm >> (4 * l);
+          const float w00 = ((ok & 5u) == 5u) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
+          const float w01 = ((ok & 6u) == 6u) ? wl * dx * (1.f - dy) : 0.f;
+          const float w10 = ((ok & 9u) == 9u) ? wl * (1.f - dx) * dy : 0.f;
+          const float w11 = ((ok & 10u) == 10u) ? wl * dx * dy : 0.f;
+          const float wc[4] = {w00, w01, w10, w11};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc.x = fmaf(wc[c], val[li][c].x, acc.x); acc.y = fmaf(wc[c], val[li][c].y, acc.y);
+            acc.z = fmaf(wc[c], val[li][c].z, acc.z); acc.w = fmaf(wc[c], val[li][c].w, acc.w);
+          }
         }
       }
     }
