@@ -168,7 +168,9 @@ def main():
                 with torch.cuda.stream(s):
                     step()
                 torch.cuda.current_stream().wait_stream(s)
-                with torch.cuda.graph(graph):
+                # thread_local: with a process group up, the RCCL watchdog thread polls events while we
+                # capture; in the default 'global' mode that would invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     static_out = step()
                 run = graph.replay
                 launch = 'hipgraph'
