@@ -1,0 +1,62 @@
+"""Parity at the BASELINE size: every layer of the 6-layer decoder (900 queries, 24 cameras = 6 x T=4, the
+full 116x200..15x25 pyramid) against the CPU oracle, plus the reference-point refinement.
+
+Layers are checked with TEACHER FORCING (each layer gets the oracle's input state).  Chaining all six is
+ill-conditioned on synthetic data: the feature maps are i.i.d. N(0,1) per pixel, so a 1e-6 rounding difference
+in a refined reference point moves the bilinear sample by ~1e-3 and the difference triples per layer (measured:
+0 / 0.7 / 2.6 / 7.9 / 17 / 55 % of query rows off by > 1e-3 after layers 1..6 when chained).  GPU only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_each_decoder_layer_900q_24cams_matches_oracle():
+    import bench
+    import graph_detr4d_amd as G
+    from graph_detr4d_amd import functional as Fn
+    from graph_detr4d_amd import synthetic
+    from oracle import torch_oracle as O
+    torch.set_num_threads(16)
+    frames, queries, layers = 4, 900, 6
+    n = 6 * frames
+    tr, regs = bench.build_decoder(G, n, layers, 'fp32', 1002)
+    feats = synthetic.feature_pyramid(n, synthetic.R50_LEVELS, seed=77)
+    qe = torch.randn(queries, 512, generator=torch.Generator().manual_seed(5))
+    metas = synthetic.make_img_metas(synthetic.camera_rig(frames), batch=1)
+    sd, layer_params = bench.state_as_oracle_params(tr)
+    pc = synthetic.PC_RANGE
+    dev = 'cuda'
+    query_pos, query = (t.unsqueeze(1).contiguous() for t in torch.split(qe, 256, dim=1))   # (Q, 1, C)
+    with torch.no_grad():
+        ref = torch.nn.functional.linear(query_pos.permute(1, 0, 2), sd['reference_points.weight'],
+                                         sd['reference_points.bias']).sigmoid()
+        import copy
+        regs_cpu = copy.deepcopy(regs)
+        tr_d, regs_d = tr.to(dev), regs.to(dev)
+        feats_d = [f.to(dev) for f in feats]
+        x = query
+        worst = []
+        for lid in range(layers):
+            # oracle: one layer + refinement from the oracle's own state
+            y_ref = O.decoder_layer(layer_params[lid], x, feats, query_pos, ref, metas, pc,
+                                    cross='Deform3DCrossAttn', num_heads=8, num_points=4)
+            tmp = regs_cpu[lid](y_ref.permute(1, 0, 2))
+            new = torch.zeros_like(ref)
+            new[..., :2] = tmp[..., :2] + O.inverse_sigmoid(ref[..., :2])
+            new[..., 2:3] = tmp[..., 4:5] + O.inverse_sigmoid(ref[..., 2:3])
+            ref_next = new.sigmoid()
+            # HIP: the same layer on the same inputs
+            y = tr_d.decoder.layers[lid](x.to(dev), key=None, value=feats_d, query_pos=query_pos.to(dev),
+                                         reference_points=ref.to(dev), img_metas=metas)
+            tmp_d = Fn.run_branch(regs_d[lid], y.permute(1, 0, 2).contiguous())
+            ref_d = Fn.refine_reference(tmp_d, ref.to(dev))
+            err = (y.cpu() - y_ref).abs().amax(dim=(1, 2))          # per query row
+            worst.append((float((err > 1e-3).float().mean()), float(err.median())))
+            # tolerance of the path: 1e-3 (north_star); a point within an ulp of a visibility threshold may
+            # flip between the GPU's and the CPU's GEMM rounding of the offsets and move ONE query row
+            assert (err > 1e-3).float().mean().item() <= 0.005, (lid, worst)
+            assert err.median().item() < 2e-4, (lid, worst)
+            assert (ref_d.cpu() - ref_next).abs().max().item() < 1e-3
+            x, ref = y_ref, ref_next                                  # teacher forcing
+    print('per-layer (fraction of rows > 1e-3, median row error):', worst)
