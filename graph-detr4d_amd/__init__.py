@@ -6,16 +6,17 @@ when mmcv/mmdet are importable, in their real registries.
 """
 __version__ = '0.1.0'
 
-from .registry import (ATTENTION, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE,  # noqa: F401
-                       build_attention, build_transformer, build_transformer_layer,
+from .registry import (ATTENTION, BBOX_CODERS, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE,  # noqa: F401
+                       build_attention, build_bbox_coder, build_transformer, build_transformer_layer,
                        build_transformer_layer_sequence)
 from .transformer_layers import (FFN, BaseTransformerLayer, DetrTransformerDecoderLayer,  # noqa: F401
                                  MultiheadAttention, TransformerLayerSequence)
 from .deform3d_cross_attn import Deform3DCrossAttn  # noqa: F401
+from .bbox_coder import NMSFreeCoder  # noqa: F401
 from .detr3d_transformer import (Detr3DCrossAtten, Detr3DTransformer, Detr3DTransformerDecoder,  # noqa: F401
                                  HDetr3DTransformer, feature_sampling, inverse_sigmoid)
 
 __all__ = ['Deform3DCrossAttn', 'Detr3DCrossAtten', 'feature_sampling', 'Detr3DTransformer',
            'Detr3DTransformerDecoder', 'HDetr3DTransformer', 'MultiheadAttention', 'FFN', 'BaseTransformerLayer',
            'DetrTransformerDecoderLayer', 'TransformerLayerSequence', 'inverse_sigmoid',
-           'ATTENTION', 'TRANSFORMER', 'TRANSFORMER_LAYER', 'TRANSFORMER_LAYER_SEQUENCE']
+           'NMSFreeCoder', 'BBOX_CODERS', 'ATTENTION', 'TRANSFORMER', 'TRANSFORMER_LAYER', 'TRANSFORMER_LAYER_SEQUENCE']

@@ -35,4 +35,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   return static_cast<uint16_t>(u >> 16);
 }
 
+// inverse_sigmoid of the reference (deform3d_cross_attn.py:16-31), eps = 1e-5
+__device__ __forceinline__ float inv_sigmoid(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float a = fminf(fmaxf(x, 1e-5f), 1.f), b = fminf(fmaxf(1.f - x, 1e-5f), 1.f);
+  return logf(a / b);
+}
+
 }  // namespace gd4d

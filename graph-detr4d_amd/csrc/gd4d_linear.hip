@@ -27,13 +27,6 @@ struct LinearParams {
   int ldx, ldy, ldr1, ldr2;
 };
 
-// inverse_sigmoid of the reference (deform3d_cross_attn.py:16-31), eps = 1e-5
-__device__ __forceinline__ float inv_sigmoid(float x) {
-  x = fminf(fmaxf(x, 0.f), 1.f);
-  const float a = fminf(fmaxf(x, 1e-5f), 1.f), b = fminf(fmaxf(1.f - x, 1e-5f), 1.f);
-  return logf(a / b);
-}
-
 constexpr int LN_TM = 32, LN_TN = 32, LN_WAVES = 4, LN_KC = 64;   // k per wave-chunk
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;

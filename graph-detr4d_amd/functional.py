@@ -113,22 +113,47 @@ def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
 
 
 def run_branch(branch, x):
-    """A head branch (reg_branches[lid]) applied to x.  nn.Sequential chains of Linear / ReLU - what
-    Detr3DHead builds (dense_heads/detr3d_head.py:58-75) - run on gd4d_linear_fwd with the ReLUs fused;
-    anything else is simply called."""
-    mods = list(branch) if isinstance(branch, torch.nn.Sequential) else None
-    if not mods or not x.is_cuda or not all(isinstance(m, (torch.nn.Linear, torch.nn.ReLU)) for m in mods) \
-            or not isinstance(mods[0], torch.nn.Linear):
+    """A head branch (reg_branches[lid] / cls_branches[lid]) applied to x.  nn.Sequential chains of Linear / LayerNorm
+    / ReLU - what the heads build (dense_heads/detr3d_head.py:58-75, detr3d_head_pe.py:368-388) - run on
+    gd4d_linear_fwd / gd4d_layernorm_fwd with the ReLUs fused; anything else is simply called."""
+    nn = torch.nn
+    mods = list(branch) if isinstance(branch, nn.Sequential) else None
+    if not mods or not x.is_cuda or not all(isinstance(m, (nn.Linear, nn.ReLU, nn.LayerNorm)) for m in mods) \
+            or not isinstance(mods[0], nn.Linear):
         return branch(x)
     i = 0
     while i < len(mods):
-        lin = mods[i]
-        if not isinstance(lin, torch.nn.Linear):
-            return branch(x) if i == 0 else torch.relu(x)
-        relu = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
-        x = linear(x, lin.weight, lin.bias, relu=relu)
+        m = mods[i]
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        if isinstance(m, nn.Linear):
+            x = linear(x, m.weight, m.bias, relu=relu)
+        elif isinstance(m, nn.LayerNorm):
+            x = layer_norm(x, m, relu=relu)
+        else:                                   # a ReLU that follows another ReLU
+            x, relu = torch.relu(x), False
         i += 2 if relu else 1
     return x
+
+
+def head_outputs(hs, init_reference, inter_references, cls_branches, reg_branches, pc_range, depth_factor=None):
+    """The per-layer epilogue of Detr3DHeadPE.forward (dense_heads/detr3d_head_pe.py:568-612).
+
+    hs (num_layers, Q, B, C) as the transformer returns it (the head permutes it to (num_layers, B, Q, C), :568);
+    init_reference (B, Q, 3), inter_references (num_layers, B, Q, 3) in [0,1]; cls_branches / reg_branches: one
+    branch per layer; depth_factor: img_metas[0]['depth_factors'][0] when the head runs with scale_pred.
+    Returns the head's dict: all_cls_scores (num_layers, B, Q, num_classes), all_bbox_preds (num_layers, B, Q, code).
+    """
+    hs = hs.permute(0, 2, 1, 3)
+    classes, coords = [], []
+    for lvl in range(hs.shape[0]):
+        reference = init_reference if lvl == 0 else inter_references[lvl - 1]
+        x = hs[lvl].contiguous()
+        classes.append(run_branch(cls_branches[lvl], x))
+        tmp = run_branch(reg_branches[lvl], x).contiguous()
+        coords.append(ops.box_head_fwd(tmp, reference.contiguous(), pc_range,
+                                       1.0 if depth_factor is None else float(depth_factor), out=tmp))
+    return {'all_cls_scores': torch.stack(classes), 'all_bbox_preds': torch.stack(coords),
+            'enc_cls_scores': None, 'enc_bbox_preds': None}
 
 
 def refine_reference(tmp, reference_points):

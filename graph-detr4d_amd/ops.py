@@ -234,6 +234,42 @@ def refine_reference_fwd(tmp, ref):
     return out
 
 
+def box_head_fwd(tmp, ref, pc_range, scale=1.0, out=None):
+    """gd4d_box_head_fwd: tmp (..., code) raw regression output, ref (..., 3) in [0,1] -> bbox_preds."""
+    lib = _lib.load()
+    out = torch.empty_like(tmp) if out is None else out
+    rng = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    code = lib.gd4d_box_head_fwd(_dev(tmp, 'tmp', torch.float32), _dev(ref, 'ref', torch.float32), rng,
+                                 float(scale), _dev(out, 'out', torch.float32), ref.numel() // 3, tmp.shape[-1],
+                                 _stream())
+    _lib.check(code, 'gd4d_box_head_fwd')
+    return out
+
+
+def nms_free_decode_fwd(cls_scores, bbox_preds, post_center_range, max_num, score_threshold=None):
+    """gd4d_nms_free_decode_fwd.  cls_scores (B, Q, C) logits, bbox_preds (B, Q, code).
+    Returns boxes (B, K, 9|7), scores (B, K), labels (B, K) int32, keep (B, K) bool, all sorted by score."""
+    lib = _lib.load()
+    b, q, c = cls_scores.shape
+    code_size = bbox_preds.shape[-1]
+    k = int(max_num)
+    if k > q * c:
+        raise RuntimeError('selected index k out of range')        # what torch.topk raises in the reference
+    dev = cls_scores.device
+    boxes = torch.empty(b, k, 9 if code_size > 8 else 7, device=dev, dtype=torch.float32)
+    scores = torch.empty(b, k, device=dev, dtype=torch.float32)
+    labels = torch.empty(b, k, device=dev, dtype=torch.int32)
+    keep = torch.empty(b, k, device=dev, dtype=torch.uint8)
+    rng = (ctypes.c_float * 6)(*[float(v) for v in post_center_range])
+    thr = -1.0 if score_threshold is None else float(score_threshold)
+    code = lib.gd4d_nms_free_decode_fwd(_dev(cls_scores, 'cls_scores', torch.float32),
+                                        _dev(bbox_preds, 'bbox_preds', torch.float32), rng, thr, _dev(boxes, 'boxes'),
+                                        _dev(scores, 'scores'), _dev(labels, 'labels'), _dev(keep, 'keep'),
+                                        b, q, c, code_size, k, _stream())
+    _lib.check(code, 'gd4d_nms_free_decode_fwd')
+    return boxes, scores, labels, keep.bool()
+
+
 def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
                    grad_out):
     """gd4d_cross_attn_bwd.  Returns (grad_value, grad_ref, grad_offsets, grad_attn_logits, grad_cam_logits)."""

@@ -66,6 +66,7 @@ TRANSFORMER_LAYER = Registry('transformer layer', _mmcv('mmcv.cnn.bricks.registr
 TRANSFORMER_LAYER_SEQUENCE = Registry('transformer-layers sequence',
                                       _mmcv('mmcv.cnn.bricks.registry.TRANSFORMER_LAYER_SEQUENCE'))
 TRANSFORMER = Registry('transformer', _mmcv('mmdet.models.utils.builder.TRANSFORMER'))
+BBOX_CODERS = Registry('bbox coder', _mmcv('mmdet.core.bbox.builder.BBOX_CODERS'))
 
 
 def build_attention(cfg, default_args=None):
@@ -82,3 +83,7 @@ def build_transformer_layer_sequence(cfg, default_args=None):
 
 def build_transformer(cfg, default_args=None):
     return build_from_cfg(cfg, TRANSFORMER, default_args)
+
+
+def build_bbox_coder(cfg, default_args=None):
+    return build_from_cfg(cfg, BBOX_CODERS, default_args)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 3
+#define GD4D_ABI_VERSION 4
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -205,6 +205,36 @@ int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void
  *   out[:, 2]   = sigmoid(tmp[:, 4]   + inverse_sigmoid(ref[:, 2]))
  * tmp (M, ldt) = reg_branches[lid](output), ldt >= 5; ref, out (M, 3) fp32. */
 int gd4d_refine_reference_fwd(const float* tmp, const float* ref, float* out, int M, int ldt, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * The step right after the decoder: head epilogue + NMS-free box decoding.
+ *
+ * gd4d_box_head_fwd - Detr3DHeadPE.forward's per-layer box epilogue
+ * (projects/mmdet3d_plugin/models/dense_heads/detr3d_head_pe.py:571-600):
+ *   out = tmp;  out[:,0:2] = sigmoid(tmp[:,0:2] + inverse_sigmoid(ref[:,0:2])) * (hi-lo) + lo  [* scale]
+ *               out[:,4]   = sigmoid(tmp[:,4]   + inverse_sigmoid(ref[:,2]))   * (hi-lo) + lo  [* scale]
+ * tmp, out (M, code) fp32 (may alias), ref (M, 3) in [0,1]; pc_range: HOST, 6 doubles; the span hi-lo is
+ * formed in double and rounded to fp32 as the reference's Python-scalar arithmetic does; scale = 1 unless the
+ * head runs with scale_pred (img_metas[0]['depth_factors'][0], :591-593).  code >= 5.
+ */
+int gd4d_box_head_fwd(const float* tmp, const float* ref, const double* pc_range, float scale, float* out,
+                      int M, int code, void* stream);
+
+/* gd4d_nms_free_decode_fwd - NMSFreeCoder.decode_single for every batch element in one launch
+ * (projects/mmdet3d_plugin/core/bbox/coders/nms_free_coder.py:47-96; denormalize_bbox,
+ * projects/mmdet3d_plugin/core/bbox/util.py:58-87):
+ *   scores = sigmoid(cls_scores).view(-1);  (score, index) = top-K, descending (ties: lower index first);
+ *   labels = index % C;  box = bbox_preds[index / C] de-normalised to (cx, cy, cz, exp w, exp l, exp h, atan2(sin, cos)
+ *   [, vx, vy]);  keep = centre inside post_center_range (closed) [and score > score_threshold].
+ * cls_scores (B, Q, C) fp32 logits; bbox_preds (B, Q, code), code 10 -> 9 box columns, code 8 -> 7;
+ * post_center_range: HOST, 6 floats (lo xyz, hi xyz); score_threshold < 0 disables the score test;
+ * boxes (B, K, 9|7), scores (B, K) fp32, labels (B, K) int32, keep (B, K) uint8.  The reference's final
+ * boolean compaction (a data-dependent size) stays with the caller.  K <= 1024 and K <= Q*C
+ * (the reference's topk raises otherwise; so does the host side).
+ */
+int gd4d_nms_free_decode_fwd(const float* cls_scores, const float* bbox_preds, const float* post_center_range,
+                             float score_threshold, float* boxes, float* scores, int32_t* labels, uint8_t* keep,
+                             int B, int Q, int C, int code_size, int K, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_cross_attn_bwd - backward of gd4d_cross_attn_fwd.

@@ -341,3 +341,55 @@ def transformer(p, layer_params, mlvl_feats, query_embed, img_metas, pc_range,
                            query_pos.permute(1, 0, 2), ref, img_metas, pc_range,
                            reg_branches=reg_branches, **kw)
     return states, ref, refs
+
+
+# ---------------------------------------------------------------------------------------------
+# the step right after the decoder
+# ---------------------------------------------------------------------------------------------
+def box_head(tmp, reference, pc_range, depth_factor=None):
+    """Per-layer box epilogue of Detr3DHeadPE.forward (models/dense_heads/detr3d_head_pe.py:571-600).
+
+    NOT pinned by a reference-generated fixture: the head class cannot be imported without all of mmdet3d;
+    this restates the 15 arithmetic lines (tests pin it against the decoder's reference-pinned refinement:
+    the sigmoid part equals detr3d_transformer.py:201-214)."""
+    ref = inverse_sigmoid(reference)
+    out = tmp.clone()
+    out[..., 0:2] = (tmp[..., 0:2] + ref[..., 0:2]).sigmoid()
+    out[..., 4:5] = (tmp[..., 4:5] + ref[..., 2:3]).sigmoid()
+    for c, lo, hi in ((0, 0, 3), (1, 1, 4), (4, 2, 5)):
+        v = out[..., c:c + 1] * (pc_range[hi] - pc_range[lo]) + pc_range[lo]
+        out[..., c:c + 1] = v if depth_factor is None else v * depth_factor
+    return out
+
+
+def denormalize_bbox(b):
+    """core/bbox/util.py:58-87: (cx, cy, log w, log l, cz, log h, sin, cos[, vx, vy]) -> (cx, cy, cz, w, l, h, rot[, vx, vy])."""
+    rot = torch.atan2(b[..., 6:7], b[..., 7:8])
+    cols = [b[..., 0:1], b[..., 1:2], b[..., 4:5], b[..., 2:3].exp(), b[..., 3:4].exp(), b[..., 5:6].exp(), rot]
+    if b.shape[-1] > 8:
+        cols += [b[..., 8:9], b[..., 9:10]]
+    return torch.cat(cols, dim=-1)
+
+
+def nms_free_decode_single(cls_scores, bbox_preds, post_center_range, max_num, num_classes, score_threshold=None):
+    """core/bbox/coders/nms_free_coder.py:47-96.  Ties in the top-k are broken by the lower flat index."""
+    s = cls_scores.sigmoid().view(-1)
+    order = np.lexsort((np.arange(s.numel()), -s.numpy().astype(np.float64)))[:max_num]
+    if max_num > s.numel():
+        raise RuntimeError('selected index k out of range')
+    idx = torch.from_numpy(order.copy())
+    scores = s[idx]
+    labels = idx % num_classes
+    boxes = denormalize_bbox(bbox_preds[idx // num_classes])
+    rng = torch.tensor(post_center_range, dtype=torch.float32)
+    mask = (boxes[..., :3] >= rng[:3]).all(1) & (boxes[..., :3] <= rng[3:]).all(1)
+    if score_threshold:
+        mask &= scores > score_threshold
+    return {'bboxes': boxes[mask], 'scores': scores[mask], 'labels': labels[mask]}
+
+
+def nms_free_decode(preds, post_center_range, max_num, num_classes, score_threshold=None):
+    """nms_free_coder.py:98-117: decode the last decoder layer, one dict per batch element."""
+    cls, box = preds['all_cls_scores'][-1], preds['all_bbox_preds'][-1]
+    return [nms_free_decode_single(cls[b], box[b], post_center_range, max_num, num_classes, score_threshold)
+            for b in range(cls.shape[0])]

@@ -103,7 +103,12 @@ class Hooks:
             h.remove()
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith('-')]    # optional fixture-name filters
+
+
 def save(name, meta, **arrays):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     os.makedirs(OUT, exist_ok=True)
     arrays = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
               for k, v in arrays.items()}
@@ -297,6 +302,31 @@ def case_decoder(name, *, cross, num_query, frames, batch, img_hw, seed, num_lay
     save(name, meta, **arrays)
 
 
+def case_decode(name, *, num_query, batch, seed, max_num, code_size=10, score_threshold=None,
+                num_layers=2):
+    """NMSFreeCoder.decode (reference core/bbox/coders/nms_free_coder.py:98-117) on head outputs."""
+    coder_mod = refstub.load_coder()
+    g = torch.Generator().manual_seed(seed)
+    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    post_range = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+    cls = torch.randn(num_layers, batch, num_query, 10, generator=g) * 2 - 2
+    box = torch.randn(num_layers, batch, num_query, code_size, generator=g)
+    box[..., 0:2] *= 40.           # cx, cy: a good part falls outside +-61.2
+    box[..., 4] *= 6.              # cz: some outside +-10
+    coder = coder_mod.NMSFreeCoder(pc_range=pc_range, post_center_range=post_range, max_num=max_num,
+                                   score_threshold=score_threshold, num_classes=10)
+    with torch.no_grad():
+        preds = coder.decode({'all_cls_scores': cls.clone(), 'all_bbox_preds': box.clone()})
+    arrays = dict(all_cls_scores=cls, all_bbox_preds=box)
+    for b, d in enumerate(preds):
+        arrays[f'bboxes{b}'] = d['bboxes']
+        arrays[f'scores{b}'] = d['scores']
+        arrays[f'labels{b}'] = d['labels']
+    meta = dict(kind='decode', pc_range=pc_range, post_center_range=post_range, max_num=max_num,
+                score_threshold=score_threshold, num_classes=10, batch=batch, code_size=code_size)
+    save(name, meta, **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     case_deform('deform_n6', num_query=48, frames=1, batch=1, img_hw=(128, 224), seed=101)
@@ -313,6 +343,9 @@ def main():
                  img_hw=(64, 112), seed=401, num_layers=2)
     case_decoder('decoder_detr3d', cross='Detr3DCrossAtten', num_query=32, frames=1, batch=1,
                  img_hw=(64, 112), seed=402, num_layers=2)
+    case_decode('decode', num_query=90, batch=2, seed=501, max_num=300)
+    case_decode('decode_thr', num_query=64, batch=1, seed=502, max_num=100, score_threshold=0.2)
+    case_decode('decode_code8', num_query=20, batch=1, seed=503, max_num=100, code_size=8)
 
 
 if __name__ == '__main__':

@@ -403,3 +403,38 @@ def load_reference(names=('deform3d_cross_attn', 'detr3d_transformer')):
                 mod.sampling_locations = None      # the undefined name of the dead CPU branch
         out[n] = sys.modules[full]
     return out
+
+
+# --------------------------------------------------------------------------------------
+# bbox coder: the step right after the decoder
+# --------------------------------------------------------------------------------------
+BBOX_CODERS = Registry('bbox_coder')
+
+
+class BaseBBoxCoder:
+    """mmdet.core.bbox.BaseBBoxCoder: an interface with encode/decode, nothing else."""
+
+    def __init__(self, **kwargs):
+        pass
+
+
+def load_coder():
+    """Import the reference's NMSFreeCoder (and the util.py it uses) unmodified.
+
+    `projects.mmdet3d_plugin.core.bbox` is installed as a chain of empty namespace modules
+    whose __path__ points into the reference tree, so the package __init__ files (which pull
+    in all of mmdet3d) do not run, while `util.py` / `array_converter.py` / the coder file
+    are found and executed as they lie.
+    """
+    install_stubs()
+    _mod('mmdet.core')
+    _mod('mmdet.core.bbox', BaseBBoxCoder=BaseBBoxCoder)
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=BBOX_CODERS)
+    rel = ''
+    for part in ('projects', 'mmdet3d_plugin', 'core', 'bbox', 'coders'):
+        rel = f'{rel}.{part}' if rel else part
+        if rel not in sys.modules:
+            m = types.ModuleType(rel)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, *rel.split('.'))]
+            sys.modules[rel] = m
+    return importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.nms_free_coder')
