@@ -8,18 +8,25 @@
 // (and above score_threshold).  The reference runs this as ~15 torch ops (topk, gathers, cat, masks).
 //
 // One workgroup (1024 threads) per batch element:
-//   1. scores = sigmoid(logit) as IEEE bits (positive floats order like unsigned ints);
-//   2. radix select of the K-th largest key: four 8-bit histogram passes in LDS;
-//   3. gather the < K keys above the threshold and the lowest-index ties at the threshold into LDS (exactly K
-//      candidates, or n if n < K), bitonic sort them descending (ties: ascending index, deterministic);
-//   4. decode + range test for the sorted candidates.
+//   1. scores = sigmoid(logit) as IEEE bits (positive floats order like unsigned ints), kept in LDS;
+//   2. radix select of the K-th largest key: four 8-bit histogram passes (per-wave private LDS histograms, the
+//      digit walk as a shuffle suffix-scan);
+//   3. gather the keys above the threshold and the lowest-index ties at the threshold: exactly K survivors;
+//   4. rank sort (each survivor counts the survivors that precede it: key descending, ties by ascending index,
+//      deterministic), decode + range test, each thread writing its survivor to its rank's row.
 // The boolean compaction of the kept boxes (a host-visible size) stays with the caller, as in the reference.
 #include "gd4d_common.h"
+
+#ifndef GD4D_DEC_STOP
+#define GD4D_DEC_STOP 0      // dev ablation builds: return after phase N
+#endif
 
 namespace gd4d {
 
 constexpr int DEC_THREADS = 1024;
-constexpr int DEC_KMAX = 1024;          // max_num supported (sorted in LDS)
+constexpr int DEC_WAVES = DEC_THREADS / 64;
+constexpr int DEC_KMAX = 1024;          // max_num supported (one sorted entry per thread)
+constexpr size_t DEC_MAX_DYN_LDS = 128 * 1024;   // score keys live in LDS: Q*C <= 32768
 
 struct DecodeParams {
   const float* cls;        // (B, Q, C) logits
@@ -38,110 +45,177 @@ __device__ __forceinline__ unsigned score_key(float logit) {
   return __float_as_uint(s);
 }
 
+__device__ __forceinline__ unsigned long long pack_cand(unsigned key, int idx) {
+  return ((unsigned long long)key << 32) | (unsigned)~(unsigned)idx;
+}
+
 __global__ __launch_bounds__(DEC_THREADS) void nms_free_decode_kernel(const DecodeParams p) {
+  extern __shared__ unsigned s_keys[];              // n score keys (computed once)
+  __shared__ unsigned s_whist[DEC_WAVES][256];      // one private digit histogram per wave
   __shared__ unsigned s_hist[256];
-  __shared__ unsigned s_key[DEC_KMAX];
-  __shared__ int s_idx[DEC_KMAX];
-  __shared__ unsigned s_prefix, s_remaining, s_count_gt;
+  __shared__ unsigned long long s_cand[DEC_KMAX];   // survivors as key << 32 | ~index: larger sorts first
+  __shared__ unsigned s_wave_total[DEC_WAVES];
+  __shared__ unsigned s_prefix, s_remaining, s_eq_total, s_count;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int n = p.Q * p.C;
   const float* cls = p.cls + (size_t)b * n;
   const int K = min(p.K, n);
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-  // ---- radix select: find the key of the K-th largest element ----
-  if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)K; }
-  __syncthreads();
+  // one workgroup on one CU cannot hide HBM latency by occupancy: issue every load up front (8 x float4 per thread
+  // covers Q*C <= 32768), then convert
+  if ((n & 3) == 0) {
+    const float4* cls4 = reinterpret_cast<const float4*>(cls);   // b*n*4 bytes: 16 B aligned when n % 4 == 0
+    const int n4 = n >> 2;
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * DEC_THREADS;
+      v[u] = i < n4 ? cls4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * DEC_THREADS;
+      if (i < n4) {
+        uint4 k;
+        k.x = score_key(v[u].x); k.y = score_key(v[u].y); k.z = score_key(v[u].z); k.w = score_key(v[u].w);
+        reinterpret_cast<uint4*>(s_keys)[i] = k;
+      }
+    }
+  } else {
+    for (int i = tid; i < n; i += DEC_THREADS) s_keys[i] = score_key(cls[i]);
+  }
+  if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)K; s_count = 0u; }
+#if GD4D_DEC_STOP == 1
+  return;
+#endif
+
+  // ---- radix select: the key of the K-th largest element, 8 bits per pass ----
   for (int pass = 3; pass >= 0; --pass) {
-    if (tid < 256) s_hist[tid] = 0u;
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DEC_WAVES * 256 / DEC_THREADS; ++u) (&s_whist[0][0])[tid + u * DEC_THREADS] = 0u;
+    __syncthreads();                                // also: keys / previous pass's prefix are visible
     const unsigned prefix = s_prefix;
     const unsigned hi_mask = pass == 3 ? 0u : (0xffffffffu << (8 * (pass + 1)));
+    unsigned* hist = s_whist[wave];
+#pragma unroll 4
     for (int i = tid; i < n; i += DEC_THREADS) {
-      const unsigned k = score_key(cls[i]);
-      if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(k >> (8 * pass)) & 255u], 1u);
+      const unsigned k = s_keys[i];
+      if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rem = s_remaining, acc = 0u;
-      int d = 255;
-      for (; d > 0; --d) {                         // walk digits from the top until the K-th falls inside
-        if (acc + s_hist[d] >= rem) break;
-        acc += s_hist[d];
+    if (tid < 256) {
+      unsigned t = 0u;
+#pragma unroll
+      for (int w = 0; w < DEC_WAVES; ++w) t += s_whist[w][tid];
+      s_hist[tid] = t;
+    }
+    __syncthreads();
+    if (wave == 0) {                                // lane l owns bins 4l..4l+3; suffix sums by shuffles
+      const unsigned h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2],
+                     h3 = s_hist[4 * lane + 3];
+      const unsigned tot = h0 + h1 + h2 + h3;
+      unsigned x = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned y = __shfl_down(x, off);
+        if (lane + off < 64) x += y;
       }
-      s_prefix = prefix | ((unsigned)d << (8 * pass));
-      s_remaining = rem - acc;                      // how many we still need among keys with this digit
+      const unsigned rem = s_remaining;
+      const unsigned a3 = x - tot, a2 = a3 + h3, a1 = a2 + h2, a0 = a1 + h1;   // keys in bins above bin b
+      int sub = -1;
+      unsigned above = 0u, here = 0u;
+      if (a3 < rem && rem <= a3 + h3) { sub = 3; above = a3; here = h3; }
+      else if (a2 < rem && rem <= a2 + h2) { sub = 2; above = a2; here = h2; }
+      else if (a1 < rem && rem <= a1 + h1) { sub = 1; above = a1; here = h1; }
+      else if (a0 < rem && rem <= a0 + h0) { sub = 0; above = a0; here = h0; }
+      if (sub >= 0) {                               // exactly one lane: the digit holding the K-th key
+        s_prefix = prefix | ((unsigned)(4 * lane + sub) << (8 * pass));
+        s_remaining = rem - above;
+        s_eq_total = here;                          // after the last pass: how many keys equal the threshold
+      }
     }
-    __syncthreads();
   }
+  __syncthreads();
+#if GD4D_DEC_STOP == 2
+  return;
+#endif
   const unsigned thr = s_prefix;                    // K-th largest key
   const unsigned need_eq = s_remaining;             // ties at the threshold to take (lowest indices first)
+  const bool all_ties = s_eq_total == need_eq;      // the usual case: every key == thr is a survivor
 
-  // ---- collect candidates: all keys > thr, then `need_eq` of the keys == thr in index order ----
-  if (tid == 0) s_count_gt = 0u;
-  for (int i = tid; i < DEC_KMAX; i += DEC_THREADS) { s_key[i] = 0u; s_idx[i] = 0x7fffffff; }
-  __syncthreads();
-  for (int i = tid; i < n; i += DEC_THREADS) {
-    const unsigned k = score_key(cls[i]);
-    if (k > thr) {
-      const unsigned slot = atomicAdd(&s_count_gt, 1u);
-      s_key[slot] = k; s_idx[slot] = i;
+  // ---- survivors: every key > thr (and every key == thr when all of them fit), in any order ----
+  for (int i0 = 0; i0 < n; i0 += DEC_THREADS) {
+    const int i = i0 + tid;
+    const unsigned k = i < n ? s_keys[i] : 0u;
+    const bool take = i < n && (k > thr || (all_ties && k == thr));
+    const unsigned long long m = __ballot(take);
+    unsigned base = 0u;
+    if (lane == 0 && m) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+    base = __shfl(base, 0);
+    if (take) s_cand[base + (unsigned)__popcll(m & lanes_below)] = pack_cand(k, i);
+  }
+  if (!all_ties) {
+    // more keys == thr than places left: the lowest flat indices win.  Each thread owns a contiguous chunk,
+    // counts its ties, a two-level scan ranks them.
+    const int chunk = (n + DEC_THREADS - 1) / DEC_THREADS;
+    const int c0 = min(tid * chunk, n), c1 = min(c0 + chunk, n);
+    unsigned mine = 0u;
+    for (int i = c0; i < c1; ++i) mine += s_keys[i] == thr ? 1u : 0u;
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned y = __shfl_up(incl, off);
+      if (lane >= off) incl += y;
+    }
+    if (lane == 63) s_wave_total[wave] = incl;
+    __syncthreads();                                // also publishes s_count (== K - need_eq)
+    const unsigned ngt = s_count;
+    unsigned rank = incl - mine;
+    for (int w = 0; w < wave; ++w) rank += s_wave_total[w];
+    if (mine > 0u && rank < need_eq) {
+      for (int i = c0; i < c1 && rank < need_eq; ++i)
+        if (s_keys[i] == thr) { s_cand[ngt + rank] = pack_cand(thr, i); ++rank; }
     }
   }
   __syncthreads();
-  const unsigned ngt = s_count_gt;                  // == K - need_eq
-  // ties: deterministic lowest-index-first needs an ordered scan; ties are rare, a single thread walks them
-  if (tid == 0 && need_eq > 0u) {
-    unsigned taken = 0u;
-    for (int i = 0; i < n && taken < need_eq; ++i)
-      if (score_key(cls[i]) == thr) { s_key[ngt + taken] = thr; s_idx[ngt + taken] = i; ++taken; }
-  }
-  __syncthreads();
+#if GD4D_DEC_STOP == 3
+  return;
+#endif
 
-  // ---- bitonic sort of DEC_KMAX (key desc, index asc); padding (key 0, idx INT_MAX) sinks to the end ----
-  for (int size = 2; size <= DEC_KMAX; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int i = tid;                            // DEC_THREADS == DEC_KMAX: one element per thread
-      const int j = i ^ stride;
-      if (j > i) {
-        const unsigned ki = s_key[i], kj = s_key[j];
-        const int ii = s_idx[i], ij = s_idx[j];
-        const bool i_before_j = ki > kj || (ki == kj && ii < ij);     // desired order: i first
-        const bool descending_block = (i & size) == 0;
-        if (descending_block ? !i_before_j : i_before_j) {
-          s_key[i] = kj; s_key[j] = ki; s_idx[i] = ij; s_idx[j] = ii;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  // ---- rank sort: candidate t's output row = how many candidates sort before it (key desc, index asc).
+  // All lanes read the same s_cand[j] (an LDS broadcast), no barriers; K^2 / 1024 compares per thread ----
+  if (tid >= K) return;
+  const unsigned long long me = s_cand[tid];
+  int r = 0;
+#pragma unroll 16
+  for (int j = 0; j < K; ++j) r += s_cand[j] > me ? 1 : 0;
+#if GD4D_DEC_STOP == 4
+  if (r == 0x12345) p.scores[0] = 0.f;
+  return;
+#endif
 
-  // ---- decode ----
+  // ---- decode my candidate into row r ----
   const int nbox = p.code > 8 ? 9 : 7;
-  for (int r = tid; r < p.K; r += DEC_THREADS) {
-    float* ob = p.boxes + ((size_t)b * p.K + r) * nbox;
-    const size_t o = (size_t)b * p.K + r;
-    if (r >= K) {                                   // fewer than K scores exist: pad
-      for (int c = 0; c < nbox; ++c) ob[c] = 0.f;
-      p.scores[o] = 0.f; p.labels[o] = 0; p.keep[o] = 0;
-      continue;
-    }
-    const int idx = s_idx[r];
-    const int qi = idx / p.C;
-    const float* bb = p.bbox + ((size_t)b * p.Q + qi) * p.code;
-    const float cx = bb[0], cy = bb[1], cz = bb[4];
-    ob[0] = cx; ob[1] = cy; ob[2] = cz;
-    ob[3] = expf(bb[2]); ob[4] = expf(bb[3]); ob[5] = expf(bb[5]);
-    ob[6] = atan2f(bb[6], bb[7]);
-    if (nbox == 9) { ob[7] = bb[8]; ob[8] = bb[9]; }
-    const float sc = __uint_as_float(s_key[r]);
-    p.scores[o] = sc;
-    p.labels[o] = idx - qi * p.C;
-    bool ok = cx >= p.range_lo[0] && cy >= p.range_lo[1] && cz >= p.range_lo[2] &&
-              cx <= p.range_hi[0] && cy <= p.range_hi[1] && cz <= p.range_hi[2];
-    if (p.score_thr >= 0.f) ok = ok && sc > p.score_thr;
-    p.keep[o] = ok ? 1 : 0;
-  }
+  const int idx = (int)~(unsigned)me;
+  const int qi = idx / p.C;
+  const size_t o = (size_t)b * p.K + r;
+  float* ob = p.boxes + o * nbox;
+  const float* bb = p.bbox + ((size_t)b * p.Q + qi) * p.code;
+  const float cx = bb[0], cy = bb[1], cz = bb[4];
+  ob[0] = cx; ob[1] = cy; ob[2] = cz;
+  ob[3] = expf(bb[2]); ob[4] = expf(bb[3]); ob[5] = expf(bb[5]);
+  ob[6] = atan2f(bb[6], bb[7]);
+  if (nbox == 9) { ob[7] = bb[8]; ob[8] = bb[9]; }
+  const float sc = __uint_as_float((unsigned)(me >> 32));
+  p.scores[o] = sc;
+  p.labels[o] = idx - qi * p.C;
+  bool ok = cx >= p.range_lo[0] && cy >= p.range_lo[1] && cz >= p.range_lo[2] &&
+            cx <= p.range_hi[0] && cy <= p.range_hi[1] && cz <= p.range_hi[2];
+  if (p.score_thr >= 0.f) ok = ok && sc > p.score_thr;
+  p.keep[o] = ok ? 1 : 0;
 }
 
 // Head box epilogue (dense_heads/detr3d_head_pe.py:571-600), one thread per query.  Un-fused fp32 arithmetic in the
@@ -175,13 +249,23 @@ extern "C" int gd4d_nms_free_decode_fwd(const float* cls_scores, const float* bb
   using namespace gd4d;
   if (!cls_scores || !bbox_preds || !post_center_range || !boxes || !scores || !labels || !keep) return GD4D_EINVAL;
   if (B <= 0 || Q <= 0 || C <= 0 || K <= 0) return GD4D_EINVAL;
+  if (K > Q * C) return GD4D_EINVAL;            // torch.topk raises in the reference
   if (K > DEC_KMAX || (code_size != 8 && code_size != 10)) return GD4D_EUNSUPPORTED;
   DecodeParams p{};
   p.cls = cls_scores; p.bbox = bbox_preds; p.boxes = boxes; p.scores = scores; p.labels = labels; p.keep = keep;
   p.Q = Q; p.C = C; p.code = code_size; p.K = K;
   for (int k = 0; k < 3; ++k) { p.range_lo[k] = post_center_range[k]; p.range_hi[k] = post_center_range[k + 3]; }
   p.score_thr = score_threshold;
-  hipLaunchKernelGGL(nms_free_decode_kernel, dim3(B), dim3(DEC_THREADS), 0, static_cast<hipStream_t>(stream), p);
+  const size_t lds = (size_t)Q * C * sizeof(unsigned);
+  if (lds > DEC_MAX_DYN_LDS) return GD4D_EUNSUPPORTED;
+  static bool configured = false;                   // allow more than the default 64 KB of LDS per workgroup
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_free_decode_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_MAX_DYN_LDS) != hipSuccess)
+      return GD4D_ELAUNCH;
+    configured = true;
+  }
+  hipLaunchKernelGGL(nms_free_decode_kernel, dim3(B), dim3(DEC_THREADS), lds, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }
 

@@ -229,7 +229,7 @@ int gd4d_box_head_fwd(const float* tmp, const float* ref, const double* pc_range
  * cls_scores (B, Q, C) fp32 logits; bbox_preds (B, Q, code), code 10 -> 9 box columns, code 8 -> 7;
  * post_center_range: HOST, 6 floats (lo xyz, hi xyz); score_threshold < 0 disables the score test;
  * boxes (B, K, 9|7), scores (B, K) fp32, labels (B, K) int32, keep (B, K) uint8.  The reference's final
- * boolean compaction (a data-dependent size) stays with the caller.  K <= 1024 and K <= Q*C
+ * boolean compaction (a data-dependent size) stays with the caller.  K <= 1024, Q*C <= 32768 and K <= Q*C
  * (the reference's topk raises otherwise; so does the host side).
  */
 int gd4d_nms_free_decode_fwd(const float* cls_scores, const float* bbox_preds, const float* post_center_range,
