@@ -261,12 +261,12 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
     captured = []
     orig = Fn.sample_aggregate
 
-    def spy(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w):
+    def spy(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=None):
         nl_pix = sum(h * w for h, w in shapes)
         captured.append(dict(head_major=(value.shape[2] == nl_pix and value.shape[1] != nl_pix), value=value, shapes=shapes, ref=ref.contiguous(), offsets=offsets.contiguous(),
                              attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img,
-                             pc_range=pc_range, img_h=img_h, img_w=img_w))
-        return orig(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w)
+                             pc_range=pc_range, img_h=img_h, img_w=img_w, order=order))
+        return orig(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=order)
     Fn.sample_aggregate = spy
     try:
         with torch.no_grad():
@@ -279,7 +279,8 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
     for c in captured:
         call = (lambda c: (lambda **kw: ops.cross_attn_fwd(c['value'], c['shapes'], c['ref'], c['offsets'], c['attn'],
                                                            c['cam'], c['l2i'], c['pc_range'], c['img_h'], c['img_w'],
-                                                           head_major=c['head_major'], **kw)))(c)
+                                                           head_major=c['head_major'], query_order=c['order'],
+                                                           **kw)))(c)
         out, mask = call(want_mask=True)
         b, n, q, hh, p = mask.shape
         nl = len(c['shapes'])

@@ -32,6 +32,7 @@ struct CrossAttnParams {
   float* out;
   uint8_t* mask_out;
   float* uv_out;
+  const int32_t* order;   // optional permutation of [0, B*Q): locality order of the queries (gd4d_query_order_fwd)
   int B, N, Q, L, S;
   int head_major;      // value layout: 0 = (B*N, S, Hh, Dh) pixel-major, 1 = (B*N, Hh, S, Dh) head-major planes
   int lvl_h[GD4D_MAX_LEVELS];
@@ -203,10 +204,15 @@ __global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttn
 // the code is branch-free - an invisible point of a visible camera (~5 %) gets weight 0 and reads
 // the map centre - so all 4 points x L levels x 4 corners loads can be issued back to back.
 // Partial sums are combined through LDS in fixed wave order (deterministic).
+#ifndef GD4D_GATHER_OCC
 #ifdef GD4D_GATHER_HALF
 #define GD4D_GATHER_OCC 4
 #else
 #define GD4D_GATHER_OCC 3
+#endif
+#endif
+#ifndef GD4D_GATHER_WAVES
+#define GD4D_GATHER_WAVES 4
 #endif
 template <typename VT, int HH, int LT, int WAVES>
 __global__ __launch_bounds__(GD4D_WAVE * WAVES, GD4D_GATHER_OCC) void cross_attn_fwd_block(const CrossAttnParams p) {
@@ -223,7 +229,17 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES, GD4D_GATHER_OCC) void cross_attn
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bq = blockIdx.x;
+  // Workgroup i runs on XCD i % 8 (round-robin dispatch), each XCD with a private L2.  With a locality order of the
+  // queries every XCD takes a contiguous range of it, so queries that look at the same camera region share an L2.
+  int bq = blockIdx.x;
+  if (p.order) {
+    const int per_xcd = (p.B * p.Q + 7) >> 3;
+    const int pos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || pos >= p.B * p.Q) return;
+    bq = p.order[pos];
+  } else if (bq >= p.B * p.Q) {
+    return;
+  }
   const int b = bq / p.Q;
   const int q = bq - b * p.Q;
   const int L = LT > 0 ? LT : p.L;
@@ -393,12 +409,12 @@ static int cross_attn_variant() {
 
 template <typename VT, int HH, int LT>
 static void launch_one(const CrossAttnParams& p, hipStream_t s) {
-  const dim3 grid(p.B * p.Q);
+  const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
   if (cross_attn_variant() == 1 && !p.head_major) {
     const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
-    hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, LT>), grid, dim3(GD4D_WAVE), lds, s, p);
+    hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, LT>), dim3(p.B * p.Q), dim3(GD4D_WAVE), lds, s, p);   // ignores p.order
   } else {
-    constexpr int WAVES = 4;
+    constexpr int WAVES = GD4D_GATHER_WAVES;
     const size_t lds = (WAVES - 1) * GD4D_WAVE * sizeof(float4) + (size_t)p.N * HH * kPoints * sizeof(float2) +
                        (size_t)p.N * sizeof(int);
     hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
@@ -434,7 +450,8 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
                                    const float* cam_logits, const float* lidar2img,
                                    const double* pc_range, float img_h, float img_w, float* out,
                                    uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
-                                   int Dh, int L, int P, int value_dtype, int value_layout, void* stream) {
+                                   int Dh, int L, int P, int value_dtype, int value_layout,
+                                   const int32_t* query_order, void* stream) {
   using namespace gd4d;
   if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img ||
       !pc_range || !out)
@@ -449,7 +466,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
   CrossAttnParams p{};
   p.value = value; p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits;
   p.cam_logits = cam_logits; p.lidar2img = lidar2img; p.out = out; p.mask_out = mask_out;
-  p.uv_out = uv_out;
+  p.uv_out = uv_out; p.order = query_order;
   p.B = B; p.N = N; p.Q = Q; p.L = L;
   p.head_major = value_layout == GD4D_LAYOUT_HEAD_MAJOR;
   int start = 0;

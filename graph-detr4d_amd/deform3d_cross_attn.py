@@ -128,8 +128,11 @@ class Deform3DCrossAttn(nn.Module):
                                               hh, self.value_dtype)
         lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
+        order = kwargs.get(Fn.QUERY_ORDER_KEY)
+        if order is None or order.numel() != b * q:
+            order = Fn.query_order(reference_points, self.pc_range)
         agg = Fn.sample_aggregate(val, shapes, reference_points, offsets, attn_logits, cam_logits,
-                                  lidar2img, self.pc_range, img_h, img_w)    # (B, Q, C)
+                                  lidar2img, self.pc_range, img_h, img_w, order=order)    # (B, Q, C)
 
         ref3d = reference_points
         if self.depth_encode:                                             # :331-333

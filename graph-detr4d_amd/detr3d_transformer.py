@@ -132,10 +132,25 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         kwargs[Fn.VALUE_CACHE_KEY] = Fn.project_values_for_layers(mods, value)
         return kwargs
 
+    def _order_queries(self, kwargs, reference_points):
+        """Locality order of the queries (Fn.query_order) for the first layer's fused kernel; later layers get theirs
+        from the fused refinement launch (without reg_branches the points, and so the order, never change)."""
+        mods = [a for layer in self.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
+        if not mods or reference_points is None or not reference_points.is_cuda or Fn.QUERY_ORDER_KEY in kwargs:
+            return kwargs
+        order = Fn.query_order(reference_points, mods[0].pc_range)
+        if order is None:
+            return kwargs
+        self._order_pc_range = mods[0].pc_range
+        kwargs = dict(kwargs)
+        kwargs[Fn.QUERY_ORDER_KEY] = order
+        return kwargs
+
     def forward(self, query, *args, reference_points=None, reg_branches=None, **kwargs):
         output = query
         intermediate, intermediate_reference_points = [], []
         kwargs = self._preproject_values(kwargs)
+        kwargs = self._order_queries(kwargs, reference_points)
         for lid, layer in enumerate(self.layers):
             output = layer(output, *args, reference_points=reference_points, **kwargs)
             if reg_branches is not None:
@@ -144,7 +159,12 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                 tmp = reg_branches[lid](output.permute(1, 0, 2)) if grad else \
                     Fn.run_branch(reg_branches[lid], output.permute(1, 0, 2).contiguous())
                 if tmp.is_cuda and tmp.dtype == torch.float32 and not grad:
-                    reference_points = Fn.refine_reference(tmp, reference_points).detach()
+                    if Fn.QUERY_ORDER_KEY in kwargs and lid + 1 < len(self.layers):
+                        # refinement + a fresh locality order for the next layer's fused kernel, one launch
+                        reference_points, kwargs[Fn.QUERY_ORDER_KEY] = Fn.refine_reference_order(
+                            tmp, reference_points, self._order_pc_range)
+                    else:
+                        reference_points = Fn.refine_reference(tmp, reference_points).detach()
                 else:
                     new_ref = torch.zeros_like(reference_points)
                     new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])

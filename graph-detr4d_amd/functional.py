@@ -1,5 +1,7 @@
 """Host-side helpers shared by the attention modules (GPU only; no CPU fallback)."""
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -184,11 +186,33 @@ def project_values_for_layers(modules, value):
     return {id(m): ((o if hm else o.view(b * n, -1, hh, c // hh)), shapes, value) for m, o in zip(modules, outs)}
 
 
+QUERY_ORDER_KEY = '_gd4d_query_order'
+
+
+def query_order(reference_points, pc_range):
+    """Locality order of the queries for the fused kernel (ops.query_order_fwd): one tiny launch; the decoder computes
+    it once per call and hands it to every layer through kwargs[QUERY_ORDER_KEY].  GD4D_QUERY_ORDER=0 disables."""
+    if not query_order_enabled(reference_points):
+        return None
+    return ops.query_order_fwd(reference_points.detach().contiguous(), pc_range)
+
+
+def query_order_enabled(reference_points):
+    """gd4d_query_order_fwd sorts in one workgroup: up to 4096 queries per call; beyond that run unordered."""
+    return os.environ.get('GD4D_QUERY_ORDER', '1') != '0' and reference_points.is_cuda and \
+        reference_points.shape[0] * reference_points.shape[1] <= 4096 and reference_points.shape[0] <= 512
+
+
+def refine_reference_order(tmp, reference_points, pc_range):
+    """refine_reference + the locality order of the refined points in one launch (ops.refine_reference_order_fwd)."""
+    return ops.refine_reference_order_fwd(tmp.contiguous(), reference_points.contiguous(), pc_range)
+
+
 def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                     img_h, img_w):
+                     img_h, img_w, order=None):
     """The fused HIP kernel (ops.cross_attn_fwd): projection + mask + softmax + gather + camera sum."""
     nl_pix = sum(h * w for h, w in shapes)
     head_major = value.shape[2] == nl_pix and value.shape[1] != nl_pix      # (B*N, Hh, S, Dh) planes
     return ops.cross_attn_fwd(value, shapes, ref.contiguous(), offsets.contiguous(),
                               attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
-                              pc_range, img_h, img_w, head_major=head_major)
+                              pc_range, img_h, img_w, head_major=head_major, query_order=order)

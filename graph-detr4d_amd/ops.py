@@ -33,10 +33,11 @@ def _value_dtype(t):
 
 
 def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                   img_h, img_w, want_mask=False, want_uv=False, out=None, head_major=False):
+                   img_h, img_w, want_mask=False, want_uv=False, out=None, head_major=False, query_order=None):
     """gd4d_cross_attn_fwd.  value (B*N, S, Hh, Dh), or (B*N, Hh, S, Dh) with head_major=True;
     ref (B,Q,3); offsets (B,Q,Hh,P,3);
     attn_logits (B,Q,Hh,L,P) (or (B,Q,Hh,L*P)); cam_logits (B,Q,N); lidar2img (B,N,4,4).
+    query_order: optional int32 permutation of [0, B*Q) from query_order_fwd (scheduling only, same result).
     Returns out (B,Q,Hh*Dh) [, mask (B,N,Q,Hh,P) uint8] [, uv (B,N,Q,Hh,P,2)]."""
     lib = _lib.load()
     b, q = ref.shape[0], ref.shape[1]
@@ -62,7 +63,7 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
         _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(out, 'out', f32),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None,
         b, n, q, hh, dh, nl, p, _value_dtype(value), _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR,
-        _stream())
+        None if query_order is None else _order_ptr(query_order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_fwd')
     res = (out,)
     if want_mask:
@@ -70,6 +71,24 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
     if want_uv:
         res += (uv,)
     return res if len(res) > 1 else out
+
+
+def _order_ptr(order, count):
+    if order.dtype != torch.int32 or order.numel() != count:
+        raise ValueError(f'query_order must be an int32 permutation of {count} entries')
+    return _dev(order, 'query_order')
+
+
+def query_order_fwd(ref, pc_range, out=None):
+    """gd4d_query_order_fwd: ref (B,Q,3) in [0,1] -> int32 (B*Q) locality order for cross_attn_fwd(query_order=)."""
+    lib = _lib.load()
+    b, q = ref.shape[0], ref.shape[1]
+    if out is None:
+        out = torch.empty(b * q, device=ref.device, dtype=torch.int32)
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    code = lib.gd4d_query_order_fwd(_dev(ref, 'ref', torch.float32), rng, _order_ptr(out, b * q), b, q, _stream())
+    _lib.check(code, 'gd4d_query_order_fwd')
+    return out
 
 
 def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_out=True,
@@ -268,6 +287,20 @@ def nms_free_decode_fwd(cls_scores, bbox_preds, post_center_range, max_num, scor
                                         b, q, c, code_size, k, _stream())
     _lib.check(code, 'gd4d_nms_free_decode_fwd')
     return boxes, scores, labels, keep.bool()
+
+
+def refine_reference_order_fwd(tmp, ref, pc_range):
+    """gd4d_refine_reference_order_fwd: tmp (B, Q, >=5), ref (B, Q, 3) -> (new ref, int32 locality order of it)."""
+    lib = _lib.load()
+    b, q = ref.shape[0], ref.shape[1]
+    out = torch.empty_like(ref)
+    order = torch.empty(b * q, device=ref.device, dtype=torch.int32)
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    code = lib.gd4d_refine_reference_order_fwd(_dev(tmp, 'tmp', torch.float32), _dev(ref, 'ref', torch.float32),
+                                               _dev(out, 'out'), rng, _dev(order, 'order'), b, q, tmp.shape[-1],
+                                               _stream())
+    _lib.check(code, 'gd4d_refine_reference_order_fwd')
+    return out, order
 
 
 def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 4
+#define GD4D_ABI_VERSION 5
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -85,6 +85,9 @@ const char* gd4d_last_hip_error(void);
  *   mask_out     optional (B, N, Q, Hh, P) uint8 visibility mask (bit-exact vs the reference's CPU
  *                arithmetic at this boundary); NULL to skip
  *   uv_out       optional (B, N, Q, Hh, P, 2) fp32 normalised image coordinates; NULL to skip
+ *   query_order  optional int32 permutation of [0, B*Q) from gd4d_query_order_fwd, or NULL.  Scheduling only: with
+ *                it each XCD (private L2) processes queries that look at the same camera region; the result is
+ *                bit-identical for any permutation.
  *
  * Attention logits for value row i = b*N+n are taken from batch (i % B): this is what the
  * reference's `query.repeat(num_cams,1,1)` (:277) pairs them with; identity for B = 1.
@@ -96,7 +99,24 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
                         const float* offsets, const float* attn_logits, const float* cam_logits,
                         const float* lidar2img, const double* pc_range, float img_h, float img_w,
                         float* out, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
-                        int Dh, int L, int P, int value_dtype, int value_layout, void* stream);
+                        int Dh, int L, int P, int value_dtype, int value_layout,
+                        const int32_t* query_order, void* stream);
+
+/* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the
+ * reference's MSDA kernel processes queries in index order).  Counting sort by (sample, azimuth of the de-normalised
+ * reference point about the lidar origin, deform3d_cross_attn.py:222-224): the cameras sit near that origin, so
+ * neighbours in this order project into the same image columns of the same cameras.
+ *   ref (B, Q, 3) fp32 in [0,1], pc_range host 6 doubles;
+ *   order (B*Q) int32 out: a permutation of [0, B*Q) (order inside an azimuth bin unspecified).
+ * Supported: B <= 512, B*Q <= 4096 (callers fall back to no order beyond that).
+ */
+int gd4d_query_order_fwd(const float* ref, const double* pc_range, int32_t* order, int B, int Q, void* stream);
+
+/* gd4d_refine_reference_order_fwd - gd4d_refine_reference_fwd (detr3d_transformer.py:201-214) and
+ * gd4d_query_order_fwd of the refined points in one launch, so that every decoder layer gets a fresh order for free.
+ *   tmp (B*Q, ldt), ref (B, Q, 3), out (B, Q, 3), order (B*Q) int32.  Same limits as gd4d_query_order_fwd. */
+int gd4d_refine_reference_order_fwd(const float* tmp, const float* ref, float* out, const double* pc_range,
+                                    int32_t* order, int B, int Q, int ldt, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_detr3d_fwd - DETR3D-baseline core: feature_sampling (detr3d_transformer.py:397-438) fused

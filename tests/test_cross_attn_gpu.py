@@ -177,3 +177,48 @@ def test_unsupported_shapes_fail_loudly():
     with pytest.raises(_lib.Gd4dError, match='not supported'):   # embed_dims 128
         ops.cross_attn_fwd(z(6, 4, 8, 16), [(2, 2)], z(1, 3, 3), z(1, 3, 8, 4, 3), z(1, 3, 8, 1, 4), z(1, 3, 6),
                            z(1, 6, 4, 4), [0, 0, 0, 1, 1, 1], 8, 8)
+
+
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n24_b2', 'deform_edge'])
+def test_query_order_is_a_permutation_and_does_not_change_the_result(name):
+    """gd4d_query_order_fwd only reschedules the workgroups: outputs, mask and uv stay bit-identical, for its own
+    order and for an arbitrary permutation."""
+    from graph_detr4d_amd import ops
+    g = Golden(name)
+    args, d, m = _inputs(g, 'cuda')
+    kw = dict(pc_range=m['pc_range'], img_h=m['img_shape'][0], img_w=m['img_shape'][1])
+    base = ops.cross_attn_fwd(**d, **kw, want_mask=True, want_uv=True)
+    bq = m['batch'] * m['num_query']
+    order = ops.query_order_fwd(d['ref'], m['pc_range'])
+    assert order.dtype == torch.int32 and order.shape == (bq,)
+    assert torch.equal(torch.sort(order.cpu().long()).values, torch.arange(bq))
+    perm = torch.randperm(bq, generator=torch.Generator().manual_seed(5)).int().cuda()
+    for o in (order, perm):
+        got = ops.cross_attn_fwd(**d, **kw, want_mask=True, want_uv=True, query_order=o)
+        for a, b_ in zip(got, base):
+            assert torch.equal(a, b_)
+    with pytest.raises(ValueError):
+        ops.cross_attn_fwd(**d, **kw, query_order=order[:-1])
+    with pytest.raises(ValueError):
+        ops.cross_attn_fwd(**d, **kw, query_order=order.long())
+
+
+def test_query_order_sorts_by_sample_then_azimuth():
+    """Keys are (sample, azimuth bin of the de-normalised reference point about the lidar origin)."""
+    import math
+    from graph_detr4d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    b, q = 2, 700
+    pc_range = [-40., -30., -5., 60., 50., 3.]                    # origin not at the centre of the range
+    ref = torch.rand(b, q, 3, generator=g)
+    order = ops.query_order_fwd(ref.cuda(), pc_range).cpu().long()
+    assert torch.equal(torch.sort(order).values, torch.arange(b * q))
+    sample = order // q
+    assert bool((sample[1:] >= sample[:-1]).all())
+    x = ref[..., 0] * 100. - 40.
+    y = ref[..., 1] * 80. - 30.
+    az = torch.atan2(y, x).reshape(-1)[order]
+    for s_ in range(b):
+        a = az[sample == s_]
+        # non-decreasing up to the width of one bin (2 pi / 2048) and fp32 rounding
+        assert bool((a[1:] - a[:-1] > -(2 * math.pi / 2048) - 1e-5).all())

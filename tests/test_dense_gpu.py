@@ -107,3 +107,25 @@ def test_refine_reference_matches_reference_formula():
     want[..., :2] = tmp[..., :2] + isg(ref[..., :2])
     want[..., 2:3] = tmp[..., 4:5] + isg(ref[..., 2:3])
     torch.testing.assert_close(got, want.sigmoid(), rtol=1e-5, atol=1e-6)
+
+
+def test_refine_reference_order_matches_separate_kernels():
+    from graph_detr4d_amd import ops
+    g = torch.Generator().manual_seed(9)
+    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    for b, q in ((1, 900), (2, 1350), (1, 37)):
+        tmp = torch.randn(b, q, 10, generator=g).cuda()
+        ref = torch.rand(b, q, 3, generator=g).cuda()
+        ref[0, 0] = torch.tensor([0., 1., 0.5])
+        new_ref, order = ops.refine_reference_order_fwd(tmp, ref, pc_range)
+        assert torch.equal(new_ref, ops.refine_reference_fwd(tmp, ref))
+        assert torch.equal(torch.sort(order.cpu().long()).values, torch.arange(b * q))
+        # same keys as the standalone order kernel: equal as multisets per azimuth bin -> compare sorted azimuths
+        alone = ops.query_order_fwd(new_ref, pc_range).cpu().long()
+        x = new_ref[..., 0].cpu().reshape(-1) * 102.4 - 51.2
+        y = new_ref[..., 1].cpu().reshape(-1) * 102.4 - 51.2
+        az = torch.atan2(y, x)
+        both = torch.stack([az[order.cpu().long()], az[alone]])
+        assert (both[0] - both[1]).abs().max().item() <= 2 * 3.1416 / (4096 // b) + 1e-5
+    with pytest.raises(Exception):
+        ops.query_order_fwd(torch.rand(1, 5000, 3).cuda(), pc_range)
