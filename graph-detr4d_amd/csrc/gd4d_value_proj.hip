@@ -31,6 +31,8 @@
 //     double buffered, so HBM reads overlap the matrix work.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gd4d_common.h"
 
 namespace gd4d {
@@ -239,7 +241,11 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValuePr
 
 }  // namespace gd4d
 
+static std::atomic<int> g_cu_limit{0};
+
 extern "C" size_t gd4d_value_proj_workspace_bytes(void) { return 0; }
+
+extern "C" int gd4d_value_proj_set_cu_limit(int cus) { return g_cu_limit.exchange(cus < 0 ? 0 : cus); }
 
 namespace gd4d {
 
@@ -808,6 +814,13 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
+  {
+    // leave CUs free for kernels of another stream (gd4d_value_proj_set_cu_limit; GD4D_VP_CUS overrides, dev switch)
+    static int env_limit = -1;
+    if (env_limit < 0) { const char* e = getenv("GD4D_VP_CUS"); env_limit = e ? atoi(e) : 0; }
+    const int limit = env_limit > 0 ? env_limit : g_cu_limit.load(std::memory_order_relaxed);
+    if (limit >= 8 && limit < cus) cus = limit - limit % 8;
+  }
   int slots = cus / NL;                                // persistent: <= one workgroup per CU
   if (slots < 1) slots = 1;
   if (slots > base) slots = base;
@@ -821,7 +834,15 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
       if (8 * (per_xcd / NL) <= base) { g2 = 8 * per_xcd; p.xcd_groups = 1; }
     }
     const int grid = g2;
-    const size_t lds2 = 2 * (size_t)VP_C * 32 * 4 + 2 * 2 * (size_t)32 * VP_C * 2 + 256;   // raw[2] + {hi,lo}[2] = 128 KB, + level table
+    size_t lds2 = 2 * (size_t)VP_C * 32 * 4 + 2 * 2 * (size_t)32 * VP_C * 2 + 256;   // raw[2] + {hi,lo}[2] = 128 KB, + level table
+    {
+      // GD4D_VP_LDS_FENCE=1: claim the CU's whole LDS so that kernels of another stream that use LDS (the query-side
+      // linears, LayerNorms, attention core) cannot co-reside on this kernel's CUs and are dispatched to the CUs
+      // GD4D_VP_CUS leaves free instead of fighting the persistent waves for issue slots.
+      static int fence = -1;
+      if (fence < 0) { const char* e = getenv("GD4D_VP_LDS_FENCE"); fence = e ? atoi(e) : 0; }
+      if (fence) lds2 = 160 * 1024;
+    }
     const bool ob = out_dtype == GD4D_BF16;
     if (vp_variant() == 3 && !p.single_product && p.dbg == 0) {     // one wave per SIMD
       auto go4 = [&](auto kern) {

@@ -120,8 +120,12 @@ class Deform3DCrossAttn(nn.Module):
         attn_logits = Fn.linear(xq, self.attention_weights.weight, self.attention_weights.bias,
                                 **kw).view(b, q, hh, nl, npt)
 
+        pipeline = kwargs.get(Fn.VALUE_PIPELINE_KEY)
+        taken = pipeline.take(self, value) if pipeline is not None else None
         cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
-        if cached is not None and cached[2] is value:
+        if taken is not None:
+            val, shapes = taken                      # projected on the side stream underneath the previous layer
+        elif cached is not None and cached[2] is value:
             val, shapes = cached[0], cached[1]       # projected by the decoder for all layers at once
         else:
             val, shapes = Fn.value_projection(value, self.value_proj.weight, self.value_proj.bias,
@@ -133,6 +137,9 @@ class Deform3DCrossAttn(nn.Module):
             order = Fn.query_order(reference_points, self.pc_range)
         agg = Fn.sample_aggregate(val, shapes, reference_points, offsets, attn_logits, cam_logits,
                                   lidar2img, self.pc_range, img_h, img_w, order=order)    # (B, Q, C)
+        if taken is not None:
+            del val, taken
+            pipeline.gather_enqueued(self)
 
         ref3d = reference_points
         if self.depth_encode:                                             # :331-333

@@ -113,24 +113,29 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         self.return_intermediate = return_intermediate
 
     def _preproject_values(self, kwargs):
-        """All layers get the same `value` pyramid, so every Deform3DCrossAttn.value_proj can run over it
-        in ONE launch (gd4d_value_proj_multi_fwd) with each layer handed its tensor.  Off by default:
-        value_proj is not HBM-bound yet, so sharing the read buys nothing (3.61 vs 3.53 ms/step measured)
-        while holding all layers' value tensors costs NL x 757 MB; GD4D_PREPROJECT=1 enables it."""
-        if os.environ.get('GD4D_PREPROJECT', '0') != '1':
-            return kwargs
+        """All layers get the same `value` pyramid and value_proj does not depend on the queries, so the decoder can
+        project for every layer up front.  GD4D_PREPROJECT selects how:
+          'stream' (default) - Fn.ValuePipeline: layer l+1's projection runs on a second HIP stream underneath the
+                       query-side kernels of layers l / l+1 (two value tensors alive)
+          '1'      - one gd4d_value_proj_multi_fwd launch on the main stream (the pyramid is read once)
+          '0'      - off: every layer projects when it runs (the reference's order)
+        Returns (kwargs, pipeline or None)."""
+        mode = os.environ.get('GD4D_PREPROJECT', 'stream')
         value = kwargs.get('value')
-        if not isinstance(value, (list, tuple)) or len(value) == 0 or not value[0].is_cuda:
-            return kwargs
+        if mode == '0' or not isinstance(value, (list, tuple)) or len(value) == 0 or not value[0].is_cuda:
+            return kwargs, None
         mods = [a for layer in self.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
         if mods and Fn.wants_grad(mods[0], *value):
-            return kwargs
+            return kwargs, None
         if len(mods) < 2 or len(mods) > 8 or len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) != 1:
-            return kwargs
+            return kwargs, None
         Fn.require_inference(*value)
         kwargs = dict(kwargs)
-        kwargs[Fn.VALUE_CACHE_KEY] = Fn.project_values_for_layers(mods, value)
-        return kwargs
+        if mode == '1':
+            kwargs[Fn.VALUE_CACHE_KEY] = Fn.project_values_for_layers(mods, value)
+            return kwargs, None
+        pipeline = kwargs[Fn.VALUE_PIPELINE_KEY] = Fn.ValuePipeline(mods, value)
+        return kwargs, pipeline
 
     def _order_queries(self, kwargs, reference_points):
         """Locality order of the queries (Fn.query_order) for the first layer's fused kernel; later layers get theirs
@@ -149,7 +154,7 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
     def forward(self, query, *args, reference_points=None, reg_branches=None, **kwargs):
         output = query
         intermediate, intermediate_reference_points = [], []
-        kwargs = self._preproject_values(kwargs)
+        kwargs, pipeline = self._preproject_values(kwargs)
         kwargs = self._order_queries(kwargs, reference_points)
         for lid, layer in enumerate(self.layers):
             output = layer(output, *args, reference_points=reference_points, **kwargs)
@@ -173,6 +178,8 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
             if self.return_intermediate:
                 intermediate.append(output)
                 intermediate_reference_points.append(reference_points)
+        if pipeline is not None:
+            pipeline.finish()
         if self.return_intermediate:
             return torch.stack(intermediate), torch.stack(intermediate_reference_points)
         return output, reference_points

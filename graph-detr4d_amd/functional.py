@@ -186,6 +186,72 @@ def project_values_for_layers(modules, value):
     return {id(m): ((o if hm else o.view(b * n, -1, hh, c // hh)), shapes, value) for m, o in zip(modules, outs)}
 
 
+_SIDE_STREAMS = {}
+VALUE_PIPELINE_KEY = '_gd4d_value_pipeline'
+
+
+class ValuePipeline:
+    """value_proj of the decoder layers on a second HIP stream, software-pipelined against the query side.
+
+    A layer's value_proj depends on the pyramid only, not on the queries; the query-side kernels (self-attention, small
+    linears, LayerNorms, FFN, reg branch) are latency-bound and leave most of the GPU idle.  So layer l+1's value_proj is
+    launched on the side stream as soon as layer l's fused gather has been enqueued (it waits for that gather's event,
+    so the bandwidth-bound gather has the GPU to itself) and runs underneath the rest of layer l and the start of layer
+    l+1; gather l+1 waits for its value tensor's event.  Two value tensors are alive at a time."""
+
+    def __init__(self, modules, value):
+        self.modules, self.value = list(modules), value
+        dev = value[0].device
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _SIDE_STREAMS.get(dev.index)
+        if self.side is None:
+            self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
+        self.ready = {}
+        self._issue(0)
+
+    # CUs the persistent value_proj kernel may take while the query side runs next to it (of 256; measured optimum:
+    # 160: 316, 192: 326, 224: 317, 256: 291 samples/s; no overlap: 302).  GD4D_PIPELINE_CUS overrides.
+    CUS = 192
+
+    def _issue(self, i):
+        m = self.modules[i]
+        old = ops.value_proj_set_cu_limit(int(os.environ.get('GD4D_PIPELINE_CUS', self.CUS)))
+        try:
+            with torch.cuda.stream(self.side):
+                val, shapes = value_projection(self.value, m.value_proj.weight, m.value_proj.bias, m.num_heads,
+                                               m.value_dtype)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+        finally:
+            ops.value_proj_set_cu_limit(old)
+        self.ready[id(m)] = (val, shapes, ev)
+
+    def take(self, module, value):
+        """(value tensor, shapes) of `module` once the main stream has been made to wait for it; None if not ours."""
+        entry = self.ready.get(id(module))
+        if entry is None or value is not self.value:
+            return None
+        self.main.wait_event(entry[2])
+        return entry[0], entry[1]
+
+    def gather_enqueued(self, module):
+        """Called right after `module`'s fused gather was enqueued on the main stream: release its value tensor and
+        start the next layer's projection behind it."""
+        if self.ready.pop(id(module), None) is None:
+            return
+        i = self.modules.index(module)
+        if i + 1 < len(self.modules):
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
+            self._issue(i + 1)
+
+    def finish(self):
+        self.main.wait_stream(self.side)             # join (also keeps a graph capture well-formed)
+        self.ready.clear()
+
+
 QUERY_ORDER_KEY = '_gd4d_query_order'
 
 

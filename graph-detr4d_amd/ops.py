@@ -253,6 +253,11 @@ def refine_reference_fwd(tmp, ref):
     return out
 
 
+def value_proj_set_cu_limit(cus):
+    """gd4d_value_proj_set_cu_limit: later value_proj launches use at most `cus` CUs (0 = all).  Returns the old limit."""
+    return _lib.load().gd4d_value_proj_set_cu_limit(int(cus))
+
+
 def box_head_fwd(tmp, ref, pc_range, scale=1.0, out=None):
     """gd4d_box_head_fwd: tmp (..., code) raw regression output, ref (..., 3) in [0,1] -> bbox_preds."""
     lib = _lib.load()

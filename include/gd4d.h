@@ -164,6 +164,10 @@ int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const
                         const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
                         int out_dtype, int out_layout, int precision, void* stream);
 size_t gd4d_value_proj_workspace_bytes(void);
+/* gd4d_value_proj_set_cu_limit - value_proj is a persistent kernel (one workgroup per CU).  With a limit it launches at
+ * most `cus` workgroups (rounded down to a multiple of 8, 0 = all CUs) so that kernels another HIP stream runs at the
+ * same time find free CUs.  Process-wide, applies to later launches; returns the previous limit. */
+int gd4d_value_proj_set_cu_limit(int cus);
 
 /* gd4d_value_proj_multi_fwd - the same projection for NL decoder layers in ONE launch.
  * Every decoder layer receives the same `value` list (Detr3DTransformerDecoder.forward passes

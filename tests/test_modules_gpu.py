@@ -1,6 +1,8 @@
 """Module-level parity on the GPU: our registry modules, loaded with the reference's state dict,
 against outputs captured from the reference's own forward (tests/golden).  Tolerance: fp32 path,
 north_star asks 1e-3; we hold 2e-4 (GEMM summation order differs between rocBLAS/MFMA and MKL)."""
+import os
+
 import pytest
 import torch
 
@@ -94,12 +96,26 @@ def test_transformer_decoder(name):
                                         nn.Linear(256, 10)) for _ in range(m['num_layers'])])
     regs.load_state_dict(g.state(prefix='reg.'), strict=True)
     regs = regs.to(DEV).eval()
+    feats, qe = [f.to(DEV) for f in g.feats()], g.t('query_embed').to(DEV)
     with torch.no_grad():
-        states, init_ref, refs = tr([f.to(DEV) for f in g.feats()], g.t('query_embed').to(DEV),
-                                    reg_branches=regs, img_metas=_metas(g))
+        states, init_ref, refs = tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
     torch.testing.assert_close(init_ref.cpu(), g.t('init_reference'), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(refs.cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(states.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+    # scheduling modes change when and where kernels run, never what they compute: value_proj pipelined on a side
+    # stream (default) / one multi-layer launch / per layer in place, locality order of the queries on / off
+    for env in (dict(GD4D_PREPROJECT='0'), dict(GD4D_PREPROJECT='1'), dict(GD4D_QUERY_ORDER='0'),
+                dict(GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0'), dict(GD4D_PIPELINE_CUS='64')):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with torch.no_grad():
+                s2, i2, r2 = tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
+    torch.cuda.synchronize()
 
 
 def test_hdetr_transformer_mask_path_equals_oracle():

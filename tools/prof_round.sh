@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/stats -o bench -- pyt
 find gpurun_out/$tag/stats -name '*kernel_trace.csv' -delete
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   n=$(echo $c | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $c -f csv -d gpurun_out/$tag/pmc_$n -o pmc -- python3 tools/bench_kernel.py --iters 5 > gpurun_out/$tag/pmc_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -f csv -d gpurun_out/$tag/pmc_$n -o pmc -- python3 tools/bench_kernel.py --iters 5 --order > gpurun_out/$tag/pmc_$n.log 2>&1
   find gpurun_out/$tag/pmc_$n -name '*kernel_trace.csv' -delete
 done
 python3 tools/pmc_summary.py gpurun_out/$tag
