@@ -25,6 +25,13 @@ struct LinearParams {
   float* y;            // (M, N), row stride ldy
   int M, K, N, n_split, flags;      // flags: bit0 ReLU on the output, bit1 inverse_sigmoid on the input
   int ldx, ldy, ldr1, ldr2;
+  // grouped mode (gd4d_linear_group_fwd): up to 4 (W, bias, y, N) sets sharing the input; blockIdx.y walks the
+  // groups' column tiles back to back.  groups == 0: the plain single-output form above.
+  int groups;
+  const float* gw[4];
+  const float* gb[4];
+  float* gy[4];
+  int gn[4];
 };
 
 constexpr int LN_TM = 32, LN_TN = 32, LN_WAVES = 4, LN_KC = 64;   // k per wave-chunk
@@ -46,7 +53,24 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * LN_TM, n0 = blockIdx.y * LN_TN;
+  const int m0 = blockIdx.x * LN_TM;
+  int n0 = blockIdx.y * LN_TN;
+  const float* W = p.w;
+  const float* Bv = p.bias;
+  float* Y = p.y;
+  int N = p.N, ldy = p.ldy;
+  if (p.groups > 0) {                      // block-uniform walk over the groups (static indices: no kernarg copy)
+    int t = blockIdx.y;
+    W = p.gw[0]; Bv = p.gb[0]; Y = p.gy[0]; N = p.gn[0];
+#pragma unroll
+    for (int gi = 1; gi < 4; ++gi) {
+      const int tiles = (N + LN_TN - 1) / LN_TN;
+      if (gi < p.groups && t >= tiles) { t -= tiles; W = p.gw[gi]; Bv = p.gb[gi]; Y = p.gy[gi]; N = p.gn[gi]; }
+      else break;
+    }
+    n0 = t * LN_TN;
+    ldy = N;
+  }
   const bool add2 = p.x2 != nullptr && n0 < p.n_split;     // block-uniform (n_split % 32 == 0)
   const bool in_isig = (p.flags & 2) != 0;
   const bool vec = (p.K % 4 == 0) && (p.ldx % 4 == 0);
@@ -58,10 +82,10 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int gm = min(m0 + 16 * t + i16, p.M - 1);
-    const int gn = min(n0 + 16 * t + i16, p.N - 1);
+    const int gn = min(n0 + 16 * t + i16, N - 1);
     xr[t] = p.x + (size_t)gm * p.ldx;
     x2r[t] = add2 ? p.x2 + (size_t)gm * p.ldx : nullptr;
-    wr[t] = p.w + (size_t)gn * p.K;
+    wr[t] = W + (size_t)gn * p.K;
   }
 
   f32x4 acc[2][2];
@@ -104,8 +128,8 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int n = n0 + 16 * c + i16;
-      if (n < p.N) {
-        if (p.bias) pre_bias[c] = p.bias[n];
+      if (n < N) {
+        if (Bv) pre_bias[c] = Bv[n];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -166,11 +190,11 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
 #pragma unroll
           for (int w = 0; w < LN_WAVES - 1; ++w) v += s_part[w][(a * 2 + c) * 4 + r][lane];
           const int m = m0 + 16 * a + 4 * g + r;
-          if (m < p.M && n < p.N) {
+          if (m < p.M && n < N) {
             v += pre_bias[c];
             if (p.flags & 1) v = fmaxf(v, 0.f);
             v += pre_res[a][c][r];
-            p.y[(size_t)m * p.ldy + n] = v;
+            Y[(size_t)m * ldy + n] = v;
           }
         }
       }
@@ -189,6 +213,11 @@ struct LayerNormParams {
   float* y;
   int M, C, relu;
   float eps;
+  // optional prologue (gd4d_small_linear_layernorm_fwd): x = lin_in W^T + b with lin_k <= 4 inputs per row
+  const float* lin_in;  // (M, lin_k)
+  const float* lin_w;   // (C, lin_k)
+  const float* lin_b;   // (C) or null
+  int lin_k, lin_isig;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.M) return;
-  const float* x = p.x + (size_t)row * p.C;
+  const float* x = p.x ? p.x + (size_t)row * p.C : nullptr;
   const float* r = p.res ? p.res + (size_t)row * p.C : nullptr;
   float4 v[4];                                   // up to 1024 channels: 4 float4 per lane
   const int nv = p.C / 4;
@@ -211,7 +240,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     const int c = lane + 64 * i;
     v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < nv) {
-      v[i] = reinterpret_cast<const float4*>(x)[c];
+      if (p.lin_in) {                              // tiny Linear instead of a load: 4 channels x lin_k inputs
+        float in[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.lin_k; ++k) {
+          const float t = p.lin_in[(size_t)row * p.lin_k + k];
+          in[k] = p.lin_isig ? inv_sigmoid(t) : t;
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wrow = p.lin_w + (size_t)(4 * c + e) * p.lin_k;
+          float a = 0.f;
+          for (int k = 0; k < p.lin_k; ++k) a = fmaf(in[k], wrow[k], a);
+          o[e] = a + (p.lin_b ? p.lin_b[4 * c + e] : 0.f);
+        }
+        v[i] = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        v[i] = reinterpret_cast<const float4*>(x)[c];
+      }
       if (r) {
         const float4 t = reinterpret_cast<const float4*>(r)[c];
         v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
@@ -279,8 +325,33 @@ extern "C" int gd4d_linear_fwd(const float* x, const float* x2, const float* w, 
   if (r2 && ldr2 < N) return GD4D_EINVAL;
   if (x2 && (n_split % LN_TN) != 0 && n_split < N) return GD4D_EUNSUPPORTED;   // split must align to tiles
   if (!aligned16(x) || !aligned16(w) || (x2 && !aligned16(x2))) return GD4D_EALIGN;
-  LinearParams p{x, x2, w, bias, r1, r2, y, M, K, N, x2 ? n_split : 0, flags, ldx, ldy, ldr1, ldr2};
+  LinearParams p{};
+  p.x = x; p.x2 = x2; p.w = w; p.bias = bias; p.r1 = r1; p.r2 = r2; p.y = y;
+  p.M = M; p.K = K; p.N = N; p.n_split = x2 ? n_split : 0; p.flags = flags;
+  p.ldx = ldx; p.ldy = ldy; p.ldr1 = ldr1; p.ldr2 = ldr2;
   const dim3 grid((M + LN_TM - 1) / LN_TM, (N + LN_TN - 1) / LN_TN);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LN_WAVES), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w, const float* const* bias,
+                                     float* const* y, const int32_t* n_out, int G, int M, int K, int ldx,
+                                     void* stream) {
+  using namespace gd4d;
+  if (!x || !w || !y || !n_out || G <= 0 || M <= 0 || K <= 0 || ldx < K) return GD4D_EINVAL;
+  if (G > 4) return GD4D_EUNSUPPORTED;
+  if (!aligned16(x) || (x2 && !aligned16(x2))) return GD4D_EALIGN;
+  LinearParams p{};
+  p.x = x; p.x2 = x2; p.M = M; p.K = K; p.ldx = ldx; p.groups = G;
+  p.n_split = 1 << 30;                    // the addend applies to every output column
+  int tiles = 0;
+  for (int g = 0; g < G; ++g) {
+    if (!w[g] || !y[g] || n_out[g] <= 0) return GD4D_EINVAL;
+    if (!aligned16(w[g])) return GD4D_EALIGN;
+    p.gw[g] = w[g]; p.gb[g] = bias ? bias[g] : nullptr; p.gy[g] = y[g]; p.gn[g] = n_out[g];
+    tiles += (n_out[g] + LN_TN - 1) / LN_TN;
+  }
+  const dim3 grid((M + LN_TM - 1) / LN_TM, tiles);
   hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LN_WAVES), 0, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }
@@ -292,7 +363,22 @@ extern "C" int gd4d_layernorm_fwd(const float* x, const float* res, const float*
   if (C % 4 != 0 || C > 1024) return GD4D_EUNSUPPORTED;
   if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || (res && !aligned16(res)))
     return GD4D_EALIGN;
-  LayerNormParams p{x, res, gamma, beta, y, M, C, relu, eps};
+  LayerNormParams p{};
+  p.x = x; p.res = res; p.gamma = gamma; p.beta = beta; p.y = y; p.M = M; p.C = C; p.relu = relu; p.eps = eps;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_small_linear_layernorm_fwd(const float* in, const float* w, const float* bias, const float* gamma,
+                                               const float* beta, float* y, int M, int Kin, int C, float eps,
+                                               int flags, void* stream) {
+  using namespace gd4d;
+  if (!in || !w || !gamma || !beta || !y || M <= 0 || C <= 0 || Kin <= 0) return GD4D_EINVAL;
+  if (Kin > 4 || C % 4 != 0 || C > 1024) return GD4D_EUNSUPPORTED;
+  if (!aligned16(y) || !aligned16(gamma) || !aligned16(beta)) return GD4D_EALIGN;
+  LayerNormParams p{};
+  p.gamma = gamma; p.beta = beta; p.y = y; p.M = M; p.C = C; p.relu = flags & GD4D_LIN_RELU; p.eps = eps;
+  p.lin_in = in; p.lin_w = w; p.lin_b = bias; p.lin_k = Kin; p.lin_isig = (flags & GD4D_LIN_INV_SIGMOID_IN) ? 1 : 0;
   hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }

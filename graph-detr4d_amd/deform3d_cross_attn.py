@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import ops
 from .registry import ATTENTION
 
 
@@ -112,13 +113,14 @@ class Deform3DCrossAttn(nn.Module):
         else:
             xq = query.permute(1, 0, 2).contiguous()
             xp = None if query_pos is None else query_pos.permute(1, 0, 2).contiguous()
-        kw = dict(x2=xp) if xp is not None else {}
-        cam_logits = Fn.linear(xq, self.cam_attention_weights.weight, self.cam_attention_weights.bias,
-                               **kw).view(b, q, n)                                   # un-scrambled
-        offsets = Fn.linear(xq, self.deform_sampling_offsets.weight, self.deform_sampling_offsets.bias,
-                            **kw).view(b, q, hh, npt, 3)
-        attn_logits = Fn.linear(xq, self.attention_weights.weight, self.attention_weights.bias,
-                                **kw).view(b, q, hh, nl, npt)
+        # one launch for the three Linears of (query + query_pos) (:211, :227, :281)
+        mods = (self.cam_attention_weights, self.deform_sampling_offsets, self.attention_weights)
+        cam_logits, offsets, attn_logits = ops.linear_group_fwd(
+            xq.contiguous(), [m_.weight.contiguous() for m_ in mods], [m_.bias for m_ in mods],
+            x2=None if xp is None else xp.contiguous())
+        cam_logits = cam_logits.view(b, q, n)                                        # un-scrambled
+        offsets = offsets.view(b, q, hh, npt, 3)
+        attn_logits = attn_logits.view(b, q, hh, nl, npt)
 
         pipeline = kwargs.get(Fn.VALUE_PIPELINE_KEY)
         taken = pipeline.take(self, value) if pipeline is not None else None

@@ -80,10 +80,15 @@ def layer_norm(x, norm, res=None, relu=False):
 
 def position_encoder(seq, ref):
     """Reference position_encoder = Linear, LN, ReLU, Linear, LN, ReLU on inverse_sigmoid(ref)
-    (deform3d_cross_attn.py:104-111,334): 4 launches (inverse_sigmoid fused into the first Linear's load,
-    ReLU into the LayerNorms)."""
-    h = linear(ref, seq[0].weight, seq[0].bias, inv_sigmoid_in=True)
-    h = layer_norm(h, seq[1], relu=True)
+    (deform3d_cross_attn.py:104-111,334): 3 launches - the 3/4-input Linear with inverse_sigmoid, LayerNorm and
+    ReLU as one (ops.small_linear_layernorm_fwd), then Linear and LayerNorm+ReLU."""
+    if ref.shape[-1] <= 4 and seq[0].out_features % 4 == 0 and seq[0].out_features <= 1024:
+        h = ops.small_linear_layernorm_fwd(ref.contiguous(), seq[0].weight.contiguous(), seq[0].bias,
+                                           seq[1].weight.contiguous(), seq[1].bias.contiguous(), seq[1].eps,
+                                           relu=True, inv_sigmoid_in=True)
+    else:
+        h = linear(ref, seq[0].weight, seq[0].bias, inv_sigmoid_in=True)
+        h = layer_norm(h, seq[1], relu=True)
     h = linear(h, seq[3].weight, seq[3].bias)
     return layer_norm(h, seq[4], relu=True)
 

@@ -197,6 +197,26 @@ def linear_fwd(x, weight, bias=None, x2=None, n_split=None, relu=False, r1=None,
     return out
 
 
+def linear_group_fwd(x, weights, biases, x2=None):
+    """gd4d_linear_group_fwd: [(x + x2) W_g^T + b_g for g] in one launch.  x (..., K) contiguous; returns a list."""
+    lib = _lib.load()
+    g = len(weights)
+    k = x.shape[-1]
+    m = x.numel() // k
+    if x2 is not None and x2.shape != x.shape:
+        raise ValueError('x2 must have the shape of x')
+    outs = [torch.empty(*x.shape[:-1], w.shape[0], device=x.device, dtype=torch.float32) for w in weights]
+    vp = ctypes.c_void_p
+    warr = (vp * g)(*[_dev(w, 'weight', torch.float32).value for w in weights])
+    barr = (vp * g)(*[None if b is None else _dev(b, 'bias', torch.float32).value for b in biases])
+    yarr = (vp * g)(*[o.data_ptr() for o in outs])
+    narr = (ctypes.c_int32 * g)(*[w.shape[0] for w in weights])
+    code = lib.gd4d_linear_group_fwd(_dev(x, 'x', torch.float32), _opt(x2, 'x2'), warr, barr, yarr, narr, g, m, k, k,
+                                     _stream())
+    _lib.check(code, 'gd4d_linear_group_fwd')
+    return outs
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-5, res=None, relu=False):
     """gd4d_layernorm_fwd over the last dimension of a contiguous tensor."""
     lib = _lib.load()
@@ -206,6 +226,20 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, res=None, relu=False):
                                   _dev(beta, 'beta', torch.float32), _dev(out, 'out'), x.numel() // c, c,
                                   float(eps), int(bool(relu)), _stream())
     _lib.check(code, 'gd4d_layernorm_fwd')
+    return out
+
+
+def small_linear_layernorm_fwd(x, weight, bias, gamma, beta, eps=1e-5, relu=False, inv_sigmoid_in=False):
+    """gd4d_small_linear_layernorm_fwd: [ReLU] LN(f(x) W^T + b) with x (..., K <= 4) -> (..., C)."""
+    lib = _lib.load()
+    k, c = x.shape[-1], weight.shape[0]
+    out = torch.empty(*x.shape[:-1], c, device=x.device, dtype=torch.float32)
+    code = lib.gd4d_small_linear_layernorm_fwd(_dev(x, 'x', torch.float32), _dev(weight, 'weight', torch.float32),
+                                               _opt(bias, 'bias'), _dev(gamma, 'gamma', torch.float32),
+                                               _dev(beta, 'beta', torch.float32), _dev(out, 'out'), x.numel() // k, k,
+                                               c, float(eps), int(bool(relu)) | (2 if inv_sigmoid_in else 0),
+                                               _stream())
+    _lib.check(code, 'gd4d_small_linear_layernorm_fwd')
     return out
 
 

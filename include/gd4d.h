@@ -202,12 +202,29 @@ int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float
                     const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
                     int flags, int ldx, int ldy, int ldr1, int ldr2, void* stream);
 
+/* gd4d_linear_group_fwd - up to 4 Linear layers that share their input, in one launch:
+ *   y_g = (x + x2) W_g^T + b_g,  g < G.
+ * Deform3DCrossAttn applies cam_attention_weights, deform_sampling_offsets and attention_weights to the same
+ * (query + query_pos) (deform3d_cross_attn.py:211, :227, :281): three launches become one.
+ *   x, x2 (M, K) row stride ldx (x2 may be NULL); w, bias, y: HOST arrays of G device pointers (bias or its entries may
+ *   be NULL), W_g (N_g, K) row-major, y_g (M, N_g) contiguous; n_out: host, G ints.  G <= 4. */
+int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w, const float* const* bias,
+                          float* const* y, const int32_t* n_out, int G, int M, int K, int ldx, void* stream);
+
 /* gd4d_layernorm_fwd - y = LayerNorm(x [+ res]) * gamma + beta [, ReLU] over the last dim
  * (biased variance, eps inside the sqrt, like ATen).  Replaces the nn.LayerNorm of
  * position_encoder (deform3d_cross_attn.py:104-111) and the decoder layer's three norms.
  * C % 4 == 0, C <= 1024. */
 int gd4d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
                        float* y, int M, int C, float eps, int relu, void* stream);
+
+/* gd4d_small_linear_layernorm_fwd - y = [ReLU] LN( f(in) W^T + b ) for a Linear with at most 4 inputs: the first stage of
+ * position_encoder, Linear(3 or 4 -> 256), LayerNorm, ReLU on inverse_sigmoid(reference points)
+ * (deform3d_cross_attn.py:104-111, :331-334), as one launch.  in (M, Kin), w (C, Kin), bias (C) or NULL, y (M, C);
+ * flags: GD4D_LIN_RELU on the output, GD4D_LIN_INV_SIGMOID_IN on the input.  Kin <= 4, C % 4 == 0, C <= 1024. */
+int gd4d_small_linear_layernorm_fwd(const float* in, const float* w, const float* bias, const float* gamma,
+                                    const float* beta, float* y, int M, int Kin, int C, float eps, int flags,
+                                    void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_mha_core_fwd - softmax(q k^T * scale [+ mask]) v per head, never materialising the score

@@ -129,3 +129,44 @@ def test_refine_reference_order_matches_separate_kernels():
         assert (both[0] - both[1]).abs().max().item() <= 2 * 3.1416 / (4096 // b) + 1e-5
     with pytest.raises(Exception):
         ops.query_order_fwd(torch.rand(1, 5000, 3).cuda(), pc_range)
+
+
+def test_linear_group_equals_separate_launches():
+    """gd4d_linear_group_fwd: the three Linears of (query + query_pos) in one launch, bit-identical to three."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(4)
+    for m in (900, 37):
+        x, x2 = torch.randn(m, 1, 256).cuda(), torch.randn(m, 1, 256).cuda()
+        ws = [torch.randn(n, 256).cuda() * 0.1 for n in (24, 96, 128, 10)]
+        bs = [torch.randn(24).cuda(), None, torch.randn(128).cuda(), torch.randn(10).cuda()]
+        for g in (1, 3, 4):
+            outs = ops.linear_group_fwd(x, ws[:g], bs[:g], x2=x2)
+            for o, w, b in zip(outs, ws, bs):
+                assert o.shape == (m, 1, w.shape[0])
+                assert torch.equal(o, ops.linear_fwd(x, w, b, x2=x2))
+        outs = ops.linear_group_fwd(x, ws[:2], bs[:2])
+        assert torch.equal(outs[1], ops.linear_fwd(x, ws[1], None))
+    from graph_detr4d_amd._lib import Gd4dError
+    with pytest.raises(Gd4dError):
+        ops.linear_group_fwd(x, ws + ws[:1], bs + bs[:1])
+
+
+@pytest.mark.parametrize('k,isig,relu', [(3, True, True), (4, True, True), (2, False, False), (1, False, True)])
+def test_small_linear_layernorm_matches_fp64(k, isig, relu):
+    from graph_detr4d_amd import ops
+    from oracle import torch_oracle as O
+    torch.manual_seed(10 + k)
+    m, c = 901, 256
+    x = torch.rand(m, k) if isig else torch.randn(m, k)
+    if isig:
+        x[0] = 0.
+        x[1] = 1.
+    w, b = torch.randn(c, k), torch.randn(c)
+    g_, be = torch.randn(c), torch.randn(c)
+    got = ops.small_linear_layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), g_.cuda(), be.cuda(), relu=relu,
+                                         inv_sigmoid_in=isig).cpu()
+    xin = O.inverse_sigmoid(x) if isig else x
+    ref = F.layer_norm(F.linear(xin.double(), w.double(), b.double()), (c,), g_.double(), be.double())
+    if relu:
+        ref = ref.relu()
+    assert (got.double() - ref).abs().max().item() < 2e-5
