@@ -98,6 +98,23 @@ class Deform3DCrossAttn(nn.Module):
 
         inp_residual = query
         q_len, b, c = query.shape
+
+        # position_encoder depends on the reference points only: fork it onto the auxiliary stream, it runs next to the
+        # query-side linears and the gather and is joined before output_proj adds it (:331-336)
+        main = torch.cuda.current_stream(query.device)
+        aux = Fn.aux_stream(query.device)
+        ev_pos = None
+        if aux is not None:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(fork)
+                pos_feat = self._position_features(reference_points)
+                ev_pos = torch.cuda.Event()
+                ev_pos.record(aux)
+        ref_event = kwargs.get(Fn.REF_EVENT_KEY)     # reference points refined on the auxiliary stream by the decoder
+        if ref_event is not None:
+            main.wait_event(ref_event)
         q = q_len
         hh, npt, nl = self.num_heads, self.num_points, self.num_levels
         n = self.num_cams
@@ -143,17 +160,23 @@ class Deform3DCrossAttn(nn.Module):
             del val, taken
             pipeline.gather_enqueued(self)
 
-        ref3d = reference_points
-        if self.depth_encode:                                             # :331-333
-            depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
-            ref3d = torch.cat([ref3d, depth], dim=-1)
-        pos_feat = Fn.position_encoder(self.position_encoder, ref3d)     # (B, Q, C)
+        if ev_pos is None:
+            pos_feat = self._position_features(reference_points)         # (B, Q, C)
+        else:
+            main.wait_event(ev_pos)
         if b == 1 and not self.training:
             # output_proj with both residuals of :336 in its epilogue; (B=1,Q,C) and (Q,1,C) share memory
             return Fn.linear(agg, self.output_proj.weight, self.output_proj.bias,
                              r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
         return self.dropout(out) + inp_residual + pos_feat.permute(1, 0, 2)
+
+    def _position_features(self, reference_points):
+        ref3d = reference_points
+        if self.depth_encode:                                             # :331-333
+            depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
+            ref3d = torch.cat([ref3d, depth], dim=-1)
+        return Fn.position_encoder(self.position_encoder, ref3d)
 
     def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
         """Training path: the same maths with autograd.  The gather runs gd4d_cross_attn_fwd/_bwd, value_proj

@@ -151,26 +151,51 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         kwargs[Fn.QUERY_ORDER_KEY] = order
         return kwargs
 
+    def _refine(self, branch, output, reference_points, kwargs, want_order):
+        """reg branch + reference-point refinement (:201-214) on the HIP kernels; with a locality order in use the
+        refinement launch also produces the next layer's order (kwargs is updated in place)."""
+        tmp = Fn.run_branch(branch, output.permute(1, 0, 2).contiguous())
+        if want_order and Fn.QUERY_ORDER_KEY in kwargs:
+            new_ref, kwargs[Fn.QUERY_ORDER_KEY] = Fn.refine_reference_order(tmp, reference_points,
+                                                                            self._order_pc_range)
+            return new_ref
+        return Fn.refine_reference(tmp, reference_points).detach()
+
     def forward(self, query, *args, reference_points=None, reg_branches=None, **kwargs):
         output = query
         intermediate, intermediate_reference_points = [], []
         kwargs, pipeline = self._preproject_values(kwargs)
         kwargs = self._order_queries(kwargs, reference_points)
+        aux = None
+        cross = [a for layer in self.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
+        deform_only = bool(cross) and all(isinstance(a, Deform3DCrossAttn) for a in cross)
         for lid, layer in enumerate(self.layers):
             output = layer(output, *args, reference_points=reference_points, **kwargs)
             if reg_branches is not None:
                 assert reference_points.shape[-1] == 3
                 grad = Fn.wants_grad(reg_branches[lid], output)
-                tmp = reg_branches[lid](output.permute(1, 0, 2)) if grad else \
-                    Fn.run_branch(reg_branches[lid], output.permute(1, 0, 2).contiguous())
-                if tmp.is_cuda and tmp.dtype == torch.float32 and not grad:
-                    if Fn.QUERY_ORDER_KEY in kwargs and lid + 1 < len(self.layers):
-                        # refinement + a fresh locality order for the next layer's fused kernel, one launch
-                        reference_points, kwargs[Fn.QUERY_ORDER_KEY] = Fn.refine_reference_order(
-                            tmp, reference_points, self._order_pc_range)
-                    else:
-                        reference_points = Fn.refine_reference(tmp, reference_points).detach()
+                fast = output.is_cuda and output.dtype == torch.float32 and not grad
+                if fast and deform_only and lid + 1 < len(self.layers):
+                    # the reg branch and the refinement feed the NEXT layer's cross-attention only: run them on the
+                    # auxiliary stream next to that layer's self-attention; its gather waits for the event
+                    # (Deform3DCrossAttn honours kwargs[REF_EVENT_KEY]; other cross-attentions stay on one stream)
+                    aux = Fn.aux_stream(output.device)
+                if fast and aux is not None and lid + 1 < len(self.layers):
+                    main = torch.cuda.current_stream(output.device)
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    kwargs = dict(kwargs)
+                    with torch.cuda.stream(aux):
+                        aux.wait_event(done)
+                        reference_points = self._refine(reg_branches[lid], output, reference_points, kwargs, True)
+                        ev = torch.cuda.Event()
+                        ev.record(aux)
+                    kwargs[Fn.REF_EVENT_KEY] = ev
+                elif fast:
+                    reference_points = self._refine(reg_branches[lid], output, reference_points, kwargs,
+                                                    lid + 1 < len(self.layers))
                 else:
+                    tmp = reg_branches[lid](output.permute(1, 0, 2))
                     new_ref = torch.zeros_like(reference_points)
                     new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
                     new_ref[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
@@ -180,6 +205,8 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                 intermediate_reference_points.append(reference_points)
         if pipeline is not None:
             pipeline.finish()
+        if aux is not None:
+            torch.cuda.current_stream(output.device).wait_stream(aux)
         if self.return_intermediate:
             return torch.stack(intermediate), torch.stack(intermediate_reference_points)
         return output, reference_points

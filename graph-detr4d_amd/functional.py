@@ -192,6 +192,22 @@ def project_values_for_layers(modules, value):
 
 
 _SIDE_STREAMS = {}
+_AUX_STREAMS = {}
+REF_EVENT_KEY = '_gd4d_ref_event'
+
+
+def aux_stream(device):
+    """Second-branch HIP stream for query-side work that is off the layer's critical path (position_encoder of the
+    reference points, the reg branch + refinement between layers).  Those kernels are tiny and latency-bound; run
+    next to the main chain they cost nothing.  None when disabled (GD4D_AUX_STREAM=0)."""
+    if os.environ.get('GD4D_AUX_STREAM', '1') == '0':
+        return None
+    s = _AUX_STREAMS.get(device.index)
+    if s is None:
+        s = _AUX_STREAMS[device.index] = torch.cuda.Stream(device)
+    return s
+
+
 VALUE_PIPELINE_KEY = '_gd4d_value_pipeline'
 
 
