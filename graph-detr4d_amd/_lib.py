@@ -34,6 +34,7 @@ SIGNATURES = {
     'gd4d_value_proj_set_cu_limit': (_i, [_i]),
     'gd4d_linear_fwd': (_i, [_vp] * 7 + [_i] * 9 + [_vp]),
     'gd4d_linear_group_fwd': (_i, [_vp] * 6 + [_i] * 4 + [_vp]),
+    'gd4d_linear_ln_fwd': (_i, [_vp] * 9 + [_i] * 5 + [_f] + [_i] * 4 + [_vp]),
     'gd4d_small_linear_layernorm_fwd': (_i, [_vp] * 6 + [_i, _i, _i, _f, _i, _vp]),
     'gd4d_layernorm_fwd': (_i, [_vp] * 5 + [_i, _i, _f, _i, _vp]),
     'gd4d_mha_core_fwd': (_i, [_vp] * 5 + [_i] * 10 + [_f, _vp]),

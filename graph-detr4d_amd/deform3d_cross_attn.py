@@ -166,6 +166,11 @@ class Deform3DCrossAttn(nn.Module):
             main.wait_event(ev_pos)
         if b == 1 and not self.training:
             # output_proj with both residuals of :336 in its epilogue; (B=1,Q,C) and (Q,1,C) share memory
+            fused = Fn.take_fused_norm(kwargs)
+            if fused is not None and Fn.rowblock_ok(agg, self.output_proj.weight, fused['norm']):
+                fused['done'] = True                 # ... and the layer's LayerNorm that follows
+                return Fn.linear_norm(agg, self.output_proj.weight, self.output_proj.bias, fused['norm'],
+                                      r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
             return Fn.linear(agg, self.output_proj.weight, self.output_proj.bias,
                              r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)

@@ -78,6 +78,32 @@ def layer_norm(x, norm, res=None, relu=False):
                              res=None if res is None else res.contiguous(), relu=relu)
 
 
+NORM_KEY = '_gd4d_fused_norm'
+
+
+def rowblock_ok(x, weight, norm=None):
+    """gd4d_linear_ln_fwd limits: K % 64 == 0; with a LayerNorm at most 256 output columns (GD4D_ROWBLOCK=0: off)."""
+    return os.environ.get('GD4D_ROWBLOCK', '1') != '0' and x.is_cuda and x.shape[-1] % 64 == 0 and \
+        (norm is None or (weight.shape[0] <= 256 and tuple(norm.normalized_shape) == (weight.shape[0],)))
+
+
+def linear_norm(x, weight, bias, norm, r1=None, r2=None, relu_after=False):
+    """LN(x W^T + b + r1 + r2) [ReLU]: one launch (ops.linear_ln_fwd) when the shapes allow, else Linear + LayerNorm."""
+    c = lambda t: None if t is None else t.contiguous()
+    if rowblock_ok(x, weight, norm):
+        return ops.linear_ln_fwd(x.contiguous(), weight.contiguous(), c(bias), norm.weight.contiguous(),
+                                 norm.bias.contiguous(), norm.eps, r1=c(r1), r2=c(r2), relu_after_ln=relu_after)
+    kw = {k: v for k, v in (('r1', r1), ('r2', r2)) if v is not None}
+    return layer_norm(linear(x, weight, bias, **kw), norm, relu=relu_after)
+
+
+def take_fused_norm(kwargs):
+    """The LayerNorm that follows this module in the layer's operation_order, if the layer offers to have it fused
+    (BaseTransformerLayer passes {'norm': module, 'done': False} under NORM_KEY); the taker sets done."""
+    holder = kwargs.get(NORM_KEY)
+    return holder if holder is not None and not holder['done'] else None
+
+
 def position_encoder(seq, ref):
     """Reference position_encoder = Linear, LN, ReLU, Linear, LN, ReLU on inverse_sigmoid(ref)
     (deform3d_cross_attn.py:104-111,334): 3 launches - the 3/4-input Linear with inverse_sigmoid, LayerNorm and
@@ -89,8 +115,7 @@ def position_encoder(seq, ref):
     else:
         h = linear(ref, seq[0].weight, seq[0].bias, inv_sigmoid_in=True)
         h = layer_norm(h, seq[1], relu=True)
-    h = linear(h, seq[3].weight, seq[3].bias)
-    return layer_norm(h, seq[4], relu=True)
+    return linear_norm(h, seq[3].weight, seq[3].bias, seq[4], relu_after=True)
 
 
 def use_head_major(value_dtype):

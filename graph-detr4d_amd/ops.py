@@ -229,6 +229,24 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, res=None, relu=False):
     return out
 
 
+def linear_ln_fwd(x, weight, bias=None, gamma=None, beta=None, eps=1e-5, x2=None, n_split=None, relu=False, r1=None,
+                  r2=None, relu_after_ln=False, out=None):
+    """gd4d_linear_ln_fwd: y = [ReLU] LN(act((x [+ x2]) W^T + b) + r1 + r2); gamma=None: no LayerNorm."""
+    lib = _lib.load()
+    k, n = x.shape[-1], weight.shape[0]
+    m = x.numel() // k
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    if x2 is not None and x2.shape != x.shape:
+        raise ValueError('x2 must have the shape of x')
+    code = lib.gd4d_linear_ln_fwd(_dev(x, 'x', torch.float32), _opt(x2, 'x2'), _dev(weight, 'weight', torch.float32),
+                                  _opt(bias, 'bias'), _opt(r1, 'r1'), _opt(r2, 'r2'), _opt(gamma, 'gamma'),
+                                  _opt(beta, 'beta'), _dev(out, 'out'), m, k, n, n if n_split is None else int(n_split),
+                                  int(bool(relu)) | (4 if relu_after_ln else 0), float(eps), k, n, n, n, _stream())
+    _lib.check(code, 'gd4d_linear_ln_fwd')
+    return out
+
+
 def small_linear_layernorm_fwd(x, weight, bias, gamma, beta, eps=1e-5, relu=False, inv_sigmoid_in=False):
     """gd4d_small_linear_layernorm_fwd: [ReLU] LN(f(x) W^T + b) with x (..., K <= 4) -> (..., C)."""
     lib = _lib.load()

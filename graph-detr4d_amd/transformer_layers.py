@@ -73,7 +73,7 @@ class MultiheadAttention(nn.Module):
         eval_mode = not self.training and not grad
         if (eval_mode and not self.batch_first and key is query and value is query
                 and query_pos is not None and key_pos is query_pos and identity.shape == query.shape):
-            return self._packed_self_attention(query, query_pos, attn_mask, identity)
+            return self._packed_self_attention(query, query_pos, attn_mask, identity, Fn.take_fused_norm(kwargs))
         q_in = query if query_pos is None else query + query_pos
         k_in = key if key_pos is None else key + key_pos
         if self.batch_first:
@@ -84,7 +84,7 @@ class MultiheadAttention(nn.Module):
             out = out.transpose(0, 1)
         return identity + self.dropout_layer(self.proj_drop(out))
 
-    def _packed_self_attention(self, query, query_pos, attn_mask, identity):
+    def _packed_self_attention(self, query, query_pos, attn_mask, identity, fused=None):
         """The decoder's case (q = k = query + query_pos, v = query): one in-projection GEMM with the
         positional add fused into its load, the attention core, and the out-projection with the
         residual fused into its epilogue - 3 launches."""
@@ -92,6 +92,9 @@ class MultiheadAttention(nn.Module):
         qkv = Fn.linear(query, self.attn.in_proj_weight, self.attn.in_proj_bias, x2=query_pos, n_split=2 * c)
         q, k, v = qkv.split(c, dim=-1)
         o = ops.mha_core_fwd(q, k, v, self.num_heads, attn_mask)
+        if fused is not None and Fn.rowblock_ok(o, self.attn.out_proj.weight, fused['norm']):
+            fused['done'] = True
+            return Fn.linear_norm(o, self.attn.out_proj.weight, self.attn.out_proj.bias, fused['norm'], r1=identity)
         return Fn.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, r1=identity)
 
     def _attention(self, q_in, k_in, v_in, attn_mask):
@@ -147,10 +150,14 @@ class FFN(nn.Module):
         self.dropout_layer = nn.Dropout(p) if dropout_layer else nn.Identity()
         self.add_identity = add_identity
 
-    def forward(self, x, identity=None):
+    def forward(self, x, identity=None, **kwargs):
         if not self.training and len(self.layers) == 3 and x.is_cuda and not Fn.wants_grad(self, x, identity):
             hdn = Fn.linear(x, self.layers[0][0].weight, self.layers[0][0].bias, relu=True)
             res = (x if identity is None else identity) if self.add_identity else None
+            fused = Fn.take_fused_norm(kwargs)
+            if fused is not None and Fn.rowblock_ok(hdn, self.layers[1].weight, fused['norm']):
+                fused['done'] = True
+                return Fn.linear_norm(hdn, self.layers[1].weight, self.layers[1].bias, fused['norm'], r1=res)
             return Fn.linear(hdn, self.layers[1].weight, self.layers[1].bias, r1=res)
         out = self.layers(x)
         if not self.add_identity:
@@ -209,35 +216,48 @@ class BaseTransformerLayer(nn.Module):
                 query_key_padding_mask=None, key_padding_mask=None, **kwargs):
         norm_i = attn_i = ffn_i = 0
         identity = query
+        skip_norm = False
         if attn_masks is None:
             attn_masks = [None] * len(self.attentions)
         elif torch.is_tensor(attn_masks):
             attn_masks = [attn_masks for _ in range(len(self.attentions))]
         else:
             assert len(attn_masks) == len(self.attentions)
-        for op in self.operation_order:
+        order = self.operation_order
+        for oi, op in enumerate(order):
+            # a LayerNorm right after an attention / FFN can run in that module's last GEMM (Fn.linear_norm)
+            holder = None
+            if op != 'norm' and oi + 1 < len(order) and order[oi + 1] == 'norm' and query.is_cuda \
+                    and not self.training and not Fn.wants_grad(self.norms[norm_i], query):
+                holder = {'norm': self.norms[norm_i], 'done': False}
+            fuse = {Fn.NORM_KEY: holder} if holder is not None else {}
             if op == 'self_attn':
                 query = self.attentions[attn_i](
                     query, query, query, identity if self.pre_norm else None, query_pos=query_pos,
                     key_pos=query_pos, attn_mask=attn_masks[attn_i],
-                    key_padding_mask=query_key_padding_mask, **kwargs)
+                    key_padding_mask=query_key_padding_mask, **fuse, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'norm':
-                norm = self.norms[norm_i]
-                query = Fn.layer_norm(query, norm) if (query.is_cuda and not Fn.wants_grad(norm, query)) \
-                    else norm(query)
+                if skip_norm:
+                    skip_norm = False
+                else:
+                    norm = self.norms[norm_i]
+                    query = Fn.layer_norm(query, norm) if (query.is_cuda and not Fn.wants_grad(norm, query)) \
+                        else norm(query)
                 norm_i += 1
             elif op == 'cross_attn':
                 query = self.attentions[attn_i](
                     query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
                     key_pos=key_pos, attn_mask=attn_masks[attn_i],
-                    key_padding_mask=key_padding_mask, **kwargs)
+                    key_padding_mask=key_padding_mask, **fuse, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'ffn':
-                query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+                query = self.ffns[ffn_i](query, identity if self.pre_norm else None, **fuse)
                 ffn_i += 1
+            if holder is not None and holder['done']:
+                skip_norm = True                     # the module already applied the LayerNorm that follows
         return query
 
 

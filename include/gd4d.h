@@ -198,6 +198,7 @@ int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
  */
 #define GD4D_LIN_RELU 1
 #define GD4D_LIN_INV_SIGMOID_IN 2
+#define GD4D_LIN_RELU_AFTER_LN 4
 int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
                     const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
                     int flags, int ldx, int ldy, int ldr1, int ldr2, void* stream);
@@ -217,6 +218,18 @@ int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w
  * C % 4 == 0, C <= 1024. */
 int gd4d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
                        float* y, int M, int C, float eps, int relu, void* stream);
+
+/* gd4d_linear_ln_fwd - y = [ReLU] LN( act((x [+ x2 for cols < n_split]) W^T + b) + r1 + r2 ), LayerNorm optional
+ * (gamma == NULL: plain Linear with the same epilogue as gd4d_linear_fwd).  One workgroup per 16 complete rows: the
+ * Linear -> LayerNorm pairs of a decoder layer (out_proj -> norm, output_proj + residual + pos_feat -> norm,
+ * FFN layers[1] + residual -> norm, position_encoder[3] -> [4] -> ReLU; deform3d_cross_attn.py:108-110, 326-336 and the
+ * mmcv layer of config ...ceph.py:71-89) become one launch each, and few fat workgroups instead of hundreds of small
+ * ones when most CUs are busy with value_proj.
+ *   flags: GD4D_LIN_RELU (before the residuals), GD4D_LIN_RELU_AFTER_LN; eps: LayerNorm eps.
+ *   Supported: K % 64 == 0, ldx % 4 == 0; with LayerNorm N <= 256; n_split % 256 == 0 (or >= N). */
+int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const float* bias, const float* r1,
+                       const float* r2, const float* gamma, const float* beta, float* y, int M, int K, int N,
+                       int n_split, int flags, float eps, int ldx, int ldy, int ldr1, int ldr2, void* stream);
 
 /* gd4d_small_linear_layernorm_fwd - y = [ReLU] LN( f(in) W^T + b ) for a Linear with at most 4 inputs: the first stage of
  * position_encoder, Linear(3 or 4 -> 256), LayerNorm, ReLU on inverse_sigmoid(reference points)

@@ -170,3 +170,48 @@ def test_small_linear_layernorm_matches_fp64(k, isig, relu):
     if relu:
         ref = ref.relu()
     assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('m,k,n,ln,relu,relu2,res', [
+    (900, 256, 256, True, False, False, 2), (900, 512, 256, True, False, False, 1), (900, 256, 256, True, False, True, 0),
+    (37, 256, 256, True, True, False, 0), (900, 256, 768, False, False, False, 0), (900, 256, 512, False, True, False, 0),
+    (901, 64, 200, True, False, False, 1), (17, 128, 10, False, False, False, 2)])
+def test_linear_ln_matches_fp64(m, k, n, ln, relu, relu2, res):
+    """gd4d_linear_ln_fwd against fp64: LN(act(x W^T + b) + r1 + r2) and the plain-Linear form."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + k + n)
+    x, w, b = torch.randn(m, 1, k), torch.randn(n, k) * 0.08, torch.randn(n)
+    r1 = torch.randn(m, 1, n) if res >= 1 else None
+    r2 = torch.randn(m, 1, n) if res >= 2 else None
+    gam, bet = (torch.randn(n), torch.randn(n)) if ln else (None, None)
+    c = lambda t: None if t is None else t.cuda()
+    got = ops.linear_ln_fwd(c(x), c(w), c(b), c(gam), c(bet), 1e-5, relu=relu, r1=c(r1), r2=c(r2),
+                            relu_after_ln=relu2).cpu()
+    ref = F.linear(x.double(), w.double(), b.double())
+    if relu:
+        ref = ref.relu()
+    for r in (r1, r2):
+        if r is not None:
+            ref = ref + r.double()
+    if ln:
+        ref = F.layer_norm(ref, (n,), gam.double(), bet.double(), 1e-5)
+    if relu2:
+        ref = ref.relu()
+    assert got.shape == (m, 1, n)
+    assert (got.double() - ref).abs().max().item() < 5e-5
+
+
+def test_linear_ln_input_addend_and_errors():
+    from graph_detr4d_amd import ops
+    from graph_detr4d_amd._lib import Gd4dError
+    torch.manual_seed(1)
+    m, k, n = 900, 256, 768
+    x, x2 = torch.randn(m, 1, k).cuda(), torch.randn(m, 1, k).cuda()
+    w, b = (torch.randn(n, k) * 0.06).cuda(), torch.randn(n).cuda()
+    got = ops.linear_ln_fwd(x, w, b, x2=x2, n_split=512)
+    ref = ops.linear_fwd(x, w, b, x2=x2, n_split=512)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+    with pytest.raises(Gd4dError):                                   # LayerNorm over more than 256 columns
+        ops.linear_ln_fwd(x, w, b, torch.ones(n).cuda(), torch.zeros(n).cuda())
+    with pytest.raises(Gd4dError):                                   # K not a multiple of 64
+        ops.linear_ln_fwd(torch.randn(5, 48).cuda(), torch.randn(8, 48).cuda())

@@ -116,6 +116,15 @@ def test_transformer_decoder(name):
             for k, v in old.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
+    # the fused Linear+LayerNorm kernel sums in another order than Linear, LayerNorm: equal within fp32 rounding
+    os.environ['GD4D_ROWBLOCK'] = '0'
+    try:
+        with torch.no_grad():
+            s3, _, r3 = tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
+    finally:
+        os.environ.pop('GD4D_ROWBLOCK')
+    torch.testing.assert_close(s3, states, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(r3, refs, rtol=1e-4, atol=1e-4)
     torch.cuda.synchronize()
 
 

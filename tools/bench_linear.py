@@ -42,6 +42,17 @@ with torch.no_grad():
         a = graph_time(lambda: ops.linear_fwd(x, w, b, out=y))
         t = graph_time(lambda: F.linear(x, w, b))
         print(f'linear {m}x{k}x{n}: gd4d {a:6.2f} us   torch {t:6.2f} us')
+    for (m, k, n) in [(900, 256, 256), (900, 512, 256), (900, 256, 768), (900, 256, 512)]:
+        x, w, b = torch.randn(m, k, device='cuda'), torch.randn(n, k, device='cuda'), torch.randn(n, device='cuda')
+        r = torch.randn(m, n, device='cuda')
+        ga, be = torch.randn(n, device='cuda'), torch.randn(n, device='cuda')
+        if n == 256:
+            a = graph_time(lambda: ops.linear_ln_fwd(x, w, b, ga, be, r1=r))
+            t = graph_time(lambda: ops.layernorm_fwd(ops.linear_fwd(x, w, b, r1=r), ga, be))
+            print(f'linear+LN {m}x{k}x{n}: row-block {a:6.2f} us   linear + layernorm launches {t:6.2f} us')
+        a = graph_time(lambda: ops.linear_ln_fwd(x, w, b, r1=r))
+        t = graph_time(lambda: ops.linear_fwd(x, w, b, r1=r))
+        print(f'linear    {m}x{k}x{n}: row-block {a:6.2f} us   32x32-tile kernel {t:6.2f} us')
     x = torch.randn(900, 1, 256, device='cuda')
     g_, b_ = torch.randn(256, device='cuda'), torch.randn(256, device='cuda')
     print(f'layernorm 900x256: gd4d {graph_time(lambda: ops.layernorm_fwd(x, g_, b_)):6.2f} us   '
