@@ -393,3 +393,113 @@ def nms_free_decode(preds, post_center_range, max_num, num_classes, score_thresh
     cls, box = preds['all_cls_scores'][-1], preds['all_bbox_preds'][-1]
     return [nms_free_decode_single(cls[b], box[b], post_center_range, max_num, num_classes, score_threshold)
             for b in range(cls.shape[0])]
+
+
+# ---------------------------------------------------------------------------------------------
+# the step feeding the path: Detr3DHeadPE's feature position embedding
+# paths below: projects/mmdet3d_plugin/models/dense_heads/detr3d_head_pe.py unless noted
+# ---------------------------------------------------------------------------------------------
+def frustum_depths(depth_num, depth_start, pc_range):
+    """:450-453 (the LID branch is the one left active): d_i = start + bin * i * (i + 1)."""
+    idx = torch.arange(depth_num, dtype=torch.float32)
+    bin_size = (pc_range[3] - depth_start) / (depth_num * (1 + depth_num))
+    return depth_start + bin_size * idx * (idx + 1)
+
+
+def frustum_points(lidar2img, feat_hw, pad_hw, depth_num, depth_start, pc_range, eps=1e-5):
+    """:438-476: pixel centres x depth bins -> lidar frame -> normalised by pc_range.
+
+    lidar2img (B, N, 4, 4) array-like.  Returns coords3d (B, N, W, H, D, 3) in pc_range units and the
+    'more than half of the depth bins fall outside the range' flag (B, N, W, H)."""
+    h, w = feat_hw
+    coords_h = torch.arange(h).float() * pad_hw[0] / h
+    coords_w = torch.arange(w).float() * pad_hw[1] / w
+    coords_d = frustum_depths(depth_num, depth_start, pc_range)
+    d = coords_d.shape[0]
+    coords = torch.stack(torch.meshgrid([coords_w, coords_h, coords_d], indexing='ij')).permute(1, 2, 3, 0)   # W, H, D, 3
+    coords = torch.cat((coords, torch.ones_like(coords[..., :1])), -1)
+    coords[..., :2] = coords[..., :2] * torch.maximum(coords[..., 2:3], torch.ones_like(coords[..., 2:3]) * eps)
+    img2lidar = torch.from_numpy(np.linalg.inv(np.asarray(lidar2img, dtype=np.float64))).float()   # :459-465 (numpy inverse)
+    b, n = img2lidar.shape[:2]
+    coords = coords.view(1, 1, w, h, d, 4, 1).repeat(b, n, 1, 1, 1, 1, 1)
+    mats = img2lidar.view(b, n, 1, 1, 1, 4, 4).repeat(1, 1, w, h, d, 1, 1)
+    c3 = torch.matmul(mats, coords).squeeze(-1)[..., :3]
+    for k in range(3):
+        c3[..., k:k + 1] = (c3[..., k:k + 1] - pc_range[k]) / (pc_range[k + 3] - pc_range[k])
+    outside = ((c3 > 1.0) | (c3 < 0.0)).flatten(-2).sum(-1) > (d * 0.5)
+    return c3, outside
+
+
+def conv1x1(x, w, b):
+    return F.conv2d(x, w, b)
+
+
+def frustum_position_embedding(p, lidar2img, masks, feat_shapes, pad_hw, depth_num, depth_start, pc_range):
+    """`position_embeding` :427-491.  p: state dict with 'position_encoder.{0,2}.{weight,bias}'; masks: list of
+    (B, N, H_l, W_l) bool; feat_shapes: [(H_l, W_l)].  Returns per level (B, N, C, H, W) embeddings and masks."""
+    out, out_masks = [], []
+    for lvl, (h, w) in enumerate(feat_shapes):
+        c3, outside = frustum_points(lidar2img, (h, w), pad_hw, depth_num, depth_start, pc_range)
+        b, n = c3.shape[:2]
+        mask = masks[lvl] | outside.permute(0, 1, 3, 2)
+        x = c3.permute(0, 1, 4, 5, 3, 2).contiguous().view(b * n, -1, h, w)          # channel = d * 3 + axis
+        x = inverse_sigmoid(x)
+        x = conv1x1(torch.relu(conv1x1(x, p['position_encoder.0.weight'], p['position_encoder.0.bias'])),
+                    p['position_encoder.2.weight'], p['position_encoder.2.bias'])
+        out.append(x.view(b, n, -1, h, w))
+        out_masks.append(mask)
+    return out, out_masks
+
+
+def sine_positional_encoding_3d(mask, num_feats=128, temperature=10000, normalize=True, scale=2 * math.pi, eps=1e-6,
+                                offset=-0.5):
+    """models/utils/positional_encoding.py:58-100.  mask (B, N, H, W) bool -> (B, N, 3 * num_feats, H, W)."""
+    not_mask = 1 - mask.to(torch.int)
+    n_embed = not_mask.cumsum(1, dtype=torch.float32)
+    y_embed = not_mask.cumsum(2, dtype=torch.float32)
+    x_embed = not_mask.cumsum(3, dtype=torch.float32)
+    if normalize:
+        n_embed = (n_embed + offset) / (n_embed[:, -1:, :, :] + eps) * scale
+        y_embed = (y_embed + offset) / (y_embed[:, :, -1:, :] + eps) * scale
+        x_embed = (x_embed + offset) / (x_embed[:, :, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_feats)
+    b, n, h, w = mask.shape
+    parts = []
+    for e in (n_embed, y_embed, x_embed):
+        pos = e[:, :, :, :, None] / dim_t
+        parts.append(torch.stack((pos[..., 0::2].sin(), pos[..., 1::2].cos()), dim=4).view(b, n, h, w, -1))
+    return torch.cat(parts, dim=4).permute(0, 1, 4, 2, 3)
+
+
+def se_gate(p, x, x_se, prefix='fpe.'):
+    """SELayer :231-243: x * sigmoid(conv_expand(relu(conv_reduce(x_se))))."""
+    g = conv1x1(torch.relu(conv1x1(x_se, p[prefix + 'conv_reduce.weight'], p[prefix + 'conv_reduce.bias'])),
+                p[prefix + 'conv_expand.weight'], p[prefix + 'conv_expand.bias'])
+    return x * torch.sigmoid(g)
+
+
+def feature_position_embedding(p, feats, lidar2img, img_shapes, pad_shape, depth_num, depth_start, pc_range):
+    """Detr3DHeadPE.forward :525-557: padding masks, frustum position embedding, SE fusion with the features, sine
+    3-D encoding through adapt_pos3d, added to the feature maps.  feats: list of (B, N, C, H_l, W_l);
+    img_shapes: per camera (h, w, 3) of sample 0..B-1 (list of lists).  Returns (new feats, intermediates)."""
+    b, n = feats[0].shape[:2]
+    pad_h, pad_w = pad_shape[0], pad_shape[1]
+    full = torch.ones(b, n, pad_h, pad_w)
+    for i in range(b):
+        for c in range(n):
+            ih, iw = img_shapes[i][c][0], img_shapes[i][c][1]
+            full[i, c, :ih, :iw] = 0
+    masks = [F.interpolate(full, size=f.shape[-2:]).to(torch.bool) for f in feats]
+    shapes = [tuple(f.shape[-2:]) for f in feats]
+    coords_pe, coords_masks = frustum_position_embedding(p, lidar2img, masks, shapes, (pad_h, pad_w), depth_num,
+                                                         depth_start, pc_range)
+    outs, sines = [], []
+    for lvl, f in enumerate(feats):
+        pe = se_gate(p, coords_pe[lvl].flatten(0, 1), f.flatten(0, 1)).view(f.shape)
+        sine = sine_positional_encoding_3d(masks[lvl])
+        s = conv1x1(torch.relu(conv1x1(sine.flatten(0, 1), p['adapt_pos3d.0.weight'], p['adapt_pos3d.0.bias'])),
+                    p['adapt_pos3d.2.weight'], p['adapt_pos3d.2.bias']).view(f.shape)
+        outs.append(f + (pe + s))
+        sines.append(sine)
+    return outs, dict(masks=masks, coords_pe=coords_pe, coords_masks=coords_masks, sine=sines)

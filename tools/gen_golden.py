@@ -18,6 +18,7 @@ import sys
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -327,6 +328,72 @@ def case_decode(name, *, num_query, batch, seed, max_num, code_size=10, score_th
     save(name, meta, **arrays)
 
 
+def case_head_pe(name, *, frames, img_hw, pad_hw, strides, seed, depth_num=64):
+    """The step feeding the path: Detr3DHeadPE's feature position embedding.
+
+    `position_embeding` (dense_heads/detr3d_head_pe.py:427-491), `SELayer` (:231-243) and
+    `SinePositionalEncoding3D` (models/utils/positional_encoding.py:15-100) are the reference's code; the masks and
+    the per-level glue are the lines :525-553 of Detr3DHeadPE.forward, which cannot be called without the rest of
+    the head and are transcribed below around those reference calls.
+    """
+    head_mod, pe_mod = refstub.load_head_pe()
+    torch.manual_seed(seed)
+    n = 6 * frames
+    levels = [(-(-pad_hw[0] // s), -(-pad_hw[1] // s)) for s in strides]
+    feats, packed = grid_features(n, levels, 1, seed)
+    rig = small_rig(frames, img_hw)
+    embed = 256
+
+    class Shell(nn.Module):                       # the attributes position_embeding reads, nothing else
+        def __init__(self):
+            super().__init__()
+            self.embed_dims, self.depth_num, self.depth_start = embed, depth_num, 1
+            self.pc_range = PC_RANGE
+            self.position_dim = 3 * depth_num
+            self.position_encoder = nn.Sequential(nn.Conv2d(self.position_dim, embed * 4, 1), nn.ReLU(),
+                                                  nn.Conv2d(embed * 4, embed, 1))          # :380-384
+            self.adapt_pos3d = nn.Sequential(nn.Conv2d(embed * 3 // 2, embed * 4, 1), nn.ReLU(),
+                                             nn.Conv2d(embed * 4, embed, 1))               # :385-389
+            self.fpe = head_mod.SELayer(embed)                                               # :390
+            self.positional_encoding = pe_mod.SinePositionalEncoding3D(num_feats=128, normalize=True, offset=-0.5)
+    shell = Shell().eval()
+    quantise_params_(shell, seed + 1, std=0.04)
+    img_shapes = [(img_hw[0] - (4 if c % 3 == 1 else 0), img_hw[1] - (8 if c % 3 == 2 else 0), 3) for c in range(n)]
+    metas = [dict(lidar2img=[rig[i] for i in range(n)], img_shape=img_shapes, pad_shape=[(pad_hw[0], pad_hw[1], 3)] * n)]
+    with torch.no_grad():
+        x = feats[0]
+        bsz, ncam = x.size(0), x.size(1)
+        in_h, in_w, _ = metas[0]['pad_shape'][0]
+        masks = [x.new_ones((bsz, ncam, in_h, in_w)) for _ in levels]                         # :529-533
+        for i in range(bsz):
+            for c in range(ncam):
+                ih, iw, _ = metas[i]['img_shape'][c]
+                for l in range(len(levels)):
+                    masks[l][i, c, :ih, :iw] = 0                                              # :535-539
+        for l in range(len(levels)):
+            masks[l] = F.interpolate(masks[l], size=feats[l].shape[-2:]).to(torch.bool)       # :542-544
+        mlvl = [f.clone() for f in feats]
+        coords_pe, coords_masks = head_mod.Detr3DHeadPE.position_embeding(shell, mlvl, metas, masks)   # :546
+        arrays = {}
+        for l in range(len(levels)):
+            arrays[f'coords_pe{l}'] = coords_pe[l].clone()
+            arrays[f'coords_mask{l}'] = coords_masks[l].to(torch.uint8)
+            pe = shell.fpe(coords_pe[l].flatten(0, 1), mlvl[l].flatten(0, 1)).view(mlvl[l].size())   # :551-552
+            sin_embed = shell.positional_encoding(masks[l])
+            arrays[f'sine{l}'] = sin_embed.clone()
+            sin_embed = shell.adapt_pos3d(sin_embed.flatten(0, 1)).view(mlvl[l].size())
+            arrays[f'out{l}'] = mlvl[l] + (pe + sin_embed)                                    # :554-557
+            arrays[f'mask{l}'] = masks[l].to(torch.uint8)
+    for l, pk in enumerate(packed):
+        arrays[f'feat{l}@q'] = pk
+    arrays['lidar2img'] = rig.astype(np.float32)
+    arrays.update(pack_state(shell))
+    meta = dict(kind='head_pe', num_cams=n, levels=levels, pc_range=PC_RANGE, depth_num=depth_num, depth_start=1,
+                img_shapes=img_shapes, pad_shape=[pad_hw[0], pad_hw[1], 3], feat_scale=FEAT_SCALE, w_scale=W_SCALE,
+                batch=1)
+    save(name, meta, **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     case_deform('deform_n6', num_query=48, frames=1, batch=1, img_hw=(128, 224), seed=101)
@@ -343,6 +410,7 @@ def main():
                  img_hw=(64, 112), seed=401, num_layers=2)
     case_decoder('decoder_detr3d', cross='Detr3DCrossAtten', num_query=32, frames=1, batch=1,
                  img_hw=(64, 112), seed=402, num_layers=2)
+    case_head_pe('head_pe', frames=1, img_hw=(64, 112), pad_hw=(64, 112), strides=(8, 16), seed=601)
     case_decode('decode', num_query=90, batch=2, seed=501, max_num=300)
     case_decode('decode_thr', num_query=64, batch=1, seed=502, max_num=100, score_threshold=0.2)
     case_decode('decode_code8', num_query=20, batch=1, seed=503, max_num=100, code_size=8)

@@ -438,3 +438,53 @@ def load_coder():
             m.__path__ = [os.path.join(REFERENCE_ROOT, *rel.split('.'))]
             sys.modules[rel] = m
     return importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.nms_free_coder')
+
+
+# --------------------------------------------------------------------------------------
+# head position embedding: the step feeding the path
+# --------------------------------------------------------------------------------------
+def load_head_pe():
+    """Import the reference's Detr3DHeadPE file and positional_encoding.py unmodified.
+
+    Only `Detr3DHeadPE.position_embeding` (a method that needs nothing of DETRHead), `SELayer` and
+    `SinePositionalEncoding3D` are used by tools/gen_golden.py; the class hierarchy, losses, assigners and
+    torchvision are name-only stubs.  `inverse_sigmoid` (third-party mmdet.models.utils.transformer) is bound to the
+    reference's own copy of that function (utils/detr3d_transformer.py:28-43).
+    Returns (head module, positional_encoding module).
+    """
+    install_stubs()
+    load_coder()                                          # projects.* namespace + mmdet.core.bbox stubs
+    ref = load_reference(('detr3d_transformer',))['detr3d_transformer']
+    sys.modules['mmcv.cnn'].Linear = nn.Linear
+    sys.modules['mmcv.cnn'].bias_init_with_prob = lambda p: float(-math.log((1 - p) / p))
+    sys.modules['mmcv.runner'].force_fp32 = lambda *a, **k: (lambda f: f)
+    sys.modules['mmcv.runner'].BaseModule = BaseModule
+    sys.modules['mmcv.cnn.bricks.transformer'].POSITIONAL_ENCODING = POSITIONAL_ENCODING
+    _mod('torchvision', transforms=None)
+    core = sys.modules['mmdet.core']
+    core.multi_apply = core.reduce_mean = core.build_sampler = core.build_assigner = None
+    _mod('mmdet.models.utils.transformer', inverse_sigmoid=ref.inverse_sigmoid)
+    heads = Registry('head')
+    sys.modules['mmdet.models'].HEADS = heads
+    _mod('mmdet.models.dense_heads', DETRHead=type('DETRHead', (nn.Module,), {}))
+    _mod('mmdet3d.core.bbox.coders', build_bbox_coder=None)
+    _mod('mmdet3d.models')
+    _mod('mmdet3d.models.builder', build_loss=None)
+    rel = ''
+    for part in ('projects', 'mmdet3d_plugin', 'models'):
+        rel = f'{rel}.{part}' if rel else part
+        if rel not in sys.modules:
+            m = types.ModuleType(rel)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, *rel.split('.'))]
+            sys.modules[rel] = m
+    for sub in ('dense_heads', 'utils'):
+        full = f'projects.mmdet3d_plugin.models.{sub}'
+        if full not in sys.modules:
+            m = types.ModuleType(full)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, *full.split('.'))]
+            sys.modules[full] = m
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        head = importlib.import_module('projects.mmdet3d_plugin.models.dense_heads.detr3d_head_pe')
+        pe = importlib.import_module('projects.mmdet3d_plugin.models.utils.positional_encoding')
+    return head, pe
