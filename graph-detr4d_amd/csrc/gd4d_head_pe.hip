@@ -1,0 +1,143 @@
+// Feature position embedding of Detr3DHeadPE - the step that rewrites the feature maps the fused sample-aggregate
+// kernel gathers from.  Reference: projects/mmdet3d_plugin/models/dense_heads/detr3d_head_pe.py
+// :427-491 (position_embeding), :525-557 (forward), models/utils/positional_encoding.py:58-100.
+//
+// The dense 1x1 convolutions of that stage are plain GEMMs and stay with the library; what is here are the three
+// bandwidth-bound pieces the reference builds out of dozens of elementwise ops and multi-GB temporaries:
+//   gd4d_frustum_pe_input_fwd  pixel x depth-bin frustum -> lidar frame -> pc_range units -> inverse_sigmoid, written
+//                              straight in the (B*N, 3*D, H, W) layout position_encoder's first conv reads, plus
+//                              the "most depth bins outside the range" flag.  The reference materialises a
+//                              (B,N,W,H,D,4,4) repeated-matrix tensor (2.3 GB at level 0, N = 24) on the way.
+//   gd4d_sine_pe3d_fwd         (camera, row, column) cumulative-sum embeddings -> 3 x 128 sin / cos channels.
+//   gd4d_se_fuse_fwd           out = feat + (pe * sigmoid(gate) + sine_embed): SELayer's gating and the two adds.
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+struct FrustumParams {
+  const float* img2lidar;   // (R, 16)
+  float* out;               // (R, 3*D, H, W)
+  uint8_t* outside;         // (R, H, W)
+  int R, H, W, D;
+  float pad_h, pad_w, depth_start, bin_size;
+  float lo[3], span[3];
+};
+
+__global__ __launch_bounds__(256) void frustum_pe_input_kernel(const FrustumParams p) {
+  const int hw = p.H * p.W;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.R * hw) return;
+  const int r = (int)(idx / hw);
+  const int pix = (int)(idx - (long long)r * hw);
+  const int y = pix / p.W, x = pix - y * p.W;
+  const float* m = p.img2lidar + (size_t)r * 16;
+  // torch.arange(H).float() * pad_h / H  (:440-441): multiply, then divide, in fp32
+  const float ch = ((float)y * p.pad_h) / (float)p.H;
+  const float cw = ((float)x * p.pad_w) / (float)p.W;
+  float* o = p.out + (size_t)r * 3 * p.D * hw + pix;
+  const float eps = 1e-5f;
+  int n_out = 0;
+  for (int d = 0; d < p.D; ++d) {
+    const float fi = (float)d;
+    const float depth = p.depth_start + (p.bin_size * fi) * (fi + 1.0f);      // :450-453
+    const float s = fmaxf(depth, eps);
+    const float px = cw * s, py = ch * s;                                     // :458
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = ((m[4 * k] * px + m[4 * k + 1] * py) + m[4 * k + 2] * depth) + m[4 * k + 3];   // :469
+      c[k] = (v - p.lo[k]) / p.span[k];                                       // :470-475
+      n_out += (c[k] > 1.0f || c[k] < 0.0f) ? 1 : 0;                          // :477
+      o[(size_t)(3 * d + k) * hw] = inv_sigmoid(c[k]);                        // :480-481 layout, channel = 3 d + axis
+    }
+  }
+  p.outside[idx] = (float)n_out > (float)p.D * 0.5f ? 1 : 0;                  // :478
+}
+
+struct SineParams {
+  const float* embed[3];    // n, y, x embeddings, each (R, H, W) (already normalised)
+  const float* dim_t;       // (F)
+  float* out;               // (R, 3*F, H, W)
+  int R, HW, F;
+};
+
+__global__ __launch_bounds__(256) void sine_pe3d_kernel(const SineParams p) {
+  // one thread per (r, channel, pixel); pixel fastest -> coalesced stores
+  const long long total = (long long)p.R * 3 * p.F * p.HW;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int pix = (int)(idx % p.HW);
+  const long long t = idx / p.HW;
+  const int ch = (int)(t % (3 * p.F));
+  const int r = (int)(t / (3 * p.F));
+  const int part = ch / p.F, f = ch - part * p.F;
+  const float* e = part == 0 ? p.embed[0] : part == 1 ? p.embed[1] : p.embed[2];
+  // positional_encoding.py:90-98 stacks (pos[..., 0::2].sin(), pos[..., 1::2].cos()) on dim 4 of a 5-D tensor, i.e.
+  // BEFORE the feature axis: the first F/2 channels are the sines of the even features, the last F/2 the cosines of
+  // the odd ones (not DETR's interleaving).
+  const int half = p.F / 2;
+  const bool is_cos = f >= half;
+  const int src = is_cos ? 2 * (f - half) + 1 : 2 * f;
+  const float v = e[(size_t)r * p.HW + pix] / p.dim_t[src];
+  p.out[idx] = is_cos ? cosf(v) : sinf(v);
+}
+
+__global__ __launch_bounds__(256) void se_fuse_kernel(const float4* __restrict__ feat, const float4* __restrict__ gate,
+                                                      const float4* __restrict__ pe, const float4* __restrict__ sine,
+                                                      float4* __restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 f = feat[i], g = gate[i], q = pe[i], s = sine[i];
+  float4 o;
+  o.x = f.x + (q.x * (1.0f / (1.0f + expf(-g.x))) + s.x);
+  o.y = f.y + (q.y * (1.0f / (1.0f + expf(-g.y))) + s.y);
+  o.z = f.z + (q.z * (1.0f / (1.0f + expf(-g.z))) + s.z);
+  o.w = f.w + (q.w * (1.0f / (1.0f + expf(-g.w))) + s.w);
+  out[i] = o;
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uint8_t* outside, int R, int H, int W, int D,
+                                         float pad_h, float pad_w, float depth_start, const double* pc_range,
+                                         void* stream) {
+  using namespace gd4d;
+  if (!img2lidar || !out || !outside || !pc_range || R <= 0 || H <= 0 || W <= 0 || D <= 0) return GD4D_EINVAL;
+  FrustumParams p{};
+  p.img2lidar = img2lidar; p.out = out; p.outside = outside; p.R = R; p.H = H; p.W = W; p.D = D;
+  p.pad_h = pad_h; p.pad_w = pad_w; p.depth_start = depth_start;
+  // Python-float arithmetic of the reference (:452), rounded to fp32 when it meets the tensor
+  p.bin_size = (float)((pc_range[3] - (double)depth_start) / ((double)D * (1.0 + (double)D)));
+  for (int k = 0; k < 3; ++k) { p.lo[k] = (float)pc_range[k]; p.span[k] = (float)(pc_range[k + 3] - pc_range[k]); }
+  const long long total = (long long)R * H * W;
+  hipLaunchKernelGGL(frustum_pe_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_sine_pe3d_fwd(const float* n_embed, const float* y_embed, const float* x_embed, const float* dim_t,
+                                  float* out, int R, int HW, int F, void* stream) {
+  using namespace gd4d;
+  if (!n_embed || !y_embed || !x_embed || !dim_t || !out || R <= 0 || HW <= 0 || F <= 0) return GD4D_EINVAL;
+  SineParams p{};
+  p.embed[0] = n_embed; p.embed[1] = y_embed; p.embed[2] = x_embed; p.dim_t = dim_t; p.out = out;
+  p.R = R; p.HW = HW; p.F = F;
+  const long long total = (long long)R * 3 * F * HW;
+  hipLaunchKernelGGL(sine_pe3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out,
+                                size_t n, void* stream) {
+  using namespace gd4d;
+  if (!feat || !gate || !pe || !sine || !out || n == 0) return GD4D_EINVAL;
+  if (n % 4 != 0) return GD4D_EUNSUPPORTED;
+  if (!aligned16(feat) || !aligned16(gate) || !aligned16(pe) || !aligned16(sine) || !aligned16(out)) return GD4D_EALIGN;
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(se_fuse_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(feat), reinterpret_cast<const float4*>(gate),
+                     reinterpret_cast<const float4*>(pe), reinterpret_cast<const float4*>(sine),
+                     reinterpret_cast<float4*>(out), n4);
+  return check_launch();
+}

@@ -1,0 +1,128 @@
+"""Feature position embedding of Detr3DHeadPE - the step feeding the decoder path.
+
+Mirror of the part of `Detr3DHeadPE` that rewrites the multi-camera feature maps before the transformer
+(projects/mmdet3d_plugin/models/dense_heads/detr3d_head_pe.py: `_init_layers` :380-390, `position_embeding` :427-491,
+`forward` :525-557): same submodule names (`position_encoder`, `adapt_pos3d`, `fpe.conv_reduce / conv_expand`), so the
+corresponding slice of a head checkpoint loads with strict=True.
+
+What runs where: the frustum geometry (+ inverse_sigmoid, written directly as the conv input, no (B,N,W,H,D,4,4)
+temporaries), the sine / cosine expansion and the SE-gate + adds are HIP kernels (ops.frustum_pe_input_fwd,
+ops.sine_pe3d_fwd, ops.se_fuse_fwd); the 1x1 convolutions are plain library GEMMs.  The sine branch depends on the
+padding masks only, so its result is cached while the masks do not change (every sample of a dataset shares them).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as Fn
+from . import ops
+
+
+class SELayer(nn.Module):
+    """detr3d_head_pe.py:231-243 (parameter holder; the gate is applied by ops.se_fuse_fwd)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, channels, 1, bias=True)
+        self.conv_expand = nn.Conv2d(channels, channels, 1, bias=True)
+
+    def gate_logits(self, x_se):
+        return self.conv_expand(F.relu(self.conv_reduce(x_se)))
+
+
+class FeaturePositionEmbedding(nn.Module):
+    def __init__(self, embed_dims=256, depth_num=64, depth_start=1, pc_range=None, num_feats=128, temperature=10000,
+                 normalize=True, scale=2 * math.pi, eps=1e-6, offset=-0.5):
+        super().__init__()
+        if pc_range is None:
+            raise ValueError('pc_range is required (the head takes it from its bbox coder)')
+        self.embed_dims, self.depth_num, self.depth_start = embed_dims, depth_num, depth_start
+        self.pc_range = list(pc_range)
+        self.position_dim = 3 * depth_num
+        self.position_encoder = nn.Sequential(nn.Conv2d(self.position_dim, embed_dims * 4, 1), nn.ReLU(),
+                                              nn.Conv2d(embed_dims * 4, embed_dims, 1))
+        self.adapt_pos3d = nn.Sequential(nn.Conv2d(embed_dims * 3 // 2, embed_dims * 4, 1), nn.ReLU(),
+                                         nn.Conv2d(embed_dims * 4, embed_dims, 1))
+        self.fpe = SELayer(embed_dims)
+        # SinePositionalEncoding3D(num_feats, temperature, normalize, scale, eps, offset) has no parameters
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+        self._sine_cache = None
+
+    # ---- pieces -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def padding_masks(img_metas, feats):
+        """:525-544: 1 outside each camera's img_shape inside the padded canvas, nearest-resized to every level."""
+        b, n = feats[0].shape[:2]
+        pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
+        full = torch.ones(b, n, pad_h, pad_w)
+        for i in range(b):
+            for c in range(n):
+                ih, iw, _ = img_metas[i]['img_shape'][c]
+                full[i, c, :ih, :iw] = 0
+        full = full.to(feats[0].device)
+        return [F.interpolate(full, size=f.shape[-2:]).to(torch.bool) for f in feats], (pad_h, pad_w)
+
+    def sine_embedding(self, mask):
+        """SinePositionalEncoding3D.forward (positional_encoding.py:58-100): tiny cumulative sums with torch, the
+        3 x num_feats sin / cos channels with ops.sine_pe3d_fwd."""
+        not_mask = 1 - mask.to(torch.int)
+        embeds = [not_mask.cumsum(d, dtype=torch.float32) for d in (1, 2, 3)]
+        if self.normalize:
+            last = [embeds[0][:, -1:], embeds[1][:, :, -1:], embeds[2][:, :, :, -1:]]
+            embeds = [(e + self.offset) / (l + self.eps) * self.scale for e, l in zip(embeds, last)]
+        dim_t = torch.arange(self.num_feats, dtype=torch.float32)
+        dim_t = (self.temperature ** (2 * (dim_t // 2) / self.num_feats)).to(mask.device)
+        b, n, h, w = mask.shape
+        out = ops.sine_pe3d_fwd(*[e.reshape(b * n, h, w).contiguous() for e in embeds], dim_t)
+        return out.view(b, n, 3 * self.num_feats, h, w)
+
+    def frustum_embedding(self, img_metas, masks, feats, pad_hw):
+        """`position_embeding` (:427-491): returns per level ((B, N, C, H, W) embedding, (B, N, H, W) mask)."""
+        b, n = feats[0].shape[:2]
+        l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
+        img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(b * n, 4, 4).to(feats[0].device)   # :459-465
+        out, out_masks = [], []
+        for lvl, f in enumerate(feats):
+            h, w = f.shape[-2:]
+            x, outside = ops.frustum_pe_input_fwd(img2lidar, (h, w), pad_hw, self.depth_num, self.depth_start,
+                                                  self.pc_range)
+            out.append(self.position_encoder(x).view(b, n, self.embed_dims, h, w))
+            out_masks.append(masks[lvl] | outside.view(b, n, h, w))
+        return out, out_masks
+
+    def _sine_branch(self, masks):
+        """adapt_pos3d(sine(mask)) per level; cached while the masks (and the weights) do not change."""
+        key = tuple(p._version for p in self.adapt_pos3d.parameters())
+        c = self._sine_cache
+        if c is not None and c[0] == key and len(c[1]) == len(masks) and \
+                all(a.shape == m.shape and a.device == m.device and torch.equal(a, m) for a, m in zip(c[1], masks)):
+            return c[2]
+        res = []
+        for m in masks:
+            s = self.sine_embedding(m)
+            res.append(self.adapt_pos3d(s.flatten(0, 1)).view(m.shape[0], m.shape[1], self.embed_dims, *m.shape[2:]))
+        if not any(p.requires_grad and torch.is_grad_enabled() for p in self.adapt_pos3d.parameters()):
+            self._sine_cache = (key, [m.clone() for m in masks], res)
+        return res
+
+    # ---- the stage ------------------------------------------------------------------------------------------------
+    def forward(self, mlvl_feats, img_metas):
+        """mlvl_feats: list of (B, N, C, H_l, W_l) fp32 GPU tensors; returns the list with the position embedding
+        added (:546-557).  Inference only (the reference trains through these ops with autograd)."""
+        feats = list(mlvl_feats)
+        Fn.require_gpu(feats[0], 'mlvl_feats')
+        Fn.require_inference(*feats)
+        with torch.no_grad():
+            masks, pad_hw = self.padding_masks(img_metas, feats)
+            coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)
+            sine = self._sine_branch(masks)
+            out = []
+            for lvl, f in enumerate(feats):
+                gate = self.fpe.gate_logits(f.flatten(0, 1)).view(f.shape)
+                out.append(ops.se_fuse_fwd(f.contiguous(), gate.contiguous(), coords_pe[lvl].contiguous(),
+                                           sine[lvl].contiguous()))
+        return out

@@ -310,6 +310,45 @@ def value_proj_set_cu_limit(cus):
     return _lib.load().gd4d_value_proj_set_cu_limit(int(cus))
 
 
+def frustum_pe_input_fwd(img2lidar, feat_hw, pad_hw, depth_num, depth_start, pc_range):
+    """gd4d_frustum_pe_input_fwd.  img2lidar (R, 4, 4) fp32 -> (x (R, 3*D, H, W) fp32, outside (R, H, W) bool)."""
+    lib = _lib.load()
+    r = img2lidar.shape[0]
+    h, w = feat_hw
+    out = torch.empty(r, 3 * depth_num, h, w, device=img2lidar.device, dtype=torch.float32)
+    outside = torch.empty(r, h, w, device=img2lidar.device, dtype=torch.uint8)
+    rng = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    code = lib.gd4d_frustum_pe_input_fwd(_dev(img2lidar, 'img2lidar', torch.float32), _dev(out, 'out'),
+                                         _dev(outside, 'outside'), r, h, w, int(depth_num), float(pad_hw[0]),
+                                         float(pad_hw[1]), float(depth_start), rng, _stream())
+    _lib.check(code, 'gd4d_frustum_pe_input_fwd')
+    return out, outside.bool()
+
+
+def sine_pe3d_fwd(n_embed, y_embed, x_embed, dim_t):
+    """gd4d_sine_pe3d_fwd.  embeds (R, H, W) fp32, dim_t (F) -> (R, 3*F, H, W)."""
+    lib = _lib.load()
+    r, h, w = n_embed.shape
+    f = dim_t.numel()
+    out = torch.empty(r, 3 * f, h, w, device=n_embed.device, dtype=torch.float32)
+    code = lib.gd4d_sine_pe3d_fwd(_dev(n_embed, 'n_embed', torch.float32), _dev(y_embed, 'y_embed', torch.float32),
+                                  _dev(x_embed, 'x_embed', torch.float32), _dev(dim_t, 'dim_t', torch.float32),
+                                  _dev(out, 'out'), r, h * w, f, _stream())
+    _lib.check(code, 'gd4d_sine_pe3d_fwd')
+    return out
+
+
+def se_fuse_fwd(feat, gate, pe, sine, out=None):
+    """gd4d_se_fuse_fwd: feat + (pe * sigmoid(gate) + sine), all the same shape."""
+    lib = _lib.load()
+    out = torch.empty_like(feat) if out is None else out
+    code = lib.gd4d_se_fuse_fwd(_dev(feat, 'feat', torch.float32), _dev(gate, 'gate', torch.float32),
+                                _dev(pe, 'pe', torch.float32), _dev(sine, 'sine', torch.float32), _dev(out, 'out'),
+                                ctypes.c_size_t(feat.numel()), _stream())
+    _lib.check(code, 'gd4d_se_fuse_fwd')
+    return out
+
+
 def box_head_fwd(tmp, ref, pc_range, scale=1.0, out=None):
     """gd4d_box_head_fwd: tmp (..., code) raw regression output, ref (..., 3) in [0,1] -> bbox_preds."""
     lib = _lib.load()

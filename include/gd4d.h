@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 5
+#define GD4D_ABI_VERSION 6
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -289,6 +289,33 @@ int gd4d_box_head_fwd(const float* tmp, const float* ref, const double* pc_range
 int gd4d_nms_free_decode_fwd(const float* cls_scores, const float* bbox_preds, const float* post_center_range,
                              float score_threshold, float* boxes, float* scores, int32_t* labels, uint8_t* keep,
                              int B, int Q, int C, int code_size, int K, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * The step feeding the path: Detr3DHeadPE's feature position embedding
+ * (projects/mmdet3d_plugin/models/dense_heads/detr3d_head_pe.py:427-491, :525-557).  Its 1x1 convolutions are plain
+ * GEMMs and stay with the library; these are the bandwidth-bound pieces.
+ *
+ * gd4d_frustum_pe_input_fwd - position_embeding :438-481 up to the input of position_encoder: for every pixel centre
+ * (x * pad_w / W, y * pad_h / H) and depth bin d_i = depth_start + bin * i * (i + 1), bin = (pc_range[3] -
+ * depth_start) / (D (D + 1)): p = img2lidar @ [u * max(d, eps), v * max(d, eps), d, 1], normalised by pc_range,
+ * inverse_sigmoid.  img2lidar (R = B*N, 4, 4) fp32 (the reference inverts lidar2img with numpy on the host);
+ * out (R, 3*D, H, W) fp32, channel = 3 * i + axis; outside (R, H, W) uint8 = more than D/2 of the 3*D normalised
+ * coordinates fall outside [0, 1] (:477-478; the caller ORs it with the padding mask).
+ */
+int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uint8_t* outside, int R, int H, int W, int D,
+                              float pad_h, float pad_w, float depth_start, const double* pc_range, void* stream);
+
+/* gd4d_sine_pe3d_fwd - SinePositionalEncoding3D (models/utils/positional_encoding.py:82-99) after the cumulative
+ * sums: out[r, part*F + f, pix] = f < F/2 ? sin(e / dim_t[2f]) : cos(e / dim_t[2(f - F/2) + 1]), e = embed_part[r, pix],
+ * part = camera, row, column (the reference stacks sin / cos BEFORE the feature axis, :90-98).
+ * n_embed / y_embed / x_embed (R, HW) fp32, dim_t (F) fp32, out (R, 3*F, HW). */
+int gd4d_sine_pe3d_fwd(const float* n_embed, const float* y_embed, const float* x_embed, const float* dim_t,
+                       float* out, int R, int HW, int F, void* stream);
+
+/* gd4d_se_fuse_fwd - out = feat + (pe * sigmoid(gate) + sine): SELayer's gate (:243) and the adds of :553-557 in one
+ * pass over n elements (n % 4 == 0, 16-byte aligned pointers; out may alias feat). */
+int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out, size_t n,
+                     void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_cross_attn_bwd - backward of gd4d_cross_attn_fwd.

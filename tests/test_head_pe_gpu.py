@@ -1,0 +1,77 @@
+"""Feature position embedding (HIP kernels + library 1x1 convs) against the reference-generated fixture and the oracle.
+GPU only."""
+import pytest
+import torch
+
+from golden_io import Golden
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(g):
+    from graph_detr4d_amd import FeaturePositionEmbedding
+    m = g.meta
+    mod = FeaturePositionEmbedding(embed_dims=256, depth_num=m['depth_num'], depth_start=m['depth_start'],
+                                   pc_range=m['pc_range'])
+    mod.load_state_dict(g.state(), strict=True)          # the head's own parameter names
+    return mod.cuda().eval()
+
+
+def _metas(g):
+    m = g.meta
+    return [dict(lidar2img=[g.arrays['lidar2img'][i] for i in range(m['num_cams'])],
+                 img_shape=[tuple(s) for s in m['img_shapes']], pad_shape=[tuple(m['pad_shape'])] * m['num_cams'])]
+
+
+def test_frustum_input_and_mask_match_reference_pieces():
+    from graph_detr4d_amd import ops
+    import numpy as np
+    g = Golden('head_pe')
+    m = g.meta
+    l2i = g.arrays['lidar2img'][None].astype(np.float64)
+    i2l = torch.from_numpy(np.linalg.inv(l2i)).float().view(-1, 4, 4).cuda()
+    for lvl, (h, w) in enumerate(m['levels']):
+        x, outside = ops.frustum_pe_input_fwd(i2l, (h, w), m['pad_shape'][:2], m['depth_num'], m['depth_start'],
+                                              m['pc_range'])
+        c3, ref_out = O.frustum_points(l2i, (h, w), m['pad_shape'][:2], m['depth_num'], m['depth_start'], m['pc_range'])
+        ref_x = O.inverse_sigmoid(c3.permute(0, 1, 4, 5, 3, 2).contiguous().view(-1, 3 * m['depth_num'], h, w))
+        assert torch.equal(outside.cpu(), ref_out.permute(0, 1, 3, 2).reshape(-1, h, w))
+        # inverse_sigmoid amplifies fp32 rounding of the coordinate near the clamps; compare where it is well conditioned
+        d = (x.cpu() - ref_x).abs()
+        assert d[ref_x.abs() < 8].max().item() < 2e-4
+        assert (d > 1e-2).float().mean().item() < 1e-3
+        mask = g.t(f'mask{lvl}').bool() | outside.view(1, -1, h, w).cpu()
+        assert torch.equal(mask, g.t(f'coords_mask{lvl}').bool())
+
+
+def test_sine_embedding_matches_reference():
+    g = Golden('head_pe')
+    mod = _module(g)
+    for lvl in range(len(g.meta['levels'])):
+        got = mod.sine_embedding(g.t(f'mask{lvl}').bool().cuda())
+        torch.testing.assert_close(got.cpu(), g.t(f'sine{lvl}'), rtol=0, atol=2e-6)
+
+
+def test_feature_position_embedding_matches_reference():
+    g = Golden('head_pe')
+    mod = _module(g)
+    feats = [f.cuda() for f in g.feats()]
+    outs = mod(feats, _metas(g))
+    for lvl, o in enumerate(outs):
+        torch.testing.assert_close(o.cpu(), g.t(f'out{lvl}'), rtol=2e-4, atol=2e-4)
+    again = mod(feats, _metas(g))                         # second call: sine branch from the cache
+    assert mod._sine_cache is not None
+    for a, b in zip(outs, again):
+        assert torch.equal(a, b)
+    from graph_detr4d_amd._lib import Gd4dError
+    with pytest.raises(Gd4dError):
+        mod.cpu()([f.cpu() for f in feats], _metas(g))
+
+
+def test_se_fuse_equals_torch():
+    from graph_detr4d_amd import ops
+    torch.manual_seed(0)
+    f, g_, pe, s = (torch.randn(3, 256, 9, 4).cuda() for _ in range(4))
+    got = ops.se_fuse_fwd(f, g_, pe, s)
+    torch.testing.assert_close(got, f + (pe * torch.sigmoid(g_) + s), rtol=1e-6, atol=1e-6)
