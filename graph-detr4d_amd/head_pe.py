@@ -51,20 +51,26 @@ class FeaturePositionEmbedding(nn.Module):
         self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
         self.scale, self.eps, self.offset = scale, eps, offset
         self._sine_cache = None
+        self._mask_cache = None
 
     # ---- pieces -------------------------------------------------------------------------------------------------
-    @staticmethod
-    def padding_masks(img_metas, feats):
-        """:525-544: 1 outside each camera's img_shape inside the padded canvas, nearest-resized to every level."""
+    def padding_masks(self, img_metas, feats):
+        """:525-544: 1 outside each camera's img_shape inside the padded canvas, nearest-resized to every level.
+        A pure function of the shapes in img_metas: built on the device once per distinct key, then reused."""
         b, n = feats[0].shape[:2]
         pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
-        full = torch.ones(b, n, pad_h, pad_w)
+        key = (str(feats[0].device), pad_h, pad_w, tuple(tuple(f.shape[-2:]) for f in feats),
+               tuple(tuple(tuple(s[:2]) for s in img_metas[i]['img_shape'][:n]) for i in range(b)))
+        if self._mask_cache is not None and self._mask_cache[0] == key:
+            return self._mask_cache[1], (pad_h, pad_w)
+        full = torch.ones(b, n, pad_h, pad_w, device=feats[0].device)
         for i in range(b):
             for c in range(n):
                 ih, iw, _ = img_metas[i]['img_shape'][c]
                 full[i, c, :ih, :iw] = 0
-        full = full.to(feats[0].device)
-        return [F.interpolate(full, size=f.shape[-2:]).to(torch.bool) for f in feats], (pad_h, pad_w)
+        masks = [F.interpolate(full, size=f.shape[-2:]).to(torch.bool) for f in feats]
+        self._mask_cache = (key, masks)
+        return masks, (pad_h, pad_w)
 
     def sine_embedding(self, mask):
         """SinePositionalEncoding3D.forward (positional_encoding.py:58-100): tiny cumulative sums with torch, the
@@ -98,15 +104,14 @@ class FeaturePositionEmbedding(nn.Module):
         """adapt_pos3d(sine(mask)) per level; cached while the masks (and the weights) do not change."""
         key = tuple(p._version for p in self.adapt_pos3d.parameters())
         c = self._sine_cache
-        if c is not None and c[0] == key and len(c[1]) == len(masks) and \
-                all(a.shape == m.shape and a.device == m.device and torch.equal(a, m) for a, m in zip(c[1], masks)):
-            return c[2]
+        if c is not None and c[0] == key and len(c[1]) == len(masks) and all(a is m for a, m in zip(c[1], masks)):
+            return c[2]                              # same mask objects as last time (padding_masks caches by shapes)
         res = []
         for m in masks:
             s = self.sine_embedding(m)
             res.append(self.adapt_pos3d(s.flatten(0, 1)).view(m.shape[0], m.shape[1], self.embed_dims, *m.shape[2:]))
         if not any(p.requires_grad and torch.is_grad_enabled() for p in self.adapt_pos3d.parameters()):
-            self._sine_cache = (key, [m.clone() for m in masks], res)
+            self._sine_cache = (key, list(masks), res)
         return res
 
     # ---- the stage ------------------------------------------------------------------------------------------------

@@ -49,10 +49,14 @@ def camera_rig(num_frames=1, img_hw=(900, 1600), cam_radius=1.5, cam_height=1.5,
     return np.stack(mats).astype(dtype)
 
 
-def make_img_metas(lidar2img, img_shape=IMG_SHAPE, batch=1):
-    """The `img_metas` contract of the attention modules."""
+def make_img_metas(lidar2img, img_shape=IMG_SHAPE, batch=1, pad_shape=None):
+    """The `img_metas` contract of the attention modules; `pad_shape` (read by the head's feature
+    position embedding) defaults to the image height rounded up to a multiple of 32 (900 -> 928, config ...ceph.py)."""
     n = lidar2img.shape[0]
-    return [dict(lidar2img=[lidar2img[i] for i in range(n)], img_shape=[tuple(img_shape)] * n)
+    if pad_shape is None:
+        pad_shape = (-(-img_shape[0] // 32) * 32, -(-img_shape[1] // 32) * 32, 3)
+    return [dict(lidar2img=[lidar2img[i] for i in range(n)], img_shape=[tuple(img_shape)] * n,
+                 pad_shape=[tuple(pad_shape)] * n)
             for _ in range(batch)]
 
 

@@ -420,6 +420,7 @@ def frustum_points(lidar2img, feat_hw, pad_hw, depth_num, depth_start, pc_range,
     coords = torch.cat((coords, torch.ones_like(coords[..., :1])), -1)
     coords[..., :2] = coords[..., :2] * torch.maximum(coords[..., 2:3], torch.ones_like(coords[..., 2:3]) * eps)
     img2lidar = torch.from_numpy(np.linalg.inv(np.asarray(lidar2img, dtype=np.float64))).float()   # :459-465 (numpy inverse)
+    img2lidar = img2lidar.to(coords.device)         # `coords.new_tensor(...)` in the reference
     b, n = img2lidar.shape[:2]
     coords = coords.view(1, 1, w, h, d, 4, 1).repeat(b, n, 1, 1, 1, 1, 1)
     mats = img2lidar.view(b, n, 1, 1, 1, 4, 4).repeat(1, 1, w, h, d, 1, 1)
@@ -485,7 +486,7 @@ def feature_position_embedding(p, feats, lidar2img, img_shapes, pad_shape, depth
     img_shapes: per camera (h, w, 3) of sample 0..B-1 (list of lists).  Returns (new feats, intermediates)."""
     b, n = feats[0].shape[:2]
     pad_h, pad_w = pad_shape[0], pad_shape[1]
-    full = torch.ones(b, n, pad_h, pad_w)
+    full = torch.ones(b, n, pad_h, pad_w, device=feats[0].device)
     for i in range(b):
         for c in range(n):
             ih, iw = img_shapes[i][c][0], img_shapes[i][c][1]

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""GPU time of the head's feature position embedding (graph_detr4d_amd.FeaturePositionEmbedding) at the headline
+size (24 cameras, R50 pyramid), with a per-piece breakdown, beside the reference's op sequence (the oracle's
+restatement) run with torch on the same GPU.  Dev tool."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import graph_detr4d_amd as G  # noqa: E402
+from graph_detr4d_amd import ops, synthetic  # noqa: E402
+
+
+def timed(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=4)
+    ap.add_argument('--cpu-oracle', action='store_true',
+                    help='also time the oracle (the reference op sequence) on the host CPU, 16 threads, same inputs')
+    a = ap.parse_args()
+    n = 6 * a.frames
+    torch.manual_seed(0)
+    mod = G.FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE).cuda().eval()
+    feats = synthetic.feature_pyramid(n, device='cuda')
+    rig = synthetic.camera_rig(a.frames)
+    metas = synthetic.make_img_metas(rig)
+    pixels = sum(f.shape[-2] * f.shape[-1] for f in feats) * n
+    with torch.no_grad():
+        first = timed(lambda: (setattr(mod, '_sine_cache', None), setattr(mod, '_mask_cache', None), mod(feats, metas)), 3)
+        steady = timed(lambda: mod(feats, metas))
+        masks, pad_hw = mod.padding_masks(metas, feats)
+        i2l = torch.from_numpy(np.linalg.inv(np.asarray(rig, dtype=np.float64))).float().cuda()
+        x0 = {}
+
+        def frustum():
+            for lvl, f in enumerate(feats):
+                x0[lvl] = ops.frustum_pe_input_fwd(i2l, f.shape[-2:], pad_hw, 64, 1, synthetic.PC_RANGE)[0]
+        t_fr = timed(frustum)
+        t_pe = timed(lambda: [mod.position_encoder(x0[l]) for l in x0])
+        t_se = timed(lambda: [mod.fpe.gate_logits(f.flatten(0, 1)) for f in feats])
+        fl = [f.flatten(0, 1) for f in feats]
+        t_fuse = timed(lambda: [ops.se_fuse_fwd(f, f, f, f) for f in fl])
+        t_sine = timed(lambda: (setattr(mod, '_sine_cache', None), mod._sine_branch(masks)))
+    flops = pixels * 2 * (192 * 1024 + 1024 * 256 + 2 * 256 * 256)
+    print(f'cameras={n} pixels={pixels}  steady-state {steady:.2f} ms (first call, sine branch not cached: {first:.2f} ms)')
+    print(f'  frustum geometry kernel {t_fr:.2f} ms ({pixels * 192 * 4 / t_fr / 1e9:.2f} TB/s written)   '
+          f'position_encoder convs {t_pe:.2f} ms   SE convs {t_se:.2f} ms   fuse kernel {t_fuse:.2f} ms '
+          f'({pixels * 256 * 4 * 5 / t_fuse / 1e9:.2f} TB/s)   sine branch {t_sine:.2f} ms (cached afterwards)')
+    print(f'  dense work per call: {flops / 1e12:.2f} TFLOP fp32 -> {flops / steady / 1e9:.1f} TFLOP/s overall')
+    if a.cpu_oracle:
+        # (the same op sequence with torch on the GPU is not timed: its (B,N,W,H,D,4,4) batched matmul - 35.6 M
+        # 4x4 products at level 0 - faults inside the library at this batch count)
+        from oracle import torch_oracle as O
+        torch.set_num_threads(16)
+        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        cf = [f.cpu() for f in feats]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.feature_position_embedding(sd, cf, np.asarray(rig)[None], [list(metas[0]['img_shape'])],
+                                         metas[0]['pad_shape'][0], 64, 1, synthetic.PC_RANGE)
+        print(f'  CPU oracle (reference op sequence, 16 threads, one call): {(time.perf_counter() - t0) * 1e3:.0f} ms')
+
+
+if __name__ == '__main__':
+    main()
