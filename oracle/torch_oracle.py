@@ -349,9 +349,8 @@ def transformer(p, layer_params, mlvl_feats, query_embed, img_metas, pc_range,
 def box_head(tmp, reference, pc_range, depth_factor=None):
     """Per-layer box epilogue of Detr3DHeadPE.forward (models/dense_heads/detr3d_head_pe.py:571-600).
 
-    NOT pinned by a reference-generated fixture: the head class cannot be imported without all of mmdet3d;
-    this restates the 15 arithmetic lines (tests pin it against the decoder's reference-pinned refinement:
-    the sigmoid part equals detr3d_transformer.py:201-214)."""
+    Pinned by tests/golden/head_pe.npz: all_bbox_preds returned by the reference's own Detr3DHeadPE.forward run on a
+    shell object (tools/gen_golden.py case_head_pe), tests/test_head_pe_oracle.py."""
     ref = inverse_sigmoid(reference)
     out = tmp.clone()
     out[..., 0:2] = (tmp[..., 0:2] + ref[..., 0:2]).sigmoid()

@@ -14,7 +14,8 @@ def _module(g):
     m = g.meta
     mod = FeaturePositionEmbedding(embed_dims=256, depth_num=m['depth_num'], depth_start=m['depth_start'],
                                    pc_range=m['pc_range'])
-    mod.load_state_dict(g.state(), strict=True)          # the head's own parameter names
+    own = ('position_encoder.', 'adapt_pos3d.', 'fpe.')
+    mod.load_state_dict({k: v for k, v in g.state().items() if k.startswith(own)}, strict=True)   # the head's names
     return mod.cuda().eval()
 
 
@@ -75,3 +76,29 @@ def test_se_fuse_equals_torch():
     f, g_, pe, s = (torch.randn(3, 256, 9, 4).cuda() for _ in range(4))
     got = ops.se_fuse_fwd(f, g_, pe, s)
     torch.testing.assert_close(got, f + (pe * torch.sigmoid(g_) + s), rtol=1e-6, atol=1e-6)
+
+
+def test_head_outputs_match_reference_forward():
+    """functional.head_outputs (cls / reg branches on the HIP linears + gd4d_box_head_fwd) against what the reference's
+    Detr3DHeadPE.forward returned for the same decoder outputs."""
+    import torch.nn as nn
+    from graph_detr4d_amd import functional as Fn
+    g = Golden('head_pe')
+    m, sd = g.meta, g.state()
+    nl = m['num_layers']
+
+    def cls():
+        return nn.Sequential(nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True),
+                             nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True), nn.Linear(256, 10))
+
+    def reg():
+        return nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 10))
+    cls_b, reg_b = nn.ModuleList(cls() for _ in range(nl)), nn.ModuleList(reg() for _ in range(nl))
+    cls_b.load_state_dict({k[len('cls_branches.'):]: v for k, v in sd.items() if k.startswith('cls_branches.')})
+    reg_b.load_state_dict({k[len('reg_branches.'):]: v for k, v in sd.items() if k.startswith('reg_branches.')})
+    cls_b.cuda().eval(), reg_b.cuda().eval()
+    with torch.no_grad():
+        got = Fn.head_outputs(g.t('hs').cuda(), g.t('init_reference').cuda(), g.t('inter_references').cuda(), cls_b,
+                              reg_b, m['pc_range'])
+    torch.testing.assert_close(got['all_cls_scores'].cpu(), g.t('all_cls_scores'), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got['all_bbox_preds'].cpu(), g.t('all_bbox_preds'), rtol=1e-4, atol=1e-4)

@@ -328,14 +328,15 @@ def case_decode(name, *, num_query, batch, seed, max_num, code_size=10, score_th
     save(name, meta, **arrays)
 
 
-def case_head_pe(name, *, frames, img_hw, pad_hw, strides, seed, depth_num=64):
-    """The step feeding the path: Detr3DHeadPE's feature position embedding.
-
-    `position_embeding` (dense_heads/detr3d_head_pe.py:427-491), `SELayer` (:231-243) and
-    `SinePositionalEncoding3D` (models/utils/positional_encoding.py:15-100) are the reference's code; the masks and
-    the per-level glue are the lines :525-553 of Detr3DHeadPE.forward, which cannot be called without the rest of
-    the head and are transcribed below around those reference calls.
+def case_head_pe(name, *, frames, img_hw, pad_hw, strides, seed, depth_num=64, num_query=40, num_layers=2):
+    """The steps either side of the path from the reference's own
+    `Detr3DHeadPE.forward` (dense_heads/detr3d_head_pe.py:495-620), run unmodified on a shell object that carries
+    exactly the attributes the method reads.  Its transformer is a recorder: it captures the feature maps the head
+    hands over - i.e. the output of the feature position embedding, :525-557 with `position_embeding` :427-491,
+    `SELayer` :231-243 and `SinePositionalEncoding3D` (models/utils/positional_encoding.py:15-100) - and returns
+    prepared decoder outputs, so the returned all_cls_scores / all_bbox_preds pin the per-layer epilogue :568-612.
     """
+    import types
     head_mod, pe_mod = refstub.load_head_pe()
     torch.manual_seed(seed)
     n = 6 * frames
@@ -343,54 +344,73 @@ def case_head_pe(name, *, frames, img_hw, pad_hw, strides, seed, depth_num=64):
     feats, packed = grid_features(n, levels, 1, seed)
     rig = small_rig(frames, img_hw)
     embed = 256
+    g = torch.Generator().manual_seed(seed + 5)
+    hs = torch.round(torch.randn(num_layers, num_query, 1, embed, generator=g) * 64) / 64          # (nl, Q, B, C)
+    init_ref = torch.rand(1, num_query, 3, generator=g)
+    inter_ref = torch.rand(num_layers, 1, num_query, 3, generator=g)
+    init_ref[0, 0] = torch.tensor([0., 1., 0.5])
+    recorded = {}
 
-    class Shell(nn.Module):                       # the attributes position_embeding reads, nothing else
+    class Recorder(nn.Module):
+        def forward(self, mlvl_feats, query_embeds, reg_branches=None, img_metas=None):
+            recorded['feats'] = [f.detach().clone() for f in mlvl_feats]
+            recorded['query_embeds'] = query_embeds.detach().clone()
+            return hs.clone(), init_ref.clone(), inter_ref.clone()
+
+    class Shell(nn.Module):                       # the attributes Detr3DHeadPE.forward / position_embeding read
         def __init__(self):
             super().__init__()
             self.embed_dims, self.depth_num, self.depth_start = embed, depth_num, 1
             self.pc_range = PC_RANGE
             self.position_dim = 3 * depth_num
+            self.with_detach, self.with_box_refine, self.scale_pred = False, True, False
             self.position_encoder = nn.Sequential(nn.Conv2d(self.position_dim, embed * 4, 1), nn.ReLU(),
                                                   nn.Conv2d(embed * 4, embed, 1))          # :380-384
             self.adapt_pos3d = nn.Sequential(nn.Conv2d(embed * 3 // 2, embed * 4, 1), nn.ReLU(),
                                              nn.Conv2d(embed * 4, embed, 1))               # :385-389
             self.fpe = head_mod.SELayer(embed)                                               # :390
             self.positional_encoding = pe_mod.SinePositionalEncoding3D(num_feats=128, normalize=True, offset=-0.5)
+            self.query_embedding = nn.Embedding(num_query, embed * 2)
+            cls = lambda: nn.Sequential(nn.Linear(embed, embed), nn.LayerNorm(embed), nn.ReLU(inplace=True),
+                                        nn.Linear(embed, embed), nn.LayerNorm(embed), nn.ReLU(inplace=True),
+                                        nn.Linear(embed, 10))                                # :368-376
+            reg = lambda: nn.Sequential(nn.Linear(embed, embed), nn.ReLU(), nn.Linear(embed, embed), nn.ReLU(),
+                                        nn.Linear(embed, 10))                                # :378-383
+            self.cls_branches = nn.ModuleList(cls() for _ in range(num_layers))
+            self.reg_branches = nn.ModuleList(reg() for _ in range(num_layers))
+            self.transformer = Recorder()
     shell = Shell().eval()
     quantise_params_(shell, seed + 1, std=0.04)
+    shell.position_embeding = types.MethodType(head_mod.Detr3DHeadPE.position_embeding, shell)
     img_shapes = [(img_hw[0] - (4 if c % 3 == 1 else 0), img_hw[1] - (8 if c % 3 == 2 else 0), 3) for c in range(n)]
     metas = [dict(lidar2img=[rig[i] for i in range(n)], img_shape=img_shapes, pad_shape=[(pad_hw[0], pad_hw[1], 3)] * n)]
     with torch.no_grad():
-        x = feats[0]
-        bsz, ncam = x.size(0), x.size(1)
-        in_h, in_w, _ = metas[0]['pad_shape'][0]
-        masks = [x.new_ones((bsz, ncam, in_h, in_w)) for _ in levels]                         # :529-533
-        for i in range(bsz):
-            for c in range(ncam):
-                ih, iw, _ = metas[i]['img_shape'][c]
-                for l in range(len(levels)):
-                    masks[l][i, c, :ih, :iw] = 0                                              # :535-539
+        outs = head_mod.Detr3DHeadPE.forward(shell, [f.clone() for f in feats], metas)        # the reference forward
+        # intermediates for finer-grained tests, from the same reference pieces
+        masks = []
+        full = torch.ones(1, n, pad_hw[0], pad_hw[1])
+        for c in range(n):
+            full[0, c, :img_shapes[c][0], :img_shapes[c][1]] = 0
         for l in range(len(levels)):
-            masks[l] = F.interpolate(masks[l], size=feats[l].shape[-2:]).to(torch.bool)       # :542-544
-        mlvl = [f.clone() for f in feats]
-        coords_pe, coords_masks = head_mod.Detr3DHeadPE.position_embeding(shell, mlvl, metas, masks)   # :546
+            masks.append(F.interpolate(full, size=feats[l].shape[-2:]).to(torch.bool))
+        coords_pe, coords_masks = shell.position_embeding([f.clone() for f in feats], metas, masks)
         arrays = {}
         for l in range(len(levels)):
             arrays[f'coords_pe{l}'] = coords_pe[l].clone()
             arrays[f'coords_mask{l}'] = coords_masks[l].to(torch.uint8)
-            pe = shell.fpe(coords_pe[l].flatten(0, 1), mlvl[l].flatten(0, 1)).view(mlvl[l].size())   # :551-552
-            sin_embed = shell.positional_encoding(masks[l])
-            arrays[f'sine{l}'] = sin_embed.clone()
-            sin_embed = shell.adapt_pos3d(sin_embed.flatten(0, 1)).view(mlvl[l].size())
-            arrays[f'out{l}'] = mlvl[l] + (pe + sin_embed)                                    # :554-557
+            arrays[f'sine{l}'] = shell.positional_encoding(masks[l]).clone()
             arrays[f'mask{l}'] = masks[l].to(torch.uint8)
+            arrays[f'out{l}'] = recorded['feats'][l]
+    assert outs['enc_cls_scores'] is None and outs['enc_bbox_preds'] is None
+    arrays.update(all_cls_scores=outs['all_cls_scores'], all_bbox_preds=outs['all_bbox_preds'], hs=hs,
+                  init_reference=init_ref, inter_references=inter_ref)
     for l, pk in enumerate(packed):
         arrays[f'feat{l}@q'] = pk
     arrays['lidar2img'] = rig.astype(np.float32)
     arrays.update(pack_state(shell))
     meta = dict(kind='head_pe', num_cams=n, levels=levels, pc_range=PC_RANGE, depth_num=depth_num, depth_start=1,
                 img_shapes=img_shapes, pad_shape=[pad_hw[0], pad_hw[1], 3], feat_scale=FEAT_SCALE, w_scale=W_SCALE,
-                batch=1)
+                batch=1, num_query=num_query, num_layers=num_layers)
     save(name, meta, **arrays)
 
 
