@@ -34,6 +34,7 @@ struct CrossAttnParams {
   float* uv_out;
   const int32_t* order;   // optional permutation of [0, B*Q): locality order of the queries (gd4d_query_order_fwd)
   int B, N, Q, L, S;
+  int raw_cam;         // 1: camera weights are the raw logits (Deform3DCrossAttnMP's neighbour pass), 0: sigmoid
   int head_major;      // value layout: 0 = (B*N, S, Hh, Dh) pixel-major, 1 = (B*N, Hh, S, Dh) head-major planes
   int lvl_h[GD4D_MAX_LEVELS];
   int lvl_w[GD4D_MAX_LEVELS];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttn
       softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * kPoints, L * kPoints, aw);
     }
     const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];   // raw-view scramble
-    const float cw = 1.0f / (1.0f + expf(-cl));
+    const float cw = p.raw_cam ? cl : 1.0f / (1.0f + expf(-cl));
     const VT* vrow = vlane + (size_t)row * p.S * kChannels;
 
 #pragma unroll
@@ -318,7 +319,7 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
       softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * kPoints, L * kPoints, aw_reg);
     }
     const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];
-    const float cw = 1.0f / (1.0f + expf(-cl));
+    const float cw = p.raw_cam ? cl : 1.0f / (1.0f + expf(-cl));
     const VT* vrow = static_cast<const VT*>(p.value) + (size_t)row * p.S * kChannels;   // wave-uniform
     // pixel stride / lane offset of the two layouts (elements)
     const unsigned pix_stride = p.head_major ? (unsigned)DH : (unsigned)kChannels;
@@ -468,7 +469,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
                                    const float* cam_logits, const float* lidar2img,
                                    const double* pc_range, float img_h, float img_w, float* out,
                                    uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
-                                   int Dh, int L, int P, int value_dtype, int value_layout,
+                                   int Dh, int L, int P, int value_dtype, int value_layout, int flags,
                                    const int32_t* query_order, void* stream) {
   using namespace gd4d;
   if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img ||
@@ -487,6 +488,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
   p.uv_out = uv_out; p.order = query_order;
   p.B = B; p.N = N; p.Q = Q; p.L = L;
   p.head_major = value_layout == GD4D_LAYOUT_HEAD_MAJOR;
+  p.raw_cam = (flags & GD4D_CA_RAW_CAM_WEIGHTS) ? 1 : 0;
   int start = 0;
   for (int l = 0; l < L; ++l) {
     const int h = level_hw[2 * l], w = level_hw[2 * l + 1];

@@ -33,7 +33,8 @@ def _value_dtype(t):
 
 
 def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                   img_h, img_w, want_mask=False, want_uv=False, out=None, head_major=False, query_order=None):
+                   img_h, img_w, want_mask=False, want_uv=False, out=None, head_major=False, query_order=None,
+                   raw_cam_weights=False):
     """gd4d_cross_attn_fwd.  value (B*N, S, Hh, Dh), or (B*N, Hh, S, Dh) with head_major=True;
     ref (B,Q,3); offsets (B,Q,Hh,P,3);
     attn_logits (B,Q,Hh,L,P) (or (B,Q,Hh,L*P)); cam_logits (B,Q,N); lidar2img (B,N,4,4).
@@ -63,7 +64,7 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
         _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(out, 'out', f32),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None,
         b, n, q, hh, dh, nl, p, _value_dtype(value), _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR,
-        None if query_order is None else _order_ptr(query_order, b * q), _stream())
+        1 if raw_cam_weights else 0, None if query_order is None else _order_ptr(query_order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_fwd')
     res = (out,)
     if want_mask:

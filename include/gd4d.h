@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 6
+#define GD4D_ABI_VERSION 7
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -54,6 +54,7 @@ enum {
 
 #define GD4D_MAX_LEVELS 8
 #define GD4D_MAX_LAYERS 8
+#define GD4D_CA_RAW_CAM_WEIGHTS 1
 
 int gd4d_abi_version(void);
 const char* gd4d_error_string(int code);
@@ -85,6 +86,8 @@ const char* gd4d_last_hip_error(void);
  *   mask_out     optional (B, N, Q, Hh, P) uint8 visibility mask (bit-exact vs the reference's CPU
  *                arithmetic at this boundary); NULL to skip
  *   uv_out       optional (B, N, Q, Hh, P, 2) fp32 normalised image coordinates; NULL to skip
+ *   flags        GD4D_CA_RAW_CAM_WEIGHTS: weight of camera n is the raw flat[b][n*Q + q] instead of its sigmoid
+ *                (the neighbour pass of Deform3DCrossAttnMP, deform3d_cross_attn_multi_point.py:424-430)
  *   query_order  optional int32 permutation of [0, B*Q) from gd4d_query_order_fwd, or NULL.  Scheduling only: with
  *                it each XCD (private L2) processes queries that look at the same camera region; the result is
  *                bit-identical for any permutation.
@@ -99,7 +102,7 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
                         const float* offsets, const float* attn_logits, const float* cam_logits,
                         const float* lidar2img, const double* pc_range, float img_h, float img_w,
                         float* out, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
-                        int Dh, int L, int P, int value_dtype, int value_layout,
+                        int Dh, int L, int P, int value_dtype, int value_layout, int flags,
                         const int32_t* query_order, void* stream);
 
 /* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the

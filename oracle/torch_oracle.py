@@ -129,7 +129,7 @@ def scrambled_cam_weights(cam_logits, num_cams):
 
 
 def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                     img_h, img_w):
+                     img_h, img_w, raw_cam=False):
     """The fused kernel's contract (a3+a5+a6+a7-reduction; deform3d_cross_attn.py:220-324).
 
     value (B*N, sum(HW), Hh, Dh) already value_proj-ed; ref (B,Q,3) in [0,1];
@@ -153,7 +153,8 @@ def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar
     w = attn_logits.softmax(-1)[rows].view(b, n, q, hh, nl, p)
     w = (w * mask.view(b, n, q, hh, 1, p)).reshape(b * n, q, hh, nl * p)
     per_cam = msda(value, shapes, loc, w).view(b, n, q, -1)                 # :302-304
-    cam = scrambled_cam_weights(cam_logits, n).sigmoid()                    # :320
+    cam = scrambled_cam_weights(cam_logits, n)
+    cam = cam if raw_cam else cam.sigmoid()                                 # :320 (MP neighbour pass: raw)
     return (per_cam * cam).sum(1), uv, mask                                  # :322-324
 
 
@@ -184,6 +185,47 @@ def deform3d_cross_attn(p, query, value, query_pos, reference_points, img_metas,
     if return_parts:
         return res, dict(agg=agg, uv=uv, mask=mask, offsets=offsets, attn_logits=attn_logits,
                          cam_logits=cam_logits, value=val, pos=pos)
+    return res
+
+
+def deform3d_cross_attn_mp(p, query, value, reference_points, img_metas, pc_range, num_heads=8, num_points=4,
+                           return_parts=False):
+    """Deform3DCrossAttnMP.forward in eval mode with multi_points=True
+    (utils/deform3d_cross_attn_multi_point.py:138-453).  reference_points (B, 9Q, 3): Q centres, then 8 blocks of Q
+    neighbour points.  Differences to Deform3DCrossAttn: no query_pos (:211-222); a second sampling pass over the
+    neighbours without offsets, one point per level (:373-417); neighbour camera weights are NOT sigmoided
+    (:424-430); a 2-way softmax blend whose logits are summed over the queries of sample 0 (:434-439)."""
+    x = query.permute(1, 0, 2)                                              # :222 (no query_pos)
+    b, q, c = x.shape
+    nl = len(value)
+    n = value[0].shape[1]
+    l2i = lidar2img_tensor(img_metas, reference_points)
+    img_h, img_w = img_metas[0]['img_shape'][0][0], img_metas[0]['img_shape'][0][1]
+    centre, nbr = reference_points[:, :q], reference_points[:, q:]          # :228, :373
+    flat, shapes = flatten_pyramid(value)
+    val = _linear(flat, p, 'value_proj').view(b * n, flat.shape[1], num_heads, c // num_heads)
+    # centre pass: exactly Deform3DCrossAttn's
+    agg, uv, mask = sample_aggregate(val, shapes, centre, _linear(x, p, 'deform_sampling_offsets')
+                                     .view(b, q, num_heads, num_points, 3),
+                                     _linear(x, p, 'attention_weights').view(b, q, num_heads, nl * num_points),
+                                     _linear(x, p, 'cam_attention_weights'), l2i, pc_range, img_h, img_w)
+    # neighbour pass.  The (B*N, Q, 256) Linear output is VIEWED as (B*N, 8Q, Hh, L*P/4) (:375-376): neighbour row r
+    # takes the 32 logits [r % 8] of query r // 8, while point r of reference_points[:, Q:] belongs to query r % Q.
+    logits_n = _linear(x, p, 'attention_weights_neighbor').reshape(b, 8 * q, num_heads, nl * num_points // 4)
+    x_n = x.repeat(1, 8, 1)                                                 # :383
+    cam_n = _linear(x_n, p, 'cam_attention_weights')                        # (B, 8Q, N), raw view below (:424-425)
+    zero_off = torch.zeros(b, 8 * q, num_heads, num_points // 4, 3)
+    agg_n, uv_n, mask_n = sample_aggregate(val, shapes, nbr, zero_off, logits_n, cam_n, l2i, pc_range, img_h, img_w,
+                                           raw_cam=True)
+    agg_n = agg_n.view(b, 8, q, c).sum(1)                                   # :431-433 (the sum over cameras is inside)
+    blend = _linear(torch.cat([agg, agg_n], -1), p, 'output_weight')        # :435-436
+    wts = blend.sum(1).softmax(-1)                                          # :437
+    mixed = agg * wts[0][0] + agg_n * wts[0][1]                             # :438 (sample 0's weights for everyone)
+    out = _linear(mixed, p, 'output_proj').permute(1, 0, 2)                 # :440-441
+    pos = position_encoder(p, inverse_sigmoid(centre)).permute(1, 0, 2)     # :447
+    res = out + query + pos                                                 # :449
+    if return_parts:
+        return res, dict(agg=agg, agg_n=agg_n, mask_n=mask_n, blend=blend, mixed=mixed, pos=pos, value=val)
     return res
 
 

@@ -164,3 +164,24 @@ def test_hdetr_transformer_mask_path_equals_oracle():
     with torch.no_grad():
         s2, _, _ = tr([f.to(DEV) for f in g.feats()], qe.to(DEV), reg_branches=None, img_metas=g.img_metas())
     assert (s2.cpu() - s_ref).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize('name', ['deform_mp_n6', 'deform_mp_n12_b2'])
+def test_deform3d_cross_attn_mp_module(name):
+    """Deform3DCrossAttnMP (centre pass + neighbour pass on the fused kernel) against the reference's forward."""
+    g = Golden(name)
+    m = g.meta
+    mod = G.build_attention(dict(type='Deform3DCrossAttnMP', num_cams=m['num_cams'], pc_range=m['pc_range'],
+                                 num_points=4, embed_dims=256))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    with torch.no_grad():
+        out = mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
+                  reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+    torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
+    with pytest.raises(ValueError), torch.no_grad():
+        mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
+            reference_points=g.t('reference_points')[:, :m['num_query']].to(DEV), img_metas=_metas(g))
+    with pytest.raises(NotImplementedError):                 # parameters require grad outside no_grad: no backward
+        mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
+            reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))

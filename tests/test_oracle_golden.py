@@ -109,3 +109,18 @@ def test_transformer_decoder_matches_reference(name):
     torch.testing.assert_close(init_ref, g.t('init_reference'), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(refs, g.t('inter_references'), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(states, g.t('inter_states'), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['deform_mp_n6', 'deform_mp_n12_b2'])
+def test_deform3d_cross_attn_mp_matches_reference(name):
+    """Deform3DCrossAttnMP: the reference's forward (its second MSDA call completed by the refstub frame hook)."""
+    g = Golden(name)
+    m = g.meta
+    out, parts = O.deform3d_cross_attn_mp(g.state(), g.t('query'), g.feats(), g.t('reference_points'), g.img_metas(),
+                                          m['pc_range'], return_parts=True)
+    b, n, q = m['batch'], m['num_cams'], m['num_query']
+    gmask = g.t('neighbor_mask').view(b, n, 8 * q, 8, 4)[..., 0]           # equal for all levels
+    assert torch.equal(parts['mask_n'][..., 0], gmask.bool())
+    torch.testing.assert_close(parts['blend'], g.t('blend_logits'), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(parts['mixed'], g.t('blended'), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out, g.t('out'), rtol=1e-4, atol=1e-4)

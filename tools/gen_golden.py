@@ -199,6 +199,46 @@ def case_deform(name, *, num_query, frames, batch, img_hw, seed, depth_encode=Fa
     save(name, meta, **arrays)
 
 
+def case_deform_mp(name, *, num_query, frames, batch, img_hw, seed, strides=(8, 16, 32, 64)):
+    """Deform3DCrossAttnMP (utils/deform3d_cross_attn_multi_point.py:35-453, config
+    detr4d_res50_deform_pe_mp_testaug_2subset_12e.py:76): centre pass + 8 neighbour points per query.  The dead CPU
+    branch of its second MSDA call site is completed by tools/refstub.py's frame hook."""
+    ref_mods = refstub.load_reference(('deform3d_cross_attn_multi_point',))
+    cls = ref_mods['deform3d_cross_attn_multi_point'].Deform3DCrossAttnMP
+    n = 6 * frames
+    torch.manual_seed(seed)
+    mod = cls(embed_dims=256, num_heads=8, num_levels=4, num_points=4, num_cams=n, pc_range=PC_RANGE).eval()
+    quantise_params_(mod, seed)
+    levels = levels_for(img_hw, strides)
+    feats, packed = grid_features(n, levels, batch, seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    q = torch.randn(num_query, batch, 256, generator=g)
+    centre = torch.rand(batch, num_query, 3, generator=g)
+    # 8 neighbours per query, block j holds neighbour j of every query (reference layout: reference_points[:, Q:])
+    nbr = (centre[:, None] + 0.04 * torch.randn(batch, 8, num_query, 3, generator=g)).clamp(0, 1)
+    ref = torch.cat([centre, nbr.reshape(batch, 8 * num_query, 3)], 1)
+    l2i = small_rig(frames, img_hw)
+    metas = synthetic.make_img_metas(l2i, img_shape=(img_hw[0], img_hw[1], 3), batch=batch)
+    hooks = Hooks(mod, ['output_proj', 'position_encoder', 'output_weight'])
+    with torch.no_grad():
+        out = mod(q, None, feats, None, reference_points=ref.clone(), img_metas=metas)
+    hooks.close()
+    cap = refstub.CAPTURED
+    meta = dict(kind='Deform3DCrossAttnMP', num_query=num_query, num_cams=n, batch=batch, levels=levels,
+                img_shape=[img_hw[0], img_hw[1], 3], pc_range=list(PC_RANGE), num_heads=8, num_points=4, seed=seed,
+                feat_scale=FEAT_SCALE, w_scale=W_SCALE)
+    arrays = dict(query=q, reference_points=ref, lidar2img=l2i, out=out,
+                  neighbor_mask=cap['mask_neighbor'].to(torch.uint8),       # (B*N, 8Q, Hh, L)
+                  neighbor_msda=cap['msda_output_neighbor'],                # (B*N, 8Q, C)
+                  blended=hooks.rec['output_proj.in'],                      # (B, Q, C) after the 2-way blend
+                  blend_logits=hooks.rec['output_weight.out'],              # (B, Q, 2)
+                  pos_feat=hooks.rec['position_encoder.out'])
+    for i, pk in enumerate(packed):
+        arrays[f'feat{i}@q'] = pk
+    arrays.update(pack_state(mod))
+    save(name, meta, **arrays)
+
+
 def case_detr3d(name, *, num_query, frames, batch, img_hw, seed):
     ref_mods = refstub.load_reference()
     m = ref_mods['detr3d_transformer']
@@ -422,6 +462,8 @@ def main():
     case_deform('deform_n24_b2', num_query=24, frames=4, batch=2, img_hw=(64, 112), seed=103)
     case_deform('deform_edge', num_query=16, frames=1, batch=1, img_hw=(64, 128), seed=104,
                 edge=True, pc_range=[0., 0., 0., 1., 1., 1.])
+    case_deform_mp('deform_mp_n6', num_query=20, frames=1, batch=1, img_hw=(128, 224), seed=151)
+    case_deform_mp('deform_mp_n12_b2', num_query=12, frames=2, batch=2, img_hw=(64, 112), seed=152)
     case_detr3d('detr3d_n6', num_query=24, frames=1, batch=1, img_hw=(128, 224), seed=201)
     case_detr3d('detr3d_n12_b2', num_query=16, frames=2, batch=2, img_hw=(64, 112), seed=202)
     case_self_attn('self_attn', num_query=50, batch=2, seed=301, with_mask=False)

@@ -144,6 +144,19 @@ def _msda_stub(value, spatial_shapes, sampling_locations, attention_weights):
     for k, v in loc.items():
         if torch.is_tensor(v):
             CAPTURED[k] = v.detach().clone()
+    if 'reference_points_neighbor_cam' in loc and 'attention_weights_neighbor' in loc:
+        # Second call site of Deform3DCrossAttnMP.forward (deform3d_cross_attn_multi_point.py:408-417).  Its dead CPU
+        # branch assigns the result to `output` (clobbering the first pass) with the FIRST pass's arguments and then
+        # reads an `output_neighbor` it never defined.  What the CUDA branch computes is unambiguous (:403-406); the
+        # stub evaluates that from the caller's locals, plants it into the caller's `output_neighbor` local and hands
+        # the first-pass `output` back so the clobbering assignment is a no-op.  The reference file runs unmodified.
+        import ctypes
+        out_n = msda_pytorch(value, spatial_shapes, loc['reference_points_neighbor_cam'],
+                             loc['attention_weights_neighbor'])
+        CAPTURED['msda_output_neighbor'] = out_n.detach().clone()
+        caller.f_locals['output_neighbor'] = out_n
+        ctypes.pythonapi.PyFrame_LocalsToFast(ctypes.py_object(caller), ctypes.c_int(0))
+        return loc['output']
     if sampling_locations is None:
         sampling_locations = loc['reference_points_cam']
     out = msda_pytorch(value, spatial_shapes, sampling_locations, attention_weights)
@@ -369,6 +382,7 @@ def install_stubs():
     _mod('mmdet.models')
     _mod('mmdet.models.utils')
     _mod('mmdet.models.utils.builder', TRANSFORMER=TRANSFORMER)
+    _mod('mmdet.models.utils.transformer', DetrTransformerDecoderLayer=DetrTransformerDecoderLayer)
     _mod('mmdet3d')
     _mod('mmdet3d.core')
     _mod('mmdet3d.core.bbox')
@@ -463,7 +477,8 @@ def load_head_pe():
     _mod('torchvision', transforms=None)
     core = sys.modules['mmdet.core']
     core.multi_apply = core.reduce_mean = core.build_sampler = core.build_assigner = None
-    _mod('mmdet.models.utils.transformer', inverse_sigmoid=ref.inverse_sigmoid)
+    _mod('mmdet.models.utils.transformer', inverse_sigmoid=ref.inverse_sigmoid,
+         DetrTransformerDecoderLayer=DetrTransformerDecoderLayer)
     heads = Registry('head')
     sys.modules['mmdet.models'].HEADS = heads
     _mod('mmdet.models.dense_heads', DETRHead=type('DETRHead', (nn.Module,), {}))
