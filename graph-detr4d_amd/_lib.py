@@ -42,6 +42,8 @@ SIGNATURES = {
     'gd4d_frustum_pe_input_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
     'gd4d_sine_pe3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'gd4d_se_fuse_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    'gd4d_knn_farthest_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'gd4d_edge_conv_max_fwd': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
     'gd4d_box_head_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     'gd4d_nms_free_decode_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_multi_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

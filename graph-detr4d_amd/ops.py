@@ -350,6 +350,30 @@ def se_fuse_fwd(feat, gate, pe, sine, out=None):
     return out
 
 
+def knn_farthest_fwd(x, k):
+    """gd4d_knn_farthest_fwd: x (B, N, C) fp32 -> (B, N, K) int32 indices of the K farthest rows of the same sample."""
+    lib = _lib.load()
+    b, n, c = x.shape
+    idx = torch.empty(b, n, k, device=x.device, dtype=torch.int32)
+    code = lib.gd4d_knn_farthest_fwd(_dev(x, 'x', torch.float32), _dev(idx, 'idx'), b, n, c, int(k), _stream())
+    _lib.check(code, 'gd4d_knn_farthest_fwd')
+    return idx
+
+
+def edge_conv_max_fwd(ab, idx, scale, shift):
+    """gd4d_edge_conv_max_fwd: ab (B, N, 2C) = [W_a x | W_b x], idx (B, N, K) int32, scale / shift (C) -> (B, N, C)."""
+    lib = _lib.load()
+    b, n, c2 = ab.shape
+    c = c2 // 2
+    out = torch.empty(b, n, c, device=ab.device, dtype=torch.float32)
+    base = _dev(ab, 'ab', torch.float32)
+    code = lib.gd4d_edge_conv_max_fwd(base, ctypes.c_void_p(ab.data_ptr() + 4 * c), _dev(idx, 'idx', torch.int32),
+                                      _dev(scale, 'scale', torch.float32), _dev(shift, 'shift', torch.float32),
+                                      _dev(out, 'out'), b, n, c, idx.shape[-1], c2, _stream())
+    _lib.check(code, 'gd4d_edge_conv_max_fwd')
+    return out
+
+
 def box_head_fwd(tmp, ref, pc_range, scale=1.0, out=None):
     """gd4d_box_head_fwd: tmp (..., code) raw regression output, ref (..., 3) in [0,1] -> bbox_preds."""
     lib = _lib.load()

@@ -321,6 +321,23 @@ int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, cons
                      void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * DGCNNAttn (projects/mmdet3d_plugin/models/utils/dgcnn_attn.py:10-96), registered by the reference, used by no
+ * shipped config.
+ *
+ * gd4d_knn_farthest_fwd - edge_feats :84-86: for every row of x (B, N, C) the indices of the K rows of the same sample at
+ * the LARGEST Euclidean distance (the reference takes topk of cdist), descending, ties to the lower index.
+ * idx (B, N, K) int32.  N <= 2048, C % 4 == 0, K <= N.
+ *
+ * gd4d_edge_conv_max_fwd - conv + BatchNorm(eval) + ReLU + max over K of the edge features (:72-74, :77-78) with the
+ * 1x1 convolution split as W[:, :C] x_j + W[:, C:] x_i:  out[b, n, c] = max_k relu((a[b, idx[b,n,k], c] +
+ * b_self[b, n, c]) * scale[c] + shift[c]);  a / b_self (B*N, C) with row stride lda (two column blocks of one
+ * (B*N, 2C) Linear output), scale / shift (C) = the BatchNorm affine of eval mode, out (B*N, C) contiguous.
+ */
+int gd4d_knn_farthest_fwd(const float* x, int32_t* idx, int B, int N, int C, int K, void* stream);
+int gd4d_edge_conv_max_fwd(const float* a, const float* b_self, const int32_t* idx, const float* scale,
+                           const float* shift, float* out, int B, int N, int C, int K, int lda, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * gd4d_cross_attn_bwd - backward of gd4d_cross_attn_fwd.
  *
  * Replaces what autograd runs in the reference for deform3d_cross_attn.py:220-324: the third-party mmcv

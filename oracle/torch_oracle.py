@@ -545,3 +545,30 @@ def feature_position_embedding(p, feats, lidar2img, img_shapes, pad_shape, depth
         outs.append(f + (pe + s))
         sines.append(sine)
     return outs, dict(masks=masks, coords_pe=coords_pe, coords_masks=coords_masks, sine=sines)
+
+
+# ---------------------------------------------------------------------------------------------
+# DGCNNAttn (row a16; utils/dgcnn_attn.py), eval mode
+# ---------------------------------------------------------------------------------------------
+def dgcnn_edge_stage(p, x, k, prefix):
+    """edge_feats + conv + BatchNorm(eval) + ReLU + max over the K neighbours (dgcnn_attn.py:72-74, 82-96).
+    x (B, N, C).  Note the neighbours are the K FARTHEST points (topk of the distances, :84-86).
+    Returns ((B, C, N) features, (B, N, K) neighbour indices)."""
+    idx = torch.topk(torch.cdist(x, x), k=k, dim=2)[1]
+    b, n, c = x.shape
+    nbr = torch.gather(x.unsqueeze(1).expand(b, n, n, c), 2, idx.unsqueeze(-1).expand(b, n, k, c))   # (B, N, K, C)
+    edge = torch.cat((nbr, x.unsqueeze(2).expand(b, n, k, c)), -1).permute(0, 3, 1, 2)               # (B, 2C, N, K)
+    y = F.conv2d(edge, p[prefix + '0.weight'])
+    y = F.batch_norm(y, p[prefix + '1.running_mean'], p[prefix + '1.running_var'], p[prefix + '1.weight'],
+                     p[prefix + '1.bias'], training=False, eps=1e-5)
+    return torch.relu(y).max(dim=-1)[0], idx
+
+
+def dgcnn_attn(p, query, query_pos, k, return_parts=False):
+    """DGCNNAttn.forward (:41-80): residual + f1 + f2; the second stage always uses K = 16 (default argument, :75)."""
+    x = query if query_pos is None else query + query_pos
+    x = x.permute(1, 0, 2)
+    f1, idx1 = dgcnn_edge_stage(p, x, k, 'conv1.')
+    f2, _ = dgcnn_edge_stage(p, f1.permute(0, 2, 1), 16, 'conv2.')
+    out = query + (f1 + f2).permute(2, 0, 1)
+    return (out, dict(f1=f1, idx1=idx1)) if return_parts else out

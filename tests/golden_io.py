@@ -37,9 +37,9 @@ class Golden:
                 continue
             name = k[len(prefix):]
             if name.endswith('@q'):
-                sd[name[:-2]] = torch.from_numpy(v.astype(np.float32) / self.meta['w_scale'])
+                sd[name[:-2]] = torch.from_numpy(np.asarray(v.astype(np.float32) / self.meta['w_scale'], dtype=np.float32))
             else:
-                sd[name] = torch.from_numpy(v.astype(np.float32))
+                sd[name] = torch.from_numpy(np.asarray(v, dtype=np.float32))
         return sd
 
     def img_metas(self):

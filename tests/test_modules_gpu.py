@@ -185,3 +185,26 @@ def test_deform3d_cross_attn_mp_module(name):
     with pytest.raises(NotImplementedError):                 # parameters require grad outside no_grad: no backward
         mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
             reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+
+
+@pytest.mark.parametrize('name', ['dgcnn', 'dgcnn_k8'])
+def test_dgcnn_attn_module(name):
+    """DGCNNAttn (kNN + EdgeConv on HIP) against the reference module's forward; its training-mode torch path against
+    the same fixture with the BatchNorm in eval."""
+    g = Golden(name)
+    m = g.meta
+    mod = G.build_attention(dict(type='DGCNNAttn', embed_dims=256, num_heads=8, dropout=0.1, K=m['K']))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    q, qp = g.t('query').to(DEV), g.t('query_pos').to(DEV)
+    from graph_detr4d_amd import ops
+    idx = ops.knn_farthest_fwd((q + qp).permute(1, 0, 2).contiguous(), m['K'])
+    assert torch.equal(torch.sort(idx.cpu().long(), -1).values, torch.sort(g.t('idx1'), -1).values)
+    assert torch.equal(idx.cpu().long(), g.t('idx1')), 'descending-distance order'
+    with torch.no_grad():
+        out = mod(q, query_pos=qp)
+    torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
+    out2 = mod(q.requires_grad_(True), query_pos=qp)         # autograd -> the torch op sequence, same numbers in eval
+    torch.testing.assert_close(out2.detach().cpu(), g.t('out'), **TOL)
+    out2.sum().backward()
+    assert q.grad is not None

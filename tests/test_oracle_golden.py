@@ -124,3 +124,12 @@ def test_deform3d_cross_attn_mp_matches_reference(name):
     torch.testing.assert_close(parts['blend'], g.t('blend_logits'), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(parts['mixed'], g.t('blended'), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(out, g.t('out'), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['dgcnn', 'dgcnn_k8'])
+def test_dgcnn_attn_matches_reference(name):
+    g = Golden(name)
+    out, parts = O.dgcnn_attn(g.state(), g.t('query'), g.t('query_pos'), g.meta['K'], return_parts=True)
+    assert torch.equal(parts['idx1'], g.t('idx1'))
+    torch.testing.assert_close(parts['f1'], g.t('f1'), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out, g.t('out'), rtol=1e-5, atol=1e-5)

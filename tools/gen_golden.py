@@ -239,6 +239,30 @@ def case_deform_mp(name, *, num_query, frames, batch, img_hw, seed, strides=(8, 
     save(name, meta, **arrays)
 
 
+def case_dgcnn(name, *, num_query, batch, seed, k):
+    """DGCNNAttn (utils/dgcnn_attn.py:10-96): kNN-graph EdgeConv self-attention, eval mode (BatchNorm running stats)."""
+    mod_ref = refstub.load_reference(('dgcnn_attn',))['dgcnn_attn']
+    torch.manual_seed(seed)
+    mod = mod_ref.DGCNNAttn(embed_dims=256, num_heads=8, dropout=0.1, K=k).eval()
+    quantise_params_(mod, seed, std=0.05)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for bn in (mod.conv1[1], mod.conv2[1]):
+            bn.running_mean.copy_(torch.round(torch.randn(256, generator=g) * 0.2 * W_SCALE) / W_SCALE)
+            bn.running_var.copy_(torch.round((0.5 + torch.rand(256, generator=g)) * W_SCALE) / W_SCALE)
+    q = torch.round(torch.randn(num_query, batch, 256, generator=g) * 64) / 64
+    qp = torch.round(torch.randn(num_query, batch, 256, generator=g) * 64) / 64
+    with torch.no_grad():
+        out = mod(q, query_pos=qp)
+        x = (q + qp).permute(1, 0, 2)
+        idx1 = torch.topk(torch.cdist(x, x), k=k, dim=2)[1]
+        f1 = mod.conv1(mod.edge_feats(x, K=k)).max(dim=-1)[0]
+    meta = dict(kind='DGCNNAttn', num_query=num_query, batch=batch, K=k, w_scale=W_SCALE)
+    arrays = dict(query=q, query_pos=qp, out=out, idx1=idx1, f1=f1)
+    arrays.update(pack_state(mod))
+    save(name, meta, **arrays)
+
+
 def case_detr3d(name, *, num_query, frames, batch, img_hw, seed):
     ref_mods = refstub.load_reference()
     m = ref_mods['detr3d_transformer']
@@ -464,6 +488,8 @@ def main():
                 edge=True, pc_range=[0., 0., 0., 1., 1., 1.])
     case_deform_mp('deform_mp_n6', num_query=20, frames=1, batch=1, img_hw=(128, 224), seed=151)
     case_deform_mp('deform_mp_n12_b2', num_query=12, frames=2, batch=2, img_hw=(64, 112), seed=152)
+    case_dgcnn('dgcnn', num_query=70, batch=2, seed=161, k=16)
+    case_dgcnn('dgcnn_k8', num_query=40, batch=1, seed=162, k=8)
     case_detr3d('detr3d_n6', num_query=24, frames=1, batch=1, img_hw=(128, 224), seed=201)
     case_detr3d('detr3d_n12_b2', num_query=16, frames=2, batch=2, img_hw=(64, 112), seed=202)
     case_self_attn('self_attn', num_query=50, batch=2, seed=301, with_mask=False)
