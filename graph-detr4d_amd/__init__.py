@@ -16,10 +16,10 @@ from .deform3d_cross_attn_mp import Deform3DCrossAttnMP  # noqa: F401
 from .bbox_coder import NMSFreeCoder  # noqa: F401
 from .dgcnn_attn import DGCNNAttn  # noqa: F401
 from .head_pe import FeaturePositionEmbedding  # noqa: F401
-from .detr3d_transformer import (Detr3DCrossAtten, Detr3DTransformer, Detr3DTransformerDecoder,  # noqa: F401
+from .detr3d_transformer import (Detr3DCrossAtten, Detr3DCrossAttenV2, Detr3DTransformer, Detr3DTransformerDecoder,  # noqa: F401
                                  HDetr3DTransformer, feature_sampling, inverse_sigmoid)
 
-__all__ = ['Deform3DCrossAttn', 'Deform3DCrossAttnMP', 'DGCNNAttn', 'Detr3DCrossAtten', 'feature_sampling', 'Detr3DTransformer',
+__all__ = ['Deform3DCrossAttn', 'Deform3DCrossAttnMP', 'DGCNNAttn', 'Detr3DCrossAtten', 'Detr3DCrossAttenV2', 'feature_sampling', 'Detr3DTransformer',
            'Detr3DTransformerDecoder', 'HDetr3DTransformer', 'MultiheadAttention', 'FFN', 'BaseTransformerLayer',
            'DetrTransformerDecoderLayer', 'TransformerLayerSequence', 'inverse_sigmoid',
            'NMSFreeCoder', 'FeaturePositionEmbedding', 'BBOX_CODERS', 'ATTENTION', 'TRANSFORMER', 'TRANSFORMER_LAYER', 'TRANSFORMER_LAYER_SEQUENCE']

@@ -29,6 +29,7 @@ SIGNATURES = {
     'gd4d_cross_attn_bwd': (_i, [_vp] * 8 + [_f, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),
     'gd4d_detr3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                              _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_detr3d_v2_fwd': (_i, [_vp] * 7 + [_f, _f, _vp, _vp] + [_i] * 7 + [_vp]),
     'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_workspace_bytes': (_c.c_size_t, []),
     'gd4d_value_proj_set_cu_limit': (_i, [_i]),

@@ -106,6 +106,111 @@ __global__ __launch_bounds__(256) void detr3d_fwd_kernel(const Detr3dParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gd4d_detr3d_v2_fwd: Detr3DCrossAttenV2 (detr3d_transformer.py:441-710) - the 2-D-offset deformable variant.
+// Same work mapping as above (workgroup = query, thread = channel, NCHW maps untouched); head h = c / Dh reads its
+// own sampling locations: grid coordinate of the projected reference point + offset / (W_l, H_l) (:696-700), weights =
+// softmax over level x point per (camera, head) times the camera's visibility (:602-611, :617).
+// Quirk reproduced: the reference stacks samples as (..., point, level) and multiplies them with weights laid out
+// (..., level, point) (:611 against :705-707), so the sample at (point i, level j) meets weight (level i, point j) -
+// well-formed only for num_levels == num_points, which the host enforces.
+struct Detr3dV2Params {
+  const float* feats[GD4D_MAX_LEVELS];
+  const float* ref;
+  const float* attn_logits;   // (B, Q, N, Hh, L*P)
+  const float* offsets;       // (B, Q, N, Hh, L, P, 2) pixels of the level
+  const float* lidar2img;
+  float* out;                 // (B, Q, C)
+  uint8_t* mask_out;          // (B, N, Q) or null
+  int B, N, Q, C, L, Hh;
+  int lvl_h[GD4D_MAX_LEVELS];
+  int lvl_w[GD4D_MAX_LEVELS];
+  float rng_scale[3];
+  float rng_lo[3];
+  float img_h, img_w;
+};
+
+__global__ __launch_bounds__(256) void detr3d_v2_fwd_kernel(const Detr3dV2Params p) {
+  extern __shared__ float s_mem[];
+  const int LP = p.L * p.L;                                   // num_points == num_levels
+  float2* s_uv = reinterpret_cast<float2*>(s_mem);            // [N] grid coords in [-1,1]
+  float* s_w = s_mem + 2 * p.N;                               // [N][Hh][L*P] softmax * vis
+  int* s_vis = reinterpret_cast<int*>(s_w + p.N * p.Hh * LP); // [N]
+  const int bq = blockIdx.x;
+  const int b = bq / p.Q, q = bq - b * p.Q;
+  const int t = threadIdx.x;
+  if (t < p.N) {
+    const int n = t;
+    const float* rp = p.ref + (size_t)bq * 3;
+    const float X = rp[0] * p.rng_scale[0] + p.rng_lo[0];
+    const float Y = rp[1] * p.rng_scale[1] + p.rng_lo[1];
+    const float Z = rp[2] * p.rng_scale[2] + p.rng_lo[2];
+    const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
+    const float eps = 1e-5f;
+    const float cx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+    const float cy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+    const float cz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+    bool vis = cz > eps;
+    const float zc = fmaxf(cz, eps);
+    float u = (cx / zc) / p.img_w;
+    float v = (cy / zc) / p.img_h;
+    u = (u - 0.5f) * 2.f;                                     // :676
+    v = (v - 0.5f) * 2.f;
+    vis = vis && (u > -1.f) && (u < 1.f) && (v > -1.f) && (v < 1.f);
+    s_uv[n] = make_float2(u, v);
+    s_vis[n] = vis ? 1 : 0;
+    if (p.mask_out) p.mask_out[((size_t)b * p.N + n) * p.Q + q] = vis ? 1 : 0;
+  }
+  __syncthreads();
+  for (int e = t; e < p.N * p.Hh; e += blockDim.x) {          // one thread per (camera, head): softmax over L*P
+    const int n = e / p.Hh;
+    const float* lg = p.attn_logits + ((size_t)bq * p.N * p.Hh + e) * LP;
+    float* w = s_w + (size_t)e * LP;
+    if (!s_vis[n]) { for (int i = 0; i < LP; ++i) w[i] = 0.f; continue; }
+    float mx = lg[0];
+    for (int i = 1; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+    float sum = 0.f;
+    for (int i = 0; i < LP; ++i) { w[i] = expf(lg[i] - mx); sum += w[i]; }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < LP; ++i) w[i] *= inv;
+  }
+  __syncthreads();
+  const int Dh = p.C / p.Hh;
+  for (int c = t; c < p.C; c += blockDim.x) {
+    const int h = c / Dh;
+    float acc = 0.f;
+    for (int n = 0; n < p.N; ++n) {
+      if (!s_vis[n]) continue;                                // workgroup-uniform
+      const float2 g = s_uv[n];
+      const float* w = s_w + ((size_t)n * p.Hh + h) * LP;
+      const float* off = p.offsets + (((size_t)bq * p.N + n) * p.Hh + h) * LP * 2;
+      for (int l = 0; l < p.L; ++l) {
+        const int H = p.lvl_h[l], W = p.lvl_w[l];
+        const float* plane = p.feats[l] + ((size_t)(b * p.N + n) * p.C + c) * H * W;
+        for (int pt = 0; pt < p.L; ++pt) {
+          const float gx = g.x + off[(l * p.L + pt) * 2] / (float)W;          // :699-700
+          const float gy = g.y + off[(l * p.L + pt) * 2 + 1] / (float)H;
+          const float x = unnormalize(gx, W), y = unnormalize(gy, H);
+          const float xf = floorf(x), yf = floorf(y);
+          const float dx = x - xf, dy = y - yf;
+          const bool x0ok = xf >= 0.f && xf <= (float)(W - 1), x1ok = xf + 1.f >= 0.f && xf + 1.f <= (float)(W - 1);
+          const bool y0ok = yf >= 0.f && yf <= (float)(H - 1), y1ok = yf + 1.f >= 0.f && yf + 1.f <= (float)(H - 1);
+          float s = 0.f;
+          if ((x0ok || x1ok) && (y0ok || y1ok)) {
+            const int x0 = (int)xf, y0 = (int)yf;
+            if (x0ok && y0ok) s += (1.f - dx) * (1.f - dy) * plane[y0 * W + x0];
+            if (x1ok && y0ok) s += dx * (1.f - dy) * plane[y0 * W + x0 + 1];
+            if (x0ok && y1ok) s += (1.f - dx) * dy * plane[(y0 + 1) * W + x0];
+            if (x1ok && y1ok) s += dx * dy * plane[(y0 + 1) * W + x0 + 1];
+          }
+          acc = fmaf(w[pt * p.L + l], s, acc);                // weight of (level = pt, point = l): the reference's pairing
+        }
+      }
+    }
+    p.out[(size_t)bq * p.C + c] = acc;
+  }
+}
+
 }  // namespace gd4d
 
 extern "C" int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const float* ref,
@@ -135,5 +240,34 @@ extern "C" int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw
   p.img_h = img_h; p.img_w = img_w;
   const size_t lds = sizeof(float) * (size_t)(2 * N + N * L) + sizeof(int) * (size_t)N;
   hipLaunchKernelGGL(detr3d_fwd_kernel, dim3(B * Q), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+extern "C" int gd4d_detr3d_v2_fwd(const void* const* feats, const int32_t* level_hw, const float* ref,
+                                  const float* attn_logits, const float* offsets, const float* lidar2img,
+                                  const double* pc_range, float img_h, float img_w, float* out, uint8_t* mask_out,
+                                  int B, int N, int Q, int C, int Hh, int L, int P, void* stream) {
+  using namespace gd4d;
+  if (!feats || !level_hw || !ref || !attn_logits || !offsets || !lidar2img || !pc_range || !out) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || C <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
+  if (L > GD4D_MAX_LEVELS || P != L || N > 256 || C % Hh != 0) return GD4D_EUNSUPPORTED;
+  Detr3dV2Params p{};
+  for (int l = 0; l < L; ++l) {
+    if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
+    p.feats[l] = static_cast<const float*>(feats[l]);
+    p.lvl_h[l] = level_hw[2 * l];
+    p.lvl_w[l] = level_hw[2 * l + 1];
+  }
+  p.ref = ref; p.attn_logits = attn_logits; p.offsets = offsets; p.lidar2img = lidar2img;
+  p.out = out; p.mask_out = mask_out;
+  p.B = B; p.N = N; p.Q = Q; p.C = C; p.L = L; p.Hh = Hh;
+  for (int k = 0; k < 3; ++k) {
+    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
+    p.rng_lo[k] = static_cast<float>(pc_range[k]);
+  }
+  p.img_h = img_h; p.img_w = img_w;
+  const size_t lds = sizeof(float) * (size_t)(2 * N + N * Hh * L * L) + sizeof(int) * (size_t)N;
+  if (lds > 64 * 1024) return GD4D_EUNSUPPORTED;
+  hipLaunchKernelGGL(detr3d_v2_fwd_kernel, dim3(B * Q), dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }

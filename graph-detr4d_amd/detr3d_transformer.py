@@ -104,6 +104,81 @@ class Detr3DCrossAtten(nn.Module):
         return self.dropout(out) + inp_residual + pos_feat.permute(1, 0, 2)
 
 
+@ATTENTION.register_module()
+class Detr3DCrossAttenV2(nn.Module):
+    """2-D-offset deformable variant (reference :441-710; registered by the reference, used by no shipped config): per
+    (camera, head, level, point) pixel offsets around the projected reference point, softmax over level x point per
+    (camera, head), samples of the head's channel slice of the raw NCHW maps.  Same constructor keywords and
+    state-dict keys (`attention_weights`, `sampling_offsets`, `output_proj`, `position_encoder`).  The sampling core is
+    gd4d_detr3d_v2_fwd (incl. the reference's level/point weight transposition); batch 1, num_points == num_levels as
+    the reference's broadcasts require (:611, :698-700).  Inference only."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=5, num_cams=6, im2col_step=64,
+                 pc_range=None, dropout=0.1, norm_cfg=None, init_cfg=None, batch_first=False):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}')
+        self.norm_cfg, self.init_cfg, self.pc_range, self.im2col_step = norm_cfg, init_cfg, pc_range, im2col_step
+        self.embed_dims, self.num_levels, self.num_heads = embed_dims, num_levels, num_heads
+        self.num_points, self.num_cams, self.batch_first = num_points, num_cams, batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.attention_weights = nn.Linear(embed_dims, num_cams * num_heads * num_levels * num_points)
+        self.sampling_offsets = nn.Linear(embed_dims, num_cams * num_heads * num_levels * num_points * 2)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.position_encoder = nn.Sequential(
+            nn.Linear(3, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True),
+            nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True))
+        self.init_weight()
+
+    def init_weight(self):
+        """Reference :527-543: zero offset weights, per-head direction x (i+1) pixels as bias, zero logits."""
+        import math
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        theta = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([theta.cos(), theta.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(1, self.num_heads, 1, 1, 2) \
+            .repeat(self.num_cams, 1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.view(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if residual is not None:
+            raise NameError('Detr3DCrossAttenV2: residual must be None (as in the reference)')
+        img_metas = kwargs['img_metas']
+        Fn.require_gpu(query, 'query')
+        Fn.require_inference(query, query_pos, reference_points, *value)
+        q, b, c = query.shape
+        if b != 1:
+            raise RuntimeError('Detr3DCrossAttenV2: batch size must be 1 (the reference broadcasts (B*N, Q) against '
+                               '(B*heads, N, Q) coordinates)')
+        if self.num_points != self.num_levels:
+            raise RuntimeError('Detr3DCrossAttenV2: num_points must equal num_levels (the reference multiplies '
+                               '(..., point, level) samples with (..., level, point) weights)')
+        n, hh, nl, npt = self.num_cams, self.num_heads, self.num_levels, self.num_points
+        logits, offsets = ops.linear_group_fwd(
+            query.contiguous(), [self.attention_weights.weight.contiguous(), self.sampling_offsets.weight.contiguous()],
+            [self.attention_weights.bias, self.sampling_offsets.bias],
+            x2=None if query_pos is None else query_pos.contiguous())
+        lidar2img = Fn.lidar2img_device(img_metas, query)
+        img_h, img_w = Fn.img_hw(img_metas)
+        agg = ops.detr3d_v2_fwd([f.contiguous() for f in value], reference_points.contiguous(),
+                                logits.view(b, q, n, hh, nl * npt), offsets.view(b, q, n, hh, nl, npt, 2), lidar2img,
+                                self.pc_range, img_h, img_w, hh)
+        pos_feat = Fn.position_encoder(self.position_encoder, reference_points)
+        if not self.training:
+            return Fn.linear(agg, self.output_proj.weight, self.output_proj.bias,
+                             r1=query.view(1, q, c), r2=pos_feat).view(q, 1, c)
+        out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
+        return self.dropout(out) + query + pos_feat.permute(1, 0, 2)
+
+
 @TRANSFORMER_LAYER_SEQUENCE.register_module()
 class Detr3DTransformerDecoder(TransformerLayerSequence):
     """Reference :153-225: loop over layers, refine reference points with reg_branches."""

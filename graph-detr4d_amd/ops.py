@@ -121,6 +121,29 @@ def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_
     return dict(out=out, mask=mask, sampled=sampled)
 
 
+def detr3d_v2_fwd(feats, ref, attn_logits, offsets, lidar2img, pc_range, img_h, img_w, num_heads, want_mask=False):
+    """gd4d_detr3d_v2_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) fp32; attn_logits (B, Q, N, Hh, L*P);
+    offsets (B, Q, N, Hh, L, P, 2), P == L.  Returns out (B, Q, C) [, mask (B, N, Q) uint8]."""
+    lib = _lib.load()
+    b, n, c = feats[0].shape[:3]
+    q = ref.shape[1]
+    nl = len(feats)
+    if attn_logits.numel() != b * q * n * num_heads * nl * nl or offsets.numel() != 2 * attn_logits.numel():
+        raise ValueError('attn_logits / offsets must be (B, Q, N, heads, L*P) / (..., L, P, 2) with P == L')
+    f32 = torch.float32
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    out = torch.empty(b, q, c, device=ref.device, dtype=f32)
+    mask = torch.empty(b, n, q, device=ref.device, dtype=torch.uint8) if want_mask else None
+    code = lib.gd4d_detr3d_v2_fwd(ptrs, lv, _dev(ref, 'ref', f32), _dev(attn_logits, 'attn_logits', f32),
+                                  _dev(offsets, 'offsets', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h),
+                                  float(img_w), _dev(out, 'out'), _dev(mask, 'mask') if want_mask else None,
+                                  b, n, q, c, int(num_heads), nl, nl, _stream())
+    _lib.check(code, 'gd4d_detr3d_v2_fwd')
+    return (out, mask) if want_mask else out
+
+
 def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None, num_heads=8, head_major=False,
                    bf16_math=False):
     """gd4d_value_proj_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) or (R, C, H_l, W_l) fp32;

@@ -145,6 +145,20 @@ int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const flo
                     float img_h, float img_w, float* out, uint8_t* mask_out, float* sampled_out,
                     int B, int N, int Q, int C, int L, int P, void* stream);
 
+/* gd4d_detr3d_v2_fwd - sampling core of Detr3DCrossAttenV2 (detr3d_transformer.py:441-710, the 2-D-offset deformable
+ * variant; registered by the reference, used by no shipped config): projection + [-1,1] visibility test of the reference
+ * point (:662-682), per (camera, head) softmax over level x point (:602-611), bilinear samples (grid_sample,
+ * align_corners=False, zero padding) of each head's channel slice of the NCHW maps at ref + offset / (W_l, H_l)
+ * (:692-705), sum over cameras, levels, points (:617-620).  The reference pairs the sample at (point i, level j) with the
+ * weight of (level i, point j) (:611 against :705-707); reproduced, hence P == L is required.
+ *   feats / level_hw / ref / lidar2img / pc_range / img_h / img_w as gd4d_detr3d_fwd;
+ *   attn_logits (B, Q, N, Hh, L*P), offsets (B, Q, N, Hh, L, P, 2) in pixels of the level;
+ *   out (B, Q, C) (channel = head * C/Hh + d: input of output_proj), mask_out optional (B, N, Q) uint8. */
+int gd4d_detr3d_v2_fwd(const void* const* feats, const int32_t* level_hw, const float* ref,
+                       const float* attn_logits, const float* offsets, const float* lidar2img,
+                       const double* pc_range, float img_h, float img_w, float* out, uint8_t* mask_out, int B,
+                       int N, int Q, int C, int Hh, int L, int P, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * gd4d_value_proj_fwd - value_proj (Linear C -> C) over the flattened multi-camera pyramid.
  *

@@ -572,3 +572,60 @@ def dgcnn_attn(p, query, query_pos, k, return_parts=False):
     f2, _ = dgcnn_edge_stage(p, f1.permute(0, 2, 1), 16, 'conv2.')
     out = query + (f1 + f2).permute(2, 0, 1)
     return (out, dict(f1=f1, idx1=idx1)) if return_parts else out
+
+
+# ---------------------------------------------------------------------------------------------
+# Detr3DCrossAttenV2 (row a11; utils/detr3d_transformer.py:441-710), eval mode, batch 1
+# ---------------------------------------------------------------------------------------------
+def detr3d_cross_atten_v2(p, query, value, query_pos, reference_points, img_metas, pc_range, num_heads=8, num_points=4,
+                          return_parts=False):
+    """Per (camera, head, level, point) 2-D offsets (in pixels of the level) around the projected reference point,
+    softmax over level x point per (camera, head), bilinear samples of the head's channel slice of the raw NCHW maps
+    (grid_sample, align_corners=False, zero padding), sum over cameras / levels / points.
+
+    Quirk reproduced (:611-617 against :705-707): the samples are stacked as (..., point, level) but multiplied with
+    weights laid out (..., level, point); with num_levels == num_points the product pairs the sample at
+    (point i, level j) with the weight of (level i, point j)."""
+    x = query if query_pos is None else query + query_pos
+    x = x.permute(1, 0, 2)
+    b, q, c = x.shape
+    assert b == 1, 'the reference broadcasts (B*N, Q) against (B*heads, N, Q): batch 1 only (:698-700)'
+    n, nl = value[0].shape[1], len(value)
+    d = c // num_heads
+    logits = _linear(x, p, 'attention_weights').view(b, q, n, num_heads, nl * num_points)
+    w = logits.softmax(-1).view(b, q, n, num_heads, nl, num_points)
+    off = _linear(x, p, 'sampling_offsets').view(b, q, n, num_heads, nl, num_points, 2)
+    l2i = lidar2img_tensor(img_metas, reference_points)
+    img_h, img_w = img_metas[0]['img_shape'][0][0], img_metas[0]['img_shape'][0][1]
+    uv, _ = project(denormalise(reference_points, pc_range), l2i, img_h, img_w)      # (B, N, Q, 2) in [0, 1] units
+    z_ok = _z_positive(denormalise(reference_points, pc_range), l2i)
+    g = (uv - 0.5) * 2                                                               # :676
+    mask = z_ok & (g[..., 0] > -1.0) & (g[..., 0] < 1.0) & (g[..., 1] > -1.0) & (g[..., 1] < 1.0)   # (B, N, Q)
+    out = torch.zeros(q, num_heads, d)
+    for lvl, feat in enumerate(value):
+        h_l, w_l = feat.shape[-2:]
+        f = feat.view(b, n, num_heads, d, h_l, w_l).transpose(1, 2).flatten(0, 2)    # (heads*N, d, H, W)
+        o = off[:, :, :, :, lvl].permute(0, 3, 2, 1, 4, 5).flatten(0, 1)            # (heads, N, Q, P, 2)
+        loc = g.view(b * n, q, 1, 2)[None] + o / torch.tensor([w_l, h_l], dtype=torch.float32)
+        s = F.grid_sample(f, loc.flatten(0, 1), mode='bilinear', padding_mode='zeros', align_corners=False)
+        s = s.view(num_heads, n, d, q, num_points)                                   # (heads, N, d, Q, P)
+        # weight of the sample (point i, THIS level j = lvl): w[..., level i, point j]   (the transposition quirk)
+        wq = w[0, :, :, :, :, lvl].permute(2, 1, 0, 3)                               # (heads, N, Q, i) = w[q,n,h,i,lvl]
+        wq = wq * mask[0].view(1, n, q, 1)
+        out += torch.einsum('hndqp,hnqp->qhd', s, wq)
+    agg = out.reshape(q, 1, c)
+    res = _linear(agg, p, 'output_proj')
+    pos = position_encoder(p, inverse_sigmoid(reference_points)).permute(1, 0, 2)
+    res = res + query + pos
+    if return_parts:
+        return res, dict(agg=agg, mask=mask, logits=logits, offsets=off)
+    return res
+
+
+def _z_positive(points, lidar2img, eps=1e-5):
+    """Depth test of the projection block on its own (the [0,1] test of `project` does not apply to V2's [-1,1] one)."""
+    b, m, _ = points.shape
+    n = lidar2img.shape[1]
+    hom = torch.cat((points, torch.ones_like(points[..., :1])), -1).view(b, 1, m, 4).repeat(1, n, 1, 1).unsqueeze(-1)
+    cam = torch.matmul(lidar2img.view(b, n, 1, 4, 4).repeat(1, 1, m, 1, 1), hom).squeeze(-1)
+    return cam[..., 2] > eps

@@ -208,3 +208,31 @@ def test_dgcnn_attn_module(name):
     torch.testing.assert_close(out2.detach().cpu(), g.t('out'), **TOL)
     out2.sum().backward()
     assert q.grad is not None
+
+
+@pytest.mark.parametrize('name', ['detr3d_v2_n6', 'detr3d_v2_n12'])
+def test_detr3d_cross_atten_v2_module(name):
+    """Detr3DCrossAttenV2 (gd4d_detr3d_v2_fwd) against the reference module's forward, mask bit-exact."""
+    from graph_detr4d_amd import ops
+    g = Golden(name)
+    m = g.meta
+    n, q = m['num_cams'], m['num_query']
+    mod = G.build_attention(dict(type='Detr3DCrossAttenV2', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                 embed_dims=256))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    feats = [f.to(DEV) for f in g.feats()]
+    with torch.no_grad():
+        out = mod(g.t('query').to(DEV), None, feats, query_pos=g.t('query_pos').to(DEV),
+                  reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+    torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
+    l2i = torch.from_numpy(g.arrays['lidar2img']).unsqueeze(0).to(DEV)
+    agg, mask = ops.detr3d_v2_fwd(feats, g.t('reference_points').to(DEV), g.t('attn_logits').view(1, q, n, 8, 16).to(DEV),
+                                  g.t('offsets').view(1, q, n, 8, 4, 4, 2).to(DEV), l2i, m['pc_range'],
+                                  m['img_shape'][0], m['img_shape'][1], 8, want_mask=True)
+    assert torch.equal(mask.cpu().bool(), g.t('mask').view(1, q, n).permute(0, 2, 1).bool())
+    torch.testing.assert_close(agg.cpu(), g.t('agg').permute(1, 0, 2), rtol=1e-4, atol=1e-5)
+    mod5 = G.build_attention(dict(type='Detr3DCrossAttenV2', num_cams=n, pc_range=m['pc_range'], num_points=5,
+                                  embed_dims=256)).to(DEV).eval()
+    with pytest.raises(RuntimeError), torch.no_grad():
+        mod5(g.t('query').to(DEV), None, feats, reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))

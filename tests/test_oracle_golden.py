@@ -133,3 +133,16 @@ def test_dgcnn_attn_matches_reference(name):
     assert torch.equal(parts['idx1'], g.t('idx1'))
     torch.testing.assert_close(parts['f1'], g.t('f1'), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(out, g.t('out'), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['detr3d_v2_n6', 'detr3d_v2_n12'])
+def test_detr3d_cross_atten_v2_matches_reference(name):
+    g = Golden(name)
+    m = g.meta
+    out, parts = O.detr3d_cross_atten_v2(g.state(), g.t('query'), g.feats(), g.t('query_pos'), g.t('reference_points'),
+                                         g.img_metas(), m['pc_range'], return_parts=True)
+    gmask = g.t('mask').view(1, m['num_query'], m['num_cams']).permute(0, 2, 1).bool()     # (1,1,Q,N,1,1) -> (B,N,Q)
+    assert torch.equal(parts['mask'], gmask)
+    assert 0 < gmask.float().mean().item() < 1
+    torch.testing.assert_close(parts['agg'], g.t('agg'), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out, g.t('out'), rtol=1e-4, atol=1e-4)

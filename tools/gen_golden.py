@@ -293,6 +293,43 @@ def case_detr3d(name, *, num_query, frames, batch, img_hw, seed):
     save(name, meta, **arrays)
 
 
+def case_detr3d_v2(name, *, num_query, frames, img_hw, seed, strides=(8, 16, 32, 64)):
+    """Detr3DCrossAttenV2 (utils/detr3d_transformer.py:441-710): 2-D-offset deformable variant on head-split NCHW maps.
+    Batch 1 (its feature_sampling broadcasts (B*N, Q) coordinates against (B*heads, N, Q) offsets, :698-700)."""
+    m = refstub.load_reference()['detr3d_transformer']
+    n = 6 * frames
+    torch.manual_seed(seed)
+    mod = m.Detr3DCrossAttenV2(embed_dims=256, num_heads=8, num_levels=4, num_points=4, num_cams=n,
+                               pc_range=PC_RANGE).eval()
+    quantise_params_(mod, seed)
+    with torch.no_grad():                                    # offsets of a few pixels, logits with some spread
+        mod.sampling_offsets.bias.mul_(1.5)
+        mod.attention_weights.bias.copy_(torch.round(torch.randn(mod.attention_weights.bias.shape) * 512) / 1024)
+    levels = levels_for(img_hw, strides)
+    feats, packed = grid_features(n, levels, 1, seed + 1)
+    q, qp, ref = make_inputs(num_query, 1, seed + 2)
+    l2i = small_rig(frames, img_hw)
+    metas = synthetic.make_img_metas(l2i, img_shape=(img_hw[0], img_hw[1], 3), batch=1)
+    hooks = Hooks(mod, ['attention_weights', 'sampling_offsets', 'output_proj'])
+    with torch.no_grad():
+        out = mod(q, None, feats, None, query_pos=qp, reference_points=ref, img_metas=metas)
+        _, _, mask = mod.feature_sampling(feats, ref, hooks.rec['sampling_offsets.out'].view(1, num_query, n, 8, 4, 4, 2),
+                                          PC_RANGE, metas)
+    hooks.close()
+    meta = dict(kind='Detr3DCrossAttenV2', num_query=num_query, num_cams=n, batch=1, levels=levels,
+                img_shape=[img_hw[0], img_hw[1], 3], pc_range=list(PC_RANGE), num_heads=8, num_points=4, seed=seed,
+                feat_scale=FEAT_SCALE, w_scale=W_SCALE)
+    arrays = dict(query=q, query_pos=qp, reference_points=ref, lidar2img=l2i, out=out,
+                  mask=mask.to(torch.uint8),                                   # (1, 1, Q, N, 1, 1)
+                  attn_logits=hooks.rec['attention_weights.out'],              # (1, Q, N*8*16)
+                  offsets=hooks.rec['sampling_offsets.out'],                   # (1, Q, N*8*4*4*2)
+                  agg=hooks.rec['output_proj.in'])                             # (Q, 1, 256)
+    for i, pk in enumerate(packed):
+        arrays[f'feat{i}@q'] = pk
+    arrays.update(pack_state(mod))
+    save(name, meta, **arrays)
+
+
 def case_self_attn(name, *, num_query, batch, seed, with_mask):
     refstub.install_stubs()
     torch.manual_seed(seed)
@@ -492,6 +529,8 @@ def main():
     case_dgcnn('dgcnn_k8', num_query=40, batch=1, seed=162, k=8)
     case_detr3d('detr3d_n6', num_query=24, frames=1, batch=1, img_hw=(128, 224), seed=201)
     case_detr3d('detr3d_n12_b2', num_query=16, frames=2, batch=2, img_hw=(64, 112), seed=202)
+    case_detr3d_v2('detr3d_v2_n6', num_query=24, frames=1, img_hw=(128, 224), seed=211)
+    case_detr3d_v2('detr3d_v2_n12', num_query=16, frames=2, img_hw=(64, 112), seed=212)
     case_self_attn('self_attn', num_query=50, batch=2, seed=301, with_mask=False)
     case_self_attn('self_attn_mask', num_query=48, batch=1, seed=302, with_mask=True)
     case_decoder('decoder_deform', cross='Deform3DCrossAttn', num_query=32, frames=1, batch=1,
