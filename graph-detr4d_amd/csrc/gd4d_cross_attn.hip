@@ -33,7 +33,7 @@ struct CrossAttnParams {
   uint8_t* mask_out;
   float* uv_out;
   const int32_t* order;   // optional permutation of [0, B*Q): locality order of the queries (gd4d_query_order_fwd)
-  int B, N, Q, L, S;
+  int B, N, Q, L, S, P;
   int raw_cam;         // 1: camera weights are the raw logits (Deform3DCrossAttnMP's neighbour pass), 0: sigmoid
   int head_major;      // value layout: 0 = (B*N, S, Hh, Dh) pixel-major, 1 = (B*N, Hh, S, Dh) head-major planes
   int lvl_h[GD4D_MAX_LEVELS];
@@ -219,12 +219,12 @@ __global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttn
 #ifndef GD4D_GATHER_WAVES
 #define GD4D_GATHER_WAVES 4
 #endif
-template <typename VT, int HH, int LT, int WAVES, bool BMULTI>
+template <typename VT, int HH, int LT, int WAVES, bool BMULTI, int PT>
 __global__ __launch_bounds__(GD4D_WAVE * WAVES, (BMULTI || sizeof(VT) == 2) ? GD4D_GATHER_OCC : 4)
 void cross_attn_fwd_block(const CrossAttnParams p) {
   constexpr int DH = kChannels / HH;
   constexpr int LANES_PER_HEAD = DH / 4;
-  constexpr int E = HH * kPoints;
+  constexpr int E = HH * PT;
   constexpr int LMAX = LT > 0 ? LT : GD4D_MAX_LEVELS;
   constexpr int THREADS = GD4D_WAVE * WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -288,16 +288,16 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
     }
   }
   if (!BMULTI && tid < HH) {                       // one thread per head: softmax over L*P, parked in LDS
-    float w[LMAX * kPoints];
-    softmax_lp(p.attn_logits + ((size_t)bq * HH + tid) * L * kPoints, L * kPoints, w);
-    for (int i = 0; i < L * kPoints; ++i) s_aw[tid * (LMAX * kPoints) + i] = w[i];
+    float w[LMAX * PT];
+    softmax_lp(p.attn_logits + ((size_t)bq * HH + tid) * L * PT, L * PT, w);
+    for (int i = 0; i < L * PT; ++i) s_aw[tid * (LMAX * PT) + i] = w[i];
   }
   __syncthreads();
 
   // ---------------- phase B ----------------
   const int h = lane / LANES_PER_HEAD;
-  float aw_reg[BMULTI ? LMAX * kPoints : 1];
-  const float* aw_lds = s_aw + h * (LMAX * kPoints);
+  float aw_reg[BMULTI ? LMAX * PT : 1];
+  const float* aw_lds = s_aw + h * (LMAX * PT);
 
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned long long cams = __ballot(lane < p.N && s_camvis[lane < p.N ? lane : 0] != 0);
@@ -307,16 +307,16 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
     cams &= cams - 1;
     if ((idx++ % WAVES) != wave) continue;                   // round-robin deal of visible cameras
 
-    const float2* su = s_uv + n * E + h * kPoints;
-    float2 pu[BMULTI ? kPoints : 1];
+    const float2* su = s_uv + n * E + h * PT;
+    float2 pu[BMULTI ? PT : 1];
     if (BMULTI) {
 #pragma unroll
-      for (int k = 0; k < kPoints; ++k) pu[BMULTI ? k : 0] = su[k];
+      for (int k = 0; k < PT; ++k) pu[BMULTI ? k : 0] = su[k];
     }
     const int row = b * p.N + n;
     if (BMULTI) {
       const int bb = row % p.B;
-      softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * kPoints, L * kPoints, aw_reg);
+      softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * PT, L * PT, aw_reg);
     }
     const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];
     const float cw = p.raw_cam ? cl : 1.0f / (1.0f + expf(-cl));
@@ -326,7 +326,7 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
     const unsigned lane_off = p.head_major ? (unsigned)(h * p.S * DH + (lane % LANES_PER_HEAD) * 4) : (unsigned)(lane * 4);
 
 #pragma unroll
-    for (int k = 0; k < kPoints; ++k) {
+    for (int k = 0; k < PT; ++k) {
       const float2 puk = BMULTI ? pu[BMULTI ? k : 0] : su[k];
       const bool pv = puk.x >= 0.f;
       const float u = pv ? puk.x : 0.5f, v = pv ? puk.y : 0.5f;
@@ -379,7 +379,7 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
         for (int li = 0; li < LB; ++li) {
           const int l = hb * LB + li;
           if (l >= LMAX || (LT == 0 && l >= L)) break;
-          const float wl = (BMULTI ? aw_reg[BMULTI ? l * kPoints + k : 0] : aw_lds[l * kPoints + k]) * cwk;
+          const float wl = (BMULTI ? aw_reg[BMULTI ? l * PT + k : 0] : aw_lds[l * PT + k]) * cwk;
           const float dx = fx[l], dy = fy[l];
           const unsigned ok = okm >> (4 * l);
           const float w00 = ((ok & 5u) == 5u) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
@@ -422,21 +422,28 @@ static int cross_attn_variant() {
   return v;
 }
 
+template <typename VT, int HH, int LT, int PT>
+static void launch_block(const CrossAttnParams& p, hipStream_t s) {
+  constexpr int WAVES = GD4D_GATHER_WAVES;
+  const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
+  const size_t lds = (WAVES - 1) * GD4D_WAVE * sizeof(float4) + (size_t)p.N * HH * PT * sizeof(float2) +
+                     (size_t)((p.N + 3) & ~3) * sizeof(int) +
+                     (size_t)HH * (LT > 0 ? LT : GD4D_MAX_LEVELS) * PT * sizeof(float);
+  if (p.B > 1)
+    hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES, true, PT>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
+  else
+    hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES, false, PT>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
+}
+
 template <typename VT, int HH, int LT>
 static void launch_one(const CrossAttnParams& p, hipStream_t s) {
-  const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
-  if (cross_attn_variant() == 1 && !p.head_major) {
+  if (p.P == 1) {                                      // one point per level (Deform3DCrossAttnMP's neighbour pass)
+    launch_block<VT, HH, LT, 1>(p, s);
+  } else if (cross_attn_variant() == 1 && !p.head_major) {
     const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
     hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, LT>), dim3(p.B * p.Q), dim3(GD4D_WAVE), lds, s, p);   // ignores p.order
   } else {
-    constexpr int WAVES = GD4D_GATHER_WAVES;
-    const size_t lds = (WAVES - 1) * GD4D_WAVE * sizeof(float4) + (size_t)p.N * HH * kPoints * sizeof(float2) +
-                       (size_t)((p.N + 3) & ~3) * sizeof(int) +
-                       (size_t)HH * (LT > 0 ? LT : GD4D_MAX_LEVELS) * kPoints * sizeof(float);
-    if (p.B > 1)
-      hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES, true>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
-    else
-      hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES, false>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
+    launch_block<VT, HH, LT, kPoints>(p, s);
   }
 }
 
@@ -477,7 +484,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
     return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || Dh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f))
     return GD4D_EINVAL;
-  if (Hh * Dh != kChannels || P != kPoints || L > GD4D_MAX_LEVELS || N > 64) return GD4D_EUNSUPPORTED;
+  if (Hh * Dh != kChannels || (P != kPoints && P != 1) || L > GD4D_MAX_LEVELS || N > 64) return GD4D_EUNSUPPORTED;
   if (value_dtype != GD4D_F32 && value_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (value_layout != GD4D_LAYOUT_PIXEL_MAJOR && value_layout != GD4D_LAYOUT_HEAD_MAJOR) return GD4D_EUNSUPPORTED;
   if (!aligned16(value) || !aligned16(out)) return GD4D_EALIGN;
@@ -486,7 +493,7 @@ extern "C" int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, c
   p.value = value; p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits;
   p.cam_logits = cam_logits; p.lidar2img = lidar2img; p.out = out; p.mask_out = mask_out;
   p.uv_out = uv_out; p.order = query_order;
-  p.B = B; p.N = N; p.Q = Q; p.L = L;
+  p.B = B; p.N = N; p.Q = Q; p.L = L; p.P = P;
   p.head_major = value_layout == GD4D_LAYOUT_HEAD_MAJOR;
   p.raw_cam = (flags & GD4D_CA_RAW_CAM_WEIGHTS) ? 1 : 0;
   int start = 0;

@@ -12,9 +12,8 @@ of Deform3DCrossAttn's).  Differences of the reference that are reproduced:
   * centre and neighbour results are blended with a 2-way softmax whose logits are summed over the queries, and the
     weights of sample 0 are used for the whole batch (:435-438).
 
-Both passes run on the fused HIP kernel: the neighbour pass as 8Q pseudo-queries with zero offsets whose level logits
-are replicated over the kernel's four sampling points (softmax over 16 equal-per-level logits x four identical samples
-= softmax over the 4 levels) and GD4D_CA_RAW_CAM_WEIGHTS.  Inference only.
+Both passes run on the fused HIP kernel: the neighbour pass as 8Q pseudo-queries with zero offsets in the kernel's
+one-point-per-level form (P = 1) and GD4D_CA_RAW_CAM_WEIGHTS.  Inference only.
 """
 import torch
 import torch.nn as nn
@@ -73,9 +72,9 @@ class Deform3DCrossAttnMP(Deform3DCrossAttn):
                                   img_h, img_w, order=Fn.query_order(centre, self.pc_range))
         if self.multi_points:
             nbr = reference_points[:, q:].contiguous()                          # (B, 8Q, 3), block j = neighbour j
-            # raw view of the (B, Q, 256) logits as (B, 8Q, heads, levels), replicated over the 4 kernel points
-            logits_n = outs[3].view(b, 8 * q, hh, nl, 1).expand(-1, -1, -1, -1, npt).contiguous()
-            zero_off = torch.zeros(b, 8 * q, hh, npt, 3, device=query.device)
+            # raw view of the (B, Q, 256) logits as (B, 8Q, heads, levels): one point per level (the kernel's P = 1 form)
+            logits_n = outs[3].view(b, 8 * q, hh, nl, 1)
+            zero_off = torch.zeros(b, 8 * q, hh, 1, 3, device=query.device)
             cam_n = cam_logits.repeat(1, 8, 1)                                  # cam_attention_weights(query.repeat(1,8,1))
             head_major = val.shape[2] == sum(h * w for h, w in shapes) and val.shape[1] != val.shape[2]
             agg_n = ops.cross_attn_fwd(val, shapes, nbr, zero_off, logits_n, cam_n.contiguous(), lidar2img,

@@ -95,7 +95,8 @@ const char* gd4d_last_hip_error(void);
  * Attention logits for value row i = b*N+n are taken from batch (i % B): this is what the
  * reference's `query.repeat(num_cams,1,1)` (:277) pairs them with; identity for B = 1.
  *
- * Supported: Hh*Dh == 256 and Dh % 4 == 0 (fp32) / Dh % 8 == 0 (bf16), P == 4, 1 <= L <= 8,
+ * Supported: Hh*Dh == 256 and Dh % 4 == 0 (fp32) / Dh % 8 == 0 (bf16), P == 4 (or P == 1: one point per level, the
+ * neighbour pass of Deform3DCrossAttnMP), 1 <= L <= 8,
  * N <= 64.  `value` 16-byte aligned.
  */
 int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float* ref,

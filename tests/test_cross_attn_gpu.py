@@ -222,3 +222,27 @@ def test_query_order_sorts_by_sample_then_azimuth():
         a = az[sample == s_]
         # non-decreasing up to the width of one bin (2 pi / 2048) and fp32 rounding
         assert bool((a[1:] - a[:-1] > -(2 * math.pi / 2048) - 1e-5).all())
+
+
+@pytest.mark.parametrize('b,n,q,raw', [(1, 6, 37, False), (2, 12, 20, True), (1, 24, 64, True)])
+def test_one_point_per_level_and_raw_camera_weights(b, n, q, raw):
+    """P = 1 form of the fused kernel (no offsets needed, one sample per level) and GD4D_CA_RAW_CAM_WEIGHTS - the
+    neighbour pass of Deform3DCrossAttnMP - against the oracle."""
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import torch_oracle as O
+    g = torch.Generator().manual_seed(100 * b + n + q)
+    levels = [(16, 28), (8, 14), (4, 7), (2, 4)]
+    s = sum(h * w for h, w in levels)
+    val = torch.randn(b * n, s, 8, 32, generator=g)
+    rig = torch.from_numpy(synthetic.camera_rig(n // 6, (128, 224))).unsqueeze(0).expand(b, -1, -1, -1).contiguous()
+    ref = torch.rand(b, q, 3, generator=g)
+    off = torch.randn(b, q, 8, 1, 3, generator=g)
+    attn = torch.randn(b, q, 8, 4, 1, generator=g)
+    cam = torch.randn(b, q, n, generator=g)
+    c = lambda t: t.cuda()
+    out, mask = ops.cross_attn_fwd(c(val), levels, c(ref), c(off), c(attn), c(cam), c(rig), synthetic.PC_RANGE, 128, 224,
+                                   want_mask=True, raw_cam_weights=raw)
+    exp, _, emask = O.sample_aggregate(val, levels, ref, off, attn.view(b, q, 8, 4), cam, rig, synthetic.PC_RANGE,
+                                       128, 224, raw_cam=raw)
+    assert torch.equal(mask.cpu().bool(), emask)
+    torch.testing.assert_close(out.cpu(), exp, rtol=RTOL, atol=ATOL)
