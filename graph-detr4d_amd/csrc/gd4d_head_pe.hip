@@ -19,6 +19,7 @@ struct FrustumParams {
   float* out;               // (R, 3*D, H, W)
   uint8_t* outside;         // (R, H, W)
   int R, H, W, D;
+  int chlast, S, start;     // chlast: out is (R, S, 3*D) rows, this level occupying pixels [start, start + H*W) of each row
   float pad_h, pad_w, depth_start, bin_size;
   float lo[3], span[3];
 };
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void frustum_pe_input_kernel(const FrustumPara
   const float ch = ((float)y * p.pad_h) / (float)p.H;
   const float cw = ((float)x * p.pad_w) / (float)p.W;
   float* o = p.out + (size_t)r * 3 * p.D * hw + pix;
+  const size_t cstride = (size_t)hw;
   const float eps = 1e-5f;
   int n_out = 0;
   for (int d = 0; d < p.D; ++d) {
@@ -48,10 +50,44 @@ __global__ __launch_bounds__(256) void frustum_pe_input_kernel(const FrustumPara
       const float v = ((m[4 * k] * px + m[4 * k + 1] * py) + m[4 * k + 2] * depth) + m[4 * k + 3];   // :469
       c[k] = (v - p.lo[k]) / p.span[k];                                       // :470-475
       n_out += (c[k] > 1.0f || c[k] < 0.0f) ? 1 : 0;                          // :477
-      o[(size_t)(3 * d + k) * hw] = inv_sigmoid(c[k]);                        // :480-481 layout, channel = 3 d + axis
+      o[(size_t)(3 * d + k) * cstride] = inv_sigmoid(c[k]);                   // :480-481 layout, channel = 3 d + axis
     }
   }
   p.outside[idx] = (float)n_out > (float)p.D * 0.5f ? 1 : 0;                  // :478
+}
+
+// Channels-last form: one wave per pixel, lane = depth bin, so a wave writes its pixel's 3*D consecutive floats as one
+// contiguous run (the per-pixel form above would scatter 4-byte stores 3*D floats apart).
+__global__ __launch_bounds__(256) void frustum_pe_chlast_kernel(const FrustumParams p) {
+  const int hw = p.H * p.W;
+  const int lane = threadIdx.x & 63;
+  const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (long long)p.R * hw) return;
+  const int r = (int)(idx / hw);
+  const int pix = (int)(idx - (long long)r * hw);
+  const int y = pix / p.W, x = pix - y * p.W;
+  const float* m = p.img2lidar + (size_t)r * 16;
+  const float ch = ((float)y * p.pad_h) / (float)p.H;
+  const float cw = ((float)x * p.pad_w) / (float)p.W;
+  float* o = p.out + ((size_t)r * p.S + p.start + pix) * 3 * p.D;
+  const float eps = 1e-5f;
+  int n_out = 0;
+  for (int d = lane; d < p.D; d += 64) {
+    const float fi = (float)d;
+    const float depth = p.depth_start + (p.bin_size * fi) * (fi + 1.0f);
+    const float s = fmaxf(depth, eps);
+    const float px = cw * s, py = ch * s;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = ((m[4 * k] * px + m[4 * k + 1] * py) + m[4 * k + 2] * depth) + m[4 * k + 3];
+      const float c = (v - p.lo[k]) / p.span[k];
+      n_out += (c > 1.0f || c < 0.0f) ? 1 : 0;
+      o[3 * d + k] = inv_sigmoid(c);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off);
+  if (lane == 0) p.outside[idx] = (float)n_out > (float)p.D * 0.5f ? 1 : 0;
 }
 
 struct SineParams {
@@ -96,22 +132,59 @@ __global__ __launch_bounds__(256) void se_fuse_kernel(const float4* __restrict__
   out[i] = o;
 }
 
+// out[r, c, pix] = feat[r, c, pix] + (pe[r, start + pix, c] * sigmoid(gate[r, start + pix, c]) + sine[r, c, pix]):
+// the channels-last products of the GEMM path meet the NCHW maps; 32 x 32 (channel, pixel) tiles through LDS so that
+// both sides are read and written coalesced.
+__global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __restrict__ feat, const float* __restrict__ gate,
+                                                             const float* __restrict__ pe, const float* __restrict__ sine,
+                                                             float* __restrict__ out, int C, int HW, int S, int start) {
+  __shared__ float tile[32][33];
+  const int r = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                       // read channels-last: tx = channel, rows = pixels
+    const int pix = p0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (pix < HW) {
+      const size_t o = ((size_t)r * S + start + pix) * C + c;
+      v = pe[o] * (1.0f / (1.0f + expf(-gate[o])));
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                       // write NCHW: tx = pixel, rows = channels
+    const int c = c0 + ty + 8 * i, pix = p0 + tx;
+    if (pix < HW) {
+      const size_t o = ((size_t)r * C + c) * HW + pix;
+      out[o] = feat[o] + (tile[tx][ty + 8 * i] + sine[o]);
+    }
+  }
+}
+
 }  // namespace gd4d
 
 extern "C" int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uint8_t* outside, int R, int H, int W, int D,
                                          float pad_h, float pad_w, float depth_start, const double* pc_range,
-                                         void* stream) {
+                                         int row_pixels, int row_start, void* stream) {
   using namespace gd4d;
   if (!img2lidar || !out || !outside || !pc_range || R <= 0 || H <= 0 || W <= 0 || D <= 0) return GD4D_EINVAL;
+  if (row_pixels < 0 || (row_pixels > 0 && (row_start < 0 || row_start + H * W > row_pixels))) return GD4D_EINVAL;
   FrustumParams p{};
   p.img2lidar = img2lidar; p.out = out; p.outside = outside; p.R = R; p.H = H; p.W = W; p.D = D;
+  p.chlast = row_pixels > 0 ? 1 : 0; p.S = row_pixels; p.start = row_start;
   p.pad_h = pad_h; p.pad_w = pad_w; p.depth_start = depth_start;
   // Python-float arithmetic of the reference (:452), rounded to fp32 when it meets the tensor
   p.bin_size = (float)((pc_range[3] - (double)depth_start) / ((double)D * (1.0 + (double)D)));
   for (int k = 0; k < 3; ++k) { p.lo[k] = (float)pc_range[k]; p.span[k] = (float)(pc_range[k + 3] - pc_range[k]); }
   const long long total = (long long)R * H * W;
-  hipLaunchKernelGGL(frustum_pe_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p);
+  if (p.chlast)
+    hipLaunchKernelGGL(frustum_pe_chlast_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(frustum_pe_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
   return check_launch();
 }
 
@@ -139,5 +212,16 @@ extern "C" int gd4d_se_fuse_fwd(const float* feat, const float* gate, const floa
                      reinterpret_cast<const float4*>(feat), reinterpret_cast<const float4*>(gate),
                      reinterpret_cast<const float4*>(pe), reinterpret_cast<const float4*>(sine),
                      reinterpret_cast<float4*>(out), n4);
+  return check_launch();
+}
+
+extern "C" int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out,
+                                       int R, int C, int HW, int row_pixels, int row_start, void* stream) {
+  using namespace gd4d;
+  if (!feat || !gate || !pe || !sine || !out || R <= 0 || C <= 0 || HW <= 0) return GD4D_EINVAL;
+  if (row_start < 0 || row_start + HW > row_pixels) return GD4D_EINVAL;
+  if (C % 32 != 0 || R > 65535) return GD4D_EUNSUPPORTED;
+  hipLaunchKernelGGL(se_fuse_chlast_kernel, dim3((HW + 31) / 32, C / 32, R), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), feat, gate, pe, sine, out, C, HW, row_pixels, row_start);
   return check_launch();
 }

@@ -11,6 +11,7 @@ ops.sine_pe3d_fwd, ops.se_fuse_fwd); the 1x1 convolutions are plain library GEMM
 padding masks only, so its result is cached while the masks do not change (every sample of a dataset shares them).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -52,6 +53,7 @@ class FeaturePositionEmbedding(nn.Module):
         self.scale, self.eps, self.offset = scale, eps, offset
         self._sine_cache = None
         self._mask_cache = None
+        self._split_cache = None
 
     # ---- pieces -------------------------------------------------------------------------------------------------
     def padding_masks(self, img_metas, feats):
@@ -114,17 +116,66 @@ class FeaturePositionEmbedding(nn.Module):
             self._sine_cache = (key, list(masks), res)
         return res
 
+    # ---- split-bf16 GEMM path ----------------------------------------------------------------------------------------
+    def _split_weights(self):
+        """bf16 (hi, lo) splits of the five 1x1-conv weights for gd4d_gemm_bf16x3_fwd, remade when a weight changes."""
+        convs = dict(pe0=self.position_encoder[0], pe2=self.position_encoder[2], se1=self.fpe.conv_expand)
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs.values())
+        if self._split_cache is None or self._split_cache[0] != key:
+            self._split_cache = (key, {k: ops.split_bf16_fwd(c.weight.detach().view(c.out_channels, c.in_channels)
+                                                             .contiguous()) for k, c in convs.items()})
+        return self._split_cache[1]
+
+    def _forward_gemm(self, feats, img_metas, masks, pad_hw, sine):
+        """The dense part on the bf16 matrix cores (three split products per output, fp32-class):
+        frustum kernel (channels-last, all levels side by side) -> GEMM 192 -> 1024 (+ReLU) -> GEMM 1024 -> 256;
+        SE gate: conv_reduce over the NCHW maps with the value_proj kernel (NCHW in, channels-last out), conv_expand
+        as a GEMM with the ReLU applied on its input; one transposing pass fuses gate, embedding, sine branch, feats."""
+        b, n = feats[0].shape[:2]
+        r = b * n
+        dev = feats[0].device
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        s_tot = sum(h * w for h, w in shapes)
+        starts = [sum(h * w for h, w in shapes[:i]) for i in range(len(shapes))]
+        l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
+        img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(r, 4, 4).to(dev)          # :459-465
+        x = torch.empty(r, s_tot, self.position_dim, device=dev, dtype=torch.float32)
+        for (h, w), st in zip(shapes, starts):
+            ops.frustum_pe_input_fwd(img2lidar, (h, w), pad_hw, self.depth_num, self.depth_start, self.pc_range,
+                                     out=x, row_start=st)
+        sw = self._split_weights()
+        pe0, pe2 = self.position_encoder[0], self.position_encoder[2]
+        hid = ops.gemm_bf16x3_fwd(x.view(r * s_tot, -1), *sw['pe0'], pe0.bias, relu=True)
+        del x
+        pe = ops.gemm_bf16x3_fwd(hid, *sw['pe2'], pe2.bias)                                      # (R*S, C)
+        del hid
+        cr, ce = self.fpe.conv_reduce, self.fpe.conv_expand
+        g1 = ops.value_proj_fwd([f.contiguous() for f in feats], cr.weight.view(self.embed_dims, -1).contiguous(),
+                                cr.bias.contiguous())                                             # (R, S, C) channels-last
+        gate = ops.gemm_bf16x3_fwd(g1.view(r * s_tot, -1), *sw['se1'], ce.bias, relu_in=True)
+        del g1
+        pe, gate = pe.view(r, s_tot, -1), gate.view(r, s_tot, -1)
+        out = []
+        for lvl, (f, st) in enumerate(zip(feats, starts)):
+            o = ops.se_fuse_chlast_fwd(f.flatten(0, 1).contiguous(), gate, pe, sine[lvl].flatten(0, 1).contiguous(), st)
+            out.append(o.view(f.shape))
+        return out
+
     # ---- the stage ------------------------------------------------------------------------------------------------
     def forward(self, mlvl_feats, img_metas):
         """mlvl_feats: list of (B, N, C, H_l, W_l) fp32 GPU tensors; returns the list with the position embedding
-        added (:546-557).  Inference only (the reference trains through these ops with autograd)."""
+        added (:546-557).  Inference only (the reference trains through these ops with autograd).
+        GD4D_HEAD_PE=conv keeps the 1x1 convolutions on the library instead of gd4d_gemm_bf16x3_fwd."""
         feats = list(mlvl_feats)
         Fn.require_gpu(feats[0], 'mlvl_feats')
         Fn.require_inference(*feats)
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
-            coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)
             sine = self._sine_branch(masks)
+            gemm_ok = self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256
+            if gemm_ok and os.environ.get('GD4D_HEAD_PE', 'gemm') != 'conv':
+                return self._forward_gemm(feats, img_metas, masks, pad_hw, sine)
+            coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)
             out = []
             for lvl, f in enumerate(feats):
                 gate = self.fpe.gate_logits(f.flatten(0, 1)).view(f.shape)

@@ -334,19 +334,40 @@ def value_proj_set_cu_limit(cus):
     return _lib.load().gd4d_value_proj_set_cu_limit(int(cus))
 
 
-def frustum_pe_input_fwd(img2lidar, feat_hw, pad_hw, depth_num, depth_start, pc_range):
-    """gd4d_frustum_pe_input_fwd.  img2lidar (R, 4, 4) fp32 -> (x (R, 3*D, H, W) fp32, outside (R, H, W) bool)."""
+def frustum_pe_input_fwd(img2lidar, feat_hw, pad_hw, depth_num, depth_start, pc_range, out=None, row_start=0):
+    """gd4d_frustum_pe_input_fwd.  img2lidar (R, 4, 4) fp32 -> (x, outside (R, H, W) bool).  Without `out`: x is a new
+    NCHW (R, 3*D, H, W) tensor; with `out` (R, S, 3*D) the level is written channels-last at pixels
+    [row_start, row_start + H*W) of every row."""
     lib = _lib.load()
     r = img2lidar.shape[0]
     h, w = feat_hw
-    out = torch.empty(r, 3 * depth_num, h, w, device=img2lidar.device, dtype=torch.float32)
+    row_pixels = 0
+    if out is None:
+        out = torch.empty(r, 3 * depth_num, h, w, device=img2lidar.device, dtype=torch.float32)
+    else:
+        row_pixels = out.shape[1]
+        if out.shape != (r, row_pixels, 3 * depth_num):
+            raise ValueError('out must be (R, S, 3*D)')
     outside = torch.empty(r, h, w, device=img2lidar.device, dtype=torch.uint8)
     rng = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
-    code = lib.gd4d_frustum_pe_input_fwd(_dev(img2lidar, 'img2lidar', torch.float32), _dev(out, 'out'),
+    code = lib.gd4d_frustum_pe_input_fwd(_dev(img2lidar, 'img2lidar', torch.float32), _dev(out, 'out', torch.float32),
                                          _dev(outside, 'outside'), r, h, w, int(depth_num), float(pad_hw[0]),
-                                         float(pad_hw[1]), float(depth_start), rng, _stream())
+                                         float(pad_hw[1]), float(depth_start), rng, int(row_pixels), int(row_start),
+                                         _stream())
     _lib.check(code, 'gd4d_frustum_pe_input_fwd')
     return out, outside.bool()
+
+
+def se_fuse_chlast_fwd(feat, gate, pe, sine, row_start, out=None):
+    """gd4d_se_fuse_chlast_fwd: feat / sine (R, C, H, W) NCHW, gate / pe (R, S, C) channels-last -> (R, C, H, W)."""
+    lib = _lib.load()
+    r, c, h, w = feat.shape
+    out = torch.empty_like(feat) if out is None else out
+    code = lib.gd4d_se_fuse_chlast_fwd(_dev(feat, 'feat', torch.float32), _dev(gate, 'gate', torch.float32),
+                                       _dev(pe, 'pe', torch.float32), _dev(sine, 'sine', torch.float32), _dev(out, 'out'),
+                                       r, c, h * w, gate.shape[1], int(row_start), _stream())
+    _lib.check(code, 'gd4d_se_fuse_chlast_fwd')
+    return out
 
 
 def sine_pe3d_fwd(n_embed, y_embed, x_embed, dim_t):
@@ -370,6 +391,31 @@ def se_fuse_fwd(feat, gate, pe, sine, out=None):
                                 _dev(pe, 'pe', torch.float32), _dev(sine, 'sine', torch.float32), _dev(out, 'out'),
                                 ctypes.c_size_t(feat.numel()), _stream())
     _lib.check(code, 'gd4d_se_fuse_fwd')
+    return out
+
+
+def split_bf16_fwd(w):
+    """gd4d_split_bf16_fwd: fp32 tensor -> (hi, lo) bf16 tensors of the same shape with w ~= hi + lo."""
+    lib = _lib.load()
+    hi = torch.empty(w.shape, device=w.device, dtype=torch.bfloat16)
+    lo = torch.empty(w.shape, device=w.device, dtype=torch.bfloat16)
+    code = lib.gd4d_split_bf16_fwd(_dev(w, 'w', torch.float32), _dev(hi, 'hi'), _dev(lo, 'lo'),
+                                   ctypes.c_size_t(w.numel()), _stream())
+    _lib.check(code, 'gd4d_split_bf16_fwd')
+    return hi, lo
+
+
+def gemm_bf16x3_fwd(a, w_hi, w_lo, bias=None, relu=False, out=None, relu_in=False):
+    """gd4d_gemm_bf16x3_fwd: a (M, K) fp32 row-major, w_hi / w_lo (N, K) bf16 -> act(a W^T + b) (M, N) fp32."""
+    lib = _lib.load()
+    m, k = a.shape
+    n = w_hi.shape[0]
+    if out is None:
+        out = torch.empty(m, n, device=a.device, dtype=torch.float32)
+    code = lib.gd4d_gemm_bf16x3_fwd(_dev(a, 'a', torch.float32), _dev(w_hi, 'w_hi', torch.bfloat16),
+                                    _dev(w_lo, 'w_lo', torch.bfloat16), _opt(bias, 'bias'), _dev(out, 'out'), m, n, k, k, n,
+                                    int(bool(relu)) | (16 if relu_in else 0), _stream())
+    _lib.check(code, 'gd4d_gemm_bf16x3_fwd')
     return out
 
 

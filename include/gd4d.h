@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 7
+#define GD4D_ABI_VERSION 8
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -217,6 +217,7 @@ int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
 #define GD4D_LIN_RELU 1
 #define GD4D_LIN_INV_SIGMOID_IN 2
 #define GD4D_LIN_RELU_AFTER_LN 4
+#define GD4D_GEMM_RELU_IN 16       /* gd4d_gemm_bf16x3_fwd: ReLU on the elements of A as they are read */
 int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
                     const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
                     int flags, int ldx, int ldy, int ldr1, int ldr2, void* stream);
@@ -321,7 +322,11 @@ int gd4d_nms_free_decode_fwd(const float* cls_scores, const float* bbox_preds, c
  * coordinates fall outside [0, 1] (:477-478; the caller ORs it with the padding mask).
  */
 int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uint8_t* outside, int R, int H, int W, int D,
-                              float pad_h, float pad_w, float depth_start, const double* pc_range, void* stream);
+                              float pad_h, float pad_w, float depth_start, const double* pc_range, int row_pixels,
+                              int row_start, void* stream);
+/*   row_pixels == 0: the NCHW layout above.  row_pixels > 0: channels-last, out is (R, row_pixels, 3*D) and this level
+ *   fills pixels [row_start, row_start + H*W) of every row (all levels of the pyramid side by side, the A operand of
+ *   gd4d_gemm_bf16x3_fwd). */
 
 /* gd4d_sine_pe3d_fwd - SinePositionalEncoding3D (models/utils/positional_encoding.py:82-99) after the cumulative
  * sums: out[r, part*F + f, pix] = f < F/2 ? sin(e / dim_t[2f]) : cos(e / dim_t[2(f - F/2) + 1]), e = embed_part[r, pix],
@@ -334,6 +339,22 @@ int gd4d_sine_pe3d_fwd(const float* n_embed, const float* y_embed, const float* 
  * pass over n elements (n % 4 == 0, 16-byte aligned pointers; out may alias feat). */
 int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out, size_t n,
                      void* stream);
+/* gd4d_se_fuse_chlast_fwd - the same with channels-last gate / pe (R, row_pixels, C) (this level at pixels
+ * [row_start, row_start + HW)) against NCHW feat / sine / out (R, C, HW): a tiled transpose through LDS.  C % 32 == 0. */
+int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out, int R,
+                            int C, int HW, int row_pixels, int row_start, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * gd4d_gemm_bf16x3_fwd - C = act(A W^T + b): row-major fp32 A (M, K) and C (M, N), W (N, K) given as its bf16 split
+ * (w = w_hi + w_lo, made once per weight by gd4d_split_bf16_fwd); three bf16 MFMA products per output accumulate in fp32
+ * (fp32-class: about 2^-16 relative per product).  The 1x1 convolutions of the head's feature position embedding
+ * (detr3d_head_pe.py:380-390 applied at :481-482, :551-556) in channels-last form.  flags: GD4D_LIN_RELU (output),
+ * GD4D_GEMM_RELU_IN (input: the previous layer's activation).
+ * Supported: N % 128 == 0, K % 32 == 0, lda % 4 == 0.
+ */
+int gd4d_split_bf16_fwd(const float* w, uint16_t* hi, uint16_t* lo, size_t n, void* stream);
+int gd4d_gemm_bf16x3_fwd(const float* a, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias, float* c, int M,
+                         int N, int K, int lda, int ldc, int flags, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * DGCNNAttn (projects/mmdet3d_plugin/models/utils/dgcnn_attn.py:10-96), registered by the reference, used by no

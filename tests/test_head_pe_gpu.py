@@ -58,9 +58,16 @@ def test_feature_position_embedding_matches_reference():
     g = Golden('head_pe')
     mod = _module(g)
     feats = [f.cuda() for f in g.feats()]
-    outs = mod(feats, _metas(g))
+    outs = mod(feats, _metas(g))                          # default: dense part on gd4d_gemm_bf16x3_fwd
     for lvl, o in enumerate(outs):
         torch.testing.assert_close(o.cpu(), g.t(f'out{lvl}'), rtol=2e-4, atol=2e-4)
+    import os
+    os.environ['GD4D_HEAD_PE'] = 'conv'                   # library 1x1 convolutions
+    try:
+        for lvl, o in enumerate(mod(feats, _metas(g))):
+            torch.testing.assert_close(o.cpu(), g.t(f'out{lvl}'), rtol=2e-4, atol=2e-4)
+    finally:
+        os.environ.pop('GD4D_HEAD_PE')
     again = mod(feats, _metas(g))                         # second call: sine branch from the cache
     assert mod._sine_cache is not None
     for a, b in zip(outs, again):

@@ -43,6 +43,9 @@ def main():
     with torch.no_grad():
         first = timed(lambda: (setattr(mod, '_sine_cache', None), setattr(mod, '_mask_cache', None), mod(feats, metas)), 3)
         steady = timed(lambda: mod(feats, metas))
+        os.environ['GD4D_HEAD_PE'] = 'conv'
+        steady_conv = timed(lambda: mod(feats, metas))
+        os.environ.pop('GD4D_HEAD_PE')
         masks, pad_hw = mod.padding_masks(metas, feats)
         i2l = torch.from_numpy(np.linalg.inv(np.asarray(rig, dtype=np.float64))).float().cuda()
         x0 = {}
@@ -56,8 +59,31 @@ def main():
         fl = [f.flatten(0, 1) for f in feats]
         t_fuse = timed(lambda: [ops.se_fuse_fwd(f, f, f, f) for f in fl])
         t_sine = timed(lambda: (setattr(mod, '_sine_cache', None), mod._sine_branch(masks)))
+    with torch.no_grad():
+        r = n
+        s_tot = pixels // n
+        xcl = torch.empty(r, s_tot, 192, device='cuda')
+        st = [0]
+        for f in feats[:-1]:
+            st.append(st[-1] + f.shape[-2] * f.shape[-1])
+        t_frc = timed(lambda: [ops.frustum_pe_input_fwd(i2l, f.shape[-2:], pad_hw, 64, 1, synthetic.PC_RANGE, out=xcl,
+                                                        row_start=s0) for f, s0 in zip(feats, st)])
+        sw = mod._split_weights()
+        hid = torch.empty(r * s_tot, 1024, device='cuda')
+        pe_o = torch.empty(r * s_tot, 256, device='cuda')
+        t_g1 = timed(lambda: ops.gemm_bf16x3_fwd(xcl.view(r * s_tot, 192), *sw['pe0'], mod.position_encoder[0].bias,
+                                                 relu=True, out=hid))
+        t_g2 = timed(lambda: ops.gemm_bf16x3_fwd(hid, *sw['pe2'], mod.position_encoder[2].bias, out=pe_o))
+        crw = mod.fpe.conv_reduce.weight.view(256, 256).contiguous()
+        t_vp = timed(lambda: ops.value_proj_fwd([f for f in feats], crw, mod.fpe.conv_reduce.bias))
+        t_g3 = timed(lambda: ops.gemm_bf16x3_fwd(pe_o, *sw['se1'], mod.fpe.conv_expand.bias, relu_in=True))
+        t_fz = timed(lambda: [ops.se_fuse_chlast_fwd(f.flatten(0, 1), pe_o.view(r, s_tot, 256), pe_o.view(r, s_tot, 256),
+                                                     f.flatten(0, 1), s0) for f, s0 in zip(feats, st)])
+    print(f'  GEMM path pieces: frustum (channels-last) {t_frc:.2f}  GEMM 192->1024 {t_g1:.2f}  GEMM 1024->256 {t_g2:.2f}  '
+          f'conv_reduce (value_proj kernel) {t_vp:.2f}  GEMM 256->256 {t_g3:.2f}  transposing fuse {t_fz:.2f} ms')
     flops = pixels * 2 * (192 * 1024 + 1024 * 256 + 2 * 256 * 256)
-    print(f'cameras={n} pixels={pixels}  steady-state {steady:.2f} ms (first call, sine branch not cached: {first:.2f} ms)')
+    print(f'cameras={n} pixels={pixels}  steady-state {steady:.2f} ms with gd4d_gemm_bf16x3_fwd, {steady_conv:.2f} ms with library '
+          f'1x1 convolutions (first call, sine branch not cached: {first:.2f} ms)')
     print(f'  frustum geometry kernel {t_fr:.2f} ms ({pixels * 192 * 4 / t_fr / 1e9:.2f} TB/s written)   '
           f'position_encoder convs {t_pe:.2f} ms   SE convs {t_se:.2f} ms   fuse kernel {t_fuse:.2f} ms '
           f'({pixels * 256 * 4 * 5 / t_fuse / 1e9:.2f} TB/s)   sine branch {t_sine:.2f} ms (cached afterwards)')
