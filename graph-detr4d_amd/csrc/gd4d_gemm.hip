@@ -7,11 +7,12 @@
 // layer's 256 -> 256 over 739 800 pixels: 0.87 TFLOP per sample), where a library fp32 GEMM runs on the fp32 MFMA
 // (157 TFLOP/s peak) and this runs on the bf16 MFMA (2.5 PFLOP/s peak, three products per output).
 //
-// Workgroup = 128 x 128 output tile, 4 waves in a 2 x 2 arrangement, each wave 2 x 2 tiles of v_mfma_f32_32x32x16_bf16.
+// Workgroup = 256 x 256 output tile, 16 waves in a 4 x 4 arrangement, each wave 2 x 2 tiles of v_mfma_f32_32x32x16_bf16
+// (with 128 x 128 tiles the kernel was bound by L2 -> CU traffic: 12 GB per GEMM at 9 TB/s; 256 x 256 halves it).
 // K advances in steps of 32 through a double-buffered LDS stage holding the tile's A_hi / A_lo / W_hi / W_lo as
 // [k-group of 8][row][8 x bf16] so that every MFMA fragment is one conflict-free ds_read_b128 per lane.  Global loads of
 // step k+1 are issued into registers before the MFMAs of step k and converted / parked into the other buffer after
-// them: one barrier per step.  64 KB of LDS per workgroup -> two workgroups per CU cover each other's barriers.
+// them: one barrier per step.  128 KB of LDS, one workgroup of 16 waves per CU.
 #include "gd4d_common.h"
 
 namespace gd4d {
@@ -20,8 +21,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 32, GM_THREADS = 256;
-constexpr int GM_ARR = 4 * GM_BM * 16;               // bytes of one [4 k-groups][128 rows][16 B] array: 8 KB
+constexpr int GM_BM = 256, GM_BN = 256, GM_BK = 32, GM_THREADS = 1024;   // 16 waves, 4 x 4, each 64 x 64
+constexpr int GM_ARR = 4 * GM_BM * 16;               // bytes of one [4 k-groups][256 rows][16 B] array: 16 KB
 constexpr int GM_STAGE = 4 * GM_ARR;                 // A_hi, A_lo, W_hi, W_lo
 
 struct GemmParams {
@@ -54,32 +55,34 @@ __device__ __forceinline__ void gm_split8(const float4& p, const float4& q, u32x
   l = u32x4{ll[0], ll[1], ll[2], ll[3]};
 }
 
-__global__ __launch_bounds__(GM_THREADS, 2) void gemm_bf16x3_kernel(const GemmParams p) {
+__global__ __launch_bounds__(GM_THREADS) void gemm_bf16x3_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;
   const int l32 = lane & 31, kg = lane >> 5;
   const int n0 = blockIdx.x * GM_BN;                   // n fastest: the workgroups sharing an A tile run together
   const int m0 = blockIdx.y * GM_BM;
 
   // staging role: 16-byte chunk (row = 64 pass + tid / 4, k-group = tid % 4) of the 128 x 32 tiles
   const int srow = tid >> 2, sk = tid & 3;
-  const float* a_src[2];
-  const uint16_t* wh_src[2];
-  const uint16_t* wl_src[2];
+  constexpr int PASSES = GM_BM * 4 / GM_THREADS;      // 16-byte chunks per thread and operand
+  constexpr int PROWS = GM_THREADS / 4;
+  const float* a_src[PASSES];
+  const uint16_t* wh_src[PASSES];
+  const uint16_t* wl_src[PASSES];
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int r = 64 * ps + srow;
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int r = PROWS * ps + srow;
     a_src[ps] = p.a + (size_t)min(m0 + r, p.M - 1) * p.lda + 8 * sk;
     wh_src[ps] = p.w_hi + (size_t)(n0 + r) * p.K + 8 * sk;
     wl_src[ps] = p.w_lo + (size_t)(n0 + r) * p.K + 8 * sk;
   }
-  float4 ra[2][2];
-  u32x4 rwh[2], rwl[2];
+  float4 ra[PASSES][2];
+  u32x4 rwh[PASSES], rwl[PASSES];
   auto issue = [&](int k0) {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
       ra[ps][0] = *reinterpret_cast<const float4*>(a_src[ps] + k0);
       ra[ps][1] = *reinterpret_cast<const float4*>(a_src[ps] + k0 + 4);
       rwh[ps] = *reinterpret_cast<const u32x4*>(wh_src[ps] + k0);
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_bf16x3_kernel(const GemmPa
   auto park = [&](int stage) {
     char* base = smem + stage * GM_STAGE;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int off = (sk * GM_BM + 64 * ps + srow) * 16;
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int off = (sk * GM_BM + PROWS * ps + srow) * 16;
       u32x4 h, l;
       if (p.relu_in) {                                  // activation of the previous layer, applied on the way in
         float4& x = ra[ps][0];

@@ -350,7 +350,7 @@ int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* p
  * (fp32-class: about 2^-16 relative per product).  The 1x1 convolutions of the head's feature position embedding
  * (detr3d_head_pe.py:380-390 applied at :481-482, :551-556) in channels-last form.  flags: GD4D_LIN_RELU (output),
  * GD4D_GEMM_RELU_IN (input: the previous layer's activation).
- * Supported: N % 128 == 0, K % 32 == 0, lda % 4 == 0.
+ * Supported: N % 256 == 0, K % 32 == 0, lda % 4 == 0.
  */
 int gd4d_split_bf16_fwd(const float* w, uint16_t* hi, uint16_t* lo, size_t n, void* stream);
 int gd4d_gemm_bf16x3_fwd(const float* a, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias, float* c, int M,

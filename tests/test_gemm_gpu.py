@@ -15,8 +15,8 @@ def test_split_is_exact_to_16_bits():
     assert bool((err <= w.abs() * 2.0 ** -16 + 1e-38).all())
 
 
-@pytest.mark.parametrize('m,k,n,relu', [(1000, 192, 1024, True), (777, 1024, 256, False), (128, 32, 128, False),
-                                        (5, 256, 256, True), (4097, 64, 128, False)])
+@pytest.mark.parametrize('m,k,n,relu', [(1000, 192, 1024, True), (777, 1024, 256, False), (128, 32, 256, False),
+                                        (5, 256, 256, True), (4097, 64, 256, False)])
 def test_gemm_bf16x3_matches_fp64(m, k, n, relu):
     from graph_detr4d_amd import ops
     torch.manual_seed(m + k + n)
@@ -36,10 +36,10 @@ def test_gemm_errors():
     from graph_detr4d_amd import ops
     from graph_detr4d_amd._lib import Gd4dError
     a = torch.randn(10, 48).cuda()
-    hi, lo = ops.split_bf16_fwd(torch.randn(128, 48).cuda())
+    hi, lo = ops.split_bf16_fwd(torch.randn(256, 48).cuda())
     with pytest.raises(Gd4dError):                       # K % 32
         ops.gemm_bf16x3_fwd(a, hi, lo)
     a = torch.randn(10, 64).cuda()
-    hi, lo = ops.split_bf16_fwd(torch.randn(100, 64).cuda())
-    with pytest.raises(Gd4dError):                       # N % 128
+    hi, lo = ops.split_bf16_fwd(torch.randn(128, 64).cuda())
+    with pytest.raises(Gd4dError):                       # N % 256
         ops.gemm_bf16x3_fwd(a, hi, lo)
