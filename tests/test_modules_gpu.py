@@ -236,3 +236,48 @@ def test_detr3d_cross_atten_v2_module(name):
                                   embed_dims=256)).to(DEV).eval()
     with pytest.raises(RuntimeError), torch.no_grad():
         mod5(g.t('query').to(DEV), None, feats, reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+
+
+def test_decoder_under_hipgraph_capture_matches_eager():
+    """The three-stream schedule (value_proj pipeline on a side stream, position_encoder / reg branch on the auxiliary
+    stream) captured into one hipGraph - what bench.py replays - gives the eager result bit for bit, replay after
+    replay."""
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                         embed_dims=256)],
+                         feedforward_channels=512, ffn_dropout=0.1,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    nn = torch.nn
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                        nn.Linear(256, 10)) for _ in range(m['num_layers'])])
+    regs.load_state_dict(g.state(prefix='reg.'), strict=True)
+    regs = regs.to(DEV).eval()
+    feats, qe, metas = [f.to(DEV) for f in g.feats()], g.t('query_embed').to(DEV), _metas(g)
+    with torch.no_grad():
+        eager = tr(feats, qe, reg_branches=regs, img_metas=metas)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                              # warm-up on the capture stream (allocator, lazy init)
+            tr(feats, qe, reg_branches=regs, img_metas=metas)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            captured = tr(feats, qe, reg_branches=regs, img_metas=metas)
+        for _ in range(3):
+            for t in captured:
+                t.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(captured, eager):
+                assert torch.equal(a, b)
