@@ -18,8 +18,11 @@ class CrossAttnFunction(torch.autograd.Function):
     def forward(ctx, value, ref, offsets, attn_logits, cam_logits, lidar2img, shapes, pc_range, img_h, img_w):
         value, ref, offsets = value.contiguous(), ref.contiguous(), offsets.contiguous()
         attn_logits, cam_logits = attn_logits.contiguous(), cam_logits.contiguous()
+        from . import functional as Fn
+        order = Fn.query_order(ref, pc_range)                   # locality order: forward reads and backward atomics
         out = ops.cross_attn_fwd(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                                 img_h, img_w)
+                                 img_h, img_w, query_order=order)
+        ctx.order = order
         ctx.save_for_backward(value, ref, offsets, attn_logits, cam_logits, lidar2img)
         ctx.meta = (shapes, pc_range, img_h, img_w)
         return out
@@ -33,7 +36,8 @@ class CrossAttnFunction(torch.autograd.Function):
         if value.dtype != torch.float32:
             raise NotImplementedError('training needs the fp32 value tensor (value_dtype="fp32")')
         gv, gr, go, ga, gc = ops.cross_attn_bwd(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img,
-                                                pc_range, img_h, img_w, grad_out.contiguous())
+                                                pc_range, img_h, img_w, grad_out.contiguous(),
+                                                query_order=ctx.order)
         return gv, gr, go, ga.view_as(attn_logits), gc, None, None, None, None, None
 
 

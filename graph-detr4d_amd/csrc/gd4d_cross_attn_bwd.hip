@@ -35,6 +35,7 @@ struct CrossAttnBwdParams {
   float* grad_offsets;         // (B, Q, Hh, P, 3)
   float* grad_attn_logits;     // (B, Q, Hh, L, P)
   float* grad_cam_logits;      // (B, Q, N), un-scrambled layout like cam_logits
+  const int32_t* order;       // optional locality order of the queries (gd4d_query_order_fwd), as in the forward
   int B, N, Q, L, S;
   int lvl_h[GD4D_MAX_LEVELS];
   int lvl_w[GD4D_MAX_LEVELS];
@@ -72,7 +73,15 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bq = blockIdx.x;
+  // with a locality order every XCD (workgroup i -> XCD i % 8) takes a contiguous range of it: the atomic adds into
+  // grad_value then meet in that XCD's L2 like the forward's reads do
+  int bq = blockIdx.x;
+  if (p.order) {
+    const int per_xcd = (p.B * p.Q + 7) >> 3;
+    const int pos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || pos >= p.B * p.Q) return;
+    bq = p.order[pos];
+  }
   const int b = bq / p.Q;
   const int q = bq - b * p.Q;
   const int h = lane / LPH;
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
 template <int HH>
 static int launch_bwd(const CrossAttnBwdParams& p, hipStream_t s) {
   constexpr int WAVES = 4;
-  const dim3 grid(p.B * p.Q);
+  const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
   auto lds_for = [&](int L) {
     return (size_t)WAVES * HH * (L * kBP + 3 * kBP) * sizeof(float) + 64 * sizeof(int) + (size_t)HH * kBP * 3 * sizeof(float);
   };
@@ -279,7 +288,7 @@ extern "C" int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, c
                                    const float* grad_out, void* grad_value, float* grad_ref,
                                    float* grad_offsets, float* grad_attn_logits, float* grad_cam_logits,
                                    int B, int N, int Q, int Hh, int Dh, int L, int P, int value_dtype,
-                                   int value_layout, void* stream) {
+                                   int value_layout, const int32_t* query_order, void* stream) {
   using namespace gd4d;
   if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range ||
       !grad_out || !grad_value || !grad_ref || !grad_offsets || !grad_attn_logits || !grad_cam_logits)
@@ -293,7 +302,7 @@ extern "C" int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, c
   p.value = static_cast<const float*>(value); p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits;
   p.cam_logits = cam_logits; p.lidar2img = lidar2img; p.grad_out = grad_out;
   p.grad_value = static_cast<float*>(grad_value); p.grad_ref = grad_ref; p.grad_offsets = grad_offsets;
-  p.grad_attn_logits = grad_attn_logits; p.grad_cam_logits = grad_cam_logits;
+  p.grad_attn_logits = grad_attn_logits; p.grad_cam_logits = grad_cam_logits; p.order = query_order;
   p.B = B; p.N = N; p.Q = Q; p.L = L;
   int start = 0;
   for (int l = 0; l < L; ++l) {
