@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -41,8 +41,8 @@ SIGNATURES = {
     'gd4d_mha_core_fwd': (_i, [_vp] * 5 + [_i] * 10 + [_f, _vp]),
     'gd4d_refine_reference_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_frustum_pe_input_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _i, _vp]),
-    'gd4d_se_fuse_chlast_fwd': (_i, [_vp] * 5 + [_i] * 5 + [_vp]),
-    'gd4d_sine_pe3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'gd4d_se_fuse_chlast_fwd': (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
+    'gd4d_sine_pe3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'gd4d_se_fuse_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_split_bf16_fwd': (_i, [_vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_gemm_bf16x3_fwd': (_i, [_vp] * 5 + [_i] * 6 + [_vp]),

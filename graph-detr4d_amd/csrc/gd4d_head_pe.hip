@@ -93,19 +93,27 @@ __global__ __launch_bounds__(256) void frustum_pe_chlast_kernel(const FrustumPar
 struct SineParams {
   const float* embed[3];    // n, y, x embeddings, each (R, H, W) (already normalised)
   const float* dim_t;       // (F)
-  float* out;               // (R, 3*F, H, W)
-  int R, HW, F;
+  float* out;               // (R, 3*F, H, W), or channels-last (R, S, 3*F) when S > 0 (this level at pixels [start, start + HW))
+  int R, HW, F, S, start;
 };
 
 __global__ __launch_bounds__(256) void sine_pe3d_kernel(const SineParams p) {
-  // one thread per (r, channel, pixel); pixel fastest -> coalesced stores
+  // one thread per (r, channel, pixel); the fastest index is the one that is contiguous in the output layout
   const long long total = (long long)p.R * 3 * p.F * p.HW;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int pix = (int)(idx % p.HW);
-  const long long t = idx / p.HW;
-  const int ch = (int)(t % (3 * p.F));
-  const int r = (int)(t / (3 * p.F));
+  int pix, ch, r;
+  if (p.S > 0) {                                    // channels-last: channel fastest
+    ch = (int)(idx % (3 * p.F));
+    const long long t = idx / (3 * p.F);
+    pix = (int)(t % p.HW);
+    r = (int)(t / p.HW);
+  } else {
+    pix = (int)(idx % p.HW);
+    const long long t = idx / p.HW;
+    ch = (int)(t % (3 * p.F));
+    r = (int)(t / (3 * p.F));
+  }
   const int part = ch / p.F, f = ch - part * p.F;
   const float* e = part == 0 ? p.embed[0] : part == 1 ? p.embed[1] : p.embed[2];
   // positional_encoding.py:90-98 stacks (pos[..., 0::2].sin(), pos[..., 1::2].cos()) on dim 4 of a 5-D tensor, i.e.
@@ -115,7 +123,9 @@ __global__ __launch_bounds__(256) void sine_pe3d_kernel(const SineParams p) {
   const bool is_cos = f >= half;
   const int src = is_cos ? 2 * (f - half) + 1 : 2 * f;
   const float v = e[(size_t)r * p.HW + pix] / p.dim_t[src];
-  p.out[idx] = is_cos ? cosf(v) : sinf(v);
+  const float o = is_cos ? cosf(v) : sinf(v);
+  if (p.S > 0) p.out[((size_t)r * p.S + p.start + pix) * 3 * p.F + ch] = o;
+  else p.out[idx] = o;
 }
 
 __global__ __launch_bounds__(256) void se_fuse_kernel(const float4* __restrict__ feat, const float4* __restrict__ gate,
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(256) void se_fuse_kernel(const float4* __restrict__
 // both sides are read and written coalesced.
 __global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __restrict__ feat, const float* __restrict__ gate,
                                                              const float* __restrict__ pe, const float* __restrict__ sine,
-                                                             float* __restrict__ out, int C, int HW, int S, int start) {
+                                                             float* __restrict__ out, int C, int HW, int S, int start,
+                                                             int sine_chlast) {
   __shared__ float tile[32][33];
   const int r = blockIdx.z;
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -149,6 +160,7 @@ __global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __rest
     if (pix < HW) {
       const size_t o = ((size_t)r * S + start + pix) * C + c;
       v = pe[o] * (1.0f / (1.0f + expf(-gate[o])));
+      if (sine_chlast) v += sine[o];
     }
     tile[ty + 8 * i][tx] = v;
   }
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __rest
     const int c = c0 + ty + 8 * i, pix = p0 + tx;
     if (pix < HW) {
       const size_t o = ((size_t)r * C + c) * HW + pix;
-      out[o] = feat[o] + (tile[tx][ty + 8 * i] + sine[o]);
+      out[o] = feat[o] + (sine_chlast ? tile[tx][ty + 8 * i] : tile[tx][ty + 8 * i] + sine[o]);
     }
   }
 }
@@ -189,10 +201,12 @@ extern "C" int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uin
 }
 
 extern "C" int gd4d_sine_pe3d_fwd(const float* n_embed, const float* y_embed, const float* x_embed, const float* dim_t,
-                                  float* out, int R, int HW, int F, void* stream) {
+                                  float* out, int R, int HW, int F, int row_pixels, int row_start, void* stream) {
   using namespace gd4d;
   if (!n_embed || !y_embed || !x_embed || !dim_t || !out || R <= 0 || HW <= 0 || F <= 0) return GD4D_EINVAL;
+  if (row_pixels < 0 || (row_pixels > 0 && (row_start < 0 || row_start + HW > row_pixels))) return GD4D_EINVAL;
   SineParams p{};
+  p.S = row_pixels; p.start = row_start;
   p.embed[0] = n_embed; p.embed[1] = y_embed; p.embed[2] = x_embed; p.dim_t = dim_t; p.out = out;
   p.R = R; p.HW = HW; p.F = F;
   const long long total = (long long)R * 3 * F * HW;
@@ -216,12 +230,14 @@ extern "C" int gd4d_se_fuse_fwd(const float* feat, const float* gate, const floa
 }
 
 extern "C" int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out,
-                                       int R, int C, int HW, int row_pixels, int row_start, void* stream) {
+                                       int R, int C, int HW, int row_pixels, int row_start, int sine_chlast,
+                                       void* stream) {
   using namespace gd4d;
   if (!feat || !gate || !pe || !sine || !out || R <= 0 || C <= 0 || HW <= 0) return GD4D_EINVAL;
   if (row_start < 0 || row_start + HW > row_pixels) return GD4D_EINVAL;
   if (C % 32 != 0 || R > 65535) return GD4D_EUNSUPPORTED;
   hipLaunchKernelGGL(se_fuse_chlast_kernel, dim3((HW + 31) / 32, C / 32, R), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), feat, gate, pe, sine, out, C, HW, row_pixels, row_start);
+                     static_cast<hipStream_t>(stream), feat, gate, pe, sine, out, C, HW, row_pixels, row_start,
+                     sine_chlast ? 1 : 0);
   return check_launch();
 }

@@ -74,9 +74,9 @@ class FeaturePositionEmbedding(nn.Module):
         self._mask_cache = (key, masks)
         return masks, (pad_h, pad_w)
 
-    def sine_embedding(self, mask):
-        """SinePositionalEncoding3D.forward (positional_encoding.py:58-100): tiny cumulative sums with torch, the
-        3 x num_feats sin / cos channels with ops.sine_pe3d_fwd."""
+    def _sine_embeds(self, mask):
+        """The three cumulative-sum embeddings of SinePositionalEncoding3D.forward (positional_encoding.py:70-84) -
+        tiny tensors, torch - and the dim_t divisors."""
         not_mask = 1 - mask.to(torch.int)
         embeds = [not_mask.cumsum(d, dtype=torch.float32) for d in (1, 2, 3)]
         if self.normalize:
@@ -85,8 +85,14 @@ class FeaturePositionEmbedding(nn.Module):
         dim_t = torch.arange(self.num_feats, dtype=torch.float32)
         dim_t = (self.temperature ** (2 * (dim_t // 2) / self.num_feats)).to(mask.device)
         b, n, h, w = mask.shape
-        out = ops.sine_pe3d_fwd(*[e.reshape(b * n, h, w).contiguous() for e in embeds], dim_t)
-        return out.view(b, n, 3 * self.num_feats, h, w)
+        return [e.reshape(b * n, h, w).contiguous() for e in embeds], dim_t
+
+    def sine_embedding(self, mask):
+        """SinePositionalEncoding3D.forward (positional_encoding.py:58-100): the 3 x num_feats sin / cos channels with
+        ops.sine_pe3d_fwd, (B, N, 3 * num_feats, H, W)."""
+        embeds, dim_t = self._sine_embeds(mask)
+        b, n, h, w = mask.shape
+        return ops.sine_pe3d_fwd(*embeds, dim_t).view(b, n, 3 * self.num_feats, h, w)
 
     def frustum_embedding(self, img_metas, masks, feats, pad_hw):
         """`position_embeding` (:427-491): returns per level ((B, N, C, H, W) embedding, (B, N, H, W) mask)."""
@@ -102,16 +108,33 @@ class FeaturePositionEmbedding(nn.Module):
             out_masks.append(masks[lvl] | outside.view(b, n, h, w))
         return out, out_masks
 
-    def _sine_branch(self, masks):
-        """adapt_pos3d(sine(mask)) per level; cached while the masks (and the weights) do not change."""
-        key = tuple(p._version for p in self.adapt_pos3d.parameters())
+    def _sine_branch(self, masks, chlast=False):
+        """adapt_pos3d(sine(mask)); cached while the masks (and the weights) do not change.  chlast=False: per level
+        (B, N, C, H, W) through the library convolutions; chlast=True: one (B*N, S, C) channels-last tensor for all
+        levels through gd4d_gemm_bf16x3_fwd (no library call at all)."""
+        key = (chlast,) + tuple(p._version for p in self.adapt_pos3d.parameters())
         c = self._sine_cache
         if c is not None and c[0] == key and len(c[1]) == len(masks) and all(a is m for a, m in zip(c[1], masks)):
             return c[2]                              # same mask objects as last time (padding_masks caches by shapes)
-        res = []
-        for m in masks:
-            s = self.sine_embedding(m)
-            res.append(self.adapt_pos3d(s.flatten(0, 1)).view(m.shape[0], m.shape[1], self.embed_dims, *m.shape[2:]))
+        if chlast:
+            b, n = masks[0].shape[:2]
+            sizes = [m.shape[2] * m.shape[3] for m in masks]
+            x = torch.empty(b * n, sum(sizes), 3 * self.num_feats, device=masks[0].device, dtype=torch.float32)
+            start = 0
+            for m, sz in zip(masks, sizes):
+                embeds, dim_t = self._sine_embeds(m)
+                ops.sine_pe3d_fwd(*embeds, dim_t, out=x, row_start=start)
+                start += sz
+            c0, c2 = self.adapt_pos3d[0], self.adapt_pos3d[2]
+            w0 = ops.split_bf16_fwd(c0.weight.detach().view(c0.out_channels, -1).contiguous())
+            w2 = ops.split_bf16_fwd(c2.weight.detach().view(c2.out_channels, -1).contiguous())
+            hid = ops.gemm_bf16x3_fwd(x.view(-1, x.shape[-1]), *w0, c0.bias, relu=True)
+            res = ops.gemm_bf16x3_fwd(hid, *w2, c2.bias).view(b * n, sum(sizes), -1)
+        else:
+            res = []
+            for m in masks:
+                s = self.sine_embedding(m)
+                res.append(self.adapt_pos3d(s.flatten(0, 1)).view(m.shape[0], m.shape[1], self.embed_dims, *m.shape[2:]))
         if not any(p.requires_grad and torch.is_grad_enabled() for p in self.adapt_pos3d.parameters()):
             self._sine_cache = (key, list(masks), res)
         return res
@@ -157,7 +180,7 @@ class FeaturePositionEmbedding(nn.Module):
         pe, gate = pe.view(r, s_tot, -1), gate.view(r, s_tot, -1)
         out = []
         for lvl, (f, st) in enumerate(zip(feats, starts)):
-            o = ops.se_fuse_chlast_fwd(f.flatten(0, 1).contiguous(), gate, pe, sine[lvl].flatten(0, 1).contiguous(), st)
+            o = ops.se_fuse_chlast_fwd(f.flatten(0, 1).contiguous(), gate, pe, sine, st)
             out.append(o.view(f.shape))
         return out
 
@@ -171,10 +194,11 @@ class FeaturePositionEmbedding(nn.Module):
         Fn.require_inference(*feats)
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
-            sine = self._sine_branch(masks)
-            gemm_ok = self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256
+            gemm_ok = self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256 and \
+                (3 * self.num_feats) % 32 == 0
             if gemm_ok and os.environ.get('GD4D_HEAD_PE', 'gemm') != 'conv':
-                return self._forward_gemm(feats, img_metas, masks, pad_hw, sine)
+                return self._forward_gemm(feats, img_metas, masks, pad_hw, self._sine_branch(masks, chlast=True))
+            sine = self._sine_branch(masks)
             coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)
             out = []
             for lvl, f in enumerate(feats):

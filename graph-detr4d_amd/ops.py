@@ -359,26 +359,32 @@ def frustum_pe_input_fwd(img2lidar, feat_hw, pad_hw, depth_num, depth_start, pc_
 
 
 def se_fuse_chlast_fwd(feat, gate, pe, sine, row_start, out=None):
-    """gd4d_se_fuse_chlast_fwd: feat / sine (R, C, H, W) NCHW, gate / pe (R, S, C) channels-last -> (R, C, H, W)."""
+    """gd4d_se_fuse_chlast_fwd: feat (R, C, H, W) NCHW, gate / pe (R, S, C) channels-last, sine NCHW like feat or
+    channels-last like gate -> (R, C, H, W)."""
     lib = _lib.load()
     r, c, h, w = feat.shape
     out = torch.empty_like(feat) if out is None else out
     code = lib.gd4d_se_fuse_chlast_fwd(_dev(feat, 'feat', torch.float32), _dev(gate, 'gate', torch.float32),
                                        _dev(pe, 'pe', torch.float32), _dev(sine, 'sine', torch.float32), _dev(out, 'out'),
-                                       r, c, h * w, gate.shape[1], int(row_start), _stream())
+                                       r, c, h * w, gate.shape[1], int(row_start), int(sine.dim() == 3), _stream())
     _lib.check(code, 'gd4d_se_fuse_chlast_fwd')
     return out
 
 
-def sine_pe3d_fwd(n_embed, y_embed, x_embed, dim_t):
-    """gd4d_sine_pe3d_fwd.  embeds (R, H, W) fp32, dim_t (F) -> (R, 3*F, H, W)."""
+def sine_pe3d_fwd(n_embed, y_embed, x_embed, dim_t, out=None, row_start=0):
+    """gd4d_sine_pe3d_fwd.  embeds (R, H, W) fp32, dim_t (F) -> (R, 3*F, H, W); with `out` (R, S, 3*F) the level is
+    written channels-last at pixels [row_start, row_start + H*W) of every row."""
     lib = _lib.load()
     r, h, w = n_embed.shape
     f = dim_t.numel()
-    out = torch.empty(r, 3 * f, h, w, device=n_embed.device, dtype=torch.float32)
+    row_pixels = 0
+    if out is None:
+        out = torch.empty(r, 3 * f, h, w, device=n_embed.device, dtype=torch.float32)
+    else:
+        row_pixels = out.shape[1]
     code = lib.gd4d_sine_pe3d_fwd(_dev(n_embed, 'n_embed', torch.float32), _dev(y_embed, 'y_embed', torch.float32),
                                   _dev(x_embed, 'x_embed', torch.float32), _dev(dim_t, 'dim_t', torch.float32),
-                                  _dev(out, 'out'), r, h * w, f, _stream())
+                                  _dev(out, 'out', torch.float32), r, h * w, f, int(row_pixels), int(row_start), _stream())
     _lib.check(code, 'gd4d_sine_pe3d_fwd')
     return out
 

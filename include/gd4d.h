@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 9
+#define GD4D_ABI_VERSION 10
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -333,7 +333,9 @@ int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uint8_t* outsi
  * part = camera, row, column (the reference stacks sin / cos BEFORE the feature axis, :90-98).
  * n_embed / y_embed / x_embed (R, HW) fp32, dim_t (F) fp32, out (R, 3*F, HW). */
 int gd4d_sine_pe3d_fwd(const float* n_embed, const float* y_embed, const float* x_embed, const float* dim_t,
-                       float* out, int R, int HW, int F, void* stream);
+                       float* out, int R, int HW, int F, int row_pixels, int row_start, void* stream);
+/*   row_pixels == 0: (R, 3*F, HW) as above; row_pixels > 0: channels-last (R, row_pixels, 3*F), this level at pixels
+ *   [row_start, row_start + HW) (the A operand of gd4d_gemm_bf16x3_fwd for adapt_pos3d). */
 
 /* gd4d_se_fuse_fwd - out = feat + (pe * sigmoid(gate) + sine): SELayer's gate (:243) and the adds of :553-557 in one
  * pass over n elements (n % 4 == 0, 16-byte aligned pointers; out may alias feat). */
@@ -342,7 +344,8 @@ int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, cons
 /* gd4d_se_fuse_chlast_fwd - the same with channels-last gate / pe (R, row_pixels, C) (this level at pixels
  * [row_start, row_start + HW)) against NCHW feat / sine / out (R, C, HW): a tiled transpose through LDS.  C % 32 == 0. */
 int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out, int R,
-                            int C, int HW, int row_pixels, int row_start, void* stream);
+                            int C, int HW, int row_pixels, int row_start, int sine_chlast, void* stream);
+/*   sine_chlast != 0: `sine` is channels-last (R, row_pixels, C) like gate / pe instead of NCHW. */
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_gemm_bf16x3_fwd - C = act(A W^T + b): row-major fp32 A (M, K) and C (M, N), W (N, K) given as its bf16 split
