@@ -5,7 +5,6 @@ Mirror of projects/mmdet3d_plugin/core/bbox/coders/nms_free_coder.py:17-118 (sam
 denormalize_bbox's cat, range masks) run as one launch of gd4d_nms_free_decode_fwd for all batch elements; only the
 final boolean compaction - whose size the host must learn - is left to torch, as in the reference.
 """
-import torch
 
 from . import ops
 from .registry import BBOX_CODERS

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_bf16x3_kernel(const GemmParam
   const int n0 = blockIdx.x * GM_BN;                   // n fastest: the workgroups sharing an A tile run together
   const int m0 = blockIdx.y * GM_BM;
 
-  // staging role: 16-byte chunk (row = 64 pass + tid / 4, k-group = tid % 4) of the 128 x 32 tiles
+  // staging role: 16-byte chunk (row = tid / 4, k-group = tid % 4) of the 256 x 32 tiles
   const int srow = tid >> 2, sk = tid & 3;
   constexpr int PASSES = GM_BM * 4 / GM_THREADS;      // 16-byte chunks per thread and operand
   constexpr int PROWS = GM_THREADS / 4;

@@ -3,7 +3,6 @@ import numpy as np
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib, ops
 
