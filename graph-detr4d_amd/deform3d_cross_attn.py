@@ -186,7 +186,6 @@ class Deform3DCrossAttn(nn.Module):
     def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
         """Training path: the same maths with autograd.  The gather runs gd4d_cross_attn_fwd/_bwd, value_proj
         runs the HIP forward with a GEMM backward, the small dense layers are torch ops."""
-        import torch.nn.functional as F
         from .autograd import CrossAttnFunction, ValueProjFunction
         inp_residual = query
         x = query if query_pos is None else query + query_pos
