@@ -218,7 +218,7 @@ def main():
 
 def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels):
     """Secondary mode: one training step of the decoder per sample - forward, a synthetic loss, backward
-    (gd4d_cross_attn_bwd + GEMM backward of value_proj), ONE flat gradient all-reduce over RCCL, SGD.
+    (gd4d_cross_attn_bwd, gd4d_value_proj_bwd_*, gd4d_linear_bwd_weight), ONE flat gradient all-reduce over RCCL, SGD.
     The feature pyramid requires grad (it comes from the backbone in the reference's training)."""
     for f in feats:
         f.requires_grad_(True)
@@ -227,8 +227,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     reducer = D.FlatGradAllReducer(params)
     tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
 
-    def run():
-        opt.zero_grad(set_to_none=False)
+    def step():
+        reducer.zero_grad()
         for f in feats:
             f.grad = None
         states, _, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
@@ -236,6 +236,31 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
         loss.backward()
         reducer.reduce()
         opt.step()
+
+    # The step is ~2500 launches, most of them small: eagerly it is bound by the host's launch rate, not by the GPU.
+    # Capture forward + backward + all-reduce + SGD into one hipGraph (warm-up on a side stream first so that autograd
+    # and the allocator have seen every shape), replay it per step.
+    run, launch = step, 'eager'
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    if not a.no_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                step()
+            graph.replay()
+            torch.cuda.synchronize()
+            run, launch = graph.replay, 'hipgraph'
+        except Exception as e:                        # report, never hide
+            print(f'[bench] hipGraph capture of the training step failed ({type(e).__name__}: {e}); running eagerly',
+                  file=sys.stderr)
+            run, launch = step, 'eager'
     elapsed = D.timed_steps(run, a.steps, a.warmup, dev)
     if rank == 0:
         line = {
@@ -246,7 +271,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             'config': {'workload': f'training step of the {a.layers}-layer decoder (forward + backward + flat gradient '
                                    f'all-reduce of {reducer.bytes_per_step() / 1e6:.1f} MB + SGD), {a.queries} queries, '
                                    f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
-                       'launch': 'eager', 'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
+                       'launch': launch, 'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'roofline': None, 'cpu_baseline': None,
         }
         print(json.dumps(line))

@@ -2,7 +2,7 @@
 
 Inference takes the fully fused HIP path (functional.py); with autograd enabled the modules switch to:
   * CrossAttnFunction  - gd4d_cross_attn_fwd / gd4d_cross_attn_bwd (hand-written HIP both ways);
-  * ValueProjFunction  - gd4d_value_proj_fwd forward; backward = two library GEMMs (torch.matmul);
+  * ValueProjFunction  - gd4d_value_proj_fwd / gd4d_value_proj_bwd_input + _bwd_weight (HIP both ways);
   * small dense layers - torch ops, so autograd sees them (their HIP kernels are forward-only).
 """
 import torch
@@ -56,14 +56,73 @@ class ValueProjFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         weight, *feats = ctx.saved_tensors
         c = weight.shape[0]
-        go = grad_out.reshape(-1, grad_out.shape[-2], c)                       # (R, S, C)
-        r = go.shape[0]
-        flat = torch.cat([f.reshape(r, c, -1) for f in feats], dim=2)           # (R, C, S)
-        grad_w = torch.einsum('rso,rcs->oc', go, flat) if ctx.needs_input_grad[0] else None
-        grad_b = go.sum(dim=(0, 1)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        go = grad_out.reshape(-1, grad_out.shape[-2], c).contiguous()          # (R, S, C)
+        grad_w = grad_b = None
+        if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
+            grad_w, grad_b = ops.value_proj_bwd_weight(go, feats, want_bias=ctx.has_bias)
         grads = [None] * len(feats)
         if any(ctx.needs_input_grad[2:]):
-            gin = torch.matmul(go, weight).transpose(1, 2)                      # (R, C, S)
-            parts = gin.split([f.shape[-2] * f.shape[-1] for f in feats], dim=2)
-            grads = [p.reshape(f.shape) for p, f in zip(parts, feats)]
+            gin = ops.value_proj_bwd_input(go, weight, [tuple(f.shape[-2:]) for f in feats])
+            grads = [g.view(f.shape) for g, f in zip(gin, feats)]
         return (grad_w, grad_b, *grads)
+
+
+class ValueProjMultiFunction(torch.autograd.Function):
+    """value_proj of every decoder layer over the one pyramid they share (detr3d_transformer.py:192-198): one
+    gd4d_value_proj_multi_fwd launch forward; backward runs once, when the gradients of all the layers' value tensors
+    exist, and accumulates the pyramid's gradient in place (gd4d_value_proj_bwd_input with accumulate) instead of
+    leaving autograd to add NL full-size tensors.
+
+    apply(nl, w_0 .. w_{nl-1}, b_0 .. b_{nl-1}, feat_0 .. feat_{L-1}) -> nl tensors (R, S, C)."""
+
+    @staticmethod
+    def forward(ctx, nl, *args):
+        weights = [w.contiguous() for w in args[:nl]]
+        biases = [b.contiguous() for b in args[nl:2 * nl]]
+        feats = [f.contiguous() for f in args[2 * nl:]]
+        outs = ops.value_proj_multi_fwd(feats, weights, biases)
+        ctx.save_for_backward(*weights, *feats)
+        ctx.nl = nl
+        ctx.set_materialize_grads(False)          # a layer whose value tensor is unused arrives as None, not as zeros
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grad_outs):
+        nl = ctx.nl
+        weights, feats = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        c = weights[0].shape[0]
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        need_feats = any(ctx.needs_input_grad[1 + 2 * nl:])
+        gws, gbs = [None] * nl, [None] * nl
+        gin = None
+        for i, go in enumerate(grad_outs):
+            if go is None:
+                continue
+            go = go.reshape(-1, go.shape[-2], c).contiguous()
+            if ctx.needs_input_grad[1 + i] or ctx.needs_input_grad[1 + nl + i]:
+                gws[i], gbs[i] = ops.value_proj_bwd_weight(go, feats)
+            if need_feats:
+                gin = ops.value_proj_bwd_input(go, weights[i], shapes, grads=gin, accumulate=gin is not None)
+        grads = [None] * len(feats) if gin is None else [g.view(f.shape) for g, f in zip(gin, feats)]
+        return (None, *gws, *gbs, *grads)
+
+
+class LinearFunction(torch.autograd.Function):
+    """nn.Linear for the decoder's dense layers in training: library GEMM forward and input gradient, weight / bias
+    gradient by gd4d_linear_bwd_weight (the library runs that 256 x 256 x ~900 contraction on a single compute unit)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)                  # x: (M, K), see functional.linear_autograd
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        gx = torch.matmul(grad_y, weight) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = ops.linear_bwd_weight(x.contiguous(), grad_y, want_bias=ctx.has_bias)
+        return gx, gw, gb

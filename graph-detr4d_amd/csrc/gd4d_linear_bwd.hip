@@ -1,0 +1,111 @@
+// gd4d_linear_bwd_weight: weight and bias gradient of the decoder's small dense layers (training),
+//   dw[n][k] = sum_m dy[m][n] * x[m][k],   db[n] = sum_m dy[m][n]            (m: the ~900 query rows)
+// A library fp32 GEMM picks one 256 x 256 macro tile for these shapes (N, K <= 512, M ~ 900) and runs the whole
+// contraction on ONE compute unit: ~205 us per layer where the arithmetic is 0.1 GFLOP (measured with rocprofv3 on the
+// training step, 30 such GEMMs per step).  Here every 16 (n) x 32 (k) block of dw is one workgroup; its sixteen waves
+// split the rows, run v_mfma_f32_16x16x4_f32 on operands loaded straight from global memory (the reduction index m
+// is the ROW of both operands, which is exactly how the fp32 MFMA wants A^T and B: one float per lane, 16 consecutive
+// columns per row = one 64 B segment) and are summed through LDS in a fixed order: deterministic, no atomics.
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct LinBwdParams {
+  const float* x;    // (M, K), row stride ldx
+  const float* dy;   // (M, N), row stride ldy
+  float* dw;         // (N, K) contiguous
+  float* db;         // (N) or null
+  int M, N, K, ldx, ldy;
+};
+
+constexpr int LB_TN = 16, LB_TK = 32, LB_WAVES = 16, LB_UNROLL = 4, LB_T = LB_TK / 16;
+
+__global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_kernel(const LinBwdParams p) {
+  __shared__ float part[LB_WAVES][LB_TN * LB_TK];
+  __shared__ float bpart[LB_WAVES][LB_TN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, r4 = lane >> 4;
+  const int k0 = blockIdx.x * LB_TK, n0 = blockIdx.y * LB_TN;
+
+  // rows of this wave: its share of M rounded up to whole MFMA steps of 4 rows
+  const int per = ((p.M + LB_WAVES - 1) / LB_WAVES + 3) & ~3;
+  const int m_begin = wave * per, m_end = min(m_begin + per, p.M);
+
+  const int n = n0 + c16;
+  const bool n_ok = n < p.N;
+  const float* dy_col = p.dy + (n_ok ? n : p.N - 1);
+  const float* x_col[LB_T];
+  bool k_ok[LB_T];
+#pragma unroll
+  for (int t = 0; t < LB_T; ++t) {
+    const int k = k0 + 16 * t + c16;
+    k_ok[t] = k < p.K;
+    x_col[t] = p.x + (k_ok[t] ? k : p.K - 1);
+  }
+
+  f32x4 acc[LB_T];
+#pragma unroll
+  for (int t = 0; t < LB_T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  for (int m0 = m_begin; m0 < m_end; m0 += 4 * LB_UNROLL) {
+    float a[LB_UNROLL], b[LB_UNROLL][LB_T];
+#pragma unroll
+    for (int u = 0; u < LB_UNROLL; ++u) {            // all loads of the unrolled steps first, then the MFMAs
+      const int m = m0 + 4 * u + r4;
+      const bool m_ok = m < m_end;
+      const size_t mr = (size_t)(m_ok ? m : m_end - 1);
+      const float av = dy_col[mr * p.ldy];
+      a[u] = (m_ok && n_ok) ? av : 0.f;
+#pragma unroll
+      for (int t = 0; t < LB_T; ++t) {
+        const float bv = x_col[t][mr * p.ldx];
+        b[u][t] = (m_ok && k_ok[t]) ? bv : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LB_UNROLL; ++u) {
+      bsum += a[u];
+#pragma unroll
+      for (int t = 0; t < LB_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][t], acc[t], 0, 0, 0);
+    }
+  }
+
+  // C/D of 16x16x4: column j = lane & 15 (k), rows i = 4 * (lane >> 4) + r (n)
+#pragma unroll
+  for (int t = 0; t < LB_T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][(4 * r4 + r) * LB_TK + 16 * t + c16] = acc[t][r];
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 16) bpart[wave][lane] = bsum;
+  __syncthreads();
+  for (int i = threadIdx.x; i < LB_TN * LB_TK; i += 64 * LB_WAVES) {
+    const int nn = n0 + i / LB_TK, kk = k0 + i % LB_TK;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LB_WAVES; ++w) s += part[w][i];
+    if (nn < p.N && kk < p.K) p.dw[(size_t)nn * p.K + kk] = s;
+  }
+  if (p.db && blockIdx.x == 0 && threadIdx.x < LB_TN && n0 + threadIdx.x < p.N) {
+    const int i = threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LB_WAVES; ++w) s += bpart[w][i];
+    p.db[n0 + i] = s;
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_linear_bwd_weight(const float* x, const float* grad_y, float* grad_w, float* grad_b, int M, int K,
+                                      int N, int ldx, int ldy, void* stream) {
+  using namespace gd4d;
+  if (!x || !grad_y || !grad_w || M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return GD4D_EINVAL;
+  LinBwdParams p{x, grad_y, grad_w, grad_b, M, N, K, ldx, ldy};
+  const dim3 grid((K + LB_TK - 1) / LB_TK, (N + LB_TN - 1) / LB_TN);
+  hipLaunchKernelGGL(linear_bwd_weight_kernel, grid, dim3(64 * LB_WAVES), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}

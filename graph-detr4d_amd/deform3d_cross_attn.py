@@ -94,7 +94,9 @@ class Deform3DCrossAttn(nn.Module):
         img_metas = kwargs['img_metas']
         Fn.require_gpu(query, 'query')
         if Fn.wants_grad(self, query, query_pos, reference_points, *value):
-            return self._forward_autograd(query, value, query_pos, reference_points, img_metas)
+            cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
+            return self._forward_autograd(query, value, query_pos, reference_points, img_metas,
+                                          cached[0] if cached is not None and cached[2] is value else None)
 
         inp_residual = query
         q_len, b, c = query.shape
@@ -183,7 +185,7 @@ class Deform3DCrossAttn(nn.Module):
             ref3d = torch.cat([ref3d, depth], dim=-1)
         return Fn.position_encoder(self.position_encoder, ref3d)
 
-    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
+    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas, projected=None):
         """Training path: the same maths with autograd.  The gather runs gd4d_cross_attn_fwd/_bwd, value_proj
         runs the HIP forward with a GEMM backward, the small dense layers are torch ops."""
         from .autograd import CrossAttnFunction, ValueProjFunction
@@ -192,20 +194,24 @@ class Deform3DCrossAttn(nn.Module):
         x = x.permute(1, 0, 2)                                            # (B, Q, C)
         b, q, c = x.shape
         hh, npt, nl = self.num_heads, self.num_points, self.num_levels
-        cam_logits = self.cam_attention_weights(x)                        # un-scrambled (B, Q, N)
-        offsets = self.deform_sampling_offsets(x).view(b, q, hh, npt, 3)
-        attn_logits = self.attention_weights(x).view(b, q, hh, nl, npt)
+        x = x.contiguous()
+        cam_logits = Fn.sequential_autograd(self.cam_attention_weights, x)   # un-scrambled (B, Q, N)
+        offsets = Fn.sequential_autograd(self.deform_sampling_offsets, x).view(b, q, hh, npt, 3)
+        attn_logits = Fn.sequential_autograd(self.attention_weights, x).view(b, q, hh, nl, npt)
         shapes = [tuple(v.shape[-2:]) for v in value]
-        val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)
-        val = val.view(val.shape[0], -1, hh, c // hh)
+        if projected is None:
+            val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)
+            val = val.view(val.shape[0], -1, hh, c // hh)
+        else:
+            val = projected                      # the decoder projected for all its layers (one autograd node)
         lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
         agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
                                       shapes, self.pc_range, img_h, img_w)
-        out = self.output_proj(agg).permute(1, 0, 2)
+        out = Fn.sequential_autograd(self.output_proj, agg).permute(1, 0, 2)
         ref3d = reference_points
         if self.depth_encode:
             depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
             ref3d = torch.cat([ref3d, depth], dim=-1)
-        pos_feat = self.position_encoder(Fn.inverse_sigmoid(ref3d)).permute(1, 0, 2)
+        pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(ref3d)).permute(1, 0, 2)
         return self.dropout(out) + inp_residual + pos_feat

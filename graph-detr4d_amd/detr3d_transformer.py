@@ -200,9 +200,15 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         if mode == '0' or not isinstance(value, (list, tuple)) or len(value) == 0 or not value[0].is_cuda:
             return kwargs, None
         mods = [a for layer in self.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
-        if mods and Fn.wants_grad(mods[0], *value):
-            return kwargs, None
         if len(mods) < 2 or len(mods) > 8 or len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) != 1:
+            return kwargs, None
+        if Fn.wants_grad(mods[0], *value):
+            # training: one autograd node for all the layers' projections (the pyramid's gradient is summed in place)
+            if any(m.value_proj.bias is None or m.value_dtype != torch.float32 for m in mods) \
+                    or value[0].shape[0] != 1 or any(v.dtype != torch.float32 for v in value):
+                return kwargs, None
+            kwargs = dict(kwargs)
+            kwargs[Fn.VALUE_CACHE_KEY] = Fn.project_values_for_layers_autograd(mods, value)
             return kwargs, None
         Fn.require_inference(*value)
         kwargs = dict(kwargs)

@@ -103,12 +103,43 @@ class FlatGradAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.views = None
 
     def _buffer(self, like, extra):
         n = self.numel + extra
         if self.flat is None or self.flat.numel() != n or self.flat.device != like.device:
             self.flat = torch.zeros(n, dtype=torch.float32, device=like.device)
+            self.views = None
         return self.flat
+
+    def _bind(self, flat):
+        """Make every parameter's .grad a view of the flat buffer (keeping its value): autograd then accumulates
+        straight into the buffer and a step needs no per-parameter gather / scatter copies (two small launches per
+        parameter otherwise - hundreds per step, more than the decoder's own kernels)."""
+        if self.views is None:
+            self.views, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                self.views.append(flat[off:off + n].view_as(p))
+                off += n
+        for p, v in zip(self.params, self.views):
+            if p.grad is v:
+                continue
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+            p.grad = v
+
+    @torch.no_grad()
+    def zero_grad(self):
+        """Zero all gradients with one launch (bound buffer); falls back to per-parameter zeroing before the first step."""
+        if self.flat is not None and self.views is not None and all(p.grad is v for p, v in zip(self.params, self.views)):
+            self.flat.zero_()
+            return
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
 
     @torch.no_grad()
     def reduce(self, extras=None):
@@ -117,30 +148,14 @@ class FlatGradAllReducer:
         like = self.params[0]
         ne = 0 if extras is None else extras.numel()
         flat = self._buffer(like, ne)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                flat[off:off + n].zero_()
-            else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        self._bind(flat)
         if ne:
-            flat[off:off + ne].copy_(extras.reshape(-1).float())
+            flat[self.numel:].copy_(extras.reshape(-1).float())
         world = dist.get_world_size() if dist.is_initialized() else 1
         if world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        off = 0
-        scale = 1.0 / world
-        for p in self.params:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p) * scale
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
-        return flat[off:off + ne].clone() if ne else None
+            flat[:self.numel].mul_(1.0 / world)
+        return flat[self.numel:].clone() if ne else None
 
     def bytes_per_step(self):
         return self.numel * 4

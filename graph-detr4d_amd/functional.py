@@ -23,6 +23,27 @@ def require_inference(*tensors):
             'graph-detr4d_amd: this entry point has no backward - call it under torch.no_grad()')
 
 
+def linear_autograd(x, weight, bias=None):
+    """F.linear with autograd (training path); on the GPU in fp32 the weight gradient runs on gd4d_linear_bwd_weight."""
+    if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
+        from .autograd import LinearFunction
+        # 2-D inside the Function: its output must not be a view (in-place ReLUs follow in the nn.Sequential stacks)
+        y = LinearFunction.apply(x.reshape(-1, x.shape[-1]), weight, bias)
+        return y.view(*x.shape[:-1], weight.shape[0])
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def sequential_autograd(module, x):
+    """Run an nn.Sequential / nn.Linear / any module with autograd, its nn.Linear layers through linear_autograd."""
+    if isinstance(module, torch.nn.Linear):
+        return linear_autograd(x, module.weight, module.bias)
+    if isinstance(module, torch.nn.Sequential):
+        for m in module:
+            x = sequential_autograd(m, x)
+        return x
+    return module(x)
+
+
 def require_gpu(t, name):
     if not t.is_cuda:
         raise _lib.Gd4dError(f'{name} is on {t.device}: graph-detr4d_amd runs on the GPU only '
@@ -213,6 +234,19 @@ def project_values_for_layers(modules, value):
                                     modules[0].value_dtype, num_heads=hh, head_major=hm,
                                     bf16_math=modules[0].value_dtype == torch.bfloat16)
     return {id(m): ((o if hm else o.view(b * n, -1, hh, c // hh)), shapes, value) for m, o in zip(modules, outs)}
+
+
+def project_values_for_layers_autograd(modules, value):
+    """Training counterpart of project_values_for_layers: the same launch behind autograd.ValueProjMultiFunction, whose
+    backward sums the pyramid's gradient over the layers in place.  fp32 pixel-major value tensors (what
+    gd4d_cross_attn_bwd takes)."""
+    from .autograd import ValueProjMultiFunction
+    shapes = [tuple(v.shape[-2:]) for v in value]
+    b, n, c = value[0].shape[:3]
+    hh = modules[0].num_heads
+    outs = ValueProjMultiFunction.apply(len(modules), *[m.value_proj.weight for m in modules],
+                                        *[m.value_proj.bias for m in modules], *value)
+    return {id(m): (o.view(b * n, -1, hh, c // hh), shapes, value) for m, o in zip(modules, outs)}
 
 
 _SIDE_STREAMS = {}

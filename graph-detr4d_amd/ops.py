@@ -196,6 +196,72 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_he
     return outs
 
 
+def linear_bwd_weight(x, grad_y, want_bias=True):
+    """gd4d_linear_bwd_weight.  x (..., K), grad_y (..., N) fp32 with the same leading shape (contiguous rows).
+    Returns (grad_w (N, K), grad_b (N) or None)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    k, n = x.shape[-1], grad_y.shape[-1]
+    m = x.numel() // k
+    if grad_y.numel() // n != m:
+        raise ValueError('x and grad_y must have the same number of rows')
+    gw = torch.empty(n, k, device=x.device, dtype=f32)
+    gb = torch.empty(n, device=x.device, dtype=f32) if want_bias else None
+    code = lib.gd4d_linear_bwd_weight(_dev(x, 'x', f32), _dev(grad_y, 'grad_y', f32), _dev(gw, 'grad_w'),
+                                      _dev(gb, 'grad_b') if want_bias else None, m, k, n, k, n, _stream())
+    _lib.check(code, 'gd4d_linear_bwd_weight')
+    return gw, gb
+
+
+_VP_BWD_WS = {}
+
+
+def value_proj_bwd_input(grad_out, weight, shapes, grads=None, accumulate=False):
+    """gd4d_value_proj_bwd_input.  grad_out (R, S, C) fp32; weight (C, C); shapes: per level (H_l, W_l).
+    Returns the list of L gradients (R, C, H_l, W_l); with `grads` given they are written (accumulate=False) or added
+    to (accumulate=True) in place."""
+    lib = _lib.load()
+    f32 = torch.float32
+    c = weight.shape[0]
+    r = grad_out.numel() // (c * sum(h * w for h, w in shapes))
+    nl = len(shapes)
+    if grads is None:
+        if accumulate:
+            raise ValueError('accumulate=True needs the tensors to add to')
+        grads = [torch.empty(r, c, h, w, device=grad_out.device, dtype=f32) for h, w in shapes]
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(g, f'grads[{i}]', f32).value for i, g in enumerate(grads)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in shapes for x in hw])
+    code = lib.gd4d_value_proj_bwd_input(_dev(grad_out, 'grad_out', f32), _dev(weight, 'weight', f32), ptrs, lv,
+                                         r, c, nl, int(bool(accumulate)), _stream())
+    _lib.check(code, 'gd4d_value_proj_bwd_input')
+    return grads
+
+
+def value_proj_bwd_weight(grad_out, feats, want_bias=True):
+    """gd4d_value_proj_bwd_weight.  grad_out (R, S, C) fp32; feats: the L NCHW levels the forward read.
+    Returns (grad_weight (C, C), grad_bias (C) or None)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    c = feats[0].shape[-3]
+    nl = len(feats)
+    r = feats[0].numel() // (c * feats[0].shape[-1] * feats[0].shape[-2])
+    dev = grad_out.device
+    nbytes = lib.gd4d_value_proj_bwd_weight_workspace_bytes()
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _VP_BWD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _VP_BWD_WS[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    gw = torch.empty(c, c, device=dev, dtype=f32)
+    gb = torch.empty(c, device=dev, dtype=f32) if want_bias else None
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    code = lib.gd4d_value_proj_bwd_weight(_dev(grad_out, 'grad_out', f32), ptrs, lv, _dev(gw, 'grad_weight'),
+                                          _dev(gb, 'grad_bias') if want_bias else None, _dev(ws, 'workspace'),
+                                          ctypes.c_size_t(nbytes), r, c, nl, _stream())
+    _lib.check(code, 'gd4d_value_proj_bwd_weight')
+    return gw, gb
+
+
 def _opt(t, name):
     return _dev(t, name, torch.float32) if t is not None else None
 

@@ -75,7 +75,7 @@ class MultiheadAttention(nn.Module):
                 and query_pos is not None and key_pos is query_pos and identity.shape == query.shape):
             return self._packed_self_attention(query, query_pos, attn_mask, identity, Fn.take_fused_norm(kwargs))
         q_in = query if query_pos is None else query + query_pos
-        k_in = key if key_pos is None else key + key_pos
+        k_in = q_in if (key is query and key_pos is query_pos) else (key if key_pos is None else key + key_pos)
         if self.batch_first:
             q_in, k_in, value = (t.transpose(0, 1) for t in (q_in, k_in, value))
         out = self._attention_autograd(q_in, k_in, value, attn_mask) if grad else \
@@ -115,16 +115,22 @@ class MultiheadAttention(nn.Module):
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         lq, b, _ = q_in.shape
         lk = k_in.shape[0]
-        qh = F.linear(q_in, w[:c], bias[:c]).reshape(lq, b * h, d).transpose(0, 1)
-        kh = F.linear(k_in, w[c:2 * c], bias[c:2 * c]).reshape(lk, b * h, d).transpose(0, 1)
-        vh = F.linear(v_in, w[2 * c:], bias[2 * c:]).reshape(lk, b * h, d).transpose(0, 1)
+        if k_in is q_in:                                  # decoder self-attention: one GEMM for q and k
+            qk = Fn.linear_autograd(q_in.contiguous(), w[:2 * c], bias[:2 * c])
+            qh, kh = qk[..., :c], qk[..., c:]
+        else:
+            qh = Fn.linear_autograd(q_in.contiguous(), w[:c], bias[:c])
+            kh = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c])
+        qh = qh.reshape(lq, b * h, d).transpose(0, 1)
+        kh = kh.reshape(lk, b * h, d).transpose(0, 1)
+        vh = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:]).reshape(lk, b * h, d).transpose(0, 1)
         scores = torch.bmm(qh * (1.0 / math.sqrt(d)), kh.transpose(1, 2))
         if attn_mask is not None:
             scores = scores.masked_fill(attn_mask, float('-inf')) if attn_mask.dtype == torch.bool \
                 else scores + attn_mask
         attn = F.dropout(scores.softmax(-1), p=self.attn_drop, training=self.training)
         o = torch.bmm(attn, vh).transpose(0, 1).reshape(lq, b, c)
-        return F.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
+        return Fn.linear_autograd(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
 
 @FEEDFORWARD_NETWORK.register_module()
@@ -159,7 +165,7 @@ class FFN(nn.Module):
                 fused['done'] = True
                 return Fn.linear_norm(hdn, self.layers[1].weight, self.layers[1].bias, fused['norm'], r1=res)
             return Fn.linear(hdn, self.layers[1].weight, self.layers[1].bias, r1=res)
-        out = self.layers(x)
+        out = Fn.sequential_autograd(self.layers, x) if x.is_cuda else self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:

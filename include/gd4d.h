@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 10
+#define GD4D_ABI_VERSION 11
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -198,6 +198,25 @@ int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                               void* const* outs, int R, int C, int L, int NL, int Hh, int in_dtype,
                               int out_dtype, int out_layout, int precision, void* stream);
 
+/* gd4d_value_proj_bwd_input / _bwd_weight - backward of gd4d_value_proj_fwd (fp32, pixel-major grad_out): what autograd
+ * derives for `self.value_proj(value_flatten)` and the flatten / transpose / cat in front of it
+ * (deform3d_cross_attn.py:264-280), without the transposed copies and on the bf16 MFMA with split operands (fp32-class).
+ *   grad_out     (R, S, C) fp32: gradient of the projected value tensor, as gd4d_cross_attn_bwd writes it
+ *   grad_feats   host array of L device pointers, level l = (R, C, H_l, W_l) fp32 NCHW:
+ *                grad_feats_l[r, ci, pix] (+)= sum_co grad_out[r, start_l + pix, co] * weight[co, ci]
+ *                accumulate != 0 adds to the tensors' contents (every decoder layer projects the same pyramid, so its
+ *                gradient is the sum over the layers); 0 overwrites.
+ *   grad_weight  (C, C): sum over rows of grad_out[row, co] * feats[row, ci];  grad_bias (C) or NULL: column sums of
+ *                grad_out.  Partial sums per workgroup go to `workspace` (gd4d_value_proj_bwd_weight_workspace_bytes(),
+ *                16-byte aligned) and are added in a fixed order: results are run-to-run identical.
+ * Supported: C == 256, L <= 8. */
+int gd4d_value_proj_bwd_input(const float* grad_out, const float* weight, float* const* grad_feats,
+                              const int32_t* level_hw, int R, int C, int L, int accumulate, void* stream);
+size_t gd4d_value_proj_bwd_weight_workspace_bytes(void);
+int gd4d_value_proj_bwd_weight(const float* grad_out, const void* const* feats, const int32_t* level_hw,
+                               float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes, int R,
+                               int C, int L, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * gd4d_linear_fwd - the decoder's small dense layers on the fp32 MFMA, with the elementwise
  * neighbours fused:  y = act((x [+ x2 for output columns < n_split]) W^T + bias) [+ r1] [+ r2]
@@ -230,6 +249,15 @@ int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float
  *   be NULL), W_g (N_g, K) row-major, y_g (M, N_g) contiguous; n_out: host, G ints.  G <= 4. */
 int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w, const float* const* bias,
                           float* const* y, const int32_t* n_out, int G, int M, int K, int ldx, void* stream);
+
+/* gd4d_linear_bwd_weight - weight / bias gradient of an nn.Linear over the query rows (training):
+ *   grad_w[n][k] = sum_m grad_y[m][n] * x[m][k]   (N, K) contiguous;   grad_b[n] = sum_m grad_y[m][n]  (or NULL)
+ * What autograd's `grad_output.t().mm(input)` computes for the decoder's dense layers (config ...ceph.py:71-89,
+ * deform3d_cross_attn.py:104-111,204-228,326), where the library GEMM runs these M ~ 900, N, K <= 512 shapes on one
+ * compute unit.  fp32 MFMA, one workgroup per 16 x 32 block of grad_w, fixed summation order.
+ *   x (M, K) row stride ldx;  grad_y (M, N) row stride ldy. */
+int gd4d_linear_bwd_weight(const float* x, const float* grad_y, float* grad_w, float* grad_b, int M, int K, int N,
+                           int ldx, int ldy, void* stream);
 
 /* gd4d_layernorm_fwd - y = LayerNorm(x [+ res]) * gamma + beta [, ReLU] over the last dim
  * (biased variance, eps inside the sqrt, like ATen).  Replaces the nn.LayerNorm of

@@ -215,3 +215,33 @@ def test_linear_ln_input_addend_and_errors():
         ops.linear_ln_fwd(x, w, b, torch.ones(n).cuda(), torch.zeros(n).cuda())
     with pytest.raises(Gd4dError):                                   # K not a multiple of 64
         ops.linear_ln_fwd(torch.randn(5, 48).cuda(), torch.randn(8, 48).cuda())
+
+
+@pytest.mark.parametrize('m,k,n', [(900, 256, 256), (900, 256, 24), (900, 4, 256), (900, 512, 256), (900, 256, 512),
+                                   (7, 3, 5), (1801, 96, 10)])
+def test_linear_bwd_weight_matches_fp64(m, k, n):
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + k + n)
+    x, gy = torch.randn(m, k), torch.randn(m, n)
+    gw, gb = ops.linear_bwd_weight(x.cuda(), gy.cuda())
+    want_w, want_b = gy.double().t() @ x.double(), gy.double().sum(0)
+    assert (gw.cpu().double() - want_w).abs().max().item() < 2e-4
+    assert (gb.cpu().double() - want_b).abs().max().item() < 2e-4
+    gw2, none = ops.linear_bwd_weight(x.cuda(), gy.cuda(), want_bias=False)
+    assert none is None and torch.equal(gw, gw2)
+
+
+def test_linear_function_gradients():
+    from graph_detr4d_amd import functional as Fn
+    torch.manual_seed(11)
+    seq = torch.nn.Sequential(torch.nn.Linear(4, 256), torch.nn.LayerNorm(256), torch.nn.ReLU(inplace=True),
+                              torch.nn.Linear(256, 256), torch.nn.ReLU(inplace=True), torch.nn.Linear(256, 10)).cuda()
+    x = torch.randn(1, 900, 4, device='cuda', requires_grad=True)
+    Fn.sequential_autograd(seq, x).square().sum().backward()
+    got = [p.grad.clone() for p in seq.parameters()] + [x.grad.clone()]
+    for p in seq.parameters():
+        p.grad = None
+    x.grad = None
+    seq(x).square().sum().backward()
+    for a, b in zip(got, [p.grad for p in seq.parameters()] + [x.grad]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * b.abs().max().item())
