@@ -114,6 +114,12 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
     for (int i = 0; i < LP; ++i) aw[i] *= inv;
   }
   const float4 g = *reinterpret_cast<const float4*>(p.grad_out + (size_t)bq * kBC + lane * 4);
+  // the same row again, lane-contiguous: channel 64 i + lane.  The atomic adds into grad_value use THIS mapping, so one
+  // wave instruction covers whole 128-byte lines (64 consecutive channels of a pixel row) instead of 8 dwords in each
+  // of 8 lines: a quarter of the L2 atomic requests.
+  float gl4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gl4[i] = p.grad_out[(size_t)bq * kBC + 64 * i + lane];
 
   float ga[LP];                                    // dL/d a (before the softmax backward), this head
   float gpt[kBP][3];                               // dL/d (metre point) of this head's points
@@ -153,13 +159,15 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
 
 #pragma unroll
     for (int k = 0; k < kBP; ++k) {
-      if (!vis[k]) continue;                         // divergent per head group
+      if (!__any(vis[k])) continue;                  // wave-uniform; heads that do not see the point run with ok = false
+      const bool vk = vis[k];
+      const float uk = vk ? u[k] : 0.5f, vvk = vk ? v[k] : 0.5f;
       float gu = 0.f, gv = 0.f;                      // dL/du, dL/dv (before cw), accumulated over levels
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         const int W = p.lvl_w[l], H = p.lvl_h[l];
-        const float x = fmaf(u[k], (float)W, -0.5f);
-        const float y = fmaf(v[k], (float)H, -0.5f);
+        const float x = fmaf(uk, (float)W, -0.5f);
+        const float y = fmaf(vvk, (float)H, -0.5f);
         const float xf = floorf(x), yf = floorf(y);
         const float dx = x - xf, dy = y - yf;
         const int x0 = (int)xf, y0 = (int)yf;
@@ -167,18 +175,24 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
         const float a = aw[l * kBP + k];
         const float wq = cw * a;                     // weight of this (camera, level, point) on out
         float d[4] = {0.f, 0.f, 0.f, 0.f};            // <g_h, v_corner>
-        const bool ok[4] = {x0ok && y0ok, x1ok && y0ok, x0ok && y1ok, x1ok && y1ok};
+        const bool ok[4] = {vk && x0ok && y0ok, vk && x1ok && y0ok, vk && x0ok && y1ok, vk && x1ok && y1ok};
         const float bw[4] = {(1.f - dx) * (1.f - dy), dx * (1.f - dy), (1.f - dx) * dy, dx * dy};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          const int pix = ok[c] ? p.lvl_start[l] + (y0 + (c >> 1)) * W + (x0 + (c & 1)) : -1;   // head-group uniform
           if (ok[c]) {
-            const size_t pix = (size_t)p.lvl_start[l] + (size_t)(y0 + (c >> 1)) * W + (x0 + (c & 1));
-            const float4 val = *reinterpret_cast<const float4*>(vrow + pix * kBC + lane * 4);
+            const float4 val = *reinterpret_cast<const float4*>(vrow + (size_t)pix * kBC + lane * 4);
             d[c] = (g.x * val.x + g.y * val.y) + (g.z * val.z + g.w * val.w);
-            float* gdst = gvrow + pix * kBC + lane * 4;
-            const float s = wq * bw[c];
-            atomicAdd(gdst + 0, s * g.x); atomicAdd(gdst + 1, s * g.y);
-            atomicAdd(gdst + 2, s * g.z); atomicAdd(gdst + 3, s * g.w);
+          }
+          const float s = wq * bw[c];
+          // scatter: instruction i adds channels [64 i, 64 i + 64) of this corner's pixel rows; lane -> channel
+          // 64 i + lane, whose head's pixel and weight come from that head's lane group
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int src = ((64 * i + lane) / DH) * LPH;
+            const int hp = __shfl(pix, src);
+            const float hs = __shfl(s, src);
+            if (hp >= 0) atomicAdd(gvrow + (size_t)hp * kBC + 64 * i + lane, hs * gl4[i]);
           }
         }
 #pragma unroll
@@ -193,8 +207,8 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
         gv += a * dTdy * (float)H;
       }
       gu *= cw; gv *= cw;
-      // u = cx / (cz * Wimg), v = cy / (cz * Himg)   (cz > eps for visible points)
-      const float iz = 1.0f / czv[k];
+      // u = cx / (cz * Wimg), v = cy / (cz * Himg)   (cz > eps for visible points; gu = gv = 0 for the others)
+      const float iz = vk ? 1.0f / czv[k] : 0.f;
       const float gcx = gu * iz / p.img_w;
       const float gcy = gv * iz / p.img_h;
       const float gcz = -(gu * cxv[k] * iz * iz / p.img_w + gv * cyv[k] * iz * iz / p.img_h);
