@@ -629,3 +629,106 @@ def _z_positive(points, lidar2img, eps=1e-5):
     hom = torch.cat((points, torch.ones_like(points[..., :1])), -1).view(b, 1, m, 4).repeat(1, n, 1, 1).unsqueeze(-1)
     cam = torch.matmul(lidar2img.view(b, n, 1, 4, 4).repeat(1, 1, m, 1, 1), hom).squeeze(-1)
     return cam[..., 2] > eps
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Head loss: Hungarian assignment + per-layer focal / L1 losses.  Test infrastructure only.
+# ----------------------------------------------------------------------------------------------------------------------
+def normalize_bbox(bboxes):
+    """core/bbox/util.py:38-58: (cx, cy, cz, w, l, h, rot[, vx, vy]) -> (cx, cy, log w, log l, cz, log h, sin, cos[, vx, vy])."""
+    parts = [bboxes[..., 0:1], bboxes[..., 1:2], bboxes[..., 3:4].log(), bboxes[..., 4:5].log(), bboxes[..., 2:3],
+             bboxes[..., 5:6].log(), bboxes[..., 6:7].sin(), bboxes[..., 6:7].cos()]
+    if bboxes.size(-1) > 7:
+        parts += [bboxes[..., 7:8], bboxes[..., 8:9]]
+    return torch.cat(parts, dim=-1)
+
+
+def focal_loss_cost(cls_pred, gt_labels, weight=2.0, alpha=0.25, gamma=2.0, eps=1e-12):
+    """mmdet 2.x FocalLossCost (third-party, absent from /root/reference; published definition): (Q, C) logits and (G,)
+    labels -> (Q, G).  Config: ...ceph.py:133 (`cls_cost=dict(type='FocalLossCost', weight=2.0)`)."""
+    p = cls_pred.sigmoid()
+    neg = -(1 - p + eps).log() * (1 - alpha) * p.pow(gamma)
+    pos = -(p + eps).log() * alpha * (1 - p).pow(gamma)
+    return (pos[:, gt_labels] - neg[:, gt_labels]) * weight
+
+
+def hungarian_cost(bbox_pred, cls_pred, gt_bboxes, gt_labels, cls_weight=2.0, reg_weight=0.25):
+    """hungarian_assigner_3d.py:117-130 with BBox3DL1Cost (match_costs/match_cost.py:17-30): the (Q, G) matrix handed to
+    scipy, non-finite entries replaced (nan / +inf -> 100, -inf -> -100)."""
+    cost = focal_loss_cost(cls_pred, gt_labels, cls_weight) + \
+        torch.cdist(bbox_pred[:, :8], normalize_bbox(gt_bboxes)[:, :8], p=1) * reg_weight
+    return torch.nan_to_num(cost.detach().cpu(), nan=100.0, posinf=100.0, neginf=-100.0)
+
+
+def hungarian_assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, cls_weight=2.0, reg_weight=0.25):
+    """HungarianAssigner3D.assign (hungarian_assigner_3d.py:62-144): assigned_gt_inds (Q,) long, 0 = background,
+    g + 1 = matched to ground truth g."""
+    from scipy.optimize import linear_sum_assignment
+    q, g = bbox_pred.size(0), gt_bboxes.size(0)
+    inds = bbox_pred.new_zeros(q, dtype=torch.long)
+    if g == 0 or q == 0:
+        return inds
+    rows, cols = linear_sum_assignment(hungarian_cost(bbox_pred, cls_pred, gt_bboxes, gt_labels, cls_weight, reg_weight))
+    inds[torch.from_numpy(rows)] = torch.from_numpy(cols) + 1
+    return inds
+
+
+def sigmoid_focal_loss_sum(pred, labels, num_classes, alpha=0.25, gamma=2.0):
+    """mmdet FocalLoss(use_sigmoid=True) before weighting / normalisation (published python path): labels ==
+    num_classes are background."""
+    t = F.one_hot(labels, num_classes=num_classes + 1)[:, :num_classes].type_as(pred)
+    p = pred.sigmoid()
+    pt = (1 - p) * t + p * (1 - t)
+    w = (alpha * t + (1 - alpha) * (1 - t)) * pt.pow(gamma)
+    return (F.binary_cross_entropy_with_logits(pred, t, reduction='none') * w).sum()
+
+
+def head_loss_single(cls_scores, bbox_preds, gt_bboxes_list, gt_labels_list, code_weights, num_classes=10,
+                     cls_cost_weight=2.0, reg_cost_weight=0.25, loss_cls_weight=2.0, loss_bbox_weight=0.25,
+                     bg_cls_weight=0.0, world_mean=lambda t: t):
+    """Detr3DHeadPE.loss_single (detr3d_head_pe.py:782-845) with get_targets / _get_target_single (:688-780):
+    cls_scores (B, Q, C), bbox_preds (B, Q, 10), per-sample ground truth (G_b, 9) / (G_b,).  `world_mean` stands for
+    mmdet's reduce_mean (identity in one process).  Returns (loss_cls, loss_bbox, assigned list)."""
+    b, q, c = cls_scores.shape
+    labels, targets, weights, assigned = [], [], [], []
+    num_pos = num_neg = 0
+    for i in range(b):
+        inds = hungarian_assign(bbox_preds[i], cls_scores[i], gt_bboxes_list[i], gt_labels_list[i], cls_cost_weight,
+                                reg_cost_weight)
+        assigned.append(inds)
+        pos = inds > 0
+        lab = gt_labels_list[i].new_full((q,), num_classes, dtype=torch.long)
+        lab[pos] = gt_labels_list[i][inds[pos] - 1].long()
+        tgt = torch.zeros_like(bbox_preds[i])[..., :gt_bboxes_list[i].size(1)]
+        tgt[pos] = gt_bboxes_list[i][inds[pos] - 1]
+        w = torch.zeros_like(bbox_preds[i])
+        w[pos] = 1.0
+        labels.append(lab); targets.append(tgt); weights.append(w)
+        num_pos += int(pos.sum()); num_neg += int((~pos).sum())
+    labels, targets, weights = torch.cat(labels), torch.cat(targets), torch.cat(weights)
+    cls_avg = world_mean(cls_scores.new_tensor([num_pos * 1.0 + num_neg * bg_cls_weight]))
+    cls_avg = max(cls_avg, 1)
+    loss_cls = loss_cls_weight * sigmoid_focal_loss_sum(cls_scores.reshape(-1, c), labels, num_classes) / cls_avg
+    pos_avg = torch.clamp(world_mean(loss_cls.new_tensor([num_pos])), min=1).item()
+    pred = bbox_preds.reshape(-1, bbox_preds.size(-1))
+    norm = normalize_bbox(targets)
+    ok = torch.isfinite(norm).all(dim=-1)
+    weights = weights * code_weights
+    if ok.any():
+        loss_bbox = loss_bbox_weight * ((pred[ok, :10] - norm[ok, :10]).abs() * weights[ok, :10]).sum() / pos_avg
+    else:
+        loss_bbox = pred.sum() * 0
+    return torch.nan_to_num(loss_cls).reshape(()), torch.nan_to_num(loss_bbox).reshape(()), assigned
+
+
+def head_loss(all_cls_scores, all_bbox_preds, gt_bboxes_list, gt_labels_list, code_weights, **kw):
+    """Detr3DHeadPE.loss (detr3d_head_pe.py:1014-1094) without the two-stage branch: loss_single per decoder layer; the
+    last layer's terms are `loss_cls` / `loss_bbox`, the others `d{i}.loss_cls` / `d{i}.loss_bbox`."""
+    out, per_layer = {}, []
+    for l in range(all_cls_scores.shape[0]):
+        per_layer.append(head_loss_single(all_cls_scores[l], all_bbox_preds[l], gt_bboxes_list, gt_labels_list,
+                                          code_weights, **kw))
+    out['loss_cls'], out['loss_bbox'] = per_layer[-1][0], per_layer[-1][1]
+    for i, (lc, lb, _) in enumerate(per_layer[:-1]):
+        out[f'd{i}.loss_cls'], out[f'd{i}.loss_bbox'] = lc, lb
+    return out, [p[2] for p in per_layer]

@@ -14,6 +14,7 @@ around 1 MB, is exact in fp32 AND in bf16 (features), and is platform independen
 import json
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -515,6 +516,93 @@ def case_head_pe(name, *, frames, img_hw, pad_hw, strides, seed, depth_num=64, n
     save(name, meta, **arrays)
 
 
+def case_head_loss(name, *, num_query, gts, seed, num_layers=3, degenerate=False):
+    """Training-side step after the path: the reference's own `Detr3DHeadPE.loss`
+    (dense_heads/detr3d_head_pe.py:1014-1094) -> `loss_single` (:782-845) -> `get_targets` / `_get_target_single`
+    (:688-780) -> `HungarianAssigner3D.assign` (core/bbox/assigners/hungarian_assigner_3d.py:62-144) with `BBox3DL1Cost`
+    (core/bbox/match_costs/match_cost.py:7-30) and `normalize_bbox` (core/bbox/util.py:38-58), run unmodified on a
+    shell object.  Captured: the cost matrix handed to scipy per (layer, sample), the assignment, every loss term and
+    the gradient of their sum with respect to the head outputs.  gts: ground-truth count per sample."""
+    head_mod, asg_mod = refstub.load_head_loss()
+    g = torch.Generator().manual_seed(seed)
+    batch = len(gts)
+    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    cls = (torch.randn(num_layers, batch, num_query, 10, generator=g) * 2 - 2).requires_grad_()
+    box = torch.randn(num_layers, batch, num_query, 10, generator=g)
+    box[..., 0:2] *= 30.
+    box = box.requires_grad_()
+    gt_boxes, gt_labels = [], []
+    for n in gts:
+        b = torch.randn(n, 9, generator=g)
+        b[:, 0:2] *= 30.                                   # centre x, y (metres)
+        b[:, 3:6] = b[:, 3:6].abs() * 2 + 0.3               # w, l, h > 0
+        if degenerate and n > 1:
+            b[1, 3] = 0.                                    # log(0) = -inf: cost 100 after nan_to_num, excluded from the L1 loss
+        gt_boxes.append(b)
+        gt_labels.append(torch.randint(0, 10, (n,), generator=g))
+
+    class Boxes:                                            # what `loss` reads of LiDARInstance3DBoxes (:1059-1061)
+        def __init__(self, t):
+            self.gravity_center, self.tensor = t[:, :3], t
+
+    class Shell(nn.Module):                                 # the attributes loss / loss_single / _get_target_single read
+        def __init__(self):
+            super().__init__()
+            self.num_classes = self.cls_out_channels = 10
+            self.bg_cls_weight, self.sync_cls_avg_factor = 0.0, True
+            self.pc_range = pc_range
+            self.code_weights = nn.Parameter(torch.tensor([1., 1., 1., 1., 1., 1., 1., 1., 0.2, 0.2]), requires_grad=False)
+            self.assigner = asg_mod.HungarianAssigner3D(cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                                        reg_cost=dict(type='BBox3DL1Cost', weight=0.25),
+                                                        iou_cost=dict(type='IoUCost', weight=0.0), pc_range=pc_range)
+            self.sampler = refstub.PseudoSampler()
+            self.loss_cls = refstub.FocalLoss(gamma=2.0, alpha=0.25, loss_weight=2.0)
+            self.loss_bbox = refstub.L1Loss(loss_weight=0.25)
+    shell = Shell()
+    for fn in ('loss_single', 'get_targets', '_get_target_single'):
+        setattr(shell, fn, types.MethodType(getattr(head_mod.Detr3DHeadPE, fn), shell))
+    costs, assigned = [], []
+    real_lsa = asg_mod.linear_sum_assignment
+
+    def spy(cost):
+        costs.append(cost.clone())
+        return real_lsa(cost)
+    real_assign = shell.assigner.assign
+
+    def assign_spy(*a, **k):
+        r = real_assign(*a, **k)
+        assigned.append(r.gt_inds.clone())
+        return r
+    asg_mod.linear_sum_assignment = spy
+    shell.assigner.assign = assign_spy
+    try:
+        loss_fn = getattr(head_mod.Detr3DHeadPE.loss, '__wrapped__', head_mod.Detr3DHeadPE.loss)
+        losses = loss_fn(shell, [Boxes(b) for b in gt_boxes], gt_labels,
+                         dict(all_cls_scores=cls, all_bbox_preds=box, enc_cls_scores=None, enc_bbox_preds=None))
+    finally:
+        asg_mod.linear_sum_assignment = real_lsa
+    total = sum(losses.values())
+    total.backward()
+    arrays = dict(all_cls_scores=cls.detach(), all_bbox_preds=box.detach(), grad_cls=cls.grad, grad_box=box.grad)
+    for b in range(batch):
+        arrays[f'gt_boxes{b}'] = gt_boxes[b]
+        arrays[f'gt_labels{b}'] = gt_labels[b]
+    ci = 0
+    for l in range(num_layers):
+        for b in range(batch):
+            arrays[f'assigned_l{l}_b{b}'] = assigned[l * batch + b]
+            if gts[b] > 0:
+                arrays[f'cost_l{l}_b{b}'] = costs[ci]
+                ci += 1
+    for k, v in losses.items():
+        arrays['loss.' + k] = v.detach()
+    meta = dict(kind='head_loss', pc_range=pc_range, num_layers=num_layers, batch=batch, gts=list(gts),
+                loss_keys=list(losses.keys()), cls_cost_weight=2.0, reg_cost_weight=0.25, loss_cls_weight=2.0,
+                loss_bbox_weight=0.25, alpha=0.25, gamma=2.0,
+                code_weights=[1., 1., 1., 1., 1., 1., 1., 1., 0.2, 0.2])
+    save(name, meta, **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     case_deform('deform_n6', num_query=48, frames=1, batch=1, img_hw=(128, 224), seed=101)
@@ -541,6 +629,9 @@ def main():
     case_decode('decode', num_query=90, batch=2, seed=501, max_num=300)
     case_decode('decode_thr', num_query=64, batch=1, seed=502, max_num=100, score_threshold=0.2)
     case_decode('decode_code8', num_query=20, batch=1, seed=503, max_num=100, code_size=8)
+    case_head_loss('head_loss', num_query=60, gts=(7,), seed=701)
+    case_head_loss('head_loss_b2', num_query=40, gts=(5, 0), seed=702, num_layers=2)
+    case_head_loss('head_loss_degenerate', num_query=30, gts=(6,), seed=703, num_layers=2, degenerate=True)
 
 
 if __name__ == '__main__':

@@ -503,3 +503,127 @@ def load_head_pe():
         head = importlib.import_module('projects.mmdet3d_plugin.models.dense_heads.detr3d_head_pe')
         pe = importlib.import_module('projects.mmdet3d_plugin.models.utils.positional_encoding')
     return head, pe
+
+
+# --------------------------------------------------------------------------------------
+# head loss: Hungarian assignment + the per-layer loss with its normalisers
+# --------------------------------------------------------------------------------------
+MATCH_COST = Registry('match cost')
+BBOX_ASSIGNERS = Registry('bbox assigner')
+
+
+class FocalLossCost:
+    """mmdet 2.x `FocalLossCost` (third-party, not under /root/reference), restated from its published definition:
+    cost[q, g] = (pos(p[q, label_g]) - neg(p[q, label_g])) * weight with p = sigmoid(logit),
+    neg = -log(1 - p + eps) (1 - alpha) p^gamma, pos = -log(p + eps) alpha (1 - p)^gamma."""
+
+    def __init__(self, weight=1., alpha=0.25, gamma=2, eps=1e-12):
+        self.weight, self.alpha, self.gamma, self.eps = weight, alpha, gamma, eps
+
+    def __call__(self, cls_pred, gt_labels):
+        cls_pred = cls_pred.sigmoid()
+        neg_cost = -(1 - cls_pred + self.eps).log() * (1 - self.alpha) * cls_pred.pow(self.gamma)
+        pos_cost = -(cls_pred + self.eps).log() * self.alpha * (1 - cls_pred).pow(self.gamma)
+        cls_cost = pos_cost[:, gt_labels] - neg_cost[:, gt_labels]
+        return cls_cost * self.weight
+
+
+class IoUCost:
+    """Placeholder of the config's `IoUCost(weight=0.0)` ("fake cost", never called by HungarianAssigner3D.assign)."""
+
+    def __init__(self, iou_mode='giou', weight=1.):
+        self.weight = weight
+
+
+class AssignResult:
+    """mmdet `AssignResult`: a record of (num_gts, gt_inds, max_overlaps, labels)."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+class PseudoSampler:
+    """mmdet `PseudoSampler`: positives = assigned (> 0), negatives = background (== 0), no sampling."""
+
+    def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        res = types.SimpleNamespace()
+        res.pos_inds, res.neg_inds = pos_inds, neg_inds
+        res.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        res.pos_gt_bboxes = gt_bboxes.view(-1, gt_bboxes.shape[-1])[res.pos_assigned_gt_inds.long(), :]
+        return res
+
+
+def _weight_reduce_mean(loss, weight, avg_factor):
+    """mmdet `weight_reduce_loss(..., reduction='mean', avg_factor)`: sum(loss * weight) / avg_factor."""
+    if weight is not None:
+        loss = loss * weight
+    return loss.sum() / avg_factor
+
+
+class FocalLoss(nn.Module):
+    """mmdet 2.x `FocalLoss(use_sigmoid=True)`, restated from its published python path (`py_sigmoid_focal_loss`):
+    BCE-with-logits(pred, one-hot) * (alpha t + (1 - alpha)(1 - t)) * pt^gamma, pt = (1 - p) t + p (1 - t);
+    labels == num_classes are background (all-zero target row)."""
+
+    def __init__(self, gamma=2.0, alpha=0.25, loss_weight=1.0):
+        super().__init__()
+        self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        num_classes = pred.size(1)
+        t = F.one_hot(target, num_classes=num_classes + 1)[:, :num_classes].type_as(pred)
+        p = pred.sigmoid()
+        pt = (1 - p) * t + p * (1 - t)
+        focal_weight = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)
+        loss = F.binary_cross_entropy_with_logits(pred, t, reduction='none') * focal_weight
+        if weight is not None:
+            weight = weight.view(-1, 1)
+        return self.loss_weight * _weight_reduce_mean(loss, weight, avg_factor)
+
+
+class L1Loss(nn.Module):
+    """mmdet `L1Loss`: loss_weight * sum(|pred - target| * weight) / avg_factor (zero when there is no target)."""
+
+    def __init__(self, loss_weight=1.0):
+        super().__init__()
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        if target.numel() == 0:
+            return pred.sum() * 0
+        return self.loss_weight * _weight_reduce_mean((pred - target).abs(), weight, avg_factor)
+
+
+def multi_apply(func, *args, **kwargs):
+    """mmdet `multi_apply`: map, then transpose the tuple of results."""
+    results = map(lambda *a: func(*a, **kwargs), *args)
+    return tuple(map(list, zip(*results)))
+
+
+def load_head_loss():
+    """Import the reference's Detr3DHeadPE (for `loss`, `loss_single`, `get_targets`, `_get_target_single`), its
+    `HungarianAssigner3D` and `BBox3DL1Cost` unmodified.  The mmdet pieces they call (FocalLossCost, AssignResult,
+    PseudoSampler, FocalLoss, L1Loss, multi_apply, reduce_mean) are third-party and absent from /root/reference: they are
+    restated above from their published definitions (single process: reduce_mean is the identity).
+    Returns (head module, assigner module)."""
+    head, _ = load_head_pe()
+    head.multi_apply = multi_apply
+    head.reduce_mean = lambda t: t
+    MATCH_COST.register_module(module=FocalLossCost)
+    MATCH_COST.register_module(module=IoUCost)
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=BBOX_CODERS, BBOX_ASSIGNERS=BBOX_ASSIGNERS)
+    _mod('mmdet.core.bbox.assigners', AssignResult=AssignResult, BaseAssigner=object)
+    _mod('mmdet.core.bbox.match_costs', build_match_cost=lambda cfg: MATCH_COST.build(cfg))
+    _mod('mmdet.core.bbox.match_costs.builder', MATCH_COST=MATCH_COST)
+    _mod('mmdet.core.bbox.iou_calculators', bbox_overlaps=None)
+    for sub in ('assigners', 'match_costs'):
+        full = f'projects.mmdet3d_plugin.core.bbox.{sub}'
+        if full not in sys.modules:
+            m = types.ModuleType(full)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, *full.split('.'))]
+            sys.modules[full] = m
+    importlib.import_module('projects.mmdet3d_plugin.core.bbox.match_costs.match_cost')     # registers BBox3DL1Cost
+    asg = importlib.import_module('projects.mmdet3d_plugin.core.bbox.assigners.hungarian_assigner_3d')
+    return head, asg
