@@ -591,3 +591,38 @@ def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
         None if query_order is None else _order_ptr(query_order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_bwd')
     return gv, gr, go, ga, gc
+
+
+def match_cost_fwd(cls, box, gt_boxes, gt_labels, gt_start, max_gt, cls_weight=2.0, reg_weight=0.25, alpha=0.25):
+    """gd4d_match_cost_fwd.  cls (NL, B, Q, C), box (NL, B, Q, code) fp32; gt_boxes (sumG, 7..9) fp32, gt_labels (sumG)
+    int32, gt_start (B + 1) int32 - all on the GPU; max_gt = largest per-sample count.  Returns the flat cost buffer
+    (NL * Q * sumG): block (l, b) at Q * (l * sumG + gt_start[b]), shape (Q, G_b)."""
+    lib = _lib.load()
+    f32, i32 = torch.float32, torch.int32
+    nl, b, q, c = cls.shape
+    sum_gt = gt_boxes.shape[0]
+    cost = torch.empty(nl * q * sum_gt, device=cls.device, dtype=f32)
+    code = lib.gd4d_match_cost_fwd(_dev(cls, 'cls', f32), _dev(box, 'box', f32), _dev(gt_boxes, 'gt_boxes', f32),
+                                   _dev(gt_labels, 'gt_labels', i32), _dev(gt_start, 'gt_start', i32),
+                                   _dev(cost, 'cost'), nl, b, q, c, box.shape[-1], gt_boxes.shape[-1], sum_gt,
+                                   int(max_gt), float(cls_weight), float(reg_weight), float(alpha), _stream())
+    _lib.check(code, 'gd4d_match_cost_fwd')
+    return cost
+
+
+def head_loss_fwd_bwd(cls, box, assigned, gt_boxes, gt_labels, code_weights, avg_factors, alpha=0.25,
+                      loss_cls_weight=2.0, loss_bbox_weight=0.25):
+    """gd4d_head_loss_fwd_bwd.  Returns (loss (NL, 2), grad_cls like cls, grad_box like box)."""
+    lib = _lib.load()
+    f32, i32 = torch.float32, torch.int32
+    nl, b, q, c = cls.shape
+    loss = torch.empty(nl, 2, device=cls.device, dtype=f32)
+    gcls, gbox = torch.empty_like(cls), torch.empty_like(box)
+    code = lib.gd4d_head_loss_fwd_bwd(_dev(cls, 'cls', f32), _dev(box, 'box', f32), _dev(assigned, 'assigned', i32),
+                                      _dev(gt_boxes, 'gt_boxes', f32), _dev(gt_labels, 'gt_labels', i32),
+                                      _dev(code_weights, 'code_weights', f32), _dev(avg_factors, 'avg_factors', f32),
+                                      _dev(loss, 'loss'), _dev(gcls, 'grad_cls'), _dev(gbox, 'grad_box'), nl, b, q, c,
+                                      box.shape[-1], gt_boxes.shape[-1], float(alpha), float(loss_cls_weight),
+                                      float(loss_bbox_weight), _stream())
+    _lib.check(code, 'gd4d_head_loss_fwd_bwd')
+    return loss, gcls, gbox

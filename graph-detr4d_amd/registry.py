@@ -67,6 +67,7 @@ TRANSFORMER_LAYER_SEQUENCE = Registry('transformer-layers sequence',
                                       _mmcv('mmcv.cnn.bricks.registry.TRANSFORMER_LAYER_SEQUENCE'))
 TRANSFORMER = Registry('transformer', _mmcv('mmdet.models.utils.builder.TRANSFORMER'))
 BBOX_CODERS = Registry('bbox coder', _mmcv('mmdet.core.bbox.builder.BBOX_CODERS'))
+BBOX_ASSIGNERS = Registry('bbox assigner', _mmcv('mmdet.core.bbox.builder.BBOX_ASSIGNERS'))
 
 
 def build_attention(cfg, default_args=None):
@@ -87,3 +88,7 @@ def build_transformer(cfg, default_args=None):
 
 def build_bbox_coder(cfg, default_args=None):
     return build_from_cfg(cfg, BBOX_CODERS, default_args)
+
+
+def build_assigner(cfg, default_args=None):
+    return build_from_cfg(cfg, BBOX_ASSIGNERS, default_args)

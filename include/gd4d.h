@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 11
+#define GD4D_ABI_VERSION 12
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -431,6 +431,33 @@ int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, const float*
                         float* grad_cam_logits, int B, int N, int Q, int Hh, int Dh, int L, int P,
                         int value_dtype, int value_layout, const int32_t* query_order,
                        void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Training-side step right after the path: HungarianAssigner3D's cost matrix and the per-layer
+ * losses of Detr3DHeadPE.loss_single for ALL decoder layers at once, so that a step has one device -> host copy (the
+ * cost matrices; the assignment itself runs on the host like the reference's scipy call), one host -> device copy and
+ * no .item().
+ *
+ * gd4d_match_cost_fwd - cost[l][b] (Q, G_b) = FocalLossCost(cls)[q, label_g] * cls_weight
+ *                       + sum_{k<8} |box[q,k] - normalize_bbox(gt)[g,k]| * reg_weight, then nan_to_num(100, 100, -100)
+ *   (core/bbox/assigners/hungarian_assigner_3d.py:117-130, core/bbox/match_costs/match_cost.py:17-30,
+ *    core/bbox/util.py:38-58; FocalLossCost is mmdet's: alpha, gamma = 2, eps = 1e-12.)
+ *   cls (NL, B, Q, C) logits; box (NL, B, Q, code >= 8); gt_boxes (sum_gt, gt_dim in 7..9) gravity-centre boxes
+ *   (cx, cy, cz, w, l, h, rot[, vx, vy]); gt_labels (sum_gt) int32; gt_start DEVICE (B + 1) int32 prefix offsets;
+ *   cost: block (l, b) at element offset Q * (l * sum_gt + gt_start[b]), row-major (Q, G_b).  max_gt = max_b G_b <= 1024.
+ *
+ * gd4d_head_loss_fwd_bwd - loss (NL, 2) = (loss_cls, loss_bbox) per decoder layer and their gradients
+ *   (dense_heads/detr3d_head_pe.py:782-845 with :700-742; mmdet FocalLoss(use_sigmoid, gamma = 2, alpha) and L1Loss):
+ *   assigned (NL, B, Q) int32 = index into gt_boxes / gt_labels or -1 for background; code_weights (10);
+ *   avg_factors DEVICE 2 floats (cls_avg_factor, num_total_pos: the two all-reduced normalisers, clamped to >= 1 here);
+ *   grad_cls / grad_box = d(loss_cls[l]) / d cls[l], d(loss_bbox[l]) / d box[l]. */
+int gd4d_match_cost_fwd(const float* cls, const float* box, const float* gt_boxes, const int32_t* gt_labels,
+                        const int32_t* gt_start, float* cost, int NL, int B, int Q, int C, int code, int gt_dim,
+                        int sum_gt, int max_gt, float cls_weight, float reg_weight, float alpha, void* stream);
+int gd4d_head_loss_fwd_bwd(const float* cls, const float* box, const int32_t* assigned, const float* gt_boxes,
+                           const int32_t* gt_labels, const float* code_weights, const float* avg_factors, float* loss,
+                           float* grad_cls, float* grad_box, int NL, int B, int Q, int C, int code, int gt_dim,
+                           float alpha, float loss_cls_weight, float loss_bbox_weight, void* stream);
 
 #ifdef __cplusplus
 }
