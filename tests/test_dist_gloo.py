@@ -86,8 +86,20 @@ def _grad_worker(rank, world, port, q):
     local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
     red = D.FlatGradAllReducer(net.parameters())
     extras = red.reduce(extras=torch.tensor([float(rank + 1), 10.0]))
-    q.put((rank, [None if g is None else g.numpy() for g in local],
-           [None if p.grad is None else p.grad.numpy() for p in net.parameters()], extras.numpy(), red.bytes_per_step()))
+    first = [None if p.grad is None else p.grad.numpy().copy() for p in net.parameters()]
+    # second step: .grad is now a view of the flat buffer - zero_grad is one fill, autograd accumulates in place
+    bound = [p.grad for p in net.parameters() if p.requires_grad]
+    red.zero_grad()
+    assert all(float(g.abs().sum()) == 0.0 for g in bound)
+    net(x).sum().backward()
+    assert all(p.grad is g for p, g in zip((p for p in net.parameters() if p.requires_grad), bound))
+    red.reduce()
+    second = [None if p.grad is None else p.grad.numpy().copy() for p in net.parameters()]
+    # the head loss's normalisers: one 2-element all-reduce (mean over the ranks)
+    from graph_detr4d_amd.criterion import Detr3DCriterion
+    avg = Detr3DCriterion().normalisers([3 + 4 * rank], 900, torch.device('cpu'))
+    q.put((rank, [None if g is None else g.numpy() for g in local], first, extras.numpy(), red.bytes_per_step(),
+           second, avg.numpy()))
     D.shutdown()
 
 
@@ -104,7 +116,15 @@ def test_flat_gradient_allreduce_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, loc0, avg0, ex0, nbytes), (_, loc1, avg1, ex1, _) = res
+    (_, loc0, avg0, ex0, nbytes, sec0, norm0), (_, loc1, avg1, ex1, _, sec1, norm1) = res
+    np.testing.assert_allclose(norm0, [5.0, 5.0])             # (3 + 7) / 2 positives, bg_cls_weight = 0
+    np.testing.assert_allclose(norm1, [5.0, 5.0])
+    for s0, s1, l0, l1 in zip(sec0, sec1, loc0, loc1):
+        if s0 is None:
+            continue
+        np.testing.assert_array_equal(s0, s1)
+        if l0 is not None and l1 is not None:                 # second step: every parameter has a gradient again
+            np.testing.assert_allclose(s0, (l0 + l1) / 2, rtol=1e-6)
     assert nbytes == (8 * 16 + 16 + 16 * 4) * 4             # frozen bias excluded
     for a0, a1, l0, l1 in zip(avg0, avg1, loc0, loc1):
         if a0 is None:                                        # the frozen parameter

@@ -128,3 +128,44 @@ def test_full_size_one_sync_step():
         torch.testing.assert_close(losses[k].cpu(), want[k], rtol=1e-5, atol=1e-6)
     sum(losses.values()).backward()
     assert torch.isfinite(cls.grad).all() and torch.isfinite(box.grad).all() and box.grad.abs().sum() > 0
+
+
+def test_head_epilogue_and_loss_train_end_to_end():
+    """hs -> cls / reg branches -> box epilogue (functional.head_outputs, autograd path) -> Detr3DCriterion -> backward,
+    against the oracle's box_head + head_loss with torch autograd on the CPU."""
+    import copy
+    from graph_detr4d_amd import Detr3DCriterion
+    from graph_detr4d_amd import functional as Fn
+    torch.manual_seed(9)
+    nl, q, c = 2, 50, 256
+    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    mk_cls = lambda: torch.nn.Sequential(torch.nn.Linear(c, c), torch.nn.LayerNorm(c), torch.nn.ReLU(inplace=True),
+                                         torch.nn.Linear(c, 10))
+    mk_reg = lambda: torch.nn.Sequential(torch.nn.Linear(c, c), torch.nn.ReLU(), torch.nn.Linear(c, 10))
+    cls_b = torch.nn.ModuleList(mk_cls() for _ in range(nl))
+    reg_b = torch.nn.ModuleList(mk_reg() for _ in range(nl))
+    hs = torch.randn(nl, q, 1, c)
+    init_ref, inter_ref = torch.rand(1, q, 3), torch.rand(nl, 1, q, 3)
+    gt = torch.randn(6, 9)
+    gt[:, 0:2] *= 30.
+    gt[:, 3:6] = gt[:, 3:6].abs() * 2 + 0.3
+    lab = torch.randint(0, 10, (6,))
+    # oracle on the CPU
+    hs_c = hs.clone().requires_grad_()
+    cls_c, reg_c = copy.deepcopy(cls_b), copy.deepcopy(reg_b)
+    x = hs_c.permute(0, 2, 1, 3)
+    all_cls = torch.stack([cls_c[l](x[l]) for l in range(nl)])
+    all_box = torch.stack([O.box_head(reg_c[l](x[l]), init_ref if l == 0 else inter_ref[l - 1], pc_range) for l in range(nl)])
+    want, _ = O.head_loss(all_cls, all_box, [gt], [lab], torch.tensor([1.] * 8 + [.2, .2]))
+    sum(want.values()).backward()
+    # product path on the GPU
+    hs_g = hs.cuda().requires_grad_()
+    cls_g, reg_g = cls_b.cuda(), reg_b.cuda()
+    outs = Fn.head_outputs(hs_g, init_ref.cuda(), inter_ref.cuda(), cls_g, reg_g, pc_range)
+    got = Detr3DCriterion().cuda().loss([gt.cuda()], [lab.cuda()], outs)
+    for k in want:
+        torch.testing.assert_close(got[k].cpu(), want[k].detach(), rtol=1e-4, atol=1e-5)
+    sum(got.values()).backward()
+    torch.testing.assert_close(hs_g.grad.cpu(), hs_c.grad, rtol=1e-3, atol=1e-6)
+    for pg, pc in zip(list(cls_g.parameters()) + list(reg_g.parameters()), list(cls_c.parameters()) + list(reg_c.parameters())):
+        torch.testing.assert_close(pg.grad.cpu(), pc.grad, rtol=1e-3, atol=1e-5)
