@@ -46,6 +46,10 @@ def parse():
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'train': forward + backward + one flat RCCL gradient all-reduce + SGD per step (secondary metric)")
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
+    ap.add_argument('--criterion', action='store_true',
+                    help='--mode train: the head (cls / reg branches, box epilogue) and its real loss (Hungarian '
+                         'assignment + focal / L1 terms over all layers) instead of a synthetic loss; eager launch')
+    ap.add_argument('--gts', type=int, default=40, help='--criterion: ground-truth boxes per sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None, help='torch threads of the CPU baseline (default: min(cores, 16), the fastest measured)')
     ap.add_argument('--cpu-layers', type=int, default=None,
@@ -222,17 +226,86 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     The feature pyramid requires grad (it comes from the backbone in the reference's training)."""
     for f in feats:
         f.requires_grad_(True)
-    params = list(tr.parameters()) + list(regs.parameters())
+    crit = cls_branches = None
+    if a.criterion:
+        # the reference's training loss (dense_heads/detr3d_head_pe.py:568-612 + :1014-1094): class branches as in
+        # Detr3DHeadPE._init_layers, synthetic ground truth inside the point-cloud range
+        from graph_detr4d_amd import Detr3DCriterion, synthetic
+        from graph_detr4d_amd import functional as Fn
+        nn = torch.nn
+        torch.manual_seed(77)
+        cls_branches = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True),
+                                                    nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True),
+                                                    nn.Linear(256, 10)) for _ in range(a.layers)]).to(dev)
+        crit = Detr3DCriterion(pc_range=synthetic.PC_RANGE).to(dev)
+        g = torch.Generator().manual_seed(78 + rank)
+        gt = torch.randn(a.gts, 9, generator=g)
+        gt[:, 0:2] *= 25.
+        gt[:, 3:6] = gt[:, 3:6].abs() * 2 + 0.3
+        gt_boxes, gt_labels = [gt.to(dev)], [torch.randint(0, 10, (a.gts,), generator=g).to(dev)]
+    params = list(tr.parameters()) + list(regs.parameters()) + (list(cls_branches.parameters()) if a.criterion else [])
     opt = torch.optim.SGD(params, lr=1e-4)
     reducer = D.FlatGradAllReducer(params)
     tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
+
+    class DecoderAndHead(torch.nn.Module):
+        """query_embed + pyramid -> (all_cls_scores, all_bbox_preds): the part of the step in front of the assignment."""
+
+        def __init__(self):
+            super().__init__()
+            self.tr, self.regs, self.cls_branches = tr, regs, cls_branches
+
+        def forward(self, query_embed, *pyramid):
+            states, init_ref, refs = self.tr(list(pyramid), query_embed, reg_branches=self.regs, img_metas=metas)
+            outs = Fn.head_outputs(states, init_ref, refs, self.cls_branches, self.regs, synthetic.PC_RANGE)
+            return outs['all_cls_scores'], outs['all_bbox_preds']
+
+    front = DecoderAndHead() if a.criterion else None
+    front_launch = 'eager'
+    if a.criterion and not a.no_graph:
+        # The assignment's host round trip cannot sit inside one capture of the whole step, so the part in front of it
+        # and its backward are captured as two hipGraphs (torch.cuda.make_graphed_callables); the loss and its backward
+        # (three launches) run eagerly between them.
+        try:
+            q_in = query_embed.clone().requires_grad_(False)
+            front = torch.cuda.make_graphed_callables(front, (q_in, *feats))
+            front_launch = 'hipgraph (forward, backward) + eager loss'
+        except Exception as e:                        # report, never hide
+            print(f'[bench] hipGraph capture of decoder + head failed ({type(e).__name__}: {e}); running eagerly',
+                  file=sys.stderr)
+            front = DecoderAndHead()
 
     def step():
         reducer.zero_grad()
         for f in feats:
             f.grad = None
-        states, _, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
-        loss = (states ** 2).mean()
+        if os.environ.get('GD4D_BENCH_SPLIT'):       # dev: serialised wall-clock split of the step
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if a.criterion:
+                all_cls, all_box = front(query_embed, *feats)
+            else:
+                states, init_ref, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            if a.criterion:
+                loss = sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box)).values())
+            else:
+                loss = (states ** 2).mean()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            reducer.reduce()
+            opt.step()
+            torch.cuda.synchronize(); t4 = time.perf_counter()
+            print(f'[split] forward {1e3 * (t1 - t0):.2f}  loss {1e3 * (t2 - t1):.2f}  backward {1e3 * (t3 - t2):.2f}  '
+                  f'reduce + SGD {1e3 * (t4 - t3):.2f} ms', file=sys.stderr)
+            return
+        if a.criterion:
+            all_cls, all_box = front(query_embed, *feats)
+            outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box)
+            loss = sum(crit.loss(gt_boxes, gt_labels, outs).values())        # the step's one device synchronisation
+        else:
+            states, init_ref, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
+            loss = (states ** 2).mean()
         loss.backward()
         reducer.reduce()
         opt.step()
@@ -240,11 +313,11 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     # The step is ~2500 launches, most of them small: eagerly it is bound by the host's launch rate, not by the GPU.
     # Capture forward + backward + all-reduce + SGD into one hipGraph (warm-up on a side stream first so that autograd
     # and the allocator have seen every shape), replay it per step.
-    run, launch = step, 'eager'
+    run, launch = step, front_launch
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    if not a.no_graph:
+    if not a.no_graph and not a.criterion:            # the assignment's host round trip cannot sit inside a capture
         try:
             graph = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
@@ -268,7 +341,9 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             'value': D.aggregate_throughput(1, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'training step of the {a.layers}-layer decoder (forward + backward + flat gradient '
+            'config': {'workload': ('training step of the decoder + head with the reference\'s loss (Hungarian assignment, '
+                                    f'{a.gts} boxes; ' if a.criterion else '') +
+                                   f'training step of the {a.layers}-layer decoder (forward + backward + flat gradient '
                                    f'all-reduce of {reducer.bytes_per_step() / 1e6:.1f} MB + SGD), {a.queries} queries, '
                                    f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
                        'launch': launch, 'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},

@@ -200,17 +200,20 @@ def head_outputs(hs, init_reference, inter_references, cls_branches, reg_branche
     if wants_grad(cls_branches, hs) or wants_grad(reg_branches):
         # training: the same arithmetic as torch ops so that autograd sees it (weight gradients of the branches'
         # Linears through gd4d_linear_bwd_weight)
-        lo = hs.new_tensor(pc_range[:3])
-        span = hs.new_tensor(pc_range[3:]) - lo
         scale = 1.0 if depth_factor is None else float(depth_factor)
+        lo = [float(v) for v in pc_range[:3]]
+        span = [float(pc_range[3 + i]) - lo[i] for i in range(3)]       # python scalars: no host -> device copy (graph capture)
         for lvl in range(hs.shape[0]):
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
             x = hs[lvl].contiguous()
             classes.append(sequential_autograd(cls_branches[lvl], x))
             tmp = sequential_autograd(reg_branches[lvl], x)
-            xy = (tmp[..., 0:2] + reference[..., 0:2]).sigmoid() * span[:2] + lo[:2]
-            z = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid() * span[2:3] + lo[2:3]
-            coords.append(torch.cat([xy * scale, tmp[..., 2:4], z * scale, tmp[..., 5:]], dim=-1))
+            sx = (tmp[..., 0:1] + reference[..., 0:1]).sigmoid() * span[0] + lo[0]
+            sy = (tmp[..., 1:2] + reference[..., 1:2]).sigmoid() * span[1] + lo[1]
+            sz = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid() * span[2] + lo[2]
+            if depth_factor is not None:
+                sx, sy, sz = sx * scale, sy * scale, sz * scale
+            coords.append(torch.cat([sx, sy, tmp[..., 2:4], sz, tmp[..., 5:]], dim=-1))
         return {'all_cls_scores': torch.stack(classes), 'all_bbox_preds': torch.stack(coords),
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
     for lvl in range(hs.shape[0]):
