@@ -33,6 +33,7 @@ struct VpBwdParams {
   int tiles[GD4D_MAX_LEVELS];
   int tile_base[GD4D_MAX_LEVELS + 1];
   int R, L, S;
+  int dbg;                              // dev ablation bits (GD4D_VW_DBG): 1 = no MFMAs, 2 = no global loads, 4 = no conversion / LDS writes
 };
 
 __device__ __forceinline__ unsigned vb_cvt_pk_bf16(float lo_elem, float hi_elem) {
@@ -290,9 +291,10 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
   // staging roles: x chunk (ci = tid / 4, g = tid % 4); gout chunk (co = tid % 256, g = tid / 256)
   const int xci = tid >> 2, xg = tid & 3;
   const int yco = tid & 255, yg = tid >> 8;
-  float xs[8], ys[8];
+  float xs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ys[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   auto issue = [&]() {
+    if (p.dbg & 2) return;
     const int pix0 = c.tin * VW_BK;
     const float* xrow = reinterpret_cast<const float*>(c.ptr) + ((size_t)c.row * VB_C + xci) * c.hw;
     const int px = pix0 + 8 * xg;
@@ -308,18 +310,27 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
     }
     const float* yrow = p.gout + ((size_t)c.row * p.S + c.start) * VB_C + yco;
     const int py = pix0 + 8 * yg;
+    if (pix0 + VW_BK <= c.hw) {                        // full tile (workgroup-uniform): no clamps, one base address
+      const float* y0 = yrow + (size_t)py * VB_C;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ys[j] = yrow[(size_t)min(py + j, c.hw - 1) * VB_C];
+      for (int j = 0; j < 8; ++j) ys[j] = y0[j * VB_C];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ys[j] = yrow[(size_t)min(py + j, c.hw - 1) * VB_C];
+    }
   };
   auto park = [&](int stage, int rem) {            // rem: valid pixels of the tile the registers hold
+    if (p.dbg & 4) return;
     char* base = smem + stage * VW_STAGE;
     u32x4 h, l;
+    if (rem < VW_BK) {                                 // tail tile (workgroup-uniform): zero what lies beyond the row
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ys[j] = 8 * yg + j < rem ? ys[j] : 0.f;
-      xs[j] = 8 * xg + j < rem ? xs[j] : 0.f;
-      bsum += ys[j];
+      for (int j = 0; j < 8; ++j) {
+        ys[j] = 8 * yg + j < rem ? ys[j] : 0.f;
+        xs[j] = 8 * xg + j < rem ? xs[j] : 0.f;
+      }
     }
+    bsum += ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
     vb_split8(ys, h, l);
     const int yoff = (yg * VB_C + yco) * 16;
     *reinterpret_cast<u32x4*>(base + yoff) = h;
@@ -353,6 +364,7 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
       rem_next = c.hw - c.tin * VW_BK;
     }
     const char* base = smem + cur * VW_STAGE;
+    if (!(p.dbg & 1))
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -489,6 +501,7 @@ extern "C" int gd4d_value_proj_bwd_weight(const float* grad_out, const void* con
   }
   p.gout = grad_out;
   p.ws = static_cast<float*>(workspace);
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GD4D_VW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   const int total = p.tile_base[L];
   int grid = vb_cus();
   if (grid > VW_MAX_PARTS) grid = VW_MAX_PARTS;
