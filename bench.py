@@ -423,7 +423,36 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                     achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, alg_bytes_per_launch=tot_bytes / launches,
                     us_per_launch=tot_ms / launches * 1e3, launches_per_step=launches)
-    return roofline, {'cross_attn_fwd_per_layer': per_layer}
+    kernels = {'cross_attn_fwd_per_layer': per_layer}
+    # The other large kernel of a step, reported beside the headline roofline: value_proj (one launch per layer, the
+    # layers' weights in turn), HIP events on the launch stream.  Algorithmic bytes: the pyramid read once + the value
+    # tensor written once; flops: 2 * rows * 256 * 256 (x3 on the matrix pipe: split-bf16).
+    try:
+        from graph_detr4d_amd import functional as Fn
+        mods = [m for layer in tr.decoder.layers for m in layer.attentions if hasattr(m, 'value_proj')]
+        vals = [f.contiguous() for f in feats]
+        run = lambda m: Fn.value_projection(vals, m.value_proj.weight, m.value_proj.bias, m.num_heads, m.value_dtype)  # noqa: E731
+        with torch.no_grad():
+            out0, _ = run(mods[0])
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                for m in mods:
+                    run(m)
+            e1.record()
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / (3 * len(mods)) * 1e3
+        rd = sum(f.numel() * f.element_size() for f in vals)
+        wr = out0.numel() * out0.element_size()
+        rows = rd // (256 * 4)
+        fl = 2.0 * rows * 256 * 256
+        kernels['value_proj_fwd'] = dict(us_per_launch_back_to_back=us, alg_bytes_per_launch=rd + wr,
+                                         hbm_gbs=(rd + wr) / us / 1e3, hbm_frac=(rd + wr) / us / 1e3 / HBM_PEAK_GBS,
+                                         gflop_per_launch=fl / 1e9, mfma_tflops_x3=3 * fl / us / 1e6,
+                                         mfma_frac_of_2500=3 * fl / us / 1e6 / 2500.0, launches_per_step=len(mods))
+    except Exception as e:                                    # secondary figure: report, never fail the bench line
+        kernels['value_proj_fwd'] = {'error': f'{type(e).__name__}: {e}'}
+    return roofline, kernels
 
 
 if __name__ == '__main__':
