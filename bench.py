@@ -246,6 +246,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     params = list(tr.parameters()) + list(regs.parameters()) + (list(cls_branches.parameters()) if a.criterion else [])
     opt = torch.optim.SGD(params, lr=1e-4)
     reducer = D.FlatGradAllReducer(params)
+    reducer.bind()                                    # .grad = views of one flat buffer from the start (graph captures)
     tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
 
     class DecoderAndHead(torch.nn.Module):
@@ -262,23 +263,45 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
 
     front = DecoderAndHead() if a.criterion else None
     front_launch = 'eager'
+    graphs = None
     if a.criterion and not a.no_graph:
         # The assignment's host round trip cannot sit inside one capture of the whole step, so the part in front of it
-        # and its backward are captured as two hipGraphs (torch.cuda.make_graphed_callables); the loss and its backward
-        # (three launches) run eagerly between them.
+        # and its backward are captured as two hipGraphs sharing one memory pool; the loss (three launches and the host
+        # assignment) runs eagerly between them.  The backward is captured with torch.autograd.backward, so the
+        # accumulation into the bound .grad views is part of the graph (handing the gradients back to an eager
+        # AccumulateGrad per parameter costs ~250 cross-stream dependencies, 5 ms per step).
         try:
-            q_in = query_embed.clone().requires_grad_(False)
-            front = torch.cuda.make_graphed_callables(front, (q_in, *feats))
-            front_launch = 'hipgraph (forward, backward) + eager loss'
+            for f in feats:
+                f.grad = None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                     # warm-up off the default stream, as captures require
+                oc, ob = front(query_embed, *feats)
+                torch.autograd.backward((oc, ob), (torch.zeros_like(oc), torch.zeros_like(ob)))
+            torch.cuda.current_stream().wait_stream(side)
+            for f in feats:
+                f.grad = None                                 # the capture below then adopts the gradient buffers
+            g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fwd, capture_error_mode='thread_local'):
+                out_cls, out_box = front(query_embed, *feats)
+            grad_cls, grad_box = torch.zeros_like(out_cls), torch.zeros_like(out_box)
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode='thread_local'):
+                torch.autograd.backward((out_cls, out_box), (grad_cls, grad_box))
+            graphs = (g_fwd, g_bwd, out_cls, out_box, grad_cls, grad_box)
+            front_launch = 'hipgraph (forward), eager loss + assignment, hipgraph (backward)'
         except Exception as e:                        # report, never hide
             print(f'[bench] hipGraph capture of decoder + head failed ({type(e).__name__}: {e}); running eagerly',
                   file=sys.stderr)
-            front = DecoderAndHead()
+            graphs = None
+
+    def criterion_loss(all_cls, all_box):
+        return sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box)).values())
 
     def step():
         reducer.zero_grad()
-        for f in feats:
-            f.grad = None
+        if graphs is None:                            # (captured backward: the pyramid's .grad buffers belong to the graph)
+            for f in feats:
+                f.grad = None
         if os.environ.get('GD4D_BENCH_SPLIT'):       # dev: serialised wall-clock split of the step
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if a.criterion:
@@ -286,23 +309,31 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             else:
                 states, init_ref, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            if a.criterion:
-                loss = sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box)).values())
-            else:
-                loss = (states ** 2).mean()
+            loss = criterion_loss(all_cls, all_box) if a.criterion else (states ** 2).mean()
             torch.cuda.synchronize(); t2 = time.perf_counter()
             loss.backward()
+            t3c = time.perf_counter()
             torch.cuda.synchronize(); t3 = time.perf_counter()
+            print(f'[split] backward: host returned after {1e3 * (t3c - t2):.2f} ms', file=sys.stderr)
             reducer.reduce()
             opt.step()
             torch.cuda.synchronize(); t4 = time.perf_counter()
             print(f'[split] forward {1e3 * (t1 - t0):.2f}  loss {1e3 * (t2 - t1):.2f}  backward {1e3 * (t3 - t2):.2f}  '
                   f'reduce + SGD {1e3 * (t4 - t3):.2f} ms', file=sys.stderr)
             return
+        if a.criterion and graphs is not None:
+            g_fwd, g_bwd, out_cls, out_box, grad_cls, grad_box = graphs
+            g_fwd.replay()
+            c, b = out_cls.detach().requires_grad_(), out_box.detach().requires_grad_()
+            criterion_loss(c, b).backward()                                  # the step's one device synchronisation
+            grad_cls.copy_(c.grad)
+            grad_box.copy_(b.grad)
+            g_bwd.replay()
+            reducer.reduce()
+            opt.step()
+            return
         if a.criterion:
-            all_cls, all_box = front(query_embed, *feats)
-            outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box)
-            loss = sum(crit.loss(gt_boxes, gt_labels, outs).values())        # the step's one device synchronisation
+            loss = criterion_loss(*front(query_embed, *feats))
         else:
             states, init_ref, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
             loss = (states ** 2).mean()
@@ -316,6 +347,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     run, launch = step, front_launch
     for _ in range(2):
         step()
+        if rank == 0 and os.environ.get('GD4D_BENCH_CHECK'):
+            print(f'[check] warm step: |grad| = {float(reducer.flat.double().norm()):.9e}', file=sys.stderr)
     torch.cuda.synchronize()
     if not a.no_graph and not a.criterion:            # the assignment's host round trip cannot sit inside a capture
         try:
@@ -335,6 +368,12 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                   file=sys.stderr)
             run, launch = step, 'eager'
     elapsed = D.timed_steps(run, a.steps, a.warmup, dev)
+    if rank == 0 and os.environ.get('GD4D_BENCH_CHECK'):      # dev: the launch modes must train identically
+        flat = reducer.flat
+        psum = sum(float(p.detach().double().sum()) for p in params)
+        print(f'[check] |grad| = {float(flat.double().norm()):.9e}  sum(params) = {psum:.9e}  '
+              f'|d pyramid| = {float(sum(f.grad.double().norm() ** 2 for f in feats if f.grad is not None) ** 0.5):.6e}',
+              file=sys.stderr)
     if rank == 0:
         line = {
             'metric': f'decoder_train_samples_per_sec_{a.queries}q_T{a.frames}',

@@ -132,6 +132,12 @@ class FlatGradAllReducer:
             p.grad = v
 
     @torch.no_grad()
+    def bind(self):
+        """Allocate the flat buffer and bind every .grad to it now (parameters without a gradient get zeros).  Needed
+        before a backward pass is captured in a hipGraph: the capture records the addresses it accumulates into."""
+        self._bind(self._buffer(self.params[0], 0 if self.flat is None else self.flat.numel() - self.numel))
+
+    @torch.no_grad()
     def zero_grad(self):
         """Zero all gradients with one launch (bound buffer); falls back to per-parameter zeroing before the first step."""
         if self.flat is not None and self.views is not None and all(p.grad is v for p, v in zip(self.params, self.views)):
