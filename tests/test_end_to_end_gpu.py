@@ -6,7 +6,6 @@ inputs and weights.  GPU only."""
 import pytest
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 import graph_detr4d_amd as G
 from graph_detr4d_amd import functional as Fn

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import graph_detr4d_amd as G
-from golden_io import Golden, sub
+from golden_io import Golden
 from graph_detr4d_amd import _lib
 
 PC = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]

@@ -1,6 +1,5 @@
 """Pin the CPU oracle (oracle/torch_oracle.py) against golden vectors captured from the
 reference itself (tools/gen_golden.py).  CPU only."""
-import numpy as np
 import pytest
 import torch
 
