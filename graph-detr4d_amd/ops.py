@@ -626,3 +626,24 @@ def head_loss_fwd_bwd(cls, box, assigned, gt_boxes, gt_labels, code_weights, avg
                                       float(loss_bbox_weight), _stream())
     _lib.check(code, 'gd4d_head_loss_fwd_bwd')
     return loss, gcls, gbox
+
+
+def linear_sum_assignment_batch(cost, problems, num_threads=8):
+    """gd4d_linear_sum_assignment_batch (host).  cost: contiguous float32 numpy array; problems: list of
+    (offset, rows, cols) into it.  Returns a list of int32 arrays (rows,): assigned column per row or -1."""
+    import numpy as np
+    lib = _lib.load()
+    cost = np.ascontiguousarray(cost, dtype=np.float32)
+    n = len(problems)
+    offs = np.asarray([p[0] for p in problems], dtype=np.int64)
+    rows = np.asarray([p[1] for p in problems], dtype=np.int32)
+    cols = np.asarray([p[2] for p in problems], dtype=np.int32)
+    if n and int((offs + rows.astype(np.int64) * cols).max()) > cost.size:
+        raise ValueError('a problem reaches past the end of the cost buffer')
+    out_off = np.concatenate([[0], np.cumsum(rows, dtype=np.int64)]).astype(np.int64)
+    out = np.empty(int(out_off[-1]), dtype=np.int32)
+    as_p = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    code = lib.gd4d_linear_sum_assignment_batch(as_p(cost), as_p(offs), as_p(rows), as_p(cols), n, as_p(out),
+                                                as_p(out_off), int(num_threads))
+    _lib.check(code, 'gd4d_linear_sum_assignment_batch')
+    return [out[out_off[i]:out_off[i + 1]] for i in range(n)]

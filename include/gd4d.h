@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 12
+#define GD4D_ABI_VERSION 13
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -458,6 +458,16 @@ int gd4d_head_loss_fwd_bwd(const float* cls, const float* box, const int32_t* as
                            const int32_t* gt_labels, const float* code_weights, const float* avg_factors, float* loss,
                            float* grad_cls, float* grad_box, int NL, int B, int Q, int C, int code, int gt_dim,
                            float alpha, float loss_cls_weight, float loss_bbox_weight, void* stream);
+
+/* gd4d_linear_sum_assignment_batch - HOST function (no GPU work): the linear sum assignment the reference delegates to
+ * scipy (hungarian_assigner_3d.py:125-131), for a batch of independent problems solved on `num_threads` host threads.
+ * Problem p: cost + cost_offset[p], row-major (rows[p], cols[p]) fp32, finite (run nan_to_num first; the cost kernel
+ * does).  Output: col_of_row + out_offset[p], rows[p] int32: the column assigned to each row or -1.  Every column is
+ * assigned when cols <= rows (all ground-truth boxes matched), every row when rows <= cols.  The method is the
+ * shortest-augmenting-path algorithm scipy uses; the optimum is the same, and so is the matching whenever it is unique. */
+int gd4d_linear_sum_assignment_batch(const float* cost, const int64_t* cost_offset, const int32_t* rows,
+                                     const int32_t* cols, int num_problems, int32_t* col_of_row,
+                                     const int64_t* out_offset, int num_threads);
 
 #ifdef __cplusplus
 }

@@ -36,3 +36,35 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(_lib.Gd4dError):
         ops.cross_attn_fwd(z(6, 4, 8, 32), [(2, 2)], z(1, 3, 3), z(1, 3, 8, 4, 3), z(1, 3, 8, 1, 4),
                            z(1, 3, 6), z(1, 6, 4, 4), [0, 0, 0, 1, 1, 1], 8, 8)
+
+
+def test_host_linear_sum_assignment_matches_scipy():
+    """gd4d_linear_sum_assignment_batch is host code: checked here without a GPU against scipy (what the reference
+    calls, hungarian_assigner_3d.py:130), including tie-heavy and constant-column matrices and the threaded path."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from graph_detr4d_amd import ops
+    rng = np.random.default_rng(0)
+    mats = []
+    for trial in range(120):
+        r, c = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+        if trial % 3 == 0:
+            m = rng.standard_normal((r, c))
+        elif trial % 3 == 1:
+            m = rng.integers(0, 4, (r, c)).astype(np.float64)              # many ties
+        else:
+            m = rng.standard_normal((r, c))
+            m[:, rng.integers(0, c)] = 100.0                               # a nan_to_num column
+        mats.append(m.astype(np.float32))
+    mats += [np.zeros((0, 5), np.float32), np.zeros((4, 0), np.float32)]
+    flat = np.concatenate([m.ravel() for m in mats])
+    offs = np.concatenate([[0], np.cumsum([m.size for m in mats])])
+    problems = [(int(offs[i]), m.shape[0], m.shape[1]) for i, m in enumerate(mats)]
+    for threads in (1, 4):
+        got = ops.linear_sum_assignment_batch(flat, problems, threads)
+        for m, a in zip(mats, got):
+            want = np.full(m.shape[0], -1, np.int32)
+            if m.size:
+                rows, cols = linear_sum_assignment(m)
+                want[rows] = cols
+            np.testing.assert_array_equal(a, want)

@@ -53,7 +53,7 @@ def main():
     torch.cuda.synchronize()
     assign = (time.perf_counter() - t0) / a.iters
     print(f'{a.layers} layers x {a.queries} queries x {a.gts} boxes: loss + backward {wall * 1e3:.2f} ms per step '
-          f'(cost launch + copy + {a.layers} scipy assignments + copy: {assign * 1e3:.2f} ms; 1 device synchronisation)')
+          f'(cost launch + copy + {a.layers} host assignments + copy: {assign * 1e3:.2f} ms; 1 device synchronisation)')
 
 
 if __name__ == '__main__':
