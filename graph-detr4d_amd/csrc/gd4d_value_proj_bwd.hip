@@ -33,7 +33,7 @@ struct VpBwdParams {
   int tiles[GD4D_MAX_LEVELS];
   int tile_base[GD4D_MAX_LEVELS + 1];
   int R, L, S;
-  int dbg;                              // dev ablation bits (GD4D_VW_DBG): 1 = no MFMAs, 2 = no global loads, 4 = no conversion / LDS writes
+  int dbg;                              // dev ablation bits (GD4D_VW_DBG): 1 = no MFMAs, 2 = no global loads, 4 = no conversion / LDS writes, 8 = no pyramid loads, 16 = no grad_out loads
 };
 
 __device__ __forceinline__ unsigned vb_cvt_pk_bf16(float lo_elem, float hi_elem) {
@@ -277,11 +277,13 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
   const int wm = wave >> 2, wn = wave & 3;
   const int l32 = lane & 31, kg = lane >> 5;
 
+  // tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the workgroups running at the same time read NEIGHBOURING 128-byte
+  // pieces of every pyramid row (one DRAM page serves many of them); contiguous per-workgroup ranges made the pyramid
+  // read the slowest part of the kernel (2.5 TB/s for that operand alone)
   const int total = p.tile_base[GD4D_MAX_LEVELS];
-  const int per = (total + gridDim.x - 1) / gridDim.x;
-  const int t0 = blockIdx.x * per;
-  const int t1 = min(t0 + per, total);
-  const int steps = max(t1 - t0, 0);
+  const int stride = gridDim.x;
+  const int t0 = blockIdx.x;
+  const int steps = t0 < total ? (total - t0 + stride - 1) / stride : 0;
 
   if (tid == 0) vb_fill_table(tab, p, true);
   __syncthreads();
@@ -299,7 +301,8 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
     const float* xrow = reinterpret_cast<const float*>(c.ptr) + ((size_t)c.row * VB_C + xci) * c.hw;
     const int px = pix0 + 8 * xg;
     const bool wide = (c.hw % 4 == 0) && ((c.ptr & 15u) == 0);    // workgroup-uniform
-    if (wide) {
+    if (p.dbg & 8) {
+    } else if (wide) {
       // a quad that starts inside the row ends inside it; out-of-row quads re-read the last one and are zeroed in park
       const float4 a = *reinterpret_cast<const float4*>(xrow + min(px, c.hw - 4));
       const float4 b = *reinterpret_cast<const float4*>(xrow + min(px + 4, c.hw - 4));
@@ -310,7 +313,8 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
     }
     const float* yrow = p.gout + ((size_t)c.row * p.S + c.start) * VB_C + yco;
     const int py = pix0 + 8 * yg;
-    if (pix0 + VW_BK <= c.hw) {                        // full tile (workgroup-uniform): no clamps, one base address
+    if (p.dbg & 16) {
+    } else if (pix0 + VW_BK <= c.hw) {                        // full tile (workgroup-uniform): no clamps, one base address
       const float* y0 = yrow + (size_t)py * VB_C;
 #pragma unroll
       for (int j = 0; j < 8; ++j) ys[j] = y0[j * VB_C];
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
     const bool has_next = s + 1 < steps;
     int rem_next = 0;
     if (has_next) {                                   // uniform branch; loads fly behind the MFMAs below
-      vb_advance(c, tab, p, 1);
+      vb_advance(c, tab, p, stride);
       issue();
       rem_next = c.hw - c.tin * VW_BK;
     }
