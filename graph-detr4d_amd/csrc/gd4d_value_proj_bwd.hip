@@ -213,15 +213,17 @@ __global__ __launch_bounds__(512, 2) void value_proj_bwd_input_kernel(const VpBw
     }
   };
 
+  // `nxt` is the tile whose grad_out rows sit in the staging registers: its loads are issued as soon as the previous
+  // tile has been parked (before the barrier), so they are in flight across the barrier and the whole MFMA phase.
   issue_loads(cur);
   init_acc(cur);
   park(cur, 0);
+  if (slot + slots < total) { vb_advance(nxt, tab, p, slots); issue_loads(nxt); }
   __syncthreads();
 
   int buf = 0;
   for (int t = slot; t < total; t += slots) {
     const bool has_next = t + slots < total;
-    if (has_next) { vb_advance(nxt, tab, p, slots); issue_loads(nxt); }   // in flight during the MFMA phase
     const char* hi_img = smem + buf * 2 * IMG;
     const char* lo_img = hi_img + IMG;
 #pragma unroll
@@ -248,17 +250,21 @@ __global__ __launch_bounds__(512, 2) void value_proj_bwd_input_kernel(const VpBw
       }
     }
     cur = nxt;
-    if (has_next) { init_acc(cur); park(cur, buf ^ 1); }      // the other buffer: its readers finished before the last barrier
+    if (has_next) {
+      init_acc(cur);
+      park(cur, buf ^ 1);                                      // the other buffer: its readers finished before the last barrier
+      if (t + 2 * slots < total) { vb_advance(nxt, tab, p, slots); issue_loads(nxt); }
+    }
     __syncthreads();
     buf ^= 1;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// d(weight), d(bias).  K = all pixels of all cameras.  One persistent 1024-thread workgroup per CU owns a contiguous
-// range of 32-pixel tiles and the whole 256 x 256 result in its accumulators (16 waves, 4 x 4, each 64 x 64 = 2 x 2 MFMA
-// 32x32x16 tiles: the arrangement of gd4d_gemm_bf16x3_fwd), then writes its partial to the workspace; a second small
-// kernel adds the partials in a fixed order (deterministic, no atomics).
+// d(weight), d(bias).  K = all pixels of all cameras.  One persistent 1024-thread workgroup per CU takes every
+// gridDim.x-th 32-pixel tile and keeps the whole 256 x 256 result in its accumulators (16 waves, 4 x 4, each 64 x 64 =
+// 2 x 2 MFMA 32x32x16 tiles: the arrangement of gd4d_gemm_bf16x3_fwd), then writes its partial to the workspace; a
+// second small kernel adds the partials in a fixed order (deterministic, no atomics).
 //
 // The contraction index is the pixel, which is the contiguous index of the NCHW pyramid but the row index of grad_out.
 // MFMA fragments want 8 consecutive k per lane, but a sum over k does not care which 8 as long as both operands agree:
@@ -353,20 +359,22 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // The loads of tile s + 1 are issued as soon as the registers are free - right after tile s has been converted and
+  // parked, BEFORE the barrier - so they are in flight across the barrier wait and the whole MFMA phase of step s.
+  int rem_next = 0;                                   // valid pixels of the tile the staging registers hold
   if (steps > 0) {
     issue();
     park(0, c.hw - c.tin * VW_BK);
+    if (steps > 1) {
+      vb_advance(c, tab, p, stride);
+      issue();
+      rem_next = c.hw - c.tin * VW_BK;
+    }
   }
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const int cur = s & 1;
     const bool has_next = s + 1 < steps;
-    int rem_next = 0;
-    if (has_next) {                                   // uniform branch; loads fly behind the MFMAs below
-      vb_advance(c, tab, p, stride);
-      issue();
-      rem_next = c.hw - c.tin * VW_BK;
-    }
     const char* base = smem + cur * VW_STAGE;
     if (!(p.dbg & 1))
 #pragma unroll
@@ -390,7 +398,14 @@ __global__ __launch_bounds__(VW_THREADS) void value_proj_bwd_weight_kernel(const
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
         }
     }
-    if (has_next) park(cur ^ 1, rem_next);
+    if (has_next) {
+      park(cur ^ 1, rem_next);
+      if (s + 2 < steps) {                              // uniform branch
+        vb_advance(c, tab, p, stride);
+        issue();
+        rem_next = c.hw - c.tin * VW_BK;
+      }
+    }
     __syncthreads();
   }
 
