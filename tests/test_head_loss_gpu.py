@@ -169,3 +169,23 @@ def test_head_epilogue_and_loss_train_end_to_end():
     torch.testing.assert_close(hs_g.grad.cpu(), hs_c.grad, rtol=1e-3, atol=1e-6)
     for pg, pc in zip(list(cls_g.parameters()) + list(reg_g.parameters()), list(cls_c.parameters()) + list(reg_c.parameters())):
         torch.testing.assert_close(pg.grad.cpu(), pc.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_no_ground_truth_at_all():
+    """Every query is background: focal term only, normalisers clamp to 1, no host round trip."""
+    from graph_detr4d_amd import Detr3DCriterion, HungarianAssigner3D
+    torch.manual_seed(3)
+    cls = (torch.randn(2, 1, 30, 10) - 2).cuda().requires_grad_()
+    box = torch.randn(2, 1, 30, 10).cuda().requires_grad_()
+    gt, lab = torch.zeros(0, 9), torch.zeros(0, dtype=torch.long)
+    crit = Detr3DCriterion().cuda()
+    got = crit.loss([gt.cuda()], [lab.cuda()], dict(all_cls_scores=cls, all_bbox_preds=box))
+    want, _ = O.head_loss(cls.detach().cpu(), box.detach().cpu(), [gt], [lab], torch.tensor([1.] * 8 + [.2, .2]))
+    for k in want:
+        torch.testing.assert_close(got[k].cpu(), want[k], rtol=1e-5, atol=1e-6)
+    assert float(got['loss_bbox'].detach()) == 0.0
+    sum(got.values()).backward()
+    assert float(box.grad.abs().sum()) == 0.0 and float(cls.grad.abs().sum()) > 0
+    r = HungarianAssigner3D(cls_cost=dict(type='FocalLossCost', weight=2.0), reg_cost=dict(type='BBox3DL1Cost', weight=0.25)) \
+        .assign(box[0, 0].detach(), cls[0, 0].detach(), gt.cuda(), lab.cuda())
+    assert r.num_gts == 0 and int(r.gt_inds.abs().sum()) == 0
