@@ -20,7 +20,6 @@ def main():
     ap.add_argument('--head-major', action='store_true')
     ap.add_argument('--order', action='store_true', help='pass gd4d_query_order_fwd order to the kernel')
     ap.add_argument('--order-azimuth', action='store_true', help='pass a host-side azimuth argsort as the order')
-    ap.add_argument('--order-host', default='', help='host-side order: camu | camu_rev | cam | shuffle_in_range')
     ap.add_argument('--sort-queries', action='store_true', help='order the queries by azimuth (locality probe)')
     ap.add_argument('--rotate', type=int, default=6,
                     help='distinct value tensors to rotate through (cache-cold like the real decoder; 1 = warm)')
@@ -58,24 +57,6 @@ def main():
     if a.order_azimuth:
         ang = torch.atan2(ref[0, :, 1] - 0.5, ref[0, :, 0] - 0.5)
         hm['query_order'] = torch.argsort(ang).int()
-    if a.order_host:
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from oracle import torch_oracle as O
-        uv0, m0 = O.project(O.denormalise(ref.cpu(), synthetic.PC_RANGE), l2i.cpu(), 900, 1600)
-        first = torch.where(m0[0].any(0), m0[0].float().argmax(0), torch.full((q,), n))
-        u = uv0[0].gather(0, first.clamp(max=n - 1)[None, :, None].expand(1, q, 2))[0, :, 0]
-        ub = (u * 32).clamp(0, 31).long()
-        if a.order_host == 'camu':
-            key = first * 32 + ub
-        elif a.order_host == 'camu_rev':
-            key = first * 32 + (31 - ub)
-        elif a.order_host == 'cam':
-            key = first
-        elif a.order_host == 'camu_fine':
-            key = first.double() + u.double().clamp(0, 0.999)
-        else:
-            raise SystemExit('bad --order-host')
-        hm['query_order'] = torch.argsort(key, stable=True).int().to(dev)
     out, mask = ops.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600,
                                    want_mask=True, **hm)
     vis = int(mask.sum().item())
@@ -92,7 +73,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    print(f'order={int(a.order) + 2 * int(a.order_azimuth)}{a.order_host} sorted={int(a.sort_queries)} head_major={int(a.head_major)} rotate={a.rotate} N={n} Q={q} {a.dtype} visible(h,p) tuples={vis} ({vis / mask.numel():.3f}) '
+    print(f'order={int(a.order) + 2 * int(a.order_azimuth)} sorted={int(a.sort_queries)} head_major={int(a.head_major)} rotate={a.rotate} N={n} Q={q} {a.dtype} visible(h,p) tuples={vis} ({vis / mask.numel():.3f}) '
           f'alg_bytes={alg / 1e6:.1f} MB  {ms * 1e3:.1f} us  {alg / ms / 1e9:.2f} TB/s  '
           f'frac_of_8TB/s={alg / ms / 1e9 / 8:.3f}')
 
