@@ -30,8 +30,6 @@ def timed(fn, n=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=4)
-    ap.add_argument('--cpu-oracle', action='store_true',
-                    help='also time the oracle (the reference op sequence) on the host CPU, 16 threads, same inputs')
     a = ap.parse_args()
     n = 6 * a.frames
     torch.manual_seed(0)
@@ -88,18 +86,6 @@ def main():
           f'position_encoder convs {t_pe:.2f} ms   SE convs {t_se:.2f} ms   fuse kernel {t_fuse:.2f} ms '
           f'({pixels * 256 * 4 * 5 / t_fuse / 1e9:.2f} TB/s)   sine branch {t_sine:.2f} ms (cached afterwards)')
     print(f'  dense work per call: {flops / 1e12:.2f} TFLOP fp32 -> {flops / steady / 1e9:.1f} TFLOP/s overall')
-    if a.cpu_oracle:
-        # (the same op sequence with torch on the GPU is not timed: its (B,N,W,H,D,4,4) batched matmul - 35.6 M
-        # 4x4 products at level 0 - faults inside the library at this batch count)
-        from oracle import torch_oracle as O
-        torch.set_num_threads(16)
-        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
-        cf = [f.cpu() for f in feats]
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            O.feature_position_embedding(sd, cf, np.asarray(rig)[None], [list(metas[0]['img_shape'])],
-                                         metas[0]['pad_shape'][0], 64, 1, synthetic.PC_RANGE)
-        print(f'  CPU oracle (reference op sequence, 16 threads, one call): {(time.perf_counter() - t0) * 1e3:.0f} ms')
 
 
 if __name__ == '__main__':
