@@ -278,14 +278,17 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             with torch.cuda.stream(side):                     # warm-up off the default stream, as captures require
                 oc, ob = front(query_embed, *feats)
                 torch.autograd.backward((oc, ob), (torch.zeros_like(oc), torch.zeros_like(ob)))
+                del oc, ob                                    # nothing may keep the warm-up's autograd graph alive
             torch.cuda.current_stream().wait_stream(side)
             for f in feats:
                 f.grad = None                                 # the capture below then adopts the gradient buffers
+            # warm-up and both captures on ONE stream: the parameters' AccumulateGrad nodes then sit on the stream that
+            # produces their gradients (no cross-stream hand-offs inside the backward graph)
             g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd, capture_error_mode='thread_local'):
+            with torch.cuda.graph(g_fwd, stream=side, capture_error_mode='thread_local'):
                 out_cls, out_box = front(query_embed, *feats)
             grad_cls, grad_box = torch.zeros_like(out_cls), torch.zeros_like(out_box)
-            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), stream=side, capture_error_mode='thread_local'):
                 torch.autograd.backward((out_cls, out_box), (grad_cls, grad_box))
             graphs = (g_fwd, g_bwd, out_cls, out_box, grad_cls, grad_box)
             front_launch = 'hipgraph (forward), eager loss + assignment, hipgraph (backward)'
@@ -358,7 +361,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             with torch.cuda.stream(s):
                 step()
             torch.cuda.current_stream().wait_stream(s)
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            with torch.cuda.graph(graph, stream=s, capture_error_mode='thread_local'):   # same stream as the warm-up
                 step()
             graph.replay()
             torch.cuda.synchronize()
