@@ -7,7 +7,7 @@ from golden_io import Golden
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
-CASES = ['head_loss', 'head_loss_b2', 'head_loss_degenerate']
+CASES = ['head_loss', 'head_loss_b2', 'head_loss_degenerate', 'head_loss_b2_both']
 
 
 def _gt(g, dev='cuda'):
@@ -64,7 +64,7 @@ def test_assigner_matches_reference(name):
         start += g.meta['gts'][b]
 
 
-@pytest.mark.parametrize('name', ['head_loss', 'head_loss_b2'])
+@pytest.mark.parametrize('name', ['head_loss', 'head_loss_b2', 'head_loss_b2_both'])
 def test_criterion_losses_and_gradients_match_reference(name):
     from graph_detr4d_amd import Detr3DCriterion
     g = Golden(name)

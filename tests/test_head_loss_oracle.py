@@ -6,7 +6,7 @@ import torch
 from golden_io import Golden
 from oracle import torch_oracle as O
 
-CASES = ['head_loss', 'head_loss_b2', 'head_loss_degenerate']
+CASES = ['head_loss', 'head_loss_b2', 'head_loss_degenerate', 'head_loss_b2_both']
 
 
 def _gt(g):

@@ -632,6 +632,7 @@ def main():
     case_head_loss('head_loss', num_query=60, gts=(7,), seed=701)
     case_head_loss('head_loss_b2', num_query=40, gts=(5, 0), seed=702, num_layers=2)
     case_head_loss('head_loss_degenerate', num_query=30, gts=(6,), seed=703, num_layers=2, degenerate=True)
+    case_head_loss('head_loss_b2_both', num_query=36, gts=(4, 6), seed=704, num_layers=2)
 
 
 if __name__ == '__main__':
