@@ -11,8 +11,8 @@
 // (with 128 x 128 tiles the kernel was bound by L2 -> CU traffic: 12 GB per GEMM at 9 TB/s; 256 x 256 halves it).
 // K advances in steps of 32 through a double-buffered LDS stage holding the tile's A_hi / A_lo / W_hi / W_lo as
 // [k-group of 8][row][8 x bf16] so that every MFMA fragment is one conflict-free ds_read_b128 per lane.  Global loads of
-// step k+1 are issued into registers before the MFMAs of step k and converted / parked into the other buffer after
-// them: one barrier per step.  128 KB of LDS, one workgroup of 16 waves per CU.
+// step k+2 are issued into registers as soon as step k+1 has been converted / parked into the other buffer (before the
+// barrier), so they are in flight across the barrier and the MFMAs of step k+1: one barrier per step.  128 KB of LDS, one workgroup of 16 waves per CU.
 #include "gd4d_common.h"
 
 namespace gd4d {
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_bf16x3_kernel(const GemmParam
   const int steps = p.K / GM_BK;
   issue(0);
   park(0);
+  if (steps > 1) issue(GM_BK);                          // step 1's operands: in flight across the barrier and step 0's MFMAs
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const int cur = s & 1;
-    if (s + 1 < steps) issue((s + 1) * GM_BK);          // uniform branch; loads fly behind the MFMAs below
     const char* base = smem + cur * GM_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_bf16x3_kernel(const GemmParam
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
         }
     }
-    if (s + 1 < steps) park(cur ^ 1);                    // the other buffer: its readers finished before the last barrier
+    if (s + 1 < steps) {
+      park(cur ^ 1);                                     // the other buffer: its readers finished before the last barrier
+      if (s + 2 < steps) issue((s + 2) * GM_BK);         // registers are free again: next loads go out before the barrier
+    }
     __syncthreads();
   }
 
