@@ -130,9 +130,12 @@ def main():
         raise SystemExit('for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    D.init(backend='nccl', device=dev)               # RCCL; no-op for a single process
+    # (GD4D_DIST_BACKEND=gloo with every rank on one GPU is a dev path to exercise the N > 1 code on a 1-GPU box)
+    backend = os.environ.get('GD4D_DIST_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    D.init(backend=backend, device=dev)              # "nccl" = RCCL; no-op for a single process
 
     import graph_detr4d_amd as G
     from graph_detr4d_amd import _lib, ops, synthetic
@@ -224,6 +227,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     """Secondary mode: one training step of the decoder per sample - forward, a synthetic loss, backward
     (gd4d_cross_attn_bwd, gd4d_value_proj_bwd_*, gd4d_linear_bwd_weight), ONE flat gradient all-reduce over RCCL, SGD.
     The feature pyramid requires grad (it comes from the backbone in the reference's training)."""
+    world_size = max(a.gpus, 1)
     for f in feats:
         f.requires_grad_(True)
     crit = cls_branches = None
@@ -341,12 +345,16 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             states, init_ref, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
             loss = (states ** 2).mean()
         loss.backward()
-        reducer.reduce()
-        opt.step()
+        if finish:
+            reducer.reduce()
+            opt.step()
 
     # The step is ~2500 launches, most of them small: eagerly it is bound by the host's launch rate, not by the GPU.
-    # Capture forward + backward + all-reduce + SGD into one hipGraph (warm-up on a side stream first so that autograd
-    # and the allocator have seen every shape), replay it per step.
+    # One process: forward + backward + SGD are captured into one hipGraph (warm-up on a side stream first so that
+    # autograd and the allocator have seen every shape) and replayed per step.  Several ranks: the capture ends before
+    # the gradient all-reduce - the collective and the (few, fused) optimizer launches stay eager, so the step does not
+    # depend on the communication backend being capturable.
+    finish = True
     run, launch = step, front_launch
     for _ in range(2):
         step()
@@ -361,15 +369,24 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             with torch.cuda.stream(s):
                 step()
             torch.cuda.current_stream().wait_stream(s)
+            finish = world_size == 1                  # (read by step(): captured with or without all-reduce + SGD)
             with torch.cuda.graph(graph, stream=s, capture_error_mode='thread_local'):   # same stream as the warm-up
                 step()
-            graph.replay()
+            if world_size == 1:
+                run, launch = graph.replay, 'hipgraph'
+            else:
+                def run():
+                    graph.replay()
+                    reducer.reduce()
+                    opt.step()
+                launch = 'hipgraph (forward + backward), eager all-reduce + SGD'
+            run()
             torch.cuda.synchronize()
-            run, launch = graph.replay, 'hipgraph'
         except Exception as e:                        # report, never hide
             print(f'[bench] hipGraph capture of the training step failed ({type(e).__name__}: {e}); running eagerly',
                   file=sys.stderr)
             run, launch = step, 'eager'
+        finish = True
     elapsed = D.timed_steps(run, a.steps, a.warmup, dev)
     if rank == 0 and os.environ.get('GD4D_BENCH_CHECK'):      # dev: the launch modes must train identically
         flat = reducer.flat
