@@ -308,13 +308,21 @@ class ValuePipeline:
         self.ready = {}
         self._issue(0)
 
-    # CUs the persistent value_proj kernel may take while the query side runs next to it (of 256; measured optimum:
-    # 160: 316, 192: 326, 224: 317, 256: 291 samples/s; no overlap: 302).  GD4D_PIPELINE_CUS overrides.
+    # CUs the persistent value_proj kernel may take while the query side runs next to it: 3/4 of the device (192 of the
+    # MI355X's 256; measured there: 160: 323, 176: 340, 192: 347, 208: 337, 224: 345, 240: 304 samples/s; no overlap:
+    # 302).  GD4D_PIPELINE_CUS overrides.
     CUS = 192
+
+    def _cu_share(self):
+        env = os.environ.get('GD4D_PIPELINE_CUS')
+        if env:
+            return int(env)
+        cus = torch.cuda.get_device_properties(self.value[0].device).multi_processor_count
+        return self.CUS if cus == 256 else max(8, (cus * 3 // 4) // 8 * 8)
 
     def _issue(self, i):
         m = self.modules[i]
-        old = ops.value_proj_set_cu_limit(int(os.environ.get('GD4D_PIPELINE_CUS', self.CUS)))
+        old = ops.value_proj_set_cu_limit(self._cu_share())
         try:
             with torch.cuda.stream(self.side):
                 val, shapes = value_projection(self.value, m.value_proj.weight, m.value_proj.bias, m.num_heads,
