@@ -68,3 +68,33 @@ def test_host_linear_sum_assignment_matches_scipy():
                 rows, cols = linear_sum_assignment(m)
                 want[rows] = cols
             np.testing.assert_array_equal(a, want)
+
+
+def test_argument_validation_returns_before_any_gpu_work():
+    """Every entry point checks its arguments first: bad calls come back with an error code on a box without a GPU."""
+    import ctypes
+    from graph_detr4d_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    one = (ctypes.c_float * 4)()
+    ptr = ctypes.cast(one, ctypes.c_void_p)
+    EINVAL, EUNSUPPORTED = -1, -2
+    # null pointers
+    assert lib.gd4d_value_proj_bwd_input(null, ptr, ptr, ptr, 1, 256, 1, 0, null) == EINVAL
+    assert lib.gd4d_value_proj_bwd_weight(ptr, ptr, ptr, null, null, ptr, 0, 1, 256, 1, null) == EINVAL
+    assert lib.gd4d_linear_bwd_weight(null, ptr, ptr, null, 4, 4, 4, 4, 4, null) == EINVAL
+    assert lib.gd4d_match_cost_fwd(ptr, ptr, ptr, ptr, null, ptr, 1, 1, 4, 10, 10, 9, 1, 1, 2.0, 0.25, 0.25, null) == EINVAL
+    assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, null, ptr, ptr, ptr, 1, 1, 4, 10, 10, 9,
+                                      0.25, 2.0, 0.25, null) == EINVAL
+    assert lib.gd4d_linear_sum_assignment_batch(null, ptr, ptr, ptr, 1, ptr, ptr, 1) == EINVAL
+    # shapes the kernels are not built for
+    lv = (ctypes.c_int32 * 2)(4, 4)
+    lvp = ctypes.cast(lv, ctypes.c_void_p)
+    assert lib.gd4d_value_proj_bwd_input(ptr, ptr, ptr, lvp, 1, 128, 1, 0, null) == EUNSUPPORTED          # C != 256
+    assert lib.gd4d_match_cost_fwd(ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 4, 10, 10, 9, 5000, 5000,
+                                   2.0, 0.25, 0.25, null) == EUNSUPPORTED                                  # > 1024 boxes per sample
+    assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 4, 10, 4, 9,
+                                      0.25, 2.0, 0.25, null) == EUNSUPPORTED                               # box code < 8
+    # workspace too small for the weight gradient
+    assert lib.gd4d_value_proj_bwd_weight(ptr, ptr, lvp, ptr, null, ptr, 16, 1, 256, 1, null) == EINVAL
+    assert lib.gd4d_value_proj_bwd_weight_workspace_bytes() >= 256 * (256 * 256 + 256) * 4
