@@ -85,3 +85,59 @@ def test_decoder_layer_trains_one_step():
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0]
     assert layer.attentions[1].value_proj.weight.grad.abs().max() > 0
+
+
+def test_decoder_training_step_under_hipgraph_equals_eager():
+    """Forward + backward of the 2-layer decoder (one autograd node for both layers' value_proj, gradients accumulated
+    into the flat buffer dist.FlatGradAllReducer binds) captured in a hipGraph: replaying it gives the eager gradients."""
+    from graph_detr4d_amd import dist as D
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.0),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                         embed_dims=256, dropout=0.0)],
+                         feedforward_channels=512, ffn_dropout=0.0,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    qe = g.t('query_embed').to(DEV)
+    feats = [f.to(DEV).requires_grad_() for f in g.feats()]
+    metas = g.img_metas()
+    params = [p for p in tr.parameters() if p.requires_grad]
+    red = D.FlatGradAllReducer(params)
+    red.bind()
+
+    def step():
+        red.zero_grad()
+        states, _, _ = tr(feats, qe, reg_branches=None, img_metas=metas)
+        (states ** 2).mean().backward()
+
+    step()
+    torch.cuda.synchronize()
+    eager = red.flat.clone()
+    eager_feat = [f.grad.clone() for f in feats]
+    assert float(eager.abs().sum()) > 0
+    for f in feats:
+        f.grad = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    for f in feats:
+        f.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step()
+    for _ in range(2):                                # replay after replay: nothing accumulates across steps
+        graph.replay()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(red.flat, eager, rtol=1e-4, atol=1e-6 * float(eager.abs().max()) + 1e-9)
+        for f, e in zip(feats, eager_feat):
+            torch.testing.assert_close(f.grad, e, rtol=1e-4, atol=1e-6 * float(e.abs().max()) + 1e-12)
