@@ -86,6 +86,9 @@ class HungarianAssigner3D:
         cost = ops.match_cost_fwd(all_cls_scores.detach().contiguous().float(), all_bbox_preds.detach().contiguous().float(),
                                   boxes, labels, start_dev, max(counts), self.cls_weight, self.reg_weight, self.alpha)
         cost = cost.cpu().numpy()                            # THE synchronisation of the step
+        if np.isnan(cost).any():                             # the kernel's marker for a label outside [0, num_classes)
+            raise IndexError(f'gt_labels must lie in [0, {all_cls_scores.shape[-1]}): the reference indexes '
+                             'cls_pred[:, gt_labels] with them (core/bbox/match_costs/match_cost.py:17-30)')
         sum_gt = int(start[-1])
         problems = [(q * (l * sum_gt + int(start[i])), q, counts[i]) for l in range(nl) for i in range(b)]
         # host threads pay off only when a problem is worth more than starting one (measured: 6 x (900 x 45) takes

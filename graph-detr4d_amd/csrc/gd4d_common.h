@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gd4d.h"
 
 #define GD4D_WAVE 64
@@ -19,6 +23,22 @@ inline int check_launch() {
     return GD4D_ELAUNCH;
   }
   return GD4D_OK;
+}
+
+// Allow `bytes` of dynamic LDS for `kern` on the CURRENT device.  hipFuncAttributeMaxDynamicSharedMemorySize is a
+// per-device attribute, so what has been granted is remembered per (kernel, device id) - a process driving several GPUs
+// configures each of them (a process-wide "configured" flag would leave every device but the first at 64 KB).
+inline bool allow_dynamic_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> guard(mu);
+  int& have = granted[std::make_pair(kern, dev)];
+  if (have >= bytes) return true;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  have = bytes;
+  return true;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

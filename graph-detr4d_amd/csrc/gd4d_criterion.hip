@@ -55,7 +55,12 @@ __global__ __launch_bounds__(256) void match_cost_kernel(const MatchCostParams p
   for (int e = threadIdx.x; e < nq * G; e += blockDim.x) {
     const int ql = e / G, g = e - ql * G;
     const int q = q0 + ql;
-    const float x = p.cls[(row0 + q) * p.C + s_lab[g]];
+    const int lab = s_lab[g];
+    if (lab < 0 || lab >= p.C) {                          // the reference's cls_pred[:, gt_labels] raises here; the host
+      out[(size_t)q * G + g] = __builtin_nanf("");        // sees the NaN (valid costs are never NaN) and raises too
+      continue;
+    }
+    const float x = p.cls[(row0 + q) * p.C + lab];
     const float pr = 1.0f / (1.0f + expf(-x));
     const float neg = -logf(1.0f - pr + 1e-12f) * (1.0f - p.alpha) * (pr * pr);
     const float pos = -logf(pr + 1e-12f) * p.alpha * ((1.0f - pr) * (1.0f - pr));
@@ -81,7 +86,7 @@ struct HeadLossParams {
   float* loss;                 // (NL, 2): loss_cls, loss_bbox
   float* grad_cls;             // like cls
   float* grad_box;             // like box
-  int NL, B, Q, C, code, gt_dim;
+  int NL, B, Q, C, code, gt_dim, sumG;
   float alpha, cls_weight, box_weight;
 };
 
@@ -96,8 +101,10 @@ __global__ __launch_bounds__(1024) void head_loss_kernel(const HeadLossParams p)
   float sum_cls = 0.f, sum_box = 0.f;
   for (int r = threadIdx.x; r < p.B * p.Q; r += blockDim.x) {
     const size_t row = (size_t)l * p.B * p.Q + r;
-    const int a = p.assigned[row];
-    const int label = a >= 0 ? p.gt_labels[a] : p.C;
+    int a = p.assigned[row];
+    if (a >= p.sumG) a = -1;                               // never index past the ground truth (host validates; memory safety)
+    int label = a >= 0 ? p.gt_labels[a] : p.C;
+    if (label < 0 || label > p.C) label = p.C;
     const float* x = p.cls + row * p.C;
     float* gx = p.grad_cls + row * p.C;
     for (int c = 0; c < p.C; ++c) {
@@ -141,7 +148,9 @@ __global__ __launch_bounds__(1024) void head_loss_kernel(const HeadLossParams p)
     float s = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_red[threadIdx.x][w];
     s *= threadIdx.x == 0 ? kc : kb;
-    if (s != s) s = 0.f;                                   // torch.nan_to_num on the two loss terms (:844-845)
+    if (s != s) s = 0.f;                                   // torch.nan_to_num on the two loss terms (:844-845):
+    else if (s == INFINITY) s = 3.402823466e38f;           // nan -> 0, +/-inf -> +/-FLT_MAX
+    else if (s == -INFINITY) s = -3.402823466e38f;
     p.loss[2 * l + threadIdx.x] = s;
   }
 }
@@ -166,16 +175,16 @@ extern "C" int gd4d_match_cost_fwd(const float* cls, const float* box, const flo
 extern "C" int gd4d_head_loss_fwd_bwd(const float* cls, const float* box, const int32_t* assigned, const float* gt_boxes,
                                       const int32_t* gt_labels, const float* code_weights, const float* avg_factors,
                                       float* loss, float* grad_cls, float* grad_box, int NL, int B, int Q, int C,
-                                      int code, int gt_dim, float alpha, float loss_cls_weight, float loss_bbox_weight,
-                                      void* stream) {
+                                      int code, int gt_dim, int sum_gt, float alpha, float loss_cls_weight,
+                                      float loss_bbox_weight, void* stream) {
   using namespace gd4d;
   if (!cls || !box || !assigned || !gt_boxes || !gt_labels || !code_weights || !avg_factors || !loss || !grad_cls ||
       !grad_box)
     return GD4D_EINVAL;
-  if (NL <= 0 || B <= 0 || Q <= 0 || C <= 0) return GD4D_EINVAL;
+  if (NL <= 0 || B <= 0 || Q <= 0 || C <= 0 || sum_gt <= 0) return GD4D_EINVAL;
   if (code < 8 || code > 16 || gt_dim < 7 || gt_dim > 9) return GD4D_EUNSUPPORTED;
   HeadLossParams p{cls, box, assigned, gt_boxes, gt_labels, code_weights, avg_factors, loss, grad_cls, grad_box,
-                   NL, B, Q, C, code, gt_dim, alpha, loss_cls_weight, loss_bbox_weight};
+                   NL, B, Q, C, code, gt_dim, sum_gt, alpha, loss_cls_weight, loss_bbox_weight};
   hipLaunchKernelGGL(head_loss_kernel, dim3(NL), dim3(1024), 0, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }

@@ -258,13 +258,8 @@ extern "C" int gd4d_nms_free_decode_fwd(const float* cls_scores, const float* bb
   p.score_thr = score_threshold;
   const size_t lds = (size_t)Q * C * sizeof(unsigned);
   if (lds > DEC_MAX_DYN_LDS) return GD4D_EUNSUPPORTED;
-  static bool configured = false;                   // allow more than the default 64 KB of LDS per workgroup
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_free_decode_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_MAX_DYN_LDS) != hipSuccess)
-      return GD4D_ELAUNCH;
-    configured = true;
-  }
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(nms_free_decode_kernel), (int)DEC_MAX_DYN_LDS))   // > 64 KB of LDS
+    return GD4D_ELAUNCH;
   hipLaunchKernelGGL(nms_free_decode_kernel, dim3(B), dim3(DEC_THREADS), lds, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }

@@ -200,13 +200,7 @@ extern "C" int gd4d_gemm_bf16x3_fwd(const float* a, const uint16_t* w_hi, const 
   if (!aligned16(a) || !aligned16(w_hi) || !aligned16(w_lo)) return GD4D_EALIGN;
   GemmParams p{a, w_hi, w_lo, bias, c, M, N, K, lda, ldc, (flags & GD4D_LIN_RELU) ? 1 : 0,
                (flags & GD4D_GEMM_RELU_IN) ? 1 : 0};
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * GM_STAGE) != hipSuccess)
-      return GD4D_ELAUNCH;
-    configured = true;
-  }
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16x3_kernel), 2 * GM_STAGE)) return GD4D_ELAUNCH;
   const dim3 grid(N / GM_BN, (M + GM_BM - 1) / GM_BM);
   hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(GM_THREADS), 2 * GM_STAGE, static_cast<hipStream_t>(stream), p);
   return check_launch();

@@ -846,7 +846,7 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
     const bool ob = out_dtype == GD4D_BF16;
     if (vp_variant() == 3 && !p.single_product && p.dbg == 0) {     // one wave per SIMD
       auto go4 = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds2);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds2, st, p);
       };
       if (p.head_major) { if (ob) go4(value_proj_w4_kernel<true, true>); else go4(value_proj_w4_kernel<false, true>); }
@@ -854,7 +854,7 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
       return check_launch();
     }
     auto go = [&](auto kern) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds2);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(VP_THREADS), lds2, st, p);
     };
     switch (p.dbg) {                                 // ablation builds exist for fp32 output only
@@ -875,14 +875,10 @@ static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, 
   }
   const size_t lds = 2 * 2 * (size_t)BM * VP_C * 2;    // 2 buffers x (hi, lo) x [BM][256] bf16
   if (out_dtype == GD4D_BF16) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_kernel<BM, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    (void)allow_dynamic_lds(reinterpret_cast<const void*>(value_proj_kernel<BM, true>), (int)lds);
     hipLaunchKernelGGL((value_proj_kernel<BM, true>), dim3(grid), dim3(VP_THREADS), lds, st, p);
   } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_kernel<BM, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    (void)allow_dynamic_lds(reinterpret_cast<const void*>(value_proj_kernel<BM, false>), (int)lds);
     hipLaunchKernelGGL((value_proj_kernel<BM, false>), dim3(grid), dim3(VP_THREADS), lds, st, p);
   }
   return check_launch();

@@ -493,7 +493,7 @@ extern "C" int gd4d_value_proj_bwd_input(const float* grad_out, const float* wei
   const size_t lds = 4 * (size_t)64 * VB_C * 2 + 256;
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   };
   if (accumulate) go(value_proj_bwd_input_kernel<true>); else go(value_proj_bwd_input_kernel<false>);
@@ -527,13 +527,7 @@ extern "C" int gd4d_value_proj_bwd_weight(const float* grad_out, const void* con
   if (grid > total) grid = total;
   const size_t lds = 2 * (size_t)VW_STAGE + 256;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(value_proj_bwd_weight_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return GD4D_ELAUNCH;
-    configured = true;
-  }
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(value_proj_bwd_weight_kernel), (int)lds)) return GD4D_ELAUNCH;
   hipLaunchKernelGGL(value_proj_bwd_weight_kernel, dim3(grid), dim3(VW_THREADS), lds, st, p);
   if (int rc = check_launch()) return rc;
   constexpr int N = VB_C * VB_C + VB_C;

@@ -88,28 +88,71 @@ def aggregate_throughput(units_per_rank_step, steps, world, elapsed):
 
 
 class FlatGradAllReducer:
-    """Data-parallel gradient averaging with ONE collective per step.
+    """Data-parallel gradient averaging over ONE flat fp32 buffer.
 
     The reference trains under MMDistributedDataParallel (projects/mmdet3d_plugin/apis/
     mmdet_distill_train.py:78-82): bucketed NCCL all-reduces of ~25 MB plus two scalar all-reduces per
     decoder layer in the loss.  On MI355X the 8 GPUs are fully connected by point-to-point xGMI links
     (7 x ~153 GB/s per GPU), a ring is per-link bound and small collectives are latency bound, so the
-    gradients of the whole module are packed into one contiguous fp32 buffer and reduced with a single
-    RCCL all-reduce (SUM, then scaled by 1/world) - fewer, larger collectives.  Extra scalars (e.g. the
-    loss normalisers the reference reduces one by one) can ride in the same buffer via `extras`.
+    gradients of the whole module live in one contiguous fp32 buffer (every .grad is a view of it) and are
+    reduced by RCCL all-reduces over slices of that buffer (SUM, then scaled by 1/world):
+
+      * reduce()            - one collective for the whole buffer (fewer, larger collectives: right for the
+                              22 MB of the decoder alone);
+      * buckets + overlap   - `buckets` = groups of parameters in the order their gradients become final
+                              during backward (the last decoder layer first).  The buffer is laid out bucket by
+                              bucket; install_hooks() starts the asynchronous all-reduce of a bucket as soon as
+                              autograd has accumulated its last gradient, so the collective of layer l travels
+                              over xGMI while layer l-1 is still in its backward (what the 140-330 MB of the full
+                              model need); finish() waits for the collectives and scales.  reduce_buckets() issues
+                              the same slices back to back (after a captured backward, where hooks do not run).
+                              All three give bit-identical buffers: a slice-wise SUM is the same SUM.
+
+    Extra scalars (e.g. the loss normalisers the reference reduces one by one) ride behind the gradients
+    (`extras`, summed, not averaged).  Their capacity is fixed at construction (`max_extras`): the buffer is
+    allocated ONCE and never moves afterwards - a hipGraph capture of the backward records its addresses.
     """
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, max_extras=0, buckets=None):
+        params = [p for p in params if p.requires_grad]
+        if buckets is not None:
+            buckets = [[p for p in b if p.requires_grad] for b in buckets]
+            buckets = [b for b in buckets if b]
+            seen = {id(p) for b in buckets for p in b}
+            rest = [p for p in params if id(p) not in seen]
+            if len(seen) != sum(len(b) for b in buckets):
+                raise ValueError('a parameter appears in more than one bucket')
+            if rest:
+                buckets.append(rest)                         # whatever the caller did not place goes last
+            params = [p for b in buckets for p in b]
+        else:
+            buckets = [params]
+        self.params = params
         self.numel = sum(p.numel() for p in self.params)
+        self.max_extras = int(max_extras)
         self.flat = None
         self.views = None
+        # [start, end) of every bucket inside the flat buffer
+        self.bucket_ranges, off = [], 0
+        for b in buckets:
+            n = sum(p.numel() for p in b)
+            self.bucket_ranges.append((off, off + n))
+            off += n
+        self._bucket_of = {}
+        for bi, b in enumerate(buckets):
+            for p in b:
+                self._bucket_of[id(p)] = bi
+        self._bucket_sizes = [len(b) for b in buckets]
+        self._pending = None
+        self._handles = []
+        self._hooks = []
 
-    def _buffer(self, like, extra):
-        n = self.numel + extra
-        if self.flat is None or self.flat.numel() != n or self.flat.device != like.device:
-            self.flat = torch.zeros(n, dtype=torch.float32, device=like.device)
+    def _buffer(self, like):
+        if self.flat is None:
+            self.flat = torch.zeros(self.numel + self.max_extras, dtype=torch.float32, device=like.device)
             self.views = None
+        elif self.flat.device != like.device:
+            raise RuntimeError('FlatGradAllReducer: the parameters moved to another device after the buffer was bound')
         return self.flat
 
     def _bind(self, flat):
@@ -133,9 +176,10 @@ class FlatGradAllReducer:
 
     @torch.no_grad()
     def bind(self):
-        """Allocate the flat buffer and bind every .grad to it now (parameters without a gradient get zeros).  Needed
-        before a backward pass is captured in a hipGraph: the capture records the addresses it accumulates into."""
-        self._bind(self._buffer(self.params[0], 0 if self.flat is None else self.flat.numel() - self.numel))
+        """Allocate the flat buffer (gradients + max_extras) and bind every .grad to it now (parameters without a
+        gradient get zeros).  Needed before a backward pass is captured in a hipGraph: the capture records the
+        addresses it accumulates into; the buffer is never reallocated afterwards."""
+        self._bind(self._buffer(self.params[0]))
 
     @torch.no_grad()
     def zero_grad(self):
@@ -147,21 +191,114 @@ class FlatGradAllReducer:
             if p.grad is not None:
                 p.grad.zero_()
 
+    def _world(self):
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    def _stage_extras(self, flat, extras):
+        ne = 0 if extras is None else extras.numel()
+        if ne > self.max_extras:
+            raise ValueError(f'FlatGradAllReducer: {ne} extras but the buffer was sized for max_extras='
+                             f'{self.max_extras}; the bound buffer never grows (its address may be captured in a '
+                             f'hipGraph) - pass max_extras at construction')
+        if self.max_extras:
+            flat[self.numel:].zero_()
+        if ne:
+            flat[self.numel:self.numel + ne].copy_(extras.reshape(-1).float())
+        return ne
+
     @torch.no_grad()
     def reduce(self, extras=None):
-        """Average .grad of every parameter over all ranks (missing grads count as zero).
-        extras: optional 1-D float tensor reduced (summed, NOT averaged) in the same collective; returned."""
-        like = self.params[0]
-        ne = 0 if extras is None else extras.numel()
-        flat = self._buffer(like, ne)
+        """Average .grad of every parameter over all ranks (missing grads count as zero) with ONE collective.
+        extras: optional 1-D float tensor (<= max_extras elements) reduced (summed, NOT averaged) in the same
+        collective; returned."""
+        flat = self._buffer(self.params[0])
         self._bind(flat)
-        if ne:
-            flat[self.numel:].copy_(extras.reshape(-1).float())
-        world = dist.get_world_size() if dist.is_initialized() else 1
+        ne = self._stage_extras(flat, extras)
+        world = self._world()
         if world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat[:self.numel].mul_(1.0 / world)
-        return flat[self.numel:].clone() if ne else None
+        return flat[self.numel:self.numel + ne].clone() if ne else None
+
+    # ---- bucketed form: the all-reduce of a bucket overlaps the backward of the layers below it ----
+    def _launch_bucket(self, bi):
+        lo, hi = self.bucket_ranges[bi]
+        if self._world() > 1 and hi > lo:
+            self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self._launched.append(bi)
+
+    def install_hooks(self):
+        """Register post-accumulate hooks: when the last gradient of a bucket has been accumulated during backward, the
+        bucket's all-reduce starts (asynchronously, on the backend's own stream).  Call begin_step() before each
+        backward and finish() after it."""
+        if self._hooks:
+            return
+        self.bind()
+
+        def make(p):
+            def hook(_):
+                if self._pending is None:
+                    return
+                bi = self._bucket_of[id(p)]
+                self._pending[bi] -= 1
+                if self._pending[bi] == 0:
+                    self._launch_bucket(bi)
+            return hook
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(make(p)))
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def begin_step(self):
+        """Arm the hooks for one backward pass (zero_grad() first)."""
+        self._pending = list(self._bucket_sizes)
+        self._handles, self._launched = [], []
+
+    @torch.no_grad()
+    def finish(self, extras=None):
+        """After backward: launch the buckets whose hooks never completed (parameters without a gradient this step),
+        reduce the extras, wait for every collective and scale the gradients by 1/world."""
+        flat = self._buffer(self.params[0])
+        if self._pending is None:
+            self.begin_step()
+        for bi in range(len(self.bucket_ranges)):
+            if bi not in self._launched:
+                self._launch_bucket(bi)
+        ne = self._stage_extras(flat, extras)
+        world = self._world()
+        if world > 1 and self.max_extras:
+            self._handles.append(dist.all_reduce(flat[self.numel:], op=dist.ReduceOp.SUM, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles, self._pending = [], None
+        if world > 1:
+            flat[:self.numel].mul_(1.0 / world)
+        return flat[self.numel:self.numel + ne].clone() if ne else None
+
+    @torch.no_grad()
+    def reduce_buckets(self, extras=None):
+        """The bucketed collectives issued back to back (no hooks: e.g. after a hipGraph replay of the backward)."""
+        self._bind(self._buffer(self.params[0]))
+        self.begin_step()
+        return self.finish(extras)
 
     def bytes_per_step(self):
         return self.numel * 4
+
+    def describe(self):
+        """Self-description for the bench line: bytes per step and per bucket."""
+        return dict(allreduce_bytes=self.bytes_per_step() + 4 * self.max_extras,
+                    buckets=[(hi - lo) * 4 for lo, hi in self.bucket_ranges])
+
+
+def decoder_buckets(transformer, *others):
+    """Gradient buckets of a Detr3DTransformer in the order backward finalises them: `others` (head branches - their
+    gradients arrive first), then the decoder layers from the last to the first, then the rest."""
+    buckets = [list(m.parameters()) for m in others if m is not None]
+    layers = list(transformer.decoder.layers)
+    for layer in reversed(layers):
+        buckets.append(list(layer.parameters()))
+    return buckets

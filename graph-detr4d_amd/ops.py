@@ -4,6 +4,8 @@ Every function requires CUDA(HIP)-resident, contiguous tensors and raises otherw
 path has no CPU fallback.
 """
 import ctypes
+import functools
+import inspect
 
 import torch
 
@@ -622,8 +624,8 @@ def head_loss_fwd_bwd(cls, box, assigned, gt_boxes, gt_labels, code_weights, avg
                                       _dev(gt_boxes, 'gt_boxes', f32), _dev(gt_labels, 'gt_labels', i32),
                                       _dev(code_weights, 'code_weights', f32), _dev(avg_factors, 'avg_factors', f32),
                                       _dev(loss, 'loss'), _dev(gcls, 'grad_cls'), _dev(gbox, 'grad_box'), nl, b, q, c,
-                                      box.shape[-1], gt_boxes.shape[-1], float(alpha), float(loss_cls_weight),
-                                      float(loss_bbox_weight), _stream())
+                                      box.shape[-1], gt_boxes.shape[-1], gt_boxes.shape[0], float(alpha),
+                                      float(loss_cls_weight), float(loss_bbox_weight), _stream())
     _lib.check(code, 'gd4d_head_loss_fwd_bwd')
     return loss, gcls, gbox
 
@@ -647,3 +649,33 @@ def linear_sum_assignment_batch(cost, problems, num_threads=8):
                                                 as_p(out_off), int(num_threads))
     _lib.check(code, 'gd4d_linear_sum_assignment_batch')
     return [out[out_off[i]:out_off[i + 1]] for i in range(n)]
+
+
+def _first_tensor(args):
+    for a in args:
+        if torch.is_tensor(a):
+            return a
+        if isinstance(a, (list, tuple)) and a and torch.is_tensor(a[0]):
+            return a[0]
+    return None
+
+
+def _on_tensor_device(fn):
+    """Run `fn` with the device of its first tensor argument current: _stream() then hands the C ABI that device's
+    current stream and the library's per-device state (CU count, LDS attributes) refers to the right GPU, also when
+    one process drives several GPUs or the tensors live on a non-current device."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        t = _first_tensor(args)
+        if t is None or not t.is_cuda or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return wrapped
+
+
+_HOST_ONLY = {'linear_sum_assignment_batch', 'value_proj_set_cu_limit'}
+for _name, _fn in list(globals().items()):
+    if inspect.isfunction(_fn) and _fn.__module__ == __name__ and not _name.startswith('_') and _name not in _HOST_ONLY:
+        globals()[_name] = _on_tensor_device(_fn)
+del _name, _fn

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 13
+#define GD4D_ABI_VERSION 14
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -450,14 +450,18 @@ int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, const float*
  *   (dense_heads/detr3d_head_pe.py:782-845 with :700-742; mmdet FocalLoss(use_sigmoid, gamma = 2, alpha) and L1Loss):
  *   assigned (NL, B, Q) int32 = index into gt_boxes / gt_labels or -1 for background; code_weights (10);
  *   avg_factors DEVICE 2 floats (cls_avg_factor, num_total_pos: the two all-reduced normalisers, clamped to >= 1 here);
- *   grad_cls / grad_box = d(loss_cls[l]) / d cls[l], d(loss_bbox[l]) / d box[l]. */
+ *   grad_cls / grad_box = d(loss_cls[l]) / d cls[l], d(loss_bbox[l]) / d box[l].
+ *   Labels: a gt_labels entry outside [0, C) makes gd4d_match_cost_fwd write NaN into that column's costs (valid costs
+ *   are never NaN: nan_to_num has been applied) - the host raises, as the reference's indexing does; the loss kernel
+ *   treats assigned >= sum_gt or such a label as background (memory safety only).  The loss terms pass through
+ *   torch.nan_to_num semantics (nan -> 0, +/-inf -> +/-FLT_MAX). */
 int gd4d_match_cost_fwd(const float* cls, const float* box, const float* gt_boxes, const int32_t* gt_labels,
                         const int32_t* gt_start, float* cost, int NL, int B, int Q, int C, int code, int gt_dim,
                         int sum_gt, int max_gt, float cls_weight, float reg_weight, float alpha, void* stream);
 int gd4d_head_loss_fwd_bwd(const float* cls, const float* box, const int32_t* assigned, const float* gt_boxes,
                            const int32_t* gt_labels, const float* code_weights, const float* avg_factors, float* loss,
                            float* grad_cls, float* grad_box, int NL, int B, int Q, int C, int code, int gt_dim,
-                           float alpha, float loss_cls_weight, float loss_bbox_weight, void* stream);
+                           int sum_gt, float alpha, float loss_cls_weight, float loss_bbox_weight, void* stream);
 
 /* gd4d_linear_sum_assignment_batch - HOST function (no GPU work): the linear sum assignment the reference delegates to
  * scipy (hungarian_assigner_3d.py:125-131), for a batch of independent problems solved on `num_threads` host threads.

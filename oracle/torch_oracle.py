@@ -330,9 +330,10 @@ def _sub(p, prefix):
 
 def decoder_layer(p, query, value, query_pos, reference_points, img_metas, pc_range,
                   cross='Deform3DCrossAttn', num_heads=8, num_points=4, attn_mask=None,
-                  depth_encode=False):
+                  depth_encode=False, return_parts=False):
     """Post-norm DetrTransformerDecoderLayer (third-party mmdet/mmcv), order
-    self_attn, norm, cross_attn, norm, ffn, norm (config :88-89; Appendix A.4)."""
+    self_attn, norm, cross_attn, norm, ffn, norm (config :88-89; Appendix A.4).
+    return_parts (Deform3DCrossAttn only): also return the cross-attention's intermediates (mask, uv, ...)."""
     c = query.shape[-1]
 
     def ln(x, i):
@@ -340,15 +341,18 @@ def decoder_layer(p, query, value, query_pos, reference_points, img_metas, pc_ra
     x = multihead_self_attn(p, query, query_pos, num_heads, attn_mask, prefix='attentions.0.attn.')
     x = ln(x, 0)
     cp = _sub(p, 'attentions.1.')
+    parts = None
     if cross == 'Deform3DCrossAttn':
         x = deform3d_cross_attn(cp, x, value, query_pos, reference_points, img_metas, pc_range,
-                                num_heads, num_points, depth_encode)
+                                num_heads, num_points, depth_encode, return_parts=return_parts)
+        if return_parts:
+            x, parts = x
     else:
         x = detr3d_cross_atten(cp, x, value, query_pos, reference_points, img_metas, pc_range,
                                num_points)
     x = ln(x, 1)
     x = ffn(p, x)
-    return ln(x, 2)
+    return (ln(x, 2), parts) if return_parts else ln(x, 2)
 
 
 def decoder(layer_params, query, value, query_pos, reference_points, img_metas, pc_range,

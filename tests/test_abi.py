@@ -84,7 +84,7 @@ def test_argument_validation_returns_before_any_gpu_work():
     assert lib.gd4d_value_proj_bwd_weight(ptr, ptr, ptr, null, null, ptr, 0, 1, 256, 1, null) == EINVAL
     assert lib.gd4d_linear_bwd_weight(null, ptr, ptr, null, 4, 4, 4, 4, 4, null) == EINVAL
     assert lib.gd4d_match_cost_fwd(ptr, ptr, ptr, ptr, null, ptr, 1, 1, 4, 10, 10, 9, 1, 1, 2.0, 0.25, 0.25, null) == EINVAL
-    assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, null, ptr, ptr, ptr, 1, 1, 4, 10, 10, 9,
+    assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, null, ptr, ptr, ptr, 1, 1, 4, 10, 10, 9, 1,
                                       0.25, 2.0, 0.25, null) == EINVAL
     assert lib.gd4d_linear_sum_assignment_batch(null, ptr, ptr, ptr, 1, ptr, ptr, 1) == EINVAL
     # shapes the kernels are not built for
@@ -93,7 +93,7 @@ def test_argument_validation_returns_before_any_gpu_work():
     assert lib.gd4d_value_proj_bwd_input(ptr, ptr, ptr, lvp, 1, 128, 1, 0, null) == EUNSUPPORTED          # C != 256
     assert lib.gd4d_match_cost_fwd(ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 4, 10, 10, 9, 5000, 5000,
                                    2.0, 0.25, 0.25, null) == EUNSUPPORTED                                  # > 1024 boxes per sample
-    assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 4, 10, 4, 9,
+    assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 4, 10, 4, 9, 1,
                                       0.25, 2.0, 0.25, null) == EUNSUPPORTED                               # box code < 8
     # workspace too small for the weight gradient
     assert lib.gd4d_value_proj_bwd_weight(ptr, ptr, lvp, ptr, null, ptr, 16, 1, 256, 1, null) == EINVAL

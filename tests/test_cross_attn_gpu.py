@@ -82,10 +82,13 @@ def test_fused_kernel_vs_oracle_seeded_midsize():
                                    l2i.cuda(), synthetic.PC_RANGE, 900, 1600, want_mask=True)
     # torch's batched matmul on THIS host decides m_ref; the C-level arithmetic is pinned by the
     # golden tests above, so here only require agreement away from the decision thresholds.
-    mism = (mask.cpu() != m_ref.to(torch.uint8))
+    mism = (mask.cpu() != m_ref.to(torch.uint8))                 # (B, N, Q, Hh, P)
     assert mism.float().mean().item() < 1e-4
-    if not mism.any():
-        torch.testing.assert_close(out.cpu(), o_ref, rtol=RTOL, atol=ATOL)
+    # a flipped visibility bit changes ONE query row; every other row is compared, always
+    flipped = mism.any(dim=4).any(dim=3).any(dim=1)              # (B, Q)
+    assert flipped.sum().item() <= 3, f'{int(flipped.sum())} query rows with a flipped mask bit'
+    keep = ~flipped
+    torch.testing.assert_close(out.cpu()[keep], o_ref[keep], rtol=RTOL, atol=ATOL)
 
 
 def test_linearity_and_invisible_cameras_full_size():

@@ -84,8 +84,16 @@ def _grad_worker(rank, world, port, q):
     net(x).sum().backward()
     net[0].bias.grad = None                                  # a parameter without grad on this rank
     local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
-    red = D.FlatGradAllReducer(net.parameters())
+    red = D.FlatGradAllReducer(net.parameters(), max_extras=2)
+    red.bind()                                                # the address a hipGraph capture would record ...
+    ptr = red.flat.data_ptr()
     extras = red.reduce(extras=torch.tensor([float(rank + 1), 10.0]))
+    assert red.flat.data_ptr() == ptr                         # ... never moves (extras used to reallocate)
+    try:
+        red.reduce(extras=torch.ones(3))
+        raise AssertionError('more extras than max_extras must be refused')
+    except ValueError:
+        pass
     first = [None if p.grad is None else p.grad.numpy().copy() for p in net.parameters()]
     # second step: .grad is now a view of the flat buffer - zero_grad is one fill, autograd accumulates in place
     bound = [p.grad for p in net.parameters() if p.requires_grad]
@@ -135,3 +143,71 @@ def test_flat_gradient_allreduce_two_ranks():
         np.testing.assert_allclose(a0, ((z if l0 is None else l0) + (z if l1 is None else l1)) / 2, rtol=1e-6)
     np.testing.assert_allclose(ex0, [3.0, 20.0])              # extras are summed, not averaged
     np.testing.assert_allclose(ex1, [3.0, 20.0])
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import copy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from graph_detr4d_amd import dist as D
+    D.init(backend='gloo')
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                              torch.nn.Linear(16, 4))
+    net2 = copy.deepcopy(net)
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(rank + 1))
+    # single-shot reducer
+    one = D.FlatGradAllReducer(net.parameters(), max_extras=1)
+    one.bind()
+    net(x).square().sum().backward()
+    ex1 = one.reduce(extras=torch.tensor([float(rank + 1)]))
+    # bucketed reducer, last layer first, all-reduces launched from post-accumulate hooks during backward
+    buckets = [list(net2[4].parameters()), list(net2[2].parameters())]      # net2[0] is left to the tail bucket
+    two = D.FlatGradAllReducer(net2.parameters(), max_extras=1, buckets=buckets)
+    two.install_hooks()
+    ptr = two.flat.data_ptr()
+    launched = []
+    for _ in range(2):                                                       # two steps: hooks re-arm
+        two.zero_grad()
+        two.begin_step()
+        net2(x).square().sum().backward()
+        launched.append(list(two._launched))                                 # buckets started by hooks, before finish()
+        ex2 = two.finish(extras=torch.tensor([float(rank + 1)]))
+    assert two.flat.data_ptr() == ptr
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters()}
+    g2 = {n: p.grad.clone() for n, p in net2.named_parameters()}
+    same = all(torch.equal(g1[n], g2[n]) for n in g1)
+    # the back-to-back form (after a captured backward) on the same gradients
+    two.zero_grad()
+    net2(x).square().sum().backward()
+    two.remove_hooks()
+    two.reduce_buckets()
+    g3 = {n: p.grad.clone() for n, p in net2.named_parameters()}
+    same3 = all(torch.equal(g1[n], g3[n]) for n in g1)
+    q.put((rank, same, same3, launched, float(ex1), float(ex2), two.describe()))
+    D.shutdown()
+
+
+def test_bucketed_overlapped_allreduce_equals_single_shot():
+    """the reducer chunked by layer in reverse order (hooks start a bucket's all-reduce during
+    backward) gives bit-identical gradients to the single-shot reducer, on 2 gloo ranks."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, same3, launched, ex1, ex2, desc in res:
+        assert same and same3
+        assert launched == [[0, 1, 2], [0, 1, 2]]          # every bucket was started by its hook, last layer first
+        assert ex1 == ex2 == 3.0
+        assert desc['buckets'] == [(16 * 4 + 4) * 4, (16 * 16 + 16) * 4, (8 * 16 + 16) * 4]
+        assert desc['allreduce_bytes'] == sum(desc['buckets']) + 4

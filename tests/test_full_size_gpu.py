@@ -15,7 +15,7 @@ def test_each_decoder_layer_900q_24cams_matches_oracle():
     import bench
     import graph_detr4d_amd as G
     from graph_detr4d_amd import functional as Fn
-    from graph_detr4d_amd import synthetic
+    from graph_detr4d_amd import ops, synthetic
     from oracle import torch_oracle as O
     torch.set_num_threads(16)
     frames, queries, layers = 4, 900, 6
@@ -39,24 +39,43 @@ def test_each_decoder_layer_900q_24cams_matches_oracle():
         worst = []
         for lid in range(layers):
             # oracle: one layer + refinement from the oracle's own state
-            y_ref = O.decoder_layer(layer_params[lid], x, feats, query_pos, ref, metas, pc,
-                                    cross='Deform3DCrossAttn', num_heads=8, num_points=4)
+            y_ref, parts = O.decoder_layer(layer_params[lid], x, feats, query_pos, ref, metas, pc,
+                                           cross='Deform3DCrossAttn', num_heads=8, num_points=4, return_parts=True)
             tmp = regs_cpu[lid](y_ref.permute(1, 0, 2))
             new = torch.zeros_like(ref)
             new[..., :2] = tmp[..., :2] + O.inverse_sigmoid(ref[..., :2])
             new[..., 2:3] = tmp[..., 4:5] + O.inverse_sigmoid(ref[..., 2:3])
             ref_next = new.sigmoid()
             # HIP: the same layer on the same inputs
-            y = tr_d.decoder.layers[lid](x.to(dev), key=None, value=feats_d, query_pos=query_pos.to(dev),
-                                         reference_points=ref.to(dev), img_metas=metas)
+            captured = {}
+            orig = Fn.sample_aggregate
+
+            def spy(value, shapes, ref_, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=None):
+                hm = value.shape[2] == sum(h * w for h, w in shapes) and value.shape[1] != value.shape[2]
+                _, captured['mask'] = ops.cross_attn_fwd(value, shapes, ref_.contiguous(), offsets.contiguous(),
+                                                         attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
+                                                         pc_range, img_h, img_w, head_major=hm, want_mask=True)
+                return orig(value, shapes, ref_, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
+                            order=order)
+            Fn.sample_aggregate = spy
+            try:
+                y = tr_d.decoder.layers[lid](x.to(dev), key=None, value=feats_d, query_pos=query_pos.to(dev),
+                                             reference_points=ref.to(dev), img_metas=metas)
+            finally:
+                Fn.sample_aggregate = orig
             tmp_d = Fn.run_branch(regs_d[lid], y.permute(1, 0, 2).contiguous())
             ref_d = Fn.refine_reference(tmp_d, ref.to(dev))
+            # The visibility mask is the path's only discontinuity: a point within an ulp of a threshold can flip
+            # between the GPU's and the CPU's GEMM rounding of the offsets and move ONE query row.  Both masks are
+            # captured, exactly the rows with a flipped bit are excluded (their number is bounded), and every other
+            # row must meet the path's tolerance (north_star: 1e-3) strictly.
+            mism = captured['mask'].cpu().bool() != parts['mask']                     # (B, N, Q, Hh, P)
+            flipped = mism.any(dim=4).any(dim=3).any(dim=1)[0]                        # (Q,)
             err = (y.cpu() - y_ref).abs().amax(dim=(1, 2))          # per query row
-            worst.append((float((err > 1e-3).float().mean()), float(err.median())))
-            # tolerance of the path: 1e-3 (north_star); a point within an ulp of a visibility threshold may
-            # flip between the GPU's and the CPU's GEMM rounding of the offsets and move ONE query row
-            assert (err > 1e-3).float().mean().item() <= 0.005, (lid, worst)
+            worst.append((int(flipped.sum()), float(err[~flipped].max()), float(err.median())))
+            assert flipped.sum().item() <= 8, (lid, worst)
+            assert err[~flipped].max().item() < 1e-3, (lid, worst)
             assert err.median().item() < 2e-4, (lid, worst)
             assert (ref_d.cpu() - ref_next).abs().max().item() < 1e-3
             x, ref = y_ref, ref_next                                  # teacher forcing
-    print('per-layer (fraction of rows > 1e-3, median row error):', worst)
+    print('per-layer (rows with a flipped mask bit, max error of the other rows, median row error):', worst)
