@@ -43,13 +43,18 @@ def parse():
     ap.add_argument('--levels', default='r50', choices=['r50', 'vov'])
     ap.add_argument('--value-dtype', default='fp32', choices=['fp32', 'bf16'],
                     help='storage of the projected value tensor (fp32 = the reference-parity mode)')
-    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
-                    help="'train': forward + backward + one flat RCCL gradient all-reduce + SGD per step (secondary metric)")
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train', 'distill'],
+                    help="'train': forward + backward + one flat RCCL gradient all-reduce + SGD per step (secondary metric); "
+                         "'distill': BASELINE configs[4] - teacher pass (no grad), student pass and teacher-query-guided "
+                         "student pass over one pyramid, instance distillation loss, backward, all-reduce, SGD")
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
     ap.add_argument('--criterion', action='store_true',
                     help='--mode train: the head (cls / reg branches, box epilogue) and its real loss (Hungarian '
                          'assignment + focal / L1 terms over all layers) instead of a synthetic loss; eager launch')
     ap.add_argument('--gts', type=int, default=40, help='--criterion: ground-truth boxes per sample')
+    ap.add_argument('--overlap-comm', action='store_true',
+                    help='--mode train/distill with several ranks: eager backward, every bucket\'s all-reduce starts from a '
+                         'post-accumulate hook while the backward of the layers below is still running')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None, help='torch threads of the CPU baseline (default: min(cores, 16), the fastest measured)')
     ap.add_argument('--cpu-layers', type=int, default=None,
@@ -158,8 +163,8 @@ def main():
     def step():
         return tr(feats, query_embed, reg_branches=regs, img_metas=metas)
 
-    if a.mode == 'train':
-        train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels)
+    if a.mode in ('train', 'distill'):
+        train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels, G)
         return
 
     launch = 'eager'
@@ -189,7 +194,8 @@ def main():
                       file=sys.stderr)
                 run, launch = step, 'eager'
 
-        elapsed = D.timed_steps(run, a.steps, a.warmup, dev)   # barrier + synchronise both sides, MAX over ranks
+        stats = {}
+        elapsed = D.timed_steps(run, a.steps, a.warmup, dev, stats)   # barrier + synchronise both sides, MAX over ranks
 
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
@@ -217,19 +223,47 @@ def main():
                                    f'batch 1 per GPU, pyramid resident in HBM',
                        'baseline_config': 'configs[2]', 'launch': launch,
                        'parallelism': f'replicas x{a.gpus}' if a.gpus > 1 else 'single GPU'},
+            'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
+            'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3, 'allreduce_bytes_per_step': 0,
             'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
         }
         print(json.dumps(line))
     D.shutdown()
 
 
-def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels):
+def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels, G=None):
     """Secondary mode: one training step of the decoder per sample - forward, a synthetic loss, backward
     (gd4d_cross_attn_bwd, gd4d_value_proj_bwd_*, gd4d_linear_bwd_weight), ONE flat gradient all-reduce over RCCL, SGD.
-    The feature pyramid requires grad (it comes from the backbone in the reference's training)."""
+    The feature pyramid requires grad (it comes from the backbone in the reference's training).
+
+    --mode distill (BASELINE configs[4]; distillation/distillers/mix_distill.py:92-106): per step the teacher's
+    decoder + head run under no_grad on the teacher's pyramid and queries; the student's decoder runs on its own
+    queries and again on the teacher's queries (dense_heads/detr3d_head_pe.py:560-566, :617-625) over ONE pyramid whose
+    value tensors are projected once (Detr3DTransformer.forward_shared); the loss is the student's loss plus the
+    instance distillation terms of get_instance_distill_loss (mix_distill.py:140-168: BCE-with-logits against the
+    teacher's sigmoid scores and L1 on the boxes, both re-weighted by the teacher's max score)."""
     world_size = max(a.gpus, 1)
     for f in feats:
         f.requires_grad_(True)
+    distill = a.mode == 'distill'
+    teacher = None
+    if distill:
+        from graph_detr4d_amd import functional as Fn, synthetic
+        nn = torch.nn
+        t_tr, t_regs = build_decoder(G, n_cams, a.layers, a.value_dtype, 2000 + 4)       # the teacher: its own weights
+        t_tr, t_regs = t_tr.to(dev), t_regs.to(dev)
+
+        def branches(seed):
+            torch.manual_seed(seed)
+            return nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True),
+                                                nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True),
+                                                nn.Linear(256, 10)) for _ in range(a.layers)]).to(dev)
+        t_cls, s_cls = branches(81).eval(), branches(82)
+        t_feats = [f.to(dev) for f in synthetic.feature_pyramid(n_cams, levels, seed=2000 + 4 + rank)]
+        t_queries = torch.randn(a.queries, 512, generator=torch.Generator().manual_seed(83)).to(dev)   # teacher.query_embedding
+        for p_ in list(t_tr.parameters()) + list(t_regs.parameters()) + list(t_cls.parameters()):
+            p_.requires_grad_(False)
+        teacher = (t_tr, t_regs, t_cls, t_feats, t_queries, s_cls)
     crit = cls_branches = None
     if a.criterion:
         # the reference's training loss (dense_heads/detr3d_head_pe.py:568-612 + :1014-1094): class branches as in
@@ -247,9 +281,14 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
         gt[:, 0:2] *= 25.
         gt[:, 3:6] = gt[:, 3:6].abs() * 2 + 0.3
         gt_boxes, gt_labels = [gt.to(dev)], [torch.randint(0, 10, (a.gts,), generator=g).to(dev)]
-    params = list(tr.parameters()) + list(regs.parameters()) + (list(cls_branches.parameters()) if a.criterion else [])
+    params = list(tr.parameters()) + list(regs.parameters()) + (list(cls_branches.parameters()) if a.criterion else []) \
+        + (list(teacher[5].parameters()) if distill else [])
     opt = torch.optim.SGD(params, lr=1e-4)
-    reducer = D.FlatGradAllReducer(params)
+    # gradient buckets in the order backward finalises them (head branches, then the decoder layers last to first): with
+    # several ranks the slices are all-reduced back to back after the captured backward (reduce_buckets), or from
+    # post-accumulate hooks while the backward is still running (--overlap-comm, eager launch)
+    reducer = D.FlatGradAllReducer(params, buckets=D.decoder_buckets(tr, regs, cls_branches if a.criterion else None,
+                                                                     teacher[5] if distill else None))
     reducer.bind()                                    # .grad = views of one flat buffer from the start (graph captures)
     tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
 
@@ -304,6 +343,23 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     def criterion_loss(all_cls, all_box):
         return sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box)).values())
 
+    def distill_loss():
+        t_tr, t_regs, t_cls, t_feats, t_queries, s_cls = teacher
+        with torch.no_grad():                                           # mix_distill.py:92-96
+            t_states, t_init, t_refs = t_tr(t_feats, t_queries, reg_branches=t_regs, img_metas=metas)
+            t_out = Fn.head_outputs(t_states, t_init, t_refs, t_cls, t_regs, synthetic.PC_RANGE)
+        (s_states, s_init, s_refs), (g_states, g_init, g_refs) = tr.forward_shared(
+            feats, [query_embed, t_queries], reg_branches=regs, img_metas=metas)
+        guided = Fn.head_outputs(g_states, g_init, g_refs, s_cls, regs, synthetic.PC_RANGE)
+        loss = (s_states ** 2).mean()                                   # stand-in for the student's own loss
+        t_score = t_out['all_cls_scores'].sigmoid()                     # get_instance_distill_loss, reweight_score=True
+        qs = t_score.max(dim=-1, keepdim=True)[0]
+        ncls = t_score.shape[-1]
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(guided['all_cls_scores'], t_score, reduction='none')
+        l1 = (guided['all_bbox_preds'] - t_out['all_bbox_preds']).abs()
+        den = qs.sum(dim=(1, 2, 3)) * ncls + 1e-10                      # per decoder stage
+        return loss + ((qs * bce).sum(dim=(1, 2, 3)) / den).sum() + ((qs * l1).sum(dim=(1, 2, 3)) / den).sum()
+
     def step():
         reducer.zero_grad()
         if graphs is None:                            # (captured backward: the pyramid's .grad buffers belong to the graph)
@@ -339,14 +395,23 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             reducer.reduce()
             opt.step()
             return
-        if a.criterion:
+        if distill:
+            loss = distill_loss()
+        elif a.criterion:
             loss = criterion_loss(*front(query_embed, *feats))
         else:
             states, init_ref, refs = tr(feats, query_embed, reg_branches=regs, img_metas=metas)
             loss = (states ** 2).mean()
+        if overlap:
+            reducer.begin_step()
         loss.backward()
         if finish:
-            reducer.reduce()
+            if overlap:
+                reducer.finish()
+            elif world_size > 1:
+                reducer.reduce_buckets()
+            else:
+                reducer.reduce()
             opt.step()
 
     # The step is ~2500 launches, most of them small: eagerly it is bound by the host's launch rate, not by the GPU.
@@ -355,6 +420,10 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     # the gradient all-reduce - the collective and the (few, fused) optimizer launches stay eager, so the step does not
     # depend on the communication backend being capturable.
     finish = True
+    overlap = bool(a.overlap_comm) and world_size > 1
+    if overlap:
+        reducer.install_hooks()
+        a.no_graph = True                              # hooks run on the host during an eager backward
     run, launch = step, front_launch
     for _ in range(2):
         step()
@@ -377,9 +446,9 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             else:
                 def run():
                     graph.replay()
-                    reducer.reduce()
+                    reducer.reduce_buckets()
                     opt.step()
-                launch = 'hipgraph (forward + backward), eager all-reduce + SGD'
+                launch = 'hipgraph (forward + backward), eager bucketed all-reduce + SGD'
             run()
             torch.cuda.synchronize()
         except Exception as e:                        # report, never hide
@@ -387,7 +456,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                   file=sys.stderr)
             run, launch = step, 'eager'
         finish = True
-    elapsed = D.timed_steps(run, a.steps, a.warmup, dev)
+    stats = {}
+    elapsed = D.timed_steps(run, a.steps, a.warmup, dev, stats)
     if rank == 0 and os.environ.get('GD4D_BENCH_CHECK'):      # dev: the launch modes must train identically
         flat = reducer.flat
         psum = sum(float(p.detach().double().sum()) for p in params)
@@ -396,16 +466,24 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
               file=sys.stderr)
     if rank == 0:
         line = {
-            'metric': f'decoder_train_samples_per_sec_{a.queries}q_T{a.frames}',
+            'metric': f'decoder_{"distill" if distill else "train"}_samples_per_sec_{a.queries}q_T{a.frames}',
             'value': D.aggregate_throughput(1, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('training step of the decoder + head with the reference\'s loss (Hungarian assignment, '
+            'config': {'workload': ('distillation step (teacher pass under no_grad, student pass + teacher-query-guided student '
+                                    'pass sharing one value projection, instance distillation loss); ' if distill else '') +
+                                   ('training step of the decoder + head with the reference\'s loss (Hungarian assignment, '
                                     f'{a.gts} boxes; ' if a.criterion else '') +
                                    f'training step of the {a.layers}-layer decoder (forward + backward + flat gradient '
                                    f'all-reduce of {reducer.bytes_per_step() / 1e6:.1f} MB + SGD), {a.queries} queries, '
                                    f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
-                       'launch': launch, 'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
+                       'baseline_config': 'configs[4]' if distill else ('configs[3]' if a.levels == 'vov' else 'configs[2] + backward'),
+                       'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),
+                       'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
+            'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
+            'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3,
+            'allreduce_bytes_per_step': reducer.describe()['allreduce_bytes'] if world_size > 1 else 0,
+            'allreduce_buckets': reducer.describe()['buckets'],
             'roofline': None, 'cpu_baseline': None,
         }
         print(json.dumps(line))
@@ -471,16 +549,26 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
     for d in per_layer:
         d['us_mean'] = tot_ms / launches * 1e3
     achieved = tot_bytes / tot_ms / 1e6                      # GB/s, mean over the decoder's launches
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_cross_attn.json')
-    if os.path.exists(pmc_path) and a.queries == 900 and a.frames == 4 and a.levels == 'r50' and a.value_dtype == 'fp32':
-        # PMC cannot be read from inside the bench; the committed rocprofv3 --pmc pass of this kernel on
-        # this workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction) supplies it.
-        pm = json.load(open(pmc_path))
-        traffic = pm['hbm_read_bytes_per_launch'] + pm['hbm_write_bytes_per_launch']
+    # PMC cannot be read from inside the bench: `traffic` comes from a committed rocprofv3 --pmc pass of this kernel on
+    # this workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; tools/prof_pmc.sh).  The record
+    # carries the sha256 of the kernel source it was measured on; if the source has changed since, the figure is stale
+    # and is NOT reported (traffic = null).
+    traffic, traffic_source = None, None
+    if a.queries == 900 and a.frames == 4 and a.levels == 'r50' and a.value_dtype == 'fp32':
+        import glob
+        import hashlib
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, 'graph-detr4d_amd', 'csrc', 'gd4d_cross_attn.hip'), 'rb').read()).hexdigest()
+        for pmc_path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_cross_attn.json')), reverse=True):
+            pm = json.load(open(pmc_path))
+            if pm.get('kernel_source_sha256') == src_hash:
+                traffic = pm['hbm_read_bytes_per_launch'] + pm['hbm_write_bytes_per_launch']
+                traffic_source = os.path.relpath(pmc_path, ROOT)
+                break
+        if traffic is None:
+            traffic_source = 'no committed PMC pass matches the current gd4d_cross_attn.hip (sha256 ' + src_hash[:12] + ')'
     roofline = dict(kernel='gd4d::cross_attn_fwd_block (fused project+sample+aggregate)', bound='hbm',
                     achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, alg_bytes_per_launch=tot_bytes / launches,
+                    traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot_bytes / launches,
                     us_per_launch=tot_ms / launches * 1e3, launches_per_step=launches)
     kernels = {'cross_attn_fwd_per_layer': per_layer}
     # The other large kernel of a step, reported beside the headline roofline: value_proj (one launch per layer, the

@@ -17,6 +17,7 @@ from .bbox_coder import NMSFreeCoder  # noqa: F401
 from .criterion import Detr3DCriterion, HungarianAssigner3D  # noqa: F401
 from .dgcnn_attn import DGCNNAttn  # noqa: F401
 from .head_pe import FeaturePositionEmbedding  # noqa: F401
+from . import functional, plumbing  # noqa: F401
 from .detr3d_transformer import (Detr3DCrossAtten, Detr3DCrossAttenV2, Detr3DTransformer, Detr3DTransformerDecoder,  # noqa: F401
                                  HDetr3DTransformer, feature_sampling, inverse_sigmoid)
 

@@ -197,6 +197,8 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         Returns (kwargs, pipeline or None)."""
         mode = os.environ.get('GD4D_PREPROJECT', 'stream')
         value = kwargs.get('value')
+        if kwargs.get(Fn.VALUE_CACHE_KEY) is not None:       # the caller projected already (Detr3DTransformer.forward_shared)
+            return kwargs, None
         if mode == '0' or not isinstance(value, (list, tuple)) or len(value) == 0 or not value[0].is_cuda:
             return kwargs, None
         mods = [a for layer in self.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
@@ -332,6 +334,31 @@ class Detr3DTransformer(nn.Module):
             query_pos=query_pos.permute(1, 0, 2).contiguous(), reference_points=reference_points,
             reg_branches=reg_branches, **kwargs)
         return inter_states, init_reference_out, inter_references
+
+
+    def forward_shared(self, mlvl_feats, query_embeds, reg_branches=None, **kwargs):
+        """Several query sets through the decoder over ONE feature pyramid: [forward(mlvl_feats, qe, ...) for qe in
+        query_embeds], with the layers' value tensors projected once and shared by all the passes.
+
+        This is the distillation step's student side (distillation/distillers/mix_distill.py:92-106): the head runs the
+        transformer on its own `query_embedding` and then again on the teacher's (`teacher_queries`,
+        dense_heads/detr3d_head_pe.py:560-566 and :617-625) - same weights, same `mlvl_feats`, so value_proj (the
+        dominant dense contraction, deform3d_cross_attn.py:264-280) of the second pass is redundant.  With autograd on,
+        the shared tensors sit behind one autograd node and receive the gradients of every pass."""
+        mods = [a for layer in self.decoder.layers for a in layer.attentions if isinstance(a, Deform3DCrossAttn)]
+        share = len(mods) >= 1 and len(mods) <= 8 and mlvl_feats[0].is_cuda and \
+            len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) == 1
+        if share and Fn.wants_grad(mods[0], *mlvl_feats):
+            share = all(m.value_proj.bias is not None and m.value_dtype == torch.float32 for m in mods) and \
+                mlvl_feats[0].shape[0] == 1 and all(v.dtype == torch.float32 for v in mlvl_feats)
+            cache = Fn.project_values_for_layers_autograd(mods, mlvl_feats) if share else None
+        elif share:
+            Fn.require_inference(*mlvl_feats)
+            cache = Fn.project_values_for_layers(mods, mlvl_feats)
+        else:
+            cache = None
+        extra = {} if cache is None else {Fn.VALUE_CACHE_KEY: cache}
+        return [self.forward(mlvl_feats, qe, reg_branches=reg_branches, **extra, **kwargs) for qe in query_embeds]
 
 
 @TRANSFORMER.register_module()

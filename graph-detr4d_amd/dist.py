@@ -69,17 +69,26 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
-def timed_steps(run, steps, warmup, device=None):
+def timed_steps(run, steps, warmup, device=None, stats=None):
     """`warmup` untimed calls of run(), then exactly `steps` timed calls bracketed by sync();
-    returns the MAX elapsed seconds over ranks."""
+    returns the MAX elapsed seconds over ranks.  `stats` (a dict), when given, also receives every rank's view of the
+    job: ranks, the slowest and the fastest rank's seconds up to its own device synchronise (before the closing
+    barrier) - a self-describing record for multi-GPU runs."""
     for _ in range(warmup):
         run()
     sync(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
+    if device is not None and torch.device(device).type == 'cuda':
+        torch.cuda.synchronize(device)
+    own = time.perf_counter() - t0                            # this rank alone
     sync(device)
-    return max_over_ranks(time.perf_counter() - t0, device)
+    total = max_over_ranks(time.perf_counter() - t0, device)
+    if stats is not None:
+        stats.update(ranks=dist.get_world_size() if dist.is_initialized() else 1,
+                     rank_seconds_max=max_over_ranks(own, device), rank_seconds_min=-max_over_ranks(-own, device))
+    return total
 
 
 def aggregate_throughput(units_per_rank_step, steps, world, elapsed):

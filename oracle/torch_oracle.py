@@ -158,9 +158,17 @@ def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar
     return (per_cam * cam).sum(1), uv, mask                                  # :322-324
 
 
+def _bf16r(t):
+    return t.bfloat16().float()
+
+
 def deform3d_cross_attn(p, query, value, query_pos, reference_points, img_metas, pc_range,
-                        num_heads=8, num_points=4, depth_encode=False, return_parts=False):
-    """Deform3DCrossAttn.forward in eval mode, deform3d_cross_attn.py:196-339 (Appendix A.1)."""
+                        num_heads=8, num_points=4, depth_encode=False, return_parts=False, value_dtype='fp32'):
+    """Deform3DCrossAttn.forward in eval mode, deform3d_cross_attn.py:196-339 (Appendix A.1).
+
+    value_dtype='bf16' restates the build's opt-in reduced-precision mode (not a reference mode): value_proj on
+    bf16-rounded features and weights (exact products, fp32 accumulate, fp32 bias) and the projected value tensor
+    rounded to bf16; everything else fp32."""
     x = query if query_pos is None else query + query_pos                   # :203-204
     x = x.permute(1, 0, 2)                                                  # :207
     b, q, c = x.shape
@@ -172,7 +180,11 @@ def deform3d_cross_attn(p, query, value, query_pos, reference_points, img_metas,
     offsets = _linear(x, p, 'deform_sampling_offsets').view(b, q, num_heads, num_points, 3)
     attn_logits = _linear(x, p, 'attention_weights').view(b, q, num_heads, nl * num_points)
     flat, shapes = flatten_pyramid(value)
-    val = _linear(flat, p, 'value_proj').view(b * n, flat.shape[1], num_heads, c // num_heads)
+    if value_dtype == 'bf16':
+        val = _bf16r(F.linear(_bf16r(flat), _bf16r(p['value_proj.weight']), p['value_proj.bias']))
+    else:
+        val = _linear(flat, p, 'value_proj')
+    val = val.view(b * n, flat.shape[1], num_heads, c // num_heads)
     agg, uv, mask = sample_aggregate(val, shapes, reference_points, offsets, attn_logits,
                                      cam_logits, l2i, pc_range, img_h, img_w)
     out = _linear(agg, p, 'output_proj').permute(1, 0, 2)                   # :326-327
@@ -330,7 +342,7 @@ def _sub(p, prefix):
 
 def decoder_layer(p, query, value, query_pos, reference_points, img_metas, pc_range,
                   cross='Deform3DCrossAttn', num_heads=8, num_points=4, attn_mask=None,
-                  depth_encode=False, return_parts=False):
+                  depth_encode=False, return_parts=False, value_dtype='fp32'):
     """Post-norm DetrTransformerDecoderLayer (third-party mmdet/mmcv), order
     self_attn, norm, cross_attn, norm, ffn, norm (config :88-89; Appendix A.4).
     return_parts (Deform3DCrossAttn only): also return the cross-attention's intermediates (mask, uv, ...)."""
@@ -344,7 +356,8 @@ def decoder_layer(p, query, value, query_pos, reference_points, img_metas, pc_ra
     parts = None
     if cross == 'Deform3DCrossAttn':
         x = deform3d_cross_attn(cp, x, value, query_pos, reference_points, img_metas, pc_range,
-                                num_heads, num_points, depth_encode, return_parts=return_parts)
+                                num_heads, num_points, depth_encode, return_parts=return_parts,
+                                value_dtype=value_dtype)
         if return_parts:
             x, parts = x
     else:

@@ -1,4 +1,6 @@
 import os
+import socket
+import subprocess
 import sys
 
 import pytest
@@ -10,6 +12,37 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def pytest_sessionstart(session):
+    """Two-rank dry run of the data-parallel training bench on a 1-GPU box: both ranks on the one
+    GPU, gloo instead of RCCL (RCCL refuses two ranks on one device).  It is started HERE, before this process has
+    touched the GPU - a child must not be exec'ed from a process that has initialised it - and only when the GPU tests
+    are selected on a box that has a GPU; tests/test_configs_gpu.py asserts on the recorded result."""
+    session.config._gd4d_dp2_dryrun = None
+    mark = session.config.getoption('-m') or ''
+    if 'gpu' not in mark or 'not gpu' in mark or os.environ.get('GD4D_SKIP_DP2_DRYRUN'):
+        return
+    import torch
+    if torch.cuda.device_count() == 0:                      # (counting devices does not initialise the GPU)
+        return
+    env = dict(os.environ, GD4D_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--mode', 'train', '--levels',
+           'vov', '--frames', '1', '--layers', '2', '--steps', '2', '--warmup', '1']
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        session.config._gd4d_dp2_dryrun = dict(rc=r.returncode, out=r.stdout, err=r.stderr[-6000:])
+    except Exception as e:                                   # reported by the test that reads it
+        session.config._gd4d_dp2_dryrun = dict(rc=-1, out='', err=f'{type(e).__name__}: {e}')
 
 
 @pytest.fixture(scope='session')

@@ -48,15 +48,20 @@ def test_fused_kernel_matches_reference_golden(name, head_major):
     torch.testing.assert_close(out.cpu(), g.t('agg'), rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize('name', ['deform_n6', 'deform_n24_b2'])
-def test_fused_kernel_bf16_values(name):
-    """bf16 storage of the value tensor, fp32 accumulate: compare with the oracle fed the SAME
-    bf16-rounded values (so only summation order differs)."""
+@pytest.mark.parametrize('head_major', [False, True])
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n24_b2', 'deform_edge'])
+def test_fused_kernel_bf16_values(name, head_major):
+    """bf16 storage of the value tensor, fp32 accumulate, in both value layouts (head-major is the layout the
+    module uses for bf16 storage - configs[1]): compare with the oracle fed the SAME bf16-rounded values (so only
+    summation order differs)."""
     from graph_detr4d_amd import ops
     from oracle import torch_oracle as O
     g = Golden(name)
     args, d, m = _inputs(g, 'cuda', torch.bfloat16)
-    out = ops.cross_attn_fwd(**d, pc_range=m['pc_range'], img_h=m['img_shape'][0], img_w=m['img_shape'][1])
+    if head_major:
+        d['value'] = d['value'].permute(0, 2, 1, 3).contiguous()
+    out = ops.cross_attn_fwd(**d, pc_range=m['pc_range'], img_h=m['img_shape'][0], img_w=m['img_shape'][1],
+                             head_major=head_major)
     ref, _, _ = O.sample_aggregate(args['value'].float(), args['level_hw'], args['ref'], args['offsets'],
                                    args['attn_logits'].flatten(-2), args['cam_logits'], args['lidar2img'],
                                    m['pc_range'], m['img_shape'][0], m['img_shape'][1])
@@ -136,8 +141,10 @@ def test_linearity_and_invisible_cameras_full_size():
     (16, [(12, 20), (6, 10), (3, 5), (2, 3)], 6, 50),      # Dh = 16
     (8, [(6, 10), (3, 5)], 64, 9),                         # the 64-camera maximum
 ])
-def test_fused_kernel_shape_coverage_vs_c_oracle(heads, levels, n, q):
-    """Every compiled template path against the plain-C oracle (bit-exact mask / uv)."""
+@pytest.mark.parametrize('head_major', [False, True])
+def test_fused_kernel_shape_coverage_vs_c_oracle(heads, levels, n, q, head_major):
+    """Every compiled template path against the plain-C oracle (bit-exact mask / uv), fp32 and bf16 storage, both
+    value layouts."""
     import numpy as np
     from graph_detr4d_amd import ops
     from oracle import c_oracle
@@ -158,8 +165,9 @@ def test_fused_kernel_shape_coverage_vs_c_oracle(heads, levels, n, q):
     pc = synthetic.PC_RANGE
     o_ref, m_ref, uv_ref = c_oracle.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, pc, 900, 1600)
     t = lambda a: torch.from_numpy(a).cuda()                # noqa: E731
-    out, mask, uv = ops.cross_attn_fwd(t(val), levels, t(ref), t(offsets), t(attn), t(cam), t(l2i), pc, 900, 1600,
-                                       want_mask=True, want_uv=True)
+    lay = (lambda v: v.permute(0, 2, 1, 3).contiguous()) if head_major else (lambda v: v)   # noqa: E731
+    out, mask, uv = ops.cross_attn_fwd(lay(t(val)), levels, t(ref), t(offsets), t(attn), t(cam), t(l2i), pc, 900, 1600,
+                                       want_mask=True, want_uv=True, head_major=head_major)
     assert m_ref.sum() > 0
     assert np.array_equal(mask.cpu().numpy(), m_ref)
     assert np.array_equal(uv.cpu().numpy(), uv_ref)
@@ -167,7 +175,8 @@ def test_fused_kernel_shape_coverage_vs_c_oracle(heads, levels, n, q):
     # bf16 storage of the same values
     vb = t(val).bfloat16()
     o_b, _, _ = c_oracle.cross_attn_fwd(vb.float().cpu().numpy(), levels, ref, offsets, attn, cam, l2i, pc, 900, 1600)
-    out_b = ops.cross_attn_fwd(vb, levels, t(ref), t(offsets), t(attn), t(cam), t(l2i), pc, 900, 1600)
+    out_b = ops.cross_attn_fwd(lay(vb), levels, t(ref), t(offsets), t(attn), t(cam), t(l2i), pc, 900, 1600,
+                               head_major=head_major)
     np.testing.assert_allclose(out_b.cpu().numpy(), o_b, rtol=1e-4, atol=1e-4)
 
 
