@@ -1,37 +1,33 @@
-// gd4d_value_proj_fwd: value_proj over the multi-camera FPN pyramid for gfx950.
+// gd4d_value_proj (A-stationary form): value_proj over the multi-camera FPN pyramid for NL decoder layers in one launch.
 //
-// Reference: Deform3DCrossAttn.forward, deform3d_cross_attn.py:264-280 - every level
-// (B*N, C, H, W) is flattened + transposed to channels-last, the levels are concatenated and a
-// Linear(256 -> 256) is applied (a 739 800 x 256 x 256 GEMM at N = 24, the dominant dense
-// contraction of a decoder layer), then viewed (B*N, S, Hh, Dh).
+// Reference: Deform3DCrossAttn.forward, deform3d_cross_attn.py:264-280 (flatten + transpose + cat + Linear 256 -> 256 +
+// view (B*N, S, Hh, Dh)), once per decoder layer over the SAME pyramid (detr3d_transformer.py:192-198).
 //
-// This kernel reads the NCHW maps exactly as the caller holds them and writes the channels-last
-// head-major value tensor in ONE pass (the reference makes a transposed copy, a concatenated copy
-// and the GEMM output): HBM traffic = read pyramid once + write value once.
+//   out_l[r, start + pix, co] = sum_ci in[r, ci, pix] * W_l[co, ci] + bias_l[co]        l = 0 .. NL-1
 //
-//   out[r, start_l + pix, co] = sum_ci in_l[r, ci, pix] * W[co, ci] + bias[co]
+// Why this shape.  The first kernels of this file's family kept W in registers and streamed pixel tiles through LDS
+// (DMA -> convert -> fragment reads): ~450 issued instructions per 48 MFMAs, phases that added instead of overlapping
+// (profiles/r01f_value_proj_ablation.md).  Here the roles are swapped:
+//   * a wave owns a tile of 32 pixels for a whole PASS: it loads the tile's 256 input channels straight from the NCHW
+//     maps into registers (pixel-contiguous dword loads: a lane needs 8 channels of ONE pixel per MFMA k-step), splits
+//     them once into bf16 hi / lo A-fragments (128 VGPRs) - no LDS staging, no transpose, no conversion in the loop;
+//   * the weights of all NL layers are pre-split into bf16 hi / lo MFMA B-fragments in a workspace image (1.5 MB for 6
+//     layers, L2-resident) and streamed through a 2-slot LDS ring in CHUNKS of (layer, 32 output channels): 32 KB of
+//     fragments + the 32 bias values, fetched by LDS-DMA one chunk ahead;
+//   * per chunk a wave runs 16 k-steps x 3 MFMA 32x32x16 (a_hi*w_hi, a_lo*w_hi, a_hi*w_lo: fp32-class split-bf16
+//     arithmetic, fp32 accumulate) with 2 ds_read_b128 per k-step, computing the TRANSPOSED product (channels x pixels)
+//     so that a lane holds 4 x 4 consecutive channels of its pixel and the 32 x 32 result leaves in four 16-byte stores
+//     per lane (16 dword stores per lane made the kernel store-ISSUE bound: ablation in profiles/r02_value_proj.md).
+// A pass is 8*NL chunks: the tile's load + split is amortised over 384*NL MFMAs per wave, the steady state issues ~3
+// instructions per MFMA, and the pyramid is read from HBM once for all NL layers.  Traffic per pixel: 1 KB in, NL KB
+// out, 1.5 MB of W per (waves per workgroup x 32) pixels from L2 into LDS.
 //
-// Arithmetic: split-bf16 ("bf16x3") on the MFMA pipe.  x = hi + lo with hi = bf16(x),
-// lo = bf16(x - hi); a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulate.  Dropped terms are
-// <= ~2^-17 relative per product, i.e. fp32-class results (measured <= 2e-5 abs against an fp32
-// GEMM on N(0,1) features) at 3/16 of the cost of the f32-input MFMA.  The f32-input MFMA would make
-// this layer MFMA-bound at ~0.65 ms (157 TF peak); bf16x3 puts it under the HBM time (~0.28 ms).
-//
-// Structure (per CU: one persistent 512-thread workgroup = 8 waves, 2 per SIMD):
-//   * wave w owns output channels [32w, 32w+32) and keeps its W_hi / W_lo MFMA B-fragments for
-//     the whole K = 256 in registers (2 x 64 VGPRs), loaded once per launch;
-//   * per tile of BM pixels: all 512 threads load the fp32 (ci, pix) block with pixel-contiguous
-//     (coalesced) dword loads, split to hi/lo bf16 with v_cvt_pk_bf16_f32 and park it in LDS as
-//     [pix][ci] rows (the transpose happens in registers: a lane gathers 8 ci of ONE pixel and
-//     issues one ds_write_b128), 16-byte chunks XOR-swizzled by (pix & 15) so that both the
-//     writes and the ds_read_b128 A-fragment reads are bank-conflict free;
-//   * each wave then runs K/16 x 3 MFMA 32x32x16 per 32-pixel sub-tile and stores its 32 channels
-//     (128 B per pixel row, one full L2 line) straight from the accumulators;
-//   * next tile's global loads are issued before the MFMA phase (register prefetch) and LDS is
-//     double buffered, so HBM reads overlap the matrix work.
+// Synchronisation: one raw s_barrier per chunk (all waves of a workgroup consume the same chunk stream), preceded by
+// "s_waitcnt vmcnt(0)": the wave's DMA pieces of this chunk were the LAST memory operations of the previous phase (its
+// stores come first), issued half a phase ago.
 #include <stdlib.h>
 
-#include <atomic>
+#include <type_traits>
 
 #include "gd4d_common.h"
 
@@ -40,894 +36,478 @@ namespace gd4d {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
 
-constexpr int VP_C = 256;          // in = out channels (embed_dims of every reference config)
-constexpr int VP_THREADS = 512;
-constexpr int VP_KSTEPS = VP_C / 16;
+constexpr int VA_C = 256;
+constexpr int VA_KSTEPS = VA_C / 16;
+constexpr int VA_TILE = 32;                    // pixels per wave tile (= MFMA M)
+constexpr int VA_RING = 2;                     // LDS ring slots: the DMA runs one chunk ahead
 
-struct ValueProjParams {
-  const void* in[GD4D_MAX_LEVELS];   // level l: (R, C, HW_l)
+constexpr int va_chunk_bytes(bool single) { return VA_KSTEPS * (single ? 1 : 2) * 1024; }
+// workspace image: NL * 8 chunks, then the bias table [NL][256] fp32
+constexpr size_t va_image_bytes(int NL, bool single) { return (size_t)NL * 8 * va_chunk_bytes(single) + (size_t)NL * VA_C * 4; }
+
+struct VpaParams {
+  const void* in[GD4D_MAX_LEVELS];     // level l: (R, C, HW_l) fp32
   int hw[GD4D_MAX_LEVELS];
-  int start[GD4D_MAX_LEVELS];        // pixel offset of level l inside a row of `out`
-  int tiles[GD4D_MAX_LEVELS];        // tiles per camera-row at level l
+  int start[GD4D_MAX_LEVELS];          // pixel offset of level l inside a row of `out`
+  int tiles[GD4D_MAX_LEVELS];          // tiles per camera-row at level l
   int tile_base[GD4D_MAX_LEVELS + 1];  // prefix over levels of R * tiles[l]
-  const float* weight[GD4D_MAX_LAYERS];   // per decoder layer: (C, C) row-major [co][ci]
-  const float* bias[GD4D_MAX_LAYERS];     // (C) or null
-  void* out[GD4D_MAX_LAYERS];             // (R, S, C)
-  int R, L, S, NL;
-  int head_major, Hh, Dh;                 // output layout: (R, S, C) or (R, Hh, S, Dh)
-  int xcd_groups;                         // 1: layer groups co-located per XCD (grid % (8*NL) == 0)
-  int single_product;                     // 1: bf16-class single product (GD4D_VP_PRECISION_BF16)
-  int dbg;                                // dev ablation bits (GD4D_VP_DBG): 1 = skip stores, 2 = skip MFMAs
+  void* out[GD4D_MAX_LAYERS];
+  const char* wimg;                    // workspace: NL * 8 chunks
+  int R, L, S, NL, Hh, Dh, total;
+  unsigned long long* trace;           // dev (DBG & 16): per wave of the first 8 workgroups, cycles spent per phase segment
 };
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo_elem, float hi_elem) {
+__device__ __forceinline__ unsigned va_cvt_pk_bf16(float lo_elem, float hi_elem) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
   return r;
 }
 
-// split two floats into packed (hi, hi) and (lo, lo) bf16 pairs
-struct HiLo { unsigned hi, lo; };
-__device__ __forceinline__ HiLo split2(float a, float b) {
-  HiLo r;
-  r.hi = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(r.hi << 16);          // exact: hi is a rounding of a
-  const float rb = b - __uint_as_float(r.hi & 0xffff0000u);
-  r.lo = cvt_pk_bf16(ra, rb);
-  return r;
+// 8 consecutive floats -> one 16-byte chunk of bf16 hi halves and one of bf16 lo halves; x ~= hi + lo to ~2^-17 relative
+__device__ __forceinline__ void va_split8(const float* v, u32x4& h, u32x4& l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hh[i] = va_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float ra = v[2 * i] - __uint_as_float(hh[i] << 16);              // exact: hi is a rounding of the input
+    const float rb = v[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u);
+    ll[i] = va_cvt_pk_bf16(ra, rb);
+  }
+  h = u32x4{hh[0], hh[1], hh[2], hh[3]};
+  l = u32x4{ll[0], ll[1], ll[2], ll[3]};
 }
 
-// 8 consecutive floats -> one 16-byte chunk of hi halves and one of lo halves
-__device__ __forceinline__ void split8(const float* v, u32x4& h, u32x4& l) {
-  const HiLo a = split2(v[0], v[1]), b = split2(v[2], v[3]), c = split2(v[4], v[5]), d = split2(v[6], v[7]);
-  h = u32x4{a.hi, b.hi, c.hi, d.hi};
-  l = u32x4{a.lo, b.lo, c.lo, d.lo};
+__device__ __forceinline__ bf16x8 va_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight image: chunk (layer, cb) = [s = 0..15][part = hi, lo][lane = 0..63][8 bf16], so that a 16-byte LDS-DMA per
+// lane lands every fragment where lane `lane` reads it with one ds_read_b128 (conflict-free); behind the chunks the
+// biases of all layers as one fp32 table (copied into LDS once per workgroup).
+// Fragment of lane l at k-step s: W[co = 32*cb + (l & 31)][ci = 16*s + 8*(l >> 5) .. +8].
+struct VpaWeights { const float* w[GD4D_MAX_LAYERS]; const float* b[GD4D_MAX_LAYERS]; };
+
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void value_proj_wimg_kernel(const VpaWeights ptrs, char* wimg) {
+  constexpr int PARTS = SINGLE ? 1 : 2;
+  constexpr int CHUNK = va_chunk_bytes(SINGLE);
+  const int chunk = blockIdx.x;                               // layer * 8 + cb
+  const int layer = chunk >> 3, cb = chunk & 7;
+  const float* w = ptrs.w[0];
+  const float* bias = ptrs.b[0];
+#pragma unroll
+  for (int l = 1; l < GD4D_MAX_LAYERS; ++l)
+    if (l == layer) { w = ptrs.w[l]; bias = ptrs.b[l]; }
+  char* dst = wimg + (size_t)chunk * CHUNK;
+  for (int e = threadIdx.x; e < VA_KSTEPS * 64; e += blockDim.x) {
+    const int s = e >> 6, lane = e & 63;
+    const float* src = w + (size_t)(32 * cb + (lane & 31)) * VA_C + 16 * s + 8 * (lane >> 5);
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32x4 h, l;
+    va_split8(v, h, l);
+    *reinterpret_cast<u32x4*>(dst + (s * PARTS) * 1024 + lane * 16) = h;
+    if (!SINGLE) *reinterpret_cast<u32x4*>(dst + (s * PARTS + 1) * 1024 + lane * 16) = l;
+  }
+  if (threadIdx.x < 32) {
+    float* table = reinterpret_cast<float*>(wimg + (size_t)gridDim.x * CHUNK);
+    table[layer * VA_C + 32 * cb + threadIdx.x] = bias ? bias[32 * cb + threadIdx.x] : 0.f;
+  }
 }
 
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
-  return __builtin_bit_cast(bf16x8, v);
-}
+// ---------------------------------------------------------------------------------------------------------------
+// WAVES waves per workgroup, one workgroup per CU.  SINGLE: one bf16 product a_hi*w_hi (bf16-class, for bf16 value storage).
+// DBG: compile-time ablation bits (dev only, production = 0): 1 no stores, 2 no MFMAs, 4 no fragment reads, 8 no DMA,
+// 16 s_memtime trace of the phase segments (wait + barrier / k-loop)
+//
+// One PHASE = one chunk: [counted vmcnt: my pieces of this chunk have landed] [s_barrier] [k-loop].  Everything else
+// rides inside the k-loop, behind MFMAs, one memory instruction every other k-step (the two waves that share a SIMD use
+// opposite k-step parities): first the DMA pieces of the NEXT chunk (the other ring slot was read in the previous phase:
+// every wave has passed this phase's barrier, hence finished reading it), then the stores of the PREVIOUS chunk's
+// result, which sits in the other of two accumulator sets (no copy, no add between two phases).
+//
+// The product is computed TRANSPOSED, D[channel][pixel] = W_frag (A operand, from LDS) x x_frag (B operand, the tile's
+// registers): a lane ends up with 4 x 4 consecutive channels of ITS pixel.  Before it leaves, the 32 x 32 result is
+// turned through a private 4.5 KB LDS patch (4 ds_write_b128 + 4 ds_read_b128 per wave, pitch 144 B: conflict-free)
+// so that 8 consecutive lanes hold one pixel's 32 channels: every store instruction then writes 8 FULL 128-byte lines.
+// This is what the CU's store path wants (tools/microbench/write_probe.hip, one CU alone): full lines 16 B per lane
+// 63 B/clk, dword stores of two lines 33 B/clk, 16-byte pieces of 32 different lines 16 B/clk - the path costs 2 cycles
+// per line TOUCHED, and at 32 KB of results per 3072 MFMA cycles the partial-line forms took 1000-2000 of them.
+template <int WAVES, bool OUT_BF16, bool HEAD_MAJOR, bool SINGLE, int DBG = 0>
+__global__ __launch_bounds__(64 * WAVES, 2) void value_proj_astat_kernel(const VpaParams p) {
+  constexpr int PARTS = SINGLE ? 1 : 2;
+  constexpr int CHUNK = VA_KSTEPS * PARTS * 1024;
+  constexpr int PIECES = CHUNK / 1024 / WAVES;                // 16-byte DMA instructions per wave and chunk
+  static_assert(PIECES * WAVES * 1024 == CHUNK, "pieces divide evenly");
+  static_assert(VA_RING == 2, "the phase loop below is unrolled by 2 (8 * NL chunks per pass)");
+  constexpr int NOPS = PIECES + 4;                            // memory instructions per wave and phase
+  static_assert(2 * NOPS <= VA_KSTEPS, "one memory instruction every other k-step");
+  constexpr int PITCH = 144;                                  // bytes per pixel row of the transposing patch
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ring[2][CHUNK] | bias[NL][256] | patch[WAVES] - ONE object
+  char* const bias_lds = smem + VA_RING * CHUNK;
 
-// byte offset of 16-byte chunk `chunk` (8 bf16) of row `row` in a [rows][256] bf16 LDS image
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * (VP_C * 2) + ((chunk ^ (row & 15)) << 4);
-}
-
-template <int BM, bool OUT_BF16>
-__global__ __launch_bounds__(VP_THREADS, 2) void value_proj_kernel(const ValueProjParams p) {
-  constexpr int PIX_GROUPS = VP_THREADS / BM;          // threads sharing one pixel column
-  constexpr int CPT = VP_C / PIX_GROUPS;               // input channels per thread per tile
-  constexpr int SUB = BM / 32;                         // 32-pixel MFMA sub-tiles per tile
-  constexpr int IMG = BM * VP_C * 2;                   // bytes of one bf16 [BM][256] image
-  static_assert(CPT % 8 == 0, "a thread packs whole 16-byte chunks");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][hi, lo][BM][256] bf16
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31;           // MFMA column (output channel within the wave's block) / A row
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31;           // MFMA column = this lane's pixel inside the tile
   const int kg = lane >> 5;            // which 8 of the 16 k of a step this lane holds
+  const bool odd_wave = wave >= WAVES / 2;   // waves w and w + WAVES/2 share a SIMD: they get opposite k-step parities
+  // LDS byte addresses inside this wave's patch: where this lane parks its quads, and where it picks up a line piece
+  const unsigned patch = (unsigned)(VA_RING * CHUNK + p.NL * VA_C * 4 + wave * (VA_TILE * PITCH));
+  const unsigned st_w = patch + col * PITCH + kg * 16;               // + 32 i: channels 8 i + 4 kg .. of pixel col
+  const unsigned st_r = patch + (lane >> 3) * PITCH + (lane & 7) * 16;   // + 8 m * PITCH: pixel 8 m + lane/8, channels 4 (lane & 7) ..
 
-  // Workgroup -> (layer, slot).  Consecutive workgroups serve different layers of the SAME tile
-  // sequence, so the NL layer groups sweep the pyramid in step and all but the first reader of a
-  // tile are served from L2 / Infinity Cache instead of HBM.
-  const int layer = blockIdx.x % p.NL;
-  const int slot = blockIdx.x / p.NL;
-  const int slots = gridDim.x / p.NL;
-  const float* __restrict__ weight = p.weight[layer];
-  void* __restrict__ outp = p.out[layer];
+  const int slots = gridDim.x * WAVES;
+  const int P = 8 * p.NL;                                      // chunks per pass (even)
+  const int full_passes = p.total / slots;
+  const int npass = full_passes + (p.total - full_passes * slots ? 1 : 0);
 
-  // ---- W fragments for this wave: co = 32*wave + col, k = 16*s + 8*kg .. +8 ----
-  bf16x8 whi[VP_KSTEPS], wlo[VP_KSTEPS];
-  {
-    const float* wrow = weight + (size_t)(32 * wave + col) * VP_C + 8 * kg;
-#pragma unroll
-    for (int s = 0; s < VP_KSTEPS; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * s);
-      const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s + 4);
-      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      u32x4 h, l;
-      split8(v, h, l);
-      whi[s] = as_bf16x8(h);
-      wlo[s] = as_bf16x8(l);
-    }
-  }
-  const float bias = p.bias[layer] ? p.bias[layer][32 * wave + col] : 0.f;
-
-  // staging role of this thread: pixel column `spix` of the tile, channels [sc0, sc0 + CPT)
-  const int spix = tid % BM;
-  const int sc0 = (tid / BM) * CPT;
-  float stage[CPT];
-
-  const int total = p.tile_base[p.L];
-  auto decode = [&](int t, int& lvl, int& row, int& pix0) {
-    lvl = 0;
-#pragma unroll
-    for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
-      if (l < p.L && t >= p.tile_base[l]) lvl = l;
-    const int rel = t - p.tile_base[lvl];
-    row = rel / p.tiles[lvl];
-    pix0 = (rel - row * p.tiles[lvl]) * BM;
-  };
-  auto issue_loads = [&](int t) {
-    int lvl, row, pix0;
-    decode(t, lvl, row, pix0);
-    const int hw = p.hw[lvl];
-    const int pix = pix0 + spix;
-    const float* src = static_cast<const float*>(p.in[lvl]) + ((size_t)row * VP_C + sc0) * hw + pix;
-    if (pix < hw) {
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) stage[k] = src[(size_t)k * hw];
-    } else {
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) stage[k] = 0.f;
-    }
-  };
-  auto park = [&](int buf) {
-    char* hi_img = smem + buf * 2 * IMG;
-    char* lo_img = hi_img + IMG;
-#pragma unroll
-    for (int c = 0; c < CPT / 8; ++c) {
-      u32x4 h, l;
-      split8(stage + 8 * c, h, l);
-      const int off = lds_off(spix, sc0 / 8 + c);
-      *reinterpret_cast<u32x4*>(hi_img + off) = h;
-      *reinterpret_cast<u32x4*>(lo_img + off) = l;
-    }
+  const unsigned lane16 = lane * 16;
+  // DMA piece i (0 .. PIECES - 1) of chunk `c` into ring slot `b`: wave w moves the 1-KB pieces w, w + WAVES, ...
+  auto issue_piece = [&](int c, int b, int i) {
+    if (DBG & 8) return;
+    const int piece = wave + i * WAVES;
+    unsigned lo = lane16;
+    asm volatile("" : "+v"(lo));                               // opaque: keeps hipcc from hoisting (and spilling) one
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(p.wimg + (size_t)c * CHUNK + piece * 1024 + lo),   // 64-bit address per piece
+                                     (lds_void_t*)(smem + b * CHUNK + piece * 1024), 16, 0, 0);
   };
 
-  int t = slot;
-  if (t >= total) return;
-  issue_loads(t);
-  park(0);
-  __syncthreads();
+  f32x16 accA, accB;                   // phases in ring slot 0 accumulate into accA, slot 1 into accB
+  char* prev_out = nullptr;            // where the result of the previous phase goes: base of (layer, camera row, tile, chunk)
+  int prev_valid = 0;                  // its number of existing pixel rows (>= 32: all)
+  int prev_head_stride = 0;            // HEAD_MAJOR with Dh < 32: bytes between the chunk's two heads
+  bool have_prev = false;
+  int steady = 0;                      // the previous phase issued exactly PIECES pieces, then 4 stores
+  unsigned long long seg[4] = {0, 0, 0, 0};
 
-  int buf = 0;
-  for (; t < total; t += slots) {
-    const int tn = t + slots;
-    const bool has_next = tn < total;
-    if (has_next) issue_loads(tn);            // register prefetch: in flight during the MFMA phase
-
-    int lvl, row, pix0;
-    decode(t, lvl, row, pix0);
-    const char* hi_img = smem + buf * 2 * IMG;
-    const char* lo_img = hi_img + IMG;
-
-    f32x16 acc[SUB];
-#pragma unroll
-    for (int m = 0; m < SUB; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = bias;
-
-#pragma unroll
-    for (int s = 0; s < VP_KSTEPS; ++s) {
-#pragma unroll
-      for (int m = 0; m < SUB; ++m) {
-        const int off = lds_off(32 * m + col, 2 * s + kg);
-        const bf16x8 ahi = as_bf16x8(*reinterpret_cast<const u32x4*>(hi_img + off));
-        const bf16x8 alo = as_bf16x8(*reinterpret_cast<const u32x4*>(lo_img + off));
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[s], acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[s], acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi[s], acc[m], 0, 0, 0);
-      }
-    }
-
-    // ---- epilogue: C/D layout col = lane&31 (co), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pix) ----
-    {
-      const int hw = p.hw[lvl];
-      const size_t obase = ((size_t)row * p.S + p.start[lvl] + pix0 + 4 * kg) * VP_C + 32 * wave + col;
-      const bool full = pix0 + BM <= hw;                     // workgroup-uniform
-#pragma unroll
-      for (int m = 0; m < SUB; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dp = 32 * m + (r & 3) + 8 * (r >> 2);    // pixel offset inside the tile (minus 4*kg)
-          if (full || pix0 + dp + 4 * kg < hw) {
-            if (OUT_BF16)
-              static_cast<uint16_t*>(outp)[obase + (size_t)dp * VP_C] = f32_to_bf16(acc[m][r]);
-            else
-              static_cast<float*>(outp)[obase + (size_t)dp * VP_C] = acc[m][r];
-          }
-        }
-      }
-    }
-
-    if (has_next) park(buf ^ 1);              // other buffer: nobody reads it during this iteration
-    __syncthreads();
-    buf ^= 1;
-  }
-}
-
-}  // namespace gd4d
-
-static std::atomic<int> g_cu_limit{0};
-
-extern "C" size_t gd4d_value_proj_workspace_bytes(void) { return 0; }
-
-extern "C" int gd4d_value_proj_set_cu_limit(int cus) { return g_cu_limit.exchange(cus < 0 ? 0 : cus); }
-
-namespace gd4d {
-
-// ---------------------------------------------------------------------------------------------
-// v2: software-pipelined variant (BM = 32).  Counters on the kernel above showed the MFMA pipe only
-// ~38 % busy and the waves parked ~44 % of the time: every tile ran load -> MFMA -> store -> convert
-// as workgroup-wide phases.  Here the phases of THREE consecutive tiles overlap inside one barrier
-// interval:
-//     tile t+2 : HBM -> LDS raw fp32 image by LDS-DMA (global_load_lds, no VGPR staging)
-//     tile t+1 : raw fp32 -> hi/lo bf16 [pix][ci] image, sliced into the 16 k-steps of ...
-//     tile t   : ... the MFMA loop, so VALU/LDS conversion work issues under the matrix pipe
-//     tile t-1 : accumulators are stored at the top of the interval (they drain during the MFMAs)
-// One __syncthreads per tile.  LDS: 2 raw images (2 x 32 KB) + 2 bf16 hi/lo images (2 x 32 KB).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
-#define GD4D_SGPR(x) __builtin_amdgcn_readfirstlane(x)
-
-// SINGLE: one bf16 product a_hi*w_hi (bf16-class accuracy, for bf16 value storage) instead of the
-// fp32-class three-product split: 1/3 of the MFMAs, no lo image (half the LDS traffic).
-template <bool OUT_BF16, int DBG, bool HEAD_MAJOR = false, bool SINGLE = false>   // DBG: compile-time ablation bits (dev only; production = 0)
-__global__ __launch_bounds__(VP_THREADS, 2) void value_proj_pipe_kernel(const ValueProjParams p) {
-  constexpr int BM = 32;
-  constexpr int RAW = VP_C * BM * 4;               // bytes of one raw [256 ci][32 pix] fp32 image
-  constexpr int IMG = BM * VP_C * 2;               // bytes of one bf16 [32 pix][256 ci] image
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // raw[2] | {hi, lo}[2]
-  char* const raw_base = smem;
-  char* const img_base = smem + 2 * RAW;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31;
-  const int kg = lane >> 5;
-
-  // Workgroup -> (layer, slot).  Observed dispatch places workgroup b on XCD b % 8 (speed only): the
-  // NL workgroups that serve the same slot are put on ONE XCD so they sweep the same tiles through
-  // the same L2 - the pyramid is then fetched once per slot instead of once per layer.
-  int layer, slot, slots;
-  {
-    const int per_xcd = gridDim.x / 8;             // host guarantees gridDim.x % 8 == 0 when p.xcd_groups
-    if (p.xcd_groups) {
-      const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-      layer = idx % p.NL;
-      slot = xcd * (per_xcd / p.NL) + idx / p.NL;
-      slots = 8 * (per_xcd / p.NL);
-    } else {
-      layer = blockIdx.x % p.NL;
-      slot = blockIdx.x / p.NL;
-      slots = gridDim.x / p.NL;
-    }
-  }
-  const float* __restrict__ weight = p.weight[layer];
-  void* __restrict__ outp = p.out[layer];
-
-  bf16x8 whi[VP_KSTEPS], wlo[VP_KSTEPS];
-  {
-    const float* wrow = weight + (size_t)(32 * wave + col) * VP_C + 8 * kg;
-#pragma unroll
-    for (int s = 0; s < VP_KSTEPS; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * s);
-      const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s + 4);
-      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      u32x4 h, l;
-      split8(v, h, l);
-      whi[s] = as_bf16x8(h);
-      wlo[s] = as_bf16x8(l);
-    }
-  }
-  const float bias = p.bias[layer] ? p.bias[layer][32 * wave + col] : 0.f;
-
-  const int total = p.tile_base[p.L];
-  const int ntile = slot < total ? (total - slot + slots - 1) / slots : 0;
-  if (ntile == 0) return;
-
-  // Level table in the tail of LDS (dynamic indexing of the by-value kernarg struct would make the
-  // compiler copy it to scratch).  Written with static indices; read only at level boundaries.
-  int* const tab = reinterpret_cast<int*>(smem + 2 * RAW + 4 * IMG);     // [L][6]: hw, tiles, start, base, in.lo, in.hi
-  if (tid == 0) {
-#pragma unroll
-    for (int l = 0; l < GD4D_MAX_LEVELS; ++l) {
-      const uintptr_t a = reinterpret_cast<uintptr_t>(p.in[l]);
-      tab[6 * l + 0] = p.hw[l]; tab[6 * l + 1] = p.tiles[l]; tab[6 * l + 2] = p.start[l];
-      tab[6 * l + 3] = p.tile_base[l]; tab[6 * l + 4] = (int)(unsigned)(a & 0xffffffffu); tab[6 * l + 5] = (int)(unsigned)(a >> 32);
-    }
-  }
-  __syncthreads();
-
-  // Tile cursor (DMA side, runs two tiles ahead): plain workgroup-uniform scalars, advanced without
-  // divisions; level parameters change only at level boundaries.
-  int c_lvl, c_row, c_tin, c_hw, c_tiles, c_start;
-  const float* c_in;
-  auto set_level = [&](int lvl) {
-    c_lvl = lvl;
-    c_hw = GD4D_SGPR(tab[6 * lvl + 0]); c_tiles = GD4D_SGPR(tab[6 * lvl + 1]); c_start = GD4D_SGPR(tab[6 * lvl + 2]);
-    const unsigned lo = (unsigned)GD4D_SGPR(tab[6 * lvl + 4]), hi = (unsigned)GD4D_SGPR(tab[6 * lvl + 5]);
-    c_in = reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
+  // The previous phase's accumulators -> the patch -> back, line-major: afterwards quad m of `acc` holds channels
+  // 4 (lane & 7) .. + 4 of pixel 8 m + lane / 8.  Inline asm on purpose: hipcc would put "s_waitcnt vmcnt(0)" in front of
+  // a visible LDS store while LDS-DMA is in flight (it cannot tell the patch from the ring).
+  auto transpose_prev = [&](f32x16& acc) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 q0 = {acc[0], acc[1], acc[2], acc[3]}, q1 = {acc[4], acc[5], acc[6], acc[7]};
+    f32x4 q2 = {acc[8], acc[9], acc[10], acc[11]}, q3 = {acc[12], acc[13], acc[14], acc[15]};
+    // LDS operations of a wave execute in order: the reads below see the writes, and may land in the registers the
+    // writes were issued from
+    asm volatile("ds_write_b128 %4, %0\n\tds_write_b128 %4, %1 offset:32\n\tds_write_b128 %4, %2 offset:64\n\t"
+                 "ds_write_b128 %4, %3 offset:96\n\t"
+                 "ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %5 offset:%7\n\t"
+                 "ds_read_b128 %3, %5 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                 : "v"(st_w), "v"(st_r), "n"(8 * PITCH), "n"(16 * PITCH), "n"(24 * PITCH) : "memory");
+    acc[0] = q0[0]; acc[1] = q0[1]; acc[2] = q0[2]; acc[3] = q0[3];
+    acc[4] = q1[0]; acc[5] = q1[1]; acc[6] = q1[2]; acc[7] = q1[3];
+    acc[8] = q2[0]; acc[9] = q2[1]; acc[10] = q2[2]; acc[11] = q2[3];
+    acc[12] = q3[0]; acc[13] = q3[1]; acc[14] = q3[2]; acc[15] = q3[3];
   };
-  {
-    int lvl = 0;
-#pragma unroll
-    for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
-      if (l < p.L && slot >= p.tile_base[l]) lvl = l;
-    set_level(GD4D_SGPR(lvl));
-    const int rel = slot - GD4D_SGPR(tab[6 * c_lvl + 3]);
-    c_row = GD4D_SGPR(rel / c_tiles);                 // the only division, once per workgroup
-    c_tin = GD4D_SGPR(rel - c_row * c_tiles);
-  }
-  auto advance = [&]() {
-    c_tin += slots;
-    while (c_tin >= c_tiles && c_lvl < p.L) {
-      c_tin -= c_tiles;
-      if (++c_row == p.R) {
-        c_row = 0;
-        if (c_lvl + 1 < p.L) set_level(c_lvl + 1); else c_lvl = p.L;
-      }
-    }
-    c_tin = GD4D_SGPR(c_tin); c_row = GD4D_SGPR(c_row); c_lvl = GD4D_SGPR(c_lvl);
-  };
-
-  // LDS-DMA of the tile under the cursor into raw image `rb`.  Wave w fills ci rows [32w, 32w+32).
-  auto issue_dma = [&](int rb) {
-    if (DBG & 4) return;
-    const int hw = c_hw;
-    const int pix0 = c_tin * BM;
-    const float* src = c_in + (size_t)c_row * VP_C * hw;
-    char* dst = raw_base + rb * RAW + (32 * wave) * (BM * 4);
-    const bool wide = (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);   // wave-uniform
-    if (wide) {
-      // one instruction = 8 ci rows x 128 B; a quad that starts inside the row also ends inside it
-      int pq = pix0 + 4 * (lane & 7);
-      if (pq >= hw) pq = hw - 4;                    // tail lanes re-read the last quad (never stored)
-      const float* g = src + (size_t)(32 * wave + (lane >> 3)) * hw + pq;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(8 * i) * hw),
-                                         (lds_void_t*)(dst + i * 8 * (BM * 4)), 16, 0, 0);
-    } else {
-      // one instruction = 2 ci rows x 128 B, one pixel per lane (clamped exactly at the row end)
-      const int px = min(pix0 + (lane & 31), hw - 1);
-      const float* g = src + (size_t)(32 * wave + (lane >> 5)) * hw + px;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(2 * i) * hw),
-                                         (lds_void_t*)(dst + i * 2 * (BM * 4)), 4, 0, 0);
-    }
-  };
-
-  // conversion role of this thread: pixel spix, channels [16*scg, 16*scg + 16)
-  const int spix = tid & 31;
-  const int scg = tid >> 5;
-
-  // FIFO of (first output pixel row, valid pixel rows) for tiles k, k+1, k+2 - filled at DMA time
-  int orow0 = 0, orem0 = 0, orow1 = 0, orem1 = 0, orow2 = 0, orem2 = 0;
-  auto tile_info = [&](int& orow, int& orem) {
-    orow = GD4D_SGPR(c_row * p.S + c_start + c_tin * BM);
-    orem = GD4D_SGPR(c_hw - c_tin * BM);
-  };
-
-  // ---- prologue: tiles 0 and 1 in flight, tile 0 converted ----
-  issue_dma(0);
-  tile_info(orow0, orem0);
-  advance();
-  if (ntile > 1) { issue_dma(1); tile_info(orow1, orem1); advance(); }
-  __syncthreads();                                 // (drains the DMAs)
-  {
-    const float* rawf = reinterpret_cast<const float*>(raw_base) + (16 * scg) * BM + spix;
-    float cv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) cv[j] = rawf[j * BM];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      u32x4 h, l;
-      split8(cv + 8 * c, h, l);
-      const int off = lds_off(spix, 2 * scg + c);
-      *reinterpret_cast<u32x4*>(img_base + off) = h;
-      if (!SINGLE) *reinterpret_cast<u32x4*>(img_base + IMG + off) = l;
-    }
-  }
-  __syncthreads();
-
-  f32x16 prev;                                     // accumulators of the previous tile, stored one interval later
-  int prow = 0, prem = 0;                          // its first output pixel row / valid pixel rows
-  // head-major: element offset of this lane's (head, channel) inside a camera row's planes
-  const size_t hm_base = (size_t)((32 * wave + col) / p.Dh) * p.S * p.Dh + (32 * wave + col) % p.Dh;
-  int pcam = 0, ppix = 0;                          // camera row / first pixel (in-row) of the previous tile
-  // store accumulator row r of the previous tile (one store instruction)
-  auto store_one = [&](int r, bool full) {
-    if (DBG & 1) { asm volatile("" ::"v"(prev[r])); return; }
-    const int dp = (r & 3) + 8 * (r >> 2);
-    size_t o;
-    if (HEAD_MAJOR) {
-      // prow = cam_row * S + pixel-in-row; plane (cam_row, head) holds S x Dh elements
-      o = hm_base + (size_t)(pcam * p.Hh) * p.S * p.Dh + (size_t)(ppix + 4 * kg + dp) * p.Dh;
-    } else {
-      o = ((size_t)prow + 4 * kg + dp) * VP_C + 32 * wave + col;
-    }
-    if (full || dp + 4 * kg < prem) {
-      if (OUT_BF16) static_cast<uint16_t*>(outp)[o] = f32_to_bf16(prev[r]);
-      else static_cast<float*>(outp)[o] = prev[r];
-    }
-  };
-
-  for (int k = 0; k < ntile; ++k) {
-    // VMEM program order of this interval: [DMA of tile k+2] then [<= 16 stores of tile k-1].
-    // The counted wait at the bottom lets the stores stay in flight across the barrier.
-    if (k + 2 < ntile) { issue_dma(k & 1); tile_info(orow2, orem2); advance(); }
-    // The 16 stores of tile k-1 are spread over the 16 k-steps below (one each), so every store has
-    // ~96 cycles of MFMA work to drain behind instead of backing up the wave's issue.
-    const bool has_prev = k > 0;
-    const bool full_prev = prem >= BM;              // workgroup-uniform; tail tiles take the guarded path
-    const int ib = k & 1;
-    const char* hi_img = img_base + ib * 2 * IMG;
-    const char* lo_img = hi_img + IMG;
-    char* nhi_img = img_base + (ib ^ 1) * 2 * IMG;  // tile k+1 is converted into the other image ...
-    char* nlo_img = nhi_img + IMG;
-    const float* rawf = reinterpret_cast<const float*>(raw_base + (ib ^ 1) * RAW) + (16 * scg) * BM + spix;  // ... from raw[(k+1)&1]
-
-    f32x16 acc0, acc1;                              // two independent MFMA chains
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = 0.f; }
-    float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // A fragments through a 3-deep register ring: the reads for k-step s+2 are issued before the
-    // MFMAs of step s, so LDS latency is covered by matrix work instead of alternating with it.
-    u32x4 fh[3], fl[3];
-    auto frag_load = [&](int s2, u32x4& h, u32x4& l) {
-      if (DBG & 8) { h = u32x4{0u, 0u, 0u, 0u}; l = h; return; }
-      const int off = lds_off(col, 2 * s2 + kg);
-      h = *reinterpret_cast<const u32x4*>(hi_img + off);
-      l = *reinterpret_cast<const u32x4*>(lo_img + off);
-    };
-    frag_load(0, fh[0], fl[0]);
-    frag_load(1, fh[1], fl[1]);
-#pragma unroll
-    for (int s = 0; s < VP_KSTEPS; ++s) {
-      if (s + 2 < VP_KSTEPS) frag_load(s + 2, fh[(s + 2) % 3], fl[(s + 2) % 3]);
-      // 1/16 of the next tile's conversion per k-step (harmless garbage after the last tile)
-      if (!(DBG & 16)) cv[s & 7] = rawf[s * BM];
-      if (has_prev) store_one(s, full_prev);
-      __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ABOVE this step's MFMAs
-      const bf16x8 ahi = as_bf16x8(fh[s % 3]);
-      const bf16x8 alo = as_bf16x8(fl[s % 3]);
-      if (!(DBG & 2)) {
-        if (DBG & 32) __builtin_amdgcn_s_setprio(1);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi[s], acc0, 0, 0, 0);
-        if (!SINGLE) {
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[s], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[s], acc1, 0, 0, 0);
-        }
-        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
+  // store quad m of the (transposed) previous result: pixel 8 m + lane / 8, channels 4 (lane & 7) ..
+  const int lpix = lane >> 3, lgrp = lane & 7;
+  auto store_group = [&](const f32x16& acc, int m) {
+    if (DBG & 1) { asm volatile("" ::"v"(acc[4 * m]), "v"(acc[4 * m + 1]), "v"(acc[4 * m + 2]), "v"(acc[4 * m + 3])); return; }
+    int q = 8 * m + lpix;
+    asm volatile("" : "+v"(q));                                // opaque (see issue_piece)
+    constexpr int ES = OUT_BF16 ? 2 : 4;
+    size_t o;                                                  // byte offset from prev_out
+    if (!HEAD_MAJOR) o = ((size_t)q * VA_C + 4 * lgrp) * ES;
+    else if (p.Dh >= 32) o = ((size_t)q * p.Dh + 4 * lgrp) * ES;
+    else o = (size_t)(4 * lgrp / p.Dh) * prev_head_stride + ((size_t)q * p.Dh + (4 * lgrp) % p.Dh) * ES;
+    if (q < prev_valid) {
+      if (OUT_BF16) {
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(acc[4 * m]) | ((unsigned)f32_to_bf16(acc[4 * m + 1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(acc[4 * m + 2]) | ((unsigned)f32_to_bf16(acc[4 * m + 3]) << 16);
+        *reinterpret_cast<uint2*>(prev_out + o) = pk;
       } else {
-        asm volatile("" ::"v"(ahi), "v"(alo));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if ((s & 7) == 7 && !(DBG & 16)) {
-        u32x4 h, l;
-        split8(cv, h, l);
-        const int woff = lds_off(spix, 2 * scg + (s >> 3));
-        *reinterpret_cast<u32x4*>(nhi_img + woff) = h;
-        if (!SINGLE) *reinterpret_cast<u32x4*>(nlo_img + woff) = l;
+        *reinterpret_cast<float4*>(prev_out + o) = make_float4(acc[4 * m], acc[4 * m + 1], acc[4 * m + 2], acc[4 * m + 3]);
       }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) prev[r] = SINGLE ? acc0[r] : acc0[r] + acc1[r];
-    prow = orow0; prem = orem0;
-    if (HEAD_MAJOR) { pcam = GD4D_SGPR(prow / p.S); ppix = GD4D_SGPR(prow - pcam * p.S); }   // once per tile
-    orow0 = orow1; orem0 = orem1; orow1 = orow2; orem1 = orem2;
-    // Raw barrier + explicit waits (a __syncthreads() here makes the compiler drain vmcnt(0), i.e. wait
-    // for every store of the previous tile).  Needed before the barrier: this wave's LDS writes done
-    // (lgkmcnt) and the DMA of tile k+2 landed - it was issued BEFORE the <= 16 stores, and VMEM ops
-    // retire in order, so "at most 16 outstanding" implies the DMA is complete.
-    // (k = 0 issues no stores, so nothing sits behind the DMA in the queue: full drain there too)
-    if (has_prev && full_prev) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) store_one(r, prem >= BM);
-}
+  };
 
-// ---------------------------------------------------------------------------------------------
-// v3: one wave per SIMD.  4 waves per workgroup (one workgroup per CU), wave w owns output channels
-// [64w, 64w+64) and keeps W_hi / W_lo fragments for both 32-channel blocks in registers (256 of the
-// 512 VGPR+AGPR entries a lone wave may use).  Compared with the 8-wave kernels: every A fragment
-// pair read from LDS feeds 6 MFMAs instead of 3 (half the LDS fragment traffic per tile), the matrix
-// pipe of a SIMD belongs to one wave (no two-wave arbitration), and the wave's other work (DMA issue,
-// conversion slices, stores of the previous tile) is interleaved into its own MFMA stream.
-template <bool OUT_BF16, bool HEAD_MAJOR>
-__global__ __launch_bounds__(256, 1) void value_proj_w4_kernel(const ValueProjParams p) {
-  constexpr int BM = 32;
-  constexpr int RAW = VP_C * BM * 4;
-  constexpr int IMG = BM * VP_C * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // raw[2] | {hi, lo}[2]
-  char* const raw_base = smem;
-  char* const img_base = smem + 2 * RAW;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31;
-  const int kg = lane >> 5;
-
-  int layer, slot, slots;
+  // prologue: the bias table into LDS; chunk 0 of the first pass on its way
   {
-    const int per_xcd = gridDim.x / 8;
-    if (p.xcd_groups) {
-      const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-      layer = idx % p.NL;
-      slot = xcd * (per_xcd / p.NL) + idx / p.NL;
-      slots = 8 * (per_xcd / p.NL);
-    } else {
-      layer = blockIdx.x % p.NL;
-      slot = blockIdx.x / p.NL;
-      slots = gridDim.x / p.NL;
-    }
-  }
-  const float* __restrict__ weight = p.weight[layer];
-  void* __restrict__ outp = p.out[layer];
-
-  bf16x8 whi[2][VP_KSTEPS], wlo[2][VP_KSTEPS];
-  float bias[2];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int co = 64 * wave + 32 * cb + col;
-    const float* wrow = weight + (size_t)co * VP_C + 8 * kg;
-#pragma unroll
-    for (int s = 0; s < VP_KSTEPS; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * s);
-      const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s + 4);
-      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      u32x4 h, l;
-      split8(v, h, l);
-      whi[cb][s] = as_bf16x8(h);
-      wlo[cb][s] = as_bf16x8(l);
-    }
-    bias[cb] = p.bias[layer] ? p.bias[layer][co] : 0.f;
-  }
-
-  const int total = p.tile_base[p.L];
-  const int ntile = slot < total ? (total - slot + slots - 1) / slots : 0;
-  if (ntile == 0) return;
-
-  // level table in the tail of LDS (see value_proj_pipe_kernel)
-  int* const tab = reinterpret_cast<int*>(smem + 2 * RAW + 4 * IMG);
-  if (tid == 0) {
-#pragma unroll
-    for (int l = 0; l < GD4D_MAX_LEVELS; ++l) {
-      const uintptr_t a = reinterpret_cast<uintptr_t>(p.in[l]);
-      tab[6 * l + 0] = p.hw[l]; tab[6 * l + 1] = p.tiles[l]; tab[6 * l + 2] = p.start[l];
-      tab[6 * l + 3] = p.tile_base[l]; tab[6 * l + 4] = (int)(unsigned)(a & 0xffffffffu); tab[6 * l + 5] = (int)(unsigned)(a >> 32);
-    }
+    const float* table = reinterpret_cast<const float*>(p.wimg + (size_t)P * CHUNK);
+    for (int i = threadIdx.x; i < p.NL * VA_C; i += 64 * WAVES) reinterpret_cast<float*>(bias_lds)[i] = table[i];
   }
   __syncthreads();
-  int c_lvl, c_row, c_tin, c_hw, c_tiles, c_start;
-  const float* c_in;
-  auto set_level = [&](int lvl) {
-    c_lvl = lvl;
-    c_hw = GD4D_SGPR(tab[6 * lvl + 0]); c_tiles = GD4D_SGPR(tab[6 * lvl + 1]); c_start = GD4D_SGPR(tab[6 * lvl + 2]);
-    const unsigned lo = (unsigned)GD4D_SGPR(tab[6 * lvl + 4]), hi = (unsigned)GD4D_SGPR(tab[6 * lvl + 5]);
-    c_in = reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
-  };
-  {
-    int lvl = 0;
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) issue_piece(0, 0, i);
+
+  for (int pass = 0; pass < npass; ++pass) {
+    // Tile of this wave.  Full passes give a workgroup WAVES consecutive tiles (contiguous output); the last, partial
+    // pass is dealt wave-major so that its tiles spread over all workgroups instead of filling the first few.
+    const int t = pass < full_passes ? pass * slots + blockIdx.x * WAVES + wave
+                                     : full_passes * slots + wave * gridDim.x + blockIdx.x;
+    const bool active = t < p.total;                           // wave-uniform
+    const float* src = static_cast<const float*>(p.in[0]);
+    int hw = p.hw[0], ostart = p.start[0], tiles = p.tiles[0], tbase = 0;
 #pragma unroll
     for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
-      if (l < p.L && slot >= p.tile_base[l]) lvl = l;
-    set_level(GD4D_SGPR(lvl));
-    const int rel = slot - GD4D_SGPR(tab[6 * c_lvl + 3]);
-    c_row = GD4D_SGPR(rel / c_tiles);
-    c_tin = GD4D_SGPR(rel - c_row * c_tiles);
-  }
-  auto advance = [&]() {
-    c_tin += slots;
-    while (c_tin >= c_tiles && c_lvl < p.L) {
-      c_tin -= c_tiles;
-      if (++c_row == p.R) {
-        c_row = 0;
-        if (c_lvl + 1 < p.L) set_level(c_lvl + 1); else c_lvl = p.L;
+      if (l < p.L && t >= p.tile_base[l]) {
+        src = static_cast<const float*>(p.in[l]); hw = p.hw[l]; ostart = p.start[l]; tiles = p.tiles[l]; tbase = p.tile_base[l];
       }
-    }
-    c_tin = GD4D_SGPR(c_tin); c_row = GD4D_SGPR(c_row); c_lvl = GD4D_SGPR(c_lvl);
-  };
+    const int rel = active ? t - tbase : 0;
+    const int row = __builtin_amdgcn_readfirstlane(rel / tiles);
+    const int pix0 = __builtin_amdgcn_readfirstlane((rel - row * tiles) * VA_TILE);
+    const int valid = __builtin_amdgcn_readfirstlane(hw - pix0);       // pixel rows of the tile that exist (>= 32: full)
 
-  // LDS-DMA: wave w fills ci rows [64w, 64w+64) of the raw image
-  auto issue_dma = [&](int rb) {
-    const int hw = c_hw;
-    const int pix0 = c_tin * BM;
-    const float* src = c_in + (size_t)c_row * VP_C * hw;
-    char* dst = raw_base + rb * RAW + (64 * wave) * (BM * 4);
-    const bool wide = (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    if (wide) {
-      int pq = pix0 + 4 * (lane & 7);
-      if (pq >= hw) pq = hw - 4;
-      const float* g = src + (size_t)(64 * wave + (lane >> 3)) * hw + pq;
+    // ---- the tile's fragments (B operand): ci = 16*s + 8*kg + j at pixel pix0 + col ----
+    u32x4 ahi[VA_KSTEPS], alo[VA_KSTEPS];
+    if (active) {
+      const int pix = min(pix0 + col, hw - 1);                 // tail lanes re-read the last pixel (never stored)
+      const float* gp = src + ((size_t)row * VA_C + 8 * kg) * hw + pix;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(8 * i) * hw),
-                                         (lds_void_t*)(dst + i * 8 * (BM * 4)), 16, 0, 0);
+      for (int s4 = 0; s4 < VA_KSTEPS; s4 += 4) {              // 4 k-steps (32 loads) per batch bounds the staging registers
+        float v[4][8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[s][j] = gp[(size_t)(16 * (s4 + s) + j) * hw];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          u32x4 h, l;
+          va_split8(v[s], h, l);
+          ahi[s4 + s] = h;
+          alo[s4 + s] = l;
+        }
+      }
     } else {
-      const int px = min(pix0 + (lane & 31), hw - 1);
-      const float* g = src + (size_t)(64 * wave + (lane >> 5)) * hw + px;
 #pragma unroll
-      for (int i = 0; i < 32; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)(2 * i) * hw),
-                                         (lds_void_t*)(dst + i * 2 * (BM * 4)), 4, 0, 0);
+      for (int s = 0; s < VA_KSTEPS; ++s) { ahi[s] = u32x4{0u, 0u, 0u, 0u}; alo[s] = ahi[s]; }
     }
-  };
+    // wave-uniform element offset of the tile's first pixel inside a layer's value tensor (+ channel block per chunk)
+    const size_t tile_elem = HEAD_MAJOR ? ((size_t)row * p.Hh * p.S + ostart + pix0) * p.Dh
+                                        : ((size_t)row * p.S + ostart + pix0) * VA_C;
 
-  // conversion role: pixel spix, channels [32*scg, 32*scg + 32)
-  const int spix = tid & 31;
-  const int scg = tid >> 5;                         // 0..7
-
-  int orow0 = 0, orem0 = 0, orow1 = 0, orem1 = 0, orow2 = 0, orem2 = 0;
-  auto tile_info = [&](int& orow, int& orem) {
-    orow = GD4D_SGPR(c_row * p.S + c_start + c_tin * BM);
-    orem = GD4D_SGPR(c_hw - c_tin * BM);
-  };
-
-  issue_dma(0);
-  tile_info(orow0, orem0);
-  advance();
-  if (ntile > 1) { issue_dma(1); tile_info(orow1, orem1); advance(); }
-  __syncthreads();
-  {
-    const float* rawf = reinterpret_cast<const float*>(raw_base) + (32 * scg) * BM + spix;
+    // one phase; SLOT = ring slot = accumulator set (compile-time: the ring offsets become immediates);
+    // STAG = 1: this wave's memory instructions sit in the odd k-steps
+    auto phase = [&](auto slot_c, auto stag_c, int c) {
+      constexpr int SLOT = decltype(slot_c)::value;
+      constexpr int STAG = decltype(stag_c)::value;
+      f32x16& cur = SLOT ? accB : accA;
+      f32x16& old = SLOT ? accA : accB;
+      unsigned long long tt0 = 0, tt1 = 0;
+      if (DBG & 16) tt0 = __builtin_amdgcn_s_memtime();
+      // my pieces of this chunk were issued at the start of the previous phase; a steady wave issued exactly 4 stores since
+      if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                            // chunk complete in SLOT; the other slot is free for the DMA
+      asm volatile("" ::: "memory");
+      if (DBG & 16) tt1 = __builtin_amdgcn_s_memtime();
+      const int nc = c + 1 == P ? 0 : c + 1;                   // next chunk of the (periodic) stream
+      const bool more = pass < npass - 1 || c + 1 < P;         // none behind the end of the last pass
+      if (!active) {                                           // no tile in the last, partial pass: feed the ring, drain
+        if (more) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float cv[8];
+          for (int i = 0; i < PIECES; ++i) issue_piece(nc, SLOT ^ 1, i);
+        }
+        if (have_prev) {
+          transpose_prev(old);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cv[j] = rawf[(8 * c + j) * BM];
-      u32x4 h, l;
-      split8(cv, h, l);
-      const int off = lds_off(spix, 4 * scg + c);
-      *reinterpret_cast<u32x4*>(img_base + off) = h;
-      *reinterpret_cast<u32x4*>(img_base + IMG + off) = l;
+          for (int m = 0; m < 4; ++m) store_group(old, m);
+        }
+        have_prev = false;
+        steady = 0;
+        return;
+      }
+      const char* wb = smem + SLOT * CHUNK;
+      {
+        const char* bp = bias_lds + (c * 32 + kg * 4) * 4;     // bias[layer][32 cb + 8 i + 4 kg .. +4]  (c = 8 layer + cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 bv = *reinterpret_cast<const u32x4*>(bp + 32 * i);
+          cur[4 * i + 0] = __uint_as_float(bv[0]); cur[4 * i + 1] = __uint_as_float(bv[1]);
+          cur[4 * i + 2] = __uint_as_float(bv[2]); cur[4 * i + 3] = __uint_as_float(bv[3]);
+        }
+      }
+      u32x4 wh[2], wl[2];
+      if (DBG & 4) { wh[0] = u32x4{1u, 2u, 3u, (unsigned)lane}; wl[0] = wh[0]; wh[1] = wh[0]; wl[1] = wh[0]; }
+      else {
+        wh[0] = *reinterpret_cast<const u32x4*>(wb + lane * 16);
+        if (!SINGLE) wl[0] = *reinterpret_cast<const u32x4*>(wb + 1024 + lane * 16);
+      }
+      const bool stores_now = have_prev;
+#pragma unroll
+      for (int s = 0; s < VA_KSTEPS; ++s) {
+        if (s + 1 < VA_KSTEPS && !(DBG & 4)) {                 // next k-step's W fragments while this step's MFMAs run
+          wh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(wb + ((s + 1) * PARTS) * 1024 + lane * 16);
+          if (!SINGLE) wl[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(wb + ((s + 1) * PARTS + 1) * 1024 + lane * 16);
+        }
+        if (s == 2 * PIECES + STAG - 1) { if (stores_now) transpose_prev(old); }    // between the pieces and the stores
+        if (s >= STAG && ((s - STAG) & 1) == 0) {              // this wave's memory instruction of the k-step, if any
+          const int j = (s - STAG) >> 1;
+          if (j < PIECES) { if (more) issue_piece(nc, SLOT ^ 1, j); }                // pieces FIRST in the queue,
+          else if (j < NOPS) { if (stores_now) store_group(old, j - PIECES); }       // then the stores
+        }
+        if (DBG & 2) { asm volatile("" ::"v"(wh[s & 1]), "v"(wl[s & 1]), "v"(ahi[s]), "v"(alo[s])); continue; }
+        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(wh[s & 1]), va_frag(ahi[s]), cur, 0, 0, 0);
+        if (!SINGLE) {
+          cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(wh[s & 1]), va_frag(alo[s]), cur, 0, 0, 0);
+          cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(wl[s & 1]), va_frag(ahi[s]), cur, 0, 0, 0);
+        }
+      }
+      // a full tile issues exactly 4 store instructions (a partial one may skip instructions whose 8 pixels are all absent)
+      steady = more && stores_now && prev_valid >= VA_TILE && !(DBG & 9);
+      // this phase's result stays in `cur`; the next phase stores it
+      have_prev = true;
+      {
+        const int layer = c >> 3, cb = c & 7;
+        void* outp = p.out[0];
+#pragma unroll
+        for (int l = 1; l < GD4D_MAX_LAYERS; ++l)
+          if (l == layer) outp = p.out[l];
+        constexpr int ES = OUT_BF16 ? 2 : 4;
+        size_t e = tile_elem;
+        if (!HEAD_MAJOR) e += 32 * cb;
+        else e += (size_t)((32 * cb) / p.Dh) * p.S * p.Dh + (32 * cb) % p.Dh;
+        prev_out = static_cast<char*>(outp) + e * ES;
+        prev_head_stride = p.S * p.Dh * ES;
+        prev_valid = valid;
+      }
+      if (DBG & 16) {
+        const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
+        seg[0] += tt1 - tt0; seg[1] += tt2 - tt1; seg[2] += 1;
+      }
+    };
+    steady = 0;                        // (the tile's loads above drained the queue: counts restart)
+    using std::integral_constant;
+    if (odd_wave) {
+      for (int c = 0; c < P; c += 2) {
+        phase(integral_constant<int, 0>{}, integral_constant<int, 1>{}, c);
+        phase(integral_constant<int, 1>{}, integral_constant<int, 1>{}, c + 1);
+      }
+    } else {
+      for (int c = 0; c < P; c += 2) {
+        phase(integral_constant<int, 0>{}, integral_constant<int, 0>{}, c);
+        phase(integral_constant<int, 1>{}, integral_constant<int, 0>{}, c + 1);
+      }
     }
   }
-  __syncthreads();
-
-  f32x16 prev[2];
-  int prow = 0, prem = 0, pcam = 0, ppix = 0;
-  const size_t hm_base0 = (size_t)((64 * wave + col) / p.Dh) * p.S * p.Dh + (64 * wave + col) % p.Dh;
-  const size_t hm_base1 = (size_t)((64 * wave + 32 + col) / p.Dh) * p.S * p.Dh + (64 * wave + 32 + col) % p.Dh;
-  auto store_one = [&](int cb, int r, bool full) {
-    const int dp = (r & 3) + 8 * (r >> 2);
-    size_t o;
-    if (HEAD_MAJOR) o = (cb ? hm_base1 : hm_base0) + (size_t)(pcam * p.Hh) * p.S * p.Dh + (size_t)(ppix + 4 * kg + dp) * p.Dh;
-    else o = ((size_t)prow + 4 * kg + dp) * VP_C + 64 * wave + 32 * cb + col;
-    if (full || dp + 4 * kg < prem) {
-      if (OUT_BF16) static_cast<uint16_t*>(outp)[o] = f32_to_bf16(prev[cb][r]);
-      else static_cast<float*>(outp)[o] = prev[cb][r];
-    }
-  };
-
-  for (int k = 0; k < ntile; ++k) {
-    if (k + 2 < ntile) { issue_dma(k & 1); tile_info(orow2, orem2); advance(); }
-    const bool has_prev = k > 0;
-    const bool full_prev = prem >= BM;
-    const int ib = k & 1;
-    const char* hi_img = img_base + ib * 2 * IMG;
-    const char* lo_img = hi_img + IMG;
-    char* nhi_img = img_base + (ib ^ 1) * 2 * IMG;
-    char* nlo_img = nhi_img + IMG;
-    const float* rawf = reinterpret_cast<const float*>(raw_base + (ib ^ 1) * RAW) + (32 * scg) * BM + spix;
-
-    f32x16 acc[2];
+  // the last phase's result (P is even: it sits in accB)
+  if (have_prev) {
+    transpose_prev(accB);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[cb][r] = bias[cb];
-    float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    u32x4 fh[2], fl[2];
-    {
-      const int off = lds_off(col, kg);
-      fh[0] = *reinterpret_cast<const u32x4*>(hi_img + off);
-      fl[0] = *reinterpret_cast<const u32x4*>(lo_img + off);
-    }
-#pragma unroll
-    for (int s = 0; s < VP_KSTEPS; ++s) {
-      if (s + 1 < VP_KSTEPS) {                       // prefetch the next step's A fragments
-        const int off = lds_off(col, 2 * (s + 1) + kg);
-        fh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(hi_img + off);
-        fl[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(lo_img + off);
-      }
-      // 2/32 of the next tile's conversion and 2/32 of the previous tile's stores per k-step
-      cv[(2 * s) & 7] = rawf[(2 * s) * BM];
-      cv[(2 * s + 1) & 7] = rawf[(2 * s + 1) * BM];
-      if (has_prev) { store_one(0, s, full_prev); store_one(1, s, full_prev); }
-      __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 ahi = as_bf16x8(fh[s & 1]);
-      const bf16x8 alo = as_bf16x8(fl[s & 1]);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi[cb][s], acc[cb], 0, 0, 0);
-      }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo[cb][s], acc[cb], 0, 0, 0);
-      }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi[cb][s], acc[cb], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if ((s & 3) == 3) {                            // 8 channels gathered: one chunk of the next image
-        u32x4 h, l;
-        split8(cv, h, l);
-        const int woff = lds_off(spix, 4 * scg + (s >> 2));
-        *reinterpret_cast<u32x4*>(nhi_img + woff) = h;
-        *reinterpret_cast<u32x4*>(nlo_img + woff) = l;
-      }
-    }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) prev[cb][r] = acc[cb][r];
-    prow = orow0; prem = orem0;
-    if (HEAD_MAJOR) { pcam = GD4D_SGPR(prow / p.S); ppix = GD4D_SGPR(prow - pcam * p.S); }
-    orow0 = orow1; orem0 = orem1; orow1 = orow2; orem1 = orem2;
-    // DMA of tile k+2 was issued before this interval's 32 stores (see value_proj_pipe_kernel)
-    if (has_prev && full_prev) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    for (int m = 0; m < 4; ++m) store_group(accB, m);
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { store_one(0, r, prem >= BM); store_one(1, r, prem >= BM); }
+  if ((DBG & 16) && p.trace && blockIdx.x < 8 && lane == 0) {
+    unsigned long long* t = p.trace + (blockIdx.x * WAVES + wave) * 8;
+    for (int i = 0; i < 4; ++i) t[i] = seg[i];
+  }
 }
 
-static int vp_variant() {
-  static int v = 0;
-  if (!v) {
-    const char* e = getenv("GD4D_VP_VARIANT");        // dev A/B switch: 1 = phase kernel, 2 = pipelined
-    v = e ? atoi(e) : 2;
-    if (v < 1 || v > 3) v = 2;
-  }
-  return v;
-}
-
-static int vp_tile_pixels() {
-  static int bm = 0;
-  if (!bm) {
-    const char* e = getenv("GD4D_VP_BM");            // dev A/B switch
-    bm = (e && atoi(e) == 64) ? 64 : 32;
-  }
-  return bm;
-}
-
-template <int BM>
-static int vp_launch(ValueProjParams& p, const int32_t* level_hw, int R, int L, int NL, int out_dtype,
-                     hipStream_t st) {
-  int s = 0, base = 0;
-  for (int l = 0; l < L; ++l) {
-    const int hw = level_hw[2 * l] * level_hw[2 * l + 1];
-    p.hw[l] = hw;
-    p.start[l] = s;
-    p.tiles[l] = (hw + BM - 1) / BM;
-    p.tile_base[l] = base;
-    s += hw;
-    base += R * p.tiles[l];
-  }
-  for (int l = L; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
-  p.S = s;
+static int va_cus() {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
-  {
-    // leave CUs free for kernels of another stream (gd4d_value_proj_set_cu_limit; GD4D_VP_CUS overrides, dev switch)
-    static int env_limit = -1;
-    if (env_limit < 0) { const char* e = getenv("GD4D_VP_CUS"); env_limit = e ? atoi(e) : 0; }
-    const int limit = env_limit > 0 ? env_limit : g_cu_limit.load(std::memory_order_relaxed);
-    if (limit >= 8 && limit < cus) cus = limit - limit % 8;
-  }
-  int slots = cus / NL;                                // persistent: <= one workgroup per CU
-  if (slots < 1) slots = 1;
-  if (slots > base) slots = base;
-  const int grid = slots * NL;
-  if (BM == 32 && (vp_variant() >= 2 || p.head_major || p.single_product)) {
-    // co-locate the NL workgroups of a slot on one XCD: grid = 8 XCDs x (cus/8 rounded down to a multiple of NL)
-    int g2 = grid;
-    p.xcd_groups = 0;
-    if (NL > 1 && cus % 8 == 0 && (cus / 8) >= NL) {
-      const int per_xcd = ((cus / 8) / NL) * NL;
-      if (8 * (per_xcd / NL) <= base) { g2 = 8 * per_xcd; p.xcd_groups = 1; }
-    }
-    const int grid = g2;
-    size_t lds2 = 2 * (size_t)VP_C * 32 * 4 + 2 * 2 * (size_t)32 * VP_C * 2 + 256;   // raw[2] + {hi,lo}[2] = 128 KB, + level table
-    {
-      // GD4D_VP_LDS_FENCE=1: claim the CU's whole LDS so that kernels of another stream that use LDS (the query-side
-      // linears, LayerNorms, attention core) cannot co-reside on this kernel's CUs and are dispatched to the CUs
-      // GD4D_VP_CUS leaves free instead of fighting the persistent waves for issue slots.
-      static int fence = -1;
-      if (fence < 0) { const char* e = getenv("GD4D_VP_LDS_FENCE"); fence = e ? atoi(e) : 0; }
-      if (fence) lds2 = 160 * 1024;
-    }
-    const bool ob = out_dtype == GD4D_BF16;
-    if (vp_variant() == 3 && !p.single_product && p.dbg == 0) {     // one wave per SIMD
-      auto go4 = [&](auto kern) {
-        (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds2);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds2, st, p);
-      };
-      if (p.head_major) { if (ob) go4(value_proj_w4_kernel<true, true>); else go4(value_proj_w4_kernel<false, true>); }
-      else { if (ob) go4(value_proj_w4_kernel<true, false>); else go4(value_proj_w4_kernel<false, false>); }
-      return check_launch();
-    }
-    auto go = [&](auto kern) {
-      (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds2);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(VP_THREADS), lds2, st, p);
-    };
-    switch (p.dbg) {                                 // ablation builds exist for fp32 output only
-      case 1: go(value_proj_pipe_kernel<false, 1>); break;
-      case 2: go(value_proj_pipe_kernel<false, 2>); break;
-      case 3: go(value_proj_pipe_kernel<false, 3>); break;
-      case 7: go(value_proj_pipe_kernel<false, 7>); break;
-      case 31: go(value_proj_pipe_kernel<false, 31>); break;
-      case 32: go(value_proj_pipe_kernel<false, 32>); break;
-      default:
-        if (p.single_product) {                      // bf16 output only (validated by the caller)
-          if (p.head_major) go(value_proj_pipe_kernel<true, 0, true, true>); else go(value_proj_pipe_kernel<true, 0, false, true>);
-        } else if (p.head_major) { if (ob) go(value_proj_pipe_kernel<true, 0, true>); else go(value_proj_pipe_kernel<false, 0, true>); }
-        else { if (ob) go(value_proj_pipe_kernel<true, 0>); else go(value_proj_pipe_kernel<false, 0>); }
-        break;
-    }
-    return check_launch();
-  }
-  const size_t lds = 2 * 2 * (size_t)BM * VP_C * 2;    // 2 buffers x (hi, lo) x [BM][256] bf16
-  if (out_dtype == GD4D_BF16) {
-    (void)allow_dynamic_lds(reinterpret_cast<const void*>(value_proj_kernel<BM, true>), (int)lds);
-    hipLaunchKernelGGL((value_proj_kernel<BM, true>), dim3(grid), dim3(VP_THREADS), lds, st, p);
-  } else {
-    (void)allow_dynamic_lds(reinterpret_cast<const void*>(value_proj_kernel<BM, false>), (int)lds);
-    hipLaunchKernelGGL((value_proj_kernel<BM, false>), dim3(grid), dim3(VP_THREADS), lds, st, p);
-  }
-  return check_launch();
+  return cus;
 }
 
 }  // namespace gd4d
 
+extern "C" size_t gd4d_value_proj_workspace_bytes(int NL) {
+  if (NL <= 0 || NL > GD4D_MAX_LAYERS) return 0;
+  return gd4d::va_image_bytes(NL, false) + 4096;                // the weight image (the larger, split form) + dev trace
+}
+
 extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                                          const float* const* weights, const float* const* biases,
-                                         void* const* outs, int R, int C, int L, int NL, int Hh,
-                                         int in_dtype, int out_dtype, int out_layout, int precision,
-                                         void* stream) {
+                                         void* const* outs, int R, int C, int L, int NL, int Hh, int in_dtype,
+                                         int out_dtype, int out_layout, int precision, void* workspace,
+                                         size_t workspace_bytes, int max_cus, void* stream) {
   using namespace gd4d;
-  if (!feats || !level_hw || !weights || !outs) return GD4D_EINVAL;
+  if (!feats || !level_hw || !weights || !outs || !workspace) return GD4D_EINVAL;
   if (R <= 0 || C <= 0 || L <= 0 || NL <= 0) return GD4D_EINVAL;
-  if (C != VP_C || L > GD4D_MAX_LEVELS || NL > GD4D_MAX_LAYERS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+  if (C != VA_C || L > GD4D_MAX_LEVELS || NL > GD4D_MAX_LAYERS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
   if (out_dtype != GD4D_F32 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (out_layout != GD4D_LAYOUT_PIXEL_MAJOR && out_layout != GD4D_LAYOUT_HEAD_MAJOR) return GD4D_EUNSUPPORTED;
   if (Hh <= 0 || C % Hh != 0) return GD4D_EINVAL;
   if (precision != GD4D_VP_PRECISION_F32 && precision != GD4D_VP_PRECISION_BF16) return GD4D_EUNSUPPORTED;
   if (precision == GD4D_VP_PRECISION_BF16 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
-  ValueProjParams p{};
+  if (workspace_bytes < gd4d_value_proj_workspace_bytes(NL)) return GD4D_EINVAL;
+  if (!aligned16(workspace)) return GD4D_EALIGN;
+  const bool single = precision == GD4D_VP_PRECISION_BF16;
+  VpaParams p{};
+  int s = 0, base = 0;
   for (int l = 0; l < L; ++l) {
     if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
-    p.in[l] = feats[l];
+    const int hw = level_hw[2 * l] * level_hw[2 * l + 1];
+    p.in[l] = feats[l]; p.hw[l] = hw; p.start[l] = s; p.tiles[l] = (hw + VA_TILE - 1) / VA_TILE; p.tile_base[l] = base;
+    s += hw;
+    base += R * p.tiles[l];
   }
+  for (int l = L; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
+  for (int l = L; l < GD4D_MAX_LEVELS; ++l) { p.tiles[l] = 1; p.hw[l] = 1; }
+  p.S = s; p.R = R; p.L = L; p.NL = NL; p.Hh = Hh; p.Dh = C / Hh; p.total = base;
   for (int i = 0; i < NL; ++i) {
     if (!weights[i] || !outs[i]) return GD4D_EINVAL;
     if (!aligned16(weights[i])) return GD4D_EALIGN;
-    p.weight[i] = weights[i];
-    p.bias[i] = biases ? biases[i] : nullptr;
     p.out[i] = outs[i];
   }
-  p.R = R; p.L = L; p.NL = NL;
-  p.head_major = out_layout == GD4D_LAYOUT_HEAD_MAJOR; p.Hh = Hh; p.Dh = C / Hh;
-  p.single_product = precision == GD4D_VP_PRECISION_BF16;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GD4D_VP_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return (vp_tile_pixels() == 64 && !p.head_major && !p.single_product) ? vp_launch<64>(p, level_hw, R, L, NL, out_dtype, st)
-                                                   : vp_launch<32>(p, level_hw, R, L, NL, out_dtype, st);
+  char* wimg = static_cast<char*>(workspace);
+  p.wimg = wimg;
+  VpaWeights pack{};                                           // by value: kernel arguments are capturable, a copy is not
+  for (int i = 0; i < NL; ++i) { pack.w[i] = weights[i]; pack.b[i] = biases ? biases[i] : nullptr; }
+  if (single) hipLaunchKernelGGL(value_proj_wimg_kernel<true>, dim3(NL * 8), dim3(256), 0, st, pack, wimg);
+  else hipLaunchKernelGGL(value_proj_wimg_kernel<false>, dim3(NL * 8), dim3(256), 0, st, pack, wimg);
+  if (int rc = check_launch()) return rc;
+
+  int cus = va_cus();
+  if (max_cus >= 8 && max_cus < cus) cus = max_cus - max_cus % 8;   // leave CUs to kernels of another stream
+  constexpr int waves = 8;                                     // one persistent 8-wave workgroup per CU
+  int grid = cus;
+  const int need = (base + waves - 1) / waves;
+  if (grid > need) grid = need;
+  const size_t lds = VA_RING * (size_t)va_chunk_bytes(single) + (size_t)NL * VA_C * 4 + 8 * VA_TILE * 144;   // ring, bias, patches
+  const bool ob = out_dtype == GD4D_BF16, hm = out_layout == GD4D_LAYOUT_HEAD_MAJOR;
+  auto go = [&](auto kern) {
+    (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, st, p);
+  };
+#define GD4D_VA_DISPATCH(W)                                                                                         \
+  if (single) { if (hm) go(value_proj_astat_kernel<W, true, true, true>); else go(value_proj_astat_kernel<W, true, false, true>); } \
+  else if (ob) { if (hm) go(value_proj_astat_kernel<W, true, true, false>); else go(value_proj_astat_kernel<W, true, false, false>); } \
+  else { if (hm) go(value_proj_astat_kernel<W, false, true, false>); else go(value_proj_astat_kernel<W, false, false, false>); }
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("GD4D_VA_DBG"); dbg = e ? atoi(e) : 0; }
+  if (dbg & 16) {                                               // dev: the trace buffer rides in the workspace's tail
+    p.trace = reinterpret_cast<unsigned long long*>(wimg + va_image_bytes(NL, false));
+  }
+  if (dbg && !single && !ob && !hm) {                          // ablation builds: fp32, pixel-major, 8 waves only
+    switch (dbg) {
+      case 1: go(value_proj_astat_kernel<8, false, false, false, 1>); break;
+      case 2: go(value_proj_astat_kernel<8, false, false, false, 2>); break;
+      case 3: go(value_proj_astat_kernel<8, false, false, false, 3>); break;
+      case 4: go(value_proj_astat_kernel<8, false, false, false, 4>); break;
+      case 5: go(value_proj_astat_kernel<8, false, false, false, 5>); break;
+      case 13: go(value_proj_astat_kernel<8, false, false, false, 13>); break;
+      case 15: go(value_proj_astat_kernel<8, false, false, false, 15>); break;
+      case 6: go(value_proj_astat_kernel<8, false, false, false, 6>); break;
+      case 10: go(value_proj_astat_kernel<8, false, false, false, 10>); break;
+      case 14: go(value_proj_astat_kernel<8, false, false, false, 14>); break;
+      case 8: go(value_proj_astat_kernel<8, false, false, false, 8>); break;
+      case 12: go(value_proj_astat_kernel<8, false, false, false, 12>); break;
+      case 16: go(value_proj_astat_kernel<8, false, false, false, 16>); break;
+      case 17: go(value_proj_astat_kernel<8, false, false, false, 17>); break;
+      default: go(value_proj_astat_kernel<8, false, false, false, 0>); break;
+    }
+    return check_launch();
+  }
+  GD4D_VA_DISPATCH(8)
+#undef GD4D_VA_DISPATCH
+  return check_launch();
 }
 
 extern "C" int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
                                    const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
-                                   int out_dtype, int out_layout, int precision, void* stream) {
+                                   int out_dtype, int out_layout, int precision, void* workspace,
+                                   size_t workspace_bytes, int max_cus, void* stream) {
   if (!weight || !out) return GD4D_EINVAL;
   const float* ws[1] = {weight};
   const float* bs[1] = {bias};
   void* os[1] = {out};
   return gd4d_value_proj_multi_fwd(feats, level_hw, ws, bs, os, R, C, L, 1, Hh, in_dtype, out_dtype, out_layout,
-                                   precision, stream);
+                                   precision, workspace, workspace_bytes, max_cus, stream);
 }

@@ -157,7 +157,7 @@ def use_head_major(value_dtype):
     return value_dtype == torch.bfloat16
 
 
-def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
+def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32, max_cus=0):
     """value_proj over the flattened multi-camera pyramid (deform3d_cross_attn.py:264-280), one HIP
     pass (ops.value_proj_fwd): NCHW in, channels-last head-major out, no transposed/concatenated copies.
 
@@ -168,7 +168,7 @@ def value_projection(value, weight, bias, num_heads, out_dtype=torch.float32):
     hm = use_head_major(out_dtype)
     out = ops.value_proj_fwd([v.contiguous() for v in value], weight.contiguous(),
                              None if bias is None else bias.contiguous(), out_dtype,
-                             num_heads=num_heads, head_major=hm, bf16_math=out_dtype == torch.bfloat16)
+                             num_heads=num_heads, head_major=hm, bf16_math=out_dtype == torch.bfloat16, max_cus=max_cus)
     return (out if hm else out.view(b * n, -1, num_heads, c // num_heads)), shapes
 
 
@@ -330,15 +330,11 @@ class ValuePipeline:
 
     def _issue(self, i):
         m = self.modules[i]
-        old = ops.value_proj_set_cu_limit(self._cu_share())
-        try:
-            with torch.cuda.stream(self.side):
-                val, shapes = value_projection(self.value, m.value_proj.weight, m.value_proj.bias, m.num_heads,
-                                               m.value_dtype)
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-        finally:
-            ops.value_proj_set_cu_limit(old)
+        with torch.cuda.stream(self.side):
+            val, shapes = value_projection(self.value, m.value_proj.weight, m.value_proj.bias, m.num_heads,
+                                           m.value_dtype, max_cus=self._cu_share())
+            ev = torch.cuda.Event()
+            ev.record(self.side)
         self.ready[id(m)] = (val, shapes, ev)
 
     def take(self, module, value):

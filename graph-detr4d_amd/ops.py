@@ -146,33 +146,25 @@ def detr3d_v2_fwd(feats, ref, attn_logits, offsets, lidar2img, pc_range, img_h, 
     return (out, mask) if want_mask else out
 
 
+def _vp_workspace(nlayers, device):
+    """Scratch for the weight fragments of a value_proj launch (rewritten by every call: stream-ordered, so a fresh
+    tensor per call keeps concurrent launches on different streams apart; the caching allocator makes it free)."""
+    nbytes = _lib.load().gd4d_value_proj_workspace_bytes(int(nlayers))
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
+
+
 def value_proj_fwd(feats, weight, bias, out_dtype=torch.float32, out=None, num_heads=8, head_major=False,
-                   bf16_math=False):
+                   bf16_math=False, max_cus=0):
     """gd4d_value_proj_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) or (R, C, H_l, W_l) fp32;
     weight (C, C); bias (C) or None.  Returns (R, S, C) in `out_dtype`, or (R, Hh, S, C/Hh) with
-    head_major=True."""
-    lib = _lib.load()
-    f32 = torch.float32
-    c = weight.shape[0]
-    r = feats[0].numel() // (c * feats[0].shape[-1] * feats[0].shape[-2])
-    nl = len(feats)
-    s = sum(f.shape[-1] * f.shape[-2] for f in feats)
-    if out is None:
-        shape = (r, num_heads, s, c // num_heads) if head_major else (r, s, c)
-        out = torch.empty(*shape, device=weight.device, dtype=out_dtype)
-    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
-    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
-    code = lib.gd4d_value_proj_fwd(ptrs, lv, _dev(weight, 'weight', f32),
-                                   _dev(bias, 'bias', f32) if bias is not None else None,
-                                   _dev(out, 'out'), r, c, nl, num_heads, _lib.F32, _value_dtype(out),
-                                   _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR, int(bool(bf16_math)),
-                                   _stream())
-    _lib.check(code, 'gd4d_value_proj_fwd')
-    return out
+    head_major=True.  max_cus: occupy at most that many CUs (0 = all)."""
+    o = value_proj_multi_fwd(feats, [weight], [bias], out_dtype, num_heads, head_major, bf16_math, max_cus,
+                             outs=None if out is None else [out])
+    return o[0]
 
 
 def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_heads=8, head_major=False,
-                         bf16_math=False):
+                         bf16_math=False, max_cus=0, outs=None):
     """gd4d_value_proj_multi_fwd: project the same pyramid with NL (weight, bias) pairs in one
     launch.  Returns a list of NL tensors (R, S, C) (or (R, Hh, S, C/Hh) with head_major=True)."""
     lib = _lib.load()
@@ -183,7 +175,9 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_he
     nl = len(feats)
     s = sum(f.shape[-1] * f.shape[-2] for f in feats)
     shape = (r, num_heads, s, c // num_heads) if head_major else (r, s, c)
-    outs = [torch.empty(*shape, device=weights[0].device, dtype=out_dtype) for _ in range(nlayers)]
+    if outs is None:
+        outs = [torch.empty(*shape, device=weights[0].device, dtype=out_dtype) for _ in range(nlayers)]
+    ws, nbytes = _vp_workspace(nlayers, weights[0].device)
     ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
     wp = (ctypes.c_void_p * nlayers)(*[_dev(w, 'weight', f32).value for w in weights])
@@ -193,7 +187,8 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_he
     code = lib.gd4d_value_proj_multi_fwd(ptrs, lv, wp, bp, op, r, c, nl, nlayers, num_heads, _lib.F32,
                                          _value_dtype(outs[0]),
                                          _lib.HEAD_MAJOR if head_major else _lib.PIXEL_MAJOR,
-                                         int(bool(bf16_math)), _stream())
+                                         int(bool(bf16_math)), _dev(ws, 'workspace'), ctypes.c_size_t(nbytes),
+                                         int(max_cus), _stream())
     _lib.check(code, 'gd4d_value_proj_multi_fwd')
     return outs
 
@@ -395,11 +390,6 @@ def refine_reference_fwd(tmp, ref):
                                          _dev(out, 'out'), ref.numel() // 3, tmp.shape[-1], _stream())
     _lib.check(code, 'gd4d_refine_reference_fwd')
     return out
-
-
-def value_proj_set_cu_limit(cus):
-    """gd4d_value_proj_set_cu_limit: later value_proj launches use at most `cus` CUs (0 = all).  Returns the old limit."""
-    return _lib.load().gd4d_value_proj_set_cu_limit(int(cus))
 
 
 def frustum_pe_input_fwd(img2lidar, feat_hw, pad_hw, depth_num, depth_start, pc_range, out=None, row_start=0):
@@ -674,7 +664,7 @@ def _on_tensor_device(fn):
     return wrapped
 
 
-_HOST_ONLY = {'linear_sum_assignment_batch', 'value_proj_set_cu_limit'}
+_HOST_ONLY = {'linear_sum_assignment_batch'}
 for _name, _fn in list(globals().items()):
     if inspect.isfunction(_fn) and _fn.__module__ == __name__ and not _name.startswith('_') and _name not in _HOST_ONLY:
         globals()[_name] = _on_tensor_device(_fn)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 14
+#define GD4D_ABI_VERSION 15
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -176,27 +176,30 @@ int gd4d_detr3d_v2_fwd(const void* const* feats, const int32_t* level_hw, const 
  *             (R, Hh, S, C/Hh) for GD4D_LAYOUT_HEAD_MAJOR;  S = sum_l H_l*W_l
  * Arithmetic: split-bf16 x3 MFMA with fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi):
  * fp32-class accuracy (<= ~2^-17 relative per product), see DESIGN.md.
- * Supported: C == 256, in_dtype == GD4D_F32, L <= 8.  No workspace.
+ * Supported: C == 256, in_dtype == GD4D_F32, L <= 8.
+ *   workspace  device, gd4d_value_proj_workspace_bytes(NL) bytes, 16-byte aligned: the launch first rewrites the weights
+ *              as bf16 hi / lo MFMA fragments there (one small kernel, every call: the weights may have changed)
+ *   max_cus    0 = the whole device; otherwise at most this many CUs (rounded down to a multiple of 8) are occupied by
+ *              the persistent workgroups, so that kernels of another HIP stream find free CUs (a call argument, not
+ *              process-wide state)
  */
 int gd4d_value_proj_fwd(const void* const* feats, const int32_t* level_hw, const float* weight,
                         const float* bias, void* out, int R, int C, int L, int Hh, int in_dtype,
-                        int out_dtype, int out_layout, int precision, void* stream);
-size_t gd4d_value_proj_workspace_bytes(void);
-/* gd4d_value_proj_set_cu_limit - value_proj is a persistent kernel (one workgroup per CU).  With a limit it launches at
- * most `cus` workgroups (rounded down to a multiple of 8, 0 = all CUs) so that kernels another HIP stream runs at the
- * same time find free CUs.  Process-wide, applies to later launches; returns the previous limit. */
-int gd4d_value_proj_set_cu_limit(int cus);
+                        int out_dtype, int out_layout, int precision, void* workspace, size_t workspace_bytes,
+                        int max_cus, void* stream);
+size_t gd4d_value_proj_workspace_bytes(int NL);
 
 /* gd4d_value_proj_multi_fwd - the same projection for NL decoder layers in ONE launch.
  * Every decoder layer receives the same `value` list (Detr3DTransformerDecoder.forward passes
  * `*args` unchanged to each layer, detr3d_transformer.py:192-198), so the NL value_proj GEMMs share
- * their input: the layer groups sweep the pyramid together and it is read from HBM once instead of
- * NL times.  weights / biases / outs: host arrays of NL device pointers (biases or its entries may
- * be NULL).  NL <= GD4D_MAX_LAYERS.  Results are bit-identical to NL gd4d_value_proj_fwd calls. */
+ * their input: a wave keeps its pixel tile's A fragments in registers for all NL layers and the pyramid is read
+ * from HBM once instead of NL times.  weights / biases / outs: host arrays of NL device pointers (biases or its
+ * entries may be NULL).  NL <= GD4D_MAX_LAYERS.  Results are bit-identical to NL gd4d_value_proj_fwd calls. */
 int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t* level_hw,
                               const float* const* weights, const float* const* biases,
                               void* const* outs, int R, int C, int L, int NL, int Hh, int in_dtype,
-                              int out_dtype, int out_layout, int precision, void* stream);
+                              int out_dtype, int out_layout, int precision, void* workspace,
+                              size_t workspace_bytes, int max_cus, void* stream);
 
 /* gd4d_value_proj_bwd_input / _bwd_weight - backward of gd4d_value_proj_fwd (fp32, pixel-major grad_out): what autograd
  * derives for `self.value_proj(value_flatten)` and the flatten / transpose / cat in front of it
