@@ -1,0 +1,389 @@
+// gd4d_row_chain_fwd: a CHAIN of row-local operations (Linear, LayerNorm, adds, ReLU, reference-point refinement) over
+// blocks of 16 complete rows, one launch.
+//
+// Between two points where a decoder layer needs all queries at once (the attention core, the fused sample-aggregate
+// kernel) everything the reference does is row-local: nn.MultiheadAttention's out_proj + residual, norms[i], the
+// Linears of Deform3DCrossAttn on query + query_pos (deform3d_cross_attn.py:211, :227, :281), output_proj + residuals
+// (:326-336), mmcv's FFN, the next layer's in_proj, the head's reg branch and the reference-point refinement
+// (detr3d_transformer.py:199-214), position_encoder (:104-111).  The reference launches ~40 ATen kernels per layer for
+// them; round 1 of this build 14-18 (each 5-25 us, latency-bound, 3-6 % MFMA busy).  Here a workgroup owns 16 rows,
+// keeps their activations in LDS (four 16 x 516 fp32 buffers) and walks a small PROGRAM of operations over them; the
+// weights stream from L2 straight into MFMA operand registers.  A decoder layer becomes: attention core, chain A
+// (out_proj .. cross-attention Linears), fused sample-aggregate, chain B (output_proj .. FFN .. next in_proj .. reg branch).
+//
+// Arithmetic of the GEMMs: split-bf16 x3 on v_mfma_f32_16x16x32_bf16 (x = hi + lo, a w ~= a_hi w_hi + a_lo w_hi +
+// a_hi w_lo, fp32 accumulate: <= ~2^-16 relative per product, the numerics class of gd4d_value_proj_fwd).  With 16 rows
+// per workgroup only ceil(M / 16) = 57 workgroups exist, so a chain is bound by what ONE compute unit can do: the
+// fp32-input MFMA (64 FLOP/clk/SIMD) made chain B 121 us (1.3 GFLOP on 57 CUs), the bf16 pipe is 16x faster per
+// product.  The weights are pre-split into MFMA B-fragment order (gd4d_chain_weight_image, cached by the caller while
+// the weights do not change) so they stream from L2 as whole 1-KB pieces; the activations are split when read from LDS.
+// LayerNorm two-pass like ATen (mean, centred sum of squares, biased variance, eps inside the square root).
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+typedef __attribute__((ext_vector_type(4))) float rc4;
+
+constexpr int RC_M = 16;            // rows per workgroup
+constexpr int RC_WAVES = 4;
+constexpr int RC_LD = 516;          // floats per LDS row (512 + 4: the float4 row reads of 16 rows spread over the banks)
+constexpr int RC_BUFS = 4;
+constexpr int RC_DEPTH = 4;         // weight-fragment ring depth (k-steps of 32)
+constexpr int RC_TILES = 4;         // 16-column MFMA tiles per wave and pass (64 columns)
+
+// One operation; the program is an array of these in device memory (gd4d.h: gd4d_chain_op).
+typedef gd4d_chain_op ChainOp;
+
+__device__ __forceinline__ float rc_act_in(float v, int flags) { return (flags & GD4D_CHAIN_INV_SIGMOID) ? inv_sigmoid(v) : v; }
+
+#ifndef RC_DBG
+#define RC_DBG 0      // dev ablation (compile with -DRC_DBG=n): 1 = no MFMAs, 2 = no weight loads
+#endif
+typedef __attribute__((ext_vector_type(8))) __bf16 rc_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned rc_u4;
+
+__device__ __forceinline__ unsigned rc_cvt_pk_bf16(float lo_elem, float hi_elem) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
+  return r;
+}
+// 8 consecutive floats -> bf16 hi halves and bf16 lo halves (x ~= hi + lo)
+__device__ __forceinline__ void rc_split8(const float* v, rc_u4& h, rc_u4& l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hh[i] = rc_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    ll[i] = rc_cvt_pk_bf16(v[2 * i] - __uint_as_float(hh[i] << 16), v[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u));
+  }
+  h = rc_u4{hh[0], hh[1], hh[2], hh[3]};
+  l = rc_u4{ll[0], ll[1], ll[2], ll[3]};
+}
+__device__ __forceinline__ rc_bf16x8 rc_frag(rc_u4 v) { return __builtin_bit_cast(rc_bf16x8, v); }
+
+// Weight image (gd4d_chain_weight_image): [tile t of 16 output columns][k-step s of 32][hi, lo][lane][8 bf16]; lane l of
+// a fragment holds W[n = 16 t + (l & 15)][k = 32 s + 8 (l >> 4) .. + 8] - the B operand of v_mfma_f32_16x16x32_bf16.
+__global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __restrict__ w, char* __restrict__ img, int N, int K) {
+  const int ksteps = K / 32;
+  const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // fragment = t * ksteps + s
+  const int tiles = (N + 15) / 16;
+  if (frag >= tiles * ksteps) return;
+  const int t = frag / ksteps, s = frag - t * ksteps;
+  const int n = 16 * t + (lane & 15);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = n < N ? w[(size_t)n * K + 32 * s + 8 * (lane >> 4) + j] : 0.f;
+  rc_u4 h, l;
+  rc_split8(v, h, l);
+  char* dst = img + (size_t)frag * 2048 + lane * 16;
+  *reinterpret_cast<rc_u4*>(dst) = h;
+  *reinterpret_cast<rc_u4*>(dst + 1024) = l;
+}
+
+// GEMM over the workgroup's 16 rows: out[:, n] = act(sum_k in[:, k] * W[n, k] + bias[n]) (+ residuals), n < N.
+// Wave w owns columns [256 pass + 64 w, + 64) of every pass; A fragments are split from the LDS buffer, the W fragments
+// come pre-split from the image (global / L2) through a register ring RC_DEPTH k-steps deep.
+__device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const float* a_row = &bufs[op.src][i16][8 * g];
+  const int K = op.K, N = op.N;
+  const int steps = K / 32, tiles = (N + 15) / 16;
+  const char* img = reinterpret_cast<const char*>(op.p0);
+  for (int n_base = 64 * wave; n_base < N; n_base += 64 * RC_WAVES) {
+    const char* wf[RC_TILES];                                  // tiles past the end re-read the last one (never stored)
+#pragma unroll
+    for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * 2048 + lane * 16;
+    rc4 acc[RC_TILES];
+#pragma unroll
+    for (int c = 0; c < RC_TILES; ++c) acc[c] = rc4{0.f, 0.f, 0.f, 0.f};
+    // bias: unconditional loads from clamped addresses, issued before the K loop (a load under a predicate becomes its
+    // own basic block closed by s_waitcnt vmcnt(0): a dozen serialised L2 round trips in the epilogue otherwise)
+    float e_bias[RC_TILES];
+    {
+      const float* bias_p = op.p1 ? op.p1 : reinterpret_cast<const float*>(op.p0);
+      const float bias_on = op.p1 ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c) e_bias[c] = bias_p[min(n_base + 16 * c + i16, N - 1)] * bias_on;
+    }
+    rc_u4 bh[RC_DEPTH][RC_TILES], bl[RC_DEPTH][RC_TILES];
+    auto issue = [&](int slot, int j) {
+      if (RC_DBG & 2) return;
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c) {
+        bh[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048);
+        bl[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048 + 1024);
+      }
+    };
+    if (RC_DBG & 2) {
+#pragma unroll
+      for (int d = 0; d < RC_DEPTH; ++d)
+#pragma unroll
+        for (int c = 0; c < RC_TILES; ++c) { bh[d][c] = rc_u4{1u, 2u, 3u, (unsigned)lane}; bl[d][c] = bh[d][c]; }
+    }
+#pragma unroll
+    for (int d = 0; d < RC_DEPTH; ++d) issue(d, min(d, steps - 1));
+    auto consume = [&](int d, int j) {
+      const float4 t0 = *reinterpret_cast<const float4*>(a_row + 32 * j);
+      const float4 t1 = *reinterpret_cast<const float4*>(a_row + 32 * j + 4);
+      const float a[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      rc_u4 ah, al;
+      rc_split8(a, ah, al);
+      if (RC_DBG & 1) { asm volatile("" ::"v"(ah), "v"(al), "v"(bh[d][0]), "v"(bl[d][3])); return; }
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c) {
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(al), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bl[d][c]), acc[c], 0, 0, 0);
+      }
+    };
+    // host guarantees steps % RC_DEPTH == 0 (K % 128 == 0)
+    for (int j0 = 0; j0 + RC_DEPTH < steps; j0 += RC_DEPTH) {
+#pragma unroll
+      for (int d = 0; d < RC_DEPTH; ++d) {
+        consume(d, j0 + d);
+        issue(d, j0 + d + RC_DEPTH);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < RC_DEPTH; ++d) consume(d, steps - RC_DEPTH + d);
+    // C/D of 16x16x32: col = lane & 15 (+ 16 c), row = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int c = 0; c < RC_TILES; ++c) {
+      const int n = n_base + 16 * c + i16;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r, m = m0 + row;
+        float v = acc[c][r] + e_bias[c];
+        if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
+        if (op.res >= 0) v += bufs[op.res][row][n];
+        if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
+        if (op.gout && m < M) op.gout[(size_t)m * op.ldg + n] = v;
+      }
+    }
+  }
+}
+
+// LayerNorm over N columns (N % 64 == 0, N <= 512) of the 16 rows: wave w normalises rows 4 w .. 4 w + 3, 16 lanes per
+// row, a lane owns columns 64 ch + 4 l16 .. + 4 of every 64-column chunk.  gamma / beta are requested first.
+__device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
+  constexpr int MAXCH = (RC_LD - 4) / 64;
+  const int row = 4 * wave + (lane >> 4), l16 = lane & 15, N = op.N, nch = N / 64;
+  float4 gm[MAXCH], bt[MAXCH], x[MAXCH];
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    const int n = min(64 * ch, N - 64) + 4 * l16;              // chunks past N repeat the last one (unused)
+    gm[ch] = *reinterpret_cast<const float4*>(op.p0 + n);
+    bt[ch] = *reinterpret_cast<const float4*>(op.p1 + n);
+    x[ch] = *reinterpret_cast<const float4*>(&bufs[op.src][row][n]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < nch) s += (x[ch].x + x[ch].y) + (x[ch].z + x[ch].w);
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+    if (ch < nch) {
+      const float a = x[ch].x - mean, b = x[ch].y - mean, c = x[ch].z - mean, d = x[ch].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q / (float)N + op.eps);
+  const int m = m0 + row;
+  const bool relu = op.flags & GD4D_CHAIN_RELU;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    if (ch >= nch) break;
+    const int n = 64 * ch + 4 * l16;
+    float4 v;
+    v.x = (x[ch].x - mean) * rstd * gm[ch].x + bt[ch].x; v.y = (x[ch].y - mean) * rstd * gm[ch].y + bt[ch].y;
+    v.z = (x[ch].z - mean) * rstd * gm[ch].z + bt[ch].z; v.w = (x[ch].w - mean) * rstd * gm[ch].w + bt[ch].w;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (op.dst >= 0) *reinterpret_cast<float4*>(&bufs[op.dst][row][n]) = v;
+    if (op.gout && m < M) *reinterpret_cast<float4*>(op.gout + (size_t)m * op.ldg + n) = v;
+  }
+}
+
+// Rows of global tensors into / onto an LDS buffer, float4 per lane, every load issued before the first use:
+//   LOAD: dst[:, dst_col + n] = f(p0[m, n]) (+ p1[m, n]);   ADD: dst[:, n] = src[:, n] (+ res[:, n]) (+ p2[m, n])
+// wave w handles rows 4 w .. 4 w + 3; N % 4 == 0, N <= 512 (two 256-column chunks per row).
+template <bool IS_ADD>
+__device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
+  const int N = op.N;
+  const float* ga = IS_ADD ? op.p2 : op.p0;                  // first global operand (may be null for ADD)
+  const float* gb = IS_ADD ? nullptr : op.p1;                 // second global operand (LOAD only)
+  const int lda = IS_ADD ? op.ld2 : op.ld0, ldb = op.ld1;
+  float4 va[4][2], vb[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = min(m0 + 4 * wave + r, M - 1);              // rows past M repeat the last row (never stored)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = min(256 * cb + 4 * lane, N - 4);
+      va[r][cb] = ga ? *reinterpret_cast<const float4*>(ga + (size_t)m * lda + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[r][cb] = gb ? *reinterpret_cast<const float4*>(gb + (size_t)m * ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * wave + r;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = 256 * cb + 4 * lane;
+      if (n >= N) continue;
+      float4 v = va[r][cb];
+      if (!IS_ADD && (op.flags & GD4D_CHAIN_INV_SIGMOID)) { v.x = inv_sigmoid(v.x); v.y = inv_sigmoid(v.y); v.z = inv_sigmoid(v.z); v.w = inv_sigmoid(v.w); }
+      v.x += vb[r][cb].x; v.y += vb[r][cb].y; v.z += vb[r][cb].z; v.w += vb[r][cb].w;
+      if (IS_ADD) {
+        const float4 s0 = *reinterpret_cast<const float4*>(&bufs[op.src][row][n]);
+        v.x += s0.x; v.y += s0.y; v.z += s0.z; v.w += s0.w;
+        if (op.res >= 0) {
+          const float4 s1 = *reinterpret_cast<const float4*>(&bufs[op.res][row][n]);
+          v.x += s1.x; v.y += s1.y; v.z += s1.z; v.w += s1.w;
+        }
+      }
+      *reinterpret_cast<float4*>(&bufs[op.dst][row][(IS_ADD ? 0 : op.dst_col) + n]) = v;
+    }
+  }
+}
+
+// The program travels BY VALUE as the kernel argument (<= 2.9 KB of the 4 KB kernarg segment): no upload, no lifetime
+// to manage, and a hipGraph capture keeps its own copy.  It is read through the kernarg pointer with a run-time index
+// (wave-uniform scalar loads); indexing the by-value struct directly would make the compiler copy it to scratch.
+struct ChainProgram {
+  int nops, M, pad0, pad1;
+  ChainOp ops[GD4D_CHAIN_MAX_OPS];
+};
+
+__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainProgram by_value) {
+  typedef const __attribute__((address_space(4))) ChainProgram* kernarg_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const kernarg_ptr_t pp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // explicit arguments start at 0
+#else
+  const ChainProgram* pp = &by_value;
+#endif
+  const int nops = pp->nops, M = pp->M;
+  (void)by_value;
+  extern __shared__ __attribute__((aligned(16))) char rc_smem[];
+  float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * RC_M;
+  for (int oi = 0; oi < nops; ++oi) {
+    const ChainOp op = pp->ops[oi];                        // uniform: scalar loads
+    switch (op.kind) {
+      case GD4D_CHAIN_LOAD: {                              // dst[:, :N] = f(p0[m, :N]) (+ p1[m, :N])
+        if ((op.N & 3) == 0 && (op.dst_col & 3) == 0) { rc_rows<false>(op, bufs, m0, M, lane, wave); break; }
+        for (int e = tid; e < RC_M * op.N; e += 64 * RC_WAVES) {      // a handful of columns (reference points)
+          const int row = e / op.N, n = e - row * op.N;
+          const int m = min(m0 + row, M - 1);
+          float v = rc_act_in(op.p0[(size_t)m * op.ld0 + n], op.flags);
+          if (op.p1) v += op.p1[(size_t)m * op.ld1 + n];
+          bufs[op.dst][row][op.dst_col + n] = v;
+        }
+        break;
+      }
+      case GD4D_CHAIN_GEMM: rc_gemm(op, bufs, m0, M, lane, wave); break;
+      case GD4D_CHAIN_LAYERNORM: rc_layernorm(op, bufs, m0, M, lane, wave); break;
+      case GD4D_CHAIN_ADD: rc_rows<true>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
+      case GD4D_CHAIN_SMALL_LINEAR: {                      // K <= 8 inputs (position_encoder's first Linear): plain FMAs
+        for (int e = tid; e < RC_M * op.N; e += 64 * RC_WAVES) {
+          const int row = e / op.N, n = e - row * op.N;
+          float v = op.p1 ? op.p1[n] : 0.f;
+          for (int k = 0; k < op.K; ++k) v = fmaf(bufs[op.src][row][k], op.p0[(size_t)n * op.K + k], v);
+          if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
+          bufs[op.dst][row][n] = v;
+        }
+        break;
+      }
+      case GD4D_CHAIN_REFINE: {                            // detr3d_transformer.py:201-214 on src = reg-branch output
+        if (tid < RC_M && m0 + tid < M) {
+          const int m = m0 + tid;
+          const float* t = bufs[op.src][tid];
+          const float* r = op.p0 + (size_t)m * 3;
+          float* o = op.gout + (size_t)m * 3;
+          const float x = t[0] + inv_sigmoid(r[0]), y = t[1] + inv_sigmoid(r[1]), z = t[4] + inv_sigmoid(r[2]);
+          o[0] = 1.0f / (1.0f + expf(-x));
+          o[1] = 1.0f / (1.0f + expf(-y));
+          o[2] = 1.0f / (1.0f + expf(-z));
+        }
+        break;
+      }
+      default: break;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" size_t gd4d_chain_op_bytes(void) { return sizeof(gd4d_chain_op); }
+
+extern "C" size_t gd4d_chain_weight_image_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return (size_t)((N + 15) / 16) * (K / 32) * 2048;
+}
+
+extern "C" int gd4d_chain_weight_image(const float* weight, int N, int K, void* image, void* stream) {
+  using namespace gd4d;
+  if (!weight || !image || N <= 0 || K <= 0) return GD4D_EINVAL;
+  if (K % 64 != 0) return GD4D_EUNSUPPORTED;
+  if (!aligned16(image)) return GD4D_EALIGN;
+  const int frags = ((N + 15) / 16) * (K / 32);
+  hipLaunchKernelGGL(chain_weight_image_kernel, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), weight,
+                     static_cast<char*>(image), N, K);
+  return check_launch();
+}
+
+extern "C" int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream) {
+  using namespace gd4d;
+  if (!program || nops <= 0 || M <= 0) return GD4D_EINVAL;
+  if (nops > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
+  for (int i = 0; i < nops; ++i) {
+    const gd4d_chain_op& op = program[i];
+    const bool buf_ok = op.src < RC_BUFS && op.dst < RC_BUFS && op.res < RC_BUFS;
+    if (!buf_ok) return GD4D_EINVAL;
+    switch (op.kind) {
+      case GD4D_CHAIN_LOAD:
+        if (!op.p0 || op.dst < 0 || op.N <= 0 || op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4) return GD4D_EINVAL;
+        if ((op.N & 3) == 0 && (op.dst_col & 3) == 0 &&         // the float4 path
+            (!aligned16(op.p0) || (op.ld0 & 3) || (op.p1 && (!aligned16(op.p1) || (op.ld1 & 3))))) return GD4D_EALIGN;
+        break;
+      case GD4D_CHAIN_GEMM:
+        if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout) || op.p2) return GD4D_EINVAL;
+        if (op.K % (32 * RC_DEPTH) != 0 || op.K > RC_LD - 4) return GD4D_EUNSUPPORTED;
+        if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4)) return GD4D_EINVAL;
+        if (op.dst >= 0 && op.dst == op.src) return GD4D_EINVAL;          // waves would overwrite rows others still read
+        if (!aligned16(op.p0)) return GD4D_EALIGN;
+        break;
+      case GD4D_CHAIN_LAYERNORM:
+        if (!op.p0 || !op.p1 || op.src < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
+        if (op.N % 64 != 0) return GD4D_EUNSUPPORTED;
+        if (!aligned16(op.p0) || !aligned16(op.p1) || (op.gout && (!aligned16(op.gout) || (op.ldg & 3)))) return GD4D_EALIGN;
+        break;
+      case GD4D_CHAIN_ADD:
+        if (op.src < 0 || op.dst < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.N & 3)) return GD4D_EINVAL;
+        if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
+        break;
+      case GD4D_CHAIN_SMALL_LINEAR:
+        if (!op.p0 || op.src < 0 || op.dst < 0 || op.dst == op.src || op.K <= 0 || op.K > 8 || op.N <= 0 || op.N > RC_LD - 4)
+          return GD4D_EINVAL;
+        break;
+      case GD4D_CHAIN_REFINE:
+        if (op.src < 0 || !op.p0 || !op.gout) return GD4D_EINVAL;
+        break;
+      default: return GD4D_EINVAL;
+    }
+  }
+  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD;
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
+  ChainProgram prog{};
+  prog.nops = nops; prog.M = M;
+  for (int i = 0; i < nops; ++i) prog.ops[i] = program[i];
+  hipLaunchKernelGGL(row_chain_kernel, dim3((M + RC_M - 1) / RC_M), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream),
+                     prog);
+  return check_launch();
+}

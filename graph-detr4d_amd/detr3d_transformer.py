@@ -190,14 +190,17 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
     def _preproject_values(self, kwargs):
         """All layers get the same `value` pyramid and value_proj does not depend on the queries, so the decoder can
         project for every layer up front.  GD4D_PREPROJECT selects how:
-          '1' (default) - one gd4d_value_proj_multi_fwd launch on the main stream: a wave keeps its pixel tile in
+          'auto' (default) - Fn.ValuePipeline over groups of two layers ('g2,2,2' for six): measured best on MI355X at
+                       the headline size (2.93 ms per step; 'g3,3' 3.00, one launch 3.12, per layer 3.21)
+          '1'      - one gd4d_value_proj_multi_fwd launch on the main stream: a wave keeps its pixel tile in
                        registers for all the layers, the pyramid is read (and split) once - 1.98 ms for six layers against
                        6 x 0.48 ms one by one (NL value tensors alive: 4.5 GB at the headline size)
-          'stream' - Fn.ValuePipeline: layer l+1's projection runs on a second HIP stream underneath the
-                       query-side kernels of layers l / l+1 (two value tensors alive)
+          'g3,3', 'g2,2,2', ... - Fn.ValuePipeline over layer GROUPS: one multi-layer launch per group on a second HIP
+                       stream, group g+1 underneath the query-side kernels of group g
+          'stream' - = 'g1,1,...': the round-1 per-layer pipeline (two value tensors alive)
           '0'      - off: every layer projects when it runs (the reference's order)
         Returns (kwargs, pipeline or None)."""
-        mode = os.environ.get('GD4D_PREPROJECT', '1')
+        mode = os.environ.get('GD4D_PREPROJECT', 'auto')
         value = kwargs.get('value')
         if kwargs.get(Fn.VALUE_CACHE_KEY) is not None:       # the caller projected already (Detr3DTransformer.forward_shared)
             return kwargs, None
@@ -216,10 +219,11 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
             return kwargs, None
         Fn.require_inference(*value)
         kwargs = dict(kwargs)
-        if mode == '1':
+        groups = Fn.pipeline_groups(mode, len(mods))
+        if groups is None:                                   # '1' (and anything unparsable): one launch for all layers
             kwargs[Fn.VALUE_CACHE_KEY] = Fn.project_values_for_layers(mods, value)
             return kwargs, None
-        pipeline = kwargs[Fn.VALUE_PIPELINE_KEY] = Fn.ValuePipeline(mods, value)
+        pipeline = kwargs[Fn.VALUE_PIPELINE_KEY] = Fn.ValuePipeline(mods, value, groups)
         return kwargs, pipeline
 
     def _order_queries(self, kwargs, reference_points):
@@ -251,6 +255,21 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         intermediate, intermediate_reference_points = [], []
         kwargs, pipeline = self._preproject_values(kwargs)
         kwargs = self._order_queries(kwargs, reference_points)
+        from . import fused_decoder
+        if not args and kwargs.get('key') is None and kwargs.get('query_pos') is not None and 'img_metas' in kwargs \
+                and kwargs.get('key_padding_mask') is None and kwargs.get('query_key_padding_mask') is None \
+                and fused_decoder.applicable(self, query, kwargs.get('value'), reference_points, reg_branches,
+                                             kwargs.get('attn_masks')):
+            # every layer is the post-norm (self-attention, Deform3DCrossAttn, FFN) layer: 4 launches per layer
+            outs, refs = fused_decoder.run(
+                self, query.contiguous(), kwargs['query_pos'].contiguous(), kwargs['value'], reference_points, reg_branches,
+                kwargs['img_metas'], kwargs.get('attn_masks'), pipeline, kwargs.get(Fn.VALUE_CACHE_KEY),
+                kwargs.get(Fn.QUERY_ORDER_KEY), getattr(self, '_order_pc_range', None), self.return_intermediate)
+            if pipeline is not None:
+                pipeline.finish()
+            if self.return_intermediate:
+                return torch.stack(outs), torch.stack(refs)
+            return outs[0], refs[0]
         aux = None
         cross = [a for layer in self.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
         deform_only = bool(cross) and all(isinstance(a, Deform3DCrossAttn) for a in cross)

@@ -297,16 +297,27 @@ VALUE_PIPELINE_KEY = '_gd4d_value_pipeline'
 
 
 class ValuePipeline:
-    """value_proj of the decoder layers on a second HIP stream, software-pipelined against the query side.
+    """value_proj of the decoder layers on a second HIP stream, in GROUPS of consecutive layers (one multi-layer launch
+    per group), software-pipelined against the query side.
 
     A layer's value_proj depends on the pyramid only, not on the queries; the query-side kernels (self-attention, small
-    linears, LayerNorms, FFN, reg branch) are latency-bound and leave most of the GPU idle.  So layer l+1's value_proj is
-    launched on the side stream as soon as layer l's fused gather has been enqueued (it waits for that gather's event,
-    so the bandwidth-bound gather has the GPU to itself) and runs underneath the rest of layer l and the start of layer
-    l+1; gather l+1 waits for its value tensor's event.  Two value tensors are alive at a time."""
+    linears, LayerNorms, FFN, reg branch) are latency-bound and leave most of the GPU idle.  Group g+1 is launched on the
+    side stream as soon as the FIRST gather of group g has been enqueued (it waits for that gather's event) and runs
+    underneath the query side of group g's layers; the first gather of group g+1 waits for its event.  Larger groups
+    amortise the pyramid's read + split over more layers (a six-layer launch costs 1.98 ms, six single ones 2.9 ms) but
+    expose more of the query-side chain: groups=(1,)*6 is the round-1 per-layer pipeline, groups=(6,) one launch."""
 
-    def __init__(self, modules, value):
+    def __init__(self, modules, value, groups=None, first_cus=0):
         self.modules, self.value = list(modules), value
+        n = len(self.modules)
+        groups = tuple(groups) if groups else (1,) * n
+        if sum(groups) != n or any(g < 1 for g in groups):
+            raise ValueError(f'layer groups {groups} do not partition {n} layers')
+        self.bounds, lo = [], 0
+        for g in groups:
+            self.bounds.append((lo, lo + g))
+            lo += g
+        self.group_of = {id(m): gi for gi, (a, b) in enumerate(self.bounds) for m in self.modules[a:b]}
         dev = value[0].device
         self.main = torch.cuda.current_stream(dev)
         self.side = _SIDE_STREAMS.get(dev.index)
@@ -314,28 +325,38 @@ class ValuePipeline:
             self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
         self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
         self.ready = {}
-        self._issue(0)
+        self.issued = 0
+        self._issue(first_cus)                       # nothing runs next to the first group: the whole device
 
-    # CUs the persistent value_proj kernel may take while the query side runs next to it: 3/4 of the device (192 of the
-    # MI355X's 256; measured there: 160: 323, 176: 340, 192: 347, 208: 337, 224: 345, 240: 304 samples/s; no overlap:
-    # 302).  GD4D_PIPELINE_CUS overrides.
-    CUS = 192
-
-    def _cu_share(self):
+    # CUs the persistent value_proj kernel may take while the query side runs next to it (its workgroups own the whole
+    # register file of their CUs, so the query-side kernels only ever run on the CUs left free): 7/8 of the device for
+    # multi-layer groups, 3/4 for single layers (round 1, per-layer pipeline on MI355X: 160: 323, 176: 340, 192: 347,
+    # 208: 337, 224: 345, 240: 304 samples/s; no overlap: 302).  GD4D_PIPELINE_CUS overrides.
+    def _cu_share(self, group_size):
         env = os.environ.get('GD4D_PIPELINE_CUS')
         if env:
             return int(env)
         cus = torch.cuda.get_device_properties(self.value[0].device).multi_processor_count
-        return self.CUS if cus == 256 else max(8, (cus * 3 // 4) // 8 * 8)
+        share = cus * 3 // 4 if group_size == 1 else cus * 7 // 8
+        return max(8, share // 8 * 8)
 
-    def _issue(self, i):
-        m = self.modules[i]
+    def _issue(self, max_cus):
+        a, b = self.bounds[self.issued]
+        mods = self.modules[a:b]
         with torch.cuda.stream(self.side):
-            val, shapes = value_projection(self.value, m.value_proj.weight, m.value_proj.bias, m.num_heads,
-                                           m.value_dtype, max_cus=self._cu_share())
+            hh, dt = mods[0].num_heads, mods[0].value_dtype
+            hm = use_head_major(dt)
+            shapes = [tuple(v.shape[-2:]) for v in self.value]
+            bn, c = self.value[0].shape[0] * self.value[0].shape[1], self.value[0].shape[2]
+            outs = ops.value_proj_multi_fwd([v.contiguous() for v in self.value],
+                                            [m.value_proj.weight.contiguous() for m in mods],
+                                            [None if m.value_proj.bias is None else m.value_proj.bias.contiguous() for m in mods],
+                                            dt, num_heads=hh, head_major=hm, bf16_math=dt == torch.bfloat16, max_cus=max_cus)
             ev = torch.cuda.Event()
             ev.record(self.side)
-        self.ready[id(m)] = (val, shapes, ev)
+        for m, o in zip(mods, outs):
+            self.ready[id(m)] = ((o if hm else o.view(bn, -1, hh, c // hh)), shapes, ev)
+        self.issued += 1
 
     def take(self, module, value):
         """(value tensor, shapes) of `module` once the main stream has been made to wait for it; None if not ours."""
@@ -346,20 +367,36 @@ class ValuePipeline:
         return entry[0], entry[1]
 
     def gather_enqueued(self, module):
-        """Called right after `module`'s fused gather was enqueued on the main stream: release its value tensor and
-        start the next layer's projection behind it."""
+        """Called right after `module`'s fused gather was enqueued on the main stream: release its value tensor; behind
+        the first gather of the newest group, start the next group's projection."""
         if self.ready.pop(id(module), None) is None:
             return
-        i = self.modules.index(module)
-        if i + 1 < len(self.modules):
+        if self.group_of[id(module)] == self.issued - 1 and self.issued < len(self.bounds):
             ev = torch.cuda.Event()
             ev.record(self.main)
             self.side.wait_event(ev)
-            self._issue(i + 1)
+            a, b = self.bounds[self.issued]
+            self._issue(self._cu_share(b - a))
 
     def finish(self):
         self.main.wait_stream(self.side)             # join (also keeps a graph capture well-formed)
         self.ready.clear()
+
+
+def pipeline_groups(spec, n):
+    """GD4D_PREPROJECT: 'auto' -> groups of two layers; 'stream' -> n single layers; 'g3,3' / 'g2,2,2' / ... -> those group sizes (they must add up to
+    the number of layers, else the spec is ignored: None)."""
+    if spec == 'stream':
+        return (1,) * n
+    if spec == 'auto':
+        return (2,) * (n // 2) + ((1,) if n % 2 else ())
+    if spec.startswith('g'):
+        try:
+            g = tuple(int(x) for x in spec[1:].split(','))
+        except ValueError:
+            return None
+        return g if sum(g) == n and all(x >= 1 for x in g) else None
+    return None
 
 
 QUERY_ORDER_KEY = '_gd4d_query_order'

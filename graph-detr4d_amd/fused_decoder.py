@@ -1,0 +1,234 @@
+"""The decoder loop with the row-local work of every layer folded into two gd4d_row_chain_fwd launches.
+
+Reference: Detr3DTransformerDecoder.forward (projects/mmdet3d_plugin/models/utils/detr3d_transformer.py:166-225) over
+post-norm DetrTransformerDecoderLayers (config ...ceph.py:71-89: self_attn, norm, cross_attn, norm, ffn, norm) with
+Deform3DCrossAttn (utils/deform3d_cross_attn.py:196-339).  Per layer the generic module path launches 14-18 kernels;
+here a layer is
+
+    attention core  ->  chain A  ->  fused sample-aggregate  ->  chain B          (+ position_encoder chain, query order:
+                                                                                     off the critical path, aux stream)
+    chain A: out_proj + residual, norms[0], the three Linears of Deform3DCrossAttn on query + query_pos
+    chain B: output_proj + both residuals, norms[1], FFN, norms[2], the NEXT layer's in_proj, the reg branch and the
+             reference-point refinement (:199-214)
+
+Same arithmetic as the module path (fp32 MFMA products, two-pass LayerNorm), other summation order inside the LayerNorm
+reductions only.  Used by Detr3DTransformerDecoder.forward when every layer has this shape, batch 1, fp32, no autograd
+(GD4D_FUSED_DECODER=0 disables it); anything else takes the generic path.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .deform3d_cross_attn import Deform3DCrossAttn
+from .transformer_layers import FFN, MultiheadAttention
+
+ORDER = ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
+
+
+def _plain_reg_branch(branch, c):
+    """[Linear, ReLU]* Linear with c-wide hidden layers, as the heads build them (dense_heads/detr3d_head.py:58-75)."""
+    if not isinstance(branch, nn.Sequential) or len(branch) % 2 == 0:
+        return None
+    lins = []
+    for i, m in enumerate(branch):
+        if i % 2 == 0:
+            if not isinstance(m, nn.Linear) or m.in_features != c or (i + 1 < len(branch) and m.out_features != c):
+                return None
+            lins.append(m)
+        elif not isinstance(m, nn.ReLU):
+            return None
+    return lins if lins[-1].out_features >= 5 and len(lins) <= 4 else None
+
+
+def applicable(decoder, query, value, reference_points, reg_branches, attn_masks):
+    if os.environ.get('GD4D_FUSED_DECODER', '1') == '0' or torch.is_grad_enabled() and (
+            query.requires_grad or any(p.requires_grad for p in decoder.parameters())):
+        return False
+    if not query.is_cuda or query.dtype != torch.float32 or query.dim() != 3 or query.shape[1] != 1:
+        return False
+    if reference_points is None or reference_points.shape[-1] != 3 or not isinstance(value, (list, tuple)):
+        return False
+    c = query.shape[-1]
+    if c % 64 or c > 512:
+        return False
+    for layer in decoder.layers:
+        if tuple(layer.operation_order) != ORDER or layer.training or len(layer.attentions) != 2 or len(layer.ffns) != 1:
+            return False
+        sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+        if not isinstance(sa, MultiheadAttention) or sa.batch_first or sa.embed_dims != c:
+            return False
+        if type(ca) is not Deform3DCrossAttn or ca.embed_dims != c or len(value) != ca.num_levels:
+            return False
+        if not isinstance(ffn, FFN) or len(ffn.layers) != 3 or not ffn.add_identity or ffn.feedforward_channels % 64 \
+                or ffn.feedforward_channels > 512:
+            return False
+    if attn_masks is not None and not (isinstance(attn_masks, (list, tuple)) or torch.is_tensor(attn_masks)):
+        return False
+    if reg_branches is not None and any(_plain_reg_branch(reg_branches[i], c) is None for i in range(len(decoder.layers))):
+        return False
+    return True
+
+
+def _in_proj_ops(sa, x_pos_buf, x_buf, qkv):
+    """Two GEMMs of the packed in-projection: q, k from (x + pos), v from x (mmcv MultiheadAttention semantics)."""
+    c = sa.embed_dims
+    w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
+    return [ops.chain_gemm(x_pos_buf, w[:2 * c], b[:2 * c], out=qkv[..., :2 * c]),
+            ops.chain_gemm(x_buf, w[2 * c:], b[2 * c:], out=qkv[..., 2 * c:])]
+
+
+def _position_features(ca, reference_points, q):
+    """position_encoder(inverse_sigmoid(ref [, depth])) (deform3d_cross_attn.py:104-111, 331-334) as one chain."""
+    ref3d = reference_points
+    if ca.depth_encode:
+        depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
+        ref3d = torch.cat([ref3d, depth], dim=-1).contiguous()
+    seq = ca.position_encoder
+    out = torch.empty(1, q, ca.embed_dims, device=ref3d.device, dtype=torch.float32)
+    prog = [ops.chain_load(0, ref3d.view(q, -1), inv_sigmoid=True),
+            ops.chain_small_linear(0, seq[0].weight, seq[0].bias, 1),
+            ops.chain_layernorm(1, seq[1], dst=0, relu=True),
+            ops.chain_gemm(0, seq[3].weight, seq[3].bias, dst=1),
+            ops.chain_layernorm(1, seq[4], relu=True, out=out.view(q, -1))]
+    ops.row_chain_fwd(prog, q)
+    return out, ref3d
+
+
+def run(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, pipeline, value_cache,
+        order, order_pc_range, return_intermediate):
+    """query / query_pos (Q, 1, C) dense; reference_points (1, Q, 3).  Returns (outputs, references) per layer."""
+    q, _, c = query.shape
+    dev = query.device
+    layers = list(decoder.layers)
+    nl = len(layers)
+    main = torch.cuda.current_stream(dev)
+    aux = Fn.aux_stream(dev)
+    if attn_masks is None:
+        attn_masks = [None, None]
+    elif torch.is_tensor(attn_masks):
+        attn_masks = [attn_masks, attn_masks]
+    lidar2img = Fn.lidar2img_device(img_metas, query)
+    img_h, img_w = Fn.img_hw(img_metas)
+    x = query.view(q, c)
+    pos = query_pos.view(q, c)
+    keep = []                                            # tensors the enqueued programs point to
+
+    # layer 0's in-projection
+    qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1)), q)
+
+    outputs, references = [], []
+    ref = reference_points.contiguous()
+    ref_event = None                                     # `ref` / `order` were produced on the aux stream
+    for lid, layer in enumerate(layers):
+        sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+        hh, npt, nlv, ncam = ca.num_heads, ca.num_points, ca.num_levels, ca.num_cams
+        # position_encoder depends on the reference points only: aux stream, joined before chain B
+        ev_pos = None
+        if aux is not None:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(fork)
+                pos_feat, ref_keep = _position_features(ca, ref, q)
+                ev_pos = torch.cuda.Event()
+                ev_pos.record(aux)
+        else:
+            if ref_event is not None:
+                main.wait_event(ref_event)
+            pos_feat, ref_keep = _position_features(ca, ref, q)
+        keep += [pos_feat, ref_keep]
+
+        # attention core
+        qh, kh, vh = qkv.split(c, dim=-1)
+        o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
+
+        # chain A
+        x1 = torch.empty(q, c, device=dev, dtype=torch.float32)
+        cam = torch.empty(1, q, ncam, device=dev, dtype=torch.float32)
+        off = torch.empty(1, q, hh * npt * 3, device=dev, dtype=torch.float32)
+        att = torch.empty(1, q, hh * nlv * npt, device=dev, dtype=torch.float32)
+        prog = [ops.chain_load(0, o.view(q, c)),
+                ops.chain_load(3, x),                                              # the residual of the self-attention
+                ops.chain_gemm(0, sa.attn.out_proj.weight, sa.attn.out_proj.bias, dst=1, res=3),
+                ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1),
+                ops.chain_add(0, 2, c, add=pos),
+                ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
+                ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
+                ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
+        ops.row_chain_fwd(prog, q)
+
+        # projected values of this layer
+        taken = pipeline.take(ca, value) if pipeline is not None else None
+        cached = (value_cache or {}).get(id(ca))
+        if taken is not None:
+            val, shapes = taken
+        elif cached is not None and cached[2] is value:
+            val, shapes = cached[0], cached[1]
+        else:
+            val, shapes = Fn.value_projection(value, ca.value_proj.weight, ca.value_proj.bias, hh, ca.value_dtype)
+        if ref_event is not None:
+            main.wait_event(ref_event)
+        if order is None or order.numel() != q:
+            order = Fn.query_order(ref, ca.pc_range)
+        agg = Fn.sample_aggregate(val, shapes, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam,
+                                  lidar2img, ca.pc_range, img_h, img_w, order=order)
+        if taken is not None:
+            del val, taken
+            pipeline.gather_enqueued(ca)
+
+        # chain B
+        if ev_pos is not None:
+            main.wait_event(ev_pos)
+        x3 = torch.empty(q, 1, c, device=dev, dtype=torch.float32)
+        last = lid + 1 == nl
+        prog = [ops.chain_load(0, agg.view(q, c)),
+                ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336
+                ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
+                ops.chain_layernorm(1, layer.norms[1], dst=2),                    # x2
+                ops.chain_gemm(2, ffn.layers[0][0].weight, ffn.layers[0][0].bias, dst=0, relu=True),
+                ops.chain_gemm(0, ffn.layers[1].weight, ffn.layers[1].bias, dst=1, res=2),
+                ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c))]  # x3 = the layer's output
+        if not last:
+            qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
+            prog += [ops.chain_add(0, 3, c, add=pos)] + _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1))
+        new_ref = None
+        if reg_branches is not None:
+            lins = _plain_reg_branch(reg_branches[lid], c)
+            src, tmp = 3, (1, 2)
+            for i, lin in enumerate(lins):
+                prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                src = tmp[i % 2]
+            new_ref = torch.empty_like(ref)
+            prog.append(ops.chain_refine(src, ref, new_ref))
+        ops.row_chain_fwd(prog, q)
+        keep += [o, x1, cam, off, att, agg, x]
+
+        x = x3.view(q, c)
+        if new_ref is not None:
+            ref = new_ref
+            ref_event = None
+            if not last and order is not None:
+                # the next layer's locality order: one tiny launch next to that layer's self-attention
+                if aux is not None:
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    with torch.cuda.stream(aux):
+                        aux.wait_event(done)
+                        order = Fn.query_order(ref, order_pc_range)
+                        ref_event = torch.cuda.Event()
+                        ref_event.record(aux)
+                else:
+                    order = Fn.query_order(ref, order_pc_range)
+        if return_intermediate:
+            outputs.append(x3)
+            references.append(ref)
+    if aux is not None:
+        main.wait_stream(aux)
+    if not return_intermediate:
+        outputs, references = [x3], [ref]
+    del keep
+    return outputs, references

@@ -641,6 +641,111 @@ def linear_sum_assignment_batch(cost, problems, num_threads=8):
     return [out[out_off[i]:out_off[i + 1]] for i in range(n)]
 
 
+class ChainOp(ctypes.Structure):
+    """gd4d_chain_op (include/gd4d.h)."""
+    _fields_ = [('kind', ctypes.c_int32), ('src', ctypes.c_int32), ('dst', ctypes.c_int32), ('res', ctypes.c_int32),
+                ('K', ctypes.c_int32), ('N', ctypes.c_int32), ('flags', ctypes.c_int32), ('dst_col', ctypes.c_int32),
+                ('ld0', ctypes.c_int32), ('ld1', ctypes.c_int32), ('ld2', ctypes.c_int32), ('ldg', ctypes.c_int32),
+                ('eps', ctypes.c_float), ('reserved', ctypes.c_int32),
+                ('p0', ctypes.c_void_p), ('p1', ctypes.c_void_p), ('p2', ctypes.c_void_p), ('gout', ctypes.c_void_p)]
+
+
+CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR = 1, 2, 3, 4, 5, 6
+CHAIN_RELU, CHAIN_INV_SIGMOID = 1, 2
+
+
+def _rows(t, name):
+    """(data pointer, row stride in elements) of a fp32 GPU tensor whose last dimension is dense and whose leading
+    dimensions collapse to rows of one stride (a contiguous tensor or a last-dim slice of one)."""
+    if t is None:
+        return None, 0
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.Gd4dError(f'{name} must be a float32 GPU tensor')
+    if t.dim() == 1:
+        return t.data_ptr(), 0
+    if t.stride(-1) != 1:
+        raise ValueError(f'{name}: the last dimension must be dense')
+    ld = t.stride(-2)
+    for d in range(t.dim() - 2):
+        if t.shape[d] != 1 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+            raise ValueError(f'{name}: rows must have one stride')
+    return t.data_ptr(), ld
+
+
+def chain_load(dst, x, x2=None, dst_col=0, inv_sigmoid=False):
+    p0, ld0 = _rows(x, 'x')
+    p1, ld1 = _rows(x2, 'x2')
+    return ChainOp(kind=CHAIN_LOAD, src=-1, dst=dst, res=-1, N=x.shape[-1], dst_col=dst_col, ld0=ld0, ld1=ld1,
+                   flags=CHAIN_INV_SIGMOID if inv_sigmoid else 0, p0=p0, p1=p1)
+
+
+_CHAIN_IMAGES = {}
+
+
+def chain_weight_image(weight):
+    """The bf16 hi / lo MFMA-fragment image of a (N, K) fp32 weight (gd4d_chain_weight_image), cached while the weight
+    tensor (address, shape, version counter) does not change - one small launch after a load_state_dict or an optimizer
+    step, none in steady-state inference."""
+    import weakref
+    if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 2 or weight.stride(1) != 1 \
+            or weight.stride(0) != weight.shape[1]:
+        raise ValueError('chain weights must be dense (N, K) float32 GPU tensors')
+    base = weight._base if weight._base is not None else weight
+    key = (weight.data_ptr(), tuple(weight.shape))
+    hit = _CHAIN_IMAGES.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == base._version:
+        return hit[2]
+    lib = _lib.load()
+    n, k = weight.shape
+    nbytes = lib.gd4d_chain_weight_image_bytes(n, k)
+    if nbytes == 0:
+        raise _lib.Gd4dError(f'chain GEMM: K = {k} must be a multiple of 64')
+    img = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    with torch.cuda.device(weight.device):
+        code = lib.gd4d_chain_weight_image(ctypes.c_void_p(weight.data_ptr()), n, k, ctypes.c_void_p(img.data_ptr()), _stream())
+    _lib.check(code, 'gd4d_chain_weight_image')
+    _CHAIN_IMAGES[key] = (weakref.ref(base), base._version, img)
+    return img
+
+
+def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None):
+    """act(buf[src] W^T + b) (+ buf[res]) -> buf[dst] and / or out.  weight (N, K) contiguous rows."""
+    img = chain_weight_image(weight)
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
+                   flags=CHAIN_RELU if relu else 0, ldg=ldg, p0=img.data_ptr(),
+                   p1=None if bias is None else bias.data_ptr(), gout=g)
+
+
+def chain_small_linear(src, weight, bias, dst, relu=False):
+    return ChainOp(kind=CHAIN_SMALL_LINEAR, src=src, dst=dst, res=-1, K=weight.shape[1], N=weight.shape[0],
+                   flags=CHAIN_RELU if relu else 0, p0=weight.data_ptr(), p1=None if bias is None else bias.data_ptr())
+
+
+def chain_layernorm(src, norm, dst=-1, relu=False, out=None):
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_LAYERNORM, src=src, dst=dst, res=-1, N=norm.weight.shape[0], eps=float(norm.eps),
+                   flags=CHAIN_RELU if relu else 0, ldg=ldg, p0=norm.weight.data_ptr(), p1=norm.bias.data_ptr(), gout=g)
+
+
+def chain_add(dst, src, n, res=-1, add=None):
+    p2, ld2 = _rows(add, 'add')
+    return ChainOp(kind=CHAIN_ADD, src=src, dst=dst, res=res, N=n, ld2=ld2, p2=p2)
+
+
+def chain_refine(src, ref, out):
+    return ChainOp(kind=CHAIN_REFINE, src=src, dst=-1, res=-1, p0=ref.data_ptr(), gout=out.data_ptr())
+
+
+def row_chain_fwd(program, m):
+    """gd4d_row_chain_fwd: run the list of ChainOp over `m` rows in one launch (the tensors the operations point to must
+    stay alive until the stream has run it - the callers keep them in locals / return them)."""
+    lib = _lib.load()
+    arr = (ChainOp * len(program))(*program)
+    code = lib.gd4d_row_chain_fwd(arr, len(program), int(m), _stream())
+    _lib.check(code, 'gd4d_row_chain_fwd')
+
+
 def _first_tensor(args):
     for a in args:
         if torch.is_tensor(a):
@@ -664,7 +769,8 @@ def _on_tensor_device(fn):
     return wrapped
 
 
-_HOST_ONLY = {'linear_sum_assignment_batch'}
+_HOST_ONLY = {'linear_sum_assignment_batch', 'chain_load', 'chain_gemm', 'chain_small_linear', 'chain_layernorm',
+              'chain_add', 'chain_refine', 'row_chain_fwd', 'chain_weight_image'}
 for _name, _fn in list(globals().items()):
     if inspect.isfunction(_fn) and _fn.__module__ == __name__ and not _name.startswith('_') and _name not in _HOST_ONLY:
         globals()[_name] = _on_tensor_device(_fn)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 15
+#define GD4D_ABI_VERSION 17
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -280,6 +280,47 @@ int gd4d_layernorm_fwd(const float* x, const float* res, const float* gamma, con
 int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const float* bias, const float* r1,
                        const float* r2, const float* gamma, const float* beta, float* y, int M, int K, int N,
                        int n_split, int flags, float eps, int ldx, int ldy, int ldr1, int ldr2, void* stream);
+
+/* gd4d_row_chain_fwd - a chain of ROW-LOCAL operations over blocks of 16 rows in ONE launch: everything a decoder layer
+ * does between two points that need all queries at once (attention core, fused sample-aggregate) - out_proj + residual +
+ * LayerNorm, the Linears of Deform3DCrossAttn on query + query_pos (deform3d_cross_attn.py:211, :227, :281),
+ * output_proj + residuals (:326-336), mmcv FFN, the next layer's in_proj, the head's reg branch and reference-point
+ * refinement (detr3d_transformer.py:199-214), position_encoder (:104-111).  A workgroup keeps its 16 rows in LDS buffers
+ * 0 .. 3 (16 x 512 fp32 each) and executes `program` (host array of nops <= GD4D_CHAIN_MAX_OPS operations, copied into
+ * the kernel argument) in order:
+ *   LOAD       buf[dst][:, dst_col .. +N) = f(p0[m, :N]) (+ p1[m, :N]); row strides ld0, ld1; f = inverse_sigmoid with
+ *              GD4D_CHAIN_INV_SIGMOID
+ *   GEMM       v = act(buf[src][:, :K] . W^T + bias), p0 = the IMAGE of W (N, K) made by gd4d_chain_weight_image (bf16 hi /
+ *              lo halves in MFMA fragment order; gd4d_chain_weight_image_bytes(N, K) bytes, 16-byte aligned; rebuild it when
+ *              W changes), bias = p1 or NULL, act = ReLU with GD4D_CHAIN_RELU; then v += buf[res] (res >= 0) and v += p2[m, n] (row stride ld2) if given; written to
+ *              buf[dst][:, dst_col + n] (dst >= 0, dst != src) and / or gout[m, n] (row stride ldg).  K % 64 == 0, K <= 512.
+ *   LAYERNORM  over N columns (N % 64 == 0) of buf[src]: gamma = p0, beta = p1, eps; ReLU with GD4D_CHAIN_RELU; to buf[dst] and / or gout
+ *   ADD        buf[dst] = buf[src] + buf[res] (res >= 0) + p2[m, :N]
+ *   SMALL_LINEAR  buf[dst][:, :N] = act(buf[src][:, :K] . W^T + bias) for K <= 8 (position_encoder's first Linear)
+ *   REFINE     reference-point refinement: src = reg-branch output (>= 5 columns), p0 = reference points (M, 3) in [0, 1],
+ *              gout = refined points (M, 3)
+ * GEMMs: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (fp32-class, the arithmetic of gd4d_value_proj_fwd);
+ * everything else fp32.  M = number of rows. */
+enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_CHAIN_ADD = 4, GD4D_CHAIN_REFINE = 5,
+       GD4D_CHAIN_SMALL_LINEAR = 6 };
+#define GD4D_CHAIN_RELU 1
+#define GD4D_CHAIN_INV_SIGMOID 2
+#define GD4D_CHAIN_MAX_OPS 32
+typedef struct gd4d_chain_op {
+  int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
+  int32_t K, N, flags, dst_col;
+  int32_t ld0, ld1, ld2, ldg;       /* row strides of p0 / p1 (LOAD), p2, gout */
+  float eps;
+  int32_t reserved;
+  const float* p0;
+  const float* p1;
+  const float* p2;
+  float* gout;
+} gd4d_chain_op;
+size_t gd4d_chain_op_bytes(void);
+size_t gd4d_chain_weight_image_bytes(int N, int K);
+int gd4d_chain_weight_image(const float* weight, int N, int K, void* image, void* stream);
+int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream);
 
 /* gd4d_small_linear_layernorm_fwd - y = [ReLU] LN( f(in) W^T + b ) for a Linear with at most 4 inputs: the first stage of
  * position_encoder, Linear(3 or 4 -> 256), LayerNorm, ReLU on inverse_sigmoid(reference points)

@@ -104,8 +104,10 @@ def test_transformer_decoder(name):
     torch.testing.assert_close(states.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
     # scheduling modes change when and where kernels run, never what they compute: value_proj pipelined on a side
     # stream (default) / one multi-layer launch / per layer in place, locality order of the queries on / off
-    for env in (dict(GD4D_PREPROJECT='0'), dict(GD4D_PREPROJECT='1'), dict(GD4D_QUERY_ORDER='0'),
-                dict(GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0'), dict(GD4D_PIPELINE_CUS='64'), dict(GD4D_AUX_STREAM='0'),
+    for env in (dict(GD4D_PREPROJECT='0'), dict(GD4D_PREPROJECT='1'), dict(GD4D_PREPROJECT='stream'), dict(GD4D_PREPROJECT='g1,1'),
+                dict(GD4D_PREPROJECT='g2'), dict(GD4D_QUERY_ORDER='0'),
+                dict(GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0'), dict(GD4D_PREPROJECT='stream', GD4D_PIPELINE_CUS='64'),
+                dict(GD4D_AUX_STREAM='0'),
                 dict(GD4D_AUX_STREAM='0', GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0')):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
