@@ -571,32 +571,48 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                     traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot_bytes / launches,
                     us_per_launch=tot_ms / launches * 1e3, launches_per_step=launches)
     kernels = {'cross_attn_fwd_per_layer': per_layer}
-    # The other large kernel of a step, reported beside the headline roofline: value_proj (one launch per layer, the
-    # layers' weights in turn), HIP events on the launch stream.  Algorithmic bytes: the pyramid read once + the value
-    # tensor written once; flops: 2 * rows * 256 * 256 (x3 on the matrix pipe: split-bf16).
+    # The other large kernel of a step, reported beside the headline roofline: value_proj, launched as the decoder launches
+    # it (one multi-layer launch per group of layers, all CUs), HIP events on the launch stream.  Algorithmic bytes of a
+    # launch: the pyramid read once + one value tensor written per layer; flops: 2 * rows * 256 * 256 per layer (x3 on the
+    # matrix pipe: split-bf16).
     try:
         from graph_detr4d_amd import functional as Fn
         mods = [m for layer in tr.decoder.layers for m in layer.attentions if hasattr(m, 'value_proj')]
         vals = [f.contiguous() for f in feats]
-        run = lambda m: Fn.value_projection(vals, m.value_proj.weight, m.value_proj.bias, m.num_heads, m.value_dtype)  # noqa: E731
+        groups = Fn.pipeline_groups(os.environ.get('GD4D_PREPROJECT', 'auto'), len(mods)) or (len(mods),)
+        hm = Fn.use_head_major(mods[0].value_dtype)
+
+        def run(ms):
+            return ops.value_proj_multi_fwd(vals, [m.value_proj.weight for m in ms], [m.value_proj.bias for m in ms],
+                                            ms[0].value_dtype, num_heads=ms[0].num_heads, head_major=hm,
+                                            bf16_math=ms[0].value_dtype == torch.bfloat16)
+        bounds, lo = [], 0
+        for g_ in groups:
+            bounds.append((lo, lo + g_))
+            lo += g_
         with torch.no_grad():
-            out0, _ = run(mods[0])
+            outs0 = run(mods[bounds[0][0]:bounds[0][1]])
             torch.cuda.synchronize()
             e0.record()
             for _ in range(3):
-                for m in mods:
-                    run(m)
+                for a_, b_ in bounds:
+                    run(mods[a_:b_])
             e1.record()
             torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / (3 * len(mods)) * 1e3
+        us_all = e0.elapsed_time(e1) / 3 * 1e3                 # all layers of the decoder
         rd = sum(f.numel() * f.element_size() for f in vals)
-        wr = out0.numel() * out0.element_size()
+        wr = outs0[0].numel() * outs0[0].element_size()
         rows = rd // (256 * 4)
         fl = 2.0 * rows * 256 * 256
-        kernels['value_proj_fwd'] = dict(us_per_launch_back_to_back=us, alg_bytes_per_launch=rd + wr,
-                                         hbm_gbs=(rd + wr) / us / 1e3, hbm_frac=(rd + wr) / us / 1e3 / HBM_PEAK_GBS,
-                                         gflop_per_launch=fl / 1e9, mfma_tflops_x3=3 * fl / us / 1e6,
-                                         mfma_frac_of_2500=3 * fl / us / 1e6 / 2500.0, launches_per_step=len(mods))
+        alg = len(bounds) * rd + len(mods) * wr
+        kernels['value_proj_fwd'] = dict(layer_groups=list(groups), us_all_layers=us_all, us_per_layer=us_all / len(mods),
+                                         alg_bytes_all_layers=alg, hbm_gbs=alg / us_all / 1e3,
+                                         hbm_frac=alg / us_all / 1e3 / HBM_PEAK_GBS,
+                                         gflop_per_layer=fl / 1e9, mfma_tflops_x3=3 * fl * len(mods) / us_all / 1e6,
+                                         mfma_frac_of_2500=3 * fl * len(mods) / us_all / 1e6 / 2500.0,
+                                         launches_per_step=len(bounds),
+                                         note='bounded by the sustained (power-limited) matrix rate and the HBM write rate '
+                                              'together: profiles/r02_value_proj.md')
     except Exception as e:                                    # secondary figure: report, never fail the bench line
         kernels['value_proj_fwd'] = {'error': f'{type(e).__name__}: {e}'}
     return roofline, kernels

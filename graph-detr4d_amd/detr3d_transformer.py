@@ -191,7 +191,7 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         """All layers get the same `value` pyramid and value_proj does not depend on the queries, so the decoder can
         project for every layer up front.  GD4D_PREPROJECT selects how:
           'auto' (default) - Fn.ValuePipeline over groups of two layers ('g2,2,2' for six): measured best on MI355X at
-                       the headline size (2.93 ms per step; 'g3,3' 3.00, one launch 3.12, per layer 3.21)
+                       the headline size (2.68 ms per step with the fused decoder loop; 'g3,3' 2.66-2.73, one launch 2.98)
           '1'      - one gd4d_value_proj_multi_fwd launch on the main stream: a wave keeps its pixel tile in
                        registers for all the layers, the pyramid is read (and split) once - 1.98 ms for six layers against
                        6 x 0.48 ms one by one (NL value tensors alive: 4.5 GB at the headline size)

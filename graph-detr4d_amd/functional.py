@@ -329,16 +329,15 @@ class ValuePipeline:
         self._issue(first_cus)                       # nothing runs next to the first group: the whole device
 
     # CUs the persistent value_proj kernel may take while the query side runs next to it (its workgroups own the whole
-    # register file of their CUs, so the query-side kernels only ever run on the CUs left free): 7/8 of the device for
-    # multi-layer groups, 3/4 for single layers (round 1, per-layer pipeline on MI355X: 160: 323, 176: 340, 192: 347,
-    # 208: 337, 224: 345, 240: 304 samples/s; no overlap: 302).  GD4D_PIPELINE_CUS overrides.
+    # register file of their CUs, so the query-side kernels only ever run on the CUs left free; the row-chain kernels
+    # are 57 workgroups at 900 queries and want one round): 3/4 of the device.  MI355X, groups of two layers, fused
+    # decoder: 144: 345, 160: 352, 176: 365, 192: 373, 224: 356 samples/s.  GD4D_PIPELINE_CUS overrides.
     def _cu_share(self, group_size):
         env = os.environ.get('GD4D_PIPELINE_CUS')
         if env:
             return int(env)
         cus = torch.cuda.get_device_properties(self.value[0].device).multi_processor_count
-        share = cus * 3 // 4 if group_size == 1 else cus * 7 // 8
-        return max(8, share // 8 * 8)
+        return max(8, (cus * 3 // 4) // 8 * 8)
 
     def _issue(self, max_cus):
         a, b = self.bounds[self.issued]
