@@ -571,6 +571,46 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                     traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot_bytes / launches,
                     us_per_launch=tot_ms / launches * 1e3, launches_per_step=launches)
     kernels = {'cross_attn_fwd_per_layer': per_layer}
+    # the "all-visible" stress case next to the real-rig figure - every camera is camera 0 and every
+    # reference point sits in front of it, so all N x Q x Hh x L x P samples are taken (the algorithmic bytes are capped at
+    # the size of the value tensor).  Same kernel, same value tensors (rotated: cache-cold), same clock.
+    try:
+        c0 = captured[0]
+        b_, q_ = c0['ref'].shape[0], c0['ref'].shape[1]
+        n_ = c0['l2i'].shape[1]
+        g = torch.Generator().manual_seed(4242)
+        ref_av = torch.rand(b_, q_, 3, generator=g)
+        ref_av[..., 0] = 0.6 + 0.3 * ref_av[..., 0]
+        ref_av[..., 1] = 0.45 + 0.1 * ref_av[..., 1]
+        ref_av[..., 2] = 0.6 + 0.1 * ref_av[..., 2]
+        ref_av = ref_av.to(c0['ref'].device)
+        l2i_av = c0['l2i'][:, :1].expand(-1, n_, -1, -1).contiguous()
+        order_av = ops.query_order_fwd(ref_av, c0['pc_range'])
+        run_av = lambda c, **kw: ops.cross_attn_fwd(c['value'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'],   # noqa: E731
+                                                    l2i_av, c['pc_range'], c['img_h'], c['img_w'], head_major=c['head_major'],
+                                                    query_order=order_av, **kw)
+        out_av, mask_av = run_av(c0, want_mask=True)
+        nl_ = len(c0['shapes'])
+        v_av = int(mask_av.sum().item()) * nl_
+        es_ = c0['value'].element_size()
+        side_ = q_ * (3 + mask_av.shape[3] * mask_av.shape[4] * 3 + mask_av.shape[3] * nl_ * mask_av.shape[4] + n_) * 4 + n_ * 64 \
+            + q_ * 256 * 4
+        alg_av = min(v_av * 4 * c0['value'].shape[-1] * es_, c0['value'].numel() * es_) + side_
+        for c in captured:
+            run_av(c, out=out_av)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            for c in captured:
+                run_av(c, out=out_av)
+        e1.record()
+        torch.cuda.synchronize()
+        us_av = e0.elapsed_time(e1) / (5 * len(captured)) * 1e3
+        kernels['cross_attn_fwd_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
+                                                     us_per_launch=us_av, gbs=alg_av / us_av / 1e3,
+                                                     frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS)
+    except Exception as e:                                    # secondary figure: report, never fail the bench line
+        kernels['cross_attn_fwd_all_visible'] = {'error': f'{type(e).__name__}: {e}'}
     # The other large kernel of a step, reported beside the headline roofline: value_proj, launched as the decoder launches
     # it (one multi-layer launch per group of layers, all CUs), HIP events on the launch stream.  Algorithmic bytes of a
     # launch: the pyramid read once + one value tensor written per layer; flops: 2 * rows * 256 * 256 per layer (x3 on the

@@ -252,25 +252,52 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
   const int L = LT > 0 ? LT : p.L;
 
   // ---------------- phase A: projection, spread over the whole workgroup ----------------
+  // While phase A runs the memory system idles (all workgroups of a launch are resident at once, so the phases are
+  // globally aligned): it is kept short - the N camera matrices go through LDS once instead of 12 global loads per entry,
+  // a thread's 3-D point (its (head, point) never changes between its entries) is formed once, and the per-head softmax is
+  // computed by HH x (L * PT) threads with cross-lane reductions instead of HH threads looping (11 us -> 4 us of 40).
+  float* s_mat = s_aw + HH * (LMAX * PT);          // [N][12]: rows 0-2 of lidar2img
+  for (int i = tid; i < p.N * 12; i += THREADS) s_mat[i] = p.lidar2img[((size_t)b * p.N + i / 12) * 16 + i % 12];
+  if (!BMULTI) {                                   // softmax over L * PT logits per head, one thread per logit
+    constexpr int LP = LMAX * PT;                  // <= 32 for the compiled shapes with LT > 0
+    const int n_lp = L * PT;
+    if (LT > 0 && (LP & (LP - 1)) == 0 && LP <= 32) {
+      // LP is a power of two: head = tid / LP, groups of LP lanes reduce with xor shuffles
+      if (tid < HH * LP) {
+        const int hd = tid / LP, i = tid % LP;
+        const float x = p.attn_logits[((size_t)bq * HH + hd) * n_lp + i];
+        float mx = x;
+#pragma unroll
+        for (int o = 1; o < LP; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = expf(x - mx);
+        float sum = e;
+#pragma unroll
+        for (int o = 1; o < LP; o <<= 1) sum += __shfl_xor(sum, o);
+        s_aw[hd * LP + i] = e * (1.0f / sum);
+      }
+    } else if (tid < HH) {                         // other shapes: one thread per head
+      float w[LP];
+      softmax_lp(p.attn_logits + ((size_t)bq * HH + tid) * n_lp, n_lp, w);
+      for (int i = 0; i < n_lp; ++i) s_aw[tid * LP + i] = w[i];
+    }
+  }
+  __syncthreads();
   {
-    const float* rp = p.ref + (size_t)bq * 3;
-    const float px = rp[0] * p.rng_scale[0] + p.rng_lo[0];
-    const float py = rp[1] * p.rng_scale[1] + p.rng_lo[1];
-    const float pz = rp[2] * p.rng_scale[2] + p.rng_lo[2];
-    const float* offs = p.offsets + (size_t)bq * E * 3;
     const int total = p.N * E;
+    static_assert(E <= GD4D_WAVE && GD4D_WAVE % E == 0 && THREADS % E == 0, "a thread keeps its (head, point)");
+    const int hp = tid % E;
+    const float* rp = p.ref + (size_t)bq * 3;
+    const float* offs = p.offsets + ((size_t)bq * E + hp) * 3;
+    const float X = (rp[0] * p.rng_scale[0] + p.rng_lo[0]) + offs[0];     // two roundings, then the offset (:222-229)
+    const float Y = (rp[1] * p.rng_scale[1] + p.rng_lo[1]) + offs[1];
+    const float Z = (rp[2] * p.rng_scale[2] + p.rng_lo[2]) + offs[2];
     for (int e0 = wave * GD4D_WAVE; e0 < total; e0 += THREADS) {
       const int e = e0 + lane;
       bool vis = false;
       if (e < total) {
         const int n = e / E;
-        const int hp = e - n * E;
-        const float X = px + offs[hp * 3 + 0];
-        const float Y = py + offs[hp * 3 + 1];
-        const float Z = pz + offs[hp * 3 + 2];
-        const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
         float u, v;
-        vis = project_entry(p, m, X, Y, Z, u, v);
+        vis = project_entry(p, s_mat + n * 12, X, Y, Z, u, v);
         s_uv[e] = vis ? make_float2(u, v) : make_float2(-1.f, -1.f);
         const size_t o = (((size_t)b * p.N + n) * p.Q + q) * E + hp;
         if (p.mask_out) p.mask_out[o] = vis ? 1 : 0;
@@ -278,7 +305,6 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
       }
       // per-camera "any point of any head visible": E consecutive entries belong to one camera
       const unsigned long long bal = __ballot(vis);
-      static_assert(E <= GD4D_WAVE && GD4D_WAVE % E == 0, "E = 4*heads must divide 64");
       constexpr int CPW = GD4D_WAVE / E;          // whole cameras covered by one wave iteration
       if (lane < CPW) {
         const int n = e0 / E + lane;
@@ -286,11 +312,6 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
         if (n < p.N) s_camvis[n] = (bal & (ones << (lane * (E & 63)))) ? 1 : 0;
       }
     }
-  }
-  if (!BMULTI && tid < HH) {                       // one thread per head: softmax over L*P, parked in LDS
-    float w[LMAX * PT];
-    softmax_lp(p.attn_logits + ((size_t)bq * HH + tid) * L * PT, L * PT, w);
-    for (int i = 0; i < L * PT; ++i) s_aw[tid * (LMAX * PT) + i] = w[i];
   }
   __syncthreads();
 
@@ -301,11 +322,19 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
 
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned long long cams = __ballot(lane < p.N && s_camvis[lane < p.N ? lane : 0] != 0);
+#ifdef GD4D_GATHER_DBG_NOB
+  cams = 0;                                                  // dev ablation: projection + softmax only
+#endif
+  // Work items are dealt round-robin to the waves.  B == 1: an item is one POINT of one visible camera (all levels and
+  // corners: 16 loads in flight), so a wave's chain of dependent load rounds is ceil(P * cameras / WAVES) long - with whole
+  // cameras as items it was P * ceil(cameras / WAVES): 8 rounds instead of 5 for a query seen by five cameras, 4 instead
+  // of 2 for two.  The kernel is latency-bound (all workgroups are resident at once: it ends when the longest chain does).
+  // B > 1 keeps whole cameras (the per-camera softmax of the row-pairing quirk lives in registers).
   int idx = 0;
   while (cams) {
     const int n = __builtin_ctzll(cams);
     cams &= cams - 1;
-    if ((idx++ % WAVES) != wave) continue;                   // round-robin deal of visible cameras
+    if (BMULTI && (idx++ % WAVES) != wave) continue;         // round-robin deal of visible cameras
 
     const float2* su = s_uv + n * E + h * PT;
     float2 pu[BMULTI ? PT : 1];
@@ -327,6 +356,7 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
 
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
+      if (!BMULTI && (idx++ % WAVES) != wave) continue;      // round-robin deal of (visible camera, point) items
       const float2 puk = BMULTI ? pu[BMULTI ? k : 0] : su[k];
       const bool pv = puk.x >= 0.f;
       const float u = pv ? puk.x : 0.5f, v = pv ? puk.y : 0.5f;
@@ -428,7 +458,7 @@ static void launch_block(const CrossAttnParams& p, hipStream_t s) {
   const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
   const size_t lds = (WAVES - 1) * GD4D_WAVE * sizeof(float4) + (size_t)p.N * HH * PT * sizeof(float2) +
                      (size_t)((p.N + 3) & ~3) * sizeof(int) +
-                     (size_t)HH * (LT > 0 ? LT : GD4D_MAX_LEVELS) * PT * sizeof(float);
+                     (size_t)HH * (LT > 0 ? LT : GD4D_MAX_LEVELS) * PT * sizeof(float) + (size_t)p.N * 12 * sizeof(float);
   if (p.B > 1)
     hipLaunchKernelGGL((cross_attn_fwd_block<VT, HH, LT, WAVES, true, PT>), grid, dim3(GD4D_WAVE * WAVES), lds, s, p);
   else

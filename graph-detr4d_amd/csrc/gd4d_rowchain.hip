@@ -155,6 +155,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         const int row = 4 * g + r, m = m0 + row;
         float v = acc[c][r] + e_bias[c];
         if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
+        if (op.flags & GD4D_CHAIN_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         if (op.res >= 0) v += bufs[op.res][row][n];
         if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
         if (op.gout && m < M) op.gout[(size_t)m * op.ldg + n] = v;

@@ -262,14 +262,19 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                                              kwargs.get('attn_masks')):
             # every layer is the post-norm (self-attention, Deform3DCrossAttn, FFN) layer: 4 launches per layer
             outs, refs = fused_decoder.run(
-                self, query.contiguous(), kwargs['query_pos'].contiguous(), kwargs['value'], reference_points, reg_branches,
+                self, query, kwargs['query_pos'], kwargs['value'], reference_points, reg_branches,
                 kwargs['img_metas'], kwargs.get('attn_masks'), pipeline, kwargs.get(Fn.VALUE_CACHE_KEY),
                 kwargs.get(Fn.QUERY_ORDER_KEY), getattr(self, '_order_pc_range', None), self.return_intermediate)
             if pipeline is not None:
                 pipeline.finish()
             if self.return_intermediate:
-                return torch.stack(outs), torch.stack(refs)
+                return outs, refs
             return outs[0], refs[0]
+        # generic path: dense (Q, B, C) rows once (every kernel downstream wants them; the layers would re-copy otherwise)
+        output = query = query.contiguous()
+        if kwargs.get('query_pos') is not None and not kwargs['query_pos'].is_contiguous():
+            kwargs = dict(kwargs)
+            kwargs['query_pos'] = kwargs['query_pos'].contiguous()
         aux = None
         cross = [a for layer in self.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
         deform_only = bool(cross) and all(isinstance(a, Deform3DCrossAttn) for a in cross)
@@ -344,15 +349,20 @@ class Detr3DTransformer(nn.Module):
         assert query_embed is not None
         bs = mlvl_feats[0].size(0)
         query_pos, query = torch.split(query_embed, self.embed_dims, dim=1)
-        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
-        query = query.unsqueeze(0).expand(bs, -1, -1)
-        reference_points = self.reference_points(query_pos).sigmoid()
+        from . import fused_decoder
+        if fused_decoder.fast_input(self, query_embed, mlvl_feats):
+            # batch 1, inference: no copies - the column slices of query_embed go to the decoder as strided (Q, 1, C) views
+            # and the initial reference points come from one chain launch (no library GEMM / sigmoid / cat in the step)
+            reference_points = fused_decoder.initial_reference(self.reference_points, query_pos)
+            q_in, pos_in = query.unsqueeze(1), query_pos.unsqueeze(1)
+        else:
+            query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+            query = query.unsqueeze(0).expand(bs, -1, -1)
+            reference_points = self.reference_points(query_pos).sigmoid()
+            q_in, pos_in = query.permute(1, 0, 2), query_pos.permute(1, 0, 2)
         init_reference_out = reference_points
-        # (Q, B, C) dense copies made ONCE: query_pos / query are strided slices of query_embed, and every
-        # fused kernel downstream wants dense rows (otherwise each layer re-copies them)
         inter_states, inter_references = self.decoder(
-            query=query.permute(1, 0, 2).contiguous(), key=None, value=mlvl_feats,
-            query_pos=query_pos.permute(1, 0, 2).contiguous(), reference_points=reference_points,
+            query=q_in, key=None, value=mlvl_feats, query_pos=pos_in, reference_points=reference_points,
             reg_branches=reg_branches, **kwargs)
         return inter_states, init_reference_out, inter_references
 

@@ -80,6 +80,24 @@ def _in_proj_ops(sa, x_pos_buf, x_buf, qkv):
             ops.chain_gemm(x_buf, w[2 * c:], b[2 * c:], out=qkv[..., 2 * c:])]
 
 
+def initial_reference(linear, query_pos):
+    """sigmoid(Linear(query_pos)) (detr3d_transformer.py:133-134) as one chain launch.  query_pos (Q, C), rows may be
+    strided (a column slice of query_embed).  Returns (1, Q, 3)."""
+    q = query_pos.shape[0]
+    out = torch.empty(1, q, linear.out_features, device=query_pos.device, dtype=torch.float32)
+    ops.row_chain_fwd([ops.chain_load(0, query_pos),
+                       ops.chain_gemm(0, linear.weight, linear.bias, out=out.view(q, -1), sigmoid=True)], q)
+    return out
+
+
+def fast_input(module, query_embed, mlvl_feats):
+    """The conditions under which Detr3DTransformer hands strided views to the decoder and uses initial_reference."""
+    return (os.environ.get('GD4D_FUSED_DECODER', '1') != '0' and query_embed.is_cuda and query_embed.dtype == torch.float32
+            and mlvl_feats[0].size(0) == 1 and query_embed.dim() == 2 and query_embed.stride(1) == 1
+            and query_embed.shape[1] % 8 == 0 and (query_embed.shape[1] // 2) % 128 == 0
+            and not (torch.is_grad_enabled() and (query_embed.requires_grad or any(p.requires_grad for p in module.parameters()))))
+
+
 def _position_features(ca, reference_points, q):
     """position_encoder(inverse_sigmoid(ref [, depth])) (deform3d_cross_attn.py:104-111, 331-334) as one chain."""
     ref3d = reference_points
@@ -99,7 +117,8 @@ def _position_features(ca, reference_points, q):
 
 def run(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, pipeline, value_cache,
         order, order_pc_range, return_intermediate):
-    """query / query_pos (Q, 1, C) dense; reference_points (1, Q, 3).  Returns (outputs, references) per layer."""
+    """query / query_pos (Q, 1, C), rows may be strided; reference_points (1, Q, 3).  Returns the stacked per-layer
+    outputs (NL, Q, 1, C) and reference points (NL, 1, Q, 3) (the last layer's only without return_intermediate)."""
     q, _, c = query.shape
     dev = query.device
     layers = list(decoder.layers)
@@ -112,15 +131,17 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
         attn_masks = [attn_masks, attn_masks]
     lidar2img = Fn.lidar2img_device(img_metas, query)
     img_h, img_w = Fn.img_hw(img_metas)
-    x = query.view(q, c)
-    pos = query_pos.view(q, c)
+    x = query[:, 0, :]                                   # (Q, C) views; chain loads take a row stride
+    pos = query_pos[:, 0, :]
     keep = []                                            # tensors the enqueued programs point to
 
     # layer 0's in-projection
     qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
     ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1)), q)
 
-    outputs, references = [], []
+    n_out = nl if return_intermediate else 1
+    out_all = torch.empty(n_out, q, 1, c, device=dev, dtype=torch.float32)       # what torch.stack would build
+    ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
     ref = reference_points.contiguous()
     ref_event = None                                     # `ref` / `order` were produced on the aux stream
     for lid, layer in enumerate(layers):
@@ -183,8 +204,9 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
         # chain B
         if ev_pos is not None:
             main.wait_event(ev_pos)
-        x3 = torch.empty(q, 1, c, device=dev, dtype=torch.float32)
         last = lid + 1 == nl
+        slot = lid if return_intermediate else 0
+        x3 = out_all[slot]                                                         # (Q, 1, C)
         prog = [ops.chain_load(0, agg.view(q, c)),
                 ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336
                 ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
@@ -202,7 +224,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
             for i, lin in enumerate(lins):
                 prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
                 src = tmp[i % 2]
-            new_ref = torch.empty_like(ref)
+            new_ref = ref_all[slot]                                                 # (1, Q, 3)
             prog.append(ops.chain_refine(src, ref, new_ref))
         ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg, x]
@@ -223,12 +245,9 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                         ref_event.record(aux)
                 else:
                     order = Fn.query_order(ref, order_pc_range)
-        if return_intermediate:
-            outputs.append(x3)
-            references.append(ref)
+        if new_ref is None and (return_intermediate or last):
+            ref_all[slot].copy_(ref)
     if aux is not None:
         main.wait_stream(aux)
-    if not return_intermediate:
-        outputs, references = [x3], [ref]
     del keep
-    return outputs, references
+    return out_all, ref_all

@@ -651,7 +651,7 @@ class ChainOp(ctypes.Structure):
 
 
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR = 1, 2, 3, 4, 5, 6
-CHAIN_RELU, CHAIN_INV_SIGMOID = 1, 2
+CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID = 1, 2, 4
 
 
 def _rows(t, name):
@@ -708,12 +708,12 @@ def chain_weight_image(weight):
     return img
 
 
-def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None):
+def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False):
     """act(buf[src] W^T + b) (+ buf[res]) -> buf[dst] and / or out.  weight (N, K) contiguous rows."""
     img = chain_weight_image(weight)
     g, ldg = _rows(out, 'out')
     return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
-                   flags=CHAIN_RELU if relu else 0, ldg=ldg, p0=img.data_ptr(),
+                   flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0), ldg=ldg, p0=img.data_ptr(),
                    p1=None if bias is None else bias.data_ptr(), gout=g)
 
 

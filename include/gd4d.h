@@ -305,6 +305,7 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
        GD4D_CHAIN_SMALL_LINEAR = 6 };
 #define GD4D_CHAIN_RELU 1
 #define GD4D_CHAIN_INV_SIGMOID 2
+#define GD4D_CHAIN_SIGMOID 4        /* GEMM: sigmoid on the output (after the bias / ReLU, before the residual) */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
