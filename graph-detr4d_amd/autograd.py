@@ -3,7 +3,11 @@
 Inference takes the fully fused HIP path (functional.py); with autograd enabled the modules switch to:
   * CrossAttnFunction  - gd4d_cross_attn_fwd / gd4d_cross_attn_bwd (hand-written HIP both ways);
   * ValueProjFunction  - gd4d_value_proj_fwd / gd4d_value_proj_bwd_input + _bwd_weight (HIP both ways);
-  * small dense layers - torch ops, so autograd sees them (their HIP kernels are forward-only).
+  * LinearFunction     - gd4d_linear_fwd forward, gd4d_linear_fwd with the transposed-weight flag for the input
+                         gradient, gd4d_linear_bwd_weight for the weight / bias gradient;
+  * LayerNormFunction  - gd4d_layernorm_fwd / gd4d_layernorm_bwd (optionally with the ReLU that follows);
+  * MhaCoreFunction    - gd4d_mha_core_fwd (saving the log-sum-exp) / gd4d_mha_core_bwd.
+What is left to ATen in a training step: residual adds, ReLU between two Linears, dropout, autograd's own accumulations.
 """
 import torch
 
@@ -108,21 +112,61 @@ class ValueProjMultiFunction(torch.autograd.Function):
 
 
 class LinearFunction(torch.autograd.Function):
-    """nn.Linear for the decoder's dense layers in training: library GEMM forward and input gradient, weight / bias
-    gradient by gd4d_linear_bwd_weight (the library runs that 256 x 256 x ~900 contraction on a single compute unit)."""
+    """nn.Linear for the decoder's dense layers in training, all three products on the library's fp32 MFMA kernels:
+    forward gd4d_linear_fwd, input gradient gd4d_linear_fwd with GD4D_LIN_WEIGHT_KN (y = grad W, no transposed copy of
+    the weight), weight / bias gradient gd4d_linear_bwd_weight (a vendor GEMM runs that 256 x 256 x ~900 contraction on
+    a single compute unit)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)                  # x: (M, K), see functional.linear_autograd
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        return ops.linear_fwd(x, weight, None if bias is None else bias.contiguous())
 
     @staticmethod
     def backward(ctx, grad_y):
         x, weight = ctx.saved_tensors
         grad_y = grad_y.contiguous()
-        gx = torch.matmul(grad_y, weight) if ctx.needs_input_grad[0] else None
+        gx = ops.linear_fwd(grad_y, weight, weight_kn=True) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = ops.linear_bwd_weight(x.contiguous(), grad_y, want_bias=ctx.has_bias)
+            gw, gb = ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias)
         return gx, gw, gb
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """[ReLU] LayerNorm(x) over the last dimension: gd4d_layernorm_fwd / gd4d_layernorm_bwd (the decoder layer's norms,
+    position_encoder's LayerNorm + ReLU pairs, deform3d_cross_attn.py:104-111)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.eps, ctx.relu = eps, relu
+        return ops.layernorm_fwd(x, gamma, beta, eps, relu=relu)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, gamma, beta = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu)
+        return dx, dg, db, None, None
+
+
+class MhaCoreFunction(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) + mask) v per head (the middle of nn.MultiheadAttention): gd4d_mha_core_fwd, which also
+    saves the row log-sum-exp, and gd4d_mha_core_bwd.  q, k, v: (L, B, C) row-strided (e.g. thirds of a packed
+    in-projection)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, attn_mask, num_heads):
+        out, lse = ops.mha_core_fwd(q, k, v, num_heads, attn_mask, want_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.mask, ctx.heads = attn_mask, num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = ops.mha_core_bwd(q, k, v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask)
+        return dq, dk, dv, None, None

@@ -23,7 +23,8 @@ struct LinearParams {
   const float* r1;     // optional residual (M, N), row stride ldr1
   const float* r2;     // optional second residual, row stride ldr2
   float* y;            // (M, N), row stride ldy
-  int M, K, N, n_split, flags;      // flags: bit0 ReLU on the output, bit1 inverse_sigmoid on the input
+  int M, K, N, n_split, flags;      // flags: bit0 ReLU on the output, bit1 inverse_sigmoid on the input,
+                                    // bit3 the weight is given TRANSPOSED, (K, N) row-major (input gradient of a Linear)
   int ldx, ldy, ldr1, ldr2;
   // grouped mode (gd4d_linear_group_fwd): up to 4 (W, bias, y, N) sets sharing the input; blockIdx.y walks the
   // groups' column tiles back to back.  groups == 0: the plain single-output form above.
@@ -85,8 +86,9 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
     const int gn = min(n0 + 16 * t + i16, N - 1);
     xr[t] = p.x + (size_t)gm * p.ldx;
     x2r[t] = add2 ? p.x2 + (size_t)gm * p.ldx : nullptr;
-    wr[t] = W + (size_t)gn * p.K;
+    wr[t] = (p.flags & 8) ? W + gn : W + (size_t)gn * p.K;
   }
+  const bool wkn = (p.flags & 8) != 0;             // B[k][n] = W[k * N + n]: four row-strided dwords per lane and step
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -154,7 +156,14 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         av[j][t] = load4(xr[t], x2r[t], k, true);
-        bv[j][t] = load4(wr[t], nullptr, k, false);
+        if (!wkn) {
+          bv[j][t] = load4(wr[t], nullptr, k, false);
+        } else {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = wr[t][(size_t)min(k + e, p.K - 1) * N] * (k + e < p.K ? 1.f : 0.f);
+          bv[j][t] = f32x4{v[0], v[1], v[2], v[3]};
+        }
       }
     }
 #pragma unroll

@@ -25,6 +25,7 @@ struct MhaParams {
   const float* q; const float* k; const float* v;   // row (l*B + b), row strides ldq/ldk/ldv, head h at +32*h
   const void* mask;                                  // (Lq, Lk) uint8 (nonzero = masked) or float additive
   float* out;                                        // (Lq*B, heads*32)
+  float* lse;                                        // optional (Lq, B, heads): log sum exp of the scaled, masked scores
   int Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind;   // 0 none, 1 bool, 2 float
   float scale;
 };
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
       den += s_l[w][i] * f;
     }
     p.out[((size_t)(q0 + i) * p.B + b) * p.ldo + h * MHA_D + d] = num / den;
+    if (p.lse && d == 0) p.lse[((size_t)(q0 + i) * p.B + b) * p.H + h] = mm + logf(den);   // saved for gd4d_mha_core_bwd
   }
 }
 
@@ -169,13 +171,13 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
 
 extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask,
                                  float* out, int Lq, int Lk, int B, int H, int D, int ldq, int ldk,
-                                 int ldv, int ldo, int mask_kind, float scale, void* stream) {
+                                 int ldv, int ldo, int mask_kind, float scale, float* lse, void* stream) {
   using namespace gd4d;
   if (!q || !k || !v || !out || Lq <= 0 || Lk <= 0 || B <= 0 || H <= 0) return GD4D_EINVAL;
   if (D != MHA_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
   if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return GD4D_EINVAL;
   if (!aligned16(q) || !aligned16(k) || (ldq % 4) || (ldk % 4)) return GD4D_EALIGN;
-  MhaParams p{q, k, v, mask, out, Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind, scale};
+  MhaParams p{q, k, v, mask, out, lse, Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind, scale};
   hipLaunchKernelGGL(mha_core_kernel, dim3((Lq + 15) / 16, H, B), dim3(64 * MHA_WAVES), 0,
                      static_cast<hipStream_t>(stream), p);
   return check_launch();

@@ -1,0 +1,323 @@
+// Backward kernels of the decoder's query side (training): LayerNorm and the self-attention core.
+//
+// The reference trains through ATen autograd: layer_norm_backward (three kernels per LayerNorm), softmax / bmm
+// backward inside nn.MultiheadAttention (config ...ceph.py:74-78).  Round 1 of this build left those to ATen; here they
+// are hand-written so that a training step's kernel table is gd4d:: only (plus optimizer and collectives).
+// Everything fp32; reductions in a fixed order (run-to-run identical results).
+#include "gd4d_common.h"
+
+namespace gd4d {
+
+typedef __attribute__((ext_vector_type(4))) float t4;
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  y = [ReLU] LN(x [+ res]) * gamma + beta  (gd4d_layernorm_fwd); given dy:
+//   g = dy * gamma (dy masked by y > 0 with ReLU), xhat = (x - mean) * rstd,
+//   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),   dgamma = sum_rows dy * xhat,   dbeta = sum_rows dy.
+// mean / rstd are recomputed from x (two-pass, as the forward), nothing is saved by the forward.
+// Kernel 1: one workgroup = 16 rows (4 waves x 4 rows), C <= 1024; writes dx and the workgroup's partial dgamma / dbeta.
+// Kernel 2: adds the partials in workgroup order.
+struct LnBwdParams {
+  const float* x; const float* res; const float* gamma; const float* beta; const float* dy;
+  float* dx; float* part;      // part: [workgroups][2][C]
+  int M, C, relu;
+  float eps;
+};
+
+__device__ __forceinline__ float t_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p) {
+  __shared__ float s_part[4][2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = p.C / 4;
+  float4 ag[4], ab[4];                                   // this wave's partial dgamma / dbeta for the lane's channels
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+  float4 gm[4], bt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = min(lane + 64 * i, nv - 1);
+    gm[i] = reinterpret_cast<const float4*>(p.gamma)[c];
+    bt[i] = p.relu ? reinterpret_cast<const float4*>(p.beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = blockIdx.x * 16 + wave * 4 + rr;
+    if (row >= p.M) break;                               // wave-uniform
+    const float4* x = reinterpret_cast<const float4*>(p.x + (size_t)row * p.C);
+    const float4* r = p.res ? reinterpret_cast<const float4*>(p.res + (size_t)row * p.C) : nullptr;
+    const float4* dy = reinterpret_cast<const float4*>(p.dy + (size_t)row * p.C);
+    float4 v[4], d[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f); d[i] = v[i];
+      if (c < nv) {
+        v[i] = x[c];
+        if (r) { const float4 t = r[c]; v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w; }
+        d[i] = dy[c];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = t_wave_sum(s) / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c2 = v[i].z - mean, e = v[i].w - mean;
+        q += (a * a + b * b) + (c2 * c2 + e * e);
+      }
+    const float rstd = 1.0f / sqrtf(t_wave_sum(q) / (float)p.C + p.eps);
+    float s1 = 0.f, s2 = 0.f;
+    float4 xh[4], g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[i] = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+      if (p.relu) {                                      // the forward clamped y at 0: those outputs pass no gradient
+        if (xh[i].x * gm[i].x + bt[i].x <= 0.f) d[i].x = 0.f;
+        if (xh[i].y * gm[i].y + bt[i].y <= 0.f) d[i].y = 0.f;
+        if (xh[i].z * gm[i].z + bt[i].z <= 0.f) d[i].z = 0.f;
+        if (xh[i].w * gm[i].w + bt[i].w <= 0.f) d[i].w = 0.f;
+      }
+      g[i] = make_float4(d[i].x * gm[i].x, d[i].y * gm[i].y, d[i].z * gm[i].z, d[i].w * gm[i].w);
+      if (lane + 64 * i < nv) {
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+        ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      }
+    }
+    const float m1 = t_wave_sum(s1) / (float)p.C, m2 = t_wave_sum(s2) / (float)p.C;
+    float4* dx = reinterpret_cast<float4*>(p.dx + (size_t)row * p.C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < nv)
+        dx[lane + 64 * i] = make_float4(rstd * (g[i].x - m1 - xh[i].x * m2), rstd * (g[i].y - m1 - xh[i].y * m2),
+                                        rstd * (g[i].z - m1 - xh[i].z * m2), rstd * (g[i].w - m1 - xh[i].w * m2));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (lane + 64 * i < nv) {
+      reinterpret_cast<float4*>(s_part[wave][0])[lane + 64 * i] = ag[i];
+      reinterpret_cast<float4*>(s_part[wave][1])[lane + 64 * i] = ab[i];
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * p.C; e += 256) {
+    const int k = e / p.C, c = e - k * p.C;
+    p.part[((size_t)blockIdx.x * 2 + k) * p.C + c] = (s_part[0][k][c] + s_part[1][k][c]) + (s_part[2][k][c] + s_part[3][k][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta,
+                                                                  int parts, int C) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * C) return;
+  const int k = e / C, c = e - k * C;
+  float s = 0.f;
+  for (int w = 0; w < parts; ++w) s += part[((size_t)w * 2 + k) * C + c];
+  (k == 0 ? dgamma : dbeta)[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Self-attention core backward.  Forward (gd4d_mha_core_fwd): P = softmax(scale q k^T + mask), o = P v, per head
+// (D = 32), with lse[q] = log sum_k exp(scale q k^T + mask) saved per (query, batch, head).  Given do:
+//   Dq = sum_d do[q][d] o[q][d];  dP = do v^T;  dS = P o (dP - Dq);  dq = scale dS k;  dk = scale dS^T q;  dv = P^T do.
+// Two kernels with the forward's register layout (transposed score tiles on v_mfma_f32_16x16x4_f32: the C/D layout of
+// the score tile is the B-operand layout of the product that consumes it, so probabilities never move between lanes):
+//   dq kernel:    workgroup = 16 queries, waves split the key tiles; also writes Dq for the second kernel
+//   dk/dv kernel: workgroup = 16 keys, waves split the query tiles
+struct MhaBwdParams {
+  const float* q; const float* k; const float* v; const float* o; const float* dout;   // rows (l*B + b), head h at +32 h
+  const void* mask;
+  const float* lse;       // (Lq, B, H)
+  float* dsum;            // (Lq, B, H): Dq (written by the dq kernel, read by the dk/dv kernel)
+  float* dq; float* dk; float* dv;
+  int Lq, Lk, B, H, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, mask_kind;
+  float scale;
+};
+
+constexpr int TB_D = 32, TB_WAVES = 4;
+
+// A 16 x 16 score-like tile, transposed: T^T[row][col] = sum_d R[row][d] C[col][d], rows permuted so that lane
+// (col = lane & 15, g = lane >> 4) register r holds row g + 4 r.  rowv = the row operand's 8 values of this lane (row
+// rho = (lane & 15 >> 2) + 4 (lane & 3), dims 8 g ..), colv = the column operand's 8 values (col lane & 15, dims 8 g ..).
+__device__ __forceinline__ t4 tb_tile(const float* rowv, const float* colv) {
+  t4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s = __builtin_amdgcn_mfma_f32_16x16x4f32(rowv[i], colv[i], s, 0, 0, 0);
+  return s;
+}
+
+__device__ __forceinline__ void tb_load8(const float* src, float* dst, float mul) {
+  const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+  dst[0] = a.x * mul; dst[1] = a.y * mul; dst[2] = a.z * mul; dst[3] = a.w * mul;
+  dst[4] = c.x * mul; dst[5] = c.y * mul; dst[6] = c.z * mul; dst[7] = c.w * mul;
+}
+
+// SIDE = 0: the workgroup owns 16 queries (columns of the transposed tiles), loops over key tiles (rows): dq.
+// SIDE = 1: the workgroup owns 16 keys (columns), loops over query tiles (rows): dk and dv.
+template <int SIDE>
+__global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdParams p) {
+  __shared__ float s_acc[TB_WAVES][2][TB_D][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.x * 16;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t hoff = (size_t)h * TB_D;
+  const int Lc = SIDE == 0 ? p.Lq : p.Lk;               // extent of the column (owned) side
+  const int Lr = SIDE == 0 ? p.Lk : p.Lq;               // extent of the row (looped) side
+  const int rho = (ci >> 2) + 4 * (ci & 3);             // row (within a tile) this lane feeds as MFMA A row
+  const float NEG_INF = -__builtin_inff();
+
+  // column-side operands of this lane (column ci, dims 8 g .. 8 g + 7)
+  const int crow = min(c0 + ci, Lc - 1);
+  float cq[8], cd[8];                                    // SIDE 0: scaled q, do;  SIDE 1: k, v
+  float c_lse = 0.f, c_dsum = 0.f;
+  if (SIDE == 0) {
+    tb_load8(p.q + ((size_t)crow * p.B + b) * p.ldq + hoff + 8 * g, cq, p.scale);
+    tb_load8(p.dout + ((size_t)crow * p.B + b) * p.lddo + hoff + 8 * g, cd, 1.f);
+    float ov[8];
+    tb_load8(p.o + ((size_t)crow * p.B + b) * p.ldo + hoff + 8 * g, ov, 1.f);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d += cd[i] * ov[i];
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    c_dsum = d;
+    c_lse = p.lse[((size_t)crow * p.B + b) * p.H + h];
+    if (wave == 0 && g == 0 && c0 + ci < Lc) p.dsum[((size_t)crow * p.B + b) * p.H + h] = d;
+  } else {
+    tb_load8(p.k + ((size_t)crow * p.B + b) * p.ldk + hoff + 8 * g, cq, 1.f);
+    tb_load8(p.v + ((size_t)crow * p.B + b) * p.ldv + hoff + 8 * g, cd, 1.f);
+  }
+
+  t4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;   // SIDE 0: dq^T (a);  SIDE 1: dk^T (a), dv^T (b)
+  const int ntiles = (Lr + 15) / 16;
+  for (int rt = wave; rt < ntiles; rt += TB_WAVES) {
+    const int rbase = rt * 16;
+    const int rrow = min(rbase + rho, Lr - 1);
+    float rk[8], rv[8];                                  // SIDE 0: k, v rows;  SIDE 1: scaled q, do rows
+    if (SIDE == 0) {
+      tb_load8(p.k + ((size_t)rrow * p.B + b) * p.ldk + hoff + 8 * g, rk, 1.f);
+      tb_load8(p.v + ((size_t)rrow * p.B + b) * p.ldv + hoff + 8 * g, rv, 1.f);
+    } else {                                             // (scale q in the score; the plain q below for dk)
+      tb_load8(p.q + ((size_t)rrow * p.B + b) * p.ldq + hoff + 8 * g, rk, p.scale);
+      tb_load8(p.dout + ((size_t)rrow * p.B + b) * p.lddo + hoff + 8 * g, rv, 1.f);
+    }
+    // S^T and dP^T tiles: lane (col ci, g) register r <-> row rbase + g + 4 r
+    const t4 s = SIDE == 0 ? tb_tile(rk, cq) : tb_tile(rk, cq);
+    const t4 dp = SIDE == 0 ? tb_tile(rv, cd) : tb_tile(rv, cd);
+    float pr[4], ds[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rowi = rbase + g + 4 * r;
+      const int qi = SIDE == 0 ? c0 + ci : rowi, ki = SIDE == 0 ? rowi : c0 + ci;
+      float val = s[r];
+      bool dead = rowi >= Lr;
+      if (!dead && p.mask_kind) {
+        const size_t mi = (size_t)min(qi, p.Lq - 1) * p.Lk + min(ki, p.Lk - 1);
+        if (p.mask_kind == 1) dead = static_cast<const uint8_t*>(p.mask)[mi] != 0;
+        else val += static_cast<const float*>(p.mask)[mi];
+      }
+      float lse, dsum;
+      if (SIDE == 0) { lse = c_lse; dsum = c_dsum; }
+      else {
+        const size_t li = ((size_t)min(rowi, p.Lq - 1) * p.B + b) * p.H + h;
+        lse = p.lse[li]; dsum = p.dsum[li];
+      }
+      const float pv = dead ? 0.f : expf(val - lse);
+      pr[r] = pv;
+      ds[r] = pv * (dp[r] - dsum);
+    }
+    // products with the row side as reduction index: A = X^T[d = ci (+16)][row = rbase + g + 4 st], B = pr / ds
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int xr = min(rbase + g + 4 * st, Lr - 1);    // rows past the end carry pr = ds = 0
+      if (SIDE == 0) {                                   // dq^T += K^T dS^T
+        const float* ks = p.k + ((size_t)xr * p.B + b) * p.ldk + hoff + ci;
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[0], ds[st], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[16], ds[st], a1, 0, 0, 0);
+      } else {                                           // dk^T += Q^T dS,  dv^T += dO^T P
+        const float* qs = p.q + ((size_t)xr * p.B + b) * p.ldq + hoff + ci;
+        const float* os = p.dout + ((size_t)xr * p.B + b) * p.lddo + hoff + ci;
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[0], ds[st], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[16], ds[st], a1, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(os[0], pr[st], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(os[16], pr[st], b1, 0, 0, 0);
+      }
+    }
+  }
+  // merge the waves (fixed order); accumulators: d = 4 g + r (a0 / b0), 16 + 4 g + r (a1 / b1), column ci
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    s_acc[wave][0][4 * g + r][ci] = a0[r];
+    s_acc[wave][0][16 + 4 * g + r][ci] = a1[r];
+    if (SIDE == 1) { s_acc[wave][1][4 * g + r][ci] = b0[r]; s_acc[wave][1][16 + 4 * g + r][ci] = b1[r]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < 16 * TB_D; e += 64 * TB_WAVES) {
+    const int i = e / TB_D, d = e % TB_D;
+    if (c0 + i >= Lc) continue;
+    const size_t rowo = (size_t)(c0 + i) * p.B + b;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < TB_WAVES; ++w) { s0 += s_acc[w][0][d][i]; if (SIDE == 1) s1 += s_acc[w][1][d][i]; }
+    if (SIDE == 0) p.dq[rowo * p.lddq + hoff + d] = s0 * p.scale;       // (q was scaled going in: d(scale q)/dq)
+    else { p.dk[rowo * p.lddk + hoff + d] = s0 * p.scale; p.dv[rowo * p.lddv + hoff + d] = s1; }   // rows were q, not scale q
+  }
+}
+
+}  // namespace gd4d
+
+extern "C" size_t gd4d_layernorm_bwd_workspace_bytes(int M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)((M + 15) / 16) * 2 * C * sizeof(float);
+}
+
+extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* dy,
+                                  float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M,
+                                  int C, float eps, int relu, void* stream) {
+  using namespace gd4d;
+  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0) return GD4D_EINVAL;
+  if (relu && !beta) return GD4D_EINVAL;
+  if (C % 4 != 0 || C > 1024) return GD4D_EUNSUPPORTED;
+  if (workspace_bytes < gd4d_layernorm_bwd_workspace_bytes(M, C)) return GD4D_EINVAL;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(gamma) || (res && !aligned16(res)) ||
+      (beta && !aligned16(beta)))
+    return GD4D_EALIGN;
+  LnBwdParams p{x, res, gamma, beta, dy, dx, static_cast<float*>(workspace), M, C, relu ? 1 : 0, eps};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int parts = (M + 15) / 16;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, p);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, p.part, dgamma, dbeta, parts, C);
+  return check_launch();
+}
+
+extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                 const void* mask, const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq,
+                                 int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
+                                 int lddk, int lddv, int mask_kind, float scale, void* stream) {
+  using namespace gd4d;
+  if (!q || !k || !v || !o || !dout || !lse || !dsum || !dq || !dk || !dv || Lq <= 0 || Lk <= 0 || B <= 0 || H <= 0)
+    return GD4D_EINVAL;
+  if (D != TB_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
+  const int ld_min = H * D;
+  if (ldq < ld_min || ldk < ld_min || ldv < ld_min || ldo < ld_min || lddo < ld_min || lddq < ld_min || lddk < ld_min ||
+      lddv < ld_min)
+    return GD4D_EINVAL;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !aligned16(dout) || (ldq % 4) || (ldk % 4) ||
+      (ldv % 4) || (ldo % 4) || (lddo % 4))
+    return GD4D_EALIGN;
+  MhaBwdParams p{q, k, v, o, dout, mask, lse, dsum, dq, dk, dv, Lq, Lk, B, H, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
+                 mask_kind, scale};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mha_bwd_kernel<0>, dim3((Lq + 15) / 16, H, B), dim3(64 * TB_WAVES), 0, st, p);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(mha_bwd_kernel<1>, dim3((Lk + 15) / 16, H, B), dim3(64 * TB_WAVES), 0, st, p);
+  return check_launch();
+}

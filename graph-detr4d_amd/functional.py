@@ -33,13 +33,36 @@ def linear_autograd(x, weight, bias=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+def layer_norm_autograd(x, norm, relu=False):
+    """nn.LayerNorm `norm` [+ ReLU] with autograd on the HIP kernels (gd4d_layernorm_fwd / _bwd); anything they do not
+    cover (CPU, other dtypes, no affine parameters, > 1024 channels) goes to the module."""
+    c = x.shape[-1]
+    if x.is_cuda and x.dtype == torch.float32 and norm.weight is not None and norm.bias is not None \
+            and tuple(norm.normalized_shape) == (c,) and c % 4 == 0 and c <= 1024:
+        from .autograd import LayerNormFunction
+        return LayerNormFunction.apply(x, norm.weight, norm.bias, norm.eps, relu)
+    y = norm(x)
+    return torch.relu(y) if relu else y
+
+
 def sequential_autograd(module, x):
-    """Run an nn.Sequential / nn.Linear / any module with autograd, its nn.Linear layers through linear_autograd."""
+    """Run an nn.Sequential / nn.Linear / nn.LayerNorm / any module with autograd: nn.Linear layers through
+    linear_autograd, nn.LayerNorm (with the ReLU that follows it, if any) through layer_norm_autograd."""
     if isinstance(module, torch.nn.Linear):
         return linear_autograd(x, module.weight, module.bias)
+    if isinstance(module, torch.nn.LayerNorm):
+        return layer_norm_autograd(x, module)
     if isinstance(module, torch.nn.Sequential):
-        for m in module:
+        mods = list(module)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, torch.nn.LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU):
+                x = layer_norm_autograd(x, m, relu=True)
+                i += 2
+                continue
             x = sequential_autograd(m, x)
+            i += 1
         return x
     return module(x)
 

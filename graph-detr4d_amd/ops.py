@@ -264,12 +264,14 @@ def _opt(t, name):
 
 
 def linear_fwd(x, weight, bias=None, x2=None, n_split=None, relu=False, r1=None, r2=None, out=None,
-               inv_sigmoid_in=False):
+               inv_sigmoid_in=False, weight_kn=False):
     """gd4d_linear_fwd on the last dimension: y = act((x [+ x2 for cols < n_split]) W^T + b) [+r1] [+r2].
     x (..., K) contiguous; weight (N, K); residuals (..., N) contiguous.  Returns (..., N)."""
     lib = _lib.load()
     k = x.shape[-1]
-    n = weight.shape[0]
+    n = weight.shape[1] if weight_kn else weight.shape[0]      # weight_kn: weight is (K, N) - y = x W (a Linear's dgrad)
+    if weight_kn and weight.shape[0] != k:
+        raise ValueError('weight_kn: weight must be (K, N) with K = x.shape[-1]')
     m = x.numel() // k
     if out is None:
         out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
@@ -278,7 +280,7 @@ def linear_fwd(x, weight, bias=None, x2=None, n_split=None, relu=False, r1=None,
     code = lib.gd4d_linear_fwd(_dev(x, 'x', torch.float32), _opt(x2, 'x2'), _dev(weight, 'weight', torch.float32),
                                _opt(bias, 'bias'), _opt(r1, 'r1'), _opt(r2, 'r2'), _dev(out, 'out'),
                                m, k, n, n if n_split is None else int(n_split),
-                               int(bool(relu)) | (2 if inv_sigmoid_in else 0),
+                               int(bool(relu)) | (2 if inv_sigmoid_in else 0) | (8 if weight_kn else 0),
                                k, n, n, n, _stream())
     _lib.check(code, 'gd4d_linear_fwd')
     return out
@@ -348,11 +350,7 @@ def small_linear_layernorm_fwd(x, weight, bias, gamma, beta, eps=1e-5, relu=Fals
     return out
 
 
-def mha_core_fwd(q, k, v, num_heads, attn_mask=None):
-    """gd4d_mha_core_fwd.  q (Lq, B, C), k / v (Lk, B, C): each contiguous or a last-dim slice of a packed
-    (L, B, 3C) in-projection buffer.  attn_mask: None, bool/uint8 (Lq, Lk) (nonzero = masked) or float
-    additive (Lq, Lk).  Returns (Lq, B, C)."""
-    lib = _lib.load()
+def _mha_args(q, k, v, num_heads, attn_mask):
     lq, b, c = q.shape
     lk = k.shape[0]
     d = c // num_heads
@@ -363,7 +361,6 @@ def mha_core_fwd(q, k, v, num_heads, attn_mask=None):
         if t.stride(2) != 1 or t.stride(0) != t.stride(1) * t.shape[1]:
             raise ValueError(f'{name} must be row-strided (L, B, C)')
         return t.stride(1)
-    out = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
     kind, mptr = 0, None
     if attn_mask is not None:
         if attn_mask.dim() != 2:
@@ -374,12 +371,57 @@ def mha_core_fwd(q, k, v, num_heads, attn_mask=None):
             attn_mask, kind = attn_mask.float(), 2
         attn_mask = attn_mask.contiguous()
         mptr = _dev(attn_mask, 'attn_mask')
+    return lq, lk, b, c, d, ld, kind, mptr, attn_mask
+
+
+def mha_core_fwd(q, k, v, num_heads, attn_mask=None, want_lse=False):
+    """gd4d_mha_core_fwd.  q (Lq, B, C), k / v (Lk, B, C): each contiguous or a last-dim slice of a packed
+    (L, B, 3C) in-projection buffer.  attn_mask: None, bool/uint8 (Lq, Lk) (nonzero = masked) or float
+    additive (Lq, Lk).  Returns (Lq, B, C) [, lse (Lq, B, heads) with want_lse - what mha_core_bwd needs]."""
+    lib = _lib.load()
+    lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, attn_mask)
+    out = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
+    lse = torch.empty(lq, b, num_heads, device=q.device, dtype=torch.float32) if want_lse else None
     code = lib.gd4d_mha_core_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
                                  ctypes.c_void_p(v.data_ptr()), mptr, _dev(out, 'out'), lq, lk, b,
                                  num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, kind,
-                                 1.0 / (d ** 0.5), _stream())
+                                 1.0 / (d ** 0.5), None if lse is None else _dev(lse, 'lse'), _stream())
     _lib.check(code, 'gd4d_mha_core_fwd')
-    return out
+    return (out, lse) if want_lse else out
+
+
+def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None):
+    """gd4d_mha_core_bwd.  Returns (dq, dk, dv), each (L, B, C) contiguous."""
+    lib = _lib.load()
+    lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, attn_mask)
+    dq = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
+    dk = torch.empty(lk, b, c, device=q.device, dtype=torch.float32)
+    dv = torch.empty(lk, b, c, device=q.device, dtype=torch.float32)
+    dsum = torch.empty(lq, b, num_heads, device=q.device, dtype=torch.float32)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())    # noqa: E731
+    code = lib.gd4d_mha_core_bwd(vp(q), vp(k), vp(v), _dev(out, 'out', torch.float32), _dev(grad_out, 'grad_out', torch.float32),
+                                 mptr, _dev(lse, 'lse', torch.float32), _dev(dsum, 'dsum'), _dev(dq, 'dq'), _dev(dk, 'dk'),
+                                 _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, c, c, c,
+                                 kind, 1.0 / (d ** 0.5), _stream())
+    _lib.check(code, 'gd4d_mha_core_bwd')
+    return dq, dk, dv
+
+
+def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False):
+    """gd4d_layernorm_bwd.  Returns (dx like x, dgamma, dbeta)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    c = x.shape[-1]
+    m = x.numel() // c
+    dx = torch.empty_like(x)
+    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    nbytes = lib.gd4d_layernorm_bwd_workspace_bytes(m, c)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    code = lib.gd4d_layernorm_bwd(_dev(x, 'x', f32), _opt(res, 'res'), _dev(gamma, 'gamma', f32), _opt(beta, 'beta'),
+                                  _dev(grad_y, 'grad_y', f32), _dev(dx, 'dx'), _dev(dg, 'dgamma'), _dev(db, 'dbeta'),
+                                  _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), m, c, float(eps), int(bool(relu)), _stream())
+    _lib.check(code, 'gd4d_layernorm_bwd')
+    return dx, dg, db
 
 
 def refine_reference_fwd(tmp, ref):

@@ -115,15 +115,27 @@ class MultiheadAttention(nn.Module):
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         lq, b, _ = q_in.shape
         lk = k_in.shape[0]
+        qk = qh_lin = kh_lin = None
         if k_in is q_in:                                  # decoder self-attention: one GEMM for q and k
             qk = Fn.linear_autograd(q_in.contiguous(), w[:2 * c], bias[:2 * c])
             qh, kh = qk[..., :c], qk[..., c:]
         else:
-            qh = Fn.linear_autograd(q_in.contiguous(), w[:c], bias[:c])
-            kh = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c])
+            qh = qh_lin = Fn.linear_autograd(q_in.contiguous(), w[:c], bias[:c])
+            kh = kh_lin = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c])
+        vh_lin = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:])
+        if not (self.training and self.attn_drop > 0.) and d == 32 and q_in.dtype == torch.float32 \
+                and (attn_mask is None or attn_mask.dim() == 2):
+            # the attention core with autograd on the HIP kernels (no attention-weight dropout to apply)
+            from .autograd import MhaCoreFunction
+            if k_in is q_in:
+                qm, km = qk[..., :c], qk[..., c:]
+            else:
+                qm, km = qh_lin, kh_lin
+            o = MhaCoreFunction.apply(qm, km, vh_lin, attn_mask, h)
+            return Fn.linear_autograd(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
         qh = qh.reshape(lq, b * h, d).transpose(0, 1)
         kh = kh.reshape(lk, b * h, d).transpose(0, 1)
-        vh = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:]).reshape(lk, b * h, d).transpose(0, 1)
+        vh = vh_lin.reshape(lk, b * h, d).transpose(0, 1)
         scores = torch.bmm(qh * (1.0 / math.sqrt(d)), kh.transpose(1, 2))
         if attn_mask is not None:
             scores = scores.masked_fill(attn_mask, float('-inf')) if attn_mask.dtype == torch.bool \
@@ -249,8 +261,12 @@ class BaseTransformerLayer(nn.Module):
                     skip_norm = False
                 else:
                     norm = self.norms[norm_i]
-                    query = Fn.layer_norm(query, norm) if (query.is_cuda and not Fn.wants_grad(norm, query)) \
-                        else norm(query)
+                    if not query.is_cuda:
+                        query = norm(query)
+                    elif Fn.wants_grad(norm, query):
+                        query = Fn.layer_norm_autograd(query, norm)
+                    else:
+                        query = Fn.layer_norm(query, norm)
                 norm_i += 1
             elif op == 'cross_attn':
                 query = self.attentions[attn_i](

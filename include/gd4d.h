@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 17
+#define GD4D_ABI_VERSION 18
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -239,6 +239,7 @@ int gd4d_value_proj_bwd_weight(const float* grad_out, const void* const* feats, 
 #define GD4D_LIN_RELU 1
 #define GD4D_LIN_INV_SIGMOID_IN 2
 #define GD4D_LIN_RELU_AFTER_LN 4
+#define GD4D_LIN_WEIGHT_KN 8        /* gd4d_linear_fwd: `weight` is (K, N) row-major - y = x W (the input gradient of a Linear whose weight is W) */
 #define GD4D_GEMM_RELU_IN 16       /* gd4d_gemm_bf16x3_fwd: ReLU on the elements of A as they are read */
 int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
                     const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
@@ -343,7 +344,29 @@ int gd4d_small_linear_layernorm_fwd(const float* in, const float* w, const float
  */
 int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask, float* out,
                       int Lq, int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo,
-                      int mask_kind, float scale, void* stream);
+                      int mask_kind, float scale, float* lse, void* stream);
+/* lse: NULL, or (Lq, B, H) fp32 that receives log sum_k exp(scale q k^T + mask) per (query, batch, head) - what
+ * gd4d_mha_core_bwd needs from the forward.
+ *
+ * gd4d_mha_core_bwd - backward of the above (what autograd derives for the bmm / softmax / bmm inside
+ * nn.MultiheadAttention): given dout (gradient of out), dq = scale dS k, dk = scale dS^T q, dv = P^T dout with
+ * P = exp(scale q k^T + mask - lse), dS = P o (dout v^T - Dq), Dq = sum_d dout o.  o = the forward's output, lse = its
+ * saved statistic, dsum = (Lq, B, H) fp32 scratch (receives Dq).  dq / dk / dv: row strides lddq / lddk / lddv, head h
+ * at column offset h*D.  Two launches (a workgroup per 16 queries, then per 16 keys), fixed summation order. */
+int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, const void* mask,
+                      const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq, int Lk, int B, int H, int D,
+                      int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, int mask_kind,
+                      float scale, void* stream);
+
+/* gd4d_layernorm_bwd - backward of gd4d_layernorm_fwd (y = [ReLU] LN(x [+ res]) gamma + beta): dx (also the gradient of
+ * res), dgamma, dbeta from dy; mean / rstd are recomputed from x.  beta is read only with relu != 0 (to rebuild the
+ * sign of the forward's output).  workspace: gd4d_layernorm_bwd_workspace_bytes(M, C) bytes (per-workgroup partial
+ * column sums, added in a fixed order).  C % 4 == 0, C <= 1024.  Replaces ATen's layer_norm_backward kernels behind
+ * the decoder layer's norms and position_encoder (deform3d_cross_attn.py:104-111). */
+size_t gd4d_layernorm_bwd_workspace_bytes(int M, int C);
+int gd4d_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* dy, float* dx,
+                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M, int C, float eps,
+                       int relu, void* stream);
 
 /* gd4d_refine_reference_fwd - reference-point refinement between decoder layers
  * (Detr3DTransformerDecoder.forward, detr3d_transformer.py:201-214):

@@ -127,6 +127,18 @@ def test_transformer_decoder(name):
         os.environ.pop('GD4D_ROWBLOCK')
     torch.testing.assert_close(s3, states, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(r3, refs, rtol=1e-4, atol=1e-4)
+    # the module-by-module path (fp32-exact MFMA products in the dense layers) against the fused decoder loop (row-chain
+    # kernel, split-bf16 products): equal within fp32-class rounding, and both within 1e-3 of the reference
+    os.environ['GD4D_FUSED_DECODER'] = '0'
+    try:
+        with torch.no_grad():
+            s4, i4, r4 = tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
+    finally:
+        os.environ.pop('GD4D_FUSED_DECODER')
+    torch.testing.assert_close(s4, states, rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(r4, refs, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(i4, init_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(s4.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
     torch.cuda.synchronize()
 
 
