@@ -12,9 +12,10 @@ eval mode, batch 1 per GPU - BASELINE.json's metric "6-cam samples/sec through d
 no data-path collective), so scaling is "weak".  Rank 0 prints ONE JSON line.
 
 The JSON line also carries
-  roofline      - the fused sample-aggregate kernel (gd4d_cross_attn_fwd): algorithmic bytes per
-                  launch (SURVEY.md §8d formula, V counted from the kernel's own visibility mask)
-                  / mean launch duration measured with HIP events on the launch stream, vs 8 TB/s
+  roofline      - the step's fused sample-aggregate kernel (gd4d_cross_attn_agg_fwd in the default
+                  aggregate-then-project form, gd4d_cross_attn_fwd with GD4D_PROJECT=early): algorithmic
+                  bytes per launch (SURVEY.md §8d, V counted from the kernel's own visibility mask) / mean
+                  launch duration measured with HIP events on the launch stream, vs 8 TB/s
   cpu_baseline  - the CPU oracle (oracle/torch_oracle.py, a port of the reference path) timed on this
                   box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -490,102 +491,124 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     D.shutdown()
 
 
-def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic):
-    """Re-run the decoder once, intercepting the fused kernel's inputs per layer; then time each
-    layer's launch with HIP events on the launch stream (torch's current stream IS the stream the
-    C ABI launches on) and count V from the kernel's own mask."""
-    from graph_detr4d_amd import functional as Fn
-    captured = []
-    orig = Fn.sample_aggregate
+def _events():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def spy(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=None):
+
+def _time_rounds(calls, rounds):
+    """HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on) around
+    `rounds` x (every call once).  Returns ms per round."""
+    for c in calls:
+        c()
+    e0, e1 = _events()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(rounds):
+        for c in calls:
+            c()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / rounds
+
+
+def _all_visible_inputs(c0, ops):
+    """SURVEY.md 8(d) stress case: every camera is camera 0 and every reference point sits in front of it."""
+    b_, q_ = c0['ref'].shape[0], c0['ref'].shape[1]
+    n_ = c0['l2i'].shape[1]
+    g = torch.Generator().manual_seed(4242)
+    ref_av = torch.rand(b_, q_, 3, generator=g)
+    ref_av[..., 0] = 0.6 + 0.3 * ref_av[..., 0]
+    ref_av[..., 1] = 0.45 + 0.1 * ref_av[..., 1]
+    ref_av[..., 2] = 0.6 + 0.1 * ref_av[..., 2]
+    ref_av = ref_av.to(c0['ref'].device)
+    l2i_av = c0['l2i'][:, :1].expand(-1, n_, -1, -1).contiguous()
+    return ref_av, l2i_av, ops.query_order_fwd(ref_av, c0['pc_range'])
+
+
+def _pmc_traffic(a, source, pattern):
+    """PMC cannot be read from inside the bench: `traffic` comes from a committed rocprofv3 --pmc pass of the kernel on this
+    workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; tools/prof_pmc.sh).  The record carries
+    the sha256 of the kernel source it was measured on; if the source has changed since, the figure is stale and is NOT
+    reported (traffic = null)."""
+    if not (a.queries == 900 and a.frames == 4 and a.levels == 'r50' and a.value_dtype == 'fp32'):
+        return None, None
+    import glob
+    import hashlib
+    src_hash = hashlib.sha256(open(os.path.join(ROOT, 'graph-detr4d_amd', 'csrc', source), 'rb').read()).hexdigest()
+    for pmc_path in sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), reverse=True):
+        pm = json.load(open(pmc_path))
+        if pm.get('kernel_source_sha256') == src_hash:
+            return pm['hbm_read_bytes_per_launch'] + pm['hbm_write_bytes_per_launch'], os.path.relpath(pmc_path, ROOT)
+    return None, f'no committed PMC pass matches the current {source} (sha256 {src_hash[:12]})'
+
+
+def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic):
+    """Re-run the decoder once, intercepting the sample-aggregate inputs of every layer; then time each layer's launch of
+    the step's dominant kernel with HIP events on the launch stream and count V from the kernel's own mask.
+
+    The default step (GD4D_PROJECT=late) aggregates the raw features per head and projects afterwards: its dominant kernel
+    is gd4d_cross_attn_agg_fwd.  With GD4D_PROJECT=early it is gd4d_cross_attn_fwd on projected values.  Whichever runs
+    in the step is `roofline`; the other form is measured on the same inputs and reported under `kernels`."""
+    from graph_detr4d_amd import functional as Fn
+    early_cap, late_cap = [], []
+    orig_early, orig_late = Fn.sample_aggregate, Fn.LateValues.sample_aggregate
+
+    def spy_early(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=None):
         nl_pix = sum(h * w for h, w in shapes)
-        captured.append(dict(head_major=(value.shape[2] == nl_pix and value.shape[1] != nl_pix), value=value, shapes=shapes, ref=ref.contiguous(), offsets=offsets.contiguous(),
-                             attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img,
-                             pc_range=pc_range, img_h=img_h, img_w=img_w, order=order))
-        return orig(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=order)
-    Fn.sample_aggregate = spy
+        early_cap.append(dict(head_major=(value.shape[2] == nl_pix and value.shape[1] != nl_pix), value=value, shapes=shapes,
+                              ref=ref.contiguous(), offsets=offsets.contiguous(), attn=attn_logits.contiguous(),
+                              cam=cam_logits.contiguous(), l2i=lidar2img, pc_range=pc_range, img_h=img_h, img_w=img_w, order=order))
+        return orig_early(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=order)
+
+    def spy_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
+        late_cap.append(dict(cl=self.cl, shapes=self.shapes, module=module, ref=ref.contiguous(), offsets=offsets.contiguous(),
+                             attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img, pc_range=module.pc_range,
+                             img_h=img_h, img_w=img_w, order=order))
+        return orig_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
+    Fn.sample_aggregate, Fn.LateValues.sample_aggregate = spy_early, spy_late
     try:
         with torch.no_grad():
             tr(feats, query_embed, reg_branches=regs, img_metas=metas)
     finally:
-        Fn.sample_aggregate = orig
+        Fn.sample_aggregate, Fn.LateValues.sample_aggregate = orig_early, orig_late
     torch.cuda.synchronize()
-    # Per-launch algorithmic bytes from the kernel's own mask (SURVEY.md section 8d).
-    calls, per_layer, tot_bytes = [], [], 0.0
-    for c in captured:
-        call = (lambda c: (lambda **kw: ops.cross_attn_fwd(c['value'], c['shapes'], c['ref'], c['offsets'], c['attn'],
-                                                           c['cam'], c['l2i'], c['pc_range'], c['img_h'], c['img_w'],
-                                                           head_major=c['head_major'], query_order=c['order'],
-                                                           **kw)))(c)
-        out, mask = call(want_mask=True)
-        b, n, q, hh, p = mask.shape
-        nl = len(c['shapes'])
-        dh = c['value'].shape[-1]
-        es = c['value'].element_size()
-        v = int(mask.sum().item()) * nl                      # visible (cam, query, head, level, point) tuples
-        side = q * (3 + hh * p * 3 + hh * nl * p + n) * 4 + n * 64 + q * hh * dh * 4
-        alg = min(v * 4 * dh * es, c['value'].numel() * es) + side
-        calls.append((call, out))
-        per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg))
-        tot_bytes += alg
-    launches = len(calls)
-    # Timing: HIP events on the launch stream around ROUNDS x (layer 0..L-1) launches.  Rotating through
-    # the layers' value tensors (L x 757 MB >> 256 MB Infinity Cache) keeps every timed launch
-    # cache-cold like in the real decoder step; relaunching one layer's inputs back to back would be
-    # served from the Infinity Cache and read ~15 % too fast (measured: 39.6 vs 46 us).
+    late_mode = bool(late_cap)
+    captured = late_cap if late_mode else early_cap
+    mods = [m for layer in tr.decoder.layers for m in layer.attentions if hasattr(m, 'value_proj')]
+    hh = mods[0].num_heads
+    kernels = {}
     rounds = 20
-    for call, out in calls:
-        call(out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(rounds):
-        for call, out in calls:
-            call(out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    tot_ms = e0.elapsed_time(e1) / rounds                   # ms for one launch of every layer
-    for d in per_layer:
-        d['us_mean'] = tot_ms / launches * 1e3
-    achieved = tot_bytes / tot_ms / 1e6                      # GB/s, mean over the decoder's launches
-    # PMC cannot be read from inside the bench: `traffic` comes from a committed rocprofv3 --pmc pass of this kernel on
-    # this workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; tools/prof_pmc.sh).  The record
-    # carries the sha256 of the kernel source it was measured on; if the source has changed since, the figure is stale
-    # and is NOT reported (traffic = null).
-    traffic, traffic_source = None, None
-    if a.queries == 900 and a.frames == 4 and a.levels == 'r50' and a.value_dtype == 'fp32':
-        import glob
-        import hashlib
-        src_hash = hashlib.sha256(open(os.path.join(ROOT, 'graph-detr4d_amd', 'csrc', 'gd4d_cross_attn.hip'), 'rb').read()).hexdigest()
-        for pmc_path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_cross_attn.json')), reverse=True):
-            pm = json.load(open(pmc_path))
-            if pm.get('kernel_source_sha256') == src_hash:
-                traffic = pm['hbm_read_bytes_per_launch'] + pm['hbm_write_bytes_per_launch']
-                traffic_source = os.path.relpath(pmc_path, ROOT)
-                break
-        if traffic is None:
-            traffic_source = 'no committed PMC pass matches the current gd4d_cross_attn.hip (sha256 ' + src_hash[:12] + ')'
-    roofline = dict(kernel='gd4d::cross_attn_fwd_block (fused project+sample+aggregate)', bound='hbm',
-                    achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot_bytes / launches,
-                    us_per_launch=tot_ms / launches * 1e3, launches_per_step=launches)
-    kernels = {'cross_attn_fwd_per_layer': per_layer}
-    # SURVEY.md 8(d): the "all-visible" stress case next to the real-rig figure - every camera is camera 0 and every
-    # reference point sits in front of it, so all N x Q x Hh x L x P samples are taken (the algorithmic bytes are capped at
-    # the size of the value tensor).  Same kernel, same value tensors (rotated: cache-cold), same clock.
-    try:
-        c0 = captured[0]
-        b_, q_ = c0['ref'].shape[0], c0['ref'].shape[1]
-        n_ = c0['l2i'].shape[1]
-        g = torch.Generator().manual_seed(4242)
-        ref_av = torch.rand(b_, q_, 3, generator=g)
-        ref_av[..., 0] = 0.6 + 0.3 * ref_av[..., 0]
-        ref_av[..., 1] = 0.45 + 0.1 * ref_av[..., 1]
-        ref_av[..., 2] = 0.6 + 0.1 * ref_av[..., 2]
-        ref_av = ref_av.to(c0['ref'].device)
-        l2i_av = c0['l2i'][:, :1].expand(-1, n_, -1, -1).contiguous()
-        order_av = ops.query_order_fwd(ref_av, c0['pc_range'])
+
+    def side_bytes(q, n, nl, p):
+        return q * (3 + hh * p * 3 + hh * nl * p + n) * 4 + n * 64 + q * 256 * 4
+
+    # ---------------- projected-value gather (gd4d_cross_attn_fwd), SURVEY.md 8(d) formula ----------------
+    def measure_early(caps, tag):
+        """caps: per-layer dicts with value / shapes / query-side inputs.  Rotating through the layers' value tensors
+        (L x 757 MB >> 256 MB Infinity Cache) keeps every timed launch cache-cold like in a decoder step."""
+        calls, per_layer, tot = [], [], 0.0
+        for c in caps:
+            call = (lambda c: (lambda **kw: ops.cross_attn_fwd(c['value'], c['shapes'], c['ref'], c['offsets'], c['attn'], c['cam'],
+                                                               c['l2i'], c['pc_range'], c['img_h'], c['img_w'],
+                                                               head_major=c['head_major'], query_order=c['order'], **kw)))(c)
+            out, mask = call(want_mask=True)
+            b, n, q, _, p = mask.shape
+            nl = len(c['shapes'])
+            dh, es = c['value'].shape[-1], c['value'].element_size()
+            v = int(mask.sum().item()) * nl                  # visible (cam, query, head, level, point) tuples
+            alg = min(v * 4 * dh * es, c['value'].numel() * es) + side_bytes(q, n, nl, p)
+            calls.append((lambda call, out: (lambda: call(out=out)))(call, out))
+            per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg))
+            tot += alg
+        ms = _time_rounds(calls, rounds)
+        for d in per_layer:
+            d['us_mean'] = ms / len(calls) * 1e3
+        return dict(per_layer=per_layer, alg_bytes_per_launch=tot / len(calls), us_per_launch=ms / len(calls) * 1e3,
+                    gbs=tot / ms / 1e6, frac=tot / ms / 1e6 / HBM_PEAK_GBS, launches=len(calls))
+
+    def early_all_visible(caps):
+        c0 = caps[0]
+        ref_av, l2i_av, order_av = _all_visible_inputs(c0, ops)
         run_av = lambda c, **kw: ops.cross_attn_fwd(c['value'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'],   # noqa: E731
                                                     l2i_av, c['pc_range'], c['img_h'], c['img_w'], head_major=c['head_major'],
                                                     query_order=order_av, **kw)
@@ -593,31 +616,117 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
         nl_ = len(c0['shapes'])
         v_av = int(mask_av.sum().item()) * nl_
         es_ = c0['value'].element_size()
-        side_ = q_ * (3 + mask_av.shape[3] * mask_av.shape[4] * 3 + mask_av.shape[3] * nl_ * mask_av.shape[4] + n_) * 4 + n_ * 64 \
-            + q_ * 256 * 4
-        alg_av = min(v_av * 4 * c0['value'].shape[-1] * es_, c0['value'].numel() * es_) + side_
-        for c in captured:
-            run_av(c, out=out_av)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(5):
-            for c in captured:
-                run_av(c, out=out_av)
-        e1.record()
-        torch.cuda.synchronize()
-        us_av = e0.elapsed_time(e1) / (5 * len(captured)) * 1e3
-        kernels['cross_attn_fwd_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
-                                                     us_per_launch=us_av, gbs=alg_av / us_av / 1e3,
-                                                     frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS)
-    except Exception as e:                                    # secondary figure: report, never fail the bench line
-        kernels['cross_attn_fwd_all_visible'] = {'error': f'{type(e).__name__}: {e}'}
-    # The other large kernel of a step, reported beside the headline roofline: value_proj, launched as the decoder launches
-    # it (one multi-layer launch per group of layers, all CUs), HIP events on the launch stream.  Algorithmic bytes of a
-    # launch: the pyramid read once + one value tensor written per layer; flops: 2 * rows * 256 * 256 per layer (x3 on the
-    # matrix pipe: split-bf16).
+        alg_av = min(v_av * 4 * c0['value'].shape[-1] * es_, c0['value'].numel() * es_) + \
+            side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
+        ms = _time_rounds([(lambda c: (lambda: run_av(c, out=out_av)))(c) for c in caps], 5)
+        us_av = ms / len(caps) * 1e3
+        return dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av, us_per_launch=us_av,
+                    gbs=alg_av / us_av / 1e3, frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS)
+
+    if not late_mode:
+        e = measure_early(early_cap, 'early')
+        traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn.hip', 'r*_pmc_cross_attn.json')
+        roofline = dict(kernel='gd4d::cross_attn_fwd_block (fused project+sample+aggregate on projected values)', bound='hbm',
+                        achieved=e['gbs'], peak=HBM_PEAK_GBS, unit='GB/s', frac=e['frac'], traffic=traffic,
+                        traffic_source=traffic_source, alg_bytes_per_launch=e['alg_bytes_per_launch'],
+                        us_per_launch=e['us_per_launch'], launches_per_step=e['launches'])
+        kernels['cross_attn_fwd_per_layer'] = e['per_layer']
+        try:
+            kernels['cross_attn_fwd_all_visible'] = early_all_visible(early_cap)
+        except Exception as ex:                               # secondary figure: report, never fail the bench line
+            kernels['cross_attn_fwd_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
+    else:
+        # ---------------- aggregate-then-project: gd4d_cross_attn_agg_fwd ----------------
+        # Algorithmic bytes of a launch: SURVEY.md 8(d) with the bytes this formulation reads per corner - all C channels
+        # of the pixel (what 8(d) itself writes for the kernels that gather whole pixels, a9 / a10: V' * 4 * C * e) - and
+        # 8(d)'s cap: "if V-bytes exceed the map size, cap at map bytes" (every touched byte read once).  At the headline
+        # size V * 4 * C * 4 = 2.0 GB > the 757-MB pyramid, so the figure is the pyramid + the query-side terms + the
+        # aggregates written.  The 8(d) figure of the projected-value form (V * 4 * Dh * e, 245 MB) is reported beside it.
+        calls, per_layer, tot, tot_dh = [], [], 0.0, 0.0
+        for c in late_cap:
+            run = (lambda c: (lambda **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], c['ref'], c['offsets'], c['attn'], c['cam'],
+                                                                  c['l2i'], c['pc_range'], c['img_h'], c['img_w'], hh,
+                                                                  query_order=c['order'], **kw)))(c)
+            _, _, mask = run(want_mask=True)
+            b, n, q, _, p = mask.shape
+            nl = len(c['shapes'])
+            v = int(mask.sum().item()) * nl
+            side = side_bytes(q, n, nl, p) + q * hh * 256 * 4 + q * hh * 4      # + agg and wsum written
+            alg = min(v * 4 * 256 * 4, c['cl'].numel() * 4) + side
+            calls.append(run)
+            per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg, corner_bytes=v * 4 * 256 * 4,
+                                  alg_bytes_projected_value_form=min(v * 4 * (256 // hh) * 4, c['cl'].numel() * 4) + side_bytes(q, n, nl, p)))
+            tot += alg
+            tot_dh += per_layer[-1]['alg_bytes_projected_value_form']
+        ms = _time_rounds(calls, rounds)
+        launches = len(calls)
+        for d in per_layer:
+            d['us_mean'] = ms / launches * 1e3
+        traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn_late.hip', 'r*_pmc_cross_attn_agg.json')
+        roofline = dict(kernel='gd4d::cross_attn_agg_kernel (fused project + sample + per-head aggregate of raw features)',
+                        bound='hbm', achieved=tot / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=tot / ms / 1e6 / HBM_PEAK_GBS,
+                        traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot / launches,
+                        us_per_launch=ms / launches * 1e3, launches_per_step=launches,
+                        alg_bytes_rule='SURVEY 8(d) with C channels per corner, capped at the pyramid size (757 MB at the headline size)',
+                        frac_on_projected_value_form_bytes=tot_dh / ms / 1e6 / HBM_PEAK_GBS)
+        kernels['cross_attn_agg_per_layer'] = per_layer
+        with torch.no_grad():
+            # the two small kernels around it: the channels-last copy (once per sample) and value_proj of the aggregates
+            try:
+                cl = late_cap[0]['cl']
+                vals = [f.contiguous() for f in feats]
+                ms_cl = _time_rounds([lambda: ops.pyramid_channels_last_fwd(vals, out=cl)], 5)
+                kernels['pyramid_channels_last'] = dict(us=ms_cl * 1e3, bytes=2 * cl.numel() * 4, gbs=2 * cl.numel() * 4 / ms_cl / 1e6,
+                                                        frac=2 * cl.numel() * 4 / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1)
+                c0 = late_cap[0]
+                agg0, wsum0 = calls[0]()
+                m0 = c0['module']
+                ms_hp = _time_rounds([lambda: ops.value_proj_heads_fwd(agg0, wsum0, m0.value_proj.weight, m0.value_proj.bias)], 20)
+                kernels['value_proj_heads'] = dict(us=ms_hp * 1e3, launches_per_step=launches)
+            except Exception as ex:
+                kernels['pyramid_channels_last'] = {'error': f'{type(ex).__name__}: {ex}'}
+            # all-visible stress case of this kernel (8 x the bytes of the projected-value form per corner: its worst case)
+            try:
+                c0 = late_cap[0]
+                ref_av, l2i_av, order_av = _all_visible_inputs(c0, ops)
+                run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731
+                                                                c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av, **kw)
+                _, _, mask_av = run_av(c0, want_mask=True)
+                nl_ = len(c0['shapes'])
+                v_av = int(mask_av.sum().item()) * nl_
+                alg_av = min(v_av * 4 * 256 * 4, c0['cl'].numel() * 4) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
+                ms_av = _time_rounds([(lambda c: (lambda: run_av(c)))(c) for c in late_cap], 3)
+                us_av = ms_av / len(late_cap) * 1e3
+                kernels['cross_attn_agg_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
+                                                             corner_bytes=v_av * 4 * 256 * 4, us_per_launch=us_av,
+                                                             gbs=alg_av / us_av / 1e3, frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS,
+                                                             l2_level_gbs=v_av * 4 * 256 * 4 / us_av / 1e3)
+            except Exception as ex:
+                kernels['cross_attn_agg_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
+            # the projected-value form on the same query-side inputs (not part of the step): value_proj for every layer,
+            # then gd4d_cross_attn_fwd - SURVEY 8(d)'s own formula
+            try:
+                hm = Fn.use_head_major(mods[0].value_dtype)
+                vals = [f.contiguous() for f in feats]
+                proj = ops.value_proj_multi_fwd(vals, [m.value_proj.weight for m in mods], [m.value_proj.bias for m in mods],
+                                                mods[0].value_dtype, num_heads=hh, head_major=hm)
+                caps = []
+                for c, v in zip(late_cap, proj):
+                    bn = v.shape[0]
+                    caps.append(dict(c, value=(v if hm else v.view(bn, -1, hh, 256 // hh)), head_major=hm))
+                e = measure_early(caps, 'early')
+                kernels['cross_attn_fwd_projected_values'] = dict(
+                    note='gd4d_cross_attn_fwd on projected values (GD4D_PROJECT=early), same query-side inputs; not in the step',
+                    alg_bytes_per_launch=e['alg_bytes_per_launch'], us_per_launch=e['us_per_launch'], gbs=e['gbs'], frac=e['frac'])
+                kernels['cross_attn_fwd_projected_values_all_visible'] = early_all_visible(caps)
+                del proj, caps
+            except Exception as ex:
+                kernels['cross_attn_fwd_projected_values'] = {'error': f'{type(ex).__name__}: {ex}'}
+    # value_proj over the pyramid (the early path's other large kernel; the training step uses it): launched as the decoder
+    # launches it (one multi-layer launch per group of layers, all CUs), HIP events on the launch stream.  Algorithmic bytes
+    # of a launch: the pyramid read once + one value tensor written per layer; flops: 2 * rows * 256 * 256 per layer (x3 on
+    # the matrix pipe: split-bf16).
     try:
-        from graph_detr4d_amd import functional as Fn
-        mods = [m for layer in tr.decoder.layers for m in layer.attentions if hasattr(m, 'value_proj')]
         vals = [f.contiguous() for f in feats]
         groups = Fn.pipeline_groups(os.environ.get('GD4D_PREPROJECT', 'auto'), len(mods)) or (len(mods),)
         hm = Fn.use_head_major(mods[0].value_dtype)
@@ -632,27 +741,23 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
             lo += g_
         with torch.no_grad():
             outs0 = run(mods[bounds[0][0]:bounds[0][1]])
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(3):
-                for a_, b_ in bounds:
-                    run(mods[a_:b_])
-            e1.record()
-            torch.cuda.synchronize()
-        us_all = e0.elapsed_time(e1) / 3 * 1e3                 # all layers of the decoder
+            ms_all = _time_rounds([(lambda a_, b_: (lambda: run(mods[a_:b_])))(a_, b_) for a_, b_ in bounds], 3)
+        us_all = ms_all * 1e3                                  # all layers of the decoder
         rd = sum(f.numel() * f.element_size() for f in vals)
         wr = outs0[0].numel() * outs0[0].element_size()
         rows = rd // (256 * 4)
         fl = 2.0 * rows * 256 * 256
         alg = len(bounds) * rd + len(mods) * wr
-        kernels['value_proj_fwd'] = dict(layer_groups=list(groups), us_all_layers=us_all, us_per_layer=us_all / len(mods),
+        kernels['value_proj_fwd'] = dict(in_step=not late_mode, layer_groups=list(groups), us_all_layers=us_all,
+                                         us_per_layer=us_all / len(mods),
                                          alg_bytes_all_layers=alg, hbm_gbs=alg / us_all / 1e3,
                                          hbm_frac=alg / us_all / 1e3 / HBM_PEAK_GBS,
                                          gflop_per_layer=fl / 1e9, mfma_tflops_x3=3 * fl * len(mods) / us_all / 1e6,
                                          mfma_frac_of_2500=3 * fl * len(mods) / us_all / 1e6 / 2500.0,
-                                         launches_per_step=len(bounds),
+                                         launches_per_step=len(bounds) if not late_mode else 0,
                                          note='bounded by the sustained (power-limited) matrix rate and the HBM write rate '
                                               'together: profiles/r02_value_proj.md')
+        del outs0
     except Exception as e:                                    # secondary figure: report, never fail the bench line
         kernels['value_proj_fwd'] = {'error': f'{type(e).__name__}: {e}'}
     return roofline, kernels

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void value_proj_astat_kernel(const V
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31;           // MFMA column = this lane's pixel inside the tile
   const int kg = lane >> 5;            // which 8 of the 16 k of a step this lane holds
+  const int burst_s = (wave & 3) * 2 + (wave >> 2) * 8;      // dev (DBG & 128): the k-step of this wave's store burst
   const bool odd_wave = wave >= WAVES / 2;   // waves w and w + WAVES/2 share a SIMD: they get opposite k-step parities
   // LDS byte addresses inside this wave's patch: where this lane parks its quads, and where it picks up a line piece
   const unsigned patch = (unsigned)(VA_RING * CHUNK + p.NL * VA_C * 4 + wave * (VA_TILE * PITCH));
@@ -290,9 +291,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void value_proj_astat_kernel(const V
       unsigned long long tt0 = 0, tt1 = 0;
       if (DBG & 16) tt0 = __builtin_amdgcn_s_memtime();
       // my pieces of this chunk were issued at the start of the previous phase; a steady wave issued exactly 4 stores since
-      if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (DBG & 128) { if (steady && wave >= WAVES / 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      else if (DBG & 64) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // dev: free-running waves (no barrier)
+      else if ((DBG & 32) && steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                            // chunk complete in SLOT; the other slot is free for the DMA
+      if (!(DBG & 64)) __builtin_amdgcn_s_barrier();           // chunk complete in SLOT; the other slot is free for the DMA
       asm volatile("" ::: "memory");
       if (DBG & 16) tt1 = __builtin_amdgcn_s_memtime();
       const int nc = c + 1 == P ? 0 : c + 1;                   // next chunk of the (periodic) stream
@@ -309,6 +313,79 @@ __global__ __launch_bounds__(64 * WAVES, 2) void value_proj_astat_kernel(const V
         }
         have_prev = false;
         steady = 0;
+        return;
+      }
+      if (DBG & 32) {
+        // dev experiment: ROLE SPLIT.  Waves 0 .. WAVES/2-1 (one per SIMD) run the matrix work of TWO tiles and never
+        // touch global memory; their SIMD partners issue all of the workgroup's DMA pieces and stores (same bytes, same
+        // instruction counts per workgroup and phase as the production kernel; results are garbage).
+        const char* wb2 = smem + SLOT * CHUNK;
+        if (wave < WAVES / 2) {
+          for (int rep = 0; rep < 2; ++rep) {
+            u32x4 xh[2], xl[2];
+            xh[0] = *reinterpret_cast<const u32x4*>(wb2 + lane * 16);
+            xl[0] = *reinterpret_cast<const u32x4*>(wb2 + 1024 + lane * 16);
+#pragma unroll
+            for (int s = 0; s < VA_KSTEPS; ++s) {
+              if (s + 1 < VA_KSTEPS) {
+                xh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(wb2 + ((s + 1) * PARTS) * 1024 + lane * 16);
+                xl[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(wb2 + ((s + 1) * PARTS + 1) * 1024 + lane * 16);
+              }
+              cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(xh[s & 1]), va_frag(ahi[s]), cur, 0, 0, 0);
+              cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(xh[s & 1]), va_frag(alo[s]), cur, 0, 0, 0);
+              cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(xl[s & 1]), va_frag(ahi[s]), cur, 0, 0, 0);
+            }
+            typedef __attribute__((ext_vector_type(4))) float f32x4;
+            f32x4 q0 = {cur[0], cur[1], cur[2], cur[3]}, q1 = {cur[4], cur[5], cur[6], cur[7]};
+            f32x4 q2 = {cur[8], cur[9], cur[10], cur[11]}, q3 = {cur[12], cur[13], cur[14], cur[15]};
+            const unsigned wa = st_w + rep * (WAVES / 2) * (VA_TILE * PITCH);     // own patch, then the partner's
+            asm volatile("ds_write_b128 %4, %0\n\tds_write_b128 %4, %1 offset:32\n\tds_write_b128 %4, %2 offset:64\n\t"
+                         "ds_write_b128 %4, %3 offset:96" :: "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(wa) : "memory");
+          }
+        } else {
+          if (more) {
+#pragma unroll
+            for (int i = 0; i < 2 * PIECES; ++i) {
+              const int piece = (wave - WAVES / 2) + i * (WAVES / 2);
+              unsigned lo = lane16;
+              asm volatile("" : "+v"(lo));
+              __builtin_amdgcn_global_load_lds((glb_void_t*)(p.wimg + (size_t)nc * CHUNK + piece * 1024 + lo),
+                                               (lds_void_t*)(smem + (SLOT ^ 1) * CHUNK + piece * 1024), 16, 0, 0);
+            }
+          }
+          if (have_prev) {
+            for (int rep = 0; rep < 2; ++rep) {
+              typedef __attribute__((ext_vector_type(4))) float f32x4;
+              f32x4 q0, q1, q2, q3;
+              const unsigned ra = st_r - rep * (WAVES / 2) * (VA_TILE * PITCH);
+              asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\t"
+                           "ds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                           : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3)
+                           : "v"(ra), "n"(8 * PITCH), "n"(16 * PITCH), "n"(24 * PITCH) : "memory");
+              old[0] = q0[0]; old[1] = q0[1]; old[2] = q0[2]; old[3] = q0[3];
+              old[4] = q1[0]; old[5] = q1[1]; old[6] = q1[2]; old[7] = q1[3];
+              old[8] = q2[0]; old[9] = q2[1]; old[10] = q2[2]; old[11] = q2[3];
+              old[12] = q3[0]; old[13] = q3[1]; old[14] = q3[2]; old[15] = q3[3];
+              char* keep = prev_out;
+              if (rep) prev_out -= (size_t)(WAVES / 2) * VA_TILE * VA_C * 4;
+#pragma unroll
+              for (int m = 0; m < 4; ++m) store_group(old, m);
+              prev_out = keep;
+            }
+          }
+        }
+        steady = 0;
+        if (wave >= WAVES / 2) steady = more && have_prev && prev_valid >= VA_TILE && !(DBG & 1);
+        have_prev = true;
+        {
+          const int layer = c >> 3, cb = c & 7;
+          void* outp = p.out[0];
+#pragma unroll
+          for (int l = 1; l < GD4D_MAX_LAYERS; ++l)
+            if (l == layer) outp = p.out[l];
+          prev_out = static_cast<char*>(outp) + (tile_elem + 32 * cb) * 4;
+          prev_valid = valid;
+        }
         return;
       }
       const char* wb = smem + SLOT * CHUNK;
@@ -334,11 +411,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void value_proj_astat_kernel(const V
           wh[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(wb + ((s + 1) * PARTS) * 1024 + lane * 16);
           if (!SINGLE) wl[(s + 1) & 1] = *reinterpret_cast<const u32x4*>(wb + ((s + 1) * PARTS + 1) * 1024 + lane * 16);
         }
+        if (DBG & 128) {                                       // dev: one wave at a time pushes its 4 stores as a burst
+          if (s >= STAG && ((s - STAG) & 1) == 0) {
+            const int j = (s - STAG) >> 1;
+            if (j < PIECES) { if (more) issue_piece(nc, SLOT ^ 1, j); }
+          }
+          if (s == burst_s && stores_now) {
+            transpose_prev(old);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) store_group(old, m);
+          }
+        } else {
         if (s == 2 * PIECES + STAG - 1) { if (stores_now) transpose_prev(old); }    // between the pieces and the stores
         if (s >= STAG && ((s - STAG) & 1) == 0) {              // this wave's memory instruction of the k-step, if any
           const int j = (s - STAG) >> 1;
           if (j < PIECES) { if (more) issue_piece(nc, SLOT ^ 1, j); }                // pieces FIRST in the queue,
           else if (j < NOPS) { if (stores_now) store_group(old, j - PIECES); }       // then the stores
+        }
         }
         if (DBG & 2) { asm volatile("" ::"v"(wh[s & 1]), "v"(wl[s & 1]), "v"(ahi[s]), "v"(alo[s])); continue; }
         cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_frag(wh[s & 1]), va_frag(ahi[s]), cur, 0, 0, 0);
@@ -491,6 +580,15 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
       case 12: go(value_proj_astat_kernel<8, false, false, false, 12>); break;
       case 16: go(value_proj_astat_kernel<8, false, false, false, 16>); break;
       case 17: go(value_proj_astat_kernel<8, false, false, false, 17>); break;
+      case 76: go(value_proj_astat_kernel<8, false, false, false, 76>); break;   /* MFMA + stores, free-running */
+      case 72: go(value_proj_astat_kernel<8, false, false, false, 72>); break;   /* + fragment reads */
+      case 78: go(value_proj_astat_kernel<8, false, false, false, 78>); break;   /* stores only, free-running */
+      case 77: go(value_proj_astat_kernel<8, false, false, false, 77>); break;   /* MFMA only, free-running */
+      case 128: go(value_proj_astat_kernel<8, false, false, false, 128>); break;   /* full, staggered store bursts */
+      case 140: go(value_proj_astat_kernel<8, false, false, false, 140>); break;   /* MFMA + staggered store bursts */
+      case 136: go(value_proj_astat_kernel<8, false, false, false, 136>); break;   /* + fragment reads */
+      case 32: go(value_proj_astat_kernel<8, false, false, false, 32>); break;
+      case 33: go(value_proj_astat_kernel<8, false, false, false, 33>); break;
       default: go(value_proj_astat_kernel<8, false, false, false, 0>); break;
     }
     return check_launch();

@@ -141,26 +141,38 @@ class Deform3DCrossAttn(nn.Module):
         offsets = offsets.view(b, q, hh, npt, 3)
         attn_logits = attn_logits.view(b, q, hh, nl, npt)
 
-        pipeline = kwargs.get(Fn.VALUE_PIPELINE_KEY)
-        taken = pipeline.take(self, value) if pipeline is not None else None
-        cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
-        if taken is not None:
-            val, shapes = taken                      # projected on the side stream underneath the previous layer
-        elif cached is not None and cached[2] is value:
-            val, shapes = cached[0], cached[1]       # projected by the decoder for all layers at once
-        else:
-            val, shapes = Fn.value_projection(value, self.value_proj.weight, self.value_proj.bias,
-                                              hh, self.value_dtype)
         lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
         order = kwargs.get(Fn.QUERY_ORDER_KEY)
         if order is None or order.numel() != b * q:
             order = Fn.query_order(reference_points, self.pc_range)
-        agg = Fn.sample_aggregate(val, shapes, reference_points, offsets, attn_logits, cam_logits,
-                                  lidar2img, self.pc_range, img_h, img_w, order=order)    # (B, Q, C)
-        if taken is not None:
-            del val, taken
-            pipeline.gather_enqueued(self)
+        pipeline = kwargs.get(Fn.VALUE_PIPELINE_KEY)
+        taken = pipeline.take(self, value) if pipeline is not None else None
+        cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
+        late = kwargs.get(Fn.LATE_VALUES_KEY)
+        if late is not None and late.value is not value:
+            late = None
+        if late is None and taken is None and (cached is None or cached[2] is not value) \
+                and Fn.LateValues.applicable([self], value):
+            late = Fn.LateValues(value)              # a stand-alone call: its own channels-last copy
+        if late is not None:
+            # aggregate-then-project (csrc/gd4d_cross_attn_late.hip): raw features gathered per head, value_proj applied
+            # to the Q x Hh aggregates - no projected value tensor
+            agg = late.sample_aggregate(self, reference_points, offsets, attn_logits, cam_logits, lidar2img,
+                                        img_h, img_w, order=order)                        # (B, Q, C)
+        else:
+            if taken is not None:
+                val, shapes = taken                  # projected on the side stream underneath the previous layer
+            elif cached is not None and cached[2] is value:
+                val, shapes = cached[0], cached[1]   # projected by the decoder for all layers at once
+            else:
+                val, shapes = Fn.value_projection(value, self.value_proj.weight, self.value_proj.bias,
+                                                  hh, self.value_dtype)
+            agg = Fn.sample_aggregate(val, shapes, reference_points, offsets, attn_logits, cam_logits,
+                                      lidar2img, self.pc_range, img_h, img_w, order=order)    # (B, Q, C)
+            if taken is not None:
+                del val, taken
+                pipeline.gather_enqueued(self)
 
         if ev_pos is None:
             pos_feat = self._position_features(reference_points)         # (B, Q, C)

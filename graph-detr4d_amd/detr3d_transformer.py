@@ -253,20 +253,36 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
     def forward(self, query, *args, reference_points=None, reg_branches=None, **kwargs):
         output = query
         intermediate, intermediate_reference_points = [], []
-        kwargs, pipeline = self._preproject_values(kwargs)
-        kwargs = self._order_queries(kwargs, reference_points)
         from . import fused_decoder
-        if not args and kwargs.get('key') is None and kwargs.get('query_pos') is not None and 'img_metas' in kwargs \
-                and kwargs.get('key_padding_mask') is None and kwargs.get('query_key_padding_mask') is None \
-                and fused_decoder.applicable(self, query, kwargs.get('value'), reference_points, reg_branches,
-                                             kwargs.get('attn_masks')):
+        fused = not args and kwargs.get('key') is None and kwargs.get('query_pos') is not None and 'img_metas' in kwargs \
+            and kwargs.get('key_padding_mask') is None and kwargs.get('query_key_padding_mask') is None \
+            and fused_decoder.applicable(self, query, kwargs.get('value'), reference_points, reg_branches,
+                                         kwargs.get('attn_masks'))
+        late, own_late, pipeline = kwargs.get(Fn.LATE_VALUES_KEY), False, None
+        if late is not None and late.value is not kwargs.get('value'):
+            late = None
+        cross = [a for layer in self.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
+        if late is None and kwargs.get(Fn.VALUE_CACHE_KEY) is None and cross \
+                and all(type(a) is Deform3DCrossAttn for a in cross) and isinstance(kwargs.get('value'), (list, tuple)) \
+                and Fn.LateValues.applicable(cross, kwargs['value']) and not Fn.wants_grad(self, query, *kwargs['value']):
+            # aggregate-then-project (GD4D_PROJECT=late, default): no per-layer value tensors, ONE channels-last copy of
+            # the pyramid for all layers (made on the side stream next to layer 0's self-attention)
+            late, own_late = Fn.LateValues(kwargs['value']), True
+            kwargs = dict(kwargs)
+            kwargs[Fn.LATE_VALUES_KEY] = late
+        if late is None:
+            kwargs, pipeline = self._preproject_values(kwargs)
+        kwargs = self._order_queries(kwargs, reference_points)
+        if fused:
             # every layer is the post-norm (self-attention, Deform3DCrossAttn, FFN) layer: 4 launches per layer
             outs, refs = fused_decoder.run(
                 self, query, kwargs['query_pos'], kwargs['value'], reference_points, reg_branches,
                 kwargs['img_metas'], kwargs.get('attn_masks'), pipeline, kwargs.get(Fn.VALUE_CACHE_KEY),
-                kwargs.get(Fn.QUERY_ORDER_KEY), getattr(self, '_order_pc_range', None), self.return_intermediate)
+                kwargs.get(Fn.QUERY_ORDER_KEY), getattr(self, '_order_pc_range', None), self.return_intermediate, late=late)
             if pipeline is not None:
                 pipeline.finish()
+            if own_late:
+                late.finish()
             if self.return_intermediate:
                 return outs, refs
             return outs[0], refs[0]
@@ -314,6 +330,8 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                 intermediate_reference_points.append(reference_points)
         if pipeline is not None:
             pipeline.finish()
+        if own_late:
+            late.finish()
         if aux is not None:
             torch.cuda.current_stream(output.device).wait_stream(aux)
         if self.return_intermediate:
@@ -383,6 +401,14 @@ class Detr3DTransformer(nn.Module):
             share = all(m.value_proj.bias is not None and m.value_dtype == torch.float32 for m in mods) and \
                 mlvl_feats[0].shape[0] == 1 and all(v.dtype == torch.float32 for v in mlvl_feats)
             cache = Fn.project_values_for_layers_autograd(mods, mlvl_feats) if share else None
+        elif share and Fn.LateValues.applicable(mods, mlvl_feats):
+            # inference, aggregate-then-project: what the passes share is the channels-last copy of the pyramid
+            Fn.require_inference(*mlvl_feats)
+            late = Fn.LateValues(mlvl_feats)
+            outs = [self.forward(mlvl_feats, qe, reg_branches=reg_branches, **{Fn.LATE_VALUES_KEY: late}, **kwargs)
+                    for qe in query_embeds]
+            late.finish()
+            return outs
         elif share:
             Fn.require_inference(*mlvl_feats)
             cache = Fn.project_values_for_layers(mods, mlvl_feats)

@@ -405,6 +405,59 @@ class ValuePipeline:
         self.ready.clear()
 
 
+LATE_VALUES_KEY = '_gd4d_late_values'
+
+
+class LateValues:
+    """The aggregate-then-project form of the value path (csrc/gd4d_cross_attn_late.hip): ONE channels-last copy of the
+    pyramid for all decoder layers (the reference's flatten / transpose / cat, deform3d_cross_attn.py:264-276), made on the
+    side stream next to layer 0's self-attention; every layer then gathers raw features per head (ops.cross_attn_agg_fwd)
+    and applies its value_proj to the 900 x Hh aggregates (ops.value_proj_heads_fwd) instead of to 739 800 pixel rows.
+    GD4D_PROJECT=early keeps the projected-value path (value_proj kernel + gd4d_cross_attn_fwd)."""
+
+    def __init__(self, value):
+        dev = value[0].device
+        self.value = value
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _SIDE_STREAMS.get(dev.index)
+        if self.side is None:
+            self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
+        with torch.cuda.stream(self.side):
+            self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value])
+            self.event = torch.cuda.Event()
+            self.event.record(self.side)
+        self.waited = set()
+
+    @staticmethod
+    def applicable(modules, value):
+        if os.environ.get('GD4D_PROJECT', 'late') != 'late' or not modules or not isinstance(value, (list, tuple)):
+            return False
+        if any(v.dim() != 5 or v.shape[0] != 1 or v.dtype != torch.float32 or not v.is_cuda or v.shape[2] != 256 for v in value):
+            return False
+        rows = value[0].shape[1]
+        if rows > 64 or len(value) > 4 or rows * sum(v.shape[-1] * v.shape[-2] for v in value) >= 2 ** 31:
+            return False
+        return all(m.value_dtype == torch.float32 and m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
+                   and m.num_levels == len(value) and m.num_cams == rows for m in modules)
+
+    def sample_aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
+        """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of output_proj."""
+        cur = torch.cuda.current_stream(self.cl.device)
+        if cur.cuda_stream not in self.waited:
+            cur.wait_event(self.event)
+            self.waited.add(cur.cuda_stream)
+        agg, wsum = ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
+                                           cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
+                                           module.num_heads, query_order=order)
+        bias = module.value_proj.bias
+        return ops.value_proj_heads_fwd(agg, wsum, module.value_proj.weight.contiguous(),
+                                        None if bias is None else bias.contiguous())
+
+    def finish(self):
+        self.main.wait_stream(self.side)             # join (keeps a graph capture well-formed)
+
+
 def pipeline_groups(spec, n):
     """GD4D_PREPROJECT: 'auto' -> groups of two layers; 'stream' -> n single layers; 'g3,3' / 'g2,2,2' / ... -> those group sizes (they must add up to
     the number of layers, else the spec is ignored: None)."""

@@ -116,7 +116,7 @@ def _position_features(ca, reference_points, q):
 
 
 def run(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, pipeline, value_cache,
-        order, order_pc_range, return_intermediate):
+        order, order_pc_range, return_intermediate, late=None):
     """query / query_pos (Q, 1, C), rows may be strided; reference_points (1, Q, 3).  Returns the stacked per-layer
     outputs (NL, Q, 1, C) and reference points (NL, 1, Q, 3) (the last layer's only without return_intermediate)."""
     q, _, c = query.shape
@@ -182,24 +182,29 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                 ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
         ops.row_chain_fwd(prog, q)
 
-        # projected values of this layer
-        taken = pipeline.take(ca, value) if pipeline is not None else None
-        cached = (value_cache or {}).get(id(ca))
-        if taken is not None:
-            val, shapes = taken
-        elif cached is not None and cached[2] is value:
-            val, shapes = cached[0], cached[1]
-        else:
-            val, shapes = Fn.value_projection(value, ca.value_proj.weight, ca.value_proj.bias, hh, ca.value_dtype)
         if ref_event is not None:
             main.wait_event(ref_event)
         if order is None or order.numel() != q:
             order = Fn.query_order(ref, ca.pc_range)
-        agg = Fn.sample_aggregate(val, shapes, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam,
-                                  lidar2img, ca.pc_range, img_h, img_w, order=order)
-        if taken is not None:
-            del val, taken
-            pipeline.gather_enqueued(ca)
+        if late is not None:
+            # aggregate-then-project: gather the raw features per head, apply value_proj to the aggregates
+            agg = late.sample_aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                        img_h, img_w, order=order)
+        else:
+            # projected values of this layer
+            taken = pipeline.take(ca, value) if pipeline is not None else None
+            cached = (value_cache or {}).get(id(ca))
+            if taken is not None:
+                val, shapes = taken
+            elif cached is not None and cached[2] is value:
+                val, shapes = cached[0], cached[1]
+            else:
+                val, shapes = Fn.value_projection(value, ca.value_proj.weight, ca.value_proj.bias, hh, ca.value_dtype)
+            agg = Fn.sample_aggregate(val, shapes, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam,
+                                      lidar2img, ca.pc_range, img_h, img_w, order=order)
+            if taken is not None:
+                del val, taken
+                pipeline.gather_enqueued(ca)
 
         # chain B
         if ev_pos is not None:

@@ -76,6 +76,76 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
     return res if len(res) > 1 else out
 
 
+def pyramid_channels_last_fwd(feats, out=None):
+    """gd4d_pyramid_channels_last_fwd.  feats: list of L tensors (R, 256, H_l, W_l) fp32 (or (B, N, 256, H, W)).
+    Returns (cl (R, S, 256) fp32, level_hw)."""
+    lib = _lib.load()
+    fl = [f.reshape(-1, *f.shape[-3:]) for f in feats]
+    r, c = fl[0].shape[0], fl[0].shape[1]
+    level_hw = [(int(f.shape[-2]), int(f.shape[-1])) for f in fl]
+    s = sum(h * w for h, w in level_hw)
+    if any(f.shape[0] != r or f.shape[1] != c for f in fl):
+        raise ValueError('feature levels disagree in rows / channels')
+    if out is None:
+        out = torch.empty(r, s, c, device=fl[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * len(fl))(*[_dev(f, 'feats', torch.float32).value for f in fl])
+    lv = (ctypes.c_int32 * (2 * len(fl)))(*[int(x) for hw in level_hw for x in hw])
+    code = lib.gd4d_pyramid_channels_last_fwd(ptrs, lv, _dev(out, 'out', torch.float32), r, c, len(fl), _lib.F32, _stream())
+    _lib.check(code, 'gd4d_pyramid_channels_last_fwd')
+    return out, level_hw
+
+
+def cross_attn_agg_fwd(feats_cl, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
+                       num_heads, want_mask=False, want_uv=False, query_order=None, raw_cam_weights=False):
+    """gd4d_cross_attn_agg_fwd.  feats_cl (B*N, S, 256) fp32 channels-last pyramid; the other arguments as cross_attn_fwd.
+    Returns agg (B, Q, Hh, 256), wsum (B, Q, Hh) [, mask] [, uv]."""
+    lib = _lib.load()
+    b, q = ref.shape[0], ref.shape[1]
+    n = lidar2img.shape[1]
+    hh, p = num_heads, offsets.shape[3]
+    nl = len(level_hw)
+    c = feats_cl.shape[-1]
+    if feats_cl.shape[0] != b * n or feats_cl.shape[1] != sum(h * w for h, w in level_hw):
+        raise ValueError(f'feats_cl shape {tuple(feats_cl.shape)} inconsistent with B*N={b * n}, levels {level_hw}')
+    if offsets.numel() != b * q * hh * p * 3 or attn_logits.numel() != b * q * hh * nl * p or cam_logits.numel() != b * q * n:
+        raise ValueError('offsets / attn_logits / cam_logits have the wrong number of elements')
+    f32 = torch.float32
+    agg = torch.empty(b, q, hh, c, device=ref.device, dtype=f32)
+    wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32)
+    mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
+    uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    code = lib.gd4d_cross_attn_agg_fwd(
+        _dev(feats_cl, 'feats_cl', f32), lv, _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32),
+        _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32),
+        rng, float(img_h), float(img_w), _dev(agg, 'agg'), _dev(wsum, 'wsum'),
+        _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None,
+        b, n, q, hh, c, nl, p, _lib.F32, 1 if raw_cam_weights else 0,
+        None if query_order is None else _order_ptr(query_order, b * q), _stream())
+    _lib.check(code, 'gd4d_cross_attn_agg_fwd')
+    res = (agg, wsum)
+    if want_mask:
+        res += (mask,)
+    if want_uv:
+        res += (uv,)
+    return res
+
+
+def value_proj_heads_fwd(agg, wsum, weight, bias=None, out=None):
+    """gd4d_value_proj_heads_fwd: agg (..., Hh, 256), wsum (..., Hh) -> out (..., 256) = value_proj of the aggregates."""
+    lib = _lib.load()
+    hh, c = agg.shape[-2], agg.shape[-1]
+    m = agg.numel() // (hh * c)
+    f32 = torch.float32
+    if out is None:
+        out = torch.empty(*agg.shape[:-2], c, device=agg.device, dtype=f32)
+    code = lib.gd4d_value_proj_heads_fwd(_dev(agg, 'agg', f32), _dev(wsum, 'wsum', f32), _dev(weight, 'weight', f32),
+                                         _opt(bias, 'bias'), _dev(out, 'out', f32), m, hh, c, _stream())
+    _lib.check(code, 'gd4d_value_proj_heads_fwd')
+    return out
+
+
 def _order_ptr(order, count):
     if order.dtype != torch.int32 or order.numel() != count:
         raise ValueError(f'query_order must be an int32 permutation of {count} entries')

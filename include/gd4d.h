@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 18
+#define GD4D_ABI_VERSION 19
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -105,6 +105,40 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
                         float* out, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
                         int Dh, int L, int P, int value_dtype, int value_layout, int flags,
                         const int32_t* query_order, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Aggregate-then-project form of the same path (inference; gd4d_cross_attn_late.hip).  value_proj is linear and the
+ * gather is a weighted sum of value rows, so per head h
+ *     out[q, h*Dh + d] = ( W_h * sum_i w_i x_i )[d] + b_h[d] * sum_i w_i
+ * over the in-bounds bilinear corners i of the head's visible samples, x_i = the RAW C-channel feature of the pixel:
+ * the per-layer projected value tensors (deform3d_cross_attn.py:264-280: N * S * 256 fp32 per decoder layer) are never
+ * written.  Three entry points:
+ *
+ * gd4d_pyramid_channels_last_fwd - the reference's flatten(3) / transpose / cat of the FPN levels (:264-276), once
+ *   per sample instead of once per layer:  feats host array of L device pointers, level l = (R, C, H_l, W_l) fp32
+ *   (R = B*N camera rows);  out (R, S, C) fp32, S = sum_l H_l*W_l, level l at pixel offset sum_{l'<l} H_l'*W_l'.
+ *   Supported: C == 256, L <= 8, fp32.
+ *
+ * gd4d_cross_attn_agg_fwd - projection + mask + softmax / camera weights + gather of raw features.  Arguments as
+ *   gd4d_cross_attn_fwd except: feats_cl = the channels-last pyramid above instead of a projected value tensor;
+ *   agg (B*Q, Hh, C) fp32 out: sum_i w_i x_i per head;  wsum (B*Q, Hh) fp32 out: sum_i w_i (in-bounds corners only -
+ *   mmcv's zero padding drops the bias with the value).  Same visibility mask / uv (bit-exact) as gd4d_cross_attn_fwd.
+ *   Supported: B == 1 (for B > 1 the reference pairs value rows with the logits of batch (row % B), :277 - use
+ *   gd4d_cross_attn_fwd), C == 256, P == 4, L <= 4, N <= 64, Hh in {4, 8, 16}, B*N*S < 2^31, fp32 features.
+ *
+ * gd4d_value_proj_heads_fwd - value_proj applied to the aggregates: out (M, Hh*Dh) with
+ *   out[r, h*Dh + d] = sum_c weight[h*Dh + d][c] * agg[r][h][c] + bias[h*Dh + d] * wsum[r][h]
+ *   (exact fp32 products on v_mfma_f32_16x16x4_f32); out is what gd4d_cross_attn_fwd returns (input of output_proj,
+ *   :326).  weight (C, C) = value_proj.weight, bias (C) or NULL.  Supported: C == 256, Hh in {4, 8, 16}. */
+int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, float* out, int R, int C, int L,
+                                   int in_dtype, void* stream);
+int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* level_hw, const float* ref, const float* offsets,
+                            const float* attn_logits, const float* cam_logits, const float* lidar2img,
+                            const double* pc_range, float img_h, float img_w, float* agg, float* wsum, uint8_t* mask_out,
+                            float* uv_out, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype, int flags,
+                            const int32_t* query_order, void* stream);
+int gd4d_value_proj_heads_fwd(const float* agg, const float* wsum, const float* weight, const float* bias, float* out,
+                              int M, int Hh, int C, void* stream);
 
 /* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the
  * reference's MSDA kernel processes queries in index order).  Counting sort by (sample, azimuth of the de-normalised

@@ -102,21 +102,33 @@ def test_transformer_decoder(name):
     torch.testing.assert_close(init_ref.cpu(), g.t('init_reference'), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(refs.cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(states.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+    def rerun(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with torch.no_grad():
+                return tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    # The default value path of Deform3DCrossAttn layers is aggregate-then-project (GD4D_PROJECT=late); the
+    # projected-value path (value_proj kernel + gd4d_cross_attn_fwd, GD4D_PROJECT=early) is the same mathematics in the
+    # reference's order of operations: both within 1e-3 of the reference, and of each other within fp32-class rounding.
+    early = rerun(dict(GD4D_PROJECT='early'))
+    torch.testing.assert_close(early[0].cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(early[2].cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(early[0], states, rtol=3e-4, atol=3e-4)
     # scheduling modes change when and where kernels run, never what they compute: value_proj pipelined on a side
-    # stream (default) / one multi-layer launch / per layer in place, locality order of the queries on / off
+    # stream / one multi-layer launch / per layer in place, locality order of the queries on / off, auxiliary stream
     for env in (dict(GD4D_PREPROJECT='0'), dict(GD4D_PREPROJECT='1'), dict(GD4D_PREPROJECT='stream'), dict(GD4D_PREPROJECT='g1,1'),
                 dict(GD4D_PREPROJECT='g2'), dict(GD4D_QUERY_ORDER='0'),
                 dict(GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0'), dict(GD4D_PREPROJECT='stream', GD4D_PIPELINE_CUS='64'),
                 dict(GD4D_AUX_STREAM='0'),
                 dict(GD4D_AUX_STREAM='0', GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0')):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            with torch.no_grad():
-                s2, i2, r2 = tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        s2, i2, r2 = rerun(dict(env, GD4D_PROJECT='early'))
+        assert torch.equal(s2, early[0]) and torch.equal(r2, early[2]) and torch.equal(i2, early[1]), env
+    for env in (dict(GD4D_QUERY_ORDER='0'), dict(GD4D_AUX_STREAM='0'), dict(GD4D_AUX_STREAM='0', GD4D_QUERY_ORDER='0')):
+        s2, i2, r2 = rerun(env)
         assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
     # the fused Linear+LayerNorm kernel sums in another order than Linear, LayerNorm: equal within fp32 rounding
     os.environ['GD4D_ROWBLOCK'] = '0'
