@@ -20,6 +20,8 @@
 //   gd4d_value_proj_heads_fwd       out = W_h agg_h + b_h wsum_h  (exact fp32 MFMA) -> (B*Q, Hh*Dh), the input of output_proj
 //
 // Same visibility mask and image coordinates as gd4d_cross_attn_fwd (shared project_entry, -ffp-contract=off).
+#include <stdlib.h>
+
 #include "gd4d_common.h"
 #include "gd4d_cross_attn_shared.h"
 
@@ -83,12 +85,11 @@ __global__ __launch_bounds__(256) void pyramid_channels_last_kernel(const ClPara
 // computed SIMD-fashion - lane (item % 4, level, corner) for four items at a time - and broadcast with v_readlane into
 // scalar registers; the loads use them as scalar offsets, the FMAs as scalar factors.  No cross-wave reduction, a fixed
 // summation order (deterministic), and only visible points are touched.
-template <int HH, int LT>
-__global__ __launch_bounds__(256, 4) void cross_attn_agg_kernel(const CrossAttnParams p) {
+template <int HH, int LT, bool LEVEL_MAJOR, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossAttnParams p) {
   constexpr int PT = kPoints;
   constexpr int E = HH * PT;
   constexpr int LP = LT * PT;
-  constexpr int WAVES = 4;
   constexpr int THREADS = GD4D_WAVE * WAVES;
   constexpr int HPW = (HH + WAVES - 1) / WAVES;               // heads per wave
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -182,6 +183,78 @@ __global__ __launch_bounds__(256, 4) void cross_attn_agg_kernel(const CrossAttnP
   __syncthreads();
 
   // ---------------- phase B ----------------
+  if (LEVEL_MAJOR) {
+    // Level-major: every wave of every (co-resident) workgroup walks the pyramid coarse -> fine, so the small, heavily
+    // re-read maps (level 3: 9 MB for 24 cameras, level 2: 36 MB) are gathered while they fit the XCD's 4-MB L2 instead of
+    // being evicted by the level-0 stream (332 MB of nearly unique lines) between two uses.
+    // Lane (item % 16, corner): 16 items x 4 corners of ONE level per set-up; a load round is 4 items x 4 corners.
+    const int it_of = lane >> 2, c_of = lane & 3;
+    const char* vbase = static_cast<const char*>(p.value) + lane * 16;
+    float4 acc[HPW];
+    float wsum_lane[HPW];
+#pragma unroll
+    for (int hi = 0; hi < HPW; ++hi) { acc[hi] = make_float4(0.f, 0.f, 0.f, 0.f); wsum_lane[hi] = 0.f; }
+#pragma unroll
+    for (int li = 0; li < LT; ++li) {
+      const int l = LT - 1 - li;
+      const int lw = p.lvl_w[l], lh = p.lvl_h[l], ls = p.lvl_start[l];
+#pragma unroll
+      for (int hi = 0; hi < HPW; ++hi) {
+        const int h = wave + hi * WAVES;
+        if (h >= HH) break;
+        const int M = __builtin_amdgcn_readfirstlane(s_cnt[h]);
+        for (int it0 = 0; it0 < M; it0 += 16) {
+          const int item = it0 + it_of;
+          const bool valid = item < M;
+          const int cand = s_items[h * ncand + min(item, M - 1)];
+          const int n = cand / PT, k = cand % PT;
+          const float2 uv = s_uv[n * E + h * PT + k];
+          const float x = fmaf(uv.x, (float)lw, -0.5f);
+          const float y = fmaf(uv.y, (float)lh, -0.5f);
+          const float xf = floorf(x), yf = floorf(y);
+          const float dx = x - xf, dy = y - yf;
+          const int xi = (int)xf + (c_of & 1), yi = (int)yf + (c_of >> 1);
+          const bool ok = valid && xi >= 0 && xi < lw && yi >= 0 && yi < lh;
+          const float wl = s_aw[h * LP + l * PT + k] * s_cw[n];
+          const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
+          const float w = ok ? wl * wx * wy : 0.f;
+          const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
+          const unsigned pixel = valid ? (unsigned)((b * p.N + n) * p.S + ls + yc * lw + xc) : 0u;
+          wsum_lane[hi] += w;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (it0 + 4 * s >= M) break;                       // wave-uniform
+            float4 val[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
+              if (p.dbg_wrap) px &= p.dbg_wrap;
+              val[j] = *reinterpret_cast<const float4*>(vbase + (size_t)px * (kChannels * 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const float wj = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(w), s * 16 + j));
+              acc[hi].x = fmaf(wj, val[j].x, acc[hi].x); acc[hi].y = fmaf(wj, val[j].y, acc[hi].y);
+              acc[hi].z = fmaf(wj, val[j].z, acc[hi].z); acc[hi].w = fmaf(wj, val[j].w, acc[hi].w);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int hi = 0; hi < HPW; ++hi) {
+      const int h = wave + hi * WAVES;
+      if (h >= HH) break;
+      *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + lane * 4) = acc[hi];
+      float t = wsum_lane[hi];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (lane == 0) p.wsum[(size_t)bq * HH + h] = t;
+    }
+    return;
+  }
+  // item-major (the first form; GD4D_AGG_VARIANT=0): lane (item % 4, level, corner), all levels of an item per load round
   const int sub = lane >> 4, l_of = (lane >> 2) & 3, c_of = lane & 3;
   int lw = p.lvl_w[0], lh = p.lvl_h[0], ls = p.lvl_start[0];
 #pragma unroll
@@ -221,7 +294,8 @@ __global__ __launch_bounds__(256, 4) void cross_attn_agg_kernel(const CrossAttnP
         float4 val[LT * 4];
 #pragma unroll
         for (int j = 0; j < LT * 4; ++j) {
-          const unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
+          unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
+              if (p.dbg_wrap) px &= p.dbg_wrap;
           val[j] = *reinterpret_cast<const float4*>(vbase + (size_t)px * (kChannels * 4));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -289,17 +363,37 @@ __global__ __launch_bounds__(64) void value_proj_heads_kernel(const HeadProjPara
 template <int HH>
 static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
   const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
+  static int lds_pad = -1;                          // dev: GD4D_AGG_LDS_PAD bytes of unused LDS per workgroup (caps residency)
+  if (lds_pad < 0) { const char* e = getenv("GD4D_AGG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
   auto lds_bytes = [&](int LT) {
-    return (size_t)p.N * HH * kPoints * sizeof(float2) + (size_t)HH * LT * kPoints * sizeof(float) + (size_t)p.N * 12 * sizeof(float) +
+    return (size_t)lds_pad + (size_t)p.N * HH * kPoints * sizeof(float2) + (size_t)HH * LT * kPoints * sizeof(float) + (size_t)p.N * 12 * sizeof(float) +
            (size_t)((p.N + 3) & ~3) * sizeof(float) + (size_t)HH * sizeof(int) + (size_t)HH * p.N * kPoints;
   };
+  // dev A/B: GD4D_AGG_VARIANT bit 0: level-major walk (default item-major); bit 1: 4 waves per query, two heads per wave
+  // (default: one wave per head - the heads of a query then work on the same camera at the same time, and what they
+  // share at the coarse levels is still in the L2)
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("GD4D_AGG_VARIANT"); variant = e ? atoi(e) : 0; }
+  auto go = [&](auto kern, int threads, size_t lds) {
+    if (lds > 65536) (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
+  };
+#define GD4D_AGG_GO(LT_)                                                                            \
+  if (variant & 2) {                                                                                 \
+    if (variant & 1) go(cross_attn_agg_kernel<HH, LT_, true, 4>, 256, lds_bytes(LT_));              \
+    else go(cross_attn_agg_kernel<HH, LT_, false, 4>, 256, lds_bytes(LT_));                         \
+  } else {                                                                                          \
+    if (variant & 1) go(cross_attn_agg_kernel<HH, LT_, true, HH>, 64 * HH, lds_bytes(LT_));         \
+    else go(cross_attn_agg_kernel<HH, LT_, false, HH>, 64 * HH, lds_bytes(LT_));                    \
+  }
   switch (p.L) {
-    case 1: hipLaunchKernelGGL((cross_attn_agg_kernel<HH, 1>), grid, dim3(256), lds_bytes(1), s, p); break;
-    case 2: hipLaunchKernelGGL((cross_attn_agg_kernel<HH, 2>), grid, dim3(256), lds_bytes(2), s, p); break;
-    case 3: hipLaunchKernelGGL((cross_attn_agg_kernel<HH, 3>), grid, dim3(256), lds_bytes(3), s, p); break;
-    case 4: hipLaunchKernelGGL((cross_attn_agg_kernel<HH, 4>), grid, dim3(256), lds_bytes(4), s, p); break;
+    case 1: GD4D_AGG_GO(1) break;
+    case 2: GD4D_AGG_GO(2) break;
+    case 3: GD4D_AGG_GO(3) break;
+    case 4: GD4D_AGG_GO(4) break;
     default: return GD4D_EUNSUPPORTED;
   }
+#undef GD4D_AGG_GO
   return check_launch();
 }
 
@@ -360,6 +454,7 @@ extern "C" int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* leve
     p.rng_lo[k] = static_cast<float>(pc_range[k]);
   }
   p.img_h = img_h; p.img_w = img_w;
+  { static long wrap = -1; if (wrap < 0) { const char* e = getenv("GD4D_AGG_DBG_WRAP"); wrap = e ? atol(e) : 0; } p.dbg_wrap = (unsigned)wrap; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (Hh) {
     case 4: return launch_agg<4>(p, s);

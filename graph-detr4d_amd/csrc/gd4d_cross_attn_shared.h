@@ -28,6 +28,7 @@ struct CrossAttnParams {
   float img_h, img_w;
   float* agg;          // gd4d_cross_attn_agg_fwd only: (B*Q, Hh, C) per-head aggregates of the raw features
   float* wsum;         //                               (B*Q, Hh) sum of the in-bounds sampling weights per head
+  unsigned dbg_wrap;   // dev (GD4D_AGG_DBG_WRAP): pixel indices are ANDed with this mask (0 = off): an all-L2-hit run
 };
 
 constexpr int kPoints = 4;   // sampling points per head (reference configs: num_points=4)

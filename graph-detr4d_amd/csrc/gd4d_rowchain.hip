@@ -36,6 +36,12 @@ typedef gd4d_chain_op ChainOp;
 
 __device__ __forceinline__ float rc_act_in(float v, int flags) { return (flags & GD4D_CHAIN_INV_SIGMOID) ? inv_sigmoid(v) : v; }
 
+#ifndef RC_ROTATE
+#define RC_ROTATE 1   // per-workgroup starting k-step of the GEMMs (0: every workgroup walks K from 0 - dev A/B)
+#endif
+#ifndef RC_PREFETCH
+#define RC_PREFETCH 1   // touch the program's weight images at the start of the launch (0: dev A/B)
+#endif
 #ifndef RC_DBG
 #define RC_DBG 0      // dev ablation (compile with -DRC_DBG=n): 1 = no MFMAs, 2 = no weight loads
 #endif
@@ -119,9 +125,16 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
 #pragma unroll
         for (int c = 0; c < RC_TILES; ++c) { bh[d][c] = rc_u4{1u, 2u, 3u, (unsigned)lane}; bl[d][c] = bh[d][c]; }
     }
+    // The workgroups of a launch run in lock step and stream the SAME weight image: un-rotated, the ~7 workgroups that
+    // share an XCD ask one L2 channel for one fragment at the same instant and take turns (17 B/clk per CU measured).
+    // Each workgroup therefore walks K from its own starting k-step (a sum may be taken in any order; the order is a
+    // function of the workgroup index only, so results are run-to-run identical).
+    const int rot = RC_ROTATE ? (int)((blockIdx.x >> 3) % (unsigned)steps) : 0;
+    auto kstep = [&](int j) { const int r = j + rot; return r >= steps ? r - steps : r; };
 #pragma unroll
-    for (int d = 0; d < RC_DEPTH; ++d) issue(d, min(d, steps - 1));
-    auto consume = [&](int d, int j) {
+    for (int d = 0; d < RC_DEPTH; ++d) issue(d, kstep(min(d, steps - 1)));
+    auto consume = [&](int d, int j0_) {
+      const int j = kstep(j0_);
       const float4 t0 = *reinterpret_cast<const float4*>(a_row + 32 * j);
       const float4 t1 = *reinterpret_cast<const float4*>(a_row + 32 * j + 4);
       const float a[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
@@ -140,7 +153,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
 #pragma unroll
       for (int d = 0; d < RC_DEPTH; ++d) {
         consume(d, j0 + d);
-        issue(d, j0 + d + RC_DEPTH);
+        issue(d, kstep(j0 + d + RC_DEPTH));
       }
     }
 #pragma unroll
@@ -273,6 +286,29 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * RC_M;
+#if RC_PREFETCH
+  // The weight images of a program (2.6 MB for chain B) are cold in this XCD's L2 when the launch starts - another
+  // kernel streamed through it since their last use - and the GEMMs below fetch them with 32 KB per wave in flight: at
+  // the ~2 us of a fabric round trip that is 17-24 B/clk per compute unit, which is what bounded every chain.  So the
+  // workgroups that share an XCD (blockIdx = xcd mod 8) first TOUCH the images of all the program's GEMMs, each its
+  // slice, one dword per 64 bytes, all requests in flight at once: the cold misses overlap instead of queueing behind
+  // a 4-deep ring.  The loads land in one sink register nobody reads (inline asm: the compiler neither waits for them
+  // nor counts them; they are older than every load it does count, and vmcnt retires in order).
+  unsigned rc_sink = 0;
+  {
+    const unsigned xcd = blockIdx.x & 7u, mine = blockIdx.x >> 3, share = (gridDim.x - xcd + 7u) >> 3;
+    for (int oi = 0; oi < nops; ++oi) {
+      if (pp->ops[oi].kind != GD4D_CHAIN_GEMM) continue;
+      const char* img = reinterpret_cast<const char*>(pp->ops[oi].p0);
+      const unsigned chunks = (unsigned)((pp->ops[oi].N + 15) / 16) * (unsigned)(pp->ops[oi].K / 32) * 32u;   // 64-byte pieces
+      const unsigned lo = (unsigned)((unsigned long long)chunks * mine / share), hi = (unsigned)((unsigned long long)chunks * (mine + 1) / share);
+      for (unsigned c = lo + tid; c < hi; c += 64 * RC_WAVES) {
+        const char* a = img + (size_t)c * 64;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(rc_sink) : "v"(a) : "memory");
+      }
+    }
+  }
+#endif
   for (int oi = 0; oi < nops; ++oi) {
     const ChainOp op = pp->ops[oi];                        // uniform: scalar loads
     switch (op.kind) {
@@ -317,6 +353,9 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
     }
     __syncthreads();
   }
+#if RC_PREFETCH
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(rc_sink) : "memory");     // (long since returned) keeps the sink register reserved
+#endif
 }
 
 }  // namespace gd4d
