@@ -57,6 +57,7 @@ def parse():
                     help='--mode train/distill with several ranks: eager backward, every bucket\'s all-reduce starts from a '
                          'post-accumulate hook while the backward of the layers below is still running')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='dev: skip the kernel-level roofline section (roofline = null)')
     ap.add_argument('--cpu-threads', type=int, default=None, help='torch threads of the CPU baseline (default: min(cores, 16), the fastest measured)')
     ap.add_argument('--cpu-layers', type=int, default=None,
                     help='decoder layers of the CPU-baseline sample (default: bounded automatically)')
@@ -200,7 +201,7 @@ def main():
 
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
-    if rank == 0:
+    if rank == 0 and not a.no_roofline:
         roofline, kernels = fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic)
 
     cpu = None
@@ -551,7 +552,7 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
     in the step is `roofline`; the other form is measured on the same inputs and reported under `kernels`."""
     from graph_detr4d_amd import functional as Fn
     early_cap, late_cap = [], []
-    orig_early, orig_late = Fn.sample_aggregate, Fn.LateValues.sample_aggregate
+    orig_early, orig_late = Fn.sample_aggregate, Fn.LateValues.aggregate
 
     def spy_early(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=None):
         nl_pix = sum(h * w for h, w in shapes)
@@ -565,12 +566,12 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                              attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img, pc_range=module.pc_range,
                              img_h=img_h, img_w=img_w, order=order))
         return orig_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
-    Fn.sample_aggregate, Fn.LateValues.sample_aggregate = spy_early, spy_late
+    Fn.sample_aggregate, Fn.LateValues.aggregate = spy_early, spy_late
     try:
         with torch.no_grad():
             tr(feats, query_embed, reg_branches=regs, img_metas=metas)
     finally:
-        Fn.sample_aggregate, Fn.LateValues.sample_aggregate = orig_early, orig_late
+        Fn.sample_aggregate, Fn.LateValues.aggregate = orig_early, orig_late
     torch.cuda.synchronize()
     late_mode = bool(late_cap)
     captured = late_cap if late_mode else early_cap

@@ -177,6 +177,90 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   }
 }
 
+// HEADGEMM: value_proj applied to per-head aggregates that live in GLOBAL memory (gd4d_cross_attn_agg_fwd's output):
+//   v[m, n] = sum_k agg[m][h][k] * W[n][k] + bias[n] * wsum[m][h],   h = n / (N / heads)
+// i.e. gd4d_value_proj_heads_fwd as the first operation of chain B (its result is the input of output_proj).  Same
+// column ownership, weight image and arithmetic as rc_gemm; the A fragments of a k-step come from the rows of the two
+// heads a wave's 64 columns belong to (Dh = 32: tiles 0, 1 -> one head, tiles 2, 3 -> the next; Dh = 64: one head),
+// through a 2-deep register ring beside the weight fragments.  Requires Dh % 32 == 0, K % 64 == 0.
+__device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
+  constexpr int HD = 2;                                        // ring depth (k-steps)
+  const int i16 = lane & 15, g = lane >> 4;
+  const int K = op.K, N = op.N, heads = op.ld0, Dh = N / heads;
+  const int steps = K / 32, tiles = (N + 15) / 16;
+  const char* img = reinterpret_cast<const char*>(op.p0);
+  const int m_ld = min(m0 + i16, M - 1);                       // rows past M repeat the last row (never stored)
+  for (int n_base = 64 * wave; n_base < N; n_base += 64 * RC_WAVES) {
+    const char* wf[RC_TILES];
+#pragma unroll
+    for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * 2048 + lane * 16;
+    const int h0 = min(n_base / Dh, heads - 1), h1 = min((n_base + 32) / Dh, heads - 1);
+    const float* a0 = op.p2 + ((size_t)m_ld * heads + h0) * K + 8 * g;
+    const float* a1 = op.p2 + ((size_t)m_ld * heads + h1) * K + 8 * g;
+    rc4 acc[RC_TILES];
+#pragma unroll
+    for (int c = 0; c < RC_TILES; ++c) acc[c] = rc4{0.f, 0.f, 0.f, 0.f};
+    float e_bias[RC_TILES];
+    {
+      const float* bias_p = op.p1 ? op.p1 : reinterpret_cast<const float*>(op.p0);
+      const float bias_on = op.p1 ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c) e_bias[c] = bias_p[min(n_base + 16 * c + i16, N - 1)] * bias_on;
+    }
+    rc_u4 bh[HD][RC_TILES], bl[HD][RC_TILES];
+    float4 av[HD][2][2];
+    auto issue = [&](int slot, int j) {
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c) {
+        bh[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048);
+        bl[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048 + 1024);
+      }
+      av[slot][0][0] = *reinterpret_cast<const float4*>(a0 + 32 * j); av[slot][0][1] = *reinterpret_cast<const float4*>(a0 + 32 * j + 4);
+      av[slot][1][0] = *reinterpret_cast<const float4*>(a1 + 32 * j); av[slot][1][1] = *reinterpret_cast<const float4*>(a1 + 32 * j + 4);
+    };
+    auto consume = [&](int d) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float a[8] = {av[d][hh][0].x, av[d][hh][0].y, av[d][hh][0].z, av[d][hh][0].w,
+                            av[d][hh][1].x, av[d][hh][1].y, av[d][hh][1].z, av[d][hh][1].w};
+        rc_u4 ah, al;
+        rc_split8(a, ah, al);
+#pragma unroll
+        for (int c = 2 * hh; c < 2 * hh + 2; ++c) {
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(al), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bl[d][c]), acc[c], 0, 0, 0);
+        }
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < HD; ++d) issue(d, min(d, steps - 1));
+    for (int j0 = 0; j0 + HD < steps; j0 += HD) {              // steps is even (K % 64 == 0)
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        consume(d);
+        issue(d, j0 + d + HD);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) consume(d);
+#pragma unroll
+    for (int c = 0; c < RC_TILES; ++c) {
+      const int n = n_base + 16 * c + i16;
+      if (n >= N) continue;
+      const int hc = c < 2 ? h0 : h1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r, m = m0 + row;
+        float v = fmaf(e_bias[c], op.p3[(size_t)min(m, M - 1) * heads + hc], acc[c][r]);
+        if (op.res >= 0) v += bufs[op.res][row][n];
+        if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
+        if (op.gout && m < M) op.gout[(size_t)m * op.ldg + n] = v;
+      }
+    }
+  }
+}
+
 // LayerNorm over N columns (N % 64 == 0, N <= 512) of the 16 rows: wave w normalises rows 4 w .. 4 w + 3, 16 lanes per
 // row, a lane owns columns 64 ch + 4 l16 .. + 4 of every 64-column chunk.  gamma / beta are requested first.
 __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
@@ -298,7 +382,16 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   {
     const unsigned xcd = blockIdx.x & 7u, mine = blockIdx.x >> 3, share = (gridDim.x - xcd + 7u) >> 3;
     for (int oi = 0; oi < nops; ++oi) {
-      if (pp->ops[oi].kind != GD4D_CHAIN_GEMM) continue;
+      if (pp->ops[oi].kind == GD4D_CHAIN_HEADGEMM) {           // this workgroup's own aggregate rows (written by another XCD: cold)
+        const int rows = min(RC_M, M - m0);
+        const char* a = reinterpret_cast<const char*>(pp->ops[oi].p2 + (size_t)m0 * pp->ops[oi].ld0 * pp->ops[oi].K);
+        const unsigned pieces = (unsigned)rows * (unsigned)pp->ops[oi].ld0 * (unsigned)pp->ops[oi].K / 16u;
+        for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) {
+          const char* q = a + (size_t)c * 64;
+          asm volatile("global_load_dword %0, %1, off" : "+v"(rc_sink) : "v"(q) : "memory");
+        }
+      }
+      if (pp->ops[oi].kind != GD4D_CHAIN_GEMM && pp->ops[oi].kind != GD4D_CHAIN_HEADGEMM) continue;
       const char* img = reinterpret_cast<const char*>(pp->ops[oi].p0);
       const unsigned chunks = (unsigned)((pp->ops[oi].N + 15) / 16) * (unsigned)(pp->ops[oi].K / 32) * 32u;   // 64-byte pieces
       const unsigned lo = (unsigned)((unsigned long long)chunks * mine / share), hi = (unsigned)((unsigned long long)chunks * (mine + 1) / share);
@@ -324,6 +417,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
         break;
       }
       case GD4D_CHAIN_GEMM: rc_gemm(op, bufs, m0, M, lane, wave); break;
+      case GD4D_CHAIN_HEADGEMM: rc_headgemm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_LAYERNORM: rc_layernorm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_ADD: rc_rows<true>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
       case GD4D_CHAIN_SMALL_LINEAR: {                      // K <= 8 inputs (position_encoder's first Linear): plain FMAs
@@ -398,6 +492,12 @@ extern "C" int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M,
         if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4)) return GD4D_EINVAL;
         if (op.dst >= 0 && op.dst == op.src) return GD4D_EINVAL;          // waves would overwrite rows others still read
         if (!aligned16(op.p0)) return GD4D_EALIGN;
+        break;
+      case GD4D_CHAIN_HEADGEMM:
+        if (!op.p0 || !op.p2 || !op.p3 || op.K <= 0 || op.N <= 0 || op.ld0 <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
+        if (op.N % op.ld0 != 0 || (op.N / op.ld0) % 32 != 0 || op.K % 64 != 0 || op.N % 64 != 0) return GD4D_EUNSUPPORTED;
+        if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4)) return GD4D_EINVAL;
+        if (!aligned16(op.p0) || !aligned16(op.p2)) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_LAYERNORM:
         if (!op.p0 || !op.p1 || op.src < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;

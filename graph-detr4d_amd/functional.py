@@ -424,7 +424,12 @@ class LateValues:
             self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
         self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
         with torch.cuda.stream(self.side):
-            self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value])
+            if 'copy' in os.environ.get('GD4D_ABLATE', '').split(','):      # dev: skip the copy (see fused_decoder._ablate)
+                r = value[0].shape[0] * value[0].shape[1]
+                self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
+                self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev)
+            else:
+                self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value])
             self.event = torch.cuda.Event()
             self.event.record(self.side)
         self.waited = set()
@@ -441,15 +446,19 @@ class LateValues:
         return all(m.value_dtype == torch.float32 and m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
                    and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
-    def sample_aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
-        """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of output_proj."""
+    def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
+        """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh) (ops.cross_attn_agg_fwd)."""
         cur = torch.cuda.current_stream(self.cl.device)
         if cur.cuda_stream not in self.waited:
             cur.wait_event(self.event)
             self.waited.add(cur.cuda_stream)
-        agg, wsum = ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
-                                           cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
-                                           module.num_heads, query_order=order)
+        return ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
+                                      cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
+                                      module.num_heads, query_order=order)
+
+    def sample_aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
+        """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of output_proj."""
+        agg, wsum = self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
         bias = module.value_proj.bias
         return ops.value_proj_heads_fwd(agg, wsum, module.value_proj.weight.contiguous(),
                                         None if bias is None else bias.contiguous())

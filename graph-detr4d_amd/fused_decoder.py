@@ -28,6 +28,12 @@ from .transformer_layers import FFN, MultiheadAttention
 ORDER = ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
 
 
+def _ablate(name):
+    """dev: GD4D_ABLATE=mha,chain_a,agg,chain_b,copy - skip that launch (outputs stay uninitialised): what a kernel costs in
+    the replayed step, gaps and cold-cache effects included (results are garbage)."""
+    return name in os.environ.get('GD4D_ABLATE', '').split(',')
+
+
 def _plain_reg_branch(branch, c):
     """[Linear, ReLU]* Linear with c-wide hidden layers, as the heads build them (dense_heads/detr3d_head.py:58-75)."""
     if not isinstance(branch, nn.Sequential) or len(branch) % 2 == 0:
@@ -165,7 +171,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
 
         # attention core
         qh, kh, vh = qkv.split(c, dim=-1)
-        o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
+        o = torch.empty(q, 1, c, device=dev, dtype=torch.float32) if _ablate('mha') else ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
 
         # chain A
         x1 = torch.empty(q, c, device=dev, dtype=torch.float32)
@@ -180,14 +186,23 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                 ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
                 ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
                 ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
-        ops.row_chain_fwd(prog, q)
+        if not _ablate('chain_a'):
+            ops.row_chain_fwd(prog, q)
 
         if ref_event is not None:
             main.wait_event(ref_event)
         if order is None or order.numel() != q:
             order = Fn.query_order(ref, ca.pc_range)
-        if late is not None:
-            # aggregate-then-project: gather the raw features per head, apply value_proj to the aggregates
+        agg_raw = None
+        if late is not None and (c // hh) % 32 == 0 and os.environ.get('GD4D_CHAIN_HEADGEMM', '1') != '0':
+            # aggregate-then-project: gather the raw features per head; value_proj of the aggregates is chain B's first op
+            if _ablate('agg'):
+                agg_raw, wsum = torch.empty(1, q, hh, c, device=dev), torch.empty(1, q, hh, device=dev)
+            else:
+                agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                               img_h, img_w, order=order)
+            agg = agg_raw
+        elif late is not None:
             agg = late.sample_aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
                                         img_h, img_w, order=order)
         else:
@@ -212,7 +227,13 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
         last = lid + 1 == nl
         slot = lid if return_intermediate else 0
         x3 = out_all[slot]                                                         # (Q, 1, C)
-        prog = [ops.chain_load(0, agg.view(q, c)),
+        if agg_raw is not None:
+            bias = ca.value_proj.bias
+            first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, bias, dst=0)
+            keep.append(wsum)
+        else:
+            first = ops.chain_load(0, agg.view(q, c))
+        prog = [first,
                 ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336
                 ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
                 ops.chain_layernorm(1, layer.norms[1], dst=2),                    # x2
@@ -223,33 +244,43 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
             qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
             prog += [ops.chain_add(0, 3, c, add=pos)] + _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1))
         new_ref = None
+        reg_prog = []
         if reg_branches is not None:
+            # reg branch + refinement (:199-214) feed the NEXT layer's gather and position_encoder only - not its
+            # self-attention: with the auxiliary stream they are their own short chain next to that self-attention
             lins = _plain_reg_branch(reg_branches[lid], c)
             src, tmp = 3, (1, 2)
             for i, lin in enumerate(lins):
-                prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                reg_prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
                 src = tmp[i % 2]
             new_ref = ref_all[slot]                                                 # (1, Q, 3)
-            prog.append(ops.chain_refine(src, ref, new_ref))
-        ops.row_chain_fwd(prog, q)
+            reg_prog.append(ops.chain_refine(src, ref, new_ref))
+        split_reg = bool(reg_prog) and aux is not None and os.environ.get('GD4D_REG_ON_AUX', '1') != '0'
+        if not split_reg:
+            prog += reg_prog
+        if not _ablate('chain_b'):
+            ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg, x]
 
         x = x3.view(q, c)
         if new_ref is not None:
-            ref = new_ref
+            old_ref, ref = ref, new_ref
             ref_event = None
-            if not last and order is not None:
-                # the next layer's locality order: one tiny launch next to that layer's self-attention
-                if aux is not None:
-                    done = torch.cuda.Event()
-                    done.record(main)
-                    with torch.cuda.stream(aux):
-                        aux.wait_event(done)
+            if aux is not None and (split_reg or (not last and order is not None)):
+                done = torch.cuda.Event()
+                done.record(main)
+                with torch.cuda.stream(aux):
+                    aux.wait_event(done)
+                    if split_reg:
+                        ops.row_chain_fwd([ops.chain_load(3, x)] + reg_prog, q)
+                        keep.append(old_ref)
+                    if not last and order is not None:
+                        # the next layer's locality order: one tiny launch next to that layer's self-attention
                         order = Fn.query_order(ref, order_pc_range)
-                        ref_event = torch.cuda.Event()
-                        ref_event.record(aux)
-                else:
-                    order = Fn.query_order(ref, order_pc_range)
+                    ref_event = torch.cuda.Event()
+                    ref_event.record(aux)
+            elif not last and order is not None:
+                order = Fn.query_order(ref, order_pc_range)
         if new_ref is None and (return_intermediate or last):
             ref_all[slot].copy_(ref)
     if aux is not None:

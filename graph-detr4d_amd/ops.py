@@ -759,10 +759,11 @@ class ChainOp(ctypes.Structure):
                 ('K', ctypes.c_int32), ('N', ctypes.c_int32), ('flags', ctypes.c_int32), ('dst_col', ctypes.c_int32),
                 ('ld0', ctypes.c_int32), ('ld1', ctypes.c_int32), ('ld2', ctypes.c_int32), ('ldg', ctypes.c_int32),
                 ('eps', ctypes.c_float), ('reserved', ctypes.c_int32),
-                ('p0', ctypes.c_void_p), ('p1', ctypes.c_void_p), ('p2', ctypes.c_void_p), ('gout', ctypes.c_void_p)]
+                ('p0', ctypes.c_void_p), ('p1', ctypes.c_void_p), ('p2', ctypes.c_void_p), ('gout', ctypes.c_void_p),
+                ('p3', ctypes.c_void_p)]
 
 
-CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR = 1, 2, 3, 4, 5, 6
+CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM = 1, 2, 3, 4, 5, 6, 7
 CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID = 1, 2, 4
 
 
@@ -827,6 +828,20 @@ def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, ou
     return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
                    flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0), ldg=ldg, p0=img.data_ptr(),
                    p1=None if bias is None else bias.data_ptr(), gout=g)
+
+
+def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):
+    """value_proj of the per-head aggregates (cross_attn_agg_fwd's agg (..., Hh, K), wsum (..., Hh), contiguous) as a chain
+    operation: v[m, n] = sum_k agg[m][h][k] W[n][k] + bias[n] wsum[m][h] (+ buf[res]) -> buf[dst] and / or out."""
+    heads, k = agg.shape[-2], agg.shape[-1]
+    n = weight.shape[0]
+    if weight.shape[1] != k or n % heads or (n // heads) % 32 or wsum.numel() * k != agg.numel():
+        raise ValueError('chain_headgemm: weight (N, K), agg (..., Hh, K), wsum (..., Hh) with (N / Hh) % 32 == 0')
+    img = chain_weight_image(weight)
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_HEADGEMM, src=-1, dst=dst, res=res, K=k, N=n, ld0=heads, ldg=ldg, p0=img.data_ptr(),
+                   p1=None if bias is None else bias.data_ptr(), p2=_dev(agg, 'agg', torch.float32).value,
+                   p3=_dev(wsum, 'wsum', torch.float32).value, gout=g)
 
 
 def chain_small_linear(src, weight, bias, dst, relu=False):

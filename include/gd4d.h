@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 19
+#define GD4D_ABI_VERSION 20
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -334,10 +334,15 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  *   SMALL_LINEAR  buf[dst][:, :N] = act(buf[src][:, :K] . W^T + bias) for K <= 8 (position_encoder's first Linear)
  *   REFINE     reference-point refinement: src = reg-branch output (>= 5 columns), p0 = reference points (M, 3) in [0, 1],
  *              gout = refined points (M, 3)
+ *   HEADGEMM   value_proj of the per-head aggregates of gd4d_cross_attn_agg_fwd, read from GLOBAL memory (what
+ *              gd4d_value_proj_heads_fwd computes, as the first operation of the chain that consumes it):
+ *              v[m, n] = sum_k p2[m][h][k] W[n][k] + bias[n] p3[m][h], h = n / (N / heads); p0 = the image of W (N, K),
+ *              p1 = bias or NULL, p2 = agg (M, heads, K), p3 = wsum (M, heads), heads = ld0; then as GEMM (+ buf[res], to
+ *              buf[dst] and / or gout).  (N / heads) % 32 == 0, K % 64 == 0.
  * GEMMs: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (fp32-class, the arithmetic of gd4d_value_proj_fwd);
  * everything else fp32.  M = number of rows. */
 enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_CHAIN_ADD = 4, GD4D_CHAIN_REFINE = 5,
-       GD4D_CHAIN_SMALL_LINEAR = 6 };
+       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7 };
 #define GD4D_CHAIN_RELU 1
 #define GD4D_CHAIN_INV_SIGMOID 2
 #define GD4D_CHAIN_SIGMOID 4        /* GEMM: sigmoid on the output (after the bias / ReLU, before the residual) */
@@ -352,6 +357,7 @@ typedef struct gd4d_chain_op {
   const float* p1;
   const float* p2;
   float* gout;
+  const float* p3;
 } gd4d_chain_op;
 size_t gd4d_chain_op_bytes(void);
 size_t gd4d_chain_weight_image_bytes(int N, int K);

@@ -61,19 +61,19 @@ def test_each_decoder_layer_900q_24cams_matches_oracle(project, monkeypatch):
                                                          pc_range, img_h, img_w, head_major=hm, want_mask=True)
                 return orig(value, shapes, ref_, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
                             order=order)
-            orig_late = Fn.LateValues.sample_aggregate
+            orig_late = Fn.LateValues.aggregate
 
             def spy_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
                 captured['mask'] = ops.cross_attn_agg_fwd(self.cl, self.shapes, ref_.contiguous(), offsets.contiguous(),
                                                           attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
                                                           module.pc_range, img_h, img_w, module.num_heads, want_mask=True)[2]
                 return orig_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
-            Fn.sample_aggregate, Fn.LateValues.sample_aggregate = spy, spy_late
+            Fn.sample_aggregate, Fn.LateValues.aggregate = spy, spy_late
             try:
                 y = tr_d.decoder.layers[lid](x.to(dev), key=None, value=feats_d, query_pos=query_pos.to(dev),
                                              reference_points=ref.to(dev), img_metas=metas)
             finally:
-                Fn.sample_aggregate, Fn.LateValues.sample_aggregate = orig, orig_late
+                Fn.sample_aggregate, Fn.LateValues.aggregate = orig, orig_late
             tmp_d = Fn.run_branch(regs_d[lid], y.permute(1, 0, 2).contiguous())
             ref_d = Fn.refine_reference(tmp_d, ref.to(dev))
             # The visibility mask is the path's only discontinuity: a point within an ulp of a threshold can flip

@@ -1,0 +1,118 @@
+"""gd4d_row_chain_fwd programs (the row-local work of a decoder layer as one launch) against fp64 references.  GPU only."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ln(n, seed):
+    torch.manual_seed(seed)
+    m = torch.nn.LayerNorm(n)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(n) * 0.3 + 1.0)
+        m.bias.copy_(torch.randn(n) * 0.2)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize('m,k,n', [(900, 256, 256), (900, 256, 768), (900, 512, 256), (37, 256, 10), (1, 128, 24), (130, 256, 96)])
+def test_chain_gemm_matches_fp64(m, k, n):
+    """split-bf16 x3 products, fp32 accumulation: fp32-class (2^-16 relative per product)."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + k + n)
+    x, w, b = torch.randn(m, k), torch.randn(n, k) * 0.08, torch.randn(n)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    out = torch.empty(m, n, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(0, xd), ops.chain_gemm(0, wd, bd, out=out)], m)
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
+    out2 = torch.empty(m, n, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(0, xd), ops.chain_gemm(0, wd, bd, out=out2)], m)
+    assert torch.equal(out, out2)                                # run-to-run identical
+
+
+@pytest.mark.parametrize('heads,m', [(8, 900), (4, 45), (8, 7)])
+def test_chain_headgemm_matches_fp64_and_the_stand_alone_kernel(heads, m):
+    """HEADGEMM = gd4d_value_proj_heads_fwd as a chain operation: value_proj of the per-head aggregates."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(heads + m)
+    dh = 256 // heads
+    agg, wsum = torch.randn(m, heads, 256), torch.rand(m, heads)
+    w, b = torch.randn(256, 256) * 0.06, torch.randn(256)
+    res = torch.randn(m, 256)
+    d = [t.to(DEV) for t in (agg, wsum, w, b, res)]
+    out = torch.empty(m, 256, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(1, d[4]), ops.chain_headgemm(d[0], d[1], d[2], d[3], dst=0, res=1, out=out)], m)
+    want = torch.einsum('mhc,hdc->mhd', agg.double(), w.double().view(heads, dh, 256)) + \
+        b.double().view(heads, dh) * wsum.double().unsqueeze(-1)
+    assert (out.cpu().double() - (want.reshape(m, 256) + res.double())).abs().max().item() < 1e-4
+    alone = ops.value_proj_heads_fwd(d[0], d[1], d[2], d[3])
+    torch.testing.assert_close(out - d[4], alone, rtol=1e-4, atol=1e-4)
+    nob = torch.empty(m, 256, device=DEV)
+    ops.row_chain_fwd([ops.chain_headgemm(d[0], d[1], d[2], None, out=nob)], m)
+    assert (nob.cpu().double() - torch.einsum('mhc,hdc->mhd', agg.double(), w.double().view(heads, dh, 256)).reshape(m, 256)).abs().max().item() < 1e-4
+
+
+def test_chain_b_shaped_program_matches_torch():
+    """output_proj + two residuals, LayerNorm, FFN + residual, LayerNorm, next in-projection, reg branch, refinement - the
+    program the fused decoder loop runs after the gather (fused_decoder.run), against plain torch in fp64."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(2)
+    q, c = 900, 256
+    g = lambda *s: torch.randn(*s) * 0.06        # noqa: E731
+    agg, wsum = torch.randn(q, 8, c), torch.rand(q, 8)
+    x1, posf, pos = torch.randn(q, c), torch.randn(q, c), torch.randn(q, c)
+    wv, bv, wo, bo = g(c, c), g(c), g(c, c), g(c)
+    w1, b1, w2, b2 = g(512, c), g(512), g(c, 512), g(c)
+    win, bin_ = g(3 * c, c), g(3 * c)
+    r1, rb1, r2, rb2, r3, rb3 = g(c, c), g(c), g(c, c), g(c), g(10, c), g(10)
+    ref = torch.rand(q, 3)
+    n1, n2 = _ln(c, 1), _ln(c, 2)
+    D = lambda t: t.to(DEV)                        # noqa: E731
+    dd = {k: D(v) for k, v in dict(agg=agg, wsum=wsum, x1=x1, posf=posf, pos=pos, wv=wv, bv=bv, wo=wo, bo=bo, w1=w1, b1=b1, w2=w2,
+                                   b2=b2, win=win, bin=bin_, r1=r1, rb1=rb1, r2=r2, rb2=rb2, r3=r3, rb3=rb3, ref=ref).items()}
+    x3 = torch.empty(q, c, device=DEV)
+    qkv = torch.empty(q, 3 * c, device=DEV)
+    new_ref = torch.empty(q, 3, device=DEV)
+    prog = [ops.chain_headgemm(dd['agg'], dd['wsum'], dd['wv'], dd['bv'], dst=0),
+            ops.chain_load(3, dd['x1'], dd['posf']),
+            ops.chain_gemm(0, dd['wo'], dd['bo'], dst=1, res=3),
+            ops.chain_layernorm(1, n1, dst=2),
+            ops.chain_gemm(2, dd['w1'], dd['b1'], dst=0, relu=True),
+            ops.chain_gemm(0, dd['w2'], dd['b2'], dst=1, res=2),
+            ops.chain_layernorm(1, n2, dst=3, out=x3),
+            ops.chain_add(0, 3, c, add=dd['pos']),
+            ops.chain_gemm(0, dd['win'][:2 * c], dd['bin'][:2 * c], out=qkv[:, :2 * c]),
+            ops.chain_gemm(3, dd['win'][2 * c:], dd['bin'][2 * c:], out=qkv[:, 2 * c:]),
+            ops.chain_gemm(3, dd['r1'], dd['rb1'], dst=1, relu=True),
+            ops.chain_gemm(1, dd['r2'], dd['rb2'], dst=2, relu=True),
+            ops.chain_gemm(2, dd['r3'], dd['rb3'], dst=1),
+            ops.chain_refine(1, dd['ref'], new_ref)]
+    ops.row_chain_fwd(prog, q)
+    f = lambda t: t.double()                        # noqa: E731
+    val = (torch.einsum('mhc,hdc->mhd', f(agg), f(wv).view(8, 32, c)) + f(bv).view(8, 32) * f(wsum).unsqueeze(-1)).reshape(q, c)
+    y1 = F.linear(val, f(wo), f(bo)) + f(x1) + f(posf)
+    x2 = F.layer_norm(y1, (c,), f(n1.weight.cpu()), f(n1.bias.cpu()), n1.eps)
+    y2 = F.linear(F.linear(x2, f(w1), f(b1)).relu(), f(w2), f(b2)) + x2
+    want_x3 = F.layer_norm(y2, (c,), f(n2.weight.cpu()), f(n2.bias.cpu()), n2.eps)
+    want_qkv = torch.cat([F.linear(want_x3 + f(pos), f(win[:2 * c]), f(bin_[:2 * c])), F.linear(want_x3, f(win[2 * c:]), f(bin_[2 * c:]))], -1)
+    tmp = F.linear(F.linear(F.linear(want_x3, f(r1), f(rb1)).relu(), f(r2), f(rb2)).relu(), f(r3), f(rb3))
+    inv = lambda t: torch.log(t.clamp(min=1e-5) / (1 - t).clamp(min=1e-5))      # noqa: E731
+    want_ref = torch.stack([tmp[:, 0] + inv(f(ref)[:, 0]), tmp[:, 1] + inv(f(ref)[:, 1]), tmp[:, 4] + inv(f(ref)[:, 2])], -1).sigmoid()
+    assert (x3.cpu().double() - want_x3).abs().max().item() < 2e-4
+    assert (qkv.cpu().double() - want_qkv).abs().max().item() < 5e-4
+    assert (new_ref.cpu().double() - want_ref).abs().max().item() < 1e-4
+
+
+def test_chain_rejects_bad_programs():
+    from graph_detr4d_amd import ops
+    from graph_detr4d_amd._lib import Gd4dError
+    x = torch.randn(20, 256, device=DEV)
+    w = torch.randn(256, 256, device=DEV)
+    with pytest.raises(Gd4dError):                                   # GEMM writing its own source buffer
+        ops.row_chain_fwd([ops.chain_load(0, x), ops.chain_gemm(0, w, dst=0)], 20)
+    with pytest.raises(Gd4dError):                                   # GEMM without any destination
+        ops.row_chain_fwd([ops.chain_load(0, x), ops.chain_gemm(0, w)], 20)
+    with pytest.raises(ValueError):                                  # heads that do not divide into 32-column groups
+        ops.chain_headgemm(torch.randn(20, 16, 256, device=DEV), torch.rand(20, 16, device=DEV), w)
