@@ -77,6 +77,61 @@ __global__ __launch_bounds__(256) void pyramid_channels_last_kernel(const ClPara
   }
 }
 
+// The same copy as ONE persistent 512-thread workgroup per compute unit on `max_cus` of them (its LDS request is padded
+// past half of the CU's 160 KB so that no second one fits): the compute units it leaves alone stay completely free -
+// LDS included - for the first decoder layer's self-attention and row chains (132 KB of LDS per workgroup), which need
+// nothing from the pyramid and run underneath the copy.  Tiles of 64 pixels; the loads of the next tile are in flight
+// while the current one is written out.
+constexpr int CLP_PX = 64, CLP_THREADS = 512;
+constexpr int CLP_LDS = 84 * 1024;                              // > 80 KB: one workgroup per CU
+
+__global__ __launch_bounds__(CLP_THREADS) void pyramid_channels_last_persistent_kernel(const ClParams p) {
+  extern __shared__ __attribute__((aligned(16))) float s_tp[];  // [CLP_PX][CL_PITCH] (+ padding)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 8 waves; wave w moves channels 32 w .. 32 w + 31
+  float v[32];
+  int npx = 0, ostart = 0, pix0 = 0, row = 0;
+  auto locate = [&](int t, const float*& src, int& hw) {
+    src = p.in[0];
+    hw = p.hw[0];
+    int tiles = p.tiles[0], tbase = 0, os = p.start[0];
+#pragma unroll
+    for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
+      if (l < p.L && t >= p.tile_base[l]) { src = p.in[l]; hw = p.hw[l]; os = p.start[l]; tiles = p.tiles[l]; tbase = p.tile_base[l]; }
+    const int rel = t - tbase;
+    row = rel / tiles;
+    pix0 = (rel - row * tiles) * CLP_PX;
+    npx = min(CLP_PX, hw - pix0);
+    ostart = os;
+  };
+  auto load_tile = [&](int t) {
+    const float* src;
+    int hw;
+    locate(t, src, hw);
+    const float* gp = src + ((size_t)row * CL_C + wave * 32) * hw + pix0 + min(lane, npx - 1);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = gp[(size_t)i * hw];
+  };
+  int t = blockIdx.x;
+  if (t < p.total) load_tile(t);
+  while (t < p.total) {
+    const int c_npx = npx, c_ostart = ostart, c_pix0 = pix0, c_row = row;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s_tp[lane * CL_PITCH + wave * 32 + i] = v[i];
+    __syncthreads();
+    const int tn = t + gridDim.x;
+    if (tn < p.total) load_tile(tn);                             // in flight during the store phase
+    float* op = p.out + ((size_t)c_row * p.S + c_ostart + c_pix0) * CL_C;
+#pragma unroll
+    for (int i = 0; i < CLP_PX / 8; ++i) {
+      const int q = wave + 8 * i;
+      if (q < c_npx)
+        *reinterpret_cast<float4*>(op + (size_t)q * CL_C + lane * 4) = *reinterpret_cast<const float4*>(&s_tp[q * CL_PITCH + lane * 4]);
+    }
+    __syncthreads();
+    t = tn;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Gather of the raw features.  One workgroup (4 waves) per (batch, query); phase A (projection, mask, softmax, camera
 // weights) is gd4d_cross_attn_fwd's.  Phase B: every head belongs to ONE wave (head h -> wave h % 4), which walks the
@@ -400,17 +455,19 @@ static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
 }  // namespace gd4d
 
 extern "C" int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, float* out, int R, int C,
-                                              int L, int in_dtype, void* stream) {
+                                              int L, int in_dtype, int max_cus, void* stream) {
   using namespace gd4d;
   if (!feats || !level_hw || !out || R <= 0 || C <= 0 || L <= 0) return GD4D_EINVAL;
   if (C != CL_C || L > GD4D_MAX_LEVELS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
   if (!aligned16(out)) return GD4D_EALIGN;
+  const bool persistent = max_cus > 0;
+  const int px = persistent ? CLP_PX : CL_PX;
   ClParams p{};
   int s = 0, base = 0;
   for (int l = 0; l < L; ++l) {
     if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
     const int hw = level_hw[2 * l] * level_hw[2 * l + 1];
-    p.in[l] = static_cast<const float*>(feats[l]); p.hw[l] = hw; p.start[l] = s; p.tiles[l] = (hw + CL_PX - 1) / CL_PX;
+    p.in[l] = static_cast<const float*>(feats[l]); p.hw[l] = hw; p.start[l] = s; p.tiles[l] = (hw + px - 1) / px;
     p.tile_base[l] = base;
     s += hw;
     base += R * p.tiles[l];
@@ -418,7 +475,13 @@ extern "C" int gd4d_pyramid_channels_last_fwd(const void* const* feats, const in
   for (int l = L; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
   for (int l = L; l < GD4D_MAX_LEVELS; ++l) { p.tiles[l] = 1; p.hw[l] = 1; }
   p.out = out; p.R = R; p.L = L; p.S = s; p.total = base;
-  hipLaunchKernelGGL(pyramid_channels_last_kernel, dim3(base), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (persistent) {
+    if (!allow_dynamic_lds(reinterpret_cast<const void*>(pyramid_channels_last_persistent_kernel), CLP_LDS)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(pyramid_channels_last_persistent_kernel, dim3(min(max_cus, base)), dim3(CLP_THREADS), CLP_LDS, st, p);
+  } else {
+    hipLaunchKernelGGL(pyramid_channels_last_kernel, dim3(base), dim3(256), 0, st, p);
+  }
   return check_launch();
 }
 

@@ -429,7 +429,12 @@ class LateValues:
                 self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
                 self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev)
             else:
-                self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value])
+                # GD4D_COPY_CUS: compute units of the persistent copy (default 7/8 of the device - 192: 1.937, 224: 1.922, 256: 1.984, plain copy 2.000 ms per step - the query side of the
+                # first layer runs on the rest, underneath it); 0 = the plain one-workgroup-per-tile copy on all of them
+                env = os.environ.get('GD4D_COPY_CUS')
+                cus = torch.cuda.get_device_properties(dev).multi_processor_count
+                copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
+                self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value], max_cus=copy_cus)
             self.event = torch.cuda.Event()
             self.event.record(self.side)
         self.waited = set()

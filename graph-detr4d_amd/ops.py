@@ -76,8 +76,9 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
     return res if len(res) > 1 else out
 
 
-def pyramid_channels_last_fwd(feats, out=None):
+def pyramid_channels_last_fwd(feats, out=None, max_cus=0):
     """gd4d_pyramid_channels_last_fwd.  feats: list of L tensors (R, 256, H_l, W_l) fp32 (or (B, N, 256, H, W)).
+    max_cus > 0: one persistent workgroup on each of that many compute units (the rest stays free for another stream).
     Returns (cl (R, S, 256) fp32, level_hw)."""
     lib = _lib.load()
     fl = [f.reshape(-1, *f.shape[-3:]) for f in feats]
@@ -90,7 +91,7 @@ def pyramid_channels_last_fwd(feats, out=None):
         out = torch.empty(r, s, c, device=fl[0].device, dtype=torch.float32)
     ptrs = (ctypes.c_void_p * len(fl))(*[_dev(f, 'feats', torch.float32).value for f in fl])
     lv = (ctypes.c_int32 * (2 * len(fl)))(*[int(x) for hw in level_hw for x in hw])
-    code = lib.gd4d_pyramid_channels_last_fwd(ptrs, lv, _dev(out, 'out', torch.float32), r, c, len(fl), _lib.F32, _stream())
+    code = lib.gd4d_pyramid_channels_last_fwd(ptrs, lv, _dev(out, 'out', torch.float32), r, c, len(fl), _lib.F32, int(max_cus), _stream())
     _lib.check(code, 'gd4d_pyramid_channels_last_fwd')
     return out, level_hw
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 20
+#define GD4D_ABI_VERSION 21
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -117,6 +117,8 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
  * gd4d_pyramid_channels_last_fwd - the reference's flatten(3) / transpose / cat of the FPN levels (:264-276), once
  *   per sample instead of once per layer:  feats host array of L device pointers, level l = (R, C, H_l, W_l) fp32
  *   (R = B*N camera rows);  out (R, S, C) fp32, S = sum_l H_l*W_l, level l at pixel offset sum_{l'<l} H_l'*W_l'.
+ *   max_cus: 0 = one workgroup per tile over the whole device; > 0 = one persistent workgroup on each of max_cus compute
+ *   units, which it fills (the others stay free for kernels of another stream: the first layer's query side).
  *   Supported: C == 256, L <= 8, fp32.
  *
  * gd4d_cross_attn_agg_fwd - projection + mask + softmax / camera weights + gather of raw features.  Arguments as
@@ -131,7 +133,7 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
  *   (exact fp32 products on v_mfma_f32_16x16x4_f32); out is what gd4d_cross_attn_fwd returns (input of output_proj,
  *   :326).  weight (C, C) = value_proj.weight, bias (C) or NULL.  Supported: C == 256, Hh in {4, 8, 16}. */
 int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, float* out, int R, int C, int L,
-                                   int in_dtype, void* stream);
+                                   int in_dtype, int max_cus, void* stream);
 int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* level_hw, const float* ref, const float* offsets,
                             const float* attn_logits, const float* cam_logits, const float* lidar2img,
                             const double* pc_range, float img_h, float img_w, float* agg, float* wsum, uint8_t* mask_out,

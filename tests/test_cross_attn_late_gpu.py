@@ -30,6 +30,9 @@ def test_channels_last_is_the_reference_flatten_transpose_cat():
     cl, got_shapes = ops.pyramid_channels_last_fwd([f.cuda() for f in feats])
     assert list(map(tuple, got_shapes)) == list(map(tuple, shapes))
     assert torch.equal(cl.cpu(), flat.reshape(5, -1, 256))
+    for cus in (1, 8, 192, 4096):                                # the persistent form: one workgroup on each of `cus` CUs
+        cl2, _ = ops.pyramid_channels_last_fwd([f.cuda() for f in feats], max_cus=cus)
+        assert torch.equal(cl2, cl), cus
 
 
 @pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_edge'])
