@@ -676,14 +676,20 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
             try:
                 cl = late_cap[0]['cl']
                 vals = [f.contiguous() for f in feats]
-                ms_cl = _time_rounds([lambda: ops.pyramid_channels_last_fwd(vals, out=cl)], 5)
+                cus = torch.cuda.get_device_properties(cl.device).multi_processor_count
+                copy_cus = int(os.environ.get('GD4D_COPY_CUS') or max(8, (cus * 7 // 8) // 8 * 8))      # as Fn.LateValues launches it
+                ms_cl = _time_rounds([lambda: ops.pyramid_channels_last_fwd(vals, out=cl, max_cus=copy_cus)], 5)
                 kernels['pyramid_channels_last'] = dict(us=ms_cl * 1e3, bytes=2 * cl.numel() * 4, gbs=2 * cl.numel() * 4 / ms_cl / 1e6,
-                                                        frac=2 * cl.numel() * 4 / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1)
+                                                        frac=2 * cl.numel() * 4 / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1,
+                                                        compute_units=copy_cus,
+                                                        note='alone on the device; in the step the first layer\'s query side runs on the other CUs')
                 c0 = late_cap[0]
                 agg0, wsum0 = calls[0]()
                 m0 = c0['module']
                 ms_hp = _time_rounds([lambda: ops.value_proj_heads_fwd(agg0, wsum0, m0.value_proj.weight, m0.value_proj.bias)], 20)
-                kernels['value_proj_heads'] = dict(us=ms_hp * 1e3, launches_per_step=launches)
+                kernels['value_proj_heads'] = dict(us=ms_hp * 1e3, launches_per_step=0,
+                                                   note='stand-alone gd4d_value_proj_heads_fwd; in the fused decoder loop it is the '
+                                                        'first operation (HEADGEMM) of chain B')
             except Exception as ex:
                 kernels['pyramid_channels_last'] = {'error': f'{type(ex).__name__}: {ex}'}
             # all-visible stress case of this kernel (8 x the bytes of the projected-value form per corner: its worst case)

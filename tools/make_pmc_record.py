@@ -10,18 +10,21 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 summary, out_path, note = sys.argv[1], sys.argv[2], sys.argv[3]
+# optional 4th / 5th arguments: kernel-name substring and the source file it lives in (default: the projected-value gather)
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else 'cross_attn_fwd_block'
+SOURCE = sys.argv[5] if len(sys.argv) > 5 else 'gd4d_cross_attn.hip' 
 ctr, cur = {}, None
 for line in open(summary):
     if not line.startswith(' '):
         cur = line.strip()
         continue
-    if cur and 'cross_attn_fwd_block' in cur:
+    if cur and KERNEL in cur:
         m = re.match(r'\s+(\S+)\s+mean/dispatch\s+([0-9.]+)', line)
         if m:
             ctr[m.group(1)] = float(m.group(2))
-src = open(os.path.join(ROOT, 'graph-detr4d_amd', 'csrc', 'gd4d_cross_attn.hip'), 'rb').read()
+src = open(os.path.join(ROOT, 'graph-detr4d_amd', 'csrc', SOURCE), 'rb').read()
 rec = {
-    'kernel': 'gd4d::cross_attn_fwd_block (fused project + sample + aggregate)',
+    'kernel': 'gd4d::' + KERNEL + ' (' + SOURCE + ')',
     'kernel_source_sha256': hashlib.sha256(src).hexdigest(),
     'workload': note,
     'FETCH_SIZE_KB': ctr.get('FETCH_SIZE'), 'WRITE_SIZE_KB': ctr.get('WRITE_SIZE'),

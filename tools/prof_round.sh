@@ -2,19 +2,27 @@
 # Round measurement bundle (run on the GPU box through gpurun):
 #   1. default bench line            -> gpurun_out/<tag>/bench.json
 #   2. rocprofv3 kernel stats of the SAME command -> gpurun_out/<tag>/stats/
-#   3. PMC HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the fused kernel alone
+#   3. PMC passes (HBM traffic FETCH_SIZE / WRITE_SIZE in separate passes, L2 hits, wait buckets) of the step's gather
+#      (gd4d_cross_attn_agg_fwd, tools/bench_late.py) and of the projected-value gather (tools/bench_kernel.py)
 tag=${1:-round}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$tag
 python3 bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
-tail -c 600 gpurun_out/$tag/bench.json
+tail -c 400 gpurun_out/$tag/bench.json
 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/stats -o bench -- python3 bench.py > gpurun_out/$tag/bench_profiled.json 2> gpurun_out/$tag/bench_profiled.err
+t=$(find gpurun_out/$tag/stats -name '*kernel_trace.csv' | head -1)
+python3 tools/step_timeline.py $t > gpurun_out/$tag/step_timeline.txt 2>&1
 find gpurun_out/$tag/stats -name '*kernel_trace.csv' -delete
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
-  n=$(echo $c | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $c -f csv -d gpurun_out/$tag/pmc_$n -o pmc -- python3 tools/bench_kernel.py --iters 5 --order > gpurun_out/$tag/pmc_$n.log 2>&1
-  find gpurun_out/$tag/pmc_$n -name '*kernel_trace.csv' -delete
+for which in agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
+  name=${which%%:*}; cmd=$(echo ${which#*:} | tr ':' ' ')
+  mkdir -p gpurun_out/$tag/pmc_$name
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+    i=$((i+1))
+    rocprofv3 --kernel-trace --pmc $grp -f csv -d gpurun_out/$tag/pmc_$name/p$i -o pmc -- python3 $cmd > gpurun_out/$tag/pmc_$name/p$i.log 2>&1 || echo "pass $name $i failed"
+    find gpurun_out/$tag/pmc_$name/p$i -name '*kernel_trace.csv' -delete
+  done
+  python3 tools/pmc_summary.py gpurun_out/$tag/pmc_$name > /dev/null
 done
-python3 tools/pmc_summary.py gpurun_out/$tag
-grep -h "alg_bytes" gpurun_out/$tag/pmc_FETCH_SIZE.log | tail -1
+grep -A 14 "cross_attn_agg" gpurun_out/$tag/pmc_agg/pmc_summary.txt | head -16
