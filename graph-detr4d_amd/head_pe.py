@@ -184,14 +184,38 @@ class FeaturePositionEmbedding(nn.Module):
             out.append(o.view(f.shape))
         return out
 
+    # ---- training ---------------------------------------------------------------------------------------------------
+    def _forward_autograd(self, feats, img_metas):
+        """The stage with autograd on (the head trains through it: gradients reach the backbone's feature maps, the two
+        position MLPs and the SE gate, detr3d_head_pe.py:546-557).  The geometry needs no gradient and stays on the HIP
+        kernels (frustum coordinates -> conv input, sine / cosine expansion, padding masks); the 1x1 convolutions, the
+        gate and the adds are torch ops here, so autograd differentiates them - the split-bf16 GEMM path of inference has
+        no backward kernels yet."""
+        with torch.no_grad():
+            masks, pad_hw = self.padding_masks(img_metas, feats)
+            b, n = feats[0].shape[:2]
+            l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
+            img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(b * n, 4, 4).to(feats[0].device)   # :459-465
+            xs = [ops.frustum_pe_input_fwd(img2lidar, tuple(f.shape[-2:]), pad_hw, self.depth_num, self.depth_start,
+                                           self.pc_range)[0] for f in feats]
+            sines = [self.sine_embedding(m) for m in masks]
+        out = []
+        for f, x, s in zip(feats, xs, sines):
+            pe = self.position_encoder(x).view(f.shape)
+            gate = self.fpe.gate_logits(f.flatten(0, 1)).view(f.shape)
+            sine = self.adapt_pos3d(s.flatten(0, 1)).view(f.shape)
+            out.append(f + (pe * torch.sigmoid(gate) + sine))
+        return out
+
     # ---- the stage ------------------------------------------------------------------------------------------------
     def forward(self, mlvl_feats, img_metas):
         """mlvl_feats: list of (B, N, C, H_l, W_l) fp32 GPU tensors; returns the list with the position embedding
-        added (:546-557).  Inference only (the reference trains through these ops with autograd).
+        added (:546-557).  With autograd on: _forward_autograd (HIP geometry, torch ops for the differentiable part).
         GD4D_HEAD_PE=conv keeps the 1x1 convolutions on the library instead of gd4d_gemm_bf16x3_fwd."""
         feats = list(mlvl_feats)
         Fn.require_gpu(feats[0], 'mlvl_feats')
-        Fn.require_inference(*feats)
+        if Fn.wants_grad(self, *feats):
+            return self._forward_autograd(feats, img_metas)
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
             gemm_ok = self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256 and \
