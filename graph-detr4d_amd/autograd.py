@@ -35,8 +35,6 @@ class CrossAttnFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         value, ref, offsets, attn_logits, cam_logits, lidar2img = ctx.saved_tensors
         shapes, pc_range, img_h, img_w = ctx.meta
-        if ref.shape[0] != 1:
-            raise NotImplementedError('gd4d_cross_attn_bwd supports batch 1 per GPU (samples_per_gpu=1)')
         if value.dtype != torch.float32:
             raise NotImplementedError('training needs the fp32 value tensor (value_dtype="fp32")')
         gv, gr, go, ga, gc = ops.cross_attn_bwd(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img,

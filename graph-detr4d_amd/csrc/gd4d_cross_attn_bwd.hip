@@ -16,8 +16,11 @@
 //   -> dL/d u = sum_l W_l dL/dx_l ; dL/d v = sum_l H_l dL/dy_l ; then through u = cx / (cz Wimg),
 //      v = cy / (cz Himg), c = M [X Y Z 1]^T to the metre-space point, i.e. to offsets[h,p] and ref.
 // The visibility mask is piecewise constant (no gradient), exactly as in the reference.
-// Supported: B == 1 (training runs samples_per_gpu = 1; the forward's row pairing for B > 1 would need
-// atomics on the logit gradients), fp32 value, pixel-major layout.
+// B > 1: the forward weights value row i = b*N + n with the logits of batch (i % B) (deform3d_cross_attn.py:277, see
+// gd4d.h), so the gradient of attn_logits[bb] collects contributions from the workgroups of EVERY sample b.  The
+// geometry owner (b, q) accumulates dL/d a per class bb = (b*N + n) % B in LDS and writes B partial rows into a
+// workspace; a second small kernel sums them over b in a fixed order and applies the softmax backward.  B == 1 keeps
+// everything in one kernel.  Supported: fp32 value, pixel-major layout.
 #include "gd4d_common.h"
 
 namespace gd4d {
@@ -36,6 +39,7 @@ struct CrossAttnBwdParams {
   float* grad_attn_logits;     // (B, Q, Hh, L, P)
   float* grad_cam_logits;      // (B, Q, N), un-scrambled layout like cam_logits
   const int32_t* order;       // optional locality order of the queries (gd4d_query_order_fwd), as in the forward
+  float* ga_part;             // B > 1: (B_geometry, B_class, Q, Hh, L*P) partial dL/d a (before the softmax backward)
   int B, N, Q, L, S;
   int lvl_h[GD4D_MAX_LEVELS];
   int lvl_w[GD4D_MAX_LEVELS];
@@ -56,7 +60,7 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <int HH, int LT, int WAVES>
+template <int HH, int LT, int WAVES, bool BMULTI>
 __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const CrossAttnBwdParams p) {
   constexpr int DH = kBC / HH;
   constexpr int LPH = DH / 4;                     // lanes per head
@@ -69,6 +73,7 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
   constexpr int PSTRIDE = LP + 3 * kBP;
   int* s_camvis = reinterpret_cast<int*>(s_part + WAVES * HH * PSTRIDE);
   float* s_pt = reinterpret_cast<float*>(s_camvis + 64);                   // [E][3] metre-space points
+  float* s_gab = s_pt + E * 3;                                             // BMULTI: [WAVES][B][HH][LP] dL/d a per logit class
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,6 +91,8 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
   const int q = bq - b * p.Q;
   const int h = lane / LPH;
   const int sub = lane % LPH;                     // position inside the head's lane group
+  if (BMULTI)
+    for (int i = tid; i < WAVES * p.B * HH * LP; i += GD4D_WAVE * WAVES) s_gab[i] = 0.f;
 
   // metre-space sample points of this query (same arithmetic as the forward)
   {
@@ -99,10 +106,10 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
   }
   __syncthreads();
 
-  // softmax weights of this lane's head
+  // softmax weights of this lane's head (B > 1: of the logit class of each camera, recomputed per camera)
   float aw[LP];
-  {
-    const float* lg = p.attn_logits + ((size_t)bq * HH + h) * LP;
+  auto softmax_of = [&](int bb) {
+    const float* lg = p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * LP;
     float mx = lg[0];
 #pragma unroll
     for (int i = 1; i < LP; ++i) mx = fmaxf(mx, lg[i]);
@@ -112,7 +119,8 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int i = 0; i < LP; ++i) aw[i] *= inv;
-  }
+  };
+  if (!BMULTI) softmax_of(b);
   const float4 g = *reinterpret_cast<const float4*>(p.grad_out + (size_t)bq * kBC + lane * 4);
   // the same row again, lane-contiguous: channel 64 i + lane.  The atomic adds into grad_value use THIS mapping, so one
   // wave instruction covers whole 128-byte lines (64 consecutive channels of a pixel row) instead of 8 dwords in each
@@ -153,6 +161,12 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
     }
     const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];
     const float cw = 1.0f / (1.0f + expf(-cl));
+    const int bb = BMULTI ? row % p.B : 0;           // logit class of this value row (:277)
+    if (BMULTI) {
+      softmax_of(bb);
+#pragma unroll
+      for (int i = 0; i < LP; ++i) ga[i] = 0.f;      // per camera; parked per class below
+    }
     const float* vrow = p.value + (size_t)row * p.S * kBC;
     float* gvrow = p.grad_value + (size_t)row * p.S * kBC;
     float cam_acc = 0.f;                             // sum_{l,p} a * T of this head (group-uniform)
@@ -216,6 +230,11 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
       gpt[k][1] += gcx * m[1] + gcy * m[5] + gcz * m[9];
       gpt[k][2] += gcx * m[2] + gcy * m[6] + gcz * m[10];
     }
+    if (BMULTI && sub == 0) {                        // one lane per (wave, head): no race
+      float* dst = s_gab + (((size_t)wave * p.B + bb) * HH + h) * LP;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) dst[i] += ga[i];
+    }
     // camera-logit gradient: sum over heads of (a * T), one lane per head then across the groups
     float cs = (sub == 0) ? cam_acc : 0.f;
 #pragma unroll
@@ -242,6 +261,18 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
       for (int w = 0; w < WAVES; ++w) t += s_part[((size_t)w * HH + hh) * PSTRIDE + i];
       tot[i] = t;
     }
+    if (BMULTI) {                                    // partial dL/d a of every class -> workspace; softmax backward later
+      for (int cls = 0; cls < p.B; ++cls) {
+        float* dstp = p.ga_part + ((((size_t)b * p.B + cls) * p.Q + q) * HH + hh) * LP;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) t += s_gab[(((size_t)w * p.B + cls) * HH + hh) * LP + i];
+          dstp[i] = t;
+        }
+      }
+    }
     // softmax backward: dlogit_i = a_i (ga_i - sum_j a_j ga_j)
     const float* lg = p.attn_logits + ((size_t)bq * HH + hh) * LP;
     float a2[LP];
@@ -254,9 +285,11 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < LP; ++i) { a2[i] /= sum; dot += a2[i] * tot[i]; }
-    float* gl = p.grad_attn_logits + ((size_t)bq * HH + hh) * LP;
+    if (!BMULTI) {
+      float* gl = p.grad_attn_logits + ((size_t)bq * HH + hh) * LP;
 #pragma unroll
-    for (int i = 0; i < LP; ++i) gl[i] = a2[i] * (tot[i] - dot);
+      for (int i = 0; i < LP; ++i) gl[i] = a2[i] * (tot[i] - dot);
+    }
     float* go = p.grad_offsets + ((size_t)bq * HH + hh) * kBP * 3;
 #pragma unroll
     for (int i = 0; i < kBP * 3; ++i) go[i] = tot[LP + i];
@@ -277,24 +310,71 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
   }
 }
 
+// B > 1: grad_attn_logits[bb, q, h, :] from the partial rows of all geometry owners b (fixed order) - softmax backward.
+template <int LP>
+__global__ __launch_bounds__(64) void cross_attn_bwd_logits_kernel(const CrossAttnBwdParams p, int HH) {
+  const int bbq = blockIdx.x;                      // bb * Q + q
+  const int bb = bbq / p.Q, q = bbq - bb * p.Q;
+  const int hh = threadIdx.x;
+  if (hh >= HH) return;
+  float tot[LP];
+#pragma unroll
+  for (int i = 0; i < LP; ++i) tot[i] = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    const float* src = p.ga_part + ((((size_t)b * p.B + bb) * p.Q + q) * HH + hh) * LP;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) tot[i] += src[i];
+  }
+  const float* lg = p.attn_logits + ((size_t)bbq * HH + hh) * LP;
+  float a2[LP];
+  float mx = lg[0];
+#pragma unroll
+  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { a2[i] = expf(lg[i] - mx); sum += a2[i]; }
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { a2[i] /= sum; dot += a2[i] * tot[i]; }
+  float* gl = p.grad_attn_logits + ((size_t)bbq * HH + hh) * LP;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) gl[i] = a2[i] * (tot[i] - dot);
+}
+
 template <int HH>
 static int launch_bwd(const CrossAttnBwdParams& p, hipStream_t s) {
   constexpr int WAVES = 4;
   const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
+  const bool multi = p.B > 1;
   auto lds_for = [&](int L) {
-    return (size_t)WAVES * HH * (L * kBP + 3 * kBP) * sizeof(float) + 64 * sizeof(int) + (size_t)HH * kBP * 3 * sizeof(float);
+    return (size_t)WAVES * HH * (L * kBP + 3 * kBP) * sizeof(float) + 64 * sizeof(int) + (size_t)HH * kBP * 3 * sizeof(float) +
+           (multi ? (size_t)WAVES * p.B * HH * L * kBP * sizeof(float) : 0);
   };
+#define GD4D_BWD_GO(L_)                                                                                                       \
+  if (multi) {                                                                                                                \
+    hipLaunchKernelGGL((cross_attn_bwd_block<HH, L_, WAVES, true>), grid, dim3(GD4D_WAVE * WAVES), lds_for(L_), s, p);        \
+    if (int rc = check_launch()) return rc;                                                                                   \
+    hipLaunchKernelGGL((cross_attn_bwd_logits_kernel<L_ * kBP>), dim3(p.B * p.Q), dim3(64), 0, s, p, HH);                     \
+  } else {                                                                                                                    \
+    hipLaunchKernelGGL((cross_attn_bwd_block<HH, L_, WAVES, false>), grid, dim3(GD4D_WAVE * WAVES), lds_for(L_), s, p);       \
+  }
   switch (p.L) {
-    case 1: hipLaunchKernelGGL((cross_attn_bwd_block<HH, 1, WAVES>), grid, dim3(GD4D_WAVE * WAVES), lds_for(1), s, p); break;
-    case 2: hipLaunchKernelGGL((cross_attn_bwd_block<HH, 2, WAVES>), grid, dim3(GD4D_WAVE * WAVES), lds_for(2), s, p); break;
-    case 3: hipLaunchKernelGGL((cross_attn_bwd_block<HH, 3, WAVES>), grid, dim3(GD4D_WAVE * WAVES), lds_for(3), s, p); break;
-    case 4: hipLaunchKernelGGL((cross_attn_bwd_block<HH, 4, WAVES>), grid, dim3(GD4D_WAVE * WAVES), lds_for(4), s, p); break;
+    case 1: GD4D_BWD_GO(1) break;
+    case 2: GD4D_BWD_GO(2) break;
+    case 3: GD4D_BWD_GO(3) break;
+    case 4: GD4D_BWD_GO(4) break;
     default: return GD4D_EUNSUPPORTED;
   }
+#undef GD4D_BWD_GO
   return check_launch();
 }
 
 }  // namespace gd4d
+
+extern "C" size_t gd4d_cross_attn_bwd_workspace_bytes(int B, int Q, int Hh, int L, int P) {
+  if (B <= 1 || Q <= 0 || Hh <= 0 || L <= 0 || P <= 0) return 0;
+  return (size_t)B * B * Q * Hh * L * P * sizeof(float);
+}
 
 extern "C" int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, const float* ref,
                                    const float* offsets, const float* attn_logits, const float* cam_logits,
@@ -302,21 +382,24 @@ extern "C" int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, c
                                    const float* grad_out, void* grad_value, float* grad_ref,
                                    float* grad_offsets, float* grad_attn_logits, float* grad_cam_logits,
                                    int B, int N, int Q, int Hh, int Dh, int L, int P, int value_dtype,
-                                   int value_layout, const int32_t* query_order, void* stream) {
+                                   int value_layout, const int32_t* query_order, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   using namespace gd4d;
   if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range ||
       !grad_out || !grad_value || !grad_ref || !grad_offsets || !grad_attn_logits || !grad_cam_logits)
     return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || Dh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
-  if (B != 1 || Hh * Dh != kBC || P != kBP || L > 4 || N > 64 || value_dtype != GD4D_F32 ||
+  if (B > 8 || Hh * Dh != kBC || P != kBP || L > 4 || N > 64 || value_dtype != GD4D_F32 ||
       value_layout != GD4D_LAYOUT_PIXEL_MAJOR)
     return GD4D_EUNSUPPORTED;
+  if (B > 1 && (!workspace || workspace_bytes < gd4d_cross_attn_bwd_workspace_bytes(B, Q, Hh, L, P))) return GD4D_EWORKSPACE;
   if (!aligned16(value) || !aligned16(grad_out) || !aligned16(grad_value)) return GD4D_EALIGN;
   CrossAttnBwdParams p{};
   p.value = static_cast<const float*>(value); p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits;
   p.cam_logits = cam_logits; p.lidar2img = lidar2img; p.grad_out = grad_out;
   p.grad_value = static_cast<float*>(grad_value); p.grad_ref = grad_ref; p.grad_offsets = grad_offsets;
   p.grad_attn_logits = grad_attn_logits; p.grad_cam_logits = grad_cam_logits; p.order = query_order;
+  p.ga_part = static_cast<float*>(workspace);
   p.B = B; p.N = N; p.Q = Q; p.L = L;
   int start = 0;
   for (int l = 0; l < L; ++l) {

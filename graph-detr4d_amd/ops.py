@@ -687,13 +687,16 @@ def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
     gc = torch.empty(b, q, n, device=ref.device, dtype=f32)
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
     rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    nbytes = lib.gd4d_cross_attn_bwd_workspace_bytes(b, q, hh, nl, p)          # B > 1: partial logit gradients per sample
+    ws = torch.empty(nbytes, device=ref.device, dtype=torch.uint8) if nbytes else None
     code = lib.gd4d_cross_attn_bwd(
         _dev(value, 'value', f32), lv, _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32),
         _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32),
         _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(grad_out, 'grad_out', f32),
         _dev(gv, 'grad_value'), _dev(gr, 'grad_ref'), _dev(go, 'grad_offsets'), _dev(ga, 'grad_attn_logits'),
         _dev(gc, 'grad_cam_logits'), b, n, q, hh, dh, nl, p, _lib.F32, _lib.PIXEL_MAJOR,
-        None if query_order is None else _order_ptr(query_order, b * q), _stream())
+        None if query_order is None else _order_ptr(query_order, b * q),
+        None if ws is None else _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), _stream())
     _lib.check(code, 'gd4d_cross_attn_bwd')
     return gv, gr, go, ga, gc
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 21
+#define GD4D_ABI_VERSION 22
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -529,7 +529,11 @@ int gd4d_edge_conv_max_fwd(const float* a, const float* b_self, const int32_t* i
  *   grad_offsets      (B, Q, Hh, P, 3) dL/d offsets (metres)
  *   grad_attn_logits  (B, Q, Hh, L, P)
  *   grad_cam_logits   (B, Q, N)        in the un-scrambled layout of cam_logits
- * Supported: B == 1 (samples_per_gpu = 1, every training config), fp32 pixel-major value, L <= 4.
+ *   workspace         B > 1 only: gd4d_cross_attn_bwd_workspace_bytes(B, Q, Hh, L, P) bytes.  The forward weights value row
+ *                     i = b*N + n with the logits of batch (i % B) (:277), so grad_attn_logits[bb] collects contributions of
+ *                     every sample b: each (b, q) workgroup writes its partial per logit class, a second launch adds them
+ *                     over b in a fixed order and applies the softmax backward.  NULL / 0 for B == 1.
+ * Supported: B <= 8, fp32 pixel-major value, L <= 4.
  * Accumulation order of grad_value is not deterministic (fp32 atomics), like the mmcv kernel.
  * query_order: optional, as in gd4d_cross_attn_fwd (scheduling only: the atomic adds into grad_value of queries that
  * look at the same camera region meet in one XCD's L2; 847 -> 826 us at the headline size).
@@ -539,8 +543,9 @@ int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, const float*
                         const double* pc_range, float img_h, float img_w, const float* grad_out,
                         void* grad_value, float* grad_ref, float* grad_offsets, float* grad_attn_logits,
                         float* grad_cam_logits, int B, int N, int Q, int Hh, int Dh, int L, int P,
-                        int value_dtype, int value_layout, const int32_t* query_order,
-                       void* stream);
+                        int value_dtype, int value_layout, const int32_t* query_order, void* workspace,
+                        size_t workspace_bytes, void* stream);
+size_t gd4d_cross_attn_bwd_workspace_bytes(int B, int Q, int Hh, int L, int P);
 
 /* --------------------------------------------------------------------------------------------
  * Training-side step right after the path: HungarianAssigner3D's cost matrix and the per-layer

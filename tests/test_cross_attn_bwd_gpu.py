@@ -23,8 +23,10 @@ def _case(name):
     return g, m, shapes, l2i, t
 
 
-@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_edge'])
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_edge', 'deform_n24_b2'])
 def test_backward_matches_autograd_of_oracle(name):
+    """deform_n24_b2: batch 2 - the forward pairs value row b*N + n with the logits of batch (b*N + n) % B
+    (deform3d_cross_attn.py:277), so grad_attn_logits of a batch collects rows of both samples."""
     from graph_detr4d_amd import ops
     from oracle import torch_oracle as O
     g, m, shapes, l2i, t = _case(name)
@@ -73,4 +75,37 @@ def test_backward_full_size_runs_and_is_consistent():
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
     assert ga.abs().max() > 0 and gc.abs().max() > 0 and go.abs().max() > 0
     # softmax-logit gradients sum to zero per head
+    assert ga.sum(dim=(-1, -2)).abs().max().item() < 1e-3
+
+
+def test_backward_batch3_against_oracle_seeded():
+    """B = 3, N = 7 (N not a multiple of B: every sample meets every logit class): all five gradients against autograd
+    of the oracle; the logit gradients sum to zero per head."""
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import torch_oracle as O
+    torch.manual_seed(9)
+    b, q, n = 3, 40, 7
+    levels = [(16, 28), (8, 14), (4, 7), (2, 4)]
+    rig = torch.from_numpy(synthetic.camera_rig(2)[:n])
+    l2i = rig.unsqueeze(0).expand(b, -1, -1, -1).contiguous()
+    t = dict(value=torch.randn(b * n, sum(h * w for h, w in levels), 8, 32), ref=torch.rand(b, q, 3),
+             offsets=torch.randn(b, q, 8, 4, 3) * 2.0, attn=torch.randn(b, q, 8, 16), cam=torch.randn(b, q, n))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    out, _, _ = O.sample_aggregate(leaves['value'], levels, leaves['ref'], leaves['offsets'], leaves['attn'], leaves['cam'], l2i,
+                                   synthetic.PC_RANGE, 900, 1600)
+    gout = torch.randn_like(out)
+    (out * gout).sum().backward()
+    d = {k: v.cuda() for k, v in t.items()}
+    fwd = ops.cross_attn_fwd(d['value'], levels, d['ref'], d['offsets'], d['attn'].view(b, q, 8, 4, 4).contiguous(), d['cam'],
+                             l2i.cuda(), synthetic.PC_RANGE, 900, 1600)
+    torch.testing.assert_close(fwd.cpu(), out.detach(), rtol=1e-4, atol=1e-4)
+    gv, gr, go, ga, gc = ops.cross_attn_bwd(d['value'], levels, d['ref'], d['offsets'], d['attn'].view(b, q, 8, 4, 4).contiguous(),
+                                            d['cam'], l2i.cuda(), synthetic.PC_RANGE, 900, 1600, gout.cuda())
+    tol = dict(rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(gv.cpu(), leaves['value'].grad, **tol)
+    torch.testing.assert_close(ga.cpu().flatten(-2), leaves['attn'].grad, **tol)
+    torch.testing.assert_close(gc.cpu(), leaves['cam'].grad, **tol)
+    for got, want in ((go.cpu(), leaves['offsets'].grad), (gr.cpu(), leaves['ref'].grad)):
+        scale = want.abs().max().clamp(min=1e-6)
+        assert ((got - want).abs().max() / scale).item() < 2e-3
     assert ga.sum(dim=(-1, -2)).abs().max().item() < 1e-3

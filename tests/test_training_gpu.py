@@ -14,8 +14,9 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp(min=1e-8)).item()
 
 
-@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth'])
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_n24_b2'])
 def test_cross_attn_module_gradients(name):
+    """deform_n24_b2: the batch-2 fixture (the reference's row-pairing of value rows and logits, :277, in both directions)."""
     from oracle import torch_oracle as O
     g = Golden(name)
     m = g.meta
