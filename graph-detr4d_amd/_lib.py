@@ -22,6 +22,7 @@ SIGNATURES = {
     'gd4d_abi_version': (_i, []),
     'gd4d_error_string': (_c.c_char_p, [_i]),
     'gd4d_last_hip_error': (_c.c_char_p, []),
+    'gd4d_trace_enable': (_i, [_vp]),
     'gd4d_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'gd4d_pyramid_channels_last_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -23,3 +23,15 @@ extern "C" const char* gd4d_error_string(int code) {
 extern "C" const char* gd4d_last_hip_error(void) {
   return gd4d::g_last == hipSuccess ? "" : hipGetErrorString(gd4d::g_last);
 }
+
+// dev: device-side timeline of the kernels of a (replayed) step - see gd4d_common.h / tools/trace_step.py
+extern "C" void gd4d_trace_set_rowchain(unsigned long long*);
+extern "C" void gd4d_trace_set_mha(unsigned long long*);
+extern "C" void gd4d_trace_set_late(unsigned long long*);
+extern "C" int gd4d_trace_enable(void* buffer) {
+  unsigned long long* p = static_cast<unsigned long long*>(buffer);
+  gd4d_trace_set_rowchain(p);
+  gd4d_trace_set_mha(p);
+  gd4d_trace_set_late(p);
+  return GD4D_OK;
+}

@@ -62,4 +62,17 @@ __device__ __forceinline__ float inv_sigmoid(float x) {
   return logf(a / b);
 }
 
+// ---- dev tracing (gd4d_trace_enable): block 0 of a kernel stamps s_memrealtime (100 MHz) at entry / exit -----------
+// buffer: [0] entries written, [1] capacity (entries), then {id, time} pairs.  One device-global pointer per translation
+// unit (no relocatable device code); nullptr = off: one scalar load per kernel.
+#define GD4D_TRACE_UNIT(tag)                                                                          \
+  __device__ unsigned long long* g_trace_##tag = nullptr;                                              \
+  void trace_set_##tag(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_##tag), &p, sizeof(p)); }
+__device__ __forceinline__ void trace_mark(unsigned long long* t, unsigned long long id) {
+  if (t && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    const unsigned long long slot = atomicAdd(t, 1ull);
+    if (slot < t[1]) { t[2 + 2 * slot] = id; t[3 + 2 * slot] = __builtin_amdgcn_s_memrealtime(); }
+  }
+}
+
 }  // namespace gd4d

@@ -31,6 +31,8 @@ namespace gd4d {
 // NCHW -> channels-last.  One workgroup = 32 pixels x 256 channels of one (camera row, level): 128-byte pixel runs in,
 // one contiguous 32-KB block out, turned through LDS (pitch 260 floats: the dword writes of a half-wave are 2-way
 // conflicted at most, which costs nothing on ds_write_b32; the float4 reads are aligned).
+GD4D_TRACE_UNIT(late)
+
 struct ClParams {
   const float* in[GD4D_MAX_LEVELS];    // level l: (R, C, HW_l) fp32
   int hw[GD4D_MAX_LEVELS];
@@ -88,6 +90,7 @@ constexpr int CLP_LDS = 84 * 1024;                              // > 80 KB: one 
 __global__ __launch_bounds__(CLP_THREADS) void pyramid_channels_last_persistent_kernel(const ClParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_tp[];  // [CLP_PX][CL_PITCH] (+ padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 8 waves; wave w moves channels 32 w .. 32 w + 31
+  trace_mark(g_trace_late, 4ull);
   float v[32];
   int npx = 0, ostart = 0, pix0 = 0, row = 0;
   auto locate = [&](int t, const float*& src, int& hw) {
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(CLP_THREADS) void pyramid_channels_last_persistent_
     __syncthreads();
     t = tn;
   }
+  trace_mark(g_trace_late, 0x84ull);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  trace_mark(g_trace_late, 3ull);
   int bq = blockIdx.x;
   if (p.order) {                                   // XCD-contiguous ranges of the locality order (see gd4d_cross_attn_fwd)
     const int per_xcd = (p.B * p.Q + 7) >> 3;
@@ -453,6 +458,8 @@ static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
 }
 
 }  // namespace gd4d
+
+extern "C" void gd4d_trace_set_late(unsigned long long* p) { gd4d::trace_set_late(p); }
 
 extern "C" int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, float* out, int R, int C,
                                               int L, int in_dtype, int max_cus, void* stream) {

@@ -24,6 +24,8 @@ namespace gd4d {
 
 typedef __attribute__((ext_vector_type(4))) float rc4;
 
+GD4D_TRACE_UNIT(rowchain)
+
 constexpr int RC_M = 16;            // rows per workgroup
 constexpr int RC_WAVES = 4;
 constexpr int RC_LD = 516;          // floats per LDS row (512 + 4: the float4 row reads of 16 rows spread over the banks)
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * RC_M;
+  trace_mark(g_trace_rowchain, 1ull | ((unsigned long long)nops << 8));
 #if RC_PREFETCH
   // The weight images of a program (2.6 MB for chain B) are cold in this XCD's L2 when the launch starts - another
   // kernel streamed through it since their last use - and the GEMMs below fetch them with 32 KB per wave in flight: at
@@ -450,9 +453,12 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
 #if RC_PREFETCH
   asm volatile("s_waitcnt vmcnt(0)" :: "v"(rc_sink) : "memory");     // (long since returned) keeps the sink register reserved
 #endif
+  trace_mark(g_trace_rowchain, 0x81ull | ((unsigned long long)nops << 8));
 }
 
 }  // namespace gd4d
+
+extern "C" void gd4d_trace_set_rowchain(unsigned long long* p) { gd4d::trace_set_rowchain(p); }
 
 extern "C" size_t gd4d_chain_op_bytes(void) { return sizeof(gd4d_chain_op); }
 

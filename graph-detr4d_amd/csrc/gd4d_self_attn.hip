@@ -33,7 +33,10 @@ struct MhaParams {
 constexpr int MHA_D = 32;
 constexpr int MHA_WAVES = 8;
 
+GD4D_TRACE_UNIT(mha)
+
 __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParams p) {
+  trace_mark(g_trace_mha, 2ull);
   __shared__ float s_m[MHA_WAVES][16];
   __shared__ float s_l[MHA_WAVES][16];
   __shared__ float s_o[MHA_WAVES][MHA_D][17];
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
 }
 
 }  // namespace gd4d
+
+extern "C" void gd4d_trace_set_mha(unsigned long long* p) { gd4d::trace_set_mha(p); }
 
 extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask,
                                  float* out, int Lq, int Lk, int B, int H, int D, int ldq, int ldk,

@@ -60,6 +60,10 @@ int gd4d_abi_version(void);
 const char* gd4d_error_string(int code);
 /* Text of the last HIP error seen by this thread inside the library ("" if none). */
 const char* gd4d_last_hip_error(void);
+/* dev: device-side timeline.  buffer = device uint64 array {entries written, capacity, then (id, 100-MHz time) pairs}
+ * zeroed by the caller with [1] = capacity; block 0 of the row-chain, attention-core, channels-last and aggregate kernels
+ * stamps its entry (and exit) time while a buffer is set.  NULL disables.  Synchronises the device (hipMemcpyToSymbol). */
+int gd4d_trace_enable(void* buffer);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_cross_attn_fwd - fused 3D->2D projection + visibility mask + masked softmax weights +
