@@ -355,8 +355,8 @@ __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][R
 // to manage, and a hipGraph capture keeps its own copy.  It is read through the kernarg pointer with a run-time index
 // (wave-uniform scalar loads); indexing the by-value struct directly would make the compiler copy it to scratch.
 struct ChainProgram {
-  int nops, M, pad0, pad1;
-  ChainOp ops[GD4D_CHAIN_MAX_OPS];
+  int nops, M, nops2, split;      // split > 0: workgroups [0, split) run ops[0, nops), workgroups [split, 2 split) run
+  ChainOp ops[GD4D_CHAIN_MAX_OPS];   // ops[nops, nops + nops2) over the SAME rows (gd4d_row_chain2_fwd)
 };
 
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainProgram by_value) {
@@ -366,12 +366,17 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
 #else
   const ChainProgram* pp = &by_value;
 #endif
-  const int nops = pp->nops, M = pp->M;
+  const int M = pp->M, split = pp->split;
+  const bool second = split > 0 && (int)blockIdx.x >= split;       // workgroup-uniform: which of the two programs
+  const int op_base = second ? pp->nops : 0;
+  const int nops = second ? pp->nops2 : pp->nops;
+  const int wg = second ? (int)blockIdx.x - split : (int)blockIdx.x;   // row block
+  const int wg_lo = second ? split : 0, wg_hi = split > 0 ? (second ? 2 * split : split) : (int)gridDim.x;
   (void)by_value;
   extern __shared__ __attribute__((aligned(16))) char rc_smem[];
   float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * RC_M;
+  const int m0 = wg * RC_M;
   trace_mark(g_trace_rowchain, 1ull | ((unsigned long long)nops << 8));
 #if RC_PREFETCH
   // The weight images of a program (2.6 MB for chain B) are cold in this XCD's L2 when the launch starts - another
@@ -383,8 +388,11 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   // nor counts them; they are older than every load it does count, and vmcnt retires in order).
   unsigned rc_sink = 0;
   {
-    const unsigned xcd = blockIdx.x & 7u, mine = blockIdx.x >> 3, share = (gridDim.x - xcd + 7u) >> 3;
-    for (int oi = 0; oi < nops; ++oi) {
+    // the workgroups of THIS program that sit on this XCD: indices first, first + 8, ... below wg_hi
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned first = (unsigned)wg_lo + ((xcd - (unsigned)wg_lo) & 7u);
+    const unsigned mine = (blockIdx.x - first) >> 3, share = ((unsigned)wg_hi - 1u - first) / 8u + 1u;
+    for (int oi = op_base; oi < op_base + nops; ++oi) {
       if (pp->ops[oi].kind == GD4D_CHAIN_HEADGEMM) {           // this workgroup's own aggregate rows (written by another XCD: cold)
         const int rows = min(RC_M, M - m0);
         const char* a = reinterpret_cast<const char*>(pp->ops[oi].p2 + (size_t)m0 * pp->ops[oi].ld0 * pp->ops[oi].K);
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
     }
   }
 #endif
-  for (int oi = 0; oi < nops; ++oi) {
+  for (int oi = op_base; oi < op_base + nops; ++oi) {
     const ChainOp op = pp->ops[oi];                        // uniform: scalar loads
     switch (op.kind) {
       case GD4D_CHAIN_LOAD: {                              // dst[:, :N] = f(p0[m, :N]) (+ p1[m, :N])
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
         for (int e = tid; e < RC_M * op.N; e += 64 * RC_WAVES) {
           const int row = e / op.N, n = e - row * op.N;
           float v = op.p1 ? op.p1[n] : 0.f;
-          for (int k = 0; k < op.K; ++k) v = fmaf(bufs[op.src][row][k], op.p0[(size_t)n * op.K + k], v);
+          for (int k = 0; k < op.K; ++k) v = fmaf(rc_act_in(bufs[op.src][row][k], op.flags), op.p0[(size_t)n * op.K + k], v);
           if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
           bufs[op.dst][row][n] = v;
         }
@@ -443,6 +451,9 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
           o[0] = 1.0f / (1.0f + expf(-x));
           o[1] = 1.0f / (1.0f + expf(-y));
           o[2] = 1.0f / (1.0f + expf(-z));
+          if (op.dst >= 0) { bufs[op.dst][tid][0] = o[0]; bufs[op.dst][tid][1] = o[1]; bufs[op.dst][tid][2] = o[2]; }
+        } else if (tid < RC_M && op.dst >= 0) {              // rows past M: finite filler (never stored)
+          bufs[op.dst][tid][0] = bufs[op.dst][tid][1] = bufs[op.dst][tid][2] = 0.5f;
         }
         break;
       }
@@ -478,10 +489,8 @@ extern "C" int gd4d_chain_weight_image(const float* weight, int N, int K, void* 
   return check_launch();
 }
 
-extern "C" int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream) {
+static int rc_validate(const gd4d_chain_op* program, int nops) {
   using namespace gd4d;
-  if (!program || nops <= 0 || M <= 0) return GD4D_EINVAL;
-  if (nops > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
   for (int i = 0; i < nops; ++i) {
     const gd4d_chain_op& op = program[i];
     const bool buf_ok = op.src < RC_BUFS && op.dst < RC_BUFS && op.res < RC_BUFS;
@@ -519,17 +528,39 @@ extern "C" int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M,
           return GD4D_EINVAL;
         break;
       case GD4D_CHAIN_REFINE:
-        if (op.src < 0 || !op.p0 || !op.gout) return GD4D_EINVAL;
+        if (op.src < 0 || !op.p0 || !op.gout || (op.dst >= 0 && op.dst == op.src)) return GD4D_EINVAL;
         break;
       default: return GD4D_EINVAL;
     }
   }
+  return GD4D_OK;
+}
+
+static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int nb, int M, void* stream) {
+  using namespace gd4d;
+  if (!a || na <= 0 || M <= 0 || nb < 0 || (nb > 0 && !b)) return GD4D_EINVAL;
+  if (na + nb > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
+  if (int rc = rc_validate(a, na)) return rc;
+  if (nb > 0)
+    if (int rc = rc_validate(b, nb)) return rc;
   const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD;
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
+  const int blocks = (M + RC_M - 1) / RC_M;
   ChainProgram prog{};
-  prog.nops = nops; prog.M = M;
-  for (int i = 0; i < nops; ++i) prog.ops[i] = program[i];
-  hipLaunchKernelGGL(row_chain_kernel, dim3((M + RC_M - 1) / RC_M), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream),
+  prog.nops = na; prog.M = M; prog.nops2 = nb; prog.split = nb > 0 ? blocks : 0;
+  for (int i = 0; i < na; ++i) prog.ops[i] = a[i];
+  for (int i = 0; i < nb; ++i) prog.ops[na + i] = b[i];
+  hipLaunchKernelGGL(row_chain_kernel, dim3(nb > 0 ? 2 * blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream),
                      prog);
   return check_launch();
+}
+
+extern "C" int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream) {
+  return rc_launch(program, nops, nullptr, 0, M, stream);
+}
+
+extern "C" int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
+                                   void* stream) {
+  if (!program_b || nops_b <= 0) return GD4D_EINVAL;
+  return rc_launch(program_a, nops_a, program_b, nops_b, M, stream);
 }

@@ -121,6 +121,126 @@ def _position_features(ca, reference_points, q):
     return out, ref3d
 
 
+def _position_ops(ca, out, ref=None, ref_buf=None):
+    """position_encoder(inverse_sigmoid(ref)) (deform3d_cross_attn.py:104-111, 331-334) as chain operations writing `out`
+    (Q, C): from the global reference points `ref` (Q, 3), or from the points a REFINE operation parked in LDS buffer
+    `ref_buf` (columns 0..2).  depth_encode = False only."""
+    seq = ca.position_encoder
+    if ref_buf is None:
+        head, src, inv = [ops.chain_load(0, ref, inv_sigmoid=True)], 0, False
+    else:
+        head, src, inv = [], ref_buf, True
+    mid = 1 if src != 1 else 2
+    nxt = [b for b in (0, 2, 3) if b not in (src, mid)][0]
+    return head + [ops.chain_small_linear(src, seq[0].weight, seq[0].bias, mid, inv_sigmoid=inv),
+                   ops.chain_layernorm(mid, seq[1], dst=nxt, relu=True),
+                   ops.chain_gemm(nxt, seq[3].weight, seq[3].bias, dst=mid),
+                   ops.chain_layernorm(mid, seq[4], relu=True, out=out)]
+
+
+def run_single(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, order,
+               return_intermediate, late):
+    """The decoder loop on ONE stream (besides the channels-last copy's).  A cross-stream dependency costs ~10 us in a
+    replayed hipGraph against ~2 us for a kernel boundary on one stream (tools/trace_step.py), and the auxiliary-stream
+    schedule of run() pays four of them per layer.  Here what used to run on the auxiliary stream - the previous layer's
+    reg branch + reference-point refinement and this layer's position_encoder, all row-local and off the
+    self-attention's path - is the SECOND program of chain A's launch (gd4d_row_chain2_fwd: twice the workgroups, each
+    half on its own compute units):
+
+        attention core -> [chain A | reg(l-1), refine, position_encoder(l)] -> aggregate -> chain B'
+
+    The locality order of the queries is the one of the initial reference points for every layer (the refinements move a
+    point little; a stale order costs ~2 us per aggregate launch, a fresh one a launch + boundary on the critical path)."""
+    q, _, c = query.shape
+    dev = query.device
+    layers = list(decoder.layers)
+    nl = len(layers)
+    if attn_masks is None:
+        attn_masks = [None, None]
+    elif torch.is_tensor(attn_masks):
+        attn_masks = [attn_masks, attn_masks]
+    lidar2img = Fn.lidar2img_device(img_metas, query)
+    img_h, img_w = Fn.img_hw(img_metas)
+    x = query[:, 0, :]
+    pos = query_pos[:, 0, :]
+    keep = []
+    qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1)), q)
+    n_out = nl if return_intermediate else 1
+    out_all = torch.empty(n_out, q, 1, c, device=dev, dtype=torch.float32)
+    ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
+    ref = reference_points.contiguous()
+    pending = None                                       # (reg linears, x of the previous layer, its ref, where the new ref goes)
+    for lid, layer in enumerate(layers):
+        sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+        hh, npt, nlv, ncam = ca.num_heads, ca.num_points, ca.num_levels, ca.num_cams
+        last = lid + 1 == nl
+        slot = lid if return_intermediate else 0
+        qh, kh, vh = qkv.split(c, dim=-1)
+        o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
+
+        x1 = torch.empty(q, c, device=dev, dtype=torch.float32)
+        cam = torch.empty(1, q, ncam, device=dev, dtype=torch.float32)
+        off = torch.empty(1, q, hh * npt * 3, device=dev, dtype=torch.float32)
+        att = torch.empty(1, q, hh * nlv * npt, device=dev, dtype=torch.float32)
+        prog_a = [ops.chain_load(0, o.view(q, c)),
+                  ops.chain_load(3, x),
+                  ops.chain_gemm(0, sa.attn.out_proj.weight, sa.attn.out_proj.bias, dst=1, res=3),
+                  ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1),
+                  ops.chain_add(0, 2, c, add=pos),
+                  ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
+                  ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
+                  ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
+        pos_feat = torch.empty(1, q, c, device=dev, dtype=torch.float32)
+        if pending is not None:
+            lins, x_prev, ref_prev, new_ref = pending
+            prog_b, src, tmp = [ops.chain_load(3, x_prev)], 3, (1, 2)
+            for i, lin in enumerate(lins):
+                prog_b.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                src = tmp[i % 2]
+            park = 0 if src != 0 else 3
+            prog_b.append(ops.chain_refine(src, ref_prev, new_ref, dst=park))
+            prog_b += _position_ops(ca, pos_feat.view(q, c), ref_buf=park)
+            keep += [x_prev, ref_prev]
+            ref = new_ref
+        else:
+            prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
+        ops.row_chain2_fwd(prog_a, prog_b, q)
+
+        agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                       img_h, img_w, order=order)
+        x3 = out_all[slot]
+        prog = [ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0),
+                ops.chain_load(3, x1, pos_feat.view(q, c)),
+                ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
+                ops.chain_layernorm(1, layer.norms[1], dst=2),
+                ops.chain_gemm(2, ffn.layers[0][0].weight, ffn.layers[0][0].bias, dst=0, relu=True),
+                ops.chain_gemm(0, ffn.layers[1].weight, ffn.layers[1].bias, dst=1, res=2),
+                ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c))]
+        if not last:
+            qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
+            prog += [ops.chain_add(0, 3, c, add=pos)] + _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1))
+        pending = None
+        if reg_branches is not None:
+            lins = _plain_reg_branch(reg_branches[lid], c)
+            new_ref = ref_all[slot]
+            if last:                                     # nothing follows: the last refinement closes chain B'
+                src, tmp = 3, (1, 2)
+                for i, lin in enumerate(lins):
+                    prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                    src = tmp[i % 2]
+                prog.append(ops.chain_refine(src, ref, new_ref))
+            else:
+                pending = (lins, x3.view(q, c), ref, new_ref)
+        elif return_intermediate or last:
+            ref_all[slot].copy_(ref)
+        ops.row_chain_fwd(prog, q)
+        keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]
+        x = x3.view(q, c)
+    del keep
+    return out_all, ref_all
+
+
 def run(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, pipeline, value_cache,
         order, order_pc_range, return_intermediate, late=None):
     """query / query_pos (Q, 1, C), rows may be strided; reference_points (1, Q, 3).  Returns the stacked per-layer
@@ -129,6 +249,12 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
     dev = query.device
     layers = list(decoder.layers)
     nl = len(layers)
+    if late is not None and os.environ.get('GD4D_SCHEDULE', 'single') == 'single' and not os.environ.get('GD4D_ABLATE') \
+            and all((c // l.attentions[1].num_heads) % 32 == 0 and not l.attentions[1].depth_encode for l in layers):
+        if order is None or order.numel() != q:
+            order = Fn.query_order(reference_points.contiguous(), layers[0].attentions[1].pc_range)
+        return run_single(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, order,
+                          return_intermediate, late)
     main = torch.cuda.current_stream(dev)
     aux = Fn.aux_stream(dev)
     if attn_masks is None:
@@ -274,7 +400,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                     if split_reg:
                         ops.row_chain_fwd([ops.chain_load(3, x)] + reg_prog, q)
                         keep.append(old_ref)
-                    if not last and order is not None:
+                    if not last and order is not None and os.environ.get('GD4D_ORDER_ONCE', '0') != '1':
                         # the next layer's locality order: one tiny launch next to that layer's self-attention
                         order = Fn.query_order(ref, order_pc_range)
                     ref_event = torch.cuda.Event()

@@ -848,9 +848,11 @@ def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):
                    p3=_dev(wsum, 'wsum', torch.float32).value, gout=g)
 
 
-def chain_small_linear(src, weight, bias, dst, relu=False):
+def chain_small_linear(src, weight, bias, dst, relu=False, inv_sigmoid=False):
+    """buf[dst] = act(f(buf[src][:, :K]) W^T + b) for K <= 8; f = inverse_sigmoid with inv_sigmoid=True."""
     return ChainOp(kind=CHAIN_SMALL_LINEAR, src=src, dst=dst, res=-1, K=weight.shape[1], N=weight.shape[0],
-                   flags=CHAIN_RELU if relu else 0, p0=weight.data_ptr(), p1=None if bias is None else bias.data_ptr())
+                   flags=(CHAIN_RELU if relu else 0) | (CHAIN_INV_SIGMOID if inv_sigmoid else 0), p0=weight.data_ptr(),
+                   p1=None if bias is None else bias.data_ptr())
 
 
 def chain_layernorm(src, norm, dst=-1, relu=False, out=None):
@@ -864,8 +866,10 @@ def chain_add(dst, src, n, res=-1, add=None):
     return ChainOp(kind=CHAIN_ADD, src=src, dst=dst, res=res, N=n, ld2=ld2, p2=p2)
 
 
-def chain_refine(src, ref, out):
-    return ChainOp(kind=CHAIN_REFINE, src=src, dst=-1, res=-1, p0=ref.data_ptr(), gout=out.data_ptr())
+def chain_refine(src, ref, out, dst=-1):
+    """Reference-point refinement of buf[src] (the reg branch's output) and `ref` into `out`; dst >= 0 also parks the
+    refined points in buf[dst][:, 0:3]."""
+    return ChainOp(kind=CHAIN_REFINE, src=src, dst=dst, res=-1, p0=ref.data_ptr(), gout=out.data_ptr())
 
 
 def row_chain_fwd(program, m):
@@ -875,6 +879,15 @@ def row_chain_fwd(program, m):
     arr = (ChainOp * len(program))(*program)
     code = lib.gd4d_row_chain_fwd(arr, len(program), int(m), _stream())
     _lib.check(code, 'gd4d_row_chain_fwd')
+
+
+def row_chain2_fwd(program_a, program_b, m):
+    """gd4d_row_chain2_fwd: two independent programs over the same `m` rows in one launch (each on its own workgroups)."""
+    lib = _lib.load()
+    a = (ChainOp * len(program_a))(*program_a)
+    b = (ChainOp * len(program_b))(*program_b)
+    code = lib.gd4d_row_chain2_fwd(a, len(program_a), b, len(program_b), int(m), _stream())
+    _lib.check(code, 'gd4d_row_chain2_fwd')
 
 
 def _first_tensor(args):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 22
+#define GD4D_ABI_VERSION 23
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -369,6 +369,14 @@ size_t gd4d_chain_op_bytes(void);
 size_t gd4d_chain_weight_image_bytes(int N, int K);
 int gd4d_chain_weight_image(const float* weight, int N, int K, void* image, void* stream);
 int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream);
+/* Two independent programs over the same M rows in ONE launch (twice the workgroups, each half runs one program on its own
+ * compute units): e.g. chain A of a decoder layer next to the previous layer's reg branch + refinement + this layer's
+ * position_encoder - what would otherwise need a second stream and two cross-stream dependencies per layer (10 us each in a
+ * replayed graph against 2 us for a boundary on one stream).  nops_a + nops_b <= GD4D_CHAIN_MAX_OPS.
+ * REFINE with dst >= 0 also parks the refined point in buf[dst][:, 0..2]; SMALL_LINEAR honours GD4D_CHAIN_INV_SIGMOID on its
+ * inputs - together: refinement and position_encoder in one program without a round trip through global memory. */
+int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
+                        void* stream);
 
 /* gd4d_small_linear_layernorm_fwd - y = [ReLU] LN( f(in) W^T + b ) for a Linear with at most 4 inputs: the first stage of
  * position_encoder, Linear(3 or 4 -> 256), LayerNorm, ReLU on inverse_sigmoid(reference points)

@@ -127,9 +127,17 @@ def test_transformer_decoder(name):
                 dict(GD4D_AUX_STREAM='0', GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0')):
         s2, i2, r2 = rerun(dict(env, GD4D_PROJECT='early'))
         assert torch.equal(s2, early[0]) and torch.equal(r2, early[2]) and torch.equal(i2, early[1]), env
-    for env in (dict(GD4D_QUERY_ORDER='0'), dict(GD4D_AUX_STREAM='0'), dict(GD4D_AUX_STREAM='0', GD4D_QUERY_ORDER='0')):
+    # (the default loop runs on one stream with chain A and the reg / position chain as the two programs of one launch;
+    #  GD4D_SCHEDULE=aux is the three-stream schedule of the same kernels)
+    for env in (dict(GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux'), dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0'),
+                dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0', GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux', GD4D_REG_ON_AUX='0'),
+                dict(GD4D_COPY_CUS='0')):
         s2, i2, r2 = rerun(env)
         assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
+    # value_proj of the aggregates as its own launch (exact fp32 MFMA) instead of chain B's first operation (split-bf16)
+    s2, i2, r2 = rerun(dict(GD4D_SCHEDULE='aux', GD4D_CHAIN_HEADGEMM='0'))
+    torch.testing.assert_close(s2, states, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(r2, refs, rtol=1e-4, atol=1e-4)
     # the fused Linear+LayerNorm kernel sums in another order than Linear, LayerNorm: equal within fp32 rounding
     os.environ['GD4D_ROWBLOCK'] = '0'
     try:
