@@ -372,6 +372,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
     for (int o = 32; o > 0; o >>= 1) wsum_lane += __shfl_xor(wsum_lane, o);
     if (lane == 0) p.wsum[(size_t)bq * HH + h] = wsum_lane;
   }
+  trace_mark(g_trace_late, 0x83ull);                  // (end of workgroup 0's first wave - a sample, not the kernel's end)
 }
 
 // ---------------------------------------------------------------------------------------------------------------

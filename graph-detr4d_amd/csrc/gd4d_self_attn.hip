@@ -168,6 +168,7 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
     p.out[((size_t)(q0 + i) * p.B + b) * p.ldo + h * MHA_D + d] = num / den;
     if (p.lse && d == 0) p.lse[((size_t)(q0 + i) * p.B + b) * p.H + h] = mm + logf(den);   // saved for gd4d_mha_core_bwd
   }
+  trace_mark(g_trace_mha, 0x82ull);
 }
 
 }  // namespace gd4d

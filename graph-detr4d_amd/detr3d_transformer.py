@@ -368,6 +368,15 @@ class Detr3DTransformer(nn.Module):
         bs = mlvl_feats[0].size(0)
         query_pos, query = torch.split(query_embed, self.embed_dims, dim=1)
         from . import fused_decoder
+        own_late = None
+        if fused_decoder.fast_input(self, query_embed, mlvl_feats) and kwargs.get(Fn.LATE_VALUES_KEY) is None \
+                and kwargs.get(Fn.VALUE_CACHE_KEY) is None:
+            # the channels-last copy of the pyramid needs nothing but the pyramid: fork it first, before the query side
+            cross = [a for layer in self.decoder.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
+            if cross and all(type(a) is Deform3DCrossAttn for a in cross) and Fn.LateValues.applicable(cross, mlvl_feats):
+                own_late = Fn.LateValues(mlvl_feats)
+                kwargs = dict(kwargs)
+                kwargs[Fn.LATE_VALUES_KEY] = own_late
         if fused_decoder.fast_input(self, query_embed, mlvl_feats):
             # batch 1, inference: no copies - the column slices of query_embed go to the decoder as strided (Q, 1, C) views
             # and the initial reference points come from one chain launch (no library GEMM / sigmoid / cat in the step)
@@ -382,6 +391,8 @@ class Detr3DTransformer(nn.Module):
         inter_states, inter_references = self.decoder(
             query=q_in, key=None, value=mlvl_feats, query_pos=pos_in, reference_points=reference_points,
             reg_branches=reg_branches, **kwargs)
+        if own_late is not None:
+            own_late.finish()
         return inter_states, init_reference_out, inter_references
 
 
