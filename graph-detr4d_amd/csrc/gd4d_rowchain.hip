@@ -44,6 +44,9 @@ __device__ __forceinline__ float rc_act_in(float v, int flags) { return (flags &
 #ifndef RC_PREFETCH
 #define RC_PREFETCH 1   // touch the program's weight images at the start of the launch (0: dev A/B)
 #endif
+#ifndef RC_TRACE_OPS
+#define RC_TRACE_OPS 0   // dev: stamp every operation's end in the device timeline (tools/trace_step.py)
+#endif
 #ifndef RC_DBG
 #define RC_DBG 0      // dev ablation (compile with -DRC_DBG=n): 1 = no MFMAs, 2 = no weight loads
 #endif
@@ -460,6 +463,9 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
       default: break;
     }
     __syncthreads();
+#if RC_TRACE_OPS
+    trace_mark(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32));
+#endif
   }
 #if RC_PREFETCH
   asm volatile("s_waitcnt vmcnt(0)" :: "v"(rc_sink) : "memory");     // (long since returned) keeps the sink register reserved

@@ -57,7 +57,13 @@ def main():
     print(f'{n} stamps; step (events) {e0.elapsed_time(e1) * 1e3:.1f} us; first stamp -> last stamp {(ent[-1][1] - t0) / 100:.1f} us')
     prev = t0
     for ident, t in ent:
-        kind, end, nops = ident & 0x7f, bool(ident & 0x80), ident >> 8
+        if ident & 0x40 and not ident & 0x80:          # RC_TRACE_OPS build: end of one chain operation (block 0)
+            opk, n_, k_ = (ident >> 8) & 0xff, (ident >> 16) & 0xffff, ident >> 32
+            opn = {1: 'LOAD', 2: 'GEMM', 3: 'LAYERNORM', 4: 'ADD', 5: 'REFINE', 6: 'SMALL_LINEAR', 7: 'HEADGEMM'}.get(opk, str(opk))
+            print(f'{(t - t0) / 100:9.1f} us  (+{(t - prev) / 100:7.1f})      op {opn} N={n_} K={k_}')
+            prev = t
+            continue
+        kind, end, nops = ident & 0x3f, bool(ident & 0x80), ident >> 8
         name = NAMES.get(kind, str(kind)) + (f'[{nops} ops]' if kind == 1 else '')
         print(f'{(t - t0) / 100:9.1f} us  (+{(t - prev) / 100:7.1f})  {"end  " if end else "start"} {name}')
         prev = t
