@@ -134,7 +134,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
     // share an XCD ask one L2 channel for one fragment at the same instant and take turns (17 B/clk per CU measured).
     // Each workgroup therefore walks K from its own starting k-step (a sum may be taken in any order; the order is a
     // function of the workgroup index only, so results are run-to-run identical).
-    const int rot = RC_ROTATE ? (int)((blockIdx.x >> 3) % (unsigned)steps) : 0;
+    const int rot = RC_ROTATE ? (int)(((unsigned)(m0 / RC_M) >> 3) % (unsigned)steps) : 0;   // by ROW BLOCK: the same in a one- and a two-program launch
     auto kstep = [&](int j) { const int r = j + rot; return r >= steps ? r - steps : r; };
 #pragma unroll
     for (int d = 0; d < RC_DEPTH; ++d) issue(d, kstep(min(d, steps - 1)));

@@ -437,6 +437,9 @@ class LateValues:
                 self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value], max_cus=copy_cus)
             self.event = torch.cuda.Event()
             self.event.record(self.side)
+        # allocated under the side stream, read by kernels of the main stream: tell the allocator, so that the block is
+        # not handed out again (to a side-stream allocation) while those kernels are still queued
+        self.cl.record_stream(self.main)
         self.waited = set()
 
     @staticmethod
@@ -457,6 +460,8 @@ class LateValues:
         if cur.cuda_stream not in self.waited:
             cur.wait_event(self.event)
             self.waited.add(cur.cuda_stream)
+            if cur.cuda_stream != self.main.cuda_stream:
+                self.cl.record_stream(cur)
         return ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                       cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
                                       module.num_heads, query_order=order)

@@ -105,6 +105,51 @@ def test_chain_b_shaped_program_matches_torch():
     assert (new_ref.cpu().double() - want_ref).abs().max().item() < 1e-4
 
 
+def test_two_programs_in_one_launch_equal_two_launches():
+    """gd4d_row_chain2_fwd: chain A of a decoder layer next to [reg branch, refinement parked in LDS, position_encoder with
+    inverse_sigmoid inside SMALL_LINEAR] - bit-identical to the same programs launched one after the other (the second
+    one reading the refined points back from global memory), for row counts with and without a partial last block."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(4)
+    c = 256
+    g = lambda *s: (torch.randn(*s) * 0.06).to(DEV)        # noqa: E731
+    w = {k: g(*s) for k, s in dict(o=(c, c), cam=(24, c), off=(96, c), att=(128, c), r1=(c, c), r2=(c, c), r3=(10, c),
+                                   p0=(c, 3), p3=(c, c)).items()}
+    b = {k: g(v.shape[0]) for k, v in w.items()}
+    n0, l1, l4 = _ln(c, 1), _ln(c, 2), _ln(c, 3)
+    for q in (900, 37):
+        o, x, pos, xprev = g(q, c), g(q, c), g(q, c), g(q, c)
+        ref = torch.rand(q, 3, device=DEV)
+
+        def prog_a(x1, cam, off, att):
+            return [ops.chain_load(0, o), ops.chain_load(3, x), ops.chain_gemm(0, w['o'], b['o'], dst=1, res=3),
+                    ops.chain_layernorm(1, n0, dst=2, out=x1), ops.chain_add(0, 2, c, add=pos),
+                    ops.chain_gemm(0, w['cam'], b['cam'], out=cam), ops.chain_gemm(0, w['off'], b['off'], out=off),
+                    ops.chain_gemm(0, w['att'], b['att'], out=att)]
+
+        def reg_ops(new_ref, park):
+            return [ops.chain_load(3, xprev), ops.chain_gemm(3, w['r1'], b['r1'], dst=1, relu=True),
+                    ops.chain_gemm(1, w['r2'], b['r2'], dst=2, relu=True), ops.chain_gemm(2, w['r3'], b['r3'], dst=1),
+                    ops.chain_refine(1, ref, new_ref, dst=park)]
+
+        def pos_ops(out, from_global=None):
+            head = [ops.chain_load(0, from_global, inv_sigmoid=True)] if from_global is not None else []
+            return head + [ops.chain_small_linear(0, w['p0'], b['p0'], 1, inv_sigmoid=from_global is None),
+                           ops.chain_layernorm(1, l1, dst=2, relu=True), ops.chain_gemm(2, w['p3'], b['p3'], dst=1),
+                           ops.chain_layernorm(1, l4, relu=True, out=out)]
+        e = lambda *s: torch.empty(*s, device=DEV)          # noqa: E731
+        got = dict(x1=e(q, c), cam=e(q, 24), off=e(q, 96), att=e(q, 128), ref=e(q, 3), pf=e(q, c))
+        ops.row_chain2_fwd(prog_a(got['x1'], got['cam'], got['off'], got['att']),
+                           reg_ops(got['ref'], 0) + pos_ops(got['pf']), q)
+        want = dict(x1=e(q, c), cam=e(q, 24), off=e(q, 96), att=e(q, 128), ref=e(q, 3), pf=e(q, c))
+        ops.row_chain_fwd(prog_a(want['x1'], want['cam'], want['off'], want['att']), q)
+        ops.row_chain_fwd(reg_ops(want['ref'], -1), q)
+        ops.row_chain_fwd(pos_ops(want['pf'], from_global=want['ref']), q)
+        for k in got:
+            assert torch.equal(got[k], want[k]), (q, k)
+        assert torch.isfinite(got['pf']).all() and got['ref'].min() > 0 and got['ref'].max() < 1
+
+
 def test_chain_rejects_bad_programs():
     from graph_detr4d_amd import ops
     from graph_detr4d_amd._lib import Gd4dError
