@@ -561,11 +561,11 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                               cam=cam_logits.contiguous(), l2i=lidar2img, pc_range=pc_range, img_h=img_h, img_w=img_w, order=order))
         return orig_early(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=order)
 
-    def spy_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
+    def spy_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, **vp):
         late_cap.append(dict(cl=self.cl, shapes=self.shapes, module=module, ref=ref.contiguous(), offsets=offsets.contiguous(),
                              attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img, pc_range=module.pc_range,
-                             img_h=img_h, img_w=img_w, order=order))
-        return orig_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
+                             img_h=img_h, img_w=img_w, order=order, vp=vp))
+        return orig_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order, **vp)
     Fn.sample_aggregate, Fn.LateValues.aggregate = spy_early, spy_late
     try:
         with torch.no_grad():
@@ -645,10 +645,11 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
         # aggregates written.  The 8(d) figure of the projected-value form (V * 4 * Dh * e, 245 MB) is reported beside it.
         calls, per_layer, tot, tot_dh = [], [], 0.0, 0.0
         for c in late_cap:
+            # (as the step launches it: with value_proj of the aggregates in the epilogue when the step does that)
             run = (lambda c: (lambda **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], c['ref'], c['offsets'], c['attn'], c['cam'],
                                                                   c['l2i'], c['pc_range'], c['img_h'], c['img_w'], hh,
-                                                                  query_order=c['order'], **kw)))(c)
-            _, _, mask = run(want_mask=True)
+                                                                  query_order=c['order'], **c['vp'], **kw)))(c)
+            mask = run(want_mask=True)[-1]
             b, n, q, _, p = mask.shape
             nl = len(c['shapes'])
             v = int(mask.sum().item()) * nl
@@ -684,12 +685,13 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                                                         compute_units=copy_cus,
                                                         note='alone on the device; in the step the first layer\'s query side runs on the other CUs')
                 c0 = late_cap[0]
-                agg0, wsum0 = calls[0]()
                 m0 = c0['module']
+                agg0, wsum0 = ops.cross_attn_agg_fwd(c0['cl'], c0['shapes'], c0['ref'], c0['offsets'], c0['attn'], c0['cam'], c0['l2i'],
+                                                     c0['pc_range'], c0['img_h'], c0['img_w'], hh, query_order=c0['order'])
                 ms_hp = _time_rounds([lambda: ops.value_proj_heads_fwd(agg0, wsum0, m0.value_proj.weight, m0.value_proj.bias)], 20)
                 kernels['value_proj_heads'] = dict(us=ms_hp * 1e3, launches_per_step=0,
-                                                   note='stand-alone gd4d_value_proj_heads_fwd; in the fused decoder loop it is the '
-                                                        'first operation (HEADGEMM) of chain B')
+                                                   note='stand-alone gd4d_value_proj_heads_fwd; in the step value_proj of the aggregates '
+                                                        'runs in the epilogue of gd4d_cross_attn_agg_fwd')
             except Exception as ex:
                 kernels['pyramid_channels_last'] = {'error': f'{type(ex).__name__}: {ex}'}
             # all-visible stress case of this kernel (8 x the bytes of the projected-value form per corner: its worst case)
@@ -697,8 +699,9 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                 c0 = late_cap[0]
                 ref_av, l2i_av, order_av = _all_visible_inputs(c0, ops)
                 run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731
-                                                                c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av, **kw)
-                _, _, mask_av = run_av(c0, want_mask=True)
+                                                                c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av,
+                                                                **c['vp'], **kw)
+                mask_av = run_av(c0, want_mask=True)[-1]
                 nl_ = len(c0['shapes'])
                 v_av = int(mask_av.sum().item()) * nl_
                 alg_av = min(v_av * 4 * 256 * 4, c0['cl'].numel() * 4) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])

@@ -306,11 +306,11 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
     for (int hi = 0; hi < HPW; ++hi) {
       const int h = wave + hi * WAVES;
       if (h >= HH) break;
-      *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + lane * 4) = acc[hi];
+      if (p.agg) *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + lane * 4) = acc[hi];
       float t = wsum_lane[hi];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-      if (lane == 0) p.wsum[(size_t)bq * HH + h] = t;
+      if (lane == 0 && p.wsum) p.wsum[(size_t)bq * HH + h] = t;
     }
     return;
   }
@@ -367,10 +367,54 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
         }
       }
     }
-    *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + lane * 4) = acc;
+    if (p.agg) *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + lane * 4) = acc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wsum_lane += __shfl_xor(wsum_lane, o);
-    if (lane == 0) p.wsum[(size_t)bq * HH + h] = wsum_lane;
+    if (lane == 0 && p.wsum) p.wsum[(size_t)bq * HH + h] = wsum_lane;
+    if (p.vp_w) {
+      // value_proj of this head's aggregate in the epilogue (exact fp32): out[h*Dh + d] = <W[h*Dh + d, :], agg> + b wsum.
+      // A lane holds 4 of the 256 channels, so every output is a 4-term partial per lane and a sum over the wave; the
+      // Dh sums are taken together by a butterfly (each exchange halves the values a lane keeps: 16 + 8 + 4 + 2 + 1
+      // shuffles for 32 outputs instead of 32 x 6).  The rows of W are 1-KB wave loads from the L2 (every workgroup
+      // reads the same 256 KB).  The other workgroups keep the memory system busy meanwhile, and the row chain that
+      // follows starts with a 1-KB row per query instead of gathering 8 KB of aggregates per query cold.
+      constexpr int DH = kChannels / HH;
+      constexpr int NB = DH < 32 ? DH : 32;             // outputs per butterfly
+      const float* wrow = p.vp_w + (size_t)(h * DH) * kChannels + lane * 4;
+#pragma unroll
+      for (int d0 = 0; d0 < DH; d0 += NB) {
+        float v[NB];
+#pragma unroll
+        for (int r0 = 0; r0 < NB; r0 += 8) {
+          float4 wv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + (size_t)(d0 + r0 + j) * kChannels);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[r0 + j] = fmaf(wv[j].x, acc.x, fmaf(wv[j].y, acc.y, fmaf(wv[j].z, acc.z, wv[j].w * acc.w)));
+        }
+        int n = NB, mask = 32;
+#pragma unroll
+        for (; n > 1; n >>= 1, mask >>= 1) {
+          const bool upper = (lane & mask) != 0;
+#pragma unroll
+          for (int j = 0; j < n / 2; ++j) {
+            const float send = upper ? v[j] : v[j + n / 2];
+            const float keep = upper ? v[j + n / 2] : v[j];
+            v[j] = keep + __shfl_xor(send, mask);
+          }
+        }
+        float tot = v[0];
+#pragma unroll
+        for (; mask > 0; mask >>= 1) tot += __shfl_xor(tot, mask);
+        // NB = 32: lane L holds output L >> 1;  NB = 16: output L >> 2
+        constexpr int SH = NB == 32 ? 1 : 2;
+        const int d = d0 + (lane >> SH);
+        if ((lane & ((1 << SH) - 1)) == 0) {
+          const float bv = p.vp_b ? p.vp_b[h * DH + d] : 0.f;
+          p.out[(size_t)bq * kChannels + h * DH + d] = fmaf(bv, wsum_lane, tot);
+        }
+      }
+    }
   }
   trace_mark(g_trace_late, 0x83ull);                  // (end of workgroup 0's first wave - a sample, not the kernel's end)
 }
@@ -435,6 +479,7 @@ static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
   // share at the coarse levels is still in the L2)
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GD4D_AGG_VARIANT"); variant = e ? atoi(e) : 0; }
+  if (variant != 0 && p.vp_w) return GD4D_EUNSUPPORTED;       // the value_proj epilogue lives in the default form only
   auto go = [&](auto kern, int threads, size_t lds) {
     if (lds > 65536) (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
@@ -497,16 +542,19 @@ extern "C" int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* leve
                                        const float* attn_logits, const float* cam_logits, const float* lidar2img,
                                        const double* pc_range, float img_h, float img_w, float* agg, float* wsum,
                                        uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh, int C, int L, int P,
-                                       int feats_dtype, int flags, const int32_t* query_order, void* stream) {
+                                       int feats_dtype, int flags, const int32_t* query_order, const float* vp_weight,
+                                       const float* vp_bias, float* out, void* stream) {
   using namespace gd4d;
-  if (!feats_cl || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range || !agg || !wsum)
-    return GD4D_EINVAL;
+  if (!feats_cl || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range) return GD4D_EINVAL;
+  if (vp_weight ? !out : (!agg || !wsum)) return GD4D_EINVAL;       // either the projected output or the raw aggregates
+  if ((agg != nullptr) != (wsum != nullptr)) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
   // B > 1 pairs value rows with the logits of batch (row % B) (deform3d_cross_attn.py:277): gd4d_cross_attn_fwd has that form
   if (C != kChannels || P != kPoints || L > 4 || N > 64 || B != 1 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
-  if (!aligned16(feats_cl) || !aligned16(agg)) return GD4D_EALIGN;
+  if (!aligned16(feats_cl) || (agg && !aligned16(agg)) || (vp_weight && !aligned16(vp_weight))) return GD4D_EALIGN;
   CrossAttnParams p{};
+  p.vp_w = vp_weight; p.vp_b = vp_bias; p.out = out;
   p.value = feats_cl; p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits; p.cam_logits = cam_logits;
   p.lidar2img = lidar2img; p.agg = agg; p.wsum = wsum; p.mask_out = mask_out; p.uv_out = uv_out; p.order = query_order;
   p.B = B; p.N = N; p.Q = Q; p.L = L; p.P = P;

@@ -28,6 +28,8 @@ struct CrossAttnParams {
   float img_h, img_w;
   float* agg;          // gd4d_cross_attn_agg_fwd only: (B*Q, Hh, C) per-head aggregates of the raw features
   float* wsum;         //                               (B*Q, Hh) sum of the in-bounds sampling weights per head
+  const float* vp_w;   // gd4d_cross_attn_agg_fwd, optional: value_proj weight (C, C) / bias (C) applied to the aggregates in
+  const float* vp_b;   //   the kernel's epilogue: out (B*Q, C) = W_h agg_h + b_h wsum_h  (agg / wsum may then be NULL)
   unsigned dbg_wrap;   // dev (GD4D_AGG_DBG_WRAP): pixel indices are ANDed with this mask (0 = off): an all-L2-hit run
 };
 

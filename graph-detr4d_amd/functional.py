@@ -454,8 +454,10 @@ class LateValues:
         return all(m.value_dtype == torch.float32 and m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
                    and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
-    def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
-        """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh) (ops.cross_attn_agg_fwd)."""
+    def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, vp_weight=None,
+                  vp_bias=None):
+        """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh) (ops.cross_attn_agg_fwd); with
+        vp_weight: (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
         cur = torch.cuda.current_stream(self.cl.device)
         if cur.cuda_stream not in self.waited:
             cur.wait_event(self.event)
@@ -464,14 +466,19 @@ class LateValues:
                 self.cl.record_stream(cur)
         return ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                       cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
-                                      module.num_heads, query_order=order)
+                                      module.num_heads, query_order=order, vp_weight=vp_weight, vp_bias=vp_bias)
 
     def sample_aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
-        """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of output_proj."""
-        agg, wsum = self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
+        """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of
+        output_proj.  value_proj of the per-head aggregates runs in the gather kernel's epilogue (GD4D_AGG_EPILOGUE=0: as
+        its own launch, gd4d_value_proj_heads_fwd)."""
         bias = module.value_proj.bias
-        return ops.value_proj_heads_fwd(agg, wsum, module.value_proj.weight.contiguous(),
-                                        None if bias is None else bias.contiguous())
+        weight, bias = module.value_proj.weight.contiguous(), None if bias is None else bias.contiguous()
+        if os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
+            return self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order,
+                                  vp_weight=weight, vp_bias=bias)[0]
+        agg, wsum = self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
+        return ops.value_proj_heads_fwd(agg, wsum, weight, bias)
 
     def finish(self):
         self.main.wait_stream(self.side)             # join (keeps a graph capture well-formed)

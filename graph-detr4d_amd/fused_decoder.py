@@ -207,10 +207,18 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
         ops.row_chain2_fwd(prog_a, prog_b, q)
 
-        agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
-                                       img_h, img_w, order=order)
+        if os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
+            # value_proj of the aggregates in the gather's epilogue: chain B' starts from one 1-KB row per query
+            agg = late.sample_aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                        img_h, img_w, order=order)
+            first = ops.chain_load(0, agg.view(q, c))
+            agg_raw, wsum = agg, agg
+        else:
+            agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                           img_h, img_w, order=order)
+            first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0)
         x3 = out_all[slot]
-        prog = [ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0),
+        prog = [first,
                 ops.chain_load(3, x1, pos_feat.view(q, c)),
                 ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
                 ops.chain_layernorm(1, layer.norms[1], dst=2),
@@ -320,7 +328,8 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
         if order is None or order.numel() != q:
             order = Fn.query_order(ref, ca.pc_range)
         agg_raw = None
-        if late is not None and (c // hh) % 32 == 0 and os.environ.get('GD4D_CHAIN_HEADGEMM', '1') != '0':
+        if late is not None and os.environ.get('GD4D_AGG_EPILOGUE', '1') == '0' and (c // hh) % 32 == 0 \
+                and os.environ.get('GD4D_CHAIN_HEADGEMM', '1') != '0':
             # aggregate-then-project: gather the raw features per head; value_proj of the aggregates is chain B's first op
             if _ablate('agg'):
                 agg_raw, wsum = torch.empty(1, q, hh, c, device=dev), torch.empty(1, q, hh, device=dev)

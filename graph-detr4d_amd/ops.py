@@ -97,9 +97,11 @@ def pyramid_channels_last_fwd(feats, out=None, max_cus=0):
 
 
 def cross_attn_agg_fwd(feats_cl, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
-                       num_heads, want_mask=False, want_uv=False, query_order=None, raw_cam_weights=False):
+                       num_heads, want_mask=False, want_uv=False, query_order=None, raw_cam_weights=False,
+                       vp_weight=None, vp_bias=None):
     """gd4d_cross_attn_agg_fwd.  feats_cl (B*N, S, 256) fp32 channels-last pyramid; the other arguments as cross_attn_fwd.
-    Returns agg (B, Q, Hh, 256), wsum (B, Q, Hh) [, mask] [, uv]."""
+    Returns agg (B, Q, Hh, 256), wsum (B, Q, Hh) [, mask] [, uv]; with vp_weight (256, 256) [, vp_bias]: value_proj of the
+    aggregates applied in the kernel's epilogue - returns out (B, Q, 256) [, mask] [, uv] instead."""
     lib = _lib.load()
     b, q = ref.shape[0], ref.shape[1]
     n = lidar2img.shape[1]
@@ -111,8 +113,10 @@ def cross_attn_agg_fwd(feats_cl, level_hw, ref, offsets, attn_logits, cam_logits
     if offsets.numel() != b * q * hh * p * 3 or attn_logits.numel() != b * q * hh * nl * p or cam_logits.numel() != b * q * n:
         raise ValueError('offsets / attn_logits / cam_logits have the wrong number of elements')
     f32 = torch.float32
-    agg = torch.empty(b, q, hh, c, device=ref.device, dtype=f32)
-    wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32)
+    fused = vp_weight is not None
+    agg = None if fused else torch.empty(b, q, hh, c, device=ref.device, dtype=f32)
+    wsum = None if fused else torch.empty(b, q, hh, device=ref.device, dtype=f32)
+    out = torch.empty(b, q, c, device=ref.device, dtype=f32) if fused else None
     mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
     uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
@@ -120,12 +124,14 @@ def cross_attn_agg_fwd(feats_cl, level_hw, ref, offsets, attn_logits, cam_logits
     code = lib.gd4d_cross_attn_agg_fwd(
         _dev(feats_cl, 'feats_cl', f32), lv, _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32),
         _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32),
-        rng, float(img_h), float(img_w), _dev(agg, 'agg'), _dev(wsum, 'wsum'),
+        rng, float(img_h), float(img_w), None if fused else _dev(agg, 'agg'), None if fused else _dev(wsum, 'wsum'),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None,
         b, n, q, hh, c, nl, p, _lib.F32, 1 if raw_cam_weights else 0,
-        None if query_order is None else _order_ptr(query_order, b * q), _stream())
+        None if query_order is None else _order_ptr(query_order, b * q),
+        _dev(vp_weight, 'vp_weight', f32) if fused else None, _opt(vp_bias, 'vp_bias') if fused else None,
+        _dev(out, 'out') if fused else None, _stream())
     _lib.check(code, 'gd4d_cross_attn_agg_fwd')
-    res = (agg, wsum)
+    res = (out,) if fused else (agg, wsum)
     if want_mask:
         res += (mask,)
     if want_uv:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 23
+#define GD4D_ABI_VERSION 24
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -129,6 +129,8 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
  *   gd4d_cross_attn_fwd except: feats_cl = the channels-last pyramid above instead of a projected value tensor;
  *   agg (B*Q, Hh, C) fp32 out: sum_i w_i x_i per head;  wsum (B*Q, Hh) fp32 out: sum_i w_i (in-bounds corners only -
  *   mmcv's zero padding drops the bias with the value).  Same visibility mask / uv (bit-exact) as gd4d_cross_attn_fwd.
+ *   vp_weight (C, C), vp_bias (C) or NULL, out (B*Q, C): optional - value_proj applied to the aggregates in the kernel's
+ *   epilogue (exact fp32 FMAs), out = what gd4d_value_proj_heads_fwd would return; agg / wsum may then be NULL.
  *   Supported: B == 1 (for B > 1 the reference pairs value rows with the logits of batch (row % B), :277 - use
  *   gd4d_cross_attn_fwd), C == 256, P == 4, L <= 4, N <= 64, Hh in {4, 8, 16}, B*N*S < 2^31, fp32 features.
  *
@@ -142,7 +144,8 @@ int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* level_hw, const
                             const float* attn_logits, const float* cam_logits, const float* lidar2img,
                             const double* pc_range, float img_h, float img_w, float* agg, float* wsum, uint8_t* mask_out,
                             float* uv_out, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype, int flags,
-                            const int32_t* query_order, void* stream);
+                            const int32_t* query_order, const float* vp_weight, const float* vp_bias, float* out,
+                            void* stream);
 int gd4d_value_proj_heads_fwd(const float* agg, const float* wsum, const float* weight, const float* bias, float* out,
                               int M, int Hh, int C, void* stream);
 

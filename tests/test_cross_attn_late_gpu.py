@@ -107,6 +107,13 @@ def test_late_projection_vs_oracle_and_projected_value_kernel(heads, levels, n, 
     assert flipped.sum().item() <= 2
     keep = ~flipped
     torch.testing.assert_close(out.cpu()[keep], o_ref[keep], rtol=RTOL, atol=ATOL)
+    # value_proj in the kernel's epilogue (exact fp32 FMAs, butterfly sums) = the stand-alone projection of the aggregates
+    fused, fmask = ops.cross_attn_agg_fwd(cl, shp, *d, synthetic.PC_RANGE, 900, 1600, heads, want_mask=True,
+                                          vp_weight=w.to(dev), vp_bias=bias.to(dev))
+    assert torch.equal(fmask, mask)
+    torch.testing.assert_close(fused, out, rtol=2e-5, atol=2e-5)
+    nob, = ops.cross_attn_agg_fwd(cl, shp, *d, synthetic.PC_RANGE, 900, 1600, heads, vp_weight=w.to(dev))
+    torch.testing.assert_close(nob, ops.value_proj_heads_fwd(agg, wsum, w.to(dev)), rtol=2e-5, atol=2e-5)
     order = ops.query_order_fwd(d[0], synthetic.PC_RANGE)
     out2, *_ = _late([f.to(dev) for f in feats], w.to(dev), bias.to(dev), *d, synthetic.PC_RANGE, 900, 1600, heads=heads, order=order)
     assert torch.equal(out, out2)                                    # scheduling only

@@ -63,11 +63,11 @@ def test_each_decoder_layer_900q_24cams_matches_oracle(project, monkeypatch):
                             order=order)
             orig_late = Fn.LateValues.aggregate
 
-            def spy_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
+            def spy_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, **vp):
                 captured['mask'] = ops.cross_attn_agg_fwd(self.cl, self.shapes, ref_.contiguous(), offsets.contiguous(),
                                                           attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
                                                           module.pc_range, img_h, img_w, module.num_heads, want_mask=True)[2]
-                return orig_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
+                return orig_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order, **vp)
             Fn.sample_aggregate, Fn.LateValues.aggregate = spy, spy_late
             try:
                 y = tr_d.decoder.layers[lid](x.to(dev), key=None, value=feats_d, query_pos=query_pos.to(dev),

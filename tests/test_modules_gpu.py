@@ -134,10 +134,13 @@ def test_transformer_decoder(name):
                 dict(GD4D_COPY_CUS='0')):
         s2, i2, r2 = rerun(env)
         assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
-    # value_proj of the aggregates as its own launch (exact fp32 MFMA) instead of chain B's first operation (split-bf16)
-    s2, i2, r2 = rerun(dict(GD4D_SCHEDULE='aux', GD4D_CHAIN_HEADGEMM='0'))
-    torch.testing.assert_close(s2, states, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(r2, refs, rtol=1e-4, atol=1e-4)
+    # value_proj of the aggregates: in the gather's epilogue (default, exact fp32), as its own launch (exact fp32 MFMA), or
+    # as chain B's first operation (split-bf16) - the same numbers within fp32-class rounding
+    for env in (dict(GD4D_SCHEDULE='aux', GD4D_CHAIN_HEADGEMM='0'), dict(GD4D_AGG_EPILOGUE='0'),
+                dict(GD4D_SCHEDULE='aux', GD4D_AGG_EPILOGUE='0')):
+        s2, i2, r2 = rerun(env)
+        torch.testing.assert_close(s2, states, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(r2, refs, rtol=1e-4, atol=1e-4)
     # the fused Linear+LayerNorm kernel sums in another order than Linear, LayerNorm: equal within fp32 rounding
     os.environ['GD4D_ROWBLOCK'] = '0'
     try:
