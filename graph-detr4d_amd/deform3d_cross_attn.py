@@ -95,8 +95,9 @@ class Deform3DCrossAttn(nn.Module):
         Fn.require_gpu(query, 'query')
         if Fn.wants_grad(self, query, query_pos, reference_points, *value):
             cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
-            return self._forward_autograd(query, value, query_pos, reference_points, img_metas,
-                                          cached[0] if cached is not None and cached[2] is value else None)
+            hit = cached is not None and cached[2] is value
+            return self._forward_autograd(query, value, query_pos, reference_points, img_metas, cached[0] if hit else None,
+                                          cached[3] if hit and len(cached) > 3 else None)
 
         inp_residual = query
         q_len, b, c = query.shape
@@ -197,7 +198,7 @@ class Deform3DCrossAttn(nn.Module):
             ref3d = torch.cat([ref3d, depth], dim=-1)
         return Fn.position_encoder(self.position_encoder, ref3d)
 
-    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas, projected=None):
+    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas, projected=None, cl=None):
         """Training path: the same maths with autograd.  The gather runs gd4d_cross_attn_fwd/_bwd, value_proj
         runs the HIP forward with a GEMM backward, the small dense layers are torch ops."""
         from .autograd import CrossAttnFunction, ValueProjFunction
@@ -218,8 +219,12 @@ class Deform3DCrossAttn(nn.Module):
             val = projected                      # the decoder projected for all its layers (one autograd node)
         lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
-        agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
-                                      shapes, self.pc_range, img_h, img_w)
+        if cl is not None:       # the decoder made a channels-last copy: value_proj's weight gradient comes from this node
+            agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
+                                          shapes, self.pc_range, img_h, img_w, cl, self.value_proj.weight, self.value_proj.bias)
+        else:
+            agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
+                                          shapes, self.pc_range, img_h, img_w)
         out = Fn.sequential_autograd(self.output_proj, agg).permute(1, 0, 2)
         ref3d = reference_points
         if self.depth_encode:

@@ -294,9 +294,16 @@ def project_values_for_layers_autograd(modules, value):
     shapes = [tuple(v.shape[-2:]) for v in value]
     b, n, c = value[0].shape[:3]
     hh = modules[0].num_heads
-    outs = ValueProjMultiFunction.apply(len(modules), *[m.value_proj.weight for m in modules],
+    # value_proj's weight gradient from per-head aggregates of the raw pyramid instead of a contraction over every pixel
+    # row (autograd.CrossAttnFunction): needs ONE channels-last copy of the pyramid per step (no gradient)
+    cl = None
+    if os.environ.get('GD4D_TRAIN_VP_WGRAD', 'agg') == 'agg' and LateValues.applicable(modules, value, ignore_mode=True):
+        with torch.no_grad():
+            cl = ops.pyramid_channels_last_fwd([v.detach().contiguous() for v in value])[0]
+    outs = ValueProjMultiFunction.apply(-len(modules) if cl is not None else len(modules),
+                                        *[m.value_proj.weight for m in modules],
                                         *[m.value_proj.bias for m in modules], *value)
-    return {id(m): (o.view(b * n, -1, hh, c // hh), shapes, value) for m, o in zip(modules, outs)}
+    return {id(m): (o.view(b * n, -1, hh, c // hh), shapes, value, cl) for m, o in zip(modules, outs)}
 
 
 _SIDE_STREAMS = {}
@@ -443,8 +450,9 @@ class LateValues:
         self.waited = set()
 
     @staticmethod
-    def applicable(modules, value):
-        if os.environ.get('GD4D_PROJECT', 'late') != 'late' or not modules or not isinstance(value, (list, tuple)):
+    def applicable(modules, value, ignore_mode=False):
+        if (not ignore_mode and os.environ.get('GD4D_PROJECT', 'late') != 'late') or not modules \
+                or not isinstance(value, (list, tuple)):
             return False
         if any(v.dim() != 5 or v.shape[0] != 1 or v.dtype != torch.float32 or not v.is_cuda or v.shape[2] != 256 for v in value):
             return False

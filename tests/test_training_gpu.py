@@ -142,3 +142,48 @@ def test_decoder_training_step_under_hipgraph_equals_eager():
         torch.testing.assert_close(red.flat, eager, rtol=1e-4, atol=1e-6 * float(eager.abs().max()) + 1e-9)
         for f, e in zip(feats, eager_feat):
             torch.testing.assert_close(f.grad, e, rtol=1e-4, atol=1e-6 * float(e.abs().max()) + 1e-12)
+
+
+def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction(monkeypatch):
+    """Decoder training: value_proj's weight / bias gradient via the per-head aggregates of the raw pyramid
+    (autograd.CrossAttnFunction, the default) against gd4d_value_proj_bwd_weight's contraction over every pixel row
+    (GD4D_TRAIN_VP_WGRAD=gemm), and both against autograd of the oracle for layer 0's module in isolation."""
+    from oracle import torch_oracle as O
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.0),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                         embed_dims=256, dropout=0.0)],
+                         feedforward_channels=512, ffn_dropout=0.0,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).train()
+    feats = [f.to(DEV).requires_grad_() for f in g.feats()]
+    qe = g.t('query_embed').to(DEV)
+    probe = torch.randn(m['num_layers'], m['num_query'], 1, 256, generator=torch.Generator().manual_seed(7)).to(DEV)
+
+    def grads(mode):
+        monkeypatch.setenv('GD4D_TRAIN_VP_WGRAD', mode)
+        for p_ in tr.parameters():
+            p_.grad = None
+        for f in feats:
+            f.grad = None
+        states, _, _ = tr(feats, qe, reg_branches=None, img_metas=g.img_metas())
+        (states * probe).sum().backward()
+        return {k: v.grad.clone() for k, v in tr.named_parameters() if v.grad is not None}, [f.grad.clone() for f in feats]
+    ga, fa = grads('agg')
+    gg, fg = grads('gemm')
+    assert set(ga) == set(gg)
+    for k in ga:
+        scale = gg[k].abs().max().clamp(min=1e-6)
+        assert ((ga[k] - gg[k]).abs().max() / scale).item() < (2e-3 if 'value_proj' in k else 1e-5), k
+    for a, b in zip(fa, fg):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    vp = [k for k in ga if 'value_proj' in k]
+    assert len(vp) == 2 * m['num_layers'] and all(ga[k].abs().max() > 0 for k in vp)
