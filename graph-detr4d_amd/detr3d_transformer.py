@@ -319,6 +319,13 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                 elif fast:
                     reference_points = self._refine(reg_branches[lid], output, reference_points, kwargs,
                                                     lid + 1 < len(self.layers))
+                elif output.is_cuda and output.dtype == torch.float32 and reference_points.dtype == torch.float32:
+                    # training: the refined points are DETACHED (:213) - nothing of this branch call reaches a loss (the head
+                    # applies reg_branches to the layer outputs itself, with gradients) - so it runs without autograd on the
+                    # inference kernels, like the branch above
+                    with torch.no_grad():
+                        reference_points = self._refine(reg_branches[lid], output.detach(), reference_points.detach(),
+                                                        dict(kwargs), False)
                 else:
                     tmp = reg_branches[lid](output.permute(1, 0, 2))
                     new_ref = torch.zeros_like(reference_points)
