@@ -79,10 +79,11 @@ class Detr3DCrossAtten(nn.Module):
             raise NameError('Detr3DCrossAtten: residual must be None (as in the reference)')
         img_metas = kwargs['img_metas']
         Fn.require_gpu(query, 'query')
-        Fn.require_inference(query, query_pos, reference_points, *value)
         if self.num_points != 1:
             raise NotImplementedError('Detr3DCrossAtten: the gfx950 kernel is built for '
                                       'num_points=1 (every reference config)')
+        if Fn.wants_grad(self, query, query_pos, reference_points, *value):
+            return self._forward_autograd(query, value, query_pos, reference_points, img_metas)
         inp_residual = query
         q, b, c = query.shape
         if b == 1:
@@ -102,6 +103,47 @@ class Detr3DCrossAtten(nn.Module):
                              r1=inp_residual.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
         return self.dropout(out) + inp_residual + pos_feat.permute(1, 0, 2)
+
+
+    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
+        """Training path (the DETR3D configs train this module): the reference's operations (:352-390, feature_sampling
+        :397-438) as differentiable torch ops on the GPU - projection, F.grid_sample per level (bilinear, zero padding,
+        align_corners=False), sigmoid weights x mask, sums over levels / points / cameras - with the dense layers on the
+        HIP kernels' autograd functions.  The sampling kernel gd4d_detr3d_fwd has no backward; this is the way
+        gradients reach the feature maps, the query and (in layer 0) the reference points."""
+        inp_residual = query
+        x = query if query_pos is None else query + query_pos
+        x = x.permute(1, 0, 2).contiguous()                                   # (B, Q, C)
+        b, q, c = x.shape
+        n, nl = self.num_cams, self.num_levels
+        logits = Fn.sequential_autograd(self.attention_weights, x).view(b, 1, q, n, self.num_points, nl)
+        lidar2img = Fn.lidar2img_device(img_metas, query)                     # (B, N, 4, 4)
+        img_h, img_w = Fn.img_hw(img_metas)
+        rng = self.pc_range
+        lo = reference_points.new_tensor(rng[:3])
+        scale = reference_points.new_tensor([rng[3] - rng[0], rng[4] - rng[1], rng[5] - rng[2]])
+        pts = reference_points * scale + lo                                   # metres (:402-405)
+        pts = torch.cat([pts, torch.ones_like(pts[..., :1])], dim=-1)         # (B, Q, 4)
+        cam = torch.matmul(lidar2img.view(b, n, 1, 4, 4), pts.view(b, 1, q, 4, 1)).squeeze(-1)   # (B, N, Q, 4)
+        eps = 1e-5
+        mask = cam[..., 2:3] > eps
+        xy = cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.full_like(cam[..., 2:3], eps))
+        xy = torch.stack([xy[..., 0] / img_w, xy[..., 1] / img_h], dim=-1)
+        xy = (xy - 0.5) * 2
+        mask = mask & (xy[..., 0:1] > -1.0) & (xy[..., 0:1] < 1.0) & (xy[..., 1:2] > -1.0) & (xy[..., 1:2] < 1.0)
+        mask = mask.view(b, n, 1, q, 1, 1).permute(0, 2, 3, 1, 4, 5)          # (B, 1, Q, N, 1, 1)
+        sampled = []
+        for feat in value:
+            bn, cc, h, w = feat.shape[0] * feat.shape[1], feat.shape[2], feat.shape[3], feat.shape[4]
+            s_ = torch.nn.functional.grid_sample(feat.reshape(bn, cc, h, w), xy.reshape(bn, q, 1, 2), align_corners=False)
+            sampled.append(s_.view(b, n, cc, q, 1).permute(0, 2, 3, 1, 4))   # (B, C, Q, N, 1)
+        out = torch.stack(sampled, -1)                                        # (B, C, Q, N, 1, L)
+        out = torch.nan_to_num(out)
+        weights = logits.sigmoid() * mask.to(logits.dtype)
+        out = (out * weights).sum(-1).sum(-1).sum(-1).permute(2, 0, 1)       # (Q, B, C)
+        out = Fn.sequential_autograd(self.output_proj, out.contiguous())
+        pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(reference_points)).permute(1, 0, 2)
+        return self.dropout(out) + inp_residual + pos_feat
 
 
 @ATTENTION.register_module()

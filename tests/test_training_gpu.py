@@ -187,3 +187,40 @@ def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     vp = [k for k in ga if 'value_proj' in k]
     assert len(vp) == 2 * m['num_layers'] and all(ga[k].abs().max() > 0 for k in vp)
+
+
+def test_detr3d_cross_atten_trains():
+    """The DETR3D baseline module with autograd on: output = the inference path's, gradients (query, query_pos, reference
+    points, feature maps, every parameter) = autograd of the oracle (detr3d_transformer.py:352-438)."""
+    from oracle import torch_oracle as O
+    g = Golden('detr3d_n6')
+    m = g.meta
+    mod = G.build_attention(dict(type='Detr3DCrossAtten', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=1,
+                                 embed_dims=256), dict(batch_first=False))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    with torch.no_grad():
+        want = mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()], None, query_pos=g.t('query_pos').to(DEV),
+                   reference_points=g.t('reference_points').to(DEV), img_metas=g.img_metas())
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    p_cpu = {k: v.clone().requires_grad_(True) for k, v in g.state().items()}
+    q_cpu, qp_cpu = g.t('query').clone().requires_grad_(True), g.t('query_pos').clone().requires_grad_(True)
+    ref_cpu = g.t('reference_points').clone().requires_grad_(True)
+    feats_cpu = [f.clone().requires_grad_(True) for f in g.feats()]
+    out_ref = O.detr3d_cross_atten(p_cpu, q_cpu, feats_cpu, qp_cpu, ref_cpu, g.img_metas(), m['pc_range'])
+    out_ref = out_ref[0] if isinstance(out_ref, tuple) else out_ref
+    (out_ref * gout).sum().backward()
+    q, qp = g.t('query').to(DEV).requires_grad_(True), g.t('query_pos').to(DEV).requires_grad_(True)
+    ref = g.t('reference_points').to(DEV).requires_grad_(True)
+    feats = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    out = mod(q, None, feats, None, query_pos=qp, reference_points=ref, img_metas=g.img_metas())
+    torch.testing.assert_close(out.detach(), want, rtol=2e-4, atol=2e-4)
+    (out * gout.to(DEV)).sum().backward()
+    assert _rel(q.grad.cpu(), q_cpu.grad) < 2e-3
+    assert _rel(qp.grad.cpu(), qp_cpu.grad) < 2e-3
+    assert _rel(ref.grad.cpu(), ref_cpu.grad) < 5e-3
+    for a, b in zip(feats, feats_cpu):
+        assert _rel(a.grad.cpu(), b.grad) < 2e-3
+    for k, prm in mod.named_parameters():
+        assert prm.grad is not None, k
+        assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
