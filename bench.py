@@ -653,11 +653,12 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
             b, n, q, _, p = mask.shape
             nl = len(c['shapes'])
             v = int(mask.sum().item()) * nl
+            es = c['cl'].element_size()                                         # 4, or 2 with value_dtype='bf16' (bf16 storage)
             side = side_bytes(q, n, nl, p) + q * hh * 256 * 4 + q * hh * 4      # + agg and wsum written
-            alg = min(v * 4 * 256 * 4, c['cl'].numel() * 4) + side
+            alg = min(v * 4 * 256 * es, c['cl'].numel() * es) + side
             calls.append(run)
-            per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg, corner_bytes=v * 4 * 256 * 4,
-                                  alg_bytes_projected_value_form=min(v * 4 * (256 // hh) * 4, c['cl'].numel() * 4) + side_bytes(q, n, nl, p)))
+            per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg, corner_bytes=v * 4 * 256 * es,
+                                  alg_bytes_projected_value_form=min(v * 4 * (256 // hh) * es, c['cl'].numel() * es) + side_bytes(q, n, nl, p)))
             tot += alg
             tot_dh += per_layer[-1]['alg_bytes_projected_value_form']
         ms = _time_rounds(calls, rounds)
@@ -669,7 +670,7 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                         bound='hbm', achieved=tot / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=tot / ms / 1e6 / HBM_PEAK_GBS,
                         traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot / launches,
                         us_per_launch=ms / launches * 1e3, launches_per_step=launches,
-                        alg_bytes_rule='SURVEY 8(d) with C channels per corner, capped at the pyramid size (757 MB at the headline size)',
+                        alg_bytes_rule='SURVEY 8(d) with C channels per corner, capped at the size of the channels-last pyramid (757 MB at the headline size in fp32)',
                         frac_on_projected_value_form_bytes=tot_dh / ms / 1e6 / HBM_PEAK_GBS)
         kernels['cross_attn_agg_per_layer'] = per_layer
         with torch.no_grad():
@@ -679,9 +680,10 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                 vals = [f.contiguous() for f in feats]
                 cus = torch.cuda.get_device_properties(cl.device).multi_processor_count
                 copy_cus = int(os.environ.get('GD4D_COPY_CUS') or max(8, (cus * 7 // 8) // 8 * 8))      # as Fn.LateValues launches it
-                ms_cl = _time_rounds([lambda: ops.pyramid_channels_last_fwd(vals, out=cl, max_cus=copy_cus)], 5)
-                kernels['pyramid_channels_last'] = dict(us=ms_cl * 1e3, bytes=2 * cl.numel() * 4, gbs=2 * cl.numel() * 4 / ms_cl / 1e6,
-                                                        frac=2 * cl.numel() * 4 / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1,
+                ms_cl = _time_rounds([lambda: ops.pyramid_channels_last_fwd(vals, out=cl, max_cus=copy_cus, out_dtype=cl.dtype)], 5)
+                cl_bytes = cl.numel() * (4 + cl.element_size())                 # fp32 NCHW read, channels-last copy written
+                kernels['pyramid_channels_last'] = dict(us=ms_cl * 1e3, bytes=cl_bytes, gbs=cl_bytes / ms_cl / 1e6,
+                                                        frac=cl_bytes / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1,
                                                         compute_units=copy_cus,
                                                         note='alone on the device; in the step the first layer\'s query side runs on the other CUs')
                 c0 = late_cap[0]
@@ -704,13 +706,14 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                 mask_av = run_av(c0, want_mask=True)[-1]
                 nl_ = len(c0['shapes'])
                 v_av = int(mask_av.sum().item()) * nl_
-                alg_av = min(v_av * 4 * 256 * 4, c0['cl'].numel() * 4) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
+                es_ = c0['cl'].element_size()
+                alg_av = min(v_av * 4 * 256 * es_, c0['cl'].numel() * es_) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
                 ms_av = _time_rounds([(lambda c: (lambda: run_av(c)))(c) for c in late_cap], 3)
                 us_av = ms_av / len(late_cap) * 1e3
                 kernels['cross_attn_agg_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
-                                                             corner_bytes=v_av * 4 * 256 * 4, us_per_launch=us_av,
+                                                             corner_bytes=v_av * 4 * 256 * es_, us_per_launch=us_av,
                                                              gbs=alg_av / us_av / 1e3, frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS,
-                                                             l2_level_gbs=v_av * 4 * 256 * 4 / us_av / 1e3)
+                                                             l2_level_gbs=v_av * 4 * 256 * es_ / us_av / 1e3)
             except Exception as ex:
                 kernels['cross_attn_agg_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
             # the projected-value form on the same query-side inputs (not part of the step): value_proj for every layer,

@@ -39,12 +39,26 @@ struct ClParams {
   int start[GD4D_MAX_LEVELS];
   int tiles[GD4D_MAX_LEVELS];
   int tile_base[GD4D_MAX_LEVELS + 1];  // prefix over levels of R * tiles[l]
-  float* out;                          // (R, S, C)
+  void* out;                           // (R, S, C) fp32 or bf16
   int R, L, S, total;
 };
 
 constexpr int CL_PX = 32, CL_C = 256, CL_PITCH = 260;
 
+// stores 4 consecutive channels of one pixel: 16 bytes fp32 or 8 bytes bf16 (round to nearest even)
+template <bool OUT_BF16>
+__device__ __forceinline__ void cl_store4(void* base, size_t elem, float4 v) {
+  if (OUT_BF16) {
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+    pk.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(base) + elem) = pk;
+  } else {
+    *reinterpret_cast<float4*>(static_cast<float*>(base) + elem) = v;
+  }
+}
+
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void pyramid_channels_last_kernel(const ClParams p) {
   __shared__ __attribute__((aligned(16))) float s_t[CL_PX * CL_PITCH];
   const int t = blockIdx.x;
@@ -70,12 +84,12 @@ __global__ __launch_bounds__(256) void pyramid_channels_last_kernel(const ClPara
 #pragma unroll
   for (int i = 0; i < 32; ++i) s_t[px * CL_PITCH + wave * 64 + 2 * i + ch_lo] = v[i];
   __syncthreads();
-  float* op = p.out + ((size_t)row * p.S + ostart + pix0) * CL_C;
+  const size_t obase = ((size_t)row * p.S + ostart + pix0) * CL_C;
 #pragma unroll
   for (int i = 0; i < CL_PX / 4; ++i) {
-    const int q = wave + 4 * i;                                  // pixel of this wave instruction: 1 KB contiguous
+    const int q = wave + 4 * i;                                  // pixel of this wave instruction: 1 KB (512 B) contiguous
     if (q < npx)
-      *reinterpret_cast<float4*>(op + (size_t)q * CL_C + lane * 4) = *reinterpret_cast<const float4*>(&s_t[q * CL_PITCH + lane * 4]);
+      cl_store4<OUT_BF16>(p.out, obase + (size_t)q * CL_C + lane * 4, *reinterpret_cast<const float4*>(&s_t[q * CL_PITCH + lane * 4]));
   }
 }
 
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(256) void pyramid_channels_last_kernel(const ClPara
 constexpr int CLP_PX = 64, CLP_THREADS = 512;
 constexpr int CLP_LDS = 84 * 1024;                              // > 80 KB: one workgroup per CU
 
+template <bool OUT_BF16>
 __global__ __launch_bounds__(CLP_THREADS) void pyramid_channels_last_persistent_kernel(const ClParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_tp[];  // [CLP_PX][CL_PITCH] (+ padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 8 waves; wave w moves channels 32 w .. 32 w + 31
@@ -123,12 +138,12 @@ __global__ __launch_bounds__(CLP_THREADS) void pyramid_channels_last_persistent_
     __syncthreads();
     const int tn = t + gridDim.x;
     if (tn < p.total) load_tile(tn);                             // in flight during the store phase
-    float* op = p.out + ((size_t)c_row * p.S + c_ostart + c_pix0) * CL_C;
+    const size_t obase = ((size_t)c_row * p.S + c_ostart + c_pix0) * CL_C;
 #pragma unroll
     for (int i = 0; i < CLP_PX / 8; ++i) {
       const int q = wave + 8 * i;
       if (q < c_npx)
-        *reinterpret_cast<float4*>(op + (size_t)q * CL_C + lane * 4) = *reinterpret_cast<const float4*>(&s_tp[q * CL_PITCH + lane * 4]);
+        cl_store4<OUT_BF16>(p.out, obase + (size_t)q * CL_C + lane * 4, *reinterpret_cast<const float4*>(&s_tp[q * CL_PITCH + lane * 4]));
     }
     __syncthreads();
     t = tn;
@@ -144,8 +159,9 @@ __global__ __launch_bounds__(CLP_THREADS) void pyramid_channels_last_persistent_
 // computed SIMD-fashion - lane (item % 4, level, corner) for four items at a time - and broadcast with v_readlane into
 // scalar registers; the loads use them as scalar offsets, the FMAs as scalar factors.  No cross-wave reduction, a fixed
 // summation order (deterministic), and only visible points are touched.
-template <int HH, int LT, bool LEVEL_MAJOR, int WAVES>
+template <int HH, int LT, bool LEVEL_MAJOR, int WAVES, typename VT = float>
 __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossAttnParams p) {
+  constexpr int ES = sizeof(VT);                                // bytes per stored channel (4: fp32, 2: bf16)
   constexpr int PT = kPoints;
   constexpr int E = HH * PT;
   constexpr int LP = LT * PT;
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
     // being evicted by the level-0 stream (332 MB of nearly unique lines) between two uses.
     // Lane (item % 16, corner): 16 items x 4 corners of ONE level per set-up; a load round is 4 items x 4 corners.
     const int it_of = lane >> 2, c_of = lane & 3;
-    const char* vbase = static_cast<const char*>(p.value) + lane * 16;
+    const char* vbase = static_cast<const char*>(p.value) + lane * 4 * ES;
     float4 acc[HPW];
     float wsum_lane[HPW];
 #pragma unroll
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
             for (int j = 0; j < 16; ++j) {
               unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
               if (p.dbg_wrap) px &= p.dbg_wrap;
-              val[j] = *reinterpret_cast<const float4*>(vbase + (size_t)px * (kChannels * 4));
+              val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(vbase + (size_t)px * (kChannels * ES)));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
 #pragma unroll
   for (int l = 1; l < LT; ++l)
     if (l_of == l) { lw = p.lvl_w[l]; lh = p.lvl_h[l]; ls = p.lvl_start[l]; }
-  const char* vbase = static_cast<const char*>(p.value) + lane * 16;         // + pixel * 1024
+  const char* vbase = static_cast<const char*>(p.value) + lane * 4 * ES;     // + pixel * (1024 or 512)
 #pragma unroll
   for (int hi = 0; hi < HPW; ++hi) {
     const int h = wave + hi * WAVES;
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
         for (int j = 0; j < LT * 4; ++j) {
           unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
               if (p.dbg_wrap) px &= p.dbg_wrap;
-          val[j] = *reinterpret_cast<const float4*>(vbase + (size_t)px * (kChannels * 4));
+          val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(vbase + (size_t)px * (kChannels * ES)));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(64) void value_proj_heads_kernel(const HeadProjPara
 }
 
 template <int HH>
-static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
+static int launch_agg(const CrossAttnParams& p, hipStream_t s, bool bf16) {
   const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
   static int lds_pad = -1;                          // dev: GD4D_AGG_LDS_PAD bytes of unused LDS per workgroup (caps residency)
   if (lds_pad < 0) { const char* e = getenv("GD4D_AGG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
@@ -484,8 +500,11 @@ static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
     if (lds > 65536) (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
   };
+  if (bf16 && variant != 0) return GD4D_EUNSUPPORTED;         // bf16 storage: the default form only
 #define GD4D_AGG_GO(LT_)                                                                            \
-  if (variant & 2) {                                                                                 \
+  if (bf16) {                                                                                       \
+    go(cross_attn_agg_kernel<HH, LT_, false, HH, uint16_t>, 64 * HH, lds_bytes(LT_));               \
+  } else if (variant & 2) {                                                                                 \
     if (variant & 1) go(cross_attn_agg_kernel<HH, LT_, true, 4>, 256, lds_bytes(LT_));              \
     else go(cross_attn_agg_kernel<HH, LT_, false, 4>, 256, lds_bytes(LT_));                         \
   } else {                                                                                          \
@@ -507,11 +526,13 @@ static int launch_agg(const CrossAttnParams& p, hipStream_t s) {
 
 extern "C" void gd4d_trace_set_late(unsigned long long* p) { gd4d::trace_set_late(p); }
 
-extern "C" int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, float* out, int R, int C,
-                                              int L, int in_dtype, int max_cus, void* stream) {
+extern "C" int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C,
+                                              int L, int in_dtype, int out_dtype, int max_cus, void* stream) {
   using namespace gd4d;
   if (!feats || !level_hw || !out || R <= 0 || C <= 0 || L <= 0) return GD4D_EINVAL;
   if (C != CL_C || L > GD4D_MAX_LEVELS || in_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+  if (out_dtype != GD4D_F32 && out_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
+  const bool ob = out_dtype == GD4D_BF16;
   if (!aligned16(out)) return GD4D_EALIGN;
   const bool persistent = max_cus > 0;
   const int px = persistent ? CLP_PX : CL_PX;
@@ -530,10 +551,17 @@ extern "C" int gd4d_pyramid_channels_last_fwd(const void* const* feats, const in
   p.out = out; p.R = R; p.L = L; p.S = s; p.total = base;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (persistent) {
-    if (!allow_dynamic_lds(reinterpret_cast<const void*>(pyramid_channels_last_persistent_kernel), CLP_LDS)) return GD4D_ELAUNCH;
-    hipLaunchKernelGGL(pyramid_channels_last_persistent_kernel, dim3(min(max_cus, base)), dim3(CLP_THREADS), CLP_LDS, st, p);
+    if (ob) {
+      if (!allow_dynamic_lds(reinterpret_cast<const void*>(pyramid_channels_last_persistent_kernel<true>), CLP_LDS)) return GD4D_ELAUNCH;
+      hipLaunchKernelGGL(pyramid_channels_last_persistent_kernel<true>, dim3(min(max_cus, base)), dim3(CLP_THREADS), CLP_LDS, st, p);
+    } else {
+      if (!allow_dynamic_lds(reinterpret_cast<const void*>(pyramid_channels_last_persistent_kernel<false>), CLP_LDS)) return GD4D_ELAUNCH;
+      hipLaunchKernelGGL(pyramid_channels_last_persistent_kernel<false>, dim3(min(max_cus, base)), dim3(CLP_THREADS), CLP_LDS, st, p);
+    }
+  } else if (ob) {
+    hipLaunchKernelGGL(pyramid_channels_last_kernel<true>, dim3(base), dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL(pyramid_channels_last_kernel, dim3(base), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(pyramid_channels_last_kernel<false>, dim3(base), dim3(256), 0, st, p);
   }
   return check_launch();
 }
@@ -550,7 +578,8 @@ extern "C" int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* leve
   if ((agg != nullptr) != (wsum != nullptr)) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
   // B > 1 pairs value rows with the logits of batch (row % B) (deform3d_cross_attn.py:277): gd4d_cross_attn_fwd has that form
-  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B != 1 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B != 1) return GD4D_EUNSUPPORTED;
+  if (feats_dtype != GD4D_F32 && feats_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
   if (!aligned16(feats_cl) || (agg && !aligned16(agg)) || (vp_weight && !aligned16(vp_weight))) return GD4D_EALIGN;
   CrossAttnParams p{};
@@ -575,10 +604,11 @@ extern "C" int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* leve
   p.img_h = img_h; p.img_w = img_w;
   { static long wrap = -1; if (wrap < 0) { const char* e = getenv("GD4D_AGG_DBG_WRAP"); wrap = e ? atol(e) : 0; } p.dbg_wrap = (unsigned)wrap; }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {
-    case 4: return launch_agg<4>(p, s);
-    case 8: return launch_agg<8>(p, s);
-    default: return launch_agg<16>(p, s);
+    case 4: return launch_agg<4>(p, s, bf16);
+    case 8: return launch_agg<8>(p, s, bf16);
+    default: return launch_agg<16>(p, s, bf16);
   }
 }
 

@@ -155,7 +155,7 @@ class Deform3DCrossAttn(nn.Module):
             late = None
         if late is None and taken is None and (cached is None or cached[2] is not value) \
                 and Fn.LateValues.applicable([self], value):
-            late = Fn.LateValues(value)              # a stand-alone call: its own channels-last copy
+            late = Fn.LateValues(value, self.value_dtype)   # a stand-alone call: its own channels-last copy
         if late is not None:
             # aggregate-then-project (csrc/gd4d_cross_attn_late.hip): raw features gathered per head, value_proj applied
             # to the Q x Hh aggregates - no projected value tensor

@@ -309,7 +309,7 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                 and Fn.LateValues.applicable(cross, kwargs['value']) and not Fn.wants_grad(self, query, *kwargs['value']):
             # aggregate-then-project (GD4D_PROJECT=late, default): no per-layer value tensors, ONE channels-last copy of
             # the pyramid for all layers (made on the side stream next to layer 0's self-attention)
-            late, own_late = Fn.LateValues(kwargs['value']), True
+            late, own_late = Fn.LateValues(kwargs['value'], cross[0].value_dtype), True
             kwargs = dict(kwargs)
             kwargs[Fn.LATE_VALUES_KEY] = late
         if late is None:
@@ -423,7 +423,7 @@ class Detr3DTransformer(nn.Module):
             # the channels-last copy of the pyramid needs nothing but the pyramid: fork it first, before the query side
             cross = [a for layer in self.decoder.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
             if cross and all(type(a) is Deform3DCrossAttn for a in cross) and Fn.LateValues.applicable(cross, mlvl_feats):
-                own_late = Fn.LateValues(mlvl_feats)
+                own_late = Fn.LateValues(mlvl_feats, cross[0].value_dtype)
                 kwargs = dict(kwargs)
                 kwargs[Fn.LATE_VALUES_KEY] = own_late
         if fused_decoder.fast_input(self, query_embed, mlvl_feats):
@@ -464,7 +464,7 @@ class Detr3DTransformer(nn.Module):
         elif share and Fn.LateValues.applicable(mods, mlvl_feats):
             # inference, aggregate-then-project: what the passes share is the channels-last copy of the pyramid
             Fn.require_inference(*mlvl_feats)
-            late = Fn.LateValues(mlvl_feats)
+            late = Fn.LateValues(mlvl_feats, mods[0].value_dtype)
             outs = [self.forward(mlvl_feats, qe, reg_branches=reg_branches, **{Fn.LATE_VALUES_KEY: late}, **kwargs)
                     for qe in query_embeds]
             late.finish()

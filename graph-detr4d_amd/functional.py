@@ -422,7 +422,9 @@ class LateValues:
     and applies its value_proj to the 900 x Hh aggregates (ops.value_proj_heads_fwd) instead of to 739 800 pixel rows.
     GD4D_PROJECT=early keeps the projected-value path (value_proj kernel + gd4d_cross_attn_fwd)."""
 
-    def __init__(self, value):
+    def __init__(self, value, dtype=torch.float32):
+        """dtype: storage type of the channels-last copy - torch.bfloat16 for modules built with value_dtype='bf16' (half the
+        bytes to copy and to gather, bf16-rounded features, fp32 accumulation)."""
         dev = value[0].device
         self.value = value
         self.main = torch.cuda.current_stream(dev)
@@ -434,14 +436,14 @@ class LateValues:
             if 'copy' in os.environ.get('GD4D_ABLATE', '').split(','):      # dev: skip the copy (see fused_decoder._ablate)
                 r = value[0].shape[0] * value[0].shape[1]
                 self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
-                self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev)
+                self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev, dtype=dtype)
             else:
                 # GD4D_COPY_CUS: compute units of the persistent copy (default 7/8 of the device - 192: 1.937, 224: 1.922, 256: 1.984, plain copy 2.000 ms per step - the query side of the
                 # first layer runs on the rest, underneath it); 0 = the plain one-workgroup-per-tile copy on all of them
                 env = os.environ.get('GD4D_COPY_CUS')
                 cus = torch.cuda.get_device_properties(dev).multi_processor_count
                 copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
-                self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value], max_cus=copy_cus)
+                self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value], max_cus=copy_cus, out_dtype=dtype)
             self.event = torch.cuda.Event()
             self.event.record(self.side)
         # allocated under the side stream, read by kernels of the main stream: tell the allocator, so that the block is
@@ -459,8 +461,9 @@ class LateValues:
         rows = value[0].shape[1]
         if rows > 64 or len(value) > 4 or rows * sum(v.shape[-1] * v.shape[-2] for v in value) >= 2 ** 31:
             return False
-        return all(m.value_dtype == torch.float32 and m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
-                   and m.num_levels == len(value) and m.num_cams == rows for m in modules)
+        return len({m.value_dtype for m in modules}) == 1 and \
+            all(m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
+                and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
     def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, vp_weight=None,
                   vp_bias=None):

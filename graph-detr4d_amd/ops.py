@@ -76,10 +76,11 @@ def cross_attn_fwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
     return res if len(res) > 1 else out
 
 
-def pyramid_channels_last_fwd(feats, out=None, max_cus=0):
+def pyramid_channels_last_fwd(feats, out=None, max_cus=0, out_dtype=torch.float32):
     """gd4d_pyramid_channels_last_fwd.  feats: list of L tensors (R, 256, H_l, W_l) fp32 (or (B, N, 256, H, W)).
     max_cus > 0: one persistent workgroup on each of that many compute units (the rest stays free for another stream).
-    Returns (cl (R, S, 256) fp32, level_hw)."""
+    out_dtype torch.bfloat16: bf16 storage of the copy (reduced precision; the aggregate kernel accumulates in fp32).
+    Returns (cl (R, S, 256), level_hw)."""
     lib = _lib.load()
     fl = [f.reshape(-1, *f.shape[-3:]) for f in feats]
     r, c = fl[0].shape[0], fl[0].shape[1]
@@ -88,10 +89,11 @@ def pyramid_channels_last_fwd(feats, out=None, max_cus=0):
     if any(f.shape[0] != r or f.shape[1] != c for f in fl):
         raise ValueError('feature levels disagree in rows / channels')
     if out is None:
-        out = torch.empty(r, s, c, device=fl[0].device, dtype=torch.float32)
+        out = torch.empty(r, s, c, device=fl[0].device, dtype=out_dtype)
     ptrs = (ctypes.c_void_p * len(fl))(*[_dev(f, 'feats', torch.float32).value for f in fl])
     lv = (ctypes.c_int32 * (2 * len(fl)))(*[int(x) for hw in level_hw for x in hw])
-    code = lib.gd4d_pyramid_channels_last_fwd(ptrs, lv, _dev(out, 'out', torch.float32), r, c, len(fl), _lib.F32, int(max_cus), _stream())
+    code = lib.gd4d_pyramid_channels_last_fwd(ptrs, lv, _dev(out, 'out'), r, c, len(fl), _lib.F32, _value_dtype(out), int(max_cus),
+                                              _stream())
     _lib.check(code, 'gd4d_pyramid_channels_last_fwd')
     return out, level_hw
 
@@ -122,11 +124,11 @@ def cross_attn_agg_fwd(feats_cl, level_hw, ref, offsets, attn_logits, cam_logits
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
     rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
     code = lib.gd4d_cross_attn_agg_fwd(
-        _dev(feats_cl, 'feats_cl', f32), lv, _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32),
+        _dev(feats_cl, 'feats_cl'), lv, _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32),
         _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32),
         rng, float(img_h), float(img_w), None if fused else _dev(agg, 'agg'), None if fused else _dev(wsum, 'wsum'),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None,
-        b, n, q, hh, c, nl, p, _lib.F32, 1 if raw_cam_weights else 0,
+        b, n, q, hh, c, nl, p, _value_dtype(feats_cl), 1 if raw_cam_weights else 0,
         None if query_order is None else _order_ptr(query_order, b * q),
         _dev(vp_weight, 'vp_weight', f32) if fused else None, _opt(vp_bias, 'vp_bias') if fused else None,
         _dev(out, 'out') if fused else None, _stream())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 24
+#define GD4D_ABI_VERSION 25
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -120,7 +120,9 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
  *
  * gd4d_pyramid_channels_last_fwd - the reference's flatten(3) / transpose / cat of the FPN levels (:264-276), once
  *   per sample instead of once per layer:  feats host array of L device pointers, level l = (R, C, H_l, W_l) fp32
- *   (R = B*N camera rows);  out (R, S, C) fp32, S = sum_l H_l*W_l, level l at pixel offset sum_{l'<l} H_l'*W_l'.
+ *   (R = B*N camera rows);  out (R, S, C) fp32 or bf16 (out_dtype; bf16 = round to nearest even: the reduced-precision
+ *   storage mode of `value_dtype='bf16'`, fp32 accumulation downstream), S = sum_l H_l*W_l, level l at pixel offset
+ *   sum_{l'<l} H_l'*W_l'.
  *   max_cus: 0 = one workgroup per tile over the whole device; > 0 = one persistent workgroup on each of max_cus compute
  *   units, which it fills (the others stay free for kernels of another stream: the first layer's query side).
  *   Supported: C == 256, L <= 8, fp32.
@@ -132,14 +134,15 @@ int gd4d_cross_attn_fwd(const void* value, const int32_t* level_hw, const float*
  *   vp_weight (C, C), vp_bias (C) or NULL, out (B*Q, C): optional - value_proj applied to the aggregates in the kernel's
  *   epilogue (exact fp32 FMAs), out = what gd4d_value_proj_heads_fwd would return; agg / wsum may then be NULL.
  *   Supported: B == 1 (for B > 1 the reference pairs value rows with the logits of batch (row % B), :277 - use
- *   gd4d_cross_attn_fwd), C == 256, P == 4, L <= 4, N <= 64, Hh in {4, 8, 16}, B*N*S < 2^31, fp32 features.
+ *   gd4d_cross_attn_fwd), C == 256, P == 4, L <= 4, N <= 64, Hh in {4, 8, 16}, B*N*S < 2^31, features fp32 or
+ *   bf16 (feats_dtype).
  *
  * gd4d_value_proj_heads_fwd - value_proj applied to the aggregates: out (M, Hh*Dh) with
  *   out[r, h*Dh + d] = sum_c weight[h*Dh + d][c] * agg[r][h][c] + bias[h*Dh + d] * wsum[r][h]
  *   (exact fp32 products on v_mfma_f32_16x16x4_f32); out is what gd4d_cross_attn_fwd returns (input of output_proj,
  *   :326).  weight (C, C) = value_proj.weight, bias (C) or NULL.  Supported: C == 256, Hh in {4, 8, 16}. */
-int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, float* out, int R, int C, int L,
-                                   int in_dtype, int max_cus, void* stream);
+int gd4d_pyramid_channels_last_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C, int L,
+                                   int in_dtype, int out_dtype, int max_cus, void* stream);
 int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* level_hw, const float* ref, const float* offsets,
                             const float* attn_logits, const float* cam_logits, const float* lidar2img,
                             const double* pc_range, float img_h, float img_w, float* agg, float* wsum, uint8_t* mask_out,

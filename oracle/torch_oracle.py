@@ -168,7 +168,7 @@ def deform3d_cross_attn(p, query, value, query_pos, reference_points, img_metas,
 
     value_dtype='bf16' restates the build's opt-in reduced-precision mode (not a reference mode): value_proj on
     bf16-rounded features and weights (exact products, fp32 accumulate, fp32 bias) and the projected value tensor
-    rounded to bf16; everything else fp32."""
+    rounded to bf16; everything else fp32.  value_dtype='bf16_features': only the features are rounded to bf16."""
     x = query if query_pos is None else query + query_pos                   # :203-204
     x = x.permute(1, 0, 2)                                                  # :207
     b, q, c = x.shape
@@ -182,6 +182,10 @@ def deform3d_cross_attn(p, query, value, query_pos, reference_points, img_metas,
     flat, shapes = flatten_pyramid(value)
     if value_dtype == 'bf16':
         val = _bf16r(F.linear(_bf16r(flat), _bf16r(p['value_proj.weight']), p['value_proj.bias']))
+    elif value_dtype == 'bf16_features':
+        # the aggregate-then-project form of the same opt-in mode: the FEATURES are what is stored in bf16 (the
+        # channels-last copy); value_proj (linear, so it commutes with the weighted sum of the gather) stays fp32
+        val = F.linear(_bf16r(flat), p['value_proj.weight'], p['value_proj.bias'])
     else:
         val = _linear(flat, p, 'value_proj')
     val = val.view(b * n, flat.shape[1], num_heads, c // num_heads)

@@ -161,3 +161,33 @@ def test_full_size_late_equals_early():
     # linear in the features, zero for zero features up to the bias term
     out_z, *_ = _late([torch.zeros_like(f) for f in feats], w, None, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600)
     assert out_z.abs().max().item() == 0.0
+
+
+def test_bf16_storage_of_the_channels_last_copy():
+    """value_dtype='bf16' in the aggregate-then-project form: the copy rounds the features to bf16 (nearest even, exactly
+    torch's .bfloat16()), both copy kernels; the aggregate kernel on the bf16 copy equals the fp32 kernel on the same
+    rounded features up to the summation order (fp32 accumulation in both)."""
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import torch_oracle as O
+    torch.manual_seed(13)
+    levels = [(29, 50), (15, 25), (8, 13), (3, 5)]
+    n, q = 6, 200
+    feats = [torch.randn(1, n, 256, h, w) for h, w in levels]
+    flat, shapes = O.flatten_pyramid(feats)
+    fd = [f.cuda() for f in feats]
+    cl16, _ = ops.pyramid_channels_last_fwd(fd, out_dtype=torch.bfloat16)
+    assert cl16.dtype == torch.bfloat16 and torch.equal(cl16.cpu(), flat.reshape(n, -1, 256).bfloat16())
+    for cus in (8, 224):
+        assert torch.equal(ops.pyramid_channels_last_fwd(fd, out_dtype=torch.bfloat16, max_cus=cus)[0], cl16)
+    l2i = torch.from_numpy(synthetic.camera_rig(1)).unsqueeze(0).cuda()
+    ref, off = torch.rand(1, q, 3).cuda(), (torch.randn(1, q, 8, 4, 3) * 2).cuda()
+    attn, cam = torch.randn(1, q, 8, 4, 4).cuda(), torch.randn(1, q, n).cuda()
+    w, b = (torch.randn(256, 256) * 0.06).cuda(), torch.randn(256).cuda()
+    args = (shapes, ref, off, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8)
+    a16, s16, m16 = ops.cross_attn_agg_fwd(cl16, *args, want_mask=True)
+    a32, s32, m32 = ops.cross_attn_agg_fwd(cl16.float(), *args, want_mask=True)
+    assert torch.equal(m16, m32) and torch.equal(s16, s32)
+    torch.testing.assert_close(a16, a32, rtol=1e-6, atol=1e-6)
+    o16, = ops.cross_attn_agg_fwd(cl16, *args, vp_weight=w, vp_bias=b)
+    o32, = ops.cross_attn_agg_fwd(cl16.float(), *args, vp_weight=w, vp_bias=b)
+    torch.testing.assert_close(o16, o32, rtol=1e-5, atol=1e-5)
