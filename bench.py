@@ -49,6 +49,9 @@ def parse():
                          "'distill': BASELINE configs[4] - teacher pass (no grad), student pass and teacher-query-guided "
                          "student pass over one pyramid, instance distillation loss, backward, all-reduce, SGD")
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
+    ap.add_argument('--inflight', type=int, default=2,
+                    help="--mode infer: independent samples in flight per GPU, each on its own HIP stream with its own hipGraph "
+                         "(a step = one sample on every stream); 1 = one sample at a time")
     ap.add_argument('--criterion', action='store_true',
                     help='--mode train: the head (cls / reg branches, box epilogue) and its real loss (Hungarian '
                          'assignment + focal / L1 terms over all layers) instead of a synthetic loss; eager launch')
@@ -169,35 +172,74 @@ def main():
         train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels, G)
         return
 
+    # S samples in flight: a decoder layer alternates between an HBM-bound phase (the aggregate launch) and a
+    # latency-bound one (attention core + row chains on a few dozen workgroups); with one sample on the device the memory
+    # system idles during the second.  Request i has its own pyramid, queries, HIP stream and hipGraph; the streams run
+    # free (no join between steps; the closing synchronise of the timed region waits for all of them).  One graph per
+    # request, not one graph with S branches: a capture in which a forked stream forks again (request stream -> its
+    # copy stream) sends this runtime's hipStreamEndCapture into an endless recursion.
+    from graph_detr4d_amd import functional as Fn
+    n_req = max(1, a.inflight)
+    reqs = [(feats, query_embed)]
+    for i in range(1, n_req):
+        gi = torch.Generator().manual_seed(seed + 3 + 7919 * i)
+        reqs.append(([f.to(dev) for f in synthetic.feature_pyramid(n_cams, levels, seed=seed + 7919 * i)],
+                     torch.randn(a.queries, 512, generator=gi).to(dev)))
+    streams = [torch.cuda.Stream(dev) for _ in range(n_req)]
+
+    def request(i):
+        return tr(reqs[i][0], reqs[i][1], reg_branches=regs, img_metas=metas)
+
     launch = 'eager'
-    run = step
+    graphs = []
+    single_ms = None
     with torch.no_grad():
         out = step()
         torch.cuda.synchronize()
+        eager_outs = []
+        for i in range(n_req):                        # every request once eagerly on its own stream (allocations, caches)
+            with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                eager_outs.append(request(i))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(eager_outs[0][0], out[0], rtol=0, atol=0)      # the stream does not change a result
         if not a.no_graph:
             try:
-                graph = torch.cuda.CUDAGraph()
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    step()
-                torch.cuda.current_stream().wait_stream(s)
-                # thread_local: with a process group up, the RCCL watchdog thread polls events while we
-                # capture; in the default 'global' mode that would invalidate the capture
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    static_out = step()
-                run = graph.replay
+                for i in range(n_req):
+                    g_i = torch.cuda.CUDAGraph()
+                    # thread_local: with a process group up, the RCCL watchdog thread polls events while we
+                    # capture; in the default 'global' mode that would invalidate the capture
+                    with torch.cuda.graph(g_i, stream=streams[i], capture_error_mode='thread_local'), Fn.request_slot(i):
+                        static_out = request(i)
+                    g_i.replay()
+                    torch.cuda.synchronize()
+                    torch.testing.assert_close(static_out[0], eager_outs[i][0], rtol=1e-5, atol=1e-5)
+                    graphs.append(g_i)
                 launch = 'hipgraph'
-                graph.replay()
-                torch.cuda.synchronize()
-                torch.testing.assert_close(static_out[0], out[0], rtol=1e-5, atol=1e-5)
             except Exception as e:                    # report, never hide
                 print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly',
                       file=sys.stderr)
-                run, launch = step, 'eager'
+                graphs, launch = [], 'eager'
+
+        def run():
+            for i in range(n_req):
+                with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                    if graphs:
+                        graphs[i].replay()
+                    else:
+                        request(i)
+
+        def run_one():
+            with torch.cuda.stream(streams[0]), Fn.request_slot(0):
+                if graphs:
+                    graphs[0].replay()
+                else:
+                    request(0)
 
         stats = {}
+        torch.cuda.synchronize()
         elapsed = D.timed_steps(run, a.steps, a.warmup, dev, stats)   # barrier + synchronise both sides, MAX over ranks
+        if n_req > 1:                                 # one sample at a time, same graphs: the latency of a request
+            single_ms = D.timed_steps(run_one, a.steps, a.warmup, dev, {}) / a.steps * 1e3
 
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
@@ -214,7 +256,7 @@ def main():
         ms = elapsed / a.steps * 1e3
         line = {
             'metric': f'decoder_samples_per_sec_{a.queries}q_T{a.frames}',
-            'value': D.aggregate_throughput(1, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
+            'value': D.aggregate_throughput(n_req, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if a.value_dtype == 'fp32' else 'bf16-storage/f32-accumulate',
@@ -222,11 +264,16 @@ def main():
             'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
                                    f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
                                    f'{"x".join(str(h) + "*" + str(w) for h, w in levels)}, 256 ch, '
-                                   f'batch 1 per GPU, pyramid resident in HBM',
-                       'baseline_config': 'configs[2]', 'launch': launch,
+                                   f'batch 1 per request, {n_req} independent request(s) in flight per GPU (one HIP stream '
+                                   f'and one hipGraph each; a step = one sample on every stream), pyramids resident in HBM',
+                       'baseline_config': 'configs[2]', 'launch': launch, 'inflight': n_req, 'global_batch': n_req * a.gpus,
+                       'samples_per_step': n_req * a.gpus,
                        'parallelism': f'replicas x{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3, 'allreduce_bytes_per_step': 0,
+            'one_in_flight': None if single_ms is None else {
+                'ms_per_sample': single_ms, 'samples_per_s': a.gpus * 1e3 / single_ms,
+                'note': 'the same graphs replayed one request at a time (latency of a request; round-1/2 lines were this)'},
             'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
         }
         print(json.dumps(line))

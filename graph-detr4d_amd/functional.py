@@ -79,14 +79,31 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps, max=1) / (1 - x).clamp(min=eps, max=1))
 
 
-_L2I_BUFFERS = {}          # (device index, shape) -> [host copy, persistent device tensor]
+_L2I_BUFFERS = {}          # (device index, request slot, shape) -> [host copy, persistent device tensor]
+_REQUEST_SLOT = [0]
+
+
+class request_slot:
+    """Context manager for callers that keep several samples in flight on different streams (bench.py --inflight): the
+    per-sample persistent device buffers (the lidar2img matrices) are kept per slot, so that refreshing one request's
+    matrices cannot change what another request's queued kernels read."""
+
+    def __init__(self, slot):
+        self.slot, self.prev = int(slot), 0
+
+    def __enter__(self):
+        self.prev, _REQUEST_SLOT[0] = _REQUEST_SLOT[0], self.slot
+
+    def __exit__(self, *exc):
+        _REQUEST_SLOT[0] = self.prev
+
 
 
 def lidar2img_device(img_metas, like):
     """(B, N, 4, 4) fp32 device tensor from img_metas[*]['lidar2img'].
 
     The reference re-uploads it in every layer (deform3d_cross_attn.py:215-219, a host->device
-    copy x6 per sample).  Here ONE persistent device buffer per (device, shape) is kept and refreshed IN PLACE
+    copy x6 per sample).  Here ONE persistent device buffer per (device, request slot, shape) is kept and refreshed IN PLACE
     when the host values change (compared every call, so in-place edits by augmentations are seen): a hipGraph
     captured over the decoder keeps a valid address, and replaying it for a new sample only needs this function
     (or the decoder) to be called once outside the graph to refresh the buffer.  A refresh cannot be recorded into
@@ -94,7 +111,7 @@ def lidar2img_device(img_metas, like):
     is capturing raises instead of baking stale matrices into the graph.
     """
     host = np.ascontiguousarray(np.asarray([m['lidar2img'] for m in img_metas]), dtype=np.float32)
-    key = (like.device.index, host.shape)
+    key = (like.device.index, _REQUEST_SLOT[0], host.shape)
     entry = _L2I_BUFFERS.get(key)
     if entry is not None and np.array_equal(entry[0], host):
         return entry[1]
@@ -308,6 +325,18 @@ def project_values_for_layers_autograd(modules, value):
 
 _SIDE_STREAMS = {}
 _AUX_STREAMS = {}
+
+
+def _companion_stream(table, device):
+    """The side / auxiliary stream that belongs to the CURRENT stream of `device`: requests that run concurrently on
+    different streams (bench.py --inflight) must not meet on one shared companion stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    s = table.get(key)
+    if s is None:
+        s = table[key] = torch.cuda.Stream(device)
+    return s
+
+
 REF_EVENT_KEY = '_gd4d_ref_event'
 
 
@@ -317,10 +346,7 @@ def aux_stream(device):
     next to the main chain they cost nothing.  None when disabled (GD4D_AUX_STREAM=0)."""
     if os.environ.get('GD4D_AUX_STREAM', '1') == '0':
         return None
-    s = _AUX_STREAMS.get(device.index)
-    if s is None:
-        s = _AUX_STREAMS[device.index] = torch.cuda.Stream(device)
-    return s
+    return _companion_stream(_AUX_STREAMS, device)
 
 
 VALUE_PIPELINE_KEY = '_gd4d_value_pipeline'
@@ -350,9 +376,7 @@ class ValuePipeline:
         self.group_of = {id(m): gi for gi, (a, b) in enumerate(self.bounds) for m in self.modules[a:b]}
         dev = value[0].device
         self.main = torch.cuda.current_stream(dev)
-        self.side = _SIDE_STREAMS.get(dev.index)
-        if self.side is None:
-            self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        self.side = _companion_stream(_SIDE_STREAMS, dev)
         self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
         self.ready = {}
         self.issued = 0
@@ -428,9 +452,7 @@ class LateValues:
         dev = value[0].device
         self.value = value
         self.main = torch.cuda.current_stream(dev)
-        self.side = _SIDE_STREAMS.get(dev.index)
-        if self.side is None:
-            self.side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        self.side = _companion_stream(_SIDE_STREAMS, dev)
         self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
         with torch.cuda.stream(self.side):
             if 'copy' in os.environ.get('GD4D_ABLATE', '').split(','):      # dev: skip the copy (see fused_decoder._ablate)

@@ -318,3 +318,51 @@ def test_decoder_under_hipgraph_capture_matches_eager():
             torch.cuda.synchronize()
             for a, b in zip(captured, eager):
                 assert torch.equal(a, b)
+
+
+def test_requests_in_flight_on_their_own_streams_equal_one_at_a_time():
+    """What bench.py --inflight does: independent samples (own pyramid, own queries, own lidar2img) on their own HIP
+    streams, each inside Fn.request_slot(i) and each with its own hipGraph, replayed concurrently - every request's
+    result is the one-at-a-time result bit for bit, replay after replay (per-stream copy streams, per-slot lidar2img
+    buffers: neither request sees the other's)."""
+    import numpy as np
+    import bench
+    from graph_detr4d_amd import functional as Fn, synthetic
+    n, q = 6, 300
+    tr, regs = bench.build_decoder(G, n, 2, 'fp32', 77)
+    tr, regs = tr.to(DEV).eval(), regs.to(DEV).eval()
+    levels = [(29, 50), (15, 25), (8, 13), (4, 7)]
+    rig = synthetic.camera_rig(1)
+    reqs = []
+    for i in range(2):
+        feats = [f.to(DEV) for f in synthetic.feature_pyramid(n, levels, seed=5 + i)]
+        qe = torch.randn(q, 512, generator=torch.Generator().manual_seed(9 + i)).to(DEV)
+        rig_i = rig.copy()
+        rig_i[:, :2, :] *= np.float32(1.0 + 0.03 * i)            # a different camera calibration per request
+        reqs.append((feats, qe, synthetic.make_img_metas(rig_i, batch=1)))
+    with torch.no_grad():
+        ref = [tr(f, qe, reg_branches=regs, img_metas=mt) for f, qe, mt in reqs]
+        torch.cuda.synchronize()
+        assert not torch.equal(ref[0][0], ref[1][0])
+        streams = [torch.cuda.Stream() for _ in reqs]
+        graphs, outs = [], []
+        for i, (f, qe, mt) in enumerate(reqs):
+            with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                eager = tr(f, qe, reg_branches=regs, img_metas=mt)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(eager, ref[i]))
+            g_i = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_i, stream=streams[i], capture_error_mode='thread_local'), Fn.request_slot(i):
+                outs.append(tr(f, qe, reg_branches=regs, img_metas=mt))
+            graphs.append(g_i)
+        for _ in range(3):
+            for o in outs:
+                for t in o:
+                    t.zero_()
+            for _k in range(4):                                  # free-running streams, several steps deep
+                for i, g_i in enumerate(graphs):
+                    with torch.cuda.stream(streams[i]):
+                        g_i.replay()
+            torch.cuda.synchronize()
+            for o, r in zip(outs, ref):
+                assert all(torch.equal(a, b) for a, b in zip(o, r))
