@@ -1,5 +1,9 @@
-"""Dev: S independent samples in flight on S HIP streams (one hipGraph with S parallel branches) - does the latency-bound
-query side of one sample hide under the aggregate launches of another?  python tools/bench_inflight.py [S ...]"""
+"""Dev: S independent samples in flight on S HIP streams - does the latency-bound query side of one sample hide under the
+aggregate launches of another?  python tools/bench_inflight.py [S ...]
+MODE=graphs (default): one hipGraph per request, replayed on its own stream (what bench.py --inflight does).
+MODE=fork / first_on_cur: ONE graph with a branch per request - the request's own fork to its copy stream makes
+hipStreamEndCapture recurse without end on this runtime (MODE=nested reproduces it with plain torch ops; MODE=nested2,
+where the inner stream is forked from the origin and only waited for, captures fine)."""
 import os
 import sys
 import time
@@ -83,30 +87,7 @@ def main():
                 if mode == 'dummy':
                     dummy.add_(1.0)
                 return outs
-            if os.environ.get('MODE', 'graphs') == 'interleaved':
-                def step():
-                    return tr.forward_inflight([(feats[i], qe[i], dict(img_metas=metas)) for i in range(s_n)], reg_branches=regs)
-                eager = step()
-                torch.cuda.synchronize()
-                ok_eager = all(torch.equal(o[0], r[0]) and torch.equal(o[2], r[2]) for o, r in zip(eager, ref))
-                print('eager identical:', ok_eager, flush=True)
-                for _ in range(3):
-                    step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    step()
-                t1 = time.perf_counter()
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                print(f'eager: host {1e3 * (t1 - t0) / 20:.3f} ms per step, with device {1e3 * (t2 - t0) / 20:.3f} ms per step', flush=True)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    outs = step()
-                outs = [(o[0], o[2]) for o in outs]
-                ref_ = ref
-                ref = [(r[0], r[2]) for r in ref]
-            elif os.environ.get('MODE', 'graphs') == 'graphs':
+            if os.environ.get('MODE', 'graphs') == 'graphs':
                 # one hipGraph per sample, replayed on its own stream (a single graph with nested forks - request
                 # stream -> its copy stream - sends this runtime's EndCapture into an endless recursion)
                 graphs, outs = [], []
@@ -150,8 +131,6 @@ def main():
                 g.replay()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / n * 1e3
-            if os.environ.get('MODE') == 'interleaved':
-                ref = ref_
             print(f'inflight {s_n}: {ms:.3f} ms per step of {s_n} samples = {ms / s_n:.3f} ms per sample, '
                   f'{s_n / ms * 1e3:.1f} samples/s, identical to one-at-a-time: {ok}', flush=True)
 
