@@ -42,7 +42,7 @@ __device__ __forceinline__ float rc_act_in(float v, int flags) { return (flags &
 #define RC_ROTATE 1   // per-workgroup starting k-step of the GEMMs (0: every workgroup walks K from 0 - dev A/B)
 #endif
 #ifndef RC_PREFETCH
-#define RC_PREFETCH 1   // touch the program's weight images at the start of the launch (0: dev A/B)
+#define RC_PREFETCH 1   // bit 0: touch the program's weight images at the start of the launch; bit 1 (dev, off): also its small operands
 #endif
 #ifndef RC_TRACE_OPS
 #define RC_TRACE_OPS 0   // dev: stamp every operation's end in the device timeline (tools/trace_step.py)
@@ -387,22 +387,67 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   // the ~2 us of a fabric round trip that is 17-24 B/clk per compute unit, which is what bounded every chain.  So the
   // workgroups that share an XCD (blockIdx = xcd mod 8) first TOUCH the images of all the program's GEMMs, each its
   // slice, one dword per 64 bytes, all requests in flight at once: the cold misses overlap instead of queueing behind
-  // a 4-deep ring.  The loads land in one sink register nobody reads (inline asm: the compiler neither waits for them
-  // nor counts them; they are older than every load it does count, and vmcnt retires in order).
-  unsigned rc_sink = 0;
+  // a 4-deep ring.  The touches are LDS-DMA loads (global_load_lds_dword: no destination register - an in-flight load
+  // into a register the compiler believes to be free corrupts whatever it puts there next) into a 256-byte dump area per
+  // wave behind the row buffers that nobody reads.
+  typedef __attribute__((address_space(3))) void rc_lds_void_t;
+  typedef const __attribute__((address_space(1))) void rc_glb_void_t;
+  rc_lds_void_t* rc_dump = (rc_lds_void_t*)(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * wave);
+  auto touch1 = [&](const char* q) { __builtin_amdgcn_global_load_lds((rc_glb_void_t*)q, rc_dump, 4, 0, 0); };
   {
     // the workgroups of THIS program that sit on this XCD: indices first, first + 8, ... below wg_hi
     const unsigned xcd = blockIdx.x & 7u;
     const unsigned first = (unsigned)wg_lo + ((xcd - (unsigned)wg_lo) & 7u);
     const unsigned mine = (blockIdx.x - first) >> 3, share = ((unsigned)wg_hi - 1u - first) / 8u + 1u;
-    for (int oi = op_base; oi < op_base + nops; ++oi) {
+    // First the SMALL operands of every operation - this workgroup's rows of the global tensors the LOAD / ADD / REFINE
+    // operations read, bias vectors, LayerNorm parameters, SMALL_LINEAR weights: a few KB, all cold (activations were
+    // written by a kernel on another XCD, parameters were evicted by the gather).  Untouched, each operation starts with a
+    // fabric round trip of its own (~2.5 us, one after the other along the chain: 31 of chain B's 50 us were left with
+    // neither MFMAs nor weight loads); touched here, they overlap each other and the first operation.
+    // MEASURED (RC_PREFETCH=3 against 1, 200 steps each, twice): 1.870 / 1.889 ms per step against 1.852 / 1.854 - chain
+    // B's own time drops by 4 us (block 0's timeline) but every chain's first operation waits for these touches as well
+    // (vmcnt retires in order), and the launches with few GEMMs lose more than chain B gains.  Off by default.
+    auto touch = [&](const void* base, size_t bytes) {
+      if (!base || bytes < 4) return;
+      const char* b = reinterpret_cast<const char*>(base);
+      const unsigned pieces = (unsigned)((bytes + 63) / 64) + 1u;     // + 1: a range that is not 64-byte aligned
+      for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) {
+        const char* q = b + min((size_t)c * 64, bytes - 4);
+        touch1(q);
+      }
+    };
+    if (RC_PREFETCH & 2) {
+      const int rows = min(RC_M, M - m0);
+      for (int oi = op_base; oi < op_base + nops; ++oi) {
+        const ChainOp& o = pp->ops[oi];
+        const size_t nb = (size_t)o.N * 4;
+        switch (o.kind) {
+          case GD4D_CHAIN_LOAD:
+            for (int r = 0; r < rows; ++r) {
+              touch(o.p0 + (size_t)(m0 + r) * o.ld0, nb);
+              if (o.p1) touch(o.p1 + (size_t)(m0 + r) * o.ld1, nb);
+            }
+            break;
+          case GD4D_CHAIN_ADD:
+            if (o.p2) for (int r = 0; r < rows; ++r) touch(o.p2 + (size_t)(m0 + r) * o.ld2, nb);
+            break;
+          case GD4D_CHAIN_GEMM: touch(o.p1, nb); break;
+          case GD4D_CHAIN_HEADGEMM: touch(o.p1, nb); touch(o.p3 + (size_t)m0 * o.ld0, (size_t)rows * o.ld0 * 4); break;
+          case GD4D_CHAIN_LAYERNORM: touch(o.p0, nb); touch(o.p1, nb); break;
+          case GD4D_CHAIN_SMALL_LINEAR: touch(o.p0, nb * o.K); touch(o.p1, nb); break;
+          case GD4D_CHAIN_REFINE: touch(o.p0 + (size_t)m0 * 3, (size_t)rows * 12); break;
+          default: break;
+        }
+      }
+    }
+    for (int oi = op_base; (RC_PREFETCH & 1) && oi < op_base + nops; ++oi) {
       if (pp->ops[oi].kind == GD4D_CHAIN_HEADGEMM) {           // this workgroup's own aggregate rows (written by another XCD: cold)
         const int rows = min(RC_M, M - m0);
         const char* a = reinterpret_cast<const char*>(pp->ops[oi].p2 + (size_t)m0 * pp->ops[oi].ld0 * pp->ops[oi].K);
         const unsigned pieces = (unsigned)rows * (unsigned)pp->ops[oi].ld0 * (unsigned)pp->ops[oi].K / 16u;
         for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) {
           const char* q = a + (size_t)c * 64;
-          asm volatile("global_load_dword %0, %1, off" : "+v"(rc_sink) : "v"(q) : "memory");
+          touch1(q);
         }
       }
       if (pp->ops[oi].kind != GD4D_CHAIN_GEMM && pp->ops[oi].kind != GD4D_CHAIN_HEADGEMM) continue;
@@ -411,7 +456,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
       const unsigned lo = (unsigned)((unsigned long long)chunks * mine / share), hi = (unsigned)((unsigned long long)chunks * (mine + 1) / share);
       for (unsigned c = lo + tid; c < hi; c += 64 * RC_WAVES) {
         const char* a = img + (size_t)c * 64;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(rc_sink) : "v"(a) : "memory");
+        touch1(a);
       }
     }
   }
@@ -467,9 +512,6 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
     trace_mark(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32));
 #endif
   }
-#if RC_PREFETCH
-  asm volatile("s_waitcnt vmcnt(0)" :: "v"(rc_sink) : "memory");     // (long since returned) keeps the sink register reserved
-#endif
   trace_mark(g_trace_rowchain, 0x81ull | ((unsigned long long)nops << 8));
 }
 
@@ -549,7 +591,7 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   if (int rc = rc_validate(a, na)) return rc;
   if (nb > 0)
     if (int rc = rc_validate(b, nb)) return rc;
-  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD;
+  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES;      // row buffers + the prefetch dump area
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
   const int blocks = (M + RC_M - 1) / RC_M;
   ChainProgram prog{};
