@@ -61,6 +61,9 @@ def parse():
                          'post-accumulate hook while the backward of the layers below is still running')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='dev: skip the kernel-level roofline section (roofline = null)')
+    ap.add_argument('--no-stress', action='store_true',
+                    help='skip the all-visible stress launches of the gather kernels (SURVEY 8d): a rocprofv3 --stats run then '
+                         'averages only launches on the real workload')
     ap.add_argument('--cpu-threads', type=int, default=None, help='torch threads of the CPU baseline (default: min(cores, 16), the fastest measured)')
     ap.add_argument('--cpu-layers', type=int, default=None,
                     help='decoder layers of the CPU-baseline sample (default: bounded automatically)')
@@ -680,7 +683,8 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                         us_per_launch=e['us_per_launch'], launches_per_step=e['launches'])
         kernels['cross_attn_fwd_per_layer'] = e['per_layer']
         try:
-            kernels['cross_attn_fwd_all_visible'] = early_all_visible(early_cap)
+            if not a.no_stress:
+                kernels['cross_attn_fwd_all_visible'] = early_all_visible(early_cap)
         except Exception as ex:                               # secondary figure: report, never fail the bench line
             kernels['cross_attn_fwd_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
     else:
@@ -744,25 +748,26 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
             except Exception as ex:
                 kernels['pyramid_channels_last'] = {'error': f'{type(ex).__name__}: {ex}'}
             # all-visible stress case of this kernel (8 x the bytes of the projected-value form per corner: its worst case)
-            try:
-                c0 = late_cap[0]
-                ref_av, l2i_av, order_av = _all_visible_inputs(c0, ops)
-                run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731
-                                                                c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av,
-                                                                **c['vp'], **kw)
-                mask_av = run_av(c0, want_mask=True)[-1]
-                nl_ = len(c0['shapes'])
-                v_av = int(mask_av.sum().item()) * nl_
-                es_ = c0['cl'].element_size()
-                alg_av = min(v_av * 4 * 256 * es_, c0['cl'].numel() * es_) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
-                ms_av = _time_rounds([(lambda c: (lambda: run_av(c)))(c) for c in late_cap], 3)
-                us_av = ms_av / len(late_cap) * 1e3
-                kernels['cross_attn_agg_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
-                                                             corner_bytes=v_av * 4 * 256 * es_, us_per_launch=us_av,
-                                                             gbs=alg_av / us_av / 1e3, frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS,
-                                                             l2_level_gbs=v_av * 4 * 256 * es_ / us_av / 1e3)
-            except Exception as ex:
-                kernels['cross_attn_agg_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
+            if not a.no_stress:
+                try:
+                    c0 = late_cap[0]
+                    ref_av, l2i_av, order_av = _all_visible_inputs(c0, ops)
+                    run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731
+                                                                    c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av,
+                                                                    **c['vp'], **kw)
+                    mask_av = run_av(c0, want_mask=True)[-1]
+                    nl_ = len(c0['shapes'])
+                    v_av = int(mask_av.sum().item()) * nl_
+                    es_ = c0['cl'].element_size()
+                    alg_av = min(v_av * 4 * 256 * es_, c0['cl'].numel() * es_) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
+                    ms_av = _time_rounds([(lambda c: (lambda: run_av(c)))(c) for c in late_cap], 3)
+                    us_av = ms_av / len(late_cap) * 1e3
+                    kernels['cross_attn_agg_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
+                                                                 corner_bytes=v_av * 4 * 256 * es_, us_per_launch=us_av,
+                                                                 gbs=alg_av / us_av / 1e3, frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS,
+                                                                 l2_level_gbs=v_av * 4 * 256 * es_ / us_av / 1e3)
+                except Exception as ex:
+                    kernels['cross_attn_agg_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
             # the projected-value form on the same query-side inputs (not part of the step): value_proj for every layer,
             # then gd4d_cross_attn_fwd - SURVEY 8(d)'s own formula
             try:
@@ -778,7 +783,8 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                 kernels['cross_attn_fwd_projected_values'] = dict(
                     note='gd4d_cross_attn_fwd on projected values (GD4D_PROJECT=early), same query-side inputs; not in the step',
                     alg_bytes_per_launch=e['alg_bytes_per_launch'], us_per_launch=e['us_per_launch'], gbs=e['gbs'], frac=e['frac'])
-                kernels['cross_attn_fwd_projected_values_all_visible'] = early_all_visible(caps)
+                if not a.no_stress:
+                    kernels['cross_attn_fwd_projected_values_all_visible'] = early_all_visible(caps)
                 del proj, caps
             except Exception as ex:
                 kernels['cross_attn_fwd_projected_values'] = {'error': f'{type(ex).__name__}: {ex}'}

@@ -11,9 +11,17 @@ mkdir -p gpurun_out/$tag
 python3 bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 tail -c 400 gpurun_out/$tag/bench.json
 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/stats -o bench -- python3 bench.py > gpurun_out/$tag/bench_profiled.json 2> gpurun_out/$tag/bench_profiled.err
-t=$(find gpurun_out/$tag/stats -name '*kernel_trace.csv' | head -1)
-python3 tools/step_timeline.py $t > gpurun_out/$tag/step_timeline.txt 2>&1
 find gpurun_out/$tag/stats -name '*kernel_trace.csv' -delete
+# one sample in flight, no all-visible stress launches: the run whose average duration of the aggregate kernel is the
+# figure `roofline` is priced on (in the default run two samples' launches overlap and the stress launches share the name)
+rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/stats1 -o bench -- python3 bench.py --inflight 1 --no-stress > gpurun_out/$tag/bench_inflight1.json 2> gpurun_out/$tag/bench_inflight1.err
+find gpurun_out/$tag/stats1 -name '*kernel_trace.csv' -delete
+# timeline of one step with ONE sample in flight (the default bench interleaves two), profiled and from the device's own clock
+rocprofv3 --kernel-trace -f csv -d gpurun_out/$tag/tl -o bench -- python3 bench.py --inflight 1 --no-roofline --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/$tag/bench_tl.json 2> gpurun_out/$tag/bench_tl.err
+t=$(find gpurun_out/$tag/tl -name '*kernel_trace.csv' | head -1)
+python3 tools/step_timeline.py $t > gpurun_out/$tag/step_timeline.txt 2>&1
+find gpurun_out/$tag/tl -name '*kernel_trace.csv' -delete
+python3 tools/trace_step.py > gpurun_out/$tag/step_timeline_device.txt 2>&1
 for which in agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
   name=${which%%:*}; cmd=$(echo ${which#*:} | tr ':' ' ')
   mkdir -p gpurun_out/$tag/pmc_$name
