@@ -42,7 +42,7 @@ __device__ __forceinline__ float rc_act_in(float v, int flags) { return (flags &
 #define RC_ROTATE 1   // per-workgroup starting k-step of the GEMMs (0: every workgroup walks K from 0 - dev A/B)
 #endif
 #ifndef RC_PREFETCH
-#define RC_PREFETCH 1   // bit 0: touch the program's weight images at the start of the launch; bit 1 (dev, off): also its small operands
+#define RC_PREFETCH 1   // bit 0: touch the program's weight images; bit 1: also its small operands; bit 2: images after the leading LOADs
 #endif
 #ifndef RC_TRACE_OPS
 #define RC_TRACE_OPS 0   // dev: stamp every operation's end in the device timeline (tools/trace_step.py)
@@ -394,74 +394,77 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   typedef const __attribute__((address_space(1))) void rc_glb_void_t;
   rc_lds_void_t* rc_dump = (rc_lds_void_t*)(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * wave);
   auto touch1 = [&](const char* q) { __builtin_amdgcn_global_load_lds((rc_glb_void_t*)q, rc_dump, 4, 0, 0); };
-  {
-    // the workgroups of THIS program that sit on this XCD: indices first, first + 8, ... below wg_hi
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned first = (unsigned)wg_lo + ((xcd - (unsigned)wg_lo) & 7u);
-    const unsigned mine = (blockIdx.x - first) >> 3, share = ((unsigned)wg_hi - 1u - first) / 8u + 1u;
-    // First the SMALL operands of every operation - this workgroup's rows of the global tensors the LOAD / ADD / REFINE
-    // operations read, bias vectors, LayerNorm parameters, SMALL_LINEAR weights: a few KB, all cold (activations were
-    // written by a kernel on another XCD, parameters were evicted by the gather).  Untouched, each operation starts with a
-    // fabric round trip of its own (~2.5 us, one after the other along the chain: 31 of chain B's 50 us were left with
-    // neither MFMAs nor weight loads); touched here, they overlap each other and the first operation.
-    // MEASURED (RC_PREFETCH=3 against 1, 200 steps each, twice): 1.870 / 1.889 ms per step against 1.852 / 1.854 - chain
-    // B's own time drops by 4 us (block 0's timeline) but every chain's first operation waits for these touches as well
-    // (vmcnt retires in order), and the launches with few GEMMs lose more than chain B gains.  Off by default.
-    auto touch = [&](const void* base, size_t bytes) {
-      if (!base || bytes < 4) return;
-      const char* b = reinterpret_cast<const char*>(base);
-      const unsigned pieces = (unsigned)((bytes + 63) / 64) + 1u;     // + 1: a range that is not 64-byte aligned
-      for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) {
-        const char* q = b + min((size_t)c * 64, bytes - 4);
-        touch1(q);
-      }
-    };
-    if (RC_PREFETCH & 2) {
-      const int rows = min(RC_M, M - m0);
-      for (int oi = op_base; oi < op_base + nops; ++oi) {
-        const ChainOp& o = pp->ops[oi];
-        const size_t nb = (size_t)o.N * 4;
-        switch (o.kind) {
-          case GD4D_CHAIN_LOAD:
-            for (int r = 0; r < rows; ++r) {
-              touch(o.p0 + (size_t)(m0 + r) * o.ld0, nb);
-              if (o.p1) touch(o.p1 + (size_t)(m0 + r) * o.ld1, nb);
-            }
-            break;
-          case GD4D_CHAIN_ADD:
-            if (o.p2) for (int r = 0; r < rows; ++r) touch(o.p2 + (size_t)(m0 + r) * o.ld2, nb);
-            break;
-          case GD4D_CHAIN_GEMM: touch(o.p1, nb); break;
-          case GD4D_CHAIN_HEADGEMM: touch(o.p1, nb); touch(o.p3 + (size_t)m0 * o.ld0, (size_t)rows * o.ld0 * 4); break;
-          case GD4D_CHAIN_LAYERNORM: touch(o.p0, nb); touch(o.p1, nb); break;
-          case GD4D_CHAIN_SMALL_LINEAR: touch(o.p0, nb * o.K); touch(o.p1, nb); break;
-          case GD4D_CHAIN_REFINE: touch(o.p0 + (size_t)m0 * 3, (size_t)rows * 12); break;
-          default: break;
-        }
+  // the workgroups of THIS program that sit on this XCD: indices first, first + 8, ... below wg_hi
+  const unsigned xcd = blockIdx.x & 7u;
+  const unsigned first = (unsigned)wg_lo + ((xcd - (unsigned)wg_lo) & 7u);
+  const unsigned mine = (blockIdx.x - first) >> 3, share = ((unsigned)wg_hi - 1u - first) / 8u + 1u;
+  auto touch = [&](const void* base, size_t bytes) {
+    if (!base || bytes < 4) return;
+    const char* b = reinterpret_cast<const char*>(base);
+    const unsigned pieces = (unsigned)((bytes + 63) / 64) + 1u;     // + 1: a range that is not 64-byte aligned
+    for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) touch1(b + min((size_t)c * 64, bytes - 4));
+  };
+  // (bit 1) The SMALL operands of the operations from `from` on - this workgroup's rows of the global tensors the LOAD /
+  // ADD / REFINE operations read, bias vectors, LayerNorm parameters, SMALL_LINEAR weights: a few KB, all cold (activations
+  // were written by a kernel on another XCD, parameters were evicted by the gather).  Untouched, each operation starts
+  // with a fabric round trip of its own (~2.5 us, one after the other along the chain: 31 of chain B's 50 us were left
+  // with neither MFMAs nor weight loads).
+  // MEASURED, ms per step over 200 steps, twice: RC_PREFETCH=1 (default) 1.864 / 1.862; =5 (images after the leading
+  // LOADs) 1.863 / 1.869; =7 (+ small operands) 1.880 / 1.874; =3 1.886 / 1.886.  Walking the program for the small
+  // touches (scalar loads of every operation's fields, a loop per operand) costs every launch more than the warm
+  // parameters save chain B (-4 us in block 0's timeline): bits 1 and 2 stay off.
+  auto touch_small = [&](int from) {
+    const int rows = min(RC_M, M - m0);
+    for (int oi = from; oi < op_base + nops; ++oi) {
+      const ChainOp& o = pp->ops[oi];
+      const size_t nb = (size_t)o.N * 4;
+      switch (o.kind) {
+        case GD4D_CHAIN_LOAD:
+          for (int r = 0; r < rows; ++r) {
+            touch(o.p0 + (size_t)(m0 + r) * o.ld0, nb);
+            if (o.p1) touch(o.p1 + (size_t)(m0 + r) * o.ld1, nb);
+          }
+          break;
+        case GD4D_CHAIN_ADD:
+          if (o.p2) for (int r = 0; r < rows; ++r) touch(o.p2 + (size_t)(m0 + r) * o.ld2, nb);
+          break;
+        case GD4D_CHAIN_GEMM: touch(o.p1, nb); break;
+        case GD4D_CHAIN_HEADGEMM: touch(o.p1, nb); touch(o.p3 + (size_t)m0 * o.ld0, (size_t)rows * o.ld0 * 4); break;
+        case GD4D_CHAIN_LAYERNORM: touch(o.p0, nb); touch(o.p1, nb); break;
+        case GD4D_CHAIN_SMALL_LINEAR: touch(o.p0, nb * o.K); touch(o.p1, nb); break;
+        case GD4D_CHAIN_REFINE: touch(o.p0 + (size_t)m0 * 3, (size_t)rows * 12); break;
+        default: break;
       }
     }
-    for (int oi = op_base; (RC_PREFETCH & 1) && oi < op_base + nops; ++oi) {
+  };
+  // (bit 0) the weight images of the program's GEMMs, this workgroup's share of each
+  auto touch_images = [&]() {
+    for (int oi = op_base; oi < op_base + nops; ++oi) {
       if (pp->ops[oi].kind == GD4D_CHAIN_HEADGEMM) {           // this workgroup's own aggregate rows (written by another XCD: cold)
         const int rows = min(RC_M, M - m0);
         const char* a = reinterpret_cast<const char*>(pp->ops[oi].p2 + (size_t)m0 * pp->ops[oi].ld0 * pp->ops[oi].K);
         const unsigned pieces = (unsigned)rows * (unsigned)pp->ops[oi].ld0 * (unsigned)pp->ops[oi].K / 16u;
-        for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) {
-          const char* q = a + (size_t)c * 64;
-          touch1(q);
-        }
+        for (unsigned c = tid; c < pieces; c += 64 * RC_WAVES) touch1(a + (size_t)c * 64);
       }
       if (pp->ops[oi].kind != GD4D_CHAIN_GEMM && pp->ops[oi].kind != GD4D_CHAIN_HEADGEMM) continue;
       const char* img = reinterpret_cast<const char*>(pp->ops[oi].p0);
       const unsigned chunks = (unsigned)((pp->ops[oi].N + 15) / 16) * (unsigned)(pp->ops[oi].K / 32) * 32u;   // 64-byte pieces
       const unsigned lo = (unsigned)((unsigned long long)chunks * mine / share), hi = (unsigned)((unsigned long long)chunks * (mine + 1) / share);
-      for (unsigned c = lo + tid; c < hi; c += 64 * RC_WAVES) {
-        const char* a = img + (size_t)c * 64;
-        touch1(a);
-      }
+      for (unsigned c = lo + tid; c < hi; c += 64 * RC_WAVES) touch1(img + (size_t)c * 64);
     }
-  }
+  };
+  // (bit 2) The image touches go out AFTER the program's leading LOAD operations: vmcnt retires in order, so a LOAD
+  // issued behind ~370 KB of touches per workgroup sees its rows only when all of those have arrived.
+  int lead = 0;
+  if (RC_PREFETCH & 4)
+    while (lead < nops && pp->ops[op_base + lead].kind == GD4D_CHAIN_LOAD) ++lead;
+  if (RC_PREFETCH & 2) touch_small(op_base + lead);
+  if ((RC_PREFETCH & 1) && lead == 0) touch_images();
 #endif
   for (int oi = op_base; oi < op_base + nops; ++oi) {
+#if RC_PREFETCH
+    if ((RC_PREFETCH & 1) && lead > 0 && oi == op_base + lead) touch_images();
+#endif
     const ChainOp op = pp->ops[oi];                        // uniform: scalar loads
     switch (op.kind) {
       case GD4D_CHAIN_LOAD: {                              // dst[:, :N] = f(p0[m, :N]) (+ p1[m, :N])
