@@ -27,14 +27,16 @@ class CrossAttnFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, ref, offsets, attn_logits, cam_logits, lidar2img, shapes, pc_range, img_h, img_w, cl=None,
-                vp_weight=None, vp_bias=None):
+                vp_weight=None, vp_bias=None, raw_cam=False):
+        """raw_cam: the camera weights are the raw logits, no sigmoid (Deform3DCrossAttnMP's neighbour pass)."""
         value, ref, offsets = value.contiguous(), ref.contiguous(), offsets.contiguous()
         attn_logits, cam_logits = attn_logits.contiguous(), cam_logits.contiguous()
         from . import functional as Fn
         order = Fn.query_order(ref, pc_range)                   # locality order: forward reads and backward atomics
         out = ops.cross_attn_fwd(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                                 img_h, img_w, query_order=order)
+                                 img_h, img_w, query_order=order, raw_cam_weights=raw_cam)
         ctx.order = order
+        ctx.raw_cam = bool(raw_cam)
         ctx.save_for_backward(value, ref, offsets, attn_logits, cam_logits, lidar2img)
         ctx.meta = (shapes, pc_range, img_h, img_w)
         ctx.cl = cl                                              # (no gradient, not an autograd tensor of this node)
@@ -49,18 +51,19 @@ class CrossAttnFunction(torch.autograd.Function):
             raise NotImplementedError('training needs the fp32 value tensor (value_dtype="fp32")')
         grad_out = grad_out.contiguous()
         gv, gr, go, ga, gc = ops.cross_attn_bwd(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img,
-                                                pc_range, img_h, img_w, grad_out, query_order=ctx.order)
+                                                pc_range, img_h, img_w, grad_out, query_order=ctx.order,
+                                                raw_cam_weights=ctx.raw_cam)
         gw = gb = None
         if ctx.cl is not None and (ctx.needs_input_grad[11] or ctx.needs_input_grad[12]):
             hh = value.shape[2]
             b, q, c = grad_out.shape
             agg, wsum = ops.cross_attn_agg_fwd(ctx.cl, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                                               img_h, img_w, hh, query_order=ctx.order)
+                                               img_h, img_w, hh, query_order=ctx.order, raw_cam_weights=ctx.raw_cam)
             g = grad_out.view(b * q, hh, c // hh)
             gw = torch.einsum('qhd,qhc->hdc', g, agg.view(b * q, hh, c)).reshape(c, c)
             if ctx.has_bias:
                 gb = (g * wsum.view(b * q, hh, 1)).sum(0).reshape(c)
-        return gv, gr, go, ga.view_as(attn_logits), gc, None, None, None, None, None, None, gw, gb
+        return gv, gr, go, ga.view_as(attn_logits), gc, None, None, None, None, None, None, gw, gb, None
 
 
 class ValueProjFunction(torch.autograd.Function):

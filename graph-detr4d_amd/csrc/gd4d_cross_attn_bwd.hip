@@ -41,6 +41,7 @@ struct CrossAttnBwdParams {
   const int32_t* order;       // optional locality order of the queries (gd4d_query_order_fwd), as in the forward
   float* ga_part;             // B > 1: (B_geometry, B_class, Q, Hh, L*P) partial dL/d a (before the softmax backward)
   int B, N, Q, L, S;
+  int raw_cam;                // GD4D_CA_RAW_CAM_WEIGHTS: the camera weights are the raw logits (no sigmoid), as in the forward
   int lvl_h[GD4D_MAX_LEVELS];
   int lvl_w[GD4D_MAX_LEVELS];
   int lvl_start[GD4D_MAX_LEVELS];
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
       continue;
     }
     const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];
-    const float cw = 1.0f / (1.0f + expf(-cl));
+    const float cw = p.raw_cam ? cl : 1.0f / (1.0f + expf(-cl));
     const int bb = BMULTI ? row % p.B : 0;           // logit class of this value row (:277)
     if (BMULTI) {
       softmax_of(bb);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
     float cs = (sub == 0) ? cam_acc : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
-    if (lane == 0) p.grad_cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q] = cw * (1.f - cw) * cs;
+    if (lane == 0) p.grad_cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q] = (p.raw_cam ? 1.f : cw * (1.f - cw)) * cs;
   }
 
   // ---- combine the waves' partial sums (fixed order), softmax backward, write ----
@@ -382,7 +383,7 @@ extern "C" int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, c
                                    const float* grad_out, void* grad_value, float* grad_ref,
                                    float* grad_offsets, float* grad_attn_logits, float* grad_cam_logits,
                                    int B, int N, int Q, int Hh, int Dh, int L, int P, int value_dtype,
-                                   int value_layout, const int32_t* query_order, void* workspace,
+                                   int value_layout, int flags, const int32_t* query_order, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   using namespace gd4d;
   if (!value || !level_hw || !ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range ||
@@ -401,6 +402,7 @@ extern "C" int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, c
   p.grad_attn_logits = grad_attn_logits; p.grad_cam_logits = grad_cam_logits; p.order = query_order;
   p.ga_part = static_cast<float*>(workspace);
   p.B = B; p.N = N; p.Q = Q; p.L = L;
+  p.raw_cam = (flags & GD4D_CA_RAW_CAM_WEIGHTS) ? 1 : 0;
   int start = 0;
   for (int l = 0; l < L; ++l) {
     const int h = level_hw[2 * l], w = level_hw[2 * l + 1];

@@ -13,7 +13,10 @@ of Deform3DCrossAttn's).  Differences of the reference that are reproduced:
     weights of sample 0 are used for the whole batch (:435-438).
 
 Both passes run on the fused HIP kernel: the neighbour pass as 8Q pseudo-queries with zero offsets in the kernel's
-one-point-per-level form (P = 1) and GD4D_CA_RAW_CAM_WEIGHTS.  Inference only.
+one-point-per-level form (P = 1) and GD4D_CA_RAW_CAM_WEIGHTS.  With autograd on, both passes go through
+autograd.CrossAttnFunction (gd4d_cross_attn_fwd / _bwd); the backward kernel has the four-point form only, so the
+neighbour pass is presented to it as four points per level of which three carry a logit of -1e30 (softmax weight and
+gradient exactly zero).
 """
 import torch
 import torch.nn as nn
@@ -48,7 +51,7 @@ class Deform3DCrossAttnMP(Deform3DCrossAttn):
         img_metas = kwargs['img_metas']
         Fn.require_gpu(query, 'query')
         if Fn.wants_grad(self, query, reference_points, *value):
-            raise NotImplementedError('Deform3DCrossAttnMP has no backward here: call it under torch.no_grad()')
+            return self._forward_autograd(query, value, reference_points, img_metas)
         q, b, c = query.shape
         hh, npt, nl, n = self.num_heads, self.num_points, self.num_levels, self.num_cams
         if len(value) != nl or value[0].shape[1] != n:
@@ -89,3 +92,43 @@ class Deform3DCrossAttnMP(Deform3DCrossAttn):
                              r1=query.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg.contiguous(), self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
         return self.dropout(out) + query + pos_feat.permute(1, 0, 2)
+
+    def _forward_autograd(self, query, value, reference_points, img_metas):
+        """Training path: the same maths with autograd (the gathers on gd4d_cross_attn_fwd / _bwd, value_proj on the HIP
+        forward with its GEMM backward, dense layers and the blend as differentiable ops)."""
+        from .autograd import CrossAttnFunction, ValueProjFunction
+        q, b, c = query.shape
+        hh, npt, nl, n = self.num_heads, self.num_points, self.num_levels, self.num_cams
+        if len(value) != nl or value[0].shape[1] != n:
+            raise ValueError(f'expected {nl} levels x {n} cameras')
+        want = 9 * q if self.multi_points else q
+        if reference_points.shape[1] != want:
+            raise ValueError(f'reference_points must hold {want} points ({q} queries), got {reference_points.shape[1]}')
+        if self.value_dtype != torch.float32:
+            raise NotImplementedError('training needs value_dtype="fp32"')
+        x = query.permute(1, 0, 2).contiguous()                               # (B, Q, C); no query_pos (:211-222)
+        cam_logits = Fn.sequential_autograd(self.cam_attention_weights, x)
+        offsets = Fn.sequential_autograd(self.deform_sampling_offsets, x).view(b, q, hh, npt, 3)
+        attn_logits = Fn.sequential_autograd(self.attention_weights, x).view(b, q, hh, nl, npt)
+        shapes = [tuple(v.shape[-2:]) for v in value]
+        val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)
+        val = val.view(val.shape[0], -1, hh, c // hh)
+        lidar2img = Fn.lidar2img_device(img_metas, query)
+        img_h, img_w = Fn.img_hw(img_metas)
+        centre = reference_points[:, :q].contiguous()
+        agg = CrossAttnFunction.apply(val, centre, offsets, attn_logits, cam_logits, lidar2img, shapes, self.pc_range,
+                                      img_h, img_w)
+        if self.multi_points:
+            nbr = reference_points[:, q:].contiguous()
+            logits_n = Fn.sequential_autograd(self.attention_weights_neighbor, x).reshape(b, 8 * q, hh, nl, 1)
+            logits_n = torch.nn.functional.pad(logits_n, (0, npt - 1), value=-1e30)     # three points of zero weight
+            zero_off = torch.zeros(b, 8 * q, hh, npt, 3, device=query.device)
+            agg_n = CrossAttnFunction.apply(val, nbr, zero_off, logits_n, cam_logits.repeat(1, 8, 1), lidar2img, shapes,
+                                            self.pc_range, img_h, img_w, None, None, None, True)
+            agg_n = agg_n.view(b, 8, q, c).sum(1)
+            blend = Fn.sequential_autograd(self.output_weight, torch.cat([agg, agg_n], -1))
+            wts = blend.sum(1).softmax(-1)                                       # (B, 2); sample 0's are used (:438)
+            agg = agg * wts[0][0] + agg_n * wts[0][1]
+        pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(centre)).permute(1, 0, 2)
+        out = Fn.sequential_autograd(self.output_proj, agg).permute(1, 0, 2)
+        return self.dropout(out) + query + pos_feat

@@ -679,7 +679,7 @@ def refine_reference_order_fwd(tmp, ref, pc_range):
 
 
 def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
-                   grad_out, query_order=None):
+                   grad_out, query_order=None, raw_cam_weights=False):
     """gd4d_cross_attn_bwd.  Returns (grad_value, grad_ref, grad_offsets, grad_attn_logits, grad_cam_logits)."""
     lib = _lib.load()
     f32 = torch.float32
@@ -702,7 +702,7 @@ def cross_attn_bwd(value, level_hw, ref, offsets, attn_logits, cam_logits, lidar
         _dev(attn_logits, 'attn_logits', f32), _dev(cam_logits, 'cam_logits', f32),
         _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(grad_out, 'grad_out', f32),
         _dev(gv, 'grad_value'), _dev(gr, 'grad_ref'), _dev(go, 'grad_offsets'), _dev(ga, 'grad_attn_logits'),
-        _dev(gc, 'grad_cam_logits'), b, n, q, hh, dh, nl, p, _lib.F32, _lib.PIXEL_MAJOR,
+        _dev(gc, 'grad_cam_logits'), b, n, q, hh, dh, nl, p, _lib.F32, _lib.PIXEL_MAJOR, 1 if raw_cam_weights else 0,
         None if query_order is None else _order_ptr(query_order, b * q),
         None if ws is None else _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), _stream())
     _lib.check(code, 'gd4d_cross_attn_bwd')

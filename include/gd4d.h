@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 25
+#define GD4D_ABI_VERSION 26
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -551,6 +551,7 @@ int gd4d_edge_conv_max_fwd(const float* a, const float* b_self, const int32_t* i
  *                     i = b*N + n with the logits of batch (i % B) (:277), so grad_attn_logits[bb] collects contributions of
  *                     every sample b: each (b, q) workgroup writes its partial per logit class, a second launch adds them
  *                     over b in a fixed order and applies the softmax backward.  NULL / 0 for B == 1.
+ *   flags             GD4D_CA_RAW_CAM_WEIGHTS as in the forward (Deform3DCrossAttnMP's neighbour pass).
  * Supported: B <= 8, fp32 pixel-major value, L <= 4.
  * Accumulation order of grad_value is not deterministic (fp32 atomics), like the mmcv kernel.
  * query_order: optional, as in gd4d_cross_attn_fwd (scheduling only: the atomic adds into grad_value of queries that
@@ -561,7 +562,7 @@ int gd4d_cross_attn_bwd(const void* value, const int32_t* level_hw, const float*
                         const double* pc_range, float img_h, float img_w, const float* grad_out,
                         void* grad_value, float* grad_ref, float* grad_offsets, float* grad_attn_logits,
                         float* grad_cam_logits, int B, int N, int Q, int Hh, int Dh, int L, int P,
-                        int value_dtype, int value_layout, const int32_t* query_order, void* workspace,
+                        int value_dtype, int value_layout, int flags, const int32_t* query_order, void* workspace,
                         size_t workspace_bytes, void* stream);
 size_t gd4d_cross_attn_bwd_workspace_bytes(int B, int Q, int Hh, int L, int P);
 

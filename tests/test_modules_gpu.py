@@ -219,9 +219,11 @@ def test_deform3d_cross_attn_mp_module(name):
     with pytest.raises(ValueError), torch.no_grad():
         mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
             reference_points=g.t('reference_points')[:, :m['num_query']].to(DEV), img_metas=_metas(g))
-    with pytest.raises(NotImplementedError):                 # parameters require grad outside no_grad: no backward
-        mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
-            reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+    # with autograd on, the training path (both passes through the backward-capable four-point form) gives the same output
+    out_t = mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()],
+                reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
+    assert out_t.requires_grad
+    torch.testing.assert_close(out_t.detach().cpu(), g.t('out'), **TOL)
 
 
 @pytest.mark.parametrize('name', ['dgcnn', 'dgcnn_k8'])

@@ -224,3 +224,42 @@ def test_detr3d_cross_atten_trains():
     for k, prm in mod.named_parameters():
         assert prm.grad is not None, k
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
+
+
+@pytest.mark.parametrize('name', ['deform_mp_n6', 'deform_mp_n12_b2'])
+def test_deform3d_cross_attn_mp_trains(name):
+    """Deform3DCrossAttnMP with autograd on (config detr4d_res50_deform_pe_mp...: the multi-point variant): gradients of the
+    query, the reference points (centres and neighbours), the feature maps and every parameter that takes part against
+    autograd of the oracle (deform3d_cross_attn_multi_point.py:196-453)."""
+    from oracle import torch_oracle as O
+    g = Golden(name)
+    m = g.meta
+    mod = G.build_attention(dict(type='Deform3DCrossAttnMP', num_cams=m['num_cams'], pc_range=m['pc_range'],
+                                 num_points=4, embed_dims=256))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    gout = torch.randn(g.t('out').shape, generator=torch.Generator().manual_seed(3))
+    p_cpu = {k: v.clone().requires_grad_(True) for k, v in g.state().items()}
+    q_cpu = g.t('query').clone().requires_grad_(True)
+    ref_cpu = g.t('reference_points').clone().requires_grad_(True)
+    feats_cpu = [f.clone().requires_grad_(True) for f in g.feats()]
+    out_ref = O.deform3d_cross_attn_mp(p_cpu, q_cpu, feats_cpu, ref_cpu, g.img_metas(), m['pc_range'])
+    out_ref = out_ref[0] if isinstance(out_ref, tuple) else out_ref
+    torch.testing.assert_close(out_ref.detach(), g.t('out'), rtol=2e-4, atol=2e-4)
+    (out_ref * gout).sum().backward()
+    q = g.t('query').to(DEV).requires_grad_(True)
+    ref = g.t('reference_points').to(DEV).requires_grad_(True)
+    feats = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    out = mod(q, None, feats, reference_points=ref, img_metas=g.img_metas())
+    torch.testing.assert_close(out.detach().cpu(), out_ref.detach(), rtol=2e-4, atol=2e-4)
+    (out * gout.to(DEV)).sum().backward()
+    assert _rel(q.grad.cpu(), q_cpu.grad) < 2e-3
+    assert _rel(ref.grad.cpu(), ref_cpu.grad) < 5e-3
+    for a, b in zip(feats, feats_cpu):
+        assert _rel(a.grad.cpu(), b.grad) < 2e-3
+    for k, prm in mod.named_parameters():
+        if p_cpu[k].grad is None:                               # deform_sampling_offsets_neighbor: unused by the reference
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+            continue
+        assert prm.grad is not None, k
+        assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
