@@ -153,7 +153,8 @@ class Detr3DCrossAttenV2(nn.Module):
     (camera, head), samples of the head's channel slice of the raw NCHW maps.  Same constructor keywords and
     state-dict keys (`attention_weights`, `sampling_offsets`, `output_proj`, `position_encoder`).  The sampling core is
     gd4d_detr3d_v2_fwd (incl. the reference's level/point weight transposition); batch 1, num_points == num_levels as
-    the reference's broadcasts require (:611, :698-700).  Inference only."""
+    the reference's broadcasts require (:611, :698-700).  With autograd on: the same operations as differentiable torch
+    ops on the GPU (_forward_autograd)."""
 
     def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=5, num_cams=6, im2col_step=64,
                  pc_range=None, dropout=0.1, norm_cfg=None, init_cfg=None, batch_first=False):
@@ -195,7 +196,6 @@ class Detr3DCrossAttenV2(nn.Module):
             raise NameError('Detr3DCrossAttenV2: residual must be None (as in the reference)')
         img_metas = kwargs['img_metas']
         Fn.require_gpu(query, 'query')
-        Fn.require_inference(query, query_pos, reference_points, *value)
         q, b, c = query.shape
         if b != 1:
             raise RuntimeError('Detr3DCrossAttenV2: batch size must be 1 (the reference broadcasts (B*N, Q) against '
@@ -203,6 +203,8 @@ class Detr3DCrossAttenV2(nn.Module):
         if self.num_points != self.num_levels:
             raise RuntimeError('Detr3DCrossAttenV2: num_points must equal num_levels (the reference multiplies '
                                '(..., point, level) samples with (..., level, point) weights)')
+        if Fn.wants_grad(self, query, query_pos, reference_points, *value):
+            return self._forward_autograd(query, value, query_pos, reference_points, img_metas)
         n, hh, nl, npt = self.num_cams, self.num_heads, self.num_levels, self.num_points
         logits, offsets = ops.linear_group_fwd(
             query.contiguous(), [self.attention_weights.weight.contiguous(), self.sampling_offsets.weight.contiguous()],
@@ -219,6 +221,46 @@ class Detr3DCrossAttenV2(nn.Module):
                              r1=query.view(1, q, c), r2=pos_feat).view(q, 1, c)
         out = Fn.linear(agg, self.output_proj.weight, self.output_proj.bias).permute(1, 0, 2)
         return self.dropout(out) + query + pos_feat.permute(1, 0, 2)
+
+    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
+        """Training path: reference :597-710 as differentiable torch ops on the GPU - projection of the reference
+        points, per level F.grid_sample (bilinear, zero padding, align_corners=False) of every head's channel slice at
+        the projected point + pixel offsets, softmax over level x point, the (point, level) x (level, point) pairing of
+        :611 / :705-707, visibility mask, sums over cameras / levels / points.  gd4d_detr3d_v2_fwd has no backward."""
+        x = query if query_pos is None else query + query_pos
+        x = x.permute(1, 0, 2).contiguous()                                   # (1, Q, C)
+        b, q, c = x.shape
+        n, hh, nl, npt = self.num_cams, self.num_heads, self.num_levels, self.num_points
+        d = c // hh
+        w = Fn.sequential_autograd(self.attention_weights, x).view(b, q, n, hh, nl * npt).softmax(-1)
+        w = w.view(b, q, n, hh, nl, npt)
+        off = Fn.sequential_autograd(self.sampling_offsets, x).view(b, q, n, hh, nl, npt, 2)
+        lidar2img = Fn.lidar2img_device(img_metas, query)
+        img_h, img_w = Fn.img_hw(img_metas)
+        rng = self.pc_range
+        lo = reference_points.new_tensor(rng[:3])
+        scale = reference_points.new_tensor([rng[3] - rng[0], rng[4] - rng[1], rng[5] - rng[2]])
+        pts = reference_points * scale + lo
+        pts = torch.cat([pts, torch.ones_like(pts[..., :1])], dim=-1)
+        cam = torch.matmul(lidar2img.view(b, n, 1, 4, 4), pts.view(b, 1, q, 4, 1)).squeeze(-1)   # (1, N, Q, 4)
+        eps = 1e-5
+        z_ok = cam[..., 2] > eps
+        xy = cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.full_like(cam[..., 2:3], eps))
+        g = (torch.stack([xy[..., 0] / img_w, xy[..., 1] / img_h], dim=-1) - 0.5) * 2
+        mask = (z_ok & (g[..., 0] > -1.0) & (g[..., 0] < 1.0) & (g[..., 1] > -1.0) & (g[..., 1] < 1.0)).to(x.dtype)
+        out = x.new_zeros(q, hh, d)
+        for lvl, feat in enumerate(value):
+            h_l, w_l = feat.shape[-2:]
+            f = feat.view(b, n, hh, d, h_l, w_l).transpose(1, 2).flatten(0, 2)             # (heads * N, d, H, W)
+            o = off[:, :, :, :, lvl].permute(0, 3, 2, 1, 4, 5).flatten(0, 1)                # (heads, N, Q, P, 2)
+            loc = g.view(b * n, q, 1, 2)[None] + o / o.new_tensor([w_l, h_l])
+            s_ = torch.nn.functional.grid_sample(f, loc.flatten(0, 1), mode='bilinear', padding_mode='zeros',
+                                                 align_corners=False).view(hh, n, d, q, npt)
+            wq = w[0, :, :, :, :, lvl].permute(2, 1, 0, 3) * mask[0].view(1, n, q, 1)       # weight (level i, point lvl)
+            out = out + torch.einsum('hndqp,hnqp->qhd', s_, wq)
+        res = Fn.sequential_autograd(self.output_proj, out.reshape(q, 1, c))
+        pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(reference_points)).permute(1, 0, 2)
+        return self.dropout(res) + query + pos_feat
 
 
 @TRANSFORMER_LAYER_SEQUENCE.register_module()

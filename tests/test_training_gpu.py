@@ -263,3 +263,42 @@ def test_deform3d_cross_attn_mp_trains(name):
             continue
         assert prm.grad is not None, k
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
+
+
+@pytest.mark.parametrize('name', ['detr3d_v2_n6', 'detr3d_v2_n12'])
+def test_detr3d_cross_atten_v2_trains(name):
+    """Detr3DCrossAttenV2 with autograd on: output = the inference kernel's, gradients = autograd of the oracle
+    (detr3d_transformer.py:441-710)."""
+    from oracle import torch_oracle as O
+    g = Golden(name)
+    m = g.meta
+    mod = G.build_attention(dict(type='Detr3DCrossAttenV2', num_cams=m['num_cams'], pc_range=m['pc_range'],
+                                 num_points=m['num_points'], embed_dims=256))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    args = lambda t: dict(query_pos=t('query_pos'), reference_points=t('reference_points'))   # noqa: E731
+    with torch.no_grad():
+        want = mod(g.t('query').to(DEV), None, [f.to(DEV) for f in g.feats()], None, img_metas=g.img_metas(),
+                   **{k: v.to(DEV) for k, v in args(g.t).items()})
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+    p_cpu = {k: v.clone().requires_grad_(True) for k, v in g.state().items()}
+    q_cpu, qp_cpu = g.t('query').clone().requires_grad_(True), g.t('query_pos').clone().requires_grad_(True)
+    ref_cpu = g.t('reference_points').clone().requires_grad_(True)
+    feats_cpu = [f.clone().requires_grad_(True) for f in g.feats()]
+    out_ref = O.detr3d_cross_atten_v2(p_cpu, q_cpu, feats_cpu, qp_cpu, ref_cpu, g.img_metas(), m['pc_range'],
+                                      num_points=m['num_points'])
+    (out_ref * gout).sum().backward()
+    q, qp = g.t('query').to(DEV).requires_grad_(True), g.t('query_pos').to(DEV).requires_grad_(True)
+    ref = g.t('reference_points').to(DEV).requires_grad_(True)
+    feats = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    out = mod(q, None, feats, None, query_pos=qp, reference_points=ref, img_metas=g.img_metas())
+    torch.testing.assert_close(out.detach(), want, rtol=2e-4, atol=2e-4)
+    (out * gout.to(DEV)).sum().backward()
+    assert _rel(q.grad.cpu(), q_cpu.grad) < 2e-3
+    assert _rel(qp.grad.cpu(), qp_cpu.grad) < 2e-3
+    assert _rel(ref.grad.cpu(), ref_cpu.grad) < 5e-3
+    for a, b in zip(feats, feats_cpu):
+        assert _rel(a.grad.cpu(), b.grad) < 2e-3
+    for k, prm in mod.named_parameters():
+        assert prm.grad is not None, k
+        assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
