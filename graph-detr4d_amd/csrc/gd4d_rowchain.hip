@@ -27,11 +27,27 @@ typedef __attribute__((ext_vector_type(4))) float rc4;
 GD4D_TRACE_UNIT(rowchain)
 
 constexpr int RC_M = 16;            // rows per workgroup
-constexpr int RC_WAVES = 4;
+// Waves per workgroup x 16-column tiles per wave and pass: 8 x 2 (two waves per SIMD, 163 registers) against the first
+// version's 4 x 4 (one wave per SIMD, 276 registers): the same bytes in flight per compute unit, but twice the waves to
+// issue the fragment loads and to hide each other's MFMA chains - 1.79 against 1.87 ms per step, results bit-identical
+// (a column's sum does not depend on which wave owns it).  -DRC_WAVES_N=4 -DRC_TILES_N=4 rebuilds the first form.
+#ifndef RC_WAVES_N
+#define RC_WAVES_N 8
+#endif
+#ifndef RC_TILES_N
+#define RC_TILES_N 2
+#endif
+constexpr int RC_WAVES = RC_WAVES_N;
 constexpr int RC_LD = 516;          // floats per LDS row (512 + 4: the float4 row reads of 16 rows spread over the banks)
 constexpr int RC_BUFS = 4;
-constexpr int RC_DEPTH = 4;         // weight-fragment ring depth (k-steps of 32)
-constexpr int RC_TILES = 4;         // 16-column MFMA tiles per wave and pass (64 columns)
+#ifndef RC_DEPTH_N
+#define RC_DEPTH_N 2
+#endif
+constexpr int RC_DEPTH = RC_DEPTH_N; // weight-fragment ring depth in k-steps of 32 (8 waves: 1, 2 equal, 4 +0.8 %, 8 +2 % per step)
+constexpr int RC_TILES = RC_TILES_N; // 16-column MFMA tiles per wave and pass
+constexpr int RC_COLS = 16 * RC_TILES;   // columns per wave and pass
+constexpr int RC_ROWS_PER_WAVE = RC_M / RC_WAVES;
+static_assert(RC_TILES % 2 == 0 && RC_M % RC_WAVES == 0 && RC_WAVES * RC_COLS == 256, "a pass of all waves covers 256 columns");
 
 // One operation; the program is an array of these in device memory (gd4d.h: gd4d_chain_op).
 typedef gd4d_chain_op ChainOp;
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __
 }
 
 // GEMM over the workgroup's 16 rows: out[:, n] = act(sum_k in[:, k] * W[n, k] + bias[n]) (+ residuals), n < N.
-// Wave w owns columns [256 pass + 64 w, + 64) of every pass; A fragments are split from the LDS buffer, the W fragments
+// Wave w owns columns [256 pass + RC_COLS w, + RC_COLS) of every pass; A fragments are split from the LDS buffer, the W fragments
 // come pre-split from the image (global / L2) through a register ring RC_DEPTH k-steps deep.
 __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   const int i16 = lane & 15, g = lane >> 4;
@@ -99,7 +115,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   const int K = op.K, N = op.N;
   const int steps = K / 32, tiles = (N + 15) / 16;
   const char* img = reinterpret_cast<const char*>(op.p0);
-  for (int n_base = 64 * wave; n_base < N; n_base += 64 * RC_WAVES) {
+  for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
     const char* wf[RC_TILES];                                  // tiles past the end re-read the last one (never stored)
 #pragma unroll
     for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * 2048 + lane * 16;
@@ -153,7 +169,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bl[d][c]), acc[c], 0, 0, 0);
       }
     };
-    // host guarantees steps % RC_DEPTH == 0 (K % 128 == 0)
+    // host guarantees steps % RC_DEPTH == 0 (K % (32 RC_DEPTH) == 0)
     for (int j0 = 0; j0 + RC_DEPTH < steps; j0 += RC_DEPTH) {
 #pragma unroll
       for (int d = 0; d < RC_DEPTH; ++d) {
@@ -195,13 +211,18 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
   const int steps = K / 32, tiles = (N + 15) / 16;
   const char* img = reinterpret_cast<const char*>(op.p0);
   const int m_ld = min(m0 + i16, M - 1);                       // rows past M repeat the last row (never stored)
-  for (int n_base = 64 * wave; n_base < N; n_base += 64 * RC_WAVES) {
+  for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
     const char* wf[RC_TILES];
 #pragma unroll
     for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * 2048 + lane * 16;
-    const int h0 = min(n_base / Dh, heads - 1), h1 = min((n_base + 32) / Dh, heads - 1);
-    const float* a0 = op.p2 + ((size_t)m_ld * heads + h0) * K + 8 * g;
-    const float* a1 = op.p2 + ((size_t)m_ld * heads + h1) * K + 8 * g;
+    constexpr int NG = RC_TILES / 2;                           // groups of two tiles (32 columns), each inside one head
+    int hg[NG];
+    const float* ag[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      hg[gi] = min((n_base + 32 * gi) / Dh, heads - 1);
+      ag[gi] = op.p2 + ((size_t)m_ld * heads + hg[gi]) * K + 8 * g;
+    }
     rc4 acc[RC_TILES];
 #pragma unroll
     for (int c = 0; c < RC_TILES; ++c) acc[c] = rc4{0.f, 0.f, 0.f, 0.f};
@@ -213,19 +234,22 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
       for (int c = 0; c < RC_TILES; ++c) e_bias[c] = bias_p[min(n_base + 16 * c + i16, N - 1)] * bias_on;
     }
     rc_u4 bh[HD][RC_TILES], bl[HD][RC_TILES];
-    float4 av[HD][2][2];
+    float4 av[HD][NG][2];
     auto issue = [&](int slot, int j) {
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) {
         bh[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048);
         bl[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048 + 1024);
       }
-      av[slot][0][0] = *reinterpret_cast<const float4*>(a0 + 32 * j); av[slot][0][1] = *reinterpret_cast<const float4*>(a0 + 32 * j + 4);
-      av[slot][1][0] = *reinterpret_cast<const float4*>(a1 + 32 * j); av[slot][1][1] = *reinterpret_cast<const float4*>(a1 + 32 * j + 4);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        av[slot][gi][0] = *reinterpret_cast<const float4*>(ag[gi] + 32 * j);
+        av[slot][gi][1] = *reinterpret_cast<const float4*>(ag[gi] + 32 * j + 4);
+      }
     };
     auto consume = [&](int d) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
+      for (int hh = 0; hh < NG; ++hh) {
         const float a[8] = {av[d][hh][0].x, av[d][hh][0].y, av[d][hh][0].z, av[d][hh][0].w,
                             av[d][hh][1].x, av[d][hh][1].y, av[d][hh][1].z, av[d][hh][1].w};
         rc_u4 ah, al;
@@ -253,7 +277,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
     for (int c = 0; c < RC_TILES; ++c) {
       const int n = n_base + 16 * c + i16;
       if (n >= N) continue;
-      const int hc = c < 2 ? h0 : h1;
+      const int hc = hg[c / 2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * g + r, m = m0 + row;
@@ -270,6 +294,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
 // row, a lane owns columns 64 ch + 4 l16 .. + 4 of every 64-column chunk.  gamma / beta are requested first.
 __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   constexpr int MAXCH = (RC_LD - 4) / 64;
+  if (wave >= RC_M / 4) return;                                // 4 rows per wave: with more than 4 waves the rest wait at the barrier
   const int row = 4 * wave + (lane >> 4), l16 = lane & 15, N = op.N, nch = N / 64;
   float4 gm[MAXCH], bt[MAXCH], x[MAXCH];
 #pragma unroll
@@ -313,17 +338,17 @@ __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC
 
 // Rows of global tensors into / onto an LDS buffer, float4 per lane, every load issued before the first use:
 //   LOAD: dst[:, dst_col + n] = f(p0[m, n]) (+ p1[m, n]);   ADD: dst[:, n] = src[:, n] (+ res[:, n]) (+ p2[m, n])
-// wave w handles rows 4 w .. 4 w + 3; N % 4 == 0, N <= 512 (two 256-column chunks per row).
+// wave w handles RC_ROWS_PER_WAVE consecutive rows; N % 4 == 0, N <= 512 (two 256-column chunks per row).
 template <bool IS_ADD>
 __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   const int N = op.N;
   const float* ga = IS_ADD ? op.p2 : op.p0;                  // first global operand (may be null for ADD)
   const float* gb = IS_ADD ? nullptr : op.p1;                 // second global operand (LOAD only)
   const int lda = IS_ADD ? op.ld2 : op.ld0, ldb = op.ld1;
-  float4 va[4][2], vb[4][2];
+  float4 va[RC_ROWS_PER_WAVE][2], vb[RC_ROWS_PER_WAVE][2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = min(m0 + 4 * wave + r, M - 1);              // rows past M repeat the last row (never stored)
+  for (int r = 0; r < RC_ROWS_PER_WAVE; ++r) {
+    const int m = min(m0 + RC_ROWS_PER_WAVE * wave + r, M - 1);              // rows past M repeat the last row (never stored)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int n = min(256 * cb + 4 * lane, N - 4);
@@ -332,8 +357,8 @@ __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][R
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 4 * wave + r;
+  for (int r = 0; r < RC_ROWS_PER_WAVE; ++r) {
+    const int row = RC_ROWS_PER_WAVE * wave + r;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int n = 256 * cb + 4 * lane;
