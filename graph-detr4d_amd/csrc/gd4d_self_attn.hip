@@ -32,6 +32,10 @@ struct MhaParams {
 
 constexpr int MHA_D = 32;
 constexpr int MHA_WAVES = 8;
+#ifndef MHA_PF_N
+#define MHA_PF_N 1
+#endif
+constexpr int MHA_PF = MHA_PF_N;       // tiles of keys a wave requests ahead (one chunk)
 
 GD4D_TRACE_UNIT(mha)
 
@@ -66,10 +70,11 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
 
   const int ntiles = (p.Lk + 15) / 16;
   const size_t hoff = (size_t)h * MHA_D;
-  // register prefetch: the next tile's K row (2 x float4) and V columns (8 dwords) are requested
-  // before the current tile's MFMAs, so L2 latency overlaps the matrix work.
-  float4 ka, kc;
-  float vv[8];
+  // A wave walks its tiles of keys in chunks of MHA_PF tiles whose K rows and V columns are requested together.  Measured
+  // at 900 x 900 (ms per decoder step): MHA_PF = 1 (70 registers, three workgroups per compute unit) 1.759, 2 (96) 1.760,
+  // 4 (128) 1.762, 8 (220 registers, one workgroup per unit) 1.827; one tile of look-ahead across iterations (the first
+  // version) 1.778.  q / k / v arrive cold from another XCD (~2 us per round trip), but other workgroups on the unit hide
+  // that better than a deeper request queue in this one does.
   auto fetch = [&](int kt, float4& a, float4& c, float* vdst) {
     const int kbase = kt * 16;
     const int krow = min(kbase + krho, p.Lk - 1);
@@ -84,62 +89,62 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
       vdst[2 * st + 1] = vs[16];
     }
   };
-  if (wave < ntiles) fetch(wave, ka, kc, vv);
-  for (int kt = wave; kt < ntiles; kt += MHA_WAVES) {
-    const int kbase = kt * 16;
-    float4 na = ka, nc = kc;
-    float nv[8];
+  for (int base = wave; base < ntiles; base += MHA_WAVES * MHA_PF) {
+    float4 ka[MHA_PF], kc[MHA_PF];
+    float vv[MHA_PF][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) nv[i] = vv[i];
-    if (kt + MHA_WAVES < ntiles) fetch(kt + MHA_WAVES, na, nc, nv);
-    // ---- S^T = K Q^T ----
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qf[0], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qf[1], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qf[2], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qf[3], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.x, qf[4], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.y, qf[5], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.z, qf[6], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.w, qf[7], s, 0, 0, 0);
-    // lane (qi, g) reg r  <->  key kbase + g + 4r
-    float sc[4];
+    for (int i = 0; i < MHA_PF; ++i) fetch(min(base + i * MHA_WAVES, ntiles - 1), ka[i], kc[i], vv[i]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kbase + g + 4 * r;
-      float val = s[r];
-      if (key >= p.Lk) {
-        val = NEG_INF;
-      } else if (p.mask_kind) {
-        const size_t mi = (size_t)min(q0 + qi, p.Lq - 1) * p.Lk + key;
-        if (p.mask_kind == 1) { if (static_cast<const uint8_t*>(p.mask)[mi]) val = NEG_INF; }
-        else val += static_cast<const float*>(p.mask)[mi];
+    for (int i = 0; i < MHA_PF; ++i) {
+      const int kt = base + i * MHA_WAVES;
+      if (kt >= ntiles) break;                                   // wave-uniform
+      const int kbase = kt * 16;
+      // ---- S^T = K Q^T ----
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, qf[0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].y, qf[1], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].z, qf[2], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].w, qf[3], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[i].x, qf[4], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[i].y, qf[5], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[i].z, qf[6], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[i].w, qf[7], s, 0, 0, 0);
+      // lane (qi, g) reg r  <->  key kbase + g + 4r
+      float sc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kbase + g + 4 * r;
+        float val = s[r];
+        if (key >= p.Lk) {
+          val = NEG_INF;
+        } else if (p.mask_kind) {
+          const size_t mi = (size_t)min(q0 + qi, p.Lq - 1) * p.Lk + key;
+          if (p.mask_kind == 1) { if (static_cast<const uint8_t*>(p.mask)[mi]) val = NEG_INF; }
+          else val += static_cast<const float*>(p.mask)[mi];
+        }
+        sc[r] = val;
       }
-      sc[r] = val;
+      float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax);
+      // all keys so far masked: keep everything at zero weight without creating NaN here
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float corr = expf(m - m_use);           // m = -inf -> 0
+      float pr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[r] = expf(sc[r] - m_use);
+      l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o0[r] *= corr; o1[r] *= corr; }
+      // ---- O^T += V^T P^T : A = V^T[d = lane&15 (+16)][key = kbase + g + 4s], B = P^T = pr[s] ----
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[i][2 * st], pr[st], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[i][2 * st + 1], pr[st], o1, 0, 0, 0);
+      }
     }
-    float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m, tmax);
-    // all keys so far masked: keep everything at zero weight without creating NaN here
-    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-    const float corr = expf(m - m_use);           // m = -inf -> 0
-    float pr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] = expf(sc[r] - m_use);
-    l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
-    m = m_new;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { o0[r] *= corr; o1[r] *= corr; }
-    // ---- O^T += V^T P^T : A = V^T[d = lane&15 (+16)][key = kbase + g + 4s], B = P^T = pr[s] ----
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[2 * st], pr[st], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[2 * st + 1], pr[st], o1, 0, 0, 0);
-    }
-    ka = na; kc = nc;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vv[i] = nv[i];
   }
 
   // ---- merge the key-slices ----
