@@ -30,7 +30,8 @@ constexpr int RC_M = 16;            // rows per workgroup
 // Waves per workgroup x 16-column tiles per wave and pass: 8 x 2 (two waves per SIMD, 163 registers) against the first
 // version's 4 x 4 (one wave per SIMD, 276 registers): the same bytes in flight per compute unit, but twice the waves to
 // issue the fragment loads and to hide each other's MFMA chains - 1.79 against 1.87 ms per step, results bit-identical
-// (a column's sum does not depend on which wave owns it).  -DRC_WAVES_N=4 -DRC_TILES_N=4 rebuilds the first form.
+// (a column's sum does not depend on which wave owns it).  -DRC_WAVES_N=4 -DRC_TILES_N=4 rebuilds the first form;
+// 16 x 1 (128 registers, 33 spilled) measured 1.83 ms.
 #ifndef RC_WAVES_N
 #define RC_WAVES_N 8
 #endif
@@ -47,7 +48,7 @@ constexpr int RC_DEPTH = RC_DEPTH_N; // weight-fragment ring depth in k-steps of
 constexpr int RC_TILES = RC_TILES_N; // 16-column MFMA tiles per wave and pass
 constexpr int RC_COLS = 16 * RC_TILES;   // columns per wave and pass
 constexpr int RC_ROWS_PER_WAVE = RC_M / RC_WAVES;
-static_assert(RC_TILES % 2 == 0 && RC_M % RC_WAVES == 0 && RC_WAVES * RC_COLS == 256, "a pass of all waves covers 256 columns");
+static_assert((RC_TILES == 1 || RC_TILES % 2 == 0) && RC_M % RC_WAVES == 0 && RC_WAVES * RC_COLS == 256, "a pass of all waves covers 256 columns");
 
 // One operation; the program is an array of these in device memory (gd4d.h: gd4d_chain_op).
 typedef gd4d_chain_op ChainOp;
@@ -215,12 +216,13 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
     const char* wf[RC_TILES];
 #pragma unroll
     for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * 2048 + lane * 16;
-    constexpr int NG = RC_TILES / 2;                           // groups of two tiles (32 columns), each inside one head
+    constexpr int TPG = RC_TILES >= 2 ? 2 : 1;                 // tiles per group: up to 32 columns, inside one head
+    constexpr int NG = RC_TILES / TPG;
     int hg[NG];
     const float* ag[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-      hg[gi] = min((n_base + 32 * gi) / Dh, heads - 1);
+      hg[gi] = min((n_base + 16 * TPG * gi) / Dh, heads - 1);
       ag[gi] = op.p2 + ((size_t)m_ld * heads + hg[gi]) * K + 8 * g;
     }
     rc4 acc[RC_TILES];
@@ -255,7 +257,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
         rc_u4 ah, al;
         rc_split8(a, ah, al);
 #pragma unroll
-        for (int c = 2 * hh; c < 2 * hh + 2; ++c) {
+        for (int c = TPG * hh; c < TPG * hh + TPG; ++c) {
           acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
           acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(al), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
           acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bl[d][c]), acc[c], 0, 0, 0);
@@ -277,7 +279,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
     for (int c = 0; c < RC_TILES; ++c) {
       const int n = n_base + 16 * c + i16;
       if (n >= N) continue;
-      const int hc = hg[c / 2];
+      const int hc = hg[c / TPG];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * g + r, m = m0 + row;
