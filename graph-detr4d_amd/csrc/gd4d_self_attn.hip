@@ -31,7 +31,10 @@ struct MhaParams {
 };
 
 constexpr int MHA_D = 32;
-constexpr int MHA_WAVES = 8;
+#ifndef MHA_WAVES_N
+#define MHA_WAVES_N 8
+#endif
+constexpr int MHA_WAVES = MHA_WAVES_N;
 #ifndef MHA_PF_N
 #define MHA_PF_N 1
 #endif
