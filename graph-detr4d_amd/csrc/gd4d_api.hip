@@ -28,10 +28,12 @@ extern "C" const char* gd4d_last_hip_error(void) {
 extern "C" void gd4d_trace_set_rowchain(unsigned long long*);
 extern "C" void gd4d_trace_set_mha(unsigned long long*);
 extern "C" void gd4d_trace_set_late(unsigned long long*);
+extern "C" void gd4d_trace_set_sliced(unsigned long long*);
 extern "C" int gd4d_trace_enable(void* buffer) {
   unsigned long long* p = static_cast<unsigned long long*>(buffer);
   gd4d_trace_set_rowchain(p);
   gd4d_trace_set_mha(p);
   gd4d_trace_set_late(p);
+  gd4d_trace_set_sliced(p);
   return GD4D_OK;
 }

@@ -437,6 +437,7 @@ class ValuePipeline:
 
 
 LATE_VALUES_KEY = '_gd4d_late_values'
+AGG_DEFAULT = 'sliced'
 
 
 class LateValues:
@@ -448,55 +449,92 @@ class LateValues:
 
     def __init__(self, value, dtype=torch.float32):
         """dtype: storage type of the channels-last copy - torch.bfloat16 for modules built with value_dtype='bf16' (half the
-        bytes to copy and to gather, bf16-rounded features, fp32 accumulation)."""
+        bytes to copy and to gather, bf16-rounded features, fp32 accumulation).
+
+        Three sources for the gather (GD4D_AGG=rows|sliced, default AGG_DEFAULT):
+          rows    gd4d_pyramid_channels_last_fwd -> (R, S, 256), gd4d_cross_attn_agg_fwd (one workgroup per query, value_proj
+                  in its epilogue); batch 1 only
+          sliced  gd4d_pyramid_slice_planar_fwd -> (8, R, S, 32), gd4d_cross_attn_plan_fwd + gd4d_cross_attn_agg_sliced_fwd
+          in place (no copy at all): when the caller's levels are already stored channels-last (..., H, W, 256), fp32 or
+                  bf16 - the reference's own flatten / transpose (deform3d_cross_attn.py:264-276) has nothing left to do;
+                  always the sliced kernels, which read per-level pointers with strides."""
         dev = value[0].device
         self.value = value
         self.main = torch.cuda.current_stream(dev)
+        self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
+        self.cl = self.pyramid = self.event = None
+        self.waited = set()
+        if all(ops.PyramidView.is_channels_last_level(v) for v in value) and len({v.dtype for v in value}) == 1 \
+                and value[0].dtype in (torch.float32, torch.bfloat16):
+            self.mode, self.side = 'sliced', None
+            self.pyramid = ops.PyramidView.channels_last_levels(list(value))
+            return
+        self.mode = os.environ.get('GD4D_AGG', AGG_DEFAULT)
+        if self.mode == 'rows' and value[0].shape[0] != 1:
+            self.mode = 'sliced'                     # B > 1: the row % B pairing lives in the plan kernel
         self.side = _companion_stream(_SIDE_STREAMS, dev)
         self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
         with torch.cuda.stream(self.side):
+            # GD4D_COPY_CUS: compute units of the persistent copy (default 7/8 of the device - 192: 1.937, 224: 1.922, 256: 1.984, plain copy 2.000 ms per step - the query side of the
+            # first layer runs on the rest, underneath it); 0 = the plain one-workgroup-per-tile copy on all of them
+            env = os.environ.get('GD4D_COPY_CUS')
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
+            src = [v.contiguous() for v in value]
             if 'copy' in os.environ.get('GD4D_ABLATE', '').split(','):      # dev: skip the copy (see fused_decoder._ablate)
                 r = value[0].shape[0] * value[0].shape[1]
-                self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
                 self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev, dtype=dtype)
+                self.mode = 'rows'
+            elif self.mode == 'sliced':
+                self.cl, _ = ops.pyramid_slice_planar_fwd(src, max_cus=copy_cus, out_dtype=dtype)
+                self.pyramid = ops.PyramidView.slice_planar(self.cl, self.shapes)
             else:
-                # GD4D_COPY_CUS: compute units of the persistent copy (default 7/8 of the device - 192: 1.937, 224: 1.922, 256: 1.984, plain copy 2.000 ms per step - the query side of the
-                # first layer runs on the rest, underneath it); 0 = the plain one-workgroup-per-tile copy on all of them
-                env = os.environ.get('GD4D_COPY_CUS')
-                cus = torch.cuda.get_device_properties(dev).multi_processor_count
-                copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
-                self.cl, self.shapes = ops.pyramid_channels_last_fwd([v.contiguous() for v in value], max_cus=copy_cus, out_dtype=dtype)
+                self.cl, _ = ops.pyramid_channels_last_fwd(src, max_cus=copy_cus, out_dtype=dtype)
             self.event = torch.cuda.Event()
             self.event.record(self.side)
         # allocated under the side stream, read by kernels of the main stream: tell the allocator, so that the block is
         # not handed out again (to a side-stream allocation) while those kernels are still queued
         self.cl.record_stream(self.main)
-        self.waited = set()
 
     @staticmethod
     def applicable(modules, value, ignore_mode=False):
         if (not ignore_mode and os.environ.get('GD4D_PROJECT', 'late') != 'late') or not modules \
                 or not isinstance(value, (list, tuple)):
             return False
-        if any(v.dim() != 5 or v.shape[0] != 1 or v.dtype != torch.float32 or not v.is_cuda or v.shape[2] != 256 for v in value):
+        in_place = all(torch.is_tensor(v) and ops.PyramidView.is_channels_last_level(v) for v in value)
+        ok_dtype = (torch.float32, torch.bfloat16) if in_place else (torch.float32,)
+        if any(v.dim() != 5 or v.shape[0] > 16 or v.dtype not in ok_dtype or not v.is_cuda or v.shape[2] != 256 for v in value):
             return False
         rows = value[0].shape[1]
-        if rows > 64 or len(value) > 4 or rows * sum(v.shape[-1] * v.shape[-2] for v in value) >= 2 ** 31:
+        if rows > 64 or len(value) > 4 or value[0].shape[0] * rows * sum(v.shape[-1] * v.shape[-2] for v in value) >= 2 ** 31:
             return False
         return len({m.value_dtype for m in modules}) == 1 and \
             all(m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
                 and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
-    def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, vp_weight=None,
-                  vp_bias=None):
-        """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh) (ops.cross_attn_agg_fwd); with
-        vp_weight: (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
+    def _wait_copy(self):
+        if self.event is None:
+            return
         cur = torch.cuda.current_stream(self.cl.device)
         if cur.cuda_stream not in self.waited:
             cur.wait_event(self.event)
             self.waited.add(cur.cuda_stream)
             if cur.cuda_stream != self.main.cuda_stream:
                 self.cl.record_stream(cur)
+
+    def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, vp_weight=None,
+                  vp_bias=None):
+        """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh); rows mode with vp_weight:
+        (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
+        self._wait_copy()
+        if self.mode == 'sliced':
+            plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
+                                           cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
+                                           query_order=order)
+            agg = ops.cross_attn_agg_sliced_fwd(plan)
+            if vp_weight is not None:
+                return (ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, vp_bias),)
+            return agg, plan.wsum
         return ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                       cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
                                       module.num_heads, query_order=order, vp_weight=vp_weight, vp_bias=vp_bias)
@@ -514,7 +552,8 @@ class LateValues:
         return ops.value_proj_heads_fwd(agg, wsum, weight, bias)
 
     def finish(self):
-        self.main.wait_stream(self.side)             # join (keeps a graph capture well-formed)
+        if self.side is not None:
+            self.main.wait_stream(self.side)         # join (keeps a graph capture well-formed)
 
 
 def pipeline_groups(spec, n):

@@ -207,7 +207,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
         ops.row_chain2_fwd(prog_a, prog_b, q)
 
-        if os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
+        if late.mode != 'sliced' and os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
             # value_proj of the aggregates in the gather's epilogue: chain B' starts from one 1-KB row per query
             agg = late.sample_aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
                                         img_h, img_w, order=order)
@@ -328,7 +328,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
         if order is None or order.numel() != q:
             order = Fn.query_order(ref, ca.pc_range)
         agg_raw = None
-        if late is not None and os.environ.get('GD4D_AGG_EPILOGUE', '1') == '0' and (c // hh) % 32 == 0 \
+        if late is not None and (late.mode == 'sliced' or os.environ.get('GD4D_AGG_EPILOGUE', '1') == '0') and (c // hh) % 32 == 0 \
                 and os.environ.get('GD4D_CHAIN_HEADGEMM', '1') != '0':
             # aggregate-then-project: gather the raw features per head; value_proj of the aggregates is chain B's first op
             if _ablate('agg'):

@@ -141,6 +141,169 @@ def cross_attn_agg_fwd(feats_cl, level_hw, ref, offsets, attn_logits, cam_logits
     return res
 
 
+def pyramid_slice_planar_fwd(feats, out=None, max_cus=0, out_dtype=torch.float32):
+    """gd4d_pyramid_slice_planar_fwd.  feats as pyramid_channels_last_fwd.  Returns (sp (8, R, S, 32), level_hw): the
+    channels-last pyramid with the channel axis cut into 8 planes of 32 (the layout gd4d_cross_attn_agg_sliced_fwd
+    gathers from when it has to make its own copy)."""
+    lib = _lib.load()
+    fl = [f.reshape(-1, *f.shape[-3:]) for f in feats]
+    r, c = fl[0].shape[0], fl[0].shape[1]
+    level_hw = [(int(f.shape[-2]), int(f.shape[-1])) for f in fl]
+    s = sum(h * w for h, w in level_hw)
+    if any(f.shape[0] != r or f.shape[1] != c for f in fl):
+        raise ValueError('feature levels disagree in rows / channels')
+    if c != 256:
+        raise ValueError('the slice-planar copy is built for 256 channels')
+    if out is None:
+        out = torch.empty(8, r, s, 32, device=fl[0].device, dtype=out_dtype)
+    ptrs = (ctypes.c_void_p * len(fl))(*[_dev(f, 'feats', torch.float32).value for f in fl])
+    lv = (ctypes.c_int32 * (2 * len(fl)))(*[int(x) for hw in level_hw for x in hw])
+    code = lib.gd4d_pyramid_slice_planar_fwd(ptrs, lv, _dev(out, 'out'), r, c, len(fl), _lib.F32, _value_dtype(out), int(max_cus),
+                                             _stream())
+    _lib.check(code, 'gd4d_pyramid_slice_planar_fwd')
+    return out, level_hw
+
+
+class PyramidView:
+    """How gd4d_cross_attn_agg_sliced_fwd addresses a 256-channel pyramid: per-level base pointers + byte strides
+    (include/gd4d.h).  Three sources: the slice-planar copy, the pixel-major copy, caller-owned channels-last levels
+    read in place."""
+
+    def __init__(self, tensors, ptrs, level_hw, cam_stride, pix_stride, slice_stride, dtype, rows):
+        self.tensors, self.ptrs, self.level_hw = tensors, ptrs, [tuple(int(x) for x in hw) for hw in level_hw]
+        self.cam_stride, self.pix_stride, self.slice_stride = [int(x) for x in cam_stride], int(pix_stride), int(slice_stride)
+        self.dtype, self.rows = dtype, int(rows)
+
+    @property
+    def device(self):
+        return self.tensors[0].device
+
+    @staticmethod
+    def _starts(level_hw):
+        out, s = [], 0
+        for h, w in level_hw:
+            out.append(s)
+            s += h * w
+        return out, s
+
+    @classmethod
+    def slice_planar(cls, sp, level_hw):
+        """sp (8, R, S, 32) from pyramid_slice_planar_fwd."""
+        es = sp.element_size()
+        starts, s = cls._starts(level_hw)
+        if sp.dim() != 4 or sp.shape[0] != 8 or sp.shape[2] != s or sp.shape[3] != 32 or not sp.is_contiguous():
+            raise ValueError(f'slice-planar pyramid {tuple(sp.shape)} inconsistent with levels {level_hw}')
+        r = sp.shape[1]
+        return cls([sp], [sp.data_ptr() + st * 32 * es for st in starts], level_hw, [s * 32 * es] * len(starts), 32 * es,
+                   r * s * 32 * es, sp.dtype, r)
+
+    @classmethod
+    def pixel_major(cls, cl, level_hw):
+        """cl (R, S, 256) from pyramid_channels_last_fwd."""
+        es = cl.element_size()
+        starts, s = cls._starts(level_hw)
+        if cl.dim() != 3 or cl.shape[1] != s or cl.shape[2] != 256 or not cl.is_contiguous():
+            raise ValueError(f'channels-last pyramid {tuple(cl.shape)} inconsistent with levels {level_hw}')
+        return cls([cl], [cl.data_ptr() + st * 256 * es for st in starts], level_hw, [s * 256 * es] * len(starts), 256 * es,
+                   32 * es, cl.dtype, cl.shape[0])
+
+    @staticmethod
+    def is_channels_last_level(t):
+        """(..., 256, H, W) whose memory is (..., H, W, 256): what `x.permute(.., 2, 3, 1).contiguous().permute(.., 3, 1, 2)`
+        or torch.channels_last on the (rows, C, H, W) view gives."""
+        if t.dim() not in (4, 5) or t.shape[-3] != 256:
+            return False
+        c, h, w = t.shape[-3:]
+        if t.stride(-3) != 1 or t.stride(-1) != c or t.stride(-2) != w * c:
+            return False
+        if t.dim() == 5:
+            return t.stride(1) == h * w * c and (t.shape[0] == 1 or t.stride(0) == t.shape[1] * h * w * c)
+        return t.stride(0) == h * w * c
+
+    @classmethod
+    def channels_last_levels(cls, levels):
+        """levels: L tensors (B, N, 256, H, W) or (R, 256, H, W) with channels-last strides, fp32 or bf16: no copy."""
+        if not all(cls.is_channels_last_level(t) for t in levels) or len({t.dtype for t in levels}) != 1:
+            raise ValueError('channels_last_levels needs (.., 256, H, W) tensors stored as (.., H, W, 256), one dtype')
+        es = levels[0].element_size()
+        rows = levels[0].numel() // (256 * levels[0].shape[-1] * levels[0].shape[-2])
+        hw = [(int(t.shape[-2]), int(t.shape[-1])) for t in levels]
+        return cls(list(levels), [t.data_ptr() for t in levels], hw, [h * w * 256 * es for h, w in hw], 256 * es, 32 * es,
+                   levels[0].dtype, rows)
+
+
+def cross_attn_plan_bytes(b, n, q, num_heads, points=4):
+    return int(_lib.load().gd4d_cross_attn_plan_bytes(b, n, q, num_heads, points))
+
+
+class Plan:
+    """Output of cross_attn_plan_fwd: the plan buffer, the locality order it is stored by, the pyramid it addresses and
+    wsum (B, Q, Hh) - the sum of the in-bounds sampling weights per head."""
+
+    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum):
+        self.buf, self.order, self.pyramid, self.b, self.q, self.num_heads, self.wsum = buf, order, pyramid, b, q, num_heads, wsum
+
+
+def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, num_heads,
+                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None):
+    """gd4d_cross_attn_plan_fwd: projection + mask + softmax + camera weights + bilinear corners of one decoder layer's
+    cross-attention -> what gd4d_cross_attn_agg_sliced_fwd walks on `pyramid` (a PyramidView).  The other arguments as
+    cross_attn_fwd; plan: a Plan to overwrite.  Returns Plan [, mask (B, N, Q, Hh, P) uint8] [, uv (B, N, Q, Hh, P, 2)]."""
+    lib = _lib.load()
+    b, q = ref.shape[0], ref.shape[1]
+    n = lidar2img.shape[1]
+    hh, p, nl = num_heads, offsets.shape[3], len(pyramid.level_hw)
+    if pyramid.rows != b * n:
+        raise ValueError(f'pyramid has {pyramid.rows} camera rows, expected B*N = {b * n}')
+    if offsets.numel() != b * q * hh * p * 3 or attn_logits.numel() != b * q * hh * nl * p or cam_logits.numel() != b * q * n:
+        raise ValueError('offsets / attn_logits / cam_logits have the wrong number of elements')
+    f32 = torch.float32
+    nbytes = cross_attn_plan_bytes(b, n, q, hh, p)
+    buf = torch.empty(nbytes, device=ref.device, dtype=torch.uint8) if plan is None else plan.buf
+    wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32) if plan is None else plan.wsum
+    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum)
+    mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
+    uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in pyramid.level_hw for x in hw])
+    cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
+    code = lib.gd4d_cross_attn_plan_fwd(
+        _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32), _dev(attn_logits, 'attn_logits', f32),
+        _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w),
+        lv, cs, pyramid.pix_stride, _dev(buf, 'plan', torch.uint8), buf.numel(), _dev(wsum, 'wsum', f32),
+        _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None, b, n, q, hh, nl, p,
+        1 if raw_cam_weights else 0, None if query_order is None else _order_ptr(query_order, b * q), _stream())
+    _lib.check(code, 'gd4d_cross_attn_plan_fwd')
+    res = (plan,)
+    if want_mask:
+        res += (mask,)
+    if want_uv:
+        res += (uv,)
+    return res if len(res) > 1 else plan
+
+
+def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
+    """gd4d_cross_attn_agg_sliced_fwd on the pyramid the Plan was made for.  Returns agg (B, Q, Hh, 256); with plan.wsum
+    (B, Q, Hh) that is what cross_attn_agg_fwd returns (other summation order)."""
+    lib = _lib.load()
+    pyramid = plan.pyramid
+    dev = pyramid.device
+    b, q, hh, query_order = plan.b, plan.q, plan.num_heads, plan.order
+    if not plan.buf.is_cuda or plan.buf.device != dev:
+        raise _lib.Gd4dError('plan must live on the pyramid\'s GPU (no CPU fallback in graph-detr4d_amd)')
+    nl = len(pyramid.level_hw)
+    f32 = torch.float32
+    if agg is None:
+        agg = torch.empty(b, q, hh, 256, device=dev, dtype=f32)
+    ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
+    code = lib.gd4d_cross_attn_agg_sliced_fwd(
+        ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32), b, pyramid.rows // b, q, hh,
+        256, nl, 4, _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+        None if query_order is None else _order_ptr(query_order, b * q), int(slices[0]), int(slices[1]), _stream())
+    _lib.check(code, 'gd4d_cross_attn_agg_sliced_fwd')
+    return agg
+
+
 def value_proj_heads_fwd(agg, wsum, weight, bias=None, out=None):
     """gd4d_value_proj_heads_fwd: agg (..., Hh, 256), wsum (..., Hh) -> out (..., 256) = value_proj of the aggregates."""
     lib = _lib.load()
@@ -921,7 +1084,7 @@ def _on_tensor_device(fn):
     return wrapped
 
 
-_HOST_ONLY = {'linear_sum_assignment_batch', 'chain_load', 'chain_gemm', 'chain_small_linear', 'chain_layernorm',
+_HOST_ONLY = {'linear_sum_assignment_batch', 'cross_attn_plan_bytes', 'chain_load', 'chain_gemm', 'chain_small_linear', 'chain_layernorm',
               'chain_add', 'chain_refine', 'row_chain_fwd', 'chain_weight_image'}
 for _name, _fn in list(globals().items()):
     if inspect.isfunction(_fn) and _fn.__module__ == __name__ and not _name.startswith('_') and _name not in _HOST_ONLY:

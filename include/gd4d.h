@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 26
+#define GD4D_ABI_VERSION 27
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -151,6 +151,48 @@ int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* level_hw, const
                             void* stream);
 int gd4d_value_proj_heads_fwd(const float* agg, const float* wsum, const float* weight, const float* bias, float* out,
                               int M, int Hh, int C, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Channel-sliced form of the aggregate-then-project gather (gd4d_cross_attn_sliced.hip; the default of the inference
+ * step).  Same arithmetic and same reference lines as gd4d_cross_attn_agg_fwd (deform3d_cross_attn.py:220-258, :277,
+ * :281-284, :301-304, :320-324), another shape of the work: the 256 channels are cut into 8 slices of 32 (one 128-byte
+ * line per bilinear corner), a workgroup is one (query, slice), and the workgroups of an XCD run slice-major - at any
+ * time an XCD gathers ONE slice of all its queries, 1/8 of the footprint its 4-MB L2 has to hold.
+ *
+ * gd4d_pyramid_slice_planar_fwd - as gd4d_pyramid_channels_last_fwd (the reference's flatten / transpose / cat,
+ *   :264-276) but out = (8, R, S, 32): slice s of every pixel in one contiguous plane.
+ *
+ * gd4d_cross_attn_plan_fwd - per (sample, query), once per decoder layer: everything that does not depend on the slice.
+ *   Projection + visibility mask (bit-exact, the routine of gd4d_cross_attn_fwd) + softmax over L*P + camera weights +
+ *   the bilinear corner of every visible sample at every level: writes `plan` (gd4d_cross_attn_plan_bytes(B, N, Q, Hh, P)
+ *   bytes, 16-byte aligned) - per head the number of visible (camera, point) items and, per pass of 4 items, 64 pairs
+ *   {byte offset inside the level, weight} in the order the gather's lanes consume them - and wsum (B*Q, Hh) fp32 =
+ *   sum_i w_i over the in-bounds corners (mmcv's zero padding drops the bias with the value).  The byte offsets are
+ *       r * cam_stride_bytes[l] + (y*W_l + x) * pix_stride_bytes       (camera row r = b*N + n, level l = level_hw[l])
+ *   of the pyramid the gather will read.  Value row i = b*N + n takes the logits of batch (i % B) (:277).  mask_out /
+ *   uv_out as gd4d_cross_attn_fwd.  query_order (or NULL): the plan is stored by POSITION in that order - hand the same
+ *   order to gd4d_cross_attn_agg_sliced_fwd.  Supported: P == 4, L <= 4, N <= 64, B <= 16, Hh in {4, 8, 16}, every
+ *   level's bytes < 2^32.
+ *
+ * gd4d_cross_attn_agg_sliced_fwd - the gather: agg (B*Q, Hh, C) fp32 = sum_i w_i x_i, from a pyramid addressed as
+ *     address(level l, camera row r, pixel y*W_l + x, slice s, channel k of the slice)
+ *         = level_ptrs[l] + r * cam_stride_bytes[l] + (y*W_l + x) * pix_stride_bytes + s * slice_stride_bytes + k * elem
+ *   level_ptrs: host array of L device pointers.  This covers the slice-planar copy (pix 128, slice R*S*128), the
+ *   pixel-major copy of gd4d_pyramid_channels_last_fwd (pix 1024, slice 128) and caller-owned channels-last (NHWC) levels
+ *   read in place without any copy (per-level pointers, pix 1024, slice 128; bf16: half of each).  slice_lo / slice_n:
+ *   the slices of this launch (0, 8 = all).  query_order: the one the plan was made with (scheduling only: results are
+ *   bit-identical for any permutation).  Supported: C == 256, P == 4, L <= 4, N <= 64, B <= 16, Hh in {4, 8, 16}. */
+size_t gd4d_cross_attn_plan_bytes(int B, int N, int Q, int Hh, int P);
+int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
+                             const float* lidar2img, const double* pc_range, float img_h, float img_w,
+                             const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,
+                             size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh,
+                             int L, int P, int flags, const int32_t* query_order, void* stream);
+int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan, float* agg,
+                                   int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                   const int32_t* query_order, int slice_lo, int slice_n, void* stream);
+int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C, int L,
+                                  int in_dtype, int out_dtype, int max_cus, void* stream);
 
 /* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the
  * reference's MSDA kernel processes queries in index order).  Counting sort by (sample, azimuth of the de-normalised

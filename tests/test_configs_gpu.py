@@ -50,13 +50,13 @@ def test_config0_resnet18_plumbing_to_one_layer_detr3d_decoder():
 def test_config1_bf16_module_matches_oracle_in_bf16_mode(name, project, monkeypatch):
     """Deform3DCrossAttn(value_dtype='bf16') against the oracle's restatement of that arithmetic.  project = 'early':
     head-major bf16 value tensor from the single-product value_proj, the fused gather in bf16 storage (oracle
-    value_dtype='bf16').  project = 'late' (default for B = 1): the channels-last copy of the FEATURES is stored in bf16,
-    aggregation and value_proj of the aggregates in fp32 (oracle value_dtype='bf16_features')."""
+    value_dtype='bf16').  project = 'late' (default): the channels-last copy of the FEATURES is stored in bf16,
+    aggregation and value_proj of the aggregates in fp32 (oracle value_dtype='bf16_features'); B > 1 included."""
     from oracle import torch_oracle as O
     monkeypatch.setenv('GD4D_PROJECT', project)
     g = Golden(name)
     m = g.meta
-    late = project == 'late' and m['batch'] == 1
+    late = project == 'late'                   # B > 1 too: the sliced gather has the row % B pairing
     mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=m['pc_range'],
                                  num_points=4, embed_dims=256, depth_encode=m['depth_encode'], value_dtype='bf16'),
                             dict(batch_first=False))

@@ -1,0 +1,194 @@
+"""Channel-sliced aggregate-then-project gather (gd4d_pyramid_slice_planar_fwd, gd4d_cross_attn_plan_fwd,
+gd4d_cross_attn_agg_sliced_fwd) through the C ABI: against golden vectors captured from the reference (incl. the B = 2
+row-pairing quirk), against the CPU oracle, against the one-workgroup-per-query aggregate kernel, and on every pyramid
+source it can read (its own slice-planar copy, the pixel-major copy, caller-owned channels-last levels in place).
+GPU only."""
+import pytest
+import torch
+
+from golden_io import Golden
+
+pytestmark = pytest.mark.gpu
+
+ATOL = RTOL = 1e-4        # fp32 path: only summation order differs from the reference (north_star: 1e-3)
+
+
+def _sliced(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads=8, order=None, want=False, slices=None):
+    from graph_detr4d_amd import ops
+    b, q = ref.shape[0], ref.shape[1]
+    res = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads,
+                                  want_mask=want, want_uv=want, query_order=order)
+    plan = res[0] if want else res
+    if slices is None:
+        agg = ops.cross_attn_agg_sliced_fwd(plan)
+    else:                                            # the slices in several launches, any order
+        agg = torch.full((b, q, heads, 256), float('nan'), device=ref.device)
+        for lo, n in slices:
+            ops.cross_attn_agg_sliced_fwd(plan, slices=(lo, n), agg=agg)
+    return (agg, plan.wsum) + (tuple(res[1:]) if want else ())
+
+
+def test_slice_planar_is_the_reference_flatten_transpose_cat():
+    """deform3d_cross_attn.py:264-276 with the channel axis cut into 8 planes: sp[s, r, pixel, k] = flat[r, pixel, 32 s + k]."""
+    from graph_detr4d_amd import ops
+    from oracle import torch_oracle as O
+    torch.manual_seed(3)
+    feats = [torch.randn(1, 5, 256, h, w) for h, w in [(29, 50), (15, 25), (8, 13), (3, 5)]]   # odd sizes: partial tiles
+    flat, shapes = O.flatten_pyramid(feats)
+    want = flat.reshape(5, -1, 8, 32).permute(2, 0, 1, 3).contiguous()
+    fd = [f.cuda() for f in feats]
+    sp, got_shapes = ops.pyramid_slice_planar_fwd(fd)
+    assert list(map(tuple, got_shapes)) == list(map(tuple, shapes))
+    assert torch.equal(sp.cpu(), want)
+    for cus in (1, 8, 224, 4096):                                # the persistent form: one workgroup on each of `cus` CUs
+        assert torch.equal(ops.pyramid_slice_planar_fwd(fd, max_cus=cus)[0], sp), cus
+    sp16, _ = ops.pyramid_slice_planar_fwd(fd, out_dtype=torch.bfloat16)
+    assert sp16.dtype == torch.bfloat16 and torch.equal(sp16.cpu(), want.bfloat16())
+    assert torch.equal(ops.pyramid_slice_planar_fwd(fd, out_dtype=torch.bfloat16, max_cus=8)[0], sp16)
+
+
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_edge', 'deform_n24_b2'])
+def test_sliced_matches_reference_golden(name):
+    """mask / uv bit-exact, value_proj of the aggregates = the reference's MSDA output summed over cameras; deform_n24_b2
+    pins the B > 1 pairing of value row i with the logits of batch (i % B) (deform3d_cross_attn.py:277)."""
+    from graph_detr4d_amd import ops
+    g = Golden(name)
+    m = g.meta
+    b, n, q = m['batch'], m['num_cams'], m['num_query']
+    sd = g.state()
+    dev = 'cuda'
+    l2i = torch.from_numpy(g.arrays['lidar2img']).unsqueeze(0).expand(b, -1, -1, -1).contiguous().to(dev)
+    feats = [f.to(dev) for f in g.feats()]
+    sp, shapes = ops.pyramid_slice_planar_fwd(feats)
+    pyr = ops.PyramidView.slice_planar(sp, shapes)
+    agg, wsum, mask, uv = _sliced(pyr, g.t('reference_points').to(dev), g.t('offsets').view(b, q, 8, 4, 3).contiguous().to(dev),
+                                  g.t('attn_logits').view(b, q, 8, 4, 4).contiguous().to(dev), g.t('cam_logits').to(dev), l2i,
+                                  m['pc_range'], m['img_shape'][0], m['img_shape'][1], want=True)
+    out = ops.value_proj_heads_fwd(agg, wsum, sd['value_proj.weight'].to(dev), sd['value_proj.bias'].to(dev))
+    gmask = g.t('mask').view(b, n, q, 8, 4, 4)[..., 0, :]
+    guv = g.t('uv').view(b, n, q, 8, 4, 4, 2)[..., 0, :, :]
+    assert torch.equal(mask.cpu(), gmask), 'visibility mask must be bit-exact'
+    assert torch.equal(uv.cpu(), guv), 'projected coordinates must be bit-exact'
+    torch.testing.assert_close(out.cpu(), g.t('agg'), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('heads,levels,n,q,b', [
+    (8, [(29, 50), (15, 25), (8, 13), (4, 7)], 12, 300, 1),
+    (8, [(16, 28)], 6, 64, 1),
+    (8, [(16, 28), (8, 14)], 7, 50, 1),
+    (8, [(16, 28), (8, 14), (4, 7)], 1, 33, 1),
+    (4, [(16, 28), (8, 14), (4, 7), (2, 4)], 6, 40, 1),
+    (16, [(16, 28), (8, 14), (4, 7), (2, 4)], 6, 40, 1),
+    (8, [(12, 20), (6, 10), (3, 5), (2, 3)], 64, 20, 1),
+    (8, [(16, 28), (8, 14), (4, 7), (2, 4)], 6, 37, 3),
+])
+def test_sliced_vs_oracle_and_other_kernels(heads, levels, n, q, b):
+    """Every compiled (heads, levels) form against the plain-torch oracle (value_proj then sample_aggregate, incl. B > 1),
+    against gd4d_cross_attn_agg_fwd (B = 1) and on all three pyramid sources; locality order and split launches are
+    scheduling only (bit-identical)."""
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import torch_oracle as O
+    torch.manual_seed(heads * 100 + len(levels) * 10 + n + b)
+    dh, nl = 256 // heads, len(levels)
+    rig = synthetic.camera_rig((n + 5) // 6)[:n]
+    l2i = torch.from_numpy(rig).unsqueeze(0).expand(b, -1, -1, -1).contiguous()
+    feats = [torch.randn(b, n, 256, h, w) for h, w in levels]
+    w, bias = torch.randn(256, 256) * 0.06, torch.randn(256)
+    ref = torch.rand(b, q, 3)
+    offsets = torch.randn(b, q, heads, 4, 3) * 2.0
+    attn = torch.randn(b, q, heads, nl, 4)
+    cam = torch.randn(b, q, n)
+    flat, shapes = O.flatten_pyramid(feats)
+    val = torch.nn.functional.linear(flat, w, bias).view(b * n, -1, heads, dh)
+    o_ref, uv_ref, m_ref = O.sample_aggregate(val, shapes, ref, offsets, attn.flatten(-2), cam, l2i, synthetic.PC_RANGE, 900, 1600)
+    dev = 'cuda'
+    d = [t.to(dev) for t in (ref, offsets, attn, cam, l2i)]
+    fd = [f.to(dev) for f in feats]
+    sp, shp = ops.pyramid_slice_planar_fwd(fd)
+    pyr = ops.PyramidView.slice_planar(sp, shp)
+    agg, wsum, mask, uv = _sliced(pyr, *d, synthetic.PC_RANGE, 900, 1600, heads=heads, want=True)
+    out = ops.value_proj_heads_fwd(agg, wsum, w.to(dev), bias.to(dev))
+    mism = mask.cpu() != m_ref.to(torch.uint8)
+    flipped = mism.any(dim=4).any(dim=3).any(dim=1)                  # (B, Q): torch's matmul decides m_ref on this host
+    assert flipped.sum().item() <= 2
+    keep = ~flipped
+    torch.testing.assert_close(out.cpu()[keep], o_ref[keep], rtol=RTOL, atol=ATOL)
+    if b == 1:
+        cl, _ = ops.pyramid_channels_last_fwd(fd)
+        a0, s0, m0, u0 = ops.cross_attn_agg_fwd(cl, shp, *d, synthetic.PC_RANGE, 900, 1600, heads, want_mask=True, want_uv=True)
+        assert torch.equal(mask, m0) and torch.equal(uv, u0)         # one projection routine in all kernels
+        torch.testing.assert_close(agg, a0, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(wsum, s0, rtol=1e-5, atol=1e-6)
+        # the pixel-major copy read through strides
+        a1, s1 = _sliced(ops.PyramidView.pixel_major(cl, shp), *d, synthetic.PC_RANGE, 900, 1600, heads=heads)
+        assert torch.equal(a1, agg) and torch.equal(s1, wsum)
+    # caller-owned channels-last levels, read in place (no copy)
+    nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fd]
+    assert all(ops.PyramidView.is_channels_last_level(t) for t in nhwc) and not ops.PyramidView.is_channels_last_level(fd[0])
+    a2, s2 = _sliced(ops.PyramidView.channels_last_levels(nhwc), *d, synthetic.PC_RANGE, 900, 1600, heads=heads)
+    assert torch.equal(a2, agg) and torch.equal(s2, wsum)
+    # scheduling only: locality order, slices in separate launches
+    order = ops.query_order_fwd(d[0], synthetic.PC_RANGE)
+    a3, s3 = _sliced(pyr, *d, synthetic.PC_RANGE, 900, 1600, heads=heads, order=order)
+    assert torch.equal(a3, agg) and torch.equal(s3, wsum)
+    a4, s4 = _sliced(pyr, *d, synthetic.PC_RANGE, 900, 1600, heads=heads, order=order, slices=[(4, 4), (0, 3), (3, 1)])
+    assert torch.equal(a4, agg) and torch.equal(s4, wsum)
+    # wsum is the sum of the in-bounds weights: with a zero weight matrix the output is bias * wsum
+    out0 = ops.value_proj_heads_fwd(agg, wsum, torch.zeros_like(w).to(dev), bias.to(dev))
+    torch.testing.assert_close(out0, (bias.to(dev).view(heads, dh) * wsum.unsqueeze(-1)).reshape(b, q, 256), rtol=1e-6, atol=1e-6)
+
+
+def test_bf16_storage_sliced():
+    """value_dtype='bf16': bf16-rounded features (copy or caller-owned), fp32 accumulation - equals the fp32 kernel on the
+    same rounded features within summation order."""
+    from graph_detr4d_amd import ops, synthetic
+    torch.manual_seed(13)
+    levels = [(29, 50), (15, 25), (8, 13), (3, 5)]
+    n, q = 6, 200
+    fd = [torch.randn(1, n, 256, h, w).cuda() for h, w in levels]
+    l2i = torch.from_numpy(synthetic.camera_rig(1)).unsqueeze(0).cuda()
+    ref, off = torch.rand(1, q, 3).cuda(), (torch.randn(1, q, 8, 4, 3) * 2).cuda()
+    attn, cam = torch.randn(1, q, 8, 4, 4).cuda(), torch.randn(1, q, n).cuda()
+    args = (ref, off, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600)
+    sp16, shp = ops.pyramid_slice_planar_fwd(fd, out_dtype=torch.bfloat16)
+    a16, s16 = _sliced(ops.PyramidView.slice_planar(sp16, shp), *args)
+    a32, s32 = _sliced(ops.PyramidView.slice_planar(sp16.float(), shp), *args)
+    assert torch.equal(s16, s32)
+    torch.testing.assert_close(a16, a32, rtol=1e-6, atol=1e-6)
+    nhwc16 = [f.bfloat16().permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fd]
+    a16b, s16b = _sliced(ops.PyramidView.channels_last_levels(nhwc16), *args)
+    assert torch.equal(a16b, a16) and torch.equal(s16b, s16)
+
+
+def test_full_size_sliced_equals_rows_and_early():
+    """BASELINE configs[2] size (900 queries, 24 cameras, R50 pyramid): the sliced gather against the one-workgroup-per-
+    query aggregate kernel (summation order only) and against the projected-value path within 1e-3 (north_star)."""
+    from graph_detr4d_amd import ops, synthetic
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(21)
+    b, q, n = 1, 900, 24
+    feats = [torch.randn(b, n, 256, h, w, generator=g).to(dev) for h, w in synthetic.R50_LEVELS]
+    w = (torch.randn(256, 256, generator=g) * 0.06).to(dev)
+    bias = torch.randn(256, generator=g).to(dev)
+    l2i = torch.from_numpy(synthetic.camera_rig(4)).unsqueeze(0).to(dev)
+    ref = torch.rand(b, q, 3, generator=g).to(dev)
+    offsets = (torch.randn(b, q, 8, 4, 3, generator=g) * 2).to(dev)
+    attn = torch.randn(b, q, 8, 4, 4, generator=g).to(dev)
+    cam = torch.randn(b, q, n, generator=g).to(dev)
+    args = (ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600)
+    order = ops.query_order_fwd(ref, synthetic.PC_RANGE)
+    sp, shapes = ops.pyramid_slice_planar_fwd(feats, max_cus=224)
+    agg, wsum, mask, uv = _sliced(ops.PyramidView.slice_planar(sp, shapes), *args, order=order, want=True)
+    cl, _ = ops.pyramid_channels_last_fwd(feats)
+    a0, s0, m0 = ops.cross_attn_agg_fwd(cl, shapes, *args, 8, want_mask=True, query_order=order)
+    assert torch.equal(mask, m0)
+    torch.testing.assert_close(agg, a0, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(wsum, s0, rtol=1e-5, atol=1e-6)
+    out = ops.value_proj_heads_fwd(agg, wsum, w, bias)
+    val = ops.value_proj_fwd(feats, w, bias).view(b * n, -1, 8, 32)
+    early = ops.cross_attn_fwd(val, shapes, *args)
+    assert (out - early).abs().max().item() < 1e-3
+    assert out.abs().max().item() > 0.1
+    # run-to-run identical (fixed summation order)
+    agg2, wsum2 = _sliced(ops.PyramidView.slice_planar(sp, shapes), *args, order=order)
+    assert torch.equal(agg, agg2) and torch.equal(wsum, wsum2)

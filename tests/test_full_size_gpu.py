@@ -11,11 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('project', ['late', 'early'])
+@pytest.mark.parametrize('project', ['late', 'late-rows', 'early'])
 def test_each_decoder_layer_900q_24cams_matches_oracle(project, monkeypatch):
-    """project = 'late': the default aggregate-then-project value path (channels-last copy, gd4d_cross_attn_agg_fwd,
-    gd4d_value_proj_heads_fwd); 'early': value_proj over the pyramid + gd4d_cross_attn_fwd (the reference's order)."""
-    monkeypatch.setenv('GD4D_PROJECT', project)
+    """project = 'late': the default aggregate-then-project value path (slice-planar copy, gd4d_cross_attn_plan_fwd,
+    gd4d_cross_attn_agg_sliced_fwd, gd4d_value_proj_heads_fwd); 'late-rows': its one-workgroup-per-query form
+    (gd4d_cross_attn_agg_fwd); 'early': value_proj over the pyramid + gd4d_cross_attn_fwd (the reference's order)."""
+    monkeypatch.setenv('GD4D_PROJECT', 'early' if project == 'early' else 'late')
+    monkeypatch.setenv('GD4D_AGG', 'rows' if project == 'late-rows' else 'sliced')
     import bench
     import graph_detr4d_amd as G
     from graph_detr4d_amd import functional as Fn
@@ -64,9 +66,14 @@ def test_each_decoder_layer_900q_24cams_matches_oracle(project, monkeypatch):
             orig_late = Fn.LateValues.aggregate
 
             def spy_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, **vp):
-                captured['mask'] = ops.cross_attn_agg_fwd(self.cl, self.shapes, ref_.contiguous(), offsets.contiguous(),
-                                                          attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
-                                                          module.pc_range, img_h, img_w, module.num_heads, want_mask=True)[2]
+                if self.mode == 'sliced':
+                    captured['mask'] = ops.cross_attn_plan_fwd(self.pyramid, ref_.contiguous(), offsets.contiguous(),
+                                                               attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
+                                                               module.pc_range, img_h, img_w, module.num_heads, want_mask=True)[1]
+                else:
+                    captured['mask'] = ops.cross_attn_agg_fwd(self.cl, self.shapes, ref_.contiguous(), offsets.contiguous(),
+                                                              attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
+                                                              module.pc_range, img_h, img_w, module.num_heads, want_mask=True)[2]
                 return orig_late(self, module, ref_, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order, **vp)
             Fn.sample_aggregate, Fn.LateValues.aggregate = spy, spy_late
             try:

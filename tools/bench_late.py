@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--all-visible', action='store_true')
     ap.add_argument('--no-order', action='store_true')
     ap.add_argument('--levels', default='r50')
+    ap.add_argument('--split', action='store_true')
     a = ap.parse_args()
     dev = 'cuda'
     n, q = 6 * a.frames, a.queries
@@ -76,6 +77,29 @@ def main():
     print(f'aggregate (raw gather): {t_agg:.1f} us per layer;  corner bytes {alg_raw / 1e6:.0f} MB -> {alg_raw / t_agg / 1e6:.2f} TB/s at the L2; '
           f'capped at the tensor {min(alg_raw, nbytes) / 1e6:.0f} MB -> {min(alg_raw, nbytes) / t_agg / 1e6:.2f} TB/s')
     print(f'value_proj of the aggregates: {t_hp:.1f} us per layer')
+    # channel-sliced form: slice-planar copy, plan, gather
+    sp, _ = ops.pyramid_slice_planar_fwd(feats)
+    pyr = ops.PyramidView.slice_planar(sp, shapes)
+    t_sp = timed(lambda: ops.pyramid_slice_planar_fwd(feats, out=sp), a.iters)
+    t_sp_p = timed(lambda: ops.pyramid_slice_planar_fwd(feats, out=sp, max_cus=224), a.iters)
+    plan = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8, query_order=order)
+    t_plan = timed(lambda: [ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8, plan=plan, query_order=order)
+                            for _ in range(6)], a.iters, 6)
+    sa, sw = ops.cross_attn_agg_sliced_fwd(plan), plan.wsum
+    print(f'sliced vs rows: max |agg diff| {(sa - agg).abs().max().item():.2e}  max |wsum diff| {(sw - wsum).abs().max().item():.2e}')
+    t_sl = timed(lambda: [ops.cross_attn_agg_sliced_fwd(plan, agg=sa) for _ in range(6)], a.iters, 6)
+    print(f'slice-planar copy: {t_sp:.1f} us  (persistent on 224 CUs: {t_sp_p:.1f} us)')
+    print(f'plan: {t_plan:.1f} us per layer')
+    print(f'sliced aggregate: {t_sl:.1f} us per layer  ({alg_raw / t_sl / 1e6:.2f} TB/s at the L2)')
+    pm = ops.PyramidView.pixel_major(cl, shapes)
+    plan_pm = ops.cross_attn_plan_fwd(pm, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8, query_order=order)
+    t_pm = timed(lambda: [ops.cross_attn_agg_sliced_fwd(plan_pm, agg=sa) for _ in range(6)], a.iters, 6)
+    print(f'sliced aggregate on the pixel-major copy (= caller-owned NHWC levels): {t_pm:.1f} us per layer')
+    if a.split:
+        for parts in ([(0, 4), (4, 4)], [(i, 1) for i in range(8)]):
+            t = timed(lambda: [[ops.cross_attn_agg_sliced_fwd(plan, slices=sl, agg=sa) for sl in parts]
+                               for _ in range(6)], a.iters, 6)
+            print(f'sliced aggregate in {len(parts)} launches: {t:.1f} us per layer')
     print(f'six layers: {t_cl + 6 * (t_agg + t_hp):.0f} us')
 
 

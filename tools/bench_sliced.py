@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Full-size timing of the channel-sliced gather alone (dev tool; bench.py is the contract).
+  --alias      all camera rows alias row 0 (cam_stride = 0): a phase's footprint is one camera's slice (3.9 MB) - the
+               kernel's own floor with the L2 misses taken away
+  --layout     planar | pixel   the slice-planar copy or the pixel-major copy (= caller-owned channels-last levels)"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graph_detr4d_amd import ops, synthetic  # noqa: E402
+from bench_late import timed  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=4)
+    ap.add_argument('--queries', type=int, default=900)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--alias', action='store_true')
+    ap.add_argument('--no-order', action='store_true')
+    ap.add_argument('--layout', default='planar')
+    ap.add_argument('--levels', default='r50')
+    ap.add_argument('--dtype', default='fp32')
+    a = ap.parse_args()
+    dev = 'cuda'
+    n, q = 6 * a.frames, a.queries
+    levels = synthetic.R50_LEVELS if a.levels == 'r50' else synthetic.VOV_LEVELS
+    g = torch.Generator().manual_seed(0)
+    feats = [torch.randn(1, n, 256, h, w, generator=g).to(dev) for h, w in levels]
+    l2i = torch.from_numpy(synthetic.camera_rig(a.frames)).unsqueeze(0).to(dev)
+    ref = torch.rand(1, q, 3, generator=g).to(dev)
+    offsets = (torch.randn(1, q, 8, 4, 3, generator=g) * 1.5).to(dev)
+    attn = torch.randn(1, q, 8, 4, 4, generator=g).to(dev)
+    cam = torch.randn(1, q, n, generator=g).to(dev)
+    order = None if a.no_order else ops.query_order_fwd(ref, synthetic.PC_RANGE)
+    dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    if a.layout == 'planar':
+        sp, shapes = ops.pyramid_slice_planar_fwd(feats, out_dtype=dt)
+        pyr = ops.PyramidView.slice_planar(sp, shapes)
+    else:
+        cl, shapes = ops.pyramid_channels_last_fwd(feats, out_dtype=dt)
+        pyr = ops.PyramidView.pixel_major(cl, shapes)
+    del feats
+    if a.alias:
+        pyr.cam_stride = [0] * len(pyr.cam_stride)
+    plan, mask = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
+                                         query_order=order, want_mask=True)
+    vis = int(mask.sum().item())
+    corner_bytes = vis * len(levels) * 4 * 256 * (2 if a.dtype == 'bf16' else 4)
+    sa, sw = ops.cross_attn_agg_sliced_fwd(plan), plan.wsum
+    t_plan = timed(lambda: [ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
+                                                    plan=plan, query_order=order) for _ in range(6)], a.iters, 6)
+    t = timed(lambda: [ops.cross_attn_agg_sliced_fwd(plan, agg=sa) for _ in range(6)], a.iters, 6)
+    print(f'variant {os.environ.get("GD4D_SLICED_VARIANT", "0")} layout {a.layout} alias {a.alias} {a.dtype}: plan {t_plan:.1f} us, '
+          f'sliced gather {t:.1f} us per launch ({corner_bytes / t / 1e6:.2f} TB/s of corner bytes)')
+
+
+if __name__ == '__main__':
+    main()
