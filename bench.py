@@ -250,6 +250,14 @@ def main():
         elapsed = D.timed_steps(run, a.steps, a.warmup, dev, stats)   # barrier + synchronise both sides, MAX over ranks
         if n_req > 1:                                 # one sample at a time, same graphs: the latency of a request
             single_ms = D.timed_steps(run_one, a.steps, a.warmup, dev, {}) / a.steps * 1e3
+        else:
+            single_ms = elapsed / a.steps * 1e3
+
+        def run_eager():                              # no hipGraph: the modules dropped in without the capture recipe
+            with torch.cuda.stream(streams[0]), Fn.request_slot(0):
+                request(0)
+        eager_steps = max(1, min(a.steps, 10))
+        eager_ms = D.timed_steps(run_eager, eager_steps, 2, dev, {}) / eager_steps * 1e3
 
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
@@ -270,20 +278,27 @@ def main():
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if a.value_dtype == 'fp32' else 'bf16-storage/f32-accumulate',
+            'dtype_detail': 'features, gather, aggregation, softmax, LayerNorm, attention core: fp32; the query-side GEMMs of the row '
+                            'chains (in/out-proj, the Linears of the cross-attention, value_proj of the aggregates, FFN, reg branch) '
+                            'are split-bf16 x3 products on the bf16 MFMA with fp32 accumulation (~2^-16 relative per product, inside '
+                            'the 1e-3 contract)',
+            'value_batch1': a.gpus * 1e3 / single_ms, 'ms_per_sample_batch1': single_ms,
+            'eager_ms_per_sample': eager_ms,
             'data': 'synthetic',
             'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
                                    f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
                                    f'{"x".join(str(h) + "*" + str(w) for h, w in levels)}, 256 ch, '
                                    f'batch 1 per request, {n_req} independent request(s) in flight per GPU (one HIP stream '
                                    f'and one hipGraph each; a step = one sample on every stream), pyramids resident in HBM',
-                       'baseline_config': 'configs[2]', 'launch': launch, 'inflight': n_req, 'global_batch': n_req * a.gpus,
+                       'baseline_config': 'configs[2]', 'launch': launch, 'inflight': n_req, 'input_layout': a.input_layout, 'global_batch': n_req * a.gpus,
                        'samples_per_step': n_req * a.gpus,
                        'parallelism': f'replicas x{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3, 'allreduce_bytes_per_step': 0,
             'one_in_flight': None if single_ms is None else {
                 'ms_per_sample': single_ms, 'samples_per_s': a.gpus * 1e3 / single_ms,
-                'note': 'the same graphs replayed one request at a time (latency of a request; round-1/2 lines were this)'},
+                'note': 'the same graphs replayed one request at a time (latency of a request; round-1/2 lines were this); '
+                        '= value_batch1 / ms_per_sample_batch1'},
             'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
         }
         print(json.dumps(line))
@@ -583,6 +598,27 @@ def _all_visible_inputs(c0, ops):
     return ref_av, l2i_av, ops.query_order_fwd(ref_av, c0['pc_range'])
 
 
+def _unique_pixels(mask, uv, shapes):
+    """Distinct (camera row, level, pixel) a launch touches: the in-bounds bilinear corners of every visible sample, from the
+    kernel's own mask (B, N, Q, Hh, P) and uv (B, N, Q, Hh, P, 2) - mmcv's sampling grid (x = u W - 0.5, corners floor / +1)."""
+    b, n = mask.shape[0], mask.shape[1]
+    vis = mask.bool()
+    rows = torch.arange(b * n, device=mask.device).view(b, n, 1, 1, 1).expand_as(mask)[vis].long()
+    u, v = uv[..., 0][vis], uv[..., 1][vis]
+    total = 0
+    for (h, w) in shapes:
+        x, y = u * w - 0.5, v * h - 0.5
+        x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+        keys = []
+        for dx in (0, 1):
+            for dy in (0, 1):
+                xi, yi = x0 + dx, y0 + dy
+                ok = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)
+                keys.append(((rows * h + yi) * w + xi)[ok])
+        total += int(torch.unique(torch.cat(keys)).numel())
+    return total
+
+
 def _pmc_traffic(a, source, pattern):
     """PMC cannot be read from inside the bench: `traffic` comes from a committed rocprofv3 --pmc pass of the kernel on this
     workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; tools/prof_pmc.sh).  The record carries
@@ -619,7 +655,7 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
         return orig_early(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, order=order)
 
     def spy_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, **vp):
-        late_cap.append(dict(cl=self.cl, shapes=self.shapes, module=module, ref=ref.contiguous(), offsets=offsets.contiguous(),
+        late_cap.append(dict(late=self, cl=self.cl, shapes=self.shapes, module=module, ref=ref.contiguous(), offsets=offsets.contiguous(),
                              attn=attn_logits.contiguous(), cam=cam_logits.contiguous(), l2i=lidar2img, pc_range=module.pc_range,
                              img_h=img_h, img_w=img_w, order=order, vp=vp))
         return orig_late(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order, **vp)
@@ -695,82 +731,121 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
         except Exception as ex:                               # secondary figure: report, never fail the bench line
             kernels['cross_attn_fwd_all_visible'] = {'error': f'{type(ex).__name__}: {ex}'}
     else:
-        # ---------------- aggregate-then-project: gd4d_cross_attn_agg_fwd ----------------
-        # Algorithmic bytes of a launch: SURVEY.md 8(d) with the bytes this formulation reads per corner - all C channels
-        # of the pixel (what 8(d) itself writes for the kernels that gather whole pixels, a9 / a10: V' * 4 * C * e) - and
-        # 8(d)'s cap: "if V-bytes exceed the map size, cap at map bytes" (every touched byte read once).  At the headline
-        # size V * 4 * C * 4 = 2.0 GB > the 757-MB pyramid, so the figure is the pyramid + the query-side terms + the
-        # aggregates written.  The 8(d) figure of the projected-value form (V * 4 * Dh * e, 245 MB) is reported beside it.
-        calls, per_layer, tot, tot_dh = [], [], 0.0, 0.0
+        # ---------------- aggregate-then-project: the step's gather of RAW features ----------------
+        # roofline.frac is SURVEY.md 8(d) verbatim: V * 4 corners * Dh * e + the query-side terms + the output, V counted from
+        # the kernel's own bit-exact mask - the bytes the reference's formulation (gather of PROJECTED values) would have
+        # to move.  This formulation deliberately gathers all C = 8 Dh channels of a corner (so that value_proj over the
+        # pyramid disappears from the step); what it moves is reported beside it: gathered_bytes (V * 4 * C * e, uncapped),
+        # unique_bytes (every touched (pixel, 128-byte line) once - the compulsory HBM reads of a launch) and the counter
+        # traffic of the committed PMC pass.
+        sliced = late_cap[0]['late'].mode == 'sliced'
+        calls, per_layer, tot8d, tot_c, tot_u = [], [], 0.0, 0.0, 0.0
+        plan_calls = []
         for c in late_cap:
-            # (as the step launches it: with value_proj of the aggregates in the epilogue when the step does that)
-            run = (lambda c: (lambda **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], c['ref'], c['offsets'], c['attn'], c['cam'],
-                                                                  c['l2i'], c['pc_range'], c['img_h'], c['img_w'], hh,
-                                                                  query_order=c['order'], **c['vp'], **kw)))(c)
-            mask = run(want_mask=True)[-1]
+            if sliced:
+                plan, mask, uv = ops.cross_attn_plan_fwd(c['late'].pyramid, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], c['pc_range'],
+                                                         c['img_h'], c['img_w'], hh, query_order=c['order'], want_mask=True, want_uv=True)
+                agg_buf = ops.cross_attn_agg_sliced_fwd(plan)
+                calls.append((lambda plan, agg_buf: (lambda: ops.cross_attn_agg_sliced_fwd(plan, agg=agg_buf)))(plan, agg_buf))
+                plan_calls.append((lambda c, plan: (lambda: ops.cross_attn_plan_fwd(
+                    c['late'].pyramid, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], c['pc_range'], c['img_h'], c['img_w'], hh,
+                    query_order=c['order'], plan=plan)))(c, plan))
+                es = c['late'].pyramid.tensors[0].element_size()
+            else:
+                # (as the step launches it: with value_proj of the aggregates in the epilogue when the step does that)
+                run = (lambda c: (lambda **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], c['ref'], c['offsets'], c['attn'], c['cam'],
+                                                                      c['l2i'], c['pc_range'], c['img_h'], c['img_w'], hh,
+                                                                      query_order=c['order'], **c['vp'], **kw)))(c)
+                res = run(want_mask=True, want_uv=True)
+                mask, uv = res[-2], res[-1]
+                calls.append(run)
+                es = c['cl'].element_size()                                     # 4, or 2 with value_dtype='bf16' (bf16 storage)
             b, n, q, _, p = mask.shape
             nl = len(c['shapes'])
             v = int(mask.sum().item()) * nl
-            es = c['cl'].element_size()                                         # 4, or 2 with value_dtype='bf16' (bf16 storage)
-            side = side_bytes(q, n, nl, p) + q * hh * 256 * 4 + q * hh * 4      # + agg and wsum written
-            alg = min(v * 4 * 256 * es, c['cl'].numel() * es) + side
-            calls.append(run)
-            per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg, corner_bytes=v * 4 * 256 * es,
-                                  alg_bytes_projected_value_form=min(v * 4 * (256 // hh) * es, c['cl'].numel() * es) + side_bytes(q, n, nl, p)))
-            tot += alg
-            tot_dh += per_layer[-1]['alg_bytes_projected_value_form']
+            pyramid_bytes = b * n * sum(h * w for h, w in c['shapes']) * 256 * es
+            side = side_bytes(q, n, nl, p)
+            alg8d = min(v * 4 * (256 // hh) * es, pyramid_bytes) + side
+            uniq = _unique_pixels(mask, uv, c['shapes']) * 256 * es
+            per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg8d,
+                                  gathered_bytes=v * 4 * 256 * es, unique_bytes=uniq))
+            tot8d += alg8d
+            tot_c += v * 4 * 256 * es
+            tot_u += uniq
         ms = _time_rounds(calls, rounds)
         launches = len(calls)
         for d in per_layer:
             d['us_mean'] = ms / launches * 1e3
-        traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn_late.hip', 'r*_pmc_cross_attn_agg.json')
-        roofline = dict(kernel='gd4d::cross_attn_agg_kernel (fused project + sample + per-head aggregate of raw features)',
-                        bound='hbm', achieved=tot / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=tot / ms / 1e6 / HBM_PEAK_GBS,
-                        traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=tot / launches,
-                        us_per_launch=ms / launches * 1e3, launches_per_step=launches,
-                        alg_bytes_rule='SURVEY 8(d) with C channels per corner, capped at the size of the channels-last pyramid (757 MB at the headline size in fp32)',
-                        frac_on_projected_value_form_bytes=tot_dh / ms / 1e6 / HBM_PEAK_GBS)
+        if sliced:
+            traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn_sliced.hip', 'r*_pmc_cross_attn_sliced.json')
+            kname = 'gd4d::cross_attn_agg_sliced_kernel (gather of raw features, one workgroup per (query, 32-channel slice); ' \
+                    'projection / mask / weights come from gd4d::cross_attn_plan_kernel, timed beside it)'
+            ms_plan = _time_rounds(plan_calls, rounds)
+            kernels['cross_attn_plan'] = dict(us_per_launch=ms_plan / launches * 1e3, launches_per_step=launches,
+                                              note='projection + mask + softmax + bilinear corners, once per (layer, query)')
+        else:
+            traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn_late.hip', 'r*_pmc_cross_attn_agg.json')
+            kname = 'gd4d::cross_attn_agg_kernel (fused project + sample + per-head aggregate of raw features)'
+        us = ms / launches * 1e3
+        roofline = dict(kernel=kname, bound='hbm', achieved=tot8d / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=tot8d / ms / 1e6 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source,
+                        alg_bytes_per_launch=tot8d / launches, us_per_launch=us, launches_per_step=launches,
+                        alg_bytes_rule='SURVEY 8(d) verbatim: V * 4 * Dh * e (V from the bit-exact mask, capped at the pyramid) + '
+                                       'Q * (3 + Hh*P*3 + Hh*L*P + N) * 4 + N * 64 + Q * C * 4',
+                        gathered_bytes_per_launch=tot_c / launches,
+                        frac_on_gathered_bytes=tot_c / ms / 1e6 / HBM_PEAK_GBS,
+                        unique_bytes_per_launch=tot_u / launches, frac_on_unique_bytes=tot_u / ms / 1e6 / HBM_PEAK_GBS,
+                        frac_on_counter_bytes=None if traffic is None else traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        note='this kernel gathers C = 8 Dh channels per corner (8 x the 8(d) bytes) so that value_proj over the '
+                             'pyramid (97 GFLOP + 757 MB written per layer) leaves the step; frac prices its time against the '
+                             '8(d) bytes all the same')
         kernels['cross_attn_agg_per_layer'] = per_layer
         with torch.no_grad():
-            # the two small kernels around it: the channels-last copy (once per sample) and value_proj of the aggregates
+            # the two small kernels around it: the per-sample copy of the pyramid and value_proj of the aggregates
             try:
-                cl = late_cap[0]['cl']
-                vals = [f.contiguous() for f in feats]
-                cus = torch.cuda.get_device_properties(cl.device).multi_processor_count
-                copy_cus = int(os.environ.get('GD4D_COPY_CUS') or max(8, (cus * 7 // 8) // 8 * 8))      # as Fn.LateValues launches it
-                ms_cl = _time_rounds([lambda: ops.pyramid_channels_last_fwd(vals, out=cl, max_cus=copy_cus, out_dtype=cl.dtype)], 5)
-                cl_bytes = cl.numel() * (4 + cl.element_size())                 # fp32 NCHW read, channels-last copy written
-                kernels['pyramid_channels_last'] = dict(us=ms_cl * 1e3, bytes=cl_bytes, gbs=cl_bytes / ms_cl / 1e6,
-                                                        frac=cl_bytes / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1,
-                                                        compute_units=copy_cus,
-                                                        note='alone on the device; in the step the first layer\'s query side runs on the other CUs')
-                c0 = late_cap[0]
-                m0 = c0['module']
-                agg0, wsum0 = ops.cross_attn_agg_fwd(c0['cl'], c0['shapes'], c0['ref'], c0['offsets'], c0['attn'], c0['cam'], c0['l2i'],
-                                                     c0['pc_range'], c0['img_h'], c0['img_w'], hh, query_order=c0['order'])
-                ms_hp = _time_rounds([lambda: ops.value_proj_heads_fwd(agg0, wsum0, m0.value_proj.weight, m0.value_proj.bias)], 20)
-                kernels['value_proj_heads'] = dict(us=ms_hp * 1e3, launches_per_step=0,
-                                                   note='stand-alone gd4d_value_proj_heads_fwd; in the step value_proj of the aggregates '
-                                                        'runs in the epilogue of gd4d_cross_attn_agg_fwd')
+                late0 = late_cap[0]['late']
+                cl = late0.cl
+                if cl is None:
+                    kernels['pyramid_copy'] = dict(us=0.0, launches_per_step=0, note='caller-owned channels-last levels are gathered in place: no copy')
+                else:
+                    vals = [f.contiguous() for f in feats]
+                    cus = torch.cuda.get_device_properties(cl.device).multi_processor_count
+                    copy_cus = int(os.environ.get('GD4D_COPY_CUS') or max(8, (cus * 7 // 8) // 8 * 8))      # as Fn.LateValues launches it
+                    copy = ops.pyramid_slice_planar_fwd if sliced else ops.pyramid_channels_last_fwd
+                    ms_cl = _time_rounds([lambda: copy(vals, out=cl, max_cus=copy_cus, out_dtype=cl.dtype)], 5)
+                    cl_bytes = cl.numel() * (4 + cl.element_size())             # fp32 NCHW read, channels-last copy written
+                    kernels['pyramid_copy'] = dict(kernel='gd4d_pyramid_slice_planar_fwd' if sliced else 'gd4d_pyramid_channels_last_fwd',
+                                                   us=ms_cl * 1e3, bytes=cl_bytes, gbs=cl_bytes / ms_cl / 1e6,
+                                                   frac=cl_bytes / ms_cl / 1e6 / HBM_PEAK_GBS, launches_per_step=1, compute_units=copy_cus,
+                                                   note='alone on the device; in the step the first layer\'s query side runs on the other CUs')
             except Exception as ex:
-                kernels['pyramid_channels_last'] = {'error': f'{type(ex).__name__}: {ex}'}
+                kernels['pyramid_copy'] = {'error': f'{type(ex).__name__}: {ex}'}
             # all-visible stress case of this kernel (8 x the bytes of the projected-value form per corner: its worst case)
             if not a.no_stress:
                 try:
                     c0 = late_cap[0]
                     ref_av, l2i_av, order_av = _all_visible_inputs(c0, ops)
-                    run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731
-                                                                    c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av,
-                                                                    **c['vp'], **kw)
-                    mask_av = run_av(c0, want_mask=True)[-1]
+                    if sliced:
+                        plan_av, mask_av = ops.cross_attn_plan_fwd(c0['late'].pyramid, ref_av, c0['offsets'], c0['attn'], c0['cam'], l2i_av,
+                                                                   c0['pc_range'], c0['img_h'], c0['img_w'], hh, query_order=order_av,
+                                                                   want_mask=True)
+                        agg_av = ops.cross_attn_agg_sliced_fwd(plan_av)
+                        av_calls = [lambda: ops.cross_attn_agg_sliced_fwd(plan_av, agg=agg_av)]
+                        es_ = c0['late'].pyramid.tensors[0].element_size()
+                    else:
+                        run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731
+                                                                        c['pc_range'], c['img_h'], c['img_w'], hh, query_order=order_av,
+                                                                        **c['vp'], **kw)
+                        mask_av = run_av(c0, want_mask=True)[-1]
+                        av_calls = [(lambda c: (lambda: run_av(c)))(c) for c in late_cap]
+                        es_ = c0['cl'].element_size()
                     nl_ = len(c0['shapes'])
                     v_av = int(mask_av.sum().item()) * nl_
-                    es_ = c0['cl'].element_size()
-                    alg_av = min(v_av * 4 * 256 * es_, c0['cl'].numel() * es_) + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
-                    ms_av = _time_rounds([(lambda c: (lambda: run_av(c)))(c) for c in late_cap], 3)
-                    us_av = ms_av / len(late_cap) * 1e3
+                    alg_av = v_av * 4 * (256 // hh) * es_ + side_bytes(mask_av.shape[2], mask_av.shape[1], nl_, mask_av.shape[4])
+                    ms_av = _time_rounds(av_calls, 3)
+                    us_av = ms_av / len(av_calls) * 1e3
                     kernels['cross_attn_agg_all_visible'] = dict(visible_frac=v_av / (mask_av.numel() * nl_), alg_bytes=alg_av,
-                                                                 corner_bytes=v_av * 4 * 256 * es_, us_per_launch=us_av,
+                                                                 gathered_bytes=v_av * 4 * 256 * es_, us_per_launch=us_av,
                                                                  gbs=alg_av / us_av / 1e3, frac=alg_av / us_av / 1e3 / HBM_PEAK_GBS,
                                                                  l2_level_gbs=v_av * 4 * 256 * es_ / us_av / 1e3)
                 except Exception as ex:

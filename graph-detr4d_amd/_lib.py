@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 27
+ABI_VERSION = 28
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -67,6 +67,8 @@ SIGNATURES = {
     'gd4d_row_chain2_fwd': (_i, [_vp, _i, _vp, _i, _i, _vp]),
     'gd4d_chain_weight_image_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_chain_weight_image': (_i, [_vp, _i, _i, _vp, _vp]),
+    'gd4d_chain_weight_image_exact_bytes': (_c.c_size_t, [_i, _i]),
+    'gd4d_chain_weight_image_exact': (_i, [_vp, _i, _i, _vp, _vp]),
     'gd4d_linear_sum_assignment_batch': (_i, [_vp] * 4 + [_i, _vp, _vp, _i]),
     'gd4d_match_cost_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_f] * 3 + [_vp]),
     'gd4d_head_loss_fwd_bwd': (_i, [_vp] * 10 + [_i] * 7 + [_f] * 3 + [_vp]),

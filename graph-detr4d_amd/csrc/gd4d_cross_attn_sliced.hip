@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
   float* s_mat = reinterpret_cast<float*>(s_uv + p.N * E);                   // [N][12]
   float* s_cw = s_mat + p.N * 12;                                            // [N]
   float* s_aw = s_cw + ((p.N + 3) & ~3);                                     // [B][HH][LP] softmax weights per logit batch
-  uint8_t* s_items = reinterpret_cast<uint8_t*>(s_aw + p.B * HH * LP);       // [WAVES][N * PT]: camera * PT + point
+  float4* s_items = reinterpret_cast<float4*>(s_aw + ((p.B * HH * LP + 3) & ~3));   // [WAVES][N * PT]: {u, v, row * PT + point, camera weight}
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   trace_mark(g_trace_sliced, 5ull);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
   __syncthreads();
   // wave w: heads w, w + WAVES, ...: compact the visible (camera, point) pairs, then one pass = 4 items x 4 levels x 4 corners
   const int ncand = p.N * PT;
-  uint8_t* items = s_items + wave * ncand;
+  float4* items = s_items + wave * ncand;
   const int sub = lane >> 4, l_of = (lane >> 2) & 3, c_of = lane & 3;       // this lane's (item % 4, level, corner)
   int lw = pp.g.lvl_w[0], lh = pp.g.lvl_h[0];
   unsigned cstr = pp.g.cam_stride[0];
@@ -147,23 +147,27 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
     int M = 0;
     for (int c0 = 0; c0 < ncand; c0 += GD4D_WAVE) {
       const int cand = c0 + lane;
-      const bool vis = cand < ncand && s_uv[(min(cand, ncand - 1) / PT) * E + h * PT + (cand % PT)].x >= 0.f;
+      const int n = min(cand, ncand - 1) / PT, k = cand % PT;
+      const float2 uvc = s_uv[n * E + h * PT + k];
+      const bool vis = cand < ncand && uvc.x >= 0.f;
       const unsigned long long bal = __ballot(vis);
-      if (vis) items[M + __popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)cand;
+      if (vis) items[M + __popcll(bal & ((1ull << lane) - 1ull))] = make_float4(uvc.x, uvc.y, __int_as_float((b * p.N + n) * PT + k), s_cw[n]);
       M += __popcll(bal);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // wave-private list: no workgroup barrier
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint2* out = pp.pair + ((size_t)pos * HH + h) * pp.cap_t * 64;
+    const float* aw_h = s_aw + h * LP + min(l_of, LT - 1) * PT;             // + (row % B) * HH * LP + point
     float wsum_lane = 0.f;
     for (int it0 = 0; it0 < M; it0 += 4) {
       const int item = it0 + sub;
-      const int cand = items[min(item, M - 1)];
-      const int n = cand / PT, k = cand % PT;
-      const float2 uv = s_uv[n * E + h * PT + k];
-      const int row = b * p.N + n;
-      const float wl = s_aw[((row % p.B) * HH + h) * LP + min(l_of, LT - 1) * PT + k] * s_cw[n];
+      const float4 rec = items[min(item, M - 1)];
+      const float2 uv = make_float2(rec.x, rec.y);
+      const int rk = __float_as_int(rec.z);
+      const int row = rk / PT, k = rk % PT;
+      const int lb = p.B == 1 ? 0 : row % p.B;                              // logits of batch (row % B) (:277)
+      const float wl = aw_h[lb * HH * LP + k] * rec.w;
       const float x = fmaf(uv.x, flw, -0.5f);
       const float y = fmaf(uv.y, flh, -0.5f);
       const float xf = floorf(x), yf = floorf(y);
@@ -434,27 +438,30 @@ extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, 
   const dim3 grid(B * Q);
   auto lds = [&](int LT) {
     return (size_t)N * Hh * kPoints * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
-           (size_t)B * Hh * LT * kPoints * sizeof(float) + (size_t)8 * N * kPoints;
+           (size_t)((B * Hh * LT * kPoints + 3) & ~3) * sizeof(float) + (size_t)8 * N * kPoints * sizeof(float4);
   };
   // one wave per head up to 8 heads (the heads' pass loops are the kernel's longest dependent chain)
-#define GD4D_PLAN_GO(HH_, LT_)                                                                                      \
-  hipLaunchKernelGGL((cross_attn_plan_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8)>), grid, dim3(64 * (HH_ < 8 ? HH_ : 8)), lds(LT_), s, pp)
-#define GD4D_PLAN_L(HH_)                         \
-  switch (L) {                                   \
-    case 1: GD4D_PLAN_GO(HH_, 1); break;         \
-    case 2: GD4D_PLAN_GO(HH_, 2); break;         \
-    case 3: GD4D_PLAN_GO(HH_, 3); break;         \
-    default: GD4D_PLAN_GO(HH_, 4); break;        \
+  auto go = [&](auto kern, int waves, size_t bytes) -> int {
+    if (bytes > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * waves), bytes, s, pp);
+    return check_launch();
+  };
+#define GD4D_PLAN_GO(HH_, LT_) return go(cross_attn_plan_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8)>, (HH_ < 8 ? HH_ : 8), lds(LT_))
+#define GD4D_PLAN_L(HH_)                  \
+  switch (L) {                            \
+    case 1: GD4D_PLAN_GO(HH_, 1);         \
+    case 2: GD4D_PLAN_GO(HH_, 2);         \
+    case 3: GD4D_PLAN_GO(HH_, 3);         \
+    default: GD4D_PLAN_GO(HH_, 4);        \
   }
-  if (lds(L) > 65536) return GD4D_EUNSUPPORTED;
+  if (lds(L) > 160 * 1024) return GD4D_EUNSUPPORTED;
   switch (Hh) {
-    case 4: GD4D_PLAN_L(4) break;
-    case 8: GD4D_PLAN_L(8) break;
-    default: GD4D_PLAN_L(16) break;
+    case 4: GD4D_PLAN_L(4)
+    case 8: GD4D_PLAN_L(8)
+    default: GD4D_PLAN_L(16)
   }
 #undef GD4D_PLAN_L
 #undef GD4D_PLAN_GO
-  return check_launch();
 }
 
 namespace gd4d {

@@ -86,10 +86,26 @@ __device__ __forceinline__ void rc_split8(const float* v, rc_u4& h, rc_u4& l) {
   h = rc_u4{hh[0], hh[1], hh[2], hh[3]};
   l = rc_u4{ll[0], ll[1], ll[2], ll[3]};
 }
+// 8 consecutive floats -> three bf16 pieces (x = hi + mid + lo to ~2^-25: GD4D_CHAIN_EXACT)
+__device__ __forceinline__ void rc_split8x3(const float* v, rc_u4& h, rc_u4& m, rc_u4& l) {
+  unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hh[i] = rc_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float r0 = v[2 * i] - __uint_as_float(hh[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u);
+    mm[i] = rc_cvt_pk_bf16(r0, r1);
+    ll[i] = rc_cvt_pk_bf16(r0 - __uint_as_float(mm[i] << 16), r1 - __uint_as_float(mm[i] & 0xffff0000u));
+  }
+  h = rc_u4{hh[0], hh[1], hh[2], hh[3]};
+  m = rc_u4{mm[0], mm[1], mm[2], mm[3]};
+  l = rc_u4{ll[0], ll[1], ll[2], ll[3]};
+}
 __device__ __forceinline__ rc_bf16x8 rc_frag(rc_u4 v) { return __builtin_bit_cast(rc_bf16x8, v); }
 
 // Weight image (gd4d_chain_weight_image): [tile t of 16 output columns][k-step s of 32][hi, lo][lane][8 bf16]; lane l of
 // a fragment holds W[n = 16 t + (l & 15)][k = 32 s + 8 (l >> 4) .. + 8] - the B operand of v_mfma_f32_16x16x32_bf16.
+// PLANES = 3 (gd4d_chain_weight_image_exact): [hi, mid, lo] - the operand of a GD4D_CHAIN_EXACT GEMM.
+template <int PLANES>
 __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __restrict__ w, char* __restrict__ img, int N, int K) {
   const int ksteps = K / 32;
   const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // fragment = t * ksteps + s
@@ -100,17 +116,30 @@ __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = n < N ? w[(size_t)n * K + 32 * s + 8 * (lane >> 4) + j] : 0.f;
-  rc_u4 h, l;
-  rc_split8(v, h, l);
-  char* dst = img + (size_t)frag * 2048 + lane * 16;
-  *reinterpret_cast<rc_u4*>(dst) = h;
-  *reinterpret_cast<rc_u4*>(dst + 1024) = l;
+  char* dst = img + (size_t)frag * (PLANES * 1024) + lane * 16;
+  if (PLANES == 3) {
+    rc_u4 h, m, l;
+    rc_split8x3(v, h, m, l);
+    *reinterpret_cast<rc_u4*>(dst) = h;
+    *reinterpret_cast<rc_u4*>(dst + 1024) = m;
+    *reinterpret_cast<rc_u4*>(dst + 2048) = l;
+  } else {
+    rc_u4 h, l;
+    rc_split8(v, h, l);
+    *reinterpret_cast<rc_u4*>(dst) = h;
+    *reinterpret_cast<rc_u4*>(dst + 1024) = l;
+  }
 }
 
 // GEMM over the workgroup's 16 rows: out[:, n] = act(sum_k in[:, k] * W[n, k] + bias[n]) (+ residuals), n < N.
 // Wave w owns columns [256 pass + RC_COLS w, + RC_COLS) of every pass; A fragments are split from the LDS buffer, the W fragments
 // come pre-split from the image (global / L2) through a register ring RC_DEPTH k-steps deep.
+// EXACT (GD4D_CHAIN_EXACT): both operands cut into THREE bf16 pieces and the six products of combined order <= 2 summed
+// (x y ~= sum_{i + j <= 2} x_i y_j, ~2^-24 relative: fp32-class), for the GEMMs whose outputs become reference points -
+// a point's error is multiplied by the 102-m range and the focal length before it selects pixels.
+template <bool EXACT>
 __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
+  constexpr int FRAG = EXACT ? 3072 : 2048;
   const int i16 = lane & 15, g = lane >> 4;
   const float* a_row = &bufs[op.src][i16][8 * g];
   const int K = op.K, N = op.N;
@@ -119,7 +148,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
     const char* wf[RC_TILES];                                  // tiles past the end re-read the last one (never stored)
 #pragma unroll
-    for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * 2048 + lane * 16;
+    for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * FRAG + lane * 16;
     rc4 acc[RC_TILES];
 #pragma unroll
     for (int c = 0; c < RC_TILES; ++c) acc[c] = rc4{0.f, 0.f, 0.f, 0.f};
@@ -132,20 +161,21 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) e_bias[c] = bias_p[min(n_base + 16 * c + i16, N - 1)] * bias_on;
     }
-    rc_u4 bh[RC_DEPTH][RC_TILES], bl[RC_DEPTH][RC_TILES];
+    rc_u4 bh[RC_DEPTH][RC_TILES], bl[RC_DEPTH][RC_TILES], bm[EXACT ? RC_DEPTH : 1][RC_TILES];
     auto issue = [&](int slot, int j) {
       if (RC_DBG & 2) return;
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) {
-        bh[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048);
-        bl[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * 2048 + 1024);
+        bh[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * FRAG);
+        if (EXACT) bm[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * FRAG + 1024);
+        bl[slot][c] = *reinterpret_cast<const rc_u4*>(wf[c] + (size_t)j * FRAG + (EXACT ? 2048 : 1024));
       }
     };
     if (RC_DBG & 2) {
 #pragma unroll
       for (int d = 0; d < RC_DEPTH; ++d)
 #pragma unroll
-        for (int c = 0; c < RC_TILES; ++c) { bh[d][c] = rc_u4{1u, 2u, 3u, (unsigned)lane}; bl[d][c] = bh[d][c]; }
+        for (int c = 0; c < RC_TILES; ++c) { bh[d][c] = rc_u4{1u, 2u, 3u, (unsigned)lane}; bl[d][c] = bh[d][c]; if (EXACT) bm[d][c] = bh[d][c]; }
     }
     // The workgroups of a launch run in lock step and stream the SAME weight image: un-rotated, the ~7 workgroups that
     // share an XCD ask one L2 channel for one fragment at the same instant and take turns (17 B/clk per CU measured).
@@ -160,6 +190,20 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
       const float4 t0 = *reinterpret_cast<const float4*>(a_row + 32 * j);
       const float4 t1 = *reinterpret_cast<const float4*>(a_row + 32 * j + 4);
       const float a[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      if (EXACT) {
+        rc_u4 ah, am, al;
+        rc_split8x3(a, ah, am, al);
+#pragma unroll
+        for (int c = 0; c < RC_TILES; ++c) {                   // smallest terms first
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(al), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bl[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(am), rc_frag(bm[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(am), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bm[d][c]), acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rc_frag(ah), rc_frag(bh[d][c]), acc[c], 0, 0, 0);
+        }
+        return;
+      }
       rc_u4 ah, al;
       rc_split8(a, ah, al);
       if (RC_DBG & 1) { asm volatile("" ::"v"(ah), "v"(al), "v"(bh[d][0]), "v"(bl[d][3])); return; }
@@ -475,7 +519,8 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
       }
       if (pp->ops[oi].kind != GD4D_CHAIN_GEMM && pp->ops[oi].kind != GD4D_CHAIN_HEADGEMM) continue;
       const char* img = reinterpret_cast<const char*>(pp->ops[oi].p0);
-      const unsigned chunks = (unsigned)((pp->ops[oi].N + 15) / 16) * (unsigned)(pp->ops[oi].K / 32) * 32u;   // 64-byte pieces
+      const unsigned chunks = (unsigned)((pp->ops[oi].N + 15) / 16) * (unsigned)(pp->ops[oi].K / 32) *
+                              ((pp->ops[oi].flags & GD4D_CHAIN_EXACT) ? 48u : 32u);   // 64-byte pieces (2 or 3 planes of 1 KB per fragment)
       const unsigned lo = (unsigned)((unsigned long long)chunks * mine / share), hi = (unsigned)((unsigned long long)chunks * (mine + 1) / share);
       for (unsigned c = lo + tid; c < hi; c += 64 * RC_WAVES) touch1(img + (size_t)c * 64);
     }
@@ -505,7 +550,10 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
         }
         break;
       }
-      case GD4D_CHAIN_GEMM: rc_gemm(op, bufs, m0, M, lane, wave); break;
+      case GD4D_CHAIN_GEMM:
+        if (op.flags & GD4D_CHAIN_EXACT) rc_gemm<true>(op, bufs, m0, M, lane, wave);
+        else rc_gemm<false>(op, bufs, m0, M, lane, wave);
+        break;
       case GD4D_CHAIN_HEADGEMM: rc_headgemm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_LAYERNORM: rc_layernorm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_ADD: rc_rows<true>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
@@ -562,7 +610,23 @@ extern "C" int gd4d_chain_weight_image(const float* weight, int N, int K, void* 
   if (K % 64 != 0) return GD4D_EUNSUPPORTED;
   if (!aligned16(image)) return GD4D_EALIGN;
   const int frags = ((N + 15) / 16) * (K / 32);
-  hipLaunchKernelGGL(chain_weight_image_kernel, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), weight,
+  hipLaunchKernelGGL(chain_weight_image_kernel<2>, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), weight,
+                     static_cast<char*>(image), N, K);
+  return check_launch();
+}
+
+extern "C" size_t gd4d_chain_weight_image_exact_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return (size_t)((N + 15) / 16) * (K / 32) * 3072;
+}
+
+extern "C" int gd4d_chain_weight_image_exact(const float* weight, int N, int K, void* image, void* stream) {
+  using namespace gd4d;
+  if (!weight || !image || N <= 0 || K <= 0) return GD4D_EINVAL;
+  if (K % 64 != 0) return GD4D_EUNSUPPORTED;
+  if (!aligned16(image)) return GD4D_EALIGN;
+  const int frags = ((N + 15) / 16) * (K / 32);
+  hipLaunchKernelGGL(chain_weight_image_kernel<3>, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), weight,
                      static_cast<char*>(image), N, K);
   return check_launch();
 }

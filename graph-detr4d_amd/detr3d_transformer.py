@@ -263,13 +263,25 @@ class Detr3DCrossAttenV2(nn.Module):
         return self.dropout(res) + query + pos_feat
 
 
+def _watch_weight_updates(module):
+    """The fused decoder loop caches MFMA-fragment images of its GEMM weights (ops.chain_weight_image), keyed on the
+    tensors' version counters.  Writes through `.data` (checkpoint loaders, mmcv's EMA hook) do not bump those: forget
+    the images whenever a state dict is loaded; train() / eval() do the same (below)."""
+    module.register_load_state_dict_post_hook(lambda m, incompatible: ops.invalidate_chain_images())
+
+
 @TRANSFORMER_LAYER_SEQUENCE.register_module()
 class Detr3DTransformerDecoder(TransformerLayerSequence):
     """Reference :153-225: loop over layers, refine reference points with reg_branches."""
 
     def __init__(self, *args, return_intermediate=False, **kwargs):
         super().__init__(*args, **kwargs)
+        _watch_weight_updates(self)
         self.return_intermediate = return_intermediate
+
+    def train(self, mode=True):
+        ops.invalidate_chain_images()        # mode switches bracket the weight updates that do not bump version counters (EMA swaps)
+        return super().train(mode)
 
     def _preproject_values(self, kwargs):
         """All layers get the same `value` pyramid and value_proj does not depend on the queries, so the decoder can
@@ -341,7 +353,7 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         fused = not args and kwargs.get('key') is None and kwargs.get('query_pos') is not None and 'img_metas' in kwargs \
             and kwargs.get('key_padding_mask') is None and kwargs.get('query_key_padding_mask') is None \
             and fused_decoder.applicable(self, query, kwargs.get('value'), reference_points, reg_branches,
-                                         kwargs.get('attn_masks'))
+                                         kwargs.get('attn_masks'), query_pos=kwargs.get('query_pos'))
         late, own_late, pipeline = kwargs.get(Fn.LATE_VALUES_KEY), False, None
         if late is not None and late.value is not kwargs.get('value'):
             late = None
@@ -443,6 +455,11 @@ class Detr3DTransformer(nn.Module):
         self.num_cams = num_cams
         self.two_stage_num_proposals = two_stage_num_proposals
         self.reference_points = nn.Linear(self.embed_dims, 3)
+        _watch_weight_updates(self)
+
+    def train(self, mode=True):
+        ops.invalidate_chain_images()
+        return super().train(mode)
 
     def init_weights(self):
         for p in self.parameters():
@@ -460,15 +477,15 @@ class Detr3DTransformer(nn.Module):
         query_pos, query = torch.split(query_embed, self.embed_dims, dim=1)
         from . import fused_decoder
         own_late = None
-        if fused_decoder.fast_input(self, query_embed, mlvl_feats) and kwargs.get(Fn.LATE_VALUES_KEY) is None \
-                and kwargs.get(Fn.VALUE_CACHE_KEY) is None:
+        fast = fused_decoder.fast_input(self, query_embed, mlvl_feats)
+        if fast and kwargs.get(Fn.LATE_VALUES_KEY) is None and kwargs.get(Fn.VALUE_CACHE_KEY) is None:
             # the channels-last copy of the pyramid needs nothing but the pyramid: fork it first, before the query side
             cross = [a for layer in self.decoder.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
             if cross and all(type(a) is Deform3DCrossAttn for a in cross) and Fn.LateValues.applicable(cross, mlvl_feats):
                 own_late = Fn.LateValues(mlvl_feats, cross[0].value_dtype)
                 kwargs = dict(kwargs)
                 kwargs[Fn.LATE_VALUES_KEY] = own_late
-        if fused_decoder.fast_input(self, query_embed, mlvl_feats):
+        if fast:
             # batch 1, inference: no copies - the column slices of query_embed go to the decoder as strided (Q, 1, C) views
             # and the initial reference points come from one chain launch (no library GEMM / sigmoid / cat in the step)
             reference_points = fused_decoder.initial_reference(self.reference_points, query_pos)

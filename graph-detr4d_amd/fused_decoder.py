@@ -49,9 +49,12 @@ def _plain_reg_branch(branch, c):
     return lins if lins[-1].out_features >= 5 and len(lins) <= 4 else None
 
 
-def applicable(decoder, query, value, reference_points, reg_branches, attn_masks):
-    if os.environ.get('GD4D_FUSED_DECODER', '1') == '0' or torch.is_grad_enabled() and (
-            query.requires_grad or any(p.requires_grad for p in decoder.parameters())):
+def applicable(decoder, query, value, reference_points, reg_branches, attn_masks, query_pos=None):
+    """The forward-only fused loop must not be taken when autograd has to see the call: a parameter, the queries, the
+    reference points OR THE FEATURE MAPS (a frozen decoder on a backbone that is being fine-tuned, input-gradient
+    analysis) requiring grad sends the call down the generic path, whose modules build the autograd graph."""
+    if os.environ.get('GD4D_FUSED_DECODER', '1') == '0' or Fn.wants_grad(
+            decoder, query, query_pos, reference_points, *(value if isinstance(value, (list, tuple)) else ())):
         return False
     if not query.is_cuda or query.dtype != torch.float32 or query.dim() != 3 or query.shape[1] != 1:
         return False
@@ -87,12 +90,14 @@ def _in_proj_ops(sa, x_pos_buf, x_buf, qkv):
 
 
 def initial_reference(linear, query_pos):
-    """sigmoid(Linear(query_pos)) (detr3d_transformer.py:133-134) as one chain launch.  query_pos (Q, C), rows may be
+    """sigmoid(Linear(query_pos)) (detr3d_transformer.py:133-134) as one chain launch, fp32-class products (GD4D_CHAIN_EXACT, as
+    the reg branches below): a reference point is multiplied by the 102-m range and a focal length before it selects pixels,
+    so the 2^-16 of a split-bf16 x3 product would move samples by hundredths of a pixel.  query_pos (Q, C), rows may be
     strided (a column slice of query_embed).  Returns (1, Q, 3)."""
     q = query_pos.shape[0]
     out = torch.empty(1, q, linear.out_features, device=query_pos.device, dtype=torch.float32)
     ops.row_chain_fwd([ops.chain_load(0, query_pos),
-                       ops.chain_gemm(0, linear.weight, linear.bias, out=out.view(q, -1), sigmoid=True)], q)
+                       ops.chain_gemm(0, linear.weight, linear.bias, out=out.view(q, -1), sigmoid=True, exact=True)], q)
     return out
 
 
@@ -101,7 +106,7 @@ def fast_input(module, query_embed, mlvl_feats):
     return (os.environ.get('GD4D_FUSED_DECODER', '1') != '0' and query_embed.is_cuda and query_embed.dtype == torch.float32
             and mlvl_feats[0].size(0) == 1 and query_embed.dim() == 2 and query_embed.stride(1) == 1
             and query_embed.shape[1] % 8 == 0 and (query_embed.shape[1] // 2) % 128 == 0
-            and not (torch.is_grad_enabled() and (query_embed.requires_grad or any(p.requires_grad for p in module.parameters()))))
+            and not Fn.wants_grad(module, query_embed, *mlvl_feats))
 
 
 def _position_features(ca, reference_points, q):
@@ -196,7 +201,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             lins, x_prev, ref_prev, new_ref = pending
             prog_b, src, tmp = [ops.chain_load(3, x_prev)], 3, (1, 2)
             for i, lin in enumerate(lins):
-                prog_b.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                prog_b.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
                 src = tmp[i % 2]
             park = 0 if src != 0 else 3
             prog_b.append(ops.chain_refine(src, ref_prev, new_ref, dst=park))
@@ -235,7 +240,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             if last:                                     # nothing follows: the last refinement closes chain B'
                 src, tmp = 3, (1, 2)
                 for i, lin in enumerate(lins):
-                    prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                    prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
                     src = tmp[i % 2]
                 prog.append(ops.chain_refine(src, ref, new_ref))
             else:
@@ -386,7 +391,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
             lins = _plain_reg_branch(reg_branches[lid], c)
             src, tmp = 3, (1, 2)
             for i, lin in enumerate(lins):
-                reg_prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins)))
+                reg_prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
                 src = tmp[i % 2]
             new_ref = ref_all[slot]                                                 # (1, Q, 3)
             reg_prog.append(ops.chain_refine(src, ref, new_ref))

@@ -939,7 +939,7 @@ class ChainOp(ctypes.Structure):
 
 
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM = 1, 2, 3, 4, 5, 6, 7
-CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID = 1, 2, 4
+CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT = 1, 2, 4, 8
 
 
 def _rows(t, name):
@@ -968,41 +968,52 @@ def chain_load(dst, x, x2=None, dst_col=0, inv_sigmoid=False):
 
 
 _CHAIN_IMAGES = {}
+_CHAIN_EPOCH = [0]
 
 
-def chain_weight_image(weight):
-    """The bf16 hi / lo MFMA-fragment image of a (N, K) fp32 weight (gd4d_chain_weight_image), cached while the weight
-    tensor (address, shape, version counter) does not change - one small launch after a load_state_dict or an optimizer
-    step, none in steady-state inference."""
+def invalidate_chain_images():
+    """Forget every cached weight image.  The cache notices re-assignment and in-place autograd-visible writes (a tensor's
+    version counter), but NOT writes through `.data` (p.data.copy_(), mmcv's EMA swap): call this after such an update -
+    the package's modules do it from train() / eval() and after load_state_dict."""
+    _CHAIN_IMAGES.clear()
+    _CHAIN_EPOCH[0] += 1
+
+
+def chain_weight_image(weight, exact=False):
+    """The bf16 hi / lo (exact: hi / mid / lo) MFMA-fragment image of a (N, K) fp32 weight (gd4d_chain_weight_image[_exact]),
+    cached while the weight tensor (address, shape, version counter) does not change - one small launch after a
+    load_state_dict or an optimizer step, none in steady-state inference.  Entries die with their tensor."""
     import weakref
     if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 2 or weight.stride(1) != 1 \
             or weight.stride(0) != weight.shape[1]:
         raise ValueError('chain weights must be dense (N, K) float32 GPU tensors')
     base = weight._base if weight._base is not None else weight
-    key = (weight.data_ptr(), tuple(weight.shape))
+    key = (weight.data_ptr(), tuple(weight.shape), bool(exact))
     hit = _CHAIN_IMAGES.get(key)
     if hit is not None and hit[0]() is base and hit[1] == base._version:
         return hit[2]
     lib = _lib.load()
     n, k = weight.shape
-    nbytes = lib.gd4d_chain_weight_image_bytes(n, k)
+    nbytes = (lib.gd4d_chain_weight_image_exact_bytes if exact else lib.gd4d_chain_weight_image_bytes)(n, k)
     if nbytes == 0:
         raise _lib.Gd4dError(f'chain GEMM: K = {k} must be a multiple of 64')
     img = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
     with torch.cuda.device(weight.device):
-        code = lib.gd4d_chain_weight_image(ctypes.c_void_p(weight.data_ptr()), n, k, ctypes.c_void_p(img.data_ptr()), _stream())
+        fn = lib.gd4d_chain_weight_image_exact if exact else lib.gd4d_chain_weight_image
+        code = fn(ctypes.c_void_p(weight.data_ptr()), n, k, ctypes.c_void_p(img.data_ptr()), _stream())
     _lib.check(code, 'gd4d_chain_weight_image')
-    _CHAIN_IMAGES[key] = (weakref.ref(base), base._version, img)
+    _CHAIN_IMAGES[key] = (weakref.ref(base, lambda _r, key=key: _CHAIN_IMAGES.pop(key, None)), base._version, img)
     return img
 
 
-def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False):
-    """act(buf[src] W^T + b) (+ buf[res]) -> buf[dst] and / or out.  weight (N, K) contiguous rows."""
-    img = chain_weight_image(weight)
+def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False, exact=False):
+    """act(buf[src] W^T + b) (+ buf[res]) -> buf[dst] and / or out.  weight (N, K) contiguous rows.  exact: fp32-class
+    products (GD4D_CHAIN_EXACT) instead of split-bf16 x3 - for outputs that become reference points."""
+    img = chain_weight_image(weight, exact)
     g, ldg = _rows(out, 'out')
     return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
-                   flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0), ldg=ldg, p0=img.data_ptr(),
-                   p1=None if bias is None else bias.data_ptr(), gout=g)
+                   flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0) | (CHAIN_EXACT if exact else 0), ldg=ldg,
+                   p0=img.data_ptr(), p1=None if bias is None else bias.data_ptr(), gout=g)
 
 
 def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):
@@ -1084,7 +1095,7 @@ def _on_tensor_device(fn):
     return wrapped
 
 
-_HOST_ONLY = {'linear_sum_assignment_batch', 'cross_attn_plan_bytes', 'chain_load', 'chain_gemm', 'chain_small_linear', 'chain_layernorm',
+_HOST_ONLY = {'linear_sum_assignment_batch', 'cross_attn_plan_bytes', 'invalidate_chain_images', 'chain_load', 'chain_gemm', 'chain_small_linear', 'chain_layernorm',
               'chain_add', 'chain_refine', 'row_chain_fwd', 'chain_weight_image'}
 for _name, _fn in list(globals().items()):
     if inspect.isfunction(_fn) and _fn.__module__ == __name__ and not _name.startswith('_') and _name not in _HOST_ONLY:

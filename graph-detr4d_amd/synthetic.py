@@ -86,7 +86,8 @@ def randomise_cross_attn_(module, seed=0):
     g = torch.Generator(device='cpu').manual_seed(seed + 13)
 
     def _n(p, std):
-        p.data.copy_((torch.randn(p.shape, generator=g) * std).to(p.device, p.dtype))
+        with torch.no_grad():                        # (not p.data.copy_: that would not bump the version the weight-image cache watches)
+            p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device, p.dtype))
     _n(module.attention_weights.weight, 0.05)
     if hasattr(module, 'cam_attention_weights'):
         _n(module.cam_attention_weights.weight, 0.05)
@@ -106,6 +107,7 @@ def randomise_all_(module, seed=0, std=0.05):
         if p.dim() == 1 and leaf == 'weight':              # LayerNorm gain
             r = r + 1.0
         if 'deform_sampling_offsets.bias' in name:         # keep the metre-scale head directions
-            r = p.data.cpu() + r
-        p.data.copy_(r.to(p.device, p.dtype))
+            r = p.detach().cpu() + r
+        with torch.no_grad():
+            p.copy_(r.to(p.device, p.dtype))
     return module

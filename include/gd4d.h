@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 27
+#define GD4D_ABI_VERSION 28
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -400,6 +400,10 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
 #define GD4D_CHAIN_RELU 1
 #define GD4D_CHAIN_INV_SIGMOID 2
 #define GD4D_CHAIN_SIGMOID 4        /* GEMM: sigmoid on the output (after the bias / ReLU, before the residual) */
+#define GD4D_CHAIN_EXACT 8          /* GEMM: fp32-class products - both operands cut into three bf16 pieces, the six products of
+                                       combined order <= 2 (~2^-24 relative); p0 = the image of gd4d_chain_weight_image_exact.  For
+                                       the GEMMs that produce reference points (initial reference, reg branch): a point's error is
+                                       multiplied by the 102-m range and the focal length before it selects pixels */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
@@ -416,6 +420,8 @@ typedef struct gd4d_chain_op {
 size_t gd4d_chain_op_bytes(void);
 size_t gd4d_chain_weight_image_bytes(int N, int K);
 int gd4d_chain_weight_image(const float* weight, int N, int K, void* image, void* stream);
+size_t gd4d_chain_weight_image_exact_bytes(int N, int K);
+int gd4d_chain_weight_image_exact(const float* weight, int N, int K, void* image, void* stream);
 int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream);
 /* Two independent programs over the same M rows in ONE launch (twice the workgroups, each half runs one program on its own
  * compute units): e.g. chain A of a decoder layer next to the previous layer's reg branch + refinement + this layer's

@@ -368,3 +368,95 @@ def test_requests_in_flight_on_their_own_streams_equal_one_at_a_time():
             torch.cuda.synchronize()
             for o, r in zip(outs, ref):
                 assert all(torch.equal(a, b) for a, b in zip(o, r))
+
+
+def _decoder_from_golden(name='decoder_deform'):
+    g = Golden(name)
+    m = g.meta
+    n = m['num_cams']
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                         embed_dims=256)],
+                         feedforward_channels=512, ffn_dropout=0.1,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    nn = torch.nn
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                        nn.Linear(256, 10)) for _ in range(m['num_layers'])])
+    regs.load_state_dict(g.state(prefix='reg.'), strict=True)
+    return g, tr, regs.to(DEV).eval()
+
+
+def test_fused_decoder_sees_weight_updates(monkeypatch):
+    """The fused loop caches MFMA images of its GEMM weights.  In-place updates that autograd sees (optimizer steps,
+    `with no_grad(): p.copy_()`) bump the version counter the cache watches; updates through `.data` (checkpoint loaders,
+    mmcv's EMA swap) do not - those are caught by load_state_dict and by the train() / eval() switches that bracket them.
+    After every kind of update the fused path must equal the generic path (GD4D_FUSED_DECODER=0), which reads the weights
+    directly."""
+    from graph_detr4d_amd import ops
+    g, tr, regs = _decoder_from_golden()
+    feats, qe, metas = [f.to(DEV) for f in g.feats()], g.t('query_embed').to(DEV), _metas(g)
+
+    def both():
+        with torch.no_grad():
+            fused = tr(feats, qe, reg_branches=regs, img_metas=metas)[0].clone()
+            monkeypatch.setenv('GD4D_FUSED_DECODER', '0')
+            generic = tr(feats, qe, reg_branches=regs, img_metas=metas)[0].clone()
+            monkeypatch.delenv('GD4D_FUSED_DECODER')
+        return fused, generic
+    f0, g0 = both()
+    torch.testing.assert_close(f0, g0, rtol=5e-4, atol=5e-4)
+    lin = tr.decoder.layers[0].ffns[0].layers[1]
+    # (a) version-bumping in-place write: picked up by the cache itself
+    with torch.no_grad():
+        lin.weight.mul_(1.5)
+    f1, g1 = both()
+    assert (g1 - g0).abs().max().item() > 1e-2
+    torch.testing.assert_close(f1, g1, rtol=5e-4, atol=5e-4)
+    # (b) a write through .data, bracketed by mode switches as an EMA hook's swap is
+    tr.train()
+    lin.weight.data.mul_(0.5)
+    tr.eval()
+    f2, g2 = both()
+    assert (g2 - g1).abs().max().item() > 1e-2
+    torch.testing.assert_close(f2, g2, rtol=5e-4, atol=5e-4)
+    # (c) load_state_dict (copies through .data as well)
+    sd = {k: v.clone() for k, v in tr.state_dict().items()}
+    sd['decoder.layers.0.ffns.0.layers.1.weight'] *= 2.0
+    tr.load_state_dict(sd, strict=True)
+    f3, g3 = both()
+    assert (g3 - g2).abs().max().item() > 1e-2
+    torch.testing.assert_close(f3, g3, rtol=5e-4, atol=5e-4)
+    # (d) the explicit call for anything else
+    regs[0][4].weight.data.mul_(3.0)
+    ops.invalidate_chain_images()
+    with torch.no_grad():
+        r_f = tr(feats, qe, reg_branches=regs, img_metas=metas)[2].clone()
+        monkeypatch.setenv('GD4D_FUSED_DECODER', '0')
+        r_g = tr(feats, qe, reg_branches=regs, img_metas=metas)[2].clone()
+    torch.testing.assert_close(r_f, r_g, rtol=1e-4, atol=1e-4)
+
+
+def test_frozen_decoder_still_gives_the_feature_maps_their_gradient():
+    """A frozen decoder (no parameter requires grad) on feature maps that DO require grad - fine-tuning the backbone,
+    input-gradient analysis: the forward-only fused loop must not be taken; the pyramid gets its gradient."""
+    from graph_detr4d_amd import fused_decoder
+    g, tr, regs = _decoder_from_golden()
+    for p in list(tr.parameters()) + list(regs.parameters()):
+        p.requires_grad_(False)
+    feats = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    qe, metas = g.t('query_embed').to(DEV), _metas(g)
+    assert not fused_decoder.fast_input(tr, qe, feats)
+    states, _, _ = tr(feats, qe, reg_branches=regs, img_metas=metas)
+    assert states.requires_grad
+    states.square().sum().backward()
+    assert all(f.grad is not None and f.grad.abs().max().item() > 0 for f in feats)
+    with torch.no_grad():                                     # same numbers as the inference path
+        ref = tr([f.detach() for f in feats], qe, reg_branches=regs, img_metas=metas)[0]
+    torch.testing.assert_close(states.detach(), ref, rtol=1e-3, atol=1e-3)

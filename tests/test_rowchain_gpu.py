@@ -161,3 +161,25 @@ def test_chain_rejects_bad_programs():
         ops.row_chain_fwd([ops.chain_load(0, x), ops.chain_gemm(0, w)], 20)
     with pytest.raises(ValueError):                                  # heads that do not divide into 32-column groups
         ops.chain_headgemm(torch.randn(20, 16, 256, device=DEV), torch.rand(20, 16, device=DEV), w)
+
+
+@pytest.mark.parametrize('m,k,n', [(900, 256, 256), (900, 256, 3), (37, 256, 10), (130, 512, 96)])
+def test_chain_gemm_exact_matches_fp64_to_fp32_class(m, k, n):
+    """GD4D_CHAIN_EXACT: three bf16 pieces per operand, six products - fp32-class (what a reference point needs: its error
+    is multiplied by the 102-m range and the focal length); two orders of magnitude below the split-bf16 x3 form."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + k + n)
+    x, w, b = torch.randn(m, k), torch.randn(n, k) * 0.08, torch.randn(n)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    out, out3 = torch.empty(m, n, device=DEV), torch.empty(m, n, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(0, xd), ops.chain_gemm(0, wd, bd, out=out, exact=True)], m)
+    ops.row_chain_fwd([ops.chain_load(0, xd), ops.chain_gemm(0, wd, bd, out=out3)], m)
+    ref = F.linear(x.double(), w.double(), b.double())
+    err, err3 = (out.cpu().double() - ref).abs().max().item(), (out3.cpu().double() - ref).abs().max().item()
+    fp32 = (F.linear(x, w, b).double() - ref).abs().max().item()           # what a plain fp32 GEMM on the host does
+    assert err < max(3e-6, 4 * fp32), (err, fp32)
+    assert err < err3 or err3 < 3e-6
+    # sigmoid epilogue (the initial reference points, detr3d_transformer.py:133-134)
+    sig = torch.empty(m, n, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(0, xd), ops.chain_gemm(0, wd, bd, out=sig, sigmoid=True, exact=True)], m)
+    assert (sig.cpu().double() - torch.sigmoid(ref)).abs().max().item() < max(1e-6, fp32)
