@@ -304,7 +304,9 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
               unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
+#ifdef GD4D_DEV
               if (p.dbg_wrap) px &= p.dbg_wrap;
+#endif
               val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(vbase + (size_t)px * (kChannels * ES)));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -371,7 +373,9 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
 #pragma unroll
         for (int j = 0; j < LT * 4; ++j) {
           unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
+#ifdef GD4D_DEV
               if (p.dbg_wrap) px &= p.dbg_wrap;
+#endif
           val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(vbase + (size_t)px * (kChannels * ES)));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -484,8 +488,12 @@ __global__ __launch_bounds__(64) void value_proj_heads_kernel(const HeadProjPara
 template <int HH>
 static int launch_agg(const CrossAttnParams& p, hipStream_t s, bool bf16) {
   const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
-  static int lds_pad = -1;                          // dev: GD4D_AGG_LDS_PAD bytes of unused LDS per workgroup (caps residency)
-  if (lds_pad < 0) { const char* e = getenv("GD4D_AGG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+  // The dev switches of this unit (GD4D_AGG_LDS_PAD: unused LDS per workgroup, caps residency; GD4D_AGG_VARIANT;
+  // GD4D_AGG_DBG_WRAP: wrapped pixel indices = an all-L2-hit run with WRONG results) exist in -DGD4D_DEV builds only.
+  int lds_pad = 0;
+#ifdef GD4D_DEV
+  { const char* e = getenv("GD4D_AGG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+#endif
   auto lds_bytes = [&](int LT) {
     return (size_t)lds_pad + (size_t)p.N * HH * kPoints * sizeof(float2) + (size_t)HH * LT * kPoints * sizeof(float) + (size_t)p.N * 12 * sizeof(float) +
            (size_t)((p.N + 3) & ~3) * sizeof(float) + (size_t)HH * sizeof(int) + (size_t)HH * p.N * kPoints;
@@ -493,8 +501,10 @@ static int launch_agg(const CrossAttnParams& p, hipStream_t s, bool bf16) {
   // dev A/B: GD4D_AGG_VARIANT bit 0: level-major walk (default item-major); bit 1: 4 waves per query, two heads per wave
   // (default: one wave per head - the heads of a query then work on the same camera at the same time, and what they
   // share at the coarse levels is still in the L2)
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GD4D_AGG_VARIANT"); variant = e ? atoi(e) : 0; }
+  int variant = 0;
+#ifdef GD4D_DEV
+  { const char* e = getenv("GD4D_AGG_VARIANT"); variant = e ? atoi(e) : 0; }
+#endif
   if (variant != 0 && p.vp_w) return GD4D_EUNSUPPORTED;       // the value_proj epilogue lives in the default form only
   auto go = [&](auto kern, int threads, size_t lds) {
     if (lds > 65536) (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
@@ -602,7 +612,9 @@ extern "C" int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* leve
     p.rng_lo[k] = static_cast<float>(pc_range[k]);
   }
   p.img_h = img_h; p.img_w = img_w;
-  { static long wrap = -1; if (wrap < 0) { const char* e = getenv("GD4D_AGG_DBG_WRAP"); wrap = e ? atol(e) : 0; } p.dbg_wrap = (unsigned)wrap; }
+#ifdef GD4D_DEV
+  { const char* e = getenv("GD4D_AGG_DBG_WRAP"); p.dbg_wrap = (unsigned)(e ? atol(e) : 0); }
+#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {

@@ -474,16 +474,20 @@ static int launch_sliced(const SlicedParams& p, int L, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * HH), lds, s, p);
     return check_launch();
   };
-  static int variant = -1;                          // dev A/B (GD4D_SLICED_VARIANT): 1 = 8 waves per SIMD, 5 = no feature loads
-  if (variant < 0) { const char* e = getenv("GD4D_SLICED_VARIANT"); variant = e ? atoi(e) : 0; }
-  if (HH == 8 && L == 4 && sizeof(VT) == 4) {
-    switch (variant) {
-      case 1: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 8, 0>);
-      case 2: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 4, 0>);
-      case 5: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 6, 3>);
-      default: break;
+#ifdef GD4D_DEV                                      // dev A/B (GD4D_SLICED_VARIANT): 1 / 2 = 8 / 4 waves per SIMD, 5 = no feature loads
+  {
+    const char* e = getenv("GD4D_SLICED_VARIANT");
+    const int variant = e ? atoi(e) : 0;
+    if (HH == 8 && L == 4 && sizeof(VT) == 4) {
+      switch (variant) {
+        case 1: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 8, 0>);
+        case 2: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 4, 0>);
+        case 5: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 6, 3>);
+        default: break;
+      }
     }
   }
+#endif
   constexpr int OCC = HH == 16 ? 4 : 6;                             // waves per SIMD
   switch (L) {
     case 1: return go(cross_attn_agg_sliced_kernel<HH, 1, VT, OCC, 0>);
@@ -520,7 +524,10 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
   p.order = query_order; p.agg = agg;
   p.BQ = B * Q; p.per_xcd = (B * Q + 7) / 8; p.cap_t = plan_cap_t(N, P);
   p.slice_lo = slice_lo; p.slice_n = slice_n;
-  { static int blk = -1; if (blk < 0) { const char* e = getenv("GD4D_SLICED_BLK"); blk = e ? atoi(e) : 0; } p.blk = blk > 0 && blk < p.per_xcd ? blk : p.per_xcd; }
+  p.blk = p.per_xcd;                                // one block = the XCD's whole sector: plain slice-major
+#ifdef GD4D_DEV
+  { const char* e = getenv("GD4D_SLICED_BLK"); const int blk = e ? atoi(e) : 0; if (blk > 0 && blk < p.per_xcd) p.blk = blk; }
+#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {

@@ -67,6 +67,17 @@ def sequential_autograd(module, x):
     return module(x)
 
 
+def dev_ablations():
+    """GD4D_ABLATE=mha,chain_a,agg,chain_b,copy skips launches (outputs stay UNINITIALISED: timing tools only).  It is
+    honoured only together with GD4D_DEV=1; set alone it raises instead of silently producing garbage."""
+    spec = os.environ.get('GD4D_ABLATE', '')
+    if not spec:
+        return ()
+    if os.environ.get('GD4D_DEV') != '1':
+        raise RuntimeError('GD4D_ABLATE leaves outputs uninitialised; it is a dev switch and needs GD4D_DEV=1')
+    return tuple(spec.split(','))
+
+
 def require_gpu(t, name):
     if not t.is_cuda:
         raise _lib.Gd4dError(f'{name} is on {t.device}: graph-detr4d_amd runs on the GPU only '
@@ -79,8 +90,8 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps, max=1) / (1 - x).clamp(min=eps, max=1))
 
 
-_L2I_BUFFERS = {}          # (device index, request slot, shape) -> [host copy, persistent device tensor]
-_REQUEST_SLOT = [0]
+_L2I_BUFFERS = {}          # (device index, request slot | stream, shape) -> [host copy, persistent device tensor]
+_REQUEST_SLOT = [None]     # None: no request_slot() active - the buffers are kept per HIP stream
 
 
 class request_slot:
@@ -89,7 +100,7 @@ class request_slot:
     matrices cannot change what another request's queued kernels read."""
 
     def __init__(self, slot):
-        self.slot, self.prev = int(slot), 0
+        self.slot, self.prev = int(slot), None
 
     def __enter__(self):
         self.prev, _REQUEST_SLOT[0] = _REQUEST_SLOT[0], self.slot
@@ -111,11 +122,24 @@ def lidar2img_device(img_metas, like):
     is capturing raises instead of baking stale matrices into the graph.
     """
     host = np.ascontiguousarray(np.asarray([m['lidar2img'] for m in img_metas]), dtype=np.float32)
-    key = (like.device.index, _REQUEST_SLOT[0], host.shape)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if torch.is_grad_enabled() and not capturing:
+        # autograd saves this tensor (CrossAttnFunction, matmul): an in-place refresh by a second forward before the first
+        # backward (losses summed over samples, a student pass with other metas) would trip the saved-tensor version
+        # check - a fresh tensor per call instead.  (Under capture the persistent buffer is what a replay needs.)
+        return torch.from_numpy(host).to(like.device)
+    # without an explicit request_slot() the buffers are per stream: concurrent streams cannot alias each other's matrices
+    slot = _REQUEST_SLOT[0] if _REQUEST_SLOT[0] is not None else ('stream', torch.cuda.current_stream(like.device).cuda_stream)
+    key = (like.device.index, slot, host.shape)
     entry = _L2I_BUFFERS.get(key)
     if entry is not None and np.array_equal(entry[0], host):
         return entry[1]
-    if torch.cuda.is_current_stream_capturing():
+    if capturing:
+        # a capture runs on its own stream: bake in the buffer an eager call (on whichever stream) filled with these very
+        # matrices - the one a later eager call with new metas on that stream refreshes before the next replay
+        for (dev_i, _, shape), other in _L2I_BUFFERS.items():
+            if dev_i == like.device.index and shape == host.shape and np.array_equal(other[0], host):
+                return other[1]
         raise RuntimeError('graph-detr4d_amd: img_metas[*][\'lidar2img\'] changed (or was never uploaded) while a '
                            'hipGraph is being captured; call the module once eagerly with these metas first')
     src = torch.from_numpy(host)
@@ -481,7 +505,7 @@ class LateValues:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
             src = [v.contiguous() for v in value]
-            if 'copy' in os.environ.get('GD4D_ABLATE', '').split(','):      # dev: skip the copy (see fused_decoder._ablate)
+            if 'copy' in dev_ablations():            # dev: skip the copy (see fused_decoder._ablate)
                 r = value[0].shape[0] * value[0].shape[1]
                 self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev, dtype=dtype)
                 self.mode = 'rows'

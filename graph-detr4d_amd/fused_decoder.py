@@ -31,7 +31,7 @@ ORDER = ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
 def _ablate(name):
     """dev: GD4D_ABLATE=mha,chain_a,agg,chain_b,copy - skip that launch (outputs stay uninitialised): what a kernel costs in
     the replayed step, gaps and cold-cache effects included (results are garbage)."""
-    return name in os.environ.get('GD4D_ABLATE', '').split(',')
+    return name in Fn.dev_ablations()
 
 
 def _plain_reg_branch(branch, c):
@@ -96,6 +96,9 @@ def initial_reference(linear, query_pos):
     strided (a column slice of query_embed).  Returns (1, Q, 3)."""
     q = query_pos.shape[0]
     out = torch.empty(1, q, linear.out_features, device=query_pos.device, dtype=torch.float32)
+    if query_pos.device.index != torch.cuda.current_device():
+        with torch.cuda.device(query_pos.device):
+            return initial_reference(linear, query_pos)
     ops.row_chain_fwd([ops.chain_load(0, query_pos),
                        ops.chain_gemm(0, linear.weight, linear.bias, out=out.view(q, -1), sigmoid=True, exact=True)], q)
     return out
@@ -258,6 +261,11 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
         order, order_pc_range, return_intermediate, late=None):
     """query / query_pos (Q, 1, C), rows may be strided; reference_points (1, Q, 3).  Returns the stacked per-layer
     outputs (NL, Q, 1, C) and reference points (NL, 1, Q, 3) (the last layer's only without return_intermediate)."""
+    if query.device.index != torch.cuda.current_device():
+        # the chain launches take no tensor argument their wrapper could read the device from: make the model's GPU current
+        with torch.cuda.device(query.device):
+            return run(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, pipeline,
+                       value_cache, order, order_pc_range, return_intermediate, late=late)
     q, _, c = query.shape
     dev = query.device
     layers = list(decoder.layers)

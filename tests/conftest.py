@@ -31,9 +31,8 @@ def pytest_sessionstart(session):
     mark = session.config.getoption('-m') or ''
     if 'gpu' not in mark or 'not gpu' in mark or os.environ.get('GD4D_SKIP_DP2_DRYRUN'):
         return
-    import torch
-    if torch.cuda.device_count() == 0:                      # (counting devices does not initialise the GPU)
-        return
+    if not os.path.exists('/dev/kfd'):                      # no GPU on this box; decided WITHOUT touching the HIP runtime:
+        return                                              # a child must not be started from a process that initialised it
     env = dict(os.environ, GD4D_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--mode', 'train', '--levels',

@@ -3,7 +3,8 @@
 #   1. default bench line            -> gpurun_out/<tag>/bench.json
 #   2. rocprofv3 kernel stats of the SAME command -> gpurun_out/<tag>/stats/
 #   3. PMC passes (HBM traffic FETCH_SIZE / WRITE_SIZE in separate passes, L2 hits, wait buckets) of the step's gather
-#      (gd4d_cross_attn_agg_fwd, tools/bench_late.py) and of the projected-value gather (tools/bench_kernel.py)
+#      (gd4d_cross_attn_agg_sliced_fwd, tools/bench_sliced.py), of its one-workgroup-per-query form (tools/bench_late.py) and of
+#      the projected-value gather (tools/bench_kernel.py); issue / MFMA / LDS counters of the row chains and the attention core
 tag=${1:-round}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -22,7 +23,7 @@ t=$(find gpurun_out/$tag/tl -name '*kernel_trace.csv' | head -1)
 python3 tools/step_timeline.py $t > gpurun_out/$tag/step_timeline.txt 2>&1
 find gpurun_out/$tag/tl -name '*kernel_trace.csv' -delete
 python3 tools/trace_step.py > gpurun_out/$tag/step_timeline_device.txt 2>&1
-for which in agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
+for which in sliced:tools/bench_sliced.py:--iters:3 agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
   name=${which%%:*}; cmd=$(echo ${which#*:} | tr ':' ' ')
   mkdir -p gpurun_out/$tag/pmc_$name
   i=0
@@ -33,4 +34,7 @@ for which in agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters
   done
   python3 tools/pmc_summary.py gpurun_out/$tag/pmc_$name > /dev/null
 done
-grep -A 14 "cross_attn_agg" gpurun_out/$tag/pmc_agg/pmc_summary.txt | head -16
+grep -A 14 "cross_attn_agg_sliced" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | head -16
+# the query side of the step (row chains, attention core): issue / MFMA / LDS / wait counters, one sample in flight
+bash tools/prof_pmc.sh $tag/pmc_step bench.py --inflight 1 --no-roofline --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+grep -A 40 "row_chain_kernel\|mha_core_kernel" gpurun_out/$tag/pmc_step/pmc_summary.txt | head -100
