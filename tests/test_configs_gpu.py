@@ -351,3 +351,37 @@ def test_config3_two_rank_training_step_dry_run(request):
     assert line['allreduce_bytes_per_step'] == sum(line['allreduce_buckets']) > 1e6
     assert len(line['allreduce_buckets']) == 4              # reg branches, decoder layer 1, layer 0, the rest (reference_points)
     assert 'configs[3]' in line['config']['baseline_config']
+
+
+def _one_line(res):
+    import json
+    assert res is not None, 'the two-rank dry run was not started (no GPU visible at session start?)'
+    assert res['rc'] == 0, res['err']
+    lines = [ln for ln in res['out'].splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res['out']                      # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_config3_two_rank_training_step_with_overlapped_all_reduce_dry_run(request):
+    """The same two-rank step with --overlap-comm: per-decoder-layer gradient buckets all-reduced from autograd hooks in
+    reverse layer order underneath the backward (apis/mmdet_distill_train.py:78-82 is DDP's bucketed overlap).  gloo on one
+    GPU: the path runs and describes itself; what RCCL over xGMI hides is UNMEASURED until a multi-GPU record exists."""
+    line = _one_line(request.config._gd4d_dp2_overlap)
+    assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['scaling'] == 'weak'
+    assert line['allreduce_bytes_per_step'] == sum(line['allreduce_buckets']) > 1e6 and len(line['allreduce_buckets']) == 4
+    assert line['config'].get('overlap_comm') is True
+    plain = _one_line(request.config._gd4d_dp2_dryrun)
+    assert line['allreduce_bytes_per_step'] == plain['allreduce_bytes_per_step']
+
+
+def test_two_rank_inference_line_describes_itself(request):
+    """`bench.py --gpus 2 --inflight 2` (replicas; no collective on the data path): value = samples of all ranks and all
+    requests in flight per second, per-rank min / max beside the MAX-reduced step, batch-1 fields present."""
+    line = _one_line(request.config._gd4d_dp2_infer)
+    assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['scaling'] == 'weak' and line['allreduce_bytes_per_step'] == 0
+    cfg = line['config']
+    assert cfg['inflight'] == 2 and cfg['samples_per_step'] == 4 and cfg['global_batch'] == 4 and 'replicas x2' in cfg['parallelism']
+    assert abs(line['value'] - cfg['samples_per_step'] * 1e3 / line['ms_per_step']) < 1e-6 * line['value']
+    assert 0 < line['ms_per_step_rank_min'] <= line['ms_per_step_rank_max'] <= line['ms_per_step'] * 1.0001
+    assert line['value_batch1'] > 0 and abs(line['value_batch1'] - 2 * 1e3 / line['ms_per_sample_batch1']) < 1e-6 * line['value_batch1']
+    assert line['eager_ms_per_sample'] > 0 and line['roofline'] is None and line['cpu_baseline'] is None
