@@ -214,11 +214,12 @@ class PyramidView:
         if t.dim() not in (4, 5) or t.shape[-3] != 256:
             return False
         c, h, w = t.shape[-3:]
-        if t.stride(-3) != 1 or t.stride(-1) != c or t.stride(-2) != w * c:
-            return False
+        want = {-3: 1, -1: c, -2: w * c}
         if t.dim() == 5:
-            return t.stride(1) == h * w * c and (t.shape[0] == 1 or t.stride(0) == t.shape[1] * h * w * c)
-        return t.stride(0) == h * w * c
+            want[1], want[0] = h * w * c, t.shape[1] * h * w * c
+        else:
+            want[0] = h * w * c
+        return all(t.shape[d] == 1 or t.stride(d) == st for d, st in want.items())   # (the stride of a size-1 dim is free)
 
     @classmethod
     def channels_last_levels(cls, levels):

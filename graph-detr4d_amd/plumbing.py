@@ -67,12 +67,18 @@ class ImageFeatureExtractor(nn.Module):
 
     forward(img (B, N, 3, H, W) or (N, 3, H, W), img_metas) -> list of L tensors (B, N, C, H_l, W_l) fp32 on
     `out_device` (the reference's @auto_fp16(out_fp32=True): whatever precision the backbone ran in, the decoder
-    receives fp32).  Every meta gets `input_shape` = the image size fed to the backbone (:43-46)."""
+    receives fp32).  Every meta gets `input_shape` = the image size fed to the backbone (:43-46).
 
-    def __init__(self, backbone, neck=None, out_device=None):
+    channels_last=True: the same logical (B, N, C, H, W) tensors, STORED (B, N, H, W, C) - torch.channels_last on the
+    folded (B*N, C, H, W) maps, which is what a backbone run in channels_last memory format returns anyway.  The decoder's
+    cross-attention then gathers them in place (ops.PyramidView.channels_last_levels): the reference's per-layer
+    flatten / transpose / cat (deform3d_cross_attn.py:264-276) and this build's once-per-sample copy both disappear."""
+
+    def __init__(self, backbone, neck=None, out_device=None, channels_last=False):
         super().__init__()
         self.img_backbone, self.img_neck = backbone, neck
         self.out_device = out_device
+        self.channels_last = bool(channels_last)
 
     def forward(self, img, img_metas):
         if img is None:
@@ -92,6 +98,12 @@ class ImageFeatureExtractor(nn.Module):
         out = []
         for f in feats:
             bn, c, h, w = f.shape
-            f = f.view(b, bn // b, c, h, w).float()
-            out.append(f.contiguous() if self.out_device is None else f.to(self.out_device).contiguous())
+            f = f.float()
+            if self.out_device is not None:
+                f = f.to(self.out_device)
+            if self.channels_last:
+                f = f.contiguous(memory_format=torch.channels_last)       # (B*N, C, H, W) with strides (HWC, 1, WC, C): no-op if it already is
+                out.append(f.view(b, bn // b, c, h, w))
+            else:
+                out.append(f.contiguous().view(b, bn // b, c, h, w))
         return out

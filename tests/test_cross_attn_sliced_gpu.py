@@ -192,3 +192,59 @@ def test_full_size_sliced_equals_rows_and_early():
     # run-to-run identical (fixed summation order)
     agg2, wsum2 = _sliced(ops.PyramidView.slice_planar(sp, shapes), *args, order=order)
     assert torch.equal(agg, agg2) and torch.equal(wsum, wsum2)
+
+
+def test_transformer_on_channels_last_levels_equals_the_copied_path():
+    """Detr3DTransformer fed (B, N, C, H, W) levels stored channels-last: no copy kernel is launched (the gather reads the
+    caller's tensors through per-level pointers and strides) and the result is the copied path's, bit for bit - fp32 and,
+    with value_dtype='bf16' modules, bf16 levels (equal to the bf16 slice-planar copy of the fp32 levels)."""
+    import graph_detr4d_amd as G
+    from graph_detr4d_amd import functional as Fn, ops
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+
+    def build(value_dtype):
+        tr = G.build_transformer(dict(
+            type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+            decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                         transformerlayers=dict(
+                             type='DetrTransformerDecoderLayer',
+                             attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                        dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                             embed_dims=256, value_dtype=value_dtype)],
+                             feedforward_channels=512, ffn_dropout=0.1,
+                             operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+        tr.load_state_dict(g.state(), strict=True)
+        return tr.cuda().eval()
+    nn = torch.nn
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                        nn.Linear(256, 10)) for _ in range(m['num_layers'])])
+    regs.load_state_dict(g.state(prefix='reg.'), strict=True)
+    regs = regs.cuda().eval()
+    feats = [f.cuda() for f in g.feats()]
+    qe, metas = g.t('query_embed').cuda(), g.img_metas()
+    copies = []
+    orig = ops.pyramid_slice_planar_fwd
+
+    def counting(*a, **k):
+        copies.append(1)
+        return orig(*a, **k)
+    ops.pyramid_slice_planar_fwd = counting
+    try:
+        for value_dtype, store in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
+            tr = build(value_dtype)
+            nhwc = [f.to(store).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+            assert Fn.LateValues.applicable([tr.decoder.layers[0].attentions[1]], nhwc)
+            with torch.no_grad():
+                del copies[:]
+                want = tr(feats, qe, reg_branches=regs, img_metas=metas)
+                assert len(copies) == 1
+                got = tr(nhwc, qe, reg_branches=regs, img_metas=metas)
+                assert len(copies) == 1, 'channels-last levels must be gathered in place'
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), value_dtype
+            if value_dtype == 'fp32':
+                torch.testing.assert_close(got[0].cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+    finally:
+        ops.pyramid_slice_planar_fwd = orig

@@ -51,3 +51,20 @@ def test_config0_oracle_runs_on_cpu():
     _, _, mask = O.feature_sampling(c['feats'], init_ref, synthetic.PC_RANGE, c['metas'])
     frac = mask.float().mean().item()
     assert 0.05 < frac < 0.6, frac
+
+
+def test_extractor_can_hand_over_channels_last_levels():
+    """channels_last=True: the same values, stored (B, N, H, W, C) - what the decoder's gather reads in place
+    (ops.PyramidView.channels_last_levels) instead of re-laying the maps out (deform3d_cross_attn.py:264-276)."""
+    from graph_detr4d_amd import ops
+    c = config0()
+    ex = plumbing.ImageFeatureExtractor(c['extractor'].img_backbone, channels_last=True)
+    img = torch.randn(2, 3, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        nhwc = ex(img, [dict(), dict()])
+        nchw = c['extractor'](img, [dict(), dict()])
+    for a, b in zip(nhwc, nchw):
+        assert a.shape == b.shape and torch.equal(a, b)
+        assert ops.PyramidView.is_channels_last_level(a)
+        assert a.shape[-1] * a.shape[-2] == 1 or not ops.PyramidView.is_channels_last_level(b)   # (a 1 x 1 map is both)
+        assert a.permute(0, 1, 3, 4, 2).is_contiguous()                     # (B, N, H, W, C) in memory
