@@ -123,31 +123,35 @@ def lidar2img_device(img_metas, like):
     """
     host = np.ascontiguousarray(np.asarray([m['lidar2img'] for m in img_metas]), dtype=np.float32)
     capturing = torch.cuda.is_current_stream_capturing()
-    if torch.is_grad_enabled() and not capturing:
-        # autograd saves this tensor (CrossAttnFunction, matmul): an in-place refresh by a second forward before the first
-        # backward (losses summed over samples, a student pass with other metas) would trip the saved-tensor version
-        # check - a fresh tensor per call instead.  (Under capture the persistent buffer is what a replay needs.)
-        return torch.from_numpy(host).to(like.device)
     # without an explicit request_slot() the buffers are per stream: concurrent streams cannot alias each other's matrices
     slot = _REQUEST_SLOT[0] if _REQUEST_SLOT[0] is not None else ('stream', torch.cuda.current_stream(like.device).cuda_stream)
     key = (like.device.index, slot, host.shape)
     entry = _L2I_BUFFERS.get(key)
-    if entry is not None and np.array_equal(entry[0], host):
-        return entry[1]
-    if capturing:
-        # a capture runs on its own stream: bake in the buffer an eager call (on whichever stream) filled with these very
-        # matrices - the one a later eager call with new metas on that stream refreshes before the next replay
-        for (dev_i, _, shape), other in _L2I_BUFFERS.items():
-            if dev_i == like.device.index and shape == host.shape and np.array_equal(other[0], host):
-                return other[1]
-        raise RuntimeError('graph-detr4d_amd: img_metas[*][\'lidar2img\'] changed (or was never uploaded) while a '
-                           'hipGraph is being captured; call the module once eagerly with these metas first')
-    src = torch.from_numpy(host)
-    if entry is None:
-        entry = _L2I_BUFFERS[key] = [host.copy(), src.to(like.device)]
-    else:
-        entry[1].copy_(src)
-        entry[0] = host.copy()
+    if entry is None or not np.array_equal(entry[0], host):
+        if capturing:
+            # a capture runs on its own stream: bake in the buffer an eager call (on whichever stream) filled with these very
+            # matrices - the one a later eager call with new metas on that stream refreshes before the next replay
+            entry = None
+            for (dev_i, _, shape), other in _L2I_BUFFERS.items():
+                if dev_i == like.device.index and shape == host.shape and np.array_equal(other[0], host):
+                    entry = other
+                    break
+            if entry is None:
+                raise RuntimeError('graph-detr4d_amd: img_metas[*][\'lidar2img\'] changed (or was never uploaded) while a '
+                                   'hipGraph is being captured; call the module once eagerly with these metas first')
+        else:
+            src = torch.from_numpy(host)
+            if entry is None:
+                entry = _L2I_BUFFERS[key] = [host.copy(), src.to(like.device)]
+            else:
+                entry[1].copy_(src)
+                entry[0] = host.copy()
+    if torch.is_grad_enabled() and not capturing:
+        # autograd saves this tensor (CrossAttnFunction, matmul): an in-place refresh of the persistent buffer by a second
+        # forward before the first backward (losses summed over samples, a student pass with other metas) would trip the
+        # saved-tensor version check - hand out a private copy (1.5 KB device-to-device).  Under capture the persistent
+        # buffer itself is what a replay needs.
+        return entry[1].clone()
     return entry[1]
 
 
