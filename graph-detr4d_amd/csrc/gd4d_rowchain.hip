@@ -161,6 +161,21 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) e_bias[c] = bias_p[min(n_base + 16 * c + i16, N - 1)] * bias_on;
     }
+    // global addends p2 (+ p3) of the epilogue - the residual rows a LOAD operation would otherwise park in a buffer first:
+    // requested here, consumed after the K loop (their fabric round trip hides under the weight stream)
+    float e_add[RC_TILES][4];
+    if (op.p2) {
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c) {
+        const int n = min(n_base + 16 * c + i16, N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t m = (size_t)min(m0 + 4 * g + r, M - 1);
+          const float a2 = op.p2[m * op.ld2 + n];
+          e_add[c][r] = op.p3 ? a2 + op.p3[m * op.ld1 + n] : a2;
+        }
+      }
+    }
     rc_u4 bh[RC_DEPTH][RC_TILES], bl[RC_DEPTH][RC_TILES], bm[EXACT ? RC_DEPTH : 1][RC_TILES];
     auto issue = [&](int slot, int j) {
       if (RC_DBG & 2) return;
@@ -236,6 +251,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
         if (op.flags & GD4D_CHAIN_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         if (op.res >= 0) v += bufs[op.res][row][n];
+        if (op.p2) v += e_add[c][r];
         if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
         if (op.gout && m < M) op.gout[(size_t)m * op.ldg + n] = v;
       }
@@ -342,12 +358,17 @@ __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC
   constexpr int MAXCH = (RC_LD - 4) / 64;
   if (wave >= RC_M / 4) return;                                // 4 rows per wave: with more than 4 waves the rest wait at the barrier
   const int row = 4 * wave + (lane >> 4), l16 = lane & 15, N = op.N, nch = N / 64;
-  float4 gm[MAXCH], bt[MAXCH], x[MAXCH];
+  float4 gm[MAXCH], bt[MAXCH], x[MAXCH], ad[MAXCH];
+  // second output (res >= 0 with p2): buf[res] = result + p2[m, :] - the ADD operation that would follow (x + query_pos for
+  // the next projection), its global rows requested here with gamma / beta
+  const bool second = op.res >= 0 && op.p2;
+  const size_t m_ld = (size_t)min(m0 + row, M - 1);
 #pragma unroll
   for (int ch = 0; ch < MAXCH; ++ch) {
     const int n = min(64 * ch, N - 64) + 4 * l16;              // chunks past N repeat the last one (unused)
     gm[ch] = *reinterpret_cast<const float4*>(op.p0 + n);
     bt[ch] = *reinterpret_cast<const float4*>(op.p1 + n);
+    if (second) ad[ch] = *reinterpret_cast<const float4*>(op.p2 + m_ld * op.ld2 + n);
     x[ch] = *reinterpret_cast<const float4*>(&bufs[op.src][row][n]);
   }
   float s = 0.f;
@@ -379,6 +400,8 @@ __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (op.dst >= 0) *reinterpret_cast<float4*>(&bufs[op.dst][row][n]) = v;
     if (op.gout && m < M) *reinterpret_cast<float4*>(op.gout + (size_t)m * op.ldg + n) = v;
+    if (second)
+      *reinterpret_cast<float4*>(&bufs[op.res][row][n]) = make_float4(ad[ch].x + v.x, ad[ch].y + v.y, ad[ch].z + v.z, ad[ch].w + v.w);
   }
 }
 
@@ -644,7 +667,7 @@ static int rc_validate(const gd4d_chain_op* program, int nops) {
             (!aligned16(op.p0) || (op.ld0 & 3) || (op.p1 && (!aligned16(op.p1) || (op.ld1 & 3))))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_GEMM:
-        if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout) || op.p2) return GD4D_EINVAL;
+        if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout) || (op.p3 && !op.p2)) return GD4D_EINVAL;
         if (op.K % (32 * RC_DEPTH) != 0 || op.K > RC_LD - 4) return GD4D_EUNSUPPORTED;
         if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4)) return GD4D_EINVAL;
         if (op.dst >= 0 && op.dst == op.src) return GD4D_EINVAL;          // waves would overwrite rows others still read
@@ -660,6 +683,8 @@ static int rc_validate(const gd4d_chain_op* program, int nops) {
         if (!op.p0 || !op.p1 || op.src < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
         if (op.N % 64 != 0) return GD4D_EUNSUPPORTED;
         if (!aligned16(op.p0) || !aligned16(op.p1) || (op.gout && (!aligned16(op.gout) || (op.ldg & 3)))) return GD4D_EALIGN;
+        if (op.p2 && (op.res < 0 || op.res == op.src || op.res == op.dst)) return GD4D_EINVAL;    // second output: its own buffer
+        if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_ADD:
         if (op.src < 0 || op.dst < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.N & 3)) return GD4D_EINVAL;

@@ -191,11 +191,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         cam = torch.empty(1, q, ncam, device=dev, dtype=torch.float32)
         off = torch.empty(1, q, hh * npt * 3, device=dev, dtype=torch.float32)
         att = torch.empty(1, q, hh * nlv * npt, device=dev, dtype=torch.float32)
+        # (the residual x rides in out_proj's epilogue and x1 + pos leaves the LayerNorm as a second output: two operations
+        #  - two barriers and two exposed round trips - fewer than LOAD, GEMM, LAYERNORM, ADD; same values bit for bit)
         prog_a = [ops.chain_load(0, o.view(q, c)),
-                  ops.chain_load(3, x),
-                  ops.chain_gemm(0, sa.attn.out_proj.weight, sa.attn.out_proj.bias, dst=1, res=3),
-                  ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1),
-                  ops.chain_add(0, 2, c, add=pos),
+                  ops.chain_gemm(0, sa.attn.out_proj.weight, sa.attn.out_proj.bias, dst=1, add=x),
+                  ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1, dst2=0, add=pos),
                   ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
                   ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
                   ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
@@ -227,15 +227,17 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0)
         x3 = out_all[slot]
         prog = [first,
-                ops.chain_load(3, x1, pos_feat.view(q, c)),
+                ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336 (as GEMM addends: slower)
                 ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
                 ops.chain_layernorm(1, layer.norms[1], dst=2),
                 ops.chain_gemm(2, ffn.layers[0][0].weight, ffn.layers[0][0].bias, dst=0, relu=True),
-                ops.chain_gemm(0, ffn.layers[1].weight, ffn.layers[1].bias, dst=1, res=2),
-                ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c))]
+                ops.chain_gemm(0, ffn.layers[1].weight, ffn.layers[1].bias, dst=1, res=2)]
         if not last:
             qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
-            prog += [ops.chain_add(0, 3, c, add=pos)] + _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1))
+            prog += [ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c), dst2=0, add=pos)] + \
+                _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1))
+        else:
+            prog.append(ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c)))
         pending = None
         if reg_branches is not None:
             lins = _plain_reg_branch(reg_branches[lid], c)

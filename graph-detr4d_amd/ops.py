@@ -1007,14 +1007,21 @@ def chain_weight_image(weight, exact=False):
     return img
 
 
-def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False, exact=False):
-    """act(buf[src] W^T + b) (+ buf[res]) -> buf[dst] and / or out.  weight (N, K) contiguous rows.  exact: fp32-class
-    products (GD4D_CHAIN_EXACT) instead of split-bf16 x3 - for outputs that become reference points."""
+def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False, exact=False, add=None,
+               add2=None):
+    """act(buf[src] W^T + b) (+ buf[res]) (+ (add + add2)[m, :]) -> buf[dst] and / or out.  weight (N, K) contiguous rows.
+    add / add2: global (M, N) tensors added in the epilogue (their sum first, then onto the result - what a LOAD of
+    add + add2 into buf[res] would give, without the operation).  exact: fp32-class products (GD4D_CHAIN_EXACT) instead of
+    split-bf16 x3 - for outputs that become reference points."""
     img = chain_weight_image(weight, exact)
     g, ldg = _rows(out, 'out')
+    p2, ld2 = _rows(add, 'add')
+    p3, ld3 = _rows(add2, 'add2')
+    if p3 is not None and p2 is None:
+        raise ValueError('chain_gemm: add2 without add')
     return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
                    flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0) | (CHAIN_EXACT if exact else 0), ldg=ldg,
-                   p0=img.data_ptr(), p1=None if bias is None else bias.data_ptr(), gout=g)
+                   ld2=ld2, ld1=ld3, p0=img.data_ptr(), p1=None if bias is None else bias.data_ptr(), p2=p2, p3=p3, gout=g)
 
 
 def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):
@@ -1038,10 +1045,16 @@ def chain_small_linear(src, weight, bias, dst, relu=False, inv_sigmoid=False):
                    p1=None if bias is None else bias.data_ptr())
 
 
-def chain_layernorm(src, norm, dst=-1, relu=False, out=None):
+def chain_layernorm(src, norm, dst=-1, relu=False, out=None, dst2=-1, add=None):
+    """LayerNorm of buf[src] -> buf[dst] and / or out; with dst2 and add: also buf[dst2] = result + add[m, :] (the ADD
+    operation that would follow, e.g. x + query_pos for the next projection)."""
     g, ldg = _rows(out, 'out')
-    return ChainOp(kind=CHAIN_LAYERNORM, src=src, dst=dst, res=-1, N=norm.weight.shape[0], eps=float(norm.eps),
-                   flags=CHAIN_RELU if relu else 0, ldg=ldg, p0=norm.weight.data_ptr(), p1=norm.bias.data_ptr(), gout=g)
+    p2, ld2 = _rows(add, 'add')
+    if (p2 is None) != (dst2 < 0):
+        raise ValueError('chain_layernorm: dst2 and add go together')
+    return ChainOp(kind=CHAIN_LAYERNORM, src=src, dst=dst, res=dst2, N=norm.weight.shape[0], eps=float(norm.eps),
+                   flags=CHAIN_RELU if relu else 0, ldg=ldg, ld2=ld2, p0=norm.weight.data_ptr(), p1=norm.bias.data_ptr(),
+                   p2=p2, gout=g)
 
 
 def chain_add(dst, src, n, res=-1, add=None):

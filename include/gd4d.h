@@ -381,9 +381,11 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  *              GD4D_CHAIN_INV_SIGMOID
  *   GEMM       v = act(buf[src][:, :K] . W^T + bias), p0 = the IMAGE of W (N, K) made by gd4d_chain_weight_image (bf16 hi /
  *              lo halves in MFMA fragment order; gd4d_chain_weight_image_bytes(N, K) bytes, 16-byte aligned; rebuild it when
- *              W changes), bias = p1 or NULL, act = ReLU with GD4D_CHAIN_RELU; then v += buf[res] (res >= 0) and v += p2[m, n] (row stride ld2) if given; written to
+ *              W changes), bias = p1 or NULL, act = ReLU with GD4D_CHAIN_RELU; then v += buf[res] (res >= 0) and v += (p2[m, n] + p3[m, n])
+ *              (global addends, row strides ld2 / ld1; p3 optional) - residual rows without a LOAD operation in front; written to
  *              buf[dst][:, dst_col + n] (dst >= 0, dst != src) and / or gout[m, n] (row stride ldg).  K % 64 == 0, K <= 512.
- *   LAYERNORM  over N columns (N % 64 == 0) of buf[src]: gamma = p0, beta = p1, eps; ReLU with GD4D_CHAIN_RELU; to buf[dst] and / or gout
+ *   LAYERNORM  over N columns (N % 64 == 0) of buf[src]: gamma = p0, beta = p1, eps; ReLU with GD4D_CHAIN_RELU; to buf[dst] and / or gout;
+ *              with p2 (row stride ld2) and res >= 0 a second output buf[res] = result + p2[m, :] (the ADD that would follow)
  *   ADD        buf[dst] = buf[src] + buf[res] (res >= 0) + p2[m, :N]
  *   SMALL_LINEAR  buf[dst][:, :N] = act(buf[src][:, :K] . W^T + bias) for K <= 8 (position_encoder's first Linear)
  *   REFINE     reference-point refinement: src = reg-branch output (>= 5 columns), p0 = reference points (M, 3) in [0, 1],
