@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--input-layout', default='nchw', choices=['nchw', 'nhwc'],
                     help='memory layout of the resident feature levels: nchw = as the reference backbone hands them (the headline), '
                          'nhwc = channels-last levels, gathered in place without the per-sample copy')
+    ap.add_argument('--no-nhwc-figure', action='store_true', help='skip the second figure (channels-last levels gathered in place)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
     ap.add_argument('--inflight', type=int, default=2,
                     help="--mode infer: independent samples in flight per GPU, each on its own HIP stream with its own hipGraph "
@@ -259,6 +260,43 @@ def main():
         eager_steps = max(1, min(a.steps, 10))
         eager_ms = D.timed_steps(run_eager, eager_steps, 2, dev, {}) / eager_steps * 1e3
 
+        # ---- second figure: the same requests with the feature levels STORED channels-last (the FPN's output
+        # layout) - the cross-attention gathers them in place, the per-sample copy is not launched.  Same logical tensors,
+        # same results; the NCHW figure above stays the headline.
+        nhwc = None
+        if a.input_layout == 'nchw' and not a.no_nhwc_figure:
+            try:
+                reqs_cl = [([f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fi], qi) for fi, qi in reqs]
+                graphs_cl = []
+                for i in range(n_req):
+                    with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                        o_cl = tr(reqs_cl[i][0], reqs_cl[i][1], reg_branches=regs, img_metas=metas)
+                    torch.cuda.synchronize()
+                    torch.testing.assert_close(o_cl[0], eager_outs[i][0], rtol=0, atol=0)     # the layout does not change a result
+                    if graphs:
+                        g_i = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_i, stream=streams[i], capture_error_mode='thread_local'), Fn.request_slot(i):
+                            tr(reqs_cl[i][0], reqs_cl[i][1], reg_branches=regs, img_metas=metas)
+                        graphs_cl.append(g_i)
+
+                def run_cl(count):
+                    for i in range(count):
+                        with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                            if graphs_cl:
+                                graphs_cl[i].replay()
+                            else:
+                                tr(reqs_cl[i][0], reqs_cl[i][1], reg_branches=regs, img_metas=metas)
+                el_cl = D.timed_steps(lambda: run_cl(n_req), a.steps, a.warmup, dev, {})
+                one_cl = D.timed_steps(lambda: run_cl(1), a.steps, a.warmup, dev, {}) / a.steps * 1e3 if n_req > 1 else el_cl / a.steps * 1e3
+                nhwc = {'value': D.aggregate_throughput(n_req, a.steps, a.gpus, el_cl), 'unit': 'samples/s',
+                        'ms_per_step': el_cl / a.steps * 1e3, 'inflight': n_req, 'value_batch1': a.gpus * 1e3 / one_cl,
+                        'ms_per_sample_batch1': one_cl, 'launch': 'hipgraph' if graphs_cl else 'eager',
+                        'note': 'levels stored (B, N, H, W, C): gathered in place by gd4d_cross_attn_agg_sliced_fwd, no per-sample copy; '
+                                'outputs bit-identical to the NCHW run (checked)'}
+                del reqs_cl, graphs_cl
+            except Exception as e:                    # secondary figure: report, never fail the bench line
+                nhwc = {'error': f'{type(e).__name__}: {e}'}
+
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
     if rank == 0 and not a.no_roofline:
@@ -284,6 +322,7 @@ def main():
                             'the 1e-3 contract)',
             'value_batch1': a.gpus * 1e3 / single_ms, 'ms_per_sample_batch1': single_ms,
             'eager_ms_per_sample': eager_ms,
+            'channels_last_input': nhwc,
             'data': 'synthetic',
             'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
                                    f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
