@@ -131,10 +131,13 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
     }
   }
   __syncthreads();
-  // wave w: heads w, w + WAVES, ...: compact the visible (camera, point) pairs, then one pass = 4 items x 4 levels x 4 corners
+  // wave w: heads w, w + WAVES, ...: compact the visible (camera, point) pairs, then the corners: lane = (item % 16, level)
+  // works out the four corners of its (item, level) - 16 items per step of the wave (with lane = (item % 4, level, corner)
+  // the per-(item, level) arithmetic was done four times over: the pass loop was 2.2 M of the launch's 3.9 M vector
+  // instructions)
   const int ncand = p.N * PT;
   float4* items = s_items + wave * ncand;
-  const int sub = lane >> 4, l_of = (lane >> 2) & 3, c_of = lane & 3;       // this lane's (item % 4, level, corner)
+  const int i_of = lane >> 2, l_of = lane & 3;
   int lw = pp.g.lvl_w[0], lh = pp.g.lvl_h[0];
   unsigned cstr = pp.g.cam_stride[0];
 #pragma unroll
@@ -142,7 +145,8 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
     if (l_of == l) { lw = pp.g.lvl_w[l]; lh = pp.g.lvl_h[l]; cstr = pp.g.cam_stride[l]; }
   const float flw = (float)lw, flh = (float)lh;
   const float lvl_on = l_of < LT ? 1.f : 0.f;
-  const int slot = ((((sub & 1) << 2) | c_of) << 3) | ((sub >> 1) << 2) | l_of;   // [g][j]: g = (item & 1, corner), j = (item >> 1, level)
+  // where the four pairs of this lane go inside their pass: [g][j], g = (item & 1, corner), j = (item >> 1 & 1, level)
+  const int slot0 = (((i_of & 1) << 2) << 3) | (((i_of >> 1) & 1) << 2) | l_of;
   for (int h = wave; h < HH; h += WAVES) {
     int M = 0;
     for (int c0 = 0; c0 < ncand; c0 += GD4D_WAVE) {
@@ -159,28 +163,35 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint2* out = pp.pair + ((size_t)pos * HH + h) * pp.cap_t * 64;
     const float* aw_h = s_aw + h * LP + min(l_of, LT - 1) * PT;             // + (row % B) * HH * LP + point
+    const int m_pad = (M + 3) & ~3;                                         // whole passes: items past M repeat the last one, weight 0
     float wsum_lane = 0.f;
-    for (int it0 = 0; it0 < M; it0 += 4) {
-      const int item = it0 + sub;
+    for (int it0 = 0; it0 < M; it0 += 16) {
+      const int item = it0 + i_of;
       const float4 rec = items[min(item, M - 1)];
-      const float2 uv = make_float2(rec.x, rec.y);
       const int rk = __float_as_int(rec.z);
       const int row = rk / PT, k = rk % PT;
       const int lb = p.B == 1 ? 0 : row % p.B;                              // logits of batch (row % B) (:277)
       const float wl = aw_h[lb * HH * LP + k] * rec.w;
-      const float x = fmaf(uv.x, flw, -0.5f);
-      const float y = fmaf(uv.y, flh, -0.5f);
+      const float x = fmaf(rec.x, flw, -0.5f);
+      const float y = fmaf(rec.y, flh, -0.5f);
       const float xf = floorf(x), yf = floorf(y);
       const float dx = x - xf, dy = y - yf;
-      const int xi = (int)xf + (c_of & 1), yi = (int)yf + (c_of >> 1);
-      // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
-      const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
-      const float in = (item < M && xc == xi && yc == yi) ? lvl_on : 0.f;
-      const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
-      const float w = (wl * wx * wy) * in;
-      const unsigned off = (unsigned)row * cstr + (unsigned)(yc * lw + xc) * pp.g.pix_stride;
-      wsum_lane += w;
-      out[(size_t)(it0 >> 2) * 64 + slot] = make_uint2(off, __float_as_uint(w));
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float live = item < M ? lvl_on : 0.f;
+      const unsigned rbase = (unsigned)row * cstr;
+      uint2* dst = out + (size_t)(item >> 2) * 64 + slot0;
+#pragma unroll
+      for (int c_of = 0; c_of < 4; ++c_of) {
+        const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
+        // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
+        const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
+        const float in = (xc == xi && yc == yi) ? live : 0.f;
+        const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
+        const float w = (wl * wx * wy) * in;
+        const unsigned off = rbase + (unsigned)(yc * lw + xc) * pp.g.pix_stride;
+        wsum_lane += w;
+        if (item < m_pad) dst[c_of << 3] = make_uint2(off, __float_as_uint(w));
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wsum_lane += __shfl_xor(wsum_lane, o);
