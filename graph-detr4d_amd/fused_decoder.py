@@ -213,7 +213,10 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             ref = new_ref
         else:
             prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
-        ops.row_chain2_fwd(prog_a, prog_b, q)
+        if os.environ.get('GD4D_DEV_SWAP_PROGRAMS') == '1':     # dev: block 0 (the one tools/trace_step.py stamps) runs the second program
+            ops.row_chain2_fwd(prog_b, prog_a, q)
+        else:
+            ops.row_chain2_fwd(prog_a, prog_b, q)
 
         if late.mode != 'sliced' and os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
             # value_proj of the aggregates in the gather's epilogue: chain B' starts from one 1-KB row per query

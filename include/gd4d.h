@@ -387,7 +387,8 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  *   LAYERNORM  over N columns (N % 64 == 0) of buf[src]: gamma = p0, beta = p1, eps; ReLU with GD4D_CHAIN_RELU; to buf[dst] and / or gout;
  *              with p2 (row stride ld2) and res >= 0 a second output buf[res] = result + p2[m, :] (the ADD that would follow)
  *   ADD        buf[dst] = buf[src] + buf[res] (res >= 0) + p2[m, :N]
- *   SMALL_LINEAR  buf[dst][:, :N] = act(buf[src][:, :K] . W^T + bias) for K <= 8 (position_encoder's first Linear)
+ *   SMALL_LINEAR  buf[dst][:, :N] = act(buf[src][:, :K] . W^T + bias) for K <= 8 (position_encoder's first Linear); with
+ *              GD4D_CHAIN_INV_SIGMOID columns 8 .. 8 + K of buf[src] are used as scratch (the transformed inputs)
  *   REFINE     reference-point refinement: src = reg-branch output (>= 5 columns), p0 = reference points (M, 3) in [0, 1],
  *              gout = refined points (M, 3)
  *   HEADGEMM   value_proj of the per-head aggregates of gd4d_cross_attn_agg_fwd, read from GLOBAL memory (what
