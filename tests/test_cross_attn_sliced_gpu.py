@@ -248,3 +248,43 @@ def test_transformer_on_channels_last_levels_equals_the_copied_path():
                 torch.testing.assert_close(got[0].cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
     finally:
         ops.pyramid_slice_planar_fwd = orig
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_sliced_random_configurations_vs_plain_c_oracle(seed):
+    """Seeded random shapes (cameras 1 .. 64, queries 1 .. 200, 1 - 4 levels of odd sizes, 4 / 8 / 16 heads), reference points
+    that straddle the image borders and the eps plane, random rigs: agg / wsum through value_proj against the plain-C oracle
+    (oracle/gd4d_oracle.c) fed the projected values; mask and uv bit-exact."""
+    import numpy as np
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import c_oracle
+    from oracle import torch_oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    heads = int(rng.choice([4, 8, 16]))
+    nl = int(rng.integers(1, 5))
+    n = int(rng.choice([1, 2, 5, 6, 12, 24, 37, 64]))
+    q = int(rng.integers(1, 201))
+    levels = [(int(rng.integers(2, 34)), int(rng.integers(2, 50))) for _ in range(nl)]
+    torch.manual_seed(seed)
+    rig = synthetic.camera_rig((n + 5) // 6)[:n].copy()
+    rig[:, :3, 3] += rng.normal(0, 0.5, (n, 3)).astype(np.float32)          # jitter the translations
+    l2i = torch.from_numpy(rig).unsqueeze(0).contiguous()
+    feats = [torch.randn(1, n, 256, h, w) for h, w in levels]
+    w, bias = torch.randn(256, 256) * 0.06, torch.randn(256)
+    ref = torch.rand(1, q, 3)
+    ref[0, : q // 4] = torch.round(ref[0, : q // 4] * 8) / 8                # some points on coarse grid values
+    offsets = torch.randn(1, q, heads, 4, 3) * float(rng.choice([0.1, 2.0, 8.0]))
+    attn = torch.randn(1, q, heads, nl, 4) * 2
+    cam = torch.randn(1, q, n) * 2
+    flat, shapes = O.flatten_pyramid(feats)
+    val = torch.nn.functional.linear(flat, w, bias).view(n, -1, heads, 256 // heads).contiguous()
+    o_c, m_c, uv_c = c_oracle.cross_attn_fwd(val.numpy(), shapes, ref.numpy(), offsets.numpy(), attn.flatten(-2).numpy(), cam.numpy(),
+                                             l2i.numpy(), synthetic.PC_RANGE, 900, 1600)
+    dev = 'cuda'
+    sp, shp = ops.pyramid_slice_planar_fwd([f.to(dev) for f in feats])
+    order = ops.query_order_fwd(ref.to(dev), synthetic.PC_RANGE) if seed % 2 else None
+    agg, wsum, mask, uv = _sliced(ops.PyramidView.slice_planar(sp, shp), ref.to(dev), offsets.to(dev), attn.to(dev), cam.to(dev),
+                                  l2i.to(dev), synthetic.PC_RANGE, 900, 1600, heads=heads, order=order, want=True)
+    assert np.array_equal(mask.cpu().numpy(), m_c) and np.array_equal(uv.cpu().numpy(), uv_c)
+    out = ops.value_proj_heads_fwd(agg, wsum, w.to(dev), bias.to(dev))
+    np.testing.assert_allclose(out.cpu().numpy(), o_c, rtol=RTOL, atol=ATOL)
