@@ -57,8 +57,13 @@ class CrossAttnFunction(torch.autograd.Function):
         if ctx.cl is not None and (ctx.needs_input_grad[11] or ctx.needs_input_grad[12]):
             hh = value.shape[2]
             b, q, c = grad_out.shape
-            agg, wsum = ops.cross_attn_agg_fwd(ctx.cl, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
-                                               img_h, img_w, hh, query_order=ctx.order, raw_cam_weights=ctx.raw_cam)
+            if isinstance(ctx.cl, ops.PyramidView):          # plan + channel-sliced gather (the inference step's kernels)
+                plan = ops.cross_attn_plan_fwd(ctx.cl, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, hh,
+                                               query_order=ctx.order, raw_cam_weights=ctx.raw_cam)
+                agg, wsum = ops.cross_attn_agg_sliced_fwd(plan), plan.wsum
+            else:
+                agg, wsum = ops.cross_attn_agg_fwd(ctx.cl, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
+                                                   img_h, img_w, hh, query_order=ctx.order, raw_cam_weights=ctx.raw_cam)
             g = grad_out.view(b * q, hh, c // hh)
             gw = torch.einsum('qhd,qhc->hdc', g, agg.view(b * q, hh, c)).reshape(c, c)
             if ctx.has_bias:

@@ -344,7 +344,13 @@ def project_values_for_layers_autograd(modules, value):
     cl = None
     if os.environ.get('GD4D_TRAIN_VP_WGRAD', 'agg') == 'agg' and LateValues.applicable(modules, value, ignore_mode=True):
         with torch.no_grad():
-            cl = ops.pyramid_channels_last_fwd([v.detach().contiguous() for v in value])[0]
+            # (a PyramidView: the channel-sliced gather reads it; GD4D_AGG=rows keeps the pixel-major copy + gd4d_cross_attn_agg_fwd)
+            src = [v.detach().contiguous() for v in value]
+            if os.environ.get('GD4D_AGG', AGG_DEFAULT) == 'sliced':
+                sp, hw = ops.pyramid_slice_planar_fwd(src)
+                cl = ops.PyramidView.slice_planar(sp, hw)
+            else:
+                cl = ops.pyramid_channels_last_fwd(src)[0]
     outs = ValueProjMultiFunction.apply(-len(modules) if cl is not None else len(modules),
                                         *[m.value_proj.weight for m in modules],
                                         *[m.value_proj.bias for m in modules], *value)
@@ -554,15 +560,17 @@ class LateValues:
                   vp_bias=None):
         """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh); rows mode with vp_weight:
         (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
-        self._wait_copy()
         if self.mode == 'sliced':
+            # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
             plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                            cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
                                            query_order=order)
+            self._wait_copy()
             agg = ops.cross_attn_agg_sliced_fwd(plan)
             if vp_weight is not None:
                 return (ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, vp_bias),)
             return agg, plan.wsum
+        self._wait_copy()
         return ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                       cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
                                       module.num_heads, query_order=order, vp_weight=vp_weight, vp_bias=vp_bias)
