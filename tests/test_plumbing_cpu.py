@@ -68,3 +68,43 @@ def test_extractor_can_hand_over_channels_last_levels():
         assert ops.PyramidView.is_channels_last_level(a)
         assert a.shape[-1] * a.shape[-2] == 1 or not ops.PyramidView.is_channels_last_level(b)   # (a 1 x 1 map is both)
         assert a.permute(0, 1, 3, 4, 2).is_contiguous()                     # (B, N, H, W, C) in memory
+
+
+def test_pyramid_view_addresses_every_source_the_same_way():
+    """ops.PyramidView is pointers + byte strides (include/gd4d.h: address(level, row, pixel, slice, k) = level_ptr +
+    row * cam_stride + pixel * pix_stride + slice * slice_stride + k * elem).  Checked here on the host, byte for byte,
+    for the three sources the gather reads: the slice-planar copy, the pixel-major copy, channels-last levels in place."""
+    import ctypes
+    import numpy as np
+    from oracle import torch_oracle as O
+    from graph_detr4d_amd import ops
+    torch.manual_seed(5)
+    b, n = 2, 3
+    levels = [(5, 7), (3, 4), (1, 2)]
+    feats = [torch.randn(b, n, 256, h, w) for h, w in levels]
+    flat, shapes = O.flatten_pyramid(feats)                                   # (B*N, S, 256): the reference's flatten / transpose / cat
+    r, s = b * n, flat.shape[1]
+    sp = flat.reshape(r, s, 8, 32).permute(2, 0, 1, 3).contiguous()           # what gd4d_pyramid_slice_planar_fwd writes
+    cl = flat.reshape(r, s, 256).contiguous()                                 # what gd4d_pyramid_channels_last_fwd writes
+    nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+    views = {'planar': ops.PyramidView.slice_planar(sp, shapes), 'pixel': ops.PyramidView.pixel_major(cl, shapes),
+             'in place': ops.PyramidView.channels_last_levels(nhwc)}
+    starts = np.cumsum([0] + [h * w for h, w in shapes])
+
+    def read(addr):
+        return ctypes.c_float.from_address(addr).value
+    rng = np.random.default_rng(0)
+    for name, v in views.items():
+        assert v.rows == r and v.level_hw == [tuple(x) for x in shapes] and v.dtype == torch.float32
+        for _ in range(200):
+            lvl = int(rng.integers(len(levels)))
+            row, pix = int(rng.integers(r)), int(rng.integers(shapes[lvl][0] * shapes[lvl][1]))
+            sl, k = int(rng.integers(8)), int(rng.integers(32))
+            addr = v.ptrs[lvl] + row * v.cam_stride[lvl] + pix * v.pix_stride + sl * v.slice_stride + 4 * k
+            assert read(addr) == flat[row, starts[lvl] + pix, 32 * sl + k].item(), (name, lvl, row, pix, sl, k)
+    # what is NOT accepted
+    import pytest
+    with pytest.raises(ValueError):
+        ops.PyramidView.channels_last_levels(feats)                           # NCHW storage
+    with pytest.raises(ValueError):
+        ops.PyramidView.slice_planar(sp[:, :, :-1], shapes)                   # wrong pixel count
