@@ -45,7 +45,11 @@ def main():
     n0, n1, n2 = ln(c), ln(c), ln(c)
     out, qkv, ref, nref = g(q, c), g(q, 3 * c), torch.rand(q, 3, device=dev), torch.empty(q, 3, device=dev)
     cam, off, att = g(q, 24), g(q, 96), g(q, 128)
+    agg8, wsum8 = g(q, 8, c), torch.rand(q, 8, device=dev)
     progs = {
+        'HEADGEMM only (to global)': [ops.chain_headgemm(agg8, wsum8, w['o'], b['o'], out=out)],
+        'HEADGEMM + GEMM 256x256': [ops.chain_headgemm(agg8, wsum8, w['o'], b['o'], dst=0), ops.chain_gemm(0, w['o'], b['o'], out=out)],
+        'LOAD + GEMM + GEMM': [ops.chain_load(0, x), ops.chain_gemm(0, w['o'], b['o'], dst=1), ops.chain_gemm(1, w['o'], b['o'], out=out)],
         'one GEMM 256x256 (load + gemm to global)': [ops.chain_load(0, x), ops.chain_gemm(0, w['o'], b['o'], out=out)],
         'in_proj (2 loads, 2 GEMMs, N = 768)': [ops.chain_load(0, x, pos), ops.chain_load(1, x),
                                                  ops.chain_gemm(0, w['inp'][:512], b['inp'][:512], out=qkv[:, :512]),
