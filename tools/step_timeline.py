@@ -7,7 +7,7 @@ import sys
 
 def main():
     path = sys.argv[1]
-    marker = sys.argv[2] if len(sys.argv) > 2 else 'pyramid_channels_last'
+    marker = sys.argv[2] if len(sys.argv) > 2 else 'pyramid_'          # the per-sample copy: gd4d::pyramid_slice_planar_kernel (or _channels_last_)
     rows = list(csv.DictReader(open(path)))
     ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id', r.get('Queue_Id', '')))
                  for r in rows), key=lambda t: t[0])
