@@ -1,7 +1,10 @@
 """autograd.Function wrappers used when gradients are requested (training).
 
 Inference takes the fully fused HIP path (functional.py); with autograd enabled the modules switch to:
-  * CrossAttnFunction  - gd4d_cross_attn_fwd / gd4d_cross_attn_bwd (hand-written HIP both ways);
+  * PyramidSourceFunction + CrossAttnRawFunction - the inference step's kernels forward (slice-planar copy once, then per
+                         layer plan + channel-sliced gather + value_proj of the aggregates) and a backward on the RAW
+                         pyramid (gd4d_cross_attn_sliced_bwd.hip): no projected value tensor in either direction (default);
+  * CrossAttnFunction  - gd4d_cross_attn_fwd / gd4d_cross_attn_bwd on projected values (GD4D_TRAIN_VALUES=projected, bf16);
   * ValueProjFunction  - gd4d_value_proj_fwd / gd4d_value_proj_bwd_input + _bwd_weight (HIP both ways);
   * LinearFunction     - gd4d_linear_fwd forward, gd4d_linear_fwd with the transposed-weight flag for the input
                          gradient, gd4d_linear_bwd_weight for the weight / bias gradient;
@@ -69,6 +72,111 @@ class CrossAttnFunction(torch.autograd.Function):
             if ctx.has_bias:
                 gb = (g * wsum.view(b * q, hh, 1)).sum(0).reshape(c)
         return gv, gr, go, ga.view_as(attn_logits), gc, None, None, None, None, None, None, gw, gb, None
+
+
+class RawPyramid:
+    """What the layers of one training step share on the raw-pyramid path: the slice-planar copy (PyramidView) and - in the
+    backward - the sink that buckets the layers' (pixel, weight, grad_agg row) records (ops.PyramidGrad) plus the per-slice
+    dot-product workspace.  (The token that ties every layer's gather node to the pyramid's node is NOT kept here: the
+    autograd nodes hold this object, and a reference back to the graph would keep a step's graph alive into the next.)"""
+
+    def __init__(self):
+        self.pyramid = self.shapes = None
+        self.layers = 0
+        self._sink = self._dpart = None
+
+    def register(self):
+        self.layers += 1
+        return self.layers - 1
+
+    def sink(self, b, q, num_heads):
+        if self._sink is None:
+            self._sink = ops.PyramidGrad(self.pyramid, self.layers, b, q, num_heads)
+        return self._sink
+
+    def dpart(self, nbytes):
+        if self._dpart is None or self._dpart.numel() < nbytes:
+            self._dpart = torch.empty(nbytes, device=self.pyramid.device, dtype=torch.uint8)
+        return self._dpart
+
+
+class PyramidSourceFunction(torch.autograd.Function):
+    """token = apply(raw, *levels): the slice-planar copy of the NCHW levels (the reference's flatten / transpose / cat,
+    deform3d_cross_attn.py:264-276, once for all layers) lands in raw.pyramid; the returned 1-element token is what the
+    layers' CrossAttnRawFunction nodes take as their input, so this node's backward runs after ALL of them: it turns the
+    records they left in raw.sink into the gradient of the levels (gd4d_pyramid_grad_scan / _fill / _reduce)."""
+
+    @staticmethod
+    def forward(ctx, raw, *feats):
+        src = [f.contiguous() for f in feats]
+        sp, hw = ops.pyramid_slice_planar_fwd(src)
+        raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
+        raw.shapes = [tuple(f.shape) for f in feats]
+        ctx.raw = raw
+        ctx.set_materialize_grads(False)
+        return torch.empty(1, device=feats[0].device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, _):
+        raw = ctx.raw
+        if raw._sink is None or not raw._sink.plans:
+            return (None,) * (1 + len(raw.shapes))
+        grads = raw._sink.finish()
+        raw._sink = raw._dpart = None
+        return (None, *[g.view(shape) for g, shape in zip(grads, raw.shapes)])
+
+
+class CrossAttnRawFunction(torch.autograd.Function):
+    """out (B, Q, C) = value_proj of the per-head aggregates of the RAW pyramid (deform3d_cross_attn.py:220-324 with
+    value_proj commuted past the linear sampler): plan + channel-sliced gather + gd4d_value_proj_heads_fwd forward;
+    backward: gd4d_value_proj_heads_bwd, gd4d_cross_attn_dot_sliced, gd4d_cross_attn_plan_bwd for the query side, the
+    weight / bias gradient of value_proj from the saved aggregates, and the layer's records for the pyramid's gradient
+    (summed over the layers by PyramidSourceFunction's backward)."""
+
+    @staticmethod
+    def forward(ctx, token, ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, raw, pc_range, img_h, img_w,
+                raw_cam=False):
+        from . import functional as Fn
+        ref, offsets = ref.contiguous(), offsets.contiguous()
+        attn_logits, cam_logits = attn_logits.contiguous(), cam_logits.contiguous()
+        hh = offsets.shape[2]
+        order = Fn.query_order(ref, pc_range)
+        plan = ops.cross_attn_plan_fwd(raw.pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, hh,
+                                       query_order=order, raw_cam_weights=raw_cam)
+        agg = ops.cross_attn_agg_sliced_fwd(plan)
+        vp_weight = vp_weight.contiguous()
+        out = ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, None if vp_bias is None else vp_bias.contiguous())
+        ctx.save_for_backward(ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, agg, plan.wsum)
+        ctx.plan, ctx.raw, ctx.layer = plan, raw, raw.register()
+        ctx.meta = (pc_range, img_h, img_w, bool(raw_cam))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, agg, wsum = ctx.saved_tensors
+        pc_range, img_h, img_w, raw_cam = ctx.meta
+        plan, raw = ctx.plan, ctx.raw
+        b, q, c = grad_out.shape
+        hh = plan.num_heads
+        grad_out = grad_out.contiguous()
+        want_pyramid = ctx.needs_input_grad[0]
+        sink = raw.sink(b, q, hh) if want_pyramid else None
+        gagg, beta = ops.value_proj_heads_bwd(grad_out, vp_weight, None if vp_bias is None else vp_bias.contiguous(), hh,
+                                              grad_agg=None if sink is None else sink.grad_agg_rows(ctx.layer))
+        n = plan.pyramid.rows // b
+        dpart = ops.cross_attn_dot_sliced(plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(b, n, q, hh)))
+        gr, go, ga, gc = ops.cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
+                                                 img_h, img_w, raw_cam_weights=raw_cam)
+        if sink is not None:
+            sink.add_layer(ctx.layer, plan)
+        gw = gb = None
+        g = grad_out.view(b * q, hh, c // hh)
+        if ctx.needs_input_grad[6]:
+            gw = torch.einsum('qhd,qhc->hdc', g, agg.view(b * q, hh, c)).reshape(c, c)
+        if vp_bias is not None and ctx.needs_input_grad[7]:
+            gb = (g * wsum.view(b * q, hh, 1)).sum(0).reshape(c)
+        ctx.plan = None
+        return None, gr, go, ga.view_as(attn_logits), gc, None, gw, gb, None, None, None, None, None
 
 
 class ValueProjFunction(torch.autograd.Function):

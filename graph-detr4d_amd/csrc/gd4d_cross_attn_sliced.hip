@@ -28,14 +28,12 @@
 
 #include "gd4d_common.h"
 #include "gd4d_cross_attn_shared.h"
+#include "gd4d_cross_attn_sliced.h"
 
 namespace gd4d {
 
 GD4D_TRACE_UNIT(sliced)
 
-constexpr int kSlice = 32;                       // channels per slice: 128 bytes fp32 = one L2 line
-constexpr int kSlices = kChannels / kSlice;      // 8
-constexpr int kPlanHdr = 16;                     // ints per query in the plan header: item count per head
 
 // ---------------------------------------------------------------------------------------------------------------
 // Plan.  One workgroup (4 waves) per position of the locality order (pos -> bq = order[pos]); the plan is indexed by
@@ -47,12 +45,6 @@ constexpr int kPlanHdr = 16;                     // ints per query in the plan h
 //                                  items past M repeat the last item with weight 0 (their lines are already in flight)
 //     wsum[bq][h]                  sum of the in-bounds weights
 // The offsets are row * cam_stride[level] + pixel * pix_stride of the pyramid the gather will read (PyramidGeom).
-struct PyramidGeom {
-  unsigned cam_stride[4];       // bytes between camera rows of level l
-  int lvl_w[4], lvl_h[4];
-  unsigned pix_stride;          // bytes between pixels
-};
-
 struct PlanParams {
   CrossAttnParams c;       // ref, offsets, logits, lidar2img, ranges, mask_out / uv_out, order, wsum, B, N, Q, L
   PyramidGeom g;
@@ -392,9 +384,6 @@ __global__ __launch_bounds__(SP_THREADS) void pyramid_slice_planar_kernel(const 
   }
   trace_mark(g_trace_sliced, 0x84ull);
 }
-
-static int plan_cap_t(int N, int P) { return (N * P + 3) / 4; }      // passes of 4 items a head can need
-static size_t plan_hdr_bytes(int B, int Q) { return (((size_t)B * Q * kPlanHdr * sizeof(int)) + 255) & ~(size_t)255; }
 
 }  // namespace gd4d
 

@@ -1,0 +1,860 @@
+// Training backward of the channel-sliced aggregate-then-project path (gfx950): the pyramid side of a training step
+// WITHOUT a projected value tensor.
+//
+// Reference: the backward of Deform3DCrossAttn.forward is implicit autograd over deform3d_cross_attn.py:220-324 -
+// value_proj over every pixel (:264-280), mmcv's ms_deformable_col2im (grad of value by atomicAdd, grad of sampling
+// locations / attention weights), ~30 elementwise backward launches, and the gradient of the pyramid as a 97-GFLOP
+// GEMM per layer.  The projected-value path of this library (gd4d_value_proj_multi_fwd, gd4d_cross_attn_bwd,
+// gd4d_value_proj_bwd_input) keeps that order.  Here the forward is the inference step's (plan + sliced gather +
+// value_proj of the aggregates):
+//     out[q, h] = W_h A[q, h] + b_h s[q, h],   A[q, h] = sum_r w_r x_r,   s[q, h] = sum_r w_r
+// (r = in-bounds bilinear corners of the visible samples of head h; x_r = RAW 256-channel pixel), and with
+// g = dL/d out, dA = W_h^T g (256 channels), beta = <b_h, g>:
+//     dL/d w_r   = <dA[q, h], x_r> + beta[q, h]          -> softmax / camera-weight / sampling-location gradients
+//     dL/d x_r  += w_r dA[q, h]                          -> the pyramid's gradient
+//     dL/d W_h   = sum_q g[q, h] (x) A[q, h],  dL/d b_h = sum_q g[q, h] s[q, h]        (host side: 900 x Hh rows)
+//
+//   gd4d_value_proj_heads_bwd    dA, beta from g                                   (transpose of gd4d_value_proj_heads_fwd)
+//   gd4d_cross_attn_dot_sliced   D[pair] = <dA, x_r> per plan pair, one partial per channel slice: the forward's gather
+//                                with the FMA replaced by a dot product (same plan, same walk, same traffic)
+//   gd4d_cross_attn_plan_bwd     per query: the plan kernel's geometry again (bit-identical compaction), D summed over
+//                                the slices -> grad of ref / offsets / attention logits / camera logits; every partial
+//                                sum has its own LDS slot and is added in a fixed order (run-to-run identical)
+//   gd4d_pyramid_grad_count / _scan / _fill / _reduce
+//                                the pyramid's gradient WITHOUT atomics on feature data: the (pixel, weight, dA row)
+//                                records of ALL decoder layers are bucketed by pixel (counting sort: one int atomic per
+//                                record), then one pass over the pyramid sums each pixel's records (dA rows come from a
+//                                table that lives in L2 / Infinity Cache) and writes the NCHW gradient once - instead of
+//                                8x the fp32 atomics of the 32-channel form, a zero fill and NL accumulating GEMMs.
+//
+// Built with -ffp-contract=off: the visibility test must agree bit for bit with the plan kernel's (project_entry).
+#include "gd4d_common.h"
+#include "gd4d_cross_attn_shared.h"
+#include "gd4d_cross_attn_sliced.h"
+
+namespace gd4d {
+
+// ---------------------------------------------------------------------------------------------------------------
+// dA[m, h, :] = sum_d g[m, h Dh + d] W[h Dh + d, :],  beta[m, h] = sum_d g[m, h Dh + d] b[h Dh + d]
+constexpr int HB_ROWS = 8;
+
+__global__ __launch_bounds__(256) void value_proj_heads_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float* __restrict__ da,
+                                                                   float* __restrict__ beta, int M, int HH) {
+  __shared__ float s_g[HB_ROWS][kChannels];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * HB_ROWS;
+  const int rows = min(HB_ROWS, M - m0);
+  for (int i = tid; i < HB_ROWS * kChannels; i += 256) {
+    const int r = i / kChannels;
+    s_g[r][i % kChannels] = r < rows ? g[(size_t)(m0 + r) * kChannels + i % kChannels] : 0.f;
+  }
+  __syncthreads();
+  const int DH = kChannels / HH;
+  for (int h = 0; h < HH; ++h) {
+    float acc[HB_ROWS];
+#pragma unroll
+    for (int r = 0; r < HB_ROWS; ++r) acc[r] = 0.f;
+    for (int d = 0; d < DH; ++d) {
+      const float wv = w[(size_t)(h * DH + d) * kChannels + tid];
+#pragma unroll
+      for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(s_g[r][h * DH + d], wv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < HB_ROWS; ++r)
+      if (r < rows) da[((size_t)(m0 + r) * HH + h) * kChannels + tid] = acc[r];
+  }
+  if (beta && tid < HB_ROWS * HH) {
+    const int r = tid / HH, h = tid % HH;
+    if (r < rows) {
+      float t = 0.f;
+      if (bias)
+        for (int d = 0; d < DH; ++d) t = fmaf(s_g[r][h * DH + d], bias[h * DH + d], t);
+      beta[(size_t)(m0 + r) * HH + h] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gather-dot: the walk of cross_attn_agg_sliced_kernel (grid = 8 XCDs x 8 slices x per_xcd, slice-major inside an XCD,
+// wave = head, a pass = 8 loads of 8 corners x 128 B).  Per pass a lane ends up with the partial dot product of ONE
+// pair of the pass (pair index = lane, the plan's [g][j] order) over this slice's 32 channels: the 8 loads leave lane
+// (g, c) with 8 four-channel products (j = 0..7); a transposing butterfly over the 8 lanes of a corner slot (7 shuffles
+// instead of 24) leaves lane (g, c) the sum for j = c.  One coalesced 256-byte store per pass and slice.
+struct DotParams {
+  const char* lvl_base[4];
+  long long slice_stride;
+  const int* hdr;
+  const uint2* pair;
+  const int32_t* order;
+  const float* gagg;        // (BQ, HH, 256) dL/d agg
+  float* dpart;             // [kSlices][BQ * HH * cap_t * 64]
+  long long dslice;         // floats per slice of dpart
+  int BQ, per_xcd, cap_t;
+};
+
+template <int HH, int LT, int OCC>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(const DotParams p) {
+  constexpr int CH = 6, GP = 80, PASS = 8 * GP;
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
+  const int lane = threadIdx.x & 63;
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int s = jb / p.per_xcd, qi = jb - s * p.per_xcd;
+  const int pos = xcd * p.per_xcd + qi;
+  if (pos >= p.BQ) return;
+  const size_t prow = ((size_t)pos * HH + h) * p.cap_t * 64 + lane;
+  const uint2* pp = p.pair + prow;
+  float* dp = p.dpart + (size_t)s * p.dslice + prow;
+  const uint2 first = pp[0];
+  const int M = __builtin_amdgcn_readfirstlane(p.hdr[pos * kPlanHdr + h]);
+  const int bq = p.order ? p.order[pos] : pos;
+  const int T = (M + 3) >> 2;
+  char* my = s_raw + h * (CH * PASS);
+  const int g = lane >> 3, c = lane & 7;
+  char* wr = my + g * GP + c * 8;
+  const char* rd = my + g * GP;
+  const char* base[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
+  const unsigned lane_off = (unsigned)(c * 16);
+  const float4 ga = *reinterpret_cast<const float4*>(p.gagg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4);
+  const bool b4 = c & 4, b2 = c & 2, b1 = c & 1;
+
+  for (int t0 = 0; t0 < T; t0 += CH) {
+    const int nt = min(CH, T - t0);
+    if (t0 > 0) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (k >= nt) break;
+      const uint2 v = (k == 0 && t0 == 0) ? first : pp[(size_t)(t0 + k) * 64];
+      *reinterpret_cast<uint2*>(wr + k * PASS) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = 0; k < nt; ++k) {
+      const uint4* row = reinterpret_cast<const uint4*>(rd + k * PASS);
+      uint4 pr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = row[i];
+      const bool second = (t0 + k) * 4 + 2 < M;
+      float4 val[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        val[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((j & 3) >= LT) continue;
+        if (j >= 4 && !second) continue;
+        const unsigned o = ((j & 1) ? pr[j >> 1].z : pr[j >> 1].x) + lane_off;
+        val[j] = *reinterpret_cast<const float4*>(base[j & 3] + o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] = (ga.x * val[j].x + ga.y * val[j].y) + (ga.z * val[j].z + ga.w * val[j].w);
+      float e[4], f[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = b4 ? d[i + 4] : d[i], send = b4 ? d[i] : d[i + 4];
+        e[i] = keep + __shfl_xor(send, 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? e[i + 2] : e[i], send = b2 ? e[i] : e[i + 2];
+        f[i] = keep + __shfl_xor(send, 2);
+      }
+      const float keep = b1 ? f[1] : f[0], send = b1 ? f[0] : f[1];
+      dp[(size_t)(t0 + k) * 64] = keep + __shfl_xor(send, 1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Query-side gradients from D.  One workgroup per position of the locality order, phases as in cross_attn_plan_kernel
+// (the projection and the compaction are the same code: item m of head h here IS item m of the plan).
+struct PlanBwdParams {
+  CrossAttnParams c;
+  int lvl_w[4], lvl_h[4];
+  const int* hdr;
+  const float* dpart;
+  long long dslice;
+  int cap_t;
+  const float* beta;        // (BQ, HH) or NULL
+  float* grad_ref;          // (B, Q, 3)
+  float* grad_offsets;      // (B, Q, HH, P, 3)
+  float* grad_attn_logits;  // (B, Q, HH, L, P)
+  float* grad_cam_logits;   // (B, Q, N) in the raw-view layout of cam_logits
+  float* ga_part;           // B > 1: (B_geometry, B_class, Q, HH, L*P) partial dL/d a (before the softmax backward)
+  int* status;              // optional: set to 1 when an item count disagrees with the plan (cannot happen: tested)
+};
+
+template <int HH, int LT, int WAVES, bool BMULTI>
+__global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_bwd_kernel(const PlanBwdParams pp) {
+  const CrossAttnParams& p = pp.c;
+  constexpr int PT = kPoints, E = HH * PT, LP = LT * PT, THREADS = 64 * WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int ncand = p.N * PT;
+  float2* s_uv = reinterpret_cast<float2*>(smem_raw);                        // [N][E]; x < 0: not visible
+  float* s_mat = reinterpret_cast<float*>(s_uv + p.N * E);                   // [N][12]
+  float* s_cw = s_mat + p.N * 12;                                            // [N]
+  float* s_aw = s_cw + ((p.N + 3) & ~3);                                     // [B][HH][LP]
+  float* s_pt = s_aw + ((p.B * HH * LP + 3) & ~3);                           // [E][4] metre-space points
+  float4* s_items = reinterpret_cast<float4*>(s_pt + E * 4);                 // [WAVES][ncand]
+  float* s_ga = reinterpret_cast<float*>(s_items + WAVES * ncand);           // [WAVES][ncand][4]: cw T per (item, level)
+  float* s_gpt = s_ga + WAVES * ncand * 4;                                   // [WAVES][ncand][4]: dL/d point per item
+  float* s_camT = s_gpt + WAVES * ncand * 4;                                 // [HH][ncand]: sum_l a T per item
+  float* s_ref = s_camT + HH * ncand;                                        // [HH][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pos = blockIdx.x;
+  const int bq = p.order ? p.order[pos] : pos;
+  const int b = bq / p.Q, q = bq - b * p.Q;
+
+  for (int i = tid; i < p.N * 12; i += THREADS) s_mat[i] = p.lidar2img[((size_t)b * p.N + i / 12) * 16 + i % 12];
+  if (tid < p.N) {
+    const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)tid * p.Q + q];
+    s_cw[tid] = p.raw_cam ? cl : 1.0f / (1.0f + expf(-cl));
+  }
+  for (int i = tid; i < HH * ncand; i += THREADS) s_camT[i] = 0.f;
+  if ((LP & (LP - 1)) == 0 && LP <= 32 && (HH * LP) % GD4D_WAVE == 0) {      // as the plan kernel (same weights bit for bit)
+    for (int t = tid; t < p.B * HH * LP; t += THREADS) {
+      const int bh = t / LP, i = t % LP;
+      const int bb = bh / HH, hd = bh - bb * HH;
+      const float x = p.attn_logits[(((size_t)bb * p.Q + q) * HH + hd) * LP + i];
+      float mx = x;
+#pragma unroll
+      for (int o = 1; o < LP; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float e = expf(x - mx);
+      float sum = e;
+#pragma unroll
+      for (int o = 1; o < LP; o <<= 1) sum += __shfl_xor(sum, o);
+      s_aw[t] = e * (1.0f / sum);
+    }
+  } else {
+    for (int t = tid; t < p.B * HH; t += THREADS) {
+      const int bb = t / HH, hd = t - bb * HH;
+      float w[LP];
+      softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + hd) * LP, LP, w);
+#pragma unroll
+      for (int i = 0; i < LP; ++i) s_aw[t * LP + i] = w[i];
+    }
+  }
+  {
+    const int total = p.N * E;
+    static_assert(E <= GD4D_WAVE && GD4D_WAVE % E == 0 && THREADS % E == 0, "a thread keeps its (head, point)");
+    const int hp = tid % E;
+    const float* rp = p.ref + (size_t)bq * 3;
+    const float* offs = p.offsets + ((size_t)bq * E + hp) * 3;
+    const float X = (rp[0] * p.rng_scale[0] + p.rng_lo[0]) + offs[0];
+    const float Y = (rp[1] * p.rng_scale[1] + p.rng_lo[1]) + offs[1];
+    const float Z = (rp[2] * p.rng_scale[2] + p.rng_lo[2]) + offs[2];
+    if (tid < E) { s_pt[hp * 4] = X; s_pt[hp * 4 + 1] = Y; s_pt[hp * 4 + 2] = Z; }
+    __syncthreads();
+    for (int e0 = wave * GD4D_WAVE; e0 < total; e0 += THREADS) {
+      const int e = e0 + lane;
+      if (e < total) {
+        float u, v;
+        const bool vis = project_entry(p, s_mat + (e / E) * 12, X, Y, Z, u, v);
+        s_uv[e] = vis ? make_float2(u, v) : make_float2(-1.f, -1.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  float4* items = s_items + wave * ncand;
+  float* ga_w = s_ga + wave * ncand * 4;
+  float* gpt_w = s_gpt + wave * ncand * 4;
+  const int i_of = lane >> 2, l_of = lane & 3;
+  int lw = pp.lvl_w[0], lh = pp.lvl_h[0];
+#pragma unroll
+  for (int l = 1; l < LT; ++l)
+    if (l_of == l) { lw = pp.lvl_w[l]; lh = pp.lvl_h[l]; }
+  const float flw = (float)lw, flh = (float)lh;
+  const int slot0 = (((i_of & 1) << 2) << 3) | (((i_of >> 1) & 1) << 2) | l_of;
+  for (int h = wave; h < HH; h += WAVES) {
+    for (int i = lane; i < ncand * 4; i += GD4D_WAVE) { ga_w[i] = 0.f; gpt_w[i] = 0.f; }
+    int M = 0;
+    for (int c0 = 0; c0 < ncand; c0 += GD4D_WAVE) {
+      const int cand = c0 + lane;
+      const int n = min(cand, ncand - 1) / PT, k = cand % PT;
+      const float2 uvc = s_uv[n * E + h * PT + k];
+      const bool vis = cand < ncand && uvc.x >= 0.f;
+      const unsigned long long bal = __ballot(vis);
+      if (vis) items[M + __popcll(bal & ((1ull << lane) - 1ull))] = make_float4(uvc.x, uvc.y, __int_as_float((b * p.N + n) * PT + k), s_cw[n]);
+      M += __popcll(bal);
+    }
+    if (pp.status && lane == 0 && M != pp.hdr[pos * kPlanHdr + h]) *pp.status = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t prow = ((size_t)pos * HH + h) * pp.cap_t * 64;
+    const float* aw_h = s_aw + h * LP + min(l_of, LT - 1) * PT;
+    const float beta = pp.beta ? pp.beta[(size_t)bq * HH + h] : 0.f;
+    for (int it0 = 0; it0 < M; it0 += 16) {
+      const int item = it0 + i_of;
+      const bool live = item < M && l_of < LT;
+      const float4 rec = items[min(item, M - 1)];
+      const int rk = __float_as_int(rec.z);
+      const int row = rk / PT, k = rk % PT;
+      const int n = row - b * p.N;
+      const int cand = n * PT + k;
+      const int lb = p.B == 1 ? 0 : row % p.B;
+      const float a = aw_h[lb * HH * LP + k];
+      const float cw = rec.w;
+      const float x = fmaf(rec.x, flw, -0.5f);
+      const float y = fmaf(rec.y, flh, -0.5f);
+      const float xf = floorf(x), yf = floorf(y);
+      const float dx = x - xf, dy = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float* dsrc = pp.dpart + prow + (size_t)(item >> 2) * 64 + slot0;
+      float d[4];
+#pragma unroll
+      for (int c_of = 0; c_of < 4; ++c_of) {
+        const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
+        const bool in = live && xi >= 0 && xi < lw && yi >= 0 && yi < lh;
+        float t = 0.f;
+        if (in) {
+#pragma unroll
+          for (int s = 0; s < kSlices; ++s) t += dsrc[(size_t)s * pp.dslice + (c_of << 3)];
+          t += beta;
+        }
+        d[c_of] = t;                                  // corners outside the map (zero padding) and dead lanes: 0
+      }
+      const float bw0 = (1.f - dx) * (1.f - dy), bw1 = dx * (1.f - dy), bw2 = (1.f - dx) * dy, bw3 = dx * dy;
+      const float T = (bw0 * d[0] + bw1 * d[1]) + (bw2 * d[2] + bw3 * d[3]);
+      const float dTdx = (1.f - dy) * (d[1] - d[0]) + dy * (d[3] - d[2]);
+      const float dTdy = (1.f - dx) * (d[2] - d[0]) + dx * (d[3] - d[1]);
+      if (live) ga_w[cand * 4 + l_of] = cw * T;
+      float camv = a * T, gu = a * dTdx * flw, gv = a * dTdy * flh;       // dead lanes: T = 0
+      camv += __shfl_xor(camv, 1); gu += __shfl_xor(gu, 1); gv += __shfl_xor(gv, 1);
+      camv += __shfl_xor(camv, 2); gu += __shfl_xor(gu, 2); gv += __shfl_xor(gv, 2);
+      if (l_of == 0 && item < M) {
+        s_camT[h * ncand + cand] = camv;
+        gu *= cw; gv *= cw;
+        const float* m = s_mat + n * 12;
+        const float X = s_pt[(h * PT + k) * 4], Y = s_pt[(h * PT + k) * 4 + 1], Z = s_pt[(h * PT + k) * 4 + 2];
+        const float cx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+        const float cy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+        const float cz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+        const float iz = 1.0f / cz;                    // visible: cz > eps
+        const float gcx = gu * iz / p.img_w;
+        const float gcy = gv * iz / p.img_h;
+        const float gcz = -(gu * cx * iz * iz / p.img_w + gv * cy * iz * iz / p.img_h);
+        gpt_w[cand * 4 + 0] = gcx * m[0] + gcy * m[4] + gcz * m[8];
+        gpt_w[cand * 4 + 1] = gcx * m[1] + gcy * m[5] + gcz * m[9];
+        gpt_w[cand * 4 + 2] = gcx * m[2] + gcy * m[6] + gcz * m[10];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // fixed-order sums over the cameras
+    {
+      const int i = lane;                                // logit (level, point) = (i / PT, i % PT)
+      const int l = min(i, LP - 1) / PT, k = i % PT;
+      if (!BMULTI) {
+        float tot = 0.f;
+        if (i < LP)
+          for (int n = 0; n < p.N; ++n) tot += ga_w[(n * PT + k) * 4 + l];
+        const float ai = i < LP ? s_aw[h * LP + i] : 0.f;
+        float dot = ai * tot;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        if (i < LP) pp.grad_attn_logits[((size_t)bq * HH + h) * LP + i] = ai * (tot - dot);
+      } else if (i < LP) {
+        for (int cls = 0; cls < p.B; ++cls) {
+          float tot = 0.f;
+          for (int n = 0; n < p.N; ++n)
+            if ((b * p.N + n) % p.B == cls) tot += ga_w[(n * PT + k) * 4 + l];
+          pp.ga_part[((((size_t)b * p.B + cls) * p.Q + q) * HH + h) * LP + i] = tot;
+        }
+      }
+      if (lane >= 16 && lane < 16 + PT * 3) {
+        const int kk = (lane - 16) / 3, dd = (lane - 16) % 3;
+        float tot = 0.f;
+        for (int n = 0; n < p.N; ++n) tot += gpt_w[(n * PT + kk) * 4 + dd];
+        pp.grad_offsets[((size_t)bq * HH + h) * PT * 3 + (lane - 16)] = tot;
+      }
+      if (lane >= 32 && lane < 35) {
+        const int dd = lane - 32;
+        float tot = 0.f;
+        for (int kk = 0; kk < PT; ++kk) {
+          float t = 0.f;
+          for (int n = 0; n < p.N; ++n) t += gpt_w[(n * PT + kk) * 4 + dd];
+          tot += t;
+        }
+        s_ref[h * 4 + dd] = tot;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  if (tid < p.N) {
+    float cs = 0.f;
+    for (int h = 0; h < HH; ++h)
+      for (int k = 0; k < PT; ++k) cs += s_camT[h * ncand + tid * PT + k];
+    const float cw = s_cw[tid];
+    pp.grad_cam_logits[(size_t)b * p.Q * p.N + (size_t)tid * p.Q + q] = (p.raw_cam ? 1.f : cw * (1.f - cw)) * cs;
+  }
+  if (tid >= 64 && tid < 67) {
+    const int dd = tid - 64;
+    float t = 0.f;
+    for (int h = 0; h < HH; ++h) t += s_ref[h * 4 + dd];
+    pp.grad_ref[(size_t)bq * 3 + dd] = t * p.rng_scale[dd];
+  }
+}
+
+// B > 1: grad_attn_logits[bb, q, h, :] from the partial rows of all geometry owners b (fixed order) - softmax backward.
+template <int LP>
+__global__ __launch_bounds__(64) void plan_bwd_logits_kernel(const float* __restrict__ ga_part, const float* __restrict__ attn_logits,
+                                                             float* __restrict__ grad_attn_logits, int B, int Q, int HH) {
+  const int bbq = blockIdx.x;                      // bb * Q + q
+  const int bb = bbq / Q, q = bbq - bb * Q;
+  const int hh = threadIdx.x;
+  if (hh >= HH) return;
+  float tot[LP];
+#pragma unroll
+  for (int i = 0; i < LP; ++i) tot[i] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* src = ga_part + ((((size_t)b * B + bb) * Q + q) * HH + hh) * LP;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) tot[i] += src[i];
+  }
+  float a2[LP];
+  softmax_lp(attn_logits + ((size_t)bbq * HH + hh) * LP, LP, a2);
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) dot += a2[i] * tot[i];
+  float* gl = grad_attn_logits + ((size_t)bbq * HH + hh) * LP;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) gl[i] = a2[i] * (tot[i] - dot);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The pyramid's gradient.  gid = row * S + lvl_start[l] + pixel indexes the pixels of the whole pyramid (R rows).
+struct PgGeom {
+  unsigned cam_stride[4];
+  unsigned pix_stride;
+  int lvl_start[4];
+  int S;
+};
+
+// one wave per (position, head): COUNT the records of every pixel, or (FILL) hand every record its slot in the
+// pixel's bucket (cursor = exclusive scan of the counts; afterwards cursor[gid] = end of the bucket)
+template <bool FILL>
+__global__ __launch_bounds__(256) void pyramid_grad_bucket_kernel(const int* __restrict__ hdr, const uint2* __restrict__ pair,
+                                                                  int cap_t, int HH, int BQ, PgGeom g, int* __restrict__ counter,
+                                                                  uint2* __restrict__ rec, const int32_t* __restrict__ order,
+                                                                  unsigned id_base) {
+  const int lane = threadIdx.x & 63;
+  const int ph = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ph >= BQ * HH) return;
+  const int pos = ph / HH, h = ph - pos * HH;
+  const int M = hdr[pos * kPlanHdr + h];
+  const int T = (M + 3) >> 2;
+  const int l = lane & 3;
+  const unsigned cs = g.cam_stride[l], start = (unsigned)g.lvl_start[l];
+  unsigned id = 0;
+  if (FILL) id = id_base + (unsigned)((order ? order[pos] : pos) * HH + h);
+  const uint2* pp = pair + (size_t)ph * cap_t * 64 + lane;
+  for (int t = 0; t < T; ++t) {
+    const uint2 pr = pp[(size_t)t * 64];
+    if (__uint_as_float(pr.y) != 0.f) {
+      const unsigned row = pr.x / cs;
+      const unsigned pix = (pr.x - row * cs) / g.pix_stride;
+      const unsigned gid = row * (unsigned)g.S + start + pix;
+      if (FILL) {
+        const int slot = atomicAdd(counter + gid, 1);
+        rec[slot] = make_uint2(pr.y, id);
+      } else {
+        atomicAdd(counter + gid, 1);
+      }
+    }
+  }
+}
+
+constexpr int SCAN_THREADS = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_THREADS * SCAN_PER;
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* s_w, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_w[w];
+  total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void pg_scan_sums_kernel(const int* __restrict__ count, long long n, int* __restrict__ bsum) {
+  __shared__ int s_w[4];
+  const long long base = (long long)blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_PER;
+  int v = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_PER; ++i) v += base + i < n ? count[base + i] : 0;
+  int total;
+  block_exclusive_scan_256(v, s_w, total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void pg_scan_bsums_kernel(int* __restrict__ bsum, int nb) {
+  __shared__ int s_w[4];
+  int carry = 0;
+  for (int c0 = 0; c0 < nb; c0 += SCAN_THREADS) {
+    const int i = c0 + threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan_256(v, s_w, total);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void pg_scan_apply_kernel(const int* __restrict__ count, long long n,
+                                                                    const int* __restrict__ bsum, int* __restrict__ cursor) {
+  __shared__ int s_w[4];
+  const long long base = (long long)blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_PER;
+  int c[SCAN_PER];
+  int v = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_PER; ++i) { c[i] = base + i < n ? count[base + i] : 0; v += c[i]; }
+  int total;
+  int run = bsum[blockIdx.x] + block_exclusive_scan_256(v, s_w, total);
+#pragma unroll
+  for (int i = 0; i < SCAN_PER; ++i) {
+    if (base + i < n) cursor[base + i] = run;
+    run += c[i];
+  }
+}
+
+// One 512-thread workgroup per tile of 64 pixels of one (camera row, level) (the tiling of the pyramid copies), coarse
+// levels first (their pixels own hundreds of records each).  A wave takes the tile's pixels one at a time from an LDS
+// ticket; for a pixel it reads the bucket (64 records per load), then per record one 1-KB row of the dA table - lane c
+// holds channels 4c .. 4c+3 - and an FMA.  The tile is turned through LDS and written NCHW (256-byte runs), every pixel
+// of the pyramid exactly once: no zero fill, no read-modify-write.
+struct PgReduceParams {
+  float* out[GD4D_MAX_LEVELS];
+  int hw[GD4D_MAX_LEVELS];
+  int start[GD4D_MAX_LEVELS];
+  int tiles[GD4D_MAX_LEVELS];
+  int tile_base[GD4D_MAX_LEVELS + 1];
+  const int* count;
+  const int* end;
+  const uint2* rec;
+  const float* table;
+  int R, L, S, total;
+};
+
+constexpr int PG_PX = 64, PG_PITCH = 260, PG_THREADS = 512;
+
+__global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const PgReduceParams p) {
+  extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH]
+  __shared__ int s_next;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = p.total - 1 - blockIdx.x;
+  float* dst = p.out[0];
+  int hw = p.hw[0], tiles = p.tiles[0], tbase = 0, os = p.start[0];
+#pragma unroll
+  for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
+    if (l < p.L && t >= p.tile_base[l]) { dst = p.out[l]; hw = p.hw[l]; os = p.start[l]; tiles = p.tiles[l]; tbase = p.tile_base[l]; }
+  const int rel = t - tbase;
+  const int row = rel / tiles;
+  const int pix0 = (rel - row * tiles) * PG_PX;
+  const int npx = min(PG_PX, hw - pix0);
+  const int gid0 = row * p.S + os + pix0;
+  if (tid == 0) s_next = 0;
+  __syncthreads();
+  for (;;) {
+    int px = 0;
+    if (lane == 0) px = atomicAdd(&s_next, 1);
+    px = __builtin_amdgcn_readfirstlane(px);
+    if (px >= npx) break;
+    const int e = __builtin_amdgcn_readfirstlane(p.end[gid0 + px]);
+    const int cn = __builtin_amdgcn_readfirstlane(p.count[gid0 + px]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = e - cn; base < e; base += 64) {
+      const int m = min(64, e - base);
+      uint2 r = make_uint2(0u, 0u);
+      if (lane < m) r = p.rec[base + lane];
+      int i = 0;
+      for (; i + 4 <= m; i += 4) {
+        float w[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          w[u] = __uint_as_float(__builtin_amdgcn_readlane((int)r.x, i + u));
+          const unsigned id = __builtin_amdgcn_readlane((int)r.y, i + u);
+          v[u] = *reinterpret_cast<const float4*>(p.table + (size_t)id * kChannels + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+          acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+        }
+      }
+      for (; i < m; ++i) {
+        const float w = __uint_as_float(__builtin_amdgcn_readlane((int)r.x, i));
+        const unsigned id = __builtin_amdgcn_readlane((int)r.y, i);
+        const float4 v = *reinterpret_cast<const float4*>(p.table + (size_t)id * kChannels + lane * 4);
+        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
+        acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = acc;
+  }
+  __syncthreads();
+  // wave w writes channels 32 w .. 32 w + 31: lane = pixel, 256-byte runs
+  float* gp = dst + ((size_t)row * kChannels + wave * 32) * hw + pix0 + lane;
+  if (lane < npx) {
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) gp[(size_t)i * hw] = s_tp[lane * PG_PITCH + wave * 32 + i];
+  }
+}
+
+static int fill_geom(PgGeom& g, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, int L) {
+  int start = 0;
+  for (int l = 0; l < 4; ++l) { g.cam_stride[l] = 1; g.lvl_start[l] = 0; }
+  for (int l = 0; l < L; ++l) {
+    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+    if (h <= 0 || w <= 0 || cam_stride_bytes[l] <= 0 || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EINVAL;
+    g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
+    g.lvl_start[l] = start;
+    start += h * w;
+  }
+  if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
+  g.pix_stride = (unsigned)pix_stride_bytes;
+  g.S = start;
+  return GD4D_OK;
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_value_proj_heads_bwd(const float* grad_out, const float* weight, const float* bias, float* grad_agg,
+                                         float* beta, int M, int Hh, int C, void* stream) {
+  using namespace gd4d;
+  if (!grad_out || !weight || !grad_agg || M <= 0) return GD4D_EINVAL;
+  if (C != kChannels || Hh <= 0 || kChannels % Hh || Hh > 32) return GD4D_EUNSUPPORTED;
+  hipLaunchKernelGGL(value_proj_heads_bwd_kernel, dim3((M + HB_ROWS - 1) / HB_ROWS), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     grad_out, weight, bias, grad_agg, beta, M, Hh);
+  return check_launch();
+}
+
+extern "C" size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P) {
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || P <= 0) return 0;
+  return (size_t)gd4d::kSlices * B * Q * Hh * gd4d::plan_cap_t(N, P) * 64 * sizeof(float);
+}
+
+extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                                          const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh,
+                                          int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream) {
+  using namespace gd4d;
+  if (!level_ptrs || !plan || !grad_agg || !dpart) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
+  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+  if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
+  if (!aligned16(grad_agg) || !aligned16(plan) || slice_stride_bytes % 16) return GD4D_EALIGN;
+  if (dpart_bytes < gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
+  DotParams p{};
+  for (int l = 0; l < L; ++l) {
+    if (!level_ptrs[l]) return GD4D_EINVAL;
+    if (reinterpret_cast<uintptr_t>(level_ptrs[l]) % 16) return GD4D_EALIGN;
+    p.lvl_base[l] = static_cast<const char*>(level_ptrs[l]);
+  }
+  for (int l = L; l < 4; ++l) p.lvl_base[l] = p.lvl_base[0];
+  p.slice_stride = slice_stride_bytes;
+  p.hdr = static_cast<const int*>(plan);
+  p.pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan) + plan_hdr_bytes(B, Q));
+  p.order = query_order; p.gagg = grad_agg;
+  p.dpart = static_cast<float*>(dpart);
+  p.BQ = B * Q; p.per_xcd = (B * Q + 7) / 8; p.cap_t = plan_cap_t(N, P);
+  p.dslice = (long long)B * Q * Hh * p.cap_t * 64;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(8 * p.per_xcd * kSlices);
+  auto go = [&](auto kern, int hh) -> int {
+    const size_t lds = (size_t)hh * 6 * 8 * 80;
+    if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * hh), lds, s, p);
+    return check_launch();
+  };
+#define GD4D_DOT_L(HH_, OCC_)                                                  \
+  switch (L) {                                                                 \
+    case 1: return go(cross_attn_dot_sliced_kernel<HH_, 1, OCC_>, HH_);        \
+    case 2: return go(cross_attn_dot_sliced_kernel<HH_, 2, OCC_>, HH_);        \
+    case 3: return go(cross_attn_dot_sliced_kernel<HH_, 3, OCC_>, HH_);        \
+    default: return go(cross_attn_dot_sliced_kernel<HH_, 4, OCC_>, HH_);       \
+  }
+  switch (Hh) {
+    case 4: GD4D_DOT_L(4, 6)
+    case 8: GD4D_DOT_L(8, 6)
+    default: GD4D_DOT_L(16, 4)
+  }
+#undef GD4D_DOT_L
+}
+
+extern "C" int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
+                                        const float* lidar2img, const double* pc_range, float img_h, float img_w,
+                                        const int32_t* level_hw, const void* plan, const void* dpart, const float* beta,
+                                        float* grad_ref, float* grad_offsets, float* grad_attn_logits, float* grad_cam_logits,
+                                        void* workspace, size_t workspace_bytes, int32_t* status, int B, int N, int Q, int Hh, int L,
+                                        int P, int flags, const int32_t* query_order, void* stream) {
+  using namespace gd4d;
+  if (!ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range || !level_hw || !plan || !dpart || !grad_ref ||
+      !grad_offsets || !grad_attn_logits || !grad_cam_logits)
+    return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
+  if (P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
+  const size_t need = B > 1 ? (size_t)B * B * Q * Hh * L * P * sizeof(float) : 0;
+  if (B > 1 && (!workspace || workspace_bytes < need)) return GD4D_EWORKSPACE;
+  PlanBwdParams pp{};
+  CrossAttnParams& p = pp.c;
+  p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits; p.cam_logits = cam_logits; p.lidar2img = lidar2img;
+  p.order = query_order;
+  p.B = B; p.N = N; p.Q = Q; p.L = L; p.P = P;
+  p.raw_cam = (flags & GD4D_CA_RAW_CAM_WEIGHTS) ? 1 : 0;
+  for (int k = 0; k < 3; ++k) {
+    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
+    p.rng_lo[k] = static_cast<float>(pc_range[k]);
+  }
+  p.img_h = img_h; p.img_w = img_w;
+  for (int l = 0; l < 4; ++l) { pp.lvl_w[l] = 1; pp.lvl_h[l] = 1; }
+  for (int l = 0; l < L; ++l) {
+    if (level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
+    pp.lvl_h[l] = level_hw[2 * l]; pp.lvl_w[l] = level_hw[2 * l + 1];
+  }
+  pp.hdr = static_cast<const int*>(plan);
+  pp.dpart = static_cast<const float*>(dpart);
+  pp.cap_t = plan_cap_t(N, P);
+  pp.dslice = (long long)B * Q * Hh * pp.cap_t * 64;
+  pp.beta = beta;
+  pp.grad_ref = grad_ref; pp.grad_offsets = grad_offsets; pp.grad_attn_logits = grad_attn_logits;
+  pp.grad_cam_logits = grad_cam_logits; pp.ga_part = static_cast<float*>(workspace); pp.status = status;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ncand = N * kPoints;
+  auto lds = [&](int LT, int waves) {
+    return (size_t)N * Hh * kPoints * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
+           (size_t)((B * Hh * LT * kPoints + 3) & ~3) * sizeof(float) + (size_t)Hh * kPoints * 4 * sizeof(float) +
+           (size_t)waves * ncand * (sizeof(float4) + 8 * sizeof(float)) + (size_t)Hh * ncand * sizeof(float) + (size_t)Hh * 4 * sizeof(float);
+  };
+  auto go = [&](auto kern, int waves, size_t bytes) -> int {
+    if (bytes > 160 * 1024) return GD4D_EUNSUPPORTED;
+    if (bytes > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)bytes)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(B * Q), dim3(64 * waves), bytes, s, pp);
+    return check_launch();
+  };
+  int rc;
+#define GD4D_PB_GO(HH_, LT_)                                                                                                   \
+  rc = B > 1 ? go(cross_attn_plan_bwd_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8), true>, (HH_ < 8 ? HH_ : 8), lds(LT_, (HH_ < 8 ? HH_ : 8)))   \
+             : go(cross_attn_plan_bwd_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8), false>, (HH_ < 8 ? HH_ : 8), lds(LT_, (HH_ < 8 ? HH_ : 8))); \
+  if (rc == GD4D_OK && B > 1) {                                                                                                \
+    hipLaunchKernelGGL((plan_bwd_logits_kernel<LT_ * kPoints>), dim3(B * Q), dim3(64), 0, s, pp.ga_part, attn_logits,          \
+                       grad_attn_logits, B, Q, Hh);                                                                            \
+    rc = check_launch();                                                                                                       \
+  }                                                                                                                            \
+  return rc;
+#define GD4D_PB_L(HH_)                     \
+  switch (L) {                             \
+    case 1: GD4D_PB_GO(HH_, 1)             \
+    case 2: GD4D_PB_GO(HH_, 2)             \
+    case 3: GD4D_PB_GO(HH_, 3)             \
+    default: GD4D_PB_GO(HH_, 4)            \
+  }
+  switch (Hh) {
+    case 4: GD4D_PB_L(4)
+    case 8: GD4D_PB_L(8)
+    default: GD4D_PB_L(16)
+  }
+#undef GD4D_PB_L
+#undef GD4D_PB_GO
+}
+
+static int pg_bucket(bool fill, const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
+                     int32_t* counter, void* records, unsigned id_base, const int32_t* query_order, int B, int N, int Q, int Hh,
+                     int L, int P, void* stream) {
+  using namespace gd4d;
+  if (!plan || !level_hw || !cam_stride_bytes || !counter || (fill && !records)) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
+  if (P != kPoints || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  PgGeom g{};
+  if (int rc = fill_geom(g, level_hw, cam_stride_bytes, pix_stride_bytes, L)) return rc;
+  if ((long long)B * N * g.S >= (1ll << 31)) return GD4D_EUNSUPPORTED;
+  const int* hdr = static_cast<const int*>(plan);
+  const uint2* pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan) + plan_hdr_bytes(B, Q));
+  const int cap_t = plan_cap_t(N, P);
+  const dim3 grid((B * Q * Hh + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (fill)
+    hipLaunchKernelGGL(pyramid_grad_bucket_kernel<true>, grid, dim3(256), 0, s, hdr, pair, cap_t, Hh, B * Q, g, counter,
+                       static_cast<uint2*>(records), query_order, id_base);
+  else
+    hipLaunchKernelGGL(pyramid_grad_bucket_kernel<false>, grid, dim3(256), 0, s, hdr, pair, cap_t, Hh, B * Q, g, counter,
+                       static_cast<uint2*>(nullptr), query_order, 0u);
+  return check_launch();
+}
+
+extern "C" int gd4d_pyramid_grad_count(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                       int64_t pix_stride_bytes, int32_t* count, int B, int N, int Q, int Hh, int L, int P,
+                                       void* stream) {
+  return pg_bucket(false, plan, level_hw, cam_stride_bytes, pix_stride_bytes, count, nullptr, 0u, nullptr, B, N, Q, Hh, L, P, stream);
+}
+
+extern "C" int gd4d_pyramid_grad_fill(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                      int64_t pix_stride_bytes, int32_t* cursor, void* records, uint32_t id_base,
+                                      const int32_t* query_order, int B, int N, int Q, int Hh, int L, int P, void* stream) {
+  return pg_bucket(true, plan, level_hw, cam_stride_bytes, pix_stride_bytes, cursor, records, id_base, query_order, B, N, Q, Hh, L, P,
+                   stream);
+}
+
+extern "C" size_t gd4d_pyramid_grad_scan_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return (size_t)((n + gd4d::SCAN_CHUNK - 1) / gd4d::SCAN_CHUNK) * sizeof(int);
+}
+
+extern "C" int gd4d_pyramid_grad_scan(const int32_t* count, int32_t* cursor, void* workspace, size_t workspace_bytes, int64_t n,
+                                      void* stream) {
+  using namespace gd4d;
+  if (!count || !cursor || !workspace || n <= 0) return GD4D_EINVAL;
+  if (n >= (1ll << 31)) return GD4D_EUNSUPPORTED;
+  if (workspace_bytes < gd4d_pyramid_grad_scan_workspace_bytes(n)) return GD4D_EWORKSPACE;
+  const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  int* bsum = static_cast<int*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pg_scan_sums_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, count, (long long)n, bsum);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(pg_scan_bsums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, bsum, nb);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(pg_scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, count, (long long)n, bsum, cursor);
+  return check_launch();
+}
+
+extern "C" int gd4d_pyramid_grad_reduce(const int32_t* count, const int32_t* end, const void* records, const float* table,
+                                        void* const* grads, const int32_t* level_hw, int R, int C, int L, void* stream) {
+  using namespace gd4d;
+  if (!count || !end || !records || !table || !grads || !level_hw || R <= 0 || L <= 0) return GD4D_EINVAL;
+  if (C != kChannels || L > GD4D_MAX_LEVELS) return GD4D_EUNSUPPORTED;
+  if (!aligned16(table)) return GD4D_EALIGN;
+  PgReduceParams p{};
+  int s = 0, base = 0;
+  for (int l = 0; l < L; ++l) {
+    if (!grads[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
+    const int hw = level_hw[2 * l] * level_hw[2 * l + 1];
+    p.out[l] = static_cast<float*>(grads[l]); p.hw[l] = hw; p.start[l] = s; p.tiles[l] = (hw + PG_PX - 1) / PG_PX;
+    p.tile_base[l] = base;
+    s += hw;
+    base += R * p.tiles[l];
+  }
+  for (int l = L; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
+  for (int l = L; l < GD4D_MAX_LEVELS; ++l) { p.tiles[l] = 1; p.hw[l] = 1; }
+  p.count = count; p.end = end; p.rec = static_cast<const uint2*>(records); p.table = table;
+  p.R = R; p.L = L; p.S = s; p.total = base;
+  const size_t lds = (size_t)PG_PX * PG_PITCH * sizeof(float);
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(pyramid_grad_reduce_kernel), (int)lds)) return GD4D_ELAUNCH;
+  hipLaunchKernelGGL(pyramid_grad_reduce_kernel, dim3(base), dim3(PG_THREADS), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}

@@ -212,19 +212,31 @@ class Deform3DCrossAttn(nn.Module):
         offsets = Fn.sequential_autograd(self.deform_sampling_offsets, x).view(b, q, hh, npt, 3)
         attn_logits = Fn.sequential_autograd(self.attention_weights, x).view(b, q, hh, nl, npt)
         shapes = [tuple(v.shape[-2:]) for v in value]
+        lidar2img = Fn.lidar2img_device(img_metas, query)
+        img_h, img_w = Fn.img_hw(img_metas)
+        from .autograd import CrossAttnRawFunction
+        if projected is None and cl is None:     # a stand-alone call: its own copy of the pyramid, if the raw path applies
+            own = Fn.raw_pyramid_for_training([self], value)
+            cl = None if own is None else own[id(self)][3]
+        if isinstance(cl, tuple):                # (RawPyramid, token)
+            # the inference step's kernels behind autograd: no projected value tensor (gd4d_cross_attn_sliced_bwd.hip)
+            agg = CrossAttnRawFunction.apply(cl[1], reference_points, offsets, attn_logits, cam_logits, lidar2img,
+                                             self.value_proj.weight, self.value_proj.bias, cl[0], self.pc_range, img_h, img_w)
+            return self._finish_autograd(agg, reference_points, inp_residual)
         if projected is None:
             val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)
             val = val.view(val.shape[0], -1, hh, c // hh)
         else:
             val = projected                      # the decoder projected for all its layers (one autograd node)
-        lidar2img = Fn.lidar2img_device(img_metas, query)
-        img_h, img_w = Fn.img_hw(img_metas)
         if cl is not None:       # the decoder made a channels-last copy: value_proj's weight gradient comes from this node
             agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
                                           shapes, self.pc_range, img_h, img_w, cl, self.value_proj.weight, self.value_proj.bias)
         else:
             agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
                                           shapes, self.pc_range, img_h, img_w)
+        return self._finish_autograd(agg, reference_points, inp_residual)
+
+    def _finish_autograd(self, agg, reference_points, inp_residual):
         out = Fn.sequential_autograd(self.output_proj, agg).permute(1, 0, 2)
         ref3d = reference_points
         if self.depth_encode:

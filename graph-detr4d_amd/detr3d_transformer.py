@@ -306,7 +306,13 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         if len(mods) < 2 or len(mods) > 8 or len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) != 1:
             return kwargs, None
         if Fn.wants_grad(mods[0], *value):
-            # training: one autograd node for all the layers' projections (the pyramid's gradient is summed in place)
+            # training: the raw-pyramid path (one copy + one gradient pass for all layers) ...
+            raw = Fn.raw_pyramid_for_training(mods, value)
+            if raw is not None:
+                kwargs = dict(kwargs)
+                kwargs[Fn.VALUE_CACHE_KEY] = raw
+                return kwargs, None
+            # ... or one autograd node for all the layers' projections (the pyramid's gradient is summed in place)
             if any(m.value_proj.bias is None or m.value_dtype != torch.float32 for m in mods) \
                     or value[0].shape[0] != 1 or any(v.dtype != torch.float32 for v in value):
                 return kwargs, None
@@ -517,6 +523,10 @@ class Detr3DTransformer(nn.Module):
         share = len(mods) >= 1 and len(mods) <= 8 and mlvl_feats[0].is_cuda and \
             len({(m.num_heads, m.value_dtype, m.embed_dims) for m in mods}) == 1
         if share and Fn.wants_grad(mods[0], *mlvl_feats):
+            cache = Fn.raw_pyramid_for_training(mods, mlvl_feats)
+            if cache is not None:
+                return [self.forward(mlvl_feats, qe, reg_branches=reg_branches, **{Fn.VALUE_CACHE_KEY: cache}, **kwargs)
+                        for qe in query_embeds]
             share = all(m.value_proj.bias is not None and m.value_dtype == torch.float32 for m in mods) and \
                 mlvl_feats[0].shape[0] == 1 and all(v.dtype == torch.float32 for v in mlvl_feats)
             cache = Fn.project_values_for_layers_autograd(mods, mlvl_feats) if share else None

@@ -331,6 +331,24 @@ def project_values_for_layers(modules, value):
     return {id(m): ((o if hm else o.view(b * n, -1, hh, c // hh)), shapes, value) for m, o in zip(modules, outs)}
 
 
+def raw_pyramid_for_training(modules, value):
+    """Training on the inference design (the default; GD4D_TRAIN_VALUES=projected keeps the projected-value pipeline): ONE
+    slice-planar copy of the NCHW pyramid behind autograd.PyramidSourceFunction; every layer then runs plan + channel-sliced
+    gather + value_proj of its aggregates (autograd.CrossAttnRawFunction) and the pyramid's gradient is assembled once,
+    after the last layer's backward.  Returns the dict handed to the layers through kwargs[VALUE_CACHE_KEY]:
+    {id(module): (None, shapes, value, (RawPyramid, token))}, or None when the path does not apply (bf16 values, channels-last
+    levels, shapes outside the kernels' limits)."""
+    if os.environ.get('GD4D_TRAIN_VALUES', 'raw') != 'raw' or not LateValues.applicable(modules, value, ignore_mode=True):
+        return None
+    if any(v.dtype != torch.float32 for v in value) or any(m.value_dtype != torch.float32 for m in modules):
+        return None
+    from .autograd import PyramidSourceFunction, RawPyramid
+    raw = RawPyramid()
+    token = PyramidSourceFunction.apply(raw, *value)
+    shapes = [tuple(v.shape[-2:]) for v in value]
+    return {id(m): (None, shapes, value, (raw, token)) for m in modules}
+
+
 def project_values_for_layers_autograd(modules, value):
     """Training counterpart of project_values_for_layers: the same launch behind autograd.ValueProjMultiFunction, whose
     backward sums the pyramid's gradient over the layers in place.  fp32 pixel-major value tensors (what

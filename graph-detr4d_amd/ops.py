@@ -319,6 +319,150 @@ def value_proj_heads_fwd(agg, wsum, weight, bias=None, out=None):
     return out
 
 
+def value_proj_heads_bwd(grad_out, weight, bias=None, num_heads=8, grad_agg=None, beta=None):
+    """gd4d_value_proj_heads_bwd: grad_out (..., 256) -> grad_agg (..., Hh, 256) = W_h^T grad_out[.., h], beta (..., Hh) =
+    <b_h, grad_out[.., h]> (zeros without a bias): the gradient of value_proj_heads_fwd w.r.t. agg and wsum."""
+    lib = _lib.load()
+    c = grad_out.shape[-1]
+    m = grad_out.numel() // c
+    f32 = torch.float32
+    if grad_agg is None:
+        grad_agg = torch.empty(*grad_out.shape[:-1], num_heads, c, device=grad_out.device, dtype=f32)
+    if beta is None:
+        beta = torch.empty(*grad_out.shape[:-1], num_heads, device=grad_out.device, dtype=f32)
+    code = lib.gd4d_value_proj_heads_bwd(_dev(grad_out, 'grad_out', f32), _dev(weight, 'weight', f32), _opt(bias, 'bias'),
+                                         _dev(grad_agg, 'grad_agg', f32), _dev(beta, 'beta', f32), m, num_heads, c, _stream())
+    _lib.check(code, 'gd4d_value_proj_heads_bwd')
+    return grad_agg, beta
+
+
+def cross_attn_dot_bytes(b, n, q, num_heads, points=4):
+    return int(_lib.load().gd4d_cross_attn_dot_bytes(b, n, q, num_heads, points))
+
+
+def cross_attn_dot_sliced(plan, grad_agg, dpart=None):
+    """gd4d_cross_attn_dot_sliced: D[pair] = <grad_agg[q, h], raw pixel of the pair> for every pair of `plan`, as 8 per-slice
+    partials (uint8 buffer of gd4d_cross_attn_dot_bytes; only the passes the plan uses are written)."""
+    lib = _lib.load()
+    pyramid = plan.pyramid
+    b, q, hh = plan.b, plan.q, plan.num_heads
+    n = pyramid.rows // b
+    nl = len(pyramid.level_hw)
+    if pyramid.dtype != torch.float32:
+        raise NotImplementedError('the training backward reads fp32 pyramids')
+    nbytes = int(lib.gd4d_cross_attn_dot_bytes(b, n, q, hh, 4))
+    if dpart is None:
+        dpart = torch.empty(nbytes, device=pyramid.device, dtype=torch.uint8)
+    ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
+    code = lib.gd4d_cross_attn_dot_sliced(
+        ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(grad_agg, 'grad_agg', torch.float32),
+        _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4, _lib.F32,
+        None if plan.order is None else _order_ptr(plan.order, b * q), _stream())
+    _lib.check(code, 'gd4d_cross_attn_dot_sliced')
+    return dpart
+
+
+def cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
+                        raw_cam_weights=False, status=None):
+    """gd4d_cross_attn_plan_bwd: the query-side gradients of the sliced path from D (cross_attn_dot_sliced) and beta.
+    Returns (grad_ref, grad_offsets, grad_attn_logits, grad_cam_logits) - what cross_attn_bwd returns after grad_value."""
+    lib = _lib.load()
+    f32 = torch.float32
+    b, q, hh = plan.b, plan.q, plan.num_heads
+    n = lidar2img.shape[1]
+    p = offsets.shape[3]
+    level_hw = plan.pyramid.level_hw
+    nl = len(level_hw)
+    dev = ref.device
+    gr = torch.empty(b, q, 3, device=dev, dtype=f32)
+    go = torch.empty(b, q, hh, p, 3, device=dev, dtype=f32)
+    ga = torch.empty(b, q, hh, nl, p, device=dev, dtype=f32)
+    gc = torch.empty(b, q, n, device=dev, dtype=f32)
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    nbytes = lib.gd4d_cross_attn_bwd_workspace_bytes(b, q, hh, nl, p)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if nbytes else None
+    code = lib.gd4d_cross_attn_plan_bwd(
+        _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32), _dev(attn_logits, 'attn_logits', f32),
+        _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), lv,
+        _dev(plan.buf, 'plan', torch.uint8), _dev(dpart, 'dpart', torch.uint8), _opt(beta, 'beta'), _dev(gr, 'grad_ref'),
+        _dev(go, 'grad_offsets'), _dev(ga, 'grad_attn_logits'), _dev(gc, 'grad_cam_logits'),
+        None if ws is None else _dev(ws, 'workspace'), ctypes.c_size_t(nbytes),
+        None if status is None else _dev(status, 'status', torch.int32), b, n, q, hh, nl, p, 1 if raw_cam_weights else 0,
+        None if plan.order is None else _order_ptr(plan.order, b * q), _stream())
+    _lib.check(code, 'gd4d_cross_attn_plan_bwd')
+    return gr, go, ga, gc
+
+
+class PyramidGrad:
+    """The gradient of an NCHW pyramid from the plans of all decoder layers (gd4d_pyramid_grad_count / _scan / _fill /
+    _reduce): add_layer() per layer (in any order, each with its plan and its grad_agg rows), finish() once.
+
+    Buffers are sized for `layers` layers of B*Q*Hh rows; the record buffer by the plans' capacity (8 bytes per pair a
+    plan can hold - only what the counts say is touched)."""
+
+    def __init__(self, pyramid, layers, b, q, num_heads):
+        self.pyramid, self.layers, self.b, self.q, self.hh = pyramid, int(layers), int(b), int(q), int(num_heads)
+        dev = pyramid.device
+        self.n = pyramid.rows // self.b
+        self.s = sum(h * w for h, w in pyramid.level_hw)
+        self.count = torch.zeros(pyramid.rows * self.s, device=dev, dtype=torch.int32)
+        self.table = torch.empty(self.layers, self.b * self.q, self.hh, 256, device=dev, dtype=torch.float32)
+        self.plans = []
+
+    def grad_agg_rows(self, layer):
+        """(B, Q, Hh, 256) view of the table: where layer `layer`'s gd4d_value_proj_heads_bwd writes."""
+        return self.table[layer].view(self.b, self.q, self.hh, 256)
+
+    def _geom(self):
+        py = self.pyramid
+        nl = len(py.level_hw)
+        return (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in py.level_hw for x in hw]), (ctypes.c_int64 * nl)(*py.cam_stride), nl
+
+    def add_layer(self, layer, plan):
+        """Count the records of `plan` (kept until finish(): its buffer must not be overwritten)."""
+        lib = _lib.load()
+        lv, cs, nl = self._geom()
+        code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), lv, cs, self.pyramid.pix_stride,
+                                           _dev(self.count, 'count', torch.int32), self.b, self.n, self.q, self.hh, nl, 4, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_count')
+        self.plans.append((int(layer), plan))
+
+    def finish(self, grads=None):
+        """-> L tensors (R, 256, H_l, W_l) fp32: the pyramid's gradient summed over the added layers."""
+        lib = _lib.load()
+        py = self.pyramid
+        dev = py.device
+        lv, cs, nl = self._geom()
+        i32 = torch.int32
+        n_pix = self.count.numel()
+        cursor = torch.empty(n_pix, device=dev, dtype=i32)
+        wsb = int(lib.gd4d_pyramid_grad_scan_workspace_bytes(n_pix))
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        code = lib.gd4d_pyramid_grad_scan(_dev(self.count, 'count', i32), _dev(cursor, 'cursor', i32), _dev(ws, 'workspace'),
+                                          ctypes.c_size_t(wsb), n_pix, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_scan')
+        cap = sum((p.buf.numel() - 0) // 8 for _, p in self.plans)          # pairs the plans can hold (header included: slack)
+        records = torch.empty(max(cap, 1) * 8, device=dev, dtype=torch.uint8)
+        rows_per_layer = self.b * self.q * self.hh
+        for layer, plan in self.plans:
+            code = lib.gd4d_pyramid_grad_fill(
+                _dev(plan.buf, 'plan', torch.uint8), lv, cs, py.pix_stride, _dev(cursor, 'cursor', i32), _dev(records, 'records'),
+                layer * rows_per_layer, None if plan.order is None else _order_ptr(plan.order, self.b * self.q),
+                self.b, self.n, self.q, self.hh, nl, 4, _stream())
+            _lib.check(code, 'gd4d_pyramid_grad_fill')
+        if grads is None:
+            grads = [torch.empty(py.rows, 256, h, w, device=dev, dtype=torch.float32) for h, w in py.level_hw]
+        for g in grads:
+            _dev(g, 'grads', torch.float32)
+        ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grads])
+        code = lib.gd4d_pyramid_grad_reduce(_dev(self.count, 'count', i32), _dev(cursor, 'end', i32), _dev(records, 'records'),
+                                            _dev(self.table, 'table', torch.float32), ptrs, lv, py.rows, 256, nl, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_reduce')
+        self.plans = []
+        return grads
+
+
 def _order_ptr(order, count):
     if order.dtype != torch.int32 or order.numel() != count:
         raise ValueError(f'query_order must be an int32 permutation of {count} entries')

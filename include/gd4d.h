@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 28
+#define GD4D_ABI_VERSION 29
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -193,6 +193,60 @@ int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int64_t slice_
                                    const int32_t* query_order, int slice_lo, int slice_n, void* stream);
 int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C, int L,
                                   int in_dtype, int out_dtype, int max_cus, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Training backward of the channel-sliced path (gd4d_cross_attn_sliced_bwd.hip): the pyramid side of a training step
+ * without a projected value tensor.  Replaces, for Deform3DCrossAttn, autograd over deform3d_cross_attn.py:264-324
+ * (value_proj over every pixel, mmcv's ms_deformable_col2im with its atomicAdd scatter, the elementwise chain).
+ * Forward = gd4d_cross_attn_plan_fwd + gd4d_cross_attn_agg_sliced_fwd + gd4d_value_proj_heads_fwd:
+ *     out[q, h] = W_h A[q, h] + b_h s[q, h],  A = sum_r w_r x_r,  s = sum_r w_r   (r: in-bounds corners, x_r: raw pixel).
+ *
+ * gd4d_value_proj_heads_bwd - grad_agg (M, Hh, C) = W_h^T grad_out[m, h], beta (M, Hh) = <b_h, grad_out[m, h]> (bias NULL:
+ *   zeros; beta NULL: not written).  The weight / bias gradients are 900 x Hh-row contractions the caller does itself
+ *   (dW_h = sum_m grad_out[m, h] (x) A[m, h], db_h = sum_m grad_out[m, h] s[m, h]).
+ * gd4d_cross_attn_dot_sliced - D[pair] = <grad_agg[q, h], x_pair> for every pair of the plan, as 8 per-slice partials:
+ *   dpart = (8, B*Q*Hh*cap_t*64) fp32, gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P) bytes; same pyramid addressing, plan and
+ *   query_order as gd4d_cross_attn_agg_sliced_fwd.  fp32 pyramids only.
+ * gd4d_cross_attn_plan_bwd - the query-side gradients: recomputes the plan kernel's geometry (same routine: item m here
+ *   is item m of the plan), dL/d w_r = sum_slices D + beta for in-bounds corners, then the chain rule of the bilinear
+ *   weights, the softmax over L*P, the camera sigmoid (GD4D_CA_RAW_CAM_WEIGHTS: none), u = cx / (cz W), v = cy / (cz H)
+ *   and lidar2img: grad_ref (B, Q, 3), grad_offsets (B, Q, Hh, P, 3), grad_attn_logits (B, Q, Hh, L, P), grad_cam_logits
+ *   (B, Q, N) in the raw-view layout of cam_logits - the outputs of gd4d_cross_attn_bwd, which it replaces.  The mask is
+ *   piecewise constant (no gradient), as in the reference.  workspace: gd4d_cross_attn_bwd_workspace_bytes (B > 1).
+ *   status (or NULL): set to 1 if an item count disagrees with the plan's header.  All sums in a fixed order.
+ * gd4d_pyramid_grad_count / _scan / _fill / _reduce - the gradient of the NCHW pyramid from the plans and grad_agg tables of
+ *   ALL decoder layers at once, without atomics on feature data: a counting sort of the (pixel, weight, table row)
+ *   records by pixel, then one pass that sums each pixel's records and writes every pixel of the gradient exactly once.
+ *     count   count[gid] += 1 for every pair with a non-zero weight of one layer's plan (count zeroed by the caller; one
+ *             call per layer); gid = r * S + level start + y*W_l + x over the R = B*N camera rows
+ *     scan    cursor = exclusive prefix sum of count (n = R * S entries; workspace: gd4d_pyramid_grad_scan_workspace_bytes)
+ *     fill    records[cursor[gid]++] = {weight, id_base + bq * Hh + h} (one call per layer, the layer's plan and order;
+ *             records: 8 bytes per counted pair).  Afterwards cursor[gid] is the END of pixel gid's bucket.
+ *     reduce  grads[l] (R, C, H_l, W_l) fp32 = sum over the bucket of weight * table[id, :]; table (rows, C) holds the
+ *             grad_agg of every layer (row id as handed to fill).  The order inside a bucket follows the atomic slot
+ *             hand-out (like the atomicAdd scatter it replaces, sums may differ in the last bits between runs). */
+int gd4d_value_proj_heads_bwd(const float* grad_out, const float* weight, const float* bias, float* grad_agg, float* beta,
+                              int M, int Hh, int C, void* stream);
+size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P);
+int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                               const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,
+                               int P, int feats_dtype, const int32_t* query_order, void* stream);
+int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
+                             const float* lidar2img, const double* pc_range, float img_h, float img_w, const int32_t* level_hw,
+                             const void* plan, const void* dpart, const float* beta, float* grad_ref, float* grad_offsets,
+                             float* grad_attn_logits, float* grad_cam_logits, void* workspace, size_t workspace_bytes,
+                             int32_t* status, int B, int N, int Q, int Hh, int L, int P, int flags, const int32_t* query_order,
+                             void* stream);
+int gd4d_pyramid_grad_count(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
+                            int32_t* count, int B, int N, int Q, int Hh, int L, int P, void* stream);
+size_t gd4d_pyramid_grad_scan_workspace_bytes(int64_t n);
+int gd4d_pyramid_grad_scan(const int32_t* count, int32_t* cursor, void* workspace, size_t workspace_bytes, int64_t n,
+                           void* stream);
+int gd4d_pyramid_grad_fill(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
+                           int32_t* cursor, void* records, uint32_t id_base, const int32_t* query_order, int B, int N, int Q,
+                           int Hh, int L, int P, void* stream);
+int gd4d_pyramid_grad_reduce(const int32_t* count, const int32_t* end, const void* records, const float* table,
+                             void* const* grads, const int32_t* level_hw, int R, int C, int L, void* stream);
 
 /* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the
  * reference's MSDA kernel processes queries in index order).  Counting sort by (sample, azimuth of the de-normalised

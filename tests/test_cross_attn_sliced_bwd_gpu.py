@@ -1,0 +1,152 @@
+"""Training backward on the RAW pyramid (csrc/gd4d_cross_attn_sliced_bwd.hip): gd4d_value_proj_heads_bwd,
+gd4d_cross_attn_dot_sliced, gd4d_cross_attn_plan_bwd and the gd4d_pyramid_grad_* bucket sort against the projected-value
+backward (gd4d_cross_attn_bwd + the value_proj chain rule in torch; itself checked against autograd of the oracle in
+tests/test_training_gpu.py) and against fp64.  The module-level gradients against the oracle's autograd run through this
+path by default (tests/test_training_gpu.py).  GPU only."""
+import pytest
+import torch
+
+from graph_detr4d_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+from graph_detr4d_amd import synthetic  # noqa: E402
+
+PC_RANGE = synthetic.PC_RANGE
+
+
+def _case(heads, levels, n, q, b, seed):
+    gen = torch.Generator().manual_seed(seed)
+    hw = [(24, 40), (12, 20), (6, 10), (3, 5)][:levels]
+    feats = [torch.randn(b, n, 256, h, w, generator=gen) for h, w in hw]
+    l2i = torch.from_numpy(synthetic.camera_rig((n + 5) // 6)[:n]).unsqueeze(0).repeat(b, 1, 1, 1)
+    l2i = l2i + 0.01 * torch.randn(b, n, 4, 4, generator=gen) * (torch.arange(b).view(b, 1, 1, 1) > 0)
+    ref = torch.rand(b, q, 3, generator=gen)
+    offsets = torch.randn(b, q, heads, 4, 3, generator=gen) * 2.0
+    attn = torch.randn(b, q, heads, levels, 4, generator=gen)
+    cam = torch.randn(b, q, n, generator=gen)
+    w_v = torch.randn(256, 256, generator=gen) / 16
+    b_v = torch.randn(256, generator=gen)
+    gout = torch.randn(b, q, 256, generator=gen)
+    to = lambda t: t.to(DEV)
+    return dict(hw=hw, feats=[to(f) for f in feats], l2i=to(l2i.contiguous()), ref=to(ref), offsets=to(offsets), attn=to(attn), cam=to(cam),
+                w_v=to(w_v), b_v=to(b_v), gout=to(gout), heads=heads, b=b, n=n, q=q)
+
+
+def _projected_backward(c, raw_cam=False):
+    """The projected-value route: value = value_proj(pyramid) (torch), gd4d_cross_attn_bwd, chain rule back to the pyramid."""
+    b, n, hh = c['b'], c['n'], c['heads']
+    flat = torch.cat([f.flatten(3).permute(0, 1, 3, 2) for f in c['feats']], 2).reshape(b * n, -1, 256)     # (R, S, 256)
+    val = (flat @ c['w_v'].t() + c['b_v']).view(b * n, -1, hh, 256 // hh).contiguous()
+    order = ops.query_order_fwd(c['ref'], PC_RANGE)
+    gv, gr, go, ga, gc = ops.cross_attn_bwd(val, c['hw'], c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], PC_RANGE, 900, 1600,
+                                            c['gout'], query_order=order, raw_cam_weights=raw_cam)
+    gflat = gv.view(b * n, -1, 256).double() @ c['w_v'].double()                                               # (R, S, 256)
+    gfeats, s = [], 0
+    for h, w in c['hw']:
+        gfeats.append(gflat[:, s:s + h * w].permute(0, 2, 1).reshape(b * n, 256, h, w).float())
+        s += h * w
+    return gfeats, gr, go, ga, gc
+
+
+def _raw_backward(c, layers=1, raw_cam=False):
+    b, n, q, hh = c['b'], c['n'], c['q'], c['heads']
+    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
+    pyr = ops.PyramidView.slice_planar(sp, hw)
+    order = ops.query_order_fwd(c['ref'], PC_RANGE)
+    sink = ops.PyramidGrad(pyr, layers, b, q, hh)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    out = None
+    for layer in range(layers):
+        plan = ops.cross_attn_plan_fwd(pyr, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], PC_RANGE, 900, 1600, hh,
+                                       query_order=order, raw_cam_weights=raw_cam)
+        gagg, beta = ops.value_proj_heads_bwd(c['gout'], c['w_v'], c['b_v'], hh, grad_agg=sink.grad_agg_rows(layer))
+        dpart = ops.cross_attn_dot_sliced(plan, gagg)
+        out = ops.cross_attn_plan_bwd(plan, dpart, beta, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], PC_RANGE, 900, 1600,
+                                      raw_cam_weights=raw_cam, status=status)
+        sink.add_layer(layer, plan)
+    gfeats = sink.finish()
+    assert int(status.item()) == 0, 'an item count of the backward disagrees with the plan'
+    return (gfeats,) + tuple(out)
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-12)).item()
+
+
+def test_value_proj_heads_bwd_matches_fp64():
+    gen = torch.Generator().manual_seed(3)
+    for hh in (4, 8, 16):
+        g = torch.randn(2, 37, 256, generator=gen).to(DEV)
+        w = (torch.randn(256, 256, generator=gen) / 16).to(DEV)
+        bias = torch.randn(256, generator=gen).to(DEV)
+        gagg, beta = ops.value_proj_heads_bwd(g, w, bias, hh)
+        dh = 256 // hh
+        want = torch.einsum('bqhd,hdc->bqhc', g.double().view(2, 37, hh, dh), w.double().view(hh, dh, 256))
+        want_b = (g.double().view(2, 37, hh, dh) * bias.double().view(hh, dh)).sum(-1)
+        assert _rel(gagg, want) < 1e-5
+        assert _rel(beta, want_b) < 1e-5
+        _, beta0 = ops.value_proj_heads_bwd(g, w, None, hh)
+        assert float(beta0.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('heads,levels,n,q,b', [(8, 4, 6, 96, 1), (8, 4, 24, 64, 1), (8, 4, 6, 50, 2), (8, 3, 6, 40, 1),
+                                                 (4, 4, 6, 40, 1), (16, 2, 7, 33, 3), (8, 1, 12, 30, 1)])
+def test_raw_backward_matches_projected_backward(heads, levels, n, q, b):
+    c = _case(heads, levels, n, q, b, seed=11 + heads + levels + n + b)
+    gf_p, gr_p, go_p, ga_p, gc_p = _projected_backward(c)
+    gf_r, gr_r, go_r, ga_r, gc_r = _raw_backward(c)
+    assert _rel(gr_r, gr_p) < 2e-4
+    assert _rel(go_r, go_p) < 2e-4
+    assert _rel(ga_r, ga_p) < 2e-4
+    assert _rel(gc_r, gc_p) < 2e-4
+    for a, e in zip(gf_r, gf_p):
+        assert a.shape == e.shape
+        assert _rel(a, e) < 2e-4
+        # every pixel the projected route leaves at exactly zero (never sampled) is exactly zero here too
+        assert float(a[e == 0].abs().max() if (e == 0).any() else 0.0) < 1e-6 * float(e.abs().max())
+
+
+def test_raw_backward_raw_camera_weights():
+    """GD4D_CA_RAW_CAM_WEIGHTS (Deform3DCrossAttnMP's neighbour pass): no sigmoid on the camera logits."""
+    c = _case(8, 4, 6, 48, 1, seed=5)
+    p, r = _projected_backward(c, raw_cam=True), _raw_backward(c, raw_cam=True)
+    for a, e in zip(r[1:], p[1:]):
+        assert _rel(a, e) < 2e-4
+    for a, e in zip(r[0], p[0]):
+        assert _rel(a, e) < 2e-4
+
+
+def test_pyramid_gradient_sums_over_layers():
+    """Three layers with the same inputs and grad rows: the one-pass gradient is three times a single layer's."""
+    c = _case(8, 4, 6, 64, 1, seed=9)
+    one = _raw_backward(c, layers=1)[0]
+    three = _raw_backward(c, layers=3)[0]
+    for a, e in zip(three, one):
+        torch.testing.assert_close(a, 3 * e, rtol=1e-5, atol=1e-6 * float(e.abs().max()))
+
+
+def test_query_side_gradients_are_bit_reproducible():
+    """Every partial sum of gd4d_cross_attn_plan_bwd has its own slot and a fixed order: two runs agree bit for bit (the
+    pyramid's gradient follows the atomic slot hand-out of the bucket fill, like the atomicAdd scatter it replaces)."""
+    c = _case(8, 4, 12, 80, 1, seed=21)
+    a, b = _raw_backward(c), _raw_backward(c)
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
+
+
+def test_full_size_raw_backward_matches_projected_backward():
+    """900 queries x 24 cameras, R50 pyramid: the shapes bench.py --mode train runs."""
+    gen = torch.Generator().manual_seed(0)
+    n, q = 24, 900
+    hw = synthetic.R50_LEVELS
+    c = dict(hw=hw, feats=[torch.randn(1, n, 256, h, w, generator=gen).to(DEV) for h, w in hw],
+             l2i=torch.from_numpy(synthetic.camera_rig(4)).unsqueeze(0).to(DEV), ref=torch.rand(1, q, 3, generator=gen).to(DEV),
+             offsets=(torch.randn(1, q, 8, 4, 3, generator=gen) * 1.5).to(DEV), attn=torch.randn(1, q, 8, 4, 4, generator=gen).to(DEV),
+             cam=torch.randn(1, q, n, generator=gen).to(DEV), w_v=(torch.randn(256, 256, generator=gen) / 16).to(DEV),
+             b_v=torch.randn(256, generator=gen).to(DEV), gout=torch.randn(1, q, 256, generator=gen).to(DEV), heads=8, b=1, n=n, q=q)
+    p, r = _projected_backward(c), _raw_backward(c)
+    for a, e in zip(r[1:], p[1:]):
+        assert _rel(a, e) < 5e-4
+    for a, e in zip(r[0], p[0]):
+        assert _rel(a, e) < 5e-4
