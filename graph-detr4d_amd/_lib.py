@@ -36,11 +36,15 @@ SIGNATURES = {
     'gd4d_cross_attn_dot_bytes': (_c.c_size_t, [_i] * 5),
     'gd4d_cross_attn_dot_sliced': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp, _vp]),
     'gd4d_cross_attn_plan_bwd': (_i, [_vp] * 6 + [_f, _f] + [_vp] * 9 + [_c.c_size_t, _vp] + [_i] * 7 + [_vp, _vp]),
-    'gd4d_pyramid_grad_count': (_i, [_vp, _vp, _vp, _c.c_int64, _vp] + [_i] * 6 + [_vp]),
+    'gd4d_pyramid_grad_chunks': (_c.c_int64, [_vp, _i, _i]),
+    'gd4d_pyramid_grad_slots_bytes': (_c.c_size_t, [_i] * 5),
+    'gd4d_pyramid_grad_count': (_i, [_vp, _vp, _vp, _c.c_int64, _vp, _vp, _c.c_size_t] + [_i] * 6 + [_vp]),
     'gd4d_pyramid_grad_scan_workspace_bytes': (_c.c_size_t, [_c.c_int64]),
     'gd4d_pyramid_grad_scan': (_i, [_vp, _vp, _vp, _c.c_size_t, _c.c_int64, _vp]),
-    'gd4d_pyramid_grad_fill': (_i, [_vp, _vp, _vp, _c.c_int64, _vp, _vp, _c.c_uint32, _vp] + [_i] * 6 + [_vp]),
-    'gd4d_pyramid_grad_reduce': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
+    'gd4d_pyramid_grad_fill': (_i, [_vp, _vp, _vp, _vp, _c.c_uint32, _vp] + [_i] * 5 + [_vp]),
+    'gd4d_pyramid_grad_chunk_geometry': (_i, [_vp, _i, _i, _vp]),
+    'gd4d_pyramid_grad_sort': (_i, [_vp] * 5 + [_c.c_int64, _vp]),
+    'gd4d_pyramid_grad_reduce': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
     'gd4d_query_order_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_refine_reference_order_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'gd4d_cross_attn_bwd': (_i, [_vp] * 8 + [_f, _f] + [_vp] * 6 + [_i] * 10 + [_vp, _vp, _c.c_size_t, _vp]),

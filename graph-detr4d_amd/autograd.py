@@ -12,6 +12,8 @@ Inference takes the fully fused HIP path (functional.py); with autograd enabled 
   * MhaCoreFunction    - gd4d_mha_core_fwd (saving the log-sum-exp) / gd4d_mha_core_bwd.
 What is left to ATen in a training step: residual adds, ReLU between two Linears, dropout, autograd's own accumulations.
 """
+import os
+
 import torch
 
 from . import ops
@@ -75,24 +77,86 @@ class CrossAttnFunction(torch.autograd.Function):
 
 
 class RawPyramid:
-    """What the layers of one training step share on the raw-pyramid path: the slice-planar copy (PyramidView) and - in the
-    backward - the sink that buckets the layers' (pixel, weight, grad_agg row) records (ops.PyramidGrad) plus the per-slice
-    dot-product workspace.  (The token that ties every layer's gather node to the pyramid's node is NOT kept here: the
-    autograd nodes hold this object, and a reference back to the graph would keep a step's graph alive into the next.)"""
+    """What the layers of one training step share on the raw-pyramid path: the slice-planar copy (PyramidView) and the sink
+    that turns the layers' (pixel, weight, grad_agg row) records into the pyramid's gradient (ops.PyramidGrad), plus the
+    per-slice dot-product workspace.  (The token that ties every layer's gather node to the pyramid's node is NOT kept here:
+    the autograd nodes hold this object, and a reference back to the graph would keep a step's graph alive into the next.)
+
+    Only the last pass over the records needs gradients: a layer's records are counted right after its plan in the FORWARD
+    pass, scan / fill / sort are issued by the first backward node, the reduction as soon as the last layer's grad_agg rows
+    exist.  GD4D_TRAIN_SIDE=1 puts all of that on a side stream (join() at the end of the forward pass and the pyramid
+    node's backward join it) - measured and NOT the default: inside a replayed hipGraph the cross-stream edges cost more
+    than the overlap returns on this runtime (training step 11.8 ms against 9.7 ms with everything on one stream)."""
 
     def __init__(self):
         self.pyramid = self.shapes = None
-        self.layers = 0
-        self._sink = self._dpart = None
+        self.layers = self.pending = 0
+        self.needs_grad = False
+        self.main = self.side = None
+        self.sink = self.grads = self._dpart = None
+        self._forked = self._prepared = False
 
     def register(self):
         self.layers += 1
+        self.pending += 1
         return self.layers - 1
 
-    def sink(self, b, q, num_heads):
-        if self._sink is None:
-            self._sink = ops.PyramidGrad(self.pyramid, self.layers, b, q, num_heads)
-        return self._sink
+    def _fork(self):
+        if self.side is self.main:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self._forked = True
+
+    def count(self, layer, plan):
+        """Forward pass: hand the records of `plan` their slots (side stream)."""
+        if not self.needs_grad:
+            return
+        if self.sink is None:
+            self.sink = ops.PyramidGrad(self.pyramid, 0, plan.b, plan.q, plan.num_heads)
+        self._fork()                                 # the plan was written on the main stream
+        with torch.cuda.stream(self.side):
+            self.sink.add_layer(layer, plan)
+        if self.side is not self.main:
+            plan.buf.record_stream(self.side)
+            if plan.order is not None:
+                plan.order.record_stream(self.side)
+
+    def join(self):
+        """Make the main stream wait for the side stream's work (end of the forward pass; keeps a capture well-formed)."""
+        if self._forked:
+            self.main.wait_stream(self.side)
+            self._forked = False
+
+    def begin_backward(self):
+        """First backward node of the step: the table for every registered layer; scan + fill + sort on the side stream."""
+        if not self.needs_grad or self._prepared or self.sink is None:
+            return
+        self.sink.alloc_table(self.layers)
+        self._fork()
+        with torch.cuda.stream(self.side):
+            self.sink.prepare()
+        self._prepared = True
+
+    def layer_done(self):
+        """A layer's grad_agg rows are written (main stream); after the last one the reduction starts on the side stream."""
+        self.pending -= 1
+        if self.pending == 0:
+            self._reduce()
+
+    def _reduce(self):
+        if not self.needs_grad or self.sink is None or self.grads is not None:
+            return
+        self.begin_backward()
+        py = self.pyramid
+        grads = [torch.empty(py.rows, 256, h, w, device=py.device, dtype=torch.float32) for h, w in py.level_hw]
+        self._fork()                                 # the table rows were written on the main stream
+        with torch.cuda.stream(self.side):
+            self.sink.reduce(grads)
+        if self.side is not self.main:
+            self.sink.table.record_stream(self.side)
+        self.grads = grads
 
     def dpart(self, nbytes):
         if self._dpart is None or self._dpart.numel() < nbytes:
@@ -103,15 +167,19 @@ class RawPyramid:
 class PyramidSourceFunction(torch.autograd.Function):
     """token = apply(raw, *levels): the slice-planar copy of the NCHW levels (the reference's flatten / transpose / cat,
     deform3d_cross_attn.py:264-276, once for all layers) lands in raw.pyramid; the returned 1-element token is what the
-    layers' CrossAttnRawFunction nodes take as their input, so this node's backward runs after ALL of them: it turns the
-    records they left in raw.sink into the gradient of the levels (gd4d_pyramid_grad_scan / _fill / _reduce)."""
+    layers' CrossAttnRawFunction nodes take as their input, so this node's backward runs after ALL of them: it hands out
+    the gradient of the levels that the layers' records and grad_agg rows add up to (gd4d_pyramid_grad_*)."""
 
     @staticmethod
     def forward(ctx, raw, *feats):
+        from . import functional as Fn
         src = [f.contiguous() for f in feats]
         sp, hw = ops.pyramid_slice_planar_fwd(src)
         raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
         raw.shapes = [tuple(f.shape) for f in feats]
+        raw.needs_grad = any(ctx.needs_input_grad[1:])
+        raw.main = torch.cuda.current_stream(sp.device)
+        raw.side = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if os.environ.get('GD4D_TRAIN_SIDE', '0') == '1' else raw.main
         ctx.raw = raw
         ctx.set_materialize_grads(False)
         return torch.empty(1, device=feats[0].device, dtype=torch.float32)
@@ -119,10 +187,11 @@ class PyramidSourceFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _):
         raw = ctx.raw
-        if raw._sink is None or not raw._sink.plans:
+        if raw.sink is None:
             return (None,) * (1 + len(raw.shapes))
-        grads = raw._sink.finish()
-        raw._sink = raw._dpart = None
+        raw._reduce()                                # (already running unless a layer's output was never used)
+        raw.join()
+        grads, raw.grads, raw.sink, raw._dpart = raw.grads, None, None, None
         return (None, *[g.view(shape) for g, shape in zip(grads, raw.shapes)])
 
 
@@ -130,8 +199,8 @@ class CrossAttnRawFunction(torch.autograd.Function):
     """out (B, Q, C) = value_proj of the per-head aggregates of the RAW pyramid (deform3d_cross_attn.py:220-324 with
     value_proj commuted past the linear sampler): plan + channel-sliced gather + gd4d_value_proj_heads_fwd forward;
     backward: gd4d_value_proj_heads_bwd, gd4d_cross_attn_dot_sliced, gd4d_cross_attn_plan_bwd for the query side, the
-    weight / bias gradient of value_proj from the saved aggregates, and the layer's records for the pyramid's gradient
-    (summed over the layers by PyramidSourceFunction's backward)."""
+    weight / bias gradient of value_proj from the saved aggregates, and the layer's grad_agg rows for the pyramid's gradient
+    (assembled over the layers by RawPyramid / PyramidSourceFunction's backward)."""
 
     @staticmethod
     def forward(ctx, token, ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, raw, pc_range, img_h, img_w,
@@ -143,11 +212,14 @@ class CrossAttnRawFunction(torch.autograd.Function):
         order = Fn.query_order(ref, pc_range)
         plan = ops.cross_attn_plan_fwd(raw.pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, hh,
                                        query_order=order, raw_cam_weights=raw_cam)
+        ctx.layer = raw.register()
+        if ctx.needs_input_grad[0]:
+            raw.count(ctx.layer, plan)
         agg = ops.cross_attn_agg_sliced_fwd(plan)
         vp_weight = vp_weight.contiguous()
         out = ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, None if vp_bias is None else vp_bias.contiguous())
         ctx.save_for_backward(ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, agg, plan.wsum)
-        ctx.plan, ctx.raw, ctx.layer = plan, raw, raw.register()
+        ctx.plan, ctx.raw = plan, raw
         ctx.meta = (pc_range, img_h, img_w, bool(raw_cam))
         return out
 
@@ -159,16 +231,16 @@ class CrossAttnRawFunction(torch.autograd.Function):
         b, q, c = grad_out.shape
         hh = plan.num_heads
         grad_out = grad_out.contiguous()
-        want_pyramid = ctx.needs_input_grad[0]
-        sink = raw.sink(b, q, hh) if want_pyramid else None
+        want_pyramid = ctx.needs_input_grad[0] and raw.sink is not None
+        if want_pyramid:
+            raw.begin_backward()
         gagg, beta = ops.value_proj_heads_bwd(grad_out, vp_weight, None if vp_bias is None else vp_bias.contiguous(), hh,
-                                              grad_agg=None if sink is None else sink.grad_agg_rows(ctx.layer))
+                                              grad_agg=raw.sink.grad_agg_rows(ctx.layer) if want_pyramid else None)
+        raw.layer_done()
         n = plan.pyramid.rows // b
         dpart = ops.cross_attn_dot_sliced(plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(b, n, q, hh)))
         gr, go, ga, gc = ops.cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
                                                  img_h, img_w, raw_cam_weights=raw_cam)
-        if sink is not None:
-            sink.add_layer(ctx.layer, plan)
         gw = gb = None
         g = grad_out.view(b * q, hh, c // hh)
         if ctx.needs_input_grad[6]:

@@ -28,6 +28,8 @@
 //                                8x the fp32 atomics of the 32-channel form, a zero fill and NL accumulating GEMMs.
 //
 // Built with -ffp-contract=off: the visibility test must agree bit for bit with the plan kernel's (project_entry).
+#include <stdlib.h>
+
 #include "gd4d_common.h"
 #include "gd4d_cross_attn_shared.h"
 #include "gd4d_cross_attn_sliced.h"
@@ -431,21 +433,28 @@ __global__ __launch_bounds__(64) void plan_bwd_logits_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The pyramid's gradient.  gid = row * S + lvl_start[l] + pixel indexes the pixels of the whole pyramid (R rows).
-struct PgGeom {
+// The pyramid's gradient.  The pixels are grouped into CHUNKS of at most 64 (cw x ch pixels of one camera row and
+// level, both powers of two: 32 x 2 on the fine levels, smaller on the coarse ones, where a pixel owns hundreds of
+// records); a record is bucketed by CHUNK, not by pixel: the 4 corners of a sample - and at the coarse levels most
+// samples of a head - share a chunk, so a wave adds them to the chunk's counter with ONE atomic (the L2 retires ~15 G
+// atomic requests/s whatever their width: per-pixel buckets cost 1.8 ms per step in atomics alone).
+struct PgChunks {
   unsigned cam_stride[4];
   unsigned pix_stride;
-  int lvl_start[4];
-  int S;
+  int lvl_w[4], lvl_h[4];
+  int cws[4], chs[4];            // log2 of the chunk width / height
+  int CW[4], CH[4];              // chunks across / down one camera row of level l
+  int chunk_base[5];             // first chunk of level l; within a level (row, cy, cx)
+  int total;
 };
 
-// one wave per (position, head): COUNT the records of every pixel, or (FILL) hand every record its slot in the
-// pixel's bucket (cursor = exclusive scan of the counts; afterwards cursor[gid] = end of the bucket)
-template <bool FILL>
-__global__ __launch_bounds__(256) void pyramid_grad_bucket_kernel(const int* __restrict__ hdr, const uint2* __restrict__ pair,
-                                                                  int cap_t, int HH, int BQ, PgGeom g, int* __restrict__ counter,
-                                                                  uint2* __restrict__ rec, const int32_t* __restrict__ order,
-                                                                  unsigned id_base) {
+// One wave per (position, head), one pass of 64 pairs at a time: every pair with a non-zero weight gets a slot in its
+// chunk's bucket.  Lanes with the same chunk are matched first (no memory traffic), their leader asks for the whole
+// group's slots with one returning atomic; {chunk << 6 | pixel-in-chunk, slot} is parked in the plan's layout for the
+// fill (which runs after the scan over the counts of ALL layers).
+__global__ __launch_bounds__(256) void pyramid_grad_count_kernel(const int* __restrict__ hdr, const uint2* __restrict__ pair,
+                                                                 int cap_t, int HH, int BQ, PgChunks g, int* __restrict__ count,
+                                                                 uint2* __restrict__ slots) {
   const int lane = threadIdx.x & 63;
   const int ph = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ph >= BQ * HH) return;
@@ -453,22 +462,55 @@ __global__ __launch_bounds__(256) void pyramid_grad_bucket_kernel(const int* __r
   const int M = hdr[pos * kPlanHdr + h];
   const int T = (M + 3) >> 2;
   const int l = lane & 3;
-  const unsigned cs = g.cam_stride[l], start = (unsigned)g.lvl_start[l];
-  unsigned id = 0;
-  if (FILL) id = id_base + (unsigned)((order ? order[pos] : pos) * HH + h);
-  const uint2* pp = pair + (size_t)ph * cap_t * 64 + lane;
+  const unsigned cs = g.cam_stride[l];
+  const int W = g.lvl_w[l], cws = g.cws[l], chs = g.chs[l], CWl = g.CW[l], CHl = g.CH[l], cbase = g.chunk_base[l];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const size_t prow = (size_t)ph * cap_t * 64 + lane;
   for (int t = 0; t < T; ++t) {
-    const uint2 pr = pp[(size_t)t * 64];
-    if (__uint_as_float(pr.y) != 0.f) {
-      const unsigned row = pr.x / cs;
-      const unsigned pix = (pr.x - row * cs) / g.pix_stride;
-      const unsigned gid = row * (unsigned)g.S + start + pix;
-      if (FILL) {
-        const int slot = atomicAdd(counter + gid, 1);
-        rec[slot] = make_uint2(pr.y, id);
-      } else {
-        atomicAdd(counter + gid, 1);
-      }
+    const uint2 pr = pair[prow + (size_t)t * 64];
+    const bool valid = __uint_as_float(pr.y) != 0.f;
+    const unsigned row = pr.x / cs;
+    const unsigned pix = (pr.x - row * cs) / g.pix_stride;
+    const int y = (int)pix / W, x = (int)pix - y * W;
+    const int key = cbase + ((int)row * CHl + (y >> chs)) * CWl + (x >> cws);
+    const int pxin = ((y & ((1 << chs) - 1)) << cws) | (x & ((1 << cws) - 1));
+    unsigned long long rem = __ballot(valid);
+    int leader = lane, rank = 0, n = 0;
+    while (rem) {
+      const int ld = __ffsll((long long)rem) - 1;
+      const int k = __builtin_amdgcn_readlane(key, ld);
+      const bool mine = valid && key == k;
+      const unsigned long long m = __ballot(mine);
+      if (mine) { leader = ld; rank = __popcll(m & lt); }
+      if (lane == ld) n = __popcll(m);
+      rem &= ~m;
+    }
+    int base = 0;
+    if (valid && leader == lane) base = atomicAdd(count + key, n);
+    base = __shfl(base, leader);
+    slots[prow + (size_t)t * 64] = valid ? make_uint2(((unsigned)key << 6) | (unsigned)pxin, (unsigned)(base + rank))
+                                         : make_uint2(0xffffffffu, 0xffffffffu);
+  }
+}
+
+// records[start[chunk] + slot] = {weight, pixel-in-chunk << 26 | table row}: no atomics
+__global__ __launch_bounds__(256) void pyramid_grad_fill_kernel(const int* __restrict__ hdr, const uint2* __restrict__ pair,
+                                                                const uint2* __restrict__ slots, int cap_t, int HH, int BQ,
+                                                                const int* __restrict__ start, uint2* __restrict__ rec,
+                                                                const int32_t* __restrict__ order, unsigned id_base) {
+  const int lane = threadIdx.x & 63;
+  const int ph = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ph >= BQ * HH) return;
+  const int pos = ph / HH, h = ph - pos * HH;
+  const int M = hdr[pos * kPlanHdr + h];
+  const int T = (M + 3) >> 2;
+  const unsigned id = id_base + (unsigned)((order ? order[pos] : pos) * HH + h);
+  const size_t prow = (size_t)ph * cap_t * 64 + lane;
+  for (int t = 0; t < T; ++t) {
+    const uint2 sr = slots[prow + (size_t)t * 64];
+    if (sr.y != 0xffffffffu) {
+      const uint2 pr = pair[prow + (size_t)t * 64];
+      rec[(size_t)start[sr.x >> 6] + sr.y] = make_uint2(pr.y, ((sr.x & 63u) << 26) | id);
     }
   }
 }
@@ -533,103 +575,196 @@ __global__ __launch_bounds__(SCAN_THREADS) void pg_scan_apply_kernel(const int* 
   }
 }
 
-// One 512-thread workgroup per tile of 64 pixels of one (camera row, level) (the tiling of the pyramid copies), coarse
-// levels first (their pixels own hundreds of records each).  A wave takes the tile's pixels one at a time from an LDS
-// ticket; for a pixel it reads the bucket (64 records per load), then per record one 1-KB row of the dA table - lane c
-// holds channels 4c .. 4c+3 - and an FMA.  The tile is turned through LDS and written NCHW (256-byte runs), every pixel
-// of the pyramid exactly once: no zero fill, no read-modify-write.
-struct PgReduceParams {
-  float* out[GD4D_MAX_LEVELS];
-  int hw[GD4D_MAX_LEVELS];
-  int start[GD4D_MAX_LEVELS];
-  int tiles[GD4D_MAX_LEVELS];
-  int tile_base[GD4D_MAX_LEVELS + 1];
-  const int* count;
-  const int* end;
-  const uint2* rec;
-  const float* table;
-  int R, L, S, total;
-};
+// Sort every chunk's records by pixel (6-bit keys, one 512-thread workgroup per chunk, two passes over the chunk: count
+// per pixel - lanes of a wave that hold the same pixel are matched with 6 ballots and share one LDS atomic - a 64-entry
+// scan, then placement).  Output: the records again, grouped by pixel (sorted[start[chunk] + ...]), and pxoff[chunk][65],
+// the start of every pixel's run inside the chunk.  Needs nothing from the backward pass: it runs beside it.
+struct PgMatch { int leader, rank, cnt; };
 
-constexpr int PG_PX = 64, PG_PITCH = 260, PG_THREADS = 512;
+__device__ __forceinline__ PgMatch pg_match(bool valid, unsigned px, int lane) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 6; ++bit) {
+    const bool on = (px >> bit) & 1u;
+    const unsigned long long bal = __ballot(on);
+    peers &= on ? bal : ~bal;
+  }
+  PgMatch m;
+  m.leader = valid ? __ffsll((long long)peers) - 1 : lane;
+  m.rank = __popcll(peers & ((1ull << lane) - 1ull));
+  m.cnt = __popcll(peers);
+  return m;
+}
 
-__global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const PgReduceParams p) {
-  extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH]
-  __shared__ int s_next;
+constexpr int PG_THREADS = 512;
+
+__global__ __launch_bounds__(PG_THREADS) void pyramid_grad_sort_kernel(const int* __restrict__ count, const int* __restrict__ start,
+                                                                       const uint2* __restrict__ rec, uint2* __restrict__ sorted,
+                                                                       int* __restrict__ pxoff) {
+  __shared__ int s_hist[64], s_cur[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = p.total - 1 - blockIdx.x;
-  float* dst = p.out[0];
-  int hw = p.hw[0], tiles = p.tiles[0], tbase = 0, os = p.start[0];
-#pragma unroll
-  for (int l = 1; l < GD4D_MAX_LEVELS; ++l)
-    if (l < p.L && t >= p.tile_base[l]) { dst = p.out[l]; hw = p.hw[l]; os = p.start[l]; tiles = p.tiles[l]; tbase = p.tile_base[l]; }
-  const int rel = t - tbase;
-  const int row = rel / tiles;
-  const int pix0 = (rel - row * tiles) * PG_PX;
-  const int npx = min(PG_PX, hw - pix0);
-  const int gid0 = row * p.S + os + pix0;
-  if (tid == 0) s_next = 0;
+  const int chunk = blockIdx.x;
+  const int n = count[chunk];
+  const size_t base = (size_t)start[chunk];
+  if (tid < 64) s_hist[tid] = 0;
   __syncthreads();
-  for (;;) {
-    int px = 0;
-    if (lane == 0) px = atomicAdd(&s_next, 1);
-    px = __builtin_amdgcn_readfirstlane(px);
-    if (px >= npx) break;
-    const int e = __builtin_amdgcn_readfirstlane(p.end[gid0 + px]);
-    const int cn = __builtin_amdgcn_readfirstlane(p.count[gid0 + px]);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = e - cn; base < e; base += 64) {
-      const int m = min(64, e - base);
-      uint2 r = make_uint2(0u, 0u);
-      if (lane < m) r = p.rec[base + lane];
-      int i = 0;
-      for (; i + 4 <= m; i += 4) {
-        float w[4];
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          w[u] = __uint_as_float(__builtin_amdgcn_readlane((int)r.x, i + u));
-          const unsigned id = __builtin_amdgcn_readlane((int)r.y, i + u);
-          v[u] = *reinterpret_cast<const float4*>(p.table + (size_t)id * kChannels + lane * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
-          acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
-        }
-      }
-      for (; i < m; ++i) {
-        const float w = __uint_as_float(__builtin_amdgcn_readlane((int)r.x, i));
-        const unsigned id = __builtin_amdgcn_readlane((int)r.y, i);
-        const float4 v = *reinterpret_cast<const float4*>(p.table + (size_t)id * kChannels + lane * 4);
-        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
-        acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
-      }
-    }
-    *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = acc;
+  for (int i0 = 0; i0 < n; i0 += PG_THREADS) {
+    const int i = i0 + tid;
+    const bool valid = i < n;
+    const unsigned px = valid ? rec[base + i].y >> 26 : 0u;
+    const PgMatch m = pg_match(valid, px, lane);
+    if (valid && m.leader == lane) atomicAdd(&s_hist[px], m.cnt);
   }
   __syncthreads();
-  // wave w writes channels 32 w .. 32 w + 31: lane = pixel, 256-byte runs
-  float* gp = dst + ((size_t)row * kChannels + wave * 32) * hw + pix0 + lane;
-  if (lane < npx) {
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) gp[(size_t)i * hw] = s_tp[lane * PG_PITCH + wave * 32 + i];
+  if (wave == 0) {
+    const int v = s_hist[lane];
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    s_cur[lane] = inc - v;
+    pxoff[(size_t)chunk * 65 + lane] = inc - v;
+    if (lane == 63) pxoff[(size_t)chunk * 65 + 64] = inc;
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += PG_THREADS) {
+    const int i = i0 + tid;
+    const bool valid = i < n;
+    const uint2 r = valid ? rec[base + i] : make_uint2(0u, 0u);
+    const unsigned px = r.y >> 26;
+    const PgMatch m = pg_match(valid, px, lane);
+    int at = 0;
+    if (valid && m.leader == lane) at = atomicAdd(&s_cur[px], m.cnt);
+    at = __shfl(at, m.leader);
+    if (valid) sorted[base + at + m.rank] = r;
   }
 }
 
-static int fill_geom(PgGeom& g, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, int L) {
-  int start = 0;
-  for (int l = 0; l < 4; ++l) { g.cam_stride[l] = 1; g.lvl_start[l] = 0; }
+// One 512-thread workgroup per chunk, a wave per eighth of the chunk's pixels.  Everything a wave touches is wave-
+// uniform - its pixels, their runs, the records - so the records arrive through the SCALAR cache (s_load, eight at a
+// time) and the weight and the table row's address are scalar registers: per record one 1-KB row of the dA table (lane c
+// holds channels 4c .. 4c+3) and four FMAs with a scalar multiplier; no cross-lane traffic, no branch per record (the
+// first version took the records from LDS with v_readlane and compared pixels per record: 16 scalar + 16 vector
+// instructions per record on 4 waves per SIMD, 0.9 ms of the 1.0 without a single table load).  A finished pixel is one
+// row of an LDS tile; the tile is then written NCHW, every pixel of the pyramid exactly once: no zero fill, no
+// read-modify-write.  Grid = 8 XCDs x an eighth of the chunks (chunk_order: the walk; or level by level, coarse first).
+struct PgReduceParams {
+  float* out[GD4D_MAX_LEVELS];
+  PgChunks g;
+  int per_xcd[GD4D_MAX_LEVELS];  // chunks of level l per XCD (walk without chunk_order)
+  const int32_t* chunk_order;    // optional: the walk, a permutation of the chunks; XCD x takes entries [x per, (x + 1) per)
+  int per;                       //   per = ceil(chunks / 8)
+  const int* start;
+  const int* pxoff;
+  const uint2* rec;              // sorted by pixel inside every chunk
+  const float* table;
+  int R, L;
+};
+
+constexpr int PG_PX = 64, PG_PITCH = 260, PG_UNROLL = 8;
+
+// U records of one pixel's run.  FULL: all U exist (consecutive scalar loads, merged by the compiler); else the tail
+// repeats the last record with weight 0.  VARIANT (dev builds): 0 = the product, 1 = every record reads one of 64 rows,
+// 2 / 3 = no table loads.
+template <int U, bool FULL, int VARIANT>
+__device__ __forceinline__ void pg_group(const float* __restrict__ table, const uint2* __restrict__ rec, int i, int b, int lane, float4& acc) {
+  float w[U];
+  float4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint2 r = FULL ? rec[i + u] : rec[min(i + u, b - 1)];   // uniform address: scalar loads
+    w[u] = (FULL || i + u < b) ? __uint_as_float(r.x) : 0.f;
+    const unsigned id = VARIANT == 1 ? (r.y & 63u) : (r.y & 0x3ffffffu);
+    if (VARIANT >= 2) v[u] = make_float4(__uint_as_float(r.y), 0.f, 0.f, 0.f);
+    else v[u] = *reinterpret_cast<const float4*>(table + (size_t)id * kChannels + lane * 4);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+    acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+  }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const PgReduceParams p) {
+  extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7;
+  int j = blockIdx.x >> 3, l = p.L - 1, idx, chunk;
+  if (p.chunk_order) {
+    const int e = xcd * p.per + j;
+    if (j >= p.per || e >= p.g.total) return;
+    chunk = p.chunk_order[e];
+    l = 0;
+    while (l + 1 < p.L && chunk >= p.g.chunk_base[l + 1]) ++l;
+    idx = chunk - p.g.chunk_base[l];
+  } else {
+    while (l > 0 && j >= p.per_xcd[l]) { j -= p.per_xcd[l]; --l; }
+    const int n_l = p.g.chunk_base[l + 1] - p.g.chunk_base[l];
+    idx = xcd * p.per_xcd[l] + j;
+    if (j >= p.per_xcd[l] || idx >= n_l) return;
+    chunk = p.g.chunk_base[l] + idx;
+  }
+  const int CWl = p.g.CW[l], CHl = p.g.CH[l], cws = p.g.cws[l], chs = p.g.chs[l], W = p.g.lvl_w[l], H = p.g.lvl_h[l];
+  const int row = idx / (CHl * CWl);
+  const int rem = idx - row * (CHl * CWl);
+  const int cy = rem / CWl, cx = rem - cy * CWl;
+  const int* po = p.pxoff + (size_t)chunk * 65;
+  const uint2* rec = p.rec + p.start[chunk];
+  if (VARIANT == 4) { if (po[0] < 0) s_tp[0] = 1.f; return; }
+  const int ppw = (1 << (cws + chs)) >> 3;
+  for (int px = wave * ppw; px < (wave + 1) * ppw; ++px) {
+    const int a = po[px], b = po[px + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = a;
+    for (; i + PG_UNROLL <= b; i += PG_UNROLL) pg_group<PG_UNROLL, true, VARIANT>(p.table, rec, i, b, lane, acc);
+    if (b - i > 4) pg_group<8, false, VARIANT>(p.table, rec, i, b, lane, acc);
+    else if (b - i > 0) pg_group<4, false, VARIANT>(p.table, rec, i, b, lane, acc);
+    *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = acc;
+  }
+  __syncthreads();
+  // wave w writes channels 32 w .. 32 w + 31; lane = pixel of the chunk (runs of cw pixels)
+  const int py = lane >> cws, pxx = lane & ((1 << cws) - 1);
+  const int y = (cy << chs) + py, x = (cx << cws) + pxx;
+  if (VARIANT == 3) return;
+  if (py < (1 << chs) && y < H && x < W) {
+    float* gp = p.out[l] + ((size_t)row * kChannels + wave * 32) * ((size_t)H * W) + (size_t)y * W + x;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) __builtin_nontemporal_store(s_tp[lane * PG_PITCH + wave * 32 + i], gp + (size_t)i * H * W);
+  }
+}
+
+// chunk shapes: ~64 pixels on the two finest levels, a quarter per level beyond (records per pixel grow 4x per level)
+static int fill_chunks(PgChunks& g, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, int R, int L) {
+  if (L <= 0 || L > 4 || R <= 0) return GD4D_EINVAL;
+  long long base = 0;
+  for (int l = 0; l < 4; ++l) { g.cam_stride[l] = 1; g.lvl_w[l] = 1; g.lvl_h[l] = 1; g.cws[l] = 0; g.chs[l] = 0; g.CW[l] = 1; g.CH[l] = 1; }
+  const long long hw0 = (long long)level_hw[0] * level_hw[1];
   for (int l = 0; l < L; ++l) {
     const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
-    if (h <= 0 || w <= 0 || cam_stride_bytes[l] <= 0 || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EINVAL;
-    g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
-    g.lvl_start[l] = start;
-    start += h * w;
+    if (h <= 0 || w <= 0) return GD4D_EINVAL;
+    if (cam_stride_bytes) {
+      if (cam_stride_bytes[l] <= 0 || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EINVAL;
+      g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
+    }
+    long long want = 256ll * h * w / (hw0 > 0 ? hw0 : 1);            // 64 x (pixels of this level / pixels of level 1)
+    int px = 64;
+    while (px > 8 && px > want) px >>= 1;                           // (8 waves of the reduce kernel: at least a pixel each)
+    int chs = 1, cws = 0;
+    while ((2 << cws) * 2 <= px) ++cws;                             // cw = px / 2, ch = 2
+    g.lvl_w[l] = w; g.lvl_h[l] = h; g.cws[l] = cws; g.chs[l] = chs;
+    g.CW[l] = (w + (1 << cws) - 1) >> cws; g.CH[l] = (h + (1 << chs) - 1) >> chs;
+    g.chunk_base[l] = (int)base;
+    base += (long long)R * g.CW[l] * g.CH[l];
+    if (base >= (1ll << 25)) return GD4D_EUNSUPPORTED;
   }
-  if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
-  g.pix_stride = (unsigned)pix_stride_bytes;
-  g.S = start;
+  for (int l = L; l <= 4; ++l) g.chunk_base[l] = (int)base;
+  if (cam_stride_bytes && (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31))) return GD4D_EINVAL;
+  g.pix_stride = cam_stride_bytes ? (unsigned)pix_stride_bytes : 1u;
+  g.total = (int)base;
   return GD4D_OK;
 }
 
@@ -774,41 +909,47 @@ extern "C" int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, 
 #undef GD4D_PB_GO
 }
 
-static int pg_bucket(bool fill, const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
-                     int32_t* counter, void* records, unsigned id_base, const int32_t* query_order, int B, int N, int Q, int Hh,
-                     int L, int P, void* stream) {
-  using namespace gd4d;
-  if (!plan || !level_hw || !cam_stride_bytes || !counter || (fill && !records)) return GD4D_EINVAL;
-  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
-  if (P != kPoints || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
-  PgGeom g{};
-  if (int rc = fill_geom(g, level_hw, cam_stride_bytes, pix_stride_bytes, L)) return rc;
-  if ((long long)B * N * g.S >= (1ll << 31)) return GD4D_EUNSUPPORTED;
-  const int* hdr = static_cast<const int*>(plan);
-  const uint2* pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan) + plan_hdr_bytes(B, Q));
-  const int cap_t = plan_cap_t(N, P);
-  const dim3 grid((B * Q * Hh + 3) / 4);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (fill)
-    hipLaunchKernelGGL(pyramid_grad_bucket_kernel<true>, grid, dim3(256), 0, s, hdr, pair, cap_t, Hh, B * Q, g, counter,
-                       static_cast<uint2*>(records), query_order, id_base);
-  else
-    hipLaunchKernelGGL(pyramid_grad_bucket_kernel<false>, grid, dim3(256), 0, s, hdr, pair, cap_t, Hh, B * Q, g, counter,
-                       static_cast<uint2*>(nullptr), query_order, 0u);
-  return check_launch();
+extern "C" int64_t gd4d_pyramid_grad_chunks(const int32_t* level_hw, int R, int L) {
+  gd4d::PgChunks g{};
+  if (!level_hw || gd4d::fill_chunks(g, level_hw, nullptr, 0, R, L) != GD4D_OK) return 0;
+  return g.total;
+}
+
+extern "C" size_t gd4d_pyramid_grad_slots_bytes(int B, int N, int Q, int Hh, int P) {
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || P <= 0) return 0;
+  return (size_t)B * Q * Hh * gd4d::plan_cap_t(N, P) * 64 * sizeof(uint2);
 }
 
 extern "C" int gd4d_pyramid_grad_count(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes,
-                                       int64_t pix_stride_bytes, int32_t* count, int B, int N, int Q, int Hh, int L, int P,
-                                       void* stream) {
-  return pg_bucket(false, plan, level_hw, cam_stride_bytes, pix_stride_bytes, count, nullptr, 0u, nullptr, B, N, Q, Hh, L, P, stream);
+                                       int64_t pix_stride_bytes, int32_t* count, void* slots, size_t slots_bytes, int B, int N,
+                                       int Q, int Hh, int L, int P, void* stream) {
+  using namespace gd4d;
+  if (!plan || !level_hw || !cam_stride_bytes || !count || !slots) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
+  if (P != kPoints || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if (slots_bytes < gd4d_pyramid_grad_slots_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
+  PgChunks g{};
+  if (int rc = fill_chunks(g, level_hw, cam_stride_bytes, pix_stride_bytes, B * N, L)) return rc;
+  const int* hdr = static_cast<const int*>(plan);
+  const uint2* pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan) + plan_hdr_bytes(B, Q));
+  hipLaunchKernelGGL(pyramid_grad_count_kernel, dim3((B * Q * Hh + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hdr, pair,
+                     plan_cap_t(N, P), Hh, B * Q, g, count, static_cast<uint2*>(slots));
+  return check_launch();
 }
 
-extern "C" int gd4d_pyramid_grad_fill(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes,
-                                      int64_t pix_stride_bytes, int32_t* cursor, void* records, uint32_t id_base,
-                                      const int32_t* query_order, int B, int N, int Q, int Hh, int L, int P, void* stream) {
-  return pg_bucket(true, plan, level_hw, cam_stride_bytes, pix_stride_bytes, cursor, records, id_base, query_order, B, N, Q, Hh, L, P,
-                   stream);
+extern "C" int gd4d_pyramid_grad_fill(const void* plan, const void* slots, const int32_t* start, void* records, uint32_t id_base,
+                                      const int32_t* query_order, int B, int N, int Q, int Hh, int P, void* stream) {
+  using namespace gd4d;
+  if (!plan || !slots || !start || !records) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0) return GD4D_EINVAL;
+  if (P != kPoints || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if ((unsigned long long)id_base + (unsigned long long)B * Q * Hh > (1ull << 26)) return GD4D_EUNSUPPORTED;
+  const int* hdr = static_cast<const int*>(plan);
+  const uint2* pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan) + plan_hdr_bytes(B, Q));
+  hipLaunchKernelGGL(pyramid_grad_fill_kernel, dim3((B * Q * Hh + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hdr, pair,
+                     static_cast<const uint2*>(slots), plan_cap_t(N, P), Hh, B * Q, start, static_cast<uint2*>(records), query_order,
+                     id_base);
+  return check_launch();
 }
 
 extern "C" size_t gd4d_pyramid_grad_scan_workspace_bytes(int64_t n) {
@@ -833,28 +974,64 @@ extern "C" int gd4d_pyramid_grad_scan(const int32_t* count, int32_t* cursor, voi
   return check_launch();
 }
 
-extern "C" int gd4d_pyramid_grad_reduce(const int32_t* count, const int32_t* end, const void* records, const float* table,
-                                        void* const* grads, const int32_t* level_hw, int R, int C, int L, void* stream) {
+extern "C" int gd4d_pyramid_grad_chunk_geometry(const int32_t* level_hw, int R, int L, int32_t* out) {
+  gd4d::PgChunks g{};
+  if (!level_hw || !out) return GD4D_EINVAL;
+  if (int rc = gd4d::fill_chunks(g, level_hw, nullptr, 0, R, L)) return rc;
+  for (int l = 0; l < L; ++l) {
+    out[5 * l] = g.cws[l]; out[5 * l + 1] = g.chs[l]; out[5 * l + 2] = g.CW[l]; out[5 * l + 3] = g.CH[l]; out[5 * l + 4] = g.chunk_base[l];
+  }
+  return GD4D_OK;
+}
+
+extern "C" int gd4d_pyramid_grad_sort(const int32_t* count, const int32_t* start, const void* records, void* sorted,
+                                      int32_t* pxoff, int64_t chunks, void* stream) {
   using namespace gd4d;
-  if (!count || !end || !records || !table || !grads || !level_hw || R <= 0 || L <= 0) return GD4D_EINVAL;
+  if (!count || !start || !records || !sorted || !pxoff || chunks <= 0) return GD4D_EINVAL;
+  if (chunks >= (1ll << 25)) return GD4D_EUNSUPPORTED;
+  hipLaunchKernelGGL(pyramid_grad_sort_kernel, dim3((unsigned)chunks), dim3(PG_THREADS), 0, static_cast<hipStream_t>(stream), count, start,
+                     static_cast<const uint2*>(records), static_cast<uint2*>(sorted), pxoff);
+  return check_launch();
+}
+
+extern "C" int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxoff, const void* sorted, const float* table,
+                                        void* const* grads, const int32_t* level_hw, const int32_t* chunk_order, int R, int C, int L,
+                                        void* stream) {
+  using namespace gd4d;
+  if (!start || !pxoff || !sorted || !table || !grads || !level_hw || R <= 0 || L <= 0) return GD4D_EINVAL;
   if (C != kChannels || L > GD4D_MAX_LEVELS) return GD4D_EUNSUPPORTED;
   if (!aligned16(table)) return GD4D_EALIGN;
   PgReduceParams p{};
-  int s = 0, base = 0;
+  if (int rc = fill_chunks(p.g, level_hw, nullptr, 0, R, L)) return rc;
+  int per = 0;
   for (int l = 0; l < L; ++l) {
-    if (!grads[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
-    const int hw = level_hw[2 * l] * level_hw[2 * l + 1];
-    p.out[l] = static_cast<float*>(grads[l]); p.hw[l] = hw; p.start[l] = s; p.tiles[l] = (hw + PG_PX - 1) / PG_PX;
-    p.tile_base[l] = base;
-    s += hw;
-    base += R * p.tiles[l];
+    if (!grads[l]) return GD4D_EINVAL;
+    p.out[l] = static_cast<float*>(grads[l]);
+    p.per_xcd[l] = (p.g.chunk_base[l + 1] - p.g.chunk_base[l] + 7) / 8;
+    per += p.per_xcd[l];
   }
-  for (int l = L; l <= GD4D_MAX_LEVELS; ++l) p.tile_base[l] = base;
-  for (int l = L; l < GD4D_MAX_LEVELS; ++l) { p.tiles[l] = 1; p.hw[l] = 1; }
-  p.count = count; p.end = end; p.rec = static_cast<const uint2*>(records); p.table = table;
-  p.R = R; p.L = L; p.S = s; p.total = base;
+  p.start = start; p.pxoff = pxoff; p.rec = static_cast<const uint2*>(sorted); p.table = table;
+  p.R = R; p.L = L;
+  p.chunk_order = chunk_order;
+  p.per = (p.g.total + 7) / 8;
+  if (chunk_order) per = p.per;
   const size_t lds = (size_t)PG_PX * PG_PITCH * sizeof(float);
-  if (!allow_dynamic_lds(reinterpret_cast<const void*>(pyramid_grad_reduce_kernel), (int)lds)) return GD4D_ELAUNCH;
-  hipLaunchKernelGGL(pyramid_grad_reduce_kernel, dim3(base), dim3(PG_THREADS), lds, static_cast<hipStream_t>(stream), p);
-  return check_launch();
+  auto go = [&](auto kern) -> int {
+    if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(8 * per), dim3(PG_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    return check_launch();
+  };
+#ifdef GD4D_DEV                                      // dev ablations (GD4D_PG_VARIANT): 1 = 64 table rows, 2 = no table loads, 3 = nor the write-out, 4 = chunk lookup only
+  {
+    const char* e = getenv("GD4D_PG_VARIANT");
+    switch (e ? atoi(e) : 0) {
+      case 1: return go(pyramid_grad_reduce_kernel<1>);
+      case 2: return go(pyramid_grad_reduce_kernel<2>);
+      case 3: return go(pyramid_grad_reduce_kernel<3>);
+      case 4: return go(pyramid_grad_reduce_kernel<4>);
+      default: break;
+    }
+  }
+#endif
+  return go(pyramid_grad_reduce_kernel<0>);
 }

@@ -215,6 +215,7 @@ class Deform3DCrossAttn(nn.Module):
         lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)
         from .autograd import CrossAttnRawFunction
+        own = None
         if projected is None and cl is None:     # a stand-alone call: its own copy of the pyramid, if the raw path applies
             own = Fn.raw_pyramid_for_training([self], value)
             cl = None if own is None else own[id(self)][3]
@@ -222,6 +223,8 @@ class Deform3DCrossAttn(nn.Module):
             # the inference step's kernels behind autograd: no projected value tensor (gd4d_cross_attn_sliced_bwd.hip)
             agg = CrossAttnRawFunction.apply(cl[1], reference_points, offsets, attn_logits, cam_logits, lidar2img,
                                              self.value_proj.weight, self.value_proj.bias, cl[0], self.pc_range, img_h, img_w)
+            if own is not None:
+                cl[0].join()                     # (the decoder joins its layers' side-stream work itself, after the last one)
             return self._finish_autograd(agg, reference_points, inp_residual)
         if projected is None:
             val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)

@@ -441,6 +441,9 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
             pipeline.finish()
         if own_late:
             late.finish()
+        for entry in {id(v): v for v in (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).values()}.values():
+            if len(entry) > 3 and isinstance(entry[3], tuple):       # training on the raw pyramid: the record counts of
+                entry[3][0].join()                                   # the layers ran on the side stream - join it
         if aux is not None:
             torch.cuda.current_stream(output.device).wait_stream(aux)
         if self.return_intermediate:

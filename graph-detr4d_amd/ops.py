@@ -394,73 +394,141 @@ def cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits
     return gr, go, ga, gc
 
 
+_CHUNK_WALKS = {}
+
+
+def _chunk_walk(level_hw, rows, device, regions=(6, 10)):
+    """The order gd4d_pyramid_grad_reduce walks the chunks in: camera by camera, and inside a camera image region by image
+    region (regions[0] x regions[1] per image) with ALL levels of a region together - the workgroups an XCD runs at one
+    time then need the table rows of the few queries that look at one region, not of a whole camera (level-major, the
+    64 chunks in flight per XCD cover most of a camera's coarse maps: 77 % L2 hits, 2.8 GB from the fabric per pass).
+    Cached per geometry (an int32 permutation on the device)."""
+    import numpy as np
+    key = (tuple(level_hw), int(rows), str(device), regions)
+    hit = _CHUNK_WALKS.get(key)
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    nl = len(level_hw)
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
+    geo = (ctypes.c_int32 * (5 * nl))()
+    _lib.check(lib.gd4d_pyramid_grad_chunk_geometry(lv, int(rows), nl, geo), 'gd4d_pyramid_grad_chunk_geometry')
+    keys, ids = [], []
+    span = max(int(geo[5 * l + 2]) * int(geo[5 * l + 3]) for l in range(nl))
+    for l, (h, w) in enumerate(level_hw):
+        cws, chs, cw_n, ch_n, base = geo[5 * l:5 * l + 5]
+        r, cy, cx = np.meshgrid(np.arange(rows), np.arange(ch_n), np.arange(cw_n), indexing='ij')
+        v = np.minimum((cy + 0.5) * (1 << chs) / h, 0.999999)
+        u = np.minimum((cx + 0.5) * (1 << cws) / w, 0.999999)
+        ry, rx = (v * regions[0]).astype(np.int64), (u * regions[1]).astype(np.int64)
+        rx = np.where(ry % 2 == 1, regions[1] - 1 - rx, rx)                        # boustrophedon: neighbours stay neighbours
+        k = (((r * regions[0] + ry) * regions[1] + rx) * nl + (nl - 1 - l)) * span + cy * cw_n + cx
+        keys.append(k.reshape(-1))
+        ids.append((base + (r * ch_n + cy) * cw_n + cx).reshape(-1))
+    keys, ids = np.concatenate(keys), np.concatenate(ids)
+    walk = torch.from_numpy(ids[np.argsort(keys, kind='stable')].astype(np.int32)).to(device)
+    _CHUNK_WALKS[key] = walk
+    return walk
+
+
 class PyramidGrad:
     """The gradient of an NCHW pyramid from the plans of all decoder layers (gd4d_pyramid_grad_count / _scan / _fill /
     _reduce): add_layer() per layer (in any order, each with its plan and its grad_agg rows), finish() once.
 
-    Buffers are sized for `layers` layers of B*Q*Hh rows; the record buffer by the plans' capacity (8 bytes per pair a
-    plan can hold - only what the counts say is touched)."""
+    Buffers are sized for `layers` layers of B*Q*Hh rows; the slot / record buffers by the plans' capacity (8 bytes per
+    pair a plan can hold - only what the counts say is touched)."""
 
-    def __init__(self, pyramid, layers, b, q, num_heads):
+    def __init__(self, pyramid, layers, b, q, num_heads, chunk_walk=True):
         self.pyramid, self.layers, self.b, self.q, self.hh = pyramid, int(layers), int(b), int(q), int(num_heads)
         dev = pyramid.device
+        lib = _lib.load()
         self.n = pyramid.rows // self.b
-        self.s = sum(h * w for h, w in pyramid.level_hw)
-        self.count = torch.zeros(pyramid.rows * self.s, device=dev, dtype=torch.int32)
-        self.table = torch.empty(self.layers, self.b * self.q, self.hh, 256, device=dev, dtype=torch.float32)
-        self.plans = []
+        nl = len(pyramid.level_hw)
+        self._lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in pyramid.level_hw for x in hw])
+        self._cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
+        self.chunks = int(lib.gd4d_pyramid_grad_chunks(self._lv, pyramid.rows, nl))
+        if self.chunks <= 0:
+            raise _lib.Gd4dError('gd4d_pyramid_grad_chunks: unsupported pyramid')
+        self.count = torch.zeros(self.chunks, device=dev, dtype=torch.int32)
+        self.table = None
+        if self.layers > 0:
+            self.alloc_table(self.layers)
+        self.slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, self.q, self.hh, 4))
+        self.plans, self.prepared = [], None
+        self.order = _chunk_walk(pyramid.level_hw, pyramid.rows, dev) if chunk_walk else None
+
+    def alloc_table(self, layers):
+        """The grad_agg table for `layers` layers (zeros: a layer whose backward never runs contributes nothing)."""
+        self.layers = int(layers)
+        self.table = torch.zeros(self.layers, self.b * self.q, self.hh, 256, device=self.pyramid.device, dtype=torch.float32)
 
     def grad_agg_rows(self, layer):
         """(B, Q, Hh, 256) view of the table: where layer `layer`'s gd4d_value_proj_heads_bwd writes."""
         return self.table[layer].view(self.b, self.q, self.hh, 256)
 
-    def _geom(self):
+    def add_layer(self, layer, plan):
+        """Hand every record of `plan` its slot (the plan is kept until finish(): its buffer must not be overwritten)."""
+        lib = _lib.load()
+        slots = torch.empty(self.slot_bytes, device=self.pyramid.device, dtype=torch.uint8)
+        code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), self._lv, self._cs, self.pyramid.pix_stride,
+                                           _dev(self.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(self.slot_bytes),
+                                           self.b, self.n, self.q, self.hh, len(self.pyramid.level_hw), 4, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_count')
+        self.plans.append((int(layer), plan, slots))
+
+    def prepare(self):
+        """scan + fill + sort: the layers' records bucketed by chunk and grouped by pixel.  Needs the counts of every layer
+        (add_layer) and nothing from the backward pass."""
+        lib = _lib.load()
+        dev = self.pyramid.device
+        i32 = torch.int32
+        start = torch.empty(self.chunks, device=dev, dtype=i32)
+        wsb = int(lib.gd4d_pyramid_grad_scan_workspace_bytes(self.chunks))
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        code = lib.gd4d_pyramid_grad_scan(_dev(self.count, 'count', i32), _dev(start, 'start', i32), _dev(ws, 'workspace'),
+                                          ctypes.c_size_t(wsb), self.chunks, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_scan')
+        nbytes = max(len(self.plans), 1) * self.slot_bytes
+        records = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        rows_per_layer = self.b * self.q * self.hh
+        for layer, plan, slots in self.plans:
+            code = lib.gd4d_pyramid_grad_fill(
+                _dev(plan.buf, 'plan', torch.uint8), _dev(slots, 'slots'), _dev(start, 'start', i32), _dev(records, 'records'),
+                layer * rows_per_layer, None if plan.order is None else _order_ptr(plan.order, self.b * self.q),
+                self.b, self.n, self.q, self.hh, 4, _stream())
+            _lib.check(code, 'gd4d_pyramid_grad_fill')
+        sorted_ = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        pxoff = torch.empty(self.chunks, 65, device=dev, dtype=i32)
+        code = lib.gd4d_pyramid_grad_sort(_dev(self.count, 'count', i32), _dev(start, 'start', i32), _dev(records, 'records'),
+                                          _dev(sorted_, 'sorted'), _dev(pxoff, 'pxoff', i32), self.chunks, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_sort')
+        self.prepared = (start, pxoff, sorted_)
+        self.plans = []
+
+    def reduce(self, grads=None):
+        """-> L tensors (R, 256, H_l, W_l) fp32: the pyramid's gradient summed over the layers (prepare() first; the table
+        rows of every layer must have been written)."""
+        lib = _lib.load()
         py = self.pyramid
         nl = len(py.level_hw)
-        return (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in py.level_hw for x in hw]), (ctypes.c_int64 * nl)(*py.cam_stride), nl
-
-    def add_layer(self, layer, plan):
-        """Count the records of `plan` (kept until finish(): its buffer must not be overwritten)."""
-        lib = _lib.load()
-        lv, cs, nl = self._geom()
-        code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), lv, cs, self.pyramid.pix_stride,
-                                           _dev(self.count, 'count', torch.int32), self.b, self.n, self.q, self.hh, nl, 4, _stream())
-        _lib.check(code, 'gd4d_pyramid_grad_count')
-        self.plans.append((int(layer), plan))
-
-    def finish(self, grads=None):
-        """-> L tensors (R, 256, H_l, W_l) fp32: the pyramid's gradient summed over the added layers."""
-        lib = _lib.load()
-        py = self.pyramid
-        dev = py.device
-        lv, cs, nl = self._geom()
         i32 = torch.int32
-        n_pix = self.count.numel()
-        cursor = torch.empty(n_pix, device=dev, dtype=i32)
-        wsb = int(lib.gd4d_pyramid_grad_scan_workspace_bytes(n_pix))
-        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-        code = lib.gd4d_pyramid_grad_scan(_dev(self.count, 'count', i32), _dev(cursor, 'cursor', i32), _dev(ws, 'workspace'),
-                                          ctypes.c_size_t(wsb), n_pix, _stream())
-        _lib.check(code, 'gd4d_pyramid_grad_scan')
-        cap = sum((p.buf.numel() - 0) // 8 for _, p in self.plans)          # pairs the plans can hold (header included: slack)
-        records = torch.empty(max(cap, 1) * 8, device=dev, dtype=torch.uint8)
-        rows_per_layer = self.b * self.q * self.hh
-        for layer, plan in self.plans:
-            code = lib.gd4d_pyramid_grad_fill(
-                _dev(plan.buf, 'plan', torch.uint8), lv, cs, py.pix_stride, _dev(cursor, 'cursor', i32), _dev(records, 'records'),
-                layer * rows_per_layer, None if plan.order is None else _order_ptr(plan.order, self.b * self.q),
-                self.b, self.n, self.q, self.hh, nl, 4, _stream())
-            _lib.check(code, 'gd4d_pyramid_grad_fill')
+        start, pxoff, sorted_ = self.prepared
         if grads is None:
-            grads = [torch.empty(py.rows, 256, h, w, device=dev, dtype=torch.float32) for h, w in py.level_hw]
+            grads = [torch.empty(py.rows, 256, h, w, device=py.device, dtype=torch.float32) for h, w in py.level_hw]
         for g in grads:
             _dev(g, 'grads', torch.float32)
         ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grads])
-        code = lib.gd4d_pyramid_grad_reduce(_dev(self.count, 'count', i32), _dev(cursor, 'end', i32), _dev(records, 'records'),
-                                            _dev(self.table, 'table', torch.float32), ptrs, lv, py.rows, 256, nl, _stream())
+        code = lib.gd4d_pyramid_grad_reduce(_dev(start, 'start', i32), _dev(pxoff, 'pxoff', i32), _dev(sorted_, 'sorted'),
+                                            _dev(self.table, 'table', torch.float32), ptrs, self._lv,
+                                            None if self.order is None else _dev(self.order, 'chunk_order', i32), py.rows, 256, nl,
+                                            _stream())
         _lib.check(code, 'gd4d_pyramid_grad_reduce')
-        self.plans = []
+        self.prepared = None
         return grads
+
+    def finish(self, grads=None):
+        self.prepare()
+        return self.reduce(grads)
 
 
 def _order_ptr(order, count):

@@ -214,17 +214,28 @@ int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level
  *   (B, Q, N) in the raw-view layout of cam_logits - the outputs of gd4d_cross_attn_bwd, which it replaces.  The mask is
  *   piecewise constant (no gradient), as in the reference.  workspace: gd4d_cross_attn_bwd_workspace_bytes (B > 1).
  *   status (or NULL): set to 1 if an item count disagrees with the plan's header.  All sums in a fixed order.
- * gd4d_pyramid_grad_count / _scan / _fill / _reduce - the gradient of the NCHW pyramid from the plans and grad_agg tables of
- *   ALL decoder layers at once, without atomics on feature data: a counting sort of the (pixel, weight, table row)
- *   records by pixel, then one pass that sums each pixel's records and writes every pixel of the gradient exactly once.
- *     count   count[gid] += 1 for every pair with a non-zero weight of one layer's plan (count zeroed by the caller; one
- *             call per layer); gid = r * S + level start + y*W_l + x over the R = B*N camera rows
- *     scan    cursor = exclusive prefix sum of count (n = R * S entries; workspace: gd4d_pyramid_grad_scan_workspace_bytes)
- *     fill    records[cursor[gid]++] = {weight, id_base + bq * Hh + h} (one call per layer, the layer's plan and order;
- *             records: 8 bytes per counted pair).  Afterwards cursor[gid] is the END of pixel gid's bucket.
- *     reduce  grads[l] (R, C, H_l, W_l) fp32 = sum over the bucket of weight * table[id, :]; table (rows, C) holds the
- *             grad_agg of every layer (row id as handed to fill).  The order inside a bucket follows the atomic slot
- *             hand-out (like the atomicAdd scatter it replaces, sums may differ in the last bits between runs). */
+ * gd4d_pyramid_grad_count / _scan / _fill / _sort / _reduce - the gradient of the NCHW pyramid from the plans and grad_agg tables of
+ *   ALL decoder layers at once, without atomics on feature data: the (pixel, weight, table row) records are bucketed by
+ *   CHUNK (<= 64 pixels: cw x ch of one camera row and level, 32 x 2 on the fine levels, smaller on the coarse ones;
+ *   gd4d_pyramid_grad_chunks(level_hw, R, L) chunks in all) and grouped by pixel inside a chunk, then one pass sums each
+ *   pixel's records and writes every pixel of the gradient exactly once.  Only that last pass needs the gradients: count
+ *   can run in the forward pass, scan / fill / sort beside the backward pass.
+ *     count   one call per layer: every pair of the layer's plan with a non-zero weight takes a slot in its chunk's
+ *             bucket (count (chunks) int32, zeroed by the caller before the first layer; lanes of a wave that share a
+ *             chunk share one atomic); slots (gd4d_pyramid_grad_slots_bytes, the plan's layout) keeps {chunk, pixel in
+ *             chunk, slot} for fill
+ *     scan    start = exclusive prefix sum of count (n = chunks; workspace: gd4d_pyramid_grad_scan_workspace_bytes)
+ *     fill    one call per layer: records[start[chunk] + slot] = {weight, pixel-in-chunk << 26 | id_base + bq * Hh + h}
+ *             (8 bytes per counted pair; id_base + B*Q*Hh <= 2^26)
+ *     sort    every chunk's records grouped by pixel: sorted (same size and chunk offsets as records), pxoff (chunks, 65)
+ *             int32 = where every pixel's run starts inside its chunk ([64] = the chunk's record count)
+ *     reduce  grads[l] (R, C, H_l, W_l) fp32 = per pixel, sum over its run of weight * table[id, :]; table
+ *             (rows, C) holds the grad_agg of every layer (row id as handed to fill).  The order of the additions follows
+ *             the slot hand-out (like the atomicAdd scatter it replaces, sums may differ in the last bits between runs).
+ *             chunk_order (or NULL): a permutation of the chunks - the order the workgroups walk them in, XCD x taking
+ *             the x-th eighth; results do not depend on it.  gd4d_pyramid_grad_chunk_geometry writes per level
+ *             {log2 cw, log2 ch, chunks across, chunks down, first chunk} (5 int32) for callers that build one: chunk id
+ *             = first + (r * down + y / ch) * across + x / cw. */
 int gd4d_value_proj_heads_bwd(const float* grad_out, const float* weight, const float* bias, float* grad_agg, float* beta,
                               int M, int Hh, int C, void* stream);
 size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P);
@@ -237,16 +248,22 @@ int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float
                              float* grad_attn_logits, float* grad_cam_logits, void* workspace, size_t workspace_bytes,
                              int32_t* status, int B, int N, int Q, int Hh, int L, int P, int flags, const int32_t* query_order,
                              void* stream);
+int64_t gd4d_pyramid_grad_chunks(const int32_t* level_hw, int R, int L);
+size_t gd4d_pyramid_grad_slots_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_pyramid_grad_count(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
-                            int32_t* count, int B, int N, int Q, int Hh, int L, int P, void* stream);
+                            int32_t* count, void* slots, size_t slots_bytes, int B, int N, int Q, int Hh, int L, int P,
+                            void* stream);
 size_t gd4d_pyramid_grad_scan_workspace_bytes(int64_t n);
 int gd4d_pyramid_grad_scan(const int32_t* count, int32_t* cursor, void* workspace, size_t workspace_bytes, int64_t n,
                            void* stream);
-int gd4d_pyramid_grad_fill(const void* plan, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
-                           int32_t* cursor, void* records, uint32_t id_base, const int32_t* query_order, int B, int N, int Q,
-                           int Hh, int L, int P, void* stream);
-int gd4d_pyramid_grad_reduce(const int32_t* count, const int32_t* end, const void* records, const float* table,
-                             void* const* grads, const int32_t* level_hw, int R, int C, int L, void* stream);
+int gd4d_pyramid_grad_fill(const void* plan, const void* slots, const int32_t* start, void* records, uint32_t id_base,
+                           const int32_t* query_order, int B, int N, int Q, int Hh, int P, void* stream);
+int gd4d_pyramid_grad_chunk_geometry(const int32_t* level_hw, int R, int L, int32_t* out);
+int gd4d_pyramid_grad_sort(const int32_t* count, const int32_t* start, const void* records, void* sorted, int32_t* pxoff,
+                           int64_t chunks, void* stream);
+int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxoff, const void* sorted, const float* table,
+                             void* const* grads, const int32_t* level_hw, const int32_t* chunk_order, int R, int C, int L,
+                             void* stream);
 
 /* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the
  * reference's MSDA kernel processes queries in index order).  Counting sort by (sample, azimuth of the de-normalised

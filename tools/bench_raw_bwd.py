@@ -19,7 +19,8 @@ def main():
     ap.add_argument('--layers', type=int, default=6)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--levels', default='r50')
-    ap.add_argument('--no-fill', action='store_true')
+    ap.add_argument('--no-walk', action='store_true')
+    ap.add_argument('--regions', default='6,10')
     a = ap.parse_args()
     dev = 'cuda'
     n, q, nl = 6 * a.frames, a.queries, a.layers
@@ -41,7 +42,9 @@ def main():
         order = ops.query_order_fwd(ref, synthetic.PC_RANGE)
         plan = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8, query_order=order)
         lay.append((ref, offsets, attn, cam, plan, torch.randn(1, q, 256, generator=g).to(dev)))
-    sink = ops.PyramidGrad(pyr, nl, 1, q, 8)
+    sink = ops.PyramidGrad(pyr, nl, 1, q, 8, chunk_walk=False)
+    if not a.no_walk:
+        sink.order = ops._chunk_walk(pyr.level_hw, pyr.rows, pyr.device, tuple(int(x) for x in a.regions.split(',')))
     dpart = torch.empty(ops.cross_attn_dot_bytes(1, n, q, 8), device=dev, dtype=torch.uint8)
     beta = torch.empty(1, q, 8, device=dev)
     status = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -70,36 +73,20 @@ def main():
         counts()
         sink.finish(grads)
 
-    import ctypes
-    from graph_detr4d_amd import _lib
-    lib = _lib.load()
-
-    def scan_fill():                       # (counts must be current)
+    def prepare():
         counts()
-        lv, cs, nlv = sink._geom()
-        n_pix = sink.count.numel()
-        cursor = torch.empty(n_pix, device=dev, dtype=torch.int32)
-        wsb = int(lib.gd4d_pyramid_grad_scan_workspace_bytes(n_pix))
-        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-        lib.gd4d_pyramid_grad_scan(sink.count.data_ptr(), cursor.data_ptr(), ws.data_ptr(), ctypes.c_size_t(wsb), n_pix, ops._stream())
-        if a.no_fill:
-            return
-        cap = sum(p.buf.numel() // 8 for _, p in sink.plans)
-        records = torch.empty(cap * 8, device=dev, dtype=torch.uint8)
-        for layer, plan in sink.plans:
-            lib.gd4d_pyramid_grad_fill(plan.buf.data_ptr(), lv, cs, pyr.pix_stride, cursor.data_ptr(), records.data_ptr(),
-                                       layer * q * 8, plan.order.data_ptr(), 1, n, q, 8, nlv, 4, ops._stream())
+        sink.prepare()
 
     heads()
     t_h = timed(heads, a.iters, nl)
     t_d = timed(dots, a.iters, nl)
     t_p = timed(planb, a.iters, nl)
     t_c = timed(counts, a.iters, 1)
-    t_sf = timed(scan_fill, a.iters, 1)
+    t_sf = timed(prepare, a.iters, 1)
     t_f = timed(finish, a.iters, 1)
     recs = int(sink.count.sum().item())
     print(f'per layer: heads_bwd {t_h:.1f} us, gather-dot {t_d:.1f} us, plan_bwd {t_p:.1f} us; per step ({nl} layers): zero + counts {t_c:.1f} us, '
-          f'counts + scan [+ fill] {t_sf:.1f} us, counts + scan + fill + reduce {t_f:.1f} us ({recs / 1e6:.2f} M records); status {int(status.item())}')
+          f'counts + scan + fill + sort {t_sf:.1f} us, all + reduce {t_f:.1f} us ({recs / 1e6:.2f} M records); status {int(status.item())}')
 
 
 if __name__ == '__main__':
