@@ -38,42 +38,38 @@ namespace gd4d {
 
 // ---------------------------------------------------------------------------------------------------------------
 // dA[m, h, :] = sum_d g[m, h Dh + d] W[h Dh + d, :],  beta[m, h] = sum_d g[m, h Dh + d] b[h Dh + d]
-constexpr int HB_ROWS = 8;
+// One workgroup per (16 rows, head), thread = output channel: the head's Dh weight rows are requested up front (the
+// first version walked all heads of 8 rows in one workgroup, a chain of Hh * Dh dependent loads: 101 us in the step).
+constexpr int HB_ROWS = 16;
 
+template <int DH>
 __global__ __launch_bounds__(256) void value_proj_heads_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, float* __restrict__ da,
                                                                    float* __restrict__ beta, int M, int HH) {
-  __shared__ float s_g[HB_ROWS][kChannels];
+  __shared__ float s_g[HB_ROWS][DH];
   const int tid = threadIdx.x;
-  const int m0 = blockIdx.x * HB_ROWS;
+  const int h = blockIdx.x % HH;
+  const int m0 = (blockIdx.x / HH) * HB_ROWS;
   const int rows = min(HB_ROWS, M - m0);
-  for (int i = tid; i < HB_ROWS * kChannels; i += 256) {
-    const int r = i / kChannels;
-    s_g[r][i % kChannels] = r < rows ? g[(size_t)(m0 + r) * kChannels + i % kChannels] : 0.f;
+  float wv[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) wv[d] = w[(size_t)(h * DH + d) * kChannels + tid];
+  for (int i = tid; i < HB_ROWS * DH; i += 256) {
+    const int r = i / DH, d = i % DH;
+    s_g[r][d] = r < rows ? g[(size_t)(m0 + r) * kChannels + h * DH + d] : 0.f;
   }
   __syncthreads();
-  const int DH = kChannels / HH;
-  for (int h = 0; h < HH; ++h) {
-    float acc[HB_ROWS];
+  for (int r = 0; r < rows; ++r) {
+    float acc = 0.f;
 #pragma unroll
-    for (int r = 0; r < HB_ROWS; ++r) acc[r] = 0.f;
-    for (int d = 0; d < DH; ++d) {
-      const float wv = w[(size_t)(h * DH + d) * kChannels + tid];
-#pragma unroll
-      for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(s_g[r][h * DH + d], wv, acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < HB_ROWS; ++r)
-      if (r < rows) da[((size_t)(m0 + r) * HH + h) * kChannels + tid] = acc[r];
+    for (int d = 0; d < DH; ++d) acc = fmaf(s_g[r][d], wv[d], acc);
+    da[((size_t)(m0 + r) * HH + h) * kChannels + tid] = acc;
   }
-  if (beta && tid < HB_ROWS * HH) {
-    const int r = tid / HH, h = tid % HH;
-    if (r < rows) {
-      float t = 0.f;
-      if (bias)
-        for (int d = 0; d < DH; ++d) t = fmaf(s_g[r][h * DH + d], bias[h * DH + d], t);
-      beta[(size_t)(m0 + r) * HH + h] = t;
-    }
+  if (beta && tid < rows) {
+    float t = 0.f;
+    if (bias)
+      for (int d = 0; d < DH; ++d) t = fmaf(s_g[tid][d], bias[h * DH + d], t);
+    beta[(size_t)(m0 + tid) * HH + h] = t;
   }
 }
 
@@ -774,9 +770,15 @@ extern "C" int gd4d_value_proj_heads_bwd(const float* grad_out, const float* wei
                                          float* beta, int M, int Hh, int C, void* stream) {
   using namespace gd4d;
   if (!grad_out || !weight || !grad_agg || M <= 0) return GD4D_EINVAL;
-  if (C != kChannels || Hh <= 0 || kChannels % Hh || Hh > 32) return GD4D_EUNSUPPORTED;
-  hipLaunchKernelGGL(value_proj_heads_bwd_kernel, dim3((M + HB_ROWS - 1) / HB_ROWS), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     grad_out, weight, bias, grad_agg, beta, M, Hh);
+  if (C != kChannels || (Hh != 4 && Hh != 8 && Hh != 16)) return GD4D_EUNSUPPORTED;
+  const dim3 grid(((M + HB_ROWS - 1) / HB_ROWS) * Hh);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (kChannels / Hh) {
+    case 64: hipLaunchKernelGGL(value_proj_heads_bwd_kernel<64>, grid, dim3(256), 0, s, grad_out, weight, bias, grad_agg, beta, M, Hh); break;
+    case 32: hipLaunchKernelGGL(value_proj_heads_bwd_kernel<32>, grid, dim3(256), 0, s, grad_out, weight, bias, grad_agg, beta, M, Hh); break;
+    case 16: hipLaunchKernelGGL(value_proj_heads_bwd_kernel<16>, grid, dim3(256), 0, s, grad_out, weight, bias, grad_agg, beta, M, Hh); break;
+    default: return GD4D_EUNSUPPORTED;
+  }
   return check_launch();
 }
 
