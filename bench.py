@@ -600,8 +600,97 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             'allreduce_buckets': reducer.describe()['buckets'],
             'roofline': None, 'cpu_baseline': None,
         }
+        if not a.no_roofline and not distill and n_cams <= 64 and len(levels) <= 4:
+            line['roofline'], line['kernels'] = _train_kernel_figures(a, n_cams, levels, dev)
         print(json.dumps(line))
     D.shutdown()
+
+
+def _train_kernel_figures(a, n_cams, levels, dev):
+    """The pyramid side of the training step, kernel by kernel, on synthetic inputs of the step's shapes (HIP events on the
+    launch stream, each kernel replayed from a hipGraph of `layers` launches on `layers` different query sets).  roofline =
+    the gather-dot kernel of the backward pass (the longest single kernel type of the step): SURVEY 8(d)'s algorithmic bytes
+    (V visible (query, head, camera, point, level) tuples x 4 corners x Dh x 4 B, V from the plan kernel's own mask) over
+    its duration, against 8 TB/s - the same recipe as the inference line's roofline; the kernel itself reads 8x that
+    (256 raw channels per corner instead of Dh = 32 projected ones: what removes value_proj over the pyramid)."""
+    from graph_detr4d_amd import ops, synthetic
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+    from bench_late import timed
+    nl, q, hh = a.layers, a.queries, 8
+    g = torch.Generator().manual_seed(11)
+    feats = [torch.randn(1, n_cams, 256, h, w, generator=g).to(dev) for h, w in levels]
+    l2i = torch.from_numpy(synthetic.camera_rig(max(1, n_cams // 6))[:n_cams]).unsqueeze(0).to(dev)
+    sp, shapes = ops.pyramid_slice_planar_fwd(feats)
+    pyr = ops.PyramidView.slice_planar(sp, shapes)
+    del feats
+    w_v, b_v = (torch.randn(256, 256, generator=g) / 16).to(dev), torch.randn(256, generator=g).to(dev)
+    lay, vis = [], 0
+    for _ in range(nl):
+        ref = torch.rand(1, q, 3, generator=g).to(dev)
+        off = (torch.randn(1, q, hh, 4, 3, generator=g) * 1.5).to(dev)
+        attn = torch.randn(1, q, hh, len(levels), 4, generator=g).to(dev)
+        cam = torch.randn(1, q, n_cams, generator=g).to(dev)
+        order = ops.query_order_fwd(ref, synthetic.PC_RANGE)
+        plan, mask = ops.cross_attn_plan_fwd(pyr, ref, off, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, hh, query_order=order,
+                                             want_mask=True)
+        vis += int(mask.sum().item())
+        lay.append((ref, off, attn, cam, plan, torch.randn(1, q, 256, generator=g).to(dev)))
+    vis /= nl                                                        # visible (camera, query, head, point) tuples per launch
+    sink = ops.PyramidGrad(pyr, nl, 1, q, hh)
+    dpart = torch.empty(ops.cross_attn_dot_bytes(1, n_cams, q, hh), device=dev, dtype=torch.uint8)
+    beta = torch.empty(1, q, hh, device=dev)
+    agg = ops.cross_attn_agg_sliced_fwd(lay[0][4])
+    grads = [torch.empty(n_cams, 256, h, w, device=dev) for h, w in levels]
+
+    def counts():
+        sink.count.zero_()
+        sink.plans = []
+        for i, L in enumerate(lay):
+            sink.add_layer(i, L[4])
+
+    def prepare():
+        counts()
+        sink.prepare()
+
+    def finish():
+        prepare()
+        sink.reduce(grads)
+    it = 5
+    t = {
+        'cross_attn_plan': timed(lambda: [ops.cross_attn_plan_fwd(pyr, L[0], L[1], L[2], L[3], l2i, synthetic.PC_RANGE, 900, 1600, hh,
+                                                                  plan=L[4], query_order=L[4].order) for L in lay], it, nl),
+        'cross_attn_agg_sliced': timed(lambda: [ops.cross_attn_agg_sliced_fwd(L[4], agg=agg) for L in lay], it, nl),
+        'value_proj_heads_bwd': timed(lambda: [ops.value_proj_heads_bwd(L[5], w_v, b_v, hh, grad_agg=sink.grad_agg_rows(i), beta=beta)
+                                               for i, L in enumerate(lay)], it, nl),
+        'cross_attn_dot_sliced': timed(lambda: [ops.cross_attn_dot_sliced(L[4], sink.grad_agg_rows(i), dpart=dpart)
+                                                for i, L in enumerate(lay)], it, nl),
+        'cross_attn_plan_bwd': timed(lambda: [ops.cross_attn_plan_bwd(L[4], dpart, beta, L[0], L[1], L[2], L[3], l2i, synthetic.PC_RANGE,
+                                                                      900, 1600) for L in lay], it, nl),
+    }
+    t_counts, t_prep, t_all = timed(counts, it, 1), timed(prepare, it, 1), timed(finish, it, 1)
+    records = int(sink.count.sum().item()) if sink.count.sum().item() else 0
+    counts()
+    records = int(sink.count.sum().item())
+    sink.plans = []
+    es = 4
+    alg = vis * len(levels) * 4 * (256 // hh) * es + q * (3 + hh * 12 + hh * len(levels) * 4 + n_cams) * 4 + n_cams * 64 + q * hh * 256 * 4
+    dot_us = t['cross_attn_dot_sliced']
+    kernels = {k: {'us_per_launch': v, 'launches_per_step': nl} for k, v in t.items()}
+    kernels['cross_attn_dot_sliced'].update({'gathered_bytes_per_launch': vis * len(levels) * 4 * 256 * es,
+                                             'gathered_GBps': vis * len(levels) * 4 * 256 * es / dot_us / 1e3})
+    kernels['pyramid_grad_count'] = {'us_per_launch': (t_counts) / nl, 'launches_per_step': nl, 'records_per_step': records,
+                                     'note': 'one slot atomic per group of lanes that share a chunk'}
+    kernels['pyramid_grad_scan_fill_sort'] = {'us_per_step': t_prep - t_counts}
+    kernels['pyramid_grad_reduce'] = {'us_per_step': t_all - t_prep, 'table_bytes_read': records * 1024,
+                                      'table_GBps': records * 1024 / (t_all - t_prep) / 1e3,
+                                      'gradient_bytes_written': sum(n_cams * 256 * h * w * 4 for h, w in levels),
+                                      'note': 'd(pyramid) of all layers in one pass: every pixel written once, no atomics on feature data'}
+    roofline = {'kernel': 'gd4d_cross_attn_dot_sliced (backward gather, per decoder layer)', 'bound': 'hbm',
+                'achieved': alg / dot_us / 1e3, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / dot_us / 1e3 / 8000.0, 'traffic': None,
+                'algorithmic_bytes_per_launch': alg, 'us_per_launch': dot_us,
+                'note': 'algorithmic bytes as SURVEY 8(d) defines them for the forward gather (Dh = 32 projected channels per corner); '
+                        'the kernel gathers 256 raw channels per corner (kernels.cross_attn_dot_sliced.gathered_GBps)'}
+    return roofline, kernels
 
 
 def _events():

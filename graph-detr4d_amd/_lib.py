@@ -33,6 +33,8 @@ SIGNATURES = {
     'gd4d_pyramid_slice_planar_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_heads_fwd': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),
     'gd4d_value_proj_heads_bwd': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),
+    'gd4d_value_proj_heads_bwd_weight_workspace_bytes': (_c.c_size_t, []),
+    'gd4d_value_proj_heads_bwd_weight': (_i, [_vp] * 6 + [_c.c_size_t, _i, _i, _i, _vp]),
     'gd4d_cross_attn_dot_bytes': (_c.c_size_t, [_i] * 5),
     'gd4d_cross_attn_dot_sliced': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp, _vp]),
     'gd4d_cross_attn_plan_bwd': (_i, [_vp] * 6 + [_f, _f] + [_vp] * 9 + [_c.c_size_t, _vp] + [_i] * 7 + [_vp, _vp]),

@@ -242,11 +242,8 @@ class CrossAttnRawFunction(torch.autograd.Function):
         gr, go, ga, gc = ops.cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
                                                  img_h, img_w, raw_cam_weights=raw_cam)
         gw = gb = None
-        g = grad_out.view(b * q, hh, c // hh)
-        if ctx.needs_input_grad[6]:
-            gw = torch.einsum('qhd,qhc->hdc', g, agg.view(b * q, hh, c)).reshape(c, c)
-        if vp_bias is not None and ctx.needs_input_grad[7]:
-            gb = (g * wsum.view(b * q, hh, 1)).sum(0).reshape(c)
+        if ctx.needs_input_grad[6] or (vp_bias is not None and ctx.needs_input_grad[7]):
+            gw, gb = ops.value_proj_heads_bwd_weight(grad_out, agg, wsum, want_bias=vp_bias is not None)
         ctx.plan = None
         return None, gr, go, ga.view_as(attn_logits), gc, None, gw, gb, None, None, None, None, None
 

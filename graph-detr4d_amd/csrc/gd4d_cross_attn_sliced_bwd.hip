@@ -73,6 +73,62 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_kernel(const float* 
   }
 }
 
+// dW[h Dh + d, c] = sum_m g[m, h Dh + d] agg[m, h, c],  db[h Dh + d] = sum_m g[m, h Dh + d] wsum[m, h]
+// Split over the rows: workgroup (head, 64 input channels, slice ks of HW_KS) sums its rows into a partial (wave = 64
+// channels x one group of Dh / 4 outputs: the g values it needs are wave-uniform - scalar loads); a second launch adds the
+// HW_KS partials in a fixed order (run-to-run identical).  (One workgroup per (head, channels) over all 900 rows: 112 us.)
+constexpr int HW_KS = 8;
+
+template <int DH>
+__global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const float* __restrict__ g, const float* __restrict__ agg,
+                                                                           const float* __restrict__ wsum, float* __restrict__ part,
+                                                                           float* __restrict__ part_b, int M, int HH) {
+  constexpr int DPT = DH / 4;                       // outputs per thread
+  const int tid = threadIdx.x;
+  const int c = tid & 63;
+  const int dg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = kChannels / 64;
+  const int ks = blockIdx.x % HW_KS, hc = blockIdx.x / HW_KS;
+  const int h = hc / tiles, c0 = (hc % tiles) * 64;
+  const int per = (M + HW_KS - 1) / HW_KS;
+  const int m0 = ks * per, m1 = min(M, m0 + per);
+  float acc[DPT];
+#pragma unroll
+  for (int i = 0; i < DPT; ++i) acc[i] = 0.f;
+  float accb = 0.f;
+  const bool do_bias = part_b && c0 == 0 && c < DPT;   // lane c < DPT of wave dg: db of output dg DPT + c over these rows
+  const float* ap = agg + (size_t)h * kChannels + c0 + c;
+  const float* gp = g + h * DH + dg * DPT;
+#pragma unroll 4
+  for (int m = m0; m < m1; ++m) {
+    const float a = ap[(size_t)m * HH * kChannels];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) acc[i] = fmaf(gp[(size_t)m * kChannels + i], a, acc[i]);
+    if (do_bias) accb = fmaf(g[(size_t)m * kChannels + h * DH + dg * DPT + c], wsum[(size_t)m * HH + h], accb);
+  }
+#pragma unroll
+  for (int i = 0; i < DPT; ++i) part[((size_t)ks * kChannels + h * DH + dg * DPT + i) * kChannels + c0 + c] = acc[i];
+  if (do_bias) part_b[ks * kChannels + h * DH + dg * DPT + c] = accb;
+}
+
+__global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_sum_kernel(const float* __restrict__ part, const float* __restrict__ part_b,
+                                                                               float* __restrict__ gw, float* __restrict__ gb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;      // kChannels * kChannels / 4 float4 results
+  float4 t = reinterpret_cast<const float4*>(part)[i];
+#pragma unroll
+  for (int ks = 1; ks < HW_KS; ++ks) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(size_t)ks * (kChannels * kChannels / 4) + i];
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  reinterpret_cast<float4*>(gw)[i] = t;
+  if (gb && i < kChannels) {
+    float b = part_b[i];
+#pragma unroll
+    for (int ks = 1; ks < HW_KS; ++ks) b += part_b[ks * kChannels + i];
+    gb[i] = b;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Gather-dot: the walk of cross_attn_agg_sliced_kernel (grid = 8 XCDs x 8 slices x per_xcd, slice-major inside an XCD,
 // wave = head, a pass = 8 loads of 8 corners x 128 B).  Per pass a lane ends up with the partial dot product of ONE
@@ -659,33 +715,31 @@ struct PgReduceParams {
   int R, L;
 };
 
-constexpr int PG_PX = 64, PG_PITCH = 260, PG_UNROLL = 8;
+constexpr int PG_PX = 64, PG_PITCH = 260;
 
-// U records of one pixel's run.  FULL: all U exist (consecutive scalar loads, merged by the compiler); else the tail
-// repeats the last record with weight 0.  VARIANT (dev builds): 0 = the product, 1 = every record reads one of 64 rows,
-// 2 / 3 = no table loads.
-template <int U, bool FULL, int VARIANT>
-__device__ __forceinline__ void pg_group(const float* __restrict__ table, const uint2* __restrict__ rec, int i, int b, int lane, float4& acc) {
-  float w[U];
-  float4 v[U];
+// A group = up to 8 consecutive records of one pixel's run.  The walk of a wave is a software pipeline over its groups:
+// the records of group k + 2 are requested (one scalar load of 64 bytes) and the table rows of group k + 1 (8 vector
+// loads) before the FMAs of group k wait for theirs - without it every group paid the scalar-load and the vector-load
+// latency in turn (0.3 ms of the 0.8 the kernel took with neither table loads nor the write-out).
+struct PgGroup { int i, n, px, last; };            // first record, records (0 = none left), pixel, ends the pixel's run
+
+template <int VARIANT>
+__device__ __forceinline__ void pg_issue(const float* __restrict__ table, const uint2 (&r)[8], int n, int lane, float4 (&v)[8]) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint2 r = FULL ? rec[i + u] : rec[min(i + u, b - 1)];   // uniform address: scalar loads
-    w[u] = (FULL || i + u < b) ? __uint_as_float(r.x) : 0.f;
-    const unsigned id = VARIANT == 1 ? (r.y & 63u) : (r.y & 0x3ffffffu);
-    if (VARIANT >= 2) v[u] = make_float4(__uint_as_float(r.y), 0.f, 0.f, 0.f);
+  for (int u = 0; u < 8; ++u) {
+    // past the run: the first record again, weight 0 below (a uniform branch per load - not issuing what the run does not
+    // have - was measured slower: 0.90 against 0.81 ms; it breaks the clause of eight loads)
+    unsigned id = (u < n ? r[u].y : r[0].y) & 0x3ffffffu;
+    if (VARIANT == 1) id &= 63u;
+    if (VARIANT >= 2) v[u] = make_float4(__uint_as_float(id), 0.f, 0.f, 0.f);
     else v[u] = *reinterpret_cast<const float4*>(table + (size_t)id * kChannels + lane * 4);
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
-    acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
   }
 }
 
 template <int VARIANT>
 __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const PgReduceParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH]
+  __shared__ int s_po[8][12];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xcd = blockIdx.x & 7;
@@ -711,15 +765,58 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const P
   const int* po = p.pxoff + (size_t)chunk * 65;
   const uint2* rec = p.rec + p.start[chunk];
   if (VARIANT == 4) { if (po[0] < 0) s_tp[0] = 1.f; return; }
-  const int ppw = (1 << (cws + chs)) >> 3;
-  for (int px = wave * ppw; px < (wave + 1) * ppw; ++px) {
-    const int a = po[px], b = po[px + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int i = a;
-    for (; i + PG_UNROLL <= b; i += PG_UNROLL) pg_group<PG_UNROLL, true, VARIANT>(p.table, rec, i, b, lane, acc);
-    if (b - i > 4) pg_group<8, false, VARIANT>(p.table, rec, i, b, lane, acc);
-    else if (b - i > 0) pg_group<4, false, VARIANT>(p.table, rec, i, b, lane, acc);
-    *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = acc;
+  const int ppw = (1 << (cws + chs)) >> 3;                        // pixels per wave: 1, 2 or 8
+  const int px0 = wave * ppw;
+  if (lane <= ppw) s_po[wave][lane] = po[px0 + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // cursor over the wave's runs; pixels without records get their row of zeros on the way
+  int cpx = px0 - 1, ci = 0, cb = 0;
+  auto next = [&]() -> PgGroup {
+    while (ci >= cb) {
+      ++cpx;
+      if (cpx >= px0 + ppw) return PgGroup{0, 0, 0, 0};
+      ci = __builtin_amdgcn_readfirstlane(s_po[wave][cpx - px0]);
+      cb = __builtin_amdgcn_readfirstlane(s_po[wave][cpx - px0 + 1]);
+      if (ci >= cb) *reinterpret_cast<float4*>(&s_tp[cpx * PG_PITCH + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    PgGroup g{ci, min(8, cb - ci), cpx, cb - ci <= 8};
+    ci += 8;
+    return g;
+  };
+  auto fetch = [&](const PgGroup& g, uint2 (&r)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = rec[g.i + u];               // uniform address: ONE 64-byte scalar load (may run past
+  };                                                                // the run: those records get weight 0)
+  uint2 r0[8], r1[8], r2[8];
+  float4 v0[8], v1[8];
+  PgGroup g0 = next(), g1{0, 0, 0, 0}, g2{0, 0, 0, 0};
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g0.n) {
+    fetch(g0, r0);
+    g1 = next();
+    if (g1.n) fetch(g1, r1);
+    pg_issue<VARIANT>(p.table, r0, g0.n, lane, v0);
+    for (;;) {
+      g2 = g1.n ? next() : PgGroup{0, 0, 0, 0};
+      if (g2.n) fetch(g2, r2);
+      if (g1.n) pg_issue<VARIANT>(p.table, r1, g1.n, lane, v1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = u < g0.n ? __uint_as_float(r0[u].x) : 0.f;
+        acc.x = fmaf(w, v0[u].x, acc.x); acc.y = fmaf(w, v0[u].y, acc.y);
+        acc.z = fmaf(w, v0[u].z, acc.z); acc.w = fmaf(w, v0[u].w, acc.w);
+      }
+      if (g0.last) {
+        *reinterpret_cast<float4*>(&s_tp[g0.px * PG_PITCH + lane * 4]) = acc;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (!g1.n) break;
+      g0 = g1; g1 = g2;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { r0[u] = r1[u]; r1[u] = r2[u]; v0[u] = v1[u]; }
+    }
   }
   __syncthreads();
   // wave w writes channels 32 w .. 32 w + 31; lane = pixel of the chunk (runs of cw pixels)
@@ -779,6 +876,34 @@ extern "C" int gd4d_value_proj_heads_bwd(const float* grad_out, const float* wei
     case 16: hipLaunchKernelGGL(value_proj_heads_bwd_kernel<16>, grid, dim3(256), 0, s, grad_out, weight, bias, grad_agg, beta, M, Hh); break;
     default: return GD4D_EUNSUPPORTED;
   }
+  return check_launch();
+}
+
+extern "C" size_t gd4d_value_proj_heads_bwd_weight_workspace_bytes(void) {
+  return (size_t)gd4d::HW_KS * (gd4d::kChannels + 1) * gd4d::kChannels * sizeof(float);
+}
+
+extern "C" int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const float* agg, const float* wsum, float* grad_weight,
+                                                float* grad_bias, void* workspace, size_t workspace_bytes, int M, int Hh, int C,
+                                                void* stream) {
+  using namespace gd4d;
+  if (!grad_out || !agg || !grad_weight || !workspace || M <= 0 || (grad_bias && !wsum)) return GD4D_EINVAL;
+  if (C != kChannels || (Hh != 4 && Hh != 8 && Hh != 16)) return GD4D_EUNSUPPORTED;
+  if (workspace_bytes < gd4d_value_proj_heads_bwd_weight_workspace_bytes()) return GD4D_EWORKSPACE;
+  if (!aligned16(workspace) || !aligned16(grad_weight)) return GD4D_EALIGN;
+  float* part = static_cast<float*>(workspace);
+  float* part_b = grad_bias ? part + (size_t)HW_KS * kChannels * kChannels : nullptr;
+  const dim3 grid(Hh * (kChannels / 64) * HW_KS);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (kChannels / Hh) {
+    case 64: hipLaunchKernelGGL(value_proj_heads_bwd_weight_kernel<64>, grid, dim3(256), 0, s, grad_out, agg, wsum, part, part_b, M, Hh); break;
+    case 32: hipLaunchKernelGGL(value_proj_heads_bwd_weight_kernel<32>, grid, dim3(256), 0, s, grad_out, agg, wsum, part, part_b, M, Hh); break;
+    case 16: hipLaunchKernelGGL(value_proj_heads_bwd_weight_kernel<16>, grid, dim3(256), 0, s, grad_out, agg, wsum, part, part_b, M, Hh); break;
+    default: return GD4D_EUNSUPPORTED;
+  }
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(value_proj_heads_bwd_weight_sum_kernel, dim3(kChannels * kChannels / 4 / 256), dim3(256), 0, s, part, part_b, grad_weight,
+                     grad_bias);
   return check_launch();
 }
 

@@ -336,6 +336,25 @@ def value_proj_heads_bwd(grad_out, weight, bias=None, num_heads=8, grad_agg=None
     return grad_agg, beta
 
 
+def value_proj_heads_bwd_weight(grad_out, agg, wsum=None, want_bias=True):
+    """gd4d_value_proj_heads_bwd_weight: grad_out (..., 256), agg (..., Hh, 256), wsum (..., Hh) -> (grad_weight (256, 256),
+    grad_bias (256) or None): value_proj's gradients from the per-head aggregates of the forward pass."""
+    lib = _lib.load()
+    f32 = torch.float32
+    hh, c = agg.shape[-2], agg.shape[-1]
+    m = grad_out.numel() // c
+    gw = torch.empty(c, c, device=grad_out.device, dtype=f32)
+    gb = torch.empty(c, device=grad_out.device, dtype=f32) if want_bias else None
+    wsb = int(lib.gd4d_value_proj_heads_bwd_weight_workspace_bytes())
+    ws = torch.empty(wsb, device=grad_out.device, dtype=torch.uint8)
+    code = lib.gd4d_value_proj_heads_bwd_weight(_dev(grad_out, 'grad_out', f32), _dev(agg, 'agg', f32),
+                                                _dev(wsum, 'wsum', f32) if want_bias else None, _dev(gw, 'grad_weight'),
+                                                _dev(gb, 'grad_bias') if want_bias else None, _dev(ws, 'workspace'),
+                                                ctypes.c_size_t(wsb), m, hh, c, _stream())
+    _lib.check(code, 'gd4d_value_proj_heads_bwd_weight')
+    return gw, gb
+
+
 def cross_attn_dot_bytes(b, n, q, num_heads, points=4):
     return int(_lib.load().gd4d_cross_attn_dot_bytes(b, n, q, num_heads, points))
 

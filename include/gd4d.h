@@ -202,8 +202,11 @@ int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level
  *     out[q, h] = W_h A[q, h] + b_h s[q, h],  A = sum_r w_r x_r,  s = sum_r w_r   (r: in-bounds corners, x_r: raw pixel).
  *
  * gd4d_value_proj_heads_bwd - grad_agg (M, Hh, C) = W_h^T grad_out[m, h], beta (M, Hh) = <b_h, grad_out[m, h]> (bias NULL:
- *   zeros; beta NULL: not written).  The weight / bias gradients are 900 x Hh-row contractions the caller does itself
- *   (dW_h = sum_m grad_out[m, h] (x) A[m, h], db_h = sum_m grad_out[m, h] s[m, h]).
+ *   zeros; beta NULL: not written).
+ * gd4d_value_proj_heads_bwd_weight - value_proj's own gradients from the forward's aggregates: grad_weight (C, C) with
+ *   dW_h = sum_m grad_out[m, h] (x) agg[m, h], grad_bias (C) (or NULL) with db_h = sum_m grad_out[m, h] wsum[m, h]: a
+ *   contraction over the M = B*Q rows instead of gd4d_value_proj_bwd_weight's over every pixel; fixed summation order
+ *   (workspace: gd4d_value_proj_heads_bwd_weight_workspace_bytes, 16-byte aligned).
  * gd4d_cross_attn_dot_sliced - D[pair] = <grad_agg[q, h], x_pair> for every pair of the plan, as 8 per-slice partials:
  *   dpart = (8, B*Q*Hh*cap_t*64) fp32, gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P) bytes; same pyramid addressing, plan and
  *   query_order as gd4d_cross_attn_agg_sliced_fwd.  fp32 pyramids only.
@@ -238,6 +241,10 @@ int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level
  *             = first + (r * down + y / ch) * across + x / cw. */
 int gd4d_value_proj_heads_bwd(const float* grad_out, const float* weight, const float* bias, float* grad_agg, float* beta,
                               int M, int Hh, int C, void* stream);
+size_t gd4d_value_proj_heads_bwd_weight_workspace_bytes(void);
+int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const float* agg, const float* wsum, float* grad_weight,
+                                     float* grad_bias, void* workspace, size_t workspace_bytes, int M, int Hh, int C,
+                                     void* stream);
 size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
                                const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,

@@ -90,6 +90,23 @@ def test_value_proj_heads_bwd_matches_fp64():
         assert float(beta0.abs().max()) == 0.0
 
 
+def test_value_proj_heads_bwd_weight_matches_fp64():
+    gen = torch.Generator().manual_seed(4)
+    for hh in (4, 8, 16):
+        g = torch.randn(3, 301, 256, generator=gen).to(DEV)
+        agg = torch.randn(3, 301, hh, 256, generator=gen).to(DEV)
+        wsum = torch.rand(3, 301, hh, generator=gen).to(DEV)
+        gw, gb = ops.value_proj_heads_bwd_weight(g, agg, wsum)
+        dh = 256 // hh
+        gd = g.double().view(-1, hh, dh)
+        want = torch.einsum('mhd,mhc->hdc', gd, agg.double().view(-1, hh, 256)).reshape(256, 256)
+        want_b = (gd * wsum.double().view(-1, hh, 1)).sum(0).reshape(256)
+        assert _rel(gw, want) < 1e-5
+        assert _rel(gb, want_b) < 1e-5
+        gw2, none = ops.value_proj_heads_bwd_weight(g, agg, want_bias=False)
+        assert none is None and torch.equal(gw2, gw)
+
+
 @pytest.mark.parametrize('heads,levels,n,q,b', [(8, 4, 6, 96, 1), (8, 4, 24, 64, 1), (8, 4, 6, 50, 2), (8, 3, 6, 40, 1),
                                                  (4, 4, 6, 40, 1), (16, 2, 7, 33, 3), (8, 1, 12, 30, 1)])
 def test_raw_backward_matches_projected_backward(heads, levels, n, q, b):
