@@ -64,6 +64,7 @@ def parse():
                     help='--mode train/distill with several ranks: eager backward, every bucket\'s all-reduce starts from a '
                          'post-accumulate hook while the backward of the layers below is still running')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fuse-wgrad', action='store_true', help='--mode train: leave the accumulation of parameter gradients to autograd')
     ap.add_argument('--no-roofline', action='store_true', help='dev: skip the kernel-level roofline section (roofline = null)')
     ap.add_argument('--no-stress', action='store_true',
                     help='skip the all-visible stress launches of the gather kernels (SURVEY 8d): a rocprofv3 --stats run then '
@@ -402,7 +403,10 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     # post-accumulate hooks while the backward is still running (--overlap-comm, eager launch)
     reducer = D.FlatGradAllReducer(params, buckets=D.decoder_buckets(tr, regs, cls_branches if a.criterion else None,
                                                                      teacher[5] if distill else None))
-    reducer.bind()                                    # .grad = views of one flat buffer from the start (graph captures)
+    # .grad = views of one flat buffer from the start (graph captures); unless the all-reduce is driven by autograd hooks
+    # (--overlap-comm) the weight-gradient kernels add into those views themselves (no accumulation launch per parameter)
+    fuse = not (a.overlap_comm and world_size > 1) and not a.no_fuse_wgrad
+    reducer.bind(fuse_weight_grads=fuse)
     tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
 
     class DecoderAndHead(torch.nn.Module):
@@ -592,7 +596,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                                    f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
                        'baseline_config': 'configs[4]' if distill else ('configs[3]' if a.levels == 'vov' else 'configs[2] + backward'),
                        'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),
-                       'overlap_comm': overlap,
+                       'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse,
                        'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3,

@@ -206,6 +206,8 @@ class CrossAttnRawFunction(torch.autograd.Function):
     def forward(ctx, token, ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, raw, pc_range, img_h, img_w,
                 raw_cam=False):
         from . import functional as Fn
+        mw, mb = Fn.main_grad(vp_weight), Fn.main_grad(vp_bias)
+        ctx.main = (mw, mb) if mw is not None and (vp_bias is None or mb is not None) else None
         ref, offsets = ref.contiguous(), offsets.contiguous()
         attn_logits, cam_logits = attn_logits.contiguous(), cam_logits.contiguous()
         hh = offsets.shape[2]
@@ -243,7 +245,10 @@ class CrossAttnRawFunction(torch.autograd.Function):
                                                  img_h, img_w, raw_cam_weights=raw_cam)
         gw = gb = None
         if ctx.needs_input_grad[6] or (vp_bias is not None and ctx.needs_input_grad[7]):
-            gw, gb = ops.value_proj_heads_bwd_weight(grad_out, agg, wsum, want_bias=vp_bias is not None)
+            if ctx.main is not None:
+                ops.value_proj_heads_bwd_weight(grad_out, agg, wsum, want_bias=vp_bias is not None, into=ctx.main)
+            else:
+                gw, gb = ops.value_proj_heads_bwd_weight(grad_out, agg, wsum, want_bias=vp_bias is not None)
         ctx.plan = None
         return None, gr, go, ga.view_as(attn_logits), gc, None, gw, gb, None, None, None, None, None
 
@@ -323,10 +328,13 @@ class LinearFunction(torch.autograd.Function):
     a single compute unit)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, main_w=None, main_b=None):
+        """main_w / main_b: where the weight / bias gradient is to be ADDED by the backward kernel itself (views of a flat
+        gradient buffer, dist.FlatGradAllReducer.bind(fuse_weight_grads=True)); autograd then gets None for them."""
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)                  # x: (M, K), see functional.linear_autograd
         ctx.has_bias = bias is not None
+        ctx.main = (main_w, main_b) if main_w is not None else None
         return ops.linear_fwd(x, weight, None if bias is None else bias.contiguous())
 
     @staticmethod
@@ -336,8 +344,11 @@ class LinearFunction(torch.autograd.Function):
         gx = ops.linear_fwd(grad_y, weight, weight_kn=True) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias)
-        return gx, gw, gb
+            if ctx.main is not None:
+                ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias, into=ctx.main)
+            else:
+                gw, gb = ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias)
+        return gx, gw, gb, None, None
 
 
 class LayerNormFunction(torch.autograd.Function):
@@ -345,17 +356,21 @@ class LayerNormFunction(torch.autograd.Function):
     position_encoder's LayerNorm + ReLU pairs, deform3d_cross_attn.py:104-111)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, main_g=None, main_b=None):
         x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
         ctx.save_for_backward(x, gamma, beta)
         ctx.eps, ctx.relu = eps, relu
+        ctx.main = (main_g, main_b) if main_g is not None and main_b is not None else None
         return ops.layernorm_fwd(x, gamma, beta, eps, relu=relu)
 
     @staticmethod
     def backward(ctx, grad_y):
         x, gamma, beta = ctx.saved_tensors
+        if ctx.main is not None:                          # dgamma / dbeta added to the flat gradient buffer by the kernel
+            dx, _, _ = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu, into=ctx.main)
+            return dx, None, None, None, None, None, None
         dx, dg, db = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu)
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None, None
 
 
 class MhaCoreFunction(torch.autograd.Function):

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const 
 }
 
 __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_sum_kernel(const float* __restrict__ part, const float* __restrict__ part_b,
-                                                                               float* __restrict__ gw, float* __restrict__ gb) {
+                                                                               float* __restrict__ gw, float* __restrict__ gb, int accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;      // kChannels * kChannels / 4 float4 results
   float4 t = reinterpret_cast<const float4*>(part)[i];
 #pragma unroll
@@ -120,12 +120,14 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_sum_kernel(co
     const float4 v = reinterpret_cast<const float4*>(part)[(size_t)ks * (kChannels * kChannels / 4) + i];
     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
   }
-  reinterpret_cast<float4*>(gw)[i] = t;
+  float* o = gw + 4 * (size_t)i;                     // (a view of a flat gradient buffer need not be 16-byte aligned)
+  if (accumulate) { t.x += o[0]; t.y += o[1]; t.z += o[2]; t.w += o[3]; }
+  o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
   if (gb && i < kChannels) {
     float b = part_b[i];
 #pragma unroll
     for (int ks = 1; ks < HW_KS; ++ks) b += part_b[ks * kChannels + i];
-    gb[i] = b;
+    gb[i] = accumulate ? gb[i] + b : b;
   }
 }
 
@@ -885,12 +887,12 @@ extern "C" size_t gd4d_value_proj_heads_bwd_weight_workspace_bytes(void) {
 
 extern "C" int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const float* agg, const float* wsum, float* grad_weight,
                                                 float* grad_bias, void* workspace, size_t workspace_bytes, int M, int Hh, int C,
-                                                void* stream) {
+                                                int accumulate, void* stream) {
   using namespace gd4d;
   if (!grad_out || !agg || !grad_weight || !workspace || M <= 0 || (grad_bias && !wsum)) return GD4D_EINVAL;
   if (C != kChannels || (Hh != 4 && Hh != 8 && Hh != 16)) return GD4D_EUNSUPPORTED;
   if (workspace_bytes < gd4d_value_proj_heads_bwd_weight_workspace_bytes()) return GD4D_EWORKSPACE;
-  if (!aligned16(workspace) || !aligned16(grad_weight)) return GD4D_EALIGN;
+  if (!aligned16(workspace)) return GD4D_EALIGN;
   float* part = static_cast<float*>(workspace);
   float* part_b = grad_bias ? part + (size_t)HW_KS * kChannels * kChannels : nullptr;
   const dim3 grid(Hh * (kChannels / 64) * HW_KS);
@@ -903,7 +905,7 @@ extern "C" int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const flo
   }
   if (int rc = check_launch()) return rc;
   hipLaunchKernelGGL(value_proj_heads_bwd_weight_sum_kernel, dim3(kChannels * kChannels / 4 / 256), dim3(256), 0, s, part, part_b, grad_weight,
-                     grad_bias);
+                     grad_bias, accumulate ? 1 : 0);
   return check_launch();
 }
 

@@ -18,6 +18,7 @@ struct LinBwdParams {
   float* dw;         // (N, K) contiguous
   float* db;         // (N) or null
   int M, N, K, ldx, ldy;
+  int accumulate;    // add to dw / db instead of overwriting them
 };
 
 constexpr int LB_TN = 16, LB_TK = 32, LB_WAVES = 16, LB_UNROLL = 4, LB_T = LB_TK / 16;
@@ -87,24 +88,27 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_kernel(const 
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < LB_WAVES; ++w) s += part[w][i];
-    if (nn < p.N && kk < p.K) p.dw[(size_t)nn * p.K + kk] = s;
+    if (nn < p.N && kk < p.K) {
+      float* d = p.dw + (size_t)nn * p.K + kk;
+      *d = p.accumulate ? *d + s : s;
+    }
   }
   if (p.db && blockIdx.x == 0 && threadIdx.x < LB_TN && n0 + threadIdx.x < p.N) {
     const int i = threadIdx.x;
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < LB_WAVES; ++w) s += bpart[w][i];
-    p.db[n0 + i] = s;
+    p.db[n0 + i] = p.accumulate ? p.db[n0 + i] + s : s;
   }
 }
 
 }  // namespace gd4d
 
 extern "C" int gd4d_linear_bwd_weight(const float* x, const float* grad_y, float* grad_w, float* grad_b, int M, int K,
-                                      int N, int ldx, int ldy, void* stream) {
+                                      int N, int ldx, int ldy, int accumulate, void* stream) {
   using namespace gd4d;
   if (!x || !grad_y || !grad_w || M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return GD4D_EINVAL;
-  LinBwdParams p{x, grad_y, grad_w, grad_b, M, N, K, ldx, ldy};
+  LinBwdParams p{x, grad_y, grad_w, grad_b, M, N, K, ldx, ldy, accumulate ? 1 : 0};
   const dim3 grid((K + LB_TK - 1) / LB_TK, (N + LB_TN - 1) / LB_TN);
   hipLaunchKernelGGL(linear_bwd_weight_kernel, grid, dim3(64 * LB_WAVES), 0, static_cast<hipStream_t>(stream), p);
   return check_launch();

@@ -112,14 +112,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p)
   }
 }
 
+// 64 columns per workgroup, four threads per column over the partial rows (independent loads), added in a fixed order
+// (one thread per column walking all partial rows was a chain of dependent loads: 14 us)
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta,
-                                                                  int parts, int C) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 2 * C) return;
+                                                                  int parts, int C, int accumulate) {
+  __shared__ float s_p[4][64];
+  const int col = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
   const int k = e / C, c = e - k * C;
   float s = 0.f;
-  for (int w = 0; w < parts; ++w) s += part[((size_t)w * 2 + k) * C + c];
-  (k == 0 ? dgamma : dbeta)[c] = s;
+  if (e < 2 * C) {
+#pragma unroll 4
+    for (int w = pg; w < parts; w += 4) s += part[((size_t)w * 2 + k) * C + c];
+  }
+  s_p[pg][col] = s;
+  __syncthreads();
+  if (pg == 0 && e < 2 * C) {
+    const float t = ((s_p[0][col] + s_p[1][col]) + s_p[2][col]) + s_p[3][col];
+    float* d = (k == 0 ? dgamma : dbeta) + c;
+    *d = accumulate ? *d + t : t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -280,9 +292,10 @@ extern "C" size_t gd4d_layernorm_bwd_workspace_bytes(int M, int C) {
 
 extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* dy,
                                   float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M,
-                                  int C, float eps, int relu, void* stream) {
+                                  int C, float eps, int flags, void* stream) {
   using namespace gd4d;
   if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0) return GD4D_EINVAL;
+  const int relu = flags & GD4D_LN_RELU;
   if (relu && !beta) return GD4D_EINVAL;
   if (C % 4 != 0 || C > 1024) return GD4D_EUNSUPPORTED;
   if (workspace_bytes < gd4d_layernorm_bwd_workspace_bytes(M, C)) return GD4D_EINVAL;
@@ -294,7 +307,8 @@ extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float*
   const int parts = (M + 15) / 16;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, p);
   if (int rc = check_launch()) return rc;
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, p.part, dgamma, dbeta, parts, C);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, p.part, dgamma, dbeta, parts, C,
+                     (flags & GD4D_LN_ACCUMULATE) ? 1 : 0);
   return check_launch();
 }
 

@@ -184,11 +184,30 @@ class FlatGradAllReducer:
             p.grad = v
 
     @torch.no_grad()
-    def bind(self):
+    def bind(self, fuse_weight_grads=False):
         """Allocate the flat buffer (gradients + max_extras) and bind every .grad to it now (parameters without a
         gradient get zeros).  Needed before a backward pass is captured in a hipGraph: the capture records the
-        addresses it accumulates into; the buffer is never reallocated afterwards."""
+        addresses it accumulates into; the buffer is never reallocated afterwards.
+
+        fuse_weight_grads: additionally tell this package's autograd Functions (Linear, LayerNorm, value_proj of the
+        aggregates) where a parameter's gradient lives (`param._gd4d_main_grad` = its view of the flat buffer): their
+        backward kernels then ADD the weight / bias gradient there themselves and hand autograd nothing for the parameter -
+        no fresh gradient tensor and no accumulation launch per parameter (~190 of a decoder step's ~290 elementwise adds).
+        After backward, `.grad` (the same view) holds exactly what autograd would have accumulated.  Not with
+        install_hooks(): a parameter whose gradient bypasses autograd fires no post-accumulate hook."""
         self._bind(self._buffer(self.params[0]))
+        if fuse_weight_grads:
+            if self._hooks:
+                raise RuntimeError('fuse_weight_grads bypasses autograd\'s accumulation: it cannot be combined with install_hooks()')
+            for p, v in zip(self.params, self.views):
+                p._gd4d_main_grad = v
+            self.fused = True
+
+    def unfuse(self):
+        for p in self.params:
+            if hasattr(p, '_gd4d_main_grad'):
+                del p._gd4d_main_grad
+        self.fused = False
 
     @torch.no_grad()
     def zero_grad(self):
@@ -242,6 +261,8 @@ class FlatGradAllReducer:
         backward and finish() after it."""
         if self._hooks:
             return
+        if getattr(self, 'fused', False):
+            raise RuntimeError('install_hooks() needs autograd to accumulate the gradients: unfuse() first')
         self.bind()
 
         def make(p):

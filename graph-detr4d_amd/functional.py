@@ -23,12 +23,27 @@ def require_inference(*tensors):
             'graph-detr4d_amd: this entry point has no backward - call it under torch.no_grad()')
 
 
-def linear_autograd(x, weight, bias=None):
-    """F.linear with autograd (training path); on the GPU in fp32 the weight gradient runs on gd4d_linear_bwd_weight."""
+def main_grad(t, rows=None):
+    """Where the gradient of parameter `t` is accumulated when a dist.FlatGradAllReducer was bound with
+    fuse_weight_grads=True (its view of the flat buffer), else None.  rows=(lo, hi): the same for the row slice t[lo:hi]
+    (the thirds of a packed in-projection)."""
+    m = getattr(t, '_gd4d_main_grad', None) if t is not None else None
+    if m is None or rows is None:
+        return m
+    return m[rows[0]:rows[1]]
+
+
+def linear_autograd(x, weight, bias=None, main=None):
+    """F.linear with autograd (training path); on the GPU in fp32 the weight gradient runs on gd4d_linear_bwd_weight.
+    main = (weight gradient buffer, bias gradient buffer): see main_grad(); default: the parameters' own."""
     if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
         from .autograd import LinearFunction
+        if main is None:
+            main = (main_grad(weight), main_grad(bias))
+        if main[0] is None or (bias is not None and main[1] is None) or not torch.is_grad_enabled():
+            main = (None, None)
         # 2-D inside the Function: its output must not be a view (in-place ReLUs follow in the nn.Sequential stacks)
-        y = LinearFunction.apply(x.reshape(-1, x.shape[-1]), weight, bias)
+        y = LinearFunction.apply(x.reshape(-1, x.shape[-1]), weight, bias, main[0], main[1])
         return y.view(*x.shape[:-1], weight.shape[0])
     return torch.nn.functional.linear(x, weight, bias)
 
@@ -40,7 +55,10 @@ def layer_norm_autograd(x, norm, relu=False):
     if x.is_cuda and x.dtype == torch.float32 and norm.weight is not None and norm.bias is not None \
             and tuple(norm.normalized_shape) == (c,) and c % 4 == 0 and c <= 1024:
         from .autograd import LayerNormFunction
-        return LayerNormFunction.apply(x, norm.weight, norm.bias, norm.eps, relu)
+        mg, mb = main_grad(norm.weight), main_grad(norm.bias)
+        if mg is None or mb is None:
+            mg = mb = None
+        return LayerNormFunction.apply(x, norm.weight, norm.bias, norm.eps, relu, mg, mb)
     y = norm(x)
     return torch.relu(y) if relu else y
 

@@ -336,21 +336,25 @@ def value_proj_heads_bwd(grad_out, weight, bias=None, num_heads=8, grad_agg=None
     return grad_agg, beta
 
 
-def value_proj_heads_bwd_weight(grad_out, agg, wsum=None, want_bias=True):
+def value_proj_heads_bwd_weight(grad_out, agg, wsum=None, want_bias=True, into=None):
     """gd4d_value_proj_heads_bwd_weight: grad_out (..., 256), agg (..., Hh, 256), wsum (..., Hh) -> (grad_weight (256, 256),
-    grad_bias (256) or None): value_proj's gradients from the per-head aggregates of the forward pass."""
+    grad_bias (256) or None): value_proj's gradients from the per-head aggregates of the forward pass.  into=(w_buf, b_buf):
+    added to these instead."""
     lib = _lib.load()
     f32 = torch.float32
     hh, c = agg.shape[-2], agg.shape[-1]
     m = grad_out.numel() // c
-    gw = torch.empty(c, c, device=grad_out.device, dtype=f32)
-    gb = torch.empty(c, device=grad_out.device, dtype=f32) if want_bias else None
+    if into is None:
+        gw = torch.empty(c, c, device=grad_out.device, dtype=f32)
+        gb = torch.empty(c, device=grad_out.device, dtype=f32) if want_bias else None
+    else:
+        gw, gb = into[0], (into[1] if want_bias else None)
     wsb = int(lib.gd4d_value_proj_heads_bwd_weight_workspace_bytes())
     ws = torch.empty(wsb, device=grad_out.device, dtype=torch.uint8)
     code = lib.gd4d_value_proj_heads_bwd_weight(_dev(grad_out, 'grad_out', f32), _dev(agg, 'agg', f32),
-                                                _dev(wsum, 'wsum', f32) if want_bias else None, _dev(gw, 'grad_weight'),
-                                                _dev(gb, 'grad_bias') if want_bias else None, _dev(ws, 'workspace'),
-                                                ctypes.c_size_t(wsb), m, hh, c, _stream())
+                                                _dev(wsum, 'wsum', f32) if want_bias else None, _dev(gw, 'grad_weight', f32),
+                                                _dev(gb, 'grad_bias', f32) if want_bias else None, _dev(ws, 'workspace'),
+                                                ctypes.c_size_t(wsb), m, hh, c, 0 if into is None else 1, _stream())
     _lib.check(code, 'gd4d_value_proj_heads_bwd_weight')
     return gw, gb
 
@@ -667,19 +671,27 @@ def value_proj_multi_fwd(feats, weights, biases, out_dtype=torch.float32, num_he
     return outs
 
 
-def linear_bwd_weight(x, grad_y, want_bias=True):
+def linear_bwd_weight(x, grad_y, want_bias=True, into=None):
     """gd4d_linear_bwd_weight.  x (..., K), grad_y (..., N) fp32 with the same leading shape (contiguous rows).
-    Returns (grad_w (N, K), grad_b (N) or None)."""
+    Returns (grad_w (N, K), grad_b (N) or None).  into=(w_buf, b_buf or None): the sums are ADDED to these tensors (views
+    of a flat gradient buffer) and returned."""
     lib = _lib.load()
     f32 = torch.float32
     k, n = x.shape[-1], grad_y.shape[-1]
     m = x.numel() // k
     if grad_y.numel() // n != m:
         raise ValueError('x and grad_y must have the same number of rows')
-    gw = torch.empty(n, k, device=x.device, dtype=f32)
-    gb = torch.empty(n, device=x.device, dtype=f32) if want_bias else None
-    code = lib.gd4d_linear_bwd_weight(_dev(x, 'x', f32), _dev(grad_y, 'grad_y', f32), _dev(gw, 'grad_w'),
-                                      _dev(gb, 'grad_b') if want_bias else None, m, k, n, k, n, _stream())
+    if into is None:
+        gw = torch.empty(n, k, device=x.device, dtype=f32)
+        gb = torch.empty(n, device=x.device, dtype=f32) if want_bias else None
+    else:
+        gw, gb = into
+        if tuple(gw.shape) != (n, k) or (want_bias and (gb is None or gb.numel() != n)):
+            raise ValueError('linear_bwd_weight: the accumulation targets do not match the gradient shapes')
+        gb = gb if want_bias else None
+    code = lib.gd4d_linear_bwd_weight(_dev(x, 'x', f32), _dev(grad_y, 'grad_y', f32), _dev(gw, 'grad_w', f32),
+                                      _dev(gb, 'grad_b', f32) if gb is not None else None, m, k, n, k, n, 0 if into is None else 1,
+                                      _stream())
     _lib.check(code, 'gd4d_linear_bwd_weight')
     return gw, gb
 
@@ -881,19 +893,20 @@ def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None):
     return dq, dk, dv
 
 
-def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False):
-    """gd4d_layernorm_bwd.  Returns (dx like x, dgamma, dbeta)."""
+def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False, into=None):
+    """gd4d_layernorm_bwd.  Returns (dx like x, dgamma, dbeta); into=(g_buf, b_buf): dgamma / dbeta are ADDED to these."""
     lib = _lib.load()
     f32 = torch.float32
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
-    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    dg, db = (torch.empty_like(gamma), torch.empty_like(gamma)) if into is None else into
     nbytes = lib.gd4d_layernorm_bwd_workspace_bytes(m, c)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     code = lib.gd4d_layernorm_bwd(_dev(x, 'x', f32), _opt(res, 'res'), _dev(gamma, 'gamma', f32), _opt(beta, 'beta'),
-                                  _dev(grad_y, 'grad_y', f32), _dev(dx, 'dx'), _dev(dg, 'dgamma'), _dev(db, 'dbeta'),
-                                  _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), m, c, float(eps), int(bool(relu)), _stream())
+                                  _dev(grad_y, 'grad_y', f32), _dev(dx, 'dx'), _dev(dg, 'dgamma', f32), _dev(db, 'dbeta', f32),
+                                  _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), m, c, float(eps),
+                                  (1 if relu else 0) | (0 if into is None else 2), _stream())
     _lib.check(code, 'gd4d_layernorm_bwd')
     return dx, dg, db
 

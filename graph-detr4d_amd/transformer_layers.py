@@ -116,13 +116,16 @@ class MultiheadAttention(nn.Module):
         lq, b, _ = q_in.shape
         lk = k_in.shape[0]
         qk = qh_lin = kh_lin = None
+        # (with dist.FlatGradAllReducer.bind(fuse_weight_grads=True) the gradient of a row slice of the packed in-projection is
+        # added straight to the same rows of the parameter's view of the flat buffer)
+        rows = lambda lo, hi: (Fn.main_grad(w, (lo, hi)), Fn.main_grad(bias, (lo, hi)))
         if k_in is q_in:                                  # decoder self-attention: one GEMM for q and k
-            qk = Fn.linear_autograd(q_in.contiguous(), w[:2 * c], bias[:2 * c])
+            qk = Fn.linear_autograd(q_in.contiguous(), w[:2 * c], bias[:2 * c], main=rows(0, 2 * c))
             qh, kh = qk[..., :c], qk[..., c:]
         else:
-            qh = qh_lin = Fn.linear_autograd(q_in.contiguous(), w[:c], bias[:c])
-            kh = kh_lin = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c])
-        vh_lin = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:])
+            qh = qh_lin = Fn.linear_autograd(q_in.contiguous(), w[:c], bias[:c], main=rows(0, c))
+            kh = kh_lin = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c], main=rows(c, 2 * c))
+        vh_lin = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:], main=rows(2 * c, 3 * c))
         if not (self.training and self.attn_drop > 0.) and d == 32 and q_in.dtype == torch.float32 \
                 and (attn_mask is None or attn_mask.dim() == 2):
             # the attention core with autograd on the HIP kernels (no attention-weight dropout to apply)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 29
+#define GD4D_ABI_VERSION 30
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -206,7 +206,8 @@ int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level
  * gd4d_value_proj_heads_bwd_weight - value_proj's own gradients from the forward's aggregates: grad_weight (C, C) with
  *   dW_h = sum_m grad_out[m, h] (x) agg[m, h], grad_bias (C) (or NULL) with db_h = sum_m grad_out[m, h] wsum[m, h]: a
  *   contraction over the M = B*Q rows instead of gd4d_value_proj_bwd_weight's over every pixel; fixed summation order
- *   (workspace: gd4d_value_proj_heads_bwd_weight_workspace_bytes, 16-byte aligned).
+ *   (workspace: gd4d_value_proj_heads_bwd_weight_workspace_bytes, 16-byte aligned; accumulate != 0: added to grad_weight /
+ *   grad_bias).
  * gd4d_cross_attn_dot_sliced - D[pair] = <grad_agg[q, h], x_pair> for every pair of the plan, as 8 per-slice partials:
  *   dpart = (8, B*Q*Hh*cap_t*64) fp32, gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P) bytes; same pyramid addressing, plan and
  *   query_order as gd4d_cross_attn_agg_sliced_fwd.  fp32 pyramids only.
@@ -244,7 +245,7 @@ int gd4d_value_proj_heads_bwd(const float* grad_out, const float* weight, const 
 size_t gd4d_value_proj_heads_bwd_weight_workspace_bytes(void);
 int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const float* agg, const float* wsum, float* grad_weight,
                                      float* grad_bias, void* workspace, size_t workspace_bytes, int M, int Hh, int C,
-                                     void* stream);
+                                     int accumulate, void* stream);
 size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
                                const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,
@@ -425,9 +426,11 @@ int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w
  * What autograd's `grad_output.t().mm(input)` computes for the decoder's dense layers (config ...ceph.py:71-89,
  * deform3d_cross_attn.py:104-111,204-228,326), where the library GEMM runs these M ~ 900, N, K <= 512 shapes on one
  * compute unit.  fp32 MFMA, one workgroup per 16 x 32 block of grad_w, fixed summation order.
- *   x (M, K) row stride ldx;  grad_y (M, N) row stride ldy. */
+ *   x (M, K) row stride ldx;  grad_y (M, N) row stride ldy.  accumulate != 0: the sums are ADDED to grad_w / grad_b (a
+ *   training step that keeps every parameter gradient in one flat buffer lets the kernel accumulate there instead of
+ *   leaving autograd an add per parameter). */
 int gd4d_linear_bwd_weight(const float* x, const float* grad_y, float* grad_w, float* grad_b, int M, int K, int N,
-                           int ldx, int ldy, void* stream);
+                           int ldx, int ldy, int accumulate, void* stream);
 
 /* gd4d_layernorm_fwd - y = LayerNorm(x [+ res]) * gamma + beta [, ReLU] over the last dim
  * (biased variance, eps inside the sqrt, like ATen).  Replaces the nn.LayerNorm of
@@ -550,12 +553,15 @@ int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const floa
 /* gd4d_layernorm_bwd - backward of gd4d_layernorm_fwd (y = [ReLU] LN(x [+ res]) gamma + beta): dx (also the gradient of
  * res), dgamma, dbeta from dy; mean / rstd are recomputed from x.  beta is read only with relu != 0 (to rebuild the
  * sign of the forward's output).  workspace: gd4d_layernorm_bwd_workspace_bytes(M, C) bytes (per-workgroup partial
- * column sums, added in a fixed order).  C % 4 == 0, C <= 1024.  Replaces ATen's layer_norm_backward kernels behind
+ * column sums, added in a fixed order).  C % 4 == 0, C <= 1024.  flags: GD4D_LN_RELU (the forward applied a ReLU),
+ * GD4D_LN_ACCUMULATE (dgamma / dbeta are added to, not overwritten).  Replaces ATen's layer_norm_backward kernels behind
  * the decoder layer's norms and position_encoder (deform3d_cross_attn.py:104-111). */
+#define GD4D_LN_RELU 1
+#define GD4D_LN_ACCUMULATE 2
 size_t gd4d_layernorm_bwd_workspace_bytes(int M, int C);
 int gd4d_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* dy, float* dx,
                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M, int C, float eps,
-                       int relu, void* stream);
+                       int flags, void* stream);
 
 /* gd4d_refine_reference_fwd - reference-point refinement between decoder layers
  * (Detr3DTransformerDecoder.forward, detr3d_transformer.py:201-214):

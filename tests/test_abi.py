@@ -82,7 +82,7 @@ def test_argument_validation_returns_before_any_gpu_work():
     # null pointers
     assert lib.gd4d_value_proj_bwd_input(null, ptr, ptr, ptr, 1, 256, 1, 0, null) == EINVAL
     assert lib.gd4d_value_proj_bwd_weight(ptr, ptr, ptr, null, null, ptr, 0, 1, 256, 1, null) == EINVAL
-    assert lib.gd4d_linear_bwd_weight(null, ptr, ptr, null, 4, 4, 4, 4, 4, null) == EINVAL
+    assert lib.gd4d_linear_bwd_weight(null, ptr, ptr, null, 4, 4, 4, 4, 4, 0, null) == EINVAL
     assert lib.gd4d_match_cost_fwd(ptr, ptr, ptr, ptr, null, ptr, 1, 1, 4, 10, 10, 9, 1, 1, 2.0, 0.25, 0.25, null) == EINVAL
     assert lib.gd4d_head_loss_fwd_bwd(ptr, ptr, ptr, ptr, ptr, ptr, null, ptr, ptr, ptr, 1, 1, 4, 10, 10, 9, 1,
                                       0.25, 2.0, 0.25, null) == EINVAL

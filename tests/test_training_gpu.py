@@ -144,6 +144,58 @@ def test_decoder_training_step_under_hipgraph_equals_eager():
             torch.testing.assert_close(f.grad, e, rtol=1e-4, atol=1e-6 * float(e.abs().max()) + 1e-12)
 
 
+def test_weight_gradients_accumulated_by_the_kernels_equal_autograds():
+    """dist.FlatGradAllReducer.bind(fuse_weight_grads=True): the weight-gradient kernels (Linear, LayerNorm, value_proj of the
+    aggregates, the row slices of the packed in-projection) add into the parameters' views of the flat buffer themselves and
+    autograd gets nothing for those parameters - the buffer must end up with what autograd accumulates, and a second
+    backward without zero_grad must double it."""
+    from graph_detr4d_amd import dist as D
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.0),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                         embed_dims=256, dropout=0.0)],
+                         feedforward_channels=512, ffn_dropout=0.0,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    qe = g.t('query_embed').to(DEV)
+    feats = [f.to(DEV).requires_grad_() for f in g.feats()]
+    params = [p for p in tr.parameters() if p.requires_grad]
+    red = D.FlatGradAllReducer(params)
+
+    def backward():
+        states, _, _ = tr(feats, qe, reg_branches=None, img_metas=g.img_metas())
+        (states ** 2).mean().backward()
+    red.bind()
+    red.zero_grad()
+    backward()
+    want = red.flat.clone()
+    want_feats = [f.grad.clone() for f in feats]
+    for f in feats:
+        f.grad = None
+    red.bind(fuse_weight_grads=True)
+    assert all(getattr(p, '_gd4d_main_grad', None) is p.grad for p in params)
+    red.zero_grad()
+    backward()
+    scale = float(want.abs().max())
+    torch.testing.assert_close(red.flat, want, rtol=1e-5, atol=1e-6 * scale)
+    for f, e in zip(feats, want_feats):
+        assert ((f.grad - e).abs().max() / e.abs().max()).item() < 1e-5
+    backward()                                        # no zero_grad in between: gradients accumulate
+    torch.testing.assert_close(red.flat, 2 * want, rtol=1e-5, atol=2e-6 * scale)
+    with pytest.raises(RuntimeError):
+        red.install_hooks()
+    red.unfuse()
+    assert not any(hasattr(p, '_gd4d_main_grad') for p in params)
+
+
 def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction(monkeypatch):
     """Decoder training, three routes to the same gradients: the raw-pyramid path (the default: plan + sliced gather forward,
     gd4d_cross_attn_sliced_bwd.hip backward, no projected value tensor), the projected-value path with value_proj's weight /
