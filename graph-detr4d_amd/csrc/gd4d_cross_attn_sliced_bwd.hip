@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_kernel(const float* 
 // dW[h Dh + d, c] = sum_m g[m, h Dh + d] agg[m, h, c],  db[h Dh + d] = sum_m g[m, h Dh + d] wsum[m, h]
 // Split over the rows: workgroup (head, 64 input channels, slice ks of HW_KS) sums its rows into a partial (wave = 64
 // channels x one group of Dh / 4 outputs: the g values it needs are wave-uniform - scalar loads); a second launch adds the
-// HW_KS partials in a fixed order (run-to-run identical).  (One workgroup per (head, channels) over all 900 rows: 112 us.)
-constexpr int HW_KS = 8;
+// HW_KS partials in a fixed order (run-to-run identical).  (One workgroup per (head, channels) over all 900 rows: 112 us;
+// 8 slices of 113 rows, one workgroup per compute unit: 51 us - four loads in flight per wave.)
+constexpr int HW_KS = 32;
 
 template <int DH>
 __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const float* __restrict__ g, const float* __restrict__ agg,
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const 
   const bool do_bias = part_b && c0 == 0 && c < DPT;   // lane c < DPT of wave dg: db of output dg DPT + c over these rows
   const float* ap = agg + (size_t)h * kChannels + c0 + c;
   const float* gp = g + h * DH + dg * DPT;
-#pragma unroll 4
+#pragma unroll 8
   for (int m = m0; m < m1; ++m) {
     const float a = ap[(size_t)m * HH * kChannels];
 #pragma unroll

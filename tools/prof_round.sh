@@ -38,3 +38,14 @@ grep -A 14 "cross_attn_agg_sliced" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | 
 # the query side of the step (row chains, attention core): issue / MFMA / LDS / wait counters, one sample in flight
 bash tools/prof_pmc.sh $tag/pmc_step bench.py --inflight 1 --no-roofline --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
 grep -A 40 "row_chain_kernel\|mha_core_kernel" gpurun_out/$tag/pmc_step/pmc_summary.txt | head -100
+# training: bench lines + kernel stats of the step, PMC passes of the raw-pyramid backward kernels (tools/bench_raw_bwd.py)
+mkdir -p gpurun_out/$tag/train
+python3 bench.py --mode train --steps 20 --warmup 3 > gpurun_out/$tag/train/train.json 2> gpurun_out/$tag/train/train.err
+python3 bench.py --mode train --steps 10 --warmup 3 --criterion > gpurun_out/$tag/train/train_criterion.json 2> gpurun_out/$tag/train/train_criterion.err
+python3 bench.py --mode train --steps 5 --warmup 2 --levels vov > gpurun_out/$tag/train/train_vov.json 2> gpurun_out/$tag/train/train_vov.err
+python3 bench.py --mode distill --steps 5 --warmup 2 > gpurun_out/$tag/train/distill.json 2> gpurun_out/$tag/train/distill.err
+GD4D_TRAIN_VALUES=projected python3 bench.py --mode train --steps 10 --warmup 3 --no-fuse-wgrad > gpurun_out/$tag/train/train_projected_values.json 2> gpurun_out/$tag/train/train_projected_values.err
+for f in train train_criterion train_vov distill train_projected_values; do tail -1 gpurun_out/$tag/train/$f.json | cut -c1-200; done
+bash tools/prof_train_stats.sh $tag/train --no-roofline | head -12
+bash tools/prof_pmc.sh $tag/pmc_rawbwd tools/bench_raw_bwd.py --iters 2 > /dev/null 2>&1
+grep -A 26 "dot_sliced_kernel\|grad_reduce_kernel\|grad_count_kernel" gpurun_out/$tag/pmc_rawbwd/pmc_summary.txt | head -90
