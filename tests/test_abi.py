@@ -98,3 +98,55 @@ def test_argument_validation_returns_before_any_gpu_work():
     # workspace too small for the weight gradient
     assert lib.gd4d_value_proj_bwd_weight(ptr, ptr, lvp, ptr, null, ptr, 16, 1, 256, 1, null) == EINVAL
     assert lib.gd4d_value_proj_bwd_weight_workspace_bytes() >= 256 * (256 * 256 + 256) * 4
+
+
+def test_training_entry_points_validate_before_any_gpu_work():
+    """The raw-pyramid training backward (gd4d_cross_attn_sliced_bwd.hip): sizes, workspaces and unsupported shapes are
+    refused with an error code on a box without a GPU; the size helpers agree with the layouts include/gd4d.h states."""
+    import ctypes
+    from graph_detr4d_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    EINVAL, EUNSUPPORTED, EWORKSPACE = -1, -2, -5
+    b, n, q, hh = 1, 24, 900, 8
+    cap_t = (n * 4 + 3) // 4
+    assert lib.gd4d_cross_attn_dot_bytes(b, n, q, hh, 4) == 8 * b * q * hh * cap_t * 64 * 4
+    assert lib.gd4d_pyramid_grad_slots_bytes(b, n, q, hh, 4) == b * q * hh * cap_t * 64 * 8
+    assert lib.gd4d_cross_attn_dot_bytes(0, n, q, hh, 4) == 0
+    lv = (ctypes.c_int32 * 8)(116, 200, 58, 100, 29, 50, 15, 25)
+    lvp = ctypes.cast(lv, ctypes.c_void_p)
+    chunks = lib.gd4d_pyramid_grad_chunks(lvp, 24, 4)
+    geo = (ctypes.c_int32 * 20)()
+    assert lib.gd4d_pyramid_grad_chunk_geometry(lvp, 24, 4, ctypes.cast(geo, ctypes.c_void_p)) == 0
+    total = 0
+    for l, (h, w) in enumerate([(116, 200), (58, 100), (29, 50), (15, 25)]):
+        cws, chs, cw_n, ch_n, base = geo[5 * l:5 * l + 5]
+        assert base == total and (1 << cws) * (1 << chs) in (8, 16, 32, 64)
+        assert cw_n == -(-w >> cws) and ch_n == -(-h >> chs)                    # ceil
+        total += 24 * cw_n * ch_n
+    assert chunks == total
+    assert lib.gd4d_pyramid_grad_chunks(lvp, 0, 4) == 0
+    # null pointers / bad sizes
+    assert lib.gd4d_value_proj_heads_bwd(null, ptr, ptr, ptr, ptr, 4, 8, 256, null) == EINVAL
+    assert lib.gd4d_value_proj_heads_bwd(ptr, ptr, ptr, ptr, ptr, 4, 8, 128, null) == EUNSUPPORTED            # C != 256
+    assert lib.gd4d_value_proj_heads_bwd(ptr, ptr, ptr, ptr, ptr, 4, 3, 256, null) == EUNSUPPORTED            # heads
+    assert lib.gd4d_value_proj_heads_bwd_weight(ptr, ptr, ptr, ptr, ptr, ptr, 16, 4, 8, 256, 0, null) == EWORKSPACE
+    assert lib.gd4d_value_proj_heads_bwd_weight(ptr, ptr, null, ptr, ptr, ptr, 1 << 30, 4, 8, 256, 0, null) == EINVAL   # bias without wsum
+    ptrs = (ctypes.c_void_p * 4)(ptr.value, ptr.value, ptr.value, ptr.value)
+    assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, ptr, ptr, ptr, 16, 1, 6, 4, 8, 256, 4, 4, _lib.F32, null, null) == EWORKSPACE
+    assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, ptr, ptr, ptr, 1 << 40, 1, 6, 4, 8, 256, 4, 4, _lib.BF16, null, null) == EUNSUPPORTED
+    assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, null, ptr, ptr, 1 << 40, 1, 6, 4, 8, 256, 4, 4, _lib.F32, null, null) == EINVAL
+    rng = ctypes.cast((ctypes.c_double * 6)(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), ctypes.c_void_p)
+    assert lib.gd4d_cross_attn_plan_bwd(ptr, ptr, ptr, ptr, ptr, rng, 900.0, 1600.0, lvp, ptr, null, null, ptr, ptr, ptr, ptr,
+                                        null, 0, null, 1, 6, 4, 8, 4, 4, 0, null, null) == EINVAL            # no dpart
+    assert lib.gd4d_cross_attn_plan_bwd(ptr, ptr, ptr, ptr, ptr, rng, 900.0, 1600.0, lvp, ptr, ptr, null, ptr, ptr, ptr, ptr,
+                                        null, 0, null, 2, 6, 4, 8, 4, 4, 0, null, null) == EWORKSPACE        # B > 1 needs the workspace
+    cs = ctypes.cast((ctypes.c_int64 * 4)(4096, 4096, 4096, 4096), ctypes.c_void_p)
+    assert lib.gd4d_pyramid_grad_count(ptr, lvp, cs, 128, ptr, ptr, 16, 1, 6, 4, 8, 4, 4, null) == EWORKSPACE
+    assert lib.gd4d_pyramid_grad_count(ptr, lvp, cs, 128, ptr, ptr, 1 << 40, 1, 6, 4, 8, 4, 3, null) == EUNSUPPORTED      # P != 4
+    assert lib.gd4d_pyramid_grad_scan(ptr, ptr, ptr, 0, 100000, null) == EWORKSPACE
+    assert lib.gd4d_pyramid_grad_fill(ptr, ptr, ptr, ptr, (1 << 26) - 8, null, 1, 6, 4, 8, 4, null) == EUNSUPPORTED      # row ids need 26 bits
+    assert lib.gd4d_pyramid_grad_sort(ptr, ptr, ptr, ptr, null, 10, null) == EINVAL
+    assert lib.gd4d_pyramid_grad_reduce(ptr, ptr, ptr, ptr, ptrs, lvp, null, 24, 128, 4, null) == EUNSUPPORTED
