@@ -230,6 +230,10 @@ class CrossAttnRawFunction(torch.autograd.Function):
         ref, offsets, attn_logits, cam_logits, lidar2img, vp_weight, vp_bias, agg, wsum = ctx.saved_tensors
         pc_range, img_h, img_w, raw_cam = ctx.meta
         plan, raw = ctx.plan, ctx.raw
+        if plan is None:
+            raise RuntimeError('graph-detr4d_amd: the raw-pyramid training path keeps a layer\'s plan and records for ONE backward '
+                               'pass; a second backward through the same graph (retain_graph) is not supported - run the forward '
+                               'again, or set GD4D_TRAIN_VALUES=projected')
         b, q, c = grad_out.shape
         hh = plan.num_heads
         grad_out = grad_out.contiguous()
@@ -390,3 +394,24 @@ class MhaCoreFunction(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = ops.mha_core_bwd(q, k, v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask)
         return dq, dk, dv, None, None
+
+
+class MhaCorePackedFunction(torch.autograd.Function):
+    """Self-attention core on a packed (L, B, 2C) projection qk = [q | k] (one GEMM for both, transformer_layers.py): the
+    backward kernel writes dq and dk into the halves of ONE buffer, so autograd has no slices to put back together (two zero
+    fills, two copies and an add per layer otherwise)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, attn_mask, num_heads):
+        c = qk.shape[-1] // 2
+        out, lse = ops.mha_core_fwd(qk[..., :c], qk[..., c:], v, num_heads, attn_mask, want_lse=True)
+        ctx.save_for_backward(qk, v, out, lse)
+        ctx.mask, ctx.heads = attn_mask, num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        qk, v, out, lse = ctx.saved_tensors
+        c = qk.shape[-1] // 2
+        dqk, dv = ops.mha_core_bwd(qk[..., :c], qk[..., c:], v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask, packed_qk=True)
+        return dqk, dv, None, None

@@ -392,6 +392,21 @@ extern "C" int gd4d_small_linear_layernorm_fwd(const float* in, const float* w, 
   return check_launch();
 }
 
+namespace gd4d {
+__global__ __launch_bounds__(256) void inverse_sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = inv_sigmoid(x[i]);
+}
+}  // namespace gd4d
+
+extern "C" int gd4d_inverse_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {
+  using namespace gd4d;
+  if (!x || !y || n <= 0) return GD4D_EINVAL;
+  hipLaunchKernelGGL(inverse_sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y,
+                     (long long)n);
+  return check_launch();
+}
+
 extern "C" int gd4d_refine_reference_fwd(const float* tmp, const float* ref, float* out, int M, int ldt,
                                          void* stream) {
   using namespace gd4d;

@@ -245,5 +245,8 @@ class Deform3DCrossAttn(nn.Module):
         if self.depth_encode:
             depth = (ref3d[..., 0:1] ** 2 + ref3d[..., 1:2] ** 2) ** 0.5
             ref3d = torch.cat([ref3d, depth], dim=-1)
-        pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(ref3d)).permute(1, 0, 2)
+        # (the decoder hands over DETACHED reference points: their inverse_sigmoid is then one launch instead of six ATen ones)
+        isig = ops.inverse_sigmoid_fwd(ref3d.contiguous()) if ref3d.is_cuda and ref3d.dtype == torch.float32 \
+            and not ref3d.requires_grad else Fn.inverse_sigmoid(ref3d)
+        pos_feat = Fn.sequential_autograd(self.position_encoder, isig).permute(1, 0, 2)
         return self.dropout(out) + inp_residual + pos_feat

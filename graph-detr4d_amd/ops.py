@@ -876,21 +876,30 @@ def mha_core_fwd(q, k, v, num_heads, attn_mask=None, want_lse=False):
     return (out, lse) if want_lse else out
 
 
-def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None):
-    """gd4d_mha_core_bwd.  Returns (dq, dk, dv), each (L, B, C) contiguous."""
+def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_qk=False):
+    """gd4d_mha_core_bwd.  Returns (dq, dk, dv), each (L, B, C) contiguous; packed_qk (self-attention, q and k the two halves
+    of one (L, B, 2C) projection): (dqk (L, B, 2C), dv) - the kernel writes both halves of one buffer."""
     lib = _lib.load()
     lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, attn_mask)
-    dq = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
-    dk = torch.empty(lk, b, c, device=q.device, dtype=torch.float32)
-    dv = torch.empty(lk, b, c, device=q.device, dtype=torch.float32)
-    dsum = torch.empty(lq, b, num_heads, device=q.device, dtype=torch.float32)
+    f32 = torch.float32
+    if packed_qk:
+        if lq != lk:
+            raise ValueError('packed_qk needs as many queries as keys')
+        dqk = torch.empty(lq, b, 2 * c, device=q.device, dtype=f32)
+        dq, dk, ldd = dqk[..., :c], dqk[..., c:], 2 * c
+    else:
+        dq = torch.empty(lq, b, c, device=q.device, dtype=f32)
+        dk = torch.empty(lk, b, c, device=q.device, dtype=f32)
+        ldd = c
+    dv = torch.empty(lk, b, c, device=q.device, dtype=f32)
+    dsum = torch.empty(lq, b, num_heads, device=q.device, dtype=f32)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())    # noqa: E731
-    code = lib.gd4d_mha_core_bwd(vp(q), vp(k), vp(v), _dev(out, 'out', torch.float32), _dev(grad_out, 'grad_out', torch.float32),
-                                 mptr, _dev(lse, 'lse', torch.float32), _dev(dsum, 'dsum'), _dev(dq, 'dq'), _dev(dk, 'dk'),
-                                 _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, c, c, c,
+    code = lib.gd4d_mha_core_bwd(vp(q), vp(k), vp(v), _dev(out, 'out', f32), _dev(grad_out, 'grad_out', f32),
+                                 mptr, _dev(lse, 'lse', f32), _dev(dsum, 'dsum'), vp(dq), vp(dk),
+                                 _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, ldd, ldd, c,
                                  kind, 1.0 / (d ** 0.5), _stream())
     _lib.check(code, 'gd4d_mha_core_bwd')
-    return dq, dk, dv
+    return (dqk, dv) if packed_qk else (dq, dk, dv)
 
 
 def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False, into=None):
@@ -909,6 +918,15 @@ def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False, into=N
                                   (1 if relu else 0) | (0 if into is None else 2), _stream())
     _lib.check(code, 'gd4d_layernorm_bwd')
     return dx, dg, db
+
+
+def inverse_sigmoid_fwd(x):
+    """gd4d_inverse_sigmoid_fwd: the reference's inverse_sigmoid (eps = 1e-5) as one launch; no autograd."""
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    code = lib.gd4d_inverse_sigmoid_fwd(_dev(x, 'x', torch.float32), _dev(y, 'y'), x.numel(), _stream())
+    _lib.check(code, 'gd4d_inverse_sigmoid_fwd')
+    return y
 
 
 def refine_reference_fwd(tmp, ref):

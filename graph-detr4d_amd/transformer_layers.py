@@ -129,12 +129,11 @@ class MultiheadAttention(nn.Module):
         if not (self.training and self.attn_drop > 0.) and d == 32 and q_in.dtype == torch.float32 \
                 and (attn_mask is None or attn_mask.dim() == 2):
             # the attention core with autograd on the HIP kernels (no attention-weight dropout to apply)
-            from .autograd import MhaCoreFunction
+            from .autograd import MhaCoreFunction, MhaCorePackedFunction
             if k_in is q_in:
-                qm, km = qk[..., :c], qk[..., c:]
+                o = MhaCorePackedFunction.apply(qk, vh_lin, attn_mask, h)
             else:
-                qm, km = qh_lin, kh_lin
-            o = MhaCoreFunction.apply(qm, km, vh_lin, attn_mask, h)
+                o = MhaCoreFunction.apply(qh_lin, kh_lin, vh_lin, attn_mask, h)
             return Fn.linear_autograd(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
         qh = qh.reshape(lq, b * h, d).transpose(0, 1)
         kh = kh.reshape(lk, b * h, d).transpose(0, 1)

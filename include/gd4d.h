@@ -563,6 +563,12 @@ int gd4d_layernorm_bwd(const float* x, const float* res, const float* gamma, con
                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M, int C, float eps,
                        int flags, void* stream);
 
+/* gd4d_inverse_sigmoid_fwd - y = log(clamp(x, eps, 1) / clamp(1 - x, eps, 1)) with x clamped to [0, 1], eps = 1e-5: the
+ * reference's inverse_sigmoid (deform3d_cross_attn.py:16-31) as ONE launch for callers that need the tensor itself (the
+ * input of position_encoder's first Linear in a training step, where the reference points carry no gradient; the
+ * inference kernels apply it while loading). */
+int gd4d_inverse_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+
 /* gd4d_refine_reference_fwd - reference-point refinement between decoder layers
  * (Detr3DTransformerDecoder.forward, detr3d_transformer.py:201-214):
  *   out[:, 0:2] = sigmoid(tmp[:, 0:2] + inverse_sigmoid(ref[:, 0:2]));

@@ -54,6 +54,22 @@ def test_cross_attn_module_gradients(name):
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
 
 
+def test_raw_pyramid_path_refuses_a_second_backward_through_one_graph():
+    g = Golden('deform_n6')
+    m = g.meta
+    mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=4,
+                                 embed_dims=256, depth_encode=m['depth_encode']), dict(batch_first=False))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    feats = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    out = mod(g.t('query').to(DEV), None, feats, None, query_pos=g.t('query_pos').to(DEV),
+              reference_points=g.t('reference_points').to(DEV), img_metas=g.img_metas())
+    out.sum().backward(retain_graph=True)
+    assert all(f.grad is not None for f in feats)
+    with pytest.raises(RuntimeError, match='second backward'):
+        out.sum().backward()
+
+
 def test_decoder_layer_trains_one_step():
     """A full post-norm decoder layer in train() mode: loss decreases under SGD on the HIP path."""
     g = Golden('decoder_deform')
