@@ -53,6 +53,7 @@ SIGNATURES = {
     'gd4d_cross_attn_bwd_workspace_bytes': (_c.c_size_t, [_i] * 5),
     'gd4d_detr3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                              _i, _i, _i, _i, _i, _i, _vp]),
+    'gd4d_detr3d_bwd': (_i, [_vp] * 6 + [_f, _f] + [_vp] * 4 + [_i] * 6 + [_vp]),
     'gd4d_detr3d_v2_fwd': (_i, [_vp] * 7 + [_f, _f, _vp, _vp] + [_i] * 7 + [_vp]),
     'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _c.c_size_t, _i, _vp]),
     'gd4d_value_proj_workspace_bytes': (_c.c_size_t, [_i]),

@@ -415,3 +415,25 @@ class MhaCorePackedFunction(torch.autograd.Function):
         c = qk.shape[-1] // 2
         dqk, dv = ops.mha_core_bwd(qk[..., :c], qk[..., c:], v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask, packed_qk=True)
         return dqk, dv, None, None
+
+
+class Detr3DSampleFunction(torch.autograd.Function):
+    """out (B, Q, C) = sum over cameras and levels of sigmoid(logit) x mask x bilinear sample of the NCHW maps at the
+    projected reference point (Detr3DCrossAtten, detr3d_transformer.py:373-383 + feature_sampling :397-438):
+    gd4d_detr3d_fwd / gd4d_detr3d_bwd.  apply(ref, logits, lidar2img, pc_range, img_h, img_w, *feats)."""
+
+    @staticmethod
+    def forward(ctx, ref, logits, lidar2img, pc_range, img_h, img_w, *feats):
+        ref, logits = ref.contiguous(), logits.contiguous()
+        feats = [f.contiguous() for f in feats]
+        ctx.save_for_backward(ref, logits, lidar2img, *feats)
+        ctx.meta = (pc_range, img_h, img_w)
+        return ops.detr3d_fwd(feats, ref, logits, lidar2img, pc_range, img_h, img_w)['out']
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ref, logits, lidar2img, *feats = ctx.saved_tensors
+        pc_range, img_h, img_w = ctx.meta
+        gf, gl, gr = ops.detr3d_bwd(feats, ref, logits, lidar2img, pc_range, img_h, img_w, grad_out.contiguous(),
+                                    want_feats=any(ctx.needs_input_grad[6:]), want_ref=ctx.needs_input_grad[0])
+        return (gr, gl, None, None, None, None, *(gf if gf is not None else [None] * len(feats)))

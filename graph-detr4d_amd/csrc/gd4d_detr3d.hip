@@ -213,6 +213,174 @@ __global__ __launch_bounds__(256) void detr3d_v2_fwd_kernel(const Detr3dV2Params
 
 }  // namespace gd4d
 
+namespace gd4d {
+
+// ---------------------------------------------------------------------------------------------
+// gd4d_detr3d_bwd: backward of detr3d_fwd_kernel's `out` (the reference: autograd through feature_sampling's
+// F.grid_sample per level, the sigmoid weights, the mask product and the sums, detr3d_transformer.py:373-383, :397-438).
+// Same work mapping (workgroup = (batch, query), thread = channel).  With g = dL/d out (C), w = sigmoid(logit) * vis and
+// s[c, n, l] the bilinear sample:
+//   dL/d feats[l][b*N+n, c, corner] += g[c] w[n,l] b_corner                (atomic fp32 add; ~1 camera x L levels x 4 corners)
+//   dL/d logit[n,l] = vis w (1 - w) sum_c g[c] s[c,n,l]
+//   dL/d (x, y)     = w sum_c g[c] ds/d(x, y)  (pixel units) -> grid coordinate -> u = cx / (cz W_img), v = cy / (cz H_img)
+//                     -> lidar2img -> metres -> reference point.  The mask is piecewise constant (no gradient).
+// The sums over channels meet in LDS in a fixed order.
+struct Detr3dBwdParams {
+  const float* feats[GD4D_MAX_LEVELS];
+  float* gfeats[GD4D_MAX_LEVELS];   // zero-initialised by the caller, or NULL
+  const float* ref;
+  const float* attn_logits;
+  const float* lidar2img;
+  const float* grad_out;            // (B, Q, C)
+  float* grad_logits;               // (B, Q, N, 1, L)
+  float* grad_ref;                  // (B, Q, 3)
+  int B, N, Q, C, L;
+  int lvl_h[GD4D_MAX_LEVELS];
+  int lvl_w[GD4D_MAX_LEVELS];
+  float rng_scale[3];
+  float rng_lo[3];
+  float img_h, img_w;
+};
+
+__global__ __launch_bounds__(256) void detr3d_bwd_kernel(const Detr3dBwdParams p) {
+  extern __shared__ float s_mem[];
+  float2* s_uv = reinterpret_cast<float2*>(s_mem);            // [N]
+  float* s_cam = s_mem + 2 * p.N;                             // [N][4]: cx, cy, cz, vis
+  float* s_red = s_cam + 4 * p.N;                             // [4 waves][3]
+  float* s_pt = s_red + 12;                                   // [3] dL/d (metre point), accumulated by thread 0
+  const int bq = blockIdx.x;
+  const int b = bq / p.Q;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* rp = p.ref + (size_t)bq * 3;
+  const float X = rp[0] * p.rng_scale[0] + p.rng_lo[0];
+  const float Y = rp[1] * p.rng_scale[1] + p.rng_lo[1];
+  const float Z = rp[2] * p.rng_scale[2] + p.rng_lo[2];
+  if (t < p.N) {
+    const float* m = p.lidar2img + ((size_t)b * p.N + t) * 16;
+    const float eps = 1e-5f;
+    const float cx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+    const float cy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+    const float cz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+    bool vis = cz > eps;
+    const float zc = fmaxf(cz, eps);
+    float u = (cx / zc) / p.img_w;
+    float v = (cy / zc) / p.img_h;
+    u = (u - 0.5f) * 2.f;
+    v = (v - 0.5f) * 2.f;
+    vis = vis && (u > -1.f) && (u < 1.f) && (v > -1.f) && (v < 1.f);
+    s_uv[t] = make_float2(u, v);
+    s_cam[4 * t] = cx; s_cam[4 * t + 1] = cy; s_cam[4 * t + 2] = cz; s_cam[4 * t + 3] = vis ? 1.f : 0.f;
+  }
+  if (t < 3) s_pt[t] = 0.f;
+  __syncthreads();
+  // (C <= 256 * 4: a thread owns up to 4 channels, all of them inside every reduction)
+  for (int n = 0; n < p.N; ++n) {
+    const bool vis = s_cam[4 * n + 3] != 0.f;                 // workgroup-uniform
+    if (!vis) {
+      if (t < p.L) p.grad_logits[((size_t)bq * p.N + n) * p.L + t] = 0.f;
+      continue;
+    }
+    const float2 g2 = s_uv[n];
+    float gu = 0.f, gv = 0.f;                                 // dL/d(u, v) in [0, 1] image units, summed over the levels (thread 0)
+    for (int l = 0; l < p.L; ++l) {
+      const int H = p.lvl_h[l], W = p.lvl_w[l];
+      const float x = unnormalize(g2.x, W), y = unnormalize(g2.y, H);
+      const float xf = floorf(x), yf = floorf(y);
+      const float dx = x - xf, dy = y - yf;
+      const bool x0ok = xf >= 0.f && xf <= (float)(W - 1), x1ok = xf + 1.f >= 0.f && xf + 1.f <= (float)(W - 1);
+      const bool y0ok = yf >= 0.f && yf <= (float)(H - 1), y1ok = yf + 1.f >= 0.f && yf + 1.f <= (float)(H - 1);
+      const float lg = p.attn_logits[((size_t)bq * p.N + n) * p.L + l];
+      const float w = 1.0f / (1.0f + expf(-lg));
+      float part[3] = {0.f, 0.f, 0.f};                        // sum_c g s, sum_c g ds/dx, sum_c g ds/dy
+      if ((x0ok || x1ok) && (y0ok || y1ok)) {
+        const int x0 = (int)xf, y0 = (int)yf;
+        for (int c = t; c < p.C; c += 256) {
+          const size_t plane = ((size_t)(b * p.N + n) * p.C + c) * H * W;
+          const float* fp = p.feats[l] + plane;
+          const float v00 = (x0ok && y0ok) ? fp[y0 * W + x0] : 0.f;
+          const float v01 = (x1ok && y0ok) ? fp[y0 * W + x0 + 1] : 0.f;
+          const float v10 = (x0ok && y1ok) ? fp[(y0 + 1) * W + x0] : 0.f;
+          const float v11 = (x1ok && y1ok) ? fp[(y0 + 1) * W + x0 + 1] : 0.f;
+          const float g = p.grad_out[(size_t)bq * p.C + c];
+          const float sv = ((1.f - dx) * (1.f - dy) * v00 + dx * (1.f - dy) * v01) + ((1.f - dx) * dy * v10 + dx * dy * v11);
+          part[0] += g * sv;
+          part[1] += g * ((1.f - dy) * (v01 - v00) + dy * (v11 - v10));
+          part[2] += g * ((1.f - dx) * (v10 - v00) + dx * (v11 - v01));
+          if (p.gfeats[l]) {
+            float* gp = p.gfeats[l] + plane;
+            const float gw = g * w;
+            if (x0ok && y0ok) atomicAdd(gp + y0 * W + x0, gw * (1.f - dx) * (1.f - dy));
+            if (x1ok && y0ok) atomicAdd(gp + y0 * W + x0 + 1, gw * dx * (1.f - dy));
+            if (x0ok && y1ok) atomicAdd(gp + (y0 + 1) * W + x0, gw * (1.f - dx) * dy);
+            if (x1ok && y1ok) atomicAdd(gp + (y0 + 1) * W + x0 + 1, gw * dx * dy);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part[k] += __shfl_xor(part[k], o);
+      }
+      __syncthreads();                                        // (s_red of the previous level has been read)
+      if (lane == 0) { s_red[wave * 3] = part[0]; s_red[wave * 3 + 1] = part[1]; s_red[wave * 3 + 2] = part[2]; }
+      __syncthreads();
+      if (t == 0) {
+        float tot[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tot[k] = ((s_red[k] + s_red[3 + k]) + s_red[6 + k]) + s_red[9 + k];
+        p.grad_logits[((size_t)bq * p.N + n) * p.L + l] = w * (1.f - w) * tot[0];
+        // x = ((gx + 1) W - 1) / 2, gx = (u - 0.5) 2  ->  dx/du = W ; likewise dy/dv = H
+        gu += w * tot[1] * (float)W;
+        gv += w * tot[2] * (float)H;
+      }
+    }
+    if (t == 0) {
+      const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
+      const float cx = s_cam[4 * n], cy = s_cam[4 * n + 1], cz = s_cam[4 * n + 2];
+      const float iz = 1.0f / cz;                             // visible: cz > eps
+      const float gcx = gu * iz / p.img_w;
+      const float gcy = gv * iz / p.img_h;
+      const float gcz = -(gu * cx * iz * iz / p.img_w + gv * cy * iz * iz / p.img_h);
+      s_pt[0] += gcx * m[0] + gcy * m[4] + gcz * m[8];
+      s_pt[1] += gcx * m[1] + gcy * m[5] + gcz * m[9];
+      s_pt[2] += gcx * m[2] + gcy * m[6] + gcz * m[10];
+    }
+  }
+  __syncthreads();
+  if (t < 3 && p.grad_ref) p.grad_ref[(size_t)bq * 3 + t] = s_pt[t] * p.rng_scale[t];
+}
+
+}  // namespace gd4d
+
+extern "C" int gd4d_detr3d_bwd(const void* const* feats, const int32_t* level_hw, const float* ref, const float* attn_logits,
+                               const float* lidar2img, const double* pc_range, float img_h, float img_w, const float* grad_out,
+                               void* const* grad_feats, float* grad_logits, float* grad_ref, int B, int N, int Q, int C, int L,
+                               int P, void* stream) {
+  using namespace gd4d;
+  if (!feats || !level_hw || !ref || !attn_logits || !lidar2img || !pc_range || !grad_out || !grad_logits) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || C <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
+  if (L > GD4D_MAX_LEVELS || P != 1 || N > 256) return GD4D_EUNSUPPORTED;
+  Detr3dBwdParams p{};
+  for (int l = 0; l < L; ++l) {
+    if (!feats[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return GD4D_EINVAL;
+    p.feats[l] = static_cast<const float*>(feats[l]);
+    p.gfeats[l] = grad_feats ? static_cast<float*>(grad_feats[l]) : nullptr;
+    p.lvl_h[l] = level_hw[2 * l];
+    p.lvl_w[l] = level_hw[2 * l + 1];
+  }
+  p.ref = ref; p.attn_logits = attn_logits; p.lidar2img = lidar2img; p.grad_out = grad_out;
+  p.grad_logits = grad_logits; p.grad_ref = grad_ref;
+  p.B = B; p.N = N; p.Q = Q; p.C = C; p.L = L;
+  for (int k = 0; k < 3; ++k) {
+    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
+    p.rng_lo[k] = static_cast<float>(pc_range[k]);
+  }
+  p.img_h = img_h; p.img_w = img_w;
+  const size_t lds = sizeof(float) * (size_t)(2 * N + 4 * N + 12 + 3);
+  hipLaunchKernelGGL(detr3d_bwd_kernel, dim3(B * Q), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
 extern "C" int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const float* ref,
                                const float* attn_logits, const float* lidar2img,
                                const double* pc_range, float img_h, float img_w, float* out,

@@ -106,11 +106,11 @@ class Detr3DCrossAtten(nn.Module):
 
 
     def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
-        """Training path (the DETR3D configs train this module): the reference's operations (:352-390, feature_sampling
-        :397-438) as differentiable torch ops on the GPU - projection, F.grid_sample per level (bilinear, zero padding,
-        align_corners=False), sigmoid weights x mask, sums over levels / points / cameras - with the dense layers on the
-        HIP kernels' autograd functions.  The sampling kernel gd4d_detr3d_fwd has no backward; this is the way
-        gradients reach the feature maps, the query and (in layer 0) the reference points."""
+        """Training path (the DETR3D configs train this module): the sampling core (:373-383, feature_sampling :397-438) on its
+        HIP kernels both ways (autograd.Detr3DSampleFunction: gd4d_detr3d_fwd / gd4d_detr3d_bwd - gradients reach the feature
+        maps, the attention logits and the reference points), the dense layers on the HIP kernels' autograd functions.
+        GD4D_DETR3D_TRAIN=torch (and num_points != 1): the reference's operations as differentiable torch ops on the GPU -
+        projection, F.grid_sample per level (bilinear, zero padding, align_corners=False), sigmoid weights x mask, sums."""
         inp_residual = query
         x = query if query_pos is None else query + query_pos
         x = x.permute(1, 0, 2).contiguous()                                   # (B, Q, C)
@@ -119,6 +119,15 @@ class Detr3DCrossAtten(nn.Module):
         logits = Fn.sequential_autograd(self.attention_weights, x).view(b, 1, q, n, self.num_points, nl)
         lidar2img = Fn.lidar2img_device(img_metas, query)                     # (B, N, 4, 4)
         img_h, img_w = Fn.img_hw(img_metas)
+        if self.num_points == 1 and os.environ.get('GD4D_DETR3D_TRAIN', 'hip') == 'hip' and len(value) <= 8 and n <= 256 \
+                and all(v.is_cuda and v.dtype == torch.float32 for v in value) and reference_points.dtype == torch.float32:
+            # the sampling core on its HIP kernels both ways (gd4d_detr3d_fwd / gd4d_detr3d_bwd)
+            from .autograd import Detr3DSampleFunction
+            agg = Detr3DSampleFunction.apply(reference_points, logits.reshape(b, q, n, 1, nl), lidar2img, self.pc_range, img_h, img_w,
+                                             *value)
+            out = Fn.sequential_autograd(self.output_proj, agg).permute(1, 0, 2)
+            pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(reference_points)).permute(1, 0, 2)
+            return self.dropout(out) + inp_residual + pos_feat
         rng = self.pc_range
         lo = reference_points.new_tensor(rng[:3])
         scale = reference_points.new_tensor([rng[3] - rng[0], rng[4] - rng[1], rng[5] - rng[2]])

@@ -601,6 +601,28 @@ def detr3d_fwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, want_
     return dict(out=out, mask=mask, sampled=sampled)
 
 
+def detr3d_bwd(feats, ref, attn_logits, lidar2img, pc_range, img_h, img_w, grad_out, want_feats=True, want_ref=True):
+    """gd4d_detr3d_bwd: gradients of detr3d_fwd(...)['out'].  Returns (grad_feats: list like feats or None,
+    grad_logits like attn_logits, grad_ref (B, Q, 3) or None)."""
+    lib = _lib.load()
+    b, n, c = feats[0].shape[:3]
+    q = ref.shape[1]
+    nl = len(feats)
+    f32 = torch.float32
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    gf = [torch.zeros_like(f) for f in feats] if want_feats else None
+    gptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gf]) if want_feats else None
+    gl = torch.empty(b * q * n * nl, device=ref.device, dtype=f32).view_as(attn_logits)
+    gr = torch.empty(b, q, 3, device=ref.device, dtype=f32) if want_ref else None
+    code = lib.gd4d_detr3d_bwd(ptrs, lv, _dev(ref, 'ref', f32), _dev(attn_logits, 'attn_logits', f32),
+                               _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w), _dev(grad_out, 'grad_out', f32),
+                               gptrs, _dev(gl, 'grad_logits'), _dev(gr, 'grad_ref') if want_ref else None, b, n, q, c, nl, 1, _stream())
+    _lib.check(code, 'gd4d_detr3d_bwd')
+    return gf, gl, gr
+
+
 def detr3d_v2_fwd(feats, ref, attn_logits, offsets, lidar2img, pc_range, img_h, img_w, num_heads, want_mask=False):
     """gd4d_detr3d_v2_fwd.  feats: list of L tensors (B, N, C, H_l, W_l) fp32; attn_logits (B, Q, N, Hh, L*P);
     offsets (B, Q, N, Hh, L, P, 2), P == L.  Returns out (B, Q, C) [, mask (B, N, Q) uint8]."""

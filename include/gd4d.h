@@ -313,6 +313,16 @@ int gd4d_detr3d_fwd(const void* const* feats, const int32_t* level_hw, const flo
                     float img_h, float img_w, float* out, uint8_t* mask_out, float* sampled_out,
                     int B, int N, int Q, int C, int L, int P, void* stream);
 
+/* gd4d_detr3d_bwd - backward of gd4d_detr3d_fwd's `out` (the reference: autograd through feature_sampling's F.grid_sample
+ * per level, the sigmoid weights, the mask product and the sums, detr3d_transformer.py:373-383, :397-438): grad_feats
+ * (host array of L device pointers to tensors shaped like feats, ZERO-INITIALISED by the caller - the samples' corners are
+ * added with fp32 atomics - or NULL: no feature gradient), grad_logits (B, Q, N, 1, L), grad_ref (B, Q, 3) or NULL.  The
+ * visibility mask carries no gradient, as in the reference.  Same limits as the forward (P == 1). */
+int gd4d_detr3d_bwd(const void* const* feats, const int32_t* level_hw, const float* ref, const float* attn_logits,
+                    const float* lidar2img, const double* pc_range, float img_h, float img_w, const float* grad_out,
+                    void* const* grad_feats, float* grad_logits, float* grad_ref, int B, int N, int Q, int C, int L, int P,
+                    void* stream);
+
 /* gd4d_detr3d_v2_fwd - sampling core of Detr3DCrossAttenV2 (detr3d_transformer.py:441-710, the 2-D-offset deformable
  * variant; registered by the reference, used by no shipped config): projection + [-1,1] visibility test of the reference
  * point (:662-682), per (camera, head) softmax over level x point (:602-611), bilinear samples (grid_sample,

@@ -262,11 +262,14 @@ def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction
     assert len(vp) == 2 * m['num_layers'] and all(ga[k].abs().max() > 0 for k in vp)
 
 
-def test_detr3d_cross_atten_trains():
+@pytest.mark.parametrize('name,route', [('detr3d_n6', 'hip'), ('detr3d_n12_b2', 'hip'), ('detr3d_n6', 'torch')])
+def test_detr3d_cross_atten_trains(name, route, monkeypatch):
     """The DETR3D baseline module with autograd on: output = the inference path's, gradients (query, query_pos, reference
-    points, feature maps, every parameter) = autograd of the oracle (detr3d_transformer.py:352-438)."""
+    points, feature maps, every parameter) = autograd of the oracle (detr3d_transformer.py:352-438).  route hip: the sampling
+    core on gd4d_detr3d_fwd / gd4d_detr3d_bwd (the default); torch: differentiable torch ops on the GPU."""
     from oracle import torch_oracle as O
-    g = Golden('detr3d_n6')
+    monkeypatch.setenv('GD4D_DETR3D_TRAIN', route)
+    g = Golden(name)
     m = g.meta
     mod = G.build_attention(dict(type='Detr3DCrossAtten', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=1,
                                  embed_dims=256), dict(batch_first=False))
