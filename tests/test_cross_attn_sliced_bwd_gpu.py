@@ -167,3 +167,36 @@ def test_full_size_raw_backward_matches_projected_backward():
         assert _rel(a, e) < 5e-4
     for a, e in zip(r[0], p[0]):
         assert _rel(a, e) < 5e-4
+
+
+@pytest.mark.parametrize('seed', [101, 102, 103, 104])
+def test_raw_backward_random_seeds(seed):
+    c = _case(8, 4, 12, 72, 1, seed=seed)
+    p, r = _projected_backward(c), _raw_backward(c)
+    for a, e in zip(r[1:], p[1:]):
+        assert _rel(a, e) < 2e-4
+    for a, e in zip(r[0], p[0]):
+        assert _rel(a, e) < 2e-4
+
+
+def test_raw_backward_edge_cases():
+    """One camera, one query; and a step in which NO sample is visible (every reference point behind the cameras' image
+    planes is impossible with a ring of cameras, so the points are pushed far above the rig): all gradients exactly zero."""
+    c = _case(8, 4, 1, 1, 1, seed=7)
+    p, r = _projected_backward(c), _raw_backward(c)
+    for a, e in zip(r[1:], p[1:]):
+        assert torch.allclose(a, e, rtol=2e-4, atol=2e-4 * float(e.abs().max()) + 1e-12)
+    for a, e in zip(r[0], p[0]):
+        assert torch.allclose(a, e, rtol=2e-4, atol=2e-4 * float(e.abs().max()) + 1e-12)
+    c = _case(8, 4, 6, 40, 1, seed=8)
+    c['offsets'] = torch.zeros_like(c['offsets'])
+    c['offsets'][..., 2] = 500.0                       # 500 m above every camera: outside every image
+    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
+    plan, mask = ops.cross_attn_plan_fwd(ops.PyramidView.slice_planar(sp, hw), c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'],
+                                         PC_RANGE, 900, 1600, 8, want_mask=True)
+    assert int(mask.sum().item()) == 0
+    r = _raw_backward(c)
+    for t in r[1:]:
+        assert float(t.abs().max()) == 0.0
+    for t in r[0]:
+        assert float(t.abs().max()) == 0.0
