@@ -90,6 +90,7 @@ SIGNATURES = {
     'gd4d_match_cost_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_f] * 3 + [_vp]),
     'gd4d_head_loss_fwd_bwd': (_i, [_vp] * 10 + [_i] * 7 + [_f] * 3 + [_vp]),
     'gd4d_linear_bwd_weight': (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
+    'gd4d_linear_bwd_weight_group': (_i, [_vp] * 5 + [_i, _i, _vp]),
     'gd4d_value_proj_bwd_input': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_bwd_weight_workspace_bytes': (_c.c_size_t, []),
     'gd4d_value_proj_bwd_weight': (_i, [_vp] * 6 + [_c.c_size_t, _i, _i, _i, _vp]),

@@ -325,6 +325,37 @@ class ValueProjMultiFunction(torch.autograd.Function):
         return (None, *gws, *gbs, *grads)
 
 
+# Weight gradients that go straight into the flat gradient buffer (ctx.main) are read by nobody before the optimizer: they
+# are queued during the backward pass and issued sixteen per launch (gd4d_linear_bwd_weight_group) - at the latest from a
+# callback the autograd engine runs when the backward pass ends (inside a hipGraph capture that is still inside the capture).
+# GD4D_TRAIN_DEFER_WGRAD=0: one launch per Linear, where autograd reaches it.
+_WGRAD_QUEUE = []
+_WGRAD_TASK = [None]          # the backward pass (autograd graph task) the queued entries belong to
+_WGRAD_GROUP = 16
+
+
+def _flush_weight_grads():
+    global _WGRAD_QUEUE
+    queue, _WGRAD_QUEUE = _WGRAD_QUEUE, []
+    for i in range(0, len(queue), _WGRAD_GROUP):
+        ops.linear_bwd_weight_group(queue[i:i + _WGRAD_GROUP], accumulate=True)
+
+
+def _queue_weight_grad(x, grad_y, main_w, main_b):
+    task = torch._C._current_graph_task_id() if hasattr(torch._C, '_current_graph_task_id') else None
+    if os.environ.get('GD4D_TRAIN_DEFER_WGRAD', '1') == '0' or task is None or task < 0:
+        ops.linear_bwd_weight(x, grad_y, want_bias=main_b is not None, into=(main_w, main_b))
+        return
+    if _WGRAD_TASK[0] != task:
+        del _WGRAD_QUEUE[:]                           # left behind by a backward pass that raised: never add those
+        _WGRAD_TASK[0] = task
+    if not _WGRAD_QUEUE:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
+    _WGRAD_QUEUE.append((x, grad_y, main_w, main_b))
+    if len(_WGRAD_QUEUE) >= _WGRAD_GROUP:
+        _flush_weight_grads()
+
+
 class LinearFunction(torch.autograd.Function):
     """nn.Linear for the decoder's dense layers in training, all three products on the library's fp32 MFMA kernels:
     forward gd4d_linear_fwd, input gradient gd4d_linear_fwd with GD4D_LIN_WEIGHT_KN (y = grad W, no transposed copy of
@@ -349,7 +380,7 @@ class LinearFunction(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if ctx.main is not None:
-                ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias, into=ctx.main)
+                _queue_weight_grad(x, grad_y, ctx.main[0], ctx.main[1] if ctx.has_bias else None)
             else:
                 gw, gb = ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias)
         return gx, gw, gb, None, None

@@ -23,12 +23,11 @@ struct LinBwdParams {
 
 constexpr int LB_TN = 16, LB_TK = 32, LB_WAVES = 16, LB_UNROLL = 4, LB_T = LB_TK / 16;
 
-__global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_kernel(const LinBwdParams p) {
+__device__ __forceinline__ void linear_bwd_weight_tile(const LinBwdParams& p, int k0, int n0, bool first_k_tile) {
   __shared__ float part[LB_WAVES][LB_TN * LB_TK];
   __shared__ float bpart[LB_WAVES][LB_TN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, r4 = lane >> 4;
-  const int k0 = blockIdx.x * LB_TK, n0 = blockIdx.y * LB_TN;
 
   // rows of this wave: its share of M rounded up to whole MFMA steps of 4 rows
   const int per = ((p.M + LB_WAVES - 1) / LB_WAVES + 3) & ~3;
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_kernel(const 
       *d = p.accumulate ? *d + s : s;
     }
   }
-  if (p.db && blockIdx.x == 0 && threadIdx.x < LB_TN && n0 + threadIdx.x < p.N) {
+  if (p.db && first_k_tile && threadIdx.x < LB_TN && n0 + threadIdx.x < p.N) {
     const int i = threadIdx.x;
     float s = 0.f;
 #pragma unroll
@@ -102,7 +101,63 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_kernel(const 
   }
 }
 
+__global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_kernel(const LinBwdParams p) {
+  linear_bwd_weight_tile(p, blockIdx.x * LB_TK, blockIdx.y * LB_TN, blockIdx.x == 0);
+}
+
+// Several independent weight gradients in ONE launch (a decoder layer's backward produces eleven of these 13-us launches,
+// each filling half the device for a chain of four dependent load rounds; nothing reads a weight gradient before the
+// optimizer, so the training step queues them and issues them sixteen at a time): workgroup b works on tile b - tile0[i]
+// of problem i.
+constexpr int LB_GROUP = 16;
+
+struct LinBwdGroup {
+  LinBwdParams p[LB_GROUP];
+  int tile0[LB_GROUP + 1];      // first workgroup of problem i
+  int tiles_k[LB_GROUP];        // k tiles of problem i
+  int count;
+};
+
+__global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_weight_group_kernel(const LinBwdGroup g) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < LB_GROUP; ++j)
+    if (j < g.count && (int)blockIdx.x >= g.tile0[j]) i = j;
+  // (a by-value struct indexed with a runtime index would go through scratch: pick the problem with selects)
+  LinBwdParams p = g.p[0];
+  int tk = g.tiles_k[0], t0 = g.tile0[0];
+#pragma unroll
+  for (int j = 1; j < LB_GROUP; ++j)
+    if (j == i) { p = g.p[j]; tk = g.tiles_k[j]; t0 = g.tile0[j]; }
+  const int t = blockIdx.x - t0;
+  const int kt = t % tk, nt = t / tk;
+  linear_bwd_weight_tile(p, kt * LB_TK, nt * LB_TN, kt == 0);
+}
+
 }  // namespace gd4d
+
+extern "C" int gd4d_linear_bwd_weight_group(const void* const* x, const void* const* grad_y, void* const* grad_w, void* const* grad_b,
+                                            const int32_t* dims, int count, int accumulate, void* stream) {
+  using namespace gd4d;
+  if (!x || !grad_y || !grad_w || !grad_b || !dims || count <= 0) return GD4D_EINVAL;
+  if (count > LB_GROUP) return GD4D_EUNSUPPORTED;
+  LinBwdGroup g{};
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const int M = dims[5 * i], K = dims[5 * i + 1], N = dims[5 * i + 2], ldx = dims[5 * i + 3], ldy = dims[5 * i + 4];
+    if (!x[i] || !grad_y[i] || !grad_w[i] || M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return GD4D_EINVAL;
+    g.p[i] = LinBwdParams{static_cast<const float*>(x[i]), static_cast<const float*>(grad_y[i]), static_cast<float*>(grad_w[i]),
+                          static_cast<float*>(grad_b[i]), M, N, K, ldx, ldy, accumulate ? 1 : 0};
+    g.tile0[i] = tiles;
+    g.tiles_k[i] = (K + LB_TK - 1) / LB_TK;
+    tiles += g.tiles_k[i] * ((N + LB_TN - 1) / LB_TN);
+  }
+  for (int i = count; i <= LB_GROUP; ++i) g.tile0[i] = tiles;
+  for (int i = count; i < LB_GROUP; ++i) { g.p[i] = g.p[0]; g.tiles_k[i] = 1; }
+  g.count = count;
+  hipLaunchKernelGGL(linear_bwd_weight_group_kernel, dim3(tiles), dim3(64 * LB_WAVES), 0, static_cast<hipStream_t>(stream), g);
+  return check_launch();
+}
 
 extern "C" int gd4d_linear_bwd_weight(const float* x, const float* grad_y, float* grad_w, float* grad_b, int M, int K,
                                       int N, int ldx, int ldy, int accumulate, void* stream) {

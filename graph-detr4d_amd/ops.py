@@ -718,6 +718,27 @@ def linear_bwd_weight(x, grad_y, want_bias=True, into=None):
     return gw, gb
 
 
+def linear_bwd_weight_group(problems, accumulate=True):
+    """gd4d_linear_bwd_weight_group: problems = list (<= 16) of (x (M, K), grad_y (M, N), grad_w (N, K), grad_b (N) or None);
+    the sums are added to (accumulate) or written into grad_w / grad_b.  One launch for all of them."""
+    lib = _lib.load()
+    f32 = torch.float32
+    n = len(problems)
+    xs, gys, gws, gbs, dims = [], [], [], [], []
+    for x, gy, gw, gb in problems:
+        k, nn_ = x.shape[-1], gy.shape[-1]
+        m = x.numel() // k
+        if gy.numel() // nn_ != m or tuple(gw.shape) != (nn_, k) or (gb is not None and gb.numel() != nn_):
+            raise ValueError('linear_bwd_weight_group: inconsistent shapes')
+        xs.append(_dev(x, 'x', f32).value); gys.append(_dev(gy, 'grad_y', f32).value); gws.append(_dev(gw, 'grad_w', f32).value)
+        gbs.append(_dev(gb, 'grad_b', f32).value if gb is not None else None)
+        dims += [m, k, nn_, k, nn_]
+    arr = lambda v: (ctypes.c_void_p * n)(*v)          # noqa: E731
+    code = lib.gd4d_linear_bwd_weight_group(arr(xs), arr(gys), arr(gws), arr(gbs), (ctypes.c_int32 * (5 * n))(*dims), n,
+                                            1 if accumulate else 0, _stream())
+    _lib.check(code, 'gd4d_linear_bwd_weight_group')
+
+
 _VP_BWD_WS = {}
 
 

@@ -441,6 +441,11 @@ int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w
  *   leaving autograd an add per parameter). */
 int gd4d_linear_bwd_weight(const float* x, const float* grad_y, float* grad_w, float* grad_b, int M, int K, int N,
                            int ldx, int ldy, int accumulate, void* stream);
+/* gd4d_linear_bwd_weight_group - up to 16 independent gd4d_linear_bwd_weight problems in ONE launch (host arrays of `count`
+ * device pointers; grad_b[i] may be NULL; dims = count x {M, K, N, ldx, ldy}).  A training step queues the weight gradients
+ * of a decoder layer (nothing reads them before the optimizer) instead of issuing eleven half-empty launches. */
+int gd4d_linear_bwd_weight_group(const void* const* x, const void* const* grad_y, void* const* grad_w, void* const* grad_b,
+                                 const int32_t* dims, int count, int accumulate, void* stream);
 
 /* gd4d_layernorm_fwd - y = LayerNorm(x [+ res]) * gamma + beta [, ReLU] over the last dim
  * (biased variance, eps inside the sqrt, like ATen).  Replaces the nn.LayerNorm of

@@ -341,3 +341,29 @@ def test_multihead_attention_module_gradients_on_hip_kernels():
     assert [n for n, _ in mod.named_parameters()] == ['attn.' + n for n in names]
     for a, b_ in zip(got, [want[n].grad for n in names] + [q.grad]):
         torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-4 * b_.abs().max().item())
+
+
+def test_linear_bwd_weight_group_matches_the_single_launches():
+    """gd4d_linear_bwd_weight_group: sixteen problems of different shapes in one launch, overwriting and accumulating."""
+    from graph_detr4d_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(900, 256, 256), (900, 256, 512), (900, 512, 256), (900, 256, 24), (900, 256, 96), (900, 256, 128), (900, 256, 768),
+              (37, 64, 10), (900, 3, 256), (1, 256, 256), (450, 128, 33), (900, 256, 3), (64, 64, 64), (900, 256, 256), (128, 512, 17),
+              (900, 40, 8)]
+    probs, want = [], []
+    for i, (m, k, n) in enumerate(shapes):
+        x = torch.randn(m, k, generator=gen).to('cuda')
+        gy = torch.randn(m, n, generator=gen).to('cuda')
+        gw0 = torch.randn(n, k, generator=gen).to('cuda')
+        gb0 = torch.randn(n, generator=gen).to('cuda') if i % 3 else None
+        w1, b1 = ops.linear_bwd_weight(x, gy, want_bias=gb0 is not None)
+        want.append((gw0 + w1, None if gb0 is None else gb0 + b1, w1, b1))
+        probs.append((x, gy, gw0.clone(), None if gb0 is None else gb0.clone()))
+    ops.linear_bwd_weight_group(probs, accumulate=True)
+    for (x, gy, gw, gb), (ew, eb, _, _) in zip(probs, want):
+        torch.testing.assert_close(gw, ew, rtol=1e-6, atol=1e-5)
+        if gb is not None:
+            torch.testing.assert_close(gb, eb, rtol=1e-6, atol=1e-5)
+    ops.linear_bwd_weight_group(probs[:5], accumulate=False)
+    for (x, gy, gw, gb), (_, _, w1, b1) in zip(probs[:5], want[:5]):
+        assert torch.equal(gw, w1) and (gb is None or torch.equal(gb, b1))
