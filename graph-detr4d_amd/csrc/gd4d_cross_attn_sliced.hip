@@ -54,10 +54,9 @@ struct PlanParams {
 };
 
 template <int HH, int LT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanParams pp) {
+__device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const int pos, char* smem_raw) {
   const CrossAttnParams& p = pp.c;
   constexpr int PT = kPoints, E = HH * PT, LP = LT * PT, THREADS = 64 * WAVES;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float2* s_uv = reinterpret_cast<float2*>(smem_raw);                        // [N][E]; x < 0: not visible
   float* s_mat = reinterpret_cast<float*>(s_uv + p.N * E);                   // [N][12]
   float* s_cw = s_mat + p.N * 12;                                            // [N]
@@ -65,8 +64,6 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
   float4* s_items = reinterpret_cast<float4*>(s_aw + ((p.B * HH * LP + 3) & ~3));   // [WAVES][N * PT]: {u, v, row * PT + point, camera weight}
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  trace_mark(g_trace_sliced, 5ull);
-  const int pos = blockIdx.x;
   const int bq = p.order ? p.order[pos] : pos;
   const int b = bq / p.Q, q = bq - b * p.Q;
 
@@ -193,6 +190,13 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanP
     }
     __builtin_amdgcn_wave_barrier();                                       // the list is rewritten for the next head
   }
+}
+
+template <int HH, int LT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanParams pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  trace_mark(g_trace_sliced, 5ull);
+  cross_attn_plan_body<HH, LT, WAVES>(pp, blockIdx.x, smem_raw);
   trace_mark(g_trace_sliced, 0x85ull);
 }
 
@@ -221,23 +225,25 @@ struct SlicedParams {
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-template <int HH, int LT, typename VT, int OCC, int POLICY>
-__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_sliced_kernel(const SlicedParams p) {
+// (the walk: which (position, slice) workgroup `block` is; false: none)
+__device__ __forceinline__ bool sliced_walk(const SlicedParams& p, int block, int& pos, int& sl) {
+  const int xcd = block & 7, jb = block >> 3;
+  const int per_blk = p.blk * p.slice_n;                   // workgroups of one block of queries
+  const int kb = jb / per_blk, rb = jb - kb * per_blk;
+  sl = rb / p.blk;
+  const int qi = kb * p.blk + (rb - sl * p.blk);
+  pos = xcd * p.per_xcd + qi;
+  return qi < p.per_xcd && pos < p.BQ;
+}
+
+template <int HH, int LT, typename VT, int POLICY>
+__device__ __forceinline__ void cross_attn_agg_sliced_body(const SlicedParams& p, const int pos, const int sl, char* s_raw) {
   constexpr int ES = sizeof(VT);
   constexpr int CH = 6;                                   // passes staged per round (30 KB per workgroup: 4 per CU)
   constexpr int GP = 80;                                  // LDS bytes per corner slot: 64 B of pairs + 16 B pad (conflict-free b128)
   constexpr int PASS = 8 * GP;
-  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  trace_mark(g_trace_sliced, 6ull);
-  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int per_blk = p.blk * p.slice_n;                   // workgroups of one block of queries
-  const int kb = jb / per_blk, rb = jb - kb * per_blk;
-  const int sl = rb / p.blk;
-  const int qi = kb * p.blk + (rb - sl * p.blk);
-  const int pos = xcd * p.per_xcd + qi;
-  if (qi >= p.per_xcd || pos >= p.BQ) return;
   const int s = p.slice_lo + sl;
   const uint2* pp = p.pair + ((size_t)pos * HH + h) * p.cap_t * 64 + lane;
   const uint2 first = pp[0];                              // speculative: pass 0 (garbage, unused, when M = 0)
@@ -302,6 +308,71 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_sliced_kernel(con
     acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
   }
   if (g == 0) *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4) = acc;
+}
+
+template <int HH, int LT, typename VT, int OCC, int POLICY>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_sliced_kernel(const SlicedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
+  trace_mark(g_trace_sliced, 6ull);
+  int pos, sl;
+  if (!sliced_walk(p, blockIdx.x, pos, sl)) return;
+  cross_attn_agg_sliced_body<HH, LT, VT, POLICY>(p, pos, sl, s_raw);
+  trace_mark(g_trace_sliced, 0x86ull);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Plan UNDER the gather: one launch for both.  The workgroups of an XCD are dispatched in index order and slice-major, so
+// the first per_xcd of them are slice 0 of every position the XCD owns: each of these first writes its position's plan
+// (cross_attn_plan_body: the plan kernel's code), publishes it (flag[pos] = 1, release at agent scope) and goes on with
+// slice 0; the workgroups of slices 1..7 of that position - later in the dispatch order, on the SAME XCD: one L2 - wait
+// for the flag (acquire) and gather.  No deadlock: a waiting workgroup was dispatched after its producer, which depends
+// on nothing.  The last of a position's 8 workgroups to finish clears flag and counter for the next launch.
+// Measured: no gain (1.733 against 1.730 ms per sample with the two launches): the plan phase occupies every CU for about as
+// long as the plan kernel does (it is bound by vector issue, not by launch width), so only a kernel boundary is saved and the
+// flag traffic added.  Kept behind GD4D_PLAN_FUSED=1; results are the two launches' bit for bit (tested).
+struct PlanAggSync {
+  int* flag;      // [BQ] 0 / 1, zero before the first launch
+  int* done;      // [BQ] slices finished
+  int* status;    // optional: set to 1 if a wait ran out (never in a correct run; tests check it)
+};
+
+template <int HH, int LT, typename VT, int OCC>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_plan_agg_kernel(const PlanParams pp, const SlicedParams p, const PlanAggSync y) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  trace_mark(g_trace_sliced, 6ull);
+  int pos, sl;
+  if (!sliced_walk(p, blockIdx.x, pos, sl)) return;
+  // Producer and consumers of a position share ONE L2 (same XCD), so no cache is written back or invalidated: an
+  // agent-scope release / acquire pair here costs an L2 write-back per producer and an L2 invalidate per workgroup on this
+  // multi-XCD part (measured: the step 4.9 ms instead of 1.7).  What is needed: the producer's plan stores acknowledged by
+  // the L2 before the flag goes out (workgroup-scope release = s_waitcnt), the flag itself exchanged memory-side (relaxed
+  // agent-scope accesses bypass L1 and L2), and a consumer CU that has never read this position's plan in this launch (its
+  // L1 was invalidated when the kernel started and nobody touches a position's plan before its flag).
+  if (sl == 0) {
+    cross_attn_plan_body<HH, LT, HH>(pp, pos, s_raw);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(y.flag + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(y.flag + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 24)) { if (y.status) *y.status = 1; break; }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  cross_attn_agg_sliced_body<HH, LT, VT, 0>(p, pos, sl, s_raw);
+  __syncthreads();                                         // every wave of this workgroup is done with the plan
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(y.done + pos, 1);
+    if (old == p.slice_n - 1) {                            // the last slice of this position: reset for the next launch
+      __hip_atomic_store(y.done + pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(y.flag + pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
@@ -394,6 +465,14 @@ extern "C" size_t gd4d_cross_attn_plan_bytes(int B, int N, int Q, int Hh, int P)
   return gd4d::plan_hdr_bytes(B, Q) + (size_t)B * Q * Hh * gd4d::plan_cap_t(N, P) * 64 * sizeof(uint2);
 }
 
+namespace gd4d {
+static int fill_plan_params(PlanParams& pp, const float* ref, const float* offsets, const float* attn_logits,
+                            const float* cam_logits, const float* lidar2img, const double* pc_range, float img_h, float img_w,
+                            const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,
+                            size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh, int L, int P,
+                            int flags, const int32_t* query_order);
+}
+
 extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, const float* attn_logits,
                                         const float* cam_logits, const float* lidar2img, const double* pc_range,
                                         float img_h, float img_w, const int32_t* level_hw, const int64_t* cam_stride_bytes,
@@ -401,39 +480,12 @@ extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, 
                                         uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh, int L, int P, int flags,
                                         const int32_t* query_order, void* stream) {
   using namespace gd4d;
-  if (!ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range || !plan || !level_hw || !cam_stride_bytes)
-    return GD4D_EINVAL;
-  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
-  if (P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
-  if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
-  if (!aligned16(plan)) return GD4D_EALIGN;
-  if (plan_bytes < gd4d_cross_attn_plan_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
-  if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
   PlanParams pp{};
-  CrossAttnParams& p = pp.c;
-  p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits; p.cam_logits = cam_logits; p.lidar2img = lidar2img;
-  p.mask_out = mask_out; p.uv_out = uv_out; p.order = query_order; p.wsum = wsum;
-  p.B = B; p.N = N; p.Q = Q; p.L = L; p.P = P;
-  p.raw_cam = (flags & GD4D_CA_RAW_CAM_WEIGHTS) ? 1 : 0;
-  for (int k = 0; k < 3; ++k) {
-    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
-    p.rng_lo[k] = static_cast<float>(pc_range[k]);
-  }
-  p.img_h = img_h; p.img_w = img_w;
-  for (int l = 0; l < 4; ++l) { pp.g.lvl_w[l] = 1; pp.g.lvl_h[l] = 1; pp.g.cam_stride[l] = 0; }
-  for (int l = 0; l < L; ++l) {
-    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
-    if (h <= 0 || w <= 0 || cam_stride_bytes[l] < 0) return GD4D_EINVAL;
-    // 32-bit byte offsets inside a level: the last pixel of the last camera row
-    const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
-                                    (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
-    if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EUNSUPPORTED;
-    pp.g.lvl_w[l] = w; pp.g.lvl_h[l] = h; pp.g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
-  }
-  pp.g.pix_stride = (unsigned)pix_stride_bytes;
-  pp.hdr = static_cast<int*>(plan);
-  pp.pair = reinterpret_cast<uint2*>(static_cast<char*>(plan) + plan_hdr_bytes(B, Q));
-  pp.cap_t = plan_cap_t(N, P);
+  if (int rc = fill_plan_params(pp, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, level_hw, cam_stride_bytes,
+                                pix_stride_bytes, plan, plan_bytes, wsum, mask_out, uv_out, B, N, Q, Hh, L, P, flags, query_order))
+    return rc;
+  const CrossAttnParams& p = pp.c;
+  (void)p;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(B * Q);
   auto lds = [&](int LT) {
@@ -463,6 +515,59 @@ extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, 
 #undef GD4D_PLAN_L
 #undef GD4D_PLAN_GO
 }
+
+static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, const float* offsets, const float* attn_logits,
+                                      const float* cam_logits, const float* lidar2img, const double* pc_range, float img_h,
+                                      float img_w, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
+                                      void* plan, size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out, int B, int N,
+                                      int Q, int Hh, int L, int P, int flags, const int32_t* query_order) {
+  using namespace gd4d;
+  if (!ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range || !plan || !level_hw || !cam_stride_bytes)
+    return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
+  if (P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
+  if (!aligned16(plan)) return GD4D_EALIGN;
+  if (plan_bytes < gd4d_cross_attn_plan_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
+  if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
+  CrossAttnParams& p = pp.c;
+  p.ref = ref; p.offsets = offsets; p.attn_logits = attn_logits; p.cam_logits = cam_logits; p.lidar2img = lidar2img;
+  p.mask_out = mask_out; p.uv_out = uv_out; p.order = query_order; p.wsum = wsum;
+  p.B = B; p.N = N; p.Q = Q; p.L = L; p.P = P;
+  p.raw_cam = (flags & GD4D_CA_RAW_CAM_WEIGHTS) ? 1 : 0;
+  for (int k = 0; k < 3; ++k) {
+    p.rng_scale[k] = static_cast<float>(pc_range[k + 3] - pc_range[k]);
+    p.rng_lo[k] = static_cast<float>(pc_range[k]);
+  }
+  p.img_h = img_h; p.img_w = img_w;
+  for (int l = 0; l < 4; ++l) { pp.g.lvl_w[l] = 1; pp.g.lvl_h[l] = 1; pp.g.cam_stride[l] = 0; }
+  for (int l = 0; l < L; ++l) {
+    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+    if (h <= 0 || w <= 0 || cam_stride_bytes[l] < 0) return GD4D_EINVAL;
+    // 32-bit byte offsets inside a level: the last pixel of the last camera row
+    const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
+                                    (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
+    if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EUNSUPPORTED;
+    pp.g.lvl_w[l] = w; pp.g.lvl_h[l] = h; pp.g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
+  }
+  pp.g.pix_stride = (unsigned)pix_stride_bytes;
+  pp.hdr = static_cast<int*>(plan);
+  pp.pair = reinterpret_cast<uint2*>(static_cast<char*>(plan) + plan_hdr_bytes(B, Q));
+  pp.cap_t = plan_cap_t(N, P);
+  return GD4D_OK;
+}
+
+namespace gd4d {
+static int fill_plan_params(PlanParams& pp, const float* ref, const float* offsets, const float* attn_logits,
+                            const float* cam_logits, const float* lidar2img, const double* pc_range, float img_h, float img_w,
+                            const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,
+                            size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out, int B, int N, int Q, int Hh, int L, int P,
+                            int flags, const int32_t* query_order) {
+  return gd4d_fill_plan_params_impl(pp, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, level_hw,
+                                    cam_stride_bytes, pix_stride_bytes, plan, plan_bytes, wsum, mask_out, uv_out, B, N, Q, Hh, L, P, flags,
+                                    query_order);
+}
+}  // namespace gd4d
 
 namespace gd4d {
 template <int HH, typename VT>
@@ -498,10 +603,10 @@ static int launch_sliced(const SlicedParams& p, int L, hipStream_t s) {
 }
 }  // namespace gd4d
 
-extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
-                                              float* agg, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                                              const int32_t* query_order, int slice_lo, int slice_n, void* stream) {
-  using namespace gd4d;
+namespace gd4d {
+static int fill_sliced_params(SlicedParams& p, const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan, float* agg,
+                              int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype, const int32_t* query_order,
+                              int slice_lo, int slice_n) {
   if (!level_ptrs || !plan || !agg) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
   if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
@@ -511,7 +616,6 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
   if (!aligned16(agg) || !aligned16(plan)) return GD4D_EALIGN;
   const int es = feats_dtype == GD4D_BF16 ? 2 : 4;
   if (slice_stride_bytes % (4 * es)) return GD4D_EALIGN;
-  SlicedParams p{};
   for (int l = 0; l < L; ++l) {
     if (!level_ptrs[l]) return GD4D_EINVAL;
     if (reinterpret_cast<uintptr_t>(level_ptrs[l]) % (4 * es)) return GD4D_EALIGN;
@@ -525,6 +629,18 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
   p.BQ = B * Q; p.per_xcd = (B * Q + 7) / 8; p.cap_t = plan_cap_t(N, P);
   p.slice_lo = slice_lo; p.slice_n = slice_n;
   p.blk = p.per_xcd;                                // one block = the XCD's whole sector: plain slice-major
+  return GD4D_OK;
+}
+}  // namespace gd4d
+
+extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                                              float* agg, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                              const int32_t* query_order, int slice_lo, int slice_n, void* stream) {
+  using namespace gd4d;
+  SlicedParams p{};
+  if (int rc = fill_sliced_params(p, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order, slice_lo,
+                                  slice_n))
+    return rc;
 #ifdef GD4D_DEV
   { const char* e = getenv("GD4D_SLICED_BLK"); const int blk = e ? atoi(e) : 0; if (blk > 0 && blk < p.per_xcd) p.blk = blk; }
 #endif
@@ -535,6 +651,57 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
     case 8: return bf16 ? launch_sliced<8, uint16_t>(p, L, s) : launch_sliced<8, float>(p, L, s);
     default: return bf16 ? launch_sliced<16, uint16_t>(p, L, s) : launch_sliced<16, float>(p, L, s);
   }
+}
+
+extern "C" size_t gd4d_cross_attn_plan_agg_sync_bytes(int B, int Q) {
+  if (B <= 0 || Q <= 0) return 0;
+  return (size_t)(2 * B * Q + 4) * sizeof(int);
+}
+
+extern "C" int gd4d_cross_attn_plan_agg_sliced_fwd(const float* ref, const float* offsets, const float* attn_logits,
+                                                   const float* cam_logits, const float* lidar2img, const double* pc_range,
+                                                   float img_h, float img_w, const int32_t* level_hw,
+                                                   const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,
+                                                   size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out,
+                                                   const void* const* level_ptrs, int64_t slice_stride_bytes, float* agg, void* sync,
+                                                   size_t sync_bytes, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                                   int flags, const int32_t* query_order, void* stream) {
+  using namespace gd4d;
+  if (!sync || sync_bytes < gd4d_cross_attn_plan_agg_sync_bytes(B, Q)) return sync ? GD4D_EWORKSPACE : GD4D_EINVAL;
+  PlanParams pp{};
+  if (int rc = fill_plan_params(pp, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, level_hw, cam_stride_bytes,
+                                pix_stride_bytes, plan, plan_bytes, wsum, mask_out, uv_out, B, N, Q, Hh, L, P, flags, query_order))
+    return rc;
+  SlicedParams p{};
+  if (int rc = fill_sliced_params(p, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order, 0, kSlices))
+    return rc;
+  PlanAggSync y{static_cast<int*>(sync), static_cast<int*>(sync) + B * Q, static_cast<int*>(sync) + 2 * B * Q};
+  const size_t plan_lds = (size_t)N * Hh * kPoints * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
+                          (size_t)((B * Hh * L * kPoints + 3) & ~3) * sizeof(float) + (size_t)Hh * N * kPoints * sizeof(float4);
+  const size_t agg_lds = (size_t)Hh * 6 * 8 * 80;
+  if (plan_lds > agg_lds + 8192) return GD4D_EUNSUPPORTED;    // (many cameras / samples: the two launches keep their own occupancy)
+  const size_t lds = plan_lds > agg_lds ? plan_lds : agg_lds;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(8 * p.per_xcd * kSlices);
+  auto go = [&](auto kern, int hh) -> int {
+    if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * hh), lds, s, pp, p, y);
+    return check_launch();
+  };
+#define GD4D_PA_L(HH_, VT_, OCC_)                                                  \
+  switch (L) {                                                                     \
+    case 1: return go(cross_attn_plan_agg_kernel<HH_, 1, VT_, OCC_>, HH_);         \
+    case 2: return go(cross_attn_plan_agg_kernel<HH_, 2, VT_, OCC_>, HH_);         \
+    case 3: return go(cross_attn_plan_agg_kernel<HH_, 3, VT_, OCC_>, HH_);         \
+    default: return go(cross_attn_plan_agg_kernel<HH_, 4, VT_, OCC_>, HH_);        \
+  }
+  const bool bf16 = feats_dtype == GD4D_BF16;
+  switch (Hh) {
+    case 4: if (bf16) { GD4D_PA_L(4, uint16_t, 6) } else { GD4D_PA_L(4, float, 6) }
+    case 8: if (bf16) { GD4D_PA_L(8, uint16_t, 6) } else { GD4D_PA_L(8, float, 6) }
+    default: if (bf16) { GD4D_PA_L(16, uint16_t, 4) } else { GD4D_PA_L(16, float, 4) }
+  }
+#undef GD4D_PA_L
 }
 
 extern "C" int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C,
