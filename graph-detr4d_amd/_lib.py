@@ -70,6 +70,7 @@ SIGNATURES = {
     'gd4d_layernorm_bwd_workspace_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_layernorm_bwd': (_i, [_vp] * 9 + [_c.c_size_t, _i, _i, _f, _i, _vp]),
     'gd4d_inverse_sigmoid_fwd': (_i, [_vp, _vp, _c.c_int64, _vp]),
+    'gd4d_layernorm_bwd_reduce_group': (_i, [_vp] * 4 + [_i, _i, _vp]),
     'gd4d_refine_reference_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_frustum_pe_input_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _i, _vp]),
     'gd4d_se_fuse_chlast_fwd': (_i, [_vp] * 5 + [_i] * 6 + [_vp]),

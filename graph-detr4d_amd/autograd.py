@@ -329,31 +329,47 @@ class ValueProjMultiFunction(torch.autograd.Function):
 # are queued during the backward pass and issued sixteen per launch (gd4d_linear_bwd_weight_group) - at the latest from a
 # callback the autograd engine runs when the backward pass ends (inside a hipGraph capture that is still inside the capture).
 # GD4D_TRAIN_DEFER_WGRAD=0: one launch per Linear, where autograd reaches it.
-_WGRAD_QUEUE = []
+_WGRAD_QUEUE, _LN_QUEUE = [], []
 _WGRAD_TASK = [None]          # the backward pass (autograd graph task) the queued entries belong to
-_WGRAD_GROUP = 16
+_WGRAD_GROUP, _LN_GROUP = 16, 32
 
 
-def _flush_weight_grads():
-    global _WGRAD_QUEUE
+def _flush_deferred():
+    global _WGRAD_QUEUE, _LN_QUEUE
     queue, _WGRAD_QUEUE = _WGRAD_QUEUE, []
     for i in range(0, len(queue), _WGRAD_GROUP):
         ops.linear_bwd_weight_group(queue[i:i + _WGRAD_GROUP], accumulate=True)
+    queue, _LN_QUEUE = _LN_QUEUE, []
+    for i in range(0, len(queue), _LN_GROUP):
+        ops.layernorm_bwd_reduce_group(queue[i:i + _LN_GROUP], accumulate=True)
+
+
+def _deferring():
+    """The current backward pass (graph task id) if parameter gradients may be queued, else None."""
+    if os.environ.get('GD4D_TRAIN_DEFER_WGRAD', '1') == '0' or not hasattr(torch._C, '_current_graph_task_id'):
+        return None
+    task = torch._C._current_graph_task_id()
+    return task if task >= 0 else None
+
+
+def _queue_deferred(queue, entry, group):
+    task = _deferring()
+    if _WGRAD_TASK[0] != task:
+        del _WGRAD_QUEUE[:]                           # left behind by a backward pass that raised: never add those
+        del _LN_QUEUE[:]
+        _WGRAD_TASK[0] = task
+    if not _WGRAD_QUEUE and not _LN_QUEUE:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+    queue.append(entry)
+    if len(queue) >= group:
+        _flush_deferred()
 
 
 def _queue_weight_grad(x, grad_y, main_w, main_b):
-    task = torch._C._current_graph_task_id() if hasattr(torch._C, '_current_graph_task_id') else None
-    if os.environ.get('GD4D_TRAIN_DEFER_WGRAD', '1') == '0' or task is None or task < 0:
+    if _deferring() is None:
         ops.linear_bwd_weight(x, grad_y, want_bias=main_b is not None, into=(main_w, main_b))
         return
-    if _WGRAD_TASK[0] != task:
-        del _WGRAD_QUEUE[:]                           # left behind by a backward pass that raised: never add those
-        _WGRAD_TASK[0] = task
-    if not _WGRAD_QUEUE:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
-    _WGRAD_QUEUE.append((x, grad_y, main_w, main_b))
-    if len(_WGRAD_QUEUE) >= _WGRAD_GROUP:
-        _flush_weight_grads()
+    _queue_deferred(_WGRAD_QUEUE, (x, grad_y, main_w, main_b), _WGRAD_GROUP)
 
 
 class LinearFunction(torch.autograd.Function):
@@ -401,8 +417,12 @@ class LayerNormFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_y):
         x, gamma, beta = ctx.saved_tensors
-        if ctx.main is not None:                          # dgamma / dbeta added to the flat gradient buffer by the kernel
-            dx, _, _ = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu, into=ctx.main)
+        if ctx.main is not None:                          # dgamma / dbeta added to the flat gradient buffer by the kernels
+            if _deferring():                              # ... the column reduce queued with the weight gradients
+                dx, ws, mc = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu, defer=True)
+                _queue_deferred(_LN_QUEUE, (ws, mc, ctx.main[0], ctx.main[1]), _LN_GROUP)
+            else:
+                dx, _, _ = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu, into=ctx.main)
             return dx, None, None, None, None, None, None
         dx, dg, db = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu)
         return dx, dg, db, None, None, None, None

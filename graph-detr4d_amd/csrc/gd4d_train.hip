@@ -134,6 +134,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
   }
 }
 
+// The column reduces of up to LN_GROUP LayerNorm backward calls in ONE launch (a training step queues them: the parameter
+// gradients are needed by nobody before the optimizer, and thirty 4-us launches are thirty launches).
+constexpr int LN_GROUP = 32;
+
+struct LnReduceGroup {
+  const float* part[LN_GROUP];
+  float* dgamma[LN_GROUP];
+  float* dbeta[LN_GROUP];
+  int parts[LN_GROUP];
+  int C[LN_GROUP];
+  int blk0[LN_GROUP + 1];       // first workgroup of problem i (64 columns of its 2 C per workgroup)
+  int count, accumulate;
+};
+
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_group_kernel(const LnReduceGroup g) {
+  __shared__ float s_p[4][64];
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < LN_GROUP; ++j)
+    if (j < g.count && (int)blockIdx.x >= g.blk0[j]) i = j;
+  const float* part = g.part[0];
+  float* dgamma = g.dgamma[0];
+  float* dbeta = g.dbeta[0];
+  int parts = g.parts[0], C = g.C[0], b0 = g.blk0[0];
+#pragma unroll
+  for (int j = 1; j < LN_GROUP; ++j)
+    if (j == i) { part = g.part[j]; dgamma = g.dgamma[j]; dbeta = g.dbeta[j]; parts = g.parts[j]; C = g.C[j]; b0 = g.blk0[j]; }
+  const int col = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int e = ((int)blockIdx.x - b0) * 64 + col;
+  const int k = e / C, c = e - k * C;
+  float s = 0.f;
+  if (e < 2 * C) {
+#pragma unroll 4
+    for (int w = pg; w < parts; w += 4) s += part[((size_t)w * 2 + k) * C + c];
+  }
+  s_p[pg][col] = s;
+  __syncthreads();
+  if (pg == 0 && e < 2 * C) {
+    const float t = ((s_p[0][col] + s_p[1][col]) + s_p[2][col]) + s_p[3][col];
+    float* d = (k == 0 ? dgamma : dbeta) + c;
+    *d = g.accumulate ? *d + t : t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Self-attention core backward.  Forward (gd4d_mha_core_fwd): P = softmax(scale q k^T + mask), o = P v, per head
 // (D = 32), with lse[q] = log sum_k exp(scale q k^T + mask) saved per (query, batch, head).  Given do:
@@ -294,7 +338,8 @@ extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float*
                                   float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M,
                                   int C, float eps, int flags, void* stream) {
   using namespace gd4d;
-  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0) return GD4D_EINVAL;
+  if (!x || !gamma || !dy || !dx || !workspace || M <= 0 || C <= 0) return GD4D_EINVAL;
+  if (!(flags & GD4D_LN_DEFER_REDUCE) && (!dgamma || !dbeta)) return GD4D_EINVAL;
   const int relu = flags & GD4D_LN_RELU;
   if (relu && !beta) return GD4D_EINVAL;
   if (C % 4 != 0 || C > 1024) return GD4D_EUNSUPPORTED;
@@ -307,6 +352,7 @@ extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float*
   const int parts = (M + 15) / 16;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, p);
   if (int rc = check_launch()) return rc;
+  if (flags & GD4D_LN_DEFER_REDUCE) return GD4D_OK;       // the caller reduces the partials later (gd4d_layernorm_bwd_reduce_group)
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, p.part, dgamma, dbeta, parts, C,
                      (flags & GD4D_LN_ACCUMULATE) ? 1 : 0);
   return check_launch();
@@ -333,5 +379,27 @@ extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v,
   hipLaunchKernelGGL(mha_bwd_kernel<0>, dim3((Lq + 15) / 16, H, B), dim3(64 * TB_WAVES), 0, st, p);
   if (int rc = check_launch()) return rc;
   hipLaunchKernelGGL(mha_bwd_kernel<1>, dim3((Lk + 15) / 16, H, B), dim3(64 * TB_WAVES), 0, st, p);
+  return check_launch();
+}
+
+extern "C" int gd4d_layernorm_bwd_reduce_group(const void* const* workspaces, void* const* dgamma, void* const* dbeta, const int32_t* dims,
+                                               int count, int accumulate, void* stream) {
+  using namespace gd4d;
+  if (!workspaces || !dgamma || !dbeta || !dims || count <= 0) return GD4D_EINVAL;
+  if (count > LN_GROUP) return GD4D_EUNSUPPORTED;
+  LnReduceGroup g{};
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const int M = dims[2 * i], C = dims[2 * i + 1];
+    if (!workspaces[i] || !dgamma[i] || !dbeta[i] || M <= 0 || C <= 0) return GD4D_EINVAL;
+    g.part[i] = static_cast<const float*>(workspaces[i]);
+    g.dgamma[i] = static_cast<float*>(dgamma[i]); g.dbeta[i] = static_cast<float*>(dbeta[i]);
+    g.parts[i] = (M + 15) / 16; g.C[i] = C; g.blk0[i] = blocks;
+    blocks += (2 * C + 63) / 64;
+  }
+  for (int i = count; i <= LN_GROUP; ++i) g.blk0[i] = blocks;
+  for (int i = count; i < LN_GROUP; ++i) { g.part[i] = g.part[0]; g.dgamma[i] = g.dgamma[0]; g.dbeta[i] = g.dbeta[0]; g.parts[i] = 0; g.C[i] = 1; }
+  g.count = count; g.accumulate = accumulate ? 1 : 0;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_group_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g);
   return check_launch();
 }

@@ -995,22 +995,38 @@ def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_
     return (dqk, dv) if packed_qk else (dq, dk, dv)
 
 
-def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False, into=None):
-    """gd4d_layernorm_bwd.  Returns (dx like x, dgamma, dbeta); into=(g_buf, b_buf): dgamma / dbeta are ADDED to these."""
+def layernorm_bwd(x, gamma, beta, grad_y, eps=1e-5, res=None, relu=False, into=None, defer=False):
+    """gd4d_layernorm_bwd.  Returns (dx like x, dgamma, dbeta); into=(g_buf, b_buf): dgamma / dbeta are ADDED to these.
+    defer=True: only dx and the partial column sums are computed - returns (dx, workspace, (M, C)) for
+    layernorm_bwd_reduce_group."""
     lib = _lib.load()
     f32 = torch.float32
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
-    dg, db = (torch.empty_like(gamma), torch.empty_like(gamma)) if into is None else into
+    dg, db = (None, None) if defer else ((torch.empty_like(gamma), torch.empty_like(gamma)) if into is None else into)
     nbytes = lib.gd4d_layernorm_bwd_workspace_bytes(m, c)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     code = lib.gd4d_layernorm_bwd(_dev(x, 'x', f32), _opt(res, 'res'), _dev(gamma, 'gamma', f32), _opt(beta, 'beta'),
-                                  _dev(grad_y, 'grad_y', f32), _dev(dx, 'dx'), _dev(dg, 'dgamma', f32), _dev(db, 'dbeta', f32),
-                                  _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), m, c, float(eps),
-                                  (1 if relu else 0) | (0 if into is None else 2), _stream())
+                                  _dev(grad_y, 'grad_y', f32), _dev(dx, 'dx'), None if defer else _dev(dg, 'dgamma', f32),
+                                  None if defer else _dev(db, 'dbeta', f32), _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), m, c,
+                                  float(eps), (1 if relu else 0) | (0 if into is None else 2) | (4 if defer else 0), _stream())
     _lib.check(code, 'gd4d_layernorm_bwd')
-    return dx, dg, db
+    return (dx, ws, (m, c)) if defer else (dx, dg, db)
+
+
+def layernorm_bwd_reduce_group(problems, accumulate=True):
+    """gd4d_layernorm_bwd_reduce_group: problems = list (<= 32) of (workspace, (M, C), dgamma, dbeta) from layernorm_bwd(defer=True)."""
+    lib = _lib.load()
+    n = len(problems)
+    f32 = torch.float32
+    arr = lambda v: (ctypes.c_void_p * n)(*v)          # noqa: E731
+    dims = [int(v) for _, mc, _, _ in problems for v in mc]
+    code = lib.gd4d_layernorm_bwd_reduce_group(arr([_dev(w, 'workspace').value for w, _, _, _ in problems]),
+                                               arr([_dev(g, 'dgamma', f32).value for _, _, g, _ in problems]),
+                                               arr([_dev(b, 'dbeta', f32).value for _, _, _, b in problems]),
+                                               (ctypes.c_int32 * (2 * n))(*dims), n, 1 if accumulate else 0, _stream())
+    _lib.check(code, 'gd4d_layernorm_bwd_reduce_group')
 
 
 def inverse_sigmoid_fwd(x):

@@ -588,10 +588,16 @@ int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const floa
  * the decoder layer's norms and position_encoder (deform3d_cross_attn.py:104-111). */
 #define GD4D_LN_RELU 1
 #define GD4D_LN_ACCUMULATE 2
+#define GD4D_LN_DEFER_REDUCE 4   /* dx and the per-workgroup partials only (dgamma / dbeta may be NULL): gd4d_layernorm_bwd_reduce_group later */
 size_t gd4d_layernorm_bwd_workspace_bytes(int M, int C);
 int gd4d_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* beta, const float* dy, float* dx,
                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M, int C, float eps,
                        int flags, void* stream);
+/* gd4d_layernorm_bwd_reduce_group - the column reduces (dgamma, dbeta from the workspaces' partials) of up to 32 earlier
+ * gd4d_layernorm_bwd calls made with GD4D_LN_DEFER_REDUCE, in ONE launch: host arrays of `count` device pointers, dims =
+ * count x {M, C} of those calls; accumulate != 0: added to dgamma / dbeta. */
+int gd4d_layernorm_bwd_reduce_group(const void* const* workspaces, void* const* dgamma, void* const* dbeta, const int32_t* dims,
+                                    int count, int accumulate, void* stream);
 
 /* gd4d_inverse_sigmoid_fwd - y = log(clamp(x, eps, 1) / clamp(1 - x, eps, 1)) with x clamped to [0, 1], eps = 1e-5: the
  * reference's inverse_sigmoid (deform3d_cross_attn.py:16-31) as ONE launch for callers that need the tensor itself (the

@@ -367,3 +367,30 @@ def test_linear_bwd_weight_group_matches_the_single_launches():
     ops.linear_bwd_weight_group(probs[:5], accumulate=False)
     for (x, gy, gw, gb), (_, _, w1, b1) in zip(probs[:5], want[:5]):
         assert torch.equal(gw, w1) and (gb is None or torch.equal(gb, b1))
+
+
+def test_layernorm_bwd_deferred_column_reduce_matches_the_direct_call():
+    """gd4d_layernorm_bwd with GD4D_LN_DEFER_REDUCE + gd4d_layernorm_bwd_reduce_group (32 problems, one launch): dx identical,
+    dgamma / dbeta equal to the direct call's, overwriting and accumulating."""
+    from graph_detr4d_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    probs, want = [], []
+    for i in range(32):
+        m, c = [(900, 256), (900, 512), (37, 64), (1, 256), (450, 1024), (900, 4)][i % 6]
+        x = torch.randn(m, c, generator=gen).to('cuda')
+        gamma, beta = torch.randn(c, generator=gen).to('cuda'), torch.randn(c, generator=gen).to('cuda')
+        gy = torch.randn(m, c, generator=gen).to('cuda')
+        relu = i % 2 == 1
+        dx0, dg0, db0 = ops.layernorm_bwd(x, gamma, beta, gy, 1e-5, relu=relu)
+        dx1, ws, mc = ops.layernorm_bwd(x, gamma, beta, gy, 1e-5, relu=relu, defer=True)
+        assert torch.equal(dx1, dx0) and mc == (m, c)
+        g0, b0 = torch.randn(c, generator=gen).to('cuda'), torch.randn(c, generator=gen).to('cuda')
+        probs.append((ws, mc, g0.clone(), b0.clone()))
+        want.append((dg0, db0, g0, b0))
+    ops.layernorm_bwd_reduce_group(probs, accumulate=True)
+    for (_, _, g, b), (dg0, db0, g0, b0) in zip(probs, want):
+        torch.testing.assert_close(g, g0 + dg0, rtol=1e-6, atol=1e-5)
+        torch.testing.assert_close(b, b0 + db0, rtol=1e-6, atol=1e-5)
+    ops.layernorm_bwd_reduce_group(probs[:7], accumulate=False)
+    for (_, _, g, b), (dg0, db0, _, _) in zip(probs[:7], want[:7]):
+        assert torch.equal(g, dg0) and torch.equal(b, db0)
