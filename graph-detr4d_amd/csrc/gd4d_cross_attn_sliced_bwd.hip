@@ -521,30 +521,44 @@ __global__ __launch_bounds__(256) void pyramid_grad_count_kernel(const int* __re
   const int W = g.lvl_w[l], cws = g.cws[l], chs = g.chs[l], CWl = g.CW[l], CHl = g.CH[l], cbase = g.chunk_base[l];
   const unsigned long long lt = (1ull << lane) - 1ull;
   const size_t prow = (size_t)ph * cap_t * 64 + lane;
-  for (int t = 0; t < T; ++t) {
+  // two passes per round: both rounds of matching first, then both returning atomics in flight together (a pass at a time,
+  // every pass waited for its own atomic's round trip)
+  struct Match { int key, pxin, leader, rank, n; bool valid; };
+  auto match = [&](int t) -> Match {
+    Match m{0, 0, lane, 0, 0, false};
+    if (t >= T) return m;
     const uint2 pr = pair[prow + (size_t)t * 64];
-    const bool valid = __uint_as_float(pr.y) != 0.f;
+    m.valid = __uint_as_float(pr.y) != 0.f;
     const unsigned row = pr.x / cs;
     const unsigned pix = (pr.x - row * cs) / g.pix_stride;
     const int y = (int)pix / W, x = (int)pix - y * W;
-    const int key = cbase + ((int)row * CHl + (y >> chs)) * CWl + (x >> cws);
-    const int pxin = ((y & ((1 << chs) - 1)) << cws) | (x & ((1 << cws) - 1));
-    unsigned long long rem = __ballot(valid);
-    int leader = lane, rank = 0, n = 0;
+    m.key = cbase + ((int)row * CHl + (y >> chs)) * CWl + (x >> cws);
+    m.pxin = ((y & ((1 << chs) - 1)) << cws) | (x & ((1 << cws) - 1));
+    unsigned long long rem = __ballot(m.valid);
     while (rem) {
       const int ld = __ffsll((long long)rem) - 1;
-      const int k = __builtin_amdgcn_readlane(key, ld);
-      const bool mine = valid && key == k;
-      const unsigned long long m = __ballot(mine);
-      if (mine) { leader = ld; rank = __popcll(m & lt); }
-      if (lane == ld) n = __popcll(m);
-      rem &= ~m;
+      const int k = __builtin_amdgcn_readlane(m.key, ld);
+      const bool mine = m.valid && m.key == k;
+      const unsigned long long mm = __ballot(mine);
+      if (mine) { m.leader = ld; m.rank = __popcll(mm & lt); }
+      if (lane == ld) m.n = __popcll(mm);
+      rem &= ~mm;
     }
-    int base = 0;
-    if (valid && leader == lane) base = atomicAdd(count + key, n);
-    base = __shfl(base, leader);
-    slots[prow + (size_t)t * 64] = valid ? make_uint2(((unsigned)key << 6) | (unsigned)pxin, (unsigned)(base + rank))
-                                         : make_uint2(0xffffffffu, 0xffffffffu);
+    return m;
+  };
+  auto finish = [&](int t, const Match& m, int base) {
+    if (t >= T) return;
+    base = __shfl(base, m.leader);
+    slots[prow + (size_t)t * 64] = m.valid ? make_uint2(((unsigned)m.key << 6) | (unsigned)m.pxin, (unsigned)(base + m.rank))
+                                           : make_uint2(0xffffffffu, 0xffffffffu);
+  };
+  for (int t = 0; t < T; t += 2) {
+    const Match m0 = match(t), m1 = match(t + 1);
+    int b0 = 0, b1 = 0;
+    if (m0.valid && m0.leader == lane) b0 = atomicAdd(count + m0.key, m0.n);
+    if (m1.valid && m1.leader == lane) b1 = atomicAdd(count + m1.key, m1.n);
+    finish(t, m0, b0);
+    finish(t + 1, m1, b1);
   }
 }
 
