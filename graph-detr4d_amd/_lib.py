@@ -30,9 +30,6 @@ SIGNATURES = {
     'gd4d_cross_attn_plan_bytes': (_c.c_size_t, [_i] * 5),
     'gd4d_cross_attn_plan_fwd': (_i, [_vp] * 6 + [_f, _f, _vp, _vp, _c.c_int64, _vp, _c.c_size_t, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp]),
     'gd4d_cross_attn_agg_sliced_fwd': (_i, [_vp, _c.c_int64, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
-    'gd4d_cross_attn_plan_agg_sync_bytes': (_c.c_size_t, [_i, _i]),
-    'gd4d_cross_attn_plan_agg_sliced_fwd': (_i, [_vp] * 6 + [_f, _f, _vp, _vp, _c.c_int64, _vp, _c.c_size_t, _vp, _vp, _vp, _vp, _c.c_int64,
-                                                   _vp, _vp, _c.c_size_t] + [_i] * 9 + [_vp, _vp]),
     'gd4d_pyramid_slice_planar_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_heads_fwd': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),
     'gd4d_value_proj_heads_bwd': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),

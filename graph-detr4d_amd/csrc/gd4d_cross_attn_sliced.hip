@@ -321,62 +321,6 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_sliced_kernel(con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Plan UNDER the gather: one launch for both.  The workgroups of an XCD are dispatched in index order and slice-major, so
-// the first per_xcd of them are slice 0 of every position the XCD owns: each of these first writes its position's plan
-// (cross_attn_plan_body: the plan kernel's code), publishes it (flag[pos] = 1, release at agent scope) and goes on with
-// slice 0; the workgroups of slices 1..7 of that position - later in the dispatch order, on the SAME XCD: one L2 - wait
-// for the flag (acquire) and gather.  No deadlock: a waiting workgroup was dispatched after its producer, which depends
-// on nothing.  The last of a position's 8 workgroups to finish clears flag and counter for the next launch.
-// Measured: no gain (1.733 against 1.730 ms per sample with the two launches): the plan phase occupies every CU for about as
-// long as the plan kernel does (it is bound by vector issue, not by launch width), so only a kernel boundary is saved and the
-// flag traffic added.  Kept behind GD4D_PLAN_FUSED=1; results are the two launches' bit for bit (tested).
-struct PlanAggSync {
-  int* flag;      // [BQ] 0 / 1, zero before the first launch
-  int* done;      // [BQ] slices finished
-  int* status;    // optional: set to 1 if a wait ran out (never in a correct run; tests check it)
-};
-
-template <int HH, int LT, typename VT, int OCC>
-__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_plan_agg_kernel(const PlanParams pp, const SlicedParams p, const PlanAggSync y) {
-  extern __shared__ __attribute__((aligned(16))) char s_raw[];
-  trace_mark(g_trace_sliced, 6ull);
-  int pos, sl;
-  if (!sliced_walk(p, blockIdx.x, pos, sl)) return;
-  // Producer and consumers of a position share ONE L2 (same XCD), so no cache is written back or invalidated: an
-  // agent-scope release / acquire pair here costs an L2 write-back per producer and an L2 invalidate per workgroup on this
-  // multi-XCD part (measured: the step 4.9 ms instead of 1.7).  What is needed: the producer's plan stores acknowledged by
-  // the L2 before the flag goes out (workgroup-scope release = s_waitcnt), the flag itself exchanged memory-side (relaxed
-  // agent-scope accesses bypass L1 and L2), and a consumer CU that has never read this position's plan in this launch (its
-  // L1 was invalidated when the kernel started and nobody touches a position's plan before its flag).
-  if (sl == 0) {
-    cross_attn_plan_body<HH, LT, HH>(pp, pos, s_raw);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(y.flag + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    if (threadIdx.x == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(y.flag + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 24)) { if (y.status) *y.status = 1; break; }
-      }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  cross_attn_agg_sliced_body<HH, LT, VT, 0>(p, pos, sl, s_raw);
-  __syncthreads();                                         // every wave of this workgroup is done with the plan
-  if (threadIdx.x == 0) {
-    const int old = atomicAdd(y.done + pos, 1);
-    if (old == p.slice_n - 1) {                            // the last slice of this position: reset for the next launch
-      __hip_atomic_store(y.done + pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(y.flag + pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  trace_mark(g_trace_sliced, 0x86ull);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // NCHW levels -> slice-planar copy (8, R, S, 32): the reference's flatten / transpose / cat (:264-276) with the channel
 // axis cut into 8 planes.  One workgroup = 32 pixels x 256 channels of one (camera row, level), turned through LDS; a
 // wave store instruction writes 8 consecutive pixels of one slice (1 KB contiguous; bf16: 512 B).
@@ -651,57 +595,6 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
     case 8: return bf16 ? launch_sliced<8, uint16_t>(p, L, s) : launch_sliced<8, float>(p, L, s);
     default: return bf16 ? launch_sliced<16, uint16_t>(p, L, s) : launch_sliced<16, float>(p, L, s);
   }
-}
-
-extern "C" size_t gd4d_cross_attn_plan_agg_sync_bytes(int B, int Q) {
-  if (B <= 0 || Q <= 0) return 0;
-  return (size_t)(2 * B * Q + 4) * sizeof(int);
-}
-
-extern "C" int gd4d_cross_attn_plan_agg_sliced_fwd(const float* ref, const float* offsets, const float* attn_logits,
-                                                   const float* cam_logits, const float* lidar2img, const double* pc_range,
-                                                   float img_h, float img_w, const int32_t* level_hw,
-                                                   const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,
-                                                   size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out,
-                                                   const void* const* level_ptrs, int64_t slice_stride_bytes, float* agg, void* sync,
-                                                   size_t sync_bytes, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                                                   int flags, const int32_t* query_order, void* stream) {
-  using namespace gd4d;
-  if (!sync || sync_bytes < gd4d_cross_attn_plan_agg_sync_bytes(B, Q)) return sync ? GD4D_EWORKSPACE : GD4D_EINVAL;
-  PlanParams pp{};
-  if (int rc = fill_plan_params(pp, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, level_hw, cam_stride_bytes,
-                                pix_stride_bytes, plan, plan_bytes, wsum, mask_out, uv_out, B, N, Q, Hh, L, P, flags, query_order))
-    return rc;
-  SlicedParams p{};
-  if (int rc = fill_sliced_params(p, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order, 0, kSlices))
-    return rc;
-  PlanAggSync y{static_cast<int*>(sync), static_cast<int*>(sync) + B * Q, static_cast<int*>(sync) + 2 * B * Q};
-  const size_t plan_lds = (size_t)N * Hh * kPoints * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
-                          (size_t)((B * Hh * L * kPoints + 3) & ~3) * sizeof(float) + (size_t)Hh * N * kPoints * sizeof(float4);
-  const size_t agg_lds = (size_t)Hh * 6 * 8 * 80;
-  if (plan_lds > agg_lds + 8192) return GD4D_EUNSUPPORTED;    // (many cameras / samples: the two launches keep their own occupancy)
-  const size_t lds = plan_lds > agg_lds ? plan_lds : agg_lds;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(8 * p.per_xcd * kSlices);
-  auto go = [&](auto kern, int hh) -> int {
-    if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * hh), lds, s, pp, p, y);
-    return check_launch();
-  };
-#define GD4D_PA_L(HH_, VT_, OCC_)                                                  \
-  switch (L) {                                                                     \
-    case 1: return go(cross_attn_plan_agg_kernel<HH_, 1, VT_, OCC_>, HH_);         \
-    case 2: return go(cross_attn_plan_agg_kernel<HH_, 2, VT_, OCC_>, HH_);         \
-    case 3: return go(cross_attn_plan_agg_kernel<HH_, 3, VT_, OCC_>, HH_);         \
-    default: return go(cross_attn_plan_agg_kernel<HH_, 4, VT_, OCC_>, HH_);        \
-  }
-  const bool bf16 = feats_dtype == GD4D_BF16;
-  switch (Hh) {
-    case 4: if (bf16) { GD4D_PA_L(4, uint16_t, 6) } else { GD4D_PA_L(4, float, 6) }
-    case 8: if (bf16) { GD4D_PA_L(8, uint16_t, 6) } else { GD4D_PA_L(8, float, 6) }
-    default: if (bf16) { GD4D_PA_L(16, uint16_t, 4) } else { GD4D_PA_L(16, float, 4) }
-  }
-#undef GD4D_PA_L
 }
 
 extern "C" int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C,

@@ -534,7 +534,6 @@ class LateValues:
         self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
         self.cl = self.pyramid = self.event = None
         self.waited = set()
-        self.fused_plan, self.sync = os.environ.get('GD4D_PLAN_FUSED', '0') == '1', None
         if all(ops.PyramidView.is_channels_last_level(v) for v in value) and len({v.dtype for v in value}) == 1 \
                 and value[0].dtype in (torch.float32, torch.bfloat16):
             self.mode, self.side = 'sliced', None
@@ -598,30 +597,12 @@ class LateValues:
         """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh); rows mode with vp_weight:
         (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
         if self.mode == 'sliced':
-            cur = torch.cuda.current_stream(ref.device).cuda_stream
-            fused = self.fused_plan and (self.event is None or cur in self.waited)   # (layer 0's plan runs underneath the copy: two launches)
-            if fused:
-                # GD4D_PLAN_FUSED=1 - plan UNDER the gather: one launch, the gather's own slice-0 workgroups write the plan.  Built,
-                # bit-identical, NOT the default: 1.733 against 1.730 ms per sample (the plan phase keeps every CU busy for as long
-                # as the plan kernel does; what it saves is one kernel boundary, what it adds is the flag traffic)
-                if self.sync is None:
-                    self.sync = ops.cross_attn_plan_agg_sync(ref.shape[0], ref.shape[1], ref.device)
-                try:
-                    plan, agg = ops.cross_attn_plan_agg_sliced_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(),
-                                                                   attn_logits.contiguous(), cam_logits.contiguous(), lidar2img,
-                                                                   module.pc_range, img_h, img_w, module.num_heads, self.sync,
-                                                                   query_order=order)
-                except _lib.Gd4dError as e:
-                    if 'code -2' not in str(e):          # GD4D_EUNSUPPORTED: the plan needs more LDS than the gather (many cameras)
-                        raise
-                    self.fused_plan = fused = False
-            if not fused:
-                # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
-                plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
-                                               cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
-                                               query_order=order)
-                self._wait_copy()
-                agg = ops.cross_attn_agg_sliced_fwd(plan)
+            # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
+            plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
+                                           cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
+                                           query_order=order)
+            self._wait_copy()
+            agg = ops.cross_attn_agg_sliced_fwd(plan)
             if vp_weight is not None:
                 return (ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, vp_bias),)
             return agg, plan.wsum

@@ -283,56 +283,6 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
     return res if len(res) > 1 else plan
 
 
-def cross_attn_plan_agg_sync(b, q, device):
-    """Zeroed synchronisation words for cross_attn_plan_agg_sliced_fwd (the kernel leaves them zero: reusable launch after
-    launch on one stream; the last int is a status word)."""
-    n = int(_lib.load().gd4d_cross_attn_plan_agg_sync_bytes(b, q)) // 4
-    return torch.zeros(n, device=device, dtype=torch.int32)
-
-
-def cross_attn_plan_agg_sliced_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, num_heads, sync,
-                                   want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, agg=None, query_order=None):
-    """gd4d_cross_attn_plan_agg_sliced_fwd: cross_attn_plan_fwd + cross_attn_agg_sliced_fwd as ONE launch (the plan is written
-    by the first workgroups of the gather itself).  Returns (Plan, agg (B, Q, Hh, 256) [, mask] [, uv])."""
-    lib = _lib.load()
-    b, q = ref.shape[0], ref.shape[1]
-    n = lidar2img.shape[1]
-    hh, p, nl = num_heads, offsets.shape[3], len(pyramid.level_hw)
-    if pyramid.rows != b * n:
-        raise ValueError(f'pyramid has {pyramid.rows} camera rows, expected B*N = {b * n}')
-    if offsets.numel() != b * q * hh * p * 3 or attn_logits.numel() != b * q * hh * nl * p or cam_logits.numel() != b * q * n:
-        raise ValueError('offsets / attn_logits / cam_logits have the wrong number of elements')
-    f32 = torch.float32
-    dev = ref.device
-    nbytes = cross_attn_plan_bytes(b, n, q, hh, p)
-    buf = torch.empty(nbytes, device=dev, dtype=torch.uint8) if plan is None else plan.buf
-    wsum = torch.empty(b, q, hh, device=dev, dtype=f32) if plan is None else plan.wsum
-    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum)
-    if agg is None:
-        agg = torch.empty(b, q, hh, 256, device=dev, dtype=f32)
-    mask = torch.empty(b, n, q, hh, p, device=dev, dtype=torch.uint8) if want_mask else None
-    uv = torch.empty(b, n, q, hh, p, 2, device=dev, dtype=f32) if want_uv else None
-    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
-    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in pyramid.level_hw for x in hw])
-    cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
-    ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
-    code = lib.gd4d_cross_attn_plan_agg_sliced_fwd(
-        _dev(ref, 'ref', f32), _dev(offsets, 'offsets', f32), _dev(attn_logits, 'attn_logits', f32),
-        _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w),
-        lv, cs, pyramid.pix_stride, _dev(buf, 'plan', torch.uint8), buf.numel(), _dev(wsum, 'wsum', f32),
-        _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None, ptrs, pyramid.slice_stride,
-        _dev(agg, 'agg', f32), _dev(sync, 'sync', torch.int32), sync.numel() * 4, b, n, q, hh, 256, nl, p,
-        _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16, 1 if raw_cam_weights else 0,
-        None if query_order is None else _order_ptr(query_order, b * q), _stream())
-    _lib.check(code, 'gd4d_cross_attn_plan_agg_sliced_fwd')
-    res = (plan, agg)
-    if want_mask:
-        res += (mask,)
-    if want_uv:
-        res += (uv,)
-    return res
-
-
 def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
     """gd4d_cross_attn_agg_sliced_fwd on the pyramid the Plan was made for.  Returns agg (B, Q, Hh, 256); with plan.wsum
     (B, Q, Hh) that is what cross_attn_agg_fwd returns (other summation order)."""

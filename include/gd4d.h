@@ -193,21 +193,6 @@ int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int64_t slice_
                                    const int32_t* query_order, int slice_lo, int slice_n, void* stream);
 int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C, int L,
                                   int in_dtype, int out_dtype, int max_cus, void* stream);
-/* gd4d_cross_attn_plan_agg_sliced_fwd - gd4d_cross_attn_plan_fwd and gd4d_cross_attn_agg_sliced_fwd (all 8 slices) as ONE
- * launch: the slice-0 workgroup of a query position writes that position's plan and publishes it; the workgroups of its other
- * slices - later in the dispatch order, on the same XCD - wait for it and gather.  Same arguments, same results bit for bit
- * (plan, wsum, mask_out, uv_out, agg).  sync: gd4d_cross_attn_plan_agg_sync_bytes(B, Q) bytes of device memory, ZERO before
- * the first launch that uses it (the kernel leaves it zero again; its last int is a status word: 1 if a wait ran out - never
- * in a correct run).  GD4D_EUNSUPPORTED when the plan needs much more LDS than the gather (many cameras / samples): use the
- * two launches. */
-size_t gd4d_cross_attn_plan_agg_sync_bytes(int B, int Q);
-int gd4d_cross_attn_plan_agg_sliced_fwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
-                                        const float* lidar2img, const double* pc_range, float img_h, float img_w,
-                                        const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
-                                        void* plan, size_t plan_bytes, float* wsum, uint8_t* mask_out, float* uv_out,
-                                        const void* const* level_ptrs, int64_t slice_stride_bytes, float* agg, void* sync,
-                                        size_t sync_bytes, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                                        int flags, const int32_t* query_order, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Training backward of the channel-sliced path (gd4d_cross_attn_sliced_bwd.hip): the pyramid side of a training step

@@ -288,35 +288,3 @@ def test_sliced_random_configurations_vs_plain_c_oracle(seed):
     assert np.array_equal(mask.cpu().numpy(), m_c) and np.array_equal(uv.cpu().numpy(), uv_c)
     out = ops.value_proj_heads_fwd(agg, wsum, w.to(dev), bias.to(dev))
     np.testing.assert_allclose(out.cpu().numpy(), o_c, rtol=RTOL, atol=ATOL)
-
-
-@pytest.mark.parametrize('heads,levels,n,q,b', [(8, 4, 6, 96, 1), (8, 4, 24, 900, 1), (4, 3, 6, 50, 1), (16, 2, 7, 33, 2), (8, 4, 12, 41, 3)])
-def test_plan_under_the_gather_is_the_two_launches_bit_for_bit(heads, levels, n, q, b):
-    """gd4d_cross_attn_plan_agg_sliced_fwd (the plan written by the gather's own first workgroups) against plan + gather as two
-    launches: plan buffer (the passes in use), wsum, mask, uv and aggregates identical; the sync words are left zero, launch
-    after launch."""
-    from graph_detr4d_amd import ops, synthetic
-    dev = 'cuda'
-    g = torch.Generator().manual_seed(50 + heads + n + q)
-    hw = synthetic.R50_LEVELS[:levels] if q == 900 else [(24, 40), (12, 20), (6, 10), (3, 5)][:levels]
-    feats = [torch.randn(b, n, 256, h, w, generator=g).to(dev) for h, w in hw]
-    l2i = torch.from_numpy(synthetic.camera_rig((n + 5) // 6)[:n]).unsqueeze(0).repeat(b, 1, 1, 1).to(dev)
-    ref = torch.rand(b, q, 3, generator=g).to(dev)
-    off = (torch.randn(b, q, heads, 4, 3, generator=g) * 1.5).to(dev)
-    attn = torch.randn(b, q, heads, levels, 4, generator=g).to(dev)
-    cam = torch.randn(b, q, n, generator=g).to(dev)
-    sp, shp = ops.pyramid_slice_planar_fwd(feats)
-    pyr = ops.PyramidView.slice_planar(sp, shp)
-    order = ops.query_order_fwd(ref, synthetic.PC_RANGE)
-    args = (ref, off, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, heads)
-    plan0, mask0, uv0 = ops.cross_attn_plan_fwd(pyr, *args, want_mask=True, want_uv=True, query_order=order)
-    agg0 = ops.cross_attn_agg_sliced_fwd(plan0)
-    sync = ops.cross_attn_plan_agg_sync(b, q, dev)
-    for _ in range(3):                                   # the same sync words, launch after launch
-        plan1, agg1, mask1, uv1 = ops.cross_attn_plan_agg_sliced_fwd(pyr, *args, sync, want_mask=True, want_uv=True, query_order=order)
-        torch.cuda.synchronize()
-        assert int(sync.abs().sum().item()) == 0, 'sync words not reset (or a wait ran out)'
-        assert torch.equal(agg1, agg0) and torch.equal(plan1.wsum, plan0.wsum)
-        assert torch.equal(mask1, mask0) and torch.equal(uv1, uv0)
-    hdr = lambda pl: pl.buf[:b * q * 16 * 4].view(torch.int32).view(b * q, 16)[:, :heads]      # noqa: E731  item counts per (position, head)
-    assert torch.equal(hdr(plan1), hdr(plan0))
