@@ -596,7 +596,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                                    f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
                        'baseline_config': 'configs[4]' if distill else ('configs[3]' if a.levels == 'vov' else 'configs[2] + backward'),
                        'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),
-                       'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse,
+                       'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse, 'input_layout': a.input_layout,
                        'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3,

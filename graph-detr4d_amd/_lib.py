@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 31
+ABI_VERSION = 32
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -46,7 +46,7 @@ SIGNATURES = {
     'gd4d_pyramid_grad_fill': (_i, [_vp, _vp, _vp, _vp, _c.c_uint32, _vp] + [_i] * 5 + [_vp]),
     'gd4d_pyramid_grad_chunk_geometry': (_i, [_vp, _i, _i, _vp]),
     'gd4d_pyramid_grad_sort': (_i, [_vp] * 5 + [_c.c_int64, _vp]),
-    'gd4d_pyramid_grad_reduce': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    'gd4d_pyramid_grad_reduce': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp]),
     'gd4d_query_order_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_refine_reference_order_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'gd4d_cross_attn_bwd': (_i, [_vp] * 8 + [_f, _f] + [_vp] * 6 + [_i] * 10 + [_vp, _vp, _c.c_size_t, _vp]),

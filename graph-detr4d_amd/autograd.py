@@ -91,7 +91,7 @@ class RawPyramid:
     def __init__(self):
         self.pyramid = self.shapes = None
         self.layers = self.pending = 0
-        self.needs_grad = False
+        self.needs_grad = self.channels_last = False
         self.main = self.side = None
         self.sink = self.grads = self._dpart = None
         self._forked = self._prepared = False
@@ -150,10 +150,11 @@ class RawPyramid:
             return
         self.begin_backward()
         py = self.pyramid
-        grads = [torch.empty(py.rows, 256, h, w, device=py.device, dtype=torch.float32) for h, w in py.level_hw]
+        grads = [torch.empty((py.rows, h, w, 256) if self.channels_last else (py.rows, 256, h, w), device=py.device, dtype=torch.float32)
+                 for h, w in py.level_hw]
         self._fork()                                 # the table rows were written on the main stream
         with torch.cuda.stream(self.side):
-            self.sink.reduce(grads)
+            grads = self.sink.reduce(grads, channels_last=self.channels_last)
         if self.side is not self.main:
             self.sink.table.record_stream(self.side)
         self.grads = grads
@@ -173,9 +174,14 @@ class PyramidSourceFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, *feats):
         from . import functional as Fn
-        src = [f.contiguous() for f in feats]
-        sp, hw = ops.pyramid_slice_planar_fwd(src)
-        raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
+        if all(ops.PyramidView.is_channels_last_level(f) for f in feats):
+            # levels stored (.., H, W, C): gathered in place, no copy; their gradient comes back in the same layout
+            raw.pyramid = ops.PyramidView.channels_last_levels(list(feats))
+            raw.channels_last = True
+            sp = feats[0]
+        else:
+            sp, hw = ops.pyramid_slice_planar_fwd([f.contiguous() for f in feats])
+            raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
         raw.shapes = [tuple(f.shape) for f in feats]
         raw.needs_grad = any(ctx.needs_input_grad[1:])
         raw.main = torch.cuda.current_stream(sp.device)
@@ -192,7 +198,7 @@ class PyramidSourceFunction(torch.autograd.Function):
         raw._reduce()                                # (already running unless a layer's output was never used)
         raw.join()
         grads, raw.grads, raw.sink, raw._dpart = raw.grads, None, None, None
-        return (None, *[g.view(shape) for g, shape in zip(grads, raw.shapes)])
+        return (None, *[g.unflatten(0, shape[:-3]) if len(shape) > 4 else g for g, shape in zip(grads, raw.shapes)])
 
 
 class CrossAttnRawFunction(torch.autograd.Function):

@@ -753,7 +753,7 @@ __device__ __forceinline__ void pg_issue(const float* __restrict__ table, const 
   }
 }
 
-template <int VARIANT>
+template <int VARIANT, bool NHWC>
 __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const PgReduceParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH]
   __shared__ int s_po[8][12];
@@ -788,6 +788,21 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const P
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // a finished pixel: one row of the LDS tile (NCHW output, turned below) or - channels-last output (R, H, W, C) - straight
+  // to memory: a pixel IS one contiguous 1-KB row there, no tile and no transpose
+  auto put = [&](int px, const float4 v) {
+    if (NHWC) {
+      const int yy = (cy << chs) + (px >> cws), xx = (cx << cws) + (px & ((1 << cws) - 1));
+      if (yy < H && xx < W)
+      {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w},
+                                    reinterpret_cast<f4v*>(p.out[l] + (((size_t)row * H + yy) * W + xx) * kChannels) + lane);
+      }
+    } else {
+      *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = v;
+    }
+  };
   // cursor over the wave's runs; pixels without records get their row of zeros on the way
   int cpx = px0 - 1, ci = 0, cb = 0;
   auto next = [&]() -> PgGroup {
@@ -796,7 +811,7 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const P
       if (cpx >= px0 + ppw) return PgGroup{0, 0, 0, 0};
       ci = __builtin_amdgcn_readfirstlane(s_po[wave][cpx - px0]);
       cb = __builtin_amdgcn_readfirstlane(s_po[wave][cpx - px0 + 1]);
-      if (ci >= cb) *reinterpret_cast<float4*>(&s_tp[cpx * PG_PITCH + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci >= cb) put(cpx, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     PgGroup g{ci, min(8, cb - ci), cpx, cb - ci <= 8};
     ci += 8;
@@ -826,7 +841,7 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const P
         acc.z = fmaf(w, v0[u].z, acc.z); acc.w = fmaf(w, v0[u].w, acc.w);
       }
       if (g0.last) {
-        *reinterpret_cast<float4*>(&s_tp[g0.px * PG_PITCH + lane * 4]) = acc;
+        put(g0.px, acc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (!g1.n) break;
@@ -835,6 +850,7 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const P
       for (int u = 0; u < 8; ++u) { r0[u] = r1[u]; r1[u] = r2[u]; v0[u] = v1[u]; }
     }
   }
+  if (NHWC) return;
   __syncthreads();
   // wave w writes channels 32 w .. 32 w + 31; lane = pixel of the chunk (runs of cw pixels)
   const int py = lane >> cws, pxx = lane & ((1 << cws) - 1);
@@ -1140,7 +1156,7 @@ extern "C" int gd4d_pyramid_grad_sort(const int32_t* count, const int32_t* start
 
 extern "C" int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxoff, const void* sorted, const float* table,
                                         void* const* grads, const int32_t* level_hw, const int32_t* chunk_order, int R, int C, int L,
-                                        void* stream) {
+                                        int channels_last, void* stream) {
   using namespace gd4d;
   if (!start || !pxoff || !sorted || !table || !grads || !level_hw || R <= 0 || L <= 0) return GD4D_EINVAL;
   if (C != kChannels || L > GD4D_MAX_LEVELS) return GD4D_EUNSUPPORTED;
@@ -1165,17 +1181,22 @@ extern "C" int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxo
     hipLaunchKernelGGL(kern, dim3(8 * per), dim3(PG_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return check_launch();
   };
+  if (channels_last) {
+    for (int l = 0; l < L; ++l)
+      if (!aligned16(grads[l])) return GD4D_EALIGN;
+    return go(pyramid_grad_reduce_kernel<0, true>);
+  }
 #ifdef GD4D_DEV                                      // dev ablations (GD4D_PG_VARIANT): 1 = 64 table rows, 2 = no table loads, 3 = nor the write-out, 4 = chunk lookup only
   {
     const char* e = getenv("GD4D_PG_VARIANT");
     switch (e ? atoi(e) : 0) {
-      case 1: return go(pyramid_grad_reduce_kernel<1>);
-      case 2: return go(pyramid_grad_reduce_kernel<2>);
-      case 3: return go(pyramid_grad_reduce_kernel<3>);
-      case 4: return go(pyramid_grad_reduce_kernel<4>);
+      case 1: return go(pyramid_grad_reduce_kernel<1, false>);
+      case 2: return go(pyramid_grad_reduce_kernel<2, false>);
+      case 3: return go(pyramid_grad_reduce_kernel<3, false>);
+      case 4: return go(pyramid_grad_reduce_kernel<4, false>);
       default: break;
     }
   }
 #endif
-  return go(pyramid_grad_reduce_kernel<0>);
+  return go(pyramid_grad_reduce_kernel<0, false>);
 }

@@ -528,30 +528,32 @@ class PyramidGrad:
         self.prepared = (start, pxoff, sorted_)
         self.plans = []
 
-    def reduce(self, grads=None):
+    def reduce(self, grads=None, channels_last=False):
         """-> L tensors (R, 256, H_l, W_l) fp32: the pyramid's gradient summed over the layers (prepare() first; the table
-        rows of every layer must have been written)."""
+        rows of every layer must have been written).  channels_last: the tensors are stored (R, H_l, W_l, 256) - the layout of
+        levels the gather read in place - and returned as (R, 256, H_l, W_l) views of that memory."""
         lib = _lib.load()
         py = self.pyramid
         nl = len(py.level_hw)
         i32 = torch.int32
         start, pxoff, sorted_ = self.prepared
         if grads is None:
-            grads = [torch.empty(py.rows, 256, h, w, device=py.device, dtype=torch.float32) for h, w in py.level_hw]
+            grads = [torch.empty((py.rows, h, w, 256) if channels_last else (py.rows, 256, h, w), device=py.device, dtype=torch.float32)
+                     for h, w in py.level_hw]
         for g in grads:
             _dev(g, 'grads', torch.float32)
         ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grads])
         code = lib.gd4d_pyramid_grad_reduce(_dev(start, 'start', i32), _dev(pxoff, 'pxoff', i32), _dev(sorted_, 'sorted'),
                                             _dev(self.table, 'table', torch.float32), ptrs, self._lv,
                                             None if self.order is None else _dev(self.order, 'chunk_order', i32), py.rows, 256, nl,
-                                            _stream())
+                                            1 if channels_last else 0, _stream())
         _lib.check(code, 'gd4d_pyramid_grad_reduce')
         self.prepared = None
-        return grads
+        return [g.permute(0, 3, 1, 2) for g in grads] if channels_last else grads
 
-    def finish(self, grads=None):
+    def finish(self, grads=None, channels_last=False):
         self.prepare()
-        return self.reduce(grads)
+        return self.reduce(grads, channels_last)
 
 
 def _order_ptr(order, count):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 31
+#define GD4D_ABI_VERSION 32
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -233,7 +233,8 @@ int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level
  *             (8 bytes per counted pair; id_base + B*Q*Hh <= 2^26)
  *     sort    every chunk's records grouped by pixel: sorted (same size and chunk offsets as records), pxoff (chunks, 65)
  *             int32 = where every pixel's run starts inside its chunk ([64] = the chunk's record count)
- *     reduce  grads[l] (R, C, H_l, W_l) fp32 = per pixel, sum over its run of weight * table[id, :]; table
+ *     reduce  grads[l] (R, C, H_l, W_l) fp32 - channels_last != 0: (R, H_l, W_l, C), the layout of levels the gather read in
+ *             place - = per pixel, sum over its run of weight * table[id, :]; table
  *             (rows, C) holds the grad_agg of every layer (row id as handed to fill).  The order of the additions follows
  *             the slot hand-out (like the atomicAdd scatter it replaces, sums may differ in the last bits between runs).
  *             chunk_order (or NULL): a permutation of the chunks - the order the workgroups walk them in, XCD x taking
@@ -271,7 +272,7 @@ int gd4d_pyramid_grad_sort(const int32_t* count, const int32_t* start, const voi
                            int64_t chunks, void* stream);
 int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxoff, const void* sorted, const float* table,
                              void* const* grads, const int32_t* level_hw, const int32_t* chunk_order, int R, int C, int L,
-                             void* stream);
+                             int channels_last, void* stream);
 
 /* gd4d_query_order_fwd - locality order of the queries for gd4d_cross_attn_fwd (no reference counterpart: the
  * reference's MSDA kernel processes queries in index order).  Counting sort by (sample, azimuth of the de-normalised

@@ -149,4 +149,4 @@ def test_training_entry_points_validate_before_any_gpu_work():
     assert lib.gd4d_pyramid_grad_scan(ptr, ptr, ptr, 0, 100000, null) == EWORKSPACE
     assert lib.gd4d_pyramid_grad_fill(ptr, ptr, ptr, ptr, (1 << 26) - 8, null, 1, 6, 4, 8, 4, null) == EUNSUPPORTED      # row ids need 26 bits
     assert lib.gd4d_pyramid_grad_sort(ptr, ptr, ptr, ptr, null, 10, null) == EINVAL
-    assert lib.gd4d_pyramid_grad_reduce(ptr, ptr, ptr, ptr, ptrs, lvp, null, 24, 128, 4, null) == EUNSUPPORTED
+    assert lib.gd4d_pyramid_grad_reduce(ptr, ptr, ptr, ptr, ptrs, lvp, null, 24, 128, 4, 0, null) == EUNSUPPORTED

@@ -54,6 +54,40 @@ def test_cross_attn_module_gradients(name):
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
 
 
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n24_b2'])
+def test_channels_last_levels_train_in_place(name):
+    """Levels stored (B, N, H, W, C) with autograd on: gathered in place forward (no copy of the pyramid), and their gradient
+    comes back from gd4d_pyramid_grad_reduce in the same layout - values equal to the NCHW run's."""
+    from graph_detr4d_amd import ops
+    g = Golden(name)
+    m = g.meta
+    mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=4,
+                                 embed_dims=256, depth_encode=m['depth_encode']), dict(batch_first=False))
+    mod.load_state_dict(g.state(), strict=True)
+    mod = mod.to(DEV).eval()
+    gout = torch.randn(g.t('out').shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run(feats):
+        for p_ in mod.parameters():
+            p_.grad = None
+        q, qp = g.t('query').to(DEV).requires_grad_(True), g.t('query_pos').to(DEV).requires_grad_(True)
+        out = mod(q, None, feats, None, query_pos=qp, reference_points=g.t('reference_points').to(DEV), img_metas=g.img_metas())
+        (out * gout).sum().backward()
+        return out.detach(), q.grad, {k: v.grad.clone() for k, v in mod.named_parameters()}
+    nchw = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    nhwc = [f.to(DEV).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3).requires_grad_(True) for f in g.feats()]
+    assert all(ops.PyramidView.is_channels_last_level(f) for f in nhwc)
+    o1, q1, p1 = run(nchw)
+    o2, q2, p2 = run(nhwc)
+    assert torch.equal(o1, o2)
+    assert _rel(q2, q1) < 1e-5
+    for k in p1:
+        assert _rel(p2[k], p1[k]) < 1e-5, k
+    for a, b in zip(nhwc, nchw):
+        assert a.grad.shape == b.grad.shape and ops.PyramidView.is_channels_last_level(a.grad)
+        assert _rel(a.grad, b.grad) < 1e-5
+
+
 def test_raw_pyramid_path_refuses_a_second_backward_through_one_graph():
     g = Golden('deform_n6')
     m = g.meta
