@@ -246,6 +246,59 @@ def test_weight_gradients_accumulated_by_the_kernels_equal_autograds():
     assert not any(hasattr(p, '_gd4d_main_grad') for p in params)
 
 
+def test_decoder_trains_with_kernel_accumulated_and_queued_gradients():
+    """Six SGD steps of the 2-layer decoder with every shortcut of the training step on (raw pyramid, weight gradients added to
+    the flat buffer by the kernels, queued and grouped; pyramid trained too): the loss goes down, and the parameters end where
+    plain autograd accumulation takes them."""
+    from graph_detr4d_amd import dist as D
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+
+    def build():
+        tr = G.build_transformer(dict(
+            type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+            decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                         transformerlayers=dict(
+                             type='DetrTransformerDecoderLayer',
+                             attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.0),
+                                        dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                             embed_dims=256, dropout=0.0)],
+                             feedforward_channels=512, ffn_dropout=0.0,
+                             operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+        tr.load_state_dict(g.state(), strict=True)
+        return tr.to(DEV).train()
+    qe = g.t('query_embed').to(DEV)
+    target = torch.randn(m['num_layers'], m['num_query'], 1, 256, generator=torch.Generator().manual_seed(11)).to(DEV)
+
+    def train(fuse):
+        tr = build()
+        feats = [f.to(DEV).clone().requires_grad_() for f in g.feats()]
+        params = [p for p in tr.parameters() if p.requires_grad]
+        red = D.FlatGradAllReducer(params)
+        red.bind(fuse_weight_grads=fuse)
+        opt = torch.optim.SGD(params + feats, lr=2e-2)
+        losses = []
+        for _ in range(6):
+            red.zero_grad()
+            for f in feats:
+                f.grad = None
+            states, _, _ = tr(feats, qe, reg_branches=None, img_metas=g.img_metas())
+            loss = ((states - target) ** 2).mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        if fuse:
+            red.unfuse()
+        return losses, torch.cat([p.detach().reshape(-1) for p in params]), torch.cat([f.detach().reshape(-1) for f in feats])
+    l1, p1, f1 = train(True)
+    l0, p0, f0 = train(False)
+    assert l1[-1] < l1[0] and all(torch.isfinite(torch.tensor(l1)))
+    assert abs(l1[-1] - l0[-1]) < 1e-4 * abs(l0[-1]) + 1e-7
+    assert ((p1 - p0).abs().max() / p0.abs().max()).item() < 1e-5
+    assert ((f1 - f0).abs().max() / f0.abs().max()).item() < 1e-5
+
+
 def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction(monkeypatch):
     """Decoder training, three routes to the same gradients: the raw-pyramid path (the default: plan + sliced gather forward,
     gd4d_cross_attn_sliced_bwd.hip backward, no projected value tensor), the projected-value path with value_proj's weight /
