@@ -92,6 +92,7 @@ class RawPyramid:
         self.pyramid = self.shapes = None
         self.layers = self.pending = 0
         self.needs_grad = self.channels_last = False
+        self.copy_dtype = torch.float32
         self.main = self.side = None
         self.sink = self.grads = self._dpart = None
         self._forked = self._prepared = False
@@ -180,7 +181,7 @@ class PyramidSourceFunction(torch.autograd.Function):
             raw.channels_last = True
             sp = feats[0]
         else:
-            sp, hw = ops.pyramid_slice_planar_fwd([f.contiguous() for f in feats])
+            sp, hw = ops.pyramid_slice_planar_fwd([f.contiguous() for f in feats], out_dtype=raw.copy_dtype)
             raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
         raw.shapes = [tuple(f.shape) for f in feats]
         raw.needs_grad = any(ctx.needs_input_grad[1:])

@@ -150,9 +150,9 @@ struct DotParams {
   int BQ, per_xcd, cap_t;
 };
 
-template <int HH, int LT, int OCC>
+template <int HH, int LT, typename VT, int OCC>
 __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(const DotParams p) {
-  constexpr int CH = 6, GP = 80, PASS = 8 * GP;
+  constexpr int CH = 6, GP = 80, PASS = 8 * GP, ES = sizeof(VT);
   extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(con
   const char* base[LT];
 #pragma unroll
   for (int l = 0; l < LT; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
-  const unsigned lane_off = (unsigned)(c * 16);
+  const unsigned lane_off = (unsigned)(c * 4 * ES);
   const float4 ga = *reinterpret_cast<const float4*>(p.gagg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4);
   const bool b4 = c & 4, b2 = c & 2, b1 = c & 1;
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(con
         if ((j & 3) >= LT) continue;
         if (j >= 4 && !second) continue;
         const unsigned o = ((j & 1) ? pr[j >> 1].z : pr[j >> 1].x) + lane_off;
-        val[j] = *reinterpret_cast<const float4*>(base[j & 3] + o);
+        val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(base[j & 3] + o));
       }
       __builtin_amdgcn_sched_barrier(0);
       float d[8];
@@ -951,14 +951,16 @@ extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t
   using namespace gd4d;
   if (!level_ptrs || !plan || !grad_agg || !dpart) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
-  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if (feats_dtype != GD4D_F32 && feats_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
-  if (!aligned16(grad_agg) || !aligned16(plan) || slice_stride_bytes % 16) return GD4D_EALIGN;
+  const int es = feats_dtype == GD4D_BF16 ? 2 : 4;
+  if (!aligned16(grad_agg) || !aligned16(plan) || slice_stride_bytes % (4 * es)) return GD4D_EALIGN;
   if (dpart_bytes < gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
   DotParams p{};
   for (int l = 0; l < L; ++l) {
     if (!level_ptrs[l]) return GD4D_EINVAL;
-    if (reinterpret_cast<uintptr_t>(level_ptrs[l]) % 16) return GD4D_EALIGN;
+    if (reinterpret_cast<uintptr_t>(level_ptrs[l]) % (4 * es)) return GD4D_EALIGN;
     p.lvl_base[l] = static_cast<const char*>(level_ptrs[l]);
   }
   for (int l = L; l < 4; ++l) p.lvl_base[l] = p.lvl_base[0];
@@ -977,17 +979,18 @@ extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t
     hipLaunchKernelGGL(kern, grid, dim3(64 * hh), lds, s, p);
     return check_launch();
   };
-#define GD4D_DOT_L(HH_, OCC_)                                                  \
-  switch (L) {                                                                 \
-    case 1: return go(cross_attn_dot_sliced_kernel<HH_, 1, OCC_>, HH_);        \
-    case 2: return go(cross_attn_dot_sliced_kernel<HH_, 2, OCC_>, HH_);        \
-    case 3: return go(cross_attn_dot_sliced_kernel<HH_, 3, OCC_>, HH_);        \
-    default: return go(cross_attn_dot_sliced_kernel<HH_, 4, OCC_>, HH_);       \
+#define GD4D_DOT_L(HH_, VT_, OCC_)                                                  \
+  switch (L) {                                                                      \
+    case 1: return go(cross_attn_dot_sliced_kernel<HH_, 1, VT_, OCC_>, HH_);        \
+    case 2: return go(cross_attn_dot_sliced_kernel<HH_, 2, VT_, OCC_>, HH_);        \
+    case 3: return go(cross_attn_dot_sliced_kernel<HH_, 3, VT_, OCC_>, HH_);        \
+    default: return go(cross_attn_dot_sliced_kernel<HH_, 4, VT_, OCC_>, HH_);       \
   }
+  const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {
-    case 4: GD4D_DOT_L(4, 6)
-    case 8: GD4D_DOT_L(8, 6)
-    default: GD4D_DOT_L(16, 4)
+    case 4: if (bf16) { GD4D_DOT_L(4, uint16_t, 6) } else { GD4D_DOT_L(4, float, 6) }
+    case 8: if (bf16) { GD4D_DOT_L(8, uint16_t, 6) } else { GD4D_DOT_L(8, float, 6) }
+    default: if (bf16) { GD4D_DOT_L(16, uint16_t, 4) } else { GD4D_DOT_L(16, float, 4) }
   }
 #undef GD4D_DOT_L
 }

@@ -358,10 +358,13 @@ def raw_pyramid_for_training(modules, value):
     levels, shapes outside the kernels' limits)."""
     if os.environ.get('GD4D_TRAIN_VALUES', 'raw') != 'raw' or not LateValues.applicable(modules, value, ignore_mode=True):
         return None
-    if any(v.dtype != torch.float32 for v in value) or any(m.value_dtype != torch.float32 for m in modules):
+    if any(v.dtype != torch.float32 for v in value):
         return None
     from .autograd import PyramidSourceFunction, RawPyramid
     raw = RawPyramid()
+    # modules built with value_dtype='bf16': the copy the gathers read is stored bf16 (half the bytes forward and backward; the
+    # features are ROUNDED, products and sums stay fp32, the gradient is that of the rounded features handed to the fp32 ones)
+    raw.copy_dtype = modules[0].value_dtype
     token = PyramidSourceFunction.apply(raw, *value)
     shapes = [tuple(v.shape[-2:]) for v in value]
     return {id(m): (None, shapes, value, (raw, token)) for m in modules}

@@ -371,15 +371,14 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None):
     b, q, hh = plan.b, plan.q, plan.num_heads
     n = pyramid.rows // b
     nl = len(pyramid.level_hw)
-    if pyramid.dtype != torch.float32:
-        raise NotImplementedError('the training backward reads fp32 pyramids')
     nbytes = int(lib.gd4d_cross_attn_dot_bytes(b, n, q, hh, 4))
     if dpart is None:
         dpart = torch.empty(nbytes, device=pyramid.device, dtype=torch.uint8)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
     code = lib.gd4d_cross_attn_dot_sliced(
         ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(grad_agg, 'grad_agg', torch.float32),
-        _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4, _lib.F32,
+        _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4,
+        _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
         None if plan.order is None else _order_ptr(plan.order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_dot_sliced')
     return dpart

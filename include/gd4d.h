@@ -210,7 +210,7 @@ int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level
  *   grad_bias).
  * gd4d_cross_attn_dot_sliced - D[pair] = <grad_agg[q, h], x_pair> for every pair of the plan, as 8 per-slice partials:
  *   dpart = (8, B*Q*Hh*cap_t*64) fp32, gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P) bytes; same pyramid addressing, plan and
- *   query_order as gd4d_cross_attn_agg_sliced_fwd.  fp32 pyramids only.
+ *   query_order as gd4d_cross_attn_agg_sliced_fwd (fp32 or bf16 pyramids; products and sums in fp32).
  * gd4d_cross_attn_plan_bwd - the query-side gradients: recomputes the plan kernel's geometry (same routine: item m here
  *   is item m of the plan), dL/d w_r = sum_slices D + beta for in-bounds corners, then the chain rule of the bilinear
  *   weights, the softmax over L*P, the camera sigmoid (GD4D_CA_RAW_CAM_WEIGHTS: none), u = cx / (cz W), v = cy / (cz H)

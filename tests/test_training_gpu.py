@@ -88,6 +88,32 @@ def test_channels_last_levels_train_in_place(name):
         assert _rel(a.grad, b.grad) < 1e-5
 
 
+def test_bf16_value_storage_trains_on_the_raw_pyramid():
+    """value_dtype='bf16' with autograd on: the copy the gathers read is stored bf16 (features rounded, products and sums fp32);
+    output and gradients stay within bf16 rounding of the fp32 module's."""
+    g = Golden('deform_n6')
+    m = g.meta
+    outs = {}
+    for vd in ('fp32', 'bf16'):
+        mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=4,
+                                     embed_dims=256, depth_encode=m['depth_encode'], value_dtype=vd), dict(batch_first=False))
+        mod.load_state_dict(g.state(), strict=True)
+        mod = mod.to(DEV).eval()
+        q = g.t('query').to(DEV).requires_grad_(True)
+        gen = torch.Generator().manual_seed(2)          # (the fixture's maps are bf16-representable: perturb them)
+        feats = [(f + 1e-3 * torch.randn(f.shape, generator=gen)).to(DEV).requires_grad_(True) for f in g.feats()]
+        out = mod(q, None, feats, None, query_pos=g.t('query_pos').to(DEV), reference_points=g.t('reference_points').to(DEV),
+                  img_metas=g.img_metas())
+        gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+        (out * gout).sum().backward()
+        outs[vd] = (out.detach(), q.grad, [f.grad for f in feats], mod.value_proj.weight.grad)
+    a, b = outs['bf16'], outs['fp32']
+    assert not torch.equal(a[0], b[0])                   # the bf16 copy really was used
+    assert _rel(a[0], b[0]) < 1e-2 and _rel(a[1], b[1]) < 2e-2 and _rel(a[3], b[3]) < 2e-2
+    for x, y in zip(a[2], b[2]):
+        assert _rel(x, y) < 2e-2
+
+
 def test_raw_pyramid_path_refuses_a_second_backward_through_one_graph():
     g = Golden('deform_n6')
     m = g.meta
