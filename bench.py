@@ -64,6 +64,7 @@ def parse():
                     help='--mode train/distill with several ranks: eager backward, every bucket\'s all-reduce starts from a '
                          'post-accumulate hook while the backward of the layers below is still running')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dropout', action='store_true', help='--mode train: modules in train() mode (dropout 0.1 as the reference trains); default: eval mode, autograd on')
     ap.add_argument('--no-fuse-wgrad', action='store_true', help='--mode train: leave the accumulation of parameter gradients to autograd')
     ap.add_argument('--no-roofline', action='store_true', help='dev: skip the kernel-level roofline section (roofline = null)')
     ap.add_argument('--no-stress', action='store_true',
@@ -407,7 +408,10 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     # (--overlap-comm) the weight-gradient kernels add into those views themselves (no accumulation launch per parameter)
     fuse = not (a.overlap_comm and world_size > 1) and not a.no_fuse_wgrad
     reducer.bind(fuse_weight_grads=fuse)
-    tr.eval()                                         # dropout off keeps the step deterministic; autograd stays on
+    if a.dropout:
+        tr.train()                                    # the reference's training mode: dropout 0.1 in the attentions and the FFN
+    else:
+        tr.eval()                                     # dropout off keeps the step deterministic; autograd stays on
 
     class DecoderAndHead(torch.nn.Module):
         """query_embed + pyramid -> (all_cls_scores, all_bbox_preds): the part of the step in front of the assignment."""
@@ -597,6 +601,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                        'baseline_config': 'configs[4]' if distill else ('configs[3]' if a.levels == 'vov' else 'configs[2] + backward'),
                        'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),
                        'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse, 'input_layout': a.input_layout,
+                       'dropout': 'on (train mode)' if a.dropout else 'off (modules in eval mode, autograd on)',
                        'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3,
