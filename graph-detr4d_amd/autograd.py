@@ -438,20 +438,23 @@ class LayerNormFunction(torch.autograd.Function):
 class MhaCoreFunction(torch.autograd.Function):
     """softmax(q k^T / sqrt(d) + mask) v per head (the middle of nn.MultiheadAttention): gd4d_mha_core_fwd, which also
     saves the row log-sum-exp, and gd4d_mha_core_bwd.  q, k, v: (L, B, C) row-strided (e.g. thirds of a packed
-    in-projection)."""
+    in-projection).  dropout_p: dropout of the probabilities (nn.MultiheadAttention in training); the mask is a function
+    of a seed drawn here (ops.mha_dropout_seed) that the backward passes to the kernels again - nothing else is stored."""
 
     @staticmethod
-    def forward(ctx, q, k, v, attn_mask, num_heads):
-        out, lse = ops.mha_core_fwd(q, k, v, num_heads, attn_mask, want_lse=True)
+    def forward(ctx, q, k, v, attn_mask, num_heads, dropout_p=0.):
+        seed = ops.mha_dropout_seed(q.device) if dropout_p > 0. else None
+        out, lse = ops.mha_core_fwd(q, k, v, num_heads, attn_mask, want_lse=True, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.mask, ctx.heads = attn_mask, num_heads
+        ctx.mask, ctx.heads, ctx.drop = attn_mask, num_heads, (dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = ops.mha_core_bwd(q, k, v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask)
-        return dq, dk, dv, None, None
+        dq, dk, dv = ops.mha_core_bwd(q, k, v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask,
+                                      dropout_p=ctx.drop[0], seed=ctx.drop[1])
+        return dq, dk, dv, None, None, None
 
 
 class MhaCorePackedFunction(torch.autograd.Function):
@@ -460,19 +463,22 @@ class MhaCorePackedFunction(torch.autograd.Function):
     fills, two copies and an add per layer otherwise)."""
 
     @staticmethod
-    def forward(ctx, qk, v, attn_mask, num_heads):
+    def forward(ctx, qk, v, attn_mask, num_heads, dropout_p=0.):
         c = qk.shape[-1] // 2
-        out, lse = ops.mha_core_fwd(qk[..., :c], qk[..., c:], v, num_heads, attn_mask, want_lse=True)
+        seed = ops.mha_dropout_seed(qk.device) if dropout_p > 0. else None
+        out, lse = ops.mha_core_fwd(qk[..., :c], qk[..., c:], v, num_heads, attn_mask, want_lse=True, dropout_p=dropout_p,
+                                    seed=seed)
         ctx.save_for_backward(qk, v, out, lse)
-        ctx.mask, ctx.heads = attn_mask, num_heads
+        ctx.mask, ctx.heads, ctx.drop = attn_mask, num_heads, (dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         qk, v, out, lse = ctx.saved_tensors
         c = qk.shape[-1] // 2
-        dqk, dv = ops.mha_core_bwd(qk[..., :c], qk[..., c:], v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask, packed_qk=True)
-        return dqk, dv, None, None
+        dqk, dv = ops.mha_core_bwd(qk[..., :c], qk[..., c:], v, out, grad_out.contiguous(), lse, ctx.heads, ctx.mask,
+                                   packed_qk=True, dropout_p=ctx.drop[0], seed=ctx.drop[1])
+        return dqk, dv, None, None, None
 
 
 class Detr3DSampleFunction(torch.autograd.Function):

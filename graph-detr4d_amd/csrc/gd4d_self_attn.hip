@@ -16,6 +16,7 @@
 // B-operand layout (k = g + 4s at step s) of the second product O^T = V^T P^T.  The probabilities
 // never move between lanes; the softmax reductions are 4 in-lane values + two xor-shuffles.
 #include "gd4d_common.h"
+#include "gd4d_mha_dropout.h"
 
 namespace gd4d {
 
@@ -28,6 +29,8 @@ struct MhaParams {
   float* lse;                                        // optional (Lq, B, heads): log sum exp of the scaled, masked scores
   int Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind;   // 0 none, 1 bool, 2 float
   float scale;
+  const uint32_t* seed;                              // dropout of the probabilities (training): two words, see mha_dropout.h
+  uint32_t drop_thresh; float inv_keep;
 };
 
 constexpr int MHA_D = 32;
@@ -42,6 +45,9 @@ constexpr int MHA_PF = MHA_PF_N;       // tiles of keys a wave requests ahead (o
 
 GD4D_TRACE_UNIT(mha)
 
+// DROP: each probability is kept with chance 1 - p and scaled by 1 / (1 - p) before it multiplies v, as F.dropout on the
+// softmax output inside nn.MultiheadAttention; the normaliser (and the saved log-sum-exp) are those of the full softmax.
+template <bool DROP>
 __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParams p) {
   trace_mark(g_trace_mha, 2ull);
   __shared__ float s_m[MHA_WAVES][16];
@@ -73,6 +79,11 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
 
   const int ntiles = (p.Lk + 15) / 16;
   const size_t hoff = (size_t)h * MHA_D;
+  uint32_t seed_lo = 0, seed_hi = 0, drop_row = 0;
+  if (DROP) {
+    seed_lo = p.seed[0]; seed_hi = p.seed[1];
+    drop_row = mha_drop_row(b, h, min(q0 + qi, p.Lq - 1), p.H, p.Lq, p.Lk);
+  }
   // A wave walks its tiles of keys in chunks of MHA_PF tiles whose K rows and V columns are requested together.  Measured
   // at 900 x 900 (ms per decoder step): MHA_PF = 1 (70 registers, three workgroups per compute unit) 1.759, 2 (96) 1.760,
   // 4 (128) 1.762, 8 (220 registers, one workgroup per unit) 1.827; one tile of look-ahead across iterations (the first
@@ -139,6 +150,11 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
       for (int r = 0; r < 4; ++r) pr[r] = expf(sc[r] - m_use);
       l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
       m = m_new;
+      if (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pr[r] = mha_drop_keep(seed_lo, seed_hi, drop_row + (uint32_t)(kbase + g + 4 * r), p.drop_thresh) ? pr[r] * p.inv_keep : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { o0[r] *= corr; o1[r] *= corr; }
       // ---- O^T += V^T P^T : A = V^T[d = lane&15 (+16)][key = kbase + g + 4s], B = P^T = pr[s] ----
@@ -185,14 +201,19 @@ extern "C" void gd4d_trace_set_mha(unsigned long long* p) { gd4d::trace_set_mha(
 
 extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask,
                                  float* out, int Lq, int Lk, int B, int H, int D, int ldq, int ldk,
-                                 int ldv, int ldo, int mask_kind, float scale, float* lse, void* stream) {
+                                 int ldv, int ldo, int mask_kind, float scale, float* lse, float drop_p, const void* seed,
+                                 void* stream) {
   using namespace gd4d;
   if (!q || !k || !v || !out || Lq <= 0 || Lk <= 0 || B <= 0 || H <= 0) return GD4D_EINVAL;
+  if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && !seed)) return GD4D_EINVAL;
+  if (drop_p > 0.f && (double)B * H * Lq * Lk >= 4294967296.0) return GD4D_EUNSUPPORTED;   // element ids are 32 bits
   if (D != MHA_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
   if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return GD4D_EINVAL;
   if (!aligned16(q) || !aligned16(k) || (ldq % 4) || (ldk % 4)) return GD4D_EALIGN;
-  MhaParams p{q, k, v, mask, out, lse, Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind, scale};
-  hipLaunchKernelGGL(mha_core_kernel, dim3((Lq + 15) / 16, H, B), dim3(64 * MHA_WAVES), 0,
-                     static_cast<hipStream_t>(stream), p);
+  MhaParams p{q, k, v, mask, out, lse, Lq, Lk, B, H, ldq, ldk, ldv, ldo, mask_kind, scale,
+              static_cast<const uint32_t*>(seed), mha_drop_thresh(drop_p), 1.f / (1.f - drop_p)};
+  const dim3 grid((Lq + 15) / 16, H, B), block(64 * MHA_WAVES);
+  if (drop_p > 0.f) hipLaunchKernelGGL(mha_core_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(mha_core_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), p);
   return check_launch();
 }

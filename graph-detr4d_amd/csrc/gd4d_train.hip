@@ -5,6 +5,7 @@
 // are hand-written so that a training step's kernel table is gd4d:: only (plus optimizer and collectives).
 // Everything fp32; reductions in a fixed order (run-to-run identical results).
 #include "gd4d_common.h"
+#include "gd4d_mha_dropout.h"
 
 namespace gd4d {
 
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_group_kernel(const L
 // Self-attention core backward.  Forward (gd4d_mha_core_fwd): P = softmax(scale q k^T + mask), o = P v, per head
 // (D = 32), with lse[q] = log sum_k exp(scale q k^T + mask) saved per (query, batch, head).  Given do:
 //   Dq = sum_d do[q][d] o[q][d];  dP = do v^T;  dS = P o (dP - Dq);  dq = scale dS k;  dk = scale dS^T q;  dv = P^T do.
+// With dropout of the probabilities (o = (P o M) v, M = keep / (1 - p), gd4d_mha_dropout.h): dv = (P o M)^T do and
+// dS = P o (M o dP - Dq); Dq = sum_k P M dP is still sum_d do o.  M is regenerated from the seed, not stored.
 // Two kernels with the forward's register layout (transposed score tiles on v_mfma_f32_16x16x4_f32: the C/D layout of
 // the score tile is the B-operand layout of the product that consumes it, so probabilities never move between lanes):
 //   dq kernel:    workgroup = 16 queries, waves split the key tiles; also writes Dq for the second kernel
@@ -194,6 +197,7 @@ struct MhaBwdParams {
   float* dq; float* dk; float* dv;
   int Lq, Lk, B, H, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, mask_kind;
   float scale;
+  const uint32_t* seed; uint32_t drop_thresh; float inv_keep;
 };
 
 constexpr int TB_D = 32, TB_WAVES = 4;
@@ -216,7 +220,7 @@ __device__ __forceinline__ void tb_load8(const float* src, float* dst, float mul
 
 // SIDE = 0: the workgroup owns 16 queries (columns of the transposed tiles), loops over key tiles (rows): dq.
 // SIDE = 1: the workgroup owns 16 keys (columns), loops over query tiles (rows): dk and dv.
-template <int SIDE>
+template <int SIDE, bool DROP>
 __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdParams p) {
   __shared__ float s_acc[TB_WAVES][2][TB_D][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,6 +255,9 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
     tb_load8(p.v + ((size_t)crow * p.B + b) * p.ldv + hoff + 8 * g, cd, 1.f);
   }
 
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (DROP) { seed_lo = p.seed[0]; seed_hi = p.seed[1]; }
+  const uint32_t drop_base = DROP ? mha_drop_row(b, h, 0, p.H, p.Lq, p.Lk) : 0u;
   t4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;   // SIDE 0: dq^T (a);  SIDE 1: dk^T (a), dv^T (b)
   const int ntiles = (Lr + 15) / 16;
   for (int rt = wave; rt < ntiles; rt += TB_WAVES) {
@@ -286,8 +293,13 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
         lse = p.lse[li]; dsum = p.dsum[li];
       }
       const float pv = dead ? 0.f : expf(val - lse);
-      pr[r] = pv;
-      ds[r] = pv * (dp[r] - dsum);
+      float mk = 1.f;
+      if (DROP) {
+        const uint32_t id = drop_base + (uint32_t)min(qi, p.Lq - 1) * (uint32_t)p.Lk + (uint32_t)min(ki, p.Lk - 1);
+        mk = mha_drop_keep(seed_lo, seed_hi, id, p.drop_thresh) ? p.inv_keep : 0.f;
+      }
+      pr[r] = pv * mk;
+      ds[r] = pv * (dp[r] * mk - dsum);
     }
     // products with the row side as reduction index: A = X^T[d = ci (+16)][row = rbase + g + 4 st], B = pr / ds
 #pragma unroll
@@ -361,10 +373,12 @@ extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float*
 extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                                  const void* mask, const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq,
                                  int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
-                                 int lddk, int lddv, int mask_kind, float scale, void* stream) {
+                                 int lddk, int lddv, int mask_kind, float scale, float drop_p, const void* seed, void* stream) {
   using namespace gd4d;
   if (!q || !k || !v || !o || !dout || !lse || !dsum || !dq || !dk || !dv || Lq <= 0 || Lk <= 0 || B <= 0 || H <= 0)
     return GD4D_EINVAL;
+  if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && !seed)) return GD4D_EINVAL;
+  if (drop_p > 0.f && (double)B * H * Lq * Lk >= 4294967296.0) return GD4D_EUNSUPPORTED;
   if (D != TB_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
   const int ld_min = H * D;
   if (ldq < ld_min || ldk < ld_min || ldv < ld_min || ldo < ld_min || lddo < ld_min || lddq < ld_min || lddk < ld_min ||
@@ -374,11 +388,14 @@ extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v,
       (ldv % 4) || (ldo % 4) || (lddo % 4))
     return GD4D_EALIGN;
   MhaBwdParams p{q, k, v, o, dout, mask, lse, dsum, dq, dk, dv, Lq, Lk, B, H, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
-                 mask_kind, scale};
+                 mask_kind, scale, static_cast<const uint32_t*>(seed), mha_drop_thresh(drop_p), 1.f / (1.f - drop_p)};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(mha_bwd_kernel<0>, dim3((Lq + 15) / 16, H, B), dim3(64 * TB_WAVES), 0, st, p);
+  const dim3 gq((Lq + 15) / 16, H, B), gk((Lk + 15) / 16, H, B), block(64 * TB_WAVES);
+  if (drop_p > 0.f) hipLaunchKernelGGL((mha_bwd_kernel<0, true>), gq, block, 0, st, p);
+  else hipLaunchKernelGGL((mha_bwd_kernel<0, false>), gq, block, 0, st, p);
   if (int rc = check_launch()) return rc;
-  hipLaunchKernelGGL(mha_bwd_kernel<1>, dim3((Lk + 15) / 16, H, B), dim3(64 * TB_WAVES), 0, st, p);
+  if (drop_p > 0.f) hipLaunchKernelGGL((mha_bwd_kernel<1, true>), gk, block, 0, st, p);
+  else hipLaunchKernelGGL((mha_bwd_kernel<1, false>), gk, block, 0, st, p);
   return check_launch();
 }
 

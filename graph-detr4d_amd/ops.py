@@ -904,27 +904,68 @@ def _mha_args(q, k, v, num_heads, attn_mask):
     return lq, lk, b, c, d, ld, kind, mptr, attn_mask
 
 
-def mha_core_fwd(q, k, v, num_heads, attn_mask=None, want_lse=False):
+def _mha_seed(dropout_p, seed, device):
+    if not dropout_p:
+        return None
+    if seed is None or seed.dtype != torch.int64 or seed.numel() < 1 or not seed.is_contiguous():
+        raise ValueError('dropout_p > 0 needs seed: a contiguous int64 device tensor (mha_dropout_seed)')
+    return _dev(seed, 'seed', torch.int64)
+
+
+def mha_dropout_seed(device):
+    """A fresh (1,) int64 device tensor holding the seed of the next dropout mask (its two 32-bit words are what
+    gd4d_mha_core_fwd / _bwd read), drawn ON THE DEVICE from torch's generator for that device: torch.manual_seed makes the
+    masks repeatable, and a captured launch draws a new seed on every replay (torch advances the generator's offset for
+    graphs, as it does for nn.Dropout in the same step)."""
+    return torch.randint(-2 ** 62, 2 ** 62, (1,), device=device, dtype=torch.int64)
+
+
+def mha_dropout_keep_mask(seed, b, num_heads, lq, lk, dropout_p):
+    """The (B, heads, Lq, Lk) bool keep mask gd4d_mha_core_fwd draws for this seed (csrc/gd4d_mha_dropout.h restated with
+    torch integer ops): what a check against torch's softmax / bmm needs.  Not used by the product path."""
+    m32 = 0xFFFFFFFF
+    s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+    lo, hi = s & m32, (s >> 32) & m32
+    ids = torch.arange(b * num_heads * lq * lk, dtype=torch.int64, device=seed.device)
+    x = ids ^ lo
+    x = (x * 0x9E3779B1) & m32
+    x = x ^ (x >> 16)
+    x = (x + hi) & m32
+    x = (x * 0x85EBCA6B) & m32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & m32
+    x = x ^ (x >> 16)
+    t = dropout_p * 4294967296.0
+    thresh = 0 if t <= 0 else (m32 if t >= 4294967295.0 else int(t + 0.5))
+    return (x >= thresh).view(b, num_heads, lq, lk)
+
+
+def mha_core_fwd(q, k, v, num_heads, attn_mask=None, want_lse=False, dropout_p=0., seed=None):
     """gd4d_mha_core_fwd.  q (Lq, B, C), k / v (Lk, B, C): each contiguous or a last-dim slice of a packed
     (L, B, 3C) in-projection buffer.  attn_mask: None, bool/uint8 (Lq, Lk) (nonzero = masked) or float
-    additive (Lq, Lk).  Returns (Lq, B, C) [, lse (Lq, B, heads) with want_lse - what mha_core_bwd needs]."""
+    additive (Lq, Lk).  Returns (Lq, B, C) [, lse (Lq, B, heads) with want_lse - what mha_core_bwd needs].
+    dropout_p, seed (mha_dropout_seed): dropout of the probabilities, as nn.MultiheadAttention in training."""
     lib = _lib.load()
     lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, attn_mask)
+    sptr = _mha_seed(dropout_p, seed, q.device)
     out = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
     lse = torch.empty(lq, b, num_heads, device=q.device, dtype=torch.float32) if want_lse else None
     code = lib.gd4d_mha_core_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()),
                                  ctypes.c_void_p(v.data_ptr()), mptr, _dev(out, 'out'), lq, lk, b,
                                  num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, kind,
-                                 1.0 / (d ** 0.5), None if lse is None else _dev(lse, 'lse'), _stream())
+                                 1.0 / (d ** 0.5), None if lse is None else _dev(lse, 'lse'), float(dropout_p), sptr,
+                                 _stream())
     _lib.check(code, 'gd4d_mha_core_fwd')
     return (out, lse) if want_lse else out
 
 
-def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_qk=False):
+def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_qk=False, dropout_p=0., seed=None):
     """gd4d_mha_core_bwd.  Returns (dq, dk, dv), each (L, B, C) contiguous; packed_qk (self-attention, q and k the two halves
-    of one (L, B, 2C) projection): (dqk (L, B, 2C), dv) - the kernel writes both halves of one buffer."""
+    of one (L, B, 2C) projection): (dqk (L, B, 2C), dv) - the kernel writes both halves of one buffer.  dropout_p / seed:
+    the forward's."""
     lib = _lib.load()
     lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, attn_mask)
+    sptr = _mha_seed(dropout_p, seed, q.device)
     f32 = torch.float32
     if packed_qk:
         if lq != lk:
@@ -941,7 +982,7 @@ def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_
     code = lib.gd4d_mha_core_bwd(vp(q), vp(k), vp(v), _dev(out, 'out', f32), _dev(grad_out, 'grad_out', f32),
                                  mptr, _dev(lse, 'lse', f32), _dev(dsum, 'dsum'), vp(dq), vp(dk),
                                  _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, ldd, ldd, c,
-                                 kind, 1.0 / (d ** 0.5), _stream())
+                                 kind, 1.0 / (d ** 0.5), float(dropout_p), sptr, _stream())
     _lib.check(code, 'gd4d_mha_core_bwd')
     return (dqk, dv) if packed_qk else (dq, dk, dv)
 

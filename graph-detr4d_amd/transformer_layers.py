@@ -10,6 +10,7 @@ the registry shim (and into real mmcv when it is importable).
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -126,14 +127,16 @@ class MultiheadAttention(nn.Module):
             qh = qh_lin = Fn.linear_autograd(q_in.contiguous(), w[:c], bias[:c], main=rows(0, c))
             kh = kh_lin = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c], main=rows(c, 2 * c))
         vh_lin = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:], main=rows(2 * c, 3 * c))
-        if not (self.training and self.attn_drop > 0.) and d == 32 and q_in.dtype == torch.float32 \
-                and (attn_mask is None or attn_mask.dim() == 2):
-            # the attention core with autograd on the HIP kernels (no attention-weight dropout to apply)
+        drop = float(self.attn_drop) if self.training else 0.
+        if d == 32 and q_in.dtype == torch.float32 and (attn_mask is None or attn_mask.dim() == 2) \
+                and b * h * lq * lk < 2 ** 32 and os.environ.get('GD4D_TRAIN_MHA', 'hip') == 'hip':
+            # the attention core with autograd on the HIP kernels; in train mode they drop probabilities as F.dropout does
+            # inside nn.MultiheadAttention (same distribution, a different generator: gd4d_mha_dropout.h)
             from .autograd import MhaCoreFunction, MhaCorePackedFunction
             if k_in is q_in:
-                o = MhaCorePackedFunction.apply(qk, vh_lin, attn_mask, h)
+                o = MhaCorePackedFunction.apply(qk, vh_lin, attn_mask, h, drop)
             else:
-                o = MhaCoreFunction.apply(qh_lin, kh_lin, vh_lin, attn_mask, h)
+                o = MhaCoreFunction.apply(qh_lin, kh_lin, vh_lin, attn_mask, h, drop)
             return Fn.linear_autograd(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
         qh = qh.reshape(lq, b * h, d).transpose(0, 1)
         kh = kh.reshape(lk, b * h, d).transpose(0, 1)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 32
+#define GD4D_ABI_VERSION 33
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -552,19 +552,28 @@ int gd4d_small_linear_layernorm_fwd(const float* in, const float* w, const float
  */
 int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask, float* out,
                       int Lq, int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo,
-                      int mask_kind, float scale, float* lse, void* stream);
+                      int mask_kind, float scale, float* lse, float drop_p, const void* seed, void* stream);
 /* lse: NULL, or (Lq, B, H) fp32 that receives log sum_k exp(scale q k^T + mask) per (query, batch, head) - what
  * gd4d_mha_core_bwd needs from the forward.
+ * drop_p in [0, 1), seed: dropout of the probabilities as nn.MultiheadAttention applies it in training (F.dropout on the
+ * softmax output: the reference's attn_drop = 0.1): with drop_p > 0 each probability is kept with chance 1 - drop_p and
+ * scaled by 1 / (1 - drop_p) before it multiplies v; lse stays that of the full softmax.  seed = two uint32 words in
+ * DEVICE memory, read by the kernel (so a captured launch draws a new mask when the words are advanced on the device);
+ * element (b, h, q, key) is kept iff mix(seed, ((b H + h) Lq + q) Lk + key) >= round(drop_p 2^32), mix as in
+ * csrc/gd4d_mha_dropout.h (two multiply / xor-shift rounds) - a function of (seed, element) only, so the backward
+ * regenerates it and no mask is stored.  B H Lq Lk must be < 2^32 with drop_p > 0.  drop_p == 0: seed is not read.
  *
  * gd4d_mha_core_bwd - backward of the above (what autograd derives for the bmm / softmax / bmm inside
  * nn.MultiheadAttention): given dout (gradient of out), dq = scale dS k, dk = scale dS^T q, dv = P^T dout with
  * P = exp(scale q k^T + mask - lse), dS = P o (dout v^T - Dq), Dq = sum_d dout o.  o = the forward's output, lse = its
  * saved statistic, dsum = (Lq, B, H) fp32 scratch (receives Dq).  dq / dk / dv: row strides lddq / lddk / lddv, head h
- * at column offset h*D.  Two launches (a workgroup per 16 queries, then per 16 keys), fixed summation order. */
+ * at column offset h*D.  Two launches (a workgroup per 16 queries, then per 16 keys), fixed summation order.
+ * drop_p / seed: the forward's (the seed words must hold what the forward read): with M = keep / (1 - drop_p),
+ * dv = (P o M)^T dout and dS = P o (M o dout v^T - Dq). */
 int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, const void* mask,
                       const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq, int Lk, int B, int H, int D,
                       int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, int mask_kind,
-                      float scale, void* stream);
+                      float scale, float drop_p, const void* seed, void* stream);
 
 /* gd4d_layernorm_bwd - backward of gd4d_layernorm_fwd (y = [ReLU] LN(x [+ res]) gamma + beta): dx (also the gradient of
  * res), dgamma, dbeta from dy; mean / rstd are recomputed from x.  beta is read only with relu != 0 (to rebuild the

@@ -107,8 +107,8 @@ def test_training_entry_points_validate_before_any_gpu_work():
     from graph_detr4d_amd import _lib
     lib = _lib.load()
     null = ctypes.c_void_p(0)
-    buf = (ctypes.c_float * 64)()
-    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    buf = (ctypes.c_float * 96)()
+    ptr = ctypes.c_void_p((ctypes.addressof(buf) + 63) & ~63)                  # 64-byte aligned: alignment checks pass
     EINVAL, EUNSUPPORTED, EWORKSPACE = -1, -2, -5
     b, n, q, hh = 1, 24, 900, 8
     cap_t = (n * 4 + 3) // 4
@@ -136,7 +136,7 @@ def test_training_entry_points_validate_before_any_gpu_work():
     assert lib.gd4d_value_proj_heads_bwd_weight(ptr, ptr, null, ptr, ptr, ptr, 1 << 30, 4, 8, 256, 0, null) == EINVAL   # bias without wsum
     ptrs = (ctypes.c_void_p * 4)(ptr.value, ptr.value, ptr.value, ptr.value)
     assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, ptr, ptr, ptr, 16, 1, 6, 4, 8, 256, 4, 4, _lib.F32, null, null) == EWORKSPACE
-    assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, ptr, ptr, ptr, 1 << 40, 1, 6, 4, 8, 256, 4, 4, _lib.BF16, null, null) == EUNSUPPORTED
+    assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, ptr, ptr, ptr, 1 << 40, 1, 6, 4, 8, 256, 4, 4, 7, null, null) == EUNSUPPORTED          # dtype
     assert lib.gd4d_cross_attn_dot_sliced(ptrs, 128, null, ptr, ptr, 1 << 40, 1, 6, 4, 8, 256, 4, 4, _lib.F32, null, null) == EINVAL
     rng = ctypes.cast((ctypes.c_double * 6)(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), ctypes.c_void_p)
     assert lib.gd4d_cross_attn_plan_bwd(ptr, ptr, ptr, ptr, ptr, rng, 900.0, 1600.0, lvp, ptr, null, null, ptr, ptr, ptr, ptr,
@@ -150,3 +150,10 @@ def test_training_entry_points_validate_before_any_gpu_work():
     assert lib.gd4d_pyramid_grad_fill(ptr, ptr, ptr, ptr, (1 << 26) - 8, null, 1, 6, 4, 8, 4, null) == EUNSUPPORTED      # row ids need 26 bits
     assert lib.gd4d_pyramid_grad_sort(ptr, ptr, ptr, ptr, null, 10, null) == EINVAL
     assert lib.gd4d_pyramid_grad_reduce(ptr, ptr, ptr, ptr, ptrs, lvp, null, 24, 128, 4, 0, null) == EUNSUPPORTED
+    # dropout of the self-attention probabilities: a rate without a seed, a rate outside [0, 1), more elements than ids
+    f = ctypes.c_float
+    assert lib.gd4d_mha_core_fwd(ptr, ptr, ptr, null, ptr, 16, 16, 1, 8, 32, 256, 256, 256, 256, 0, f(0.17), null, f(0.1), null, null) == EINVAL
+    assert lib.gd4d_mha_core_fwd(ptr, ptr, ptr, null, ptr, 16, 16, 1, 8, 32, 256, 256, 256, 256, 0, f(0.17), null, f(1.0), ptr, null) == EINVAL
+    assert lib.gd4d_mha_core_fwd(ptr, ptr, ptr, null, ptr, 30000, 30000, 1, 8, 32, 256, 256, 256, 256, 0, f(0.17), null, f(0.1), ptr, null) == EUNSUPPORTED
+    assert lib.gd4d_mha_core_bwd(ptr, ptr, ptr, ptr, ptr, null, ptr, ptr, ptr, ptr, ptr, 16, 16, 1, 8, 32, 256, 256, 256, 256, 256,
+                                 256, 256, 256, 0, f(0.17), f(0.1), null, null) == EINVAL

@@ -317,6 +317,105 @@ def test_mha_core_bwd_matches_fp64(l, b, mask):
     assert (dv.cpu().double() - gv).abs().max().item() < tol
 
 
+@pytest.mark.parametrize('l,b,mask,p', [(900, 1, None, 0.1), (50, 2, 'bool', 0.5), (77, 3, 'float', 0.1), (2700, 1, 'bool', 0.1),
+                                        (5, 1, None, 0.9)])
+def test_mha_core_dropout_matches_fp64_with_the_same_mask(l, b, mask, p):
+    """Dropout of the probabilities (nn.MultiheadAttention in training: F.dropout on the softmax output).  The kernels draw
+    the keep decision of element (b, h, q, key) from a seed; ops.mha_dropout_keep_mask restates the draw with torch integer
+    ops, and an fp64 softmax / dropout-by-that-mask / bmm gives the outputs and all three gradients to compare."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(l + 3)
+    h, d = 8, 32
+    qkv = torch.randn(l, b, 3 * h * d)
+    do = torch.randn(l, b, h * d)
+    am = None
+    if mask == 'bool':
+        kk = l // 3
+        am = torch.zeros(l, l, dtype=torch.bool)
+        am[kk:, :kk] = True
+        am[:kk, kk:] = True
+    elif mask == 'float':
+        am = torch.randn(l, l)
+    dev = qkv.cuda()
+    qv, kv, vv = dev.split(h * d, dim=-1)
+    amd = None if am is None else am.cuda()
+    seed = ops.mha_dropout_seed('cuda')
+    seed2 = ops.mha_dropout_seed('cuda')
+    assert seed.item() != seed2.item() and (seed.item() >> 32) != (seed2.item() >> 32)
+    out, lse = ops.mha_core_fwd(qv, kv, vv, h, amd, want_lse=True, dropout_p=p, seed=seed)
+    dq, dk, dv = ops.mha_core_bwd(qv, kv, vv, out, do.cuda(), lse, h, amd, dropout_p=p, seed=seed)
+    keep = ops.mha_dropout_keep_mask(seed, b, h, l, l, p).cpu()
+    frac = keep.double().mean().item()
+    assert abs(frac - (1 - p)) < 4 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-6, frac           # (4 sigma)
+    keep2 = ops.mha_dropout_keep_mask(seed2, b, h, l, l, p).cpu()
+    agree = (keep == keep2).double().mean().item()                 # independent draws agree with chance p^2 + (1-p)^2
+    assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.01 + 5 / math.sqrt(keep.numel())
+    ref = qkv.double().requires_grad_(True)
+    q, k, v = (t.reshape(l, b * h, d).transpose(0, 1) for t in ref.split(h * d, dim=-1))
+    sc = torch.bmm(q / math.sqrt(d), k.transpose(1, 2))
+    if am is not None:
+        sc = sc.masked_fill(am, float('-inf')) if am.dtype == torch.bool else sc + am.double()
+    pm = sc.softmax(-1) * keep.view(b * h, l, l).double() / (1 - p)
+    o = torch.bmm(pm, v).transpose(0, 1).reshape(l, b, h * d)
+    scale = 1 / (1 - p)
+    assert (out.cpu().double() - o).abs().max().item() < 2e-5 * scale
+    assert (lse.cpu().double() - sc.logsumexp(-1).view(b, h, l).permute(2, 0, 1)).abs().max().item() < 1e-4
+    o.backward(do.double())
+    gq, gk, gv = ref.grad.split(h * d, dim=-1)
+    tol = 1e-4 * max(1.0, math.sqrt(l) / 10) * scale
+    assert (dq.cpu().double() - gq).abs().max().item() < tol
+    assert (dk.cpu().double() - gk).abs().max().item() < tol
+    assert (dv.cpu().double() - gv).abs().max().item() < tol
+    # a rate of zero is the plain kernel, bit for bit
+    out0 = ops.mha_core_fwd(qv, kv, vv, h, amd)
+    out00 = ops.mha_core_fwd(qv, kv, vv, h, amd, dropout_p=0., seed=seed)
+    assert torch.equal(out0, out00)
+
+
+def test_multihead_attention_train_mode_runs_the_hip_core_with_dropout(monkeypatch):
+    """In train mode (attn_drop = 0.1, the reference's setting) the module keeps the core on the HIP kernels: the seed
+    counter follows torch.manual_seed (same seed, same output and gradients), consecutive calls draw different masks, and
+    the mean over many draws approaches the output without dropout (F.dropout's scaling)."""
+    from graph_detr4d_amd import ops
+    from graph_detr4d_amd.transformer_layers import MultiheadAttention
+    calls = []
+    real = ops.mha_core_fwd
+    monkeypatch.setattr(ops, 'mha_core_fwd', lambda *a, **k: (calls.append(k.get('dropout_p')), real(*a, **k))[1])
+    torch.manual_seed(5)
+    mod = MultiheadAttention(256, 8, attn_drop=0.1, proj_drop=0.0).cuda()
+    mod.train()
+    q = torch.randn(300, 2, 256, device='cuda', requires_grad=True)
+    pos = torch.randn(300, 2, 256, device='cuda')
+
+    def run():
+        q.grad = None
+        mod.zero_grad()
+        out = mod(q, query_pos=pos)
+        out.square().sum().backward()
+        return out.detach().clone(), q.grad.clone(), mod.attn.in_proj_weight.grad.clone()
+
+    torch.manual_seed(11)
+    a = run()
+    b2 = run()
+    torch.manual_seed(11)
+    c = run()
+    assert calls and all(abs(x - 0.1) < 1e-9 for x in calls)
+    assert all(torch.equal(x, y) for x, y in zip(a, c))
+    assert not torch.equal(a[0], b2[0])
+    mod.eval()
+    with torch.no_grad():
+        want = mod(q.detach(), query_pos=pos)
+    mod.train()
+    acc = torch.zeros_like(want)
+    n = 200
+    with torch.enable_grad():
+        for _ in range(n):
+            acc += mod(q, query_pos=pos).detach()
+    err = (acc / n - want).abs().max().item()
+    one = (a[0] - want).abs().max().item()
+    assert err < 0.25 * one, (err, one)                           # averaging 200 draws shrinks the deviation ~ 14 x
+
+
 def test_multihead_attention_module_gradients_on_hip_kernels():
     """MultiheadAttention with autograd on: in-proj / core / out-proj all on gd4d kernels, against nn.MultiheadAttention."""
     from graph_detr4d_amd.transformer_layers import MultiheadAttention
