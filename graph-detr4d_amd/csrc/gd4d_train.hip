@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(4))) float t4;
 //   g = dy * gamma (dy masked by y > 0 with ReLU), xhat = (x - mean) * rstd,
 //   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),   dgamma = sum_rows dy * xhat,   dbeta = sum_rows dy.
 // mean / rstd are recomputed from x (two-pass, as the forward), nothing is saved by the forward.
-// Kernel 1: one workgroup = 16 rows (4 waves x 4 rows), C <= 1024; writes dx and the workgroup's partial dgamma / dbeta.
+// Kernel 1: one workgroup = 16 rows (16 waves x 1 row for C <= 256, else 4 waves x 4 rows), C <= 1024; writes dx and the workgroup's partial dgamma / dbeta.
 // Kernel 2: adds the partials in workgroup order.
 struct LnBwdParams {
   const float* x; const float* res; const float* gamma; const float* beta; const float* dy;
@@ -31,30 +31,35 @@ __device__ __forceinline__ float t_wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p) {
-  __shared__ float s_part[4][2][1024];
+// VPL = float4s of a row per lane (C <= 256 VPL), WAVES x RPW = 16 rows.  C <= 256 runs one row per wave (16 waves): the four
+// dependent wave reductions of a row (mean, variance, the two sums of the gradient) are a latency chain of ~2 us behind a
+// cold load, and a wave that walks four rows pays it four times (10.7 us per launch in the step, 30 launches).
+template <int VPL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void layernorm_bwd_kernel(const LnBwdParams p) {
+  constexpr int RPW = 16 / WAVES;
+  __shared__ float s_part[WAVES][2][256 * VPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = p.C / 4;
-  float4 ag[4], ab[4];                                   // this wave's partial dgamma / dbeta for the lane's channels
+  float4 ag[VPL], ab[VPL];                                   // this wave's partial dgamma / dbeta for the lane's channels
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
-  float4 gm[4], bt[4];
+  for (int i = 0; i < VPL; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+  float4 gm[VPL], bt[VPL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < VPL; ++i) {
     const int c = min(lane + 64 * i, nv - 1);
     gm[i] = reinterpret_cast<const float4*>(p.gamma)[c];
     bt[i] = p.relu ? reinterpret_cast<const float4*>(p.beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = blockIdx.x * 16 + wave * 4 + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = blockIdx.x * 16 + wave * RPW + rr;
     if (row >= p.M) break;                               // wave-uniform
     const float4* x = reinterpret_cast<const float4*>(p.x + (size_t)row * p.C);
     const float4* r = p.res ? reinterpret_cast<const float4*>(p.res + (size_t)row * p.C) : nullptr;
     const float4* dy = reinterpret_cast<const float4*>(p.dy + (size_t)row * p.C);
-    float4 v[4], d[4];
+    float4 v[VPL], d[VPL];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f); d[i] = v[i];
       if (c < nv) {
@@ -67,16 +72,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p)
     const float mean = t_wave_sum(s) / (float)p.C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < VPL; ++i)
       if (lane + 64 * i < nv) {
         const float a = v[i].x - mean, b = v[i].y - mean, c2 = v[i].z - mean, e = v[i].w - mean;
         q += (a * a + b * b) + (c2 * c2 + e * e);
       }
     const float rstd = 1.0f / sqrtf(t_wave_sum(q) / (float)p.C + p.eps);
     float s1 = 0.f, s2 = 0.f;
-    float4 xh[4], g[4];
+    float4 xh[VPL], g[VPL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < VPL; ++i) {
       xh[i] = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
       if (p.relu) {                                      // the forward clamped y at 0: those outputs pass no gradient
         if (xh[i].x * gm[i].x + bt[i].x <= 0.f) d[i].x = 0.f;
@@ -95,21 +100,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdParams p)
     const float m1 = t_wave_sum(s1) / (float)p.C, m2 = t_wave_sum(s2) / (float)p.C;
     float4* dx = reinterpret_cast<float4*>(p.dx + (size_t)row * p.C);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < VPL; ++i)
       if (lane + 64 * i < nv)
         dx[lane + 64 * i] = make_float4(rstd * (g[i].x - m1 - xh[i].x * m2), rstd * (g[i].y - m1 - xh[i].y * m2),
                                         rstd * (g[i].z - m1 - xh[i].z * m2), rstd * (g[i].w - m1 - xh[i].w * m2));
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < VPL; ++i)
     if (lane + 64 * i < nv) {
       reinterpret_cast<float4*>(s_part[wave][0])[lane + 64 * i] = ag[i];
       reinterpret_cast<float4*>(s_part[wave][1])[lane + 64 * i] = ab[i];
     }
   __syncthreads();
-  for (int e = threadIdx.x; e < 2 * p.C; e += 256) {
+  for (int e = threadIdx.x; e < 2 * p.C; e += 64 * WAVES) {
     const int k = e / p.C, c = e - k * p.C;
-    p.part[((size_t)blockIdx.x * 2 + k) * p.C + c] = (s_part[0][k][c] + s_part[1][k][c]) + (s_part[2][k][c] + s_part[3][k][c]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; w += 4) t += (s_part[w][k][c] + s_part[w + 1][k][c]) + (s_part[w + 2][k][c] + s_part[w + 3][k][c]);
+    p.part[((size_t)blockIdx.x * 2 + k) * p.C + c] = t;
   }
 }
 
@@ -200,7 +208,10 @@ struct MhaBwdParams {
   const uint32_t* seed; uint32_t drop_thresh; float inv_keep;
 };
 
-constexpr int TB_D = 32, TB_WAVES = 4;
+#ifndef TB_WAVES_N
+#define TB_WAVES_N 8
+#endif
+constexpr int TB_D = 32, TB_WAVES = TB_WAVES_N;
 
 // A 16 x 16 score-like tile, transposed: T^T[row][col] = sum_d R[row][d] C[col][d], rows permuted so that lane
 // (col = lane & 15, g = lane >> 4) register r holds row g + 4 r.  rowv = the row operand's 8 values of this lane (row
@@ -260,20 +271,51 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
   const uint32_t drop_base = DROP ? mha_drop_row(b, h, 0, p.H, p.Lq, p.Lk) : 0u;
   t4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;   // SIDE 0: dq^T (a);  SIDE 1: dk^T (a), dv^T (b)
   const int ntiles = (Lr + 15) / 16;
-  for (int rt = wave; rt < ntiles; rt += TB_WAVES) {
+  // Everything a tile reads from memory, requested one tile ahead of its use (a wave has ~2 neighbours on its SIMD: without
+  // the look-ahead every tile pays a full round trip to the L2).  Both kernels at 900 x 900 x 8 heads, back to back from a
+  // graph (tools/bench_train_small.py): 75.5 us without look-ahead (4 waves), 60.9 / 62.6 / 81.3 us with it and 4 / 8 / 16
+  // waves per workgroup; with the H-DETR bool mask 100.5 -> 82.9 / 79.1 / 98.6 us.  2.9 GFLOP (S and dP are formed in both
+  // kernels): 47 TFLOP/s of fp32 MFMA, the forward kernel's rate (0.83 GFLOP in 21 us).
+  struct Tile {
+    float rk[8], rv[8];          // SIDE 0: k, v rows;  SIDE 1: scaled q, do rows (row rho of the tile, dims 8 g ..)
+    float x0[4], x1[4];          // SIDE 0: k^T[d = ci (+16)][row g + 4 st];  SIDE 1: q^T
+    float y0[4], y1[4];          // SIDE 1: do^T
+    float lse[4], dsum[4];       // SIDE 1: statistics of query row g + 4 r
+  };
+  auto load_tile = [&](int rt, Tile& t) {
     const int rbase = rt * 16;
     const int rrow = min(rbase + rho, Lr - 1);
-    float rk[8], rv[8];                                  // SIDE 0: k, v rows;  SIDE 1: scaled q, do rows
     if (SIDE == 0) {
-      tb_load8(p.k + ((size_t)rrow * p.B + b) * p.ldk + hoff + 8 * g, rk, 1.f);
-      tb_load8(p.v + ((size_t)rrow * p.B + b) * p.ldv + hoff + 8 * g, rv, 1.f);
+      tb_load8(p.k + ((size_t)rrow * p.B + b) * p.ldk + hoff + 8 * g, t.rk, 1.f);
+      tb_load8(p.v + ((size_t)rrow * p.B + b) * p.ldv + hoff + 8 * g, t.rv, 1.f);
     } else {                                             // (scale q in the score; the plain q below for dk)
-      tb_load8(p.q + ((size_t)rrow * p.B + b) * p.ldq + hoff + 8 * g, rk, p.scale);
-      tb_load8(p.dout + ((size_t)rrow * p.B + b) * p.lddo + hoff + 8 * g, rv, 1.f);
+      tb_load8(p.q + ((size_t)rrow * p.B + b) * p.ldq + hoff + 8 * g, t.rk, p.scale);
+      tb_load8(p.dout + ((size_t)rrow * p.B + b) * p.lddo + hoff + 8 * g, t.rv, 1.f);
     }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int xr = min(rbase + g + 4 * st, Lr - 1);    // rows past the end carry pr = ds = 0
+      if (SIDE == 0) {
+        const float* ks = p.k + ((size_t)xr * p.B + b) * p.ldk + hoff + ci;
+        t.x0[st] = ks[0]; t.x1[st] = ks[16];
+      } else {
+        const float* qs = p.q + ((size_t)xr * p.B + b) * p.ldq + hoff + ci;
+        const float* os = p.dout + ((size_t)xr * p.B + b) * p.lddo + hoff + ci;
+        t.x0[st] = qs[0]; t.x1[st] = qs[16]; t.y0[st] = os[0]; t.y1[st] = os[16];
+        const size_t li = ((size_t)xr * p.B + b) * p.H + h;
+        t.lse[st] = p.lse[li]; t.dsum[st] = p.dsum[li];
+      }
+    }
+  };
+  Tile cur;
+  if (wave < ntiles) load_tile(wave, cur);
+  for (int rt = wave; rt < ntiles; rt += TB_WAVES) {
+    const int rbase = rt * 16;
+    Tile nxt;
+    load_tile(min(rt + TB_WAVES, ntiles - 1), nxt);
     // S^T and dP^T tiles: lane (col ci, g) register r <-> row rbase + g + 4 r
-    const t4 s = SIDE == 0 ? tb_tile(rk, cq) : tb_tile(rk, cq);
-    const t4 dp = SIDE == 0 ? tb_tile(rv, cd) : tb_tile(rv, cd);
+    const t4 s = tb_tile(cur.rk, cq);
+    const t4 dp = tb_tile(cur.rv, cd);
     float pr[4], ds[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -286,12 +328,7 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
         if (p.mask_kind == 1) dead = static_cast<const uint8_t*>(p.mask)[mi] != 0;
         else val += static_cast<const float*>(p.mask)[mi];
       }
-      float lse, dsum;
-      if (SIDE == 0) { lse = c_lse; dsum = c_dsum; }
-      else {
-        const size_t li = ((size_t)min(rowi, p.Lq - 1) * p.B + b) * p.H + h;
-        lse = p.lse[li]; dsum = p.dsum[li];
-      }
+      const float lse = SIDE == 0 ? c_lse : cur.lse[r], dsum = SIDE == 0 ? c_dsum : cur.dsum[r];
       const float pv = dead ? 0.f : expf(val - lse);
       float mk = 1.f;
       if (DROP) {
@@ -304,20 +341,14 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
     // products with the row side as reduction index: A = X^T[d = ci (+16)][row = rbase + g + 4 st], B = pr / ds
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const int xr = min(rbase + g + 4 * st, Lr - 1);    // rows past the end carry pr = ds = 0
-      if (SIDE == 0) {                                   // dq^T += K^T dS^T
-        const float* ks = p.k + ((size_t)xr * p.B + b) * p.ldk + hoff + ci;
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[0], ds[st], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[16], ds[st], a1, 0, 0, 0);
-      } else {                                           // dk^T += Q^T dS,  dv^T += dO^T P
-        const float* qs = p.q + ((size_t)xr * p.B + b) * p.ldq + hoff + ci;
-        const float* os = p.dout + ((size_t)xr * p.B + b) * p.lddo + hoff + ci;
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[0], ds[st], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[16], ds[st], a1, 0, 0, 0);
-        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(os[0], pr[st], b0, 0, 0, 0);
-        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(os[16], pr[st], b1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x0[st], ds[st], a0, 0, 0, 0);   // dq^T += K^T dS^T  |  dk^T += Q^T dS
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x1[st], ds[st], a1, 0, 0, 0);
+      if (SIDE == 1) {                                                              // dv^T += dO^T P
+        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.y0[st], pr[st], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.y1[st], pr[st], b1, 0, 0, 0);
       }
     }
+    cur = nxt;
   }
   // merge the waves (fixed order); accumulators: d = 4 g + r (a0 / b0), 16 + 4 g + r (a1 / b1), column ci
 #pragma unroll
@@ -362,7 +393,8 @@ extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float*
   LnBwdParams p{x, res, gamma, beta, dy, dx, static_cast<float*>(workspace), M, C, relu ? 1 : 0, eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int parts = (M + 15) / 16;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, p);
+  if (C <= 256) hipLaunchKernelGGL((layernorm_bwd_kernel<1, 16>), dim3(parts), dim3(1024), 0, st, p);
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<4, 4>), dim3(parts), dim3(256), 0, st, p);
   if (int rc = check_launch()) return rc;
   if (flags & GD4D_LN_DEFER_REDUCE) return GD4D_OK;       // the caller reduces the partials later (gd4d_layernorm_bwd_reduce_group)
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, p.part, dgamma, dbeta, parts, C,
