@@ -48,8 +48,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // it loads one float4 (e = 0..3) per 16-k step j, and the four groups of a row read 64 contiguous
 // bytes - 16 cache lines per load instruction instead of 64 with a row-per-lane layout (the L1 tag
 // rate, not the MFMA, bounds these tiny GEMMs).
-__global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParams p) {
-  __shared__ float s_part[LN_WAVES - 1][16][64];
+// RES: the launch has residual operands.  Without them the sixteen prefetch registers are not allocated: 143 -> under 128
+// registers, four workgroups per CU instead of three - a 900 x 1024 output (928 workgroups) then runs in one round.
+// WAVES: how many waves split K (64 columns of it at a time each).  4 for K <= 512 (one round trip per wave up to K = 256);
+// LN_DEEP_WAVES for the deep contractions of the FFN (K = 1024: four dependent round trips per wave with 4 waves).
+template <bool RES, int WAVES>
+__device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_part)[16][64]) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -119,9 +123,9 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
   // Epilogue operands (bias, residuals) are requested NOW by the wave that will need them, so their
   // memory latency overlaps the K loop instead of following the reduction.
   float pre_bias[2] = {0.f, 0.f};
-  float pre_res[2][2][4];
+  float pre_res[RES ? 2 : 1][2][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < (RES ? 2 : 1); ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
       if (n < N) {
         if (Bv) pre_bias[c] = Bv[n];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < (RES ? 2 : 0); ++a)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * a + 4 * g + r;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
     }
   }
 
-  for (int kc = wave * LN_KC; kc < p.K; kc += LN_KC * LN_WAVES) {
+  for (int kc = wave * LN_KC; kc < p.K; kc += LN_KC * WAVES) {
     f32x4 av[4][2], bv[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                 // all 16 (+8) loads of the chunk in flight together
@@ -197,16 +201,49 @@ __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParam
         for (int r = 0; r < 4; ++r) {
           float v = acc[a][c][r];
 #pragma unroll
-          for (int w = 0; w < LN_WAVES - 1; ++w) v += s_part[w][(a * 2 + c) * 4 + r][lane];
+          for (int w = 0; w < WAVES - 1; ++w) v += s_part[w][(a * 2 + c) * 4 + r][lane];
           const int m = m0 + 16 * a + 4 * g + r;
           if (m < p.M && n < N) {
             v += pre_bias[c];
             if (p.flags & 1) v = fmaxf(v, 0.f);
-            v += pre_res[a][c][r];
+            if (RES) v += pre_res[a][c][r];
             Y[(size_t)m * ldy + n] = v;
           }
         }
       }
+  }
+}
+
+__global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel_res(const LinearParams p) {
+  __shared__ float s_part[LN_WAVES - 1][16][64];
+  linear_body<true, LN_WAVES>(p, s_part);
+}
+
+__global__ __launch_bounds__(64 * LN_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void linear_kernel(const LinearParams p) {
+  __shared__ float s_part[LN_WAVES - 1][16][64];
+  linear_body<false, LN_WAVES>(p, s_part);
+}
+
+#ifndef LN_DEEP_WAVES_N
+#define LN_DEEP_WAVES_N 16
+#endif
+constexpr int LN_DEEP_WAVES = LN_DEEP_WAVES_N, LN_DEEP_K = 768;
+
+template <bool RES>
+__global__ __launch_bounds__(64 * LN_DEEP_WAVES) void linear_kernel_deep(const LinearParams p) {
+  __shared__ float s_part[LN_DEEP_WAVES - 1][16][64];
+  linear_body<RES, LN_DEEP_WAVES>(p, s_part);
+}
+
+static void launch_linear(const LinearParams& p, dim3 grid, hipStream_t st) {
+  const bool res = p.r1 || p.r2;
+  if (p.K >= LN_DEEP_K) {
+    if (res) hipLaunchKernelGGL(linear_kernel_deep<true>, grid, dim3(64 * LN_DEEP_WAVES), 0, st, p);
+    else hipLaunchKernelGGL(linear_kernel_deep<false>, grid, dim3(64 * LN_DEEP_WAVES), 0, st, p);
+  } else if (res) {
+    hipLaunchKernelGGL(linear_kernel_res, grid, dim3(64 * LN_WAVES), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LN_WAVES), 0, st, p);
   }
 }
 
@@ -339,7 +376,7 @@ extern "C" int gd4d_linear_fwd(const float* x, const float* x2, const float* w, 
   p.M = M; p.K = K; p.N = N; p.n_split = x2 ? n_split : 0; p.flags = flags;
   p.ldx = ldx; p.ldy = ldy; p.ldr1 = ldr1; p.ldr2 = ldr2;
   const dim3 grid((M + LN_TM - 1) / LN_TM, (N + LN_TN - 1) / LN_TN);
-  hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LN_WAVES), 0, static_cast<hipStream_t>(stream), p);
+  launch_linear(p, grid, static_cast<hipStream_t>(stream));
   return check_launch();
 }
 
@@ -361,7 +398,7 @@ extern "C" int gd4d_linear_group_fwd(const float* x, const float* x2, const floa
     tiles += (n_out[g] + LN_TN - 1) / LN_TN;
   }
   const dim3 grid((M + LN_TM - 1) / LN_TM, tiles);
-  hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LN_WAVES), 0, static_cast<hipStream_t>(stream), p);
+  launch_linear(p, grid, static_cast<hipStream_t>(stream));
   return check_launch();
 }
 

@@ -47,6 +47,15 @@ def main():
         f = graph_time(lambda: ops.mha_core_fwd(q, k, v, h, m, want_lse=True, dropout_p=p, seed=seed if p else None), 50)
         t = graph_time(lambda: ops.mha_core_bwd(q, k, v, out, do, lse, h, m, dropout_p=p, seed=seed if p else None), 50)
         print(f'mha core 900 x 900, {name}: forward {f:6.1f} us, backward (two kernels) {t:6.1f} us')
+    for (k_, n_) in [(256, 512), (256, 256), (256, 1024), (1024, 256), (256, 128), (256, 96), (256, 24), (3, 256), (256, 10)]:
+        xx = torch.randn(l, k_, device=dev)
+        ww = torch.randn(n_, k_, device=dev)
+        bb = torch.randn(n_, device=dev)
+        gy = torch.randn(l, n_, device=dev)
+        f = graph_time(lambda: ops.linear_fwd(xx, ww, bb), 50)
+        t = graph_time(lambda: ops.linear_fwd(gy, ww, weight_kn=True), 50)
+        w_ = graph_time(lambda: ops.linear_bwd_weight(xx, gy, want_bias=True), 50)
+        print(f'linear 900 x {k_} -> {n_}: forward {f:5.1f} us, input gradient {t:5.1f} us, weight gradient {w_:5.1f} us')
     x = torch.randn(l, c, device=dev)
     g_, b_ = torch.randn(c, device=dev), torch.randn(c, device=dev)
     dy = torch.randn(l, c, device=dev)
