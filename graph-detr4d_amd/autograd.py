@@ -386,19 +386,26 @@ class LinearFunction(torch.autograd.Function):
     a single compute unit)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, main_w=None, main_b=None):
+    def forward(ctx, x, weight, bias, main_w=None, main_b=None, relu=False):
         """main_w / main_b: where the weight / bias gradient is to be ADDED by the backward kernel itself (views of a flat
-        gradient buffer, dist.FlatGradAllReducer.bind(fuse_weight_grads=True)); autograd then gets None for them."""
+        gradient buffer, dist.FlatGradAllReducer.bind(fuse_weight_grads=True)); autograd then gets None for them.
+        relu: y = max(x W^T + b, 0) in the kernel's epilogue (the Linear + ReLU pairs of the FFN and the branches: an
+        nn.ReLU(inplace=True) applied to a view of this node's output makes autograd rebuild the base - a clone, two
+        copies and a strided copy in the backward pass per pair)."""
         x, weight = x.contiguous(), weight.contiguous()
-        ctx.save_for_backward(x, weight)                  # x: (M, K), see functional.linear_autograd
+        y = ops.linear_fwd(x, weight, None if bias is None else bias.contiguous(), relu=relu)
+        ctx.save_for_backward(x, weight, *((y,) if relu else ()))     # x: (M, K), see functional.linear_autograd
         ctx.has_bias = bias is not None
+        ctx.relu = relu
         ctx.main = (main_w, main_b) if main_w is not None else None
-        return ops.linear_fwd(x, weight, None if bias is None else bias.contiguous())
+        return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         grad_y = grad_y.contiguous()
+        if ctx.relu:
+            grad_y = torch.ops.aten.threshold_backward(grad_y, ctx.saved_tensors[2], 0.0)
         gx = ops.linear_fwd(grad_y, weight, weight_kn=True) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -406,33 +413,41 @@ class LinearFunction(torch.autograd.Function):
                 _queue_weight_grad(x, grad_y, ctx.main[0], ctx.main[1] if ctx.has_bias else None)
             else:
                 gw, gb = ops.linear_bwd_weight(x, grad_y, want_bias=ctx.has_bias)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class LayerNormFunction(torch.autograd.Function):
-    """[ReLU] LayerNorm(x) over the last dimension: gd4d_layernorm_fwd / gd4d_layernorm_bwd (the decoder layer's norms,
-    position_encoder's LayerNorm + ReLU pairs, deform3d_cross_attn.py:104-111)."""
+    """[ReLU] LayerNorm(x [+ res]) over the last dimension: gd4d_layernorm_fwd / gd4d_layernorm_bwd (the decoder layer's
+    norms - with the residual sum that precedes them read by the kernel instead of a separate add -, position_encoder's
+    LayerNorm + ReLU pairs, deform3d_cross_attn.py:104-111).  The gradient of res is the gradient of x (one tensor)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, main_g=None, main_b=None):
+    def forward(ctx, x, gamma, beta, eps, relu, main_g=None, main_b=None, res=None):
         x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
-        ctx.save_for_backward(x, gamma, beta)
+        if res is not None:
+            if res.shape != x.shape:
+                raise ValueError('res must have the shape of x')
+            res = res.contiguous()
+        ctx.save_for_backward(x, gamma, beta, *(() if res is None else (res,)))
         ctx.eps, ctx.relu = eps, relu
         ctx.main = (main_g, main_b) if main_g is not None and main_b is not None else None
-        return ops.layernorm_fwd(x, gamma, beta, eps, relu=relu)
+        return ops.layernorm_fwd(x, gamma, beta, eps, res=res, relu=relu)
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, gamma, beta = ctx.saved_tensors
+        x, gamma, beta = ctx.saved_tensors[:3]
+        res = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        grad_y = grad_y.contiguous()
+        dg = db = None
         if ctx.main is not None:                          # dgamma / dbeta added to the flat gradient buffer by the kernels
             if _deferring():                              # ... the column reduce queued with the weight gradients
-                dx, ws, mc = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu, defer=True)
+                dx, ws, mc = ops.layernorm_bwd(x, gamma, beta, grad_y, ctx.eps, res=res, relu=ctx.relu, defer=True)
                 _queue_deferred(_LN_QUEUE, (ws, mc, ctx.main[0], ctx.main[1]), _LN_GROUP)
             else:
-                dx, _, _ = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu, into=ctx.main)
-            return dx, None, None, None, None, None, None
-        dx, dg, db = ops.layernorm_bwd(x, gamma, beta, grad_y.contiguous(), ctx.eps, relu=ctx.relu)
-        return dx, dg, db, None, None, None, None
+                dx, _, _ = ops.layernorm_bwd(x, gamma, beta, grad_y, ctx.eps, res=res, relu=ctx.relu, into=ctx.main)
+        else:
+            dx, dg, db = ops.layernorm_bwd(x, gamma, beta, grad_y, ctx.eps, res=res, relu=ctx.relu)
+        return dx, dg, db, None, None, None, None, (dx if res is not None and ctx.needs_input_grad[7] else None)
 
 
 class MhaCoreFunction(torch.autograd.Function):

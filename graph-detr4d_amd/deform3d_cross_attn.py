@@ -97,7 +97,7 @@ class Deform3DCrossAttn(nn.Module):
             cached = (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).get(id(self))
             hit = cached is not None and cached[2] is value
             return self._forward_autograd(query, value, query_pos, reference_points, img_metas, cached[0] if hit else None,
-                                          cached[3] if hit and len(cached) > 3 else None)
+                                          cached[3] if hit and len(cached) > 3 else None, offers=kwargs)
 
         inp_residual = query
         q_len, b, c = query.shape
@@ -198,7 +198,7 @@ class Deform3DCrossAttn(nn.Module):
             ref3d = torch.cat([ref3d, depth], dim=-1)
         return Fn.position_encoder(self.position_encoder, ref3d)
 
-    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas, projected=None, cl=None):
+    def _forward_autograd(self, query, value, query_pos, reference_points, img_metas, projected=None, cl=None, offers=None):
         """Training path: the same maths with autograd.  The gather runs gd4d_cross_attn_fwd/_bwd, value_proj
         runs the HIP forward with a GEMM backward, the small dense layers are torch ops."""
         from .autograd import CrossAttnFunction, ValueProjFunction
@@ -225,7 +225,7 @@ class Deform3DCrossAttn(nn.Module):
                                              self.value_proj.weight, self.value_proj.bias, cl[0], self.pc_range, img_h, img_w)
             if own is not None:
                 cl[0].join()                     # (the decoder joins its layers' side-stream work itself, after the last one)
-            return self._finish_autograd(agg, reference_points, inp_residual)
+            return self._finish_autograd(agg, reference_points, inp_residual, offers)
         if projected is None:
             val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)
             val = val.view(val.shape[0], -1, hh, c // hh)
@@ -237,9 +237,9 @@ class Deform3DCrossAttn(nn.Module):
         else:
             agg = CrossAttnFunction.apply(val, reference_points, offsets, attn_logits, cam_logits, lidar2img,
                                           shapes, self.pc_range, img_h, img_w)
-        return self._finish_autograd(agg, reference_points, inp_residual)
+        return self._finish_autograd(agg, reference_points, inp_residual, offers)
 
-    def _finish_autograd(self, agg, reference_points, inp_residual):
+    def _finish_autograd(self, agg, reference_points, inp_residual, offers=None):
         out = Fn.sequential_autograd(self.output_proj, agg).permute(1, 0, 2)
         ref3d = reference_points
         if self.depth_encode:
@@ -249,4 +249,8 @@ class Deform3DCrossAttn(nn.Module):
         isig = ops.inverse_sigmoid_fwd(ref3d.contiguous()) if ref3d.is_cuda and ref3d.dtype == torch.float32 \
             and not ref3d.requires_grad else Fn.inverse_sigmoid(ref3d)
         pos_feat = Fn.sequential_autograd(self.position_encoder, isig).permute(1, 0, 2)
+        fused = Fn.take_fused_norm(offers or {}, autograd=True)
+        if fused is not None:        # the layer's LayerNorm comes next: its kernel adds inp_residual (:336's first sum)
+            fused['done'] = True
+            return Fn.layer_norm_autograd(inp_residual, fused['norm'], res=self.dropout(out) + pos_feat)
         return self.dropout(out) + inp_residual + pos_feat

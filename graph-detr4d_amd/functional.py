@@ -33,8 +33,8 @@ def main_grad(t, rows=None):
     return m[rows[0]:rows[1]]
 
 
-def linear_autograd(x, weight, bias=None, main=None):
-    """F.linear with autograd (training path); on the GPU in fp32 the weight gradient runs on gd4d_linear_bwd_weight.
+def linear_autograd(x, weight, bias=None, main=None, relu=False):
+    """F.linear [+ ReLU] with autograd (training path); on the GPU in fp32 the weight gradient runs on gd4d_linear_bwd_weight.
     main = (weight gradient buffer, bias gradient buffer): see main_grad(); default: the parameters' own."""
     if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
         from .autograd import LinearFunction
@@ -43,29 +43,41 @@ def linear_autograd(x, weight, bias=None, main=None):
         if main[0] is None or (bias is not None and main[1] is None) or not torch.is_grad_enabled():
             main = (None, None)
         # 2-D inside the Function: its output must not be a view (in-place ReLUs follow in the nn.Sequential stacks)
-        y = LinearFunction.apply(x.reshape(-1, x.shape[-1]), weight, bias, main[0], main[1])
+        y = LinearFunction.apply(x.reshape(-1, x.shape[-1]), weight, bias, main[0], main[1], relu)
         return y.view(*x.shape[:-1], weight.shape[0])
-    return torch.nn.functional.linear(x, weight, bias)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if relu else y
 
 
-def layer_norm_autograd(x, norm, relu=False):
-    """nn.LayerNorm `norm` [+ ReLU] with autograd on the HIP kernels (gd4d_layernorm_fwd / _bwd); anything they do not
-    cover (CPU, other dtypes, no affine parameters, > 1024 channels) goes to the module."""
+def layer_norm_autograd(x, norm, relu=False, res=None):
+    """nn.LayerNorm `norm` of x [+ res] [+ ReLU] with autograd on the HIP kernels (gd4d_layernorm_fwd / _bwd); anything
+    they do not cover (CPU, other dtypes, no affine parameters, > 1024 channels) goes to the module."""
     c = x.shape[-1]
     if x.is_cuda and x.dtype == torch.float32 and norm.weight is not None and norm.bias is not None \
-            and tuple(norm.normalized_shape) == (c,) and c % 4 == 0 and c <= 1024:
+            and tuple(norm.normalized_shape) == (c,) and c % 4 == 0 and c <= 1024 \
+            and (res is None or (res.shape == x.shape and res.dtype == x.dtype)):
         from .autograd import LayerNormFunction
         mg, mb = main_grad(norm.weight), main_grad(norm.bias)
         if mg is None or mb is None:
             mg = mb = None
-        return LayerNormFunction.apply(x, norm.weight, norm.bias, norm.eps, relu, mg, mb)
-    y = norm(x)
+        return LayerNormFunction.apply(x, norm.weight, norm.bias, norm.eps, relu, mg, mb, res)
+    y = norm(x if res is None else x + res)
     return torch.relu(y) if relu else y
 
 
+def residual_norm_autograd(kwargs, identity, out):
+    """identity + out, or - when the layer offered the LayerNorm that follows (take_fused_norm) - that LayerNorm of the sum
+    with the sum formed inside the kernel (training path: one launch instead of two, no stored sum)."""
+    fused = take_fused_norm(kwargs, autograd=True)
+    if fused is not None and out.is_cuda and out.shape == identity.shape:
+        fused['done'] = True
+        return layer_norm_autograd(identity, fused['norm'], res=out)
+    return identity + out
+
+
 def sequential_autograd(module, x):
-    """Run an nn.Sequential / nn.Linear / nn.LayerNorm / any module with autograd: nn.Linear layers through
-    linear_autograd, nn.LayerNorm (with the ReLU that follows it, if any) through layer_norm_autograd."""
+    """Run an nn.Sequential / nn.Linear / nn.LayerNorm / any module with autograd: nn.Linear layers (with the ReLU that
+    follows, if any) through linear_autograd, nn.LayerNorm (with its ReLU, if any) through layer_norm_autograd."""
     if isinstance(module, torch.nn.Linear):
         return linear_autograd(x, module.weight, module.bias)
     if isinstance(module, torch.nn.LayerNorm):
@@ -77,6 +89,10 @@ def sequential_autograd(module, x):
             m = mods[i]
             if isinstance(m, torch.nn.LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU):
                 x = layer_norm_autograd(x, m, relu=True)
+                i += 2
+                continue
+            if isinstance(m, torch.nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU):
+                x = linear_autograd(x, m.weight, m.bias, relu=True)       # (the pre-activation has no other reader)
                 i += 2
                 continue
             x = sequential_autograd(m, x)
@@ -211,11 +227,14 @@ def linear_norm(x, weight, bias, norm, r1=None, r2=None, relu_after=False):
     return layer_norm(linear(x, weight, bias, **kw), norm, relu=relu_after)
 
 
-def take_fused_norm(kwargs):
+def take_fused_norm(kwargs, autograd=False):
     """The LayerNorm that follows this module in the layer's operation_order, if the layer offers to have it fused
-    (BaseTransformerLayer passes {'norm': module, 'done': False} under NORM_KEY); the taker sets done."""
+    (BaseTransformerLayer passes {'norm': module, 'done': False} under NORM_KEY); the taker sets done.  An offer is for
+    the forward-only kernels or (key 'autograd') for the training path - never both."""
     holder = kwargs.get(NORM_KEY)
-    return holder if holder is not None and not holder['done'] else None
+    if holder is None or holder['done'] or bool(holder.get('autograd')) != autograd:
+        return None
+    return holder
 
 
 def position_encoder(seq, ref):

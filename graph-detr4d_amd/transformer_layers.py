@@ -83,7 +83,8 @@ class MultiheadAttention(nn.Module):
             self._attention(q_in, k_in, value, attn_mask)
         if self.batch_first:
             out = out.transpose(0, 1)
-        return identity + self.dropout_layer(self.proj_drop(out))
+        out = self.dropout_layer(self.proj_drop(out))
+        return Fn.residual_norm_autograd(kwargs, identity, out) if grad else identity + out
 
     def _packed_self_attention(self, query, query_pos, attn_mask, identity, fused=None):
         """The decoder's case (q = k = query + query_pos, v = query): one in-projection GEMM with the
@@ -187,7 +188,7 @@ class FFN(nn.Module):
             return self.dropout_layer(out)
         if identity is None:
             identity = x
-        return identity + self.dropout_layer(out)
+        return Fn.residual_norm_autograd(kwargs, identity, self.dropout_layer(out)) if x.is_cuda else identity + self.dropout_layer(out)
 
 
 @TRANSFORMER_LAYER.register_module()
@@ -250,9 +251,12 @@ class BaseTransformerLayer(nn.Module):
         for oi, op in enumerate(order):
             # a LayerNorm right after an attention / FFN can run in that module's last GEMM (Fn.linear_norm)
             holder = None
-            if op != 'norm' and oi + 1 < len(order) and order[oi + 1] == 'norm' and query.is_cuda \
-                    and not self.training and not Fn.wants_grad(self.norms[norm_i], query):
-                holder = {'norm': self.norms[norm_i], 'done': False}
+            if op != 'norm' and oi + 1 < len(order) and order[oi + 1] == 'norm' and query.is_cuda:
+                if not self.training and not Fn.wants_grad(self.norms[norm_i], query):
+                    holder = {'norm': self.norms[norm_i], 'done': False}
+                elif not self.pre_norm:
+                    # training path: the module may hand its residual sum to the LayerNorm kernel (Fn.residual_norm_autograd)
+                    holder = {'norm': self.norms[norm_i], 'done': False, 'autograd': True}
             fuse = {Fn.NORM_KEY: holder} if holder is not None else {}
             if op == 'self_attn':
                 query = self.attentions[attn_i](

@@ -33,7 +33,7 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
     rows = []
@@ -42,6 +42,26 @@ def main():
             rows.append((e.count, e.key))
     for c, k in sorted(rows, reverse=True)[:40]:
         print(f'{c:5d}  {k}')
+    seen = set()
+    for e in prof.events():
+        if e.name in ('aten::clone', 'aten::copy_', 'aten::add') and e.input_shapes and e.input_shapes[0] and e.input_shapes[0][-1:] in ([512], [256]):
+            st, par = [], e.cpu_parent
+            while par is not None and len(st) < 4:
+                st.append(par.name)
+                par = par.cpu_parent
+            st = tuple(st)
+            key = (e.name, str(e.input_shapes[0]), st)
+            if key not in seen:
+                seen.add(key)
+                print(e.name, e.input_shapes[0], st)
+    print('--- by input shape')
+    rows = []
+    for e in prof.key_averages(group_by_input_shape=True):
+        if e.key in ('aten::add', 'aten::add_', 'aten::copy_', 'aten::fill_', 'aten::zero_', 'aten::mul', 'aten::cat', 'aten::sum',
+                     'aten::clone', 'aten::contiguous', 'aten::zeros_like', 'aten::zeros', 'aten::sub', 'aten::sigmoid'):
+            rows.append((e.count, e.key, str(e.input_shapes)[:150]))
+    for c, k, sh in sorted(rows, reverse=True)[:60]:
+        print(f'{c:5d}  {k:16s} {sh}')
 
 
 if __name__ == '__main__':
