@@ -416,6 +416,48 @@ class LinearFunction(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class LinearGroupFunction(torch.autograd.Function):
+    """Up to four nn.Linear layers applied to the same x + x2 (Deform3DCrossAttn's camera logits, metre offsets and
+    attention logits of query + query_pos, deform3d_cross_attn.py:211, :227, :281) as ONE node: forward = one
+    gd4d_linear_group_fwd launch that also stores the sum it forms (kept for the weight gradients: no add launch);
+    backward = the input gradients chained through the residual operand of gd4d_linear_fwd (y = grad_g W_g + previous:
+    no autograd sums), one tensor for x and x2.  apply(x, x2, g, W_0.., b_0.., main_w_0.., main_b_0..) -> g tensors (M, N_g)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, g, *args):
+        weights = [w.contiguous() for w in args[:g]]
+        biases = [None if b is None else b.contiguous() for b in args[g:2 * g]]
+        ctx.mains = [(args[2 * g + i], args[3 * g + i]) if args[2 * g + i] is not None else None for i in range(g)]
+        k = x.shape[-1]
+        outs, xsum = ops.linear_group_fwd(x.contiguous().view(-1, k), weights, biases, x2=x2.contiguous().view(-1, k), want_xsum=True)
+        ctx.save_for_backward(xsum, *weights)
+        ctx.g, ctx.has_bias, ctx.xshape = g, [b is not None for b in biases], x.shape
+        ctx.set_materialize_grads(False)                 # an unused output arrives as None, not as zeros
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        xsum, weights = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        g = ctx.g
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gx, gws, gbs = None, [None] * g, [None] * g
+        for i, gy in enumerate(gys):
+            if gy is None:
+                continue
+            gy = gy.contiguous()
+            if need_x:
+                gx = ops.linear_fwd(gy, weights[i], weight_kn=True, r1=gx)
+            if ctx.needs_input_grad[3 + i] or (ctx.has_bias[i] and ctx.needs_input_grad[3 + g + i]):
+                if ctx.mains[i] is not None:
+                    _queue_weight_grad(xsum, gy, ctx.mains[i][0], ctx.mains[i][1] if ctx.has_bias[i] else None)
+                else:
+                    gws[i], gbs[i] = ops.linear_bwd_weight(xsum, gy, want_bias=ctx.has_bias[i])
+        if gx is not None:
+            gx = gx.view(ctx.xshape)
+        return (gx if ctx.needs_input_grad[0] else None, gx if ctx.needs_input_grad[1] else None, None, *gws, *gbs,
+                *([None] * (2 * g)))
+
+
 class LayerNormFunction(torch.autograd.Function):
     """[ReLU] LayerNorm(x [+ res]) over the last dimension: gd4d_layernorm_fwd / gd4d_layernorm_bwd (the decoder layer's
     norms - with the residual sum that precedes them read by the kernel instead of a separate add -, position_encoder's

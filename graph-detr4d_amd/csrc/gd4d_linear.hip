@@ -23,6 +23,7 @@ struct LinearParams {
   const float* r1;     // optional residual (M, N), row stride ldr1
   const float* r2;     // optional second residual, row stride ldr2
   float* y;            // (M, N), row stride ldy
+  float* xsum;         // optional (M, K) contiguous: receives x + x2 (what a training step keeps for the weight gradient)
   int M, K, N, n_split, flags;      // flags: bit0 ReLU on the output, bit1 inverse_sigmoid on the input,
                                     // bit3 the weight is given TRANSPOSED, (K, N) row-major (input gradient of a Linear)
   int ldx, ldy, ldr1, ldr2;
@@ -79,6 +80,7 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_par
   const bool add2 = p.x2 != nullptr && n0 < p.n_split;     // block-uniform (n_split % 32 == 0)
   const bool in_isig = (p.flags & 2) != 0;
   const bool vec = (p.K % 4 == 0) && (p.ldx % 4 == 0);
+  const bool store_sum = p.xsum != nullptr && blockIdx.y == 0;    // block-uniform; the entry points require vec and x2 for it
 
   // rows of the two 16-row A blocks and the two 16-row W blocks this lane feeds (clamped rows are never stored)
   const float* xr[2];
@@ -160,6 +162,8 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_par
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         av[j][t] = load4(xr[t], x2r[t], k, true);
+        if (store_sum && m0 + 16 * t + i16 < p.M && k + 4 <= p.K)   // (the first column tile's workgroup sees every (row, k) once)
+          *reinterpret_cast<f32x4*>(p.xsum + (size_t)(m0 + 16 * t + i16) * p.K + k) = av[j][t];
         if (!wkn) {
           bv[j][t] = load4(wr[t], nullptr, k, false);
         } else {
@@ -363,16 +367,19 @@ __global__ __launch_bounds__(256) void refine_reference_kernel(const float* __re
 extern "C" int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
                                const float* r1, const float* r2, float* y, int M, int K, int N,
                                int n_split, int flags, int ldx, int ldy, int ldr1, int ldr2,
-                               void* stream) {
+                               float* xsum, void* stream) {
   using namespace gd4d;
   if (!x || !w || !y) return GD4D_EINVAL;
+  if (xsum && (!x2 || n_split < LN_TN)) return GD4D_EINVAL;
+  if (xsum && ((K % 4) || (ldx % 4) || (flags & 2))) return GD4D_EUNSUPPORTED;
+  if (xsum && !aligned16(xsum)) return GD4D_EALIGN;
   if (M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return GD4D_EINVAL;
   if (r1 && ldr1 < N) return GD4D_EINVAL;
   if (r2 && ldr2 < N) return GD4D_EINVAL;
   if (x2 && (n_split % LN_TN) != 0 && n_split < N) return GD4D_EUNSUPPORTED;   // split must align to tiles
   if (!aligned16(x) || !aligned16(w) || (x2 && !aligned16(x2))) return GD4D_EALIGN;
   LinearParams p{};
-  p.x = x; p.x2 = x2; p.w = w; p.bias = bias; p.r1 = r1; p.r2 = r2; p.y = y;
+  p.x = x; p.x2 = x2; p.w = w; p.bias = bias; p.r1 = r1; p.r2 = r2; p.y = y; p.xsum = xsum;
   p.M = M; p.K = K; p.N = N; p.n_split = x2 ? n_split : 0; p.flags = flags;
   p.ldx = ldx; p.ldy = ldy; p.ldr1 = ldr1; p.ldr2 = ldr2;
   const dim3 grid((M + LN_TM - 1) / LN_TM, (N + LN_TN - 1) / LN_TN);
@@ -382,13 +389,16 @@ extern "C" int gd4d_linear_fwd(const float* x, const float* x2, const float* w, 
 
 extern "C" int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w, const float* const* bias,
                                      float* const* y, const int32_t* n_out, int G, int M, int K, int ldx,
-                                     void* stream) {
+                                     float* xsum, void* stream) {
   using namespace gd4d;
   if (!x || !w || !y || !n_out || G <= 0 || M <= 0 || K <= 0 || ldx < K) return GD4D_EINVAL;
+  if (xsum && !x2) return GD4D_EINVAL;
+  if (xsum && ((K % 4) || (ldx % 4))) return GD4D_EUNSUPPORTED;
+  if (xsum && !aligned16(xsum)) return GD4D_EALIGN;
   if (G > 4) return GD4D_EUNSUPPORTED;
   if (!aligned16(x) || (x2 && !aligned16(x2))) return GD4D_EALIGN;
   LinearParams p{};
-  p.x = x; p.x2 = x2; p.M = M; p.K = K; p.ldx = ldx; p.groups = G;
+  p.x = x; p.x2 = x2; p.M = M; p.K = K; p.ldx = ldx; p.groups = G; p.xsum = xsum;
   p.n_split = 1 << 30;                    // the addend applies to every output column
   int tiles = 0;
   for (int g = 0; g < G; ++g) {

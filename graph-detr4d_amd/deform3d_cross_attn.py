@@ -203,14 +203,23 @@ class Deform3DCrossAttn(nn.Module):
         runs the HIP forward with a GEMM backward, the small dense layers are torch ops."""
         from .autograd import CrossAttnFunction, ValueProjFunction
         inp_residual = query
-        x = query if query_pos is None else query + query_pos
-        x = x.permute(1, 0, 2)                                            # (B, Q, C)
-        b, q, c = x.shape
         hh, npt, nl = self.num_heads, self.num_points, self.num_levels
-        x = x.contiguous()
-        cam_logits = Fn.sequential_autograd(self.cam_attention_weights, x)   # un-scrambled (B, Q, N)
-        offsets = Fn.sequential_autograd(self.deform_sampling_offsets, x).view(b, q, hh, npt, 3)
-        attn_logits = Fn.sequential_autograd(self.attention_weights, x).view(b, q, hh, nl, npt)
+        three = [self.cam_attention_weights, self.deform_sampling_offsets, self.attention_weights]
+        if Fn.can_group_linears(query, query_pos, three):
+            # the three Linears of (query + query_pos) as one node: one launch forward (which also forms the sum), chained
+            # input gradients backward
+            xq, xp = query.permute(1, 0, 2), query_pos.permute(1, 0, 2)   # (B, Q, C)
+            b, q, c = xq.shape
+            cam_logits, offsets, attn_logits = Fn.linear_group_autograd(xq.contiguous(), xp.contiguous(), three)
+            offsets, attn_logits = offsets.view(b, q, hh, npt, 3), attn_logits.view(b, q, hh, nl, npt)
+        else:
+            x = query if query_pos is None else query + query_pos
+            x = x.permute(1, 0, 2)                                        # (B, Q, C)
+            b, q, c = x.shape
+            x = x.contiguous()
+            cam_logits = Fn.sequential_autograd(self.cam_attention_weights, x)   # un-scrambled (B, Q, N)
+            offsets = Fn.sequential_autograd(self.deform_sampling_offsets, x).view(b, q, hh, npt, 3)
+            attn_logits = Fn.sequential_autograd(self.attention_weights, x).view(b, q, hh, nl, npt)
         shapes = [tuple(v.shape[-2:]) for v in value]
         lidar2img = Fn.lidar2img_device(img_metas, query)
         img_h, img_w = Fn.img_hw(img_metas)

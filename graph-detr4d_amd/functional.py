@@ -49,6 +49,26 @@ def linear_autograd(x, weight, bias=None, main=None, relu=False):
     return torch.relu(y) if relu else y
 
 
+def linear_group_autograd(x, x2, linears):
+    """[lin(x + x2) for lin in linears] (nn.Linear modules, at most 4) with autograd as ONE node and one forward launch
+    (autograd.LinearGroupFunction); x, x2 (..., K).  Returns a list of (..., N_g)."""
+    from .autograd import LinearGroupFunction
+    ws = [m.weight for m in linears]
+    bs = [m.bias for m in linears]
+    mains = [(main_grad(m.weight), main_grad(m.bias)) for m in linears]
+    mains = [(mw, mb) if mw is not None and (m.bias is None or mb is not None) and torch.is_grad_enabled() else (None, None)
+             for (mw, mb), m in zip(mains, linears)]
+    outs = LinearGroupFunction.apply(x, x2, len(linears), *ws, *bs, *[m[0] for m in mains], *[m[1] for m in mains])
+    return [o.view(*x.shape[:-1], w.shape[0]) for o, w in zip(outs, ws)]
+
+
+def can_group_linears(x, x2, linears):
+    return (x2 is not None and x.is_cuda and x.dtype == torch.float32 and x2.dtype == torch.float32 and x2.shape == x.shape
+            and x.shape[-1] % 4 == 0 and 0 < len(linears) <= 4
+            and all(isinstance(m, torch.nn.Linear) and m.weight.dtype == torch.float32 for m in linears)
+            and os.environ.get('GD4D_TRAIN_GROUP_LINEAR', '1') != '0')
+
+
 def layer_norm_autograd(x, norm, relu=False, res=None):
     """nn.LayerNorm `norm` of x [+ res] [+ ReLU] with autograd on the HIP kernels (gd4d_layernorm_fwd / _bwd); anything
     they do not cover (CPU, other dtypes, no affine parameters, > 1024 channels) goes to the module."""

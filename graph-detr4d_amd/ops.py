@@ -794,46 +794,68 @@ def _opt(t, name):
 
 
 def linear_fwd(x, weight, bias=None, x2=None, n_split=None, relu=False, r1=None, r2=None, out=None,
-               inv_sigmoid_in=False, weight_kn=False):
+               inv_sigmoid_in=False, weight_kn=False, want_xsum=False):
     """gd4d_linear_fwd on the last dimension: y = act((x [+ x2 for cols < n_split]) W^T + b) [+r1] [+r2].
-    x (..., K) contiguous; weight (N, K); residuals (..., N) contiguous.  Returns (..., N)."""
+    x (..., K) contiguous - or 2-D with a row stride (a column slice of a wider buffer, e.g. the q|k part of a packed
+    gradient); weight (N, K); residuals (..., N) contiguous.  Returns (..., N); with want_xsum (needs x2): (y, x + x2)."""
     lib = _lib.load()
     k = x.shape[-1]
     n = weight.shape[1] if weight_kn else weight.shape[0]      # weight_kn: weight is (K, N) - y = x W (a Linear's dgrad)
     if weight_kn and weight.shape[0] != k:
         raise ValueError('weight_kn: weight must be (K, N) with K = x.shape[-1]')
     m = x.numel() // k
+    ldx = k
+    if not x.is_contiguous():
+        if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < k or x2 is not None:
+            raise ValueError('x must be contiguous, or 2-D with unit column stride (and no x2)')
+        ldx = x.stride(0)
     if out is None:
         out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
     if x2 is not None and x2.shape != x.shape:
         raise ValueError('x2 must have the shape of x')
-    code = lib.gd4d_linear_fwd(_dev(x, 'x', torch.float32), _opt(x2, 'x2'), _dev(weight, 'weight', torch.float32),
+    xsum = None
+    if want_xsum:
+        if x2 is None:
+            raise ValueError('want_xsum needs x2')
+        xsum = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    xptr = _dev(x, 'x', torch.float32) if ldx == k else _devptr_strided(x, 'x')
+    code = lib.gd4d_linear_fwd(xptr, _opt(x2, 'x2'), _dev(weight, 'weight', torch.float32),
                                _opt(bias, 'bias'), _opt(r1, 'r1'), _opt(r2, 'r2'), _dev(out, 'out'),
                                m, k, n, n if n_split is None else int(n_split),
                                int(bool(relu)) | (2 if inv_sigmoid_in else 0) | (8 if weight_kn else 0),
-                               k, n, n, n, _stream())
+                               ldx, n, n, n, None if xsum is None else _dev(xsum, 'xsum'), _stream())
     _lib.check(code, 'gd4d_linear_fwd')
-    return out
+    return (out, xsum) if want_xsum else out
 
 
-def linear_group_fwd(x, weights, biases, x2=None):
-    """gd4d_linear_group_fwd: [(x + x2) W_g^T + b_g for g] in one launch.  x (..., K) contiguous; returns a list."""
+def _devptr_strided(t, name):
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.Gd4dError(f'{name}: fp32 device tensor expected, got {t.dtype} on {t.device}')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def linear_group_fwd(x, weights, biases, x2=None, want_xsum=False):
+    """gd4d_linear_group_fwd: [(x + x2) W_g^T + b_g for g] in one launch.  x (..., K) contiguous; returns a list
+    (want_xsum, needs x2: (list, x + x2))."""
     lib = _lib.load()
     g = len(weights)
     k = x.shape[-1]
     m = x.numel() // k
     if x2 is not None and x2.shape != x.shape:
         raise ValueError('x2 must have the shape of x')
+    if want_xsum and x2 is None:
+        raise ValueError('want_xsum needs x2')
     outs = [torch.empty(*x.shape[:-1], w.shape[0], device=x.device, dtype=torch.float32) for w in weights]
+    xsum = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_xsum else None
     vp = ctypes.c_void_p
     warr = (vp * g)(*[_dev(w, 'weight', torch.float32).value for w in weights])
     barr = (vp * g)(*[None if b is None else _dev(b, 'bias', torch.float32).value for b in biases])
     yarr = (vp * g)(*[o.data_ptr() for o in outs])
     narr = (ctypes.c_int32 * g)(*[w.shape[0] for w in weights])
     code = lib.gd4d_linear_group_fwd(_dev(x, 'x', torch.float32), _opt(x2, 'x2'), warr, barr, yarr, narr, g, m, k, k,
-                                     _stream())
+                                     None if xsum is None else _dev(xsum, 'xsum'), _stream())
     _lib.check(code, 'gd4d_linear_group_fwd')
-    return outs
+    return (outs, xsum) if want_xsum else outs
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, res=None, relu=False):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 33
+#define GD4D_ABI_VERSION 34
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -413,6 +413,8 @@ int gd4d_value_proj_bwd_weight(const float* grad_out, const void* const* feats, 
  * flags: GD4D_LIN_RELU = ReLU on the output (before the residuals); GD4D_LIN_INV_SIGMOID_IN = apply the
  * reference's inverse_sigmoid (deform3d_cross_attn.py:16-31) to x while loading it (position_encoder
  * input, :334).
+ * xsum: NULL, or (M, K) contiguous fp32 that receives x + x2 (needs x2, K % 4 == 0, ldx % 4 == 0, no
+ * GD4D_LIN_INV_SIGMOID_IN): a training step keeps the sum for the weight gradient without a separate add launch.
  */
 #define GD4D_LIN_RELU 1
 #define GD4D_LIN_INV_SIGMOID_IN 2
@@ -421,16 +423,16 @@ int gd4d_value_proj_bwd_weight(const float* grad_out, const void* const* feats, 
 #define GD4D_GEMM_RELU_IN 16       /* gd4d_gemm_bf16x3_fwd: ReLU on the elements of A as they are read */
 int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
                     const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
-                    int flags, int ldx, int ldy, int ldr1, int ldr2, void* stream);
+                    int flags, int ldx, int ldy, int ldr1, int ldr2, float* xsum, void* stream);
 
 /* gd4d_linear_group_fwd - up to 4 Linear layers that share their input, in one launch:
  *   y_g = (x + x2) W_g^T + b_g,  g < G.
  * Deform3DCrossAttn applies cam_attention_weights, deform_sampling_offsets and attention_weights to the same
  * (query + query_pos) (deform3d_cross_attn.py:211, :227, :281): three launches become one.
  *   x, x2 (M, K) row stride ldx (x2 may be NULL); w, bias, y: HOST arrays of G device pointers (bias or its entries may
- *   be NULL), W_g (N_g, K) row-major, y_g (M, N_g) contiguous; n_out: host, G ints.  G <= 4. */
+ *   be NULL), W_g (N_g, K) row-major, y_g (M, N_g) contiguous; n_out: host, G ints.  G <= 4.  xsum: as gd4d_linear_fwd. */
 int gd4d_linear_group_fwd(const float* x, const float* x2, const float* const* w, const float* const* bias,
-                          float* const* y, const int32_t* n_out, int G, int M, int K, int ldx, void* stream);
+                          float* const* y, const int32_t* n_out, int G, int M, int K, int ldx, float* xsum, void* stream);
 
 /* gd4d_linear_bwd_weight - weight / bias gradient of an nn.Linear over the query rows (training):
  *   grad_w[n][k] = sum_m grad_y[m][n] * x[m][k]   (N, K) contiguous;   grad_b[n] = sum_m grad_y[m][n]  (or NULL)

@@ -151,6 +151,80 @@ def test_linear_group_equals_separate_launches():
         ops.linear_group_fwd(x, ws + ws[:1], bs + bs[:1])
 
 
+def test_linear_sum_output_and_strided_rows():
+    """gd4d_linear_fwd / _group_fwd also hand out the x + x2 they form (kept by a training step for the weight gradients),
+    and gd4d_linear_fwd reads a column slice of a wider buffer in place (row stride > K)."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(14)
+    for m in (900, 37):
+        x, x2 = torch.randn(m, 1, 256).cuda(), torch.randn(m, 1, 256).cuda()
+        w, b = torch.randn(768, 256).cuda() * 0.1, torch.randn(768).cuda()
+        y, xs = ops.linear_fwd(x, w, b, x2=x2, n_split=512, want_xsum=True)
+        assert torch.equal(xs, x + x2) and torch.equal(y, ops.linear_fwd(x, w, b, x2=x2, n_split=512))
+        ws = [torch.randn(n, 256).cuda() * 0.1 for n in (24, 96, 128)]
+        outs, xs = ops.linear_group_fwd(x, ws, [None] * 3, x2=x2, want_xsum=True)
+        assert torch.equal(xs, x + x2)
+        assert all(torch.equal(o, o2) for o, o2 in zip(outs, ops.linear_group_fwd(x, ws, [None] * 3, x2=x2)))
+        wide = torch.randn(m, 768).cuda()
+        wk = torch.randn(512, 256).cuda()
+        got = ops.linear_fwd(wide[:, :512], wk, weight_kn=True)
+        assert torch.equal(got, ops.linear_fwd(wide[:, :512].contiguous(), wk, weight_kn=True))
+        got = ops.linear_fwd(wide[:, 512:], w[:40], b[:40])
+        assert torch.equal(got, ops.linear_fwd(wide[:, 512:].contiguous(), w[:40], b[:40]))
+    with pytest.raises(ValueError):
+        ops.linear_fwd(x, w, b, want_xsum=True)
+
+
+@pytest.mark.parametrize('fused_main', [False, True])
+def test_linear_group_function_gradients_match_fp64(fused_main):
+    """autograd.LinearGroupFunction (the three Linears of query + query_pos as one node) against fp64 autograd of three
+    F.linear calls: outputs, the shared input gradient, weight and bias gradients - returned to autograd, or added by the
+    kernels to given buffers (the flat gradient buffer of a training step)."""
+    from graph_detr4d_amd import functional as Fn
+    torch.manual_seed(15)
+    m = 900
+    x = torch.randn(1, m, 256, device='cuda', requires_grad=True)
+    x2 = torch.randn(1, m, 256, device='cuda', requires_grad=True)
+    lins = [torch.nn.Linear(256, n).cuda() for n in (24, 96, 128)]
+    bufs = []
+    if fused_main:
+        for lin in lins:
+            for prm in (lin.weight, lin.bias):
+                buf = torch.full_like(prm, 0.5)
+                prm._gd4d_main_grad = buf
+                bufs.append(buf)
+    outs = Fn.linear_group_autograd(x, x2, lins)
+    gos = [torch.randn_like(o) for o in outs]
+    # the third output is used twice, the second not at all in one of the two passes
+    (outs[0] * gos[0]).sum().backward(retain_graph=True)
+    gx_first = x.grad.clone()
+    x.grad = x2.grad = None
+    for lin in lins:
+        lin.weight.grad = lin.bias.grad = None
+    for buf in bufs:
+        buf.fill_(0.5)
+    sum((o * g).sum() for o, g in zip(outs, gos)).backward()
+    xd, x2d = x.detach().double().cpu().requires_grad_(True), x2.detach().double().cpu().requires_grad_(True)
+    wd = [lin.weight.detach().double().cpu().requires_grad_(True) for lin in lins]
+    bd = [lin.bias.detach().double().cpu().requires_grad_(True) for lin in lins]
+    ref = [torch.nn.functional.linear(xd + x2d, w, b) for w, b in zip(wd, bd)]
+    for o, r in zip(outs, ref):
+        assert (o.detach().cpu().double() - r).abs().max().item() < 1e-4
+    sum((r * g.cpu().double()).sum() for r, g in zip(ref, gos)).backward()
+    assert (x.grad.cpu().double() - xd.grad).abs().max().item() < 2e-4
+    assert torch.equal(x.grad, x2.grad)
+    want_first = torch.autograd.grad((torch.nn.functional.linear(xd + x2d, wd[0], bd[0]) * gos[0].cpu().double()).sum(), xd)[0]
+    assert (gx_first.cpu().double() - want_first).abs().max().item() < 2e-4   # (only one of the three outputs was used)
+    for i, lin in enumerate(lins):
+        if fused_main:
+            gw, gb = bufs[2 * i] - 0.5, bufs[2 * i + 1] - 0.5
+            assert lin.weight.grad is None and lin.bias.grad is None
+        else:
+            gw, gb = lin.weight.grad, lin.bias.grad
+        assert (gw.cpu().double() - wd[i].grad).abs().max().item() < 2e-3
+        assert (gb.cpu().double() - bd[i].grad).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize('k,isig,relu', [(3, True, True), (4, True, True), (2, False, False), (1, False, True)])
 def test_small_linear_layernorm_matches_fp64(k, isig, relu):
     from graph_detr4d_amd import ops
