@@ -197,18 +197,28 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(con
       for (int i = 0; i < 4; ++i) pr[i] = row[i];
       const bool second = (t0 + k) * 4 + 2 < M;
       float4 val[8];
+      // all eight loads of the pass issued back to back, without a branch: when items 2, 3 of the pass do not exist their
+      // loads repeat those of items 0, 1 (lines just requested) and their products are dropped below.  (Skipping them with
+      // a `continue` per load made the compiler wait for each of the four in turn, a uniform branch around the four still
+      // put the two groups one after the other: 181 us per launch.)
+      unsigned off[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        val[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((j & 3) >= LT) continue;
-        if (j >= 4 && !second) continue;
-        const unsigned o = ((j & 1) ? pr[j >> 1].z : pr[j >> 1].x) + lane_off;
-        val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(base[j & 3] + o));
+        off[j] = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
+        if (j >= 4) off[j] = second ? off[j] : off[j - 4];
+        off[j] += lane_off;
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        val[j] = (j & 3) < LT ? Quad<VT>::load(reinterpret_cast<const VT*>(base[j & 3] + off[j])) : make_float4(0.f, 0.f, 0.f, 0.f);
       __builtin_amdgcn_sched_barrier(0);
       float d[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d[j] = (ga.x * val[j].x + ga.y * val[j].y) + (ga.z * val[j].z + ga.w * val[j].w);
+      for (int j = 0; j < 8; ++j) {
+        d[j] = (ga.x * val[j].x + ga.y * val[j].y) + (ga.z * val[j].z + ga.w * val[j].w);
+        if (j >= 4) d[j] = second ? d[j] : 0.f;
+      }
       float e[4], f[2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -521,13 +531,14 @@ __global__ __launch_bounds__(256) void pyramid_grad_count_kernel(const int* __re
   const int W = g.lvl_w[l], cws = g.cws[l], chs = g.chs[l], CWl = g.CW[l], CHl = g.CH[l], cbase = g.chunk_base[l];
   const unsigned long long lt = (1ull << lane) - 1ull;
   const size_t prow = (size_t)ph * cap_t * 64 + lane;
-  // two passes per round: both rounds of matching first, then both returning atomics in flight together (a pass at a time,
-  // every pass waited for its own atomic's round trip)
+  // four passes per round: their plan rows requested together, then the four rounds of matching, then the four returning
+  // atomics in flight together (a pass at a time, every pass waited for its plan row and then for its own atomic's round
+  // trip; two per round with the second row requested after the first match: 52 us per launch)
+  constexpr int NP = 4;
   struct Match { int key, pxin, leader, rank, n; bool valid; };
-  auto match = [&](int t) -> Match {
+  auto match = [&](int t, const uint2 pr) -> Match {
     Match m{0, 0, lane, 0, 0, false};
     if (t >= T) return m;
-    const uint2 pr = pair[prow + (size_t)t * 64];
     m.valid = __uint_as_float(pr.y) != 0.f;
     const unsigned row = pr.x / cs;
     const unsigned pix = (pr.x - row * cs) / g.pix_stride;
@@ -552,13 +563,28 @@ __global__ __launch_bounds__(256) void pyramid_grad_count_kernel(const int* __re
     slots[prow + (size_t)t * 64] = m.valid ? make_uint2(((unsigned)m.key << 6) | (unsigned)m.pxin, (unsigned)(base + m.rank))
                                            : make_uint2(0xffffffffu, 0xffffffffu);
   };
-  for (int t = 0; t < T; t += 2) {
-    const Match m0 = match(t), m1 = match(t + 1);
-    int b0 = 0, b1 = 0;
-    if (m0.valid && m0.leader == lane) b0 = atomicAdd(count + m0.key, m0.n);
-    if (m1.valid && m1.leader == lane) b1 = atomicAdd(count + m1.key, m1.n);
-    finish(t, m0, b0);
-    finish(t + 1, m1, b1);
+  for (int t = 0; t < T; t += NP) {
+    uint2 pr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pr[i] = pair[prow + (size_t)min(t + i, T - 1) * 64];
+    Match m[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) m[i] = match(t + i, pr[i]);
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    static_assert(NP == 4, "four returning atomics in flight");
+    // (the four addresses exist before the first atomic is issued: computed between them, the compiler re-used the registers
+    // of an atomic in flight and waited for it first - four round trips in turn)
+    typedef __attribute__((address_space(1))) int gint;           // (global, not generic: global_atomic_add, not flat_)
+    gint* a0 = (gint*)(count + m[0].key); gint* a1 = (gint*)(count + m[1].key);
+    gint* a2 = (gint*)(count + m[2].key); gint* a3 = (gint*)(count + m[3].key);
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    if (m[0].valid && m[0].leader == lane) b0 = __hip_atomic_fetch_add(a0, m[0].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m[1].valid && m[1].leader == lane) b1 = __hip_atomic_fetch_add(a1, m[1].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m[2].valid && m[2].leader == lane) b2 = __hip_atomic_fetch_add(a2, m[2].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m[3].valid && m[3].leader == lane) b3 = __hip_atomic_fetch_add(a3, m[3].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int b[NP] = {b0, b1, b2, b3};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) finish(t + i, m[i], b[i]);
   }
 }
 
@@ -575,12 +601,27 @@ __global__ __launch_bounds__(256) void pyramid_grad_fill_kernel(const int* __res
   const int T = (M + 3) >> 2;
   const unsigned id = id_base + (unsigned)((order ? order[pos] : pos) * HH + h);
   const size_t prow = (size_t)ph * cap_t * 64 + lane;
-  for (int t = 0; t < T; ++t) {
-    const uint2 sr = slots[prow + (size_t)t * 64];
-    if (sr.y != 0xffffffffu) {
-      const uint2 pr = pair[prow + (size_t)t * 64];
-      rec[(size_t)start[sr.x >> 6] + sr.y] = make_uint2(pr.y, ((sr.x & 63u) << 26) | id);
+  // four passes at a time: their slot and pair rows requested together, then the four chunk starts (which depend on the
+  // slots), then the stores - two round trips per four passes (one pass per iteration was two dependent round trips per pass
+  // on a wave that walks ~4 passes: 26 us per launch)
+  constexpr int FP = 4;
+  for (int t = 0; t < T; t += FP) {
+    uint2 sr[FP], pr[FP];
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const size_t at = prow + (size_t)min(t + i, T - 1) * 64;
+      sr[i] = slots[at];
+      pr[i] = pair[at];
     }
+    int st[FP];
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const bool ok = t + i < T && sr[i].y != 0xffffffffu;
+      st[i] = ok ? start[sr[i].x >> 6] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < FP; ++i)
+      if (st[i] >= 0) rec[(size_t)st[i] + sr[i].y] = make_uint2(pr[i].y, ((sr[i].x & 63u) << 26) | id);
   }
 }
 
