@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const 
     const float a = ap[(size_t)m * HH * kChannels];
 #pragma unroll
     for (int i = 0; i < DPT; ++i) acc[i] = fmaf(gp[(size_t)m * kChannels + i], a, acc[i]);
-    if (do_bias) accb = fmaf(g[(size_t)m * kChannels + h * DH + dg * DPT + c], wsum[(size_t)m * HH + h], accb);
+  }
+  if (do_bias) {                                     // (its own loop: inside the one above its branch split every batch of loads)
+#pragma unroll 8
+    for (int m = m0; m < m1; ++m) accb = fmaf(g[(size_t)m * kChannels + h * DH + dg * DPT + c], wsum[(size_t)m * HH + h], accb);
   }
 #pragma unroll
   for (int i = 0; i < DPT; ++i) part[((size_t)ks * kChannels + h * DH + dg * DPT + i) * kChannels + c0 + c] = acc[i];
@@ -373,19 +376,26 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_bwd_kernel(const P
       const float xf = floorf(x), yf = floorf(y);
       const float dx = x - xf, dy = y - yf;
       const int x0 = (int)xf, y0 = (int)yf;
-      const float* dsrc = pp.dpart + prow + (size_t)(item >> 2) * 64 + slot0;
+      // the 4 x 8 slice partials of this lane's corners, all requested before the first is used (a pass of the gather-dot
+      // writes all 64 of its entries, so every address below holds a finite or at least harmless value: lanes past the list's
+      // end read their slot of its last pass; what a dead lane or a corner outside the map reads is dropped by the select).
+      // Loaded corner by corner inside `if (in)` the four groups were four round trips in turn.
+      const float* dsrc = pp.dpart + prow + (size_t)(min(item, M - 1) >> 2) * 64 + slot0;
+      float part[4][kSlices];
+#pragma unroll
+      for (int c_of = 0; c_of < 4; ++c_of)
+#pragma unroll
+        for (int s = 0; s < kSlices; ++s) part[c_of][s] = dsrc[(size_t)s * pp.dslice + (c_of << 3)];
       float d[4];
 #pragma unroll
       for (int c_of = 0; c_of < 4; ++c_of) {
         const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
         const bool in = live && xi >= 0 && xi < lw && yi >= 0 && yi < lh;
         float t = 0.f;
-        if (in) {
 #pragma unroll
-          for (int s = 0; s < kSlices; ++s) t += dsrc[(size_t)s * pp.dslice + (c_of << 3)];
-          t += beta;
-        }
-        d[c_of] = t;                                  // corners outside the map (zero padding) and dead lanes: 0
+        for (int s = 0; s < kSlices; ++s) t += part[c_of][s];
+        t += beta;
+        d[c_of] = in ? t : 0.f;                       // corners outside the map (zero padding) and dead lanes: 0
       }
       const float bw0 = (1.f - dx) * (1.f - dy), bw1 = dx * (1.f - dy), bw2 = (1.f - dx) * dy, bw3 = dx * dy;
       const float T = (bw0 * d[0] + bw1 * d[1]) + (bw2 * d[2] + bw3 * d[3]);
