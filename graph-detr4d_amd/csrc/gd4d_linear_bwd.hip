@@ -52,18 +52,25 @@ __device__ __forceinline__ void linear_bwd_weight_tile(const LinBwdParams& p, in
 
   for (int m0 = m_begin; m0 < m_end; m0 += 4 * LB_UNROLL) {
     float a[LB_UNROLL], b[LB_UNROLL][LB_T];
+    static_assert(LB_UNROLL == 4 && LB_T == 2, "the operand list of the asm below");
 #pragma unroll
-    for (int u = 0; u < LB_UNROLL; ++u) {            // all loads of the unrolled steps first, then the MFMAs
+    for (int u = 0; u < LB_UNROLL; ++u) {            // all loads of the unrolled steps first (clamped: always in bounds)
       const int m = m0 + 4 * u + r4;
-      const bool m_ok = m < m_end;
-      const size_t mr = (size_t)(m_ok ? m : m_end - 1);
-      const float av = dy_col[mr * p.ldy];
-      a[u] = (m_ok && n_ok) ? av : 0.f;
+      const size_t mr = (size_t)min(m, m_end - 1);
+      a[u] = dy_col[mr * p.ldy];
 #pragma unroll
-      for (int t = 0; t < LB_T; ++t) {
-        const float bv = x_col[t][mr * p.ldx];
-        b[u][t] = (m_ok && k_ok[t]) ? bv : 0.f;
-      }
+      for (int t = 0; t < LB_T; ++t) b[u][t] = x_col[t][mr * p.ldx];
+    }
+    // ... and all of them complete before anything is masked: with the selects next to the loads the compiler sank every load
+    // into its select's branch and waited for each where it stood - twelve round trips in turn per step of sixteen rows
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]),
+                      "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]));
+#pragma unroll
+    for (int u = 0; u < LB_UNROLL; ++u) {
+      const bool m_ok = m0 + 4 * u + r4 < m_end;
+      a[u] = (m_ok && n_ok) ? a[u] : 0.f;
+#pragma unroll
+      for (int t = 0; t < LB_T; ++t) b[u][t] = (m_ok && k_ok[t]) ? b[u][t] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < LB_UNROLL; ++u) {
