@@ -53,7 +53,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // registers, four workgroups per CU instead of three - a 900 x 1024 output (928 workgroups) then runs in one round.
 // WAVES: how many waves split K (64 columns of it at a time each).  4 for K <= 512 (one round trip per wave up to K = 256);
 // LN_DEEP_WAVES for the deep contractions of the FFN (K = 1024: four dependent round trips per wave with 4 waves).
-template <bool RES, int WAVES>
+// MODE: 0 = every form (bounds checks, scalar tails, inverse_sigmoid, an addend for some of the column tiles only: loads
+// behind selects and branches, which the compiler issues and waits for one at a time); LN_FAST [| LN_FAST_WKN] [| LN_FAST_X2] =
+// the shapes the decoder actually runs (K % 64 == 0, 16-byte rows, the addend - if any - for every column): a chunk's
+// sixteen to twenty-four loads are issued back to back and pinned before the first use.
+constexpr int LN_FAST = 1, LN_FAST_WKN = 2, LN_FAST_X2 = 4;
+template <bool RES, int WAVES, int MODE>
 __device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_part)[16][64]) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -125,35 +130,82 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_par
   // Epilogue operands (bias, residuals) are requested NOW by the wave that will need them, so their
   // memory latency overlaps the K loop instead of following the reduction.
   float pre_bias[2] = {0.f, 0.f};
-  float pre_res[RES ? 2 : 1][2][4];
-#pragma unroll
-  for (int a = 0; a < (RES ? 2 : 1); ++a)
+  constexpr int RA = RES ? 2 : 1;
+  float pre_r1[RA][2][4], pre_r2[RA][2][4];           // the two residuals apart: each a batch of unconditional loads (clamped
+#pragma unroll                                        // addresses) behind ONE uniform branch - summed as they were requested,
+  for (int a = 0; a < RA; ++a)                        // `t += r1[..]; t += r2[..]` per element, every load waited for the one before
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pre_res[a][c][r] = 0.f;
+      for (int r = 0; r < 4; ++r) { pre_r1[a][c][r] = 0.f; pre_r2[a][c][r] = 0.f; }
   if (wave == 0) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int n = n0 + 16 * c + i16;
-      if (n < N) {
-        if (Bv) pre_bias[c] = Bv[n];
+      const int n = min(n0 + 16 * c + i16, N - 1);
+      if (Bv) pre_bias[c] = Bv[n];
+    }
+    if (RES && p.r1) {
 #pragma unroll
-        for (int a = 0; a < (RES ? 2 : 0); ++a)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 16 * a + 4 * g + r;
-            if (m < p.M) {
-              float t = 0.f;
-              if (p.r1) t += p.r1[(size_t)m * p.ldr1 + n];
-              if (p.r2) t += p.r2[(size_t)m * p.ldr2 + n];
-              pre_res[a][c][r] = t;
-            }
-          }
-      }
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pre_r1[a][c][r] = p.r1[(size_t)min(m0 + 16 * a + 4 * g + r, p.M - 1) * p.ldr1 + min(n0 + 16 * c + i16, N - 1)];
+    }
+    if (RES && p.r2) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pre_r2[a][c][r] = p.r2[(size_t)min(m0 + 16 * a + 4 * g + r, p.M - 1) * p.ldr2 + min(n0 + 16 * c + i16, N - 1)];
     }
   }
 
+  if (MODE & LN_FAST) {
+    for (int kc = wave * LN_KC; kc < p.K; kc += LN_KC * WAVES) {
+      f32x4 av[4][2], bv[4][2], xv[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int k = kc + 16 * j + 4 * g;
+          av[j][t] = *reinterpret_cast<const f32x4*>(xr[t] + k);
+          if (MODE & LN_FAST_X2) xv[j][t] = *reinterpret_cast<const f32x4*>(p.x2 + (xr[t] - p.x) + k);
+          if (MODE & LN_FAST_WKN) {
+            bv[j][t] = f32x4{wr[t][(size_t)k * N], wr[t][(size_t)(k + 1) * N], wr[t][(size_t)(k + 2) * N], wr[t][(size_t)(k + 3) * N]};
+          } else {
+            bv[j][t] = *reinterpret_cast<const f32x4*>(wr[t] + k);
+          }
+        }
+      asm volatile("" : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[1][0]), "+v"(av[1][1]), "+v"(av[2][0]), "+v"(av[2][1]),
+                        "+v"(av[3][0]), "+v"(av[3][1]), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[1][0]), "+v"(bv[1][1]),
+                        "+v"(bv[2][0]), "+v"(bv[2][1]), "+v"(bv[3][0]), "+v"(bv[3][1]));
+      if (MODE & LN_FAST_X2) {
+        asm volatile("" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[1][0]), "+v"(xv[1][1]), "+v"(xv[2][0]), "+v"(xv[2][1]),
+                          "+v"(xv[3][0]), "+v"(xv[3][1]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            av[j][t] += xv[j][t];
+            if (store_sum && m0 + 16 * t + i16 < p.M)
+              *reinterpret_cast<f32x4*>(p.xsum + (size_t)(m0 + 16 * t + i16) * p.K + kc + 16 * j + 4 * g) = av[j][t];
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][a][e], bv[j][c][e], acc[a][c], 0, 0, 0);
+    }
+  } else {
   for (int kc = wave * LN_KC; kc < p.K; kc += LN_KC * WAVES) {
     f32x4 av[4][2], bv[4][2];
 #pragma unroll
@@ -185,6 +237,24 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_par
             acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][a][e], bv[j][c][e], acc[a][c], 0, 0, 0);
   }
 
+  }
+
+  // The epilogue operands requested before the K loop have arrived by now; say so HERE.  Left to the first use - inside the
+  // epilogue's per-element branches, after earlier stores - the counter can only be waited down to zero, which also waits
+  // for the previous store's acknowledgement: sixteen stores, one after the other.
+  asm volatile("" : "+v"(pre_bias[0]), "+v"(pre_bias[1]));
+  float pre_res[RA][2][4];
+#pragma unroll
+  for (int a = 0; a < RA; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (RES) {
+        asm volatile("" : "+v"(pre_r1[a][c][0]), "+v"(pre_r1[a][c][1]), "+v"(pre_r1[a][c][2]), "+v"(pre_r1[a][c][3]),
+                          "+v"(pre_r2[a][c][0]), "+v"(pre_r2[a][c][1]), "+v"(pre_r2[a][c][2]), "+v"(pre_r2[a][c][3]));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre_res[a][c][r] = pre_r1[a][c][r] + pre_r2[a][c][r];   // (0 + r1) + r2, as before
+    }
   if (wave > 0) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -220,27 +290,60 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, float (*s_par
 
 __global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel_res(const LinearParams p) {
   __shared__ float s_part[LN_WAVES - 1][16][64];
-  linear_body<true, LN_WAVES>(p, s_part);
+  linear_body<true, LN_WAVES, 0>(p, s_part);
 }
 
-__global__ __launch_bounds__(64 * LN_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void linear_kernel(const LinearParams p) {
+__global__ __launch_bounds__(64 * LN_WAVES) void linear_kernel(const LinearParams p) {
   __shared__ float s_part[LN_WAVES - 1][16][64];
-  linear_body<false, LN_WAVES>(p, s_part);
+  linear_body<false, LN_WAVES, 0>(p, s_part);
 }
 
 #ifndef LN_DEEP_WAVES_N
-#define LN_DEEP_WAVES_N 16
+#define LN_DEEP_WAVES_N 8
 #endif
-constexpr int LN_DEEP_WAVES = LN_DEEP_WAVES_N, LN_DEEP_K = 768;
+constexpr int LN_DEEP_WAVES = LN_DEEP_WAVES_N, LN_DEEP_K = 768, LN_FAST_DEEP_WAVES = 8;
 
 template <bool RES>
 __global__ __launch_bounds__(64 * LN_DEEP_WAVES) void linear_kernel_deep(const LinearParams p) {
   __shared__ float s_part[LN_DEEP_WAVES - 1][16][64];
-  linear_body<RES, LN_DEEP_WAVES>(p, s_part);
+  linear_body<RES, LN_DEEP_WAVES, 0>(p, s_part);
+}
+
+template <bool RES, int WAVES, int MODE>
+__global__ __launch_bounds__(64 * WAVES) void linear_kernel_fast(const LinearParams p) {
+  __shared__ float s_part[WAVES - 1][16][64];
+  linear_body<RES, WAVES, MODE>(p, s_part);
+}
+
+template <bool RES, int WAVES>
+static void launch_linear_fast(const LinearParams& p, dim3 grid, hipStream_t st, int mode) {
+  switch (mode) {
+    case LN_FAST: hipLaunchKernelGGL((linear_kernel_fast<RES, WAVES, LN_FAST>), grid, dim3(64 * WAVES), 0, st, p); break;
+    case LN_FAST | LN_FAST_WKN: hipLaunchKernelGGL((linear_kernel_fast<RES, WAVES, LN_FAST | LN_FAST_WKN>), grid, dim3(64 * WAVES), 0, st, p); break;
+    case LN_FAST | LN_FAST_X2: hipLaunchKernelGGL((linear_kernel_fast<RES, WAVES, LN_FAST | LN_FAST_X2>), grid, dim3(64 * WAVES), 0, st, p); break;
+    default: hipLaunchKernelGGL((linear_kernel_fast<RES, WAVES, LN_FAST | LN_FAST_WKN | LN_FAST_X2>), grid, dim3(64 * WAVES), 0, st, p); break;
+  }
 }
 
 static void launch_linear(const LinearParams& p, dim3 grid, hipStream_t st) {
   const bool res = p.r1 || p.r2;
+  const bool wkn = (p.flags & 8) != 0;
+  // the branch-free form: whole 64-column chunks of K, 16-byte rows (and for the transposed weight: N known per launch),
+  // no inverse_sigmoid on the way in, the addend - if any - for every column tile
+  const bool x2_all = p.x2 != nullptr && (p.groups > 0 || p.n_split >= p.N);
+  const bool fast = p.K % LN_KC == 0 && p.ldx % 4 == 0 && !(p.flags & 2) && (p.x2 == nullptr || x2_all) && !(wkn && p.groups > 0) &&
+                    reinterpret_cast<uintptr_t>(p.groups > 0 ? (const void*)p.gw[0] : (const void*)p.w) % 16 == 0;
+  if (fast) {
+    const int mode = LN_FAST | (wkn ? LN_FAST_WKN : 0) | (x2_all ? LN_FAST_X2 : 0);
+    if (p.K >= LN_DEEP_K) {                  // (8 waves: with 16 the 128-register budget of a 1024-thread workgroup spills)
+      if (res) launch_linear_fast<true, LN_FAST_DEEP_WAVES>(p, grid, st, mode);
+      else launch_linear_fast<false, LN_FAST_DEEP_WAVES>(p, grid, st, mode);
+    } else {
+      if (res) launch_linear_fast<true, LN_WAVES>(p, grid, st, mode);
+      else launch_linear_fast<false, LN_WAVES>(p, grid, st, mode);
+    }
+    return;
+  }
   if (p.K >= LN_DEEP_K) {
     if (res) hipLaunchKernelGGL(linear_kernel_deep<true>, grid, dim3(64 * LN_DEEP_WAVES), 0, st, p);
     else hipLaunchKernelGGL(linear_kernel_deep<false>, grid, dim3(64 * LN_DEEP_WAVES), 0, st, p);
