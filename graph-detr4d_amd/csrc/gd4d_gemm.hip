@@ -157,7 +157,10 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_bf16x3_kernel(const GemmParam
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + 64 * wn + 32 * ni + l32;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    float bv = p.bias ? p.bias[n] : 0.f;
+    // (the bias has arrived before the first store is issued: said once here - first used inside the per-row branches below,
+    // every use after a store could only wait the counter down to zero, i.e. for that store's acknowledgement: 64 in turn)
+    asm volatile("" : "+v"(bv));
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
