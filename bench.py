@@ -694,8 +694,12 @@ def _train_kernel_figures(a, n_cams, levels, dev):
                                       'table_GBps': records * 1024 / (t_all - t_prep) / 1e3,
                                       'gradient_bytes_written': sum(n_cams * 256 * h * w * 4 for h, w in levels),
                                       'note': 'd(pyramid) of all layers in one pass: every pixel written once, no atomics on feature data'}
+    # (counter bytes: the committed PMC pass of tools/bench_raw_bwd.py on this workload, while its source hash matches)
+    traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn_sliced_bwd.hip', 'r*_pmc_cross_attn_dot_sliced.json') \
+        if getattr(a, 'value_dtype', 'fp32') == 'fp32' else (None, None)
     roofline = {'kernel': 'gd4d_cross_attn_dot_sliced (backward gather, per decoder layer)', 'bound': 'hbm',
-                'achieved': alg / dot_us / 1e3, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / dot_us / 1e3 / 8000.0, 'traffic': None,
+                'achieved': alg / dot_us / 1e3, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / dot_us / 1e3 / 8000.0,
+                'traffic': traffic, 'traffic_source': traffic_source,
                 'algorithmic_bytes_per_launch': alg, 'us_per_launch': dot_us,
                 'note': 'algorithmic bytes as SURVEY 8(d) defines them for the forward gather (Dh = 32 projected channels per corner); '
                         'the kernel gathers 256 raw channels per corner (kernels.cross_attn_dot_sliced.gathered_GBps)'}
