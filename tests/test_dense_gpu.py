@@ -20,6 +20,32 @@ def test_linear_matches_fp64(m, k, n):
     assert (got.double() - ref).abs().max().item() < 2e-5 * max(1.0, math.sqrt(k) / 4)
 
 
+@pytest.mark.parametrize('k', [256, 1024])
+@pytest.mark.parametrize('wkn', [False, True])
+@pytest.mark.parametrize('x2', [False, True])
+@pytest.mark.parametrize('res', [False, True])
+def test_linear_branch_free_forms_match_fp64(k, wkn, x2, res):
+    """The instantiations of linear_kernel for K % 64 == 0 (a chunk's loads issued as one batch): plain / transposed weight /
+    addend on every column / residual operands, 4 waves and the 8-wave form of K >= 768, with row and column tails."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(k + 2 * wkn + 4 * x2 + 8 * res)
+    for m, n in ((900, 256), (37, 24), (130, 1024)):
+        x = torch.randn(m, k)
+        xa = torch.randn(m, k) if x2 else None
+        w = torch.randn(n, k) * 0.05
+        w[min(3, n - 1), 2] = 2.5                                    # asymmetric landmark
+        b = None if wkn else torch.randn(n)
+        r1, r2 = (torch.randn(m, n), torch.randn(m, n)) if res else (None, None)
+        wd = (w.t().contiguous() if wkn else w).cuda()                # weight_kn: the (K, N) layout
+        c = lambda t: None if t is None else t.cuda()                # noqa: E731
+        got = ops.linear_fwd(x.cuda(), wd, c(b), x2=c(xa), r1=c(r1), r2=c(r2), weight_kn=wkn).cpu()
+        ref = F.linear((x + xa if x2 else x).double(), w.double(), None if b is None else b.double())
+        if res:
+            ref = ref + r1.double() + r2.double()
+        assert got.shape == (m, n)
+        assert (got.double() - ref).abs().max().item() < 2e-5 * max(1.0, math.sqrt(k) / 4) * (3 if res else 1)
+
+
 def test_linear_fused_epilogue_and_input_addend():
     """y = relu((x + x2 [cols < 512]) W^T + b) + r1 + r2  - the in-projection / FFN / output_proj forms."""
     from graph_detr4d_amd import ops
