@@ -472,6 +472,31 @@ def test_mha_core_dropout_matches_fp64_with_the_same_mask(l, b, mask, p):
     assert torch.equal(out0, out00)
 
 
+def test_mha_core_dropout_with_different_query_and_key_counts():
+    """Lq != Lk (the general MultiheadAttention call): the element ids of the dropout draw use both extents; forward and the
+    two backward kernels against fp64 with the mask rebuilt on the host."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(21)
+    lq, lk, b, h, d, p = 50, 77, 2, 8, 32, 0.3
+    q = torch.randn(lq, b, h * d)
+    k, v = torch.randn(lk, b, h * d), torch.randn(lk, b, h * d)
+    do = torch.randn(lq, b, h * d)
+    am = torch.randn(lq, lk)
+    seed = ops.mha_dropout_seed('cuda')
+    out, lse = ops.mha_core_fwd(q.cuda(), k.cuda(), v.cuda(), h, am.cuda(), want_lse=True, dropout_p=p, seed=seed)
+    dq, dk, dv = ops.mha_core_bwd(q.cuda(), k.cuda(), v.cuda(), out, do.cuda(), lse, h, am.cuda(), dropout_p=p, seed=seed)
+    keep = ops.mha_dropout_keep_mask(seed, b, h, lq, lk, p).cpu()
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    heads = lambda t, n: t.reshape(n, b * h, d).transpose(0, 1)       # noqa: E731
+    sc = torch.bmm(heads(qd, lq) / math.sqrt(d), heads(kd, lk).transpose(1, 2)) + am.double()
+    pm = sc.softmax(-1) * keep.view(b * h, lq, lk).double() / (1 - p)
+    o = torch.bmm(pm, heads(vd, lk)).transpose(0, 1).reshape(lq, b, h * d)
+    assert (out.cpu().double() - o).abs().max().item() < 4e-5
+    o.backward(do.double())
+    for got, want in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+        assert (got.cpu().double() - want).abs().max().item() < 2e-4
+
+
 def test_multihead_attention_train_mode_runs_the_hip_core_with_dropout(monkeypatch):
     """In train mode (attn_drop = 0.1, the reference's setting) the module keeps the core on the HIP kernels: the seed
     counter follows torch.manual_seed (same seed, same output and gradients), consecutive calls draw different masks, and
