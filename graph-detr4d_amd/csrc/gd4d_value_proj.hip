@@ -559,6 +559,7 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
   if (single) { if (hm) go(value_proj_astat_kernel<W, true, true, true>); else go(value_proj_astat_kernel<W, true, false, true>); } \
   else if (ob) { if (hm) go(value_proj_astat_kernel<W, true, true, false>); else go(value_proj_astat_kernel<W, true, false, false>); } \
   else { if (hm) go(value_proj_astat_kernel<W, false, true, false>); else go(value_proj_astat_kernel<W, false, false, false>); }
+#ifdef GD4D_DEV                                      // ablation forms (some compute nothing or store nothing): -DGD4D_DEV builds only
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("GD4D_VA_DBG"); dbg = e ? atoi(e) : 0; }
   if (dbg & 16) {                                               // dev: the trace buffer rides in the workspace's tail
@@ -593,6 +594,7 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
     }
     return check_launch();
   }
+#endif
   GD4D_VA_DISPATCH(8)
 #undef GD4D_VA_DISPATCH
   return check_launch();
