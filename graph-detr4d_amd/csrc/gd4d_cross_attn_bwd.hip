@@ -192,13 +192,23 @@ __global__ __launch_bounds__(GD4D_WAVE * WAVES) void cross_attn_bwd_block(const 
         float d[4] = {0.f, 0.f, 0.f, 0.f};            // <g_h, v_corner>
         const bool ok[4] = {vk && x0ok && y0ok, vk && x1ok && y0ok, vk && x0ok && y1ok, vk && x1ok && y1ok};
         const float bw[4] = {(1.f - dx) * (1.f - dy), dx * (1.f - dy), (1.f - dx) * dy, dx * dy};
+        // the four corners' value rows requested together (a load under `if (ok[c])`, each followed by the corner's atomics,
+        // was one round trip per corner); corners outside the map read the level's first pixel and are dropped by the select
+        int pixc[4];
+        float4 valc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int pix = ok[c] ? p.lvl_start[l] + (y0 + (c >> 1)) * W + (x0 + (c & 1)) : -1;   // head-group uniform
-          if (ok[c]) {
-            const float4 val = *reinterpret_cast<const float4*>(vrow + (size_t)pix * kBC + lane * 4);
-            d[c] = (g.x * val.x + g.y * val.y) + (g.z * val.z + g.w * val.w);
-          }
+          pixc[c] = ok[c] ? p.lvl_start[l] + (y0 + (c >> 1)) * W + (x0 + (c & 1)) : -1;   // head-group uniform
+          valc[c] = *reinterpret_cast<const float4*>(vrow + (size_t)max(pixc[c], p.lvl_start[l]) * kBC + lane * 4);
+        }
+        asm volatile("" : "+v"(valc[0].x), "+v"(valc[0].y), "+v"(valc[0].z), "+v"(valc[0].w), "+v"(valc[1].x), "+v"(valc[1].y),
+                          "+v"(valc[1].z), "+v"(valc[1].w), "+v"(valc[2].x), "+v"(valc[2].y), "+v"(valc[2].z), "+v"(valc[2].w),
+                          "+v"(valc[3].x), "+v"(valc[3].y), "+v"(valc[3].z), "+v"(valc[3].w));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int pix = pixc[c];
+          const float4 val = valc[c];
+          d[c] = ok[c] ? (g.x * val.x + g.y * val.y) + (g.z * val.z + g.w * val.w) : 0.f;
           const float s = wq * bw[c];
           // scatter: instruction i adds channels [64 i, 64 i + 64) of this corner's pixel rows; lane -> channel
           // 64 i + lane, whose head's pixel and weight come from that head's lane group

@@ -88,9 +88,10 @@ def test_channels_last_levels_train_in_place(name):
         assert _rel(a.grad, b.grad) < 1e-5
 
 
-def test_bf16_value_storage_trains_on_the_raw_pyramid():
+def test_bf16_value_storage_trains_on_the_raw_pyramid(monkeypatch):
     """value_dtype='bf16' with autograd on: the copy the gathers read is stored bf16 (features rounded, products and sums fp32);
     output and gradients stay within bf16 rounding of the fp32 module's."""
+    monkeypatch.setenv('GD4D_TRAIN_VALUES', 'raw')           # (what the test is about, whatever the caller's environment says)
     g = Golden('deform_n6')
     m = g.meta
     outs = {}
