@@ -459,7 +459,14 @@ __global__ __launch_bounds__(64) void value_proj_heads_kernel(const HeadProjPara
   hp4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = hp4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+  // the epilogue's operands, requested before the K loop (a wave is alone on its SIMD here: read where they are used - per
+  // element, between the stores - each wsum load waited for the store before it)
+  float e_bias[NT], e_ws[4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) e_bias[t] = p.bias ? p.bias[h * 16 * NT + t * 16 + i] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e_ws[r] = p.wsum[(size_t)min(r0 + 4 * g + r, p.M - 1) * p.HH + h];
+#pragma unroll 4
   for (int kb = 0; kb < kChannels / 32; ++kb) {                // the k order inside a block is (8 g + e): any order sums
     const float4 a0 = *reinterpret_cast<const float4*>(ap + 32 * kb), a1 = *reinterpret_cast<const float4*>(ap + 32 * kb + 4);
     const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -472,15 +479,17 @@ __global__ __launch_bounds__(64) void value_proj_heads_kernel(const HeadProjPara
       for (int e = 0; e < 8; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bb[e], acc[t], 0, 0, 0);
     }
   }
+  asm volatile("" : "+v"(e_ws[0]), "+v"(e_ws[1]), "+v"(e_ws[2]), "+v"(e_ws[3]));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(e_bias[t]));
   // D layout: lane (n = i, g) register r = row 4 g + r
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = h * 16 * NT + t * 16 + i;
-    const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int orow = r0 + 4 * g + r;
-      if (orow < p.M) p.out[(size_t)orow * kChannels + col] = fmaf(bv, p.wsum[(size_t)orow * p.HH + h], acc[t][r]);
+      if (orow < p.M) p.out[(size_t)orow * kChannels + col] = fmaf(e_bias[t], e_ws[r], acc[t][r]);
     }
   }
 }
