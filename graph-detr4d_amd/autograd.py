@@ -91,15 +91,19 @@ class RawPyramid:
     def __init__(self):
         self.pyramid = self.shapes = None
         self.layers = self.pending = 0
+        self.layer_q = []                              # queries per sample of every registered layer
         self.needs_grad = self.channels_last = False
         self.copy_dtype = torch.float32
         self.main = self.side = None
         self.sink = self.grads = self._dpart = None
         self._forked = self._prepared = False
 
-    def register(self):
+    def register(self, q):
+        """A layer (one CrossAttnRawFunction node) with `q` queries per sample: the passes that share this pyramid
+        (Detr3DTransformer.forward_shared: student queries, then teacher_queries) need not agree on it."""
         self.layers += 1
         self.pending += 1
+        self.layer_q.append(int(q))
         return self.layers - 1
 
     def _fork(self):
@@ -116,6 +120,9 @@ class RawPyramid:
             return
         if self.sink is None:
             self.sink = ops.PyramidGrad(self.pyramid, 0, plan.b, plan.q, plan.num_heads)
+        if (plan.b, plan.num_heads) != (self.sink.b, self.sink.hh) or self.layer_q[layer] != plan.q:
+            raise ops._lib.Gd4dError(f'RawPyramid: layer {layer} registered with {self.layer_q[layer]} queries hands in a plan of '
+                                     f'(B, Q, Hh) = ({plan.b}, {plan.q}, {plan.num_heads}); the sink has B = {self.sink.b}, Hh = {self.sink.hh}')
         self._fork()                                 # the plan was written on the main stream
         with torch.cuda.stream(self.side):
             self.sink.add_layer(layer, plan)
@@ -134,7 +141,7 @@ class RawPyramid:
         """First backward node of the step: the table for every registered layer; scan + fill + sort on the side stream."""
         if not self.needs_grad or self._prepared or self.sink is None:
             return
-        self.sink.alloc_table(self.layers)
+        self.sink.alloc_table(self.layer_q)
         self._fork()
         with torch.cuda.stream(self.side):
             self.sink.prepare()
@@ -221,7 +228,7 @@ class CrossAttnRawFunction(torch.autograd.Function):
         order = Fn.query_order(ref, pc_range)
         plan = ops.cross_attn_plan_fwd(raw.pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, hh,
                                        query_order=order, raw_cam_weights=raw_cam)
-        ctx.layer = raw.register()
+        ctx.layer = raw.register(plan.q)
         if ctx.needs_input_grad[0]:
             raw.count(ctx.layer, plan)
         agg = ops.cross_attn_agg_sliced_fwd(plan)
@@ -336,47 +343,74 @@ class ValueProjMultiFunction(torch.autograd.Function):
 # are queued during the backward pass and issued sixteen per launch (gd4d_linear_bwd_weight_group) - at the latest from a
 # callback the autograd engine runs when the backward pass ends (inside a hipGraph capture that is still inside the capture).
 # GD4D_TRAIN_DEFER_WGRAD=0: one launch per Linear, where autograd reaches it.
-_WGRAD_QUEUE, _LN_QUEUE = [], []
-_WGRAD_TASK = [None]          # the backward pass (autograd graph task) the queued entries belong to
 _WGRAD_GROUP, _LN_GROUP = 16, 32
+_MAX_TASKS = 4
+# One pair of queues per backward pass (autograd graph-task id): a nested / re-entrant backward (reentrant checkpointing,
+# autograd.grad inside a hook) has its own id and must neither flush nor drop the outer pass's entries.  A pass that raised
+# never runs its callback and leaves its queues behind: they are never added to anything and are evicted, oldest id first,
+# once more than _MAX_TASKS passes have queues (passes nest two deep at most in this package).
+_DEFERRED = {}                # task id -> {'w': [...], 'ln': [...]}
 
 
-def _flush_deferred():
-    global _WGRAD_QUEUE, _LN_QUEUE
-    queue, _WGRAD_QUEUE = _WGRAD_QUEUE, []
-    for i in range(0, len(queue), _WGRAD_GROUP):
-        ops.linear_bwd_weight_group(queue[i:i + _WGRAD_GROUP], accumulate=True)
-    queue, _LN_QUEUE = _LN_QUEUE, []
-    for i in range(0, len(queue), _LN_GROUP):
-        ops.layernorm_bwd_reduce_group(queue[i:i + _LN_GROUP], accumulate=True)
+def _issue(kind, entries):
+    if kind == 'w':
+        ops.linear_bwd_weight_group(entries, accumulate=True)
+    else:
+        ops.layernorm_bwd_reduce_group(entries, accumulate=True)
+
+
+def _flush_deferred(task=None):
+    """Issue what `task` (default: every pass) has queued.  Entries of one launch never share a target: see _queue_deferred."""
+    for t in ([task] if task is not None else list(_DEFERRED)):
+        queues = _DEFERRED.pop(t, None)
+        if not queues:
+            continue
+        for kind, group in (('w', _WGRAD_GROUP), ('ln', _LN_GROUP)):
+            q = queues[kind]
+            for i in range(0, len(q), group):
+                _issue(kind, q[i:i + group])
 
 
 def _deferring():
-    """The current backward pass (graph task id) if parameter gradients may be queued, else None."""
+    """The current backward pass (graph task id, 0 for the first pass of a process) if parameter gradients may be queued,
+    else None - test with `is not None`."""
     if os.environ.get('GD4D_TRAIN_DEFER_WGRAD', '1') == '0' or not hasattr(torch._C, '_current_graph_task_id'):
         return None
     task = torch._C._current_graph_task_id()
     return task if task >= 0 else None
 
 
-def _queue_deferred(queue, entry, group):
+def _targets(kind, entry):
+    tensors = entry[2:4]                              # (.., main_w, main_b) / (.., main_gamma, main_beta)
+    return [t.data_ptr() for t in tensors if t is not None]
+
+
+def _queue_deferred(kind, entry, group):
     task = _deferring()
-    if _WGRAD_TASK[0] != task:
-        del _WGRAD_QUEUE[:]                           # left behind by a backward pass that raised: never add those
-        del _LN_QUEUE[:]
-        _WGRAD_TASK[0] = task
-    if not _WGRAD_QUEUE and not _LN_QUEUE:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
-    queue.append(entry)
-    if len(queue) >= group:
-        _flush_deferred()
+    queues = _DEFERRED.get(task)
+    if queues is None:
+        while len(_DEFERRED) >= _MAX_TASKS:
+            del _DEFERRED[min(_DEFERRED)]             # left behind by a backward pass that raised
+        queues = _DEFERRED[task] = {'w': [], 'ln': [], 'busy': {'w': set(), 'ln': set()}}
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_deferred(task))
+    q, busy = queues[kind], queues['busy'][kind]
+    tg = _targets(kind, entry)
+    # the grouped kernels add with a plain read-modify-write per problem: two problems of ONE launch that add into the same
+    # gradient view (a module applied twice, the head's branches shared by all levels when with_box_refine=False,
+    # detr3d_head_pe.py:410-413, tied weights) would race - such an entry starts a new launch
+    if any(t in busy for t in tg) or len(q) >= group:
+        _issue(kind, q[:])
+        del q[:]
+        busy.clear()
+    q.append(entry)
+    busy.update(tg)
 
 
 def _queue_weight_grad(x, grad_y, main_w, main_b):
     if _deferring() is None:
         ops.linear_bwd_weight(x, grad_y, want_bias=main_b is not None, into=(main_w, main_b))
         return
-    _queue_deferred(_WGRAD_QUEUE, (x, grad_y, main_w, main_b), _WGRAD_GROUP)
+    _queue_deferred('w', (x, grad_y, main_w, main_b), _WGRAD_GROUP)
 
 
 class LinearFunction(torch.autograd.Function):
@@ -482,9 +516,9 @@ class LayerNormFunction(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         dg = db = None
         if ctx.main is not None:                          # dgamma / dbeta added to the flat gradient buffer by the kernels
-            if _deferring():                              # ... the column reduce queued with the weight gradients
+            if _deferring() is not None:                  # ... the column reduce queued with the weight gradients
                 dx, ws, mc = ops.layernorm_bwd(x, gamma, beta, grad_y, ctx.eps, res=res, relu=ctx.relu, defer=True)
-                _queue_deferred(_LN_QUEUE, (ws, mc, ctx.main[0], ctx.main[1]), _LN_GROUP)
+                _queue_deferred('ln', (ws, mc, ctx.main[0], ctx.main[1]), _LN_GROUP)
             else:
                 dx, _, _ = ops.layernorm_bwd(x, gamma, beta, grad_y, ctx.eps, res=res, relu=ctx.relu, into=ctx.main)
         else:

@@ -19,7 +19,10 @@ struct PyramidGeom {
 };
 
 // plan = [header: kPlanHdr ints per position, padded to 256 B][pairs: (position, head, pass < cap_t, 64) uint2]
+// GD4D_CA_PLAN_ITEMS: [the same header][items: (position, head, item < cap_i) x {u, v, camera row, M}{level weight 0..3}];
+// cap_i * 32 <= cap_t * 512, so gd4d_cross_attn_plan_bytes covers both forms
 static inline int plan_cap_t(int N, int P) { return (N * P + 3) / 4; }      // passes of 4 items a head can need
+static inline int plan_cap_items(int N, int P) { return (N * P + 15) & ~15; }  // GD4D_CA_PLAN_ITEMS: 32-byte records a head can need
 static inline size_t plan_hdr_bytes(int B, int Q) { return (((size_t)B * Q * kPlanHdr * sizeof(int)) + 255) & ~(size_t)255; }
 
 }  // namespace gd4d

@@ -51,6 +51,8 @@ struct PlanParams {
   int* hdr;
   uint2* pair;
   int cap_t;               // passes reserved per head
+  float4* item;            // GD4D_CA_PLAN_ITEMS: the plan holds ITEMS (two float4 each, below) instead of pairs; else nullptr
+  int cap_i;               // items reserved per head (a multiple of 16)
 };
 
 template <int HH, int LT, int WAVES>
@@ -150,6 +152,33 @@ __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // wave-private list: no workgroup barrier
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (pp.item) {
+      // ITEMS form (the inference step): 32 bytes per visible (camera, point) item - {u, v, camera row, M} {weight of
+      // level 0..3} - instead of 4 levels x 4 corners x {offset, weight} = 128: the eight slices of a query re-read their
+      // plan a phase (~12 us) apart, too far for the L2, and the pairs were 107 of the gather's 499 MB of fabric reads
+      // (profiles/r03_pmc_cross_attn_sliced.json).  The corner arithmetic moves into the gather, lane = (item, level), 16
+      // items per step (gd4d_cross_attn_agg_items_fwd), which also sums wsum.  M rides in every record: the gather needs
+      // one round trip, not header-then-items (record 0 is written for M = 0 too).
+      float4* out = pp.item + ((size_t)pos * HH + h) * pp.cap_i * 2;
+      for (int it0 = 0; it0 < max(M, 1); it0 += GD4D_WAVE) {
+        const int item = it0 + lane;
+        if (item < max(M, 1)) {
+          const float4 rec = M ? items[item] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int rk = __float_as_int(rec.z);
+          const int row = rk / PT, k = rk % PT;
+          const int lb = p.B == 1 ? 0 : row % p.B;                          // logits of batch (row % B) (:277)
+          const float* aw = s_aw + lb * HH * LP + h * LP + k;
+          float wl[4];
+#pragma unroll
+          for (int l = 0; l < 4; ++l) wl[l] = (l < LT && M) ? aw[l * PT] * rec.w : 0.f;
+          out[item * 2] = make_float4(rec.x, rec.y, __int_as_float(row), __int_as_float(M));
+          out[item * 2 + 1] = make_float4(wl[0], wl[1], wl[2], wl[3]);
+        }
+      }
+      if (lane == 0) pp.hdr[pos * kPlanHdr + h] = M;
+      __builtin_amdgcn_wave_barrier();                                     // the list is rewritten for the next head
+      continue;
+    }
     uint2* out = pp.pair + ((size_t)pos * HH + h) * pp.cap_t * 64;
     const float* aw_h = s_aw + h * LP + min(l_of, LT - 1) * PT;             // + (row % B) * HH * LP + point
     const int m_pad = (M + 3) & ~3;                                         // whole passes: items past M repeat the last one, weight 0
@@ -317,6 +346,152 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_sliced_kernel(con
   int pos, sl;
   if (!sliced_walk(p, blockIdx.x, pos, sl)) return;
   cross_attn_agg_sliced_body<HH, LT, VT, POLICY>(p, pos, sl, s_raw);
+  trace_mark(g_trace_sliced, 0x86ull);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gather from the ITEMS form of the plan (GD4D_CA_PLAN_ITEMS; the inference step's default).  Same walk, same pass loop
+// and the same products in the same order as cross_attn_agg_sliced_body - results are bit-identical to it - but the
+// {offset, weight} pairs of a pass are worked out HERE from 32-byte item records, lane = (item % 16, level), 16 items
+// (four passes) per step, and parked in the wave's LDS patch in the layout the pass loop reads.  That is ~45 vector
+// instructions per four passes on top of the ~160 the passes cost, for a plan a quarter of the size: the pairs were
+// 107 MB of the 499 MB a launch pulled over the fabric, because the eight slices of a query read them a phase apart.
+// The slice-0 workgroup of a query also sums wsum (same lanes, same order as the plan kernel's pairs form).
+struct ItemsParams {
+  SlicedParams s;
+  PyramidGeom g;
+  const float4* item;
+  float* wsum;                  // (BQ, HH), written by the workgroups of slice 0
+  int cap_i;
+};
+
+template <int HH, int LT, typename VT, int POLICY>
+__device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip, const int pos, const int sl, char* s_raw) {
+  const SlicedParams& p = ip.s;
+  constexpr int ES = sizeof(VT);
+  constexpr int CH = 4;                                   // passes per step = 16 items (20 KB of LDS per workgroup of 8 waves)
+  constexpr int GP = 80;                                  // LDS bytes per corner slot: 64 B of pairs + 16 B pad (conflict-free b128)
+  constexpr int PASS = 8 * GP;
+  const int lane = threadIdx.x & 63;
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = p.slice_lo + sl;
+  const int i_of = lane >> 2, l_of = lane & 3;
+  const float4* rec = ip.item + ((size_t)pos * HH + h) * ip.cap_i * 2;
+  // speculative: the first 16 records (cap_i >= 16; what lies past M is replaced below before it is used)
+  float4 a = rec[i_of * 2];
+  float wl = reinterpret_cast<const float*>(rec + i_of * 2 + 1)[l_of];
+  const int bq = p.order ? p.order[pos] : pos;
+  char* my = s_raw + h * (CH * PASS);
+  const int g = lane >> 3, c = lane & 7;
+  const char* rd = my + g * GP;
+  // where the four pairs of this lane go inside their pass: [g][j], g = (item & 1, corner), j = (item >> 1 & 1, level)
+  char* wr = my + (i_of >> 2) * PASS + ((i_of & 1) << 2) * GP + ((((i_of >> 1) & 1) << 2) | l_of) * 8;
+  const char* base[LT];
+#pragma unroll
+  for (int l = 0; l < LT; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
+  const unsigned lane_off = (unsigned)(c * 4 * ES);
+  int lw = ip.g.lvl_w[0], lh = ip.g.lvl_h[0];
+  unsigned cstr = ip.g.cam_stride[0];
+#pragma unroll
+  for (int l = 1; l < LT; ++l)
+    if (l_of == l) { lw = ip.g.lvl_w[l]; lh = ip.g.lvl_h[l]; cstr = ip.g.cam_stride[l]; }
+  const float flw = (float)lw, flh = (float)lh;
+  const float lvl_on = l_of < LT ? 1.f : 0.f;
+
+  const int M = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));       // every record carries its head's count
+  const int T = (M + 3) >> 2;
+  if (M < 16 && M > 0) {                                                    // wave-uniform: items past M repeat the last one
+    const int src = (min(i_of, M - 1) << 2) | l_of;
+    a.x = __shfl(a.x, src); a.y = __shfl(a.y, src); a.z = __shfl(a.z, src); wl = __shfl(wl, src);
+  }
+  f2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+  float wsum_lane = 0.f;
+  for (int it0 = 0; it0 < M; it0 += 16) {
+    const int item = it0 + i_of;
+    const int m_pad = (M + 3) & ~3;
+    {
+      const int row = __float_as_int(a.z);
+      const float x = fmaf(a.x, flw, -0.5f);
+      const float y = fmaf(a.y, flh, -0.5f);
+      const float xf = floorf(x), yf = floorf(y);
+      const float dx = x - xf, dy = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float live = item < M ? lvl_on : 0.f;
+      const unsigned rbase = (unsigned)row * cstr;
+      if (it0 > 0) __builtin_amdgcn_wave_barrier();                        // the previous step's passes have read the patch
+#pragma unroll
+      for (int c_of = 0; c_of < 4; ++c_of) {
+        const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
+        // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
+        const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
+        const float in = (xc == xi && yc == yi) ? live : 0.f;
+        const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
+        const float w = (wl * wx * wy) * in;
+        const unsigned off = rbase + (unsigned)(yc * lw + xc) * ip.g.pix_stride;
+        wsum_lane += w;
+        if (item < m_pad && l_of < LT) *reinterpret_cast<uint2*>(wr + c_of * GP) = make_uint2(off, __float_as_uint(w));
+      }
+    }
+    if (it0 + 16 < M) {                                                     // the next step's records fly under this step's passes
+      const int nx = min(item + 16, M - 1);
+      a = rec[nx * 2];
+      wl = reinterpret_cast<const float*>(rec + nx * 2 + 1)[l_of];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // wave-private LDS patch: no workgroup barrier
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int t0 = it0 >> 2;
+    const int nt = min(CH, T - t0);
+    for (int k = 0; k < nt; ++k) {
+      const uint4* row = reinterpret_cast<const uint4*>(rd + k * PASS);
+      uint4 pr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = row[i];                          // pairs j = 2 i, 2 i + 1: {off, w, off, w}
+      const bool second = (t0 + k) * 4 + 2 < M;                            // wave-uniform: items 2, 3 of the pass exist
+      float4 val[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((j & 3) >= LT) continue;
+        if (j >= 4 && !second) break;
+        const unsigned o = ((j & 1) ? pr[j >> 1].z : pr[j >> 1].x) + lane_off;
+        const VT* ap = reinterpret_cast<const VT*>(base[j & 3] + o);
+        if (POLICY == 3) val[j] = make_float4(__uint_as_float(o), 0.f, 0.f, 0.f);   // dev: no loads - the issue floor
+        else val[j] = Quad<VT>::load(ap);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((j & 3) >= LT) continue;
+        if (j >= 4 && !second) break;
+        const float w = __uint_as_float((j & 1) ? pr[j >> 1].w : pr[j >> 1].y);
+        const f2v ww = {w, w};
+        acc0 = __builtin_elementwise_fma(ww, f2v{val[j].x, val[j].y}, acc0);
+        acc1 = __builtin_elementwise_fma(ww, f2v{val[j].z, val[j].w}, acc1);
+      }
+    }
+  }
+  float4 acc = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+  // the 8 corner slots meet in a fixed order (deterministic)
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+    acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+  }
+  if (g == 0) *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4) = acc;
+  if (s == 0 && ip.wsum) {                                                 // wave-uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wsum_lane += __shfl_xor(wsum_lane, o);
+    if (lane == 0) ip.wsum[(size_t)bq * HH + h] = wsum_lane;
+  }
+}
+
+template <int HH, int LT, typename VT, int OCC, int POLICY>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_kernel(const ItemsParams ip) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
+  trace_mark(g_trace_sliced, 6ull);
+  int pos, sl;
+  if (!sliced_walk(ip.s, blockIdx.x, pos, sl)) return;
+  cross_attn_agg_items_body<HH, LT, VT, POLICY>(ip, pos, sl, s_raw);
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
@@ -498,6 +673,9 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
   pp.hdr = static_cast<int*>(plan);
   pp.pair = reinterpret_cast<uint2*>(static_cast<char*>(plan) + plan_hdr_bytes(B, Q));
   pp.cap_t = plan_cap_t(N, P);
+  pp.item = nullptr;
+  pp.cap_i = plan_cap_items(N, P);
+  if (flags & GD4D_CA_PLAN_ITEMS) pp.item = reinterpret_cast<float4*>(pp.pair);   // same place, a quarter of the bytes
   return GD4D_OK;
 }
 
@@ -594,6 +772,77 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
     case 4: return bf16 ? launch_sliced<4, uint16_t>(p, L, s) : launch_sliced<4, float>(p, L, s);
     case 8: return bf16 ? launch_sliced<8, uint16_t>(p, L, s) : launch_sliced<8, float>(p, L, s);
     default: return bf16 ? launch_sliced<16, uint16_t>(p, L, s) : launch_sliced<16, float>(p, L, s);
+  }
+}
+
+namespace gd4d {
+template <int HH, typename VT>
+static int launch_items(const ItemsParams& ip, int L, hipStream_t s) {
+  const SlicedParams& p = ip.s;
+  const size_t lds = (size_t)HH * 4 * 8 * 80;                       // [HH][CH][8][GP]
+  const dim3 grid(8 * ((p.per_xcd + p.blk - 1) / p.blk) * p.blk * p.slice_n);
+  auto go = [&](auto kern) -> int {
+    if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * HH), lds, s, ip);
+    return check_launch();
+  };
+#ifdef GD4D_DEV                                      // dev A/B (GD4D_SLICED_VARIANT): 1 / 2 = 8 / 4 waves per SIMD, 5 = no feature loads
+  {
+    const char* e = getenv("GD4D_SLICED_VARIANT");
+    const int variant = e ? atoi(e) : 0;
+    if (HH == 8 && L == 4 && sizeof(VT) == 4) {
+      switch (variant) {
+        case 1: return go(cross_attn_agg_items_kernel<HH, 4, VT, 8, 0>);
+        case 2: return go(cross_attn_agg_items_kernel<HH, 4, VT, 4, 0>);
+        case 5: return go(cross_attn_agg_items_kernel<HH, 4, VT, 6, 3>);
+        default: break;
+      }
+    }
+  }
+#endif
+  constexpr int OCC = HH == 16 ? 4 : 6;                             // waves per SIMD
+  switch (L) {
+    case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, OCC, 0>);
+    case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, OCC, 0>);
+    case 3: return go(cross_attn_agg_items_kernel<HH, 3, VT, OCC, 0>);
+    default: return go(cross_attn_agg_items_kernel<HH, 4, VT, OCC, 0>);
+  }
+}
+}  // namespace gd4d
+
+extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                             int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
+                                             float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                             const int32_t* query_order, int slice_lo, int slice_n, void* stream) {
+  using namespace gd4d;
+  ItemsParams ip{};
+  if (int rc = fill_sliced_params(ip.s, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order,
+                                  slice_lo, slice_n))
+    return rc;
+  if (!level_hw || !cam_stride_bytes) return GD4D_EINVAL;
+  if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
+  for (int l = 0; l < 4; ++l) { ip.g.lvl_w[l] = 1; ip.g.lvl_h[l] = 1; ip.g.cam_stride[l] = 0; }
+  for (int l = 0; l < L; ++l) {
+    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+    if (h <= 0 || w <= 0 || cam_stride_bytes[l] < 0) return GD4D_EINVAL;
+    const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
+                                    (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
+    if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EUNSUPPORTED;
+    ip.g.lvl_w[l] = w; ip.g.lvl_h[l] = h; ip.g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
+  }
+  ip.g.pix_stride = (unsigned)pix_stride_bytes;
+  ip.item = reinterpret_cast<const float4*>(ip.s.pair);
+  ip.wsum = wsum;
+  ip.cap_i = plan_cap_items(N, P);
+#ifdef GD4D_DEV
+  { const char* e = getenv("GD4D_SLICED_BLK"); const int blk = e ? atoi(e) : 0; if (blk > 0 && blk < ip.s.per_xcd) ip.s.blk = blk; }
+#endif
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool bf16 = feats_dtype == GD4D_BF16;
+  switch (Hh) {
+    case 4: return bf16 ? launch_items<4, uint16_t>(ip, L, s) : launch_items<4, float>(ip, L, s);
+    case 8: return bf16 ? launch_items<8, uint16_t>(ip, L, s) : launch_items<8, float>(ip, L, s);
+    default: return bf16 ? launch_items<16, uint16_t>(ip, L, s) : launch_items<16, float>(ip, L, s);
   }
 }
 

@@ -640,9 +640,10 @@ class LateValues:
         (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
         if self.mode == 'sliced':
             # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
+            # GD4D_PLAN=pairs: the 128-bytes-per-item form the training kernels read (bit-identical results)
             plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                            cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
-                                           query_order=order)
+                                           query_order=order, items=os.environ.get('GD4D_PLAN', 'items') != 'pairs')
             self._wait_copy()
             agg = ops.cross_attn_agg_sliced_fwd(plan)
             if vp_weight is not None:

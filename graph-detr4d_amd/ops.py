@@ -239,17 +239,28 @@ def cross_attn_plan_bytes(b, n, q, num_heads, points=4):
 
 class Plan:
     """Output of cross_attn_plan_fwd: the plan buffer, the locality order it is stored by, the pyramid it addresses and
-    wsum (B, Q, Hh) - the sum of the in-bounds sampling weights per head."""
+    wsum (B, Q, Hh) - the sum of the in-bounds sampling weights per head (items form: filled by the gather, not by the
+    plan kernel).  items: the buffer holds the ITEMS form (include/gd4d.h, GD4D_CA_PLAN_ITEMS) - gather only; the
+    training backward kernels need the pairs form."""
 
-    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum):
+    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False):
         self.buf, self.order, self.pyramid, self.b, self.q, self.num_heads, self.wsum = buf, order, pyramid, b, q, num_heads, wsum
+        self.items = bool(items)
+
+    def need_pairs(self, who):
+        if self.items:
+            raise _lib.Gd4dError(f'{who} reads the pairs form of the plan; this one was made with items=True')
+
+
+CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS = 1, 2
 
 
 def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, num_heads,
-                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None):
+                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None, items=False):
     """gd4d_cross_attn_plan_fwd: projection + mask + softmax + camera weights + bilinear corners of one decoder layer's
     cross-attention -> what gd4d_cross_attn_agg_sliced_fwd walks on `pyramid` (a PyramidView).  The other arguments as
-    cross_attn_fwd; plan: a Plan to overwrite.  Returns Plan [, mask (B, N, Q, Hh, P) uint8] [, uv (B, N, Q, Hh, P, 2)]."""
+    cross_attn_fwd; plan: a Plan to overwrite; items: the 32-bytes-per-item form (the corners are worked out by the gather,
+    which then also fills wsum).  Returns Plan [, mask (B, N, Q, Hh, P) uint8] [, uv (B, N, Q, Hh, P, 2)]."""
     lib = _lib.load()
     b, q = ref.shape[0], ref.shape[1]
     n = lidar2img.shape[1]
@@ -262,7 +273,7 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
     nbytes = cross_attn_plan_bytes(b, n, q, hh, p)
     buf = torch.empty(nbytes, device=ref.device, dtype=torch.uint8) if plan is None else plan.buf
     wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32) if plan is None else plan.wsum
-    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum)
+    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items)
     mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
     uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
     rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
@@ -273,7 +284,8 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
         _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w),
         lv, cs, pyramid.pix_stride, _dev(buf, 'plan', torch.uint8), buf.numel(), _dev(wsum, 'wsum', f32),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None, b, n, q, hh, nl, p,
-        1 if raw_cam_weights else 0, None if query_order is None else _order_ptr(query_order, b * q), _stream())
+        (CA_RAW_CAM_WEIGHTS if raw_cam_weights else 0) | (CA_PLAN_ITEMS if items else 0),
+        None if query_order is None else _order_ptr(query_order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_plan_fwd')
     res = (plan,)
     if want_mask:
@@ -297,6 +309,16 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
     if agg is None:
         agg = torch.empty(b, q, hh, 256, device=dev, dtype=f32)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
+    if plan.items:
+        lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in pyramid.level_hw for x in hw])
+        cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
+        code = lib.gd4d_cross_attn_agg_items_fwd(
+            ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
+            _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, 4,
+            _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+            None if query_order is None else _order_ptr(query_order, b * q), int(slices[0]), int(slices[1]), _stream())
+        _lib.check(code, 'gd4d_cross_attn_agg_items_fwd')
+        return agg
     code = lib.gd4d_cross_attn_agg_sliced_fwd(
         ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32), b, pyramid.rows // b, q, hh,
         256, nl, 4, _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
@@ -367,6 +389,7 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None):
     """gd4d_cross_attn_dot_sliced: D[pair] = <grad_agg[q, h], raw pixel of the pair> for every pair of `plan`, as 8 per-slice
     partials (uint8 buffer of gd4d_cross_attn_dot_bytes; only the passes the plan uses are written)."""
     lib = _lib.load()
+    plan.need_pairs('gd4d_cross_attn_dot_sliced')
     pyramid = plan.pyramid
     b, q, hh = plan.b, plan.q, plan.num_heads
     n = pyramid.rows // b
@@ -457,8 +480,8 @@ class PyramidGrad:
     """The gradient of an NCHW pyramid from the plans of all decoder layers (gd4d_pyramid_grad_count / _scan / _fill /
     _reduce): add_layer() per layer (in any order, each with its plan and its grad_agg rows), finish() once.
 
-    Buffers are sized for `layers` layers of B*Q*Hh rows; the slot / record buffers by the plans' capacity (8 bytes per
-    pair a plan can hold - only what the counts say is touched)."""
+    Buffers are sized for `layers` layers of B*Q*Hh rows (alloc_table with a list: per-layer Q); the slot / record buffers by
+    the plans' capacity (8 bytes per pair a plan can hold - only what the counts say is touched)."""
 
     def __init__(self, pyramid, layers, b, q, num_heads, chunk_walk=True):
         self.pyramid, self.layers, self.b, self.q, self.hh = pyramid, int(layers), int(b), int(q), int(num_heads)
@@ -472,7 +495,7 @@ class PyramidGrad:
         if self.chunks <= 0:
             raise _lib.Gd4dError('gd4d_pyramid_grad_chunks: unsupported pyramid')
         self.count = torch.zeros(self.chunks, device=dev, dtype=torch.int32)
-        self.table = None
+        self.table, self.layer_q = None, {}
         if self.layers > 0:
             self.alloc_table(self.layers)
         self.slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, self.q, self.hh, 4))
@@ -480,23 +503,47 @@ class PyramidGrad:
         self.order = _chunk_walk(pyramid.level_hw, pyramid.rows, dev) if chunk_walk else None
 
     def alloc_table(self, layers):
-        """The grad_agg table for `layers` layers (zeros: a layer whose backward never runs contributes nothing)."""
-        self.layers = int(layers)
-        self.table = torch.zeros(self.layers, self.b * self.q, self.hh, 256, device=self.pyramid.device, dtype=torch.float32)
+        """The grad_agg table (zeros: a layer whose backward never runs contributes nothing).  layers: a count (every layer
+        has the constructor's Q) or a list of per-layer query counts - the passes of Detr3DTransformer.forward_shared share
+        one pyramid but need not have the same number of queries (teacher_queries, detr3d_head_pe.py:560-566)."""
+        qs = [self.q] * int(layers) if isinstance(layers, int) else [int(x) for x in layers]
+        for layer, q in self.layer_q.items():
+            if layer < len(qs) and qs[layer] != q:
+                raise _lib.Gd4dError(f'PyramidGrad: layer {layer} was counted with {q} queries, the table is asked for {qs[layer]}')
+        self.layers = len(qs)
+        self.table_q = qs
+        self.row_base = [0]
+        for q in qs:
+            self.row_base.append(self.row_base[-1] + self.b * q * self.hh)
+        if self.row_base[-1] >= 1 << 26:
+            raise _lib.Gd4dError('PyramidGrad: more than 2^26 table rows (a record keeps its row in 26 bits)')
+        self.table = torch.zeros(max(self.row_base[-1], 1), 256, device=self.pyramid.device, dtype=torch.float32)
 
     def grad_agg_rows(self, layer):
-        """(B, Q, Hh, 256) view of the table: where layer `layer`'s gd4d_value_proj_heads_bwd writes."""
-        return self.table[layer].view(self.b, self.q, self.hh, 256)
+        """(B, Q_layer, Hh, 256) view of the table: where layer `layer`'s gd4d_value_proj_heads_bwd writes."""
+        return self.table[self.row_base[layer]:self.row_base[layer + 1]].view(self.b, self.table_q[layer], self.hh, 256)
 
     def add_layer(self, layer, plan):
-        """Hand every record of `plan` its slot (the plan is kept until finish(): its buffer must not be overwritten)."""
+        """Hand every record of `plan` its slot (the plan is kept until finish(): its buffer must not be overwritten).  The
+        plan's own (B, Q, Hh) say where its pairs are; B and Hh must be the sink's (they fix the pyramid rows / the table's
+        row width), Q is per layer."""
         lib = _lib.load()
-        slots = torch.empty(self.slot_bytes, device=self.pyramid.device, dtype=torch.uint8)
+        plan.need_pairs('gd4d_pyramid_grad_count')
+        layer = int(layer)
+        if plan.b != self.b or plan.num_heads != self.hh or plan.pyramid.rows != self.pyramid.rows:
+            raise _lib.Gd4dError(f'PyramidGrad: plan of (B, Hh, rows) = ({plan.b}, {plan.num_heads}, {plan.pyramid.rows}) handed to a '
+                                 f'sink of ({self.b}, {self.hh}, {self.pyramid.rows})')
+        if self.table is not None and (layer >= self.layers or self.table_q[layer] != plan.q):
+            raise _lib.Gd4dError(f'PyramidGrad: layer {layer} has {plan.q} queries, the table was made for '
+                                 f'{self.table_q[layer] if layer < self.layers else "fewer layers"}')
+        self.layer_q[layer] = plan.q
+        slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, plan.q, self.hh, 4))
+        slots = torch.empty(slot_bytes, device=self.pyramid.device, dtype=torch.uint8)
         code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), self._lv, self._cs, self.pyramid.pix_stride,
-                                           _dev(self.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(self.slot_bytes),
-                                           self.b, self.n, self.q, self.hh, len(self.pyramid.level_hw), 4, _stream())
+                                           _dev(self.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(slot_bytes),
+                                           self.b, self.n, plan.q, self.hh, len(self.pyramid.level_hw), 4, _stream())
         _lib.check(code, 'gd4d_pyramid_grad_count')
-        self.plans.append((int(layer), plan, slots))
+        self.plans.append((layer, plan, slots))
 
     def prepare(self):
         """scan + fill + sort: the layers' records bucketed by chunk and grouped by pixel.  Needs the counts of every layer
@@ -510,14 +557,17 @@ class PyramidGrad:
         code = lib.gd4d_pyramid_grad_scan(_dev(self.count, 'count', i32), _dev(start, 'start', i32), _dev(ws, 'workspace'),
                                           ctypes.c_size_t(wsb), self.chunks, _stream())
         _lib.check(code, 'gd4d_pyramid_grad_scan')
-        nbytes = max(len(self.plans), 1) * self.slot_bytes
+        if self.table is None:
+            raise _lib.Gd4dError('PyramidGrad.prepare: alloc_table() first (the records carry table rows)')
+        nbytes = max(sum(slots.numel() for _, _, slots in self.plans), self.slot_bytes)
         records = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        rows_per_layer = self.b * self.q * self.hh
         for layer, plan, slots in self.plans:
+            if layer >= self.layers or self.table_q[layer] != plan.q:
+                raise _lib.Gd4dError(f'PyramidGrad: layer {layer} ({plan.q} queries) does not match the table')
             code = lib.gd4d_pyramid_grad_fill(
                 _dev(plan.buf, 'plan', torch.uint8), _dev(slots, 'slots'), _dev(start, 'start', i32), _dev(records, 'records'),
-                layer * rows_per_layer, None if plan.order is None else _order_ptr(plan.order, self.b * self.q),
-                self.b, self.n, self.q, self.hh, 4, _stream())
+                self.row_base[layer], None if plan.order is None else _order_ptr(plan.order, self.b * plan.q),
+                self.b, self.n, plan.q, self.hh, 4, _stream())
             _lib.check(code, 'gd4d_pyramid_grad_fill')
         sorted_ = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         pxoff = torch.empty(self.chunks, 65, device=dev, dtype=i32)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 34
+#define GD4D_ABI_VERSION 35
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -55,6 +55,7 @@ enum {
 #define GD4D_MAX_LEVELS 8
 #define GD4D_MAX_LAYERS 8
 #define GD4D_CA_RAW_CAM_WEIGHTS 1
+#define GD4D_CA_PLAN_ITEMS 2      /* gd4d_cross_attn_plan_fwd: write the ITEMS form of the plan (gd4d_cross_attn_agg_items_fwd) */
 
 int gd4d_abi_version(void);
 const char* gd4d_error_string(int code);
@@ -181,8 +182,21 @@ int gd4d_value_proj_heads_fwd(const float* agg, const float* wsum, const float* 
  *   pixel-major copy of gd4d_pyramid_channels_last_fwd (pix 1024, slice 128) and caller-owned channels-last (NHWC) levels
  *   read in place without any copy (per-level pointers, pix 1024, slice 128; bf16: half of each).  slice_lo / slice_n:
  *   the slices of this launch (0, 8 = all).  query_order: the one the plan was made with (scheduling only: results are
- *   bit-identical for any permutation).  Supported: C == 256, P == 4, L <= 4, N <= 64, B <= 16, Hh in {4, 8, 16}. */
+ *   bit-identical for any permutation).  Supported: C == 256, P == 4, L <= 4, N <= 64, B <= 16, Hh in {4, 8, 16}.
+ *
+ * The ITEMS form of the plan (flags & GD4D_CA_PLAN_ITEMS; what the inference step uses).  The eight slices of a query
+ *   read their plan a phase apart - too far for the L2 - so the plan's bytes are paid eight times over the fabric.  In
+ *   this form gd4d_cross_attn_plan_fwd stores 32 bytes per visible (camera, point) item - {u, v, camera row, count}
+ *   {softmax x camera weight of level 0..3} - instead of 4 levels x 4 corners x {offset, weight} = 128 bytes, does not
+ *   touch `wsum`, and gd4d_cross_attn_agg_items_fwd does the corner arithmetic itself (lane = (item, level), 16 items per
+ *   step, the same operations in the same order: agg and wsum are bit-identical to the pairs form) from the geometry
+ *   arguments, which must be the ones the plan was made with.  wsum (B*Q, Hh) is written by the launch that contains
+ *   slice 0 (NULL: not wanted).  The training backward kernels read the pairs form only. */
 size_t gd4d_cross_attn_plan_bytes(int B, int N, int Q, int Hh, int P);
+int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                  int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
+                                  float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                  const int32_t* query_order, int slice_lo, int slice_n, void* stream);
 int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
                              const float* lidar2img, const double* pc_range, float img_h, float img_w,
                              const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,

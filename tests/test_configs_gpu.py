@@ -297,9 +297,12 @@ def test_config4_two_query_sets_over_one_pyramid_match_oracle_run_twice():
     torch.testing.assert_close(got[0][0].cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)   # the reference's own output
 
 
-def test_config4_shared_projection_gradients_equal_two_separate_passes():
+@pytest.mark.parametrize('extra_teacher_queries', [0, 7])
+def test_config4_shared_projection_gradients_equal_two_separate_passes(extra_teacher_queries):
     """Training: with the value tensors shared between the student's two passes (one autograd node), every gradient
-    equals the one obtained with two independent forward() calls."""
+    equals the one obtained with two independent forward() calls - also when the teacher hands in its own number of queries
+    (detr3d_head_pe.py:560-566 takes teacher_queries as they come): the passes then share the pyramid's gradient sink with
+    different per-layer query counts."""
     g = Golden('decoder_deform')
     m = g.meta
     n = m['num_cams']
@@ -313,7 +316,7 @@ def test_config4_shared_projection_gradients_equal_two_separate_passes():
     regs.load_state_dict(g.state(prefix='reg.'), strict=True)
     regs = regs.to(DEV)
     qe_s = g.t('query_embed').to(DEV)
-    qe_t = (torch.randn(qe_s.shape[0], 512, generator=torch.Generator().manual_seed(45)) * 0.5).to(DEV)
+    qe_t = (torch.randn(qe_s.shape[0] + extra_teacher_queries, 512, generator=torch.Generator().manual_seed(45)) * 0.5).to(DEV)
     grads = []
     for shared in (True, False):
         feats = [f.to(DEV).requires_grad_() for f in g.feats()]

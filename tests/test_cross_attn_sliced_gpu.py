@@ -13,12 +13,18 @@ pytestmark = pytest.mark.gpu
 ATOL = RTOL = 1e-4        # fp32 path: only summation order differs from the reference (north_star: 1e-3)
 
 
-def _sliced(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads=8, order=None, want=False, slices=None):
+ITEMS = True              # module default of _sliced: the plan form of the inference step (32-byte items; the gather works out the
+                          # corners and wsum); every test below also checks it against the pairs form, bit for bit
+
+
+def _sliced_form(items, pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads=8, order=None, want=False, slices=None):
     from graph_detr4d_amd import ops
     b, q = ref.shape[0], ref.shape[1]
     res = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads,
-                                  want_mask=want, want_uv=want, query_order=order)
+                                  want_mask=want, want_uv=want, query_order=order, items=items)
     plan = res[0] if want else res
+    if items:
+        plan.wsum.fill_(float('nan'))                # the gather (slice 0) must write every row
     if slices is None:
         agg = ops.cross_attn_agg_sliced_fwd(plan)
     else:                                            # the slices in several launches, any order
@@ -26,6 +32,28 @@ def _sliced(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads=8, 
         for lo, n in slices:
             ops.cross_attn_agg_sliced_fwd(plan, slices=(lo, n), agg=agg)
     return (agg, plan.wsum) + (tuple(res[1:]) if want else ())
+
+
+def _sliced(*args, **kwargs):
+    """Both forms of the plan; they must agree bit for bit (same products, same order); returns the items form's result."""
+    got = _sliced_form(ITEMS, *args, **kwargs)
+    other = _sliced_form(not ITEMS, *args, **kwargs)
+    for a, b in zip(got, other):
+        assert torch.equal(a, b), 'items form and pairs form of the plan disagree'
+    return got
+
+
+def test_items_plan_is_refused_by_the_training_kernels():
+    from graph_detr4d_amd import _lib, ops, synthetic
+    torch.manual_seed(1)
+    fd = [torch.randn(1, 6, 256, h, w).cuda() for h, w in [(16, 28), (8, 14)]]
+    sp, shp = ops.pyramid_slice_planar_fwd(fd)
+    l2i = torch.from_numpy(synthetic.camera_rig(1)).unsqueeze(0).cuda()
+    plan = ops.cross_attn_plan_fwd(ops.PyramidView.slice_planar(sp, shp), torch.rand(1, 9, 3).cuda(), torch.randn(1, 9, 8, 4, 3).cuda(),
+                                   torch.randn(1, 9, 8, 2, 4).cuda(), torch.randn(1, 9, 6).cuda(), l2i, synthetic.PC_RANGE, 900, 1600, 8,
+                                   items=True)
+    with pytest.raises(_lib.Gd4dError):
+        ops.cross_attn_dot_sliced(plan, torch.zeros(1, 9, 8, 256).cuda())
 
 
 def test_slice_planar_is_the_reference_flatten_transpose_cat():

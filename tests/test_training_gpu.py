@@ -273,6 +273,35 @@ def test_weight_gradients_accumulated_by_the_kernels_equal_autograds():
     assert not any(hasattr(p, '_gd4d_main_grad') for p in params)
 
 
+def test_queued_weight_gradients_of_a_module_applied_twice_do_not_race():
+    """A parameter used by several nodes of one backward pass (the head's cls / reg branches are ONE module for all six levels
+    when with_box_refine=False, detr3d_head_pe.py:410-413; tied weights): its queued weight-gradient entries must not share a
+    grouped launch (the kernels add with a plain read-modify-write).  Gradients equal autograd's, run to run identical."""
+    from graph_detr4d_amd import dist as D, functional as Fn
+    torch.manual_seed(5)
+    nn = torch.nn
+    branch = nn.Sequential(nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(), nn.Linear(256, 10)).to(DEV)
+    xs = [torch.randn(300, 256, device=DEV) for _ in range(6)]
+    params = list(branch.parameters())
+
+    def loss_of(apply):
+        return sum((apply(x) ** 2).mean() * (i + 1) for i, x in enumerate(xs))
+    loss_of(branch).backward()
+    want = [p.grad.clone() for p in params]
+    red = D.FlatGradAllReducer(params)
+    red.bind(fuse_weight_grads=True)
+    runs = []
+    for _ in range(3):
+        red.zero_grad()
+        loss_of(lambda x: Fn.sequential_autograd(branch, x)).backward()
+        runs.append([p.grad.clone() for p in params])
+    red.unfuse()
+    for g, w in zip(runs[0], want):
+        torch.testing.assert_close(g, w, rtol=1e-4, atol=1e-5 * float(w.abs().max()) + 1e-9)
+    for other in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], other))
+
+
 def test_decoder_trains_with_kernel_accumulated_and_queued_gradients():
     """Six SGD steps of the 2-layer decoder with every shortcut of the training step on (raw pyramid, weight gradients added to
     the flat buffer by the kernels, queued and grouped; pyramid trained too): the loss goes down, and the parameters end where

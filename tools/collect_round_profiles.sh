@@ -16,7 +16,7 @@ cp $g/pmc_fwd/pmc_summary.txt profiles/${pre}_pmc_cross_attn.txt
 cp $g/pmc_step/pmc_summary.txt profiles/${pre}_pmc_step_inflight1.txt
 cp $g/pmc_rawbwd/pmc_summary.txt profiles/${pre}_pmc_train_raw_backward.txt
 python3 tools/make_pmc_record.py $g/pmc_sliced/pmc_summary.txt profiles/${pre}_pmc_cross_attn_sliced.json \
-  "tools/bench_sliced.py: 900 x 24 x 4 levels, fp32 slice-planar pyramid; one launch = the gather of one decoder layer" cross_attn_agg_sliced_kernel gd4d_cross_attn_sliced.hip
+  "tools/bench_sliced.py: 900 x 24 x 4 levels, fp32 slice-planar pyramid; one launch = the gather of one decoder layer (items form of the plan)" cross_attn_agg_items_kernel gd4d_cross_attn_sliced.hip
 python3 tools/make_pmc_record.py $g/pmc_agg/pmc_summary.txt profiles/${pre}_pmc_cross_attn_agg.json \
   "tools/bench_late.py: 900 x 24 x 4 levels, fp32 channels-last pyramid; one launch = the row-form aggregate of one decoder layer" cross_attn_agg_kernel gd4d_cross_attn_late.hip
 python3 tools/make_pmc_record.py $g/pmc_fwd/pmc_summary.txt profiles/${pre}_pmc_cross_attn.json \

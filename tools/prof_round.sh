@@ -34,7 +34,7 @@ for which in sliced:tools/bench_sliced.py:--iters:3 agg:tools/bench_late.py:--it
   done
   python3 tools/pmc_summary.py gpurun_out/$tag/pmc_$name > /dev/null
 done
-grep -A 14 "cross_attn_agg_sliced" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | head -16
+grep -A 14 "cross_attn_agg_items" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | head -16
 # the query side of the step (row chains, attention core): issue / MFMA / LDS / wait counters, one sample in flight
 bash tools/prof_pmc.sh $tag/pmc_step bench.py --inflight 1 --no-roofline --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
 grep -A 40 "row_chain_kernel\|mha_core_kernel" gpurun_out/$tag/pmc_step/pmc_summary.txt | head -100

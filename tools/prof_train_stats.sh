@@ -9,7 +9,11 @@ find gpurun_out/$tag/stats -name '*kernel_trace.csv' -delete
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open('gpurun_out/$tag/stats/train_kernel_stats.csv')))
-steps=7+2
+import json
+# timed + warm-up steps as the bench line reports them (the script's own --steps 5 --warmup 2 unless "$@" overrode them) + the two
+# untimed passes bench.py runs before them (the eager check pass and the first pass that binds the gradient buffer)
+line=json.loads([l for l in open('gpurun_out/$tag/profiled.json') if l.startswith('{')][-1])
+steps=int(line['steps'])+int(line['warmup'])+2
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('kernel time per step (ms):', round(tot/steps/1e6,3))
 for r in rows[:28]:
