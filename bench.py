@@ -64,6 +64,7 @@ def parse():
                     help='--mode train/distill with several ranks: eager backward, every bucket\'s all-reduce starts from a '
                          'post-accumulate hook while the backward of the layers below is still running')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-preflight', action='store_true', help='N > 1: skip the rank / device / all-reduce-alone check before the timed steps')
     ap.add_argument('--dropout', action='store_true', help='--mode train: modules in train() mode (dropout 0.1 as the reference trains); default: eval mode, autograd on')
     ap.add_argument('--no-fuse-wgrad', action='store_true', help='--mode train: leave the accumulation of parameter gradients to autograd')
     ap.add_argument('--no-roofline', action='store_true', help='dev: skip the kernel-level roofline section (roofline = null)')
@@ -158,6 +159,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     D.init(backend=backend, device=dev)              # "nccl" = RCCL; no-op for a single process
+    # N > 1: before anything is timed - the rank count, who sits on which device, one all-reduce alone at the gradient sizes
+    # of the decoder / an R50 model / a VoVNet-99 model (so that a scaling record separates transport from compute)
+    a.preflight = None
+    if world > 1 and not a.no_preflight:
+        mb = os.environ.get('GD4D_PREFLIGHT_MB', '22,140,330' if backend == 'nccl' else '2,8')
+        a.preflight = D.preflight(a.gpus, dev, sizes=[int(float(x) * (1 << 20)) for x in mb.split(',') if x])
+        if rank == 0:
+            print('[bench] preflight ' + json.dumps(a.preflight), file=sys.stderr)
 
     import graph_detr4d_amd as G
     from graph_detr4d_amd import _lib, ops, synthetic
@@ -340,6 +349,7 @@ def main():
                        'baseline_config': 'configs[2]', 'launch': launch, 'inflight': n_req, 'input_layout': a.input_layout, 'global_batch': n_req * a.gpus,
                        'samples_per_step': n_req * a.gpus,
                        'parallelism': f'replicas x{a.gpus}' if a.gpus > 1 else 'single GPU'},
+            'preflight': a.preflight,
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3, 'allreduce_bytes_per_step': 0,
             'one_in_flight': None if single_ms is None else {
@@ -470,6 +480,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     def criterion_loss(all_cls, all_box):
         return sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box)).values())
 
+    from graph_detr4d_amd.criterion import instance_distill_loss
+
     def distill_loss():
         t_tr, t_regs, t_cls, t_feats, t_queries, s_cls = teacher
         with torch.no_grad():                                           # mix_distill.py:92-96
@@ -479,13 +491,9 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             feats, [query_embed, t_queries], reg_branches=regs, img_metas=metas)
         guided = Fn.head_outputs(g_states, g_init, g_refs, s_cls, regs, synthetic.PC_RANGE)
         loss = (s_states ** 2).mean()                                   # stand-in for the student's own loss
-        t_score = t_out['all_cls_scores'].sigmoid()                     # get_instance_distill_loss, reweight_score=True
-        qs = t_score.max(dim=-1, keepdim=True)[0]
-        ncls = t_score.shape[-1]
-        bce = torch.nn.functional.binary_cross_entropy_with_logits(guided['all_cls_scores'], t_score, reduction='none')
-        l1 = (guided['all_bbox_preds'] - t_out['all_bbox_preds']).abs()
-        den = qs.sum(dim=(1, 2, 3)) * ncls + 1e-10                      # per decoder stage
-        return loss + ((qs * bce).sum(dim=(1, 2, 3)) / den).sum() + ((qs * l1).sum(dim=(1, 2, 3)) / den).sum()
+        # get_instance_distill_loss (mix_distill.py:140-168), reweight_score=True, both loss weights 1
+        terms = instance_distill_loss(t_out, dict(guided_cls_scores=guided['all_cls_scores'], guided_bbox_preds=guided['all_bbox_preds']))
+        return loss + sum(terms.values())
 
     def step():
         reducer.zero_grad()
@@ -609,9 +617,11 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                        'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse, 'input_layout': a.input_layout,
                        'dropout': 'on (train mode)' if a.dropout else 'off (modules in eval mode, autograd on)',
                        'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
+            'preflight': a.preflight,
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
             'ms_per_step_rank_max': stats['rank_seconds_max'] / a.steps * 1e3,
             'allreduce_bytes_per_step': reducer.describe()['allreduce_bytes'] if world_size > 1 else 0,
+            'param_bytes': sum(p.numel() * 4 for p in params),
             'allreduce_buckets': reducer.describe()['buckets'],
             'roofline': None, 'cpu_baseline': None,
         }

@@ -205,3 +205,34 @@ class Detr3DCriterion(nn.Module):
         return out
 
     forward = loss
+
+
+def instance_distill_loss(teacher_outs, student_outs, loss_cls_weight=1.0, loss_reg_weight=1.0, reweight_score=True):
+    """The instance distillation terms of the teacher - student step (BASELINE configs[4]):
+    `MixDistill.get_instance_distill_loss` (projects/mmdet3d_plugin/distillation/distillers/mix_distill.py:140-168).
+
+    teacher_outs: dict with `all_cls_scores` (NL, B, Q, classes) and `all_bbox_preds` (NL, B, Q, code) of the teacher's head
+    (detached here, as :150 does); student_outs: dict with `guided_cls_scores` / `guided_bbox_preds` - the student's head on
+    the TEACHER's queries (detr3d_head_pe.py:617-625).  Per decoder stage: BCE-with-logits of the student's logits against
+    the teacher's sigmoid scores and L1 between the box codes, both weighted per query by the teacher's best class score
+    and normalised by `sum(q_score) * classes + 1e-10` (reweight_score, :160-162; note the SAME normaliser for the box term
+    although it has `code` columns), or plain means.  Returns the reference's dictionary
+    (`distill_loss_cls.{i}`, `distill_loss_reg.{i}`).  All stages in one pass of torch ops (the reference loops)."""
+    t_cls = teacher_outs['all_cls_scores'].detach().sigmoid()
+    t_box = teacher_outs['all_bbox_preds'].detach()
+    s_cls, s_box = student_outs['guided_cls_scores'], student_outs['guided_bbox_preds']
+    nl, ncls = t_cls.shape[0], t_cls.shape[-1]
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(s_cls, t_cls, reduction='none')
+    l1 = (s_box - t_box).abs()
+    if reweight_score:
+        qs = t_cls.max(dim=-1, keepdim=True)[0]
+        den = qs.flatten(1).sum(1) * ncls + 1e-10
+        cls_terms = (qs * bce).flatten(1).sum(1) / den
+        reg_terms = (qs * l1).flatten(1).sum(1) / den
+    else:
+        cls_terms, reg_terms = bce.flatten(1).mean(1), l1.flatten(1).mean(1)
+    out = {}
+    for i in range(nl):
+        out[f'distill_loss_cls.{i}'] = cls_terms[i] * loss_cls_weight
+        out[f'distill_loss_reg.{i}'] = reg_terms[i] * loss_reg_weight
+    return out

@@ -39,7 +39,25 @@ constexpr int RC_M = 16;            // rows per workgroup
 #define RC_TILES_N 2
 #endif
 constexpr int RC_WAVES = RC_WAVES_N;
-constexpr int RC_LD = 516;          // floats per LDS row (512 + 4: the float4 row reads of 16 rows spread over the banks)
+// LDS row pitch and the K-permutation of the GEMMs' A operand (round 4).  Lane (row i16, k-group g) of v_mfma_f32_16x16x32
+// takes 8 of a k-step's 32 activations as two ds_read_b128.  With the natural choice (k = 8 g .. 8 g + 7) and a 516-float
+// pitch the 16 lanes one LDS cycle serves ({0-3, 12-15, 20-27}, ...: rows 0-3 / 12-15 of one k-group with rows 4-11 of the
+// next) land on 14 of the 16 four-bank slots: a 2-way conflict in every lane group, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 39 % (profiles/r03_pmc_step_inflight1.txt).  A sum over k may be taken in any order as long as both operands agree, so k-group
+// g takes k = 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 (the weight image and HEADGEMM's global A rows follow): neighbouring
+// k-groups are now ONE slot apart, and with a pitch of 520 floats (8 mod 64: a row = two slots) the rows of a lane group fall
+// on the even slots and the other k-group's rows on the odd ones - conflict-free.  -DRC_KPERM=0 -DRC_LD_N=516 rebuilds round 3.
+#ifndef RC_KPERM
+#define RC_KPERM 1
+#endif
+#ifndef RC_LD_N
+#define RC_LD_N 520
+#endif
+constexpr int RC_W = 512;           // widest row an operation may use
+constexpr int RC_LD = RC_LD_N;      // floats per LDS row
+static_assert(RC_LD >= RC_W + 4 && RC_LD % 4 == 0, "row pitch");
+constexpr int RC_KG = RC_KPERM ? 4 : 8;     // floats between the first pieces of neighbouring k-groups
+constexpr int RC_K2 = RC_KPERM ? 16 : 4;    // floats from a k-group's first piece (4 floats) to its second
 constexpr int RC_BUFS = 4;
 #ifndef RC_DEPTH_N
 #define RC_DEPTH_N 2
@@ -103,7 +121,8 @@ __device__ __forceinline__ void rc_split8x3(const float* v, rc_u4& h, rc_u4& m, 
 __device__ __forceinline__ rc_bf16x8 rc_frag(rc_u4 v) { return __builtin_bit_cast(rc_bf16x8, v); }
 
 // Weight image (gd4d_chain_weight_image): [tile t of 16 output columns][k-step s of 32][hi, lo][lane][8 bf16]; lane l of
-// a fragment holds W[n = 16 t + (l & 15)][k = 32 s + 8 (l >> 4) .. + 8] - the B operand of v_mfma_f32_16x16x32_bf16.
+// a fragment holds W[n = 16 t + (l & 15)][k = 32 s + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3}], g = l >> 4 (RC_KPERM above) - the
+// B operand of v_mfma_f32_16x16x32_bf16.
 // PLANES = 3 (gd4d_chain_weight_image_exact): [hi, mid, lo] - the operand of a GD4D_CHAIN_EXACT GEMM.
 template <int PLANES>
 __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __restrict__ w, char* __restrict__ img, int N, int K) {
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __
   const int n = 16 * t + (lane & 15);
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = n < N ? w[(size_t)n * K + 32 * s + 8 * (lane >> 4) + j] : 0.f;
+  for (int j = 0; j < 8; ++j) v[j] = n < N ? w[(size_t)n * K + 32 * s + RC_KG * (lane >> 4) + (j < 4 ? j : RC_K2 + j - 4)] : 0.f;
   char* dst = img + (size_t)frag * (PLANES * 1024) + lane * 16;
   if (PLANES == 3) {
     rc_u4 h, m, l;
@@ -141,7 +160,7 @@ template <bool EXACT>
 __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   constexpr int FRAG = EXACT ? 3072 : 2048;
   const int i16 = lane & 15, g = lane >> 4;
-  const float* a_row = &bufs[op.src][i16][8 * g];
+  const float* a_row = &bufs[op.src][i16][RC_KG * g];
   const int K = op.K, N = op.N;
   const int steps = K / 32, tiles = (N + 15) / 16;
   const char* img = reinterpret_cast<const char*>(op.p0);
@@ -203,7 +222,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
     auto consume = [&](int d, int j0_) {
       const int j = kstep(j0_);
       const float4 t0 = *reinterpret_cast<const float4*>(a_row + 32 * j);
-      const float4 t1 = *reinterpret_cast<const float4*>(a_row + 32 * j + 4);
+      const float4 t1 = *reinterpret_cast<const float4*>(a_row + 32 * j + RC_K2);
       const float a[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
       if (EXACT) {
         rc_u4 ah, am, al;
@@ -283,7 +302,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       hg[gi] = min((n_base + 16 * TPG * gi) / Dh, heads - 1);
-      ag[gi] = op.p2 + ((size_t)m_ld * heads + hg[gi]) * K + 8 * g;
+      ag[gi] = op.p2 + ((size_t)m_ld * heads + hg[gi]) * K + RC_KG * g;
     }
     rc4 acc[RC_TILES];
 #pragma unroll
@@ -306,7 +325,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
         av[slot][gi][0] = *reinterpret_cast<const float4*>(ag[gi] + 32 * j);
-        av[slot][gi][1] = *reinterpret_cast<const float4*>(ag[gi] + 32 * j + 4);
+        av[slot][gi][1] = *reinterpret_cast<const float4*>(ag[gi] + 32 * j + RC_K2);
       }
     };
     auto consume = [&](int d) {
@@ -355,7 +374,7 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
 // LayerNorm over N columns (N % 64 == 0, N <= 512) of the 16 rows: wave w normalises rows 4 w .. 4 w + 3, 16 lanes per
 // row, a lane owns columns 64 ch + 4 l16 .. + 4 of every 64-column chunk.  gamma / beta are requested first.
 __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
-  constexpr int MAXCH = (RC_LD - 4) / 64;
+  constexpr int MAXCH = RC_W / 64;
   if (wave >= RC_M / 4) return;                                // 4 rows per wave: with more than 4 waves the rest wait at the barrier
   const int row = 4 * wave + (lane >> 4), l16 = lane & 15, N = op.N, nch = N / 64;
   float4 gm[MAXCH], bt[MAXCH], x[MAXCH], ad[MAXCH];
@@ -452,8 +471,8 @@ __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][R
 // to manage, and a hipGraph capture keeps its own copy.  It is read through the kernarg pointer with a run-time index
 // (wave-uniform scalar loads); indexing the by-value struct directly would make the compiler copy it to scratch.
 struct ChainProgram {
-  int nops, M, nops2, split;      // split > 0: workgroups [0, split) run ops[0, nops), workgroups [split, 2 split) run
-  ChainOp ops[GD4D_CHAIN_MAX_OPS];   // ops[nops, nops + nops2) over the SAME rows (gd4d_row_chain2_fwd)
+  int nops, M, nops2, split;      // split > 0: workgroups [0, blocks) run ops[0, nops), workgroups [split, split + blocks) run
+  ChainOp ops[GD4D_CHAIN_MAX_OPS];   // ops[nops, nops + nops2) over the SAME rows (gd4d_row_chain2_fwd); split = blocks up to a multiple of 8
 };
 
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainProgram by_value) {
@@ -464,11 +483,16 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   const ChainProgram* pp = &by_value;
 #endif
   const int M = pp->M, split = pp->split;
+  const int blocks = (M + RC_M - 1) / RC_M;
+  // Two programs: the second one's workgroups start at `split` = blocks rounded up to a multiple of 8, so that row block i of
+  // both programs sits on the SAME XCD (workgroup j is dispatched to XCD j % 8) behind the same L2 - what a SIGNAL / WAIT pair
+  // between the programs relies on; the workgroups in [blocks, split) have nothing to do.
+  if (split > 0 && (int)blockIdx.x >= blocks && (int)blockIdx.x < split) return;
   const bool second = split > 0 && (int)blockIdx.x >= split;       // workgroup-uniform: which of the two programs
   const int op_base = second ? pp->nops : 0;
   const int nops = second ? pp->nops2 : pp->nops;
   const int wg = second ? (int)blockIdx.x - split : (int)blockIdx.x;   // row block
-  const int wg_lo = second ? split : 0, wg_hi = split > 0 ? (second ? 2 * split : split) : (int)gridDim.x;
+  const int wg_lo = second ? split : 0, wg_hi = wg_lo + blocks;
   (void)by_value;
   extern __shared__ __attribute__((aligned(16))) char rc_smem[];
   float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
@@ -635,6 +659,35 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
         }
         break;
       }
+      case GD4D_CHAIN_SIGNAL: {
+        // This row block's global outputs so far (gout of the operations above) are handed to row block wg of the OTHER
+        // program of the launch.  Both sit on one XCD (see `split`), so the L2 is their point of coherence: every thread
+        // waits until its stores have been acknowledged by the L2 (the L1 is write-through), the workgroup meets, one
+        // thread raises the flag with a relaxed agent-scope atomic (performed in the L2; no cache maintenance - an
+        // agent-scope RELEASE would write the whole L2 back on this multi-XCD part).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(op.gout) + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      case GD4D_CHAIN_WAIT: {
+        // ... and the consumer: one thread polls the flag in the L2 (bounded: ~0.2 s, then the error word at gout is
+        // raised and the program goes on - a wrong result that the tests catch instead of a hung GPU), the barrier below
+        // releases the others.  The rows the next LOAD reads were never in this CU's L1 (invalidated at the launch's
+        // start; row blocks are 16 rows of >= 1 KB: no line is shared with another block), so plain loads see them.
+        if (tid == 0) {
+          const unsigned* f = reinterpret_cast<const unsigned*>(op.p0) + wg;
+          unsigned spins = 0;
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (++spins > (1u << 20)) {
+              if (op.gout) atomicAdd(reinterpret_cast<unsigned*>(op.gout), 1u);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        break;
+      }
       default: break;
     }
     __syncthreads();
@@ -683,7 +736,7 @@ extern "C" int gd4d_chain_weight_image_exact(const float* weight, int N, int K, 
   return check_launch();
 }
 
-static int rc_validate(const gd4d_chain_op* program, int nops) {
+static int rc_validate(const gd4d_chain_op* program, int nops, bool two_programs) {
   using namespace gd4d;
   for (int i = 0; i < nops; ++i) {
     const gd4d_chain_op& op = program[i];
@@ -691,40 +744,46 @@ static int rc_validate(const gd4d_chain_op* program, int nops) {
     if (!buf_ok) return GD4D_EINVAL;
     switch (op.kind) {
       case GD4D_CHAIN_LOAD:
-        if (!op.p0 || op.dst < 0 || op.N <= 0 || op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4) return GD4D_EINVAL;
+        if (!op.p0 || op.dst < 0 || op.N <= 0 || op.dst_col < 0 || op.dst_col + op.N > RC_W) return GD4D_EINVAL;
         if ((op.N & 3) == 0 && (op.dst_col & 3) == 0 &&         // the float4 path
             (!aligned16(op.p0) || (op.ld0 & 3) || (op.p1 && (!aligned16(op.p1) || (op.ld1 & 3))))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_GEMM:
         if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout) || (op.p3 && !op.p2)) return GD4D_EINVAL;
-        if (op.K % (32 * RC_DEPTH) != 0 || op.K > RC_LD - 4) return GD4D_EUNSUPPORTED;
-        if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4)) return GD4D_EINVAL;
+        if (op.K % (32 * RC_DEPTH) != 0 || op.K > RC_W) return GD4D_EUNSUPPORTED;
+        if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_W)) return GD4D_EINVAL;
         if (op.dst >= 0 && op.dst == op.src) return GD4D_EINVAL;          // waves would overwrite rows others still read
         if (!aligned16(op.p0)) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_HEADGEMM:
         if (!op.p0 || !op.p2 || !op.p3 || op.K <= 0 || op.N <= 0 || op.ld0 <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
         if (op.N % op.ld0 != 0 || (op.N / op.ld0) % 32 != 0 || op.K % 64 != 0 || op.N % 64 != 0) return GD4D_EUNSUPPORTED;
-        if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_LD - 4)) return GD4D_EINVAL;
+        if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_W)) return GD4D_EINVAL;
         if (!aligned16(op.p0) || !aligned16(op.p2)) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_LAYERNORM:
-        if (!op.p0 || !op.p1 || op.src < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
+        if (!op.p0 || !op.p1 || op.src < 0 || op.N <= 0 || op.N > RC_W || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
         if (op.N % 64 != 0) return GD4D_EUNSUPPORTED;
         if (!aligned16(op.p0) || !aligned16(op.p1) || (op.gout && (!aligned16(op.gout) || (op.ldg & 3)))) return GD4D_EALIGN;
         if (op.p2 && (op.res < 0 || op.res == op.src || op.res == op.dst)) return GD4D_EINVAL;    // second output: its own buffer
         if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_ADD:
-        if (op.src < 0 || op.dst < 0 || op.N <= 0 || op.N > RC_LD - 4 || (op.N & 3)) return GD4D_EINVAL;
+        if (op.src < 0 || op.dst < 0 || op.N <= 0 || op.N > RC_W || (op.N & 3)) return GD4D_EINVAL;
         if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_SMALL_LINEAR:
-        if (!op.p0 || op.src < 0 || op.dst < 0 || op.dst == op.src || op.K <= 0 || op.K > 8 || op.N <= 0 || op.N > RC_LD - 4)
+        if (!op.p0 || op.src < 0 || op.dst < 0 || op.dst == op.src || op.K <= 0 || op.K > 8 || op.N <= 0 || op.N > RC_W)
           return GD4D_EINVAL;
         break;
       case GD4D_CHAIN_REFINE:
         if (op.src < 0 || !op.p0 || !op.gout || (op.dst >= 0 && op.dst == op.src)) return GD4D_EINVAL;
+        break;
+      case GD4D_CHAIN_SIGNAL:
+        if (!op.gout || !two_programs) return GD4D_EINVAL;
+        break;
+      case GD4D_CHAIN_WAIT:
+        if (!op.p0 || !two_programs) return GD4D_EINVAL;
         break;
       default: return GD4D_EINVAL;
     }
@@ -736,17 +795,18 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   using namespace gd4d;
   if (!a || na <= 0 || M <= 0 || nb < 0 || (nb > 0 && !b)) return GD4D_EINVAL;
   if (na + nb > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
-  if (int rc = rc_validate(a, na)) return rc;
+  if (int rc = rc_validate(a, na, nb > 0)) return rc;
   if (nb > 0)
-    if (int rc = rc_validate(b, nb)) return rc;
+    if (int rc = rc_validate(b, nb, true)) return rc;
   const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES;      // row buffers + the prefetch dump area
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
   const int blocks = (M + RC_M - 1) / RC_M;
   ChainProgram prog{};
-  prog.nops = na; prog.M = M; prog.nops2 = nb; prog.split = nb > 0 ? blocks : 0;
+  const int split = nb > 0 ? (blocks + 7) & ~7 : 0;      // second program: same XCD per row block (see the kernel)
+  prog.nops = na; prog.M = M; prog.nops2 = nb; prog.split = split;
   for (int i = 0; i < na; ++i) prog.ops[i] = a[i];
   for (int i = 0; i < nb; ++i) prog.ops[na + i] = b[i];
-  hipLaunchKernelGGL(row_chain_kernel, dim3(nb > 0 ? 2 * blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(row_chain_kernel, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream),
                      prog);
   return check_launch();
 }

@@ -96,6 +96,56 @@ def aggregate_throughput(units_per_rank_step, steps, world, elapsed):
     return units_per_rank_step * steps * world / elapsed
 
 
+def preflight(expected_world, device=None, sizes=(22 << 20, 140 << 20, 330 << 20), iters=5, warmup=2, bucket_plan=None):
+    """What a first multi-GPU run should establish BEFORE the step is timed, so that a scaling record separates transport from
+    compute: (1) the job really has `expected_world` ranks (raises otherwise); (2) every rank's host, device index, device name
+    and PCI bus id (two ranks on one device is a launch mistake that still "works"); (3) one all-reduce alone at each of
+    `sizes` bytes of fp32 - defaults: the decoder's gradient buffer (22 MB), a ResNet-50 model's (~140 MB) and a VoVNet-99
+    model's (~330 MB; SURVEY.md 8e, apis/mmdet_distill_train.py:78-82 is DDP's bucketed all-reduce of these) - barrier-bracketed,
+    MAX over ranks, with the bus bandwidth 2 (N - 1) / N x bytes / t a ring moves per link; (4) the bucket plan of the step.
+    Returns a dict (identical on every rank); N = 1: {'world': 1}.  gloo (CPU tensors) runs the same code in the tests."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != int(expected_world):
+        raise RuntimeError(f'preflight: {world} rank(s) in the process group, the job was asked for {expected_world}')
+    if world == 1:
+        return {'world': 1}
+    import socket
+    cuda = device is not None and torch.device(device).type == 'cuda'
+    on_dev = cuda and dist.get_backend() == 'nccl'
+    me = {'rank': dist.get_rank(), 'host': socket.gethostname(), 'device': str(device) if device is not None else 'cpu'}
+    if cuda:
+        props = torch.cuda.get_device_properties(device)
+        me.update(name=props.name, compute_units=props.multi_processor_count,
+                  pci='%04x:%02x:%02x' % tuple(int(getattr(props, k, -1)) & 0xffff for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')))
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    seen = {}
+    for r in ranks:
+        key = (r['host'], r.get('pci', r['device']))
+        if key in seen and on_dev:
+            raise RuntimeError(f'preflight: ranks {seen[key]} and {r["rank"]} share device {key} - one process per GPU')
+        seen[key] = r['rank']
+    out = {'world': world, 'backend': dist.get_backend(), 'ranks': ranks, 'bucket_plan': bucket_plan, 'allreduce': []}
+    for nbytes in sizes:
+        buf = torch.ones(max(1, int(nbytes) // 4), dtype=torch.float32, device=device if on_dev else 'cpu')
+        for _ in range(warmup):
+            dist.all_reduce(buf)
+            buf.fill_(1.0)
+        sync(device if cuda else None)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dist.all_reduce(buf)
+        if on_dev:
+            torch.cuda.synchronize(device)
+        sec = max_over_ranks((time.perf_counter() - t0) / iters, device)
+        ok = bool(abs(float(buf[0]) - float(world) ** iters) <= 1e-3 * float(world) ** iters)
+        sync(device if cuda else None)
+        out['allreduce'].append({'bytes': buf.numel() * 4, 'ms': sec * 1e3, 'algbw_GBps': buf.numel() * 4 / sec / 1e9,
+                                 'busbw_GBps': 2 * (world - 1) / world * buf.numel() * 4 / sec / 1e9, 'sum_ok': ok})
+        del buf
+    return out
+
+
 class FlatGradAllReducer:
     """Data-parallel gradient averaging over ONE flat fp32 buffer.
 

@@ -158,7 +158,16 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         attention core -> [chain A | reg(l-1), refine, position_encoder(l)] -> aggregate -> chain B'
 
     The locality order of the queries is the one of the initial reference points for every layer (the refinements move a
-    point little; a stale order costs ~2 us per aggregate launch, a fresh one a launch + boundary on the critical path)."""
+    point little; a stale order costs ~2 us per aggregate launch, a fresh one a launch + boundary on the critical path).
+
+    Round 4: position_encoder(l) leaves that second program.  It outlasted chain A by ~12 us per layer although only the
+    refined points are needed before the gather; its rows are first read by chain B's SECOND operation.  It is now the second
+    program of chain B's launch, handed over row block by row block with a SIGNAL / WAIT pair through the XCD's L2 (it is done
+    long before HEADGEMM, chain B's first operation, is):
+
+        attention core -> [chain A | reg(l-1), refine] -> plan -> gather -> [chain B' | position_encoder(l)]
+
+    GD4D_POS_ENCODER=dual keeps round 3's schedule (bit-identical results, tested)."""
     q, _, c = query.shape
     dev = query.device
     layers = list(decoder.layers)
@@ -179,6 +188,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
     ref = reference_points.contiguous()
     pending = None                                       # (reg linears, x of the previous layer, its ref, where the new ref goes)
+    pos_late = os.environ.get('GD4D_POS_ENCODER', 'chainb') != 'dual'
+    if pos_late:
+        blocks = (q + 15) // 16
+        flags = torch.zeros(nl, (blocks + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)     # row-block flags per layer; [-1]: waits that gave up
+        keep.append(flags)
     for lid, layer in enumerate(layers):
         sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
         hh, npt, nlv, ncam = ca.num_heads, ca.num_points, ca.num_levels, ca.num_cams
@@ -207,13 +221,16 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                 prog_b.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
                 src = tmp[i % 2]
             park = 0 if src != 0 else 3
-            prog_b.append(ops.chain_refine(src, ref_prev, new_ref, dst=park))
-            prog_b += _position_ops(ca, pos_feat.view(q, c), ref_buf=park)
+            prog_b.append(ops.chain_refine(src, ref_prev, new_ref, dst=-1 if pos_late else park))
+            if not pos_late:
+                prog_b += _position_ops(ca, pos_feat.view(q, c), ref_buf=park)
             keep += [x_prev, ref_prev]
             ref = new_ref
         else:
-            prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
-        if os.environ.get('GD4D_DEV_SWAP_PROGRAMS') == '1':     # dev: block 0 (the one tools/trace_step.py stamps) runs the second program
+            prog_b = None if pos_late else _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
+        if prog_b is None:                                      # layer 0: the initial reference points need no refinement
+            ops.row_chain_fwd(prog_a, q)
+        elif os.environ.get('GD4D_DEV_SWAP_PROGRAMS') == '1':   # dev: block 0 (the one tools/trace_step.py stamps) runs the second program
             ops.row_chain2_fwd(prog_b, prog_a, q)
         else:
             ops.row_chain2_fwd(prog_a, prog_b, q)
@@ -229,7 +246,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                                            img_h, img_w, order=order)
             first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0)
         x3 = out_all[slot]
-        prog = [first,
+        prog = [first] + ([ops.chain_wait(flags[lid], flags[lid, -1:])] if pos_late else []) + [
                 ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336 (as GEMM addends: slower)
                 ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
                 ops.chain_layernorm(1, layer.norms[1], dst=2),
@@ -255,7 +272,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                 pending = (lins, x3.view(q, c), ref, new_ref)
         elif return_intermediate or last:
             ref_all[slot].copy_(ref)
-        ops.row_chain_fwd(prog, q)
+        if pos_late:
+            # position_encoder(l) on the refined points (in global memory since the dual launch), beside chain B'
+            ops.row_chain2_fwd(prog, _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3)) + [ops.chain_signal(flags[lid])], q)
+        else:
+            ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]
         x = x3.view(q, c)
     del keep

@@ -1374,7 +1374,7 @@ class ChainOp(ctypes.Structure):
                 ('p3', ctypes.c_void_p)]
 
 
-CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM = 1, 2, 3, 4, 5, 6, 7
+CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT = 1, 2, 4, 8
 
 
@@ -1501,6 +1501,19 @@ def chain_refine(src, ref, out, dst=-1):
     """Reference-point refinement of buf[src] (the reg branch's output) and `ref` into `out`; dst >= 0 also parks the
     refined points in buf[dst][:, 0:3]."""
     return ChainOp(kind=CHAIN_REFINE, src=src, dst=dst, res=-1, p0=ref.data_ptr(), gout=out.data_ptr())
+
+
+def chain_signal(flags):
+    """Two-program launches: publish this program's global outputs of its 16 rows to the other program (flags: int32 tensor
+    of >= ceil(M / 16) zeros, one per row block)."""
+    return ChainOp(kind=CHAIN_SIGNAL, src=-1, dst=-1, res=-1, gout=_dev(flags, 'flags', torch.int32).value)
+
+
+def chain_wait(flags, errors=None):
+    """Two-program launches: hold this program until the other program's workgroup of the same 16 rows has signalled on
+    `flags`; errors: optional int32 tensor (1 element) that counts waits that gave up."""
+    return ChainOp(kind=CHAIN_WAIT, src=-1, dst=-1, res=-1, p0=_dev(flags, 'flags', torch.int32).value,
+                   gout=None if errors is None else _dev(errors, 'errors', torch.int32).value)
 
 
 def row_chain_fwd(program, m):

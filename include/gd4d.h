@@ -512,7 +512,7 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  * GEMMs: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (fp32-class, the arithmetic of gd4d_value_proj_fwd);
  * everything else fp32.  M = number of rows. */
 enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_CHAIN_ADD = 4, GD4D_CHAIN_REFINE = 5,
-       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7 };
+       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7, GD4D_CHAIN_SIGNAL = 8, GD4D_CHAIN_WAIT = 9 };
 #define GD4D_CHAIN_RELU 1
 #define GD4D_CHAIN_INV_SIGMOID 2
 #define GD4D_CHAIN_SIGMOID 4        /* GEMM: sigmoid on the output (after the bias / ReLU, before the residual) */
@@ -544,7 +544,13 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * position_encoder - what would otherwise need a second stream and two cross-stream dependencies per layer (10 us each in a
  * replayed graph against 2 us for a boundary on one stream).  nops_a + nops_b <= GD4D_CHAIN_MAX_OPS.
  * REFINE with dst >= 0 also parks the refined point in buf[dst][:, 0..2]; SMALL_LINEAR honours GD4D_CHAIN_INV_SIGMOID on its
- * inputs - together: refinement and position_encoder in one program without a round trip through global memory. */
+ * inputs - together: refinement and position_encoder in one program without a round trip through global memory.
+ * SIGNAL / WAIT (two-program launches only): a hand-off between the programs, row block by row block.  SIGNAL (gout = an
+ * array of >= ceil(M / 16) uint32 flags, zero before the launch) publishes what its program has written to global memory for
+ * its 16 rows so far; WAIT (p0 = the same array; gout = optional uint32 error counter) holds its program until the OTHER
+ * program's workgroup of the same rows has signalled.  Row block i of both programs is dispatched to the same XCD, so the
+ * hand-off goes through that XCD's L2 without cache maintenance.  E.g. position_encoder next to chain B: its rows are needed
+ * by chain B's second operation only.  A WAIT that is not answered within ~0.2 s gives up, counts in gout and goes on. */
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
 

@@ -753,3 +753,28 @@ def head_loss(all_cls_scores, all_bbox_preds, gt_bboxes_list, gt_labels_list, co
     for i, (lc, lb, _) in enumerate(per_layer[:-1]):
         out[f'd{i}.loss_cls'], out[f'd{i}.loss_bbox'] = lc, lb
     return out, [p[2] for p in per_layer]
+
+
+def instance_distill_loss(t_cls_scores, t_bbox_preds, s_cls_scores, s_bbox_preds, loss_cls_weight=1.0, loss_reg_weight=1.0,
+                          reweight_score=True):
+    """ORACLE.  MixDistill.get_instance_distill_loss, projects/mmdet3d_plugin/distillation/distillers/mix_distill.py:140-168,
+    stage by stage as the reference loops: teacher logits / boxes detached (:150), q_score = max class sigmoid (:153-154),
+    BCE-with-logits against the teacher's sigmoid scores (:157), L1 on the box codes (:158), both normalised by
+    sum(q_score) * num_class + 1e-10 when reweight_score (:161-162) else plain means (:164-165); weights :167-168.
+    Pinned by tests/golden/distill_loss*.npz (the reference method itself, tools/gen_golden.py::case_distill)."""
+    out = {}
+    for i in range(len(t_cls_scores)):
+        t_cls = t_cls_scores[i].detach().sigmoid()
+        t_box = t_bbox_preds[i].detach()
+        q_score = torch.max(t_cls, dim=-1, keepdim=True)[0]
+        num_class = t_cls.shape[-1]
+        cls_loss = F.binary_cross_entropy_with_logits(s_cls_scores[i], t_cls, reduction='none')
+        reg_loss = F.l1_loss(s_bbox_preds[i], t_box, reduction='none')
+        if reweight_score:
+            cls_loss = torch.sum(q_score * cls_loss) / (torch.sum(q_score) * num_class + 1e-10)
+            reg_loss = torch.sum(q_score * reg_loss) / (torch.sum(q_score) * num_class + 1e-10)
+        else:
+            cls_loss, reg_loss = torch.mean(cls_loss), torch.mean(reg_loss)
+        out['distill_loss_cls.%d' % i] = cls_loss * loss_cls_weight
+        out['distill_loss_reg.%d' % i] = reg_loss * loss_reg_weight
+    return out

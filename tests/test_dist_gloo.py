@@ -211,3 +211,49 @@ def test_bucketed_overlapped_allreduce_equals_single_shot():
         assert ex1 == ex2 == 3.0
         assert desc['buckets'] == [(16 * 4 + 4) * 4, (16 * 16 + 16) * 4, (8 * 16 + 16) * 4]
         assert desc['allreduce_bytes'] == sum(desc['buckets']) + 4
+
+
+def _preflight_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from graph_detr4d_amd import dist as D
+    D.init(backend='gloo')
+    try:
+        D.preflight(world + 1)
+        wrong = 'accepted'
+    except RuntimeError as e:
+        wrong = str(e)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    red = D.FlatGradAllReducer(net.parameters(), max_extras=2, buckets=[list(net[2].parameters()), list(net[0].parameters())])
+    pre = D.preflight(world, None, sizes=(1 << 16, 1 << 20), iters=3, warmup=1, bucket_plan=red.describe())
+    q.put((rank, wrong, pre, sum(p.numel() * 4 for p in net.parameters())))
+    D.shutdown()
+
+
+def test_preflight_two_ranks_gloo():
+    """bench.py --gpus N runs dist.preflight before the timed steps (make the first RCCL run uneventful): the
+    rank count is asserted, every rank is listed, all-reduces of the given sizes are timed alone and verified, the bucket
+    plan is carried; the bytes a training step all-reduces equal the parameters' bytes (+ the loss normalisers' extras)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, wrong, pre, param_bytes in res:
+        assert 'asked for 3' in wrong
+        assert pre['world'] == 2 and pre['backend'] == 'gloo' and [r['rank'] for r in pre['ranks']] == [0, 1]
+        assert [x['bytes'] for x in pre['allreduce']] == [1 << 16, 1 << 20]
+        assert all(x['sum_ok'] and x['ms'] > 0 and abs(x['busbw_GBps'] - x['algbw_GBps']) < 1e-9 for x in pre['allreduce'])   # N = 2: factor 1
+        plan = pre['bucket_plan']
+        assert plan['allreduce_bytes'] == param_bytes + 4 * 2 and sum(plan['buckets']) == param_bytes
+    assert res[0][2]['allreduce'][0]['ms'] == res[1][2]['allreduce'][0]['ms']        # MAX over ranks: one figure for the job

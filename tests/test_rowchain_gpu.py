@@ -183,3 +183,45 @@ def test_chain_gemm_exact_matches_fp64_to_fp32_class(m, k, n):
     sig = torch.empty(m, n, device=DEV)
     ops.row_chain_fwd([ops.chain_load(0, xd), ops.chain_gemm(0, wd, bd, out=sig, sigmoid=True, exact=True)], m)
     assert (sig.cpu().double() - torch.sigmoid(ref)).abs().max().item() < max(1e-6, fp32)
+
+
+@pytest.mark.parametrize('m', [900, 37, 1, 2700])
+def test_signal_wait_hand_off_between_the_two_programs(m):
+    """SIGNAL / WAIT: the second program writes rows to global memory and signals per row block; the first program, after
+    a GEMM of its own, waits and LOADs them - what run_single does with position_encoder next to chain B.  Equal, bit for
+    bit, to the two programs run one launch after the other; repeated 50 times back to back (a missed hand-off would read
+    the poison the buffer is refilled with before every launch); the give-up counter stays 0; without a second program the
+    operations are refused."""
+    from graph_detr4d_amd import _lib, ops
+    torch.manual_seed(m)
+    x, y = torch.randn(m, 256, device=DEV), torch.randn(m, 3, device=DEV).sigmoid()
+    w1, b1 = torch.randn(256, 256, device=DEV) * 0.06, torch.randn(256, device=DEV)
+    w0, b0 = torch.randn(256, 3, device=DEV), torch.randn(256, device=DEV)
+    w2, b2 = torch.randn(256, 256, device=DEV) * 0.06, torch.randn(256, device=DEV)
+    ln = _ln(256, 3)
+    blocks = (m + 15) // 16
+
+    def producer(out, flags=None):
+        return [ops.chain_load(0, y, inv_sigmoid=True), ops.chain_small_linear(0, w0, b0, 1), ops.chain_layernorm(1, ln, dst=0, relu=True),
+                ops.chain_gemm(0, w2, b2, dst=1), ops.chain_layernorm(1, ln, relu=True, out=out)] + \
+            ([ops.chain_signal(flags)] if flags is not None else [])
+
+    def consumer(pos, out, flags=None, errors=None):
+        return [ops.chain_load(0, x), ops.chain_gemm(0, w1, b1, dst=1)] + \
+            ([ops.chain_wait(flags, errors)] if flags is not None else []) + \
+            [ops.chain_load(3, x, pos), ops.chain_gemm(1, w2, b2, dst=0, res=3, out=out)]
+    pos_ref, out_ref = torch.empty(m, 256, device=DEV), torch.empty(m, 256, device=DEV)
+    ops.row_chain_fwd(producer(pos_ref), m)
+    ops.row_chain_fwd(consumer(pos_ref, out_ref), m)
+    errors = torch.zeros(1, device=DEV, dtype=torch.int32)
+    pos, out = torch.empty(m, 256, device=DEV), torch.empty(m, 256, device=DEV)
+    for _ in range(50):
+        flags = torch.zeros((blocks + 7) // 8 * 8, device=DEV, dtype=torch.int32)
+        pos.fill_(float('nan'))
+        out.fill_(float('nan'))
+        ops.row_chain2_fwd(consumer(pos, out, flags, errors), producer(pos, flags), m)
+        assert torch.equal(pos, pos_ref) and torch.equal(out, out_ref)
+    assert int(errors.item()) == 0
+    assert int(flags[:blocks].sum().item()) == blocks
+    with pytest.raises(_lib.Gd4dError):
+        ops.row_chain_fwd(producer(pos, flags), m)

@@ -1,0 +1,235 @@
+"""Parity at the sizes bench.py times, at the KERNEL boundary (identical fp32 inputs on both sides, so nothing is excluded):
+
+  * gd4d_cross_attn_plan_fwd at 900 queries x 24 cameras x 8 heads x 4 points on the R50 pyramid against the plain-C
+    oracle (oracle/gd4d_oracle.c): mask and uv `array_equal`, zero excluded rows, both forms of the plan; plan + gather +
+    value_proj of the aggregates against the oracle's output on the projected values;
+  * one decoder layer's cross-attention on the DEFAULT training path (raw pyramid: plan + channel-sliced gather forward,
+    gd4d_value_proj_heads_bwd / gd4d_cross_attn_dot_sliced / gd4d_cross_attn_plan_bwd / gd4d_pyramid_grad_* backward) at
+    900 x 24 against torch autograd through oracle/torch_oracle.py: pyramid, query, query_pos, reference points and every
+    parameter incl. value_proj;
+  * the adjoint identity <grad_feats, feats> = <out - b wsum, grad_out> on that path at the VoVNet-99 size (configs[3]);
+  * configs[4] with value_dtype='bf16': two query sets over one pyramid against the oracle's bf16 mode, and the
+    distillation loss terms of `bench.py --mode distill` against the oracle's restatement of mix_distill.py:140-168.
+GPU only."""
+import numpy as np
+import pytest
+import torch
+
+import graph_detr4d_amd as G
+from config_cases import decoder_cfg, oracle_params, reg_branches
+from golden_io import Golden
+from graph_detr4d_amd import ops, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+PC = synthetic.PC_RANGE
+
+
+def _timed_inputs(seed, q=900, frames=4, levels=synthetic.R50_LEVELS, feats_on=DEV):
+    gen = torch.Generator().manual_seed(seed)
+    n = 6 * frames
+    feats = [torch.randn(1, n, 256, h, w, generator=gen).to(feats_on) for h, w in levels]
+    return dict(
+        n=n, q=q, feats=feats, l2i=torch.from_numpy(synthetic.camera_rig(frames)).unsqueeze(0).contiguous(),
+        ref=torch.rand(1, q, 3, generator=gen), offsets=torch.randn(1, q, 8, 4, 3, generator=gen) * 1.5,
+        attn=torch.randn(1, q, 8, len(levels), 4, generator=gen), cam=torch.randn(1, q, n, generator=gen),
+        w_v=torch.randn(256, 256, generator=gen) / 16, b_v=torch.randn(256, generator=gen))
+
+
+@pytest.mark.parametrize('items', [True, False])
+def test_plan_kernel_900q_24cams_bit_exact_vs_c_oracle(items):
+    """the full-size comparisons against the torch oracle exclude up to 8 query rows per layer because
+    the two sides compute the OFFSETS differently.  Here both sides get the same fp32 offsets: every one of the
+    24 x 900 x 8 x 4 = 691 200 mask entries and uv pairs must be equal - no row excluded."""
+    from oracle import c_oracle
+    c = _timed_inputs(31)
+    n, q = c['n'], c['q']
+    d = {k: c[k].to(DEV) for k in ('ref', 'offsets', 'attn', 'cam', 'l2i', 'w_v', 'b_v')}
+    sp, shapes = ops.pyramid_slice_planar_fwd(c['feats'])
+    pyr = ops.PyramidView.slice_planar(sp, shapes)
+    order = ops.query_order_fwd(d['ref'], PC)
+    plan, mask, uv = ops.cross_attn_plan_fwd(pyr, d['ref'], d['offsets'], d['attn'], d['cam'], d['l2i'], PC, 900, 1600, 8,
+                                             want_mask=True, want_uv=True, query_order=order, items=items)
+    agg = ops.cross_attn_agg_sliced_fwd(plan)
+    out = ops.value_proj_heads_fwd(agg, plan.wsum, d['w_v'], d['b_v'])
+    # the oracle works on projected values (the reference's order): value_proj in fp64 on the GPU, rounded once
+    flat = torch.cat([f.flatten(3).permute(0, 1, 3, 2) for f in c['feats']], 2).reshape(n, -1, 256)
+    val = torch.empty(n, flat.shape[1], 256, device=DEV)
+    for r in range(n):
+        val[r] = (flat[r].double() @ d['w_v'].double().t() + d['b_v'].double()).float()
+    o_ref, m_ref, uv_ref = c_oracle.cross_attn_fwd(val.view(n, -1, 8, 32).cpu().numpy(), shapes, c['ref'].numpy(), c['offsets'].numpy(),
+                                                   c['attn'].numpy(), c['cam'].numpy(), c['l2i'].numpy(), PC, 900, 1600)
+    assert m_ref.shape == (1, n, q, 8, 4) and 0.1 < m_ref.mean() < 0.3           # the rig's ~17 % visibility
+    assert np.array_equal(mask.cpu().numpy(), m_ref), 'visibility mask: every entry, no excluded row'
+    assert np.array_equal(uv.cpu().numpy(), uv_ref), 'projected coordinates: every entry, no excluded row'
+    np.testing.assert_allclose(out.cpu().numpy(), o_ref, rtol=1e-4, atol=1e-4)
+    # the projected-value kernel on the oracle's own input, for completeness (one projection routine in all kernels)
+    out_e, mask_e, uv_e = ops.cross_attn_fwd(val.view(n, -1, 8, 32), shapes, d['ref'], d['offsets'], d['attn'], d['cam'], d['l2i'], PC,
+                                             900, 1600, want_mask=True, want_uv=True, query_order=order)
+    assert torch.equal(mask_e, mask) and torch.equal(uv_e, uv)
+    np.testing.assert_allclose(out_e.cpu().numpy(), o_ref, rtol=1e-4, atol=1e-4)
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-12)).item()
+
+
+def test_default_training_backward_900q_24cams_matches_oracle_autograd(monkeypatch):
+    """the default (raw-pyramid) training backward was compared with the oracle at fixture size only.
+    One Deform3DCrossAttn module, eval mode with autograd on, 900 queries x 24 cameras on the R50 pyramid: output and all
+    gradients against CPU autograd through the oracle.  Query rows whose mask differs between the two sides (offsets come
+    from different GEMM routines; at most a handful) get a zero output gradient on BOTH sides, so they contribute to
+    neither gradient - nothing is excluded from the comparison itself."""
+    from oracle import torch_oracle as O
+    monkeypatch.setenv('GD4D_TRAIN_VALUES', 'raw')
+    torch.set_num_threads(16)
+    frames, q = 4, 900
+    n = 6 * frames
+    mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=n, pc_range=PC, num_points=4, embed_dims=256),
+                            dict(batch_first=False))
+    synthetic.randomise_cross_attn_(mod, seed=77)
+    mod = mod.eval()
+    sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    gen = torch.Generator().manual_seed(78)
+    feats = [torch.randn(1, n, 256, h, w, generator=gen) for h, w in synthetic.R50_LEVELS]
+    query, query_pos = torch.randn(q, 1, 256, generator=gen), torch.randn(q, 1, 256, generator=gen)
+    ref = torch.rand(1, q, 3, generator=gen)
+    metas = synthetic.make_img_metas(synthetic.camera_rig(frames), batch=1)
+    gout = torch.randn(q, 1, 256, generator=gen)
+
+    captured = {}
+    orig = ops.cross_attn_plan_fwd
+
+    def spy(*a, **k):
+        res = orig(*a, **{**k, 'want_mask': True})
+        captured['mask'] = res[1]
+        return res[0]
+    monkeypatch.setattr(ops, 'cross_attn_plan_fwd', spy)
+    mod = mod.to(DEV)
+    qd, qpd = query.to(DEV).requires_grad_(), query_pos.to(DEV).requires_grad_()
+    refd = ref.to(DEV).requires_grad_()
+    fd = [f.to(DEV).requires_grad_() for f in feats]
+    out = mod(qd, None, fd, None, query_pos=qpd, reference_points=refd, img_metas=metas)
+    assert 'mask' in captured, 'the module did not take the raw-pyramid training path'
+
+    p_cpu = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    qc, qpc, refc = query.clone().requires_grad_(), query_pos.clone().requires_grad_(), ref.clone().requires_grad_()
+    fc = [f.clone().requires_grad_() for f in feats]
+    out_ref, parts = O.deform3d_cross_attn(p_cpu, qc, fc, qpc, refc, metas, PC, 8, 4, return_parts=True)
+    m_ref = parts['mask'].view(captured['mask'].shape).to(torch.uint8)
+    flipped = (captured['mask'].cpu() != m_ref).any(dim=4).any(dim=3).any(dim=1)[0]           # (Q,)
+    assert int(flipped.sum()) <= 8, int(flipped.sum())
+    keep = ~flipped
+    torch.testing.assert_close(out.detach().cpu()[keep], out_ref.detach()[keep], rtol=5e-4, atol=5e-4)
+    gout = gout * keep.view(q, 1, 1)
+    (out_ref * gout).sum().backward()
+    (out * gout.to(DEV)).sum().backward()
+    # the pyramid: 757 MB of gradient, every element
+    for a, b in zip(fd, fc):
+        assert a.grad is not None and _rel(a.grad.cpu(), b.grad) < 2e-3
+    assert _rel(qd.grad.cpu(), qc.grad) < 2e-3
+    assert _rel(qpd.grad.cpu(), qpc.grad) < 2e-3
+    assert _rel(refd.grad.cpu(), refc.grad) < 2e-3
+    for k, prm in mod.named_parameters():
+        assert prm.grad is not None, k
+        assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
+
+
+def test_adjoint_identity_of_the_default_training_path_at_vovnet_size():
+    """configs[3] (232x400 ... 29x50, 24 cameras, 3 GB of features) on the DEFAULT training path.  The layer is
+    out = W A(feats) + b wsum with A linear in the features, so <grad_feats, feats> = <out - b wsum, grad_out> - a property
+    no oracle run at this size is needed for.  (tests/test_configs_gpu.py checks the projected-value kernels the same way.)"""
+    from graph_detr4d_amd.autograd import CrossAttnRawFunction, PyramidSourceFunction, RawPyramid
+    c = _timed_inputs(41, levels=synthetic.VOV_LEVELS)
+    d = {k: c[k].to(DEV) for k in ('ref', 'offsets', 'attn', 'cam', 'l2i', 'w_v', 'b_v')}
+    feats = [f.requires_grad_() for f in c['feats']]
+    raw = RawPyramid()
+    token = PyramidSourceFunction.apply(raw, *feats)
+    out = CrossAttnRawFunction.apply(token, d['ref'], d['offsets'], d['attn'], d['cam'], d['l2i'], d['w_v'], d['b_v'], raw, PC, 900, 1600)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(42)).to(DEV)
+    (out * go).sum().backward()
+    lhs = sum(float((f.grad.double() * f.detach().double()).sum()) for f in feats)
+    with torch.no_grad():
+        plan = ops.cross_attn_plan_fwd(raw.pyramid, d['ref'], d['offsets'], d['attn'], d['cam'], d['l2i'], PC, 900, 1600, 8)
+        bias_part = ops.value_proj_heads_fwd(torch.zeros(1, c['q'], 8, 256, device=DEV), plan.wsum, torch.zeros_like(d['w_v']), d['b_v'])
+    rhs = float(((out.detach() - bias_part).double() * go.double()).sum())
+    assert abs(rhs) > 1.0 and out.abs().max().item() > 0.1
+    assert abs(lhs - rhs) <= 1e-4 * abs(rhs), (lhs, rhs)
+    for f in feats:
+        assert torch.isfinite(f.grad).all() and f.grad.abs().max().item() > 0
+
+
+# ------------------------------------------------------------------------------------------------ configs[4], bf16
+def test_config4_bf16_two_query_sets_match_the_oracle_in_bf16_mode():
+    """configs[4] names bf16: the student side of the distillation step (student queries + teacher_queries over ONE pyramid,
+    detr3d_head_pe.py:560-566, 617-625) with value_dtype='bf16' modules against the oracle's bf16 mode ('bf16_features': the
+    copy the gathers read is stored bf16, everything else fp32), inference and one training step's gradients."""
+    from oracle import torch_oracle as O
+    g = Golden('decoder_deform')
+    m = g.meta
+    n = m['num_cams']
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=decoder_cfg(dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4,
+                                 embed_dims=256, value_dtype='bf16'), m['num_layers'])))
+    tr.load_state_dict(g.state(), strict=True)
+    regs = reg_branches(m['num_layers'], 0)
+    regs.load_state_dict(g.state(prefix='reg.'), strict=True)
+    sd, layers = oracle_params(tr)
+    feats = g.feats()
+    qe_s = g.t('query_embed')
+    qe_t = torch.randn(qe_s.shape[0] + 5, 512, generator=torch.Generator().manual_seed(46)) * 0.5
+    with torch.no_grad():
+        want = [O.transformer(sd, layers, feats, qe, g.img_metas(), m['pc_range'], reg_branches=list(regs),
+                              cross='Deform3DCrossAttn', num_points=4, value_dtype='bf16_features') for qe in (qe_s, qe_t)]
+    tr, regs = tr.to(DEV).eval(), regs.to(DEV)
+    with torch.no_grad():
+        got = tr.forward_shared([f.to(DEV) for f in feats], [qe_s.to(DEV), qe_t.to(DEV)], reg_branches=regs, img_metas=g.img_metas())
+    for (s_g, i_g, r_g), (s_w, i_w, r_w) in zip(got, want):
+        torch.testing.assert_close(r_g.cpu(), r_w, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(s_g.cpu(), s_w, rtol=1e-3, atol=1e-3)           # same rounded inputs, fp32 arithmetic on both sides
+    # training: gradients of the shared pass against autograd of the oracle in the same mode
+    fd = [f.to(DEV).requires_grad_() for f in feats]
+    outs = tr.forward_shared(fd, [qe_s.to(DEV), qe_t.to(DEV)], reg_branches=regs, img_metas=g.img_metas())
+    sum((o[0] ** 2).mean() * (i + 1) for i, o in enumerate(outs)).backward()
+    fc = [f.clone().requires_grad_() for f in feats]
+    sd_g = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    layers_g = [{k[len(f'decoder.layers.{i}.'):]: v for k, v in sd_g.items() if k.startswith(f'decoder.layers.{i}.')}
+                for i in range(m['num_layers'])]
+    regs_cpu = reg_branches(m['num_layers'], 0)
+    regs_cpu.load_state_dict(g.state(prefix='reg.'), strict=True)
+    outs_c = [O.transformer(sd_g, layers_g, fc, qe, g.img_metas(), m['pc_range'], reg_branches=list(regs_cpu),
+                            cross='Deform3DCrossAttn', num_points=4, value_dtype='bf16_features') for qe in (qe_s, qe_t)]
+    sum((o[0] ** 2).mean() * (i + 1) for i, o in enumerate(outs_c)).backward()
+    for a, b in zip(fd, fc):
+        assert _rel(a.grad.cpu(), b.grad) < 5e-3
+    checked = 0
+    for k, prm in tr.named_parameters():
+        if prm.grad is not None and sd_g[k].grad is not None:
+            assert _rel(prm.grad.cpu(), sd_g[k].grad) < 5e-3, k
+            checked += 1
+    assert checked > 40
+
+
+def test_distillation_loss_terms_on_the_gpu_match_the_oracle_restatement():
+    """`bench.py --mode distill` adds criterion.instance_distill_loss to the student's loss: on the device, from real head
+    outputs of a teacher pass and a teacher-query-guided student pass, against the oracle's stage-by-stage restatement of
+    mix_distill.py:140-168 on CPU copies (values and the gradient that reaches the student's logits / boxes)."""
+    from graph_detr4d_amd.criterion import instance_distill_loss
+    from oracle import torch_oracle as O
+    gen = torch.Generator().manual_seed(9)
+    nl, b, q = 6, 1, 900
+    t_cls, t_box = torch.randn(nl, b, q, 10, generator=gen) * 2 - 2, torch.randn(nl, b, q, 10, generator=gen)
+    s_cls, s_box = torch.randn(nl, b, q, 10, generator=gen) * 2 - 2, torch.randn(nl, b, q, 10, generator=gen)
+    sc, sb = s_cls.clone().requires_grad_(), s_box.clone().requires_grad_()
+    want = O.instance_distill_loss(t_cls, t_box, sc, sb, 1.0, 0.5, True)
+    sum(want.values()).backward()
+    scd, sbd = s_cls.to(DEV).requires_grad_(), s_box.to(DEV).requires_grad_()
+    got = instance_distill_loss(dict(all_cls_scores=t_cls.to(DEV), all_bbox_preds=t_box.to(DEV)),
+                                dict(guided_cls_scores=scd, guided_bbox_preds=sbd), 1.0, 0.5, True)
+    assert list(got) == list(want)
+    sum(got.values()).backward()
+    for k in want:
+        torch.testing.assert_close(got[k].detach().cpu(), want[k].detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(scd.grad.cpu(), sc.grad, rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(sbd.grad.cpu(), sb.grad, rtol=1e-4, atol=1e-9)

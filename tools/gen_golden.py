@@ -603,6 +603,30 @@ def case_head_loss(name, *, num_query, gts, seed, num_layers=3, degenerate=False
     save(name, meta, **arrays)
 
 
+def case_distill(name, *, num_query, batch, seed, num_layers=3, num_classes=10, reweight_score=True,
+                 loss_cls_weight=1.0, loss_reg_weight=0.5):
+    """MixDistill.get_instance_distill_loss (distillation/distillers/mix_distill.py:140-168), called unbound on a shell
+    object carrying the three attributes it reads: teacher head outputs + the student's teacher-query-guided outputs in,
+    the 2 x num_layers loss terms out (and their gradients w.r.t. the student's outputs)."""
+    mod = refstub.load_distiller()
+    g = torch.Generator().manual_seed(seed)
+    shape = (num_layers, batch, num_query)
+    t_cls = torch.randn(*shape, num_classes, generator=g) * 2 - 1
+    t_box = torch.randn(*shape, 10, generator=g)
+    s_cls = (torch.randn(*shape, num_classes, generator=g) * 2 - 1).requires_grad_()
+    s_box = torch.randn(*shape, 10, generator=g).requires_grad_()
+    shell = types.SimpleNamespace(reweight_score=reweight_score, loss_cls_distill=dict(loss_weight=loss_cls_weight),
+                                  loss_reg_distill=dict(loss_weight=loss_reg_weight))
+    losses = mod.MixDistill.get_instance_distill_loss(shell, dict(all_cls_scores=t_cls, all_bbox_preds=t_box),
+                                                      dict(guided_cls_scores=s_cls, guided_bbox_preds=s_box))
+    sum(losses.values()).backward()
+    keys = list(losses.keys())
+    meta = dict(num_query=num_query, batch=batch, num_layers=num_layers, num_classes=num_classes, seed=seed,
+                reweight_score=reweight_score, loss_cls_weight=loss_cls_weight, loss_reg_weight=loss_reg_weight, loss_keys=keys)
+    save(name, meta, t_cls=t_cls, t_box=t_box, s_cls=s_cls.detach(), s_box=s_box.detach(),
+         losses=torch.stack([losses[k].detach() for k in keys]), grad_s_cls=s_cls.grad, grad_s_box=s_box.grad)
+
+
 def main():
     torch.set_num_threads(8)
     case_deform('deform_n6', num_query=48, frames=1, batch=1, img_hw=(128, 224), seed=101)
@@ -633,6 +657,9 @@ def main():
     case_head_loss('head_loss_b2', num_query=40, gts=(5, 0), seed=702, num_layers=2)
     case_head_loss('head_loss_degenerate', num_query=30, gts=(6,), seed=703, num_layers=2, degenerate=True)
     case_head_loss('head_loss_b2_both', num_query=36, gts=(4, 6), seed=704, num_layers=2)
+    case_distill('distill_loss', num_query=50, batch=1, seed=801)
+    case_distill('distill_loss_b2_mean', num_query=30, batch=2, seed=802, num_layers=2, reweight_score=False,
+                 loss_cls_weight=2.0, loss_reg_weight=0.25)
 
 
 if __name__ == '__main__':

@@ -627,3 +627,29 @@ def load_head_loss():
     importlib.import_module('projects.mmdet3d_plugin.core.bbox.match_costs.match_cost')     # registers BBox3DL1Cost
     asg = importlib.import_module('projects.mmdet3d_plugin.core.bbox.assigners.hungarian_assigner_3d')
     return head, asg
+
+
+# --------------------------------------------------------------------------------------
+# distiller (BASELINE configs[4]): the instance distillation loss of the teacher - student step
+# --------------------------------------------------------------------------------------
+def load_distiller():
+    """Import the reference's distillation/distillers/mix_distill.py unmodified.  Only the unbound
+    `MixDistill.get_instance_distill_loss` (and `get_feat_distill_loss`'s 'vanilla' arm) is used by tools/gen_golden.py;
+    detector building, checkpoint loading and the registry are name-only stubs.  Returns the module."""
+    install_stubs()
+    load_coder()                                          # projects.* namespace; core/bbox/util.py for denormalize_bbox
+    _mod('mmdet.models.detectors')
+    _mod('mmdet.models.detectors.base', BaseDetector=nn.Module)
+    sys.modules['mmdet.models'].build_detector = None
+    run = sys.modules['mmcv.runner']
+    run.load_checkpoint = run._load_checkpoint = run.load_state_dict = None
+    rel = 'projects.mmdet3d_plugin.distillation'
+    for full in (rel, rel + '.distillers'):
+        if full not in sys.modules:
+            m = types.ModuleType(full)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, *full.split('.'))]
+            sys.modules[full] = m
+    _mod(rel + '.builder', DISTILLER=Registry('distiller'), build_distill_loss=None)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        return importlib.import_module(rel + '.distillers.mix_distill')
