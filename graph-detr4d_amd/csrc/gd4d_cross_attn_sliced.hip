@@ -365,7 +365,10 @@ struct ItemsParams {
   int cap_i;
 };
 
-template <int HH, int LT, typename VT, int POLICY>
+// WIDE: a level spans 4 GiB or more (VoVNet-99 level 0 stored channels-last, two samples: 4.6 GB) - the offsets parked in LDS
+// are then in units of 16 bytes (every stride is a multiple of 16; the host hands cam_stride / pix_stride pre-divided) and a
+// load forms its address with a 64-bit shift-add.
+template <int HH, int LT, typename VT, int POLICY, bool WIDE>
 __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip, const int pos, const int sl, char* s_raw) {
   const SlicedParams& p = ip.s;
   constexpr int ES = sizeof(VT);
@@ -453,8 +456,10 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
       for (int j = 0; j < 8; ++j) {
         if ((j & 3) >= LT) continue;
         if (j >= 4 && !second) break;
-        const unsigned o = ((j & 1) ? pr[j >> 1].z : pr[j >> 1].x) + lane_off;
-        const VT* ap = reinterpret_cast<const VT*>(base[j & 3] + o);
+        const unsigned raw = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
+        const unsigned o = raw + lane_off;
+        const VT* ap = WIDE ? reinterpret_cast<const VT*>(base[j & 3] + (((size_t)raw << 4) + lane_off))
+                            : reinterpret_cast<const VT*>(base[j & 3] + o);
         if (POLICY == 3) val[j] = make_float4(__uint_as_float(o), 0.f, 0.f, 0.f);   // dev: no loads - the issue floor
         else val[j] = Quad<VT>::load(ap);
       }
@@ -485,13 +490,13 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
   }
 }
 
-template <int HH, int LT, typename VT, int OCC, int POLICY>
+template <int HH, int LT, typename VT, int OCC, int POLICY, bool WIDE = false>
 __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_kernel(const ItemsParams ip) {
   extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
   trace_mark(g_trace_sliced, 6ull);
   int pos, sl;
   if (!sliced_walk(ip.s, blockIdx.x, pos, sl)) return;
-  cross_attn_agg_items_body<HH, LT, VT, POLICY>(ip, pos, sl, s_raw);
+  cross_attn_agg_items_body<HH, LT, VT, POLICY, WIDE>(ip, pos, sl, s_raw);
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
@@ -666,7 +671,8 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
     // 32-bit byte offsets inside a level: the last pixel of the last camera row
     const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
                                     (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
-    if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EUNSUPPORTED;
+    // (the ITEMS form stores no offsets: its gather checks the spans itself and switches to 16-byte units past 4 GiB)
+    if (!(flags & GD4D_CA_PLAN_ITEMS) && (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32))) return GD4D_EUNSUPPORTED;
     pp.g.lvl_w[l] = w; pp.g.lvl_h[l] = h; pp.g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
   }
   pp.g.pix_stride = (unsigned)pix_stride_bytes;
@@ -777,7 +783,7 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
 
 namespace gd4d {
 template <int HH, typename VT>
-static int launch_items(const ItemsParams& ip, int L, hipStream_t s) {
+static int launch_items(const ItemsParams& ip, int L, bool wide, hipStream_t s) {
   const SlicedParams& p = ip.s;
   const size_t lds = (size_t)HH * 4 * 8 * 80;                       // [HH][CH][8][GP]
   const dim3 grid(8 * ((p.per_xcd + p.blk - 1) / p.blk) * p.blk * p.slice_n);
@@ -801,6 +807,14 @@ static int launch_items(const ItemsParams& ip, int L, hipStream_t s) {
   }
 #endif
   constexpr int OCC = HH == 16 ? 4 : 6;                             // waves per SIMD
+  if (wide) {                                                       // (a 64-bit address per load: 4 waves per SIMD, no spills)
+    switch (L) {
+      case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, 4, 0, true>);
+      case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, 4, 0, true>);
+      case 3: return go(cross_attn_agg_items_kernel<HH, 3, VT, 4, 0, true>);
+      default: return go(cross_attn_agg_items_kernel<HH, 4, VT, 4, 0, true>);
+    }
+  }
   switch (L) {
     case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, OCC, 0>);
     case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, OCC, 0>);
@@ -822,15 +836,27 @@ extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, cons
   if (!level_hw || !cam_stride_bytes) return GD4D_EINVAL;
   if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
   for (int l = 0; l < 4; ++l) { ip.g.lvl_w[l] = 1; ip.g.lvl_h[l] = 1; ip.g.cam_stride[l] = 0; }
+  // offsets inside a level are 32 bits: bytes while every level spans < 4 GiB, units of 16 bytes otherwise (< 64 GiB)
+  bool wide = false;
+  unsigned long long span_max = 0;
   for (int l = 0; l < L; ++l) {
     const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
     if (h <= 0 || w <= 0 || cam_stride_bytes[l] < 0) return GD4D_EINVAL;
     const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
                                     (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
-    if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) return GD4D_EUNSUPPORTED;
-    ip.g.lvl_w[l] = w; ip.g.lvl_h[l] = h; ip.g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
+    span_max = span > span_max ? span : span_max;
+    if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) wide = true;
+    if ((cam_stride_bytes[l] & 15) || (pix_stride_bytes & 15)) {
+      if (span >= (1ull << 32)) return GD4D_EUNSUPPORTED;
+    }
   }
-  ip.g.pix_stride = (unsigned)pix_stride_bytes;
+  if (wide && ((pix_stride_bytes & 15) || span_max >= (1ull << 36))) return GD4D_EUNSUPPORTED;
+  for (int l = 0; l < L; ++l) {
+    if (wide && ((cam_stride_bytes[l] & 15) || (cam_stride_bytes[l] >> 4) >= (1ll << 32))) return GD4D_EUNSUPPORTED;
+    ip.g.lvl_w[l] = level_hw[2 * l + 1]; ip.g.lvl_h[l] = level_hw[2 * l];
+    ip.g.cam_stride[l] = (unsigned)(wide ? cam_stride_bytes[l] >> 4 : cam_stride_bytes[l]);
+  }
+  ip.g.pix_stride = (unsigned)(wide ? pix_stride_bytes >> 4 : pix_stride_bytes);
   ip.item = reinterpret_cast<const float4*>(ip.s.pair);
   ip.wsum = wsum;
   ip.cap_i = plan_cap_items(N, P);
@@ -840,9 +866,9 @@ extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {
-    case 4: return bf16 ? launch_items<4, uint16_t>(ip, L, s) : launch_items<4, float>(ip, L, s);
-    case 8: return bf16 ? launch_items<8, uint16_t>(ip, L, s) : launch_items<8, float>(ip, L, s);
-    default: return bf16 ? launch_items<16, uint16_t>(ip, L, s) : launch_items<16, float>(ip, L, s);
+    case 4: return bf16 ? launch_items<4, uint16_t>(ip, L, wide, s) : launch_items<4, float>(ip, L, wide, s);
+    case 8: return bf16 ? launch_items<8, uint16_t>(ip, L, wide, s) : launch_items<8, float>(ip, L, wide, s);
+    default: return bf16 ? launch_items<16, uint16_t>(ip, L, wide, s) : launch_items<16, float>(ip, L, wide, s);
   }
 }
 

@@ -191,7 +191,9 @@ int gd4d_value_proj_heads_fwd(const float* agg, const float* wsum, const float* 
  *   touch `wsum`, and gd4d_cross_attn_agg_items_fwd does the corner arithmetic itself (lane = (item, level), 16 items per
  *   step, the same operations in the same order: agg and wsum are bit-identical to the pairs form) from the geometry
  *   arguments, which must be the ones the plan was made with.  wsum (B*Q, Hh) is written by the launch that contains
- *   slice 0 (NULL: not wanted).  The training backward kernels read the pairs form only. */
+ *   slice 0 (NULL: not wanted).  A level may span up to 64 GiB (offsets in units of 16 bytes once a level reaches 4 GiB -
+ *   e.g. VoVNet-99 level 0 stored channels-last with B >= 2; all strides must then be multiples of 16); the pairs form is
+ *   limited to 4 GiB per level.  The training backward kernels read the pairs form only. */
 size_t gd4d_cross_attn_plan_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
                                   int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
