@@ -55,10 +55,12 @@ struct PlanParams {
   int cap_i;               // items reserved per head (a multiple of 16)
 };
 
-template <int HH, int LT, int WAVES>
+// PT = sampling points per head (the reference's num_points, deform3d_cross_attn.py:52-69; every shipped config: 4).  An item is
+// a visible (camera, point) pair whatever PT is, so the gather does not know it.
+template <int HH, int LT, int WAVES, int PT = kPoints>
 __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const int pos, char* smem_raw) {
   const CrossAttnParams& p = pp.c;
-  constexpr int PT = kPoints, E = HH * PT, LP = LT * PT, THREADS = 64 * WAVES;
+  constexpr int E = HH * PT, LP = LT * PT, THREADS = 64 * WAVES;
   float2* s_uv = reinterpret_cast<float2*>(smem_raw);                        // [N][E]; x < 0: not visible
   float* s_mat = reinterpret_cast<float*>(s_uv + p.N * E);                   // [N][12]
   float* s_cw = s_mat + p.N * 12;                                            // [N]
@@ -221,11 +223,11 @@ __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const
   }
 }
 
-template <int HH, int LT, int WAVES>
+template <int HH, int LT, int WAVES, int PT = kPoints>
 __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_kernel(const PlanParams pp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   trace_mark(g_trace_sliced, 5ull);
-  cross_attn_plan_body<HH, LT, WAVES>(pp, blockIdx.x, smem_raw);
+  cross_attn_plan_body<HH, LT, WAVES, PT>(pp, blockIdx.x, smem_raw);
   trace_mark(g_trace_sliced, 0x85ull);
 }
 
@@ -613,8 +615,8 @@ extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(B * Q);
   auto lds = [&](int LT) {
-    return (size_t)N * Hh * kPoints * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
-           (size_t)((B * Hh * LT * kPoints + 3) & ~3) * sizeof(float) + (size_t)8 * N * kPoints * sizeof(float4);
+    return (size_t)N * Hh * P * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
+           (size_t)((B * Hh * LT * P + 3) & ~3) * sizeof(float) + (size_t)8 * N * P * sizeof(float4);
   };
   // one wave per head up to 8 heads (the heads' pass loops are the kernel's longest dependent chain)
   auto go = [&](auto kern, int waves, size_t bytes) -> int {
@@ -631,6 +633,21 @@ extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, 
     default: GD4D_PLAN_GO(HH_, 4);        \
   }
   if (lds(L) > 160 * 1024) return GD4D_EUNSUPPORTED;
+  if (P != kPoints) {                                 // num_points 1 / 2 / 8: compiled for the reference's default of 8 heads
+#define GD4D_PLAN_P(PT_)                                                                  \
+    switch (L) {                                                                          \
+      case 1: return go(cross_attn_plan_kernel<8, 1, 8, PT_>, 8, lds(1));                 \
+      case 2: return go(cross_attn_plan_kernel<8, 2, 8, PT_>, 8, lds(2));                 \
+      case 3: return go(cross_attn_plan_kernel<8, 3, 8, PT_>, 8, lds(3));                 \
+      default: return go(cross_attn_plan_kernel<8, 4, 8, PT_>, 8, lds(4));                \
+    }
+    switch (P) {
+      case 1: GD4D_PLAN_P(1)
+      case 2: GD4D_PLAN_P(2)
+      default: GD4D_PLAN_P(8)
+    }
+#undef GD4D_PLAN_P
+  }
   switch (Hh) {
     case 4: GD4D_PLAN_L(4)
     case 8: GD4D_PLAN_L(8)
@@ -649,7 +666,7 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
   if (!ref || !offsets || !attn_logits || !cam_logits || !lidar2img || !pc_range || !plan || !level_hw || !cam_stride_bytes)
     return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
-  if (P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if ((P != 1 && P != 2 && P != 4 && P != 8) || (P != kPoints && Hh != 8) || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
   if (!aligned16(plan)) return GD4D_EALIGN;
   if (plan_bytes < gd4d_cross_attn_plan_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
@@ -737,7 +754,8 @@ static int fill_sliced_params(SlicedParams& p, const void* const* level_ptrs, in
                               int slice_lo, int slice_n) {
   if (!level_ptrs || !plan || !agg) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
-  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if (C != kChannels || (P != 1 && P != 2 && P != 4 && P != 8) || (P != kPoints && Hh != 8) || L > 4 || N > 64 || B > 16)
+    return GD4D_EUNSUPPORTED;
   if (feats_dtype != GD4D_F32 && feats_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
   if (slice_lo < 0 || slice_n <= 0 || slice_lo + slice_n > kSlices) return GD4D_EINVAL;

@@ -621,7 +621,7 @@ class LateValues:
         if rows > 64 or len(value) > 4 or value[0].shape[0] * rows * sum(v.shape[-1] * v.shape[-2] for v in value) >= 2 ** 31:
             return False
         return len({m.value_dtype for m in modules}) == 1 and \
-            all(m.num_points == 4 and m.num_heads in (4, 8, 16) and m.embed_dims == 256
+            all((m.num_points == 4 or (m.num_points in (1, 2, 8) and m.num_heads == 8)) and m.num_heads in (4, 8, 16) and m.embed_dims == 256
                 and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
     def _wait_copy(self):

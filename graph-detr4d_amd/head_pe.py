@@ -36,10 +36,14 @@ class SELayer(nn.Module):
 
 class FeaturePositionEmbedding(nn.Module):
     def __init__(self, embed_dims=256, depth_num=64, depth_start=1, pc_range=None, num_feats=128, temperature=10000,
-                 normalize=True, scale=2 * math.pi, eps=1e-6, offset=-0.5):
+                 normalize=True, scale=2 * math.pi, eps=1e-6, offset=-0.5, with_detach=True, cams_per_frame=6):
+        """with_detach (the head's keyword and default, detr3d_head_pe.py:326, :358): level 0's past-frame cameras - every
+        camera after the first `cams_per_frame` = 6, hard-coded at :514-515 - reach this stage and the decoder DETACHED
+        (:512-516): same values, no gradient back to the backbone through them.  A no-op for single-frame inputs."""
         super().__init__()
         if pc_range is None:
             raise ValueError('pc_range is required (the head takes it from its bbox coder)')
+        self.with_detach, self.cams_per_frame = bool(with_detach), int(cams_per_frame)
         self.embed_dims, self.depth_num, self.depth_start = embed_dims, depth_num, depth_start
         self.pc_range = list(pc_range)
         self.position_dim = 3 * depth_num
@@ -214,6 +218,9 @@ class FeaturePositionEmbedding(nn.Module):
         GD4D_HEAD_PE=conv keeps the 1x1 convolutions on the library instead of gd4d_gemm_bf16x3_fwd."""
         feats = list(mlvl_feats)
         Fn.require_gpu(feats[0], 'mlvl_feats')
+        if self.with_detach and feats[0].shape[1] > self.cams_per_frame and feats[0].requires_grad and torch.is_grad_enabled():
+            k = self.cams_per_frame                           # :512-516 (level 0 only, as the reference)
+            feats[0] = torch.cat([feats[0][:, :k], feats[0][:, k:].detach()], 1)
         if Fn.wants_grad(self, *feats):
             return self._forward_autograd(feats, img_metas)
         with torch.no_grad():

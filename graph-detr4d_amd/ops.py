@@ -243,13 +243,16 @@ class Plan:
     plan kernel).  items: the buffer holds the ITEMS form (include/gd4d.h, GD4D_CA_PLAN_ITEMS) - gather only; the
     training backward kernels need the pairs form."""
 
-    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False):
+    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False, points=4):
         self.buf, self.order, self.pyramid, self.b, self.q, self.num_heads, self.wsum = buf, order, pyramid, b, q, num_heads, wsum
-        self.items = bool(items)
+        self.items, self.points = bool(items), int(points)
 
     def need_pairs(self, who):
         if self.items:
             raise _lib.Gd4dError(f'{who} reads the pairs form of the plan; this one was made with items=True')
+        if self.points != 4:
+            raise _lib.Gd4dError(f'{who} is built for num_points = 4 (every shipped config); this plan has {self.points} - the '
+                                 'forward kernels take 1 / 2 / 4 / 8, the training backward 4 only')
 
 
 CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS = 1, 2
@@ -273,7 +276,7 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
     nbytes = cross_attn_plan_bytes(b, n, q, hh, p)
     buf = torch.empty(nbytes, device=ref.device, dtype=torch.uint8) if plan is None else plan.buf
     wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32) if plan is None else plan.wsum
-    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items)
+    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items, points=p)
     mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
     uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
     rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
@@ -314,14 +317,14 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
         cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
         code = lib.gd4d_cross_attn_agg_items_fwd(
             ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
-            _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, 4,
+            _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, plan.points,
             _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
             None if query_order is None else _order_ptr(query_order, b * q), int(slices[0]), int(slices[1]), _stream())
         _lib.check(code, 'gd4d_cross_attn_agg_items_fwd')
         return agg
     code = lib.gd4d_cross_attn_agg_sliced_fwd(
         ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32), b, pyramid.rows // b, q, hh,
-        256, nl, 4, _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+        256, nl, plan.points, _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
         None if query_order is None else _order_ptr(query_order, b * q), int(slices[0]), int(slices[1]), _stream())
     _lib.check(code, 'gd4d_cross_attn_agg_sliced_fwd')
     return agg

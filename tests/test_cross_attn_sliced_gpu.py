@@ -344,3 +344,58 @@ def test_levels_of_more_than_4_gib_are_gathered_in_place():
     assert torch.equal(got_a, want_a) and torch.equal(got_s, want_s)
     with pytest.raises(_lib.Gd4dError):
         _sliced_form(False, view, *args)
+
+
+@pytest.mark.parametrize('points,levels,n,q,b', [(1, [(16, 28), (8, 14), (4, 7), (2, 4)], 6, 50, 1), (2, [(16, 28), (8, 14)], 12, 40, 1),
+                                                 (8, [(16, 28), (8, 14), (4, 7), (2, 4)], 6, 33, 1), (8, [(12, 20)], 7, 20, 2),
+                                                 (1, [(12, 20), (6, 10), (3, 5)], 24, 30, 2)])
+def test_num_points_other_than_four_vs_plain_c_oracle(points, levels, n, q, b):
+    """The reference's constructor takes any num_points (deform3d_cross_attn.py:52-69; every shipped config: 4).  1, 2 and 8
+    points per head (8 heads) through plan + gather + value_proj of the aggregates against the plain-C oracle on the projected
+    values: mask / uv bit-exact, both plan forms identical."""
+    import numpy as np
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import c_oracle
+    rng = np.random.default_rng(points * 100 + n)
+    nl = len(levels)
+    feats = [rng.standard_normal((b, n, 256, h, w)).astype(np.float32) for h, w in levels]
+    w_v, b_v = (rng.standard_normal((256, 256)) * 0.06).astype(np.float32), rng.standard_normal(256).astype(np.float32)
+    ref = rng.random((b, q, 3)).astype(np.float32)
+    offsets = (rng.standard_normal((b, q, 8, points, 3)) * 1.5).astype(np.float32)
+    attn = rng.standard_normal((b, q, 8, nl, points)).astype(np.float32)
+    cam = rng.standard_normal((b, q, n)).astype(np.float32)
+    l2i = np.broadcast_to(synthetic.camera_rig((n + 5) // 6)[:n][None], (b, n, 4, 4)).astype(np.float32).copy()
+    flat = np.concatenate([f.reshape(b * n, 256, -1).transpose(0, 2, 1) for f in feats], 1)               # (R, S, 256)
+    val = (flat.astype(np.float64) @ w_v.astype(np.float64).T + b_v).astype(np.float32).reshape(b * n, -1, 8, 32)
+    if b == 1:
+        o_ref, m_ref, uv_ref = c_oracle.cross_attn_fwd(val, levels, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600)
+    t = lambda a: torch.from_numpy(a).cuda()                # noqa: E731
+    sp, shp = ops.pyramid_slice_planar_fwd([t(f) for f in feats])
+    agg, wsum, mask, uv = _sliced(ops.PyramidView.slice_planar(sp, shp), t(ref), t(offsets), t(attn), t(cam), t(l2i), synthetic.PC_RANGE,
+                                  900, 1600, want=True)
+    out = ops.value_proj_heads_fwd(agg, wsum, t(w_v), t(b_v))
+    assert mask.shape == (b, n, q, 8, points) and mask.sum().item() > 0
+    if b == 1:
+        assert np.array_equal(mask.cpu().numpy(), m_ref) and np.array_equal(uv.cpu().numpy(), uv_ref)
+        np.testing.assert_allclose(out.cpu().numpy(), o_ref, rtol=1e-4, atol=1e-4)
+    else:                                                    # B > 1 (the row % B pairing): against the torch oracle
+        from oracle import torch_oracle as O
+        o_t, _, m_t = O.sample_aggregate(torch.from_numpy(val), levels, torch.from_numpy(ref), torch.from_numpy(offsets),
+                                         torch.from_numpy(attn).flatten(-2), torch.from_numpy(cam), torch.from_numpy(l2i),
+                                         synthetic.PC_RANGE, 900, 1600)
+        flipped = (mask.cpu() != m_t.to(torch.uint8)).any(dim=4).any(dim=3).any(dim=1)
+        assert flipped.sum().item() <= 2
+        torch.testing.assert_close(out.cpu()[~flipped], o_t[~flipped], rtol=1e-4, atol=1e-4)
+
+
+def test_training_kernels_refuse_num_points_other_than_four():
+    from graph_detr4d_amd import _lib, ops, synthetic
+    torch.manual_seed(2)
+    fd = [torch.randn(1, 6, 256, 16, 28).cuda()]
+    sp, shp = ops.pyramid_slice_planar_fwd(fd)
+    l2i = torch.from_numpy(synthetic.camera_rig(1)).unsqueeze(0).cuda()
+    plan = ops.cross_attn_plan_fwd(ops.PyramidView.slice_planar(sp, shp), torch.rand(1, 9, 3).cuda(), torch.randn(1, 9, 8, 2, 3).cuda(),
+                                   torch.randn(1, 9, 8, 1, 2).cuda(), torch.randn(1, 9, 6).cuda(), l2i, synthetic.PC_RANGE, 900, 1600, 8)
+    assert plan.points == 2
+    with pytest.raises(_lib.Gd4dError):
+        ops.cross_attn_dot_sliced(plan, torch.zeros(1, 9, 8, 256).cuda())

@@ -142,3 +142,31 @@ def test_head_outputs_match_reference_forward():
                               reg_b, m['pc_range'])
     torch.testing.assert_close(got['all_cls_scores'].cpu(), g.t('all_cls_scores'), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(got['all_bbox_preds'].cpu(), g.t('all_bbox_preds'), rtol=1e-4, atol=1e-4)
+
+
+def test_with_detach_cuts_the_gradient_of_level_0_past_frames():
+    """detr3d_head_pe.py:512-516 (`with_detach`, default True): level 0's cameras after the first six reach the stage
+    detached - same outputs, no gradient to the backbone through them; every other (level, camera) keeps its gradient.
+    with_detach=False restores it."""
+    from graph_detr4d_amd import FeaturePositionEmbedding, synthetic
+    img_hw, levels, n = (64, 112), [(8, 14), (4, 7)], 12
+    rig = synthetic.camera_rig(2, img_hw)
+    metas = synthetic.make_img_metas(rig, img_shape=(img_hw[0], img_hw[1], 3), pad_shape=(img_hw[0], img_hw[1], 3))
+    gen = torch.Generator().manual_seed(5)
+    base = [torch.randn(1, n, 256, h, w, generator=gen) for h, w in levels]
+    probes = [torch.randn(1, n, 256, h, w, generator=gen).cuda() for h, w in levels]
+    res = {}
+    for detach in (True, False):
+        mod = FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE, with_detach=detach)
+        synthetic.randomise_all_(mod, seed=9, std=0.04)
+        mod = mod.cuda().eval()
+        feats = [f.cuda().requires_grad_() for f in base]
+        outs = mod(feats, metas)
+        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+        res[detach] = ([o.detach() for o in outs], [f.grad for f in feats])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)                                        # values do not change
+    g_det, g_full = res[True][1], res[False][1]
+    assert float(g_det[0][:, 6:].abs().max()) == 0.0 and float(g_full[0][:, 6:].abs().max()) > 0
+    assert torch.equal(g_det[0][:, :6], g_full[0][:, :6]) and torch.equal(g_det[1], g_full[1])
+    assert FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE).with_detach is True      # the head's default (:326)
