@@ -160,11 +160,16 @@ template <bool EXACT>
 __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   constexpr int FRAG = EXACT ? 3072 : 2048;
   const int i16 = lane & 15, g = lane >> 4;
-  const float* a_row = &bufs[op.src][i16][RC_KG * g];
   const int K = op.K, N = op.N;
   const int steps = K / 32, tiles = (N + 15) / 16;
   const char* img = reinterpret_cast<const char*>(op.p0);
+  // GD4D_CHAIN_SRC2: the passes from column ld0 on (a multiple of 256 = one pass of all waves) take their A operand from buffer
+  // `res` instead of `src` - the packed in-projection (q, k from x + pos, v from x) as ONE operation.
+  // GD4D_CHAIN_SPLIT_OUT: the N columns go to three global tensors (gout | p2 | p3, each as wide as its row stride) - the
+  // three Linears of query + query_pos (camera logits, offsets, attention logits) as ONE operation over their stacked weights.
+  const bool src2 = (op.flags & GD4D_CHAIN_SRC2) != 0, split_out = (op.flags & GD4D_CHAIN_SPLIT_OUT) != 0;
   for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
+    const float* a_row = &bufs[(src2 && n_base >= op.ld0) ? op.res : op.src][i16][RC_KG * g];
     const char* wf[RC_TILES];                                  // tiles past the end re-read the last one (never stored)
 #pragma unroll
     for (int c = 0; c < RC_TILES; ++c) wf[c] = img + (size_t)min(n_base / 16 + c, tiles - 1) * steps * FRAG + lane * 16;
@@ -183,7 +188,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
     // global addends p2 (+ p3) of the epilogue - the residual rows a LOAD operation would otherwise park in a buffer first:
     // requested here, consumed after the K loop (their fabric round trip hides under the weight stream)
     float e_add[RC_TILES][4];
-    if (op.p2) {
+    if (op.p2 && !split_out) {
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) {
         const int n = min(n_base + 16 * c + i16, N - 1);
@@ -269,10 +274,20 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         float v = acc[c][r] + e_bias[c];
         if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
         if (op.flags & GD4D_CHAIN_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-        if (op.res >= 0) v += bufs[op.res][row][n];
-        if (op.p2) v += e_add[c][r];
+        if (op.res >= 0 && !src2) v += bufs[op.res][row][n];
+        if (op.p2 && !split_out) v += e_add[c][r];
         if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
-        if (op.gout && m < M) op.gout[(size_t)m * op.ldg + n] = v;
+        if (split_out) {
+          if (m < M) {
+            const int c1 = op.ldg, c2 = op.ldg + op.ld2;
+            float* o = n < c1 ? op.gout + (size_t)m * op.ldg + n
+                     : n < c2 ? const_cast<float*>(op.p2) + (size_t)m * op.ld2 + (n - c1)
+                              : const_cast<float*>(op.p3) + (size_t)m * op.ld1 + (n - c2);
+            *o = v;
+          }
+        } else if (op.gout && m < M) {
+          op.gout[(size_t)m * op.ldg + n] = v;
+        }
       }
     }
   }
@@ -754,6 +769,11 @@ static int rc_validate(const gd4d_chain_op* program, int nops, bool two_programs
         if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_W)) return GD4D_EINVAL;
         if (op.dst >= 0 && op.dst == op.src) return GD4D_EINVAL;          // waves would overwrite rows others still read
         if (!aligned16(op.p0)) return GD4D_EALIGN;
+        if (op.flags & GD4D_CHAIN_SRC2)
+          if (op.res < 0 || op.res == op.dst || op.ld0 <= 0 || op.ld0 % (RC_COLS * RC_WAVES) != 0 || op.ld0 >= op.N) return GD4D_EINVAL;
+        if (op.flags & GD4D_CHAIN_SPLIT_OUT)
+          if (!op.gout || !op.p2 || !op.p3 || op.ldg <= 0 || op.ld2 <= 0 || op.ld1 <= 0 || op.ldg + op.ld2 + op.ld1 != op.N)
+            return GD4D_EINVAL;
         break;
       case GD4D_CHAIN_HEADGEMM:
         if (!op.p0 || !op.p2 || !op.p3 || op.K <= 0 || op.N <= 0 || op.ld0 <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;

@@ -82,11 +82,18 @@ def applicable(decoder, query, value, reference_points, reg_branches, attn_masks
 
 
 def _in_proj_ops(sa, x_pos_buf, x_buf, qkv):
-    """Two GEMMs of the packed in-projection: q, k from (x + pos), v from x (mmcv MultiheadAttention semantics)."""
+    """The packed in-projection: q, k from (x + pos), v from x (mmcv MultiheadAttention semantics) - one GEMM operation whose
+    last 256 columns read the other buffer (GD4D_CHAIN_FUSE_GEMMS=0: two operations; bit-identical)."""
     c = sa.embed_dims
     w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
+    if c % 128 == 0 and _fuse_gemms():
+        return [ops.chain_gemm_two_sources(x_pos_buf, x_buf, 2 * c, w, b, qkv)]
     return [ops.chain_gemm(x_pos_buf, w[:2 * c], b[:2 * c], out=qkv[..., :2 * c]),
             ops.chain_gemm(x_buf, w[2 * c:], b[2 * c:], out=qkv[..., 2 * c:])]
+
+
+def _fuse_gemms():
+    return os.environ.get('GD4D_CHAIN_FUSE_GEMMS', '1') != '0'
 
 
 def initial_reference(linear, query_pos):
@@ -209,10 +216,15 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         #  - two barriers and two exposed round trips - fewer than LOAD, GEMM, LAYERNORM, ADD; same values bit for bit)
         prog_a = [ops.chain_load(0, o.view(q, c)),
                   ops.chain_gemm(0, sa.attn.out_proj.weight, sa.attn.out_proj.bias, dst=1, add=x),
-                  ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1, dst2=0, add=pos),
-                  ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
-                  ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
-                  ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
+                  ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1, dst2=0, add=pos)]
+        if _fuse_gemms():    # the three Linears of query + query_pos as one GEMM over the stacked weights (248 columns: one pass)
+            prog_a.append(ops.chain_gemm_three_outputs(
+                0, [ca.cam_attention_weights, ca.deform_sampling_offsets, ca.attention_weights],
+                [cam.view(q, -1), off.view(q, -1), att.view(q, -1)]))
+        else:
+            prog_a += [ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
+                       ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
+                       ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
         pos_feat = torch.empty(1, q, c, device=dev, dtype=torch.float32)
         if pending is not None:
             lins, x_prev, ref_prev, new_ref = pending

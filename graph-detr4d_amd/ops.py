@@ -1378,7 +1378,7 @@ class ChainOp(ctypes.Structure):
 
 
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
-CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT = 1, 2, 4, 8
+CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT = 1, 2, 4, 8, 16, 32
 
 
 def _rows(t, name):
@@ -1460,6 +1460,47 @@ def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, ou
     return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
                    flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0) | (CHAIN_EXACT if exact else 0), ldg=ldg,
                    ld2=ld2, ld1=ld3, p0=img.data_ptr(), p1=None if bias is None else bias.data_ptr(), p2=p2, p3=p3, gout=g)
+
+
+def chain_gemm_two_sources(src, src2, split, weight, bias, out):
+    """One GEMM over a stacked weight (N, K) whose output columns [0, split) are computed from buf[src] and [split, N) from
+    buf[src2] (split a multiple of 256): nn.MultiheadAttention's packed in-projection with q, k from x + pos and v from x."""
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=weight.shape[1], N=weight.shape[0], flags=CHAIN_SRC2, ld0=int(split),
+                   ldg=ldg, p0=chain_weight_image(weight).data_ptr(), p1=None if bias is None else bias.data_ptr(), gout=g)
+
+
+_STACKED = {}
+
+
+def _stacked_linears(linears):
+    """cat of the Linears' weights / biases (cached while none of them changes: addresses and version counters)."""
+    key = tuple(id(m) for m in linears)
+    sig = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else (m.bias.data_ptr(), m.bias._version))
+                for m in linears) + (_CHAIN_EPOCH[0],)
+    hit = _STACKED.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        w = torch.cat([m.weight for m in linears], 0).contiguous()
+        b = torch.cat([m.bias if m.bias is not None else m.weight.new_zeros(m.weight.shape[0]) for m in linears], 0).contiguous()
+    _STACKED[key] = (sig, w, b)
+    return w, b
+
+
+def chain_gemm_three_outputs(src, linears, outs):
+    """Three nn.Linear of ONE input (buf[src]) as one GEMM over their stacked weights; column block i goes to outs[i] (M, N_i),
+    dense rows.  The sums of a column do not depend on the operation it is part of: bit-identical to three chain_gemm."""
+    if len(linears) != 3 or len(outs) != 3:
+        raise ValueError('chain_gemm_three_outputs takes three Linears and three outputs')
+    w, b = _stacked_linears(linears)
+    ptrs = [_rows(o, 'out') for o in outs]
+    for (ptr, ld), m in zip(ptrs, linears):
+        if ld != m.weight.shape[0]:
+            raise ValueError('chain_gemm_three_outputs: every output must be dense, as wide as its Linear')
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=-1, K=w.shape[1], N=w.shape[0], flags=CHAIN_SPLIT_OUT,
+                   ldg=ptrs[0][1], ld2=ptrs[1][1], ld1=ptrs[2][1], p0=chain_weight_image(w).data_ptr(), p1=b.data_ptr(),
+                   gout=ptrs[0][0], p2=ptrs[1][0], p3=ptrs[2][0])
 
 
 def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):

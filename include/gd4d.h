@@ -522,6 +522,11 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
                                        combined order <= 2 (~2^-24 relative); p0 = the image of gd4d_chain_weight_image_exact.  For
                                        the GEMMs that produce reference points (initial reference, reg branch): a point's error is
                                        multiplied by the 102-m range and the focal length before it selects pixels */
+#define GD4D_CHAIN_SRC2 16          /* GEMM: columns >= ld0 (a multiple of 256) take their A operand from buffer `res` (which is then
+                                       no residual): the packed in-projection - q, k from x + pos, v from x - as one operation */
+#define GD4D_CHAIN_SPLIT_OUT 32     /* GEMM: the N columns leave for THREE global tensors: [0, ldg) -> gout, the next ld2 -> p2, the
+                                       last ld1 -> p3 (each as wide as its row stride; p2 / p3 are outputs, not addends) - the
+                                       Linears of one input stacked into one weight (deform3d_cross_attn.py:211, :227, :281) */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */

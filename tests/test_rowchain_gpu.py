@@ -225,3 +225,32 @@ def test_signal_wait_hand_off_between_the_two_programs(m):
     assert int(flags[:blocks].sum().item()) == blocks
     with pytest.raises(_lib.Gd4dError):
         ops.row_chain_fwd(producer(pos, flags), m)
+
+
+@pytest.mark.parametrize('m', [900, 45])
+def test_fused_gemm_forms_equal_their_separate_operations(m):
+    """GD4D_CHAIN_SRC2 (the packed in-projection as one operation whose last 256 columns read another buffer) and
+    GD4D_CHAIN_SPLIT_OUT (three Linears of one input as one GEMM over the stacked weights, three outputs): a column's sum does
+    not depend on the operation it is part of - bit-identical to the separate operations; also after a weight update."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + 1)
+    x, pos = torch.randn(m, 256, device=DEV), torch.randn(m, 256, device=DEV)
+    w, b = torch.randn(768, 256, device=DEV) * 0.06, torch.randn(768, device=DEV)
+    a, bq = torch.empty(m, 768, device=DEV), torch.empty(m, 768, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(3, x), ops.chain_gemm(0, w[:512], b[:512], out=a[:, :512]),
+                       ops.chain_gemm(3, w[512:], b[512:], out=a[:, 512:])], m)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(3, x), ops.chain_gemm_two_sources(0, 3, 512, w, b, bq)], m)
+    assert torch.equal(a, bq)
+    ref = torch.cat([F.linear((x + pos).double(), w[:512].double(), b[:512].double()), F.linear(x.double(), w[512:].double(), b[512:].double())], 1)
+    assert (bq.double() - ref).abs().max().item() < 1e-4
+    lins = [torch.nn.Linear(256, n).to(DEV) for n in (24, 96, 128)]
+    for _ in range(2):
+        sep = [torch.empty(m, l.out_features, device=DEV) for l in lins]
+        one = [torch.full((m, l.out_features), float('nan'), device=DEV) for l in lins]
+        ops.row_chain_fwd([ops.chain_load(0, x)] + [ops.chain_gemm(0, l.weight, l.bias, out=o) for l, o in zip(lins, sep)], m)
+        ops.row_chain_fwd([ops.chain_load(0, x), ops.chain_gemm_three_outputs(0, lins, one)], m)
+        for s_, o_ in zip(sep, one):
+            assert torch.equal(s_, o_)
+        with torch.no_grad():                                   # the stacked weight follows an in-place update (version counter)
+            lins[1].weight.mul_(1.5)
+            lins[2].bias.add_(0.25)
