@@ -6,7 +6,7 @@
 //   (deform3d_cross_attn.py:326-336), mmcv FFN layers[1] (+ residual) -> norms[2], position_encoder[3] -> [4] -> ReLU
 //   (deform3d_cross_attn.py:108-110).
 // gd4d_linear_fwd tiles the output 32 x 32 over many small workgroups: lowest latency on an idle GPU, but LayerNorm
-// needs whole rows, and when value_proj of the next layer holds three quarters of the CUs hundreds of
+// needs whole rows, and when value_proj of the next layer holds three quarters of the CUs (docs/design_notes_r01_r03.md 4.5) hundreds of
 // small workgroups queue up in rounds.  Here a workgroup owns 16 rows x up to 256 columns (4 waves x 64 columns, each
 // wave the full K), so ceil(M / 16) = 57 workgroups do the whole layer, the row statistics are two LDS exchanges, and
 // LayerNorm costs no extra launch.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per kernel of a csrc/*.hip file: global loads, s_waitcnt vmcnt instructions and how many of them are vmcnt(0), registers.
 Many vmcnt(0) next to few loads = loads the compiler waits for one at a time (a load under a select / `continue`, dependent
-`t += p[i]` chains, an operand first used after stores: DESIGN.md section 4.7).  Compiles for gfx950 with the library's flags;
+`t += p[i]` chains, an operand first used after stores: docs/design_notes_r01_r03.md section 4.7).  Compiles for gfx950 with the library's flags;
 no GPU needed.  usage: python tools/isa_waits.py gd4d_linear.hip [name-substring]"""
 import os
 import re
