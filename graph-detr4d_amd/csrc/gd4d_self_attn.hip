@@ -64,6 +64,12 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
   const int q0 = blockIdx.x * 16;
   const int h = blockIdx.y, b = blockIdx.z;
   const float NEG_INF = -__builtin_inff();
+  // The softmax runs in base 2: q is scaled by scale * log2(e), so a probability is ONE v_exp_f32 (exp2) instead of expf's
+  // range reduction + exp2 + ldexp (~15 instructions, five times per tile of keys: the kernel issued 195 vector instructions
+  // per tile and was bound by them - 5.0 M per launch = 8 us of the 13.4, profiles/r04_pmc_step_inflight1.txt).  The saved
+  // log-sum-exp is converted back to natural units; an additive mask is scaled like the scores.
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  const float qscale = p.scale * LOG2E;
 
   // Q^T as B operand: lane (col = query qi, g) holds q[qi][8g + s] at k-step s (any k<->dim map works
   // as long as A uses the same one).  Rows beyond Lq are clamped (their outputs are never written).
@@ -72,8 +78,8 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
     const int qrow = min(q0 + qi, p.Lq - 1);
     const float* src = p.q + ((size_t)qrow * p.B + b) * p.ldq + h * MHA_D + 8 * g;
     const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
-    qf[0] = a.x * p.scale; qf[1] = a.y * p.scale; qf[2] = a.z * p.scale; qf[3] = a.w * p.scale;
-    qf[4] = c.x * p.scale; qf[5] = c.y * p.scale; qf[6] = c.z * p.scale; qf[7] = c.w * p.scale;
+    qf[0] = a.x * qscale; qf[1] = a.y * qscale; qf[2] = a.z * qscale; qf[3] = a.w * qscale;
+    qf[4] = c.x * qscale; qf[5] = c.y * qscale; qf[6] = c.z * qscale; qf[7] = c.w * qscale;
   }
   const int krho = (qi >> 2) + 4 * (qi & 3);     // key (within a tile) held by MFMA row rho = lane&15
 
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
         } else if (MASK == 1) {
           if (mk[i][r] != 0.f) val = NEG_INF;
         } else if (MASK == 2) {
-          val += mk[i][r];
+          val += mk[i][r] * LOG2E;
         }
         sc[r] = val;
       }
@@ -157,10 +163,10 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
       const float m_new = fmaxf(m, tmax);
       // all keys so far masked: keep everything at zero weight without creating NaN here
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float corr = expf(m - m_use);           // m = -inf -> 0
+      const float corr = __builtin_amdgcn_exp2f(m - m_use);           // m = -inf -> 0
       float pr[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pr[r] = expf(sc[r] - m_use);
+      for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
       l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
       m = m_new;
       if (DROP) {
@@ -198,12 +204,12 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_kernel(const MhaParam
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int w = 0; w < MHA_WAVES; ++w) {
-      const float f = expf(s_m[w][i] - mm);                    // fully masked row: -inf - -inf = NaN, as ATen
+      const float f = __builtin_amdgcn_exp2f(s_m[w][i] - mm);  // fully masked row: -inf - -inf = NaN, as ATen
       num += s_o[w][d][i] * f;
       den += s_l[w][i] * f;
     }
     p.out[((size_t)(q0 + i) * p.B + b) * p.ldo + h * MHA_D + d] = num / den;
-    if (p.lse && d == 0) p.lse[((size_t)(q0 + i) * p.B + b) * p.H + h] = mm + logf(den);   // saved for gd4d_mha_core_bwd
+    if (p.lse && d == 0) p.lse[((size_t)(q0 + i) * p.B + b) * p.H + h] = mm * LN2 + logf(den);   // natural units; saved for gd4d_mha_core_bwd
   }
   trace_mark(g_trace_mha, 0x82ull);
 }
