@@ -330,10 +330,11 @@ def main():
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (bf16x3 GEMMs)' if a.value_dtype == 'fp32' else 'bf16-storage/f32-accumulate (bf16x3 GEMMs)',
-            'dtype_detail': 'features, gather, aggregation, softmax, LayerNorm, attention core: fp32; the query-side GEMMs of the row '
-                            'chains (in/out-proj, the Linears of the cross-attention, value_proj of the aggregates, FFN, reg branch) '
-                            'are split-bf16 x3 products on the bf16 MFMA with fp32 accumulation (~2^-16 relative per product, inside '
-                            'the 1e-3 contract)',
+            'dtype_detail': 'features, gather, aggregation, softmax, LayerNorm: fp32; the query-side GEMMs of the row chains (in/out-proj, '
+                            'the Linears of the cross-attention, value_proj of the aggregates, FFN) and the two products of the attention '
+                            'core are split-bf16 x3 products on the bf16 MFMA with fp32 accumulation (~2^-16 relative per product, '
+                            'inside the 1e-3 contract); the GEMMs whose outputs become reference points (initial reference, reg branch) '
+                            'use six products (~2^-24)',
             'value_batch1': a.gpus * 1e3 / single_ms, 'ms_per_sample_batch1': single_ms,
             'eager_ms_per_sample': eager_ms,
             'channels_last_input': nhwc,

@@ -577,7 +577,10 @@ int gd4d_small_linear_layernorm_fwd(const float* in, const float* w, const float
  *   q (Lq*B rows), k, v (Lk*B rows): row index l*B + b, row strides ldq/ldk/ldv, head h at column
  *   offset h*D (so q, k, v may alias the three thirds of one packed in-projection buffer);
  *   mask: NULL, or (Lq, Lk) uint8 with nonzero = masked (mask_kind 1), or (Lq, Lk) fp32 additive
- *   (mask_kind 2);  out (Lq*B, H*D) row stride ldo.  Supported: D == 32.  fp32 throughout.
+ *   (mask_kind 2);  out (Lq*B, H*D) row stride ldo.  Supported: D == 32.  Softmax in fp32 (base 2); the two products
+ *   on the fp32 MFMA when lse or dropout is asked for (training: the backward kernels recompute the probabilities in
+ *   fp32), else (inference) as split-bf16 x3 products on the bf16 MFMA with fp32 accumulation (~2^-16 relative per
+ *   product, the arithmetic of the GEMMs around it; GD4D_MHA_FP32=1 in the environment keeps the fp32 kernel).
  */
 int gd4d_mha_core_fwd(const float* q, const float* k, const float* v, const void* mask, float* out,
                       int Lq, int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo,
