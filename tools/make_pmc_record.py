@@ -15,13 +15,12 @@ KERNEL = sys.argv[4] if len(sys.argv) > 4 else 'cross_attn_fwd_block'
 SOURCE = sys.argv[5] if len(sys.argv) > 5 else 'gd4d_cross_attn.hip' 
 ctr, cur = {}, None
 for line in open(summary):
-    if not line.startswith(' '):
+    m = re.match(r'\s+(\S+)\s+mean/dispatch\s+([0-9.]+)', line)
+    if not m:                                     # a kernel name (some come with a leading blank from the demangler)
         cur = line.strip()
         continue
     if cur and KERNEL in cur:
-        m = re.match(r'\s+(\S+)\s+mean/dispatch\s+([0-9.]+)', line)
-        if m:
-            ctr[m.group(1)] = float(m.group(2))
+        ctr[m.group(1)] = float(m.group(2))
 src = open(os.path.join(ROOT, 'graph-detr4d_amd', 'csrc', SOURCE), 'rb').read()
 rec = {
     'kernel': 'gd4d::' + KERNEL + ' (' + SOURCE + ')',
