@@ -291,6 +291,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]
         x = x3.view(q, c)
+    if pos_late and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
+        # debugging aid: a WAIT that gave up (~0.2 s unanswered) counts in the last word of its layer's flag row
+        torch.cuda.synchronize(dev)
+        if int(flags[:, -1].sum().item()) != 0:
+            raise RuntimeError('graph-detr4d_amd: a SIGNAL / WAIT hand-off between chain programs timed out')
     del keep
     return out_all, ref_all
 

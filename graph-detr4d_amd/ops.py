@@ -415,6 +415,7 @@ def cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits
     """gd4d_cross_attn_plan_bwd: the query-side gradients of the sliced path from D (cross_attn_dot_sliced) and beta.
     Returns (grad_ref, grad_offsets, grad_attn_logits, grad_cam_logits) - what cross_attn_bwd returns after grad_value."""
     lib = _lib.load()
+    plan.need_pairs('gd4d_cross_attn_plan_bwd')
     f32 = torch.float32
     b, q, hh = plan.b, plan.q, plan.num_heads
     n = lidar2img.shape[1]
@@ -1474,17 +1475,22 @@ _STACKED = {}
 
 
 def _stacked_linears(linears):
-    """cat of the Linears' weights / biases (cached while none of them changes: addresses and version counters)."""
+    """cat of the Linears' weights / biases, cached while none of them changes: the entry holds weak references to the weight
+    tensors it was built from (an id() or an address alone can be handed to another object after a free) plus their version
+    counters and the image epoch."""
+    import weakref
     key = tuple(id(m) for m in linears)
     sig = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else (m.bias.data_ptr(), m.bias._version))
                 for m in linears) + (_CHAIN_EPOCH[0],)
     hit = _STACKED.get(key)
-    if hit is not None and hit[0] == sig:
+    if hit is not None and hit[0] == sig and all(r() is m.weight for r, m in zip(hit[3], linears)):
         return hit[1], hit[2]
     with torch.no_grad():
         w = torch.cat([m.weight for m in linears], 0).contiguous()
         b = torch.cat([m.bias if m.bias is not None else m.weight.new_zeros(m.weight.shape[0]) for m in linears], 0).contiguous()
-    _STACKED[key] = (sig, w, b)
+    if len(_STACKED) > 256:                               # modules come and go in long-lived processes
+        _STACKED.clear()
+    _STACKED[key] = (sig, w, b, [weakref.ref(m.weight) for m in linears])
     return w, b
 
 

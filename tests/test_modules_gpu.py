@@ -443,6 +443,22 @@ def test_fused_decoder_sees_weight_updates(monkeypatch):
         monkeypatch.setenv('GD4D_FUSED_DECODER', '0')
         r_g = tr(feats, qe, reg_branches=regs, img_metas=metas)[2].clone()
     torch.testing.assert_close(r_f, r_g, rtol=1e-4, atol=1e-4)
+    monkeypatch.delenv('GD4D_FUSED_DECODER')
+    # (e) the three Linears of query + query_pos run as ONE GEMM over a cached stack of their weights: the stack follows an
+    # in-place update of one of them and a .data write to another (bracketed by the mode switches)
+    monkeypatch.setenv('GD4D_CHECK_HANDOFF', '1')                 # and no SIGNAL / WAIT hand-off of the loop may time out
+    ca = tr.decoder.layers[1].attentions[1]
+    with torch.no_grad():
+        ca.attention_weights.weight.mul_(-1.5)
+    f4, g4 = both()
+    assert (g4 - g3).abs().max().item() > 1e-3
+    torch.testing.assert_close(f4, g4, rtol=5e-4, atol=5e-4)
+    tr.train()
+    ca.deform_sampling_offsets.bias.data.mul_(0.5)
+    tr.eval()
+    f5, g5 = both()
+    assert (g5 - g4).abs().max().item() > 1e-3
+    torch.testing.assert_close(f5, g5, rtol=5e-4, atol=5e-4)
 
 
 def test_frozen_decoder_still_gives_the_feature_maps_their_gradient():
