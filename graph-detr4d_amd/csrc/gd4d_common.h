@@ -68,11 +68,14 @@ __device__ __forceinline__ float inv_sigmoid(float x) {
 #define GD4D_TRACE_UNIT(tag)                                                                          \
   __device__ unsigned long long* g_trace_##tag = nullptr;                                              \
   void trace_set_##tag(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_##tag), &p, sizeof(p)); }
-__device__ __forceinline__ void trace_mark(unsigned long long* t, unsigned long long id) {
-  if (t && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+__device__ __forceinline__ void trace_mark_if(unsigned long long* t, unsigned long long id, bool stamping_block) {
+  if (t && stamping_block && threadIdx.x == 0) {
     const unsigned long long slot = atomicAdd(t, 1ull);
     if (slot < t[1]) { t[2 + 2 * slot] = id; t[3 + 2 * slot] = __builtin_amdgcn_s_memrealtime(); }
   }
+}
+__device__ __forceinline__ void trace_mark(unsigned long long* t, unsigned long long id) {
+  trace_mark_if(t, id, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
 }
 
 }  // namespace gd4d

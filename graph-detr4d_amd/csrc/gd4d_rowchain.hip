@@ -513,7 +513,8 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = wg * RC_M;
-  trace_mark(g_trace_rowchain, 1ull | ((unsigned long long)nops << 8));
+  // (row block 0 of EITHER program stamps the timeline: kind 1 = the first program, 7 = the second)
+  trace_mark_if(g_trace_rowchain, (second ? 7ull : 1ull) | ((unsigned long long)nops << 8), wg == 0);
 #if RC_PREFETCH
   // The weight images of a program (2.6 MB for chain B) are cold in this XCD's L2 when the launch starts - another
   // kernel streamed through it since their last use - and the GEMMs below fetch them with 32 KB per wave in flight: at
@@ -707,10 +708,10 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
     }
     __syncthreads();
 #if RC_TRACE_OPS
-    trace_mark(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32));
+    trace_mark_if(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32), wg == 0 && !second);
 #endif
   }
-  trace_mark(g_trace_rowchain, 0x81ull | ((unsigned long long)nops << 8));
+  trace_mark_if(g_trace_rowchain, (second ? 0x87ull : 0x81ull) | ((unsigned long long)nops << 8), wg == 0);
 }
 
 }  // namespace gd4d
@@ -751,7 +752,9 @@ extern "C" int gd4d_chain_weight_image_exact(const float* weight, int N, int K, 
   return check_launch();
 }
 
-static int rc_validate(const gd4d_chain_op* program, int nops, bool two_programs) {
+// which: 0 = the only program of a launch, 1 = the first of two, 2 = the second of two
+static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
+  const bool two_programs = which != 0;
   using namespace gd4d;
   for (int i = 0; i < nops; ++i) {
     const gd4d_chain_op& op = program[i];
@@ -799,11 +802,15 @@ static int rc_validate(const gd4d_chain_op* program, int nops, bool two_programs
       case GD4D_CHAIN_REFINE:
         if (op.src < 0 || !op.p0 || !op.gout || (op.dst >= 0 && op.dst == op.src)) return GD4D_EINVAL;
         break;
+      // Workgroups of a launch are dispatched in index order, the first program's before the second's: a WAIT in the SECOND
+      // program is answered by a workgroup that was dispatched before the waiting one - resident or finished, and never
+      // blocked itself - whatever else keeps the device busy.  The other direction could leave every compute unit to
+      // spinning consumers whose producers are still in the queue (five requests in flight would do): refused.
       case GD4D_CHAIN_SIGNAL:
-        if (!op.gout || !two_programs) return GD4D_EINVAL;
+        if (!op.gout || !two_programs || which != 1) return GD4D_EINVAL;
         break;
       case GD4D_CHAIN_WAIT:
-        if (!op.p0 || !two_programs) return GD4D_EINVAL;
+        if (!op.p0 || !two_programs || which != 2) return GD4D_EINVAL;
         break;
       default: return GD4D_EINVAL;
     }
@@ -815,9 +822,9 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   using namespace gd4d;
   if (!a || na <= 0 || M <= 0 || nb < 0 || (nb > 0 && !b)) return GD4D_EINVAL;
   if (na + nb > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
-  if (int rc = rc_validate(a, na, nb > 0)) return rc;
+  if (int rc = rc_validate(a, na, nb > 0 ? 1 : 0)) return rc;
   if (nb > 0)
-    if (int rc = rc_validate(b, nb, true)) return rc;
+    if (int rc = rc_validate(b, nb, 2)) return rc;
   const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES;      // row buffers + the prefetch dump area
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
   const int blocks = (M + RC_M - 1) / RC_M;

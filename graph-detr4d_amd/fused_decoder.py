@@ -285,8 +285,10 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         elif return_intermediate or last:
             ref_all[slot].copy_(ref)
         if pos_late:
-            # position_encoder(l) on the refined points (in global memory since the dual launch), beside chain B'
-            ops.row_chain2_fwd(prog, _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3)) + [ops.chain_signal(flags[lid])], q)
+            # position_encoder(l) on the refined points (in global memory since the dual launch), beside chain B'.  The
+            # SIGNALling program goes FIRST: its workgroups are dispatched before the waiting ones (gd4d.h: no deadlock however
+            # many requests are in flight).
+            ops.row_chain2_fwd(_position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3)) + [ops.chain_signal(flags[lid])], prog, q)
         else:
             ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]

@@ -557,7 +557,10 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * its 16 rows so far; WAIT (p0 = the same array; gout = optional uint32 error counter) holds its program until the OTHER
  * program's workgroup of the same rows has signalled.  Row block i of both programs is dispatched to the same XCD, so the
  * hand-off goes through that XCD's L2 without cache maintenance.  E.g. position_encoder next to chain B: its rows are needed
- * by chain B's second operation only.  A WAIT that is not answered within ~0.2 s gives up, counts in gout and goes on. */
+ * by chain B's second operation only.  SIGNAL belongs in program_a, WAIT in program_b (anything else is GD4D_EINVAL): the
+ * workgroups of a launch are dispatched in index order, program_a's first, so a waiting workgroup's producer is always
+ * resident or finished - no deadlock however busy the device is.  A WAIT that is not answered within ~0.2 s (it cannot
+ * happen under that rule) gives up, counts in gout and goes on. */
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
 

@@ -219,12 +219,14 @@ def test_signal_wait_hand_off_between_the_two_programs(m):
         flags = torch.zeros((blocks + 7) // 8 * 8, device=DEV, dtype=torch.int32)
         pos.fill_(float('nan'))
         out.fill_(float('nan'))
-        ops.row_chain2_fwd(consumer(pos, out, flags, errors), producer(pos, flags), m)
+        ops.row_chain2_fwd(producer(pos, flags), consumer(pos, out, flags, errors), m)      # the SIGNALling program first
         assert torch.equal(pos, pos_ref) and torch.equal(out, out_ref)
     assert int(errors.item()) == 0
     assert int(flags[:blocks].sum().item()) == blocks
     with pytest.raises(_lib.Gd4dError):
         ops.row_chain_fwd(producer(pos, flags), m)
+    with pytest.raises(_lib.Gd4dError):                            # the waiting program first: its producers would be dispatched
+        ops.row_chain2_fwd(consumer(pos, out, flags, errors), producer(pos, flags), m)      # after it - refused (deadlock-prone)
 
 
 @pytest.mark.parametrize('m', [900, 45])

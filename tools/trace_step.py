@@ -13,7 +13,8 @@ import bench  # noqa: E402
 import graph_detr4d_amd as G  # noqa: E402
 from graph_detr4d_amd import _lib, synthetic  # noqa: E402
 
-NAMES = {1: 'row_chain', 2: 'mha_core', 3: 'aggregate', 4: 'channels_last_copy', 5: 'plan', 6: 'sliced_aggregate'}
+NAMES = {1: 'row_chain', 2: 'mha_core', 3: 'aggregate', 4: 'channels_last_copy', 5: 'plan', 6: 'sliced_aggregate',
+         7: 'row_chain (second program)'}
 
 
 def main():
@@ -64,7 +65,7 @@ def main():
             prev = t
             continue
         kind, end, nops = ident & 0x3f, bool(ident & 0x80), ident >> 8
-        name = NAMES.get(kind, str(kind)) + (f'[{nops} ops]' if kind == 1 else '')
+        name = NAMES.get(kind, str(kind)) + (f'[{nops} ops]' if kind in (1, 7) else '')
         print(f'{(t - t0) / 100:9.1f} us  (+{(t - prev) / 100:7.1f})  {"end  " if end else "start"} {name}')
         prev = t
 
