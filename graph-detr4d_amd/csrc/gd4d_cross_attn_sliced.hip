@@ -501,11 +501,11 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
   constexpr int CH = 4;                                   // passes per step = 16 items (20 KB of LDS per workgroup of 8 waves)
   constexpr int GP = 80;                                  // LDS bytes per corner slot: 64 B of pairs + 16 B pad (conflict-free b128)
   constexpr int PASS = 8 * GP;
+  constexpr int F4 = STAGE_LO ? 3 : 2;                    // float4 per item record
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = p.slice_lo + sl;
   const int i_of = lane >> 2, l_of = lane & 3;
-  constexpr int F4 = STAGE_LO ? 3 : 2;                    // float4 per item record
   const float4* rec = ip.item + ((size_t)pos * HH + h) * ip.cap_i * F4;
   // speculative: the first 16 records (cap_i >= 16; what lies past M is replaced below before it is used)
   float4 a = rec[i_of * F4];
@@ -530,84 +530,92 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
   const float flw = (float)lw, flh = (float)lh;
   const float lvl_on = l_of < LT ? 1.f : 0.f;
 
-  // ---- the stage: this query's unique lines of levels STAGE_LO .. 3, slice s, once for all eight head-waves ----
+  // ---- the stage: this query's unique lines of levels STAGE_LO .. 3, slice s, once for all eight head-waves.  The lines
+  // are requested as LDS-DMA loads (no registers; a wave's 64 lanes fill 8 consecutive 128-byte lines) right away and land
+  // while the waves walk the DIRECT levels of all their items (sweep 1); one barrier; then the staged levels (sweep 2). ----
   constexpr int STAGE_CAP = STAGE_LO == 0 ? 0 : (STAGE_LO >= 3 ? kStageCap3 : kStageCap2);
   char* stage = s_raw + HH * (CH * PASS);
   bool staged = false;
   if (STAGE_LO) {
-    static_assert(STAGE_LO == 0 || (sizeof(VT) == 4 && LT == 4 && !WIDE), "staging: fp32 lines, four levels, 32-bit offsets");
+    static_assert(STAGE_LO == 0 || (sizeof(VT) == 4 && LT == 4 && !WIDE && HH == 8), "staging: fp32 lines, four levels, 32-bit offsets, 8 waves");
     const int U = __builtin_amdgcn_readfirstlane(p.hdr[pos * kPlanHdr + kStageHdr]);
     staged = U != kStageNone;
     if (staged) {
+      typedef __attribute__((address_space(3))) void lds_void_t;
+      typedef const __attribute__((address_space(1))) void glb_void_t;
       const unsigned* ul = ip.ulist + (size_t)pos * ip.stage_cap;
-      const int u0 = threadIdx.x >> 3, c8 = threadIdx.x & 7;
       constexpr int ITER = (STAGE_CAP + 63) / 64;
-      float4 sv[ITER > 0 ? ITER : 1];
+      unsigned e[ITER > 0 ? ITER : 1];
 #pragma unroll
-      for (int i = 0; i < ITER; ++i) {                                       // all requests first (clamped: always a valid entry)
-        const unsigned e = ul[min(u0 + 64 * i, max(U - 1, 0))];
-        const char* lb = (STAGE_LO < LT - 1 && (e & 1u)) ? base[LT - 1] : base[STAGE_LO < LT ? STAGE_LO : 0];
-        sv[i] = *reinterpret_cast<const float4*>(lb + (e & ~1u) + c8 * 16);
+      for (int i = 0; i < ITER; ++i) e[i] = ul[min(64 * i + 8 * h + g, max(U - 1, 0))];      // (clamped: always a valid entry)
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        if (64 * i + 8 * h >= U) break;                                      // wave-uniform: none of this wave's eight lines exists
+        const char* lb = (STAGE_LO < LT - 1 && (e[i] & 1u)) ? base[LT - 1] : base[STAGE_LO < LT ? STAGE_LO : 0];
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(lb + (e[i] & ~1u) + c * 16), (lds_void_t*)(stage + (64 * i + 8 * h) * 128), 16, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < ITER; ++i)
-        if (u0 + 64 * i < U) *reinterpret_cast<float4*>(stage + (u0 + 64 * i) * 128 + c8 * 16) = sv[i];
     }
-    __syncthreads();
   }
 
   const int M = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));       // every record carries its head's count
   const int T = (M + 3) >> 2;
-  if (M < 16 && M > 0) {                                                    // wave-uniform: items past M repeat the last one
-    const int src = (min(i_of, M - 1) << 2) | l_of;
-    a.x = __shfl(a.x, src); a.y = __shfl(a.y, src); a.z = __shfl(a.z, src); wl = __shfl(wl, src);
-    if (STAGE_LO) { sl2.x = __shfl(sl2.x, src); sl2.y = __shfl(sl2.y, src); }
-  }
   f2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
   float wsum_lane = 0.f;
-  for (int it0 = 0; it0 < M; it0 += 16) {
-    const int item = it0 + i_of;
-    const int m_pad = (M + 3) & ~3;
-    {
-      const int row = __float_as_int(a.z);
-      const float x = fmaf(a.x, flw, -0.5f);
-      const float y = fmaf(a.y, flh, -0.5f);
-      const float xf = floorf(x), yf = floorf(y);
-      const float dx = x - xf, dy = y - yf;
-      const int x0 = (int)xf, y0 = (int)yf;
-      const float live = item < M ? lvl_on : 0.f;
-      const unsigned rbase = (unsigned)row * cstr;
-      if (it0 > 0) __builtin_amdgcn_wave_barrier();                        // the previous step's passes have read the patch
+  // MODE 0: every level in one sweep (the unstaged gather); 1: the direct levels; 2: the staged levels, read from LDS
+  auto sweep = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const bool mine = MODE == 0 || (MODE == 1 ? l_of < STAGE_LO : l_of >= STAGE_LO);   // this lane's level belongs to the sweep
+    if (MODE == 2) {                                                        // the first records again (L1 / L2 hits)
+      a = rec[i_of * F4];
+      wl = reinterpret_cast<const float*>(rec + i_of * F4 + 1)[l_of];
+      if (l_of >= STAGE_LO) sl2 = reinterpret_cast<const uint2*>(rec + i_of * F4 + 2)[l_of - STAGE_LO];
+    }
+    if (M < 16 && M > 0) {                                                  // wave-uniform: items past M repeat the last one
+      const int src = (min(i_of, M - 1) << 2) | l_of;
+      a.x = __shfl(a.x, src); a.y = __shfl(a.y, src); a.z = __shfl(a.z, src); wl = __shfl(wl, src);
+      if (STAGE_LO) { sl2.x = __shfl(sl2.x, src); sl2.y = __shfl(sl2.y, src); }
+    }
+    for (int it0 = 0; it0 < M; it0 += 16) {
+      const int item = it0 + i_of;
+      const int m_pad = (M + 3) & ~3;
+      {
+        const int row = __float_as_int(a.z);
+        const float x = fmaf(a.x, flw, -0.5f);
+        const float y = fmaf(a.y, flh, -0.5f);
+        const float xf = floorf(x), yf = floorf(y);
+        const float dx = x - xf, dy = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float live = item < M ? lvl_on : 0.f;
+        const unsigned rbase = (unsigned)row * cstr;
+        if (it0 > 0 || MODE == 2) __builtin_amdgcn_wave_barrier();          // the previous step's passes have read the patch
 #pragma unroll
-      for (int c_of = 0; c_of < 4; ++c_of) {
-        const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
-        // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
-        const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
-        const float in = (xc == xi && yc == yi) ? live : 0.f;
-        const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
-        const float w = (wl * wx * wy) * in;
-        unsigned off = rbase + (unsigned)(yc * lw + xc) * ip.g.pix_stride;
-        if (STAGE_LO && staged && l_of >= STAGE_LO) {                      // the corner's line sits in the stage: its LDS byte offset
-          const unsigned two = (c_of >> 1) ? sl2.y : sl2.x;
-          off = ((c_of & 1) ? (two >> 16) : (two & 0xffffu)) * 128u;
+        for (int c_of = 0; c_of < 4; ++c_of) {
+          const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
+          // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
+          const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
+          const float in = (xc == xi && yc == yi) ? live : 0.f;
+          const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
+          const float w = (wl * wx * wy) * in;
+          unsigned off = rbase + (unsigned)(yc * lw + xc) * ip.g.pix_stride;
+          if (MODE == 2) {                                                  // the corner's line sits in the stage: its LDS byte offset
+            const unsigned two = (c_of >> 1) ? sl2.y : sl2.x;
+            off = ((c_of & 1) ? (two >> 16) : (two & 0xffffu)) * 128u;
+          }
+          if (mine) wsum_lane += w;
+          if (mine && item < m_pad && l_of < LT) *reinterpret_cast<uint2*>(wr + c_of * GP) = make_uint2(off, __float_as_uint(w));
         }
-        wsum_lane += w;
-        if (item < m_pad && l_of < LT) *reinterpret_cast<uint2*>(wr + c_of * GP) = make_uint2(off, __float_as_uint(w));
       }
-    }
-    if (it0 + 16 < M) {                                                     // the next step's records fly under this step's passes
-      const int nx = min(item + 16, M - 1);
-      a = rec[nx * F4];
-      wl = reinterpret_cast<const float*>(rec + nx * F4 + 1)[l_of];
-      if (STAGE_LO && l_of >= STAGE_LO) sl2 = reinterpret_cast<const uint2*>(rec + nx * F4 + 2)[l_of - STAGE_LO];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // wave-private LDS patch: no workgroup barrier
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int t0 = it0 >> 2;
-    const int nt = min(CH, T - t0);
-    auto passes = [&](auto st_tag) {
-      constexpr bool ST = decltype(st_tag)::value;                         // the staged levels' corners come from LDS
+      if (it0 + 16 < M) {                                                   // the next step's records fly under this step's passes
+        const int nx = min(item + 16, M - 1);
+        a = rec[nx * F4];
+        wl = reinterpret_cast<const float*>(rec + nx * F4 + 1)[l_of];
+        if (STAGE_LO && l_of >= STAGE_LO) sl2 = reinterpret_cast<const uint2*>(rec + nx * F4 + 2)[l_of - STAGE_LO];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // wave-private LDS patch: no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int t0 = it0 >> 2;
+      const int nt = min(CH, T - t0);
       for (int k = 0; k < nt; ++k) {
         const uint4* row = reinterpret_cast<const uint4*>(rd + k * PASS);
         uint4 pr[4];
@@ -618,28 +626,23 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if ((j & 3) >= LT) continue;
+          if (MODE == 1 && (j & 3) >= STAGE_LO) continue;
+          if (MODE == 2 && (j & 3) < STAGE_LO) continue;
           if (j >= 4 && !second) break;
           const unsigned raw = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
           const unsigned o = raw + lane_off;
-          if (ST && (j & 3) >= STAGE_LO) continue;                         // (below, after the global requests are out)
+          if (MODE == 2) { val[j] = *reinterpret_cast<const float4*>(stage + o); continue; }
           const VT* ap = WIDE ? reinterpret_cast<const VT*>(base[j & 3] + (((size_t)raw << 4) + lane_off))
                               : reinterpret_cast<const VT*>(base[j & 3] + o);
           if (POLICY == 3) val[j] = make_float4(__uint_as_float(o), 0.f, 0.f, 0.f);   // dev: no loads - the issue floor
           else val[j] = Quad<VT>::load(ap);
         }
-        if (ST) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if ((j & 3) < STAGE_LO || (j & 3) >= LT) continue;
-            if (j >= 4 && !second) break;
-            const unsigned raw = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
-            val[j] = *reinterpret_cast<const float4*>(stage + raw + lane_off);
-          }
-        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if ((j & 3) >= LT) continue;
+          if (MODE == 1 && (j & 3) >= STAGE_LO) continue;
+          if (MODE == 2 && (j & 3) < STAGE_LO) continue;
           if (j >= 4 && !second) break;
           const float w = __uint_as_float((j & 1) ? pr[j >> 1].w : pr[j >> 1].y);
           const f2v ww = {w, w};
@@ -647,9 +650,15 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
           acc1 = __builtin_elementwise_fma(ww, f2v{val[j].z, val[j].w}, acc1);
         }
       }
-    };
-    if (STAGE_LO && staged) passes(std::true_type{});
-    else passes(std::false_type{});
+    }
+  };
+  if (STAGE_LO && staged) {                                                 // (workgroup-uniform: every wave of it takes this branch)
+    sweep(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's share of the stage has landed
+    __syncthreads();
+    sweep(std::integral_constant<int, 2>{});
+  } else {
+    sweep(std::integral_constant<int, 0>{});
   }
   float4 acc = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
   // the 8 corner slots meet in a fixed order (deterministic)

@@ -46,8 +46,11 @@ def _sliced(*args, **kwargs):
     pyr, ref, offsets = args[0], args[1], args[2]
     if ops.stage_supported(pyr, ref.shape[0], kwargs.get('heads', 8), offsets.shape[3]):
         for stage in (3, 2):
+            # the staged gather walks the direct levels of all items first, then the staged ones: the same products in
+            # another order (agg within fp32 rounding of a ~17-term sum); wsum, mask, uv unchanged bit for bit
             st = _sliced_form(True, *args, stage=stage, **kwargs)
-            for a, b in zip(got, st):
+            torch.testing.assert_close(st[0], got[0], rtol=1e-5, atol=2e-5)
+            for a, b in zip(got[1:], st[1:]):
                 assert torch.equal(a, b), f'stage = {stage} disagrees with the unstaged gather'
     return got
 
@@ -443,4 +446,9 @@ def test_staged_gather_full_size_and_overflowing_queries():
                 assert staged_frac > (0.5 if stage == 2 else 0.8), staged_frac
             plan.wsum.fill_(float('nan'))
             agg = ops.cross_attn_agg_sliced_fwd(plan)
-            assert torch.equal(agg, base[0]) and torch.equal(plan.wsum, base[1]), (stage, all_visible)
+            assert torch.equal(plan.wsum, base[1]), (stage, all_visible)
+            torch.testing.assert_close(agg, base[0], rtol=1e-5, atol=5e-5)      # staged queries: another summation order
+            if all_visible and staged_frac == 0:
+                assert torch.equal(agg, base[0])                                # nothing staged: the unstaged sweep, bit for bit
+            agg2 = ops.cross_attn_agg_sliced_fwd(plan)
+            assert torch.equal(agg, agg2)                                       # run-to-run identical
