@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 36
+ABI_VERSION = 37
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -56,6 +56,7 @@ SIGNATURES = {
                              _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_detr3d_bwd': (_i, [_vp] * 6 + [_f, _f] + [_vp] * 4 + [_i] * 6 + [_vp]),
     'gd4d_detr3d_v2_fwd': (_i, [_vp] * 7 + [_f, _f, _vp, _vp] + [_i] * 7 + [_vp]),
+    'gd4d_detr3d_v2_bwd': (_i, [_vp] * 7 + [_f, _f] + [_vp] * 5 + [_i] * 6 + [_vp]),
     'gd4d_value_proj_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _c.c_size_t, _i, _vp]),
     'gd4d_value_proj_workspace_bytes': (_c.c_size_t, [_i]),
     'gd4d_linear_fwd': (_i, [_vp] * 7 + [_i] * 9 + [_vp, _vp]),

@@ -592,3 +592,25 @@ class Detr3DSampleFunction(torch.autograd.Function):
         gf, gl, gr = ops.detr3d_bwd(feats, ref, logits, lidar2img, pc_range, img_h, img_w, grad_out.contiguous(),
                                     want_feats=any(ctx.needs_input_grad[6:]), want_ref=ctx.needs_input_grad[0])
         return (gr, gl, None, None, None, None, *(gf if gf is not None else [None] * len(feats)))
+
+
+class Detr3DV2SampleFunction(torch.autograd.Function):
+    """out (B, Q, C) of Detr3DCrossAttenV2's sampling (detr3d_transformer.py:597-710: projected reference point + per-head
+    2-D offsets, softmax over level x point, the (point, level) x (level, point) pairing, visibility, sums):
+    gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd.  apply(ref, logits, offsets, lidar2img, pc_range, img_h, img_w, num_heads, *feats)."""
+
+    @staticmethod
+    def forward(ctx, ref, logits, offsets, lidar2img, pc_range, img_h, img_w, num_heads, *feats):
+        ref, logits, offsets = ref.contiguous(), logits.contiguous(), offsets.contiguous()
+        feats = [f.contiguous() for f in feats]
+        ctx.save_for_backward(ref, logits, offsets, lidar2img, *feats)
+        ctx.meta = (pc_range, img_h, img_w, int(num_heads))
+        return ops.detr3d_v2_fwd(feats, ref, logits, offsets, lidar2img, pc_range, img_h, img_w, num_heads)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ref, logits, offsets, lidar2img, *feats = ctx.saved_tensors
+        pc_range, img_h, img_w, hh = ctx.meta
+        gf, gl, go, gr = ops.detr3d_v2_bwd(feats, ref, logits, offsets, lidar2img, pc_range, img_h, img_w, hh, grad_out.contiguous(),
+                                           want_feats=any(ctx.needs_input_grad[8:]), want_ref=ctx.needs_input_grad[0])
+        return (gr, gl.view_as(logits), go.view_as(offsets), None, None, None, None, None, *(gf if gf is not None else [None] * len(feats)))

@@ -232,10 +232,24 @@ class Detr3DCrossAttenV2(nn.Module):
         return self.dropout(out) + query + pos_feat.permute(1, 0, 2)
 
     def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
-        """Training path: reference :597-710 as differentiable torch ops on the GPU - projection of the reference
-        points, per level F.grid_sample (bilinear, zero padding, align_corners=False) of every head's channel slice at
-        the projected point + pixel offsets, softmax over level x point, the (point, level) x (level, point) pairing of
-        :611 / :705-707, visibility mask, sums over cameras / levels / points.  gd4d_detr3d_v2_fwd has no backward."""
+        """Training path.  The sampling (reference :597-710: projected reference point + per-head pixel offsets, softmax over
+        level x point, the (point, level) x (level, point) pairing of :611 / :705-707, visibility, the sums) runs on
+        gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd behind autograd.Detr3DV2SampleFunction (embed_dims <= 256;
+        GD4D_V2_BWD=torch or wider models: the same maths as differentiable torch ops, below); the Linears and LayerNorms are
+        the package's autograd Functions."""
+        if self.embed_dims <= 256 and os.environ.get('GD4D_V2_BWD', 'hip') != 'torch':
+            from .autograd import Detr3DV2SampleFunction
+            x = (query if query_pos is None else query + query_pos).permute(1, 0, 2).contiguous()      # (1, Q, C)
+            b, q, c = x.shape
+            n, hh, nl, npt = self.num_cams, self.num_heads, self.num_levels, self.num_points
+            logits = Fn.sequential_autograd(self.attention_weights, x).view(b, q, n, hh, nl * npt)
+            off = Fn.sequential_autograd(self.sampling_offsets, x).view(b, q, n, hh, nl, npt, 2)
+            lidar2img = Fn.lidar2img_device(img_metas, query)
+            img_h, img_w = Fn.img_hw(img_metas)
+            agg = Detr3DV2SampleFunction.apply(reference_points, logits, off, lidar2img, self.pc_range, img_h, img_w, hh, *value)
+            res = Fn.sequential_autograd(self.output_proj, agg.reshape(q, 1, c))
+            pos_feat = Fn.sequential_autograd(self.position_encoder, Fn.inverse_sigmoid(reference_points)).permute(1, 0, 2)
+            return self.dropout(res) + query + pos_feat
         x = query if query_pos is None else query + query_pos
         x = x.permute(1, 0, 2).contiguous()                                   # (1, Q, C)
         b, q, c = x.shape

@@ -717,6 +717,31 @@ def detr3d_v2_fwd(feats, ref, attn_logits, offsets, lidar2img, pc_range, img_h, 
     return (out, mask) if want_mask else out
 
 
+def detr3d_v2_bwd(feats, ref, attn_logits, offsets, lidar2img, pc_range, img_h, img_w, num_heads, grad_out, want_feats=True,
+                  want_ref=True):
+    """gd4d_detr3d_v2_bwd: the gradients of detr3d_v2_fwd's `out`.  Returns (grad_feats list or None, grad_attn_logits
+    (B, Q, N, Hh, L*P), grad_offsets (B, Q, N, Hh, L, P, 2), grad_ref (B, Q, 3) or None).  C <= 256."""
+    lib = _lib.load()
+    b, n, c = feats[0].shape[:3]
+    q = ref.shape[1]
+    nl = len(feats)
+    f32 = torch.float32
+    ptrs = (ctypes.c_void_p * nl)(*[_dev(f, f'feats[{i}]', f32).value for i, f in enumerate(feats)])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[-2:]])
+    rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
+    gfeats = [torch.zeros_like(f) for f in feats] if want_feats else None
+    gptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gfeats]) if want_feats else None
+    gl = torch.empty(b, q, n, num_heads, nl * nl, device=ref.device, dtype=f32)
+    go = torch.empty(b, q, n, num_heads, nl, nl, 2, device=ref.device, dtype=f32)
+    gr = torch.empty(b, q, 3, device=ref.device, dtype=f32) if want_ref else None
+    code = lib.gd4d_detr3d_v2_bwd(ptrs, lv, _dev(ref, 'ref', f32), _dev(attn_logits, 'attn_logits', f32),
+                                  _dev(offsets, 'offsets', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w),
+                                  _dev(grad_out, 'grad_out', f32), gptrs, _dev(gl, 'grad_logits'), _dev(go, 'grad_offsets'),
+                                  _dev(gr, 'grad_ref') if want_ref else None, b, n, q, c, nl, int(num_heads), _stream())
+    _lib.check(code, 'gd4d_detr3d_v2_bwd')
+    return gfeats, gl, go, gr
+
+
 def _vp_workspace(nlayers, device):
     """Scratch for the weight fragments of a value_proj launch (rewritten by every call: stream-ordered, so a fresh
     tensor per call keeps concurrent launches on different streams apart; the caching allocator makes it free)."""

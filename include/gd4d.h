@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 36
+#define GD4D_ABI_VERSION 37
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -363,6 +363,13 @@ int gd4d_detr3d_v2_fwd(const void* const* feats, const int32_t* level_hw, const 
                        const float* attn_logits, const float* offsets, const float* lidar2img,
                        const double* pc_range, float img_h, float img_w, float* out, uint8_t* mask_out, int B,
                        int N, int Q, int C, int Hh, int L, int P, void* stream);
+/* gd4d_detr3d_v2_bwd - backward of gd4d_detr3d_v2_fwd (the reference: autograd through detr3d_transformer.py:597-710):
+ *   grad_feats[l] (B*N, C, H_l, W_l) += (atomic; zero them first; NULL array: not wanted), grad_logits (B, Q, N, Hh, L*P),
+ *   grad_offsets (B, Q, N, Hh, L, P, 2), grad_ref (B, Q, 3) or NULL, from grad_out (B, Q, C).  P == L as the forward; C <= 256. */
+int gd4d_detr3d_v2_bwd(const void* const* feats, const int32_t* level_hw, const float* ref, const float* attn_logits,
+                       const float* offsets, const float* lidar2img, const double* pc_range, float img_h, float img_w,
+                       const float* grad_out, void* const* grad_feats, float* grad_logits, float* grad_offsets, float* grad_ref,
+                       int B, int N, int Q, int C, int L, int Hh, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_value_proj_fwd - value_proj (Linear C -> C) over the flattened multi-camera pyramid.

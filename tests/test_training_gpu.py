@@ -484,11 +484,18 @@ def test_deform3d_cross_attn_mp_trains(name):
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
 
 
+@pytest.mark.parametrize('route', ['hip', 'torch'])
 @pytest.mark.parametrize('name', ['detr3d_v2_n6', 'detr3d_v2_n12'])
-def test_detr3d_cross_atten_v2_trains(name):
+def test_detr3d_cross_atten_v2_trains(name, route, monkeypatch):
     """Detr3DCrossAttenV2 with autograd on: output = the inference kernel's, gradients = autograd of the oracle
-    (detr3d_transformer.py:441-710)."""
+    (detr3d_transformer.py:441-710).  route 'hip': gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd behind one autograd node (the
+    default); 'torch': the same sampling as differentiable torch ops (GD4D_V2_BWD=torch; models wider than 256 channels)."""
     from oracle import torch_oracle as O
+    from graph_detr4d_amd import ops
+    monkeypatch.setenv('GD4D_V2_BWD', route)
+    calls = []
+    real = ops.detr3d_v2_bwd
+    monkeypatch.setattr(ops, 'detr3d_v2_bwd', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     g = Golden(name)
     m = g.meta
     mod = G.build_attention(dict(type='Detr3DCrossAttenV2', num_cams=m['num_cams'], pc_range=m['pc_range'],
@@ -521,3 +528,4 @@ def test_detr3d_cross_atten_v2_trains(name):
     for k, prm in mod.named_parameters():
         assert prm.grad is not None, k
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
+    assert len(calls) == (1 if route == 'hip' else 0)
