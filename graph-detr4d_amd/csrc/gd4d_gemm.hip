@@ -31,7 +31,7 @@ struct GemmParams {
   const uint16_t* w_lo;
   const float* bias;
   float* c;
-  int M, N, K, lda, ldc, relu, relu_in;
+  int M, N, K, lda, ldc, relu, relu_in, mask_c;
 };
 
 __device__ __forceinline__ unsigned gm_cvt_pk_bf16(float lo_elem, float hi_elem) {
@@ -169,6 +169,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_bf16x3_kernel(const GemmParam
         if (m < p.M) {
           float v = acc[mi][ni][r] + bv;
           if (p.relu) v = fmaxf(v, 0.f);
+          // backward through a ReLU: c holds the forward's activation and is replaced by the gradient where it was > 0
+          if (p.mask_c && !(p.c[(size_t)m * p.ldc + n] > 0.f)) v = 0.f;
           p.c[(size_t)m * p.ldc + n] = v;
         }
       }
@@ -183,6 +185,142 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   const uint16_t h = f32_to_bf16(v);
   hi[i] = h;
   lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+}
+
+// ---- gd4d_gemm_tn_bf16x3: C (M, N) = sum over rows r of A[r, :M]^T B[r, :N] ------------------------------------------
+// The weight gradient of a Linear / 1x1 convolution over R rows (A = gradient of the output, B = the layer's input), with
+// the column sums of A (the bias gradient) on the side.  Same split-bf16 x 3 arithmetic as the forward.
+//
+// Both operands are read straight from HBM in the MFMA's own fragment layout - no LDS, no barrier: the contraction index
+// (rows) is the slow axis of both matrices, so a lane that owns output row i of an MFMA tile needs 8 consecutive ROWS of
+// one column.  A 16-byte load of columns 4 l32 .. 4 l32 + 3 serves FOUR tiles at once when tile `mi` is defined as the
+// columns {4 i + mi}: the tiles interleave in memory, every load is a dwordx4 (dwordx2 for B's two tiles), and the
+// interleave is undone for free when the result is stored.  Wave = 128 (M) x 64 (N): 4 x 2 tiles of 32x32x16, 24 MFMAs
+// per 16 rows against 16 loads; workgroup = 2 x 2 waves = 256 x 128.  Rows are cut into `splits` ranges (grid.y), each
+// writing its partial product; gemm_tn_reduce_kernel adds the partials in split order (fixed summation order, no atomics).
+struct GemmTnParams {
+  const float* a;
+  const float* b;
+  float* part;      // (splits, M, N)
+  float* colpart;   // (splits, M) or null
+  long long R;
+  int M, N, lda, ldb, rows_per_split, relu_b;
+};
+
+__device__ __forceinline__ void tn_split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hh[i] = gm_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float ra = v[2 * i] - __uint_as_float(hh[i] << 16);
+    const float rb = v[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u);
+    ll[i] = gm_cvt_pk_bf16(ra, rb);
+  }
+  h = __builtin_bit_cast(bf16x8, u32x4{hh[0], hh[1], hh[2], hh[3]});
+  l = __builtin_bit_cast(bf16x8, u32x4{ll[0], ll[1], ll[2], ll[3]});
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(const GemmTnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, kg = lane >> 5;
+  const int tiles_n = (p.N + 127) / 128;
+  const int m_base = ((int)blockIdx.x / tiles_n) * 256 + 128 * wm;
+  const int n_base = ((int)blockIdx.x % tiles_n) * 128 + 64 * wn;
+  if (m_base >= p.M || n_base >= p.N) return;          // (no barrier anywhere in this kernel)
+  const int split = blockIdx.y;
+  const long long r_begin = (long long)split * p.rows_per_split;
+  const long long r_end = min(p.R, r_begin + p.rows_per_split);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const float* ap = p.a + (size_t)(r_begin + 8 * kg) * p.lda + m_base + 4 * l32;
+  const float* bp = p.b + (size_t)(r_begin + 8 * kg) * p.ldb + n_base + 2 * l32;
+  float4 ra[8];
+  float2 rb[8];
+  auto issue = [&](long long r0) {                      // rows r0 + 8 kg + j; past the end: row R - 1, zeroed when used
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long back = max(0ll, r0 + 8 * kg + j - (p.R - 1));
+      ra[j] = *reinterpret_cast<const float4*>(ap + (ptrdiff_t)(r0 - r_begin + j - back) * p.lda);
+      rb[j] = *reinterpret_cast<const float2*>(bp + (ptrdiff_t)(r0 - r_begin + j - back) * p.ldb);
+    }
+  };
+  issue(r_begin);
+  for (long long r0 = r_begin; r0 < r_end; r0 += 16) {
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+    {
+      float va[4][8], vb[2][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool live = r0 + 8 * kg + j < r_end;
+        va[0][j] = live ? ra[j].x : 0.f; va[1][j] = live ? ra[j].y : 0.f;
+        va[2][j] = live ? ra[j].z : 0.f; va[3][j] = live ? ra[j].w : 0.f;
+        float bx = rb[j].x, by = rb[j].y;
+        if (p.relu_b) { bx = fmaxf(bx, 0.f); by = fmaxf(by, 0.f); }
+        vb[0][j] = bx; vb[1][j] = by;
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[mi] += va[mi][j];
+        tn_split8(va[mi], ah[mi], al[mi]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) tn_split8(vb[ni], bh[ni], bl[ni]);
+    }
+    if (r0 + 16 < r_end) issue(r0 + 16);                // the raw registers are free: next rows in flight under the MFMAs
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+      }
+  }
+
+  // tile (mi, ni), element (i, jn) is C[m_base + 4 i + mi][n_base + 2 jn + ni]; a lane holds jn = l32 and
+  // i = 8 (r >> 2) + 4 kg + (r & 3): its two ni values are neighbours in memory
+  float* out = p.part + (size_t)split * p.M * p.N;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 8 * (r >> 2) + 4 * kg + (r & 3);
+      *reinterpret_cast<float2*>(out + (size_t)(m_base + 4 * i + mi) * p.N + n_base + 2 * l32) =
+          make_float2(acc[mi][0][r], acc[mi][1][r]);
+    }
+  if (p.colpart && n_base == 0) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) csum[mi] += __shfl_xor(csum[mi], 32);
+    if (kg == 0)
+      *reinterpret_cast<float4*>(p.colpart + (size_t)split * p.M + m_base + 4 * l32) =
+          make_float4(csum[0], csum[1], csum[2], csum[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ colpart,
+                                                             float* __restrict__ c, float* __restrict__ colsum, int mn, int m,
+                                                             int splits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < mn) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * mn + i];
+    c[i] = s;
+  }
+  if (colsum && i < m) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += colpart[(size_t)k * m + i];
+    colsum[i] = s;
+  }
 }
 
 }  // namespace gd4d
@@ -202,9 +340,44 @@ extern "C" int gd4d_gemm_bf16x3_fwd(const float* a, const uint16_t* w_hi, const 
   if (N % GM_BN != 0 || K % GM_BK != 0 || lda % 4 != 0) return GD4D_EUNSUPPORTED;
   if (!aligned16(a) || !aligned16(w_hi) || !aligned16(w_lo)) return GD4D_EALIGN;
   GemmParams p{a, w_hi, w_lo, bias, c, M, N, K, lda, ldc, (flags & GD4D_LIN_RELU) ? 1 : 0,
-               (flags & GD4D_GEMM_RELU_IN) ? 1 : 0};
+               (flags & GD4D_GEMM_RELU_IN) ? 1 : 0, (flags & GD4D_GEMM_MASK_C) ? 1 : 0};
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16x3_kernel), 2 * GM_STAGE)) return GD4D_ELAUNCH;
   const dim3 grid(N / GM_BN, (M + GM_BM - 1) / GM_BM);
   hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(GM_THREADS), 2 * GM_STAGE, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}
+
+namespace gd4d {
+static int tn_splits(long long R, int M, int N) {
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  long long want = (1024 + tiles - 1) / tiles;                      // about four workgroups per CU
+  const long long most = (R + 255) / 256;                           // at least 256 rows per split
+  if (want > most) want = most;
+  return (int)(want < 1 ? 1 : want);
+}
+}  // namespace gd4d
+
+extern "C" size_t gd4d_gemm_tn_bf16x3_workspace_bytes(long long R, int M, int N) {
+  if (R <= 0 || M <= 0 || N <= 0) return 0;
+  return (size_t)gd4d::tn_splits(R, M, N) * ((size_t)M * N + M) * sizeof(float);
+}
+
+extern "C" int gd4d_gemm_tn_bf16x3(const float* a, const float* b, float* c, float* colsum, void* workspace, long long R, int M,
+                                   int N, int lda, int ldb, int flags, void* stream) {
+  using namespace gd4d;
+  if (!a || !b || !c || !workspace || R <= 0 || M <= 0 || N <= 0 || lda < M || ldb < N) return GD4D_EINVAL;
+  if (M % 128 != 0 || N % 64 != 0 || lda % 4 != 0 || ldb % 2 != 0 || (size_t)M * N > (size_t)1 << 30) return GD4D_EUNSUPPORTED;
+  if (!aligned16(a) || ((uintptr_t)b & 7) || !aligned16(workspace)) return GD4D_EALIGN;
+  const int splits = tn_splits(R, M, N);
+  long long rows = (R + splits - 1) / splits;
+  rows = (rows + 15) / 16 * 16;
+  float* part = static_cast<float*>(workspace);
+  float* colpart = part + (size_t)splits * M * N;
+  GemmTnParams p{a, b, part, colsum ? colpart : nullptr, R, M, N, lda, ldb, (int)rows, (flags & GD4D_GEMM_RELU_IN) ? 1 : 0};
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, part, colpart, c, colsum, M * N, M,
+                     splits);
   return check_launch();
 }

@@ -175,6 +175,39 @@ __global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __rest
   }
 }
 
+// Backward of se_fuse_chlast_kernel for one level.  grad_out arrives NCHW; everything downstream (the weight-gradient
+// contractions over pixels) wants channels-last rows, so this is the transposing pass in the other direction:
+//   grad_sine[o] = g,   grad_pe[o] = g sigmoid(gate[o]),   grad_gate[o] = g pe[o] sigmoid'(gate[o])     (o = channels-last)
+// grad_pe / grad_gate may be the pe / gate buffers themselves (each element is read, then written, by one thread).
+__global__ __launch_bounds__(256) void se_fuse_chlast_bwd_kernel(const float* __restrict__ grad_out, const float* gate,
+                                                                 const float* pe, float* grad_gate, float* grad_pe,
+                                                                 float* __restrict__ grad_sine, int C, int HW, int S,
+                                                                 int start) {
+  __shared__ float tile[32][33];
+  const int r = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                       // read NCHW: tx = pixel, rows = channels
+    const int c = c0 + ty + 8 * i, pix = p0 + tx;
+    tile[ty + 8 * i][tx] = pix < HW ? grad_out[((size_t)r * C + c) * HW + pix] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                       // write channels-last: tx = channel, rows = pixels
+    const int pix = p0 + ty + 8 * i, c = c0 + tx;
+    if (pix < HW) {
+      const size_t o = ((size_t)r * S + start + pix) * C + c;
+      const float g = tile[tx][ty + 8 * i];
+      const float s = 1.0f / (1.0f + expf(-gate[o]));
+      const float pv = pe[o];
+      grad_sine[o] = g;
+      grad_pe[o] = g * s;
+      grad_gate[o] = g * pv * (s * (1.0f - s));
+    }
+  }
+}
+
 }  // namespace gd4d
 
 extern "C" int gd4d_frustum_pe_input_fwd(const float* img2lidar, float* out, uint8_t* outside, int R, int H, int W, int D,
@@ -239,5 +272,18 @@ extern "C" int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, con
   hipLaunchKernelGGL(se_fuse_chlast_kernel, dim3((HW + 31) / 32, C / 32, R), dim3(256), 0,
                      static_cast<hipStream_t>(stream), feat, gate, pe, sine, out, C, HW, row_pixels, row_start,
                      sine_chlast ? 1 : 0);
+  return check_launch();
+}
+
+extern "C" int gd4d_se_fuse_chlast_bwd(const float* grad_out, const float* gate, const float* pe, float* grad_gate,
+                                       float* grad_pe, float* grad_sine, int R, int C, int HW, int row_pixels, int row_start,
+                                       void* stream) {
+  using namespace gd4d;
+  if (!grad_out || !gate || !pe || !grad_gate || !grad_pe || !grad_sine || R <= 0 || C <= 0 || HW <= 0) return GD4D_EINVAL;
+  if (row_start < 0 || row_start + HW > row_pixels) return GD4D_EINVAL;
+  if (C % 32 != 0 || R > 65535) return GD4D_EUNSUPPORTED;
+  hipLaunchKernelGGL(se_fuse_chlast_bwd_kernel, dim3((HW + 31) / 32, C / 32, R), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), grad_out, gate, pe, grad_gate, grad_pe, grad_sine, C, HW, row_pixels,
+                     row_start);
   return check_launch();
 }

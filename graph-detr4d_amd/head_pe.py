@@ -34,6 +34,98 @@ class SELayer(nn.Module):
         return self.conv_expand(F.relu(self.conv_reduce(x_se)))
 
 
+class _HeadPEFunction(torch.autograd.Function):
+    """The differentiable part of the stage on the library's kernels, forward and backward: the two position MLPs
+    (Conv1x1 -> ReLU -> Conv1x1, detr3d_head_pe.py:380-390), the SE gate (:231-243) and the sum (:556), all in
+    channels-last rows over every level side by side.
+
+    forward:  hid = relu(x W0^T + b0), pe = hid W2^T + b2 (gd4d_gemm_bf16x3_fwd); the same for the sine input;
+              g1 = conv_reduce(feats) (gd4d_value_proj_fwd, NCHW in), gate = relu(g1) We^T + be; out = feats + pe
+              sigmoid(gate) + sine (gd4d_se_fuse_chlast_fwd).
+    backward: gd4d_se_fuse_chlast_bwd (transposes grad_out, gate / pe derivatives in place), gd4d_gemm_tn_bf16x3 for every
+              weight / bias gradient, gd4d_gemm_bf16x3_fwd with GD4D_GEMM_MASK_C for the gradients at the ReLUs (written
+              over the saved activations: the buffers are used once, so a second backward through the same graph is
+              refused), gd4d_value_proj_bwd_weight / _bwd_input for conv_reduce (NCHW side).
+    Inputs x / xs (frustum coordinates, sine expansion) carry no gradient (the reference builds them under no_grad /
+    from masks)."""
+
+    @staticmethod
+    def forward(ctx, x, xs, starts, nl, *args):
+        feats = [f.contiguous() for f in args[:nl]]
+        w0, b0, w2, b2, a0, ab0, a2, ab2, wr, br, we, be = args[nl:]
+        r = feats[0].shape[0]
+        s_tot = x.shape[1]
+        c = w2.shape[0]
+        flat = lambda w: w.detach().reshape(w.shape[0], -1).contiguous()
+        split = lambda w: ops.split_bf16_fwd(flat(w))
+        hid = ops.gemm_bf16x3_fwd(x.view(r * s_tot, -1), *split(w0), b0, relu=True)
+        pe = ops.gemm_bf16x3_fwd(hid, *split(w2), b2).view(r, s_tot, c)
+        hs = ops.gemm_bf16x3_fwd(xs.view(r * s_tot, -1), *split(a0), ab0, relu=True)
+        sine = ops.gemm_bf16x3_fwd(hs, *split(a2), ab2).view(r, s_tot, c)
+        g1 = ops.value_proj_fwd(feats, flat(wr), br.detach().contiguous())
+        gate = ops.gemm_bf16x3_fwd(g1.view(r * s_tot, -1), *split(we), be, relu_in=True).view(r, s_tot, c)
+        out = [ops.se_fuse_chlast_fwd(f, gate, pe, sine, st) for f, st in zip(feats, starts)]
+        del sine
+        ctx.bufs = dict(x=x, xs=xs, hid=hid, hs=hs, g1=g1, gate=gate, pe=pe, feats=feats)
+        ctx.weights = (flat(w2), flat(a2), flat(wr), flat(we))
+        ctx.shapes = [tuple(w.shape) for w in (w0, w2, a0, a2, wr, we)]
+        ctx.starts, ctx.nl = starts, nl
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if ctx.bufs is None:
+            raise RuntimeError('FeaturePositionEmbedding: the saved activations were consumed by the first backward '
+                               '(retain_graph / double backward are not supported on the HIP path; GD4D_HEAD_PE_BWD=torch)')
+        b, ctx.bufs = ctx.bufs, None
+        nl, starts = ctx.nl, ctx.starts
+        w2, a2, wr, we = ctx.weights
+        feats = b['feats']
+        r, s_tot, c = b['pe'].shape
+        need = ctx.needs_input_grad[4:]
+        need_f, need_p = need[:nl], need[nl:]
+        dsine = torch.empty_like(b['pe'])
+        dfeat = []
+        for l in range(nl):
+            g = grads[l]
+            g = torch.zeros_like(feats[l]) if g is None else g.contiguous()
+            ops.se_fuse_chlast_bwd(g, b['gate'], b['pe'], dsine, starts[l])       # gate / pe now hold their gradients
+            dfeat.append(g)
+        rows = r * s_tot
+        dgate, dpe = b['gate'].view(rows, c), b['pe'].view(rows, c)
+        out = [None] * 12
+        tsplit = lambda w: ops.split_bf16_fwd(w.t().contiguous())
+
+        def mlp(dy, hidden, inp, w_second, idx):
+            """Conv -> ReLU -> Conv from the gradient of its output: fills out[idx .. idx + 3] (w0, b0, w2, b2)."""
+            if not any(need_p[idx:idx + 4]):
+                return
+            gw, gb = ops.gemm_tn_bf16x3(dy, hidden)                               # second conv: (C, hidden)
+            out[idx + 2], out[idx + 3] = gw, gb
+            if need_p[idx] or need_p[idx + 1]:
+                ops.gemm_bf16x3_fwd(dy, *tsplit(w_second), out=hidden, mask_out=True)   # gradient at the ReLU's input
+                out[idx], out[idx + 1] = ops.gemm_tn_bf16x3(hidden, inp.view(rows, -1))
+
+        mlp(dpe, b['hid'], b['x'], w2, 0)
+        mlp(dsine.view(rows, c), b['hs'], b['xs'], a2, 4)
+        del dsine
+        g1 = b['g1'].view(rows, c)
+        out[10], out[11] = ops.gemm_tn_bf16x3(dgate, g1, relu_b=True)
+        if any(need_f) or need_p[8] or need_p[9]:
+            ops.gemm_bf16x3_fwd(dgate, *tsplit(we), out=g1, mask_out=True)        # gradient of conv_reduce's output
+            out[8], out[9] = ops.value_proj_bwd_weight(b['g1'], feats)
+            if any(need_f):
+                shapes = [tuple(f.shape[-2:]) for f in feats]
+                dfeat = [g.clone() if g is go else g for g, go in zip(dfeat, grads)]     # grad_out is autograd's: not in place
+                ops.value_proj_bwd_input(b['g1'], wr, shapes, grads=dfeat, accumulate=True)
+        for i, sh in enumerate(ctx.shapes):                                       # conv weights are (out, in, 1, 1)
+            if out[2 * i] is not None:
+                out[2 * i] = out[2 * i].view(sh)
+        shaped = [o if n else None for o, n in zip(out, need_p)]
+        dfeat = [g if n else None for g, n in zip(dfeat, need_f)]
+        return (None, None, None, None, *dfeat, *shaped)
+
+
 class FeaturePositionEmbedding(nn.Module):
     def __init__(self, embed_dims=256, depth_num=64, depth_start=1, pc_range=None, num_feats=128, temperature=10000,
                  normalize=True, scale=2 * math.pi, eps=1e-6, offset=-0.5, with_detach=True, cams_per_frame=6):
@@ -192,14 +284,18 @@ class FeaturePositionEmbedding(nn.Module):
     def _forward_autograd(self, feats, img_metas):
         """The stage with autograd on (the head trains through it: gradients reach the backbone's feature maps, the two
         position MLPs and the SE gate, detr3d_head_pe.py:546-557).  The geometry needs no gradient and stays on the HIP
-        kernels (frustum coordinates -> conv input, sine / cosine expansion, padding masks); the 1x1 convolutions, the
-        gate and the adds are torch ops here, so autograd differentiates them - the split-bf16 GEMM path of inference has
-        no backward kernels yet."""
+        kernels (frustum coordinates -> conv input, sine / cosine expansion, padding masks); the differentiable part runs on
+        _HeadPEFunction (the library's GEMMs forward and backward) when the shapes fit it; otherwise - or with
+        GD4D_HEAD_PE_BWD=torch - the 1x1 convolutions, the gate and the adds are torch ops and autograd differentiates
+        them."""
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
             b, n = feats[0].shape[:2]
             l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
             img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(b * n, 4, 4).to(feats[0].device)   # :459-465
+        if self._gemm_ok(feats) and os.environ.get('GD4D_HEAD_PE_BWD', 'hip') != 'torch':
+            return self._forward_hip_train(feats, masks, pad_hw, img2lidar)
+        with torch.no_grad():
             xs = [ops.frustum_pe_input_fwd(img2lidar, tuple(f.shape[-2:]), pad_hw, self.depth_num, self.depth_start,
                                            self.pc_range)[0] for f in feats]
             sines = [self.sine_embedding(m) for m in masks]
@@ -210,6 +306,34 @@ class FeaturePositionEmbedding(nn.Module):
             sine = self.adapt_pos3d(s.flatten(0, 1)).view(f.shape)
             out.append(f + (pe * torch.sigmoid(gate) + sine))
         return out
+
+    def _gemm_ok(self, feats):
+        return self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256 and \
+            (3 * self.num_feats) % 32 == 0
+
+    def _forward_hip_train(self, feats, masks, pad_hw, img2lidar):
+        """Training on the library's own kernels (_HeadPEFunction): geometry as in _forward_gemm, channels-last, all
+        levels side by side."""
+        b, n = feats[0].shape[:2]
+        r = b * n
+        dev = feats[0].device
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        sizes = [h * w for h, w in shapes]
+        starts = [sum(sizes[:i]) for i in range(len(sizes))]
+        with torch.no_grad():
+            x = torch.empty(r, sum(sizes), self.position_dim, device=dev, dtype=torch.float32)
+            xs = torch.empty(r, sum(sizes), 3 * self.num_feats, device=dev, dtype=torch.float32)
+            for (h, w), st, m in zip(shapes, starts, masks):
+                ops.frustum_pe_input_fwd(img2lidar, (h, w), pad_hw, self.depth_num, self.depth_start, self.pc_range,
+                                         out=x, row_start=st)
+                embeds, dim_t = self._sine_embeds(m)
+                ops.sine_pe3d_fwd(*embeds, dim_t, out=xs, row_start=st)
+        pe0, pe2, a0, a2 = self.position_encoder[0], self.position_encoder[2], self.adapt_pos3d[0], self.adapt_pos3d[2]
+        cr, ce = self.fpe.conv_reduce, self.fpe.conv_expand
+        out = _HeadPEFunction.apply(x, xs, starts, len(feats), *[f.flatten(0, 1) for f in feats],
+                                    pe0.weight, pe0.bias, pe2.weight, pe2.bias, a0.weight, a0.bias, a2.weight, a2.bias,
+                                    cr.weight, cr.bias, ce.weight, ce.bias)
+        return [o.view(f.shape) for o, f in zip(out, feats)]
 
     # ---- the stage ------------------------------------------------------------------------------------------------
     def forward(self, mlvl_feats, img_metas):
@@ -225,9 +349,7 @@ class FeaturePositionEmbedding(nn.Module):
             return self._forward_autograd(feats, img_metas)
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
-            gemm_ok = self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256 and \
-                (3 * self.num_feats) % 32 == 0
-            if gemm_ok and os.environ.get('GD4D_HEAD_PE', 'gemm') != 'conv':
+            if self._gemm_ok(feats) and os.environ.get('GD4D_HEAD_PE', 'gemm') != 'conv':
                 return self._forward_gemm(feats, img_metas, masks, pad_hw, self._sine_branch(masks, chlast=True))
             sine = self._sine_branch(masks)
             coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)

@@ -1212,6 +1212,18 @@ def sine_pe3d_fwd(n_embed, y_embed, x_embed, dim_t, out=None, row_start=0):
     return out
 
 
+def se_fuse_chlast_bwd(grad_out, gate, pe, grad_sine, row_start):
+    """gd4d_se_fuse_chlast_bwd for one level: grad_out (R, C, H, W); gate / pe (R, S, C) are REPLACED by their gradients on
+    the level's rows, grad_sine (R, S, C) receives grad_out channels-last."""
+    lib = _lib.load()
+    r, c, h, w = grad_out.shape
+    code = lib.gd4d_se_fuse_chlast_bwd(_dev(grad_out, 'grad_out', torch.float32), _dev(gate, 'gate', torch.float32),
+                                       _dev(pe, 'pe', torch.float32), _dev(gate, 'gate'), _dev(pe, 'pe'),
+                                       _dev(grad_sine, 'grad_sine', torch.float32), r, c, h * w, gate.shape[1],
+                                       int(row_start), _stream())
+    _lib.check(code, 'gd4d_se_fuse_chlast_bwd')
+
+
 def se_fuse_fwd(feat, gate, pe, sine, out=None):
     """gd4d_se_fuse_fwd: feat + (pe * sigmoid(gate) + sine), all the same shape."""
     lib = _lib.load()
@@ -1234,18 +1246,47 @@ def split_bf16_fwd(w):
     return hi, lo
 
 
-def gemm_bf16x3_fwd(a, w_hi, w_lo, bias=None, relu=False, out=None, relu_in=False):
-    """gd4d_gemm_bf16x3_fwd: a (M, K) fp32 row-major, w_hi / w_lo (N, K) bf16 -> act(a W^T + b) (M, N) fp32."""
+def gemm_bf16x3_fwd(a, w_hi, w_lo, bias=None, relu=False, out=None, relu_in=False, mask_out=False):
+    """gd4d_gemm_bf16x3_fwd: a (M, K) fp32 row-major, w_hi / w_lo (N, K) bf16 -> act(a W^T + b) (M, N) fp32.
+    mask_out: `out` holds a ReLU's forward output and is replaced by the result where it was > 0, by 0 elsewhere."""
     lib = _lib.load()
     m, k = a.shape
     n = w_hi.shape[0]
     if out is None:
+        if mask_out:
+            raise ValueError('mask_out=True needs `out` = the activations of the forward')
         out = torch.empty(m, n, device=a.device, dtype=torch.float32)
     code = lib.gd4d_gemm_bf16x3_fwd(_dev(a, 'a', torch.float32), _dev(w_hi, 'w_hi', torch.bfloat16),
                                     _dev(w_lo, 'w_lo', torch.bfloat16), _opt(bias, 'bias'), _dev(out, 'out'), m, n, k, k, n,
-                                    int(bool(relu)) | (16 if relu_in else 0), _stream())
+                                    int(bool(relu)) | (16 if relu_in else 0) | (32 if mask_out else 0), _stream())
     _lib.check(code, 'gd4d_gemm_bf16x3_fwd')
     return out
+
+
+_TN_WS = {}
+
+
+def gemm_tn_bf16x3(a, b, relu_b=False, want_colsum=True):
+    """gd4d_gemm_tn_bf16x3: a (R, M), b (R, N) fp32 row-major -> (a^T b (M, N), column sums of a (M) or None): the weight /
+    bias gradients of a Linear over R rows (a = output gradient, b = input; relu_b: ReLU on b as it is read)."""
+    lib = _lib.load()
+    r, m = a.shape
+    n = b.shape[1]
+    if b.shape[0] != r:
+        raise ValueError(f'gemm_tn_bf16x3: {tuple(a.shape)} against {tuple(b.shape)}')
+    dev = a.device
+    nbytes = lib.gd4d_gemm_tn_bf16x3_workspace_bytes(r, m, n)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _TN_WS[key] = ws
+    c = torch.empty(m, n, device=dev, dtype=torch.float32)
+    col = torch.empty(m, device=dev, dtype=torch.float32) if want_colsum else None
+    code = lib.gd4d_gemm_tn_bf16x3(_dev(a, 'a', torch.float32), _dev(b, 'b', torch.float32), _dev(c, 'c'), _opt(col, 'colsum'),
+                                   _dev(ws, 'workspace'), r, m, n, m, n, 16 if relu_b else 0, _stream())
+    _lib.check(code, 'gd4d_gemm_tn_bf16x3')
+    return c, col
 
 
 def knn_farthest_fwd(x, k):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 37
+#define GD4D_ABI_VERSION 38
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -453,7 +453,8 @@ int gd4d_value_proj_bwd_weight(const float* grad_out, const void* const* feats, 
 #define GD4D_LIN_INV_SIGMOID_IN 2
 #define GD4D_LIN_RELU_AFTER_LN 4
 #define GD4D_LIN_WEIGHT_KN 8        /* gd4d_linear_fwd: `weight` is (K, N) row-major - y = x W (the input gradient of a Linear whose weight is W) */
-#define GD4D_GEMM_RELU_IN 16       /* gd4d_gemm_bf16x3_fwd: ReLU on the elements of A as they are read */
+#define GD4D_GEMM_RELU_IN 16       /* gd4d_gemm_bf16x3_fwd: ReLU on the elements of A as they are read (gd4d_gemm_tn_bf16x3: of B) */
+#define GD4D_GEMM_MASK_C 32        /* gd4d_gemm_bf16x3_fwd: c holds a ReLU's output on entry; result written where it was > 0, else 0 */
 int gd4d_linear_fwd(const float* x, const float* x2, const float* w, const float* bias,
                     const float* r1, const float* r2, float* y, int M, int K, int N, int n_split,
                     int flags, int ldx, int ldy, int ldr1, int ldr2, float* xsum, void* stream);
@@ -726,6 +727,12 @@ int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, cons
 int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out, int R,
                             int C, int HW, int row_pixels, int row_start, int sine_chlast, void* stream);
 /*   sine_chlast != 0: `sine` is channels-last (R, row_pixels, C) like gate / pe instead of NCHW. */
+/* gd4d_se_fuse_chlast_bwd - its backward for one level (what autograd derives from detr3d_head_pe.py:241-243, :556):
+ * grad_out NCHW (R, C, HW) -> channels-last rows [row_start, row_start + HW) of grad_sine = g, grad_pe = g sigmoid(gate),
+ * grad_gate = g pe sigmoid'(gate).  grad_pe / grad_gate may alias pe / gate (in place).  The gradient of `feat` through
+ * the sum is grad_out itself. */
+int gd4d_se_fuse_chlast_bwd(const float* grad_out, const float* gate, const float* pe, float* grad_gate, float* grad_pe,
+                            float* grad_sine, int R, int C, int HW, int row_pixels, int row_start, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * gd4d_gemm_bf16x3_fwd - C = act(A W^T + b): row-major fp32 A (M, K) and C (M, N), W (N, K) given as its bf16 split
@@ -738,6 +745,20 @@ int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* p
 int gd4d_split_bf16_fwd(const float* w, uint16_t* hi, uint16_t* lo, size_t n, void* stream);
 int gd4d_gemm_bf16x3_fwd(const float* a, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias, float* c, int M,
                          int N, int K, int lda, int ldc, int flags, void* stream);
+/* GD4D_GEMM_MASK_C: the input gradient of Linear -> ReLU -> Linear's first half: A = gradient of the second Linear's
+ * output, W = its weight transposed, c = the ReLU's output of the forward, replaced in place by the gradient at the
+ * ReLU's input.
+ *
+ * gd4d_gemm_tn_bf16x3 - C (M, N) = sum_r A[r, :M]^T B[r, :N] over R rows, colsum (M) = sum_r A[r, :] (NULL: skipped): the
+ * weight and bias gradients of a Linear / 1x1 convolution over R pixels (A = output gradient (R, M), B = the layer's
+ * input (R, N)), i.e. what autograd computes for detr3d_head_pe.py:380-390's convolutions.  Same split-bf16 x 3
+ * arithmetic; the rows are cut into ranges whose partial products go to `workspace`
+ * (gd4d_gemm_tn_bf16x3_workspace_bytes(R, M, N)) and are added in range order - the same bits every run.
+ * flags: GD4D_GEMM_RELU_IN = ReLU on B as it is read.  Supported: M % 128 == 0, N % 64 == 0, lda % 4 == 0, ldb % 2 == 0.
+ */
+size_t gd4d_gemm_tn_bf16x3_workspace_bytes(long long R, int M, int N);
+int gd4d_gemm_tn_bf16x3(const float* a, const float* b, float* c, float* colsum, void* workspace, long long R, int M, int N,
+                        int lda, int ldb, int flags, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * DGCNNAttn (projects/mmdet3d_plugin/models/utils/dgcnn_attn.py:10-96), registered by the reference, used by no

@@ -78,10 +78,17 @@ def test_feature_position_embedding_matches_reference():
         mod.cpu()([f.cpu() for f in feats], _metas(g))
 
 
-def test_feature_position_embedding_trains():
+@pytest.mark.parametrize('route', ['hip', 'torch'])
+def test_feature_position_embedding_trains(route, monkeypatch):
     """With autograd on, the stage equals the inference path and its gradients - to the feature maps (the backbone's),
-    the two position MLPs and the SE gate - equal autograd of the oracle (a restatement of detr3d_head_pe.py:525-557)."""
+    the two position MLPs and the SE gate - equal autograd of the oracle (a restatement of detr3d_head_pe.py:525-557).
+    hip: forward and backward on the library's own kernels (_HeadPEFunction); torch: the 1x1 convolutions as torch ops."""
     import numpy as np
+    from graph_detr4d_amd import head_pe, ops
+    monkeypatch.setenv('GD4D_HEAD_PE_BWD', route)
+    calls = []
+    real = ops.gemm_tn_bf16x3
+    monkeypatch.setattr(ops, 'gemm_tn_bf16x3', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     g = Golden('head_pe')
     m = g.meta
     mod = _module(g)
@@ -108,6 +115,85 @@ def test_feature_position_embedding_trains():
         assert prm.grad is not None, name
         tol = 2e-3 * max(1.0, want.abs().max().item())
         assert (prm.grad.cpu() - want).abs().max().item() < tol, name
+    assert len(calls) == (5 if route == 'hip' else 0)          # the five weight gradients that are GEMMs over pixels
+
+
+def test_head_pe_second_backward_is_refused():
+    g = Golden('head_pe')
+    mod = _module(g)
+    feats = [f.cuda().requires_grad_() for f in g.feats()]
+    loss = sum(o.sum() for o in mod(feats, _metas(g)))
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='consumed'):
+        loss.backward()
+
+
+@pytest.mark.parametrize('rows,m,n,relu_b', [(1000, 256, 1024, False), (4099, 1024, 192, False), (777, 256, 256, True),
+                                               (15, 128, 64, False), (70000, 1024, 384, False)])
+def test_gemm_tn_bf16x3_matches_fp64(rows, m, n, relu_b):
+    """C = A^T B and the column sums of A against fp64; ragged row counts (tail of 16, empty splits), every (M, N) the head
+    uses; the same bits on a second run (fixed summation order)."""
+    from graph_detr4d_amd import ops
+    gen = torch.Generator().manual_seed(rows)
+    a = torch.randn(rows, m, generator=gen).cuda()
+    b = torch.randn(rows, n, generator=gen).cuda()
+    c, col = ops.gemm_tn_bf16x3(a, b, relu_b=relu_b)
+    bb = b.double().clamp_min(0) if relu_b else b.double()
+    want = a.double().t() @ bb
+    scale = (a.double().abs().t() @ bb.abs()).max().item()
+    assert (c.double() - want).abs().max().item() < 1.5e-5 * scale          # 2^-16 per product (dropped lo x lo term)
+    torch.testing.assert_close(col.double(), a.double().sum(0), rtol=1e-5, atol=1e-4 * rows ** 0.5)
+    c2, col2 = ops.gemm_tn_bf16x3(a, b, relu_b=relu_b)
+    assert torch.equal(c, c2) and torch.equal(col, col2)
+    c3, none = ops.gemm_tn_bf16x3(a, b, relu_b=relu_b, want_colsum=False)
+    assert none is None and torch.equal(c, c3)
+
+
+def test_gemm_tn_rejects_unsupported_shapes():
+    from graph_detr4d_amd import ops, _lib
+    a, b = torch.randn(64, 100).cuda(), torch.randn(64, 64).cuda()
+    with pytest.raises(_lib.Gd4dError):
+        ops.gemm_tn_bf16x3(a, b)
+    with pytest.raises(ValueError):
+        ops.gemm_tn_bf16x3(torch.randn(64, 128).cuda(), torch.randn(63, 64).cuda())
+
+
+def test_gemm_mask_out_is_the_gradient_at_a_relu():
+    from graph_detr4d_amd import ops
+    torch.manual_seed(5)
+    dy, w = torch.randn(300, 256).cuda(), torch.randn(256, 1024).cuda() * 0.1          # y = h W^T, W (256, 1024)
+    h = torch.relu(torch.randn(300, 1024)).cuda()
+    want = (dy.double() @ w.double()) * (h > 0)
+    got = h.clone()
+    ops.gemm_bf16x3_fwd(dy, *ops.split_bf16_fwd(w.t().contiguous()), out=got, mask_out=True)
+    torch.testing.assert_close(got.double(), want, rtol=1e-4, atol=1e-4)
+    assert ((got == 0) | (h > 0)).all()
+    with pytest.raises(ValueError):
+        ops.gemm_bf16x3_fwd(dy, *ops.split_bf16_fwd(w.t().contiguous()), mask_out=True)
+
+
+def test_se_fuse_chlast_bwd_equals_autograd():
+    from graph_detr4d_amd import ops
+    torch.manual_seed(1)
+    r, c, sizes = 3, 256, [(9, 4), (5, 7)]
+    s_tot = sum(h * w for h, w in sizes)
+    gate, pe = (torch.randn(r, s_tot, c).cuda().requires_grad_() for _ in range(2))
+    gouts = [torch.randn(r, c, h, w).cuda() for h, w in sizes]
+    start, loss = 0, 0
+    for (h, w), go in zip(sizes, gouts):
+        sl = slice(start, start + h * w)
+        val = (pe[:, sl] * torch.sigmoid(gate[:, sl])).transpose(1, 2).reshape(r, c, h, w)
+        loss = loss + (val * go).sum()
+        start += h * w
+    loss.backward()
+    g_buf, p_buf, ds = gate.detach().clone(), pe.detach().clone(), torch.empty(r, s_tot, c).cuda()
+    start = 0
+    for (h, w), go in zip(sizes, gouts):
+        ops.se_fuse_chlast_bwd(go, g_buf, p_buf, ds, start)
+        torch.testing.assert_close(ds[:, start:start + h * w], go.flatten(2).transpose(1, 2))
+        start += h * w
+    torch.testing.assert_close(g_buf, gate.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p_buf, pe.grad, rtol=1e-5, atol=1e-6)
 
 
 def test_se_fuse_equals_torch():
