@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 38
+ABI_VERSION = 39
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -77,6 +77,8 @@ SIGNATURES = {
     'gd4d_se_fuse_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_split_bf16_fwd': (_i, [_vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_gemm_bf16x3_fwd': (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
+    'gd4d_image_job_bytes': (ctypes.c_size_t, []),
+    'gd4d_chain_weight_image_group': (_i, [_vp, _i, _i, _vp]),
     'gd4d_gemm_tn_bf16x3_workspace_bytes': (ctypes.c_size_t, [ctypes.c_longlong, _i, _i]),
     'gd4d_gemm_tn_bf16x3': (_i, [_vp] * 5 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     'gd4d_se_fuse_chlast_bwd': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),

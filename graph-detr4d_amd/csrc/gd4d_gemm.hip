@@ -307,19 +307,34 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(const GemmTnParams 
   }
 }
 
+// Sum of the partial products in split order.  Four elements per thread (float4), the splits cut into four consecutive
+// groups (threadIdx.y) whose sums meet in LDS and are added in group order: a fixed order whatever the launch.
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ colpart,
                                                              float* __restrict__ c, float* __restrict__ colsum, int mn, int m,
                                                              int splits) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < mn) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * mn + i];
-    c[i] = s;
+  __shared__ float4 sums[4][64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = 4 * (blockIdx.x * 64 + tx);
+  const int per = (splits + 3) / 4;
+  const int k0 = grp * per, k1 = min(splits, k0 + per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < mn)
+    for (int k = k0; k < k1; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * mn + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sums[grp][tx] = s;
+  __syncthreads();
+  if (grp == 0 && i < mn) {
+#pragma unroll
+    for (int g = 1; g < 4; ++g) { s.x += sums[g][tx].x; s.y += sums[g][tx].y; s.z += sums[g][tx].z; s.w += sums[g][tx].w; }
+    *reinterpret_cast<float4*>(c + i) = s;
   }
-  if (colsum && i < m) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += colpart[(size_t)k * m + i];
-    colsum[i] = s;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (colsum && j < m) {
+    float t = 0.f;
+    for (int k = 0; k < splits; ++k) t += colpart[(size_t)k * m + j];
+    colsum[j] = t;
   }
 }
 
@@ -367,7 +382,7 @@ extern "C" int gd4d_gemm_tn_bf16x3(const float* a, const float* b, float* c, flo
   using namespace gd4d;
   if (!a || !b || !c || !workspace || R <= 0 || M <= 0 || N <= 0 || lda < M || ldb < N) return GD4D_EINVAL;
   if (M % 128 != 0 || N % 64 != 0 || lda % 4 != 0 || ldb % 2 != 0 || (size_t)M * N > (size_t)1 << 30) return GD4D_EUNSUPPORTED;
-  if (!aligned16(a) || ((uintptr_t)b & 7) || !aligned16(workspace)) return GD4D_EALIGN;
+  if (!aligned16(a) || ((uintptr_t)b & 7) || !aligned16(workspace) || !aligned16(c)) return GD4D_EALIGN;
   const int splits = tn_splits(R, M, N);
   long long rows = (R + splits - 1) / splits;
   rows = (rows + 15) / 16 * 16;
@@ -377,7 +392,7 @@ extern "C" int gd4d_gemm_tn_bf16x3(const float* a, const float* b, float* c, flo
   const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, part, colpart, c, colsum, M * N, M,
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((M * N / 4 + 63) / 64), dim3(256), 0, st, part, colpart, c, colsum, M * N, M,
                      splits);
   return check_launch();
 }

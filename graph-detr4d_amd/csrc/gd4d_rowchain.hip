@@ -150,6 +150,60 @@ __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __
   }
 }
 
+// Every weight image a TRAINING step needs - forward (W) and backward (W^T) operands of its chains - in ONE launch: the weights
+// change with every optimizer step, and inside a replayed hipGraph nothing can notice that from the host.  A job describes a
+// logical matrix S = up to three row blocks stacked (the Linears of one input; unused blocks have 0 rows) of `cols` columns;
+// its image is that of S (N = rows, K = cols) or, transposed, of S^T (N = cols, K = rows, zero-padded to a multiple of 64: the
+// backward GEMM's A operand carries zeros there).  planes = 2 / 3: bf16 hi / lo (/ mid); planes = 0: no image - the job
+// concatenates 1-D segments (cols = 1: the stacked bias) into fp32 `image`.  frag0 = the job's first fragment in the launch
+// (a fragment = 64 lanes x 8 values; jobs sorted by frag0).
+__global__ __launch_bounds__(256) void chain_weight_image_group_kernel(const gd4d_image_job* __restrict__ jobs, int count, int total) {
+  const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (frag >= total) return;
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].frag0 <= frag) lo = mid; else hi = mid - 1;
+  }
+  const gd4d_image_job J = jobs[lo];
+  const int f = frag - J.frag0;
+  const int R = J.rows[0] + J.rows[1] + J.rows[2];
+  auto elem = [&](int r, int c) -> float {
+    if (r >= R || c >= J.cols) return 0.f;
+    int j = 0;
+    if (r >= J.rows[0]) { r -= J.rows[0]; j = 1; if (r >= J.rows[1]) { r -= J.rows[1]; j = 2; } }
+    return J.seg[j][(size_t)r * J.cols + c];
+  };
+  if (J.planes == 0) {
+    const int i = f * 64 + lane;
+    if (i < R) static_cast<float*>(J.image)[i] = elem(i, 0);
+    return;
+  }
+  const int N = J.transposed ? J.cols : R, K = J.transposed ? R : J.cols;
+  const int ksteps = ((K + 63) & ~63) / 32;
+  const int t = f / ksteps, s = f - t * ksteps;
+  const int n = 16 * t + (lane & 15);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * s + RC_KG * (lane >> 4) + (j < 4 ? j : RC_K2 + j - 4);
+    v[j] = n < N ? (J.transposed ? elem(k, n) : elem(n, k)) : 0.f;
+  }
+  char* dst = static_cast<char*>(J.image) + (size_t)f * (J.planes * 1024) + lane * 16;
+  if (J.planes == 3) {
+    rc_u4 h, m, l;
+    rc_split8x3(v, h, m, l);
+    *reinterpret_cast<rc_u4*>(dst) = h;
+    *reinterpret_cast<rc_u4*>(dst + 1024) = m;
+    *reinterpret_cast<rc_u4*>(dst + 2048) = l;
+  } else {
+    rc_u4 h, l;
+    rc_split8(v, h, l);
+    *reinterpret_cast<rc_u4*>(dst) = h;
+    *reinterpret_cast<rc_u4*>(dst + 1024) = l;
+  }
+}
+
 // GEMM over the workgroup's 16 rows: out[:, n] = act(sum_k in[:, k] * W[n, k] + bias[n]) (+ residuals), n < N.
 // Wave w owns columns [256 pass + RC_COLS w, + RC_COLS) of every pass; A fragments are split from the LDS buffer, the W fragments
 // come pre-split from the image (global / L2) through a register ring RC_DEPTH k-steps deep.
@@ -168,6 +222,11 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   // GD4D_CHAIN_SPLIT_OUT: the N columns go to three global tensors (gout | p2 | p3, each as wide as its row stride) - the
   // three Linears of query + query_pos (camera logits, offsets, attention logits) as ONE operation over their stacked weights.
   const bool src2 = (op.flags & GD4D_CHAIN_SRC2) != 0, split_out = (op.flags & GD4D_CHAIN_SPLIT_OUT) != 0;
+  // GD4D_CHAIN_MASK_P2: p2 is not an addend but the OUTPUT a ReLU produced in the forward pass - the result (the gradient at that
+  // ReLU's output) passes where it was > 0, times `eps` when that is non-zero (the 1 / (1 - p) of a dropout that followed the ReLU
+  // and left its zeros in p2 as well)
+  const bool mask_p2 = (op.flags & GD4D_CHAIN_MASK_P2) != 0;
+  const float mask_scale = op.eps != 0.f ? op.eps : 1.f;
   for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
     const float* a_row = &bufs[(src2 && n_base >= op.ld0) ? op.res : op.src][i16][RC_KG * g];
     const char* wf[RC_TILES];                                  // tiles past the end re-read the last one (never stored)
@@ -274,8 +333,9 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         float v = acc[c][r] + e_bias[c];
         if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
         if (op.flags & GD4D_CHAIN_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        if (mask_p2) v = e_add[c][r] > 0.f ? v * mask_scale : 0.f;
         if (op.res >= 0 && !src2) v += bufs[op.res][row][n];
-        if (op.p2 && !split_out) v += e_add[c][r];
+        if (op.p2 && !split_out && !mask_p2) v += e_add[c][r];
         if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
         if (split_out) {
           if (m < M) {
@@ -439,6 +499,101 @@ __device__ __forceinline__ void rc_layernorm(const ChainOp& op, float (*bufs)[RC
   }
 }
 
+// LN_BWD: the backward of LAYERNORM ([ReLU] LN(x) gamma + beta) over the 16 rows: buf[src] = gradient of the output, buf[res] = the
+// forward's INPUT x (mean / rstd are recomputed, two-pass, as the forward did); dx -> buf[dst] (dst == src allowed: a lane
+// reads its columns before it writes them) and / or gout; the row block's partial dgamma / dbeta -> p2[(block * 2 + {0, 1}) * N + c]
+// (the layout of gd4d_layernorm_bwd's workspace: gd4d_layernorm_bwd_reduce_group adds the blocks in order).  Rows past M count
+// as zero gradients.  Waves 0 .. 3 own 4 rows each, 16 lanes per row; the partial sums meet in `scratch` ([4][2][RC_W] floats).
+__device__ __forceinline__ void rc_layernorm_bwd(const ChainOp& op, float (*bufs)[RC_M][RC_LD], float* scratch, int m0, int M, int wg,
+                                                 int tid) {
+  constexpr int MAXCH = RC_W / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int N = op.N, nch = N / 64;
+  const bool relu = op.flags & GD4D_CHAIN_RELU;
+  if (wave < RC_M / 4) {
+    const int row = 4 * wave + (lane >> 4), l16 = lane & 15;
+    const bool live = m0 + row < M;
+    float4 gm[MAXCH], bt[MAXCH], x[MAXCH], d[MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const int n = min(64 * ch, N - 64) + 4 * l16;
+      gm[ch] = *reinterpret_cast<const float4*>(op.p0 + n);
+      bt[ch] = relu ? *reinterpret_cast<const float4*>(op.p1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[ch] = *reinterpret_cast<const float4*>(&bufs[op.res][row][n]);
+      d[ch] = *reinterpret_cast<const float4*>(&bufs[op.src][row][n]);
+      if (!live) d[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < nch) s += (x[ch].x + x[ch].y) + (x[ch].z + x[ch].w);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+      if (ch < nch) {
+        const float a = x[ch].x - mean, b = x[ch].y - mean, c = x[ch].z - mean, e = x[ch].w - mean;
+        q += (a * a + b * b) + (c * c + e * e);
+      }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)N + op.eps);
+    float s1 = 0.f, s2 = 0.f;
+    float4 xh[MAXCH], g[MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      xh[ch] = make_float4((x[ch].x - mean) * rstd, (x[ch].y - mean) * rstd, (x[ch].z - mean) * rstd, (x[ch].w - mean) * rstd);
+      if (relu) {                                          // the forward clamped at 0: those outputs pass no gradient
+        if (xh[ch].x * gm[ch].x + bt[ch].x <= 0.f) d[ch].x = 0.f;
+        if (xh[ch].y * gm[ch].y + bt[ch].y <= 0.f) d[ch].y = 0.f;
+        if (xh[ch].z * gm[ch].z + bt[ch].z <= 0.f) d[ch].z = 0.f;
+        if (xh[ch].w * gm[ch].w + bt[ch].w <= 0.f) d[ch].w = 0.f;
+      }
+      g[ch] = make_float4(d[ch].x * gm[ch].x, d[ch].y * gm[ch].y, d[ch].z * gm[ch].z, d[ch].w * gm[ch].w);
+      if (ch < nch) {
+        s1 += (g[ch].x + g[ch].y) + (g[ch].z + g[ch].w);
+        s2 += (g[ch].x * xh[ch].x + g[ch].y * xh[ch].y) + (g[ch].z * xh[ch].z + g[ch].w * xh[ch].w);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const float m1 = s1 / (float)N, m2 = s2 / (float)N;
+    const int m = m0 + row;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      if (ch >= nch) break;
+      const int n = 64 * ch + 4 * l16;
+      const float4 v = make_float4(rstd * (g[ch].x - m1 - xh[ch].x * m2), rstd * (g[ch].y - m1 - xh[ch].y * m2),
+                                   rstd * (g[ch].z - m1 - xh[ch].z * m2), rstd * (g[ch].w - m1 - xh[ch].w * m2));
+      if (op.dst >= 0) *reinterpret_cast<float4*>(&bufs[op.dst][row][n]) = v;
+      if (op.gout && m < M) *reinterpret_cast<float4*>(op.gout + (size_t)m * op.ldg + n) = v;
+      if (op.p2) {                                         // the wave's four rows, in row order
+        float4 a = make_float4(d[ch].x * xh[ch].x, d[ch].y * xh[ch].y, d[ch].z * xh[ch].z, d[ch].w * xh[ch].w), b = d[ch];
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+          b.x += __shfl_xor(b.x, o); b.y += __shfl_xor(b.y, o); b.z += __shfl_xor(b.z, o); b.w += __shfl_xor(b.w, o);
+        }
+        if (lane < 16) {
+          *reinterpret_cast<float4*>(scratch + (wave * 2 + 0) * RC_W + n) = a;
+          *reinterpret_cast<float4*>(scratch + (wave * 2 + 1) * RC_W + n) = b;
+        }
+      }
+    }
+  }
+  if (!op.p2) return;
+  __syncthreads();
+  float* part = const_cast<float*>(op.p2);
+  for (int e = tid; e < 2 * N; e += 64 * RC_WAVES) {
+    const int k = e / N, c = e - k * N;
+    const float t = (scratch[(0 * 2 + k) * RC_W + c] + scratch[(1 * 2 + k) * RC_W + c]) +
+                    (scratch[(2 * 2 + k) * RC_W + c] + scratch[(3 * 2 + k) * RC_W + c]);
+    part[((size_t)wg * 2 + k) * N + c] = t;
+  }
+}
+
 // Rows of global tensors into / onto an LDS buffer, float4 per lane, every load issued before the first use:
 //   LOAD: dst[:, dst_col + n] = f(p0[m, n]) (+ p1[m, n]);   ADD: dst[:, n] = src[:, n] (+ res[:, n]) (+ p2[m, n])
 // wave w handles RC_ROWS_PER_WAVE consecutive rows; N % 4 == 0, N <= 512 (two 256-column chunks per row).
@@ -478,6 +633,9 @@ __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][R
         }
       }
       *reinterpret_cast<float4*>(&bufs[op.dst][row][(IS_ADD ? 0 : op.dst_col) + n]) = v;
+      // gout: the rows also leave for global memory (a training step keeps x + query_pos, the input of the projections that
+      // follow, for their weight gradients; a backward chain's running sums)
+      if (op.gout && m0 + row < M) *reinterpret_cast<float4*>(op.gout + (size_t)(m0 + row) * op.ldg + n) = v;
     }
   }
 }
@@ -620,6 +778,9 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
       case GD4D_CHAIN_HEADGEMM: rc_headgemm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_LAYERNORM: rc_layernorm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_ADD: rc_rows<true>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
+      case GD4D_CHAIN_LN_BWD:
+        rc_layernorm_bwd(op, bufs, reinterpret_cast<float*>(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES), m0, M, wg, tid);
+        break;
       case GD4D_CHAIN_SMALL_LINEAR: {                      // K <= 8 inputs (position_encoder's first Linear): plain FMAs
         // The first version evaluated inverse_sigmoid (a division and a logarithm) for every (row, output, input) and
         // fetched the weights inside the loop: 5.1 us for 16 x 256 x 3 MACs, on the critical path of the dual launch.
@@ -647,6 +808,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
               if (k < K) v = fmaf(bufs[op.src][row][col0 + k], w[k], v);
             if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
             bufs[op.dst][row][n] = v;
+            if (op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
           }
         } else {
           for (int e = tid; e < RC_M * N; e += 64 * RC_WAVES) {
@@ -655,6 +817,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
             for (int k = 0; k < K; ++k) v = fmaf(bufs[op.src][row][col0 + k], op.p0[(size_t)n * K + k], v);
             if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
             bufs[op.dst][row][n] = v;
+            if (op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
           }
         }
         break;
@@ -752,6 +915,16 @@ extern "C" int gd4d_chain_weight_image_exact(const float* weight, int N, int K, 
   return check_launch();
 }
 
+extern "C" size_t gd4d_image_job_bytes(void) { return sizeof(gd4d_image_job); }
+
+extern "C" int gd4d_chain_weight_image_group(const gd4d_image_job* jobs_device, int count, int total_frags, void* stream) {
+  using namespace gd4d;
+  if (!jobs_device || count <= 0 || total_frags <= 0) return GD4D_EINVAL;
+  hipLaunchKernelGGL(chain_weight_image_group_kernel, dim3((total_frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     jobs_device, count, total_frags);
+  return check_launch();
+}
+
 // which: 0 = the only program of a launch, 1 = the first of two, 2 = the second of two
 static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
   const bool two_programs = which != 0;
@@ -765,6 +938,7 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (!op.p0 || op.dst < 0 || op.N <= 0 || op.dst_col < 0 || op.dst_col + op.N > RC_W) return GD4D_EINVAL;
         if ((op.N & 3) == 0 && (op.dst_col & 3) == 0 &&         // the float4 path
             (!aligned16(op.p0) || (op.ld0 & 3) || (op.p1 && (!aligned16(op.p1) || (op.ld1 & 3))))) return GD4D_EALIGN;
+        if (op.gout && ((op.N & 3) || (op.dst_col & 3) || !aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_GEMM:
         if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout) || (op.p3 && !op.p2)) return GD4D_EINVAL;
@@ -774,6 +948,7 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (!aligned16(op.p0)) return GD4D_EALIGN;
         if (op.flags & GD4D_CHAIN_SRC2)
           if (op.res < 0 || op.res == op.dst || op.ld0 <= 0 || op.ld0 % (RC_COLS * RC_WAVES) != 0 || op.ld0 >= op.N) return GD4D_EINVAL;
+        if ((op.flags & GD4D_CHAIN_MASK_P2) && (!op.p2 || op.p3 || (op.flags & (GD4D_CHAIN_SPLIT_OUT | GD4D_CHAIN_SRC2)))) return GD4D_EINVAL;
         if (op.flags & GD4D_CHAIN_SPLIT_OUT)
           if (!op.gout || !op.p2 || !op.p3 || op.ldg <= 0 || op.ld2 <= 0 || op.ld1 <= 0 || op.ldg + op.ld2 + op.ld1 != op.N)
             return GD4D_EINVAL;
@@ -791,9 +966,17 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (op.p2 && (op.res < 0 || op.res == op.src || op.res == op.dst)) return GD4D_EINVAL;    // second output: its own buffer
         if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
         break;
+      case GD4D_CHAIN_LN_BWD:
+        if (!op.p0 || op.src < 0 || op.res < 0 || op.res == op.src || op.res == op.dst || op.N <= 0 || op.N > RC_W) return GD4D_EINVAL;
+        if (op.dst < 0 && !op.gout && !op.p2) return GD4D_EINVAL;
+        if ((op.flags & GD4D_CHAIN_RELU) && !op.p1) return GD4D_EINVAL;
+        if (op.N % 64 != 0) return GD4D_EUNSUPPORTED;
+        if (!aligned16(op.p0) || (op.p1 && !aligned16(op.p1)) || (op.gout && (!aligned16(op.gout) || (op.ldg & 3)))) return GD4D_EALIGN;
+        break;
       case GD4D_CHAIN_ADD:
         if (op.src < 0 || op.dst < 0 || op.N <= 0 || op.N > RC_W || (op.N & 3)) return GD4D_EINVAL;
         if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
+        if (op.gout && (!aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_SMALL_LINEAR:
         if (!op.p0 || op.src < 0 || op.dst < 0 || op.dst == op.src || op.K <= 0 || op.K > 8 || op.N <= 0 || op.N > RC_W)
@@ -825,7 +1008,7 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   if (int rc = rc_validate(a, na, nb > 0 ? 1 : 0)) return rc;
   if (nb > 0)
     if (int rc = rc_validate(b, nb, 2)) return rc;
-  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES;      // row buffers + the prefetch dump area
+  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES + sizeof(float) * 8 * RC_W;   // row buffers + the prefetch dump area + LN_BWD's partial sums
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
   const int blocks = (M + RC_M - 1) / RC_M;
   ChainProgram prog{};

@@ -398,6 +398,13 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         if late is None:
             kwargs, pipeline = self._preproject_values(kwargs)
         kwargs = self._order_queries(kwargs, reference_points)
+        if not fused and query.is_cuda and torch.is_grad_enabled():
+            # training on the raw pyramid: the whole loop as ONE autograd node whose forward and backward are row chains
+            from . import fused_train
+            if fused_train.applicable(self, query, kwargs.get('query_pos'), kwargs.get('value'), reference_points, reg_branches,
+                                      kwargs.get('attn_masks'), kwargs.get(Fn.VALUE_CACHE_KEY), args, kwargs):
+                return fused_train.run(self, query, kwargs['query_pos'], kwargs['value'], reference_points, reg_branches,
+                                       kwargs['img_metas'], kwargs.get('attn_masks'), kwargs[Fn.VALUE_CACHE_KEY])
         if fused:
             # every layer is the post-norm (self-attention, Deform3DCrossAttn, FFN) layer: 4 launches per layer
             outs, refs = fused_decoder.run(

@@ -1461,7 +1461,8 @@ class ChainOp(ctypes.Structure):
 
 
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
-CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT = 1, 2, 4, 8, 16, 32
+CHAIN_LN_BWD = 10
+CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT, CHAIN_MASK_P2 = 1, 2, 4, 8, 16, 32, 64
 
 
 def _rows(t, name):
@@ -1482,11 +1483,13 @@ def _rows(t, name):
     return t.data_ptr(), ld
 
 
-def chain_load(dst, x, x2=None, dst_col=0, inv_sigmoid=False):
+def chain_load(dst, x, x2=None, dst_col=0, inv_sigmoid=False, out=None):
+    """buf[dst][:, dst_col ..] = f(x) (+ x2); out: the rows are also stored there."""
     p0, ld0 = _rows(x, 'x')
     p1, ld1 = _rows(x2, 'x2')
-    return ChainOp(kind=CHAIN_LOAD, src=-1, dst=dst, res=-1, N=x.shape[-1], dst_col=dst_col, ld0=ld0, ld1=ld1,
-                   flags=CHAIN_INV_SIGMOID if inv_sigmoid else 0, p0=p0, p1=p1)
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_LOAD, src=-1, dst=dst, res=-1, N=x.shape[-1], dst_col=dst_col, ld0=ld0, ld1=ld1, ldg=ldg,
+                   flags=CHAIN_INV_SIGMOID if inv_sigmoid else 0, p0=p0, p1=p1, gout=g)
 
 
 _CHAIN_IMAGES = {}
@@ -1528,29 +1531,115 @@ def chain_weight_image(weight, exact=False):
     return img
 
 
+class ImageJob(ctypes.Structure):
+    """gd4d_image_job (include/gd4d.h)."""
+    _fields_ = [('seg', ctypes.c_void_p * 3), ('rows', ctypes.c_int32 * 3), ('cols', ctypes.c_int32), ('transposed', ctypes.c_int32),
+                ('planes', ctypes.c_int32), ('frag0', ctypes.c_int32), ('reserved', ctypes.c_int32), ('image', ctypes.c_void_p)]
+
+
+class WeightImage:
+    """A chain GEMM operand made by an ImageSet: the image tensor and the (N, K) of the GEMM it serves (K already padded)."""
+
+    def __init__(self, img, n, k, exact):
+        self.img, self.n, self.k, self.exact = img, n, k, exact
+
+
+class ImageSet:
+    """The weight images of a TRAINING step's chains (gd4d_chain_weight_image_group): declared once (add / add_concat; the
+    parameters' storage must stay where it is), rebuilt by ONE launch per step (refresh) into buffers whose addresses never
+    change - a captured hipGraph replays the rebuild with the step, after every optimizer update."""
+
+    def __init__(self, device):
+        self.device = device
+        self._jobs, self._keep, self._frags = [], [], 0
+        self._table = None
+        self.sources = []
+
+    def _segments(self, tensors, cols):
+        if not 1 <= len(tensors) <= 3:
+            raise ValueError('an image stacks one to three row blocks')
+        seg, rows = (ctypes.c_void_p * 3)(), (ctypes.c_int32 * 3)()
+        for i, t in enumerate(tensors):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() % cols:
+                raise ValueError('image sources must be dense float32 GPU tensors of `cols` columns')
+            seg[i], rows[i] = t.data_ptr(), t.numel() // cols
+            self.sources.append(t)
+        return seg, rows, int(sum(rows))
+
+    def add(self, tensors, transposed=False, exact=False):
+        """Image of the row blocks `tensors` (each (r_i, cols)) stacked - or of the stack's transpose."""
+        cols = tensors[0].shape[-1]
+        seg, rows, r = self._segments(tensors, cols)
+        n, k = (cols, r) if transposed else (r, cols)
+        kp = (k + 63) // 64 * 64
+        planes = 3 if exact else 2
+        frags = (n + 15) // 16 * (kp // 32)
+        img = torch.empty(frags * planes * 1024, device=self.device, dtype=torch.uint8)
+        self._jobs.append(ImageJob(seg=seg, rows=rows, cols=cols, transposed=int(transposed), planes=planes, frag0=self._frags,
+                                   image=img.data_ptr()))
+        self._frags += frags
+        self._table = None
+        return WeightImage(img, n, kp, exact)
+
+    def add_concat(self, vectors):
+        """fp32 concatenation of 1-D tensors (a stacked bias), refreshed with the images."""
+        seg, rows, r = self._segments(vectors, 1)
+        out = torch.empty(r, device=self.device, dtype=torch.float32)
+        self._jobs.append(ImageJob(seg=seg, rows=rows, cols=1, transposed=0, planes=0, frag0=self._frags, image=out.data_ptr()))
+        self._frags += (r + 63) // 64
+        self._table = None
+        return out
+
+    def signature(self):
+        return tuple(t.data_ptr() for t in self.sources)
+
+    def refresh(self):
+        lib = _lib.load()
+        if self._table is None:
+            arr = (ImageJob * len(self._jobs))(*self._jobs)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._table = raw.to(self.device)
+        with torch.cuda.device(self.device):
+            code = lib.gd4d_chain_weight_image_group(ctypes.c_void_p(self._table.data_ptr()), len(self._jobs), self._frags, _stream())
+        _lib.check(code, 'gd4d_chain_weight_image_group')
+
+
+def _image_of(weight, exact=False):
+    """(image pointer, N, K) of a chain GEMM operand: a WeightImage of an ImageSet, or a weight tensor (cached image)."""
+    if isinstance(weight, WeightImage):
+        if weight.exact != bool(exact):
+            raise ValueError('chain GEMM: the image was made for the other arithmetic (exact)')
+        return weight.img.data_ptr(), weight.n, weight.k
+    return chain_weight_image(weight, exact).data_ptr(), weight.shape[0], weight.shape[1]
+
+
 def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False, exact=False, add=None,
-               add2=None):
+               add2=None, mask=None, mask_scale=0.):
     """act(buf[src] W^T + b) (+ buf[res]) (+ (add + add2)[m, :]) -> buf[dst] and / or out.  weight (N, K) contiguous rows.
     add / add2: global (M, N) tensors added in the epilogue (their sum first, then onto the result - what a LOAD of
     add + add2 into buf[res] would give, without the operation).  exact: fp32-class products (GD4D_CHAIN_EXACT) instead of
     split-bf16 x3 - for outputs that become reference points."""
-    img = chain_weight_image(weight, exact)
+    img, n, k = _image_of(weight, exact)
     g, ldg = _rows(out, 'out')
-    p2, ld2 = _rows(add, 'add')
+    if mask is not None and (add is not None or add2 is not None):
+        raise ValueError('chain_gemm: mask (a backward chain\'s ReLU) and global addends exclude each other')
+    p2, ld2 = _rows(add if mask is None else mask, 'add')
     p3, ld3 = _rows(add2, 'add2')
     if p3 is not None and p2 is None:
         raise ValueError('chain_gemm: add2 without add')
-    return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=weight.shape[1], N=weight.shape[0], dst_col=dst_col,
-                   flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0) | (CHAIN_EXACT if exact else 0), ldg=ldg,
-                   ld2=ld2, ld1=ld3, p0=img.data_ptr(), p1=None if bias is None else bias.data_ptr(), p2=p2, p3=p3, gout=g)
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=k, N=n, dst_col=dst_col,
+                   flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0) | (CHAIN_EXACT if exact else 0) |
+                   (CHAIN_MASK_P2 if mask is not None else 0), ldg=ldg, eps=float(mask_scale) if mask is not None else 0.,
+                   ld2=ld2, ld1=ld3, p0=img, p1=None if bias is None else bias.data_ptr(), p2=p2, p3=p3, gout=g)
 
 
 def chain_gemm_two_sources(src, src2, split, weight, bias, out):
     """One GEMM over a stacked weight (N, K) whose output columns [0, split) are computed from buf[src] and [split, N) from
     buf[src2] (split a multiple of 256): nn.MultiheadAttention's packed in-projection with q, k from x + pos and v from x."""
     g, ldg = _rows(out, 'out')
-    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=weight.shape[1], N=weight.shape[0], flags=CHAIN_SRC2, ld0=int(split),
-                   ldg=ldg, p0=chain_weight_image(weight).data_ptr(), p1=None if bias is None else bias.data_ptr(), gout=g)
+    img, n, k = _image_of(weight)
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=k, N=n, flags=CHAIN_SRC2, ld0=int(split),
+                   ldg=ldg, p0=img, p1=None if bias is None else bias.data_ptr(), gout=g)
 
 
 _STACKED = {}
@@ -1576,18 +1665,23 @@ def _stacked_linears(linears):
     return w, b
 
 
-def chain_gemm_three_outputs(src, linears, outs):
+def chain_gemm_three_outputs(src, linears, outs, stacked=None):
     """Three nn.Linear of ONE input (buf[src]) as one GEMM over their stacked weights; column block i goes to outs[i] (M, N_i),
     dense rows.  The sums of a column do not depend on the operation it is part of: bit-identical to three chain_gemm."""
     if len(linears) != 3 or len(outs) != 3:
         raise ValueError('chain_gemm_three_outputs takes three Linears and three outputs')
-    w, b = _stacked_linears(linears)
     ptrs = [_rows(o, 'out') for o in outs]
     for (ptr, ld), m in zip(ptrs, linears):
         if ld != m.weight.shape[0]:
             raise ValueError('chain_gemm_three_outputs: every output must be dense, as wide as its Linear')
-    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=-1, K=w.shape[1], N=w.shape[0], flags=CHAIN_SPLIT_OUT,
-                   ldg=ptrs[0][1], ld2=ptrs[1][1], ld1=ptrs[2][1], p0=chain_weight_image(w).data_ptr(), p1=b.data_ptr(),
+    if stacked is not None:                   # (WeightImage of the stacked weights, stacked bias) of an ImageSet
+        img, n, k = _image_of(stacked[0])
+        b = stacked[1]
+    else:
+        w, b = _stacked_linears(linears)
+        img, n, k = _image_of(w)
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=-1, K=k, N=n, flags=CHAIN_SPLIT_OUT,
+                   ldg=ptrs[0][1], ld2=ptrs[1][1], ld1=ptrs[2][1], p0=img, p1=b.data_ptr(),
                    gout=ptrs[0][0], p2=ptrs[1][0], p3=ptrs[2][0])
 
 
@@ -1595,21 +1689,30 @@ def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):
     """value_proj of the per-head aggregates (cross_attn_agg_fwd's agg (..., Hh, K), wsum (..., Hh), contiguous) as a chain
     operation: v[m, n] = sum_k agg[m][h][k] W[n][k] + bias[n] wsum[m][h] (+ buf[res]) -> buf[dst] and / or out."""
     heads, k = agg.shape[-2], agg.shape[-1]
-    n = weight.shape[0]
-    if weight.shape[1] != k or n % heads or (n // heads) % 32 or wsum.numel() * k != agg.numel():
+    img, n, wk = _image_of(weight)
+    if wk != k or n % heads or (n // heads) % 32 or wsum.numel() * k != agg.numel():
         raise ValueError('chain_headgemm: weight (N, K), agg (..., Hh, K), wsum (..., Hh) with (N / Hh) % 32 == 0')
-    img = chain_weight_image(weight)
     g, ldg = _rows(out, 'out')
-    return ChainOp(kind=CHAIN_HEADGEMM, src=-1, dst=dst, res=res, K=k, N=n, ld0=heads, ldg=ldg, p0=img.data_ptr(),
+    return ChainOp(kind=CHAIN_HEADGEMM, src=-1, dst=dst, res=res, K=k, N=n, ld0=heads, ldg=ldg, p0=img,
                    p1=None if bias is None else bias.data_ptr(), p2=_dev(agg, 'agg', torch.float32).value,
                    p3=_dev(wsum, 'wsum', torch.float32).value, gout=g)
 
 
-def chain_small_linear(src, weight, bias, dst, relu=False, inv_sigmoid=False):
+def chain_small_linear(src, weight, bias, dst, relu=False, inv_sigmoid=False, out=None):
     """buf[dst] = act(f(buf[src][:, :K]) W^T + b) for K <= 8; f = inverse_sigmoid with inv_sigmoid=True."""
-    return ChainOp(kind=CHAIN_SMALL_LINEAR, src=src, dst=dst, res=-1, K=weight.shape[1], N=weight.shape[0],
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_SMALL_LINEAR, src=src, dst=dst, res=-1, K=weight.shape[1], N=weight.shape[0], ldg=ldg, gout=g,
                    flags=(CHAIN_RELU if relu else 0) | (CHAIN_INV_SIGMOID if inv_sigmoid else 0), p0=weight.data_ptr(),
                    p1=None if bias is None else bias.data_ptr())
+
+
+def chain_layernorm_bwd(src, x_buf, norm, dst=-1, relu=False, out=None, part=None):
+    """Backward of chain_layernorm: buf[src] = gradient of the output, buf[x_buf] = the forward's input; dx -> buf[dst] (may
+    be src) and / or out; part: (ceil(M / 16), 2, N) fp32 partial dgamma / dbeta (layernorm_bwd_reduce_group adds them)."""
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_LN_BWD, src=src, dst=dst, res=x_buf, N=norm.weight.shape[0], eps=float(norm.eps),
+                   flags=CHAIN_RELU if relu else 0, ldg=ldg, p0=norm.weight.data_ptr(), p1=norm.bias.data_ptr(),
+                   p2=None if part is None else _dev(part, 'part', torch.float32).value, gout=g)
 
 
 def chain_layernorm(src, norm, dst=-1, relu=False, out=None, dst2=-1, add=None):
@@ -1624,9 +1727,11 @@ def chain_layernorm(src, norm, dst=-1, relu=False, out=None, dst2=-1, add=None):
                    p2=p2, gout=g)
 
 
-def chain_add(dst, src, n, res=-1, add=None):
+def chain_add(dst, src, n, res=-1, add=None, out=None):
+    """buf[dst] = buf[src] (+ buf[res]) (+ add[m, :]); out: the sum is also stored there."""
     p2, ld2 = _rows(add, 'add')
-    return ChainOp(kind=CHAIN_ADD, src=src, dst=dst, res=res, N=n, ld2=ld2, p2=p2)
+    g, ldg = _rows(out, 'out')
+    return ChainOp(kind=CHAIN_ADD, src=src, dst=dst, res=res, N=n, ld2=ld2, p2=p2, ldg=ldg, gout=g)
 
 
 def chain_refine(src, ref, out, dst=-1):
@@ -1690,7 +1795,7 @@ def _on_tensor_device(fn):
 
 
 _HOST_ONLY = {'linear_sum_assignment_batch', 'cross_attn_plan_bytes', 'invalidate_chain_images', 'chain_load', 'chain_gemm', 'chain_small_linear', 'chain_layernorm',
-              'chain_add', 'chain_refine', 'row_chain_fwd', 'chain_weight_image'}
+              'chain_add', 'chain_refine', 'row_chain_fwd', 'chain_weight_image', 'chain_layernorm_bwd'}
 for _name, _fn in list(globals().items()):
     if inspect.isfunction(_fn) and _fn.__module__ == __name__ and not _name.startswith('_') and _name not in _HOST_ONLY:
         globals()[_name] = _on_tensor_device(_fn)

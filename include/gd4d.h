@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 38
+#define GD4D_ABI_VERSION 39
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -511,7 +511,8 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  * 0 .. 3 (16 x 512 fp32 each) and executes `program` (host array of nops <= GD4D_CHAIN_MAX_OPS operations, copied into
  * the kernel argument) in order:
  *   LOAD       buf[dst][:, dst_col .. +N) = f(p0[m, :N]) (+ p1[m, :N]); row strides ld0, ld1; f = inverse_sigmoid with
- *              GD4D_CHAIN_INV_SIGMOID
+ *              GD4D_CHAIN_INV_SIGMOID.  LOAD, ADD and SMALL_LINEAR also store their result to gout[m, :N] (row stride ldg) when
+ *              it is given
  *   GEMM       v = act(buf[src][:, :K] . W^T + bias), p0 = the IMAGE of W (N, K) made by gd4d_chain_weight_image (bf16 hi /
  *              lo halves in MFMA fragment order; gd4d_chain_weight_image_bytes(N, K) bytes, 16-byte aligned; rebuild it when
  *              W changes), bias = p1 or NULL, act = ReLU with GD4D_CHAIN_RELU; then v += buf[res] (res >= 0) and v += (p2[m, n] + p3[m, n])
@@ -529,10 +530,17 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  *              v[m, n] = sum_k p2[m][h][k] W[n][k] + bias[n] p3[m][h], h = n / (N / heads); p0 = the image of W (N, K),
  *              p1 = bias or NULL, p2 = agg (M, heads, K), p3 = wsum (M, heads), heads = ld0; then as GEMM (+ buf[res], to
  *              buf[dst] and / or gout).  (N / heads) % 32 == 0, K % 64 == 0.
+ *   LN_BWD     backward of LAYERNORM: buf[src] = gradient of its output, buf[res] = the forward's input (statistics are
+ *              recomputed), p0 = gamma, p1 = beta (needed with GD4D_CHAIN_RELU: the forward's ReLU); dx -> buf[dst] (dst == src
+ *              allowed) and / or gout; p2 = (ceil(M / 16), 2, N) partial dgamma / dbeta of the row blocks, the layout of
+ *              gd4d_layernorm_bwd's workspace (gd4d_layernorm_bwd_reduce_group adds them), or NULL
  * GEMMs: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (fp32-class, the arithmetic of gd4d_value_proj_fwd);
- * everything else fp32.  M = number of rows. */
+ * everything else fp32.  M = number of rows.
+ * A training step runs the same programs with every intermediate also written to global memory (gout), and backward programs
+ * built from GEMMs over the TRANSPOSED weights' images (input gradients; GD4D_CHAIN_MASK_P2 at a ReLU), LN_BWD and ADD; the
+ * weight gradients are contractions over all rows (gd4d_linear_bwd_weight_group) of what those programs wrote. */
 enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_CHAIN_ADD = 4, GD4D_CHAIN_REFINE = 5,
-       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7, GD4D_CHAIN_SIGNAL = 8, GD4D_CHAIN_WAIT = 9 };
+       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7, GD4D_CHAIN_SIGNAL = 8, GD4D_CHAIN_WAIT = 9, GD4D_CHAIN_LN_BWD = 10 };
 #define GD4D_CHAIN_RELU 1
 #define GD4D_CHAIN_INV_SIGMOID 2
 #define GD4D_CHAIN_SIGMOID 4        /* GEMM: sigmoid on the output (after the bias / ReLU, before the residual) */
@@ -545,6 +553,8 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
 #define GD4D_CHAIN_SPLIT_OUT 32     /* GEMM: the N columns leave for THREE global tensors: [0, ldg) -> gout, the next ld2 -> p2, the
                                        last ld1 -> p3 (each as wide as its row stride; p2 / p3 are outputs, not addends) - the
                                        Linears of one input stacked into one weight (deform3d_cross_attn.py:211, :227, :281) */
+#define GD4D_CHAIN_MASK_P2 64       /* GEMM (a backward chain): p2[m, n] is the output a ReLU produced in the forward pass, not an
+                                       addend - the result passes where it was > 0 (times eps when eps != 0), else 0 */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
@@ -563,6 +573,21 @@ size_t gd4d_chain_weight_image_bytes(int N, int K);
 int gd4d_chain_weight_image(const float* weight, int N, int K, void* image, void* stream);
 size_t gd4d_chain_weight_image_exact_bytes(int N, int K);
 int gd4d_chain_weight_image_exact(const float* weight, int N, int K, void* image, void* stream);
+/* gd4d_chain_weight_image_group - every image a training step needs in ONE launch (the weights change with each optimizer
+ * step; inside a replayed hipGraph the host cannot notice).  jobs_device: `count` jobs in DEVICE memory, sorted by frag0.  A job's
+ * logical matrix S = up to three row blocks seg[i] (rows[i] x cols, dense; unused: 0 rows) stacked; image = that of S
+ * (N = sum rows, K = cols) or with transposed != 0 of S^T (N = cols, K = sum rows zero-padded to a multiple of 64);
+ * planes = 2 (gd4d_chain_weight_image's layout), 3 (.._exact's) or 0 (no image: cols = 1, the segments are concatenated into
+ * fp32 `image` - a stacked bias).  A job owns fragments [frag0, frag0 + n): n = ceil(N / 16) * (K_padded / 32) for an image,
+ * ceil(sum rows / 64) for a concatenation; total_frags = the sum. */
+typedef struct gd4d_image_job {
+  const float* seg[3];
+  int32_t rows[3];
+  int32_t cols, transposed, planes, frag0, reserved;
+  void* image;
+} gd4d_image_job;
+size_t gd4d_image_job_bytes(void);
+int gd4d_chain_weight_image_group(const gd4d_image_job* jobs_device, int count, int total_frags, void* stream);
 int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream);
 /* Two independent programs over the same M rows in ONE launch (twice the workgroups, each half runs one program on its own
  * compute units): e.g. chain A of a decoder layer next to the previous layer's reg branch + refinement + this layer's

@@ -233,3 +233,71 @@ def test_distillation_loss_terms_on_the_gpu_match_the_oracle_restatement():
         torch.testing.assert_close(got[k].detach().cpu(), want[k].detach(), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(scd.grad.cpu(), sc.grad, rtol=1e-4, atol=1e-9)
     torch.testing.assert_close(sbd.grad.cpu(), sb.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_head_position_embedding_backward_at_vovnet_size_matches_fp64():
+    """FeaturePositionEmbedding forward + backward on the library's kernels (_HeadPEFunction: split-bf16 GEMMs over 185k
+    pixels per GEMM at 6 cameras, four VoVNet levels) against the same formulas (detr3d_head_pe.py:380-390, :231-243, :556)
+    evaluated in fp64 by torch on the same frustum / sine inputs.  A pre-activation within fp32 rounding of zero can sit on
+    either side of a ReLU, and the derivative follows the side the FORWARD took: the fp64 evaluation uses the forward's own
+    ReLU decisions (recomputed here with the same kernels, which are deterministic), so every gradient is compared
+    tightly - relative to the largest entry for the parameters (sums over every pixel), element-wise for the maps."""
+    import torch.nn.functional as F
+    from graph_detr4d_amd import FeaturePositionEmbedding
+    from graph_detr4d_amd import head_pe as HP
+    torch.manual_seed(0)
+    n, shapes = 6, [(116, 200), (58, 100), (29, 50), (15, 25)]
+    mod = FeaturePositionEmbedding(pc_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]).cuda()
+    rng = np.random.default_rng(0)
+    l2i = [np.eye(4) + 0.1 * rng.standard_normal((4, 4)) for _ in range(n)]
+    metas = [dict(pad_shape=[(928, 1600, 3)] * n, img_shape=[(900, 1600, 3)] * n, lidar2img=l2i)]
+    feats = [torch.randn(1, n, 256, h, w, device='cuda').requires_grad_() for h, w in shapes]
+    probes = [torch.randn_like(f) for f in feats]
+    captured = {}
+    real = HP._HeadPEFunction.apply
+
+    def spy(x, xs, starts, nl, *rest):
+        captured.update(x=x.clone(), xs=xs.clone(), starts=starts)
+        return real(x, xs, starts, nl, *rest)
+    HP._HeadPEFunction.apply = spy
+    try:
+        outs = mod(feats, metas)
+    finally:
+        HP._HeadPEFunction.apply = real
+    torch.autograd.backward(outs, probes)
+
+    prm = dict(mod.named_parameters())
+    with torch.no_grad():                                             # the forward's ReLU decisions
+        def first_layer_mask(inp, name):
+            w = prm[name + '.weight'].detach().flatten(1).contiguous()
+            return ops.gemm_bf16x3_fwd(inp.view(-1, inp.shape[-1]), *ops.split_bf16_fwd(w), prm[name + '.bias'], relu=True) > 0
+        mask_pe = first_layer_mask(captured['x'], 'position_encoder.0').view(n, -1, 1024)
+        mask_ad = first_layer_mask(captured['xs'], 'adapt_pos3d.0').view(n, -1, 1024)
+        mask_se = ops.value_proj_fwd([f.detach()[0].contiguous() for f in feats],
+                                     prm['fpe.conv_reduce.weight'].detach().flatten(1).contiguous(),
+                                     prm['fpe.conv_reduce.bias'].detach().contiguous()) > 0
+
+    # fp64, channels-last rows, plain torch
+    p64 = {k: v.detach().double().flatten(1).requires_grad_() if v.dim() == 4 else v.detach().double().requires_grad_()
+           for k, v in prm.items()}
+    f64 = [f.detach().double().requires_grad_() for f in feats]
+    x, xs = captured['x'].double(), captured['xs'].double()
+    rows_f = torch.cat([f[0].flatten(2).transpose(1, 2) for f in f64], 1)                     # (N, S, C)
+    lin = lambda t, name: F.linear(t, p64[name + '.weight'], p64[name + '.bias'])
+    pe = lin(lin(x, 'position_encoder.0') * mask_pe, 'position_encoder.2')
+    sine = lin(lin(xs, 'adapt_pos3d.0') * mask_ad, 'adapt_pos3d.2')
+    gate = lin(lin(rows_f, 'fpe.conv_reduce') * mask_se, 'fpe.conv_expand')
+    res = rows_f + (pe * torch.sigmoid(gate) + sine)
+    loss, start = 0, 0
+    for (h, w), o, pr in zip(shapes, outs, probes):
+        want = res[:, start:start + h * w].transpose(1, 2).reshape(1, n, 256, h, w)
+        torch.testing.assert_close(o.double(), want, rtol=1e-4, atol=1e-4)
+        loss = loss + (want * pr.double()).sum()
+        start += h * w
+    loss.backward()
+    for name, p in prm.items():
+        want = p64[name].grad.view(p.shape)
+        err = (p.grad.double() - want).abs().max().item()
+        assert err < 1e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
+    for f, w in zip(feats, f64):
+        torch.testing.assert_close(f.grad.double(), w.grad, rtol=1e-4, atol=1e-4)
