@@ -19,6 +19,7 @@
 // the weights do not change) so they stream from L2 as whole 1-KB pieces; the activations are split when read from LDS.
 // LayerNorm two-pass like ATen (mean, centred sum of squares, biased variance, eps inside the square root).
 #include "gd4d_common.h"
+#include "gd4d_mha_dropout.h"
 
 namespace gd4d {
 
@@ -227,6 +228,12 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   // and left its zeros in p2 as well)
   const bool mask_p2 = (op.flags & GD4D_CHAIN_MASK_P2) != 0;
   const float mask_scale = op.eps != 0.f ? op.eps : 1.f;
+  // GD4D_CHAIN_DROPOUT (a training step with the modules in train mode): the output - after bias / activation, before the
+  // residuals - is dropped like nn.Dropout does: kept elements times eps = 1 / (1 - p).  Which elements: csrc/gd4d_mha_dropout.h's
+  // hash of (the 64-bit seed at p3, m N + n) against the threshold in `reserved` - a backward chain regenerates it (DROPMASK).
+  const bool drop = (op.flags & GD4D_CHAIN_DROPOUT) != 0;
+  const uint32_t drop_lo = drop ? reinterpret_cast<const uint32_t*>(op.p3)[0] : 0u;
+  const uint32_t drop_hi = drop ? reinterpret_cast<const uint32_t*>(op.p3)[1] : 0u;
   for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
     const float* a_row = &bufs[(src2 && n_base >= op.ld0) ? op.res : op.src][i16][RC_KG * g];
     const char* wf[RC_TILES];                                  // tiles past the end re-read the last one (never stored)
@@ -255,7 +262,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         for (int r = 0; r < 4; ++r) {
           const size_t m = (size_t)min(m0 + 4 * g + r, M - 1);
           const float a2 = op.p2[m * op.ld2 + n];
-          e_add[c][r] = op.p3 ? a2 + op.p3[m * op.ld1 + n] : a2;
+          e_add[c][r] = (op.p3 && !drop) ? a2 + op.p3[m * op.ld1 + n] : a2;
         }
       }
     }
@@ -333,6 +340,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         float v = acc[c][r] + e_bias[c];
         if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
         if (op.flags & GD4D_CHAIN_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        if (drop) v = mha_drop_keep(drop_lo, drop_hi, (uint32_t)m * (uint32_t)N + (uint32_t)n, (uint32_t)op.reserved) ? v * op.eps : 0.f;
         if (mask_p2) v = e_add[c][r] > 0.f ? v * mask_scale : 0.f;
         if (op.res >= 0 && !src2) v += bufs[op.res][row][n];
         if (op.p2 && !split_out && !mask_p2) v += e_add[c][r];
@@ -778,6 +786,22 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
       case GD4D_CHAIN_HEADGEMM: rc_headgemm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_LAYERNORM: rc_layernorm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_ADD: rc_rows<true>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
+      case GD4D_CHAIN_DROPMASK: {                         // buf[dst] = nn.Dropout's mask of a forward GEMM applied to buf[src]
+        const uint32_t lo = reinterpret_cast<const uint32_t*>(op.p0)[0], hi = reinterpret_cast<const uint32_t*>(op.p0)[1];
+        const int nv = op.N / 4;
+        for (int e = tid; e < RC_M * nv; e += 64 * RC_WAVES) {
+          const int row = e / nv, n = 4 * (e - row * nv);
+          const uint32_t id = (uint32_t)(m0 + row) * (uint32_t)op.N + (uint32_t)n;
+          float4 v = *reinterpret_cast<const float4*>(&bufs[op.src][row][n]);
+          v.x = mha_drop_keep(lo, hi, id, (uint32_t)op.reserved) ? v.x * op.eps : 0.f;
+          v.y = mha_drop_keep(lo, hi, id + 1, (uint32_t)op.reserved) ? v.y * op.eps : 0.f;
+          v.z = mha_drop_keep(lo, hi, id + 2, (uint32_t)op.reserved) ? v.z * op.eps : 0.f;
+          v.w = mha_drop_keep(lo, hi, id + 3, (uint32_t)op.reserved) ? v.w * op.eps : 0.f;
+          *reinterpret_cast<float4*>(&bufs[op.dst][row][n]) = v;
+          if (op.gout && m0 + row < M) *reinterpret_cast<float4*>(op.gout + (size_t)(m0 + row) * op.ldg + n) = v;
+        }
+        break;
+      }
       case GD4D_CHAIN_LN_BWD:
         rc_layernorm_bwd(op, bufs, reinterpret_cast<float*>(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES), m0, M, wg, tid);
         break;
@@ -941,13 +965,16 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (op.gout && ((op.N & 3) || (op.dst_col & 3) || !aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_GEMM:
-        if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout) || (op.p3 && !op.p2)) return GD4D_EINVAL;
+        if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
+        if (op.p3 && !op.p2 && !(op.flags & GD4D_CHAIN_DROPOUT)) return GD4D_EINVAL;      // a second addend without a first
         if (op.K % (32 * RC_DEPTH) != 0 || op.K > RC_W) return GD4D_EUNSUPPORTED;
         if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_W)) return GD4D_EINVAL;
         if (op.dst >= 0 && op.dst == op.src) return GD4D_EINVAL;          // waves would overwrite rows others still read
         if (!aligned16(op.p0)) return GD4D_EALIGN;
         if (op.flags & GD4D_CHAIN_SRC2)
           if (op.res < 0 || op.res == op.dst || op.ld0 <= 0 || op.ld0 % (RC_COLS * RC_WAVES) != 0 || op.ld0 >= op.N) return GD4D_EINVAL;
+        if ((op.flags & GD4D_CHAIN_DROPOUT) && (!op.p3 || ((uintptr_t)op.p3 & 7) || (op.flags & (GD4D_CHAIN_SPLIT_OUT | GD4D_CHAIN_MASK_P2))))
+          return GD4D_EINVAL;
         if ((op.flags & GD4D_CHAIN_MASK_P2) && (!op.p2 || op.p3 || (op.flags & (GD4D_CHAIN_SPLIT_OUT | GD4D_CHAIN_SRC2)))) return GD4D_EINVAL;
         if (op.flags & GD4D_CHAIN_SPLIT_OUT)
           if (!op.gout || !op.p2 || !op.p3 || op.ldg <= 0 || op.ld2 <= 0 || op.ld1 <= 0 || op.ldg + op.ld2 + op.ld1 != op.N)
@@ -965,6 +992,10 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (!aligned16(op.p0) || !aligned16(op.p1) || (op.gout && (!aligned16(op.gout) || (op.ldg & 3)))) return GD4D_EALIGN;
         if (op.p2 && (op.res < 0 || op.res == op.src || op.res == op.dst)) return GD4D_EINVAL;    // second output: its own buffer
         if (op.p2 && (!aligned16(op.p2) || (op.ld2 & 3))) return GD4D_EALIGN;
+        break;
+      case GD4D_CHAIN_DROPMASK:
+        if (!op.p0 || ((uintptr_t)op.p0 & 7) || op.src < 0 || op.dst < 0 || op.N <= 0 || op.N > RC_W || (op.N & 3)) return GD4D_EINVAL;
+        if (op.gout && (!aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_LN_BWD:
         if (!op.p0 || op.src < 0 || op.res < 0 || op.res == op.src || op.res == op.dst || op.N <= 0 || op.N > RC_W) return GD4D_EINVAL;

@@ -35,13 +35,27 @@ from .fused_decoder import ORDER, _plain_reg_branch
 from .transformer_layers import FFN, MultiheadAttention
 
 
-def _dropout_active(layer):
+def draw_seeds(n, device):
+    """n 64-bit dropout seeds on the device (ops.mha_dropout_seed's recipe: torch's generator, so torch.manual_seed repeats the
+    masks and a replayed hipGraph draws new ones) - one launch for all the dropout sites of a step."""
+    return torch.randint(-2 ** 62, 2 ** 62, (n,), device=device, dtype=torch.int64)
+
+
+def _dropouts(layer):
+    """The layer's dropout probabilities where the chains apply them - (attention probabilities, after out_proj, after
+    output_proj, after the FFN's ReLU, after its second Linear) - or None when the modules drop anywhere else.
+    mmcv: MultiheadAttention = identity + dropout_layer(proj_drop(out)); Deform3DCrossAttn: dropout(output_proj(..)) + residuals
+    (deform3d_cross_attn.py:336); FFN: Linear, ReLU, Dropout, Linear, Dropout, then identity + dropout_layer(out)."""
     if not layer.training:
-        return False
+        return (0., 0., 0., 0., 0.)
     sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
-    ps = [sa.attn_drop, getattr(sa.proj_drop, 'p', 0.), getattr(sa.dropout_layer, 'p', 0.), getattr(ca.dropout, 'p', 0.),
-          getattr(ffn.dropout_layer, 'p', 0.)] + [m.p for m in ffn.layers.modules() if isinstance(m, torch.nn.Dropout)]
-    return any(float(p) > 0. for p in ps)
+    prob = lambda m: float(getattr(m, 'p', 0.))          # noqa: E731
+    if prob(sa.proj_drop) > 0. and prob(sa.dropout_layer) > 0.:
+        return None                                       # two dropouts in a row: not one Bernoulli mask
+    if prob(ffn.layers[2]) > 0. and prob(ffn.dropout_layer) > 0.:
+        return None
+    return (float(sa.attn_drop), max(prob(sa.proj_drop), prob(sa.dropout_layer)), prob(ca.dropout), prob(ffn.layers[0][2]),
+            max(prob(ffn.layers[2]), prob(ffn.dropout_layer)))
 
 
 def applicable(decoder, query, query_pos, value, reference_points, reg_branches, attn_masks, raw_entry, args, kwargs):
@@ -61,7 +75,7 @@ def applicable(decoder, query, query_pos, value, reference_points, reg_branches,
     if attn_masks is not None and not (torch.is_tensor(attn_masks) and attn_masks.dim() == 2):
         return False
     for layer in decoder.layers:
-        if tuple(layer.operation_order) != ORDER or len(layer.attentions) != 2 or len(layer.ffns) != 1 or _dropout_active(layer):
+        if tuple(layer.operation_order) != ORDER or len(layer.attentions) != 2 or len(layer.ffns) != 1 or _dropouts(layer) is None:
             return False
         sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
         if not isinstance(sa, MultiheadAttention) or sa.batch_first or sa.embed_dims != c or c // sa.num_heads != 32:
@@ -72,7 +86,7 @@ def applicable(decoder, query, query_pos, value, reference_points, reg_branches,
         if entry is None or len(entry) < 4 or not isinstance(entry[3], tuple):
             return False
         if not isinstance(ffn, FFN) or len(ffn.layers) != 3 or not ffn.add_identity or ffn.feedforward_channels % 64 \
-                or ffn.feedforward_channels > 512:
+                or ffn.feedforward_channels > 512 or len(ffn.layers[0]) != 3:
             return False
         lins = [sa.attn.out_proj, ca.cam_attention_weights, ca.deform_sampling_offsets, ca.attention_weights, ca.value_proj,
                 ca.output_proj, ca.position_encoder[0], ca.position_encoder[3], ffn.layers[0][0], ffn.layers[1]]
@@ -184,6 +198,8 @@ class DecoderTrainFunction(torch.autograd.Function):
         want_pyramid = ctx.needs_input_grad[1]
         out_all, ref_all = new(nl, q, 1, c), new(nl, 1, q, 3)
         saved = []
+        drops = [_dropouts(layer) for layer in layers]
+        seeds = draw_seeds(5 * nl, dev) if any(any(pr > 0. for pr in d) for d in drops) else None
         qkv, xp = new(q, 1, 3 * c), new(q, c)
         im0 = imgs.layers[0]
         p0 = dict(zip(NAMES, params[:PER_LAYER]))
@@ -197,12 +213,15 @@ class DecoderTrainFunction(torch.autograd.Function):
             fc = ffn.feedforward_channels
             last = lid + 1 == nl
             s = _Meta(x=x, xp=xp, qkv=qkv, ref=ref)
+            # the dropout sites of the layer: (seed, p) each, or None
+            s.drop = [(seeds[5 * lid + i:5 * lid + i + 1], pr) if pr > 0. else None for i, pr in enumerate(drops[lid])]
             qh, kh, vh = qkv.split(c, dim=-1)
-            s.o, s.lse = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, mask, want_lse=True)
+            s.o, s.lse = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, mask, want_lse=True,
+                                          dropout_p=drops[lid][0], seed=s.drop[0][0] if s.drop[0] else None)
             s.y1, s.x1, s.x1p = new(q, c), new(q, c), new(q, c)
             s.cam, s.off, s.att = new(1, q, ncam), new(1, q, hh * npt * 3), new(1, q, hh * nlv * npt)
             prog_a = [ops.chain_load(0, s.o.view(q, c)),
-                      ops.chain_gemm(0, im['outproj'], p['out_b'], dst=1, add=x, out=s.y1),
+                      ops.chain_gemm(0, im['outproj'], p['out_b'], dst=1, add=x, out=s.y1, dropout=s.drop[1]),
                       ops.chain_layernorm(1, layer.norms[0], dst=2, out=s.x1),
                       ops.chain_add(0, 2, c, add=pos, out=s.x1p),
                       ops.chain_gemm_three_outputs(0, [ca.cam_attention_weights, ca.deform_sampling_offsets, ca.attention_weights],
@@ -228,10 +247,10 @@ class DecoderTrainFunction(torch.autograd.Function):
             x3 = out_all[lid].view(q, c)
             prog = [ops.chain_headgemm(s.agg, s.plan.wsum, im['vp'], p['vp_b'], dst=0, out=s.v),
                     ops.chain_load(3, s.x1, s.pos_feat),
-                    ops.chain_gemm(0, im['outputproj'], p['op_b'], dst=1, res=3, out=s.y2),
+                    ops.chain_gemm(0, im['outputproj'], p['op_b'], dst=1, res=3, out=s.y2, dropout=s.drop[2]),
                     ops.chain_layernorm(1, layer.norms[1], dst=2, out=s.x2),
-                    ops.chain_gemm(2, im['ffn0'], p['f0_b'], dst=0, relu=True, out=s.h),
-                    ops.chain_gemm(0, im['ffn1'], p['f1_b'], dst=1, res=2, out=s.y3),
+                    ops.chain_gemm(2, im['ffn0'], p['f0_b'], dst=0, relu=True, out=s.h, dropout=s.drop[3]),   # h: after the dropout
+                    ops.chain_gemm(0, im['ffn1'], p['f1_b'], dst=1, res=2, out=s.y3, dropout=s.drop[4]),
                     ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3)]
             if not last:
                 qkv, xp = new(q, 1, 3 * c), new(q, c)
@@ -341,23 +360,36 @@ class DecoderTrainFunction(torch.autograd.Function):
             first, second = (g_here, g_next) if g_here is not None else (g_next, None)
             gy3, ghp, gy2, gv, gmid1, gmid0 = new(q, c), new(q, fc), new(q, c), new(q, c), new(q, c), new(q, c)
             ws_n2, ws_n1, ws_p4, ws_p1, ws_n0 = part(), part(), part(), part(), part()
+            # With dropout after a Linear the gradient at that Linear's output is the masked one (DROPMASK regenerates the
+            # forward's mask); the unmasked one is still what the residual branch passes on.
+            d_out, d_op, d_h, d_f1 = s.drop[1], s.drop[2], s.drop[3], s.drop[4]
+            gy3m = new(q, c) if d_f1 else gy3
+            gy2m = new(q, c) if d_op else gy2
             prog = [ops.chain_load(0, first, second),
                     ops.chain_load(1, s.y3),
-                    ops.chain_layernorm_bwd(0, 1, layer.norms[2], dst=0, out=gy3, part=ws_n2),
-                    ops.chain_gemm(0, im['ffn1_t'], None, dst=2, mask=s.h, out=ghp),
-                    ops.chain_gemm(2, im['ffn0_t'], None, dst=1, res=0),
-                    ops.chain_load(3, s.y2),
-                    ops.chain_layernorm_bwd(1, 3, layer.norms[1], dst=1, out=gy2, part=ws_n1),
-                    ops.chain_gemm(1, im['outputproj_t'], None, out=gv),
-                    ops.chain_load(3, s.mid1),
-                    ops.chain_layernorm_bwd(1, 3, pe[4], dst=2, relu=True, out=gmid1, part=ws_p4),
-                    ops.chain_gemm(2, im['pos3_t'], None, dst=0),
-                    ops.chain_load(3, s.mid0),
-                    ops.chain_layernorm_bwd(0, 3, pe[1], dst=0, relu=True, out=gmid0, part=ws_p1)]
+                    ops.chain_layernorm_bwd(0, 1, layer.norms[2], dst=0, out=None if d_f1 else gy3, part=ws_n2)]
+            src = 0
+            if d_f1:
+                prog.append(ops.chain_dropmask(0, 1, c, d_f1[0], d_f1[1], out=gy3m))
+                src = 1
+            prog += [ops.chain_gemm(src, im['ffn1_t'], None, dst=2, mask=s.h, mask_scale=1.0 / (1.0 - d_h[1]) if d_h else 0., out=ghp),
+                     ops.chain_gemm(2, im['ffn0_t'], None, dst=1, res=0),
+                     ops.chain_load(3, s.y2),
+                     ops.chain_layernorm_bwd(1, 3, layer.norms[1], dst=1, out=gy2, part=ws_n1)]
+            src = 1
+            if d_op:
+                prog.append(ops.chain_dropmask(1, 0, c, d_op[0], d_op[1], out=gy2m))
+                src = 0
+            prog += [ops.chain_gemm(src, im['outputproj_t'], None, out=gv),
+                     ops.chain_load(3, s.mid1),
+                     ops.chain_layernorm_bwd(1, 3, pe[4], dst=2, relu=True, out=gmid1, part=ws_p4),
+                     ops.chain_gemm(2, im['pos3_t'], None, dst=0),
+                     ops.chain_load(3, s.mid0),
+                     ops.chain_layernorm_bwd(0, 3, pe[1], dst=0, relu=True, out=gmid0, part=ws_p1)]
             ops.row_chain_fwd(prog, q)
-            wgrad(base, 'f1_w', s.h, gy3)
+            wgrad(base, 'f1_w', s.h, gy3m)
             wgrad(base, 'f0_w', s.x2, ghp)
-            wgrad(base, 'op_w', s.v, gy2)
+            wgrad(base, 'op_w', s.v, gy2m)
             wgrad(base, 'pe3_w', s.a1, gmid1)
             isig = ops.inverse_sigmoid_fwd(s.ref.view(q, 3))
             wgrad(base, 'pe0_w', isig, gmid0)
@@ -396,14 +428,18 @@ class DecoderTrainFunction(torch.autograd.Function):
             prog += [ops.chain_gemm(0, im['three_t'], None, dst=2, out=gx1p),
                      ops.chain_add(1, 2, c, add=gy2),
                      ops.chain_load(3, s.y1),
-                     ops.chain_layernorm_bwd(1, 3, layer.norms[0], dst=1, out=gy1, part=ws_n0),
-                     ops.chain_gemm(1, im['outproj_t'], None, out=g_o.view(q, c))]
+                     ops.chain_layernorm_bwd(1, 3, layer.norms[0], dst=1, out=gy1, part=ws_n0)]
+            gy1m = new(q, c) if d_out else gy1
+            if d_out:
+                prog.append(ops.chain_dropmask(1, 0, c, d_out[0], d_out[1], out=gy1m))
+            prog.append(ops.chain_gemm(0 if d_out else 1, im['outproj_t'], None, out=g_o.view(q, c)))
             ops.row_chain_fwd(prog, q)
             wgrad(base, 'cam_w', s.x1p, gcat[0]); wgrad(base, 'off_w', s.x1p, gcat[1]); wgrad(base, 'att_w', s.x1p, gcat[2])
-            wgrad(base, 'out_w', s.o.view(q, c), gy1)
+            wgrad(base, 'out_w', s.o.view(q, c), gy1m)
             lngrad(base, 'n0_w', ws_n0)
             qh, kh, vh = s.qkv.split(c, dim=-1)
-            dqk, dv = ops.mha_core_bwd(qh, kh, vh, s.o, g_o, s.lse, sa.num_heads, meta.attn_mask, packed_qk=True)
+            dqk, dv = ops.mha_core_bwd(qh, kh, vh, s.o, g_o, s.lse, sa.num_heads, meta.attn_mask, packed_qk=True,
+                                       dropout_p=s.drop[0][1] if s.drop[0] else 0., seed=s.drop[0][0] if s.drop[0] else None)
             gx, gxp = new(q, c), new(q, c)
             gpos_new = new(q, c)
             prog = [ops.chain_load(0, dqk.view(q, 2 * c)), ops.chain_load(1, dv.view(q, c)),

@@ -1461,8 +1461,8 @@ class ChainOp(ctypes.Structure):
 
 
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
-CHAIN_LN_BWD = 10
-CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT, CHAIN_MASK_P2 = 1, 2, 4, 8, 16, 32, 64
+CHAIN_LN_BWD, CHAIN_DROPMASK = 10, 11
+CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT, CHAIN_MASK_P2, CHAIN_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def _rows(t, name):
@@ -1613,8 +1613,30 @@ def _image_of(weight, exact=False):
     return chain_weight_image(weight, exact).data_ptr(), weight.shape[0], weight.shape[1]
 
 
+def chain_dropout_args(p):
+    """(threshold, scale) of a dropout with probability p as the chain operations take them (gd4d_mha_dropout.h)."""
+    t = float(p) * 4294967296.0
+    thresh = 0 if t <= 0 else (0xFFFFFFFF if t >= 4294967295.0 else int(t + 0.5))
+    return thresh, 1.0 / (1.0 - float(p))
+
+
+def chain_dropout_keep_mask(seed, m, n, p):
+    """The (m, n) bool keep mask a chain GEMM with dropout=(seed, p) and N = n draws (restated with torch integer ops, as
+    mha_dropout_keep_mask): for tests against torch with the same mask."""
+    return mha_dropout_keep_mask(seed, 1, 1, m, n, p).view(m, n)
+
+
+def chain_dropmask(src, dst, n, seed, p, out=None):
+    """buf[dst] = (the keep mask of a forward GEMM with dropout=(seed, p), N = n) * buf[src] / (1 - p); out: also stored."""
+    thresh, scale = chain_dropout_args(p)
+    g, ldg = _rows(out, 'out')
+    c_thresh = thresh - (1 << 32) if thresh >= (1 << 31) else thresh
+    return ChainOp(kind=CHAIN_DROPMASK, src=src, dst=dst, res=-1, N=n, eps=scale, reserved=c_thresh, ldg=ldg, gout=g,
+                   p0=_dev(seed, 'seed', torch.int64).value)
+
+
 def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False, exact=False, add=None,
-               add2=None, mask=None, mask_scale=0.):
+               add2=None, mask=None, mask_scale=0., dropout=None):
     """act(buf[src] W^T + b) (+ buf[res]) (+ (add + add2)[m, :]) -> buf[dst] and / or out.  weight (N, K) contiguous rows.
     add / add2: global (M, N) tensors added in the epilogue (their sum first, then onto the result - what a LOAD of
     add + add2 into buf[res] would give, without the operation).  exact: fp32-class products (GD4D_CHAIN_EXACT) instead of
@@ -1627,9 +1649,16 @@ def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, ou
     p3, ld3 = _rows(add2, 'add2')
     if p3 is not None and p2 is None:
         raise ValueError('chain_gemm: add2 without add')
+    eps, reserved, flags = float(mask_scale) if mask is not None else 0., 0, 0
+    if dropout is not None and float(dropout[1]) > 0.:      # (seed: (1,) int64 device tensor, p): nn.Dropout on the output
+        if mask is not None or p3 is not None:
+            raise ValueError('chain_gemm: dropout excludes mask and add2')
+        thresh, eps = chain_dropout_args(dropout[1])
+        reserved = thresh - (1 << 32) if thresh >= (1 << 31) else thresh
+        p3, flags = _dev(dropout[0], 'seed', torch.int64).value, CHAIN_DROPOUT
     return ChainOp(kind=CHAIN_GEMM, src=src, dst=dst, res=res, K=k, N=n, dst_col=dst_col,
                    flags=(CHAIN_RELU if relu else 0) | (CHAIN_SIGMOID if sigmoid else 0) | (CHAIN_EXACT if exact else 0) |
-                   (CHAIN_MASK_P2 if mask is not None else 0), ldg=ldg, eps=float(mask_scale) if mask is not None else 0.,
+                   (CHAIN_MASK_P2 if mask is not None else 0) | flags, ldg=ldg, eps=eps, reserved=reserved,
                    ld2=ld2, ld1=ld3, p0=img, p1=None if bias is None else bias.data_ptr(), p2=p2, p3=p3, gout=g)
 
 

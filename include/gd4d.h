@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 39
+#define GD4D_ABI_VERSION 40
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -534,13 +534,15 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  *              recomputed), p0 = gamma, p1 = beta (needed with GD4D_CHAIN_RELU: the forward's ReLU); dx -> buf[dst] (dst == src
  *              allowed) and / or gout; p2 = (ceil(M / 16), 2, N) partial dgamma / dbeta of the row blocks, the layout of
  *              gd4d_layernorm_bwd's workspace (gd4d_layernorm_bwd_reduce_group adds them), or NULL
+ *   DROPMASK   buf[dst][:, :N] = the dropout mask a forward GEMM with GD4D_CHAIN_DROPOUT drew (p0 = its seed, reserved = its
+ *              threshold, eps = its scale, N = its N) applied to buf[src]: the gradient at that GEMM's output; also to gout
  * GEMMs: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (fp32-class, the arithmetic of gd4d_value_proj_fwd);
  * everything else fp32.  M = number of rows.
  * A training step runs the same programs with every intermediate also written to global memory (gout), and backward programs
  * built from GEMMs over the TRANSPOSED weights' images (input gradients; GD4D_CHAIN_MASK_P2 at a ReLU), LN_BWD and ADD; the
  * weight gradients are contractions over all rows (gd4d_linear_bwd_weight_group) of what those programs wrote. */
 enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_CHAIN_ADD = 4, GD4D_CHAIN_REFINE = 5,
-       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7, GD4D_CHAIN_SIGNAL = 8, GD4D_CHAIN_WAIT = 9, GD4D_CHAIN_LN_BWD = 10 };
+       GD4D_CHAIN_SMALL_LINEAR = 6, GD4D_CHAIN_HEADGEMM = 7, GD4D_CHAIN_SIGNAL = 8, GD4D_CHAIN_WAIT = 9, GD4D_CHAIN_LN_BWD = 10, GD4D_CHAIN_DROPMASK = 11 };
 #define GD4D_CHAIN_RELU 1
 #define GD4D_CHAIN_INV_SIGMOID 2
 #define GD4D_CHAIN_SIGMOID 4        /* GEMM: sigmoid on the output (after the bias / ReLU, before the residual) */
@@ -555,6 +557,9 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
                                        Linears of one input stacked into one weight (deform3d_cross_attn.py:211, :227, :281) */
 #define GD4D_CHAIN_MASK_P2 64       /* GEMM (a backward chain): p2[m, n] is the output a ReLU produced in the forward pass, not an
                                        addend - the result passes where it was > 0 (times eps when eps != 0), else 0 */
+#define GD4D_CHAIN_DROPOUT 128      /* GEMM (training, modules in train mode): nn.Dropout on the output - after bias / activation, before
+                                       the residuals: element (m, n) is kept iff gd4d_mha_dropout.h's hash of (the 64-bit seed at p3,
+                                       m N + n) >= reserved (= round(p 2^32)); kept elements are multiplied by eps = 1 / (1 - p) */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */

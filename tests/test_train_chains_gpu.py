@@ -123,18 +123,71 @@ def test_chain_training_refuses_a_second_backward(monkeypatch):
         loss.backward()
 
 
-def test_train_mode_with_dropout_takes_the_generic_path(monkeypatch):
+class _HashDropout(nn.Dropout):
+    """nn.Dropout with the chains' mask: element (row, column) of a (.., C) tensor kept iff the hash of (seed, row C + column)
+    says so (ops.chain_dropout_keep_mask) - puts the GENERIC path on the masks the chain path draws."""
+
+    def __init__(self, p, seed):
+        super().__init__(p)
+        self.seed = seed
+
+    def forward(self, x):
+        if not self.training or self.p == 0.:
+            return x
+        n = x.shape[-1]
+        keep = ops.chain_dropout_keep_mask(self.seed, x.numel() // n, n, self.p).view(x.shape)
+        return x * keep / (1.0 - self.p)
+
+
+@pytest.mark.parametrize('with_reg', [False, True])
+def test_chain_training_step_in_train_mode_equals_the_generic_path_on_the_same_masks(with_reg, monkeypatch):
+    """Modules in train mode (dropout 0.1 on the attention probabilities, after out_proj, after output_proj, inside and after the
+    FFN - the reference's config): the chain path draws its masks from per-site seeds; the generic path is put on the SAME
+    masks (its nn.Dropout modules replaced by _HashDropout, the attention core handed the same seeds) and must then agree in
+    the outputs and in every gradient."""
     from graph_detr4d_amd import fused_train
-    monkeypatch.setenv('GD4D_TRAIN_CHAINS', '1')
     g = Golden('decoder_deform')
     tr = _transformer(g).train()
-    calls = []
-    real = fused_train.run
-    monkeypatch.setattr(fused_train, 'run', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    feats = [f.to(DEV).requires_grad_() for f in g.feats()]
-    states, _, _ = tr(feats, g.t('query_embed').to(DEV), reg_branches=None, img_metas=g.img_metas())
-    states.sum().backward()
-    assert not calls
+    nl = g.meta['num_layers']
+    reg = _reg_branches(nl) if with_reg else None
+    seeds = torch.randint(-2 ** 62, 2 ** 62, (5 * nl,), generator=torch.Generator().manual_seed(9), dtype=torch.int64).to(DEV)
+    monkeypatch.setattr(fused_train, 'draw_seeds', lambda n, dev: seeds.clone())
+    a = _run(tr, g, reg, True, monkeypatch)
+    # generic path on the same masks
+    for lid, layer in enumerate(tr.decoder.layers):
+        sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+        site = lambda i: seeds[5 * lid + i:5 * lid + i + 1]          # noqa: E731
+        sa.dropout_layer = _HashDropout(sa.dropout_layer.p, site(1))
+        ca.dropout = _HashDropout(ca.dropout.p, site(2))
+        ffn.layers[0][2] = _HashDropout(ffn.layers[0][2].p, site(3))
+        ffn.layers[2] = _HashDropout(ffn.layers[2].p, site(4))
+    tr.train()
+    order = [seeds[5 * lid:5 * lid + 1] for lid in range(nl)]
+    monkeypatch.setattr(ops, 'mha_dropout_seed', lambda dev: order.pop(0))
+    b = _run(tr, g, reg, False, monkeypatch)
+    assert not order
+    _compare(a, b)
+    # and the masks matter: eval mode gives other outputs
+    c_ = _run(tr.eval(), g, reg, True, monkeypatch)
+    assert (c_['states'] - a['states']).abs().max() > 1e-2
+
+
+def test_chain_gemm_dropout_and_dropmask_use_the_documented_mask():
+    torch.manual_seed(4)
+    m, p = 70, 0.3
+    x, w, b = torch.randn(m, 256, device=DEV), torch.randn(512, 256, device=DEV) * 0.05, torch.randn(512, device=DEV)
+    res = torch.randn(m, 512, device=DEV)
+    seed = ops.mha_dropout_seed(torch.device(DEV))
+    out, out0 = torch.empty(m, 512, device=DEV), torch.empty(m, 512, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(0, x), ops.chain_gemm(0, w, b, relu=True, out=out, add=res, dropout=(seed, p))], m)
+    ops.row_chain_fwd([ops.chain_load(0, x), ops.chain_gemm(0, w, b, relu=True, out=out0)], m)
+    keep = ops.chain_dropout_keep_mask(seed, m, 512, p)
+    assert 0.6 < keep.float().mean().item() < 0.8
+    torch.testing.assert_close(out, out0 * keep / (1 - p) + res, rtol=1e-6, atol=1e-6)
+    gr = torch.randn(m, 512, device=DEV)
+    masked = torch.empty(m, 512, device=DEV)
+    ops.row_chain_fwd([ops.chain_load(1, gr), ops.chain_dropmask(1, 2, 512, seed, p, out=masked)], m)
+    torch.testing.assert_close(masked, gr * keep / (1 - p), rtol=1e-6, atol=1e-7)
 
 
 # ---- the chain operations ---------------------------------------------------------------------------------------------------
