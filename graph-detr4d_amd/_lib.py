@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 40
+ABI_VERSION = 42
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -69,6 +69,7 @@ SIGNATURES = {
     'gd4d_layernorm_bwd_workspace_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_layernorm_bwd': (_i, [_vp] * 9 + [_c.c_size_t, _i, _i, _f, _i, _vp]),
     'gd4d_inverse_sigmoid_fwd': (_i, [_vp, _vp, _c.c_int64, _vp]),
+    'gd4d_inverse_sigmoid_bwd': (_i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp]),
     'gd4d_layernorm_bwd_reduce_group': (_i, [_vp] * 4 + [_i, _i, _vp]),
     'gd4d_refine_reference_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_frustum_pe_input_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _i, _vp]),

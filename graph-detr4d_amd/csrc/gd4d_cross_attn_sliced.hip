@@ -59,6 +59,7 @@ struct PlanParams {
   int stage_lo;            // GD4D_CA_PLAN_STAGE*: levels stage_lo .. 3 are staged by the gather (0: none)
   int stage_cap;           // staged lines a query may have; more: that query is gathered without staging
   unsigned* ulist;         // (position, stage_cap): the unique {byte offset | level - stage_lo} of a query's staged corners
+  int both;                // GD4D_CA_PLAN_BOTH: `item` is a second region; the pairs are written as well
 };
 
 // ---- staging (round 4): the coarse levels' corners through LDS ---------------------------------------------------------------
@@ -297,9 +298,11 @@ __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const
           }
         }
       }
-      if (lane == 0) pp.hdr[pos * kPlanHdr + h] = M;
-      __builtin_amdgcn_wave_barrier();                                     // the list is rewritten for the next head
-      continue;
+      if (!pp.both) {
+        if (lane == 0) pp.hdr[pos * kPlanHdr + h] = M;
+        __builtin_amdgcn_wave_barrier();                                   // the list is rewritten for the next head
+        continue;
+      }                                                                    // both forms: the pairs follow (they write hdr and wsum)
     }
     uint2* out = pp.pair + ((size_t)pos * HH + h) * pp.cap_t * 64;
     const float* aw_h = s_aw + h * LP + min(l_of, LT - 1) * PT;             // + (row % B) * HH * LP + point
@@ -886,7 +889,17 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
   pp.item = nullptr;
   pp.cap_i = plan_cap_items(N, P);
   pp.item_f4 = 2; pp.stage_lo = 0; pp.stage_cap = 0; pp.ulist = nullptr;
+  pp.both = 0;
   if (flags & GD4D_CA_PLAN_ITEMS) pp.item = reinterpret_cast<float4*>(pp.pair);   // same place, a quarter of the bytes
+  if (flags & GD4D_CA_PLAN_BOTH) {
+    // A training step: the forward gather walks the ITEMS (a quarter of the plan bytes), the backward kernels the pairs.  The
+    // buffer holds two plans back to back - [0, bytes): header + pairs, [bytes, 2 bytes): a header's room + items, so that
+    // plan + bytes is what gd4d_cross_attn_agg_items_fwd takes.
+    const size_t one = gd4d_cross_attn_plan_bytes(B, N, Q, Hh, P);
+    if ((flags & (GD4D_CA_PLAN_ITEMS | GD4D_CA_PLAN_STAGE3 | GD4D_CA_PLAN_STAGE23)) || plan_bytes < 2 * one) return GD4D_EINVAL;
+    pp.item = reinterpret_cast<float4*>(static_cast<char*>(plan) + one + plan_hdr_bytes(B, Q));
+    pp.both = 1;
+  }
   if (flags & (GD4D_CA_PLAN_STAGE3 | GD4D_CA_PLAN_STAGE23)) {
     // the coarse levels' corners through the gather's LDS stage: items of three float4, the unique lines behind them
     if (!(flags & GD4D_CA_PLAN_ITEMS) || Hh != 8 || L != 4 || P != kPoints || (pix_stride_bytes & 63)) return GD4D_EUNSUPPORTED;

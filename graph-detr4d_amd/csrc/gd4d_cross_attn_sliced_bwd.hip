@@ -206,11 +206,14 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(con
       // put the two groups one after the other: 181 us per launch.)
       unsigned off[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        off[j] = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
-        if (j >= 4) off[j] = second ? off[j] : off[j - 4];
-        off[j] += lane_off;
-      }
+      for (int j = 0; j < 8; ++j) off[j] = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
+      // (items 2, 3 absent: the offsets of items 0, 1 again - BEFORE the lane's share is added: adding it to an offset that
+      //  already carries it read up to 112 bytes past the pixel, i.e. past the END of the pyramid for the last pixel of the last
+      //  camera row of the last slice - a fault when the allocation ends where the mapped memory does)
+#pragma unroll
+      for (int j = 4; j < 8; ++j) off[j] = second ? off[j] : off[j - 4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) off[j] += lane_off;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; ++j)

@@ -547,7 +547,26 @@ __global__ __launch_bounds__(256) void inverse_sigmoid_kernel(const float* __res
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] = inv_sigmoid(x[i]);
 }
+// what autograd derives for the reference's inverse_sigmoid (clamp to [0, 1], clamp(x, eps), clamp(1 - x, eps), log of the ratio):
+// d/dx = [x > eps] / x + [1 - x > eps] / (1 - x) inside [0, 1], 0 outside
+__global__ __launch_bounds__(256) void inverse_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                  const float* __restrict__ add, float* __restrict__ gx, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i], eps = 1e-5f;
+  float d = 0.f;
+  if (v >= 0.f && v <= 1.f) d = (v > eps ? 1.0f / v : 0.f) + (1.0f - v > eps ? 1.0f / (1.0f - v) : 0.f);
+  gx[i] = gy[i] * d + (add ? add[i] : 0.f);
+}
 }  // namespace gd4d
+
+extern "C" int gd4d_inverse_sigmoid_bwd(const float* x, const float* grad_y, const float* add, float* grad_x, int64_t n, void* stream) {
+  using namespace gd4d;
+  if (!x || !grad_y || !grad_x || n <= 0) return GD4D_EINVAL;
+  hipLaunchKernelGGL(inverse_sigmoid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     grad_y, add, grad_x, (long long)n);
+  return check_launch();
+}
 
 extern "C" int gd4d_inverse_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {
   using namespace gd4d;

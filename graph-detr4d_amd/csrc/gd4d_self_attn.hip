@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_bf16x3_kernel(const M
   const int q0 = blockIdx.x * 16;
   const int h = blockIdx.y, b = blockIdx.z;
   const float NEG_INF = -__builtin_inff();
-  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   const float qscale = p.scale * LOG2E;                       // base-2 softmax, as above
 
   mha_u4 qh, ql;                                              // Q^T as B operand: lane (query qi, g) holds q[qi][8 g .. 8 g + 7]
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_bf16x3_kernel(const M
       den += s_l[w][i] * f;
     }
     p.out[((size_t)(q0 + i) * p.B + b) * p.ldo + h * MHA_D + d] = num / den;
+    if (p.lse && d == 0) p.lse[((size_t)(q0 + i) * p.B + b) * p.H + h] = mm * LN2 + logf(den);   // a training step's forward: for gd4d_mha_core_bwd
   }
   trace_mark(g_trace_mha, 0x82ull);
 }
@@ -418,7 +419,7 @@ extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v,
   const dim3 grid((Lq + 15) / 16, H, B), block(64 * MHA_WAVES);
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const bool fp32_only = [] { const char* e = getenv("GD4D_MHA_FP32"); return e && e[0] == '1'; }();
-  if (drop_p == 0.f && !lse && !fp32_only) {          // inference: split-bf16 x3 products (GD4D_MHA_FP32=1: the fp32 kernel)
+  if (drop_p == 0.f && !fp32_only) {                  // no dropout: split-bf16 x3 products (GD4D_MHA_FP32=1: the fp32 kernel)
     if (mask_kind == 0) hipLaunchKernelGGL((mha_core_bf16x3_kernel<0>), grid, block, 0, st, p);
     else if (mask_kind == 1) hipLaunchKernelGGL((mha_core_bf16x3_kernel<1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((mha_core_bf16x3_kernel<2>), grid, block, 0, st, p);

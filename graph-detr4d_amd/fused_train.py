@@ -238,7 +238,8 @@ class DecoderTrainFunction(torch.autograd.Function):
             # plan + gather on the raw pyramid (autograd.CrossAttnRawFunction's forward without its value_proj launch)
             order = Fn.query_order(ref, ca.pc_range)
             s.plan = ops.cross_attn_plan_fwd(raw.pyramid, ref, s.off.view(1, q, hh, npt, 3), s.att.view(1, q, hh, nlv, npt), s.cam,
-                                             meta.lidar2img, ca.pc_range, meta.img_h, meta.img_w, hh, query_order=order)
+                                             meta.lidar2img, ca.pc_range, meta.img_h, meta.img_w, hh, query_order=order,
+                                             both=os.environ.get('GD4D_TRAIN_PLAN', 'both') == 'both')
             s.layer = raw.register(s.plan.q)
             if want_pyramid:
                 raw.count(s.layer, s.plan)
@@ -455,14 +456,8 @@ class DecoderTrainFunction(torch.autograd.Function):
                 # The reference points a layer reads carry a gradient when they are the decoder's INPUT: layer 0's always, every
                 # layer's without reg branches (no refinement, so no detach: detr3d_transformer.py:199-214).  Two parts: the
                 # plan's, and position_encoder's through its first Linear and inverse_sigmoid (torch ops on 900 x 3 values).
-                r = s.ref.view(q, 3)
-                g_isig = gmid0 @ p['pe0_w'].detach()
-                eps = 1e-5
-                rc = r.clamp(0, 1)
-                d = torch.where(rc > eps, 1.0 / rc.clamp_min(eps), torch.zeros_like(rc)) + \
-                    torch.where(1 - rc > eps, 1.0 / (1 - rc).clamp_min(eps), torch.zeros_like(rc))
-                d = torch.where((r < 0) | (r > 1), torch.zeros_like(d), d)
-                part_ref = (gr.view(q, 3) + g_isig * d).view(1, q, 3)
+                g_isig = ops.linear_fwd(gmid0, p['pe0_w'].detach().contiguous(), weight_kn=True)           # (Q, 3) = gmid0 W
+                part_ref = ops.inverse_sigmoid_bwd(s.ref.view(q, 3), g_isig, add=gr.contiguous().view(q, 3)).view(1, q, 3)
                 g_ref0 = part_ref if g_ref0 is None else g_ref0 + part_ref
         for i in range(0, len(local_w), 16):
             ops.linear_bwd_weight_group(local_w[i:i + 16], accumulate=False)

@@ -243,9 +243,10 @@ class Plan:
     plan kernel).  items: the buffer holds the ITEMS form (include/gd4d.h, GD4D_CA_PLAN_ITEMS) - gather only; the
     training backward kernels need the pairs form."""
 
-    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False, points=4, stage=0):
+    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False, points=4, stage=0, items_buf=None):
         self.buf, self.order, self.pyramid, self.b, self.q, self.num_heads, self.wsum = buf, order, pyramid, b, q, num_heads, wsum
         self.items, self.points, self.stage = bool(items), int(points), int(stage)
+        self.items_buf = items_buf           # both=True: `buf` holds the pairs, this view the items (the forward gather's form)
 
     def need_pairs(self, who):
         if self.items:
@@ -255,7 +256,7 @@ class Plan:
                                  'forward kernels take 1 / 2 / 4 / 8, the training backward 4 only')
 
 
-CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS, CA_PLAN_STAGE3, CA_PLAN_STAGE23 = 1, 2, 4, 8
+CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS, CA_PLAN_STAGE3, CA_PLAN_STAGE23, CA_PLAN_BOTH = 1, 2, 4, 8, 16
 
 
 def stage_supported(pyramid, b, num_heads, points):
@@ -270,12 +271,14 @@ def stage_supported(pyramid, b, num_heads, points):
 
 
 def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, num_heads,
-                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None, items=False, stage=0):
+                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None, items=False, stage=0,
+                        both=False):
     """gd4d_cross_attn_plan_fwd: projection + mask + softmax + camera weights + bilinear corners of one decoder layer's
     cross-attention -> what gd4d_cross_attn_agg_sliced_fwd walks on `pyramid` (a PyramidView).  The other arguments as
     cross_attn_fwd; plan: a Plan to overwrite; items: the 32-bytes-per-item form (the corners are worked out by the gather,
     which then also fills wsum); stage (with items): 3 / 2 = the corners of level 3 / levels 2 and 3 go through the gather's LDS
-    stage (stage_supported() says whether it applies; results bit-identical).
+    stage (stage_supported() says whether it applies; results bit-identical).  both: pairs AND items in one launch (a training
+    step: the forward gather reads the items, the backward kernels the pairs).
     Returns Plan [, mask (B, N, Q, Hh, P) uint8] [, uv (B, N, Q, Hh, P, 2)]."""
     lib = _lib.load()
     b, q = ref.shape[0], ref.shape[1]
@@ -287,11 +290,14 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
         raise ValueError('offsets / attn_logits / cam_logits have the wrong number of elements')
     f32 = torch.float32
     nbytes = cross_attn_plan_bytes(b, n, q, hh, p)
-    buf = torch.empty(nbytes, device=ref.device, dtype=torch.uint8) if plan is None else plan.buf
+    if both and (items or stage or plan is not None):
+        raise ValueError('both=True excludes items / stage / plan')
+    buf = torch.empty(2 * nbytes if both else nbytes, device=ref.device, dtype=torch.uint8) if plan is None else plan.buf
     wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32) if plan is None else plan.wsum
     if stage not in (0, 2, 3) or (stage and not items):
         raise ValueError('stage must be 0, 2 or 3 and needs items=True')
-    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items, points=p, stage=stage)
+    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items, points=p, stage=stage,
+                items_buf=buf[nbytes:] if both else None)
     mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
     uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
     rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
@@ -303,7 +309,7 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
         lv, cs, pyramid.pix_stride, _dev(buf, 'plan', torch.uint8), buf.numel(), _dev(wsum, 'wsum', f32),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None, b, n, q, hh, nl, p,
         (CA_RAW_CAM_WEIGHTS if raw_cam_weights else 0) | (CA_PLAN_ITEMS if items else 0) |
-        (CA_PLAN_STAGE3 if stage == 3 else CA_PLAN_STAGE23 if stage == 2 else 0),
+        (CA_PLAN_STAGE3 if stage == 3 else CA_PLAN_STAGE23 if stage == 2 else 0) | (CA_PLAN_BOTH if both else 0),
         None if query_order is None else _order_ptr(query_order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_plan_fwd')
     res = (plan,)
@@ -328,11 +334,12 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
     if agg is None:
         agg = torch.empty(b, q, hh, 256, device=dev, dtype=f32)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
-    if plan.items:
+    if plan.items or plan.items_buf is not None:
         lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in pyramid.level_hw for x in hw])
         cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
         code = lib.gd4d_cross_attn_agg_items_fwd(
-            ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
+            ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride,
+            _dev(plan.buf if plan.items else plan.items_buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
             _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, plan.points,
             _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
             None if query_order is None else _order_ptr(query_order, b * q), int(slices[0]), int(slices[1]), plan.stage, _stream())
@@ -1145,6 +1152,16 @@ def inverse_sigmoid_fwd(x):
     code = lib.gd4d_inverse_sigmoid_fwd(_dev(x, 'x', torch.float32), _dev(y, 'y'), x.numel(), _stream())
     _lib.check(code, 'gd4d_inverse_sigmoid_fwd')
     return y
+
+
+def inverse_sigmoid_bwd(x, grad_y, add=None):
+    """gd4d_inverse_sigmoid_bwd: grad_y * d inverse_sigmoid(x) / dx (+ add)."""
+    lib = _lib.load()
+    gx = torch.empty_like(x)
+    code = lib.gd4d_inverse_sigmoid_bwd(_dev(x, 'x', torch.float32), _dev(grad_y, 'grad_y', torch.float32), _opt(add, 'add'),
+                                        _dev(gx, 'grad_x'), x.numel(), _stream())
+    _lib.check(code, 'gd4d_inverse_sigmoid_bwd')
+    return gx
 
 
 def refine_reference_fwd(tmp, ref):

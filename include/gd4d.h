@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 40
+#define GD4D_ABI_VERSION 42
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -58,6 +58,8 @@ enum {
 #define GD4D_CA_PLAN_ITEMS 2      /* gd4d_cross_attn_plan_fwd: write the ITEMS form of the plan (gd4d_cross_attn_agg_items_fwd) */
 #define GD4D_CA_PLAN_STAGE3 4     /* with ITEMS: also de-duplicate the query's corners on level 3 for the gather's LDS stage (stage = 3) */
 #define GD4D_CA_PLAN_STAGE23 8    /* ... on levels 2 and 3 (stage = 2) */
+#define GD4D_CA_PLAN_BOTH 16      /* pairs AND items: plan_bytes >= 2 x gd4d_cross_attn_plan_bytes(); [0, bytes) is the pairs plan (what the
+                                     training backward kernels read), plan + bytes an items plan for gd4d_cross_attn_agg_items_fwd */
 
 int gd4d_abi_version(void);
 const char* gd4d_error_string(int code);
@@ -682,6 +684,9 @@ int gd4d_layernorm_bwd_reduce_group(const void* const* workspaces, void* const* 
  * input of position_encoder's first Linear in a training step, where the reference points carry no gradient; the
  * inference kernels apply it while loading). */
 int gd4d_inverse_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+/* gd4d_inverse_sigmoid_bwd - grad_x = grad_y * d inverse_sigmoid(x) / dx (+ add, when given): what autograd derives for it
+ * (1 / x where x > eps, plus 1 / (1 - x) where 1 - x > eps; 0 outside [0, 1]).  Layer 0's reference points in a training step. */
+int gd4d_inverse_sigmoid_bwd(const float* x, const float* grad_y, const float* add, float* grad_x, int64_t n, void* stream);
 
 /* gd4d_refine_reference_fwd - reference-point refinement between decoder layers
  * (Detr3DTransformerDecoder.forward, detr3d_transformer.py:201-214):

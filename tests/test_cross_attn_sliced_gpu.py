@@ -44,6 +44,21 @@ def _sliced(*args, **kwargs):
     for a, b in zip(got, other):
         assert torch.equal(a, b), 'items form and pairs form of the plan disagree'
     pyr, ref, offsets = args[0], args[1], args[2]
+    if not kwargs.get('want') and kwargs.get('slices') is None:
+        # both forms from ONE launch (a training step): the pairs region is the pairs-only plan byte for byte, the forward gather
+        # on its items region gives the same aggregate
+        attn, cam, l2i, pc_range, img_h, img_w = args[3:9]
+        heads, order = kwargs.get('heads', 8), kwargs.get('order')
+        both = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads, query_order=order, both=True)
+        pairs = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads, query_order=order)
+        assert both.buf.numel() == 2 * pairs.buf.numel() and not both.items
+        hdr = ops._lib.load().gd4d_cross_attn_plan_bytes(ref.shape[0], pyr.rows // ref.shape[0], ref.shape[1], heads, offsets.shape[3])
+        assert hdr == pairs.buf.numel()
+        assert torch.equal(both.wsum, pairs.wsum)
+        agg_b = ops.cross_attn_agg_sliced_fwd(both)
+        assert torch.equal(agg_b, got[0]) and torch.equal(both.wsum, got[1])
+        both.items_buf = None                            # ... and the pairs of the same buffer through the pairs gather
+        assert torch.equal(ops.cross_attn_agg_sliced_fwd(both), got[0])
     if ops.stage_supported(pyr, ref.shape[0], kwargs.get('heads', 8), offsets.shape[3]):
         for stage in (3, 2):
             # the staged gather walks the direct levels of all items first, then the staged ones: the same products in
