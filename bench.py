@@ -605,7 +605,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             'metric': f'decoder_{"distill" if distill else "train"}_samples_per_sec_{a.queries}q_T{a.frames}',
             'value': D.aggregate_throughput(1, a.steps, a.gpus, elapsed), 'unit': 'samples/s', 'n_gpus': a.gpus,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (bf16x3 GEMMs)' if _chain_calls() else 'f32', 'data': 'synthetic',
             'config': {'workload': ('distillation step (teacher pass under no_grad, student pass + teacher-query-guided student '
                                     'pass sharing one value projection, instance distillation loss); ' if distill else '') +
                                    ('training step of the decoder + head with the reference\'s loss (Hungarian assignment, '
@@ -617,6 +618,9 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                        'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),
                        'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse, 'input_layout': a.input_layout,
                        'dropout': 'on (train mode)' if a.dropout else 'off (modules in eval mode, autograd on)',
+                       'query_side': ('row chains forward and backward, one autograd node for the decoder (graph_detr4d_amd/fused_train.py)'
+                                      if _chain_calls() else
+                                      'one autograd node per Linear / LayerNorm / attention core (the generic path)'),
                        'parallelism': f'dp{a.gpus}' if a.gpus > 1 else 'single GPU'},
             'preflight': a.preflight,
             'ranks': stats['ranks'], 'ms_per_step_rank_min': stats['rank_seconds_min'] / a.steps * 1e3,
@@ -630,6 +634,11 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             line['roofline'], line['kernels'] = _train_kernel_figures(a, n_cams, levels, dev)
         print(json.dumps(line))
     D.shutdown()
+
+
+def _chain_calls():
+    from graph_detr4d_amd import fused_train
+    return fused_train.CALLS[0]
 
 
 def _train_kernel_figures(a, n_cams, levels, dev):

@@ -94,7 +94,8 @@ class RawPyramid:
         self.layer_q = []                              # queries per sample of every registered layer
         self.needs_grad = self.channels_last = False
         self.copy_dtype = torch.float32
-        self.main = self.side = None
+        self.main = self.side = self.side_bwd = None
+        self.copy_event = None
         self.sink = self.grads = self._dpart = None
         self._forked = self._prepared = False
 
@@ -106,12 +107,13 @@ class RawPyramid:
         self.layer_q.append(int(q))
         return self.layers - 1
 
-    def _fork(self):
-        if self.side is self.main:
+    def _fork(self, side=None):
+        side = self.side if side is None else side
+        if side is self.main:
             return
         ev = torch.cuda.Event()
         ev.record(self.main)
-        self.side.wait_event(ev)
+        side.wait_event(ev)
         self._forked = True
 
     def count(self, layer, plan):
@@ -131,6 +133,12 @@ class RawPyramid:
             if plan.order is not None:
                 plan.order.record_stream(self.side)
 
+    def wait_copy(self):
+        """Before the first kernel that reads the pyramid: the copy may still be running beside the main stream."""
+        if self.copy_event is not None:
+            torch.cuda.current_stream(self.pyramid.device).wait_event(self.copy_event)
+            self.copy_event = None
+
     def join(self):
         """Make the main stream wait for the side stream's work (end of the forward pass; keeps a capture well-formed)."""
         if self._forked:
@@ -142,8 +150,8 @@ class RawPyramid:
         if not self.needs_grad or self._prepared or self.sink is None:
             return
         self.sink.alloc_table(self.layer_q)
-        self._fork()
-        with torch.cuda.stream(self.side):
+        self._fork(self.side_bwd)
+        with torch.cuda.stream(self.side_bwd):
             self.sink.prepare()
         self._prepared = True
 
@@ -160,11 +168,11 @@ class RawPyramid:
         py = self.pyramid
         grads = [torch.empty((py.rows, h, w, 256) if self.channels_last else (py.rows, 256, h, w), device=py.device, dtype=torch.float32)
                  for h, w in py.level_hw]
-        self._fork()                                 # the table rows were written on the main stream
-        with torch.cuda.stream(self.side):
+        self._fork(self.side_bwd)                    # the table rows were written on the main stream
+        with torch.cuda.stream(self.side_bwd):
             grads = self.sink.reduce(grads, channels_last=self.channels_last)
-        if self.side is not self.main:
-            self.sink.table.record_stream(self.side)
+        if self.side_bwd is not self.main:
+            self.sink.table.record_stream(self.side_bwd)
         self.grads = grads
 
     def dpart(self, nbytes):
@@ -188,12 +196,28 @@ class PyramidSourceFunction(torch.autograd.Function):
             raw.channels_last = True
             sp = feats[0]
         else:
-            sp, hw = ops.pyramid_slice_planar_fwd([f.contiguous() for f in feats], out_dtype=raw.copy_dtype)
+            src = [f.contiguous() for f in feats]
+            if os.environ.get('GD4D_TRAIN_COPY_SIDE', '0') == '1':
+                # dev switch: the copy beside layer 0's query side (nothing reads it before the first gather: raw.wait_copy())
+                main = torch.cuda.current_stream(feats[0].device)
+                side = Fn._companion_stream(Fn._SIDE_STREAMS, feats[0].device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    sp, hw = ops.pyramid_slice_planar_fwd(src, out_dtype=raw.copy_dtype)
+                raw.copy_event = torch.cuda.Event()
+                raw.copy_event.record(side)
+                sp.record_stream(main)
+                for f in src:
+                    f.record_stream(side)
+            else:
+                sp, hw = ops.pyramid_slice_planar_fwd(src, out_dtype=raw.copy_dtype)
             raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
         raw.shapes = [tuple(f.shape) for f in feats]
         raw.needs_grad = any(ctx.needs_input_grad[1:])
         raw.main = torch.cuda.current_stream(sp.device)
-        raw.side = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if os.environ.get('GD4D_TRAIN_SIDE', '0') == '1' else raw.main
+        mode = os.environ.get('GD4D_TRAIN_SIDE', '0')        # '1': counts, scan / fill / sort and the reduction beside the main stream; 'count': the counts only
+        raw.side = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if mode in ('1', 'count') else raw.main
+        raw.side_bwd = raw.side if mode == '1' else raw.main
         ctx.raw = raw
         ctx.set_materialize_grads(False)
         return torch.empty(1, device=feats[0].device, dtype=torch.float32)
@@ -231,6 +255,7 @@ class CrossAttnRawFunction(torch.autograd.Function):
         ctx.layer = raw.register(plan.q)
         if ctx.needs_input_grad[0]:
             raw.count(ctx.layer, plan)
+        raw.wait_copy()
         agg = ops.cross_attn_agg_sliced_fwd(plan)
         vp_weight = vp_weight.contiguous()
         out = ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, None if vp_bias is None else vp_bias.contiguous())
@@ -352,11 +377,36 @@ _MAX_TASKS = 4
 _DEFERRED = {}                # task id -> {'w': [...], 'ln': [...]}
 
 
+_WGRAD_SIDE = {}                # device index -> [side stream, work outstanding]
+
+
 def _issue(kind, entries):
     if kind == 'w':
+        if os.environ.get('GD4D_TRAIN_WGRAD_SIDE', '0') == '1' and entries:
+            # dev switch: the grouped weight-gradient launches (nothing reads their results before the optimizer) beside the main
+            # stream; the pass's last flush joins (_flush_deferred)
+            from . import functional as Fn
+            dev = entries[0][0].device
+            main = torch.cuda.current_stream(dev)
+            side = Fn._companion_stream(Fn._SIDE_STREAMS, dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.linear_bwd_weight_group(entries, accumulate=True)
+            for x, gy, _, _ in entries:
+                x.record_stream(side)
+                gy.record_stream(side)
+            _WGRAD_SIDE[dev.index] = [side, True]
+            return
         ops.linear_bwd_weight_group(entries, accumulate=True)
     else:
         ops.layernorm_bwd_reduce_group(entries, accumulate=True)
+
+
+def _join_wgrad_side():
+    for idx, st in _WGRAD_SIDE.items():
+        if st[1]:
+            torch.cuda.current_stream(idx).wait_stream(st[0])
+            st[1] = False
 
 
 def _flush_deferred(task=None):
@@ -369,6 +419,7 @@ def _flush_deferred(task=None):
             q = queues[kind]
             for i in range(0, len(q), group):
                 _issue(kind, q[i:i + group])
+    _join_wgrad_side()
 
 
 def _deferring():
