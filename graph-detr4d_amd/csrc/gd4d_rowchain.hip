@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void chain_weight_image_group_kernel(const gd4
 // EXACT (GD4D_CHAIN_EXACT): both operands cut into THREE bf16 pieces and the six products of combined order <= 2 summed
 // (x y ~= sum_{i + j <= 2} x_i y_j, ~2^-24 relative: fp32-class), for the GEMMs whose outputs become reference points -
 // a point's error is multiplied by the 102-m range and the focal length before it selects pixels.
-template <bool EXACT>
+template <bool EXACT, bool TRAIN>
 __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   constexpr int FRAG = EXACT ? 3072 : 2048;
   const int i16 = lane & 15, g = lane >> 4;
@@ -226,12 +226,12 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   // GD4D_CHAIN_MASK_P2: p2 is not an addend but the OUTPUT a ReLU produced in the forward pass - the result (the gradient at that
   // ReLU's output) passes where it was > 0, times `eps` when that is non-zero (the 1 / (1 - p) of a dropout that followed the ReLU
   // and left its zeros in p2 as well)
-  const bool mask_p2 = (op.flags & GD4D_CHAIN_MASK_P2) != 0;
+  const bool mask_p2 = TRAIN && (op.flags & GD4D_CHAIN_MASK_P2) != 0;      // (TRAIN: the training operations live in their own instantiation of the kernel - the inference step's chains ran 10 % slower with them compiled in)
   const float mask_scale = op.eps != 0.f ? op.eps : 1.f;
   // GD4D_CHAIN_DROPOUT (a training step with the modules in train mode): the output - after bias / activation, before the
   // residuals - is dropped like nn.Dropout does: kept elements times eps = 1 / (1 - p).  Which elements: csrc/gd4d_mha_dropout.h's
   // hash of (the 64-bit seed at p3, m N + n) against the threshold in `reserved` - a backward chain regenerates it (DROPMASK).
-  const bool drop = (op.flags & GD4D_CHAIN_DROPOUT) != 0;
+  const bool drop = TRAIN && (op.flags & GD4D_CHAIN_DROPOUT) != 0;
   const uint32_t drop_lo = drop ? reinterpret_cast<const uint32_t*>(op.p3)[0] : 0u;
   const uint32_t drop_hi = drop ? reinterpret_cast<const uint32_t*>(op.p3)[1] : 0u;
   for (int n_base = RC_COLS * wave; n_base < N; n_base += RC_COLS * RC_WAVES) {
@@ -605,7 +605,7 @@ __device__ __forceinline__ void rc_layernorm_bwd(const ChainOp& op, float (*bufs
 // Rows of global tensors into / onto an LDS buffer, float4 per lane, every load issued before the first use:
 //   LOAD: dst[:, dst_col + n] = f(p0[m, n]) (+ p1[m, n]);   ADD: dst[:, n] = src[:, n] (+ res[:, n]) (+ p2[m, n])
 // wave w handles RC_ROWS_PER_WAVE consecutive rows; N % 4 == 0, N <= 512 (two 256-column chunks per row).
-template <bool IS_ADD>
+template <bool IS_ADD, bool TRAIN>
 __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][RC_LD], int m0, int M, int lane, int wave) {
   const int N = op.N;
   const float* ga = IS_ADD ? op.p2 : op.p0;                  // first global operand (may be null for ADD)
@@ -643,7 +643,7 @@ __device__ __forceinline__ void rc_rows(const ChainOp& op, float (*bufs)[RC_M][R
       *reinterpret_cast<float4*>(&bufs[op.dst][row][(IS_ADD ? 0 : op.dst_col) + n]) = v;
       // gout: the rows also leave for global memory (a training step keeps x + query_pos, the input of the projections that
       // follow, for their weight gradients; a backward chain's running sums)
-      if (op.gout && m0 + row < M) *reinterpret_cast<float4*>(op.gout + (size_t)(m0 + row) * op.ldg + n) = v;
+      if (TRAIN && op.gout && m0 + row < M) *reinterpret_cast<float4*>(op.gout + (size_t)(m0 + row) * op.ldg + n) = v;
     }
   }
 }
@@ -656,6 +656,7 @@ struct ChainProgram {
   ChainOp ops[GD4D_CHAIN_MAX_OPS];   // ops[nops, nops + nops2) over the SAME rows (gd4d_row_chain2_fwd); split = blocks up to a multiple of 8
 };
 
+template <bool TRAIN>
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainProgram by_value) {
   typedef const __attribute__((address_space(4))) ChainProgram* kernarg_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
     const ChainOp op = pp->ops[oi];                        // uniform: scalar loads
     switch (op.kind) {
       case GD4D_CHAIN_LOAD: {                              // dst[:, :N] = f(p0[m, :N]) (+ p1[m, :N])
-        if ((op.N & 3) == 0 && (op.dst_col & 3) == 0) { rc_rows<false>(op, bufs, m0, M, lane, wave); break; }
+        if ((op.N & 3) == 0 && (op.dst_col & 3) == 0) { rc_rows<false, TRAIN>(op, bufs, m0, M, lane, wave); break; }
         for (int e = tid; e < RC_M * op.N; e += 64 * RC_WAVES) {      // a handful of columns (reference points)
           const int row = e / op.N, n = e - row * op.N;
           const int m = min(m0 + row, M - 1);
@@ -780,13 +781,14 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
         break;
       }
       case GD4D_CHAIN_GEMM:
-        if (op.flags & GD4D_CHAIN_EXACT) rc_gemm<true>(op, bufs, m0, M, lane, wave);
-        else rc_gemm<false>(op, bufs, m0, M, lane, wave);
+        if (op.flags & GD4D_CHAIN_EXACT) rc_gemm<true, TRAIN>(op, bufs, m0, M, lane, wave);
+        else rc_gemm<false, TRAIN>(op, bufs, m0, M, lane, wave);
         break;
       case GD4D_CHAIN_HEADGEMM: rc_headgemm(op, bufs, m0, M, lane, wave); break;
       case GD4D_CHAIN_LAYERNORM: rc_layernorm(op, bufs, m0, M, lane, wave); break;
-      case GD4D_CHAIN_ADD: rc_rows<true>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
+      case GD4D_CHAIN_ADD: rc_rows<true, TRAIN>(op, bufs, m0, M, lane, wave); break;   // dst = src + (res buffer) + (p2 global)
       case GD4D_CHAIN_DROPMASK: {                         // buf[dst] = nn.Dropout's mask of a forward GEMM applied to buf[src]
+        if (!TRAIN) break;
         const uint32_t lo = reinterpret_cast<const uint32_t*>(op.p0)[0], hi = reinterpret_cast<const uint32_t*>(op.p0)[1];
         const int nv = op.N / 4;
         for (int e = tid; e < RC_M * nv; e += 64 * RC_WAVES) {
@@ -803,7 +805,8 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
         break;
       }
       case GD4D_CHAIN_LN_BWD:
-        rc_layernorm_bwd(op, bufs, reinterpret_cast<float*>(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES), m0, M, wg, tid);
+        if (TRAIN)
+          rc_layernorm_bwd(op, bufs, reinterpret_cast<float*>(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES), m0, M, wg, tid);
         break;
       case GD4D_CHAIN_SMALL_LINEAR: {                      // K <= 8 inputs (position_encoder's first Linear): plain FMAs
         // The first version evaluated inverse_sigmoid (a division and a logarithm) for every (row, output, input) and
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
               if (k < K) v = fmaf(bufs[op.src][row][col0 + k], w[k], v);
             if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
             bufs[op.dst][row][n] = v;
-            if (op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
+            if (TRAIN && op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
           }
         } else {
           for (int e = tid; e < RC_M * N; e += 64 * RC_WAVES) {
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
             for (int k = 0; k < K; ++k) v = fmaf(bufs[op.src][row][col0 + k], op.p0[(size_t)n * K + k], v);
             if (op.flags & GD4D_CHAIN_RELU) v = fmaxf(v, 0.f);
             bufs[op.dst][row][n] = v;
-            if (op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
+            if (TRAIN && op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
           }
         }
         break;
@@ -1039,16 +1042,31 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   if (int rc = rc_validate(a, na, nb > 0 ? 1 : 0)) return rc;
   if (nb > 0)
     if (int rc = rc_validate(b, nb, 2)) return rc;
-  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES + sizeof(float) * 8 * RC_W;   // row buffers + the prefetch dump area + LN_BWD's partial sums
-  if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_kernel), (int)lds)) return GD4D_ELAUNCH;
+  // the operations only a training step uses (and the stores of LOAD / ADD / SMALL_LINEAR) are compiled into a second
+  // instantiation: with them in, the inference step's chains ran 10 % slower (221 against 163 registers, longer epilogues)
+  bool train = false;
+  for (int w = 0; w < 2; ++w) {
+    const gd4d_chain_op* pr = w ? b : a;
+    for (int i = 0; i < (w ? nb : na); ++i) {
+      const gd4d_chain_op& op = pr[i];
+      train = train || op.kind == GD4D_CHAIN_LN_BWD || op.kind == GD4D_CHAIN_DROPMASK ||
+              (op.kind == GD4D_CHAIN_GEMM && (op.flags & (GD4D_CHAIN_MASK_P2 | GD4D_CHAIN_DROPOUT))) ||
+              ((op.kind == GD4D_CHAIN_LOAD || op.kind == GD4D_CHAIN_ADD || op.kind == GD4D_CHAIN_SMALL_LINEAR) && op.gout);
+    }
+  }
+  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES + (train ? sizeof(float) * 8 * RC_W : 0);   // row buffers + the prefetch dump area (+ LN_BWD's partial sums)
+  const void* kern = train ? reinterpret_cast<const void*>(row_chain_kernel<true>) : reinterpret_cast<const void*>(row_chain_kernel<false>);
+  if (!allow_dynamic_lds(kern, (int)lds)) return GD4D_ELAUNCH;
   const int blocks = (M + RC_M - 1) / RC_M;
   ChainProgram prog{};
   const int split = nb > 0 ? (blocks + 7) & ~7 : 0;      // second program: same XCD per row block (see the kernel)
   prog.nops = na; prog.M = M; prog.nops2 = nb; prog.split = split;
   for (int i = 0; i < na; ++i) prog.ops[i] = a[i];
   for (int i = 0; i < nb; ++i) prog.ops[na + i] = b[i];
-  hipLaunchKernelGGL(row_chain_kernel, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream),
-                     prog);
+  if (train)
+    hipLaunchKernelGGL(row_chain_kernel<true>, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog);
+  else
+    hipLaunchKernelGGL(row_chain_kernel<false>, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog);
   return check_launch();
 }
 
