@@ -73,3 +73,39 @@ def test_forward_fails_loudly_without_gpu_and_with_residual():
     with pytest.raises(KeyError):
         with torch.no_grad():
             m(q, None, feats, None, query_pos=q, reference_points=torch.rand(1, 5, 3))   # img_metas mandatory
+
+
+def test_chain_training_path_host_logic():
+    """What graph_detr4d_amd/fused_train.py decides on the host, no GPU needed: the parameter order it hands autograd, where a
+    layer's dropouts sit (mmcv's MultiheadAttention / FFN and Deform3DCrossAttn, config ...ceph.py:71-89), when the path refuses
+    (CPU tensors, two dropouts in a row that are not one Bernoulli mask), and the dropout threshold / scale the chain operations
+    take (csrc/gd4d_mha_dropout.h)."""
+    from graph_detr4d_amd import fused_train, ops
+    dec = G.build_transformer_layer_sequence(_decoder_cfg(dict(type='Deform3DCrossAttn', num_cams=6, pc_range=PC, num_points=4,
+                                                               embed_dims=256, dropout=0.1)))
+    layer = dec.layers[0]
+    prm = fused_train._layer_params(layer)
+    assert len(prm) == fused_train.PER_LAYER == len(fused_train.NAMES) == 32
+    named = dict(layer.named_parameters())
+    assert prm[0] is named['attentions.0.attn.in_proj_weight'] and prm[fused_train.NAMES.index('f1_b')] is named['ffns.0.layers.1.bias']
+    assert {id(p) for p in prm} == {id(p) for p in named.values()}           # every parameter of the layer, once
+    layer.eval()
+    assert fused_train._dropouts(layer) == (0., 0., 0., 0., 0.)
+    layer.train()
+    assert fused_train._dropouts(layer) == pytest.approx((0.1, 0.1, 0.1, 0.1, 0.1))
+    layer.attentions[0].proj_drop.p = 0.2                                     # proj_drop AND dropout_layer: two masks in a row
+    assert fused_train._dropouts(layer) is None
+    layer.attentions[0].proj_drop.p = 0.
+    q = torch.zeros(5, 1, 256)
+    assert not fused_train.applicable(dec, q, q, [torch.zeros(1, 6, 256, 4, 4)] * 4, torch.zeros(1, 5, 3), None, None,
+                                      {id(layer.attentions[1]): (None, None, None, (object(), object()))}, (), dict(img_metas=[]))
+    thresh, scale = ops.chain_dropout_args(0.1)
+    assert thresh == round(0.1 * 2 ** 32) and scale == pytest.approx(1 / 0.9)
+    assert ops.chain_dropout_args(0.)[0] == 0
+    # the fragment arithmetic of the grouped image builder (include/gd4d.h: gd4d_image_job)
+    assert ops.ImageJob.seg.size == 24 and ctypes_sizeof(ops.ImageJob) == 64
+
+
+def ctypes_sizeof(t):
+    import ctypes
+    return ctypes.sizeof(t)
