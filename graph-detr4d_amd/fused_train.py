@@ -25,6 +25,7 @@ BaseTransformerLayer / MultiheadAttention / FFN (config ...ceph.py:71-89); what 
 GD4D_TRAIN_CHAINS=0 keeps the generic path.
 """
 import os
+import weakref
 
 import torch
 
@@ -159,13 +160,17 @@ def _sources(decoder, reg_branches):
     return tuple(out)
 
 
+_IMAGE_SETS = weakref.WeakKeyDictionary()      # decoder -> (key, _Images): NOT an attribute of the module (a deepcopy / pickle of the
+#                                                 model - EMA hooks, torch.save(model) - must not meet raw device pointers)
+
+
 def _images(decoder, reg_branches, device):
-    st = getattr(decoder, '_gd4d_train_images', None)
+    st = _IMAGE_SETS.get(decoder)
     key = (None if reg_branches is None else id(reg_branches), str(device))
     if st is not None and st[0] == key and _sources(decoder, reg_branches) == st[1].signature:
         return st[1]                                   # the parameters still live where the job table points
     imgs = _Images(decoder, reg_branches, device)
-    decoder.__dict__['_gd4d_train_images'] = (key, imgs)
+    _IMAGE_SETS[decoder] = (key, imgs)
     return imgs
 
 

@@ -282,3 +282,22 @@ def test_image_set_equals_single_images_and_survives_weight_updates():
     ops.invalidate_chain_images()
     check()
     assert ptrs == [i.img.data_ptr() for i in (i_stack, i_stack_t, i_qk_t, i_v_t, i_exact)]
+
+
+def test_model_can_be_copied_and_saved_after_a_chain_training_step(monkeypatch, tmp_path):
+    """The images of a decoder's weights (raw device pointers in a job table) are kept beside the module, not in it: an EMA
+    hook's deepcopy and torch.save(model) after a training step work, and the copy trains on its own images."""
+    import copy
+    monkeypatch.setenv('GD4D_TRAIN_CHAINS', '1')
+    g = Golden('decoder_deform')
+    tr = _transformer(g)
+    a = _run(tr, g, None, True, monkeypatch)
+    twin = copy.deepcopy(tr)
+    torch.save(tr, tmp_path / 'model.pt')
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.mul_(1.01)
+    b = _run(twin, g, None, True, monkeypatch)
+    c = _run(tr, g, None, True, monkeypatch)
+    assert (b['states'] - a['states']).abs().max() > 1e-4              # the copy read ITS weights
+    torch.testing.assert_close(c['states'], a['states'], rtol=0, atol=0)  # ... and the original still its own
