@@ -290,7 +290,11 @@ def _watch_weight_updates(module):
     """The fused decoder loop caches MFMA-fragment images of its GEMM weights (ops.chain_weight_image), keyed on the
     tensors' version counters.  Writes through `.data` (checkpoint loaders, mmcv's EMA hook) do not bump those: forget
     the images whenever a state dict is loaded; train() / eval() do the same (below)."""
-    module.register_load_state_dict_post_hook(lambda m, incompatible: ops.invalidate_chain_images())
+    module.register_load_state_dict_post_hook(_forget_chain_images)     # (a module-level function: torch.save(model) pickles hooks)
+
+
+def _forget_chain_images(module, incompatible_keys):
+    ops.invalidate_chain_images()
 
 
 @TRANSFORMER_LAYER_SEQUENCE.register_module()
