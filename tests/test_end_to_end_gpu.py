@@ -16,11 +16,20 @@ pytestmark = pytest.mark.gpu
 POST_RANGE = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
 
 
-def test_features_to_boxes_matches_oracle_pipeline():
+@pytest.mark.parametrize('case', ['small', 'mid'])
+def test_features_to_boxes_matches_oracle_pipeline(case):
+    """small: 60 queries x 6 cameras x 2 layers - everything must agree element for element.  mid: 300 queries x 12 cameras
+    (two frames) x 3 layers on 256 x 448 images - large enough that a sample or two sits within rounding of a visibility
+    boundary (the two sides compute the offsets with different GEMM arithmetic): the decoder states are compared row by row
+    with a counted number of outliers, the decoded detections as sets."""
     torch.manual_seed(7)
-    n, q, nl = 6, 60, 2
-    img_hw, levels = (128, 224), [(16, 28), (8, 14), (4, 7), (2, 4)]
-    rig = synthetic.camera_rig(1, img_hw)
+    if case == 'small':
+        n, q, nl, frames = 6, 60, 2, 1
+        img_hw, levels = (128, 224), [(16, 28), (8, 14), (4, 7), (2, 4)]
+    else:
+        n, q, nl, frames = 12, 300, 3, 2
+        img_hw, levels = (256, 448), [(32, 56), (16, 28), (8, 14), (4, 7)]
+    rig = synthetic.camera_rig(frames, img_hw)
     metas = synthetic.make_img_metas(rig, img_shape=(img_hw[0], img_hw[1], 3), pad_shape=(img_hw[0], img_hw[1], 3))
     g = torch.Generator().manual_seed(3)
     feats = [torch.randn(1, n, 256, h, w, generator=g) for h, w in levels]
@@ -80,16 +89,24 @@ def test_features_to_boxes_matches_oracle_pipeline():
 
     for a, b in zip(gfeats, ofeats):
         torch.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-4)
-    torch.testing.assert_close(gstates.cpu(), states, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(outs['all_cls_scores'].cpu(), exp_cls, rtol=2e-3, atol=2e-3)
-    torch.testing.assert_close(outs['all_bbox_preds'].cpu(), exp_box, rtol=2e-3, atol=2e-3)
+    if case == 'small':
+        torch.testing.assert_close(gstates.cpu(), states, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(outs['all_cls_scores'].cpu(), exp_cls, rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(outs['all_bbox_preds'].cpu(), exp_box, rtol=2e-3, atol=2e-3)
+    else:
+        row_err = (gstates.cpu() - states).abs().amax(dim=(2, 3))            # (layers, queries)
+        assert (row_err[0] > 1e-3).sum().item() <= 2 and (row_err > 2e-3).float().mean().item() <= 0.03, \
+            ((row_err[0] > 1e-3).sum().item(), (row_err > 2e-3).float().mean().item())
+        assert row_err.median().item() < 2e-4
     # decoded detections: same count, scores agree rank by rank; as sets (near-ties may swap ranks, and the last few of the
     # top-k may differ) every detection has a partner with the same label, score and box
     assert got['scores'].shape == exp['scores'].shape and got['scores'].numel() > 10
     gs, es = got['scores'].cpu(), exp['scores']
-    torch.testing.assert_close(gs, es, rtol=0, atol=2e-3)
+    if case == 'small':
+        torch.testing.assert_close(gs, es, rtol=0, atol=2e-3)
     gb, gl = got['bboxes'].cpu(), got['labels'].cpu()
     same = (gl[:, None] == exp['labels'][None]) & ((gs[:, None] - es[None]).abs() < 2e-3) & \
         ((gb[:, None] - exp['bboxes'][None]).abs().amax(-1) < 5e-3)
-    assert same.any(1).float().mean().item() >= 0.97
-    assert same.any(0).float().mean().item() >= 0.97
+    need = 0.97 if case == 'small' else 0.93
+    assert same.any(1).float().mean().item() >= need
+    assert same.any(0).float().mean().item() >= need
