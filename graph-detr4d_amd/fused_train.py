@@ -73,6 +73,10 @@ def applicable(decoder, query, query_pos, value, reference_points, reg_branches,
     c = query.shape[-1]
     if c != 256 or not isinstance(value, (list, tuple)) or value[0].shape[0] != 1:
         return False
+    if isinstance(attn_masks, (list, tuple)):           # [self-attention mask, cross-attention mask]: Deform3DCrossAttn takes none
+        if len(attn_masks) != 2:
+            return False
+        attn_masks = attn_masks[0]
     if attn_masks is not None and not (torch.is_tensor(attn_masks) and attn_masks.dim() == 2):
         return False
     for layer in decoder.layers:
@@ -484,6 +488,8 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
     layers = list(decoder.layers)
     ca0 = layers[0].attentions[1]
     raw, token = raw_entry[id(ca0)][3]
+    if isinstance(attn_masks, (list, tuple)):
+        attn_masks = attn_masks[0]
     img_h, img_w = Fn.img_hw(img_metas)
     meta = _Meta(decoder=decoder, raw=raw, reg_branches=reg_branches, lidar2img=Fn.lidar2img_device(img_metas, query),
                  img_h=img_h, img_w=img_w, attn_mask=attn_masks)

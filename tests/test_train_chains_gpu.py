@@ -38,7 +38,7 @@ def _reg_branches(nl, seed=5):
                          for _ in range(nl)).to(DEV)
 
 
-def _run(tr, g, reg, chains, monkeypatch, fuse=False, probe_seed=3):
+def _run(tr, g, reg, chains, monkeypatch, fuse=False, probe_seed=3, **kw):
     from graph_detr4d_amd import dist as D, fused_train
     monkeypatch.setenv('GD4D_TRAIN_CHAINS', '1' if chains else '0')
     calls = []
@@ -54,7 +54,7 @@ def _run(tr, g, reg, chains, monkeypatch, fuse=False, probe_seed=3):
         red = D.FlatGradAllReducer(params)
         red.bind(fuse_weight_grads=True)
         red.zero_grad()
-    states, init_ref, inter_refs = tr(feats, qe, reg_branches=reg, img_metas=g.img_metas())
+    states, init_ref, inter_refs = tr(feats, qe, reg_branches=reg, img_metas=g.img_metas(), **kw)
     gen = torch.Generator().manual_seed(probe_seed)
     probe = torch.randn(states.shape, generator=gen).to(DEV)
     ((states * probe).sum() + (init_ref ** 2).sum()).backward()
@@ -301,3 +301,22 @@ def test_model_can_be_copied_and_saved_after_a_chain_training_step(monkeypatch, 
     c = _run(tr, g, None, True, monkeypatch)
     assert (b['states'] - a['states']).abs().max() > 1e-4              # the copy read ITS weights
     torch.testing.assert_close(c['states'], a['states'], rtol=0, atol=0)  # ... and the original still its own
+
+
+@pytest.mark.parametrize('form', ['bool', 'float', 'list'])
+def test_chain_training_step_with_a_self_attention_mask(form, monkeypatch):
+    """H-DETR's decoder_self_attn_mask (h_detr3d_transformer.py:129-167: query groups must not see each other) in training: a
+    (Q, Q) bool or additive float mask, or mmcv's [self-attention mask, cross-attention mask] list."""
+    g = Golden('decoder_deform')
+    tr = _transformer(g)
+    q = g.meta['num_query']
+    m = torch.zeros(q, q, dtype=torch.bool)
+    m[: q // 2, q // 2:] = True
+    m[q // 2:, : q // 2] = True
+    m = m.to(DEV)
+    mask = m if form == 'bool' else torch.zeros(q, q, device=DEV).masked_fill(m, -1e4) if form == 'float' else [m, None]
+    a = _run(tr, g, None, True, monkeypatch, attn_masks=mask)
+    b = _run(tr, g, None, False, monkeypatch, attn_masks=mask)
+    _compare(a, b)
+    c_ = _run(tr, g, None, True, monkeypatch)
+    assert (c_['states'] - a['states']).abs().max() > 1e-3          # the mask matters
