@@ -1610,12 +1610,16 @@ class ImageSet:
     def signature(self):
         return tuple(t.data_ptr() for t in self.sources)
 
-    def refresh(self):
-        lib = _lib.load()
+    def finalize(self):
+        """Upload the job table (a host-to-device copy: call it outside a graph capture; refresh() does it on first use)."""
         if self._table is None:
             arr = (ImageJob * len(self._jobs))(*self._jobs)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._table = raw.to(self.device)
+
+    def refresh(self):
+        lib = _lib.load()
+        self.finalize()
         with torch.cuda.device(self.device):
             code = lib.gd4d_chain_weight_image_group(ctypes.c_void_p(self._table.data_ptr()), len(self._jobs), self._frags, _stream())
         _lib.check(code, 'gd4d_chain_weight_image_group')
