@@ -285,6 +285,7 @@ class DecoderTrainFunction(torch.autograd.Function):
             x, ref = x3, new_ref
         raw.join()
         ctx.meta, ctx.saved, ctx.params, ctx.imgs = meta, saved, params, imgs
+        ctx.versions = [p_._version for p_ in params]        # the backward chains read the images of THESE weights (and their transposes)
         ctx.pos = pos
         ctx.set_materialize_grads(False)
         if not dec.return_intermediate:
@@ -300,6 +301,10 @@ class DecoderTrainFunction(torch.autograd.Function):
             raise RuntimeError('graph-detr4d_amd: the chain training path keeps its activations for ONE backward pass '
                                '(retain_graph is not supported; GD4D_TRAIN_CHAINS=0 selects the generic path)')
         ctx.saved = None
+        if [p_._version for p_ in params] != ctx.versions:
+            raise RuntimeError('graph-detr4d_amd: a decoder parameter was modified in place between the forward and the backward pass '
+                               '(the backward chains use the weight images the forward pass built) - as autograd itself refuses '
+                               'a saved tensor that was modified in place')
         dec, raw = meta.decoder, meta.raw
         layers = list(dec.layers)
         nl = len(layers)

@@ -320,3 +320,17 @@ def test_chain_training_step_with_a_self_attention_mask(form, monkeypatch):
     _compare(a, b)
     c_ = _run(tr, g, None, True, monkeypatch)
     assert (c_['states'] - a['states']).abs().max() > 1e-3          # the mask matters
+
+
+def test_backward_after_an_in_place_weight_update_is_refused(monkeypatch):
+    """The backward chains read the images (W and W^T) the forward pass built: an optimizer step between the two is refused,
+    as autograd refuses a saved tensor that was modified in place."""
+    monkeypatch.setenv('GD4D_TRAIN_CHAINS', '1')
+    g = Golden('decoder_deform')
+    tr = _transformer(g)
+    feats = [f.to(DEV).requires_grad_() for f in g.feats()]
+    states, _, _ = tr(feats, g.t('query_embed').to(DEV), reg_branches=None, img_metas=g.img_metas())
+    with torch.no_grad():
+        tr.decoder.layers[0].ffns[0].layers[1].weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        states.sum().backward()
