@@ -529,3 +529,32 @@ def test_detr3d_cross_atten_v2_trains(name, route, monkeypatch):
         assert prm.grad is not None, k
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
     assert len(calls) == (1 if route == 'hip' else 0)
+
+
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_grouped_weight_gradients_match_fp64(accumulate):
+    """gd4d_linear_bwd_weight_group on one call with the shapes a training step queues (256 / 512-wide Linears, the narrow camera /
+    offset / position_encoder / branch layers, the packed in-projection), 900 and 37 rows, against fp64; accumulate adds to what
+    the targets hold; the same bits on a second call."""
+    from graph_detr4d_amd import ops
+    gen = torch.Generator().manual_seed(17)
+    shapes = [(900, 256, 256), (900, 256, 512), (900, 512, 256), (900, 256, 24), (900, 256, 96), (900, 3, 256), (37, 256, 128),
+              (900, 256, 10), (900, 256, 768)]                       # (rows, inputs K, outputs N)
+    probs, want = [], []
+    for m, k, n in shapes:
+        x, gy = torch.randn(m, k, generator=gen).to(DEV), torch.randn(m, n, generator=gen).to(DEV)
+        gw0, gb0 = torch.randn(n, k, generator=gen).to(DEV), torch.randn(n, generator=gen).to(DEV)
+        probs.append((x, gy, gw0.clone(), gb0.clone()))
+        base_w, base_b = (gw0.double(), gb0.double()) if accumulate else (0, 0)
+        want.append((gy.double().t() @ x.double() + base_w, gy.double().sum(0) + base_b,
+                     (gy.double().abs().t() @ x.double().abs()).max().item()))
+    ops.linear_bwd_weight_group(probs, accumulate=accumulate)
+    for (x, gy, gw, gb), (ww, wb, scale) in zip(probs, want):
+        assert (gw.double() - ww).abs().max().item() < 1.5e-5 * scale + 1e-5, (tuple(x.shape), tuple(gy.shape))
+        torch.testing.assert_close(gb.double(), wb, rtol=1e-5, atol=2e-4)
+    again = [(x, gy, torch.zeros_like(gw), torch.zeros_like(gb)) for x, gy, gw, gb in probs]
+    once = [(x, gy, torch.zeros_like(gw), torch.zeros_like(gb)) for x, gy, gw, gb in probs]
+    ops.linear_bwd_weight_group(again, accumulate=False)
+    ops.linear_bwd_weight_group(once, accumulate=False)
+    for a, b in zip(again, once):
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
