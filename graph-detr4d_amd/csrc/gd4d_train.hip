@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
         else val += static_cast<const float*>(p.mask)[mi];
       }
       const float lse = SIDE == 0 ? c_lse : cur.lse[r], dsum = SIDE == 0 ? c_dsum : cur.dsum[r];
-      const float pv = dead ? 0.f : expf(val - lse);
+      const float pv = dead ? 0.f : __builtin_amdgcn_exp2f((val - lse) * 1.4426950408889634f);   // one v_exp_f32 (as the forward kernels), not expf's range reduction
       float mk = 1.f;
       if (DROP) {
         const uint32_t id = drop_base + (uint32_t)min(qi, p.Lq - 1) * (uint32_t)p.Lk + (uint32_t)min(ki, p.Lk - 1);

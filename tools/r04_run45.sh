@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+o=gpurun_out/r04_run45; mkdir -p $o
+timeout 900 python3 -m pytest tests/test_dense_gpu.py tests/test_training_gpu.py tests/test_train_chains_gpu.py -x -q -m gpu -p no:cacheprovider > $o/tests.log 2>&1; echo "tests rc=$? $(tail -1 $o/tests.log)"; grep -n "^E " $o/tests.log | head -5
+python3 tools/bench_train_small.py 2>&1 | tail -4
+for rep in 1 2 3; do
+python3 bench.py --mode train --steps 30 --warmup 3 --no-roofline --dropout > $o/new_$rep.json 2> $o/new_$rep.err; echo "new $(tail -1 $o/new_$rep.json | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')"
+done
