@@ -591,12 +591,10 @@ __global__ __launch_bounds__(256) void pyramid_grad_count_kernel(const int* __re
     gint* a0 = (gint*)(count + m[0].key); gint* a1 = (gint*)(count + m[1].key);
     gint* a2 = (gint*)(count + m[2].key); gint* a3 = (gint*)(count + m[3].key);
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
-#ifndef PG_COUNT_WHATIF_NOATOMIC   // dev what-if (timing only): no atomics - is the kernel bound by them or by its matching loops?
     if (m[0].valid && m[0].leader == lane) b0 = __hip_atomic_fetch_add(a0, m[0].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (m[1].valid && m[1].leader == lane) b1 = __hip_atomic_fetch_add(a1, m[1].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (m[2].valid && m[2].leader == lane) b2 = __hip_atomic_fetch_add(a2, m[2].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (m[3].valid && m[3].leader == lane) b3 = __hip_atomic_fetch_add(a3, m[3].n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
     const int b[NP] = {b0, b1, b2, b3};
 #pragma unroll
     for (int i = 0; i < NP; ++i) finish(t + i, m[i], b[i]);

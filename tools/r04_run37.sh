@@ -1,5 +1,6 @@
 #!/bin/bash
-# what-if: the record-count kernel without its atomics / without its matching loop
+# what-if: the record-count kernel without its atomics (the #ifndef PG_COUNT_WHATIF_NOATOMIC around the four atomics of
+# pyramid_grad_count_kernel that this script compiled against was removed again: the PMC records are keyed to the source's hash)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p /tmp/v; cp graph-detr4d_amd/libgd4d.so /tmp/v/base.so
 touch graph-detr4d_amd/csrc/gd4d_cross_attn_sliced_bwd.hip
