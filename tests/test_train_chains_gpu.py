@@ -334,3 +334,34 @@ def test_backward_after_an_in_place_weight_update_is_refused(monkeypatch):
         tr.decoder.layers[0].ffns[0].layers[1].weight.mul_(1.5)
     with pytest.raises(RuntimeError, match='modified in place'):
         states.sum().backward()
+
+
+def test_side_stream_dev_switches_give_the_same_step(monkeypatch):
+    """GD4D_TRAIN_SIDE=count / GD4D_TRAIN_WGRAD_SIDE / GD4D_TRAIN_COPY_SIDE (measured slower inside a replayed hipGraph, kept as dev
+    switches): the same outputs and parameter gradients as the one-stream schedule bit for bit, the pyramid's gradient within rounding, with the
+    flat-buffer gradient path on."""
+    from graph_detr4d_amd import dist as D
+    g = Golden('decoder_deform')
+    tr = _transformer(g)
+    params = [p for p in tr.parameters() if p.requires_grad]
+
+    def step():
+        red = D.FlatGradAllReducer(params)
+        red.bind(fuse_weight_grads=True)
+        red.zero_grad()
+        feats = [f.to(DEV).clone().requires_grad_() for f in g.feats()]
+        states, _, _ = tr(feats, g.t('query_embed').to(DEV), reg_branches=None, img_metas=g.img_metas())
+        (states ** 2).mean().backward()
+        torch.cuda.synchronize()
+        out = (states.detach().clone(), red.flat.clone(), [f.grad.clone() for f in feats])
+        red.unfuse()
+        return out
+    monkeypatch.setenv('GD4D_TRAIN_CHAINS', '1')
+    base = step()
+    monkeypatch.setenv('GD4D_TRAIN_SIDE', 'count')
+    monkeypatch.setenv('GD4D_TRAIN_WGRAD_SIDE', '1')
+    monkeypatch.setenv('GD4D_TRAIN_COPY_SIDE', '1')
+    side = step()
+    assert torch.equal(base[0], side[0]) and torch.equal(base[1], side[1])
+    for a, b in zip(base[2], side[2]):          # (the records of a pixel are summed in slot order, and slots are handed out by atomics)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
