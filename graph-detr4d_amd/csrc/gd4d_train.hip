@@ -223,6 +223,34 @@ __device__ __forceinline__ t4 tb_tile(const float* rowv, const float* colv) {
   return s;
 }
 
+// The same tile on the 32-deep bf16 MFMA with split operands (x = hi + lo; hi hi + lo hi + hi lo: ~2^-16 relative per product, the
+// arithmetic of the forward kernel): a lane's eight values ARE its k-group of the 16 x 16 x 32 instruction (dims 8 g .. 8 g + 7) and
+// the C/D rows come out in the same order, so the operands and the row permutation above carry over unchanged - 3 instructions
+// instead of 8.  -DTB_SCORES_FP32=1 keeps the fp32 MFMA.
+typedef __attribute__((ext_vector_type(8))) __bf16 tb_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned tb_u4;
+struct TbSplit { tb_u4 h, l; };
+__device__ __forceinline__ TbSplit tb_split8(const float* v) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hh[i]) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+    const float r0 = v[2 * i] - __uint_as_float(hh[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ll[i]) : "v"(r0), "v"(r1));
+  }
+  return TbSplit{tb_u4{hh[0], hh[1], hh[2], hh[3]}, tb_u4{ll[0], ll[1], ll[2], ll[3]}};
+}
+__device__ __forceinline__ t4 tb_tile3(const TbSplit& row, const TbSplit& col) {
+  t4 s = {0.f, 0.f, 0.f, 0.f};
+  s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tb_bf16x8, row.l), __builtin_bit_cast(tb_bf16x8, col.h), s, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tb_bf16x8, row.h), __builtin_bit_cast(tb_bf16x8, col.l), s, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tb_bf16x8, row.h), __builtin_bit_cast(tb_bf16x8, col.h), s, 0, 0, 0);
+  return s;
+}
+#ifndef TB_SCORES_FP32
+#define TB_SCORES_FP32 0
+#endif
+
 __device__ __forceinline__ void tb_load8(const float* src, float* dst, float mul) {
   const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
   dst[0] = a.x * mul; dst[1] = a.y * mul; dst[2] = a.z * mul; dst[3] = a.w * mul;
@@ -266,6 +294,7 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
     tb_load8(p.v + ((size_t)crow * p.B + b) * p.ldv + hoff + 8 * g, cd, 1.f);
   }
 
+  const TbSplit cq3 = tb_split8(cq), cd3 = tb_split8(cd);          // the column side's operands: split once
   uint32_t seed_lo = 0, seed_hi = 0;
   if (DROP) { seed_lo = p.seed[0]; seed_hi = p.seed[1]; }
   const uint32_t drop_base = DROP ? mha_drop_row(b, h, 0, p.H, p.Lq, p.Lk) : 0u;
@@ -314,8 +343,8 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
     Tile nxt;
     load_tile(min(rt + TB_WAVES, ntiles - 1), nxt);
     // S^T and dP^T tiles: lane (col ci, g) register r <-> row rbase + g + 4 r
-    const t4 s = tb_tile(cur.rk, cq);
-    const t4 dp = tb_tile(cur.rv, cd);
+    const t4 s = TB_SCORES_FP32 ? tb_tile(cur.rk, cq) : tb_tile3(tb_split8(cur.rk), cq3);
+    const t4 dp = TB_SCORES_FP32 ? tb_tile(cur.rv, cd) : tb_tile3(tb_split8(cur.rv), cd3);
     float pr[4], ds[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
