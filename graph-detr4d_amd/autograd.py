@@ -288,7 +288,9 @@ class CrossAttnRawFunction(torch.autograd.Function):
                                                  img_h, img_w, raw_cam_weights=raw_cam)
         gw = gb = None
         if ctx.needs_input_grad[6] or (vp_bias is not None and ctx.needs_input_grad[7]):
-            if ctx.main is not None:
+            if ctx.main is not None and _deferring() is not None and agg.shape[-1] == 256:
+                _queue_deferred('vp', (grad_out, (agg, wsum), ctx.main[0], ctx.main[1] if vp_bias is not None else None), _VP_GROUP)
+            elif ctx.main is not None:
                 ops.value_proj_heads_bwd_weight(grad_out, agg, wsum, want_bias=vp_bias is not None, into=ctx.main)
             else:
                 gw, gb = ops.value_proj_heads_bwd_weight(grad_out, agg, wsum, want_bias=vp_bias is not None)
@@ -368,13 +370,13 @@ class ValueProjMultiFunction(torch.autograd.Function):
 # are queued during the backward pass and issued sixteen per launch (gd4d_linear_bwd_weight_group) - at the latest from a
 # callback the autograd engine runs when the backward pass ends (inside a hipGraph capture that is still inside the capture).
 # GD4D_TRAIN_DEFER_WGRAD=0: one launch per Linear, where autograd reaches it.
-_WGRAD_GROUP, _LN_GROUP = 16, 32
+_WGRAD_GROUP, _LN_GROUP, _VP_GROUP = 16, 32, 8
 _MAX_TASKS = 4
 # One pair of queues per backward pass (autograd graph-task id): a nested / re-entrant backward (reentrant checkpointing,
 # autograd.grad inside a hook) has its own id and must neither flush nor drop the outer pass's entries.  A pass that raised
 # never runs its callback and leaves its queues behind: they are never added to anything and are evicted, oldest id first,
 # once more than _MAX_TASKS passes have queues (passes nest two deep at most in this package).
-_DEFERRED = {}                # task id -> {'w': [...], 'ln': [...]}
+_DEFERRED = {}                # task id -> {'w': [...], 'ln': [...], 'vp': [...]}
 
 
 _WGRAD_SIDE = {}                # device index -> [side stream, work outstanding]
@@ -398,6 +400,8 @@ def _issue(kind, entries):
             _WGRAD_SIDE[dev.index] = [side, True]
             return
         ops.linear_bwd_weight_group(entries, accumulate=True)
+    elif kind == 'vp':                      # value_proj of the aggregates: (grad_out, (agg, wsum), main_w, main_b) per layer
+        ops.value_proj_heads_bwd_weight_group([(g, aw[0], aw[1], mw, mb) for g, aw, mw, mb in entries], accumulate=True)
     else:
         ops.layernorm_bwd_reduce_group(entries, accumulate=True)
 
@@ -415,7 +419,7 @@ def _flush_deferred(task=None):
         queues = _DEFERRED.pop(t, None)
         if not queues:
             continue
-        for kind, group in (('w', _WGRAD_GROUP), ('ln', _LN_GROUP)):
+        for kind, group in (('w', _WGRAD_GROUP), ('ln', _LN_GROUP), ('vp', _VP_GROUP)):
             q = queues[kind]
             for i in range(0, len(q), group):
                 _issue(kind, q[i:i + group])
@@ -442,7 +446,7 @@ def _queue_deferred(kind, entry, group):
     if queues is None:
         while len(_DEFERRED) >= _MAX_TASKS:
             del _DEFERRED[min(_DEFERRED)]             # left behind by a backward pass that raised
-        queues = _DEFERRED[task] = {'w': [], 'ln': [], 'busy': {'w': set(), 'ln': set()}}
+        queues = _DEFERRED[task] = {'w': [], 'ln': [], 'vp': [], 'busy': {'w': set(), 'ln': set(), 'vp': set()}}
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_deferred(task))
     q, busy = queues[kind], queues['busy'][kind]
     tg = _targets(kind, entry)

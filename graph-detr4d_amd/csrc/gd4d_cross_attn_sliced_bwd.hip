@@ -81,15 +81,15 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_kernel(const float* 
 constexpr int HW_KS = 32;
 
 template <int DH>
-__global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const float* __restrict__ g, const float* __restrict__ agg,
-                                                                           const float* __restrict__ wsum, float* __restrict__ part,
-                                                                           float* __restrict__ part_b, int M, int HH) {
+__device__ __forceinline__ void value_proj_heads_bwd_weight_body(const float* __restrict__ g, const float* __restrict__ agg,
+                                                                 const float* __restrict__ wsum, float* __restrict__ part,
+                                                                 float* __restrict__ part_b, int M, int HH, int block) {
   constexpr int DPT = DH / 4;                       // outputs per thread
   const int tid = threadIdx.x;
   const int c = tid & 63;
   const int dg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = kChannels / 64;
-  const int ks = blockIdx.x % HW_KS, hc = blockIdx.x / HW_KS;
+  const int ks = block % HW_KS, hc = block / HW_KS;
   const int h = hc / tiles, c0 = (hc % tiles) * 64;
   const int per = (M + HW_KS - 1) / HW_KS;
   const int m0 = ks * per, m1 = min(M, m0 + per);
@@ -115,9 +115,57 @@ __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const 
   if (do_bias) part_b[ks * kChannels + h * DH + dg * DPT + c] = accb;
 }
 
+template <int DH>
+__global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_kernel(const float* __restrict__ g, const float* __restrict__ agg,
+                                                                           const float* __restrict__ wsum, float* __restrict__ part,
+                                                                           float* __restrict__ part_b, int M, int HH) {
+  value_proj_heads_bwd_weight_body<DH>(g, agg, wsum, part, part_b, M, HH, blockIdx.x);
+}
+
+// The same for up to HW_GROUP layers of a training step in ONE launch (blockIdx.y = layer): a layer's launch is one workgroup
+// per compute unit waiting on its loads (12 us) followed by a 5-us sum - six layers side by side take hardly longer than one.
+constexpr int HW_GROUP = 8;
+struct HwGroup {
+  const float* g[HW_GROUP]; const float* agg[HW_GROUP]; const float* wsum[HW_GROUP];
+  float* gw[HW_GROUP]; float* gb[HW_GROUP];
+  int M[HW_GROUP];
+  float* part;                 // [layer][HW_KS * C * C + HW_KS * C]
+  int count, accumulate;
+};
+__device__ __forceinline__ size_t hw_part_stride() { return (size_t)HW_KS * (kChannels + 1) * kChannels; }
+
+template <int DH>
+__global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_group_kernel(const HwGroup q, int HH) {
+  const int l = blockIdx.y;
+  const float* g = q.g[0]; const float* agg = q.agg[0]; const float* wsum = q.wsum[0]; int M = q.M[0]; bool bias = q.gb[0] != nullptr;
+#pragma unroll
+  for (int j = 1; j < HW_GROUP; ++j)
+    if (j == l) { g = q.g[j]; agg = q.agg[j]; wsum = q.wsum[j]; M = q.M[j]; bias = q.gb[j] != nullptr; }
+  float* part = q.part + (size_t)l * hw_part_stride();
+  value_proj_heads_bwd_weight_body<DH>(g, agg, wsum, part, bias ? part + (size_t)HW_KS * kChannels * kChannels : nullptr, M, HH, blockIdx.x);
+}
+
+__device__ __forceinline__ void value_proj_heads_bwd_weight_sum_body(const float* __restrict__ part, const float* __restrict__ part_b,
+                                                                     float* __restrict__ gw, float* __restrict__ gb, int accumulate, int block);
+
+__global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_sum_group_kernel(const HwGroup q) {
+  const int l = blockIdx.y;
+  float* gw = q.gw[0]; float* gb = q.gb[0];
+#pragma unroll
+  for (int j = 1; j < HW_GROUP; ++j)
+    if (j == l) { gw = q.gw[j]; gb = q.gb[j]; }
+  const float* part = q.part + (size_t)l * hw_part_stride();
+  value_proj_heads_bwd_weight_sum_body(part, part + (size_t)HW_KS * kChannels * kChannels, gw, gb, q.accumulate, blockIdx.x);
+}
+
 __global__ __launch_bounds__(256) void value_proj_heads_bwd_weight_sum_kernel(const float* __restrict__ part, const float* __restrict__ part_b,
                                                                                float* __restrict__ gw, float* __restrict__ gb, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;      // kChannels * kChannels / 4 float4 results
+  value_proj_heads_bwd_weight_sum_body(part, part_b, gw, gb, accumulate, blockIdx.x);
+}
+
+__device__ __forceinline__ void value_proj_heads_bwd_weight_sum_body(const float* __restrict__ part, const float* __restrict__ part_b,
+                                                                     float* __restrict__ gw, float* __restrict__ gb, int accumulate, int block) {
+  const int i = block * 256 + threadIdx.x;           // kChannels * kChannels / 4 float4 results
   float4 t = reinterpret_cast<const float4*>(part)[i];
 #pragma unroll
   for (int ks = 1; ks < HW_KS; ++ks) {
@@ -991,6 +1039,36 @@ extern "C" int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const flo
   if (int rc = check_launch()) return rc;
   hipLaunchKernelGGL(value_proj_heads_bwd_weight_sum_kernel, dim3(kChannels * kChannels / 4 / 256), dim3(256), 0, s, part, part_b, grad_weight,
                      grad_bias, accumulate ? 1 : 0);
+  return check_launch();
+}
+
+extern "C" int gd4d_value_proj_heads_bwd_weight_group(const void* const* grad_out, const void* const* agg, const void* const* wsum,
+                                                      void* const* grad_weight, void* const* grad_bias, const int32_t* rows, int count,
+                                                      void* workspace, size_t workspace_bytes, int Hh, int C, int accumulate, void* stream) {
+  using namespace gd4d;
+  if (!grad_out || !agg || !wsum || !grad_weight || !grad_bias || !rows || !workspace || count <= 0) return GD4D_EINVAL;
+  if (count > HW_GROUP || C != kChannels || (Hh != 4 && Hh != 8 && Hh != 16)) return GD4D_EUNSUPPORTED;
+  if (workspace_bytes < (size_t)count * gd4d_value_proj_heads_bwd_weight_workspace_bytes()) return GD4D_EWORKSPACE;
+  if (!aligned16(workspace)) return GD4D_EALIGN;
+  HwGroup q{};
+  for (int i = 0; i < HW_GROUP; ++i) {
+    const int j = i < count ? i : 0;
+    if (i < count && (!grad_out[j] || !agg[j] || !grad_weight[j] || rows[j] <= 0 || (grad_bias[j] && !wsum[j]))) return GD4D_EINVAL;
+    q.g[i] = static_cast<const float*>(grad_out[j]); q.agg[i] = static_cast<const float*>(agg[j]);
+    q.wsum[i] = static_cast<const float*>(wsum[j]); q.gw[i] = static_cast<float*>(grad_weight[j]);
+    q.gb[i] = static_cast<float*>(grad_bias[j]); q.M[i] = rows[j];
+  }
+  q.part = static_cast<float*>(workspace); q.count = count; q.accumulate = accumulate ? 1 : 0;
+  const dim3 grid(Hh * (kChannels / 64) * HW_KS, count);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (kChannels / Hh) {
+    case 64: hipLaunchKernelGGL(value_proj_heads_bwd_weight_group_kernel<64>, grid, dim3(256), 0, s, q, Hh); break;
+    case 32: hipLaunchKernelGGL(value_proj_heads_bwd_weight_group_kernel<32>, grid, dim3(256), 0, s, q, Hh); break;
+    case 16: hipLaunchKernelGGL(value_proj_heads_bwd_weight_group_kernel<16>, grid, dim3(256), 0, s, q, Hh); break;
+    default: return GD4D_EUNSUPPORTED;
+  }
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(value_proj_heads_bwd_weight_sum_group_kernel, dim3(kChannels * kChannels / 4 / 256, count), dim3(256), 0, s, q);
   return check_launch();
 }
 

@@ -295,7 +295,7 @@ class DecoderTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out_all, _g_ref):
-        from .autograd import _LN_GROUP, _WGRAD_GROUP, _deferring, _queue_deferred
+        from .autograd import _LN_GROUP, _VP_GROUP, _WGRAD_GROUP, _deferring, _queue_deferred
         meta, saved, params, imgs = ctx.meta, ctx.saved, ctx.params, ctx.imgs
         if saved is None:
             raise RuntimeError('graph-detr4d_amd: the chain training path keeps its activations for ONE backward pass '
@@ -424,8 +424,10 @@ class DecoderTrainFunction(torch.autograd.Function):
             ivw, ivb = base + NAMES.index('vp_w'), base + NAMES.index('vp_b')
             if need[ivw] or need[ivb]:
                 mw, mb = (Fn.main_grad(params[ivw]), Fn.main_grad(params[ivb])) if deferring else (None, None)
-                if mw is not None and mb is not None:
+                if mw is not None and mb is not None and os.environ.get('GD4D_TRAIN_DEFER_VP', '1') == '0':
                     ops.value_proj_heads_bwd_weight(gv.view(1, q, c), s.agg, s.plan.wsum, want_bias=True, into=(mw, mb))
+                elif mw is not None and mb is not None:
+                    _queue_deferred('vp', (gv.view(1, q, c), (s.agg, s.plan.wsum), mw, mb), _VP_GROUP)
                 else:
                     grads[ivw], grads[ivb] = ops.value_proj_heads_bwd_weight(gv.view(1, q, c), s.agg, s.plan.wsum, want_bias=True)
             s.plan = None

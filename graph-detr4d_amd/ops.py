@@ -407,6 +407,33 @@ def value_proj_heads_bwd_weight(grad_out, agg, wsum=None, want_bias=True, into=N
     return gw, gb
 
 
+_VPH_WS = {}
+
+
+def value_proj_heads_bwd_weight_group(problems, accumulate=True):
+    """gd4d_value_proj_heads_bwd_weight_group: problems = list (<= 8) of (grad_out (..., 256), agg (..., Hh, 256), wsum (..., Hh),
+    grad_weight (256, 256), grad_bias (256) or None) - value_proj's gradients of several layers in one pair of launches, added to
+    (accumulate) or written into the targets."""
+    lib = _lib.load()
+    f32 = torch.float32
+    n = len(problems)
+    hh, c = problems[0][1].shape[-2], problems[0][1].shape[-1]
+    dev = problems[0][0].device
+    nbytes = n * int(lib.gd4d_value_proj_heads_bwd_weight_workspace_bytes())
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _VPH_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _VPH_WS[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    arr = lambda v: (ctypes.c_void_p * n)(*v)          # noqa: E731
+    rows = (ctypes.c_int32 * n)(*[int(g.numel() // c) for g, _, _, _, _ in problems])
+    code = lib.gd4d_value_proj_heads_bwd_weight_group(
+        arr([_dev(g, 'grad_out', f32).value for g, _, _, _, _ in problems]), arr([_dev(a, 'agg', f32).value for _, a, _, _, _ in problems]),
+        arr([_dev(w, 'wsum', f32).value for _, _, w, _, _ in problems]), arr([_dev(gw, 'grad_weight', f32).value for _, _, _, gw, _ in problems]),
+        arr([None if gb is None else _dev(gb, 'grad_bias', f32).value for _, _, _, _, gb in problems]), rows, n,
+        _dev(ws, 'workspace'), ctypes.c_size_t(nbytes), hh, c, 1 if accumulate else 0, _stream())
+    _lib.check(code, 'gd4d_value_proj_heads_bwd_weight_group')
+
+
 def cross_attn_dot_bytes(b, n, q, num_heads, points=4):
     return int(_lib.load().gd4d_cross_attn_dot_bytes(b, n, q, num_heads, points))
 

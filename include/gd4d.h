@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 42
+#define GD4D_ABI_VERSION 43
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -275,6 +275,12 @@ size_t gd4d_value_proj_heads_bwd_weight_workspace_bytes(void);
 int gd4d_value_proj_heads_bwd_weight(const float* grad_out, const float* agg, const float* wsum, float* grad_weight,
                                      float* grad_bias, void* workspace, size_t workspace_bytes, int M, int Hh, int C,
                                      int accumulate, void* stream);
+/* ... for up to 8 layers of a training step in ONE pair of launches (host arrays of `count` device pointers; rows[i] = M of
+ * problem i; grad_bias[i] may be NULL; workspace: count x gd4d_value_proj_heads_bwd_weight_workspace_bytes()): nothing reads
+ * these gradients before the optimizer, so a step queues them like the Linears' (gd4d_linear_bwd_weight_group). */
+int gd4d_value_proj_heads_bwd_weight_group(const void* const* grad_out, const void* const* agg, const void* const* wsum,
+                                           void* const* grad_weight, void* const* grad_bias, const int32_t* rows, int count,
+                                           void* workspace, size_t workspace_bytes, int Hh, int C, int accumulate, void* stream);
 size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
                                const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,

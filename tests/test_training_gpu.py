@@ -558,3 +558,33 @@ def test_grouped_weight_gradients_match_fp64(accumulate):
     ops.linear_bwd_weight_group(once, accumulate=False)
     for a, b in zip(again, once):
         assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+def test_value_proj_heads_weight_gradients_of_several_layers_in_one_launch():
+    """gd4d_value_proj_heads_bwd_weight_group (what a training step queues per layer and issues once) equals the per-layer
+    entry point bit for bit, problems with different row counts, with and without a bias target, accumulate on and off."""
+    from graph_detr4d_amd import ops
+    gen = torch.Generator().manual_seed(23)
+    probs = []
+    for m, bias in ((900, True), (900, True), (907, False), (37, True)):
+        g_ = torch.randn(1, m, 256, generator=gen).to(DEV)
+        agg, wsum = torch.randn(1, m, 8, 256, generator=gen).to(DEV), torch.rand(1, m, 8, generator=gen).to(DEV)
+        probs.append((g_, agg, wsum, bias))
+    for accumulate in (False, True):
+        base_w = [torch.randn(256, 256, generator=gen).to(DEV) for _ in probs]
+        base_b = [torch.randn(256, generator=gen).to(DEV) for _ in probs]
+        one = [(w.clone(), b.clone()) for w, b in zip(base_w, base_b)]
+        for (g_, agg, wsum, bias), (w, b) in zip(probs, one):
+            if accumulate:
+                ops.value_proj_heads_bwd_weight(g_, agg, wsum, want_bias=bias, into=(w, b if bias else None))
+            else:
+                gw, gb = ops.value_proj_heads_bwd_weight(g_, agg, wsum, want_bias=bias)
+                w.copy_(gw)
+                if bias:
+                    b.copy_(gb)
+        grp = [(w.clone(), b.clone()) for w, b in zip(base_w, base_b)]
+        ops.value_proj_heads_bwd_weight_group([(g_, agg, wsum, w, b if bias else None) for (g_, agg, wsum, bias), (w, b) in zip(probs, grp)],
+                                              accumulate=accumulate)
+        for (a_w, a_b), (b_w, b_b), (_, _, _, bias) in zip(one, grp, probs):
+            assert torch.equal(a_w, b_w)
+            assert torch.equal(a_b, b_b)          # (untouched where the problem has no bias target)
