@@ -777,6 +777,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
           float v = rc_act_in(op.p0[(size_t)m * op.ld0 + n], op.flags);
           if (op.p1) v += op.p1[(size_t)m * op.ld1 + n];
           bufs[op.dst][row][op.dst_col + n] = v;
+          if (TRAIN && op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = v;
         }
         break;
       }
@@ -965,7 +966,7 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (!op.p0 || op.dst < 0 || op.N <= 0 || op.dst_col < 0 || op.dst_col + op.N > RC_W) return GD4D_EINVAL;
         if ((op.N & 3) == 0 && (op.dst_col & 3) == 0 &&         // the float4 path
             (!aligned16(op.p0) || (op.ld0 & 3) || (op.p1 && (!aligned16(op.p1) || (op.ld1 & 3))))) return GD4D_EALIGN;
-        if (op.gout && ((op.N & 3) || (op.dst_col & 3) || !aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;
+        if (op.gout && (op.N & 3) == 0 && (op.dst_col & 3) == 0 && (!aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;   // (the float4 path)
         break;
       case GD4D_CHAIN_GEMM:
         if (!op.p0 || op.src < 0 || op.K <= 0 || op.N <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;

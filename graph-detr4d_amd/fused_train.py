@@ -238,7 +238,8 @@ class DecoderTrainFunction(torch.autograd.Function):
                                                    stacked=(im['three'], im['three_b']))]
             pe = ca.position_encoder
             s.mid0, s.a1, s.mid1, s.pos_feat = new(q, c), new(q, c), new(q, c), new(q, c)
-            prog_p = [ops.chain_load(0, ref.view(q, 3), inv_sigmoid=True),
+            s.isig = new(q, 3)                        # inverse_sigmoid(ref): the input of position_encoder's first Linear (its weight gradient)
+            prog_p = [ops.chain_load(0, ref.view(q, 3), inv_sigmoid=True, out=s.isig),
                       ops.chain_small_linear(0, p['pe0_w'], p['pe0_b'], 1, out=s.mid0),
                       ops.chain_layernorm(1, pe[1], dst=2, relu=True, out=s.a1),
                       ops.chain_gemm(2, im['pos3'], p['pe3_b'], dst=1, out=s.mid1),
@@ -407,8 +408,7 @@ class DecoderTrainFunction(torch.autograd.Function):
             wgrad(base, 'f0_w', s.x2, ghp)
             wgrad(base, 'op_w', s.v, gy2m)
             wgrad(base, 'pe3_w', s.a1, gmid1)
-            isig = ops.inverse_sigmoid_fwd(s.ref.view(q, 3))
-            wgrad(base, 'pe0_w', isig, gmid0)
+            wgrad(base, 'pe0_w', s.isig, gmid0)
             lngrad(base, 'n2_w', ws_n2); lngrad(base, 'n1_w', ws_n1); lngrad(base, 'pe4_w', ws_p4); lngrad(base, 'pe1_w', ws_p1)
             # the gather's backward (autograd.CrossAttnRawFunction.backward)
             p = dict(zip(NAMES, params[base:base + PER_LAYER]))
