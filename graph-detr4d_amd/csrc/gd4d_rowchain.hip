@@ -527,7 +527,10 @@ __device__ __forceinline__ void rc_layernorm_bwd(const ChainOp& op, float (*bufs
       const int n = min(64 * ch, N - 64) + 4 * l16;
       gm[ch] = *reinterpret_cast<const float4*>(op.p0 + n);
       bt[ch] = relu ? *reinterpret_cast<const float4*>(op.p1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      x[ch] = *reinterpret_cast<const float4*>(&bufs[op.res][row][n]);
+      // the forward's input: from buf[res], or (p3 given) straight from its rows in global memory - a LOAD operation and its
+      // barrier less per LayerNorm of a backward chain
+      x[ch] = op.p3 ? *reinterpret_cast<const float4*>(op.p3 + (size_t)min(m0 + row, M - 1) * op.ld1 + n)
+                    : *reinterpret_cast<const float4*>(&bufs[op.res][row][n]);
       d[ch] = *reinterpret_cast<const float4*>(&bufs[op.src][row][n]);
       if (!live) d[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -1002,7 +1005,9 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (op.gout && (!aligned16(op.gout) || (op.ldg & 3))) return GD4D_EALIGN;
         break;
       case GD4D_CHAIN_LN_BWD:
-        if (!op.p0 || op.src < 0 || op.res < 0 || op.res == op.src || op.res == op.dst || op.N <= 0 || op.N > RC_W) return GD4D_EINVAL;
+        if (!op.p0 || op.src < 0 || op.N <= 0 || op.N > RC_W) return GD4D_EINVAL;
+        if (!op.p3 && (op.res < 0 || op.res == op.src || op.res == op.dst)) return GD4D_EINVAL;
+        if (op.p3 && (!aligned16(op.p3) || (op.ld1 & 3) || op.ld1 < op.N)) return GD4D_EALIGN;
         if (op.dst < 0 && !op.gout && !op.p2) return GD4D_EINVAL;
         if ((op.flags & GD4D_CHAIN_RELU) && !op.p1) return GD4D_EINVAL;
         if (op.N % 64 != 0) return GD4D_EUNSUPPORTED;

@@ -358,7 +358,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         part = lambda: new(blocks * 2 * c)                                   # noqa: E731
         g_next = None                        # gradient of a layer's OUTPUT coming from the layer after it
         gpos = None                          # running gradient of query_pos
-        g_ref0 = padz = None
+        g_ref0 = padz = carry = carry_keep = None
         if want_pyramid:
             raw.begin_backward()
         for lid in range(nl - 1, -1, -1):
@@ -372,9 +372,15 @@ class DecoderTrainFunction(torch.autograd.Function):
             if g_out_all is not None:
                 g_here = g_out_all[lid if dec.return_intermediate else 0].contiguous().view(q, c) \
                     if (dec.return_intermediate or lid == nl - 1) else None
-            if g_here is None and g_next is None:
+            if g_here is None and g_next is None and carry is None:
                 g_here = torch.zeros(q, c, device=dev, dtype=f32)
-            first, second = (g_here, g_next) if g_here is not None else (g_next, None)
+            if carry is None:
+                first, second = (g_here, g_next) if g_here is not None else (g_next, None)
+                head, g_src = [ops.chain_load(0, first, second)], 0
+            elif g_here is not None:                   # the layer above's in-projection backward left its input gradient in buffer 3
+                head, g_src = carry + [ops.chain_add(0, 3, c, add=g_here)], 0
+            else:
+                head, g_src = carry, 3
             gy3, ghp, gy2, gv, gmid1, gmid0 = new(q, c), new(q, fc), new(q, c), new(q, c), new(q, c), new(q, c)
             ws_n2, ws_n1, ws_p4, ws_p1, ws_n0 = part(), part(), part(), part(), part()
             # With dropout after a Linear the gradient at that Linear's output is the masked one (DROPMASK regenerates the
@@ -382,27 +388,22 @@ class DecoderTrainFunction(torch.autograd.Function):
             d_out, d_op, d_h, d_f1 = s.drop[1], s.drop[2], s.drop[3], s.drop[4]
             gy3m = new(q, c) if d_f1 else gy3
             gy2m = new(q, c) if d_op else gy2
-            prog = [ops.chain_load(0, first, second),
-                    ops.chain_load(1, s.y3),
-                    ops.chain_layernorm_bwd(0, 1, layer.norms[2], dst=0, out=None if d_f1 else gy3, part=ws_n2)]
+            prog = head + [ops.chain_layernorm_bwd(g_src, s.y3, layer.norms[2], dst=0, out=None if d_f1 else gy3, part=ws_n2)]
             src = 0
             if d_f1:
                 prog.append(ops.chain_dropmask(0, 1, c, d_f1[0], d_f1[1], out=gy3m))
                 src = 1
             prog += [ops.chain_gemm(src, im['ffn1_t'], None, dst=2, mask=s.h, mask_scale=1.0 / (1.0 - d_h[1]) if d_h else 0., out=ghp),
                      ops.chain_gemm(2, im['ffn0_t'], None, dst=1, res=0),
-                     ops.chain_load(3, s.y2),
-                     ops.chain_layernorm_bwd(1, 3, layer.norms[1], dst=1, out=gy2, part=ws_n1)]
+                     ops.chain_layernorm_bwd(1, s.y2, layer.norms[1], dst=1, out=gy2, part=ws_n1)]
             src = 1
             if d_op:
                 prog.append(ops.chain_dropmask(1, 0, c, d_op[0], d_op[1], out=gy2m))
                 src = 0
             prog += [ops.chain_gemm(src, im['outputproj_t'], None, out=gv),
-                     ops.chain_load(3, s.mid1),
-                     ops.chain_layernorm_bwd(1, 3, pe[4], dst=2, relu=True, out=gmid1, part=ws_p4),
+                     ops.chain_layernorm_bwd(1, s.mid1, pe[4], dst=2, relu=True, out=gmid1, part=ws_p4),
                      ops.chain_gemm(2, im['pos3_t'], None, dst=0),
-                     ops.chain_load(3, s.mid0),
-                     ops.chain_layernorm_bwd(0, 3, pe[1], dst=0, relu=True, out=gmid0, part=ws_p1)]
+                     ops.chain_layernorm_bwd(0, s.mid0, pe[1], dst=0, relu=True, out=gmid0, part=ws_p1)]
             ops.row_chain_fwd(prog, q)
             wgrad(base, 'f1_w', s.h, gy3m)
             wgrad(base, 'f0_w', s.x2, ghp)
@@ -446,8 +447,7 @@ class DecoderTrainFunction(torch.autograd.Function):
                 prog.append(ops.chain_load(0, padz, dst_col=col))
             prog += [ops.chain_gemm(0, im['three_t'], None, dst=2, out=gx1p),
                      ops.chain_add(1, 2, c, add=gy2),
-                     ops.chain_load(3, s.y1),
-                     ops.chain_layernorm_bwd(1, 3, layer.norms[0], dst=1, out=gy1, part=ws_n0)]
+                     ops.chain_layernorm_bwd(1, s.y1, layer.norms[0], dst=1, out=gy1, part=ws_n0)]
             gy1m = new(q, c) if d_out else gy1
             if d_out:
                 prog.append(ops.chain_dropmask(1, 0, c, d_out[0], d_out[1], out=gy1m))
@@ -459,14 +459,19 @@ class DecoderTrainFunction(torch.autograd.Function):
             qh, kh, vh = s.qkv.split(c, dim=-1)
             dqk, dv = ops.mha_core_bwd(qh, kh, vh, s.o, g_o, s.lse, sa.num_heads, meta.attn_mask, packed_qk=True,
                                        dropout_p=s.drop[0][1] if s.drop[0] else 0., seed=s.drop[0][0] if s.drop[0] else None)
-            gx, gxp = new(q, c), new(q, c)
+            # in-projection backward: launched with the NEXT layer's chain B' backward (its result stays in LDS), alone for layer 0
+            gx = new(q, c) if lid == 0 else None
             gpos_new = new(q, c)
             prog = [ops.chain_load(0, dqk.view(q, 2 * c)), ops.chain_load(1, dv.view(q, c)),
-                    ops.chain_gemm(0, im['inproj_qk_t'], None, dst=2, out=gxp),
+                    ops.chain_gemm(0, im['inproj_qk_t'], None, dst=2),
                     ops.chain_gemm(1, im['inproj_v_t'], None, dst=3, res=2, add=gy1, out=gx),
                     ops.chain_load(0, gx1p, gpos),
                     ops.chain_add(0, 0, c, res=2, out=gpos_new)]
-            ops.row_chain_fwd(prog, q)
+            if lid == 0:
+                ops.row_chain_fwd(prog, q)
+                carry = None
+            else:
+                carry, carry_keep = prog, (dqk, dv, gy1, gx1p, gpos, gpos_new)
             wgrad(base, 'in_w', s.xp, dqk.view(q, 2 * c), rows=(0, 2 * c))
             wgrad(base, 'in_w', s.x, dv.view(q, c), rows=(2 * c, 3 * c))
             g_next, gpos = gx, gpos_new

@@ -1784,12 +1784,14 @@ def chain_small_linear(src, weight, bias, dst, relu=False, inv_sigmoid=False, ou
 
 
 def chain_layernorm_bwd(src, x_buf, norm, dst=-1, relu=False, out=None, part=None):
-    """Backward of chain_layernorm: buf[src] = gradient of the output, buf[x_buf] = the forward's input; dx -> buf[dst] (may
-    be src) and / or out; part: (ceil(M / 16), 2, N) fp32 partial dgamma / dbeta (layernorm_bwd_reduce_group adds them)."""
+    """Backward of chain_layernorm: buf[src] = gradient of the output; the forward's input = buf[x_buf], or - x_buf a tensor -
+    its rows in global memory (no LOAD operation needed); dx -> buf[dst] (may be src) and / or out; part: (ceil(M / 16), 2, N)
+    fp32 partial dgamma / dbeta (layernorm_bwd_reduce_group adds them)."""
     g, ldg = _rows(out, 'out')
-    return ChainOp(kind=CHAIN_LN_BWD, src=src, dst=dst, res=x_buf, N=norm.weight.shape[0], eps=float(norm.eps),
-                   flags=CHAIN_RELU if relu else 0, ldg=ldg, p0=norm.weight.data_ptr(), p1=norm.bias.data_ptr(),
-                   p2=None if part is None else _dev(part, 'part', torch.float32).value, gout=g)
+    p3, ld3 = (None, 0) if isinstance(x_buf, int) else _rows(x_buf, 'x')
+    return ChainOp(kind=CHAIN_LN_BWD, src=src, dst=dst, res=x_buf if isinstance(x_buf, int) else -1, N=norm.weight.shape[0],
+                   eps=float(norm.eps), flags=CHAIN_RELU if relu else 0, ldg=ldg, ld1=ld3, p0=norm.weight.data_ptr(),
+                   p1=norm.bias.data_ptr(), p2=None if part is None else _dev(part, 'part', torch.float32).value, gout=g, p3=p3)
 
 
 def chain_layernorm(src, norm, dst=-1, relu=False, out=None, dst2=-1, add=None):

@@ -538,8 +538,8 @@ int gd4d_linear_ln_fwd(const float* x, const float* x2, const float* w, const fl
  *              v[m, n] = sum_k p2[m][h][k] W[n][k] + bias[n] p3[m][h], h = n / (N / heads); p0 = the image of W (N, K),
  *              p1 = bias or NULL, p2 = agg (M, heads, K), p3 = wsum (M, heads), heads = ld0; then as GEMM (+ buf[res], to
  *              buf[dst] and / or gout).  (N / heads) % 32 == 0, K % 64 == 0.
- *   LN_BWD     backward of LAYERNORM: buf[src] = gradient of its output, buf[res] = the forward's input (statistics are
- *              recomputed), p0 = gamma, p1 = beta (needed with GD4D_CHAIN_RELU: the forward's ReLU); dx -> buf[dst] (dst == src
+ *   LN_BWD     backward of LAYERNORM: buf[src] = gradient of its output, buf[res] - or, when p3 is given, the global rows
+ *              p3[m, :N] (row stride ld1) - = the forward's input (statistics are recomputed), p0 = gamma, p1 = beta (needed with GD4D_CHAIN_RELU: the forward's ReLU); dx -> buf[dst] (dst == src
  *              allowed) and / or gout; p2 = (ceil(M / 16), 2, N) partial dgamma / dbeta of the row blocks, the layout of
  *              gd4d_layernorm_bwd's workspace (gd4d_layernorm_bwd_reduce_group adds them), or NULL
  *   DROPMASK   buf[dst][:, :N] = the dropout mask a forward GEMM with GD4D_CHAIN_DROPOUT drew (p0 = its seed, reserved = its

@@ -208,6 +208,10 @@ def test_chain_layernorm_bwd_matches_autograd(m, n, relu):
     ops.row_chain_fwd([ops.chain_load(0, gy), ops.chain_load(1, x.detach()),
                        ops.chain_layernorm_bwd(0, 1, norm, dst=0, relu=relu, out=dx, part=part)], m)
     torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-5)
+    # the forward's input straight from global memory (no LOAD operation): the same bits
+    dx_g, part_g = torch.empty(m, n, device=DEV), torch.empty_like(part)
+    ops.row_chain_fwd([ops.chain_load(0, gy), ops.chain_layernorm_bwd(0, x.detach(), norm, dst=0, relu=relu, out=dx_g, part=part_g)], m)
+    assert torch.equal(dx_g, dx) and torch.equal(part_g, part)
     dg, db = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
     ops.layernorm_bwd_reduce_group([(part, (m, n), dg, db)], accumulate=False)
     torch.testing.assert_close(dg, norm.weight.grad, rtol=1e-4, atol=1e-4)
