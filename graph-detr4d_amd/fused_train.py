@@ -214,6 +214,9 @@ class DecoderTrainFunction(torch.autograd.Function):
         p0 = dict(zip(NAMES, params[:PER_LAYER]))
         ops.row_chain_fwd([ops.chain_load(0, x, pos, out=xp), ops.chain_load(1, x),
                            ops.chain_gemm_two_sources(0, 1, 2 * c, im0['inproj'], p0['in_b'], qkv.view(q, -1))], q)
+        # the locality order of the INITIAL reference points for every layer, as the inference loop (fused_decoder.run_single): the
+        # refinements move a point little, a stale order costs a gather ~2 us, a fresh one a launch
+        order = Fn.query_order(ref, layers[0].attentions[1].pc_range)
         for lid, layer in enumerate(layers):
             p = dict(zip(NAMES, params[lid * PER_LAYER:(lid + 1) * PER_LAYER]))
             im = imgs.layers[lid]
@@ -246,7 +249,6 @@ class DecoderTrainFunction(torch.autograd.Function):
                       ops.chain_layernorm(1, pe[4], relu=True, out=s.pos_feat)]
             ops.row_chain2_fwd(prog_a, prog_p, q)
             # plan + gather on the raw pyramid (autograd.CrossAttnRawFunction's forward without its value_proj launch)
-            order = Fn.query_order(ref, ca.pc_range)
             s.plan = ops.cross_attn_plan_fwd(raw.pyramid, ref, s.off.view(1, q, hh, npt, 3), s.att.view(1, q, hh, nlv, npt), s.cam,
                                              meta.lidar2img, ca.pc_range, meta.img_h, meta.img_w, hh, query_order=order,
                                              both=os.environ.get('GD4D_TRAIN_PLAN', 'both') == 'both')
