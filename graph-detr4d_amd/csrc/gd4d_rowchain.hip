@@ -159,12 +159,17 @@ __global__ __launch_bounds__(256) void chain_weight_image_kernel(const float* __
 // concatenates 1-D segments (cols = 1: the stacked bias) into fp32 `image`.  frag0 = the job's first fragment in the launch
 // (a fragment = 64 lanes x 8 values; jobs sorted by frag0).
 __global__ __launch_bounds__(256) void chain_weight_image_group_kernel(const gd4d_image_job* __restrict__ jobs, int count, int total) {
+  // which job: a binary search over the jobs' first fragments - from LDS (seven dependent global loads per wave otherwise:
+  // the launch was bound by them, 57 us for 16 k fragments)
+  __shared__ int s_frag0[GD4D_IMAGE_JOBS_MAX];
+  for (int i = threadIdx.x; i < count; i += 256) s_frag0[i] = jobs[i].frag0;
+  __syncthreads();
   const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (frag >= total) return;
   int lo = 0, hi = count - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].frag0 <= frag) lo = mid; else hi = mid - 1;
+    if (s_frag0[mid] <= frag) lo = mid; else hi = mid - 1;
   }
   const gd4d_image_job J = jobs[lo];
   const int f = frag - J.frag0;
@@ -185,10 +190,23 @@ __global__ __launch_bounds__(256) void chain_weight_image_group_kernel(const gd4
   const int t = f / ksteps, s = f - t * ksteps;
   const int n = 16 * t + (lane & 15);
   float v[8];
+  if (!J.transposed && (J.cols & 3) == 0 && RC_KG == 4) {
+    // a lane's row is fixed: its block once, then its two pieces of the k-step as 16-byte loads (K = cols is a multiple of 64 here)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (n < N) {
+      int r = n, j = 0;
+      if (r >= J.rows[0]) { r -= J.rows[0]; j = 1; if (r >= J.rows[1]) { r -= J.rows[1]; j = 2; } }
+      const float* rowp = J.seg[j] + (size_t)r * J.cols + 32 * s + RC_KG * (lane >> 4);
+      if (32 * s + RC_KG * (lane >> 4) + 3 < J.cols) a = *reinterpret_cast<const float4*>(rowp);
+      if (32 * s + RC_KG * (lane >> 4) + RC_K2 + 3 < J.cols) b = *reinterpret_cast<const float4*>(rowp + RC_K2);
+    }
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = 32 * s + RC_KG * (lane >> 4) + (j < 4 ? j : RC_K2 + j - 4);
-    v[j] = n < N ? (J.transposed ? elem(k, n) : elem(n, k)) : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * s + RC_KG * (lane >> 4) + (j < 4 ? j : RC_K2 + j - 4);
+      v[j] = n < N ? (J.transposed ? elem(k, n) : elem(n, k)) : 0.f;
+    }
   }
   char* dst = static_cast<char*>(J.image) + (size_t)f * (J.planes * 1024) + lane * 16;
   if (J.planes == 3) {
@@ -951,6 +969,7 @@ extern "C" size_t gd4d_image_job_bytes(void) { return sizeof(gd4d_image_job); }
 extern "C" int gd4d_chain_weight_image_group(const gd4d_image_job* jobs_device, int count, int total_frags, void* stream) {
   using namespace gd4d;
   if (!jobs_device || count <= 0 || total_frags <= 0) return GD4D_EINVAL;
+  if (count > GD4D_IMAGE_JOBS_MAX) return GD4D_EUNSUPPORTED;
   hipLaunchKernelGGL(chain_weight_image_group_kernel, dim3((total_frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
                      jobs_device, count, total_frags);
   return check_launch();

@@ -1647,6 +1647,8 @@ class ImageSet:
     def refresh(self):
         lib = _lib.load()
         self.finalize()
+        if len(self._jobs) > 1024:
+            raise _lib.Gd4dError('ImageSet: more than 1024 jobs (GD4D_IMAGE_JOBS_MAX) - split the set')
         with torch.cuda.device(self.device):
             code = lib.gd4d_chain_weight_image_group(ctypes.c_void_p(self._table.data_ptr()), len(self._jobs), self._frags, _stream())
         _lib.check(code, 'gd4d_chain_weight_image_group')

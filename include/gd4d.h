@@ -593,6 +593,7 @@ int gd4d_chain_weight_image_exact(const float* weight, int N, int K, void* image
  * planes = 2 (gd4d_chain_weight_image's layout), 3 (.._exact's) or 0 (no image: cols = 1, the segments are concatenated into
  * fp32 `image` - a stacked bias).  A job owns fragments [frag0, frag0 + n): n = ceil(N / 16) * (K_padded / 32) for an image,
  * ceil(sum rows / 64) for a concatenation; total_frags = the sum. */
+#define GD4D_IMAGE_JOBS_MAX 1024   /* jobs per gd4d_chain_weight_image_group launch */
 typedef struct gd4d_image_job {
   const float* seg[3];
   int32_t rows[3];
