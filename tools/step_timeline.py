@@ -19,7 +19,7 @@ def main():
     if not pairs:
         print('no complete step between two marker kernels')
         return
-    a, b = pairs[-1]
+    a, b = min(pairs, key=lambda ab: ks[ab[1]][0] - ks[ab[0]][0])      # the shortest complete step: no profiler flush inside it
     step = ks[a:b]
     t0 = step[0][0]
     print(f'{len(step)} kernels, step span {(ks[b][0] - t0) / 1e3:.1f} us')
