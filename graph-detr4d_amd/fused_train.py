@@ -209,6 +209,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         saved = []
         drops = [_dropouts(layer) for layer in layers]
         seeds = draw_seeds(5 * nl, dev) if any(any(pr > 0. for pr in d) for d in drops) else None
+        flags = torch.zeros(nl, (q + 15) // 16 // 8 * 8 + 16, device=dev, dtype=torch.int32) if meta.reg_branches is not None else None   # hand-off flags per row block; [-1]: waits that gave up
         qkv, xp = new(q, 1, 3 * c), new(q, c)
         im0 = imgs.layers[0]
         p0 = dict(zip(NAMES, params[:PER_LAYER]))
@@ -272,21 +273,33 @@ class DecoderTrainFunction(torch.autograd.Function):
                 prog += [ops.chain_add(0, 3, c, add=pos, out=xp),
                          ops.chain_gemm_two_sources(0, 3, 2 * c, imgs.layers[lid + 1]['inproj'], pn['in_b'], qkv.view(q, -1))]
             if meta.reg_branches is not None:
-                # reg branch + refinement (:199-214); the refined points are DETACHED (:213): no gradient leaves this tail
+                # reg branch + refinement (:199-214); the refined points are DETACHED (:213): no gradient leaves this tail.  It needs
+                # the layer's output only, so it runs as the launch's second program beside the next layer's in-projection: the first
+                # program SIGNALs once its rows of x3 are stored (gd4d.h: the signalling program goes first).
                 lins = _plain_reg_branch(meta.reg_branches[lid], c)
+                new_ref = ref_all[lid]
+                tail = [] if last else [ops.chain_wait(flags[lid], flags[lid, -1:]), ops.chain_load(3, x3)]
                 src, tmp = 3, (1, 2)
                 for i, (lin, wimg) in enumerate(zip(lins, im['reg'])):
-                    prog.append(ops.chain_gemm(src, wimg, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
+                    tail.append(ops.chain_gemm(src, wimg, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
                     src = tmp[i % 2]
-                new_ref = ref_all[lid]
-                prog.append(ops.chain_refine(src, ref, new_ref))
+                tail.append(ops.chain_refine(src, ref, new_ref))
+                if last or os.environ.get('GD4D_TRAIN_REG_BESIDE', '1') == '0':      # nothing to run beside: the tail closes the chain
+                    ops.row_chain_fwd(prog + tail[(0 if last else 2):], q)
+                else:
+                    at = 7                                  # after the LayerNorm that stores x3
+                    ops.row_chain2_fwd(prog[:at] + [ops.chain_signal(flags[lid])] + prog[at:], tail, q)
             else:
                 new_ref = ref
                 ref_all[lid].copy_(ref)
-            ops.row_chain_fwd(prog, q)
+                ops.row_chain_fwd(prog, q)
             saved.append(s)
             x, ref = x3, new_ref
         raw.join()
+        if flags is not None and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(dev)                      # debugging aid, as in fused_decoder: a WAIT that gave up counts in [-1]
+            if int(flags[:, -1].sum().item()) != 0:
+                raise RuntimeError('graph-detr4d_amd: a SIGNAL / WAIT hand-off between chain programs timed out')
         ctx.meta, ctx.saved, ctx.params, ctx.imgs = meta, saved, params, imgs
         ctx.versions = [p_._version for p_ in params]        # the backward chains read the images of THESE weights (and their transposes)
         ctx.pos = pos
