@@ -19,6 +19,7 @@
 // the weights do not change) so they stream from L2 as whole 1-KB pieces; the activations are split when read from LDS.
 // LayerNorm two-pass like ATen (mean, centred sum of squares, biased variance, eps inside the square root).
 #include "gd4d_common.h"
+#include "gd4d_mha_body.h"
 #include "gd4d_mha_dropout.h"
 
 namespace gd4d {
@@ -677,26 +678,30 @@ struct ChainProgram {
   ChainOp ops[GD4D_CHAIN_MAX_OPS];   // ops[nops, nops + nops2) over the SAME rows (gd4d_row_chain2_fwd); split = blocks up to a multiple of 8
 };
 
-template <bool TRAIN>
-__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainProgram by_value) {
-  typedef const __attribute__((address_space(4))) ChainProgram* kernarg_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
-  const kernarg_ptr_t pp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // explicit arguments start at 0
+typedef const __attribute__((address_space(4))) ChainProgram* rc_prog_ptr_t;   // the kernel argument segment: scalar loads
 #else
-  const ChainProgram* pp = &by_value;
+typedef const ChainProgram* rc_prog_ptr_t;
 #endif
+
+// bx: the workgroup's index among the launch's CHAIN workgroups (blockIdx.x; the fused attention launch takes its attention
+// workgroups out of the numbering - a multiple of 8 of them, so bx and blockIdx.x name the same XCD).
+// MHA: mha_flags != nullptr = this workgroup's rows of the first LOAD's source are written by the attention workgroups of the
+// SAME launch: it waits (after its prefetch touches are out) until mha_count of them have reported for its row block.
+template <bool TRAIN, bool MHA>
+__device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int bx, const unsigned* mha_flags, const int mha_count,
+                                               unsigned* mha_err) {
   const int M = pp->M, split = pp->split;
   const int blocks = (M + RC_M - 1) / RC_M;
   // Two programs: the second one's workgroups start at `split` = blocks rounded up to a multiple of 8, so that row block i of
   // both programs sits on the SAME XCD (workgroup j is dispatched to XCD j % 8) behind the same L2 - what a SIGNAL / WAIT pair
   // between the programs relies on; the workgroups in [blocks, split) have nothing to do.
-  if (split > 0 && (int)blockIdx.x >= blocks && (int)blockIdx.x < split) return;
-  const bool second = split > 0 && (int)blockIdx.x >= split;       // workgroup-uniform: which of the two programs
+  if (split > 0 && bx >= blocks && bx < split) return;
+  const bool second = split > 0 && bx >= split;                    // workgroup-uniform: which of the two programs
   const int op_base = second ? pp->nops : 0;
   const int nops = second ? pp->nops2 : pp->nops;
-  const int wg = second ? (int)blockIdx.x - split : (int)blockIdx.x;   // row block
+  const int wg = second ? bx - split : bx;                         // row block
   const int wg_lo = second ? split : 0, wg_hi = wg_lo + blocks;
-  (void)by_value;
   extern __shared__ __attribute__((aligned(16))) char rc_smem[];
   float (*bufs)[RC_M][RC_LD] = reinterpret_cast<float (*)[RC_M][RC_LD]>(rc_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -717,9 +722,9 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   rc_lds_void_t* rc_dump = (rc_lds_void_t*)(rc_smem + sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * wave);
   auto touch1 = [&](const char* q) { __builtin_amdgcn_global_load_lds((rc_glb_void_t*)q, rc_dump, 4, 0, 0); };
   // the workgroups of THIS program that sit on this XCD: indices first, first + 8, ... below wg_hi
-  const unsigned xcd = blockIdx.x & 7u;
+  const unsigned xcd = (unsigned)bx & 7u;
   const unsigned first = (unsigned)wg_lo + ((xcd - (unsigned)wg_lo) & 7u);
-  const unsigned mine = (blockIdx.x - first) >> 3, share = ((unsigned)wg_hi - 1u - first) / 8u + 1u;
+  const unsigned mine = ((unsigned)bx - first) >> 3, share = ((unsigned)wg_hi - 1u - first) / 8u + 1u;
   auto touch = [&](const void* base, size_t bytes) {
     if (!base || bytes < 4) return;
     const char* b = reinterpret_cast<const char*>(base);
@@ -784,6 +789,20 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   if (RC_PREFETCH & 2) touch_small(op_base + lead);
   if ((RC_PREFETCH & 1) && lead == 0) touch_images();
 #endif
+  if (MHA && (second || split == 0)) {                       // the launch's last program
+    // (the WAIT operation's scheme: the attention workgroups of this row block sit on this XCD, the flag is a counter in its L2)
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(mha_flags + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)mha_count) {
+        if (++spins > (1u << 20)) {                        // ~0.2 s unanswered: count it and go on (a wrong result, not a hung GPU)
+          if (mha_err) atomicAdd(mha_err, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+  }
   for (int oi = op_base; oi < op_base + nops; ++oi) {
 #if RC_PREFETCH
     if ((RC_PREFETCH & 1) && lead > 0 && oi == op_base + lead) touch_images();
@@ -924,6 +943,64 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
 #endif
   }
   trace_mark_if(g_trace_rowchain, (second ? 0x87ull : 0x81ull) | ((unsigned long long)nops << 8), wg == 0);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainProgram by_value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const rc_prog_ptr_t pp = (rc_prog_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // explicit arguments start at 0
+#else
+  const ChainProgram* pp = &by_value;
+#endif
+  (void)by_value;
+  row_chain_body<TRAIN, false>(pp, (int)blockIdx.x, nullptr, 0, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The self-attention core and the chain that consumes it in ONE launch (gd4d_row_chain_mha_fwd).  A kernel boundary inside a
+// replayed graph costs 3 - 6 us, the attention core takes 11 and chain A 14: per decoder layer the pair of launches was
+//     boundary, attention 11.4, boundary, [chain A 14.2 | reg branch of the previous layer + refinement 19.1]
+// Workgroups [0, hi) of this launch are the attention core's (gd4d_mha_body.h; head-major, `stride` = row blocks rounded up to
+// a multiple of 8 per head: the H workgroups of a row block sit on the XCD of that block's chain workgroup); each adds 1 to its
+// row block's counter once its rows of the output are in the L2 (the SIGNAL operation's scheme).  The chain workgroups follow
+// (workgroups are dispatched in index order, so whoever waits was dispatched after those it waits for): the LAST program's
+// request their weight images, wait for the counter to reach H and run; a first program (the previous layer's reg branch)
+// runs as soon as it has a compute unit.  Every workgroup of the launch owns the chain's LDS (one per compute unit), so the
+// attention workgroups ask for all their rows up front (AHEAD = 4) instead of relying on a neighbour to hide the round trips.
+// MEASURED (tools/r04_run57.sh, r04_run58.sh; one request at a time, 200 steps, three interleaved pairs): 1.609 - 1.618 ms per
+// sample against 1.602 - 1.607 for the two launches (1.665 with one step of look-ahead in the attention workgroups).  An
+// attention workgroup alone on its compute unit takes 9.6 us (issue-bound: two waves per SIMD, one dependent chain each), the
+// 8 x 57 of them need two rounds, so the chain starts 18.5 us into the launch - what the separate kernel (two to three small
+// workgroups per compute unit, 11.4 us) and the boundary cost together.  Not the default (GD4D_FUSE_MHA=1 selects it).
+struct MhaRole {
+  MhaParams p;
+  unsigned* flags;             // >= stride counters, zero before the launch
+  unsigned* err;               // optional: waits that gave up
+  int hi, stride;              // hi = H * stride attention workgroups
+};
+
+__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_mha_kernel(const ChainProgram by_value, const MhaRole mr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const rc_prog_ptr_t pp = (rc_prog_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const ChainProgram* pp = &by_value;
+#endif
+  (void)by_value;
+  const int bx = (int)blockIdx.x;
+  if (bx < mr.hi) {
+    extern __shared__ __attribute__((aligned(16))) char rc_smem[];
+    const int idx = bx;
+    const int h = idx / mr.stride, r = idx - h * mr.stride;
+    if (r * 16 >= mr.p.Lq) return;
+    trace_mark_if(g_trace_rowchain, 9ull, idx == 0);
+    mha_core_bf16x3_body<0, 4>(mr.p, r, h, 0, *reinterpret_cast<MhaShared*>(rc_smem));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(mr.flags + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    trace_mark_if(g_trace_rowchain, 0x89ull, idx == 0);
+    return;
+  }
+  row_chain_body<false, true>(pp, bx - mr.hi, mr.flags, mr.p.H, mr.err);
 }
 
 }  // namespace gd4d
@@ -1092,6 +1169,53 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
     hipLaunchKernelGGL(row_chain_kernel<true>, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog);
   else
     hipLaunchKernelGGL(row_chain_kernel<false>, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog);
+  return check_launch();
+}
+
+extern "C" int gd4d_row_chain_mha_fwd(const gd4d_chain_op* program, int nops, const gd4d_chain_op* program_side, int nops_side, int M,
+                                      const float* q, const float* k, const float* v, float* attn_out, int H, int D, int ldq, int ldk,
+                                      int ldv, int ldo, float scale, int32_t* flags, int32_t* errors, void* stream) {
+  using namespace gd4d;
+  if (!program || nops <= 0 || M <= 0 || nops_side < 0 || (nops_side > 0 && !program_side)) return GD4D_EINVAL;
+  if (!q || !k || !v || !attn_out || !flags || H <= 0) return GD4D_EINVAL;
+  if (D != MHA_D) return GD4D_EUNSUPPORTED;
+  if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return GD4D_EINVAL;
+  if (!aligned16(q) || !aligned16(k) || (ldq % 4) || (ldk % 4)) return GD4D_EALIGN;
+  if (nops + nops_side > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
+  const bool two = nops_side > 0;
+  if (two)
+    if (int rc = rc_validate(program_side, nops_side, 1)) return rc;
+  if (int rc = rc_validate(program, nops, two ? 2 : 0)) return rc;
+  for (int w = 0; w < 2; ++w)                              // inference chains only (no operation of the training instantiation)
+    for (int i = 0; i < (w ? nops_side : nops); ++i) {
+      const gd4d_chain_op& op = (w ? program_side : program)[i];
+      if (op.kind == GD4D_CHAIN_LN_BWD || op.kind == GD4D_CHAIN_DROPMASK ||
+          (op.kind == GD4D_CHAIN_GEMM && (op.flags & (GD4D_CHAIN_MASK_P2 | GD4D_CHAIN_DROPOUT))) ||
+          ((op.kind == GD4D_CHAIN_LOAD || op.kind == GD4D_CHAIN_ADD || op.kind == GD4D_CHAIN_SMALL_LINEAR) && op.gout))
+        return GD4D_EUNSUPPORTED;
+    }
+  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES;
+  static_assert(sizeof(MhaShared) <= sizeof(float) * RC_BUFS * RC_M * RC_LD, "the attention workgroups use the row buffers' LDS");
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_mha_kernel), (int)lds)) return GD4D_ELAUNCH;
+  const int blocks = (M + RC_M - 1) / RC_M, stride = (blocks + 7) & ~7;
+  ChainProgram prog{};
+  prog.M = M;
+  if (two) {                                               // the side program first, the waiting one last
+    prog.nops = nops_side; prog.nops2 = nops; prog.split = stride;
+    for (int i = 0; i < nops_side; ++i) prog.ops[i] = program_side[i];
+    for (int i = 0; i < nops; ++i) prog.ops[nops_side + i] = program[i];
+  } else {
+    prog.nops = nops; prog.nops2 = 0; prog.split = 0;
+    for (int i = 0; i < nops; ++i) prog.ops[i] = program[i];
+  }
+  MhaRole mr{};
+  mr.p = MhaParams{q, k, v, nullptr, attn_out, nullptr, M, M, 1, H, ldq, ldk, ldv, ldo, 0, scale, nullptr, 0u, 1.f};
+  mr.flags = reinterpret_cast<unsigned*>(flags);
+  mr.err = reinterpret_cast<unsigned*>(errors);
+  mr.hi = H * stride;
+  mr.stride = stride;
+  hipLaunchKernelGGL(row_chain_mha_kernel, dim3(mr.hi + (two ? stride : 0) + blocks), dim3(64 * RC_WAVES), lds,
+                     static_cast<hipStream_t>(stream), prog, mr);
   return check_launch();
 }
 

@@ -196,6 +196,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     ref = reference_points.contiguous()
     pending = None                                       # (reg linears, x of the previous layer, its ref, where the new ref goes)
     pos_late = os.environ.get('GD4D_POS_ENCODER', 'chainb') != 'dual'
+    mha_fused = os.environ.get('GD4D_FUSE_MHA', '0') != '0'      # off: measured 0.5 % slower than the two launches (docs/measurements_r04.md §3)
+    mha_all = os.environ.get('GD4D_FUSE_MHA') == 'all'
+    if mha_fused:
+        mha_flags = torch.zeros(nl, ((q + 15) // 16 + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)   # per layer: a counter per row block; [-1]: waits that gave up
+        keep.append(mha_flags)
     if pos_late:
         blocks = (q + 15) // 16
         flags = torch.zeros(nl, (blocks + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)     # row-block flags per layer; [-1]: waits that gave up
@@ -206,7 +211,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         last = lid + 1 == nl
         slot = lid if return_intermediate else 0
         qh, kh, vh = qkv.split(c, dim=-1)
-        o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
+        # attention core and chain A in one launch (gd4d_row_chain_mha_fwd; GD4D_FUSE_MHA=1, =all: layer 0 too): two graph
+        # boundaries per layer less - but every workgroup of that launch owns the chain's 133 KB of LDS, so the attention
+        # workgroups run one per compute unit, in two rounds: no gain (kept as the record of the attempt, tested)
+        fuse_mha = mha_fused and attn_masks[0] is None and (lid > 0 or mha_all)    # (layer 0 shares the device with the copy)
+        o = torch.empty(q, 1, c, device=dev, dtype=torch.float32) if fuse_mha else ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
 
         x1 = torch.empty(q, c, device=dev, dtype=torch.float32)
         cam = torch.empty(1, q, ncam, device=dev, dtype=torch.float32)
@@ -240,7 +249,9 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             ref = new_ref
         else:
             prog_b = None if pos_late else _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
-        if prog_b is None:                                      # layer 0: the initial reference points need no refinement
+        if fuse_mha:
+            ops.row_chain_mha_fwd(prog_a, prog_b, q, qh, kh, vh, sa.num_heads, mha_flags[lid], mha_flags[lid, -1:], out=o)
+        elif prog_b is None:                                    # layer 0: the initial reference points need no refinement
             ops.row_chain_fwd(prog_a, q)
         elif os.environ.get('GD4D_DEV_SWAP_PROGRAMS') == '1':   # dev: block 0 (the one tools/trace_step.py stamps) runs the second program
             ops.row_chain2_fwd(prog_b, prog_a, q)
@@ -298,6 +309,10 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         torch.cuda.synchronize(dev)
         if int(flags[:, -1].sum().item()) != 0:
             raise RuntimeError('graph-detr4d_amd: a SIGNAL / WAIT hand-off between chain programs timed out')
+    if mha_fused and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(dev)
+        if int(mha_flags[:, -1].sum().item()) != 0:
+            raise RuntimeError('graph-detr4d_amd: a chain waited in vain for the attention workgroups of its launch')
     del keep
     return out_all, ref_all
 

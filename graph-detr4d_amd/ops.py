@@ -1852,6 +1852,30 @@ def row_chain2_fwd(program_a, program_b, m):
     _lib.check(code, 'gd4d_row_chain2_fwd')
 
 
+def row_chain_mha_fwd(program, program_side, m, q, k, v, num_heads, flags, errors=None, out=None):
+    """gd4d_row_chain_mha_fwd: the self-attention core (no mask, batch 1; q / k / v (M, 1, C) slices of the packed in-projection
+    as for mha_core_fwd) and the chain `program` that reads its output, in one launch; program_side (list or None) runs beside
+    both.  out: the attention output (M, 1, C) that program's LOAD names (allocated here when None; returned).  flags: int32
+    zeros, >= ceil(M / 16) rounded up to a multiple of 8."""
+    lib = _lib.load()
+    lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, None)
+    if b != 1 or lq != m or lk != m:
+        raise ValueError('row_chain_mha_fwd: batch 1 and as many keys as rows')
+    if out is None:
+        out = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
+    prog = program
+    a = (ChainOp * len(prog))(*prog)
+    side = program_side or []
+    sb = (ChainOp * len(side))(*side) if side else None
+    code = lib.gd4d_row_chain_mha_fwd(a, len(prog), sb, len(side), int(m), ctypes.c_void_p(q.data_ptr()),
+                                      ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()), _dev(out, 'out'),
+                                      num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, 1.0 / (d ** 0.5),
+                                      _dev(flags, 'flags', torch.int32), None if errors is None else _dev(errors, 'errors', torch.int32),
+                                      _stream())
+    _lib.check(code, 'gd4d_row_chain_mha_fwd')
+    return out
+
+
 def _first_tensor(args):
     for a in args:
         if torch.is_tensor(a):

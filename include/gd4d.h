@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 43
+#define GD4D_ABI_VERSION 44
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -620,6 +620,21 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * happen under that rule) gives up, counts in gout and goes on. */
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
+
+/* gd4d_row_chain_mha_fwd - the decoder's self-attention core (gd4d_mha_core_fwd without mask, batch 1, Lq = Lk = M: mmcv
+ * MultiheadAttention between its in- and out-projection, config detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78) and
+ * the chain that consumes its output in ONE launch: the first workgroups are the attention core's (one per 16 queries and
+ * head), `program` - whose rows of attn_out they write - follows them and starts a row block as soon as that block's H
+ * attention workgroups have reported (same XCD, a counter in its L2; flags: >= ceil(M / 16) rounded up to a multiple of 8
+ * int32 counters, zero before the launch; errors: optional counter of waits that gave up, as WAIT's).  program_side
+ * (optional, nops_side may be 0): an independent program over the same rows that runs beside both from the start (the
+ * previous layer's reg branch + refinement); it may SIGNAL, `program` may WAIT.  Replaces gd4d_mha_core_fwd followed by
+ * gd4d_row_chain2_fwd(program, program_side): two kernel boundaries of a replayed graph (3 - 6 us each against 11 us of
+ * attention) and the side program's excess over chain A.  Inference chains only (no operation of the training set);
+ * results bit-identical to the two launches. */
+int gd4d_row_chain_mha_fwd(const gd4d_chain_op* program, int nops, const gd4d_chain_op* program_side, int nops_side, int M,
+                           const float* q, const float* k, const float* v, float* attn_out, int H, int D, int ldq, int ldk,
+                           int ldv, int ldo, float scale, int32_t* flags, int32_t* errors, void* stream);
 
 /* gd4d_small_linear_layernorm_fwd - y = [ReLU] LN( f(in) W^T + b ) for a Linear with at most 4 inputs: the first stage of
  * position_encoder, Linear(3 or 4 -> 256), LayerNorm, ReLU on inverse_sigmoid(reference points)

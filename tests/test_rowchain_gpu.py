@@ -256,3 +256,51 @@ def test_fused_gemm_forms_equal_their_separate_operations(m):
         with torch.no_grad():                                   # the stacked weight follows an in-place update (version counter)
             lins[1].weight.mul_(1.5)
             lins[2].bias.add_(0.25)
+
+
+@pytest.mark.parametrize('m', [900, 37, 16])
+def test_attention_core_and_its_chain_in_one_launch(m):
+    """gd4d_row_chain_mha_fwd: the attention workgroups and the chain that reads their output in one launch (plus an
+    independent side program) - bit-identical to gd4d_mha_core_fwd followed by the two-program launch; 30 launches back to
+    back over a poisoned output; every row block's counter ends at the head count, no wait gives up; masks / training
+    operations are refused."""
+    from graph_detr4d_amd import _lib, ops
+    torch.manual_seed(m)
+    c, heads = 256, 8
+    g = lambda *s: (torch.randn(*s) * 0.06).to(DEV)        # noqa: E731
+    qkv = torch.randn(m, 1, 3 * c, device=DEV)
+    qh, kh, vh = qkv.split(c, dim=-1)
+    x, pos, xprev = g(m, c), g(m, c), g(m, c)
+    ref = torch.rand(m, 3, device=DEV)
+    w = {k: g(*s) for k, s in dict(o=(c, c), off=(96, c), r1=(c, c), r3=(10, c)).items()}
+    b = {k: g(v.shape[0]) for k, v in w.items()}
+    n0 = _ln(c, 1)
+    blocks = (m + 15) // 16
+
+    def prog_a(o, x1, off):
+        return [ops.chain_load(0, o.view(m, c)), ops.chain_gemm(0, w['o'], b['o'], dst=1, add=x),
+                ops.chain_layernorm(1, n0, dst=2, out=x1, dst2=0, add=pos), ops.chain_gemm(0, w['off'], b['off'], out=off)]
+
+    def side(new_ref):
+        return [ops.chain_load(3, xprev), ops.chain_gemm(3, w['r1'], b['r1'], dst=1, relu=True, exact=True),
+                ops.chain_gemm(1, w['r3'], b['r3'], dst=2, exact=True), ops.chain_refine(2, ref, new_ref)]
+    e = lambda *s: torch.empty(*s, device=DEV)              # noqa: E731
+    o_ref = ops.mha_core_fwd(qh, kh, vh, heads)
+    want = dict(x1=e(m, c), off=e(m, 96), ref=e(m, 3))
+    ops.row_chain2_fwd(prog_a(o_ref, want['x1'], want['off']), side(want['ref']), m)
+    errors = torch.zeros(1, device=DEV, dtype=torch.int32)
+    for with_side in (True, False):
+        for _ in range(30):
+            flags = torch.zeros((blocks + 7) // 8 * 8, device=DEV, dtype=torch.int32)
+            o = torch.full((m, 1, c), float('nan'), device=DEV)
+            got = dict(x1=e(m, c).fill_(float('nan')), off=e(m, 96).fill_(float('nan')), ref=e(m, 3).fill_(float('nan')))
+            ops.row_chain_mha_fwd(prog_a(o, got['x1'], got['off']), side(got['ref']) if with_side else None, m, qh, kh, vh, heads,
+                                  flags, errors, out=o)
+            assert torch.equal(o, o_ref)
+            for k in got:
+                if with_side or k != 'ref':
+                    assert torch.equal(got[k], want[k]), (k, with_side)
+        assert int(errors.item()) == 0
+        assert torch.equal(flags[:blocks], torch.full((blocks,), heads, device=DEV, dtype=torch.int32))
+    with pytest.raises(_lib.Gd4dError):                          # a training-set operation
+        ops.row_chain_mha_fwd([ops.chain_load(0, o.view(m, c), out=got['x1'])], None, m, qh, kh, vh, heads, flags, errors, out=o)
