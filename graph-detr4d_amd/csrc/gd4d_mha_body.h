@@ -17,6 +17,11 @@ struct MhaParams {
   float scale;
   const uint32_t* seed;                              // dropout of the probabilities (training): two words, see mha_dropout.h
   uint32_t drop_thresh; float inv_keep;
+  // pre-split operands (gd4d_mha_core_presplit_fwd; written by the in-projection's epilogue, GD4D_CHAIN_SPLIT_KV; B = 1), bf16, in
+  // the MFMA operand layout itself - a wave's load of a fragment is 1 KB contiguous:
+  const unsigned short* ksp;   // K: [plane hi, lo][head][tile of 16 keys][lane = 16 (c / 8) + key % 16][8 channels 8 (c / 8) ..]
+  const unsigned short* vsp;   // V: [plane][head][step of 32 keys][half = d / 16][lane = 16 g + d % 16][j] <-> key 32 s + 16 (j >> 2) + 4 g + (j & 3)
+  long long ks_plane, vs_plane;   // elements per plane
 };
 
 constexpr int MHA_D = 32;
@@ -73,7 +78,7 @@ struct MhaShared {
 };
 
 // One workgroup (8 waves) = one (16-query tile qblock, head h, batch b); the stores of `out` are the last thing it issues.
-template <int MASK, int AHEAD = 1>
+template <int MASK, int AHEAD = 1, bool PRE = false>
 __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const int qblock, const int h, const int b, MhaShared& sh) {
   float (&s_m)[MHA_WAVES][16] = sh.m;
   float (&s_l)[MHA_WAVES][16] = sh.l;
@@ -104,9 +109,35 @@ __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const i
   // One step of look-ahead (MHA_LOOKAHEAD, default on): q / k / v arrive cold from other XCDs (~2 us per round trip) and a wave
   // has only ~4 steps, so "request, wait, compute" per step was a chain of four exposed round trips; the next step's rows are
   // requested before this step's are consumed.
-  struct StepData { float4 ka[2], kc[2]; float v0[8], v1[8], mk[8]; };
+  // PRE: K and V arrive as the MFMA operands themselves (bf16 hi / lo planes): 8 loads of 16 / 8 bytes per step instead of 4
+  // float4 + 16 dwords, and none of the 112 conversion instructions per step (two thirds of the kernel's splits)
+  struct StepData { float4 ka[2], kc[2]; float v0[8], v1[8], mk[8]; mha_u4 pkh[2], pkl[2], pvh[2], pvl[2]; };
   auto fetch = [&](int kt, StepData& d) {
     const int kbase = min(kt, nsteps - 1) * 32;
+    if (PRE) {
+      const int tiles = (p.Lk + 15) / 16;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {                          // (a tile past the end: the last one again - its scores are -inf)
+        const unsigned short* src = p.ksp + (((size_t)h * tiles + min(kbase / 16 + t, tiles - 1)) * 64 + lane) * 8;
+        d.pkh[t] = *reinterpret_cast<const mha_u4*>(src);
+        d.pkl[t] = *reinterpret_cast<const mha_u4*>(src + p.ks_plane);
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned short* src = p.vsp + ((((size_t)h * nsteps + kbase / 32) * 2 + half) * 64 + lane) * 8;
+        d.pvh[half] = *reinterpret_cast<const mha_u4*>(src);
+        d.pvl[half] = *reinterpret_cast<const mha_u4*>(src + p.vs_plane);
+      }
+      if (MASK) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const size_t mi = mask_row + min(kbase + 16 * (j >> 2) + 4 * g + (j & 3), p.Lk - 1);
+          if (MASK == 1) d.mk[j] = static_cast<const uint8_t*>(p.mask)[mi] ? 1.f : 0.f;
+          else d.mk[j] = static_cast<const float*>(p.mask)[mi];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int krow = min(kbase + 16 * t + qi, p.Lk - 1);
@@ -144,7 +175,8 @@ __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const i
     for (int t = 0; t < 2; ++t) {
       const float kf[8] = {ka[t].x, ka[t].y, ka[t].z, ka[t].w, kc[t].x, kc[t].y, kc[t].z, kc[t].w};
       mha_u4 kh, kl;
-      mha_split8(kf, kh, kl);
+      if (PRE) { kh = d.pkh[t]; kl = d.pkl[t]; }
+      else mha_split8(kf, kh, kl);
       const f32x4 st = mha_mfma3(kh, kl, qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int r = 0; r < 4; ++r) {                            // lane (qi, g) reg r <-> key kbase + 16 t + 4 g + r
@@ -176,9 +208,11 @@ __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const i
     // ---- O^T += V^T P^T: A = V^T[d = lane & 15 (+ 16)][k = 8 g + j], B = P^T = this lane's own eight probabilities ----
     mha_u4 ph, pl, vh, vl;
     mha_split8(pr, ph, pl);
-    mha_split8(v0, vh, vl);
+    if (PRE) { vh = d.pvh[0]; vl = d.pvl[0]; }
+    else mha_split8(v0, vh, vl);
     o0 = mha_mfma3(vh, vl, ph, pl, o0);
-    mha_split8(v1, vh, vl);
+    if (PRE) { vh = d.pvh[1]; vl = d.pvl[1]; }
+    else mha_split8(v1, vh, vl);
     o1 = mha_mfma3(vh, vl, ph, pl, o1);
   };
   if (AHEAD > 1) {

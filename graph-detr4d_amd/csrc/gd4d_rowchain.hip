@@ -242,6 +242,9 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   // GD4D_CHAIN_SPLIT_OUT: the N columns go to three global tensors (gout | p2 | p3, each as wide as its row stride) - the
   // three Linears of query + query_pos (camera logits, offsets, attention logits) as ONE operation over their stacked weights.
   const bool src2 = (op.flags & GD4D_CHAIN_SRC2) != 0, split_out = (op.flags & GD4D_CHAIN_SPLIT_OUT) != 0;
+  // GD4D_CHAIN_SPLIT_KV: pass 1 (K) and pass 2 (V) of the packed in-projection also leave as bf16 hi / lo planes (p2: K row-major,
+  // p3: V^T) - the operands gd4d_mha_core_presplit_fwd feeds to its MFMAs without converting anything
+  const bool split_kv = !TRAIN && (op.flags & GD4D_CHAIN_SPLIT_KV) != 0;
   // GD4D_CHAIN_MASK_P2: p2 is not an addend but the OUTPUT a ReLU produced in the forward pass - the result (the gradient at that
   // ReLU's output) passes where it was > 0, times `eps` when that is non-zero (the 1 / (1 - p) of a dropout that followed the ReLU
   // and left its zeros in p2 as well)
@@ -273,7 +276,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
     // global addends p2 (+ p3) of the epilogue - the residual rows a LOAD operation would otherwise park in a buffer first:
     // requested here, consumed after the K loop (their fabric round trip hides under the weight stream)
     float e_add[RC_TILES][4];
-    if (op.p2 && !split_out) {
+    if (op.p2 && !split_out && !split_kv) {
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) {
         const int n = min(n_base + 16 * c + i16, N - 1);
@@ -353,6 +356,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
     for (int c = 0; c < RC_TILES; ++c) {
       const int n = n_base + 16 * c + i16;
       if (n >= N) continue;
+      float kv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * g + r, m = m0 + row;
@@ -362,7 +366,8 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
         if (drop) v = mha_drop_keep(drop_lo, drop_hi, (uint32_t)m * (uint32_t)N + (uint32_t)n, (uint32_t)op.reserved) ? v * op.eps : 0.f;
         if (mask_p2) v = e_add[c][r] > 0.f ? v * mask_scale : 0.f;
         if (op.res >= 0 && !src2) v += bufs[op.res][row][n];
-        if (op.p2 && !split_out && !mask_p2) v += e_add[c][r];
+        if (op.p2 && !split_out && !mask_p2 && !split_kv) v += e_add[c][r];
+        if (split_kv) kv[r] = v;
         if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
         if (split_out) {
           if (m < M) {
@@ -372,8 +377,40 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
                               : const_cast<float*>(op.p3) + (size_t)m * op.ld1 + (n - c2);
             *o = v;
           }
-        } else if (op.gout && m < M) {
+        } else if (op.gout && m < M && !(split_kv && n_base >= RC_COLS * RC_WAVES)) {   // (K and V leave as planes only)
           op.gout[(size_t)m * op.ldg + n] = v;
+        }
+      }
+      if (split_kv && n_base >= RC_COLS * RC_WAVES) {          // (pass-uniform: pass 1 = K, pass 2 = V)
+        const unsigned h01 = rc_cvt_pk_bf16(kv[0], kv[1]), h23 = rc_cvt_pk_bf16(kv[2], kv[3]);
+        const unsigned l01 = rc_cvt_pk_bf16(kv[0] - __uint_as_float(h01 << 16), kv[1] - __uint_as_float(h01 & 0xffff0000u));
+        const unsigned l23 = rc_cvt_pk_bf16(kv[2] - __uint_as_float(h23 << 16), kv[3] - __uint_as_float(h23 & 0xffff0000u));
+        constexpr int C3 = RC_COLS * RC_WAVES;                 // = N / 3
+        const int blk = m0 / RC_M, blocks = (M + RC_M - 1) / RC_M;
+        if (n_base < 2 * C3) {
+          // K: [head][tile = this row block][lane = 16 (c / 8) + key % 16][c % 8] - the A operand of S^T = K Q^T (rows past M too)
+          const int nn = n - C3, hd = nn >> 5, cc = nn & 31;
+          unsigned short* kh = reinterpret_cast<unsigned short*>(const_cast<float*>(op.p2)) +
+                               (((size_t)hd * blocks + blk) * 64 + (cc >> 3) * 16 + 4 * g) * 8 + (cc & 7);
+          unsigned short* kl = kh + op.ld2;
+          const unsigned hh[4] = {h01 & 0xffffu, h01 >> 16, h23 & 0xffffu, h23 >> 16};
+          const unsigned ll[4] = {l01 & 0xffffu, l01 >> 16, l23 & 0xffffu, l23 >> 16};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { kh[r * 8] = (unsigned short)hh[r]; kl[r * 8] = (unsigned short)ll[r]; }
+        } else {
+          // V: [head][step of 32 keys][half = d / 16][lane = 16 g + d % 16][j = 4 (block & 1) + r]: the A operand of O^T = V^T P^T;
+          // the four keys of this lane are one 8-byte store per plane.  An odd last block also zeroes the step's other half
+          // (nobody else writes it; its probabilities are 0 and 0 x anything finite is 0).
+          const int nn = n - 2 * C3, hd = nn >> 5, dd = nn & 31, steps = (blocks + 1) >> 1;
+          unsigned short* vh = reinterpret_cast<unsigned short*>(const_cast<float*>(op.p3)) +
+                               ((((size_t)hd * steps + (blk >> 1)) * 2 + (dd >> 4)) * 64 + 16 * g + (dd & 15)) * 8 + 4 * (blk & 1);
+          unsigned short* vl = vh + op.ld1;
+          *reinterpret_cast<uint2*>(vh) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(vl) = make_uint2(l01, l23);
+          if (blk == blocks - 1 && !(blk & 1)) {
+            *reinterpret_cast<uint2*>(vh + 4) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(vl + 4) = make_uint2(0u, 0u);
+          }
         }
       }
     }
@@ -1082,6 +1119,12 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
         if (op.flags & GD4D_CHAIN_SPLIT_OUT)
           if (!op.gout || !op.p2 || !op.p3 || op.ldg <= 0 || op.ld2 <= 0 || op.ld1 <= 0 || op.ldg + op.ld2 + op.ld1 != op.N)
             return GD4D_EINVAL;
+        if (op.flags & GD4D_CHAIN_SPLIT_KV) {
+          if (op.flags & (GD4D_CHAIN_SPLIT_OUT | GD4D_CHAIN_MASK_P2 | GD4D_CHAIN_DROPOUT | GD4D_CHAIN_RELU | GD4D_CHAIN_SIGMOID)) return GD4D_EINVAL;
+          if (op.N != 3 * RC_COLS * RC_WAVES) return GD4D_EUNSUPPORTED;
+          if (!op.p2 || !op.p3 || op.ld2 <= 0 || op.ld1 <= 0 || (op.ld1 & 7) || (op.ld2 & 7)) return GD4D_EINVAL;
+          if (!aligned16(op.p2) || !aligned16(op.p3)) return GD4D_EALIGN;
+        }
         break;
       case GD4D_CHAIN_HEADGEMM:
         if (!op.p0 || !op.p2 || !op.p3 || op.K <= 0 || op.N <= 0 || op.ld0 <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
@@ -1144,6 +1187,14 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   if (int rc = rc_validate(a, na, nb > 0 ? 1 : 0)) return rc;
   if (nb > 0)
     if (int rc = rc_validate(b, nb, 2)) return rc;
+  for (int w = 0; w < 2; ++w)                              // the K / V planes must hold this launch's row blocks
+    for (int i = 0; i < (w ? nb : na); ++i) {
+      const gd4d_chain_op& op = (w ? b : a)[i];
+      if (op.kind == GD4D_CHAIN_GEMM && (op.flags & GD4D_CHAIN_SPLIT_KV)) {
+        const long long blocks = (M + RC_M - 1) / RC_M, heads = RC_COLS * RC_WAVES / 32;
+        if (op.ld2 < heads * blocks * 512 || op.ld1 < heads * ((blocks + 1) / 2) * 1024) return GD4D_EINVAL;
+      }
+    }
   // the operations only a training step uses (and the stores of LOAD / ADD / SMALL_LINEAR) are compiled into a second
   // instantiation: with them in, the inference step's chains ran 10 % slower (221 against 163 registers, longer epilogues)
   bool train = false;

@@ -208,6 +208,15 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_bf16x3_kernel(const M
   trace_mark(g_trace_mha, 0x82ull);
 }
 
+// ... with K and V as pre-split bf16 planes (written by the in-projection: GD4D_CHAIN_SPLIT_KV); batch 1
+template <int MASK>
+__global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_presplit_kernel(const MhaParams p) {
+  trace_mark(g_trace_mha, 2ull);
+  __shared__ MhaShared sh;
+  mha_core_bf16x3_body<MASK, 1, true>(p, blockIdx.x, blockIdx.y, 0, sh);
+  trace_mark(g_trace_mha, 0x82ull);
+}
+
 }  // namespace gd4d
 
 extern "C" void gd4d_trace_set_mha(unsigned long long* p) { gd4d::trace_set_mha(p); }
@@ -241,5 +250,26 @@ extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v,
     else if (mask_kind == 1) hipLaunchKernelGGL((mha_core_kernel<false, 1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((mha_core_kernel<false, 2>), grid, block, 0, st, p);
   }
+  return check_launch();
+}
+
+extern "C" int gd4d_mha_core_presplit_fwd(const float* q, const void* k_planes, const void* v_planes, float* out, int L, int H, int D,
+                                          int ldq, int ldo, long long k_plane_stride, long long v_plane_stride, const void* mask,
+                                          int mask_kind, float scale, void* stream) {
+  using namespace gd4d;
+  if (!q || !k_planes || !v_planes || !out || L <= 0 || H <= 0) return GD4D_EINVAL;
+  if (D != MHA_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
+  const long long tiles = (L + 15) / 16, steps = (L + 31) / 32;
+  if (ldq < H * D || ldo < H * D || k_plane_stride < H * tiles * 512 || v_plane_stride < H * steps * 1024 ||
+      (k_plane_stride & 7) || (v_plane_stride & 7))
+    return GD4D_EINVAL;
+  if (!aligned16(q) || (ldq % 4) || !aligned16(k_planes) || !aligned16(v_planes)) return GD4D_EALIGN;
+  MhaParams p{q, nullptr, nullptr, mask, out, nullptr, L, L, 1, H, ldq, 0, 0, ldo, mask_kind, scale, nullptr, 0u, 1.f,
+              static_cast<const unsigned short*>(k_planes), static_cast<const unsigned short*>(v_planes), k_plane_stride, v_plane_stride};
+  const dim3 grid((L + 15) / 16, H, 1), block(64 * MHA_WAVES);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mask_kind == 0) hipLaunchKernelGGL(mha_core_presplit_kernel<0>, grid, block, 0, st, p);
+  else if (mask_kind == 1) hipLaunchKernelGGL(mha_core_presplit_kernel<1>, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(mha_core_presplit_kernel<2>, grid, block, 0, st, p);
   return check_launch();
 }

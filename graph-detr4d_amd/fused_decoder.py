@@ -81,15 +81,29 @@ def applicable(decoder, query, value, reference_points, reg_branches, attn_masks
     return True
 
 
-def _in_proj_ops(sa, x_pos_buf, x_buf, qkv):
+def _in_proj_ops(sa, x_pos_buf, x_buf, qkv, kv=None):
     """The packed in-projection: q, k from (x + pos), v from x (mmcv MultiheadAttention semantics) - one GEMM operation whose
-    last 256 columns read the other buffer (GD4D_CHAIN_FUSE_GEMMS=0: two operations; bit-identical)."""
+    last 256 columns read the other buffer (GD4D_CHAIN_FUSE_GEMMS=0: two operations; bit-identical).  kv (ops.KVPlanes): K and
+    V also leave as the attention core's split-bf16 operands (_kv_planes decides)."""
     c = sa.embed_dims
     w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
     if c % 128 == 0 and _fuse_gemms():
-        return [ops.chain_gemm_two_sources(x_pos_buf, x_buf, 2 * c, w, b, qkv)]
+        return [ops.chain_gemm_two_sources(x_pos_buf, x_buf, 2 * c, w, b, qkv, kv=kv)]
     return [ops.chain_gemm(x_pos_buf, w[:2 * c], b[:2 * c], out=qkv[..., :2 * c]),
             ops.chain_gemm(x_buf, w[2 * c:], b[2 * c:], out=qkv[..., 2 * c:])]
+
+
+def _kv_planes(layers, q, c, attn_mask, dev):
+    """The K / V planes of run_single's attention launches, or None: one pair for all layers (a layer's attention core has read
+    them before the in-projection of the next writes them - one stream).  Needs the one-operation in-projection, 256 channels
+    (H-DETR's 2-D mask rides along)."""
+    if os.environ.get('GD4D_MHA_PRESPLIT', '1') == '0' or c != 256 or not _fuse_gemms() or (attn_mask is not None and attn_mask.dim() != 2):
+        return None
+    if os.environ.get('GD4D_FUSE_MHA', '0') != '0' or os.environ.get('GD4D_MHA_FP32') == '1':
+        return None
+    if layers[0].attentions[0].num_heads != 8:
+        return None
+    return ops.KVPlanes(q, c, dev, heads=8)
 
 
 def _fuse_gemms():
@@ -189,7 +203,8 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     pos = query_pos[:, 0, :]
     keep = []
     qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
-    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1)), q)
+    kv = _kv_planes(layers, q, c, attn_masks[0], dev)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1), kv), q)
     n_out = nl if return_intermediate else 1
     out_all = torch.empty(n_out, q, 1, c, device=dev, dtype=torch.float32)
     ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
@@ -215,7 +230,12 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         # boundaries per layer less - but every workgroup of that launch owns the chain's 133 KB of LDS, so the attention
         # workgroups run one per compute unit, in two rounds: no gain (kept as the record of the attempt, tested)
         fuse_mha = mha_fused and attn_masks[0] is None and (lid > 0 or mha_all)    # (layer 0 shares the device with the copy)
-        o = torch.empty(q, 1, c, device=dev, dtype=torch.float32) if fuse_mha else ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
+        if fuse_mha:
+            o = torch.empty(q, 1, c, device=dev, dtype=torch.float32)
+        elif kv is not None:
+            o = ops.mha_core_presplit_fwd(qh, kv, sa.num_heads, attn_masks[0])
+        else:
+            o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
 
         x1 = torch.empty(q, c, device=dev, dtype=torch.float32)
         cam = torch.empty(1, q, ncam, device=dev, dtype=torch.float32)
@@ -278,7 +298,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         if not last:
             qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
             prog += [ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c), dst2=0, add=pos)] + \
-                _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1))
+                _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1), kv)
         else:
             prog.append(ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c)))
         pending = None

@@ -1507,6 +1507,7 @@ class ChainOp(ctypes.Structure):
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 CHAIN_LN_BWD, CHAIN_DROPMASK = 10, 11
 CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT, CHAIN_MASK_P2, CHAIN_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128
+CHAIN_SPLIT_KV = 256
 
 
 def _rows(t, name):
@@ -1712,13 +1713,44 @@ def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, ou
                    ld2=ld2, ld1=ld3, p0=img, p1=None if bias is None else bias.data_ptr(), p2=p2, p3=p3, gout=g)
 
 
-def chain_gemm_two_sources(src, src2, split, weight, bias, out):
+class KVPlanes:
+    """The attention core's K / V operands as split-bf16 planes in its MFMA fragment layout (GD4D_CHAIN_SPLIT_KV ->
+    gd4d_mha_core_presplit_fwd; include/gd4d.h has the layouts): k (2, H, tiles, 64, 8), v (2, H, steps, 2, 64, 8) bf16."""
+
+    def __init__(self, m, c, device, heads=8):
+        self.m, self.c, self.heads = int(m), int(c), int(heads)
+        self.tiles, self.steps = (self.m + 15) // 16, (self.m + 31) // 32
+        self.k = torch.empty(2, heads, self.tiles, 64, 8, device=device, dtype=torch.bfloat16)
+        self.v = torch.empty(2, heads, self.steps, 2, 64, 8, device=device, dtype=torch.bfloat16)
+
+    def k_rows(self):
+        """(2, tiles * 16, C): the planes as plain rows (tests)."""
+        h, t = self.heads, self.tiles
+        return self.k.view(2, h, t, 4, 16, 8).permute(0, 2, 4, 1, 3, 5).reshape(2, t * 16, h * 32)
+
+    def v_rows(self):
+        """(2, steps * 32, C): the planes as plain rows (tests)."""
+        h, s = self.heads, self.steps
+        # [plane][h][s][half][g][qi][t][r]  ->  key = 32 s + 16 t + 4 g + r, channel = 32 h + 16 half + qi
+        return self.v.view(2, h, s, 2, 4, 16, 2, 4).permute(0, 2, 6, 4, 7, 1, 3, 5).reshape(2, s * 32, h * 32)
+
+
+def chain_gemm_two_sources(src, src2, split, weight, bias, out, kv=None):
     """One GEMM over a stacked weight (N, K) whose output columns [0, split) are computed from buf[src] and [split, N) from
-    buf[src2] (split a multiple of 256): nn.MultiheadAttention's packed in-projection with q, k from x + pos and v from x."""
+    buf[src2] (split a multiple of 256): nn.MultiheadAttention's packed in-projection with q, k from x + pos and v from x.
+    kv (KVPlanes, N = 768): the K and V columns are written as the attention core's split-bf16 operands INSTEAD of fp32 (out
+    receives the Q columns only)."""
     g, ldg = _rows(out, 'out')
     img, n, k = _image_of(weight)
-    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=k, N=n, flags=CHAIN_SRC2, ld0=int(split),
-                   ldg=ldg, p0=img, p1=None if bias is None else bias.data_ptr(), gout=g)
+    op = ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=k, N=n, flags=CHAIN_SRC2, ld0=int(split),
+                 ldg=ldg, p0=img, p1=None if bias is None else bias.data_ptr(), gout=g)
+    if kv is not None:
+        if n != 3 * kv.c or kv.c != 256 or kv.heads != 8:
+            raise ValueError('kv planes: the packed in-projection of 256 channels, 8 heads')
+        op.flags |= CHAIN_SPLIT_KV
+        op.p2, op.ld2 = kv.k.data_ptr(), kv.k[0].numel()
+        op.p3, op.ld1 = kv.v.data_ptr(), kv.v[0].numel()
+    return op
 
 
 _STACKED = {}
@@ -1850,6 +1882,25 @@ def row_chain2_fwd(program_a, program_b, m):
     b = (ChainOp * len(program_b))(*program_b)
     code = lib.gd4d_row_chain2_fwd(a, len(program_a), b, len(program_b), int(m), _stream())
     _lib.check(code, 'gd4d_row_chain2_fwd')
+
+
+def mha_core_presplit_fwd(q, kv, num_heads, attn_mask=None):
+    """gd4d_mha_core_presplit_fwd: the self-attention core (batch 1) on K / V planes a chain GEMM wrote (KVPlanes).
+    q (M, 1, C), attn_mask as for mha_core_fwd.  Returns (M, 1, C); bit-identical to mha_core_fwd on the fp32 rows."""
+    lib = _lib.load()
+    lq, b, c = q.shape
+    _, _, _, _, _, _, kind, mptr, keep = _mha_args(q, q, q, num_heads, attn_mask)
+    if b != 1 or lq != kv.m or c != kv.c or num_heads != kv.heads:
+        raise ValueError('mha_core_presplit_fwd: batch 1, the planes of these rows')
+    if not q.is_cuda or q.dtype != torch.float32 or q.stride(2) != 1:
+        raise _lib.Gd4dError('q must be a float32 GPU tensor with unit channel stride')
+    d = c // num_heads
+    out = torch.empty(lq, 1, c, device=q.device, dtype=torch.float32)
+    code = lib.gd4d_mha_core_presplit_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(kv.k.data_ptr()),
+                                          ctypes.c_void_p(kv.v.data_ptr()), _dev(out, 'out'), lq, num_heads, d, q.stride(0), c,
+                                          kv.k[0].numel(), kv.v[0].numel(), mptr, kind, 1.0 / (d ** 0.5), _stream())
+    _lib.check(code, 'gd4d_mha_core_presplit_fwd')
+    return out
 
 
 def row_chain_mha_fwd(program, program_side, m, q, k, v, num_heads, flags, errors=None, out=None):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 44
+#define GD4D_ABI_VERSION 45
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -568,6 +568,16 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
 #define GD4D_CHAIN_DROPOUT 128      /* GEMM (training, modules in train mode): nn.Dropout on the output - after bias / activation, before
                                        the residuals: element (m, n) is kept iff gd4d_mha_dropout.h's hash of (the 64-bit seed at p3,
                                        m N + n) >= reserved (= round(p 2^32)); kept elements are multiplied by eps = 1 / (1 - p) */
+#define GD4D_CHAIN_SPLIT_KV 256      /* GEMM with N = 768 (nn.MultiheadAttention's packed in-projection, C = 256, 8 heads of 32): gout
+                                       receives the Q columns [0, 256) only; the K columns [256, 512) and the V columns [512, 768) leave
+                                       as the split-bf16 OPERANDS of the attention core (x = hi + lo: the split gd4d_mha_core_fwd makes of every K / V row once per
+                                       16-query tile, i.e. 57 times), in its MFMA fragment layout (a wave's load = 1 KB contiguous):
+                                       p2 = K, bf16 [head][tile of 16 keys][lane = 16 (c / 8) + key % 16][c % 8] (c = channel within the
+                                       head), hi plane then lo plane `ld2` elements further (ld2 >= 8 ceil(M / 16) 512);
+                                       p3 = V, bf16 [head][step of 32 keys][d / 16][lane = 16 g + d % 16][j] with key = 32 step +
+                                       16 (j >> 2) + 4 g + (j & 3), hi plane then lo plane `ld1` elements further (ld1 >= 8
+                                       ceil(M / 32) 1024).  Rows past M of the last block are written too (finite).  p2 / p3 are
+                                       outputs, not addends.  Read by gd4d_mha_core_presplit_fwd */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
@@ -620,6 +630,16 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * happen under that rule) gives up, counts in gout and goes on. */
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
+
+/* gd4d_mha_core_presplit_fwd - gd4d_mha_core_fwd (batch 1, Lq = Lk = L, no dropout; mask / mask_kind as there) with K and V handed over as the
+ * split-bf16 operands of its MFMAs instead of fp32 rows: the two plane pairs a GEMM operation with GD4D_CHAIN_SPLIT_KV writes
+ * beside the fp32 in-projection (layouts there; k_plane_stride / v_plane_stride = elements from the hi to the lo plane).  The
+ * kernel converted every K / V row once per 16-query tile (57 times at 900 queries: 112 of its 313 vector instructions per 32
+ * keys) and fetched V with 16 dword loads per step; here a step is eight 16-byte loads, each 1 KB contiguous per wave.
+ * Results bit-identical to gd4d_mha_core_fwd on the same q, k, v. */
+int gd4d_mha_core_presplit_fwd(const float* q, const void* k_planes, const void* v_planes, float* out, int L, int H, int D,
+                               int ldq, int ldo, long long k_plane_stride, long long v_plane_stride, const void* mask,
+                               int mask_kind, float scale, void* stream);
 
 /* gd4d_row_chain_mha_fwd - the decoder's self-attention core (gd4d_mha_core_fwd without mask, batch 1, Lq = Lk = M: mmcv
  * MultiheadAttention between its in- and out-projection, config detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78) and

@@ -133,7 +133,7 @@ def test_transformer_decoder(name):
                 dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0', GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux', GD4D_REG_ON_AUX='0'),
                 dict(GD4D_COPY_CUS='0'), dict(GD4D_POS_ENCODER='dual'), dict(GD4D_PLAN='pairs'),
                 dict(GD4D_CHAIN_FUSE_GEMMS='0'), dict(GD4D_CHAIN_FUSE_GEMMS='0', GD4D_PLAN='pairs', GD4D_MHA_FP32='0'),
-                dict(GD4D_POS_ENCODER='dual', GD4D_PLAN='pairs'), dict(GD4D_FUSE_MHA='1'), dict(GD4D_FUSE_MHA='all', GD4D_POS_ENCODER='dual')):
+                dict(GD4D_POS_ENCODER='dual', GD4D_PLAN='pairs'), dict(GD4D_FUSE_MHA='1'), dict(GD4D_FUSE_MHA='all', GD4D_POS_ENCODER='dual'), dict(GD4D_MHA_PRESPLIT='0')):
         s2, i2, r2 = rerun(env)
         assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
     # value_proj of the aggregates: in the gather's epilogue (default, exact fp32), as its own launch (exact fp32 MFMA), or

@@ -304,3 +304,43 @@ def test_attention_core_and_its_chain_in_one_launch(m):
         assert torch.equal(flags[:blocks], torch.full((blocks,), heads, device=DEV, dtype=torch.int32))
     with pytest.raises(_lib.Gd4dError):                          # a training-set operation
         ops.row_chain_mha_fwd([ops.chain_load(0, o.view(m, c), out=got['x1'])], None, m, qh, kh, vh, heads, flags, errors, out=o)
+
+
+@pytest.mark.parametrize('m', [900, 37, 16, 929])
+def test_in_projection_writes_the_attention_cores_split_operands(m):
+    """GD4D_CHAIN_SPLIT_KV + gd4d_mha_core_presplit_fwd: the packed in-projection also writes K (row-major) and V^T as bf16 hi / lo
+    planes - hi = bf16(x), lo = bf16(x - hi), bit for bit what torch's round-to-nearest-even conversion gives on the fp32 output -
+    and the attention core on those planes equals gd4d_mha_core_fwd on the fp32 rows bit for bit (poisoned planes first: every
+    element a tile reads was written, incl. the rows past M of the last block)."""
+    from graph_detr4d_amd import _lib, ops
+    torch.manual_seed(m)
+    c, heads = 256, 8
+    x, pos = torch.randn(m, c, device=DEV), torch.randn(m, c, device=DEV)
+    w, b = torch.randn(3 * c, c, device=DEV) * 0.08, torch.randn(3 * c, device=DEV) * 0.2
+    qkv_ref = torch.empty(m, 1, 3 * c, device=DEV)
+    prog = lambda out, kv: [ops.chain_load(0, x, pos), ops.chain_load(1, x), ops.chain_gemm_two_sources(0, 1, 2 * c, w, b, out.view(m, -1), kv=kv)]  # noqa: E731
+    ops.row_chain_fwd(prog(qkv_ref, None), m)
+    kv = ops.KVPlanes(m, c, DEV)
+    kv.k.view(torch.int16).fill_(0x7fc0)                    # bf16 NaN
+    kv.v.view(torch.int16).fill_(0x7fc0)
+    qkv = torch.full((m, 1, 3 * c), 7.0, device=DEV)
+    ops.row_chain_fwd(prog(qkv, kv), m)
+    assert torch.equal(qkv[..., :c], qkv_ref[..., :c]) and bool((qkv[..., c:] == 7.0).all())    # fp32: the Q columns only
+    kf, vf = qkv_ref[:, 0, c:2 * c], qkv_ref[:, 0, 2 * c:]
+    for planes, ref in ((kv.k_rows(), kf), (kv.v_rows(), vf)):
+        hi = ref.to(torch.bfloat16)
+        assert torch.equal(planes[0, :m], hi) and torch.equal(planes[1, :m], (ref - hi.float()).to(torch.bfloat16))
+        assert bool(torch.isfinite(planes.float()).all())    # the filler keys of the last block / step
+    qh, kh, vh = qkv_ref.split(c, dim=-1)
+    want = ops.mha_core_fwd(qh, kh, vh, heads)
+    got = ops.mha_core_presplit_fwd(qkv[..., :c], kv, heads)
+    assert torch.equal(got, want)
+    blocked = torch.rand(m, m, device=DEV) < 0.3                 # H-DETR's kind of mask (bool), and an additive one
+    blocked.fill_diagonal_(False)
+    for mask in (blocked, torch.randn(m, m, device=DEV)):
+        assert torch.equal(ops.mha_core_presplit_fwd(qkv[..., :c], kv, heads, mask), ops.mha_core_fwd(qh, kh, vh, heads, mask))
+    with pytest.raises(_lib.Gd4dError):                          # planes only beside the whole 768-column projection
+        op = ops.chain_gemm(0, w[:c], b[:c], out=qkv_ref.view(m, -1)[:, :c])
+        op.flags |= ops.CHAIN_SPLIT_KV
+        op.p2, op.p3, op.ld1, op.ld2 = kv.k.data_ptr(), kv.v.data_ptr(), kv.v[0].numel(), kv.k[0].numel()
+        ops.row_chain_fwd([ops.chain_load(0, x), op], m)
