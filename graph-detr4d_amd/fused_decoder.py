@@ -188,7 +188,16 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
 
         attention core -> [chain A | reg(l-1), refine] -> plan -> gather -> [chain B' | position_encoder(l)]
 
-    GD4D_POS_ENCODER=dual keeps round 3's schedule (bit-identical results, tested)."""
+    GD4D_POS_ENCODER=chaina swaps the two side programs (measured: no gain, tools/r04_run64.sh):
+
+        attention core -> [chain A | position_encoder(l)] -> plan -> gather -> [chain B' | reg(l), refine]
+
+    position_encoder reads the refined points from global memory (written by the launch before), no hand-off; the reg branch
+    WAITs for chain B' to SIGNAL that its rows of the layer's output are stored and runs beside the next layer's in-projection:
+    the dual launch 19.0 -> 14.6 us, chain B's launch 51 -> 54.7 us (the reg branch outlasts the in-projection by 6 us, and chain
+    B' itself is no faster without its WAIT: its first 14 us are cold weight images and rows, not position_encoder).
+
+    GD4D_POS_ENCODER=dual keeps round 3's schedule (all three bit-identical, tested)."""
     q, _, c = query.shape
     dev = query.device
     layers = list(decoder.layers)
@@ -210,13 +219,15 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
     ref = reference_points.contiguous()
     pending = None                                       # (reg linears, x of the previous layer, its ref, where the new ref goes)
-    pos_late = os.environ.get('GD4D_POS_ENCODER', 'chainb') != 'dual'
+    pos_mode = os.environ.get('GD4D_POS_ENCODER', 'chainb')
+    pos_late = pos_mode not in ('chaina', 'dual')         # the default: [chain A | reg branch], [chain B' | position_encoder]
+    pos_a = pos_mode == 'chaina'                          # [chain A | position_encoder], [chain B' | reg branch]
     mha_fused = os.environ.get('GD4D_FUSE_MHA', '0') != '0'      # off: measured 0.5 % slower than the two launches (docs/measurements_r04.md §3)
     mha_all = os.environ.get('GD4D_FUSE_MHA') == 'all'
     if mha_fused:
         mha_flags = torch.zeros(nl, ((q + 15) // 16 + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)   # per layer: a counter per row block; [-1]: waits that gave up
         keep.append(mha_flags)
-    if pos_late:
+    if pos_late or pos_a:
         blocks = (q + 15) // 16
         flags = torch.zeros(nl, (blocks + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)     # row-block flags per layer; [-1]: waits that gave up
         keep.append(flags)
@@ -255,7 +266,9 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                        ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
                        ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
         pos_feat = torch.empty(1, q, c, device=dev, dtype=torch.float32)
-        if pending is not None:
+        if pos_a:                                              # the refined points are in global memory since chain B' of the layer before
+            prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
+        elif pending is not None:
             lins, x_prev, ref_prev, new_ref = pending
             prog_b, src, tmp = [ops.chain_load(3, x_prev)], 3, (1, 2)
             for i, lin in enumerate(lins):
@@ -297,15 +310,28 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                 ops.chain_gemm(0, ffn.layers[1].weight, ffn.layers[1].bias, dst=1, res=2)]
         if not last:
             qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
-            prog += [ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c), dst2=0, add=pos)] + \
-                _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1), kv)
+            prog.append(ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c), dst2=0, add=pos))
+            x3_stored = len(prog)                        # operations of chain B' up to the one that stores the layer's output
+            prog += _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1), kv)
         else:
             prog.append(ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c)))
         pending = None
+        tail = None
         if reg_branches is not None:
             lins = _plain_reg_branch(reg_branches[lid], c)
             new_ref = ref_all[slot]
-            if last:                                     # nothing follows: the last refinement closes chain B'
+            if pos_a and not last:
+                # reg branch + refinement as the launch's second program, beside the next layer's in-projection: chain B'
+                # SIGNALs once its rows of the layer's output are stored (the signalling program goes first)
+                tail, src, tmp = [ops.chain_wait(flags[lid], flags[lid, -1:]), ops.chain_load(3, x3.view(q, c))], 3, (1, 2)
+                for i, lin in enumerate(lins):
+                    tail.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
+                    src = tmp[i % 2]
+                tail.append(ops.chain_refine(src, ref, new_ref))
+                prog = prog[:x3_stored] + [ops.chain_signal(flags[lid])] + prog[x3_stored:]
+                keep.append(ref)
+                ref_next = new_ref
+            elif last:                                   # nothing follows: the last refinement closes chain B'
                 src, tmp = 3, (1, 2)
                 for i, lin in enumerate(lins):
                     prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
@@ -315,7 +341,10 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                 pending = (lins, x3.view(q, c), ref, new_ref)
         elif return_intermediate or last:
             ref_all[slot].copy_(ref)
-        if pos_late:
+        if tail is not None:
+            ops.row_chain2_fwd(prog, tail, q)
+            ref = ref_next
+        elif pos_late:
             # position_encoder(l) on the refined points (in global memory since the dual launch), beside chain B'.  The
             # SIGNALling program goes FIRST: its workgroups are dispatched before the waiting ones (gd4d.h: no deadlock however
             # many requests are in flight).
@@ -324,7 +353,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]
         x = x3.view(q, c)
-    if pos_late and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
+    if (pos_late or pos_a) and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
         # debugging aid: a WAIT that gave up (~0.2 s unanswered) counts in the last word of its layer's flag row
         torch.cuda.synchronize(dev)
         if int(flags[:, -1].sum().item()) != 0:

@@ -131,7 +131,7 @@ def test_transformer_decoder(name):
     #  GD4D_SCHEDULE=aux is the three-stream schedule of the same kernels)
     for env in (dict(GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux'), dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0'),
                 dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0', GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux', GD4D_REG_ON_AUX='0'),
-                dict(GD4D_COPY_CUS='0'), dict(GD4D_POS_ENCODER='dual'), dict(GD4D_PLAN='pairs'),
+                dict(GD4D_COPY_CUS='0'), dict(GD4D_POS_ENCODER='dual'), dict(GD4D_POS_ENCODER='chaina'), dict(GD4D_POS_ENCODER='chaina', GD4D_FUSE_MHA='1'), dict(GD4D_PLAN='pairs'),
                 dict(GD4D_CHAIN_FUSE_GEMMS='0'), dict(GD4D_CHAIN_FUSE_GEMMS='0', GD4D_PLAN='pairs', GD4D_MHA_FP32='0'),
                 dict(GD4D_POS_ENCODER='dual', GD4D_PLAN='pairs'), dict(GD4D_FUSE_MHA='1'), dict(GD4D_FUSE_MHA='all', GD4D_POS_ENCODER='dual'), dict(GD4D_MHA_PRESPLIT='0')):
         s2, i2, r2 = rerun(env)
