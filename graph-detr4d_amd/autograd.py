@@ -116,15 +116,29 @@ class RawPyramid:
         side.wait_event(ev)
         self._forked = True
 
-    def count(self, layer, plan):
-        """Forward pass: hand the records of `plan` their slots (side stream)."""
-        if not self.needs_grad:
-            return
+    def _sink_for(self, layer, plan):
         if self.sink is None:
             self.sink = ops.PyramidGrad(self.pyramid, 0, plan.b, plan.q, plan.num_heads)
         if (plan.b, plan.num_heads) != (self.sink.b, self.sink.hh) or self.layer_q[layer] != plan.q:
             raise ops._lib.Gd4dError(f'RawPyramid: layer {layer} registered with {self.layer_q[layer]} queries hands in a plan of '
                                      f'(B, Q, Hh) = ({plan.b}, {plan.q}, {plan.num_heads}); the sink has B = {self.sink.b}, Hh = {self.sink.hh}')
+        return self.sink
+
+    def count_with_gather(self, layer, plan):
+        """Forward pass on ONE stream: the records' slots are handed out by the forward gather's launch
+        (ops.cross_attn_agg_sliced_fwd(count=...)).  Returns the aggregates; None when the plan / pyramid is not of the kind
+        that launch takes (count() + the gather then)."""
+        if (not self.needs_grad or self.side is not self.main or plan.items or plan.items_buf is None or plan.stage
+                or plan.num_heads != 8 or len(self.pyramid.level_hw) != 4 or self.pyramid.dtype != torch.float32
+                or os.environ.get('GD4D_TRAIN_COUNT', 'gather') != 'gather'):
+            return None
+        return ops.cross_attn_agg_sliced_fwd(plan, count=(self._sink_for(layer, plan), layer))
+
+    def count(self, layer, plan):
+        """Forward pass: hand the records of `plan` their slots (side stream)."""
+        if not self.needs_grad:
+            return
+        self._sink_for(layer, plan)
         self._fork()                                 # the plan was written on the main stream
         with torch.cuda.stream(self.side):
             self.sink.add_layer(layer, plan)

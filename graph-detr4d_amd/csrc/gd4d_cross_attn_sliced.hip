@@ -31,6 +31,7 @@
 #include "gd4d_common.h"
 #include "gd4d_cross_attn_shared.h"
 #include "gd4d_cross_attn_sliced.h"
+#include "gd4d_pyramid_count.h"
 
 namespace gd4d {
 
@@ -688,6 +689,35 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_kernel(cons
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
+// The forward gather of a TRAINING step and the first step of the pyramid-gradient bookkeeping (gd4d_pyramid_count.h: a slot per
+// record, one returning atomic per group of lanes that share a chunk) in ONE launch.  Both read the plan only; the count lives on
+// L2 atomic round trips (45 us per layer by itself), the gather on the fabric: one after the other they took 135 + 45 us.  Every
+// (every + 1)-th group of 8 workgroups counts - 8 (position, head) waves per workgroup, while count groups remain -, the others
+// are the gather's, renumbered (a multiple of 8 leaves: a workgroup keeps its XCD and the walk its order).
+struct CountArgs {
+  const int* hdr;
+  const uint2* pair;
+  int* count;
+  uint2* slots;
+  PgChunks g;
+  int cap_t, BQ, groups, every;    // groups = count workgroups / 8 (rounded up); one count group after `every` gather groups
+};
+
+template <int HH, int LT, typename VT, int OCC>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_count_kernel(const ItemsParams ip, const CountArgs ca) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  const int grp = blockIdx.x >> 3, period = ca.every + 1;
+  const int k = grp / period;
+  if (grp - k * period == ca.every && k < ca.groups) {
+    pyramid_grad_count_body(ca.hdr, ca.pair, ca.cap_t, HH, ca.BQ, ca.g, ca.count, ca.slots,
+                            (k * 8 + (int)(blockIdx.x & 7)) * HH + (int)(threadIdx.x >> 6));
+    return;
+  }
+  int pos, sl;
+  if (!sliced_walk(ip.s, (int)blockIdx.x - 8 * min(k, ca.groups), pos, sl)) return;
+  cross_attn_agg_items_body<HH, LT, VT, 0, false, 0>(ip, pos, sl, s_raw);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // NCHW levels -> slice-planar copy (8, R, S, 32): the reference's flatten / transpose / cat (:264-276) with the channel
 // axis cut into 8 planes.  One workgroup = 32 pixels x 256 channels of one (camera row, level), turned through LDS; a
@@ -1012,10 +1042,20 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
 
 namespace gd4d {
 template <int HH, typename VT>
-static int launch_items(const ItemsParams& ip, int L, bool wide, int stage_lo, hipStream_t s) {
+static int launch_items(const ItemsParams& ip, int L, bool wide, int stage_lo, hipStream_t s, CountArgs* ca = nullptr) {
   const SlicedParams& p = ip.s;
   const size_t lds = (size_t)HH * 4 * 8 * 80 + (size_t)ip.stage_cap * 128;   // [HH][CH][8][GP] (+ the stage)
   const dim3 grid(8 * ((p.per_xcd + p.blk - 1) / p.blk) * p.blk * p.slice_n);
+  if (ca) {                                            // gather + record count in one launch (training forward)
+    if (HH != 8 || L != 4 || sizeof(VT) != 4 || wide || stage_lo) return GD4D_EUNSUPPORTED;
+    const int wgs = (ca->BQ * HH + HH - 1) / HH;       // a count workgroup = HH (position, head) waves
+    ca->groups = (wgs + 7) / 8;
+    const int ggroups = (int)(grid.x / 8);
+    ca->every = ggroups / ca->groups;
+    if (ca->every < 1) return GD4D_EUNSUPPORTED;
+    hipLaunchKernelGGL((cross_attn_agg_items_count_kernel<8, 4, float, 6>), dim3(grid.x + 8 * ca->groups), dim3(64 * 8), lds, s, ip, *ca);
+    return check_launch();
+  }
   auto go = [&](auto kern) -> int {
     if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(64 * HH), lds, s, ip);
@@ -1060,10 +1100,10 @@ static int launch_items(const ItemsParams& ip, int L, bool wide, int stage_lo, h
 }
 }  // namespace gd4d
 
-extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
-                                             int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
-                                             float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                                             const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream) {
+static int items_fwd_impl(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                         int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
+                         float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                         const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream, gd4d::CountArgs* ca) {
   using namespace gd4d;
   if (stage != 0 && stage != 2 && stage != 3) return GD4D_EINVAL;
   ItemsParams ip{};
@@ -1108,11 +1148,43 @@ extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, cons
 #endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
+  if (ca) return (Hh == 8 && !bf16) ? launch_items<8, float>(ip, L, wide, stage, s, ca) : GD4D_EUNSUPPORTED;
   switch (Hh) {
     case 4: return bf16 ? launch_items<4, uint16_t>(ip, L, wide, stage, s) : launch_items<4, float>(ip, L, wide, stage, s);
     case 8: return bf16 ? launch_items<8, uint16_t>(ip, L, wide, stage, s) : launch_items<8, float>(ip, L, wide, stage, s);
     default: return bf16 ? launch_items<16, uint16_t>(ip, L, wide, stage, s) : launch_items<16, float>(ip, L, wide, stage, s);
   }
+}
+
+extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                             int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
+                                             float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                             const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream) {
+  return items_fwd_impl(level_ptrs, level_hw, cam_stride_bytes, pix_stride_bytes, slice_stride_bytes, plan, agg, wsum, B, N, Q, Hh, C,
+                        L, P, feats_dtype, query_order, slice_lo, slice_n, stage, stream, nullptr);
+}
+
+extern "C" int gd4d_cross_attn_agg_items_count_fwd(const void* const* level_ptrs, const int32_t* level_hw,
+                                                   const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
+                                                   int64_t slice_stride_bytes, const void* plan_items, float* agg, float* wsum, int B,
+                                                   int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                                   const int32_t* query_order, const void* plan_pairs, int32_t* count, void* slots,
+                                                   size_t slots_bytes, void* stream) {
+  using namespace gd4d;
+  if (!plan_pairs || !count || !slots || !level_hw || !cam_stride_bytes) return GD4D_EINVAL;
+  if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
+  if (P != kPoints || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if (slots_bytes < (size_t)B * Q * Hh * plan_cap_t(N, P) * 64 * sizeof(uint2)) return GD4D_EWORKSPACE;
+  CountArgs ca{};
+  if (int rc = fill_chunks(ca.g, level_hw, cam_stride_bytes, pix_stride_bytes, B * N, L)) return rc;
+  ca.hdr = static_cast<const int*>(plan_pairs);
+  ca.pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan_pairs) + plan_hdr_bytes(B, Q));
+  ca.count = count;
+  ca.slots = static_cast<uint2*>(slots);
+  ca.cap_t = plan_cap_t(N, P);
+  ca.BQ = B * Q;
+  return items_fwd_impl(level_ptrs, level_hw, cam_stride_bytes, pix_stride_bytes, slice_stride_bytes, plan_items, agg, wsum, B, N, Q, Hh,
+                        C, L, P, feats_dtype, query_order, 0, 8, 0, stream, &ca);
 }
 
 extern "C" int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C,

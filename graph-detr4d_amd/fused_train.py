@@ -254,10 +254,12 @@ class DecoderTrainFunction(torch.autograd.Function):
                                              meta.lidar2img, ca.pc_range, meta.img_h, meta.img_w, hh, query_order=order,
                                              both=os.environ.get('GD4D_TRAIN_PLAN', 'both') == 'both')
             s.layer = raw.register(s.plan.q)
-            if want_pyramid:
-                raw.count(s.layer, s.plan)
             raw.wait_copy()
-            s.agg = ops.cross_attn_agg_sliced_fwd(s.plan)
+            s.agg = raw.count_with_gather(s.layer, s.plan) if want_pyramid else None    # slots + gather in one launch
+            if s.agg is None:
+                if want_pyramid:
+                    raw.count(s.layer, s.plan)
+                s.agg = ops.cross_attn_agg_sliced_fwd(s.plan)
             s.v, s.y2, s.x2, s.h, s.y3 = new(q, c), new(q, c), new(q, c), new(q, fc), new(q, c)
             x3 = out_all[lid].view(q, c)
             prog = [ops.chain_headgemm(s.agg, s.plan.wsum, im['vp'], p['vp_b'], dst=0, out=s.v),

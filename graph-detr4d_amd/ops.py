@@ -320,9 +320,11 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
     return res if len(res) > 1 else plan
 
 
-def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
+def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None, count=None):
     """gd4d_cross_attn_agg_sliced_fwd on the pyramid the Plan was made for.  Returns agg (B, Q, Hh, 256); with plan.wsum
-    (B, Q, Hh) that is what cross_attn_agg_fwd returns (other summation order)."""
+    (B, Q, Hh) that is what cross_attn_agg_fwd returns (other summation order).
+    count = (PyramidGrad, layer): a training step's forward - the records of this plan get their slots in the SAME launch
+    (gd4d_cross_attn_agg_items_count_fwd; needs the plan in both forms, 8 heads, 4 levels, fp32; PyramidGrad.add_layer otherwise)."""
     lib = _lib.load()
     pyramid = plan.pyramid
     dev = pyramid.device
@@ -337,6 +339,22 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None):
     if plan.items or plan.items_buf is not None:
         lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in pyramid.level_hw for x in hw])
         cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
+        if count is not None:
+            sink, layer = count
+            if plan.items or plan.items_buf is None or tuple(slices) != (0, 8) or plan.stage:
+                raise _lib.Gd4dError('gather + record count in one launch: a plan in both forms, all slices, no stage')
+            slots, slot_bytes = sink.begin_layer(layer, plan)
+            code = lib.gd4d_cross_attn_agg_items_count_fwd(
+                ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, _dev(plan.items_buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
+                _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, plan.points,
+                _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+                None if query_order is None else _order_ptr(query_order, b * q), _dev(plan.buf, 'plan', torch.uint8),
+                _dev(sink.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(slot_bytes), _stream())
+            if code == -2:                               # GD4D_EUNSUPPORTED (e.g. a pyramid of 4 GiB or more): the caller launches the two
+                return None
+            _lib.check(code, 'gd4d_cross_attn_agg_items_count_fwd')
+            sink.plans.append((int(layer), plan, slots))
+            return agg
         code = lib.gd4d_cross_attn_agg_items_fwd(
             ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride,
             _dev(plan.buf if plan.items else plan.items_buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
@@ -582,6 +600,18 @@ class PyramidGrad:
         plan's own (B, Q, Hh) say where its pairs are; B and Hh must be the sink's (they fix the pyramid rows / the table's
         row width), Q is per layer."""
         lib = _lib.load()
+        slots, slot_bytes = self.begin_layer(layer, plan)
+        layer = int(layer)
+        code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), self._lv, self._cs, self.pyramid.pix_stride,
+                                           _dev(self.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(slot_bytes),
+                                           self.b, self.n, plan.q, self.hh, len(self.pyramid.level_hw), 4, _stream())
+        _lib.check(code, 'gd4d_pyramid_grad_count')
+        self.plans.append((layer, plan, slots))
+
+    def begin_layer(self, layer, plan):
+        """The checks of add_layer and the layer's slot buffer (the count itself: add_layer, or the forward gather's launch -
+        cross_attn_agg_sliced_fwd(count=...), which then appends to self.plans)."""
+        lib = _lib.load()
         plan.need_pairs('gd4d_pyramid_grad_count')
         layer = int(layer)
         if plan.b != self.b or plan.num_heads != self.hh or plan.pyramid.rows != self.pyramid.rows:
@@ -593,11 +623,7 @@ class PyramidGrad:
         self.layer_q[layer] = plan.q
         slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, plan.q, self.hh, 4))
         slots = torch.empty(slot_bytes, device=self.pyramid.device, dtype=torch.uint8)
-        code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), self._lv, self._cs, self.pyramid.pix_stride,
-                                           _dev(self.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(slot_bytes),
-                                           self.b, self.n, plan.q, self.hh, len(self.pyramid.level_hw), 4, _stream())
-        _lib.check(code, 'gd4d_pyramid_grad_count')
-        self.plans.append((layer, plan, slots))
+        return slots, slot_bytes
 
     def prepare(self):
         """scan + fill + sort: the layers' records bucketed by chunk and grouped by pixel.  Needs the counts of every layer

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 45
+#define GD4D_ABI_VERSION 46
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -211,6 +211,18 @@ int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* 
                                   int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
                                   float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
                                   const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream);
+
+/* gd4d_cross_attn_agg_items_count_fwd - a TRAINING step's forward gather and the first step of the pyramid gradient's bookkeeping
+ * in one launch: gd4d_cross_attn_agg_items_fwd (all slices, no stage) on plan_items and gd4d_pyramid_grad_count on plan_pairs (the
+ * two forms of one plan: GD4D_CA_PLAN_BOTH) - the same results as the two launches (the slots, as there, in an order the atomics
+ * decide).  Both only read the plan; the count lives on L2 atomic round trips, the gather on the fabric: every ninth group of
+ * eight workgroups counts, the others gather (each keeps its XCD).  8 heads, 4 levels, fp32 features, narrow offsets
+ * (GD4D_EUNSUPPORTED otherwise: launch the two). */
+int gd4d_cross_attn_agg_items_count_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                        int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan_items, float* agg,
+                                        float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                        const int32_t* query_order, const void* plan_pairs, int32_t* count, void* slots,
+                                        size_t slots_bytes, void* stream);
 int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
                              const float* lidar2img, const double* pc_range, float img_h, float img_w,
                              const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes, void* plan,

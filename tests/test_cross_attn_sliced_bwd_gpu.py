@@ -124,6 +124,37 @@ def test_raw_backward_matches_projected_backward(heads, levels, n, q, b):
         assert float(a[e == 0].abs().max() if (e == 0).any() else 0.0) < 1e-6 * float(e.abs().max())
 
 
+@pytest.mark.parametrize('n,q', [(6, 96), (24, 900), (6, 37)])
+def test_record_count_in_the_forward_gathers_launch(n, q):
+    """gd4d_cross_attn_agg_items_count_fwd: the forward gather of a training step hands out the records' slots as well - the
+    aggregates are bit-identical to the gather alone, the per-chunk counts equal gd4d_pyramid_grad_count's, and the pyramid's
+    gradient built from those slots equals the one built from the separate launch (another slot order: fp32 rounding)."""
+    c = _case(8, 4, n, q, 1, seed=3 + n + q)
+    b, hh = c['b'], c['heads']
+    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
+    pyr = ops.PyramidView.slice_planar(sp, hw)
+    order = ops.query_order_fwd(c['ref'], PC_RANGE)
+    got = {}
+    for merged in (False, True):
+        sink = ops.PyramidGrad(pyr, 2, b, q, hh)
+        for layer in range(2):
+            plan = ops.cross_attn_plan_fwd(pyr, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], PC_RANGE, 900, 1600, hh,
+                                           query_order=order, both=True)
+            if merged:
+                agg = ops.cross_attn_agg_sliced_fwd(plan, count=(sink, layer))
+                assert agg is not None
+            else:
+                agg = ops.cross_attn_agg_sliced_fwd(plan)
+                sink.add_layer(layer, plan)
+            ops.value_proj_heads_bwd(c['gout'], c['w_v'], c['b_v'], hh, grad_agg=sink.grad_agg_rows(layer))
+        counts = sink.count.clone()
+        got[merged] = (agg, plan.wsum.clone(), counts, sink.finish())
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    assert torch.equal(got[True][2], got[False][2]) and int(got[True][2].sum()) > 0
+    for a, e in zip(got[True][3], got[False][3]):
+        assert _rel(a, e) < 1e-5
+
+
 def test_raw_backward_raw_camera_weights():
     """GD4D_CA_RAW_CAM_WEIGHTS (Deform3DCrossAttnMP's neighbour pass): no sigmoid on the camera logits."""
     c = _case(8, 4, 6, 48, 1, seed=5)
