@@ -94,7 +94,7 @@ class RawPyramid:
         self.layer_q = []                              # queries per sample of every registered layer
         self.needs_grad = self.channels_last = False
         self.copy_dtype = torch.float32
-        self.main = self.side = self.side_bwd = None
+        self.main = self.side = self.side_bwd = self.side_prep = None
         self.copy_event = None
         self.sink = self.grads = self._dpart = None
         self._forked = self._prepared = False
@@ -164,9 +164,11 @@ class RawPyramid:
         if not self.needs_grad or self._prepared or self.sink is None:
             return
         self.sink.alloc_table(self.layer_q)
-        self._fork(self.side_bwd)
-        with torch.cuda.stream(self.side_bwd):
+        prep = self.side_prep if self.side_prep is not None and self.side_bwd is self.main else self.side_bwd
+        self._fork(prep)
+        with torch.cuda.stream(prep):
             self.sink.prepare()
+        self._prep_stream = prep
         self._prepared = True
 
     def layer_done(self):
@@ -182,6 +184,11 @@ class RawPyramid:
         py = self.pyramid
         grads = [torch.empty((py.rows, h, w, 256) if self.channels_last else (py.rows, 256, h, w), device=py.device, dtype=torch.float32)
                  for h, w in py.level_hw]
+        prep = getattr(self, '_prep_stream', None)
+        if prep is not None and prep is not self.side_bwd:       # GD4D_TRAIN_SIDE=prepare: scan / fill / sort ran beside the backward chains
+            self.side_bwd.wait_stream(prep)
+            for t in self.sink.prepared:
+                t.record_stream(self.side_bwd)
         self._fork(self.side_bwd)                    # the table rows were written on the main stream
         with torch.cuda.stream(self.side_bwd):
             grads = self.sink.reduce(grads, channels_last=self.channels_last)
@@ -232,6 +239,7 @@ class PyramidSourceFunction(torch.autograd.Function):
         mode = os.environ.get('GD4D_TRAIN_SIDE', '0')        # '1': counts, scan / fill / sort and the reduction beside the main stream; 'count': the counts only
         raw.side = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if mode in ('1', 'count') else raw.main
         raw.side_bwd = raw.side if mode == '1' else raw.main
+        raw.side_prep = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if mode == 'prepare' else None   # dev: scan / fill / sort only
         ctx.raw = raw
         ctx.set_materialize_grads(False)
         return torch.empty(1, device=feats[0].device, dtype=torch.float32)
