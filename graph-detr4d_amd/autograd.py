@@ -448,6 +448,19 @@ def _flush_deferred(task=None):
     _join_wgrad_side()
 
 
+def take_queued_weight_grads():
+    """The weight gradients the current backward pass has queued and not issued yet (<= 16, no two with one target), taken off the
+    queue: for a launch that lets them ride (ops.cross_attn_dot_sliced(wgrads=...)).  [] when nothing is queued."""
+    task = _deferring()
+    queues = _DEFERRED.get(task) if task is not None else None
+    if not queues or not queues['w']:
+        return []
+    q = queues['w'][:]
+    del queues['w'][:]
+    queues['busy']['w'].clear()
+    return q
+
+
 def _deferring():
     """The current backward pass (graph task id, 0 for the first pass of a process) if parameter gradients may be queued,
     else None - test with `is not None`."""

@@ -34,6 +34,7 @@
 #include "gd4d_cross_attn_shared.h"
 #include "gd4d_cross_attn_sliced.h"
 #include "gd4d_pyramid_count.h"
+#include "gd4d_linear_bwd_body.h"
 
 namespace gd4d {
 
@@ -202,13 +203,12 @@ struct DotParams {
   int BQ, per_xcd, cap_t;
 };
 
-template <int HH, int LT, typename VT, int OCC>
-__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(const DotParams p) {
+template <int HH, int LT, typename VT>
+__device__ __forceinline__ void cross_attn_dot_sliced_body(const DotParams& p, const int bid, char* s_raw) {   // s_raw: [HH][CH][8][GP]
   constexpr int CH = 6, GP = 80, PASS = 8 * GP, ES = sizeof(VT);
-  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int xcd = bid & 7, jb = bid >> 3;
   const int s = jb / p.per_xcd, qi = jb - s * p.per_xcd;
   const int pos = xcd * p.per_xcd + qi;
   if (pos >= p.BQ) return;
@@ -289,6 +289,44 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(con
       dp[(size_t)(t0 + k) * 64] = keep + __shfl_xor(send, 1);
     }
   }
+}
+
+template <int HH, int LT, typename VT, int OCC>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_kernel(const DotParams p) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  cross_attn_dot_sliced_body<HH, LT, VT>(p, (int)blockIdx.x, s_raw);
+}
+
+// A backward gather-dot and up to 16 queued weight gradients of the decoder's Linears (gd4d_linear_bwd_body.h) in ONE launch
+// (gd4d_cross_attn_dot_sliced_wgrad).  Nothing reads a weight gradient before the optimizer; a training step queued them and issued
+// them sixteen per launch when the backward pass ended: five launches of 36 - 47 us, each a chain of dependent load rounds on
+// fp32 MFMA tiles.  Here the tiles of what is queued when a layer's gather-dot starts are guest workgroups of that launch (8
+// waves each instead of 16), spread evenly among the gather-dot's, which live on the fabric's random reads; the gather-dot's are
+// renumbered (a multiple of 8 leaves: XCD and walk unchanged).
+struct WgradGuest {
+  DotParams p;                                 // (one kernel argument: the descriptor below is read through the argument segment)
+  LinBwdGroup g;
+  int tiles, guest_groups, total_groups;       // groups of 8 workgroups: guests among all
+};
+
+template <int HH, int LT, typename VT, int OCC>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_wgrad_kernel(const WgradGuest wg) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  static_assert(sizeof(LinBwdShared<HH>) <= (size_t)HH * 6 * 8 * 80, "the guest's partial tiles fit the gather-dot's LDS");
+  const long long grp = blockIdx.x >> 3;
+  const int before = (int)(grp * wg.guest_groups / wg.total_groups);          // guest groups in front of this one
+  if ((int)((grp + 1) * wg.guest_groups / wg.total_groups) > before) {
+    const int tile = before * 8 + (int)(blockIdx.x & 7);
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) WgradGuest* args_ptr_t;
+    const lin_group_ptr_t gp = &((args_ptr_t)__builtin_amdgcn_kernarg_segment_ptr())->g;
+#else
+    const lin_group_ptr_t gp = &wg.g;
+#endif
+    if (tile < wg.tiles) linear_bwd_weight_group_tile<HH>(gp, tile, *reinterpret_cast<LinBwdShared<HH>*>(s_raw));
+    return;
+  }
+  cross_attn_dot_sliced_body<HH, LT, VT>(wg.p, (int)blockIdx.x - 8 * before, s_raw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -970,9 +1008,9 @@ extern "C" size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P) 
   return (size_t)gd4d::kSlices * B * Q * Hh * gd4d::plan_cap_t(N, P) * 64 * sizeof(float);
 }
 
-extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
-                                          const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh,
-                                          int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream) {
+static int dot_sliced_impl(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                          const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh,
+                          int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream, gd4d::WgradGuest* wg) {
   using namespace gd4d;
   if (!level_ptrs || !plan || !grad_agg || !dpart) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
@@ -998,6 +1036,15 @@ extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t
   p.dslice = (long long)B * Q * Hh * p.cap_t * 64;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(8 * p.per_xcd * kSlices);
+  if (wg) {                                              // queued weight gradients ride along
+    if (Hh != 8 || L != 4 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
+    wg->guest_groups = (wg->tiles + 7) / 8;
+    wg->total_groups = (int)(grid.x / 8) + wg->guest_groups;
+    wg->p = p;
+    hipLaunchKernelGGL((cross_attn_dot_sliced_wgrad_kernel<8, 4, float, 6>), dim3(8 * wg->total_groups), dim3(64 * 8),
+                       (size_t)8 * 6 * 8 * 80, s, *wg);
+    return check_launch();
+  }
   auto go = [&](auto kern, int hh) -> int {
     const size_t lds = (size_t)hh * 6 * 8 * 80;
     if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
@@ -1018,6 +1065,25 @@ extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t
     default: if (bf16) { GD4D_DOT_L(16, uint16_t, 4) } else { GD4D_DOT_L(16, float, 4) }
   }
 #undef GD4D_DOT_L
+}
+
+extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                                          const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh,
+                                          int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream) {
+  return dot_sliced_impl(level_ptrs, slice_stride_bytes, plan, grad_agg, dpart, dpart_bytes, B, N, Q, Hh, C, L, P, feats_dtype,
+                         query_order, stream, nullptr);
+}
+
+extern "C" int gd4d_cross_attn_dot_sliced_wgrad(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                                                const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh,
+                                                int C, int L, int P, int feats_dtype, const int32_t* query_order,
+                                                const void* const* x, const void* const* grad_y, void* const* grad_w,
+                                                void* const* grad_b, const int32_t* dims, int count, int accumulate, void* stream) {
+  using namespace gd4d;
+  WgradGuest wg{};
+  if (int rc = fill_lin_bwd_group(wg.g, wg.tiles, x, grad_y, grad_w, grad_b, dims, count, accumulate)) return rc;
+  return dot_sliced_impl(level_ptrs, slice_stride_bytes, plan, grad_agg, dpart, dpart_bytes, B, N, Q, Hh, C, L, P, feats_dtype,
+                         query_order, stream, &wg);
 }
 
 extern "C" int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,

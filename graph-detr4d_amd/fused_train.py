@@ -313,7 +313,7 @@ class DecoderTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out_all, _g_ref):
-        from .autograd import _LN_GROUP, _VP_GROUP, _WGRAD_GROUP, _deferring, _queue_deferred
+        from .autograd import _LN_GROUP, _VP_GROUP, _WGRAD_GROUP, _deferring, _queue_deferred, take_queued_weight_grads
         meta, saved, params, imgs = ctx.meta, ctx.saved, ctx.params, ctx.imgs
         if saved is None:
             raise RuntimeError('graph-detr4d_amd: the chain training path keeps its activations for ONE backward pass '
@@ -337,6 +337,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         grads = [None] * len(params)
         local_w, local_ln = [], []
         deferring = _deferring() is not None
+        ride_wgrads = deferring and os.environ.get('GD4D_TRAIN_WGRAD', 'dot') == 'dot'     # queued weight gradients ride in the gather-dots' launches
 
         def targets(iw, ib, rows):
             """Where the gradients of parameters iw / ib (a weight and its bias, or gamma and beta) go: their views of the flat
@@ -435,7 +436,11 @@ class DecoderTrainFunction(torch.autograd.Function):
                                                   grad_agg=raw.sink.grad_agg_rows(s.layer) if want_pyramid else None)
             raw.layer_done()
             n_cam_rows = s.plan.pyramid.rows
-            dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)))
+            # the weight gradients queued so far (this layer's chain B, the layer above's chain A / in-projection) ride in the
+            # gather-dot's launch instead of waiting for the pass's end
+            riders = take_queued_weight_grads() if ride_wgrads and ops.wgrads_ride_with(s.plan) else None
+            dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)),
+                                              wgrads=riders)
             off5, att5 = s.off.view(1, q, hh, ca.num_points, 3), s.att.view(1, q, hh, ca.num_levels, ca.num_points)
             gr, go, ga, gc = ops.cross_attn_plan_bwd(s.plan, dpart, beta, s.ref, off5, att5, s.cam, meta.lidar2img, ca.pc_range,
                                                      meta.img_h, meta.img_w)

@@ -456,9 +456,28 @@ def cross_attn_dot_bytes(b, n, q, num_heads, points=4):
     return int(_lib.load().gd4d_cross_attn_dot_bytes(b, n, q, num_heads, points))
 
 
-def cross_attn_dot_sliced(plan, grad_agg, dpart=None):
+def _wgrad_arrays(problems):
+    """The C arrays of gd4d_linear_bwd_weight_group for problems = [(x (M, K), grad_y (M, N), grad_w (N, K), grad_b (N) or None)]."""
+    f32 = torch.float32
+    n = len(problems)
+    xs, gys, gws, gbs, dims = [], [], [], [], []
+    for x, gy, gw, gb in problems:
+        k, nn_ = x.shape[-1], gy.shape[-1]
+        m = x.numel() // k
+        if gy.numel() // nn_ != m or tuple(gw.shape) != (nn_, k) or (gb is not None and gb.numel() != nn_):
+            raise ValueError('weight-gradient group: inconsistent shapes')
+        xs.append(_dev(x, 'x', f32).value); gys.append(_dev(gy, 'grad_y', f32).value); gws.append(_dev(gw, 'grad_w', f32).value)
+        gbs.append(_dev(gb, 'grad_b', f32).value if gb is not None else None)
+        dims += [m, k, nn_, k, nn_]
+    arr = lambda v: (ctypes.c_void_p * n)(*v)          # noqa: E731
+    return arr(xs), arr(gys), arr(gws), arr(gbs), (ctypes.c_int32 * (5 * n))(*dims), n
+
+
+def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None):
     """gd4d_cross_attn_dot_sliced: D[pair] = <grad_agg[q, h], raw pixel of the pair> for every pair of `plan`, as 8 per-slice
-    partials (uint8 buffer of gd4d_cross_attn_dot_bytes; only the passes the plan uses are written)."""
+    partials (uint8 buffer of gd4d_cross_attn_dot_bytes; only the passes the plan uses are written).
+    wgrads: up to 16 weight-gradient problems (as linear_bwd_weight_group takes them; added to their targets) whose tiles ride
+    in the launch (gd4d_cross_attn_dot_sliced_wgrad; 8 heads, 4 levels, fp32: wgrads_ride_with(plan) says whether)."""
     lib = _lib.load()
     plan.need_pairs('gd4d_cross_attn_dot_sliced')
     pyramid = plan.pyramid
@@ -469,6 +488,15 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None):
     if dpart is None:
         dpart = torch.empty(nbytes, device=pyramid.device, dtype=torch.uint8)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
+    if wgrads:
+        xs, gys, gws, gbs, dims, cnt = _wgrad_arrays(wgrads)
+        code = lib.gd4d_cross_attn_dot_sliced_wgrad(
+            ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(grad_agg, 'grad_agg', torch.float32),
+            _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4,
+            _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+            None if plan.order is None else _order_ptr(plan.order, b * q), xs, gys, gws, gbs, dims, cnt, 1, _stream())
+        _lib.check(code, 'gd4d_cross_attn_dot_sliced_wgrad')
+        return dpart
     code = lib.gd4d_cross_attn_dot_sliced(
         ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(grad_agg, 'grad_agg', torch.float32),
         _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4,
@@ -476,6 +504,11 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None):
         None if plan.order is None else _order_ptr(plan.order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_dot_sliced')
     return dpart
+
+
+def wgrads_ride_with(plan):
+    """Whether cross_attn_dot_sliced(plan, ..., wgrads=...) has a launch for this plan's shape."""
+    return plan.num_heads == 8 and len(plan.pyramid.level_hw) == 4 and plan.pyramid.dtype == torch.float32
 
 
 def cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w,
@@ -878,20 +911,8 @@ def linear_bwd_weight_group(problems, accumulate=True):
     """gd4d_linear_bwd_weight_group: problems = list (<= 16) of (x (M, K), grad_y (M, N), grad_w (N, K), grad_b (N) or None);
     the sums are added to (accumulate) or written into grad_w / grad_b.  One launch for all of them."""
     lib = _lib.load()
-    f32 = torch.float32
-    n = len(problems)
-    xs, gys, gws, gbs, dims = [], [], [], [], []
-    for x, gy, gw, gb in problems:
-        k, nn_ = x.shape[-1], gy.shape[-1]
-        m = x.numel() // k
-        if gy.numel() // nn_ != m or tuple(gw.shape) != (nn_, k) or (gb is not None and gb.numel() != nn_):
-            raise ValueError('linear_bwd_weight_group: inconsistent shapes')
-        xs.append(_dev(x, 'x', f32).value); gys.append(_dev(gy, 'grad_y', f32).value); gws.append(_dev(gw, 'grad_w', f32).value)
-        gbs.append(_dev(gb, 'grad_b', f32).value if gb is not None else None)
-        dims += [m, k, nn_, k, nn_]
-    arr = lambda v: (ctypes.c_void_p * n)(*v)          # noqa: E731
-    code = lib.gd4d_linear_bwd_weight_group(arr(xs), arr(gys), arr(gws), arr(gbs), (ctypes.c_int32 * (5 * n))(*dims), n,
-                                            1 if accumulate else 0, _stream())
+    xs, gys, gws, gbs, dims, n = _wgrad_arrays(problems)
+    code = lib.gd4d_linear_bwd_weight_group(xs, gys, gws, gbs, dims, n, 1 if accumulate else 0, _stream())
     _lib.check(code, 'gd4d_linear_bwd_weight_group')
 
 

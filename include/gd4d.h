@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 46
+#define GD4D_ABI_VERSION 47
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -297,6 +297,18 @@ size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
                                const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,
                                int P, int feats_dtype, const int32_t* query_order, void* stream);
+
+/* gd4d_cross_attn_dot_sliced_wgrad - gd4d_cross_attn_dot_sliced and gd4d_linear_bwd_weight_group (its arguments: up to 16 weight /
+ * bias gradients of the decoder's Linears, dims = {M, K, N, ldx, ldy} per problem) in one launch: the weight-gradient tiles are
+ * guest workgroups of the gather-dot (8 waves each, so their row sums are taken in another - fixed - order than the stand-alone
+ * kernel's 16 waves: equal within fp32 rounding).  Nothing reads a weight gradient before the optimizer: a training step hands
+ * what it has queued to the next backward gather instead of five launches when the backward pass ends.  8 heads, 4 levels, fp32
+ * features (GD4D_EUNSUPPORTED otherwise). */
+int gd4d_cross_attn_dot_sliced_wgrad(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                                     const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C,
+                                     int L, int P, int feats_dtype, const int32_t* query_order, const void* const* x,
+                                     const void* const* grad_y, void* const* grad_w, void* const* grad_b, const int32_t* dims,
+                                     int count, int accumulate, void* stream);
 int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
                              const float* lidar2img, const double* pc_range, float img_h, float img_w, const int32_t* level_hw,
                              const void* plan, const void* dpart, const float* beta, float* grad_ref, float* grad_offsets,

@@ -155,6 +155,37 @@ def test_record_count_in_the_forward_gathers_launch(n, q):
         assert _rel(a, e) < 1e-5
 
 
+def test_weight_gradients_ride_in_the_gather_dots_launch():
+    """gd4d_cross_attn_dot_sliced_wgrad: the tiles of queued weight gradients are guest workgroups of a gather-dot - D is
+    bit-identical to the gather-dot alone (over the passes the plan uses), the weight / bias gradients are added to their targets
+    and equal an fp64 evaluation (and the 16-wave stand-alone kernel within fp32 rounding)."""
+    c = _case(8, 4, 6, 96, 1, seed=31)
+    hh = c['heads']
+    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
+    pyr = ops.PyramidView.slice_planar(sp, hw)
+    order = ops.query_order_fwd(c['ref'], PC_RANGE)
+    plan = ops.cross_attn_plan_fwd(pyr, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], PC_RANGE, 900, 1600, hh, query_order=order)
+    gagg, _ = ops.value_proj_heads_bwd(c['gout'], c['w_v'], c['b_v'], hh)
+    nb = ops.cross_attn_dot_bytes(1, 6, c['q'], hh)
+    want = ops.cross_attn_dot_sliced(plan, gagg, dpart=torch.zeros(nb, device=DEV, dtype=torch.uint8))
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(900, 256, 768, True), (900, 256, 256, True), (900, 512, 256, False), (900, 3, 256, True), (37, 256, 10, True)]
+    probs, refs = [], []
+    for m, k, n, bias in shapes:
+        x, gy = torch.randn(m, k, generator=gen).to(DEV), torch.randn(m, n, generator=gen).to(DEV)
+        gw, gb = torch.randn(n, k, generator=gen).to(DEV), (torch.randn(n, generator=gen).to(DEV) if bias else None)
+        refs.append((gw.double() + gy.double().t() @ x.double(), None if gb is None else gb.double() + gy.double().sum(0)))
+        probs.append((x, gy, gw, gb))
+    alone = [(gw.clone(), None if gb is None else gb.clone()) for _, _, gw, gb in probs]
+    ops.linear_bwd_weight_group([(x, gy, a[0], a[1]) for (x, gy, _, _), a in zip(probs, alone)], accumulate=True)
+    got = ops.cross_attn_dot_sliced(plan, gagg, dpart=torch.zeros(nb, device=DEV, dtype=torch.uint8), wgrads=probs)
+    assert torch.equal(got, want)
+    for (x, gy, gw, gb), (rw, rb), (aw, ab) in zip(probs, refs, alone):
+        assert _rel(gw, rw) < 2e-6 and _rel(gw, aw) < 2e-6
+        if gb is not None:
+            assert _rel(gb, rb) < 2e-6 and _rel(gb, ab) < 2e-6
+
+
 def test_raw_backward_raw_camera_weights():
     """GD4D_CA_RAW_CAM_WEIGHTS (Deform3DCrossAttnMP's neighbour pass): no sigmoid on the camera logits."""
     c = _case(8, 4, 6, 48, 1, seed=5)
