@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 47
+ABI_VERSION = 48
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -69,6 +69,7 @@ SIGNATURES = {
     'gd4d_layernorm_fwd': (_i, [_vp] * 5 + [_i, _i, _f, _i, _vp]),
     'gd4d_mha_core_fwd': (_i, [_vp] * 5 + [_i] * 10 + [_f, _vp, _f, _vp, _vp]),
     'gd4d_mha_core_bwd': (_i, [_vp] * 11 + [_i] * 14 + [_f, _f, _vp, _vp]),
+    'gd4d_mha_core_bwd_fill': (_i, [_vp] * 11 + [_i] * 14 + [_f, _f, _vp] + [_vp, _i, _vp, _vp] + [_i] * 4 + [_vp]),
     'gd4d_layernorm_bwd_workspace_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_layernorm_bwd': (_i, [_vp] * 9 + [_c.c_size_t, _i, _i, _f, _i, _vp]),
     'gd4d_inverse_sigmoid_fwd': (_i, [_vp, _vp, _c.c_int64, _vp]),

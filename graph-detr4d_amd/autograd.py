@@ -98,6 +98,7 @@ class RawPyramid:
         self.copy_event = None
         self.sink = self.grads = self._dpart = None
         self._forked = self._prepared = False
+        self.fills_ride = False                        # set by the chain training path (fused_train)
 
     def register(self, q):
         """A layer (one CrossAttnRawFunction node) with `q` queries per sample: the passes that share this pyramid
@@ -164,12 +165,29 @@ class RawPyramid:
         if not self.needs_grad or self._prepared or self.sink is None:
             return
         self.sink.alloc_table(self.layer_q)
+        if self.fills_ride:
+            # one stream, the chain training path: the fills ride in the attention backward's launches (fills_for_launch); what is
+            # left of them, and the sort, run before the reduction (_reduce)
+            self.sink.scan()
+            self._launches_left = max(len(self.layer_q) - 1, 0)   # attention backward launches in front of the reduction
+            self._prepared = True
+            return
         prep = self.side_prep if self.side_prep is not None and self.side_bwd is self.main else self.side_bwd
         self._fork(prep)
         with torch.cuda.stream(prep):
             self.sink.prepare()
         self._prep_stream = prep
         self._prepared = True
+
+    def fills_for_launch(self):
+        """What the next attention backward carries (ops.mha_core_bwd(fills=...)), or None."""
+        if not self.needs_grad or self.sink is None or self.sink._scanned is None:
+            return None
+        left = getattr(self, '_launches_left', 0)
+        if left <= 0 or not self.sink.plans:
+            return None
+        self._launches_left = left - 1
+        return self.sink.take_fills(-(-len(self.sink.plans) // left))
 
     def layer_done(self):
         """A layer's grad_agg rows are written (main stream); after the last one the reduction starts on the side stream."""
@@ -181,6 +199,8 @@ class RawPyramid:
         if not self.needs_grad or self.sink is None or self.grads is not None:
             return
         self.begin_backward()
+        if self.sink._scanned is not None:
+            self.sink.finish_prepare()               # the fills nobody carried, and the sort
         py = self.pyramid
         grads = [torch.empty((py.rows, h, w, 256) if self.channels_last else (py.rows, 256, h, w), device=py.device, dtype=torch.float32)
                  for h, w in py.level_hw]

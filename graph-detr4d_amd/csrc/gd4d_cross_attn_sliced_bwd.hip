@@ -34,6 +34,7 @@
 #include "gd4d_cross_attn_shared.h"
 #include "gd4d_cross_attn_sliced.h"
 #include "gd4d_pyramid_count.h"
+#include "gd4d_pyramid_fill.h"
 #include "gd4d_linear_bwd_body.h"
 
 namespace gd4d {
@@ -611,41 +612,12 @@ __global__ __launch_bounds__(256) void pyramid_grad_count_kernel(const int* __re
   pyramid_grad_count_body(hdr, pair, cap_t, HH, BQ, g, count, slots, blockIdx.x * 4 + (threadIdx.x >> 6));   // gd4d_pyramid_count.h
 }
 
-// records[start[chunk] + slot] = {weight, pixel-in-chunk << 26 | table row}: no atomics
+// (the fill's body: gd4d_pyramid_fill.h - shared with the attention backward's launch)
 __global__ __launch_bounds__(256) void pyramid_grad_fill_kernel(const int* __restrict__ hdr, const uint2* __restrict__ pair,
                                                                 const uint2* __restrict__ slots, int cap_t, int HH, int BQ,
                                                                 const int* __restrict__ start, uint2* __restrict__ rec,
                                                                 const int32_t* __restrict__ order, unsigned id_base) {
-  const int lane = threadIdx.x & 63;
-  const int ph = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ph >= BQ * HH) return;
-  const int pos = ph / HH, h = ph - pos * HH;
-  const int M = hdr[pos * kPlanHdr + h];
-  const int T = (M + 3) >> 2;
-  const unsigned id = id_base + (unsigned)((order ? order[pos] : pos) * HH + h);
-  const size_t prow = (size_t)ph * cap_t * 64 + lane;
-  // four passes at a time: their slot and pair rows requested together, then the four chunk starts (which depend on the
-  // slots), then the stores - two round trips per four passes (one pass per iteration was two dependent round trips per pass
-  // on a wave that walks ~4 passes: 26 us per launch)
-  constexpr int FP = 4;
-  for (int t = 0; t < T; t += FP) {
-    uint2 sr[FP], pr[FP];
-#pragma unroll
-    for (int i = 0; i < FP; ++i) {
-      const size_t at = prow + (size_t)min(t + i, T - 1) * 64;
-      sr[i] = slots[at];
-      pr[i] = pair[at];
-    }
-    int st[FP];
-#pragma unroll
-    for (int i = 0; i < FP; ++i) {
-      const bool ok = t + i < T && sr[i].y != 0xffffffffu;
-      st[i] = ok ? start[sr[i].x >> 6] : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < FP; ++i)
-      if (st[i] >= 0) rec[(size_t)st[i] + sr[i].y] = make_uint2(pr[i].y, ((sr[i].x & 63u) << 26) | id);
-  }
+  pyramid_grad_fill_body(hdr, pair, slots, cap_t, HH, BQ, start, rec, order, id_base, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 constexpr int SCAN_THREADS = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_THREADS * SCAN_PER;

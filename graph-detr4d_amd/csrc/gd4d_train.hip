@@ -6,6 +6,7 @@
 // Everything fp32; reductions in a fixed order (run-to-run identical results).
 #include "gd4d_common.h"
 #include "gd4d_mha_dropout.h"
+#include "gd4d_pyramid_fill.h"
 
 namespace gd4d {
 
@@ -260,12 +261,12 @@ __device__ __forceinline__ void tb_load8(const float* src, float* dst, float mul
 // SIDE = 0: the workgroup owns 16 queries (columns of the transposed tiles), loops over key tiles (rows): dq.
 // SIDE = 1: the workgroup owns 16 keys (columns), loops over query tiles (rows): dk and dv.
 template <int SIDE, bool DROP>
-__global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdParams p) {
-  __shared__ float s_acc[TB_WAVES][2][TB_D][17];
+__device__ __forceinline__ void mha_bwd_body(const MhaBwdParams& p, const int bx, const int by, const int bz,
+                                             float (&s_acc)[TB_WAVES][2][TB_D][17]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ci = lane & 15, g = lane >> 4;
-  const int c0 = blockIdx.x * 16;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int c0 = bx * 16;
+  const int h = by, b = bz;
   const size_t hoff = (size_t)h * TB_D;
   const int Lc = SIDE == 0 ? p.Lq : p.Lk;               // extent of the column (owned) side
   const int Lr = SIDE == 0 ? p.Lk : p.Lq;               // extent of the row (looped) side
@@ -399,6 +400,32 @@ __global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdPara
   }
 }
 
+template <int SIDE, bool DROP>
+__global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_kernel(const MhaBwdParams p) {
+  __shared__ float s_acc[TB_WAVES][2][TB_D][17];
+  mha_bwd_body<SIDE, DROP>(p, blockIdx.x, blockIdx.y, blockIdx.z, s_acc);
+}
+
+// The dk / dv kernel with up to two layers' record fills of the pyramid gradient as guest workgroups (gd4d_mha_core_bwd_fill;
+// gd4d_pyramid_fill.h).  The fills of a training step need the scan over ALL layers' counts and nothing from the backward pass:
+// six launches of 22 us sat between the passes.  They stream plans and scatter 8-byte records - memory work; this kernel is
+// bound by its matrix and vector pipes.  (Beside the backward gather-dot, which lives on the fabric too, they hid nothing.)
+struct MhaBwdFillArgs {
+  MhaBwdParams p;
+  FillGuest fg;
+  int nx;                      // key tiles (the host grid's x extent)
+};
+
+template <bool DROP>
+__global__ __launch_bounds__(64 * TB_WAVES) void mha_bwd_fill_kernel(const MhaBwdFillArgs a) {
+  __shared__ float s_acc[TB_WAVES][2][TB_D][17];
+  int host;
+  if (fill_guest_or_host(a.fg, host)) return;
+  const int bx = host % a.nx, rest = host / a.nx;
+  if (rest >= a.p.H * a.p.B) return;
+  mha_bwd_body<1, DROP>(a.p, bx, rest % a.p.H, rest / a.p.H, s_acc);
+}
+
 }  // namespace gd4d
 
 extern "C" size_t gd4d_layernorm_bwd_workspace_bytes(int M, int C) {
@@ -431,10 +458,11 @@ extern "C" int gd4d_layernorm_bwd(const float* x, const float* res, const float*
   return check_launch();
 }
 
-extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
-                                 const void* mask, const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq,
-                                 int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
-                                 int lddk, int lddv, int mask_kind, float scale, float drop_p, const void* seed, void* stream) {
+static int mha_core_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                             const void* mask, const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq,
+                             int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
+                             int lddk, int lddv, int mask_kind, float scale, float drop_p, const void* seed, void* stream,
+                             gd4d::FillGuest* fg) {
   using namespace gd4d;
   if (!q || !k || !v || !o || !dout || !lse || !dsum || !dq || !dk || !dv || Lq <= 0 || Lk <= 0 || B <= 0 || H <= 0)
     return GD4D_EINVAL;
@@ -455,9 +483,59 @@ extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v,
   if (drop_p > 0.f) hipLaunchKernelGGL((mha_bwd_kernel<0, true>), gq, block, 0, st, p);
   else hipLaunchKernelGGL((mha_bwd_kernel<0, false>), gq, block, 0, st, p);
   if (int rc = check_launch()) return rc;
+  if (fg) {                                              // the dk / dv kernel carries the fills
+    MhaBwdFillArgs a{};
+    a.p = p; a.fg = *fg; a.nx = (int)gk.x;
+    const int hosts = (int)(gk.x * gk.y * gk.z);
+    const int wgs = fg->wgs0 + (fg->hdr[1] ? (fg->BQ[1] * fg->HH + 7) / 8 : 0);
+    a.fg.guest_groups = (wgs + 7) / 8;
+    a.fg.total_groups = (hosts + 7) / 8 + a.fg.guest_groups;
+    const dim3 grid(8 * a.fg.total_groups);
+    if (drop_p > 0.f) hipLaunchKernelGGL((mha_bwd_fill_kernel<true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mha_bwd_fill_kernel<false>), grid, block, 0, st, a);
+    return check_launch();
+  }
   if (drop_p > 0.f) hipLaunchKernelGGL((mha_bwd_kernel<1, true>), gk, block, 0, st, p);
   else hipLaunchKernelGGL((mha_bwd_kernel<1, false>), gk, block, 0, st, p);
   return check_launch();
+}
+
+extern "C" int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                 const void* mask, const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq,
+                                 int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
+                                 int lddk, int lddv, int mask_kind, float scale, float drop_p, const void* seed, void* stream) {
+  return mha_core_bwd_impl(q, k, v, o, dout, mask, lse, dsum, dq, dk, dv, Lq, Lk, B, H, D, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
+                           mask_kind, scale, drop_p, seed, stream, nullptr);
+}
+
+extern "C" int gd4d_mha_core_bwd_fill(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                      const void* mask, const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq,
+                                      int Lk, int B, int H, int D, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
+                                      int lddk, int lddv, int mask_kind, float scale, float drop_p, const void* seed,
+                                      const gd4d_fill_job* jobs, int njobs, const int32_t* start, void* records, int fill_B,
+                                      int fill_N, int fill_Hh, int fill_P, void* stream) {
+  using namespace gd4d;
+  if (!jobs || njobs < 1 || njobs > 2 || !start || !records || fill_B <= 0 || fill_N <= 0 || fill_Hh <= 0) return GD4D_EINVAL;
+  if (fill_P != kPoints || fill_N > 64 || fill_B > 16 || fill_Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  FillGuest fg{};
+  for (int j = 0; j < njobs; ++j) {
+    const gd4d_fill_job& jb = jobs[j];
+    if (!jb.plan || !jb.slots || jb.Q <= 0) return GD4D_EINVAL;
+    if ((unsigned long long)jb.id_base + (unsigned long long)fill_B * jb.Q * fill_Hh > (1ull << 26)) return GD4D_EUNSUPPORTED;
+    fg.hdr[j] = static_cast<const int*>(jb.plan);
+    fg.pair[j] = reinterpret_cast<const uint2*>(static_cast<const char*>(jb.plan) + plan_hdr_bytes(fill_B, jb.Q));
+    fg.slots[j] = static_cast<const uint2*>(jb.slots);
+    fg.order[j] = jb.query_order;
+    fg.id_base[j] = jb.id_base;
+    fg.BQ[j] = fill_B * jb.Q;
+  }
+  fg.HH = fill_Hh;
+  fg.cap_t = plan_cap_t(fill_N, fill_P);
+  fg.wgs0 = (fg.BQ[0] * fill_Hh + 7) / 8;
+  fg.start = start;
+  fg.rec = static_cast<uint2*>(records);
+  return mha_core_bwd_impl(q, k, v, o, dout, mask, lse, dsum, dq, dk, dv, Lq, Lk, B, H, D, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
+                           mask_kind, scale, drop_p, seed, stream, &fg);
 }
 
 extern "C" int gd4d_layernorm_bwd_reduce_group(const void* const* workspaces, void* const* dgamma, void* const* dbeta, const int32_t* dims,

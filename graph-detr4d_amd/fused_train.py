@@ -378,6 +378,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         gpos = None                          # running gradient of query_pos
         g_ref0 = padz = carry = carry_keep = None
         if want_pyramid:
+            raw.fills_ride = (raw.side_bwd is raw.main and raw.side_prep is None and os.environ.get('GD4D_TRAIN_FILL', 'mha') == 'mha')
             raw.begin_backward()
         for lid in range(nl - 1, -1, -1):
             layer, s, im = layers[lid], saved[lid], imgs.layers[lid]
@@ -480,7 +481,8 @@ class DecoderTrainFunction(torch.autograd.Function):
             lngrad(base, 'n0_w', ws_n0)
             qh, kh, vh = s.qkv.split(c, dim=-1)
             dqk, dv = ops.mha_core_bwd(qh, kh, vh, s.o, g_o, s.lse, sa.num_heads, meta.attn_mask, packed_qk=True,
-                                       dropout_p=s.drop[0][1] if s.drop[0] else 0., seed=s.drop[0][0] if s.drop[0] else None)
+                                       dropout_p=s.drop[0][1] if s.drop[0] else 0., seed=s.drop[0][0] if s.drop[0] else None,
+                                       fills=raw.fills_for_launch() if want_pyramid else None)    # record fills of the pyramid gradient ride
             # in-projection backward: launched with the NEXT layer's chain B' backward (its result stays in LDS), alone for layer 0
             gx = new(q, c) if lid == 0 else None
             gpos_new = new(q, c)

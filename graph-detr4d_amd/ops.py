@@ -600,6 +600,7 @@ class PyramidGrad:
         if self.chunks <= 0:
             raise _lib.Gd4dError('gd4d_pyramid_grad_chunks: unsupported pyramid')
         self.count = torch.zeros(self.chunks, device=dev, dtype=torch.int32)
+        self._scanned, self._riding = None, []
         self.table, self.layer_q = None, {}
         if self.layers > 0:
             self.alloc_table(self.layers)
@@ -661,6 +662,13 @@ class PyramidGrad:
     def prepare(self):
         """scan + fill + sort: the layers' records bucketed by chunk and grouped by pixel.  Needs the counts of every layer
         (add_layer) and nothing from the backward pass."""
+        if self._scanned is None:
+            self.scan()
+        self.finish_prepare()
+
+    def scan(self):
+        """The first part of prepare(): the chunks' starts.  The fills may then ride in other launches (take_fills ->
+        mha_core_bwd(fills=...)); finish_prepare() launches whatever is left of them, and the sort."""
         lib = _lib.load()
         dev = self.pyramid.device
         i32 = torch.int32
@@ -673,10 +681,29 @@ class PyramidGrad:
         if self.table is None:
             raise _lib.Gd4dError('PyramidGrad.prepare: alloc_table() first (the records carry table rows)')
         nbytes = max(sum(slots.numel() for _, _, slots in self.plans), self.slot_bytes)
-        records = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        self._scanned = (start, torch.empty(nbytes, device=dev, dtype=torch.uint8), nbytes)
         for layer, plan, slots in self.plans:
             if layer >= self.layers or self.table_q[layer] != plan.q:
                 raise _lib.Gd4dError(f'PyramidGrad: layer {layer} ({plan.q} queries) does not match the table')
+
+    def take_fills(self, n):
+        """Up to n (<= 2) pending fills for another launch to carry: ([(plan, slots, first table row)], start, records, B, N, Hh),
+        or None when none is left."""
+        n = min(int(n), 2, len(self.plans))
+        if n <= 0 or self._scanned is None:
+            return None
+        start, records, _ = self._scanned
+        jobs = [(plan, slots, self.row_base[layer]) for layer, plan, slots in self.plans[:n]]
+        self._riding += self.plans[:n]                     # (their buffers live until finish_prepare)
+        self.plans = self.plans[n:]
+        return jobs, start, records, self.b, self.n, self.hh
+
+    def finish_prepare(self):
+        lib = _lib.load()
+        dev = self.pyramid.device
+        i32 = torch.int32
+        start, records, nbytes = self._scanned
+        for layer, plan, slots in self.plans:
             code = lib.gd4d_pyramid_grad_fill(
                 _dev(plan.buf, 'plan', torch.uint8), _dev(slots, 'slots'), _dev(start, 'start', i32), _dev(records, 'records'),
                 self.row_base[layer], None if plan.order is None else _order_ptr(plan.order, self.b * plan.q),
@@ -689,6 +716,8 @@ class PyramidGrad:
         _lib.check(code, 'gd4d_pyramid_grad_sort')
         self.prepared = (start, pxoff, sorted_)
         self.plans = []
+        self._riding = []
+        self._scanned = None
 
     def reduce(self, grads=None, channels_last=False):
         """-> L tensors (R, 256, H_l, W_l) fp32: the pyramid's gradient summed over the layers (prepare() first; the table
@@ -1157,10 +1186,17 @@ def mha_core_fwd(q, k, v, num_heads, attn_mask=None, want_lse=False, dropout_p=0
     return (out, lse) if want_lse else out
 
 
-def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_qk=False, dropout_p=0., seed=None):
+class FillJob(ctypes.Structure):
+    """gd4d_fill_job (include/gd4d.h)."""
+    _fields_ = [('plan', ctypes.c_void_p), ('slots', ctypes.c_void_p), ('query_order', ctypes.c_void_p),
+                ('id_base', ctypes.c_uint32), ('Q', ctypes.c_int32)]
+
+
+def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_qk=False, dropout_p=0., seed=None, fills=None):
     """gd4d_mha_core_bwd.  Returns (dq, dk, dv), each (L, B, C) contiguous; packed_qk (self-attention, q and k the two halves
     of one (L, B, 2C) projection): (dqk (L, B, 2C), dv) - the kernel writes both halves of one buffer.  dropout_p / seed:
-    the forward's."""
+    the forward's.  fills: what PyramidGrad.take_fills returned - one or two layers' record fills of the pyramid gradient ride
+    in the dk / dv launch (gd4d_mha_core_bwd_fill)."""
     lib = _lib.load()
     lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, attn_mask)
     sptr = _mha_seed(dropout_p, seed, q.device)
@@ -1177,6 +1213,18 @@ def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_
     dv = torch.empty(lk, b, c, device=q.device, dtype=f32)
     dsum = torch.empty(lq, b, num_heads, device=q.device, dtype=f32)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())    # noqa: E731
+    if fills is not None:
+        jobs, start, records, fb, fn, fhh = fills
+        arr = (FillJob * len(jobs))(*[FillJob(_dev(pl.buf, 'plan', torch.uint8).value, _dev(sl, 'slots').value,
+                                               None if pl.order is None else _order_ptr(pl.order, fb * pl.q).value, int(base), int(pl.q))
+                                       for pl, sl, base in jobs])
+        code = lib.gd4d_mha_core_bwd_fill(vp(q), vp(k), vp(v), _dev(out, 'out', f32), _dev(grad_out, 'grad_out', f32),
+                                          mptr, _dev(lse, 'lse', f32), _dev(dsum, 'dsum'), vp(dq), vp(dk),
+                                          _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, ldd, ldd, c,
+                                          kind, 1.0 / (d ** 0.5), float(dropout_p), sptr, arr, len(jobs),
+                                          _dev(start, 'start', torch.int32), _dev(records, 'records'), fb, fn, fhh, 4, _stream())
+        _lib.check(code, 'gd4d_mha_core_bwd_fill')
+        return (dqk, dv) if packed_qk else (dq, dk, dv)
     code = lib.gd4d_mha_core_bwd(vp(q), vp(k), vp(v), _dev(out, 'out', f32), _dev(grad_out, 'grad_out', f32),
                                  mptr, _dev(lse, 'lse', f32), _dev(dsum, 'dsum'), vp(dq), vp(dk),
                                  _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, ldd, ldd, c,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 47
+#define GD4D_ABI_VERSION 48
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -725,6 +725,24 @@ int gd4d_mha_core_bwd(const float* q, const float* k, const float* v, const floa
                       const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq, int Lk, int B, int H, int D,
                       int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, int mask_kind,
                       float scale, float drop_p, const void* seed, void* stream);
+
+/* gd4d_mha_core_bwd_fill - gd4d_mha_core_bwd whose second launch (dk / dv) also carries gd4d_pyramid_grad_fill of one or two
+ * plans as guest workgroups (jobs: each plan with its slots, first table row and query order; fill_B / fill_N / fill_Hh / fill_P
+ * as gd4d_pyramid_grad_fill's B, N, Hh, P; start / records as there).  The fills need the scan over all layers' counts and nothing
+ * from the backward pass - a training step hands them to its attention backward launches, whose matrix / vector work hides their
+ * memory traffic.  Same results as the separate launches. */
+typedef struct gd4d_fill_job {
+  const void* plan;             /* pairs form (header + pairs) */
+  const void* slots;            /* what gd4d_pyramid_grad_count wrote for it */
+  const int32_t* query_order;   /* the plan's (may be NULL) */
+  uint32_t id_base;             /* first table row of the plan's layer */
+  int32_t Q;                    /* the plan's query count */
+} gd4d_fill_job;
+int gd4d_mha_core_bwd_fill(const float* q, const float* k, const float* v, const float* o, const float* dout, const void* mask,
+                           const float* lse, float* dsum, float* dq, float* dk, float* dv, int Lq, int Lk, int B, int H, int D,
+                           int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, int mask_kind, float scale,
+                           float drop_p, const void* seed, const gd4d_fill_job* jobs, int njobs, const int32_t* start,
+                           void* records, int fill_B, int fill_N, int fill_Hh, int fill_P, void* stream);
 
 /* gd4d_layernorm_bwd - backward of gd4d_layernorm_fwd (y = [ReLU] LN(x [+ res]) gamma + beta): dx (also the gradient of
  * res), dgamma, dbeta from dy; mean / rstd are recomputed from x.  beta is read only with relu != 0 (to rebuild the

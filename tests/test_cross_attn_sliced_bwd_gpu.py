@@ -186,6 +186,40 @@ def test_weight_gradients_ride_in_the_gather_dots_launch():
             assert _rel(gb, rb) < 2e-6 and _rel(gb, ab) < 2e-6
 
 
+def test_record_fills_ride_in_the_attention_backwards_launch():
+    """gd4d_mha_core_bwd_fill: the fills of two (then one) layers are guest workgroups of the dk / dv launch - dq, dk, dv are
+    bit-identical to gd4d_mha_core_bwd, and the pyramid's gradient equals the one of the stand-alone fills (another slot order: fp32
+    rounding)."""
+    c = _case(8, 4, 6, 96, 1, seed=21)
+    b, q, hh = c['b'], c['q'], c['heads']
+    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
+    pyr = ops.PyramidView.slice_planar(sp, hw)
+    order = ops.query_order_fwd(c['ref'], PC_RANGE)
+    gen = torch.Generator().manual_seed(2)
+    qkv = torch.randn(200, 1, 768, generator=gen).to(DEV)
+    qh, kh, vh = qkv.split(256, dim=-1)
+    do = torch.randn(200, 1, 256, generator=gen).to(DEV)
+    out, lse = ops.mha_core_fwd(qh, kh, vh, 8, want_lse=True)
+    want = ops.mha_core_bwd(qh, kh, vh, out, do, lse, 8, packed_qk=True)
+    res = {}
+    for riding in (False, True):
+        sink = ops.PyramidGrad(pyr, 3, b, q, hh)
+        for layer in range(3):
+            plan = ops.cross_attn_plan_fwd(pyr, c['ref'], c['offsets'] * (1 + 0.1 * layer), c['attn'], c['cam'], c['l2i'], PC_RANGE,
+                                           900, 1600, hh, query_order=order)
+            sink.add_layer(layer, plan)
+            ops.value_proj_heads_bwd(c['gout'], c['w_v'], c['b_v'], hh, grad_agg=sink.grad_agg_rows(layer))
+        if riding:
+            sink.scan()
+            for n in (2, 1):
+                got = ops.mha_core_bwd(qh, kh, vh, out, do, lse, 8, packed_qk=True, fills=sink.take_fills(n))
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            assert sink.plans == [] and len(sink._riding) == 3 and sink.take_fills(2) is None
+        res[riding] = sink.finish()
+    for a, e in zip(res[True], res[False]):
+        assert _rel(a, e) < 1e-5
+
+
 def test_raw_backward_raw_camera_weights():
     """GD4D_CA_RAW_CAM_WEIGHTS (Deform3DCrossAttnMP's neighbour pass): no sigmoid on the camera logits."""
     c = _case(8, 4, 6, 48, 1, seed=5)
