@@ -32,5 +32,5 @@ tail -1 gpurun_out/r04c/bench_inflight1.json | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']
 print('inflight1:', round(d['value'],1), d['ms_per_step'], 'frac', r['frac'], 'us', r.get('us_per_launch'))"
 ulimit -c 0
-timeout 1500 python3 -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/r04c/pytest_final.log 2>&1; echo "all rc=$? $(tail -1 gpurun_out/r04c/pytest_final.log)"
+timeout 600 python3 -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/r04c/pytest_final.log 2>&1; echo "all rc=$? $(tail -1 gpurun_out/r04c/pytest_final.log)"
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
