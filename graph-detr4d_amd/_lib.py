@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 48
+ABI_VERSION = 49
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -95,7 +95,7 @@ SIGNATURES = {
     'gd4d_chain_op_bytes': (_c.c_size_t, []),
     'gd4d_row_chain_fwd': (_i, [_vp, _i, _i, _vp]),
     'gd4d_row_chain2_fwd': (_i, [_vp, _i, _vp, _i, _i, _vp]),
-    'gd4d_mha_core_presplit_fwd': (_i, [_vp] * 4 + [_i] * 5 + [_c.c_longlong, _c.c_longlong, _vp, _i, _f, _vp]),
+    'gd4d_mha_core_presplit_fwd': (_i, [_vp] * 4 + [_i] * 5 + [_c.c_longlong, _c.c_longlong, _vp, _i, _f, _vp, _f, _vp, _vp]),
     'gd4d_row_chain_mha_fwd': (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 4 + [_i] * 6 + [_f, _vp, _vp, _vp]),
     'gd4d_chain_weight_image_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_chain_weight_image': (_i, [_vp, _i, _i, _vp, _vp]),

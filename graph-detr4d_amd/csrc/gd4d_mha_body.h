@@ -3,6 +3,7 @@
 // Reference: see gd4d_self_attn.hip.
 #pragma once
 #include "gd4d_common.h"
+#include "gd4d_mha_dropout.h"
 
 namespace gd4d {
 
@@ -78,7 +79,9 @@ struct MhaShared {
 };
 
 // One workgroup (8 waves) = one (16-query tile qblock, head h, batch b); the stores of `out` are the last thing it issues.
-template <int MASK, int AHEAD = 1, bool PRE = false>
+// DROP (training, modules in train mode): the probabilities are dropped as in the fp32 kernel of gd4d_self_attn.hip - same element
+// ids, same hash, the normaliser and the saved log-sum-exp those of the full softmax.
+template <int MASK, int AHEAD = 1, bool PRE = false, bool DROP = false>
 __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const int qblock, const int h, const int b, MhaShared& sh) {
   float (&s_m)[MHA_WAVES][16] = sh.m;
   float (&s_l)[MHA_WAVES][16] = sh.l;
@@ -103,6 +106,11 @@ __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const i
   }
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};    // O^T rows d = 4g + r, and 16 + 4g + r
   float m = NEG_INF, l = 0.f;
+  uint32_t seed_lo = 0, seed_hi = 0, drop_row = 0;
+  if (DROP) {
+    seed_lo = p.seed[0]; seed_hi = p.seed[1];
+    drop_row = mha_drop_row(b, h, min(q0 + qi, p.Lq - 1), p.H, p.Lq, p.Lk);
+  }
   const int nsteps = (p.Lk + 31) / 32;
   const size_t hoff = (size_t)h * MHA_D;
   const size_t mask_row = (size_t)min(q0 + qi, p.Lq - 1) * p.Lk;
@@ -203,6 +211,12 @@ __device__ __forceinline__ void mha_core_bf16x3_body(const MhaParams& p, const i
     for (int j = 0; j < 8; ++j) pr[j] = __builtin_amdgcn_exp2f(sc[j] - m_use);
     l = l * corr + (((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])));
     m = m_new;
+    if (DROP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        pr[j] = mha_drop_keep(seed_lo, seed_hi, drop_row + (uint32_t)(kbase + 16 * (j >> 2) + 4 * g + (j & 3)), p.drop_thresh)
+                    ? pr[j] * p.inv_keep : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { o0[r] *= corr; o1[r] *= corr; }
     // ---- O^T += V^T P^T: A = V^T[d = lane & 15 (+ 16)][k = 8 g + j], B = P^T = this lane's own eight probabilities ----

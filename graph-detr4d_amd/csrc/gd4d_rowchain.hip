@@ -244,7 +244,8 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
   const bool src2 = (op.flags & GD4D_CHAIN_SRC2) != 0, split_out = (op.flags & GD4D_CHAIN_SPLIT_OUT) != 0;
   // GD4D_CHAIN_SPLIT_KV: pass 1 (K) and pass 2 (V) of the packed in-projection also leave as bf16 hi / lo planes (p2: K row-major,
   // p3: V^T) - the operands gd4d_mha_core_presplit_fwd feeds to its MFMAs without converting anything
-  const bool split_kv = !TRAIN && (op.flags & GD4D_CHAIN_SPLIT_KV) != 0;
+  const bool split_kv = (op.flags & GD4D_CHAIN_SPLIT_KV) != 0;
+  const bool kv_fp32_too = (op.flags & GD4D_CHAIN_SPLIT_KV_KEEP) != 0;    // (a training step: the attention BACKWARD reads fp32 rows)
   // GD4D_CHAIN_MASK_P2: p2 is not an addend but the OUTPUT a ReLU produced in the forward pass - the result (the gradient at that
   // ReLU's output) passes where it was > 0, times `eps` when that is non-zero (the 1 / (1 - p) of a dropout that followed the ReLU
   // and left its zeros in p2 as well)
@@ -377,7 +378,7 @@ __device__ __forceinline__ void rc_gemm(const ChainOp& op, float (*bufs)[RC_M][R
                               : const_cast<float*>(op.p3) + (size_t)m * op.ld1 + (n - c2);
             *o = v;
           }
-        } else if (op.gout && m < M && !(split_kv && n_base >= RC_COLS * RC_WAVES)) {   // (K and V leave as planes only)
+        } else if (op.gout && m < M && !(split_kv && !kv_fp32_too && n_base >= RC_COLS * RC_WAVES)) {   // (K and V leave as planes only)
           op.gout[(size_t)m * op.ldg + n] = v;
         }
       }

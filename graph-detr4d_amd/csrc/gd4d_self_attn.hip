@@ -209,11 +209,11 @@ __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_bf16x3_kernel(const M
 }
 
 // ... with K and V as pre-split bf16 planes (written by the in-projection: GD4D_CHAIN_SPLIT_KV); batch 1
-template <int MASK>
+template <int MASK, bool DROP>
 __global__ __launch_bounds__(64 * MHA_WAVES) void mha_core_presplit_kernel(const MhaParams p) {
   trace_mark(g_trace_mha, 2ull);
   __shared__ MhaShared sh;
-  mha_core_bf16x3_body<MASK, 1, true>(p, blockIdx.x, blockIdx.y, 0, sh);
+  mha_core_bf16x3_body<MASK, 1, true, DROP>(p, blockIdx.x, blockIdx.y, 0, sh);
   trace_mark(g_trace_mha, 0x82ull);
 }
 
@@ -255,21 +255,30 @@ extern "C" int gd4d_mha_core_fwd(const float* q, const float* k, const float* v,
 
 extern "C" int gd4d_mha_core_presplit_fwd(const float* q, const void* k_planes, const void* v_planes, float* out, int L, int H, int D,
                                           int ldq, int ldo, long long k_plane_stride, long long v_plane_stride, const void* mask,
-                                          int mask_kind, float scale, void* stream) {
+                                          int mask_kind, float scale, float* lse, float drop_p, const void* seed, void* stream) {
   using namespace gd4d;
   if (!q || !k_planes || !v_planes || !out || L <= 0 || H <= 0) return GD4D_EINVAL;
+  if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && !seed)) return GD4D_EINVAL;
+  if (drop_p > 0.f && (double)H * L * L >= 4294967296.0) return GD4D_EUNSUPPORTED;   // element ids are 32 bits
   if (D != MHA_D || mask_kind < 0 || mask_kind > 2 || (mask_kind && !mask)) return GD4D_EUNSUPPORTED;
   const long long tiles = (L + 15) / 16, steps = (L + 31) / 32;
   if (ldq < H * D || ldo < H * D || k_plane_stride < H * tiles * 512 || v_plane_stride < H * steps * 1024 ||
       (k_plane_stride & 7) || (v_plane_stride & 7))
     return GD4D_EINVAL;
   if (!aligned16(q) || (ldq % 4) || !aligned16(k_planes) || !aligned16(v_planes)) return GD4D_EALIGN;
-  MhaParams p{q, nullptr, nullptr, mask, out, nullptr, L, L, 1, H, ldq, 0, 0, ldo, mask_kind, scale, nullptr, 0u, 1.f,
+  MhaParams p{q, nullptr, nullptr, mask, out, lse, L, L, 1, H, ldq, 0, 0, ldo, mask_kind, scale,
+              static_cast<const uint32_t*>(seed), mha_drop_thresh(drop_p), 1.f / (1.f - drop_p),
               static_cast<const unsigned short*>(k_planes), static_cast<const unsigned short*>(v_planes), k_plane_stride, v_plane_stride};
   const dim3 grid((L + 15) / 16, H, 1), block(64 * MHA_WAVES);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (mask_kind == 0) hipLaunchKernelGGL(mha_core_presplit_kernel<0>, grid, block, 0, st, p);
-  else if (mask_kind == 1) hipLaunchKernelGGL(mha_core_presplit_kernel<1>, grid, block, 0, st, p);
-  else hipLaunchKernelGGL(mha_core_presplit_kernel<2>, grid, block, 0, st, p);
+  if (drop_p > 0.f) {
+    if (mask_kind == 0) hipLaunchKernelGGL((mha_core_presplit_kernel<0, true>), grid, block, 0, st, p);
+    else if (mask_kind == 1) hipLaunchKernelGGL((mha_core_presplit_kernel<1, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mha_core_presplit_kernel<2, true>), grid, block, 0, st, p);
+  } else {
+    if (mask_kind == 0) hipLaunchKernelGGL((mha_core_presplit_kernel<0, false>), grid, block, 0, st, p);
+    else if (mask_kind == 1) hipLaunchKernelGGL((mha_core_presplit_kernel<1, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mha_core_presplit_kernel<2, false>), grid, block, 0, st, p);
+  }
   return check_launch();
 }

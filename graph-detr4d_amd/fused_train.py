@@ -213,8 +213,14 @@ class DecoderTrainFunction(torch.autograd.Function):
         qkv, xp = new(q, 1, 3 * c), new(q, c)
         im0 = imgs.layers[0]
         p0 = dict(zip(NAMES, params[:PER_LAYER]))
+        # K / V also as the attention core's split-bf16 operands (one pair of planes for all layers: a layer's core has read them
+        # before the next in-projection writes them); the fp32 rows stay for the attention backward
+        kv = None
+        if (c == 256 and layers[0].attentions[0].num_heads == 8 and (mask is None or mask.dim() == 2)
+                and os.environ.get('GD4D_MHA_PRESPLIT', '1') != '0' and os.environ.get('GD4D_MHA_FP32') != '1'):
+            kv = ops.KVPlanes(q, c, dev, heads=8)
         ops.row_chain_fwd([ops.chain_load(0, x, pos, out=xp), ops.chain_load(1, x),
-                           ops.chain_gemm_two_sources(0, 1, 2 * c, im0['inproj'], p0['in_b'], qkv.view(q, -1))], q)
+                           ops.chain_gemm_two_sources(0, 1, 2 * c, im0['inproj'], p0['in_b'], qkv.view(q, -1), kv=kv, keep_fp32=True)], q)
         # the locality order of the INITIAL reference points for every layer, as the inference loop (fused_decoder.run_single): the
         # refinements move a point little, a stale order costs a gather ~2 us, a fresh one a launch
         order = Fn.query_order(ref, layers[0].attentions[1].pc_range)
@@ -229,8 +235,12 @@ class DecoderTrainFunction(torch.autograd.Function):
             # the dropout sites of the layer: (seed, p) each, or None
             s.drop = [(seeds[5 * lid + i:5 * lid + i + 1], pr) if pr > 0. else None for i, pr in enumerate(drops[lid])]
             qh, kh, vh = qkv.split(c, dim=-1)
-            s.o, s.lse = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, mask, want_lse=True,
-                                          dropout_p=drops[lid][0], seed=s.drop[0][0] if s.drop[0] else None)
+            if kv is not None:
+                s.o, s.lse = ops.mha_core_presplit_fwd(qh, kv, sa.num_heads, mask, want_lse=True,
+                                                       dropout_p=drops[lid][0], seed=s.drop[0][0] if s.drop[0] else None)
+            else:
+                s.o, s.lse = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, mask, want_lse=True,
+                                              dropout_p=drops[lid][0], seed=s.drop[0][0] if s.drop[0] else None)
             s.y1, s.x1, s.x1p = new(q, c), new(q, c), new(q, c)
             s.cam, s.off, s.att = new(1, q, ncam), new(1, q, hh * npt * 3), new(1, q, hh * nlv * npt)
             prog_a = [ops.chain_load(0, s.o.view(q, c)),
@@ -273,7 +283,7 @@ class DecoderTrainFunction(torch.autograd.Function):
                 qkv, xp = new(q, 1, 3 * c), new(q, c)
                 pn = dict(zip(NAMES, params[(lid + 1) * PER_LAYER:(lid + 2) * PER_LAYER]))
                 prog += [ops.chain_add(0, 3, c, add=pos, out=xp),
-                         ops.chain_gemm_two_sources(0, 3, 2 * c, imgs.layers[lid + 1]['inproj'], pn['in_b'], qkv.view(q, -1))]
+                         ops.chain_gemm_two_sources(0, 3, 2 * c, imgs.layers[lid + 1]['inproj'], pn['in_b'], qkv.view(q, -1), kv=kv, keep_fp32=True)]
             if meta.reg_branches is not None:
                 # reg branch + refinement (:199-214); the refined points are DETACHED (:213): no gradient leaves this tail.  It needs
                 # the layer's output only, so it runs as the launch's second program beside the next layer's in-projection: the first

@@ -1602,7 +1602,7 @@ class ChainOp(ctypes.Structure):
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 CHAIN_LN_BWD, CHAIN_DROPMASK = 10, 11
 CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT, CHAIN_MASK_P2, CHAIN_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128
-CHAIN_SPLIT_KV = 256
+CHAIN_SPLIT_KV, CHAIN_SPLIT_KV_KEEP = 256, 512
 
 
 def _rows(t, name):
@@ -1830,11 +1830,11 @@ class KVPlanes:
         return self.v.view(2, h, s, 2, 4, 16, 2, 4).permute(0, 2, 6, 4, 7, 1, 3, 5).reshape(2, s * 32, h * 32)
 
 
-def chain_gemm_two_sources(src, src2, split, weight, bias, out, kv=None):
+def chain_gemm_two_sources(src, src2, split, weight, bias, out, kv=None, keep_fp32=False):
     """One GEMM over a stacked weight (N, K) whose output columns [0, split) are computed from buf[src] and [split, N) from
     buf[src2] (split a multiple of 256): nn.MultiheadAttention's packed in-projection with q, k from x + pos and v from x.
     kv (KVPlanes, N = 768): the K and V columns are written as the attention core's split-bf16 operands INSTEAD of fp32 (out
-    receives the Q columns only)."""
+    receives the Q columns only; keep_fp32 - a training step, whose attention backward reads fp32 rows: all columns)."""
     g, ldg = _rows(out, 'out')
     img, n, k = _image_of(weight)
     op = ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=k, N=n, flags=CHAIN_SRC2, ld0=int(split),
@@ -1842,7 +1842,7 @@ def chain_gemm_two_sources(src, src2, split, weight, bias, out, kv=None):
     if kv is not None:
         if n != 3 * kv.c or kv.c != 256 or kv.heads != 8:
             raise ValueError('kv planes: the packed in-projection of 256 channels, 8 heads')
-        op.flags |= CHAIN_SPLIT_KV
+        op.flags |= CHAIN_SPLIT_KV | (CHAIN_SPLIT_KV_KEEP if keep_fp32 else 0)
         op.p2, op.ld2 = kv.k.data_ptr(), kv.k[0].numel()
         op.p3, op.ld1 = kv.v.data_ptr(), kv.v[0].numel()
     return op
@@ -1979,9 +1979,10 @@ def row_chain2_fwd(program_a, program_b, m):
     _lib.check(code, 'gd4d_row_chain2_fwd')
 
 
-def mha_core_presplit_fwd(q, kv, num_heads, attn_mask=None):
+def mha_core_presplit_fwd(q, kv, num_heads, attn_mask=None, want_lse=False, dropout_p=0., seed=None):
     """gd4d_mha_core_presplit_fwd: the self-attention core (batch 1) on K / V planes a chain GEMM wrote (KVPlanes).
-    q (M, 1, C), attn_mask as for mha_core_fwd.  Returns (M, 1, C); bit-identical to mha_core_fwd on the fp32 rows."""
+    q (M, 1, C); attn_mask, want_lse, dropout_p / seed as for mha_core_fwd.  Returns (M, 1, C) [, lse]; without dropout
+    bit-identical to mha_core_fwd on the fp32 rows."""
     lib = _lib.load()
     lq, b, c = q.shape
     _, _, _, _, _, _, kind, mptr, keep = _mha_args(q, q, q, num_heads, attn_mask)
@@ -1991,11 +1992,14 @@ def mha_core_presplit_fwd(q, kv, num_heads, attn_mask=None):
         raise _lib.Gd4dError('q must be a float32 GPU tensor with unit channel stride')
     d = c // num_heads
     out = torch.empty(lq, 1, c, device=q.device, dtype=torch.float32)
+    lse = torch.empty(lq, 1, num_heads, device=q.device, dtype=torch.float32) if want_lse else None
+    sptr = _mha_seed(dropout_p, seed, q.device)
     code = lib.gd4d_mha_core_presplit_fwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(kv.k.data_ptr()),
                                           ctypes.c_void_p(kv.v.data_ptr()), _dev(out, 'out'), lq, num_heads, d, q.stride(0), c,
-                                          kv.k[0].numel(), kv.v[0].numel(), mptr, kind, 1.0 / (d ** 0.5), _stream())
+                                          kv.k[0].numel(), kv.v[0].numel(), mptr, kind, 1.0 / (d ** 0.5),
+                                          None if lse is None else _dev(lse, 'lse'), float(dropout_p), sptr, _stream())
     _lib.check(code, 'gd4d_mha_core_presplit_fwd')
-    return out
+    return (out, lse) if want_lse else out
 
 
 def row_chain_mha_fwd(program, program_side, m, q, k, v, num_heads, flags, errors=None, out=None):

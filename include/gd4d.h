@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 48
+#define GD4D_ABI_VERSION 49
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -602,6 +602,7 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
                                        16 (j >> 2) + 4 g + (j & 3), hi plane then lo plane `ld1` elements further (ld1 >= 8
                                        ceil(M / 32) 1024).  Rows past M of the last block are written too (finite).  p2 / p3 are
                                        outputs, not addends.  Read by gd4d_mha_core_presplit_fwd */
+#define GD4D_CHAIN_SPLIT_KV_KEEP 512 /* with GD4D_CHAIN_SPLIT_KV: gout receives the K and V columns too (fp32, for gd4d_mha_core_bwd) */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
@@ -655,15 +656,16 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
 
-/* gd4d_mha_core_presplit_fwd - gd4d_mha_core_fwd (batch 1, Lq = Lk = L, no dropout; mask / mask_kind as there) with K and V handed over as the
+/* gd4d_mha_core_presplit_fwd - gd4d_mha_core_fwd (batch 1, Lq = Lk = L; mask / mask_kind, lse, drop_p / seed as there) with K and V handed over as the
  * split-bf16 operands of its MFMAs instead of fp32 rows: the two plane pairs a GEMM operation with GD4D_CHAIN_SPLIT_KV writes
  * beside the fp32 in-projection (layouts there; k_plane_stride / v_plane_stride = elements from the hi to the lo plane).  The
  * kernel converted every K / V row once per 16-query tile (57 times at 900 queries: 112 of its 313 vector instructions per 32
  * keys) and fetched V with 16 dword loads per step; here a step is eight 16-byte loads, each 1 KB contiguous per wave.
- * Results bit-identical to gd4d_mha_core_fwd on the same q, k, v. */
+ * Results bit-identical to gd4d_mha_core_fwd on the same q, k, v without dropout; with drop_p > 0 that entry point runs its
+ * fp32-MFMA kernel: the same elements dropped, values equal to ~2^-16 relative. */
 int gd4d_mha_core_presplit_fwd(const float* q, const void* k_planes, const void* v_planes, float* out, int L, int H, int D,
                                int ldq, int ldo, long long k_plane_stride, long long v_plane_stride, const void* mask,
-                               int mask_kind, float scale, void* stream);
+                               int mask_kind, float scale, float* lse, float drop_p, const void* seed, void* stream);
 
 /* gd4d_row_chain_mha_fwd - the decoder's self-attention core (gd4d_mha_core_fwd without mask, batch 1, Lq = Lk = M: mmcv
  * MultiheadAttention between its in- and out-projection, config detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78) and

@@ -339,6 +339,19 @@ def test_in_projection_writes_the_attention_cores_split_operands(m):
     blocked.fill_diagonal_(False)
     for mask in (blocked, torch.randn(m, m, device=DEV)):
         assert torch.equal(ops.mha_core_presplit_fwd(qkv[..., :c], kv, heads, mask), ops.mha_core_fwd(qh, kh, vh, heads, mask))
+    # a training step: the fp32 K / V rows stay (keep_fp32), the core drops probabilities as the fp32 kernel does and saves the
+    # log-sum-exp: the same elements dropped, values within the split-bf16 products' 2^-16
+    kv2 = ops.KVPlanes(m, c, DEV)
+    qkv2 = torch.empty(m, 1, 3 * c, device=DEV)
+    op = ops.chain_gemm_two_sources(0, 1, 2 * c, w, b, qkv2.view(m, -1), kv=kv2, keep_fp32=True)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x), op], m)
+    assert torch.equal(qkv2, qkv_ref) and torch.equal(kv2.k, kv.k) and torch.equal(kv2.v, kv.v)
+    seed = ops.mha_dropout_seed(DEV)
+    for pdrop in (0., 0.1):
+        want, want_lse = ops.mha_core_fwd(qh, kh, vh, heads, want_lse=True, dropout_p=pdrop, seed=seed if pdrop else None)
+        got, got_lse = ops.mha_core_presplit_fwd(qkv2[..., :c], kv2, heads, want_lse=True, dropout_p=pdrop, seed=seed if pdrop else None)
+        torch.testing.assert_close(got, want, rtol=1e-3, atol=2e-4)      # (without dropout the two are bit-identical: above)
+        torch.testing.assert_close(got_lse, want_lse, rtol=1e-5, atol=1e-5)
     with pytest.raises(_lib.Gd4dError):                          # planes only beside the whole 768-column projection
         op = ops.chain_gemm(0, w[:c], b[:c], out=qkv_ref.view(m, -1)[:, :c])
         op.flags |= ops.CHAIN_SPLIT_KV
