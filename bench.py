@@ -67,6 +67,7 @@ def parse():
     ap.add_argument('--no-preflight', action='store_true', help='N > 1: skip the rank / device / all-reduce-alone check before the timed steps')
     ap.add_argument('--dropout', action='store_true', help='--mode train: modules in train() mode (dropout 0.1 as the reference trains); default: eval mode, autograd on')
     ap.add_argument('--no-fuse-wgrad', action='store_true', help='--mode train: leave the accumulation of parameter gradients to autograd')
+    ap.add_argument('--torch-sgd', action='store_true', help='--mode train: torch.optim.SGD.step() instead of the one-launch flat SGD (dist.FlatGradAllReducer.sgd_step)')
     ap.add_argument('--no-roofline', action='store_true', help='dev: skip the kernel-level roofline section (roofline = null)')
     ap.add_argument('--no-stress', action='store_true',
                     help='skip the all-visible stress launches of the gather kernels (SURVEY 8d): a rocprofv3 --stats run then '
@@ -416,15 +417,27 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     params = list(tr.parameters()) + list(regs.parameters()) + (list(cls_branches.parameters()) if a.criterion else []) \
         + (list(teacher[5].parameters()) if distill else [])
     opt = torch.optim.SGD(params, lr=1e-4)
+    # plain SGD as ONE launch over the flat parameter / gradient buffers (dist.FlatGradAllReducer.sgd_step: the same update, bit
+    # for bit) instead of torch.optim.SGD's four multi-tensor launches (~110 us of the step); --torch-sgd keeps the optimizer object
+    flat_sgd = not a.torch_sgd
+
+    def sgd_step():
+        if flat_sgd:
+            reducer.sgd_step(1e-4)
+        else:
+            opt.step()
     # gradient buckets in the order backward finalises them (head branches, then the decoder layers last to first): with
     # several ranks the slices are all-reduced back to back after the captured backward (reduce_buckets), or from
     # post-accumulate hooks while the backward is still running (--overlap-comm, eager launch)
     reducer = D.FlatGradAllReducer(params, buckets=D.decoder_buckets(tr, regs, cls_branches if a.criterion else None,
-                                                                     teacher[5] if distill else None))
+                                                                     teacher[5] if distill else None),
+                                   align=4 if flat_sgd else 1)      # (16-byte slices: the flat parameter buffer's layout too)
     # .grad = views of one flat buffer from the start (graph captures); unless the all-reduce is driven by autograd hooks
     # (--overlap-comm) the weight-gradient kernels add into those views themselves (no accumulation launch per parameter)
     fuse = not (a.overlap_comm and world_size > 1) and not a.no_fuse_wgrad
     reducer.bind(fuse_weight_grads=fuse)
+    if flat_sgd:
+        reducer.flatten_params()                      # before anything captures a parameter's address
     if a.dropout:
         tr.train()                                    # the reference's training mode: dropout 0.1 in the attentions and the FFN
     else:
@@ -515,7 +528,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             torch.cuda.synchronize(); t3 = time.perf_counter()
             print(f'[split] backward: host returned after {1e3 * (t3c - t2):.2f} ms', file=sys.stderr)
             reducer.reduce()
-            opt.step()
+            sgd_step()
             torch.cuda.synchronize(); t4 = time.perf_counter()
             print(f'[split] forward {1e3 * (t1 - t0):.2f}  loss {1e3 * (t2 - t1):.2f}  backward {1e3 * (t3 - t2):.2f}  '
                   f'reduce + SGD {1e3 * (t4 - t3):.2f} ms', file=sys.stderr)
@@ -529,7 +542,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             grad_box.copy_(b.grad)
             g_bwd.replay()
             reducer.reduce()
-            opt.step()
+            sgd_step()
             return
         if distill:
             loss = distill_loss()
@@ -548,7 +561,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                 reducer.reduce_buckets()
             else:
                 reducer.reduce()
-            opt.step()
+            sgd_step()
 
     # The step is ~2500 launches, most of them small: eagerly it is bound by the host's launch rate, not by the GPU.
     # One process: forward + backward + SGD are captured into one hipGraph (warm-up on a side stream first so that
@@ -583,7 +596,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                 def run():
                     graph.replay()
                     reducer.reduce_buckets()
-                    opt.step()
+                    sgd_step()
                 launch = 'hipgraph (forward + backward), eager bucketed all-reduce + SGD'
             run()
             torch.cuda.synchronize()
@@ -618,6 +631,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                        'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),
                        'overlap_comm': overlap, 'weight_grads_accumulated_by_kernels': fuse, 'input_layout': a.input_layout,
                        'dropout': 'on (train mode)' if a.dropout else 'off (modules in eval mode, autograd on)',
+                       'optimizer': 'SGD lr 1e-4, ' + ('one launch over the flat parameter / gradient buffers (dist.FlatGradAllReducer.sgd_step)' if flat_sgd else 'torch.optim.SGD.step()'),
                        'query_side': ('row chains forward and backward, one autograd node for the decoder (graph_detr4d_amd/fused_train.py)'
                                       if _chain_calls() else
                                       'one autograd node per Linear / LayerNorm / attention core (the generic path)'),

@@ -352,7 +352,9 @@ def test_config3_two_rank_training_step_dry_run(request):
     assert line['value'] > 0 and abs(line['value'] - 2 * 1e3 / line['ms_per_step']) < 1e-6 * line['value']
     assert 0 < line['ms_per_step_rank_min'] <= line['ms_per_step_rank_max'] <= line['ms_per_step'] * 1.0001
     assert line['allreduce_bytes_per_step'] == sum(line['allreduce_buckets']) > 1e6
-    assert line['allreduce_bytes_per_step'] == line['param_bytes']            # what DDP would all-reduce (mmdet_distill_train.py:78-82)
+    # what DDP would all-reduce (mmdet_distill_train.py:78-82), plus the padding that starts every parameter's slice of the flat
+    # buffers at 16 bytes (the one-launch SGD's layout: < 16 bytes per parameter)
+    assert line['param_bytes'] <= line['allreduce_bytes_per_step'] <= line['param_bytes'] + 12 * 400
     assert len(line['allreduce_buckets']) == 4              # reg branches, decoder layer 1, layer 0, the rest (reference_points)
     pre = line['preflight']                                  # ran before the timed steps: ranks, devices, all-reduces alone
     assert pre['world'] == 2 and len(pre['ranks']) == 2 and all(x['sum_ok'] for x in pre['allreduce'])

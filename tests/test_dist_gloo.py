@@ -4,6 +4,7 @@ import os
 import socket
 import time
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -257,3 +258,36 @@ def test_preflight_two_ranks_gloo():
         plan = pre['bucket_plan']
         assert plan['allreduce_bytes'] == param_bytes + 4 * 2 and sum(plan['buckets']) == param_bytes
     assert res[0][2]['allreduce'][0]['ms'] == res[1][2]['allreduce'][0]['ms']        # MAX over ranks: one figure for the job
+
+
+def test_flat_sgd_step_equals_torch_sgd():
+    """FlatGradAllReducer.flatten_params / sgd_step: every parameter becomes a view of one flat buffer (values kept, modules
+    still see them), and the one-launch update equals torch.optim.SGD(lr) bit for bit over three steps; version counters move."""
+    import copy
+    import torch
+    from graph_detr4d_amd import dist as D
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 3))
+    ref = copy.deepcopy(net)
+    with pytest.raises(RuntimeError):
+        D.FlatGradAllReducer(list(net.parameters())).flatten_params()      # slices of 16 bytes only
+    red = D.FlatGradAllReducer(list(net.parameters()), align=4)
+    red.bind()
+    before = [p.detach().clone() for p in net.parameters()]
+    fp = red.flatten_params()
+    assert fp.numel() == red.numel >= sum(p.numel() for p in net.parameters()) and all(p.data_ptr() % 16 == 0 for p in net.parameters())
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p, b) and p.data_ptr() >= fp.data_ptr() and p.data_ptr() < fp.data_ptr() + 4 * fp.numel()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.05)
+    for step in range(3):
+        x = torch.randn(11, 7)
+        red.zero_grad()
+        opt.zero_grad()
+        net(x).square().mean().backward()
+        ref(x).square().mean().backward()
+        v0 = [p._version for p in net.parameters()]
+        red.sgd_step(0.05)
+        opt.step()
+        assert all(p._version > v for p, v in zip(net.parameters(), v0))
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.equal(p, q)
