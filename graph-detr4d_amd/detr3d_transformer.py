@@ -536,7 +536,12 @@ class Detr3DTransformer(nn.Module):
         else:
             query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
             query = query.unsqueeze(0).expand(bs, -1, -1)
-            reference_points = self.reference_points(query_pos).sigmoid()
+            # (training: the library's Linear forward / input gradient, its weight gradient queued with the decoder's - through
+            #  torch this one 256 -> 3 Linear was a 25-us library GEMM in the backward pass)
+            if os.environ.get('GD4D_REFPOINTS_TORCH') == '1':
+                reference_points = self.reference_points(query_pos).sigmoid()
+            else:
+                reference_points = Fn.linear_autograd(query_pos, self.reference_points.weight, self.reference_points.bias).sigmoid()
             q_in, pos_in = query.permute(1, 0, 2), query_pos.permute(1, 0, 2)
         init_reference_out = reference_points
         inter_states, inter_references = self.decoder(
