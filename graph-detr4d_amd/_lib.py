@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 49
+ABI_VERSION = 50
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -40,6 +40,7 @@ SIGNATURES = {
     'gd4d_value_proj_heads_bwd_weight_group': (_i, [_vp] * 6 + [_i, _vp, _c.c_size_t, _i, _i, _i, _vp]),
     'gd4d_cross_attn_dot_bytes': (_c.c_size_t, [_i] * 5),
     'gd4d_cross_attn_dot_sliced': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp, _vp]),
+    'gd4d_cross_attn_dot_sliced_fused': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp] + [_vp] * 5 + [_i, _i, _vp]),
     'gd4d_cross_attn_dot_sliced_wgrad': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp] + [_vp] * 5 + [_i, _i, _vp]),
     'gd4d_cross_attn_plan_bwd': (_i, [_vp] * 6 + [_f, _f] + [_vp] * 9 + [_c.c_size_t, _vp] + [_i] * 7 + [_vp, _vp]),
     'gd4d_pyramid_grad_chunks': (_c.c_int64, [_vp, _i, _i]),

@@ -443,15 +443,24 @@ class DecoderTrainFunction(torch.autograd.Function):
             # the gather's backward (autograd.CrossAttnRawFunction.backward)
             p = dict(zip(NAMES, params[base:base + PER_LAYER]))
             vp_w, vp_b = p['vp_w'].detach().contiguous(), p['vp_b'].detach().contiguous()
-            gagg, beta = ops.value_proj_heads_bwd(gv.view(1, q, c), vp_w, vp_b, hh,
-                                                  grad_agg=raw.sink.grad_agg_rows(s.layer) if want_pyramid else None)
-            raw.layer_done()
             n_cam_rows = s.plan.pyramid.rows
             # the weight gradients queued so far (this layer's chain B, the layer above's chain A / in-projection) ride in the
             # gather-dot's launch instead of waiting for the pass's end
             riders = take_queued_weight_grads() if ride_wgrads and ops.wgrads_ride_with(s.plan) else None
-            dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)),
-                                              wgrads=riders)
+            if ops.wgrads_ride_with(s.plan) and os.environ.get('GD4D_TRAIN_HEADS_BWD', 'own') == 'dot':
+                # dev switch: value_proj_heads_bwd computed INSIDE that launch (bit-identical; measured +0.2 ms per step: every
+                # workgroup streams its 4 KB of value_proj's weight through the L2 the gather-dot is bound by)
+                beta = new(1, q, hh)
+                dpart = ops.cross_attn_dot_sliced(s.plan, None, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)),
+                                                  wgrads=riders,
+                                                  heads=(gv.view(1, q, c), vp_w, vp_b, raw.sink.grad_agg_rows(s.layer) if want_pyramid else None, beta))
+                raw.layer_done()
+            else:
+                gagg, beta = ops.value_proj_heads_bwd(gv.view(1, q, c), vp_w, vp_b, hh,
+                                                      grad_agg=raw.sink.grad_agg_rows(s.layer) if want_pyramid else None)
+                raw.layer_done()
+                dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)),
+                                                  wgrads=riders)
             off5, att5 = s.off.view(1, q, hh, ca.num_points, 3), s.att.view(1, q, hh, ca.num_levels, ca.num_points)
             gr, go, ga, gc = ops.cross_attn_plan_bwd(s.plan, dpart, beta, s.ref, off5, att5, s.cam, meta.lidar2img, ca.pc_range,
                                                      meta.img_h, meta.img_w)

@@ -473,11 +473,13 @@ def _wgrad_arrays(problems):
     return arr(xs), arr(gys), arr(gws), arr(gbs), (ctypes.c_int32 * (5 * n))(*dims), n
 
 
-def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None):
+def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None, heads=None):
     """gd4d_cross_attn_dot_sliced: D[pair] = <grad_agg[q, h], raw pixel of the pair> for every pair of `plan`, as 8 per-slice
     partials (uint8 buffer of gd4d_cross_attn_dot_bytes; only the passes the plan uses are written).
     wgrads: up to 16 weight-gradient problems (as linear_bwd_weight_group takes them; added to their targets) whose tiles ride
-    in the launch (gd4d_cross_attn_dot_sliced_wgrad; 8 heads, 4 levels, fp32: wgrads_ride_with(plan) says whether)."""
+    in the launch (gd4d_cross_attn_dot_sliced_wgrad; 8 heads, 4 levels, fp32: wgrads_ride_with(plan) says whether).
+    heads = (grad_out (B, Q, 256), vp_weight, vp_bias or None, grad_agg_out (B, Q, Hh, 256) or None, beta_out (B, Q, Hh) or None)
+    with grad_agg=None: value_proj_heads_bwd is computed inside the launch too (gd4d_cross_attn_dot_sliced_fused; same shapes)."""
     lib = _lib.load()
     plan.need_pairs('gd4d_cross_attn_dot_sliced')
     pyramid = plan.pyramid
@@ -488,6 +490,22 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None):
     if dpart is None:
         dpart = torch.empty(nbytes, device=pyramid.device, dtype=torch.uint8)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
+    if heads is not None:
+        gout, vw, vb, table, beta = heads
+        f32 = torch.float32
+        if wgrads:
+            xs, gys, gws, gbs, dims, cnt = _wgrad_arrays(wgrads)
+        else:
+            xs = gys = gws = gbs = dims = None
+            cnt = 0
+        code = lib.gd4d_cross_attn_dot_sliced_fused(
+            ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(gout, 'grad_out', f32), _dev(vw, 'vp_weight', f32),
+            None if vb is None else _dev(vb, 'vp_bias', f32), None if table is None else _dev(table, 'grad_agg_out', f32),
+            None if beta is None else _dev(beta, 'beta_out', f32), _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256,
+            nl, 4, _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+            None if plan.order is None else _order_ptr(plan.order, b * q), xs, gys, gws, gbs, dims, cnt, 1, _stream())
+        _lib.check(code, 'gd4d_cross_attn_dot_sliced_fused')
+        return dpart
     if wgrads:
         xs, gys, gws, gbs, dims, cnt = _wgrad_arrays(wgrads)
         code = lib.gd4d_cross_attn_dot_sliced_wgrad(

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 49
+#define GD4D_ABI_VERSION 50
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -307,6 +307,19 @@ int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t slice_stri
 int gd4d_cross_attn_dot_sliced_wgrad(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
                                      const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C,
                                      int L, int P, int feats_dtype, const int32_t* query_order, const void* const* x,
+                                     const void* const* grad_y, void* const* grad_w, void* const* grad_b, const int32_t* dims,
+                                     int count, int accumulate, void* stream);
+
+/* gd4d_cross_attn_dot_sliced_fused - the whole pyramid side of a decoder layer's backward in front of gd4d_cross_attn_plan_bwd as ONE
+ * launch: gd4d_value_proj_heads_bwd (grad_out (B Q, 256) = the gradient at value_proj's output, vp_weight / vp_bias -> the layer's
+ * grad_agg rows, written to grad_agg_out (B, Q, Hh, 256; may be NULL), and beta_out (B, Q, Hh; may be NULL)) computed inside the
+ * gather-dot - every workgroup forms its 32 channels of its (query, head) row with the stand-alone kernel's very sums - plus the
+ * weight-gradient riders of gd4d_cross_attn_dot_sliced_wgrad (count may be 0).  D, grad_agg and beta are bit-identical to the
+ * separate launches.  8 heads, 4 levels, fp32 features. */
+int gd4d_cross_attn_dot_sliced_fused(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
+                                     const float* grad_out, const float* vp_weight, const float* vp_bias, float* grad_agg_out,
+                                     float* beta_out, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,
+                                     int P, int feats_dtype, const int32_t* query_order, const void* const* x,
                                      const void* const* grad_y, void* const* grad_w, void* const* grad_b, const int32_t* dims,
                                      int count, int accumulate, void* stream);
 int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
