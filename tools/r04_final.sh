@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 4, final tree: the whole measurement bundle (tools/prof_round.sh), the training lines beside it, the other configurations,
-# the training timeline and the full GPU test run.  Collected into profiles/ with tools/collect_round_profiles.sh r04c r04 + the
-# copies at the end of this file's twin in docs/measurements_r04.md.
+# the training timeline and the full GPU test run.  Collected into profiles/ with tools/collect_round_profiles.sh r04c r04; the
+# dropout / per-module training lines, the training timeline and the configs/ lines are copied by hand (profiles/r04_bench_*.json,
+# r04_step_timeline_train_dropout_profiled.txt).
 cd "$GRAFT_REPO_ROOT"
 bash tools/prof_round.sh r04c > /dev/null 2>&1
 o=gpurun_out/r04c/train; mkdir -p $o
