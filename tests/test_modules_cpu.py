@@ -109,3 +109,31 @@ def test_chain_training_path_host_logic():
 def ctypes_sizeof(t):
     import ctypes
     return ctypes.sizeof(t)
+
+
+def test_kv_plane_layouts_match_the_header():
+    """ops.KVPlanes: the fragment layouts include/gd4d.h documents for GD4D_CHAIN_SPLIT_KV (K: [head][tile][lane = 16 (c / 8) + key %
+    16][c % 8]; V: [head][step][d / 16][lane = 16 g + d % 16][j], key = 32 step + 16 (j >> 2) + 4 g + (j & 3)) and the row views the GPU
+    tests compare against - built element by element from the formulas, on the CPU."""
+    import torch
+    from graph_detr4d_amd import ops
+    m, c, heads = 37, 256, 8
+    kv = ops.KVPlanes(m, c, 'cpu', heads=heads)
+    assert kv.k.shape == (2, heads, 3, 64, 8) and kv.v.shape == (2, heads, 2, 2, 64, 8)
+    rows_k = torch.arange(kv.tiles * 16 * c, dtype=torch.float32).view(kv.tiles * 16, c) % 251
+    rows_v = (torch.arange(kv.steps * 32 * c, dtype=torch.float32).view(kv.steps * 32, c) * 3) % 241
+    k = torch.zeros(heads, kv.tiles, 64, 8)
+    for key in range(kv.tiles * 16):
+        for ch in range(c):
+            h, cc = divmod(ch, 32)
+            k[h, key // 16, (cc // 8) * 16 + key % 16, cc % 8] = rows_k[key, ch]
+    v = torch.zeros(heads, kv.steps, 2, 64, 8)
+    for key in range(kv.steps * 32):
+        step, ko = divmod(key, 32)
+        t, kk = divmod(ko, 16)
+        g, r = divmod(kk, 4)
+        for ch in range(c):
+            h, d = divmod(ch, 32)
+            v[h, step, d // 16, g * 16 + d % 16, 4 * t + r] = rows_v[key, ch]
+    kv.k[0], kv.v[0] = k.to(torch.bfloat16), v.to(torch.bfloat16)
+    assert torch.equal(kv.k_rows()[0].float(), rows_k) and torch.equal(kv.v_rows()[0].float(), rows_v)
