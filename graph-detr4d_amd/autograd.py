@@ -129,7 +129,7 @@ class RawPyramid:
         """Forward pass on ONE stream: the records' slots are handed out by the forward gather's launch
         (ops.cross_attn_agg_sliced_fwd(count=...)).  Returns the aggregates; None when the plan / pyramid is not of the kind
         that launch takes (count() + the gather then)."""
-        if (not self.needs_grad or self.side is not self.main or plan.items or plan.items_buf is None or plan.stage
+        if (not self.needs_grad or self.side is not self.main or plan.items or plan.items_buf is None
                 or plan.num_heads != 8 or len(self.pyramid.level_hw) != 4 or self.pyramid.dtype != torch.float32
                 or os.environ.get('GD4D_TRAIN_COUNT', 'gather') != 'gather'):
             return None

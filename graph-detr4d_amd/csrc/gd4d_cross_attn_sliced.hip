@@ -56,53 +56,8 @@ struct PlanParams {
   int cap_t;               // passes reserved per head
   float4* item;            // GD4D_CA_PLAN_ITEMS: the plan holds ITEMS (two float4 each, below) instead of pairs; else nullptr
   int cap_i;               // items reserved per head (a multiple of 16)
-  int item_f4;             // float4 per item: 2, or 3 with staging (the third: LDS slots of the staged levels' corners)
-  int stage_lo;            // GD4D_CA_PLAN_STAGE*: levels stage_lo .. 3 are staged by the gather (0: none)
-  int stage_cap;           // staged lines a query may have; more: that query is gathered without staging
-  unsigned* ulist;         // (position, stage_cap): the unique {byte offset | level - stage_lo} of a query's staged corners
   int both;                // GD4D_CA_PLAN_BOTH: `item` is a second region; the pairs are written as well
 };
-
-// ---- staging (round 4): the coarse levels' corners through LDS ---------------------------------------------------------------
-// On the bench's geometry only 21 % (level 3) / 40 % (level 2) of a (query, camera)'s corner reads are distinct pixels - the
-// re-use is ACROSS the heads of a query, i.e. across the waves of a gather workgroup, where neither the texture unit's merging
-// nor the L1 gets it for free: every corner read moves 128 bytes over the 64 B/clk L1 path (a what-if build that served the
-// corners of levels 3 / 2-3 / 1-3 from LDS ran 108 / 90 / 67 us against 124).  So the plan kernel de-duplicates a query's
-// corners of the staged levels (an LDS hash set over the byte offsets), numbers the unique lines, and hands every item the LDS
-// slots of its corners; a gather workgroup loads the query's unique lines of its slice ONCE into LDS (one cooperative phase, one
-// barrier), after which its head-waves walk their items as before, reading those corners with ds_read_b128.  Results are
-// bit-identical to the unstaged gather (the same values in the same order, whatever the slot numbering).
-constexpr int ST_SIZE = 2048;                    // hash-table entries (a query has up to ~850 unique lines on levels 2 + 3 here)
-constexpr unsigned ST_EMPTY = 0xffffffffu;
-constexpr int kStageNone = 0xffff;               // hdr[pos][kStageHdr]: this query is not staged (too many lines)
-constexpr int kStageHdr = 8;                     // (staging needs Hh == 8: header slots 8 .. 15 are free)
-constexpr int kStageCap3 = 192, kStageCap2 = 384;   // lines of LDS stage when level 3 / levels 2 + 3 are staged (24 / 48 KB)
-
-__device__ __forceinline__ unsigned st_hash(unsigned key) { return (key * 2654435761u) >> 21; }        // 11 bits
-__device__ __forceinline__ bool st_insert(unsigned* keys, unsigned key) {
-  unsigned h = st_hash(key);
-  for (int probe = 0; probe < ST_SIZE; ++probe) {
-    const unsigned old = atomicCAS(&keys[h], ST_EMPTY, key);
-    if (old == ST_EMPTY || old == key) return true;
-    h = (h + 1) & (ST_SIZE - 1);
-  }
-  return false;
-}
-__device__ __forceinline__ int st_find(const unsigned* keys, unsigned key) {
-  unsigned h = st_hash(key);
-  for (int probe = 0; probe < ST_SIZE && keys[h] != key; ++probe) h = (h + 1) & (ST_SIZE - 1);
-  return (int)h;
-}
-// the four corners of a sample as the gather forms them (clamped onto the map): pixel index y W + x of corner c
-__device__ __forceinline__ void corner_pixels(float u, float v, int lw, int lh, int (&pix)[4]) {
-  const float x = fmaf(u, (float)lw, -0.5f), y = fmaf(v, (float)lh, -0.5f);
-  const int x0 = (int)floorf(x), y0 = (int)floorf(y);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int xc = min(max(x0 + (c & 1), 0), lw - 1), yc = min(max(y0 + (c >> 1), 0), lh - 1);
-    pix[c] = yc * lw + xc;
-  }
-}
 
 // PT = sampling points per head (the reference's num_points, deform3d_cross_attn.py:52-69; every shipped config: 4).  An item is
 // a visible (camera, point) pair whatever PT is, so the gather does not know it.
@@ -173,60 +128,6 @@ __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const
     }
   }
   __syncthreads();
-  // ---- staging: the unique lines of the query's corners on levels stage_lo .. 3 (see the comment at ST_SIZE) ----
-  unsigned* st_keys = reinterpret_cast<unsigned*>(s_items + WAVES * p.N * PT);
-  unsigned short* st_slot = reinterpret_cast<unsigned short*>(st_keys + ST_SIZE);
-  int* st_misc = reinterpret_cast<int*>(st_slot + ST_SIZE);                  // [0]: table overflow, [1 ..]: wave totals per pass
-  bool staged = false;
-  if (pp.stage_lo) {
-    for (int i = tid; i < ST_SIZE; i += THREADS) st_keys[i] = ST_EMPTY;
-    if (tid == 0) st_misc[0] = 0;
-    __syncthreads();
-    const int total = p.N * E;
-    for (int e = tid; e < total; e += THREADS) {
-      const float2 uvc = s_uv[e];
-      if (uvc.x < 0.f) continue;
-      const unsigned row = (unsigned)(b * p.N + e / E);
-      for (int l = pp.stage_lo; l < LT; ++l) {
-        int pix[4];
-        corner_pixels(uvc.x, uvc.y, pp.g.lvl_w[l], pp.g.lvl_h[l], pix);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (!st_insert(st_keys, (row * pp.g.cam_stride[l] + (unsigned)pix[c] * pp.g.pix_stride) | (unsigned)(l - pp.stage_lo)))
-            st_misc[0] = 1;
-      }
-    }
-    __syncthreads();
-    // number the occupied entries: ST_SIZE / THREADS passes of one entry per thread (ballot + popcount, wave totals through LDS)
-    constexpr int PASSES = ST_SIZE / THREADS;
-    static_assert(ST_SIZE % THREADS == 0, "one entry per thread and pass");
-    bool occ[PASSES];
-    int pre[PASSES];
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      occ[ps] = st_keys[ps * THREADS + tid] != ST_EMPTY;
-      const unsigned long long bal = __ballot(occ[ps]);
-      pre[ps] = __popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) st_misc[1 + ps * WAVES + wave] = __popcll(bal);
-    }
-    __syncthreads();
-    int u_total = 0;
-    for (int i = 0; i < PASSES * WAVES; ++i) u_total += st_misc[1 + i];
-    staged = st_misc[0] == 0 && u_total <= pp.stage_cap;
-    unsigned* ul = pp.ulist + (size_t)pos * pp.stage_cap;
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      int base = 0;
-      for (int i = 0; i < ps * WAVES + wave; ++i) base += st_misc[1 + i];
-      if (occ[ps]) {
-        const int sl = base + pre[ps];
-        st_slot[ps * THREADS + tid] = (unsigned short)sl;
-        if (staged) ul[sl] = st_keys[ps * THREADS + tid];
-      }
-    }
-    if (tid == 0) pp.hdr[pos * kPlanHdr + kStageHdr] = staged ? u_total : kStageNone;
-    __syncthreads();
-  }
   // wave w: heads w, w + WAVES, ...: compact the visible (camera, point) pairs, then the corners: lane = (item % 16, level)
   // works out the four corners of its (item, level) - 16 items per step of the wave (with lane = (item % 4, level, corner)
   // the per-(item, level) arithmetic was done four times over: the pass loop was 2.2 M of the launch's 3.9 M vector
@@ -264,8 +165,7 @@ __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const
       // (profiles/r03_pmc_cross_attn_sliced.json).  The corner arithmetic moves into the gather, lane = (item, level), 16
       // items per step (gd4d_cross_attn_agg_items_fwd), which also sums wsum.  M rides in every record: the gather needs
       // one round trip, not header-then-items (record 0 is written for M = 0 too).
-      const int f4 = pp.item_f4;
-      float4* out = pp.item + ((size_t)pos * HH + h) * pp.cap_i * f4;
+      float4* out = pp.item + ((size_t)pos * HH + h) * pp.cap_i * 2;
       for (int it0 = 0; it0 < max(M, 1); it0 += GD4D_WAVE) {
         const int item = it0 + lane;
         if (item < max(M, 1)) {
@@ -277,26 +177,8 @@ __device__ __forceinline__ void cross_attn_plan_body(const PlanParams& pp, const
           float wl[4];
 #pragma unroll
           for (int l = 0; l < 4; ++l) wl[l] = (l < LT && M) ? aw[l * PT] * rec.w : 0.f;
-          out[item * f4] = make_float4(rec.x, rec.y, __int_as_float(row), __int_as_float(M));
-          out[item * f4 + 1] = make_float4(wl[0], wl[1], wl[2], wl[3]);
-          if (f4 == 3) {                                                    // LDS slots of the staged levels' corners (16 bits each)
-            unsigned sl[4] = {0u, 0u, 0u, 0u};
-            if (staged && M) {
-              for (int l = pp.stage_lo; l < LT; ++l) {
-                int pix[4];
-                corner_pixels(rec.x, rec.y, pp.g.lvl_w[l], pp.g.lvl_h[l], pix);
-                unsigned s4[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                  s4[c] = st_slot[st_find(st_keys, ((unsigned)row * pp.g.cam_stride[l] + (unsigned)pix[c] * pp.g.pix_stride) |
-                                                   (unsigned)(l - pp.stage_lo))];
-                const int o2 = (l - pp.stage_lo) * 2;
-                sl[o2] = s4[0] | (s4[1] << 16);
-                sl[o2 + 1] = s4[2] | (s4[3] << 16);
-              }
-            }
-            out[item * f4 + 2] = make_float4(__uint_as_float(sl[0]), __uint_as_float(sl[1]), __uint_as_float(sl[2]), __uint_as_float(sl[3]));
-          }
+          out[item * 2] = make_float4(rec.x, rec.y, __int_as_float(row), __int_as_float(M));
+          out[item * 2 + 1] = make_float4(wl[0], wl[1], wl[2], wl[3]);
         }
       }
       if (!pp.both) {
@@ -391,7 +273,7 @@ __device__ __forceinline__ bool sliced_walk(const SlicedParams& p, int block, in
   return qi < p.per_xcd && pos < p.BQ;
 }
 
-template <int HH, int LT, typename VT, int POLICY>
+template <int HH, int LT, typename VT>
 __device__ __forceinline__ void cross_attn_agg_sliced_body(const SlicedParams& p, const int pos, const int sl, char* s_raw) {
   constexpr int ES = sizeof(VT);
   constexpr int CH = 6;                                   // passes staged per round (30 KB per workgroup: 4 per CU)
@@ -440,8 +322,7 @@ __device__ __forceinline__ void cross_attn_agg_sliced_body(const SlicedParams& p
         if (j >= 4 && !second) break;
         const unsigned o = ((j & 1) ? pr[j >> 1].z : pr[j >> 1].x) + lane_off;
         const VT* ap = reinterpret_cast<const VT*>(base[j & 3] + o);
-        if (POLICY == 3) val[j] = make_float4(__uint_as_float(o), 0.f, 0.f, 0.f);   // dev: no loads - the issue floor
-        else val[j] = Quad<VT>::load(ap);
+        val[j] = Quad<VT>::load(ap);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -465,20 +346,20 @@ __device__ __forceinline__ void cross_attn_agg_sliced_body(const SlicedParams& p
   if (g == 0) *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4) = acc;
 }
 
-template <int HH, int LT, typename VT, int OCC, int POLICY>
+template <int HH, int LT, typename VT, int OCC>
 __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_sliced_kernel(const SlicedParams p) {
   extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
   trace_mark(g_trace_sliced, 6ull);
   int pos, sl;
   if (!sliced_walk(p, blockIdx.x, pos, sl)) return;
-  cross_attn_agg_sliced_body<HH, LT, VT, POLICY>(p, pos, sl, s_raw);
+  cross_attn_agg_sliced_body<HH, LT, VT>(p, pos, sl, s_raw);
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gather from the ITEMS form of the plan (GD4D_CA_PLAN_ITEMS; the inference step's default).  Same walk, same pass loop
-// and the same products in the same order as cross_attn_agg_sliced_body - results are bit-identical to it - but the
-// {offset, weight} pairs of a pass are worked out HERE from 32-byte item records, lane = (item % 16, level), 16 items
+// and the same products in the same order as cross_attn_agg_sliced_body - results are bit-identical to it -
+// but the {offset, weight} pairs of a pass are worked out HERE from 32-byte item records, lane = (item % 16, level), 16 items
 // (four passes) per step, and parked in the wave's LDS patch in the layout the pass loop reads.  That is ~45 vector
 // instructions per four passes on top of the ~160 the passes cost, for a plan a quarter of the size: the pairs were
 // 107 MB of the 499 MB a launch pulled over the fabric, because the eight slices of a query read them a phase apart.
@@ -489,180 +370,121 @@ struct ItemsParams {
   const float4* item;
   float* wsum;                  // (BQ, HH), written by the workgroups of slice 0
   int cap_i;
-  const unsigned* ulist;        // staging: (position, stage_cap) unique lines
-  int stage_cap;
 };
 
 // WIDE: a level spans 4 GiB or more (VoVNet-99 level 0 stored channels-last, two samples: 4.6 GB) - the offsets parked in LDS
 // are then in units of 16 bytes (every stride is a multiple of 16; the host hands cam_stride / pix_stride pre-divided) and a
 // load forms its address with a 64-bit shift-add.
-// STAGE_LO (2 or 3; 0: none): the corners of levels STAGE_LO .. 3 come from the workgroup's LDS stage (see ST_SIZE above): the
-// query's unique lines of this slice are loaded once by all 512 threads, one barrier, then the head-waves run as before.
-template <int HH, int LT, typename VT, int POLICY, bool WIDE, int STAGE_LO = 0>
+template <int HH, int LT, typename VT, bool WIDE>
 __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip, const int pos, const int sl, char* s_raw) {
   const SlicedParams& p = ip.s;
   constexpr int ES = sizeof(VT);
-  constexpr int CH = 4;                                   // passes per step = 16 items (20 KB of LDS per workgroup of 8 waves)
+  constexpr int LA = LT, LAP = 4;                         // a lane set = the four level slots of an item
+  constexpr int IPP = 16 / LAP;                           // items per pass: 4
+  constexpr int IPS = 64 / LAP;                           // items per step (four passes): 16
+  constexpr int CH = 4;                                   // passes per step (20 KB of LDS per workgroup of 8 waves)
   constexpr int GP = 80;                                  // LDS bytes per corner slot: 64 B of pairs + 16 B pad (conflict-free b128)
   constexpr int PASS = 8 * GP;
-  constexpr int F4 = STAGE_LO ? 3 : 2;                    // float4 per item record
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = p.slice_lo + sl;
-  const int i_of = lane >> 2, l_of = lane & 3;
-  const float4* rec = ip.item + ((size_t)pos * HH + h) * ip.cap_i * F4;
-  // speculative: the first 16 records (cap_i >= 16; what lies past M is replaced below before it is used)
-  float4 a = rec[i_of * F4];
-  float wl = reinterpret_cast<const float*>(rec + i_of * F4 + 1)[l_of];
-  uint2 sl2 = make_uint2(0u, 0u);                         // staged levels: the LDS slots of this lane's four corners (16 bits each)
-  if (STAGE_LO && l_of >= STAGE_LO) sl2 = reinterpret_cast<const uint2*>(rec + i_of * F4 + 2)[l_of - STAGE_LO];
+  const int i_of = lane / LAP, l_of = lane % LAP;
+  const float4* rec = ip.item + ((size_t)pos * HH + h) * ip.cap_i * 2;
+  // speculative: the first records (what lies past M is replaced below before it is used)
+  const int i_first = min(i_of, ip.cap_i - 1);
+  float4 a = rec[i_first * 2];
+  float wl = reinterpret_cast<const float*>(rec + i_first * 2 + 1)[l_of];
   const int bq = p.order ? p.order[pos] : pos;
   char* my = s_raw + h * (CH * PASS);
   const int g = lane >> 3, c = lane & 7;
   const char* rd = my + g * GP;
-  // where the four pairs of this lane go inside their pass: [g][j], g = (item & 1, corner), j = (item >> 1 & 1, level)
-  char* wr = my + (i_of >> 2) * PASS + ((i_of & 1) << 2) * GP + ((((i_of >> 1) & 1) << 2) | l_of) * 8;
-  const char* base[LT];
+  // where the four pairs of this lane go: pass i_of / IPP, inside it [g][j], g = (item & 1, corner), j = (item >> 1, level)
+  const int ip_ = i_of % IPP;
+  char* wr = my + (i_of / IPP) * PASS + ((ip_ & 1) << 2) * GP + ((ip_ >> 1) * LAP + l_of) * 8;
+  const char* base[LA];
 #pragma unroll
-  for (int l = 0; l < LT; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
+  for (int l = 0; l < LA; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
   const unsigned lane_off = (unsigned)(c * 4 * ES);
   int lw = ip.g.lvl_w[0], lh = ip.g.lvl_h[0];
   unsigned cstr = ip.g.cam_stride[0];
 #pragma unroll
-  for (int l = 1; l < LT; ++l)
+  for (int l = 1; l < LA; ++l)
     if (l_of == l) { lw = ip.g.lvl_w[l]; lh = ip.g.lvl_h[l]; cstr = ip.g.cam_stride[l]; }
   const float flw = (float)lw, flh = (float)lh;
-  const float lvl_on = l_of < LT ? 1.f : 0.f;
-
-  // ---- the stage: this query's unique lines of levels STAGE_LO .. 3, slice s, once for all eight head-waves.  The lines
-  // are requested as LDS-DMA loads (no registers; a wave's 64 lanes fill 8 consecutive 128-byte lines) right away and land
-  // while the waves walk the DIRECT levels of all their items (sweep 1); one barrier; then the staged levels (sweep 2). ----
-  constexpr int STAGE_CAP = STAGE_LO == 0 ? 0 : (STAGE_LO >= 3 ? kStageCap3 : kStageCap2);
-  char* stage = s_raw + HH * (CH * PASS);
-  bool staged = false;
-  if (STAGE_LO) {
-    static_assert(STAGE_LO == 0 || (sizeof(VT) == 4 && LT == 4 && !WIDE && HH == 8), "staging: fp32 lines, four levels, 32-bit offsets, 8 waves");
-    const int U = __builtin_amdgcn_readfirstlane(p.hdr[pos * kPlanHdr + kStageHdr]);
-    staged = U != kStageNone;
-    if (staged) {
-      typedef __attribute__((address_space(3))) void lds_void_t;
-      typedef const __attribute__((address_space(1))) void glb_void_t;
-      const unsigned* ul = ip.ulist + (size_t)pos * ip.stage_cap;
-      constexpr int ITER = (STAGE_CAP + 63) / 64;
-      unsigned e[ITER > 0 ? ITER : 1];
-#pragma unroll
-      for (int i = 0; i < ITER; ++i) e[i] = ul[min(64 * i + 8 * h + g, max(U - 1, 0))];      // (clamped: always a valid entry)
-#pragma unroll
-      for (int i = 0; i < ITER; ++i) {
-        if (64 * i + 8 * h >= U) break;                                      // wave-uniform: none of this wave's eight lines exists
-        const char* lb = (STAGE_LO < LT - 1 && (e[i] & 1u)) ? base[LT - 1] : base[STAGE_LO < LT ? STAGE_LO : 0];
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(lb + (e[i] & ~1u) + c * 16), (lds_void_t*)(stage + (64 * i + 8 * h) * 128), 16, 0, 0);
-      }
-    }
-  }
+  const float lvl_on = l_of < LA ? 1.f : 0.f;
 
   const int M = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));       // every record carries its head's count
-  const int T = (M + 3) >> 2;
-  f2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+  const int T = (M + IPP - 1) / IPP;
+  const int m_even = (M + 1) & ~1;                                         // a load covers a PAIR of items: the odd one out is
+  f2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};                                // written with weight 0 (its line is in flight already)
   float wsum_lane = 0.f;
-  // MODE 0: every level in one sweep (the unstaged gather); 1: the direct levels; 2: the staged levels, read from LDS
-  auto sweep = [&](auto mode_tag) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    const bool mine = MODE == 0 || (MODE == 1 ? l_of < STAGE_LO : l_of >= STAGE_LO);   // this lane's level belongs to the sweep
-    if (MODE == 2) {                                                        // the first records again (L1 / L2 hits)
-      a = rec[i_of * F4];
-      wl = reinterpret_cast<const float*>(rec + i_of * F4 + 1)[l_of];
-      if (l_of >= STAGE_LO) sl2 = reinterpret_cast<const uint2*>(rec + i_of * F4 + 2)[l_of - STAGE_LO];
-    }
-    if (M < 16 && M > 0) {                                                  // wave-uniform: items past M repeat the last one
-      const int src = (min(i_of, M - 1) << 2) | l_of;
-      a.x = __shfl(a.x, src); a.y = __shfl(a.y, src); a.z = __shfl(a.z, src); wl = __shfl(wl, src);
-      if (STAGE_LO) { sl2.x = __shfl(sl2.x, src); sl2.y = __shfl(sl2.y, src); }
-    }
-    for (int it0 = 0; it0 < M; it0 += 16) {
-      const int item = it0 + i_of;
-      const int m_pad = (M + 3) & ~3;
-      {
-        const int row = __float_as_int(a.z);
-        const float x = fmaf(a.x, flw, -0.5f);
-        const float y = fmaf(a.y, flh, -0.5f);
-        const float xf = floorf(x), yf = floorf(y);
-        const float dx = x - xf, dy = y - yf;
-        const int x0 = (int)xf, y0 = (int)yf;
-        const float live = item < M ? lvl_on : 0.f;
-        const unsigned rbase = (unsigned)row * cstr;
-        if (it0 > 0 || MODE == 2) __builtin_amdgcn_wave_barrier();          // the previous step's passes have read the patch
+  if (M < IPS && M > 0) {                                                   // wave-uniform: items past M repeat the last one
+    const int src = min(i_of, M - 1) * LAP + l_of;
+    a.x = __shfl(a.x, src); a.y = __shfl(a.y, src); a.z = __shfl(a.z, src); wl = __shfl(wl, src);
+  }
+  for (int it0 = 0; it0 < M; it0 += IPS) {
+    const int item = it0 + i_of;
+    {
+      const int row = __float_as_int(a.z);
+      const float x = fmaf(a.x, flw, -0.5f);
+      const float y = fmaf(a.y, flh, -0.5f);
+      const float xf = floorf(x), yf = floorf(y);
+      const float dx = x - xf, dy = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float live = item < M ? lvl_on : 0.f;
+      const unsigned rbase = (unsigned)row * cstr;
+      if (it0 > 0) __builtin_amdgcn_wave_barrier();                         // the previous step's passes have read the patch
 #pragma unroll
-        for (int c_of = 0; c_of < 4; ++c_of) {
-          const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
-          // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
-          const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
-          const float in = (xc == xi && yc == yi) ? live : 0.f;
-          const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
-          const float w = (wl * wx * wy) * in;
-          unsigned off = rbase + (unsigned)(yc * lw + xc) * ip.g.pix_stride;
-          if (MODE == 2) {                                                  // the corner's line sits in the stage: its LDS byte offset
-            const unsigned two = (c_of >> 1) ? sl2.y : sl2.x;
-            off = ((c_of & 1) ? (two >> 16) : (two & 0xffffu)) * 128u;
-          }
-          if (mine) wsum_lane += w;
-          if (mine && item < m_pad && l_of < LT) *reinterpret_cast<uint2*>(wr + c_of * GP) = make_uint2(off, __float_as_uint(w));
-        }
-      }
-      if (it0 + 16 < M) {                                                   // the next step's records fly under this step's passes
-        const int nx = min(item + 16, M - 1);
-        a = rec[nx * F4];
-        wl = reinterpret_cast<const float*>(rec + nx * F4 + 1)[l_of];
-        if (STAGE_LO && l_of >= STAGE_LO) sl2 = reinterpret_cast<const uint2*>(rec + nx * F4 + 2)[l_of - STAGE_LO];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // wave-private LDS patch: no workgroup barrier
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int t0 = it0 >> 2;
-      const int nt = min(CH, T - t0);
-      for (int k = 0; k < nt; ++k) {
-        const uint4* row = reinterpret_cast<const uint4*>(rd + k * PASS);
-        uint4 pr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pr[i] = row[i];                        // pairs j = 2 i, 2 i + 1: {off, w, off, w}
-        const bool second = (t0 + k) * 4 + 2 < M;                          // wave-uniform: items 2, 3 of the pass exist
-        float4 val[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((j & 3) >= LT) continue;
-          if (MODE == 1 && (j & 3) >= STAGE_LO) continue;
-          if (MODE == 2 && (j & 3) < STAGE_LO) continue;
-          if (j >= 4 && !second) break;
-          const unsigned raw = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
-          const unsigned o = raw + lane_off;
-          if (MODE == 2) { val[j] = *reinterpret_cast<const float4*>(stage + o); continue; }
-          const VT* ap = WIDE ? reinterpret_cast<const VT*>(base[j & 3] + (((size_t)raw << 4) + lane_off))
-                              : reinterpret_cast<const VT*>(base[j & 3] + o);
-          if (POLICY == 3) val[j] = make_float4(__uint_as_float(o), 0.f, 0.f, 0.f);   // dev: no loads - the issue floor
-          else val[j] = Quad<VT>::load(ap);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((j & 3) >= LT) continue;
-          if (MODE == 1 && (j & 3) >= STAGE_LO) continue;
-          if (MODE == 2 && (j & 3) < STAGE_LO) continue;
-          if (j >= 4 && !second) break;
-          const float w = __uint_as_float((j & 1) ? pr[j >> 1].w : pr[j >> 1].y);
-          const f2v ww = {w, w};
-          acc0 = __builtin_elementwise_fma(ww, f2v{val[j].x, val[j].y}, acc0);
-          acc1 = __builtin_elementwise_fma(ww, f2v{val[j].z, val[j].w}, acc1);
-        }
+      for (int c_of = 0; c_of < 4; ++c_of) {
+        const int xi = x0 + (c_of & 1), yi = y0 + (c_of >> 1);
+        // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
+        const int xc = min(max(xi, 0), lw - 1), yc = min(max(yi, 0), lh - 1);
+        const float in = (xc == xi && yc == yi) ? live : 0.f;
+        const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
+        const float w = (wl * wx * wy) * in;
+        const unsigned off = rbase + (unsigned)(yc * lw + xc) * ip.g.pix_stride;
+        wsum_lane += w;
+        if (item < m_even && l_of < LA) *reinterpret_cast<uint2*>(wr + c_of * GP) = make_uint2(off, __float_as_uint(w));
       }
     }
-  };
-  if (STAGE_LO && staged) {                                                 // (workgroup-uniform: every wave of it takes this branch)
-    sweep(std::integral_constant<int, 1>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's share of the stage has landed
-    __syncthreads();
-    sweep(std::integral_constant<int, 2>{});
-  } else {
-    sweep(std::integral_constant<int, 0>{});
+    if (it0 + IPS < M) {                                                    // the next step's records fly under this step's passes
+      const int nx = min(item + IPS, M - 1);
+      a = rec[nx * 2];
+      wl = reinterpret_cast<const float*>(rec + nx * 2 + 1)[l_of];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // wave-private LDS patch: no workgroup barrier
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int t0 = it0 / IPP;
+    const int nt = min(CH, T - t0);
+    for (int k = 0; k < nt; ++k) {
+      const uint4* row = reinterpret_cast<const uint4*>(rd + k * PASS);
+      uint4 pr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = row[i];                          // pairs j = 2 i, 2 i + 1: {off, w, off, w}
+      const int left = M - (t0 + k) * IPP;                                 // wave-uniform: items of this pass; load j's pair exists
+      float4 val[8];                                                       // while 2 (j / LAP) < left
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((j % LAP) >= LA) continue;
+        if (2 * (j / LAP) >= left) break;
+        const unsigned raw = (j & 1) ? pr[j >> 1].z : pr[j >> 1].x;
+        const unsigned o = raw + lane_off;
+        const VT* ap = WIDE ? reinterpret_cast<const VT*>(base[j % LAP] + (((size_t)raw << 4) + lane_off))
+                            : reinterpret_cast<const VT*>(base[j % LAP] + o);
+        val[j] = Quad<VT>::load(ap);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((j % LAP) >= LA) continue;
+        if (2 * (j / LAP) >= left) break;
+        const float w = __uint_as_float((j & 1) ? pr[j >> 1].w : pr[j >> 1].y);
+        const f2v ww = {w, w};
+        acc0 = __builtin_elementwise_fma(ww, f2v{val[j].x, val[j].y}, acc0);
+        acc1 = __builtin_elementwise_fma(ww, f2v{val[j].z, val[j].w}, acc1);
+      }
+    }
   }
   float4 acc = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
   // the 8 corner slots meet in a fixed order (deterministic)
@@ -679,13 +501,13 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
   }
 }
 
-template <int HH, int LT, typename VT, int OCC, int POLICY, bool WIDE = false, int STAGE_LO = 0>
+template <int HH, int LT, typename VT, int OCC, bool WIDE = false>
 __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_kernel(const ItemsParams ip) {
-  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP] (+ the stage: cap x 128 B)
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
   trace_mark(g_trace_sliced, 6ull);
   int pos, sl;
   if (!sliced_walk(ip.s, blockIdx.x, pos, sl)) return;
-  cross_attn_agg_items_body<HH, LT, VT, POLICY, WIDE, STAGE_LO>(ip, pos, sl, s_raw);
+  cross_attn_agg_items_body<HH, LT, VT, WIDE>(ip, pos, sl, s_raw);
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
@@ -715,7 +537,7 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_count_kerne
   }
   int pos, sl;
   if (!sliced_walk(ip.s, (int)blockIdx.x - 8 * min(k, ca.groups), pos, sl)) return;
-  cross_attn_agg_items_body<HH, LT, VT, 0, false, 0>(ip, pos, sl, s_raw);
+  cross_attn_agg_items_body<HH, LT, VT, false>(ip, pos, sl, s_raw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -804,9 +626,8 @@ extern "C" void gd4d_trace_set_sliced(unsigned long long* p) { gd4d::trace_set_s
 
 extern "C" size_t gd4d_cross_attn_plan_bytes(int B, int N, int Q, int Hh, int P) {
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || P <= 0) return 0;
-  const size_t pairs = (size_t)B * Q * Hh * gd4d::plan_cap_t(N, P) * 64 * sizeof(uint2);
-  const size_t staged = (size_t)B * Q * ((size_t)Hh * gd4d::plan_cap_items(N, P) * 48 + (size_t)gd4d::kStageCap2 * 4);   // items + slots, unique lines
-  return gd4d::plan_hdr_bytes(B, Q) + (pairs > staged ? pairs : staged);
+  const size_t pairs = (size_t)B * Q * Hh * gd4d::plan_cap_t(N, P) * 64 * sizeof(uint2);      // (the items form needs a quarter)
+  return gd4d::plan_hdr_bytes(B, Q) + pairs;
 }
 
 namespace gd4d {
@@ -834,8 +655,7 @@ extern "C" int gd4d_cross_attn_plan_fwd(const float* ref, const float* offsets, 
   const dim3 grid(B * Q);
   auto lds = [&](int LT) {
     return (size_t)N * Hh * P * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
-           (size_t)((B * Hh * LT * P + 3) & ~3) * sizeof(float) + (size_t)8 * N * P * sizeof(float4) +
-           (pp.stage_lo ? (size_t)ST_SIZE * 6 + 4 * (1 + ST_SIZE / 64) : 0);        // hash keys + slots + wave totals
+           (size_t)((B * Hh * LT * P + 3) & ~3) * sizeof(float) + (size_t)8 * N * P * sizeof(float4);
   };
   // one wave per head up to 8 heads (the heads' pass loops are the kernel's longest dependent chain)
   auto go = [&](auto kern, int waves, size_t bytes) -> int {
@@ -908,8 +728,7 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
     const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
                                     (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
     // (the ITEMS form stores no offsets: its gather checks the spans itself and switches to 16-byte units past 4 GiB)
-    if ((!(flags & GD4D_CA_PLAN_ITEMS) || (flags & (GD4D_CA_PLAN_STAGE3 | GD4D_CA_PLAN_STAGE23))) &&
-        (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32))) return GD4D_EUNSUPPORTED;
+    if (!(flags & GD4D_CA_PLAN_ITEMS) && (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32))) return GD4D_EUNSUPPORTED;
     pp.g.lvl_w[l] = w; pp.g.lvl_h[l] = h; pp.g.cam_stride[l] = (unsigned)cam_stride_bytes[l];
   }
   pp.g.pix_stride = (unsigned)pix_stride_bytes;
@@ -918,7 +737,6 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
   pp.cap_t = plan_cap_t(N, P);
   pp.item = nullptr;
   pp.cap_i = plan_cap_items(N, P);
-  pp.item_f4 = 2; pp.stage_lo = 0; pp.stage_cap = 0; pp.ulist = nullptr;
   pp.both = 0;
   if (flags & GD4D_CA_PLAN_ITEMS) pp.item = reinterpret_cast<float4*>(pp.pair);   // same place, a quarter of the bytes
   if (flags & GD4D_CA_PLAN_BOTH) {
@@ -926,19 +744,9 @@ static int gd4d_fill_plan_params_impl(gd4d::PlanParams& pp, const float* ref, co
     // buffer holds two plans back to back - [0, bytes): header + pairs, [bytes, 2 bytes): a header's room + items, so that
     // plan + bytes is what gd4d_cross_attn_agg_items_fwd takes.
     const size_t one = gd4d_cross_attn_plan_bytes(B, N, Q, Hh, P);
-    if ((flags & (GD4D_CA_PLAN_ITEMS | GD4D_CA_PLAN_STAGE3 | GD4D_CA_PLAN_STAGE23)) || plan_bytes < 2 * one) return GD4D_EINVAL;
+    if ((flags & GD4D_CA_PLAN_ITEMS) || plan_bytes < 2 * one) return GD4D_EINVAL;
     pp.item = reinterpret_cast<float4*>(static_cast<char*>(plan) + one + plan_hdr_bytes(B, Q));
     pp.both = 1;
-  }
-  if (flags & (GD4D_CA_PLAN_STAGE3 | GD4D_CA_PLAN_STAGE23)) {
-    // the coarse levels' corners through the gather's LDS stage: items of three float4, the unique lines behind them
-    if (!(flags & GD4D_CA_PLAN_ITEMS) || Hh != 8 || L != 4 || P != kPoints || (pix_stride_bytes & 63)) return GD4D_EUNSUPPORTED;
-    for (int l = 0; l < L; ++l)
-      if (cam_stride_bytes[l] & 63) return GD4D_EUNSUPPORTED;
-    pp.stage_lo = (flags & GD4D_CA_PLAN_STAGE23) ? 2 : 3;
-    pp.stage_cap = pp.stage_lo == 2 ? kStageCap2 : kStageCap3;
-    pp.item_f4 = 3;
-    pp.ulist = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pp.pair) + (size_t)B * Q * Hh * pp.cap_i * 48);
   }
   return GD4D_OK;
 }
@@ -965,26 +773,12 @@ static int launch_sliced(const SlicedParams& p, int L, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * HH), lds, s, p);
     return check_launch();
   };
-#ifdef GD4D_DEV                                      // dev A/B (GD4D_SLICED_VARIANT): 1 / 2 = 8 / 4 waves per SIMD, 5 = no feature loads
-  {
-    const char* e = getenv("GD4D_SLICED_VARIANT");
-    const int variant = e ? atoi(e) : 0;
-    if (HH == 8 && L == 4 && sizeof(VT) == 4) {
-      switch (variant) {
-        case 1: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 8, 0>);
-        case 2: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 4, 0>);
-        case 5: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, 6, 3>);
-        default: break;
-      }
-    }
-  }
-#endif
   constexpr int OCC = HH == 16 ? 4 : 6;                             // waves per SIMD
   switch (L) {
-    case 1: return go(cross_attn_agg_sliced_kernel<HH, 1, VT, OCC, 0>);
-    case 2: return go(cross_attn_agg_sliced_kernel<HH, 2, VT, OCC, 0>);
-    case 3: return go(cross_attn_agg_sliced_kernel<HH, 3, VT, OCC, 0>);
-    default: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, OCC, 0>);
+    case 1: return go(cross_attn_agg_sliced_kernel<HH, 1, VT, OCC>);
+    case 2: return go(cross_attn_agg_sliced_kernel<HH, 2, VT, OCC>);
+    case 3: return go(cross_attn_agg_sliced_kernel<HH, 3, VT, OCC>);
+    default: return go(cross_attn_agg_sliced_kernel<HH, 4, VT, OCC>);
   }
 }
 }  // namespace gd4d
@@ -1028,9 +822,6 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
   if (int rc = fill_sliced_params(p, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order, slice_lo,
                                   slice_n))
     return rc;
-#ifdef GD4D_DEV
-  { const char* e = getenv("GD4D_SLICED_BLK"); const int blk = e ? atoi(e) : 0; if (blk > 0 && blk < p.per_xcd) p.blk = blk; }
-#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {
@@ -1042,12 +833,12 @@ extern "C" int gd4d_cross_attn_agg_sliced_fwd(const void* const* level_ptrs, int
 
 namespace gd4d {
 template <int HH, typename VT>
-static int launch_items(const ItemsParams& ip, int L, bool wide, int stage_lo, hipStream_t s, CountArgs* ca = nullptr) {
+static int launch_items(const ItemsParams& ip, int L, bool wide, hipStream_t s, CountArgs* ca = nullptr) {
   const SlicedParams& p = ip.s;
-  const size_t lds = (size_t)HH * 4 * 8 * 80 + (size_t)ip.stage_cap * 128;   // [HH][CH][8][GP] (+ the stage)
+  const size_t lds = (size_t)HH * 4 * 8 * 80;                        // [HH][CH][8][GP]
   const dim3 grid(8 * ((p.per_xcd + p.blk - 1) / p.blk) * p.blk * p.slice_n);
   if (ca) {                                            // gather + record count in one launch (training forward)
-    if (HH != 8 || L != 4 || sizeof(VT) != 4 || wide || stage_lo) return GD4D_EUNSUPPORTED;
+    if (HH != 8 || L != 4 || sizeof(VT) != 4 || wide) return GD4D_EUNSUPPORTED;
     const int wgs = (ca->BQ * HH + HH - 1) / HH;       // a count workgroup = HH (position, head) waves
     ca->groups = (wgs + 7) / 8;
     const int ggroups = (int)(grid.x / 8);
@@ -1061,65 +852,36 @@ static int launch_items(const ItemsParams& ip, int L, bool wide, int stage_lo, h
     hipLaunchKernelGGL(kern, grid, dim3(64 * HH), lds, s, ip);
     return check_launch();
   };
-#ifdef GD4D_DEV                                      // dev A/B (GD4D_SLICED_VARIANT): 1 / 2 = 8 / 4 waves per SIMD, 5 = no feature loads
-  {
-    const char* e = getenv("GD4D_SLICED_VARIANT");
-    const int variant = e ? atoi(e) : 0;
-    if (HH == 8 && L == 4 && sizeof(VT) == 4) {
-      switch (variant) {
-        case 1: return go(cross_attn_agg_items_kernel<HH, 4, VT, 8, 0>);
-        case 2: return go(cross_attn_agg_items_kernel<HH, 4, VT, 4, 0>);
-        case 5: return go(cross_attn_agg_items_kernel<HH, 4, VT, 6, 3>);
-        default: break;
-      }
-    }
-  }
-#endif
   constexpr int OCC = HH == 16 ? 4 : 6;                             // waves per SIMD
-  if (stage_lo) {                                                   // (filled in only for 8 heads, 4 levels, fp32, narrow offsets)
-    if (HH == 8 && L == 4 && sizeof(VT) == 4 && !wide) {
-      if (stage_lo == 3) return go(cross_attn_agg_items_kernel<8, 4, float, 6, 0, false, 3>);
-      return go(cross_attn_agg_items_kernel<8, 4, float, 4, 0, false, 2>);
-    }
-    return GD4D_EUNSUPPORTED;
-  }
   if (wide) {                                                       // (a 64-bit address per load: 4 waves per SIMD, no spills)
     switch (L) {
-      case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, 4, 0, true>);
-      case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, 4, 0, true>);
-      case 3: return go(cross_attn_agg_items_kernel<HH, 3, VT, 4, 0, true>);
-      default: return go(cross_attn_agg_items_kernel<HH, 4, VT, 4, 0, true>);
+      case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, 4, true>);
+      case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, 4, true>);
+      case 3: return go(cross_attn_agg_items_kernel<HH, 3, VT, 4, true>);
+      default: return go(cross_attn_agg_items_kernel<HH, 4, VT, 4, true>);
     }
   }
   switch (L) {
-    case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, OCC, 0>);
-    case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, OCC, 0>);
-    case 3: return go(cross_attn_agg_items_kernel<HH, 3, VT, OCC, 0>);
-    default: return go(cross_attn_agg_items_kernel<HH, 4, VT, OCC, 0>);
+    case 1: return go(cross_attn_agg_items_kernel<HH, 1, VT, OCC>);
+    case 2: return go(cross_attn_agg_items_kernel<HH, 2, VT, OCC>);
+    case 3: return go(cross_attn_agg_items_kernel<HH, 3, VT, OCC>);
+    default: return go(cross_attn_agg_items_kernel<HH, 4, VT, OCC>);
   }
 }
-}  // namespace gd4d
 
-static int items_fwd_impl(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
-                         int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
-                         float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                         const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream, gd4d::CountArgs* ca) {
-  using namespace gd4d;
-  if (stage != 0 && stage != 2 && stage != 3) return GD4D_EINVAL;
-  ItemsParams ip{};
-  if (int rc = fill_sliced_params(ip.s, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order,
-                                  slice_lo, slice_n))
-    return rc;
+// geometry of an items-form gather: 32-bit offsets inside a level - bytes while every level spans < 4 GiB, units of 16 bytes
+// otherwise (< 64 GiB; `wide`)
+static int fill_items_geom(PyramidGeom& g, bool& wide, const int32_t* level_hw, const int64_t* cam_stride_bytes, int64_t pix_stride_bytes,
+                    int rows, int L) {
   if (!level_hw || !cam_stride_bytes) return GD4D_EINVAL;
   if (pix_stride_bytes <= 0 || pix_stride_bytes >= (1ll << 31)) return GD4D_EINVAL;
-  for (int l = 0; l < 4; ++l) { ip.g.lvl_w[l] = 1; ip.g.lvl_h[l] = 1; ip.g.cam_stride[l] = 0; }
-  // offsets inside a level are 32 bits: bytes while every level spans < 4 GiB, units of 16 bytes otherwise (< 64 GiB)
-  bool wide = false;
+  for (int l = 0; l < 4; ++l) { g.lvl_w[l] = 1; g.lvl_h[l] = 1; g.cam_stride[l] = 0; }
+  wide = false;
   unsigned long long span_max = 0;
   for (int l = 0; l < L; ++l) {
     const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
     if (h <= 0 || w <= 0 || cam_stride_bytes[l] < 0) return GD4D_EINVAL;
-    const unsigned long long span = (unsigned long long)(B * N - 1) * (unsigned long long)cam_stride_bytes[l] +
+    const unsigned long long span = (unsigned long long)(rows - 1) * (unsigned long long)cam_stride_bytes[l] +
                                     (unsigned long long)(h * w) * (unsigned long long)pix_stride_bytes;
     span_max = span > span_max ? span : span_max;
     if (span >= (1ull << 32) || cam_stride_bytes[l] >= (1ll << 32)) wide = true;
@@ -1130,38 +892,44 @@ static int items_fwd_impl(const void* const* level_ptrs, const int32_t* level_hw
   if (wide && ((pix_stride_bytes & 15) || span_max >= (1ull << 36))) return GD4D_EUNSUPPORTED;
   for (int l = 0; l < L; ++l) {
     if (wide && ((cam_stride_bytes[l] & 15) || (cam_stride_bytes[l] >> 4) >= (1ll << 32))) return GD4D_EUNSUPPORTED;
-    ip.g.lvl_w[l] = level_hw[2 * l + 1]; ip.g.lvl_h[l] = level_hw[2 * l];
-    ip.g.cam_stride[l] = (unsigned)(wide ? cam_stride_bytes[l] >> 4 : cam_stride_bytes[l]);
+    g.lvl_w[l] = level_hw[2 * l + 1]; g.lvl_h[l] = level_hw[2 * l];
+    g.cam_stride[l] = (unsigned)(wide ? cam_stride_bytes[l] >> 4 : cam_stride_bytes[l]);
   }
-  ip.g.pix_stride = (unsigned)(wide ? pix_stride_bytes >> 4 : pix_stride_bytes);
+  g.pix_stride = (unsigned)(wide ? pix_stride_bytes >> 4 : pix_stride_bytes);
+  return GD4D_OK;
+}
+}  // namespace gd4d
+
+static int items_fwd_impl(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                         int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
+                         float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                         const int32_t* query_order, int slice_lo, int slice_n, void* stream, gd4d::CountArgs* ca) {
+  using namespace gd4d;
+  ItemsParams ip{};
+  if (int rc = fill_sliced_params(ip.s, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order,
+                                  slice_lo, slice_n))
+    return rc;
+  bool wide = false;
+  if (int rc = fill_items_geom(ip.g, wide, level_hw, cam_stride_bytes, pix_stride_bytes, B * N, L)) return rc;
   ip.item = reinterpret_cast<const float4*>(ip.s.pair);
   ip.wsum = wsum;
   ip.cap_i = plan_cap_items(N, P);
-  ip.ulist = nullptr; ip.stage_cap = 0;
-  if (stage) {
-    if (wide || Hh != 8 || L != 4 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
-    ip.stage_cap = stage == 2 ? kStageCap2 : kStageCap3;
-    ip.ulist = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(ip.s.pair) + (size_t)B * Q * Hh * ip.cap_i * 48);
-  }
-#ifdef GD4D_DEV
-  { const char* e = getenv("GD4D_SLICED_BLK"); const int blk = e ? atoi(e) : 0; if (blk > 0 && blk < ip.s.per_xcd) ip.s.blk = blk; }
-#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
-  if (ca) return (Hh == 8 && !bf16) ? launch_items<8, float>(ip, L, wide, stage, s, ca) : GD4D_EUNSUPPORTED;
+  if (ca) return (Hh == 8 && !bf16) ? launch_items<8, float>(ip, L, wide, s, ca) : GD4D_EUNSUPPORTED;
   switch (Hh) {
-    case 4: return bf16 ? launch_items<4, uint16_t>(ip, L, wide, stage, s) : launch_items<4, float>(ip, L, wide, stage, s);
-    case 8: return bf16 ? launch_items<8, uint16_t>(ip, L, wide, stage, s) : launch_items<8, float>(ip, L, wide, stage, s);
-    default: return bf16 ? launch_items<16, uint16_t>(ip, L, wide, stage, s) : launch_items<16, float>(ip, L, wide, stage, s);
+    case 4: return bf16 ? launch_items<4, uint16_t>(ip, L, wide, s) : launch_items<4, float>(ip, L, wide, s);
+    case 8: return bf16 ? launch_items<8, uint16_t>(ip, L, wide, s) : launch_items<8, float>(ip, L, wide, s);
+    default: return bf16 ? launch_items<16, uint16_t>(ip, L, wide, s) : launch_items<16, float>(ip, L, wide, s);
   }
 }
 
 extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
                                              int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
                                              float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                                             const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream) {
+                                             const int32_t* query_order, int slice_lo, int slice_n, void* stream) {
   return items_fwd_impl(level_ptrs, level_hw, cam_stride_bytes, pix_stride_bytes, slice_stride_bytes, plan, agg, wsum, B, N, Q, Hh, C,
-                        L, P, feats_dtype, query_order, slice_lo, slice_n, stage, stream, nullptr);
+                        L, P, feats_dtype, query_order, slice_lo, slice_n, stream, nullptr);
 }
 
 extern "C" int gd4d_cross_attn_agg_items_count_fwd(const void* const* level_ptrs, const int32_t* level_hw,
@@ -1184,7 +952,7 @@ extern "C" int gd4d_cross_attn_agg_items_count_fwd(const void* const* level_ptrs
   ca.cap_t = plan_cap_t(N, P);
   ca.BQ = B * Q;
   return items_fwd_impl(level_ptrs, level_hw, cam_stride_bytes, pix_stride_bytes, slice_stride_bytes, plan_items, agg, wsum, B, N, Q, Hh,
-                        C, L, P, feats_dtype, query_order, 0, 8, 0, stream, &ca);
+                        C, L, P, feats_dtype, query_order, 0, 8, stream, &ca);
 }
 
 extern "C" int gd4d_pyramid_slice_planar_fwd(const void* const* feats, const int32_t* level_hw, void* out, int R, int C,

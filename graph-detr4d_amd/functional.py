@@ -552,9 +552,6 @@ LATE_VALUES_KEY = '_gd4d_late_values'
 AGG_DEFAULT = 'sliced'
 
 
-STAGE_DEFAULT = '0'          # (set after measuring: tools/r04_run16.sh)
-
-
 class LateValues:
     """The aggregate-then-project form of the value path (csrc/gd4d_cross_attn_late.hip): ONE channels-last copy of the
     pyramid for all decoder layers (the reference's flatten / transpose / cat, deform3d_cross_attn.py:264-276), made on the
@@ -643,15 +640,11 @@ class LateValues:
         (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
         if self.mode == 'sliced':
             # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
-            # GD4D_PLAN=pairs: the 128-bytes-per-item form the training kernels read; GD4D_STAGE=0 / 2 / 3: which coarse levels'
-            # corners go through the gather's LDS stage (all bit-identical results)
+            # GD4D_PLAN=pairs: the 128-bytes-per-item form the training kernels read
             items = os.environ.get('GD4D_PLAN', 'items') != 'pairs'
-            stage = int(os.environ.get('GD4D_STAGE', STAGE_DEFAULT)) if items else 0
-            if stage and not ops.stage_supported(self.pyramid, ref.shape[0], module.num_heads, offsets.shape[3]):
-                stage = 0
             plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                            cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
-                                           query_order=order, items=items, stage=stage)
+                                           query_order=order, items=items)
             self._wait_copy()
             agg = ops.cross_attn_agg_sliced_fwd(plan)
             if vp_weight is not None:

@@ -243,9 +243,9 @@ class Plan:
     plan kernel).  items: the buffer holds the ITEMS form (include/gd4d.h, GD4D_CA_PLAN_ITEMS) - gather only; the
     training backward kernels need the pairs form."""
 
-    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False, points=4, stage=0, items_buf=None):
+    def __init__(self, buf, order, pyramid, b, q, num_heads, wsum, items=False, points=4, items_buf=None):
         self.buf, self.order, self.pyramid, self.b, self.q, self.num_heads, self.wsum = buf, order, pyramid, b, q, num_heads, wsum
-        self.items, self.points, self.stage = bool(items), int(points), int(stage)
+        self.items, self.points = bool(items), int(points)
         self.items_buf = items_buf           # both=True: `buf` holds the pairs, this view the items (the forward gather's form)
 
     def need_pairs(self, who):
@@ -256,29 +256,17 @@ class Plan:
                                  'forward kernels take 1 / 2 / 4 / 8, the training backward 4 only')
 
 
-CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS, CA_PLAN_STAGE3, CA_PLAN_STAGE23, CA_PLAN_BOTH = 1, 2, 4, 8, 16
-
-
-def stage_supported(pyramid, b, num_heads, points):
-    """Whether the gather can stage the coarse levels' corners through LDS for this pyramid (include/gd4d.h): 8 heads, 4
-    points, 4 levels, fp32, every level's bytes < 2^32, strides in whole 64-byte units."""
-    if num_heads != 8 or points != 4 or len(pyramid.level_hw) != 4 or pyramid.dtype != torch.float32 or pyramid.pix_stride % 64:
-        return False
-    for (h, w), cs in zip(pyramid.level_hw, pyramid.cam_stride):
-        if cs % 64 or cs >= 2 ** 32 or (pyramid.rows - 1) * cs + h * w * pyramid.pix_stride >= 2 ** 32:
-            return False
-    return True
+CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS, CA_PLAN_BOTH = 1, 2, 16
 
 
 def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range, img_h, img_w, num_heads,
-                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None, items=False, stage=0,
+                        want_mask=False, want_uv=False, raw_cam_weights=False, plan=None, query_order=None, items=False,
                         both=False):
     """gd4d_cross_attn_plan_fwd: projection + mask + softmax + camera weights + bilinear corners of one decoder layer's
     cross-attention -> what gd4d_cross_attn_agg_sliced_fwd walks on `pyramid` (a PyramidView).  The other arguments as
     cross_attn_fwd; plan: a Plan to overwrite; items: the 32-bytes-per-item form (the corners are worked out by the gather,
-    which then also fills wsum); stage (with items): 3 / 2 = the corners of level 3 / levels 2 and 3 go through the gather's LDS
-    stage (stage_supported() says whether it applies; results bit-identical).  both: pairs AND items in one launch (a training
-    step: the forward gather reads the items, the backward kernels the pairs).
+    which then also fills wsum).  both: pairs AND items in one launch (a training step: the forward gather reads the items, the
+    backward kernels the pairs).
     Returns Plan [, mask (B, N, Q, Hh, P) uint8] [, uv (B, N, Q, Hh, P, 2)]."""
     lib = _lib.load()
     b, q = ref.shape[0], ref.shape[1]
@@ -290,14 +278,11 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
         raise ValueError('offsets / attn_logits / cam_logits have the wrong number of elements')
     f32 = torch.float32
     nbytes = cross_attn_plan_bytes(b, n, q, hh, p)
-    if both and (items or stage or plan is not None):
-        raise ValueError('both=True excludes items / stage / plan')
+    if both and (items or plan is not None):
+        raise ValueError('both=True excludes items / plan')
     buf = torch.empty(2 * nbytes if both else nbytes, device=ref.device, dtype=torch.uint8) if plan is None else plan.buf
     wsum = torch.empty(b, q, hh, device=ref.device, dtype=f32) if plan is None else plan.wsum
-    if stage not in (0, 2, 3) or (stage and not items):
-        raise ValueError('stage must be 0, 2 or 3 and needs items=True')
-    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items, points=p, stage=stage,
-                items_buf=buf[nbytes:] if both else None)
+    plan = Plan(buf, query_order, pyramid, b, q, hh, wsum, items=items, points=p, items_buf=buf[nbytes:] if both else None)
     mask = torch.empty(b, n, q, hh, p, device=ref.device, dtype=torch.uint8) if want_mask else None
     uv = torch.empty(b, n, q, hh, p, 2, device=ref.device, dtype=f32) if want_uv else None
     rng = (ctypes.c_double * 6)(*[float(x) for x in pc_range])
@@ -308,8 +293,7 @@ def cross_attn_plan_fwd(pyramid, ref, offsets, attn_logits, cam_logits, lidar2im
         _dev(cam_logits, 'cam_logits', f32), _dev(lidar2img, 'lidar2img', f32), rng, float(img_h), float(img_w),
         lv, cs, pyramid.pix_stride, _dev(buf, 'plan', torch.uint8), buf.numel(), _dev(wsum, 'wsum', f32),
         _dev(mask, 'mask') if want_mask else None, _dev(uv, 'uv') if want_uv else None, b, n, q, hh, nl, p,
-        (CA_RAW_CAM_WEIGHTS if raw_cam_weights else 0) | (CA_PLAN_ITEMS if items else 0) |
-        (CA_PLAN_STAGE3 if stage == 3 else CA_PLAN_STAGE23 if stage == 2 else 0) | (CA_PLAN_BOTH if both else 0),
+        (CA_RAW_CAM_WEIGHTS if raw_cam_weights else 0) | (CA_PLAN_ITEMS if items else 0) | (CA_PLAN_BOTH if both else 0),
         None if query_order is None else _order_ptr(query_order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_plan_fwd')
     res = (plan,)
@@ -341,8 +325,8 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None, count=None):
         cs = (ctypes.c_int64 * nl)(*pyramid.cam_stride)
         if count is not None:
             sink, layer = count
-            if plan.items or plan.items_buf is None or tuple(slices) != (0, 8) or plan.stage:
-                raise _lib.Gd4dError('gather + record count in one launch: a plan in both forms, all slices, no stage')
+            if plan.items or plan.items_buf is None or tuple(slices) != (0, 8):
+                raise _lib.Gd4dError('gather + record count in one launch: a plan in both forms, all slices')
             slots, slot_bytes = sink.begin_layer(layer, plan)
             code = lib.gd4d_cross_attn_agg_items_count_fwd(
                 ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, _dev(plan.items_buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
@@ -355,12 +339,13 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None, count=None):
             _lib.check(code, 'gd4d_cross_attn_agg_items_count_fwd')
             sink.plans.append((int(layer), plan, slots))
             return agg
+        items_buf = _dev(plan.buf if plan.items else plan.items_buf, 'plan', torch.uint8)
+        dt = _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16
+        order_p = None if query_order is None else _order_ptr(query_order, b * q)
         code = lib.gd4d_cross_attn_agg_items_fwd(
-            ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride,
-            _dev(plan.buf if plan.items else plan.items_buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
-            _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, plan.points,
-            _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
-            None if query_order is None else _order_ptr(query_order, b * q), int(slices[0]), int(slices[1]), plan.stage, _stream())
+            ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, items_buf, _dev(agg, 'agg', f32),
+            _dev(plan.wsum, 'wsum', f32), b, pyramid.rows // b, q, hh, 256, nl, plan.points, dt, order_p,
+            int(slices[0]), int(slices[1]), _stream())
         _lib.check(code, 'gd4d_cross_attn_agg_items_fwd')
         return agg
     code = lib.gd4d_cross_attn_agg_sliced_fwd(

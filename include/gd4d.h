@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 50
+#define GD4D_ABI_VERSION 51
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -56,8 +56,6 @@ enum {
 #define GD4D_MAX_LAYERS 8
 #define GD4D_CA_RAW_CAM_WEIGHTS 1
 #define GD4D_CA_PLAN_ITEMS 2      /* gd4d_cross_attn_plan_fwd: write the ITEMS form of the plan (gd4d_cross_attn_agg_items_fwd) */
-#define GD4D_CA_PLAN_STAGE3 4     /* with ITEMS: also de-duplicate the query's corners on level 3 for the gather's LDS stage (stage = 3) */
-#define GD4D_CA_PLAN_STAGE23 8    /* ... on levels 2 and 3 (stage = 2) */
 #define GD4D_CA_PLAN_BOTH 16      /* pairs AND items: plan_bytes >= 2 x gd4d_cross_attn_plan_bytes(); [0, bytes) is the pairs plan (what the
                                      training backward kernels read), plan + bytes an items plan for gd4d_cross_attn_agg_items_fwd */
 
@@ -198,22 +196,15 @@ int gd4d_value_proj_heads_fwd(const float* agg, const float* wsum, const float* 
  *   slice 0 (NULL: not wanted).  A level may span up to 64 GiB (offsets in units of 16 bytes once a level reaches 4 GiB -
  *   e.g. VoVNet-99 level 0 stored channels-last with B >= 2; all strides must then be multiples of 16); the pairs form is
  *   limited to 4 GiB per level.  The training backward kernels read the pairs form only.
- *
- * Staging (flags GD4D_CA_PLAN_STAGE3 / _STAGE23 with ITEMS; `stage` = 3 / 2 of the gather; 8 heads, 4 levels, fp32, levels
- *   < 4 GiB).  Most corner reads on the coarse levels hit pixels another HEAD of the same query also reads (21 % / 40 % of
- *   a (query, camera)'s reads on levels 3 / 2 are distinct pixels on the bench's rig), and every read moves 128 bytes over
- *   the 64 B/clk L1 path.  The plan kernel de-duplicates a query's corners on the staged levels, numbers the unique lines and
- *   gives every item the slots of its corners (a third float4 per item); a gather workgroup loads the unique lines of its
- *   slice once into LDS and its head-waves read those corners from there.  A query with more unique lines than the stage
- *   holds (192 / 384) is gathered without staging.  agg and wsum are bit-identical to the unstaged forms. */
+ * */
 size_t gd4d_cross_attn_plan_bytes(int B, int N, int Q, int Hh, int P);
 int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
                                   int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
                                   float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
-                                  const int32_t* query_order, int slice_lo, int slice_n, int stage, void* stream);
+                                  const int32_t* query_order, int slice_lo, int slice_n, void* stream);
 
 /* gd4d_cross_attn_agg_items_count_fwd - a TRAINING step's forward gather and the first step of the pyramid gradient's bookkeeping
- * in one launch: gd4d_cross_attn_agg_items_fwd (all slices, no stage) on plan_items and gd4d_pyramid_grad_count on plan_pairs (the
+ * in one launch: gd4d_cross_attn_agg_items_fwd (all slices, every level) on plan_items and gd4d_pyramid_grad_count on plan_pairs (the
  * two forms of one plan: GD4D_CA_PLAN_BOTH) - the same results as the two launches (the slots, as there, in an order the atomics
  * decide).  Both only read the plan; the count lives on L2 atomic round trips, the gather on the fabric: every ninth group of
  * eight workgroups counts, the others gather (each keeps its XCD).  8 heads, 4 levels, fp32 features, narrow offsets

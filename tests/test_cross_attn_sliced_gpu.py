@@ -17,12 +17,11 @@ ITEMS = True              # module default of _sliced: the plan form of the infe
                           # corners and wsum); every test below also checks it against the pairs form, bit for bit
 
 
-def _sliced_form(items, pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads=8, order=None, want=False, slices=None,
-                 stage=0):
+def _sliced_form(items, pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads=8, order=None, want=False, slices=None):
     from graph_detr4d_amd import ops
     b, q = ref.shape[0], ref.shape[1]
     res = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_w, heads,
-                                  want_mask=want, want_uv=want, query_order=order, items=items, stage=stage)
+                                  want_mask=want, want_uv=want, query_order=order, items=items)
     plan = res[0] if want else res
     if items:
         plan.wsum.fill_(float('nan'))                # the gather (slice 0) must write every row
@@ -36,8 +35,7 @@ def _sliced_form(items, pyr, ref, offsets, attn, cam, l2i, pc_range, img_h, img_
 
 
 def _sliced(*args, **kwargs):
-    """Every form of the plan - pairs, items, items with the corners of level 3 / levels 2 + 3 staged through the gather's LDS -
-    must agree bit for bit (same products, same order); returns the items form's result."""
+    """Both forms of the plan - pairs, items - must agree bit for bit (same products, same order); returns the items form's result."""
     from graph_detr4d_amd import ops
     got = _sliced_form(ITEMS, *args, **kwargs)
     other = _sliced_form(not ITEMS, *args, **kwargs)
@@ -59,14 +57,6 @@ def _sliced(*args, **kwargs):
         assert torch.equal(agg_b, got[0]) and torch.equal(both.wsum, got[1])
         both.items_buf = None                            # ... and the pairs of the same buffer through the pairs gather
         assert torch.equal(ops.cross_attn_agg_sliced_fwd(both), got[0])
-    if ops.stage_supported(pyr, ref.shape[0], kwargs.get('heads', 8), offsets.shape[3]):
-        for stage in (3, 2):
-            # the staged gather walks the direct levels of all items first, then the staged ones: the same products in
-            # another order (agg within fp32 rounding of a ~17-term sum); wsum, mask, uv unchanged bit for bit
-            st = _sliced_form(True, *args, stage=stage, **kwargs)
-            torch.testing.assert_close(st[0], got[0], rtol=1e-5, atol=2e-5)
-            for a, b in zip(got[1:], st[1:]):
-                assert torch.equal(a, b), f'stage = {stage} disagrees with the unstaged gather'
     return got
 
 
@@ -426,44 +416,3 @@ def test_training_kernels_refuse_num_points_other_than_four():
     assert plan.points == 2
     with pytest.raises(_lib.Gd4dError):
         ops.cross_attn_dot_sliced(plan, torch.zeros(1, 9, 8, 256).cuda())
-
-
-def test_staged_gather_full_size_and_overflowing_queries():
-    """The LDS stage at the timed size (900 x 24, R50 pyramid): bit-identical to the unstaged gather with level 3 / levels 2 + 3
-    staged, most queries staged (the header says so), and the queries whose unique lines exceed the stage (all cameras made
-    identical: every camera sees every query) are gathered without it - same results."""
-    from graph_detr4d_amd import ops, synthetic
-    dev = 'cuda'
-    g = torch.Generator(device='cpu').manual_seed(23)
-    b, q, n = 1, 900, 24
-    feats = [torch.randn(b, n, 256, h, w, generator=g).to(dev) for h, w in synthetic.R50_LEVELS]
-    sp, shapes = ops.pyramid_slice_planar_fwd(feats)
-    pyr = ops.PyramidView.slice_planar(sp, shapes)
-    rig = synthetic.camera_rig(4)
-    for all_visible in (False, True):
-        l2i = torch.from_numpy(rig if not all_visible else rig[:1].repeat(n, 0)).unsqueeze(0).contiguous().to(dev)
-        ref = torch.rand(b, q, 3, generator=g)
-        if all_visible:
-            ref[..., 0] = 0.75 + 0.2 * ref[..., 0]                 # in front of camera 0, all of them
-            ref[..., 1] = 0.45 + 0.1 * ref[..., 1]
-        args = (ref.to(dev), (torch.randn(b, q, 8, 4, 3, generator=g) * 1.5).to(dev), torch.randn(b, q, 8, 4, 4, generator=g).to(dev),
-                torch.randn(b, q, n, generator=g).to(dev), l2i, synthetic.PC_RANGE, 900, 1600)
-        order = ops.query_order_fwd(args[0], synthetic.PC_RANGE)
-        base = _sliced_form(True, pyr, *args, order=order)
-        for stage, cap in ((3, 192), (2, 384)):
-            plan = ops.cross_attn_plan_fwd(pyr, *args[:5], synthetic.PC_RANGE, 900, 1600, 8, query_order=order, items=True, stage=stage)
-            hdr = plan.buf[:q * 64].view(torch.int32).view(q, 16)[:, 8]
-            staged_frac = (hdr != 0xffff).float().mean().item()
-            assert ((hdr == 0xffff) | (hdr <= cap)).all()
-            if all_visible:
-                assert staged_frac < 0.2, staged_frac               # 24 cameras' worth of lines does not fit
-            else:
-                assert staged_frac > (0.5 if stage == 2 else 0.8), staged_frac
-            plan.wsum.fill_(float('nan'))
-            agg = ops.cross_attn_agg_sliced_fwd(plan)
-            assert torch.equal(plan.wsum, base[1]), (stage, all_visible)
-            torch.testing.assert_close(agg, base[0], rtol=1e-5, atol=5e-5)      # staged queries: another summation order
-            if all_visible and staged_frac == 0:
-                assert torch.equal(agg, base[0])                                # nothing staged: the unstaged sweep, bit for bit
-            agg2 = ops.cross_attn_agg_sliced_fwd(plan)
-            assert torch.equal(agg, agg2)                                       # run-to-run identical

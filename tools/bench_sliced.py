@@ -25,7 +25,6 @@ def main():
     ap.add_argument('--levels', default='r50')
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--plan', default='items', help='items (the inference step) | pairs (what the training kernels read)')
-    ap.add_argument('--stage', type=int, default=0, help='0 | 3 | 2: corners of level 3 / levels 2 + 3 through the LDS stage')
     a = ap.parse_args()
     dev = 'cuda'
     n, q = 6 * a.frames, a.queries
@@ -50,14 +49,14 @@ def main():
         pyr.cam_stride = [0] * len(pyr.cam_stride)
     items = a.plan == 'items'
     plan, mask = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
-                                         query_order=order, want_mask=True, items=items, stage=a.stage)
+                                         query_order=order, want_mask=True, items=items)
     vis = int(mask.sum().item())
     corner_bytes = vis * len(levels) * 4 * 256 * (2 if a.dtype == 'bf16' else 4)
     sa, sw = ops.cross_attn_agg_sliced_fwd(plan), plan.wsum
     t_plan = timed(lambda: [ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
-                                                    plan=plan, query_order=order, items=items, stage=a.stage) for _ in range(6)], a.iters, 6)
+                                                    plan=plan, query_order=order, items=items) for _ in range(6)], a.iters, 6)
     t = timed(lambda: [ops.cross_attn_agg_sliced_fwd(plan, agg=sa) for _ in range(6)], a.iters, 6)
-    print(f'plan {a.plan} stage {a.stage} variant {os.environ.get("GD4D_SLICED_VARIANT", "0")} layout {a.layout} alias {a.alias} {a.dtype}: plan {t_plan:.1f} us, '
+    print(f'plan {a.plan} layout {a.layout} alias {a.alias} {a.dtype}: plan {t_plan:.1f} us, '
           f'sliced gather {t:.1f} us per launch ({corner_bytes / t / 1e6:.2f} TB/s of corner bytes)')
 
 
