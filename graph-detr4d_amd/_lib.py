@@ -40,7 +40,6 @@ SIGNATURES = {
     'gd4d_value_proj_heads_bwd_weight_group': (_i, [_vp] * 6 + [_i, _vp, _c.c_size_t, _i, _i, _i, _vp]),
     'gd4d_cross_attn_dot_bytes': (_c.c_size_t, [_i] * 5),
     'gd4d_cross_attn_dot_sliced': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp, _vp]),
-    'gd4d_cross_attn_dot_sliced_fused': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp] + [_vp] * 5 + [_i, _i, _vp]),
     'gd4d_cross_attn_dot_sliced_wgrad': (_i, [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_size_t] + [_i] * 8 + [_vp] + [_vp] * 5 + [_i, _i, _vp]),
     'gd4d_cross_attn_plan_bwd': (_i, [_vp] * 6 + [_f, _f] + [_vp] * 9 + [_c.c_size_t, _vp] + [_i] * 7 + [_vp, _vp]),
     'gd4d_pyramid_grad_chunks': (_c.c_int64, [_vp, _i, _i]),
@@ -97,7 +96,9 @@ SIGNATURES = {
     'gd4d_row_chain_fwd': (_i, [_vp, _i, _i, _vp]),
     'gd4d_row_chain2_fwd': (_i, [_vp, _i, _vp, _i, _i, _vp]),
     'gd4d_mha_core_presplit_fwd': (_i, [_vp] * 4 + [_i] * 5 + [_c.c_longlong, _c.c_longlong, _vp, _i, _f, _vp, _f, _vp, _vp]),
-    'gd4d_row_chain_mha_fwd': (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 4 + [_i] * 6 + [_f, _vp, _vp, _vp]),
+    'gd4d_xcd_placement_probe': (_i, [_vp, _i, _vp]),
+    'gd4d_adamw_flat_workspace_bytes': (_c.c_size_t, []),
+    'gd4d_adamw_flat': (_i, [_vp] * 6 + [_c.c_size_t, _c.c_int64] + [_f] * 6 + [_vp]),
     'gd4d_chain_weight_image_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_chain_weight_image': (_i, [_vp, _i, _i, _vp, _vp]),
     'gd4d_chain_weight_image_exact_bytes': (_c.c_size_t, [_i, _i]),

@@ -84,9 +84,8 @@ class RawPyramid:
 
     Only the last pass over the records needs gradients: a layer's records are counted right after its plan in the FORWARD
     pass, scan / fill / sort are issued by the first backward node, the reduction as soon as the last layer's grad_agg rows
-    exist.  GD4D_TRAIN_SIDE=1 puts all of that on a side stream (join() at the end of the forward pass and the pyramid
-    node's backward join it) - measured and NOT the default: inside a replayed hipGraph the cross-stream edges cost more
-    than the overlap returns on this runtime (training step 11.8 ms against 9.7 ms with everything on one stream)."""
+    exist.  Everything runs on the step's one stream: side streams for the counts, the bookkeeping and the copy were built and
+    measured in rounds 3 - 4 and were slower inside a replayed hipGraph (docs/measurements_r04.md section 7); they are gone."""
 
     def __init__(self):
         self.pyramid = self.shapes = None
@@ -94,10 +93,8 @@ class RawPyramid:
         self.layer_q = []                              # queries per sample of every registered layer
         self.needs_grad = self.channels_last = False
         self.copy_dtype = torch.float32
-        self.main = self.side = self.side_bwd = self.side_prep = None
-        self.copy_event = None
         self.sink = self.grads = self._dpart = None
-        self._forked = self._prepared = False
+        self._prepared = False
         self.fills_ride = False                        # set by the chain training path (fused_train)
 
     def register(self, q):
@@ -107,15 +104,6 @@ class RawPyramid:
         self.pending += 1
         self.layer_q.append(int(q))
         return self.layers - 1
-
-    def _fork(self, side=None):
-        side = self.side if side is None else side
-        if side is self.main:
-            return
-        ev = torch.cuda.Event()
-        ev.record(self.main)
-        side.wait_event(ev)
-        self._forked = True
 
     def _sink_for(self, layer, plan):
         if self.sink is None:
@@ -129,39 +117,19 @@ class RawPyramid:
         """Forward pass on ONE stream: the records' slots are handed out by the forward gather's launch
         (ops.cross_attn_agg_sliced_fwd(count=...)).  Returns the aggregates; None when the plan / pyramid is not of the kind
         that launch takes (count() + the gather then)."""
-        if (not self.needs_grad or self.side is not self.main or plan.items or plan.items_buf is None
-                or plan.num_heads != 8 or len(self.pyramid.level_hw) != 4 or self.pyramid.dtype != torch.float32
-                or os.environ.get('GD4D_TRAIN_COUNT', 'gather') != 'gather'):
+        if (not self.needs_grad or plan.items or plan.items_buf is None
+                or plan.num_heads != 8 or len(self.pyramid.level_hw) != 4 or self.pyramid.dtype != torch.float32):
             return None
         return ops.cross_attn_agg_sliced_fwd(plan, count=(self._sink_for(layer, plan), layer))
 
     def count(self, layer, plan):
-        """Forward pass: hand the records of `plan` their slots (side stream)."""
+        """Forward pass: hand the records of `plan` their slots."""
         if not self.needs_grad:
             return
-        self._sink_for(layer, plan)
-        self._fork()                                 # the plan was written on the main stream
-        with torch.cuda.stream(self.side):
-            self.sink.add_layer(layer, plan)
-        if self.side is not self.main:
-            plan.buf.record_stream(self.side)
-            if plan.order is not None:
-                plan.order.record_stream(self.side)
-
-    def wait_copy(self):
-        """Before the first kernel that reads the pyramid: the copy may still be running beside the main stream."""
-        if self.copy_event is not None:
-            torch.cuda.current_stream(self.pyramid.device).wait_event(self.copy_event)
-            self.copy_event = None
-
-    def join(self):
-        """Make the main stream wait for the side stream's work (end of the forward pass; keeps a capture well-formed)."""
-        if self._forked:
-            self.main.wait_stream(self.side)
-            self._forked = False
+        self._sink_for(layer, plan).add_layer(layer, plan)
 
     def begin_backward(self):
-        """First backward node of the step: the table for every registered layer; scan + fill + sort on the side stream."""
+        """First backward node of the step: the table for every registered layer; scan + fill + sort."""
         if not self.needs_grad or self._prepared or self.sink is None:
             return
         self.sink.alloc_table(self.layer_q)
@@ -172,11 +140,7 @@ class RawPyramid:
             self._launches_left = max(len(self.layer_q) - 1, 0)   # attention backward launches in front of the reduction
             self._prepared = True
             return
-        prep = self.side_prep if self.side_prep is not None and self.side_bwd is self.main else self.side_bwd
-        self._fork(prep)
-        with torch.cuda.stream(prep):
-            self.sink.prepare()
-        self._prep_stream = prep
+        self.sink.prepare()
         self._prepared = True
 
     def fills_for_launch(self):
@@ -190,7 +154,7 @@ class RawPyramid:
         return self.sink.take_fills(-(-len(self.sink.plans) // left))
 
     def layer_done(self):
-        """A layer's grad_agg rows are written (main stream); after the last one the reduction starts on the side stream."""
+        """A layer's grad_agg rows are written; after the last one the reduction starts."""
         self.pending -= 1
         if self.pending == 0:
             self._reduce()
@@ -204,16 +168,7 @@ class RawPyramid:
         py = self.pyramid
         grads = [torch.empty((py.rows, h, w, 256) if self.channels_last else (py.rows, 256, h, w), device=py.device, dtype=torch.float32)
                  for h, w in py.level_hw]
-        prep = getattr(self, '_prep_stream', None)
-        if prep is not None and prep is not self.side_bwd:       # GD4D_TRAIN_SIDE=prepare: scan / fill / sort ran beside the backward chains
-            self.side_bwd.wait_stream(prep)
-            for t in self.sink.prepared:
-                t.record_stream(self.side_bwd)
-        self._fork(self.side_bwd)                    # the table rows were written on the main stream
-        with torch.cuda.stream(self.side_bwd):
-            grads = self.sink.reduce(grads, channels_last=self.channels_last)
-        if self.side_bwd is not self.main:
-            self.sink.table.record_stream(self.side_bwd)
+        grads = self.sink.reduce(grads, channels_last=self.channels_last)
         self.grads = grads
 
     def dpart(self, nbytes):
@@ -237,29 +192,10 @@ class PyramidSourceFunction(torch.autograd.Function):
             raw.channels_last = True
             sp = feats[0]
         else:
-            src = [f.contiguous() for f in feats]
-            if os.environ.get('GD4D_TRAIN_COPY_SIDE', '0') == '1':
-                # dev switch: the copy beside layer 0's query side (nothing reads it before the first gather: raw.wait_copy())
-                main = torch.cuda.current_stream(feats[0].device)
-                side = Fn._companion_stream(Fn._SIDE_STREAMS, feats[0].device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    sp, hw = ops.pyramid_slice_planar_fwd(src, out_dtype=raw.copy_dtype)
-                raw.copy_event = torch.cuda.Event()
-                raw.copy_event.record(side)
-                sp.record_stream(main)
-                for f in src:
-                    f.record_stream(side)
-            else:
-                sp, hw = ops.pyramid_slice_planar_fwd(src, out_dtype=raw.copy_dtype)
+            sp, hw = ops.pyramid_slice_planar_fwd([f.contiguous() for f in feats], out_dtype=raw.copy_dtype)
             raw.pyramid = ops.PyramidView.slice_planar(sp, hw)
         raw.shapes = [tuple(f.shape) for f in feats]
         raw.needs_grad = any(ctx.needs_input_grad[1:])
-        raw.main = torch.cuda.current_stream(sp.device)
-        mode = os.environ.get('GD4D_TRAIN_SIDE', '0')        # '1': counts, scan / fill / sort and the reduction beside the main stream; 'count': the counts only
-        raw.side = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if mode in ('1', 'count') else raw.main
-        raw.side_bwd = raw.side if mode == '1' else raw.main
-        raw.side_prep = Fn._companion_stream(Fn._SIDE_STREAMS, sp.device) if mode == 'prepare' else None   # dev: scan / fill / sort only
         ctx.raw = raw
         ctx.set_materialize_grads(False)
         return torch.empty(1, device=feats[0].device, dtype=torch.float32)
@@ -269,8 +205,7 @@ class PyramidSourceFunction(torch.autograd.Function):
         raw = ctx.raw
         if raw.sink is None:
             return (None,) * (1 + len(raw.shapes))
-        raw._reduce()                                # (already running unless a layer's output was never used)
-        raw.join()
+        raw._reduce()                                # (already issued unless a layer's output was never used)
         grads, raw.grads, raw.sink, raw._dpart = raw.grads, None, None, None
         return (None, *[g.unflatten(0, shape[:-3]) if len(shape) > 4 else g for g, shape in zip(grads, raw.shapes)])
 
@@ -297,7 +232,6 @@ class CrossAttnRawFunction(torch.autograd.Function):
         ctx.layer = raw.register(plan.q)
         if ctx.needs_input_grad[0]:
             raw.count(ctx.layer, plan)
-        raw.wait_copy()
         agg = ops.cross_attn_agg_sliced_fwd(plan)
         vp_weight = vp_weight.contiguous()
         out = ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, None if vp_bias is None else vp_bias.contiguous())
@@ -411,48 +345,23 @@ class ValueProjMultiFunction(torch.autograd.Function):
 # Weight gradients that go straight into the flat gradient buffer (ctx.main) are read by nobody before the optimizer: they
 # are queued during the backward pass and issued sixteen per launch (gd4d_linear_bwd_weight_group) - at the latest from a
 # callback the autograd engine runs when the backward pass ends (inside a hipGraph capture that is still inside the capture).
-# GD4D_TRAIN_DEFER_WGRAD=0: one launch per Linear, where autograd reaches it.
 _WGRAD_GROUP, _LN_GROUP, _VP_GROUP = 16, 32, 8
-_MAX_TASKS = 4
+_MAX_TASKS = 2
 # One pair of queues per backward pass (autograd graph-task id): a nested / re-entrant backward (reentrant checkpointing,
 # autograd.grad inside a hook) has its own id and must neither flush nor drop the outer pass's entries.  A pass that raised
-# never runs its callback and leaves its queues behind: they are never added to anything and are evicted, oldest id first,
-# once more than _MAX_TASKS passes have queues (passes nest two deep at most in this package).
+# never runs its callback and leaves its queues behind (pinning activations): they are never added to anything and are evicted,
+# oldest id first, as soon as a later pass needs a queue and _MAX_TASKS exist - passes nest two deep at most in this package and a
+# nested pass has the larger id, so what goes is never a live outer pass.
 _DEFERRED = {}                # task id -> {'w': [...], 'ln': [...], 'vp': [...]}
-
-
-_WGRAD_SIDE = {}                # device index -> [side stream, work outstanding]
 
 
 def _issue(kind, entries):
     if kind == 'w':
-        if os.environ.get('GD4D_TRAIN_WGRAD_SIDE', '0') == '1' and entries:
-            # dev switch: the grouped weight-gradient launches (nothing reads their results before the optimizer) beside the main
-            # stream; the pass's last flush joins (_flush_deferred)
-            from . import functional as Fn
-            dev = entries[0][0].device
-            main = torch.cuda.current_stream(dev)
-            side = Fn._companion_stream(Fn._SIDE_STREAMS, dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ops.linear_bwd_weight_group(entries, accumulate=True)
-            for x, gy, _, _ in entries:
-                x.record_stream(side)
-                gy.record_stream(side)
-            _WGRAD_SIDE[dev.index] = [side, True]
-            return
         ops.linear_bwd_weight_group(entries, accumulate=True)
     elif kind == 'vp':                      # value_proj of the aggregates: (grad_out, (agg, wsum), main_w, main_b) per layer
         ops.value_proj_heads_bwd_weight_group([(g, aw[0], aw[1], mw, mb) for g, aw, mw, mb in entries], accumulate=True)
     else:
         ops.layernorm_bwd_reduce_group(entries, accumulate=True)
-
-
-def _join_wgrad_side():
-    for idx, st in _WGRAD_SIDE.items():
-        if st[1]:
-            torch.cuda.current_stream(idx).wait_stream(st[0])
-            st[1] = False
 
 
 def _flush_deferred(task=None):
@@ -465,7 +374,6 @@ def _flush_deferred(task=None):
             q = queues[kind]
             for i in range(0, len(q), group):
                 _issue(kind, q[i:i + group])
-    _join_wgrad_side()
 
 
 def take_queued_weight_grads():
@@ -484,7 +392,7 @@ def take_queued_weight_grads():
 def _deferring():
     """The current backward pass (graph task id, 0 for the first pass of a process) if parameter gradients may be queued,
     else None - test with `is not None`."""
-    if os.environ.get('GD4D_TRAIN_DEFER_WGRAD', '1') == '0' or not hasattr(torch._C, '_current_graph_task_id'):
+    if not hasattr(torch._C, '_current_graph_task_id'):
         return None
     task = torch._C._current_graph_task_id()
     return task if task >= 0 else None

@@ -120,3 +120,172 @@ extern "C" int gd4d_linear_sum_assignment_batch(const float* cost, const int64_t
     if (!ok[p]) return GD4D_EUNSUPPORTED;
   return GD4D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// gd4d_hungarian_assign_fwd: the same solver ON THE DEVICE (round 5) - the assignment of a training step no
+// longer leaves the GPU (no device -> host copy of the cost matrix, no host solve, no copy back: the `--criterion` step is one
+// graph).  One workgroup per (decoder layer, sample) problem: all threads turn the problem's (Q, G) float block of
+// gd4d_match_cost_fwd into a double matrix with the shorter side as rows (what lsa_problem does), then ONE WAVE runs lsa_solve
+// above, operation for operation in double - the scan over the remaining columns spread over the 64 lanes, its arg-min as a
+// reduction that reproduces the sequential scan's choice exactly:
+//     sequential:  a candidate replaces the best so far if it is shorter, or equally short and its column is unassigned
+//     => the winner is, among the positions of minimal length, the LAST one whose column is unassigned if there is one,
+//        else the FIRST one                                                  (positions = indices into `remaining`)
+// so ties break as scipy's / the host solver's do and the matching is bit-identical to theirs.  Per-column state (v, shortest,
+// path, row4col, remaining, SC) lives in LDS (32 B per column), the matrix in global memory (L2-resident).
+namespace gd4d {
+
+constexpr int HA_THREADS = 256;
+
+struct HaParams {
+  const float* cost;
+  const int32_t* gt_start;      // (B + 1) on the device
+  int32_t* assigned;            // (NL, B, Q)
+  int32_t* status;              // (NL * B): 0 = solved, 1 = a NaN cost (label outside [0, classes): gd4d_match_cost_fwd's marker), 2 = infeasible
+  double* work;                 // per problem Q * max_gt doubles
+  int NL, B, Q, sum_gt, max_gt;
+};
+
+__device__ __forceinline__ double ha_shfl_xor(double x, int o) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __shfl_xor(lo, o); hi = __shfl_xor(hi, o);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void ha_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(HA_THREADS) void hungarian_assign_kernel(const HaParams p) {
+  extern __shared__ __attribute__((aligned(16))) char ha_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int prob = blockIdx.x, l = prob / p.B, b = prob - l * p.B;
+  const int g0 = p.gt_start[b], G = p.gt_start[b + 1] - g0, Q = p.Q;
+  int32_t* out = p.assigned + (size_t)prob * Q;
+  for (int q = tid; q < Q; q += HA_THREADS) out[q] = -1;
+  if (G <= 0 || Q <= 0) { if (tid == 0) p.status[prob] = 0; return; }
+  if (G > p.max_gt) { if (tid == 0) p.status[prob] = 2; return; }
+  const float* c = p.cost + (size_t)Q * ((size_t)l * p.sum_gt + g0);        // (Q, G) row-major
+  const bool transposed = G < Q;                                             // rows = the shorter side
+  const int nr = transposed ? G : Q, nc = transposed ? Q : G;
+  double* m = p.work + (size_t)prob * Q * p.max_gt;                          // (nr, nc)
+  __shared__ int s_nan;
+  if (tid == 0) s_nan = 0;
+  __syncthreads();
+  bool nan = false;
+  for (int idx = tid; idx < nr * nc; idx += HA_THREADS) {
+    const int r = idx / nc, j = idx - r * nc;
+    const float x = transposed ? c[(size_t)j * G + r] : c[idx];
+    nan = nan || (x != x);
+    m[idx] = (double)x;
+  }
+  if (nan) s_nan = 1;
+  // LDS: per column v, shortest (double), path, row4col, remaining, SC (int); per row u (double), col4row, SR (int)
+  double* v = reinterpret_cast<double*>(ha_smem);
+  double* shortest = v + nc;
+  double* u = shortest + nc;
+  int* path = reinterpret_cast<int*>(u + nr);
+  int* row4col = path + nc;
+  int* remaining = row4col + nc;
+  int* SC = remaining + nc;
+  int* col4row = SC + nc;
+  int* SR = col4row + nr;
+  for (int j = tid; j < nc; j += HA_THREADS) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+  for (int r = tid; r < nr; r += HA_THREADS) { u[r] = 0.0; col4row[r] = -1; }
+  __threadfence_block();
+  __syncthreads();
+  if (s_nan) { if (tid == 0) p.status[prob] = 1; return; }
+  if (tid >= 64) return;                                                     // one wave solves
+  const double inf = __builtin_inf();
+  bool ok = true;
+  for (int cur = 0; cur < nr && ok; ++cur) {
+    for (int j = lane; j < nc; j += 64) { remaining[j] = nc - j - 1; SC[j] = 0; shortest[j] = inf; }
+    for (int r = lane; r < nr; r += 64) SR[r] = 0;
+    ha_wave_sync();
+    double min_val = 0.0;
+    int i = cur, sink = -1, num_remaining = nc;
+    while (sink == -1) {
+      if (lane == 0) SR[i] = 1;
+      const double ui = u[i];
+      const double* ci = m + (size_t)i * nc;
+      double lowest = inf;
+      int pos_un = -1, pos_first = 0x7fffffff;
+      for (int it = lane; it < num_remaining; it += 64) {
+        const int j = remaining[it];
+        const double r = ((min_val + ci[j]) - ui) - v[j];
+        double sj = shortest[j];
+        if (r < sj) { path[j] = i; shortest[j] = r; sj = r; }
+        const bool un = row4col[j] == -1;
+        if (sj < lowest) { lowest = sj; pos_first = it; pos_un = un ? it : -1; }
+        else if (sj == lowest) { if (un) pos_un = it; if (it < pos_first) pos_first = it; }
+      }
+      double gmin = lowest;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const double t = ha_shfl_xor(gmin, o); gmin = t < gmin ? t : gmin; }
+      if (!(lowest == gmin)) { pos_un = -1; pos_first = 0x7fffffff; }       // (an idle lane holds inf: it takes part only when gmin is inf)
+      if (lane >= num_remaining && gmin == inf) { pos_un = -1; pos_first = 0x7fffffff; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        pos_un = max(pos_un, __shfl_xor(pos_un, o));
+        pos_first = min(pos_first, __shfl_xor(pos_first, o));
+      }
+      min_val = gmin;
+      if (min_val == inf) { ok = false; break; }                            // infeasible (cannot happen after nan_to_num)
+      const int index = pos_un >= 0 ? pos_un : pos_first;
+      const int j = remaining[index];
+      const int rj = row4col[j];
+      const int last = remaining[num_remaining - 1];
+      ha_wave_sync();                                                        // every lane has read before lane 0 rewrites
+      if (rj == -1) sink = j; else i = rj;
+      --num_remaining;
+      if (lane == 0) { SC[j] = 1; remaining[index] = last; }
+      ha_wave_sync();
+    }
+    if (!ok) break;
+    // dual update
+    for (int r = lane; r < nr; r += 64)
+      if (SR[r] && r != cur) u[r] += min_val - shortest[col4row[r]];
+    for (int j = lane; j < nc; j += 64)
+      if (SC[j]) v[j] -= min_val - shortest[j];
+    ha_wave_sync();
+    if (lane == 0) {
+      u[cur] += min_val;
+      int j = sink;                                                          // augment along the path
+      while (true) {
+        const int r = path[j];
+        row4col[j] = r;
+        const int t = col4row[r]; col4row[r] = j; j = t;
+        if (r == cur) break;
+      }
+    }
+    ha_wave_sync();
+  }
+  if (!ok) { if (lane == 0) p.status[prob] = 2; return; }
+  for (int r = lane; r < nr; r += 64) {
+    if (transposed) out[col4row[r]] = r + g0;                                // row = box r, its column = the prediction
+    else out[r] = col4row[r] + g0;
+  }
+  if (lane == 0) p.status[prob] = 0;
+}
+
+}  // namespace gd4d
+
+extern "C" size_t gd4d_hungarian_assign_workspace_bytes(int NL, int B, int Q, int max_gt) {
+  if (NL <= 0 || B <= 0 || Q <= 0 || max_gt <= 0) return 0;
+  return (size_t)NL * B * Q * max_gt * sizeof(double);
+}
+
+extern "C" int gd4d_hungarian_assign_fwd(const float* cost, const int32_t* gt_start, int32_t* assigned, int32_t* status, void* workspace,
+                                         size_t workspace_bytes, int NL, int B, int Q, int sum_gt, int max_gt, void* stream) {
+  using namespace gd4d;
+  if (!cost || !gt_start || !assigned || !status || NL <= 0 || B <= 0 || Q <= 0 || sum_gt < 0 || max_gt < 0) return GD4D_EINVAL;
+  if (max_gt > 0 && (!workspace || workspace_bytes < gd4d_hungarian_assign_workspace_bytes(NL, B, Q, max_gt))) return GD4D_EWORKSPACE;
+  const int nc = Q > max_gt ? Q : max_gt, nr = Q > max_gt ? max_gt : Q;
+  const size_t lds = (size_t)nc * (8 + 8 + 4 + 4 + 4 + 4) + (size_t)nr * (8 + 4 + 4) + 64;
+  if (lds > 160 * 1024) return GD4D_EUNSUPPORTED;
+  if (lds > 65536 && !allow_dynamic_lds(reinterpret_cast<const void*>(hungarian_assign_kernel), (int)lds)) return GD4D_ELAUNCH;
+  HaParams p{cost, gt_start, assigned, status, static_cast<double*>(workspace), NL, B, Q, sum_gt, max_gt};
+  hipLaunchKernelGGL(hungarian_assign_kernel, dim3(NL * B), dim3(HA_THREADS), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch();
+}

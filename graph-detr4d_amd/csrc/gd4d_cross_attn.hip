@@ -5,7 +5,8 @@
 // mask), :281-284 (softmax * mask), :301-304 (third-party mmcv MSDA gather), :320-324 (camera
 // weights, sum over cameras).  Maths restated in SURVEY.md Appendix A.1.
 //
-// Work mapping (wave64): one wavefront = one (batch, query).  The 256 output channels of a query
+// Work mapping (wave64): one WORKGROUP of waves = one (batch, query) (a first version gave a query one wave: latency-bound on
+// ~17 dependent load batches; it is gone).  The 256 output channels of a query
 // are exactly 64 lanes x float4, so lane `c4` owns channels [4*c4, 4*c4+4) and belongs to head
 // h = 4*c4 / Dh.  With Hh = 8, Dh = 32 the 8 lanes of a head read one 128-byte line per bilinear
 // corner (a full L2 line, fully coalesced); no cross-lane reduction is ever needed and the wave
@@ -23,120 +24,11 @@
 
 namespace gd4d {
 
-// LT > 0: number of levels known at compile time (fully unrolled gather); LT == 0: runtime p.L.
-template <typename VT, int HH, int LT>
-__global__ __launch_bounds__(GD4D_WAVE) void cross_attn_fwd_wave(const CrossAttnParams p) {
-  constexpr int DH = kChannels / HH;
-  constexpr int LANES_PER_HEAD = DH / 4;
-  constexpr int E = HH * kPoints;          // projection entries per camera
-  constexpr int LMAX = LT > 0 ? LT : GD4D_MAX_LEVELS;
-  extern __shared__ float2 s_uv[];         // [N][E]; x < 0 marks "not visible"
-
-  const int lane = threadIdx.x;
-  const int bq = blockIdx.x;
-  const int b = bq / p.Q;
-  const int q = bq - b * p.Q;
-  const int L = LT > 0 ? LT : p.L;
-
-  // ---------------- phase A ----------------
-  {
-    const float* rp = p.ref + (size_t)bq * 3;
-    const float px = rp[0] * p.rng_scale[0] + p.rng_lo[0];     // two roundings (contract off)
-    const float py = rp[1] * p.rng_scale[1] + p.rng_lo[1];
-    const float pz = rp[2] * p.rng_scale[2] + p.rng_lo[2];
-    const float* offs = p.offsets + (size_t)bq * E * 3;
-    const int total = p.N * E;
-    for (int e = lane; e < total; e += GD4D_WAVE) {
-      const int n = e / E;
-      const int hp = e - n * E;
-      const float X = px + offs[hp * 3 + 0];
-      const float Y = py + offs[hp * 3 + 1];
-      const float Z = pz + offs[hp * 3 + 2];
-      const float* m = p.lidar2img + ((size_t)b * p.N + n) * 16;
-      float u, v;
-      const bool vis = project_entry(p, m, X, Y, Z, u, v);
-      s_uv[e] = vis ? make_float2(u, v) : make_float2(-1.f, -1.f);
-      const size_t o = (((size_t)b * p.N + n) * p.Q + q) * E + hp;
-      if (p.mask_out) p.mask_out[o] = vis ? 1 : 0;
-      if (p.uv_out) { p.uv_out[o * 2] = u; p.uv_out[o * 2 + 1] = v; }
-    }
-  }
-  __syncthreads();
-
-  // ---------------- phase B ----------------
-  const int h = lane / LANES_PER_HEAD;
-  float aw[LMAX * kPoints];
-  if (p.B == 1) softmax_lp(p.attn_logits + ((size_t)bq * HH + h) * L * kPoints, L * kPoints, aw);
-
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const VT* vlane = static_cast<const VT*>(p.value) + lane * 4;
-  for (int n = 0; n < p.N; ++n) {
-    const float2* su = s_uv + n * E + h * kPoints;
-    float2 pu[kPoints];
-#pragma unroll
-    for (int k = 0; k < kPoints; ++k) pu[k] = su[k];
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < kPoints; ++k) any |= pu[k].x >= 0.f;
-    if (!__any(any)) continue;                               // wave-uniform skip
-
-    const int row = b * p.N + n;
-    if (p.B > 1) {   // reference quirk: logits of batch (row % B), deform3d_cross_attn.py:277
-      const int bb = row % p.B;
-      softmax_lp(p.attn_logits + (((size_t)bb * p.Q + q) * HH + h) * L * kPoints, L * kPoints, aw);
-    }
-    const float cl = p.cam_logits[(size_t)b * p.Q * p.N + (size_t)n * p.Q + q];   // raw-view scramble
-    const float cw = p.raw_cam ? cl : 1.0f / (1.0f + expf(-cl));
-    const VT* vrow = vlane + (size_t)row * p.S * kChannels;
-
-#pragma unroll
-    for (int k = 0; k < kPoints; ++k) {
-      if (pu[k].x >= 0.f) {
-        const float u = pu[k].x, v = pu[k].y;
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) {
-          if (LT == 0 && l >= L) break;
-          const int W = p.lvl_w[l], H = p.lvl_h[l];
-          const float x = fmaf(u, (float)W, -0.5f);
-          const float y = fmaf(v, (float)H, -0.5f);
-          const float xf = floorf(x), yf = floorf(y);
-          const float dx = x - xf, dy = y - yf;
-          const int x0 = (int)xf, y0 = (int)yf;
-          const float wl = aw[l * kPoints + k] * cw;
-          const bool x0ok = x0 >= 0, x1ok = x0 + 1 < W;      // x0 <= W-1 and x0+1 >= 0 always hold for u in (0,1)
-          const bool y0ok = y0 >= 0, y1ok = y0 + 1 < H;
-          const float w00 = (x0ok && y0ok) ? wl * (1.f - dx) * (1.f - dy) : 0.f;
-          const float w01 = (x1ok && y0ok) ? wl * dx * (1.f - dy) : 0.f;
-          const float w10 = (x0ok && y1ok) ? wl * (1.f - dx) * dy : 0.f;
-          const float w11 = (x1ok && y1ok) ? wl * dx * dy : 0.f;
-          // corners outside the map contribute 0 (zero padding); their loads are clamped onto the map
-          const int xa = x0ok ? x0 : 0, xb = x1ok ? x0 + 1 : W - 1;
-          const int ya = y0ok ? y0 : 0, yb = y1ok ? y0 + 1 : H - 1;
-          const VT* lvl = vrow + (size_t)p.lvl_start[l] * kChannels;
-          const float4 v00 = Quad<VT>::load(lvl + (ya * W + xa) * kChannels);
-          const float4 v01 = Quad<VT>::load(lvl + (ya * W + xb) * kChannels);
-          const float4 v10 = Quad<VT>::load(lvl + (yb * W + xa) * kChannels);
-          const float4 v11 = Quad<VT>::load(lvl + (yb * W + xb) * kChannels);
-          acc.x = fmaf(w00, v00.x, acc.x); acc.y = fmaf(w00, v00.y, acc.y);
-          acc.z = fmaf(w00, v00.z, acc.z); acc.w = fmaf(w00, v00.w, acc.w);
-          acc.x = fmaf(w01, v01.x, acc.x); acc.y = fmaf(w01, v01.y, acc.y);
-          acc.z = fmaf(w01, v01.z, acc.z); acc.w = fmaf(w01, v01.w, acc.w);
-          acc.x = fmaf(w10, v10.x, acc.x); acc.y = fmaf(w10, v10.y, acc.y);
-          acc.z = fmaf(w10, v10.z, acc.z); acc.w = fmaf(w10, v10.w, acc.w);
-          acc.x = fmaf(w11, v11.x, acc.x); acc.y = fmaf(w11, v11.y, acc.y);
-          acc.z = fmaf(w11, v11.z, acc.z); acc.w = fmaf(w11, v11.w, acc.w);
-        }
-      }
-    }
-  }
-  *reinterpret_cast<float4*>(p.out + (size_t)bq * kChannels + lane * 4) = acc;
-}
-
 // ---------------------------------------------------------------------------------------------
-// v2: one WORKGROUP of WAVES wavefronts per (batch, query).  Same lane -> (head, channel quad)
+// One WORKGROUP of WAVES wavefronts per (batch, query).  Same lane -> (head, channel quad)
 // mapping as above inside each wave; the query's VISIBLE cameras are compacted (ballot) and dealt
 // round-robin to the waves, so a query seen by many cameras no longer serialises its gathers in
-// one wave (the v1 kernel is latency-bound: ~17 dependent load batches per wave).  Inside a camera
+// one wave.  Inside a camera
 // the code is branch-free - an invisible point of a visible camera (~5 %) gets weight 0 and reads
 // the map centre - so all 4 points x L levels x 4 corners loads can be issued back to back.
 // Partial sums are combined through LDS in fixed wave order (deterministic).
@@ -377,16 +269,6 @@ void cross_attn_fwd_block(const CrossAttnParams p) {
   if (wave == 0) *reinterpret_cast<float4*>(p.out + (size_t)bq * kChannels + lane * 4) = acc;
 }
 
-static int cross_attn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GD4D_CROSS_ATTN_VARIANT");     // dev A/B switch: 1 = wave per query, 2 = workgroup per query
-    v = e ? atoi(e) : 2;
-    if (v != 1) v = 2;
-  }
-  return v;
-}
-
 template <typename VT, int HH, int LT, int PT>
 static void launch_block(const CrossAttnParams& p, hipStream_t s) {
   constexpr int WAVES = GD4D_GATHER_WAVES;
@@ -404,9 +286,6 @@ template <typename VT, int HH, int LT>
 static void launch_one(const CrossAttnParams& p, hipStream_t s) {
   if (p.P == 1) {                                      // one point per level (Deform3DCrossAttnMP's neighbour pass)
     launch_block<VT, HH, LT, 1>(p, s);
-  } else if (cross_attn_variant() == 1 && !p.head_major) {
-    const size_t lds = (size_t)p.N * HH * kPoints * sizeof(float2);
-    hipLaunchKernelGGL((cross_attn_fwd_wave<VT, HH, LT>), dim3(p.B * p.Q), dim3(GD4D_WAVE), lds, s, p);   // ignores p.order
   } else {
     launch_block<VT, HH, LT, kPoints>(p, s);
   }

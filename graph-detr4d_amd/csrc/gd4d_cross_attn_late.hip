@@ -304,9 +304,6 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
               unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
-#ifdef GD4D_DEV
-              if (p.dbg_wrap) px &= p.dbg_wrap;
-#endif
               val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(vbase + (size_t)px * (kChannels * ES)));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -373,9 +370,6 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_agg_kernel(const CrossA
 #pragma unroll
         for (int j = 0; j < LT * 4; ++j) {
           unsigned px = (unsigned)__builtin_amdgcn_readlane((int)pixel, s * 16 + j);
-#ifdef GD4D_DEV
-              if (p.dbg_wrap) px &= p.dbg_wrap;
-#endif
           val[j] = Quad<VT>::load(reinterpret_cast<const VT*>(vbase + (size_t)px * (kChannels * ES)));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -497,39 +491,19 @@ __global__ __launch_bounds__(64) void value_proj_heads_kernel(const HeadProjPara
 template <int HH>
 static int launch_agg(const CrossAttnParams& p, hipStream_t s, bool bf16) {
   const dim3 grid(p.order ? ((p.B * p.Q + 7) / 8) * 8 : p.B * p.Q);
-  // The dev switches of this unit (GD4D_AGG_LDS_PAD: unused LDS per workgroup, caps residency; GD4D_AGG_VARIANT;
-  // GD4D_AGG_DBG_WRAP: wrapped pixel indices = an all-L2-hit run with WRONG results) exist in -DGD4D_DEV builds only.
-  int lds_pad = 0;
-#ifdef GD4D_DEV
-  { const char* e = getenv("GD4D_AGG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-#endif
   auto lds_bytes = [&](int LT) {
-    return (size_t)lds_pad + (size_t)p.N * HH * kPoints * sizeof(float2) + (size_t)HH * LT * kPoints * sizeof(float) + (size_t)p.N * 12 * sizeof(float) +
+    return (size_t)p.N * HH * kPoints * sizeof(float2) + (size_t)HH * LT * kPoints * sizeof(float) + (size_t)p.N * 12 * sizeof(float) +
            (size_t)((p.N + 3) & ~3) * sizeof(float) + (size_t)HH * sizeof(int) + (size_t)HH * p.N * kPoints;
   };
-  // dev A/B: GD4D_AGG_VARIANT bit 0: level-major walk (default item-major); bit 1: 4 waves per query, two heads per wave
-  // (default: one wave per head - the heads of a query then work on the same camera at the same time, and what they
-  // share at the coarse levels is still in the L2)
-  int variant = 0;
-#ifdef GD4D_DEV
-  { const char* e = getenv("GD4D_AGG_VARIANT"); variant = e ? atoi(e) : 0; }
-#endif
-  if (variant != 0 && p.vp_w) return GD4D_EUNSUPPORTED;       // the value_proj epilogue lives in the default form only
+  // (item-major walk, one wave per head: the heads of a query work on the same camera at the same time, and what they share at
+  //  the coarse levels is still in the L2; the level-major / two-heads-per-wave forms of rounds 2 - 3 measured slower and are gone)
   auto go = [&](auto kern, int threads, size_t lds) {
     if (lds > 65536) (void)allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
   };
-  if (bf16 && variant != 0) return GD4D_EUNSUPPORTED;         // bf16 storage: the default form only
 #define GD4D_AGG_GO(LT_)                                                                            \
-  if (bf16) {                                                                                       \
-    go(cross_attn_agg_kernel<HH, LT_, false, HH, uint16_t>, 64 * HH, lds_bytes(LT_));               \
-  } else if (variant & 2) {                                                                                 \
-    if (variant & 1) go(cross_attn_agg_kernel<HH, LT_, true, 4>, 256, lds_bytes(LT_));              \
-    else go(cross_attn_agg_kernel<HH, LT_, false, 4>, 256, lds_bytes(LT_));                         \
-  } else {                                                                                          \
-    if (variant & 1) go(cross_attn_agg_kernel<HH, LT_, true, HH>, 64 * HH, lds_bytes(LT_));         \
-    else go(cross_attn_agg_kernel<HH, LT_, false, HH>, 64 * HH, lds_bytes(LT_));                    \
-  }
+  if (bf16) go(cross_attn_agg_kernel<HH, LT_, false, HH, uint16_t>, 64 * HH, lds_bytes(LT_));       \
+  else go(cross_attn_agg_kernel<HH, LT_, false, HH>, 64 * HH, lds_bytes(LT_));
   switch (p.L) {
     case 1: GD4D_AGG_GO(1) break;
     case 2: GD4D_AGG_GO(2) break;
@@ -621,9 +595,6 @@ extern "C" int gd4d_cross_attn_agg_fwd(const void* feats_cl, const int32_t* leve
     p.rng_lo[k] = static_cast<float>(pc_range[k]);
   }
   p.img_h = img_h; p.img_w = img_w;
-#ifdef GD4D_DEV
-  { const char* e = getenv("GD4D_AGG_DBG_WRAP"); p.dbg_wrap = (unsigned)(e ? atol(e) : 0); }
-#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bf16 = feats_dtype == GD4D_BF16;
   switch (Hh) {

@@ -202,17 +202,9 @@ struct DotParams {
   float* dpart;             // [kSlices][BQ * HH * cap_t * 64]
   long long dslice;         // floats per slice of dpart
   int BQ, per_xcd, cap_t;
-  // HEADS (gd4d_cross_attn_dot_sliced_fused): grad_agg is not read but COMPUTED here - gd4d_value_proj_heads_bwd's arithmetic,
-  // this workgroup's 32 channels of its (query, head) row - from the gradient at value_proj's output, and written to `table`
-  // (the pyramid gradient's dA rows; may be null) and, by slice 0, beta
-  const float* gout;        // (BQ, 256) dL/d out
-  const float* vp_w;        // (256, 256) value_proj weight
-  const float* vp_b;        // (256) or null
-  float* table;             // (BQ, HH, 256) or null
-  float* beta;              // (BQ, HH) or null
 };
 
-template <int HH, int LT, typename VT, bool HEADS = false>
+template <int HH, int LT, typename VT>
 __device__ __forceinline__ void cross_attn_dot_sliced_body(const DotParams& p, const int bid, char* s_raw) {   // s_raw: [HH][CH][8][GP]
   constexpr int CH = 6, GP = 80, PASS = 8 * GP, ES = sizeof(VT);
   const int lane = threadIdx.x & 63;
@@ -236,30 +228,7 @@ __device__ __forceinline__ void cross_attn_dot_sliced_body(const DotParams& p, c
 #pragma unroll
   for (int l = 0; l < LT; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
   const unsigned lane_off = (unsigned)(c * 4 * ES);
-  float4 ga;
-  if (HEADS) {
-    // dA[bq, h, 32 s + 4 c ..] = sum_d g[bq, h Dh + d] W[h Dh + d, 32 s + 4 c ..], d ascending, fused multiply-adds: the very sums
-    // of value_proj_heads_bwd_kernel (that launch, 8 us + a graph boundary per layer, is gone from the chain training path)
-    constexpr int DH = kChannels / HH;
-    const float* grow = p.gout + (size_t)bq * kChannels + h * DH;                       // wave-uniform: scalar loads
-    const float* wcol = p.vp_w + (size_t)(h * DH) * kChannels + s * kSlice + c * 4;
-    ga = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int d = 0; d < DH; ++d) {
-      const float gd = grow[d];
-      const float4 w4 = *reinterpret_cast<const float4*>(wcol + (size_t)d * kChannels);
-      ga.x = fmaf(gd, w4.x, ga.x); ga.y = fmaf(gd, w4.y, ga.y); ga.z = fmaf(gd, w4.z, ga.z); ga.w = fmaf(gd, w4.w, ga.w);
-    }
-    if (p.table && lane < 8) *reinterpret_cast<float4*>(p.table + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4) = ga;
-    if (p.beta && s == 0 && lane == 0) {
-      float t = 0.f;
-      if (p.vp_b)
-        for (int d = 0; d < DH; ++d) t = fmaf(grow[d], p.vp_b[h * DH + d], t);
-      p.beta[(size_t)bq * HH + h] = t;
-    }
-  } else {
-    ga = *reinterpret_cast<const float4*>(p.gagg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4);
-  }
+  const float4 ga = *reinterpret_cast<const float4*>(p.gagg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4);
   const bool b4 = c & 4, b2 = c & 2, b1 = c & 1;
 
   for (int t0 = 0; t0 < T; t0 += CH) {
@@ -341,7 +310,7 @@ struct WgradGuest {
   int tiles, guest_groups, total_groups;       // groups of 8 workgroups: guests among all
 };
 
-template <int HH, int LT, typename VT, int OCC, bool HEADS>
+template <int HH, int LT, typename VT, int OCC>
 __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_wgrad_kernel(const WgradGuest wg) {
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
   static_assert(sizeof(LinBwdShared<HH>) <= (size_t)HH * 6 * 8 * 80, "the guest's partial tiles fit the gather-dot's LDS");
@@ -358,7 +327,7 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_dot_sliced_wgrad_kern
     if (tile < wg.tiles) linear_bwd_weight_group_tile<HH>(gp, tile, *reinterpret_cast<LinBwdShared<HH>*>(s_raw));
     return;
   }
-  cross_attn_dot_sliced_body<HH, LT, VT, HEADS>(wg.p, (int)blockIdx.x - 8 * before, s_raw);
+  cross_attn_dot_sliced_body<HH, LT, VT>(wg.p, (int)blockIdx.x - 8 * before, s_raw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1013,19 +982,15 @@ extern "C" size_t gd4d_cross_attn_dot_bytes(int B, int N, int Q, int Hh, int P) 
 
 static int dot_sliced_impl(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
                           const float* grad_agg, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh,
-                          int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream, gd4d::WgradGuest* wg,
-                          const float* grad_out = nullptr, const float* vp_weight = nullptr, const float* vp_bias = nullptr,
-                          float* table = nullptr, float* beta = nullptr) {
+                          int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream, gd4d::WgradGuest* wg) {
   using namespace gd4d;
-  const bool heads = grad_out != nullptr;
-  if (!level_ptrs || !plan || (!grad_agg && !heads) || !dpart) return GD4D_EINVAL;
-  if (heads && (!wg || !vp_weight || !aligned16(grad_out) || !aligned16(vp_weight) || (table && !aligned16(table)))) return GD4D_EINVAL;
+  if (!level_ptrs || !plan || !grad_agg || !dpart) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
   if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
   if (feats_dtype != GD4D_F32 && feats_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
   const int es = feats_dtype == GD4D_BF16 ? 2 : 4;
-  if ((grad_agg && !aligned16(grad_agg)) || !aligned16(plan) || slice_stride_bytes % (4 * es)) return GD4D_EALIGN;
+  if (!aligned16(grad_agg) || !aligned16(plan) || slice_stride_bytes % (4 * es)) return GD4D_EALIGN;
   if (dpart_bytes < gd4d_cross_attn_dot_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
   DotParams p{};
   for (int l = 0; l < L; ++l) {
@@ -1047,14 +1012,9 @@ static int dot_sliced_impl(const void* const* level_ptrs, int64_t slice_stride_b
     if (Hh != 8 || L != 4 || feats_dtype != GD4D_F32) return GD4D_EUNSUPPORTED;
     wg->guest_groups = (wg->tiles + 7) / 8;
     wg->total_groups = (int)(grid.x / 8) + wg->guest_groups;
-    p.gout = grad_out; p.vp_w = vp_weight; p.vp_b = vp_bias; p.table = table; p.beta = beta;
     wg->p = p;
-    if (heads)
-      hipLaunchKernelGGL((cross_attn_dot_sliced_wgrad_kernel<8, 4, float, 6, true>), dim3(8 * wg->total_groups), dim3(64 * 8),
-                         (size_t)8 * 6 * 8 * 80, s, *wg);
-    else
-      hipLaunchKernelGGL((cross_attn_dot_sliced_wgrad_kernel<8, 4, float, 6, false>), dim3(8 * wg->total_groups), dim3(64 * 8),
-                         (size_t)8 * 6 * 8 * 80, s, *wg);
+    hipLaunchKernelGGL((cross_attn_dot_sliced_wgrad_kernel<8, 4, float, 6>), dim3(8 * wg->total_groups), dim3(64 * 8),
+                       (size_t)8 * 6 * 8 * 80, s, *wg);
     return check_launch();
   }
   auto go = [&](auto kern, int hh) -> int {
@@ -1084,22 +1044,6 @@ extern "C" int gd4d_cross_attn_dot_sliced(const void* const* level_ptrs, int64_t
                                           int C, int L, int P, int feats_dtype, const int32_t* query_order, void* stream) {
   return dot_sliced_impl(level_ptrs, slice_stride_bytes, plan, grad_agg, dpart, dpart_bytes, B, N, Q, Hh, C, L, P, feats_dtype,
                          query_order, stream, nullptr);
-}
-
-extern "C" int gd4d_cross_attn_dot_sliced_fused(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
-                                                const float* grad_out, const float* vp_weight, const float* vp_bias,
-                                                float* grad_agg_out, float* beta_out, void* dpart, size_t dpart_bytes, int B, int N,
-                                                int Q, int Hh, int C, int L, int P, int feats_dtype, const int32_t* query_order,
-                                                const void* const* x, const void* const* grad_y, void* const* grad_w,
-                                                void* const* grad_b, const int32_t* dims, int count, int accumulate, void* stream) {
-  using namespace gd4d;
-  if (!grad_out || !vp_weight) return GD4D_EINVAL;
-  WgradGuest wg{};
-  if (count > 0) {
-    if (int rc = fill_lin_bwd_group(wg.g, wg.tiles, x, grad_y, grad_w, grad_b, dims, count, accumulate)) return rc;
-  }
-  return dot_sliced_impl(level_ptrs, slice_stride_bytes, plan, nullptr, dpart, dpart_bytes, B, N, Q, Hh, C, L, P, feats_dtype,
-                         query_order, stream, &wg, grad_out, vp_weight, vp_bias, grad_agg_out, beta_out);
 }
 
 extern "C" int gd4d_cross_attn_dot_sliced_wgrad(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
@@ -1308,17 +1252,5 @@ extern "C" int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxo
       if (!aligned16(grads[l])) return GD4D_EALIGN;
     return go(pyramid_grad_reduce_kernel<0, true>);
   }
-#ifdef GD4D_DEV                                      // dev ablations (GD4D_PG_VARIANT): 1 = 64 table rows, 2 = no table loads, 3 = nor the write-out, 4 = chunk lookup only
-  {
-    const char* e = getenv("GD4D_PG_VARIANT");
-    switch (e ? atoi(e) : 0) {
-      case 1: return go(pyramid_grad_reduce_kernel<1, false>);
-      case 2: return go(pyramid_grad_reduce_kernel<2, false>);
-      case 3: return go(pyramid_grad_reduce_kernel<3, false>);
-      case 4: return go(pyramid_grad_reduce_kernel<4, false>);
-      default: break;
-    }
-  }
-#endif
   return go(pyramid_grad_reduce_kernel<0, false>);
 }

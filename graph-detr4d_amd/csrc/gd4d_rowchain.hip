@@ -19,7 +19,6 @@
 // the weights do not change) so they stream from L2 as whole 1-KB pieces; the activations are split when read from LDS.
 // LayerNorm two-pass like ATen (mean, centred sum of squares, biased variance, eps inside the square root).
 #include "gd4d_common.h"
-#include "gd4d_mha_body.h"
 #include "gd4d_mha_dropout.h"
 
 namespace gd4d {
@@ -722,13 +721,9 @@ typedef const __attribute__((address_space(4))) ChainProgram* rc_prog_ptr_t;   /
 typedef const ChainProgram* rc_prog_ptr_t;
 #endif
 
-// bx: the workgroup's index among the launch's CHAIN workgroups (blockIdx.x; the fused attention launch takes its attention
-// workgroups out of the numbering - a multiple of 8 of them, so bx and blockIdx.x name the same XCD).
-// MHA: mha_flags != nullptr = this workgroup's rows of the first LOAD's source are written by the attention workgroups of the
-// SAME launch: it waits (after its prefetch touches are out) until mha_count of them have reported for its row block.
-template <bool TRAIN, bool MHA>
-__device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int bx, const unsigned* mha_flags, const int mha_count,
-                                               unsigned* mha_err) {
+// bx: the workgroup's index in the launch (blockIdx.x).
+template <bool TRAIN>
+__device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int bx) {
   const int M = pp->M, split = pp->split;
   const int blocks = (M + RC_M - 1) / RC_M;
   // Two programs: the second one's workgroups start at `split` = blocks rounded up to a multiple of 8, so that row block i of
@@ -827,20 +822,10 @@ __device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int
   if (RC_PREFETCH & 2) touch_small(op_base + lead);
   if ((RC_PREFETCH & 1) && lead == 0) touch_images();
 #endif
-  if (MHA && (second || split == 0)) {                       // the launch's last program
-    // (the WAIT operation's scheme: the attention workgroups of this row block sit on this XCD, the flag is a counter in its L2)
-    if (tid == 0) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(mha_flags + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)mha_count) {
-        if (++spins > (1u << 20)) {                        // ~0.2 s unanswered: count it and go on (a wrong result, not a hung GPU)
-          if (mha_err) atomicAdd(mha_err, 1u);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    __syncthreads();
-  }
+  // A WAIT that gives up (below) poisons what the program LOADs afterwards: a hand-off that failed must not look like a result.
+  __shared__ int rc_poison;
+  if (tid == 0) rc_poison = 0;
+  bool poisoned = false;
   for (int oi = op_base; oi < op_base + nops; ++oi) {
 #if RC_PREFETCH
     if ((RC_PREFETCH & 1) && lead > 0 && oi == op_base + lead) touch_images();
@@ -956,9 +941,9 @@ __device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int
         break;
       }
       case GD4D_CHAIN_WAIT: {
-        // ... and the consumer: one thread polls the flag in the L2 (bounded: ~0.2 s, then the error word at gout is
-        // raised and the program goes on - a wrong result that the tests catch instead of a hung GPU), the barrier below
-        // releases the others.  The rows the next LOAD reads were never in this CU's L1 (invalidated at the launch's
+        // ... and the consumer: one thread polls the flag in the L2 (bounded: ~0.2 s - then the error word at gout is raised,
+        // the rows this program LOADs from here on are replaced by NaN, and the program goes on: a loud wrong result instead of
+        // a hung GPU; the host reads the error word, ops.check_handoff), the barrier below releases the others.  The rows the next LOAD reads were never in this CU's L1 (invalidated at the launch's
         // start; row blocks are 16 rows of >= 1 KB: no line is shared with another block), so plain loads see them.
         if (tid == 0) {
           const unsigned* f = reinterpret_cast<const unsigned*>(op.p0) + wg;
@@ -966,6 +951,7 @@ __device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int
           while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             if (++spins > (1u << 20)) {
               if (op.gout) atomicAdd(reinterpret_cast<unsigned*>(op.gout), 1u);
+              rc_poison = 1;
               break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -976,6 +962,15 @@ __device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int
       default: break;
     }
     __syncthreads();
+    if (op.kind == GD4D_CHAIN_WAIT) poisoned = rc_poison != 0;             // (workgroup-uniform)
+    if (poisoned && op.kind == GD4D_CHAIN_LOAD && op.dst >= 0) {
+      for (int e = tid; e < RC_M * op.N; e += 64 * RC_WAVES) {
+        const int row = e / op.N, n = e - row * op.N;
+        bufs[op.dst][row][op.dst_col + n] = __builtin_nanf("");
+        if (TRAIN && op.gout && m0 + row < M) op.gout[(size_t)(m0 + row) * op.ldg + n] = __builtin_nanf("");
+      }
+      __syncthreads();
+    }
 #if RC_TRACE_OPS
     trace_mark_if(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32), wg == 0 && !second);
 #endif
@@ -991,54 +986,15 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   const ChainProgram* pp = &by_value;
 #endif
   (void)by_value;
-  row_chain_body<TRAIN, false>(pp, (int)blockIdx.x, nullptr, 0, nullptr);
+  row_chain_body<TRAIN>(pp, (int)blockIdx.x);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The self-attention core and the chain that consumes it in ONE launch (gd4d_row_chain_mha_fwd).  A kernel boundary inside a
-// replayed graph costs 3 - 6 us, the attention core takes 11 and chain A 14: per decoder layer the pair of launches was
-//     boundary, attention 11.4, boundary, [chain A 14.2 | reg branch of the previous layer + refinement 19.1]
-// Workgroups [0, hi) of this launch are the attention core's (gd4d_mha_body.h; head-major, `stride` = row blocks rounded up to
-// a multiple of 8 per head: the H workgroups of a row block sit on the XCD of that block's chain workgroup); each adds 1 to its
-// row block's counter once its rows of the output are in the L2 (the SIGNAL operation's scheme).  The chain workgroups follow
-// (workgroups are dispatched in index order, so whoever waits was dispatched after those it waits for): the LAST program's
-// request their weight images, wait for the counter to reach H and run; a first program (the previous layer's reg branch)
-// runs as soon as it has a compute unit.  Every workgroup of the launch owns the chain's LDS (one per compute unit), so the
-// attention workgroups ask for all their rows up front (AHEAD = 4) instead of relying on a neighbour to hide the round trips.
-// MEASURED (tools/r04_run57.sh, r04_run58.sh; one request at a time, 200 steps, three interleaved pairs): 1.609 - 1.618 ms per
-// sample against 1.602 - 1.607 for the two launches (1.665 with one step of look-ahead in the attention workgroups).  An
-// attention workgroup alone on its compute unit takes 9.6 us (issue-bound: two waves per SIMD, one dependent chain each), the
-// 8 x 57 of them need two rounds, so the chain starts 18.5 us into the launch - what the separate kernel (two to three small
-// workgroups per compute unit, 11.4 us) and the boundary cost together.  Not the default (GD4D_FUSE_MHA=1 selects it).
-struct MhaRole {
-  MhaParams p;
-  unsigned* flags;             // >= stride counters, zero before the launch
-  unsigned* err;               // optional: waits that gave up
-  int hi, stride;              // hi = H * stride attention workgroups
-};
-
-__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_mha_kernel(const ChainProgram by_value, const MhaRole mr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const rc_prog_ptr_t pp = (rc_prog_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-  const ChainProgram* pp = &by_value;
-#endif
-  (void)by_value;
-  const int bx = (int)blockIdx.x;
-  if (bx < mr.hi) {
-    extern __shared__ __attribute__((aligned(16))) char rc_smem[];
-    const int idx = bx;
-    const int h = idx / mr.stride, r = idx - h * mr.stride;
-    if (r * 16 >= mr.p.Lq) return;
-    trace_mark_if(g_trace_rowchain, 9ull, idx == 0);
-    mha_core_bf16x3_body<0, 4>(mr.p, r, h, 0, *reinterpret_cast<MhaShared*>(rc_smem));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(mr.flags + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    trace_mark_if(g_trace_rowchain, 0x89ull, idx == 0);
-    return;
-  }
-  row_chain_body<false, true>(pp, bx - mr.hi, mr.flags, mr.p.H, mr.err);
+// XCC id of every workgroup of a launch (gd4d_xcd_placement_probe): the hand-offs above rely on workgroups j and j + 8 k sharing
+// an XCD; the host checks that once per device before it builds programs with SIGNAL / WAIT.
+__global__ void xcd_placement_probe_kernel(int32_t* out) {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(v & 0xfu);
 }
 
 }  // namespace gd4d
@@ -1172,8 +1128,8 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
       case GD4D_CHAIN_SIGNAL:
         if (!op.gout || !two_programs || which != 1) return GD4D_EINVAL;
         break;
-      case GD4D_CHAIN_WAIT:
-        if (!op.p0 || !two_programs || which != 2) return GD4D_EINVAL;
+      case GD4D_CHAIN_WAIT:       // (what was handed over must enter through a LOAD: that is where a time-out is poisoned)
+        if (!op.p0 || !op.gout || !two_programs || which != 2 || i + 1 >= nops || program[i + 1].kind != GD4D_CHAIN_LOAD) return GD4D_EINVAL;
         break;
       default: return GD4D_EINVAL;
     }
@@ -1224,51 +1180,10 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   return check_launch();
 }
 
-extern "C" int gd4d_row_chain_mha_fwd(const gd4d_chain_op* program, int nops, const gd4d_chain_op* program_side, int nops_side, int M,
-                                      const float* q, const float* k, const float* v, float* attn_out, int H, int D, int ldq, int ldk,
-                                      int ldv, int ldo, float scale, int32_t* flags, int32_t* errors, void* stream) {
-  using namespace gd4d;
-  if (!program || nops <= 0 || M <= 0 || nops_side < 0 || (nops_side > 0 && !program_side)) return GD4D_EINVAL;
-  if (!q || !k || !v || !attn_out || !flags || H <= 0) return GD4D_EINVAL;
-  if (D != MHA_D) return GD4D_EUNSUPPORTED;
-  if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return GD4D_EINVAL;
-  if (!aligned16(q) || !aligned16(k) || (ldq % 4) || (ldk % 4)) return GD4D_EALIGN;
-  if (nops + nops_side > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
-  const bool two = nops_side > 0;
-  if (two)
-    if (int rc = rc_validate(program_side, nops_side, 1)) return rc;
-  if (int rc = rc_validate(program, nops, two ? 2 : 0)) return rc;
-  for (int w = 0; w < 2; ++w)                              // inference chains only (no operation of the training instantiation)
-    for (int i = 0; i < (w ? nops_side : nops); ++i) {
-      const gd4d_chain_op& op = (w ? program_side : program)[i];
-      if (op.kind == GD4D_CHAIN_LN_BWD || op.kind == GD4D_CHAIN_DROPMASK ||
-          (op.kind == GD4D_CHAIN_GEMM && (op.flags & (GD4D_CHAIN_MASK_P2 | GD4D_CHAIN_DROPOUT))) ||
-          ((op.kind == GD4D_CHAIN_LOAD || op.kind == GD4D_CHAIN_ADD || op.kind == GD4D_CHAIN_SMALL_LINEAR) && op.gout))
-        return GD4D_EUNSUPPORTED;
-    }
-  const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES;
-  static_assert(sizeof(MhaShared) <= sizeof(float) * RC_BUFS * RC_M * RC_LD, "the attention workgroups use the row buffers' LDS");
-  if (!allow_dynamic_lds(reinterpret_cast<const void*>(row_chain_mha_kernel), (int)lds)) return GD4D_ELAUNCH;
-  const int blocks = (M + RC_M - 1) / RC_M, stride = (blocks + 7) & ~7;
-  ChainProgram prog{};
-  prog.M = M;
-  if (two) {                                               // the side program first, the waiting one last
-    prog.nops = nops_side; prog.nops2 = nops; prog.split = stride;
-    for (int i = 0; i < nops_side; ++i) prog.ops[i] = program_side[i];
-    for (int i = 0; i < nops; ++i) prog.ops[nops_side + i] = program[i];
-  } else {
-    prog.nops = nops; prog.nops2 = 0; prog.split = 0;
-    for (int i = 0; i < nops; ++i) prog.ops[i] = program[i];
-  }
-  MhaRole mr{};
-  mr.p = MhaParams{q, k, v, nullptr, attn_out, nullptr, M, M, 1, H, ldq, ldk, ldv, ldo, 0, scale, nullptr, 0u, 1.f};
-  mr.flags = reinterpret_cast<unsigned*>(flags);
-  mr.err = reinterpret_cast<unsigned*>(errors);
-  mr.hi = H * stride;
-  mr.stride = stride;
-  hipLaunchKernelGGL(row_chain_mha_kernel, dim3(mr.hi + (two ? stride : 0) + blocks), dim3(64 * RC_WAVES), lds,
-                     static_cast<hipStream_t>(stream), prog, mr);
-  return check_launch();
+extern "C" int gd4d_xcd_placement_probe(int32_t* out, int blocks, void* stream) {
+  if (!out || blocks <= 0) return GD4D_EINVAL;
+  hipLaunchKernelGGL(gd4d::xcd_placement_probe_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), out);
+  return gd4d::check_launch();
 }
 
 extern "C" int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stream) {

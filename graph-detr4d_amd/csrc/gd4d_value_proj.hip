@@ -559,42 +559,6 @@ extern "C" int gd4d_value_proj_multi_fwd(const void* const* feats, const int32_t
   if (single) { if (hm) go(value_proj_astat_kernel<W, true, true, true>); else go(value_proj_astat_kernel<W, true, false, true>); } \
   else if (ob) { if (hm) go(value_proj_astat_kernel<W, true, true, false>); else go(value_proj_astat_kernel<W, true, false, false>); } \
   else { if (hm) go(value_proj_astat_kernel<W, false, true, false>); else go(value_proj_astat_kernel<W, false, false, false>); }
-#ifdef GD4D_DEV                                      // ablation forms (some compute nothing or store nothing): -DGD4D_DEV builds only
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("GD4D_VA_DBG"); dbg = e ? atoi(e) : 0; }
-  if (dbg & 16) {                                               // dev: the trace buffer rides in the workspace's tail
-    p.trace = reinterpret_cast<unsigned long long*>(wimg + va_image_bytes(NL, false));
-  }
-  if (dbg && !single && !ob && !hm) {                          // ablation builds: fp32, pixel-major, 8 waves only
-    switch (dbg) {
-      case 1: go(value_proj_astat_kernel<8, false, false, false, 1>); break;
-      case 2: go(value_proj_astat_kernel<8, false, false, false, 2>); break;
-      case 3: go(value_proj_astat_kernel<8, false, false, false, 3>); break;
-      case 4: go(value_proj_astat_kernel<8, false, false, false, 4>); break;
-      case 5: go(value_proj_astat_kernel<8, false, false, false, 5>); break;
-      case 13: go(value_proj_astat_kernel<8, false, false, false, 13>); break;
-      case 15: go(value_proj_astat_kernel<8, false, false, false, 15>); break;
-      case 6: go(value_proj_astat_kernel<8, false, false, false, 6>); break;
-      case 10: go(value_proj_astat_kernel<8, false, false, false, 10>); break;
-      case 14: go(value_proj_astat_kernel<8, false, false, false, 14>); break;
-      case 8: go(value_proj_astat_kernel<8, false, false, false, 8>); break;
-      case 12: go(value_proj_astat_kernel<8, false, false, false, 12>); break;
-      case 16: go(value_proj_astat_kernel<8, false, false, false, 16>); break;
-      case 17: go(value_proj_astat_kernel<8, false, false, false, 17>); break;
-      case 76: go(value_proj_astat_kernel<8, false, false, false, 76>); break;   /* MFMA + stores, free-running */
-      case 72: go(value_proj_astat_kernel<8, false, false, false, 72>); break;   /* + fragment reads */
-      case 78: go(value_proj_astat_kernel<8, false, false, false, 78>); break;   /* stores only, free-running */
-      case 77: go(value_proj_astat_kernel<8, false, false, false, 77>); break;   /* MFMA only, free-running */
-      case 128: go(value_proj_astat_kernel<8, false, false, false, 128>); break;   /* full, staggered store bursts */
-      case 140: go(value_proj_astat_kernel<8, false, false, false, 140>); break;   /* MFMA + staggered store bursts */
-      case 136: go(value_proj_astat_kernel<8, false, false, false, 136>); break;   /* + fragment reads */
-      case 32: go(value_proj_astat_kernel<8, false, false, false, 32>); break;
-      case 33: go(value_proj_astat_kernel<8, false, false, false, 33>); break;
-      default: go(value_proj_astat_kernel<8, false, false, false, 0>); break;
-    }
-    return check_launch();
-  }
-#endif
   GD4D_VA_DISPATCH(8)
 #undef GD4D_VA_DISPATCH
   return check_launch();

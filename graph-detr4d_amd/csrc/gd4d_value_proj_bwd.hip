@@ -520,11 +520,7 @@ extern "C" int gd4d_value_proj_bwd_weight(const float* grad_out, const void* con
   }
   p.gout = grad_out;
   p.ws = static_cast<float*>(workspace);
-#ifdef GD4D_DEV                                      // ablation flags (they skip parts of the work): -DGD4D_DEV builds only
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GD4D_VW_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
-#else
   p.dbg = 0;
-#endif
   const int total = p.tile_base[L];
   int grid = vb_cus();
   if (grid > VW_MAX_PARTS) grid = VW_MAX_PARTS;

@@ -232,8 +232,6 @@ class Deform3DCrossAttn(nn.Module):
             # the inference step's kernels behind autograd: no projected value tensor (gd4d_cross_attn_sliced_bwd.hip)
             agg = CrossAttnRawFunction.apply(cl[1], reference_points, offsets, attn_logits, cam_logits, lidar2img,
                                              self.value_proj.weight, self.value_proj.bias, cl[0], self.pc_range, img_h, img_w)
-            if own is not None:
-                cl[0].join()                     # (the decoder joins its layers' side-stream work itself, after the last one)
             return self._finish_autograd(agg, reference_points, inp_residual, offers)
         if projected is None:
             val = ValueProjFunction.apply(self.value_proj.weight, self.value_proj.bias, *value)

@@ -109,7 +109,7 @@ class Detr3DCrossAtten(nn.Module):
         """Training path (the DETR3D configs train this module): the sampling core (:373-383, feature_sampling :397-438) on its
         HIP kernels both ways (autograd.Detr3DSampleFunction: gd4d_detr3d_fwd / gd4d_detr3d_bwd - gradients reach the feature
         maps, the attention logits and the reference points), the dense layers on the HIP kernels' autograd functions.
-        GD4D_DETR3D_TRAIN=torch (and num_points != 1): the reference's operations as differentiable torch ops on the GPU -
+        GD4D_TORCH_OPS=1: the reference's operations as differentiable torch ops on the GPU (num_points != 1 needs it) -
         projection, F.grid_sample per level (bilinear, zero padding, align_corners=False), sigmoid weights x mask, sums."""
         inp_residual = query
         x = query if query_pos is None else query + query_pos
@@ -119,8 +119,10 @@ class Detr3DCrossAtten(nn.Module):
         logits = Fn.sequential_autograd(self.attention_weights, x).view(b, 1, q, n, self.num_points, nl)
         lidar2img = Fn.lidar2img_device(img_metas, query)                     # (B, N, 4, 4)
         img_h, img_w = Fn.img_hw(img_metas)
-        if self.num_points == 1 and os.environ.get('GD4D_DETR3D_TRAIN', 'hip') == 'hip' and len(value) <= 8 and n <= 256 \
-                and all(v.is_cuda and v.dtype == torch.float32 for v in value) and reference_points.dtype == torch.float32:
+        if not Fn.torch_ops_route(f'Detr3DCrossAtten training with num_points = {self.num_points}, {len(value)} levels, {n} cameras',
+                                  self.num_points == 1 and len(value) <= 8 and n <= 256
+                                  and all(v.is_cuda and v.dtype == torch.float32 for v in value)
+                                  and reference_points.dtype == torch.float32):
             # the sampling core on its HIP kernels both ways (gd4d_detr3d_fwd / gd4d_detr3d_bwd)
             from .autograd import Detr3DSampleFunction
             agg = Detr3DSampleFunction.apply(reference_points, logits.reshape(b, q, n, 1, nl), lidar2img, self.pc_range, img_h, img_w,
@@ -234,10 +236,10 @@ class Detr3DCrossAttenV2(nn.Module):
     def _forward_autograd(self, query, value, query_pos, reference_points, img_metas):
         """Training path.  The sampling (reference :597-710: projected reference point + per-head pixel offsets, softmax over
         level x point, the (point, level) x (level, point) pairing of :611 / :705-707, visibility, the sums) runs on
-        gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd behind autograd.Detr3DV2SampleFunction (embed_dims <= 256;
-        GD4D_V2_BWD=torch or wider models: the same maths as differentiable torch ops, below); the Linears and LayerNorms are
-        the package's autograd Functions."""
-        if self.embed_dims <= 256 and os.environ.get('GD4D_V2_BWD', 'hip') != 'torch':
+        gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd behind autograd.Detr3DV2SampleFunction (embed_dims <= 256; wider models raise;
+        GD4D_TORCH_OPS=1: the same maths as differentiable torch ops, below); the Linears and LayerNorms are the package's
+        autograd Functions."""
+        if not Fn.torch_ops_route(f'Detr3DCrossAttenV2 training with embed_dims = {self.embed_dims}', self.embed_dims <= 256):
             from .autograd import Detr3DV2SampleFunction
             x = (query if query_pos is None else query + query_pos).permute(1, 0, 2).contiguous()      # (1, Q, C)
             b, q, c = x.shape
@@ -475,9 +477,6 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
             pipeline.finish()
         if own_late:
             late.finish()
-        for entry in {id(v): v for v in (kwargs.get(Fn.VALUE_CACHE_KEY) or {}).values()}.values():
-            if len(entry) > 3 and isinstance(entry[3], tuple):       # training on the raw pyramid: the record counts of
-                entry[3][0].join()                                   # the layers ran on the side stream - join it
         if aux is not None:
             torch.cuda.current_stream(output.device).wait_stream(aux)
         if self.return_intermediate:
@@ -538,10 +537,7 @@ class Detr3DTransformer(nn.Module):
             query = query.unsqueeze(0).expand(bs, -1, -1)
             # (training: the library's Linear forward / input gradient, its weight gradient queued with the decoder's - through
             #  torch this one 256 -> 3 Linear was a 25-us library GEMM in the backward pass)
-            if os.environ.get('GD4D_REFPOINTS_TORCH') == '1':
-                reference_points = self.reference_points(query_pos).sigmoid()
-            else:
-                reference_points = Fn.linear_autograd(query_pos, self.reference_points.weight, self.reference_points.bias).sigmoid()
+            reference_points = Fn.linear_autograd(query_pos, self.reference_points.weight, self.reference_points.bias).sigmoid()
             q_in, pos_in = query.permute(1, 0, 2), query_pos.permute(1, 0, 2)
         init_reference_out = reference_points
         inter_states, inter_references = self.decoder(

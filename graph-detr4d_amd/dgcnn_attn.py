@@ -60,7 +60,8 @@ class DGCNNAttn(nn.Module):
         x = query if query_pos is None else query + query_pos
         x = x.permute(1, 0, 2)                                                        # (B, N, C)
         Fn.require_gpu(query, 'query')
-        if self.training or Fn.wants_grad(self, query, query_pos):
+        if (self.training or Fn.wants_grad(self, query, query_pos)) and Fn.torch_ops_route(
+                'DGCNNAttn with autograd / in train mode (batch-statistics BatchNorm; the kernels are inference-only)', False):
             f1 = self.conv1(self._edge_feats(x, self.K)).max(dim=-1)[0]               # (B, C, N)
             f2 = self.conv2(self._edge_feats(f1.permute(0, 2, 1), 16)).max(dim=-1)[0]
             return residual + self.dropout((f1 + f2).permute(2, 0, 1))

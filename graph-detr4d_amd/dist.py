@@ -105,20 +105,33 @@ def preflight(expected_world, device=None, sizes=(22 << 20, 140 << 20, 330 << 20
     MAX over ranks, with the bus bandwidth 2 (N - 1) / N x bytes / t a ring moves per link; (4) the bucket plan of the step.
     Returns a dict (identical on every rank); N = 1: {'world': 1}.  gloo (CPU tensors) runs the same code in the tests."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world != int(expected_world):
-        raise RuntimeError(f'preflight: {world} rank(s) in the process group, the job was asked for {expected_world}')
     if world == 1:
+        if int(expected_world) != 1:
+            raise RuntimeError(f'preflight: 1 rank(s) in the process group, the job was asked for {expected_world}')
         return {'world': 1}
     import socket
     cuda = device is not None and torch.device(device).type == 'cuda'
     on_dev = cuda and dist.get_backend() == 'nccl'
-    me = {'rank': dist.get_rank(), 'host': socket.gethostname(), 'device': str(device) if device is not None else 'cpu'}
+    me = {'rank': dist.get_rank(), 'host': socket.gethostname(), 'device': str(device) if device is not None else 'cpu',
+          'expected_world': int(expected_world)}
     if cuda:
         props = torch.cuda.get_device_properties(device)
-        me.update(name=props.name, compute_units=props.multi_processor_count,
-                  pci='%04x:%02x:%02x' % tuple(int(getattr(props, k, -1)) & 0xffff for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')))
+        me.update(name=props.name, compute_units=props.multi_processor_count)
+        # a hardware identity of the device, if this torch build exposes one (a build without the PCI attributes must not make
+        # every rank of a host look like one device): PCI address, else the UUID, else nothing - the check below then falls
+        # back to (host, device index)
+        if all(hasattr(props, k) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')):
+            me['pci'] = '%04x:%02x:%02x' % (int(props.pci_domain_id) & 0xffff, int(props.pci_bus_id) & 0xff, int(props.pci_device_id) & 0xff)
+        elif getattr(props, 'uuid', None) is not None:
+            me['pci'] = 'uuid:' + str(props.uuid)
     ranks = [None] * world
     dist.all_gather_object(ranks, me)
+    # a rank that was asked for another world size (launched with the wrong --gpus) fails the WHOLE job, on every rank, here - not
+    # that rank alone while the others wait for it in the first collective
+    bad = [r['rank'] for r in ranks if r['expected_world'] != world]
+    if bad:
+        raise RuntimeError(f'preflight: {world} rank(s) in the process group, rank(s) {bad} were asked for '
+                           f'{sorted({r["expected_world"] for r in ranks if r["expected_world"] != world})}')
     seen = {}
     for r in ranks:
         key = (r['host'], r.get('pci', r['device']))
@@ -131,7 +144,7 @@ def preflight(expected_world, device=None, sizes=(22 << 20, 140 << 20, 330 << 20
         for _ in range(warmup):
             dist.all_reduce(buf)
             buf.fill_(1.0)
-        sync(device if cuda else None)
+            sync(device if cuda else None)            # (every rank has refilled before anybody reduces again)
         t0 = time.perf_counter()
         for _ in range(iters):
             dist.all_reduce(buf)
@@ -287,6 +300,37 @@ class FlatGradAllReducer:
             self._bind(flat)
         fp.add_(flat[:self.numel], alpha=-float(lr))
         if not (fp.is_cuda and torch.cuda.is_current_stream_capturing()):
+            bump = getattr(torch.autograd.graph, 'increment_version', None)
+            for p in self.params:
+                if bump is not None:
+                    bump(p)
+                else:
+                    p.add_(0)
+
+    @torch.no_grad()
+    def adamw_step(self, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=35.0):
+        """The reference's optimizer step (projects/configs/detr4d/detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:205-213: AdamW
+        lr 2e-4, weight decay 0.01, grad_clip max_norm 35 / L2) over the flat parameter and gradient buffers: gd4d_adamw_flat, two
+        launches instead of clip_grad_norm_ + torch.optim.AdamW's dozen multi-tensor launches over 230 tensors; the step counter
+        lives on the device, so the update can sit inside a replayed hipGraph.  One learning rate for every parameter (the
+        decoder's; the reference scales the backbone's by 0.1 - not part of this buffer).  Needs bind(); calls flatten_params().
+        After the step self.last_grad_norm (a device scalar) holds the norm before clipping."""
+        from . import _lib
+        fp = self.flatten_params()
+        flat = self._buffer(self.params[0])
+        if self.views is None or any(p.grad is not v for p, v in zip(self.params, self.views)):
+            self._bind(flat)
+        if getattr(self, '_adam', None) is None:
+            lib = _lib.load()
+            self._adam = (torch.zeros_like(fp), torch.zeros_like(fp), torch.zeros(2, device=fp.device, dtype=torch.float32),
+                          torch.empty(int(lib.gd4d_adamw_flat_workspace_bytes()), device=fp.device, dtype=torch.uint8))
+        m, v, state, ws = self._adam
+        code = _lib.load().gd4d_adamw_flat(fp.data_ptr(), flat.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                           float(weight_decay), float(max_norm or 0.), torch.cuda.current_stream(fp.device).cuda_stream)
+        _lib.check(code, 'gd4d_adamw_flat')
+        self.last_grad_norm = state[1]
+        if not torch.cuda.is_current_stream_capturing():
             bump = getattr(torch.autograd.graph, 'increment_version', None)
             for p in self.params:
                 if bump is not None:

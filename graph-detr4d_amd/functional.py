@@ -65,8 +65,7 @@ def linear_group_autograd(x, x2, linears):
 def can_group_linears(x, x2, linears):
     return (x2 is not None and x.is_cuda and x.dtype == torch.float32 and x2.dtype == torch.float32 and x2.shape == x.shape
             and x.shape[-1] % 4 == 0 and 0 < len(linears) <= 4
-            and all(isinstance(m, torch.nn.Linear) and m.weight.dtype == torch.float32 for m in linears)
-            and os.environ.get('GD4D_TRAIN_GROUP_LINEAR', '1') != '0')
+            and all(isinstance(m, torch.nn.Linear) and m.weight.dtype == torch.float32 for m in linears))
 
 
 def layer_norm_autograd(x, norm, relu=False, res=None):
@@ -121,15 +120,16 @@ def sequential_autograd(module, x):
     return module(x)
 
 
-def dev_ablations():
-    """GD4D_ABLATE=mha,chain_a,agg,chain_b,copy skips launches (outputs stay UNINITIALISED: timing tools only).  It is
-    honoured only together with GD4D_DEV=1; set alone it raises instead of silently producing garbage."""
-    spec = os.environ.get('GD4D_ABLATE', '')
-    if not spec:
-        return ()
-    if os.environ.get('GD4D_DEV') != '1':
-        raise RuntimeError('GD4D_ABLATE leaves outputs uninitialised; it is a dev switch and needs GD4D_DEV=1')
-    return tuple(spec.split(','))
+def torch_ops_route(what, supported):
+    """Whether `what` runs through differentiable torch ops instead of the library's kernels.  There is no silent detour: shapes
+    the kernels cover run on them (unless GD4D_TORCH_OPS=1 selects the torch-op route, which the tests compare against); shapes
+    they do not cover raise, naming the switch."""
+    if os.environ.get('GD4D_TORCH_OPS') == '1':
+        return True
+    if supported:
+        return False
+    raise _lib.Gd4dError(f'{what}: outside the limits of graph-detr4d_amd\'s kernels.  GD4D_TORCH_OPS=1 runs this module through '
+                         'differentiable torch ops instead (slower; an explicit choice, not a fallback).')
 
 
 def require_gpu(t, name):
@@ -232,8 +232,8 @@ NORM_KEY = '_gd4d_fused_norm'
 
 
 def rowblock_ok(x, weight, norm=None):
-    """gd4d_linear_ln_fwd limits: K % 64 == 0; with a LayerNorm at most 256 output columns (GD4D_ROWBLOCK=0: off)."""
-    return os.environ.get('GD4D_ROWBLOCK', '1') != '0' and x.is_cuda and x.shape[-1] % 64 == 0 and \
+    """gd4d_linear_ln_fwd limits: K % 64 == 0; with a LayerNorm at most 256 output columns."""
+    return x.is_cuda and x.shape[-1] % 64 == 0 and \
         (norm is None or (weight.shape[0] <= 256 and tuple(norm.normalized_shape) == (weight.shape[0],)))
 
 
@@ -420,7 +420,7 @@ def project_values_for_layers_autograd(modules, value):
     # value_proj's weight gradient from per-head aggregates of the raw pyramid instead of a contraction over every pixel
     # row (autograd.CrossAttnFunction): needs ONE channels-last copy of the pyramid per step (no gradient)
     cl = None
-    if os.environ.get('GD4D_TRAIN_VP_WGRAD', 'agg') == 'agg' and LateValues.applicable(modules, value, ignore_mode=True):
+    if LateValues.applicable(modules, value, ignore_mode=True):
         with torch.no_grad():
             # (a PyramidView: the channel-sliced gather reads it; GD4D_AGG=rows keeps the pixel-major copy + gd4d_cross_attn_agg_fwd)
             src = [v.detach().contiguous() for v in value]
@@ -593,11 +593,7 @@ class LateValues:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
             src = [v.contiguous() for v in value]
-            if 'copy' in dev_ablations():            # dev: skip the copy (see fused_decoder._ablate)
-                r = value[0].shape[0] * value[0].shape[1]
-                self.cl = torch.empty(r, sum(h * w for h, w in self.shapes), value[0].shape[2], device=dev, dtype=dtype)
-                self.mode = 'rows'
-            elif self.mode == 'sliced':
+            if self.mode == 'sliced':
                 self.cl, _ = ops.pyramid_slice_planar_fwd(src, max_cus=copy_cus, out_dtype=dtype)
                 self.pyramid = ops.PyramidView.slice_planar(self.cl, self.shapes)
             else:
@@ -657,15 +653,12 @@ class LateValues:
 
     def sample_aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
         """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of
-        output_proj.  value_proj of the per-head aggregates runs in the gather kernel's epilogue (GD4D_AGG_EPILOGUE=0: as
-        its own launch, gd4d_value_proj_heads_fwd)."""
+        output_proj.  value_proj of the per-head aggregates runs in the gather kernel's epilogue (rows form) or as its own launch
+        (sliced form: gd4d_value_proj_heads_fwd)."""
         bias = module.value_proj.bias
         weight, bias = module.value_proj.weight.contiguous(), None if bias is None else bias.contiguous()
-        if os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
-            return self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order,
-                                  vp_weight=weight, vp_bias=bias)[0]
-        agg, wsum = self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order)
-        return ops.value_proj_heads_fwd(agg, wsum, weight, bias)
+        return self.aggregate(module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=order,
+                              vp_weight=weight, vp_bias=bias)[0]
 
     def finish(self):
         if self.side is not None:

@@ -26,12 +26,10 @@ from .deform3d_cross_attn import Deform3DCrossAttn
 from .transformer_layers import FFN, MultiheadAttention
 
 ORDER = ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
-
-
-def _ablate(name):
-    """dev: GD4D_ABLATE=mha,chain_a,agg,chain_b,copy - skip that launch (outputs stay uninitialised): what a kernel costs in
-    the replayed step, gaps and cold-cache effects included (results are garbage)."""
-    return name in Fn.dev_ablations()
+# The stacked GEMM that produces the sampling offsets (with the camera and attention logits) on six bf16 products (~2^-24) like the
+# GEMMs that produce reference points: an offset in metres goes through a camera matrix before the visibility mask is decided
+# (measured: docs/measurements_r05.md section 3)
+OFFSETS_EXACT = True
 
 
 def _plain_reg_branch(branch, c):
@@ -83,11 +81,11 @@ def applicable(decoder, query, value, reference_points, reg_branches, attn_masks
 
 def _in_proj_ops(sa, x_pos_buf, x_buf, qkv, kv=None):
     """The packed in-projection: q, k from (x + pos), v from x (mmcv MultiheadAttention semantics) - one GEMM operation whose
-    last 256 columns read the other buffer (GD4D_CHAIN_FUSE_GEMMS=0: two operations; bit-identical).  kv (ops.KVPlanes): K and
-    V also leave as the attention core's split-bf16 operands (_kv_planes decides)."""
+    last 256 columns read the other buffer (two operations when the width does not allow it; bit-identical).  kv (ops.KVPlanes):
+    K and V also leave as the attention core's split-bf16 operands (_kv_planes decides)."""
     c = sa.embed_dims
     w, b = sa.attn.in_proj_weight, sa.attn.in_proj_bias
-    if c % 128 == 0 and _fuse_gemms():
+    if c % 128 == 0:
         return [ops.chain_gemm_two_sources(x_pos_buf, x_buf, 2 * c, w, b, qkv, kv=kv)]
     return [ops.chain_gemm(x_pos_buf, w[:2 * c], b[:2 * c], out=qkv[..., :2 * c]),
             ops.chain_gemm(x_buf, w[2 * c:], b[2 * c:], out=qkv[..., 2 * c:])]
@@ -97,17 +95,11 @@ def _kv_planes(layers, q, c, attn_mask, dev):
     """The K / V planes of run_single's attention launches, or None: one pair for all layers (a layer's attention core has read
     them before the in-projection of the next writes them - one stream).  Needs the one-operation in-projection, 256 channels
     (H-DETR's 2-D mask rides along)."""
-    if os.environ.get('GD4D_MHA_PRESPLIT', '1') == '0' or c != 256 or not _fuse_gemms() or (attn_mask is not None and attn_mask.dim() != 2):
-        return None
-    if os.environ.get('GD4D_FUSE_MHA', '0') != '0' or os.environ.get('GD4D_MHA_FP32') == '1':
+    if c != 256 or (attn_mask is not None and attn_mask.dim() != 2) or os.environ.get('GD4D_MHA_FP32') == '1':
         return None
     if layers[0].attentions[0].num_heads != 8:
         return None
     return ops.KVPlanes(q, c, dev, heads=8)
-
-
-def _fuse_gemms():
-    return os.environ.get('GD4D_CHAIN_FUSE_GEMMS', '1') != '0'
 
 
 def initial_reference(linear, query_pos):
@@ -188,16 +180,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
 
         attention core -> [chain A | reg(l-1), refine] -> plan -> gather -> [chain B' | position_encoder(l)]
 
-    GD4D_POS_ENCODER=chaina swaps the two side programs (measured: no gain, tools/r04_run64.sh):
-
-        attention core -> [chain A | position_encoder(l)] -> plan -> gather -> [chain B' | reg(l), refine]
-
-    position_encoder reads the refined points from global memory (written by the launch before), no hand-off; the reg branch
-    WAITs for chain B' to SIGNAL that its rows of the layer's output are stored and runs beside the next layer's in-projection:
-    the dual launch 19.0 -> 14.6 us, chain B's launch 51 -> 54.7 us (the reg branch outlasts the in-projection by 6 us, and chain
-    B' itself is no faster without its WAIT: its first 14 us are cold weight images and rows, not position_encoder).
-
-    GD4D_POS_ENCODER=dual keeps round 3's schedule (all three bit-identical, tested)."""
+    A WAIT that times out poisons its rows (NaN) and counts in the device's error word: ops.poll_handoff() below (eager calls),
+    ops.check_handoff() after a replayed graph (the owner of the graph calls it where it synchronises anyway).  The hand-off needs
+    workgroups j and j + 8 k on one XCD: ops.handoff_placement_ok() tests that once per device; where it does not hold, and with
+    GD4D_POS_ENCODER=dual, round 3's schedule runs instead - [chain A | reg(l-1), refine, position_encoder(l)], chain B' alone
+    (bit-identical results, tested)."""
     q, _, c = query.shape
     dev = query.device
     layers = list(decoder.layers)
@@ -219,17 +206,11 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
     ref = reference_points.contiguous()
     pending = None                                       # (reg linears, x of the previous layer, its ref, where the new ref goes)
-    pos_mode = os.environ.get('GD4D_POS_ENCODER', 'chainb')
-    pos_late = pos_mode not in ('chaina', 'dual')         # the default: [chain A | reg branch], [chain B' | position_encoder]
-    pos_a = pos_mode == 'chaina'                          # [chain A | position_encoder], [chain B' | reg branch]
-    mha_fused = os.environ.get('GD4D_FUSE_MHA', '0') != '0'      # off: measured 0.5 % slower than the two launches (docs/measurements_r04.md §3)
-    mha_all = os.environ.get('GD4D_FUSE_MHA') == 'all'
-    if mha_fused:
-        mha_flags = torch.zeros(nl, ((q + 15) // 16 + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)   # per layer: a counter per row block; [-1]: waits that gave up
-        keep.append(mha_flags)
-    if pos_late or pos_a:
+    pos_late = ops.handoff_enabled(dev, 'GD4D_POS_ENCODER')       # [chain A | reg branch], [chain B' | position_encoder]: the default
+    if pos_late:
         blocks = (q + 15) // 16
-        flags = torch.zeros(nl, (blocks + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)     # row-block flags per layer; [-1]: waits that gave up
+        flags = torch.zeros(nl, (blocks + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)     # row-block flags per layer
+        err = ops.handoff_error_word(dev)
         keep.append(flags)
     for lid, layer in enumerate(layers):
         sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
@@ -237,13 +218,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         last = lid + 1 == nl
         slot = lid if return_intermediate else 0
         qh, kh, vh = qkv.split(c, dim=-1)
-        # attention core and chain A in one launch (gd4d_row_chain_mha_fwd; GD4D_FUSE_MHA=1, =all: layer 0 too): two graph
-        # boundaries per layer less - but every workgroup of that launch owns the chain's 133 KB of LDS, so the attention
-        # workgroups run one per compute unit, in two rounds: no gain (kept as the record of the attempt, tested)
-        fuse_mha = mha_fused and attn_masks[0] is None and (lid > 0 or mha_all)    # (layer 0 shares the device with the copy)
-        if fuse_mha:
-            o = torch.empty(q, 1, c, device=dev, dtype=torch.float32)
-        elif kv is not None:
+        if kv is not None:
             o = ops.mha_core_presplit_fwd(qh, kv, sa.num_heads, attn_masks[0])
         else:
             o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
@@ -257,18 +232,12 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         prog_a = [ops.chain_load(0, o.view(q, c)),
                   ops.chain_gemm(0, sa.attn.out_proj.weight, sa.attn.out_proj.bias, dst=1, add=x),
                   ops.chain_layernorm(1, layer.norms[0], dst=2, out=x1, dst2=0, add=pos)]
-        if _fuse_gemms():    # the three Linears of query + query_pos as one GEMM over the stacked weights (248 columns: one pass)
-            prog_a.append(ops.chain_gemm_three_outputs(
-                0, [ca.cam_attention_weights, ca.deform_sampling_offsets, ca.attention_weights],
-                [cam.view(q, -1), off.view(q, -1), att.view(q, -1)]))
-        else:
-            prog_a += [ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
-                       ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
-                       ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
+        # the three Linears of query + query_pos as one GEMM over the stacked weights (248 columns: one pass)
+        prog_a.append(ops.chain_gemm_three_outputs(
+            0, [ca.cam_attention_weights, ca.deform_sampling_offsets, ca.attention_weights],
+            [cam.view(q, -1), off.view(q, -1), att.view(q, -1)], exact=OFFSETS_EXACT))
         pos_feat = torch.empty(1, q, c, device=dev, dtype=torch.float32)
-        if pos_a:                                              # the refined points are in global memory since chain B' of the layer before
-            prog_b = _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
-        elif pending is not None:
+        if pending is not None:
             lins, x_prev, ref_prev, new_ref = pending
             prog_b, src, tmp = [ops.chain_load(3, x_prev)], 3, (1, 2)
             for i, lin in enumerate(lins):
@@ -282,16 +251,12 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             ref = new_ref
         else:
             prog_b = None if pos_late else _position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3))
-        if fuse_mha:
-            ops.row_chain_mha_fwd(prog_a, prog_b, q, qh, kh, vh, sa.num_heads, mha_flags[lid], mha_flags[lid, -1:], out=o)
-        elif prog_b is None:                                    # layer 0: the initial reference points need no refinement
+        if prog_b is None:                                      # layer 0: the initial reference points need no refinement
             ops.row_chain_fwd(prog_a, q)
-        elif os.environ.get('GD4D_DEV_SWAP_PROGRAMS') == '1':   # dev: block 0 (the one tools/trace_step.py stamps) runs the second program
-            ops.row_chain2_fwd(prog_b, prog_a, q)
         else:
             ops.row_chain2_fwd(prog_a, prog_b, q)
 
-        if late.mode != 'sliced' and os.environ.get('GD4D_AGG_EPILOGUE', '1') != '0':
+        if late.mode != 'sliced':
             # value_proj of the aggregates in the gather's epilogue: chain B' starts from one 1-KB row per query
             agg = late.sample_aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
                                         img_h, img_w, order=order)
@@ -302,7 +267,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                                            img_h, img_w, order=order)
             first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0)
         x3 = out_all[slot]
-        prog = [first] + ([ops.chain_wait(flags[lid], flags[lid, -1:])] if pos_late else []) + [
+        prog = [first] + ([ops.chain_wait(flags[lid], err)] if pos_late else []) + [
                 ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336 (as GEMM addends: slower)
                 ops.chain_gemm(0, ca.output_proj.weight, ca.output_proj.bias, dst=1, res=3),
                 ops.chain_layernorm(1, layer.norms[1], dst=2),
@@ -311,27 +276,14 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         if not last:
             qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
             prog.append(ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c), dst2=0, add=pos))
-            x3_stored = len(prog)                        # operations of chain B' up to the one that stores the layer's output
             prog += _in_proj_ops(layers[lid + 1].attentions[0], 0, 3, qkv.view(q, -1), kv)
         else:
             prog.append(ops.chain_layernorm(1, layer.norms[2], dst=3, out=x3.view(q, c)))
         pending = None
-        tail = None
         if reg_branches is not None:
             lins = _plain_reg_branch(reg_branches[lid], c)
             new_ref = ref_all[slot]
-            if pos_a and not last:
-                # reg branch + refinement as the launch's second program, beside the next layer's in-projection: chain B'
-                # SIGNALs once its rows of the layer's output are stored (the signalling program goes first)
-                tail, src, tmp = [ops.chain_wait(flags[lid], flags[lid, -1:]), ops.chain_load(3, x3.view(q, c))], 3, (1, 2)
-                for i, lin in enumerate(lins):
-                    tail.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
-                    src = tmp[i % 2]
-                tail.append(ops.chain_refine(src, ref, new_ref))
-                prog = prog[:x3_stored] + [ops.chain_signal(flags[lid])] + prog[x3_stored:]
-                keep.append(ref)
-                ref_next = new_ref
-            elif last:                                   # nothing follows: the last refinement closes chain B'
+            if last:                                     # nothing follows: the last refinement closes chain B'
                 src, tmp = 3, (1, 2)
                 for i, lin in enumerate(lins):
                     prog.append(ops.chain_gemm(src, lin.weight, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
@@ -341,27 +293,16 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                 pending = (lins, x3.view(q, c), ref, new_ref)
         elif return_intermediate or last:
             ref_all[slot].copy_(ref)
-        if tail is not None:
-            ops.row_chain2_fwd(prog, tail, q)
-            ref = ref_next
-        elif pos_late:
+        if pos_late:
             # position_encoder(l) on the refined points (in global memory since the dual launch), beside chain B'.  The
-            # SIGNALling program goes FIRST: its workgroups are dispatched before the waiting ones (gd4d.h: no deadlock however
-            # many requests are in flight).
+            # SIGNALling program goes FIRST: its workgroups are dispatched before the waiting ones (gd4d.h).
             ops.row_chain2_fwd(_position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3)) + [ops.chain_signal(flags[lid])], prog, q)
         else:
             ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]
         x = x3.view(q, c)
-    if (pos_late or pos_a) and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
-        # debugging aid: a WAIT that gave up (~0.2 s unanswered) counts in the last word of its layer's flag row
-        torch.cuda.synchronize(dev)
-        if int(flags[:, -1].sum().item()) != 0:
-            raise RuntimeError('graph-detr4d_amd: a SIGNAL / WAIT hand-off between chain programs timed out')
-    if mha_fused and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
-        torch.cuda.synchronize(dev)
-        if int(mha_flags[:, -1].sum().item()) != 0:
-            raise RuntimeError('graph-detr4d_amd: a chain waited in vain for the attention workgroups of its launch')
+    if pos_late:
+        ops.poll_handoff(dev)                                # non-blocking (eager calls); a graph's owner: ops.check_handoff()
     del keep
     return out_all, ref_all
 
@@ -379,8 +320,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
     dev = query.device
     layers = list(decoder.layers)
     nl = len(layers)
-    if late is not None and os.environ.get('GD4D_SCHEDULE', 'single') == 'single' and not os.environ.get('GD4D_ABLATE') \
-            and all((c // l.attentions[1].num_heads) % 32 == 0 and not l.attentions[1].depth_encode for l in layers):
+    if late is not None and all((c // l.attentions[1].num_heads) % 32 == 0 and not l.attentions[1].depth_encode for l in layers):
         if order is None or order.numel() != q:
             order = Fn.query_order(reference_points.contiguous(), layers[0].attentions[1].pc_range)
         return run_single(decoder, query, query_pos, value, reference_points, reg_branches, img_metas, attn_masks, order,
@@ -427,7 +367,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
 
         # attention core
         qh, kh, vh = qkv.split(c, dim=-1)
-        o = torch.empty(q, 1, c, device=dev, dtype=torch.float32) if _ablate('mha') else ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
+        o = ops.mha_core_fwd(qh, kh, vh, sa.num_heads, attn_masks[0])
 
         # chain A
         x1 = torch.empty(q, c, device=dev, dtype=torch.float32)
@@ -442,22 +382,17 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                 ops.chain_gemm(0, ca.cam_attention_weights.weight, ca.cam_attention_weights.bias, out=cam.view(q, -1)),
                 ops.chain_gemm(0, ca.deform_sampling_offsets.weight, ca.deform_sampling_offsets.bias, out=off.view(q, -1)),
                 ops.chain_gemm(0, ca.attention_weights.weight, ca.attention_weights.bias, out=att.view(q, -1))]
-        if not _ablate('chain_a'):
-            ops.row_chain_fwd(prog, q)
+        ops.row_chain_fwd(prog, q)
 
         if ref_event is not None:
             main.wait_event(ref_event)
         if order is None or order.numel() != q:
             order = Fn.query_order(ref, ca.pc_range)
         agg_raw = None
-        if late is not None and (late.mode == 'sliced' or os.environ.get('GD4D_AGG_EPILOGUE', '1') == '0') and (c // hh) % 32 == 0 \
-                and os.environ.get('GD4D_CHAIN_HEADGEMM', '1') != '0':
+        if late is not None and late.mode == 'sliced' and (c // hh) % 32 == 0:
             # aggregate-then-project: gather the raw features per head; value_proj of the aggregates is chain B's first op
-            if _ablate('agg'):
-                agg_raw, wsum = torch.empty(1, q, hh, c, device=dev), torch.empty(1, q, hh, device=dev)
-            else:
-                agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
-                                               img_h, img_w, order=order)
+            agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                           img_h, img_w, order=order)
             agg = agg_raw
         elif late is not None:
             agg = late.sample_aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
@@ -512,11 +447,10 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                 src = tmp[i % 2]
             new_ref = ref_all[slot]                                                 # (1, Q, 3)
             reg_prog.append(ops.chain_refine(src, ref, new_ref))
-        split_reg = bool(reg_prog) and aux is not None and os.environ.get('GD4D_REG_ON_AUX', '1') != '0'
+        split_reg = bool(reg_prog) and aux is not None
         if not split_reg:
             prog += reg_prog
-        if not _ablate('chain_b'):
-            ops.row_chain_fwd(prog, q)
+        ops.row_chain_fwd(prog, q)
         keep += [o, x1, cam, off, att, agg, x]
 
         x = x3.view(q, c)
@@ -531,7 +465,7 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                     if split_reg:
                         ops.row_chain_fwd([ops.chain_load(3, x)] + reg_prog, q)
                         keep.append(old_ref)
-                    if not last and order is not None and os.environ.get('GD4D_ORDER_ONCE', '0') != '1':
+                    if not last and order is not None:
                         # the next layer's locality order: one tiny launch next to that layer's self-attention
                         order = Fn.query_order(ref, order_pc_range)
                     ref_event = torch.cuda.Event()

@@ -209,7 +209,9 @@ class DecoderTrainFunction(torch.autograd.Function):
         saved = []
         drops = [_dropouts(layer) for layer in layers]
         seeds = draw_seeds(5 * nl, dev) if any(any(pr > 0. for pr in d) for d in drops) else None
-        flags = torch.zeros(nl, (q + 15) // 16 // 8 * 8 + 16, device=dev, dtype=torch.int32) if meta.reg_branches is not None else None   # hand-off flags per row block; [-1]: waits that gave up
+        beside = meta.reg_branches is not None and ops.handoff_enabled(dev, 'GD4D_TRAIN_REG_BESIDE')
+        flags = torch.zeros(nl, (q + 15) // 16 // 8 * 8 + 16, device=dev, dtype=torch.int32) if beside else None   # hand-off flags per row block
+        err = ops.handoff_error_word(dev) if beside else None    # a WAIT that gives up counts here (and poisons its rows): ops.check_handoff
         qkv, xp = new(q, 1, 3 * c), new(q, c)
         im0 = imgs.layers[0]
         p0 = dict(zip(NAMES, params[:PER_LAYER]))
@@ -217,7 +219,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         # before the next in-projection writes them); the fp32 rows stay for the attention backward
         kv = None
         if (c == 256 and layers[0].attentions[0].num_heads == 8 and (mask is None or mask.dim() == 2)
-                and os.environ.get('GD4D_MHA_PRESPLIT', '1') != '0' and os.environ.get('GD4D_MHA_FP32') != '1'):
+                and os.environ.get('GD4D_MHA_FP32') != '1'):
             kv = ops.KVPlanes(q, c, dev, heads=8)
         ops.row_chain_fwd([ops.chain_load(0, x, pos, out=xp), ops.chain_load(1, x),
                            ops.chain_gemm_two_sources(0, 1, 2 * c, im0['inproj'], p0['in_b'], qkv.view(q, -1), kv=kv, keep_fp32=True)], q)
@@ -261,10 +263,8 @@ class DecoderTrainFunction(torch.autograd.Function):
             ops.row_chain2_fwd(prog_a, prog_p, q)
             # plan + gather on the raw pyramid (autograd.CrossAttnRawFunction's forward without its value_proj launch)
             s.plan = ops.cross_attn_plan_fwd(raw.pyramid, ref, s.off.view(1, q, hh, npt, 3), s.att.view(1, q, hh, nlv, npt), s.cam,
-                                             meta.lidar2img, ca.pc_range, meta.img_h, meta.img_w, hh, query_order=order,
-                                             both=os.environ.get('GD4D_TRAIN_PLAN', 'both') == 'both')
+                                             meta.lidar2img, ca.pc_range, meta.img_h, meta.img_w, hh, query_order=order, both=True)
             s.layer = raw.register(s.plan.q)
-            raw.wait_copy()
             s.agg = raw.count_with_gather(s.layer, s.plan) if want_pyramid else None    # slots + gather in one launch
             if s.agg is None:
                 if want_pyramid:
@@ -290,14 +290,14 @@ class DecoderTrainFunction(torch.autograd.Function):
                 # program SIGNALs once its rows of x3 are stored (gd4d.h: the signalling program goes first).
                 lins = _plain_reg_branch(meta.reg_branches[lid], c)
                 new_ref = ref_all[lid]
-                tail = [] if last else [ops.chain_wait(flags[lid], flags[lid, -1:]), ops.chain_load(3, x3)]
+                tail = [ops.chain_wait(flags[lid], err), ops.chain_load(3, x3)] if (beside and not last) else []
                 src, tmp = 3, (1, 2)
                 for i, (lin, wimg) in enumerate(zip(lins, im['reg'])):
                     tail.append(ops.chain_gemm(src, wimg, lin.bias, dst=tmp[i % 2], relu=i + 1 < len(lins), exact=True))
                     src = tmp[i % 2]
                 tail.append(ops.chain_refine(src, ref, new_ref))
-                if last or os.environ.get('GD4D_TRAIN_REG_BESIDE', '1') == '0':      # nothing to run beside: the tail closes the chain
-                    ops.row_chain_fwd(prog + tail[(0 if last else 2):], q)
+                if last or not beside:                       # nothing to run beside (or no hand-off on this device): the tail closes the chain
+                    ops.row_chain_fwd(prog + tail, q)
                 else:
                     at = 7                                  # after the LayerNorm that stores x3
                     ops.row_chain2_fwd(prog[:at] + [ops.chain_signal(flags[lid])] + prog[at:], tail, q)
@@ -307,11 +307,8 @@ class DecoderTrainFunction(torch.autograd.Function):
                 ops.row_chain_fwd(prog, q)
             saved.append(s)
             x, ref = x3, new_ref
-        raw.join()
-        if flags is not None and os.environ.get('GD4D_CHECK_HANDOFF') == '1' and not torch.cuda.is_current_stream_capturing():
-            torch.cuda.synchronize(dev)                      # debugging aid, as in fused_decoder: a WAIT that gave up counts in [-1]
-            if int(flags[:, -1].sum().item()) != 0:
-                raise RuntimeError('graph-detr4d_amd: a SIGNAL / WAIT hand-off between chain programs timed out')
+        if beside:
+            ops.poll_handoff(dev)                            # non-blocking; ops.check_handoff() is the blocking form
         ctx.meta, ctx.saved, ctx.params, ctx.imgs = meta, saved, params, imgs
         ctx.versions = [p_._version for p_ in params]        # the backward chains read the images of THESE weights (and their transposes)
         ctx.pos = pos
@@ -347,7 +344,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         grads = [None] * len(params)
         local_w, local_ln = [], []
         deferring = _deferring() is not None
-        ride_wgrads = deferring and os.environ.get('GD4D_TRAIN_WGRAD', 'dot') == 'dot'     # queued weight gradients ride in the gather-dots' launches
+        ride_wgrads = deferring                              # queued weight gradients ride in the gather-dots' launches
 
         def targets(iw, ib, rows):
             """Where the gradients of parameters iw / ib (a weight and its bias, or gamma and beta) go: their views of the flat
@@ -388,7 +385,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         gpos = None                          # running gradient of query_pos
         g_ref0 = padz = carry = carry_keep = None
         if want_pyramid:
-            raw.fills_ride = (raw.side_bwd is raw.main and raw.side_prep is None and os.environ.get('GD4D_TRAIN_FILL', 'mha') == 'mha')
+            raw.fills_ride = True                            # the record fills ride in the attention backward's launches
             raw.begin_backward()
         for lid in range(nl - 1, -1, -1):
             layer, s, im = layers[lid], saved[lid], imgs.layers[lid]
@@ -447,29 +444,17 @@ class DecoderTrainFunction(torch.autograd.Function):
             # the weight gradients queued so far (this layer's chain B, the layer above's chain A / in-projection) ride in the
             # gather-dot's launch instead of waiting for the pass's end
             riders = take_queued_weight_grads() if ride_wgrads and ops.wgrads_ride_with(s.plan) else None
-            if ops.wgrads_ride_with(s.plan) and os.environ.get('GD4D_TRAIN_HEADS_BWD', 'own') == 'dot':
-                # dev switch: value_proj_heads_bwd computed INSIDE that launch (bit-identical; measured +0.2 ms per step: every
-                # workgroup streams its 4 KB of value_proj's weight through the L2 the gather-dot is bound by)
-                beta = new(1, q, hh)
-                dpart = ops.cross_attn_dot_sliced(s.plan, None, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)),
-                                                  wgrads=riders,
-                                                  heads=(gv.view(1, q, c), vp_w, vp_b, raw.sink.grad_agg_rows(s.layer) if want_pyramid else None, beta))
-                raw.layer_done()
-            else:
-                gagg, beta = ops.value_proj_heads_bwd(gv.view(1, q, c), vp_w, vp_b, hh,
-                                                      grad_agg=raw.sink.grad_agg_rows(s.layer) if want_pyramid else None)
-                raw.layer_done()
-                dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)),
-                                                  wgrads=riders)
+            gagg, beta = ops.value_proj_heads_bwd(gv.view(1, q, c), vp_w, vp_b, hh,
+                                                  grad_agg=raw.sink.grad_agg_rows(s.layer) if want_pyramid else None)
+            raw.layer_done()
+            dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)), wgrads=riders)
             off5, att5 = s.off.view(1, q, hh, ca.num_points, 3), s.att.view(1, q, hh, ca.num_levels, ca.num_points)
             gr, go, ga, gc = ops.cross_attn_plan_bwd(s.plan, dpart, beta, s.ref, off5, att5, s.cam, meta.lidar2img, ca.pc_range,
                                                      meta.img_h, meta.img_w)
             ivw, ivb = base + NAMES.index('vp_w'), base + NAMES.index('vp_b')
             if need[ivw] or need[ivb]:
                 mw, mb = (Fn.main_grad(params[ivw]), Fn.main_grad(params[ivb])) if deferring else (None, None)
-                if mw is not None and mb is not None and os.environ.get('GD4D_TRAIN_DEFER_VP', '1') == '0':
-                    ops.value_proj_heads_bwd_weight(gv.view(1, q, c), s.agg, s.plan.wsum, want_bias=True, into=(mw, mb))
-                elif mw is not None and mb is not None:
+                if mw is not None and mb is not None:
                     _queue_deferred('vp', (gv.view(1, q, c), (s.agg, s.plan.wsum), mw, mb), _VP_GROUP)
                 else:
                     grads[ivw], grads[ivb] = ops.value_proj_heads_bwd_weight(gv.view(1, q, c), s.agg, s.plan.wsum, want_bias=True)
@@ -550,6 +535,11 @@ def run(decoder, query, query_pos, value, reference_points, reg_branches, img_me
                  img_h=img_h, img_w=img_w, attn_mask=attn_masks)
     params = [t for layer in layers for t in _layer_params(layer)]
     outs, refs = DecoderTrainFunction.apply(meta, token, query, query_pos, reference_points, *params)
+    if reg_branches is None:
+        # no refinement, so no detach (detr3d_transformer.py:199-214): every layer's reference points ARE the caller's tensor and
+        # the box loss of every level reaches it through inverse_sigmoid(inter_references) - the Function's own copies are marked
+        # non-differentiable (right for refined, detached points only)
+        refs = reference_points.unsqueeze(0).expand(refs.shape[0], *reference_points.shape)
     if decoder.return_intermediate:
         return outs, refs
     return outs[0], refs[0]

@@ -70,14 +70,24 @@ class _HeadPEFunction(torch.autograd.Function):
         ctx.weights = (flat(w2), flat(a2), flat(wr), flat(we))
         ctx.shapes = [tuple(w.shape) for w in (w0, w2, a0, a2, wr, we)]
         ctx.starts, ctx.nl = starts, nl
+        # what the backward reads is kept OUTSIDE save_for_backward (buffers are overwritten in place there; flat(w) are views of the
+        # live parameters): an in-place update between the two passes (an optimizer step inside a captured step, EMA) would go
+        # unnoticed - so the versions are recorded and compared, as fused_train does and as autograd does for its saved tensors
+        ctx.watched = list(args)
+        ctx.versions = [t._version for t in ctx.watched]
         return tuple(out)
 
     @staticmethod
     def backward(ctx, *grads):
         if ctx.bufs is None:
             raise RuntimeError('FeaturePositionEmbedding: the saved activations were consumed by the first backward '
-                               '(retain_graph / double backward are not supported on the HIP path; GD4D_HEAD_PE_BWD=torch)')
+                               '(retain_graph / double backward are not supported on the HIP path; GD4D_TORCH_OPS=1 runs the torch-op route)')
+        if [t._version for t in ctx.watched] != ctx.versions:
+            raise RuntimeError('FeaturePositionEmbedding: a feature map or a parameter of the position embedding was modified in place '
+                               'between the forward and the backward pass (the backward reads them) - as autograd itself refuses a '
+                               'saved tensor that was modified in place')
         b, ctx.bufs = ctx.bufs, None
+        ctx.watched = None
         nl, starts = ctx.nl, ctx.starts
         w2, a2, wr, we = ctx.weights
         feats = b['feats']
@@ -285,15 +295,14 @@ class FeaturePositionEmbedding(nn.Module):
         """The stage with autograd on (the head trains through it: gradients reach the backbone's feature maps, the two
         position MLPs and the SE gate, detr3d_head_pe.py:546-557).  The geometry needs no gradient and stays on the HIP
         kernels (frustum coordinates -> conv input, sine / cosine expansion, padding masks); the differentiable part runs on
-        _HeadPEFunction (the library's GEMMs forward and backward) when the shapes fit it; otherwise - or with
-        GD4D_HEAD_PE_BWD=torch - the 1x1 convolutions, the gate and the adds are torch ops and autograd differentiates
-        them."""
+        _HeadPEFunction (the library's GEMMs forward and backward); shapes it does not take raise; with GD4D_TORCH_OPS=1 the 1x1
+        convolutions, the gate and the adds are torch ops and autograd differentiates them."""
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
             b, n = feats[0].shape[:2]
             l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
             img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(b * n, 4, 4).to(feats[0].device)   # :459-465
-        if self._gemm_ok(feats) and os.environ.get('GD4D_HEAD_PE_BWD', 'hip') != 'torch':
+        if not Fn.torch_ops_route(self._route_name(feats), self._gemm_ok(feats)):
             return self._forward_hip_train(feats, masks, pad_hw, img2lidar)
         with torch.no_grad():
             xs = [ops.frustum_pe_input_fwd(img2lidar, tuple(f.shape[-2:]), pad_hw, self.depth_num, self.depth_start,
@@ -306,6 +315,10 @@ class FeaturePositionEmbedding(nn.Module):
             sine = self.adapt_pos3d(s.flatten(0, 1)).view(f.shape)
             out.append(f + (pe * torch.sigmoid(gate) + sine))
         return out
+
+    def _route_name(self, feats):
+        return (f'Detr3DHeadPE position embedding with embed_dims = {self.embed_dims}, position_dim = {self.position_dim}, '
+                f'{feats[0].shape[2]} channels, num_feats = {self.num_feats} (kernels: 256 / a multiple of 32 / 256 / 3 num_feats a multiple of 32)')
 
     def _gemm_ok(self, feats):
         return self.embed_dims == 256 and self.position_dim % 32 == 0 and feats[0].shape[2] == 256 and \
@@ -338,8 +351,8 @@ class FeaturePositionEmbedding(nn.Module):
     # ---- the stage ------------------------------------------------------------------------------------------------
     def forward(self, mlvl_feats, img_metas):
         """mlvl_feats: list of (B, N, C, H_l, W_l) fp32 GPU tensors; returns the list with the position embedding
-        added (:546-557).  With autograd on: _forward_autograd (HIP geometry, torch ops for the differentiable part).
-        GD4D_HEAD_PE=conv keeps the 1x1 convolutions on the library instead of gd4d_gemm_bf16x3_fwd."""
+        added (:546-557).  With autograd on: _forward_autograd.  GD4D_TORCH_OPS=1 runs the 1x1 convolutions as torch ops (MIOpen)
+        instead of gd4d_gemm_bf16x3_fwd; shapes the GEMM route does not take raise without it."""
         feats = list(mlvl_feats)
         Fn.require_gpu(feats[0], 'mlvl_feats')
         if self.with_detach and feats[0].shape[1] > self.cams_per_frame and feats[0].requires_grad and torch.is_grad_enabled():
@@ -349,7 +362,7 @@ class FeaturePositionEmbedding(nn.Module):
             return self._forward_autograd(feats, img_metas)
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
-            if self._gemm_ok(feats) and os.environ.get('GD4D_HEAD_PE', 'gemm') != 'conv':
+            if not Fn.torch_ops_route(self._route_name(feats), self._gemm_ok(feats)):
                 return self._forward_gemm(feats, img_metas, masks, pad_hw, self._sine_branch(masks, chlast=True))
             sine = self._sine_branch(masks)
             coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)

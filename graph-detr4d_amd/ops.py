@@ -458,13 +458,11 @@ def _wgrad_arrays(problems):
     return arr(xs), arr(gys), arr(gws), arr(gbs), (ctypes.c_int32 * (5 * n))(*dims), n
 
 
-def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None, heads=None):
+def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None):
     """gd4d_cross_attn_dot_sliced: D[pair] = <grad_agg[q, h], raw pixel of the pair> for every pair of `plan`, as 8 per-slice
     partials (uint8 buffer of gd4d_cross_attn_dot_bytes; only the passes the plan uses are written).
     wgrads: up to 16 weight-gradient problems (as linear_bwd_weight_group takes them; added to their targets) whose tiles ride
-    in the launch (gd4d_cross_attn_dot_sliced_wgrad; 8 heads, 4 levels, fp32: wgrads_ride_with(plan) says whether).
-    heads = (grad_out (B, Q, 256), vp_weight, vp_bias or None, grad_agg_out (B, Q, Hh, 256) or None, beta_out (B, Q, Hh) or None)
-    with grad_agg=None: value_proj_heads_bwd is computed inside the launch too (gd4d_cross_attn_dot_sliced_fused; same shapes)."""
+    in the launch (gd4d_cross_attn_dot_sliced_wgrad; 8 heads, 4 levels, fp32: wgrads_ride_with(plan) says whether)."""
     lib = _lib.load()
     plan.need_pairs('gd4d_cross_attn_dot_sliced')
     pyramid = plan.pyramid
@@ -475,22 +473,6 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None, heads=None):
     if dpart is None:
         dpart = torch.empty(nbytes, device=pyramid.device, dtype=torch.uint8)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
-    if heads is not None:
-        gout, vw, vb, table, beta = heads
-        f32 = torch.float32
-        if wgrads:
-            xs, gys, gws, gbs, dims, cnt = _wgrad_arrays(wgrads)
-        else:
-            xs = gys = gws = gbs = dims = None
-            cnt = 0
-        code = lib.gd4d_cross_attn_dot_sliced_fused(
-            ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(gout, 'grad_out', f32), _dev(vw, 'vp_weight', f32),
-            None if vb is None else _dev(vb, 'vp_bias', f32), None if table is None else _dev(table, 'grad_agg_out', f32),
-            None if beta is None else _dev(beta, 'beta_out', f32), _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256,
-            nl, 4, _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
-            None if plan.order is None else _order_ptr(plan.order, b * q), xs, gys, gws, gbs, dims, cnt, 1, _stream())
-        _lib.check(code, 'gd4d_cross_attn_dot_sliced_fused')
-        return dpart
     if wgrads:
         xs, gys, gws, gbs, dims, cnt = _wgrad_arrays(wgrads)
         code = lib.gd4d_cross_attn_dot_sliced_wgrad(
@@ -1874,9 +1856,11 @@ def _stacked_linears(linears):
     return w, b
 
 
-def chain_gemm_three_outputs(src, linears, outs, stacked=None):
+def chain_gemm_three_outputs(src, linears, outs, stacked=None, exact=False):
     """Three nn.Linear of ONE input (buf[src]) as one GEMM over their stacked weights; column block i goes to outs[i] (M, N_i),
-    dense rows.  The sums of a column do not depend on the operation it is part of: bit-identical to three chain_gemm."""
+    dense rows.  The sums of a column do not depend on the operation it is part of: bit-identical to three chain_gemm.
+    exact: fp32-class products (GD4D_CHAIN_EXACT) - one of the outputs are sampling offsets in metres, which a camera matrix turns
+    into pixels before the visibility mask is decided."""
     if len(linears) != 3 or len(outs) != 3:
         raise ValueError('chain_gemm_three_outputs takes three Linears and three outputs')
     ptrs = [_rows(o, 'out') for o in outs]
@@ -1884,12 +1868,12 @@ def chain_gemm_three_outputs(src, linears, outs, stacked=None):
         if ld != m.weight.shape[0]:
             raise ValueError('chain_gemm_three_outputs: every output must be dense, as wide as its Linear')
     if stacked is not None:                   # (WeightImage of the stacked weights, stacked bias) of an ImageSet
-        img, n, k = _image_of(stacked[0])
+        img, n, k = _image_of(stacked[0], exact)
         b = stacked[1]
     else:
         w, b = _stacked_linears(linears)
-        img, n, k = _image_of(w)
-    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=-1, K=k, N=n, flags=CHAIN_SPLIT_OUT,
+        img, n, k = _image_of(w, exact)
+    return ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=-1, K=k, N=n, flags=CHAIN_SPLIT_OUT | (CHAIN_EXACT if exact else 0),
                    ldg=ptrs[0][1], ld2=ptrs[1][1], ld1=ptrs[2][1], p0=img, p1=b.data_ptr(),
                    gout=ptrs[0][0], p2=ptrs[1][0], p3=ptrs[2][0])
 
@@ -1957,9 +1941,104 @@ def chain_signal(flags):
     return ChainOp(kind=CHAIN_SIGNAL, src=-1, dst=-1, res=-1, gout=_dev(flags, 'flags', torch.int32).value)
 
 
+_HANDOFF = {}       # device index -> {'word': int32[1] on the device, 'pinned': int32[1] host, 'event': Event or None, 'placement': bool}
+
+
+def _handoff_state(device):
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _HANDOFF.get(idx)
+    if st is None:
+        dev = torch.device('cuda', idx)
+        st = _HANDOFF[idx] = {'word': None, 'dev': dev, 'pinned': None, 'event': None, 'placement': None}
+    return st
+
+
+def handoff_error_word(device):
+    """The device's sticky error word of the SIGNAL / WAIT hand-offs between chain programs: a WAIT that gives up (~0.2 s
+    unanswered) adds 1 to it and POISONS the rows it hands on (NaN), so a time-out is a wrong answer nobody can mistake for a right
+    one, and check_handoff() / poll_handoff() turn it into an exception."""
+    st = _handoff_state(device)
+    if st['word'] is None:
+        st['word'] = torch.zeros(1, device=st['dev'], dtype=torch.int32)
+    return st['word']
+
+
+def check_handoff(device=None):
+    """Blocking: raises Gd4dError if a hand-off has timed out on `device` (default: every device used so far) since the last check.
+    Call it where a host sync exists anyway - after a request's graph replay (or every N replays), at the end of a step."""
+    sts = list(_HANDOFF.items()) if device is None else [(None, _handoff_state(device))]
+    for _, st in sts:
+        if st['word'] is None:
+            continue
+        n = int(st['word'].item())
+        st['event'] = None
+        if n:
+            st['word'].zero_()
+            raise _lib.Gd4dError(f'{n} SIGNAL / WAIT hand-off(s) between chain programs timed out: the affected rows are NaN. '
+                                 'GD4D_POS_ENCODER=dual / GD4D_TRAIN_REG_BESIDE=0 run the same step without hand-offs.')
+
+
+def poll_handoff(device):
+    """Non-blocking form for eager launches (not inside a graph capture): looks at the copy of the error word an earlier call
+    requested, if it has arrived, and requests the next one - a time-out surfaces one call later at the latest, without a sync."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = _handoff_state(device)
+    if st['word'] is None:
+        return
+    if st['event'] is not None and st['event'].query():
+        st['event'] = None
+        if int(st['pinned'][0]) != 0:
+            check_handoff(device)
+    if st['event'] is None:
+        if st['pinned'] is None:
+            st['pinned'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        st['pinned'].copy_(st['word'], non_blocking=True)
+        st['event'] = torch.cuda.Event()
+        st['event'].record()
+
+
+def handoff_placement_ok(device):
+    """One-time self-test per device: the hand-offs publish their rows to the XCD's L2 only, so they need workgroup j and workgroup
+    j + 8 k of a launch on the SAME XCD (what the dispatcher does today, not what any specification promises).
+    gd4d_xcd_placement_probe records every workgroup's XCC id; False if the pattern does not hold (or cannot be probed because
+    the first use falls inside a graph capture) - the callers then take the schedules without hand-offs."""
+    st = _handoff_state(device)
+    if st['placement'] is None:
+        if torch.cuda.is_current_stream_capturing():
+            import warnings
+            warnings.warn('graph-detr4d_amd: first use inside a graph capture - the XCD placement self-test cannot run, the step is '
+                          'built without SIGNAL / WAIT hand-offs (run one eager forward before capturing to get them)')
+            return False
+        lib = _lib.load()
+        idx = torch.device(device).index
+        with torch.cuda.device(idx if idx is not None else torch.cuda.current_device()):
+            blocks = 2048
+            out = torch.full((blocks,), -1, device=st['dev'], dtype=torch.int32)
+            _lib.check(lib.gd4d_xcd_placement_probe(_dev(out, 'out', torch.int32), blocks, _stream()), 'gd4d_xcd_placement_probe')
+            ids = out.cpu()
+        st['placement'] = bool((ids >= 0).all() and (ids == ids[:8].repeat(blocks // 8)).all())
+        if not st['placement']:
+            import warnings
+            warnings.warn('graph-detr4d_amd: workgroups j and j + 8 k do not share an XCD on this device - chain programs run '
+                          'without SIGNAL / WAIT hand-offs')
+    return st['placement']
+
+
+def handoff_enabled(device, env):
+    """Whether a step may use hand-offs: the switch `env` (GD4D_POS_ENCODER=dual / GD4D_TRAIN_REG_BESIDE=0 turn them off) and the
+    placement self-test."""
+    import os
+    if os.environ.get(env, '1') in ('0', 'dual'):
+        return False
+    return handoff_placement_ok(device)
+
+
 def chain_wait(flags, errors=None):
     """Two-program launches: hold this program until the other program's workgroup of the same 16 rows has signalled on
-    `flags`; errors: optional int32 tensor (1 element) that counts waits that gave up."""
+    `flags`; errors: int32 tensor (1 element) that counts waits that gave up (handoff_error_word()).  A WAIT that gives up
+    poisons what the program LOADs afterwards (NaN)."""
     return ChainOp(kind=CHAIN_WAIT, src=-1, dst=-1, res=-1, p0=_dev(flags, 'flags', torch.int32).value,
                    gout=None if errors is None else _dev(errors, 'errors', torch.int32).value)
 
@@ -2003,30 +2082,6 @@ def mha_core_presplit_fwd(q, kv, num_heads, attn_mask=None, want_lse=False, drop
                                           None if lse is None else _dev(lse, 'lse'), float(dropout_p), sptr, _stream())
     _lib.check(code, 'gd4d_mha_core_presplit_fwd')
     return (out, lse) if want_lse else out
-
-
-def row_chain_mha_fwd(program, program_side, m, q, k, v, num_heads, flags, errors=None, out=None):
-    """gd4d_row_chain_mha_fwd: the self-attention core (no mask, batch 1; q / k / v (M, 1, C) slices of the packed in-projection
-    as for mha_core_fwd) and the chain `program` that reads its output, in one launch; program_side (list or None) runs beside
-    both.  out: the attention output (M, 1, C) that program's LOAD names (allocated here when None; returned).  flags: int32
-    zeros, >= ceil(M / 16) rounded up to a multiple of 8."""
-    lib = _lib.load()
-    lq, lk, b, c, d, ld, kind, mptr, keep = _mha_args(q, k, v, num_heads, None)
-    if b != 1 or lq != m or lk != m:
-        raise ValueError('row_chain_mha_fwd: batch 1 and as many keys as rows')
-    if out is None:
-        out = torch.empty(lq, b, c, device=q.device, dtype=torch.float32)
-    prog = program
-    a = (ChainOp * len(prog))(*prog)
-    side = program_side or []
-    sb = (ChainOp * len(side))(*side) if side else None
-    code = lib.gd4d_row_chain_mha_fwd(a, len(prog), sb, len(side), int(m), ctypes.c_void_p(q.data_ptr()),
-                                      ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()), _dev(out, 'out'),
-                                      num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, 1.0 / (d ** 0.5),
-                                      _dev(flags, 'flags', torch.int32), None if errors is None else _dev(errors, 'errors', torch.int32),
-                                      _stream())
-    _lib.check(code, 'gd4d_row_chain_mha_fwd')
-    return out
 
 
 def _first_tensor(args):

@@ -129,8 +129,9 @@ class MultiheadAttention(nn.Module):
             kh = kh_lin = Fn.linear_autograd(k_in.contiguous(), w[c:2 * c], bias[c:2 * c], main=rows(c, 2 * c))
         vh_lin = Fn.linear_autograd(v_in.contiguous(), w[2 * c:], bias[2 * c:], main=rows(2 * c, 3 * c))
         drop = float(self.attn_drop) if self.training else 0.
-        if d == 32 and q_in.dtype == torch.float32 and (attn_mask is None or attn_mask.dim() == 2) \
-                and b * h * lq * lk < 2 ** 32 and os.environ.get('GD4D_TRAIN_MHA', 'hip') == 'hip':
+        if not Fn.torch_ops_route(f'MultiheadAttention training with head dim {d}, mask dim {None if attn_mask is None else attn_mask.dim()}',
+                                  d == 32 and q_in.dtype == torch.float32 and (attn_mask is None or attn_mask.dim() == 2)
+                                  and b * h * lq * lk < 2 ** 32):
             # the attention core with autograd on the HIP kernels; in train mode they drop probabilities as F.dropout does
             # inside nn.MultiheadAttention (same distribution, a different generator: gd4d_mha_dropout.h)
             from .autograd import MhaCoreFunction, MhaCorePackedFunction

@@ -301,18 +301,6 @@ int gd4d_cross_attn_dot_sliced_wgrad(const void* const* level_ptrs, int64_t slic
                                      const void* const* grad_y, void* const* grad_w, void* const* grad_b, const int32_t* dims,
                                      int count, int accumulate, void* stream);
 
-/* gd4d_cross_attn_dot_sliced_fused - the whole pyramid side of a decoder layer's backward in front of gd4d_cross_attn_plan_bwd as ONE
- * launch: gd4d_value_proj_heads_bwd (grad_out (B Q, 256) = the gradient at value_proj's output, vp_weight / vp_bias -> the layer's
- * grad_agg rows, written to grad_agg_out (B, Q, Hh, 256; may be NULL), and beta_out (B, Q, Hh; may be NULL)) computed inside the
- * gather-dot - every workgroup forms its 32 channels of its (query, head) row with the stand-alone kernel's very sums - plus the
- * weight-gradient riders of gd4d_cross_attn_dot_sliced_wgrad (count may be 0).  D, grad_agg and beta are bit-identical to the
- * separate launches.  8 heads, 4 levels, fp32 features. */
-int gd4d_cross_attn_dot_sliced_fused(const void* const* level_ptrs, int64_t slice_stride_bytes, const void* plan,
-                                     const float* grad_out, const float* vp_weight, const float* vp_bias, float* grad_agg_out,
-                                     float* beta_out, void* dpart, size_t dpart_bytes, int B, int N, int Q, int Hh, int C, int L,
-                                     int P, int feats_dtype, const int32_t* query_order, const void* const* x,
-                                     const void* const* grad_y, void* const* grad_w, void* const* grad_b, const int32_t* dims,
-                                     int count, int accumulate, void* stream);
 int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, const float* attn_logits, const float* cam_logits,
                              const float* lidar2img, const double* pc_range, float img_h, float img_w, const int32_t* level_hw,
                              const void* plan, const void* dpart, const float* beta, float* grad_ref, float* grad_offsets,
@@ -650,13 +638,16 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * inputs - together: refinement and position_encoder in one program without a round trip through global memory.
  * SIGNAL / WAIT (two-program launches only): a hand-off between the programs, row block by row block.  SIGNAL (gout = an
  * array of >= ceil(M / 16) uint32 flags, zero before the launch) publishes what its program has written to global memory for
- * its 16 rows so far; WAIT (p0 = the same array; gout = optional uint32 error counter) holds its program until the OTHER
- * program's workgroup of the same rows has signalled.  Row block i of both programs is dispatched to the same XCD, so the
- * hand-off goes through that XCD's L2 without cache maintenance.  E.g. position_encoder next to chain B: its rows are needed
- * by chain B's second operation only.  SIGNAL belongs in program_a, WAIT in program_b (anything else is GD4D_EINVAL): the
- * workgroups of a launch are dispatched in index order, program_a's first, so a waiting workgroup's producer is always
- * resident or finished - no deadlock however busy the device is.  A WAIT that is not answered within ~0.2 s (it cannot
- * happen under that rule) gives up, counts in gout and goes on. */
+ * its 16 rows so far; WAIT (p0 = the same array; gout = a uint32 error counter) holds its program until the OTHER
+ * program's workgroup of the same rows has signalled; the operation after a WAIT must be the LOAD of what was handed over.
+ * Row block i of both programs is dispatched to the same XCD (workgroups j and j + 8 k share one - the dispatcher's behaviour
+ * today, which no specification promises: gd4d_xcd_placement_probe lets the host check it once per device before it builds such
+ * programs), so the hand-off goes through that XCD's L2 without cache maintenance.  E.g. position_encoder next to chain B: its
+ * rows are needed by chain B's second operation only.  SIGNAL belongs in program_a, WAIT in program_b (anything else is
+ * GD4D_EINVAL): the workgroups of a launch are dispatched in index order, program_a's first, so a waiting workgroup's
+ * producer is resident or finished.  A WAIT that is not answered within ~0.2 s gives up LOUDLY: it adds 1 to the error counter
+ * at gout, and every LOAD its program executes from then on delivers NaN instead of the rows - the result cannot be mistaken for
+ * a right one; the host reads the counter where it synchronises anyway (once per request, after the replayed graph) and raises. */
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
 
@@ -671,20 +662,22 @@ int gd4d_mha_core_presplit_fwd(const float* q, const void* k_planes, const void*
                                int ldq, int ldo, long long k_plane_stride, long long v_plane_stride, const void* mask,
                                int mask_kind, float scale, float* lse, float drop_p, const void* seed, void* stream);
 
-/* gd4d_row_chain_mha_fwd - the decoder's self-attention core (gd4d_mha_core_fwd without mask, batch 1, Lq = Lk = M: mmcv
- * MultiheadAttention between its in- and out-projection, config detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:74-78) and
- * the chain that consumes its output in ONE launch: the first workgroups are the attention core's (one per 16 queries and
- * head), `program` - whose rows of attn_out they write - follows them and starts a row block as soon as that block's H
- * attention workgroups have reported (same XCD, a counter in its L2; flags: >= ceil(M / 16) rounded up to a multiple of 8
- * int32 counters, zero before the launch; errors: optional counter of waits that gave up, as WAIT's).  program_side
- * (optional, nops_side may be 0): an independent program over the same rows that runs beside both from the start (the
- * previous layer's reg branch + refinement); it may SIGNAL, `program` may WAIT.  Replaces gd4d_mha_core_fwd followed by
- * gd4d_row_chain2_fwd(program, program_side): two kernel boundaries of a replayed graph (3 - 6 us each against 11 us of
- * attention) and the side program's excess over chain A.  Inference chains only (no operation of the training set);
- * results bit-identical to the two launches. */
-int gd4d_row_chain_mha_fwd(const gd4d_chain_op* program, int nops, const gd4d_chain_op* program_side, int nops_side, int M,
-                           const float* q, const float* k, const float* v, float* attn_out, int H, int D, int ldq, int ldk,
-                           int ldv, int ldo, float scale, int32_t* flags, int32_t* errors, void* stream);
+/* gd4d_adamw_flat - the optimizer step of the reference's training recipe over ONE flat fp32 parameter / gradient buffer: clipping
+ * of the gradient's L2 norm (torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: none) followed by
+ * AdamW (torch.optim.AdamW's update, decoupled weight decay) - optimizer + optimizer_config of
+ * projects/configs/detr4d/detr4d_res50_deform_pe_testaug_320_fullset_ceph.py:205-213 (AdamW lr 2e-4, weight_decay 0.01,
+ * grad_clip max_norm 35, norm_type 2).  Two launches whatever the number of parameters.  params / grads / exp_avg / exp_avg_sq: n
+ * floats each, 16-byte aligned (exp_avg, exp_avg_sq zero before the first step); state: 2 floats on the device - [0] the step
+ * counter (zero before the first step; advanced here, so a replayed hipGraph keeps counting), [1] receives the norm before
+ * clipping; workspace: gd4d_adamw_flat_workspace_bytes().  The norm's partial sums are added in a fixed order (run-to-run identical). */
+size_t gd4d_adamw_flat_workspace_bytes(void);
+int gd4d_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* state, void* workspace,
+                    size_t workspace_bytes, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float max_norm, void* stream);
+
+/* gd4d_xcd_placement_probe - out[b] = the XCC (XCD) id workgroup b of a `blocks`-workgroup launch ran on: the self-test behind
+ * SIGNAL / WAIT above (expected: out[b] == out[b % 8]). */
+int gd4d_xcd_placement_probe(int32_t* out, int blocks, void* stream);
 
 /* gd4d_small_linear_layernorm_fwd - y = [ReLU] LN( f(in) W^T + b ) for a Linear with at most 4 inputs: the first stage of
  * position_encoder, Linear(3 or 4 -> 256), LayerNorm, ReLU on inverse_sigmoid(reference points)

@@ -49,7 +49,7 @@ def pytest_sessionstart(session):
     session.config._gd4d_dp2_overlap = two_ranks('--mode', 'train', '--levels', 'vov', '--frames', '1', '--layers', '2', '--steps', '2',
                                                  '--warmup', '1', '--overlap-comm')
     # the N > 1 INFERENCE line (replicas, two requests in flight per rank): what the driver's scaling runs launch
-    session.config._gd4d_dp2_infer = two_ranks('--inflight', '2', '--frames', '1', '--steps', '3', '--warmup', '1', '--no-roofline',
+    session.config._gd4d_dp2_infer = two_ranks('--inflight', '2', '--frames', '1', '--steps', '3', '--warmup', '1', '--no-roofline', '--min-seconds', '0.05',
                                                '--no-cpu-baseline')
 
 

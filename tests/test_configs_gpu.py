@@ -383,13 +383,17 @@ def test_config3_two_rank_training_step_with_overlapped_all_reduce_dry_run(reque
 
 
 def test_two_rank_inference_line_describes_itself(request):
-    """`bench.py --gpus 2 --inflight 2` (replicas; no collective on the data path): value = samples of all ranks and all
-    requests in flight per second, per-rank min / max beside the MAX-reduced step, batch-1 fields present."""
+    """`bench.py --gpus 2 --inflight 2` (replicas; no collective on the data path): value = samples of all ranks per second with ONE
+    request at a time per GPU (SURVEY 8(d)'s batch-1 definition), the median of several K-step windows with min / max beside it; the
+    two-in-flight figure is a secondary field; per-rank min / max beside the MAX-reduced step."""
     line = _one_line(request.config._gd4d_dp2_infer)
     assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['scaling'] == 'weak' and line['allreduce_bytes_per_step'] == 0
     cfg = line['config']
-    assert cfg['inflight'] == 2 and cfg['samples_per_step'] == 4 and cfg['global_batch'] == 4 and 'replicas x2' in cfg['parallelism']
+    assert cfg['inflight'] == 1 and cfg['samples_per_step'] == 2 and cfg['global_batch'] == 2 and 'replicas x2' in cfg['parallelism']
+    assert cfg['metric_8d'] == 'value'
     assert abs(line['value'] - cfg['samples_per_step'] * 1e3 / line['ms_per_step']) < 1e-6 * line['value']
-    assert 0 < line['ms_per_step_rank_min'] <= line['ms_per_step_rank_max'] <= line['ms_per_step'] * 1.0001
+    assert line['windows'] >= 1 and line['ms_per_step_min'] <= line['ms_per_step_median'] == line['ms_per_step'] <= line['ms_per_step_max']
+    assert line['requests_in_flight']['requests'] == 2 and line['value_inflight2'] == line['requests_in_flight']['value'] > 0
+    assert 0 < line['ms_per_step_rank_min'] <= line['ms_per_step_rank_max']
     assert line['value_batch1'] > 0 and abs(line['value_batch1'] - 2 * 1e3 / line['ms_per_sample_batch1']) < 1e-6 * line['value_batch1']
     assert line['eager_ms_per_sample'] > 0 and line['roofline'] is None and line['cpu_baseline'] is None

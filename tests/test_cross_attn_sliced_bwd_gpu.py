@@ -186,35 +186,6 @@ def test_weight_gradients_ride_in_the_gather_dots_launch():
             assert _rel(gb, rb) < 2e-6 and _rel(gb, ab) < 2e-6
 
 
-def test_heads_backward_inside_the_gather_dots_launch():
-    """gd4d_cross_attn_dot_sliced_fused: grad_agg = W_h^T g and beta are formed inside the gather-dot (every workgroup its 32
-    channels of its row) - grad_agg, beta and D bit-identical to gd4d_value_proj_heads_bwd + gd4d_cross_attn_dot_sliced, with and
-    without weight-gradient riders, with and without a bias / the table output."""
-    c = _case(8, 4, 6, 96, 1, seed=41)
-    hh, q = c['heads'], c['q']
-    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
-    pyr = ops.PyramidView.slice_planar(sp, hw)
-    order = ops.query_order_fwd(c['ref'], PC_RANGE)
-    plan = ops.cross_attn_plan_fwd(pyr, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], PC_RANGE, 900, 1600, hh, query_order=order)
-    nb = ops.cross_attn_dot_bytes(1, 6, q, hh)
-    z = lambda: torch.zeros(nb, device=DEV, dtype=torch.uint8)           # noqa: E731
-    gen = torch.Generator().manual_seed(6)
-    x, gy = torch.randn(96, 256, generator=gen).to(DEV), torch.randn(96, 512, generator=gen).to(DEV)
-    for bias in (c['b_v'], None):
-        gagg, beta = ops.value_proj_heads_bwd(c['gout'], c['w_v'], bias, hh)
-        want = ops.cross_attn_dot_sliced(plan, gagg, dpart=z())
-        for riders in (False, True):
-            table, bout = torch.full_like(gagg, float('nan')), torch.full_like(beta, float('nan'))
-            gw = torch.zeros(512, 256, device=DEV)
-            got = ops.cross_attn_dot_sliced(plan, None, dpart=z(), wgrads=[(x, gy, gw, None)] if riders else None,
-                                            heads=(c['gout'], c['w_v'], bias, table, bout))
-            assert torch.equal(got, want) and torch.equal(table, gagg) and torch.equal(bout, beta)
-            if riders:
-                assert _rel(gw, gy.double().t() @ x.double()) < 2e-6
-        got = ops.cross_attn_dot_sliced(plan, None, dpart=z(), heads=(c['gout'], c['w_v'], bias, None, None))     # no table wanted
-        assert torch.equal(got, want)
-
-
 def test_record_fills_ride_in_the_attention_backwards_launch():
     """gd4d_mha_core_bwd_fill: the fills of two (then one) layers are guest workgroups of the dk / dv launch - dq, dk, dv are
     bit-identical to gd4d_mha_core_bwd, and the pyramid's gradient equals the one of the stand-alone fills (another slot order: fp32

@@ -251,13 +251,91 @@ def test_preflight_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, wrong, pre, param_bytes in res:
-        assert 'asked for 3' in wrong
+        assert 'asked for [3]' in wrong
         assert pre['world'] == 2 and pre['backend'] == 'gloo' and [r['rank'] for r in pre['ranks']] == [0, 1]
         assert [x['bytes'] for x in pre['allreduce']] == [1 << 16, 1 << 20]
         assert all(x['sum_ok'] and x['ms'] > 0 and abs(x['busbw_GBps'] - x['algbw_GBps']) < 1e-9 for x in pre['allreduce'])   # N = 2: factor 1
         plan = pre['bucket_plan']
         assert plan['allreduce_bytes'] == param_bytes + 4 * 2 and sum(plan['buckets']) == param_bytes
     assert res[0][2]['allreduce'][0]['ms'] == res[1][2]['allreduce'][0]['ms']        # MAX over ranks: one figure for the job
+
+
+def _uneven_worker(rank, world, port, q, samples):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from graph_detr4d_amd import dist as D
+    D.init(backend='gloo')
+    # (1) one rank was launched for another job size: EVERY rank's preflight raises (nobody is left waiting in a collective)
+    try:
+        D.preflight(8 if rank == 2 else world, None, sizes=(1 << 12,), iters=1, warmup=0)
+        failed = 'accepted'
+    except RuntimeError as e:
+        failed = str(e)
+    pre = D.preflight(world, None, sizes=(1 << 12,), iters=2, warmup=1)
+    # (2) 10 samples over 4 ranks: shards of 3, 3, 2, 2 - in the last step ranks 2 and 3 have no sample, take part in the
+    # all-reduce with a zero gradient, and every rank ends every step with the same parameters
+    mine = D.sample_indices(samples, rank, world)
+    steps = -(-samples // world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    red = D.FlatGradAllReducer(net.parameters())
+    red.bind()
+    sums = []
+    for step in range(steps):
+        red.zero_grad()
+        if step < len(mine):
+            x = torch.randn(4, 6, generator=torch.Generator().manual_seed(D.sample_seed(100, mine[step])))
+            net(x).square().mean().backward()
+        red.reduce()
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(p.grad, alpha=-0.1)
+        sums.append([float(p.detach().double().sum()) for p in net.parameters()])
+    q.put((rank, failed, pre['world'], mine, sums))
+    D.shutdown()
+
+
+def test_four_ranks_uneven_shards_and_a_rank_that_fails_preflight():
+    """world size 4 on gloo with a sample count that does not divide (10 = 3 + 3 + 2 + 2) - ranks without a sample in
+    the last step still take part in the all-reduce (zero gradient) and all ranks hold the same parameters after every step, equal
+    to a single process averaging the same per-sample gradients over 4; and a rank asked for another world size fails the job
+    on EVERY rank instead of leaving three ranks in a collective."""
+    world, samples = 4, 10
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q, samples)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[3] for r in res] == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    for rank, failed, w, mine, sums in res:
+        assert 'rank(s) [2] were asked for [8]' in failed, failed
+        assert w == 4
+        assert sums == res[0][4]                                   # the same parameters on every rank after every step
+    # the single-process reference: per step the mean over 4 ranks of the per-sample gradients (absent samples count as zero)
+    from graph_detr4d_amd import dist as D
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    for step in range(3):
+        acc = [torch.zeros_like(p) for p in net.parameters()]
+        for r in range(world):
+            mine = D.sample_indices(samples, r, world)
+            if step < len(mine):
+                x = torch.randn(4, 6, generator=torch.Generator().manual_seed(D.sample_seed(100, mine[step])))
+                gs = torch.autograd.grad(net(x).square().mean(), list(net.parameters()))
+                acc = [a + g for a, g in zip(acc, gs)]
+        with torch.no_grad():
+            for p, a in zip(net.parameters(), acc):
+                p.add_(a / world, alpha=-0.1)
+        want = [float(p.detach().double().sum()) for p in net.parameters()]
+        np.testing.assert_allclose(res[0][4][step], want, rtol=1e-5)
 
 
 def test_flat_sgd_step_equals_torch_sgd():

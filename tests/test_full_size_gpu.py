@@ -91,7 +91,7 @@ def test_each_decoder_layer_900q_24cams_matches_oracle(project, monkeypatch):
             flipped = mism.any(dim=4).any(dim=3).any(dim=1)[0]                        # (Q,)
             err = (y.cpu() - y_ref).abs().amax(dim=(1, 2))          # per query row
             worst.append((int(flipped.sum()), float(err[~flipped].max()), float(err.median())))
-            assert flipped.sum().item() <= 8, (lid, worst)
+            assert flipped.sum().item() <= 2, (lid, worst)           # observed: 0 in every layer (profiles/r05_flipped_rows_offsets_exact_ab.txt)
             assert err[~flipped].max().item() < 1e-3, (lid, worst)
             assert err.median().item() < 2e-4, (lid, worst)
             assert (ref_d.cpu() - ref_next).abs().max().item() < 1e-3
@@ -154,7 +154,7 @@ def test_fused_decoder_900q_24cams_matches_oracle():
         err = (y.cpu() - y_ref).abs().amax(dim=(1, 2))                                # per query row
         rerr = (ref_d.cpu() - ref_next).abs().amax(dim=(0, 2))
         worst.append((int(flipped.sum()), float(err[~flipped].max()), float(err.median()), float(rerr[~flipped].max())))
-        assert flipped.sum().item() <= 8, (lid, worst)
+        assert flipped.sum().item() <= 2, (lid, worst)               # observed: 0 in every layer (profiles/r05_flipped_rows_offsets_exact_ab.txt)
         assert err[~flipped].max().item() < 1e-3, (lid, worst)                        # north_star: 1e-3 fp32
         assert err.median().item() < 2e-4, (lid, worst)
         assert rerr[~flipped].max().item() < 1e-3, (lid, worst)

@@ -63,12 +63,12 @@ def test_feature_position_embedding_matches_reference():
         for lvl, o in enumerate(outs):
             torch.testing.assert_close(o.cpu(), g.t(f'out{lvl}'), rtol=2e-4, atol=2e-4)
         import os
-        os.environ['GD4D_HEAD_PE'] = 'conv'               # library 1x1 convolutions
+        os.environ['GD4D_TORCH_OPS'] = '1'                # the 1x1 convolutions as torch ops
         try:
             for lvl, o in enumerate(mod(feats, _metas(g))):
                 torch.testing.assert_close(o.cpu(), g.t(f'out{lvl}'), rtol=2e-4, atol=2e-4)
         finally:
-            os.environ.pop('GD4D_HEAD_PE')
+            os.environ.pop('GD4D_TORCH_OPS')
         again = mod(feats, _metas(g))                     # second call: sine branch from the cache
     assert mod._sine_cache is not None
     for a, b in zip(outs, again):
@@ -85,7 +85,8 @@ def test_feature_position_embedding_trains(route, monkeypatch):
     hip: forward and backward on the library's own kernels (_HeadPEFunction); torch: the 1x1 convolutions as torch ops."""
     import numpy as np
     from graph_detr4d_amd import head_pe, ops
-    monkeypatch.setenv('GD4D_HEAD_PE_BWD', route)
+    if route == 'torch':
+        monkeypatch.setenv('GD4D_TORCH_OPS', '1')
     calls = []
     real = ops.gemm_tn_bf16x3
     monkeypatch.setattr(ops, 'gemm_tn_bf16x3', lambda *a, **k: (calls.append(1), real(*a, **k))[1])

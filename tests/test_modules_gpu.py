@@ -127,31 +127,20 @@ def test_transformer_decoder(name):
                 dict(GD4D_AUX_STREAM='0', GD4D_PREPROJECT='0', GD4D_QUERY_ORDER='0')):
         s2, i2, r2 = rerun(dict(env, GD4D_PROJECT='early'))
         assert torch.equal(s2, early[0]) and torch.equal(r2, early[2]) and torch.equal(i2, early[1]), env
-    # (the default loop runs on one stream with chain A and the reg / position chain as the two programs of one launch;
-    #  GD4D_SCHEDULE=aux is the three-stream schedule of the same kernels)
-    for env in (dict(GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux'), dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0'),
-                dict(GD4D_SCHEDULE='aux', GD4D_AUX_STREAM='0', GD4D_QUERY_ORDER='0'), dict(GD4D_SCHEDULE='aux', GD4D_REG_ON_AUX='0'),
-                dict(GD4D_COPY_CUS='0'), dict(GD4D_POS_ENCODER='dual'), dict(GD4D_POS_ENCODER='chaina'), dict(GD4D_POS_ENCODER='chaina', GD4D_FUSE_MHA='1'), dict(GD4D_PLAN='pairs'),
-                dict(GD4D_CHAIN_FUSE_GEMMS='0'), dict(GD4D_CHAIN_FUSE_GEMMS='0', GD4D_PLAN='pairs', GD4D_MHA_FP32='0'),
-                dict(GD4D_POS_ENCODER='dual', GD4D_PLAN='pairs'), dict(GD4D_FUSE_MHA='1'), dict(GD4D_FUSE_MHA='all', GD4D_POS_ENCODER='dual'), dict(GD4D_MHA_PRESPLIT='0')):
+    # (the default loop runs on one stream with chain A and the reg branch as the two programs of one launch, position_encoder
+    #  beside chain B' through a SIGNAL / WAIT hand-off; GD4D_POS_ENCODER=dual is the same step without hand-offs)
+    for env in (dict(GD4D_QUERY_ORDER='0'), dict(GD4D_COPY_CUS='0'), dict(GD4D_POS_ENCODER='dual'), dict(GD4D_PLAN='pairs'),
+                dict(GD4D_POS_ENCODER='dual', GD4D_PLAN='pairs')):
         s2, i2, r2 = rerun(env)
         assert torch.equal(s2, states) and torch.equal(r2, refs) and torch.equal(i2, init_ref), env
-    # value_proj of the aggregates: in the gather's epilogue (default, exact fp32), as its own launch (exact fp32 MFMA), or
-    # as chain B's first operation (split-bf16) - the same numbers within fp32-class rounding
-    for env in (dict(GD4D_SCHEDULE='aux', GD4D_CHAIN_HEADGEMM='0'), dict(GD4D_AGG_EPILOGUE='0'),
-                dict(GD4D_SCHEDULE='aux', GD4D_AGG_EPILOGUE='0')):
+    from graph_detr4d_amd import ops
+    ops.check_handoff()                                           # no SIGNAL / WAIT hand-off of the loop has timed out
+    # the attention core with fp32 MFMA products instead of split bf16, the one-workgroup-per-query aggregate kernel (value_proj
+    # in its epilogue): the same numbers within fp32-class rounding
+    for env in (dict(GD4D_MHA_FP32='1'), dict(GD4D_AGG='rows')):
         s2, i2, r2 = rerun(env)
         torch.testing.assert_close(s2, states, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(r2, refs, rtol=1e-4, atol=1e-4)
-    # the fused Linear+LayerNorm kernel sums in another order than Linear, LayerNorm: equal within fp32 rounding
-    os.environ['GD4D_ROWBLOCK'] = '0'
-    try:
-        with torch.no_grad():
-            s3, _, r3 = tr(feats, qe, reg_branches=regs, img_metas=_metas(g))
-    finally:
-        os.environ.pop('GD4D_ROWBLOCK')
-    torch.testing.assert_close(s3, states, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(r3, refs, rtol=1e-4, atol=1e-4)
     # the module-by-module path (fp32-exact MFMA products in the dense layers) against the fused decoder loop (row-chain
     # kernel, split-bf16 products): equal within fp32-class rounding, and both within 1e-3 of the reference
     os.environ['GD4D_FUSED_DECODER'] = '0'
@@ -229,7 +218,7 @@ def test_deform3d_cross_attn_mp_module(name):
 
 
 @pytest.mark.parametrize('name', ['dgcnn', 'dgcnn_k8'])
-def test_dgcnn_attn_module(name):
+def test_dgcnn_attn_module(name, monkeypatch):
     """DGCNNAttn (kNN + EdgeConv on HIP) against the reference module's forward; its training-mode torch path against
     the same fixture with the BatchNorm in eval."""
     g = Golden(name)
@@ -245,7 +234,12 @@ def test_dgcnn_attn_module(name):
     with torch.no_grad():
         out = mod(q, query_pos=qp)
     torch.testing.assert_close(out.cpu(), g.t('out'), **TOL)
-    out2 = mod(q.requires_grad_(True), query_pos=qp)         # autograd -> the torch op sequence, same numbers in eval
+    # autograd: the kernels are inference-only and there is no silent detour - a loud error that names the switch, and with
+    # GD4D_TORCH_OPS=1 the reference's op sequence as torch ops (same numbers in eval)
+    with pytest.raises(ops._lib.Gd4dError, match='GD4D_TORCH_OPS'):
+        mod(q.clone().requires_grad_(True), query_pos=qp)
+    monkeypatch.setenv('GD4D_TORCH_OPS', '1')
+    out2 = mod(q.requires_grad_(True), query_pos=qp)
     torch.testing.assert_close(out2.detach().cpu(), g.t('out'), **TOL)
     out2.sum().backward()
     assert q.grad is not None
@@ -446,7 +440,6 @@ def test_fused_decoder_sees_weight_updates(monkeypatch):
     monkeypatch.delenv('GD4D_FUSED_DECODER')
     # (e) the three Linears of query + query_pos run as ONE GEMM over a cached stack of their weights: the stack follows an
     # in-place update of one of them and a .data write to another (bracketed by the mode switches)
-    monkeypatch.setenv('GD4D_CHECK_HANDOFF', '1')                 # and no SIGNAL / WAIT hand-off of the loop may time out
     ca = tr.decoder.layers[1].attentions[1]
     with torch.no_grad():
         ca.attention_weights.weight.mul_(-1.5)
@@ -459,6 +452,7 @@ def test_fused_decoder_sees_weight_updates(monkeypatch):
     f5, g5 = both()
     assert (g5 - g4).abs().max().item() > 1e-3
     torch.testing.assert_close(f5, g5, rtol=5e-4, atol=5e-4)
+    ops.check_handoff()                                           # and no SIGNAL / WAIT hand-off of the loop has timed out
 
 
 def test_frozen_decoder_still_gives_the_feature_maps_their_gradient():

@@ -118,7 +118,8 @@ def test_default_training_backward_900q_24cams_matches_oracle_autograd(monkeypat
     out_ref, parts = O.deform3d_cross_attn(p_cpu, qc, fc, qpc, refc, metas, PC, 8, 4, return_parts=True)
     m_ref = parts['mask'].view(captured['mask'].shape).to(torch.uint8)
     flipped = (captured['mask'].cpu() != m_ref).any(dim=4).any(dim=3).any(dim=1)[0]           # (Q,)
-    assert int(flipped.sum()) <= 8, int(flipped.sum())
+    print('rows with a flipped mask bit:', int(flipped.sum()))
+    assert int(flipped.sum()) <= 2, int(flipped.sum())           # observed: 0
     keep = ~flipped
     torch.testing.assert_close(out.detach().cpu()[keep], out_ref.detach()[keep], rtol=5e-4, atol=5e-4)
     gout = gout * keep.view(q, 1, 1)

@@ -57,7 +57,10 @@ def _run(tr, g, reg, chains, monkeypatch, fuse=False, probe_seed=3, **kw):
     states, init_ref, inter_refs = tr(feats, qe, reg_branches=reg, img_metas=g.img_metas(), **kw)
     gen = torch.Generator().manual_seed(probe_seed)
     probe = torch.randn(states.shape, generator=gen).to(DEV)
-    ((states * probe).sum() + (init_ref ** 2).sum()).backward()
+    probe_r = torch.randn(inter_refs.shape, generator=gen).to(DEV)
+    # (inter_refs carries a gradient exactly when there is no refinement - and so no detach, detr3d_transformer.py:199-214:
+    #  the box loss of every level then reaches the reference points' Linear through inverse_sigmoid(inter_references))
+    ((states * probe).sum() + (init_ref ** 2).sum() + (inter_refs * probe_r).sum()).backward()
     assert len(calls) == (1 if chains else 0)
     if fuse:
         grads = {n_: Dg.clone() for n_, Dg in zip([n_ for n_, p in tr.named_parameters() if p.requires_grad],
@@ -340,32 +343,39 @@ def test_backward_after_an_in_place_weight_update_is_refused(monkeypatch):
         states.sum().backward()
 
 
-def test_side_stream_dev_switches_give_the_same_step(monkeypatch):
-    """GD4D_TRAIN_SIDE=count / GD4D_TRAIN_WGRAD_SIDE / GD4D_TRAIN_COPY_SIDE (measured slower inside a replayed hipGraph, kept as dev
-    switches): the same outputs and parameter gradients as the one-stream schedule bit for bit, the pyramid's gradient within rounding, with the
-    flat-buffer gradient path on."""
-    from graph_detr4d_amd import dist as D
+def test_without_reg_branches_the_reference_points_keep_their_gradient(monkeypatch):
+    """without reg branches the decoder returns the caller's reference points un-detached for every layer; the chain
+    path must hand back a tensor autograd can follow (its Function marks its own copies non-differentiable), so that a loss on
+    inter_references reaches the reference points' Linear exactly as on the per-module path."""
     g = Golden('decoder_deform')
     tr = _transformer(g)
-    params = [p for p in tr.parameters() if p.requires_grad]
-
-    def step():
-        red = D.FlatGradAllReducer(params)
-        red.bind(fuse_weight_grads=True)
-        red.zero_grad()
-        feats = [f.to(DEV).clone().requires_grad_() for f in g.feats()]
-        states, _, _ = tr(feats, g.t('query_embed').to(DEV), reg_branches=None, img_metas=g.img_metas())
-        (states ** 2).mean().backward()
-        torch.cuda.synchronize()
-        out = (states.detach().clone(), red.flat.clone(), [f.grad.clone() for f in feats])
-        red.unfuse()
-        return out
+    a = _run(tr, g, None, True, monkeypatch)
+    b = _run(tr, g, None, False, monkeypatch)
+    _compare(a, b)
+    ga, gb = a['params']['reference_points.weight'], b['params']['reference_points.weight']
+    assert gb.abs().max() > 0
+    torch.testing.assert_close(ga, gb, rtol=2e-3, atol=2e-3 * float(gb.abs().max()))
+    # ... and the probe on inter_references is what makes the difference visible: without it the two gradients differ from these
+    g2 = Golden('decoder_deform')
+    tr2 = _transformer(g2)
+    qe = g2.t('query_embed').to(DEV).clone().requires_grad_()
     monkeypatch.setenv('GD4D_TRAIN_CHAINS', '1')
-    base = step()
-    monkeypatch.setenv('GD4D_TRAIN_SIDE', 'count')
-    monkeypatch.setenv('GD4D_TRAIN_WGRAD_SIDE', '1')
-    monkeypatch.setenv('GD4D_TRAIN_COPY_SIDE', '1')
-    side = step()
-    assert torch.equal(base[0], side[0]) and torch.equal(base[1], side[1])
-    for a, b in zip(base[2], side[2]):          # (the records of a pixel are summed in slot order, and slots are handed out by atomics)
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+    states, init_ref, inter_refs = tr2([f.to(DEV).clone().requires_grad_() for f in g2.feats()], qe, reg_branches=None, img_metas=g2.img_metas())
+    assert inter_refs.requires_grad
+
+
+def test_the_step_without_hand_offs_is_the_same_step(monkeypatch):
+    """GD4D_TRAIN_REG_BESIDE=0 (what a device that fails the XCD placement self-test gets): the reg branch closes chain B instead of
+    running beside the next in-projection through a SIGNAL / WAIT hand-off - same outputs, same gradients, bit for bit."""
+    from graph_detr4d_amd import ops
+    g = Golden('decoder_deform')
+    tr = _transformer(g)
+    reg = _reg_branches(6)
+    a = _run(tr, g, reg, True, monkeypatch)
+    ops.check_handoff()
+    monkeypatch.setenv('GD4D_TRAIN_REG_BESIDE', '0')
+    b = _run(tr, g, reg, True, monkeypatch)
+    assert torch.equal(a['states'], b['states']) and torch.equal(a['refs'], b['refs']) and torch.equal(a['qe'], b['qe'])
+    for k in a['params']:
+        if a['params'][k] is not None:
+            assert torch.equal(a['params'][k], b['params'][k]), k

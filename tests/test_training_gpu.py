@@ -359,7 +359,8 @@ def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction
     """Decoder training, three routes to the same gradients: the raw-pyramid path (the default: plan + sliced gather forward,
     gd4d_cross_attn_sliced_bwd.hip backward, no projected value tensor), the projected-value path with value_proj's weight /
     bias gradient from the per-head aggregates (autograd.CrossAttnFunction), and the projected-value path with
-    gd4d_value_proj_bwd_weight's contraction over every pixel row (GD4D_TRAIN_VP_WGRAD=gemm)."""
+    gd4d_value_proj_bwd_weight's contraction over every pixel row (what it does when the aggregates' kernels do not apply:
+    functional.LateValues.applicable patched to say so)."""
     from oracle import torch_oracle as O
     g = Golden('decoder_deform')
     m = g.meta
@@ -381,8 +382,13 @@ def test_value_proj_weight_gradient_from_aggregates_equals_the_pixel_contraction
     probe = torch.randn(m['num_layers'], m['num_query'], 1, 256, generator=torch.Generator().manual_seed(7)).to(DEV)
 
     def grads(values, mode):
+        from graph_detr4d_amd import functional as Fn
         monkeypatch.setenv('GD4D_TRAIN_VALUES', values)
-        monkeypatch.setenv('GD4D_TRAIN_VP_WGRAD', mode)
+        real = Fn.LateValues.applicable
+        if mode == 'gemm':
+            monkeypatch.setattr(Fn.LateValues, 'applicable', staticmethod(lambda *a, **k: False))
+        else:
+            monkeypatch.setattr(Fn.LateValues, 'applicable', real)
         for p_ in tr.parameters():
             p_.grad = None
         for f in feats:
@@ -411,7 +417,8 @@ def test_detr3d_cross_atten_trains(name, route, monkeypatch):
     points, feature maps, every parameter) = autograd of the oracle (detr3d_transformer.py:352-438).  route hip: the sampling
     core on gd4d_detr3d_fwd / gd4d_detr3d_bwd (the default); torch: differentiable torch ops on the GPU."""
     from oracle import torch_oracle as O
-    monkeypatch.setenv('GD4D_DETR3D_TRAIN', route)
+    if route == 'torch':
+        monkeypatch.setenv('GD4D_TORCH_OPS', '1')
     g = Golden(name)
     m = g.meta
     mod = G.build_attention(dict(type='Detr3DCrossAtten', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=1,
@@ -489,10 +496,11 @@ def test_deform3d_cross_attn_mp_trains(name):
 def test_detr3d_cross_atten_v2_trains(name, route, monkeypatch):
     """Detr3DCrossAttenV2 with autograd on: output = the inference kernel's, gradients = autograd of the oracle
     (detr3d_transformer.py:441-710).  route 'hip': gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd behind one autograd node (the
-    default); 'torch': the same sampling as differentiable torch ops (GD4D_V2_BWD=torch; models wider than 256 channels)."""
+    default); 'torch': the same sampling as differentiable torch ops (GD4D_TORCH_OPS=1)."""
     from oracle import torch_oracle as O
     from graph_detr4d_amd import ops
-    monkeypatch.setenv('GD4D_V2_BWD', route)
+    if route == 'torch':
+        monkeypatch.setenv('GD4D_TORCH_OPS', '1')
     calls = []
     real = ops.detr3d_v2_bwd
     monkeypatch.setattr(ops, 'detr3d_v2_bwd', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
