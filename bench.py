@@ -484,42 +484,12 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
 
     front = DecoderAndHead() if a.criterion else None
     front_launch = 'eager'
-    graphs = None
-    if a.criterion and not a.no_graph:
-        # The assignment's host round trip cannot sit inside one capture of the whole step, so the part in front of it
-        # and its backward are captured as two hipGraphs sharing one memory pool; the loss (three launches and the host
-        # assignment) runs eagerly between them.  The backward is captured with torch.autograd.backward, so the
-        # accumulation into the bound .grad views is part of the graph (handing the gradients back to an eager
-        # AccumulateGrad per parameter costs ~250 cross-stream dependencies, 5 ms per step).
-        try:
-            for f in feats:
-                f.grad = None
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                     # warm-up off the default stream, as captures require
-                oc, ob = front(query_embed, *feats)
-                torch.autograd.backward((oc, ob), (torch.zeros_like(oc), torch.zeros_like(ob)))
-                del oc, ob                                    # nothing may keep the warm-up's autograd graph alive
-            torch.cuda.current_stream().wait_stream(side)
-            for f in feats:
-                f.grad = None                                 # the capture below then adopts the gradient buffers
-            # warm-up and both captures on ONE stream: the parameters' AccumulateGrad nodes then sit on the stream that
-            # produces their gradients (no cross-stream hand-offs inside the backward graph)
-            g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd, stream=side, capture_error_mode='thread_local'):
-                out_cls, out_box = front(query_embed, *feats)
-            grad_cls, grad_box = torch.zeros_like(out_cls), torch.zeros_like(out_box)
-            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), stream=side, capture_error_mode='thread_local'):
-                torch.autograd.backward((out_cls, out_box), (grad_cls, grad_box))
-            graphs = (g_fwd, g_bwd, out_cls, out_box, grad_cls, grad_box)
-            front_launch = 'hipgraph (forward), eager loss + assignment, hipgraph (backward)'
-        except Exception as e:                        # report, never hide
-            print(f'[bench] hipGraph capture of decoder + head failed ({type(e).__name__}: {e}); running eagerly',
-                  file=sys.stderr)
-            graphs = None
+    prepared = crit.prepare_ground_truth(gt_boxes, gt_labels, a.queries, dev) if a.criterion else None   # (resident ground truth: outside any capture)
 
     def criterion_loss(all_cls, all_box):
-        return sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box)).values())
+        # cost matrices, the Hungarian assignment (gd4d_hungarian_assign_fwd: on the device since round 5 - no host round trip, so
+        # the step below is ONE hipGraph) and the focal / L1 terms of every layer
+        return sum(crit.loss(gt_boxes, gt_labels, dict(all_cls_scores=all_cls, all_bbox_preds=all_box), prepared=prepared).values())
 
     from graph_detr4d_amd.criterion import instance_distill_loss
 
@@ -538,9 +508,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
 
     def step():
         reducer.zero_grad()
-        if graphs is None:                            # (captured backward: the pyramid's .grad buffers belong to the graph)
-            for f in feats:
-                f.grad = None
+        for f in feats:
+            f.grad = None
         if a.split:                                  # dev: serialised wall-clock split of the step
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if a.criterion:
@@ -559,17 +528,6 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
             torch.cuda.synchronize(); t4 = time.perf_counter()
             print(f'[split] forward {1e3 * (t1 - t0):.2f}  loss {1e3 * (t2 - t1):.2f}  backward {1e3 * (t3 - t2):.2f}  '
                   f'reduce + SGD {1e3 * (t4 - t3):.2f} ms', file=sys.stderr)
-            return
-        if a.criterion and graphs is not None:
-            g_fwd, g_bwd, out_cls, out_box, grad_cls, grad_box = graphs
-            g_fwd.replay()
-            c, b = out_cls.detach().requires_grad_(), out_box.detach().requires_grad_()
-            criterion_loss(c, b).backward()                                  # the step's one device synchronisation
-            grad_cls.copy_(c.grad)
-            grad_box.copy_(b.grad)
-            g_bwd.replay()
-            reducer.reduce()
-            sgd_step()
             return
         if distill:
             loss = distill_loss()
@@ -606,7 +564,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
         if rank == 0 and a.check:
             print(f'[check] warm step: |grad| = {float(reducer.flat.double().norm()):.9e}', file=sys.stderr)
     torch.cuda.synchronize()
-    if not a.no_graph and not a.criterion:            # the assignment's host round trip cannot sit inside a capture
+    if not a.no_graph:
         try:
             graph = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
@@ -636,6 +594,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
     elapsed = D.timed_steps(run, a.steps, a.warmup, dev, stats)
     from graph_detr4d_amd import ops as _ops
     _ops.check_handoff()                              # a hand-off that timed out inside the replayed step raises here
+    if a.criterion:
+        crit.assigner.check_status()                  # ... and so does an assignment that met a label out of range
     if rank == 0 and a.check:                                 # dev: the launch modes must train identically
         flat = reducer.flat
         psum = sum(float(p.detach().double().sum()) for p in params)

@@ -104,6 +104,8 @@ SIGNATURES = {
     'gd4d_chain_weight_image_exact_bytes': (_c.c_size_t, [_i, _i]),
     'gd4d_chain_weight_image_exact': (_i, [_vp, _i, _i, _vp, _vp]),
     'gd4d_linear_sum_assignment_batch': (_i, [_vp] * 4 + [_i, _vp, _vp, _i]),
+    'gd4d_hungarian_assign_workspace_bytes': (_c.c_size_t, [_i] * 4),
+    'gd4d_hungarian_assign_fwd': (_i, [_vp] * 5 + [_c.c_size_t] + [_i] * 5 + [_vp]),
     'gd4d_match_cost_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_f] * 3 + [_vp]),
     'gd4d_head_loss_fwd_bwd': (_i, [_vp] * 10 + [_i] * 7 + [_f] * 3 + [_vp]),
     'gd4d_linear_bwd_weight': (_i, [_vp] * 4 + [_i] * 6 + [_vp]),

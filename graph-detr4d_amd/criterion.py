@@ -73,10 +73,15 @@ class HungarianAssigner3D:
             raise NotImplementedError('FocalLossCost gamma is fixed at 2 in the kernel')
         self.pc_range = pc_range
 
-    def assign_layers(self, all_cls_scores, all_bbox_preds, gt_bboxes_list, gt_labels_list, packed=None):
+    def assign_layers(self, all_cls_scores, all_bbox_preds, gt_bboxes_list, gt_labels_list, packed=None, host=False):
         """All decoder layers and samples at once.  all_cls_scores (NL, B, Q, C), all_bbox_preds (NL, B, Q, code);
         per-sample ground truth.  Returns assigned (NL, B, Q) int32 on the device: index into the concatenated ground
-        truth (pack_ground_truth) or -1 for background.  One launch, one device -> host copy, one host -> device copy."""
+        truth (pack_ground_truth) or -1 for background.
+        Default: two launches (gd4d_match_cost_fwd, gd4d_hungarian_assign_fwd) and NO host synchronisation - the matching is
+        the host solver's, bit for bit (ties included).  A label outside [0, num_classes) - the reference's indexing raises on it
+        (core/bbox/match_costs/match_cost.py:17-30) - leaves its sample unmatched and is reported by check_status(), which the
+        next call polls without blocking (and which raises IndexError).  host=True: round 4's route (cost matrix to the host,
+        gd4d_linear_sum_assignment_batch, back) - kept as the comparison the tests make."""
         nl, b, q, _ = all_cls_scores.shape
         dev = all_cls_scores.device
         packed = packed or pack_ground_truth(gt_bboxes_list, gt_labels_list, dev)
@@ -85,11 +90,16 @@ class HungarianAssigner3D:
         boxes, labels, start_dev, start, counts = packed
         cost = ops.match_cost_fwd(all_cls_scores.detach().contiguous().float(), all_bbox_preds.detach().contiguous().float(),
                                   boxes, labels, start_dev, max(counts), self.cls_weight, self.reg_weight, self.alpha)
+        sum_gt = int(start[-1])
+        if not host:
+            self.poll_status()
+            assigned, status = ops.hungarian_assign_fwd(cost, start_dev, nl, b, q, sum_gt, max(counts))
+            self._status = (status, all_cls_scores.shape[-1])
+            return assigned
         cost = cost.cpu().numpy()                            # THE synchronisation of the step
         if np.isnan(cost).any():                             # the kernel's marker for a label outside [0, num_classes)
             raise IndexError(f'gt_labels must lie in [0, {all_cls_scores.shape[-1]}): the reference indexes '
                              'cls_pred[:, gt_labels] with them (core/bbox/match_costs/match_cost.py:17-30)')
-        sum_gt = int(start[-1])
         problems = [(q * (l * sum_gt + int(start[i])), q, counts[i]) for l in range(nl) for i in range(b)]
         # host threads pay off only when a problem is worth more than starting one (measured: 6 x (900 x 45) takes
         # 1.0 ms on one thread, 2.5 ms on six)
@@ -102,6 +112,42 @@ class HungarianAssigner3D:
                 a[a >= 0] += int(start[i])
         return torch.from_numpy(assigned).to(dev, non_blocking=True)
 
+    _status = None          # (status tensor of the last device assignment, num_classes)
+    _pending = None         # (pinned copy, event, num_classes) requested by poll_status
+
+    def check_status(self):
+        """Blocking: raises if the last device assignment met a label outside [0, num_classes) (IndexError, as the reference's
+        indexing) or an infeasible problem."""
+        if self._status is None:
+            return
+        status, ncls = self._status
+        self._status = self._pending = None
+        self._raise_for(status.cpu(), ncls)
+
+    @staticmethod
+    def _raise_for(st, ncls):
+        if bool((st == 1).any()):
+            raise IndexError(f'gt_labels must lie in [0, {ncls}): the reference indexes cls_pred[:, gt_labels] with them '
+                             '(core/bbox/match_costs/match_cost.py:17-30)')
+        if bool((st == 2).any()):
+            raise ops._lib.Gd4dError('gd4d_hungarian_assign_fwd: an assignment problem was infeasible')
+
+    def poll_status(self):
+        """Non-blocking: looks at the copy of the previous call's status if it has arrived, requests one of the current."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._pending is not None and self._pending[1].query():
+            pinned, _, ncls = self._pending
+            self._pending = None
+            self._raise_for(pinned, ncls)
+        if self._pending is None and self._status is not None:
+            status, ncls = self._status
+            pinned = torch.empty(status.shape, dtype=status.dtype).pin_memory()
+            pinned.copy_(status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (pinned, ev, ncls)
+
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_bboxes_ignore=None, eps=1e-7):
         """The reference's per-layer, per-sample entry point (:62-144): gt_inds 0 = background, g + 1 = matched."""
         assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
@@ -113,6 +159,7 @@ class HungarianAssigner3D:
                 gt_inds[:] = 0
             return AssignResult(num_gts, gt_inds, None, labels=lab)
         a = self.assign_layers(cls_pred[None, None], bbox_pred[None, None], [gt_bboxes], [gt_labels])[0, 0].long()
+        self.check_status()                                              # (the reference's entry point raises where it stands)
         gt_inds = a + 1                                                  # -1 -> 0 background, g -> g + 1
         pos = a >= 0
         lab[pos] = gt_labels[a[pos]].long()
@@ -178,17 +225,22 @@ class Detr3DCriterion(nn.Module):
                 avg[0] = local_cls
         return avg
 
-    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
+    def prepare_ground_truth(self, gt_bboxes_list, gt_labels_list, num_query, device):
+        """What `loss` derives from the ground truth alone - the packed boxes / labels / offsets on the device and the two
+        normalisers - as one object to hand back to it (`prepared=`): a step whose ground truth is resident (a captured hipGraph
+        cannot contain the host -> device copies) computes it once, outside the capture."""
+        gts = [gt_tensor(g) for g in gt_bboxes_list]
+        packed = pack_ground_truth(gts, gt_labels_list, device)
+        return gts, packed, self.normalisers([int(g.shape[0]) for g in gts], num_query, device)
+
+    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None, prepared=None):
         assert gt_bboxes_ignore is None, f'{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None.'
         if preds_dicts.get('enc_cls_scores') is not None:
             raise NotImplementedError('two-stage proposals are not used by the shipped configs')
         cls, box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
         nl, b, q, c = cls.shape
         dev = cls.device
-        gts = [gt_tensor(g) for g in gt_bboxes_list]
-        packed = pack_ground_truth(gts, gt_labels_list, dev)
-        counts = [int(g.shape[0]) for g in gts]
-        avg = self.normalisers(counts, q, dev)
+        gts, packed, avg = prepared if prepared is not None else self.prepare_ground_truth(gt_bboxes_list, gt_labels_list, q, dev)
         if packed is None:                                   # no ground truth anywhere: every query is background
             boxes = torch.ones(1, 9, device=dev)
             labels = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_apply_kernel(float* __restr
     if (max_norm > 0.f) coef = fminf(1.f, max_norm / (norm + 1e-6f));         // clip_grad_norm_'s clamp
     const float step = state[0];
     s_coef = coef;
-    s_c1 = lr / (1.f - powf(b1, step));
-    s_c2 = 1.f / sqrtf(1.f - powf(b2, step));
+    s_c1 = (float)((double)lr / (1.0 - pow((double)b1, (double)step)));     // (bias corrections in double, as torch's host code)
+    s_c2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)step)));
     if (blockIdx.x == 0) state[1] = norm;                                     // (for the host: the norm before clipping)
   }
   __syncthreads();

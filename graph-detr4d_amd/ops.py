@@ -1574,6 +1574,27 @@ def linear_sum_assignment_batch(cost, problems, num_threads=8):
     return [out[out_off[i]:out_off[i + 1]] for i in range(n)]
 
 
+def hungarian_assign_fwd(cost, gt_start, nl, b, q, sum_gt, max_gt, assigned=None, status=None, workspace=None):
+    """gd4d_hungarian_assign_fwd: the assignment of every (layer, sample) block of match_cost_fwd's buffer on the device.  Returns
+    (assigned (NL, B, Q) int32: index into the packed ground truth or -1, status (NL * B) int32: 0 solved / 1 NaN cost (bad label) /
+    2 infeasible).  No host synchronisation."""
+    lib = _lib.load()
+    dev = cost.device
+    i32 = torch.int32
+    if assigned is None:
+        assigned = torch.empty(nl, b, q, device=dev, dtype=i32)
+    if status is None:
+        status = torch.empty(nl * b, device=dev, dtype=i32)
+    nbytes = int(lib.gd4d_hungarian_assign_workspace_bytes(nl, b, q, max(int(max_gt), 1)))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    code = lib.gd4d_hungarian_assign_fwd(_dev(cost, 'cost', torch.float32), _dev(gt_start, 'gt_start', i32), _dev(assigned, 'assigned', i32),
+                                         _dev(status, 'status', i32), _dev(workspace, 'workspace', torch.uint8), workspace.numel(),
+                                         int(nl), int(b), int(q), int(sum_gt), int(max_gt), _stream())
+    _lib.check(code, 'gd4d_hungarian_assign_fwd')
+    return assigned, status
+
+
 class ChainOp(ctypes.Structure):
     """gd4d_chain_op (include/gd4d.h)."""
     _fields_ = [('kind', ctypes.c_int32), ('src', ctypes.c_int32), ('dst', ctypes.c_int32), ('res', ctypes.c_int32),

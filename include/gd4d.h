@@ -970,6 +970,21 @@ int gd4d_linear_sum_assignment_batch(const float* cost, const int64_t* cost_offs
                                      const int32_t* cols, int num_problems, int32_t* col_of_row,
                                      const int64_t* out_offset, int num_threads);
 
+/* gd4d_hungarian_assign_fwd - the same assignment ON THE DEVICE: HungarianAssigner3D.assign's matching
+ * (core/bbox/assigners/hungarian_assigner_3d.py:120-131: nan_to_num - done by gd4d_match_cost_fwd -, linear_sum_assignment, the scatter
+ * of :140-144) for every (decoder layer, sample) of a step in one launch, so that the step's loss needs no device -> host copy
+ * (dense_heads/detr3d_head_pe.py:822-836 calls the assigner once per layer and sample).  cost: gd4d_match_cost_fwd's buffer (block
+ * (l, b) at Q (l sum_gt + gt_start[b]), (Q, G_b) row-major); gt_start (B + 1) on the device; assigned (NL, B, Q) receives the index
+ * into the packed ground truth (gt_start[b] + column) of a matched prediction, -1 otherwise; status (NL * B): 0 = solved, 1 = the
+ * block holds a NaN (a label outside [0, classes): gd4d_match_cost_fwd's marker - everything stays -1; the host raises when it
+ * looks), 2 = infeasible / more boxes than max_gt.  One workgroup per problem; one wave runs the shortest-augmenting-path solver of
+ * gd4d_linear_sum_assignment_batch operation for operation in fp64, its scan spread over the lanes with an arg-min that reproduces
+ * the sequential scan's choice (ties included): the matching is IDENTICAL to the host solver's.  workspace:
+ * gd4d_hungarian_assign_workspace_bytes (a double copy of every problem, the shorter side as rows); max(Q, max_gt) <= ~4800 (LDS). */
+size_t gd4d_hungarian_assign_workspace_bytes(int NL, int B, int Q, int max_gt);
+int gd4d_hungarian_assign_fwd(const float* cost, const int32_t* gt_start, int32_t* assigned, int32_t* status, void* workspace,
+                              size_t workspace_bytes, int NL, int B, int Q, int sum_gt, int max_gt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

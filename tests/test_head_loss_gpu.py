@@ -189,3 +189,131 @@ def test_no_ground_truth_at_all():
     r = HungarianAssigner3D(cls_cost=dict(type='FocalLossCost', weight=2.0), reg_cost=dict(type='BBox3DL1Cost', weight=0.25)) \
         .assign(box[0, 0].detach(), cls[0, 0].detach(), gt.cuda(), lab.cuda())
     assert r.num_gts == 0 and int(r.gt_inds.abs().sum()) == 0
+
+
+def _solve_both(cost_blocks, q):
+    """cost_blocks: list of (Q, G_b) float32 CPU tensors, one per sample (one layer).  Returns (device assignment, host
+    assignment) as lists of (Q,) int64 with the per-sample column or -1, and the device status."""
+    import numpy as np
+    from graph_detr4d_amd import ops
+    counts = [int(c.shape[1]) for c in cost_blocks]
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    sum_gt = int(start[-1])
+    flat = torch.cat([c.contiguous().reshape(-1) for c in cost_blocks]) if sum_gt else torch.zeros(1)
+    b = len(cost_blocks)
+    assigned, status = ops.hungarian_assign_fwd(flat.cuda(), torch.from_numpy(start).cuda(), 1, b, q, sum_gt, max(counts + [0]))
+    problems = [(q * int(start[i]), q, counts[i]) for i in range(b)]
+    host = ops.linear_sum_assignment_batch(flat.numpy(), problems, num_threads=1)
+    dev = assigned[0].cpu().long()
+    dev_cols = [torch.where(dev[i] >= 0, dev[i] - int(start[i]), dev[i]) for i in range(b)]
+    return dev_cols, [torch.from_numpy(np.asarray(h)).long() for h in host], status.cpu()
+
+
+def test_device_assignment_equals_the_host_solver_on_a_thousand_problems():
+    """gd4d_hungarian_assign_fwd against gd4d_linear_sum_assignment_batch (the scipy algorithm) - index work, so
+    BIT-EXACT: 1000 random problems of 900 predictions x 0..100 boxes, in batches of 50 samples per launch; costs with the
+    nan_to_num clamps (+-100) in them, with exact ties (costs rounded to a coarse grid, duplicated boxes, all-equal blocks)."""
+    import numpy as np
+    rng = np.random.default_rng(42)
+    q = 900
+    total = 0
+    for batch in range(20):
+        blocks = []
+        for k in range(50):
+            g = int(rng.integers(0, 101))
+            kind = (batch * 50 + k) % 5
+            c = rng.normal(0, 3, (q, g)).astype(np.float32)
+            if kind == 1:                                   # coarse grid: many exact ties
+                c = np.round(c * 2) / 2
+            elif kind == 2 and g:                           # clamps: +100 / -100 entries (nan_to_num), whole clamped columns
+                m = rng.random((q, g))
+                c[m < 0.05] = 100.0
+                c[m > 0.99] = -100.0
+                c[:, rng.integers(0, g)] = 100.0
+            elif kind == 3 and g > 1:                       # duplicated boxes: identical columns
+                c[:, 1::2] = c[:, 0:-1:2][:, :c[:, 1::2].shape[1]]
+            elif kind == 4:                                 # a constant block: everything ties
+                c[:] = 1.5
+            blocks.append(torch.from_numpy(np.ascontiguousarray(c)))
+        dev, host, status = _solve_both(blocks, q)
+        assert int(status.abs().sum()) == 0
+        for d, h, blk in zip(dev, host, blocks):
+            assert torch.equal(d, h), f'batch {batch}: device and host matchings differ ({blk.shape})'
+            g = blk.shape[1]
+            assert int((d >= 0).sum()) == min(g, q) and (g == 0 or sorted(d[d >= 0].tolist()) == list(range(g)))
+            total += 1
+    assert total == 1000
+
+
+@pytest.mark.parametrize('q,g', [(7, 30), (64, 64), (1, 5), (5, 1), (130, 129), (2700, 60)])
+def test_device_assignment_other_shapes(q, g):
+    """More boxes than predictions (the untransposed orientation), square problems, H-DETR's 2700 queries; a NaN block is reported
+    (status 1, nothing matched) - the marker gd4d_match_cost_fwd leaves for a label outside [0, classes)."""
+    import numpy as np
+    rng = np.random.default_rng(q * 1000 + g)
+    blocks = [torch.from_numpy(np.round(rng.normal(0, 2, (q, g)).astype(np.float32) * 4) / 4) for _ in range(3)]
+    dev, host, status = _solve_both(blocks, q)
+    assert int(status.abs().sum()) == 0
+    for d, h in zip(dev, host):
+        assert torch.equal(d, h)
+    bad = [b.clone() for b in blocks]
+    bad[1][q // 2, g // 2] = float('nan')
+    dev, _, status = _solve_both(bad, q)
+    assert status.tolist() == [0, 1, 0] and int((dev[1] >= 0).sum()) == 0 and torch.equal(dev[0], host[0]) and torch.equal(dev[2], host[2])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_device_assigner_equals_the_host_route_on_the_reference_fixtures(name):
+    """assign_layers (device route, the default) == assign_layers(host=True) on the reference's own head-loss fixtures."""
+    from graph_detr4d_amd import HungarianAssigner3D
+    g = Golden(name)
+    cls, box = g.t('all_cls_scores').cuda(), g.t('all_bbox_preds').cuda()
+    boxes, labels = _gt(g)
+    asg = HungarianAssigner3D(cls_cost=dict(type='FocalLossCost', weight=2.0), reg_cost=dict(type='BBox3DL1Cost', weight=0.25),
+                              iou_cost=dict(type='IoUCost', weight=0.0), pc_range=g.meta['pc_range'])
+    a_dev = asg.assign_layers(cls, box, boxes, labels)
+    asg.check_status()
+    a_host = asg.assign_layers(cls, box, boxes, labels, host=True)
+    assert torch.equal(a_dev.cpu(), a_host.cpu())
+
+
+def test_a_label_out_of_range_raises_on_the_device_route_too():
+    from graph_detr4d_amd import HungarianAssigner3D
+    torch.manual_seed(0)
+    cls, box = torch.randn(2, 1, 20, 10).cuda(), torch.randn(2, 1, 20, 10).cuda()
+    gt = torch.randn(3, 9)
+    gt[:, 3:6] = gt[:, 3:6].abs() + 0.3
+    asg = HungarianAssigner3D(cls_cost=dict(type='FocalLossCost', weight=2.0), reg_cost=dict(type='BBox3DL1Cost', weight=0.25))
+    a = asg.assign_layers(cls, box, [gt.cuda()], [torch.tensor([1, 12, 3]).cuda()])
+    assert int((a >= 0).sum()) == 0
+    with pytest.raises(IndexError):
+        asg.check_status()
+    with pytest.raises(IndexError):
+        asg.assign(box[0, 0], cls[0, 0], gt.cuda(), torch.tensor([1, 12, 3]).cuda())
+
+
+def test_flat_adamw_with_clipping_equals_torch():
+    """dist.FlatGradAllReducer.adamw_step (gd4d_adamw_flat: clip_grad_norm_(35) + AdamW lr 2e-4 wd 0.01, the reference's recipe,
+    ...ceph.py:205-213) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over five steps, with gradients large enough
+    for the clip to bite and small enough not to; the norm it reports = torch's."""
+    import copy
+    from graph_detr4d_amd import dist as D
+    torch.manual_seed(0)
+    # (no normalisation after the last Linear: sum(LayerNorm(.)^2) is a constant, its gradient rounding noise that Adam would amplify)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.LayerNorm(96), torch.nn.ReLU(), torch.nn.Linear(96, 33)).cuda()
+    ref = copy.deepcopy(net)
+    red = D.FlatGradAllReducer(list(net.parameters()), align=4)
+    red.bind()
+    opt = torch.optim.AdamW(ref.parameters(), lr=2e-4, weight_decay=0.01)
+    for step in range(5):
+        x = torch.randn(16, 64, device='cuda') * (300.0 if step % 2 == 0 else 0.01)
+        red.zero_grad()
+        opt.zero_grad()
+        net(x).square().sum().backward()
+        ref(x).square().sum().backward()
+        want_norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 35.0)
+        opt.step()
+        red.adamw_step(lr=2e-4, weight_decay=0.01, max_norm=35.0)
+        torch.testing.assert_close(red.last_grad_norm, want_norm, rtol=1e-5, atol=0)
+        for p, r in zip(net.parameters(), ref.parameters()):
+            torch.testing.assert_close(p, r, rtol=1e-5, atol=2e-7)
