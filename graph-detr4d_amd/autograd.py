@@ -76,6 +76,42 @@ class CrossAttnFunction(torch.autograd.Function):
         return gv, gr, go, ga.view_as(attn_logits), gc, None, None, None, None, None, None, gw, gb, None
 
 
+class BoxHeadFunction(torch.autograd.Function):
+    """bbox_preds of ALL decoder layers from the reg branches' raw outputs (dense_heads/detr3d_head_pe.py:585-605): columns 0, 1, 4 of
+    tmp (.., code) get inverse_sigmoid(reference) added, a sigmoid, the point-cloud range and the depth factor; the others pass.
+    forward: gd4d_box_head_fwd on the stacked layers (one launch); backward: a handful of elementwise ops on the same stack -
+    the per-layer torch-op epilogue was ~50 launches per layer and step with autograd on.  The reference points carry a gradient
+    only where they are not detached (layer 0's `init_reference`; every layer without refinement)."""
+
+    @staticmethod
+    def forward(ctx, tmp, ref, pc_range, scale):
+        out = ops.box_head_fwd(tmp.contiguous(), ref.contiguous(), pc_range, scale)
+        ctx.save_for_backward(out, ref)
+        ctx.pc_range, ctx.scale = [float(v) for v in pc_range], float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, ref = ctx.saved_tensors
+        cols = (0, 1, 4)
+        gt = g.clone()
+        ds = []
+        for i, col in enumerate(cols):                                       # (python scalars only: no host -> device copy inside a capture)
+            span = (ctx.pc_range[3 + i] - ctx.pc_range[i]) * ctx.scale
+            s = (out[..., col] - ctx.pc_range[i] * ctx.scale) / span         # the sigmoid's value
+            ds.append(g[..., col] * (span * (s * (1.0 - s))))
+            gt[..., col] = ds[-1]
+        d = torch.stack(ds, dim=-1)
+        gref = None
+        if ctx.needs_input_grad[1]:
+            eps = 1e-5                                                       # inverse_sigmoid (deform3d_cross_attn.py:16-31): clamp to [0, 1],
+            inside = (ref >= 0) & (ref <= 1)                                 # log(max(x, eps) / max(1 - x, eps))
+            dinv = torch.where(ref > eps, 1.0 / ref.clamp(min=eps), torch.zeros_like(ref)) + \
+                torch.where((1.0 - ref) > eps, 1.0 / (1.0 - ref).clamp(min=eps), torch.zeros_like(ref))
+            gref = torch.where(inside, d * dinv, torch.zeros_like(ref))
+        return gt, gref, None, None
+
+
 class RawPyramid:
     """What the layers of one training step share on the raw-pyramid path: the slice-planar copy (PyramidView) and the sink
     that turns the layers' (pixel, weight, grad_agg row) records into the pyramid's gradient (ops.PyramidGrad), plus the
@@ -107,7 +143,7 @@ class RawPyramid:
 
     def _sink_for(self, layer, plan):
         if self.sink is None:
-            self.sink = ops.PyramidGrad(self.pyramid, 0, plan.b, plan.q, plan.num_heads)
+            self.sink = ops.PyramidGrad(self.pyramid, 0, plan.b, plan.q, plan.num_heads, points=plan.points)
         if (plan.b, plan.num_heads) != (self.sink.b, self.sink.hh) or self.layer_q[layer] != plan.q:
             raise ops._lib.Gd4dError(f'RawPyramid: layer {layer} registered with {self.layer_q[layer]} queries hands in a plan of '
                                      f'(B, Q, Hh) = ({plan.b}, {plan.q}, {plan.num_heads}); the sink has B = {self.sink.b}, Hh = {self.sink.hh}')
@@ -259,7 +295,7 @@ class CrossAttnRawFunction(torch.autograd.Function):
                                               grad_agg=raw.sink.grad_agg_rows(ctx.layer) if want_pyramid else None)
         raw.layer_done()
         n = plan.pyramid.rows // b
-        dpart = ops.cross_attn_dot_sliced(plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(b, n, q, hh)))
+        dpart = ops.cross_attn_dot_sliced(plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(b, n, q, hh, plan.points)))
         gr, go, ga, gc = ops.cross_attn_plan_bwd(plan, dpart, beta, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
                                                  img_h, img_w, raw_cam_weights=raw_cam)
         gw = gb = None

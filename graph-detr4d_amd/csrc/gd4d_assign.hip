@@ -125,8 +125,9 @@ extern "C" int gd4d_linear_sum_assignment_batch(const float* cost, const int64_t
 // gd4d_hungarian_assign_fwd: the same solver ON THE DEVICE (round 5) - the assignment of a training step no
 // longer leaves the GPU (no device -> host copy of the cost matrix, no host solve, no copy back: the `--criterion` step is one
 // graph).  One workgroup per (decoder layer, sample) problem: all threads turn the problem's (Q, G) float block of
-// gd4d_match_cost_fwd into a double matrix with the shorter side as rows (what lsa_problem does), then ONE WAVE runs lsa_solve
-// above, operation for operation in double - the scan over the remaining columns spread over the 64 lanes, its arg-min as a
+// gd4d_match_cost_fwd into a double matrix with the shorter side as rows (what lsa_problem does), then run lsa_solve above,
+// operation for operation in double - the scan over the remaining columns spread over the workgroup's 256 threads (a first version
+// gave it to one wave: 266 us for six 900 x 40 problems, bound by the scan's dependent round trips), its arg-min as a
 // reduction that reproduces the sequential scan's choice exactly:
 //     sequential:  a candidate replaces the best so far if it is shorter, or equally short and its column is unassigned
 //     => the winner is, among the positions of minimal length, the LAST one whose column is unassigned if there is one,
@@ -196,60 +197,86 @@ __global__ __launch_bounds__(HA_THREADS) void hungarian_assign_kernel(const HaPa
   __threadfence_block();
   __syncthreads();
   if (s_nan) { if (tid == 0) p.status[prob] = 1; return; }
-  if (tid >= 64) return;                                                     // one wave solves
+  // ---- the solver: every thread of the workgroup walks the same control flow; the scan over the remaining columns is spread over
+  // all of them (at 900 columns: <= 4 per thread, their cost loads in flight together), its arg-min meets through LDS ----
+  __shared__ double s_low[HA_THREADS / 64];
+  __shared__ int s_pun[HA_THREADS / 64], s_pfirst[HA_THREADS / 64];
+  const int wave = tid >> 6;
   const double inf = __builtin_inf();
   bool ok = true;
   for (int cur = 0; cur < nr && ok; ++cur) {
-    for (int j = lane; j < nc; j += 64) { remaining[j] = nc - j - 1; SC[j] = 0; shortest[j] = inf; }
-    for (int r = lane; r < nr; r += 64) SR[r] = 0;
-    ha_wave_sync();
+    for (int j = tid; j < nc; j += HA_THREADS) { remaining[j] = nc - j - 1; SC[j] = 0; shortest[j] = inf; }
+    for (int r = tid; r < nr; r += HA_THREADS) SR[r] = 0;
+    __syncthreads();
     double min_val = 0.0;
     int i = cur, sink = -1, num_remaining = nc;
     while (sink == -1) {
-      if (lane == 0) SR[i] = 1;
+      if (tid == 0) SR[i] = 1;
       const double ui = u[i];
       const double* ci = m + (size_t)i * nc;
       double lowest = inf;
       int pos_un = -1, pos_first = 0x7fffffff;
-      for (int it = lane; it < num_remaining; it += 64) {
-        const int j = remaining[it];
-        const double r = ((min_val + ci[j]) - ui) - v[j];
-        double sj = shortest[j];
-        if (r < sj) { path[j] = i; shortest[j] = r; sj = r; }
-        const bool un = row4col[j] == -1;
-        if (sj < lowest) { lowest = sj; pos_first = it; pos_un = un ? it : -1; }
-        else if (sj == lowest) { if (un) pos_un = it; if (it < pos_first) pos_first = it; }
-      }
-      double gmin = lowest;
+      // (the row's costs come from global memory - L2 hits of ~1 us each if taken one by one: four positions' loads go out
+      //  together, then the four are worked through in position order)
+      for (int it0 = tid; it0 < num_remaining; it0 += HA_THREADS * 4) {
+        int js[4];
+        double cs[4];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { const double t = ha_shfl_xor(gmin, o); gmin = t < gmin ? t : gmin; }
-      if (!(lowest == gmin)) { pos_un = -1; pos_first = 0x7fffffff; }       // (an idle lane holds inf: it takes part only when gmin is inf)
-      if (lane >= num_remaining && gmin == inf) { pos_un = -1; pos_first = 0x7fffffff; }
+        for (int k = 0; k < 4; ++k) js[k] = remaining[min(it0 + HA_THREADS * k, num_remaining - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs[k] = ci[js[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int it = it0 + HA_THREADS * k;
+          if (it >= num_remaining) break;
+          const int j = js[k];
+          const double r = ((min_val + cs[k]) - ui) - v[j];
+          double sj = shortest[j];
+          if (r < sj) { path[j] = i; shortest[j] = r; sj = r; }
+          const bool un = row4col[j] == -1;
+          if (sj < lowest) { lowest = sj; pos_first = it; pos_un = un ? it : -1; }
+          else if (sj == lowest) { if (un) pos_un = it; if (it < pos_first) pos_first = it; }
+        }
+      }
+      double wmin = lowest;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const double t = ha_shfl_xor(wmin, o); wmin = t < wmin ? t : wmin; }
+      if (lane == 0) s_low[wave] = wmin;
+      __syncthreads();
+      double gmin = s_low[0];
+#pragma unroll
+      for (int w = 1; w < HA_THREADS / 64; ++w) gmin = s_low[w] < gmin ? s_low[w] : gmin;
+      if (!(lowest == gmin) || tid >= num_remaining) { pos_un = -1; pos_first = 0x7fffffff; }   // (threads without a position hold inf)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         pos_un = max(pos_un, __shfl_xor(pos_un, o));
         pos_first = min(pos_first, __shfl_xor(pos_first, o));
       }
+      if (lane == 0) { s_pun[wave] = pos_un; s_pfirst[wave] = pos_first; }
+      __syncthreads();
+      pos_un = s_pun[0]; pos_first = s_pfirst[0];
+#pragma unroll
+      for (int w = 1; w < HA_THREADS / 64; ++w) { pos_un = max(pos_un, s_pun[w]); pos_first = min(pos_first, s_pfirst[w]); }
       min_val = gmin;
       if (min_val == inf) { ok = false; break; }                            // infeasible (cannot happen after nan_to_num)
       const int index = pos_un >= 0 ? pos_un : pos_first;
       const int j = remaining[index];
       const int rj = row4col[j];
       const int last = remaining[num_remaining - 1];
-      ha_wave_sync();                                                        // every lane has read before lane 0 rewrites
+      __syncthreads();                                                       // every thread has read before thread 0 rewrites
       if (rj == -1) sink = j; else i = rj;
       --num_remaining;
-      if (lane == 0) { SC[j] = 1; remaining[index] = last; }
-      ha_wave_sync();
+      if (tid == 0) { SC[j] = 1; remaining[index] = last; }
+      __syncthreads();
     }
     if (!ok) break;
     // dual update
-    for (int r = lane; r < nr; r += 64)
+    for (int r = tid; r < nr; r += HA_THREADS)
       if (SR[r] && r != cur) u[r] += min_val - shortest[col4row[r]];
-    for (int j = lane; j < nc; j += 64)
+    for (int j = tid; j < nc; j += HA_THREADS)
       if (SC[j]) v[j] -= min_val - shortest[j];
-    ha_wave_sync();
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0) {
       u[cur] += min_val;
       int j = sink;                                                          // augment along the path
       while (true) {
@@ -259,14 +286,14 @@ __global__ __launch_bounds__(HA_THREADS) void hungarian_assign_kernel(const HaPa
         if (r == cur) break;
       }
     }
-    ha_wave_sync();
+    __syncthreads();
   }
-  if (!ok) { if (lane == 0) p.status[prob] = 2; return; }
-  for (int r = lane; r < nr; r += 64) {
+  if (!ok) { if (tid == 0) p.status[prob] = 2; return; }
+  for (int r = tid; r < nr; r += HA_THREADS) {
     if (transposed) out[col4row[r]] = r + g0;                                // row = box r, its column = the prediction
     else out[r] = col4row[r] + g0;
   }
-  if (lane == 0) p.status[prob] = 0;
+  if (tid == 0) p.status[prob] = 0;
 }
 
 }  // namespace gd4d

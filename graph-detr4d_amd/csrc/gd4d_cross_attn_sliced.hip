@@ -941,7 +941,7 @@ extern "C" int gd4d_cross_attn_agg_items_count_fwd(const void* const* level_ptrs
   using namespace gd4d;
   if (!plan_pairs || !count || !slots || !level_hw || !cam_stride_bytes) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
-  if (P != kPoints || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if ((P != kPoints && P != 8) || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
   if (slots_bytes < (size_t)B * Q * Hh * plan_cap_t(N, P) * 64 * sizeof(uint2)) return GD4D_EWORKSPACE;
   CountArgs ca{};
   if (int rc = fill_chunks(ca.g, level_hw, cam_stride_bytes, pix_stride_bytes, B * N, L)) return rc;

@@ -349,10 +349,14 @@ struct PlanBwdParams {
   int* status;              // optional: set to 1 when an item count disagrees with the plan (cannot happen: tested)
 };
 
-template <int HH, int LT, int WAVES, bool BMULTI>
+// PT = sampling points per head: 4 (every shipped config) or 8 (8 heads; what num_points 5 .. 8 are padded to - the reference's
+// constructor default is 5, deform3d_cross_attn.py:56: padded points carry a NaN offset, so they are never visible, and a -inf
+// logit, so their softmax weight is exactly 0)
+template <int HH, int LT, int WAVES, bool BMULTI, int PT = kPoints>
 __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_bwd_kernel(const PlanBwdParams pp) {
   const CrossAttnParams& p = pp.c;
-  constexpr int PT = kPoints, E = HH * PT, LP = LT * PT, THREADS = 64 * WAVES;
+  constexpr int E = HH * PT, LP = LT * PT, THREADS = 64 * WAVES;
+  static_assert(LP <= GD4D_WAVE && PT * 3 <= GD4D_WAVE, "a lane per logit / per offset component");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int ncand = p.N * PT;
   float2* s_uv = reinterpret_cast<float2*>(smem_raw);                        // [N][E]; x < 0: not visible
@@ -537,14 +541,14 @@ __global__ __launch_bounds__(64 * WAVES) void cross_attn_plan_bwd_kernel(const P
           pp.ga_part[((((size_t)b * p.B + cls) * p.Q + q) * HH + h) * LP + i] = tot;
         }
       }
-      if (lane >= 16 && lane < 16 + PT * 3) {
-        const int kk = (lane - 16) / 3, dd = (lane - 16) % 3;
+      if (lane < PT * 3) {
+        const int kk = lane / 3, dd = lane % 3;
         float tot = 0.f;
         for (int n = 0; n < p.N; ++n) tot += gpt_w[(n * PT + kk) * 4 + dd];
-        pp.grad_offsets[((size_t)bq * HH + h) * PT * 3 + (lane - 16)] = tot;
+        pp.grad_offsets[((size_t)bq * HH + h) * PT * 3 + lane] = tot;
       }
-      if (lane >= 32 && lane < 35) {
-        const int dd = lane - 32;
+      if (lane >= 61) {
+        const int dd = lane - 61;
         float tot = 0.f;
         for (int kk = 0; kk < PT; ++kk) {
           float t = 0.f;
@@ -986,7 +990,7 @@ static int dot_sliced_impl(const void* const* level_ptrs, int64_t slice_stride_b
   using namespace gd4d;
   if (!level_ptrs || !plan || !grad_agg || !dpart) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
-  if (C != kChannels || P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if (C != kChannels || (P != kPoints && P != 8) || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;    // (P only sizes the plan)
   if (feats_dtype != GD4D_F32 && feats_dtype != GD4D_BF16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
   const int es = feats_dtype == GD4D_BF16 ? 2 : 4;
@@ -1069,7 +1073,7 @@ extern "C" int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, 
       !grad_offsets || !grad_attn_logits || !grad_cam_logits)
     return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0 || !(img_h > 0.f) || !(img_w > 0.f)) return GD4D_EINVAL;
-  if (P != kPoints || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
+  if ((P != kPoints && !(P == 8 && Hh == 8)) || L > 4 || N > 64 || B > 16) return GD4D_EUNSUPPORTED;
   if (Hh != 4 && Hh != 8 && Hh != 16) return GD4D_EUNSUPPORTED;
   const size_t need = B > 1 ? (size_t)B * B * Q * Hh * L * P * sizeof(float) : 0;
   if (B > 1 && (!workspace || workspace_bytes < need)) return GD4D_EWORKSPACE;
@@ -1097,10 +1101,10 @@ extern "C" int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, 
   pp.grad_ref = grad_ref; pp.grad_offsets = grad_offsets; pp.grad_attn_logits = grad_attn_logits;
   pp.grad_cam_logits = grad_cam_logits; pp.ga_part = static_cast<float*>(workspace); pp.status = status;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int ncand = N * kPoints;
+  const int ncand = N * P;
   auto lds = [&](int LT, int waves) {
-    return (size_t)N * Hh * kPoints * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
-           (size_t)((B * Hh * LT * kPoints + 3) & ~3) * sizeof(float) + (size_t)Hh * kPoints * 4 * sizeof(float) +
+    return (size_t)N * Hh * P * sizeof(float2) + (size_t)N * 12 * sizeof(float) + (size_t)((N + 3) & ~3) * sizeof(float) +
+           (size_t)((B * Hh * LT * P + 3) & ~3) * sizeof(float) + (size_t)Hh * P * 4 * sizeof(float) +
            (size_t)waves * ncand * (sizeof(float4) + 8 * sizeof(float)) + (size_t)Hh * ncand * sizeof(float) + (size_t)Hh * 4 * sizeof(float);
   };
   auto go = [&](auto kern, int waves, size_t bytes) -> int {
@@ -1110,26 +1114,27 @@ extern "C" int gd4d_cross_attn_plan_bwd(const float* ref, const float* offsets, 
     return check_launch();
   };
   int rc;
-#define GD4D_PB_GO(HH_, LT_)                                                                                                   \
-  rc = B > 1 ? go(cross_attn_plan_bwd_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8), true>, (HH_ < 8 ? HH_ : 8), lds(LT_, (HH_ < 8 ? HH_ : 8)))   \
-             : go(cross_attn_plan_bwd_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8), false>, (HH_ < 8 ? HH_ : 8), lds(LT_, (HH_ < 8 ? HH_ : 8))); \
+#define GD4D_PB_GO(HH_, LT_, PT_)                                                                                              \
+  rc = B > 1 ? go(cross_attn_plan_bwd_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8), true, PT_>, (HH_ < 8 ? HH_ : 8), lds(LT_, (HH_ < 8 ? HH_ : 8)))   \
+             : go(cross_attn_plan_bwd_kernel<HH_, LT_, (HH_ < 8 ? HH_ : 8), false, PT_>, (HH_ < 8 ? HH_ : 8), lds(LT_, (HH_ < 8 ? HH_ : 8))); \
   if (rc == GD4D_OK && B > 1) {                                                                                                \
-    hipLaunchKernelGGL((plan_bwd_logits_kernel<LT_ * kPoints>), dim3(B * Q), dim3(64), 0, s, pp.ga_part, attn_logits,          \
+    hipLaunchKernelGGL((plan_bwd_logits_kernel<LT_ * PT_>), dim3(B * Q), dim3(64), 0, s, pp.ga_part, attn_logits,              \
                        grad_attn_logits, B, Q, Hh);                                                                            \
     rc = check_launch();                                                                                                       \
   }                                                                                                                            \
   return rc;
-#define GD4D_PB_L(HH_)                     \
+#define GD4D_PB_L(HH_, PT_)                \
   switch (L) {                             \
-    case 1: GD4D_PB_GO(HH_, 1)             \
-    case 2: GD4D_PB_GO(HH_, 2)             \
-    case 3: GD4D_PB_GO(HH_, 3)             \
-    default: GD4D_PB_GO(HH_, 4)            \
+    case 1: GD4D_PB_GO(HH_, 1, PT_)        \
+    case 2: GD4D_PB_GO(HH_, 2, PT_)        \
+    case 3: GD4D_PB_GO(HH_, 3, PT_)        \
+    default: GD4D_PB_GO(HH_, 4, PT_)       \
   }
+  if (P == 8) { GD4D_PB_L(8, 8) }
   switch (Hh) {
-    case 4: GD4D_PB_L(4)
-    case 8: GD4D_PB_L(8)
-    default: GD4D_PB_L(16)
+    case 4: GD4D_PB_L(4, 4)
+    case 8: GD4D_PB_L(8, 4)
+    default: GD4D_PB_L(16, 4)
   }
 #undef GD4D_PB_L
 #undef GD4D_PB_GO
@@ -1152,7 +1157,7 @@ extern "C" int gd4d_pyramid_grad_count(const void* plan, const int32_t* level_hw
   using namespace gd4d;
   if (!plan || !level_hw || !cam_stride_bytes || !count || !slots) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0 || L <= 0) return GD4D_EINVAL;
-  if (P != kPoints || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if ((P != kPoints && P != 8) || L > 4 || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
   if (slots_bytes < gd4d_pyramid_grad_slots_bytes(B, N, Q, Hh, P)) return GD4D_EWORKSPACE;
   PgChunks g{};
   if (int rc = fill_chunks(g, level_hw, cam_stride_bytes, pix_stride_bytes, B * N, L)) return rc;
@@ -1168,7 +1173,7 @@ extern "C" int gd4d_pyramid_grad_fill(const void* plan, const void* slots, const
   using namespace gd4d;
   if (!plan || !slots || !start || !records) return GD4D_EINVAL;
   if (B <= 0 || N <= 0 || Q <= 0 || Hh <= 0) return GD4D_EINVAL;
-  if (P != kPoints || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if ((P != kPoints && P != 8) || N > 64 || B > 16 || Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
   if ((unsigned long long)id_base + (unsigned long long)B * Q * Hh > (1ull << 26)) return GD4D_EUNSUPPORTED;
   const int* hdr = static_cast<const int*>(plan);
   const uint2* pair = reinterpret_cast<const uint2*>(static_cast<const char*>(plan) + plan_hdr_bytes(B, Q));

@@ -1,0 +1,305 @@
+// gd4d_mlp2_bf16x3_fwd: out = relu(X W1^T + b1) W2^T + b2 in ONE kernel - the head's position-embedding MLPs, two 1x1 convolutions
+// with a ReLU between them over every pixel of every camera (dense_heads/detr3d_head_pe.py:380-390 `position_encoder`, applied at
+// :543-553; 192 -> 1024 -> 256 over 739 800 pixels at 24 cameras).  As two GEMMs the 739 800 x 1024 hidden activation (3 GB fp32)
+// made a round trip through HBM; here it never leaves the registers.
+//
+// Arithmetic: gd4d_gemm_bf16x3_fwd's - both operands of both products split into bf16 hi + lo, the three products hi hi + hi lo +
+// lo hi accumulated in fp32 on the bf16 MFMA (~2^-16 relative per product).
+//
+// A wave owns 32 rows of X and ALL 256 output columns (8 tiles of v_mfma_f32_32x32x16_bf16, 128 accumulator registers).  The
+// hidden axis is walked in chunks of 32:
+//   phase A  H^T[32 hidden, 32 rows] = W1c X^T  - the TRANSPOSED product, so that the accumulator layout (a lane = one X row,
+//            16 hidden units) is already the A-operand layout of the next product: bias, ReLU and the hi / lo split happen in
+//            registers; hidden unit <-> k-slot is a fixed permutation inside a chunk, baked into W2's image
+//   phase B  out[32 rows, 256] += H[32 rows, 32 hidden] W2c^T
+// The weights are static: gd4d_mlp2_image lays both out as MFMA fragments (hi / lo planes, 1 KB per fragment and wave), a chunk's
+// 24 + 32 KB (+ its 32 entries of b1) are fetched by LDS-DMA into a double-buffered stage while the previous chunk computes; the
+// waves of a workgroup share them.
+// X stays in REGISTERS, split once per tile (K1 / 16 steps x 8 registers: 96 at K1 = 192).  A first version re-read it per chunk
+// from memory: 32 x 568 MB, and 32 workgroups x 196 KB of X per XCD do not fit its 4-MB L2 - 3.6 ms, slower than the two GEMMs it
+// replaces (docs/measurements_r05.md).  With 128 accumulators, 96 - 128 registers of X and the fragments in flight a wave needs
+// ~300 registers: ONE wave per SIMD (4 waves = 128 rows per workgroup, 512 registers each), the instruction stream itself keeps the
+// matrix pipe busy (phase B: 48 MFMAs against 32 LDS reads).  One barrier per chunk.  114 KB of LDS, one workgroup per compute unit.
+#include "gd4d_common.h"
+
+// Measured and left off (tools/_r05_t8.sh, 2.16 ms with neither): the next stage's DMA pieces issued during phase A as well (2.23 - 2.27),
+// two alternating accumulators in phase A (2.23), both (2.31).
+#ifndef ML_DMA_IN_A
+#define ML_DMA_IN_A 0
+#endif
+#ifndef ML_TWO_ACC
+#define ML_TWO_ACC 0
+#endif
+
+namespace gd4d {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ml_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float ml_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned ml_u32x4;
+
+constexpr int ML_WAVES = 4, ML_THREADS = 64 * ML_WAVES, ML_BM = 32 * ML_WAVES, ML_HC = 32, ML_N2 = 256, ML_NT = ML_N2 / 32;
+constexpr int ML_S2 = ML_NT * 2 * 2 * 1024;          // bytes of a chunk of W2's image: [tile][step][plane][1 KB]
+
+struct Mlp2Params {
+  const float* x;
+  const char* w1img;
+  const char* w2img;
+  const float* b2;
+  float* out;
+  int M, K1, H, ldx, ldo;
+};
+
+__device__ __forceinline__ unsigned ml_cvt_pk_bf16(float lo_elem, float hi_elem) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
+  return r;
+}
+// 8 floats -> 16 bytes of bf16 "hi" halves and 16 bytes of bf16 "lo" (residual) halves
+__device__ __forceinline__ void ml_split8(const float (&v)[8], ml_u32x4& h, ml_u32x4& l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hh[i] = ml_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float ra = v[2 * i] - __uint_as_float(hh[i] << 16);              // exact: hi is a rounding of the value
+    const float rb = v[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u);
+    ll[i] = ml_cvt_pk_bf16(ra, rb);
+  }
+  h = ml_u32x4{hh[0], hh[1], hh[2], hh[3]};
+  l = ml_u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
+__device__ __forceinline__ ml_bf16x8 ml_frag(const ml_u32x4& v) { return __builtin_bit_cast(ml_bf16x8, v); }
+
+// hidden unit (inside its chunk of 32) that accumulator register r of a lane with k-group kg holds after phase A: the C / D row
+// of v_mfma_f32_32x32x16 - and, read as r = 8 s + e, the k-slot e of phase B's step s
+__host__ __device__ __forceinline__ int ml_hidden_of(int kg, int r) { return 4 * kg + (r & 3) + 8 * (r >> 2); }
+
+template <int STEPS1>
+__global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char ml_smem[];
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void glb_void_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, kg = lane >> 5;
+  constexpr int S1 = STEPS1 * 2048 + 1024;             // bytes of a chunk of W1's image: [step][plane][1 KB], then 1 KB holding b1's 32 entries
+  constexpr int STAGE = S1 + ML_S2;
+  const int nchunks = p.H / ML_HC;
+  const int m0 = blockIdx.x * ML_BM + wave * 32;
+  const float* xrow = p.x + (size_t)min(m0 + l32, p.M - 1) * p.ldx + 8 * kg;
+
+  // A stage = a chunk's fragments, 1 KB each: a wave instruction (LDS-DMA) moves one.  Wave w moves pieces w, w + 4, ..; issuing
+  // one costs 60 - 185 cycles, so the next chunk's pieces go out one at a time BETWEEN the MFMA groups of this chunk's phase B.
+  constexpr int n1 = S1 >> 10, npieces = STAGE >> 10;
+  constexpr int PER_WAVE = (npieces + ML_WAVES - 1) / ML_WAVES;
+  auto stage_piece = [&](int c, int buf, int k) {        // k-th piece of this wave
+    const int i = wave + ML_WAVES * k;
+    if (i >= npieces) return;
+    const char* src = i < n1 ? p.w1img + (size_t)c * S1 + ((size_t)i << 10) : p.w2img + (size_t)c * ML_S2 + ((size_t)(i - n1) << 10);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(src + lane * 16), (lds_void_t*)(ml_smem + buf * STAGE + (i << 10)), 16, 0, 0);
+  };
+  auto stage_load = [&](int c, int buf) {
+    for (int k = 0; k < PER_WAVE; ++k) stage_piece(c, buf, k);
+  };
+  stage_load(0, 0);
+
+  // this lane's row of X, split once: step st = channels 16 st + 8 kg .. + 7
+  ml_u32x4 xh[STEPS1], xl[STEPS1];
+#pragma unroll
+  for (int st = 0; st < STEPS1; ++st) {
+    const float4 a = *reinterpret_cast<const float4*>(xrow + 16 * st), b = *reinterpret_cast<const float4*>(xrow + 16 * st + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    ml_split8(v, xh[st], xl[st]);
+  }
+
+  ml_f32x16 acc[ML_NT];
+#pragma unroll
+  for (int t = 0; t < ML_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage c has landed
+    __syncthreads();                                   // ... everybody's has; and everybody is done with the other buffer
+    const bool more = c + 1 < nchunks;
+    const char* s1 = ml_smem + (c & 1) * STAGE;
+    const char* s2 = s1 + S1;
+    // ---- phase A: H^T = W1c X^T (A operand = W1 fragment, B operand = X fragment) ----
+    // Two accumulators, even and odd steps: an MFMA that follows a gap in the instruction stream (the LDS requests, a DMA piece)
+    // then depends on a result two steps old, not on the one just issued (a dependent MFMA behind a gap waits out the full latency).
+    ml_f32x16 h, h_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h[r] = 0.f; h_odd[r] = 0.f; }
+    // (one wave per SIMD: nobody else hides an LDS round trip, so a step's fragments are requested a step ahead and the matrix
+    //  pipe works on step st while they travel; the next chunk's stage goes out a piece per step - the other buffer is free
+    //  since the barrier above)
+    const char* f1 = s1 + lane * 16;
+    ml_u32x4 wh = *reinterpret_cast<const ml_u32x4*>(f1), wl = *reinterpret_cast<const ml_u32x4*>(f1 + 1024);
+#pragma unroll
+    for (int st = 0; st < STEPS1; ++st) {
+      ml_u32x4 nh = wh, nl = wl;
+      if (st + 1 < STEPS1) {
+        nh = *reinterpret_cast<const ml_u32x4*>(f1 + (st + 1) * 2048);
+        nl = *reinterpret_cast<const ml_u32x4*>(f1 + (st + 1) * 2048 + 1024);
+      }
+      if (ML_DMA_IN_A && more && st < PER_WAVE) stage_piece(c + 1, (c + 1) & 1, st);
+      if (ML_TWO_ACC && (st & 1)) {
+        h_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wl), ml_frag(xh[st]), h_odd, 0, 0, 0);
+        h_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xl[st]), h_odd, 0, 0, 0);
+        h_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xh[st]), h_odd, 0, 0, 0);
+      } else {
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wl), ml_frag(xh[st]), h, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xl[st]), h, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xh[st]), h, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);               // (keep the requests in front of the MFMAs they travel under)
+      wh = nh; wl = nl;
+    }
+    if (STEPS1 > 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[r] += h_odd[r];
+    }
+    // bias, ReLU, hi / lo split: registers 8 s .. 8 s + 7 are the A operand of phase B's step s; b1's entries of registers
+    // 4 j .. 4 j + 3 are the consecutive hidden units 4 kg + 8 j + (0 .. 3)
+    ml_u32x4 ah[2], al[2];
+    {
+      const float* b1c = reinterpret_cast<const float*>(s1 + STEPS1 * 2048);
+      float4 bq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const float4*>(b1c + 4 * kg + 8 * j);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 ba = bq[2 * s], bb = bq[2 * s + 1];
+        const float v[8] = {fmaxf(h[8 * s] + ba.x, 0.f), fmaxf(h[8 * s + 1] + ba.y, 0.f), fmaxf(h[8 * s + 2] + ba.z, 0.f),
+                            fmaxf(h[8 * s + 3] + ba.w, 0.f), fmaxf(h[8 * s + 4] + bb.x, 0.f), fmaxf(h[8 * s + 5] + bb.y, 0.f),
+                            fmaxf(h[8 * s + 6] + bb.z, 0.f), fmaxf(h[8 * s + 7] + bb.w, 0.f)};
+        ml_split8(v, ah[s], al[s]);
+      }
+    }
+    // ---- phase B: out += H W2c^T (step-major: the first step's MFMAs run while the second step's operand is still being split) ----
+    constexpr int GROUPS = 2 * ML_NT;
+    const char* f2 = s2 + lane * 16;
+    ml_u32x4 vh = *reinterpret_cast<const ml_u32x4*>(f2), vl = *reinterpret_cast<const ml_u32x4*>(f2 + 1024);
+#pragma unroll
+    for (int grp = 0; grp < GROUPS; ++grp) {
+      const int s = grp / ML_NT, t = grp % ML_NT;
+      ml_u32x4 nh = vh, nl = vl;
+      if (grp + 1 < GROUPS) {                          // the next group's fragments: [tile][step][plane]
+        const int s_n = (grp + 1) / ML_NT, t_n = (grp + 1) % ML_NT;
+        nh = *reinterpret_cast<const ml_u32x4*>(f2 + ((t_n * 2 + s_n) * 2) * 1024);
+        nl = *reinterpret_cast<const ml_u32x4*>(f2 + ((t_n * 2 + s_n) * 2) * 1024 + 1024);
+      }
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(al[s]), ml_frag(vh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vl), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vh), acc[t], 0, 0, 0);
+      // the next chunk's stage, a piece per MFMA group (the other buffer: nobody reads it until the next barrier)
+      if (more && (ML_DMA_IN_A ? STEPS1 : 0) + grp < PER_WAVE) stage_piece(c + 1, (c + 1) & 1, (ML_DMA_IN_A ? STEPS1 : 0) + grp);
+      __builtin_amdgcn_sched_barrier(0);
+      vh = nh; vl = nl;
+    }
+    if (more)
+      for (int k = (ML_DMA_IN_A ? STEPS1 : 0) + GROUPS; k < PER_WAVE; ++k) stage_piece(c + 1, (c + 1) & 1, k);
+  }
+  // C / D of 32x32x16: column n = lane & 31, rows 4 (lane >> 5) + (r & 3) + 8 (r >> 2)
+#pragma unroll
+  for (int t = 0; t < ML_NT; ++t) {
+    const int n = 32 * t + l32;
+    const float bv = p.b2 ? p.b2[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + ml_hidden_of(kg, r);
+      if (m < p.M) p.out[(size_t)m * p.ldo + n] = acc[t][r] + bv;
+    }
+  }
+}
+
+// One thread per 16-byte piece of the two images.
+//   W1 image  [chunk]{[step of 16 inputs][plane hi / lo][lane 64][8 bf16], 1 KB: b1[32 chunk .. + 32]}:   lane (l32, kg), element e = W1[32 chunk + l32][16 step + 8 kg + e]
+//   W2 image  [chunk][tile of 32 outputs][step s][plane][lane 64][8 bf16]:  element e = W2[32 tile + l32][32 chunk + hidden_of(kg, 8 s + e)]
+__global__ __launch_bounds__(256) void mlp2_image_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ b1,
+                                                         char* __restrict__ img1, char* __restrict__ img2, int H, int K1) {
+  const int steps1 = K1 / 16, nchunks = H / ML_HC;
+  const size_t S1 = (size_t)steps1 * 2048 + 1024;
+  const long long p1 = (long long)nchunks * steps1 * 64, p2 = (long long)nchunks * ML_NT * 2 * 64;   // pieces per plane pair
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float v[8];
+  char* dst;
+  if (i < p1) {
+    const int lane = (int)(i & 63);
+    const long long cs = i >> 6;                       // chunk * steps1 + step
+    const int st = (int)(cs % steps1), c = (int)(cs / steps1);
+    const int l32 = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w1[(size_t)(ML_HC * c + l32) * K1 + 16 * st + 8 * kg + e];
+    dst = img1 + (size_t)c * S1 + (size_t)st * 2048 + lane * 16;
+    if (st == 0 && lane < 8) {                         // the chunk's 32 entries of b1 behind its fragments
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b1) bv = *reinterpret_cast<const float4*>(b1 + ML_HC * c + 4 * lane);
+      *reinterpret_cast<float4*>(img1 + (size_t)c * S1 + (size_t)steps1 * 2048 + lane * 16) = bv;
+    }
+  } else if (i < p1 + p2) {
+    const long long j = i - p1;
+    const int lane = (int)(j & 63);
+    const long long cts = j >> 6;                      // (chunk * NT + tile) * 2 + s
+    const int s = (int)(cts & 1), t = (int)((cts >> 1) % ML_NT), c = (int)((cts >> 1) / ML_NT);
+    const int l32 = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w2[(size_t)(32 * t + l32) * H + ML_HC * c + ml_hidden_of(kg, 8 * s + e)];
+    dst = img2 + (size_t)cts * 2048 + lane * 16;
+  } else {
+    return;
+  }
+  ml_u32x4 h, l;
+  ml_split8(v, h, l);
+  *reinterpret_cast<ml_u32x4*>(dst) = h;
+  *reinterpret_cast<ml_u32x4*>(dst + 1024) = l;
+}
+
+static bool mlp2_shape_ok(int K1, int H, int N2) {          // (K1 / 16 is a template argument: the instantiated step counts)
+  const int st = K1 / 16;
+  return K1 > 0 && K1 % 16 == 0 && (st == 1 || st == 2 || st == 4 || st == 8 || st == 12 || st == 16) && H > 0 && H % ML_HC == 0 && N2 == ML_N2;
+}
+
+}  // namespace gd4d
+
+extern "C" size_t gd4d_mlp2_image_bytes(int K1, int H, int N2) {
+  if (!gd4d::mlp2_shape_ok(K1, H, N2)) return 0;
+  return (size_t)H * K1 * 4 + (size_t)(H / gd4d::ML_HC) * 1024 + (size_t)N2 * H * 4;      // bf16 hi + lo of both weights, b1 per chunk
+}
+
+extern "C" int gd4d_mlp2_image(const float* w1, const float* b1, const float* w2, int K1, int H, int N2, void* image, void* stream) {
+  using namespace gd4d;
+  if (!w1 || !w2 || !image) return GD4D_EINVAL;
+  if (!mlp2_shape_ok(K1, H, N2)) return GD4D_EUNSUPPORTED;
+  if (!aligned16(image)) return GD4D_EALIGN;
+  const long long pieces = (long long)(H / ML_HC) * (K1 / 16) * 64 + (long long)(H / ML_HC) * ML_NT * 2 * 64;
+  char* img1 = static_cast<char*>(image);
+  if (b1 && !aligned16(b1)) return GD4D_EALIGN;
+  char* img2 = img1 + (size_t)H * K1 * 4 + (size_t)(H / ML_HC) * 1024;
+  hipLaunchKernelGGL(mlp2_image_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w1, w2, b1,
+                     img1, img2, H, K1);
+  return check_launch();
+}
+
+extern "C" int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const float* b2, float* out, int M, int K1,
+                                    int H, int N2, int ldx, int ldo, void* stream) {
+  using namespace gd4d;
+  if (!x || !image || !out || M <= 0 || ldx < K1 || ldo < N2) return GD4D_EINVAL;
+  if (!mlp2_shape_ok(K1, H, N2) || ldx % 4 != 0) return GD4D_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(image)) return GD4D_EALIGN;
+  const char* img1 = static_cast<const char*>(image);
+  Mlp2Params p{x, img1, img1 + (size_t)H * K1 * 4 + (size_t)(H / ML_HC) * 1024, b2, out, M, K1, H, ldx, ldo};
+  const int lds = 2 * ((K1 / 16) * 2048 + 1024 + ML_S2);
+  auto go = [&](auto kern) -> int {
+    if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((M + ML_BM - 1) / ML_BM), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    return check_launch();
+  };
+  switch (K1 / 16) {
+    case 1: return go(mlp2_kernel<1>);
+    case 2: return go(mlp2_kernel<2>);
+    case 4: return go(mlp2_kernel<4>);
+    case 8: return go(mlp2_kernel<8>);
+    case 12: return go(mlp2_kernel<12>);
+    default: return go(mlp2_kernel<16>);
+  }
+}

@@ -516,7 +516,7 @@ extern "C" int gd4d_mha_core_bwd_fill(const float* q, const float* k, const floa
                                       int fill_N, int fill_Hh, int fill_P, void* stream) {
   using namespace gd4d;
   if (!jobs || njobs < 1 || njobs > 2 || !start || !records || fill_B <= 0 || fill_N <= 0 || fill_Hh <= 0) return GD4D_EINVAL;
-  if (fill_P != kPoints || fill_N > 64 || fill_B > 16 || fill_Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  if ((fill_P != kPoints && fill_P != 8) || fill_N > 64 || fill_B > 16 || fill_Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
   FillGuest fg{};
   for (int j = 0; j < njobs; ++j) {
     const gd4d_fill_job& jb = jobs[j];

@@ -228,6 +228,10 @@ class Deform3DCrossAttn(nn.Module):
         if projected is None and cl is None:     # a stand-alone call: its own copy of the pyramid, if the raw path applies
             own = Fn.raw_pyramid_for_training([self], value)
             cl = None if own is None else own[id(self)][3]
+        # (the training kernels take 4 points per head, or 8 with 8 heads; other counts are padded with points that are never
+        #  visible and weigh nothing - functional.pad_points; autograd slices the padding's gradients away)
+        offsets, attn_logits = Fn.pad_points(offsets, attn_logits, (4, 8) if (hh == 8 and isinstance(cl, tuple)) else (4,),
+                                             'Deform3DCrossAttn (training)')
         if isinstance(cl, tuple):                # (RawPyramid, token)
             # the inference step's kernels behind autograd: no projected value tensor (gd4d_cross_attn_sliced_bwd.hip)
             agg = CrossAttnRawFunction.apply(cl[1], reference_points, offsets, attn_logits, cam_logits, lidar2img,

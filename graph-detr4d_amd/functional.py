@@ -132,6 +132,24 @@ def torch_ops_route(what, supported):
                          'differentiable torch ops instead (slower; an explicit choice, not a fallback).')
 
 
+def pad_points(offsets, attn_logits, supported, what):
+    """offsets (B, Q, Hh, P, 3), attn_logits (B, Q, Hh, L, P) with any P <= max(supported) -> the same tensors padded along the
+    point axis to the next count in `supported` (the kernels are compiled for 1 / 2 / 4 / 8 points per head; the reference's
+    constructor default is 5, deform3d_cross_attn.py:56).  A padded point gets a NaN offset - its projection then fails every
+    comparison of the visibility test (deform3d_cross_attn.py:239, :249-252), so it is never visible, never gathered, and its
+    mask entries are 0 - and a -inf logit: its softmax weight is exactly 0 and the real points' weights are those of the
+    softmax over L x P.  Differentiable (the gradients of the padding are dropped by the slice autograd makes of F.pad)."""
+    p = offsets.shape[3]
+    tgt = next((s_ for s_ in sorted(supported) if s_ >= p), None)
+    if tgt is None:
+        raise _lib.Gd4dError(f'{what}: num_points = {p}, the kernels take up to {max(supported)} points per head')
+    if tgt == p:
+        return offsets, attn_logits
+    pad = tgt - p
+    return (torch.nn.functional.pad(offsets, (0, 0, 0, pad), value=float('nan')).contiguous(),
+            torch.nn.functional.pad(attn_logits, (0, pad), value=float('-inf')).contiguous())
+
+
 def require_gpu(t, name):
     if not t.is_cuda:
         raise _lib.Gd4dError(f'{name} is on {t.device}: graph-detr4d_amd runs on the GPU only '
@@ -331,23 +349,17 @@ def head_outputs(hs, init_reference, inter_references, cls_branches, reg_branche
     hs = hs.permute(0, 2, 1, 3)
     classes, coords = [], []
     if wants_grad(cls_branches, hs) or wants_grad(reg_branches):
-        # training: the same arithmetic as torch ops so that autograd sees it (weight gradients of the branches'
-        # Linears through gd4d_linear_bwd_weight)
-        scale = 1.0 if depth_factor is None else float(depth_factor)
-        lo = [float(v) for v in pc_range[:3]]
-        span = [float(pc_range[3 + i]) - lo[i] for i in range(3)]       # python scalars: no host -> device copy (graph capture)
+        # training: the branches through the package's autograd Functions (weight gradients through gd4d_linear_bwd_weight), the
+        # box epilogue of all layers as ONE autograd node (autograd.BoxHeadFunction)
+        from .autograd import BoxHeadFunction
+        tmps = []
         for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
             x = hs[lvl].contiguous()
             classes.append(sequential_autograd(cls_branches[lvl], x))
-            tmp = sequential_autograd(reg_branches[lvl], x)
-            sx = (tmp[..., 0:1] + reference[..., 0:1]).sigmoid() * span[0] + lo[0]
-            sy = (tmp[..., 1:2] + reference[..., 1:2]).sigmoid() * span[1] + lo[1]
-            sz = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid() * span[2] + lo[2]
-            if depth_factor is not None:
-                sx, sy, sz = sx * scale, sy * scale, sz * scale
-            coords.append(torch.cat([sx, sy, tmp[..., 2:4], sz, tmp[..., 5:]], dim=-1))
-        return {'all_cls_scores': torch.stack(classes), 'all_bbox_preds': torch.stack(coords),
+            tmps.append(sequential_autograd(reg_branches[lvl], x))
+        refs = torch.cat([init_reference.unsqueeze(0), inter_references[:-1]], 0) if hs.shape[0] > 1 else init_reference.unsqueeze(0)
+        boxes = BoxHeadFunction.apply(torch.stack(tmps), refs, pc_range, 1.0 if depth_factor is None else float(depth_factor))
+        return {'all_cls_scores': torch.stack(classes), 'all_bbox_preds': boxes,
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
     for lvl in range(hs.shape[0]):
         reference = init_reference if lvl == 0 else inter_references[lvl - 1]
@@ -617,7 +629,7 @@ class LateValues:
         if rows > 64 or len(value) > 4 or value[0].shape[0] * rows * sum(v.shape[-1] * v.shape[-2] for v in value) >= 2 ** 31:
             return False
         return len({m.value_dtype for m in modules}) == 1 and \
-            all((m.num_points == 4 or (m.num_points in (1, 2, 8) and m.num_heads == 8)) and m.num_heads in (4, 8, 16) and m.embed_dims == 256
+            all((m.num_points <= 4 or (m.num_points <= 8 and m.num_heads == 8)) and m.num_heads in (4, 8, 16) and m.embed_dims == 256
                 and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
     def _wait_copy(self):
@@ -634,6 +646,10 @@ class LateValues:
                   vp_bias=None):
         """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh); rows mode with vp_weight:
         (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
+        # (kernels: 1 / 2 / 4 / 8 points per head with 8 heads on the sliced form, 4 otherwise; other counts - the reference's
+        #  constructor default is 5 - are padded with points that are never visible and weigh nothing)
+        offsets, attn_logits = pad_points(offsets, attn_logits, (1, 2, 4, 8) if self.mode == 'sliced' and module.num_heads == 8 else (4,),
+                                          'Deform3DCrossAttn')
         if self.mode == 'sliced':
             # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
             # GD4D_PLAN=pairs: the 128-bytes-per-item form the training kernels read
@@ -706,6 +722,7 @@ def refine_reference_order(tmp, reference_points, pc_range):
 def sample_aggregate(value, shapes, ref, offsets, attn_logits, cam_logits, lidar2img, pc_range,
                      img_h, img_w, order=None):
     """The fused HIP kernel (ops.cross_attn_fwd): projection + mask + softmax + gather + camera sum."""
+    offsets, attn_logits = pad_points(offsets, attn_logits, (1, 4), 'Deform3DCrossAttn on projected values')
     nl_pix = sum(h * w for h, w in shapes)
     head_major = value.shape[2] == nl_pix and value.shape[1] != nl_pix      # (B*N, Hh, S, Dh) planes
     return ops.cross_attn_fwd(value, shapes, ref.contiguous(), offsets.contiguous(),

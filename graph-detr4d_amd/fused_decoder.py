@@ -69,6 +69,8 @@ def applicable(decoder, query, value, reference_points, reg_branches, attn_masks
             return False
         if type(ca) is not Deform3DCrossAttn or ca.embed_dims != c or len(value) != ca.num_levels:
             return False
+        if ca.num_points not in ((1, 2, 4, 8) if ca.num_heads == 8 else (4,)):     # (other counts: the module path pads them)
+            return False
         if not isinstance(ffn, FFN) or len(ffn.layers) != 3 or not ffn.add_identity or ffn.feedforward_channels % 64 \
                 or ffn.feedforward_channels > 512:
             return False

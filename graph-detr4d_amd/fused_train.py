@@ -87,6 +87,8 @@ def applicable(decoder, query, query_pos, value, reference_points, reg_branches,
             return False
         if type(ca) is not Deform3DCrossAttn or ca.embed_dims != c or len(value) != ca.num_levels or ca.depth_encode:
             return False
+        if not (ca.num_points == 4 or (ca.num_points == 8 and ca.num_heads == 8)):      # (other counts: the per-module path pads them)
+            return False
         entry = raw_entry.get(id(ca))
         if entry is None or len(entry) < 4 or not isinstance(entry[3], tuple):
             return False
@@ -447,7 +449,7 @@ class DecoderTrainFunction(torch.autograd.Function):
             gagg, beta = ops.value_proj_heads_bwd(gv.view(1, q, c), vp_w, vp_b, hh,
                                                   grad_agg=raw.sink.grad_agg_rows(s.layer) if want_pyramid else None)
             raw.layer_done()
-            dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh)), wgrads=riders)
+            dpart = ops.cross_attn_dot_sliced(s.plan, gagg, dpart=raw.dpart(ops.cross_attn_dot_bytes(1, n_cam_rows, q, hh, s.plan.points)), wgrads=riders)
             off5, att5 = s.off.view(1, q, hh, ca.num_points, 3), s.att.view(1, q, hh, ca.num_levels, ca.num_points)
             gr, go, ga, gc = ops.cross_attn_plan_bwd(s.plan, dpart, beta, s.ref, off5, att5, s.cam, meta.lidar2img, ca.pc_range,
                                                      meta.img_h, meta.img_w)

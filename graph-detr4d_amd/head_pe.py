@@ -249,10 +249,16 @@ class FeaturePositionEmbedding(nn.Module):
     def _split_weights(self):
         """bf16 (hi, lo) splits of the five 1x1-conv weights for gd4d_gemm_bf16x3_fwd, remade when a weight changes."""
         convs = dict(pe0=self.position_encoder[0], pe2=self.position_encoder[2], se1=self.fpe.conv_expand)
-        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs.values())
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs.values()) + \
+            (self.position_encoder[0].bias.data_ptr(), self.position_encoder[0].bias._version)
         if self._split_cache is None or self._split_cache[0] != key:
-            self._split_cache = (key, {k: ops.split_bf16_fwd(c.weight.detach().view(c.out_channels, c.in_channels)
-                                                             .contiguous()) for k, c in convs.items()})
+            flat = lambda c: c.weight.detach().view(c.out_channels, c.in_channels).contiguous()      # noqa: E731
+            cache = {k: ops.split_bf16_fwd(flat(c)) for k, c in convs.items()}
+            pe0, pe2 = convs['pe0'], convs['pe2']
+            # the position MLP as one kernel (gd4d_mlp2_bf16x3_fwd) where its shape allows: the image holds W1, b1 and W2
+            cache['pe_mlp'] = ops.mlp2_image(flat(pe0), pe0.bias.detach(), flat(pe2)) \
+                if ops.mlp2_supported(pe0.in_channels, pe0.out_channels, pe2.out_channels) else None
+            self._split_cache = (key, cache)
         return self._split_cache[1]
 
     def _forward_gemm(self, feats, img_metas, masks, pad_hw, sine):
@@ -274,10 +280,15 @@ class FeaturePositionEmbedding(nn.Module):
                                      out=x, row_start=st)
         sw = self._split_weights()
         pe0, pe2 = self.position_encoder[0], self.position_encoder[2]
-        hid = ops.gemm_bf16x3_fwd(x.view(r * s_tot, -1), *sw['pe0'], pe0.bias, relu=True)
-        del x
-        pe = ops.gemm_bf16x3_fwd(hid, *sw['pe2'], pe2.bias)                                      # (R*S, C)
-        del hid
+        if sw.get('pe_mlp') is not None:
+            # Conv1x1, ReLU, Conv1x1 in ONE kernel: the (R*S, 1024) hidden activation (3 GB at 24 cameras) stays in registers
+            pe = ops.mlp2_bf16x3_fwd(x.view(r * s_tot, -1), sw['pe_mlp'], pe2.bias)             # (R*S, C)
+            del x
+        else:
+            hid = ops.gemm_bf16x3_fwd(x.view(r * s_tot, -1), *sw['pe0'], pe0.bias, relu=True)
+            del x
+            pe = ops.gemm_bf16x3_fwd(hid, *sw['pe2'], pe2.bias)                                  # (R*S, C)
+            del hid
         cr, ce = self.fpe.conv_reduce, self.fpe.conv_expand
         g1 = ops.value_proj_fwd([f.contiguous() for f in feats], cr.weight.view(self.embed_dims, -1).contiguous(),
                                 cr.bias.contiguous())                                             # (R, S, C) channels-last

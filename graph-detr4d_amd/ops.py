@@ -251,9 +251,9 @@ class Plan:
     def need_pairs(self, who):
         if self.items:
             raise _lib.Gd4dError(f'{who} reads the pairs form of the plan; this one was made with items=True')
-        if self.points != 4:
-            raise _lib.Gd4dError(f'{who} is built for num_points = 4 (every shipped config); this plan has {self.points} - the '
-                                 'forward kernels take 1 / 2 / 4 / 8, the training backward 4 only')
+        if self.points not in (4, 8) or (self.points == 8 and self.num_heads != 8):
+            raise _lib.Gd4dError(f'{who} is built for 4 points per head (every shipped config) and for 8 with 8 heads; this plan has '
+                                 f'{self.points} - functional.pad_points pads other counts up to them')
 
 
 CA_RAW_CAM_WEIGHTS, CA_PLAN_ITEMS, CA_PLAN_BOTH = 1, 2, 16
@@ -469,7 +469,7 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None):
     b, q, hh = plan.b, plan.q, plan.num_heads
     n = pyramid.rows // b
     nl = len(pyramid.level_hw)
-    nbytes = int(lib.gd4d_cross_attn_dot_bytes(b, n, q, hh, 4))
+    nbytes = int(lib.gd4d_cross_attn_dot_bytes(b, n, q, hh, plan.points))
     if dpart is None:
         dpart = torch.empty(nbytes, device=pyramid.device, dtype=torch.uint8)
     ptrs = (ctypes.c_void_p * nl)(*pyramid.ptrs)
@@ -477,14 +477,14 @@ def cross_attn_dot_sliced(plan, grad_agg, dpart=None, wgrads=None):
         xs, gys, gws, gbs, dims, cnt = _wgrad_arrays(wgrads)
         code = lib.gd4d_cross_attn_dot_sliced_wgrad(
             ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(grad_agg, 'grad_agg', torch.float32),
-            _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4,
+            _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, plan.points,
             _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
             None if plan.order is None else _order_ptr(plan.order, b * q), xs, gys, gws, gbs, dims, cnt, 1, _stream())
         _lib.check(code, 'gd4d_cross_attn_dot_sliced_wgrad')
         return dpart
     code = lib.gd4d_cross_attn_dot_sliced(
         ptrs, pyramid.slice_stride, _dev(plan.buf, 'plan', torch.uint8), _dev(grad_agg, 'grad_agg', torch.float32),
-        _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, 4,
+        _dev(dpart, 'dpart', torch.uint8), dpart.numel(), b, n, q, hh, 256, nl, plan.points,
         _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
         None if plan.order is None else _order_ptr(plan.order, b * q), _stream())
     _lib.check(code, 'gd4d_cross_attn_dot_sliced')
@@ -573,8 +573,9 @@ class PyramidGrad:
     Buffers are sized for `layers` layers of B*Q*Hh rows (alloc_table with a list: per-layer Q); the slot / record buffers by
     the plans' capacity (8 bytes per pair a plan can hold - only what the counts say is touched)."""
 
-    def __init__(self, pyramid, layers, b, q, num_heads, chunk_walk=True):
+    def __init__(self, pyramid, layers, b, q, num_heads, chunk_walk=True, points=4):
         self.pyramid, self.layers, self.b, self.q, self.hh = pyramid, int(layers), int(b), int(q), int(num_heads)
+        self.points = int(points)                 # points per head of the plans this sink takes (4, or 8 with 8 heads)
         dev = pyramid.device
         lib = _lib.load()
         self.n = pyramid.rows // self.b
@@ -589,7 +590,7 @@ class PyramidGrad:
         self.table, self.layer_q = None, {}
         if self.layers > 0:
             self.alloc_table(self.layers)
-        self.slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, self.q, self.hh, 4))
+        self.slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, self.q, self.hh, self.points))
         self.plans, self.prepared = [], None
         self.order = _chunk_walk(pyramid.level_hw, pyramid.rows, dev) if chunk_walk else None
 
@@ -623,7 +624,7 @@ class PyramidGrad:
         layer = int(layer)
         code = lib.gd4d_pyramid_grad_count(_dev(plan.buf, 'plan', torch.uint8), self._lv, self._cs, self.pyramid.pix_stride,
                                            _dev(self.count, 'count', torch.int32), _dev(slots, 'slots'), ctypes.c_size_t(slot_bytes),
-                                           self.b, self.n, plan.q, self.hh, len(self.pyramid.level_hw), 4, _stream())
+                                           self.b, self.n, plan.q, self.hh, len(self.pyramid.level_hw), plan.points, _stream())
         _lib.check(code, 'gd4d_pyramid_grad_count')
         self.plans.append((layer, plan, slots))
 
@@ -640,7 +641,10 @@ class PyramidGrad:
             raise _lib.Gd4dError(f'PyramidGrad: layer {layer} has {plan.q} queries, the table was made for '
                                  f'{self.table_q[layer] if layer < self.layers else "fewer layers"}')
         self.layer_q[layer] = plan.q
-        slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, plan.q, self.hh, 4))
+        lib = _lib.load()
+        if plan.points != self.points:
+            raise _lib.Gd4dError(f'PyramidGrad: a plan with {plan.points} points per head handed to a sink made for {self.points}')
+        slot_bytes = int(lib.gd4d_pyramid_grad_slots_bytes(self.b, self.n, plan.q, self.hh, plan.points))
         slots = torch.empty(slot_bytes, device=self.pyramid.device, dtype=torch.uint8)
         return slots, slot_bytes
 
@@ -692,7 +696,7 @@ class PyramidGrad:
             code = lib.gd4d_pyramid_grad_fill(
                 _dev(plan.buf, 'plan', torch.uint8), _dev(slots, 'slots'), _dev(start, 'start', i32), _dev(records, 'records'),
                 self.row_base[layer], None if plan.order is None else _order_ptr(plan.order, self.b * plan.q),
-                self.b, self.n, plan.q, self.hh, 4, _stream())
+                self.b, self.n, plan.q, self.hh, plan.points, _stream())
             _lib.check(code, 'gd4d_pyramid_grad_fill')
         sorted_ = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         pxoff = torch.empty(self.chunks, 65, device=dev, dtype=i32)
@@ -1207,7 +1211,7 @@ def mha_core_bwd(q, k, v, out, grad_out, lse, num_heads, attn_mask=None, packed_
                                           mptr, _dev(lse, 'lse', f32), _dev(dsum, 'dsum'), vp(dq), vp(dk),
                                           _dev(dv, 'dv'), lq, lk, b, num_heads, d, ld(q, 'q'), ld(k, 'k'), ld(v, 'v'), c, c, ldd, ldd, c,
                                           kind, 1.0 / (d ** 0.5), float(dropout_p), sptr, arr, len(jobs),
-                                          _dev(start, 'start', torch.int32), _dev(records, 'records'), fb, fn, fhh, 4, _stream())
+                                          _dev(start, 'start', torch.int32), _dev(records, 'records'), fb, fn, fhh, int(jobs[0][0].points), _stream())
         _lib.check(code, 'gd4d_mha_core_bwd_fill')
         return (dqk, dv) if packed_qk else (dq, dk, dv)
     code = lib.gd4d_mha_core_bwd(vp(q), vp(k), vp(v), _dev(out, 'out', f32), _dev(grad_out, 'grad_out', f32),
@@ -1384,6 +1388,41 @@ def gemm_bf16x3_fwd(a, w_hi, w_lo, bias=None, relu=False, out=None, relu_in=Fals
                                     _dev(w_lo, 'w_lo', torch.bfloat16), _opt(bias, 'bias'), _dev(out, 'out'), m, n, k, k, n,
                                     int(bool(relu)) | (16 if relu_in else 0) | (32 if mask_out else 0), _stream())
     _lib.check(code, 'gd4d_gemm_bf16x3_fwd')
+    return out
+
+
+def mlp2_image(w1, b1, w2):
+    """gd4d_mlp2_image: the MFMA-fragment image of a two-layer MLP's W1 (H, K1), b1 (H) or None, W2 (N2, H) for mlp2_bf16x3_fwd."""
+    lib = _lib.load()
+    h, k1 = w1.shape
+    n2 = w2.shape[0]
+    nbytes = int(lib.gd4d_mlp2_image_bytes(k1, h, n2))
+    if nbytes == 0 or w2.shape[1] != h:
+        raise _lib.Gd4dError(f'mlp2: K1 = {k1} (a multiple of 16, <= 256), H = {h} (a multiple of 32), N2 = {n2} (256) are the kernel\'s limits')
+    img = torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
+    code = lib.gd4d_mlp2_image(_dev(w1.contiguous(), 'w1', torch.float32), None if b1 is None else _dev(b1.contiguous(), 'b1', torch.float32),
+                               _dev(w2.contiguous(), 'w2', torch.float32), k1, h, n2, _dev(img, 'image', torch.uint8), _stream())
+    _lib.check(code, 'gd4d_mlp2_image')
+    img.shape_khn = (k1, h, n2)
+    return img
+
+
+def mlp2_supported(k1, h, n2):
+    return int(_lib.load().gd4d_mlp2_image_bytes(int(k1), int(h), int(n2))) > 0
+
+
+def mlp2_bf16x3_fwd(x, image, b2=None, out=None):
+    """gd4d_mlp2_bf16x3_fwd: x (M, K1) fp32 -> relu(x W1^T + b1) W2^T + b2 (M, N2), the hidden activation never stored."""
+    lib = _lib.load()
+    k1, h, n2 = image.shape_khn
+    m = x.shape[0]
+    if x.shape[1] != k1:
+        raise ValueError(f'mlp2_bf16x3_fwd: x has {x.shape[1]} columns, the image was made for {k1}')
+    if out is None:
+        out = torch.empty(m, n2, device=x.device, dtype=torch.float32)
+    code = lib.gd4d_mlp2_bf16x3_fwd(_dev(x, 'x', torch.float32), _dev(image, 'image', torch.uint8), _opt(b2, 'b2'),
+                                    _dev(out, 'out', torch.float32), m, k1, h, n2, k1, n2, _stream())
+    _lib.check(code, 'gd4d_mlp2_bf16x3_fwd')
     return out
 
 

@@ -662,6 +662,18 @@ int gd4d_mha_core_presplit_fwd(const float* q, const void* k_planes, const void*
                                int ldq, int ldo, long long k_plane_stride, long long v_plane_stride, const void* mask,
                                int mask_kind, float scale, float* lse, float drop_p, const void* seed, void* stream);
 
+/* gd4d_mlp2_bf16x3_fwd - out = relu(x W1^T + b1) W2^T + b2 in ONE kernel (gd4d_mlp2.hip): the head's position-embedding MLPs -
+ * Conv1x1, ReLU, Conv1x1 over every pixel of every camera (dense_heads/detr3d_head_pe.py:380-390 `position_encoder`, applied at
+ * :543-553: 192 -> 1024 -> 256 over 739 800 pixels at 24 cameras).  The hidden activation (3 GB as a tensor) stays in registers:
+ * per chunk of 32 hidden units a wave computes the TRANSPOSED first product, whose accumulator layout is the A operand of the
+ * second.  Arithmetic as gd4d_gemm_bf16x3_fwd (split bf16 x 3 on the bf16 MFMA, fp32 accumulation).  x (M, K1) fp32 rows of
+ * stride ldx; image: gd4d_mlp2_image of W1 (H, K1), b1 (H; NULL = zeros) and W2 (N2, H) (gd4d_mlp2_image_bytes; remake it when one
+ * of them changes); b2 (N2) or NULL; out (M, N2) rows of stride ldo.  K1 in {16, 32, 64, 128, 192, 256}, H % 32 == 0, N2 == 256. */
+size_t gd4d_mlp2_image_bytes(int K1, int H, int N2);
+int gd4d_mlp2_image(const float* w1, const float* b1, const float* w2, int K1, int H, int N2, void* image, void* stream);
+int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const float* b2, float* out, int M, int K1, int H, int N2, int ldx,
+                         int ldo, void* stream);
+
 /* gd4d_adamw_flat - the optimizer step of the reference's training recipe over ONE flat fp32 parameter / gradient buffer: clipping
  * of the gradient's L2 norm (torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: none) followed by
  * AdamW (torch.optim.AdamW's update, decoupled weight decay) - optimizer + optimizer_config of
@@ -977,8 +989,8 @@ int gd4d_linear_sum_assignment_batch(const float* cost, const int64_t* cost_offs
  * (l, b) at Q (l sum_gt + gt_start[b]), (Q, G_b) row-major); gt_start (B + 1) on the device; assigned (NL, B, Q) receives the index
  * into the packed ground truth (gt_start[b] + column) of a matched prediction, -1 otherwise; status (NL * B): 0 = solved, 1 = the
  * block holds a NaN (a label outside [0, classes): gd4d_match_cost_fwd's marker - everything stays -1; the host raises when it
- * looks), 2 = infeasible / more boxes than max_gt.  One workgroup per problem; one wave runs the shortest-augmenting-path solver of
- * gd4d_linear_sum_assignment_batch operation for operation in fp64, its scan spread over the lanes with an arg-min that reproduces
+ * looks), 2 = infeasible / more boxes than max_gt.  One workgroup per problem runs the shortest-augmenting-path solver of
+ * gd4d_linear_sum_assignment_batch operation for operation in fp64, its scan spread over the threads with an arg-min that reproduces
  * the sequential scan's choice (ties included): the matching is IDENTICAL to the host solver's.  workspace:
  * gd4d_hungarian_assign_workspace_bytes (a double copy of every problem, the shorter side as rows); max(Q, max_gt) <= ~4800 (LDS). */
 size_t gd4d_hungarian_assign_workspace_bytes(int NL, int B, int Q, int max_gt);

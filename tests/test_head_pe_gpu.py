@@ -257,3 +257,24 @@ def test_with_detach_cuts_the_gradient_of_level_0_past_frames():
     assert float(g_det[0][:, 6:].abs().max()) == 0.0 and float(g_full[0][:, 6:].abs().max()) > 0
     assert torch.equal(g_det[0][:, :6], g_full[0][:, :6]) and torch.equal(g_det[1], g_full[1])
     assert FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE).with_detach is True      # the head's default (:326)
+
+
+@pytest.mark.parametrize('m,k1,h', [(1000, 192, 1024), (257, 192, 1024), (31, 64, 64), (4096, 256, 256), (300, 16, 32)])
+def test_fused_two_layer_mlp_matches_fp64(m, k1, h):
+    """gd4d_mlp2_bf16x3_fwd (relu(x W1^T + b1) W2^T + b2 with the hidden activation kept in registers) against fp64, at the
+    position_encoder's shape (192 -> 1024 -> 256), the SE layer's (256 -> 256 -> 256), ragged row counts and the smallest shapes;
+    within split-bf16 x 3 rounding of both products (the same bound as two gd4d_gemm_bf16x3_fwd calls); run-to-run identical."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(m + k1)
+    x = torch.randn(m, k1)
+    w1, b1 = torch.randn(h, k1) / k1 ** 0.5, torch.randn(h) * 0.1
+    w2, b2 = torch.randn(256, h) / h ** 0.5, torch.randn(256) * 0.1
+    want = (torch.relu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()).float()
+    img = ops.mlp2_image(w1.cuda(), b1.cuda(), w2.cuda())
+    got = ops.mlp2_bf16x3_fwd(x.cuda(), img, b2.cuda())
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
+    assert torch.equal(ops.mlp2_bf16x3_fwd(x.cuda(), img, b2.cuda()), got)
+    hid = ops.gemm_bf16x3_fwd(x.cuda(), *ops.split_bf16_fwd(w1.cuda()), b1.cuda(), relu=True) if (h % 256 == 0 and k1 % 32 == 0) else None
+    if hid is not None:                                  # ... and as close to fp64 as the two-GEMM route is
+        two = ops.gemm_bf16x3_fwd(hid, *ops.split_bf16_fwd(w2.cuda()), b2.cuda())
+        assert (got.cpu() - want).abs().max() <= 2 * (two.cpu() - want).abs().max() + 1e-6

@@ -472,3 +472,56 @@ def test_frozen_decoder_still_gives_the_feature_maps_their_gradient():
     with torch.no_grad():                                     # same numbers as the inference path
         ref = tr([f.detach() for f in feats], qe, reg_branches=regs, img_metas=metas)[0]
     torch.testing.assert_close(states.detach(), ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('points', [1, 2, 3, 4, 5, 6, 8])
+def test_deform3d_cross_attn_any_num_points_matches_the_oracle(points):
+    """the reference class takes any num_points (its constructor default is 5, deform3d_cross_attn.py:56); the
+    kernels are compiled for 1 / 2 / 4 / 8 points per head and the module pads the others with points that are never visible and
+    weigh nothing (functional.pad_points).  Inference output against the torch oracle on the deform_n6 fixture's inputs with
+    freshly drawn weights of the right shapes, on the default (sliced aggregate) path and on the projected-value path where its
+    kernels allow (<= 4 points); the training path's output and gradients against oracle autograd for every count."""
+    from graph_detr4d_amd import synthetic
+    from oracle import torch_oracle as O
+    g = Golden('deform_n6')
+    m = g.meta
+    torch.manual_seed(points)
+    mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=m['num_cams'], pc_range=m['pc_range'], num_points=points,
+                                 embed_dims=256, depth_encode=m['depth_encode']), dict(batch_first=False))
+    synthetic.randomise_all_(mod, seed=points)
+    mod = mod.to(DEV).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+    q, qp, ref = g.t('query'), g.t('query_pos'), g.t('reference_points')
+    want = O.deform3d_cross_attn(sd, q, g.feats(), qp, ref, g.img_metas(), m['pc_range'], m['num_heads'], points,
+                                 depth_encode=m['depth_encode'])
+    feats = [f.to(DEV) for f in g.feats()]
+    call = lambda fe, qq: mod(qq, None, fe, None, query_pos=qp.to(DEV), reference_points=ref.to(DEV), img_metas=_metas(g))   # noqa: E731
+    with torch.no_grad():
+        out = call(feats, q.to(DEV))
+    torch.testing.assert_close(out.cpu(), want, **TOL)
+    if points <= 4:
+        os.environ['GD4D_PROJECT'] = 'early'
+        try:
+            with torch.no_grad():
+                out_e = call(feats, q.to(DEV))
+        finally:
+            os.environ.pop('GD4D_PROJECT')
+        torch.testing.assert_close(out_e.cpu(), want, **TOL)
+    # training: output and gradients (query, feature maps, every parameter) against autograd through the oracle
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(7))
+    q_c = q.clone().requires_grad_(True)
+    f_c = [f.clone().requires_grad_(True) for f in g.feats()]
+    p_c = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o_c = O.deform3d_cross_attn(p_c, q_c, f_c, qp, ref, g.img_metas(), m['pc_range'], m['num_heads'], points, depth_encode=m['depth_encode'])
+    (o_c * gout).sum().backward()
+    q_d = q.to(DEV).requires_grad_(True)
+    f_d = [f.to(DEV).requires_grad_(True) for f in g.feats()]
+    o_d = call(f_d, q_d)
+    torch.testing.assert_close(o_d.detach().cpu(), want, **TOL)
+    (o_d * gout.to(DEV)).sum().backward()
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max().clamp(min=1e-12))      # noqa: E731
+    assert rel(q_d.grad, q_c.grad) < 2e-3
+    assert max(rel(a.grad, b.grad) for a, b in zip(f_d, f_c)) < 2e-3
+    for name, p in mod.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        assert rel(p.grad, p_c[name].grad) < 3e-3, (name, rel(p.grad, p_c[name].grad))

@@ -41,9 +41,9 @@ def main():
     with torch.no_grad():
         first = timed(lambda: (setattr(mod, '_sine_cache', None), setattr(mod, '_mask_cache', None), mod(feats, metas)), 3)
         steady = timed(lambda: mod(feats, metas))
-        os.environ['GD4D_HEAD_PE'] = 'conv'
+        os.environ['GD4D_TORCH_OPS'] = '1'
         steady_conv = timed(lambda: mod(feats, metas))
-        os.environ.pop('GD4D_HEAD_PE')
+        os.environ.pop('GD4D_TORCH_OPS')
         masks, pad_hw = mod.padding_masks(metas, feats)
         i2l = torch.from_numpy(np.linalg.inv(np.asarray(rig, dtype=np.float64))).float().cuda()
         x0 = {}
