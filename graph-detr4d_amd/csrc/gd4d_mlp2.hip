@@ -22,8 +22,11 @@
 // matrix pipe busy (phase B: 48 MFMAs against 32 LDS reads).  One barrier per chunk.  114 KB of LDS, one workgroup per compute unit.
 #include "gd4d_common.h"
 
-// Measured and left off (tools/_r05_t8.sh, 2.16 ms with neither): the next stage's DMA pieces issued during phase A as well (2.23 - 2.27),
-// two alternating accumulators in phase A (2.23), both (2.31).
+// Measured and left off (docs/measurements_r05.md section 5; 2.16 ms with neither): the next stage's DMA pieces issued during phase A as
+// well (2.23 - 2.27 ms), two alternating accumulators in phase A (2.23), both (2.31); a branch-free stage (padded piece count) with
+// the requests pinned in front of the MFMAs by sched_group_barrier and the DMA as one burst between the phases (2.40), at the chunk's
+// start (2.25 - 2.28) or a piece at the head of every group (2.29).  Counters of this version (profiles/r05_pmc_mlp2.txt): matrix
+// pipe busy 37 %, waves parked at a counter / the barrier 33 % of their cycles, stalled at issue 38 %, active 29 %.
 #ifndef ML_DMA_IN_A
 #define ML_DMA_IN_A 0
 #endif

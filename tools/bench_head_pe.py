@@ -30,6 +30,7 @@ def timed(fn, n=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=4)
+    ap.add_argument('--hip-only', action='store_true', help='only the library\'s own route (what a rocprofv3 --stats run should see)')
     a = ap.parse_args()
     n = 6 * a.frames
     torch.manual_seed(0)
@@ -41,6 +42,9 @@ def main():
     with torch.no_grad():
         first = timed(lambda: (setattr(mod, '_sine_cache', None), setattr(mod, '_mask_cache', None), mod(feats, metas)), 3)
         steady = timed(lambda: mod(feats, metas))
+        if a.hip_only:
+            print(f'cameras={n} pixels={pixels}  steady-state {steady:.2f} ms (first call, sine branch not cached: {first:.2f} ms)')
+            return
         os.environ['GD4D_TORCH_OPS'] = '1'
         steady_conv = timed(lambda: mod(feats, metas))
         os.environ.pop('GD4D_TORCH_OPS')
@@ -77,6 +81,8 @@ def main():
         t_g3 = timed(lambda: ops.gemm_bf16x3_fwd(pe_o, *sw['se1'], mod.fpe.conv_expand.bias, relu_in=True))
         t_fz = timed(lambda: [ops.se_fuse_chlast_fwd(f.flatten(0, 1), pe_o.view(r, s_tot, 256), pe_o.view(r, s_tot, 256),
                                                      f.flatten(0, 1), s0) for f, s0 in zip(feats, st)])
+        t_mlp = timed(lambda: ops.mlp2_bf16x3_fwd(xcl.view(r * s_tot, 192), sw['pe_mlp'], mod.position_encoder[2].bias, out=pe_o))
+    print(f'  fused position MLP 192->1024->256 (gd4d_mlp2_bf16x3_fwd) {t_mlp:.2f} ms')
     print(f'  GEMM path pieces: frustum (channels-last) {t_frc:.2f}  GEMM 192->1024 {t_g1:.2f}  GEMM 1024->256 {t_g2:.2f}  '
           f'conv_reduce (value_proj kernel) {t_vp:.2f}  GEMM 256->256 {t_g3:.2f}  transposing fuse {t_fz:.2f} ms')
     flops = pixels * 2 * (192 * 1024 + 1024 * 256 + 2 * 256 * 256)

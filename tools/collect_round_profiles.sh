@@ -30,3 +30,7 @@ for p in "train:bench_train" "train_criterion:bench_train_criterion" "train_vov:
 done
 cp $g/train/stats/train_kernel_stats.csv profiles/${pre}_kernel_stats_train_step.csv
 echo collected
+cp $(find $g/hpe -name '*kernel_stats.csv' | head -1) profiles/${pre}_kernel_stats_head_pe.csv
+cp $g/head_pe_breakdown.txt profiles/${pre}_head_pe_breakdown.txt
+cp $g/pmc_mlp2/pmc_summary.txt profiles/${pre}_pmc_mlp2.txt
+echo collected head pe

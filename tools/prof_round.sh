@@ -49,3 +49,9 @@ for f in train train_criterion train_vov distill train_projected_values; do tail
 bash tools/prof_train_stats.sh $tag/train --no-roofline | head -12
 bash tools/prof_pmc.sh $tag/pmc_rawbwd tools/bench_raw_bwd.py --iters 2 > /dev/null 2>&1
 grep -A 26 "dot_sliced_kernel\|grad_reduce_kernel\|grad_count_kernel" gpurun_out/$tag/pmc_rawbwd/pmc_summary.txt | head -90
+# the head's feature position embedding: kernel stats of the library's own route, PMC of the fused position MLP
+rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/hpe -o hpe -- python3 tools/bench_head_pe.py --hip-only > gpurun_out/$tag/hpe.log 2>&1
+find gpurun_out/$tag/hpe -name '*kernel_trace.csv' -delete
+python3 tools/bench_head_pe.py 2>/dev/null | grep -v amdgpu > gpurun_out/$tag/head_pe_breakdown.txt
+bash tools/prof_pmc.sh $tag/pmc_mlp2 tools/bench_mlp2.py > /dev/null 2>&1
+grep -A 30 "mlp2_kernel" gpurun_out/$tag/pmc_mlp2/pmc_summary.txt | head -40
