@@ -4,6 +4,7 @@ import os
 import socket
 import time
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
