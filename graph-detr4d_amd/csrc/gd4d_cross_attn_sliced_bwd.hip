@@ -751,14 +751,25 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_sort_kernel(const int
   }
 }
 
-// One 512-thread workgroup per chunk, a wave per eighth of the chunk's pixels.  Everything a wave touches is wave-
-// uniform - its pixels, their runs, the records - so the records arrive through the SCALAR cache (s_load, eight at a
-// time) and the weight and the table row's address are scalar registers: per record one 1-KB row of the dA table (lane c
-// holds channels 4c .. 4c+3) and four FMAs with a scalar multiplier; no cross-lane traffic, no branch per record (the
-// first version took the records from LDS with v_readlane and compared pixels per record: 16 scalar + 16 vector
-// instructions per record on 4 waves per SIMD, 0.9 ms of the 1.0 without a single table load).  A finished pixel is one
-// row of an LDS tile; the tile is then written NCHW, every pixel of the pyramid exactly once: no zero fill, no
-// read-modify-write.  Grid = 8 XCDs x an eighth of the chunks (chunk_order: the walk; or level by level, coarse first).
+// One 512-thread workgroup per chunk.  Per record: one 1-KB row of the dA table (lane c holds channels 4c .. 4c+3) and four
+// FMAs with a scalar multiplier.  A finished pixel is one row of an LDS tile; the tile is then written NCHW, every pixel of
+// the pyramid exactly once: no zero fill, no read-modify-write.  Grid = 8 XCDs x an eighth of the chunks (chunk_order: the
+// walk; or level by level, coarse first).
+//   * A wave takes an eighth of the chunk's RECORDS (whole groups of 8), whatever pixels they belong to; a pixel that starts
+//     in an earlier wave's share is a partial sum in part[wave], added to the pixel's row after the barrier, in wave order
+//     (a fixed order: run-to-run identical).  (Rounds 3 - 4 handed out PIXELS: the slowest of the 8 waves set the pace, and a
+//     group of 8 loads never crossed a pixel - at level 0, 4.6 records per pixel, 8 loads were issued per 4.6 records.)
+//   * The records arrive by VECTOR loads, 64 per instruction (lane = record), the next 64 requested a batch ahead; vector
+//     loads return in order, so the wait for a group's table rows does not wait for anything issued after them.  (Rounds 3 - 4:
+//     one scalar load per group of 8 - scalar loads return out of order, the wait for one group's records also waited for
+//     the prefetched next one: an exposed latency per group.)  A record's weight / table row / pixel reach the scalar side by
+//     v_readlane; pixel boundaries inside a group are found by comparing scalars (fast path: the group's last record has the
+//     current pixel - records are sorted by pixel).
+//   * Two groups of 8 table rows in flight per wave (16 KB; 16 waves per compute unit).
+// What bounds it (docs/measurements_r05.md section 9): 0.73 ms, of which the write-out alone - 757 MB as 128-byte runs, one per
+// (channel, row of 32 pixels) - takes 0.37 - 0.55 ms when nothing else runs (1-KB runs: 0.2 ms), and the table rows'
+// 11.9 GB through the L1s (0.3 ms at 64 B/clk per compute unit).  A persistent form (workgroups that stay and prefetch
+// their next chunk: docs/r05/persistent_walk_reduce_prototype.hip.txt) measured slower.
 struct PgReduceParams {
   float* out[GD4D_MAX_LEVELS];
   PgChunks g;
@@ -773,30 +784,21 @@ struct PgReduceParams {
 };
 
 constexpr int PG_PX = 64, PG_PITCH = 260;
+constexpr int PG_PART = 8 * kChannels;              // floats: one partial row per wave
 
-// A group = up to 8 consecutive records of one pixel's run.  The walk of a wave is a software pipeline over its groups:
-// the records of group k + 2 are requested (one scalar load of 64 bytes) and the table rows of group k + 1 (8 vector
-// loads) before the FMAs of group k wait for theirs - without it every group paid the scalar-load and the vector-load
-// latency in turn (0.3 ms of the 0.8 the kernel took with neither table loads nor the write-out).
-struct PgGroup { int i, n, px, last; };            // first record, records (0 = none left), pixel, ends the pixel's run
-
-template <int VARIANT>
-__device__ __forceinline__ void pg_issue(const float* __restrict__ table, const uint2 (&r)[8], int n, int lane, float4 (&v)[8]) {
+__device__ __forceinline__ void pg_issue(const float* __restrict__ table, unsigned ry, int g, int lane, float4 (&v)[8]) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    // past the run: the first record again, weight 0 below (a uniform branch per load - not issuing what the run does not
-    // have - was measured slower: 0.90 against 0.81 ms; it breaks the clause of eight loads)
-    unsigned id = (u < n ? r[u].y : r[0].y) & 0x3ffffffu;
-    if (VARIANT == 1) id &= 63u;
-    if (VARIANT >= 2) v[u] = make_float4(__uint_as_float(id), 0.f, 0.f, 0.f);
-    else v[u] = *reinterpret_cast<const float4*>(table + (size_t)id * kChannels + lane * 4);
+    const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)ry, g * 8 + u) & 0x3ffffffu;
+    v[u] = *reinterpret_cast<const float4*>(table + (size_t)id * kChannels + lane * 4);
   }
 }
 
-template <int VARIANT, bool NHWC>
+template <bool NHWC>
 __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const PgReduceParams p) {
-  extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH]
-  __shared__ int s_po[8][12];
+  extern __shared__ __attribute__((aligned(16))) float s_tp[];   // [PG_PX][PG_PITCH] + [8][kChannels]
+  __shared__ int s_head[8];                                       // pixel whose partial sum wave w left in part[w], or -1
+  float* s_part = s_tp + PG_PX * PG_PITCH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xcd = blockIdx.x & 7;
@@ -821,81 +823,115 @@ __global__ __launch_bounds__(PG_THREADS) void pyramid_grad_reduce_kernel(const P
   const int cy = rem / CWl, cx = rem - cy * CWl;
   const int* po = p.pxoff + (size_t)chunk * 65;
   const uint2* rec = p.rec + p.start[chunk];
-  if (VARIANT == 4) { if (po[0] < 0) s_tp[0] = 1.f; return; }
-  const int ppw = (1 << (cws + chs)) >> 3;                        // pixels per wave: 1, 2 or 8
-  const int px0 = wave * ppw;
-  if (lane <= ppw) s_po[wave][lane] = po[px0 + lane];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // a finished pixel: one row of the LDS tile (NCHW output, turned below) or - channels-last output (R, H, W, C) - straight
-  // to memory: a pixel IS one contiguous 1-KB row there, no tile and no transpose
-  auto put = [&](int px, const float4 v) {
-    if (NHWC) {
+  const int npx = 1 << (cws + chs);
+  // lane = pixel: its run [x0, x1) of the chunk's records; n = all of them; this wave's share [s, e)
+  const int x0 = po[lane], x1 = po[lane + 1];
+  const int n = __builtin_amdgcn_readlane(x1, 63);
+  const int G = (n + 7) >> 3;
+  const int s = 8 * ((G * wave) >> 3), e = min(n, 8 * ((G * (wave + 1)) >> 3));
+  auto fetch = [&](int at) -> uint2 {
+    uint2 r = rec[min(at + lane, max(e - 1, 0))];
+    if (at + lane >= e) r.x = 0u;                                  // past the share: the last record again, weight 0
+    return r;
+  };
+  // the first batch of records, and the record in front of the share (its pixel says whether the share starts inside a run)
+  uint2 rc = make_uint2(0u, 0u);
+  unsigned prev_y = 0u;
+  if (s < e) {
+    rc = fetch(s);
+    if (s > 0) prev_y = rec[s - 1].y;
+  }
+  // a pixel without records gets its row of zeros from the wave whose share its position falls into (the last wave: the end)
+  {
+    const bool mine = lane < npx && x0 == x1 && ((x0 >= s && x0 < e) || (wave == 7 && x0 == n));
+    unsigned long long m = __ballot(mine);
+    while (m) {
+      const int px = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  int head = -1;
+  if (s < e) {
+    int cur = __builtin_amdgcn_readfirstlane((int)(rc.y >> 26));
+    bool open = s > 0 && (int)((unsigned)__builtin_amdgcn_readfirstlane((int)prev_y) >> 26) == cur;   // (wave-uniform)
+    if (open) head = cur;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {
+      float* dst = open ? s_part + wave * kChannels + lane * 4 : &s_tp[cur * PG_PITCH + lane * 4];
+      *reinterpret_cast<float4*>(dst) = acc;
+      open = false;
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto fma_group = [&](unsigned rx, unsigned ry, int g, const float4 (&v)[8]) {
+      const int last = (int)((unsigned)__builtin_amdgcn_readlane((int)ry, g * 8 + 7) >> 26);
+      if (last == cur) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)rx, g * 8 + u));
+          acc.x = fmaf(w, v[u].x, acc.x); acc.y = fmaf(w, v[u].y, acc.y);
+          acc.z = fmaf(w, v[u].z, acc.z); acc.w = fmaf(w, v[u].w, acc.w);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int px = (int)((unsigned)__builtin_amdgcn_readlane((int)ry, g * 8 + u) >> 26);
+          if (px != cur) { flush(); cur = px; }
+          const float w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)rx, g * 8 + u));
+          acc.x = fmaf(w, v[u].x, acc.x); acc.y = fmaf(w, v[u].y, acc.y);
+          acc.z = fmaf(w, v[u].z, acc.z); acc.w = fmaf(w, v[u].w, acc.w);
+        }
+      }
+    };
+    float4 v0[8], v1[8];
+    pg_issue(p.table, rc.y, 0, lane, v0);
+    for (int bb = s; bb < e; bb += 64) {
+      const bool more = bb + 64 < e;
+      uint2 rn = rc;
+      if (more) rn = fetch(bb + 64);
+      const int ng = min(8, (e - bb + 7) >> 3);
+#pragma unroll
+      for (int g = 0; g < 8; g += 2) {
+        if (g + 1 < ng) pg_issue(p.table, rc.y, g + 1, lane, v1);
+        if (g < ng) fma_group(rc.x, rc.y, g, v0);
+        if (g + 2 < ng) pg_issue(p.table, rc.y, g + 2, lane, v0);
+        else if (g + 2 == 8 && more) pg_issue(p.table, rn.y, 0, lane, v0);     // the next batch's first group
+        if (g + 1 < ng) fma_group(rc.x, rc.y, g + 1, v1);
+      }
+      rc = rn;
+    }
+    flush();
+  }
+  if (lane == 0) s_head[wave] = head;
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < 8; ++w) {
+      const int px = s_head[w];
+      if (px < 0) continue;
+      float4 a = *reinterpret_cast<const float4*>(&s_tp[px * PG_PITCH + lane * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(s_part + w * kChannels + lane * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = a;
+    }
+  }
+  __syncthreads();
+  if (NHWC) {
+    // channels-last output (R, H, W, C): a pixel is one contiguous 1-KB row; wave w writes pixels w, w + 8, ...
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    for (int px = wave; px < npx; px += 8) {
       const int yy = (cy << chs) + (px >> cws), xx = (cx << cws) + (px & ((1 << cws) - 1));
-      if (yy < H && xx < W)
-      {
-        typedef float f4v __attribute__((ext_vector_type(4)));
+      if (yy < H && xx < W) {
+        const float4 v = *reinterpret_cast<const float4*>(&s_tp[px * PG_PITCH + lane * 4]);
         __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w},
                                     reinterpret_cast<f4v*>(p.out[l] + (((size_t)row * H + yy) * W + xx) * kChannels) + lane);
       }
-    } else {
-      *reinterpret_cast<float4*>(&s_tp[px * PG_PITCH + lane * 4]) = v;
     }
-  };
-  // cursor over the wave's runs; pixels without records get their row of zeros on the way
-  int cpx = px0 - 1, ci = 0, cb = 0;
-  auto next = [&]() -> PgGroup {
-    while (ci >= cb) {
-      ++cpx;
-      if (cpx >= px0 + ppw) return PgGroup{0, 0, 0, 0};
-      ci = __builtin_amdgcn_readfirstlane(s_po[wave][cpx - px0]);
-      cb = __builtin_amdgcn_readfirstlane(s_po[wave][cpx - px0 + 1]);
-      if (ci >= cb) put(cpx, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    PgGroup g{ci, min(8, cb - ci), cpx, cb - ci <= 8};
-    ci += 8;
-    return g;
-  };
-  auto fetch = [&](const PgGroup& g, uint2 (&r)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = rec[g.i + u];               // uniform address: ONE 64-byte scalar load (may run past
-  };                                                                // the run: those records get weight 0)
-  uint2 r0[8], r1[8], r2[8];
-  float4 v0[8], v1[8];
-  PgGroup g0 = next(), g1{0, 0, 0, 0}, g2{0, 0, 0, 0};
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g0.n) {
-    fetch(g0, r0);
-    g1 = next();
-    if (g1.n) fetch(g1, r1);
-    pg_issue<VARIANT>(p.table, r0, g0.n, lane, v0);
-    for (;;) {
-      g2 = g1.n ? next() : PgGroup{0, 0, 0, 0};
-      if (g2.n) fetch(g2, r2);
-      if (g1.n) pg_issue<VARIANT>(p.table, r1, g1.n, lane, v1);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float w = u < g0.n ? __uint_as_float(r0[u].x) : 0.f;
-        acc.x = fmaf(w, v0[u].x, acc.x); acc.y = fmaf(w, v0[u].y, acc.y);
-        acc.z = fmaf(w, v0[u].z, acc.z); acc.w = fmaf(w, v0[u].w, acc.w);
-      }
-      if (g0.last) {
-        put(g0.px, acc);
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (!g1.n) break;
-      g0 = g1; g1 = g2;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { r0[u] = r1[u]; r1[u] = r2[u]; v0[u] = v1[u]; }
-    }
+    return;
   }
-  if (NHWC) return;
-  __syncthreads();
-  // wave w writes channels 32 w .. 32 w + 31; lane = pixel of the chunk (runs of cw pixels)
+  // wave w writes channels 32 w .. 32 w + 31; lane = pixel of the chunk (runs of cw pixels).  Non-temporal: kept in the L2
+  // (plain stores) the written lines push out the table rows - the write-out alone is twice as fast, the kernel slower.
   const int py = lane >> cws, pxx = lane & ((1 << cws) - 1);
   const int y = (cy << chs) + py, x = (cx << cws) + pxx;
-  if (VARIANT == 3) return;
   if (py < (1 << chs) && y < H && x < W) {
     float* gp = p.out[l] + ((size_t)row * kChannels + wave * 32) * ((size_t)H * W) + (size_t)y * W + x;
 #pragma unroll 8
@@ -1246,7 +1282,7 @@ extern "C" int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxo
   p.chunk_order = chunk_order;
   p.per = (p.g.total + 7) / 8;
   if (chunk_order) per = p.per;
-  const size_t lds = (size_t)PG_PX * PG_PITCH * sizeof(float);
+  const size_t lds = ((size_t)PG_PX * PG_PITCH + PG_PART) * sizeof(float);
   auto go = [&](auto kern) -> int {
     if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(8 * per), dim3(PG_THREADS), lds, static_cast<hipStream_t>(stream), p);
@@ -1255,7 +1291,7 @@ extern "C" int gd4d_pyramid_grad_reduce(const int32_t* start, const int32_t* pxo
   if (channels_last) {
     for (int l = 0; l < L; ++l)
       if (!aligned16(grads[l])) return GD4D_EALIGN;
-    return go(pyramid_grad_reduce_kernel<0, true>);
+    return go(pyramid_grad_reduce_kernel<true>);
   }
-  return go(pyramid_grad_reduce_kernel<0, false>);
+  return go(pyramid_grad_reduce_kernel<false>);
 }

@@ -271,7 +271,6 @@ __device__ __forceinline__ void mha_bwd_body(const MhaBwdParams& p, const int bx
   const int Lc = SIDE == 0 ? p.Lq : p.Lk;               // extent of the column (owned) side
   const int Lr = SIDE == 0 ? p.Lk : p.Lq;               // extent of the row (looped) side
   const int rho = (ci >> 2) + 4 * (ci & 3);             // row (within a tile) this lane feeds as MFMA A row
-  const float NEG_INF = -__builtin_inff();
 
   // column-side operands of this lane (column ci, dims 8 g .. 8 g + 7)
   const int crow = min(c0 + ci, Lc - 1);

@@ -394,7 +394,7 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
             late = None
         cross = [a for layer in self.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
         if late is None and kwargs.get(Fn.VALUE_CACHE_KEY) is None and cross \
-                and all(type(a) is Deform3DCrossAttn for a in cross) and isinstance(kwargs.get('value'), (list, tuple)) \
+                and all(isinstance(a, Deform3DCrossAttn) for a in cross) and isinstance(kwargs.get('value'), (list, tuple)) \
                 and Fn.LateValues.applicable(cross, kwargs['value']) and not Fn.wants_grad(self, query, *kwargs['value']):
             # aggregate-then-project (GD4D_PROJECT=late, default): no per-layer value tensors, ONE channels-last copy of
             # the pyramid for all layers (made on the side stream next to layer 0's self-attention)
@@ -523,7 +523,7 @@ class Detr3DTransformer(nn.Module):
         if fast and kwargs.get(Fn.LATE_VALUES_KEY) is None and kwargs.get(Fn.VALUE_CACHE_KEY) is None:
             # the channels-last copy of the pyramid needs nothing but the pyramid: fork it first, before the query side
             cross = [a for layer in self.decoder.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
-            if cross and all(type(a) is Deform3DCrossAttn for a in cross) and Fn.LateValues.applicable(cross, mlvl_feats):
+            if cross and all(isinstance(a, Deform3DCrossAttn) for a in cross) and Fn.LateValues.applicable(cross, mlvl_feats):
                 own_late = Fn.LateValues(mlvl_feats, cross[0].value_dtype)
                 kwargs = dict(kwargs)
                 kwargs[Fn.LATE_VALUES_KEY] = own_late

@@ -643,9 +643,10 @@ class LateValues:
                 self.cl.record_stream(cur)
 
     def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, vp_weight=None,
-                  vp_bias=None):
+                  vp_bias=None, raw_cam_weights=False):
         """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh); rows mode with vp_weight:
-        (out (B, Q, C),) - value_proj applied in the kernel's epilogue."""
+        (out (B, Q, C),) - value_proj applied in the kernel's epilogue.  raw_cam_weights: the camera logits are used as they
+        are, without the sigmoid (the neighbour pass of Deform3DCrossAttnMP)."""
         # (kernels: 1 / 2 / 4 / 8 points per head with 8 heads on the sliced form, 4 otherwise; other counts - the reference's
         #  constructor default is 5 - are padded with points that are never visible and weigh nothing)
         offsets, attn_logits = pad_points(offsets, attn_logits, (1, 2, 4, 8) if self.mode == 'sliced' and module.num_heads == 8 else (4,),
@@ -656,7 +657,7 @@ class LateValues:
             items = os.environ.get('GD4D_PLAN', 'items') != 'pairs'
             plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                            cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
-                                           query_order=order, items=items)
+                                           query_order=order, items=items, raw_cam_weights=raw_cam_weights)
             self._wait_copy()
             agg = ops.cross_attn_agg_sliced_fwd(plan)
             if vp_weight is not None:
@@ -665,7 +666,8 @@ class LateValues:
         self._wait_copy()
         return ops.cross_attn_agg_fwd(self.cl, self.shapes, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                       cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w,
-                                      module.num_heads, query_order=order, vp_weight=vp_weight, vp_bias=vp_bias)
+                                      module.num_heads, query_order=order, vp_weight=vp_weight, vp_bias=vp_bias,
+                                      raw_cam_weights=raw_cam_weights)
 
     def sample_aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None):
         """What functional.sample_aggregate returns on the projected values of `module`: (B, Q, C), the input of

@@ -194,9 +194,18 @@ def test_hdetr_transformer_mask_path_equals_oracle():
     assert (s2.cpu() - s_ref).abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize('route', ['raw', 'projected'])
 @pytest.mark.parametrize('name', ['deform_mp_n6', 'deform_mp_n12_b2'])
-def test_deform3d_cross_attn_mp_module(name):
-    """Deform3DCrossAttnMP (centre pass + neighbour pass on the fused kernel) against the reference's forward."""
+def test_deform3d_cross_attn_mp_module(name, route, monkeypatch):
+    """Deform3DCrossAttnMP (centre pass + neighbour pass) against the reference's forward: on the raw pyramid (the default:
+    aggregate-then-project, value_proj never runs over the pixels) and on the projected-value kernels."""
+    from graph_detr4d_amd import ops
+    if route == 'projected':
+        monkeypatch.setenv('GD4D_PROJECT', 'early')
+        monkeypatch.setenv('GD4D_TRAIN_VALUES', 'projected')
+    pixel_rows = []
+    real = ops.value_proj_fwd
+    monkeypatch.setattr(ops, 'value_proj_fwd', lambda *a, **k: (pixel_rows.append(1), real(*a, **k))[1])
     g = Golden(name)
     m = g.meta
     mod = G.build_attention(dict(type='Deform3DCrossAttnMP', num_cams=m['num_cams'], pc_range=m['pc_range'],
@@ -215,6 +224,7 @@ def test_deform3d_cross_attn_mp_module(name):
                 reference_points=g.t('reference_points').to(DEV), img_metas=_metas(g))
     assert out_t.requires_grad
     torch.testing.assert_close(out_t.detach().cpu(), g.t('out'), **TOL)
+    assert bool(pixel_rows) == (route == 'projected'), 'value_proj over the pixel rows runs on the projected route only'
 
 
 @pytest.mark.parametrize('name', ['dgcnn', 'dgcnn_k8'])

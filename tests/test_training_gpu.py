@@ -452,12 +452,20 @@ def test_detr3d_cross_atten_trains(name, route, monkeypatch):
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
 
 
+@pytest.mark.parametrize('route', ['raw', 'projected'])
 @pytest.mark.parametrize('name', ['deform_mp_n6', 'deform_mp_n12_b2'])
-def test_deform3d_cross_attn_mp_trains(name):
+def test_deform3d_cross_attn_mp_trains(name, route, monkeypatch):
     """Deform3DCrossAttnMP with autograd on (config detr4d_res50_deform_pe_mp...: the multi-point variant): gradients of the
     query, the reference points (centres and neighbours), the feature maps and every parameter that takes part against
-    autograd of the oracle (deform3d_cross_attn_multi_point.py:196-453)."""
+    autograd of the oracle (deform3d_cross_attn_multi_point.py:196-453).  route 'raw' (default): both passes are
+    CrossAttnRawFunction nodes on one slice-planar copy; 'projected': GD4D_TRAIN_VALUES=projected."""
     from oracle import torch_oracle as O
+    from graph_detr4d_amd import ops
+    if route == 'projected':
+        monkeypatch.setenv('GD4D_TRAIN_VALUES', 'projected')
+    pixel_rows = []
+    real = ops.value_proj_fwd
+    monkeypatch.setattr(ops, 'value_proj_fwd', lambda *a, **k: (pixel_rows.append(1), real(*a, **k))[1])
     g = Golden(name)
     m = g.meta
     mod = G.build_attention(dict(type='Deform3DCrossAttnMP', num_cams=m['num_cams'], pc_range=m['pc_range'],
@@ -489,6 +497,7 @@ def test_deform3d_cross_attn_mp_trains(name):
             continue
         assert prm.grad is not None, k
         assert _rel(prm.grad.cpu(), p_cpu[k].grad) < 3e-3, k
+    assert bool(pixel_rows) == (route == 'projected')
 
 
 @pytest.mark.parametrize('route', ['hip', 'torch'])
