@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 51
+ABI_VERSION = 52
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -77,7 +77,7 @@ SIGNATURES = {
     'gd4d_layernorm_bwd_reduce_group': (_i, [_vp] * 4 + [_i, _i, _vp]),
     'gd4d_refine_reference_fwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_frustum_pe_input_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _i, _vp]),
-    'gd4d_se_fuse_chlast_fwd': (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
+    'gd4d_se_fuse_chlast_fwd': (_i, [_vp] * 5 + [_i] * 7 + [_vp]),
     'gd4d_sine_pe3d_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'gd4d_se_fuse_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_split_bf16_fwd': (_i, [_vp, _vp, _vp, _c.c_size_t, _vp]),

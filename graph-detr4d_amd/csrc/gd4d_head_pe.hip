@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void se_fuse_kernel(const float4* __restrict__
 
 // out[r, c, pix] = feat[r, c, pix] + (pe[r, start + pix, c] * sigmoid(gate[r, start + pix, c]) + sine[r, c, pix]):
 // the channels-last products of the GEMM path meet the NCHW maps; 32 x 32 (channel, pixel) tiles through LDS so that
-// both sides are read and written coalesced.
+// both sides are read and written coalesced.  OUT_CHLAST: the result is stored (R, H, W, C) - the layout the decoder's
+// gathers read in place (no per-sample copy there): then it is `feat` that goes through the tile, the sum is the same
+// expression, so both layouts hold the same bits.
+template <bool OUT_CHLAST>
 __global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __restrict__ feat, const float* __restrict__ gate,
                                                              const float* __restrict__ pe, const float* __restrict__ sine,
                                                              float* __restrict__ out, int C, int HW, int S, int start,
@@ -153,6 +156,24 @@ __global__ __launch_bounds__(256) void se_fuse_chlast_kernel(const float* __rest
   const int r = blockIdx.z;
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+  if (OUT_CHLAST) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                     // read NCHW: tx = pixel, rows = channels
+      const int c = c0 + ty + 8 * i, pix = p0 + tx;
+      tile[ty + 8 * i][tx] = pix < HW ? feat[((size_t)r * C + c) * HW + pix] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                     // channels-last: tx = channel, rows = pixels
+      const int pix = p0 + ty + 8 * i, c = c0 + tx;
+      if (pix < HW) {
+        const size_t o = ((size_t)r * S + start + pix) * C + c;
+        const float v = pe[o] * (1.0f / (1.0f + expf(-gate[o]))) + sine[o];
+        out[((size_t)r * HW + pix) * C + c] = tile[tx][ty + 8 * i] + v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {                                       // read channels-last: tx = channel, rows = pixels
     const int pix = p0 + ty + 8 * i, c = c0 + tx;
@@ -263,15 +284,19 @@ extern "C" int gd4d_se_fuse_fwd(const float* feat, const float* gate, const floa
 }
 
 extern "C" int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out,
-                                       int R, int C, int HW, int row_pixels, int row_start, int sine_chlast,
+                                       int R, int C, int HW, int row_pixels, int row_start, int sine_chlast, int out_chlast,
                                        void* stream) {
   using namespace gd4d;
   if (!feat || !gate || !pe || !sine || !out || R <= 0 || C <= 0 || HW <= 0) return GD4D_EINVAL;
   if (row_start < 0 || row_start + HW > row_pixels) return GD4D_EINVAL;
-  if (C % 32 != 0 || R > 65535) return GD4D_EUNSUPPORTED;
-  hipLaunchKernelGGL(se_fuse_chlast_kernel, dim3((HW + 31) / 32, C / 32, R), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), feat, gate, pe, sine, out, C, HW, row_pixels, row_start,
-                     sine_chlast ? 1 : 0);
+  if (C % 32 != 0 || R > 65535 || (out_chlast && !sine_chlast)) return GD4D_EUNSUPPORTED;
+  const dim3 grid((HW + 31) / 32, C / 32, R);
+  if (out_chlast)
+    hipLaunchKernelGGL(se_fuse_chlast_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, gate, pe, sine, out,
+                       C, HW, row_pixels, row_start, 1);
+  else
+    hipLaunchKernelGGL(se_fuse_chlast_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, gate, pe, sine, out,
+                       C, HW, row_pixels, row_start, sine_chlast ? 1 : 0);
   return check_launch();
 }
 

@@ -138,14 +138,20 @@ class _HeadPEFunction(torch.autograd.Function):
 
 class FeaturePositionEmbedding(nn.Module):
     def __init__(self, embed_dims=256, depth_num=64, depth_start=1, pc_range=None, num_feats=128, temperature=10000,
-                 normalize=True, scale=2 * math.pi, eps=1e-6, offset=-0.5, with_detach=True, cams_per_frame=6):
+                 normalize=True, scale=2 * math.pi, eps=1e-6, offset=-0.5, with_detach=True, cams_per_frame=6,
+                 channels_last_out=False):
         """with_detach (the head's keyword and default, detr3d_head_pe.py:326, :358): level 0's past-frame cameras - every
         camera after the first `cams_per_frame` = 6, hard-coded at :514-515 - reach this stage and the decoder DETACHED
-        (:512-516): same values, no gradient back to the backbone through them.  A no-op for single-frame inputs."""
+        (:512-516): same values, no gradient back to the backbone through them.  A no-op for single-frame inputs.
+        channels_last_out (not a keyword of the reference; inference): the returned (B, N, C, H, W) tensors hold the same values
+        but their MEMORY is (B, N, H, W, C) - the decoder's gathers read such levels in place, so its per-sample slice-planar
+        copy (0.27 ms of a 1.6-ms sample at 24 cameras) does not run.  Leave it off when other code takes `.view()`s of the maps."""
         super().__init__()
         if pc_range is None:
             raise ValueError('pc_range is required (the head takes it from its bbox coder)')
         self.with_detach, self.cams_per_frame = bool(with_detach), int(cams_per_frame)
+        self.channels_last_out = bool(channels_last_out)
+        self.cache_position_embedding = True      # inference: per camera, keyed by its matrix (757 MB at 24 cameras; False: recompute)
         self.embed_dims, self.depth_num, self.depth_start = embed_dims, depth_num, depth_start
         self.pc_range = list(pc_range)
         self.position_dim = 3 * depth_num
@@ -160,6 +166,7 @@ class FeaturePositionEmbedding(nn.Module):
         self._sine_cache = None
         self._mask_cache = None
         self._split_cache = None
+        self._pe_cache = None
 
     # ---- pieces -------------------------------------------------------------------------------------------------
     def padding_masks(self, img_metas, feats):
@@ -258,8 +265,26 @@ class FeaturePositionEmbedding(nn.Module):
             # the position MLP as one kernel (gd4d_mlp2_bf16x3_fwd) where its shape allows: the image holds W1, b1 and W2
             cache['pe_mlp'] = ops.mlp2_image(flat(pe0), pe0.bias.detach(), flat(pe2)) \
                 if ops.mlp2_supported(pe0.in_channels, pe0.out_channels, pe2.out_channels) else None
+            cache['key'] = key
             self._split_cache = (key, cache)
         return self._split_cache[1]
+
+    def _position_mlp(self, img2lidar, shapes, starts, s_tot, pad_hw, sw, out=None):
+        """position_encoder(frustum) for the cameras of `img2lidar` (R', 4, 4) -> (R', S, C) channels-last rows (`out`: written there)."""
+        r = img2lidar.shape[0]
+        if out is not None:
+            out = out.view(r * s_tot, -1)
+        x = torch.empty(r, s_tot, self.position_dim, device=img2lidar.device, dtype=torch.float32)
+        for (h, w), st in zip(shapes, starts):
+            ops.frustum_pe_input_fwd(img2lidar, (h, w), pad_hw, self.depth_num, self.depth_start, self.pc_range,
+                                     out=x, row_start=st)
+        pe0, pe2 = self.position_encoder[0], self.position_encoder[2]
+        if sw.get('pe_mlp') is not None:
+            # Conv1x1, ReLU, Conv1x1 in ONE kernel: the (R*S, 1024) hidden activation (3 GB at 24 cameras) stays in registers
+            return ops.mlp2_bf16x3_fwd(x.view(r * s_tot, -1), sw['pe_mlp'], pe2.bias, out=out).view(r, s_tot, -1)
+        hid = ops.gemm_bf16x3_fwd(x.view(r * s_tot, -1), *sw['pe0'], pe0.bias, relu=True)
+        del x
+        return ops.gemm_bf16x3_fwd(hid, *sw['pe2'], pe2.bias, out=out).view(r, s_tot, -1)
 
     def _forward_gemm(self, feats, img_metas, masks, pad_hw, sine):
         """The dense part on the bf16 matrix cores (three split products per output, fp32-class):
@@ -273,22 +298,32 @@ class FeaturePositionEmbedding(nn.Module):
         s_tot = sum(h * w for h, w in shapes)
         starts = [sum(h * w for h, w in shapes[:i]) for i in range(len(shapes))]
         l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
-        img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(r, 4, 4).to(dev)          # :459-465
-        x = torch.empty(r, s_tot, self.position_dim, device=dev, dtype=torch.float32)
-        for (h, w), st in zip(shapes, starts):
-            ops.frustum_pe_input_fwd(img2lidar, (h, w), pad_hw, self.depth_num, self.depth_start, self.pc_range,
-                                     out=x, row_start=st)
+        mats = np.ascontiguousarray(np.linalg.inv(l2i).astype(np.float32).reshape(r, 16))        # :459-465
         sw = self._split_weights()
-        pe0, pe2 = self.position_encoder[0], self.position_encoder[2]
-        if sw.get('pe_mlp') is not None:
-            # Conv1x1, ReLU, Conv1x1 in ONE kernel: the (R*S, 1024) hidden activation (3 GB at 24 cameras) stays in registers
-            pe = ops.mlp2_bf16x3_fwd(x.view(r * s_tot, -1), sw['pe_mlp'], pe2.bias)             # (R*S, C)
-            del x
+        # The embedding of a camera is a function of its matrix, the level shapes and the MLP's weights - not of the features.  It is
+        # kept per camera and recomputed for the cameras whose matrix changed: the current frame's cameras keep their calibration
+        # from sample to sample (the past frames' matrices carry the ego motion and change every time).
+        b2 = self.position_encoder[2].bias
+        pkey = (str(dev), tuple(shapes), tuple(pad_hw), r, sw['key'], b2.data_ptr(), b2._version)
+        c = self._pe_cache if self.cache_position_embedding else None
+        if c is not None and c[0] == pkey:
+            changed = [i for i in range(r) if not np.array_equal(mats[i], c[1][i])]
         else:
-            hid = ops.gemm_bf16x3_fwd(x.view(r * s_tot, -1), *sw['pe0'], pe0.bias, relu=True)
-            del x
-            pe = ops.gemm_bf16x3_fwd(hid, *sw['pe2'], pe2.bias)                                  # (R*S, C)
-            del hid
+            c, changed = None, list(range(r))
+        if changed:
+            i2l = torch.from_numpy(mats[changed]).view(-1, 4, 4).to(dev)
+            if c is None:
+                pe = self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw)
+            elif changed[-1] - changed[0] + 1 == len(changed):
+                # a run of cameras (the past frames follow the current one): the MLP writes their rows of the kept tensor
+                pe = c[2]
+                self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw, out=pe[changed[0]:changed[-1] + 1])
+            else:
+                pe = c[2]
+                pe.index_copy_(0, torch.as_tensor(changed, device=dev), self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw))
+            self._pe_cache = (pkey, mats, pe) if self.cache_position_embedding else None
+        else:
+            pe = c[2]
         cr, ce = self.fpe.conv_reduce, self.fpe.conv_expand
         g1 = ops.value_proj_fwd([f.contiguous() for f in feats], cr.weight.view(self.embed_dims, -1).contiguous(),
                                 cr.bias.contiguous())                                             # (R, S, C) channels-last
@@ -297,8 +332,8 @@ class FeaturePositionEmbedding(nn.Module):
         pe, gate = pe.view(r, s_tot, -1), gate.view(r, s_tot, -1)
         out = []
         for lvl, (f, st) in enumerate(zip(feats, starts)):
-            o = ops.se_fuse_chlast_fwd(f.flatten(0, 1).contiguous(), gate, pe, sine, st)
-            out.append(o.view(f.shape))
+            o = ops.se_fuse_chlast_fwd(f.flatten(0, 1).contiguous(), gate, pe, sine, st, out_channels_last=self.channels_last_out)
+            out.append(o.unflatten(0, (b, n)) if self.channels_last_out else o.view(f.shape))
         return out
 
     # ---- training ---------------------------------------------------------------------------------------------------

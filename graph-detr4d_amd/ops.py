@@ -1309,17 +1309,20 @@ def frustum_pe_input_fwd(img2lidar, feat_hw, pad_hw, depth_num, depth_start, pc_
     return out, outside.bool()
 
 
-def se_fuse_chlast_fwd(feat, gate, pe, sine, row_start, out=None):
+def se_fuse_chlast_fwd(feat, gate, pe, sine, row_start, out=None, out_channels_last=False):
     """gd4d_se_fuse_chlast_fwd: feat (R, C, H, W) NCHW, gate / pe (R, S, C) channels-last, sine NCHW like feat or
-    channels-last like gate -> (R, C, H, W)."""
+    channels-last like gate -> (R, C, H, W).  out_channels_last: the result's MEMORY is (R, H, W, C) - returned as its
+    (R, C, H, W) view, the same values; what PyramidView.is_channels_last_level recognises and the gathers read in place."""
     lib = _lib.load()
     r, c, h, w = feat.shape
-    out = torch.empty_like(feat) if out is None else out
+    if out is None:
+        out = torch.empty((r, h, w, c) if out_channels_last else (r, c, h, w), device=feat.device, dtype=torch.float32)
     code = lib.gd4d_se_fuse_chlast_fwd(_dev(feat, 'feat', torch.float32), _dev(gate, 'gate', torch.float32),
                                        _dev(pe, 'pe', torch.float32), _dev(sine, 'sine', torch.float32), _dev(out, 'out'),
-                                       r, c, h * w, gate.shape[1], int(row_start), int(sine.dim() == 3), _stream())
+                                       r, c, h * w, gate.shape[1], int(row_start), int(sine.dim() == 3),
+                                       1 if out_channels_last else 0, _stream())
     _lib.check(code, 'gd4d_se_fuse_chlast_fwd')
-    return out
+    return out.permute(0, 3, 1, 2) if out_channels_last else out
 
 
 def sine_pe3d_fwd(n_embed, y_embed, x_embed, dim_t, out=None, row_start=0):

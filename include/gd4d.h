@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 51
+#define GD4D_ABI_VERSION 52
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -855,8 +855,10 @@ int gd4d_se_fuse_fwd(const float* feat, const float* gate, const float* pe, cons
 /* gd4d_se_fuse_chlast_fwd - the same with channels-last gate / pe (R, row_pixels, C) (this level at pixels
  * [row_start, row_start + HW)) against NCHW feat / sine / out (R, C, HW): a tiled transpose through LDS.  C % 32 == 0. */
 int gd4d_se_fuse_chlast_fwd(const float* feat, const float* gate, const float* pe, const float* sine, float* out, int R,
-                            int C, int HW, int row_pixels, int row_start, int sine_chlast, void* stream);
-/*   sine_chlast != 0: `sine` is channels-last (R, row_pixels, C) like gate / pe instead of NCHW. */
+                            int C, int HW, int row_pixels, int row_start, int sine_chlast, int out_chlast, void* stream);
+/*   sine_chlast != 0: `sine` is channels-last (R, row_pixels, C) like gate / pe instead of NCHW.
+ *   out_chlast != 0 (needs sine_chlast): `out` is stored (R, HW, C) - the level in the layout the decoder's gathers read in place
+ *   (gd4d_cross_attn_agg_items_fwd with pixel stride C * 4: no per-sample slice-planar copy); the same bits as the NCHW result. */
 /* gd4d_se_fuse_chlast_bwd - its backward for one level (what autograd derives from detr3d_head_pe.py:241-243, :556):
  * grad_out NCHW (R, C, HW) -> channels-last rows [row_start, row_start + HW) of grad_sine = g, grad_pe = g sigmoid(gate),
  * grad_gate = g pe sigmoid'(gate).  grad_pe / grad_gate may alias pe / gate (in place).  The gradient of `feat` through

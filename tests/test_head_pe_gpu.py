@@ -1,5 +1,6 @@
 """Feature position embedding (HIP kernels + library 1x1 convs) against the reference-generated fixture and the oracle.
 GPU only."""
+import numpy as np
 import pytest
 import torch
 
@@ -76,6 +77,94 @@ def test_feature_position_embedding_matches_reference():
     from graph_detr4d_amd._lib import Gd4dError
     with pytest.raises(Gd4dError):
         mod.cpu()([f.cpu() for f in feats], _metas(g))
+
+
+def test_position_embedding_is_kept_per_camera_and_follows_the_matrices():
+    """Inference keeps position_encoder(frustum) per camera, keyed by the camera's img2lidar matrix: a call with some matrices changed
+    recomputes those cameras only and equals a fresh module bit for bit; a weight update drops the cache."""
+    import copy
+    from graph_detr4d_amd import ops
+    g = Golden('head_pe')
+    mod = _module(g)
+    feats = [f.cuda() for f in g.feats()]
+    metas = _metas(g)
+    rows = []
+    real = ops.mlp2_bf16x3_fwd
+    ops.mlp2_bf16x3_fwd = lambda x, *a, **k: (rows.append(x.shape[0]), real(x, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            first = mod(feats, metas)
+            same = mod(feats, metas)
+            assert len(rows) == 1, 'nothing changed: no camera recomputed'
+            for a, b in zip(first, same):
+                assert torch.equal(a, b)
+            n = feats[0].shape[1]
+            moved = copy.deepcopy(metas)
+            for cam in (1, n - 1):                                        # two cameras get another pose
+                m = np.array(moved[0]['lidar2img'][cam], dtype=np.float64)
+                m[:3, 3] += np.array([0.7, -0.4, 0.2]) * (cam + 1)
+                moved[0]['lidar2img'][cam] = m
+            got = mod(feats, moved)
+            s_tot = sum(f.shape[-2] * f.shape[-1] for f in feats)
+            assert rows[-1] == 2 * s_tot, 'two cameras recomputed'
+            fresh = _module(g)
+            want = fresh(feats, moved)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+            assert not torch.equal(got[0][:, 1], first[0][:, 1]) and torch.equal(got[0][:, 0], first[0][:, 0])
+            run = copy.deepcopy(moved)                                    # a RUN of cameras: written in place, no scatter
+            for cam in (2, 3):
+                m = np.array(run[0]['lidar2img'][cam], dtype=np.float64)
+                m[:3, 3] -= 0.3 * cam
+                run[0]['lidar2img'][cam] = m
+            got_run = mod(feats, run)
+            assert rows[-1] == 2 * s_tot
+            for a, b in zip(got_run, _module(g)(feats, run)):
+                assert torch.equal(a, b)
+            mod.position_encoder[2].bias.add_(0.5)                        # a weight update: everything is recomputed
+            count = len(rows)
+            upd = mod(feats, moved)
+            assert len(rows) == count + 1 and rows[-1] == n * s_tot * feats[0].shape[0]
+            assert not torch.equal(upd[0], got[0])
+    finally:
+        ops.mlp2_bf16x3_fwd = real
+
+
+def test_channels_last_output_holds_the_same_bits_and_is_gathered_in_place():
+    """FeaturePositionEmbedding(channels_last_out=True): the (B, N, C, H, W) results equal the default's bit for bit, their memory is
+    (B, N, H, W, C), and the cross-attention reads them in place (no slice-planar copy) with the same output."""
+    from graph_detr4d_amd import ops
+    import graph_detr4d_amd as G
+    g = Golden('head_pe')
+    mod = _module(g)
+    feats = [f.cuda() for f in g.feats()]
+    with torch.no_grad():
+        want = mod(feats, _metas(g))
+        mod.channels_last_out = True
+        got = mod(feats, _metas(g))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+        assert ops.PyramidView.is_channels_last_level(a) and not ops.PyramidView.is_channels_last_level(b)
+    copies = []
+    real = ops.pyramid_slice_planar_fwd
+    ops.pyramid_slice_planar_fwd = lambda *a, **k: (copies.append(1), real(*a, **k))[1]
+    try:
+        n = feats[0].shape[1]
+        attn = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=n, pc_range=g.meta['pc_range'], num_points=4, embed_dims=256,
+                                      num_levels=len(feats))).cuda().eval()
+        torch.manual_seed(0)
+        q, b = 50, feats[0].shape[0]
+        query, pos = torch.randn(q, b, 256, device='cuda'), torch.randn(q, b, 256, device='cuda')
+        ref = torch.rand(b, q, 3, device='cuda')
+        metas = _metas(g)
+        with torch.no_grad():
+            o_cl = attn(query, None, got, query_pos=pos, reference_points=ref, img_metas=metas)
+            assert not copies, 'channels-last levels are gathered in place'
+            o_nchw = attn(query, None, want, query_pos=pos, reference_points=ref, img_metas=metas)
+            assert copies
+    finally:
+        ops.pyramid_slice_planar_fwd = real
+    torch.testing.assert_close(o_cl, o_nchw, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize('route', ['hip', 'torch'])
