@@ -52,6 +52,35 @@ struct Mlp2Params {
   int M, K1, H, ldx, ldo;
 };
 
+// The SE form (gd4d_mlp2_se_fuse_fwd): the rows are the pixels of NCHW feature levels laid side by side - row m = camera r,
+// level l, pixel pix with m = r S + start[l] + pix - X is read from the maps themselves and the epilogue is the head's fuse:
+//   out[r, pix, n] = feat[r, n, pix] + (pe[m, n] * sigmoid(acc[m, n] + b2[n]) + sine[m, n]),     out stored (R, HW_l, 256) per level.
+struct Mlp2Se {
+  const float* feat[4];     // (R, 256, HW_l)
+  float* out[4];            // (R, HW_l, 256)
+  const float* pe;          // (R S, 256) channels-last rows
+  const float* sine;        // (R S, 256)
+  int hw[4];
+  int start[5];             // first row of level l inside a camera's S rows; start[l >= L] = S
+  int S;
+};
+
+// sigmoid on the transcendental unit (v_exp_f32, v_rcp_f32: ~1e-7 absolute - the library's expf and an IEEE division are ~45
+// instructions per element, and with one wave per SIMD the epilogue's arithmetic is not hidden by anything)
+__device__ __forceinline__ float ml_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+struct Mlp2Row { const float* f; float* o; int pix, hw; };     // feat / out of the row's camera and level; its pixel
+
+__device__ __forceinline__ Mlp2Row ml_row_of(const Mlp2Se& q, int m) {
+  const int r = m / q.S;
+  const int rem = m - r * q.S;
+  const int l = (rem >= q.start[1]) + (rem >= q.start[2]) + (rem >= q.start[3]);
+  const int hw = q.hw[l];
+  return Mlp2Row{q.feat[l] + (size_t)r * ML_N2 * hw, q.out[l] + (size_t)r * hw * ML_N2, rem - q.start[l], hw};
+}
+
 __device__ __forceinline__ unsigned ml_cvt_pk_bf16(float lo_elem, float hi_elem) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_elem), "v"(hi_elem));
@@ -76,8 +105,8 @@ __device__ __forceinline__ ml_bf16x8 ml_frag(const ml_u32x4& v) { return __built
 // of v_mfma_f32_32x32x16 - and, read as r = 8 s + e, the k-slot e of phase B's step s
 __host__ __device__ __forceinline__ int ml_hidden_of(int kg, int r) { return 4 * kg + (r & 3) + 8 * (r >> 2); }
 
-template <int STEPS1>
-__global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p) {
+template <int STEPS1, bool SE = false>
+__global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p, const Mlp2Se q) {
   extern __shared__ __attribute__((aligned(16))) char ml_smem[];
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -87,8 +116,12 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p)
   constexpr int S1 = STEPS1 * 2048 + 1024;             // bytes of a chunk of W1's image: [step][plane][1 KB], then 1 KB holding b1's 32 entries
   constexpr int STAGE = S1 + ML_S2;
   const int nchunks = p.H / ML_HC;
-  const int m0 = blockIdx.x * ML_BM + wave * 32;
-  const float* xrow = p.x + (size_t)min(m0 + l32, p.M - 1) * p.ldx + 8 * kg;
+  // A workgroup walks tiles blockIdx, blockIdx + grid, ..: the next tile's rows of X are requested when this tile's products start
+  // and the weight stages form a ring across tiles (the stage after a tile's last chunk is the next tile's chunk 0).  Launched with
+  // one workgroup per tile (see mlp2_grid).
+  const int ntiles = (p.M + ML_BM - 1) / ML_BM;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
 
   // A stage = a chunk's fragments, 1 KB each: a wave instruction (LDS-DMA) moves one.  Wave w moves pieces w, w + 4, ..; issuing
   // one costs 60 - 185 cycles, so the next chunk's pieces go out one at a time BETWEEN the MFMA groups of this chunk's phase B.
@@ -100,19 +133,41 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p)
     const char* src = i < n1 ? p.w1img + (size_t)c * S1 + ((size_t)i << 10) : p.w2img + (size_t)c * ML_S2 + ((size_t)(i - n1) << 10);
     __builtin_amdgcn_global_load_lds((glb_void_t*)(src + lane * 16), (lds_void_t*)(ml_smem + buf * STAGE + (i << 10)), 16, 0, 0);
   };
-  auto stage_load = [&](int c, int buf) {
-    for (int k = 0; k < PER_WAVE; ++k) stage_piece(c, buf, k);
-  };
-  stage_load(0, 0);
+  for (int k = 0; k < PER_WAVE; ++k) stage_piece(0, 0, k);
+  int cc = 0;                                          // chunks this workgroup has walked: chunk cc's stage is buffer cc & 1
 
-  // this lane's row of X, split once: step st = channels 16 st + 8 kg .. + 7
+  // this lane's row of X: step st = channels 16 st + 8 kg .. + 7 (requested a tile ahead, split into bf16 hi / lo when its tile starts)
+  float xr[STEPS1][8];
+  auto load_x = [&](int tl) {
+    const int m = min(tl * ML_BM + wave * 32 + l32, p.M - 1);
+    if (SE) {
+      // NCHW maps: channel c of this lane's pixel is hw floats further - a wave instruction reads 32 consecutive pixels of two channels
+      const Mlp2Row g = ml_row_of(q, m);
+      const float* xc = g.f + (size_t)(8 * kg) * g.hw + g.pix;
+#pragma unroll
+      for (int st = 0; st < STEPS1; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[st][e] = xc[(size_t)(16 * st + e) * g.hw];
+    } else {
+      const float* xrow = p.x + (size_t)m * p.ldx + 8 * kg;
+#pragma unroll
+      for (int st = 0; st < STEPS1; ++st) {
+        const float4 a = *reinterpret_cast<const float4*>(xrow + 16 * st), b = *reinterpret_cast<const float4*>(xrow + 16 * st + 4);
+        xr[st][0] = a.x; xr[st][1] = a.y; xr[st][2] = a.z; xr[st][3] = a.w;
+        xr[st][4] = b.x; xr[st][5] = b.y; xr[st][6] = b.z; xr[st][7] = b.w;
+      }
+    }
+  };
+  load_x(tile);
+
+  for (;;) {
+  const int m0 = tile * ML_BM + wave * 32;
   ml_u32x4 xh[STEPS1], xl[STEPS1];
 #pragma unroll
-  for (int st = 0; st < STEPS1; ++st) {
-    const float4 a = *reinterpret_cast<const float4*>(xrow + 16 * st), b = *reinterpret_cast<const float4*>(xrow + 16 * st + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    ml_split8(v, xh[st], xl[st]);
-  }
+  for (int st = 0; st < STEPS1; ++st) ml_split8(xr[st], xh[st], xl[st]);
+  const int next_tile = tile + (int)gridDim.x;
+  const bool last_tile = next_tile >= ntiles;
+  if (!last_tile) load_x(next_tile);
 
   ml_f32x16 acc[ML_NT];
 #pragma unroll
@@ -120,11 +175,12 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage c has landed
+  for (int c = 0; c < nchunks; ++c, ++cc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of this chunk's stage has landed
     __syncthreads();                                   // ... everybody's has; and everybody is done with the other buffer
-    const bool more = c + 1 < nchunks;
-    const char* s1 = ml_smem + (c & 1) * STAGE;
+    const bool more = !(last_tile && c + 1 == nchunks);
+    const int cn = c + 1 < nchunks ? c + 1 : 0;        // (the ring: behind a tile's last chunk comes the next tile's first)
+    const char* s1 = ml_smem + (cc & 1) * STAGE;
     const char* s2 = s1 + S1;
     // ---- phase A: H^T = W1c X^T (A operand = W1 fragment, B operand = X fragment) ----
     // Two accumulators, even and odd steps: an MFMA that follows a gap in the instruction stream (the LDS requests, a DMA piece)
@@ -144,7 +200,7 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p)
         nh = *reinterpret_cast<const ml_u32x4*>(f1 + (st + 1) * 2048);
         nl = *reinterpret_cast<const ml_u32x4*>(f1 + (st + 1) * 2048 + 1024);
       }
-      if (ML_DMA_IN_A && more && st < PER_WAVE) stage_piece(c + 1, (c + 1) & 1, st);
+      if (ML_DMA_IN_A && more && st < PER_WAVE) stage_piece(cn, (cc + 1) & 1, st);
       if (ML_TWO_ACC && (st & 1)) {
         h_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wl), ml_frag(xh[st]), h_odd, 0, 0, 0);
         h_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xl[st]), h_odd, 0, 0, 0);
@@ -195,14 +251,69 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p)
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vl), acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vh), acc[t], 0, 0, 0);
       // the next chunk's stage, a piece per MFMA group (the other buffer: nobody reads it until the next barrier)
-      if (more && (ML_DMA_IN_A ? STEPS1 : 0) + grp < PER_WAVE) stage_piece(c + 1, (c + 1) & 1, (ML_DMA_IN_A ? STEPS1 : 0) + grp);
+      if (more && (ML_DMA_IN_A ? STEPS1 : 0) + grp < PER_WAVE) stage_piece(cn, (cc + 1) & 1, (ML_DMA_IN_A ? STEPS1 : 0) + grp);
       __builtin_amdgcn_sched_barrier(0);
       vh = nh; vl = nl;
     }
     if (more)
-      for (int k = (ML_DMA_IN_A ? STEPS1 : 0) + GROUPS; k < PER_WAVE; ++k) stage_piece(c + 1, (c + 1) & 1, k);
+      for (int k = (ML_DMA_IN_A ? STEPS1 : 0) + GROUPS; k < PER_WAVE; ++k) stage_piece(cn, (cc + 1) & 1, k);
   }
   // C / D of 32x32x16: column n = lane & 31, rows 4 (lane >> 5) + (r & 3) + 8 (r >> 2)
+  if (SE) {
+    // a lane holds, per tile, 4 groups of 4 consecutive rows (pixels) of ONE channel: the channels-last operands and the result
+    // are coalesced over the lanes (consecutive channels), the map's four pixels are one 16-byte read per lane (any 4-byte
+    // alignment; a group that crosses the end of a level or of the rows goes pixel by pixel)
+    typedef float ml_f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int mj = m0 + 4 * kg + 8 * j;
+      if (mj >= p.M) continue;
+      const Mlp2Row g = ml_row_of(q, mj);
+      const bool whole = g.pix + 3 < g.hw && mj + 3 < p.M;
+      if (whole) {
+        // every read of the group's 8 tiles is requested before the first is used (one wave per SIMD: nothing else hides a round trip)
+        ml_f4u f4[ML_NT];
+        float pv[ML_NT][4], sv[ML_NT][4];
+#pragma unroll
+        for (int t = 0; t < ML_NT; ++t) {
+          const int n = 32 * t + l32;
+          f4[t] = *reinterpret_cast<const ml_f4u*>(g.f + (size_t)n * g.hw + g.pix);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const size_t o = (size_t)(mj + i) * ML_N2 + n;
+            pv[t][i] = q.pe[o]; sv[t][i] = q.sine[o];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < ML_NT; ++t) {
+          const int n = 32 * t + l32;
+          const float bv = p.b2 ? p.b2[n] : 0.f;
+          const float fv[4] = {f4[t].x, f4[t].y, f4[t].z, f4[t].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float gate = acc[t][4 * j + i] + bv;
+            g.o[(size_t)(g.pix + i) * ML_N2 + n] = fv[i] + (pv[t][i] * ml_sigmoid(gate) + sv[t][i]);
+          }
+        }
+        continue;
+      }
+      for (int i = 0; i < 4; ++i) {                       // a group across the end of a level / camera / the rows: pixel by pixel
+        const int m = mj + i;
+        if (m >= p.M) break;
+        const Mlp2Row gi = ml_row_of(q, m);
+#pragma unroll
+        for (int t = 0; t < ML_NT; ++t) {
+          const int n = 32 * t + l32;
+          const size_t o = (size_t)m * ML_N2 + n;
+          float a = 0.f;                                   // acc[t][4 j + i] with a runtime i: a select, not an indexed register
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a = i == k ? acc[t][4 * j + k] : a;
+          const float gate = a + (p.b2 ? p.b2[n] : 0.f);
+          gi.o[(size_t)gi.pix * ML_N2 + n] = gi.f[(size_t)n * gi.hw + gi.pix] + (q.pe[o] * ml_sigmoid(gate) + q.sine[o]);
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < ML_NT; ++t) {
     const int n = 32 * t + l32;
@@ -212,6 +323,10 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p)
       const int m = m0 + ml_hidden_of(kg, r);
       if (m < p.M) p.out[(size_t)m * p.ldo + n] = acc[t][r] + bv;
     }
+  }
+  }
+  if (last_tile) break;
+  tile = next_tile;
   }
 }
 
@@ -257,6 +372,12 @@ __global__ __launch_bounds__(256) void mlp2_image_kernel(const float* __restrict
   *reinterpret_cast<ml_u32x4*>(dst + 1024) = l;
 }
 
+// One workgroup per tile.  (The kernel walks tiles blockIdx, blockIdx + grid, .. with the next tile's rows requested a tile ahead and the
+// weight stages as a ring across tiles: a grid of one workgroup per compute unit measured the same - 2.19 / 0.98 / 1.33 ms against
+// 2.19 / 1.01 / 1.31 ms for the three shapes of tools/bench_mlp2.py - so the launch, the rows' round trip and the first stage are not
+// what a tile waits for; the hardware's own hand-out of tiles is kept.)
+static int mlp2_grid(int M) { return (M + ML_BM - 1) / ML_BM; }
+
 static bool mlp2_shape_ok(int K1, int H, int N2) {          // (K1 / 16 is a template argument: the instantiated step counts)
   const int st = K1 / 16;
   return K1 > 0 && K1 % 16 == 0 && (st == 1 || st == 2 || st == 4 || st == 8 || st == 12 || st == 16) && H > 0 && H % ML_HC == 0 && N2 == ML_N2;
@@ -292,9 +413,10 @@ extern "C" int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const flo
   const char* img1 = static_cast<const char*>(image);
   Mlp2Params p{x, img1, img1 + (size_t)H * K1 * 4 + (size_t)(H / ML_HC) * 1024, b2, out, M, K1, H, ldx, ldo};
   const int lds = 2 * ((K1 / 16) * 2048 + 1024 + ML_S2);
+  const Mlp2Se none{};
   auto go = [&](auto kern) -> int {
     if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((M + ML_BM - 1) / ML_BM), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, none);
     return check_launch();
   };
   switch (K1 / 16) {
@@ -305,4 +427,33 @@ extern "C" int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const flo
     case 12: return go(mlp2_kernel<12>);
     default: return go(mlp2_kernel<16>);
   }
+}
+
+extern "C" int gd4d_mlp2_se_fuse_fwd(const void* const* feats, const int32_t* level_hw, int L, int R, const void* image, const float* b2,
+                                     const float* pe, const float* sine, void* const* outs, int C, int H, void* stream) {
+  using namespace gd4d;
+  if (!feats || !level_hw || !image || !pe || !sine || !outs || L <= 0 || R <= 0) return GD4D_EINVAL;
+  if (L > 4 || C != ML_N2 || !mlp2_shape_ok(C, H, C)) return GD4D_EUNSUPPORTED;
+  if (!aligned16(image)) return GD4D_EALIGN;
+  Mlp2Se q{};
+  long long S = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int ll = l < L ? l : 0;
+    if (l < L && (!feats[l] || !outs[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0)) return GD4D_EINVAL;
+    q.feat[l] = static_cast<const float*>(feats[ll]); q.out[l] = static_cast<float*>(outs[ll]);
+    q.hw[l] = level_hw[2 * ll] * level_hw[2 * ll + 1];
+    q.start[l] = (int)S;
+    if (l < L) S += q.hw[l];
+  }
+  for (int l = L; l <= 4; ++l) q.start[l] = (int)S;
+  if (S * R >= (1ll << 31)) return GD4D_EUNSUPPORTED;
+  q.S = (int)S; q.pe = pe; q.sine = sine;
+  const int M = (int)(S * R), K1 = C;
+  const char* img1 = static_cast<const char*>(image);
+  Mlp2Params p{nullptr, img1, img1 + (size_t)H * K1 * 4 + (size_t)(H / ML_HC) * 1024, b2, nullptr, M, K1, H, 0, 0};
+  const int lds = 2 * ((K1 / 16) * 2048 + 1024 + ML_S2);
+  auto kern = mlp2_kernel<16, true>;
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, q);
+  return check_launch();
 }

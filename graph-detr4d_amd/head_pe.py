@@ -256,8 +256,10 @@ class FeaturePositionEmbedding(nn.Module):
     def _split_weights(self):
         """bf16 (hi, lo) splits of the five 1x1-conv weights for gd4d_gemm_bf16x3_fwd, remade when a weight changes."""
         convs = dict(pe0=self.position_encoder[0], pe2=self.position_encoder[2], se1=self.fpe.conv_expand)
+        cr = self.fpe.conv_reduce
         key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs.values()) + \
-            (self.position_encoder[0].bias.data_ptr(), self.position_encoder[0].bias._version)
+            (self.position_encoder[0].bias.data_ptr(), self.position_encoder[0].bias._version) + \
+            (cr.weight.data_ptr(), cr.weight._version, cr.bias.data_ptr(), cr.bias._version)
         if self._split_cache is None or self._split_cache[0] != key:
             flat = lambda c: c.weight.detach().view(c.out_channels, c.in_channels).contiguous()      # noqa: E731
             cache = {k: ops.split_bf16_fwd(flat(c)) for k, c in convs.items()}
@@ -265,6 +267,10 @@ class FeaturePositionEmbedding(nn.Module):
             # the position MLP as one kernel (gd4d_mlp2_bf16x3_fwd) where its shape allows: the image holds W1, b1 and W2
             cache['pe_mlp'] = ops.mlp2_image(flat(pe0), pe0.bias.detach(), flat(pe2)) \
                 if ops.mlp2_supported(pe0.in_channels, pe0.out_channels, pe2.out_channels) else None
+            # the SE gate's two convolutions (and the fuse behind them) as one kernel too: gd4d_mlp2_se_fuse_fwd
+            ce = convs['se1']
+            cache['se_mlp'] = ops.mlp2_image(flat(cr), cr.bias.detach(), flat(ce)) \
+                if cr.in_channels == 256 and ops.mlp2_supported(cr.in_channels, cr.out_channels, ce.out_channels) else None
             cache['key'] = key
             self._split_cache = (key, cache)
         return self._split_cache[1]
@@ -325,6 +331,10 @@ class FeaturePositionEmbedding(nn.Module):
         else:
             pe = c[2]
         cr, ce = self.fpe.conv_reduce, self.fpe.conv_expand
+        if self.channels_last_out and sw.get('se_mlp') is not None and len(feats) <= 4:
+            # channels-last output: gate, sigmoid, product and the adds in the MLP kernel's epilogue (no gate tensor, no transposing pass)
+            outs = ops.mlp2_se_fuse_fwd([f.flatten(0, 1).contiguous() for f in feats], sw['se_mlp'], ce.bias, pe.view(r, s_tot, -1), sine)
+            return [o.unflatten(0, (b, n)) for o in outs]
         g1 = ops.value_proj_fwd([f.contiguous() for f in feats], cr.weight.view(self.embed_dims, -1).contiguous(),
                                 cr.bias.contiguous())                                             # (R, S, C) channels-last
         gate = ops.gemm_bf16x3_fwd(g1.view(r * s_tot, -1), *sw['se1'], ce.bias, relu_in=True)

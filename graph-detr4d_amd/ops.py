@@ -1429,6 +1429,30 @@ def mlp2_bf16x3_fwd(x, image, b2=None, out=None):
     return out
 
 
+def mlp2_se_fuse_fwd(feats, image, b2, pe, sine):
+    """gd4d_mlp2_se_fuse_fwd: feats = L levels (R, 256, H_l, W_l) NCHW, image = mlp2_image(conv_reduce.weight, conv_reduce.bias,
+    conv_expand.weight), b2 = conv_expand.bias, pe / sine (R, S, 256) channels-last rows of all levels side by side ->
+    L tensors feat + (pe * sigmoid(gate) + sine) as (R, 256, H_l, W_l) VIEWS of (R, H_l, W_l, 256) memory (channels-last levels)."""
+    lib = _lib.load()
+    k1, h, n2 = image.shape_khn
+    nl = len(feats)
+    r = feats[0].shape[0]
+    f32 = torch.float32
+    if k1 != 256 or n2 != 256 or any(f.shape[0] != r or f.shape[1] != 256 or f.dim() != 4 for f in feats):
+        raise ValueError('mlp2_se_fuse_fwd: (R, 256, H, W) levels and a 256 -> H -> 256 image expected')
+    s_tot = sum(f.shape[2] * f.shape[3] for f in feats)
+    if tuple(pe.shape) != (r, s_tot, 256) or tuple(sine.shape) != (r, s_tot, 256):
+        raise ValueError(f'mlp2_se_fuse_fwd: pe / sine must be ({r}, {s_tot}, 256)')
+    outs = [torch.empty(r, f.shape[2], f.shape[3], 256, device=f.device, dtype=f32) for f in feats]
+    fp = (ctypes.c_void_p * nl)(*[_dev(f, 'feats', f32).value for f in feats])
+    op = (ctypes.c_void_p * nl)(*[o.data_ptr() for o in outs])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[2:]])
+    code = lib.gd4d_mlp2_se_fuse_fwd(fp, lv, nl, r, _dev(image, 'image', torch.uint8), _opt(b2, 'b2'), _dev(pe, 'pe', f32),
+                                     _dev(sine, 'sine', f32), op, 256, h, _stream())
+    _lib.check(code, 'gd4d_mlp2_se_fuse_fwd')
+    return [o.permute(0, 3, 1, 2) for o in outs]
+
+
 _TN_WS = {}
 
 

@@ -673,6 +673,16 @@ size_t gd4d_mlp2_image_bytes(int K1, int H, int N2);
 int gd4d_mlp2_image(const float* w1, const float* b1, const float* w2, int K1, int H, int N2, void* image, void* stream);
 int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const float* b2, float* out, int M, int K1, int H, int N2, int ldx,
                          int ldo, void* stream);
+/* gd4d_mlp2_se_fuse_fwd - the feature-dependent half of the head's position embedding as ONE kernel: SELayer's gate
+ * (models/dense_heads/detr3d_head_pe.py:236-243: conv_reduce -> ReLU -> conv_expand -> sigmoid) and the adds of :553-557,
+ *     out[r, pix, :] = feat[r, :, pix] + (pe[m, :] * sigmoid(relu(feat[r, :, pix] W1^T + b1) W2^T + b2) + sine[m, :]),
+ * over the pixels of L <= 4 NCHW levels feats[l] (R, C, H_l, W_l) laid side by side (row m = r S + start_l + pix, S = sum H_l W_l);
+ * pe / sine (R S, C) channels-last rows (gd4d_mlp2_bf16x3_fwd's / gd4d_gemm_bf16x3_fwd's output), image = gd4d_mlp2_image of
+ * conv_reduce's (H, C) weight, its bias and conv_expand's (C, H) weight, b2 = conv_expand's bias.  outs[l] (R, H_l W_l, C): the
+ * level CHANNELS-LAST - what gd4d_cross_attn_agg_items_fwd gathers in place.  Replaces gd4d_value_proj_fwd + gd4d_gemm_bf16x3_fwd +
+ * gd4d_se_fuse_chlast_fwd (two 757-MB intermediates at 24 cameras).  C = 256, H % 32 == 0. */
+int gd4d_mlp2_se_fuse_fwd(const void* const* feats, const int32_t* level_hw, int L, int R, const void* image, const float* b2,
+                          const float* pe, const float* sine, void* const* outs, int C, int H, void* stream);
 
 /* gd4d_adamw_flat - the optimizer step of the reference's training recipe over ONE flat fp32 parameter / gradient buffer: clipping
  * of the gradient's L2 norm (torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: none) followed by

@@ -131,8 +131,8 @@ def test_position_embedding_is_kept_per_camera_and_follows_the_matrices():
 
 
 def test_channels_last_output_holds_the_same_bits_and_is_gathered_in_place():
-    """FeaturePositionEmbedding(channels_last_out=True): the (B, N, C, H, W) results equal the default's bit for bit, their memory is
-    (B, N, H, W, C), and the cross-attention reads them in place (no slice-planar copy) with the same output."""
+    """FeaturePositionEmbedding(channels_last_out=True): the (B, N, C, H, W) results equal the default's (1e-5) and the reference's
+    fixture, their memory is (B, N, H, W, C), and the cross-attention reads them in place (no slice-planar copy) with the same output."""
     from graph_detr4d_amd import ops
     import graph_detr4d_amd as G
     g = Golden('head_pe')
@@ -142,9 +142,22 @@ def test_channels_last_output_holds_the_same_bits_and_is_gathered_in_place():
         want = mod(feats, _metas(g))
         mod.channels_last_out = True
         got = mod(feats, _metas(g))
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and torch.equal(a, b)
+    for lvl, (a, b) in enumerate(zip(got, want)):
+        # (the gate's two convolutions run in another kernel on this route - gd4d_mlp2_se_fuse_fwd: the same split-bf16 products,
+        #  another summation order)
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(a.cpu(), g.t(f'out{lvl}'), rtol=2e-4, atol=2e-4)
         assert ops.PyramidView.is_channels_last_level(a) and not ops.PyramidView.is_channels_last_level(b)
+    fused = []
+    real_se = ops.mlp2_se_fuse_fwd
+    ops.mlp2_se_fuse_fwd = lambda *a, **k: (fused.append(1), real_se(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            again = mod(feats, _metas(g))
+    finally:
+        ops.mlp2_se_fuse_fwd = real_se
+    assert fused and all(torch.equal(a, b) for a, b in zip(again, got)), 'one kernel for gate + fuse, run-to-run identical'
     copies = []
     real = ops.pyramid_slice_planar_fwd
     ops.pyramid_slice_planar_fwd = lambda *a, **k: (copies.append(1), real(*a, **k))[1]
@@ -164,7 +177,7 @@ def test_channels_last_output_holds_the_same_bits_and_is_gathered_in_place():
             assert copies
     finally:
         ops.pyramid_slice_planar_fwd = real
-    torch.testing.assert_close(o_cl, o_nchw, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(o_cl, o_nchw, rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize('route', ['hip', 'torch'])

@@ -37,6 +37,27 @@ def main():
         fl = 2.0 * m * (k1 * h + h * 256)
         print(f'M = {m}, {k1} -> {h} -> 256: fused {t_f:.3f} ms ({3 * fl / t_f / 1e9:.0f} TFLOP/s of bf16 products, {3 * fl / t_f / 1e9 / 2500 * 100:.0f} % of 2.5 PF), '
               f'two GEMMs {t_2:.3f} ms')
+    # the SE form: NCHW levels in, gate + fuse in the epilogue, channels-last levels out (24 cameras, R50 level sizes)
+    from graph_detr4d_amd import synthetic
+    r = 24
+    feats = [torch.randn(r, 256, h_, w_, device='cuda') for h_, w_ in synthetic.R50_LEVELS]
+    s_tot = sum(f.shape[2] * f.shape[3] for f in feats)
+    w1, b1 = torch.randn(256, 256, device='cuda') / 16, torch.randn(256, device='cuda')
+    w2, b2 = torch.randn(256, 256, device='cuda') / 16, torch.randn(256, device='cuda')
+    img = ops.mlp2_image(w1, b1, w2)
+    pe, sine = torch.randn(r, s_tot, 256, device='cuda'), torch.randn(r, s_tot, 256, device='cuda')
+    t_se = timed(lambda: ops.mlp2_se_fuse_fwd(feats, img, b2, pe, sine))
+    s2 = ops.split_bf16_fwd(w2)
+
+    def three():
+        g1 = ops.value_proj_fwd([f.view(1, r, 256, f.shape[2], f.shape[3]) for f in feats], w1, b1)
+        gate = ops.gemm_bf16x3_fwd(g1.view(r * s_tot, -1), *s2, b2, relu_in=True).view(r, s_tot, -1)
+        st = 0
+        for f in feats:
+            ops.se_fuse_chlast_fwd(f, gate, pe, sine, st, out_channels_last=True)
+            st += f.shape[2] * f.shape[3]
+    t_3 = timed(three)
+    print(f'SE gate + fuse over {r * s_tot} pixels: one kernel {t_se:.3f} ms, value_proj + GEMM + transposing fuse {t_3:.3f} ms')
 
 
 if __name__ == '__main__':
