@@ -130,6 +130,31 @@ def test_position_embedding_is_kept_per_camera_and_follows_the_matrices():
         ops.mlp2_bf16x3_fwd = real
 
 
+@pytest.mark.parametrize('levels,r', [([(7, 9), (5, 3), (3, 3)], 3), ([(16, 28), (8, 14), (4, 7), (2, 4)], 2), ([(5, 5)], 1), ([(29, 50), (15, 25)], 5)])
+def test_se_gate_and_fuse_as_one_kernel_matches_fp64(levels, r):
+    """gd4d_mlp2_se_fuse_fwd on level sizes that put camera / level boundaries inside its groups of 4 pixels and its 128-row tiles (odd
+    pixel counts per camera): out = feat + (pe * sigmoid(relu(feat W1^T + b1) W2^T + b2) + sine) against fp64, channels-last levels out."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(len(levels) * 10 + r)
+    feats = [torch.randn(r, 256, h, w, device='cuda') for h, w in levels]
+    s_tot = sum(h * w for h, w in levels)
+    w1, b1 = torch.randn(256, 256, device='cuda') / 16, torch.randn(256, device='cuda')
+    w2, b2 = torch.randn(256, 256, device='cuda') / 16, torch.randn(256, device='cuda')
+    pe, sine = torch.randn(r, s_tot, 256, device='cuda'), torch.randn(r, s_tot, 256, device='cuda')
+    outs = ops.mlp2_se_fuse_fwd(feats, ops.mlp2_image(w1, b1, w2), b2, pe, sine)
+    again = ops.mlp2_se_fuse_fwd(feats, ops.mlp2_image(w1, b1, w2), b2, pe, sine)
+    st = 0
+    for f, o, o2 in zip(feats, outs, again):
+        hw = f.shape[2] * f.shape[3]
+        assert o.shape == f.shape and ops.PyramidView.is_channels_last_level(o) and torch.equal(o, o2)
+        x = f.double().flatten(2).transpose(1, 2)                                       # (R, HW, C)
+        gate = torch.relu(x @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+        want = x + (pe[:, st:st + hw].double() * torch.sigmoid(gate) + sine[:, st:st + hw].double())
+        got = o.permute(0, 2, 3, 1).reshape(r, hw, 256).double()
+        assert (got - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item())
+        st += hw
+
+
 def test_channels_last_output_holds_the_same_bits_and_is_gathered_in_place():
     """FeaturePositionEmbedding(channels_last_out=True): the (B, N, C, H, W) results equal the default's (1e-5) and the reference's
     fixture, their memory is (B, N, H, W, C), and the cross-attention reads them in place (no slice-planar copy) with the same output."""
