@@ -137,3 +137,46 @@ def test_kv_plane_layouts_match_the_header():
             v[h, step, d // 16, g * 16 + d % 16, 4 * t + r] = rows_v[key, ch]
     kv.k[0], kv.v[0] = k.to(torch.bfloat16), v.to(torch.bfloat16)
     assert torch.equal(kv.k_rows()[0].float(), rows_k) and torch.equal(kv.v_rows()[0].float(), rows_v)
+
+
+def test_point_padding_keeps_the_softmax_and_never_becomes_visible():
+    """functional.pad_points (any num_points <= 8 on kernels compiled for 1 / 2 / 4 / 8): the padded points carry NaN offsets - every
+    comparison of the visibility test (deform3d_cross_attn.py:239, :249-252) is false for them - and -inf logits, so the softmax over
+    levels x points gives the real points exactly the weights it gives them without the padding; the padding's gradients are dropped."""
+    import pytest
+    from graph_detr4d_amd import functional as Fn
+    from graph_detr4d_amd._lib import Gd4dError
+    torch.manual_seed(0)
+    b, q, hh, nl = 2, 7, 8, 4
+    for p, tgt in ((1, 1), (2, 2), (3, 4), (4, 4), (5, 8), (6, 8), (8, 8)):
+        off = torch.randn(b, q, hh, p, 3, requires_grad=True)
+        lg = torch.randn(b, q, hh, nl, p, requires_grad=True)
+        po, pl = Fn.pad_points(off, lg, (1, 2, 4, 8), 'test')
+        assert po.shape == (b, q, hh, tgt, 3) and pl.shape == (b, q, hh, nl, tgt)
+        assert torch.equal(po[..., :p, :], off) and torch.isnan(po[..., p:, :]).all()
+        assert torch.equal(pl[..., :p], lg) and torch.isinf(pl[..., p:]).all() and (pl[..., p:] < 0).all()
+        coords = po.detach()[..., 0]
+        assert not ((coords[..., p:] > 0) & (coords[..., p:] < 1)).any(), 'a NaN coordinate passes no visibility comparison'
+        w_pad = pl.detach().flatten(-2).softmax(-1).view(b, q, hh, nl, tgt)
+        w = lg.detach().flatten(-2).softmax(-1).view(b, q, hh, nl, p)
+        # (exactly 0 for the padding; the real points' weights differ from the unpadded softmax only by the order torch sums in -
+        #  the kernel's own sum adds exact zeros)
+        assert (w_pad[..., p:] == 0).all() and torch.allclose(w_pad[..., :p], w, rtol=1e-6, atol=1e-8)
+        (po[..., :p, :].sum() + pl[..., :p].sum()).backward()
+        assert torch.equal(off.grad, torch.ones_like(off)) and torch.equal(lg.grad, torch.ones_like(lg))
+    with pytest.raises(Gd4dError):
+        Fn.pad_points(torch.zeros(1, 1, 4, 5, 3), torch.zeros(1, 1, 4, 4, 5), (4,), 'test')
+
+
+def test_torch_op_routes_are_explicit(monkeypatch):
+    """functional.torch_ops_route: the kernels' route unless GD4D_TORCH_OPS=1 asks for torch ops; a shape the kernels do not cover
+    raises and names the switch instead of taking another route silently."""
+    import pytest
+    from graph_detr4d_amd import functional as Fn
+    from graph_detr4d_amd._lib import Gd4dError
+    monkeypatch.delenv('GD4D_TORCH_OPS', raising=False)
+    assert Fn.torch_ops_route('a module', True) is False
+    with pytest.raises(Gd4dError, match='GD4D_TORCH_OPS'):
+        Fn.torch_ops_route('a module with embed_dims = 512', False)
+    monkeypatch.setenv('GD4D_TORCH_OPS', '1')
+    assert Fn.torch_ops_route('a module', True) is True and Fn.torch_ops_route('a module', False) is True
