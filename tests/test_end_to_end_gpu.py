@@ -16,13 +16,17 @@ pytestmark = pytest.mark.gpu
 POST_RANGE = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
 
 
-@pytest.mark.parametrize('case', ['small', 'mid'])
+@pytest.mark.parametrize('case', ['small', 'mid', 'small-channels-last'])
 def test_features_to_boxes_matches_oracle_pipeline(case):
-    """small: 60 queries x 6 cameras x 2 layers - everything must agree element for element.  mid: 300 queries x 12 cameras
+    """small-channels-last: the position-embedding stage hands the decoder channels-last levels (FeaturePositionEmbedding(
+    channels_last_out=True): SE gate + fuse as one kernel, the levels gathered in place - no slice-planar copy in the decoder).
+    small: 60 queries x 6 cameras x 2 layers - everything must agree element for element.  mid: 300 queries x 12 cameras
     (two frames) x 3 layers on 256 x 448 images - large enough that a sample or two sits within rounding of a visibility
     boundary (the two sides compute the offsets with different GEMM arithmetic): the decoder states are compared row by row
     with a counted number of outliers, the decoded detections as sets."""
     torch.manual_seed(7)
+    channels_last = case.endswith('channels-last')
+    case = case.split('-')[0]
     if case == 'small':
         n, q, nl, frames = 6, 60, 2, 1
         img_hw, levels = (128, 224), [(16, 28), (8, 14), (4, 7), (2, 4)]
@@ -35,7 +39,7 @@ def test_features_to_boxes_matches_oracle_pipeline(case):
     feats = [torch.randn(1, n, 256, h, w, generator=g) for h, w in levels]
     query_embed = torch.randn(q, 512, generator=g)
 
-    pe = G.FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE)
+    pe = G.FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE, channels_last_out=channels_last)
     tr = G.build_transformer(dict(
         type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
         decoder=dict(type='Detr3DTransformerDecoder', num_layers=nl, return_intermediate=True,
@@ -83,7 +87,16 @@ def test_features_to_boxes_matches_oracle_pipeline(case):
                                     max_num=100, num_classes=10))
     with torch.no_grad():
         gfeats = pe([f.cuda() for f in feats], metas)
-        gstates, ginit, grefs = tr(gfeats, query_embed.cuda(), reg_branches=reg_b, img_metas=metas)
+        from graph_detr4d_amd import ops
+        assert all(ops.PyramidView.is_channels_last_level(f) for f in gfeats) == channels_last
+        copies = []
+        real_copy = ops.pyramid_slice_planar_fwd
+        ops.pyramid_slice_planar_fwd = lambda *a, **k: (copies.append(1), real_copy(*a, **k))[1]
+        try:
+            gstates, ginit, grefs = tr(gfeats, query_embed.cuda(), reg_branches=reg_b, img_metas=metas)
+        finally:
+            ops.pyramid_slice_planar_fwd = real_copy
+        assert bool(copies) != channels_last, 'the decoder copies NCHW levels once per sample and reads channels-last levels in place'
         outs = Fn.head_outputs(gstates, ginit, grefs, cls_b, reg_b, synthetic.PC_RANGE)
         got = coder.decode(outs)[0]
 
