@@ -167,6 +167,7 @@ class FeaturePositionEmbedding(nn.Module):
         self._mask_cache = None
         self._split_cache = None
         self._pe_cache = None
+        self._pe_read = None
 
     # ---- pieces -------------------------------------------------------------------------------------------------
     def padding_masks(self, img_metas, feats):
@@ -318,6 +319,9 @@ class FeaturePositionEmbedding(nn.Module):
             c, changed = None, list(range(r))
         if changed:
             i2l = torch.from_numpy(mats[changed]).view(-1, 4, 4).to(dev)
+            if c is not None and self._pe_read is not None:
+                # the kept tensor is updated in place: after whatever still reads it (a previous call on another stream)
+                torch.cuda.current_stream(dev).wait_event(self._pe_read)
             if c is None:
                 pe = self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw)
             elif changed[-1] - changed[0] + 1 == len(changed):
@@ -334,6 +338,7 @@ class FeaturePositionEmbedding(nn.Module):
         if self.channels_last_out and sw.get('se_mlp') is not None and len(feats) <= 4:
             # channels-last output: gate, sigmoid, product and the adds in the MLP kernel's epilogue (no gate tensor, no transposing pass)
             outs = ops.mlp2_se_fuse_fwd([f.flatten(0, 1).contiguous() for f in feats], sw['se_mlp'], ce.bias, pe.view(r, s_tot, -1), sine)
+            self._mark_pe_read(dev)
             return [o.unflatten(0, (b, n)) for o in outs]
         g1 = ops.value_proj_fwd([f.contiguous() for f in feats], cr.weight.view(self.embed_dims, -1).contiguous(),
                                 cr.bias.contiguous())                                             # (R, S, C) channels-last
@@ -344,7 +349,13 @@ class FeaturePositionEmbedding(nn.Module):
         for lvl, (f, st) in enumerate(zip(feats, starts)):
             o = ops.se_fuse_chlast_fwd(f.flatten(0, 1).contiguous(), gate, pe, sine, st, out_channels_last=self.channels_last_out)
             out.append(o.unflatten(0, (b, n)) if self.channels_last_out else o.view(f.shape))
+        self._mark_pe_read(dev)
         return out
+
+    def _mark_pe_read(self, dev):
+        if self.cache_position_embedding and not torch.cuda.is_current_stream_capturing():
+            self._pe_read = torch.cuda.Event()
+            self._pe_read.record(torch.cuda.current_stream(dev))
 
     # ---- training ---------------------------------------------------------------------------------------------------
     def _forward_autograd(self, feats, img_metas):
