@@ -370,30 +370,43 @@ struct ItemsParams {
   const float4* item;
   float* wsum;                  // (BQ, HH), written by the workgroups of slice 0
   int cap_i;
+  // gd4d_cross_attn_agg_items_coarse_fwd: the coarse levels [2, 4) are gathered from PROJECTED rows (value_proj applied per pixel,
+  // bias included: (R, H_l W_l, 256) fp32, head h = bytes [128 h, 128 h + 128) of a pixel's row) by a ninth "slice" of workgroups
+  PyramidGeom gc;               // their geometry (entries 2, 3)
+  const char* proj_base[4];     // entries 2, 3
+  float* pagg;                  // (BQ, 256): sum over the coarse levels' corners of w * projected row, head-major columns
 };
 
 // WIDE: a level spans 4 GiB or more (VoVNet-99 level 0 stored channels-last, two samples: 4.6 GB) - the offsets parked in LDS
 // are then in units of 16 bytes (every stride is a multiple of 16; the host hands cam_stride / pix_stride pre-divided) and a
 // load forms its address with a 64-bit shift-add.
-template <int HH, int LT, typename VT, bool WIDE>
+//
+// LAP = level slots of an item's lane set (4: lane = (item % 16, level); 2: lane = (item % 32, level) - a pass of 8 loads then
+// covers 8 items x 2 levels), LV0 = the first level gathered (levels LV0 .. LV0 + LT - 1 of the records and the geometry).
+// COARSE (gd4d_cross_attn_agg_items_coarse_fwd): the workgroup is the query's ninth "slice": wave h gathers head h's 128 bytes of
+// the PROJECTED rows of levels LV0 .. (ip.gc / ip.proj_base) and writes pagg instead of agg.
+template <int HH, int LT, typename VT, bool WIDE, int LAP = 4, int LV0 = 0, bool COARSE = false>
 __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip, const int pos, const int sl, char* s_raw) {
   const SlicedParams& p = ip.s;
+  const PyramidGeom& geo = COARSE ? ip.gc : ip.g;
   constexpr int ES = sizeof(VT);
-  constexpr int LA = LT, LAP = 4;                         // a lane set = the four level slots of an item
-  constexpr int IPP = 16 / LAP;                           // items per pass: 4
-  constexpr int IPS = 64 / LAP;                           // items per step (four passes): 16
+  constexpr int LA = LT;                                  // a lane set = the LAP level slots of an item
+  static_assert(LA <= LAP && LV0 + LAP <= 4 && (LAP == 2 || LAP == 4), "level slots");
+  static_assert(!COARSE || (std::is_same<VT, float>::value && !WIDE && HH * kSlice == kChannels), "projected rows: fp32, 32 channels per head");
+  constexpr int IPP = 16 / LAP;                           // items per pass: 4 (LAP = 2: 8)
+  constexpr int IPS = 64 / LAP;                           // items per step (four passes): 16 (32)
   constexpr int CH = 4;                                   // passes per step (20 KB of LDS per workgroup of 8 waves)
   constexpr int GP = 80;                                  // LDS bytes per corner slot: 64 B of pairs + 16 B pad (conflict-free b128)
   constexpr int PASS = 8 * GP;
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int s = p.slice_lo + sl;
+  const int s = COARSE ? h : p.slice_lo + sl;
   const int i_of = lane / LAP, l_of = lane % LAP;
   const float4* rec = ip.item + ((size_t)pos * HH + h) * ip.cap_i * 2;
   // speculative: the first records (what lies past M is replaced below before it is used)
   const int i_first = min(i_of, ip.cap_i - 1);
   float4 a = rec[i_first * 2];
-  float wl = reinterpret_cast<const float*>(rec + i_first * 2 + 1)[l_of];
+  float wl = reinterpret_cast<const float*>(rec + i_first * 2 + 1)[LV0 + l_of];
   const int bq = p.order ? p.order[pos] : pos;
   char* my = s_raw + h * (CH * PASS);
   const int g = lane >> 3, c = lane & 7;
@@ -403,13 +416,14 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
   char* wr = my + (i_of / IPP) * PASS + ((ip_ & 1) << 2) * GP + ((ip_ >> 1) * LAP + l_of) * 8;
   const char* base[LA];
 #pragma unroll
-  for (int l = 0; l < LA; ++l) base[l] = p.lvl_base[l] + (size_t)s * p.slice_stride;
+  for (int l = 0; l < LA; ++l)
+    base[l] = COARSE ? ip.proj_base[LV0 + l] + (size_t)s * (kSlice * sizeof(float)) : p.lvl_base[LV0 + l] + (size_t)s * p.slice_stride;
   const unsigned lane_off = (unsigned)(c * 4 * ES);
-  int lw = ip.g.lvl_w[0], lh = ip.g.lvl_h[0];
-  unsigned cstr = ip.g.cam_stride[0];
+  int lw = geo.lvl_w[LV0], lh = geo.lvl_h[LV0];
+  unsigned cstr = geo.cam_stride[LV0];
 #pragma unroll
   for (int l = 1; l < LA; ++l)
-    if (l_of == l) { lw = ip.g.lvl_w[l]; lh = ip.g.lvl_h[l]; cstr = ip.g.cam_stride[l]; }
+    if (l_of == l) { lw = geo.lvl_w[LV0 + l]; lh = geo.lvl_h[LV0 + l]; cstr = geo.cam_stride[LV0 + l]; }
   const float flw = (float)lw, flh = (float)lh;
   const float lvl_on = l_of < LA ? 1.f : 0.f;
 
@@ -442,7 +456,7 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
         const float in = (xc == xi && yc == yi) ? live : 0.f;
         const float wx = (c_of & 1) ? dx : 1.f - dx, wy = (c_of >> 1) ? dy : 1.f - dy;
         const float w = (wl * wx * wy) * in;
-        const unsigned off = rbase + (unsigned)(yc * lw + xc) * ip.g.pix_stride;
+        const unsigned off = rbase + (unsigned)(yc * lw + xc) * geo.pix_stride;
         wsum_lane += w;
         if (item < m_even && l_of < LA) *reinterpret_cast<uint2*>(wr + c_of * GP) = make_uint2(off, __float_as_uint(w));
       }
@@ -450,7 +464,7 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
     if (it0 + IPS < M) {                                                    // the next step's records fly under this step's passes
       const int nx = min(item + IPS, M - 1);
       a = rec[nx * 2];
-      wl = reinterpret_cast<const float*>(rec + nx * 2 + 1)[l_of];
+      wl = reinterpret_cast<const float*>(rec + nx * 2 + 1)[LV0 + l_of];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // wave-private LDS patch: no workgroup barrier
     __builtin_amdgcn_wave_barrier();
@@ -493,6 +507,10 @@ __device__ __forceinline__ void cross_attn_agg_items_body(const ItemsParams& ip,
     acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
     acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
   }
+  if (COARSE) {
+    if (g == 0) *reinterpret_cast<float4*>(ip.pagg + (size_t)bq * kChannels + h * kSlice + c * 4) = acc;
+    return;
+  }
   if (g == 0) *reinterpret_cast<float4*>(p.agg + ((size_t)bq * HH + h) * kChannels + s * kSlice + c * 4) = acc;
   if (s == 0 && ip.wsum) {                                                 // wave-uniform
 #pragma unroll
@@ -508,6 +526,25 @@ __global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_kernel(cons
   int pos, sl;
   if (!sliced_walk(ip.s, blockIdx.x, pos, sl)) return;
   cross_attn_agg_items_body<HH, LT, VT, WIDE>(ip, pos, sl, s_raw);
+  trace_mark(g_trace_sliced, 0x86ull);
+}
+
+// gd4d_cross_attn_agg_items_coarse_fwd (4 levels, 8 heads): the fine levels 0, 1 from the RAW pyramid as above - 8 items x 2 levels
+// per pass -, the coarse levels 2, 3 from rows value_proj has already been applied to.  A raw corner is 1 KB through the L1s
+// (8 slices x 128 B) whatever its level; a projected corner of a head is its own 128 B.  Levels 2-3 are 6 % of the pixels
+// but were 42 us of the 124-us launch (docs/measurements_r05.md section 1): projecting their 43 800 rows per layer costs less
+// than gathering them raw.  The projected rows are gathered by a NINTH workgroup per query (walk: slice index 8, the last
+// phase of an XCD), wave = head as everywhere: the same number of loads as one raw slice of the two fine levels, so the
+// launch stays balanced; its sums go to pagg (BQ, 256), which HEADGEMM adds to W_h agg_h + b_h wsum_h (wsum then
+// holds the fine levels' weights only: the projected rows carry their bias).
+template <int HH, typename VT, int OCC, bool WIDE = false>
+__global__ __launch_bounds__(64 * HH, OCC) void cross_attn_agg_items_coarse_kernel(const ItemsParams ip) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];   // [HH][CH][8][GP]
+  trace_mark(g_trace_sliced, 6ull);
+  int pos, sl;
+  if (!sliced_walk(ip.s, blockIdx.x, pos, sl)) return;
+  if (sl == kSlices) cross_attn_agg_items_body<HH, 2, float, false, 2, 2, true>(ip, pos, sl, s_raw);
+  else cross_attn_agg_items_body<HH, 2, VT, WIDE, 2, 0, false>(ip, pos, sl, s_raw);
   trace_mark(g_trace_sliced, 0x86ull);
 }
 
@@ -930,6 +967,48 @@ extern "C" int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, cons
                                              const int32_t* query_order, int slice_lo, int slice_n, void* stream) {
   return items_fwd_impl(level_ptrs, level_hw, cam_stride_bytes, pix_stride_bytes, slice_stride_bytes, plan, agg, wsum, B, N, Q, Hh, C,
                         L, P, feats_dtype, query_order, slice_lo, slice_n, stream, nullptr);
+}
+
+extern "C" int gd4d_cross_attn_agg_items_coarse_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                                    int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* const* proj_ptrs,
+                                                    const int64_t* proj_cam_stride_bytes, const void* plan, float* agg, float* wsum,
+                                                    float* pagg, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                                    const int32_t* query_order, void* stream) {
+  using namespace gd4d;
+  if (!proj_ptrs || !proj_cam_stride_bytes || !pagg || !wsum) return GD4D_EINVAL;
+  if (L != 4 || Hh != 8) return GD4D_EUNSUPPORTED;                   // (two fine + two coarse levels; a head = one 32-channel slice)
+  ItemsParams ip{};
+  if (int rc = fill_sliced_params(ip.s, level_ptrs, slice_stride_bytes, plan, agg, B, N, Q, Hh, C, L, P, feats_dtype, query_order, 0, kSlices))
+    return rc;
+  bool wide = false;
+  if (int rc = fill_items_geom(ip.g, wide, level_hw, cam_stride_bytes, pix_stride_bytes, B * N, 2)) return rc;   // (spans of the fine levels)
+  if (!aligned16(pagg)) return GD4D_EALIGN;
+  ip.gc = ip.g;
+  for (int l = 2; l < 4; ++l) {
+    const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+    if (h <= 0 || w <= 0 || !proj_ptrs[l - 2] || proj_cam_stride_bytes[l - 2] < (int64_t)h * w * kChannels * 4) return GD4D_EINVAL;
+    if (!aligned16(proj_ptrs[l - 2]) || (proj_cam_stride_bytes[l - 2] & 15)) return GD4D_EALIGN;
+    const unsigned long long span = (unsigned long long)(B * N) * (unsigned long long)proj_cam_stride_bytes[l - 2];
+    if (span >= (1ull << 32)) return GD4D_EUNSUPPORTED;
+    ip.gc.lvl_w[l] = w; ip.gc.lvl_h[l] = h; ip.gc.cam_stride[l] = (unsigned)proj_cam_stride_bytes[l - 2];
+    ip.proj_base[l] = static_cast<const char*>(proj_ptrs[l - 2]);
+  }
+  ip.gc.pix_stride = kChannels * 4;
+  ip.proj_base[0] = ip.proj_base[1] = ip.proj_base[2];
+  ip.item = reinterpret_cast<const float4*>(ip.s.pair);
+  ip.wsum = wsum; ip.pagg = pagg;
+  ip.cap_i = plan_cap_items(N, P);
+  ip.s.slice_n = kSlices + 1;                                        // the walk's ninth phase: the projected rows
+  const SlicedParams& p = ip.s;
+  const size_t lds = (size_t)8 * 4 * 8 * 80;                         // [HH][CH][8][GP]
+  const dim3 grid(8 * ((p.per_xcd + p.blk - 1) / p.blk) * p.blk * p.slice_n);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto go = [&](auto kern) -> int {
+    hipLaunchKernelGGL(kern, grid, dim3(64 * 8), lds, s, ip);
+    return check_launch();
+  };
+  if (feats_dtype == GD4D_BF16) return wide ? go(cross_attn_agg_items_coarse_kernel<8, uint16_t, 4, true>) : go(cross_attn_agg_items_coarse_kernel<8, uint16_t, 6>);
+  return wide ? go(cross_attn_agg_items_coarse_kernel<8, float, 4, true>) : go(cross_attn_agg_items_coarse_kernel<8, float, 6>);
 }
 
 extern "C" int gd4d_cross_attn_agg_items_count_fwd(const void* const* level_ptrs, const int32_t* level_hw,

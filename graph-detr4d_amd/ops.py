@@ -356,6 +356,57 @@ def cross_attn_agg_sliced_fwd(plan, slices=(0, 8), agg=None, count=None):
     return agg
 
 
+class CoarseValues:
+    """Levels 2, 3 of a pyramid with one layer's value_proj already applied (bias included): `rows` (R, S23, 256) fp32,
+    level 2's pixels first - what gd4d_value_proj_fwd over those two levels writes (GD4D_LAYOUT_PIXEL_MAJOR)."""
+
+    def __init__(self, rows, level_hw):
+        (h2, w2), (h3, w3) = level_hw
+        if rows.dim() != 3 or rows.shape[1] != h2 * w2 + h3 * w3 or rows.shape[2] != 256 or rows.dtype != torch.float32 \
+                or not rows.is_contiguous():
+            raise ValueError(f'projected coarse levels {tuple(rows.shape)} inconsistent with {level_hw}')
+        self.rows, self.level_hw = rows, [(int(h2), int(w2)), (int(h3), int(w3))]
+        self.ptrs = [rows.data_ptr(), rows.data_ptr() + h2 * w2 * 1024]
+        self.cam_stride = [rows.shape[1] * 1024] * 2
+
+
+def coarse_supported(plan):
+    """gd4d_cross_attn_agg_items_coarse_fwd: items plan, 4 levels, 8 heads."""
+    return plan.items and len(plan.pyramid.level_hw) == 4 and plan.num_heads == 8
+
+
+def cross_attn_agg_coarse_fwd(plan, coarse, agg=None, pagg=None):
+    """gd4d_cross_attn_agg_items_coarse_fwd: levels 0, 1 gathered raw from the Plan's pyramid, levels 2, 3 from `coarse`
+    (CoarseValues of THIS layer's value_proj).  Returns agg (B, Q, 8, 256), pagg (B, Q, 256); plan.wsum holds the fine levels'
+    weight sums: value_proj_heads_fwd(agg, plan.wsum, W, b) + pagg is the layer's sampled value."""
+    lib = _lib.load()
+    pyramid = plan.pyramid
+    dev = pyramid.device
+    b, q, hh, query_order = plan.b, plan.q, plan.num_heads, plan.order
+    if not coarse_supported(plan):
+        raise _lib.Gd4dError('the coarse-projected gather takes an items plan over 4 levels with 8 heads')
+    if list(coarse.level_hw) != [tuple(x) for x in pyramid.level_hw[2:]] or coarse.rows.shape[0] != pyramid.rows \
+            or coarse.rows.device != dev:
+        raise ValueError('projected coarse levels do not belong to this pyramid')
+    f32 = torch.float32
+    if agg is None:
+        agg = torch.empty(b, q, hh, 256, device=dev, dtype=f32)
+    if pagg is None:
+        pagg = torch.empty(b, q, 256, device=dev, dtype=f32)
+    ptrs = (ctypes.c_void_p * 4)(*pyramid.ptrs)
+    lv = (ctypes.c_int32 * 8)(*[int(x) for hw in pyramid.level_hw for x in hw])
+    cs = (ctypes.c_int64 * 4)(*pyramid.cam_stride)
+    pp = (ctypes.c_void_p * 2)(*coarse.ptrs)
+    pcs = (ctypes.c_int64 * 2)(*coarse.cam_stride)
+    code = lib.gd4d_cross_attn_agg_items_coarse_fwd(
+        ptrs, lv, cs, pyramid.pix_stride, pyramid.slice_stride, pp, pcs, _dev(plan.buf, 'plan', torch.uint8), _dev(agg, 'agg', f32),
+        _dev(plan.wsum, 'wsum', f32), _dev(pagg, 'pagg', f32), b, pyramid.rows // b, q, hh, 256, 4, plan.points,
+        _lib.F32 if pyramid.dtype == torch.float32 else _lib.BF16,
+        None if query_order is None else _order_ptr(query_order, b * q), _stream())
+    _lib.check(code, 'gd4d_cross_attn_agg_items_coarse_fwd')
+    return agg, pagg
+
+
 def value_proj_heads_fwd(agg, wsum, weight, bias=None, out=None):
     """gd4d_value_proj_heads_fwd: agg (..., Hh, 256), wsum (..., Hh) -> out (..., 256) = value_proj of the aggregates."""
     lib = _lib.load()

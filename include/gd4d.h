@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 52
+#define GD4D_ABI_VERSION 53
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -202,6 +202,25 @@ int gd4d_cross_attn_agg_items_fwd(const void* const* level_ptrs, const int32_t* 
                                   int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* plan, float* agg,
                                   float* wsum, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
                                   const int32_t* query_order, int slice_lo, int slice_n, void* stream);
+
+/* gd4d_cross_attn_agg_items_coarse_fwd - the same gather (deform3d_cross_attn.py:264-280, :301-304, :320-324) with the two COARSE
+ * levels taken from rows value_proj has already been applied to.  value_proj is linear and the gather a weighted sum:
+ *     out[q, h] = W_h (sum over fine-level corners w_i x_i) + b_h (sum of those w_i)  +  sum over coarse-level corners w_i (W_h x_i + b_h)
+ * A raw corner costs 1 KB through the L1s whatever its level (8 slices x 128 B), a projected corner of head h its own 128 B; levels 2-3
+ * are 6 % of the pixels (43 800 rows at 24 cameras: gd4d_value_proj_fwd over them is ~ 6 % of the whole pyramid's) and were a third of
+ * the launch.  L == 4 and Hh == 8 (a head = 32 channels = one 128-byte line) only.
+ *   level_ptrs .. slice_stride_bytes: the raw pyramid as gd4d_cross_attn_agg_items_fwd takes it (levels 0, 1 are read; entries 2, 3 of
+ *   level_hw are the coarse levels' shapes); proj_ptrs[0 .. 1]: levels 2, 3 projected - (R, H_l W_l, 256) fp32 rows, pixel-major, the
+ *   bias included (gd4d_value_proj_fwd on those two levels, GD4D_LAYOUT_PIXEL_MAJOR), camera row r of level l at
+ *   proj_ptrs[l - 2] + r * proj_cam_stride_bytes[l - 2]; plan: the ITEMS form.
+ *   agg (B*Q, 8, 256), wsum (B*Q, 8): the FINE levels' aggregates and weight sums; pagg (B*Q, 256): the coarse levels' part, already
+ *   projected, columns head-major - GD4D_CHAIN_HEADGEMM / gd4d_value_proj_heads_fwd of (agg, wsum) plus pagg is the layer's
+ *   sampled value (what output_proj takes).  One launch: a ninth workgroup per query (the walk's last phase) gathers the projected rows. */
+int gd4d_cross_attn_agg_items_coarse_fwd(const void* const* level_ptrs, const int32_t* level_hw, const int64_t* cam_stride_bytes,
+                                         int64_t pix_stride_bytes, int64_t slice_stride_bytes, const void* const* proj_ptrs,
+                                         const int64_t* proj_cam_stride_bytes, const void* plan, float* agg, float* wsum,
+                                         float* pagg, int B, int N, int Q, int Hh, int C, int L, int P, int feats_dtype,
+                                         const int32_t* query_order, void* stream);
 
 /* gd4d_cross_attn_agg_items_count_fwd - a TRAINING step's forward gather and the first step of the pyramid gradient's bookkeeping
  * in one launch: gd4d_cross_attn_agg_items_fwd (all slices, every level) on plan_items and gd4d_pyramid_grad_count on plan_pairs (the

@@ -416,3 +416,99 @@ def test_training_kernels_refuse_num_points_other_than_four():
     assert plan.points == 2
     with pytest.raises(_lib.Gd4dError):
         ops.cross_attn_dot_sliced(plan, torch.zeros(1, 9, 8, 256).cuda())
+
+
+def _coarse_layer(pyr, feats, w_v, b_v, args, heads=8, order=None):
+    """One layer's sampled value through gd4d_cross_attn_agg_items_coarse_fwd: levels 0, 1 raw, levels 2, 3 projected first."""
+    from graph_detr4d_amd import ops
+    proj = ops.value_proj_fwd([f.contiguous() for f in feats[2:]], w_v, b_v)
+    coarse = ops.CoarseValues(proj, [tuple(f.shape[-2:]) for f in feats[2:]])
+    res = ops.cross_attn_plan_fwd(pyr, *args, heads, want_mask=True, want_uv=True, query_order=order, items=True)
+    plan = res[0]
+    plan.wsum.fill_(float('nan'))
+    b, q = args[0].shape[0], args[0].shape[1]
+    agg = torch.full((b, q, heads, 256), float('nan'), device=args[0].device)
+    pagg = torch.full((b, q, 256), float('nan'), device=args[0].device)
+    ops.cross_attn_agg_coarse_fwd(plan, coarse, agg=agg, pagg=pagg)
+    return ops.value_proj_heads_fwd(agg, plan.wsum, w_v, b_v) + pagg, res[1], res[2]
+
+
+@pytest.mark.parametrize('name', ['deform_n6', 'deform_n12_depth', 'deform_edge', 'deform_n24_b2'])
+def test_coarse_projected_gather_matches_reference_golden(name):
+    """gd4d_cross_attn_agg_items_coarse_fwd (levels 2, 3 gathered from value_proj's rows, levels 0, 1 raw) against the reference's
+    MSDA output summed over cameras; mask / uv stay bit-exact (the plan is the same plan)."""
+    from graph_detr4d_amd import ops
+    g = Golden(name)
+    m = g.meta
+    b, n, q = m['batch'], m['num_cams'], m['num_query']
+    sd = g.state()
+    dev = 'cuda'
+    l2i = torch.from_numpy(g.arrays['lidar2img']).unsqueeze(0).expand(b, -1, -1, -1).contiguous().to(dev)
+    feats = [f.to(dev) for f in g.feats()]
+    sp, shapes = ops.pyramid_slice_planar_fwd(feats)
+    args = (g.t('reference_points').to(dev), g.t('offsets').view(b, q, 8, 4, 3).contiguous().to(dev),
+            g.t('attn_logits').view(b, q, 8, 4, 4).contiguous().to(dev), g.t('cam_logits').to(dev), l2i,
+            m['pc_range'], m['img_shape'][0], m['img_shape'][1])
+    w_v, b_v = sd['value_proj.weight'].to(dev), sd['value_proj.bias'].to(dev)
+    out, mask, uv = _coarse_layer(ops.PyramidView.slice_planar(sp, shapes), feats, w_v, b_v, args)
+    assert torch.equal(mask.cpu(), g.t('mask').view(b, n, q, 8, 4, 4)[..., 0, :]), 'visibility mask must be bit-exact'
+    assert torch.equal(uv.cpu(), g.t('uv').view(b, n, q, 8, 4, 4, 2)[..., 0, :, :]), 'projected coordinates must be bit-exact'
+    torch.testing.assert_close(out.cpu(), g.t('agg'), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('levels,n,q,b,source', [
+    ([(29, 50), (15, 25), (8, 13), (4, 7)], 12, 300, 1, 'planar'),
+    ([(16, 28), (8, 14), (4, 7), (2, 4)], 6, 37, 3, 'planar'),
+    ([(12, 20), (6, 10), (3, 5), (2, 3)], 64, 20, 1, 'nhwc'),
+    ([(29, 50), (15, 25), (8, 13), (4, 7)], 7, 129, 2, 'pixel_major'),
+])
+def test_coarse_projected_gather_vs_the_raw_gather_and_the_oracle(levels, n, q, b, source):
+    """The same layer through the all-raw items gather and through the coarse-projected one: equal to summation order (value_proj
+    commutes with the bilinear sum), both equal to the torch oracle; on every pyramid source, with a locality order."""
+    from graph_detr4d_amd import ops, synthetic
+    from oracle import torch_oracle as O
+    torch.manual_seed(len(levels) * 10 + n + b)
+    rig = synthetic.camera_rig((n + 5) // 6)[:n]
+    l2i = torch.from_numpy(rig).unsqueeze(0).expand(b, -1, -1, -1).contiguous()
+    feats = [torch.randn(b, n, 256, h, w) for h, w in levels]
+    ref = torch.rand(b, q, 3)
+    offsets, attn, cam = torch.randn(b, q, 8, 4, 3) * 2.0, torch.randn(b, q, 8, 4, 4), torch.randn(b, q, n)
+    w_v, b_v = torch.randn(256, 256) * 0.06, torch.randn(256)
+    dev = 'cuda'
+    fd = [f.to(dev) for f in feats]
+    if source == 'planar':
+        sp, shp = ops.pyramid_slice_planar_fwd(fd)
+        pyr = ops.PyramidView.slice_planar(sp, shp)
+    elif source == 'pixel_major':
+        cl, shp = ops.pyramid_channels_last_fwd(fd)
+        pyr = ops.PyramidView.pixel_major(cl, shp)
+    else:
+        nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fd]
+        pyr = ops.PyramidView.channels_last_levels(nhwc)
+    args = (ref.to(dev), offsets.to(dev), attn.to(dev), cam.to(dev), l2i.to(dev), synthetic.PC_RANGE, 900, 1600)
+    order = ops.query_order_fwd(args[0], synthetic.PC_RANGE)
+    out, mask, uv = _coarse_layer(pyr, fd, w_v.to(dev), b_v.to(dev), args, order=order)
+    agg, wsum, mask_r, uv_r = _sliced_form(True, pyr, *args, order=order, want=True)
+    raw = ops.value_proj_heads_fwd(agg, wsum, w_v.to(dev), b_v.to(dev))
+    assert torch.equal(mask, mask_r) and torch.equal(uv, uv_r)
+    torch.testing.assert_close(out, raw, rtol=RTOL, atol=ATOL)
+    flat, shapes = O.flatten_pyramid(feats)
+    val = torch.nn.functional.linear(flat, w_v, b_v).view(b * n, -1, 8, 32)
+    want, _, m_ref = O.sample_aggregate(val, shapes, ref, offsets, attn.flatten(-2), cam, l2i, synthetic.PC_RANGE, 900, 1600)
+    flipped = (mask.cpu() != m_ref.to(torch.uint8)).any(dim=4).any(dim=3).any(dim=1)   # (B, Q): torch's matmul decides m_ref on this host
+    assert flipped.sum().item() <= 2
+    torch.testing.assert_close(out.cpu()[~flipped], want[~flipped], rtol=RTOL, atol=ATOL)
+
+
+def test_coarse_projected_gather_refuses_what_it_is_not_built_for():
+    from graph_detr4d_amd import _lib, ops, synthetic
+    torch.manual_seed(2)
+    fd = [torch.randn(1, 6, 256, h, w).cuda() for h, w in [(16, 28), (8, 14), (4, 7)]]
+    sp, shp = ops.pyramid_slice_planar_fwd(fd)
+    l2i = torch.from_numpy(synthetic.camera_rig(1)).unsqueeze(0).cuda()
+    plan = ops.cross_attn_plan_fwd(ops.PyramidView.slice_planar(sp, shp), torch.rand(1, 9, 3).cuda(), torch.randn(1, 9, 8, 4, 3).cuda(),
+                                   torch.randn(1, 9, 8, 3, 4).cuda(), torch.randn(1, 9, 6).cuda(), l2i, synthetic.PC_RANGE, 900, 1600, 8,
+                                   items=True)
+    coarse = ops.CoarseValues(torch.zeros(6, 8 * 14 + 4 * 7, 256).cuda(), [(8, 14), (4, 7)])
+    with pytest.raises(_lib.Gd4dError):
+        ops.cross_attn_agg_coarse_fwd(plan, coarse)

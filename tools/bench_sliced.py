@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--levels', default='r50')
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--plan', default='items', help='items (the inference step) | pairs (what the training kernels read)')
+    ap.add_argument('--coarse', action='store_true', help='also time gd4d_cross_attn_agg_items_coarse_fwd and the projection of levels 2-3')
     a = ap.parse_args()
     dev = 'cuda'
     n, q = 6 * a.frames, a.queries
@@ -44,6 +45,14 @@ def main():
     else:
         cl, shapes = ops.pyramid_channels_last_fwd(feats, out_dtype=dt)
         pyr = ops.PyramidView.pixel_major(cl, shapes)
+    coarse = None
+    if a.coarse:
+        wv, bv = (torch.randn(256, 256, generator=g) * 0.06).to(dev), torch.randn(256, generator=g).to(dev)
+        cf = [f.contiguous() for f in feats[2:]]
+        proj = ops.value_proj_fwd(cf, wv, bv)
+        coarse = ops.CoarseValues(proj, [tuple(f.shape[-2:]) for f in cf])
+        t_proj = timed(lambda: [ops.value_proj_fwd(cf, wv, bv, out=proj) for _ in range(6)], a.iters, 6)
+        print(f'value_proj over levels 2-3 ({proj.shape[0] * proj.shape[1]} rows, weight image launch included): {t_proj:.1f} us')
     del feats
     if a.alias:
         pyr.cam_stride = [0] * len(pyr.cam_stride)
@@ -56,6 +65,14 @@ def main():
     t_plan = timed(lambda: [ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
                                                     plan=plan, query_order=order, items=items) for _ in range(6)], a.iters, 6)
     t = timed(lambda: [ops.cross_attn_agg_sliced_fwd(plan, agg=sa) for _ in range(6)], a.iters, 6)
+    if coarse is not None:
+        ca, cp = ops.cross_attn_agg_coarse_fwd(plan, coarse)
+        tc = timed(lambda: [ops.cross_attn_agg_coarse_fwd(plan, coarse, agg=ca, pagg=cp) for _ in range(6)], a.iters, 6)
+        ops.cross_attn_agg_sliced_fwd(plan, agg=sa)
+        full = ops.value_proj_heads_fwd(sa, plan.wsum, wv, bv)
+        ops.cross_attn_agg_coarse_fwd(plan, coarse, agg=ca, pagg=cp)
+        mixed = ops.value_proj_heads_fwd(ca, plan.wsum, wv, bv) + cp
+        print(f'coarse-projected gather {tc:.1f} us per launch; max |difference| to the raw gather {float((mixed - full).abs().max()):.2e}')
     print(f'plan {a.plan} layout {a.layout} alias {a.alias} {a.dtype}: plan {t_plan:.1f} us, '
           f'sliced gather {t:.1f} us per launch ({corner_bytes / t / 1e6:.2f} TB/s of corner bytes)')
 
