@@ -918,14 +918,26 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
         plan_calls = []
         for c in late_cap:
             if sliced:
+                coarse_on = bool(c['vp'].get('coarse'))                          # the step gathers the coarse levels from projected rows
                 plan, mask, uv = ops.cross_attn_plan_fwd(c['late'].pyramid, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], c['pc_range'],
                                                          c['img_h'], c['img_w'], hh, query_order=c['order'], want_mask=True, want_uv=True,
-                                                         items=items)
-                agg_buf = ops.cross_attn_agg_sliced_fwd(plan)
-                calls.append((lambda plan, agg_buf: (lambda: ops.cross_attn_agg_sliced_fwd(plan, agg=agg_buf)))(plan, agg_buf))
+                                                         items=items or coarse_on)
+                if coarse_on:
+                    # this layer's projected coarse rows (its own buffer here; the step re-uses one) - made once, outside the timing
+                    late_c = c['late']
+                    rows_c = torch.empty_like(late_c.coarse.rows)
+                    ops.value_proj_guest_fwd(ops.chain_guest(late_c.coarse_src, ops.value_proj_image(c['module'].value_proj.weight,
+                                                                                                     c['module'].value_proj.bias), rows_c))
+                    cv = ops.CoarseValues(rows_c, late_c.shapes[2:])
+                    agg_buf, pagg_buf = ops.cross_attn_agg_coarse_fwd(plan, cv)
+                    calls.append((lambda plan, cv, agg_buf, pagg_buf: (lambda: ops.cross_attn_agg_coarse_fwd(plan, cv, agg=agg_buf, pagg=pagg_buf)))(
+                        plan, cv, agg_buf, pagg_buf))
+                else:
+                    agg_buf = ops.cross_attn_agg_sliced_fwd(plan)
+                    calls.append((lambda plan, agg_buf: (lambda: ops.cross_attn_agg_sliced_fwd(plan, agg=agg_buf)))(plan, agg_buf))
                 plan_calls.append((lambda c, plan: (lambda: ops.cross_attn_plan_fwd(
                     c['late'].pyramid, c['ref'], c['offsets'], c['attn'], c['cam'], c['l2i'], c['pc_range'], c['img_h'], c['img_w'], hh,
-                    query_order=c['order'], plan=plan, items=items)))(c, plan))
+                    query_order=c['order'], plan=plan, items=plan.items)))(c, plan))
                 es = c['late'].pyramid.tensors[0].element_size()
             else:
                 # (as the step launches it: with value_proj of the aggregates in the epilogue when the step does that)
@@ -954,8 +966,12 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
             d['us_mean'] = ms / launches * 1e3
         if sliced:
             traffic, traffic_source = _pmc_traffic(a, 'gd4d_cross_attn_sliced.hip', 'r*_pmc_cross_attn_sliced.json')
-            kname = ('gd4d::cross_attn_agg_items_kernel' if items else 'gd4d::cross_attn_agg_sliced_kernel') + \
-                    ' (gather of raw features, one workgroup per (query, 32-channel slice); ' \
+            coarse_step = bool(late_cap[0]['vp'].get('coarse'))
+            kname = ('gd4d::cross_attn_agg_items_coarse_kernel (levels 0-1: raw features, one workgroup per (query, 32-channel slice); levels 2-3: '
+                     'rows the layer\'s value_proj was applied to by guest workgroups of the previous row-chain launch, a ninth workgroup per query; '
+                     if coarse_step else
+                     ('gd4d::cross_attn_agg_items_kernel' if items else 'gd4d::cross_attn_agg_sliced_kernel') +
+                     ' (gather of raw features, one workgroup per (query, 32-channel slice); ') + \
                     'projection / mask / weights come from gd4d::cross_attn_plan_kernel, timed beside it)'
             ms_plan = _time_rounds(plan_calls, rounds)
             kernels['cross_attn_plan'] = dict(us_per_launch=ms_plan / launches * 1e3, launches_per_step=launches,
@@ -985,7 +1001,7 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                 if cl is None:
                     kernels['pyramid_copy'] = dict(us=0.0, launches_per_step=0, note='caller-owned channels-last levels are gathered in place: no copy')
                 else:
-                    vals = [f.contiguous() for f in feats]
+                    vals = [f.contiguous() for f in feats][:2 if late0.partial else None]   # (coarse levels projected: the copy leaves them out)
                     cus = torch.cuda.get_device_properties(cl.device).multi_processor_count
                     copy_cus = int(os.environ.get('GD4D_COPY_CUS') or max(8, (cus * 7 // 8) // 8 * 8))      # as Fn.LateValues launches it
                     copy = ops.pyramid_slice_planar_fwd if sliced else ops.pyramid_channels_last_fwd
@@ -1005,9 +1021,14 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                     if sliced:
                         plan_av, mask_av = ops.cross_attn_plan_fwd(c0['late'].pyramid, ref_av, c0['offsets'], c0['attn'], c0['cam'], l2i_av,
                                                                    c0['pc_range'], c0['img_h'], c0['img_w'], hh, query_order=order_av,
-                                                                   want_mask=True, items=items)
-                        agg_av = ops.cross_attn_agg_sliced_fwd(plan_av)
-                        av_calls = [lambda: ops.cross_attn_agg_sliced_fwd(plan_av, agg=agg_av)]
+                                                                   want_mask=True, items=items or bool(late_cap[0]['vp'].get('coarse')))
+                        if late_cap[0]['vp'].get('coarse'):
+                            cv0 = c0['late'].coarse                                 # (rows of the last layer's projection: any will do for timing)
+                            agg_av, pagg_av = ops.cross_attn_agg_coarse_fwd(plan_av, cv0)
+                            av_calls = [lambda: ops.cross_attn_agg_coarse_fwd(plan_av, cv0, agg=agg_av, pagg=pagg_av)]
+                        else:
+                            agg_av = ops.cross_attn_agg_sliced_fwd(plan_av)
+                            av_calls = [lambda: ops.cross_attn_agg_sliced_fwd(plan_av, agg=agg_av)]
                         es_ = c0['late'].pyramid.tensors[0].element_size()
                     else:
                         run_av = lambda c, **kw: ops.cross_attn_agg_fwd(c['cl'], c['shapes'], ref_av, c['offsets'], c['attn'], c['cam'], l2i_av,   # noqa: E731

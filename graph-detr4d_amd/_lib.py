@@ -32,6 +32,11 @@ SIGNATURES = {
     'gd4d_cross_attn_agg_sliced_fwd': (_i, [_vp, _c.c_int64, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
     'gd4d_cross_attn_agg_items_fwd': (_i, [_vp, _vp, _vp, _c.c_int64, _c.c_int64, _vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _i, _vp]),
     'gd4d_cross_attn_agg_items_coarse_fwd': (_i, [_vp, _vp, _vp, _c.c_int64, _c.c_int64, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp]),
+    'gd4d_chain_guest_bytes': (_c.c_size_t, []),
+    'gd4d_value_proj_image_bytes': (_c.c_size_t, []),
+    'gd4d_value_proj_image': (_i, [_vp, _vp, _vp, _vp]),
+    'gd4d_value_proj_guest_fwd': (_i, [_vp, _i, _vp]),
+    'gd4d_row_chain_guest_fwd': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     'gd4d_cross_attn_agg_items_count_fwd': (_i, [_vp, _vp, _vp, _c.c_int64, _c.c_int64, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_pyramid_slice_planar_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_heads_fwd': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),

@@ -20,6 +20,7 @@
 // LayerNorm two-pass like ATen (mean, centred sum of squares, biased variance, eps inside the square root).
 #include "gd4d_common.h"
 #include "gd4d_mha_dropout.h"
+#include "gd4d_value_proj_body.h"
 
 namespace gd4d {
 
@@ -453,6 +454,15 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
 #pragma unroll
       for (int c = 0; c < RC_TILES; ++c) e_bias[c] = bias_p[min(n_base + 16 * c + i16, N - 1)] * bias_on;
     }
+    // GD4D_CHAIN_ADD_GOUT: the (M, N) addend at gout, requested before the k loop (the lane's own output elements)
+    float addend[RC_TILES][4];
+    if (op.flags & GD4D_CHAIN_ADD_GOUT) {
+#pragma unroll
+      for (int c = 0; c < RC_TILES; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          addend[c][r] = op.gout[(size_t)min(m0 + 4 * g + r, M - 1) * op.ldg + min(n_base + 16 * c + i16, N - 1)];
+    }
     rc_u4 bh[HD][RC_TILES], bl[HD][RC_TILES];
     float4 av[HD][NG][2];
     auto issue = [&](int slot, int j) {
@@ -503,8 +513,9 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
         const int row = 4 * g + r, m = m0 + row;
         float v = fmaf(e_bias[c], op.p3[(size_t)min(m, M - 1) * heads + hc], acc[c][r]);
         if (op.res >= 0) v += bufs[op.res][row][n];
+        if (op.flags & GD4D_CHAIN_ADD_GOUT) v += addend[c][r];
         if (op.dst >= 0) bufs[op.dst][row][op.dst_col + n] = v;
-        if (op.gout && m < M) op.gout[(size_t)m * op.ldg + n] = v;
+        if (op.gout && !(op.flags & GD4D_CHAIN_ADD_GOUT) && m < M) op.gout[(size_t)m * op.ldg + n] = v;
       }
     }
   }
@@ -989,6 +1000,30 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_kernel(const ChainPro
   row_chain_body<TRAIN>(pp, (int)blockIdx.x);
 }
 
+// gd4d_row_chain_guest_fwd: the row chain(s) of a launch plus GUEST workgroups that run one decoder layer's value_proj over a few
+// pyramid levels (value_proj_astat_body, gd4d_value_proj_body.h).  A chain occupies ceil(M / 16) (two programs: twice that)
+// of the 256 compute units for 15-50 us and is bound by the latency of ONE unit; the others idle.  The guests are dispatched
+// after the chain's workgroups (higher indices), ask for the same LDS (one workgroup per compute unit) and share nothing with
+// the chain: no hand-off, no second stream, no cross-stream edge in a replayed graph - the launch ends when both have.
+template <bool IN_CHLAST>
+__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_guest_kernel(const ChainProgram by_value, const VpaParams guest, const int gbase,
+                                                                         const int gcount) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const rc_prog_ptr_t pp = (rc_prog_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // explicit arguments start at 0
+#else
+  const ChainProgram* pp = &by_value;
+#endif
+  (void)by_value;
+  if ((int)blockIdx.x >= gbase) {                                       // workgroup-uniform
+    extern __shared__ __attribute__((aligned(16))) char rc_smem[];
+    trace_mark_if(g_trace_rowchain, 9ull, (int)blockIdx.x == gbase);
+    value_proj_astat_body<RC_WAVES, false, false, false, 0, IN_CHLAST>(guest, (int)blockIdx.x - gbase, gcount, rc_smem);
+    trace_mark_if(g_trace_rowchain, 0x89ull, (int)blockIdx.x == gbase);
+    return;
+  }
+  row_chain_body<false>(pp, (int)blockIdx.x);
+}
+
 // XCC id of every workgroup of a launch (gd4d_xcd_placement_probe): the hand-offs above rely on workgroups j and j + 8 k sharing
 // an XCD; the host checks that once per device before it builds programs with SIGNAL / WAIT.
 __global__ void xcd_placement_probe_kernel(int32_t* out) {
@@ -1086,6 +1121,7 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
       case GD4D_CHAIN_HEADGEMM:
         if (!op.p0 || !op.p2 || !op.p3 || op.K <= 0 || op.N <= 0 || op.ld0 <= 0 || (op.dst < 0 && !op.gout)) return GD4D_EINVAL;
         if (op.N % op.ld0 != 0 || (op.N / op.ld0) % 32 != 0 || op.K % 64 != 0 || op.N % 64 != 0) return GD4D_EUNSUPPORTED;
+        if ((op.flags & GD4D_CHAIN_ADD_GOUT) && (!op.gout || op.dst < 0 || op.ldg < op.N)) return GD4D_EINVAL;
         if (op.dst >= 0 && (op.dst_col < 0 || op.dst_col + op.N > RC_W)) return GD4D_EINVAL;
         if (!aligned16(op.p0) || !aligned16(op.p2)) return GD4D_EALIGN;
         break;
@@ -1137,7 +1173,8 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
   return GD4D_OK;
 }
 
-static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int nb, int M, void* stream) {
+static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int nb, int M, void* stream,
+                     const gd4d_chain_guest* guest = nullptr) {
   using namespace gd4d;
   if (!a || na <= 0 || M <= 0 || nb < 0 || (nb > 0 && !b)) return GD4D_EINVAL;
   if (na + nb > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
@@ -1173,6 +1210,31 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   prog.nops = na; prog.M = M; prog.nops2 = nb; prog.split = split;
   for (int i = 0; i < na; ++i) prog.ops[i] = a[i];
   for (int i = 0; i < nb; ++i) prog.ops[na + i] = b[i];
+  if (guest) {
+    // the guests' job (gd4d_value_proj_fwd's geometry: one layer, pixel-major fp32 rows)
+    if (train) return GD4D_EUNSUPPORTED;
+    VpaParams g{};
+    if (int rc = va_guest_params(guest, g)) return rc;
+    const int base = g.total;
+    if (va_lds_bytes(1, false, RC_WAVES) > lds) return GD4D_EUNSUPPORTED;
+    const int chain_wgs = nb > 0 ? split + blocks : blocks;
+    const int gbase = chain_wgs;                           // (every index below it is a chain workgroup with rows to work on)
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int need = (base + RC_WAVES - 1) / RC_WAVES;
+    // One workgroup per compute unit (the launch's LDS request).  Default: one workgroup per 8 tiles up to the number of compute
+    // units - every wave makes ONE pass; the guests that find no free unit start when the first program's workgroups end (20 of
+    // chain B's 55 us).  Measured at 174 workgroups of work, 142 units free: 142 guests x two passes 645 samples/s, 174 x one 659-661.
+    int gcount = guest->workgroups > 0 ? guest->workgroups : cus;
+    if (gcount < 8) gcount = 8;
+    if (gcount > need) gcount = need;
+    auto go = [&](auto kern) -> int {
+      if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return GD4D_ELAUNCH;
+      hipLaunchKernelGGL(kern, dim3(gbase + gcount), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog, g, gbase, gcount);
+      return check_launch();
+    };
+    return g.in_chlast ? go(row_chain_guest_kernel<true>) : go(row_chain_guest_kernel<false>);
+  }
   if (train)
     hipLaunchKernelGGL(row_chain_kernel<true>, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog);
   else
@@ -1194,4 +1256,12 @@ extern "C" int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, c
                                    void* stream) {
   if (!program_b || nops_b <= 0) return GD4D_EINVAL;
   return rc_launch(program_a, nops_a, program_b, nops_b, M, stream);
+}
+
+extern "C" size_t gd4d_chain_guest_bytes(void) { return sizeof(gd4d_chain_guest); }
+
+extern "C" int gd4d_row_chain_guest_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
+                                        const gd4d_chain_guest* guest, void* stream) {
+  if (!guest || nops_b < 0 || (nops_b > 0 && !program_b)) return GD4D_EINVAL;
+  return rc_launch(program_a, nops_a, nops_b > 0 ? program_b : nullptr, nops_b, M, stream, guest);
 }

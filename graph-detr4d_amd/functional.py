@@ -571,7 +571,7 @@ class LateValues:
     and applies its value_proj to the 900 x Hh aggregates (ops.value_proj_heads_fwd) instead of to 739 800 pixel rows.
     GD4D_PROJECT=early keeps the projected-value path (value_proj kernel + gd4d_cross_attn_fwd)."""
 
-    def __init__(self, value, dtype=torch.float32):
+    def __init__(self, value, dtype=torch.float32, coarse_for=None):
         """dtype: storage type of the channels-last copy - torch.bfloat16 for modules built with value_dtype='bf16' (half the
         bytes to copy and to gather, bf16-rounded features, fp32 accumulation).
 
@@ -581,17 +581,32 @@ class LateValues:
           sliced  gd4d_pyramid_slice_planar_fwd -> (8, R, S, 32), gd4d_cross_attn_plan_fwd + gd4d_cross_attn_agg_sliced_fwd
           in place (no copy at all): when the caller's levels are already stored channels-last (..., H, W, 256), fp32 or
                   bf16 - the reference's own flatten / transpose (deform3d_cross_attn.py:264-276) has nothing left to do;
-                  always the sliced kernels, which read per-level pointers with strides."""
+                  always the sliced kernels, which read per-level pointers with strides.
+
+        coarse_for: the cross-attention modules of a decoder whose fused loop (fused_decoder.run_single) will consume this object
+        with the coarse levels projected first (coarse_setup).  Then the FIRST module's projection of the two coarse levels is
+        enqueued here, on the side stream in front of the copy - no chain launch precedes the first gather for it to ride in -
+        and the copy leaves the coarse levels out (nobody reads them raw; a consumer that does after all: _ensure_full)."""
         dev = value[0].device
         self.value = value
         self.main = torch.cuda.current_stream(dev)
         self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
-        self.cl = self.pyramid = self.event = None
+        self.cl = self.pyramid = self.event = self.src = None
+        self.coarse = self.coarse_src = self.coarse_first = None
+        self.partial = False
         self.waited = set()
         if all(ops.PyramidView.is_channels_last_level(v) for v in value) and len({v.dtype for v in value}) == 1 \
                 and value[0].dtype in (torch.float32, torch.bfloat16):
             self.mode, self.side = 'sliced', None
             self.pyramid = ops.PyramidView.channels_last_levels(list(value))
+            if coarse_for and self.coarse_setup(coarse_for):
+                self.side = _companion_stream(_SIDE_STREAMS, dev)
+                self.side.wait_stream(self.main)
+                with torch.cuda.stream(self.side):
+                    self._project_first(coarse_for[0])
+                    self.event = torch.cuda.Event()
+                    self.event.record(self.side)
+                self.coarse.rows.record_stream(self.main)
             return
         self.mode = os.environ.get('GD4D_AGG', AGG_DEFAULT)
         if self.mode == 'rows' and value[0].shape[0] != 1:
@@ -605,9 +620,21 @@ class LateValues:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
             src = [v.contiguous() for v in value]
+            self.src, self.copy_cus, self.copy_dtype = src, copy_cus, dtype
             if self.mode == 'sliced':
-                self.cl, _ = ops.pyramid_slice_planar_fwd(src, max_cus=copy_cus, out_dtype=dtype)
-                self.pyramid = ops.PyramidView.slice_planar(self.cl, self.shapes)
+                if coarse_for and self.coarse_setup(coarse_for):
+                    self._project_first(coarse_for[0])
+                    self.coarse.rows.record_stream(self.main)
+                    self.partial = os.environ.get('GD4D_COARSE_FULL_COPY') != '1'
+                if self.partial:
+                    # the fine levels only: (8, R, S01, 32); the view's coarse entries are never dereferenced by the coarse gather
+                    self.cl, _ = ops.pyramid_slice_planar_fwd(src[:2], max_cus=copy_cus, out_dtype=dtype)
+                    fine = ops.PyramidView.slice_planar(self.cl, self.shapes[:2])
+                    self.pyramid = ops.PyramidView([self.cl], fine.ptrs + fine.ptrs[:1] * 2, self.shapes, fine.cam_stride + fine.cam_stride[:1] * 2,
+                                                   fine.pix_stride, fine.slice_stride, fine.dtype, fine.rows)
+                else:
+                    self.cl, _ = ops.pyramid_slice_planar_fwd(src, max_cus=copy_cus, out_dtype=dtype)
+                    self.pyramid = ops.PyramidView.slice_planar(self.cl, self.shapes)
             else:
                 self.cl, _ = ops.pyramid_channels_last_fwd(src, max_cus=copy_cus, out_dtype=dtype)
             self.event = torch.cuda.Event()
@@ -615,6 +642,25 @@ class LateValues:
         # allocated under the side stream, read by kernels of the main stream: tell the allocator, so that the block is
         # not handed out again (to a side-stream allocation) while those kernels are still queued
         self.cl.record_stream(self.main)
+
+    def _project_first(self, module):
+        """(current stream = the side stream) the first layer's projection of the coarse levels, a launch of its own."""
+        ops.value_proj_guest_fwd(self.coarse_guest(module))
+        self.coarse_first = module
+
+    def take_first(self, module):
+        """Whether the coarse rows of `module` were enqueued at construction and nobody has overwritten them yet (once)."""
+        hit, self.coarse_first = self.coarse_first is module, None
+        return hit
+
+    def _ensure_full(self):
+        """A consumer that gathers ALL levels raw came after the copy was made for the coarse-projected gather: copy again, all levels."""
+        if not self.partial:
+            return
+        self._wait_copy()
+        self.cl, _ = ops.pyramid_slice_planar_fwd(self.src, max_cus=0, out_dtype=self.copy_dtype)
+        self.pyramid = ops.PyramidView.slice_planar(self.cl, self.shapes)
+        self.partial = False
 
     @staticmethod
     def applicable(modules, value, ignore_mode=False):
@@ -632,33 +678,71 @@ class LateValues:
             all((m.num_points <= 4 or (m.num_points <= 8 and m.num_heads == 8)) and m.num_heads in (4, 8, 16) and m.embed_dims == 256
                 and m.num_levels == len(value) and m.num_cams == rows for m in modules)
 
+    def coarse_setup(self, modules):
+        """Arrange for the two COARSE levels to be gathered from projected rows (ops.cross_attn_agg_coarse_fwd): one (R, S23, 256)
+        buffer that a layer's value_proj fills before that layer's gather - coarse_guest(module) is the job, run by guest
+        workgroups of a row-chain launch (ops.row_chain_fwd(..., guest=)) - and that the next layer's overwrites after it.  A raw
+        corner costs 1 KB through the L1s whatever its level, a projected one 128 B per head; levels 2-3 are 6 % of the pixels and
+        were a third of the gather.  Returns whether it applies: 4 levels, 8 heads, fp32 source levels (GD4D_COARSE=0: off)."""
+        if self.coarse is not None:
+            return True
+        if os.environ.get('GD4D_COARSE', '1') == '0' or self.mode != 'sliced' or len(self.shapes) != 4 or not modules:
+            return False
+        if any(m.num_heads != 8 or m.embed_dims != 256 for m in modules) or self.value[0].dtype != torch.float32:
+            return False
+        src = list(self.value[2:]) if self.src is None else list(self.src[2:])
+        rows = src[0].numel() // (256 * self.shapes[2][0] * self.shapes[2][1])
+        s23 = sum(h * w for h, w in self.shapes[2:])
+        # The projection must fit the window it hides in: ~30 us for the 43 800 rows of the R50 pyramid at 24 cameras beside a 55-us
+        # chain; the VoVNet-99 pyramid's coarse levels are 4 x that while its gather gains the same ~30 us (GD4D_COARSE_MAX_ROWS).
+        if rows * s23 > int(os.environ.get('GD4D_COARSE_MAX_ROWS', '65536')):
+            return False
+        buf = torch.empty(rows, s23, 256, device=src[0].device, dtype=torch.float32)
+        self.coarse_src, self.coarse = src, ops.CoarseValues(buf, self.shapes[2:])
+        return True
+
+    def coarse_guest(self, module, workgroups=0):
+        """The ChainGuest that projects the coarse levels with `module`'s value_proj into the buffer coarse_setup made."""
+        bias = module.value_proj.bias
+        img = ops.value_proj_image(module.value_proj.weight, bias)
+        return ops.chain_guest(self.coarse_src, img, self.coarse.rows, workgroups=workgroups)
+
     def _wait_copy(self):
         if self.event is None:
             return
-        cur = torch.cuda.current_stream(self.cl.device)
+        made = [t for t in (self.cl, None if self.coarse is None else self.coarse.rows) if t is not None]   # what the side stream wrote
+        cur = torch.cuda.current_stream(made[0].device)
         if cur.cuda_stream not in self.waited:
             cur.wait_event(self.event)
             self.waited.add(cur.cuda_stream)
             if cur.cuda_stream != self.main.cuda_stream:
-                self.cl.record_stream(cur)
+                for t in made:
+                    t.record_stream(cur)
 
     def aggregate(self, module, ref, offsets, attn_logits, cam_logits, lidar2img, img_h, img_w, order=None, vp_weight=None,
-                  vp_bias=None, raw_cam_weights=False):
+                  vp_bias=None, raw_cam_weights=False, coarse=False):
         """Per-head aggregates of the raw features: agg (B, Q, Hh, C), wsum (B, Q, Hh); rows mode with vp_weight:
         (out (B, Q, C),) - value_proj applied in the kernel's epilogue.  raw_cam_weights: the camera logits are used as they
-        are, without the sigmoid (the neighbour pass of Deform3DCrossAttnMP)."""
+        are, without the sigmoid (the neighbour pass of Deform3DCrossAttnMP).  coarse (after coarse_setup, the buffer holding THIS
+        module's projection): (agg, wsum, pagg) - the fine levels' aggregates and weight sums and the coarse levels' already
+        projected part (B, Q, C); value_proj of (agg, wsum) plus pagg is the layer's sampled value."""
         # (kernels: 1 / 2 / 4 / 8 points per head with 8 heads on the sliced form, 4 otherwise; other counts - the reference's
         #  constructor default is 5 - are padded with points that are never visible and weigh nothing)
         offsets, attn_logits = pad_points(offsets, attn_logits, (1, 2, 4, 8) if self.mode == 'sliced' and module.num_heads == 8 else (4,),
                                           'Deform3DCrossAttn')
+        if not coarse:
+            self._ensure_full()
         if self.mode == 'sliced':
             # (the plan needs nothing from the pyramid but its strides: layer 0's runs underneath the copy)
             # GD4D_PLAN=pairs: the 128-bytes-per-item form the training kernels read
-            items = os.environ.get('GD4D_PLAN', 'items') != 'pairs'
+            items = coarse or os.environ.get('GD4D_PLAN', 'items') != 'pairs'     # (the coarse-projected gather walks items)
             plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                            cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
                                            query_order=order, items=items, raw_cam_weights=raw_cam_weights)
             self._wait_copy()
+            if coarse:
+                agg, pagg = ops.cross_attn_agg_coarse_fwd(plan, self.coarse)
+                return agg, plan.wsum, pagg
             agg = ops.cross_attn_agg_sliced_fwd(plan)
             if vp_weight is not None:
                 return (ops.value_proj_heads_fwd(agg, plan.wsum, vp_weight, vp_bias),)

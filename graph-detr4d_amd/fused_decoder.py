@@ -202,7 +202,16 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     keep = []
     qkv = torch.empty(q, 1, 3 * c, device=dev, dtype=torch.float32)
     kv = _kv_planes(layers, q, c, attn_masks[0], dev)
-    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1), kv), q)
+    # The two coarse pyramid levels are gathered from PROJECTED rows (LateValues.coarse_setup): layer l's value_proj over them is
+    # the guest job of a chain launch that runs before gather l on compute units the chain leaves idle - layer 0's rides here,
+    # layer l + 1's in chain B' of layer l (one buffer: gather l has read it by then).
+    coarse = late.mode == 'sliced' and late.coarse_setup([l.attentions[1] for l in layers])
+    guest_wgs = int(os.environ.get('GD4D_GUEST_WGS', '0'))          # dev: guest workgroups per launch (0: what the chain leaves free)
+    first_guest = None
+    if coarse and not late.take_first(layers[0].attentions[1]):      # (not enqueued beside the copy when `late` was made: rides here)
+        first_guest = late.coarse_guest(layers[0].attentions[1], workgroups=guest_wgs)
+    ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1), kv), q,
+                      guest=first_guest)
     n_out = nl if return_intermediate else 1
     out_all = torch.empty(n_out, q, 1, c, device=dev, dtype=torch.float32)
     ref_all = torch.empty(n_out, 1, q, 3, device=dev, dtype=torch.float32)
@@ -264,10 +273,16 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
                                         img_h, img_w, order=order)
             first = ops.chain_load(0, agg.view(q, c))
             agg_raw, wsum = agg, agg
+        elif coarse:
+            agg_raw, wsum, pagg = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
+                                                 img_h, img_w, order=order, coarse=True)
+            first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0, addend=pagg.view(q, c))
+            keep.append(pagg)
         else:
             agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
                                            img_h, img_w, order=order)
             first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0)
+        guest = late.coarse_guest(layers[lid + 1].attentions[1], workgroups=guest_wgs) if coarse and not last else None
         x3 = out_all[slot]
         prog = [first] + ([ops.chain_wait(flags[lid], err)] if pos_late else []) + [
                 ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336 (as GEMM addends: slower)
@@ -298,9 +313,10 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
         if pos_late:
             # position_encoder(l) on the refined points (in global memory since the dual launch), beside chain B'.  The
             # SIGNALling program goes FIRST: its workgroups are dispatched before the waiting ones (gd4d.h).
-            ops.row_chain2_fwd(_position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3)) + [ops.chain_signal(flags[lid])], prog, q)
+            ops.row_chain2_fwd(_position_ops(ca, pos_feat.view(q, c), ref=ref.view(q, 3)) + [ops.chain_signal(flags[lid])], prog, q,
+                               guest=guest)
         else:
-            ops.row_chain_fwd(prog, q)
+            ops.row_chain_fwd(prog, q, guest=guest)
         keep += [o, x1, cam, off, att, agg_raw, wsum, pos_feat, x]
         x = x3.view(q, c)
     if pos_late:

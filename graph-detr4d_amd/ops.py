@@ -1725,7 +1725,7 @@ class ChainOp(ctypes.Structure):
 CHAIN_LOAD, CHAIN_GEMM, CHAIN_LAYERNORM, CHAIN_ADD, CHAIN_REFINE, CHAIN_SMALL_LINEAR, CHAIN_HEADGEMM, CHAIN_SIGNAL, CHAIN_WAIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 CHAIN_LN_BWD, CHAIN_DROPMASK = 10, 11
 CHAIN_RELU, CHAIN_INV_SIGMOID, CHAIN_SIGMOID, CHAIN_EXACT, CHAIN_SRC2, CHAIN_SPLIT_OUT, CHAIN_MASK_P2, CHAIN_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128
-CHAIN_SPLIT_KV, CHAIN_SPLIT_KV_KEEP = 256, 512
+CHAIN_SPLIT_KV, CHAIN_SPLIT_KV_KEEP, CHAIN_ADD_GOUT = 256, 512, 1024
 
 
 def _rows(t, name):
@@ -1764,6 +1764,7 @@ def invalidate_chain_images():
     version counter), but NOT writes through `.data` (p.data.copy_(), mmcv's EMA swap): call this after such an update -
     the package's modules do it from train() / eval() and after load_state_dict."""
     _CHAIN_IMAGES.clear()
+    _VP_IMAGES.clear()
     _CHAIN_EPOCH[0] += 1
 
 
@@ -2016,15 +2017,19 @@ def chain_gemm_three_outputs(src, linears, outs, stacked=None, exact=False):
                    gout=ptrs[0][0], p2=ptrs[1][0], p3=ptrs[2][0])
 
 
-def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None):
+def chain_headgemm(agg, wsum, weight, bias=None, dst=-1, res=-1, out=None, addend=None):
     """value_proj of the per-head aggregates (cross_attn_agg_fwd's agg (..., Hh, K), wsum (..., Hh), contiguous) as a chain
-    operation: v[m, n] = sum_k agg[m][h][k] W[n][k] + bias[n] wsum[m][h] (+ buf[res]) -> buf[dst] and / or out."""
+    operation: v[m, n] = sum_k agg[m][h][k] W[n][k] + bias[n] wsum[m][h] (+ buf[res]) (+ addend[m, n]) -> buf[dst] and / or out.
+    addend (M, N): a global tensor that is added - cross_attn_agg_coarse_fwd's pagg; excludes `out`."""
     heads, k = agg.shape[-2], agg.shape[-1]
     img, n, wk = _image_of(weight)
     if wk != k or n % heads or (n // heads) % 32 or wsum.numel() * k != agg.numel():
         raise ValueError('chain_headgemm: weight (N, K), agg (..., Hh, K), wsum (..., Hh) with (N / Hh) % 32 == 0')
-    g, ldg = _rows(out, 'out')
+    if addend is not None and (out is not None or dst < 0 or addend.shape[-1] != n):
+        raise ValueError('chain_headgemm: an addend (M, N) goes with dst >= 0 and no `out`')
+    g, ldg = _rows(out if addend is None else addend, 'out')
     return ChainOp(kind=CHAIN_HEADGEMM, src=-1, dst=dst, res=res, K=k, N=n, ld0=heads, ldg=ldg, p0=img,
+                   flags=CHAIN_ADD_GOUT if addend is not None else 0,
                    p1=None if bias is None else bias.data_ptr(), p2=_dev(agg, 'agg', torch.float32).value,
                    p3=_dev(wsum, 'wsum', torch.float32).value, gout=g)
 
@@ -2181,20 +2186,95 @@ def chain_wait(flags, errors=None):
                    gout=None if errors is None else _dev(errors, 'errors', torch.int32).value)
 
 
-def row_chain_fwd(program, m):
+class ChainGuest(ctypes.Structure):
+    """gd4d_chain_guest (include/gd4d.h): value_proj of one decoder layer over a few pyramid levels, run by guest workgroups of a
+    row-chain launch."""
+    _fields_ = [('feats', ctypes.c_void_p * 8), ('level_hw', ctypes.c_int32 * 16), ('L', ctypes.c_int32), ('R', ctypes.c_int32),
+                ('chlast', ctypes.c_int32), ('workgroups', ctypes.c_int32), ('image', ctypes.c_void_p), ('out', ctypes.c_void_p)]
+
+
+_VP_IMAGES = {}
+
+
+def value_proj_image(weight, bias=None):
+    """gd4d_value_proj_image of a layer's value_proj (256, 256) weight and bias: the split-bf16 fragment image the guests of
+    row_chain_fwd(..., guest=) stream through LDS.  Cached like chain_weight_image (address, version counters of weight AND bias;
+    invalidate_chain_images() forgets these too)."""
+    import weakref
+    if not weight.is_cuda or weight.dtype != torch.float32 or tuple(weight.shape) != (256, 256) or not weight.is_contiguous():
+        raise ValueError('value_proj_image: a contiguous (256, 256) float32 GPU weight')
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != 256 or not bias.is_contiguous() or bias.device != weight.device):
+        raise ValueError('value_proj_image: bias (256) float32 on the weight\'s GPU')
+    wb = weight._base if weight._base is not None else weight
+    bb = None if bias is None else (bias._base if bias._base is not None else bias)
+    key = (weight.data_ptr(), None if bias is None else bias.data_ptr())
+    hit = _VP_IMAGES.get(key)
+    if hit is not None and hit[0]() is wb and hit[1] == wb._version and hit[4] == _CHAIN_EPOCH[0] and \
+            (bb is None or (hit[2]() is bb and hit[3] == bb._version)):
+        return hit[5]
+    lib = _lib.load()
+    img = torch.empty(int(lib.gd4d_value_proj_image_bytes()), device=weight.device, dtype=torch.uint8)
+    with torch.cuda.device(weight.device):
+        code = lib.gd4d_value_proj_image(_dev(weight, 'weight', torch.float32), None if bias is None else _dev(bias, 'bias', torch.float32),
+                                         _dev(img, 'image'), _stream())
+    _lib.check(code, 'gd4d_value_proj_image')
+    _VP_IMAGES[key] = (weakref.ref(wb), wb._version, None if bb is None else weakref.ref(bb), None if bb is None else bb._version,
+                       _CHAIN_EPOCH[0], img)
+    return img
+
+
+def chain_guest(levels, image, out, workgroups=0):
+    """A ChainGuest: project `levels` - (R, 256, H, W) / (B, N, 256, H, W) fp32, all contiguous (NCHW) or all stored channels-last -
+    with the value_proj whose `image` this is into out (R, sum H W, 256) fp32."""
+    chlast = [PyramidView.is_channels_last_level(t) and not t.is_contiguous() for t in levels]
+    if any(chlast) != all(chlast) or (not any(chlast) and not all(t.is_contiguous() for t in levels)):
+        raise ValueError('chain_guest: the levels must be all NCHW-contiguous or all channels-last')
+    if any(t.dtype != torch.float32 or not t.is_cuda or t.shape[-3] != 256 for t in levels) or len(levels) > 4:
+        raise ValueError('chain_guest: up to 4 float32 GPU levels of 256 channels')
+    r = levels[0].numel() // (256 * levels[0].shape[-1] * levels[0].shape[-2])
+    s = sum(t.shape[-1] * t.shape[-2] for t in levels)
+    if tuple(out.shape) != (r, s, 256) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != levels[0].device:
+        raise ValueError(f'chain_guest: out must be ({r}, {s}, 256) float32, contiguous')
+    g = ChainGuest()
+    for i, t in enumerate(levels):
+        g.feats[i] = t.data_ptr()
+        g.level_hw[2 * i], g.level_hw[2 * i + 1] = int(t.shape[-2]), int(t.shape[-1])
+    g.L, g.R, g.chlast, g.workgroups = len(levels), r, int(all(chlast)), int(workgroups)
+    g.image, g.out = image.data_ptr(), out.data_ptr()
+    g._keep = (levels, image, out)
+    return g
+
+
+def value_proj_guest_fwd(guest, max_cus=0):
+    """gd4d_value_proj_guest_fwd: a ChainGuest's job as a launch of its own."""
+    code = _lib.load().gd4d_value_proj_guest_fwd(ctypes.byref(guest), int(max_cus), _stream())
+    _lib.check(code, 'gd4d_value_proj_guest_fwd')
+
+
+def row_chain_fwd(program, m, guest=None):
     """gd4d_row_chain_fwd: run the list of ChainOp over `m` rows in one launch (the tensors the operations point to must
-    stay alive until the stream has run it - the callers keep them in locals / return them)."""
+    stay alive until the stream has run it - the callers keep them in locals / return them).  guest (ChainGuest): the launch
+    also carries that value_proj job on the compute units the chain leaves idle (gd4d_row_chain_guest_fwd)."""
     lib = _lib.load()
     arr = (ChainOp * len(program))(*program)
+    if guest is not None:
+        code = lib.gd4d_row_chain_guest_fwd(arr, len(program), None, 0, int(m), ctypes.byref(guest), _stream())
+        _lib.check(code, 'gd4d_row_chain_guest_fwd')
+        return
     code = lib.gd4d_row_chain_fwd(arr, len(program), int(m), _stream())
     _lib.check(code, 'gd4d_row_chain_fwd')
 
 
-def row_chain2_fwd(program_a, program_b, m):
-    """gd4d_row_chain2_fwd: two independent programs over the same `m` rows in one launch (each on its own workgroups)."""
+def row_chain2_fwd(program_a, program_b, m, guest=None):
+    """gd4d_row_chain2_fwd: two independent programs over the same `m` rows in one launch (each on its own workgroups);
+    guest as row_chain_fwd."""
     lib = _lib.load()
     a = (ChainOp * len(program_a))(*program_a)
     b = (ChainOp * len(program_b))(*program_b)
+    if guest is not None:
+        code = lib.gd4d_row_chain_guest_fwd(a, len(program_a), b, len(program_b), int(m), ctypes.byref(guest), _stream())
+        _lib.check(code, 'gd4d_row_chain_guest_fwd')
+        return
     code = lib.gd4d_row_chain2_fwd(a, len(program_a), b, len(program_b), int(m), _stream())
     _lib.check(code, 'gd4d_row_chain2_fwd')
 

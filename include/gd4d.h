@@ -614,6 +614,8 @@ enum { GD4D_CHAIN_LOAD = 1, GD4D_CHAIN_GEMM = 2, GD4D_CHAIN_LAYERNORM = 3, GD4D_
                                        ceil(M / 32) 1024).  Rows past M of the last block are written too (finite).  p2 / p3 are
                                        outputs, not addends.  Read by gd4d_mha_core_presplit_fwd */
 #define GD4D_CHAIN_SPLIT_KV_KEEP 512 /* with GD4D_CHAIN_SPLIT_KV: gout receives the K and V columns too (fp32, for gd4d_mha_core_bwd) */
+#define GD4D_CHAIN_ADD_GOUT 1024     /* HEADGEMM: gout (M, N; row stride ldg) is READ, not written: v += gout[m, n] - the part of the sampled value
+                                        gd4d_cross_attn_agg_items_coarse_fwd gathered from already projected rows (pagg); needs dst >= 0 */
 #define GD4D_CHAIN_MAX_OPS 32
 typedef struct gd4d_chain_op {
   int32_t kind, src, dst, res;      /* LDS buffer ids, -1 = none */
@@ -669,6 +671,34 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * a right one; the host reads the counter where it synchronises anyway (once per request, after the replayed graph) and raises. */
 int gd4d_row_chain2_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
                         void* stream);
+
+/* gd4d_row_chain_guest_fwd - gd4d_row_chain_fwd / gd4d_row_chain2_fwd (nops_b = 0: one program) with GUEST workgroups in the same launch
+ * that run value_proj (deform3d_cross_attn.py:264-280: Linear 256 -> 256 over pixel rows) of ONE decoder layer over up to 4 pyramid
+ * levels - the job of gd4d_value_proj_fwd with GD4D_LAYOUT_PIXEL_MAJOR fp32 output, same kernel body, same bits.  A chain keeps
+ * ceil(M / 16) (two programs: twice that) compute units busy, latency-bound, while the rest of the device idles; the inference step
+ * uses that window to project the NEXT layer's two coarse levels (43 800 rows at 24 cameras), which
+ * gd4d_cross_attn_agg_items_coarse_fwd then gathers as 128-byte rows.  The guests are dispatched behind the chain's workgroups and
+ * share nothing with them (no hand-off; the launch ends when both have ended).
+ *   feats[l]: level l as (R, 256, H_l W_l) fp32 NCHW rows, or with chlast != 0 as (R, H_l W_l, 256) channels-last rows;
+ *   image: gd4d_value_proj_image of the layer's weight (256, 256) and bias (256; NULL = zeros) - gd4d_value_proj_image_bytes() bytes,
+ *   16-byte aligned, remade when either changes; out: (R, sum_l H_l W_l, 256) fp32, level 0's pixels first;
+ *   workgroups: guest workgroups to add (0: as many as the chain leaves compute units free, at most one per 8 tiles of 32 pixels).
+ * Inference programs only (GD4D_EUNSUPPORTED for the training operations). */
+typedef struct gd4d_chain_guest {
+  const void* feats[GD4D_MAX_LEVELS];
+  int32_t level_hw[2 * GD4D_MAX_LEVELS];
+  int32_t L, R, chlast, workgroups;
+  const void* image;
+  void* out;
+} gd4d_chain_guest;
+size_t gd4d_chain_guest_bytes(void);
+size_t gd4d_value_proj_image_bytes(void);
+int gd4d_value_proj_image(const float* weight, const float* bias, void* image, void* stream);
+int gd4d_row_chain_guest_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
+                             const gd4d_chain_guest* guest, void* stream);
+/* gd4d_value_proj_guest_fwd - the same job as a launch of its own (the first decoder layer's, whose gather no chain precedes: it runs on
+ * the side stream, beside the first layer's query side).  max_cus as gd4d_value_proj_fwd. */
+int gd4d_value_proj_guest_fwd(const gd4d_chain_guest* job, int max_cus, void* stream);
 
 /* gd4d_mha_core_presplit_fwd - gd4d_mha_core_fwd (batch 1, Lq = Lk = L; mask / mask_kind, lse, drop_p / seed as there) with K and V handed over as the
  * split-bf16 operands of its MFMAs instead of fp32 rows: the two plane pairs a GEMM operation with GD4D_CHAIN_SPLIT_KV writes

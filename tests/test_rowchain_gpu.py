@@ -359,3 +359,51 @@ def test_in_projection_writes_the_attention_cores_split_operands(m):
         op.flags |= ops.CHAIN_SPLIT_KV
         op.p2, op.p3, op.ld1, op.ld2 = kv.k.data_ptr(), kv.v.data_ptr(), kv.v[0].numel(), kv.k[0].numel()
         ops.row_chain_fwd([ops.chain_load(0, x), op], m)
+
+
+@pytest.mark.parametrize('two_programs,layout,workgroups', [(False, 'nchw', 0), (True, 'nchw', 0), (True, 'nhwc', 0), (False, 'nhwc', 3),
+                                                            (True, 'nchw', 500)])
+def test_guest_workgroups_project_pyramid_levels_beside_the_chain(two_programs, layout, workgroups):
+    """gd4d_row_chain_guest_fwd: the chain's results are those of the plain launch, bit for bit, and the guests' rows are
+    gd4d_value_proj_fwd's (same body: bit-identical from NCHW levels; channels-last levels hold the same values)."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(11)
+    m, r = 900, 5
+    x, w, b = torch.randn(m, 256, device=DEV), torch.randn(256, 256, device=DEV) * 0.08, torch.randn(256, device=DEV)
+    levels = [torch.randn(1, r, 256, h, ww, device=DEV) for h, ww in [(29, 50), (15, 25)]]       # partial tiles in both
+    wv, bv = torch.randn(256, 256, device=DEV) * 0.06, torch.randn(256, device=DEV)
+    want_rows = ops.value_proj_fwd(levels, wv, bv)
+    src = levels if layout == 'nchw' else [t.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for t in levels]
+    out = torch.full_like(want_rows, float('nan'))
+    guest = ops.chain_guest(src, ops.value_proj_image(wv, bv), out, workgroups=workgroups)
+    prog_a = lambda o: [ops.chain_load(0, x), ops.chain_gemm(0, w, b, out=o)]
+    prog_b = lambda o: [ops.chain_load(1, x), ops.chain_gemm(1, w, None, out=o, relu=True)]
+    plain_a, plain_b = torch.empty(m, 256, device=DEV), torch.empty(m, 256, device=DEV)
+    got_a, got_b = torch.empty(m, 256, device=DEV), torch.empty(m, 256, device=DEV)
+    if two_programs:
+        ops.row_chain2_fwd(prog_a(plain_a), prog_b(plain_b), m)
+        ops.row_chain2_fwd(prog_a(got_a), prog_b(got_b), m, guest=guest)
+        assert torch.equal(got_b, plain_b)
+    else:
+        ops.row_chain_fwd(prog_a(plain_a), m)
+        ops.row_chain_fwd(prog_a(got_a), m, guest=guest)
+    assert torch.equal(got_a, plain_a)
+    assert torch.equal(out, want_rows)
+    # the cached image follows the weights
+    assert ops.value_proj_image(wv, bv) is ops.value_proj_image(wv, bv)
+    img = ops.value_proj_image(wv, bv)
+    bv.add_(1.0)
+    assert ops.value_proj_image(wv, bv) is not img
+
+
+def test_headgemm_adds_a_global_addend():
+    """GD4D_CHAIN_ADD_GOUT: HEADGEMM + pagg (the coarse levels' already projected part) = the two-step sum, bit for bit."""
+    from graph_detr4d_amd import ops
+    torch.manual_seed(5)
+    m = 900
+    agg, wsum = torch.randn(m, 8, 256, device=DEV), torch.rand(m, 8, device=DEV)
+    w, b, pagg = torch.randn(256, 256, device=DEV) * 0.06, torch.randn(256, device=DEV), torch.randn(m, 256, device=DEV)
+    plain, got = torch.empty(m, 256, device=DEV), torch.empty(m, 256, device=DEV)
+    ops.row_chain_fwd([ops.chain_headgemm(agg, wsum, w, b, dst=0), ops.chain_load(1, pagg), ops.chain_add(2, 0, 256, res=1, out=plain)], m)
+    ops.row_chain_fwd([ops.chain_headgemm(agg, wsum, w, b, dst=0, addend=pagg), ops.chain_add(2, 0, 256, out=got)], m)
+    assert torch.equal(got, plain)

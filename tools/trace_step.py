@@ -14,7 +14,7 @@ import graph_detr4d_amd as G  # noqa: E402
 from graph_detr4d_amd import _lib, synthetic  # noqa: E402
 
 NAMES = {1: 'row_chain', 2: 'mha_core', 3: 'aggregate', 4: 'channels_last_copy', 5: 'plan', 6: 'sliced_aggregate',
-         7: 'row_chain (second program)', 9: 'mha_core (in the chain launch)'}
+         7: 'row_chain (second program)', 9: 'value_proj guest (first guest workgroup)'}
 
 
 def main():
