@@ -53,6 +53,10 @@ def parse():
                          'nhwc = channels-last levels, gathered in place without the per-sample copy')
     ap.add_argument('--no-nhwc-figure', action='store_true', help='skip the second figure (channels-last levels gathered in place)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
+    ap.add_argument('--rotate', type=int, default=3,
+                    help='K resident samples (own pyramid, queries and camera rig each) served round-robin by K hipGraphs, every graph '
+                         'replaying a sample it was NOT captured on (inputs written into its static buffers in place, lidar2img '
+                         'refreshed; checked against eager bit for bit before the timed region); 1 = one sample replayed')
     ap.add_argument('--inflight', type=int, default=2,
                     help="--mode infer: independent samples in flight per GPU, each on its own HIP stream with its own hipGraph "
                          "(a step = one sample on every stream); 1 = one sample at a time")
@@ -243,6 +247,8 @@ def main():
                     # capture; in the default 'global' mode that would invalidate the capture
                     with torch.cuda.graph(g_i, stream=streams[i], capture_error_mode='thread_local'), Fn.request_slot(i):
                         static_out = request(i)
+                    if i == 0:
+                        static_out0 = static_out
                     g_i.replay()
                     torch.cuda.synchronize()
                     torch.testing.assert_close(static_out[0], eager_outs[i][0], rtol=1e-5, atol=1e-5)
@@ -261,10 +267,68 @@ def main():
                     else:
                         request(i)
 
+        # --rotate K: the serving pattern the figure stands for.  K samples stay resident (own pyramid, queries, rig); graph k is
+        # captured on sample k's static buffers and then serves sample (k + 1) % K - written into those buffers in place, its
+        # lidar2img matrices refreshed through Fn.lidar2img_device OUTSIDE the graph; each is checked against the eager result of
+        # the sample it now holds, bit for bit.  The timed steps replay the K graphs round-robin: consecutive steps read different
+        # pyramids.
+        rotate = None
+        rot_graphs = [graphs[0]] if graphs else []
+        if graphs and a.rotate > 1:
+            import numpy as np
+            K = a.rotate
+            resident = [(reqs[0][0], reqs[0][1], metas)]
+            for k in range(1, K):
+                gk = torch.Generator().manual_seed(seed + 3 + 104729 * k)
+                fk = [f.to(dev) for f in synthetic.feature_pyramid(n_cams, levels, seed=seed + 104729 * k)]
+                if a.input_layout == 'nhwc':
+                    fk = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fk]
+                rig_k = rig.copy()
+                rig_k[:, :3, 3] += (np.random.RandomState(k).randn(n_cams, 3) * np.array([20.0, 20.0, 0.02])).astype(np.float32)
+                resident.append((fk, torch.randn(a.queries, 512, generator=gk).to(dev), synthetic.make_img_metas(rig_k, batch=1)))
+            with Fn.request_slot(9000):                                # eager truth, on lidar2img buffers no graph reads
+                truth = [tr(f, qe, reg_branches=regs, img_metas=mt) for f, qe, mt in resident]
+            torch.cuda.synchronize()
+            # static buffers: graph 0 keeps request 0's (reqs[0]); graphs 1 .. K-1 get their own, captured on sample k
+            static = [(reqs[0][0], reqs[0][1])]
+            rot_outs = [static_out0]
+            for k in range(1, K):
+                fk, qk, mk = resident[k]
+                static.append(([torch.empty_like(f).copy_(f) for f in fk], qk.clone()))
+                torch.cuda.synchronize()                               # (made on the default stream, read on the request's stream)
+                with torch.cuda.stream(streams[0]), Fn.request_slot(1000 + k):
+                    tr(static[k][0], static[k][1], reg_branches=regs, img_metas=mk)
+                torch.cuda.synchronize()
+                g_k = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_k, stream=streams[0], capture_error_mode='thread_local'), Fn.request_slot(1000 + k):
+                    rot_outs.append(tr(static[k][0], static[k][1], reg_branches=regs, img_metas=mk))
+                rot_graphs.append(g_k)
+            resident[0] = ([f.clone() for f in reqs[0][0]], reqs[0][1].clone(), metas)      # (sample 0 itself, apart from graph 0's buffers)
+            for k in range(K):                                         # graph k now serves sample (k + 1) % K
+                fs, qs, ms = resident[(k + 1) % K]
+                with torch.cuda.stream(streams[0]), Fn.request_slot(0 if k == 0 else 1000 + k):
+                    for dst, src in zip(static[k][0], fs):
+                        dst.copy_(src)
+                    static[k][1].copy_(qs)
+                    Fn.lidar2img_device(ms, static[k][1])
+                    for t in rot_outs[k]:
+                        t.fill_(float('nan'))
+                    rot_graphs[k].replay()
+                torch.cuda.synchronize()
+                for got, want in zip(rot_outs[k], truth[(k + 1) % K]):
+                    if not torch.equal(got, want):
+                        raise SystemExit(f'[bench] --rotate: graph {k} replayed on sample {(k + 1) % K} differs from the eager result')
+            ops.check_handoff()
+            rotate = {'samples': K, 'graphs': K,
+                      'check': 'every graph replayed on a sample it was not captured on (features, queries written into its static buffers '
+                               'in place, lidar2img refreshed outside the graph): equal to the eager result bit for bit'}
+        rot_step = [0]
+
         def run_one():
             with torch.cuda.stream(streams[0]), Fn.request_slot(0):
-                if graphs:
-                    graphs[0].replay()
+                if rot_graphs:
+                    rot_graphs[rot_step[0] % len(rot_graphs)].replay()
+                    rot_step[0] += 1
                 else:
                     request(0)
 
@@ -284,6 +348,14 @@ def main():
         windows_ms = sorted(w / a.steps * 1e3 for w in windows)
         elapsed = sorted(windows)[len(windows) // 2]
         single_ms = elapsed / a.steps * 1e3
+        if rotate is not None:                        # graph 0's buffers hold sample 0 again (what the sections below and the CPU baseline read)
+            with torch.cuda.stream(streams[0]), Fn.request_slot(0):
+                for dst, src in zip(static[0][0], resident[0][0]):
+                    dst.copy_(src)
+                static[0][1].copy_(resident[0][1])
+                Fn.lidar2img_device(metas, static[0][1])
+            torch.cuda.synchronize()
+            del resident, static, truth
         inflight = None
         if n_req > 1:                                 # secondary: n_req requests in flight (a step = one sample on every stream)
             el2 = sorted(D.timed_steps(run, a.steps, a.warmup if i == 0 else 0, dev, {}) for i in range(max(3, min(len(windows), 15))))
@@ -306,6 +378,7 @@ def main():
         if a.input_layout == 'nchw' and not a.no_nhwc_figure:
             try:
                 reqs_cl = [([f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fi], qi) for fi, qi in reqs]
+                torch.cuda.synchronize()              # (made on the default stream, read on the requests' streams)
                 graphs_cl = []
                 for i in range(n_req):
                     with torch.cuda.stream(streams[i]), Fn.request_slot(i):
@@ -369,13 +442,17 @@ def main():
             'requests_in_flight': inflight,
             'eager_ms_per_sample': eager_ms,
             'channels_last_input': nhwc,
+            'rotate': rotate,
             'data': 'synthetic',
             'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
                                    f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
                                    f'{"x".join(str(h) + "*" + str(w) for h, w in levels)}, 256 ch, '
                                    f'batch 1 per GPU, ONE request at a time (SURVEY 8(d)\'s definition; a step = one sample through the '
                                    f'decoder, one HIP stream, one hipGraph), pyramid resident in HBM; value = the median of '
-                                   f'{len(windows_ms)} windows of {a.steps} steps',
+                                   f'{len(windows_ms)} windows of {a.steps} steps'
+                                   + ('' if rotate is None else f'; {rotate["samples"]} resident samples (own pyramid, queries, camera rig) served '
+                                      f'round-robin, every graph on a sample it was not captured on'),
+                       'rotate': 1 if rotate is None else rotate['samples'],
                        'metric_8d': 'value',
                        'baseline_config': 'configs[2]', 'launch': launch, 'inflight': 1, 'input_layout': a.input_layout, 'global_batch': a.gpus,
                        'samples_per_step': a.gpus,

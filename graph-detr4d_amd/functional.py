@@ -592,6 +592,7 @@ class LateValues:
         self.main = torch.cuda.current_stream(dev)
         self.shapes = [(int(v.shape[-2]), int(v.shape[-1])) for v in value]
         self.cl = self.pyramid = self.event = self.src = None
+        self.copy_dtype = torch.float32
         self.coarse = self.coarse_src = self.coarse_first = None
         self.partial = False
         self.waited = set()
@@ -689,6 +690,8 @@ class LateValues:
         if os.environ.get('GD4D_COARSE', '1') == '0' or self.mode != 'sliced' or len(self.shapes) != 4 or not modules:
             return False
         if any(m.num_heads != 8 or m.embed_dims != 256 for m in modules) or self.value[0].dtype != torch.float32:
+            return False
+        if getattr(self, 'copy_dtype', torch.float32) != torch.float32:      # bf16 storage: every level is gathered bf16-rounded
             return False
         src = list(self.value[2:]) if self.src is None else list(self.src[2:])
         rows = src[0].numel() // (256 * self.shapes[2][0] * self.shapes[2][1])

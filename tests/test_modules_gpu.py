@@ -535,3 +535,83 @@ def test_deform3d_cross_attn_any_num_points_matches_the_oracle(points):
     for name, p in mod.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
         assert rel(p.grad, p_c[name].grad) < 3e-3, (name, rel(p.grad, p_c[name].grad))
+
+
+def _store(feats, layout):
+    """The same logical (B, N, C, H, W) levels, stored NCHW or channels-last (B, N, H, W, C)."""
+    if layout == 'nchw':
+        return [f.clone() for f in feats]
+    return [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+
+
+@pytest.mark.parametrize('layout,inflight', [('nchw', 1), ('nhwc', 1), ('nchw', 2), ('nhwc', 2)])
+def test_a_captured_graph_serves_samples_it_was_not_captured_on(layout, inflight):
+    """The serving pattern the headline stands for: the decoder graph is captured ONCE on sample A; a new sample is written into
+    the same feature buffers and query buffer in place, its lidar2img matrices are refreshed through Fn.lidar2img_device (the
+    persistent device buffer the capture baked in), and the graph is replayed.  The result must be the eager result on the new
+    sample bit for bit - a host value baked into the capture (launch sizes, offsets, an order computed on the host) would make
+    every replay after the first wrong with rc 0.  NCHW (per-sample slice-planar copy inside the graph) and channels-last levels
+    (gathered in place), one request and two in flight (each its own static buffers, stream, slot and graph)."""
+    import numpy as np
+    import bench
+    from graph_detr4d_amd import functional as Fn
+    from graph_detr4d_amd import ops, synthetic
+    frames, queries, layers = 2, 300, 3
+    n = 6 * frames
+    levels = [(29, 50), (15, 25), (8, 13), (4, 7)]
+    tr, regs = bench.build_decoder(G, n, layers, 'fp32', 4242)
+    tr, regs = tr.to(DEV), regs.to(DEV)
+
+    def sample(k):
+        feats = [f.to(DEV) for f in synthetic.feature_pyramid(n, levels, seed=900 + k)]
+        qe = torch.randn(queries, 512, generator=torch.Generator().manual_seed(70 + k)).to(DEV)
+        rig = synthetic.camera_rig(frames)
+        rig = rig.copy()
+        rng = np.random.RandomState(k)
+        rig[:, :3, 3] += (rng.randn(n, 3) * np.array([20.0, 20.0, 0.02])).astype(np.float32)    # every camera's calibration moves
+        return _store(feats, layout), qe, synthetic.make_img_metas(rig, batch=1)
+    samples = [sample(k) for k in range(2 * inflight + 1)]
+    with torch.no_grad():
+        with Fn.request_slot(99):                                      # (eager truth on its own lidar2img buffers)
+            truth = [tr(f, qe, reg_branches=regs, img_metas=mt) for f, qe, mt in samples]
+        torch.cuda.synchronize()
+        assert not torch.equal(truth[0][0], truth[1][0])
+        streams = [torch.cuda.Stream() for _ in range(inflight)]
+        static, graphs, outs = [], [], []
+        for i in range(inflight):                                      # request i: captured on sample i
+            f0, q0, m0 = samples[i]
+            buf = ([f.clone() for f in f0], q0.clone())                   # (clone keeps the strides: NCHW or channels-last)
+            assert all(a.stride() == b.stride() and a.data_ptr() != b.data_ptr() for a, b in zip(buf[0], f0))
+            static.append(buf)
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                tr(buf[0], buf[1], reg_branches=regs, img_metas=m0)        # warm-up: allocator, lidar2img buffer of this slot
+            torch.cuda.synchronize()
+            g_i = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_i, stream=streams[i], capture_error_mode='thread_local'), Fn.request_slot(i):
+                outs.append(tr(buf[0], buf[1], reg_branches=regs, img_metas=m0))
+            graphs.append(g_i)
+
+        def serve(assignment):
+            """assignment[i] = the sample request i serves now: written into its static buffers, matrices refreshed, all replayed."""
+            for i, k in enumerate(assignment):
+                f, qe, mt = samples[k]
+                with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                    for dst, src in zip(static[i][0], f):
+                        dst.copy_(src)
+                    static[i][1].copy_(qe)
+                    Fn.lidar2img_device(mt, static[i][1])              # outside the graph: the persistent buffer, in place
+                    for t in outs[i]:
+                        t.fill_(float('nan'))
+            for i in range(inflight):
+                with torch.cuda.stream(streams[i]), Fn.request_slot(i):
+                    graphs[i].replay()
+            torch.cuda.synchronize()
+            ops.check_handoff()
+            for i, k in enumerate(assignment):
+                for a, b in zip(outs[i], truth[k]):
+                    assert torch.equal(a, b), (assignment, i, k)
+        serve(list(range(inflight)))                                   # the samples the graphs were captured on
+        serve([inflight + i for i in range(inflight)])                 # new samples
+        serve([2 * inflight] * inflight)                               # ... and again (every request the same new one)
+        serve(list(range(inflight)))                                   # back
