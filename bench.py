@@ -53,6 +53,7 @@ def parse():
                          'nhwc = channels-last levels, gathered in place without the per-sample copy')
     ap.add_argument('--no-nhwc-figure', action='store_true', help='skip the second figure (channels-last levels gathered in place)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
+    ap.add_argument('--no-exact-figure', action='store_true', help='skip the figure with every chain GEMM on six products')
     ap.add_argument('--rotate', type=int, default=3,
                     help='K resident samples (own pyramid, queries and camera rig each) served round-robin by K hipGraphs, every graph '
                          'replaying a sample it was NOT captured on (inputs written into its static buffers in place, lidar2img '
@@ -371,6 +372,34 @@ def main():
         eager_steps = max(1, min(a.steps, 10))
         eager_ms = D.timed_steps(run_eager, eager_steps, 2, dev, {}) / eager_steps * 1e3
 
+        # ---- what fp32-class arithmetic on the query side costs: the same request with EVERY chain GEMM on six bf16 products
+        # (GD4D_CHAIN_EXACT, ~2^-24 per product) instead of three (~2^-16); value_proj of the aggregates and the attention core's
+        # two products stay on three.  Secondary figure beside the x3 headline.
+        exact = None
+        if graphs and not a.no_exact_figure:
+            try:
+                with ops.all_exact():
+                    with torch.cuda.stream(streams[0]), Fn.request_slot(0):
+                        o_ex = request(0)
+                    torch.cuda.synchronize()
+                    g_ex = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_ex, stream=streams[0], capture_error_mode='thread_local'), Fn.request_slot(0):
+                        request(0)
+
+                def run_ex():
+                    with torch.cuda.stream(streams[0]), Fn.request_slot(0):
+                        g_ex.replay()
+                el_ex = sorted(D.timed_steps(run_ex, a.steps, a.warmup if i == 0 else 0, dev, {}) for i in range(7))[3]
+                ops.check_handoff()
+                exact = {'value': D.aggregate_throughput(1, a.steps, a.gpus, el_ex), 'unit': 'samples/s', 'ms_per_step': el_ex / a.steps * 1e3,
+                         'max_abs_difference_to_x3_last_layer': float((o_ex[0][-1] - eager_outs[0][0][-1]).abs().max()),
+                         'max_abs_difference_to_x3_first_layer': float((o_ex[0][0] - eager_outs[0][0][0]).abs().max()),
+                         'note': 'every GEMM operation of the row chains on six split-bf16 products (in/out-proj, the cross-attention Linears, '
+                                 'output_proj, FFN, reg branches); value_proj of the aggregates and the attention core stay on three'}
+                del g_ex, o_ex
+            except Exception as e:                    # secondary figure: report, never fail the bench line
+                exact = {'error': f'{type(e).__name__}: {e}'}
+
         # ---- second figure: the same requests with the feature levels STORED channels-last (the FPN's output
         # layout) - the cross-attention gathers them in place, the per-sample copy is not launched.  Same logical tensors,
         # same results; the NCHW figure above stays the headline.
@@ -443,6 +472,7 @@ def main():
             'eager_ms_per_sample': eager_ms,
             'channels_last_input': nhwc,
             'rotate': rotate,
+            'exact_gemms': exact,
             'data': 'synthetic',
             'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
                                    f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
@@ -659,7 +689,7 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                     graph.replay()
                     reducer.reduce_buckets()
                     sgd_step()
-                launch = 'hipgraph (forward + backward), eager bucketed all-reduce + SGD'
+                launch = 'hipgraph (forward + backward), eager bucketed all-reduce + ' + ('clip + AdamW' if a.optimizer == 'adamw' else 'SGD')
             run()
             torch.cuda.synchronize()
         except Exception as e:                        # report, never hide
@@ -691,7 +721,8 @@ def train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, le
                                    ('training step of the decoder + head with the reference\'s loss (Hungarian assignment, '
                                     f'{a.gts} boxes; ' if a.criterion else '') +
                                    f'training step of the {a.layers}-layer decoder (forward + backward + flat gradient '
-                                   f'all-reduce of {reducer.bytes_per_step() / 1e6:.1f} MB + SGD), {a.queries} queries, '
+                                   f'all-reduce of {reducer.bytes_per_step() / 1e6:.1f} MB + '
+                                   f'{"clip + AdamW" if a.optimizer == "adamw" else "SGD"}), {a.queries} queries, '
                                    f'{n_cams} cameras, batch 1 per GPU, pyramid (requires grad) resident in HBM',
                        'baseline_config': 'configs[4]' if distill else ('configs[3]' if a.levels == 'vov' else 'configs[2] + backward'),
                        'launch': launch + (', all-reduce overlapped with backward (hooks)' if overlap else ''),

@@ -18,6 +18,8 @@
 // product.  The weights are pre-split into MFMA B-fragment order (gd4d_chain_weight_image, cached by the caller while
 // the weights do not change) so they stream from L2 as whole 1-KB pieces; the activations are split when read from LDS.
 // LayerNorm two-pass like ATen (mean, centred sum of squares, biased variance, eps inside the square root).
+#include <stdlib.h>
+
 #include "gd4d_common.h"
 #include "gd4d_mha_dropout.h"
 #include "gd4d_value_proj_body.h"
@@ -967,6 +969,11 @@ __device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int
             }
             __builtin_amdgcn_s_sleep(8);
           }
+          // The consumer takes the flag down again: the flags of a request return to zero by themselves, so that one buffer per
+          // request slot serves every request (no fill in the replayed graph).  The next SIGNAL for this row block belongs to a
+          // later launch of the same stream.  (A WAIT that gave up leaves the flag alone: the host zeroes the buffers when it
+          // reports the error word, ops.check_handoff.)
+          if (!rc_poison) __hip_atomic_store(const_cast<unsigned*>(f), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         break;
       }

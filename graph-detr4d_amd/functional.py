@@ -182,6 +182,11 @@ class request_slot:
 
 
 
+def slot_key(device):
+    """What per-request persistent device buffers are keyed by: the active request_slot(), else the current stream."""
+    return _REQUEST_SLOT[0] if _REQUEST_SLOT[0] is not None else ('stream', torch.cuda.current_stream(device).cuda_stream)
+
+
 def lidar2img_device(img_metas, like):
     """(B, N, 4, 4) fp32 device tensor from img_metas[*]['lidar2img'].
 

@@ -220,7 +220,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     pos_late = ops.handoff_enabled(dev, 'GD4D_POS_ENCODER')       # [chain A | reg branch], [chain B' | position_encoder]: the default
     if pos_late:
         blocks = (q + 15) // 16
-        flags = torch.zeros(nl, (blocks + 7) // 8 * 8 + 8, device=dev, dtype=torch.int32)     # row-block flags per layer
+        flags = ops.handoff_flags(dev, nl, (blocks + 7) // 8 * 8 + 8, Fn.slot_key(dev))       # row-block flags per layer (persistent: no fill in the graph)
         err = ops.handoff_error_word(dev)
         keep.append(flags)
     for lid, layer in enumerate(layers):

@@ -212,7 +212,7 @@ class DecoderTrainFunction(torch.autograd.Function):
         drops = [_dropouts(layer) for layer in layers]
         seeds = draw_seeds(5 * nl, dev) if any(any(pr > 0. for pr in d) for d in drops) else None
         beside = meta.reg_branches is not None and ops.handoff_enabled(dev, 'GD4D_TRAIN_REG_BESIDE')
-        flags = torch.zeros(nl, (q + 15) // 16 // 8 * 8 + 16, device=dev, dtype=torch.int32) if beside else None   # hand-off flags per row block
+        flags = ops.handoff_flags(dev, nl, (q + 15) // 16 // 8 * 8 + 16, ('train', Fn.slot_key(dev))) if beside else None   # hand-off flags per row block
         err = ops.handoff_error_word(dev) if beside else None    # a WAIT that gives up counts here (and poisons its rows): ops.check_handoff
         qkv, xp = new(q, 1, 3 * c), new(q, c)
         im0 = imgs.layers[0]

@@ -6,6 +6,7 @@ path has no CPU fallback.
 import ctypes
 import functools
 import inspect
+import os
 
 import torch
 
@@ -1905,12 +1906,27 @@ def chain_dropmask(src, dst, n, seed, p, out=None):
                    p0=_dev(seed, 'seed', torch.int64).value)
 
 
+# Measurement switch (bench.py's `exact_gemms` figure; `with ops.all_exact():`): EVERY GEMM operation of the chains built while it is
+# on uses six bf16 products (GD4D_CHAIN_EXACT, ~2^-24) - what fp32-class arithmetic on the query side costs.  HEADGEMM (value_proj
+# of the aggregates) and the attention core's two products stay on three.
+ALL_EXACT = [os.environ.get('GD4D_CHAIN_ALL_EXACT') == '1']
+
+
+class all_exact:
+    def __enter__(self):
+        self.prev, ALL_EXACT[0] = ALL_EXACT[0], True
+
+    def __exit__(self, *exc):
+        ALL_EXACT[0] = self.prev
+
+
 def chain_gemm(src, weight, bias=None, dst=-1, dst_col=0, relu=False, res=-1, out=None, sigmoid=False, exact=False, add=None,
                add2=None, mask=None, mask_scale=0., dropout=None):
     """act(buf[src] W^T + b) (+ buf[res]) (+ (add + add2)[m, :]) -> buf[dst] and / or out.  weight (N, K) contiguous rows.
     add / add2: global (M, N) tensors added in the epilogue (their sum first, then onto the result - what a LOAD of
     add + add2 into buf[res] would give, without the operation).  exact: fp32-class products (GD4D_CHAIN_EXACT) instead of
     split-bf16 x3 - for outputs that become reference points."""
+    exact = exact or ALL_EXACT[0]
     img, n, k = _image_of(weight, exact)
     g, ldg = _rows(out, 'out')
     if mask is not None and (add is not None or add2 is not None):
@@ -1960,8 +1976,8 @@ def chain_gemm_two_sources(src, src2, split, weight, bias, out, kv=None, keep_fp
     kv (KVPlanes, N = 768): the K and V columns are written as the attention core's split-bf16 operands INSTEAD of fp32 (out
     receives the Q columns only; keep_fp32 - a training step, whose attention backward reads fp32 rows: all columns)."""
     g, ldg = _rows(out, 'out')
-    img, n, k = _image_of(weight)
-    op = ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=k, N=n, flags=CHAIN_SRC2, ld0=int(split),
+    img, n, k = _image_of(weight, ALL_EXACT[0])
+    op = ChainOp(kind=CHAIN_GEMM, src=src, dst=-1, res=src2, K=k, N=n, flags=CHAIN_SRC2 | (CHAIN_EXACT if ALL_EXACT[0] else 0), ld0=int(split),
                  ldg=ldg, p0=img, p1=None if bias is None else bias.data_ptr(), gout=g)
     if kv is not None:
         if n != 3 * kv.c or kv.c != 256 or kv.heads != 8:
@@ -2107,6 +2123,23 @@ def handoff_error_word(device):
     return st['word']
 
 
+_HANDOFF_FLAGS = {}       # (device index, request slot key, rows, cols) -> int32 (rows, cols), zero between requests
+
+
+def handoff_flags(device, rows, cols, slot_key):
+    """The SIGNAL / WAIT flags of one request: (rows, cols) int32, zero when a request starts - the WAITing program takes every flag
+    down again after it has seen it - so ONE persistent buffer per (device, request slot) serves every request and a replayed
+    hipGraph holds no fill.  slot_key: functional.slot_key(device) - requests in flight on different streams get their own."""
+    device = torch.device(device)
+    key = (device.index, slot_key, int(rows), int(cols))
+    buf = _HANDOFF_FLAGS.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(rows, cols, device=device, dtype=torch.int32)       # (first use inside a capture: this graph's own, filled per replay)
+        buf = _HANDOFF_FLAGS[key] = torch.zeros(rows, cols, device=device, dtype=torch.int32)
+    return buf
+
+
 def check_handoff(device=None):
     """Blocking: raises Gd4dError if a hand-off has timed out on `device` (default: every device used so far) since the last check.
     Call it where a host sync exists anyway - after a request's graph replay (or every N replays), at the end of a step."""
@@ -2118,6 +2151,8 @@ def check_handoff(device=None):
         st['event'] = None
         if n:
             st['word'].zero_()
+            for buf in _HANDOFF_FLAGS.values():          # a late SIGNAL may have raised a flag its WAIT no longer took down
+                buf.zero_()
             raise _lib.Gd4dError(f'{n} SIGNAL / WAIT hand-off(s) between chain programs timed out: the affected rows are NaN. '
                                  'GD4D_POS_ENCODER=dual / GD4D_TRAIN_REG_BESIDE=0 run the same step without hand-offs.')
 

@@ -156,6 +156,59 @@ def test_transformer_decoder(name):
     torch.cuda.synchronize()
 
 
+def test_hdetr_transformer_matches_the_reference_classes():
+    """HDetr3DTransformer against the fixture recorded from the reference's OWN HDetr3DTransformer.forward
+    (utils/h_detr3d_transformer.py:49-175) with the head's block mask (dense_heads/h_detr3d_head_pe.py:299-304) handed over as
+    `decoder_self_attn_mask=[mask, None]` (:313); fused loop and module path, eager and under a hipGraph."""
+    g = Golden('decoder_hdetr')
+    m = g.meta
+    n = m['num_cams']
+    cfg = dict(type='HDetr3DTransformer', num_feature_levels=4, num_cams=n,
+               decoder=dict(type='Detr3DTransformerDecoder', num_layers=m['num_layers'], return_intermediate=True,
+                            transformerlayers=dict(
+                                type='DetrTransformerDecoderLayer',
+                                attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                           dict(type='Deform3DCrossAttn', num_cams=n, pc_range=m['pc_range'], num_points=4, embed_dims=256)],
+                                feedforward_channels=512, ffn_dropout=0.1,
+                                operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm'))))
+    tr = G.build_transformer(cfg)
+    tr.load_state_dict(g.state(), strict=True)
+    tr = tr.to(DEV).eval()
+    nn = torch.nn
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                        nn.Linear(256, 10)) for _ in range(m['num_layers'])])
+    regs.load_state_dict(g.state(prefix='reg.'), strict=True)
+    regs = regs.to(DEV).eval()
+    feats, qe = [f.to(DEV) for f in g.feats()], g.t('query_embed').to(DEV)
+    k, nq = m['num_queries_one2one'], m['num_query']
+    self_attn_mask = torch.zeros([nq, nq]).bool().to(DEV)                 # as the head builds it
+    self_attn_mask[k:, 0:k] = True
+    self_attn_mask[0:k, k:] = True
+    assert torch.equal(self_attn_mask.cpu(), g.t('self_attn_mask').bool())
+
+    def run():
+        with torch.no_grad():
+            return tr(feats, qe, reg_branches=regs, decoder_self_attn_mask=[self_attn_mask, None], img_metas=_metas(g))
+    states, init_ref, refs = run()
+    torch.testing.assert_close(init_ref.cpu(), g.t('init_reference'), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(refs.cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(states.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+    os.environ['GD4D_FUSED_DECODER'] = '0'                               # the module path
+    try:
+        s2, _, r2 = run()
+    finally:
+        os.environ.pop('GD4D_FUSED_DECODER')
+    torch.testing.assert_close(s2.cpu(), g.t('inter_states'), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(r2.cpu(), g.t('inter_references'), rtol=1e-4, atol=1e-4)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        captured = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured[0], states) and torch.equal(captured[2], refs)
+
+
 def test_hdetr_transformer_mask_path_equals_oracle():
     """HDetr3DTransformer: 48 queries = 16 one-to-one + 32 one-to-many with the block self-attention mask
     of h_detr3d_head_pe.py:299-303, against the CPU oracle driven with the same mask."""

@@ -88,6 +88,32 @@ def test_self_attention_matches_aten(name):
     torch.testing.assert_close(out, g.t('out'), rtol=1e-5, atol=2e-5)
 
 
+def test_hdetr_transformer_matches_the_reference_classes():
+    """decoder_hdetr: the reference's own HDetr3DTransformer (utils/h_detr3d_transformer.py:49-175) driven with the block mask its head
+    builds (dense_heads/h_detr3d_head_pe.py:299-304, handed over as [mask, None]) - the masked self-attention path pinned through
+    the reference's CLASSES, not only through the self_attn_mask fixture."""
+    g = Golden('decoder_hdetr')
+    m = g.meta
+    sd = g.state()
+    layers = [sub(sd, f'decoder.layers.{i}.') for i in range(m['num_layers'])]
+    reg_sd = g.state(prefix='reg.')
+
+    def reg(i):
+        p = sub(reg_sd, f'{i}.')
+        F = torch.nn.functional
+        return lambda x: F.linear(F.relu(F.linear(F.relu(F.linear(
+            x, p['0.weight'], p['0.bias'])), p['2.weight'], p['2.bias'])), p['4.weight'], p['4.bias'])
+    mask = g.t('self_attn_mask').bool()
+    k = m['num_queries_one2one']
+    assert mask[k:, :k].all() and mask[:k, k:].all() and not mask[:k, :k].any() and not mask[k:, k:].any()
+    states, init_ref, refs = O.transformer(
+        sd, layers, g.feats(), g.t('query_embed'), g.img_metas(), m['pc_range'],
+        reg_branches=[reg(i) for i in range(m['num_layers'])], cross=m['cross'], num_points=m['num_points'], attn_mask=mask)
+    torch.testing.assert_close(init_ref, g.t('init_reference'), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(refs, g.t('inter_references'), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(states, g.t('inter_states'), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize('name', ['decoder_deform', 'decoder_detr3d'])
 def test_transformer_decoder_matches_reference(name):
     g = Golden(name)

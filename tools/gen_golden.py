@@ -405,6 +405,56 @@ def case_decoder(name, *, cross, num_query, frames, batch, img_hw, seed, num_lay
     save(name, meta, **arrays)
 
 
+def case_hdetr(name, *, num_query, one2one, frames, img_hw, seed, num_layers):
+    """The reference's OWN H-DETR classes: HDetr3DTransformer.forward (utils/h_detr3d_transformer.py:49-175) with the block
+    self-attention mask exactly as HDetr3DHeadPE.forward builds it (dense_heads/h_detr3d_head_pe.py:299-304) and hands it over
+    (`decoder_self_attn_mask=[self_attn_mask, None]`, :313)."""
+    ref_mods = refstub.load_reference(names=('deform3d_cross_attn', 'detr3d_transformer', 'h_detr3d_transformer'))
+    m = ref_mods['h_detr3d_transformer']
+    n = 6 * frames
+    torch.manual_seed(seed)
+    tr = m.HDetr3DTransformer(
+        num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=num_layers, return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=PC_RANGE, num_points=4, embed_dims=256)],
+                         feedforward_channels=512, ffn_dropout=0.1,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))).eval()
+    tr.init_weights()
+    quantise_params_(tr, seed)
+    regs = nn.ModuleList([nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256),
+                                        nn.ReLU(), nn.Linear(256, 10)) for _ in range(num_layers)])
+    quantise_params_(regs, seed + 5)
+    regs.eval()
+    levels = levels_for(img_hw)
+    feats, packed = grid_features(n, levels, 1, seed + 1)
+    g = torch.Generator().manual_seed(seed + 3)
+    query_embed = torch.randn(num_query, 512, generator=g)
+    l2i = small_rig(frames, img_hw)
+    metas = synthetic.make_img_metas(l2i, img_shape=(img_hw[0], img_hw[1], 3), batch=1)
+    # h_detr3d_head_pe.py:299-304, verbatim in effect
+    self_attn_mask = torch.zeros([num_query, num_query, ]).bool()
+    self_attn_mask[one2one:, 0: one2one] = True
+    self_attn_mask[0: one2one, one2one:] = True
+    with torch.no_grad():
+        states, init_ref, inter_refs = tr(feats, query_embed, reg_branches=regs, decoder_self_attn_mask=[self_attn_mask, None],
+                                          img_metas=metas)
+        plain, _, _ = tr(feats, query_embed, reg_branches=regs, decoder_self_attn_mask=None, img_metas=metas)
+    assert (states - plain).abs().max().item() > 1e-2, 'the mask must matter'
+    meta = dict(kind='HDetr3DTransformer', cross='Deform3DCrossAttn', num_query=num_query, num_queries_one2one=one2one, num_cams=n,
+                batch=1, levels=levels, img_shape=[img_hw[0], img_hw[1], 3], pc_range=list(PC_RANGE), num_layers=num_layers,
+                seed=seed, feat_scale=FEAT_SCALE, w_scale=W_SCALE, num_points=4)
+    arrays = dict(query_embed=query_embed, lidar2img=l2i, inter_states=states, init_reference=init_ref,
+                  inter_references=inter_refs, self_attn_mask=self_attn_mask.to(torch.uint8))
+    for i, pk in enumerate(packed):
+        arrays[f'feat{i}@q'] = pk
+    arrays.update(pack_state(tr))
+    arrays.update(pack_state(regs, prefix='reg.'))
+    save(name, meta, **arrays)
+
+
 def case_decode(name, *, num_query, batch, seed, max_num, code_size=10, score_threshold=None,
                 num_layers=2):
     """NMSFreeCoder.decode (reference core/bbox/coders/nms_free_coder.py:98-117) on head outputs."""
@@ -647,6 +697,7 @@ def main():
     case_self_attn('self_attn_mask', num_query=48, batch=1, seed=302, with_mask=True)
     case_decoder('decoder_deform', cross='Deform3DCrossAttn', num_query=32, frames=1, batch=1,
                  img_hw=(64, 112), seed=401, num_layers=2)
+    case_hdetr('decoder_hdetr', num_query=48, one2one=16, frames=1, img_hw=(64, 112), seed=431, num_layers=2)
     case_decoder('decoder_detr3d', cross='Detr3DCrossAtten', num_query=32, frames=1, batch=1,
                  img_hw=(64, 112), seed=402, num_layers=2)
     case_head_pe('head_pe', frames=1, img_hw=(64, 112), pad_hw=(64, 112), strides=(8, 16), seed=601)

@@ -382,7 +382,9 @@ def install_stubs():
     _mod('mmdet.models')
     _mod('mmdet.models.utils')
     _mod('mmdet.models.utils.builder', TRANSFORMER=TRANSFORMER)
-    _mod('mmdet.models.utils.transformer', DetrTransformerDecoderLayer=DetrTransformerDecoderLayer)
+    # (h_detr3d_transformer.py:26 imports DetrTransformerDecoder by name and never uses it: a name-only stub)
+    _mod('mmdet.models.utils.transformer', DetrTransformerDecoderLayer=DetrTransformerDecoderLayer,
+         DetrTransformerDecoder=type('DetrTransformerDecoder', (), {}))
     _mod('mmdet3d')
     _mod('mmdet3d.core')
     _mod('mmdet3d.core.bbox')
