@@ -660,7 +660,9 @@ int gd4d_row_chain_fwd(const gd4d_chain_op* program, int nops, int M, void* stre
  * SIGNAL / WAIT (two-program launches only): a hand-off between the programs, row block by row block.  SIGNAL (gout = an
  * array of >= ceil(M / 16) uint32 flags, zero before the launch) publishes what its program has written to global memory for
  * its 16 rows so far; WAIT (p0 = the same array; gout = a uint32 error counter) holds its program until the OTHER
- * program's workgroup of the same rows has signalled; the operation after a WAIT must be the LOAD of what was handed over.
+ * program's workgroup of the same rows has signalled - and takes the flag down again (the array is zero after the launch: one
+ * buffer serves launch after launch, a replayed hipGraph needs no fill); the operation after a WAIT must be the LOAD of what was
+ * handed over.
  * Row block i of both programs is dispatched to the same XCD (workgroups j and j + 8 k share one - the dispatcher's behaviour
  * today, which no specification promises: gd4d_xcd_placement_probe lets the host check it once per device before it builds such
  * programs), so the hand-off goes through that XCD's L2 without cache maintenance.  E.g. position_encoder next to chain B: its

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, '_build', 'libgd4d_oracle.so')
+_SO = os.environ.get('GD4D_ORACLE_SO') or os.path.join(_DIR, '_build', 'libgd4d_oracle.so')   # (env: the sanitizer build, tools/sanitize_cpu.sh)
 _lib = None
 
 

@@ -189,9 +189,9 @@ def test_chain_gemm_exact_matches_fp64_to_fp32_class(m, k, n):
 def test_signal_wait_hand_off_between_the_two_programs(m):
     """SIGNAL / WAIT: the second program writes rows to global memory and signals per row block; the first program, after
     a GEMM of its own, waits and LOADs them - what run_single does with position_encoder next to chain B.  Equal, bit for
-    bit, to the two programs run one launch after the other; repeated 50 times back to back (a missed hand-off would read
-    the poison the buffer is refilled with before every launch); the give-up counter stays 0; without a second program the
-    operations are refused."""
+    bit, to the two programs run one launch after the other; repeated 50 times back to back on ONE flag buffer (a missed hand-off
+    would read the poison the row buffer is refilled with before every launch; a flag left up would let the next launch's WAIT
+    through too early); the give-up counter stays 0; without a second program the operations are refused."""
     from graph_detr4d_amd import _lib, ops
     torch.manual_seed(m)
     x, y = torch.randn(m, 256, device=DEV), torch.randn(m, 3, device=DEV).sigmoid()
@@ -215,14 +215,16 @@ def test_signal_wait_hand_off_between_the_two_programs(m):
     ops.row_chain_fwd(consumer(pos_ref, out_ref), m)
     errors = torch.zeros(1, device=DEV, dtype=torch.int32)
     pos, out = torch.empty(m, 256, device=DEV), torch.empty(m, 256, device=DEV)
+    # ONE flag buffer for all 50 launches: the WAITing program takes every flag down again after it has seen it (what lets a
+    # request slot keep one persistent buffer and a replayed graph hold no fill)
+    flags = torch.zeros((blocks + 7) // 8 * 8, device=DEV, dtype=torch.int32)
     for _ in range(50):
-        flags = torch.zeros((blocks + 7) // 8 * 8, device=DEV, dtype=torch.int32)
         pos.fill_(float('nan'))
         out.fill_(float('nan'))
         ops.row_chain2_fwd(producer(pos, flags), consumer(pos, out, flags, errors), m)      # the SIGNALling program first
         assert torch.equal(pos, pos_ref) and torch.equal(out, out_ref)
+        assert int(flags.sum().item()) == 0
     assert int(errors.item()) == 0
-    assert int(flags[:blocks].sum().item()) == blocks
     with pytest.raises(_lib.Gd4dError):
         ops.row_chain_fwd(producer(pos, flags), m)
     with pytest.raises(_lib.Gd4dError):                            # the waiting program first: its producers would be dispatched
