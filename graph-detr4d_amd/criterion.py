@@ -114,6 +114,7 @@ class HungarianAssigner3D:
 
     _status = None          # (status tensor of the last device assignment, num_classes)
     _pending = None         # (pinned copy, event, num_classes) requested by poll_status
+    _pinned = None          # the pinned host buffer poll_status copies into, kept
 
     def check_status(self):
         """Blocking: raises if the last device assignment met a label outside [0, num_classes) (IndexError, as the reference's
@@ -142,7 +143,9 @@ class HungarianAssigner3D:
             self._raise_for(pinned, ncls)
         if self._pending is None and self._status is not None:
             status, ncls = self._status
-            pinned = torch.empty(status.shape, dtype=status.dtype).pin_memory()
+            pinned = self._pinned                                     # ONE pinned buffer per assigner (pin_memory() is a slow path)
+            if pinned is None or pinned.shape != status.shape or pinned.dtype != status.dtype:
+                pinned = self._pinned = torch.empty(status.shape, dtype=status.dtype).pin_memory()
             pinned.copy_(status, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -230,6 +233,13 @@ class Detr3DCriterion(nn.Module):
         normalisers - as one object to hand back to it (`prepared=`): a step whose ground truth is resident (a captured hipGraph
         cannot contain the host -> device copies) computes it once, outside the capture."""
         gts = [gt_tensor(g) for g in gt_bboxes_list]
+        # The labels are checked HERE, once, where a host look is acceptable (outside any capture): on the device a label outside
+        # [0, num_classes) is only reported through the assigner's status word - a step or more later, after an optimizer step that
+        # treated the sample as all background, and inside a replayed graph only if its owner calls check_status().
+        for lab in gt_labels_list:
+            if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= self.num_classes):
+                raise IndexError(f'gt_labels must lie in [0, {self.num_classes}): the reference indexes cls_pred[:, gt_labels] with them '
+                                 '(core/bbox/match_costs/match_cost.py:17-30)')
         packed = pack_ground_truth(gts, gt_labels_list, device)
         return gts, packed, self.normalisers([int(g.shape[0]) for g in gts], num_query, device)
 

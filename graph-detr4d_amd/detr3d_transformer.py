@@ -122,7 +122,7 @@ class Detr3DCrossAtten(nn.Module):
         if not Fn.torch_ops_route(f'Detr3DCrossAtten training with num_points = {self.num_points}, {len(value)} levels, {n} cameras',
                                   self.num_points == 1 and len(value) <= 8 and n <= 256
                                   and all(v.is_cuda and v.dtype == torch.float32 for v in value)
-                                  and reference_points.dtype == torch.float32):
+                                  and reference_points.dtype == torch.float32, module=self):
             # the sampling core on its HIP kernels both ways (gd4d_detr3d_fwd / gd4d_detr3d_bwd)
             from .autograd import Detr3DSampleFunction
             agg = Detr3DSampleFunction.apply(reference_points, logits.reshape(b, q, n, 1, nl), lidar2img, self.pc_range, img_h, img_w,
@@ -239,7 +239,7 @@ class Detr3DCrossAttenV2(nn.Module):
         gd4d_detr3d_v2_fwd / gd4d_detr3d_v2_bwd behind autograd.Detr3DV2SampleFunction (embed_dims <= 256; wider models raise;
         GD4D_TORCH_OPS=1: the same maths as differentiable torch ops, below); the Linears and LayerNorms are the package's
         autograd Functions."""
-        if not Fn.torch_ops_route(f'Detr3DCrossAttenV2 training with embed_dims = {self.embed_dims}', self.embed_dims <= 256):
+        if not Fn.torch_ops_route(f'Detr3DCrossAttenV2 training with embed_dims = {self.embed_dims}', self.embed_dims <= 256, module=self):
             from .autograd import Detr3DV2SampleFunction
             x = (query if query_pos is None else query + query_pos).permute(1, 0, 2).contiguous()      # (1, Q, C)
             b, q, c = x.shape

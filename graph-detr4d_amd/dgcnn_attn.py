@@ -30,6 +30,10 @@ class DGCNNAttn(nn.Module):
                                    nn.BatchNorm2d(embed_dims), nn.ReLU(inplace=True))
         self.K = kwargs['K']
         self.dropout = nn.Dropout(dropout)
+        # Training this module (batch-statistics BatchNorm, autograd) has no kernels of its own: `torch_ops=True` in the config dict
+        # (or module.torch_ops = True / Fn.torch_ops_for(module) / GD4D_TORCH_OPS=1) chooses its torch-op route - for THIS module
+        # only; everything else keeps its kernels.
+        self.torch_ops = bool(kwargs.get('torch_ops', False))
 
     # ---- HIP path (eval) ------------------------------------------------------------------------------------------
     @staticmethod
@@ -61,7 +65,7 @@ class DGCNNAttn(nn.Module):
         x = x.permute(1, 0, 2)                                                        # (B, N, C)
         Fn.require_gpu(query, 'query')
         if (self.training or Fn.wants_grad(self, query, query_pos)) and Fn.torch_ops_route(
-                'DGCNNAttn with autograd / in train mode (batch-statistics BatchNorm; the kernels are inference-only)', False):
+                'DGCNNAttn with autograd / in train mode (batch-statistics BatchNorm; the kernels are inference-only)', False, module=self):
             f1 = self.conv1(self._edge_feats(x, self.K)).max(dim=-1)[0]               # (B, C, N)
             f2 = self.conv2(self._edge_feats(f1.permute(0, 2, 1), 16)).max(dim=-1)[0]
             return residual + self.dropout((f1 + f2).permute(2, 0, 1))

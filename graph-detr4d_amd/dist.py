@@ -321,9 +321,12 @@ class FlatGradAllReducer:
         if self.views is None or any(p.grad is not v for p, v in zip(self.params, self.views)):
             self._bind(flat)
         if getattr(self, '_adam', None) is None:
-            lib = _lib.load()
-            self._adam = (torch.zeros_like(fp), torch.zeros_like(fp), torch.zeros(2, device=fp.device, dtype=torch.float32),
-                          torch.empty(int(lib.gd4d_adamw_flat_workspace_bytes()), device=fp.device, dtype=torch.uint8))
+            if torch.cuda.is_current_stream_capturing():
+                # zero-fills recorded into a capture would reset m, v and the device step counter on EVERY replay (each step would
+                # silently be Adam's first): the state must exist before the capture starts
+                raise RuntimeError('FlatGradAllReducer.adamw_step: first call inside a hipGraph capture - call adamw_state() (or one '
+                                   'eager step) before capturing')
+            self.adamw_state()
         m, v, state, ws = self._adam
         code = _lib.load().gd4d_adamw_flat(fp.data_ptr(), flat.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(), ws.data_ptr(),
                                            ws.numel(), self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps),
@@ -337,6 +340,31 @@ class FlatGradAllReducer:
                     bump(p)
                 else:
                     p.add_(0)
+
+    @torch.no_grad()
+    def adamw_state(self):
+        """Allocate AdamW's state (exp_avg, exp_avg_sq, {step, norm} on the device, workspace) - idempotent; call it before a capture
+        whose first adamw_step would otherwise be inside it."""
+        if getattr(self, '_adam', None) is None:
+            from . import _lib
+            fp = self.flatten_params()
+            self._adam = (torch.zeros_like(fp), torch.zeros_like(fp), torch.zeros(2, device=fp.device, dtype=torch.float32),
+                          torch.empty(int(_lib.load().gd4d_adamw_flat_workspace_bytes()), device=fp.device, dtype=torch.uint8))
+        return self._adam
+
+    def after_replays(self):
+        """A replayed hipGraph updates the parameters without bumping their version counters (the bump is host work, skipped while
+        capturing): the owner of the graph calls this after replays and before anything that caches by version reads the parameters
+        (weight images of the row chains, the head's position-embedding caches) - versions bumped, image caches forgotten."""
+        from . import ops
+        bump = getattr(torch.autograd.graph, 'increment_version', None)
+        with torch.no_grad():
+            for p in self.params:
+                if bump is not None:
+                    bump(p)
+                else:
+                    p.add_(0)
+        ops.invalidate_chain_images()
 
     def unfuse(self):
         for p in self.params:

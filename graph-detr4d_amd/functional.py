@@ -120,16 +120,34 @@ def sequential_autograd(module, x):
     return module(x)
 
 
-def torch_ops_route(what, supported):
+def torch_ops_route(what, supported, module=None):
     """Whether `what` runs through differentiable torch ops instead of the library's kernels.  There is no silent detour: shapes
-    the kernels cover run on them (unless GD4D_TORCH_OPS=1 selects the torch-op route, which the tests compare against); shapes
-    they do not cover raise, naming the switch."""
-    if os.environ.get('GD4D_TORCH_OPS') == '1':
+    the kernels cover run on them unless the torch-op route was CHOSEN - per module (`module.torch_ops = True`, the constructor
+    keyword `torch_ops=True` where a module has one, or `with Fn.torch_ops_for(module):`) or for the whole process
+    (GD4D_TORCH_OPS=1, which the tests compare against); shapes they do not cover raise, naming the switches."""
+    if os.environ.get('GD4D_TORCH_OPS') == '1' or (module is not None and getattr(module, 'torch_ops', False)):
         return True
     if supported:
         return False
-    raise _lib.Gd4dError(f'{what}: outside the limits of graph-detr4d_amd\'s kernels.  GD4D_TORCH_OPS=1 runs this module through '
-                         'differentiable torch ops instead (slower; an explicit choice, not a fallback).')
+    raise _lib.Gd4dError(f'{what}: outside the limits of graph-detr4d_amd\'s kernels.  `module.torch_ops = True` (or GD4D_TORCH_OPS=1 for '
+                         'every module of the process) runs it through differentiable torch ops instead (slower; an explicit choice, '
+                         'not a fallback).')
+
+
+class torch_ops_for:
+    """`with Fn.torch_ops_for(m1, m2):` - these modules take their torch-op routes inside the block (torch_ops_route)."""
+
+    def __init__(self, *modules):
+        self.modules, self.prev = modules, None
+
+    def __enter__(self):
+        self.prev = [getattr(m, 'torch_ops', False) for m in self.modules]
+        for m in self.modules:
+            m.torch_ops = True
+
+    def __exit__(self, *exc):
+        for m, v in zip(self.modules, self.prev):
+            m.torch_ops = v
 
 
 def pad_points(offsets, attn_logits, supported, what):

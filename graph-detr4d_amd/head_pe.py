@@ -167,7 +167,8 @@ class FeaturePositionEmbedding(nn.Module):
         self._mask_cache = None
         self._split_cache = None
         self._pe_cache = None
-        self._pe_read = None
+        self._pe_read = {}          # stream -> event: the last read of the kept embedding on that stream
+        self._pe_written = None     # event: the last (re)computation / in-place update of the kept embedding
 
     # ---- pieces -------------------------------------------------------------------------------------------------
     def padding_masks(self, img_metas, feats):
@@ -317,11 +318,19 @@ class FeaturePositionEmbedding(nn.Module):
             changed = [i for i in range(r) if not np.array_equal(mats[i], c[1][i])]
         else:
             c, changed = None, list(range(r))
+        cur = torch.cuda.current_stream(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if c is not None and self._pe_written is not None and not capturing:
+            # whatever stream wrote the kept tensor last (a recomputation, an in-place update of some cameras): this call's kernels
+            # come after it - also a call that finds every matrix unchanged and only READS the tensor (the host-side key says
+            # "unchanged" from the moment the update was ENQUEUED)
+            cur.wait_event(self._pe_written)
         if changed:
             i2l = torch.from_numpy(mats[changed]).view(-1, 4, 4).to(dev)
-            if c is not None and self._pe_read is not None:
-                # the kept tensor is updated in place: after whatever still reads it (a previous call on another stream)
-                torch.cuda.current_stream(dev).wait_event(self._pe_read)
+            if c is not None and not capturing:
+                # the kept tensor is updated in place: after EVERY outstanding read of it (earlier calls, on whichever streams)
+                for ev in self._pe_read.values():
+                    cur.wait_event(ev)
             if c is None:
                 pe = self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw)
             elif changed[-1] - changed[0] + 1 == len(changed):
@@ -331,7 +340,15 @@ class FeaturePositionEmbedding(nn.Module):
             else:
                 pe = c[2]
                 pe.index_copy_(0, torch.as_tensor(changed, device=dev), self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw))
-            self._pe_cache = (pkey, mats, pe) if self.cache_position_embedding else None
+            if self.cache_position_embedding:
+                if c is None:
+                    self._pe_read = {}                           # (a new tensor: the old one's readers hold it through record_stream)
+                self._pe_cache = (pkey, mats, pe)
+                if not capturing:
+                    self._pe_written = torch.cuda.Event()
+                    self._pe_written.record(cur)
+            else:
+                self._pe_cache = None
         else:
             pe = c[2]
         cr, ce = self.fpe.conv_reduce, self.fpe.conv_expand
@@ -353,9 +370,15 @@ class FeaturePositionEmbedding(nn.Module):
         return out
 
     def _mark_pe_read(self, dev):
-        if self.cache_position_embedding and not torch.cuda.is_current_stream_capturing():
-            self._pe_read = torch.cuda.Event()
-            self._pe_read.record(torch.cuda.current_stream(dev))
+        """This call's kernels have read the kept embedding on the current stream: an in-place update waits for them (per stream:
+        several callers may read it concurrently), and the allocator does not hand its memory out again before they are done
+        (a key change drops the tensor while another stream may still be reading it)."""
+        if self.cache_position_embedding and self._pe_cache is not None and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream(dev)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._pe_read[cur.cuda_stream] = ev
+            self._pe_cache[2].record_stream(cur)
 
     # ---- training ---------------------------------------------------------------------------------------------------
     def _forward_autograd(self, feats, img_metas):
@@ -369,7 +392,7 @@ class FeaturePositionEmbedding(nn.Module):
             b, n = feats[0].shape[:2]
             l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
             img2lidar = torch.from_numpy(np.linalg.inv(l2i)).float().view(b * n, 4, 4).to(feats[0].device)   # :459-465
-        if not Fn.torch_ops_route(self._route_name(feats), self._gemm_ok(feats)):
+        if not Fn.torch_ops_route(self._route_name(feats), self._gemm_ok(feats), module=self):
             return self._forward_hip_train(feats, masks, pad_hw, img2lidar)
         with torch.no_grad():
             xs = [ops.frustum_pe_input_fwd(img2lidar, tuple(f.shape[-2:]), pad_hw, self.depth_num, self.depth_start,
@@ -416,6 +439,13 @@ class FeaturePositionEmbedding(nn.Module):
         return [o.view(f.shape) for o, f in zip(out, feats)]
 
     # ---- the stage ------------------------------------------------------------------------------------------------
+    def train(self, mode=True):
+        """A change of mode drops what inference keeps (the per-camera embedding, the weight splits / MLP images): training updates
+        the weights - inside a replayed hipGraph without bumping the version counters the caches are keyed by."""
+        if mode != self.training:
+            self._pe_cache, self._pe_read, self._pe_written, self._split_cache = None, {}, None, None
+        return super().train(mode)
+
     def forward(self, mlvl_feats, img_metas):
         """mlvl_feats: list of (B, N, C, H_l, W_l) fp32 GPU tensors; returns the list with the position embedding
         added (:546-557).  With autograd on: _forward_autograd.  GD4D_TORCH_OPS=1 runs the 1x1 convolutions as torch ops (MIOpen)
@@ -429,7 +459,7 @@ class FeaturePositionEmbedding(nn.Module):
             return self._forward_autograd(feats, img_metas)
         with torch.no_grad():
             masks, pad_hw = self.padding_masks(img_metas, feats)
-            if not Fn.torch_ops_route(self._route_name(feats), self._gemm_ok(feats)):
+            if not Fn.torch_ops_route(self._route_name(feats), self._gemm_ok(feats), module=self):
                 return self._forward_gemm(feats, img_metas, masks, pad_hw, self._sine_branch(masks, chlast=True))
             sine = self._sine_branch(masks)
             coords_pe, _ = self.frustum_embedding(img_metas, masks, feats, pad_hw)

@@ -2153,6 +2153,10 @@ def check_handoff(device=None):
             st['word'].zero_()
             for buf in _HANDOFF_FLAGS.values():          # a late SIGNAL may have raised a flag its WAIT no longer took down
                 buf.zero_()
+            # ... and the device builds its steps WITHOUT hand-offs from here on (handoff_enabled): the probe that allowed them covers
+            # one launch shape on one stream at start-up - not a CU-masked stream, a later partition-mode change or the chain's own
+            # resource footprint - and a time-out is the evidence that it did not hold.  (Graphs captured earlier keep theirs.)
+            st['placement'] = False
             raise _lib.Gd4dError(f'{n} SIGNAL / WAIT hand-off(s) between chain programs timed out: the affected rows are NaN. '
                                  'GD4D_POS_ENCODER=dual / GD4D_TRAIN_REG_BESIDE=0 run the same step without hand-offs.')
 
@@ -2196,6 +2200,8 @@ def handoff_placement_ok(device):
             out = torch.full((blocks,), -1, device=st['dev'], dtype=torch.int32)
             _lib.check(lib.gd4d_xcd_placement_probe(_dev(out, 'out', torch.int32), blocks, _stream()), 'gd4d_xcd_placement_probe')
             ids = out.cpu()
+        # (the probe's own shape: 2048 workgroups of one wave on the current stream; a time-out later on turns the hand-offs off
+        #  for the device, check_handoff)
         st['placement'] = bool((ids >= 0).all() and (ids == ids[:8].repeat(blocks // 8)).all())
         if not st['placement']:
             import warnings

@@ -131,7 +131,7 @@ class MultiheadAttention(nn.Module):
         drop = float(self.attn_drop) if self.training else 0.
         if not Fn.torch_ops_route(f'MultiheadAttention training with head dim {d}, mask dim {None if attn_mask is None else attn_mask.dim()}',
                                   d == 32 and q_in.dtype == torch.float32 and (attn_mask is None or attn_mask.dim() == 2)
-                                  and b * h * lq * lk < 2 ** 32):
+                                  and b * h * lq * lk < 2 ** 32, module=self):
             # the attention core with autograd on the HIP kernels; in train mode they drop probabilities as F.dropout does
             # inside nn.MultiheadAttention (same distribution, a different generator: gd4d_mha_dropout.h)
             from .autograd import MhaCoreFunction, MhaCorePackedFunction

@@ -317,3 +317,49 @@ def test_flat_adamw_with_clipping_equals_torch():
         torch.testing.assert_close(red.last_grad_norm, want_norm, rtol=1e-5, atol=0)
         for p, r in zip(net.parameters(), ref.parameters()):
             torch.testing.assert_close(p, r, rtol=1e-5, atol=2e-7)
+
+
+def test_flat_adamw_inside_a_replayed_graph_keeps_its_state():
+    """adamw_step allocates its state lazily: inside a capture the zero-fills would be recorded and EVERY replay would reset m, v and
+    the step counter (each step Adam's first).  A first call inside a capture raises; with adamw_state() before the capture, N
+    replays equal N eager steps; after_replays() bumps the parameter versions the weight-image caches are keyed by."""
+    import copy
+    from graph_detr4d_amd import dist as D
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ReLU(), torch.nn.Linear(96, 32)).cuda()
+    ref = copy.deepcopy(net)
+    x = torch.randn(16, 64, device='cuda')
+    red, red_ref = D.FlatGradAllReducer(list(net.parameters()), align=4), D.FlatGradAllReducer(list(ref.parameters()), align=4)
+    red.bind()
+    red_ref.bind()
+
+    def step(model, r):
+        r.zero_grad()
+        model(x).square().sum().backward()
+        r.adamw_step(lr=1e-2, weight_decay=0.01, max_norm=35.0)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        net(x).square().sum().backward()                          # warm-up of autograd on the capture stream (no optimizer step)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g_bad = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match='adamw_state'):
+        with torch.cuda.graph(g_bad, capture_error_mode='thread_local'):
+            step(net, red)
+    torch.cuda.synchronize()
+    red.adamw_state()
+    versions = [p._version for p in net.parameters()]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        step(net, red)
+    for _ in range(4):
+        graph.replay()
+    for _ in range(4):
+        step(ref, red_ref)
+    torch.cuda.synchronize()
+    for p, r in zip(net.parameters(), ref.parameters()):
+        torch.testing.assert_close(p, r, rtol=1e-5, atol=1e-7)
+    assert int(red._adam[2][0].item()) == 4                        # the device step counter advanced with every replay
+    red.after_replays()
+    assert all(p._version > v for p, v in zip(net.parameters(), versions))

@@ -405,3 +405,47 @@ def test_fused_two_layer_mlp_matches_fp64(m, k1, h):
     if hid is not None:                                  # ... and as close to fp64 as the two-GEMM route is
         two = ops.gemm_bf16x3_fwd(hid, *ops.split_bf16_fwd(w2.cuda()), b2.cuda())
         assert (got.cpu() - want).abs().max() <= 2 * (two.cpu() - want).abs().max() + 1e-6
+
+
+def test_kept_embedding_across_streams_static_rig_and_updates():
+    """The kept per-camera embedding is safe across streams: a call on another stream that finds every matrix unchanged (static rig)
+    only READS the tensor - it must come after the stream that wrote it; an in-place update must come after every stream still
+    reading it; a key change drops the tensor while readers may be queued.  Stress: two streams alternate calls (same rig, moved
+    rig, weight update) with a long kernel queued in front of the writer each time; every result equals a fresh module's."""
+    import copy
+    g = Golden('head_pe')
+    mod = _module(g)
+    feats = [f.cuda() for f in g.feats()]
+    metas = _metas(g)
+    moved = copy.deepcopy(metas)
+    m = np.array(moved[0]['lidar2img'][1], dtype=np.float64)
+    m[:3, 3] += np.array([0.9, -0.5, 0.3])
+    moved[0]['lidar2img'][1] = m
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device='cuda')
+
+    def busy(stream):                                             # ~ms of work queued on `stream` before the next call on it
+        with torch.cuda.stream(stream):
+            for _ in range(6):
+                big @ big
+    with torch.no_grad():
+        want_static = [t.clone() for t in _module(g)(feats, metas)]
+        want_moved = [t.clone() for t in _module(g)(feats, moved)]
+        torch.cuda.synchronize()
+        for rnd in range(4):
+            busy(s1)
+            with torch.cuda.stream(s1):
+                a = mod(feats, metas if rnd % 2 == 0 else moved)     # writer: (re)computes or updates in place, behind the busy work
+            with torch.cuda.stream(s2):
+                b = mod(feats, metas if rnd % 2 == 0 else moved)     # reader on another stream: finds "unchanged" at once
+            busy(s2)
+            with torch.cuda.stream(s2):
+                c = mod(feats, metas if rnd % 2 == 0 else moved)
+            torch.cuda.synchronize()
+            want = want_static if rnd % 2 == 0 else want_moved
+            for got in (a, b, c):
+                for x, y in zip(got, want):
+                    assert torch.equal(x, y), rnd
+        mod.train()
+        assert mod._pe_cache is None and mod._split_cache is None    # a mode change drops the inference caches
+        mod.eval()

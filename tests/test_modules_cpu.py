@@ -180,3 +180,15 @@ def test_torch_op_routes_are_explicit(monkeypatch):
         Fn.torch_ops_route('a module with embed_dims = 512', False)
     monkeypatch.setenv('GD4D_TORCH_OPS', '1')
     assert Fn.torch_ops_route('a module', True) is True and Fn.torch_ops_route('a module', False) is True
+    # ... and PER MODULE: the choice of one module does not re-route the others
+    monkeypatch.delenv('GD4D_TORCH_OPS', raising=False)
+
+    class M:
+        pass
+    a, b = M(), M()
+    a.torch_ops = True
+    assert Fn.torch_ops_route('a', False, module=a) is True and Fn.torch_ops_route('b', True, module=b) is False
+    with Fn.torch_ops_for(b):
+        assert Fn.torch_ops_route('b', False, module=b) is True
+    with pytest.raises(Gd4dError, match='torch_ops'):
+        Fn.torch_ops_route('b', False, module=b)

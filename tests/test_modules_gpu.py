@@ -301,6 +301,10 @@ def test_dgcnn_attn_module(name, monkeypatch):
     # GD4D_TORCH_OPS=1 the reference's op sequence as torch ops (same numbers in eval)
     with pytest.raises(ops._lib.Gd4dError, match='GD4D_TORCH_OPS'):
         mod(q.clone().requires_grad_(True), query_pos=qp)
+    from graph_detr4d_amd import functional as Fn
+    with Fn.torch_ops_for(mod):                                          # the choice of THIS module (no process-wide switch)
+        out1 = mod(q.clone().requires_grad_(True), query_pos=qp)
+    torch.testing.assert_close(out1.detach().cpu(), g.t('out'), **TOL)
     monkeypatch.setenv('GD4D_TORCH_OPS', '1')
     out2 = mod(q.requires_grad_(True), query_pos=qp)
     torch.testing.assert_close(out2.detach().cpu(), g.t('out'), **TOL)

@@ -286,6 +286,11 @@ def test_a_hand_off_that_times_out_is_loud():
     with pytest.raises(_lib.Gd4dError, match='timed out'):
         ops.check_handoff()
     ops.check_handoff()                                          # cleared
+    # a time-out is evidence that the placement the hand-offs rely on did not hold: the device builds its steps without them from
+    # here on (until someone probes again - this test forced the time-out, so it restores the state)
+    assert ops.handoff_enabled(DEV, 'GD4D_POS_ENCODER') is False
+    ops._handoff_state(DEV)['placement'] = None
+    assert ops.handoff_enabled(DEV, 'GD4D_POS_ENCODER') is True
     # the same programs with the flags that ARE raised: finite, no error
     consumer = [ops.chain_wait(flags_a, err), ops.chain_load(1, x), ops.chain_gemm(1, w, b, out=out)]
     flags_a.zero_()
