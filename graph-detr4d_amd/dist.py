@@ -275,6 +275,11 @@ class FlatGradAllReducer:
         (sgd_step) instead of torch.optim.SGD's four multi-tensor launches over 200+ tensors (~110 us of a 5.4-ms training step)."""
         if getattr(self, 'flat_params', None) is not None:
             return self.flat_params
+        if self.params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # re-pointing the parameters at a buffer allocated (and "filled") inside a capture leaves them on memory no kernel has
+            # written - and every graph captured earlier on their old addresses
+            raise RuntimeError('FlatGradAllReducer.flatten_params: first call inside a hipGraph capture - call it (or adamw_state() / one '
+                               'eager optimizer step) before capturing')
         if self.align % 4:
             raise RuntimeError('FlatGradAllReducer.flatten_params needs align=4 (or a multiple): the kernels read weights with 16-byte loads')
         like = self.params[0]
@@ -316,6 +321,9 @@ class FlatGradAllReducer:
         decoder's; the reference scales the backbone's by 0.1 - not part of this buffer).  Needs bind(); calls flatten_params().
         After the step self.last_grad_norm (a device scalar) holds the norm before clipping."""
         from . import _lib
+        if getattr(self, '_adam', None) is None and self.params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('FlatGradAllReducer.adamw_step: first call inside a hipGraph capture (its zero-filled state would be reset by '
+                               'every replay) - call adamw_state() (or one eager step) before capturing')
         fp = self.flatten_params()
         flat = self._buffer(self.params[0])
         if self.views is None or any(p.grad is not v for p, v in zip(self.params, self.views)):
