@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--no-nhwc-figure', action='store_true', help='skip the second figure (channels-last levels gathered in place)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of hipGraph replay')
     ap.add_argument('--no-exact-figure', action='store_true', help='skip the figure with every chain GEMM on six products')
+    ap.add_argument('--no-f2b-figure', action='store_true', help='skip the features -> boxes figure (head position embedding -> decoder -> box epilogue -> decode)')
+    ap.add_argument('--only-f2b', action='store_true', help='dev: run ONLY the features -> boxes figure (what tools/prof_f2b.sh profiles)')
     ap.add_argument('--rotate', type=int, default=3,
                     help='K resident samples (own pyramid, queries and camera rig each) served round-robin by K hipGraphs, every graph '
                          'replaying a sample it was NOT captured on (inputs written into its static buffers in place, lidar2img '
@@ -206,6 +208,10 @@ def main():
 
     if a.mode in ('train', 'distill'):
         train_bench(a, D, tr, regs, feats, query_embed, metas, dev, rank, n_cams, levels, G)
+        return
+    if a.only_f2b:
+        print(json.dumps({'features_to_boxes': features_to_boxes(G, tr, regs, feats, query_embed, rig, a, D, dev, torch.cuda.Stream(dev), a.steps)}))
+        D.shutdown()
         return
 
     # S samples in flight: a decoder layer alternates between an HBM-bound phase (the aggregate launch) and a
@@ -440,6 +446,14 @@ def main():
             except Exception as e:                    # secondary figure: report, never fail the bench line
                 nhwc = {'error': f'{type(e).__name__}: {e}'}
 
+    # ---------------- features -> boxes as one request (secondary figure) ----------------
+    f2b = None
+    if rank == 0 and not a.no_f2b_figure and a.input_layout == 'nchw' and a.value_dtype == 'fp32':
+        try:
+            f2b = features_to_boxes(G, tr, regs, feats, query_embed, rig, a, D, dev, streams[0], a.steps)
+        except Exception as e:                        # secondary figure: report, never fail the bench line
+            f2b = {'error': f'{type(e).__name__}: {e}'}
+
     # ---------------- kernel-level roofline of the fused sample-aggregate kernel ----------------
     roofline, kernels = None, {}
     if rank == 0 and not a.no_roofline:
@@ -473,6 +487,7 @@ def main():
             'channels_last_input': nhwc,
             'rotate': rotate,
             'exact_gemms': exact,
+            'features_to_boxes': f2b,
             'data': 'synthetic',
             'config': {'workload': f'Graph-DETR4D decoder, {a.layers} layers, {a.queries} queries, '
                                    f'{n_cams} cameras (6 x T={a.frames}), 4 FPN levels '
@@ -916,6 +931,87 @@ def _pmc_traffic(a, source, pattern):
         if pm.get('kernel_source_sha256') == src_hash:
             return pm['hbm_read_bytes_per_launch'] + pm['hbm_write_bytes_per_launch'], os.path.relpath(pmc_path, ROOT)
     return None, f'no committed PMC pass matches the current {source} (sha256 {src_hash[:12]})'
+
+
+POST_RANGE = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+
+
+def features_to_boxes(G, tr, regs, feats, query_embed, rig, a, D, dev, stream, steps, windows=5):
+    """Features -> boxes as ONE measured request (SURVEY 8(f1) + 8(a) + 8(f2)): the head's feature position embedding
+    (dense_heads/detr3d_head_pe.py:495-557; channels-last output, which the decoder gathers in place) -> the 6-layer decoder ->
+    the cls / reg epilogue of every layer (:568-612) -> gd4d_nms_free_decode_fwd (core/bbox/coders/nms_free_coder.py:47-118, top 300)
+    as one hipGraph per request.  Before every replay the NEXT sample's camera matrices are written into the persistent device
+    buffers the graph reads (FeaturePositionEmbedding.refresh_matrices, functional.lidar2img_device) - 1.5 KB, host work of a
+    request, inside the timed steps.  Two patterns: `temporal` - the shipped T = 4 pattern: the current frame's 6 cameras keep their
+    calibration (their embedding is kept), the 18 past-frame cameras carry the ego motion and are recomputed every sample;
+    `every_camera` - nothing kept."""
+    import copy
+    import numpy as np
+    from graph_detr4d_amd import functional as Fn
+    from graph_detr4d_amd import ops, synthetic
+    nl = len(tr.decoder.layers)
+    nn = torch.nn
+    cls_b = nn.ModuleList(nn.Sequential(nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU(inplace=True), nn.Linear(256, 256),
+                                        nn.LayerNorm(256), nn.ReLU(inplace=True), nn.Linear(256, 10)) for _ in range(nl))
+    synthetic.randomise_all_(cls_b, seed=21, std=0.04)
+    cls_b = cls_b.to(dev).eval()
+    n = feats[0].shape[1]
+    metas = []
+    for k in range(4):                                   # the past frames' cameras (all but the first 6) move with every sample
+        rk = rig.copy()
+        rk[6:, :3, 3] += (np.random.RandomState(50 + k).randn(max(n - 6, 0), 3) * np.array([20.0, 20.0, 0.02])).astype(np.float32)
+        metas.append(synthetic.make_img_metas(rk, batch=1))
+    res = {}
+    with torch.no_grad():
+        for name, keep in (('temporal', True), ('every_camera', False)):
+            pe = G.FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE, channels_last_out=True)
+            synthetic.randomise_all_(pe, seed=11, std=0.04)
+            pe = pe.to(dev).eval()
+            pe.cache_position_embedding = keep
+
+            def request(mt):
+                gf = pe(feats, mt)
+                states, init, refs = tr(gf, query_embed, reg_branches=regs, img_metas=mt)
+                outs = Fn.head_outputs(states, init, refs, cls_b, regs, synthetic.PC_RANGE)
+                return ops.nms_free_decode_fwd(outs['all_cls_scores'][-1].contiguous().float(), outs['all_bbox_preds'][-1].contiguous().float(),
+                                               POST_RANGE, 300)
+
+            def refresh(mt):
+                pe.refresh_matrices(mt, dev)
+                Fn.lidar2img_device(mt, query_embed)
+            with torch.cuda.stream(stream), Fn.request_slot(7000 + (0 if keep else 1)):
+                request(metas[0])                                        # eager: allocations, caches, the kept embedding of sample 0
+                want = [t.clone() for t in request(metas[1])]            # (eager result of the sample the graph is captured on)
+                torch.cuda.synchronize()
+                request(metas[0])
+                refresh(metas[1])
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
+                    out = request(metas[1])
+                graph.replay()
+                torch.cuda.synchronize()
+                same = all(torch.equal(x, y) for x, y in zip(out, want))
+                turn = [0]
+
+                def step():
+                    turn[0] += 1
+                    with torch.cuda.stream(stream), Fn.request_slot(7000 + (0 if keep else 1)):
+                        refresh(metas[turn[0] % 4])
+                        graph.replay()
+                els = sorted(D.timed_steps(step, steps, 3 if i == 0 else 0, dev, {}) for i in range(windows))
+                ops.check_handoff()
+                kept_boxes = int(out[3].sum().item())
+            ms = els[len(els) // 2] / steps * 1e3
+            res[name] = {'ms_per_sample': ms, 'samples_per_s': 1e3 / ms, 'ms_min': els[0] / steps * 1e3, 'ms_max': els[-1] / steps * 1e3,
+                         'graph_equals_eager': bool(same), 'boxes_kept_of_300': kept_boxes}
+            del graph, pe, out, want
+            torch.cuda.empty_cache()
+    res['note'] = ('head position embedding (channels-last out) -> decoder gathering in place -> cls / reg epilogue of every layer -> '
+                   'gd4d_nms_free_decode_fwd (top 300), one hipGraph per request; the next sample\'s camera matrices are refreshed (host, '
+                   '1.5 KB) before every replay, inside the timed steps; temporal = the 6 current-frame cameras keep their embedding, the 18 '
+                   'past-frame cameras are recomputed; every_camera = nothing kept')
+    return res
 
 
 def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic):

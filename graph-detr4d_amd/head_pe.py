@@ -169,6 +169,7 @@ class FeaturePositionEmbedding(nn.Module):
         self._pe_cache = None
         self._pe_read = {}          # stream -> event: the last read of the kept embedding on that stream
         self._pe_written = None     # event: the last (re)computation / in-place update of the kept embedding
+        self._i2l = {}              # (device, request slot, R) -> [host matrices, (R, 4, 4) device tensor]: _matrices_device
 
     # ---- pieces -------------------------------------------------------------------------------------------------
     def padding_masks(self, img_metas, feats):
@@ -305,8 +306,7 @@ class FeaturePositionEmbedding(nn.Module):
         shapes = [tuple(f.shape[-2:]) for f in feats]
         s_tot = sum(h * w for h, w in shapes)
         starts = [sum(h * w for h, w in shapes[:i]) for i in range(len(shapes))]
-        l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
-        mats = np.ascontiguousarray(np.linalg.inv(l2i).astype(np.float32).reshape(r, 16))        # :459-465
+        mats = self._img2lidar(img_metas)                                                         # :459-465
         sw = self._split_weights()
         # The embedding of a camera is a function of its matrix, the level shapes and the MLP's weights - not of the features.  It is
         # kept per camera and recomputed for the cameras whose matrix changed: the current frame's cameras keep their calibration
@@ -325,15 +325,23 @@ class FeaturePositionEmbedding(nn.Module):
             # come after it - also a call that finds every matrix unchanged and only READS the tensor (the host-side key says
             # "unchanged" from the moment the update was ENQUEUED)
             cur.wait_event(self._pe_written)
+        i2l_all = self._matrices_device(mats, dev, capturing)
         if changed:
-            i2l = torch.from_numpy(mats[changed]).view(-1, 4, 4).to(dev)
+            run = changed[-1] - changed[0] + 1 == len(changed)
+            if run:
+                i2l = i2l_all[changed[0]:changed[-1] + 1]                # a view of the persistent buffer: a replayed graph reads what
+            elif capturing:                                               # refresh_matrices() put there
+                raise RuntimeError('FeaturePositionEmbedding under hipGraph capture: the cameras whose matrix changed must form one run '
+                                   '(the past frames behind the current one) - or cache_position_embedding = False')
+            else:
+                i2l = i2l_all[torch.as_tensor(changed, device=dev)]
             if c is not None and not capturing:
                 # the kept tensor is updated in place: after EVERY outstanding read of it (earlier calls, on whichever streams)
                 for ev in self._pe_read.values():
                     cur.wait_event(ev)
             if c is None:
                 pe = self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw)
-            elif changed[-1] - changed[0] + 1 == len(changed):
+            elif run:
                 # a run of cameras (the past frames follow the current one): the MLP writes their rows of the kept tensor
                 pe = c[2]
                 self._position_mlp(i2l, shapes, starts, s_tot, pad_hw, sw, out=pe[changed[0]:changed[-1] + 1])
@@ -368,6 +376,39 @@ class FeaturePositionEmbedding(nn.Module):
             out.append(o.unflatten(0, (b, n)) if self.channels_last_out else o.view(f.shape))
         self._mark_pe_read(dev)
         return out
+
+    def _matrices_device(self, mats, dev, capturing=False):
+        """The (R, 4, 4) img2lidar matrices on the device: ONE persistent buffer per (device, request slot, R), refreshed in place when
+        the host values differ - so that a hipGraph captured over this module keeps a valid address and a replay for a new sample
+        only needs refresh_matrices() outside the graph (the pattern of functional.lidar2img_device).  Under capture the buffer
+        must already hold these matrices (call the module, or refresh_matrices, eagerly first)."""
+        key = (str(dev), Fn.slot_key(dev), mats.shape[0])
+        ent = self._i2l.get(key)
+        if ent is None or not np.array_equal(ent[0], mats):
+            if capturing:
+                if ent is None:
+                    raise RuntimeError('FeaturePositionEmbedding under hipGraph capture: call the module (or refresh_matrices) once eagerly '
+                                       'with these img_metas first - their matrices are not on the device yet')
+                raise RuntimeError('FeaturePositionEmbedding under hipGraph capture: img_metas changed since the last eager call; '
+                                   'refresh_matrices(img_metas) first')
+            src = torch.from_numpy(mats).view(-1, 4, 4)
+            if ent is None:
+                ent = self._i2l[key] = [mats.copy(), src.to(dev)]
+            else:
+                ent[1].copy_(src)
+                ent[0] = mats.copy()
+        return ent[1]
+
+    @staticmethod
+    def _img2lidar(img_metas):
+        l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
+        return np.ascontiguousarray(np.linalg.inv(l2i).astype(np.float32).reshape(-1, 16))       # :459-465
+
+    def refresh_matrices(self, img_metas, device):
+        """For the owner of a hipGraph captured over this module: put the new sample's img2lidar matrices into the persistent device
+        buffer the graph reads (outside the graph, before the replay).  The graph recomputes the cameras it recomputed when it was
+        captured (e.g. the past frames' 18 of 24) from them; the cameras it kept must not have moved."""
+        return self._matrices_device(self._img2lidar(img_metas), torch.device(device))
 
     def _mark_pe_read(self, dev):
         """This call's kernels have read the kept embedding on the current stream: an in-place update waits for them (per stream:

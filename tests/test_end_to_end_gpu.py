@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 POST_RANGE = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
 
 
-@pytest.mark.parametrize('case', ['small', 'mid', 'small-channels-last'])
+@pytest.mark.parametrize('case', ['small', 'mid', 'small-channels-last', 'full-channels-last'])
 def test_features_to_boxes_matches_oracle_pipeline(case):
     """small-channels-last: the position-embedding stage hands the decoder channels-last levels (FeaturePositionEmbedding(
     channels_last_out=True): SE gate + fuse as one kernel, the levels gathered in place - no slice-planar copy in the decoder).
@@ -27,9 +27,17 @@ def test_features_to_boxes_matches_oracle_pipeline(case):
     torch.manual_seed(7)
     channels_last = case.endswith('channels-last')
     case = case.split('-')[0]
+    top = 100
     if case == 'small':
         n, q, nl, frames = 6, 60, 2, 1
         img_hw, levels = (128, 224), [(16, 28), (8, 14), (4, 7), (2, 4)]
+    elif case == 'full':
+        # the bench's size: 900 queries x 24 cameras (6 x T = 4) on the 900 x 1600 rig, the R50 pyramid 116x200 .. 15x25, top 300 -
+        # two decoder layers (chained layers on i.i.d. synthetic features amplify a rounding difference ~3 x per layer:
+        # tests/test_full_size_gpu.py checks all six with teacher forcing)
+        n, q, nl, frames = 24, 900, 2, 4
+        img_hw, levels, top = (900, 1600), list(synthetic.R50_LEVELS), 300
+        torch.set_num_threads(16)
     else:
         n, q, nl, frames = 12, 300, 3, 2
         img_hw, levels = (256, 448), [(32, 56), (16, 28), (8, 14), (4, 7)]
@@ -78,13 +86,13 @@ def test_features_to_boxes_matches_oracle_pipeline(case):
         exp_cls = torch.stack([cls_b[i](hs[i]) for i in range(nl)])
         exp_box = torch.stack([O.box_head(reg_b[i](hs[i]), init_ref if i == 0 else refs[i - 1], synthetic.PC_RANGE)
                                for i in range(nl)])
-        exp = O.nms_free_decode({'all_cls_scores': exp_cls, 'all_bbox_preds': exp_box}, POST_RANGE, 100, 10)[0]
+        exp = O.nms_free_decode({'all_cls_scores': exp_cls, 'all_bbox_preds': exp_box}, POST_RANGE, top, 10)[0]
 
     # ---- HIP pipeline ----
     for mod in (pe, tr, cls_b, reg_b):
         mod.cuda()
     coder = G.build_bbox_coder(dict(type='NMSFreeCoder', pc_range=synthetic.PC_RANGE, post_center_range=POST_RANGE,
-                                    max_num=100, num_classes=10))
+                                    max_num=top, num_classes=10))
     with torch.no_grad():
         gfeats = pe([f.cuda() for f in feats], metas)
         from graph_detr4d_amd import ops
@@ -121,5 +129,9 @@ def test_features_to_boxes_matches_oracle_pipeline(case):
     same = (gl[:, None] == exp['labels'][None]) & ((gs[:, None] - es[None]).abs() < 2e-3) & \
         ((gb[:, None] - exp['bboxes'][None]).abs().amax(-1) < 5e-3)
     need = 0.97 if case == 'small' else 0.93
+    if case == 'full':
+        print(f'full size: decoder rows off by > 1e-3 in layer 0: {(row_err[0] > 1e-3).sum().item()} of {q}; median row error '
+              f'{row_err.median().item():.2e}; top-{top} detections with a partner: {same.any(1).float().mean().item():.3f} / '
+              f'{same.any(0).float().mean().item():.3f}')
     assert same.any(1).float().mean().item() >= need
     assert same.any(0).float().mean().item() >= need
