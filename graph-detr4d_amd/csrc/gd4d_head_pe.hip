@@ -71,7 +71,7 @@ __device__ __forceinline__ float inv_sigmoid_fast(float x) {
   return (__builtin_amdgcn_logf(a) - __builtin_amdgcn_logf(b)) * 0.69314718055994530942f;
 }
 
-constexpr int FR_PIX = 16;      // pixels per wave (one pixel per wave: 740 000 waves of ~150 instructions - bound by the rate waves are launched at)
+constexpr int FR_PIX = 1;       // pixels per wave (16 per wave measured 65 against 58 us per launch: the kernel is not bound by the rate waves are launched at)
 
 __global__ __launch_bounds__(256) void frustum_pe_chlast_kernel(const FrustumParams p) {
   __shared__ __attribute__((aligned(16))) float s_row[4][3 * 64 + 4];
