@@ -361,6 +361,35 @@ def run_branch(branch, x):
     return x
 
 
+def _branch_program(branch, x_rows, out_rows, exact=False, width=512):
+    """An nn.Sequential of Linear / LayerNorm / ReLU (what the heads build) as a row-chain program over x_rows (M, C) -> out_rows
+    (M, N_last), or None if the branch has another shape.  LDS buffers 0 .. 2; exact: six bf16 products per GEMM."""
+    nn = torch.nn
+    mods = list(branch) if isinstance(branch, nn.Sequential) else None
+    if not mods or not isinstance(mods[0], nn.Linear) or not isinstance(mods[-1], nn.Linear):
+        return None
+    prog, src, i = [ops.chain_load(0, x_rows)], 0, 0
+    while i < len(mods):
+        m = mods[i]
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        last = i + (2 if relu else 1) >= len(mods)
+        dst = (src + 1) % 3
+        if isinstance(m, nn.Linear):
+            if m.in_features % 64 or m.in_features > width or (not last and (m.out_features % 64 or m.out_features > width)):
+                return None
+            prog.append(ops.chain_gemm(src, m.weight, m.bias, dst=-1 if last else dst, relu=relu, exact=exact,
+                                       out=out_rows if last else None))
+        elif isinstance(m, nn.LayerNorm) and not last:
+            if len(m.normalized_shape) != 1 or m.normalized_shape[0] % 64 or m.weight is None:
+                return None
+            prog.append(ops.chain_layernorm(src, m, dst=dst, relu=relu))
+        else:
+            return None
+        src = dst
+        i += 2 if relu else 1
+    return prog
+
+
 def head_outputs(hs, init_reference, inter_references, cls_branches, reg_branches, pc_range, depth_factor=None):
     """The per-layer epilogue of Detr3DHeadPE.forward (dense_heads/detr3d_head_pe.py:568-612).
 
@@ -384,9 +413,26 @@ def head_outputs(hs, init_reference, inter_references, cls_branches, reg_branche
         boxes = BoxHeadFunction.apply(torch.stack(tmps), refs, pc_range, 1.0 if depth_factor is None else float(depth_factor))
         return {'all_cls_scores': torch.stack(classes), 'all_bbox_preds': boxes,
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
+    chains = hs.is_cuda and hs.dtype == torch.float32 and os.environ.get('GD4D_HEAD_CHAINS', '1') != '0'
     for lvl in range(hs.shape[0]):
         reference = init_reference if lvl == 0 else inter_references[lvl - 1]
         x = hs[lvl].contiguous()
+        if chains:
+            # both branches of a layer as the two programs of ONE row-chain launch (the reg branch on six products, as the decoder
+            # computes it for the refinement): 6 launches instead of 6 x (6 Linear + 2 LayerNorm)
+            rows = x.view(-1, x.shape[-1])
+            last_c, last_r = cls_branches[lvl][-1], reg_branches[lvl][-1]
+            if isinstance(last_c, torch.nn.Linear) and isinstance(last_r, torch.nn.Linear):
+                cls = torch.empty(*x.shape[:-1], last_c.out_features, device=x.device, dtype=torch.float32)
+                tmp = torch.empty(*x.shape[:-1], last_r.out_features, device=x.device, dtype=torch.float32)
+                pc = _branch_program(cls_branches[lvl], rows, cls.view(rows.shape[0], -1))
+                pr = _branch_program(reg_branches[lvl], rows, tmp.view(rows.shape[0], -1), exact=True)
+                if pc is not None and pr is not None:
+                    ops.row_chain2_fwd(pc, pr, rows.shape[0])
+                    classes.append(cls)
+                    coords.append(ops.box_head_fwd(tmp, reference.contiguous(), pc_range,
+                                                   1.0 if depth_factor is None else float(depth_factor), out=tmp))
+                    continue
         classes.append(run_branch(cls_branches[lvl], x))
         tmp = run_branch(reg_branches[lvl], x).contiguous()
         coords.append(ops.box_head_fwd(tmp, reference.contiguous(), pc_range,
