@@ -465,6 +465,9 @@ __device__ __forceinline__ void rc_headgemm(const ChainOp& op, float (*bufs)[RC_
         for (int r = 0; r < 4; ++r)
           addend[c][r] = op.gout[(size_t)min(m0 + 4 * g + r, M - 1) * op.ldg + min(n_base + 16 * c + i16, N - 1)];
     }
+    // (Round 6, measured and not kept: ALL k-steps' aggregate rows requested at once - 64 registers - instead of this two-deep
+    //  ring: chain B' 55.7 against 55.7 us.  HEADGEMM's 18 us in block 0's timeline are the launch (~5 us until a first operation
+    //  completes in any chain) and the program's weight touches, which its first loads queue behind: not its own ring.)
     rc_u4 bh[HD][RC_TILES], bl[HD][RC_TILES];
     float4 av[HD][NG][2];
     auto issue = [&](int slot, int j) {
@@ -990,7 +993,7 @@ __device__ __forceinline__ void row_chain_body(const rc_prog_ptr_t pp, const int
       __syncthreads();
     }
 #if RC_TRACE_OPS
-    trace_mark_if(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32), wg == 0 && !second);
+    trace_mark_if(g_trace_rowchain, 0x40ull | ((unsigned long long)op.kind << 8) | ((unsigned long long)op.N << 16) | ((unsigned long long)op.K << 32) | (second ? 1ull << 63 : 0ull), wg == 0);
 #endif
   }
   trace_mark_if(g_trace_rowchain, (second ? 0x87ull : 0x81ull) | ((unsigned long long)nops << 8), wg == 0);

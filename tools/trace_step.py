@@ -59,9 +59,11 @@ def main():
     prev = t0
     for ident, t in ent:
         if ident & 0x40 and not ident & 0x80:          # RC_TRACE_OPS build: end of one chain operation (block 0)
+            second = bool(ident >> 63)
+            ident &= (1 << 63) - 1
             opk, n_, k_ = (ident >> 8) & 0xff, (ident >> 16) & 0xffff, ident >> 32
             opn = {1: 'LOAD', 2: 'GEMM', 3: 'LAYERNORM', 4: 'ADD', 5: 'REFINE', 6: 'SMALL_LINEAR', 7: 'HEADGEMM'}.get(opk, str(opk))
-            print(f'{(t - t0) / 100:9.1f} us  (+{(t - prev) / 100:7.1f})      op {opn} N={n_} K={k_}')
+            print(f'{(t - t0) / 100:9.1f} us  (+{(t - prev) / 100:7.1f})      {"[second program] " if second else ""}op {opn} N={n_} K={k_}')
             prev = t
             continue
         kind, end, nops = ident & 0x3f, bool(ident & 0x80), ident >> 8
