@@ -1159,10 +1159,15 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
             side = side_bytes(q, n, nl, p)
             alg8d = min(v * 4 * (256 // hh) * es, pyramid_bytes) + side
             uniq = _unique_pixels(mask, uv, c['shapes']) * 256 * es
+            # bytes through the L1s: a raw corner is all 256 channels (8 slices x 128 B); with the coarse levels projected first a
+            # corner of levels 2-3 is the head's own 32 fp32 channels
+            gathered = v * 4 * 256 * es
+            if sliced and c['vp'].get('coarse'):
+                gathered = (v // nl) * 2 * 4 * 256 * es + (v // nl) * 2 * 4 * (256 // hh) * 4
             per_layer.append(dict(visible_tuples=v, visible_frac=v / (mask.numel() * nl), alg_bytes=alg8d,
-                                  gathered_bytes=v * 4 * 256 * es, unique_bytes=uniq))
+                                  gathered_bytes=gathered, unique_bytes=uniq))
             tot8d += alg8d
-            tot_c += v * 4 * 256 * es
+            tot_c += gathered
             tot_u += uniq
         ms = _time_rounds(calls, rounds)
         launches = len(calls)
@@ -1193,9 +1198,14 @@ def fused_kernel_roofline(tr, regs, feats, query_embed, metas, a, ops, synthetic
                         frac_on_gathered_bytes=tot_c / ms / 1e6 / HBM_PEAK_GBS,
                         unique_bytes_per_launch=tot_u / launches, frac_on_unique_bytes=tot_u / ms / 1e6 / HBM_PEAK_GBS,
                         frac_on_counter_bytes=None if traffic is None else traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                        note='this kernel gathers C = 8 Dh channels per corner (8 x the 8(d) bytes) so that value_proj over the '
-                             'pyramid (97 GFLOP + 757 MB written per layer) leaves the step; frac prices its time against the '
-                             '8(d) bytes all the same')
+                        note=('levels 0-1: this kernel gathers C = 8 Dh channels per corner (8 x the 8(d) bytes) so that value_proj over the '
+                              'pyramid (97 GFLOP + 757 MB written per layer) leaves the step; levels 2-3 (6 % of the pixels): rows value_proj was '
+                              'applied to by guest workgroups of the previous row-chain launch (43 800 rows, 5.7 GFLOP per layer), 8(d)\'s own '
+                              'bytes; frac prices the launch against the 8(d) bytes of all four levels'
+                              if sliced and late_cap[0]['vp'].get('coarse') else
+                              'this kernel gathers C = 8 Dh channels per corner (8 x the 8(d) bytes) so that value_proj over the '
+                              'pyramid (97 GFLOP + 757 MB written per layer) leaves the step; frac prices its time against the '
+                              '8(d) bytes all the same'))
         kernels['cross_attn_agg_per_layer'] = per_layer
         with torch.no_grad():
             # the two small kernels around it: the per-sample copy of the pyramid and value_proj of the aggregates

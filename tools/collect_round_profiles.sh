@@ -16,7 +16,7 @@ cp $g/pmc_fwd/pmc_summary.txt profiles/${pre}_pmc_cross_attn.txt
 cp $g/pmc_step/pmc_summary.txt profiles/${pre}_pmc_step_inflight1.txt
 cp $g/pmc_rawbwd/pmc_summary.txt profiles/${pre}_pmc_train_raw_backward.txt
 python3 tools/make_pmc_record.py $g/pmc_sliced/pmc_summary.txt profiles/${pre}_pmc_cross_attn_sliced.json \
-  "tools/bench_sliced.py: 900 x 24 x 4 levels, fp32 slice-planar pyramid; one launch = the gather of one decoder layer (items form of the plan)" cross_attn_agg_items_kernel gd4d_cross_attn_sliced.hip
+  "tools/bench_sliced.py --coarse: 900 x 24 x 4 levels, fp32 slice-planar pyramid, levels 2-3 from projected rows; one launch = the gather of one decoder layer (items form of the plan)" cross_attn_agg_items_coarse_kernel gd4d_cross_attn_sliced.hip
 python3 tools/make_pmc_record.py $g/pmc_agg/pmc_summary.txt profiles/${pre}_pmc_cross_attn_agg.json \
   "tools/bench_late.py: 900 x 24 x 4 levels, fp32 channels-last pyramid; one launch = the row-form aggregate of one decoder layer" cross_attn_agg_kernel gd4d_cross_attn_late.hip
 python3 tools/make_pmc_record.py $g/pmc_fwd/pmc_summary.txt profiles/${pre}_pmc_cross_attn.json \
@@ -33,4 +33,5 @@ echo collected
 cp $(find $g/hpe -name '*kernel_stats.csv' | head -1) profiles/${pre}_kernel_stats_head_pe.csv
 cp $g/head_pe_breakdown.txt profiles/${pre}_head_pe_breakdown.txt
 cp $g/pmc_mlp2/pmc_summary.txt profiles/${pre}_pmc_mlp2.txt
+cp gpurun_out/f2b/f2b_kernel_stats.csv profiles/${pre}_kernel_stats_features_to_boxes.csv 2>/dev/null
 echo collected head pe

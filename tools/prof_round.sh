@@ -23,7 +23,7 @@ t=$(find gpurun_out/$tag/tl -name '*kernel_trace.csv' | head -1)
 python3 tools/step_timeline.py $t > gpurun_out/$tag/step_timeline.txt 2>&1
 find gpurun_out/$tag/tl -name '*kernel_trace.csv' -delete
 python3 tools/trace_step.py > gpurun_out/$tag/step_timeline_device.txt 2>&1
-for which in sliced:tools/bench_sliced.py:--iters:3 agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
+for which in sliced:tools/bench_sliced.py:--iters:3:--coarse agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
   name=${which%%:*}; cmd=$(echo ${which#*:} | tr ':' ' ')
   mkdir -p gpurun_out/$tag/pmc_$name
   i=0
@@ -34,7 +34,7 @@ for which in sliced:tools/bench_sliced.py:--iters:3 agg:tools/bench_late.py:--it
   done
   python3 tools/pmc_summary.py gpurun_out/$tag/pmc_$name > /dev/null
 done
-grep -A 14 "cross_attn_agg_items" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | head -16
+grep -A 14 "cross_attn_agg_items_coarse" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | head -16
 # the query side of the step (row chains, attention core): issue / MFMA / LDS / wait counters, one sample in flight
 bash tools/prof_pmc.sh $tag/pmc_step bench.py --inflight 1 --no-roofline --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
 grep -A 40 "row_chain_kernel\|mha_core_kernel" gpurun_out/$tag/pmc_step/pmc_summary.txt | head -100
@@ -55,3 +55,5 @@ find gpurun_out/$tag/hpe -name '*kernel_trace.csv' -delete
 python3 tools/bench_head_pe.py 2>/dev/null | grep -v amdgpu > gpurun_out/$tag/head_pe_breakdown.txt
 bash tools/prof_pmc.sh $tag/pmc_mlp2 tools/bench_mlp2.py > /dev/null 2>&1
 grep -A 30 "mlp2_kernel" gpurun_out/$tag/pmc_mlp2/pmc_summary.txt | head -40
+# features -> boxes as one request (head position embedding -> decoder -> box epilogue -> decode): kernel statistics
+bash tools/prof_f2b.sh | tail -3
