@@ -398,7 +398,8 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
                 and Fn.LateValues.applicable(cross, kwargs['value']) and not Fn.wants_grad(self, query, *kwargs['value']):
             # aggregate-then-project (GD4D_PROJECT=late, default): no per-layer value tensors, ONE channels-last copy of
             # the pyramid for all layers (made on the side stream next to layer 0's self-attention)
-            late, own_late = Fn.LateValues(kwargs['value'], cross[0].value_dtype, coarse_for=cross if fused else None), True
+            single = fused and all((query.shape[-1] // a.num_heads) % 32 == 0 and not a.depth_encode for a in cross)
+            late, own_late = Fn.LateValues(kwargs['value'], cross[0].value_dtype, coarse_for=cross if single else None), True
             kwargs = dict(kwargs)
             kwargs[Fn.LATE_VALUES_KEY] = late
         if late is None:
@@ -524,7 +525,10 @@ class Detr3DTransformer(nn.Module):
             # the channels-last copy of the pyramid needs nothing but the pyramid: fork it first, before the query side
             cross = [a for layer in self.decoder.layers for a in layer.attentions if getattr(a, 'operation_name', '') == 'cross_attn']
             if cross and all(isinstance(a, Deform3DCrossAttn) for a in cross) and Fn.LateValues.applicable(cross, mlvl_feats):
-                own_late = Fn.LateValues(mlvl_feats, cross[0].value_dtype, coarse_for=cross)
+                # (the loop that gathers the coarse levels from projected rows: the first layer's projection is forked with the copy)
+                single = fused_decoder.takes_single_stream_loop(self.decoder, query.unsqueeze(1), mlvl_feats, query_pos[None, :, :3],
+                                                                reg_branches, kwargs.get('attn_masks'), query_pos.unsqueeze(1))
+                own_late = Fn.LateValues(mlvl_feats, cross[0].value_dtype, coarse_for=cross if single else None)
                 kwargs = dict(kwargs)
                 kwargs[Fn.LATE_VALUES_KEY] = own_late
         if fast:

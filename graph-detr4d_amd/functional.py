@@ -695,7 +695,7 @@ class LateValues:
                 if coarse_for and self.coarse_setup(coarse_for):
                     self._project_first(coarse_for[0])
                     self.coarse.rows.record_stream(self.main)
-                    self.partial = os.environ.get('GD4D_COARSE_FULL_COPY') != '1'
+                    self.partial = True
                 if self.partial:
                     # the fine levels only: (8, R, S01, 32); the view's coarse entries are never dereferenced by the coarse gather
                     self.cl, _ = ops.pyramid_slice_planar_fwd(src[:2], max_cus=copy_cus, out_dtype=dtype)

@@ -81,6 +81,15 @@ def applicable(decoder, query, value, reference_points, reg_branches, attn_masks
     return True
 
 
+def takes_single_stream_loop(decoder, query, value, reference_points, reg_branches, attn_masks, query_pos):
+    """Whether a Detr3DTransformerDecoder.forward with these arguments ends in run_single - the loop that gathers the coarse levels
+    from projected rows (LateValues(coarse_for=...) is only worth preparing for it: another consumer copies the pyramid again)."""
+    if not applicable(decoder, query, value, reference_points, reg_branches, attn_masks, query_pos=query_pos):
+        return False
+    c = query.shape[-1]
+    return all((c // l.attentions[1].num_heads) % 32 == 0 and not l.attentions[1].depth_encode for l in decoder.layers)
+
+
 def _in_proj_ops(sa, x_pos_buf, x_buf, qkv, kv=None):
     """The packed in-projection: q, k from (x + pos), v from x (mmcv MultiheadAttention semantics) - one GEMM operation whose
     last 256 columns read the other buffer (two operations when the width does not allow it; bit-identical).  kv (ops.KVPlanes):
@@ -206,10 +215,9 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
     # the guest job of a chain launch that runs before gather l on compute units the chain leaves idle - layer 0's rides here,
     # layer l + 1's in chain B' of layer l (one buffer: gather l has read it by then).
     coarse = late.mode == 'sliced' and late.coarse_setup([l.attentions[1] for l in layers])
-    guest_wgs = int(os.environ.get('GD4D_GUEST_WGS', '0'))          # dev: guest workgroups per launch (0: what the chain leaves free)
     first_guest = None
     if coarse and not late.take_first(layers[0].attentions[1]):      # (not enqueued beside the copy when `late` was made: rides here)
-        first_guest = late.coarse_guest(layers[0].attentions[1], workgroups=guest_wgs)
+        first_guest = late.coarse_guest(layers[0].attentions[1])
     ops.row_chain_fwd([ops.chain_load(0, x, pos), ops.chain_load(1, x)] + _in_proj_ops(layers[0].attentions[0], 0, 1, qkv.view(q, -1), kv), q,
                       guest=first_guest)
     n_out = nl if return_intermediate else 1
@@ -282,7 +290,7 @@ def run_single(decoder, query, query_pos, value, reference_points, reg_branches,
             agg_raw, wsum = late.aggregate(ca, ref, off.view(1, q, hh, npt, 3), att.view(1, q, hh, nlv, npt), cam, lidar2img,
                                            img_h, img_w, order=order)
             first = ops.chain_headgemm(agg_raw, wsum, ca.value_proj.weight, ca.value_proj.bias, dst=0)
-        guest = late.coarse_guest(layers[lid + 1].attentions[1], workgroups=guest_wgs) if coarse and not last else None
+        guest = late.coarse_guest(layers[lid + 1].attentions[1]) if coarse and not last else None
         x3 = out_all[slot]
         prog = [first] + ([ops.chain_wait(flags[lid], err)] if pos_late else []) + [
                 ops.chain_load(3, x1, pos_feat.view(q, c)),                       # the two residuals of :336 (as GEMM addends: slower)
