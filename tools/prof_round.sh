@@ -6,9 +6,11 @@
 #      (gd4d_cross_attn_agg_sliced_fwd, tools/bench_sliced.py), of its one-workgroup-per-query form (tools/bench_late.py) and of
 #      the projected-value gather (tools/bench_kernel.py); issue / MFMA / LDS counters of the row chains and the attention core
 tag=${1:-round}
+stages=${2:-1234}      # 1: bench lines + kernel stats + timelines, 2: PMC passes of the inference kernels, 3: training, 4: head PE + features -> boxes
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$tag
+if [[ $stages == *1* ]]; then
 python3 bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 tail -c 400 gpurun_out/$tag/bench.json
 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/stats -o bench -- python3 bench.py > gpurun_out/$tag/bench_profiled.json 2> gpurun_out/$tag/bench_profiled.err
@@ -23,6 +25,9 @@ t=$(find gpurun_out/$tag/tl -name '*kernel_trace.csv' | head -1)
 python3 tools/step_timeline.py $t > gpurun_out/$tag/step_timeline.txt 2>&1
 find gpurun_out/$tag/tl -name '*kernel_trace.csv' -delete
 python3 tools/trace_step.py > gpurun_out/$tag/step_timeline_device.txt 2>&1
+python3 tools/trace_step.py nhwc > gpurun_out/$tag/step_timeline_device_nhwc.txt 2>&1
+fi
+if [[ $stages == *2* ]]; then
 for which in sliced:tools/bench_sliced.py:--iters:3:--coarse agg:tools/bench_late.py:--iters:2 fwd:tools/bench_kernel.py:--iters:5:--order; do
   name=${which%%:*}; cmd=$(echo ${which#*:} | tr ':' ' ')
   mkdir -p gpurun_out/$tag/pmc_$name
@@ -33,11 +38,15 @@ for which in sliced:tools/bench_sliced.py:--iters:3:--coarse agg:tools/bench_lat
     find gpurun_out/$tag/pmc_$name/p$i -name '*kernel_trace.csv' -delete
   done
   python3 tools/pmc_summary.py gpurun_out/$tag/pmc_$name > /dev/null
+  find gpurun_out/$tag/pmc_$name -name '*counter_collection.csv' -delete
 done
 grep -A 14 "cross_attn_agg_items_coarse" gpurun_out/$tag/pmc_sliced/pmc_summary.txt | head -16
 # the query side of the step (row chains, attention core): issue / MFMA / LDS / wait counters, one sample in flight
 bash tools/prof_pmc.sh $tag/pmc_step bench.py --inflight 1 --no-roofline --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
 grep -A 40 "row_chain_kernel\|mha_core_kernel" gpurun_out/$tag/pmc_step/pmc_summary.txt | head -100
+find gpurun_out/$tag/pmc_step -name '*counter_collection.csv' -delete
+fi
+if [[ $stages == *3* ]]; then
 # training: bench lines + kernel stats of the step, PMC passes of the raw-pyramid backward kernels (tools/bench_raw_bwd.py)
 mkdir -p gpurun_out/$tag/train
 python3 bench.py --mode train --steps 20 --warmup 3 > gpurun_out/$tag/train/train.json 2> gpurun_out/$tag/train/train.err
@@ -49,6 +58,9 @@ for f in train train_criterion train_vov distill train_projected_values; do tail
 bash tools/prof_train_stats.sh $tag/train --no-roofline | head -12
 bash tools/prof_pmc.sh $tag/pmc_rawbwd tools/bench_raw_bwd.py --iters 2 > /dev/null 2>&1
 grep -A 26 "dot_sliced_kernel\|grad_reduce_kernel\|grad_count_kernel" gpurun_out/$tag/pmc_rawbwd/pmc_summary.txt | head -90
+find gpurun_out/$tag/pmc_rawbwd -name '*counter_collection.csv' -delete
+fi
+if [[ $stages == *4* ]]; then
 # the head's feature position embedding: kernel stats of the library's own route, PMC of the fused position MLP
 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/$tag/hpe -o hpe -- python3 tools/bench_head_pe.py --hip-only > gpurun_out/$tag/hpe.log 2>&1
 find gpurun_out/$tag/hpe -name '*kernel_trace.csv' -delete
@@ -57,3 +69,7 @@ bash tools/prof_pmc.sh $tag/pmc_mlp2 tools/bench_mlp2.py > /dev/null 2>&1
 grep -A 30 "mlp2_kernel" gpurun_out/$tag/pmc_mlp2/pmc_summary.txt | head -40
 # features -> boxes as one request (head position embedding -> decoder -> box epilogue -> decode): kernel statistics
 bash tools/prof_f2b.sh | tail -3
+find gpurun_out/$tag/pmc_mlp2 -name '*counter_collection.csv' -delete
+fi
+find gpurun_out -name '*agent_info.csv' -delete; find gpurun_out -name '*domain_stats.csv' -delete
+du -sh gpurun_out | tail -1

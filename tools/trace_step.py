@@ -22,6 +22,9 @@ def main():
     n_cams, layers, queries = 24, 6, 900
     tr, regs = bench.build_decoder(G, n_cams, layers, 'fp32', 1002)
     feats = [f.to(dev) for f in synthetic.feature_pyramid(n_cams, synthetic.R50_LEVELS, seed=1002)]
+    if 'nhwc' in sys.argv[1:]:                           # the levels stored channels-last: gathered in place, no per-sample copy
+        feats = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+        torch.cuda.synchronize()
     qe = torch.randn(queries, 512, generator=torch.Generator().manual_seed(1005)).to(dev)
     metas = synthetic.make_img_metas(synthetic.camera_rig(4), batch=1)
     tr, regs = tr.to(dev), regs.to(dev)
