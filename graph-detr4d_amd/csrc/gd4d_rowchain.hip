@@ -1211,6 +1211,12 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
               ((op.kind == GD4D_CHAIN_LOAD || op.kind == GD4D_CHAIN_ADD || op.kind == GD4D_CHAIN_SMALL_LINEAR) && op.gout);
     }
   }
+  // the guests' job (gd4d_value_proj_fwd's geometry: one layer, pixel-major fp32 rows) - checked before anything touches the device
+  VpaParams g{};
+  if (guest) {
+    if (train) return GD4D_EUNSUPPORTED;
+    if (int rc = va_guest_params(guest, g)) return rc;
+  }
   const size_t lds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES + (train ? sizeof(float) * 8 * RC_W : 0);   // row buffers + the prefetch dump area (+ LN_BWD's partial sums)
   const void* kern = train ? reinterpret_cast<const void*>(row_chain_kernel<true>) : reinterpret_cast<const void*>(row_chain_kernel<false>);
   if (!allow_dynamic_lds(kern, (int)lds)) return GD4D_ELAUNCH;
@@ -1221,10 +1227,6 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
   for (int i = 0; i < na; ++i) prog.ops[i] = a[i];
   for (int i = 0; i < nb; ++i) prog.ops[na + i] = b[i];
   if (guest) {
-    // the guests' job (gd4d_value_proj_fwd's geometry: one layer, pixel-major fp32 rows)
-    if (train) return GD4D_EUNSUPPORTED;
-    VpaParams g{};
-    if (int rc = va_guest_params(guest, g)) return rc;
     const int base = g.total;
     if (va_lds_bytes(1, false, RC_WAVES) > lds) return GD4D_EUNSUPPORTED;
     const int chain_wgs = nb > 0 ? split + blocks : blocks;

@@ -157,3 +157,47 @@ def test_training_entry_points_validate_before_any_gpu_work():
     assert lib.gd4d_mha_core_fwd(ptr, ptr, ptr, null, ptr, 30000, 30000, 1, 8, 32, 256, 256, 256, 256, 0, f(0.17), null, f(0.1), ptr, null) == EUNSUPPORTED
     assert lib.gd4d_mha_core_bwd(ptr, ptr, ptr, ptr, ptr, null, ptr, ptr, ptr, ptr, ptr, 16, 16, 1, 8, 32, 256, 256, 256, 256, 256,
                                  256, 256, 256, 0, f(0.17), f(0.1), null, null) == EINVAL
+
+
+def test_round6_entry_points_validate_before_any_gpu_work():
+    """The coarse-projected gather, the guest launch and the value_proj image: null pointers, unsupported shapes and misuse come back
+    as error codes on a box without a GPU; the guest struct has the size the header declares."""
+    import ctypes
+    from graph_detr4d_amd import _lib, ops
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 96)()
+    ptr = ctypes.c_void_p((ctypes.addressof(buf) + 63) & ~63)
+    EINVAL, EUNSUPPORTED = -1, -2
+    assert lib.gd4d_chain_guest_bytes() == ctypes.sizeof(ops.ChainGuest)
+    assert lib.gd4d_value_proj_image_bytes() == 8 * 32768 + 1024               # 8 chunks of split-bf16 fragments + the bias table
+    assert lib.gd4d_value_proj_image(null, null, ptr, null) == EINVAL
+    # the coarse gather: two fine + two coarse levels, 8 heads, every pointer there
+    lv = (ctypes.c_int32 * 8)(16, 28, 8, 14, 4, 7, 2, 4)
+    cs = (ctypes.c_int64 * 4)(16 * 28 * 1024, 8 * 14 * 1024, 4 * 7 * 1024, 2 * 4 * 1024)
+    lp = (ctypes.c_void_p * 4)(ptr.value, ptr.value, ptr.value, ptr.value)
+    pp = (ctypes.c_void_p * 2)(ptr.value, ptr.value)
+    pcs = (ctypes.c_int64 * 2)(4 * 7 * 1024, 2 * 4 * 1024)
+    args = lambda L=4, hh=8, pagg=ptr, proj=pp: (lp, lv, cs, 1024, 128, proj, pcs, ptr, ptr, ptr, pagg, 1, 6, 9, hh, 256, L, 4, 0, null, null)
+    assert lib.gd4d_cross_attn_agg_items_coarse_fwd(*args(L=3)) == EUNSUPPORTED
+    assert lib.gd4d_cross_attn_agg_items_coarse_fwd(*args(hh=4)) == EUNSUPPORTED
+    assert lib.gd4d_cross_attn_agg_items_coarse_fwd(*args(pagg=null)) == EINVAL
+    assert lib.gd4d_cross_attn_agg_items_coarse_fwd(*args(proj=null)) == EINVAL
+    short = (ctypes.c_int64 * 2)(4 * 7 * 1024 - 16, 2 * 4 * 1024)              # a camera stride shorter than the level's rows
+    a = list(args())
+    a[6] = short
+    assert lib.gd4d_cross_attn_agg_items_coarse_fwd(*a) == EINVAL
+    # the guest launch: a guest is required, its job must be complete, training operations are refused
+    op = ops.ChainOp(kind=ops.CHAIN_LOAD, src=-1, dst=0, res=-1, N=256, p0=ptr.value)
+    prog = (ops.ChainOp * 1)(op)
+    assert lib.gd4d_row_chain_guest_fwd(prog, 1, null, 0, 16, null, null) == EINVAL
+    g = ops.ChainGuest()
+    assert lib.gd4d_row_chain_guest_fwd(prog, 1, null, 0, 16, ctypes.byref(g), null) == EINVAL      # no image / out / levels
+    g.image, g.out, g.L, g.R = ptr.value, ptr.value, 1, 2
+    g.feats[0] = ptr.value
+    g.level_hw[0], g.level_hw[1] = 4, 7
+    store = ops.ChainOp(kind=ops.CHAIN_LOAD, src=-1, dst=0, res=-1, N=256, p0=ptr.value, gout=ptr.value, ldg=256)   # a store from LOAD: a training program
+    assert lib.gd4d_row_chain_guest_fwd((ops.ChainOp * 1)(store), 1, null, 0, 16, ctypes.byref(g), null) == EUNSUPPORTED
+    g.L = 9
+    assert lib.gd4d_row_chain_guest_fwd(prog, 1, null, 0, 16, ctypes.byref(g), null) == EINVAL
+    assert lib.gd4d_value_proj_guest_fwd(null, 0, null) == EINVAL

@@ -512,3 +512,36 @@ def test_coarse_projected_gather_refuses_what_it_is_not_built_for():
     coarse = ops.CoarseValues(torch.zeros(6, 8 * 14 + 4 * 7, 256).cuda(), [(8, 14), (4, 7)])
     with pytest.raises(_lib.Gd4dError):
         ops.cross_attn_agg_coarse_fwd(plan, coarse)
+
+
+def test_late_values_prepared_for_the_coarse_gather_still_serve_an_all_raw_consumer():
+    """LateValues(coarse_for=...) copies the two fine levels only and projects the first layer's coarse levels beside the copy - for the
+    fused decoder loop.  A consumer that gathers every level raw after all (a module called on its own with this object) must get the
+    full copy (made again, once) and the same result as from an object built for it."""
+    import graph_detr4d_amd as G
+    from graph_detr4d_amd import functional as Fn
+    from graph_detr4d_amd import ops, synthetic
+    torch.manual_seed(4)
+    n, q = 6, 70
+    levels = [(29, 50), (15, 25), (8, 13), (4, 7)]
+    mod = G.build_attention(dict(type='Deform3DCrossAttn', num_cams=n, pc_range=synthetic.PC_RANGE, num_points=4, embed_dims=256)).cuda().eval()
+    synthetic.randomise_cross_attn_(mod, seed=3)
+    feats = [torch.randn(1, n, 256, h, w).cuda() for h, w in levels]
+    l2i = torch.from_numpy(synthetic.camera_rig(1)).unsqueeze(0).cuda()
+    ref, off = torch.rand(1, q, 3).cuda(), (torch.randn(1, q, 8, 4, 3) * 2).cuda()
+    attn, cam = torch.randn(1, q, 8, 4, 4).cuda(), torch.randn(1, q, n).cuda()
+    with torch.no_grad():
+        plain = Fn.LateValues(feats)
+        want_agg, want_wsum = plain.aggregate(mod, ref, off, attn, cam, l2i, 900, 1600)
+        plain.finish()
+        late = Fn.LateValues(feats, coarse_for=[mod])
+        assert late.partial and late.coarse is not None and late.take_first(mod) and not late.take_first(mod)
+        agg_c, wsum_c, pagg = late.aggregate(mod, ref, off, attn, cam, l2i, 900, 1600, coarse=True)        # what the fused loop asks for
+        w_v, b_v = mod.value_proj.weight, mod.value_proj.bias
+        torch.testing.assert_close(ops.value_proj_heads_fwd(agg_c, wsum_c, w_v, b_v) + pagg,
+                                   ops.value_proj_heads_fwd(want_agg, want_wsum, w_v, b_v), rtol=RTOL, atol=ATOL)
+        got_agg, got_wsum = late.aggregate(mod, ref, off, attn, cam, l2i, 900, 1600)                     # ... and an all-raw consumer
+        assert not late.partial
+        late.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(got_agg, want_agg) and torch.equal(got_wsum, want_wsum)
