@@ -672,3 +672,44 @@ def test_a_captured_graph_serves_samples_it_was_not_captured_on(layout, inflight
         serve([inflight + i for i in range(inflight)])                 # new samples
         serve([2 * inflight] * inflight)                               # ... and again (every request the same new one)
         serve(list(range(inflight)))                                   # back
+
+
+@pytest.mark.parametrize('num_points', [1, 2, 8])
+def test_fused_loop_with_projected_coarse_levels_for_other_point_counts(num_points, monkeypatch):
+    """The decoder loop gathers the coarse levels from projected rows for every compiled point count (1 / 2 / 4 / 8 with 8 heads): equal
+    to the all-raw loop (GD4D_COARSE=0) and to the module path within summation order."""
+    from graph_detr4d_amd import synthetic
+    torch.manual_seed(num_points)
+    n, q, nl = 6, 70, 2
+    levels = [(29, 50), (15, 25), (8, 13), (4, 7)]
+    tr = G.build_transformer(dict(
+        type='Detr3DTransformer', num_feature_levels=4, num_cams=n,
+        decoder=dict(type='Detr3DTransformerDecoder', num_layers=nl, return_intermediate=True,
+                     transformerlayers=dict(
+                         type='DetrTransformerDecoderLayer',
+                         attn_cfgs=[dict(type='MultiheadAttention', embed_dims=256, num_heads=8, dropout=0.1),
+                                    dict(type='Deform3DCrossAttn', num_cams=n, pc_range=synthetic.PC_RANGE, num_points=num_points,
+                                         embed_dims=256)],
+                         feedforward_channels=512, ffn_dropout=0.1,
+                         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))))
+    tr.init_weights()
+    for i, layer in enumerate(tr.decoder.layers):
+        synthetic.randomise_cross_attn_(layer.attentions[1], seed=40 + i)
+    tr = tr.to(DEV).eval()
+    feats = [torch.randn(1, n, 256, h, w, device=DEV) for h, w in levels]
+    qe = torch.randn(q, 512, device=DEV)
+    metas = synthetic.make_img_metas(synthetic.camera_rig(1), batch=1)
+    from graph_detr4d_amd import ops
+    seen = []
+    real = ops.cross_attn_agg_coarse_fwd
+    monkeypatch.setattr(ops, 'cross_attn_agg_coarse_fwd', lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        coarse = tr(feats, qe, reg_branches=None, img_metas=metas)
+        assert len(seen) == nl, 'the fused loop gathers the coarse levels from projected rows'
+        monkeypatch.setenv('GD4D_COARSE', '0')
+        raw = tr(feats, qe, reg_branches=None, img_metas=metas)
+        assert len(seen) == nl
+        monkeypatch.setenv('GD4D_FUSED_DECODER', '0')
+        module = tr(feats, qe, reg_branches=None, img_metas=metas)
+    torch.testing.assert_close(coarse[0], raw[0], rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(coarse[0], module[0], rtol=1e-3, atol=1e-3)
