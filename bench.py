@@ -448,7 +448,8 @@ def main():
 
     # ---------------- features -> boxes as one request (secondary figure) ----------------
     f2b = None
-    if rank == 0 and not a.no_f2b_figure and a.input_layout == 'nchw' and a.value_dtype == 'fp32':
+    # (single-GPU runs only: its timing windows use the job's barrier - a figure one rank computes alone would leave the others behind)
+    if world == 1 and not a.no_f2b_figure and a.input_layout == 'nchw' and a.value_dtype == 'fp32':
         try:
             f2b = features_to_boxes(G, tr, regs, feats, query_embed, rig, a, D, dev, streams[0], a.steps)
         except Exception as e:                        # secondary figure: report, never fail the bench line
