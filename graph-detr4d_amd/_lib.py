@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 53
+ABI_VERSION = 54
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -107,6 +107,7 @@ SIGNATURES = {
     'gd4d_mlp2_image': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'gd4d_mlp2_bf16x3_fwd': (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
     'gd4d_mlp2_se_fuse_fwd': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'gd4d_mlp2_frustum_fwd': (_i, [_vp, _vp, _i, _i, _c.c_float, _c.c_float, _i, _c.c_float, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_adamw_flat_workspace_bytes': (_c.c_size_t, []),
     'gd4d_adamw_flat': (_i, [_vp] * 6 + [_c.c_size_t, _c.c_int64] + [_f] * 6 + [_vp]),
     'gd4d_chain_weight_image_bytes': (_c.c_size_t, [_i, _i]),

@@ -73,6 +73,28 @@ __device__ __forceinline__ float ml_sigmoid(float x) {
 
 struct Mlp2Row { const float* f; float* o; int pix, hw; };     // feat / out of the row's camera and level; its pixel
 
+// The FRUSTUM form (gd4d_mlp2_frustum_fwd): X is not read at all.  Row m = camera r, level l, pixel (y, x); its 3 D = 192 inputs are the
+// head's frustum coordinates (dense_heads/detr3d_head_pe.py:427-491: pixel centre x depth bin -> lidar frame by the camera's img2lidar
+// matrix -> pc_range units -> inverse_sigmoid) - a function of 12 matrix entries and the pixel index, generated in registers when the
+// tile's rows would have been loaded (gd4d_frustum_pe_input_fwd's arithmetic, operation for operation; the (R, S, 192) tensor it wrote
+// and this kernel re-read - 568 MB each way at 24 cameras - does not exist).  Lane (row, kg) holds input channels 96 kg + j,
+// j = 8 step + e: depth bin 32 kg + j / 3, axis j % 3 - so which axis a register holds is known at compile time; W1's image is made
+// from W1 with its columns in that order (ops.mlp2_frustum_image).
+struct Mlp2Fr {
+  const float* i2l;         // (R, 16) img2lidar
+  int w[4], h[4], hw[4];
+  int start[5];
+  int S;
+  float pad_h, pad_w, depth_start, bin_size;
+  float lo[3], span[3];
+};
+
+__device__ __forceinline__ float ml_inv_sigmoid_fast(float x) {      // gd4d_head_pe.hip's inv_sigmoid_fast
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float a = fminf(fmaxf(x, 1e-5f), 1.f), b = fminf(fmaxf(1.f - x, 1e-5f), 1.f);
+  return (__builtin_amdgcn_logf(a) - __builtin_amdgcn_logf(b)) * 0.69314718055994530942f;
+}
+
 __device__ __forceinline__ Mlp2Row ml_row_of(const Mlp2Se& q, int m) {
   const int r = m / q.S;
   const int rem = m - r * q.S;
@@ -105,8 +127,9 @@ __device__ __forceinline__ ml_bf16x8 ml_frag(const ml_u32x4& v) { return __built
 // of v_mfma_f32_32x32x16 - and, read as r = 8 s + e, the k-slot e of phase B's step s
 __host__ __device__ __forceinline__ int ml_hidden_of(int kg, int r) { return 4 * kg + (r & 3) + 8 * (r >> 2); }
 
-template <int STEPS1, bool SE = false>
-__global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p, const Mlp2Se q) {
+template <int STEPS1, bool SE = false, bool FR = false>
+__global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p, const Mlp2Se q, const Mlp2Fr fr) {
+  static_assert(!FR || (STEPS1 == 12 && !SE), "the frustum form: 3 x 64 depth bins");
   extern __shared__ __attribute__((aligned(16))) char ml_smem[];
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -140,7 +163,35 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p,
   float xr[STEPS1][8];
   auto load_x = [&](int tl) {
     const int m = min(tl * ML_BM + wave * 32 + l32, p.M - 1);
-    if (SE) {
+    if (FR) {
+      const int r = m / fr.S;
+      const int rem = m - r * fr.S;
+      const int l = (rem >= fr.start[1]) + (rem >= fr.start[2]) + (rem >= fr.start[3]);
+      const int pix = rem - fr.start[l];
+      const int W = fr.w[l], H = fr.h[l];
+      const int y = pix / W, x = pix - y * W;
+      const float* mt = fr.i2l + (size_t)r * 16;
+      float mm[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) mm[i] = mt[i];
+      const float ch = ((float)y * fr.pad_h) / (float)H;          // torch.arange(H).float() * pad_h / H (:440-441)
+      const float cw = ((float)x * fr.pad_w) / (float)W;
+      const float fi0 = kg ? 32.0f : 0.0f;
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) {
+        const float fi = fi0 + (float)dd;
+        const float depth = fr.depth_start + (fr.bin_size * fi) * (fi + 1.0f);      // :450-453
+        const float sdep = fmaxf(depth, 1e-5f);
+        const float px = cw * sdep, py = ch * sdep;                                  // :458
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float v = ((mm[4 * k] * px + mm[4 * k + 1] * py) + mm[4 * k + 2] * depth) + mm[4 * k + 3];   // :469
+          const float c = (v - fr.lo[k]) / fr.span[k];                               // :470-475
+          const int j = 3 * dd + k;
+          xr[j >> 3][j & 7] = ml_inv_sigmoid_fast(c);                               // :480-481
+        }
+      }
+    } else if (SE) {
       // NCHW maps: channel c of this lane's pixel is hw floats further - a wave instruction reads 32 consecutive pixels of two channels
       const Mlp2Row g = ml_row_of(q, m);
       const float* xc = g.f + (size_t)(8 * kg) * g.hw + g.pix;
@@ -414,9 +465,10 @@ extern "C" int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const flo
   Mlp2Params p{x, img1, img1 + (size_t)H * K1 * 4 + (size_t)(H / ML_HC) * 1024, b2, out, M, K1, H, ldx, ldo};
   const int lds = 2 * ((K1 / 16) * 2048 + 1024 + ML_S2);
   const Mlp2Se none{};
+  const Mlp2Fr nofr{};
   auto go = [&](auto kern) -> int {
     if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, none);
+    hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, none, nofr);
     return check_launch();
   };
   switch (K1 / 16) {
@@ -454,6 +506,44 @@ extern "C" int gd4d_mlp2_se_fuse_fwd(const void* const* feats, const int32_t* le
   const int lds = 2 * ((K1 / 16) * 2048 + 1024 + ML_S2);
   auto kern = mlp2_kernel<16, true>;
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, q);
+  const Mlp2Fr nofr{};
+  hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, q, nofr);
+  return check_launch();
+}
+
+// out (R S, 256; row stride ldo) = position_encoder(frustum coordinates of every pixel of every level of every camera): see Mlp2Fr.
+// `image`: gd4d_mlp2_image of (W1 with its columns permuted - column 16 st + 8 kg + e of the image's W1 = column 96 kg + 8 st + e of
+// the module's -, b1, W2).  D must be 64 (K1 = 192).
+extern "C" int gd4d_mlp2_frustum_fwd(const float* img2lidar, const int32_t* level_hw, int L, int R, float pad_h, float pad_w, int D,
+                                     float depth_start, const double* pc_range, const void* image, const float* b2, float* out,
+                                     int H, int ldo, void* stream) {
+  using namespace gd4d;
+  if (!img2lidar || !level_hw || !pc_range || !image || !out || L <= 0 || R <= 0 || ldo < ML_N2) return GD4D_EINVAL;
+  const int K1 = 3 * D;
+  if (L > 4 || D != 64 || !mlp2_shape_ok(K1, H, ML_N2)) return GD4D_EUNSUPPORTED;
+  if (!aligned16(image)) return GD4D_EALIGN;
+  Mlp2Fr fr{};
+  long long S = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int ll = l < L ? l : 0;
+    if (l < L && (level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0)) return GD4D_EINVAL;
+    fr.h[l] = level_hw[2 * ll]; fr.w[l] = level_hw[2 * ll + 1]; fr.hw[l] = fr.h[l] * fr.w[l];
+    fr.start[l] = (int)S;
+    if (l < L) S += fr.hw[l];
+  }
+  for (int l = L; l <= 4; ++l) fr.start[l] = (int)S;
+  if (S * R >= (1ll << 31)) return GD4D_EUNSUPPORTED;
+  fr.S = (int)S; fr.i2l = img2lidar; fr.pad_h = pad_h; fr.pad_w = pad_w; fr.depth_start = depth_start;
+  // (the frustum kernel's constants: Python-float arithmetic of the reference (:452), rounded to fp32 when it meets the tensor)
+  fr.bin_size = (float)((pc_range[3] - (double)depth_start) / ((double)D * (1.0 + (double)D)));
+  for (int k = 0; k < 3; ++k) { fr.lo[k] = (float)pc_range[k]; fr.span[k] = (float)(pc_range[k + 3] - pc_range[k]); }
+  const int M = (int)(S * R);
+  const char* img1 = static_cast<const char*>(image);
+  Mlp2Params p{nullptr, img1, img1 + (size_t)H * K1 * 4 + (size_t)(H / ML_HC) * 1024, b2, out, M, K1, H, 0, ldo};
+  const int lds = 2 * ((K1 / 16) * 2048 + 1024 + ML_S2);
+  const Mlp2Se none{};
+  auto kern = mlp2_kernel<12, false, true>;
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, none, fr);
   return check_launch();
 }

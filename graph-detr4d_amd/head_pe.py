@@ -270,6 +270,10 @@ class FeaturePositionEmbedding(nn.Module):
             # the position MLP as one kernel (gd4d_mlp2_bf16x3_fwd) where its shape allows: the image holds W1, b1 and W2
             cache['pe_mlp'] = ops.mlp2_image(flat(pe0), pe0.bias.detach(), flat(pe2)) \
                 if ops.mlp2_supported(pe0.in_channels, pe0.out_channels, pe2.out_channels) else None
+            # ... and with the frustum coordinates generated in its prologue (gd4d_mlp2_frustum_fwd; GD4D_PE_FRUSTUM=0: the two kernels)
+            cache['pe_mlp_fr'] = ops.mlp2_frustum_image(flat(pe0), pe0.bias.detach(), flat(pe2)) \
+                if cache['pe_mlp'] is not None and pe0.in_channels == 192 and self.depth_num == 64 and len(self.pc_range) == 6 \
+                and os.environ.get('GD4D_PE_FRUSTUM', '1') != '0' else None
             # the SE gate's two convolutions (and the fuse behind them) as one kernel too: gd4d_mlp2_se_fuse_fwd
             ce = convs['se1']
             cache['se_mlp'] = ops.mlp2_image(flat(cr), cr.bias.detach(), flat(ce)) \
@@ -281,6 +285,10 @@ class FeaturePositionEmbedding(nn.Module):
     def _position_mlp(self, img2lidar, shapes, starts, s_tot, pad_hw, sw, out=None):
         """position_encoder(frustum) for the cameras of `img2lidar` (R', 4, 4) -> (R', S, C) channels-last rows (`out`: written there)."""
         r = img2lidar.shape[0]
+        if sw.get('pe_mlp_fr') is not None and len(shapes) <= 4:
+            # ONE kernel: the frustum inputs are generated in the MLP's prologue (no (R, S, 192) tensor)
+            return ops.mlp2_frustum_fwd(img2lidar, shapes, pad_hw, self.depth_num, self.depth_start, self.pc_range, sw['pe_mlp_fr'],
+                                        self.position_encoder[2].bias, out=out)
         if out is not None:
             out = out.view(r * s_tot, -1)
         x = torch.empty(r, s_tot, self.position_dim, device=img2lidar.device, dtype=torch.float32)

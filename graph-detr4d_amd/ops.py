@@ -1505,6 +1505,39 @@ def mlp2_se_fuse_fwd(feats, image, b2, pe, sine):
     return [o.permute(0, 3, 1, 2) for o in outs]
 
 
+def mlp2_frustum_image(w1, b1, w2):
+    """The image gd4d_mlp2_frustum_fwd takes: mlp2_image of W1 (H, 192) with its columns in the order the kernel's lanes generate the
+    frustum inputs in - column 16 st + 8 kg + e of the image's W1 = column 96 kg + 8 st + e of the module's."""
+    if w1.shape[1] != 192:
+        raise _lib.Gd4dError('mlp2_frustum_image: position_encoder[0] must take 3 x 64 depth bins')
+    col = torch.arange(192, device=w1.device)
+    st, kg, e = col // 16, (col % 16) // 8, col % 8
+    return mlp2_image(w1[:, 96 * kg + 8 * st + e].contiguous(), b1, w2)
+
+
+def mlp2_frustum_fwd(img2lidar, level_hw, pad_hw, depth_num, depth_start, pc_range, image, b2=None, out=None):
+    """gd4d_mlp2_frustum_fwd: img2lidar (R, 4, 4) -> position_encoder(frustum coordinates) (R, S, 256), S = the pixels of `level_hw`'s
+    levels side by side; image: mlp2_frustum_image.  No (R, S, 192) frustum tensor is written or read."""
+    lib = _lib.load()
+    k1, h, n2 = image.shape_khn
+    r = img2lidar.shape[0]
+    nl = len(level_hw)
+    s_tot = sum(int(a) * int(b) for a, b in level_hw)
+    if k1 != 3 * depth_num or n2 != 256:
+        raise ValueError(f'mlp2_frustum_fwd: the image is {k1} -> {h} -> {n2}, the frustum has {3 * depth_num} channels')
+    if out is None:
+        out = torch.empty(r, s_tot, n2, device=img2lidar.device, dtype=torch.float32)
+    elif out.numel() != r * s_tot * n2:
+        raise ValueError('mlp2_frustum_fwd: out must hold (R, S, 256)')
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for hw in level_hw for x in hw])
+    rng = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    code = lib.gd4d_mlp2_frustum_fwd(_dev(img2lidar, 'img2lidar', torch.float32), lv, nl, r, float(pad_hw[0]), float(pad_hw[1]),
+                                     int(depth_num), float(depth_start), rng, _dev(image, 'image', torch.uint8), _opt(b2, 'b2'),
+                                     _dev(out, 'out', torch.float32), h, n2, _stream())
+    _lib.check(code, 'gd4d_mlp2_frustum_fwd')
+    return out.view(r, s_tot, n2)
+
+
 _TN_WS = {}
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 53
+#define GD4D_ABI_VERSION 54
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -734,6 +734,18 @@ int gd4d_mlp2_bf16x3_fwd(const float* x, const void* image, const float* b2, flo
  * gd4d_se_fuse_chlast_fwd (two 757-MB intermediates at 24 cameras).  C = 256, H % 32 == 0. */
 int gd4d_mlp2_se_fuse_fwd(const void* const* feats, const int32_t* level_hw, int L, int R, const void* image, const float* b2,
                           const float* pe, const float* sine, void* const* outs, int C, int H, void* stream);
+/* gd4d_mlp2_frustum_fwd - position_encoder(frustum coordinates) as ONE kernel that reads no X: gd4d_frustum_pe_input_fwd's arithmetic
+ * (dense_heads/detr3d_head_pe.py:427-491: pixel centre x depth bin -> lidar frame by the camera's img2lidar -> pc_range units ->
+ * inverse_sigmoid; operation for operation) runs in the MLP's prologue - the 3 D = 192 inputs of a row are a function of 12 matrix
+ * entries and the pixel index, generated in registers where gd4d_mlp2_bf16x3_fwd loads them; the (R, S, 192) tensor between the two
+ * kernels (568 MB written and read at 24 cameras) is gone.  img2lidar (R, 16); level_hw: L <= 4 levels laid side by side (row m =
+ * r S + start_l + y W_l + x); pad_h / pad_w, D (64 only), depth_start, pc_range: as gd4d_frustum_pe_input_fwd; image: gd4d_mlp2_image of
+ * W1 with its COLUMNS PERMUTED - column 16 st + 8 kg + e of the image's W1 is column 96 kg + 8 st + e of position_encoder[0]'s weight
+ * (a lane then holds depth bins 32 kg .. 32 kg + 31: the axis of each register is a compile-time constant) -, b1, W2; out (R S, 256),
+ * row stride ldo.  Same values as the two kernels up to the summation order of the first product. */
+int gd4d_mlp2_frustum_fwd(const float* img2lidar, const int32_t* level_hw, int L, int R, float pad_h, float pad_w, int D,
+                          float depth_start, const double* pc_range, const void* image, const float* b2, float* out, int H, int ldo,
+                          void* stream);
 
 /* gd4d_adamw_flat - the optimizer step of the reference's training recipe over ONE flat fp32 parameter / gradient buffer: clipping
  * of the gradient's L2 norm (torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: none) followed by

@@ -89,8 +89,10 @@ def test_position_embedding_is_kept_per_camera_and_follows_the_matrices():
     feats = [f.cuda() for f in g.feats()]
     metas = _metas(g)
     rows = []
-    real = ops.mlp2_bf16x3_fwd
+    real, real_fr = ops.mlp2_bf16x3_fwd, ops.mlp2_frustum_fwd
     ops.mlp2_bf16x3_fwd = lambda x, *a, **k: (rows.append(x.shape[0]), real(x, *a, **k))[1]
+    ops.mlp2_frustum_fwd = lambda i2l, shapes, *a, **k: (rows.append(i2l.shape[0] * sum(h * w for h, w in shapes)),
+                                                         real_fr(i2l, shapes, *a, **k))[1]
     try:
         with torch.no_grad():
             first = mod(feats, metas)
@@ -127,7 +129,7 @@ def test_position_embedding_is_kept_per_camera_and_follows_the_matrices():
             assert len(rows) == count + 1 and rows[-1] == n * s_tot * feats[0].shape[0]
             assert not torch.equal(upd[0], got[0])
     finally:
-        ops.mlp2_bf16x3_fwd = real
+        ops.mlp2_bf16x3_fwd, ops.mlp2_frustum_fwd = real, real_fr
 
 
 @pytest.mark.parametrize('levels,r', [([(7, 9), (5, 3), (3, 3)], 3), ([(16, 28), (8, 14), (4, 7), (2, 4)], 2), ([(5, 5)], 1), ([(29, 50), (15, 25)], 5)])
@@ -405,6 +407,39 @@ def test_fused_two_layer_mlp_matches_fp64(m, k1, h):
     if hid is not None:                                  # ... and as close to fp64 as the two-GEMM route is
         two = ops.gemm_bf16x3_fwd(hid, *ops.split_bf16_fwd(w2.cuda()), b2.cuda())
         assert (got.cpu() - want).abs().max() <= 2 * (two.cpu() - want).abs().max() + 1e-6
+
+
+@pytest.mark.parametrize('levels,r', [([(7, 9), (5, 3), (3, 3)], 3), ([(16, 28), (8, 14), (4, 7), (2, 4)], 6), ([(5, 5)], 1), ([(29, 50), (15, 25)], 5)])
+def test_frustum_inputs_generated_inside_the_mlp_equal_the_two_kernels(levels, r):
+    """gd4d_mlp2_frustum_fwd (the frustum coordinates generated in the MLP's prologue, no (R, S, 192) tensor) against
+    gd4d_frustum_pe_input_fwd -> gd4d_mlp2_bf16x3_fwd: the same inputs operation for operation, the first product summed in another
+    order (1e-4), and against fp64 on the frustum kernel's inputs (2e-4: the MLP's own bound); level sizes that put camera and level
+    boundaries inside a 128-row tile; run-to-run identical; the rows of `out=` views."""
+    from graph_detr4d_amd import ops, synthetic
+    torch.manual_seed(len(levels) + r)
+    rig = synthetic.camera_rig((r + 5) // 6)[:r].astype(np.float64)
+    i2l = torch.from_numpy(np.linalg.inv(rig).astype(np.float32)).cuda()
+    pad_hw = (928, 1600)
+    w1, b1 = torch.randn(1024, 192) / 192 ** 0.5, torch.randn(1024) * 0.1
+    w2, b2 = torch.randn(256, 1024) / 32, torch.randn(256) * 0.1
+    s_tot = sum(h * w for h, w in levels)
+    x = torch.empty(r, s_tot, 192, device='cuda')
+    st = 0
+    for h, w in levels:
+        ops.frustum_pe_input_fwd(i2l, (h, w), pad_hw, 64, 1.0, synthetic.PC_RANGE, out=x, row_start=st)
+        st += h * w
+    two = ops.mlp2_bf16x3_fwd(x.view(r * s_tot, -1), ops.mlp2_image(w1.cuda(), b1.cuda(), w2.cuda()), b2.cuda()).view(r, s_tot, 256)
+    img = ops.mlp2_frustum_image(w1.cuda(), b1.cuda(), w2.cuda())
+    got = ops.mlp2_frustum_fwd(i2l, levels, pad_hw, 64, 1.0, synthetic.PC_RANGE, img, b2.cuda())
+    assert got.shape == (r, s_tot, 256)
+    torch.testing.assert_close(got, two, rtol=1e-5, atol=1e-4)
+    want = (torch.relu(x.cpu().double().view(-1, 192) @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()).float()
+    torch.testing.assert_close(got.cpu().view(-1, 256), want, rtol=2e-4, atol=2e-4)
+    assert torch.equal(ops.mlp2_frustum_fwd(i2l, levels, pad_hw, 64, 1.0, synthetic.PC_RANGE, img, b2.cuda()), got)
+    if r > 2:                                                     # a run of cameras written into their rows of a kept tensor
+        kept = torch.full((r, s_tot, 256), float('nan'), device='cuda')
+        ops.mlp2_frustum_fwd(i2l[1:3], levels, pad_hw, 64, 1.0, synthetic.PC_RANGE, img, b2.cuda(), out=kept[1:3])
+        assert torch.equal(kept[1:3], got[1:3]) and torch.isnan(kept[0]).all()
 
 
 def test_kept_embedding_across_streams_static_rig_and_updates():
