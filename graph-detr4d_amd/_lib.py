@@ -108,6 +108,8 @@ SIGNATURES = {
     'gd4d_mlp2_bf16x3_fwd': (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
     'gd4d_mlp2_se_fuse_fwd': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'gd4d_mlp2_frustum_fwd': (_i, [_vp, _vp, _i, _i, _c.c_float, _c.c_float, _i, _c.c_float, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'gd4d_mlp2_pe_se_fwd': (_i, [_vp, _vp, _vp, _i, _i, _c.c_float, _c.c_float, _i, _c.c_float, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp,
+                                  _vp, _vp]),
     'gd4d_adamw_flat_workspace_bytes': (_c.c_size_t, []),
     'gd4d_adamw_flat': (_i, [_vp] * 6 + [_c.c_size_t, _c.c_int64] + [_f] * 6 + [_vp]),
     'gd4d_chain_weight_image_bytes': (_c.c_size_t, [_i, _i]),

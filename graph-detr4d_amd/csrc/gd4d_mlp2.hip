@@ -381,6 +381,240 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gd4d_mlp2_pe_se_fwd: BOTH MLPs of the head's position embedding and the fuse in one kernel, for cameras whose embedding is not kept
+// (the past-frame cameras of the temporal pattern - their matrices carry the ego motion and change with every sample - or every
+// camera): per tile of 128 pixels
+//     pe   = position_encoder(frustum coordinates)          192 -> 1024 -> 256, the inputs generated in registers (Mlp2Fr)
+//     gate = conv_expand(relu(conv_reduce(feat)))           256 ->  256 -> 256, the inputs read from the NCHW maps (Mlp2Se)
+//     out  = feat + (pe * sigmoid(gate) + sine)             channels-last, the layout the decoder gathers in place
+// The two products share the accumulator layout (a lane = one output channel of a tile of 32, 16 rows), so `pe` never leaves the
+// registers: 128 of them wait while the second MLP runs.  Against gd4d_mlp2_frustum_fwd + gd4d_mlp2_se_fuse_fwd the (R S, 256)
+// embedding between them - 757 MB written and read at 24 cameras - does not exist.  Registers: 128 (pe) + 128 (gate) + 128 (the
+// maps' rows, bf16 hi / lo) + fragments: one wave per SIMD, as both kernels it is made of.  LDS: the larger of the two stage pairs.
+// A phase = one MLP's walk over its hidden chunks (mlp2_kernel's chunk body, one tile per workgroup, no ring across tiles).
+template <int STEPS1>
+__device__ __forceinline__ void ml_phase(const char* __restrict__ w1img, const char* __restrict__ w2img, const int nchunks, char* smem,
+                                         const ml_u32x4 (&xh)[STEPS1], const ml_u32x4 (&xl)[STEPS1], ml_f32x16 (&acc)[ML_NT],
+                                         const int wave, const int lane) {
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void glb_void_t;
+  constexpr int S1 = STEPS1 * 2048 + 1024;
+  constexpr int STAGE = S1 + ML_S2;
+  constexpr int n1 = S1 >> 10, npieces = STAGE >> 10;
+  constexpr int PER_WAVE = (npieces + ML_WAVES - 1) / ML_WAVES;
+  const int kg = lane >> 5;
+  auto stage_piece = [&](int c, int buf, int k) {
+    const int i = wave + ML_WAVES * k;
+    if (i >= npieces) return;
+    const char* src = i < n1 ? w1img + (size_t)c * S1 + ((size_t)i << 10) : w2img + (size_t)c * ML_S2 + ((size_t)(i - n1) << 10);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(src + lane * 16), (lds_void_t*)(smem + buf * STAGE + (i << 10)), 16, 0, 0);
+  };
+  __syncthreads();                                     // (the previous phase's stages are done with)
+  for (int k = 0; k < PER_WAVE; ++k) stage_piece(0, 0, k);
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool more = c + 1 < nchunks;
+    const char* s1 = smem + (c & 1) * STAGE;
+    const char* s2 = s1 + S1;
+    ml_f32x16 h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[r] = 0.f;
+    const char* f1 = s1 + lane * 16;
+    ml_u32x4 wh = *reinterpret_cast<const ml_u32x4*>(f1), wl = *reinterpret_cast<const ml_u32x4*>(f1 + 1024);
+#pragma unroll
+    for (int st = 0; st < STEPS1; ++st) {
+      ml_u32x4 nh = wh, nl = wl;
+      if (st + 1 < STEPS1) {
+        nh = *reinterpret_cast<const ml_u32x4*>(f1 + (st + 1) * 2048);
+        nl = *reinterpret_cast<const ml_u32x4*>(f1 + (st + 1) * 2048 + 1024);
+      }
+      h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wl), ml_frag(xh[st]), h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xl[st]), h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(wh), ml_frag(xh[st]), h, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      wh = nh; wl = nl;
+    }
+    ml_u32x4 ah[2], al[2];
+    {
+      const float* b1c = reinterpret_cast<const float*>(s1 + STEPS1 * 2048);
+      float4 bq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const float4*>(b1c + 4 * kg + 8 * j);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 ba = bq[2 * s], bb = bq[2 * s + 1];
+        const float v[8] = {fmaxf(h[8 * s] + ba.x, 0.f), fmaxf(h[8 * s + 1] + ba.y, 0.f), fmaxf(h[8 * s + 2] + ba.z, 0.f),
+                            fmaxf(h[8 * s + 3] + ba.w, 0.f), fmaxf(h[8 * s + 4] + bb.x, 0.f), fmaxf(h[8 * s + 5] + bb.y, 0.f),
+                            fmaxf(h[8 * s + 6] + bb.z, 0.f), fmaxf(h[8 * s + 7] + bb.w, 0.f)};
+        ml_split8(v, ah[s], al[s]);
+      }
+    }
+    constexpr int GROUPS = 2 * ML_NT;
+    const char* f2 = s2 + lane * 16;
+    ml_u32x4 vh = *reinterpret_cast<const ml_u32x4*>(f2), vl = *reinterpret_cast<const ml_u32x4*>(f2 + 1024);
+#pragma unroll
+    for (int grp = 0; grp < GROUPS; ++grp) {
+      const int s = grp / ML_NT, t = grp % ML_NT;
+      ml_u32x4 nh = vh, nl = vl;
+      if (grp + 1 < GROUPS) {
+        const int s_n = (grp + 1) / ML_NT, t_n = (grp + 1) % ML_NT;
+        nh = *reinterpret_cast<const ml_u32x4*>(f2 + ((t_n * 2 + s_n) * 2) * 1024);
+        nl = *reinterpret_cast<const ml_u32x4*>(f2 + ((t_n * 2 + s_n) * 2) * 1024 + 1024);
+      }
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(al[s]), ml_frag(vh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vl), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vh), acc[t], 0, 0, 0);
+      if (more && grp < PER_WAVE) stage_piece(c + 1, (c + 1) & 1, grp);
+      __builtin_amdgcn_sched_barrier(0);
+      vh = nh; vl = nl;
+    }
+    if (more)
+      for (int k = GROUPS; k < PER_WAVE; ++k) stage_piece(c + 1, (c + 1) & 1, k);
+  }
+}
+
+struct Mlp2PeSe {
+  const char* pe_w1; const char* pe_w2; const float* pe_b2; int pe_h;       // position_encoder: gd4d_mlp2_image of (W1 permuted, b1, W2)
+  const char* se_w1; const char* se_w2; const float* se_b2; int se_h;       // SELayer: conv_reduce / conv_expand
+  float* pe_out;                                                            // (R S, 256) or NULL: the embedding, if somebody keeps it
+  int M;
+};
+
+__global__ __launch_bounds__(ML_THREADS, 1) void mlp2_pe_se_kernel(const Mlp2PeSe p, const Mlp2Se q, const Mlp2Fr fr) {
+  extern __shared__ __attribute__((aligned(16))) char ml_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, kg = lane >> 5;
+  const int m0 = blockIdx.x * ML_BM + wave * 32;
+  const int m = min(m0 + l32, p.M - 1);
+  // ---- position_encoder(frustum): the inputs generated (mlp2_kernel's frustum form) ----
+  ml_f32x16 pe[ML_NT];
+#pragma unroll
+  for (int t = 0; t < ML_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pe[t][r] = 0.f;
+  {
+    ml_u32x4 fh[12], fl[12];
+    {
+      const int r = m / fr.S;
+      const int rem = m - r * fr.S;
+      const int l = (rem >= fr.start[1]) + (rem >= fr.start[2]) + (rem >= fr.start[3]);
+      const int pix = rem - fr.start[l];
+      const int W = fr.w[l], H = fr.h[l];
+      const int y = pix / W, x = pix - y * W;
+      const float* mt = fr.i2l + (size_t)r * 16;
+      float mm[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) mm[i] = mt[i];
+      const float ch = ((float)y * fr.pad_h) / (float)H;
+      const float cw = ((float)x * fr.pad_w) / (float)W;
+      const float fi0 = kg ? 32.0f : 0.0f;
+      float xf[12][8];
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) {
+        const float fi = fi0 + (float)dd;
+        const float depth = fr.depth_start + (fr.bin_size * fi) * (fi + 1.0f);
+        const float sdep = fmaxf(depth, 1e-5f);
+        const float px = cw * sdep, py = ch * sdep;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float v = ((mm[4 * k] * px + mm[4 * k + 1] * py) + mm[4 * k + 2] * depth) + mm[4 * k + 3];
+          const float c = (v - fr.lo[k]) / fr.span[k];
+          const int j = 3 * dd + k;
+          xf[j >> 3][j & 7] = ml_inv_sigmoid_fast(c);
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 12; ++st) ml_split8(xf[st], fh[st], fl[st]);
+    }
+    ml_phase<12>(p.pe_w1, p.pe_w2, p.pe_h / ML_HC, ml_smem, fh, fl, pe, wave, lane);
+  }
+#pragma unroll
+  for (int t = 0; t < ML_NT; ++t) {
+    const float bv = p.pe_b2 ? p.pe_b2[32 * t + l32] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pe[t][r] += bv;
+  }
+  if (p.pe_out) {
+#pragma unroll
+    for (int t = 0; t < ML_NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mr = m0 + ml_hidden_of(kg, r);
+        if (mr < p.M) p.pe_out[(size_t)mr * ML_N2 + 32 * t + l32] = pe[t][r];
+      }
+  }
+  // ---- the gate ----
+  ml_f32x16 acc[ML_NT];
+#pragma unroll
+  for (int t = 0; t < ML_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  {
+    float xr[16][8];
+    {
+      const Mlp2Row g = ml_row_of(q, m);
+      const float* xc = g.f + (size_t)(8 * kg) * g.hw + g.pix;
+#pragma unroll
+      for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[st][e] = xc[(size_t)(16 * st + e) * g.hw];
+    }
+    ml_u32x4 xh[16], xl[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) ml_split8(xr[st], xh[st], xl[st]);
+    ml_phase<16>(p.se_w1, p.se_w2, p.se_h / ML_HC, ml_smem, xh, xl, acc, wave, lane);
+  }
+  // ---- out = feat + (pe * sigmoid(gate) + sine): mlp2_kernel's SE epilogue with pe in registers ----
+  typedef float ml_f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mj = m0 + 4 * kg + 8 * j;
+    if (mj >= p.M) continue;
+    const Mlp2Row g = ml_row_of(q, mj);
+    const bool whole = g.pix + 3 < g.hw && mj + 3 < p.M;
+    if (whole) {
+      ml_f4u f4[ML_NT];
+      float sv[ML_NT][4];
+#pragma unroll
+      for (int t = 0; t < ML_NT; ++t) {
+        const int n = 32 * t + l32;
+        f4[t] = *reinterpret_cast<const ml_f4u*>(g.f + (size_t)n * g.hw + g.pix);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[t][i] = q.sine[(size_t)(mj + i) * ML_N2 + n];
+      }
+#pragma unroll
+      for (int t = 0; t < ML_NT; ++t) {
+        const int n = 32 * t + l32;
+        const float bv = p.se_b2 ? p.se_b2[n] : 0.f;
+        const float fv[4] = {f4[t].x, f4[t].y, f4[t].z, f4[t].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gate = acc[t][4 * j + i] + bv;
+          g.o[(size_t)(g.pix + i) * ML_N2 + n] = fv[i] + (pe[t][4 * j + i] * ml_sigmoid(gate) + sv[t][i]);
+        }
+      }
+      continue;
+    }
+    for (int i = 0; i < 4; ++i) {                         // a group across the end of a level / camera / the rows: pixel by pixel
+      const int mi = mj + i;
+      if (mi >= p.M) break;
+      const Mlp2Row gi = ml_row_of(q, mi);
+#pragma unroll
+      for (int t = 0; t < ML_NT; ++t) {
+        const int n = 32 * t + l32;
+        float a = 0.f, pv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a = i == k ? acc[t][4 * j + k] : a; pv = i == k ? pe[t][4 * j + k] : pv; }
+        const float gate = a + (p.se_b2 ? p.se_b2[n] : 0.f);
+        gi.o[(size_t)gi.pix * ML_N2 + n] = gi.f[(size_t)n * gi.hw + gi.pix] + (pv * ml_sigmoid(gate) + q.sine[(size_t)mi * ML_N2 + n]);
+      }
+    }
+  }
+}
+
 // One thread per 16-byte piece of the two images.
 //   W1 image  [chunk]{[step of 16 inputs][plane hi / lo][lane 64][8 bf16], 1 KB: b1[32 chunk .. + 32]}:   lane (l32, kg), element e = W1[32 chunk + l32][16 step + 8 kg + e]
 //   W2 image  [chunk][tile of 32 outputs][step s][plane][lane 64][8 bf16]:  element e = W2[32 tile + l32][32 chunk + hidden_of(kg, 8 s + e)]
@@ -545,5 +779,46 @@ extern "C" int gd4d_mlp2_frustum_fwd(const float* img2lidar, const int32_t* leve
   auto kern = mlp2_kernel<12, false, true>;
   if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, none, fr);
+  return check_launch();
+}
+
+// See mlp2_pe_se_kernel.  pe_image: gd4d_mlp2_image of (position_encoder[0]'s weight with its columns permuted as gd4d_mlp2_frustum_fwd
+// takes it, its bias, position_encoder[2]'s weight); se_image: as gd4d_mlp2_se_fuse_fwd; the geometry arguments as gd4d_mlp2_frustum_fwd,
+// feats / sine / outs as gd4d_mlp2_se_fuse_fwd.  pe_out: NULL, or (R S, 256) to keep the embedding as well.
+extern "C" int gd4d_mlp2_pe_se_fwd(const float* img2lidar, const void* const* feats, const int32_t* level_hw, int L, int R, float pad_h,
+                                   float pad_w, int D, float depth_start, const double* pc_range, const void* pe_image,
+                                   const float* pe_b2, int pe_H, const void* se_image, const float* se_b2, int se_H, const float* sine,
+                                   void* const* outs, float* pe_out, void* stream) {
+  using namespace gd4d;
+  if (!img2lidar || !feats || !level_hw || !pc_range || !pe_image || !se_image || !sine || !outs || L <= 0 || R <= 0) return GD4D_EINVAL;
+  const int K1 = 3 * D, C = ML_N2;
+  if (L > 4 || D != 64 || !mlp2_shape_ok(K1, pe_H, C) || !mlp2_shape_ok(C, se_H, C)) return GD4D_EUNSUPPORTED;
+  if (!aligned16(pe_image) || !aligned16(se_image)) return GD4D_EALIGN;
+  Mlp2Fr fr{};
+  Mlp2Se q{};
+  long long S = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int ll = l < L ? l : 0;
+    if (l < L && (!feats[l] || !outs[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0)) return GD4D_EINVAL;
+    fr.h[l] = level_hw[2 * ll]; fr.w[l] = level_hw[2 * ll + 1]; fr.hw[l] = fr.h[l] * fr.w[l];
+    q.feat[l] = static_cast<const float*>(feats[ll]); q.out[l] = static_cast<float*>(outs[ll]); q.hw[l] = fr.hw[l];
+    fr.start[l] = q.start[l] = (int)S;
+    if (l < L) S += fr.hw[l];
+  }
+  for (int l = L; l <= 4; ++l) fr.start[l] = q.start[l] = (int)S;
+  if (S * R >= (1ll << 31)) return GD4D_EUNSUPPORTED;
+  fr.S = q.S = (int)S; q.sine = sine; q.pe = nullptr;
+  fr.i2l = img2lidar; fr.pad_h = pad_h; fr.pad_w = pad_w; fr.depth_start = depth_start;
+  fr.bin_size = (float)((pc_range[3] - (double)depth_start) / ((double)D * (1.0 + (double)D)));
+  for (int k = 0; k < 3; ++k) { fr.lo[k] = (float)pc_range[k]; fr.span[k] = (float)(pc_range[k + 3] - pc_range[k]); }
+  const int M = (int)(S * R);
+  const char* pi = static_cast<const char*>(pe_image);
+  const char* si = static_cast<const char*>(se_image);
+  Mlp2PeSe p{pi, pi + (size_t)pe_H * K1 * 4 + (size_t)(pe_H / ML_HC) * 1024, pe_b2, pe_H,
+             si, si + (size_t)se_H * C * 4 + (size_t)(se_H / ML_HC) * 1024, se_b2, se_H, pe_out, M};
+  const int lds = 2 * (16 * 2048 + 1024 + ML_S2);                  // the second MLP's stage pair (the larger)
+  auto kern = mlp2_pe_se_kernel;
+  if (!allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return GD4D_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(mlp2_grid(M)), dim3(ML_THREADS), lds, static_cast<hipStream_t>(stream), p, q, fr);
   return check_launch();
 }

@@ -167,6 +167,8 @@ class FeaturePositionEmbedding(nn.Module):
         self._mask_cache = None
         self._split_cache = None
         self._pe_cache = None
+        self._pe_stale = set()      # cameras whose rows of the kept embedding were not written by the last call (_forward_one_kernel)
+        self._pe_moving = set()     # cameras whose matrix changed between the last two calls
         self._pe_read = {}          # stream -> event: the last read of the kept embedding on that stream
         self._pe_written = None     # event: the last (re)computation / in-place update of the kept embedding
         self._i2l = {}              # (device, request slot, R) -> [host matrices, (R, 4, 4) device tensor]: _matrices_device
@@ -321,6 +323,9 @@ class FeaturePositionEmbedding(nn.Module):
         # from sample to sample (the past frames' matrices carry the ego motion and change every time).
         b2 = self.position_encoder[2].bias
         pkey = (str(dev), tuple(shapes), tuple(pad_hw), r, sw['key'], b2.data_ptr(), b2._version)
+        if self.channels_last_out and sw.get('se_mlp') is not None and sw.get('pe_mlp_fr') is not None and len(feats) <= 4 \
+                and os.environ.get('GD4D_PE_FUSED', '1') != '0':
+            return self._forward_one_kernel(feats, mats, sw, sine, shapes, starts, s_tot, pad_hw, pkey)
         c = self._pe_cache if self.cache_position_embedding else None
         if c is not None and c[0] == pkey:
             changed = [i for i in range(r) if not np.array_equal(mats[i], c[1][i])]
@@ -384,6 +389,79 @@ class FeaturePositionEmbedding(nn.Module):
             out.append(o.unflatten(0, (b, n)) if self.channels_last_out else o.view(f.shape))
         self._mark_pe_read(dev)
         return out
+
+    @staticmethod
+    def _runs(idx):
+        """Sorted camera indices -> the contiguous runs [a, e) they form."""
+        runs = []
+        for i in idx:
+            if runs and runs[-1][1] == i:
+                runs[-1][1] = i + 1
+            else:
+                runs.append([i, i + 1])
+        return [tuple(x) for x in runs]
+
+    def _forward_one_kernel(self, feats, mats, sw, sine, shapes, starts, s_tot, pad_hw, pkey):
+        """The channels-last route with both MLPs in ONE kernel for the cameras that keep moving (gd4d_mlp2_pe_se_fwd: the embedding of
+        such a camera is used once - it stays in the kernel's registers and is never stored).  Per camera:
+          matrix unchanged, rows valid           -> kept: SE gate + fuse on the kept rows (gd4d_mlp2_se_fuse_fwd)
+          changed now AND between the last two calls (the past frames of the temporal pattern: their matrices carry the ego motion)
+                                                 -> one kernel, nothing stored; its kept rows are stale from then on
+          changed for the first time, or stale and no longer moving
+                                                 -> recomputed INTO the kept tensor (gd4d_mlp2_frustum_fwd), then as a kept camera
+        cache_position_embedding = False: every camera through the one kernel, no (R, S, 256) tensor at all.  The same values bit for
+        bit whichever way a camera goes (tested)."""
+        b, n = feats[0].shape[:2]
+        r = b * n
+        dev = feats[0].device
+        cur = torch.cuda.current_stream(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        keep = self.cache_position_embedding
+        c = self._pe_cache if keep else None
+        if c is not None and c[0] != pkey:
+            c = None
+        if c is None:
+            self._pe_stale, self._pe_moving = set(), set()
+            really, need = set(), set(range(r))
+        else:
+            really = {i for i in range(r) if not np.array_equal(mats[i], c[1][i])}
+            need = really | self._pe_stale
+        fused = sorted(need) if not keep else sorted(i for i in need if i in really and i in self._pe_moving)
+        store = sorted(need - set(fused))
+        if c is not None and self._pe_written is not None and not capturing:
+            cur.wait_event(self._pe_written)                     # (see _forward_gemm)
+        i2l_all = self._matrices_device(mats, dev, capturing)
+        pe = None if c is None else c[2]
+        if store:
+            if pe is None:
+                pe = torch.empty(r, s_tot, self.embed_dims, device=dev, dtype=torch.float32)
+                self._pe_read = {}
+            elif not capturing:
+                for ev in self._pe_read.values():                # in place: after every outstanding read of the kept tensor
+                    cur.wait_event(ev)
+            for a, e in self._runs(store):
+                self._position_mlp(i2l_all[a:e], shapes, starts, s_tot, pad_hw, sw, out=pe[a:e])
+            if not capturing:
+                self._pe_written = torch.cuda.Event()
+                self._pe_written.record(cur)
+        if keep:
+            self._pe_cache = (pkey, mats, pe)
+            self._pe_moving, self._pe_stale = really, set(fused)
+        else:
+            self._pe_cache = None
+        ce, b2 = self.fpe.conv_expand, self.position_encoder[2].bias
+        flat = [f.flatten(0, 1).contiguous() for f in feats]
+        outs = [torch.empty(r, h, w, self.embed_dims, device=dev, dtype=torch.float32) for h, w in shapes]
+        sine = sine.view(r, s_tot, -1)
+        for a, e in self._runs(fused):
+            ops.mlp2_pe_se_fwd(i2l_all[a:e], [f[a:e] for f in flat], pad_hw, self.depth_num, self.depth_start, self.pc_range,
+                               sw['pe_mlp_fr'], b2, sw['se_mlp'], ce.bias, sine[a:e], outs=[o[a:e] for o in outs])
+        kept = sorted(set(range(r)) - set(fused))
+        for a, e in self._runs(kept):
+            ops.mlp2_se_fuse_fwd([f[a:e] for f in flat], sw['se_mlp'], ce.bias, pe[a:e], sine[a:e], outs=[o[a:e] for o in outs])
+        if kept:
+            self._mark_pe_read(dev)
+        return [o.permute(0, 3, 1, 2).unflatten(0, (b, n)) for o in outs]
 
     def _matrices_device(self, mats, dev, capturing=False):
         """The (R, 4, 4) img2lidar matrices on the device: ONE persistent buffer per (device, request slot, R), refreshed in place when
@@ -493,6 +571,7 @@ class FeaturePositionEmbedding(nn.Module):
         the weights - inside a replayed hipGraph without bumping the version counters the caches are keyed by."""
         if mode != self.training:
             self._pe_cache, self._pe_read, self._pe_written, self._split_cache = None, {}, None, None
+            self._pe_stale, self._pe_moving = set(), set()
         return super().train(mode)
 
     def forward(self, mlvl_feats, img_metas):

@@ -1481,10 +1481,44 @@ def mlp2_bf16x3_fwd(x, image, b2=None, out=None):
     return out
 
 
-def mlp2_se_fuse_fwd(feats, image, b2, pe, sine):
+def mlp2_pe_se_fwd(img2lidar, feats, pad_hw, depth_num, depth_start, pc_range, pe_image, pe_b2, se_image, se_b2, sine, outs=None,
+                   pe_out=None):
+    """gd4d_mlp2_pe_se_fwd: position_encoder(frustum) and the SE gate + fuse in one kernel - mlp2_frustum_fwd + mlp2_se_fuse_fwd without
+    the (R, S, 256) embedding between them.  feats: L levels (R, 256, H_l, W_l) NCHW of the cameras of img2lidar (R, 4, 4); sine
+    (R, S, 256); outs: L (R, H_l, W_l, 256) tensors to write (made when None); pe_out (R, S, 256): store the embedding as well.
+    Returns the levels as (R, 256, H_l, W_l) views of channels-last memory."""
+    lib = _lib.load()
+    f32 = torch.float32
+    k1, pe_h, n2 = pe_image.shape_khn
+    sk, se_h, sn = se_image.shape_khn
+    nl = len(feats)
+    r = img2lidar.shape[0]
+    if k1 != 3 * depth_num or n2 != 256 or sk != 256 or sn != 256 or any(f.shape[0] != r or f.shape[1] != 256 or f.dim() != 4 for f in feats):
+        raise ValueError('mlp2_pe_se_fwd: a 3 D -> H -> 256 image, a 256 -> H -> 256 image and (R, 256, H, W) levels expected')
+    s_tot = sum(f.shape[2] * f.shape[3] for f in feats)
+    if sine.numel() != r * s_tot * 256 or (pe_out is not None and pe_out.numel() != r * s_tot * 256):
+        raise ValueError(f'mlp2_pe_se_fwd: sine / pe_out must hold ({r}, {s_tot}, 256)')
+    if outs is None:
+        outs = [torch.empty(r, f.shape[2], f.shape[3], 256, device=f.device, dtype=f32) for f in feats]
+    elif any(tuple(o.shape) != (r, f.shape[2], f.shape[3], 256) for o, f in zip(outs, feats)):
+        raise ValueError('mlp2_pe_se_fwd: outs must be (R, H_l, W_l, 256) per level')
+    fp = (ctypes.c_void_p * nl)(*[_dev(f, 'feats', f32).value for f in feats])
+    op = (ctypes.c_void_p * nl)(*[_dev(o, 'outs', f32).value for o in outs])
+    lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[2:]])
+    rng = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    code = lib.gd4d_mlp2_pe_se_fwd(_dev(img2lidar, 'img2lidar', f32), fp, lv, nl, r, float(pad_hw[0]), float(pad_hw[1]), int(depth_num),
+                                   float(depth_start), rng, _dev(pe_image, 'pe_image', torch.uint8), _opt(pe_b2, 'pe_b2'), pe_h,
+                                   _dev(se_image, 'se_image', torch.uint8), _opt(se_b2, 'se_b2'), se_h, _dev(sine, 'sine', f32), op,
+                                   None if pe_out is None else _dev(pe_out, 'pe_out', f32), _stream())
+    _lib.check(code, 'gd4d_mlp2_pe_se_fwd')
+    return [o.permute(0, 3, 1, 2) for o in outs]
+
+
+def mlp2_se_fuse_fwd(feats, image, b2, pe, sine, outs=None):
     """gd4d_mlp2_se_fuse_fwd: feats = L levels (R, 256, H_l, W_l) NCHW, image = mlp2_image(conv_reduce.weight, conv_reduce.bias,
     conv_expand.weight), b2 = conv_expand.bias, pe / sine (R, S, 256) channels-last rows of all levels side by side ->
-    L tensors feat + (pe * sigmoid(gate) + sine) as (R, 256, H_l, W_l) VIEWS of (R, H_l, W_l, 256) memory (channels-last levels)."""
+    L tensors feat + (pe * sigmoid(gate) + sine) as (R, 256, H_l, W_l) VIEWS of (R, H_l, W_l, 256) memory (channels-last levels;
+    outs: the L (R, H_l, W_l, 256) tensors to write)."""
     lib = _lib.load()
     k1, h, n2 = image.shape_khn
     nl = len(feats)
@@ -1495,9 +1529,12 @@ def mlp2_se_fuse_fwd(feats, image, b2, pe, sine):
     s_tot = sum(f.shape[2] * f.shape[3] for f in feats)
     if tuple(pe.shape) != (r, s_tot, 256) or tuple(sine.shape) != (r, s_tot, 256):
         raise ValueError(f'mlp2_se_fuse_fwd: pe / sine must be ({r}, {s_tot}, 256)')
-    outs = [torch.empty(r, f.shape[2], f.shape[3], 256, device=f.device, dtype=f32) for f in feats]
+    if outs is None:
+        outs = [torch.empty(r, f.shape[2], f.shape[3], 256, device=f.device, dtype=f32) for f in feats]
+    elif any(tuple(o.shape) != (r, f.shape[2], f.shape[3], 256) for o, f in zip(outs, feats)):
+        raise ValueError('mlp2_se_fuse_fwd: outs must be (R, H_l, W_l, 256) per level')
     fp = (ctypes.c_void_p * nl)(*[_dev(f, 'feats', f32).value for f in feats])
-    op = (ctypes.c_void_p * nl)(*[o.data_ptr() for o in outs])
+    op = (ctypes.c_void_p * nl)(*[_dev(o, 'outs', f32).value for o in outs])
     lv = (ctypes.c_int32 * (2 * nl))(*[int(x) for f in feats for x in f.shape[2:]])
     code = lib.gd4d_mlp2_se_fuse_fwd(fp, lv, nl, r, _dev(image, 'image', torch.uint8), _opt(b2, 'b2'), _dev(pe, 'pe', f32),
                                      _dev(sine, 'sine', f32), op, 256, h, _stream())

@@ -746,6 +746,16 @@ int gd4d_mlp2_se_fuse_fwd(const void* const* feats, const int32_t* level_hw, int
 int gd4d_mlp2_frustum_fwd(const float* img2lidar, const int32_t* level_hw, int L, int R, float pad_h, float pad_w, int D,
                           float depth_start, const double* pc_range, const void* image, const float* b2, float* out, int H, int ldo,
                           void* stream);
+/* gd4d_mlp2_pe_se_fwd - gd4d_mlp2_frustum_fwd and gd4d_mlp2_se_fuse_fwd as ONE kernel, for cameras whose embedding nobody keeps (the
+ * past-frame cameras of the temporal pattern, whose matrices change with every sample; or every camera): per tile of 128 pixels the
+ * position MLP's result waits in 128 registers while the gate's MLP runs, the epilogue is the head's fuse (:553-557) - the (R S, 256)
+ * embedding between the two kernels (757 MB written and read at 24 cameras) does not exist.  Arguments: the geometry of
+ * gd4d_mlp2_frustum_fwd (pe_image: its permuted image; pe_b2, pe_H), the maps / sine / outs of gd4d_mlp2_se_fuse_fwd (se_image, se_b2,
+ * se_H); pe_out: NULL, or (R S, 256) to store the embedding as well.  The same values as the two kernels bit for bit. */
+int gd4d_mlp2_pe_se_fwd(const float* img2lidar, const void* const* feats, const int32_t* level_hw, int L, int R, float pad_h,
+                        float pad_w, int D, float depth_start, const double* pc_range, const void* pe_image, const float* pe_b2,
+                        int pe_H, const void* se_image, const float* se_b2, int se_H, const float* sine, void* const* outs,
+                        float* pe_out, void* stream);
 
 /* gd4d_adamw_flat - the optimizer step of the reference's training recipe over ONE flat fp32 parameter / gradient buffer: clipping
  * of the gradient's L2 norm (torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: none) followed by
