@@ -109,7 +109,20 @@ def main():
         t_fz = timed(lambda: [ops.se_fuse_chlast_fwd(f.flatten(0, 1), pe_o.view(r, s_tot, 256), pe_o.view(r, s_tot, 256),
                                                      f.flatten(0, 1), s0) for f, s0 in zip(feats, st)])
         t_mlp = timed(lambda: ops.mlp2_bf16x3_fwd(xcl.view(r * s_tot, 192), sw['pe_mlp'], mod.position_encoder[2].bias, out=pe_o))
-    print(f'  fused position MLP 192->1024->256 (gd4d_mlp2_bf16x3_fwd) {t_mlp:.2f} ms')
+        t_fr_mlp = t_se_k = t_one = float('nan')
+        if sw.get('pe_mlp_fr') is not None and sw.get('se_mlp') is not None:
+            shp = [tuple(f.shape[-2:]) for f in feats]
+            sine = mod._sine_branch(masks, chlast=True).view(r, s_tot, 256)
+            fl4 = [f.flatten(0, 1).contiguous() for f in feats]
+            outs = [torch.empty(r, h, w, 256, device='cuda') for h, w in shp]
+            b2, ce = mod.position_encoder[2].bias, mod.fpe.conv_expand
+            t_fr_mlp = timed(lambda: ops.mlp2_frustum_fwd(i2l, shp, pad_hw, 64, 1, synthetic.PC_RANGE, sw['pe_mlp_fr'], b2, out=pe_o))
+            t_se_k = timed(lambda: ops.mlp2_se_fuse_fwd(fl4, sw['se_mlp'], ce.bias, pe_o.view(r, s_tot, 256), sine, outs=outs))
+            t_one = timed(lambda: ops.mlp2_pe_se_fwd(i2l, fl4, pad_hw, 64, 1, synthetic.PC_RANGE, sw['pe_mlp_fr'], b2, sw['se_mlp'], ce.bias,
+                                                     sine, outs=outs))
+    print(f'  position MLP 192->1024->256 reading its rows (gd4d_mlp2_bf16x3_fwd) {t_mlp:.2f} ms, generating them (gd4d_mlp2_frustum_fwd) '
+          f'{t_fr_mlp:.2f} ms; SE gate + fuse (gd4d_mlp2_se_fuse_fwd) {t_se_k:.2f} ms; both MLPs + fuse as one kernel (gd4d_mlp2_pe_se_fwd) '
+          f'{t_one:.2f} ms')
     print(f'  GEMM path pieces: frustum (channels-last) {t_frc:.2f}  GEMM 192->1024 {t_g1:.2f}  GEMM 1024->256 {t_g2:.2f}  '
           f'conv_reduce (value_proj kernel) {t_vp:.2f}  GEMM 256->256 {t_g3:.2f}  transposing fuse {t_fz:.2f} ms')
     flops = pixels * 2 * (192 * 1024 + 1024 * 256 + 2 * 256 * 256)
