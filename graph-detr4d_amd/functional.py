@@ -664,6 +664,7 @@ class LateValues:
         self.copy_dtype = torch.float32
         self.coarse = self.coarse_src = self.coarse_first = None
         self.partial = False
+        self.project_late = False
         self.waited = set()
         if all(ops.PyramidView.is_channels_last_level(v) for v in value) and len({v.dtype for v in value}) == 1 \
                 and value[0].dtype in (torch.float32, torch.bfloat16):
@@ -684,16 +685,23 @@ class LateValues:
         self.side = _companion_stream(_SIDE_STREAMS, dev)
         self.side.wait_stream(self.main)             # the pyramid was produced on the main stream
         with torch.cuda.stream(self.side):
-            # GD4D_COPY_CUS: compute units of the persistent copy (default 7/8 of the device - 192: 1.937, 224: 1.922, 256: 1.984, plain copy 2.000 ms per step - the query side of the
-            # first layer runs on the rest, underneath it); 0 = the plain one-workgroup-per-tile copy on all of them
+            # GD4D_COPY_CUS: compute units of the persistent copy (default 3/4 of the device: the query side of the first layer and the
+            # first projection of the coarse levels run on the rest, underneath it - round 6, samples/s one request / two in flight:
+            # 160: 646 / 798, 192: 656-658 / 807-810, 224: 657-659 / 785-789, 256: 659 / 778); 0 = the plain one-workgroup-per-tile copy
             env = os.environ.get('GD4D_COPY_CUS')
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            copy_cus = int(env) if env else max(8, (cus * 7 // 8) // 8 * 8)
+            copy_cus = int(env) if env else max(8, (cus * 3 // 4) // 8 * 8)
             src = [v.contiguous() for v in value]
             self.src, self.copy_cus, self.copy_dtype = src, copy_cus, dtype
             if self.mode == 'sliced':
                 if coarse_for and self.coarse_setup(coarse_for):
-                    self._project_first(coarse_for[0])
+                    # The first layer's projection of the coarse levels: on the MAIN stream behind plan 0 (aggregate), where that
+                    # stream would otherwise only wait for the copy - in front of the copy it was 19-26 us of the request's critical
+                    # path (one request at a time: 667 against 658 samples/s; two in flight: 786 against 808 - GD4D_FIRST_PROJ=side).
+                    if os.environ.get('GD4D_FIRST_PROJ', 'main') == 'main':
+                        self.coarse_first, self.project_late = coarse_for[0], True
+                    else:
+                        self._project_first(coarse_for[0])
                     self.coarse.rows.record_stream(self.main)
                     self.partial = True
                 if self.partial:
@@ -811,6 +819,9 @@ class LateValues:
             plan = ops.cross_attn_plan_fwd(self.pyramid, ref.contiguous(), offsets.contiguous(), attn_logits.contiguous(),
                                            cam_logits.contiguous(), lidar2img, module.pc_range, img_h, img_w, module.num_heads,
                                            query_order=order, items=items, raw_cam_weights=raw_cam_weights)
+            if coarse and self.project_late:
+                self.project_late = False
+                ops.value_proj_guest_fwd(self.coarse_guest(module))
             self._wait_copy()
             if coarse:
                 agg, pagg = ops.cross_attn_agg_coarse_fwd(plan, self.coarse)
