@@ -27,11 +27,22 @@
 // the requests pinned in front of the MFMAs by sched_group_barrier and the DMA as one burst between the phases (2.40), at the chunk's
 // start (2.25 - 2.28) or a piece at the head of every group (2.29).  Counters of this version (profiles/r05_pmc_mlp2.txt): matrix
 // pipe busy 37 %, waves parked at a counter / the barrier 33 % of their cycles, stalled at issue 38 %, active 29 %.
+// Round 6, what bounds it (timing builds, position MLP at 24 cameras, same box): as shipped 2.03 ms; without the stage DMA, its waits and
+// the barriers 1.77; additionally without the LDS fragment reads - the bare stream of 84 MFMAs + the ReLU / split per chunk - 1.69 ms,
+// i.e. 1.2 PFLOP/s of bf16 products is what this instruction stream reaches on the device under load; the kernel is at 83 % of that.
+// Two output tiles per phase-B group with their MFMAs alternating (the dependent-accumulate distance 2 instead of 1): 2.10 (slower;
+// 1.73 against 1.70 in the bare stream) - dependent accumulation is forwarded and costs nothing.
 #ifndef ML_DMA_IN_A
 #define ML_DMA_IN_A 0
 #endif
 #ifndef ML_TWO_ACC
 #define ML_TWO_ACC 0
+#endif
+#ifndef ML_AHEAD
+#define ML_AHEAD 1           // (ml_phase) groups of phase B whose fragments are in flight (2, 3: the same 2.94-2.97 ms)
+#endif
+#ifndef ML_SPLIT_WAIT
+#define ML_SPLIT_WAIT 1      // same box: position MLP 2.12-2.15 -> 2.08 ms, SE gate + fuse 1.30 -> 1.22 ms, the one-kernel form 2.89 = 2.89
 #endif
 
 namespace gd4d {
@@ -227,7 +238,11 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p,
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   for (int c = 0; c < nchunks; ++c, ++cc) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of this chunk's stage has landed
+    // A wave's pieces of a stage go out W1's first (7 - 9 of them), then W2's (8 per wave: 32 pieces, 4 waves) and complete in that
+    // order: the first product only needs W1's - waiting for all of them here exposed the round trip of pieces issued two or three
+    // MFMA groups ago (ML_SPLIT_WAIT=0: the single wait).
+    if (ML_SPLIT_WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of this chunk's stage has landed
     __syncthreads();                                   // ... everybody's has; and everybody is done with the other buffer
     const bool more = !(last_tile && c + 1 == nchunks);
     const int cn = c + 1 < nchunks ? c + 1 : 0;        // (the ring: behind a tile's last chunk comes the next tile's first)
@@ -286,6 +301,10 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp2_kernel(const Mlp2Params p,
       }
     }
     // ---- phase B: out += H W2c^T (step-major: the first step's MFMAs run while the second step's operand is still being split) ----
+    if (ML_SPLIT_WAIT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W2's pieces of this chunk
+      __syncthreads();
+    }
     constexpr int GROUPS = 2 * ML_NT;
     const char* f2 = s2 + lane * 16;
     ml_u32x4 vh = *reinterpret_cast<const ml_u32x4*>(f2), vl = *reinterpret_cast<const ml_u32x4*>(f2 + 1024);
@@ -413,7 +432,8 @@ __device__ __forceinline__ void ml_phase(const char* __restrict__ w1img, const c
   __syncthreads();                                     // (the previous phase's stages are done with)
   for (int k = 0; k < PER_WAVE; ++k) stage_piece(0, 0, k);
   for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ML_SPLIT_WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (W1's pieces: see mlp2_kernel)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool more = c + 1 < nchunks;
     const char* s1 = smem + (c & 1) * STAGE;
@@ -451,24 +471,34 @@ __device__ __forceinline__ void ml_phase(const char* __restrict__ w1img, const c
         ml_split8(v, ah[s], al[s]);
       }
     }
+    if (ML_SPLIT_WAIT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     constexpr int GROUPS = 2 * ML_NT;
     const char* f2 = s2 + lane * 16;
-    ml_u32x4 vh = *reinterpret_cast<const ml_u32x4*>(f2), vl = *reinterpret_cast<const ml_u32x4*>(f2 + 1024);
+    // group g's fragments: [tile][step][plane]; requested ML_AHEAD groups before their MFMAs
+    auto frag_at = [&](int g) -> const char* { return f2 + (((g % ML_NT) * 2 + g / ML_NT) * 2) * 1024; };
+    ml_u32x4 qh[ML_AHEAD + 1], ql[ML_AHEAD + 1];
+#pragma unroll
+    for (int a = 0; a < ML_AHEAD; ++a) {
+      qh[a] = *reinterpret_cast<const ml_u32x4*>(frag_at(a));
+      ql[a] = *reinterpret_cast<const ml_u32x4*>(frag_at(a) + 1024);
+    }
 #pragma unroll
     for (int grp = 0; grp < GROUPS; ++grp) {
       const int s = grp / ML_NT, t = grp % ML_NT;
-      ml_u32x4 nh = vh, nl = vl;
-      if (grp + 1 < GROUPS) {
-        const int s_n = (grp + 1) / ML_NT, t_n = (grp + 1) % ML_NT;
-        nh = *reinterpret_cast<const ml_u32x4*>(f2 + ((t_n * 2 + s_n) * 2) * 1024);
-        nl = *reinterpret_cast<const ml_u32x4*>(f2 + ((t_n * 2 + s_n) * 2) * 1024 + 1024);
+      if (grp + ML_AHEAD < GROUPS) {
+        qh[ML_AHEAD] = *reinterpret_cast<const ml_u32x4*>(frag_at(grp + ML_AHEAD));
+        ql[ML_AHEAD] = *reinterpret_cast<const ml_u32x4*>(frag_at(grp + ML_AHEAD) + 1024);
       }
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(al[s]), ml_frag(vh), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vl), acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(vh), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(al[s]), ml_frag(qh[0]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(ql[0]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml_frag(ah[s]), ml_frag(qh[0]), acc[t], 0, 0, 0);
       if (more && grp < PER_WAVE) stage_piece(c + 1, (c + 1) & 1, grp);
       __builtin_amdgcn_sched_barrier(0);
-      vh = nh; vl = nl;
+#pragma unroll
+      for (int a = 0; a < ML_AHEAD; ++a) { qh[a] = qh[a + 1]; ql[a] = ql[a + 1]; }
     }
     if (more)
       for (int k = GROUPS; k < PER_WAVE; ++k) stage_piece(c + 1, (c + 1) & 1, k);
