@@ -201,3 +201,39 @@ def test_round6_entry_points_validate_before_any_gpu_work():
     g.L = 9
     assert lib.gd4d_row_chain_guest_fwd(prog, 1, null, 0, 16, ctypes.byref(g), null) == EINVAL
     assert lib.gd4d_value_proj_guest_fwd(null, 0, null) == EINVAL
+
+
+def test_position_embedding_one_kernel_entry_points_validate_before_any_gpu_work():
+    """gd4d_mlp2_frustum_fwd / gd4d_mlp2_pe_se_fwd (ABI 54): null pointers, depth counts other than 64, hidden widths the images are not
+    built for and more than 4 levels come back as error codes on a box without a GPU."""
+    import ctypes
+    from graph_detr4d_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 96)()
+    ptr = ctypes.c_void_p((ctypes.addressof(buf) + 63) & ~63)
+    odd = ctypes.c_void_p(ptr.value + 4)
+    EINVAL, EUNSUPPORTED, EALIGN = -1, -2, -3
+    lv = (ctypes.c_int32 * 10)(16, 28, 8, 14, 4, 7, 2, 4, 1, 2)
+    rng = (ctypes.c_double * 6)(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0)
+    fr = lambda i2l=ptr, L=4, D=64, img=ptr, out=ptr, H=1024, ldo=256: (i2l, lv, L, 6, 928.0, 1600.0, D, 1.0, rng, img, null, out, H, ldo, null)
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(i2l=null)) == EINVAL
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(out=null)) == EINVAL
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(ldo=128)) == EINVAL
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(L=5)) == EUNSUPPORTED
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(D=32)) == EUNSUPPORTED
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(H=1000)) == EUNSUPPORTED
+    assert lib.gd4d_mlp2_frustum_fwd(*fr(img=odd)) == EALIGN
+    fp = (ctypes.c_void_p * 4)(ptr.value, ptr.value, ptr.value, ptr.value)
+    ps = lambda feats=fp, L=4, D=64, pe_h=1024, se_h=256, sine=ptr, outs=fp, se_img=ptr: (
+        ptr, feats, lv, L, 6, 928.0, 1600.0, D, 1.0, rng, ptr, null, pe_h, se_img, null, se_h, sine, outs, null, null)
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(feats=null)) == EINVAL
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(sine=null)) == EINVAL
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(outs=null)) == EINVAL
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(L=5)) == EUNSUPPORTED
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(D=48)) == EUNSUPPORTED
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(se_h=100)) == EUNSUPPORTED
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(se_img=odd)) == EALIGN
+    holes = (ctypes.c_void_p * 4)(ptr.value, 0, ptr.value, ptr.value)
+    assert lib.gd4d_mlp2_pe_se_fwd(*ps(feats=holes)) == EINVAL
+
