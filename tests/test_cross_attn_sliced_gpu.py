@@ -514,13 +514,14 @@ def test_coarse_projected_gather_refuses_what_it_is_not_built_for():
         ops.cross_attn_agg_coarse_fwd(plan, coarse)
 
 
-def test_late_values_prepared_for_the_coarse_gather_still_serve_an_all_raw_consumer():
+def test_late_values_prepared_for_the_coarse_gather_still_serve_an_all_raw_consumer(monkeypatch):
     """LateValues(coarse_for=...) copies the two fine levels only and projects the first layer's coarse levels beside the copy - for the
     fused decoder loop.  A consumer that gathers every level raw after all (a module called on its own with this object) must get the
     full copy (made again, once) and the same result as from an object built for it."""
     import graph_detr4d_amd as G
     from graph_detr4d_amd import functional as Fn
     from graph_detr4d_amd import ops, synthetic
+    monkeypatch.delenv('GD4D_COARSE', raising=False)              # (the default route, whatever the caller's environment says)
     torch.manual_seed(4)
     n, q = 6, 70
     levels = [(29, 50), (15, 25), (8, 13), (4, 7)]

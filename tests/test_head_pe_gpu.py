@@ -475,13 +475,15 @@ def test_both_mlps_and_the_fuse_as_one_kernel_equal_the_two_kernels(levels, r):
             assert torch.equal(o[1:3].permute(0, 3, 1, 2), b[1:3]) and torch.isnan(o[0]).all()
 
 
-def test_cameras_that_keep_moving_go_through_one_kernel_and_nothing_is_lost():
+def test_cameras_that_keep_moving_go_through_one_kernel_and_nothing_is_lost(monkeypatch):
     """channels_last_out route: a camera whose matrix changed between the last two calls AND changes again is computed by
     gd4d_mlp2_pe_se_fwd (its embedding is not stored, its kept rows are stale); when it stops moving its rows are recomputed into the
     kept tensor once and then reused.  Every call equals a fresh module's output bit for bit; cache_position_embedding = False sends
     every camera through the one kernel."""
     import copy
     from graph_detr4d_amd import ops
+    for name in ('GD4D_PE_FUSED', 'GD4D_PE_FRUSTUM'):             # (the default routes, whatever the caller's environment says)
+        monkeypatch.delenv(name, raising=False)
     g = Golden('head_pe')
     feats = [f.cuda() for f in g.feats()]
     metas = _metas(g)

