@@ -547,6 +547,44 @@ def test_cameras_that_keep_moving_go_through_one_kernel_and_nothing_is_lost(monk
         ops.mlp2_pe_se_fwd, ops.mlp2_frustum_fwd, ops.mlp2_se_fuse_fwd = real
 
 
+def test_one_kernel_route_at_the_bench_size_equals_the_two_kernel_route(monkeypatch):
+    """24 cameras on the R50 pyramid (739 800 pixels - the size bench.py's features_to_boxes runs): every camera through
+    gd4d_mlp2_pe_se_fwd (cache_position_embedding = False) against the position MLP + SE gate / fuse kernels (GD4D_PE_FUSED=0) and
+    against the module with its frustum tensor written and read (GD4D_PE_FRUSTUM=0): bit for bit / within the first product's
+    summation order; the 5 780 tiles cross every camera and level boundary."""
+    from graph_detr4d_amd import FeaturePositionEmbedding, ops, synthetic
+    torch.manual_seed(5)
+    n = 24
+    rig = synthetic.camera_rig(4)
+    metas = synthetic.make_img_metas(rig, batch=1)
+    feats = [torch.randn(1, n, 256, h, w, device='cuda') * 0.5 for h, w in synthetic.R50_LEVELS]
+
+    def run():
+        mod = FeaturePositionEmbedding(pc_range=synthetic.PC_RANGE, channels_last_out=True)
+        synthetic.randomise_all_(mod, seed=11, std=0.04)
+        mod = mod.cuda().eval()
+        mod.cache_position_embedding = False
+        with torch.no_grad():
+            return [o.clone() for o in mod(feats, metas)]
+    for name in ('GD4D_PE_FUSED', 'GD4D_PE_FRUSTUM'):
+        monkeypatch.delenv(name, raising=False)
+    seen = []
+    real = ops.mlp2_pe_se_fwd
+    monkeypatch.setattr(ops, 'mlp2_pe_se_fwd', lambda i2l, *a, **k: (seen.append(i2l.shape[0]), real(i2l, *a, **k))[1])
+    one = run()
+    assert seen == [n]
+    monkeypatch.setenv('GD4D_PE_FUSED', '0')
+    two = run()
+    assert seen == [n]
+    for a, b in zip(one, two):
+        assert ops.PyramidView.is_channels_last_level(a) and torch.equal(a, b)
+    monkeypatch.setenv('GD4D_PE_FRUSTUM', '0')
+    plain = run()
+    for a, b in zip(one, plain):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-4)
+        assert (a - b).abs().mean().item() < 2e-6
+
+
 def test_kept_embedding_across_streams_static_rig_and_updates():
     """The kept per-camera embedding is safe across streams: a call on another stream that finds every matrix unchanged (static rig)
     only READS the tensor - it must come after the stream that wrote it; an in-place update must come after every stream still
