@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GD4D_LIB_PATH') or os.path.join(_HERE, 'libgd4d.so')   # env override: dev A/B builds
-ABI_VERSION = 54
+ABI_VERSION = 55
 PIXEL_MAJOR, HEAD_MAJOR = 0, 1
 
 F32, BF16 = 0, 1
@@ -37,6 +37,7 @@ SIGNATURES = {
     'gd4d_value_proj_image': (_i, [_vp, _vp, _vp, _vp]),
     'gd4d_value_proj_guest_fwd': (_i, [_vp, _i, _vp]),
     'gd4d_row_chain_guest_fwd': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    'gd4d_row_chain_fill_fwd': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'gd4d_cross_attn_agg_items_count_fwd': (_i, [_vp, _vp, _vp, _c.c_int64, _c.c_int64, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'gd4d_pyramid_slice_planar_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'gd4d_value_proj_heads_fwd': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),

@@ -173,7 +173,9 @@ class RawPyramid:
             # one stream, the chain training path: the fills ride in the attention backward's launches (fills_for_launch); what is
             # left of them, and the sort, run before the reduction (_reduce)
             self.sink.scan()
-            self._launches_left = max(len(self.layer_q) - 1, 0)   # attention backward launches in front of the reduction
+            # launches in front of the reduction that can carry fills: every layer's first backward chain (fills_ride = 'chain'), or
+            # the attention backward launches of all layers but the last one walked
+            self._launches_left = len(self.layer_q) if self.fills_ride == 'chain' else max(len(self.layer_q) - 1, 0)
             self._prepared = True
             return
         self.sink.prepare()

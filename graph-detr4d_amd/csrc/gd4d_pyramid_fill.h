@@ -7,6 +7,7 @@
 namespace gd4d {
 
 // records[start[chunk] + slot] = {weight, pixel-in-chunk << 26 | table row}: no atomics
+template <int FP = 4>
 __device__ __forceinline__ void pyramid_grad_fill_body(const int* __restrict__ hdr, const uint2* __restrict__ pair,
                                                        const uint2* __restrict__ slots, int cap_t, int HH, int BQ,
                                                        const int* __restrict__ start, uint2* __restrict__ rec,
@@ -21,7 +22,7 @@ __device__ __forceinline__ void pyramid_grad_fill_body(const int* __restrict__ h
   // four passes at a time: their slot and pair rows requested together, then the four chunk starts (which depend on the
   // slots), then the stores - two round trips per four passes (one pass per iteration was two dependent round trips per pass
   // on a wave that walks ~4 passes: 26 us per launch)
-  constexpr int FP = 4;
+  // (FP = 8 for the guests of a training chain - gd4d_rowchain.hip: few waves, each walks several rows one after the other)
   for (int t = 0; t < T; t += FP) {
     uint2 sr[FP], pr[FP];
 #pragma unroll

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "gd4d_common.h"
+#include "gd4d_pyramid_fill.h"
 #include "gd4d_mha_dropout.h"
 #include "gd4d_value_proj_body.h"
 
@@ -1034,6 +1035,36 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain_guest_kernel(const Ch
   row_chain_body<false>(pp, (int)blockIdx.x);
 }
 
+// A TRAINING chain with the pyramid gradient's record fills as guests (gd4d_row_chain_fill_fwd): the fills of a step need the scan
+// over all layers' counts and nothing from the backward pass; they stream plans and scatter 8-byte records - memory work a backward
+// chain (57 of the 256 compute units for 50-70 us, bound by the latency of one) leaves room for.  Until round 6 they rode in the
+// attention backward's dk / dv launch, which they made 20-38 us longer (53-71 against 33 us).  Guest workgroups sit behind the
+// chain's, stay (gcount of them) and walk the (position, head) rows of up to two jobs: wave w of guest g takes rows
+// g RC_WAVES + w, + gcount RC_WAVES, ...
+#ifndef RC_FILL_FP
+#define RC_FILL_FP 8
+#endif
+__global__ __launch_bounds__(64 * RC_WAVES) void row_chain_fill_kernel(const ChainProgram by_value, const FillGuest fg, const int gbase,
+                                                                        const int gcount) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const rc_prog_ptr_t pp = (rc_prog_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // explicit arguments start at 0
+#else
+  const ChainProgram* pp = &by_value;
+#endif
+  (void)by_value;
+  if ((int)blockIdx.x >= gbase) {                                       // workgroup-uniform
+    const int rows0 = fg.BQ[0] * fg.HH, rows1 = fg.hdr[1] ? fg.BQ[1] * fg.HH : 0;
+    const int wave = (int)(threadIdx.x >> 6), step = gcount * RC_WAVES;
+    for (int ph = ((int)blockIdx.x - gbase) * RC_WAVES + wave; ph < rows0 + rows1; ph += step) {
+      const int job = ph >= rows0 ? 1 : 0;
+      pyramid_grad_fill_body<RC_FILL_FP>(fg.hdr[job], fg.pair[job], fg.slots[job], fg.cap_t, fg.HH, fg.BQ[job], fg.start, fg.rec,
+                                         fg.order[job], fg.id_base[job], ph - (job ? rows0 : 0));
+    }
+    return;
+  }
+  row_chain_body<true>(pp, (int)blockIdx.x);
+}
+
 // XCC id of every workgroup of a launch (gd4d_xcd_placement_probe): the hand-offs above rely on workgroups j and j + 8 k sharing
 // an XCD; the host checks that once per device before it builds programs with SIGNAL / WAIT.
 __global__ void xcd_placement_probe_kernel(int32_t* out) {
@@ -1184,7 +1215,7 @@ static int rc_validate(const gd4d_chain_op* program, int nops, int which) {
 }
 
 static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int nb, int M, void* stream,
-                     const gd4d_chain_guest* guest = nullptr) {
+                     const gd4d_chain_guest* guest = nullptr, const gd4d::FillGuest* fills = nullptr, int fill_workgroups = 0) {
   using namespace gd4d;
   if (!a || na <= 0 || M <= 0 || nb < 0 || (nb > 0 && !b)) return GD4D_EINVAL;
   if (na + nb > GD4D_CHAIN_MAX_OPS) return GD4D_EUNSUPPORTED;
@@ -1247,6 +1278,23 @@ static int rc_launch(const gd4d_chain_op* a, int na, const gd4d_chain_op* b, int
     };
     return g.in_chlast ? go(row_chain_guest_kernel<true>) : go(row_chain_guest_kernel<false>);
   }
+  if (fills) {                                             // (the training instantiation, whatever the program holds)
+    if (guest) return GD4D_EINVAL;
+    const void* fk = reinterpret_cast<const void*>(row_chain_fill_kernel);
+    const size_t flds = sizeof(float) * RC_BUFS * RC_M * RC_LD + 256 * RC_WAVES + sizeof(float) * 8 * RC_W;
+    if (!allow_dynamic_lds(fk, (int)flds)) return GD4D_ELAUNCH;
+    const int gbase = nb > 0 ? split + blocks : blocks;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int rows = fills->BQ[0] * fills->HH + (fills->hdr[1] ? fills->BQ[1] * fills->HH : 0);
+    const int need = (rows + RC_WAVES - 1) / RC_WAVES;
+    int gcount = fill_workgroups > 0 ? fill_workgroups : 2 * cus;     // (the chain's LDS request: the guests share compute units at most two by two)
+    if (gcount > need) gcount = need;
+    if (gcount < 1) gcount = 1;
+    hipLaunchKernelGGL(row_chain_fill_kernel, dim3(gbase + gcount), dim3(64 * RC_WAVES), flds, static_cast<hipStream_t>(stream), prog, *fills,
+                       gbase, gcount);
+    return check_launch();
+  }
   if (train)
     hipLaunchKernelGGL(row_chain_kernel<true>, dim3(nb > 0 ? split + blocks : blocks), dim3(64 * RC_WAVES), lds, static_cast<hipStream_t>(stream), prog);
   else
@@ -1276,4 +1324,32 @@ extern "C" int gd4d_row_chain_guest_fwd(const gd4d_chain_op* program_a, int nops
                                         const gd4d_chain_guest* guest, void* stream) {
   if (!guest || nops_b < 0 || (nops_b > 0 && !program_b)) return GD4D_EINVAL;
   return rc_launch(program_a, nops_a, nops_b > 0 ? program_b : nullptr, nops_b, M, stream, guest);
+}
+
+// A training chain (one or two programs) that carries record fills of the pyramid gradient as guest workgroups: see row_chain_fill_kernel.
+// jobs / start / records / fill_*: as gd4d_mha_core_bwd_fill.  workgroups: guest workgroups (0: two per compute unit).
+extern "C" int gd4d_row_chain_fill_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
+                                       const gd4d_fill_job* jobs, int njobs, const int32_t* start, void* records, int fill_B, int fill_N,
+                                       int fill_Hh, int fill_P, int workgroups, void* stream) {
+  using namespace gd4d;
+  if (!jobs || njobs < 1 || njobs > 2 || !start || !records || fill_B <= 0 || fill_N <= 0 || fill_Hh <= 0) return GD4D_EINVAL;
+  if (nops_b < 0 || (nops_b > 0 && !program_b) || workgroups < 0) return GD4D_EINVAL;
+  if ((fill_P != kPoints && fill_P != 8) || fill_N > 64 || fill_B > 16 || fill_Hh > kPlanHdr) return GD4D_EUNSUPPORTED;
+  FillGuest fg{};
+  for (int j = 0; j < njobs; ++j) {
+    const gd4d_fill_job& jb = jobs[j];
+    if (!jb.plan || !jb.slots || jb.Q <= 0) return GD4D_EINVAL;
+    if ((unsigned long long)jb.id_base + (unsigned long long)fill_B * jb.Q * fill_Hh > (1ull << 26)) return GD4D_EUNSUPPORTED;
+    fg.hdr[j] = static_cast<const int*>(jb.plan);
+    fg.pair[j] = reinterpret_cast<const uint2*>(static_cast<const char*>(jb.plan) + plan_hdr_bytes(fill_B, jb.Q));
+    fg.slots[j] = static_cast<const uint2*>(jb.slots);
+    fg.order[j] = jb.query_order;
+    fg.id_base[j] = jb.id_base;
+    fg.BQ[j] = fill_B * jb.Q;
+  }
+  fg.HH = fill_Hh;
+  fg.cap_t = plan_cap_t(fill_N, fill_P);
+  fg.start = start;
+  fg.rec = static_cast<uint2*>(records);
+  return rc_launch(program_a, nops_a, nops_b > 0 ? program_b : nullptr, nops_b, M, stream, nullptr, &fg, workgroups);
 }

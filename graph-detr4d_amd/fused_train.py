@@ -386,8 +386,11 @@ class DecoderTrainFunction(torch.autograd.Function):
         g_next = None                        # gradient of a layer's OUTPUT coming from the layer after it
         gpos = None                          # running gradient of query_pos
         g_ref0 = padz = carry = carry_keep = None
+        fills_in = os.environ.get('GD4D_FILLS_RIDE', 'chain')               # 'chain' | 'mha': which launches carry the record fills
         if want_pyramid:
-            raw.fills_ride = True                            # the record fills ride in the attention backward's launches
+            # the pyramid gradient's record fills ride as guests of every layer's first backward chain (57 of the 256 compute units
+            # busy for 50-70 us); until round 6: of the attention backward's dk / dv launches, which they made 20-38 us longer
+            raw.fills_ride = 'chain' if fills_in == 'chain' else True
             raw.begin_backward()
         for lid in range(nl - 1, -1, -1):
             layer, s, im = layers[lid], saved[lid], imgs.layers[lid]
@@ -432,7 +435,7 @@ class DecoderTrainFunction(torch.autograd.Function):
                      ops.chain_layernorm_bwd(1, s.mid1, pe[4], dst=2, relu=True, out=gmid1, part=ws_p4),
                      ops.chain_gemm(2, im['pos3_t'], None, dst=0),
                      ops.chain_layernorm_bwd(0, s.mid0, pe[1], dst=0, relu=True, out=gmid0, part=ws_p1)]
-            ops.row_chain_fwd(prog, q)
+            ops.row_chain_fwd(prog, q, fills=raw.fills_for_launch() if want_pyramid and fills_in == 'chain' else None)
             wgrad(base, 'f1_w', s.h, gy3m)
             wgrad(base, 'f0_w', s.x2, ghp)
             wgrad(base, 'op_w', s.v, gy2m)
@@ -488,7 +491,7 @@ class DecoderTrainFunction(torch.autograd.Function):
             qh, kh, vh = s.qkv.split(c, dim=-1)
             dqk, dv = ops.mha_core_bwd(qh, kh, vh, s.o, g_o, s.lse, sa.num_heads, meta.attn_mask, packed_qk=True,
                                        dropout_p=s.drop[0][1] if s.drop[0] else 0., seed=s.drop[0][0] if s.drop[0] else None,
-                                       fills=raw.fills_for_launch() if want_pyramid else None)    # record fills of the pyramid gradient ride
+                                       fills=raw.fills_for_launch() if want_pyramid and fills_in != 'chain' else None)
             # in-projection backward: launched with the NEXT layer's chain B' backward (its result stays in LDS), alone for layer 0
             gx = new(q, c) if lid == 0 else None
             gpos_new = new(q, c)

@@ -2362,12 +2362,26 @@ def value_proj_guest_fwd(guest, max_cus=0):
     _lib.check(code, 'gd4d_value_proj_guest_fwd')
 
 
-def row_chain_fwd(program, m, guest=None):
+def _chain_fills(lib, a, na, b, nb, m, fills):
+    """gd4d_row_chain_fill_fwd: the chain launch carries `fills` (PyramidGrad.take_fills) as guest workgroups."""
+    jobs, start, records, fb, fn, fhh = fills
+    arr = (FillJob * len(jobs))(*[FillJob(_dev(pl.buf, 'plan', torch.uint8).value, _dev(sl, 'slots').value,
+                                           None if pl.order is None else _order_ptr(pl.order, fb * pl.q).value, int(base), int(pl.q))
+                                   for pl, sl, base in jobs])
+    code = lib.gd4d_row_chain_fill_fwd(a, na, b, nb, int(m), arr, len(jobs), _dev(start, 'start', torch.int32), _dev(records, 'records'),
+                                       fb, fn, fhh, int(jobs[0][0].points), 0, _stream())
+    _lib.check(code, 'gd4d_row_chain_fill_fwd')
+
+
+def row_chain_fwd(program, m, guest=None, fills=None):
     """gd4d_row_chain_fwd: run the list of ChainOp over `m` rows in one launch (the tensors the operations point to must
     stay alive until the stream has run it - the callers keep them in locals / return them).  guest (ChainGuest): the launch
-    also carries that value_proj job on the compute units the chain leaves idle (gd4d_row_chain_guest_fwd)."""
+    also carries that value_proj job on the compute units the chain leaves idle (gd4d_row_chain_guest_fwd).  fills (training;
+    PyramidGrad.take_fills): it carries those record fills of the pyramid gradient (gd4d_row_chain_fill_fwd)."""
     lib = _lib.load()
     arr = (ChainOp * len(program))(*program)
+    if fills is not None:
+        return _chain_fills(lib, arr, len(program), None, 0, m, fills)
     if guest is not None:
         code = lib.gd4d_row_chain_guest_fwd(arr, len(program), None, 0, int(m), ctypes.byref(guest), _stream())
         _lib.check(code, 'gd4d_row_chain_guest_fwd')

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD4D_ABI_VERSION 54
+#define GD4D_ABI_VERSION 55
 
 enum { GD4D_F32 = 0, GD4D_BF16 = 1 };
 
@@ -837,6 +837,15 @@ int gd4d_mha_core_bwd_fill(const float* q, const float* k, const float* v, const
                            int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, int mask_kind, float scale,
                            float drop_p, const void* seed, const gd4d_fill_job* jobs, int njobs, const int32_t* start,
                            void* records, int fill_B, int fill_N, int fill_Hh, int fill_P, void* stream);
+
+/* gd4d_row_chain_fill_fwd - a TRAINING row chain (program_b / nops_b: a second program, or NULL / 0) that carries up to two layers'
+ * record fills of the pyramid gradient as guest workgroups - the jobs of gd4d_mha_core_bwd_fill, on the ~200 compute units a backward
+ * chain leaves idle for 50-70 us instead of in the attention backward's dk / dv launch (which they made 20-38 us longer).  workgroups:
+ * guest workgroups (0: two per compute unit); they sit behind the chain's workgroups, stay, and walk the (position, head) rows.  Same
+ * records as gd4d_pyramid_grad_fill. */
+int gd4d_row_chain_fill_fwd(const gd4d_chain_op* program_a, int nops_a, const gd4d_chain_op* program_b, int nops_b, int M,
+                            const gd4d_fill_job* jobs, int njobs, const int32_t* start, void* records, int fill_B, int fill_N,
+                            int fill_Hh, int fill_P, int workgroups, void* stream);
 
 /* gd4d_layernorm_bwd - backward of gd4d_layernorm_fwd (y = [ReLU] LN(x [+ res]) gamma + beta): dx (also the gradient of
  * res), dgamma, dbeta from dy; mean / rstd are recomputed from x.  beta is read only with relu != 0 (to rebuild the

@@ -237,3 +237,29 @@ def test_position_embedding_one_kernel_entry_points_validate_before_any_gpu_work
     holes = (ctypes.c_void_p * 4)(ptr.value, 0, ptr.value, ptr.value)
     assert lib.gd4d_mlp2_pe_se_fwd(*ps(feats=holes)) == EINVAL
 
+
+def test_fill_carrying_chain_validates_before_any_gpu_work():
+    """gd4d_row_chain_fill_fwd (ABI 55): jobs, start and records must be there, at most two jobs, a plan's table rows must fit 26 bits."""
+    import ctypes
+    from graph_detr4d_amd import _lib, ops
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 96)()
+    ptr = ctypes.c_void_p((ctypes.addressof(buf) + 63) & ~63)
+    EINVAL, EUNSUPPORTED = -1, -2
+    prog = (ops.ChainOp * 1)(ops.ChainOp(kind=ops.CHAIN_LOAD, src=-1, dst=0, res=-1, N=256, p0=ptr.value))
+    job = ops.FillJob(ptr.value, ptr.value, None, 0, 9)
+    jobs = (ops.FillJob * 1)(job)
+    call = lambda j=jobs, n=1, start=ptr, rec=ptr, hh=8, p=4, wg=0: lib.gd4d_row_chain_fill_fwd(prog, 1, null, 0, 16, j, n, start, rec, 1, 6, hh, p, wg, null)
+    assert call(j=null) == EINVAL
+    assert call(n=3) == EINVAL
+    assert call(start=null) == EINVAL
+    assert call(rec=null) == EINVAL
+    assert call(wg=-1) == EINVAL
+    assert call(p=5) == EUNSUPPORTED
+    assert call(hh=32) == EUNSUPPORTED
+    far = (ops.FillJob * 1)(ops.FillJob(ptr.value, ptr.value, None, (1 << 26) - 8, 9))
+    assert call(j=far) == EUNSUPPORTED
+    hole = (ops.FillJob * 1)(ops.FillJob(ptr.value, None, None, 0, 9))
+    assert call(j=hole) == EINVAL
+
