@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--plan', default='items', help='items (the inference step) | pairs (what the training kernels read)')
     ap.add_argument('--coarse', action='store_true', help='also time gd4d_cross_attn_agg_items_coarse_fwd and the projection of levels 2-3')
+    ap.add_argument('--footprint', action='store_true',
+                    help='count the distinct pixels the visible samples touch per level: the bytes a gather has to bring in at least once')
     a = ap.parse_args()
     dev = 'cuda'
     n, q = 6 * a.frames, a.queries
@@ -60,6 +62,31 @@ def main():
     plan, mask = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
                                          query_order=order, want_mask=True, items=items)
     vis = int(mask.sum().item())
+    if a.footprint:
+        # mmcv's MSDA / grid_sample(align_corners=False): pixel x = u W - 0.5; the four corners around it, those inside the map
+        _, m2, uv = ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8, query_order=order,
+                                            want_mask=True, want_uv=True, items=items)
+        keep = m2.bool().reshape(-1)                                   # (B, N, Q, Hh, P)
+        camid = torch.arange(n, device=dev).view(1, n, 1, 1, 1).expand_as(m2).reshape(-1)[keep]
+        headid = torch.arange(8, device=dev).view(1, 1, 1, 8, 1).expand_as(m2).reshape(-1)[keep]
+        u, v = uv[..., 0].reshape(-1)[keep], uv[..., 1].reshape(-1)[keep]
+        total_raw = total_proj = 0
+        for lvl, (h, w) in enumerate(levels):
+            x0, y0 = torch.floor(u * w - 0.5).long(), torch.floor(v * h - 0.5).long()
+            pix, pix_h = [], []
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    xx, yy = x0 + dx, y0 + dy
+                    ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+                    key = (camid[ok] * h + yy[ok]) * w + xx[ok]
+                    pix.append(key)
+                    pix_h.append(key * 8 + headid[ok])
+            upix, uph = torch.unique(torch.cat(pix)).numel(), torch.unique(torch.cat(pix_h)).numel()
+            total_raw += upix * 1024
+            total_proj += uph * 128
+            print(f'level {lvl} ({h} x {w}): {upix} of {n * h * w} pixels touched = {upix * 1024 / 1e6:.1f} MB of raw 1-KB rows; '
+                  f'{uph} (pixel, head) pairs = {uph * 128 / 1e6:.1f} MB of projected 128-byte rows')
+        print(f'at least once: all levels raw {total_raw / 1e6:.1f} MB')
     corner_bytes = vis * len(levels) * 4 * 256 * (2 if a.dtype == 'bf16' else 4)
     sa, sw = ops.cross_attn_agg_sliced_fwd(plan), plan.wsum
     t_plan = timed(lambda: [ops.cross_attn_plan_fwd(pyr, ref, offsets, attn, cam, l2i, synthetic.PC_RANGE, 900, 1600, 8,
