@@ -585,14 +585,24 @@ def test_one_kernel_route_at_the_bench_size_equals_the_two_kernel_route(monkeypa
         assert (a - b).abs().mean().item() < 2e-6
 
 
-def test_kept_embedding_across_streams_static_rig_and_updates():
-    """The kept per-camera embedding is safe across streams: a call on another stream that finds every matrix unchanged (static rig)
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_kept_embedding_across_streams_static_rig_and_updates(channels_last, monkeypatch):
+    """(channels_last: the route with the one-kernel form for moving cameras, _forward_one_kernel - camera 1 alternates between two
+    poses, so it is stored, then computed without being stored, then found stale.)
+    The kept per-camera embedding is safe across streams: a call on another stream that finds every matrix unchanged (static rig)
     only READS the tensor - it must come after the stream that wrote it; an in-place update must come after every stream still
     reading it; a key change drops the tensor while readers may be queued.  Stress: two streams alternate calls (same rig, moved
     rig, weight update) with a long kernel queued in front of the writer each time; every result equals a fresh module's."""
     import copy
+    for name in ('GD4D_PE_FUSED', 'GD4D_PE_FRUSTUM'):
+        monkeypatch.delenv(name, raising=False)
     g = Golden('head_pe')
-    mod = _module(g)
+
+    def fresh():
+        m = _module(g)
+        m.channels_last_out = channels_last
+        return m
+    mod = fresh()
     feats = [f.cuda() for f in g.feats()]
     metas = _metas(g)
     moved = copy.deepcopy(metas)
@@ -607,8 +617,8 @@ def test_kept_embedding_across_streams_static_rig_and_updates():
             for _ in range(6):
                 big @ big
     with torch.no_grad():
-        want_static = [t.clone() for t in _module(g)(feats, metas)]
-        want_moved = [t.clone() for t in _module(g)(feats, moved)]
+        want_static = [t.clone() for t in fresh()(feats, metas)]
+        want_moved = [t.clone() for t in fresh()(feats, moved)]
         torch.cuda.synchronize()
         for rnd in range(4):
             busy(s1)
