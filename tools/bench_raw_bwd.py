@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--levels', default='r50')
     ap.add_argument('--no-walk', action='store_true')
     ap.add_argument('--regions', default='6,10')
+    ap.add_argument('--alias', action='store_true', help='every camera row aliases row 0: the gather-dot without its L2 misses')
     a = ap.parse_args()
     dev = 'cuda'
     n, q, nl = 6 * a.frames, a.queries, a.layers
@@ -30,6 +31,8 @@ def main():
     l2i = torch.from_numpy(synthetic.camera_rig(a.frames)).unsqueeze(0).to(dev)
     sp, shapes = ops.pyramid_slice_planar_fwd(feats)
     pyr = ops.PyramidView.slice_planar(sp, shapes)
+    if a.alias:
+        pyr.cam_stride = [0] * len(pyr.cam_stride)
     del feats
     w_v = (torch.randn(256, 256, generator=g) / 16).to(dev)
     b_v = torch.randn(256, generator=g).to(dev)
@@ -81,6 +84,9 @@ def main():
     t_h = timed(heads, a.iters, nl)
     t_d = timed(dots, a.iters, nl)
     t_p = timed(planb, a.iters, nl)
+    if a.alias:                                           # (the bookkeeping refuses aliased rows: the gather-dot's floor only)
+        print(f'aliased camera rows: heads_bwd {t_h:.1f} us, gather-dot {t_d:.1f} us, plan_bwd {t_p:.1f} us per layer')
+        return
     t_c = timed(counts, a.iters, 1)
     t_sf = timed(prepare, a.iters, 1)
     t_f = timed(finish, a.iters, 1)
