@@ -192,3 +192,13 @@ def test_torch_op_routes_are_explicit(monkeypatch):
         assert Fn.torch_ops_route('b', False, module=b) is True
     with pytest.raises(Gd4dError, match='torch_ops'):
         Fn.torch_ops_route('b', False, module=b)
+
+
+def test_camera_runs_of_the_position_embedding():
+    """FeaturePositionEmbedding._runs: sorted camera indices -> the contiguous [a, e) runs the kernels are launched on."""
+    from graph_detr4d_amd import FeaturePositionEmbedding as F
+    assert F._runs([]) == []
+    assert F._runs([3]) == [(3, 4)]
+    assert F._runs([0, 1, 2, 5, 6, 9]) == [(0, 3), (5, 7), (9, 10)]
+    assert F._runs(list(range(6, 24))) == [(6, 24)]
+
