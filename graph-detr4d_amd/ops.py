@@ -2390,12 +2390,14 @@ def row_chain_fwd(program, m, guest=None, fills=None):
     _lib.check(code, 'gd4d_row_chain_fwd')
 
 
-def row_chain2_fwd(program_a, program_b, m, guest=None):
+def row_chain2_fwd(program_a, program_b, m, guest=None, fills=None):
     """gd4d_row_chain2_fwd: two independent programs over the same `m` rows in one launch (each on its own workgroups);
-    guest as row_chain_fwd."""
+    guest / fills as row_chain_fwd."""
     lib = _lib.load()
     a = (ChainOp * len(program_a))(*program_a)
     b = (ChainOp * len(program_b))(*program_b)
+    if fills is not None:
+        return _chain_fills(lib, a, len(program_a), b, len(program_b), m, fills)
     if guest is not None:
         code = lib.gd4d_row_chain_guest_fwd(a, len(program_a), b, len(program_b), int(m), ctypes.byref(guest), _stream())
         _lib.check(code, 'gd4d_row_chain_guest_fwd')

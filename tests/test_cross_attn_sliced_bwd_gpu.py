@@ -220,6 +220,53 @@ def test_record_fills_ride_in_the_attention_backwards_launch():
         assert _rel(a, e) < 1e-5
 
 
+def test_record_fills_ride_in_a_backward_chains_launch():
+    """gd4d_row_chain_fill_fwd: the fills of two layers, then of one, are guest workgroups of a TRAINING chain launch (one program;
+    then two programs) - the chain's outputs are bit-identical to the plain launches, and the pyramid's gradient equals the one of
+    the stand-alone fills (the records are the same records: the slots were handed out by the count)."""
+    c = _case(8, 4, 6, 96, 1, seed=23)
+    b, q, hh = c['b'], c['q'], c['heads']
+    sp, hw = ops.pyramid_slice_planar_fwd(c['feats'])
+    pyr = ops.PyramidView.slice_planar(sp, hw)
+    order = ops.query_order_fwd(c['ref'], PC_RANGE)
+    gen = torch.Generator().manual_seed(4)
+    m = 200
+    x, gy = torch.randn(m, 256, generator=gen).to(DEV), torch.randn(m, 256, generator=gen).to(DEV)
+    w1, w2 = (torch.randn(256, 256, generator=gen) / 16).to(DEV), (torch.randn(512, 256, generator=gen) / 16).to(DEV)
+    ln = torch.nn.LayerNorm(256).to(DEV)
+
+    def programs(o1, o2, o3, part):
+        # a backward-style program (a stored LOAD + a LayerNorm backward: the training instantiation) and a second, plain one
+        pa = [ops.chain_load(0, gy, out=o3), ops.chain_layernorm_bwd(0, x, ln, dst=1, out=o1, part=part), ops.chain_gemm(1, w1, None, out=o2)]
+        pb = [ops.chain_load(0, x), ops.chain_gemm(0, w2, None, out=None, dst=1)]
+        return pa, pb
+    blocks = (m + 15) // 16
+    outs = [[torch.empty(m, 256, device=DEV) for _ in range(3)] + [torch.empty(blocks * 2 * 256, device=DEV)] for _ in range(3)]
+    pa, pb = programs(*outs[0])
+    ops.row_chain_fwd(pa, m)
+    res = {}
+    for riding in (False, True):
+        sink = ops.PyramidGrad(pyr, 3, b, q, hh)
+        for layer in range(3):
+            plan = ops.cross_attn_plan_fwd(pyr, c['ref'], c['offsets'] * (1 + 0.1 * layer), c['attn'], c['cam'], c['l2i'], PC_RANGE,
+                                           900, 1600, hh, query_order=order)
+            sink.add_layer(layer, plan)
+            ops.value_proj_heads_bwd(c['gout'], c['w_v'], c['b_v'], hh, grad_agg=sink.grad_agg_rows(layer))
+        if riding:
+            sink.scan()
+            pa1, _ = programs(*outs[1])
+            ops.row_chain_fwd(pa1, m, fills=sink.take_fills(2))
+            pa2, pb2 = programs(*outs[2])
+            ops.row_chain2_fwd(pa2, pb2, m, fills=sink.take_fills(1))
+            assert sink.plans == [] and len(sink._riding) == 3 and sink.take_fills(2) is None
+            for k in (1, 2):
+                for a, e in zip(outs[k][:3], outs[0][:3]):
+                    assert torch.equal(a, e)
+        res[riding] = sink.finish()
+    for a, e in zip(res[True], res[False]):
+        assert _rel(a, e) < 1e-5
+
+
 def test_raw_backward_raw_camera_weights():
     """GD4D_CA_RAW_CAM_WEIGHTS (Deform3DCrossAttnMP's neighbour pass): no sigmoid on the camera logits."""
     c = _case(8, 4, 6, 48, 1, seed=5)
